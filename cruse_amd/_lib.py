@@ -1,0 +1,75 @@
+"""ctypes binding of libcruse_hip.so (include/cruse_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a symbol
+is absent, importing this module raises.  Build it with
+`python -c "import __graft_entry__ as g; g.build()"` or cruse_amd/csrc/build.sh.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcruse_hip.so")
+
+PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
+PREC_BY_NAME = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
+
+_T = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "q": ctypes.c_longlong,
+      "z": ctypes.c_size_t}
+
+# name -> (argument type string, restype); mirrors include/cruse_hip.h one to one
+SIGNATURES = {
+    "cruse_abi_version": ("", "i"),
+    "cruse_last_error": ("", "s"),
+    "cruse_stft_fwd": ("piiiipppifp", "i"),
+    "cruse_istft_fwd": ("ppiiiiipp", "i"),
+    "cruse_istft_bwd": ("piiiiippp", "i"),
+    "cruse_conv_gather": ("ppppiiiiiiiiiiiip", "i"),
+    "cruse_conv_scatter2": ("ppppiiiiiiiiiip", "i"),
+    "cruse_conv_wgrad_ws_bytes": ("iii", "z"),
+    "cruse_conv_wgrad": ("pppiiiiiiiiipp", "i"),
+    "cruse_channel_sum": ("pqiipp", "i"),
+    "cruse_col_sum": ("pqiipp", "i"),
+    "cruse_bn_stats": ("pqiipp", "i"),
+    "cruse_bn_finalize": ("pqiffppppp", "i"),
+    "cruse_bn_eval_stats": ("ppifppp", "i"),
+    "cruse_bn_act_fwd": ("pppppppqiiip", "i"),
+    "cruse_bn_act_bwd_reduce": ("ppppppqiiipp", "i"),
+    "cruse_bn_act_bwd_apply": ("pppppppqiiiipppp", "i"),
+    "cruse_ln_fwd": ("pppppppqiifp", "i"),
+    "cruse_ln_bwd": ("pppppqiipppp", "i"),
+    "cruse_gemm": ("iiiiipipipipiiiip", "i"),
+    "cruse_gru_ws_bytes": ("iii", "z"),
+    "cruse_gru_seq_fwd": ("ppppppppiiiiipp", "i"),
+    "cruse_gru_seq_bwd": ("pppppppppiiiiipp", "i"),
+    "cruse_mask_loss_fwd": ("ppppqiiffpppppp", "i"),
+    "cruse_sigmoid_bwd": ("pppqp", "i"),
+    "cruse_axpby": ("pppffqp", "i"),
+    "cruse_adam_step": ("ppppqfffffifp", "i"),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the CRUSE HIP library must be built for gfx950 "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (args, res) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = [_T[c] for c in args]
+        fn.restype = ctypes.c_char_p if res == "s" else _T[res]
+    if lib.cruse_abi_version() != 1:
+        raise ImportError(f"libcruse_hip.so ABI version {lib.cruse_abi_version()} != 1")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int) -> None:
+    """Mirror the reference's error behaviour: Python RuntimeError on shape/dim mismatch."""
+    if rc != 0:
+        msg = lib.cruse_last_error()
+        raise RuntimeError(f"cruse_hip error {rc}: {msg.decode() if msg else ''}")

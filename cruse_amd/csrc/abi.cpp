@@ -1,0 +1,37 @@
+// Error channel and version of the C ABI (include/cruse_hip.h).
+#include <hip/hip_runtime.h>
+#include <map>
+#include <mutex>
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/cruse_hip.h"
+
+static thread_local char g_err[512] = "";
+
+extern "C" void cruse_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* cruse_last_error(void) { return g_err; }
+extern "C" int cruse_abi_version(void) { return CRUSE_ABI_VERSION; }
+
+extern "C" void cruse_set_error(const char* fmt, ...);
+
+int cruse_ensure_dyn_lds(const void* fn, size_t bytes, const char* name) {
+    if (bytes <= 48 * 1024) return CRUSE_OK;
+    static std::mutex mu;
+    static std::map<const void*, size_t> done;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = done.find(fn);
+    if (it != done.end() && it->second >= bytes) return CRUSE_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        cruse_set_error("%s: cannot set %zu B of dynamic LDS: %s", name, bytes, hipGetErrorString(e));
+        return CRUSE_E_HIP;
+    }
+    done[fn] = bytes;
+    return CRUSE_OK;
+}

@@ -1,0 +1,20 @@
+#!/usr/bin/env bash
+# Build libcruse_hip.so for gfx950 (cross-compiles without a GPU).
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+out="$here/../libcruse_hip.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+objs=()
+pids=()
+mkdir -p "$here/build"
+for f in stft conv pointwise gemm gru; do
+  "$HIPCC" $FLAGS -c "$here/$f.hip" -o "$here/build/$f.o" &
+  pids+=($!)
+  objs+=("$here/build/$f.o")
+done
+"$HIPCC" $FLAGS -x hip -c "$here/abi.cpp" -o "$here/build/abi.o"
+objs+=("$here/build/abi.o")
+for p in "${pids[@]}"; do wait "$p"; done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$out"
+echo "built $out"

@@ -1,0 +1,478 @@
+// Frame-major direct convolutions for the CRUSE encoder / decoder / skip paths.
+//
+// Replaces nn.Conv2d((2,3),(1,2),(1,1)) + causal crop, nn.Conv2d((1,3)) skip and
+// nn.ConvTranspose2d((1,3),(1,2)) + crop of model/cruse_net.py:138-143,149-164 and
+// their autograd backward.  Activations are [B,T,C,F]: one row of C*F (= 640 at every
+// U-Net level) floats per frame, so every global access is a contiguous frame row.
+//
+// Round-1 form: f32 VALU, weights + a tile of frames staged in LDS, register tiles
+// of CO_T output channels x TT frames per thread.  HBM-bound in principle
+// (2 x 640 floats per frame per layer); see DESIGN.md for the roofline.
+#include "common.h"
+
+namespace {
+
+constexpr int TF = 8;        // frames per workgroup tile
+constexpr int TT = 4;        // frames per thread item
+constexpr int NSET = TF / TT;
+constexpr int CONV_THREADS = 320;
+
+struct ConvArgs {
+    const float* x; const float* w; const float* bias; float* y;
+    int B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout, act, accum;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    return act == 1 ? sigmoid_acc(v) : v;
+}
+
+// ---------------------------------------------------------------------------
+// gather form
+// ---------------------------------------------------------------------------
+template <int CO_T>
+__global__ __launch_bounds__(CONV_THREADS) void conv_gather_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int FinP = a.Fin + 2;                 // [left zero][Fin][right zero]
+    const int nrows = TF + a.KT - 1;            // LDS frame 0 <-> t0-(KT-1)
+    const int K3 = a.Cin * a.KT * 3;
+    float* wl = smem;                           // [K3][Cout]
+    float* xl = smem + ((K3 * a.Cout + 3) & ~3); // [nrows][Cin][FinP]
+    const int tid = threadIdx.x;
+    const int ntile = (a.T + TF - 1) / TF;
+    const int b = blockIdx.x / ntile;
+    const int t0 = (blockIdx.x % ntile) * TF;
+
+    // stage weights: wl[(ci*KT+kt)*3+kf][co]
+    for (int i = tid; i < K3 * a.Cout; i += CONV_THREADS) {
+        const int co = i % a.Cout;
+        const int k = i / a.Cout;
+        const int kf = k % 3, kt = (k / 3) % a.KT, ci = k / (3 * a.KT);
+        float v;
+        if (a.w_layout == 0) v = a.w[((co * a.Cin + ci) * a.KT + kt) * 3 + kf];
+        else v = a.w[(ci * a.Cout + co) * 3 + (2 - kf)];
+        wl[i] = v;
+    }
+    // stage input frames (zero outside the clip and in the pad columns)
+    const int rowlen = a.Cin * FinP;
+    for (int i = tid; i < nrows * rowlen; i += CONV_THREADS) {
+        const int r = i / rowlen, j = i % rowlen;
+        const int ci = j / FinP, fp = j % FinP;
+        const int t = t0 - (a.KT - 1) + r;
+        float v = 0.f;
+        if (t >= 0 && t < a.T && fp >= 1 && fp <= a.Fin)
+            v = a.x[(((long long)b * a.T + t) * a.Cin + ci) * a.Fin + (fp - 1)];
+        xl[i] = v;
+    }
+    __syncthreads();
+
+    const int tpf = (a.Cout / CO_T) * a.Fout;
+    for (int item = tid; item < NSET * tpf; item += CONV_THREADS) {
+        const int set = item / tpf;
+        const int o = item % tpf;
+        const int cq = o / a.Fout, fo = o % a.Fout;
+        const int co0 = cq * CO_T;
+        float acc[TT][CO_T];
+#pragma unroll
+        for (int c = 0; c < CO_T; ++c) {
+            const float bv = a.bias ? a.bias[co0 + c] : 0.f;
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) acc[tt][c] = bv;
+        }
+        const int fbase = fo * a.S - a.pad + 1;
+        for (int ci = 0; ci < a.Cin; ++ci) {
+            for (int kt = 0; kt < a.KT; ++kt) {
+                float wv[3][CO_T];
+                const float* wp = wl + ((ci * a.KT + kt) * 3) * a.Cout + co0;
+#pragma unroll
+                for (int kf = 0; kf < 3; ++kf) {
+                    if constexpr (CO_T == 4) {
+                        const float4 q = *reinterpret_cast<const float4*>(wp + kf * a.Cout);
+                        wv[kf][0] = q.x; wv[kf][1] = q.y; wv[kf][2] = q.z; wv[kf][3] = q.w;
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < CO_T; ++c) wv[kf][c] = wp[kf * a.Cout + c];
+                    }
+                }
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) {
+                    const float* xp = xl + ((set * TT + tt + kt) * a.Cin + ci) * FinP + fbase;
+                    const float x0 = xp[0], x1 = xp[1], x2 = xp[2];
+#pragma unroll
+                    for (int c = 0; c < CO_T; ++c)
+                        acc[tt][c] += wv[0][c] * x0 + wv[1][c] * x1 + wv[2][c] * x2;
+                }
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            const int t = t0 + set * TT + tt;
+            if (t >= a.T) continue;
+#pragma unroll
+            for (int c = 0; c < CO_T; ++c) {
+                const long long idx = (((long long)b * a.T + t) * a.Cout + co0 + c) * a.Fout + fo;
+                float v = acc[tt][c];
+                if (a.accum) v += a.y[idx]; else v = apply_act(v, a.act);
+                a.y[idx] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// scatter form, frequency stride 2 (outputs handled as (2m, 2m+1) pairs)
+// ---------------------------------------------------------------------------
+template <int CO_T>
+__global__ __launch_bounds__(CONV_THREADS) void conv_scatter2_kernel(ConvArgs a) {
+    // here: Cin = Cs (summed channels), Fin = Fg, Fout = 2*Fg
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int FgP = a.Fin + 2;
+    const int nrows = TF + a.KT - 1;            // LDS frame 0 <-> t0
+    const int K3 = a.Cin * a.KT * 3;
+    float* wl = smem;                           // [K3][Cout]
+    float* gl = smem + ((K3 * a.Cout + 3) & ~3);
+    const int tid = threadIdx.x;
+    const int ntile = (a.T + TF - 1) / TF;
+    const int b = blockIdx.x / ntile;
+    const int t0 = (blockIdx.x % ntile) * TF;
+
+    for (int i = tid; i < K3 * a.Cout; i += CONV_THREADS) {
+        const int co = i % a.Cout;
+        const int k = i / a.Cout;               // (cs*KT+kt)*3+kf
+        const int cs = k / (3 * a.KT), rem = k % (3 * a.KT);
+        wl[i] = a.w[(cs * a.Cout + co) * (a.KT * 3) + rem];
+    }
+    const int rowlen = a.Cin * FgP;
+    for (int i = tid; i < nrows * rowlen; i += CONV_THREADS) {
+        const int r = i / rowlen, j = i % rowlen;
+        const int cs = j / FgP, fp = j % FgP;
+        const int t = t0 + r;
+        float v = 0.f;
+        if (t < a.T && fp >= 1 && fp <= a.Fin)
+            v = a.x[(((long long)b * a.T + t) * a.Cin + cs) * a.Fin + (fp - 1)];
+        gl[i] = v;
+    }
+    __syncthreads();
+
+    const int Fg = a.Fin;
+    const int tpf = (a.Cout / CO_T) * Fg;
+    for (int item = tid; item < NSET * tpf; item += CONV_THREADS) {
+        const int set = item / tpf;
+        const int o = item % tpf;
+        const int cq = o / Fg, m = o % Fg;
+        const int co0 = cq * CO_T;
+        float acc0[TT][CO_T], acc1[TT][CO_T];   // fo = 2m, 2m+1
+#pragma unroll
+        for (int c = 0; c < CO_T; ++c) {
+            const float bv = a.bias ? a.bias[co0 + c] : 0.f;
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) { acc0[tt][c] = bv; acc1[tt][c] = bv; }
+        }
+        for (int cs = 0; cs < a.Cin; ++cs) {
+            for (int kt = 0; kt < a.KT; ++kt) {
+                float wv[3][CO_T];
+                const float* wp = wl + ((cs * a.KT + kt) * 3) * a.Cout + co0;
+#pragma unroll
+                for (int kf = 0; kf < 3; ++kf)
+#pragma unroll
+                    for (int c = 0; c < CO_T; ++c) wv[kf][c] = wp[kf * a.Cout + c];
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) {
+                    const int r = set * TT + tt + (a.KT - 1) - kt;
+                    const float* gp = gl + (r * a.Cin + cs) * FgP + m;   // gp[0]=g[m-1], gp[1]=g[m], gp[2]=g[m+1]
+                    const float gm1 = gp[0], g0 = gp[1], gp1 = gp[2];
+                    if (a.pad == 0) {
+#pragma unroll
+                        for (int c = 0; c < CO_T; ++c) {
+                            acc0[tt][c] += wv[0][c] * g0 + wv[2][c] * gm1;
+                            acc1[tt][c] += wv[1][c] * g0;
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < CO_T; ++c) {
+                            acc0[tt][c] += wv[1][c] * g0;
+                            acc1[tt][c] += wv[0][c] * gp1 + wv[2][c] * g0;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            const int t = t0 + set * TT + tt;
+            if (t >= a.T) continue;
+#pragma unroll
+            for (int c = 0; c < CO_T; ++c) {
+                const long long idx = (((long long)b * a.T + t) * a.Cout + co0 + c) * a.Fout + 2 * m;
+                float v0 = acc0[tt][c], v1 = acc1[tt][c];
+                if (a.accum) { v0 += a.y[idx]; v1 += a.y[idx + 1]; }
+                else { v0 = apply_act(v0, a.act); v1 = apply_act(v1, a.act); }
+                *reinterpret_cast<float2*>(a.y + idx) = make_float2(v0, v1);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// weight gradient
+// ---------------------------------------------------------------------------
+struct WgradArgs {
+    const float* a; const float* bt; float* partial;
+    int B, T, Ca, Fa, Cb, Fb, S, pad, ntiles_total;
+};
+
+constexpr int WG_THREADS = 256;
+constexpr int WG_MAX_BLOCKS = 512;
+
+template <int CB_T, int KT>
+__global__ __launch_bounds__(WG_THREADS) void conv_wgrad_kernel(WgradArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int CA_T = 4;
+    constexpr int NACC = CA_T * CB_T * KT * 3;
+    const int CaP = p.Ca + 4;                         // channel-fastest rows, 16B aligned
+    const int CbP = (CB_T == 4) ? p.Cb + 4 : p.Cb;
+    const int FbP = p.Fb + 2;
+    const int nrowb = TF + KT - 1;
+    float* al = smem;                                 // [TF][Fa][CaP]
+    float* bl = smem + TF * p.Fa * CaP;               // [nrowb][FbP][CbP]
+    const int tid = threadIdx.x;
+    const int nta = p.Ca / CA_T, ntb = p.Cb / CB_T;
+    const int NT = nta * ntb;
+    const int ntile_t = (p.T + TF - 1) / TF;
+
+    float acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
+
+    const int npos = TF * p.Fa;
+    for (int tile = blockIdx.x; tile < p.ntiles_total; tile += gridDim.x) {
+        const int b = tile / ntile_t;
+        const int t0 = (tile % ntile_t) * TF;
+        __syncthreads();
+        for (int i = tid; i < TF * p.Ca * p.Fa; i += WG_THREADS) {
+            const int fa = i % p.Fa, ca = (i / p.Fa) % p.Ca, r = i / (p.Fa * p.Ca);
+            const int t = t0 + r;
+            float v = 0.f;
+            if (t < p.T) v = p.a[(((long long)b * p.T + t) * p.Ca + ca) * p.Fa + fa];
+            al[(r * p.Fa + fa) * CaP + ca] = v;
+        }
+        for (int i = tid; i < nrowb * p.Cb * FbP; i += WG_THREADS) {
+            const int fp = i % FbP, cb = (i / FbP) % p.Cb, r = i / (FbP * p.Cb);
+            const int t = t0 - (KT - 1) + r;
+            float v = 0.f;
+            if (t >= 0 && t < p.T && fp >= 1 && fp <= p.Fb)
+                v = p.bt[(((long long)b * p.T + t) * p.Cb + cb) * p.Fb + (fp - 1)];
+            bl[(r * FbP + fp) * CbP + cb] = v;
+        }
+        __syncthreads();
+        // work items: (tile-of-outputs, position); output tile fastest so a wave shares a position
+        for (int w = tid; w < NT * npos; w += WG_THREADS) {
+            const int ot = w % NT, pos = w / NT;
+            const int ia = ot / ntb, ib = ot % ntb;
+            const int r = pos / p.Fa, fa = pos % p.Fa;
+            const float4 av = *reinterpret_cast<const float4*>(al + (r * p.Fa + fa) * CaP + ia * CA_T);
+            const float a4[4] = {av.x, av.y, av.z, av.w};
+            const int fb0 = fa * p.S - p.pad + 1;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+                for (int kf = 0; kf < 3; ++kf) {
+                    const int fidx = fb0 + kf;
+                    float bv[CB_T];
+                    if (fidx >= 0 && fidx < FbP) {
+                        const float* bp = bl + ((r + kt) * FbP + fidx) * CbP + ib * CB_T;
+                        if constexpr (CB_T == 4) {
+                            const float4 q = *reinterpret_cast<const float4*>(bp);
+                            bv[0] = q.x; bv[1] = q.y; bv[2] = q.z; bv[3] = q.w;
+                        } else {
+                            bv[0] = bp[0];
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < CB_T; ++c) bv[c] = 0.f;
+                    }
+#pragma unroll
+                    for (int i = 0; i < CA_T; ++i)
+#pragma unroll
+                        for (int j = 0; j < CB_T; ++j)
+                            acc[((i * CB_T + j) * KT + kt) * 3 + kf] += a4[i] * bv[j];
+                }
+            }
+        }
+    }
+    // NOTE: with w = tid + n*256 and NT dividing 256 (or 256 dividing NT*k) a thread keeps the
+    // same output tile for all its items only when 256 % NT == 0; the host guarantees that.
+    __syncthreads();
+    float* red = smem;                                   // [Ca*Cb*KT*3]
+    const int nout = p.Ca * p.Cb * KT * 3;
+    for (int i = tid; i < nout; i += WG_THREADS) red[i] = 0.f;
+    __syncthreads();
+    {
+        const int ot = tid % NT;
+        const int ia = ot / ntb, ib = ot % ntb;
+#pragma unroll
+        for (int i = 0; i < CA_T; ++i)
+#pragma unroll
+            for (int j = 0; j < CB_T; ++j)
+#pragma unroll
+                for (int k = 0; k < KT * 3; ++k) {
+                    const int ca = ia * CA_T + i, cb = ib * CB_T + j;
+                    atomicAdd(&red[(ca * p.Cb + cb) * (KT * 3) + k], acc[(i * CB_T + j) * (KT * 3) + k]);
+                }
+    }
+    __syncthreads();
+    for (int i = tid; i < nout; i += WG_THREADS) p.partial[(long long)blockIdx.x * nout + i] = red[i];
+}
+
+__global__ void wgrad_reduce_kernel(const float* partial, int nblk, int nout, float* dw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nout) return;
+    float s = 0.f;
+    for (int k = 0; k < nblk; ++k) s += partial[(long long)k * nout + i];
+    dw[i] += s;
+}
+
+// ---------------------------------------------------------------------------
+// channel sum: out[c] += sum_{rows,f} g[row,c,f]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* g, long long rows, int C, int F, int ld,
+                                                          float* out) {
+    // grid.x strides over rows; each thread owns a fixed column j of the C*F-wide row (row stride ld)
+    __shared__ float sacc[2048];
+    const int CF = C * F;
+    const int tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) sacc[c] = 0.f;
+    __syncthreads();
+    for (int j0 = 0; j0 < CF; j0 += 256) {
+        const int j = j0 + tid;
+        float s = 0.f;
+        if (j < CF)
+            for (long long r = blockIdx.x; r < rows; r += gridDim.x) s += g[r * ld + j];
+        if (j < CF) atomicAdd(&sacc[j / F], s);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) atomicAdd(&out[c], sacc[c]);
+}
+
+template <typename K>
+int set_smem(K kern, size_t bytes, const char* name) {
+    return cruse_ensure_dyn_lds(reinterpret_cast<const void*>(kern), bytes, name);
+}
+
+}  // namespace
+
+extern "C" int cruse_conv_gather(const float* x, const float* w, const float* bias, float* y,
+                                 int B, int T, int Cin, int Fin, int Cout, int Fout,
+                                 int KT, int S, int pad, int w_layout, int act, int accum, void* stream) {
+    CRUSE_REQUIRE(B > 0 && T > 0 && Cin > 0 && Cout > 0 && Fin > 0 && Fout > 0, CRUSE_E_SHAPE,
+                  "conv_gather: empty shape B=%d T=%d Cin=%d Cout=%d Fin=%d Fout=%d", B, T, Cin, Cout, Fin, Fout);
+    CRUSE_REQUIRE((KT == 1 || KT == 2) && (S == 1 || S == 2) && (pad == 0 || pad == 1), CRUSE_E_SHAPE,
+                  "conv_gather: unsupported KT=%d S=%d pad=%d", KT, S, pad);
+    CRUSE_REQUIRE((Fout - 1) * S - pad + 2 <= Fin, CRUSE_E_SHAPE,
+                  "conv_gather: Fout=%d reads past Fin=%d (+1 zero column)", Fout, Fin);
+    CRUSE_REQUIRE(w_layout == 0 || (KT == 1 && S == 1), CRUSE_E_SHAPE, "conv_gather: w_layout 1 needs KT=1,S=1");
+    CRUSE_REQUIRE(!(accum && act), CRUSE_E_SHAPE, "conv_gather: accum with activation");
+    ConvArgs a{x, w, bias, y, B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout, act, accum};
+    const size_t lds = (((size_t)Cin * KT * 3 * Cout + 3) & ~(size_t)3) * 4 +
+                       (size_t)(TF + KT - 1) * Cin * (Fin + 2) * 4;
+    CRUSE_REQUIRE(lds <= 160 * 1024, CRUSE_E_SHAPE, "conv_gather: tile needs %zu B of LDS", lds);
+    const int grid = B * cdiv(T, TF);
+    int rc;
+    if (Cout % 4 == 0) {
+        if ((rc = set_smem(conv_gather_kernel<4>, lds, "conv_gather"))) return rc;
+        hipLaunchKernelGGL(conv_gather_kernel<4>, dim3(grid), dim3(CONV_THREADS), lds, (hipStream_t)stream, a);
+    } else {
+        if ((rc = set_smem(conv_gather_kernel<1>, lds, "conv_gather"))) return rc;
+        hipLaunchKernelGGL(conv_gather_kernel<1>, dim3(grid), dim3(CONV_THREADS), lds, (hipStream_t)stream, a);
+    }
+    CRUSE_LAUNCH_CHECK("conv_gather");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_conv_scatter2(const float* g, const float* w, const float* bias, float* y,
+                                   int B, int T, int Cs, int Fg, int Cout, int Fout,
+                                   int KT, int pad, int act, int accum, void* stream) {
+    CRUSE_REQUIRE(B > 0 && T > 0 && Cs > 0 && Cout > 0 && Fg > 0, CRUSE_E_SHAPE, "conv_scatter2: empty shape");
+    CRUSE_REQUIRE(Fout == 2 * Fg, CRUSE_E_SHAPE, "conv_scatter2: Fout=%d must be 2*Fg=%d", Fout, 2 * Fg);
+    CRUSE_REQUIRE((KT == 1 || KT == 2) && (pad == 0 || pad == 1), CRUSE_E_SHAPE,
+                  "conv_scatter2: unsupported KT=%d pad=%d", KT, pad);
+    CRUSE_REQUIRE(!(accum && act), CRUSE_E_SHAPE, "conv_scatter2: accum with activation");
+    ConvArgs a{g, w, bias, y, B, T, Cs, Fg, Cout, Fout, KT, 2, pad, 0, act, accum};
+    const size_t lds = (((size_t)Cs * KT * 3 * Cout + 3) & ~(size_t)3) * 4 +
+                       (size_t)(TF + KT - 1) * Cs * (Fg + 2) * 4;
+    CRUSE_REQUIRE(lds <= 160 * 1024, CRUSE_E_SHAPE, "conv_scatter2: tile needs %zu B of LDS", lds);
+    const int grid = B * cdiv(T, TF);
+    int rc;
+    if (Cout % 2 == 0) {
+        if ((rc = set_smem(conv_scatter2_kernel<2>, lds, "conv_scatter2"))) return rc;
+        hipLaunchKernelGGL(conv_scatter2_kernel<2>, dim3(grid), dim3(CONV_THREADS), lds, (hipStream_t)stream, a);
+    } else {
+        if ((rc = set_smem(conv_scatter2_kernel<1>, lds, "conv_scatter2"))) return rc;
+        hipLaunchKernelGGL(conv_scatter2_kernel<1>, dim3(grid), dim3(CONV_THREADS), lds, (hipStream_t)stream, a);
+    }
+    CRUSE_LAUNCH_CHECK("conv_scatter2");
+    return CRUSE_OK;
+}
+
+extern "C" size_t cruse_conv_wgrad_ws_bytes(int Ca, int Cb, int KT) {
+    return (size_t)WG_MAX_BLOCKS * Ca * Cb * KT * 3 * sizeof(float);
+}
+
+extern "C" int cruse_conv_wgrad(const float* a, const float* bt, float* dw,
+                                int B, int T, int Ca, int Fa, int Cb, int Fb,
+                                int KT, int S, int pad, void* ws, void* stream) {
+    CRUSE_REQUIRE(B > 0 && T > 0 && Ca > 0 && Cb > 0, CRUSE_E_SHAPE, "conv_wgrad: empty shape");
+    CRUSE_REQUIRE(Ca % 4 == 0 && (Cb % 4 == 0 || Cb == 1), CRUSE_E_SHAPE,
+                  "conv_wgrad: Ca=%d must be a multiple of 4 and Cb=%d a multiple of 4 or 1", Ca, Cb);
+    CRUSE_REQUIRE((KT == 1 || KT == 2) && (S == 1 || S == 2) && (pad == 0 || pad == 1), CRUSE_E_SHAPE,
+                  "conv_wgrad: unsupported KT=%d S=%d pad=%d", KT, S, pad);
+    const int cbt = (Cb % 4 == 0) ? 4 : 1;
+    const int NT = (Ca / 4) * (Cb / cbt);
+    CRUSE_REQUIRE(WG_THREADS % NT == 0 || NT % WG_THREADS == 0, CRUSE_E_SHAPE,
+                  "conv_wgrad: %d output tiles do not divide the %d-thread block", NT, WG_THREADS);
+    // a thread must keep one output tile: items w = tid + n*256 have ot = w % NT = tid % NT iff 256 % NT == 0
+    CRUSE_REQUIRE(WG_THREADS % NT == 0, CRUSE_E_SHAPE, "conv_wgrad: %d output tiles > %d threads", NT, WG_THREADS);
+    const int CaP = Ca + 4, CbP = (cbt == 4) ? Cb + 4 : Cb;
+    const size_t lds_stage = ((size_t)TF * Fa * CaP + (size_t)(TF + KT - 1) * (Fb + 2) * CbP) * 4;
+    const size_t lds_red = (size_t)Ca * Cb * KT * 3 * 4;
+    const size_t lds = lds_stage > lds_red ? lds_stage : lds_red;
+    CRUSE_REQUIRE(lds <= 160 * 1024, CRUSE_E_SHAPE, "conv_wgrad: needs %zu B of LDS", lds);
+    const int ntiles = B * cdiv(T, TF);
+    const int grid = ntiles < WG_MAX_BLOCKS ? ntiles : WG_MAX_BLOCKS;
+    WgradArgs p{a, bt, (float*)ws, B, T, Ca, Fa, Cb, Fb, S, pad, ntiles};
+    int rc;
+#define LAUNCH_WG(CBT, KTT)                                                                             \
+    do {                                                                                                \
+        if ((rc = set_smem(conv_wgrad_kernel<CBT, KTT>, lds, "conv_wgrad"))) return rc;                 \
+        hipLaunchKernelGGL((conv_wgrad_kernel<CBT, KTT>), dim3(grid), dim3(WG_THREADS), lds,            \
+                           (hipStream_t)stream, p);                                                     \
+    } while (0)
+    if (cbt == 4 && KT == 2) LAUNCH_WG(4, 2);
+    else if (cbt == 4 && KT == 1) LAUNCH_WG(4, 1);
+    else if (cbt == 1 && KT == 2) LAUNCH_WG(1, 2);
+    else LAUNCH_WG(1, 1);
+#undef LAUNCH_WG
+    CRUSE_LAUNCH_CHECK("conv_wgrad");
+    const int nout = Ca * Cb * KT * 3;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(nout, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)ws, grid, nout, dw);
+    CRUSE_LAUNCH_CHECK("conv_wgrad_reduce");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_channel_sum(const float* g, long long rows, int C, int F, float* out, void* stream) {
+    CRUSE_REQUIRE(rows > 0 && C > 0 && F > 0 && C <= 2048, CRUSE_E_SHAPE,
+                  "channel_sum: bad shape rows=%lld C=%d F=%d (C <= 2048)", rows, C, F);
+    long long nb = rows < 512 ? rows : 512;
+    hipLaunchKernelGGL(channel_sum_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, g, rows, C, F, C * F, out);
+    CRUSE_LAUNCH_CHECK("channel_sum");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_col_sum(const float* g, long long rows, int ncol, int ld, float* out, void* stream) {
+    CRUSE_REQUIRE(rows > 0 && ncol > 0 && ncol <= 2048 && ld >= ncol, CRUSE_E_SHAPE,
+                  "col_sum: bad shape rows=%lld ncol=%d ld=%d (ncol <= 2048)", rows, ncol, ld);
+    long long nb = rows < 512 ? rows : 512;
+    hipLaunchKernelGGL(channel_sum_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, g, rows, ncol, 1, ld, out);
+    CRUSE_LAUNCH_CHECK("col_sum");
+    return CRUSE_OK;
+}

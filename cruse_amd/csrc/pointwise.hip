@@ -1,0 +1,457 @@
+// HBM-bound frame-row kernels: BatchNorm2d (training statistics, +ReLU, +skip add),
+// LayerNorm (+ group interleave, + residual), magnitude-mask application + WO-MALE loss,
+// fused Adam.  All activations are [rows = B*T][C][F] f32 with C*F contiguous per frame.
+//
+// Reference call sites: model/cruse_net.py:141-142,149-152,161-163 (BatchNorm2d + ReLU + skip
+// add), :32-33,43-51 (LayerNorm + stack/flatten interleave), :160 (gru + skip4),
+// utils/utils.py:418-420 (mask application), loss_func/loss.py:121-148 (WO-MALE),
+// tools/train_stand.py:68-71 (Adam).
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ BatchNorm ---
+// sums[c] += sum v, sums[C+c] += sum v2 where (v, v2) come from functor F per element.
+template <typename Fn>
+__device__ __forceinline__ void channel_pair_reduce(long long rows, int C, int F, double* sums, Fn fn) {
+    __shared__ double s1[256], s2[256];
+    const int CF = C * F;
+    const int tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) { s1[c] = 0.0; s2[c] = 0.0; }
+    __syncthreads();
+    for (int j0 = 0; j0 < CF; j0 += 256) {
+        const int j = j0 + tid;
+        if (j < CF) {
+            const int c = j / F;
+            float a = 0.f, b = 0.f;
+            int n = 0;
+            double da = 0.0, db = 0.0;
+            for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+                float v, v2;
+                fn(r * CF + j, c, v, v2);
+                a += v; b += v2;
+                if (++n == 64) { da += a; db += b; a = b = 0.f; n = 0; }
+            }
+            da += a; db += b;
+            atomicAdd(&s1[c], da);
+            atomicAdd(&s2[c], db);
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        atomicAdd(&sums[c], s1[c]);
+        atomicAdd(&sums[C + c], s2[c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* y, long long rows, int C, int F, double* sums) {
+    channel_pair_reduce(rows, C, F, sums, [&](long long i, int, float& v, float& v2) {
+        const float t = y[i];
+        v = t; v2 = t * t;
+    });
+}
+
+__global__ void bn_finalize_kernel(const double* sums, long long count, int C, float eps, float momentum,
+                                   float* mean, float* rstd, float* rmean, float* rvar) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = sums[c] / (double)count;
+    double var = sums[C + c] / (double)count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) {
+        const double unb = count > 1 ? var * (double)count / (double)(count - 1) : var;
+        rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * m);
+        rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * unb);
+    }
+}
+
+__global__ void bn_eval_stats_kernel(const float* rmean, const float* rvar, int C, float eps, float* mean, float* rstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    mean[c] = rmean[c];
+    rstd[c] = 1.0f / sqrtf(rvar[c] + eps);
+}
+
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* y, const float* mean, const float* rstd,
+                                                         const float* gamma, const float* beta, const float* skip,
+                                                         float* out, long long rows, int C, int F, int relu) {
+    extern __shared__ float tab[];  // [4][C]
+    for (int c = threadIdx.x; c < C; c += 256) {
+        tab[c] = mean[c]; tab[C + c] = rstd[c]; tab[2 * C + c] = gamma[c]; tab[3 * C + c] = beta[c];
+    }
+    __syncthreads();
+    const int CF = C * F;
+    const long long n4 = rows * CF / 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(y)[i];
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (skip) s = reinterpret_cast<const float4*>(skip)[i];
+        const int j = (int)((i * 4) % CF);
+        float in[4] = {v.x, v.y, v.z, v.w};
+        float sk[4] = {s.x, s.y, s.z, s.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = (j + e) / F;
+            float t = (in[e] - tab[c]) * tab[C + c] * tab[2 * C + c] + tab[3 * C + c];
+            if (relu) t = fmaxf(t, 0.f);
+            o[e] = t + sk[e];
+        }
+        reinterpret_cast<float4*>(out)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* dout, const float* y, const float* mean,
+                                                                const float* rstd, const float* gamma,
+                                                                const float* beta, long long rows, int C, int F,
+                                                                int relu, double* sums) {
+    channel_pair_reduce(rows, C, F, sums, [&](long long i, int c, float& v, float& v2) {
+        const float xh = (y[i] - mean[c]) * rstd[c];
+        float g = dout[i];
+        if (relu && !(xh * gamma[c] + beta[c] > 0.f)) g = 0.f;
+        v = g; v2 = g * xh;
+    });
+}
+
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* dout, const float* y, const float* mean,
+                                                               const float* rstd, const float* gamma,
+                                                               const float* beta, const double* sums, long long rows,
+                                                               int C, int F, int relu, int training, float* dy,
+                                                               float* dgamma, float* dbeta) {
+    extern __shared__ float tab[];  // [6][C]: mean, rstd, gamma, beta, sg/count, sgx/count
+    const double cnt = (double)rows * F;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        tab[c] = mean[c]; tab[C + c] = rstd[c]; tab[2 * C + c] = gamma[c]; tab[3 * C + c] = beta[c];
+        tab[4 * C + c] = training ? (float)(sums[c] / cnt) : 0.f;
+        tab[5 * C + c] = training ? (float)(sums[C + c] / cnt) : 0.f;
+        if (blockIdx.x == 0) {
+            if (dgamma) dgamma[c] += (float)sums[C + c];
+            if (dbeta) dbeta[c] += (float)sums[c];
+        }
+    }
+    __syncthreads();
+    const int CF = C * F;
+    const long long n4 = rows * CF / 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(y)[i];
+        const float4 d = reinterpret_cast<const float4*>(dout)[i];
+        const int j = (int)((i * 4) % CF);
+        float in[4] = {v.x, v.y, v.z, v.w};
+        float dd[4] = {d.x, d.y, d.z, d.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = (j + e) / F;
+            const float xh = (in[e] - tab[c]) * tab[C + c];
+            float g = dd[e];
+            if (relu && !(xh * tab[2 * C + c] + tab[3 * C + c] > 0.f)) g = 0.f;
+            o[e] = tab[2 * C + c] * tab[C + c] * (g - tab[4 * C + c] - xh * tab[5 * C + c]);
+        }
+        reinterpret_cast<float4*>(dy)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ------------------------------------------------------------------ LayerNorm ---
+constexpr int LN_MAXE = 16;  // H <= 1024
+
+__device__ __forceinline__ int ln_perm(int c, int H, int g) {
+    if (g <= 1) return c;
+    const int Hg = H / g;
+    return (c % Hg) * g + c / Hg;
+}
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* x, const float* gamma, const float* beta,
+                                                     const float* res, float* y, float* mean, float* rstd,
+                                                     long long rows, int H, int g, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nwave = (long long)gridDim.x * 4;
+    for (long long r = wave; r < rows; r += nwave) {
+        float v[LN_MAXE];
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < LN_MAXE; ++e) {
+            const int c = lane + 64 * e;
+            v[e] = c < H ? x[r * H + c] : 0.f;
+            s += v[e];
+        }
+        const float m = wave_sum(s) / (float)H;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < LN_MAXE; ++e) {
+            const int c = lane + 64 * e;
+            const float d = c < H ? v[e] - m : 0.f;
+            q += d * d;
+        }
+        const float rs = 1.0f / sqrtf(wave_sum(q) / (float)H + eps);
+        if (lane == 0) { if (mean) mean[r] = m; if (rstd) rstd[r] = rs; }
+#pragma unroll
+        for (int e = 0; e < LN_MAXE; ++e) {
+            const int c = lane + 64 * e;
+            if (c < H) {
+                const int p = ln_perm(c, H, g);
+                float o = (v[e] - m) * rs * gamma[p] + beta[p];
+                if (res) o += res[r * H + p];
+                y[r * H + p] = o;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const float* x, const float* mean,
+                                                     const float* rstd, const float* gamma, long long rows, int H,
+                                                     int g, float* dx, float* dgamma, float* dbeta) {
+    __shared__ float sdg[1024], sdb[1024];
+    const int lane = threadIdx.x & 63;
+    for (int c = threadIdx.x; c < H; c += 256) { sdg[c] = 0.f; sdb[c] = 0.f; }
+    __syncthreads();
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nwave = (long long)gridDim.x * 4;
+    float adg[LN_MAXE], adb[LN_MAXE];
+    int perm[LN_MAXE];
+    float gm[LN_MAXE];
+#pragma unroll
+    for (int e = 0; e < LN_MAXE; ++e) {
+        adg[e] = 0.f; adb[e] = 0.f;
+        const int c = lane + 64 * e;
+        perm[e] = c < H ? ln_perm(c, H, g) : 0;
+        gm[e] = c < H ? gamma[perm[e]] : 0.f;
+    }
+    for (long long r = wave; r < rows; r += nwave) {
+        const float m = mean[r], rs = rstd[r];
+        float xh[LN_MAXE], gd[LN_MAXE];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < LN_MAXE; ++e) {
+            const int c = lane + 64 * e;
+            if (c < H) {
+                const float d = dy[r * H + perm[e]];
+                xh[e] = (x[r * H + c] - m) * rs;
+                gd[e] = d * gm[e];
+                adg[e] += d * xh[e];
+                adb[e] += d;
+                s1 += gd[e];
+                s2 += gd[e] * xh[e];
+            } else { xh[e] = 0.f; gd[e] = 0.f; }
+        }
+        const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
+#pragma unroll
+        for (int e = 0; e < LN_MAXE; ++e) {
+            const int c = lane + 64 * e;
+            if (c < H) dx[r * H + c] = rs * (gd[e] - m1 - xh[e] * m2);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < LN_MAXE; ++e) {
+        const int c = lane + 64 * e;
+        if (c < H) { atomicAdd(&sdg[perm[e]], adg[e]); atomicAdd(&sdb[perm[e]], adb[e]); }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += 256) {
+        if (dgamma) atomicAdd(&dgamma[c], sdg[c]);
+        if (dbeta) atomicAdd(&dbeta[c], sdb[c]);
+    }
+}
+
+// ------------------------------------------------------------------ mask + loss ---
+__global__ __launch_bounds__(256) void mask_loss_kernel(const float* mask, const float* nre, const float* nim,
+                                                        const float* cmag, long long rows, int Fn, int Fs,
+                                                        float alpha, float beta, double* loss_sum, float* dmask,
+                                                        float* dlogit, float* est_re, float* est_im) {
+    __shared__ double sred[4];
+    const long long n = rows * Fs;
+    const float inv_n = (float)(1.0 / (double)n);
+    const float inv_ln10 = 0.43429448190325176f;
+    double acc = 0.0;
+    float part = 0.f;
+    int cnt = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long r = i / Fs;
+        const int f = (int)(i % Fs);
+        const float re = nre[i], im = nim[i];
+        const float m = f < Fn ? mask[r * Fn + f] : 0.f;
+        const float er = m * re, ei = m * im;
+        const float mag_est = sqrtf(er * er + ei * ei);
+        const float mag_ref = cmag[i];
+        const float mag_unp = sqrtf(re * re + im * im);
+        const float iam = mag_ref / mag_unp;
+        const float w = expf(alpha / (beta + iam));
+        const float d = log10f(mag_est + 1.f) - log10f(mag_ref + 1.f);
+        part += w * fabsf(d);
+        if (++cnt == 32) { acc += part; part = 0.f; cnt = 0; }
+        if (est_re) est_re[i] = er;
+        if (est_im) est_im[i] = ei;
+        if (f < Fn && (dmask || dlogit)) {
+            const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+            const float dm = w * sgn * inv_ln10 / (mag_est + 1.f) * mag_unp * inv_n;
+            if (dmask) dmask[r * Fn + f] = dm;
+            if (dlogit) dlogit[r * Fn + f] = dm * m * (1.f - m);
+        }
+    }
+    acc += part;
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss_sum, sred[0] + sred[1] + sred[2] + sred[3]);
+}
+
+__global__ void sigmoid_bwd_kernel(const float* dmask, const float* mask, float* dlogit, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float m = mask[i];
+        dlogit[i] = dmask[i] * m * (1.f - m);
+    }
+}
+
+__global__ void axpby_kernel(float* out, const float* x, const float* y, float a, float b, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = a * x[i] + (y ? b * y[i] : 0.f);
+}
+
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2,
+                            float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float gi = g[i] * gscale;
+        const float pi = p[i];
+        if (wd != 0.f) gi += wd * pi;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
+inline int grid_for(long long n, int per_block, int cap = 4096) {
+    long long g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+}  // namespace
+
+#define ST(s) ((hipStream_t)(s))
+
+extern "C" int cruse_bn_stats(const float* y, long long rows, int C, int F, double* sums, void* stream) {
+    CRUSE_REQUIRE(rows > 0 && C > 0 && C <= 256 && F > 0, CRUSE_E_SHAPE, "bn_stats: bad shape rows=%lld C=%d F=%d", rows, C, F);
+    CRUSE_HIP(hipMemsetAsync(sums, 0, 2 * C * sizeof(double), ST(stream)), "bn_stats memset");
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(rows, 8, 1024)), dim3(256), 0, ST(stream), y, rows, C, F, sums);
+    CRUSE_LAUNCH_CHECK("bn_stats");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_bn_finalize(const double* sums, long long count, int C, float eps, float momentum,
+                                 float* mean, float* rstd, float* running_mean, float* running_var, void* stream) {
+    CRUSE_REQUIRE(count > 0 && C > 0, CRUSE_E_SHAPE, "bn_finalize: bad shape");
+    CRUSE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), CRUSE_E_SHAPE, "bn_finalize: running stats");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, ST(stream), sums, count, C, eps, momentum,
+                       mean, rstd, running_mean, running_var);
+    CRUSE_LAUNCH_CHECK("bn_finalize");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps,
+                                   float* mean, float* rstd, void* stream) {
+    CRUSE_REQUIRE(C > 0, CRUSE_E_SHAPE, "bn_eval_stats: bad shape");
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 64)), dim3(64), 0, ST(stream), running_mean, running_var, C,
+                       eps, mean, rstd);
+    CRUSE_LAUNCH_CHECK("bn_eval_stats");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_bn_act_fwd(const float* y, const float* mean, const float* rstd, const float* gamma,
+                                const float* beta, const float* skip, float* out,
+                                long long rows, int C, int F, int relu, void* stream) {
+    CRUSE_REQUIRE(rows > 0 && C > 0 && F > 0, CRUSE_E_SHAPE, "bn_act_fwd: bad shape");
+    CRUSE_REQUIRE((C * F) % 4 == 0, CRUSE_E_ALIGN, "bn_act_fwd: C*F=%d must be a multiple of 4", C * F);
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(rows * C * F / 4, 1024)), dim3(256), 4 * C * sizeof(float),
+                       ST(stream), y, mean, rstd, gamma, beta, skip, out, rows, C, F, relu);
+    CRUSE_LAUNCH_CHECK("bn_act_fwd");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_bn_act_bwd_reduce(const float* dout, const float* y, const float* mean, const float* rstd,
+                                       const float* gamma, const float* beta, long long rows, int C, int F,
+                                       int relu, double* sums, void* stream) {
+    CRUSE_REQUIRE(rows > 0 && C > 0 && C <= 256 && F > 0, CRUSE_E_SHAPE, "bn_act_bwd_reduce: bad shape");
+    CRUSE_HIP(hipMemsetAsync(sums, 0, 2 * C * sizeof(double), ST(stream)), "bn_act_bwd_reduce memset");
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(grid_for(rows, 8, 1024)), dim3(256), 0, ST(stream), dout, y, mean,
+                       rstd, gamma, beta, rows, C, F, relu, sums);
+    CRUSE_LAUNCH_CHECK("bn_act_bwd_reduce");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_bn_act_bwd_apply(const float* dout, const float* y, const float* mean, const float* rstd,
+                                      const float* gamma, const float* beta, const double* sums,
+                                      long long rows, int C, int F, int relu, int training,
+                                      float* dy, float* dgamma, float* dbeta, void* stream) {
+    CRUSE_REQUIRE(rows > 0 && C > 0 && F > 0, CRUSE_E_SHAPE, "bn_act_bwd_apply: bad shape");
+    CRUSE_REQUIRE((C * F) % 4 == 0, CRUSE_E_ALIGN, "bn_act_bwd_apply: C*F=%d must be a multiple of 4", C * F);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for(rows * C * F / 4, 1024)), dim3(256),
+                       6 * C * sizeof(float), ST(stream), dout, y, mean, rstd, gamma, beta, sums, rows, C, F, relu,
+                       training, dy, dgamma, dbeta);
+    CRUSE_LAUNCH_CHECK("bn_act_bwd_apply");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_ln_fwd(const float* x, const float* gamma, const float* beta, const float* res,
+                            float* y, float* mean, float* rstd, long long rows, int H, int interleave_g,
+                            float eps, void* stream) {
+    CRUSE_REQUIRE(rows > 0 && H > 0 && H <= 64 * LN_MAXE, CRUSE_E_SHAPE, "ln_fwd: H=%d must be in 1..%d", H, 64 * LN_MAXE);
+    CRUSE_REQUIRE(interleave_g >= 1 && H % interleave_g == 0, CRUSE_E_SHAPE, "ln_fwd: groups=%d must divide H=%d", interleave_g, H);
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid_for(rows, 4, 2048)), dim3(256), 0, ST(stream), x, gamma, beta, res, y,
+                       mean, rstd, rows, H, interleave_g, eps);
+    CRUSE_LAUNCH_CHECK("ln_fwd");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
+                            const float* gamma, long long rows, int H, int interleave_g,
+                            float* dx, float* dgamma, float* dbeta, void* stream) {
+    CRUSE_REQUIRE(rows > 0 && H > 0 && H <= 64 * LN_MAXE, CRUSE_E_SHAPE, "ln_bwd: H=%d must be in 1..%d", H, 64 * LN_MAXE);
+    CRUSE_REQUIRE(interleave_g >= 1 && H % interleave_g == 0, CRUSE_E_SHAPE, "ln_bwd: groups=%d must divide H=%d", interleave_g, H);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid_for(rows, 32, 1024)), dim3(256), 0, ST(stream), dy, x, mean, rstd, gamma,
+                       rows, H, interleave_g, dx, dgamma, dbeta);
+    CRUSE_LAUNCH_CHECK("ln_bwd");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_mask_loss_fwd(const float* mask, const float* nre, const float* nim, const float* cmag,
+                                   long long rows, int Fn, int Fs, float alpha, float beta,
+                                   double* loss_sum, float* dmask, float* dlogit, float* est_re, float* est_im,
+                                   void* stream) {
+    CRUSE_REQUIRE(rows > 0 && Fn > 0 && Fs >= Fn, CRUSE_E_SHAPE, "mask_loss: bad shape rows=%lld Fn=%d Fs=%d", rows, Fn, Fs);
+    CRUSE_HIP(hipMemsetAsync(loss_sum, 0, sizeof(double), ST(stream)), "mask_loss memset");
+    hipLaunchKernelGGL(mask_loss_kernel, dim3(grid_for(rows * Fs, 2048, 2048)), dim3(256), 0, ST(stream), mask, nre, nim,
+                       cmag, rows, Fn, Fs, alpha, beta, loss_sum, dmask, dlogit, est_re, est_im);
+    CRUSE_LAUNCH_CHECK("mask_loss");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_sigmoid_bwd(const float* dmask, const float* mask, float* dlogit, long long n, void* stream) {
+    CRUSE_REQUIRE(n > 0, CRUSE_E_SHAPE, "sigmoid_bwd: n=%lld", n);
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, ST(stream), dmask, mask, dlogit, n);
+    CRUSE_LAUNCH_CHECK("sigmoid_bwd");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_axpby(float* out, const float* x, const float* y, float a, float b, long long n, void* stream) {
+    CRUSE_REQUIRE(n > 0, CRUSE_E_SHAPE, "axpby: n=%lld", n);
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, ST(stream), out, x, y, a, b, n);
+    CRUSE_LAUNCH_CHECK("axpby");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_adam_step(float* p, const float* g, float* m, float* v, long long n,
+                               float lr, float beta1, float beta2, float eps, float weight_decay,
+                               int step, float grad_scale, void* stream) {
+    CRUSE_REQUIRE(n > 0 && step >= 1, CRUSE_E_SHAPE, "adam_step: n=%lld step=%d", n, step);
+    const double bc1 = 1.0 - pow((double)beta1, step);
+    const double bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, ST(stream), p, g, m, v, n, lr, beta1, beta2,
+                       eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+    CRUSE_LAUNCH_CHECK("adam_step");
+    return CRUSE_OK;
+}

@@ -1,0 +1,306 @@
+"""MI355X-native `model.cruse_net`: GGRU and unet_2 with the reference's nn.Module surface.
+
+Same class names, constructor arguments, state-dict keys and weight layouts as
+model/cruse_net.py:14-55 (GGRU) and :129-165 (unet_2, repairs R1-R8 of SURVEY.md
+section 8a), so `initialize_module("model.cruse_net.unet_2", args)` and checkpoints
+keep working.  The stock torch.nn sub-modules are used ONLY as parameter containers
+(their default initialisation consumes the RNG exactly as the reference would); every
+forward/backward op runs in libcruse_hip.so through `cruse_amd.ops`.  There is no
+CPU or eager-torch fallback: calling these modules on CPU tensors raises.
+
+Internally activations are frame-major [B,T,C,F] (one 640-float row per frame at every
+U-Net level), so GGRU's transpose(1,2)+view (cruse_net.py:39-40) costs nothing.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+DEFAULT_PREC = "f32"
+
+
+def _splitk(M: int, N: int, K: int) -> int:
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    sk = max(1, (512 + tiles - 1) // tiles)
+    return max(1, min(sk, K // 256 if K >= 256 else 1))
+
+
+# ======================================================================================
+# GGRU functional core on [B,T,H] rows
+# ======================================================================================
+def ggru_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], prefix: str, groups: int, prec,
+                 residual: Optional[torch.Tensor] = None, save: bool = True):
+    """x [B,T,H] -> (ln2(gru2(ln1(interleave(gru1(x))))) [+ residual], ctx).  cruse_net.py:37-55."""
+    B, T, H = x.shape
+    g = groups
+    Hg = H // g
+    rows = B * T
+    ctx = dict(B=B, T=T, H=H, g=g, prec=prec, x=x, prefix=prefix, has_res=residual is not None)
+
+    def layer(inp, lname):
+        gi = torch.empty(B, T, g * 3 * Hg, device=x.device, dtype=torch.float32)
+        for i in range(g):
+            ops.gemm(False, True, rows, 3 * Hg, Hg, inp, i * Hg, H, P[f"{prefix}{lname}.{i}.weight_ih_l0"], 0, Hg,
+                     gi, i * 3 * Hg, 3 * H, bias=P[f"{prefix}{lname}.{i}.bias_ih_l0"], prec=prec)
+        w_hh = [P[f"{prefix}{lname}.{i}.weight_hh_l0"] for i in range(g)]
+        b_hh = [P[f"{prefix}{lname}.{i}.bias_hh_l0"] for i in range(g)]
+        return ops.gru_seq_fwd(gi, w_hh, b_hh, B, T, g, Hg, prec, save=save)
+
+    h1, r1, z1, n1, q1 = layer(x, "gru_list1")
+    l1, m1, s1 = ops.ln_fwd(h1, P[prefix + "ln1.weight"], P[prefix + "ln1.bias"], None, rows, H, g, save=save)
+    h2, r2, z2, n2, q2 = layer(l1, "gru_list2")
+    out, m2, s2 = ops.ln_fwd(h2, P[prefix + "ln2.weight"], P[prefix + "ln2.bias"], residual, rows, H, 1, save=save)
+    if save:
+        ctx.update(h1=h1, r1=r1, z1=z1, n1=n1, q1=q1, l1=l1, m1=m1, s1=s1,
+                   h2=h2, r2=r2, z2=z2, n2=n2, q2=q2, m2=m2, s2=s2)
+    return out, ctx
+
+
+def ggru_backward(ctx, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor],
+                  need_dx: bool = True) -> Optional[torch.Tensor]:
+    """dout [B,T,H] -> dx; parameter gradients are ACCUMULATED into G[name]."""
+    B, T, H, g, prec, prefix = ctx["B"], ctx["T"], ctx["H"], ctx["g"], ctx["prec"], ctx["prefix"]
+    Hg = H // g
+    rows = B * T
+
+    def layer_bwd(dh, lname, inp, h, r, z, n, q, need_dinp):
+        w_hh = [P[f"{prefix}{lname}.{i}.weight_hh_l0"] for i in range(g)]
+        dgi, dgh = ops.gru_seq_bwd(dh, w_hh, h, r, z, n, q, B, T, g, Hg, prec)
+        dinp = torch.empty(B, T, H, device=dh.device, dtype=torch.float32) if need_dinp else None
+        sk = _splitk(3 * Hg, Hg, rows)
+        for i in range(g):
+            nm = f"{prefix}{lname}.{i}."
+            # dW_hh += dgh^T h_{t-1}
+            ops.gemm(True, False, 3 * Hg, Hg, rows, dgh, i * 3 * Hg, 3 * H, h, i * Hg, H, G[nm + "weight_hh_l0"], 0, Hg,
+                     accumulate=True, splitk=sk, b_shift_T=T, prec=prec)
+            ops.col_sum(dgh, i * 3 * Hg, rows, 3 * Hg, 3 * H, G[nm + "bias_hh_l0"])
+            # dW_ih += dgi^T x
+            ops.gemm(True, False, 3 * Hg, Hg, rows, dgi, i * 3 * Hg, 3 * H, inp, i * Hg, H, G[nm + "weight_ih_l0"], 0, Hg,
+                     accumulate=True, splitk=sk, prec=prec)
+            ops.col_sum(dgi, i * 3 * Hg, rows, 3 * Hg, 3 * H, G[nm + "bias_ih_l0"])
+            if need_dinp:
+                ops.gemm(False, False, rows, Hg, 3 * Hg, dgi, i * 3 * Hg, 3 * H, P[nm + "weight_ih_l0"], 0, Hg,
+                         dinp, i * Hg, H, prec=prec)
+        return dinp
+
+    dh2 = ops.ln_bwd(dout, ctx["h2"], ctx["m2"], ctx["s2"], P[prefix + "ln2.weight"], rows, H, 1,
+                     G[prefix + "ln2.weight"], G[prefix + "ln2.bias"])
+    dl1 = layer_bwd(dh2, "gru_list2", ctx["l1"], ctx["h2"], ctx["r2"], ctx["z2"], ctx["n2"], ctx["q2"], True)
+    dh1 = ops.ln_bwd(dl1, ctx["h1"], ctx["m1"], ctx["s1"], P[prefix + "ln1.weight"], rows, H, g,
+                     G[prefix + "ln1.weight"], G[prefix + "ln1.bias"])
+    dx = layer_bwd(dh1, "gru_list1", ctx["x"], ctx["h1"], ctx["r1"], ctx["z1"], ctx["n1"], ctx["q1"], need_dx)
+    return dx
+
+
+# ======================================================================================
+# unet_2 functional core
+# ======================================================================================
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _bn_stats(y, rows, C, F, P, Bf, name, training, update_running):
+    if training:
+        sums = ops.bn_stats(y, rows, C, F)
+        rm = Bf[name + ".running_mean"] if update_running else None
+        rv = Bf[name + ".running_var"] if update_running else None
+        mean, rstd = ops.bn_finalize(sums, rows * F, C, BN_EPS, BN_MOMENTUM, rm, rv)
+        if update_running:
+            Bf[name + ".num_batches_tracked"].add_(1)
+        return mean, rstd
+    return ops.bn_eval_stats(Bf[name + ".running_mean"], Bf[name + ".running_var"], BN_EPS)
+
+
+def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, torch.Tensor], ch, groups: int,
+                  prec, training: bool, save: bool = True, update_running: bool = True):
+    """x [B,1,T,F0] (== frame-major [B,T,1,F0]) -> (mask [B,1,T,F0], ctx).  cruse_net.py:147-165."""
+    if x.dim() != 4 or x.shape[1] != ch[0]:
+        raise RuntimeError(f"unet_2 expects [B,{ch[0]},T,F], got {tuple(x.shape)}")
+    if ch[0] != 1:
+        raise RuntimeError("cruse_amd unet_2 supports ch[0] == 1 (magnitude input) only")
+    B, _, T, F0 = x.shape
+    L = len(ch) - 1
+    if F0 % (1 << L) != 0:
+        raise RuntimeError(f"unet_2: {F0} input bins are not divisible by 2**{L} (the network runs on in_feat//2*2 bins)")
+    rows = B * T
+    Fk = [F0 >> k for k in range(L + 1)]
+    ctx = dict(B=B, T=T, F=Fk, ch=tuple(ch), L=L, prec=prec, training=training, x=x)
+    cur = x
+    ys, es, ss, stats = [None], [x], [None], [None]
+    for k in range(1, L + 1):
+        y = ops.conv_gather(cur, P[f"conv{k}.weight"], P[f"conv{k}.bias"], B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k],
+                            KT=2, S=2, pad=1)
+        mean, rstd = _bn_stats(y, rows, ch[k], Fk[k], P, Bf, f"bn{k}", training, update_running)
+        e = ops.bn_act_fwd(y, mean, rstd, P[f"bn{k}.weight"], P[f"bn{k}.bias"], None, rows, ch[k], Fk[k], relu=True)
+        s = ops.conv_gather(e, P[f"skip_connect_{k}.weight"], None, B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1)
+        ys.append(y); es.append(e); ss.append(s); stats.append((mean, rstd))
+        cur = e
+    H = ch[L] * Fk[L]
+    u, gctx = ggru_forward(cur.view(B, T, H), P, "gru.", groups, prec, residual=ss[L].view(B, T, H), save=save)
+    u = u.view(B, T, ch[L], Fk[L])
+    us, vs, dstats = {L: u}, {}, {}
+    for k in range(L, 1, -1):
+        v = ops.conv_scatter2(u, P[f"conv{k}_t.weight"], P[f"conv{k}_t.bias"], B, T, ch[k], Fk[k], ch[k - 1], KT=1, pad=0)
+        mean, rstd = _bn_stats(v, rows, ch[k - 1], Fk[k - 1], P, Bf, f"bn{k}_t", training, update_running)
+        u = ops.bn_act_fwd(v, mean, rstd, P[f"bn{k}_t.weight"], P[f"bn{k}_t.bias"], ss[k - 1], rows, ch[k - 1],
+                           Fk[k - 1], relu=True)
+        vs[k] = v; dstats[k] = (mean, rstd); us[k - 1] = u
+    mask = ops.conv_scatter2(u, P["conv1_t.weight"], P["conv1_t.bias"], B, T, ch[1], Fk[1], ch[0], KT=1, pad=0, act=1)
+    if save:
+        ctx.update(ys=ys, es=es, stats=stats, gctx=gctx, us=us, vs=vs, dstats=dstats, mask=mask)
+    return mask.view(B, ch[0], T, F0), ctx
+
+
+def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor]) -> None:
+    """dlogit = dL/d(pre-sigmoid) [B,T,1,F0]; parameter gradients are ACCUMULATED into G[name]."""
+    B, T, Fk, ch, L, training = ctx["B"], ctx["T"], ctx["F"], ctx["ch"], ctx["L"], ctx["training"]
+    rows = B * T
+    ys, es, stats, us, vs, dstats = ctx["ys"], ctx["es"], ctx["stats"], ctx["us"], ctx["vs"], ctx["dstats"]
+    # ---- decoder level 1: v1 = convT_1(u1) -------------------------------------------
+    dv = dlogit
+    ops.channel_sum(dv, rows, ch[0], Fk[0], G["conv1_t.bias"])
+    ops.conv_wgrad(us[1], dv, G["conv1_t.weight"], B, T, ch[1], Fk[1], ch[0], Fk[0], KT=1, S=2, pad=0)
+    du = ops.conv_gather(dv, P["conv1_t.weight"], None, B, T, ch[0], Fk[0], ch[1], Fk[1], KT=1, S=2, pad=0)
+    ds = {1: du}                                        # gradient wrt skip_{k} output = du_k
+    # ---- decoder levels 2..L ------------------------------------------------------------
+    for k in range(2, L + 1):
+        mean, rstd = dstats[k]
+        dv = ops.bn_act_bwd(du, vs[k], mean, rstd, P[f"bn{k}_t.weight"], P[f"bn{k}_t.bias"], rows, ch[k - 1],
+                            Fk[k - 1], True, training, G[f"bn{k}_t.weight"], G[f"bn{k}_t.bias"])
+        ops.channel_sum(dv, rows, ch[k - 1], Fk[k - 1], G[f"conv{k}_t.bias"])
+        ops.conv_wgrad(us[k], dv, G[f"conv{k}_t.weight"], B, T, ch[k], Fk[k], ch[k - 1], Fk[k - 1], KT=1, S=2, pad=0)
+        du = ops.conv_gather(dv, P[f"conv{k}_t.weight"], None, B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k], KT=1, S=2, pad=0)
+        ds[k] = du
+    # ---- bottleneck: u_L = ggru(e_L) + skip_L --------------------------------------------
+    H = ch[L] * Fk[L]
+    de = ggru_backward(ctx["gctx"], du.view(B, T, H), P, G).view(B, T, ch[L], Fk[L])
+    # ---- encoder levels L..1 ----------------------------------------------------------------
+    for k in range(L, 0, -1):
+        # skip_k = conv1x3(e_k): de_k += W^T ds_k ; dW_skip += ds_k (*) e_k
+        ops.conv_gather(ds[k], P[f"skip_connect_{k}.weight"], None, B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1,
+                        w_layout=1, out=de, accum=True)
+        ops.conv_wgrad(ds[k], es[k], G[f"skip_connect_{k}.weight"], B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1)
+        mean, rstd = stats[k]
+        dy = ops.bn_act_bwd(de, ys[k], mean, rstd, P[f"bn{k}.weight"], P[f"bn{k}.bias"], rows, ch[k], Fk[k], True,
+                            training, G[f"bn{k}.weight"], G[f"bn{k}.bias"])
+        ops.channel_sum(dy, rows, ch[k], Fk[k], G[f"conv{k}.bias"])
+        ops.conv_wgrad(dy, es[k - 1], G[f"conv{k}.weight"], B, T, ch[k], Fk[k], ch[k - 1], Fk[k - 1], KT=2, S=2, pad=1)
+        if k > 1:
+            de = ops.conv_scatter2(dy, P[f"conv{k}.weight"], None, B, T, ch[k], Fk[k], ch[k - 1], KT=2, pad=1)
+
+
+# ======================================================================================
+# autograd glue + nn.Module surface
+# ======================================================================================
+class _GGRUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod, names, *params):
+        P = dict(zip(names, params))
+        need = any(p.requires_grad for p in params) or x.requires_grad
+        out, c = ggru_forward(x, P, "", mod.groups, mod.precision, save=need)
+        ctx.c, ctx.P, ctx.names = c, P, names
+        ctx.need_dx = x.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        P = ctx.P
+        G = {n: torch.zeros_like(P[n]) for n in ctx.names}
+        dx = ggru_backward(ctx.c, dout.contiguous(), P, G, need_dx=ctx.need_dx)
+        return (dx, None, None) + tuple(G[n] for n in ctx.names)
+
+
+class GGRU(nn.Module):
+    """model/cruse_net.py:14-55 (repair R1).  forward([B,C,T,F]) -> [B,C,T,F]."""
+
+    def __init__(self, in_features=None, out_features=None, mid_features=None, hidden_size=1024, groups=2,
+                 precision: str = DEFAULT_PREC):
+        super().__init__()
+        hidden_size_t = hidden_size // groups
+        self.gru_list1 = nn.ModuleList([nn.GRU(hidden_size_t, hidden_size_t, 1, batch_first=True) for _ in range(groups)])
+        self.gru_list2 = nn.ModuleList([nn.GRU(hidden_size_t, hidden_size_t, 1, batch_first=True) for _ in range(groups)])
+        self.ln1 = nn.LayerNorm(hidden_size)
+        self.ln2 = nn.LayerNorm(hidden_size)
+        self.groups = groups
+        self.mid_features = mid_features
+        self.hidden_size = hidden_size
+        self.precision = precision
+
+    def forward(self, x):
+        if x.dim() != 4:
+            raise RuntimeError(f"GGRU expects [B,C,T,F], got {tuple(x.shape)}")
+        B, C, T, F = x.shape
+        if C * F != self.hidden_size:
+            raise RuntimeError(f"GGRU: C*F = {C * F} does not match hidden_size = {self.hidden_size}")
+        rows = x.transpose(1, 2).contiguous().view(B, T, C * F)          # cruse_net.py:39-40
+        names = [n for n, _ in self.named_parameters()]
+        params = [p for _, p in self.named_parameters()]
+        out = _GGRUFn.apply(rows, self, names, *params)
+        return out.view(B, T, C, F).transpose(1, 2).contiguous()         # cruse_net.py:53-54
+
+
+class _Unet2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod, names, *params):
+        P = dict(zip(names, params))
+        Bf = dict(mod.named_buffers())
+        need = any(p.requires_grad for p in params)
+        mask, c = unet2_forward(x, P, Bf, mod.ch, mod.rnn_groups, mod.precision, mod.training, save=need)
+        ctx.c, ctx.P, ctx.names = c, P, names
+        return mask
+
+    @staticmethod
+    def backward(ctx, dmask):
+        P, c = ctx.P, ctx.c
+        used = [n for n in ctx.names if not (n.startswith("fc.") or n.startswith("bn1_t."))]
+        G = {n: torch.zeros_like(P[n]) for n in used}
+        B, T, F0 = c["B"], c["T"], c["F"][0]
+        dlogit = ops.sigmoid_bwd(dmask.contiguous().view(B, T, 1, F0), c["mask"])
+        unet2_backward(c, dlogit, P, G)
+        return (None, None, None) + tuple(G.get(n) for n in ctx.names)
+
+
+class unet_2(nn.Module):
+    """model/cruse_net.py:129-165 with repairs R2-R8.  forward([B,1,T,160]) -> mask [B,1,T,160]."""
+
+    def __init__(self, in_feat=161, ch=(1, 8, 16, 32, 64), stride=(1, 2), rnn_groups=4,
+                 precision: str = DEFAULT_PREC):
+        super().__init__()
+        if tuple(stride) != (1, 2):
+            raise RuntimeError("cruse_amd unet_2 implements stride (1,2) only (model/cruse_net.py:130 default)")
+        self.laynum = len(ch) - 1
+        hidden_size = in_feat // 2 ** self.laynum * ch[-1]
+        self.ker_x = 2
+        self.stride = stride
+        self.padding = [self.ker_x - stride[0], 3 - stride[1]]
+        for i in range(len(ch) - 1):
+            k = i + 1
+            setattr(self, f"conv{k}", nn.Conv2d(ch[k - 1], ch[k], (self.ker_x, 3), self.stride, self.padding))
+            setattr(self, f"conv{k}_t", nn.ConvTranspose2d(ch[k], ch[k - 1], (1, 3), self.stride))
+            setattr(self, f"bn{k}", nn.BatchNorm2d(ch[k]))
+            setattr(self, f"bn{k}_t", nn.BatchNorm2d(ch[k - 1]))
+            setattr(self, f"skip_connect_{k}", nn.Conv2d(ch[k], ch[k], (1, 3), padding=(0, 1), bias=False))
+        self.gru = GGRU(hidden_size=hidden_size, groups=rnn_groups, precision=precision)
+        self.elu = nn.ReLU()                      # named `elu` in the reference (:145), is a ReLU
+        self.fc = nn.Linear(in_feat, in_feat)     # unused by forward (:146); kept for checkpoints
+        self.ch = tuple(ch)
+        self.rnn_groups = rnn_groups
+        self.in_feat = in_feat
+        self.hidden_size = hidden_size
+        self.precision = precision
+
+    def set_precision(self, precision: str) -> None:
+        self.precision = precision
+        self.gru.precision = precision
+
+    def forward(self, x):
+        if x.shape[-1] * self.ch[-1] // (1 << self.laynum) != self.hidden_size:
+            raise RuntimeError(f"unet_2: {x.shape[-1]} input bins give hidden size "
+                               f"{x.shape[-1] * self.ch[-1] // (1 << self.laynum)}, expected {self.hidden_size}")
+        names = [n for n, _ in self.named_parameters()]
+        params = [p for _, p in self.named_parameters()]
+        return _Unet2Fn.apply(x.contiguous(), self, names, *params)

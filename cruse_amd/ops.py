@@ -1,0 +1,265 @@
+"""Torch-tensor wrappers over the C ABI (include/cruse_hip.h).
+
+torch is used here for device memory and the current HIP stream only; every
+arithmetic op is a kernel in libcruse_hip.so.  All tensors are f32 CUDA(HIP)
+tensors in frame-major [B,T,C,F] layout unless stated.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence
+
+import torch
+
+from ._lib import PREC_BF16, PREC_BF16X3, PREC_BY_NAME, PREC_F32, check, lib  # noqa: F401
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("cruse_amd ops need tensors on the HIP device (no CPU fallback)")
+    if not t.is_contiguous():
+        raise RuntimeError(f"cruse_amd ops need contiguous tensors, got strides {t.stride()} for shape {tuple(t.shape)}")
+    return t.data_ptr()
+
+
+def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
+    return t
+
+
+def prec_code(prec) -> int:
+    if isinstance(prec, str):
+        return PREC_BY_NAME[prec]
+    return int(prec)
+
+
+# ---------------------------------------------------------------- STFT / iSTFT
+def stft_frames(L: int, hop: int) -> int:
+    return 1 + L // hop
+
+
+def stft(wave: torch.Tensor, n_fft: int, hop: int, want_ri: bool = True, mag_bins: int = 0,
+         mag_eps: float = 0.0):
+    """wave [B,L] -> (re [B,T,F], im [B,T,F], mag [B,T,mag_bins]); absent outputs are None."""
+    _f32(wave, "stft")
+    if wave.dim() != 2:
+        raise RuntimeError(f"stft expects [B,L], got {tuple(wave.shape)}")
+    B, L = wave.shape
+    T = stft_frames(L, hop)
+    F = n_fft // 2 + 1
+    re = torch.empty(B, T, F, device=wave.device, dtype=torch.float32) if want_ri else None
+    im = torch.empty(B, T, F, device=wave.device, dtype=torch.float32) if want_ri else None
+    mag = torch.empty(B, T, mag_bins, device=wave.device, dtype=torch.float32) if mag_bins > 0 else None
+    check(lib.cruse_stft_fwd(_p(wave), B, L, n_fft, hop, _p(re), _p(im), _p(mag), mag_bins, mag_eps, _stream()))
+    return re, im, mag
+
+
+def istft(re: torch.Tensor, im: torch.Tensor, n_fft: int, hop: int, length: int) -> torch.Tensor:
+    B, T, F = re.shape
+    if F != n_fft // 2 + 1 or im.shape != re.shape:
+        raise RuntimeError(f"istft: spectrum shape {tuple(re.shape)} does not match n_fft={n_fft}")
+    wave = torch.empty(B, length, device=re.device, dtype=torch.float32)
+    check(lib.cruse_istft_fwd(_p(re), _p(im), B, T, n_fft, hop, length, _p(wave), _stream()))
+    return wave
+
+
+def istft_bwd(dwave: torch.Tensor, T: int, n_fft: int, hop: int):
+    B, L = dwave.shape
+    F = n_fft // 2 + 1
+    dre = torch.empty(B, T, F, device=dwave.device, dtype=torch.float32)
+    dim = torch.empty(B, T, F, device=dwave.device, dtype=torch.float32)
+    check(lib.cruse_istft_bwd(_p(dwave), B, T, n_fft, hop, L, _p(dre), _p(dim), _stream()))
+    return dre, dim
+
+
+# ---------------------------------------------------------------- convolutions
+def conv_gather(x, w, bias, B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout=0, act=0, out=None, accum=False):
+    if out is None:
+        out = torch.empty(B, T, Cout, Fout, device=x.device, dtype=torch.float32)
+    check(lib.cruse_conv_gather(_p(x), _p(w), _p(bias), _p(out), B, T, Cin, Fin, Cout, Fout, KT, S, pad,
+                                w_layout, act, 1 if accum else 0, _stream()))
+    return out
+
+
+def conv_scatter2(g, w, bias, B, T, Cs, Fg, Cout, KT, pad, act=0, out=None, accum=False):
+    Fout = 2 * Fg
+    if out is None:
+        out = torch.empty(B, T, Cout, Fout, device=g.device, dtype=torch.float32)
+    check(lib.cruse_conv_scatter2(_p(g), _p(w), _p(bias), _p(out), B, T, Cs, Fg, Cout, Fout, KT, pad, act,
+                                  1 if accum else 0, _stream()))
+    return out
+
+
+_wgrad_ws = {}
+
+
+def _ws(key, nbytes: int, device) -> torch.Tensor:
+    buf = _wgrad_ws.get((key, device))
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _wgrad_ws[(key, device)] = buf
+    return buf
+
+
+def conv_wgrad(a, bt, dw, B, T, Ca, Fa, Cb, Fb, KT, S, pad):
+    """dw[ca][cb][kt][kf] += ... (dw is a contiguous f32 tensor of Ca*Cb*KT*3 elements)."""
+    nbytes = lib.cruse_conv_wgrad_ws_bytes(Ca, Cb, KT)
+    ws = _ws("wgrad", nbytes, a.device)
+    check(lib.cruse_conv_wgrad(_p(a), _p(bt), _p(dw), B, T, Ca, Fa, Cb, Fb, KT, S, pad, _p(ws), _stream()))
+
+
+def channel_sum(g, rows, C, F, out):
+    check(lib.cruse_channel_sum(_p(g), rows, C, F, _p(out), _stream()))
+
+
+def col_sum(g, g_off, rows, ncol, ld, out):
+    check(lib.cruse_col_sum(g.data_ptr() + 4 * g_off, rows, ncol, ld, _p(out), _stream()))
+
+
+# ---------------------------------------------------------------- BatchNorm
+def bn_stats(y, rows, C, F):
+    sums = torch.empty(2 * C, device=y.device, dtype=torch.float64)
+    check(lib.cruse_bn_stats(_p(y), rows, C, F, _p(sums), _stream()))
+    return sums
+
+
+def bn_finalize(sums, count, C, eps, momentum, running_mean=None, running_var=None):
+    mean = torch.empty(C, device=sums.device, dtype=torch.float32)
+    rstd = torch.empty(C, device=sums.device, dtype=torch.float32)
+    check(lib.cruse_bn_finalize(_p(sums), count, C, eps, momentum, _p(mean), _p(rstd), _p(running_mean),
+                                _p(running_var), _stream()))
+    return mean, rstd
+
+
+def bn_eval_stats(running_mean, running_var, eps):
+    C = running_mean.numel()
+    mean = torch.empty(C, device=running_mean.device, dtype=torch.float32)
+    rstd = torch.empty(C, device=running_mean.device, dtype=torch.float32)
+    check(lib.cruse_bn_eval_stats(_p(running_mean), _p(running_var), C, eps, _p(mean), _p(rstd), _stream()))
+    return mean, rstd
+
+
+def bn_act_fwd(y, mean, rstd, gamma, beta, skip, rows, C, F, relu=True):
+    out = torch.empty_like(y)
+    check(lib.cruse_bn_act_fwd(_p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(skip), _p(out), rows, C, F,
+                               1 if relu else 0, _stream()))
+    return out
+
+
+def bn_act_bwd(dout, y, mean, rstd, gamma, beta, rows, C, F, relu, training, dgamma, dbeta):
+    sums = torch.empty(2 * C, device=y.device, dtype=torch.float64)
+    check(lib.cruse_bn_act_bwd_reduce(_p(dout), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), rows, C, F,
+                                      1 if relu else 0, _p(sums), _stream()))
+    dy = torch.empty_like(y)
+    check(lib.cruse_bn_act_bwd_apply(_p(dout), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(sums), rows, C, F,
+                                     1 if relu else 0, 1 if training else 0, _p(dy), _p(dgamma), _p(dbeta),
+                                     _stream()))
+    return dy
+
+
+# ---------------------------------------------------------------- LayerNorm
+def ln_fwd(x, gamma, beta, res, rows, H, interleave_g=1, eps=1e-5, save=True):
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32) if save else None
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32) if save else None
+    check(lib.cruse_ln_fwd(_p(x), _p(gamma), _p(beta), _p(res), _p(y), _p(mean), _p(rstd), rows, H, interleave_g,
+                           eps, _stream()))
+    return y, mean, rstd
+
+
+def ln_bwd(dy, x, mean, rstd, gamma, rows, H, interleave_g, dgamma, dbeta):
+    dx = torch.empty_like(x)
+    check(lib.cruse_ln_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), rows, H, interleave_g, _p(dx), _p(dgamma),
+                           _p(dbeta), _stream()))
+    return dx
+
+
+# ---------------------------------------------------------------- GEMM
+def gemm(transA, transB, M, N, K, A, a_off, lda, Bm, b_off, ldb, C, c_off, ldc, bias=None, accumulate=False,
+         splitk=1, b_shift_T=0, prec=PREC_F32):
+    """Raw-pointer GEMM; *_off are element offsets into the tensors' storage views."""
+    pa = A.data_ptr() + 4 * a_off
+    pb = Bm.data_ptr() + 4 * b_off
+    pc = C.data_ptr() + 4 * c_off
+    check(lib.cruse_gemm(1 if transA else 0, 1 if transB else 0, M, N, K, pa, lda, pb, ldb, pc, ldc, _p(bias),
+                         1 if accumulate else 0, splitk, b_shift_T, prec_code(prec), _stream()))
+
+
+# ---------------------------------------------------------------- GRU recurrence
+def _ptr_array(ts: Sequence[torch.Tensor]):
+    arr = (ctypes.c_void_p * len(ts))()
+    for i, t in enumerate(ts):
+        arr[i] = _p(t)
+    return arr
+
+
+def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G, Hg, prec, save=True):
+    dev = gi.device
+    H = G * Hg
+    h = torch.empty(B, T, H, device=dev, dtype=torch.float32)
+    if save:
+        r = torch.empty_like(h); z = torch.empty_like(h); n = torch.empty_like(h); ghn = torch.empty_like(h)
+    else:
+        r = z = n = ghn = None
+    ws = _ws("gru", lib.cruse_gru_ws_bytes(B, G, Hg), dev)
+    wa, ba = _ptr_array(w_hh), _ptr_array(b_hh)
+    check(lib.cruse_gru_seq_fwd(_p(gi), ctypes.cast(wa, ctypes.c_void_p), ctypes.cast(ba, ctypes.c_void_p), _p(h),
+                                _p(r), _p(z), _p(n), _p(ghn), B, T, G, Hg, prec_code(prec), _p(ws), _stream()))
+    return h, r, z, n, ghn
+
+
+def gru_seq_bwd(dout, w_hh: List[torch.Tensor], h, r, z, n, ghn, B, T, G, Hg, prec):
+    dev = dout.device
+    dgi = torch.empty(B, T, G * 3 * Hg, device=dev, dtype=torch.float32)
+    dgh = torch.empty_like(dgi)
+    ws = _ws("gru", lib.cruse_gru_ws_bytes(B, G, Hg), dev)
+    wa = _ptr_array(w_hh)
+    check(lib.cruse_gru_seq_bwd(_p(dout), ctypes.cast(wa, ctypes.c_void_p), _p(h), _p(r), _p(z), _p(n), _p(ghn),
+                                _p(dgi), _p(dgh), B, T, G, Hg, prec_code(prec), _p(ws), _stream()))
+    return dgi, dgh
+
+
+def gru_status() -> int:
+    """0 if no recurrence hand-off ever timed out (synchronises)."""
+    bad = 0
+    for (key, _dev), buf in _wgrad_ws.items():
+        if key == "gru":
+            bad |= int(buf[:4].view(torch.int32).item())
+    return bad
+
+
+# ---------------------------------------------------------------- mask + loss, misc
+def mask_loss(mask, nre, nim, cmag, rows, Fn, Fs, alpha=2.0, beta=1.0, want_dmask=False, want_dlogit=False,
+              want_est=False):
+    dev = mask.device
+    loss_sum = torch.empty(1, device=dev, dtype=torch.float64)
+    dmask = torch.empty(rows, Fn, device=dev, dtype=torch.float32) if want_dmask else None
+    dlogit = torch.empty(rows, Fn, device=dev, dtype=torch.float32) if want_dlogit else None
+    er = torch.empty(rows, Fs, device=dev, dtype=torch.float32) if want_est else None
+    ei = torch.empty(rows, Fs, device=dev, dtype=torch.float32) if want_est else None
+    check(lib.cruse_mask_loss_fwd(_p(mask), _p(nre), _p(nim), _p(cmag), rows, Fn, Fs, alpha, beta, _p(loss_sum),
+                                  _p(dmask), _p(dlogit), _p(er), _p(ei), _stream()))
+    return loss_sum, dmask, dlogit, er, ei
+
+
+def sigmoid_bwd(dmask, mask):
+    out = torch.empty_like(mask)
+    check(lib.cruse_sigmoid_bwd(_p(dmask), _p(mask), _p(out), mask.numel(), _stream()))
+    return out
+
+
+def axpby(out, x, y, a, b):
+    check(lib.cruse_axpby(_p(out), _p(x), _p(y), a, b, out.numel(), _stream()))
+    return out
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    check(lib.cruse_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
+                              grad_scale, _stream()))

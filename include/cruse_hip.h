@@ -1,0 +1,201 @@
+/* libcruse_hip.so -- C ABI of the MI355X (gfx950) CRUSE hot path.
+ *
+ * The reference (Okrio/CRUSE) is pure Python and has no FFI; its extension point
+ * is dotted-path module loading (train_base/utils.py:68-100).  Every entry point
+ * below therefore replaces a *PyTorch library op at one of the reference's call
+ * sites* (SURVEY.md section 2b); the call site is cited on each declaration.
+ * Host code (cruse_amd/) binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - extern "C"; every function returns int: 0 = ok, <0 = CRUSE_E_*;
+ *     cruse_last_error() returns a thread-local message.
+ *   - all buffers are caller-allocated DEVICE pointers (f32 unless noted); the
+ *     library never frees or retains them beyond the call.
+ *   - last argument is the hipStream_t (passed as void*); calls are asynchronous
+ *     and re-entrant per stream; no global mutable state.
+ *   - activation layout is "frame-major": [B, T, C, F] contiguous, i.e. one row of
+ *     C*F floats per spectrogram frame.  For C == 1 this is the reference's
+ *     [B,1,T,F]; GGRU's [B,T,C*F] view (model/cruse_net.py:39-40) is this layout
+ *     with no copy.
+ *   - "+=" outputs accumulate into the caller's buffer (gradient buffers).
+ */
+#ifndef CRUSE_HIP_H
+#define CRUSE_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRUSE_ABI_VERSION 1
+
+enum {
+    CRUSE_OK = 0,
+    CRUSE_E_SHAPE = -1,
+    CRUSE_E_ALIGN = -2,
+    CRUSE_E_DTYPE = -3,
+    CRUSE_E_HIP = -4,
+    CRUSE_E_TIMEOUT = -5
+};
+
+/* precision of the MFMA contractions (GEMMs and GRU recurrence) */
+enum {
+    CRUSE_PREC_F32 = 0,    /* v_mfma_f32_16x16x4_f32: exact f32                         */
+    CRUSE_PREC_BF16X3 = 1, /* split bf16 hi+lo, 3 bf16 MFMAs: ~2^-17 relative           */
+    CRUSE_PREC_BF16 = 2    /* operands rounded to bf16, f32 accumulate                  */
+};
+
+int cruse_abi_version(void);
+const char* cruse_last_error(void);
+
+/* ---- acoustic front end ---------------------------------------------------- */
+
+/* torch.stft(y, n_fft, hop, win=n_fft, window=hann_window(n_fft), center=True,
+ * return_complex=True) at train_base/acoustics/feature.py:22-30, fused with the
+ * [B,T,F] transposition and magnitude of utils/utils.py:397-400.
+ * wave [B,L] -> re, im [B,T,n_fft/2+1] (either may be NULL),
+ *               mag [B,T,mag_bins] = sqrt(re^2+im^2+mag_eps) for the first mag_bins bins (may be NULL).
+ * T = 1 + L/hop.  Reflect padding of n_fft/2.  n_fft == 320 runs the radix-5 x 64
+ * wavefront-shuffle FFT; any other even n_fft <= 2048 a direct DFT. */
+int cruse_stft_fwd(const float* wave, int B, int L, int n_fft, int hop,
+                   float* re, float* im, float* mag, int mag_bins, float mag_eps, void* stream);
+
+/* torch.istft(X, n_fft, hop, win=n_fft, window=hann_window(n_fft), center=True, length=L)
+ * at feature.py:53-61 / utils/utils.py:448-454.  re, im [B,T,n_fft/2+1] -> wave [B,L]. */
+int cruse_istft_fwd(const float* re, const float* im, int B, int T, int n_fft, int hop, int L,
+                    float* wave, void* stream);
+/* adjoint of cruse_istft_fwd: dwave [B,L] -> dre, dim [B,T,n_fft/2+1] */
+int cruse_istft_bwd(const float* dwave, int B, int T, int n_fft, int hop, int L,
+                    float* dre, float* dim, void* stream);
+
+/* ---- convolutions (nn.Conv2d / nn.ConvTranspose2d at model/cruse_net.py:138-143,149-164) */
+
+/* gather form:
+ *   y[b,t,co,fo] (+)= act(bias[co] + sum_{ci,kt,kf} W(co,ci,kt,kf) * x[b, t-(KT-1)+kt, ci, fo*S - pad + kf])
+ * zero outside the clip.  kf in 0..2.  w_layout 0: W = w[co][ci][kt][kf] (Conv2d weight, or a
+ * ConvTranspose2d weight read as [out=Cin_t][in=Cout_t] for its backward-data).
+ * w_layout 1 (KT == 1, S == 1): W(co,ci,0,kf) = w[ci][co][0][2-kf] (backward-data of a stride-1 conv).
+ * act 0 none, 1 sigmoid.  accum != 0: y += result (act must be 0). bias may be NULL. */
+int cruse_conv_gather(const float* x, const float* w, const float* bias, float* y,
+                      int B, int T, int Cin, int Fin, int Cout, int Fout,
+                      int KT, int S, int pad, int w_layout, int act, int accum, void* stream);
+
+/* scatter form, frequency stride 2:
+ *   y[b,t,co,fo] (+)= act(bias[co] + sum_{cs,kt,kf : (fo+pad-kf) even} w[cs][co][kt][kf] *
+ *                                     g[b, t+(KT-1)-kt, cs, (fo+pad-kf)/2])
+ * ConvTranspose2d((1,3), stride (1,2)) forward with the [..., :-1] crop (cruse_net.py:161-164):
+ * KT=1, pad=0, Fout=2*Fg.  Backward-data of the (2,3)/(1,2) encoder conv: KT=2, pad=1. */
+int cruse_conv_scatter2(const float* g, const float* w, const float* bias, float* y,
+                        int B, int T, int Cs, int Fg, int Cout, int Fout,
+                        int KT, int pad, int act, int accum, void* stream);
+
+/* weight gradient of either form:
+ *   dw[ca][cb][kt][kf] += sum_{b,t,fa} a[b,t,ca,fa] * bt[b, t-(KT-1)+kt, cb, fa*S - pad + kf]
+ * ws: scratch of cruse_conv_wgrad_ws_bytes() bytes. */
+size_t cruse_conv_wgrad_ws_bytes(int Ca, int Cb, int KT);
+int cruse_conv_wgrad(const float* a, const float* bt, float* dw,
+                     int B, int T, int Ca, int Fa, int Cb, int Fb,
+                     int KT, int S, int pad, void* ws, void* stream);
+
+/* out[c] += sum_{rows,f} g[row,c,f]   (bias gradients; F=1 gives a column sum) */
+int cruse_channel_sum(const float* g, long long rows, int C, int F, float* out, void* stream);
+/* out[j] += sum_rows g[row*ld + j], j < ncol  (GRU bias gradients: a column slice of dgi / dgh) */
+int cruse_col_sum(const float* g, long long rows, int ncol, int ld, float* out, void* stream);
+
+/* ---- BatchNorm2d (+ReLU, + skip add) (cruse_net.py:141-142,149-152,161-163) ---- */
+
+/* sums[0..C) = sum y, sums[C..2C) = sum y^2 over rows x F (f64; zeroed by the callee) */
+int cruse_bn_stats(const float* y, long long rows, int C, int F, double* sums, void* stream);
+/* training: mean/rstd from sums (biased var), running stats updated with momentum and
+ * unbiased var when running_mean != NULL (torch BatchNorm2d semantics). */
+int cruse_bn_finalize(const double* sums, long long count, int C, float eps, float momentum,
+                      float* mean, float* rstd, float* running_mean, float* running_var, void* stream);
+/* eval: mean = running_mean, rstd = 1/sqrt(running_var+eps) */
+int cruse_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps,
+                        float* mean, float* rstd, void* stream);
+/* out = [relu]((y-mean)*rstd*gamma+beta) [+ skip] */
+int cruse_bn_act_fwd(const float* y, const float* mean, const float* rstd, const float* gamma,
+                     const float* beta, const float* skip, float* out,
+                     long long rows, int C, int F, int relu, void* stream);
+/* sums[0..C) = sum g, sums[C..2C) = sum g*xhat with g = dout * [bn(y) > 0] (zeroed by the callee) */
+int cruse_bn_act_bwd_reduce(const float* dout, const float* y, const float* mean, const float* rstd,
+                            const float* gamma, const float* beta, long long rows, int C, int F,
+                            int relu, double* sums, void* stream);
+/* dy = gamma*rstd*(g - [training](sum_g + xhat*sum_gx)/count); dgamma += sum_gx; dbeta += sum_g */
+int cruse_bn_act_bwd_apply(const float* dout, const float* y, const float* mean, const float* rstd,
+                           const float* gamma, const float* beta, const double* sums,
+                           long long rows, int C, int F, int relu, int training,
+                           float* dy, float* dgamma, float* dbeta, void* stream);
+
+/* ---- LayerNorm (+ group interleave, + residual) (cruse_net.py:32-33,43-51,160) -- */
+
+/* y[row, P(c)] = (x[row,c]-mean)*rstd*gamma[P(c)] + beta[P(c)] (+ res[row,P(c)])
+ * P(i*Hg + j) = j*g + i with Hg = H/g is the stack(dim=-1)+flatten of cruse_net.py:43-45
+ * (interleave_g = g; 1 = identity / the plain cat of :49-50). eps = 1e-5. */
+int cruse_ln_fwd(const float* x, const float* gamma, const float* beta, const float* res,
+                 float* y, float* mean, float* rstd, long long rows, int H, int interleave_g,
+                 float eps, void* stream);
+int cruse_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
+                 const float* gamma, long long rows, int H, int interleave_g,
+                 float* dx, float* dgamma, float* dbeta, void* stream);
+
+/* ---- MFMA GEMM (GRU gate projections nn.GRU at cruse_net.py:23-31; their dX / dW) -- */
+
+/* C[M,N] (=|+=) op(A) * op(B) (+ bias[n]);  op(A) is [M,K]: transA==0 -> A[m*lda+k], else A[k*lda+m];
+ * op(B) is [K,N]: transB==0 -> B[k*ldb+n], else B[n*ldb+k].
+ * accumulate != 0: C += ...; splitk > 1 splits K over blockIdx.z and adds atomically (implies +=).
+ * b_shift_T > 0 (transB==0 only): row k of B is read from row k-1 and is zero when k % b_shift_T == 0
+ * (the h_{t-1} operand of dW_hh). prec: CRUSE_PREC_*. */
+int cruse_gemm(int transA, int transB, int M, int N, int K,
+               const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+               const float* bias, int accumulate, int splitk, int b_shift_T, int prec, void* stream);
+
+/* ---- grouped-GRU recurrence (nn.GRU forward/backward at cruse_net.py:44,50) ----- */
+
+/* Persistent recurrence.  gi [B,T,G,3*Hg] = x W_ih^T + b_ih (gate order r,z,n) from cruse_gemm;
+ * w_hh[g] -> [3*Hg,Hg], b_hh[g] -> [3*Hg] (HOST arrays of G device pointers); h0 = 0.
+ * Outputs, all [B,T,G*Hg] in "cat" layout (feature = g*Hg + j): h and, for backward, r, z, n and
+ * ghn = W_hn h_{t-1} + b_hn (NULL to skip).  Hg % 32 == 0, Hg <= 1024.
+ * ws: cruse_gru_ws_bytes() bytes of device scratch (flags; zeroed by the callee). */
+size_t cruse_gru_ws_bytes(int B, int G, int Hg);
+int cruse_gru_seq_fwd(const float* gi, const float* const* w_hh, const float* const* b_hh,
+                      float* h, float* r, float* z, float* n, float* ghn,
+                      int B, int T, int G, int Hg, int prec, void* ws, void* stream);
+/* dout = dL/dh [B,T,G*Hg] -> dgi (gradient wrt gi) and dgh (gradient wrt W_hh h + b_hh), both
+ * [B,T,G,3*Hg].  dW_ih, dW_hh, dX and the bias gradients follow from cruse_gemm / cruse_channel_sum. */
+int cruse_gru_seq_bwd(const float* dout, const float* const* w_hh,
+                      const float* h, const float* r, const float* z, const float* n, const float* ghn,
+                      float* dgi, float* dgh,
+                      int B, int T, int G, int Hg, int prec, void* ws, void* stream);
+
+/* ---- mask application + weighted spectral loss ------------------------------- */
+
+/* PreProcess.masking "mag_mapping" (utils/utils.py:418-420) fused with WO-MALE
+ * (loss_func/loss.py:121-148, alpha/(beta+iam), gamma = 1) and its gradient.
+ * mask [rows,Fn]; nre, nim [rows,Fs] noisy spectrum; cmag [rows,Fs] = |clean|; bins Fn..Fs-1 of the
+ * estimate are zero.  loss_sum[0] = sum W*|log10(|est|+1) - log10(|ref|+1)| (f64, zeroed by callee;
+ * the loss is loss_sum/(rows*Fs)).  Optional outputs: dmask [rows,Fn] = d(loss)/d(mask),
+ * dlogit [rows,Fn] = dmask*mask*(1-mask), est_re/est_im [rows,Fs]. */
+int cruse_mask_loss_fwd(const float* mask, const float* nre, const float* nim, const float* cmag,
+                        long long rows, int Fn, int Fs, float alpha, float beta,
+                        double* loss_sum, float* dmask, float* dlogit, float* est_re, float* est_im,
+                        void* stream);
+
+/* backward of nn.Sigmoid (cruse_net.py:164): dlogit = dmask * mask * (1 - mask) */
+int cruse_sigmoid_bwd(const float* dmask, const float* mask, float* dlogit, long long n, void* stream);
+
+/* out = a*x + b*y elementwise (x or y may alias out) */
+int cruse_axpby(float* out, const float* x, const float* y, float a, float b, long long n, void* stream);
+
+/* ---- optimizer (torch.optim.Adam at tools/train_stand.py:68-71) -------------- */
+/* One fused Adam step over a flat parameter buffer; g is multiplied by grad_scale first
+ * (1/world_size after a sum all-reduce). step >= 1. */
+int cruse_adam_step(float* p, const float* g, float* m, float* v, long long n,
+                    float lr, float beta1, float beta2, float eps, float weight_decay,
+                    int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRUSE_HIP_H */

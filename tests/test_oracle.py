@@ -1,0 +1,111 @@
+"""CPU: the oracle against the golden vectors produced by the reference's own code
+(tests/golden/make_golden.py).  Bit-exact where the op sequence is identical."""
+import numpy as np
+import torch
+
+from oracle import cruse_oracle as O
+
+
+def _c(a):
+    return torch.view_as_complex(torch.from_numpy(a).contiguous())
+
+
+def test_stft_golden(golden):
+    g = golden("g1_stft.npz")
+    for L, T in ((3200, 21), (3199, 20), (3201, 21)):
+        X = O.stft(torch.from_numpy(g[f"x_{L}"]), 320, 160, 320)
+        assert X.shape == (2, 161, T)
+        assert torch.equal(torch.view_as_real(X), torch.from_numpy(g[f"X_{L}"]))
+
+
+def test_istft_golden(golden):
+    g = golden("g7_istft.npz")
+    X = _c(g["X"])
+    y = O.istft(X, 320, 160, 320, length=3200)
+    assert torch.equal(y, torch.from_numpy(g["y_rt"]))
+    assert (y - torch.from_numpy(g["x"])).abs().max() < 1e-5
+    ym = O.istft(X * torch.from_numpy(g["m"]), 320, 160, 320, length=3200)
+    assert torch.equal(ym, torch.from_numpy(g["y_masked"]))
+
+
+def test_ggru_golden(golden):
+    g = golden("g3_ggru.npz")
+    x = torch.from_numpy(g["x"])
+    for grp in (1, 2, 4):
+        m = O.GGRU(hidden_size=640, groups=grp)
+        O.closed_form_init(m)
+        assert torch.allclose(m(x), torch.from_numpy(g[f"y_g{grp}"]), atol=1e-6)
+
+
+def test_unet2_golden(golden):
+    g = golden("g4_unet2.npz")
+    x = torch.from_numpy(g["x"])
+    for grp in (1, 4):
+        m = O.unet_2(rnn_groups=grp)
+        O.closed_form_init(m)
+        m.train()
+        y = m(x)
+        assert y.shape == (2, 1, 21, 160)
+        assert torch.allclose(y, torch.from_numpy(g[f"mask_train_g{grp}"]), atol=1e-6)
+        assert torch.allclose(m.bn1.running_mean, torch.from_numpy(g[f"bn1_running_mean_g{grp}"]), atol=1e-7)
+        m.eval()
+        assert torch.allclose(m(x), torch.from_numpy(g[f"mask_eval_g{grp}"]), atol=1e-6)
+
+
+def test_state_dict_keys():
+    m = O.unet_2(rnn_groups=2)
+    keys = set(m.state_dict().keys())
+    for k in ("conv1.weight", "conv4_t.bias", "bn3.running_var", "bn2_t.num_batches_tracked",
+              "skip_connect_4.weight", "gru.gru_list1.1.weight_ih_l0", "gru.gru_list2.0.bias_hh_l0",
+              "gru.ln1.weight", "gru.ln2.bias", "fc.weight"):
+        assert k in keys, k
+    assert m.conv4_t.weight.shape == (64, 32, 1, 3) and m.conv1.weight.shape == (8, 1, 2, 3)
+    n = sum(p.numel() for n_, p in m.named_parameters() if not n_.startswith("fc."))
+    assert sum(p.numel() for n_, p in O.unet_2(rnn_groups=1).named_parameters() if not n_.startswith("fc.")) == 4966555
+    assert sum(p.numel() for n_, p in O.unet_2(rnn_groups=4).named_parameters() if not n_.startswith("fc.")) == 1280155
+    assert n > 0
+
+
+def test_losses_golden(golden):
+    g = golden("g5_loss.npz")
+    w = O.wo_male(torch.from_numpy(g["ref"]), torch.from_numpy(g["est"]), torch.from_numpy(g["unproc"]))
+    assert torch.equal(w, torch.from_numpy(g["wo_male"]))
+    s1, s2 = torch.from_numpy(g["s1"]), torch.from_numpy(g["s2"])
+    assert torch.equal(O.sisnr(s1, s2), torch.from_numpy(g["sisnr"]))
+    assert torch.equal(O.si_snr_loss(s1, s2), torch.from_numpy(g["si_snr_loss"]))
+    try:
+        O.wo_male(torch.zeros(1, 2, 3, 4), torch.zeros(1, 2, 3, 5), torch.zeros(1, 2, 3, 4))
+        assert False
+    except RuntimeError:
+        pass
+
+
+def test_train_step_golden(golden):
+    for grp in (1, 4):
+        g = golden(f"g6_step_g{grp}.npz")
+        m = O.unet_2(rnn_groups=grp)
+        O.closed_form_init(m)
+        m.train()
+        noisy, clean = O.synth_pair(2, 3200, seed=1234)
+        assert torch.equal(noisy, torch.from_numpy(g["noisy"]))
+        loss, aux = O.train_step_loss(m, noisy, clean)
+        loss.backward()
+        assert abs(float(loss.detach()) - float(g["loss"])) < 1e-6
+        assert aux["est"].shape == (2, 21, 161, 2) and float(aux["est"][..., 160, :].abs().max()) == 0.0
+        for name, p in m.named_parameters():
+            if p.grad is None:
+                assert name.startswith("fc.") or name.startswith("bn1_t."), name
+                continue
+            gn = float(g["gn/" + name])
+            # conv biases feeding a BatchNorm have a mathematically zero gradient: pure rounding noise (~1e-8)
+            assert abs(float(p.grad.norm()) - gn) <= 1e-4 * gn + 1e-6, name
+
+
+def test_interleave_is_not_groupgru_shuffle():
+    """GGRU's stack+flatten is new[j*g+i] = cat[i*h+j]."""
+    g, h = 4, 5
+    cat = torch.arange(g * h)
+    new = torch.stack(torch.chunk(cat, g), dim=-1).flatten()
+    for i in range(g):
+        for j in range(h):
+            assert new[j * g + i] == cat[i * h + j]
