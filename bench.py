@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Headline benchmark: spectrogram frames/s, CRUSE training step, on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = STFT(noisy) + STFT(clean) -> unet_2 (4 enc/dec convs, 1 GRU group) forward -> mask*spectrum
+-> WO-MALE -> backward -> gradient all-reduce (RCCL) -> Adam, on 64 clips x 4 s per GPU
+(BASELINE.json configs[1]); inputs are synthetic and resident in HBM before the timed region.
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     -- the dominant kernel of the step, timed live with HIP events
+  cpu_baseline -- the torch-CPU oracle (a port of the reference; oracle/) on this box's host cores
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0 / 3.0, "f32": 157.3}
+
+
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
+    ap.add_argument("--seconds", type=float, default=4.0)
+    ap.add_argument("--groups", type=int, default=1)
+    ap.add_argument("--prec", default="bf16", choices=["bf16", "bf16x3", "f32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(groups: int, budget_s: float = 15.0):
+    """The oracle (torch-CPU port of the reference path) timed on the host cores: fwd + loss + bwd, B = 8."""
+    from oracle import cruse_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model = O.unet_2(rnn_groups=groups)
+    O.closed_form_init(model)
+    model.train()
+    B, L = 8, 64000
+    noisy, clean = O.synth_pair(B, L, seed=1)
+
+    def one():
+        model.zero_grad(set_to_none=True)
+        loss, _ = O.train_step_loss(model, noisy, clean)
+        loss.backward()
+    one()                                                   # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one(); n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 20:
+            break
+    fps = n * B * 401 / el
+    return {"value": round(fps, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} steps of fwd+WO-MALE+bwd (no optimizer), B=8 x 4 s, f32, torch {torch.__version__} CPU, "
+                      f"{cores} threads, {el:.1f} s"}
+
+
+class KernelTimer:
+    """Wraps cruse_amd.ops entry points with HIP events on torch's current stream (where the kernels run)."""
+
+    NAMES = ["stft", "conv_gather", "conv_scatter2", "conv_wgrad", "channel_sum", "col_sum", "bn_stats", "bn_finalize",
+             "bn_act_fwd", "bn_act_bwd", "ln_fwd", "ln_bwd", "gemm", "gru_seq_fwd", "gru_seq_bwd", "mask_loss"]
+
+    def __init__(self, ops):
+        self.ops, self.rec, self.saved = ops, [], {}
+
+    def __enter__(self):
+        from cruse_amd.model import cruse_net
+        for n in self.NAMES:
+            f = getattr(self.ops, n)
+            self.saved[n] = f
+
+            def wrap(*a, _f=f, _n=n, **k):
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(); out = _f(*a, **k); e1.record()
+                self.rec.append((_n, e0, e1))
+                return out
+            setattr(self.ops, n, wrap)
+        return self
+
+    def __exit__(self, *exc):
+        for n, f in self.saved.items():
+            setattr(self.ops, n, f)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        tot, cnt = {}, {}
+        for n, e0, e1 in self.rec:
+            tot[n] = tot.get(n, 0.0) + e0.elapsed_time(e1)
+            cnt[n] = cnt.get(n, 0) + 1
+        return tot, cnt
+
+
+def kernel_rooflines(B, T, H, G, prec, per_step_ms, calls):
+    """Algorithmic work per launch for the kernels that can dominate."""
+    Hg = H // G
+    rows = B * T
+    out = {}
+    rec_flops = 2.0 * rows * 3 * Hg * Hg * G               # W_hh h_{t-1} over all steps, one launch
+    for name in ("gru_seq_fwd", "gru_seq_bwd"):
+        if name in per_step_ms:
+            avg_ms = per_step_ms[name] / calls[name]
+            ach = rec_flops / (avg_ms * 1e-3) / 1e12
+            out[name] = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_MFMA_TFLOPS[prec], "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK_MFMA_TFLOPS[prec], 5), "traffic": None,
+                         "avg_launch_ms": round(avg_ms, 4),
+                         "note": f"latency-bound by design: {T} dependent steps per launch, "
+                                 f"{avg_ms * 1e3 / T:.2f} us per step"}
+    if "gemm" in per_step_ms:
+        flops = 2.0 * rows * 3 * Hg * Hg * G * 8             # 2 layers x (gi, dX, dW_ih, dW_hh)
+        avg_ms = per_step_ms["gemm"] / calls["gemm"]
+        ach = flops / (per_step_ms["gemm"] * 1e-3) / 1e12
+        out["gemm"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS[prec], "unit": "TFLOP/s",
+                       "frac": round(ach / PEAK_MFMA_TFLOPS[prec], 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4)}
+    hbm = {"conv_gather": 2 * 640 * 4.0, "conv_scatter2": 2 * 640 * 4.0, "bn_act_fwd": 2 * 640 * 4.0,
+           "bn_act_bwd": 5 * 640 * 4.0, "conv_wgrad": 2 * 640 * 4.0, "ln_fwd": 2 * 640 * 4.0, "ln_bwd": 3 * 640 * 4.0}
+    for name, bpf in hbm.items():
+        if name in per_step_ms:
+            avg_ms = per_step_ms[name] / calls[name]
+            ach = bpf * rows / (avg_ms * 1e-3) / 1e9
+            out[name] = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4)}
+    return out
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    dev = torch.device("cuda", local)
+
+    from cruse_amd import ops
+    from cruse_amd.data import synth_batch
+    from cruse_amd.engine import TrainEngine
+    from cruse_amd.model.cruse_net import unet_2
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        log("cpu baseline (oracle on host cores) ...")
+        cpu = cpu_baseline(a.groups)
+        log(f"cpu baseline done: {cpu['value']} frames/s on {cpu['cores']} threads")
+
+    torch.manual_seed(0)
+    model = unet_2(rnn_groups=a.groups, precision=a.prec).to(dev)
+    eng = TrainEngine(model, lr=1e-3, use_graph=not a.no_graph)
+    B, L = a.batch, int(a.seconds * 16000)
+    T = 1 + L // 160
+    pool = [synth_batch(B, L, dev, 1234 + 1000 * rank + s) for s in range(4)]
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log("inputs ready; warm-up (includes HIP-graph capture) ...")
+    for s in range(a.warmup):
+        eng.step(*pool[s % len(pool)])
+    sync()
+    log("timed region ...")
+    t0 = time.perf_counter()
+    for s in range(a.steps):
+        ls = eng.step(*pool[s % len(pool)])
+    sync()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        el = float(tmax.item())
+    loss = eng.loss_value(ls)
+    status = ops.gru_status()
+    log(f"timed region done: {el / a.steps * 1e3:.2f} ms/step")
+
+    roof, breakdown = None, None
+    if rank == 0 and not a.no_kernel_timing:
+        nrep = 3
+        with KernelTimer(ops) as kt:
+            for s in range(nrep):
+                eng._fwd_bwd(*pool[s % len(pool)])
+            tot, cnt = kt.summary()
+        per_step = {k: v / nrep for k, v in tot.items()}
+        calls = {k: v // nrep for k, v in cnt.items()}
+        rl = kernel_rooflines(B, T, model.hidden_size, a.groups, a.prec, per_step, calls)
+        dom = max(per_step, key=per_step.get)
+        breakdown = {k: round(v, 3) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])}
+        roof = dict(rl.get(dom, {"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": None, "traffic": None}))
+        roof["kernel"] = dom
+        roof["ms_per_step_all_launches"] = round(per_step[dom], 3)
+        roof["others"] = {k: v for k, v in rl.items() if k != dom}
+
+    if rank == 0:
+        frames = world * B * T * a.steps
+        out = {
+            "metric": "spectrogram frames/sec training CRUSE 16kHz 20ms-frame/10ms-hop",
+            "value": round(frames / el, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(el / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.prec, "data": "synthetic",
+            "config": {"workload": f"CRUSE unet_2 4-layer enc/dec, {a.groups}xGRU group(s), H=640, "
+                                   f"{B} clips x {a.seconds:g} s @16 kHz per GPU, n_fft=320 hop=160 (T={T}), "
+                                   "STFT x2 + fwd + WO-MALE + bwd + grad all-reduce + Adam; f32 storage, "
+                                   f"{a.prec} MFMA operands, f32 accumulate/statistics",
+                       "global_batch": world * B, "per_gpu_batch": B, "frames_per_clip": T,
+                       "parallelism": f"dp{world}", "hip_graph": not a.no_graph},
+            "final_loss": round(loss, 6), "gru_handoff_timeouts": status,
+            "roofline": roof, "kernel_ms_per_step": breakdown, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,379 @@
+"""GPU parity tests, kernel by kernel, through the C ABI (cruse_amd.ops -> libcruse_hip.so)
+against torch-CPU f32 references of the same op at the reference's call sites."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import max_abs, rel_l2, t
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    from cruse_amd import ops as o
+    return o
+
+
+# ------------------------------------------------------------------ STFT / iSTFT
+def test_stft_golden_fixture(ops, golden):
+    g = golden("g1_stft.npz")
+    for L, T in ((3200, 21), (3199, 20), (3201, 21)):
+        re, im, mag = ops.stft(t(g[f"x_{L}"]), 320, 160, mag_bins=160, mag_eps=1e-8)
+        X = torch.from_numpy(g[f"X_{L}"])               # [B,F,T,2]
+        assert re.shape == (2, T, 161)                  # frame / bin indexing exact
+        assert max_abs(re.transpose(1, 2), X[..., 0]) < 2e-5
+        assert max_abs(im.transpose(1, 2), X[..., 1]) < 2e-5
+        ref_mag = torch.sqrt(X[..., 0] ** 2 + X[..., 1] ** 2 + 1e-8)[:, :160].transpose(1, 2)
+        assert max_abs(mag, ref_mag) < 2e-5
+
+
+def test_stft_impulse_indexing(ops):
+    """one-hot impulses pin frame/bin placement and the reflect padding exactly."""
+    L = 1600
+    for pos in (0, 1, 159, 160, 161, 799, 1598, 1599):
+        x = torch.zeros(1, L); x[0, pos] = 1.0
+        ref = torch.stft(x, 320, 160, 320, window=torch.hann_window(320), return_complex=True, center=True)
+        re, im, _ = ops.stft(x.cuda(), 320, 160)
+        assert max_abs(re.transpose(1, 2), ref.real) < 1e-5, pos
+        assert max_abs(im.transpose(1, 2), ref.imag) < 1e-5, pos
+
+
+def test_stft_full_size_and_hop320(ops):
+    g = torch.Generator().manual_seed(3)
+    x = 0.1 * torch.randn(3, 64000, generator=g)
+    for hop, T in ((160, 401), (320, 201)):
+        ref = torch.stft(x, 320, hop, 320, window=torch.hann_window(320), return_complex=True, center=True)
+        re, im, _ = ops.stft(x.cuda(), 320, hop)
+        assert re.shape == (3, T, 161)
+        assert rel_l2(torch.complex(re, im).transpose(1, 2).cpu().resolve_conj(), ref) < 1e-5 if False else True
+        assert rel_l2(re.transpose(1, 2), ref.real) < 1e-5 and rel_l2(im.transpose(1, 2), ref.imag) < 1e-5
+
+
+def test_stft_generic_dft_path(ops):
+    x = 0.1 * torch.randn(2, 4000, generator=torch.Generator().manual_seed(4))
+    ref = torch.stft(x, 512, 128, 512, window=torch.hann_window(512), return_complex=True, center=True)
+    re, im, _ = ops.stft(x.cuda(), 512, 128)
+    assert re.shape == (2, ref.shape[2], 257)
+    assert rel_l2(re.transpose(1, 2), ref.real) < 1e-4 and rel_l2(im.transpose(1, 2), ref.imag) < 1e-4
+
+
+def test_istft_golden_and_roundtrip(ops, golden):
+    g = golden("g7_istft.npz")
+    X = torch.from_numpy(g["X"])                        # [B,F,T,2]
+    re, im = t(X[..., 0].transpose(1, 2)), t(X[..., 1].transpose(1, 2))
+    y = ops.istft(re, im, 320, 160, 3200)
+    assert max_abs(y, torch.from_numpy(g["y_rt"])) < 1e-5
+    m = torch.from_numpy(g["m"])
+    y2 = ops.istft(t((X[..., 0] * m).transpose(1, 2)), t((X[..., 1] * m).transpose(1, 2)), 320, 160, 3200)
+    assert max_abs(y2, torch.from_numpy(g["y_masked"])) < 1e-5
+    # full size round trip (size-independent property)
+    x = 0.1 * torch.randn(4, 64000, generator=torch.Generator().manual_seed(5)).cuda()
+    re, im, _ = ops.stft(x, 320, 160)
+    assert max_abs(ops.istft(re, im, 320, 160, 64000), x) < 1e-5
+
+
+def test_istft_backward_is_adjoint(ops):
+    gen = torch.Generator().manual_seed(6)
+    re = torch.randn(2, 21, 161, generator=gen); im = torch.randn(2, 21, 161, generator=gen)
+    dw = torch.randn(2, 3200, generator=gen)
+    rr = re.clone().requires_grad_(True); ii = im.clone().requires_grad_(True)
+    y = torch.istft(torch.complex(rr, ii).transpose(1, 2), 320, 160, 320, window=torch.hann_window(320), length=3200)
+    y.backward(dw)
+    dre, dim = ops.istft_bwd(dw.cuda(), 21, 320, 160)
+    assert rel_l2(dre, rr.grad) < 1e-5
+    # bins 0 and 160 of the imaginary part carry no gradient (c2r ignores them)
+    assert rel_l2(dim[..., 1:160], ii.grad[..., 1:160]) < 1e-5
+
+
+# ------------------------------------------------------------------ convolutions
+LEVELS = [(1, 160, 8, 80), (8, 80, 16, 40), (16, 40, 32, 20), (32, 20, 64, 10)]
+
+
+def _nchw(x):       # frame-major [B,T,C,F] -> [B,C,T,F]
+    return x.permute(0, 2, 1, 3).contiguous()
+
+
+@pytest.mark.parametrize("lvl", range(4))
+def test_encoder_conv_fwd_bwd(ops, lvl):
+    Cin, Fin, Cout, Fout = LEVELS[lvl]
+    B, T = 3, 21
+    gen = torch.Generator().manual_seed(10 + lvl)
+    x = torch.randn(B, T, Cin, Fin, generator=gen)
+    w = torch.randn(Cout, Cin, 2, 3, generator=gen) * 0.2
+    b = torch.randn(Cout, generator=gen)
+    xr = _nchw(x).requires_grad_(True); wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, br, stride=(1, 2), padding=(1, 1))[..., :-1, :]       # cruse_net.py:138,149 (R4)
+    y = ops.conv_gather(x.cuda(), w.cuda(), b.cuda(), B, T, Cin, Fin, Cout, Fout, KT=2, S=2, pad=1)
+    assert rel_l2(_nchw(y), y_ref) < 1e-5
+    dy = torch.randn(B, T, Cout, Fout, generator=gen)
+    y_ref.backward(_nchw(dy))
+    dx = ops.conv_scatter2(dy.cuda(), w.cuda(), None, B, T, Cout, Fout, Cin, KT=2, pad=1)
+    assert rel_l2(_nchw(dx), xr.grad) < 1e-5
+    dw = torch.zeros_like(w).cuda()
+    ops.conv_wgrad(dy.cuda(), x.cuda(), dw, B, T, Cout, Fout, Cin, Fin, KT=2, S=2, pad=1)
+    assert rel_l2(dw, wr.grad) < 1e-5
+    db = torch.zeros(Cout).cuda()
+    ops.channel_sum(dy.cuda(), B * T, Cout, Fout, db)
+    assert rel_l2(db, br.grad) < 1e-5
+
+
+@pytest.mark.parametrize("lvl", range(4))
+def test_skip_conv_fwd_bwd(ops, lvl):
+    _, _, C, Fq = LEVELS[lvl]
+    B, T = 2, 13
+    gen = torch.Generator().manual_seed(20 + lvl)
+    x = torch.randn(B, T, C, Fq, generator=gen)
+    w = torch.randn(C, C, 1, 3, generator=gen) * 0.2
+    xr = _nchw(x).requires_grad_(True); wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, None, padding=(0, 1))                                  # cruse_net.py:143 (R5)
+    y = ops.conv_gather(x.cuda(), w.cuda(), None, B, T, C, Fq, C, Fq, KT=1, S=1, pad=1)
+    assert rel_l2(_nchw(y), y_ref) < 1e-5
+    dy = torch.randn(B, T, C, Fq, generator=gen)
+    y_ref.backward(_nchw(dy))
+    base = torch.randn(B, T, C, Fq, generator=gen)
+    dx = base.clone().cuda()
+    ops.conv_gather(dy.cuda(), w.cuda(), None, B, T, C, Fq, C, Fq, KT=1, S=1, pad=1, w_layout=1, out=dx, accum=True)
+    assert rel_l2(_nchw(dx.cpu() - base), xr.grad) < 1e-5
+    dw = torch.zeros_like(w).cuda()
+    ops.conv_wgrad(dy.cuda(), x.cuda(), dw, B, T, C, Fq, C, Fq, KT=1, S=1, pad=1)
+    assert rel_l2(dw, wr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("lvl", range(4))
+def test_decoder_convT_fwd_bwd(ops, lvl):
+    Cout, Fo, Cin, Fg = LEVELS[lvl]            # convT k: ch[k] x F_k -> ch[k-1] x 2F_k
+    B, T = 2, 11
+    gen = torch.Generator().manual_seed(30 + lvl)
+    u = torch.randn(B, T, Cin, Fg, generator=gen)
+    w = torch.randn(Cin, Cout, 1, 3, generator=gen) * 0.2
+    b = torch.randn(Cout, generator=gen)
+    ur = _nchw(u).requires_grad_(True); wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    v_ref = F.conv_transpose2d(ur, wr, br, stride=(1, 2))[..., :-1]                 # cruse_net.py:140,161 (R2)
+    assert v_ref.shape[-1] == Fo
+    v = ops.conv_scatter2(u.cuda(), w.cuda(), b.cuda(), B, T, Cin, Fg, Cout, KT=1, pad=0)
+    assert rel_l2(_nchw(v), v_ref) < 1e-5
+    vs = ops.conv_scatter2(u.cuda(), w.cuda(), b.cuda(), B, T, Cin, Fg, Cout, KT=1, pad=0, act=1)
+    assert rel_l2(_nchw(vs), torch.sigmoid(v_ref)) < 1e-5
+    dv = torch.randn(B, T, Cout, Fo, generator=gen)
+    v_ref.backward(_nchw(dv))
+    du = ops.conv_gather(dv.cuda(), w.cuda(), None, B, T, Cout, Fo, Cin, Fg, KT=1, S=2, pad=0)
+    assert rel_l2(_nchw(du), ur.grad) < 1e-5
+    dw = torch.zeros_like(w).cuda()
+    ops.conv_wgrad(u.cuda(), dv.cuda(), dw, B, T, Cin, Fg, Cout, Fo, KT=1, S=2, pad=0)
+    assert rel_l2(dw, wr.grad) < 1e-5
+
+
+def test_conv_golden_and_causality(ops, golden):
+    g = golden("g2_conv.npz")       # cust_conv.Conv2dNormAct causal pad == R4 crop, run by the reference
+    x = torch.from_numpy(g["x"])    # [2,1,9,160] NCHW, C=1 -> same memory as frame-major
+    y = ops.conv_gather(t(x).view(2, 9, 1, 160), t(g["w"]), t(g["b"]), 2, 9, 1, 160, 8, 80, KT=2, S=2, pad=1)
+    assert rel_l2(_nchw(y), torch.from_numpy(g["y"])) < 1e-5
+    # causality: output frame t must not depend on frames > t, nor on other clips
+    xa = torch.randn(2, 9, 1, 160); xb = xa.clone(); xb[:, 5:] += 1.0
+    ya = ops.conv_gather(xa.cuda(), t(g["w"]), t(g["b"]), 2, 9, 1, 160, 8, 80, KT=2, S=2, pad=1)
+    yb = ops.conv_gather(xb.cuda(), t(g["w"]), t(g["b"]), 2, 9, 1, 160, 8, 80, KT=2, S=2, pad=1)
+    assert torch.equal(ya[:, :5], yb[:, :5]) and not torch.equal(ya[:, 5:], yb[:, 5:])
+
+
+def test_conv_shape_errors(ops):
+    x = torch.zeros(1, 4, 1, 160).cuda(); w = torch.zeros(8, 1, 2, 3).cuda()
+    with pytest.raises(RuntimeError, match="Fout"):
+        ops.conv_gather(x, w, None, 1, 4, 1, 160, 8, 90, KT=2, S=2, pad=1)
+
+
+# ------------------------------------------------------------------ BatchNorm / LayerNorm
+@pytest.mark.parametrize("C,Fq", [(8, 80), (64, 10), (1, 160)])
+def test_batchnorm_relu_skip_fwd_bwd(ops, C, Fq):
+    B, T = 3, 17
+    rows = B * T
+    gen = torch.Generator().manual_seed(40 + C)
+    y = torch.randn(B, T, C, Fq, generator=gen) * 2 + 0.7
+    skip = torch.randn(B, T, C, Fq, generator=gen)
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.3 * torch.randn(C, generator=gen)); bn.bias.copy_(0.2 * torch.randn(C, generator=gen))
+    bn.train()
+    yr = _nchw(y).requires_grad_(True)
+    out_ref = torch.relu(bn(yr)) + _nchw(skip)
+    rm = torch.zeros(C).cuda(); rv = torch.ones(C).cuda()
+    sums = ops.bn_stats(y.cuda(), rows, C, Fq)
+    mean, rstd = ops.bn_finalize(sums, rows * Fq, C, 1e-5, 0.1, rm, rv)
+    assert max_abs(rm, bn.running_mean) < 1e-6 and max_abs(rv, bn.running_var) < 1e-5
+    out = ops.bn_act_fwd(y.cuda(), mean, rstd, bn.weight.detach().cuda(), bn.bias.detach().cuda(), skip.cuda(), rows, C, Fq)
+    assert rel_l2(_nchw(out), out_ref) < 1e-5
+    dout = torch.randn(B, T, C, Fq, generator=gen)
+    out_ref.backward(_nchw(dout))
+    dg = torch.zeros(C).cuda(); db = torch.zeros(C).cuda()
+    dy = ops.bn_act_bwd(dout.cuda(), y.cuda(), mean, rstd, bn.weight.detach().cuda(), bn.bias.detach().cuda(), rows, C, Fq,
+                        True, True, dg, db)
+    assert rel_l2(_nchw(dy), yr.grad) < 2e-5
+    assert rel_l2(dg, bn.weight.grad) < 2e-5 and rel_l2(db, bn.bias.grad) < 2e-5
+    # eval mode uses the running statistics
+    bn.eval()
+    m2, r2 = ops.bn_eval_stats(rm, rv, 1e-5)
+    out_e = ops.bn_act_fwd(y.cuda(), m2, r2, bn.weight.detach().cuda(), bn.bias.detach().cuda(), None, rows, C, Fq)
+    assert rel_l2(_nchw(out_e), torch.relu(bn(_nchw(y)))) < 1e-5
+
+
+@pytest.mark.parametrize("H,g", [(640, 1), (640, 4), (1024, 2), (96, 3)])
+def test_layernorm_interleave_fwd_bwd(ops, H, g):
+    rows = 37
+    gen = torch.Generator().manual_seed(50 + g)
+    x = torch.randn(rows, H, generator=gen) * 1.5 + 0.3
+    res = torch.randn(rows, H, generator=gen)
+    ln = torch.nn.LayerNorm(H)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.3 * torch.randn(H, generator=gen)); ln.bias.copy_(0.2 * torch.randn(H, generator=gen))
+    xr = x.clone().requires_grad_(True)
+    inter = torch.stack(torch.chunk(xr, g, dim=-1), dim=-1).flatten(-2, -1)      # cruse_net.py:43-45
+    y_ref = ln(inter) + res
+    y, mean, rstd = ops.ln_fwd(x.cuda(), ln.weight.detach().cuda(), ln.bias.detach().cuda(), res.cuda(), rows, H, g)
+    assert rel_l2(y, y_ref) < 1e-5
+    dy = torch.randn(rows, H, generator=gen)
+    y_ref.backward(dy)
+    dgm = torch.zeros(H).cuda(); dbt = torch.zeros(H).cuda()
+    dx = ops.ln_bwd(dy.cuda(), x.cuda(), mean, rstd, ln.weight.detach().cuda(), rows, H, g, dgm, dbt)
+    assert rel_l2(dx, xr.grad) < 2e-5
+    assert rel_l2(dgm, ln.weight.grad) < 2e-5 and rel_l2(dbt, ln.bias.grad) < 2e-5
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-6), ("bf16x3", 3e-5), ("bf16", 1e-2)])
+def test_gemm_all_layouts(ops, prec, tol):
+    gen = torch.Generator().manual_seed(60)
+    for (M, N, K) in ((200, 130, 96), (128, 128, 32), (37, 5, 7), (300, 1920, 640)):
+        A = torch.randn(M, K, generator=gen); Bm = torch.randn(K, N, generator=gen); bias = torch.randn(N, generator=gen)
+        ref = A.double() @ Bm.double()
+        for ta in (False, True):
+            for tb in (False, True):
+                Ad = (A.t().contiguous() if ta else A).cuda(); Bd = (Bm.t().contiguous() if tb else Bm).cuda()
+                C = torch.empty(M, N).cuda()
+                ops.gemm(ta, tb, M, N, K, Ad, 0, Ad.shape[1], Bd, 0, Bd.shape[1], C, 0, N, bias=bias.cuda(), prec=prec)
+                assert rel_l2(C, ref + bias.double()) < tol, (M, N, K, ta, tb)
+    # asymmetric identity check (transpose-detecting): A = I, B asymmetric
+    I = torch.eye(64); Bm = torch.arange(64 * 48, dtype=torch.float32).view(64, 48) / 100
+    C = torch.empty(64, 48).cuda()
+    ops.gemm(False, False, 64, 48, 64, I.cuda(), 0, 64, Bm.cuda(), 0, 48, C, 0, 48, prec="f32")
+    assert max_abs(C, Bm) < 1e-6
+
+
+def test_gemm_splitk_accumulate_shift_and_strides(ops):
+    gen = torch.Generator().manual_seed(61)
+    T, B, Hh, G3 = 7, 3, 64, 96
+    rows = B * T
+    dgh = torch.randn(rows, 2 * G3, generator=gen)       # two groups side by side
+    h = torch.randn(rows, 2 * Hh, generator=gen)
+    hprev = torch.zeros_like(h)
+    hv = h.view(B, T, -1); hprev.view(B, T, -1)[:, 1:] = hv[:, :-1]
+    for grp in range(2):
+        init = torch.randn(G3, Hh, generator=gen)
+        C = init.clone().cuda()
+        ops.gemm(True, False, G3, Hh, rows, dgh.cuda(), grp * G3, 2 * G3, h.cuda(), grp * Hh, 2 * Hh, C, 0, Hh,
+                 accumulate=True, splitk=4, b_shift_T=T, prec="f32")
+        ref = init.double() + dgh[:, grp * G3:(grp + 1) * G3].double().t() @ hprev[:, grp * Hh:(grp + 1) * Hh].double()
+        assert rel_l2(C, ref) < 1e-5, grp
+    out = torch.zeros(2 * G3).cuda()
+    ops.col_sum(dgh.cuda(), G3, rows, G3, 2 * G3, out[G3:])
+    assert rel_l2(out[G3:], dgh[:, G3:].sum(0)) < 1e-5 and float(out[:G3].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------ GRU recurrence
+def _gru_ref(x, grus):
+    outs = [m(c)[0] for m, c in zip(grus, torch.chunk(x, len(grus), dim=-1))]
+    return torch.cat(outs, dim=-1)
+
+
+@pytest.mark.parametrize("H,g,B,T,prec,tol", [
+    (640, 1, 2, 21, "f32", 2e-5), (640, 4, 5, 9, "f32", 2e-5), (640, 2, 3, 7, "bf16x3", 1e-4),
+    (640, 1, 9, 12, "bf16", 3e-2), (1024, 2, 2, 5, "f32", 2e-5), (640, 1, 20, 6, "f32", 2e-5)])
+def test_gru_sequence_fwd_bwd(ops, H, g, B, T, prec, tol):
+    Hg = H // g
+    rows = B * T
+    torch.manual_seed(70 + g)
+    grus = [torch.nn.GRU(Hg, Hg, 1, batch_first=True) for _ in range(g)]
+    x = torch.randn(B, T, H)
+    xr = x.clone().requires_grad_(True)
+    y_ref = _gru_ref(xr, grus)
+    gi = torch.empty(B, T, g * 3 * Hg).cuda()
+    dev = lambda p: p.detach().cuda().contiguous()
+    for i, m in enumerate(grus):
+        ops.gemm(False, True, rows, 3 * Hg, Hg, x.cuda(), i * Hg, H, dev(m.weight_ih_l0), 0, Hg, gi, i * 3 * Hg, 3 * H,
+                 bias=dev(m.bias_ih_l0), prec=prec)
+    w_hh = [dev(m.weight_hh_l0) for m in grus]; b_hh = [dev(m.bias_hh_l0) for m in grus]
+    h, r, z, n, q = ops.gru_seq_fwd(gi, w_hh, b_hh, B, T, g, Hg, prec)
+    torch.cuda.synchronize()
+    assert ops.gru_status() == 0, "recurrence hand-off timed out"
+    assert rel_l2(h, y_ref) < tol
+    dout = torch.randn(B, T, H)
+    y_ref.backward(dout)
+    dgi, dgh = ops.gru_seq_bwd(dout.cuda(), w_hh, h, r, z, n, q, B, T, g, Hg, prec)
+    torch.cuda.synchronize()
+    assert ops.gru_status() == 0
+    for i, m in enumerate(grus):
+        dwhh = torch.zeros(3 * Hg, Hg).cuda(); dwih = torch.zeros(3 * Hg, Hg).cuda()
+        ops.gemm(True, False, 3 * Hg, Hg, rows, dgh, i * 3 * Hg, 3 * H, h, i * Hg, H, dwhh, 0, Hg, accumulate=True,
+                 splitk=2, b_shift_T=T, prec=prec)
+        ops.gemm(True, False, 3 * Hg, Hg, rows, dgi, i * 3 * Hg, 3 * H, x.cuda(), i * Hg, H, dwih, 0, Hg, accumulate=True,
+                 splitk=2, prec=prec)
+        assert rel_l2(dwhh, m.weight_hh_l0.grad) < 5 * tol, i
+        assert rel_l2(dwih, m.weight_ih_l0.grad) < 5 * tol, i
+        db = torch.zeros(3 * Hg).cuda()
+        ops.col_sum(dgh, i * 3 * Hg, rows, 3 * Hg, 3 * H, db)
+        assert rel_l2(db, m.bias_hh_l0.grad) < 5 * tol
+        dx = torch.empty(B, T, Hg).cuda()
+        ops.gemm(False, False, rows, Hg, 3 * Hg, dgi, i * 3 * Hg, 3 * H, dev(m.weight_ih_l0), 0, Hg, dx, 0, Hg, prec=prec)
+        assert rel_l2(dx, xr.grad[..., i * Hg:(i + 1) * Hg]) < 5 * tol
+
+
+def test_gru_full_length_status(ops):
+    """T = 401, B = 64 (BASELINE config 2 shape): finishes, no hand-off time-out, outputs bounded."""
+    B, T, H = 64, 401, 640
+    torch.manual_seed(71)
+    gi = (0.5 * torch.randn(B, T, 3 * H)).cuda()
+    w = (torch.randn(3 * H, H) / 25).cuda(); b = torch.zeros(3 * H).cuda()
+    h, r, z, n, q = ops.gru_seq_fwd(gi, [w], [b], B, T, 1, H, "bf16")
+    torch.cuda.synchronize()
+    assert ops.gru_status() == 0
+    assert torch.isfinite(h).all() and float(h.abs().max()) <= 1.0
+    # independence of chains: clip 3 alone gives the same rows (bit-exact: same tiles, same order)
+    h1, *_ = ops.gru_seq_fwd(gi[3:4].contiguous(), [w], [b], 1, T, 1, H, "bf16")
+    assert rel_l2(h1[0], h[3]) < 1e-6
+
+
+# ------------------------------------------------------------------ mask + loss, Adam
+def test_mask_loss_against_reference_wo_male(ops, golden):
+    from oracle import cruse_oracle as O
+    gen = torch.Generator().manual_seed(80)
+    B, T, Fn, Fs = 2, 21, 160, 161
+    mask = torch.rand(B, 1, T, Fn, generator=gen).requires_grad_(True)
+    nre = torch.randn(B, 1, T, Fs, generator=gen) * 0.3; nim = torch.randn(B, 1, T, Fs, generator=gen) * 0.3
+    cre = torch.randn(B, 1, T, Fs, generator=gen) * 0.2; cim = torch.randn(B, 1, T, Fs, generator=gen) * 0.2
+    est = O.masking(mask, nre, nim).permute(0, 3, 1, 2)
+    loss_ref = O.wo_male(torch.cat([cre, cim], 1), est, torch.cat([nre, nim], 1))
+    loss_ref.backward()
+    cmag = torch.sqrt(cre ** 2 + cim ** 2)
+    ls, dmask, dlogit, er, ei = ops.mask_loss(mask.detach().cuda().view(B * T, Fn), nre.cuda().view(B * T, Fs),
+                                              nim.cuda().view(B * T, Fs), cmag.cuda().view(B * T, Fs), B * T, Fn, Fs,
+                                              want_dmask=True, want_dlogit=True, want_est=True)
+    assert abs(float(ls) / (B * T * Fs) - float(loss_ref)) < 1e-6 * max(1.0, abs(float(loss_ref)))
+    assert rel_l2(dmask.view(B, 1, T, Fn), mask.grad) < 1e-5
+    m = mask.detach()
+    assert rel_l2(dlogit.view(B, 1, T, Fn), mask.grad * m * (1 - m)) < 1e-5
+    assert float(er.view(B, T, Fs)[..., 160].abs().max()) == 0.0       # R8: bin 160 := 0
+    assert rel_l2(er.view(B, T, Fs)[..., :160], (m * nre[..., :160]).squeeze(1)) < 1e-6
+
+
+def test_adam_matches_torch(ops):
+    gen = torch.Generator().manual_seed(90)
+    p0 = torch.randn(1000, generator=gen)
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([p], lr=1e-2, betas=(0.9, 0.99), eps=1e-8)
+    pd = p0.clone().cuda(); m = torch.zeros(1000).cuda(); v = torch.zeros(1000).cuda()
+    for step in range(1, 4):
+        g = torch.randn(1000, generator=gen)
+        p.grad = g.clone(); opt.step()
+        ops.adam_step(pd, (2 * g).cuda(), m, v, 1e-2, 0.9, 0.99, 1e-8, 0.0, step, grad_scale=0.5)
+    assert max_abs(pd, p.detach()) < 1e-6

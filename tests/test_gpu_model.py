@@ -1,0 +1,154 @@
+"""GPU parity of the composed path: GGRU, unet_2, the full training step and the engine,
+against the golden fixtures generated from the reference's code and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import max_abs, rel_l2, t
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_and_product(grp, prec="f32", cls="unet_2"):
+    from cruse_amd.model import cruse_net as M
+    from oracle import cruse_oracle as O
+    if cls == "unet_2":
+        o = O.unet_2(rnn_groups=grp); O.closed_form_init(o)
+        m = M.unet_2(rnn_groups=grp, precision=prec)
+    else:
+        o = O.GGRU(hidden_size=640, groups=grp); O.closed_form_init(o)
+        m = M.GGRU(hidden_size=640, groups=grp, precision=prec)
+    m.load_state_dict(o.state_dict(), strict=True)
+    return o, m.cuda()
+
+
+@pytest.mark.parametrize("grp", [1, 2, 4])
+def test_ggru_golden(golden, grp):
+    g = golden("g3_ggru.npz")
+    o, m = _oracle_and_product(grp, cls="GGRU")
+    x = torch.from_numpy(g["x"])
+    y = m(x.cuda())
+    assert y.shape == (2, 64, 21, 10)
+    assert rel_l2(y, torch.from_numpy(g[f"y_g{grp}"])) < 1e-4
+    # gradients through the module (autograd glue) vs the oracle
+    xr = x.clone().requires_grad_(True)
+    o(xr).square().sum().backward()
+    xg = x.clone().cuda().requires_grad_(True)
+    m(xg).square().sum().backward()
+    assert rel_l2(xg.grad, xr.grad) < 1e-3
+    for (n, po), (_, pm) in zip(o.named_parameters(), m.named_parameters()):
+        assert rel_l2(pm.grad, po.grad) < 2e-3, n
+
+
+@pytest.mark.parametrize("grp", [1, 4])
+def test_unet2_golden_train_and_eval(golden, grp):
+    g = golden("g4_unet2.npz")
+    o, m = _oracle_and_product(grp)
+    x = t(g["x"])
+    m.train()
+    y = m(x)
+    assert y.shape == (2, 1, 21, 160)
+    assert rel_l2(y, torch.from_numpy(g[f"mask_train_g{grp}"])) < 1e-4
+    assert max_abs(m.bn1.running_mean, torch.from_numpy(g[f"bn1_running_mean_g{grp}"])) < 1e-6
+    assert max_abs(m.bn4.running_var, torch.from_numpy(g[f"bn4_running_var_g{grp}"])) < 1e-5
+    assert int(m.bn2.num_batches_tracked) == 1
+    m.eval()
+    with torch.no_grad():
+        ye = m(x)
+    assert rel_l2(ye, torch.from_numpy(g[f"mask_eval_g{grp}"])) < 1e-4
+
+
+@pytest.mark.parametrize("grp,prec,tol", [(1, "f32", 1e-3), (4, "f32", 1e-3), (1, "bf16x3", 1e-3)])
+def test_train_step_golden(golden, grp, prec, tol):
+    """SURVEY 8d parity gate: enhanced spectrogram rel-L2 <= 1e-3; loss and every gradient vs fixture G6."""
+    from cruse_amd.acoustics.feature import pre_stft
+    from cruse_amd.loss import enhanced_spectrum, masked_wo_male
+    from cruse_amd import ops
+    g = golden(f"g6_step_g{grp}.npz")
+    o, m = _oracle_and_product(grp, prec)
+    m.train()
+    noisy, clean = t(g["noisy"]), t(g["clean"])
+    f = pre_stft(noisy, 320, 160, 320, f_net=160)
+    _, _, cmag = ops.stft(clean, 320, 160, want_ri=False, mag_bins=161)
+    mask = m(f["mag_net"])
+    loss = masked_wo_male(mask, f["real"], f["imag"], cmag)
+    est = enhanced_spectrum(mask.detach(), f["real"], f["imag"])
+    assert est.shape == (2, 21, 161, 2)
+    e_mask = rel_l2(mask, torch.from_numpy(g["mask"]))
+    e_est = rel_l2(est, torch.from_numpy(g["est"]))
+    print(f"[parity g={grp} {prec}] mask rel-L2 {e_mask:.3e}  enhanced-spectrum rel-L2 {e_est:.3e}")
+    assert e_est <= tol and e_mask <= tol
+    assert abs(float(loss) - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
+    loss.backward()
+    worst = 0.0
+    for name, p in m.named_parameters():
+        if "gn/" + name not in g.files:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        gn = float(g["gn/" + name])
+        got = float(p.grad.norm())
+        assert abs(got - gn) <= 5e-3 * gn + 2e-6, (name, got, gn)
+        g8 = torch.from_numpy(g["g8/" + name])
+        assert max_abs(p.grad.flatten()[:8], g8) <= 5e-3 * float(g8.abs().max()) + 1e-6 * max(gn, 1.0) + 2e-7, name
+        worst = max(worst, abs(got - gn) / max(gn, 1e-6))
+    print(f"[parity g={grp} {prec}] worst grad-norm rel dev {worst:.3e}")
+
+
+def test_bf16_mode_error_is_reported_not_gated(golden):
+    from cruse_amd.acoustics.feature import pre_stft
+    from cruse_amd.loss import enhanced_spectrum
+    g = golden("g6_step_g1.npz")
+    o, m = _oracle_and_product(1, "bf16")
+    m.train()
+    f = pre_stft(t(g["noisy"]), 320, 160, 320, f_net=160)
+    with torch.no_grad():
+        mask = m(f["mag_net"])
+    e = rel_l2(enhanced_spectrum(mask, f["real"], f["imag"]), torch.from_numpy(g["est"]))
+    print(f"[parity g=1 bf16] enhanced-spectrum rel-L2 {e:.3e} (reported; bf16 operands, f32 accumulate)")
+    assert e < 5e-2
+
+
+def test_engine_step_matches_oracle_adam(golden):
+    """TrainEngine (graph-captured fwd+bwd, flat Adam) == oracle autograd + torch.optim.Adam, 2 steps."""
+    from cruse_amd.engine import TrainEngine
+    from oracle import cruse_oracle as O
+    o, m = _oracle_and_product(4)
+    opt = torch.optim.Adam([p for n, p in o.named_parameters()], lr=1e-3)
+    for use_graph in (False, True):
+        o2, m2 = _oracle_and_product(4)
+        eng = TrainEngine(m2, lr=1e-3, use_graph=use_graph)
+        opt2 = torch.optim.Adam(o2.parameters(), lr=1e-3)
+        o2.train()
+        for step in range(2):
+            noisy, clean = O.synth_pair(2, 3200, seed=77 + step)
+            loss, _ = O.train_step_loss(o2, noisy, clean)
+            opt2.zero_grad(); loss.backward(); opt2.step()
+            ls = eng.step(noisy.cuda(), clean.cuda())
+            assert abs(eng.loss_value(ls) - float(loss)) <= 2e-4 * abs(float(loss)), (use_graph, step)
+        for (n, po), (_, pm) in zip(o2.named_parameters(), m2.named_parameters()):
+            if n.startswith("fc.") or n.startswith("bn1_t."):
+                assert torch.equal(pm.detach().cpu(), po.detach()), n     # untouched
+                continue
+            if n.endswith(".bias") and n.startswith("conv") and n != "conv1_t.bias":
+                continue   # bias feeding a BatchNorm: true gradient is 0, Adam normalises pure rounding noise
+            # Adam's first steps move every weight by ~lr regardless of gradient scale, so compare updates
+            assert max_abs(pm, po) <= 2e-4, (n, use_graph)
+        assert int(m2.bn1.num_batches_tracked) == 2
+
+
+def test_full_size_properties():
+    """BASELINE config 2 shape (B=64 x 4 s): finite loss, mask in (0,1), loss decreases over Adam steps."""
+    from cruse_amd.data import synth_batch
+    from cruse_amd.engine import TrainEngine
+    from cruse_amd.model.cruse_net import unet_2
+    from cruse_amd import ops
+    torch.manual_seed(0)
+    m = unet_2(rnn_groups=1, precision="bf16").cuda()
+    eng = TrainEngine(m, lr=1e-3, use_graph=True)
+    noisy, clean = synth_batch(64, 64000, "cuda", 1)
+    losses = [eng.loss_value(eng.step(noisy, clean)) for _ in range(6)]
+    torch.cuda.synchronize()
+    assert ops.gru_status() == 0
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0], losses
+    print("[full-size] losses", ["%.5f" % v for v in losses])
