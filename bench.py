@@ -55,7 +55,9 @@ def parse():
 def cpu_baseline(groups: int, budget_s: float = 15.0):
     """The oracle (torch-CPU port of the reference path) timed on the host cores: fwd + loss + bwd, B = 8."""
     from oracle import cruse_oracle as O
-    cores = os.cpu_count() or 1
+    # 16 threads is the fastest setting measured on the 256-core GPU host (8: 6.6k, 16: 7.0k, 32: 3.3k
+    # frames/s; torch's default of 128+ threads is >100x slower from oversubscription)
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     model = O.unet_2(rnn_groups=groups)
     O.closed_form_init(model)
