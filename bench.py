@@ -86,7 +86,7 @@ class KernelTimer:
     """Wraps cruse_amd.ops entry points with HIP events on torch's current stream (where the kernels run)."""
 
     NAMES = ["stft", "conv_gather", "conv_scatter2", "conv_wgrad", "channel_sum", "col_sum", "bn_stats", "bn_finalize",
-             "bn_act_fwd", "bn_act_bwd", "ln_fwd", "ln_bwd", "gemm", "gru_seq_fwd", "gru_seq_bwd", "mask_loss"]
+             "bn_act_fwd", "bn_act_bwd", "ln_fwd", "ln_bwd", "gemm", "gru_seq_fwd", "gru_seq_bwd", "gru_gate_grads", "mask_loss"]
 
     def __init__(self, ops):
         self.ops, self.rec, self.saved = ops, [], {}

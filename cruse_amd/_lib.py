@@ -41,8 +41,9 @@ SIGNATURES = {
     "cruse_ln_bwd": ("pppppqiipppp", "i"),
     "cruse_gemm": ("iiiiipipipipiiiip", "i"),
     "cruse_gru_ws_bytes": ("iii", "z"),
-    "cruse_gru_seq_fwd": ("ppppppppiiiiipp", "i"),
-    "cruse_gru_seq_bwd": ("pppppppppiiiiipp", "i"),
+    "cruse_gru_seq_fwd": ("pppppppiiiiipp", "i"),
+    "cruse_gru_seq_bwd": ("pppppiiiiipp", "i"),
+    "cruse_gru_gate_grads": ("pppppqiip", "i"),
     "cruse_mask_loss_fwd": ("ppppqiiffpppppp", "i"),
     "cruse_sigmoid_bwd": ("pppqp", "i"),
     "cruse_axpby": ("pppffqp", "i"),

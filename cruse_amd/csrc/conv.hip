@@ -221,7 +221,7 @@ struct WgradArgs {
 };
 
 constexpr int WG_THREADS = 256;
-constexpr int WG_MAX_BLOCKS = 512;
+constexpr int WG_MAX_BLOCKS = 256;
 
 template <int CB_T, int KT>
 __global__ __launch_bounds__(WG_THREADS) void conv_wgrad_kernel(WgradArgs p) {
@@ -324,11 +324,14 @@ __global__ __launch_bounds__(WG_THREADS) void conv_wgrad_kernel(WgradArgs p) {
 }
 
 __global__ void wgrad_reduce_kernel(const float* partial, int nblk, int nout, float* dw) {
+    // blockIdx.y owns a chunk of 16 partial slabs; one atomic per output and chunk
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nout) return;
+    const int k0 = blockIdx.y * 16, k1 = min(nblk, k0 + 16);
     float s = 0.f;
-    for (int k = 0; k < nblk; ++k) s += partial[(long long)k * nout + i];
-    dw[i] += s;
+#pragma unroll 8
+    for (int k = k0; k < k1; ++k) s += partial[(long long)k * nout + i];
+    atomicAdd(&dw[i], s);
 }
 
 // ---------------------------------------------------------------------------
@@ -453,7 +456,7 @@ extern "C" int cruse_conv_wgrad(const float* a, const float* bt, float* dw,
 #undef LAUNCH_WG
     CRUSE_LAUNCH_CHECK("conv_wgrad");
     const int nout = Ca * Cb * KT * 3;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(nout, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(nout, 256), cdiv(grid, 16)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)ws, grid, nout, dw);
     CRUSE_LAUNCH_CHECK("conv_wgrad_reduce");
     return CRUSE_OK;

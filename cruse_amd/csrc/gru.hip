@@ -6,19 +6,25 @@
 // bounds this kernel.  Design:
 //   * a CHAIN = (batch group of Bg <= 16 clips) x (GRU group); chains are independent.
 //   * a chain is served by a TEAM of P = Hg/32 workgroups; workgroup p owns hidden units
-//     [32p, 32p+32) and keeps its slice of W_hh (96 x Hg forward, Hg... x 32 backward)
-//     resident in REGISTERS as MFMA A-operand fragments for the whole sequence.
-//   * per step a workgroup (1) polls the team's P flag words, (2) gathers h_{t-1}
-//     [Bg, Hg] (the previous step's output rows of the result tensor itself -- every
-//     step has its own address, so there is no buffer reuse hazard) into LDS,
-//     (3) runs 16x16x32 MFMA tiles (K split over the 4 wavefronts, reduced through
-//     LDS), (4) applies the gate math for its 32 units, (5) publishes h_t.
-//   * inter-workgroup hand-off follows the guide's R1 recipe: payload written with
-//     agent-scope relaxed atomic (sc1, write-through) 8-byte stores, every wave drains
-//     vmcnt(0), barrier, ONE lane stores the flag; consumers poll the flag words with
-//     relaxed agent-scope loads and read the payload with agent-scope (sc1) loads.
-//     Nothing depends on dispatch order or workgroup->XCD placement; block ids are
-//     arranged so that, with the observed id%8 placement, a chain sits on one XCD.
+//     [32p, 32p+32) and keeps its slice of W_hh (96 x Hg forward, its transpose 32 x 3Hg
+//     backward) resident in REGISTERS as MFMA A-operand fragments for the whole sequence.
+//   * hand-off between the workgroups of a team uses DATA-TAGGED GRANULES (the guide's R2
+//     form): each exchanged value travels as an 8-byte {epoch tag, f32 value} pair written
+//     with a write-through (sc1) 16-byte buffer store (two granules); consumers sweep the
+//     team's panel with 16-byte sc1 buffer loads until every tag equals the step's epoch.
+//     There is no separate flag, no release fence and no store drain on the critical path;
+//     8-byte halves are single-copy atomic.  The panel is double-buffered by step parity: a
+//     workgroup can only write epoch e+2 after every team mate published e+1, which implies
+//     all of them finished reading e.  Nothing depends on dispatch order or workgroup->XCD
+//     placement; block ids are arranged so that, with the observed id%8 placement, a chain
+//     sits on one XCD (its panel then stays in that XCD's L2 / the Infinity Cache).
+//   * forward step: sweep h_{t-1} [Bg,Hg] into LDS -> 16x16x32 MFMA tiles (K split over the
+//     4 wavefronts, reduced through LDS) -> gate math for the 32 own units -> publish h_t.
+//   * backward: with c = d(gh)/d(dh) coefficients saved by the forward pass
+//     (dgh_t = dh_t * c_t elementwise), only dh_t [Bg,Hg] is exchanged per step -- the same
+//     volume as forward -- and dh_{t-1} = dout_{t-1} + z_t*dh_t + (dh_t*c_t) W_hh is the same
+//     MFMA shape.  dgi / dgh for the weight-gradient GEMMs are formed afterwards by an
+//     elementwise kernel from dh (cruse_gru_gate_grads).
 //   * all workgroups of a launch must be co-resident: grid <= number of CUs
 //     (one 256-thread workgroup per CU); larger batches are split into launches.
 #include "common.h"
@@ -27,39 +33,78 @@ namespace {
 
 constexpr int U = 32;                 // hidden units per workgroup
 constexpr int MAXG = 8;
-constexpr unsigned SPIN_LIMIT = 1u << 22;
+constexpr int CH = 10;                // 16-byte granule pairs in flight per thread and sweep batch
+constexpr unsigned SPIN_LIMIT = 1u << 21;
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct GruPtrs { const float* w_hh[MAXG]; const float* b_hh[MAXG]; };
 
 struct GruArgs {
     // forward
-    const float* gi; float* h; float* r; float* z; float* n; float* ghn;
+    const float* gi; float* h; float* coef; float* an; float* z;
     // backward
-    const float* dout; const float* hs; const float* rs; const float* zs; const float* ns; const float* ghns;
-    float* dgi; float* dgh;
+    const float* dout; const float* coefs; const float* zs; float* dh;
     GruPtrs p;
     int B, T, G, Hg, Bg, nchains, P, bg_off;
-    unsigned* flags; unsigned* status;
+    unsigned long long* xg;           // granule panels [chain][parity][Bg][Hg]
+    unsigned xg_bytes;
+    unsigned* status;
 };
 
-__device__ __forceinline__ void st_agent_f2(float* p, float a, float b) {
-    const unsigned long long v = ((unsigned long long)__float_as_uint(b) << 32) | (unsigned long long)__float_as_uint(a);
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float2 ld_agent_f2(const float* p) {
-    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
-    return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
-}
-
-// wait until all P flag words of the team are >= need (one wave polls, relaxed, bounded)
-__device__ __forceinline__ void team_wait(unsigned* flags, int P, unsigned need, unsigned* status, int tid) {
-    if (tid < 64) {
+// Sweep a team panel of granule pairs into LDS until every tag == epoch.
+//   pair e = tid + 256*i covers values (bl, v), (bl, v+1) with e = bl*(Hg/2) + v/2.
+// BWD == false: lds[bl*ld + v] = value                       (h_{t-1} panel, ld = Hg+4)
+// BWD == true : lds[bl*ld + g*Hg + v] = value * coef[g][v]   (dh_t * c_t, ld = 3Hg+4), coef rows
+//               prefetched from `cf` (+ bl*cf_row_stride) before the first poll.
+template <bool BWD>
+__device__ __forceinline__ void sweep_panel(float* lds, int ld, __amdgpu_buffer_rsrc_t rs, unsigned base_bytes,
+                                            int npair, int Hg, unsigned epoch, const float* cf,
+                                            long long cf_row_stride, unsigned* status, int tid) {
+    const int hp = Hg >> 1;
+    const int ni = (npair + 255) >> 8;
+    for (int i0 = 0; i0 < ni; i0 += CH) {
+        unsigned pend = 0;
+        float2 c[BWD ? CH : 1][3];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int e = tid + 256 * (i0 + j);
+            if (i0 + j < ni && e < npair) {
+                pend |= 1u << j;
+                if (BWD) {
+                    const int bl = e / hp, v = 2 * (e - bl * hp);
+                    const float* cp = cf + (long long)bl * cf_row_stride + v;
+                    c[BWD ? j : 0][0] = *reinterpret_cast<const float2*>(cp);
+                    c[BWD ? j : 0][1] = *reinterpret_cast<const float2*>(cp + Hg);
+                    c[BWD ? j : 0][2] = *reinterpret_cast<const float2*>(cp + 2 * Hg);
+                }
+            }
+        }
         unsigned spins = 0;
         for (;;) {
-            unsigned v = 0xffffffffu;
-            if (tid < P) v = __hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__all(v >= need)) break;
+            u32x4 g[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+                if (pend & (1u << j))
+                    g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, base_bytes + (unsigned)(tid + 256 * (i0 + j)) * 16u, 0, 16);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                if ((pend & (1u << j)) && g[j].x == epoch && g[j].z == epoch) {
+                    const int e = tid + 256 * (i0 + j);
+                    const int bl = e / hp, v = 2 * (e - bl * hp);
+                    const float v0 = __uint_as_float(g[j].y), v1 = __uint_as_float(g[j].w);
+                    if (BWD) {
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+                            *reinterpret_cast<float2*>(lds + bl * ld + q * Hg + v) =
+                                make_float2(v0 * c[BWD ? j : 0][q].x, v1 * c[BWD ? j : 0][q].y);
+                    } else {
+                        *reinterpret_cast<float2*>(lds + bl * ld + v) = make_float2(v0, v1);
+                    }
+                    pend &= ~(1u << j);
+                }
+            }
+            if (__syncthreads_and(pend == 0)) break;
             if (++spins >= SPIN_LIMIT) {
                 if (tid == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
@@ -67,25 +112,11 @@ __device__ __forceinline__ void team_wait(unsigned* flags, int P, unsigned need,
             __builtin_amdgcn_s_sleep(1);
         }
     }
-    __syncthreads();
 }
 
-// publish: every wave drains its stores, barrier, one lane sets the flag (R1)
-__device__ __forceinline__ void team_publish(unsigned* flag, unsigned epoch, int tid) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// gather a [Bg][ncol] f32 panel (rows bl -> src + bl*row_stride) into LDS [16][ld]
-__device__ __forceinline__ void gather_panel(float* lds, int ld, const float* src, long long row_stride, int nb,
-                                             int ncol, int tid) {
-    const int half = ncol >> 1;
-    for (int e = tid; e < nb * half; e += 256) {
-        const int bl = e / half, k2 = e - bl * half;
-        const float2 v = ld_agent_f2(src + (long long)bl * row_stride + 2 * k2);
-        *reinterpret_cast<float2*>(lds + bl * ld + 2 * k2) = v;
-    }
+__device__ __forceinline__ void publish_pair(__amdgpu_buffer_rsrc_t rs, unsigned off_bytes, unsigned epoch, float a, float b) {
+    const u32x4 w = {epoch, __float_as_uint(a), epoch, __float_as_uint(b)};
+    __builtin_amdgcn_raw_buffer_store_b128(w, rs, off_bytes, 0, 16);   // aux 16 = sc1 (write-through)
 }
 
 // ---------------------------------------------------------------------------------
@@ -104,7 +135,9 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
     const int u0 = part * U;
     const float* W = a.p.w_hh[grp];
     const float* bh = a.p.b_hh[grp];
-    unsigned* flags = a.flags + (size_t)chain * a.P;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.xg, 0, a.xg_bytes, 0x00020000);
+    const unsigned panel_bytes = (unsigned)(a.Bg * Hg) * 8u;
+    const unsigned cbase = (unsigned)chain * 2u * panel_bytes;
 
     for (int i = tid; i < 16 * LD; i += 256) hB[i] = 0.f;
 
@@ -124,32 +157,32 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
         }
     }
 
-    // items: (unit pair up, local batch bl); item id it = tid + 256*q
-    const int up = tid & 15;
-    const int u = 2 * up;                                   // even unit 0..30
+    // item of this thread: unit pair (u, u+1) of local clip bl
+    const int u = 2 * (tid & 15);
+    const int bl = tid >> 4;
+    const bool active = bl < nb;
     const int half = u >> 4, ru = u & 15;
+    const int lp = (ru >> 2) * 16 + bl;
     float bias[3][2];
 #pragma unroll
     for (int g = 0; g < 3; ++g) { bias[g][0] = bh[g * Hg + u0 + u]; bias[g][1] = bh[g * Hg + u0 + u + 1]; }
-    float hprev[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    float hp0 = 0.f, hp1 = 0.f;
     __syncthreads();
 
     for (int t = 0; t < a.T; ++t) {
-        float2 gir[2], giz[2], gin[2];
-#pragma unroll
-        for (int q = 0; q < 1; ++q) {
-            const int bl = (tid >> 4) + 16 * q;
-            if (bl < nb) {
-                const float* gp = a.gi + (((long long)(b0 + bl) * a.T + t) * a.G + grp) * 3 * Hg + u0 + u;
-                gir[q] = *reinterpret_cast<const float2*>(gp);
-                giz[q] = *reinterpret_cast<const float2*>(gp + Hg);
-                gin[q] = *reinterpret_cast<const float2*>(gp + 2 * Hg);
-            }
+        float2 gir = make_float2(0.f, 0.f), giz = gir, gin = gir;
+        if (active) {
+            const float* gp = a.gi + (((long long)(b0 + bl) * a.T + t) * a.G + grp) * 3 * Hg + u0 + u;
+            gir = *reinterpret_cast<const float2*>(gp);
+            giz = *reinterpret_cast<const float2*>(gp + Hg);
+            gin = *reinterpret_cast<const float2*>(gp + 2 * Hg);
         }
+        float gh[3][2];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) { gh[g][0] = bias[g][0]; gh[g][1] = bias[g][1]; }
         if (t > 0) {
-            team_wait(flags, a.P, (unsigned)t, a.status, tid);
-            gather_panel(hB, LD, a.h + ((long long)b0 * a.T + (t - 1)) * H + grp * Hg, (long long)a.T * H, nb, Hg, tid);
-            __syncthreads();
+            sweep_panel<false>(hB, LD, rs, cbase + (unsigned)((t - 1) & 1) * panel_bytes, nb * (Hg >> 1), Hg,
+                               (unsigned)t, nullptr, 0, a.status, tid);
             f32x4 acc[6];
 #pragma unroll
             for (int j = 0; j < 6; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -171,54 +204,51 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
             for (int j = 0; j < 6; ++j)
                 *reinterpret_cast<f32x4*>(red + ((wv * 6 + j) * 64 + lane) * 4) = acc[j];
             __syncthreads();
-        }
+            if (active) {
 #pragma unroll
-        for (int q = 0; q < 1; ++q) {
-            const int bl = (tid >> 4) + 16 * q;
-            if (bl < nb) {
-                float gh[3][2];
+                for (int g = 0; g < 3; ++g)
 #pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    float s0 = bias[g][0], s1 = bias[g][1];
-                    if (t > 0) {
-                        const int lp = (ru >> 2) * 16 + bl;
-#pragma unroll
-                        for (int w = 0; w < 4; ++w) {
-                            const float2 pr = *reinterpret_cast<const float2*>(
-                                red + ((w * 6 + g * 2 + half) * 64 + lp) * 4 + (ru & 3));
-                            s0 += pr.x; s1 += pr.y;
-                        }
+                    for (int w = 0; w < 4; ++w) {
+                        const float2 pr = *reinterpret_cast<const float2*>(red + ((w * 6 + g * 2 + half) * 64 + lp) * 4 + (ru & 3));
+                        gh[g][0] += pr.x; gh[g][1] += pr.y;
                     }
-                    gh[g][0] = s0; gh[g][1] = s1;
-                }
-                const float r0 = sigmoid_acc(gir[q].x + gh[0][0]), r1 = sigmoid_acc(gir[q].y + gh[0][1]);
-                const float z0 = sigmoid_acc(giz[q].x + gh[1][0]), z1 = sigmoid_acc(giz[q].y + gh[1][1]);
-                const float n0 = tanhf(gin[q].x + r0 * gh[2][0]), n1 = tanhf(gin[q].y + r1 * gh[2][1]);
-                const float h0 = (1.f - z0) * n0 + z0 * hprev[q][0];
-                const float h1 = (1.f - z1) * n1 + z1 * hprev[q][1];
-                hprev[q][0] = h0; hprev[q][1] = h1;
-                const long long o = ((long long)(b0 + bl) * a.T + t) * H + grp * Hg + u0 + u;
-                st_agent_f2(a.h + o, h0, h1);
-                if (a.r) {
-                    *reinterpret_cast<float2*>(a.r + o) = make_float2(r0, r1);
-                    *reinterpret_cast<float2*>(a.z + o) = make_float2(z0, z1);
-                    *reinterpret_cast<float2*>(a.n + o) = make_float2(n0, n1);
-                    *reinterpret_cast<float2*>(a.ghn + o) = make_float2(gh[2][0], gh[2][1]);
-                }
             }
         }
-        team_publish(flags + part, (unsigned)(t + 1), tid);
+        if (active) {
+            const float r0 = sigmoid_acc(gir.x + gh[0][0]), r1 = sigmoid_acc(gir.y + gh[0][1]);
+            const float z0 = sigmoid_acc(giz.x + gh[1][0]), z1 = sigmoid_acc(giz.y + gh[1][1]);
+            const float n0 = tanhf(gin.x + r0 * gh[2][0]), n1 = tanhf(gin.y + r1 * gh[2][1]);
+            const float h0 = (1.f - z0) * n0 + z0 * hp0;
+            const float h1 = (1.f - z1) * n1 + z1 * hp1;
+            publish_pair(rs, cbase + (unsigned)(t & 1) * panel_bytes + (unsigned)(bl * Hg + u0 + u) * 8u,
+                         (unsigned)(t + 1), h0, h1);
+            const long long o = ((long long)(b0 + bl) * a.T + t) * H + grp * Hg + u0 + u;
+            *reinterpret_cast<float2*>(a.h + o) = make_float2(h0, h1);
+            if (a.coef) {
+                // dgh = dh * (c_r, c_z, c_n); dgi_n = dh * a_n   (see header)
+                const float an0 = (1.f - z0) * (1.f - n0 * n0), an1 = (1.f - z1) * (1.f - n1 * n1);
+                const long long o3 = (((long long)(b0 + bl) * a.T + t) * a.G + grp) * 3 * Hg + u0 + u;
+                *reinterpret_cast<float2*>(a.coef + o3) =
+                    make_float2(an0 * gh[2][0] * r0 * (1.f - r0), an1 * gh[2][1] * r1 * (1.f - r1));
+                *reinterpret_cast<float2*>(a.coef + o3 + Hg) =
+                    make_float2((hp0 - n0) * z0 * (1.f - z0), (hp1 - n1) * z1 * (1.f - z1));
+                *reinterpret_cast<float2*>(a.coef + o3 + 2 * Hg) = make_float2(an0 * r0, an1 * r1);
+                *reinterpret_cast<float2*>(a.an + o) = make_float2(an0, an1);
+                *reinterpret_cast<float2*>(a.z + o) = make_float2(z0, z1);
+            }
+            hp0 = h0; hp1 = h1;
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------
-// backward
+// backward: dh_s = dout_s + z_{s+1} * dh_{s+1} + (dh_{s+1} * c_{s+1}) W_hh
 // ---------------------------------------------------------------------------------
 template <int PREC, int NKW>
 __global__ __launch_bounds__(256) void gru_bwd_kernel(GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Hg = a.Hg, K = 3 * Hg, KS = K >> 5, LD = K + 4, H = a.G * Hg;
-    float* dB = smem;                    // [16][LD]  B operand (dgh_{t+1})
+    float* dB = smem;                    // [16][LD]  B operand (dh_{s+1} * c_{s+1})
     float* red = smem + 16 * LD;         // [4 waves][2 tiles][64][4]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int chain = blockIdx.x % a.nchains, part = blockIdx.x / a.nchains;
@@ -226,7 +256,9 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruArgs a) {
     const int b0 = bgi * a.Bg, nb = min(a.Bg, a.B - b0);
     const int u0 = part * U;
     const float* W = a.p.w_hh[grp];
-    unsigned* flags = a.flags + (size_t)chain * a.P;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.xg, 0, a.xg_bytes, 0x00020000);
+    const unsigned panel_bytes = (unsigned)(a.Bg * Hg) * 8u;
+    const unsigned cbase = (unsigned)chain * 2u * panel_bytes;
 
     for (int i = tid; i < 16 * LD; i += 256) dB[i] = 0.f;
 
@@ -246,33 +278,27 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruArgs a) {
         }
     }
 
-    const int up = tid & 15;
-    const int u = 2 * up;
+    const int u = 2 * (tid & 15);
+    const int bl = tid >> 4;
+    const bool active = bl < nb;
     const int half = u >> 4, ru = u & 15;
-    float carry[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    const int lp = (ru >> 2) * 16 + bl;
+    float dh0 = 0.f, dh1 = 0.f;          // dh_{s+1} of the own units
     __syncthreads();
 
-    for (int t = a.T - 1; t >= 0; --t) {
-        float2 rr[2], zz[2], nn[2], gg[2], hp[2], dd[2];
-#pragma unroll
-        for (int q = 0; q < 1; ++q) {
-            const int bl = (tid >> 4) + 16 * q;
-            if (bl < nb) {
-                const long long o = ((long long)(b0 + bl) * a.T + t) * H + grp * Hg + u0 + u;
-                rr[q] = *reinterpret_cast<const float2*>(a.rs + o);
-                zz[q] = *reinterpret_cast<const float2*>(a.zs + o);
-                nn[q] = *reinterpret_cast<const float2*>(a.ns + o);
-                gg[q] = *reinterpret_cast<const float2*>(a.ghns + o);
-                dd[q] = *reinterpret_cast<const float2*>(a.dout + o);
-                hp[q] = t > 0 ? *reinterpret_cast<const float2*>(a.hs + o - H) : make_float2(0.f, 0.f);
-            }
+    for (int k = 0; k < a.T; ++k) {
+        const int s = a.T - 1 - k;
+        float2 dd = make_float2(0.f, 0.f), zz = dd;
+        const long long o = ((long long)(b0 + bl) * a.T + s) * H + grp * Hg + u0 + u;
+        if (active) {
+            dd = *reinterpret_cast<const float2*>(a.dout + o);
+            if (k > 0) zz = *reinterpret_cast<const float2*>(a.zs + o + H);
         }
-        const bool have_next = t < a.T - 1;
-        if (have_next) {
-            team_wait(flags, a.P, (unsigned)(a.T - 1 - t), a.status, tid);
-            gather_panel(dB, LD, a.dgh + (((long long)b0 * a.T + (t + 1)) * a.G + grp) * K, (long long)a.T * a.G * K,
-                         nb, K, tid);
-            __syncthreads();
+        float mm0 = 0.f, mm1 = 0.f;
+        if (k > 0) {
+            const float* cf = a.coefs + (((long long)b0 * a.T + (s + 1)) * a.G + grp) * K;
+            sweep_panel<true>(dB, LD, rs, cbase + (unsigned)((k - 1) & 1) * panel_bytes, nb * (Hg >> 1), Hg,
+                              (unsigned)k, cf, (long long)a.T * a.G * K, a.status, tid);
             f32x4 acc[2];
             acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
             acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -293,38 +319,38 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruArgs a) {
             *reinterpret_cast<f32x4*>(red + ((wv * 2 + 0) * 64 + lane) * 4) = acc[0];
             *reinterpret_cast<f32x4*>(red + ((wv * 2 + 1) * 64 + lane) * 4) = acc[1];
             __syncthreads();
-        }
+            if (active) {
 #pragma unroll
-        for (int q = 0; q < 1; ++q) {
-            const int bl = (tid >> 4) + 16 * q;
-            if (bl < nb) {
-                float mm0 = 0.f, mm1 = 0.f;
-                if (have_next) {
-                    const int lp = (ru >> 2) * 16 + bl;
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        const float2 pr = *reinterpret_cast<const float2*>(red + ((w * 2 + half) * 64 + lp) * 4 + (ru & 3));
-                        mm0 += pr.x; mm1 += pr.y;
-                    }
+                for (int w = 0; w < 4; ++w) {
+                    const float2 pr = *reinterpret_cast<const float2*>(red + ((w * 2 + half) * 64 + lp) * 4 + (ru & 3));
+                    mm0 += pr.x; mm1 += pr.y;
                 }
-                const float dh0 = dd[q].x + carry[q][0] + mm0, dh1 = dd[q].y + carry[q][1] + mm1;
-                const float r0 = rr[q].x, r1 = rr[q].y, z0 = zz[q].x, z1 = zz[q].y, n0 = nn[q].x, n1 = nn[q].y;
-                const float dn0 = dh0 * (1.f - z0), dn1 = dh1 * (1.f - z1);
-                const float dz0 = dh0 * (hp[q].x - n0), dz1 = dh1 * (hp[q].y - n1);
-                carry[q][0] = dh0 * z0; carry[q][1] = dh1 * z1;
-                const float dnp0 = dn0 * (1.f - n0 * n0), dnp1 = dn1 * (1.f - n1 * n1);
-                const float dzp0 = dz0 * z0 * (1.f - z0), dzp1 = dz1 * z1 * (1.f - z1);
-                const float drp0 = dnp0 * gg[q].x * r0 * (1.f - r0), drp1 = dnp1 * gg[q].y * r1 * (1.f - r1);
-                const long long o3 = (((long long)(b0 + bl) * a.T + t) * a.G + grp) * K + u0 + u;
-                *reinterpret_cast<float2*>(a.dgi + o3) = make_float2(drp0, drp1);
-                *reinterpret_cast<float2*>(a.dgi + o3 + Hg) = make_float2(dzp0, dzp1);
-                *reinterpret_cast<float2*>(a.dgi + o3 + 2 * Hg) = make_float2(dnp0, dnp1);
-                st_agent_f2(a.dgh + o3, drp0, drp1);
-                st_agent_f2(a.dgh + o3 + Hg, dzp0, dzp1);
-                st_agent_f2(a.dgh + o3 + 2 * Hg, dnp0 * r0, dnp1 * r1);
             }
         }
-        team_publish(flags + part, (unsigned)(a.T - t), tid);
+        if (active) {
+            dh0 = dd.x + zz.x * dh0 + mm0;
+            dh1 = dd.y + zz.y * dh1 + mm1;
+            publish_pair(rs, cbase + (unsigned)(k & 1) * panel_bytes + (unsigned)(bl * Hg + u0 + u) * 8u,
+                         (unsigned)(k + 1), dh0, dh1);
+            *reinterpret_cast<float2*>(a.dh + o) = make_float2(dh0, dh1);
+        }
+    }
+}
+
+// dgi = dh * (c_r, c_z, a_n), dgh = dh * (c_r, c_z, c_n); layouts [rows][G][3][Hg]
+__global__ __launch_bounds__(256) void gru_gate_grads_kernel(const float* dh, const float* coef, const float* an,
+                                                             float* dgi, float* dgh, long long rows, int G, int Hg) {
+    const int H = G * Hg;
+    const long long n = rows * H;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long row = i / H;
+        const int c = (int)(i - row * H);
+        const int g = c / Hg, j = c - g * Hg;
+        const float d = dh[i];
+        const long long o3 = (row * G + g) * 3 * Hg + j;
+        const float cr = coef[o3], cz = coef[o3 + Hg], cn = coef[o3 + 2 * Hg];
+        dgi[o3] = d * cr; dgi[o3 + Hg] = d * cz; dgi[o3 + 2 * Hg] = d * an[i];
+        dgh[o3] = d * cr; dgh[o3 + Hg] = d * cz; dgh[o3 + 2 * Hg] = d * cn;
     }
 }
 
@@ -339,7 +365,7 @@ int num_cus() {
     return cached;
 }
 
-struct Plan { int Bg, P, nbg, chains_per_launch, nlaunch; };
+struct Plan { int Bg, P, nbg, bg_per_launch, nlaunch; };
 
 int make_plan(int B, int G, int Hg, Plan& pl) {
     pl.P = Hg / U;
@@ -348,11 +374,15 @@ int make_plan(int B, int G, int Hg, Plan& pl) {
     pl.Bg = 8;
     pl.nbg = cdiv(B, pl.Bg);
     if (pl.nbg * G * pl.P > maxblk) { pl.Bg = 16; pl.nbg = cdiv(B, pl.Bg); }
-    int bg_per_launch = maxblk / (G * pl.P);
-    if (bg_per_launch > pl.nbg) bg_per_launch = pl.nbg;
-    pl.chains_per_launch = bg_per_launch * G;
-    pl.nlaunch = cdiv(pl.nbg, bg_per_launch);
+    pl.bg_per_launch = maxblk / (G * pl.P);
+    if (pl.bg_per_launch > pl.nbg) pl.bg_per_launch = pl.nbg;
+    pl.nlaunch = cdiv(pl.nbg, pl.bg_per_launch);
     return 0;
+}
+
+size_t xg_bytes_total(int B, int G, int Hg) {
+    // chains <= ceil(B/8)*G, two parities, up to 16 rows of Hg granules (8 bytes each)
+    return (size_t)cdiv(B, 8) * G * 2 * 16 * Hg * 8;
 }
 
 template <typename Kern>
@@ -390,50 +420,63 @@ int check_common(int B, int T, int G, int Hg, int prec, const char* name) {
     return CRUSE_OK;
 }
 
+template <bool FWD>
+int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* ws, size_t lds, hipStream_t s) {
+    a.status = (unsigned*)ws;
+    a.xg = (unsigned long long*)((char*)ws + 256);
+    a.xg_bytes = (unsigned)xg_bytes_total(a.B, G, Hg);
+    a.Bg = pl.Bg; a.P = pl.P;
+    int rc = CRUSE_OK;
+    for (int L = 0; L < pl.nlaunch; ++L) {
+        const int bg_off = L * pl.bg_per_launch;
+        const int nbg_here = (pl.nbg - bg_off) < pl.bg_per_launch ? (pl.nbg - bg_off) : pl.bg_per_launch;
+        a.bg_off = bg_off;
+        a.nchains = nbg_here * G;
+        // every launch gets its own panel region: chain index inside the launch + offset
+        a.xg = (unsigned long long*)((char*)ws + 256) + (size_t)bg_off * G * 2 * pl.Bg * Hg;
+        a.xg_bytes = (unsigned)((size_t)a.nchains * 2 * pl.Bg * Hg * 8);
+        const int grid = a.nchains * pl.P;
+        if (FWD) {
+            if (prec == CRUSE_PREC_F32) rc = dispatch_fwd<CRUSE_PREC_F32>(a, grid, lds, s);
+            else if (prec == CRUSE_PREC_BF16X3) rc = dispatch_fwd<CRUSE_PREC_BF16X3>(a, grid, lds, s);
+            else rc = dispatch_fwd<CRUSE_PREC_BF16>(a, grid, lds, s);
+        } else {
+            if (prec == CRUSE_PREC_F32) rc = dispatch_bwd<CRUSE_PREC_F32>(a, grid, lds, s);
+            else if (prec == CRUSE_PREC_BF16X3) rc = dispatch_bwd<CRUSE_PREC_BF16X3>(a, grid, lds, s);
+            else rc = dispatch_bwd<CRUSE_PREC_BF16>(a, grid, lds, s);
+        }
+        if (rc) return rc;
+    }
+    return rc;
+}
+
 }  // namespace
 
 extern "C" size_t cruse_gru_ws_bytes(int B, int G, int Hg) {
-    // status word + one flag word per (chain, part); chains <= ceil(B/8)*G
-    const size_t chains = (size_t)cdiv(B, 8) * G;
-    return 256 + chains * (size_t)(Hg / U) * sizeof(unsigned);
+    return 256 + xg_bytes_total(B, G, Hg);
 }
 
 extern "C" int cruse_gru_seq_fwd(const float* gi, const float* const* w_hh, const float* const* b_hh,
-                                 float* h, float* r, float* z, float* n, float* ghn,
+                                 float* h, float* coef, float* an, float* z,
                                  int B, int T, int G, int Hg, int prec, void* ws, void* stream) {
     int rc = check_common(B, T, G, Hg, prec, "gru_seq_fwd");
     if (rc) return rc;
-    CRUSE_REQUIRE((r == nullptr) == (z == nullptr) && (r == nullptr) == (n == nullptr) && (r == nullptr) == (ghn == nullptr),
-                  CRUSE_E_SHAPE, "gru_seq_fwd: r, z, n, ghn must all be given or all be NULL");
+    CRUSE_REQUIRE((coef == nullptr) == (an == nullptr) && (coef == nullptr) == (z == nullptr), CRUSE_E_SHAPE,
+                  "gru_seq_fwd: coef, an, z must all be given or all be NULL");
     Plan pl;
     CRUSE_REQUIRE(make_plan(B, G, Hg, pl) == 0, CRUSE_E_SHAPE, "gru_seq_fwd: G*Hg/32 exceeds the CU count");
     hipStream_t s = (hipStream_t)stream;
     CRUSE_HIP(hipMemsetAsync(ws, 0, cruse_gru_ws_bytes(B, G, Hg), s), "gru_seq_fwd memset");
     GruArgs a = {};
-    a.gi = gi; a.h = h; a.r = r; a.z = z; a.n = n; a.ghn = ghn;
+    a.gi = gi; a.h = h; a.coef = coef; a.an = an; a.z = z;
     for (int g = 0; g < G; ++g) { a.p.w_hh[g] = w_hh[g]; a.p.b_hh[g] = b_hh[g]; }
-    a.B = B; a.T = T; a.G = G; a.Hg = Hg; a.Bg = pl.Bg; a.P = pl.P;
-    a.status = (unsigned*)ws;
+    a.B = B; a.T = T; a.G = G; a.Hg = Hg;
     const size_t lds = ((size_t)16 * (Hg + 4) + 4 * 6 * 64 * 4) * sizeof(float);
-    for (int L = 0; L < pl.nlaunch; ++L) {
-        const int bg_off = L * (pl.chains_per_launch / G);
-        const int nbg_here = (pl.nbg - bg_off) < (pl.chains_per_launch / G) ? (pl.nbg - bg_off) : (pl.chains_per_launch / G);
-        a.bg_off = bg_off;
-        a.nchains = nbg_here * G;
-        a.flags = (unsigned*)((char*)ws + 256) + (size_t)bg_off * G * pl.P;
-        const int grid = a.nchains * pl.P;
-        if (prec == CRUSE_PREC_F32) rc = dispatch_fwd<CRUSE_PREC_F32>(a, grid, lds, s);
-        else if (prec == CRUSE_PREC_BF16X3) rc = dispatch_fwd<CRUSE_PREC_BF16X3>(a, grid, lds, s);
-        else rc = dispatch_fwd<CRUSE_PREC_BF16>(a, grid, lds, s);
-        if (rc) return rc;
-    }
-    return CRUSE_OK;
+    return run_launches<true>(a, pl, G, Hg, prec, ws, lds, s);
 }
 
-extern "C" int cruse_gru_seq_bwd(const float* dout, const float* const* w_hh,
-                                 const float* h, const float* r, const float* z, const float* n, const float* ghn,
-                                 float* dgi, float* dgh,
-                                 int B, int T, int G, int Hg, int prec, void* ws, void* stream) {
+extern "C" int cruse_gru_seq_bwd(const float* dout, const float* const* w_hh, const float* coef, const float* z,
+                                 float* dh, int B, int T, int G, int Hg, int prec, void* ws, void* stream) {
     int rc = check_common(B, T, G, Hg, prec, "gru_seq_bwd");
     if (rc) return rc;
     Plan pl;
@@ -441,23 +484,21 @@ extern "C" int cruse_gru_seq_bwd(const float* dout, const float* const* w_hh,
     hipStream_t s = (hipStream_t)stream;
     CRUSE_HIP(hipMemsetAsync(ws, 0, cruse_gru_ws_bytes(B, G, Hg), s), "gru_seq_bwd memset");
     GruArgs a = {};
-    a.dout = dout; a.hs = h; a.rs = r; a.zs = z; a.ns = n; a.ghns = ghn; a.dgi = dgi; a.dgh = dgh;
+    a.dout = dout; a.coefs = coef; a.zs = z; a.dh = dh;
     for (int g = 0; g < G; ++g) { a.p.w_hh[g] = w_hh[g]; a.p.b_hh[g] = nullptr; }
-    a.B = B; a.T = T; a.G = G; a.Hg = Hg; a.Bg = pl.Bg; a.P = pl.P;
-    a.status = (unsigned*)ws;
+    a.B = B; a.T = T; a.G = G; a.Hg = Hg;
     const size_t lds = ((size_t)16 * (3 * Hg + 4) + 4 * 2 * 64 * 4) * sizeof(float);
     CRUSE_REQUIRE(lds <= 160 * 1024, CRUSE_E_SHAPE, "gru_seq_bwd: Hg=%d needs %zu B of LDS", Hg, lds);
-    for (int L = 0; L < pl.nlaunch; ++L) {
-        const int bg_off = L * (pl.chains_per_launch / G);
-        const int nbg_here = (pl.nbg - bg_off) < (pl.chains_per_launch / G) ? (pl.nbg - bg_off) : (pl.chains_per_launch / G);
-        a.bg_off = bg_off;
-        a.nchains = nbg_here * G;
-        a.flags = (unsigned*)((char*)ws + 256) + (size_t)bg_off * G * pl.P;
-        const int grid = a.nchains * pl.P;
-        if (prec == CRUSE_PREC_F32) rc = dispatch_bwd<CRUSE_PREC_F32>(a, grid, lds, s);
-        else if (prec == CRUSE_PREC_BF16X3) rc = dispatch_bwd<CRUSE_PREC_BF16X3>(a, grid, lds, s);
-        else rc = dispatch_bwd<CRUSE_PREC_BF16>(a, grid, lds, s);
-        if (rc) return rc;
-    }
+    return run_launches<false>(a, pl, G, Hg, prec, ws, lds, s);
+}
+
+extern "C" int cruse_gru_gate_grads(const float* dh, const float* coef, const float* an, float* dgi, float* dgh,
+                                    long long rows, int G, int Hg, void* stream) {
+    CRUSE_REQUIRE(rows > 0 && G > 0 && Hg > 0, CRUSE_E_SHAPE, "gru_gate_grads: bad shape");
+    long long nblk = (rows * G * Hg + 1023) / 1024;
+    if (nblk > 4096) nblk = 4096;
+    hipLaunchKernelGGL(gru_gate_grads_kernel, dim3((int)nblk), dim3(256), 0, (hipStream_t)stream, dh, coef, an, dgi, dgh,
+                       rows, G, Hg);
+    CRUSE_LAUNCH_CHECK("gru_gate_grads");
     return CRUSE_OK;
 }

@@ -50,13 +50,13 @@ def ggru_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], prefix: str, group
         b_hh = [P[f"{prefix}{lname}.{i}.bias_hh_l0"] for i in range(g)]
         return ops.gru_seq_fwd(gi, w_hh, b_hh, B, T, g, Hg, prec, save=save)
 
-    h1, r1, z1, n1, q1 = layer(x, "gru_list1")
+    h1, c1, a1, z1 = layer(x, "gru_list1")
     l1, m1, s1 = ops.ln_fwd(h1, P[prefix + "ln1.weight"], P[prefix + "ln1.bias"], None, rows, H, g, save=save)
-    h2, r2, z2, n2, q2 = layer(l1, "gru_list2")
+    h2, c2, a2, z2 = layer(l1, "gru_list2")
     out, m2, s2 = ops.ln_fwd(h2, P[prefix + "ln2.weight"], P[prefix + "ln2.bias"], residual, rows, H, 1, save=save)
     if save:
-        ctx.update(h1=h1, r1=r1, z1=z1, n1=n1, q1=q1, l1=l1, m1=m1, s1=s1,
-                   h2=h2, r2=r2, z2=z2, n2=n2, q2=q2, m2=m2, s2=s2)
+        ctx.update(h1=h1, c1=c1, a1=a1, z1=z1, l1=l1, m1=m1, s1=s1,
+                   h2=h2, c2=c2, a2=a2, z2=z2, m2=m2, s2=s2)
     return out, ctx
 
 
@@ -67,10 +67,11 @@ def ggru_backward(ctx, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[s
     Hg = H // g
     rows = B * T
 
-    def layer_bwd(dh, lname, inp, h, r, z, n, q, need_dinp):
+    def layer_bwd(dout_h, lname, inp, h, coef, an, z, need_dinp):
         w_hh = [P[f"{prefix}{lname}.{i}.weight_hh_l0"] for i in range(g)]
-        dgi, dgh = ops.gru_seq_bwd(dh, w_hh, h, r, z, n, q, B, T, g, Hg, prec)
-        dinp = torch.empty(B, T, H, device=dh.device, dtype=torch.float32) if need_dinp else None
+        dh = ops.gru_seq_bwd(dout_h, w_hh, coef, z, B, T, g, Hg, prec)
+        dgi, dgh = ops.gru_gate_grads(dh, coef, an, rows, g, Hg)
+        dinp = torch.empty(B, T, H, device=dout_h.device, dtype=torch.float32) if need_dinp else None
         sk = _splitk(3 * Hg, Hg, rows)
         for i in range(g):
             nm = f"{prefix}{lname}.{i}."
@@ -89,10 +90,10 @@ def ggru_backward(ctx, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[s
 
     dh2 = ops.ln_bwd(dout, ctx["h2"], ctx["m2"], ctx["s2"], P[prefix + "ln2.weight"], rows, H, 1,
                      G[prefix + "ln2.weight"], G[prefix + "ln2.bias"])
-    dl1 = layer_bwd(dh2, "gru_list2", ctx["l1"], ctx["h2"], ctx["r2"], ctx["z2"], ctx["n2"], ctx["q2"], True)
+    dl1 = layer_bwd(dh2, "gru_list2", ctx["l1"], ctx["h2"], ctx["c2"], ctx["a2"], ctx["z2"], True)
     dh1 = ops.ln_bwd(dl1, ctx["h1"], ctx["m1"], ctx["s1"], P[prefix + "ln1.weight"], rows, H, g,
                      G[prefix + "ln1.weight"], G[prefix + "ln1.bias"])
-    dx = layer_bwd(dh1, "gru_list1", ctx["x"], ctx["h1"], ctx["r1"], ctx["z1"], ctx["n1"], ctx["q1"], need_dx)
+    dx = layer_bwd(dh1, "gru_list1", ctx["x"], ctx["h1"], ctx["c1"], ctx["a1"], ctx["z1"], need_dx)
     return dx
 
 

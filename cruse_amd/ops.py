@@ -201,28 +201,36 @@ def _ptr_array(ts: Sequence[torch.Tensor]):
 
 
 def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G, Hg, prec, save=True):
+    """-> (h, coef, an, z); the last three are None when save is False (inference)."""
     dev = gi.device
     H = G * Hg
     h = torch.empty(B, T, H, device=dev, dtype=torch.float32)
     if save:
-        r = torch.empty_like(h); z = torch.empty_like(h); n = torch.empty_like(h); ghn = torch.empty_like(h)
+        coef = torch.empty(B, T, 3 * H, device=dev, dtype=torch.float32)
+        an = torch.empty_like(h); z = torch.empty_like(h)
     else:
-        r = z = n = ghn = None
+        coef = an = z = None
     ws = _ws("gru", lib.cruse_gru_ws_bytes(B, G, Hg), dev)
     wa, ba = _ptr_array(w_hh), _ptr_array(b_hh)
     check(lib.cruse_gru_seq_fwd(_p(gi), ctypes.cast(wa, ctypes.c_void_p), ctypes.cast(ba, ctypes.c_void_p), _p(h),
-                                _p(r), _p(z), _p(n), _p(ghn), B, T, G, Hg, prec_code(prec), _p(ws), _stream()))
-    return h, r, z, n, ghn
+                                _p(coef), _p(an), _p(z), B, T, G, Hg, prec_code(prec), _p(ws), _stream()))
+    return h, coef, an, z
 
 
-def gru_seq_bwd(dout, w_hh: List[torch.Tensor], h, r, z, n, ghn, B, T, G, Hg, prec):
-    dev = dout.device
-    dgi = torch.empty(B, T, G * 3 * Hg, device=dev, dtype=torch.float32)
-    dgh = torch.empty_like(dgi)
-    ws = _ws("gru", lib.cruse_gru_ws_bytes(B, G, Hg), dev)
+def gru_seq_bwd(dout, w_hh: List[torch.Tensor], coef, z, B, T, G, Hg, prec):
+    """dout [B,T,H] -> dh [B,T,H] (total gradient reaching every h_t)."""
+    dh = torch.empty_like(dout)
+    ws = _ws("gru", lib.cruse_gru_ws_bytes(B, G, Hg), dout.device)
     wa = _ptr_array(w_hh)
-    check(lib.cruse_gru_seq_bwd(_p(dout), ctypes.cast(wa, ctypes.c_void_p), _p(h), _p(r), _p(z), _p(n), _p(ghn),
-                                _p(dgi), _p(dgh), B, T, G, Hg, prec_code(prec), _p(ws), _stream()))
+    check(lib.cruse_gru_seq_bwd(_p(dout), ctypes.cast(wa, ctypes.c_void_p), _p(coef), _p(z), _p(dh), B, T, G, Hg,
+                                prec_code(prec), _p(ws), _stream()))
+    return dh
+
+
+def gru_gate_grads(dh, coef, an, rows, G, Hg):
+    dgi = torch.empty_like(coef)
+    dgh = torch.empty_like(coef)
+    check(lib.cruse_gru_gate_grads(_p(dh), _p(coef), _p(an), _p(dgi), _p(dgh), rows, G, Hg, _stream()))
     return dgi, dgh
 
 

@@ -303,13 +303,14 @@ def test_gru_sequence_fwd_bwd(ops, H, g, B, T, prec, tol):
         ops.gemm(False, True, rows, 3 * Hg, Hg, x.cuda(), i * Hg, H, dev(m.weight_ih_l0), 0, Hg, gi, i * 3 * Hg, 3 * H,
                  bias=dev(m.bias_ih_l0), prec=prec)
     w_hh = [dev(m.weight_hh_l0) for m in grus]; b_hh = [dev(m.bias_hh_l0) for m in grus]
-    h, r, z, n, q = ops.gru_seq_fwd(gi, w_hh, b_hh, B, T, g, Hg, prec)
+    h, coef, an, z = ops.gru_seq_fwd(gi, w_hh, b_hh, B, T, g, Hg, prec)
     torch.cuda.synchronize()
     assert ops.gru_status() == 0, "recurrence hand-off timed out"
     assert rel_l2(h, y_ref) < tol
     dout = torch.randn(B, T, H)
     y_ref.backward(dout)
-    dgi, dgh = ops.gru_seq_bwd(dout.cuda(), w_hh, h, r, z, n, q, B, T, g, Hg, prec)
+    dh = ops.gru_seq_bwd(dout.cuda(), w_hh, coef, z, B, T, g, Hg, prec)
+    dgi, dgh = ops.gru_gate_grads(dh, coef, an, rows, g, Hg)
     torch.cuda.synchronize()
     assert ops.gru_status() == 0
     for i, m in enumerate(grus):
@@ -334,13 +335,20 @@ def test_gru_full_length_status(ops):
     torch.manual_seed(71)
     gi = (0.5 * torch.randn(B, T, 3 * H)).cuda()
     w = (torch.randn(3 * H, H) / 25).cuda(); b = torch.zeros(3 * H).cuda()
-    h, r, z, n, q = ops.gru_seq_fwd(gi, [w], [b], B, T, 1, H, "bf16")
+    h, coef, an, z = ops.gru_seq_fwd(gi, [w], [b], B, T, 1, H, "bf16")
     torch.cuda.synchronize()
     assert ops.gru_status() == 0
     assert torch.isfinite(h).all() and float(h.abs().max()) <= 1.0
     # independence of chains: clip 3 alone gives the same rows (bit-exact: same tiles, same order)
     h1, *_ = ops.gru_seq_fwd(gi[3:4].contiguous(), [w], [b], 1, T, 1, H, "bf16")
     assert rel_l2(h1[0], h[3]) < 1e-6
+    # backward at full length: finishes, finite, and the chains are independent as well
+    dout = (0.1 * torch.randn(B, T, H)).cuda()
+    dh = ops.gru_seq_bwd(dout, [w], coef, z, B, T, 1, H, "bf16")
+    torch.cuda.synchronize()
+    assert ops.gru_status() == 0 and torch.isfinite(dh).all()
+    dh5 = ops.gru_seq_bwd(dout[5:6].contiguous(), [w], coef[5:6].contiguous(), z[5:6].contiguous(), 1, T, 1, H, "bf16")
+    assert rel_l2(dh5[0], dh[5]) < 1e-6
 
 
 # ------------------------------------------------------------------ mask + loss, Adam
