@@ -25,8 +25,8 @@ SIGNATURES = {
     "cruse_stft_fwd": ("piiiipppifp", "i"),
     "cruse_istft_fwd": ("ppiiiiipp", "i"),
     "cruse_istft_bwd": ("piiiiippp", "i"),
-    "cruse_conv_gather": ("ppppiiiiiiiiiiiip", "i"),
-    "cruse_conv_scatter2": ("ppppiiiiiiiiiip", "i"),
+    "cruse_conv_gather": ("ppppiiiiiiiiiiiiip", "i"),
+    "cruse_conv_scatter2": ("ppppiiiiiiiiiiip", "i"),
     "cruse_conv_wgrad_ws_bytes": ("iii", "z"),
     "cruse_conv_wgrad": ("pppiiiiiiiiipp", "i"),
     "cruse_channel_sum": ("pqiipp", "i"),

@@ -363,9 +363,13 @@ int set_smem(K kern, size_t bytes, const char* name) {
 
 }  // namespace
 
+int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float* bias, float* y,
+                        int B, int T, int Cin, int Fin, int Cout, int Fout, int KT, int S, int pad,
+                        int w_layout, int act, int accum, int prec, hipStream_t stream);
+
 extern "C" int cruse_conv_gather(const float* x, const float* w, const float* bias, float* y,
                                  int B, int T, int Cin, int Fin, int Cout, int Fout,
-                                 int KT, int S, int pad, int w_layout, int act, int accum, void* stream) {
+                                 int KT, int S, int pad, int w_layout, int act, int accum, int prec, void* stream) {
     CRUSE_REQUIRE(B > 0 && T > 0 && Cin > 0 && Cout > 0 && Fin > 0 && Fout > 0, CRUSE_E_SHAPE,
                   "conv_gather: empty shape B=%d T=%d Cin=%d Cout=%d Fin=%d Fout=%d", B, T, Cin, Cout, Fin, Fout);
     CRUSE_REQUIRE((KT == 1 || KT == 2) && (S == 1 || S == 2) && (pad == 0 || pad == 1), CRUSE_E_SHAPE,
@@ -374,6 +378,11 @@ extern "C" int cruse_conv_gather(const float* x, const float* w, const float* bi
                   "conv_gather: Fout=%d reads past Fin=%d (+1 zero column)", Fout, Fin);
     CRUSE_REQUIRE(w_layout == 0 || (KT == 1 && S == 1), CRUSE_E_SHAPE, "conv_gather: w_layout 1 needs KT=1,S=1");
     CRUSE_REQUIRE(!(accum && act), CRUSE_E_SHAPE, "conv_gather: accum with activation");
+    if (prec >= 0) {
+        const int r = cruse_conv_mfma_try(0, x, w, bias, y, B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout, act, accum,
+                                          prec, (hipStream_t)stream);
+        if (r != 0) return r < 0 ? r : CRUSE_OK;
+    }
     ConvArgs a{x, w, bias, y, B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout, act, accum};
     const size_t lds = (((size_t)Cin * KT * 3 * Cout + 3) & ~(size_t)3) * 4 +
                        (size_t)(TF + KT - 1) * Cin * (Fin + 2) * 4;
@@ -393,12 +402,17 @@ extern "C" int cruse_conv_gather(const float* x, const float* w, const float* bi
 
 extern "C" int cruse_conv_scatter2(const float* g, const float* w, const float* bias, float* y,
                                    int B, int T, int Cs, int Fg, int Cout, int Fout,
-                                   int KT, int pad, int act, int accum, void* stream) {
+                                   int KT, int pad, int act, int accum, int prec, void* stream) {
     CRUSE_REQUIRE(B > 0 && T > 0 && Cs > 0 && Cout > 0 && Fg > 0, CRUSE_E_SHAPE, "conv_scatter2: empty shape");
     CRUSE_REQUIRE(Fout == 2 * Fg, CRUSE_E_SHAPE, "conv_scatter2: Fout=%d must be 2*Fg=%d", Fout, 2 * Fg);
     CRUSE_REQUIRE((KT == 1 || KT == 2) && (pad == 0 || pad == 1), CRUSE_E_SHAPE,
                   "conv_scatter2: unsupported KT=%d pad=%d", KT, pad);
     CRUSE_REQUIRE(!(accum && act), CRUSE_E_SHAPE, "conv_scatter2: accum with activation");
+    if (prec >= 0) {
+        const int r = cruse_conv_mfma_try(1, g, w, bias, y, B, T, Cs, Fg, Cout, Fout, KT, 2, pad, 0, act, accum, prec,
+                                          (hipStream_t)stream);
+        if (r != 0) return r < 0 ? r : CRUSE_OK;
+    }
     ConvArgs a{g, w, bias, y, B, T, Cs, Fg, Cout, Fout, KT, 2, pad, 0, act, accum};
     const size_t lds = (((size_t)Cs * KT * 3 * Cout + 3) & ~(size_t)3) * 4 +
                        (size_t)(TF + KT - 1) * Cs * (Fg + 2) * 4;

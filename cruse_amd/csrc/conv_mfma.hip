@@ -1,0 +1,225 @@
+// Implicit-GEMM convolutions on MFMA for the CRUSE encoder / decoder / skip paths
+// (nn.Conv2d / nn.ConvTranspose2d forward and backward-data, model/cruse_net.py:138-143,149-164).
+//
+//   Out[co, n] = sum_k W[co, k] * Patch[k, n],   n = (frame, position),  k = (tap, ci)
+//
+// M = output channels (16-row MFMA tiles), N = 16 positions, K = taps x Cin in steps of 32.
+// A tile of 8 frames (+1 halo) is read from HBM once (frame-major [t][c][f] rows) and
+// TRANSPOSED while it is staged into LDS as [frame][f][ci] (channel fastest, +4 pad), so a
+// lane's B fragment -- 8 consecutive ci of one tap at one position -- is two aligned
+// ds_read_b128.  Weight fragments are pre-built once per workgroup in LDS in fragment order.
+// The stride-2 transposed forms (ConvTranspose2d forward, backward-data of the stride-2
+// encoder conv) are two position classes (even / odd output bins) with their own tap lists,
+// so every class is a dense GEMM.  The kernel moves 2 x 640 floats per frame through HBM
+// against <= 0.25 MFLOP per frame: it is HBM-bound, the MFMA time is negligible.
+#include "common.h"
+
+namespace {
+
+constexpr int TFM = 8;                  // frames per workgroup tile
+constexpr int MAXTAP = 6;
+
+struct TapClass {
+    int ntaps, par;
+    int dt[MAXTAP], df[MAXTAP], wk[MAXTAP];     // frame offset, input-bin offset, weight tap index (kt*3+kf)
+};
+
+struct CMArgs {
+    const float* x; const float* w; const float* bias; float* y;
+    int B, T, Cin, Fin, Cout, Fout;
+    int S, OS, nclass, halo_lo;                  // input bin stride, output bin stride, classes, frames of halo before t0
+    int nrows;                                   // staged frames = TFM + halo
+    long long sco, sci;                          // weight strides of co and ci (tap index is fastest, 3*KT long)
+    int act, accum;
+    TapClass cls[2];
+};
+
+template <int PREC, int MT>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int CinP = a.Cin + 4, FinP = a.Fin + 2;
+    const int ks0 = (a.cls[0].ntaps * a.Cin + 31) >> 5;
+    const int ks1 = a.nclass > 1 ? (a.cls[1].ntaps * a.Cin + 31) >> 5 : 0;
+    const int nfrag = MT * (ks0 + ks1);
+    float* wl = smem;                                      // [nfrag][64 lanes][8]
+    float* xl = smem + (size_t)nfrag * 512;                // [nrows][FinP][CinP]
+    __shared__ int s_tap[2][MAXTAP][2];
+
+    const int ntile = (a.T + TFM - 1) / TFM;
+
+    if (tid < 2 * MAXTAP) {
+        const int c = tid / MAXTAP, i = tid % MAXTAP;
+        s_tap[c][i][0] = a.cls[c].dt[i];
+        s_tap[c][i][1] = a.cls[c].df[i];
+    }
+    // weight fragments: frag (c, mt, ks), lane l, element e -> W[co = mt*16 + (l&15)][k = ks*32 + (l>>4)*8 + e]
+    for (int i = tid; i < nfrag * 512; i += 256) {
+        const int e = i & 7, l = (i >> 3) & 63, fr = i >> 9;
+        int c = 0, rem = fr;
+        if (rem >= MT * ks0) { c = 1; rem -= MT * ks0; }
+        const int ksn = c ? ks1 : ks0;
+        const int mt = rem / ksn, ks = rem % ksn;
+        const int co = mt * 16 + (l & 15);
+        const int k = ks * 32 + (l >> 4) * 8 + e;
+        const int tap = k / a.Cin, ci = k % a.Cin;
+        float v = 0.f;
+        if (co < a.Cout && tap < a.cls[c].ntaps) v = a.w[co * a.sco + ci * a.sci + a.cls[c].wk[tap]];
+        wl[i] = v;
+    }
+    // zero border columns once (never overwritten)
+    for (int i = tid; i < a.nrows * 2 * a.Cin; i += 256) {
+        const int r = i / (2 * a.Cin), j = i % (2 * a.Cin);
+        const int ci = j >> 1, side = j & 1;
+        xl[(r * FinP + (side ? a.Fin + 1 : 0)) * CinP + ci] = 0.f;
+    }
+    const int rowlen = a.Cin * a.Fin;
+    const int Mpos = a.Fout / a.OS;                        // positions per frame and class
+    const int ntile_c = TFM * Mpos / 16;                   // N tiles per class
+    const int q8 = (lane >> 4) * 8;
+  for (int tile = blockIdx.x; tile < a.B * ntile; tile += gridDim.x) {
+    const int b = tile / ntile;
+    const int t0 = (tile % ntile) * TFM;
+    __syncthreads();                                       // previous tile's reads of xl are done
+    // stage + transpose input frames: global [t][ci][f] -> LDS [r][f+1][ci]; zero outside the clip
+    for (int i = tid; i < a.nrows * rowlen; i += 256) {
+        const int r = i / rowlen, j = i - r * rowlen;
+        const int ci = j / a.Fin, f = j - ci * a.Fin;
+        const int t = t0 - a.halo_lo + r;
+        float v = 0.f;
+        if (t >= 0 && t < a.T) v = a.x[((long long)b * a.T + t) * rowlen + j];
+        xl[(r * FinP + f + 1) * CinP + ci] = v;
+    }
+    __syncthreads();
+
+    for (int nt = wv; nt < a.nclass * ntile_c; nt += 4) {
+        const int c = nt / ntile_c;
+        const int p = (nt - c * ntile_c) * 16 + (lane & 15);
+        const int tl = p / Mpos, m = p - tl * Mpos;
+        const int ksn = c ? ks1 : ks0;
+        const int fbase = c ? MT * ks0 : 0;
+        const int ntaps = a.cls[c].ntaps;
+        f32x4 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < ksn; ++ks) {
+            const int k = ks * 32 + q8;
+            int tap = k / a.Cin;
+            const int ci0 = k - tap * a.Cin;
+            if (tap >= ntaps) tap = ntaps - 1;            // zero weights there; keep the address valid
+            const int r = tl + a.halo_lo + s_tap[c][tap][0];
+            const int f = a.S * m + s_tap[c][tap][1];
+            const float* pb = xl + (r * FinP + f + 1) * CinP + ci0;
+            const float4 b0 = *reinterpret_cast<const float4*>(pb);
+            const float4 b1 = *reinterpret_cast<const float4*>(pb + 4);
+            const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            Frag<PREC> fb;
+            fb.set(bv);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float* pa = wl + ((size_t)(fbase + mt * ksn + ks) * 64 + lane) * 8;
+                const float4 a0 = *reinterpret_cast<const float4*>(pa);
+                const float4 a1 = *reinterpret_cast<const float4*>(pa + 4);
+                const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                Frag<PREC> fa;
+                fa.set(av);
+                acc[mt] = mma(fa, fb, acc[mt]);
+            }
+        }
+        const int t = t0 + tl;
+        if (t < a.T) {
+            const int fo = a.OS * m + a.cls[c].par;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int co = mt * 16 + (lane >> 4) * 4 + r4;
+                    if (co < a.Cout) {
+                        const long long idx = (((long long)b * a.T + t) * a.Cout + co) * a.Fout + fo;
+                        float v = acc[mt][r4] + (a.bias ? a.bias[co] : 0.f);
+                        if (a.accum) v += a.y[idx];
+                        else if (a.act == 1) v = sigmoid_acc(v);
+                        a.y[idx] = v;
+                    }
+                }
+            }
+        }
+    }
+  }
+}
+
+template <int PREC>
+int launch_mt(const CMArgs& a, int grid, size_t lds, hipStream_t s) {
+    const int mt = (a.Cout + 15) / 16;
+    int rc;
+#define CM_LAUNCH(MTV)                                                                                     \
+    do {                                                                                                   \
+        if ((rc = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(conv_mfma_kernel<PREC, MTV>), lds, "conv_mfma"))) return rc; \
+        hipLaunchKernelGGL((conv_mfma_kernel<PREC, MTV>), dim3(grid), dim3(256), lds, s, a);               \
+    } while (0)
+    if (mt <= 1) CM_LAUNCH(1);
+    else if (mt <= 2) CM_LAUNCH(2);
+    else CM_LAUNCH(4);
+#undef CM_LAUNCH
+    return CRUSE_OK;
+}
+
+}  // namespace
+
+// Returns 1 if the MFMA path handled the call, 0 if the shape is not eligible (caller falls back
+// to the VALU kernel), < 0 on error.
+int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float* bias, float* y,
+                        int B, int T, int Cin, int Fin, int Cout, int Fout, int KT, int S, int pad,
+                        int w_layout, int act, int accum, int prec, hipStream_t stream) {
+    if (Cin % 8 != 0 || Cout < 8 || Cout > 64 || (TFM * (Fout / (scatter ? 2 : 1))) % 16 != 0) return 0;
+    CMArgs a = {};
+    a.x = x; a.w = w; a.bias = bias; a.y = y;
+    a.B = B; a.T = T; a.Cin = Cin; a.Fin = Fin; a.Cout = Cout; a.Fout = Fout;
+    a.act = act; a.accum = accum;
+    if (!scatter) {
+        // y[co,fo] = sum W(co,ci,kt,kf) x[t-(KT-1)+kt, ci, fo*S - pad + kf]
+        a.S = S; a.OS = 1; a.nclass = 1; a.halo_lo = KT - 1;
+        a.cls[0].ntaps = KT * 3; a.cls[0].par = 0;
+        for (int kt = 0; kt < KT; ++kt)
+            for (int kf = 0; kf < 3; ++kf) {
+                const int i = kt * 3 + kf;
+                a.cls[0].dt[i] = kt - (KT - 1);
+                a.cls[0].df[i] = kf - pad;
+                a.cls[0].wk[i] = w_layout == 0 ? kt * 3 + kf : (2 - kf);
+            }
+        if (w_layout == 0) { a.sco = (long long)Cin * KT * 3; a.sci = KT * 3; }
+        else { a.sco = 3; a.sci = (long long)Cout * 3; }
+    } else {
+        // y[co,fo] = sum_{(fo+pad-kf) even} w[cs][co][kt][kf] g[t+(KT-1)-kt, cs, (fo+pad-kf)/2]; fo = 2m + par
+        a.S = 1; a.OS = 2; a.nclass = 2; a.halo_lo = 0;
+        a.sco = (long long)KT * 3; a.sci = (long long)Cout * KT * 3;
+        for (int par = 0; par < 2; ++par) {
+            TapClass& c = a.cls[par];
+            c.par = par; c.ntaps = 0;
+            for (int kt = 0; kt < KT; ++kt)
+                for (int kf = 0; kf < 3; ++kf) {
+                    const int q = par + pad - kf;            // fo + pad - kf = 2m + q
+                    if (q & 1) continue;
+                    const int i = c.ntaps++;
+                    c.dt[i] = (KT - 1) - kt;
+                    c.df[i] = q / 2;                         // q in {-2,0,2} -> -1,0,+1 (exact for even q)
+                    c.wk[i] = kt * 3 + kf;
+                }
+        }
+    }
+    a.nrows = TFM + KT - 1;
+    const int ks0 = (a.cls[0].ntaps * Cin + 31) / 32, ks1 = a.nclass > 1 ? (a.cls[1].ntaps * Cin + 31) / 32 : 0;
+    const int mt = Cout <= 16 ? 1 : (Cout <= 32 ? 2 : 4);
+    const size_t lds = ((size_t)mt * (ks0 + ks1) * 512 + (size_t)a.nrows * (Fin + 2) * (Cin + 4)) * sizeof(float);
+    if (lds > 150 * 1024) return 0;
+    const int ntiles = B * ((T + TFM - 1) / TFM);
+    const int grid = ntiles < 512 ? ntiles : 512;
+    int rc;
+    if (prec == CRUSE_PREC_F32) rc = launch_mt<CRUSE_PREC_F32>(a, grid, lds, stream);
+    else if (prec == CRUSE_PREC_BF16) rc = launch_mt<CRUSE_PREC_BF16>(a, grid, lds, stream);
+    else rc = launch_mt<CRUSE_PREC_BF16X3>(a, grid, lds, stream);
+    if (rc) return rc;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cruse_set_error("conv_mfma: HIP launch failed: %s", hipGetErrorString(e)); return CRUSE_E_HIP; }
+    return 1;
+}

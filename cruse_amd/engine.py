@@ -119,12 +119,16 @@ class TrainEngine:
 
     def _capture(self, noisy, clean):
         self._static = (noisy.clone(), clean.clone())
+        # the warm-up run below must leave no trace: BatchNorm running statistics and counters are restored
+        saved = {k: v.clone() for k, v in self.Bf.items()}
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):           # warm-up on a side stream (allocations, LDS attributes)
             self._fwd_bwd(*self._static)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        for k, v in saved.items():
+            self.Bf[k].copy_(v)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._static_loss = self._fwd_bwd(*self._static)

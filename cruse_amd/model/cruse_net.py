@@ -134,10 +134,11 @@ def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, tor
     ys, es, ss, stats = [None], [x], [None], [None]
     for k in range(1, L + 1):
         y = ops.conv_gather(cur, P[f"conv{k}.weight"], P[f"conv{k}.bias"], B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k],
-                            KT=2, S=2, pad=1)
+                            KT=2, S=2, pad=1, prec=prec)
         mean, rstd = _bn_stats(y, rows, ch[k], Fk[k], P, Bf, f"bn{k}", training, update_running)
         e = ops.bn_act_fwd(y, mean, rstd, P[f"bn{k}.weight"], P[f"bn{k}.bias"], None, rows, ch[k], Fk[k], relu=True)
-        s = ops.conv_gather(e, P[f"skip_connect_{k}.weight"], None, B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1)
+        s = ops.conv_gather(e, P[f"skip_connect_{k}.weight"], None, B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1,
+                            prec=prec)
         ys.append(y); es.append(e); ss.append(s); stats.append((mean, rstd))
         cur = e
     H = ch[L] * Fk[L]
@@ -145,12 +146,14 @@ def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, tor
     u = u.view(B, T, ch[L], Fk[L])
     us, vs, dstats = {L: u}, {}, {}
     for k in range(L, 1, -1):
-        v = ops.conv_scatter2(u, P[f"conv{k}_t.weight"], P[f"conv{k}_t.bias"], B, T, ch[k], Fk[k], ch[k - 1], KT=1, pad=0)
+        v = ops.conv_scatter2(u, P[f"conv{k}_t.weight"], P[f"conv{k}_t.bias"], B, T, ch[k], Fk[k], ch[k - 1], KT=1, pad=0,
+                              prec=prec)
         mean, rstd = _bn_stats(v, rows, ch[k - 1], Fk[k - 1], P, Bf, f"bn{k}_t", training, update_running)
         u = ops.bn_act_fwd(v, mean, rstd, P[f"bn{k}_t.weight"], P[f"bn{k}_t.bias"], ss[k - 1], rows, ch[k - 1],
                            Fk[k - 1], relu=True)
         vs[k] = v; dstats[k] = (mean, rstd); us[k - 1] = u
-    mask = ops.conv_scatter2(u, P["conv1_t.weight"], P["conv1_t.bias"], B, T, ch[1], Fk[1], ch[0], KT=1, pad=0, act=1)
+    mask = ops.conv_scatter2(u, P["conv1_t.weight"], P["conv1_t.bias"], B, T, ch[1], Fk[1], ch[0], KT=1, pad=0, act=1,
+                             prec=prec)
     if save:
         ctx.update(ys=ys, es=es, stats=stats, gctx=gctx, us=us, vs=vs, dstats=dstats, mask=mask)
     return mask.view(B, ch[0], T, F0), ctx
@@ -159,13 +162,14 @@ def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, tor
 def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor]) -> None:
     """dlogit = dL/d(pre-sigmoid) [B,T,1,F0]; parameter gradients are ACCUMULATED into G[name]."""
     B, T, Fk, ch, L, training = ctx["B"], ctx["T"], ctx["F"], ctx["ch"], ctx["L"], ctx["training"]
+    prec = ctx["prec"]
     rows = B * T
     ys, es, stats, us, vs, dstats = ctx["ys"], ctx["es"], ctx["stats"], ctx["us"], ctx["vs"], ctx["dstats"]
     # ---- decoder level 1: v1 = convT_1(u1) -------------------------------------------
     dv = dlogit
     ops.channel_sum(dv, rows, ch[0], Fk[0], G["conv1_t.bias"])
     ops.conv_wgrad(us[1], dv, G["conv1_t.weight"], B, T, ch[1], Fk[1], ch[0], Fk[0], KT=1, S=2, pad=0)
-    du = ops.conv_gather(dv, P["conv1_t.weight"], None, B, T, ch[0], Fk[0], ch[1], Fk[1], KT=1, S=2, pad=0)
+    du = ops.conv_gather(dv, P["conv1_t.weight"], None, B, T, ch[0], Fk[0], ch[1], Fk[1], KT=1, S=2, pad=0, prec=prec)
     ds = {1: du}                                        # gradient wrt skip_{k} output = du_k
     # ---- decoder levels 2..L ------------------------------------------------------------
     for k in range(2, L + 1):
@@ -174,7 +178,8 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
                             Fk[k - 1], True, training, G[f"bn{k}_t.weight"], G[f"bn{k}_t.bias"])
         ops.channel_sum(dv, rows, ch[k - 1], Fk[k - 1], G[f"conv{k}_t.bias"])
         ops.conv_wgrad(us[k], dv, G[f"conv{k}_t.weight"], B, T, ch[k], Fk[k], ch[k - 1], Fk[k - 1], KT=1, S=2, pad=0)
-        du = ops.conv_gather(dv, P[f"conv{k}_t.weight"], None, B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k], KT=1, S=2, pad=0)
+        du = ops.conv_gather(dv, P[f"conv{k}_t.weight"], None, B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k], KT=1, S=2, pad=0,
+                             prec=prec)
         ds[k] = du
     # ---- bottleneck: u_L = ggru(e_L) + skip_L --------------------------------------------
     H = ch[L] * Fk[L]
@@ -183,7 +188,7 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
     for k in range(L, 0, -1):
         # skip_k = conv1x3(e_k): de_k += W^T ds_k ; dW_skip += ds_k (*) e_k
         ops.conv_gather(ds[k], P[f"skip_connect_{k}.weight"], None, B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1,
-                        w_layout=1, out=de, accum=True)
+                        w_layout=1, out=de, accum=True, prec=prec)
         ops.conv_wgrad(ds[k], es[k], G[f"skip_connect_{k}.weight"], B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1)
         mean, rstd = stats[k]
         dy = ops.bn_act_bwd(de, ys[k], mean, rstd, P[f"bn{k}.weight"], P[f"bn{k}.bias"], rows, ch[k], Fk[k], True,
@@ -191,7 +196,7 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
         ops.channel_sum(dy, rows, ch[k], Fk[k], G[f"conv{k}.bias"])
         ops.conv_wgrad(dy, es[k - 1], G[f"conv{k}.weight"], B, T, ch[k], Fk[k], ch[k - 1], Fk[k - 1], KT=2, S=2, pad=1)
         if k > 1:
-            de = ops.conv_scatter2(dy, P[f"conv{k}.weight"], None, B, T, ch[k], Fk[k], ch[k - 1], KT=2, pad=1)
+            de = ops.conv_scatter2(dy, P[f"conv{k}.weight"], None, B, T, ch[k], Fk[k], ch[k - 1], KT=2, pad=1, prec=prec)
 
 
 # ======================================================================================

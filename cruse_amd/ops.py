@@ -80,20 +80,32 @@ def istft_bwd(dwave: torch.Tensor, T: int, n_fft: int, hop: int):
 
 
 # ---------------------------------------------------------------- convolutions
-def conv_gather(x, w, bias, B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout=0, act=0, out=None, accum=False):
+CONV_PREC = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16X3, "valu": -1}
+
+
+def conv_prec(prec) -> int:
+    """MFMA precision used by the convolutions for a model precision mode: the convs are HBM-bound, so
+    the bf16 mode runs them as split-bf16 x3 (~f32 accuracy) at no measurable cost."""
+    if prec is None:
+        return -1
+    return CONV_PREC[prec] if isinstance(prec, str) else int(prec)
+
+
+def conv_gather(x, w, bias, B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout=0, act=0, out=None, accum=False,
+                prec=None):
     if out is None:
         out = torch.empty(B, T, Cout, Fout, device=x.device, dtype=torch.float32)
     check(lib.cruse_conv_gather(_p(x), _p(w), _p(bias), _p(out), B, T, Cin, Fin, Cout, Fout, KT, S, pad,
-                                w_layout, act, 1 if accum else 0, _stream()))
+                                w_layout, act, 1 if accum else 0, conv_prec(prec), _stream()))
     return out
 
 
-def conv_scatter2(g, w, bias, B, T, Cs, Fg, Cout, KT, pad, act=0, out=None, accum=False):
+def conv_scatter2(g, w, bias, B, T, Cs, Fg, Cout, KT, pad, act=0, out=None, accum=False, prec=None):
     Fout = 2 * Fg
     if out is None:
         out = torch.empty(B, T, Cout, Fout, device=g.device, dtype=torch.float32)
     check(lib.cruse_conv_scatter2(_p(g), _p(w), _p(bias), _p(out), B, T, Cs, Fg, Cout, Fout, KT, pad, act,
-                                  1 if accum else 0, _stream()))
+                                  1 if accum else 0, conv_prec(prec), _stream()))
     return out
 
 

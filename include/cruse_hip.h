@@ -76,10 +76,12 @@ int cruse_istft_bwd(const float* dwave, int B, int T, int n_fft, int hop, int L,
  * zero outside the clip.  kf in 0..2.  w_layout 0: W = w[co][ci][kt][kf] (Conv2d weight, or a
  * ConvTranspose2d weight read as [out=Cin_t][in=Cout_t] for its backward-data).
  * w_layout 1 (KT == 1, S == 1): W(co,ci,0,kf) = w[ci][co][0][2-kf] (backward-data of a stride-1 conv).
- * act 0 none, 1 sigmoid.  accum != 0: y += result (act must be 0). bias may be NULL. */
+ * act 0 none, 1 sigmoid.  accum != 0: y += result (act must be 0). bias may be NULL.
+ * prec: CRUSE_PREC_* selects the MFMA implicit-GEMM kernel (Cin % 8 == 0, 8 <= Cout <= 64);
+ * prec < 0, or an ineligible shape (Cin == 1, Cout == 1), runs the exact-f32 VALU kernel. */
 int cruse_conv_gather(const float* x, const float* w, const float* bias, float* y,
                       int B, int T, int Cin, int Fin, int Cout, int Fout,
-                      int KT, int S, int pad, int w_layout, int act, int accum, void* stream);
+                      int KT, int S, int pad, int w_layout, int act, int accum, int prec, void* stream);
 
 /* scatter form, frequency stride 2:
  *   y[b,t,co,fo] (+)= act(bias[co] + sum_{cs,kt,kf : (fo+pad-kf) even} w[cs][co][kt][kf] *
@@ -88,7 +90,7 @@ int cruse_conv_gather(const float* x, const float* w, const float* bias, float* 
  * KT=1, pad=0, Fout=2*Fg.  Backward-data of the (2,3)/(1,2) encoder conv: KT=2, pad=1. */
 int cruse_conv_scatter2(const float* g, const float* w, const float* bias, float* y,
                         int B, int T, int Cs, int Fg, int Cout, int Fout,
-                        int KT, int pad, int act, int accum, void* stream);
+                        int KT, int pad, int act, int accum, int prec, void* stream);
 
 /* weight gradient of either form:
  *   dw[ca][cb][kt][kf] += sum_{b,t,fa} a[b,t,ca,fa] * bt[b, t-(KT-1)+kt, cb, fa*S - pad + kf]

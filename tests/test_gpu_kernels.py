@@ -90,6 +90,7 @@ def test_istft_backward_is_adjoint(ops):
 
 # ------------------------------------------------------------------ convolutions
 LEVELS = [(1, 160, 8, 80), (8, 80, 16, 40), (16, 40, 32, 20), (32, 20, 64, 10)]
+PRECS = [(None, 1e-5), ("f32", 1e-5), ("bf16x3", 5e-5)]
 
 
 def _nchw(x):       # frame-major [B,T,C,F] -> [B,C,T,F]
@@ -106,12 +107,13 @@ def test_encoder_conv_fwd_bwd(ops, lvl):
     b = torch.randn(Cout, generator=gen)
     xr = _nchw(x).requires_grad_(True); wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
     y_ref = F.conv2d(xr, wr, br, stride=(1, 2), padding=(1, 1))[..., :-1, :]       # cruse_net.py:138,149 (R4)
-    y = ops.conv_gather(x.cuda(), w.cuda(), b.cuda(), B, T, Cin, Fin, Cout, Fout, KT=2, S=2, pad=1)
-    assert rel_l2(_nchw(y), y_ref) < 1e-5
     dy = torch.randn(B, T, Cout, Fout, generator=gen)
     y_ref.backward(_nchw(dy))
-    dx = ops.conv_scatter2(dy.cuda(), w.cuda(), None, B, T, Cout, Fout, Cin, KT=2, pad=1)
-    assert rel_l2(_nchw(dx), xr.grad) < 1e-5
+    for prec, tol in PRECS:          # VALU kernel and the MFMA implicit-GEMM kernel (where eligible)
+        y = ops.conv_gather(x.cuda(), w.cuda(), b.cuda(), B, T, Cin, Fin, Cout, Fout, KT=2, S=2, pad=1, prec=prec)
+        assert rel_l2(_nchw(y), y_ref) < tol, prec
+        dx = ops.conv_scatter2(dy.cuda(), w.cuda(), None, B, T, Cout, Fout, Cin, KT=2, pad=1, prec=prec)
+        assert rel_l2(_nchw(dx), xr.grad) < tol, prec
     dw = torch.zeros_like(w).cuda()
     ops.conv_wgrad(dy.cuda(), x.cuda(), dw, B, T, Cout, Fout, Cin, Fin, KT=2, S=2, pad=1)
     assert rel_l2(dw, wr.grad) < 1e-5
@@ -129,14 +131,16 @@ def test_skip_conv_fwd_bwd(ops, lvl):
     w = torch.randn(C, C, 1, 3, generator=gen) * 0.2
     xr = _nchw(x).requires_grad_(True); wr = w.clone().requires_grad_(True)
     y_ref = F.conv2d(xr, wr, None, padding=(0, 1))                                  # cruse_net.py:143 (R5)
-    y = ops.conv_gather(x.cuda(), w.cuda(), None, B, T, C, Fq, C, Fq, KT=1, S=1, pad=1)
-    assert rel_l2(_nchw(y), y_ref) < 1e-5
     dy = torch.randn(B, T, C, Fq, generator=gen)
     y_ref.backward(_nchw(dy))
     base = torch.randn(B, T, C, Fq, generator=gen)
-    dx = base.clone().cuda()
-    ops.conv_gather(dy.cuda(), w.cuda(), None, B, T, C, Fq, C, Fq, KT=1, S=1, pad=1, w_layout=1, out=dx, accum=True)
-    assert rel_l2(_nchw(dx.cpu() - base), xr.grad) < 1e-5
+    for prec, tol in PRECS:
+        y = ops.conv_gather(x.cuda(), w.cuda(), None, B, T, C, Fq, C, Fq, KT=1, S=1, pad=1, prec=prec)
+        assert rel_l2(_nchw(y), y_ref) < tol, prec
+        dx = base.clone().cuda()
+        ops.conv_gather(dy.cuda(), w.cuda(), None, B, T, C, Fq, C, Fq, KT=1, S=1, pad=1, w_layout=1, out=dx, accum=True,
+                        prec=prec)
+        assert rel_l2(_nchw(dx.cpu() - base), xr.grad) < tol, prec
     dw = torch.zeros_like(w).cuda()
     ops.conv_wgrad(dy.cuda(), x.cuda(), dw, B, T, C, Fq, C, Fq, KT=1, S=1, pad=1)
     assert rel_l2(dw, wr.grad) < 1e-5
@@ -153,14 +157,15 @@ def test_decoder_convT_fwd_bwd(ops, lvl):
     ur = _nchw(u).requires_grad_(True); wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
     v_ref = F.conv_transpose2d(ur, wr, br, stride=(1, 2))[..., :-1]                 # cruse_net.py:140,161 (R2)
     assert v_ref.shape[-1] == Fo
-    v = ops.conv_scatter2(u.cuda(), w.cuda(), b.cuda(), B, T, Cin, Fg, Cout, KT=1, pad=0)
-    assert rel_l2(_nchw(v), v_ref) < 1e-5
-    vs = ops.conv_scatter2(u.cuda(), w.cuda(), b.cuda(), B, T, Cin, Fg, Cout, KT=1, pad=0, act=1)
-    assert rel_l2(_nchw(vs), torch.sigmoid(v_ref)) < 1e-5
     dv = torch.randn(B, T, Cout, Fo, generator=gen)
     v_ref.backward(_nchw(dv))
-    du = ops.conv_gather(dv.cuda(), w.cuda(), None, B, T, Cout, Fo, Cin, Fg, KT=1, S=2, pad=0)
-    assert rel_l2(_nchw(du), ur.grad) < 1e-5
+    for prec, tol in PRECS:
+        v = ops.conv_scatter2(u.cuda(), w.cuda(), b.cuda(), B, T, Cin, Fg, Cout, KT=1, pad=0, prec=prec)
+        assert rel_l2(_nchw(v), v_ref) < tol, prec
+        vs = ops.conv_scatter2(u.cuda(), w.cuda(), b.cuda(), B, T, Cin, Fg, Cout, KT=1, pad=0, act=1, prec=prec)
+        assert rel_l2(_nchw(vs), torch.sigmoid(v_ref)) < tol, prec
+        du = ops.conv_gather(dv.cuda(), w.cuda(), None, B, T, Cout, Fo, Cin, Fg, KT=1, S=2, pad=0, prec=prec)
+        assert rel_l2(_nchw(du), ur.grad) < tol, prec
     dw = torch.zeros_like(w).cuda()
     ops.conv_wgrad(u.cuda(), dv.cuda(), dw, B, T, Cin, Fg, Cout, Fo, KT=1, S=2, pad=0)
     assert rel_l2(dw, wr.grad) < 1e-5
