@@ -221,7 +221,7 @@ struct WgradArgs {
 };
 
 constexpr int WG_THREADS = 256;
-constexpr int WG_MAX_BLOCKS = 256;
+constexpr int WG_MAX_BLOCKS = 512;
 
 template <int CB_T, int KT>
 __global__ __launch_bounds__(WG_THREADS) void conv_wgrad_kernel(WgradArgs p) {
@@ -339,18 +339,25 @@ __global__ void wgrad_reduce_kernel(const float* partial, int nblk, int nout, fl
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* g, long long rows, int C, int F, int ld,
                                                           float* out) {
-    // grid.x strides over rows; each thread owns a fixed column j of the C*F-wide row (row stride ld)
+    // grid.x strides over rows; each thread owns a fixed column j of the C*F-wide row (row stride ld);
+    // 4 independent accumulators keep 4 loads in flight per thread
     __shared__ float sacc[2048];
     const int CF = C * F;
     const int tid = threadIdx.x;
     for (int c = tid; c < C; c += 256) sacc[c] = 0.f;
     __syncthreads();
+    const long long G = gridDim.x;
     for (int j0 = 0; j0 < CF; j0 += 256) {
         const int j = j0 + tid;
-        float s = 0.f;
-        if (j < CF)
-            for (long long r = blockIdx.x; r < rows; r += gridDim.x) s += g[r * ld + j];
-        if (j < CF) atomicAdd(&sacc[j / F], s);
+        if (j < CF) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            long long r = blockIdx.x;
+            for (; r + 3 * G < rows; r += 4 * G) {
+                s0 += g[r * ld + j]; s1 += g[(r + G) * ld + j]; s2 += g[(r + 2 * G) * ld + j]; s3 += g[(r + 3 * G) * ld + j];
+            }
+            for (; r < rows; r += G) s0 += g[r * ld + j];
+            atomicAdd(&sacc[j / F], (s0 + s1) + (s2 + s3));
+        }
     }
     __syncthreads();
     for (int c = tid; c < C; c += 256) atomicAdd(&out[c], sacc[c]);

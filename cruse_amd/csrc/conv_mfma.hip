@@ -18,6 +18,7 @@ namespace {
 
 constexpr int TFM = 8;                  // frames per workgroup tile
 constexpr int MAXTAP = 6;
+constexpr int MAXV = 8;                 // float4 per thread of a staged tile (<= 8192 floats)
 
 struct TapClass {
     int ntaps, par;
@@ -34,16 +35,65 @@ struct CMArgs {
     TapClass cls[2];
 };
 
+// LDS operand storage per precision: f32 keeps floats (8 x v_mfma_f32_16x16x4_f32 per fragment pair);
+// bf16 / bf16x3 keep 1 / 2 planes of bf16 converted ONCE at staging time, so a fragment is a single
+// ds_read_b128 per plane and the inner loop has no conversion VALU work.
+template <int PREC> struct OpStore {
+    typedef __bf16 elem;
+    static constexpr int NPL = (PREC == CRUSE_PREC_BF16X3) ? 2 : 1;
+    static constexpr int PADC = 8;                         // channel pad (elements) keeping 16-byte groups
+};
+template <> struct OpStore<CRUSE_PREC_F32> {
+    typedef float elem;
+    static constexpr int NPL = 1;
+    static constexpr int PADC = 4;
+};
+
+template <int PREC>
+__device__ __forceinline__ void put_elem(typename OpStore<PREC>::elem* base, size_t plane_stride, size_t off, float v) {
+    if constexpr (PREC == CRUSE_PREC_F32) {
+        base[off] = v;
+    } else if constexpr (PREC == CRUSE_PREC_BF16) {
+        base[off] = (__bf16)v;
+    } else {
+        __bf16 h, l;
+        split_bf16(v, h, l);
+        base[off] = h;
+        base[plane_stride + off] = l;
+    }
+}
+
+template <int PREC>
+__device__ __forceinline__ Frag<PREC> get_frag(const typename OpStore<PREC>::elem* base, size_t plane_stride, size_t off) {
+    Frag<PREC> f;
+    if constexpr (PREC == CRUSE_PREC_F32) {
+        const float4 a0 = *reinterpret_cast<const float4*>(base + off);
+        const float4 a1 = *reinterpret_cast<const float4*>(base + off + 4);
+        f.v[0] = a0.x; f.v[1] = a0.y; f.v[2] = a0.z; f.v[3] = a0.w;
+        f.v[4] = a1.x; f.v[5] = a1.y; f.v[6] = a1.z; f.v[7] = a1.w;
+    } else if constexpr (PREC == CRUSE_PREC_BF16) {
+        f.h = *reinterpret_cast<const bf16x8*>(base + off);
+    } else {
+        f.h = *reinterpret_cast<const bf16x8*>(base + off);
+        f.l = *reinterpret_cast<const bf16x8*>(base + plane_stride + off);
+    }
+    return f;
+}
+
 template <int PREC, int MT>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef typename OpStore<PREC>::elem elem;
+    constexpr int NPL = OpStore<PREC>::NPL;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int CinP = a.Cin + 4, FinP = a.Fin + 2;
+    const int CinP = a.Cin + OpStore<PREC>::PADC, FinP = a.Fin + 2;
     const int ks0 = (a.cls[0].ntaps * a.Cin + 31) >> 5;
     const int ks1 = a.nclass > 1 ? (a.cls[1].ntaps * a.Cin + 31) >> 5 : 0;
     const int nfrag = MT * (ks0 + ks1);
-    float* wl = smem;                                      // [nfrag][64 lanes][8]
-    float* xl = smem + (size_t)nfrag * 512;                // [nrows][FinP][CinP]
+    const size_t wplane = (size_t)nfrag * 512;             // elements per weight plane
+    const size_t xplane = (size_t)a.nrows * FinP * CinP;   // elements per input plane
+    elem* wl = reinterpret_cast<elem*>(smem_raw);          // [NPL][nfrag][64 lanes][8]
+    elem* xl = wl + NPL * wplane;                          // [NPL][nrows][FinP][CinP]
     __shared__ int s_tap[2][MAXTAP][2];
 
     const int ntile = (a.T + TFM - 1) / TFM;
@@ -65,87 +115,105 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
         const int tap = k / a.Cin, ci = k % a.Cin;
         float v = 0.f;
         if (co < a.Cout && tap < a.cls[c].ntaps) v = a.w[co * a.sco + ci * a.sci + a.cls[c].wk[tap]];
-        wl[i] = v;
+        put_elem<PREC>(wl, wplane, (size_t)i, v);
     }
     // zero border columns once (never overwritten)
     for (int i = tid; i < a.nrows * 2 * a.Cin; i += 256) {
         const int r = i / (2 * a.Cin), j = i % (2 * a.Cin);
         const int ci = j >> 1, side = j & 1;
-        xl[(r * FinP + (side ? a.Fin + 1 : 0)) * CinP + ci] = 0.f;
+        put_elem<PREC>(xl, xplane, (size_t)(r * FinP + (side ? a.Fin + 1 : 0)) * CinP + ci, 0.f);
     }
     const int rowlen = a.Cin * a.Fin;
     const int Mpos = a.Fout / a.OS;                        // positions per frame and class
     const int ntile_c = TFM * Mpos / 16;                   // N tiles per class
     const int q8 = (lane >> 4) * 8;
-  for (int tile = blockIdx.x; tile < a.B * ntile; tile += gridDim.x) {
-    const int b = tile / ntile;
-    const int t0 = (tile % ntile) * TFM;
-    __syncthreads();                                       // previous tile's reads of xl are done
-    // stage + transpose input frames: global [t][ci][f] -> LDS [r][f+1][ci]; zero outside the clip
-    for (int i = tid; i < a.nrows * rowlen; i += 256) {
-        const int r = i / rowlen, j = i - r * rowlen;
-        const int ci = j / a.Fin, f = j - ci * a.Fin;
-        const int t = t0 - a.halo_lo + r;
-        float v = 0.f;
-        if (t >= 0 && t < a.T) v = a.x[((long long)b * a.T + t) * rowlen + j];
-        xl[(r * FinP + f + 1) * CinP + ci] = v;
-    }
-    __syncthreads();
-
-    for (int nt = wv; nt < a.nclass * ntile_c; nt += 4) {
-        const int c = nt / ntile_c;
-        const int p = (nt - c * ntile_c) * 16 + (lane & 15);
-        const int tl = p / Mpos, m = p - tl * Mpos;
-        const int ksn = c ? ks1 : ks0;
-        const int fbase = c ? MT * ks0 : 0;
-        const int ntaps = a.cls[c].ntaps;
-        f32x4 acc[MT];
+    const int nvec = a.nrows * rowlen / 4;                 // rowlen % 4 == 0 (checked by the host)
+    // register-prefetched staging: the next tile's HBM loads are in flight while this tile computes
+    float4 pre[MAXV];
+    auto prefetch = [&](int tile) {
+        const int b = tile / ntile;
+        const int t0 = (tile % ntile) * TFM;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < ksn; ++ks) {
-            const int k = ks * 32 + q8;
-            int tap = k / a.Cin;
-            const int ci0 = k - tap * a.Cin;
-            if (tap >= ntaps) tap = ntaps - 1;            // zero weights there; keep the address valid
-            const int r = tl + a.halo_lo + s_tap[c][tap][0];
-            const int f = a.S * m + s_tap[c][tap][1];
-            const float* pb = xl + (r * FinP + f + 1) * CinP + ci0;
-            const float4 b0 = *reinterpret_cast<const float4*>(pb);
-            const float4 b1 = *reinterpret_cast<const float4*>(pb + 4);
-            const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-            Frag<PREC> fb;
-            fb.set(bv);
+        for (int q = 0; q < MAXV; ++q) {
+            const int i = tid + 256 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < nvec) {
+                const int e0 = i * 4;
+                const int r = e0 / rowlen, j0 = e0 - r * rowlen;
+                const int t = t0 - a.halo_lo + r;
+                if (t >= 0 && t < a.T) v = *reinterpret_cast<const float4*>(a.x + ((long long)b * a.T + t) * rowlen + j0);
+            }
+            pre[q] = v;
+        }
+    };
+    if ((int)blockIdx.x < a.B * ntile) prefetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < a.B * ntile; tile += gridDim.x) {
+        const int b = tile / ntile;
+        const int t0 = (tile % ntile) * TFM;
+        __syncthreads();                                   // previous tile's reads of xl are done
+        // transpose while storing: [t][ci][f] (float4 along f) -> LDS [r][f+1][ci]
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const float* pa = wl + ((size_t)(fbase + mt * ksn + ks) * 64 + lane) * 8;
-                const float4 a0 = *reinterpret_cast<const float4*>(pa);
-                const float4 a1 = *reinterpret_cast<const float4*>(pa + 4);
-                const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                Frag<PREC> fa;
-                fa.set(av);
-                acc[mt] = mma(fa, fb, acc[mt]);
+        for (int q = 0; q < MAXV; ++q) {
+            const int i = tid + 256 * q;
+            if (i < nvec) {
+                const int e0 = i * 4;
+                const int r = e0 / rowlen, j0 = e0 - r * rowlen;
+                const float vv[4] = {pre[q].x, pre[q].y, pre[q].z, pre[q].w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + u;
+                    const int ci = j / a.Fin, f = j - ci * a.Fin;
+                    put_elem<PREC>(xl, xplane, (size_t)(r * FinP + f + 1) * CinP + ci, vv[u]);
+                }
             }
         }
-        const int t = t0 + tl;
-        if (t < a.T) {
-            const int fo = a.OS * m + a.cls[c].par;
+        __syncthreads();
+        if (tile + (int)gridDim.x < a.B * ntile) prefetch(tile + gridDim.x);
+
+        for (int nt = wv; nt < a.nclass * ntile_c; nt += 4) {
+            const int c = nt / ntile_c;
+            const int p = (nt - c * ntile_c) * 16 + (lane & 15);
+            const int tl = p / Mpos, m = p - tl * Mpos;
+            const int ksn = c ? ks1 : ks0;
+            const int fbase = c ? MT * ks0 : 0;
+            const int ntaps = a.cls[c].ntaps;
+            f32x4 acc[MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < ksn; ++ks) {
+                const int k = ks * 32 + q8;
+                int tap = k / a.Cin;
+                const int ci0 = k - tap * a.Cin;
+                if (tap >= ntaps) tap = ntaps - 1;        // zero weights there; keep the address valid
+                const int r = tl + a.halo_lo + s_tap[c][tap][0];
+                const int f = a.S * m + s_tap[c][tap][1];
+                const Frag<PREC> fb = get_frag<PREC>(xl, xplane, (size_t)(r * FinP + f + 1) * CinP + ci0);
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const int co = mt * 16 + (lane >> 4) * 4 + r4;
-                    if (co < a.Cout) {
-                        const long long idx = (((long long)b * a.T + t) * a.Cout + co) * a.Fout + fo;
-                        float v = acc[mt][r4] + (a.bias ? a.bias[co] : 0.f);
-                        if (a.accum) v += a.y[idx];
-                        else if (a.act == 1) v = sigmoid_acc(v);
-                        a.y[idx] = v;
+                for (int mt = 0; mt < MT; ++mt) {
+                    const Frag<PREC> fa = get_frag<PREC>(wl, wplane, ((size_t)(fbase + mt * ksn + ks) * 64 + lane) * 8);
+                    acc[mt] = mma(fa, fb, acc[mt]);
+                }
+            }
+            const int t = t0 + tl;
+            if (t < a.T) {
+                const int fo = a.OS * m + a.cls[c].par;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int co = mt * 16 + (lane >> 4) * 4 + r4;
+                        if (co < a.Cout) {
+                            const long long idx = (((long long)b * a.T + t) * a.Cout + co) * a.Fout + fo;
+                            float v = acc[mt][r4] + (a.bias ? a.bias[co] : 0.f);
+                            if (a.accum) v += a.y[idx];
+                            else if (a.act == 1) v = sigmoid_acc(v);
+                            a.y[idx] = v;
+                        }
                     }
                 }
             }
         }
     }
-  }
 }
 
 template <int PREC>
@@ -210,7 +278,14 @@ int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float
     a.nrows = TFM + KT - 1;
     const int ks0 = (a.cls[0].ntaps * Cin + 31) / 32, ks1 = a.nclass > 1 ? (a.cls[1].ntaps * Cin + 31) / 32 : 0;
     const int mt = Cout <= 16 ? 1 : (Cout <= 32 ? 2 : 4);
-    const size_t lds = ((size_t)mt * (ks0 + ks1) * 512 + (size_t)a.nrows * (Fin + 2) * (Cin + 4)) * sizeof(float);
+    if ((Cin * Fin) % 4 != 0 || ((uintptr_t)x % 16) != 0) return 0;
+    if ((TFM + KT - 1) * Cin * Fin > MAXV * 256 * 4) return 0;
+    size_t lds;
+    if (prec == CRUSE_PREC_F32)
+        lds = ((size_t)mt * (ks0 + ks1) * 512 + (size_t)a.nrows * (Fin + 2) * (Cin + 4)) * sizeof(float);
+    else
+        lds = ((size_t)mt * (ks0 + ks1) * 512 + (size_t)a.nrows * (Fin + 2) * (Cin + 8)) * 2 *
+              (prec == CRUSE_PREC_BF16X3 ? 2 : 1);
     if (lds > 150 * 1024) return 0;
     const int ntiles = B * ((T + TFM - 1) / TFM);
     const int grid = ntiles < 512 ? ntiles : 512;

@@ -8,7 +8,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, BKP = 36;  // BKP: 144-byte rows keep float4 alignment
+constexpr int BM = 128, BN = 128;
 
 struct GemmArgs {
     const float* A; const float* B; float* C; const float* bias;
@@ -16,22 +16,68 @@ struct GemmArgs {
     int accumulate, splitk, kchunk, shiftT, vecA, vecB;
 };
 
-// stage a [128 rows][32 k] tile of an operand whose K index is CONTIGUOUS in memory
-// (element (row, k) at p[row*ld + k]) into registers: 4 float4 per thread.
+// LDS operand storage: f32 keeps floats (BK = 32, 8 x f32 MFMA per fragment pair); bf16 / bf16x3 keep
+// 1 / 2 planes of bf16 converted once while staging (BK = 64), so a fragment is one ds_read_b128 per plane.
+template <int PREC> struct Tile {
+    typedef __bf16 elem;
+    static constexpr int BK = 64, PADK = 8, NPL = (PREC == CRUSE_PREC_BF16X3) ? 2 : 1;
+};
+template <> struct Tile<CRUSE_PREC_F32> {
+    typedef float elem;
+    static constexpr int BK = 32, PADK = 4, NPL = 1;
+};
+
+template <int PREC>
+__device__ __forceinline__ void put4(typename Tile<PREC>::elem* s, int plane, int off, const float4& v) {
+    if constexpr (PREC == CRUSE_PREC_F32) {
+        *reinterpret_cast<float4*>(s + off) = v;
+    } else {
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+        bf16x4 h;
+        h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+        *reinterpret_cast<bf16x4*>(s + off) = h;
+        if constexpr (PREC == CRUSE_PREC_BF16X3) {
+            bf16x4 l;
+            l[0] = (__bf16)(v.x - (float)h[0]); l[1] = (__bf16)(v.y - (float)h[1]);
+            l[2] = (__bf16)(v.z - (float)h[2]); l[3] = (__bf16)(v.w - (float)h[3]);
+            *reinterpret_cast<bf16x4*>(s + plane + off) = l;
+        }
+    }
+}
+
+template <int PREC>
+__device__ __forceinline__ Frag<PREC> get8(const typename Tile<PREC>::elem* s, int plane, int off) {
+    Frag<PREC> f;
+    if constexpr (PREC == CRUSE_PREC_F32) {
+        const float4 a0 = *reinterpret_cast<const float4*>(s + off);
+        const float4 a1 = *reinterpret_cast<const float4*>(s + off + 4);
+        f.v[0] = a0.x; f.v[1] = a0.y; f.v[2] = a0.z; f.v[3] = a0.w;
+        f.v[4] = a1.x; f.v[5] = a1.y; f.v[6] = a1.z; f.v[7] = a1.w;
+    } else {
+        f.h = *reinterpret_cast<const bf16x8*>(s + off);
+        if constexpr (PREC == CRUSE_PREC_BF16X3) f.l = *reinterpret_cast<const bf16x8*>(s + plane + off);
+    }
+    return f;
+}
+
+// [128 rows][BK k] tile of an operand whose K index is CONTIGUOUS (element (row,k) at p[row*ld + k]):
+// NV float4 per thread, 16 B along k.
+template <int BK, int NV>
 __device__ __forceinline__ void load_kmajor(const float* p, int ld, int row0, int nrows, int k0, int kend,
-                                            int vec, int tid, float4 (&r)[4]) {
+                                            int vec, int tid, float4 (&r)[NV]) {
+    constexpr int C4 = BK / 4;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NV; ++q) {
         const int idx = tid + 256 * q;
-        const int row = idx >> 3, c4 = idx & 7;
+        const int row = idx / C4, c4 = idx % C4;
         const int gr = row0 + row, gk = k0 + c4 * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gr < nrows) {
+        if (gr < nrows && gk < kend) {
             const float* src = p + (long long)gr * ld + gk;
             if (vec && gk + 3 < kend) {
                 v = *reinterpret_cast<const float4*>(src);
             } else {
-                if (gk + 0 < kend) v.x = src[0];
+                v.x = src[0];
                 if (gk + 1 < kend) v.y = src[1];
                 if (gk + 2 < kend) v.z = src[2];
                 if (gk + 3 < kend) v.w = src[3];
@@ -40,55 +86,82 @@ __device__ __forceinline__ void load_kmajor(const float* p, int ld, int row0, in
         r[q] = v;
     }
 }
-__device__ __forceinline__ void store_kmajor(float* s, int tid, const float4 (&r)[4]) {
+template <int PREC, int NV>
+__device__ __forceinline__ void store_kmajor(typename Tile<PREC>::elem* s, int plane, int tid, const float4 (&r)[NV]) {
+    constexpr int BK = Tile<PREC>::BK, BKP = BK + Tile<PREC>::PADK, C4 = BK / 4;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NV; ++q) {
         const int idx = tid + 256 * q;
-        const int row = idx >> 3, c4 = idx & 7;
-        *reinterpret_cast<float4*>(s + row * BKP + c4 * 4) = r[q];
+        const int row = idx / C4, c4 = idx % C4;
+        put4<PREC>(s, plane, row * BKP + c4 * 4, r[q]);
     }
 }
 
-// stage a tile of an operand whose ROW index is contiguous (element (row, k) at p[k*ld + row]):
-// each thread reads 4 consecutive k for one row (4 coalesced dword loads) and stores one float4.
-// shiftT > 0: k-row kk is read from kk-1 and is zero when kk % shiftT == 0.
+// operand whose ROW index is contiguous (element (row,k) at p[k*ld + row]): a thread owns 4x4 blocks
+// (4 rows x 4 k): four 16-byte loads along the rows (8 lanes = one 128-byte line), transposed in
+// registers, stored as four 4-k groups.  shiftT > 0: k-row kk is read from kk-1 and is zero when
+// kk % shiftT == 0 (the h_{t-1} operand of dW_hh).
+template <int BK>
+__device__ __forceinline__ void rm_block(int blk, int& rq, int& kq) {
+    constexpr int KQ = BK / 4;
+    rq = (blk & 7) + 8 * (blk / (8 * KQ));
+    kq = (blk >> 3) % KQ;
+}
+template <int BK, int NV>
 __device__ __forceinline__ void load_rowmajor(const float* p, int ld, int row0, int nrows, int k0, int kend,
-                                              int shiftT, int tid, float4 (&r)[4]) {
+                                              int shiftT, int vec, int tid, float4 (&r)[NV]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int idx = tid + 256 * q;
-        const int row = idx & 127, kq = idx >> 7;      // kq 0..7
-        const int gr = row0 + row;
-        float e[4] = {0.f, 0.f, 0.f, 0.f};
-        if (gr < nrows) {
+    for (int q = 0; q < NV / 4; ++q) {
+        int rq, kq;
+        rm_block<BK>(tid + 256 * q, rq, kq);
+        const int gr = row0 + rq * 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int gk = k0 + kq * 4 + j;
-                if (gk < kend) {
-                    if (shiftT > 0) {
-                        if (gk % shiftT == 0) continue;
-                        gk -= 1;
-                    }
-                    e[j] = p[(long long)gk * ld + gr];
+        for (int j = 0; j < 4; ++j) {
+            int gk = k0 + kq * 4 + j;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool ok = gk < kend && gr < nrows;
+            if (ok && shiftT > 0) {
+                if (gk % shiftT == 0) ok = false;
+                gk -= 1;
+            }
+            if (ok) {
+                const float* src = p + (long long)gk * ld + gr;
+                if (vec && gr + 3 < nrows) {
+                    v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    v.x = src[0];
+                    if (gr + 1 < nrows) v.y = src[1];
+                    if (gr + 2 < nrows) v.z = src[2];
+                    if (gr + 3 < nrows) v.w = src[3];
                 }
             }
+            r[q * 4 + j] = v;
         }
-        r[q] = make_float4(e[0], e[1], e[2], e[3]);
     }
 }
-__device__ __forceinline__ void store_rowmajor(float* s, int tid, const float4 (&r)[4]) {
+template <int PREC, int NV>
+__device__ __forceinline__ void store_rowmajor(typename Tile<PREC>::elem* s, int plane, int tid, const float4 (&r)[NV]) {
+    constexpr int BK = Tile<PREC>::BK, BKP = BK + Tile<PREC>::PADK;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int idx = tid + 256 * q;
-        const int row = idx & 127, kq = idx >> 7;
-        *reinterpret_cast<float4*>(s + row * BKP + kq * 4) = r[q];
+    for (int q = 0; q < NV / 4; ++q) {
+        int rq, kq;
+        rm_block<BK>(tid + 256 * q, rq, kq);
+        const float4 a = r[q * 4 + 0], b = r[q * 4 + 1], c = r[q * 4 + 2], d = r[q * 4 + 3];
+        put4<PREC>(s, plane, (rq * 4 + 0) * BKP + kq * 4, make_float4(a.x, b.x, c.x, d.x));
+        put4<PREC>(s, plane, (rq * 4 + 1) * BKP + kq * 4, make_float4(a.y, b.y, c.y, d.y));
+        put4<PREC>(s, plane, (rq * 4 + 2) * BKP + kq * 4, make_float4(a.z, b.z, c.z, d.z));
+        put4<PREC>(s, plane, (rq * 4 + 3) * BKP + kq * 4, make_float4(a.w, b.w, c.w, d.w));
     }
 }
 
 template <int PREC, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[BM * BKP];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * BKP];
+    typedef typename Tile<PREC>::elem elem;
+    constexpr int BK = Tile<PREC>::BK, BKP = BK + Tile<PREC>::PADK, NPL = Tile<PREC>::NPL;
+    constexpr int NV = BM * BK / 4 / 256;
+    constexpr int PLANE = BM * BKP;
+    __shared__ __attribute__((aligned(16))) elem As[NPL * PLANE];
+    __shared__ __attribute__((aligned(16))) elem Bs[NPL * PLANE];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv >> 1, wn = wv & 1;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -101,38 +174,33 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float4 ra[4], rb[4];
+    float4 ra[NV], rb[NV];
     auto gload = [&](int k0) {
-        if (TA) load_rowmajor(g.A, g.lda, m0, g.M, k0, kend, 0, tid, ra);
-        else load_kmajor(g.A, g.lda, m0, g.M, k0, kend, g.vecA, tid, ra);
-        if (TB) load_kmajor(g.B, g.ldb, n0, g.N, k0, kend, g.vecB, tid, rb);
-        else load_rowmajor(g.B, g.ldb, n0, g.N, k0, kend, g.shiftT, tid, rb);
+        if (TA) load_rowmajor<BK, NV>(g.A, g.lda, m0, g.M, k0, kend, 0, g.vecA, tid, ra);
+        else load_kmajor<BK, NV>(g.A, g.lda, m0, g.M, k0, kend, g.vecA, tid, ra);
+        if (TB) load_kmajor<BK, NV>(g.B, g.ldb, n0, g.N, k0, kend, g.vecB, tid, rb);
+        else load_rowmajor<BK, NV>(g.B, g.ldb, n0, g.N, k0, kend, g.shiftT, g.vecB, tid, rb);
     };
     if (kbeg < kend) gload(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        if (TA) store_rowmajor(As, tid, ra); else store_kmajor(As, tid, ra);
-        if (TB) store_kmajor(Bs, tid, rb); else store_rowmajor(Bs, tid, rb);
+        if (TA) store_rowmajor<PREC, NV>(As, PLANE, tid, ra); else store_kmajor<PREC, NV>(As, PLANE, tid, ra);
+        if (TB) store_kmajor<PREC, NV>(Bs, PLANE, tid, rb); else store_rowmajor<PREC, NV>(Bs, PLANE, tid, rb);
         __syncthreads();
         if (k0 + BK < kend) gload(k0 + BK);
-        Frag<PREC> fa[4], fb[4];
-        const int ko = (lane >> 4) * 8;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float* pa = As + (wm * 64 + i * 16 + (lane & 15)) * BKP + ko;
-            const float4 a0 = *reinterpret_cast<const float4*>(pa);
-            const float4 a1 = *reinterpret_cast<const float4*>(pa + 4);
-            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            fa[i].set(av);
-            const float* pb = Bs + (wn * 64 + i * 16 + (lane & 15)) * BKP + ko;
-            const float4 b0 = *reinterpret_cast<const float4*>(pb);
-            const float4 b1 = *reinterpret_cast<const float4*>(pb + 4);
-            const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-            fb[i].set(bv);
+        for (int kk = 0; kk < BK; kk += 32) {
+            Frag<PREC> fa[4], fb[4];
+            const int ko = kk + (lane >> 4) * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = get8<PREC>(As, PLANE, (wm * 64 + i * 16 + (lane & 15)) * BKP + ko);
+                fb[i] = get8<PREC>(Bs, PLANE, (wn * 64 + i * 16 + (lane & 15)) * BKP + ko);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mma(fa[i], fb[j], acc[i][j]);
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = mma(fa[i], fb[j], acc[i][j]);
         __syncthreads();
     }
 
@@ -178,14 +246,15 @@ extern "C" int cruse_gemm(int transA, int transB, int M, int N, int K,
                   "gemm: unknown precision %d", prec);
     CRUSE_REQUIRE(b_shift_T == 0 || !transB, CRUSE_E_SHAPE, "gemm: b_shift_T needs transB == 0");
     if (splitk < 1) splitk = 1;
+    const int BK = 64;   // multiple of both tile depths (32 for f32, 64 for bf16)
     int kchunk = ((K + splitk - 1) / splitk + BK - 1) / BK * BK;
     splitk = (K + kchunk - 1) / kchunk;
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.accumulate = accumulate; g.splitk = splitk; g.kchunk = kchunk; g.shiftT = b_shift_T;
-    g.vecA = (!transA && lda % 4 == 0 && ((uintptr_t)A % 16) == 0) ? 1 : 0;
-    g.vecB = (transB && ldb % 4 == 0 && ((uintptr_t)B % 16) == 0) ? 1 : 0;
+    g.vecA = (lda % 4 == 0 && ((uintptr_t)A % 16) == 0) ? 1 : 0;   // 16-byte loads along the contiguous index
+    g.vecB = (ldb % 4 == 0 && ((uintptr_t)B % 16) == 0) ? 1 : 0;
     dim3 grid(cdiv(M, BM), cdiv(N, BN), splitk);
     CRUSE_REQUIRE(grid.y <= 65535 && grid.z <= 65535, CRUSE_E_SHAPE, "gemm: grid too large");
     hipStream_t s = (hipStream_t)stream;
