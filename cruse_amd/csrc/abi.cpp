@@ -35,3 +35,21 @@ int cruse_ensure_dyn_lds(const void* fn, size_t bytes, const char* name) {
     done[fn] = bytes;
     return CRUSE_OK;
 }
+
+__global__ void cruse_zero_kernel(unsigned* p, size_t nwords) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+
+int cruse_zero_async(void* p, size_t bytes, hipStream_t stream, const char* name) {
+    if (bytes == 0) return CRUSE_OK;
+    const size_t nwords = (bytes + 3) / 4;
+    size_t nblk = (nwords + 1023) / 1024;
+    if (nblk > 1024) nblk = 1024;
+    hipLaunchKernelGGL(cruse_zero_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, (unsigned*)p, nwords);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        cruse_set_error("%s: zero-fill launch failed: %s", name, hipGetErrorString(e));
+        return CRUSE_E_HIP;
+    }
+    return CRUSE_OK;
+}

@@ -38,6 +38,10 @@ extern "C" void cruse_set_error(const char* fmt, ...);
 // repeated launches (and launches recorded during hipGraph capture) issue no attribute calls.
 int cruse_ensure_dyn_lds(const void* fn, size_t bytes, const char* name);
 
+// Zero `bytes` (multiple of 4) of device memory with a KERNEL node on `stream` (not hipMemsetAsync:
+// inside a captured hipGraph, memset nodes were observed to race with the neighbouring kernel nodes).
+int cruse_zero_async(void* p, size_t bytes, hipStream_t stream, const char* name);
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline long long cdivl(long long a, long long b) { return (a + b - 1) / b; }
 

@@ -466,7 +466,7 @@ extern "C" int cruse_gru_seq_fwd(const float* gi, const float* const* w_hh, cons
     Plan pl;
     CRUSE_REQUIRE(make_plan(B, G, Hg, pl) == 0, CRUSE_E_SHAPE, "gru_seq_fwd: G*Hg/32 exceeds the CU count");
     hipStream_t s = (hipStream_t)stream;
-    CRUSE_HIP(hipMemsetAsync(ws, 0, cruse_gru_ws_bytes(B, G, Hg), s), "gru_seq_fwd memset");
+    { int zrc = cruse_zero_async(ws, cruse_gru_ws_bytes(B, G, Hg), s, "gru_seq_fwd memset"); if (zrc) return zrc; }
     GruArgs a = {};
     a.gi = gi; a.h = h; a.coef = coef; a.an = an; a.z = z;
     for (int g = 0; g < G; ++g) { a.p.w_hh[g] = w_hh[g]; a.p.b_hh[g] = b_hh[g]; }
@@ -482,7 +482,7 @@ extern "C" int cruse_gru_seq_bwd(const float* dout, const float* const* w_hh, co
     Plan pl;
     CRUSE_REQUIRE(make_plan(B, G, Hg, pl) == 0, CRUSE_E_SHAPE, "gru_seq_bwd: G*Hg/32 exceeds the CU count");
     hipStream_t s = (hipStream_t)stream;
-    CRUSE_HIP(hipMemsetAsync(ws, 0, cruse_gru_ws_bytes(B, G, Hg), s), "gru_seq_bwd memset");
+    { int zrc = cruse_zero_async(ws, cruse_gru_ws_bytes(B, G, Hg), s, "gru_seq_bwd memset"); if (zrc) return zrc; }
     GruArgs a = {};
     a.dout = dout; a.coefs = coef; a.zs = z; a.dh = dh;
     for (int g = 0; g < G; ++g) { a.p.w_hh[g] = w_hh[g]; a.p.b_hh[g] = nullptr; }

@@ -345,7 +345,7 @@ inline int grid_for(long long n, int per_block, int cap = 4096) {
 
 extern "C" int cruse_bn_stats(const float* y, long long rows, int C, int F, double* sums, void* stream) {
     CRUSE_REQUIRE(rows > 0 && C > 0 && C <= 256 && F > 0, CRUSE_E_SHAPE, "bn_stats: bad shape rows=%lld C=%d F=%d", rows, C, F);
-    CRUSE_HIP(hipMemsetAsync(sums, 0, 2 * C * sizeof(double), ST(stream)), "bn_stats memset");
+    { int zrc = cruse_zero_async(sums, 2 * C * sizeof(double), ST(stream), "bn_stats memset"); if (zrc) return zrc; }
     hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(rows, 8, 1024)), dim3(256), 0, ST(stream), y, rows, C, F, sums);
     CRUSE_LAUNCH_CHECK("bn_stats");
     return CRUSE_OK;
@@ -385,7 +385,7 @@ extern "C" int cruse_bn_act_bwd_reduce(const float* dout, const float* y, const 
                                        const float* gamma, const float* beta, long long rows, int C, int F,
                                        int relu, double* sums, void* stream) {
     CRUSE_REQUIRE(rows > 0 && C > 0 && C <= 256 && F > 0, CRUSE_E_SHAPE, "bn_act_bwd_reduce: bad shape");
-    CRUSE_HIP(hipMemsetAsync(sums, 0, 2 * C * sizeof(double), ST(stream)), "bn_act_bwd_reduce memset");
+    { int zrc = cruse_zero_async(sums, 2 * C * sizeof(double), ST(stream), "bn_act_bwd_reduce memset"); if (zrc) return zrc; }
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(grid_for(rows, 8, 1024)), dim3(256), 0, ST(stream), dout, y, mean,
                        rstd, gamma, beta, rows, C, F, relu, sums);
     CRUSE_LAUNCH_CHECK("bn_act_bwd_reduce");
@@ -432,7 +432,7 @@ extern "C" int cruse_mask_loss_fwd(const float* mask, const float* nre, const fl
                                    double* loss_sum, float* dmask, float* dlogit, float* est_re, float* est_im,
                                    void* stream) {
     CRUSE_REQUIRE(rows > 0 && Fn > 0 && Fs >= Fn, CRUSE_E_SHAPE, "mask_loss: bad shape rows=%lld Fn=%d Fs=%d", rows, Fn, Fs);
-    CRUSE_HIP(hipMemsetAsync(loss_sum, 0, sizeof(double), ST(stream)), "mask_loss memset");
+    { int zrc = cruse_zero_async(loss_sum, sizeof(double), ST(stream), "mask_loss memset"); if (zrc) return zrc; }
     hipLaunchKernelGGL(mask_loss_kernel, dim3(grid_for(rows * Fs, 2048, 2048)), dim3(256), 0, ST(stream), mask, nre, nim,
                        cmag, rows, Fn, Fs, alpha, beta, loss_sum, dmask, dlogit, est_re, est_im);
     CRUSE_LAUNCH_CHECK("mask_loss");

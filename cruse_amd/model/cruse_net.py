@@ -18,9 +18,48 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
+import os
+
 from .. import ops
 
 DEFAULT_PREC = "f32"
+
+
+class _SideStream:
+    """Runs LEAF kernels (weight gradients, bias sums, skip convs) on a second HIP stream so they fill the
+    ~96 CUs the persistent GRU kernels leave idle.  Leaves only read tensors produced on the main stream and
+    write parameter gradients / tensors consumed after join(); they allocate nothing.  Tensors handed to the
+    side stream are kept alive until join().  CRUSE_OVERLAP=0 disables it."""
+
+    def __init__(self):
+        self.enabled = os.environ.get("CRUSE_OVERLAP", "1") == "1"
+        self.streams = {}
+        self.keep = []
+        self.active = False
+
+    def run(self, fn, *tensors):
+        if not self.enabled:
+            fn()
+            return
+        main = torch.cuda.current_stream()
+        dev = torch.cuda.current_device()
+        side = self.streams.get(dev)
+        if side is None:
+            side = self.streams[dev] = torch.cuda.Stream()
+        side.wait_stream(main)
+        self.keep.extend(tensors)
+        self.active = True
+        with torch.cuda.stream(side):
+            fn()
+
+    def join(self):
+        if self.enabled and self.active:
+            torch.cuda.current_stream().wait_stream(self.streams[torch.cuda.current_device()])
+            self.keep.clear()
+            self.active = False
+
+
+SIDE = _SideStream()
 
 
 def _splitk(M: int, N: int, K: int) -> int:
@@ -61,7 +100,7 @@ def ggru_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], prefix: str, group
 
 
 def ggru_backward(ctx, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor],
-                  need_dx: bool = True) -> Optional[torch.Tensor]:
+                  need_dx: bool = True, join: bool = True) -> Optional[torch.Tensor]:
     """dout [B,T,H] -> dx; parameter gradients are ACCUMULATED into G[name]."""
     B, T, H, g, prec, prefix = ctx["B"], ctx["T"], ctx["H"], ctx["g"], ctx["prec"], ctx["prefix"]
     Hg = H // g
@@ -73,19 +112,24 @@ def ggru_backward(ctx, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[s
         dgi, dgh = ops.gru_gate_grads(dh, coef, an, rows, g, Hg)
         dinp = torch.empty(B, T, H, device=dout_h.device, dtype=torch.float32) if need_dinp else None
         sk = _splitk(3 * Hg, Hg, rows)
-        for i in range(g):
-            nm = f"{prefix}{lname}.{i}."
-            # dW_hh += dgh^T h_{t-1}
-            ops.gemm(True, False, 3 * Hg, Hg, rows, dgh, i * 3 * Hg, 3 * H, h, i * Hg, H, G[nm + "weight_hh_l0"], 0, Hg,
-                     accumulate=True, splitk=sk, b_shift_T=T, prec=prec)
-            ops.col_sum(dgh, i * 3 * Hg, rows, 3 * Hg, 3 * H, G[nm + "bias_hh_l0"])
-            # dW_ih += dgi^T x
-            ops.gemm(True, False, 3 * Hg, Hg, rows, dgi, i * 3 * Hg, 3 * H, inp, i * Hg, H, G[nm + "weight_ih_l0"], 0, Hg,
-                     accumulate=True, splitk=sk, prec=prec)
-            ops.col_sum(dgi, i * 3 * Hg, rows, 3 * Hg, 3 * H, G[nm + "bias_ih_l0"])
-            if need_dinp:
-                ops.gemm(False, False, rows, Hg, 3 * Hg, dgi, i * 3 * Hg, 3 * H, P[nm + "weight_ih_l0"], 0, Hg,
-                         dinp, i * Hg, H, prec=prec)
+
+        def weight_grads():                      # leaves: overlap with the next recurrence / encoder backward
+            for i in range(g):
+                nm = f"{prefix}{lname}.{i}."
+                # dW_hh += dgh^T h_{t-1}
+                ops.gemm(True, False, 3 * Hg, Hg, rows, dgh, i * 3 * Hg, 3 * H, h, i * Hg, H, G[nm + "weight_hh_l0"], 0,
+                         Hg, accumulate=True, splitk=sk, b_shift_T=T, prec=prec)
+                ops.col_sum(dgh, i * 3 * Hg, rows, 3 * Hg, 3 * H, G[nm + "bias_hh_l0"])
+                # dW_ih += dgi^T x
+                ops.gemm(True, False, 3 * Hg, Hg, rows, dgi, i * 3 * Hg, 3 * H, inp, i * Hg, H, G[nm + "weight_ih_l0"], 0,
+                         Hg, accumulate=True, splitk=sk, prec=prec)
+                ops.col_sum(dgi, i * 3 * Hg, rows, 3 * Hg, 3 * H, G[nm + "bias_ih_l0"])
+
+        if need_dinp:
+            for i in range(g):
+                ops.gemm(False, False, rows, Hg, 3 * Hg, dgi, i * 3 * Hg, 3 * H,
+                         P[f"{prefix}{lname}.{i}.weight_ih_l0"], 0, Hg, dinp, i * Hg, H, prec=prec)
+        SIDE.run(weight_grads, dgi, dgh, h, inp)
         return dinp
 
     dh2 = ops.ln_bwd(dout, ctx["h2"], ctx["m2"], ctx["s2"], P[prefix + "ln2.weight"], rows, H, 1,
@@ -94,6 +138,8 @@ def ggru_backward(ctx, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[s
     dh1 = ops.ln_bwd(dl1, ctx["h1"], ctx["m1"], ctx["s1"], P[prefix + "ln1.weight"], rows, H, g,
                      G[prefix + "ln1.weight"], G[prefix + "ln1.bias"])
     dx = layer_bwd(dh1, "gru_list1", ctx["x"], ctx["h1"], ctx["c1"], ctx["a1"], ctx["z1"], need_dx)
+    if join:
+        SIDE.join()
     return dx
 
 
@@ -137,13 +183,21 @@ def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, tor
                             KT=2, S=2, pad=1, prec=prec)
         mean, rstd = _bn_stats(y, rows, ch[k], Fk[k], P, Bf, f"bn{k}", training, update_running)
         e = ops.bn_act_fwd(y, mean, rstd, P[f"bn{k}.weight"], P[f"bn{k}.bias"], None, rows, ch[k], Fk[k], relu=True)
-        s = ops.conv_gather(e, P[f"skip_connect_{k}.weight"], None, B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1,
-                            prec=prec)
+        s = torch.empty(B, T, ch[k], Fk[k], device=x.device, dtype=torch.float32)
+
+        def skip_conv(e=e, s=s, k=k):
+            ops.conv_gather(e, P[f"skip_connect_{k}.weight"], None, B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1,
+                            out=s, prec=prec)
+        if k < L:
+            SIDE.run(skip_conv, e, s)            # needed by the decoder only: overlaps the GRU forward
+        else:
+            skip_conv()
         ys.append(y); es.append(e); ss.append(s); stats.append((mean, rstd))
         cur = e
     H = ch[L] * Fk[L]
     u, gctx = ggru_forward(cur.view(B, T, H), P, "gru.", groups, prec, residual=ss[L].view(B, T, H), save=save)
     u = u.view(B, T, ch[L], Fk[L])
+    SIDE.join()
     us, vs, dstats = {L: u}, {}, {}
     for k in range(L, 1, -1):
         v = ops.conv_scatter2(u, P[f"conv{k}_t.weight"], P[f"conv{k}_t.bias"], B, T, ch[k], Fk[k], ch[k - 1], KT=1, pad=0,
@@ -167,8 +221,11 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
     ys, es, stats, us, vs, dstats = ctx["ys"], ctx["es"], ctx["stats"], ctx["us"], ctx["vs"], ctx["dstats"]
     # ---- decoder level 1: v1 = convT_1(u1) -------------------------------------------
     dv = dlogit
-    ops.channel_sum(dv, rows, ch[0], Fk[0], G["conv1_t.bias"])
-    ops.conv_wgrad(us[1], dv, G["conv1_t.weight"], B, T, ch[1], Fk[1], ch[0], Fk[0], KT=1, S=2, pad=0)
+
+    def leaf_dec1(dv=dv):
+        ops.channel_sum(dv, rows, ch[0], Fk[0], G["conv1_t.bias"])
+        ops.conv_wgrad(us[1], dv, G["conv1_t.weight"], B, T, ch[1], Fk[1], ch[0], Fk[0], KT=1, S=2, pad=0)
+    SIDE.run(leaf_dec1, dv)
     du = ops.conv_gather(dv, P["conv1_t.weight"], None, B, T, ch[0], Fk[0], ch[1], Fk[1], KT=1, S=2, pad=0, prec=prec)
     ds = {1: du}                                        # gradient wrt skip_{k} output = du_k
     # ---- decoder levels 2..L ------------------------------------------------------------
@@ -176,27 +233,37 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
         mean, rstd = dstats[k]
         dv = ops.bn_act_bwd(du, vs[k], mean, rstd, P[f"bn{k}_t.weight"], P[f"bn{k}_t.bias"], rows, ch[k - 1],
                             Fk[k - 1], True, training, G[f"bn{k}_t.weight"], G[f"bn{k}_t.bias"])
-        ops.channel_sum(dv, rows, ch[k - 1], Fk[k - 1], G[f"conv{k}_t.bias"])
-        ops.conv_wgrad(us[k], dv, G[f"conv{k}_t.weight"], B, T, ch[k], Fk[k], ch[k - 1], Fk[k - 1], KT=1, S=2, pad=0)
+
+        def leaf_dec(dv=dv, k=k):
+            ops.channel_sum(dv, rows, ch[k - 1], Fk[k - 1], G[f"conv{k}_t.bias"])
+            ops.conv_wgrad(us[k], dv, G[f"conv{k}_t.weight"], B, T, ch[k], Fk[k], ch[k - 1], Fk[k - 1], KT=1, S=2, pad=0)
+        SIDE.run(leaf_dec, dv)
         du = ops.conv_gather(dv, P[f"conv{k}_t.weight"], None, B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k], KT=1, S=2, pad=0,
                              prec=prec)
         ds[k] = du
     # ---- bottleneck: u_L = ggru(e_L) + skip_L --------------------------------------------
     H = ch[L] * Fk[L]
-    de = ggru_backward(ctx["gctx"], du.view(B, T, H), P, G).view(B, T, ch[L], Fk[L])
+    de = ggru_backward(ctx["gctx"], du.view(B, T, H), P, G, join=False).view(B, T, ch[L], Fk[L])
     # ---- encoder levels L..1 ----------------------------------------------------------------
     for k in range(L, 0, -1):
         # skip_k = conv1x3(e_k): de_k += W^T ds_k ; dW_skip += ds_k (*) e_k
         ops.conv_gather(ds[k], P[f"skip_connect_{k}.weight"], None, B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1,
                         w_layout=1, out=de, accum=True, prec=prec)
-        ops.conv_wgrad(ds[k], es[k], G[f"skip_connect_{k}.weight"], B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1)
+
+        def leaf_skip(k=k):
+            ops.conv_wgrad(ds[k], es[k], G[f"skip_connect_{k}.weight"], B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1)
+        SIDE.run(leaf_skip, ds[k])
         mean, rstd = stats[k]
         dy = ops.bn_act_bwd(de, ys[k], mean, rstd, P[f"bn{k}.weight"], P[f"bn{k}.bias"], rows, ch[k], Fk[k], True,
                             training, G[f"bn{k}.weight"], G[f"bn{k}.bias"])
-        ops.channel_sum(dy, rows, ch[k], Fk[k], G[f"conv{k}.bias"])
-        ops.conv_wgrad(dy, es[k - 1], G[f"conv{k}.weight"], B, T, ch[k], Fk[k], ch[k - 1], Fk[k - 1], KT=2, S=2, pad=1)
+
+        def leaf_enc(dy=dy, k=k):
+            ops.channel_sum(dy, rows, ch[k], Fk[k], G[f"conv{k}.bias"])
+            ops.conv_wgrad(dy, es[k - 1], G[f"conv{k}.weight"], B, T, ch[k], Fk[k], ch[k - 1], Fk[k - 1], KT=2, S=2, pad=1)
+        SIDE.run(leaf_enc, dy)
         if k > 1:
             de = ops.conv_scatter2(dy, P[f"conv{k}.weight"], None, B, T, ch[k], Fk[k], ch[k - 1], KT=2, pad=1, prec=prec)
+    SIDE.join()
 
 
 # ======================================================================================
