@@ -28,7 +28,7 @@ SIGNATURES = {
     "cruse_conv_gather": ("ppppiiiiiiiiiiiiip", "i"),
     "cruse_conv_scatter2": ("ppppiiiiiiiiiiip", "i"),
     "cruse_conv_wgrad_ws_bytes": ("iii", "z"),
-    "cruse_conv_wgrad": ("pppiiiiiiiiipp", "i"),
+    "cruse_conv_wgrad": ("pppiiiiiiiiiipp", "i"),
     "cruse_channel_sum": ("pqiipp", "i"),
     "cruse_col_sum": ("pqiipp", "i"),
     "cruse_bn_stats": ("pqiipp", "i"),

@@ -441,10 +441,29 @@ extern "C" size_t cruse_conv_wgrad_ws_bytes(int Ca, int Cb, int KT) {
     return (size_t)WG_MAX_BLOCKS * Ca * Cb * KT * 3 * sizeof(float);
 }
 
+int cruse_wgrad_mfma_try(const float* a, const float* bt, float* partial, int max_slabs,
+                         int B, int T, int Ca, int Fa, int Cb, int Fb, int KT, int S, int pad, int prec,
+                         int* nblk_out, hipStream_t stream);
+
 extern "C" int cruse_conv_wgrad(const float* a, const float* bt, float* dw,
                                 int B, int T, int Ca, int Fa, int Cb, int Fb,
-                                int KT, int S, int pad, void* ws, void* stream) {
+                                int KT, int S, int pad, int prec, void* ws, void* stream) {
     CRUSE_REQUIRE(B > 0 && T > 0 && Ca > 0 && Cb > 0, CRUSE_E_SHAPE, "conv_wgrad: empty shape");
+    CRUSE_REQUIRE((KT == 1 || KT == 2) && (S == 1 || S == 2) && (pad == 0 || pad == 1), CRUSE_E_SHAPE,
+                  "conv_wgrad: unsupported KT=%d S=%d pad=%d", KT, S, pad);
+    if (prec >= 0) {
+        int nblk = 0;
+        const int r = cruse_wgrad_mfma_try(a, bt, (float*)ws, WG_MAX_BLOCKS, B, T, Ca, Fa, Cb, Fb, KT, S, pad, prec, &nblk,
+                                           (hipStream_t)stream);
+        if (r < 0) return r;
+        if (r == 1) {
+            const int nout = Ca * Cb * KT * 3;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(nout, 256), cdiv(nblk, 16)), dim3(256), 0, (hipStream_t)stream,
+                               (const float*)ws, nblk, nout, dw);
+            CRUSE_LAUNCH_CHECK("conv_wgrad_reduce");
+            return CRUSE_OK;
+        }
+    }
     CRUSE_REQUIRE(Ca % 4 == 0 && (Cb % 4 == 0 || Cb == 1), CRUSE_E_SHAPE,
                   "conv_wgrad: Ca=%d must be a multiple of 4 and Cb=%d a multiple of 4 or 1", Ca, Cb);
     CRUSE_REQUIRE((KT == 1 || KT == 2) && (S == 1 || S == 2) && (pad == 0 || pad == 1), CRUSE_E_SHAPE,

@@ -120,11 +120,15 @@ def _ws(key, nbytes: int, device) -> torch.Tensor:
     return buf
 
 
-def conv_wgrad(a, bt, dw, B, T, Ca, Fa, Cb, Fb, KT, S, pad):
+WGRAD_PREC = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "valu": -1}
+
+
+def conv_wgrad(a, bt, dw, B, T, Ca, Fa, Cb, Fb, KT, S, pad, prec=None):
     """dw[ca][cb][kt][kf] += ... (dw is a contiguous f32 tensor of Ca*Cb*KT*3 elements)."""
     nbytes = lib.cruse_conv_wgrad_ws_bytes(Ca, Cb, KT)
     ws = _ws("wgrad", nbytes, a.device)
-    check(lib.cruse_conv_wgrad(_p(a), _p(bt), _p(dw), B, T, Ca, Fa, Cb, Fb, KT, S, pad, _p(ws), _stream()))
+    pc = -1 if prec is None else (WGRAD_PREC[prec] if isinstance(prec, str) else int(prec))
+    check(lib.cruse_conv_wgrad(_p(a), _p(bt), _p(dw), B, T, Ca, Fa, Cb, Fb, KT, S, pad, pc, _p(ws), _stream()))
 
 
 def channel_sum(g, rows, C, F, out):

@@ -94,11 +94,12 @@ int cruse_conv_scatter2(const float* g, const float* w, const float* bias, float
 
 /* weight gradient of either form:
  *   dw[ca][cb][kt][kf] += sum_{b,t,fa} a[b,t,ca,fa] * bt[b, t-(KT-1)+kt, cb, fa*S - pad + kf]
- * ws: scratch of cruse_conv_wgrad_ws_bytes() bytes. */
+ * ws: scratch of cruse_conv_wgrad_ws_bytes() bytes.  prec: CRUSE_PREC_* selects the MFMA kernel
+ * (patch matrix materialised in LDS); prec < 0 or an ineligible shape runs the f32 VALU kernel. */
 size_t cruse_conv_wgrad_ws_bytes(int Ca, int Cb, int KT);
 int cruse_conv_wgrad(const float* a, const float* bt, float* dw,
                      int B, int T, int Ca, int Fa, int Cb, int Fb,
-                     int KT, int S, int pad, void* ws, void* stream);
+                     int KT, int S, int pad, int prec, void* ws, void* stream);
 
 /* out[c] += sum_{rows,f} g[row,c,f]   (bias gradients; F=1 gives a column sum) */
 int cruse_channel_sum(const float* g, long long rows, int C, int F, float* out, void* stream);
