@@ -43,7 +43,7 @@ SIGNATURES = {
     "cruse_gru_ws_bytes": ("iii", "z"),
     "cruse_gru_seq_fwd": ("pppppppiiiiipp", "i"),
     "cruse_gru_seq_bwd": ("pppppiiiiipp", "i"),
-    "cruse_gru_gate_grads": ("pppppqiip", "i"),
+    "cruse_gru_gate_grads": ("pppppqiiip", "i"),
     "cruse_mask_loss_fwd": ("ppppqiiffpppppp", "i"),
     "cruse_sigmoid_bwd": ("pppqp", "i"),
     "cruse_axpby": ("pppffqp", "i"),

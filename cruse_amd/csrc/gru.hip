@@ -28,6 +28,7 @@
 //   * all workgroups of a launch must be co-resident: grid <= number of CUs
 //     (one 256-thread workgroup per CU); larger batches are split into launches.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -37,69 +38,196 @@ constexpr int CH = 10;                // 16-byte granule pairs in flight per thr
 constexpr unsigned SPIN_LIMIT = 1u << 21;
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 struct GruPtrs { const float* w_hh[MAXG]; const float* b_hh[MAXG]; };
 
 struct GruArgs {
     // forward
-    const float* gi; float* h; float* coef; float* an; float* z;
+    const float* gi; float* h; void* coef; float* an; float* z;
     // backward
-    const float* dout; const float* coefs; const float* zs; float* dh;
+    const float* dout; const void* coefs; const float* zs; float* dh;
     GruPtrs p;
     int B, T, G, Hg, Bg, nchains, P, bg_off;
     unsigned long long* xg;           // granule panels [chain][parity][Bg][Hg]
     unsigned xg_bytes;
     unsigned* status;
+    int dbg;                          // profiling only (CRUSE_GRU_DBG): 1 = do not wait for tags, 2 = also skip MFMA
 };
 
-// Sweep a team panel of granule pairs into LDS until every tag == epoch.
-//   pair e = tid + 256*i covers values (bl, v), (bl, v+1) with e = bl*(Hg/2) + v/2.
-// BWD == false: lds[bl*ld + v] = value                       (h_{t-1} panel, ld = Hg+4)
-// BWD == true : lds[bl*ld + g*Hg + v] = value * coef[g][v]   (dh_t * c_t, ld = 3Hg+4), coef rows
-//               prefetched from `cf` (+ bl*cf_row_stride) before the first poll.
-template <bool BWD>
-__device__ __forceinline__ void sweep_panel(float* lds, int ld, __amdgpu_buffer_rsrc_t rs, unsigned base_bytes,
-                                            int npair, int Hg, unsigned epoch, const float* cf,
-                                            long long cf_row_stride, unsigned* status, int tid) {
-    const int hp = Hg >> 1;
-    const int ni = (npair + 255) >> 8;
-    for (int i0 = 0; i0 < ni; i0 += CH) {
-        unsigned pend = 0;
-        float2 c[BWD ? CH : 1][3];
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const int e = tid + 256 * (i0 + j);
-            if (i0 + j < ni && e < npair) {
-                pend |= 1u << j;
-                if (BWD) {
-                    const int bl = e / hp, v = 2 * (e - bl * hp);
-                    const float* cp = cf + (long long)bl * cf_row_stride + v;
-                    c[BWD ? j : 0][0] = *reinterpret_cast<const float2*>(cp);
-                    c[BWD ? j : 0][1] = *reinterpret_cast<const float2*>(cp + Hg);
-                    c[BWD ? j : 0][2] = *reinterpret_cast<const float2*>(cp + 2 * Hg);
-                }
-            }
+// LDS panel storage per precision: f32 keeps floats; bf16 / bf16x3 keep 1 / 2 planes of bf16 converted
+// once when the granules arrive, so an MFMA B fragment is one ds_read_b128 per plane.
+template <int PREC> struct Panel {
+    typedef __bf16 elem;
+    static constexpr int NPL = (PREC == CRUSE_PREC_BF16X3) ? 2 : 1;
+    static constexpr int PAD = 8;
+};
+template <> struct Panel<CRUSE_PREC_F32> {
+    typedef float elem;
+    static constexpr int NPL = 1;
+    static constexpr int PAD = 4;
+};
+
+template <int PREC>
+__device__ __forceinline__ void panel_put2(typename Panel<PREC>::elem* base, int plane, int off, float v0, float v1) {
+    if constexpr (PREC == CRUSE_PREC_F32) {
+        *reinterpret_cast<float2*>(base + off) = make_float2(v0, v1);
+    } else {
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+        bf16x2 h;
+        h[0] = (__bf16)v0; h[1] = (__bf16)v1;
+        *reinterpret_cast<bf16x2*>(base + off) = h;
+        if constexpr (PREC == CRUSE_PREC_BF16X3) {
+            bf16x2 l;
+            l[0] = (__bf16)(v0 - (float)h[0]); l[1] = (__bf16)(v1 - (float)h[1]);
+            *reinterpret_cast<bf16x2*>(base + plane + off) = l;
         }
+    }
+}
+template <int PREC>
+__device__ __forceinline__ Frag<PREC> panel_get(const typename Panel<PREC>::elem* base, int plane, int off) {
+    Frag<PREC> f;
+    if constexpr (PREC == CRUSE_PREC_F32) {
+        const float4 a0 = *reinterpret_cast<const float4*>(base + off);
+        const float4 a1 = *reinterpret_cast<const float4*>(base + off + 4);
+        f.v[0] = a0.x; f.v[1] = a0.y; f.v[2] = a0.z; f.v[3] = a0.w;
+        f.v[4] = a1.x; f.v[5] = a1.y; f.v[6] = a1.z; f.v[7] = a1.w;
+    } else {
+        f.h = *reinterpret_cast<const bf16x8*>(base + off);
+        if constexpr (PREC == CRUSE_PREC_BF16X3) f.l = *reinterpret_cast<const bf16x8*>(base + plane + off);
+    }
+    return f;
+}
+
+// Hand-off granule formats.  f32 / bf16x3: 8-byte {epoch u32, value f32}, a 16-byte load carries 2 values.
+// bf16: 8-byte {epoch u32, 2 x bf16}, a 16-byte load carries 4 values (the recurrent MFMA rounds the
+// panel to bf16 anyway), which halves the sweep bytes.  The backward coefficient tensor is stored in the
+// matching type (f32 or bf16).
+template <int PREC> struct Gran {
+    static constexpr int VPL = 2;            // values per 16-byte load
+    static constexpr int CHN = CH;           // 16-byte loads in flight per thread and sweep batch
+    typedef float coef_t;
+    typedef float2 creg_t;                   // one gate's coefficients of one load, as held in registers
+};
+template <> struct Gran<CRUSE_PREC_BF16> {
+    static constexpr int VPL = 4;
+    static constexpr int CHN = CH / 2;
+    typedef __bf16 coef_t;
+    typedef u32x2 creg_t;                    // 4 bf16, unpacked at use
+};
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+__device__ __forceinline__ float bf16lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    bf16x2 h;
+    h[0] = (__bf16)a; h[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, h);
+}
+
+// per-thread sweep bookkeeping for load slots i = 0..CH-1 (load index e = tid + 256*i)
+template <int PREC> struct SweepIdx {
+    int loff[Gran<PREC>::CHN];        // LDS element offset bl*ld + v
+    int coff[Gran<PREC>::CHN];        // coefficient element offset bl*cf_row_stride + v (backward)
+    unsigned valid;
+};
+template <int PREC>
+__device__ __forceinline__ void make_idx(SweepIdx<PREC>& si, int nload, int Hg, int ld, long long cf_row_stride, int i0,
+                                         int tid) {
+    constexpr int VPL = Gran<PREC>::VPL, CHN = Gran<PREC>::CHN;
+    const int per = Hg / VPL;
+    si.valid = 0;
+#pragma unroll
+    for (int j = 0; j < CHN; ++j) {
+        const int e = tid + 256 * (i0 + j);
+        si.loff[j] = 0; si.coff[j] = 0;
+        if (e < nload) {
+            const int bl = e / per, v = VPL * (e - bl * per);
+            si.loff[j] = bl * ld + v;
+            si.coff[j] = (int)(bl * cf_row_stride) + v;
+            si.valid |= 1u << j;
+        }
+    }
+}
+
+// coefficient rows of the backward sweep, prefetched one step ahead (plain loads): 3 gates x VPL values
+template <int PREC> struct CoefRegs { typename Gran<PREC>::creg_t c[Gran<PREC>::CHN][3]; };
+
+template <int PREC>
+__device__ __forceinline__ void load_coefs(CoefRegs<PREC>& cr, const typename Gran<PREC>::coef_t* cf, int Hg,
+                                           const SweepIdx<PREC>& si) {
+#pragma unroll
+    for (int j = 0; j < Gran<PREC>::CHN; ++j) {
+        if (si.valid & (1u << j)) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                cr.c[j][q] = *reinterpret_cast<const typename Gran<PREC>::creg_t*>(cf + si.coff[j] + q * Hg);
+        }
+    }
+}
+
+// Sweep a team panel of granules into LDS until every tag == epoch.
+// BWD == false: lds[bl*ld + v] = value                       (h_{t-1} panel, ld = Hg+PAD)
+// BWD == true : lds[bl*ld + g*Hg + v] = value * coef[g][v]   (dh_t * c_t, ld = 3Hg+PAD); the coefficient
+//               registers of the first batch arrive preloaded in `cr0`.
+template <int PREC, bool BWD>
+__device__ __forceinline__ void sweep_panel(typename Panel<PREC>::elem* lds, int plane, int ld, __amdgpu_buffer_rsrc_t rs,
+                                            unsigned base_bytes, int nload, int Hg, unsigned epoch,
+                                            const SweepIdx<PREC>& si0, const CoefRegs<PREC>* cr0,
+                                            const typename Gran<PREC>::coef_t* cf, long long cf_row_stride,
+                                            unsigned* status, int tid, bool nowait) {
+    constexpr int VPL = Gran<PREC>::VPL, CHN = Gran<PREC>::CHN;
+    const int ni = (nload + 255) >> 8;
+    for (int i0 = 0; i0 < ni; i0 += CHN) {
+        SweepIdx<PREC> si;
+        CoefRegs<PREC> cr;
+        if (i0 == 0) {
+            si = si0;
+            if (BWD) cr = *cr0;
+        } else {
+            make_idx<PREC>(si, nload, Hg, ld, cf_row_stride, i0, tid);
+            if (BWD) load_coefs<PREC>(cr, cf, Hg, si);
+        }
+        unsigned pend = si.valid;
         unsigned spins = 0;
         for (;;) {
-            u32x4 g[CH];
+            u32x4 g[CHN];
 #pragma unroll
-            for (int j = 0; j < CH; ++j)
+            for (int j = 0; j < CHN; ++j)
                 if (pend & (1u << j))
                     g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, base_bytes + (unsigned)(tid + 256 * (i0 + j)) * 16u, 0, 16);
 #pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                if ((pend & (1u << j)) && g[j].x == epoch && g[j].z == epoch) {
-                    const int e = tid + 256 * (i0 + j);
-                    const int bl = e / hp, v = 2 * (e - bl * hp);
-                    const float v0 = __uint_as_float(g[j].y), v1 = __uint_as_float(g[j].w);
+            for (int j = 0; j < CHN; ++j) {
+                if ((pend & (1u << j)) && (nowait || (g[j].x == epoch && g[j].z == epoch))) {
+                    float val[VPL];
+                    if constexpr (PREC == CRUSE_PREC_BF16) {
+                        val[0] = bf16lo(g[j].y); val[1] = bf16hi(g[j].y); val[2] = bf16lo(g[j].w); val[3] = bf16hi(g[j].w);
+                    } else {
+                        val[0] = __uint_as_float(g[j].y); val[1] = __uint_as_float(g[j].w);
+                    }
                     if (BWD) {
 #pragma unroll
-                        for (int q = 0; q < 3; ++q)
-                            *reinterpret_cast<float2*>(lds + bl * ld + q * Hg + v) =
-                                make_float2(v0 * c[BWD ? j : 0][q].x, v1 * c[BWD ? j : 0][q].y);
+                        for (int q = 0; q < 3; ++q) {
+                            if constexpr (PREC == CRUSE_PREC_BF16) {
+                                const u32x2 cw = cr.c[j][q];
+                                u32x2 w;
+                                w.x = pack2(val[0] * bf16lo(cw.x), val[1] * bf16hi(cw.x));
+                                w.y = pack2(val[2] * bf16lo(cw.y), val[3] * bf16hi(cw.y));
+                                *reinterpret_cast<u32x2*>(lds + si.loff[j] + q * Hg) = w;
+                            } else {
+                                panel_put2<PREC>(lds, plane, si.loff[j] + q * Hg, val[0] * cr.c[j][q].x, val[1] * cr.c[j][q].y);
+                            }
+                        }
                     } else {
-                        *reinterpret_cast<float2*>(lds + bl * ld + v) = make_float2(v0, v1);
+                        if constexpr (PREC == CRUSE_PREC_BF16) {
+                            u32x2 w;
+                            w.x = g[j].y; w.y = g[j].w;           // already bf16 pairs: no conversion at all
+                            *reinterpret_cast<u32x2*>(lds + si.loff[j]) = w;
+                        } else {
+                            panel_put2<PREC>(lds, plane, si.loff[j], val[0], val[1]);
+                        }
                     }
                     pend &= ~(1u << j);
                 }
@@ -114,20 +242,39 @@ __device__ __forceinline__ void sweep_panel(float* lds, int ld, __amdgpu_buffer_
     }
 }
 
-__device__ __forceinline__ void publish_pair(__amdgpu_buffer_rsrc_t rs, unsigned off_bytes, unsigned epoch, float a, float b) {
-    const u32x4 w = {epoch, __float_as_uint(a), epoch, __float_as_uint(b)};
-    __builtin_amdgcn_raw_buffer_store_b128(w, rs, off_bytes, 0, 16);   // aux 16 = sc1 (write-through)
+// publish the own unit pair (u, u+1) of clip bl; pair_index = bl*Hg/2 + (u0+u)/2
+template <int PREC>
+__device__ __forceinline__ void publish_pair(__amdgpu_buffer_rsrc_t rs, unsigned panel_base, unsigned pair_index,
+                                             unsigned epoch, float a, float b) {
+    if constexpr (PREC == CRUSE_PREC_BF16) {
+        const u32x2 w = {epoch, pack2(a, b)};
+        __builtin_amdgcn_raw_buffer_store_b64(w, rs, panel_base + pair_index * 8u, 0, 16);    // aux 16 = sc1
+    } else {
+        const u32x4 w = {epoch, __float_as_uint(a), epoch, __float_as_uint(b)};
+        __builtin_amdgcn_raw_buffer_store_b128(w, rs, panel_base + pair_index * 16u, 0, 16);
+    }
 }
 
 // ---------------------------------------------------------------------------------
-// forward
+// forward.  Memory-queue discipline (vmcnt is in-order and counts stores): when a step's sweep waits for
+// its granule loads, the only older request still in flight is the previous step's publish store -- the gi
+// rows are loaded one step AHEAD and a step's saves are issued after the NEXT step's sweep has returned.
 // ---------------------------------------------------------------------------------
+template <int PREC>
+__device__ __forceinline__ void store_coef(void* base, long long off, float2 v) {
+    if constexpr (PREC == CRUSE_PREC_BF16) reinterpret_cast<unsigned*>(base)[off >> 1] = pack2(v.x, v.y);   // off is even
+    else *reinterpret_cast<float2*>(reinterpret_cast<float*>(base) + off) = v;
+}
+
 template <int PREC, int NKW>
 __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int Hg = a.Hg, KS = Hg >> 5, LD = Hg + 4, H = a.G * Hg;
-    float* hB = smem;                    // [16][LD]  B operand (h_{t-1}), rows >= nb stay zero
-    float* red = smem + 16 * LD;         // [4 waves][6 tiles][64 lanes][4]
+    typedef typename Panel<PREC>::elem elem;
+    constexpr int NPL = Panel<PREC>::NPL;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int Hg = a.Hg, KS = Hg >> 5, LD = Hg + Panel<PREC>::PAD, H = a.G * Hg;
+    const int PLANE = 16 * LD;
+    elem* hB = reinterpret_cast<elem*>(smem_raw);                 // [NPL][16][LD]  B operand (h_{t-1})
+    float* red = reinterpret_cast<float*>(hB + NPL * PLANE);      // [4 waves][6 tiles][64 lanes][4]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int chain = blockIdx.x % a.nchains, part = blockIdx.x / a.nchains;
     const int grp = chain % a.G, bgi = a.bg_off + chain / a.G;
@@ -136,10 +283,13 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
     const float* W = a.p.w_hh[grp];
     const float* bh = a.p.b_hh[grp];
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.xg, 0, a.xg_bytes, 0x00020000);
-    const unsigned panel_bytes = (unsigned)(a.Bg * Hg) * 8u;
+    const unsigned panel_bytes = (unsigned)(a.Bg * Hg) * (16u / Gran<PREC>::VPL);
     const unsigned cbase = (unsigned)chain * 2u * panel_bytes;
+    const int nload = nb * Hg / Gran<PREC>::VPL;
+    SweepIdx<PREC> si0;
+    make_idx<PREC>(si0, nload, Hg, LD, 0, 0, tid);
 
-    for (int i = tid; i < 16 * LD; i += 256) hB[i] = 0.f;
+    for (int i = tid; i < NPL * PLANE; i += 256) hB[i] = (elem)0.f;
 
     // resident weight fragments: tile j = gate*2 + half; this wave's k-steps ks = wv + 4*i
     Frag<PREC> wf[6][NKW];
@@ -167,35 +317,57 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
 #pragma unroll
     for (int g = 0; g < 3; ++g) { bias[g][0] = bh[g * Hg + u0 + u]; bias[g][1] = bh[g * Hg + u0 + u + 1]; }
     float hp0 = 0.f, hp1 = 0.f;
+    const long long gi_row = (long long)a.G * 3 * Hg;             // gi floats per frame
+    const float* gp = a.gi + ((long long)(b0 + bl) * a.T * a.G + grp) * 3 * Hg + u0 + u;
+    float2 gir = make_float2(0.f, 0.f), giz = gir, gin = gir;    // gi of the CURRENT step
+    if (active) {
+        gir = *reinterpret_cast<const float2*>(gp);
+        giz = *reinterpret_cast<const float2*>(gp + Hg);
+        gin = *reinterpret_cast<const float2*>(gp + 2 * Hg);
+    }
+    // deferred saves of the previous step
+    float2 sv_h, sv_cr, sv_cz, sv_cn, sv_an, sv_z;
+    sv_h = sv_cr = sv_cz = sv_cn = sv_an = sv_z = make_float2(0.f, 0.f);
     __syncthreads();
 
     for (int t = 0; t < a.T; ++t) {
-        float2 gir = make_float2(0.f, 0.f), giz = gir, gin = gir;
-        if (active) {
-            const float* gp = a.gi + (((long long)(b0 + bl) * a.T + t) * a.G + grp) * 3 * Hg + u0 + u;
-            gir = *reinterpret_cast<const float2*>(gp);
-            giz = *reinterpret_cast<const float2*>(gp + Hg);
-            gin = *reinterpret_cast<const float2*>(gp + 2 * Hg);
-        }
         float gh[3][2];
 #pragma unroll
         for (int g = 0; g < 3; ++g) { gh[g][0] = bias[g][0]; gh[g][1] = bias[g][1]; }
+        if (t > 0)
+            sweep_panel<PREC, false>(hB, PLANE, LD, rs, cbase + (unsigned)((t - 1) & 1) * panel_bytes, nload, Hg,
+                                     (unsigned)t, si0, nullptr, nullptr, 0, a.status, tid, a.dbg >= 1);
+        // (1) saves of step t-1, (2) gi rows of step t+1: both are old by the time of the next sweep
+        float2 nir = make_float2(0.f, 0.f), niz = nir, nin = nir;
+        if (active) {
+            if (t > 0) {
+                const long long o = ((long long)(b0 + bl) * a.T + (t - 1)) * H + grp * Hg + u0 + u;
+                *reinterpret_cast<float2*>(a.h + o) = sv_h;
+                if (a.coef) {
+                    const long long o3 = (((long long)(b0 + bl) * a.T + (t - 1)) * a.G + grp) * 3 * Hg + u0 + u;
+                    store_coef<PREC>(a.coef, o3, sv_cr);
+                    store_coef<PREC>(a.coef, o3 + Hg, sv_cz);
+                    store_coef<PREC>(a.coef, o3 + 2 * Hg, sv_cn);
+                    *reinterpret_cast<float2*>(a.an + o) = sv_an;
+                    *reinterpret_cast<float2*>(a.z + o) = sv_z;
+                }
+            }
+            if (t + 1 < a.T) {
+                const float* gq = gp + (long long)(t + 1) * gi_row;
+                nir = *reinterpret_cast<const float2*>(gq);
+                niz = *reinterpret_cast<const float2*>(gq + Hg);
+                nin = *reinterpret_cast<const float2*>(gq + 2 * Hg);
+            }
+        }
         if (t > 0) {
-            sweep_panel<false>(hB, LD, rs, cbase + (unsigned)((t - 1) & 1) * panel_bytes, nb * (Hg >> 1), Hg,
-                               (unsigned)t, nullptr, 0, a.status, tid);
             f32x4 acc[6];
 #pragma unroll
             for (int j = 0; j < 6; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < NKW; ++i) {
                 const int ks = wv + 4 * i;
-                if (ks < KS) {
-                    const float* pb = hB + (lane & 15) * LD + ks * 32 + (lane >> 4) * 8;
-                    const float4 b0v = *reinterpret_cast<const float4*>(pb);
-                    const float4 b1v = *reinterpret_cast<const float4*>(pb + 4);
-                    const float bv[8] = {b0v.x, b0v.y, b0v.z, b0v.w, b1v.x, b1v.y, b1v.z, b1v.w};
-                    Frag<PREC> fb;
-                    fb.set(bv);
+                if (ks < KS && a.dbg < 2) {
+                    const Frag<PREC> fb = panel_get<PREC>(hB, PLANE, (lane & 15) * LD + ks * 32 + (lane >> 4) * 8);
 #pragma unroll
                     for (int j = 0; j < 6; ++j) acc[j] = mma(wf[j][i], fb, acc[j]);
                 }
@@ -220,36 +392,49 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
             const float n0 = tanhf(gin.x + r0 * gh[2][0]), n1 = tanhf(gin.y + r1 * gh[2][1]);
             const float h0 = (1.f - z0) * n0 + z0 * hp0;
             const float h1 = (1.f - z1) * n1 + z1 * hp1;
-            publish_pair(rs, cbase + (unsigned)(t & 1) * panel_bytes + (unsigned)(bl * Hg + u0 + u) * 8u,
-                         (unsigned)(t + 1), h0, h1);
-            const long long o = ((long long)(b0 + bl) * a.T + t) * H + grp * Hg + u0 + u;
-            *reinterpret_cast<float2*>(a.h + o) = make_float2(h0, h1);
-            if (a.coef) {
-                // dgh = dh * (c_r, c_z, c_n); dgi_n = dh * a_n   (see header)
-                const float an0 = (1.f - z0) * (1.f - n0 * n0), an1 = (1.f - z1) * (1.f - n1 * n1);
-                const long long o3 = (((long long)(b0 + bl) * a.T + t) * a.G + grp) * 3 * Hg + u0 + u;
-                *reinterpret_cast<float2*>(a.coef + o3) =
-                    make_float2(an0 * gh[2][0] * r0 * (1.f - r0), an1 * gh[2][1] * r1 * (1.f - r1));
-                *reinterpret_cast<float2*>(a.coef + o3 + Hg) =
-                    make_float2((hp0 - n0) * z0 * (1.f - z0), (hp1 - n1) * z1 * (1.f - z1));
-                *reinterpret_cast<float2*>(a.coef + o3 + 2 * Hg) = make_float2(an0 * r0, an1 * r1);
-                *reinterpret_cast<float2*>(a.an + o) = make_float2(an0, an1);
-                *reinterpret_cast<float2*>(a.z + o) = make_float2(z0, z1);
-            }
+            publish_pair<PREC>(rs, cbase + (unsigned)(t & 1) * panel_bytes, (unsigned)(bl * Hg + u0 + u) >> 1,
+                               (unsigned)(t + 1), h0, h1);
+            // dgh = dh * (c_r, c_z, c_n); dgi_n = dh * a_n   (see header)
+            const float an0 = (1.f - z0) * (1.f - n0 * n0), an1 = (1.f - z1) * (1.f - n1 * n1);
+            sv_h = make_float2(h0, h1);
+            sv_cr = make_float2(an0 * gh[2][0] * r0 * (1.f - r0), an1 * gh[2][1] * r1 * (1.f - r1));
+            sv_cz = make_float2((hp0 - n0) * z0 * (1.f - z0), (hp1 - n1) * z1 * (1.f - z1));
+            sv_cn = make_float2(an0 * r0, an1 * r1);
+            sv_an = make_float2(an0, an1);
+            sv_z = make_float2(z0, z1);
             hp0 = h0; hp1 = h1;
+            gir = nir; giz = niz; gin = nin;
+        }
+    }
+    if (active) {
+        const int t = a.T - 1;
+        const long long o = ((long long)(b0 + bl) * a.T + t) * H + grp * Hg + u0 + u;
+        *reinterpret_cast<float2*>(a.h + o) = sv_h;
+        if (a.coef) {
+            const long long o3 = (((long long)(b0 + bl) * a.T + t) * a.G + grp) * 3 * Hg + u0 + u;
+            store_coef<PREC>(a.coef, o3, sv_cr);
+            store_coef<PREC>(a.coef, o3 + Hg, sv_cz);
+            store_coef<PREC>(a.coef, o3 + 2 * Hg, sv_cn);
+            *reinterpret_cast<float2*>(a.an + o) = sv_an;
+            *reinterpret_cast<float2*>(a.z + o) = sv_z;
         }
     }
 }
 
 // ---------------------------------------------------------------------------------
 // backward: dh_s = dout_s + z_{s+1} * dh_{s+1} + (dh_{s+1} * c_{s+1}) W_hh
+// Same queue discipline: dout/z rows and the coefficient panel of the NEXT step are requested right
+// after this step's sweep has returned; the dh save is deferred by one step.
 // ---------------------------------------------------------------------------------
 template <int PREC, int NKW>
 __global__ __launch_bounds__(256) void gru_bwd_kernel(GruArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int Hg = a.Hg, K = 3 * Hg, KS = K >> 5, LD = K + 4, H = a.G * Hg;
-    float* dB = smem;                    // [16][LD]  B operand (dh_{s+1} * c_{s+1})
-    float* red = smem + 16 * LD;         // [4 waves][2 tiles][64][4]
+    typedef typename Panel<PREC>::elem elem;
+    constexpr int NPL = Panel<PREC>::NPL;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int Hg = a.Hg, K = 3 * Hg, KS = K >> 5, LD = K + Panel<PREC>::PAD, H = a.G * Hg;
+    const int PLANE = 16 * LD;
+    elem* dB = reinterpret_cast<elem*>(smem_raw);                 // [NPL][16][LD]  B operand (dh_{s+1} * c_{s+1})
+    float* red = reinterpret_cast<float*>(dB + NPL * PLANE);      // [4 waves][2 tiles][64][4]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int chain = blockIdx.x % a.nchains, part = blockIdx.x / a.nchains;
     const int grp = chain % a.G, bgi = a.bg_off + chain / a.G;
@@ -257,10 +442,12 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruArgs a) {
     const int u0 = part * U;
     const float* W = a.p.w_hh[grp];
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.xg, 0, a.xg_bytes, 0x00020000);
-    const unsigned panel_bytes = (unsigned)(a.Bg * Hg) * 8u;
+    typedef typename Gran<PREC>::coef_t coef_t;
+    const unsigned panel_bytes = (unsigned)(a.Bg * Hg) * (16u / Gran<PREC>::VPL);
     const unsigned cbase = (unsigned)chain * 2u * panel_bytes;
+    const int nload = nb * Hg / Gran<PREC>::VPL;
 
-    for (int i = tid; i < 16 * LD; i += 256) dB[i] = 0.f;
+    for (int i = tid; i < NPL * PLANE; i += 256) dB[i] = (elem)0.f;
 
     // A operand = W_hh^T slice: A[row = unit][k = gate row j] = W_hh[j][unit]
     Frag<PREC> wf[2][NKW];
@@ -284,34 +471,43 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruArgs a) {
     const int half = u >> 4, ru = u & 15;
     const int lp = (ru >> 2) * 16 + bl;
     float dh0 = 0.f, dh1 = 0.f;          // dh_{s+1} of the own units
+    const long long own = (long long)(b0 + bl) * a.T * H + grp * Hg + u0 + u;     // + s*H
+    const long long cf_row = (long long)a.T * a.G * K;
+    const coef_t* cf_base = reinterpret_cast<const coef_t*>(a.coefs) + ((long long)b0 * a.T * a.G + grp) * K;   // + s*G*K
+    SweepIdx<PREC> si0;
+    make_idx<PREC>(si0, nload, Hg, LD, cf_row, 0, tid);
+    // operands of the CURRENT step k (time s = T-1-k): dout_s, z_{s+1}, coefficient panel c_{s+1}
+    float2 dd = make_float2(0.f, 0.f), zz = dd;
+    CoefRegs<PREC> cr;
+    if (active) dd = *reinterpret_cast<const float2*>(a.dout + own + (long long)(a.T - 1) * H);
+    float2 sv_dh = make_float2(0.f, 0.f);
     __syncthreads();
 
     for (int k = 0; k < a.T; ++k) {
         const int s = a.T - 1 - k;
-        float2 dd = make_float2(0.f, 0.f), zz = dd;
-        const long long o = ((long long)(b0 + bl) * a.T + s) * H + grp * Hg + u0 + u;
-        if (active) {
-            dd = *reinterpret_cast<const float2*>(a.dout + o);
-            if (k > 0) zz = *reinterpret_cast<const float2*>(a.zs + o + H);
+        if (k > 0)
+            sweep_panel<PREC, true>(dB, PLANE, LD, rs, cbase + (unsigned)((k - 1) & 1) * panel_bytes, nload, Hg, (unsigned)k,
+                                    si0, &cr, cf_base + (long long)(s + 1) * a.G * K, cf_row, a.status, tid, a.dbg >= 1);
+        // deferred save of dh_{s+1}; operands of step k+1 (time s-1): dout_{s-1}, z_s, c_s
+        float2 ndd = make_float2(0.f, 0.f), nzz = ndd;
+        if (active && k > 0) *reinterpret_cast<float2*>(a.dh + own + (long long)(s + 1) * H) = sv_dh;
+        if (s > 0) {
+            if (active) {
+                ndd = *reinterpret_cast<const float2*>(a.dout + own + (long long)(s - 1) * H);
+                nzz = *reinterpret_cast<const float2*>(a.zs + own + (long long)s * H);
+            }
+            load_coefs<PREC>(cr, cf_base + (long long)s * a.G * K, Hg, si0);
         }
         float mm0 = 0.f, mm1 = 0.f;
         if (k > 0) {
-            const float* cf = a.coefs + (((long long)b0 * a.T + (s + 1)) * a.G + grp) * K;
-            sweep_panel<true>(dB, LD, rs, cbase + (unsigned)((k - 1) & 1) * panel_bytes, nb * (Hg >> 1), Hg,
-                              (unsigned)k, cf, (long long)a.T * a.G * K, a.status, tid);
             f32x4 acc[2];
             acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
             acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < NKW; ++i) {
                 const int ks = wv + 4 * i;
-                if (ks < KS) {
-                    const float* pb = dB + (lane & 15) * LD + ks * 32 + (lane >> 4) * 8;
-                    const float4 b0v = *reinterpret_cast<const float4*>(pb);
-                    const float4 b1v = *reinterpret_cast<const float4*>(pb + 4);
-                    const float bv[8] = {b0v.x, b0v.y, b0v.z, b0v.w, b1v.x, b1v.y, b1v.z, b1v.w};
-                    Frag<PREC> fb;
-                    fb.set(bv);
+                if (ks < KS && a.dbg < 2) {
+                    const Frag<PREC> fb = panel_get<PREC>(dB, PLANE, (lane & 15) * LD + ks * 32 + (lane >> 4) * 8);
                     acc[0] = mma(wf[0][i], fb, acc[0]);
                     acc[1] = mma(wf[1][i], fb, acc[1]);
                 }
@@ -330,15 +526,18 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruArgs a) {
         if (active) {
             dh0 = dd.x + zz.x * dh0 + mm0;
             dh1 = dd.y + zz.y * dh1 + mm1;
-            publish_pair(rs, cbase + (unsigned)(k & 1) * panel_bytes + (unsigned)(bl * Hg + u0 + u) * 8u,
-                         (unsigned)(k + 1), dh0, dh1);
-            *reinterpret_cast<float2*>(a.dh + o) = make_float2(dh0, dh1);
+            publish_pair<PREC>(rs, cbase + (unsigned)(k & 1) * panel_bytes, (unsigned)(bl * Hg + u0 + u) >> 1,
+                               (unsigned)(k + 1), dh0, dh1);
+            sv_dh = make_float2(dh0, dh1);
+            dd = ndd; zz = nzz;
         }
     }
+    if (active) *reinterpret_cast<float2*>(a.dh + own) = sv_dh;          // s = 0
 }
 
 // dgi = dh * (c_r, c_z, a_n), dgh = dh * (c_r, c_z, c_n); layouts [rows][G][3][Hg]
-__global__ __launch_bounds__(256) void gru_gate_grads_kernel(const float* dh, const float* coef, const float* an,
+template <typename CT>
+__global__ __launch_bounds__(256) void gru_gate_grads_kernel(const float* dh, const CT* coef, const float* an,
                                                              float* dgi, float* dgh, long long rows, int G, int Hg) {
     const int H = G * Hg;
     const long long n = rows * H;
@@ -348,7 +547,7 @@ __global__ __launch_bounds__(256) void gru_gate_grads_kernel(const float* dh, co
         const int g = c / Hg, j = c - g * Hg;
         const float d = dh[i];
         const long long o3 = (row * G + g) * 3 * Hg + j;
-        const float cr = coef[o3], cz = coef[o3 + Hg], cn = coef[o3 + 2 * Hg];
+        const float cr = (float)coef[o3], cz = (float)coef[o3 + Hg], cn = (float)coef[o3 + 2 * Hg];
         dgi[o3] = d * cr; dgi[o3 + Hg] = d * cz; dgi[o3 + 2 * Hg] = d * an[i];
         dgh[o3] = d * cr; dgh[o3 + Hg] = d * cz; dgh[o3 + 2 * Hg] = d * cn;
     }
@@ -426,6 +625,7 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* ws, 
     a.xg = (unsigned long long*)((char*)ws + 256);
     a.xg_bytes = (unsigned)xg_bytes_total(a.B, G, Hg);
     a.Bg = pl.Bg; a.P = pl.P;
+    { const char* e = getenv("CRUSE_GRU_DBG"); a.dbg = e ? atoi(e) : 0; }
     int rc = CRUSE_OK;
     for (int L = 0; L < pl.nlaunch; ++L) {
         const int bg_off = L * pl.bg_per_launch;
@@ -457,7 +657,7 @@ extern "C" size_t cruse_gru_ws_bytes(int B, int G, int Hg) {
 }
 
 extern "C" int cruse_gru_seq_fwd(const float* gi, const float* const* w_hh, const float* const* b_hh,
-                                 float* h, float* coef, float* an, float* z,
+                                 float* h, void* coef, float* an, float* z,
                                  int B, int T, int G, int Hg, int prec, void* ws, void* stream) {
     int rc = check_common(B, T, G, Hg, prec, "gru_seq_fwd");
     if (rc) return rc;
@@ -471,11 +671,12 @@ extern "C" int cruse_gru_seq_fwd(const float* gi, const float* const* w_hh, cons
     a.gi = gi; a.h = h; a.coef = coef; a.an = an; a.z = z;
     for (int g = 0; g < G; ++g) { a.p.w_hh[g] = w_hh[g]; a.p.b_hh[g] = b_hh[g]; }
     a.B = B; a.T = T; a.G = G; a.Hg = Hg;
-    const size_t lds = ((size_t)16 * (Hg + 4) + 4 * 6 * 64 * 4) * sizeof(float);
+    const size_t esz = prec == CRUSE_PREC_F32 ? 4 : 2, npl = prec == CRUSE_PREC_BF16X3 ? 2 : 1;
+    const size_t lds = (size_t)16 * (Hg + (prec == CRUSE_PREC_F32 ? 4 : 8)) * esz * npl + 4 * 6 * 64 * 4 * sizeof(float);
     return run_launches<true>(a, pl, G, Hg, prec, ws, lds, s);
 }
 
-extern "C" int cruse_gru_seq_bwd(const float* dout, const float* const* w_hh, const float* coef, const float* z,
+extern "C" int cruse_gru_seq_bwd(const float* dout, const float* const* w_hh, const void* coef, const float* z,
                                  float* dh, int B, int T, int G, int Hg, int prec, void* ws, void* stream) {
     int rc = check_common(B, T, G, Hg, prec, "gru_seq_bwd");
     if (rc) return rc;
@@ -487,18 +688,23 @@ extern "C" int cruse_gru_seq_bwd(const float* dout, const float* const* w_hh, co
     a.dout = dout; a.coefs = coef; a.zs = z; a.dh = dh;
     for (int g = 0; g < G; ++g) { a.p.w_hh[g] = w_hh[g]; a.p.b_hh[g] = nullptr; }
     a.B = B; a.T = T; a.G = G; a.Hg = Hg;
-    const size_t lds = ((size_t)16 * (3 * Hg + 4) + 4 * 2 * 64 * 4) * sizeof(float);
+    const size_t esz = prec == CRUSE_PREC_F32 ? 4 : 2, npl = prec == CRUSE_PREC_BF16X3 ? 2 : 1;
+    const size_t lds = (size_t)16 * (3 * Hg + (prec == CRUSE_PREC_F32 ? 4 : 8)) * esz * npl + 4 * 2 * 64 * 4 * sizeof(float);
     CRUSE_REQUIRE(lds <= 160 * 1024, CRUSE_E_SHAPE, "gru_seq_bwd: Hg=%d needs %zu B of LDS", Hg, lds);
     return run_launches<false>(a, pl, G, Hg, prec, ws, lds, s);
 }
 
-extern "C" int cruse_gru_gate_grads(const float* dh, const float* coef, const float* an, float* dgi, float* dgh,
-                                    long long rows, int G, int Hg, void* stream) {
+extern "C" int cruse_gru_gate_grads(const float* dh, const void* coef, const float* an, float* dgi, float* dgh,
+                                    long long rows, int G, int Hg, int prec, void* stream) {
     CRUSE_REQUIRE(rows > 0 && G > 0 && Hg > 0, CRUSE_E_SHAPE, "gru_gate_grads: bad shape");
     long long nblk = (rows * G * Hg + 1023) / 1024;
     if (nblk > 4096) nblk = 4096;
-    hipLaunchKernelGGL(gru_gate_grads_kernel, dim3((int)nblk), dim3(256), 0, (hipStream_t)stream, dh, coef, an, dgi, dgh,
-                       rows, G, Hg);
+    if (prec == CRUSE_PREC_BF16)
+        hipLaunchKernelGGL(gru_gate_grads_kernel<__bf16>, dim3((int)nblk), dim3(256), 0, (hipStream_t)stream, dh,
+                           (const __bf16*)coef, an, dgi, dgh, rows, G, Hg);
+    else
+        hipLaunchKernelGGL(gru_gate_grads_kernel<float>, dim3((int)nblk), dim3(256), 0, (hipStream_t)stream, dh,
+                           (const float*)coef, an, dgi, dgh, rows, G, Hg);
     CRUSE_LAUNCH_CHECK("gru_gate_grads");
     return CRUSE_OK;
 }

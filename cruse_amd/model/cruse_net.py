@@ -109,7 +109,7 @@ def ggru_backward(ctx, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[s
     def layer_bwd(dout_h, lname, inp, h, coef, an, z, need_dinp):
         w_hh = [P[f"{prefix}{lname}.{i}.weight_hh_l0"] for i in range(g)]
         dh = ops.gru_seq_bwd(dout_h, w_hh, coef, z, B, T, g, Hg, prec)
-        dgi, dgh = ops.gru_gate_grads(dh, coef, an, rows, g, Hg)
+        dgi, dgh = ops.gru_gate_grads(dh, coef, an, rows, g, Hg, prec)
         dinp = torch.empty(B, T, H, device=dout_h.device, dtype=torch.float32) if need_dinp else None
         sk = _splitk(3 * Hg, Hg, rows)
 

@@ -222,7 +222,8 @@ def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G,
     H = G * Hg
     h = torch.empty(B, T, H, device=dev, dtype=torch.float32)
     if save:
-        coef = torch.empty(B, T, 3 * H, device=dev, dtype=torch.float32)
+        cdt = torch.bfloat16 if prec_code(prec) == PREC_BF16 else torch.float32
+        coef = torch.empty(B, T, 3 * H, device=dev, dtype=cdt)
         an = torch.empty_like(h); z = torch.empty_like(h)
     else:
         coef = an = z = None
@@ -243,10 +244,12 @@ def gru_seq_bwd(dout, w_hh: List[torch.Tensor], coef, z, B, T, G, Hg, prec):
     return dh
 
 
-def gru_gate_grads(dh, coef, an, rows, G, Hg):
-    dgi = torch.empty_like(coef)
-    dgh = torch.empty_like(coef)
-    check(lib.cruse_gru_gate_grads(_p(dh), _p(coef), _p(an), _p(dgi), _p(dgh), rows, G, Hg, _stream()))
+def gru_gate_grads(dh, coef, an, rows, G, Hg, prec):
+    if (coef.dtype == torch.bfloat16) != (prec_code(prec) == PREC_BF16):
+        raise RuntimeError("gru_gate_grads: coef dtype does not match the precision mode")
+    dgi = torch.empty(coef.shape, device=coef.device, dtype=torch.float32)
+    dgh = torch.empty_like(dgi)
+    check(lib.cruse_gru_gate_grads(_p(dh), _p(coef), _p(an), _p(dgi), _p(dgh), rows, G, Hg, prec_code(prec), _stream()))
     return dgi, dgh
 
 

@@ -159,22 +159,23 @@ int cruse_gemm(int transA, int transB, int M, int N, int K,
 /* Persistent recurrence.  gi [B,T,G,3*Hg] = x W_ih^T + b_ih (gate order r,z,n) from cruse_gemm;
  * w_hh[g] -> [3*Hg,Hg], b_hh[g] -> [3*Hg] (HOST arrays of G device pointers); h0 = 0.
  * Output h [B,T,G*Hg] in "cat" layout (feature = g*Hg + j).  For backward (all three or none):
- *   coef [B,T,G,3*Hg] = d(W_hh h + b_hh)-gradient coefficients (c_r, c_z, c_n): dgh_t = dh_t * coef_t,
+ *   coef [B,T,G,3*Hg] = d(W_hh h + b_hh)-gradient coefficients (c_r, c_z, c_n): dgh_t = dh_t * coef_t
+ *                       (bf16 elements when prec == CRUSE_PREC_BF16, f32 otherwise),
  *   an   [B,T,G*Hg]   = dgi_n coefficient ((1-z)(1-n^2)),   z [B,T,G*Hg] = update gate.
  * Hg % 32 == 0, Hg <= 1024.  ws: cruse_gru_ws_bytes() bytes of device scratch (status word +
  * hand-off panels; zeroed by the callee; word 0 becomes non-zero if a hand-off ever timed out). */
 size_t cruse_gru_ws_bytes(int B, int G, int Hg);
 int cruse_gru_seq_fwd(const float* gi, const float* const* w_hh, const float* const* b_hh,
-                      float* h, float* coef, float* an, float* z,
+                      float* h, void* coef, float* an, float* z,
                       int B, int T, int G, int Hg, int prec, void* ws, void* stream);
 /* dout = dL/dh [B,T,G*Hg] -> dh [B,T,G*Hg] = total gradient reaching h_t (incl. the recurrent path):
  * dh_s = dout_s + z_{s+1}*dh_{s+1} + (dh_{s+1}*coef_{s+1}) W_hh. */
-int cruse_gru_seq_bwd(const float* dout, const float* const* w_hh, const float* coef, const float* z,
+int cruse_gru_seq_bwd(const float* dout, const float* const* w_hh, const void* coef, const float* z,
                       float* dh, int B, int T, int G, int Hg, int prec, void* ws, void* stream);
 /* dgi = dh*(c_r,c_z,a_n) (gradient wrt gi), dgh = dh*(c_r,c_z,c_n) (gradient wrt W_hh h + b_hh), both
  * [rows,G,3*Hg]; dW_ih, dW_hh, dX and the bias gradients follow from cruse_gemm / cruse_col_sum. */
-int cruse_gru_gate_grads(const float* dh, const float* coef, const float* an, float* dgi, float* dgh,
-                         long long rows, int G, int Hg, void* stream);
+int cruse_gru_gate_grads(const float* dh, const void* coef, const float* an, float* dgi, float* dgh,
+                         long long rows, int G, int Hg, int prec, void* stream);
 
 /* ---- mask application + weighted spectral loss ------------------------------- */
 

@@ -319,7 +319,7 @@ def test_gru_sequence_fwd_bwd(ops, H, g, B, T, prec, tol):
     dout = torch.randn(B, T, H)
     y_ref.backward(dout)
     dh = ops.gru_seq_bwd(dout.cuda(), w_hh, coef, z, B, T, g, Hg, prec)
-    dgi, dgh = ops.gru_gate_grads(dh, coef, an, rows, g, Hg)
+    dgi, dgh = ops.gru_gate_grads(dh, coef, an, rows, g, Hg, prec)
     torch.cuda.synchronize()
     assert ops.gru_status() == 0
     for i, m in enumerate(grus):
