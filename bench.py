@@ -157,10 +157,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    local = local % torch.cuda.device_count()         # (test rigs may oversubscribe one GPU)
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("CRUSE_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     dev = torch.device("cuda", local)
 
     from cruse_amd import ops

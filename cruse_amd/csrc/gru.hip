@@ -173,13 +173,14 @@ __device__ __forceinline__ void load_coefs(CoefRegs<PREC>& cr, const typename Gr
 // BWD == true : lds[bl*ld + g*Hg + v] = value * coef[g][v]   (dh_t * c_t, ld = 3Hg+PAD); the coefficient
 //               registers of the first batch arrive preloaded in `cr0`.
 template <int PREC, bool BWD>
-__device__ __forceinline__ void sweep_panel(typename Panel<PREC>::elem* lds, int plane, int ld, __amdgpu_buffer_rsrc_t rs,
+__device__ __forceinline__ bool sweep_panel(typename Panel<PREC>::elem* lds, int plane, int ld, __amdgpu_buffer_rsrc_t rs,
                                             unsigned base_bytes, int nload, int Hg, unsigned epoch,
                                             const SweepIdx<PREC>& si0, const CoefRegs<PREC>* cr0,
                                             const typename Gran<PREC>::coef_t* cf, long long cf_row_stride,
                                             unsigned* status, int tid, bool nowait) {
     constexpr int VPL = Gran<PREC>::VPL, CHN = Gran<PREC>::CHN;
     const int ni = (nload + 255) >> 8;
+    bool timed_out = false;
     for (int i0 = 0; i0 < ni; i0 += CHN) {
         SweepIdx<PREC> si;
         CoefRegs<PREC> cr;
@@ -233,13 +234,15 @@ __device__ __forceinline__ void sweep_panel(typename Panel<PREC>::elem* lds, int
                 }
             }
             if (__syncthreads_and(pend == 0)) break;
-            if (++spins >= SPIN_LIMIT) {
+            if (++spins >= SPIN_LIMIT) {     // give up: flag it and let the caller run the remaining steps unsynchronised
                 if (tid == 0) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
+                timed_out = true;
+                nowait = true;
             }
             __builtin_amdgcn_s_sleep(1);
         }
     }
+    return timed_out;
 }
 
 // publish the own unit pair (u, u+1) of clip bl; pair_index = bl*Hg/2 + (u0+u)/2
@@ -326,6 +329,7 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
         gin = *reinterpret_cast<const float2*>(gp + 2 * Hg);
     }
     // deferred saves of the previous step
+    bool aborted = a.dbg >= 1;
     float2 sv_h, sv_cr, sv_cz, sv_cn, sv_an, sv_z;
     sv_h = sv_cr = sv_cz = sv_cn = sv_an = sv_z = make_float2(0.f, 0.f);
     __syncthreads();
@@ -335,8 +339,8 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
 #pragma unroll
         for (int g = 0; g < 3; ++g) { gh[g][0] = bias[g][0]; gh[g][1] = bias[g][1]; }
         if (t > 0)
-            sweep_panel<PREC, false>(hB, PLANE, LD, rs, cbase + (unsigned)((t - 1) & 1) * panel_bytes, nload, Hg,
-                                     (unsigned)t, si0, nullptr, nullptr, 0, a.status, tid, a.dbg >= 1);
+            aborted |= sweep_panel<PREC, false>(hB, PLANE, LD, rs, cbase + (unsigned)((t - 1) & 1) * panel_bytes, nload, Hg,
+                                                (unsigned)t, si0, nullptr, nullptr, 0, a.status, tid, aborted);
         // (1) saves of step t-1, (2) gi rows of step t+1: both are old by the time of the next sweep
         float2 nir = make_float2(0.f, 0.f), niz = nir, nin = nir;
         if (active) {
@@ -481,13 +485,15 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruArgs a) {
     CoefRegs<PREC> cr;
     if (active) dd = *reinterpret_cast<const float2*>(a.dout + own + (long long)(a.T - 1) * H);
     float2 sv_dh = make_float2(0.f, 0.f);
+    bool aborted = a.dbg >= 1;
     __syncthreads();
 
     for (int k = 0; k < a.T; ++k) {
         const int s = a.T - 1 - k;
         if (k > 0)
-            sweep_panel<PREC, true>(dB, PLANE, LD, rs, cbase + (unsigned)((k - 1) & 1) * panel_bytes, nload, Hg, (unsigned)k,
-                                    si0, &cr, cf_base + (long long)(s + 1) * a.G * K, cf_row, a.status, tid, a.dbg >= 1);
+            aborted |= sweep_panel<PREC, true>(dB, PLANE, LD, rs, cbase + (unsigned)((k - 1) & 1) * panel_bytes, nload, Hg,
+                                               (unsigned)k, si0, &cr, cf_base + (long long)(s + 1) * a.G * K, cf_row,
+                                               a.status, tid, aborted);
         // deferred save of dh_{s+1}; operands of step k+1 (time s-1): dout_{s-1}, z_s, c_s
         float2 ndd = make_float2(0.f, 0.f), nzz = ndd;
         if (active && k > 0) *reinterpret_cast<float2*>(a.dh + own + (long long)(s + 1) * H) = sv_dh;
