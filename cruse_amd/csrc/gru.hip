@@ -49,6 +49,7 @@ struct GruArgs {
     const float* dout; const void* coefs; const float* zs; float* dh;
     GruPtrs p;
     int B, T, G, Hg, Bg, nchains, P, bg_off;
+    unsigned long long* xid;          // XCD-id handshake granules [chain][64]
     unsigned long long* xg;           // granule panels [chain][parity][Bg][Hg]
     unsigned xg_bytes;
     unsigned* status;
@@ -245,16 +246,46 @@ __device__ __forceinline__ bool sweep_panel(typename Panel<PREC>::elem* lds, int
     return timed_out;
 }
 
+// One-time team handshake: every workgroup publishes the id of the XCD it runs on (write-through), reads
+// its P team mates' ids, and all reach the same verdict.  If the whole team shares one XCD its L2 is a
+// common coherence point: the step payload can then be published with PLAIN stores (the line stays in that
+// L2, consumers read it with L1-bypassing sc1 loads) instead of write-through stores -- ~0.5 us per step
+// faster.  Any other placement keeps the write-through form; correctness never depends on placement.
+__device__ __forceinline__ bool team_shares_xcd(unsigned long long* slots, int P, int part, unsigned* status, int tid) {
+    __shared__ int s_same;
+    const unsigned my = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xf;      // HW_REG_XCC_ID
+    constexpr unsigned MAGIC = 0xC0DE0001u;
+    if (tid == 0)
+        __hip_atomic_store(slots + part, ((unsigned long long)my << 32) | MAGIC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 64) {
+        bool ok = false, same = true;
+        for (unsigned spins = 0; spins < SPIN_LIMIT; ++spins) {
+            unsigned long long v = ((unsigned long long)my << 32) | MAGIC;
+            if (tid < P) v = __hip_atomic_load(slots + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((unsigned)v == MAGIC)) { ok = true; same = __all((unsigned)(v >> 32) == my); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (tid == 0) {
+            s_same = (ok && same) ? 1 : 0;
+            if (!ok) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    return s_same != 0;
+}
+
 // publish the own unit pair (u, u+1) of clip bl; pair_index = bl*Hg/2 + (u0+u)/2
 template <int PREC>
 __device__ __forceinline__ void publish_pair(__amdgpu_buffer_rsrc_t rs, unsigned panel_base, unsigned pair_index,
-                                             unsigned epoch, float a, float b) {
+                                             unsigned epoch, float a, float b, bool plain = false) {
     if constexpr (PREC == CRUSE_PREC_BF16) {
         const u32x2 w = {epoch, pack2(a, b)};
-        __builtin_amdgcn_raw_buffer_store_b64(w, rs, panel_base + pair_index * 8u, 0, 16);    // aux 16 = sc1
+        if (plain) __builtin_amdgcn_raw_buffer_store_b64(w, rs, panel_base + pair_index * 8u, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b64(w, rs, panel_base + pair_index * 8u, 0, 16);    // aux 16 = sc1
     } else {
         const u32x4 w = {epoch, __float_as_uint(a), epoch, __float_as_uint(b)};
-        __builtin_amdgcn_raw_buffer_store_b128(w, rs, panel_base + pair_index * 16u, 0, 16);
+        if (plain) __builtin_amdgcn_raw_buffer_store_b128(w, rs, panel_base + pair_index * 16u, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b128(w, rs, panel_base + pair_index * 16u, 0, 16);
     }
 }
 
@@ -279,7 +310,11 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
     elem* hB = reinterpret_cast<elem*>(smem_raw);                 // [NPL][16][LD]  B operand (h_{t-1})
     float* red = reinterpret_cast<float*>(hB + NPL * PLANE);      // [4 waves][6 tiles][64 lanes][4]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int chain = blockIdx.x % a.nchains, part = blockIdx.x / a.nchains;
+    // block id -> (chain, part) with chain % 8 == id % 8: under the observed id%8 -> XCD dispatch a whole
+    // team lands on one XCD for ANY number of chains (speed only; see team_shares_xcd)
+    const int chain = (int)(blockIdx.x / (8 * a.P)) * 8 + (int)(blockIdx.x & 7);
+    const int part = (int)((blockIdx.x >> 3) % a.P);
+    if (chain >= a.nchains) return;
     const int grp = chain % a.G, bgi = a.bg_off + chain / a.G;
     const int b0 = bgi * a.Bg, nb = min(a.Bg, a.B - b0);
     const int u0 = part * U;
@@ -329,7 +364,8 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
         gin = *reinterpret_cast<const float2*>(gp + 2 * Hg);
     }
     // deferred saves of the previous step
-    bool aborted = a.dbg >= 1;
+    bool aborted = a.dbg >= 1 && a.dbg < 8;
+    const bool plain = a.dbg != 9 && team_shares_xcd(a.xid + (size_t)chain * 64, a.P, part, a.status, tid);
     float2 sv_h, sv_cr, sv_cz, sv_cn, sv_an, sv_z;
     sv_h = sv_cr = sv_cz = sv_cn = sv_an = sv_z = make_float2(0.f, 0.f);
     __syncthreads();
@@ -370,7 +406,7 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
 #pragma unroll
             for (int i = 0; i < NKW; ++i) {
                 const int ks = wv + 4 * i;
-                if (ks < KS && a.dbg < 2) {
+                if (ks < KS && (a.dbg < 2 || a.dbg == 8)) {
                     const Frag<PREC> fb = panel_get<PREC>(hB, PLANE, (lane & 15) * LD + ks * 32 + (lane >> 4) * 8);
 #pragma unroll
                     for (int j = 0; j < 6; ++j) acc[j] = mma(wf[j][i], fb, acc[j]);
@@ -397,7 +433,7 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
             const float h0 = (1.f - z0) * n0 + z0 * hp0;
             const float h1 = (1.f - z1) * n1 + z1 * hp1;
             publish_pair<PREC>(rs, cbase + (unsigned)(t & 1) * panel_bytes, (unsigned)(bl * Hg + u0 + u) >> 1,
-                               (unsigned)(t + 1), h0, h1);
+                               (unsigned)(t + 1), h0, h1, plain);
             // dgh = dh * (c_r, c_z, c_n); dgi_n = dh * a_n   (see header)
             const float an0 = (1.f - z0) * (1.f - n0 * n0), an1 = (1.f - z1) * (1.f - n1 * n1);
             sv_h = make_float2(h0, h1);
@@ -440,7 +476,11 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruArgs a) {
     elem* dB = reinterpret_cast<elem*>(smem_raw);                 // [NPL][16][LD]  B operand (dh_{s+1} * c_{s+1})
     float* red = reinterpret_cast<float*>(dB + NPL * PLANE);      // [4 waves][2 tiles][64][4]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int chain = blockIdx.x % a.nchains, part = blockIdx.x / a.nchains;
+    // block id -> (chain, part) with chain % 8 == id % 8: under the observed id%8 -> XCD dispatch a whole
+    // team lands on one XCD for ANY number of chains (speed only; see team_shares_xcd)
+    const int chain = (int)(blockIdx.x / (8 * a.P)) * 8 + (int)(blockIdx.x & 7);
+    const int part = (int)((blockIdx.x >> 3) % a.P);
+    if (chain >= a.nchains) return;
     const int grp = chain % a.G, bgi = a.bg_off + chain / a.G;
     const int b0 = bgi * a.Bg, nb = min(a.Bg, a.B - b0);
     const int u0 = part * U;
@@ -485,7 +525,8 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruArgs a) {
     CoefRegs<PREC> cr;
     if (active) dd = *reinterpret_cast<const float2*>(a.dout + own + (long long)(a.T - 1) * H);
     float2 sv_dh = make_float2(0.f, 0.f);
-    bool aborted = a.dbg >= 1;
+    bool aborted = a.dbg >= 1 && a.dbg < 8;
+    const bool plain = a.dbg != 9 && team_shares_xcd(a.xid + (size_t)chain * 64, a.P, part, a.status, tid);
     __syncthreads();
 
     for (int k = 0; k < a.T; ++k) {
@@ -512,7 +553,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruArgs a) {
 #pragma unroll
             for (int i = 0; i < NKW; ++i) {
                 const int ks = wv + 4 * i;
-                if (ks < KS && a.dbg < 2) {
+                if (ks < KS && (a.dbg < 2 || a.dbg == 8)) {
                     const Frag<PREC> fb = panel_get<PREC>(dB, PLANE, (lane & 15) * LD + ks * 32 + (lane >> 4) * 8);
                     acc[0] = mma(wf[0][i], fb, acc[0]);
                     acc[1] = mma(wf[1][i], fb, acc[1]);
@@ -533,7 +574,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruArgs a) {
             dh0 = dd.x + zz.x * dh0 + mm0;
             dh1 = dd.y + zz.y * dh1 + mm1;
             publish_pair<PREC>(rs, cbase + (unsigned)(k & 1) * panel_bytes, (unsigned)(bl * Hg + u0 + u) >> 1,
-                               (unsigned)(k + 1), dh0, dh1);
+                               (unsigned)(k + 1), dh0, dh1, plain);
             sv_dh = make_float2(dh0, dh1);
             dd = ndd; zz = nzz;
         }
@@ -579,11 +620,14 @@ int make_plan(int B, int G, int Hg, Plan& pl) {
     pl.Bg = 8;
     pl.nbg = cdiv(B, pl.Bg);
     if (pl.nbg * G * pl.P > maxblk) { pl.Bg = 16; pl.nbg = cdiv(B, pl.Bg); }
-    pl.bg_per_launch = maxblk / (G * pl.P);
+    pl.bg_per_launch = ((maxblk / pl.P) / 8 * 8) / G;      // chains per launch padded to a multiple of 8
+    if (pl.bg_per_launch < 1) pl.bg_per_launch = 1;
     if (pl.bg_per_launch > pl.nbg) pl.bg_per_launch = pl.nbg;
     pl.nlaunch = cdiv(pl.nbg, pl.bg_per_launch);
     return 0;
 }
+
+size_t xid_bytes_total(int B, int G) { return (size_t)cdiv(B, 8) * G * 64 * 8; }
 
 size_t xg_bytes_total(int B, int G, int Hg) {
     // chains <= ceil(B/8)*G, two parities, up to 16 rows of Hg granules (8 bytes each)
@@ -628,8 +672,8 @@ int check_common(int B, int T, int G, int Hg, int prec, const char* name) {
 template <bool FWD>
 int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* ws, size_t lds, hipStream_t s) {
     a.status = (unsigned*)ws;
-    a.xg = (unsigned long long*)((char*)ws + 256);
-    a.xg_bytes = (unsigned)xg_bytes_total(a.B, G, Hg);
+    char* xid_base = (char*)ws + 256;
+    char* xg_base = xid_base + xid_bytes_total(a.B, G);
     a.Bg = pl.Bg; a.P = pl.P;
     { const char* e = getenv("CRUSE_GRU_DBG"); a.dbg = e ? atoi(e) : 0; }
     int rc = CRUSE_OK;
@@ -639,9 +683,10 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* ws, 
         a.bg_off = bg_off;
         a.nchains = nbg_here * G;
         // every launch gets its own panel region: chain index inside the launch + offset
-        a.xg = (unsigned long long*)((char*)ws + 256) + (size_t)bg_off * G * 2 * pl.Bg * Hg;
+        a.xid = (unsigned long long*)xid_base + (size_t)bg_off * G * 64;
+        a.xg = (unsigned long long*)xg_base + (size_t)bg_off * G * 2 * pl.Bg * Hg;
         a.xg_bytes = (unsigned)((size_t)a.nchains * 2 * pl.Bg * Hg * 8);
-        const int grid = a.nchains * pl.P;
+        const int grid = cdiv(a.nchains, 8) * 8 * pl.P;
         if (FWD) {
             if (prec == CRUSE_PREC_F32) rc = dispatch_fwd<CRUSE_PREC_F32>(a, grid, lds, s);
             else if (prec == CRUSE_PREC_BF16X3) rc = dispatch_fwd<CRUSE_PREC_BF16X3>(a, grid, lds, s);
@@ -659,7 +704,7 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* ws, 
 }  // namespace
 
 extern "C" size_t cruse_gru_ws_bytes(int B, int G, int Hg) {
-    return 256 + xg_bytes_total(B, G, Hg);
+    return 256 + xid_bytes_total(B, G) + xg_bytes_total(B, G, Hg);
 }
 
 extern "C" int cruse_gru_seq_fwd(const float* gi, const float* const* w_hh, const float* const* b_hh,

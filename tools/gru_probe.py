@@ -1,10 +1,14 @@
-import os, sys, time, torch
+"""Within-process A/B of the GRU recurrence kernels (profiling aid).  CRUSE_GRU_DBG: 0 = shipped,
+9 = force write-through publishes, 1 = no tag waits (wrong results), 2 = also no MFMA."""
+import os, sys, torch
 sys.path.insert(0, '.')
 from cruse_amd import ops
-B, T, H = 64, 401, 640
+B, T, H = int(os.environ.get("PB", 64)), 401, 640
+G = int(os.environ.get("PG", 1))
+Hg = H // G
 torch.manual_seed(0)
 gi = (0.5 * torch.randn(B, T, 3 * H)).cuda()
-w = (torch.randn(3 * H, H) / 25).cuda(); b = torch.zeros(3 * H).cuda()
+ws = [(torch.randn(3 * Hg, Hg) / 25).cuda() for _ in range(G)]; bs = [torch.zeros(3 * Hg).cuda() for _ in range(G)]
 dout = (0.1 * torch.randn(B, T, H)).cuda()
 def timeit(fn, n=5):
     fn(); torch.cuda.synchronize()
@@ -13,11 +17,13 @@ def timeit(fn, n=5):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-h, coef, an, z = ops.gru_seq_fwd(gi, [w], [b], B, T, 1, H, "bf16")
-tf = timeit(lambda: ops.gru_seq_fwd(gi, [w], [b], B, T, 1, H, "bf16"))
-tb = timeit(lambda: ops.gru_seq_bwd(dout, [w], coef, z, B, T, 1, H, "bf16"))
-print(f"dbg={os.environ.get('CRUSE_GRU_DBG','0')} B={B}: fwd {tf*1e3/T:.2f} us/step  bwd {tb*1e3/T:.2f} us/step  status {ops.gru_status()}")
-for Bx in (8, 16, 32):
-    g2 = gi[:Bx].contiguous()
-    tf = timeit(lambda: ops.gru_seq_fwd(g2, [w], [b], Bx, T, 1, H, "bf16"))
-    print(f"   B={Bx}: fwd {tf*1e3/T:.2f} us/step")
+h, coef, an, z = ops.gru_seq_fwd(gi, ws, bs, B, T, G, Hg, "bf16")
+modes = sys.argv[1:] or ["0", "9"]
+for rnd in range(3):
+    out = []
+    for m in modes:
+        os.environ["CRUSE_GRU_DBG"] = m
+        tf = timeit(lambda: ops.gru_seq_fwd(gi, ws, bs, B, T, G, Hg, "bf16"))
+        tb = timeit(lambda: ops.gru_seq_bwd(dout, ws, coef, z, B, T, G, Hg, "bf16"))
+        out.append(f"dbg={m}: fwd {tf*1e3/T:.2f} bwd {tb*1e3/T:.2f} us/step")
+    print(f"B={B} G={G} round {rnd}: " + " | ".join(out), "status", ops.gru_status())
