@@ -294,6 +294,15 @@ __device__ __forceinline__ void publish_pair(__amdgpu_buffer_rsrc_t rs, unsigned
 // its granule loads, the only older request still in flight is the previous step's publish store -- the gi
 // rows are loaded one step AHEAD and a step's saves are issued after the NEXT step's sweep has returned.
 // ---------------------------------------------------------------------------------
+// gate nonlinearities on the serial path: v_exp_f32 + v_rcp_f32 forms (abs. error ~1e-7), not the
+// libm expf/tanhf sequences (they cost ~1 us per step of pure VALU latency)
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float e = __expf(-2.0f * fabsf(x));          // in (0, 1]: no overflow
+    const float t = (1.0f - e) * __frcp_rn(1.0f + e);
+    return copysignf(t, x);
+}
+
 template <int PREC>
 __device__ __forceinline__ void store_coef(void* base, long long off, float2 v) {
     if constexpr (PREC == CRUSE_PREC_BF16) reinterpret_cast<unsigned*>(base)[off >> 1] = pack2(v.x, v.y);   // off is even
@@ -345,59 +354,63 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
         }
     }
 
-    // item of this thread: unit pair (u, u+1) of local clip bl
-    const int u = 2 * (tid & 15);
-    const int bl = tid >> 4;
-    const bool active = bl < nb;
+    // items of this thread: unit u of local clips bl = (tid >> 5) + 8*q  (NIT = Bg/8 items): the gate math
+    // (3 transcendentals per item) is spread over all 256 threads
+    const int u = tid & 31;
     const int half = u >> 4, ru = u & 15;
-    const int lp = (ru >> 2) * 16 + bl;
-    float bias[3][2];
+    const int NIT = a.Bg >> 3;
+    float bias[3];
 #pragma unroll
-    for (int g = 0; g < 3; ++g) { bias[g][0] = bh[g * Hg + u0 + u]; bias[g][1] = bh[g * Hg + u0 + u + 1]; }
-    float hp0 = 0.f, hp1 = 0.f;
+    for (int g = 0; g < 3; ++g) bias[g] = bh[g * Hg + u0 + u];
+    float hp[2] = {0.f, 0.f};
     const long long gi_row = (long long)a.G * 3 * Hg;             // gi floats per frame
-    const float* gp = a.gi + ((long long)(b0 + bl) * a.T * a.G + grp) * 3 * Hg + u0 + u;
-    float2 gir = make_float2(0.f, 0.f), giz = gir, gin = gir;    // gi of the CURRENT step
-    if (active) {
-        gir = *reinterpret_cast<const float2*>(gp);
-        giz = *reinterpret_cast<const float2*>(gp + Hg);
-        gin = *reinterpret_cast<const float2*>(gp + 2 * Hg);
+    float gic[2][3], sv[2][6];                                    // gi of the CURRENT step; deferred saves
+    const float* gp[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int bl = (tid >> 5) + 8 * q;
+        gp[q] = a.gi + ((long long)(b0 + bl) * a.T * a.G + grp) * 3 * Hg + u0 + u;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) gic[q][g] = (q < NIT && bl < nb) ? gp[q][g * Hg] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) sv[q][e] = 0.f;
     }
-    // deferred saves of the previous step
     bool aborted = a.dbg >= 1 && a.dbg < 8;
     const bool plain = a.dbg != 9 && team_shares_xcd(a.xid + (size_t)chain * 64, a.P, part, a.status, tid);
-    float2 sv_h, sv_cr, sv_cz, sv_cn, sv_an, sv_z;
-    sv_h = sv_cr = sv_cz = sv_cn = sv_an = sv_z = make_float2(0.f, 0.f);
     __syncthreads();
 
+    auto save_step = [&](int q, int t) {
+        const int bl = (tid >> 5) + 8 * q;
+        const long long o = ((long long)(b0 + bl) * a.T + t) * H + grp * Hg + u0 + u;
+        a.h[o] = sv[q][0];
+        if (a.coef) {
+            const long long o3 = (((long long)(b0 + bl) * a.T + t) * a.G + grp) * 3 * Hg + u0 + u;
+            if constexpr (PREC == CRUSE_PREC_BF16) {
+                __bf16* cp = reinterpret_cast<__bf16*>(a.coef);
+                cp[o3] = (__bf16)sv[q][1]; cp[o3 + Hg] = (__bf16)sv[q][2]; cp[o3 + 2 * Hg] = (__bf16)sv[q][3];
+            } else {
+                float* cp = reinterpret_cast<float*>(a.coef);
+                cp[o3] = sv[q][1]; cp[o3 + Hg] = sv[q][2]; cp[o3 + 2 * Hg] = sv[q][3];
+            }
+            a.an[o] = sv[q][4];
+            a.z[o] = sv[q][5];
+        }
+    };
+
     for (int t = 0; t < a.T; ++t) {
-        float gh[3][2];
-#pragma unroll
-        for (int g = 0; g < 3; ++g) { gh[g][0] = bias[g][0]; gh[g][1] = bias[g][1]; }
         if (t > 0)
             aborted |= sweep_panel<PREC, false>(hB, PLANE, LD, rs, cbase + (unsigned)((t - 1) & 1) * panel_bytes, nload, Hg,
                                                 (unsigned)t, si0, nullptr, nullptr, 0, a.status, tid, aborted);
         // (1) saves of step t-1, (2) gi rows of step t+1: both are old by the time of the next sweep
-        float2 nir = make_float2(0.f, 0.f), niz = nir, nin = nir;
-        if (active) {
-            if (t > 0) {
-                const long long o = ((long long)(b0 + bl) * a.T + (t - 1)) * H + grp * Hg + u0 + u;
-                *reinterpret_cast<float2*>(a.h + o) = sv_h;
-                if (a.coef) {
-                    const long long o3 = (((long long)(b0 + bl) * a.T + (t - 1)) * a.G + grp) * 3 * Hg + u0 + u;
-                    store_coef<PREC>(a.coef, o3, sv_cr);
-                    store_coef<PREC>(a.coef, o3 + Hg, sv_cz);
-                    store_coef<PREC>(a.coef, o3 + 2 * Hg, sv_cn);
-                    *reinterpret_cast<float2*>(a.an + o) = sv_an;
-                    *reinterpret_cast<float2*>(a.z + o) = sv_z;
-                }
-            }
-            if (t + 1 < a.T) {
-                const float* gq = gp + (long long)(t + 1) * gi_row;
-                nir = *reinterpret_cast<const float2*>(gq);
-                niz = *reinterpret_cast<const float2*>(gq + Hg);
-                nin = *reinterpret_cast<const float2*>(gq + 2 * Hg);
-            }
+        float gin_[2][3];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int bl = (tid >> 5) + 8 * q;
+            const bool act = q < NIT && bl < nb;
+            if (act && t > 0) save_step(q, t - 1);
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                gin_[q][g] = (act && t + 1 < a.T) ? gp[q][(long long)(t + 1) * gi_row + g * Hg] : 0.f;
         }
         if (t > 0) {
             f32x4 acc[6];
@@ -406,7 +419,7 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
 #pragma unroll
             for (int i = 0; i < NKW; ++i) {
                 const int ks = wv + 4 * i;
-                if (ks < KS && (a.dbg < 2 || a.dbg == 8)) {
+                if (ks < KS && (a.dbg < 2 || a.dbg >= 8)) {
                     const Frag<PREC> fb = panel_get<PREC>(hB, PLANE, (lane & 15) * LD + ks * 32 + (lane >> 4) * 8);
 #pragma unroll
                     for (int j = 0; j < 6; ++j) acc[j] = mma(wf[j][i], fb, acc[j]);
@@ -416,48 +429,56 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
             for (int j = 0; j < 6; ++j)
                 *reinterpret_cast<f32x4*>(red + ((wv * 6 + j) * 64 + lane) * 4) = acc[j];
             __syncthreads();
-            if (active) {
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (q >= NIT) continue;                      // uniform: Bg == 8 has one item per thread
+            const int bl = (tid >> 5) + 8 * q;
+            const bool act = bl < nb;
+            float gh[3] = {bias[0], bias[1], bias[2]};
+            if (t > 0) {
+                const int lp = (ru >> 2) * 16 + bl;
 #pragma unroll
                 for (int g = 0; g < 3; ++g)
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        const float2 pr = *reinterpret_cast<const float2*>(red + ((w * 6 + g * 2 + half) * 64 + lp) * 4 + (ru & 3));
-                        gh[g][0] += pr.x; gh[g][1] += pr.y;
-                    }
+                    for (int w = 0; w < 4; ++w) gh[g] += red[((w * 6 + g * 2 + half) * 64 + lp) * 4 + (ru & 3)];
             }
-        }
-        if (active) {
-            const float r0 = sigmoid_acc(gir.x + gh[0][0]), r1 = sigmoid_acc(gir.y + gh[0][1]);
-            const float z0 = sigmoid_acc(giz.x + gh[1][0]), z1 = sigmoid_acc(giz.y + gh[1][1]);
-            const float n0 = tanhf(gin.x + r0 * gh[2][0]), n1 = tanhf(gin.y + r1 * gh[2][1]);
-            const float h0 = (1.f - z0) * n0 + z0 * hp0;
-            const float h1 = (1.f - z1) * n1 + z1 * hp1;
-            publish_pair<PREC>(rs, cbase + (unsigned)(t & 1) * panel_bytes, (unsigned)(bl * Hg + u0 + u) >> 1,
-                               (unsigned)(t + 1), h0, h1, plain);
+            const float r = fast_sigmoid(gic[q][0] + gh[0]);
+            const float z = fast_sigmoid(gic[q][1] + gh[1]);
+            const float n = fast_tanh(gic[q][2] + r * gh[2]);
+            const float h = (1.f - z) * n + z * hp[q];
+            {
+                // hand-off: f32 granule per value, or one bf16x2 granule per unit pair (even lane publishes)
+                const unsigned pbase = cbase + (unsigned)(t & 1) * panel_bytes;
+                const unsigned vidx = (unsigned)(bl * Hg + u0 + u);
+                if constexpr (PREC == CRUSE_PREC_BF16) {
+                    const float hn = __shfl_xor(h, 1, 64);
+                    if (act && !(u & 1)) publish_pair<PREC>(rs, pbase, vidx >> 1, (unsigned)(t + 1), h, hn, plain);
+                } else {
+                    if (act) {
+                        const u32x2 w = {(unsigned)(t + 1), __float_as_uint(h)};
+                        if (plain) __builtin_amdgcn_raw_buffer_store_b64(w, rs, pbase + vidx * 8u, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b64(w, rs, pbase + vidx * 8u, 0, 16);
+                    }
+                }
+            }
             // dgh = dh * (c_r, c_z, c_n); dgi_n = dh * a_n   (see header)
-            const float an0 = (1.f - z0) * (1.f - n0 * n0), an1 = (1.f - z1) * (1.f - n1 * n1);
-            sv_h = make_float2(h0, h1);
-            sv_cr = make_float2(an0 * gh[2][0] * r0 * (1.f - r0), an1 * gh[2][1] * r1 * (1.f - r1));
-            sv_cz = make_float2((hp0 - n0) * z0 * (1.f - z0), (hp1 - n1) * z1 * (1.f - z1));
-            sv_cn = make_float2(an0 * r0, an1 * r1);
-            sv_an = make_float2(an0, an1);
-            sv_z = make_float2(z0, z1);
-            hp0 = h0; hp1 = h1;
-            gir = nir; giz = niz; gin = nin;
+            const float an = (1.f - z) * (1.f - n * n);
+            sv[q][0] = h;
+            sv[q][1] = an * gh[2] * r * (1.f - r);
+            sv[q][2] = (hp[q] - n) * z * (1.f - z);
+            sv[q][3] = an * r;
+            sv[q][4] = an;
+            sv[q][5] = z;
+            hp[q] = h;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) gic[q][g] = gin_[q][g];
         }
     }
-    if (active) {
-        const int t = a.T - 1;
-        const long long o = ((long long)(b0 + bl) * a.T + t) * H + grp * Hg + u0 + u;
-        *reinterpret_cast<float2*>(a.h + o) = sv_h;
-        if (a.coef) {
-            const long long o3 = (((long long)(b0 + bl) * a.T + t) * a.G + grp) * 3 * Hg + u0 + u;
-            store_coef<PREC>(a.coef, o3, sv_cr);
-            store_coef<PREC>(a.coef, o3 + Hg, sv_cz);
-            store_coef<PREC>(a.coef, o3 + 2 * Hg, sv_cn);
-            *reinterpret_cast<float2*>(a.an + o) = sv_an;
-            *reinterpret_cast<float2*>(a.z + o) = sv_z;
-        }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int bl = (tid >> 5) + 8 * q;
+        if (q < NIT && bl < nb) save_step(q, a.T - 1);
     }
 }
 
@@ -618,6 +639,7 @@ int make_plan(int B, int G, int Hg, Plan& pl) {
     const int maxblk = num_cus();
     if (G * pl.P > maxblk) return -1;
     pl.Bg = 8;
+    { const char* e = getenv("CRUSE_GRU_BG"); if (e && atoi(e) == 16) pl.Bg = 16; }   // profiling override
     pl.nbg = cdiv(B, pl.Bg);
     if (pl.nbg * G * pl.P > maxblk) { pl.Bg = 16; pl.nbg = cdiv(B, pl.Bg); }
     pl.bg_per_launch = ((maxblk / pl.P) / 8 * 8) / G;      // chains per launch padded to a multiple of 8
