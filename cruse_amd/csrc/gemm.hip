@@ -14,6 +14,7 @@ struct GemmArgs {
     const float* A; const float* B; float* C; const float* bias;
     int M, N, K, lda, ldb, ldc;
     int accumulate, splitk, kchunk, shiftT, vecA, vecB;
+    int tiles_m, tiles_n, nunits, inner;     // XCD-aware 1-D grid (see gemm_kernel)
 };
 
 // LDS operand storage: f32 keeps floats (BK = 32, 8 x f32 MFMA per fragment pair); bf16 / bf16x3 keep
@@ -164,8 +165,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) elem Bs[NPL * PLANE];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv >> 1, wn = wv & 1;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int kbeg = blockIdx.z * g.kchunk;
+    // XCD-aware tile order (block id % 8 -> XCD is the observed dispatch; speed only).  A UNIT is the set of
+    // tiles that share an operand panel: the n-tiles of one m-tile (A panel) or, with split-K, all tiles of one
+    // k-slice.  Unit u runs entirely on XCD u % 8, its tiles back to back, so the shared panel is fetched into
+    // that XCD's L2 once instead of once per tile (PMC: 1.0 GB -> see profiles/ for the NT gate projection).
+    const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3;
+    const int inner = qq % g.inner, unit = (qq / g.inner) * 8 + xcd;
+    if (unit >= g.nunits) return;
+    int tm, tn, tz;
+    if (g.splitk > 1) { tz = unit; tm = inner % g.tiles_m; tn = inner / g.tiles_m; }
+    else { tz = 0; tm = unit; tn = inner; }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = tz * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
 
     f32x4 acc[4][4];
@@ -204,7 +215,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    const bool add_bias = g.bias != nullptr && blockIdx.z == 0;
+    const bool add_bias = g.bias != nullptr && tz == 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -255,8 +266,12 @@ extern "C" int cruse_gemm(int transA, int transB, int M, int N, int K,
     g.accumulate = accumulate; g.splitk = splitk; g.kchunk = kchunk; g.shiftT = b_shift_T;
     g.vecA = (lda % 4 == 0 && ((uintptr_t)A % 16) == 0) ? 1 : 0;   // 16-byte loads along the contiguous index
     g.vecB = (ldb % 4 == 0 && ((uintptr_t)B % 16) == 0) ? 1 : 0;
-    dim3 grid(cdiv(M, BM), cdiv(N, BN), splitk);
-    CRUSE_REQUIRE(grid.y <= 65535 && grid.z <= 65535, CRUSE_E_SHAPE, "gemm: grid too large");
+    g.tiles_m = cdiv(M, BM); g.tiles_n = cdiv(N, BN);
+    if (splitk > 1) { g.nunits = splitk; g.inner = g.tiles_m * g.tiles_n; }
+    else { g.nunits = g.tiles_m; g.inner = g.tiles_n; }
+    const long long nblk = (long long)cdiv(g.nunits, 8) * 8 * g.inner;
+    CRUSE_REQUIRE(nblk < (1ll << 31), CRUSE_E_SHAPE, "gemm: grid too large");
+    dim3 grid((unsigned)nblk);
     hipStream_t s = (hipStream_t)stream;
     if (prec == CRUSE_PREC_F32) launch_prec<CRUSE_PREC_F32>(g, transA, transB, grid, s);
     else if (prec == CRUSE_PREC_BF16X3) launch_prec<CRUSE_PREC_BF16X3>(g, transA, transB, grid, s);
