@@ -45,6 +45,10 @@ SIGNATURES = {
     "cruse_gru_seq_bwd": ("pppppiiiiipp", "i"),
     "cruse_gru_gate_grads": ("pppppqiiip", "i"),
     "cruse_mask_loss_fwd": ("ppppqiiffpppppp", "i"),
+    "cruse_mask_apply": ("pppqiippp", "i"),
+    "cruse_mask_apply_bwd": ("pppppqiiipp", "i"),
+    "cruse_sisnr_fwd": ("ppiifpppp", "i"),
+    "cruse_sisnr_bwd": ("pppiifpp", "i"),
     "cruse_sigmoid_bwd": ("pppqp", "i"),
     "cruse_axpby": ("pppffqp", "i"),
     "cruse_adam_step": ("ppppqfffffifp", "i"),

@@ -1,0 +1,165 @@
+// Time-domain losses in the loop: the waveform estimate is iSTFT(mask * noisy spectrum)
+// and the criterion is SI-SNR -- `si_snr_loss` of train_base/loss.py:7-25, the only loss reachable through
+// tools/train_stand.py:73-75 besides L1/MSE (loss_func/loss.py:48-56 `sisnr` is the same quantity without
+// mean removal and with a different eps placement).
+//
+//   x_zm = x - mean(x); s_zm = s - mean(s); t = <x_zm,s_zm> s_zm / (|s_zm|^2 + eps)
+//   loss = -mean_b 20 log10(eps + |t| / (|x_zm - t| + eps))
+//
+// Everything reduces to five moments per clip (sum x, s, x^2, s^2, xs; f64), so the forward is one streaming
+// pass, and the gradient is dL/dx = A_b (x - mean x) + C_b (s - mean s) with per-clip scalars: a second
+// streaming pass.  Both are HBM-bound (8 resp. 12 bytes per sample).
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sisnr_moments_kernel(const float* x, const float* s, int B, int L, double* mom) {
+    // grid = (chunks, B); mom[b][5] accumulated with f64 atomics (zeroed by the host wrapper)
+    __shared__ double red[5][4];
+    const int b = blockIdx.y;
+    const float* xb = x + (long long)b * L;
+    const float* sb = s + (long long)b * L;
+    double m[5] = {0, 0, 0, 0, 0};
+    float p[5] = {0, 0, 0, 0, 0};
+    int n = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < L; i += gridDim.x * 256) {
+        const float a = xb[i], c = sb[i];
+        p[0] += a; p[1] += c; p[2] += a * a; p[3] += c * c; p[4] += a * c;
+        if (++n == 16) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { m[k] += p[k]; p[k] = 0.f; }
+            n = 0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        m[k] = wave_sum_d(m[k] + (double)p[k]);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = m[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        const int k = threadIdx.x;
+        atomicAdd(&mom[b * 5 + k], red[k][0] + red[k][1] + red[k][2] + red[k][3]);
+    }
+}
+
+// per clip: loss term and the gradient scalars.  coef[b] = {A, C, mean_x, mean_s}
+__global__ void sisnr_finalize_kernel(const double* mom, int B, int L, double eps, double* loss, float* coef) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double n = (double)L;
+    const double sx = mom[b * 5 + 0], ss = mom[b * 5 + 1], sxx = mom[b * 5 + 2], sss = mom[b * 5 + 3], sxs = mom[b * 5 + 4];
+    const double mx = sx / n, ms = ss / n;
+    const double P = sxs - n * mx * ms;                 // <x_zm, s_zm>
+    double S2 = sss - n * ms * ms; if (S2 < 0) S2 = 0;  // |s_zm|^2
+    double X2 = sxx - n * mx * mx; if (X2 < 0) X2 = 0;  // |x_zm|^2
+    const double S = S2 + eps;
+    const double alpha = P / S;
+    const double nt = fabs(alpha) * sqrt(S2);           // |t|
+    double e2 = X2 - 2.0 * alpha * P + alpha * alpha * S2; if (e2 < 0) e2 = 0;
+    const double ne = sqrt(e2);
+    const double r = nt / (ne + eps);
+    const double lb = -20.0 * log10(eps + r) / (double)B;
+    atomicAdd(loss, lb);
+    // d lb / d r
+    const double dr = -20.0 / (log(10.0) * (eps + r)) / (double)B;
+    // r = nt/(ne+eps);  d nt/da = sign(alpha) |s| s/S ;  d ne/da = (e - s <e,s>/S)/ne,  e = a - alpha s
+    const double sgn = alpha >= 0 ? 1.0 : -1.0;
+    const double es = P - alpha * S2;                    // <e, s>
+    const double k_nt = dr / (ne + eps) * sgn * sqrt(S2) / S;                    // * s
+    const double k_ne = ne > 0 ? -dr * nt / ((ne + eps) * (ne + eps)) / ne : 0.0; // * (e - s es/S)
+    // grad = k_nt s + k_ne (a - alpha s - s es/S) = k_ne a + (k_nt - k_ne (alpha + es/S)) s
+    coef[b * 4 + 0] = (float)k_ne;
+    coef[b * 4 + 1] = (float)(k_nt - k_ne * (alpha + es / S));
+    coef[b * 4 + 2] = (float)mx;
+    coef[b * 4 + 3] = (float)ms;
+}
+
+__global__ __launch_bounds__(256) void sisnr_grad_kernel(const float* x, const float* s, const float* coef, int B, int L,
+                                                         float gscale, float* dx) {
+    const int b = blockIdx.y;
+    const float A = coef[b * 4 + 0] * gscale, C = coef[b * 4 + 1] * gscale, mx = coef[b * 4 + 2], ms = coef[b * 4 + 3];
+    const long long o = (long long)b * L;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < L; i += gridDim.x * 256)
+        dx[o + i] = A * (x[o + i] - mx) + C * (s[o + i] - ms);
+}
+
+// est = mask * noisy spectrum on the first Fn bins, 0 above (utils/utils.py:418-420, R8)
+__global__ __launch_bounds__(256) void mask_apply_kernel(const float* mask, const float* nre, const float* nim,
+                                                         long long rows, int Fn, int Fs, float* ere, float* eim) {
+    const long long n = rows * Fs;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long r = i / Fs;
+        const int f = (int)(i - r * Fs);
+        const float m = f < Fn ? mask[r * Fn + f] : 0.f;
+        ere[i] = m * nre[i];
+        eim[i] = m * nim[i];
+    }
+}
+// dlogit = (dre*nre + dim*nim) * m (1 - m)   (dmask when `through_sigmoid` == 0)
+__global__ __launch_bounds__(256) void mask_apply_bwd_kernel(const float* dre, const float* dim, const float* nre,
+                                                             const float* nim, const float* mask, long long rows, int Fn,
+                                                             int Fs, int through_sigmoid, float* dout) {
+    const long long n = rows * Fn;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long r = i / Fn;
+        const int f = (int)(i - r * Fn);
+        const long long j = r * Fs + f;
+        float d = dre[j] * nre[j] + dim[j] * nim[j];
+        if (through_sigmoid) { const float m = mask[i]; d *= m * (1.f - m); }
+        dout[i] = d;
+    }
+}
+
+inline int blocks_for(long long n, int per) {
+    long long g = (n + per - 1) / per;
+    if (g < 1) g = 1;
+    if (g > 4096) g = 4096;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int cruse_sisnr_fwd(const float* x, const float* s, int B, int L, float eps,
+                               double* mom, double* loss, float* coef, void* stream) {
+    CRUSE_REQUIRE(B > 0 && L > 0, CRUSE_E_SHAPE, "sisnr: bad shape B=%d L=%d", B, L);
+    hipStream_t st = (hipStream_t)stream;
+    { int rc = cruse_zero_async(mom, (size_t)B * 5 * sizeof(double), st, "sisnr"); if (rc) return rc; }
+    { int rc = cruse_zero_async(loss, sizeof(double), st, "sisnr"); if (rc) return rc; }
+    int chunks = (L + 256 * 16 - 1) / (256 * 16);
+    if (chunks > 64) chunks = 64;
+    hipLaunchKernelGGL(sisnr_moments_kernel, dim3(chunks, B), dim3(256), 0, st, x, s, B, L, mom);
+    CRUSE_LAUNCH_CHECK("sisnr_moments");
+    hipLaunchKernelGGL(sisnr_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0, st, mom, B, L, (double)eps, loss, coef);
+    CRUSE_LAUNCH_CHECK("sisnr_finalize");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_sisnr_bwd(const float* x, const float* s, const float* coef, int B, int L, float grad_scale,
+                               float* dx, void* stream) {
+    CRUSE_REQUIRE(B > 0 && L > 0, CRUSE_E_SHAPE, "sisnr_bwd: bad shape");
+    int chunks = (L + 256 * 8 - 1) / (256 * 8);
+    if (chunks > 64) chunks = 64;
+    hipLaunchKernelGGL(sisnr_grad_kernel, dim3(chunks, B), dim3(256), 0, (hipStream_t)stream, x, s, coef, B, L, grad_scale, dx);
+    CRUSE_LAUNCH_CHECK("sisnr_grad");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_mask_apply(const float* mask, const float* nre, const float* nim, long long rows, int Fn, int Fs,
+                                float* est_re, float* est_im, void* stream) {
+    CRUSE_REQUIRE(rows > 0 && Fn > 0 && Fs >= Fn, CRUSE_E_SHAPE, "mask_apply: bad shape");
+    hipLaunchKernelGGL(mask_apply_kernel, dim3(blocks_for(rows * Fs, 1024)), dim3(256), 0, (hipStream_t)stream, mask, nre,
+                       nim, rows, Fn, Fs, est_re, est_im);
+    CRUSE_LAUNCH_CHECK("mask_apply");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_mask_apply_bwd(const float* dre, const float* dim, const float* nre, const float* nim,
+                                    const float* mask, long long rows, int Fn, int Fs, int through_sigmoid,
+                                    float* dout, void* stream) {
+    CRUSE_REQUIRE(rows > 0 && Fn > 0 && Fs >= Fn, CRUSE_E_SHAPE, "mask_apply_bwd: bad shape");
+    hipLaunchKernelGGL(mask_apply_bwd_kernel, dim3(blocks_for(rows * Fn, 1024)), dim3(256), 0, (hipStream_t)stream, dre, dim,
+                       nre, nim, mask, rows, Fn, Fs, through_sigmoid, dout);
+    CRUSE_LAUNCH_CHECK("mask_apply_bwd");
+    return CRUSE_OK;
+}

@@ -80,7 +80,7 @@ class FlatParams:
 class TrainEngine:
     def __init__(self, model: unet_2, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
                  n_fft=320, hop=160, precision: Optional[str] = None, use_graph: bool = True,
-                 loss_alpha=2.0, loss_beta=1.0):
+                 loss_alpha=2.0, loss_beta=1.0, loss: str = "wo_male"):
         if not torch.cuda.is_available():
             raise RuntimeError("cruse_amd.TrainEngine needs a HIP device (there is no CPU path)")
         self.model = model
@@ -92,6 +92,9 @@ class TrainEngine:
         self.prec = model.precision
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.loss_alpha, self.loss_beta = loss_alpha, loss_beta
+        if loss not in ("wo_male", "si_snr"):
+            raise ValueError(f"unknown loss {loss!r} (wo_male | si_snr)")
+        self.loss = loss
         self.flat = FlatParams(model)
         self.flat.broadcast(0)
         self.Bf = dict(model.named_buffers())
@@ -107,14 +110,26 @@ class TrainEngine:
         B, L = noisy.shape
         T = ops.stft_frames(L, self.hop)
         nre, nim, mag = ops.stft(noisy, self.n_fft, self.hop, mag_bins=self.f_net, mag_eps=1e-8)
-        _, _, cmag = ops.stft(clean, self.n_fft, self.hop, want_ri=False, mag_bins=self.f_stft, mag_eps=0.0)
+        cmag = None
+        if self.loss == "wo_male":
+            _, _, cmag = ops.stft(clean, self.n_fft, self.hop, want_ri=False, mag_bins=self.f_stft, mag_eps=0.0)
         mask, ctx = unet2_forward(mag.view(B, 1, T, self.f_net), self.flat.P, self.Bf, self.model.ch,
                                   self.model.rnn_groups, self.prec, training=True)
-        loss_sum, _, dlogit, _, _ = ops.mask_loss(mask, nre, nim, cmag, B * T, self.f_net, self.f_stft,
-                                                  self.loss_alpha, self.loss_beta, want_dlogit=True)
+        if self.loss == "wo_male":
+            loss_sum, _, dlogit, _, _ = ops.mask_loss(mask, nre, nim, cmag, B * T, self.f_net, self.f_stft,
+                                                      self.loss_alpha, self.loss_beta, want_dlogit=True)
+            self._norm = float(B * T * self.f_stft)
+        else:
+            # waveform in -> waveform loss: est = iSTFT(mask * N); SI-SNR(est, clean) and back through both
+            ere, eim = ops.mask_apply(mask, nre, nim, B * T, self.f_net, self.f_stft)
+            est = ops.istft(ere.view(B, T, self.f_stft), eim.view(B, T, self.f_stft), self.n_fft, self.hop, L)
+            loss_sum, coef = ops.sisnr_fwd(est, clean)
+            dwave = ops.sisnr_bwd(est, clean, coef)
+            dre, dim = ops.istft_bwd(dwave, T, self.n_fft, self.hop)
+            dlogit = ops.mask_apply_bwd(dre, dim, nre, nim, mask, B * T, self.f_net, self.f_stft)
+            self._norm = 1.0
         self.flat.grads.zero_()
         unet2_backward(ctx, dlogit.view(B, T, 1, self.f_net), self.flat.P, self.flat.G)
-        self._norm = float(B * T * self.f_stft)
         return loss_sum
 
     def _capture(self, noisy, clean):

@@ -54,3 +54,26 @@ def enhanced_spectrum(mask, noisy_real, noisy_imag):
     _, _, _, er, ei = ops.mask_loss(mask.contiguous(), noisy_real.contiguous(), noisy_imag.contiguous(), dummy,
                                     rows, Fn, Fs, want_est=True)
     return torch.stack([er.view(B, T, Fs), ei.view(B, T, Fs)], dim=-1)
+
+
+class _SiSnrFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, s, eps):
+        x = x.contiguous(); s = s.contiguous()
+        loss, coef = ops.sisnr_fwd(x, s, eps)
+        ctx.save_for_backward(x, s, coef)
+        return loss.to(torch.float32).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, s, coef = ctx.saved_tensors
+        return ops.sisnr_bwd(x, s, coef) * g, None, None
+
+
+def si_snr_loss():
+    """train_base/loss.py:7-25: returns si_snr(x, s, eps=1e-8) on [B,L] waveforms (HIP kernels)."""
+    def si_snr(x, s, eps=1e-8):
+        if x.shape != s.shape:
+            raise RuntimeError(f"Dimension mismatch when calculate si_snr, {x.shape} vs {s.shape}")
+        return _SiSnrFn.apply(x, s, float(eps))
+    return si_snr

@@ -276,6 +276,39 @@ def mask_loss(mask, nre, nim, cmag, rows, Fn, Fs, alpha=2.0, beta=1.0, want_dmas
     return loss_sum, dmask, dlogit, er, ei
 
 
+def mask_apply(mask, nre, nim, rows, Fn, Fs):
+    er = torch.empty(rows, Fs, device=mask.device, dtype=torch.float32)
+    ei = torch.empty_like(er)
+    check(lib.cruse_mask_apply(_p(mask), _p(nre), _p(nim), rows, Fn, Fs, _p(er), _p(ei), _stream()))
+    return er, ei
+
+
+def mask_apply_bwd(dre, dim, nre, nim, mask, rows, Fn, Fs, through_sigmoid=True):
+    out = torch.empty(rows, Fn, device=mask.device, dtype=torch.float32)
+    check(lib.cruse_mask_apply_bwd(_p(dre), _p(dim), _p(nre), _p(nim), _p(mask), rows, Fn, Fs,
+                                   1 if through_sigmoid else 0, _p(out), _stream()))
+    return out
+
+
+def sisnr_fwd(x, s, eps=1e-8):
+    """-> (loss f64[1], coef [B,4]) for si_snr_loss(x, s) of train_base/loss.py:7-25."""
+    B, L = x.shape
+    if s.shape != x.shape:
+        raise RuntimeError(f"Dimension mismatch when calculate si_snr, {tuple(x.shape)} vs {tuple(s.shape)}")
+    mom = torch.empty(B, 5, device=x.device, dtype=torch.float64)
+    loss = torch.empty(1, device=x.device, dtype=torch.float64)
+    coef = torch.empty(B, 4, device=x.device, dtype=torch.float32)
+    check(lib.cruse_sisnr_fwd(_p(x), _p(s), B, L, eps, _p(mom), _p(loss), _p(coef), _stream()))
+    return loss, coef
+
+
+def sisnr_bwd(x, s, coef, grad_scale=1.0):
+    dx = torch.empty_like(x)
+    B, L = x.shape
+    check(lib.cruse_sisnr_bwd(_p(x), _p(s), _p(coef), B, L, grad_scale, _p(dx), _stream()))
+    return dx
+
+
 def sigmoid_bwd(dmask, mask):
     out = torch.empty_like(mask)
     check(lib.cruse_sigmoid_bwd(_p(dmask), _p(mask), _p(out), mask.numel(), _stream()))

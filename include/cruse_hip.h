@@ -190,6 +190,25 @@ int cruse_mask_loss_fwd(const float* mask, const float* nre, const float* nim, c
                         double* loss_sum, float* dmask, float* dlogit, float* est_re, float* est_im,
                         void* stream);
 
+/* ---- time-domain loss in the loop ---------------------------- */
+
+/* PreProcess.masking "mag_mapping" alone (utils/utils.py:418-420): est = mask * noisy spectrum on the first Fn
+ * bins, zero above.  mask [rows,Fn]; nre, nim, est_re, est_im [rows,Fs]. */
+int cruse_mask_apply(const float* mask, const float* nre, const float* nim, long long rows, int Fn, int Fs,
+                     float* est_re, float* est_im, void* stream);
+/* its backward: dout[rows,Fn] = (dre*nre + dim*nim) [* mask*(1-mask) when through_sigmoid != 0] */
+int cruse_mask_apply_bwd(const float* dre, const float* dim, const float* nre, const float* nim,
+                         const float* mask, long long rows, int Fn, int Fs, int through_sigmoid,
+                         float* dout, void* stream);
+/* si_snr_loss of train_base/loss.py:7-25 on waveforms x (estimate), s (target) [B,L]:
+ * loss[0] = -mean_b 20 log10(eps + |t|/(|x_zm - t| + eps)) (f64; zeroed by the callee).
+ * mom [B,5] f64 scratch; coef [B,4] f32 receives the per-clip gradient scalars for cruse_sisnr_bwd. */
+int cruse_sisnr_fwd(const float* x, const float* s, int B, int L, float eps,
+                    double* mom, double* loss, float* coef, void* stream);
+/* dx = grad_scale * d loss / d x */
+int cruse_sisnr_bwd(const float* x, const float* s, const float* coef, int B, int L, float grad_scale,
+                    float* dx, void* stream);
+
 /* backward of nn.Sigmoid (cruse_net.py:164): dlogit = dmask * mask * (1 - mask) */
 int cruse_sigmoid_bwd(const float* dmask, const float* mask, float* dlogit, long long n, void* stream);
 

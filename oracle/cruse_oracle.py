@@ -291,8 +291,15 @@ def train_step_loss(model: nn.Module, noisy: torch.Tensor, clean: torch.Tensor,
     est_b2tf = est.permute(0, 3, 1, 2)                                 # [B,2,T,F]
     ref = torch.cat([cfe["real"], cfe["imag"]], dim=1)
     unproc = torch.cat([feats["real"], feats["imag"]], dim=1)
+    wave = None
     if loss_mode == "WO_MALE":
         loss = wo_male(ref, est_b2tf, unproc)
+    elif loss_mode == "SI_SNR":
+        # PreProcess.reconstruction (utils/utils.py:443-455) + si_snr_loss
+        # (train_base/loss.py:7-25), the loss reachable through tools/train_stand.py:73-75
+        spec = torch.view_as_complex(est.contiguous()).transpose(1, 2)          # [B,F,T]
+        wave = istft(spec, n_fft, hop, win, length=noisy.shape[1])
+        loss = si_snr_loss(wave, clean)
     else:
         raise ValueError(loss_mode)
-    return loss, dict(mask=mask, est=est, feats=feats, ref=ref)
+    return loss, dict(mask=mask, est=est, feats=feats, ref=ref, wave=wave)

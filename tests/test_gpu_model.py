@@ -143,6 +143,41 @@ def test_engine_step_matches_oracle_adam(golden):
         assert int(m2.bn1.num_batches_tracked) == 2
 
 
+def test_si_snr_loss_golden_and_grad(golden):
+    """si_snr_loss (train_base/loss.py:7-25): value from the reference's own run, gradient vs oracle autograd."""
+    from cruse_amd.loss import si_snr_loss
+    from oracle import cruse_oracle as O
+    g = golden("g5_loss.npz")
+    s1 = torch.from_numpy(g["s1"]); s2 = torch.from_numpy(g["s2"])
+    f = si_snr_loss()
+    x = s1.clone().cuda().requires_grad_(True)
+    val = f(x, s2.cuda())
+    assert abs(float(val) - float(g["si_snr_loss"])) <= 1e-4 * abs(float(g["si_snr_loss"]))
+    val.backward()
+    xr = s1.clone().requires_grad_(True)
+    O.si_snr_loss(xr, s2).backward()
+    assert rel_l2(x.grad, xr.grad) < 1e-4
+    with pytest.raises(RuntimeError, match="Dimension mismatch"):
+        f(torch.zeros(2, 10).cuda(), torch.zeros(2, 11).cuda())
+
+
+def test_time_domain_training_step_vs_oracle():
+    """waveform in -> waveform loss: STFT -> unet_2 -> mask -> iSTFT -> SI-SNR and all gradients."""
+    from cruse_amd.engine import TrainEngine
+    from oracle import cruse_oracle as O
+    o, m = _oracle_and_product(1)
+    eng = TrainEngine(m, lr=1e-3, use_graph=False, loss="si_snr")
+    o.train()
+    noisy, clean = O.synth_pair(2, 3200, seed=91)
+    loss, aux = O.train_step_loss(o, noisy, clean, loss_mode="SI_SNR")
+    loss.backward()
+    ls = eng.step(noisy.cuda(), clean.cuda())
+    assert abs(eng.loss_value(ls) - float(loss.detach())) <= 1e-4 * abs(float(loss.detach()))
+    for n, po in o.named_parameters():
+        if n in eng.flat.G and not (n.endswith(".bias") and n.startswith("conv") and n != "conv1_t.bias"):
+            assert rel_l2(eng.flat.G[n], po.grad) <= 5e-3, n
+
+
 def test_full_size_properties():
     """BASELINE config 2 shape (B=64 x 4 s): finite loss, mask in (0,1), loss decreases over Adam steps."""
     from cruse_amd.data import synth_batch

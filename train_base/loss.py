@@ -12,3 +12,9 @@ def wo_male_loss(alpha=2.0, beta=1.0):
     def fn(mask, noisy_real, noisy_imag, clean_mag):
         return masked_wo_male(mask, noisy_real, noisy_imag, clean_mag, alpha, beta)
     return fn
+
+
+def si_snr_loss():
+    """train_base/loss.py:7-25 on the HIP path."""
+    from cruse_amd.loss import si_snr_loss as _f
+    return _f()
