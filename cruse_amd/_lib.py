@@ -47,8 +47,11 @@ SIGNATURES = {
     "cruse_mask_loss_fwd": ("ppppqiiffpppppp", "i"),
     "cruse_mask_apply": ("pppqiippp", "i"),
     "cruse_mask_apply_bwd": ("pppppqiiipp", "i"),
+    "cruse_mask_sdnr_fwd": ("pppppqiiiffpppp", "i"),
     "cruse_sisnr_fwd": ("ppiifpppp", "i"),
     "cruse_sisnr_bwd": ("pppiifpp", "i"),
+    "cruse_deepfilter_fwd": ("ppppiiiiippp", "i"),
+    "cruse_deepfilter_bwd": ("ppppppiiiiippppp", "i"),
     "cruse_sigmoid_bwd": ("pppqp", "i"),
     "cruse_axpby": ("pppffqp", "i"),
     "cruse_adam_step": ("ppppqfffffifp", "i"),

@@ -163,3 +163,55 @@ extern "C" int cruse_mask_apply_bwd(const float* dre, const float* dim, const fl
     CRUSE_LAUNCH_CHECK("mask_apply_bwd");
     return CRUSE_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// SNR-weighted speech-distortion loss (`sdnr`, loss_func/loss.py:151-175; vad == 1 because
+// activity_detector_tf_frame is `pass`, utils/utils.py:217-219) with the mask as the gain est_g:
+//   L_noise  = mean_{b,f} sum_{c,t} (noise * g)^2        L_speech = mean_{b,f} sum_{c,t} (clean - g*clean)^2
+//   loss = alpha * L_speech + (1 - alpha) * L_noise,     alpha = 10^(snr/10) / (10^(snr/10) + 10^(beta/10))
+// clean / noise spectra are [rows,Fs] re/im pairs (c = 2), the gain is the mask on the first Fn bins and 0 above.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void sdnr_kernel(const float* mask, const float* cre, const float* cim, const float* nre,
+                                                   const float* nim, long long rows, int Fn, int Fs, float alpha,
+                                                   float inv_norm, double* loss_sum, float* dmask, float* dlogit) {
+    __shared__ double sred[4];
+    const long long n = rows * Fs;
+    double acc = 0.0;
+    float part = 0.f;
+    int cnt = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long r = i / Fs;
+        const int f = (int)(i - r * Fs);
+        const float m = f < Fn ? mask[r * Fn + f] : 0.f;
+        const float s2 = cre[i] * cre[i] + cim[i] * cim[i];                       // |clean|^2
+        const float dr = nre[i] - cre[i], di = nim[i] - cim[i];
+        const float v2 = dr * dr + di * di;                                       // |noise|^2 = |noisy - clean|^2
+        part += alpha * (1.f - m) * (1.f - m) * s2 + (1.f - alpha) * m * m * v2;
+        if (++cnt == 32) { acc += part; part = 0.f; cnt = 0; }
+        if (f < Fn && (dmask || dlogit)) {
+            const float dm = 2.f * (-alpha * (1.f - m) * s2 + (1.f - alpha) * m * v2) * inv_norm;
+            if (dmask) dmask[r * Fn + f] = dm;
+            if (dlogit) dlogit[r * Fn + f] = dm * m * (1.f - m);
+        }
+    }
+    acc = wave_sum_d(acc + part);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss_sum, sred[0] + sred[1] + sred[2] + sred[3]);
+}
+}  // namespace
+
+extern "C" int cruse_mask_sdnr_fwd(const float* mask, const float* cre, const float* cim, const float* nre, const float* nim,
+                                   long long rows, int Fn, int Fs, int B, float snr_db, float beta_db,
+                                   double* loss_sum, float* dmask, float* dlogit, void* stream) {
+    CRUSE_REQUIRE(rows > 0 && Fn > 0 && Fs >= Fn && B > 0, CRUSE_E_SHAPE, "mask_sdnr: bad shape");
+    const double st = pow(10.0, snr_db / 10.0), bt = pow(10.0, beta_db / 10.0);
+    const float alpha = (float)(st / (st + bt));
+    { int rc = cruse_zero_async(loss_sum, sizeof(double), (hipStream_t)stream, "mask_sdnr"); if (rc) return rc; }
+    // loss = loss_sum / (B * Fs)  (mean over b and f of the (c,t)-summed squares)
+    hipLaunchKernelGGL(sdnr_kernel, dim3(blocks_for(rows * Fs, 2048)), dim3(256), 0, (hipStream_t)stream, mask, cre, cim, nre,
+                       nim, rows, Fn, Fs, alpha, 1.0f / ((float)B * (float)Fs), loss_sum, dmask, dlogit);
+    CRUSE_LAUNCH_CHECK("mask_sdnr");
+    return CRUSE_OK;
+}

@@ -290,6 +290,17 @@ def mask_apply_bwd(dre, dim, nre, nim, mask, rows, Fn, Fs, through_sigmoid=True)
     return out
 
 
+def mask_sdnr(mask, cre, cim, nre, nim, rows, Fn, Fs, B, snr_db, beta_db=20.0, want_dmask=False, want_dlogit=False):
+    """sdnr (loss_func/loss.py:151-175) with the mask as gain -> (loss_sum f64[1] (divide by B*Fs), dmask, dlogit)."""
+    dev = mask.device
+    loss_sum = torch.empty(1, device=dev, dtype=torch.float64)
+    dmask = torch.empty(rows, Fn, device=dev, dtype=torch.float32) if want_dmask else None
+    dlogit = torch.empty(rows, Fn, device=dev, dtype=torch.float32) if want_dlogit else None
+    check(lib.cruse_mask_sdnr_fwd(_p(mask), _p(cre), _p(cim), _p(nre), _p(nim), rows, Fn, Fs, B, snr_db, beta_db,
+                                  _p(loss_sum), _p(dmask), _p(dlogit), _stream()))
+    return loss_sum, dmask, dlogit
+
+
 def sisnr_fwd(x, s, eps=1e-8):
     """-> (loss f64[1], coef [B,4]) for si_snr_loss(x, s) of train_base/loss.py:7-25."""
     B, L = x.shape
@@ -307,6 +318,21 @@ def sisnr_bwd(x, s, coef, grad_scale=1.0):
     B, L = x.shape
     check(lib.cruse_sisnr_bwd(_p(x), _p(s), _p(coef), B, L, grad_scale, _p(dx), _stream()))
     return dx
+
+
+def deepfilter_fwd(xr, xi, hr, hi, f_dim, t_dim):
+    B, F, T = xr.shape
+    o_r = torch.empty_like(xr); o_i = torch.empty_like(xr)
+    check(lib.cruse_deepfilter_fwd(_p(xr), _p(xi), _p(hr), _p(hi), B, F, T, f_dim, t_dim, _p(o_r), _p(o_i), _stream()))
+    return o_r, o_i
+
+
+def deepfilter_bwd(dor, doi, xr, xi, hr, hi, f_dim, t_dim):
+    B, F, T = xr.shape
+    outs = [torch.empty_like(xr) for _ in range(4)]
+    check(lib.cruse_deepfilter_bwd(_p(dor), _p(doi), _p(xr), _p(xi), _p(hr), _p(hi), B, F, T, f_dim, t_dim,
+                                   *[_p(o) for o in outs], _stream()))
+    return outs
 
 
 def sigmoid_bwd(dmask, mask):

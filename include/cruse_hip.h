@@ -200,6 +200,12 @@ int cruse_mask_apply(const float* mask, const float* nre, const float* nim, long
 int cruse_mask_apply_bwd(const float* dre, const float* dim, const float* nre, const float* nim,
                          const float* mask, long long rows, int Fn, int Fs, int through_sigmoid,
                          float* dout, void* stream);
+/* SNR-weighted speech-distortion loss `sdnr` (loss_func/loss.py:151-175, vad == 1) with the mask as gain:
+ * loss = loss_sum[0] / (B*Fs) = alpha*L_speech + (1-alpha)*L_noise, alpha = 10^(snr/10)/(10^(snr/10)+10^(beta/10)).
+ * cre/cim clean, nre/nim noisy spectra [rows,Fs] (noise = noisy - clean); optional dmask / dlogit [rows,Fn]. */
+int cruse_mask_sdnr_fwd(const float* mask, const float* cre, const float* cim, const float* nre, const float* nim,
+                        long long rows, int Fn, int Fs, int B, float snr_db, float beta_db,
+                        double* loss_sum, float* dmask, float* dlogit, void* stream);
 /* si_snr_loss of train_base/loss.py:7-25 on waveforms x (estimate), s (target) [B,L]:
  * loss[0] = -mean_b 20 log10(eps + |t|/(|x_zm - t| + eps)) (f64; zeroed by the callee).
  * mom [B,5] f64 scratch; coef [B,4] f32 receives the per-clip gradient scalars for cruse_sisnr_bwd. */
@@ -208,6 +214,15 @@ int cruse_sisnr_fwd(const float* x, const float* s, int B, int L, float eps,
 /* dx = grad_scale * d loss / d x */
 int cruse_sisnr_bwd(const float* x, const float* s, const float* coef, int B, int L, float grad_scale,
                     float* dx, void* stream);
+
+/* ---- DeepFilter head (model/deep_filter.py:15-41, BASELINE config 4) --------------- */
+/* out[b,f,t] = sum over the (2*f_dim+1) x (2*t_dim+1) neighbourhood of X*H (complex, zero outside); all
+ * tensors [B,F,T] in the reference's layout.  Imaginary part = xr*hi + xi*hr (decision: SURVEY 8a a15). */
+int cruse_deepfilter_fwd(const float* xr, const float* xi, const float* hr, const float* hi,
+                         int B, int F, int T, int f_dim, int t_dim, float* out_r, float* out_i, void* stream);
+int cruse_deepfilter_bwd(const float* dout_r, const float* dout_i, const float* xr, const float* xi,
+                         const float* hr, const float* hi, int B, int F, int T, int f_dim, int t_dim,
+                         float* dxr, float* dxi, float* dhr, float* dhi, void* stream);
 
 /* backward of nn.Sigmoid (cruse_net.py:164): dlogit = dmask * mask * (1 - mask) */
 int cruse_sigmoid_bwd(const float* dmask, const float* mask, float* dlogit, long long n, void* stream);

@@ -181,6 +181,28 @@ class unet_2(nn.Module):
         return d1
 
 
+class DeepFilter(nn.Module):
+    """model/deep_filter.py:15-41.  Repairs: ctor reshape `t_width(f_width, ...)` -> `[t_width*f_width, 1,
+    f_width, t_width]` (:26).  DECISION: imaginary part r*fi + i*fr (the reference's :38 writes
+    r*fi twice)."""
+
+    def __init__(self, t_dim, f_dim):
+        super().__init__()
+        self.t_dim, self.f_dim = t_dim, f_dim
+        t_width, f_width = t_dim * 2 + 1, f_dim * 2 + 1
+        kernel = torch.eye(t_width * f_width)
+        self.register_buffer("kernel", torch.reshape(kernel, [t_width * f_width, 1, f_width, t_width]))
+
+    def forward(self, inputs, filters):
+        ci = F.conv2d(torch.cat(inputs, 0)[:, None], self.kernel, padding=[self.f_dim, self.t_dim])   # :29-31
+        ir, ii = torch.chunk(ci, 2, 0)
+        cf = F.conv2d(torch.cat(filters, 0)[:, None], self.kernel, padding=[self.f_dim, self.t_dim])  # :33-35
+        fr, fi = torch.chunk(cf, 2, 0)
+        out_r = torch.sum(ir * fr - ii * fi, 1)                                                        # :37,39
+        out_i = torch.sum(ir * fi + ii * fr, 1)                                                        # :38,40 (decision)
+        return torch.cat([out_r, out_i], dim=1)
+
+
 # ----------------------------------------------------------------------------
 # Losses: loss_func/loss.py, train_base/loss.py
 # ----------------------------------------------------------------------------

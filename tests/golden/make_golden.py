@@ -110,12 +110,34 @@ def load_reference(ref):
     exec(top_level_block(lsrc, "def l2_norm("), ns)
     exec(top_level_block(lsrc, "def sisnr("), ns)
     exec(w, ns)
+    # --- model/deep_filter.py: ctor repair + the imaginary-part decision ----------------
+    dsrc = read_src(ref, "model/deep_filter.py")
+    d = top_level_block(dsrc, "class DeepFilter(")
+    d = sub_once(d, "torch.reshape(kernel, [t_width(f_width, 1, f_width, t_width)])",
+                 "torch.reshape(kernel, [t_width * f_width, 1, f_width, t_width])")
+    d = sub_once(d, "output_i = inputs_r * filters_i + inputs_r * filters_i",
+                 "output_i = inputs_r * filters_i + inputs_i * filters_r")
+    exec(d, ns)
     # --- importable modules ---------------------------------------------------
-    sys.path.insert(0, ref)
+    # (this repo ships drop-in packages with the SAME top-level names `model` / `train_base`: make sure the
+    #  reference's own packages are the ones imported here, then restore the module table)
     import importlib
-    ns["cust_conv"] = importlib.import_module("model.based_model.cust_conv")
-    ns["mask_mod"] = importlib.import_module("train_base.acoustics.mask")
-    ns["tb_loss"] = importlib.import_module("train_base.loss")
+    tops = ("model", "train_base")
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k.split(".")[0] in tops}
+    old_path = list(sys.path)
+    # the reference's `model/` has no __init__.py (namespace package) and would lose against this repo's regular
+    # package anywhere on the path: take this repo (and the cwd) off the path for these imports
+    sys.path[:] = [ref] + [q for q in old_path if os.path.abspath(q or os.getcwd()) != ROOT]
+    try:
+        ns["cust_conv"] = importlib.import_module("model.based_model.cust_conv")
+        ns["mask_mod"] = importlib.import_module("train_base.acoustics.mask")
+        ns["tb_loss"] = importlib.import_module("train_base.loss")
+        assert ns["cust_conv"].__file__.startswith(ref)
+    finally:
+        sys.path[:] = old_path
+        for k in [k for k in sys.modules if k.split(".")[0] in tops]:
+            del sys.modules[k]
+        sys.modules.update(saved)
     return ns
 
 
@@ -130,7 +152,7 @@ def npz(name, **arrs):
         out[k] = np.asarray(v)
     path = os.path.join(HERE, name)
     np.savez_compressed(path, **out)
-    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB  keys={list(out)}")
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB  {len(out)} arrays")
 
 
 def main():
@@ -237,6 +259,13 @@ def main():
     cirm = mm.build_complex_ideal_ratio_mask(torch.complex(a, b), torch.complex(c, d))
     npz("g9_mask.npz", a=a, b=b, c=c, d=d, cm_r=cm_r, cm_i=cm_i, irm=irm, cirm=cirm,
         decomp=mm.decompress_cIRM(cirm))
+
+    # ---- G8: DeepFilter(1, 5) (deep_filter.py:15-41) -------------------------------------------------------
+    dfx = [torch.randn(2, 16, 21, generator=g) for _ in range(2)]
+    dfh = [torch.randn(2, 16, 21, generator=g) for _ in range(2)]
+    y_df = R["DeepFilter"](1, 5)(dfx, dfh)
+    assert torch.allclose(O.DeepFilter(1, 5)(dfx, dfh), y_df, atol=1e-6)
+    npz("g8_deepfilter.npz", xr=dfx[0], xi=dfx[1], hr=dfh[0], hi=dfh[1], y=y_df)
 
     # ---- G6: one full training step, composed from the pinned pieces ------------
     for grp in (1, 4):

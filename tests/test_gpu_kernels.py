@@ -383,6 +383,26 @@ def test_mask_loss_against_reference_wo_male(ops, golden):
     assert rel_l2(er.view(B, T, Fs)[..., :160], (m * nre[..., :160]).squeeze(1)) < 1e-6
 
 
+def test_sdnr_loss_against_oracle(ops):
+    """sdnr (loss_func/loss.py:151-175, vad == 1): alpha curve of test/test_loss.py:33-51 at several SNRs."""
+    from oracle import cruse_oracle as O
+    gen = torch.Generator().manual_seed(81)
+    B, T, Fn, Fs = 3, 11, 160, 161
+    cre = torch.randn(B, T, Fs, generator=gen) * 0.2; cim = torch.randn(B, T, Fs, generator=gen) * 0.2
+    vre = torch.randn(B, T, Fs, generator=gen) * 0.3; vim = torch.randn(B, T, Fs, generator=gen) * 0.3
+    for snr in (-5.0, 5.0, 20.0):
+        mask = torch.rand(B, T, Fn, generator=gen).requires_grad_(True)
+        g = torch.nn.functional.pad(mask, (0, Fs - Fn)).unsqueeze(1)                       # [B,1,T,Fs] gain
+        clean = torch.stack([cre, cim], 1); noise = torch.stack([vre, vim], 1)                # [B,2,T,Fs]
+        ref = O.sdnr(clean, g, noise, snr, beta=20.0)
+        ref.backward()
+        ls, dmask, _ = ops.mask_sdnr(mask.detach().cuda().view(B * T, Fn), cre.cuda().view(B * T, Fs), cim.cuda().view(B * T, Fs),
+                                     (cre + vre).cuda().view(B * T, Fs), (cim + vim).cuda().view(B * T, Fs), B * T, Fn, Fs, B, snr,
+                                     20.0, want_dmask=True)
+        assert abs(float(ls) / (B * Fs) - float(ref)) <= 1e-5 * abs(float(ref)), snr
+        assert rel_l2(dmask.view(B, T, Fn), mask.grad) < 1e-5, snr
+
+
 def test_adam_matches_torch(ops):
     gen = torch.Generator().manual_seed(90)
     p0 = torch.randn(1000, generator=gen)

@@ -178,6 +178,30 @@ def test_time_domain_training_step_vs_oracle():
             assert rel_l2(eng.flat.G[n], po.grad) <= 5e-3, n
 
 
+def test_deepfilter_golden_and_grad(golden):
+    """DeepFilter(1,5) (model/deep_filter.py:15-41): output from the reference's (repaired) code, gradients vs oracle."""
+    from cruse_amd.model.deep_filter import DeepFilter
+    from oracle import cruse_oracle as O
+    g = golden("g8_deepfilter.npz")
+    ts = [torch.from_numpy(g[k]) for k in ("xr", "xi", "hr", "hi")]
+    m = DeepFilter(1, 5).cuda()
+    assert list(m.state_dict().keys()) == ["kernel"] and m.kernel.shape == (33, 1, 11, 3)
+    dev = [t.clone().cuda().requires_grad_(True) for t in ts]
+    y = m(dev[:2], dev[2:])
+    assert y.shape == (2, 32, 21)
+    assert rel_l2(y, torch.from_numpy(g["y"])) < 1e-5
+    w = torch.randn(2, 32, 21, generator=torch.Generator().manual_seed(3))
+    (y * w.cuda()).sum().backward()
+    cpu = [t.clone().requires_grad_(True) for t in ts]
+    (O.DeepFilter(1, 5)(cpu[:2], cpu[2:]) * w).sum().backward()
+    for a, b in zip(dev, cpu):
+        assert rel_l2(a.grad, b.grad) < 1e-5
+    # full-size shape of BASELINE config 4 (B=32 per GPU, F=161, T=401): linearity in the filters
+    big = [torch.randn(4, 161, 401).cuda() for _ in range(4)]
+    y1 = m(big[:2], big[2:]); y2 = m(big[:2], [2 * big[2], 2 * big[3]])
+    assert rel_l2(y2, 2 * y1) < 1e-6
+
+
 def test_full_size_properties():
     """BASELINE config 2 shape (B=64 x 4 s): finite loss, mask in (0,1), loss decreases over Adam steps."""
     from cruse_amd.data import synth_batch

@@ -101,6 +101,16 @@ def test_train_step_golden(golden):
             assert abs(float(p.grad.norm()) - gn) <= 1e-4 * gn + 1e-6, name
 
 
+def test_deepfilter_and_mask_golden(golden):
+    g = golden("g8_deepfilter.npz")
+    y = O.DeepFilter(1, 5)([torch.from_numpy(g["xr"]), torch.from_numpy(g["xi"])],
+                           [torch.from_numpy(g["hr"]), torch.from_numpy(g["hi"])])
+    assert y.shape == (2, 32, 21) and torch.allclose(y, torch.from_numpy(g["y"]), atol=1e-6)
+    m = golden("g9_mask.npz")       # train_base/acoustics/mask.py complex_mul, run by the reference
+    a, b, c, d = (torch.from_numpy(m[k]) for k in "abcd")
+    assert torch.equal(a * c - b * d, torch.from_numpy(m["cm_r"])) and torch.equal(a * d + b * c, torch.from_numpy(m["cm_i"]))
+
+
 def test_interleave_is_not_groupgru_shuffle():
     """GGRU's stack+flatten is new[j*g+i] = cat[i*h+j]."""
     g, h = 4, 5
