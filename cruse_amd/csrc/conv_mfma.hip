@@ -4,15 +4,16 @@
 //   Out[co, n] = sum_k W[co, k] * Patch[k, n],   n = (frame, position),  k = (tap, ci)
 //
 // M = output channels (16-row MFMA tiles), N = 16 positions, K = taps x Cin in steps of 32.
-// A tile of 8 frames (+1 halo) is read from HBM once (frame-major [t][c][f] rows) and
-// TRANSPOSED while it is staged into LDS as [frame][f][ci] (channel fastest, +4 pad), so a
-// lane's B fragment -- 8 consecutive ci of one tap at one position -- is two aligned
-// ds_read_b128.  Weight fragments are pre-built once per workgroup in LDS in fragment order.
+// A tile of 8 frames (+1 halo) is read from HBM once and copied RAW into LDS (frame-major
+// [t][c][f] rows, conflict-free float4 stores); a lane's B fragment -- 8 consecutive ci of one
+// tap at one position -- is gathered with 8 scalar LDS reads and converted in registers.
+// Weight fragments are pre-converted once per workgroup in LDS in fragment order.
 // The stride-2 transposed forms (ConvTranspose2d forward, backward-data of the stride-2
 // encoder conv) are two position classes (even / odd output bins) with their own tap lists,
 // so every class is a dense GEMM.  The kernel moves 2 x 640 floats per frame through HBM
 // against <= 0.25 MFLOP per frame: it is HBM-bound, the MFMA time is negligible.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -32,6 +33,7 @@ struct CMArgs {
     int nrows;                                   // staged frames = TFM + halo
     long long sco, sci;                          // weight strides of co and ci (tap index is fastest, 3*KT long)
     int act, accum;
+    unsigned long long* dbg;                     // profiling only (CRUSE_CM_DBG)
     TapClass cls[2];
 };
 
@@ -86,108 +88,132 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
     constexpr int NPL = OpStore<PREC>::NPL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int CinP = a.Cin + OpStore<PREC>::PADC, FinP = a.Fin + 2;
     const int ks0 = (a.cls[0].ntaps * a.Cin + 31) >> 5;
     const int ks1 = a.nclass > 1 ? (a.cls[1].ntaps * a.Cin + 31) >> 5 : 0;
     const int nfrag = MT * (ks0 + ks1);
     const size_t wplane = (size_t)nfrag * 512;             // elements per weight plane
-    const size_t xplane = (size_t)a.nrows * FinP * CinP;   // elements per input plane
-    elem* wl = reinterpret_cast<elem*>(smem_raw);          // [NPL][nfrag][64 lanes][8]
-    elem* xl = wl + NPL * wplane;                          // [NPL][nrows][FinP][CinP]
-    __shared__ int s_tap[2][MAXTAP][2];
+    elem* wl = reinterpret_cast<elem*>(smem_raw);          // [NPL][nfrag][64 lanes][8]  (pre-converted once)
+    float* xl = reinterpret_cast<float*>(wl + NPL * wplane);   // [nrows][Cin][Fin]: RAW copy of the frame rows
+    __shared__ int2 s_tap2[2][MAXTAP];
 
     const int ntile = (a.T + TFM - 1) / TFM;
 
     if (tid < 2 * MAXTAP) {
         const int c = tid / MAXTAP, i = tid % MAXTAP;
-        s_tap[c][i][0] = a.cls[c].dt[i];
-        s_tap[c][i][1] = a.cls[c].df[i];
+        s_tap2[c][i] = make_int2(a.cls[c].dt[i] * a.Cin * a.Fin + a.cls[c].df[i], a.cls[c].df[i]);
     }
-    // weight fragments: frag (c, mt, ks), lane l, element e -> W[co = mt*16 + (l&15)][k = ks*32 + (l>>4)*8 + e]
-    for (int i = tid; i < nfrag * 512; i += 256) {
-        const int e = i & 7, l = (i >> 3) & 63, fr = i >> 9;
+    const int ntaps0 = a.cls[0].ntaps, ntaps1 = a.cls[1].ntaps, par0 = a.cls[0].par, par1 = a.cls[1].par;
+    // weight fragments: frag (c, mt, ks), lane l, element e -> W[co = mt*16 + (l&15)][k = ks*32 + (l>>4)*8 + e].
+    // One (fragment, lane) pair per work item: the index arithmetic is done once per 8 elements and the 8 loads
+    // are independent (Cin is a power of two, so tap/ci come from shifts).
+    const int lg_cin = 31 - __clz(a.Cin);                  // Cin is a power of two (host-checked)
+    for (int it = tid; it < nfrag * 64; it += 256) {
+        const int l = it & 63, fr = it >> 6;
         int c = 0, rem = fr;
         if (rem >= MT * ks0) { c = 1; rem -= MT * ks0; }
         const int ksn = c ? ks1 : ks0;
-        const int mt = rem / ksn, ks = rem % ksn;
+        const int mt = rem / ksn, ks = rem - mt * ksn;
         const int co = mt * 16 + (l & 15);
-        const int k = ks * 32 + (l >> 4) * 8 + e;
-        const int tap = k / a.Cin, ci = k % a.Cin;
-        float v = 0.f;
-        if (co < a.Cout && tap < a.cls[c].ntaps) v = a.w[co * a.sco + ci * a.sci + a.cls[c].wk[tap]];
-        put_elem<PREC>(wl, wplane, (size_t)i, v);
-    }
-    // zero border columns once (never overwritten)
-    for (int i = tid; i < a.nrows * 2 * a.Cin; i += 256) {
-        const int r = i / (2 * a.Cin), j = i % (2 * a.Cin);
-        const int ci = j >> 1, side = j & 1;
-        put_elem<PREC>(xl, xplane, (size_t)(r * FinP + (side ? a.Fin + 1 : 0)) * CinP + ci, 0.f);
+        const int k0 = ks * 32 + (l >> 4) * 8;
+        const int tap = k0 >> lg_cin, ci0 = k0 & (a.Cin - 1);     // 8 | Cin: the 8 elements share one tap
+        float v[8];
+        const bool ok = co < a.Cout && tap < a.cls[c].ntaps;
+        const float* wp = a.w + co * a.sco + ci0 * a.sci + (ok ? a.cls[c].wk[tap] : 0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = ok ? wp[e * a.sci] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) put_elem<PREC>(wl, wplane, (size_t)it * 8 + e, v[e]);
     }
     const int rowlen = a.Cin * a.Fin;
     const int Mpos = a.Fout / a.OS;                        // positions per frame and class
     const int ntile_c = TFM * Mpos / 16;                   // N tiles per class
+    const float inv_mpos = 1.0f / (float)Mpos;
     const int q8 = (lane >> 4) * 8;
     const int nvec = a.nrows * rowlen / 4;                 // rowlen % 4 == 0 (checked by the host)
-    // register-prefetched staging: the next tile's HBM loads are in flight while this tile computes
+    // Staging is a straight, conflict-free float4 copy of the frame rows ([t][ci][f], as in HBM).  (A first
+    // version transposed to channel-fastest rows while storing: with 32..80-byte pitches those 2-byte stores
+    // were 8..16-way bank conflicted and cost ~10 us per 8-frame tile.)  The MFMA B fragment -- 8 consecutive
+    // ci of one tap at one position -- is gathered with 8 scalar ds_reads (lanes differ in f: conflict-light).
+    // per-lane output channels are tile-invariant: fetch their biases ONCE.  (A global load inside the N-tile
+    // loop forces an in-order vmcnt wait on every older request -- the next tile's prefetch and the previous
+    // N-tile's stores -- and cost ~2 us per N-tile.)
+    float biasr[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int co = mt * 16 + (lane >> 4) * 4 + r4;
+            biasr[mt][r4] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+        }
     float4 pre[MAXV];
     auto prefetch = [&](int tile) {
         const int b = tile / ntile;
-        const int t0 = (tile % ntile) * TFM;
+        const int t0 = (tile - b * ntile) * TFM;
+        const float* src = a.x + ((long long)b * a.T + (t0 - a.halo_lo)) * rowlen;
 #pragma unroll
         for (int q = 0; q < MAXV; ++q) {
             const int i = tid + 256 * q;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < nvec) {
-                const int e0 = i * 4;
-                const int r = e0 / rowlen, j0 = e0 - r * rowlen;
+                const int r = (i * 4) / rowlen;
                 const int t = t0 - a.halo_lo + r;
-                if (t >= 0 && t < a.T) v = *reinterpret_cast<const float4*>(a.x + ((long long)b * a.T + t) * rowlen + j0);
+                if (t >= 0 && t < a.T) v = *reinterpret_cast<const float4*>(src + i * 4);
             }
             pre[q] = v;
         }
     };
     if ((int)blockIdx.x < a.B * ntile) prefetch(blockIdx.x);
+    unsigned long long tm[4] = {0, 0, 0, 0};
+    const bool prof = a.dbg != nullptr;
+    unsigned long long cstart = prof ? __builtin_amdgcn_s_memtime() : 0;
     for (int tile = blockIdx.x; tile < a.B * ntile; tile += gridDim.x) {
+        const unsigned long long c0 = prof ? __builtin_amdgcn_s_memtime() : 0;
         const int b = tile / ntile;
-        const int t0 = (tile % ntile) * TFM;
+        const int t0 = (tile - b * ntile) * TFM;
         __syncthreads();                                   // previous tile's reads of xl are done
-        // transpose while storing: [t][ci][f] (float4 along f) -> LDS [r][f+1][ci]
 #pragma unroll
         for (int q = 0; q < MAXV; ++q) {
             const int i = tid + 256 * q;
-            if (i < nvec) {
-                const int e0 = i * 4;
-                const int r = e0 / rowlen, j0 = e0 - r * rowlen;
-                const float vv[4] = {pre[q].x, pre[q].y, pre[q].z, pre[q].w};
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = j0 + u;
-                    const int ci = j / a.Fin, f = j - ci * a.Fin;
-                    put_elem<PREC>(xl, xplane, (size_t)(r * FinP + f + 1) * CinP + ci, vv[u]);
-                }
-            }
+            if (i < nvec) *reinterpret_cast<float4*>(xl + i * 4) = pre[q];
         }
         __syncthreads();
+        const unsigned long long c1 = prof ? __builtin_amdgcn_s_memtime() : 0;
         if (tile + (int)gridDim.x < a.B * ntile) prefetch(tile + gridDim.x);
+        const unsigned long long c2 = prof ? __builtin_amdgcn_s_memtime() : 0;
 
+        // N-tile loop, kept free of integer divisions (Cin is a power of two, positions via a float reciprocal)
+        // and of global loads; one 64-bit base address per N-tile.  (Keeping several N-tiles in flight per wave
+        // was measured and is slower: 78 vs 57 us on the 8->16 layer.)
         for (int nt = wv; nt < a.nclass * ntile_c; nt += 4) {
-            const int c = nt / ntile_c;
+            const int c = nt >= ntile_c ? 1 : 0;
             const int p = (nt - c * ntile_c) * 16 + (lane & 15);
-            const int tl = p / Mpos, m = p - tl * Mpos;
+            const int tl = (int)(((float)p + 0.5f) * inv_mpos);
+            const int m = p - tl * Mpos;
             const int ksn = c ? ks1 : ks0;
             const int fbase = c ? MT * ks0 : 0;
-            const int ntaps = a.cls[c].ntaps;
+            const int ntaps = c ? ntaps1 : ntaps0;
             f32x4 acc[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int rowbase = (tl + a.halo_lo) * rowlen + a.S * m;
             for (int ks = 0; ks < ksn; ++ks) {
                 const int k = ks * 32 + q8;
-                int tap = k / a.Cin;
-                const int ci0 = k - tap * a.Cin;
+                int tap = k >> lg_cin;
+                const int ci0 = k & (a.Cin - 1);
                 if (tap >= ntaps) tap = ntaps - 1;        // zero weights there; keep the address valid
-                const int r = tl + a.halo_lo + s_tap[c][tap][0];
-                const int f = a.S * m + s_tap[c][tap][1];
-                const Frag<PREC> fb = get_frag<PREC>(xl, xplane, (size_t)(r * FinP + f + 1) * CinP + ci0);
+                const int2 tp = s_tap2[c][tap];           // x = dt*rowlen + df, y = df
+                const int f = a.S * m + tp.y;
+                float bv[8];
+                if (f >= 0 && f < a.Fin) {
+                    const float* pb = xl + rowbase + tp.x + ci0 * a.Fin;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bv[e] = pb[e * a.Fin];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+                }
+                Frag<PREC> fb;
+                fb.set(bv);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const Frag<PREC> fa = get_frag<PREC>(wl, wplane, ((size_t)(fbase + mt * ksn + ks) * 64 + lane) * 8);
@@ -196,23 +222,28 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
             }
             const int t = t0 + tl;
             if (t < a.T) {
-                const int fo = a.OS * m + a.cls[c].par;
+                const int fo = a.OS * m + (c ? par1 : par0);
+                float* yb = a.y + (((long long)b * a.T + t) * a.Cout + (lane >> 4) * 4) * a.Fout + fo;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) {
                         const int co = mt * 16 + (lane >> 4) * 4 + r4;
                         if (co < a.Cout) {
-                            const long long idx = (((long long)b * a.T + t) * a.Cout + co) * a.Fout + fo;
-                            float v = acc[mt][r4] + (a.bias ? a.bias[co] : 0.f);
-                            if (a.accum) v += a.y[idx];
+                            float* yp = yb + (mt * 16 + r4) * a.Fout;
+                            float v = acc[mt][r4] + biasr[mt][r4];
+                            if (a.accum) v += *yp;
                             else if (a.act == 1) v = sigmoid_acc(v);
-                            a.y[idx] = v;
+                            *yp = v;
                         }
                     }
                 }
             }
         }
+        if (prof) { const unsigned long long c3 = __builtin_amdgcn_s_memtime(); tm[0] += c1 - c0; tm[1] += c2 - c1; tm[2] += c3 - c2; tm[3] += 1; }
+    }
+    if (prof && blockIdx.x == 0 && tid == 0) {
+        a.dbg[0] = tm[0]; a.dbg[1] = tm[1]; a.dbg[2] = tm[2]; a.dbg[3] = tm[3]; a.dbg[4] = cstart; a.dbg[5] = __builtin_amdgcn_s_memtime();
     }
 }
 
@@ -239,7 +270,7 @@ int launch_mt(const CMArgs& a, int grid, size_t lds, hipStream_t s) {
 int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float* bias, float* y,
                         int B, int T, int Cin, int Fin, int Cout, int Fout, int KT, int S, int pad,
                         int w_layout, int act, int accum, int prec, hipStream_t stream) {
-    if (Cin % 8 != 0 || Cout < 8 || Cout > 64 || (TFM * (Fout / (scatter ? 2 : 1))) % 16 != 0) return 0;
+    if (Cin % 8 != 0 || (Cin & (Cin - 1)) != 0 || Cout < 8 || Cout > 64 || (TFM * (Fout / (scatter ? 2 : 1))) % 16 != 0) return 0;
     CMArgs a = {};
     a.x = x; a.w = w; a.bias = bias; a.y = y;
     a.B = B; a.T = T; a.Cin = Cin; a.Fin = Fin; a.Cout = Cout; a.Fout = Fout;
@@ -280,15 +311,27 @@ int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float
     const int mt = Cout <= 16 ? 1 : (Cout <= 32 ? 2 : 4);
     if ((Cin * Fin) % 4 != 0 || ((uintptr_t)x % 16) != 0) return 0;
     if ((TFM + KT - 1) * Cin * Fin > MAXV * 256 * 4) return 0;
-    size_t lds;
-    if (prec == CRUSE_PREC_F32)
-        lds = ((size_t)mt * (ks0 + ks1) * 512 + (size_t)a.nrows * (Fin + 2) * (Cin + 4)) * sizeof(float);
-    else
-        lds = ((size_t)mt * (ks0 + ks1) * 512 + (size_t)a.nrows * (Fin + 2) * (Cin + 8)) * 2 *
-              (prec == CRUSE_PREC_BF16X3 ? 2 : 1);
+    const size_t wbytes = (size_t)mt * (ks0 + ks1) * 512 *
+                          (prec == CRUSE_PREC_F32 ? 4 : (prec == CRUSE_PREC_BF16X3 ? 4 : 2));
+    const size_t lds = wbytes + (size_t)a.nrows * Cin * Fin * sizeof(float);
     if (lds > 150 * 1024) return 0;
+    static unsigned long long* dbgbuf = nullptr;
+    if (getenv("CRUSE_CM_DBG")) {
+        if (!dbgbuf) hipMalloc(&dbgbuf, 128);
+        else {
+            unsigned long long h[9];
+            hipMemcpy(h, dbgbuf, sizeof(h), hipMemcpyDeviceToHost);
+            fprintf(stderr, "[conv_mfma prev launch] tiles %llu  stage %llu  prefetch-issue %llu  compute %llu cycles/tile; kernel %llu cycles\n",
+                    h[3], h[3] ? h[0] / h[3] : 0, h[3] ? h[1] / h[3] : 0, h[3] ? h[2] / h[3] : 0, h[5] - h[4]);
+        }
+        a.dbg = dbgbuf;
+    }
     const int ntiles = B * ((T + TFM - 1) / TFM);
-    const int grid = ntiles < 512 ? ntiles : 512;
+    // small weight images: more, lighter workgroups hide latency better (44 vs 60 us on the 8->16 layer);
+    // large ones (up to 48 KB of fragments per workgroup) amortise their prologue over more tiles
+    int gmax = wbytes <= 16 * 1024 ? 1024 : 512;
+    { const char* e = getenv("CRUSE_CM_GRID"); if (e) gmax = atoi(e); }
+    const int grid = ntiles < gmax ? ntiles : gmax;
     int rc;
     if (prec == CRUSE_PREC_F32) rc = launch_mt<CRUSE_PREC_F32>(a, grid, lds, stream);
     else if (prec == CRUSE_PREC_BF16) rc = launch_mt<CRUSE_PREC_BF16>(a, grid, lds, stream);
