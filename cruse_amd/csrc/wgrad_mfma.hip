@@ -79,25 +79,63 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WMArgs p) {
 #pragma unroll
         for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // ---- tile-invariant coordinates, computed once (the runtime integer divisions they need used to sit
+    //      in the per-element loops and dominated the kernel) -------------------------------------------------
+    // A staging: slot q covers 4 consecutive floats of the [TFW][Ca][Fa] tile; LDS offset per element
+    int a_off[MAXV][4];
+    bool a_ok[MAXV];
+#pragma unroll
+    for (int q = 0; q < MAXV; ++q) {
+        const int i = tid + 256 * q;
+        a_ok[q] = i < nva;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = min(i, nva - 1) * 4 + u;
+            const int r = e / rowa, j = e - r * rowa;
+            const int ca = j / p.Fa, fa = j - ca * p.Fa;
+            a_off[q][u] = (ca * TFW + r) * FaP + fa;
+        }
+    }
+    // patch build: 768 virtual threads (3 slots per thread); virtual thread vt owns position vt % P of the
+    // TFW x Fa tile and the channels cb = vt / P, + ngroups, ... -- all offsets fixed per slot
+    constexpr int MAXP = 3;
+    const int P = TFW * p.Fa;
+    const int ngroups = max(1, (256 * MAXP) / P);
+    int p_dst[MAXP], p_cb0[MAXP], p_src[MAXP][3];            // dst = tl*FaP + fa; src[kf] = tl*Cb*Fb + fb (or -1)
+#pragma unroll
+    for (int sidx = 0; sidx < MAXP; ++sidx) {
+        const int vt = tid + 256 * sidx;
+        const int grp = vt / P, pos = vt - grp * P;
+        p_dst[sidx] = -1; p_cb0[sidx] = 0;
+#pragma unroll
+        for (int kf = 0; kf < 3; ++kf) p_src[sidx][kf] = -1;
+        if (grp < ngroups) {
+            const int tl = pos / p.Fa, fa = pos - tl * p.Fa;
+            p_dst[sidx] = tl * FaP + fa;
+            p_cb0[sidx] = grp;
+#pragma unroll
+            for (int kf = 0; kf < 3; ++kf) {
+                const int fb = fa * p.S - p.pad + kf;
+                p_src[sidx][kf] = (fb >= 0 && fb < p.Fb) ? tl * rowb + fb : -1;
+            }
+        }
+    }
     float4 pa[MAXV], pb[MAXV];
     auto prefetch = [&](int tile) {
         const int b = tile / ntile_t;
-        const int t0 = (tile % ntile_t) * TFW;
+        const int t0 = (tile - b * ntile_t) * TFW;
+        const float* srca = p.a + ((long long)b * p.T + t0) * rowa;
+        const float* srcb = p.bt + ((long long)b * p.T + (t0 - (p.KT - 1))) * rowb;
 #pragma unroll
         for (int q = 0; q < MAXV; ++q) {
             const int i = tid + 256 * q;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < nva) {
-                const int e0 = i * 4, r = e0 / rowa;
-                if (t0 + r < p.T) v = *reinterpret_cast<const float4*>(p.a + ((long long)b * p.T + t0) * rowa + e0);
-            }
+            if (i < nva && t0 + (i * 4) / rowa < p.T) v = *reinterpret_cast<const float4*>(srca + i * 4);
             pa[q] = v;
             float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < nvb) {
-                const int e0 = i * 4, r = e0 / rowb;
-                const int t = t0 - (p.KT - 1) + r;
-                if (t >= 0 && t < p.T)
-                    w = *reinterpret_cast<const float4*>(p.bt + ((long long)b * p.T + t) * rowb + (e0 - r * rowb));
+                const int t = t0 - (p.KT - 1) + (i * 4) / rowb;
+                if (t >= 0 && t < p.T) w = *reinterpret_cast<const float4*>(srcb + i * 4);
             }
             pb[q] = w;
         }
@@ -106,36 +144,34 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WMArgs p) {
     const int nks = TFW * p.NCH / 4;                         // K steps per tile (TFW*NCH % 4 == 0, host-checked)
     for (int tile = blockIdx.x; tile < p.ntiles_total; tile += gridDim.x) {
         __syncthreads();                                     // previous tile's fragment reads are done
-        // A image: [t][ca][fa] -> al[ca][tl][fa];  raw bt frames -> rawl
+        // A image: [t][ca][fa] -> al[ca][tl][fa];  raw bt frames -> rawl (straight copy)
 #pragma unroll
         for (int q = 0; q < MAXV; ++q) {
-            const int i = tid + 256 * q;
-            if (i < nva) {
-                const int e0 = i * 4, r = e0 / rowa, j0 = e0 - r * rowa;
+            if (a_ok[q]) {
                 const float vv[4] = {pa[q].x, pa[q].y, pa[q].z, pa[q].w};
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = j0 + u;
-                    const int ca = j / p.Fa, fa = j - ca * p.Fa;
-                    wput<PREC>(al, aplane, ((size_t)ca * TFW + r) * FaP + fa, vv[u]);
-                }
+                for (int u = 0; u < 4; ++u) wput<PREC>(al, aplane, (size_t)a_off[q][u], vv[u]);
             }
+            const int i = tid + 256 * q;
             if (i < nvb) *reinterpret_cast<float4*>(rawl + i * 4) = pb[q];
         }
         __syncthreads();
         if (tile + (int)gridDim.x < p.ntiles_total) prefetch(tile + gridDim.x);
         // patch image: pl[j = tap*Cb + cb][tl][fa] = bt[tl + kt][cb][fa*S - pad + kf]
-        const int npatch = p.ntaps * p.Cb * TFW * p.Fa;
-        for (int i = tid; i < npatch; i += 256) {
-            const int fa = i % p.Fa;
-            int rem = i / p.Fa;
-            const int tl = rem % TFW; rem /= TFW;
-            const int cb = rem % p.Cb, tap = rem / p.Cb;
-            const int kt = tap / 3, kf = tap - kt * 3;
-            const int fb = fa * p.S - p.pad + kf;
-            float v = 0.f;
-            if (fb >= 0 && fb < p.Fb) v = rawl[((tl + kt) * p.Cb + cb) * p.Fb + fb];
-            wput<PREC>(pl, bplane, ((size_t)(tap * p.Cb + cb) * TFW + tl) * FaP + fa, v);
+#pragma unroll
+        for (int sidx = 0; sidx < MAXP; ++sidx) {
+            if (p_dst[sidx] < 0) continue;
+            for (int cb = p_cb0[sidx]; cb < p.Cb; cb += ngroups) {
+                for (int kt = 0; kt < p.KT; ++kt) {
+                    const float* rsrc = rawl + (kt * p.Cb + cb) * p.Fb;
+#pragma unroll
+                    for (int kf = 0; kf < 3; ++kf) {
+                        const int so = p_src[sidx][kf];
+                        wput<PREC>(pl, bplane, (size_t)((kt * 3 + kf) * p.Cb + cb) * TFW * FaP + p_dst[sidx],
+                                   so >= 0 ? rsrc[so] : 0.f);
+                    }
+                }
+            }
         }
         __syncthreads();
         for (int ks = 0; ks < nks; ++ks) {
@@ -213,6 +249,7 @@ int cruse_wgrad_mfma_try(const float* a, const float* bt, float* partial, int ma
     if ((tfw * NCH) % 4 != 0) return 0;
     if ((Ca * Fa) % 4 != 0 || (Cb * Fb) % 4 != 0 || ((uintptr_t)a % 16) != 0 || ((uintptr_t)bt % 16) != 0) return 0;
     if (tfw * Ca * Fa > MAXV * 1024 || (tfw + KT - 1) * Cb * Fb > MAXV * 1024) return 0;
+    if (tfw * Fa > 768) return 0;
     const int esz = (prec == CRUSE_PREC_F32) ? 4 : 2, npl = (prec == CRUSE_PREC_BF16X3) ? 2 : 1;
     const size_t lds = ((size_t)mt * 16 + (size_t)ntw * 64) * tfw * FaP * esz * npl +
                        (size_t)(tfw + KT - 1) * Cb * Fb * 4;
