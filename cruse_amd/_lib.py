@@ -36,7 +36,7 @@ SIGNATURES = {
     "cruse_bn_eval_stats": ("ppifppp", "i"),
     "cruse_bn_act_fwd": ("pppppppqiiip", "i"),
     "cruse_bn_act_bwd_reduce": ("ppppppqiiipp", "i"),
-    "cruse_bn_act_bwd_apply": ("pppppppqiiiipppp", "i"),
+    "cruse_bn_act_bwd_apply": ("pppppppqiiiippppp", "i"),
     "cruse_ln_fwd": ("pppppppqiifp", "i"),
     "cruse_ln_bwd": ("pppppqiipppp", "i"),
     "cruse_gemm": ("iiiiipipipipiiiip", "i"),

@@ -11,39 +11,56 @@
 namespace {
 
 // ------------------------------------------------------------------ BatchNorm ---
-// sums[c] += sum v, sums[C+c] += sum v2 where (v, v2) come from functor F per element.
+// sums[c] += sum v, sums[C+c] += sum v2 where (v, v2) come from functor fn per element.
+// One WAVE per row (grid-stride over rows): lane l owns the float4 column groups l, l+64, l+128, ... of the
+// C*F-wide frame row, so every access is a 16-byte load and a lane's partial sums stay in registers across
+// all its rows (f32 runs of 32 rows folded into f64); the per-channel reduction happens once at the end.
+constexpr int CPR_MAXG = 3;          // float4 groups per lane: C*F <= 768
+
 template <typename Fn>
 __device__ __forceinline__ void channel_pair_reduce(long long rows, int C, int F, double* sums, Fn fn) {
     __shared__ double s1[256], s2[256];
-    const int CF = C * F;
-    const int tid = threadIdx.x;
+    const int CF = C * F, ng = CF >> 2;
+    const int tid = threadIdx.x, lane = tid & 63;
     for (int c = tid; c < C; c += 256) { s1[c] = 0.0; s2[c] = 0.0; }
     __syncthreads();
-    for (int j0 = 0; j0 < CF; j0 += 256) {
-        const int j = j0 + tid;
-        if (j < CF) {
-            const int c = j / F;
-            // 2 independent row streams per thread (more loads in flight), f32 partials folded into f64
-            float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
-            int n = 0;
-            double da = 0.0, db = 0.0;
-            const long long G = gridDim.x;
-            long long r = blockIdx.x;
-            for (; r + G < rows; r += 2 * G) {
-                float v, v2, w, w2;
-                fn(r * CF + j, c, v, v2);
-                fn((r + G) * CF + j, c, w, w2);
-                a0 += v; b0 += v2; a1 += w; b1 += w2;
-                if (++n == 32) { da += (double)a0 + (double)a1; db += (double)b0 + (double)b1; a0 = b0 = a1 = b1 = 0.f; n = 0; }
+    float a[CPR_MAXG][4], b[CPR_MAXG][4];
+    double da[CPR_MAXG][4], db[CPR_MAXG][4];
+#pragma unroll
+    for (int g = 0; g < CPR_MAXG; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[g][e] = b[g][e] = 0.f; da[g][e] = db[g][e] = 0.0; }
+    const long long wave = (long long)blockIdx.x * 4 + (tid >> 6), nwave = (long long)gridDim.x * 4;
+    int n = 0;
+    for (long long r = wave; r < rows; r += nwave) {
+#pragma unroll
+        for (int g = 0; g < CPR_MAXG; ++g) {
+            const int q = lane + 64 * g;
+            if (q < ng) {
+                float v[4], v2[4];
+                fn(r * CF + q * 4, g, v, v2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a[g][e] += v[e]; b[g][e] += v2[e]; }
             }
-            for (; r < rows; r += G) {
-                float v, v2;
-                fn(r * CF + j, c, v, v2);
-                a0 += v; b0 += v2;
+        }
+        if (++n == 32) {
+#pragma unroll
+            for (int g = 0; g < CPR_MAXG; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { da[g][e] += a[g][e]; db[g][e] += b[g][e]; a[g][e] = b[g][e] = 0.f; }
+            n = 0;
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < CPR_MAXG; ++g) {
+        const int q = lane + 64 * g;
+        if (q < ng) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = (q * 4 + e) / F;
+                atomicAdd(&s1[c], da[g][e] + (double)a[g][e]);
+                atomicAdd(&s2[c], db[g][e] + (double)b[g][e]);
             }
-            da += (double)a0 + (double)a1; db += (double)b0 + (double)b1;
-            atomicAdd(&s1[c], da);
-            atomicAdd(&s2[c], db);
         }
     }
     __syncthreads();
@@ -54,9 +71,11 @@ __device__ __forceinline__ void channel_pair_reduce(long long rows, int C, int F
 }
 
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* y, long long rows, int C, int F, double* sums) {
-    channel_pair_reduce(rows, C, F, sums, [&](long long i, int, float& v, float& v2) {
-        const float t = y[i];
-        v = t; v2 = t * t;
+    channel_pair_reduce(rows, C, F, sums, [&](long long i, int, float (&v)[4], float (&v2)[4]) {
+        const float4 t = *reinterpret_cast<const float4*>(y + i);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v2[e] = v[e] * v[e];
     });
 }
 
@@ -116,49 +135,104 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* dou
                                                                 const float* rstd, const float* gamma,
                                                                 const float* beta, long long rows, int C, int F,
                                                                 int relu, double* sums) {
-    channel_pair_reduce(rows, C, F, sums, [&](long long i, int c, float& v, float& v2) {
-        const float xh = (y[i] - mean[c]) * rstd[c];
-        float g = dout[i];
-        if (relu && !(xh * gamma[c] + beta[c] > 0.f)) g = 0.f;
-        v = g; v2 = g * xh;
+    // per-lane column constants (the lane's columns never change across rows)
+    __shared__ float tab[4][256];
+    float pm[CPR_MAXG][4], pr[CPR_MAXG][4], pg[CPR_MAXG][4], pb[CPR_MAXG][4];
+    const int lane = threadIdx.x & 63;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        tab[0][c] = mean[c]; tab[1][c] = rstd[c]; tab[2][c] = gamma[c]; tab[3][c] = beta[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < CPR_MAXG; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int col = (lane + 64 * g) * 4 + e;
+            const int c = col < C * F ? col / F : 0;
+            pm[g][e] = tab[0][c]; pr[g][e] = tab[1][c]; pg[g][e] = tab[2][c]; pb[g][e] = tab[3][c];
+        }
+    channel_pair_reduce(rows, C, F, sums, [&](long long i, int g, float (&v)[4], float (&v2)[4]) {
+        const float4 yy = *reinterpret_cast<const float4*>(y + i);
+        const float4 dd = *reinterpret_cast<const float4*>(dout + i);
+        const float yv[4] = {yy.x, yy.y, yy.z, yy.w}, dv[4] = {dd.x, dd.y, dd.z, dd.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (yv[e] - pm[g][e]) * pr[g][e];
+            float gr = dv[e];
+            if (relu && !(xh * pg[g][e] + pb[g][e] > 0.f)) gr = 0.f;
+            v[e] = gr; v2[e] = gr * xh;
+        }
     });
 }
 
+// wave-per-row like channel_pair_reduce: a lane's columns are fixed, so its six per-channel constants live in
+// registers and sum(dy) per channel (the gradient of the conv bias that feeds this BN) comes for free.
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* dout, const float* y, const float* mean,
                                                                const float* rstd, const float* gamma,
                                                                const float* beta, const double* sums, long long rows,
                                                                int C, int F, int relu, int training, float* dy,
-                                                               float* dgamma, float* dbeta) {
-    extern __shared__ float tab[];  // [6][C]: mean, rstd, gamma, beta, sg/count, sgx/count
+                                                               float* dgamma, float* dbeta, float* dbias) {
+    __shared__ float sb[256], tab[6][256];
     const double cnt = (double)rows * F;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        tab[c] = mean[c]; tab[C + c] = rstd[c]; tab[2 * C + c] = gamma[c]; tab[3 * C + c] = beta[c];
-        tab[4 * C + c] = training ? (float)(sums[c] / cnt) : 0.f;
-        tab[5 * C + c] = training ? (float)(sums[C + c] / cnt) : 0.f;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int CF = C * F, ng = CF >> 2;
+    for (int c = tid; c < C; c += 256) {
+        sb[c] = 0.f;
+        tab[0][c] = mean[c]; tab[1][c] = rstd[c]; tab[2][c] = gamma[c]; tab[3][c] = beta[c];
+        tab[4][c] = training ? (float)(sums[c] / cnt) : 0.f;
+        tab[5][c] = training ? (float)(sums[C + c] / cnt) : 0.f;
         if (blockIdx.x == 0) {
             if (dgamma) dgamma[c] += (float)sums[C + c];
             if (dbeta) dbeta[c] += (float)sums[c];
         }
     }
     __syncthreads();
-    const int CF = C * F;
-    const long long n4 = rows * CF / 4;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-        const float4 v = reinterpret_cast<const float4*>(y)[i];
-        const float4 d = reinterpret_cast<const float4*>(dout)[i];
-        const int j = (int)((i * 4) % CF);
-        float in[4] = {v.x, v.y, v.z, v.w};
-        float dd[4] = {d.x, d.y, d.z, d.w};
-        float o[4];
+    float pm[CPR_MAXG][4], pr[CPR_MAXG][4], pg[CPR_MAXG][4], pb[CPR_MAXG][4], p1[CPR_MAXG][4], p2[CPR_MAXG][4];
+    float acc[CPR_MAXG][4];
+#pragma unroll
+    for (int g = 0; g < CPR_MAXG; ++g)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int c = (j + e) / F;
-            const float xh = (in[e] - tab[c]) * tab[C + c];
-            float g = dd[e];
-            if (relu && !(xh * tab[2 * C + c] + tab[3 * C + c] > 0.f)) g = 0.f;
-            o[e] = tab[2 * C + c] * tab[C + c] * (g - tab[4 * C + c] - xh * tab[5 * C + c]);
+            const int col = (lane + 64 * g) * 4 + e;
+            const int c = col < CF ? col / F : 0;
+            pm[g][e] = tab[0][c]; pr[g][e] = tab[1][c]; pg[g][e] = tab[2][c]; pb[g][e] = tab[3][c];
+            p1[g][e] = tab[4][c]; p2[g][e] = tab[5][c];
+            acc[g][e] = 0.f;
         }
-        reinterpret_cast<float4*>(dy)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    const long long wave = (long long)blockIdx.x * 4 + (tid >> 6), nwave = (long long)gridDim.x * 4;
+    for (long long r = wave; r < rows; r += nwave) {
+#pragma unroll
+        for (int g = 0; g < CPR_MAXG; ++g) {
+            const int q = lane + 64 * g;
+            if (q < ng) {
+                const long long i = r * CF + q * 4;
+                const float4 v = *reinterpret_cast<const float4*>(y + i);
+                const float4 d = *reinterpret_cast<const float4*>(dout + i);
+                const float in[4] = {v.x, v.y, v.z, v.w}, dd[4] = {d.x, d.y, d.z, d.w};
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = (in[e] - pm[g][e]) * pr[g][e];
+                    float gr = dd[e];
+                    if (relu && !(xh * pg[g][e] + pb[g][e] > 0.f)) gr = 0.f;
+                    o[e] = pg[g][e] * pr[g][e] * (gr - p1[g][e] - xh * p2[g][e]);
+                    acc[g][e] += o[e];
+                }
+                *reinterpret_cast<float4*>(dy + i) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+    if (dbias) {
+#pragma unroll
+        for (int g = 0; g < CPR_MAXG; ++g) {
+            const int q = lane + 64 * g;
+            if (q < ng) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(&sb[(q * 4 + e) / F], acc[g][e]);
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) atomicAdd(&dbias[c], sb[c]);
     }
 }
 
@@ -345,8 +419,9 @@ inline int grid_for(long long n, int per_block, int cap = 4096) {
 
 extern "C" int cruse_bn_stats(const float* y, long long rows, int C, int F, double* sums, void* stream) {
     CRUSE_REQUIRE(rows > 0 && C > 0 && C <= 256 && F > 0, CRUSE_E_SHAPE, "bn_stats: bad shape rows=%lld C=%d F=%d", rows, C, F);
+    CRUSE_REQUIRE((C * F) % 4 == 0 && C * F <= 768, CRUSE_E_SHAPE, "bn_stats: C*F=%d must be a multiple of 4 and <= 768", C * F);
     { int zrc = cruse_zero_async(sums, 2 * C * sizeof(double), ST(stream), "bn_stats memset"); if (zrc) return zrc; }
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(rows, 8, 1024)), dim3(256), 0, ST(stream), y, rows, C, F, sums);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(rows, 16, 1024)), dim3(256), 0, ST(stream), y, rows, C, F, sums);
     CRUSE_LAUNCH_CHECK("bn_stats");
     return CRUSE_OK;
 }
@@ -385,8 +460,9 @@ extern "C" int cruse_bn_act_bwd_reduce(const float* dout, const float* y, const 
                                        const float* gamma, const float* beta, long long rows, int C, int F,
                                        int relu, double* sums, void* stream) {
     CRUSE_REQUIRE(rows > 0 && C > 0 && C <= 256 && F > 0, CRUSE_E_SHAPE, "bn_act_bwd_reduce: bad shape");
+    CRUSE_REQUIRE((C * F) % 4 == 0 && C * F <= 768, CRUSE_E_SHAPE, "bn_act_bwd_reduce: C*F=%d must be a multiple of 4 and <= 768", C * F);
     { int zrc = cruse_zero_async(sums, 2 * C * sizeof(double), ST(stream), "bn_act_bwd_reduce memset"); if (zrc) return zrc; }
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(grid_for(rows, 8, 1024)), dim3(256), 0, ST(stream), dout, y, mean,
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(grid_for(rows, 16, 1024)), dim3(256), 0, ST(stream), dout, y, mean,
                        rstd, gamma, beta, rows, C, F, relu, sums);
     CRUSE_LAUNCH_CHECK("bn_act_bwd_reduce");
     return CRUSE_OK;
@@ -395,12 +471,12 @@ extern "C" int cruse_bn_act_bwd_reduce(const float* dout, const float* y, const 
 extern "C" int cruse_bn_act_bwd_apply(const float* dout, const float* y, const float* mean, const float* rstd,
                                       const float* gamma, const float* beta, const double* sums,
                                       long long rows, int C, int F, int relu, int training,
-                                      float* dy, float* dgamma, float* dbeta, void* stream) {
-    CRUSE_REQUIRE(rows > 0 && C > 0 && F > 0, CRUSE_E_SHAPE, "bn_act_bwd_apply: bad shape");
-    CRUSE_REQUIRE((C * F) % 4 == 0, CRUSE_E_ALIGN, "bn_act_bwd_apply: C*F=%d must be a multiple of 4", C * F);
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for(rows * C * F / 4, 1024)), dim3(256),
-                       6 * C * sizeof(float), ST(stream), dout, y, mean, rstd, gamma, beta, sums, rows, C, F, relu,
-                       training, dy, dgamma, dbeta);
+                                      float* dy, float* dgamma, float* dbeta, float* dbias, void* stream) {
+    CRUSE_REQUIRE(rows > 0 && C > 0 && C <= 256 && F > 0, CRUSE_E_SHAPE, "bn_act_bwd_apply: bad shape");
+    CRUSE_REQUIRE((C * F) % 4 == 0 && C * F <= 768, CRUSE_E_SHAPE,
+                  "bn_act_bwd_apply: C*F=%d must be a multiple of 4 and <= 768", C * F);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for(rows, 16, 1024)), dim3(256), 0, ST(stream), dout, y,
+                       mean, rstd, gamma, beta, sums, rows, C, F, relu, training, dy, dgamma, dbeta, dbias);
     CRUSE_LAUNCH_CHECK("bn_act_bwd_apply");
     return CRUSE_OK;
 }

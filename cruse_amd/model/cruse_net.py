@@ -232,10 +232,10 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
     for k in range(2, L + 1):
         mean, rstd = dstats[k]
         dv = ops.bn_act_bwd(du, vs[k], mean, rstd, P[f"bn{k}_t.weight"], P[f"bn{k}_t.bias"], rows, ch[k - 1],
-                            Fk[k - 1], True, training, G[f"bn{k}_t.weight"], G[f"bn{k}_t.bias"])
+                            Fk[k - 1], True, training, G[f"bn{k}_t.weight"], G[f"bn{k}_t.bias"],
+                            dbias=G[f"conv{k}_t.bias"])
 
         def leaf_dec(dv=dv, k=k):
-            ops.channel_sum(dv, rows, ch[k - 1], Fk[k - 1], G[f"conv{k}_t.bias"])
             ops.conv_wgrad(us[k], dv, G[f"conv{k}_t.weight"], B, T, ch[k], Fk[k], ch[k - 1], Fk[k - 1], KT=1, S=2, pad=0, prec=prec)
         SIDE.run(leaf_dec, dv)
         du = ops.conv_gather(dv, P[f"conv{k}_t.weight"], None, B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k], KT=1, S=2, pad=0,
@@ -255,10 +255,9 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
         SIDE.run(leaf_skip, ds[k])
         mean, rstd = stats[k]
         dy = ops.bn_act_bwd(de, ys[k], mean, rstd, P[f"bn{k}.weight"], P[f"bn{k}.bias"], rows, ch[k], Fk[k], True,
-                            training, G[f"bn{k}.weight"], G[f"bn{k}.bias"])
+                            training, G[f"bn{k}.weight"], G[f"bn{k}.bias"], dbias=G[f"conv{k}.bias"])
 
         def leaf_enc(dy=dy, k=k):
-            ops.channel_sum(dy, rows, ch[k], Fk[k], G[f"conv{k}.bias"])
             ops.conv_wgrad(dy, es[k - 1], G[f"conv{k}.weight"], B, T, ch[k], Fk[k], ch[k - 1], Fk[k - 1], KT=2, S=2, pad=1, prec=prec)
         SIDE.run(leaf_enc, dy)
         if k > 1:

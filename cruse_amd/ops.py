@@ -169,14 +169,14 @@ def bn_act_fwd(y, mean, rstd, gamma, beta, skip, rows, C, F, relu=True):
     return out
 
 
-def bn_act_bwd(dout, y, mean, rstd, gamma, beta, rows, C, F, relu, training, dgamma, dbeta):
+def bn_act_bwd(dout, y, mean, rstd, gamma, beta, rows, C, F, relu, training, dgamma, dbeta, dbias=None):
     sums = torch.empty(2 * C, device=y.device, dtype=torch.float64)
     check(lib.cruse_bn_act_bwd_reduce(_p(dout), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), rows, C, F,
                                       1 if relu else 0, _p(sums), _stream()))
     dy = torch.empty_like(y)
     check(lib.cruse_bn_act_bwd_apply(_p(dout), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(sums), rows, C, F,
                                      1 if relu else 0, 1 if training else 0, _p(dy), _p(dgamma), _p(dbeta),
-                                     _stream()))
+                                     _p(dbias), _stream()))
     return dy
 
 

@@ -125,11 +125,12 @@ int cruse_bn_act_fwd(const float* y, const float* mean, const float* rstd, const
 int cruse_bn_act_bwd_reduce(const float* dout, const float* y, const float* mean, const float* rstd,
                             const float* gamma, const float* beta, long long rows, int C, int F,
                             int relu, double* sums, void* stream);
-/* dy = gamma*rstd*(g - [training](sum_g + xhat*sum_gx)/count); dgamma += sum_gx; dbeta += sum_g */
+/* dy = gamma*rstd*(g - [training](sum_g + xhat*sum_gx)/count); dgamma += sum_gx; dbeta += sum_g;
+ * dbias (nullable) += per-channel sum of dy -- the gradient of the bias of the conv that feeds this BN */
 int cruse_bn_act_bwd_apply(const float* dout, const float* y, const float* mean, const float* rstd,
                            const float* gamma, const float* beta, const double* sums,
                            long long rows, int C, int F, int relu, int training,
-                           float* dy, float* dgamma, float* dbeta, void* stream);
+                           float* dy, float* dgamma, float* dbeta, float* dbias, void* stream);
 
 /* ---- LayerNorm (+ group interleave, + residual) (cruse_net.py:32-33,43-51,160) -- */
 

@@ -225,6 +225,11 @@ def test_batchnorm_relu_skip_fwd_bwd(ops, C, Fq):
     m2, r2 = ops.bn_eval_stats(rm, rv, 1e-5)
     out_e = ops.bn_act_fwd(y.cuda(), m2, r2, bn.weight.detach().cuda(), bn.bias.detach().cuda(), None, rows, C, Fq)
     assert rel_l2(_nchw(out_e), torch.relu(bn(_nchw(y)))) < 1e-5
+    # the fused conv-bias gradient is the per-channel sum of dy (non-trivial in eval mode)
+    dbias = torch.zeros(C).cuda()
+    dy_e = ops.bn_act_bwd(dout.cuda(), y.cuda(), m2, r2, bn.weight.detach().cuda(), bn.bias.detach().cuda(), rows, C, Fq,
+                          True, False, None, None, dbias=dbias)
+    assert rel_l2(dbias, dy_e.double().sum(dim=(0, 1, 3)).float()) < 1e-5
 
 
 @pytest.mark.parametrize("H,g", [(640, 1), (640, 4), (1024, 2), (96, 3)])
