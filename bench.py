@@ -86,7 +86,8 @@ class KernelTimer:
     """Wraps cruse_amd.ops entry points with HIP events on torch's current stream (where the kernels run)."""
 
     NAMES = ["stft", "conv_gather", "conv_scatter2", "conv_wgrad", "channel_sum", "col_sum", "bn_stats", "bn_finalize",
-             "bn_act_fwd", "bn_act_bwd", "ln_fwd", "ln_bwd", "gemm", "gru_seq_fwd", "gru_seq_bwd", "gru_gate_grads", "mask_loss"]
+             "bn_act_fwd", "bn_act_bwd", "ln_fwd", "ln_bwd", "gemm", "gemm_bf16_nt", "cast_bf16", "transpose_bf16",
+             "gru_seq_fwd", "gru_seq_bwd", "gru_gate_grads", "gru_gate_grads_bf16", "mask_loss"]
 
     def __init__(self, ops):
         self.ops, self.rec, self.saved = ops, [], {}
@@ -138,12 +139,14 @@ def kernel_rooflines(B, T, H, G, prec, per_step_ms, calls):
                          "avg_launch_ms": round(avg_ms, 4),
                          "note": f"latency-bound by design: {T} dependent steps per launch, "
                                  f"{avg_ms * 1e3 / T:.2f} us per step"}
-    if "gemm" in per_step_ms:
-        flops = 2.0 * rows * 3 * Hg * Hg * G * 8             # 2 layers x (gi, dX, dW_ih, dW_hh)
-        avg_ms = per_step_ms["gemm"] / calls["gemm"]
-        ach = flops / (per_step_ms["gemm"] * 1e-3) / 1e12
-        out["gemm"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS[prec], "unit": "TFLOP/s",
-                       "frac": round(ach / PEAK_MFMA_TFLOPS[prec], 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4)}
+    for gname in ("gemm", "gemm_bf16_nt"):
+        if gname in per_step_ms:
+            flops = 2.0 * rows * 3 * Hg * Hg * G * 8             # 2 layers x (gi, dX, dW_ih, dW_hh)
+            avg_ms = per_step_ms[gname] / calls[gname]
+            ach = flops / (per_step_ms[gname] * 1e-3) / 1e12
+            out[gname] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS[prec], "unit": "TFLOP/s",
+                          "frac": round(ach / PEAK_MFMA_TFLOPS[prec], 4), "traffic": None,
+                          "avg_launch_ms": round(avg_ms, 4)}
     hbm = {"conv_gather": 2 * 640 * 4.0, "conv_scatter2": 2 * 640 * 4.0, "bn_act_fwd": 2 * 640 * 4.0,
            "bn_act_bwd": 5 * 640 * 4.0, "conv_wgrad": 2 * 640 * 4.0, "ln_fwd": 2 * 640 * 4.0, "ln_bwd": 3 * 640 * 4.0}
     for name, bpf in hbm.items():

@@ -40,10 +40,14 @@ SIGNATURES = {
     "cruse_ln_fwd": ("pppppppqiifp", "i"),
     "cruse_ln_bwd": ("pppppqiipppp", "i"),
     "cruse_gemm": ("iiiiipipipipiiiip", "i"),
+    "cruse_gemm_bf16_nt": ("iiipqqpqqpqpiip", "i"),
+    "cruse_cast_bf16": ("ppqp", "i"),
+    "cruse_transpose_bf16": ("pqiqpqip", "i"),
     "cruse_gru_ws_bytes": ("iii", "z"),
     "cruse_gru_seq_fwd": ("pppppppiiiiipp", "i"),
     "cruse_gru_seq_bwd": ("pppppiiiiipp", "i"),
     "cruse_gru_gate_grads": ("pppppqiiip", "i"),
+    "cruse_gru_gate_grads_bf16": ("pppppqppqiip", "i"),
     "cruse_mask_loss_fwd": ("ppppqiiffpppppp", "i"),
     "cruse_mask_apply": ("pppqiippp", "i"),
     "cruse_mask_apply_bwd": ("pppppqiiipp", "i"),

@@ -1,0 +1,310 @@
+// bf16-operand MFMA GEMM for the GRU gate projections in CRUSE_PREC_BF16 mode (nn.GRU at
+// model/cruse_net.py:23-31,44,50), plus the layout kernels that feed it:
+//   C[M,N] (+)= A[M,K] . B[N,K]^T (+ bias[n])          A, B bf16 with K contiguous, C f32
+// Every gate GEMM of the step is brought to this one NT form by keeping bf16 copies of the operands in the
+// orientation the product needs (row-major for gi / dX, time-major transposes for the weight gradients):
+//   gi     = x_bf   . W_ih_bf^T            dX     = dgi_bf . (W_ih^T)_bf^T
+//   dW_ih += dgT    . (x^T)_bf^T           dW_hh += dgT    . (h_{t-1}^T)_bf^T
+// The values are the same RNE-rounded bf16 operands the f32-input kernel in gemm.hip forms on the fly, so
+// both kernels produce the same products; this one moves half the bytes and stages tiles with LDS-DMA.
+//
+// 128x128x64 block tile, 4 wavefronts as 2x2 (64x64 = 4x4 MFMA 16x16x32 tiles each), two LDS buffers filled by
+// global_load_lds (16 B per lane, 1 KiB per wave instruction).  The LDS image of a tile is [128 rows][8 chunks
+// of 16 B]; chunk c of row r sits at position c ^ (r & 7) -- the swizzle is applied on the per-lane global
+// SOURCE address (the LDS-DMA destination is lane-linear) and undone in the fragment read address.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;      // 16 KiB
+
+typedef __attribute__((address_space(3))) void lds_ptr_t;
+typedef const __attribute__((address_space(1))) void glb_ptr_t;
+
+struct GbArgs {
+    const __bf16* A; const __bf16* B; float* C; const float* bias;
+    int M, N, K;
+    long long lda, ldb, ldc, a_ks, b_ks;     // *_ks: elements between consecutive 64-deep k-tiles of one row
+    int accumulate, splitk, kt_chunk;
+    int tiles_m, tiles_n, nunits, inner;
+};
+
+// MODE: C update -- 0 store, 1 read-add-store, 2 atomic add (split-K).
+// NST: LDS stages.  2 = one k-tile of prefetch, two blocks per CU (the short-K products, whose epilogues then
+// overlap the other block's k-loop); 3 = two k-tiles in flight behind counted vmcnt waits and one raw barrier per
+// k-tile, one block per CU (the split-K weight gradients: hundreds of k-tiles streamed once, where the k-loop is
+// bound by the latency of the next tile's loads).
+template <int MODE, int NST>
+__global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_bf16_nt_kernel(const GbArgs g) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_dyn[];
+    unsigned char (*smem)[2][TILE_BYTES] = reinterpret_cast<unsigned char (*)[2][TILE_BYTES]>(smem_dyn);   // [stage][A|B]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    // XCD-aware tile order, as in gemm.hip: a unit -- the n-tiles of one m-tile, or with split-K the m-tiles of one
+    // (k-slice, n-tile) -- stays on one XCD, so the operand panel its tiles share is fetched into that L2 once
+    const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3;
+    const int inner = qq % g.inner, unit = (qq / g.inner) * 8 + xcd;
+    if (unit >= g.nunits) return;
+    int tm, tn, tz;
+    if (g.splitk > 1) { tz = unit / g.tiles_n; tn = unit % g.tiles_n; tm = inner; }
+    else { tz = 0; tm = unit; tn = inner; }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nkt = g.K / BK;
+    const int kt0 = tz * g.kt_chunk, kt1 = min(nkt, kt0 + g.kt_chunk);
+
+    // staging: wave wv fills rows [wv*32, wv*32+32) of both tiles, 8 rows (1 KiB) per instruction
+    const __bf16* ap[4];
+    const __bf16* bp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wv * 4 + i) * 8 + (lane >> 3);
+        const int ch = (lane & 7) ^ (lane >> 3);
+        ap[i] = g.A + (long long)min(m0 + r, g.M - 1) * g.lda + ch * 8;
+        bp[i] = g.B + (long long)min(n0 + r, g.N - 1) * g.ldb + ch * 8;
+    }
+    auto stage = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(ap[i] + (long long)kt * g.a_ks),
+                                             (lds_ptr_t*)&smem[buf][0][(wv * 4 + i) * 1024], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(bp[i] + (long long)kt * g.b_ks),
+                                             (lds_ptr_t*)&smem[buf][1][(wv * 4 + i) * 1024], 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment byte offsets inside a tile: row (lane & 15) of each 16-row sub-tile, chunk kk*4 + (lane >> 4)
+    int offa[2], offb[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int c = (kk * 4 + (lane >> 4)) ^ (lane & 7);
+        offa[kk] = (wm * 64 + (lane & 15)) * 128 + c * 16;
+        offb[kk] = (wn * 64 + (lane & 15)) * 128 + c * 16;
+    }
+
+    auto compute = [&](int buf) {
+        const unsigned char* As = smem[buf][0];
+        const unsigned char* Bs = smem[buf][1];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = *reinterpret_cast<const bf16x8*>(As + offa[kk] + i * 16 * 128);
+                fb[i] = *reinterpret_cast<const bf16x8*>(Bs + offb[kk] + i * 16 * 128);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    if constexpr (NST == 2) {
+        if (kt0 < kt1) stage(kt0, 0);
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int buf = (kt - kt0) & 1;
+            __syncthreads();                   // tile kt landed (vmcnt(0) + barrier); buffer buf^1 is free again
+            if (kt + 1 < kt1) stage(kt + 1, buf ^ 1);
+            compute(buf);
+        }
+    } else {
+        // each stage() is 8 LDS-DMA loads per wave, retired in order: vmcnt(8) == "all but the newest tile landed"
+        if (kt0 < kt1) stage(kt0, 0);
+        if (kt0 + 1 < kt1) stage(kt0 + 1, 1);
+        int buf = 0;
+        for (int kt = kt0; kt < kt1; ++kt) {
+            if (kt + 1 < kt1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();      // tile kt is in LDS for every wave; stage (kt+2)%3 == (kt-1)%3 is drained
+            if (kt + 2 < kt1) stage(kt + 2, buf == 0 ? 2 : buf - 1);
+            compute(buf);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+    }
+
+    // epilogue: each wave turns its 64x64 accumulator block into row-contiguous float4 accesses through its own
+    // 32 x 68-float LDS patch (two halves), so C is written in 256-byte row segments
+    __syncthreads();                           // everyone is done with the operand tiles
+    float* patch = reinterpret_cast<float*>(smem_dyn) + wv * (32 * 68);
+    const bool add_bias = g.bias != nullptr && tz == 0;
+    const int nq = n0 + wn * 64 + (lane & 15) * 4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (add_bias) {
+        bv.x = nq < g.N ? g.bias[nq] : 0.f; bv.y = nq + 1 < g.N ? g.bias[nq + 1] : 0.f;
+        bv.z = nq + 2 < g.N ? g.bias[nq + 2] : 0.f; bv.w = nq + 3 < g.N ? g.bias[nq + 3] : 0.f;
+    }
+    const bool vec = (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0) && nq + 3 < g.N;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    patch[(ii * 16 + (lane >> 4) * 4 + r) * 68 + j * 16 + (lane & 15)] = acc[half * 2 + ii][j][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int rr = p * 4 + (lane >> 4);
+            const int m = m0 + wm * 64 + half * 32 + rr;
+            float4 v = *reinterpret_cast<const float4*>(patch + rr * 68 + (lane & 15) * 4);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            if (m < g.M) {
+                float* c = g.C + (long long)m * g.ldc + nq;
+                if (MODE == 2) {
+                    if (nq < g.N) atomicAdd(c, v.x);
+                    if (nq + 1 < g.N) atomicAdd(c + 1, v.y);
+                    if (nq + 2 < g.N) atomicAdd(c + 2, v.z);
+                    if (nq + 3 < g.N) atomicAdd(c + 3, v.w);
+                } else if (vec) {
+                    if (MODE == 1) {
+                        const float4 o = *reinterpret_cast<const float4*>(c);
+                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    }
+                    *reinterpret_cast<float4*>(c) = v;
+                } else {
+                    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (nq + q < g.N) c[q] = (MODE == 1 ? c[q] : 0.f) + e[q];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// y = bf16(x), same layout
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* x, __bf16* y, long long n4) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        bf16x4 h;
+        h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+        reinterpret_cast<bf16x4*>(y)[i] = h;
+    }
+}
+
+// Time-major K-TILED transpose: element (c, r) of x^T lives at yT[(r/64)*cols*64 + c*64 + r%64], i.e. the 64-frame
+// k-tile of every line is one 128-byte run and a whole k-tile of the operand is one contiguous block (a row-major
+// [cols][ldT] image made every k-tile of a GEMM operand tile touch 128 pages 51 KB apart).  Values:
+// bf16(x[r - shift][c]) for r < rows (0 where shift and r is the first frame of its clip), 0 for rows <= r < ldT.
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const float* x, long long rows, int cols, long long ld,
+                                                             __bf16* yT, long long ldT, int shiftT) {
+    __shared__ float tile[64][65];
+    const int tid = threadIdx.x;
+    const long long r0 = (long long)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    {
+        const int cc = tid & 63;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int rr = p * 4 + (tid >> 6);
+            const long long r = r0 + rr;
+            float v = 0.f;
+            if (r < rows && c0 + cc < cols) {
+                if (shiftT == 0) v = x[r * ld + c0 + cc];
+                else if (r % shiftT != 0) v = x[(r - 1) * ld + c0 + cc];
+            }
+            tile[rr][cc] = v;
+        }
+    }
+    __syncthreads();
+    {
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+        const int rp = tid & 31;                 // row pair
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int cc = p * 8 + (tid >> 5);
+            if (c0 + cc < cols) {
+                bf16x2 h;
+                h[0] = (__bf16)tile[2 * rp][cc]; h[1] = (__bf16)tile[2 * rp + 1][cc];
+                *reinterpret_cast<bf16x2*>(yT + (r0 >> 6) * ((long long)cols * 64) + (long long)(c0 + cc) * 64 + 2 * rp) = h;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int cruse_gemm_bf16_nt(int M, int N, int K, const void* A, long long lda, long long a_kstride,
+                                  const void* B, long long ldb, long long b_kstride,
+                                  float* C, long long ldc, const float* bias, int accumulate, int splitk,
+                                  void* stream) {
+    CRUSE_REQUIRE(M > 0 && N > 0 && K > 0, CRUSE_E_SHAPE, "gemm_bf16_nt: empty shape M=%d N=%d K=%d", M, N, K);
+    CRUSE_REQUIRE(K % BK == 0, CRUSE_E_SHAPE, "gemm_bf16_nt: K=%d must be a multiple of %d (pad with zeros)", K, BK);
+    CRUSE_REQUIRE(a_kstride >= BK && b_kstride >= BK && ldc >= N, CRUSE_E_SHAPE, "gemm_bf16_nt: strides too small");
+    CRUSE_REQUIRE((a_kstride == BK ? lda >= K : lda >= BK) && (b_kstride == BK ? ldb >= K : ldb >= BK), CRUSE_E_SHAPE,
+                  "gemm_bf16_nt: lda=%lld / ldb=%lld too small for the operand layout", lda, ldb);
+    CRUSE_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && a_kstride % 8 == 0 && b_kstride % 8 == 0 &&
+                  ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, CRUSE_E_ALIGN,
+                  "gemm_bf16_nt: operands need 16-byte aligned rows and k-tiles (strides multiples of 8)");
+    const int nkt = K / BK;
+    if (splitk < 1) splitk = 1;
+    if (splitk > nkt) splitk = nkt;
+    const int kt_chunk = cdiv(nkt, splitk);
+    splitk = cdiv(nkt, kt_chunk);
+    GbArgs g;
+    g.A = (const __bf16*)A; g.B = (const __bf16*)B; g.C = C; g.bias = bias;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.a_ks = a_kstride; g.b_ks = b_kstride;
+    g.accumulate = accumulate; g.splitk = splitk; g.kt_chunk = kt_chunk;
+    g.tiles_m = cdiv(M, BM); g.tiles_n = cdiv(N, BN);
+    if (splitk > 1) { g.nunits = splitk * g.tiles_n; g.inner = g.tiles_m; }
+    else { g.nunits = g.tiles_m; g.inner = g.tiles_n; }
+    const long long nblk = (long long)cdiv(g.nunits, 8) * 8 * g.inner;
+    CRUSE_REQUIRE(nblk < (1ll << 31), CRUSE_E_SHAPE, "gemm_bf16_nt: grid too large");
+    CRUSE_REQUIRE(splitk == 1 || accumulate, CRUSE_E_SHAPE, "gemm_bf16_nt: split-K adds into C (accumulate = 1)");
+    const dim3 grid((unsigned)nblk);
+    hipStream_t st = (hipStream_t)stream;
+    const bool deep = kt_chunk >= 64;          // long k-loops: three stages, one block per CU
+    const size_t lds = (size_t)(deep ? 3 : 2) * 2 * TILE_BYTES;
+#define CRUSE_GB_LAUNCH(MODE, NST)                                                                               \
+    do {                                                                                                         \
+        int rc0 = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_bf16_nt_kernel<MODE, NST>), lds,       \
+                                       "gemm_bf16_nt");                                                          \
+        if (rc0) return rc0;                                                                                     \
+        hipLaunchKernelGGL((gemm_bf16_nt_kernel<MODE, NST>), grid, dim3(256), lds, st, g);                       \
+    } while (0)
+    if (deep) {
+        if (splitk > 1) CRUSE_GB_LAUNCH(2, 3); else if (accumulate) CRUSE_GB_LAUNCH(1, 3); else CRUSE_GB_LAUNCH(0, 3);
+    } else {
+        if (splitk > 1) CRUSE_GB_LAUNCH(2, 2); else if (accumulate) CRUSE_GB_LAUNCH(1, 2); else CRUSE_GB_LAUNCH(0, 2);
+    }
+#undef CRUSE_GB_LAUNCH
+    CRUSE_LAUNCH_CHECK("gemm_bf16_nt");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_cast_bf16(const float* x, void* y, long long n, void* stream) {
+    CRUSE_REQUIRE(n > 0 && n % 4 == 0, CRUSE_E_SHAPE, "cast_bf16: n=%lld must be a positive multiple of 4", n);
+    CRUSE_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 8) == 0, CRUSE_E_ALIGN, "cast_bf16: unaligned buffers");
+    long long nb = (n / 4 + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)y, n / 4);
+    CRUSE_LAUNCH_CHECK("cast_bf16");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_transpose_bf16(const float* x, long long rows, int cols, long long ld, void* yT, long long ldT,
+                                    int shift_T, void* stream) {
+    CRUSE_REQUIRE(rows > 0 && cols > 0 && ld >= cols, CRUSE_E_SHAPE, "transpose_bf16: bad shape");
+    CRUSE_REQUIRE(ldT % 64 == 0 && ldT >= rows, CRUSE_E_SHAPE,
+                  "transpose_bf16: ldT=%lld must be a multiple of 64 and >= rows=%lld", ldT, rows);
+    CRUSE_REQUIRE(shift_T >= 0 && (shift_T == 0 || rows % shift_T == 0), CRUSE_E_SHAPE,
+                  "transpose_bf16: rows must be whole clips of shift_T frames");
+    CRUSE_REQUIRE(((uintptr_t)yT % 4) == 0, CRUSE_E_ALIGN, "transpose_bf16: unaligned output");
+    dim3 grid((unsigned)(ldT / 64), (unsigned)cdiv(cols, 64));
+    hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, (__bf16*)yT,
+                       ldT, shift_T);
+    CRUSE_LAUNCH_CHECK("transpose_bf16");
+    return CRUSE_OK;
+}

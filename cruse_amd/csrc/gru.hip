@@ -621,6 +621,113 @@ __global__ __launch_bounds__(256) void gru_gate_grads_kernel(const float* dh, co
     }
 }
 
+// CRUSE_PREC_BF16 form of the gate gradients, laid out for gemm_bf16.hip.  dgi and dgh share their r and z gates
+// (dgi = dh*(c_r,c_z,a_n), dgh = dh*(c_r,c_z,c_n)), so four slabs (r, z, n_i, n_h) carry both:
+//   dgi [rows][G][3][Hg] bf16  (r, z, n_i)  row-major, the A operand of dX = dgi W_ih
+//   dgT [ldT/64][G][4][Hg][64] bf16         time-major k-tiled (see transpose_bf16_kernel), the A operand of dW_ih
+//                                           (slabs 0-2) and dW_hh (0, 1, 3)
+//   db_ih[g][3*Hg] += column sums (r, z, n_i),  db_hh[g][3*Hg] += (r, z, n_h), summed from the f32 values
+// One block = 64 frames x CW hidden units of one group; the time-major copy goes through an LDS image of
+// [slab][unit][64 frames] bf16 whose 16-byte chunks are XOR-swizzled by (line >> 2) & 7.
+struct GateBiasPtrs { float* ih[MAXG]; float* hh[MAXG]; };
+constexpr int GG_RT = 4;               // 64-frame tiles per block
+
+template <int CW>
+__global__ __launch_bounds__(256) void gru_gate_grads_bf16_kernel(const float* dh, const __bf16* coef, const float* an,
+                                                                  __bf16* dgi, __bf16* dgT, long long ldT,
+                                                                  GateBiasPtrs bp, long long rows, int G, int Hg) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    __shared__ __attribute__((aligned(16))) unsigned img[4 * CW * 32];
+    __shared__ float bsum[4][CW];
+    constexpr int NCQ = CW / 4;
+    const int tid = threadIdx.x;
+    const int H = G * Hg, ntj = Hg / CW;
+    const int g = blockIdx.y / ntj, j0 = (blockIdx.y % ntj) * CW;
+    float bs[4][4];                            // bias partial sums of this thread's unit quad (fixed across items)
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bs[sl][e] = 0.f;
+    for (int i = tid; i < 4 * CW; i += 256) bsum[i / CW][i % CW] = 0.f;
+    // RT consecutive 64-frame tiles per block: the block keeps writing the same 4*CW time-major lines
+    for (int sub = 0; sub < GG_RT; ++sub) {
+        const long long r0 = ((long long)blockIdx.x * GG_RT + sub) * 64;
+        if (r0 >= ldT) break;
+        __syncthreads();                       // previous tile's image has been drained
+        for (int item = tid; item < 32 * NCQ; item += 256) {
+            const int cq = item % NCQ, q = item / NCQ;      // 256 % NCQ == 0: cq is the same for every item of a thread
+            const int j = j0 + cq * 4;
+            float v[2][4][4];                  // [row of the pair][slab][unit]
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const long long r = r0 + 2 * q + rr;
+                if (r < rows) {
+                    const float4 d4 = *reinterpret_cast<const float4*>(dh + r * H + g * Hg + j);
+                    const float4 a4 = *reinterpret_cast<const float4*>(an + r * H + g * Hg + j);
+                    const long long o3 = (r * G + g) * 3 * Hg + j;
+                    const bf16x4 cr = *reinterpret_cast<const bf16x4*>(coef + o3);
+                    const bf16x4 cz = *reinterpret_cast<const bf16x4*>(coef + o3 + Hg);
+                    const bf16x4 cn = *reinterpret_cast<const bf16x4*>(coef + o3 + 2 * Hg);
+                    const float d[4] = {d4.x, d4.y, d4.z, d4.w}, a[4] = {a4.x, a4.y, a4.z, a4.w};
+                    bf16x4 o0, o1, o2;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[rr][0][e] = d[e] * (float)cr[e]; v[rr][1][e] = d[e] * (float)cz[e];
+                        v[rr][2][e] = d[e] * a[e];         v[rr][3][e] = d[e] * (float)cn[e];
+                        o0[e] = (__bf16)v[rr][0][e]; o1[e] = (__bf16)v[rr][1][e]; o2[e] = (__bf16)v[rr][2][e];
+                    }
+                    *reinterpret_cast<bf16x4*>(dgi + o3) = o0;
+                    *reinterpret_cast<bf16x4*>(dgi + o3 + Hg) = o1;
+                    *reinterpret_cast<bf16x4*>(dgi + o3 + 2 * Hg) = o2;
+                } else {
+#pragma unroll
+                    for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[rr][sl][e] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int line = sl * CW + cq * 4 + e;
+                    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+                    bf16x2 pr;
+                    pr[0] = (__bf16)v[0][sl][e]; pr[1] = (__bf16)v[1][sl][e];
+                    img[line * 32 + (((q >> 2) ^ ((line >> 2) & 7)) << 2) + (q & 3)] = *reinterpret_cast<unsigned*>(&pr);
+                    bs[sl][e] += v[0][sl][e] + v[1][sl][e];
+                }
+        }
+        __syncthreads();
+        for (int item = tid; item < 4 * CW * 8; item += 256) {
+            const int k = item & 7, line = item >> 3;
+            const int sl = line / CW, col = line % CW;
+            const uint4 w = *reinterpret_cast<const uint4*>(&img[line * 32 + ((k ^ ((line >> 2) & 7)) << 2)]);
+            *reinterpret_cast<uint4*>(dgT + (r0 >> 6) * ((long long)4 * G * Hg * 64) + ((long long)(g * 4 + sl) * Hg + j0 + col) * 64 + k * 8) = w;
+        }
+    }
+    {
+        const int cq = tid % NCQ;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(&bsum[sl][cq * 4 + e], bs[sl][e]);
+    }
+    __syncthreads();
+    for (int i = tid; i < 4 * CW; i += 256) {
+        const int sl = i / CW, j = j0 + i % CW;
+        const float val = bsum[sl][i % CW];
+        if (sl < 2) {
+            if (bp.ih[g]) atomicAdd(bp.ih[g] + sl * Hg + j, val);
+            if (bp.hh[g]) atomicAdd(bp.hh[g] + sl * Hg + j, val);
+        } else if (sl == 2) {
+            if (bp.ih[g]) atomicAdd(bp.ih[g] + 2 * Hg + j, val);
+        } else {
+            if (bp.hh[g]) atomicAdd(bp.hh[g] + 2 * Hg + j, val);
+        }
+    }
+}
+
 int num_cus() {
     static int cached = 0;
     if (cached == 0) {
@@ -779,5 +886,29 @@ extern "C" int cruse_gru_gate_grads(const float* dh, const void* coef, const flo
         hipLaunchKernelGGL(gru_gate_grads_kernel<float>, dim3((int)nblk), dim3(256), 0, (hipStream_t)stream, dh,
                            (const float*)coef, an, dgi, dgh, rows, G, Hg);
     CRUSE_LAUNCH_CHECK("gru_gate_grads");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_gru_gate_grads_bf16(const float* dh, const void* coef, const float* an, void* dgi, void* dgT,
+                                         long long ldT, float* const* db_ih, float* const* db_hh,
+                                         long long rows, int G, int Hg, void* stream) {
+    CRUSE_REQUIRE(rows > 0 && G > 0 && G <= MAXG && Hg > 0 && Hg % 32 == 0, CRUSE_E_SHAPE,
+                  "gru_gate_grads_bf16: bad shape rows=%lld G=%d Hg=%d", rows, G, Hg);
+    CRUSE_REQUIRE(ldT % 64 == 0 && ldT >= rows && ldT < rows + 64, CRUSE_E_SHAPE,
+                  "gru_gate_grads_bf16: ldT=%lld must be rows=%lld rounded up to a multiple of 64", ldT, rows);
+    CRUSE_REQUIRE(((uintptr_t)dh % 16) == 0 && ((uintptr_t)an % 16) == 0 && ((uintptr_t)coef % 8) == 0 &&
+                  ((uintptr_t)dgi % 8) == 0 && ((uintptr_t)dgT % 16) == 0, CRUSE_E_ALIGN,
+                  "gru_gate_grads_bf16: unaligned buffers");
+    GateBiasPtrs bp = {};
+    for (int g = 0; g < G; ++g) { bp.ih[g] = db_ih ? db_ih[g] : nullptr; bp.hh[g] = db_hh ? db_hh[g] : nullptr; }
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned nrt = (unsigned)cdivl(ldT / 64, GG_RT);
+    if (Hg % 64 == 0)
+        hipLaunchKernelGGL(gru_gate_grads_bf16_kernel<64>, dim3(nrt, G * (Hg / 64)), dim3(256), 0, s, dh,
+                           (const __bf16*)coef, an, (__bf16*)dgi, (__bf16*)dgT, ldT, bp, rows, G, Hg);
+    else
+        hipLaunchKernelGGL(gru_gate_grads_bf16_kernel<32>, dim3(nrt, G * (Hg / 32)), dim3(256), 0, s, dh,
+                           (const __bf16*)coef, an, (__bf16*)dgi, (__bf16*)dgT, ldT, bp, rows, G, Hg);
+    CRUSE_LAUNCH_CHECK("gru_gate_grads_bf16");
     return CRUSE_OK;
 }

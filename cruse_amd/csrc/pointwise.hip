@@ -12,9 +12,12 @@ namespace {
 
 // ------------------------------------------------------------------ BatchNorm ---
 // sums[c] += sum v, sums[C+c] += sum v2 where (v, v2) come from functor fn per element.
+// Blocks are RED_THREADS wide so that few blocks (<= one per CU) end in global atomics on the same 2C addresses --
+// with 1024 small blocks those same-address atomics, serialised in L2, took longer than streaming the tensor.
 // One WAVE per row (grid-stride over rows): lane l owns the float4 column groups l, l+64, l+128, ... of the
 // C*F-wide frame row, so every access is a 16-byte load and a lane's partial sums stay in registers across
 // all its rows (f32 runs of 32 rows folded into f64); the per-channel reduction happens once at the end.
+constexpr int RED_THREADS = 1024;
 constexpr int CPR_MAXG = 3;          // float4 groups per lane: C*F <= 768
 
 template <typename Fn>
@@ -22,15 +25,30 @@ __device__ __forceinline__ void channel_pair_reduce(long long rows, int C, int F
     __shared__ double s1[256], s2[256];
     const int CF = C * F, ng = CF >> 2;
     const int tid = threadIdx.x, lane = tid & 63;
-    for (int c = tid; c < C; c += 256) { s1[c] = 0.0; s2[c] = 0.0; }
+    for (int c = tid; c < C; c += blockDim.x) { s1[c] = 0.0; s2[c] = 0.0; }
     __syncthreads();
     float a[CPR_MAXG][4], b[CPR_MAXG][4];
-    double da[CPR_MAXG][4], db[CPR_MAXG][4];
 #pragma unroll
     for (int g = 0; g < CPR_MAXG; ++g)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { a[g][e] = b[g][e] = 0.f; da[g][e] = db[g][e] = 0.0; }
-    const long long wave = (long long)blockIdx.x * 4 + (tid >> 6), nwave = (long long)gridDim.x * 4;
+        for (int e = 0; e < 4; ++e) { a[g][e] = b[g][e] = 0.f; }
+    auto flush = [&]() {                       // f32 runs of <= 32 rows are folded into the f64 LDS sums
+#pragma unroll
+        for (int g = 0; g < CPR_MAXG; ++g) {
+            const int q = lane + 64 * g;
+            if (q < ng) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = (q * 4 + e) / F;
+                    atomicAdd(&s1[c], (double)a[g][e]);
+                    atomicAdd(&s2[c], (double)b[g][e]);
+                    a[g][e] = b[g][e] = 0.f;
+                }
+            }
+        }
+    };
+    const int nw = blockDim.x >> 6;
+    const long long wave = (long long)blockIdx.x * nw + (tid >> 6), nwave = (long long)gridDim.x * nw;
     int n = 0;
     for (long long r = wave; r < rows; r += nwave) {
 #pragma unroll
@@ -43,34 +61,17 @@ __device__ __forceinline__ void channel_pair_reduce(long long rows, int C, int F
                 for (int e = 0; e < 4; ++e) { a[g][e] += v[e]; b[g][e] += v2[e]; }
             }
         }
-        if (++n == 32) {
-#pragma unroll
-            for (int g = 0; g < CPR_MAXG; ++g)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { da[g][e] += a[g][e]; db[g][e] += b[g][e]; a[g][e] = b[g][e] = 0.f; }
-            n = 0;
-        }
+        if (++n == 32) { flush(); n = 0; }
     }
-#pragma unroll
-    for (int g = 0; g < CPR_MAXG; ++g) {
-        const int q = lane + 64 * g;
-        if (q < ng) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = (q * 4 + e) / F;
-                atomicAdd(&s1[c], da[g][e] + (double)a[g][e]);
-                atomicAdd(&s2[c], db[g][e] + (double)b[g][e]);
-            }
-        }
-    }
+    flush();
     __syncthreads();
-    for (int c = tid; c < C; c += 256) {
+    for (int c = tid; c < C; c += blockDim.x) {
         atomicAdd(&sums[c], s1[c]);
         atomicAdd(&sums[C + c], s2[c]);
     }
 }
 
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* y, long long rows, int C, int F, double* sums) {
+__global__ __launch_bounds__(RED_THREADS) void bn_stats_kernel(const float* y, long long rows, int C, int F, double* sums) {
     channel_pair_reduce(rows, C, F, sums, [&](long long i, int, float (&v)[4], float (&v2)[4]) {
         const float4 t = *reinterpret_cast<const float4*>(y + i);
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* y, const f
     }
 }
 
-__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* dout, const float* y, const float* mean,
+__global__ __launch_bounds__(RED_THREADS) void bn_act_bwd_reduce_kernel(const float* dout, const float* y, const float* mean,
                                                                 const float* rstd, const float* gamma,
                                                                 const float* beta, long long rows, int C, int F,
                                                                 int relu, double* sums) {
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* dou
     __shared__ float tab[4][256];
     float pm[CPR_MAXG][4], pr[CPR_MAXG][4], pg[CPR_MAXG][4], pb[CPR_MAXG][4];
     const int lane = threadIdx.x & 63;
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
         tab[0][c] = mean[c]; tab[1][c] = rstd[c]; tab[2][c] = gamma[c]; tab[3][c] = beta[c];
     }
     __syncthreads();
@@ -338,6 +339,159 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const floa
     }
 }
 
+// g == 1, H % 4 == 0 forms: a lane owns float4 groups lane, lane+64, ... of the row (16-byte accesses) and a wave
+// works on NR rows at once so that their loads and the two reductions of one row overlap the other's.
+constexpr int LNV_MAXQ = 4;   // H <= 1024
+constexpr int LNV_NR = 2;     // forward; the backward kernel keeps one row per wave in flight (register budget)
+
+__global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const float* x, const float* gamma, const float* beta,
+                                                         const float* res, float* y, float* mean, float* rstd,
+                                                         long long rows, int H, float eps) {
+    const int lane = threadIdx.x & 63, nq = H >> 2;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nwave = (long long)gridDim.x * 4;
+    float4 gm[LNV_MAXQ], bt[LNV_MAXQ];
+#pragma unroll
+    for (int e = 0; e < LNV_MAXQ; ++e) {
+        const int q = lane + 64 * e;
+        gm[e] = q < nq ? reinterpret_cast<const float4*>(gamma)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        bt[e] = q < nq ? reinterpret_cast<const float4*>(beta)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (long long r0 = wave * LNV_NR; r0 < rows; r0 += nwave * LNV_NR) {
+        float4 v[LNV_NR][LNV_MAXQ], rv[LNV_NR][LNV_MAXQ];
+        float s[LNV_NR], m[LNV_NR], qq[LNV_NR];
+#pragma unroll
+        for (int k = 0; k < LNV_NR; ++k) {
+            const long long r = r0 + k;
+            s[k] = 0.f;
+#pragma unroll
+            for (int e = 0; e < LNV_MAXQ; ++e) {
+                const int q = lane + 64 * e;
+                const bool ok = q < nq && r < rows;
+                v[k][e] = ok ? reinterpret_cast<const float4*>(x + r * H)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+                rv[k][e] = (ok && res) ? reinterpret_cast<const float4*>(res + r * H)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+                s[k] += (v[k][e].x + v[k][e].y) + (v[k][e].z + v[k][e].w);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < LNV_NR; ++k) m[k] = wave_sum(s[k]) / (float)H;
+#pragma unroll
+        for (int k = 0; k < LNV_NR; ++k) {
+            qq[k] = 0.f;
+#pragma unroll
+            for (int e = 0; e < LNV_MAXQ; ++e) {
+                if (lane + 64 * e < nq) {
+                    const float a = v[k][e].x - m[k], b = v[k][e].y - m[k], c = v[k][e].z - m[k], d = v[k][e].w - m[k];
+                    qq[k] += (a * a + b * b) + (c * c + d * d);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < LNV_NR; ++k) {
+            const long long r = r0 + k;
+            const float rs = 1.0f / sqrtf(wave_sum(qq[k]) / (float)H + eps);
+            if (r >= rows) continue;
+            if (lane == 0) { if (mean) mean[r] = m[k]; if (rstd) rstd[r] = rs; }
+#pragma unroll
+            for (int e = 0; e < LNV_MAXQ; ++e) {
+                const int q = lane + 64 * e;
+                if (q < nq) {
+                    float4 o;
+                    o.x = (v[k][e].x - m[k]) * rs * gm[e].x + bt[e].x + rv[k][e].x;
+                    o.y = (v[k][e].y - m[k]) * rs * gm[e].y + bt[e].y + rv[k][e].y;
+                    o.z = (v[k][e].z - m[k]) * rs * gm[e].z + bt[e].z + rv[k][e].z;
+                    o.w = (v[k][e].w - m[k]) * rs * gm[e].w + bt[e].w + rv[k][e].w;
+                    reinterpret_cast<float4*>(y + r * H)[q] = o;
+                }
+            }
+        }
+    }
+}
+
+constexpr int LNB_NR = 1;
+__global__ __launch_bounds__(RED_THREADS) void ln_bwd_vec_kernel(const float* dy, const float* x, const float* mean,
+                                                         const float* rstd, const float* gamma, long long rows, int H,
+                                                         float* dx, float* dgamma, float* dbeta) {
+    __shared__ float sdg[1024], sdb[1024];
+    const int lane = threadIdx.x & 63, nq = H >> 2;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) { sdg[c] = 0.f; sdb[c] = 0.f; }
+    __syncthreads();
+    const int nw = blockDim.x >> 6;
+    const long long wave = (long long)blockIdx.x * nw + (threadIdx.x >> 6);
+    const long long nwave = (long long)gridDim.x * nw;
+    float4 gm[LNV_MAXQ], adg[LNV_MAXQ], adb[LNV_MAXQ];
+#pragma unroll
+    for (int e = 0; e < LNV_MAXQ; ++e) {
+        const int q = lane + 64 * e;
+        gm[e] = q < nq ? reinterpret_cast<const float4*>(gamma)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        adg[e] = make_float4(0.f, 0.f, 0.f, 0.f); adb[e] = adg[e];
+    }
+    for (long long r0 = wave * LNB_NR; r0 < rows; r0 += nwave * LNB_NR) {
+        float4 xh[LNB_NR][LNV_MAXQ], gd[LNB_NR][LNV_MAXQ];
+        float s1[LNB_NR], s2[LNB_NR], rsv[LNB_NR];
+#pragma unroll
+        for (int k = 0; k < LNB_NR; ++k) {
+            const long long r = r0 + k;
+            const bool rok = r < rows;
+            const float m = rok ? mean[r] : 0.f;
+            rsv[k] = rok ? rstd[r] : 0.f;
+            s1[k] = 0.f; s2[k] = 0.f;
+#pragma unroll
+            for (int e = 0; e < LNV_MAXQ; ++e) {
+                const int q = lane + 64 * e;
+                if (q < nq && rok) {
+                    const float4 d = reinterpret_cast<const float4*>(dy + r * H)[q];
+                    const float4 xv = reinterpret_cast<const float4*>(x + r * H)[q];
+                    float4 h, gdd;
+                    h.x = (xv.x - m) * rsv[k]; h.y = (xv.y - m) * rsv[k]; h.z = (xv.z - m) * rsv[k]; h.w = (xv.w - m) * rsv[k];
+                    gdd.x = d.x * gm[e].x; gdd.y = d.y * gm[e].y; gdd.z = d.z * gm[e].z; gdd.w = d.w * gm[e].w;
+                    adg[e].x += d.x * h.x; adg[e].y += d.y * h.y; adg[e].z += d.z * h.z; adg[e].w += d.w * h.w;
+                    adb[e].x += d.x; adb[e].y += d.y; adb[e].z += d.z; adb[e].w += d.w;
+                    s1[k] += (gdd.x + gdd.y) + (gdd.z + gdd.w);
+                    s2[k] += (gdd.x * h.x + gdd.y * h.y) + (gdd.z * h.z + gdd.w * h.w);
+                    xh[k][e] = h; gd[k][e] = gdd;
+                } else {
+                    xh[k][e] = make_float4(0.f, 0.f, 0.f, 0.f); gd[k][e] = xh[k][e];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < LNB_NR; ++k) { s1[k] = wave_sum(s1[k]) / (float)H; s2[k] = wave_sum(s2[k]) / (float)H; }
+#pragma unroll
+        for (int k = 0; k < LNB_NR; ++k) {
+            const long long r = r0 + k;
+            if (r >= rows) continue;
+#pragma unroll
+            for (int e = 0; e < LNV_MAXQ; ++e) {
+                const int q = lane + 64 * e;
+                if (q < nq) {
+                    float4 o;
+                    o.x = rsv[k] * (gd[k][e].x - s1[k] - xh[k][e].x * s2[k]);
+                    o.y = rsv[k] * (gd[k][e].y - s1[k] - xh[k][e].y * s2[k]);
+                    o.z = rsv[k] * (gd[k][e].z - s1[k] - xh[k][e].z * s2[k]);
+                    o.w = rsv[k] * (gd[k][e].w - s1[k] - xh[k][e].w * s2[k]);
+                    reinterpret_cast<float4*>(dx + r * H)[q] = o;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < LNV_MAXQ; ++e) {
+        const int q = lane + 64 * e;
+        if (q < nq) {
+            atomicAdd(&sdg[q * 4], adg[e].x); atomicAdd(&sdg[q * 4 + 1], adg[e].y);
+            atomicAdd(&sdg[q * 4 + 2], adg[e].z); atomicAdd(&sdg[q * 4 + 3], adg[e].w);
+            atomicAdd(&sdb[q * 4], adb[e].x); atomicAdd(&sdb[q * 4 + 1], adb[e].y);
+            atomicAdd(&sdb[q * 4 + 2], adb[e].z); atomicAdd(&sdb[q * 4 + 3], adb[e].w);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        if (dgamma) atomicAdd(&dgamma[c], sdg[c]);
+        if (dbeta) atomicAdd(&dbeta[c], sdb[c]);
+    }
+}
+
 // ------------------------------------------------------------------ mask + loss ---
 __global__ __launch_bounds__(256) void mask_loss_kernel(const float* mask, const float* nre, const float* nim,
                                                         const float* cmag, long long rows, int Fn, int Fs,
@@ -421,7 +575,7 @@ extern "C" int cruse_bn_stats(const float* y, long long rows, int C, int F, doub
     CRUSE_REQUIRE(rows > 0 && C > 0 && C <= 256 && F > 0, CRUSE_E_SHAPE, "bn_stats: bad shape rows=%lld C=%d F=%d", rows, C, F);
     CRUSE_REQUIRE((C * F) % 4 == 0 && C * F <= 768, CRUSE_E_SHAPE, "bn_stats: C*F=%d must be a multiple of 4 and <= 768", C * F);
     { int zrc = cruse_zero_async(sums, 2 * C * sizeof(double), ST(stream), "bn_stats memset"); if (zrc) return zrc; }
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(rows, 16, 1024)), dim3(256), 0, ST(stream), y, rows, C, F, sums);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(rows, 64, 256)), dim3(RED_THREADS), 0, ST(stream), y, rows, C, F, sums);
     CRUSE_LAUNCH_CHECK("bn_stats");
     return CRUSE_OK;
 }
@@ -462,7 +616,7 @@ extern "C" int cruse_bn_act_bwd_reduce(const float* dout, const float* y, const 
     CRUSE_REQUIRE(rows > 0 && C > 0 && C <= 256 && F > 0, CRUSE_E_SHAPE, "bn_act_bwd_reduce: bad shape");
     CRUSE_REQUIRE((C * F) % 4 == 0 && C * F <= 768, CRUSE_E_SHAPE, "bn_act_bwd_reduce: C*F=%d must be a multiple of 4 and <= 768", C * F);
     { int zrc = cruse_zero_async(sums, 2 * C * sizeof(double), ST(stream), "bn_act_bwd_reduce memset"); if (zrc) return zrc; }
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(grid_for(rows, 16, 1024)), dim3(256), 0, ST(stream), dout, y, mean,
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(grid_for(rows, 64, 256)), dim3(RED_THREADS), 0, ST(stream), dout, y, mean,
                        rstd, gamma, beta, rows, C, F, relu, sums);
     CRUSE_LAUNCH_CHECK("bn_act_bwd_reduce");
     return CRUSE_OK;
@@ -486,8 +640,14 @@ extern "C" int cruse_ln_fwd(const float* x, const float* gamma, const float* bet
                             float eps, void* stream) {
     CRUSE_REQUIRE(rows > 0 && H > 0 && H <= 64 * LN_MAXE, CRUSE_E_SHAPE, "ln_fwd: H=%d must be in 1..%d", H, 64 * LN_MAXE);
     CRUSE_REQUIRE(interleave_g >= 1 && H % interleave_g == 0, CRUSE_E_SHAPE, "ln_fwd: groups=%d must divide H=%d", interleave_g, H);
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid_for(rows, 4, 2048)), dim3(256), 0, ST(stream), x, gamma, beta, res, y,
-                       mean, rstd, rows, H, interleave_g, eps);
+    const bool vec = interleave_g == 1 && H % 4 == 0 && H <= 256 * LNV_MAXQ &&
+                     ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)res) & 15) == 0);
+    if (vec)
+        hipLaunchKernelGGL(ln_fwd_vec_kernel, dim3(grid_for(rows, 16, 2048)), dim3(256), 0, ST(stream), x, gamma, beta,
+                           res, y, mean, rstd, rows, H, eps);
+    else
+        hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid_for(rows, 4, 2048)), dim3(256), 0, ST(stream), x, gamma, beta, res, y,
+                           mean, rstd, rows, H, interleave_g, eps);
     CRUSE_LAUNCH_CHECK("ln_fwd");
     return CRUSE_OK;
 }
@@ -497,8 +657,14 @@ extern "C" int cruse_ln_bwd(const float* dy, const float* x, const float* mean, 
                             float* dx, float* dgamma, float* dbeta, void* stream) {
     CRUSE_REQUIRE(rows > 0 && H > 0 && H <= 64 * LN_MAXE, CRUSE_E_SHAPE, "ln_bwd: H=%d must be in 1..%d", H, 64 * LN_MAXE);
     CRUSE_REQUIRE(interleave_g >= 1 && H % interleave_g == 0, CRUSE_E_SHAPE, "ln_bwd: groups=%d must divide H=%d", interleave_g, H);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid_for(rows, 32, 1024)), dim3(256), 0, ST(stream), dy, x, mean, rstd, gamma,
-                       rows, H, interleave_g, dx, dgamma, dbeta);
+    const bool vec = interleave_g == 1 && H % 4 == 0 && H <= 256 * LNV_MAXQ &&
+                     ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)gamma) & 15) == 0);
+    if (vec)
+        hipLaunchKernelGGL(ln_bwd_vec_kernel, dim3(grid_for(rows, 128, 256)), dim3(RED_THREADS), 0, ST(stream), dy, x, mean,
+                           rstd, gamma, rows, H, dx, dgamma, dbeta);
+    else
+        hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid_for(rows, 32, 1024)), dim3(256), 0, ST(stream), dy, x, mean, rstd,
+                           gamma, rows, H, interleave_g, dx, dgamma, dbeta);
     CRUSE_LAUNCH_CHECK("ln_bwd");
     return CRUSE_OK;
 }

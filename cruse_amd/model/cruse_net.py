@@ -62,6 +62,17 @@ class _SideStream:
 SIDE = _SideStream()
 
 
+def _splitk_bf16(M: int, N: int, K: int) -> int:
+    """k-slices for gemm_bf16_nt's deep-pipeline form (one block per CU): fill the 256 CUs in one round."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    return max(1, min(256 // tiles, K // 1024))
+
+
+def _bf16_gemm_path(prec, Hg: int) -> bool:
+    """bf16-operand GEMMs need K = Hg and K = 3*Hg to be whole 64-deep tiles."""
+    return ops.prec_code(prec) == ops.PREC_BF16 and Hg % 64 == 0
+
+
 def _splitk(M: int, N: int, K: int) -> int:
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     sk = max(1, (512 + tiles - 1) // tiles)
@@ -80,11 +91,19 @@ def ggru_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], prefix: str, group
     rows = B * T
     ctx = dict(B=B, T=T, H=H, g=g, prec=prec, x=x, prefix=prefix, has_res=residual is not None)
 
+    fast = _bf16_gemm_path(prec, Hg)
+
     def layer(inp, lname):
         gi = torch.empty(B, T, g * 3 * Hg, device=x.device, dtype=torch.float32)
+        inp_bf = ops.cast_bf16(inp) if fast else None
         for i in range(g):
-            ops.gemm(False, True, rows, 3 * Hg, Hg, inp, i * Hg, H, P[f"{prefix}{lname}.{i}.weight_ih_l0"], 0, Hg,
-                     gi, i * 3 * Hg, 3 * H, bias=P[f"{prefix}{lname}.{i}.bias_ih_l0"], prec=prec)
+            w_ih, b_ih = P[f"{prefix}{lname}.{i}.weight_ih_l0"], P[f"{prefix}{lname}.{i}.bias_ih_l0"]
+            if fast:
+                ops.gemm_bf16_nt(rows, 3 * Hg, Hg, inp_bf, i * Hg, H, ops.cast_bf16(w_ih), 0, Hg, gi, i * 3 * Hg, 3 * H,
+                                 bias=b_ih)
+            else:
+                ops.gemm(False, True, rows, 3 * Hg, Hg, inp, i * Hg, H, w_ih, 0, Hg, gi, i * 3 * Hg, 3 * H, bias=b_ih,
+                         prec=prec)
         w_hh = [P[f"{prefix}{lname}.{i}.weight_hh_l0"] for i in range(g)]
         b_hh = [P[f"{prefix}{lname}.{i}.bias_hh_l0"] for i in range(g)]
         return ops.gru_seq_fwd(gi, w_hh, b_hh, B, T, g, Hg, prec, save=save)
@@ -106,7 +125,44 @@ def ggru_backward(ctx, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[s
     Hg = H // g
     rows = B * T
 
+    def layer_bwd_bf16(dout_h, lname, inp, h, coef, an, z, need_dinp):
+        """CRUSE_PREC_BF16: every product as gemm_bf16_nt on bf16 operand copies (see gemm_bf16.hip)."""
+        names = [f"{prefix}{lname}.{i}." for i in range(g)]
+        w_hh = [P[nm + "weight_hh_l0"] for nm in names]
+        dh = ops.gru_seq_bwd(dout_h, w_hh, coef, z, B, T, g, Hg, prec)
+        dgi, dgT, ldT = ops.gru_gate_grads_bf16(dh, coef, an, rows, g, Hg, [G[nm + "bias_ih_l0"] for nm in names],
+                                                [G[nm + "bias_hh_l0"] for nm in names])
+        dinp = torch.empty(B, T, H, device=dout_h.device, dtype=torch.float32) if need_dinp else None
+
+        inpT = torch.empty(ldT // 64, H, 64, device=dh.device, dtype=torch.bfloat16)
+        hpT = torch.empty(ldT // 64, H, 64, device=dh.device, dtype=torch.bfloat16)
+
+        def weight_grads():                      # leaves: overlap with the next recurrence / encoder backward
+            ops.transpose_bf16(inp, rows, H, out=inpT)
+            ops.transpose_bf16(h, rows, H, shift_T=T, out=hpT)
+            ka, kb = 4 * H * 64, H * 64          # k-tile strides of the K-tiled time-major operands (lda = ldb = 64)
+            for i, nm in enumerate(names):
+                # dW_ih += (r, z, n_i)^T x ; dW_hh += (r, z)^T h_{t-1} and n_h^T h_{t-1}
+                a0, b0 = 4 * i * Hg * 64, i * Hg * 64
+                ops.gemm_bf16_nt(3 * Hg, Hg, ldT, dgT, a0, 64, inpT, b0, 64, G[nm + "weight_ih_l0"], 0, Hg,
+                                 accumulate=True, splitk=_splitk_bf16(3 * Hg, Hg, ldT), a_kstride=ka, b_kstride=kb)
+                ops.gemm_bf16_nt(2 * Hg, Hg, ldT, dgT, a0, 64, hpT, b0, 64, G[nm + "weight_hh_l0"], 0, Hg,
+                                 accumulate=True, splitk=_splitk_bf16(2 * Hg, Hg, ldT), a_kstride=ka, b_kstride=kb)
+                ops.gemm_bf16_nt(Hg, Hg, ldT, dgT, a0 + 3 * Hg * 64, 64, hpT, b0, 64, G[nm + "weight_hh_l0"],
+                                 2 * Hg * Hg, Hg, accumulate=True, splitk=_splitk_bf16(Hg, Hg, ldT), a_kstride=ka,
+                                 b_kstride=kb)
+
+        if need_dinp:
+            for i, nm in enumerate(names):
+                w_t = ops.transpose_bf16(P[nm + "weight_ih_l0"], 3 * Hg, Hg)          # K-tiled [3*Hg/64, Hg, 64]
+                ops.gemm_bf16_nt(rows, Hg, 3 * Hg, dgi, i * 3 * Hg, 3 * H, w_t, 0, 64, dinp, i * Hg, H,
+                                 b_kstride=Hg * 64)
+        SIDE.run(weight_grads, dgT, h, inp, inpT, hpT)
+        return dinp
+
     def layer_bwd(dout_h, lname, inp, h, coef, an, z, need_dinp):
+        if _bf16_gemm_path(prec, Hg):
+            return layer_bwd_bf16(dout_h, lname, inp, h, coef, an, z, need_dinp)
         w_hh = [P[f"{prefix}{lname}.{i}.weight_hh_l0"] for i in range(g)]
         dh = ops.gru_seq_bwd(dout_h, w_hh, coef, z, B, T, g, Hg, prec)
         dgi, dgh = ops.gru_gate_grads(dh, coef, an, rows, g, Hg, prec)

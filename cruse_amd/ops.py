@@ -208,6 +208,31 @@ def gemm(transA, transB, M, N, K, A, a_off, lda, Bm, b_off, ldb, C, c_off, ldc, 
                          1 if accumulate else 0, splitk, b_shift_T, prec_code(prec), _stream()))
 
 
+def gemm_bf16_nt(M, N, K, A, a_off, lda, Bm, b_off, ldb, C, c_off, ldc, bias=None, accumulate=False, splitk=1,
+                 a_kstride=64, b_kstride=64):
+    """C[M,N] (+)= A[M,K] . B[N,K]^T on bf16 operands (element offsets into the tensors' storage).
+    *_kstride == 64: row-major operand; larger: the K-tiled time-major layout (lda == 64), see cruse_hip.h."""
+    if A.dtype != torch.bfloat16 or Bm.dtype != torch.bfloat16 or C.dtype != torch.float32:
+        raise RuntimeError("gemm_bf16_nt needs bf16 operands and an f32 result")
+    check(lib.cruse_gemm_bf16_nt(M, N, K, A.data_ptr() + 2 * a_off, lda, a_kstride, Bm.data_ptr() + 2 * b_off, ldb, b_kstride,
+                                 C.data_ptr() + 4 * c_off, ldc, _p(bias), 1 if accumulate else 0, splitk, _stream()))
+
+
+def cast_bf16(x, out=None):
+    y = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16) if out is None else out
+    check(lib.cruse_cast_bf16(_p(x), _p(y), x.numel(), _stream()))
+    return y
+
+
+def transpose_bf16(x, rows, cols, shift_T=0, out=None):
+    """x [rows, cols] f32 -> K-tiled time-major bf16 [ceil(rows/64), cols, 64] (zero-padded frames);
+    shift_T > 0 reads row r-1 within each clip."""
+    ldT = (rows + 63) // 64 * 64
+    y = torch.empty(ldT // 64, cols, 64, device=x.device, dtype=torch.bfloat16) if out is None else out
+    check(lib.cruse_transpose_bf16(_p(x), rows, cols, cols, _p(y), ldT, shift_T, _stream()))
+    return y
+
+
 # ---------------------------------------------------------------- GRU recurrence
 def _ptr_array(ts: Sequence[torch.Tensor]):
     arr = (ctypes.c_void_p * len(ts))()
@@ -251,6 +276,19 @@ def gru_gate_grads(dh, coef, an, rows, G, Hg, prec):
     dgh = torch.empty_like(dgi)
     check(lib.cruse_gru_gate_grads(_p(dh), _p(coef), _p(an), _p(dgi), _p(dgh), rows, G, Hg, prec_code(prec), _stream()))
     return dgi, dgh
+
+
+def gru_gate_grads_bf16(dh, coef, an, rows, G, Hg, db_ih, db_hh):
+    """bf16 gate gradients for gemm_bf16_nt: returns (dgi [rows,G,3,Hg] bf16, dgT [ldT/64,G,4,Hg,64] bf16, ldT) and
+    accumulates the bias gradients into the per-group tensors db_ih[g], db_hh[g]."""
+    if coef.dtype != torch.bfloat16:
+        raise RuntimeError("gru_gate_grads_bf16 needs the bf16 coefficients of CRUSE_PREC_BF16")
+    ldT = (rows + 63) // 64 * 64
+    dgi = torch.empty(rows, G, 3, Hg, device=dh.device, dtype=torch.bfloat16)
+    dgT = torch.empty(ldT // 64, G, 4, Hg, 64, device=dh.device, dtype=torch.bfloat16)
+    check(lib.cruse_gru_gate_grads_bf16(_p(dh), _p(coef), _p(an), _p(dgi), _p(dgT), ldT, _ptr_array(db_ih),
+                                        _ptr_array(db_hh), rows, G, Hg, _stream()))
+    return dgi, dgT, ldT
 
 
 def gru_status() -> int:

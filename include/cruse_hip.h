@@ -155,6 +155,22 @@ int cruse_gemm(int transA, int transB, int M, int N, int K,
                const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                const float* bias, int accumulate, int splitk, int b_shift_T, int prec, void* stream);
 
+/* bf16-operand form of the same products for CRUSE_PREC_BF16: C[M,N] (=|+=) A[M,K] . B[N,K]^T (+ bias[n]), C f32,
+ * K % 64 == 0.  Operand element (m, k) is A[(k/64)*a_kstride + m*lda + k%64]: a_kstride == 64 is plain row-major
+ * (lda >= K); the K-TILED time-major layout of cruse_transpose_bf16 / cruse_gru_gate_grads_bf16 has lda == 64 and
+ * a_kstride == 64 * (number of lines).  Same for B.  splitk > 1 adds atomically and needs accumulate != 0.
+ * Operand values are the RNE roundings cruse_gemm forms internally. */
+int cruse_gemm_bf16_nt(int M, int N, int K, const void* A, long long lda, long long a_kstride,
+                       const void* B, long long ldb, long long b_kstride,
+                       float* C, long long ldc, const float* bias, int accumulate, int splitk, void* stream);
+/* y[i] = bf16(x[i]), n % 4 == 0 */
+int cruse_cast_bf16(const float* x, void* y, long long n, void* stream);
+/* K-tiled time-major transpose: yT[(r/64)*cols*64 + c*64 + r%64] = bf16(x[(r - s)*ld + c]) with s = 0, or s = 1
+ * when shift_T > 0 (then 0 where r % shift_T == 0: the h_{t-1} operand of dW_hh); frames rows <= r < ldT are
+ * zero-filled (ldT % 64 == 0). */
+int cruse_transpose_bf16(const float* x, long long rows, int cols, long long ld, void* yT, long long ldT,
+                         int shift_T, void* stream);
+
 /* ---- grouped-GRU recurrence (nn.GRU forward/backward at cruse_net.py:44,50) ----- */
 
 /* Persistent recurrence.  gi [B,T,G,3*Hg] = x W_ih^T + b_ih (gate order r,z,n) from cruse_gemm;
@@ -177,6 +193,13 @@ int cruse_gru_seq_bwd(const float* dout, const float* const* w_hh, const void* c
  * [rows,G,3*Hg]; dW_ih, dW_hh, dX and the bias gradients follow from cruse_gemm / cruse_col_sum. */
 int cruse_gru_gate_grads(const float* dh, const void* coef, const float* an, float* dgi, float* dgh,
                          long long rows, int G, int Hg, int prec, void* stream);
+/* CRUSE_PREC_BF16 form feeding cruse_gemm_bf16_nt (coef bf16).  dgi and dgh share the r and z gates, so four
+ * slabs (r, z, n_i, n_h) carry both: dgi [rows,G,3,Hg] bf16 = (r,z,n_i) row-major; dgT [ldT/64,G,4,Hg,64] bf16 =
+ * the K-tiled time-major transpose (ldT = rows rounded up to 64, zero padded): dW_ih uses slabs 0-2, dW_hh 0,1,3.
+ * db_ih / db_hh: HOST arrays of G device pointers (or NULL) to [3*Hg] bias gradients, ACCUMULATED from f32. */
+int cruse_gru_gate_grads_bf16(const float* dh, const void* coef, const float* an, void* dgi, void* dgT,
+                              long long ldT, float* const* db_ih, float* const* db_hh,
+                              long long rows, int G, int Hg, void* stream);
 
 /* ---- mask application + weighted spectral loss ------------------------------- */
 

@@ -232,7 +232,7 @@ def test_batchnorm_relu_skip_fwd_bwd(ops, C, Fq):
     assert rel_l2(dbias, dy_e.double().sum(dim=(0, 1, 3)).float()) < 1e-5
 
 
-@pytest.mark.parametrize("H,g", [(640, 1), (640, 4), (1024, 2), (96, 3)])
+@pytest.mark.parametrize("H,g", [(640, 1), (640, 4), (1024, 2), (96, 3), (1024, 1), (100, 1)])
 def test_layernorm_interleave_fwd_bwd(ops, H, g):
     rows = 37
     gen = torch.Generator().manual_seed(50 + g)
@@ -419,3 +419,65 @@ def test_adam_matches_torch(ops):
         p.grad = g.clone(); opt.step()
         ops.adam_step(pd, (2 * g).cuda(), m, v, 1e-2, 0.9, 0.99, 1e-8, 0.0, step, grad_scale=0.5)
     assert max_abs(pd, p.detach()) < 1e-6
+
+
+# ------------------------------------------------------------------ bf16-operand GEMM path (CRUSE_PREC_BF16)
+@pytest.mark.parametrize("M,N,K,sk", [(300, 200, 128, 1), (128, 128, 64, 1), (1920, 640, 1088, 4), (65, 33, 256, 2)])
+def test_gemm_bf16_nt(ops, M, N, K, sk):
+    gen = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K + 64, generator=gen).cuda().to(torch.bfloat16)          # lda > K
+    Bm = torch.randn(N, K, generator=gen).cuda().to(torch.bfloat16)
+    bias = torch.randn(N, generator=gen).cuda()
+    ref = A[:, :K].double() @ Bm.double().t()
+    C = torch.full((M, N + 4), 7.0).cuda()                                      # ldc > N: the margin must survive
+    ops.gemm_bf16_nt(M, N, K, A, 0, K + 64, Bm, 0, K, C, 0, N + 4, bias=bias)
+    assert rel_l2(C[:, :N], ref + bias.double()) < 1e-6 and (C[:, N:] == 7.0).all()
+    C0 = torch.randn(M, N + 4, generator=gen).cuda()
+    C = C0.clone()
+    ops.gemm_bf16_nt(M, N, K, A, 0, K + 64, Bm, 0, K, C, 0, N + 4, accumulate=True, splitk=sk)
+    assert rel_l2(C[:, :N], ref + C0[:, :N].double()) < 1e-6 and torch.equal(C[:, N:], C0[:, N:])
+
+
+def test_bf16_layout_kernels(ops):
+    B, T, H = 3, 17, 96
+    rows = B * T
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(rows, H, generator=gen).cuda()
+    assert torch.equal(ops.cast_bf16(x), x.to(torch.bfloat16))
+    untile = lambda y: y.permute(1, 0, 2).reshape(y.shape[1], -1)          # [kt, lines, 64] -> [lines, ldT]
+    xt = ops.transpose_bf16(x, rows, H)
+    assert xt.shape == (1, H, 64)
+    xt = untile(xt)
+    assert torch.equal(xt[:, :rows], x.to(torch.bfloat16).t()) and xt[:, rows:].abs().max() == 0
+    xs = untile(ops.transpose_bf16(x, rows, H, shift_T=T))
+    ref = torch.zeros(B, T, H).cuda(); ref[:, 1:] = x.view(B, T, H)[:, :-1]
+    assert torch.equal(xs[:, :rows], ref.view(rows, H).to(torch.bfloat16).t()) and xs[:, rows:].abs().max() == 0
+    # several k-tiles + a GEMM on the K-tiled operands: C = x^T x
+    x2 = torch.randn(200, 160, generator=gen).cuda()
+    t2 = ops.transpose_bf16(x2, 200, 160)
+    assert t2.shape == (4, 160, 64) and torch.equal(untile(t2)[:, :200], x2.to(torch.bfloat16).t())
+    C = torch.zeros(160, 160).cuda()
+    ops.gemm_bf16_nt(160, 160, 256, t2, 0, 64, t2, 0, 64, C, 0, 160, accumulate=True, splitk=2, a_kstride=160 * 64,
+                     b_kstride=160 * 64)
+    xb = x2.to(torch.bfloat16).double()
+    assert rel_l2(C, xb.t() @ xb) < 1e-6
+
+
+@pytest.mark.parametrize("G,Hg", [(1, 128), (2, 96), (4, 160)])
+def test_gru_gate_grads_bf16_matches_f32_form(ops, G, Hg):
+    rows, H = 3 * 37, G * Hg
+    gen = torch.Generator().manual_seed(G * 100 + Hg)
+    dh = torch.randn(rows, H, generator=gen).cuda()
+    an = torch.rand(rows, H, generator=gen).cuda()
+    coef = torch.randn(rows, G, 3, Hg, generator=gen).cuda().to(torch.bfloat16)
+    dgi_ref, dgh_ref = ops.gru_gate_grads(dh, coef, an, rows, G, Hg, "bf16")   # f32 [rows,G,3,Hg]
+    db_ih = [torch.ones(3 * Hg).cuda() for _ in range(G)]
+    db_hh = [torch.ones(3 * Hg).cuda() for _ in range(G)]
+    dgi, dgT, ldT = ops.gru_gate_grads_bf16(dh, coef, an, rows, G, Hg, db_ih, db_hh)
+    assert ldT == 128 and torch.equal(dgi, dgi_ref.view(rows, G, 3, Hg).to(torch.bfloat16))
+    slabs = torch.cat([dgi_ref.view(rows, G, 3, Hg), dgh_ref.view(rows, G, 3, Hg)[:, :, 2:]], dim=2)   # r, z, n_i, n_h
+    dgT = dgT.permute(1, 2, 3, 0, 4).reshape(G, 4, Hg, ldT)                 # [kt,G,4,Hg,64] -> [G,4,Hg,ldT]
+    assert torch.equal(dgT[..., :rows], slabs.permute(1, 2, 3, 0).to(torch.bfloat16)) and dgT[..., rows:].abs().max() == 0
+    for g in range(G):
+        assert rel_l2(db_ih[g] - 1, dgi_ref.view(rows, G, 3 * Hg)[:, g].double().sum(0)) < 1e-5
+        assert rel_l2(db_hh[g] - 1, dgh_ref.view(rows, G, 3 * Hg)[:, g].double().sum(0)) < 1e-5
