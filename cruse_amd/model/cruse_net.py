@@ -33,9 +33,45 @@ class _SideStream:
 
     def __init__(self):
         self.enabled = os.environ.get("CRUSE_OVERLAP", "1") == "1"
+        self.defer_mask = int(os.environ.get("CRUSE_DEFER", "1"))   # 1 skip convs, 2 decoder leaves, 4 GRU weight grads
         self.streams = {}
         self.keep = []
+        self.deferred = []
         self.active = False
+
+    def _side(self):
+        dev = torch.cuda.current_device()
+        side = self.streams.get(dev)
+        if side is None:
+            side = self.streams[dev] = torch.cuda.Stream()
+        return side
+
+    def defer(self, fn, *tensors, kind=7):
+        """Queue a leaf for the next release_around(): it then starts WITH the next recurrence kernel (which leaves
+        ~96 CUs idle for its whole duration) instead of competing with the throughput-bound kernels before it."""
+        if not (self.enabled and (self.defer_mask & kind)):
+            self.run(fn, *tensors)
+            return
+        self.deferred.append(fn)
+        self.keep.extend(tensors)
+
+    def release_around(self, launch):
+        """launch() issues a recurrence kernel on the main stream; the deferred leaves are issued right after it on
+        the side stream, ordered only after the work that preceded the recurrence launch."""
+        if not (self.enabled and self.deferred):
+            return launch()
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        out = launch()
+        side = self._side()
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            for fn in self.deferred:
+                fn()
+        self.deferred.clear()
+        self.active = True
+        return out
 
     def run(self, fn, *tensors):
         if not self.enabled:
@@ -53,6 +89,10 @@ class _SideStream:
             fn()
 
     def join(self):
+        if self.enabled and self.deferred:       # nothing left to hide behind: issue what is still queued
+            fns, self.deferred = self.deferred, []
+            for fn in fns:
+                self.run(fn)
         if self.enabled and self.active:
             torch.cuda.current_stream().wait_stream(self.streams[torch.cuda.current_device()])
             self.keep.clear()
@@ -106,7 +146,7 @@ def ggru_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], prefix: str, group
                          prec=prec)
         w_hh = [P[f"{prefix}{lname}.{i}.weight_hh_l0"] for i in range(g)]
         b_hh = [P[f"{prefix}{lname}.{i}.bias_hh_l0"] for i in range(g)]
-        return ops.gru_seq_fwd(gi, w_hh, b_hh, B, T, g, Hg, prec, save=save)
+        return SIDE.release_around(lambda: ops.gru_seq_fwd(gi, w_hh, b_hh, B, T, g, Hg, prec, save=save))
 
     h1, c1, a1, z1 = layer(x, "gru_list1")
     l1, m1, s1 = ops.ln_fwd(h1, P[prefix + "ln1.weight"], P[prefix + "ln1.bias"], None, rows, H, g, save=save)
@@ -125,11 +165,11 @@ def ggru_backward(ctx, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[s
     Hg = H // g
     rows = B * T
 
-    def layer_bwd_bf16(dout_h, lname, inp, h, coef, an, z, need_dinp):
+    def layer_bwd_bf16(dout_h, lname, inp, h, coef, an, z, need_dinp, last):
         """CRUSE_PREC_BF16: every product as gemm_bf16_nt on bf16 operand copies (see gemm_bf16.hip)."""
         names = [f"{prefix}{lname}.{i}." for i in range(g)]
         w_hh = [P[nm + "weight_hh_l0"] for nm in names]
-        dh = ops.gru_seq_bwd(dout_h, w_hh, coef, z, B, T, g, Hg, prec)
+        dh = SIDE.release_around(lambda: ops.gru_seq_bwd(dout_h, w_hh, coef, z, B, T, g, Hg, prec))
         dgi, dgT, ldT = ops.gru_gate_grads_bf16(dh, coef, an, rows, g, Hg, [G[nm + "bias_ih_l0"] for nm in names],
                                                 [G[nm + "bias_hh_l0"] for nm in names])
         dinp = torch.empty(B, T, H, device=dout_h.device, dtype=torch.float32) if need_dinp else None
@@ -157,14 +197,18 @@ def ggru_backward(ctx, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[s
                 w_t = ops.transpose_bf16(P[nm + "weight_ih_l0"], 3 * Hg, Hg)          # K-tiled [3*Hg/64, Hg, 64]
                 ops.gemm_bf16_nt(rows, Hg, 3 * Hg, dgi, i * 3 * Hg, 3 * H, w_t, 0, 64, dinp, i * Hg, H,
                                  b_kstride=Hg * 64)
-        SIDE.run(weight_grads, dgT, h, inp, inpT, hpT)
+        if last:
+            SIDE.run(weight_grads, dgT, h, inp, inpT, hpT)
+        else:
+            SIDE.defer(weight_grads, dgT, h, inp, inpT, hpT, kind=4)
         return dinp
 
-    def layer_bwd(dout_h, lname, inp, h, coef, an, z, need_dinp):
+    def layer_bwd(dout_h, lname, inp, h, coef, an, z, need_dinp, last):
+        """last: no recurrence follows, so the weight-gradient leaves start at once instead of with the next one."""
         if _bf16_gemm_path(prec, Hg):
-            return layer_bwd_bf16(dout_h, lname, inp, h, coef, an, z, need_dinp)
+            return layer_bwd_bf16(dout_h, lname, inp, h, coef, an, z, need_dinp, last)
         w_hh = [P[f"{prefix}{lname}.{i}.weight_hh_l0"] for i in range(g)]
-        dh = ops.gru_seq_bwd(dout_h, w_hh, coef, z, B, T, g, Hg, prec)
+        dh = SIDE.release_around(lambda: ops.gru_seq_bwd(dout_h, w_hh, coef, z, B, T, g, Hg, prec))
         dgi, dgh = ops.gru_gate_grads(dh, coef, an, rows, g, Hg, prec)
         dinp = torch.empty(B, T, H, device=dout_h.device, dtype=torch.float32) if need_dinp else None
         sk = _splitk(3 * Hg, Hg, rows)
@@ -185,15 +229,18 @@ def ggru_backward(ctx, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[s
             for i in range(g):
                 ops.gemm(False, False, rows, Hg, 3 * Hg, dgi, i * 3 * Hg, 3 * H,
                          P[f"{prefix}{lname}.{i}.weight_ih_l0"], 0, Hg, dinp, i * Hg, H, prec=prec)
-        SIDE.run(weight_grads, dgi, dgh, h, inp)
+        if last:
+            SIDE.run(weight_grads, dgi, dgh, h, inp)
+        else:
+            SIDE.defer(weight_grads, dgi, dgh, h, inp, kind=4)
         return dinp
 
     dh2 = ops.ln_bwd(dout, ctx["h2"], ctx["m2"], ctx["s2"], P[prefix + "ln2.weight"], rows, H, 1,
                      G[prefix + "ln2.weight"], G[prefix + "ln2.bias"])
-    dl1 = layer_bwd(dh2, "gru_list2", ctx["l1"], ctx["h2"], ctx["c2"], ctx["a2"], ctx["z2"], True)
+    dl1 = layer_bwd(dh2, "gru_list2", ctx["l1"], ctx["h2"], ctx["c2"], ctx["a2"], ctx["z2"], True, False)
     dh1 = ops.ln_bwd(dl1, ctx["h1"], ctx["m1"], ctx["s1"], P[prefix + "ln1.weight"], rows, H, g,
                      G[prefix + "ln1.weight"], G[prefix + "ln1.bias"])
-    dx = layer_bwd(dh1, "gru_list1", ctx["x"], ctx["h1"], ctx["c1"], ctx["a1"], ctx["z1"], need_dx)
+    dx = layer_bwd(dh1, "gru_list1", ctx["x"], ctx["h1"], ctx["c1"], ctx["a1"], ctx["z1"], need_dx, True)
     if join:
         SIDE.join()
     return dx
@@ -245,7 +292,7 @@ def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, tor
             ops.conv_gather(e, P[f"skip_connect_{k}.weight"], None, B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1,
                             out=s, prec=prec)
         if k < L:
-            SIDE.run(skip_conv, e, s)            # needed by the decoder only: overlaps the GRU forward
+            SIDE.defer(skip_conv, e, s, kind=1)  # needed by the decoder only: issued with the GRU forward
         else:
             skip_conv()
         ys.append(y); es.append(e); ss.append(s); stats.append((mean, rstd))
@@ -281,7 +328,7 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
     def leaf_dec1(dv=dv):
         ops.channel_sum(dv, rows, ch[0], Fk[0], G["conv1_t.bias"])
         ops.conv_wgrad(us[1], dv, G["conv1_t.weight"], B, T, ch[1], Fk[1], ch[0], Fk[0], KT=1, S=2, pad=0, prec=prec)
-    SIDE.run(leaf_dec1, dv)
+    SIDE.defer(leaf_dec1, dv, kind=2)                           # decoder leaves: issued with the first GRU backward
     du = ops.conv_gather(dv, P["conv1_t.weight"], None, B, T, ch[0], Fk[0], ch[1], Fk[1], KT=1, S=2, pad=0, prec=prec)
     ds = {1: du}                                        # gradient wrt skip_{k} output = du_k
     # ---- decoder levels 2..L ------------------------------------------------------------
@@ -293,7 +340,7 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
 
         def leaf_dec(dv=dv, k=k):
             ops.conv_wgrad(us[k], dv, G[f"conv{k}_t.weight"], B, T, ch[k], Fk[k], ch[k - 1], Fk[k - 1], KT=1, S=2, pad=0, prec=prec)
-        SIDE.run(leaf_dec, dv)
+        SIDE.defer(leaf_dec, dv, kind=2)
         du = ops.conv_gather(dv, P[f"conv{k}_t.weight"], None, B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k], KT=1, S=2, pad=0,
                              prec=prec)
         ds[k] = du
