@@ -12,15 +12,18 @@
 // steps of 32 (4 lane groups x 8 bins).  A workgroup is persistent over frame tiles and keeps its
 // accumulators in registers; it writes one partial slab at the end, summed by wgrad_reduce_kernel.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int MAXV = 8;
+constexpr int RPAD = 8;
 
 struct WMArgs {
     const float* a; const float* bt; float* partial;
     int B, T, Ca, Fa, Cb, Fb, KT, S, pad;
     int FaP, NCH, ntaps, nrows, ntiles_total;
+    int dbg;                               // profiling only (CRUSE_WG_DBG bit mask: skip 1 patch build, 2 MFMA loop, 4 loads, 8 A/raw image)
 };
 
 template <int PREC> struct WStore {
@@ -37,6 +40,23 @@ __device__ __forceinline__ void wput(typename WStore<PREC>::elem* base, size_t p
     if constexpr (PREC == CRUSE_PREC_F32) base[off] = v;
     else if constexpr (PREC == CRUSE_PREC_BF16) base[off] = (__bf16)v;
     else { __bf16 h, l; split_bf16(v, h, l); base[off] = h; base[plane + off] = l; }
+}
+// two consecutive elements (even offset) in one LDS store
+template <int PREC>
+__device__ __forceinline__ void wput2(typename WStore<PREC>::elem* base, size_t plane, size_t off, float v0, float v1) {
+    if constexpr (PREC == CRUSE_PREC_F32) {
+        *reinterpret_cast<float2*>(base + off) = make_float2(v0, v1);
+    } else {
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+        bf16x2 h;
+        h[0] = (__bf16)v0; h[1] = (__bf16)v1;
+        *reinterpret_cast<bf16x2*>(base + off) = h;
+        if constexpr (PREC == CRUSE_PREC_BF16X3) {
+            bf16x2 l;
+            l[0] = (__bf16)(v0 - (float)h[0]); l[1] = (__bf16)(v1 - (float)h[1]);
+            *reinterpret_cast<bf16x2*>(base + plane + off) = l;
+        }
+    }
 }
 template <int PREC>
 __device__ __forceinline__ Frag<PREC> wget(const typename WStore<PREC>::elem* base, size_t plane, size_t off) {
@@ -61,8 +81,11 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WMArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int FaP = p.FaP, NJ = NTW * 4 * 16;               // padded patch rows
-    const size_t aplane = (size_t)MT * 16 * TFW * FaP;      // elements per A plane
-    const size_t bplane = (size_t)NJ * TFW * FaP;           // elements per patch plane
+    // operand row stride: TFW*FaP is a multiple of 64 elements, so unpadded rows put the 16 rows of a fragment read
+    // on the same LDS banks (8-16-way conflicts on every ds_read_b128); RPAD elements (16 bytes) de-phase them
+    const int RS = TFW * FaP + RPAD;
+    const size_t aplane = (size_t)MT * 16 * RS;             // elements per A plane
+    const size_t bplane = (size_t)NJ * RS;                  // elements per patch plane
     elem* al = reinterpret_cast<elem*>(smem_raw);           // [NPL][MT*16][TFW][FaP]
     elem* pl = al + NPL * aplane;                            // [NPL][NJ][TFW][FaP]
     float* rawl = reinterpret_cast<float*>(pl + NPL * bplane);   // [nrows][Cb][Fb]
@@ -71,7 +94,11 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WMArgs p) {
     const int nva = TFW * rowa / 4, nvb = p.nrows * rowb / 4;
 
     // zero both operand images once: pad bins, pad rows and pad columns stay zero for good
-    for (size_t i = tid; i < NPL * (aplane + bplane); i += 256) al[i] = (elem)0.f;
+    {
+        uint4* z = reinterpret_cast<uint4*>(al);             // both images are multiples of 16 bytes
+        const size_t n16 = NPL * (aplane + bplane) * sizeof(elem) / 16;
+        for (size_t i = tid; i < n16; i += 256) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
 
     f32x4 acc[MT][NTW];
 #pragma unroll
@@ -81,44 +108,56 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WMArgs p) {
 
     // ---- tile-invariant coordinates, computed once (the runtime integer divisions they need used to sit
     //      in the per-element loops and dominated the kernel) -------------------------------------------------
-    // A staging: slot q covers 4 consecutive floats of the [TFW][Ca][Fa] tile; LDS offset per element
-    int a_off[MAXV][4];
+    // A staging: slot q covers 4 consecutive floats of the [TFW][Ca][Fa] tile = two bin PAIRS (Fa is even, so a pair
+    // never straddles a row); LDS element offset per pair
+    int a_off[MAXV][2];
     bool a_ok[MAXV];
 #pragma unroll
     for (int q = 0; q < MAXV; ++q) {
         const int i = tid + 256 * q;
         a_ok[q] = i < nva;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = min(i, nva - 1) * 4 + u;
+        for (int u = 0; u < 2; ++u) {
+            const int e = min(i, nva - 1) * 4 + 2 * u;
             const int r = e / rowa, j = e - r * rowa;
             const int ca = j / p.Fa, fa = j - ca * p.Fa;
-            a_off[q][u] = (ca * TFW + r) * FaP + fa;
+            a_off[q][u] = ca * RS + r * FaP + fa;
         }
     }
-    // patch build: 768 virtual threads (3 slots per thread); virtual thread vt owns position vt % P of the
-    // TFW x Fa tile and the channels cb = vt / P, + ngroups, ... -- all offsets fixed per slot
+    // patch build: 768 virtual threads (3 slots per thread); virtual thread vt owns the bin PAIR vt % P2 of the
+    // TFW x Fa tile and the channels cb = vt / P2, + ngroups, ...  A pair's three taps read the 4 (S = 1) or 5
+    // (S = 2) consecutive source bins fb0 .. fb0+NSRC-1 and write three packed bf16x2 / float2 entries.
     constexpr int MAXP = 3;
-    const int P = TFW * p.Fa;
-    const int ngroups = max(1, (256 * MAXP) / P);
-    int p_dst[MAXP], p_cb0[MAXP], p_src[MAXP][3];            // dst = tl*FaP + fa; src[kf] = tl*Cb*Fb + fb (or -1)
+    const int P2 = TFW * p.Fa / 2;
+    // alignment class of the patch source reads (the staged rows start 16-byte aligned when Fb % 4 == 0)
+    const int src_al = (p.Fb % 4 != 0) ? 0 : (p.S == 2 && p.pad == 1) ? 2 : (p.S == 1 && p.pad == 1) ? 1 :
+                       (p.S == 2 && p.pad == 0) ? 3 : 0;
+    const int ngroups = max(1, (256 * MAXP) / P2);
+    const int tap_stride = p.Cb * RS, cb_stride = RS;
+    int p_dst[MAXP], p_src[MAXP];                            // dst = cb0*cb_stride + tl*FaP + fa; src = cb0*Fb + tl*rowb + fb0
+    unsigned p_ok[MAXP];                                     // bit i: source bin fb0 + i is inside [0, Fb)
 #pragma unroll
     for (int sidx = 0; sidx < MAXP; ++sidx) {
         const int vt = tid + 256 * sidx;
-        const int grp = vt / P, pos = vt - grp * P;
-        p_dst[sidx] = -1; p_cb0[sidx] = 0;
-#pragma unroll
-        for (int kf = 0; kf < 3; ++kf) p_src[sidx][kf] = -1;
+        const int grp = vt / P2, pos = vt - grp * P2;
+        p_dst[sidx] = -1; p_src[sidx] = 0; p_ok[sidx] = 0;
         if (grp < ngroups) {
-            const int tl = pos / p.Fa, fa = pos - tl * p.Fa;
-            p_dst[sidx] = tl * FaP + fa;
-            p_cb0[sidx] = grp;
-#pragma unroll
-            for (int kf = 0; kf < 3; ++kf) {
-                const int fb = fa * p.S - p.pad + kf;
-                p_src[sidx][kf] = (fb >= 0 && fb < p.Fb) ? tl * rowb + fb : -1;
-            }
+            const int tl = (2 * pos) / p.Fa, fa = 2 * pos - tl * p.Fa;
+            const int fb0 = fa * p.S - p.pad;
+            p_dst[sidx] = grp * cb_stride + tl * FaP + fa;
+            p_src[sidx] = grp * p.Fb + tl * rowb + fb0;
+            for (int i = 0; i < 5; ++i)
+                if (fb0 + i >= 0 && fb0 + i < p.Fb) p_ok[sidx] |= 1u << i;
         }
+    }
+    // frame index of every load slot inside the tile, 4 bits each (tile-invariant; the divisions used to sit in
+    // prefetch() and cost ~2 us per tile)
+    unsigned fr_a = 0, fr_b = 0;
+#pragma unroll
+    for (int q = 0; q < MAXV; ++q) {
+        const int i = tid + 256 * q;
+        fr_a |= (unsigned)min(15, (i * 4) / rowa) << (4 * q);
+        fr_b |= (unsigned)min(15, (i * 4) / rowb) << (4 * q);
     }
     float4 pa[MAXV], pb[MAXV];
     auto prefetch = [&](int tile) {
@@ -130,12 +169,13 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WMArgs p) {
         for (int q = 0; q < MAXV; ++q) {
             const int i = tid + 256 * q;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < nva && t0 + (i * 4) / rowa < p.T) v = *reinterpret_cast<const float4*>(srca + i * 4);
+            if (!(p.dbg & 4) && i < nva && t0 + (int)((fr_a >> (4 * q)) & 15u) < p.T)
+                v = *reinterpret_cast<const float4*>(srca + i * 4);
             pa[q] = v;
             float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < nvb) {
-                const int t = t0 - (p.KT - 1) + (i * 4) / rowb;
-                if (t >= 0 && t < p.T) w = *reinterpret_cast<const float4*>(srcb + i * 4);
+                const int t = t0 - (p.KT - 1) + (int)((fr_b >> (4 * q)) & 15u);
+                if (!(p.dbg & 4) && t >= 0 && t < p.T) w = *reinterpret_cast<const float4*>(srcb + i * 4);
             }
             pb[q] = w;
         }
@@ -147,10 +187,9 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WMArgs p) {
         // A image: [t][ca][fa] -> al[ca][tl][fa];  raw bt frames -> rawl (straight copy)
 #pragma unroll
         for (int q = 0; q < MAXV; ++q) {
-            if (a_ok[q]) {
-                const float vv[4] = {pa[q].x, pa[q].y, pa[q].z, pa[q].w};
-#pragma unroll
-                for (int u = 0; u < 4; ++u) wput<PREC>(al, aplane, (size_t)a_off[q][u], vv[u]);
+            if (a_ok[q] && !(p.dbg & 8)) {
+                wput2<PREC>(al, aplane, (size_t)a_off[q][0], pa[q].x, pa[q].y);
+                wput2<PREC>(al, aplane, (size_t)a_off[q][1], pa[q].z, pa[q].w);
             }
             const int i = tid + 256 * q;
             if (i < nvb) *reinterpret_cast<float4*>(rawl + i * 4) = pb[q];
@@ -160,35 +199,67 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WMArgs p) {
         // patch image: pl[j = tap*Cb + cb][tl][fa] = bt[tl + kt][cb][fa*S - pad + kf]
 #pragma unroll
         for (int sidx = 0; sidx < MAXP; ++sidx) {
-            if (p_dst[sidx] < 0) continue;
-            for (int cb = p_cb0[sidx]; cb < p.Cb; cb += ngroups) {
-                for (int kt = 0; kt < p.KT; ++kt) {
-                    const float* rsrc = rawl + (kt * p.Cb + cb) * p.Fb;
+            if (p_dst[sidx] < 0 || (p.dbg & 1)) continue;
+            const unsigned ok = p_ok[sidx];
+            int dst = p_dst[sidx], src = p_src[sidx];
+            for (int cb = (tid + 256 * sidx) / P2; cb < p.Cb; cb += ngroups) {
 #pragma unroll
-                    for (int kf = 0; kf < 3; ++kf) {
-                        const int so = p_src[sidx][kf];
-                        wput<PREC>(pl, bplane, (size_t)((kt * 3 + kf) * p.Cb + cb) * TFW * FaP + p_dst[sidx],
-                                   so >= 0 ? rsrc[so] : 0.f);
+                for (int kt = 0; kt < 2; ++kt) {
+                    if (kt < p.KT) {
+                        const float* rs_ = rawl + src + kt * rowb;      // frame tl + kt of the staged rows
+                        // fb0 is odd (2*fa - 1 or fa - 1 with fa even) except for the pad-0 decoder form: the aligned
+                        // part of the 4-5 source bins comes in one or two wide LDS reads
+                        float v[5];
+                        if (src_al == 2) {                               // S = 2, pad = 1: bins fb0+1 .. fb0+4 are 16-byte aligned
+                            const float4 w = *reinterpret_cast<const float4*>(rs_ + 1);
+                            v[0] = rs_[0]; v[1] = w.x; v[2] = w.y; v[3] = w.z; v[4] = w.w;
+                        } else if (src_al == 1) {                        // S = 1, pad = 1: bins fb0+1, fb0+2 are 8-byte aligned
+                            const float2 w = *reinterpret_cast<const float2*>(rs_ + 1);
+                            v[0] = rs_[0]; v[1] = w.x; v[2] = w.y; v[3] = rs_[3]; v[4] = 0.f;
+                        } else if (src_al == 3) {                        // S = 2, pad = 0: bins fb0 .. fb0+3 are 16-byte aligned
+                            const float4 w = *reinterpret_cast<const float4*>(rs_);
+                            v[0] = w.x; v[1] = w.y; v[2] = w.z; v[3] = w.w; v[4] = rs_[4];
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 5; ++i) v[i] = rs_[i];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) v[i] = (ok >> i) & 1u ? v[i] : 0.f;
+                        elem* d = pl + dst + kt * 3 * tap_stride;
+                        if (p.S == 2) {
+                            wput2<PREC>(d, bplane, 0, v[0], v[2]);
+                            wput2<PREC>(d, bplane, (size_t)tap_stride, v[1], v[3]);
+                            wput2<PREC>(d, bplane, (size_t)2 * tap_stride, v[2], v[4]);
+                        } else {
+                            wput2<PREC>(d, bplane, 0, v[0], v[1]);
+                            wput2<PREC>(d, bplane, (size_t)tap_stride, v[1], v[2]);
+                            wput2<PREC>(d, bplane, (size_t)2 * tap_stride, v[2], v[3]);
+                        }
                     }
                 }
+                dst += ngroups * cb_stride;
+                src += ngroups * p.Fb;
             }
         }
         __syncthreads();
-        for (int ks = 0; ks < nks; ++ks) {
-            const int chunk = ks * 4 + (lane >> 4);
-            const int tl = chunk / p.NCH, fc = chunk - tl * p.NCH;
-            const size_t poff = (size_t)tl * FaP + fc * 8;
+        // K steps: lane group (lane >> 4) takes chunk ks*4 + group; (frame, bin-chunk) advance without dividing
+        int tl = (lane >> 4) / p.NCH, fc = (lane >> 4) - tl * p.NCH;
+#pragma unroll 2
+        for (int ks = 0; ks < ((p.dbg & 2) ? 0 : nks); ++ks) {
+            const size_t poff = (size_t)(tl * FaP + fc * 8);
             Frag<PREC> fa_[MT];
 #pragma unroll
             for (int i = 0; i < MT; ++i)
-                fa_[i] = wget<PREC>(al, aplane, (size_t)(i * 16 + (lane & 15)) * TFW * FaP + poff);
+                fa_[i] = wget<PREC>(al, aplane, (size_t)(i * 16 + (lane & 15)) * RS + poff);
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 const int col = (wv * NTW + j) * 16 + (lane & 15);
-                const Frag<PREC> fb_ = wget<PREC>(pl, bplane, (size_t)col * TFW * FaP + poff);
+                const Frag<PREC> fb_ = wget<PREC>(pl, bplane, (size_t)col * RS + poff);
 #pragma unroll
                 for (int i = 0; i < MT; ++i) acc[i][j] = mma(fa_[i], fb_, acc[i][j]);
             }
+            fc += 4;
+            while (fc >= p.NCH) { fc -= p.NCH; ++tl; }
         }
     }
     // partial slab [Ca][Cb][KT*3]
@@ -239,7 +310,8 @@ int launch_mt(const WMArgs& p, int mt, int ntw, int grid, size_t lds, hipStream_
 int cruse_wgrad_mfma_try(const float* a, const float* bt, float* partial, int max_slabs,
                          int B, int T, int Ca, int Fa, int Cb, int Fb, int KT, int S, int pad, int prec,
                          int* nblk_out, hipStream_t stream) {
-    const int tfw = (prec == CRUSE_PREC_BF16) ? 8 : 4;
+    int tfw = (prec == CRUSE_PREC_BF16) ? 8 : 4;
+    { const char* e = getenv("CRUSE_WG_TFW"); if (e && atoi(e) == 4) tfw = 4; }      // profiling override
     const int FaP = (Fa + 7) / 8 * 8, NCH = FaP / 8;
     const int ntaps = KT * 3;
     const int mt = Ca <= 16 ? 1 : (Ca <= 32 ? 2 : 4);
@@ -251,7 +323,7 @@ int cruse_wgrad_mfma_try(const float* a, const float* bt, float* partial, int ma
     if (tfw * Ca * Fa > MAXV * 1024 || (tfw + KT - 1) * Cb * Fb > MAXV * 1024) return 0;
     if (tfw * Fa > 768) return 0;
     const int esz = (prec == CRUSE_PREC_F32) ? 4 : 2, npl = (prec == CRUSE_PREC_BF16X3) ? 2 : 1;
-    const size_t lds = ((size_t)mt * 16 + (size_t)ntw * 64) * tfw * FaP * esz * npl +
+    const size_t lds = ((size_t)mt * 16 + (size_t)ntw * 64) * (tfw * FaP + RPAD) * esz * npl +
                        (size_t)(tfw + KT - 1) * Cb * Fb * 4;
     if (lds > 150 * 1024) return 0;
     WMArgs p = {};
@@ -259,11 +331,14 @@ int cruse_wgrad_mfma_try(const float* a, const float* bt, float* partial, int ma
     p.B = B; p.T = T; p.Ca = Ca; p.Fa = Fa; p.Cb = Cb; p.Fb = Fb; p.KT = KT; p.S = S; p.pad = pad;
     p.FaP = FaP; p.NCH = NCH; p.ntaps = ntaps; p.nrows = tfw + KT - 1;
     p.ntiles_total = B * ((T + tfw - 1) / tfw);
+    { const char* e = getenv("CRUSE_WG_DBG"); p.dbg = e ? atoi(e) : 0; }
     int grid = p.ntiles_total < max_slabs ? p.ntiles_total : max_slabs;
-    if (grid > 512) grid = 512;
+    if (grid > 256) grid = 256;                 // one resident block per CU; fewer partial slabs to reduce
+    { const char* e = getenv("CRUSE_WG_GRID"); if (e && atoi(e) > 0 && atoi(e) < grid) grid = atoi(e); }   // profiling override
     int rc;
     if (prec == CRUSE_PREC_F32) rc = launch_mt<CRUSE_PREC_F32, 4>(p, mt, ntw, grid, lds, stream);
     else if (prec == CRUSE_PREC_BF16X3) rc = launch_mt<CRUSE_PREC_BF16X3, 4>(p, mt, ntw, grid, lds, stream);
+    else if (tfw == 4) rc = launch_mt<CRUSE_PREC_BF16, 4>(p, mt, ntw, grid, lds, stream);
     else rc = launch_mt<CRUSE_PREC_BF16, 8>(p, mt, ntw, grid, lds, stream);
     if (rc) return rc;
     hipError_t e = hipGetLastError();
