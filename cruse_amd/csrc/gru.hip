@@ -603,6 +603,155 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruArgs a) {
     if (active) *reinterpret_cast<float2*>(a.dh + own) = sv_dh;          // s = 0
 }
 
+// ---------------------------------------------------------------------------------
+// backward, REDUCE-SCATTER form (CRUSE_PREC_BF16, Bg = 8, Hg % 128 == 0, Hg <= 640).
+// The all-gather form above makes every workgroup of a team rebuild the full [Bg x 3Hg] panel dh (.) c from the
+// swept dh and 30 KB of coefficient rows per step.  Here a workgroup contracts over the gate rows it OWNS:
+//   partial_p[b, n] = sum_{k in own 96 rows} (dh_s (.) c_s)[b, k] W_hh[k, n]      for ALL n in [0, Hg)
+// (W_hh[own rows, :] lives in registers as A fragments: 3 k-steps x Hg/16 tiles, the same 120 KB as forward), and
+// publishes the partials as {epoch, 2 x bf16} granules laid out [consumer q][producer p][clip][unit pair]: a lane's four
+// units of a tile leave as ONE 16-byte store and a wave store covers 64 contiguous bytes per clip (a first layout with
+// the producer index innermost made every lane of every store hit its own cache line: 3.8 us/step).  The consumer
+// sums the P partials of its 32 units with P/4 16-byte loads per thread -- no coefficient panel, no
+// LDS image of the exchange, a 3 KB operand panel instead of 62 KB.  Sweep bytes per step are unchanged (8 x Hg
+// bf16-pair granules); publishes grow from 1 to Hg/32 stores per lane.  Same epoch / parity discipline.
+// ---------------------------------------------------------------------------------
+template <int NT>                                // 16-unit output tiles per wavefront = Hg / 64
+__global__ __launch_bounds__(256) void gru_bwd_rs_kernel(GruArgs a) {
+    constexpr int KP = 96 + 8;                   // panel row stride (bf16): 208 B, de-phases the 16 rows of a b128 read
+    constexpr int NL = NT / 2;                   // 16-byte loads per thread and sweep: (P/2 producers) x 8 B
+    __shared__ __attribute__((aligned(16))) __bf16 panel[16 * KP];
+    const int Hg = a.Hg, H = a.G * Hg, K3 = 3 * Hg, P = a.P;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int chain = (int)(blockIdx.x / (8 * P)) * 8 + (int)(blockIdx.x & 7);
+    const int part = (int)((blockIdx.x >> 3) % P);
+    if (chain >= a.nchains) return;
+    const int grp = chain % a.G, bgi = a.bg_off + chain / a.G;
+    const int b0 = bgi * 8, nb = min(8, a.B - b0);
+    const int u0 = part * U;
+    const float* W = a.p.w_hh[grp];
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.xg, 0, a.xg_bytes, 0x00020000);
+    const unsigned cons_bytes = (unsigned)P * 8u * 16u * 8u;        // [producer P][clip 8][pair 16] granules
+    const unsigned panel_bytes = (unsigned)P * cons_bytes;          // one parity of one chain
+    const unsigned cbase = (unsigned)chain * 2u * panel_bytes;
+
+    for (int i = tid; i < 16 * KP; i += 256) panel[i] = (__bf16)0.f;
+
+    // A operand = W_hh[own gate rows, :]^T: A[row = output unit][k = own gate row]; k = gate*32 + unit, so k-step == gate
+    bf16x8 wf[NT][3];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = (wv * NT + nt) * 16 + (lane & 15);
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                wf[nt][kk][e] = (__bf16)W[(long long)(kk * Hg + u0 + (lane >> 4) * 8 + e) * Hg + n];
+        }
+    }
+
+    // thread = (clip bl, unit quad pp, quarter): owns unit u0 + 4*pp + quarter and sums, for all four units of its
+    // quad, the producers [quarter*P/4, (quarter+1)*P/4) -- 16-byte loads; the quarters meet through two shuffles
+    const int quarter = tid & 3, pp = (tid >> 2) & 7, bl = tid >> 5;
+    const bool active = bl < nb;
+    const long long own = (long long)(b0 + bl) * a.T * H + grp * Hg + u0 + 4 * pp + quarter;       // + s*H
+    const __bf16* cf = reinterpret_cast<const __bf16*>(a.coefs) +
+                       ((long long)(b0 + bl) * a.T * a.G + grp) * K3 + u0 + 4 * pp + quarter;      // + s*G*K3 + gate*Hg
+    const unsigned sweep_off = cbase + (unsigned)part * cons_bytes +
+                               (unsigned)((((quarter * (P >> 2)) * 8 + bl) * 16 + 2 * pp) * 8);     // + j * 1024
+    float dh = 0.f;
+    float dd = 0.f, zz = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;          // operands of the current step (time s)
+    if (active) {
+        const long long s = a.T - 1;
+        dd = a.dout[own + s * H];
+        c0 = (float)cf[s * a.G * K3]; c1 = (float)cf[s * a.G * K3 + Hg]; c2 = (float)cf[s * a.G * K3 + 2 * Hg];
+    }
+    float sv_dh = 0.f;
+    bool nowait = a.dbg >= 1 && a.dbg < 8;
+    const bool plain = a.dbg != 9 && team_shares_xcd(a.xid + (size_t)chain * 64, P, part, a.status, tid);
+    __syncthreads();
+
+    for (int k = 0; k < a.T; ++k) {
+        const int s = a.T - 1 - k;
+        float m = 0.f;
+        if (k > 0) {
+            const unsigned base = sweep_off + (unsigned)((k - 1) & 1) * panel_bytes;
+            unsigned pend = active ? (1u << NL) - 1u : 0u;
+            unsigned spins = 0;
+            float sm[4] = {0.f, 0.f, 0.f, 0.f};
+            for (;;) {
+                u32x4 g[NL];
+#pragma unroll
+                for (int j = 0; j < NL; ++j)
+                    if (pend & (1u << j)) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (unsigned)j * 1024u, 0, 16);
+#pragma unroll
+                for (int j = 0; j < NL; ++j) {
+                    if ((pend & (1u << j)) && (nowait || (g[j].x == (unsigned)k && g[j].z == (unsigned)k))) {
+                        sm[0] += bf16lo(g[j].y); sm[1] += bf16hi(g[j].y);
+                        sm[2] += bf16lo(g[j].w); sm[3] += bf16hi(g[j].w);
+                        pend &= ~(1u << j);
+                    }
+                }
+                if (__syncthreads_and(pend == 0)) break;
+                if (++spins >= SPIN_LIMIT) {
+                    if (tid == 0) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    nowait = true;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sm[e] += __shfl_xor(sm[e], 1, 64);
+                sm[e] += __shfl_xor(sm[e], 2, 64);
+            }
+            m = quarter == 0 ? sm[0] : quarter == 1 ? sm[1] : quarter == 2 ? sm[2] : sm[3];
+        }
+        // deferred save of dh_{s+1}; then this step's value and its three gate products
+        if (active && k > 0) a.dh[own + (long long)(s + 1) * H] = sv_dh;
+        dh = dd + zz * dh + m;
+        sv_dh = dh;
+        if (active) {
+            __bf16* pr = panel + bl * KP + 4 * pp + quarter;
+            pr[0] = (__bf16)(dh * c0); pr[32] = (__bf16)(dh * c1); pr[64] = (__bf16)(dh * c2);
+        }
+        // operands of step k+1 (time s-1): dout_{s-1}, z_s, c_{s-1} -- old by the time of the next sweep
+        if (s > 0 && active) {
+            dd = a.dout[own + (long long)(s - 1) * H];
+            zz = a.zs[own + (long long)s * H];
+            const long long o = (long long)(s - 1) * a.G * K3;
+            c0 = (float)cf[o]; c1 = (float)cf[o + Hg]; c2 = (float)cf[o + 2 * Hg];
+        }
+        if (s == 0) break;                                 // nothing consumes the partials of time 0
+        __syncthreads();
+        f32x4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (a.dbg < 2 || a.dbg >= 8) {
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                const bf16x8 fb = *reinterpret_cast<const bf16x8*>(panel + (lane & 15) * KP + kk * 32 + (lane >> 4) * 8);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][kk], fb, acc[nt], 0, 0, 0);
+            }
+        }
+        // acc[nt][j]: output unit (wv*NT+nt)*16 + (lane>>4)*4 + j of clip (lane & 15): two unit pairs per tile
+        if ((lane & 15) < nb && a.dbg != 3) {
+            const unsigned pbase = cbase + (unsigned)(k & 1) * panel_bytes;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int gt = wv * NT + nt;
+                const unsigned q = (unsigned)gt >> 1;
+                const unsigned pr0 = (unsigned)(gt & 1) * 8u + (unsigned)(lane >> 4) * 2u;
+                const unsigned off = pbase + q * cons_bytes + (((((unsigned)part * 8u + (unsigned)(lane & 15)) * 16u) + pr0) << 3);
+                const u32x4 w = {(unsigned)(k + 1), pack2(acc[nt][0], acc[nt][1]), (unsigned)(k + 1), pack2(acc[nt][2], acc[nt][3])};
+                if (plain) __builtin_amdgcn_raw_buffer_store_b128(w, rs, off, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(w, rs, off, 0, 16);
+            }
+        }
+    }
+    if (active) a.dh[own] = sv_dh;                         // s = 0
+}
+
 // dgi = dh * (c_r, c_z, a_n), dgh = dh * (c_r, c_z, c_n); layouts [rows][G][3][Hg]
 template <typename CT>
 __global__ __launch_bounds__(256) void gru_gate_grads_kernel(const float* dh, const CT* coef, const float* an,
@@ -758,9 +907,17 @@ int make_plan(int B, int G, int Hg, Plan& pl) {
 
 size_t xid_bytes_total(int B, int G) { return (size_t)cdiv(B, 8) * G * 64 * 8; }
 
+// granules (8 bytes) of one parity of one chain: all-gather forms keep up to 16 rows of Hg values; the
+// reduce-scatter backward keeps [consumer P][clip 8][pair 16][producer P]
+bool bwd_rs_eligible(int Bg, int Hg, int prec) {
+    if (getenv("CRUSE_GRU_BWD_RS") && atoi(getenv("CRUSE_GRU_BWD_RS")) == 0) return false;    // A/B switch (tests, probes)
+    return prec == CRUSE_PREC_BF16 && Bg == 8 && Hg % 128 == 0 && Hg <= 640;
+}
+size_t rs_gran_per_parity(int Hg) { const size_t P = Hg / 32; return P * 8 * 16 * P; }
 size_t xg_bytes_total(int B, int G, int Hg) {
-    // chains <= ceil(B/8)*G, two parities, up to 16 rows of Hg granules (8 bytes each)
-    return (size_t)cdiv(B, 8) * G * 2 * 16 * Hg * 8;
+    size_t per = (size_t)16 * Hg;
+    if (Hg % 128 == 0 && Hg <= 640 && rs_gran_per_parity(Hg) > per) per = rs_gran_per_parity(Hg);
+    return (size_t)cdiv(B, 8) * G * 2 * per * 8;
 }
 
 template <typename Kern>
@@ -789,6 +946,16 @@ int dispatch_bwd(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
     return launch_one(gru_bwd_kernel<PREC, 24>, a, grid, lds, s, "gru_seq_bwd");
 }
 
+int dispatch_bwd_rs(const GruArgs& a, int grid, hipStream_t s) {
+    switch (a.Hg / 64) {
+        case 2: return launch_one(gru_bwd_rs_kernel<2>, a, grid, 0, s, "gru_seq_bwd");
+        case 4: return launch_one(gru_bwd_rs_kernel<4>, a, grid, 0, s, "gru_seq_bwd");
+        case 6: return launch_one(gru_bwd_rs_kernel<6>, a, grid, 0, s, "gru_seq_bwd");
+        case 8: return launch_one(gru_bwd_rs_kernel<8>, a, grid, 0, s, "gru_seq_bwd");
+        default: return launch_one(gru_bwd_rs_kernel<10>, a, grid, 0, s, "gru_seq_bwd");
+    }
+}
+
 int check_common(int B, int T, int G, int Hg, int prec, const char* name) {
     CRUSE_REQUIRE(B > 0 && T > 0 && G > 0 && G <= MAXG, CRUSE_E_SHAPE, "%s: bad shape B=%d T=%d G=%d", name, B, T, G);
     CRUSE_REQUIRE(Hg % 32 == 0 && Hg >= 32 && Hg <= 1024, CRUSE_E_SHAPE,
@@ -813,13 +980,17 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* ws, 
         a.nchains = nbg_here * G;
         // every launch gets its own panel region: chain index inside the launch + offset
         a.xid = (unsigned long long*)xid_base + (size_t)bg_off * G * 64;
-        a.xg = (unsigned long long*)xg_base + (size_t)bg_off * G * 2 * pl.Bg * Hg;
-        a.xg_bytes = (unsigned)((size_t)a.nchains * 2 * pl.Bg * Hg * 8);
+        const bool rs_form = !FWD && bwd_rs_eligible(pl.Bg, Hg, prec);
+        const size_t gpp = rs_form ? rs_gran_per_parity(Hg) : (size_t)pl.Bg * Hg;      // granules per parity and chain
+        a.xg = (unsigned long long*)xg_base + (size_t)bg_off * G * 2 * gpp;
+        a.xg_bytes = (unsigned)((size_t)a.nchains * 2 * gpp * 8);
         const int grid = cdiv(a.nchains, 8) * 8 * pl.P;
         if (FWD) {
             if (prec == CRUSE_PREC_F32) rc = dispatch_fwd<CRUSE_PREC_F32>(a, grid, lds, s);
             else if (prec == CRUSE_PREC_BF16X3) rc = dispatch_fwd<CRUSE_PREC_BF16X3>(a, grid, lds, s);
             else rc = dispatch_fwd<CRUSE_PREC_BF16>(a, grid, lds, s);
+        } else if (rs_form) {
+            rc = dispatch_bwd_rs(a, grid, s);
         } else {
             if (prec == CRUSE_PREC_F32) rc = dispatch_bwd<CRUSE_PREC_F32>(a, grid, lds, s);
             else if (prec == CRUSE_PREC_BF16X3) rc = dispatch_bwd<CRUSE_PREC_BF16X3>(a, grid, lds, s);

@@ -481,3 +481,36 @@ def test_gru_gate_grads_bf16_matches_f32_form(ops, G, Hg):
     for g in range(G):
         assert rel_l2(db_ih[g] - 1, dgi_ref.view(rows, G, 3 * Hg)[:, g].double().sum(0)) < 1e-5
         assert rel_l2(db_hh[g] - 1, dgh_ref.view(rows, G, 3 * Hg)[:, g].double().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("H,B,T", [(640, 9, 12), (128, 8, 7), (256, 3, 5), (384, 16, 6), (512, 1, 4)])
+def test_gru_bwd_reduce_scatter_matches_all_gather_form(ops, H, B, T):
+    """bf16 mode has two backward recurrence kernels (gru.hip): both must give the same dh from the same inputs."""
+    import os
+    torch.manual_seed(H + B)
+    gi = (0.5 * torch.randn(B, T, 3 * H)).cuda()
+    w = [(torch.randn(3 * H, H) / H ** 0.5).cuda()]; b = [torch.zeros(3 * H).cuda()]
+    h, coef, an, z = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16")
+    dout = torch.randn(B, T, H).cuda()
+    dh_rs = ops.gru_seq_bwd(dout, w, coef, z, B, T, 1, H, "bf16")
+    os.environ["CRUSE_GRU_BWD_RS"] = "0"
+    try:
+        dh_ag = ops.gru_seq_bwd(dout, w, coef, z, B, T, 1, H, "bf16")
+    finally:
+        del os.environ["CRUSE_GRU_BWD_RS"]
+    torch.cuda.synchronize()
+    assert ops.gru_status() == 0
+    assert torch.isfinite(dh_rs).all() and rel_l2(dh_rs, dh_ag) < 5e-3
+    # and against the f32-precision reference of the same recurrence (autograd of the closed form)
+    c = coef.float().view(B, T, 3, H)
+    wd = w[0].double()
+    ref = torch.zeros(B, T, H, dtype=torch.float64, device="cuda")
+    nxt = torch.zeros(B, H, dtype=torch.float64, device="cuda")
+    for s in range(T - 1, -1, -1):
+        cur = dout[:, s].double()
+        if s < T - 1:
+            dgh = (nxt.unsqueeze(1) * c[:, s + 1].double()).reshape(B, 3 * H)
+            cur = cur + z[:, s + 1].double() * nxt + dgh @ wd
+        ref[:, s] = cur
+        nxt = cur
+    assert rel_l2(dh_rs, ref) < 1e-2 and rel_l2(dh_ag, ref) < 1e-2
