@@ -483,6 +483,198 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
+// forward, LEAN form of the kernel above for CRUSE_PREC_BF16, Bg = 8, Hg % 128 == 0, Hg <= 640 (the bench shape).
+// Same algorithm, hand-off format and queue discipline; the step loop is rewritten for one wave per SIMD, where
+// every instruction's issue slot is exposed (the generic loop spent ~1100 instructions per step, mostly 64-bit
+// address arithmetic, exec-mask branches around each granule and the three barriers + LDS atomic of
+// __syncthreads_and per sweep attempt):
+//   * every access is a buffer instruction: per-thread constant voffset + scalar per-step soffset;
+//   * a wave waits for ITS granules with a wave-level vote and reloads all of them per attempt (no per-granule
+//     masks); block-wide agreement comes from the panel barrier that is needed anyway;
+//   * the k-loop is fully unrolled (NKW = Hg/128 k-steps per wave, all valid).
+// ---------------------------------------------------------------------------------
+template <int NKW>
+__global__ __launch_bounds__(256) void gru_fwd_lean_kernel(GruArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int Hg = a.Hg, H = a.G * Hg, LD = Hg + 8;
+    __bf16* hB = reinterpret_cast<__bf16*>(smem_raw);                    // [16][LD]  B operand (h_{t-1})
+    float* red = reinterpret_cast<float*>(hB + 16 * LD);                  // [4 waves][6 tiles][64 lanes][4]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int chain = (int)(blockIdx.x / (8 * a.P)) * 8 + (int)(blockIdx.x & 7);
+    const int part = (int)((blockIdx.x >> 3) % a.P);
+    if (chain >= a.nchains) return;
+    const int grp = chain % a.G, bgi = a.bg_off + chain / a.G;
+    const int b0 = bgi * 8, nb = min(8, a.B - b0);
+    const int u0 = part * U;
+    const float* W = a.p.w_hh[grp];
+    const float* bh = a.p.b_hh[grp];
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.xg, 0, a.xg_bytes, 0x00020000);
+    const unsigned panel_bytes = (unsigned)(8 * Hg) * 4u;              // bf16-pair granules: 4 B per value
+    const unsigned cbase = (unsigned)chain * 2u * panel_bytes;
+
+    for (int i = tid; i < 16 * LD; i += 256) hB[i] = (__bf16)0.f;
+
+    // resident weight fragments: tile j = gate*2 + half; this wave's k-steps ks = wv + 4*i
+    bf16x8 wf[6][NKW];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int row = (j >> 1) * Hg + u0 + (j & 1) * 16 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < NKW; ++i) {
+            const int ks = wv + 4 * i;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wf[j][i][e] = (__bf16)W[(long long)row * Hg + ks * 32 + (lane >> 4) * 8 + e];
+        }
+    }
+
+    // sweep slots: load e = tid + 256*j covers clip e / (Hg/4), units 4*(e % (Hg/4)) ..+3 (clamped for short chains:
+    // the last valid granule is then fetched and stored twice)
+    const int per = Hg >> 2, nload = nb * per;
+    unsigned sw_v[NKW];
+    int sw_l[NKW];
+#pragma unroll
+    for (int j = 0; j < NKW; ++j) {
+        const int e = min(tid + 256 * j, nload - 1);
+        const int bl = e / per, v = 4 * (e - bl * per);
+        sw_v[j] = (unsigned)e * 16u;
+        sw_l[j] = bl * LD + v;
+    }
+
+    // gate math: thread = (clip bl, unit u)
+    const int u = tid & 31, bl = tid >> 5;
+    const bool act = bl < nb;
+    const int blc = act ? bl : 0;
+    const int half = u >> 4, ru = u & 15;
+    const int lp = (ru >> 2) * 16 + bl;
+    float bias[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) bias[g] = bh[g * Hg + u0 + u];
+    const unsigned frame_bytes = (unsigned)H * 4u, grow_bytes = (unsigned)(a.G * 3 * Hg) * 4u, crow_bytes = grow_bytes >> 1;
+    const unsigned tot_h = (unsigned)min((long long)a.B * a.T * H * 4, 0xffffffffll);
+    const unsigned tot_g = (unsigned)min((long long)a.B * a.T * a.G * 3 * Hg * 4, 0xffffffffll);
+    const __amdgpu_buffer_rsrc_t rs_gi = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gi), 0, tot_g, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(a.h, 0, tot_h, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_an = __builtin_amdgcn_make_buffer_rsrc(a.an, 0, a.an ? tot_h : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(a.z, 0, a.z ? tot_h : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_cf = __builtin_amdgcn_make_buffer_rsrc(a.coef, 0, a.coef ? tot_g >> 1 : 0u, 0x00020000);
+    const unsigned own_v = (unsigned)(((long long)(b0 + blc) * a.T * H + grp * Hg + u0 + u) * 4);                    // + t*frame_bytes
+    const unsigned g_v = (unsigned)((((long long)(b0 + blc) * a.T * a.G + grp) * 3 * Hg + u0 + u) * 4);               // + t*grow_bytes
+    const unsigned hg4 = (unsigned)Hg * 4u;
+    const bool save = a.coef != nullptr;
+    const unsigned pub_v = (unsigned)((bl * Hg + u0 + u) >> 1) * 8u;
+    const bool pub_lane = act && !(u & 1);
+
+    float hp = 0.f, gic[3], sv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 3; ++g) gic[g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_gi, g_v + g * hg4, 0, 0));
+    bool nowait = a.dbg >= 1 && a.dbg < 8;
+    const bool plain = a.dbg != 9 && team_shares_xcd(a.xid + (size_t)chain * 64, a.P, part, a.status, tid);
+    __syncthreads();
+
+    for (int t = 0; t < a.T; ++t) {
+        if (t > 0) {
+            const unsigned soff = cbase + (unsigned)((t - 1) & 1) * panel_bytes;
+            u32x4 g[NKW];
+            unsigned spins = 0;
+            for (;;) {
+#pragma unroll
+                for (int j = 0; j < NKW; ++j) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, sw_v[j], soff, 16);
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < NKW; ++j) ok = ok && g[j].x == (unsigned)t && g[j].z == (unsigned)t;
+                if (__all(ok || nowait)) break;
+                if (++spins >= SPIN_LIMIT) {
+                    if (lane == 0) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    nowait = true;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int j = 0; j < NKW; ++j) {
+                const u32x2 w = {g[j].y, g[j].w};                   // already bf16 pairs: the LDS image as is
+                *reinterpret_cast<u32x2*>(hB + sw_l[j]) = w;
+            }
+            // saves of step t-1: issued after the sweep has returned, old by the time of the next one
+            if (act) {
+                const unsigned so = (unsigned)(t - 1) * frame_bytes;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv[0]), rs_h, own_v, so, 0);
+                if (save) {
+                    const unsigned sc = (unsigned)(t - 1) * crow_bytes;
+                    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(pack2(sv[1], 0.f) & 0xffffu), rs_cf, g_v >> 1, sc, 0);
+                    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(pack2(sv[2], 0.f) & 0xffffu), rs_cf, (g_v >> 1) + (hg4 >> 1), sc, 0);
+                    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(pack2(sv[3], 0.f) & 0xffffu), rs_cf, (g_v >> 1) + hg4, sc, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv[4]), rs_an, own_v, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv[5]), rs_z, own_v, so, 0);
+                }
+            }
+        }
+        // gi rows of step t+1 (clamped at the end: the extra row is never used)
+        float gin_[3];
+        {
+            const unsigned so = (unsigned)min(t + 1, a.T - 1) * grow_bytes;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) gin_[g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_gi, g_v + g * hg4, so, 0));
+        }
+        float gh[3] = {bias[0], bias[1], bias[2]};
+        if (t > 0) {
+            __syncthreads();                               // panel complete
+            f32x4 acc[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (a.dbg < 2 || a.dbg >= 8) {
+#pragma unroll
+                for (int i = 0; i < NKW; ++i) {
+                    const bf16x8 fb = *reinterpret_cast<const bf16x8*>(hB + (lane & 15) * LD + (wv + 4 * i) * 32 + (lane >> 4) * 8);
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][i], fb, acc[j], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(red + ((wv * 6 + j) * 64 + lane) * 4) = acc[j];
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) gh[g] += red[((w * 6 + g * 2 + half) * 64 + lp) * 4 + (ru & 3)];
+        }
+        const float r = fast_sigmoid(gic[0] + gh[0]);
+        const float z = fast_sigmoid(gic[1] + gh[1]);
+        const float n = fast_tanh(gic[2] + r * gh[2]);
+        const float h = (1.f - z) * n + z * hp;
+        {
+            const float hn = __shfl_xor(h, 1, 64);
+            if (pub_lane) {
+                const u32x2 w = {(unsigned)(t + 1), pack2(h, hn)};
+                const unsigned soff = cbase + (unsigned)(t & 1) * panel_bytes;
+                if (plain) __builtin_amdgcn_raw_buffer_store_b64(w, rs, pub_v, soff, 0);
+                else __builtin_amdgcn_raw_buffer_store_b64(w, rs, pub_v, soff, 16);
+            }
+        }
+        const float an = (1.f - z) * (1.f - n * n);
+        sv[0] = h;
+        sv[1] = an * gh[2] * r * (1.f - r);
+        sv[2] = (hp - n) * z * (1.f - z);
+        sv[3] = an * r;
+        sv[4] = an;
+        sv[5] = z;
+        hp = h;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) gic[g] = gin_[g];
+    }
+    if (act) {
+        const unsigned so = (unsigned)(a.T - 1) * frame_bytes, sc = (unsigned)(a.T - 1) * crow_bytes;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv[0]), rs_h, own_v, so, 0);
+        if (save) {
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(pack2(sv[1], 0.f) & 0xffffu), rs_cf, g_v >> 1, sc, 0);
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(pack2(sv[2], 0.f) & 0xffffu), rs_cf, (g_v >> 1) + (hg4 >> 1), sc, 0);
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(pack2(sv[3], 0.f) & 0xffffu), rs_cf, (g_v >> 1) + hg4, sc, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv[4]), rs_an, own_v, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv[5]), rs_z, own_v, so, 0);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // backward: dh_s = dout_s + z_{s+1} * dh_{s+1} + (dh_{s+1} * c_{s+1}) W_hh
 // Same queue discipline: dout/z rows and the coefficient panel of the NEXT step are requested right
 // after this step's sweep has returned; the dh save is deferred by one step.
@@ -616,11 +808,15 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruArgs a) {
 // LDS image of the exchange, a 3 KB operand panel instead of 62 KB.  Sweep bytes per step are unchanged (8 x Hg
 // bf16-pair granules); publishes grow from 1 to Hg/32 stores per lane.  Same epoch / parity discipline.
 // ---------------------------------------------------------------------------------
+// The step loop is written for ONE WAVE PER SIMD (512-register kernel): nothing hides an instruction's issue slot,
+// so the loop carries no address arithmetic (every access is a buffer instruction with a per-thread constant
+// voffset and a scalar per-step soffset), no divergent control flow, and one barrier (the waves wait for their own
+// granules with a wave-level vote; the operand panel is double-buffered by step parity instead of fenced).
 template <int NT>                                // 16-unit output tiles per wavefront = Hg / 64
 __global__ __launch_bounds__(256) void gru_bwd_rs_kernel(GruArgs a) {
     constexpr int KP = 96 + 8;                   // panel row stride (bf16): 208 B, de-phases the 16 rows of a b128 read
-    constexpr int NL = NT / 2;                   // 16-byte loads per thread and sweep: (P/2 producers) x 8 B
-    __shared__ __attribute__((aligned(16))) __bf16 panel[16 * KP];
+    constexpr int NL = NT / 2;                   // 16-byte loads per thread and sweep: (P/4 producers) x 16 B
+    __shared__ __attribute__((aligned(16))) __bf16 panel[2][16 * KP];
     const int Hg = a.Hg, H = a.G * Hg, K3 = 3 * Hg, P = a.P;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int chain = (int)(blockIdx.x / (8 * P)) * 8 + (int)(blockIdx.x & 7);
@@ -635,7 +831,7 @@ __global__ __launch_bounds__(256) void gru_bwd_rs_kernel(GruArgs a) {
     const unsigned panel_bytes = (unsigned)P * cons_bytes;          // one parity of one chain
     const unsigned cbase = (unsigned)chain * 2u * panel_bytes;
 
-    for (int i = tid; i < 16 * KP; i += 256) panel[i] = (__bf16)0.f;
+    for (int i = tid; i < 2 * 16 * KP; i += 256) panel[0][i] = (__bf16)0.f;
 
     // A operand = W_hh[own gate rows, :]^T: A[row = output unit][k = own gate row]; k = gate*32 + unit, so k-step == gate
     bf16x8 wf[NT][3];
@@ -654,17 +850,39 @@ __global__ __launch_bounds__(256) void gru_bwd_rs_kernel(GruArgs a) {
     // quad, the producers [quarter*P/4, (quarter+1)*P/4) -- 16-byte loads; the quarters meet through two shuffles
     const int quarter = tid & 3, pp = (tid >> 2) & 7, bl = tid >> 5;
     const bool active = bl < nb;
-    const long long own = (long long)(b0 + bl) * a.T * H + grp * Hg + u0 + 4 * pp + quarter;       // + s*H
-    const __bf16* cf = reinterpret_cast<const __bf16*>(a.coefs) +
-                       ((long long)(b0 + bl) * a.T * a.G + grp) * K3 + u0 + 4 * pp + quarter;      // + s*G*K3 + gate*Hg
-    const unsigned sweep_off = cbase + (unsigned)part * cons_bytes +
-                               (unsigned)((((quarter * (P >> 2)) * 8 + bl) * 16 + 2 * pp) * 8);     // + j * 1024
-    float dh = 0.f;
-    float dd = 0.f, zz = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;          // operands of the current step (time s)
-    if (active) {
-        const long long s = a.T - 1;
-        dd = a.dout[own + s * H];
-        c0 = (float)cf[s * a.G * K3]; c1 = (float)cf[s * a.G * K3 + Hg]; c2 = (float)cf[s * a.G * K3 + 2 * Hg];
+    const int blc = active ? bl : 0;                                  // inactive threads shadow clip 0 (loads only)
+    const unsigned frame_bytes = (unsigned)H * 4u, crow_bytes = (unsigned)(a.G * K3) * 2u;
+    const unsigned tot_f32 = (unsigned)min((long long)a.B * a.T * H * 4, 0xffffffffll);
+    const unsigned tot_cf = (unsigned)min((long long)a.B * a.T * a.G * K3 * 2, 0xffffffffll);
+    const __amdgpu_buffer_rsrc_t rs_dout = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dout), 0, tot_f32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.zs), 0, tot_f32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dh = __builtin_amdgcn_make_buffer_rsrc(a.dh, 0, tot_f32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_cf = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.coefs), 0, tot_cf, 0x00020000);
+    const unsigned own_v = (unsigned)(((long long)(b0 + blc) * a.T * H + grp * Hg + u0 + 4 * pp + quarter) * 4);   // + s*frame_bytes
+    const unsigned cf_v = (unsigned)((((long long)(b0 + blc) * a.T * a.G + grp) * K3 + u0 + 4 * pp + quarter) * 2);  // + s*crow_bytes
+    const unsigned hg2 = (unsigned)Hg * 2u;
+    const unsigned sweep_v = (unsigned)part * cons_bytes + (unsigned)((((quarter * (P >> 2)) * 8 + blc) * 16 + 2 * pp) * 8);
+    // publish: the MFMA leaves clips in columns (lane & 15) < 8 only, so tiles are published in PAIRS -- the lanes of
+    // the idle columns take the second tile of the pair from lane ^ 8 (a 16-lane-row rotate) and every store
+    // instruction carries 64 x 16 bytes.  Offset of this lane's 16-byte piece per tile pair (clip = lane & 7):
+    const int hi8 = (lane >> 3) & 1;
+    unsigned pub_v[NT / 2];
+#pragma unroll
+    for (int np = 0; np < NT / 2; ++np) {
+        const int gt = wv * NT + 2 * np + hi8;
+        pub_v[np] = (unsigned)(gt >> 1) * cons_bytes +
+                    (((((unsigned)part * 8u + (unsigned)(lane & 7)) * 16u) + (unsigned)(gt & 1) * 8u + (unsigned)(lane >> 4) * 2u) << 3);
+    }
+    const bool pub_lane = (lane & 7) < nb;
+    const int pw = blc * KP + 4 * pp + quarter;                      // panel element of the own unit (+ gate*32)
+
+    float dh = 0.f, dd = 0.f, zz = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;  // operands of the current step (time s)
+    {
+        const unsigned s = (unsigned)(a.T - 1);
+        dd = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_dout, own_v, s * frame_bytes, 0));
+        c0 = bf16lo(__builtin_amdgcn_raw_buffer_load_b16(rs_cf, cf_v, s * crow_bytes, 0));
+        c1 = bf16lo(__builtin_amdgcn_raw_buffer_load_b16(rs_cf, cf_v + hg2, s * crow_bytes, 0));
+        c2 = bf16lo(__builtin_amdgcn_raw_buffer_load_b16(rs_cf, cf_v + 2 * hg2, s * crow_bytes, 0));
     }
     float sv_dh = 0.f;
     bool nowait = a.dbg >= 1 && a.dbg < 8;
@@ -675,29 +893,27 @@ __global__ __launch_bounds__(256) void gru_bwd_rs_kernel(GruArgs a) {
         const int s = a.T - 1 - k;
         float m = 0.f;
         if (k > 0) {
-            const unsigned base = sweep_off + (unsigned)((k - 1) & 1) * panel_bytes;
-            unsigned pend = active ? (1u << NL) - 1u : 0u;
+            const unsigned soff = cbase + (unsigned)((k - 1) & 1) * panel_bytes;
+            u32x4 g[NL];
             unsigned spins = 0;
-            float sm[4] = {0.f, 0.f, 0.f, 0.f};
             for (;;) {
-                u32x4 g[NL];
 #pragma unroll
-                for (int j = 0; j < NL; ++j)
-                    if (pend & (1u << j)) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (unsigned)j * 1024u, 0, 16);
+                for (int j = 0; j < NL; ++j) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, sweep_v + (unsigned)j * 1024u, soff, 16);
+                bool ok = true;
 #pragma unroll
-                for (int j = 0; j < NL; ++j) {
-                    if ((pend & (1u << j)) && (nowait || (g[j].x == (unsigned)k && g[j].z == (unsigned)k))) {
-                        sm[0] += bf16lo(g[j].y); sm[1] += bf16hi(g[j].y);
-                        sm[2] += bf16lo(g[j].w); sm[3] += bf16hi(g[j].w);
-                        pend &= ~(1u << j);
-                    }
-                }
-                if (__syncthreads_and(pend == 0)) break;
+                for (int j = 0; j < NL; ++j) ok = ok && g[j].x == (unsigned)k && g[j].z == (unsigned)k;
+                if (__all(ok || !active || nowait)) break;            // wave-level: every lane's granules carry this epoch
                 if (++spins >= SPIN_LIMIT) {
-                    if (tid == 0) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     nowait = true;
                 }
                 __builtin_amdgcn_s_sleep(1);
+            }
+            float sm[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                sm[0] += bf16lo(g[j].y); sm[1] += bf16hi(g[j].y);
+                sm[2] += bf16lo(g[j].w); sm[3] += bf16hi(g[j].w);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -705,51 +921,66 @@ __global__ __launch_bounds__(256) void gru_bwd_rs_kernel(GruArgs a) {
                 sm[e] += __shfl_xor(sm[e], 2, 64);
             }
             m = quarter == 0 ? sm[0] : quarter == 1 ? sm[1] : quarter == 2 ? sm[2] : sm[3];
+            // deferred save of dh_{s+1}: issued after the sweep has returned, old by the time of the next one
+            if (active) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv_dh), rs_dh, own_v, (unsigned)(s + 1) * frame_bytes, 0);
         }
-        // deferred save of dh_{s+1}; then this step's value and its three gate products
-        if (active && k > 0) a.dh[own + (long long)(s + 1) * H] = sv_dh;
         dh = dd + zz * dh + m;
         sv_dh = dh;
+        __bf16* pn = panel[k & 1];
         if (active) {
-            __bf16* pr = panel + bl * KP + 4 * pp + quarter;
-            pr[0] = (__bf16)(dh * c0); pr[32] = (__bf16)(dh * c1); pr[64] = (__bf16)(dh * c2);
-        }
-        // operands of step k+1 (time s-1): dout_{s-1}, z_s, c_{s-1} -- old by the time of the next sweep
-        if (s > 0 && active) {
-            dd = a.dout[own + (long long)(s - 1) * H];
-            zz = a.zs[own + (long long)s * H];
-            const long long o = (long long)(s - 1) * a.G * K3;
-            c0 = (float)cf[o]; c1 = (float)cf[o + Hg]; c2 = (float)cf[o + 2 * Hg];
+            pn[pw] = (__bf16)(dh * c0); pn[pw + 32] = (__bf16)(dh * c1); pn[pw + 64] = (__bf16)(dh * c2);
         }
         if (s == 0) break;                                 // nothing consumes the partials of time 0
-        __syncthreads();
+        // operands of step k+1 (time s-1): dout_{s-1}, z_s, c_{s-1}
+        {
+            const unsigned sp = (unsigned)(s - 1);
+            dd = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_dout, own_v, sp * frame_bytes, 0));
+            zz = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_z, own_v, (unsigned)s * frame_bytes, 0));
+            c0 = bf16lo(__builtin_amdgcn_raw_buffer_load_b16(rs_cf, cf_v, sp * crow_bytes, 0));
+            c1 = bf16lo(__builtin_amdgcn_raw_buffer_load_b16(rs_cf, cf_v + hg2, sp * crow_bytes, 0));
+            c2 = bf16lo(__builtin_amdgcn_raw_buffer_load_b16(rs_cf, cf_v + 2 * hg2, sp * crow_bytes, 0));
+        }
+        __syncthreads();                                   // panel[k & 1] complete; panel[(k+1) & 1] is free again
         f32x4 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (a.dbg < 2 || a.dbg >= 8) {
 #pragma unroll
             for (int kk = 0; kk < 3; ++kk) {
-                const bf16x8 fb = *reinterpret_cast<const bf16x8*>(panel + (lane & 15) * KP + kk * 32 + (lane >> 4) * 8);
+                const bf16x8 fb = *reinterpret_cast<const bf16x8*>(pn + (lane & 15) * KP + kk * 32 + (lane >> 4) * 8);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][kk], fb, acc[nt], 0, 0, 0);
             }
         }
-        // acc[nt][j]: output unit (wv*NT+nt)*16 + (lane>>4)*4 + j of clip (lane & 15): two unit pairs per tile
-        if ((lane & 15) < nb && a.dbg != 3) {
-            const unsigned pbase = cbase + (unsigned)(k & 1) * panel_bytes;
+        // acc[nt][j]: output unit (wv*NT+nt)*16 + (lane>>4)*4 + j of clip (lane & 15); see pub_v
+        unsigned w1[NT / 2], w3[NT / 2];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int gt = wv * NT + nt;
-                const unsigned q = (unsigned)gt >> 1;
-                const unsigned pr0 = (unsigned)(gt & 1) * 8u + (unsigned)(lane >> 4) * 2u;
-                const unsigned off = pbase + q * cons_bytes + (((((unsigned)part * 8u + (unsigned)(lane & 15)) * 16u) + pr0) << 3);
-                const u32x4 w = {(unsigned)(k + 1), pack2(acc[nt][0], acc[nt][1]), (unsigned)(k + 1), pack2(acc[nt][2], acc[nt][3])};
-                if (plain) __builtin_amdgcn_raw_buffer_store_b128(w, rs, off, 0, 0);
-                else __builtin_amdgcn_raw_buffer_store_b128(w, rs, off, 0, 16);
+        for (int np = 0; np < NT / 2; ++np) {
+            const unsigned a0 = pack2(acc[2 * np][0], acc[2 * np][1]), a1 = pack2(acc[2 * np][2], acc[2 * np][3]);
+            const unsigned b0_ = pack2(acc[2 * np + 1][0], acc[2 * np + 1][1]), b1_ = pack2(acc[2 * np + 1][2], acc[2 * np + 1][3]);
+            const unsigned x0 = (unsigned)__shfl_xor((int)b0_, 8, 64), x1 = (unsigned)__shfl_xor((int)b1_, 8, 64);
+            w1[np] = hi8 ? x0 : a0;
+            w3[np] = hi8 ? x1 : a1;
+        }
+        if (pub_lane && a.dbg != 3) {
+            const unsigned soff = cbase + (unsigned)(k & 1) * panel_bytes;
+            const unsigned ep = (unsigned)(k + 1);
+            if (plain) {
+#pragma unroll
+                for (int np = 0; np < NT / 2; ++np) {
+                    const u32x4 w = {ep, w1[np], ep, w3[np]};
+                    __builtin_amdgcn_raw_buffer_store_b128(w, rs, pub_v[np], soff, 0);
+                }
+            } else {
+#pragma unroll
+                for (int np = 0; np < NT / 2; ++np) {
+                    const u32x4 w = {ep, w1[np], ep, w3[np]};
+                    __builtin_amdgcn_raw_buffer_store_b128(w, rs, pub_v[np], soff, 16);
+                }
             }
         }
     }
-    if (active) a.dh[own] = sv_dh;                         // s = 0
+    if (active) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv_dh), rs_dh, own_v, 0, 0);          // s = 0
 }
 
 // dgi = dh * (c_r, c_z, a_n), dgh = dh * (c_r, c_z, c_n); layouts [rows][G][3][Hg]
@@ -929,6 +1160,20 @@ int launch_one(Kern k, const GruArgs& a, int grid, size_t lds, hipStream_t s, co
     return CRUSE_OK;
 }
 
+bool fwd_lean_eligible(int Bg, int Hg, int prec) {
+    if (getenv("CRUSE_GRU_FWD_LEAN") && atoi(getenv("CRUSE_GRU_FWD_LEAN")) == 0) return false;   // A/B switch (tests, probes)
+    return prec == CRUSE_PREC_BF16 && Bg == 8 && Hg % 128 == 0 && Hg <= 640;
+}
+int dispatch_fwd_lean(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
+    switch (a.Hg / 128) {
+        case 1: return launch_one(gru_fwd_lean_kernel<1>, a, grid, lds, s, "gru_seq_fwd");
+        case 2: return launch_one(gru_fwd_lean_kernel<2>, a, grid, lds, s, "gru_seq_fwd");
+        case 3: return launch_one(gru_fwd_lean_kernel<3>, a, grid, lds, s, "gru_seq_fwd");
+        case 4: return launch_one(gru_fwd_lean_kernel<4>, a, grid, lds, s, "gru_seq_fwd");
+        default: return launch_one(gru_fwd_lean_kernel<5>, a, grid, lds, s, "gru_seq_fwd");
+    }
+}
+
 template <int PREC>
 int dispatch_fwd(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
     const int nkw = cdiv(a.Hg / 32, 4);
@@ -985,7 +1230,9 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* ws, 
         a.xg = (unsigned long long*)xg_base + (size_t)bg_off * G * 2 * gpp;
         a.xg_bytes = (unsigned)((size_t)a.nchains * 2 * gpp * 8);
         const int grid = cdiv(a.nchains, 8) * 8 * pl.P;
-        if (FWD) {
+        if (FWD && fwd_lean_eligible(pl.Bg, Hg, prec)) {
+            rc = dispatch_fwd_lean(a, grid, lds, s);
+        } else if (FWD) {
             if (prec == CRUSE_PREC_F32) rc = dispatch_fwd<CRUSE_PREC_F32>(a, grid, lds, s);
             else if (prec == CRUSE_PREC_BF16X3) rc = dispatch_fwd<CRUSE_PREC_BF16X3>(a, grid, lds, s);
             else rc = dispatch_fwd<CRUSE_PREC_BF16>(a, grid, lds, s);

@@ -514,3 +514,26 @@ def test_gru_bwd_reduce_scatter_matches_all_gather_form(ops, H, B, T):
         ref[:, s] = cur
         nxt = cur
     assert rel_l2(dh_rs, ref) < 1e-2 and rel_l2(dh_ag, ref) < 1e-2
+
+
+@pytest.mark.parametrize("H,B,T", [(640, 9, 12), (128, 8, 7), (256, 3, 5), (384, 16, 6), (512, 1, 4)])
+def test_gru_fwd_lean_matches_generic_kernel(ops, H, B, T):
+    """bf16 mode has two forward recurrence kernels (gru.hip): same algorithm, so the same h / coefficients."""
+    import os
+    torch.manual_seed(H + B + 1)
+    gi = (0.5 * torch.randn(B, T, 3 * H)).cuda()
+    w = [(torch.randn(3 * H, H) / H ** 0.5).cuda()]; b = [(0.1 * torch.randn(3 * H)).cuda()]
+    lean = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16")
+    os.environ["CRUSE_GRU_FWD_LEAN"] = "0"
+    try:
+        gen = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16")
+    finally:
+        del os.environ["CRUSE_GRU_FWD_LEAN"]
+    torch.cuda.synchronize()
+    assert ops.gru_status() == 0
+    for x, y, name in zip(lean, gen, ("h", "coef", "an", "z")):
+        # f32 outputs agree to rounding; the bf16 coefficients may differ by an ulp where the f32 value sits on a tie
+        tol = 2e-3 if x.dtype == torch.bfloat16 else 1e-5
+        assert torch.isfinite(x.float()).all() and rel_l2(x.float(), y.float()) < tol, name
+    h_nosave = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16", save=False)[0]
+    assert rel_l2(h_nosave, lean[0]) < 1e-6

@@ -24,6 +24,13 @@ for rnd in range(3):
     for m in modes:
         os.environ["CRUSE_GRU_DBG"] = m
         tf = timeit(lambda: ops.gru_seq_fwd(gi, ws, bs, B, T, G, Hg, "bf16"))
+        if int(m) & 16:
+            ops.gru_seq_fwd(gi, ws, bs, B, T, G, Hg, "bf16"); torch.cuda.synchronize()
+            for (key, _d), buf in ops._wgrad_ws.items():
+                if key == "gru":
+                    st = buf[64:96].view(torch.int64).tolist()
+                    n = max(st[3], 1)
+                    print(f"   fwd phases (s_memtime ticks/step, 100 MHz): sweep {st[0]/n:.1f} mfma+red {st[1]/n:.1f} gates+publish {st[2]/n:.1f}")
         tb = timeit(lambda: ops.gru_seq_bwd(dout, ws, coef, z, B, T, G, Hg, "bf16"))
         out.append(f"dbg={m}: fwd {tf*1e3/T:.2f} bwd {tb*1e3/T:.2f} us/step")
     print(f"B={B} G={G} round {rnd}: " + " | ".join(out), "status", ops.gru_status())
