@@ -7,7 +7,7 @@ def main(path, skip_steps=4):
     ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("(anonymous namespace)::", ""))
           for r in rows]
     ev.sort()
-    gru = [(s, e, n) for s, e, n in ev if "gru_fwd_kernel" in n or "gru_bwd_kernel" in n]
+    gru = [(s, e, n) for s, e, n in ev if "gru_fwd" in n or "gru_bwd" in n]
     # a step = 2 fwd + 2 bwd GRU launches; take the last complete one
     last = gru[-4:]
     t0 = last[0][0] - 3_000_000
