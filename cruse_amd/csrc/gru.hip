@@ -120,6 +120,10 @@ template <> struct Gran<CRUSE_PREC_BF16> {
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 
+// lane exchanges inside a 16-lane row as DPP moves (one VALU op) instead of ds_bpermute round trips
+__device__ __forceinline__ unsigned dpp_xor1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ unsigned dpp_xor2(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false); }   // quad_perm [2,3,0,1]
+__device__ __forceinline__ unsigned dpp_ror8(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false); }  // row_ror:8 == lane ^ 8
 __device__ __forceinline__ float bf16lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 __device__ __forceinline__ unsigned pack2(float a, float b) {
@@ -301,6 +305,16 @@ __device__ __forceinline__ float fast_tanh(float x) {
     const float e = __expf(-2.0f * fabsf(x));          // in (0, 1]: no overflow
     const float t = (1.0f - e) * __frcp_rn(1.0f + e);
     return copysignf(t, x);
+}
+
+// bf16-mode forms: bare v_exp_f32 / v_rcp_f32 (1 ulp) -- __frcp_rn expands to the ~10-instruction IEEE division
+// sequence, three of them back to back on the serial path of every step
+__device__ __forceinline__ float lean_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float lean_tanh(float x) {
+    const float e = __builtin_amdgcn_exp2f(-2.8853900817779268f * fabsf(x));      // in (0, 1]: no overflow
+    return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
 }
 
 template <int PREC>
@@ -581,7 +595,7 @@ __global__ __launch_bounds__(256) void gru_fwd_lean_kernel(GruArgs a) {
                 for (int j = 0; j < NKW; ++j) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, sw_v[j], soff, 16);
                 bool ok = true;
 #pragma unroll
-                for (int j = 0; j < NKW; ++j) ok = ok && g[j].x == (unsigned)t && g[j].z == (unsigned)t;
+                for (int j = 0; j < NKW; ++j) ok = ok & (g[j].x == (unsigned)t) & (g[j].z == (unsigned)t);
                 if (__all(ok || nowait)) break;
                 if (++spins >= SPIN_LIMIT) {
                     if (lane == 0) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -621,13 +635,11 @@ __global__ __launch_bounds__(256) void gru_fwd_lean_kernel(GruArgs a) {
             f32x4 acc[6];
 #pragma unroll
             for (int j = 0; j < 6; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (a.dbg < 2 || a.dbg >= 8) {
 #pragma unroll
-                for (int i = 0; i < NKW; ++i) {
-                    const bf16x8 fb = *reinterpret_cast<const bf16x8*>(hB + (lane & 15) * LD + (wv + 4 * i) * 32 + (lane >> 4) * 8);
+            for (int i = 0; i < NKW; ++i) {
+                const bf16x8 fb = *reinterpret_cast<const bf16x8*>(hB + (lane & 15) * LD + (wv + 4 * i) * 32 + (lane >> 4) * 8);
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][i], fb, acc[j], 0, 0, 0);
-                }
+                for (int j = 0; j < 6; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][i], fb, acc[j], 0, 0, 0);
             }
 #pragma unroll
             for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(red + ((wv * 6 + j) * 64 + lane) * 4) = acc[j];
@@ -637,12 +649,12 @@ __global__ __launch_bounds__(256) void gru_fwd_lean_kernel(GruArgs a) {
 #pragma unroll
                 for (int w = 0; w < 4; ++w) gh[g] += red[((w * 6 + g * 2 + half) * 64 + lp) * 4 + (ru & 3)];
         }
-        const float r = fast_sigmoid(gic[0] + gh[0]);
-        const float z = fast_sigmoid(gic[1] + gh[1]);
-        const float n = fast_tanh(gic[2] + r * gh[2]);
+        const float r = lean_sigmoid(gic[0] + gh[0]);
+        const float z = lean_sigmoid(gic[1] + gh[1]);
+        const float n = lean_tanh(gic[2] + r * gh[2]);
         const float h = (1.f - z) * n + z * hp;
         {
-            const float hn = __shfl_xor(h, 1, 64);
+            const float hn = __uint_as_float(dpp_xor1(__float_as_uint(h)));
             if (pub_lane) {
                 const u32x2 w = {(unsigned)(t + 1), pack2(h, hn)};
                 const unsigned soff = cbase + (unsigned)(t & 1) * panel_bytes;
@@ -901,7 +913,7 @@ __global__ __launch_bounds__(256) void gru_bwd_rs_kernel(GruArgs a) {
                 for (int j = 0; j < NL; ++j) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, sweep_v + (unsigned)j * 1024u, soff, 16);
                 bool ok = true;
 #pragma unroll
-                for (int j = 0; j < NL; ++j) ok = ok && g[j].x == (unsigned)k && g[j].z == (unsigned)k;
+                for (int j = 0; j < NL; ++j) ok = ok & (g[j].x == (unsigned)k) & (g[j].z == (unsigned)k);
                 if (__all(ok || !active || nowait)) break;            // wave-level: every lane's granules carry this epoch
                 if (++spins >= SPIN_LIMIT) {
                     if (lane == 0) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -917,8 +929,8 @@ __global__ __launch_bounds__(256) void gru_bwd_rs_kernel(GruArgs a) {
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                sm[e] += __shfl_xor(sm[e], 1, 64);
-                sm[e] += __shfl_xor(sm[e], 2, 64);
+                sm[e] += __uint_as_float(dpp_xor1(__float_as_uint(sm[e])));
+                sm[e] += __uint_as_float(dpp_xor2(__float_as_uint(sm[e])));
             }
             m = quarter == 0 ? sm[0] : quarter == 1 ? sm[1] : quarter == 2 ? sm[2] : sm[3];
             // deferred save of dh_{s+1}: issued after the sweep has returned, old by the time of the next one
@@ -941,42 +953,31 @@ __global__ __launch_bounds__(256) void gru_bwd_rs_kernel(GruArgs a) {
             c2 = bf16lo(__builtin_amdgcn_raw_buffer_load_b16(rs_cf, cf_v + 2 * hg2, sp * crow_bytes, 0));
         }
         __syncthreads();                                   // panel[k & 1] complete; panel[(k+1) & 1] is free again
-        f32x4 acc[NT];
+        // tile PAIRS, each finished (3 k-steps, the two tiles interleaved so no MFMA waits on its own accumulator) and
+        // published before the next pair starts: the stores of the first pairs travel while the MFMAs still run.
+        // acc[j]: output unit tile*16 + (lane>>4)*4 + j of clip (lane & 15); see pub_v
+        bf16x8 fb[3];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (a.dbg < 2 || a.dbg >= 8) {
-#pragma unroll
-            for (int kk = 0; kk < 3; ++kk) {
-                const bf16x8 fb = *reinterpret_cast<const bf16x8*>(pn + (lane & 15) * KP + kk * 32 + (lane >> 4) * 8);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][kk], fb, acc[nt], 0, 0, 0);
-            }
-        }
-        // acc[nt][j]: output unit (wv*NT+nt)*16 + (lane>>4)*4 + j of clip (lane & 15); see pub_v
-        unsigned w1[NT / 2], w3[NT / 2];
+        for (int kk = 0; kk < 3; ++kk)
+            fb[kk] = *reinterpret_cast<const bf16x8*>(pn + (lane & 15) * KP + kk * 32 + (lane >> 4) * 8);
+        const unsigned soff = cbase + (unsigned)(k & 1) * panel_bytes;
+        const unsigned ep = (unsigned)(k + 1);
+        const bool do_pub = pub_lane;
 #pragma unroll
         for (int np = 0; np < NT / 2; ++np) {
-            const unsigned a0 = pack2(acc[2 * np][0], acc[2 * np][1]), a1 = pack2(acc[2 * np][2], acc[2 * np][3]);
-            const unsigned b0_ = pack2(acc[2 * np + 1][0], acc[2 * np + 1][1]), b1_ = pack2(acc[2 * np + 1][2], acc[2 * np + 1][3]);
-            const unsigned x0 = (unsigned)__shfl_xor((int)b0_, 8, 64), x1 = (unsigned)__shfl_xor((int)b1_, 8, 64);
-            w1[np] = hi8 ? x0 : a0;
-            w3[np] = hi8 ? x1 : a1;
-        }
-        if (pub_lane && a.dbg != 3) {
-            const unsigned soff = cbase + (unsigned)(k & 1) * panel_bytes;
-            const unsigned ep = (unsigned)(k + 1);
-            if (plain) {
+            f32x4 c0_ = (f32x4){0.f, 0.f, 0.f, 0.f}, c1_ = c0_;
 #pragma unroll
-                for (int np = 0; np < NT / 2; ++np) {
-                    const u32x4 w = {ep, w1[np], ep, w3[np]};
-                    __builtin_amdgcn_raw_buffer_store_b128(w, rs, pub_v[np], soff, 0);
-                }
-            } else {
-#pragma unroll
-                for (int np = 0; np < NT / 2; ++np) {
-                    const u32x4 w = {ep, w1[np], ep, w3[np]};
-                    __builtin_amdgcn_raw_buffer_store_b128(w, rs, pub_v[np], soff, 16);
-                }
+            for (int kk = 0; kk < 3; ++kk) {
+                c0_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * np][kk], fb[kk], c0_, 0, 0, 0);
+                c1_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * np + 1][kk], fb[kk], c1_, 0, 0, 0);
+            }
+            const unsigned a0 = pack2(c0_[0], c0_[1]), a1 = pack2(c0_[2], c0_[3]);
+            const unsigned b0_ = pack2(c1_[0], c1_[1]), b1_ = pack2(c1_[2], c1_[3]);
+            const unsigned x0 = dpp_ror8(b0_), x1 = dpp_ror8(b1_);
+            const u32x4 w = {ep, hi8 ? x0 : a0, ep, hi8 ? x1 : a1};
+            if (do_pub) {
+                if (plain) __builtin_amdgcn_raw_buffer_store_b128(w, rs, pub_v[np], soff, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(w, rs, pub_v[np], soff, 16);
             }
         }
     }

@@ -532,8 +532,9 @@ def test_gru_fwd_lean_matches_generic_kernel(ops, H, B, T):
     torch.cuda.synchronize()
     assert ops.gru_status() == 0
     for x, y, name in zip(lean, gen, ("h", "coef", "an", "z")):
-        # f32 outputs agree to rounding; the bf16 coefficients may differ by an ulp where the f32 value sits on a tie
-        tol = 2e-3 if x.dtype == torch.bfloat16 else 1e-5
+        # same algorithm, but the lean kernel's gates use bare v_rcp/v_exp (1 ulp) and h travels as bf16: a last-bit
+        # difference can flip one bf16 rounding of the exchanged state, so "equal" means well inside bf16 resolution
+        tol = 2e-3 if x.dtype == torch.bfloat16 else 1e-4
         assert torch.isfinite(x.float()).all() and rel_l2(x.float(), y.float()) < tol, name
     h_nosave = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16", save=False)[0]
-    assert rel_l2(h_nosave, lean[0]) < 1e-6
+    assert rel_l2(h_nosave, lean[0]) < 1e-6                # same kernel, saves off: identical
