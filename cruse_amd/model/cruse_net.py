@@ -88,6 +88,18 @@ class _SideStream:
         with torch.cuda.stream(side):
             fn()
 
+    def mark(self):
+        """Event after everything issued on the side stream so far (None when nothing runs there)."""
+        if not (self.enabled and self.active):
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self._side())
+        return ev
+
+    def wait(self, ev):
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
     def join(self):
         if self.enabled and self.deferred:       # nothing left to hide behind: issue what is still queued
             fns, self.deferred = self.deferred, []
@@ -159,11 +171,22 @@ def ggru_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], prefix: str, group
 
 
 def ggru_backward(ctx, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor],
-                  need_dx: bool = True, join: bool = True) -> Optional[torch.Tensor]:
-    """dout [B,T,H] -> dx; parameter gradients are ACCUMULATED into G[name]."""
+                  need_dx: bool = True, join: bool = True, dx_init: Optional[torch.Tensor] = None,
+                  dx_ready=None) -> Optional[torch.Tensor]:
+    """dout [B,T,H] -> dx; parameter gradients are ACCUMULATED into G[name].  dx_init: a [B,T,H] tensor the input
+    gradient is ADDED to (and returned) instead of a fresh one; dx_ready() is called right before it is touched."""
     B, T, H, g, prec, prefix = ctx["B"], ctx["T"], ctx["H"], ctx["g"], ctx["prec"], ctx["prefix"]
     Hg = H // g
     rows = B * T
+
+    def dinp_buffer(dout_h, need_dinp, last):
+        if not need_dinp:
+            return None, False
+        if last and dx_init is not None:
+            if dx_ready is not None:
+                dx_ready()
+            return dx_init.view(B, T, H), True
+        return torch.empty(B, T, H, device=dout_h.device, dtype=torch.float32), False
 
     def layer_bwd_bf16(dout_h, lname, inp, h, coef, an, z, need_dinp, last):
         """CRUSE_PREC_BF16: every product as gemm_bf16_nt on bf16 operand copies (see gemm_bf16.hip)."""
@@ -192,11 +215,12 @@ def ggru_backward(ctx, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[s
                                  2 * Hg * Hg, Hg, accumulate=True, splitk=_splitk_bf16(Hg, Hg, ldT), a_kstride=ka,
                                  b_kstride=kb)
 
+        dinp, acc_dx = dinp_buffer(dout_h, need_dinp, last)
         if need_dinp:
             for i, nm in enumerate(names):
                 w_t = ops.transpose_bf16(P[nm + "weight_ih_l0"], 3 * Hg, Hg)          # K-tiled [3*Hg/64, Hg, 64]
                 ops.gemm_bf16_nt(rows, Hg, 3 * Hg, dgi, i * 3 * Hg, 3 * H, w_t, 0, 64, dinp, i * Hg, H,
-                                 b_kstride=Hg * 64)
+                                 accumulate=acc_dx, b_kstride=Hg * 64)
         if last:
             SIDE.run(weight_grads, dgT, h, inp, inpT, hpT)
         else:
@@ -210,7 +234,6 @@ def ggru_backward(ctx, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[s
         w_hh = [P[f"{prefix}{lname}.{i}.weight_hh_l0"] for i in range(g)]
         dh = SIDE.release_around(lambda: ops.gru_seq_bwd(dout_h, w_hh, coef, z, B, T, g, Hg, prec))
         dgi, dgh = ops.gru_gate_grads(dh, coef, an, rows, g, Hg, prec)
-        dinp = torch.empty(B, T, H, device=dout_h.device, dtype=torch.float32) if need_dinp else None
         sk = _splitk(3 * Hg, Hg, rows)
 
         def weight_grads():                      # leaves: overlap with the next recurrence / encoder backward
@@ -225,10 +248,11 @@ def ggru_backward(ctx, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[s
                          Hg, accumulate=True, splitk=sk, prec=prec)
                 ops.col_sum(dgi, i * 3 * Hg, rows, 3 * Hg, 3 * H, G[nm + "bias_ih_l0"])
 
+        dinp, acc_dx = dinp_buffer(dout_h, need_dinp, last)
         if need_dinp:
             for i in range(g):
                 ops.gemm(False, False, rows, Hg, 3 * Hg, dgi, i * 3 * Hg, 3 * H,
-                         P[f"{prefix}{lname}.{i}.weight_ih_l0"], 0, Hg, dinp, i * Hg, H, prec=prec)
+                         P[f"{prefix}{lname}.{i}.weight_ih_l0"], 0, Hg, dinp, i * Hg, H, accumulate=acc_dx, prec=prec)
         if last:
             SIDE.run(weight_grads, dgi, dgh, h, inp)
         else:
@@ -331,6 +355,21 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
     SIDE.defer(leaf_dec1, dv, kind=2)                           # decoder leaves: issued with the first GRU backward
     du = ops.conv_gather(dv, P["conv1_t.weight"], None, B, T, ch[0], Fk[0], ch[1], Fk[1], KT=1, S=2, pad=0, prec=prec)
     ds = {1: du}                                        # gradient wrt skip_{k} output = du_k
+    # skip_k = conv1x3(e_k) is a leaf of the decoder: its data gradient W^T ds_k and its weight gradient ds_k (*) e_k
+    # are issued here, on the side stream, into the buffer de_pre[k] that the encoder backward later ACCUMULATES its
+    # own path into -- four convs and four weight gradients less on the serial tail of the backward pass
+    de_pre = {}
+
+    def skip_leaves(k):
+        de_pre[k] = torch.empty(B, T, ch[k], Fk[k], device=dlogit.device, dtype=torch.float32)
+
+        def leaf(k=k, dsk=ds[k], out=de_pre[k]):
+            ops.conv_gather(dsk, P[f"skip_connect_{k}.weight"], None, B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1,
+                            w_layout=1, out=out, prec=prec)
+            ops.conv_wgrad(dsk, es[k], G[f"skip_connect_{k}.weight"], B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1,
+                           prec=prec)
+        SIDE.run(leaf, ds[k], de_pre[k])
+    skip_leaves(1)
     # ---- decoder levels 2..L ------------------------------------------------------------
     for k in range(2, L + 1):
         mean, rstd = dstats[k]
@@ -344,18 +383,14 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
         du = ops.conv_gather(dv, P[f"conv{k}_t.weight"], None, B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k], KT=1, S=2, pad=0,
                              prec=prec)
         ds[k] = du
+        skip_leaves(k)
+    skips_done = SIDE.mark()
     # ---- bottleneck: u_L = ggru(e_L) + skip_L --------------------------------------------
     H = ch[L] * Fk[L]
-    de = ggru_backward(ctx["gctx"], du.view(B, T, H), P, G, join=False).view(B, T, ch[L], Fk[L])
-    # ---- encoder levels L..1 ----------------------------------------------------------------
+    de = ggru_backward(ctx["gctx"], du.view(B, T, H), P, G, join=False, dx_init=de_pre[L].view(B, T, H),
+                       dx_ready=lambda: SIDE.wait(skips_done)).view(B, T, ch[L], Fk[L])
+    # ---- encoder levels L..1: de_k already holds the skip path ------------------------------
     for k in range(L, 0, -1):
-        # skip_k = conv1x3(e_k): de_k += W^T ds_k ; dW_skip += ds_k (*) e_k
-        ops.conv_gather(ds[k], P[f"skip_connect_{k}.weight"], None, B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1,
-                        w_layout=1, out=de, accum=True, prec=prec)
-
-        def leaf_skip(k=k):
-            ops.conv_wgrad(ds[k], es[k], G[f"skip_connect_{k}.weight"], B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1, prec=prec)
-        SIDE.run(leaf_skip, ds[k])
         mean, rstd = stats[k]
         dy = ops.bn_act_bwd(de, ys[k], mean, rstd, P[f"bn{k}.weight"], P[f"bn{k}.bias"], rows, ch[k], Fk[k], True,
                             training, G[f"bn{k}.weight"], G[f"bn{k}.bias"], dbias=G[f"conv{k}.bias"])
@@ -364,7 +399,8 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
             ops.conv_wgrad(dy, es[k - 1], G[f"conv{k}.weight"], B, T, ch[k], Fk[k], ch[k - 1], Fk[k - 1], KT=2, S=2, pad=1, prec=prec)
         SIDE.run(leaf_enc, dy)
         if k > 1:
-            de = ops.conv_scatter2(dy, P[f"conv{k}.weight"], None, B, T, ch[k], Fk[k], ch[k - 1], KT=2, pad=1, prec=prec)
+            de = ops.conv_scatter2(dy, P[f"conv{k}.weight"], None, B, T, ch[k], Fk[k], ch[k - 1], KT=2, pad=1,
+                                   out=de_pre[k - 1], accum=True, prec=prec)
     SIDE.join()
 
 
