@@ -139,6 +139,31 @@ class KernelTimer:
         return tot, cnt
 
 
+PMC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.csv")
+
+
+def pmc_traffic():
+    """HBM bytes per launch and kernel family from the committed rocprofv3 PMC passes (profiles/r01_pmc_hbm_traffic.csv:
+    separate FETCH_SIZE / WRITE_SIZE runs of this script at the bench shape, gfx950 correction applied as
+    MI355X_MICROARCH.md prescribes).  bench.py cannot run the PMC passes itself; the figures are valid for the
+    default workload only."""
+    out = {}
+    if not os.path.exists(PMC_FILE):
+        return out
+    import csv
+    acc = {}
+    with open(PMC_FILE) as f:
+        rows = csv.DictReader(l for l in f if not l.startswith("#"))
+        for r in rows:
+            n, b = int(r["launches"]), float(r["hbm_bytes_per_launch_corrected"])
+            a = acc.setdefault(r["bench_family"], [0, 0.0])
+            a[0] += n; a[1] += n * b
+    for fam, (n, tot) in acc.items():
+        out[fam] = tot / max(n, 1)
+    out["conv_gather"] = out["conv_scatter2"] = out.get("conv", 0.0) or None
+    return out
+
+
 def kernel_rooflines(B, T, H, G, prec, per_step_ms, calls):
     """Algorithmic work per launch for the kernels that can dominate."""
     Hg = H // G
@@ -239,6 +264,12 @@ def main():
                 kt.mark_pass()
             per_step, calls = kt.summary()
         rl = kernel_rooflines(B, T, model.hidden_size, a.groups, a.prec, per_step, calls)
+        if (B, a.seconds, a.groups, a.prec) == (64, 4.0, 1, "bf16"):         # the shape the PMC passes were taken at
+            pmc = pmc_traffic()
+            for fam, ent in rl.items():
+                if pmc.get(fam):
+                    ent["traffic"] = round(pmc[fam])
+                    ent["traffic_unit"] = "HBM bytes per launch (rocprofv3 PMC 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_hbm_traffic.csv)"
         dom = max(per_step, key=per_step.get)
         breakdown = {k: round(v, 3) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])}
         roof = dict(rl.get(dom, {"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
