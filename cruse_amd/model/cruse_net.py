@@ -277,6 +277,15 @@ BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
 
+_PENDING_COUNTERS = []      # num_batches_tracked buffers of this forward: bumped by ONE kernel at its end, not seven
+
+
+def _flush_counters():
+    if _PENDING_COUNTERS:
+        torch._foreach_add_(list(_PENDING_COUNTERS), 1)
+        _PENDING_COUNTERS.clear()
+
+
 def _bn_stats(y, rows, C, F, P, Bf, name, training, update_running):
     if training:
         sums = ops.bn_stats(y, rows, C, F)
@@ -284,7 +293,7 @@ def _bn_stats(y, rows, C, F, P, Bf, name, training, update_running):
         rv = Bf[name + ".running_var"] if update_running else None
         mean, rstd = ops.bn_finalize(sums, rows * F, C, BN_EPS, BN_MOMENTUM, rm, rv)
         if update_running:
-            Bf[name + ".num_batches_tracked"].add_(1)
+            _PENDING_COUNTERS.append(Bf[name + ".num_batches_tracked"])
         return mean, rstd
     return ops.bn_eval_stats(Bf[name + ".running_mean"], Bf[name + ".running_var"], BN_EPS)
 
@@ -304,6 +313,7 @@ def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, tor
     Fk = [F0 >> k for k in range(L + 1)]
     ctx = dict(B=B, T=T, F=Fk, ch=tuple(ch), L=L, prec=prec, training=training, x=x)
     cur = x
+    _PENDING_COUNTERS.clear()
     ys, es, ss, stats = [None], [x], [None], [None]
     for k in range(1, L + 1):
         y = ops.conv_gather(cur, P[f"conv{k}.weight"], P[f"conv{k}.bias"], B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k],
@@ -335,6 +345,7 @@ def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, tor
         vs[k] = v; dstats[k] = (mean, rstd); us[k - 1] = u
     mask = ops.conv_scatter2(u, P["conv1_t.weight"], P["conv1_t.bias"], B, T, ch[1], Fk[1], ch[0], KT=1, pad=0, act=1,
                              prec=prec)
+    _flush_counters()
     if save:
         ctx.update(ys=ys, es=es, stats=stats, gctx=gctx, us=us, vs=vs, dstats=dstats, mask=mask)
     return mask.view(B, ch[0], T, F0), ctx
