@@ -218,3 +218,22 @@ def test_full_size_properties():
     assert all(np.isfinite(losses)), losses
     assert losses[-1] < losses[0], losses
     print("[full-size] losses", ["%.5f" % v for v in losses])
+
+
+def test_inferencer_matches_oracle_waveform():
+    """base_inferencer.py:138-161 on the HIP path: enhanced waveform vs the oracle's mask -> noisy phase -> istft."""
+    from cruse_amd.inferencer import Inferencer
+    from oracle import cruse_oracle as O
+    o, m = _oracle_and_product(1)
+    o.eval()
+    inf = Inferencer(m)
+    noisy, _ = O.synth_pair(1, 4800, seed=123)
+    with torch.no_grad():
+        _, est, _ = O.enhanced_spectrum(o, noisy)                                        # [B,T,F,2]
+        ref = O.istft(torch.complex(est[..., 0], est[..., 1]).transpose(1, 2), 320, 160, 320, length=noisy.shape[-1])
+    got = inf.mag_mask_to_wave(noisy.cuda())
+    assert got.shape == noisy.shape and rel_l2(got, ref) < 1e-4
+    res = inf([(noisy, ["clip0"])], log=lambda *_: None)
+    assert res[0][0] == "clip0" and 0 < res[0][1] < 10.0
+    w = Inferencer.to_int16(ref.squeeze(0).numpy())
+    assert w.dtype == np.int16 and abs(int(np.abs(w).max()) - int(0.8 * 32767)) <= 1

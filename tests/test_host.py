@@ -138,3 +138,11 @@ def test_gloo_world2_gradient_allreduce(tmp_path):
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0 and "OK" in o, o
+
+
+def test_inferencer_import_path_and_int16_scaling():
+    """train_base/inferencer/base_inferencer.py resolves to the HIP inferencer; int16 scaling of :183-185."""
+    import numpy as np
+    from train_base.inferencer.base_inferencer import Inferencer
+    w = Inferencer.to_int16(np.array([0.0, 0.25, -0.5], dtype=np.float32))
+    assert w.dtype == np.int16 and w.tolist() == [0, int(0.8 * 32767 * 0.5), int(-0.8 * 32767)]
