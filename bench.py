@@ -296,6 +296,7 @@ def main():
         }
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()                        # rank 0's instrumented pass and report are done before anyone tears down
         dist.destroy_process_group()
 
 

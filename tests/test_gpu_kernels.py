@@ -538,3 +538,27 @@ def test_gru_fwd_lean_matches_generic_kernel(ops, H, B, T):
         assert torch.isfinite(x.float()).all() and rel_l2(x.float(), y.float()) < tol, name
     h_nosave = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16", save=False)[0]
     assert rel_l2(h_nosave, lean[0]) < 1e-6                # same kernel, saves off: identical
+
+
+def test_gru_lean_kernels_with_groups(ops):
+    """Grouped GRU (G = 2, Hg = 256) through the bf16-mode lean forward / reduce-scatter backward kernels:
+    both must agree with the generic kernels on the same inputs (chains = batch groups x GRU groups)."""
+    import os
+    B, T, G, Hg = 11, 9, 2, 256
+    torch.manual_seed(5)
+    gi = (0.5 * torch.randn(B, T, G * 3 * Hg)).cuda()
+    w = [(torch.randn(3 * Hg, Hg) / Hg ** 0.5).cuda() for _ in range(G)]
+    b = [(0.1 * torch.randn(3 * Hg)).cuda() for _ in range(G)]
+    dout = torch.randn(B, T, G * Hg).cuda()
+    lean = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16")
+    dh_rs = ops.gru_seq_bwd(dout, w, lean[1], lean[3], B, T, G, Hg, "bf16")
+    os.environ["CRUSE_GRU_FWD_LEAN"] = "0"; os.environ["CRUSE_GRU_BWD_RS"] = "0"
+    try:
+        gen = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16")
+        dh_ag = ops.gru_seq_bwd(dout, w, lean[1], lean[3], B, T, G, Hg, "bf16")
+    finally:
+        del os.environ["CRUSE_GRU_FWD_LEAN"], os.environ["CRUSE_GRU_BWD_RS"]
+    torch.cuda.synchronize()
+    assert ops.gru_status() == 0
+    assert rel_l2(lean[0], gen[0]) < 1e-4 and rel_l2(lean[1].float(), gen[1].float()) < 2e-3
+    assert rel_l2(dh_rs, dh_ag) < 5e-3
