@@ -43,6 +43,7 @@ SIGNATURES = {
     "cruse_gemm_bf16_nt": ("iiipqqpqqpqpiip", "i"),
     "cruse_cast_bf16": ("ppqp", "i"),
     "cruse_transpose_bf16": ("pqiqpqip", "i"),
+    "cruse_ktile_bf16": ("piiqpp", "i"),
     "cruse_gru_ws_bytes": ("iii", "z"),
     "cruse_gru_seq_fwd": ("pppppppiiiiipp", "i"),
     "cruse_gru_seq_bwd": ("pppppiiiiipp", "i"),

@@ -234,6 +234,22 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const float* x, lon
     }
 }
 
+// K-tiling WITHOUT transposition: element (n, k) of x [rows n][cols k] goes to y[(k/64)*rows*64 + n*64 + k%64];
+// k in [cols, kp) is zero-filled (kp = cols rounded up to 64) -- the K-contiguous operand whose K is not a
+// multiple of 64 (W_ih with Hg = 160)
+__global__ __launch_bounds__(256) void ktile_bf16_kernel(const float* x, int rows, int cols, long long ld, __bf16* y, int kp) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    const int kq = kp >> 2;
+    const long long n4 = (long long)rows * kq;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const int n = (int)(i / kq), k = (int)(i - (long long)n * kq) * 4;
+        bf16x4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (k + e < cols) ? (__bf16)x[n * ld + k + e] : (__bf16)0.f;
+        *reinterpret_cast<bf16x4*>(y + (long long)(k >> 6) * rows * 64 + (long long)n * 64 + (k & 63)) = h;
+    }
+}
+
 }  // namespace
 
 extern "C" int cruse_gemm_bf16_nt(int M, int N, int K, const void* A, long long lda, long long a_kstride,
@@ -306,5 +322,16 @@ extern "C" int cruse_transpose_bf16(const float* x, long long rows, int cols, lo
     hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, (__bf16*)yT,
                        ldT, shift_T);
     CRUSE_LAUNCH_CHECK("transpose_bf16");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_ktile_bf16(const float* x, int rows, int cols, long long ld, void* y, void* stream) {
+    CRUSE_REQUIRE(rows > 0 && cols > 0 && ld >= cols, CRUSE_E_SHAPE, "ktile_bf16: bad shape");
+    CRUSE_REQUIRE(((uintptr_t)y % 8) == 0, CRUSE_E_ALIGN, "ktile_bf16: unaligned output");
+    const int kp = (cols + 63) / 64 * 64;
+    long long nb = ((long long)rows * (kp / 4) + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(ktile_bf16_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, (__bf16*)y, kp);
+    CRUSE_LAUNCH_CHECK("ktile_bf16");
     return CRUSE_OK;
 }

@@ -121,8 +121,9 @@ def _splitk_bf16(M: int, N: int, K: int) -> int:
 
 
 def _bf16_gemm_path(prec, Hg: int) -> bool:
-    """bf16-operand GEMMs need K = Hg and K = 3*Hg to be whole 64-deep tiles."""
-    return ops.prec_code(prec) == ops.PREC_BF16 and Hg % 64 == 0
+    """bf16-operand GEMMs: K = Hg and K = 3*Hg are rounded up to whole 64-deep tiles -- the weight operand is zero
+    padded (K-tiled), the activation operand reads on into the next group / row (finite values, zero weights)."""
+    return ops.prec_code(prec) == ops.PREC_BF16 and Hg % 32 == 0
 
 
 def _splitk(M: int, N: int, K: int) -> int:
@@ -147,12 +148,13 @@ def ggru_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], prefix: str, group
 
     def layer(inp, lname):
         gi = torch.empty(B, T, g * 3 * Hg, device=x.device, dtype=torch.float32)
-        inp_bf = ops.cast_bf16(inp) if fast else None
+        inp_bf = ops.cast_bf16_padded(inp, pad=64 if Hg % 64 else 0) if fast else None
+        kp = (Hg + 63) // 64 * 64
         for i in range(g):
             w_ih, b_ih = P[f"{prefix}{lname}.{i}.weight_ih_l0"], P[f"{prefix}{lname}.{i}.bias_ih_l0"]
             if fast:
-                ops.gemm_bf16_nt(rows, 3 * Hg, Hg, inp_bf, i * Hg, H, ops.cast_bf16(w_ih), 0, Hg, gi, i * 3 * Hg, 3 * H,
-                                 bias=b_ih)
+                ops.gemm_bf16_nt(rows, 3 * Hg, kp, inp_bf, i * Hg, H, ops.ktile_bf16(w_ih, 3 * Hg, Hg), 0, 64, gi,
+                                 i * 3 * Hg, 3 * H, bias=b_ih, b_kstride=3 * Hg * 64)
             else:
                 ops.gemm(False, True, rows, 3 * Hg, Hg, inp, i * Hg, H, w_ih, 0, Hg, gi, i * 3 * Hg, 3 * H, bias=b_ih,
                          prec=prec)
@@ -218,8 +220,8 @@ def ggru_backward(ctx, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[s
         dinp, acc_dx = dinp_buffer(dout_h, need_dinp, last)
         if need_dinp:
             for i, nm in enumerate(names):
-                w_t = ops.transpose_bf16(P[nm + "weight_ih_l0"], 3 * Hg, Hg)          # K-tiled [3*Hg/64, Hg, 64]
-                ops.gemm_bf16_nt(rows, Hg, 3 * Hg, dgi, i * 3 * Hg, 3 * H, w_t, 0, 64, dinp, i * Hg, H,
+                w_t = ops.transpose_bf16(P[nm + "weight_ih_l0"], 3 * Hg, Hg)          # K-tiled [ceil(3*Hg/64), Hg, 64]
+                ops.gemm_bf16_nt(rows, Hg, w_t.shape[0] * 64, dgi, i * 3 * Hg, 3 * H, w_t, 0, 64, dinp, i * Hg, H,
                                  accumulate=acc_dx, b_kstride=Hg * 64)
         if last:
             SIDE.run(weight_grads, dgT, h, inp, inpT, hpT)

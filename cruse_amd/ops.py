@@ -224,6 +224,23 @@ def cast_bf16(x, out=None):
     return y
 
 
+def ktile_bf16(x, rows, cols):
+    """x [rows, cols] f32 -> K-tiled bf16 [ceil(cols/64), rows, 64] (k = column index, zero padded): no transposition."""
+    y = torch.empty((cols + 63) // 64, rows, 64, device=x.device, dtype=torch.bfloat16)
+    check(lib.cruse_ktile_bf16(_p(x), rows, cols, cols, _p(y), _stream()))
+    return y
+
+
+def cast_bf16_padded(x, pad=64):
+    """bf16 copy of x followed by `pad` zero elements, so a GEMM whose K is rounded up to 64 may read past the last row."""
+    n = x.numel()
+    buf = torch.empty(n + pad, device=x.device, dtype=torch.bfloat16)
+    if pad:
+        buf[n:].zero_()
+    check(lib.cruse_cast_bf16(_p(x), _p(buf), n, _stream()))
+    return buf
+
+
 def transpose_bf16(x, rows, cols, shift_T=0, out=None):
     """x [rows, cols] f32 -> K-tiled time-major bf16 [ceil(rows/64), cols, 64] (zero-padded frames);
     shift_T > 0 reads row r-1 within each clip."""
@@ -284,7 +301,12 @@ def gru_gate_grads_bf16(dh, coef, an, rows, G, Hg, db_ih, db_hh):
     if coef.dtype != torch.bfloat16:
         raise RuntimeError("gru_gate_grads_bf16 needs the bf16 coefficients of CRUSE_PREC_BF16")
     ldT = (rows + 63) // 64 * 64
-    dgi = torch.empty(rows, G, 3, Hg, device=dh.device, dtype=torch.bfloat16)
+    n = rows * G * 3 * Hg
+    pad = 64 if (3 * Hg) % 64 else 0                                           # dX rounds K = 3*Hg up to 64: zeros to read
+    dgi_buf = torch.empty(n + pad, device=dh.device, dtype=torch.bfloat16)
+    if pad:
+        dgi_buf[n:].zero_()
+    dgi = dgi_buf[:n].view(rows, G, 3, Hg)
     dgT = torch.empty(ldT // 64, G, 4, Hg, 64, device=dh.device, dtype=torch.bfloat16)
     check(lib.cruse_gru_gate_grads_bf16(_p(dh), _p(coef), _p(an), _p(dgi), _p(dgT), ldT, _ptr_array(db_ih),
                                         _ptr_array(db_hh), rows, G, Hg, _stream()))

@@ -165,6 +165,9 @@ int cruse_gemm_bf16_nt(int M, int N, int K, const void* A, long long lda, long l
                        float* C, long long ldc, const float* bias, int accumulate, int splitk, void* stream);
 /* y[i] = bf16(x[i]), n % 4 == 0 */
 int cruse_cast_bf16(const float* x, void* y, long long n, void* stream);
+/* K-tiling without transposition: y[(k/64)*rows*64 + n*64 + k%64] = bf16(x[n*ld + k]), zero for cols <= k < ceil64(cols):
+ * a K-contiguous operand (W_ih [3Hg, Hg]) whose K is not a multiple of 64. */
+int cruse_ktile_bf16(const float* x, int rows, int cols, long long ld, void* y, void* stream);
 /* K-tiled time-major transpose: yT[(r/64)*cols*64 + c*64 + r%64] = bf16(x[(r - s)*ld + c]) with s = 0, or s = 1
  * when shift_T > 0 (then 0 where r % shift_T == 0: the h_{t-1} operand of dW_hh); frames rows <= r < ldT are
  * zero-filled (ldT % 64 == 0). */

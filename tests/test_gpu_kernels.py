@@ -562,3 +562,22 @@ def test_gru_lean_kernels_with_groups(ops):
     assert ops.gru_status() == 0
     assert rel_l2(lean[0], gen[0]) < 1e-4 and rel_l2(lean[1].float(), gen[1].float()) < 2e-3
     assert rel_l2(dh_rs, dh_ag) < 5e-3
+
+
+def test_ktile_bf16_and_padded_k_gemm(ops):
+    """K not a multiple of 64 (Hg = 160): the weight operand is K-tiled with zero padding, the activation operand is
+    read past its 160 columns into finite neighbours -- the product must still be x[:, :160] @ W^T."""
+    rows, Hg = 300, 160
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(rows, 4 * Hg, generator=gen).cuda()                  # 4 groups side by side
+    w = torch.randn(3 * Hg, Hg, generator=gen).cuda()
+    wk = ops.ktile_bf16(w, 3 * Hg, Hg)
+    assert wk.shape == (3, 3 * Hg, 64)
+    flat = wk.permute(1, 0, 2).reshape(3 * Hg, 192)
+    assert torch.equal(flat[:, :Hg], w.to(torch.bfloat16)) and flat[:, Hg:].abs().max() == 0
+    xb = ops.cast_bf16_padded(x, pad=64)
+    for i in (0, 3):                                                     # first and LAST group (reads past the row end)
+        C = torch.zeros(rows, 3 * Hg).cuda()
+        ops.gemm_bf16_nt(rows, 3 * Hg, 192, xb, i * Hg, 4 * Hg, wk, 0, 64, C, 0, 3 * Hg, b_kstride=3 * Hg * 64)
+        ref = x[:, i * Hg:(i + 1) * Hg].to(torch.bfloat16).double() @ w.to(torch.bfloat16).double().t()
+        assert rel_l2(C, ref) < 1e-6, i
