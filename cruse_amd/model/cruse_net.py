@@ -197,8 +197,6 @@ def ggru_backward(ctx, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[s
         dh = SIDE.release_around(lambda: ops.gru_seq_bwd(dout_h, w_hh, coef, z, B, T, g, Hg, prec))
         dgi, dgT, ldT = ops.gru_gate_grads_bf16(dh, coef, an, rows, g, Hg, [G[nm + "bias_ih_l0"] for nm in names],
                                                 [G[nm + "bias_hh_l0"] for nm in names])
-        dinp = torch.empty(B, T, H, device=dout_h.device, dtype=torch.float32) if need_dinp else None
-
         inpT = torch.empty(ldT // 64, H, 64, device=dh.device, dtype=torch.bfloat16)
         hpT = torch.empty(ldT // 64, H, 64, device=dh.device, dtype=torch.bfloat16)
 
