@@ -507,10 +507,13 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
 //     masks); block-wide agreement comes from the panel barrier that is needed anyway;
 //   * the k-loop is fully unrolled (NKW = Hg/128 k-steps per wave, all valid).
 // ---------------------------------------------------------------------------------
-template <int NKW>
+// NKW = ceil(Hg/32 / 4) k-steps per wave, NS = ceil(Hg/128) sweep slots per thread; FULL: Hg % 128 == 0, every k-step
+// of every wave exists (the guards below then vanish at compile time -- as run-time tests they cost the bench shape
+// 0.9 us per step: the compiler no longer overlaps the fragment reads of one k-step with the MFMAs of the previous)
+template <int NKW, int NS, bool FULL>
 __global__ __launch_bounds__(256) void gru_fwd_lean_kernel(GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int Hg = a.Hg, H = a.G * Hg, LD = Hg + 8;
+    const int Hg = a.Hg, H = a.G * Hg, LD = Hg + 8, KS = Hg >> 5;
     __bf16* hB = reinterpret_cast<__bf16*>(smem_raw);                    // [16][LD]  B operand (h_{t-1})
     float* red = reinterpret_cast<float*>(hB + 16 * LD);                  // [4 waves][6 tiles][64 lanes][4]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -537,17 +540,18 @@ __global__ __launch_bounds__(256) void gru_fwd_lean_kernel(GruArgs a) {
         for (int i = 0; i < NKW; ++i) {
             const int ks = wv + 4 * i;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) wf[j][i][e] = (__bf16)W[(long long)row * Hg + ks * 32 + (lane >> 4) * 8 + e];
+            for (int e = 0; e < 8; ++e)
+                wf[j][i][e] = (FULL || ks < KS) ? (__bf16)W[(long long)row * Hg + ks * 32 + (lane >> 4) * 8 + e] : (__bf16)0.f;
         }
     }
 
     // sweep slots: load e = tid + 256*j covers clip e / (Hg/4), units 4*(e % (Hg/4)) ..+3 (clamped for short chains:
     // the last valid granule is then fetched and stored twice)
     const int per = Hg >> 2, nload = nb * per;
-    unsigned sw_v[NKW];
-    int sw_l[NKW];
+    unsigned sw_v[NS];
+    int sw_l[NS];
 #pragma unroll
-    for (int j = 0; j < NKW; ++j) {
+    for (int j = 0; j < NS; ++j) {
         const int e = min(tid + 256 * j, nload - 1);
         const int bl = e / per, v = 4 * (e - bl * per);
         sw_v[j] = (unsigned)e * 16u;
@@ -588,14 +592,14 @@ __global__ __launch_bounds__(256) void gru_fwd_lean_kernel(GruArgs a) {
     for (int t = 0; t < a.T; ++t) {
         if (t > 0) {
             const unsigned soff = cbase + (unsigned)((t - 1) & 1) * panel_bytes;
-            u32x4 g[NKW];
+            u32x4 g[NS];
             unsigned spins = 0;
             for (;;) {
 #pragma unroll
-                for (int j = 0; j < NKW; ++j) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, sw_v[j], soff, 16);
+                for (int j = 0; j < NS; ++j) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, sw_v[j], soff, 16);
                 bool ok = true;
 #pragma unroll
-                for (int j = 0; j < NKW; ++j) ok = ok & (g[j].x == (unsigned)t) & (g[j].z == (unsigned)t);
+                for (int j = 0; j < NS; ++j) ok = ok & (g[j].x == (unsigned)t) & (g[j].z == (unsigned)t);
                 if (__all(ok || nowait)) break;
                 if (++spins >= SPIN_LIMIT) {
                     if (lane == 0) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -604,7 +608,7 @@ __global__ __launch_bounds__(256) void gru_fwd_lean_kernel(GruArgs a) {
                 __builtin_amdgcn_s_sleep(1);
             }
 #pragma unroll
-            for (int j = 0; j < NKW; ++j) {
+            for (int j = 0; j < NS; ++j) {
                 const u32x2 w = {g[j].y, g[j].w};                   // already bf16 pairs: the LDS image as is
                 *reinterpret_cast<u32x2*>(hB + sw_l[j]) = w;
             }
@@ -637,9 +641,11 @@ __global__ __launch_bounds__(256) void gru_fwd_lean_kernel(GruArgs a) {
             for (int j = 0; j < 6; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < NKW; ++i) {
-                const bf16x8 fb = *reinterpret_cast<const bf16x8*>(hB + (lane & 15) * LD + (wv + 4 * i) * 32 + (lane >> 4) * 8);
+                if (FULL || wv + 4 * i < KS) {              // wave-uniform
+                    const bf16x8 fb = *reinterpret_cast<const bf16x8*>(hB + (lane & 15) * LD + (wv + 4 * i) * 32 + (lane >> 4) * 8);
 #pragma unroll
-                for (int j = 0; j < 6; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][i], fb, acc[j], 0, 0, 0);
+                    for (int j = 0; j < 6; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][i], fb, acc[j], 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(red + ((wv * 6 + j) * 64 + lane) * 4) = acc[j];
@@ -808,7 +814,7 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
-// backward, REDUCE-SCATTER form (CRUSE_PREC_BF16, Bg = 8, Hg % 128 == 0, Hg <= 640).
+// backward, REDUCE-SCATTER form (CRUSE_PREC_BF16, Bg = 8, Hg % 32 == 0, Hg <= 640).
 // The all-gather form above makes every workgroup of a team rebuild the full [Bg x 3Hg] panel dh (.) c from the
 // swept dh and 30 KB of coefficient rows per step.  Here a workgroup contracts over the gate rows it OWNS:
 //   partial_p[b, n] = sum_{k in own 96 rows} (dh_s (.) c_s)[b, k] W_hh[k, n]      for ALL n in [0, Hg)
@@ -824,12 +830,16 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruArgs a) {
 // so the loop carries no address arithmetic (every access is a buffer instruction with a per-thread constant
 // voffset and a scalar per-step soffset), no divergent control flow, and one barrier (the waves wait for their own
 // granules with a wave-level vote; the operand panel is double-buffered by step parity instead of fenced).
-template <int NT>                                // 16-unit output tiles per wavefront = Hg / 64
+// NP: tile PAIRS per wavefront -- a pair is the 32 units of one consumer; wave w owns pairs [w*NP, w*NP + NP), NP = ceil(P/4).
+// FULL: P % 4 == 0 (Hg % 128 == 0): every pair and every producer slot exists, the validity masks fold away at
+// compile time.
+template <int NP, bool FULL>
 __global__ __launch_bounds__(256) void gru_bwd_rs_kernel(GruArgs a) {
     constexpr int KP = 96 + 8;                   // panel row stride (bf16): 208 B, de-phases the 16 rows of a b128 read
-    constexpr int NL = NT / 2;                   // 16-byte loads per thread and sweep: (P/4 producers) x 16 B
+    constexpr int NT = 2 * NP;                   // 16-unit output tiles per wavefront
+    constexpr int NL = NP;                       // 16-byte loads per thread and sweep: producers quarter*NL + j, j < NL = ceil(P/4)
     __shared__ __attribute__((aligned(16))) __bf16 panel[2][16 * KP];
-    const int Hg = a.Hg, H = a.G * Hg, K3 = 3 * Hg, P = a.P;
+    const int Hg = a.Hg, H = a.G * Hg, K3 = 3 * Hg, P = a.P, NTt = Hg >> 4;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int chain = (int)(blockIdx.x / (8 * P)) * 8 + (int)(blockIdx.x & 7);
     const int part = (int)((blockIdx.x >> 3) % P);
@@ -849,17 +859,18 @@ __global__ __launch_bounds__(256) void gru_bwd_rs_kernel(GruArgs a) {
     bf16x8 wf[NT][3];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int n = (wv * NT + nt) * 16 + (lane & 15);
+        const int gt = 2 * (wv * NP + (nt >> 1)) + (nt & 1);  // pairs beyond P (P % 4 != 0) carry zero weights
+        const int n = min(gt, NTt - 1) * 16 + (lane & 15);
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk) {
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                wf[nt][kk][e] = (__bf16)W[(long long)(kk * Hg + u0 + (lane >> 4) * 8 + e) * Hg + n];
+                wf[nt][kk][e] = (FULL || gt < NTt) ? (__bf16)W[(long long)(kk * Hg + u0 + (lane >> 4) * 8 + e) * Hg + n] : (__bf16)0.f;
         }
     }
 
     // thread = (clip bl, unit quad pp, quarter): owns unit u0 + 4*pp + quarter and sums, for all four units of its
-    // quad, the producers [quarter*P/4, (quarter+1)*P/4) -- 16-byte loads; the quarters meet through two shuffles
+    // quad, the producers [quarter*NL, quarter*NL + NL) -- 16-byte loads; the quarters meet through two row moves
     const int quarter = tid & 3, pp = (tid >> 2) & 7, bl = tid >> 5;
     const bool active = bl < nb;
     const int blc = active ? bl : 0;                                  // inactive threads shadow clip 0 (loads only)
@@ -873,19 +884,27 @@ __global__ __launch_bounds__(256) void gru_bwd_rs_kernel(GruArgs a) {
     const unsigned own_v = (unsigned)(((long long)(b0 + blc) * a.T * H + grp * Hg + u0 + 4 * pp + quarter) * 4);   // + s*frame_bytes
     const unsigned cf_v = (unsigned)((((long long)(b0 + blc) * a.T * a.G + grp) * K3 + u0 + 4 * pp + quarter) * 2);  // + s*crow_bytes
     const unsigned hg2 = (unsigned)Hg * 2u;
-    const unsigned sweep_v = (unsigned)part * cons_bytes + (unsigned)((((quarter * (P >> 2)) * 8 + blc) * 16 + 2 * pp) * 8);
+    unsigned sweep_v[NL];
+    bool sweep_ok[NL];                                                // the producer exists (P % 4 != 0: the last ones may not)
+#pragma unroll
+    for (int jj = 0; jj < NL; ++jj) {
+        const int pr = quarter * NL + jj;
+        sweep_ok[jj] = FULL || pr < P;
+        sweep_v[jj] = (unsigned)part * cons_bytes + (unsigned)(((min(pr, P - 1) * 8 + blc) * 16 + 2 * pp) * 8);
+    }
     // publish: the MFMA leaves clips in columns (lane & 15) < 8 only, so tiles are published in PAIRS -- the lanes of
     // the idle columns take the second tile of the pair from lane ^ 8 (a 16-lane-row rotate) and every store
     // instruction carries 64 x 16 bytes.  Offset of this lane's 16-byte piece per tile pair (clip = lane & 7):
     const int hi8 = (lane >> 3) & 1;
-    unsigned pub_v[NT / 2];
+    unsigned pub_v[NP];
+    bool pub_ok[NP];
 #pragma unroll
-    for (int np = 0; np < NT / 2; ++np) {
-        const int gt = wv * NT + 2 * np + hi8;
+    for (int np = 0; np < NP; ++np) {
+        const int gt = 2 * (wv * NP + np) + hi8;             // this lane's tile of the pair
+        pub_ok[np] = (FULL || gt < NTt) && (lane & 7) < nb;
         pub_v[np] = (unsigned)(gt >> 1) * cons_bytes +
                     (((((unsigned)part * 8u + (unsigned)(lane & 7)) * 16u) + (unsigned)(gt & 1) * 8u + (unsigned)(lane >> 4) * 2u) << 3);
     }
-    const bool pub_lane = (lane & 7) < nb;
     const int pw = blc * KP + 4 * pp + quarter;                      // panel element of the own unit (+ gate*32)
 
     float dh = 0.f, dd = 0.f, zz = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;  // operands of the current step (time s)
@@ -910,10 +929,10 @@ __global__ __launch_bounds__(256) void gru_bwd_rs_kernel(GruArgs a) {
             unsigned spins = 0;
             for (;;) {
 #pragma unroll
-                for (int j = 0; j < NL; ++j) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, sweep_v + (unsigned)j * 1024u, soff, 16);
+                for (int j = 0; j < NL; ++j) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, sweep_v[j], soff, 16);
                 bool ok = true;
 #pragma unroll
-                for (int j = 0; j < NL; ++j) ok = ok & (g[j].x == (unsigned)k) & (g[j].z == (unsigned)k);
+                for (int j = 0; j < NL; ++j) ok = ok & (((g[j].x == (unsigned)k) & (g[j].z == (unsigned)k)) | (!FULL && !sweep_ok[j]));
                 if (__all(ok || !active || nowait)) break;            // wave-level: every lane's granules carry this epoch
                 if (++spins >= SPIN_LIMIT) {
                     if (lane == 0) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -924,8 +943,9 @@ __global__ __launch_bounds__(256) void gru_bwd_rs_kernel(GruArgs a) {
             float sm[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < NL; ++j) {
-                sm[0] += bf16lo(g[j].y); sm[1] += bf16hi(g[j].y);
-                sm[2] += bf16lo(g[j].w); sm[3] += bf16hi(g[j].w);
+                const unsigned y = (FULL || sweep_ok[j]) ? g[j].y : 0u, w = (FULL || sweep_ok[j]) ? g[j].w : 0u;
+                sm[0] += bf16lo(y); sm[1] += bf16hi(y);
+                sm[2] += bf16lo(w); sm[3] += bf16hi(w);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -962,9 +982,8 @@ __global__ __launch_bounds__(256) void gru_bwd_rs_kernel(GruArgs a) {
             fb[kk] = *reinterpret_cast<const bf16x8*>(pn + (lane & 15) * KP + kk * 32 + (lane >> 4) * 8);
         const unsigned soff = cbase + (unsigned)(k & 1) * panel_bytes;
         const unsigned ep = (unsigned)(k + 1);
-        const bool do_pub = pub_lane;
 #pragma unroll
-        for (int np = 0; np < NT / 2; ++np) {
+        for (int np = 0; np < NP; ++np) {
             f32x4 c0_ = (f32x4){0.f, 0.f, 0.f, 0.f}, c1_ = c0_;
 #pragma unroll
             for (int kk = 0; kk < 3; ++kk) {
@@ -975,7 +994,7 @@ __global__ __launch_bounds__(256) void gru_bwd_rs_kernel(GruArgs a) {
             const unsigned b0_ = pack2(c1_[0], c1_[1]), b1_ = pack2(c1_[2], c1_[3]);
             const unsigned x0 = dpp_ror8(b0_), x1 = dpp_ror8(b1_);
             const u32x4 w = {ep, hi8 ? x0 : a0, ep, hi8 ? x1 : a1};
-            if (do_pub) {
+            if (pub_ok[np]) {
                 if (plain) __builtin_amdgcn_raw_buffer_store_b128(w, rs, pub_v[np], soff, 0);
                 else __builtin_amdgcn_raw_buffer_store_b128(w, rs, pub_v[np], soff, 16);
             }
@@ -1143,12 +1162,12 @@ size_t xid_bytes_total(int B, int G) { return (size_t)cdiv(B, 8) * G * 64 * 8; }
 // reduce-scatter backward keeps [consumer P][clip 8][pair 16][producer P]
 bool bwd_rs_eligible(int Bg, int Hg, int prec) {
     if (getenv("CRUSE_GRU_BWD_RS") && atoi(getenv("CRUSE_GRU_BWD_RS")) == 0) return false;    // A/B switch (tests, probes)
-    return prec == CRUSE_PREC_BF16 && Bg == 8 && Hg % 128 == 0 && Hg <= 640;
+    return prec == CRUSE_PREC_BF16 && Bg == 8 && Hg % 32 == 0 && Hg <= 640;
 }
 size_t rs_gran_per_parity(int Hg) { const size_t P = Hg / 32; return P * 8 * 16 * P; }
 size_t xg_bytes_total(int B, int G, int Hg) {
     size_t per = (size_t)16 * Hg;
-    if (Hg % 128 == 0 && Hg <= 640 && rs_gran_per_parity(Hg) > per) per = rs_gran_per_parity(Hg);
+    if (Hg % 32 == 0 && Hg <= 640 && rs_gran_per_parity(Hg) > per) per = rs_gran_per_parity(Hg);
     return (size_t)cdiv(B, 8) * G * 2 * per * 8;
 }
 
@@ -1163,15 +1182,25 @@ int launch_one(Kern k, const GruArgs& a, int grid, size_t lds, hipStream_t s, co
 
 bool fwd_lean_eligible(int Bg, int Hg, int prec) {
     if (getenv("CRUSE_GRU_FWD_LEAN") && atoi(getenv("CRUSE_GRU_FWD_LEAN")) == 0) return false;   // A/B switch (tests, probes)
-    return prec == CRUSE_PREC_BF16 && Bg == 8 && Hg % 128 == 0 && Hg <= 640;
+    return prec == CRUSE_PREC_BF16 && Bg == 8 && Hg % 32 == 0 && Hg <= 640;
 }
 int dispatch_fwd_lean(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
-    switch (a.Hg / 128) {
-        case 1: return launch_one(gru_fwd_lean_kernel<1>, a, grid, lds, s, "gru_seq_fwd");
-        case 2: return launch_one(gru_fwd_lean_kernel<2>, a, grid, lds, s, "gru_seq_fwd");
-        case 3: return launch_one(gru_fwd_lean_kernel<3>, a, grid, lds, s, "gru_seq_fwd");
-        case 4: return launch_one(gru_fwd_lean_kernel<4>, a, grid, lds, s, "gru_seq_fwd");
-        default: return launch_one(gru_fwd_lean_kernel<5>, a, grid, lds, s, "gru_seq_fwd");
+    const int n = (a.Hg + 127) / 128;            // = k-steps per wave = sweep slots per thread
+    if (a.Hg % 128 == 0) {
+        switch (n) {
+            case 1: return launch_one(gru_fwd_lean_kernel<1, 1, true>, a, grid, lds, s, "gru_seq_fwd");
+            case 2: return launch_one(gru_fwd_lean_kernel<2, 2, true>, a, grid, lds, s, "gru_seq_fwd");
+            case 3: return launch_one(gru_fwd_lean_kernel<3, 3, true>, a, grid, lds, s, "gru_seq_fwd");
+            case 4: return launch_one(gru_fwd_lean_kernel<4, 4, true>, a, grid, lds, s, "gru_seq_fwd");
+            default: return launch_one(gru_fwd_lean_kernel<5, 5, true>, a, grid, lds, s, "gru_seq_fwd");
+        }
+    }
+    switch (n) {
+        case 1: return launch_one(gru_fwd_lean_kernel<1, 1, false>, a, grid, lds, s, "gru_seq_fwd");
+        case 2: return launch_one(gru_fwd_lean_kernel<2, 2, false>, a, grid, lds, s, "gru_seq_fwd");
+        case 3: return launch_one(gru_fwd_lean_kernel<3, 3, false>, a, grid, lds, s, "gru_seq_fwd");
+        case 4: return launch_one(gru_fwd_lean_kernel<4, 4, false>, a, grid, lds, s, "gru_seq_fwd");
+        default: return launch_one(gru_fwd_lean_kernel<5, 5, false>, a, grid, lds, s, "gru_seq_fwd");
     }
 }
 
@@ -1193,12 +1222,22 @@ int dispatch_bwd(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
 }
 
 int dispatch_bwd_rs(const GruArgs& a, int grid, hipStream_t s) {
-    switch (a.Hg / 64) {
-        case 2: return launch_one(gru_bwd_rs_kernel<2>, a, grid, 0, s, "gru_seq_bwd");
-        case 4: return launch_one(gru_bwd_rs_kernel<4>, a, grid, 0, s, "gru_seq_bwd");
-        case 6: return launch_one(gru_bwd_rs_kernel<6>, a, grid, 0, s, "gru_seq_bwd");
-        case 8: return launch_one(gru_bwd_rs_kernel<8>, a, grid, 0, s, "gru_seq_bwd");
-        default: return launch_one(gru_bwd_rs_kernel<10>, a, grid, 0, s, "gru_seq_bwd");
+    const int P = a.Hg / 32, np = (P + 3) / 4;   // tile pairs per wavefront
+    if (P % 4 == 0) {
+        switch (np) {
+            case 1: return launch_one(gru_bwd_rs_kernel<1, true>, a, grid, 0, s, "gru_seq_bwd");
+            case 2: return launch_one(gru_bwd_rs_kernel<2, true>, a, grid, 0, s, "gru_seq_bwd");
+            case 3: return launch_one(gru_bwd_rs_kernel<3, true>, a, grid, 0, s, "gru_seq_bwd");
+            case 4: return launch_one(gru_bwd_rs_kernel<4, true>, a, grid, 0, s, "gru_seq_bwd");
+            default: return launch_one(gru_bwd_rs_kernel<5, true>, a, grid, 0, s, "gru_seq_bwd");
+        }
+    }
+    switch (np) {
+        case 1: return launch_one(gru_bwd_rs_kernel<1, false>, a, grid, 0, s, "gru_seq_bwd");
+        case 2: return launch_one(gru_bwd_rs_kernel<2, false>, a, grid, 0, s, "gru_seq_bwd");
+        case 3: return launch_one(gru_bwd_rs_kernel<3, false>, a, grid, 0, s, "gru_seq_bwd");
+        case 4: return launch_one(gru_bwd_rs_kernel<4, false>, a, grid, 0, s, "gru_seq_bwd");
+        default: return launch_one(gru_bwd_rs_kernel<5, false>, a, grid, 0, s, "gru_seq_bwd");
     }
 }
 

@@ -483,7 +483,8 @@ def test_gru_gate_grads_bf16_matches_f32_form(ops, G, Hg):
         assert rel_l2(db_hh[g] - 1, dgh_ref.view(rows, G, 3 * Hg)[:, g].double().sum(0)) < 1e-5
 
 
-@pytest.mark.parametrize("H,B,T", [(640, 9, 12), (128, 8, 7), (256, 3, 5), (384, 16, 6), (512, 1, 4)])
+@pytest.mark.parametrize("H,B,T", [(640, 9, 12), (128, 8, 7), (256, 3, 5), (384, 16, 6), (512, 1, 4), (160, 10, 8),
+                                   (96, 4, 6), (32, 8, 5), (288, 7, 5)])
 def test_gru_bwd_reduce_scatter_matches_all_gather_form(ops, H, B, T):
     """bf16 mode has two backward recurrence kernels (gru.hip): both must give the same dh from the same inputs."""
     import os
@@ -516,7 +517,8 @@ def test_gru_bwd_reduce_scatter_matches_all_gather_form(ops, H, B, T):
     assert rel_l2(dh_rs, ref) < 1e-2 and rel_l2(dh_ag, ref) < 1e-2
 
 
-@pytest.mark.parametrize("H,B,T", [(640, 9, 12), (128, 8, 7), (256, 3, 5), (384, 16, 6), (512, 1, 4)])
+@pytest.mark.parametrize("H,B,T", [(640, 9, 12), (128, 8, 7), (256, 3, 5), (384, 16, 6), (512, 1, 4), (160, 10, 8),
+                                   (96, 4, 6), (32, 8, 5), (288, 7, 5)])
 def test_gru_fwd_lean_matches_generic_kernel(ops, H, B, T):
     """bf16 mode has two forward recurrence kernels (gru.hip): same algorithm, so the same h / coefficients."""
     import os
@@ -544,7 +546,12 @@ def test_gru_lean_kernels_with_groups(ops):
     """Grouped GRU (G = 2, Hg = 256) through the bf16-mode lean forward / reduce-scatter backward kernels:
     both must agree with the generic kernels on the same inputs (chains = batch groups x GRU groups)."""
     import os
-    B, T, G, Hg = 11, 9, 2, 256
+    _lean_grouped_case(ops, 11, 9, 2, 256)
+    _lean_grouped_case(ops, 9, 7, 4, 160)          # BASELINE config 3 geometry: 4 groups of 160
+
+
+def _lean_grouped_case(ops, B, T, G, Hg):
+    import os
     torch.manual_seed(5)
     gi = (0.5 * torch.randn(B, T, G * 3 * Hg)).cuda()
     w = [(torch.randn(3 * Hg, Hg) / Hg ** 0.5).cuda() for _ in range(G)]
