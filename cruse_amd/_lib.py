@@ -43,7 +43,9 @@ SIGNATURES = {
     "cruse_gemm_bf16_nt": ("iiipqqpqqpqpiip", "i"),
     "cruse_cast_bf16": ("ppqp", "i"),
     "cruse_transpose_bf16": ("pqiqpqip", "i"),
-    "cruse_ktile_bf16": ("piiqpp", "i"),
+    "cruse_ktile_bf16": ("piiqppp", "i"),
+    "cruse_cast_bf16_split": ("pppqp", "i"),
+    "cruse_gemm_bf16x3_nt": ("iiippqqppqqpqpip", "i"),
     "cruse_gru_ws_bytes": ("iii", "z"),
     "cruse_gru_seq_fwd": ("pppppppiiiiipp", "i"),
     "cruse_gru_seq_bwd": ("pppppiiiiipp", "i"),

@@ -14,6 +14,8 @@
 // SOURCE address (the LDS-DMA destination is lane-linear) and undone in the fragment read address.
 #include "common.h"
 
+extern "C" int cruse_cast_bf16_split(const float* x, void* y, void* y_lo, long long n, void* stream);
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -24,6 +26,7 @@ typedef const __attribute__((address_space(1))) void glb_ptr_t;
 
 struct GbArgs {
     const __bf16* A; const __bf16* B; float* C; const float* bias;
+    long long a_lo, b_lo;                    // element offsets of the LOW planes (split-bf16 x3 form), 0 = plain bf16
     int M, N, K;
     long long lda, ldb, ldc, a_ks, b_ks;     // *_ks: elements between consecutive 64-deep k-tiles of one row
     int accumulate, splitk, kt_chunk;
@@ -52,6 +55,10 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_bf16_nt_kernel(con
     const int m0 = tm * BM, n0 = tn * BN;
     const int nkt = g.K / BK;
     const int kt0 = tz * g.kt_chunk, kt1 = min(nkt, kt0 + g.kt_chunk);
+    // split-bf16 x3 (a_lo != 0): the k-range is walked three times on the same accumulators -- (A_hi, B_hi),
+    // (A_hi, B_lo), (A_lo, B_hi) -- as 3*(kt1-kt0) virtual k-tiles, so the staging pipeline never drains in between
+    const int nreal = kt1 - kt0;
+    const int nvirt = g.a_lo ? 3 * nreal : nreal;
 
     // staging: wave wv fills rows [wv*32, wv*32+32) of both tiles, 8 rows (1 KiB) per instruction
     const __bf16* ap[4];
@@ -63,13 +70,15 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_bf16_nt_kernel(con
         ap[i] = g.A + (long long)min(m0 + r, g.M - 1) * g.lda + ch * 8;
         bp[i] = g.B + (long long)min(n0 + r, g.N - 1) * g.ldb + ch * 8;
     }
-    auto stage = [&](int kt, int buf) {
+    auto stage = [&](int v, int buf) {               // v: virtual k-tile index in [0, nvirt)
+        const int seg = v >= 2 * nreal ? 2 : (v >= nreal ? 1 : 0);
+        const int kt = kt0 + v - seg * nreal;
+        const long long oa = (long long)kt * g.a_ks + (seg == 2 ? g.a_lo : 0);
+        const long long ob = (long long)kt * g.b_ks + (seg == 1 ? g.b_lo : 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(ap[i] + (long long)kt * g.a_ks),
-                                             (lds_ptr_t*)&smem[buf][0][(wv * 4 + i) * 1024], 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(bp[i] + (long long)kt * g.b_ks),
-                                             (lds_ptr_t*)&smem[buf][1][(wv * 4 + i) * 1024], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(ap[i] + oa), (lds_ptr_t*)&smem[buf][0][(wv * 4 + i) * 1024], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(bp[i] + ob), (lds_ptr_t*)&smem[buf][1][(wv * 4 + i) * 1024], 16, 0, 0);
         }
     };
 
@@ -107,23 +116,23 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_bf16_nt_kernel(con
         }
     };
     if constexpr (NST == 2) {
-        if (kt0 < kt1) stage(kt0, 0);
-        for (int kt = kt0; kt < kt1; ++kt) {
-            const int buf = (kt - kt0) & 1;
-            __syncthreads();                   // tile kt landed (vmcnt(0) + barrier); buffer buf^1 is free again
-            if (kt + 1 < kt1) stage(kt + 1, buf ^ 1);
+        if (nvirt > 0) stage(0, 0);
+        for (int v = 0; v < nvirt; ++v) {
+            const int buf = v & 1;
+            __syncthreads();                   // tile v landed (vmcnt(0) + barrier); buffer buf^1 is free again
+            if (v + 1 < nvirt) stage(v + 1, buf ^ 1);
             compute(buf);
         }
     } else {
         // each stage() is 8 LDS-DMA loads per wave, retired in order: vmcnt(8) == "all but the newest tile landed"
-        if (kt0 < kt1) stage(kt0, 0);
-        if (kt0 + 1 < kt1) stage(kt0 + 1, 1);
+        if (nvirt > 0) stage(0, 0);
+        if (nvirt > 1) stage(1, 1);
         int buf = 0;
-        for (int kt = kt0; kt < kt1; ++kt) {
-            if (kt + 1 < kt1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        for (int v = 0; v < nvirt; ++v) {
+            if (v + 1 < nvirt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();      // tile kt is in LDS for every wave; stage (kt+2)%3 == (kt-1)%3 is drained
-            if (kt + 2 < kt1) stage(kt + 2, buf == 0 ? 2 : buf - 1);
+            __builtin_amdgcn_s_barrier();      // tile v is in LDS for every wave; stage (v+2)%3 == (v-1)%3 is drained
+            if (v + 2 < nvirt) stage(v + 2, buf == 0 ? 2 : buf - 1);
             compute(buf);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             buf = buf == 2 ? 0 : buf + 1;
@@ -183,14 +192,17 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_bf16_nt_kernel(con
     }
 }
 
-// y = bf16(x), same layout
-__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* x, __bf16* y, long long n4) {
+// y = bf16(x), same layout; y_lo (optional) = bf16(x - y): the low plane of the split-bf16 x3 form
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* x, __bf16* y, __bf16* y_lo, long long n4) {
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         const float4 v = reinterpret_cast<const float4*>(x)[i];
-        bf16x4 h;
-        h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+        const float f[4] = {v.x, v.y, v.z, v.w};
+        bf16x4 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h[e] = (__bf16)f[e]; l[e] = (__bf16)(f[e] - (float)h[e]); }
         reinterpret_cast<bf16x4*>(y)[i] = h;
+        if (y_lo) reinterpret_cast<bf16x4*>(y_lo)[i] = l;
     }
 }
 
@@ -237,25 +249,30 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const float* x, lon
 // K-tiling WITHOUT transposition: element (n, k) of x [rows n][cols k] goes to y[(k/64)*rows*64 + n*64 + k%64];
 // k in [cols, kp) is zero-filled (kp = cols rounded up to 64) -- the K-contiguous operand whose K is not a
 // multiple of 64 (W_ih with Hg = 160)
-__global__ __launch_bounds__(256) void ktile_bf16_kernel(const float* x, int rows, int cols, long long ld, __bf16* y, int kp) {
+__global__ __launch_bounds__(256) void ktile_bf16_kernel(const float* x, int rows, int cols, long long ld, __bf16* y,
+                                                         __bf16* y_lo, int kp) {
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
     const int kq = kp >> 2;
     const long long n4 = (long long)rows * kq;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         const int n = (int)(i / kq), k = (int)(i - (long long)n * kq) * 4;
-        bf16x4 h;
+        bf16x4 h, l;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) h[e] = (k + e < cols) ? (__bf16)x[n * ld + k + e] : (__bf16)0.f;
-        *reinterpret_cast<bf16x4*>(y + (long long)(k >> 6) * rows * 64 + (long long)n * 64 + (k & 63)) = h;
+        for (int e = 0; e < 4; ++e) {
+            const float f = (k + e < cols) ? x[n * ld + k + e] : 0.f;
+            h[e] = (__bf16)f; l[e] = (__bf16)(f - (float)h[e]);
+        }
+        const long long o = (long long)(k >> 6) * rows * 64 + (long long)n * 64 + (k & 63);
+        *reinterpret_cast<bf16x4*>(y + o) = h;
+        if (y_lo) *reinterpret_cast<bf16x4*>(y_lo + o) = l;
     }
 }
 
 }  // namespace
 
-extern "C" int cruse_gemm_bf16_nt(int M, int N, int K, const void* A, long long lda, long long a_kstride,
-                                  const void* B, long long ldb, long long b_kstride,
-                                  float* C, long long ldc, const float* bias, int accumulate, int splitk,
-                                  void* stream) {
+static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, long long lda, long long a_kstride,
+                          const void* B, const void* B_lo, long long ldb, long long b_kstride,
+                          float* C, long long ldc, const float* bias, int accumulate, int splitk, void* stream) {
     CRUSE_REQUIRE(M > 0 && N > 0 && K > 0, CRUSE_E_SHAPE, "gemm_bf16_nt: empty shape M=%d N=%d K=%d", M, N, K);
     CRUSE_REQUIRE(K % BK == 0, CRUSE_E_SHAPE, "gemm_bf16_nt: K=%d must be a multiple of %d (pad with zeros)", K, BK);
     CRUSE_REQUIRE(a_kstride >= BK && b_kstride >= BK && ldc >= N, CRUSE_E_SHAPE, "gemm_bf16_nt: strides too small");
@@ -271,6 +288,8 @@ extern "C" int cruse_gemm_bf16_nt(int M, int N, int K, const void* A, long long 
     splitk = cdiv(nkt, kt_chunk);
     GbArgs g;
     g.A = (const __bf16*)A; g.B = (const __bf16*)B; g.C = C; g.bias = bias;
+    g.a_lo = A_lo ? (const __bf16*)A_lo - (const __bf16*)A : 0;
+    g.b_lo = B_lo ? (const __bf16*)B_lo - (const __bf16*)B : 0;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.a_ks = a_kstride; g.b_ks = b_kstride;
     g.accumulate = accumulate; g.splitk = splitk; g.kt_chunk = kt_chunk;
     g.tiles_m = cdiv(M, BM); g.tiles_n = cdiv(N, BN);
@@ -300,12 +319,35 @@ extern "C" int cruse_gemm_bf16_nt(int M, int N, int K, const void* A, long long 
     return CRUSE_OK;
 }
 
+extern "C" int cruse_gemm_bf16_nt(int M, int N, int K, const void* A, long long lda, long long a_kstride,
+                                  const void* B, long long ldb, long long b_kstride,
+                                  float* C, long long ldc, const float* bias, int accumulate, int splitk,
+                                  void* stream) {
+    return gemm_bf16_impl(M, N, K, A, nullptr, lda, a_kstride, B, nullptr, ldb, b_kstride, C, ldc, bias, accumulate, splitk,
+                          stream);
+}
+
+extern "C" int cruse_gemm_bf16x3_nt(int M, int N, int K, const void* A_hi, const void* A_lo, long long lda,
+                                    long long a_kstride, const void* B_hi, const void* B_lo, long long ldb,
+                                    long long b_kstride, float* C, long long ldc, const float* bias, int accumulate,
+                                    void* stream) {
+    CRUSE_REQUIRE(A_lo != nullptr && B_lo != nullptr && A_lo != A_hi && B_lo != B_hi, CRUSE_E_SHAPE,
+                  "gemm_bf16x3_nt: low planes missing");
+    CRUSE_REQUIRE(((uintptr_t)A_lo % 16) == 0 && ((uintptr_t)B_lo % 16) == 0, CRUSE_E_ALIGN, "gemm_bf16x3_nt: unaligned low planes");
+    return gemm_bf16_impl(M, N, K, A_hi, A_lo, lda, a_kstride, B_hi, B_lo, ldb, b_kstride, C, ldc, bias, accumulate, 1, stream);
+}
+
 extern "C" int cruse_cast_bf16(const float* x, void* y, long long n, void* stream) {
+    return cruse_cast_bf16_split(x, y, nullptr, n, stream);
+}
+
+extern "C" int cruse_cast_bf16_split(const float* x, void* y, void* y_lo, long long n, void* stream) {
     CRUSE_REQUIRE(n > 0 && n % 4 == 0, CRUSE_E_SHAPE, "cast_bf16: n=%lld must be a positive multiple of 4", n);
-    CRUSE_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 8) == 0, CRUSE_E_ALIGN, "cast_bf16: unaligned buffers");
+    CRUSE_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 8) == 0 && ((uintptr_t)y_lo % 8) == 0, CRUSE_E_ALIGN,
+                  "cast_bf16: unaligned buffers");
     long long nb = (n / 4 + 255) / 256;
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(cast_bf16_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)y, n / 4);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, x, (__bf16*)y, (__bf16*)y_lo, n / 4);
     CRUSE_LAUNCH_CHECK("cast_bf16");
     return CRUSE_OK;
 }
@@ -325,13 +367,14 @@ extern "C" int cruse_transpose_bf16(const float* x, long long rows, int cols, lo
     return CRUSE_OK;
 }
 
-extern "C" int cruse_ktile_bf16(const float* x, int rows, int cols, long long ld, void* y, void* stream) {
+extern "C" int cruse_ktile_bf16(const float* x, int rows, int cols, long long ld, void* y, void* y_lo, void* stream) {
     CRUSE_REQUIRE(rows > 0 && cols > 0 && ld >= cols, CRUSE_E_SHAPE, "ktile_bf16: bad shape");
-    CRUSE_REQUIRE(((uintptr_t)y % 8) == 0, CRUSE_E_ALIGN, "ktile_bf16: unaligned output");
+    CRUSE_REQUIRE(((uintptr_t)y % 8) == 0 && ((uintptr_t)y_lo % 8) == 0, CRUSE_E_ALIGN, "ktile_bf16: unaligned output");
     const int kp = (cols + 63) / 64 * 64;
     long long nb = ((long long)rows * (kp / 4) + 255) / 256;
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(ktile_bf16_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, (__bf16*)y, kp);
+    hipLaunchKernelGGL(ktile_bf16_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, (__bf16*)y,
+                       (__bf16*)y_lo, kp);
     CRUSE_LAUNCH_CHECK("ktile_bf16");
     return CRUSE_OK;
 }

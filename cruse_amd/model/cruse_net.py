@@ -148,12 +148,19 @@ def ggru_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], prefix: str, group
 
     def layer(inp, lname):
         gi = torch.empty(B, T, g * 3 * Hg, device=x.device, dtype=torch.float32)
-        inp_bf = ops.cast_bf16_padded(inp, pad=64 if Hg % 64 else 0) if fast else None
+        # The forward projection runs split-bf16 x3: its operand rounding otherwise dominates the forward error of the
+        # bf16 mode (enhanced spectrum 1.25e-3 -> 4.8e-4 rel-L2 on fixture G6); the backward GEMMs stay plain bf16.
+        x3 = (int(os.environ.get("CRUSE_GI_X3", "3")) >> (0 if lname == "gru_list1" else 1)) & 1
+        inp_hi, inp_lo = ops.cast_bf16_padded(inp, pad=64 if Hg % 64 else 0, split=True) if fast else (None, None)
         kp = (Hg + 63) // 64 * 64
         for i in range(g):
             w_ih, b_ih = P[f"{prefix}{lname}.{i}.weight_ih_l0"], P[f"{prefix}{lname}.{i}.bias_ih_l0"]
-            if fast:
-                ops.gemm_bf16_nt(rows, 3 * Hg, kp, inp_bf, i * Hg, H, ops.ktile_bf16(w_ih, 3 * Hg, Hg), 0, 64, gi,
+            if fast and x3:
+                w_hi, w_lo = ops.ktile_bf16(w_ih, 3 * Hg, Hg, split=True)
+                ops.gemm_bf16x3_nt(rows, 3 * Hg, kp, inp_hi, inp_lo, i * Hg, H, w_hi, w_lo, 0, 64, gi, i * 3 * Hg, 3 * H,
+                                   bias=b_ih, b_kstride=3 * Hg * 64)
+            elif fast:
+                ops.gemm_bf16_nt(rows, 3 * Hg, kp, inp_hi, i * Hg, H, ops.ktile_bf16(w_ih, 3 * Hg, Hg), 0, 64, gi,
                                  i * 3 * Hg, 3 * H, bias=b_ih, b_kstride=3 * Hg * 64)
             else:
                 ops.gemm(False, True, rows, 3 * Hg, Hg, inp, i * Hg, H, w_ih, 0, Hg, gi, i * 3 * Hg, 3 * H, bias=b_ih,

@@ -224,21 +224,38 @@ def cast_bf16(x, out=None):
     return y
 
 
-def ktile_bf16(x, rows, cols):
-    """x [rows, cols] f32 -> K-tiled bf16 [ceil(cols/64), rows, 64] (k = column index, zero padded): no transposition."""
+def ktile_bf16(x, rows, cols, split=False):
+    """x [rows, cols] f32 -> K-tiled bf16 [ceil(cols/64), rows, 64] (k = column index, zero padded): no transposition.
+    split: returns (hi, lo) planes with x ~= hi + lo."""
     y = torch.empty((cols + 63) // 64, rows, 64, device=x.device, dtype=torch.bfloat16)
-    check(lib.cruse_ktile_bf16(_p(x), rows, cols, cols, _p(y), _stream()))
-    return y
+    lo = torch.empty_like(y) if split else None
+    check(lib.cruse_ktile_bf16(_p(x), rows, cols, cols, _p(y), _p(lo), _stream()))
+    return (y, lo) if split else y
 
 
-def cast_bf16_padded(x, pad=64):
-    """bf16 copy of x followed by `pad` zero elements, so a GEMM whose K is rounded up to 64 may read past the last row."""
+def cast_bf16_padded(x, pad=64, split=False):
+    """bf16 copy of x followed by `pad` zero elements, so a GEMM whose K is rounded up to 64 may read past the last row.
+    split: returns (hi, lo) planes with x ~= hi + lo (both padded)."""
     n = x.numel()
     buf = torch.empty(n + pad, device=x.device, dtype=torch.bfloat16)
+    lo = torch.empty(n + pad, device=x.device, dtype=torch.bfloat16) if split else None
     if pad:
         buf[n:].zero_()
-    check(lib.cruse_cast_bf16(_p(x), _p(buf), n, _stream()))
-    return buf
+        if split:
+            lo[n:].zero_()
+    check(lib.cruse_cast_bf16_split(_p(x), _p(buf), _p(lo), n, _stream()))
+    return (buf, lo) if split else buf
+
+
+def gemm_bf16x3_nt(M, N, K, A_hi, A_lo, a_off, lda, B_hi, B_lo, b_off, ldb, C, c_off, ldc, bias=None, accumulate=False,
+                   a_kstride=64, b_kstride=64):
+    """Split-bf16 x3 form of gemm_bf16_nt: (A_hi + A_lo) . (B_hi + B_lo)^T without the lo.lo term."""
+    for t_ in (A_hi, A_lo, B_hi, B_lo):
+        if t_.dtype != torch.bfloat16:
+            raise RuntimeError("gemm_bf16x3_nt needs bf16 planes")
+    check(lib.cruse_gemm_bf16x3_nt(M, N, K, A_hi.data_ptr() + 2 * a_off, A_lo.data_ptr() + 2 * a_off, lda, a_kstride,
+                                   B_hi.data_ptr() + 2 * b_off, B_lo.data_ptr() + 2 * b_off, ldb, b_kstride,
+                                   C.data_ptr() + 4 * c_off, ldc, _p(bias), 1 if accumulate else 0, _stream()))
 
 
 def transpose_bf16(x, rows, cols, shift_T=0, out=None):

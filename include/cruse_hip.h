@@ -166,8 +166,18 @@ int cruse_gemm_bf16_nt(int M, int N, int K, const void* A, long long lda, long l
 /* y[i] = bf16(x[i]), n % 4 == 0 */
 int cruse_cast_bf16(const float* x, void* y, long long n, void* stream);
 /* K-tiling without transposition: y[(k/64)*rows*64 + n*64 + k%64] = bf16(x[n*ld + k]), zero for cols <= k < ceil64(cols):
- * a K-contiguous operand (W_ih [3Hg, Hg]) whose K is not a multiple of 64. */
-int cruse_ktile_bf16(const float* x, int rows, int cols, long long ld, void* y, void* stream);
+ * a K-contiguous operand (W_ih [3Hg, Hg]) whose K is not a multiple of 64.  y_lo (nullable): the low plane
+ * bf16(x - y) of the split-bf16 x3 form, same layout. */
+int cruse_ktile_bf16(const float* x, int rows, int cols, long long ld, void* y, void* y_lo, void* stream);
+/* y = bf16(x) and y_lo = bf16(x - y) (nullable) */
+int cruse_cast_bf16_split(const float* x, void* y, void* y_lo, long long n, void* stream);
+/* Split-bf16 x3 form of cruse_gemm_bf16_nt: A = A_hi + A_lo, B = B_hi + B_lo (bf16 planes, same layout each);
+ * C = A_hi.B_hi + A_hi.B_lo + A_lo.B_hi accumulated in one pass (~f32 operand accuracy, 3x the MFMAs).  Used for
+ * the FORWARD gate projection gi = x W_ih^T, whose bf16 operand rounding otherwise dominates the forward error of
+ * CRUSE_PREC_BF16 (1.25e-3 -> 4.8e-4 on fixture G6).  No split-K. */
+int cruse_gemm_bf16x3_nt(int M, int N, int K, const void* A_hi, const void* A_lo, long long lda, long long a_kstride,
+                         const void* B_hi, const void* B_lo, long long ldb, long long b_kstride,
+                         float* C, long long ldc, const float* bias, int accumulate, void* stream);
 /* K-tiled time-major transpose: yT[(r/64)*cols*64 + c*64 + r%64] = bf16(x[(r - s)*ld + c]) with s = 0, or s = 1
  * when shift_T > 0 (then 0 where r % shift_T == 0: the h_{t-1} operand of dW_hh); frames rows <= r < ldT are
  * zero-filled (ldT % 64 == 0). */

@@ -588,3 +588,23 @@ def test_ktile_bf16_and_padded_k_gemm(ops):
         ops.gemm_bf16_nt(rows, 3 * Hg, 192, xb, i * Hg, 4 * Hg, wk, 0, 64, C, 0, 3 * Hg, b_kstride=3 * Hg * 64)
         ref = x[:, i * Hg:(i + 1) * Hg].to(torch.bfloat16).double() @ w.to(torch.bfloat16).double().t()
         assert rel_l2(C, ref) < 1e-6, i
+
+
+def test_gemm_bf16x3_forward_projection(ops):
+    """Split-bf16 x3 form (the forward gate projection of the bf16 mode): ~f32 operand accuracy from bf16 MFMAs."""
+    rows, Hg = 400, 160
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(rows, 2 * Hg, generator=gen).cuda()
+    w = torch.randn(3 * Hg, Hg, generator=gen).cuda(); b = torch.randn(3 * Hg, generator=gen).cuda()
+    x_hi, x_lo = ops.cast_bf16_padded(x, pad=64, split=True)
+    assert rel_l2((x_hi[:x.numel()].float() + x_lo[:x.numel()].float()).view_as(x), x) < 2e-5
+    w_hi, w_lo = ops.ktile_bf16(w, 3 * Hg, Hg, split=True)
+    for i in (0, 1):
+        C = torch.zeros(rows, 3 * Hg).cuda()
+        ops.gemm_bf16x3_nt(rows, 3 * Hg, 192, x_hi, x_lo, i * Hg, 2 * Hg, w_hi, w_lo, 0, 64, C, 0, 3 * Hg, bias=b,
+                           b_kstride=3 * Hg * 64)
+        ref = x[:, i * Hg:(i + 1) * Hg].double() @ w.double().t() + b.double()
+        assert rel_l2(C, ref) < 2e-5, i
+        C1 = torch.zeros(rows, 3 * Hg).cuda()
+        ops.gemm_bf16_nt(rows, 3 * Hg, 192, x_hi, i * Hg, 2 * Hg, w_hi, 0, 64, C1, 0, 3 * Hg, bias=b, b_kstride=3 * Hg * 64)
+        assert rel_l2(C1, ref) > 50 * rel_l2(C, ref)                # the plain bf16 product is two orders coarser

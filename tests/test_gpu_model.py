@@ -94,7 +94,7 @@ def test_train_step_golden(golden, grp, prec, tol):
     print(f"[parity g={grp} {prec}] worst grad-norm rel dev {worst:.3e}")
 
 
-def test_bf16_mode_error_is_reported_not_gated(golden):
+def test_bf16_mode_forward_error(golden):
     from cruse_amd.acoustics.feature import pre_stft
     from cruse_amd.loss import enhanced_spectrum
     g = golden("g6_step_g1.npz")
@@ -104,8 +104,8 @@ def test_bf16_mode_error_is_reported_not_gated(golden):
     with torch.no_grad():
         mask = m(f["mag_net"])
     e = rel_l2(enhanced_spectrum(mask, f["real"], f["imag"]), torch.from_numpy(g["est"]))
-    print(f"[parity g=1 bf16] enhanced-spectrum rel-L2 {e:.3e} (reported; bf16 operands, f32 accumulate)")
-    assert e < 5e-2
+    print(f"[parity g=1 bf16] enhanced-spectrum rel-L2 {e:.3e} (bf16 MFMA operands; forward projection split x3)")
+    assert e <= 1e-3              # the bench mode meets the parity bar too (SURVEY 8d gates only the f32 mode)
 
 
 def test_engine_step_matches_oracle_adam(golden):
