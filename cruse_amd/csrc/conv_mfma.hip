@@ -33,7 +33,6 @@ struct CMArgs {
     int nrows;                                   // staged frames = TFM + halo
     long long sco, sci;                          // weight strides of co and ci (tap index is fastest, 3*KT long)
     int act, accum;
-    unsigned long long* dbg;                     // profiling only (CRUSE_CM_DBG)
     TapClass cls[2];
 };
 
@@ -43,12 +42,10 @@ struct CMArgs {
 template <int PREC> struct OpStore {
     typedef __bf16 elem;
     static constexpr int NPL = (PREC == CRUSE_PREC_BF16X3) ? 2 : 1;
-    static constexpr int PADC = 8;                         // channel pad (elements) keeping 16-byte groups
 };
 template <> struct OpStore<CRUSE_PREC_F32> {
     typedef float elem;
     static constexpr int NPL = 1;
-    static constexpr int PADC = 4;
 };
 
 template <int PREC>
@@ -163,11 +160,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
         }
     };
     if ((int)blockIdx.x < a.B * ntile) prefetch(blockIdx.x);
-    unsigned long long tm[4] = {0, 0, 0, 0};
-    const bool prof = a.dbg != nullptr;
-    unsigned long long cstart = prof ? __builtin_amdgcn_s_memtime() : 0;
     for (int tile = blockIdx.x; tile < a.B * ntile; tile += gridDim.x) {
-        const unsigned long long c0 = prof ? __builtin_amdgcn_s_memtime() : 0;
         const int b = tile / ntile;
         const int t0 = (tile - b * ntile) * TFM;
         __syncthreads();                                   // previous tile's reads of xl are done
@@ -177,9 +170,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
             if (i < nvec) *reinterpret_cast<float4*>(xl + i * 4) = pre[q];
         }
         __syncthreads();
-        const unsigned long long c1 = prof ? __builtin_amdgcn_s_memtime() : 0;
         if (tile + (int)gridDim.x < a.B * ntile) prefetch(tile + gridDim.x);
-        const unsigned long long c2 = prof ? __builtin_amdgcn_s_memtime() : 0;
 
         // N-tile loop, kept free of integer divisions (Cin is a power of two, positions via a float reciprocal)
         // and of global loads; one 64-bit base address per N-tile.  (Keeping several N-tiles in flight per wave
@@ -240,10 +231,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
                 }
             }
         }
-        if (prof) { const unsigned long long c3 = __builtin_amdgcn_s_memtime(); tm[0] += c1 - c0; tm[1] += c2 - c1; tm[2] += c3 - c2; tm[3] += 1; }
-    }
-    if (prof && blockIdx.x == 0 && tid == 0) {
-        a.dbg[0] = tm[0]; a.dbg[1] = tm[1]; a.dbg[2] = tm[2]; a.dbg[3] = tm[3]; a.dbg[4] = cstart; a.dbg[5] = __builtin_amdgcn_s_memtime();
     }
 }
 
@@ -315,17 +302,6 @@ int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float
                           (prec == CRUSE_PREC_F32 ? 4 : (prec == CRUSE_PREC_BF16X3 ? 4 : 2));
     const size_t lds = wbytes + (size_t)a.nrows * Cin * Fin * sizeof(float);
     if (lds > 150 * 1024) return 0;
-    static unsigned long long* dbgbuf = nullptr;
-    if (getenv("CRUSE_CM_DBG")) {
-        if (!dbgbuf) hipMalloc(&dbgbuf, 128);
-        else {
-            unsigned long long h[9];
-            hipMemcpy(h, dbgbuf, sizeof(h), hipMemcpyDeviceToHost);
-            fprintf(stderr, "[conv_mfma prev launch] tiles %llu  stage %llu  prefetch-issue %llu  compute %llu cycles/tile; kernel %llu cycles\n",
-                    h[3], h[3] ? h[0] / h[3] : 0, h[3] ? h[1] / h[3] : 0, h[3] ? h[2] / h[3] : 0, h[5] - h[4]);
-        }
-        a.dbg = dbgbuf;
-    }
     const int ntiles = B * ((T + TFM - 1) / TFM);
     // small weight images: more, lighter workgroups hide latency better (44 vs 60 us on the 8->16 layer);
     // large ones (up to 48 KB of fragments per workgroup) amortise their prologue over more tiles
