@@ -244,7 +244,6 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WMArgs p) {
         __syncthreads();
         // K steps: lane group (lane >> 4) takes chunk ks*4 + group; (frame, bin-chunk) advance without dividing
         int tl = (lane >> 4) / p.NCH, fc = (lane >> 4) - tl * p.NCH;
-#pragma unroll 2
         for (int ks = 0; ks < ((p.dbg & 2) ? 0 : nks); ++ks) {
             const size_t poff = (size_t)(tl * FaP + fc * 8);
             Frag<PREC> fa_[MT];
