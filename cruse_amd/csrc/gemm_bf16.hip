@@ -55,10 +55,10 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_bf16_nt_kernel(con
     const int m0 = tm * BM, n0 = tn * BN;
     const int nkt = g.K / BK;
     const int kt0 = tz * g.kt_chunk, kt1 = min(nkt, kt0 + g.kt_chunk);
-    // split-bf16 x3 (a_lo != 0): the k-range is walked three times on the same accumulators -- (A_hi, B_hi),
-    // (A_hi, B_lo), (A_lo, B_hi) -- as 3*(kt1-kt0) virtual k-tiles, so the staging pipeline never drains in between
+    // split-bf16 forms: the k-range is walked again on the same accumulators for every correction term -- (A_hi, B_lo)
+    // when B has a low plane, (A_lo, B_hi) when A has one too -- as extra virtual k-tiles of ONE staging pipeline
     const int nreal = kt1 - kt0;
-    const int nvirt = g.a_lo ? 3 * nreal : nreal;
+    const int nvirt = (g.b_lo ? (g.a_lo ? 3 : 2) : 1) * nreal;      // (hi,hi) [, (hi,lo) [, (lo,hi)]]
 
     // staging: wave wv fills rows [wv*32, wv*32+32) of both tiles, 8 rows (1 KiB) per instruction
     const __bf16* ap[4];
@@ -331,8 +331,7 @@ extern "C" int cruse_gemm_bf16x3_nt(int M, int N, int K, const void* A_hi, const
                                     long long a_kstride, const void* B_hi, const void* B_lo, long long ldb,
                                     long long b_kstride, float* C, long long ldc, const float* bias, int accumulate,
                                     void* stream) {
-    CRUSE_REQUIRE(A_lo != nullptr && B_lo != nullptr && A_lo != A_hi && B_lo != B_hi, CRUSE_E_SHAPE,
-                  "gemm_bf16x3_nt: low planes missing");
+    CRUSE_REQUIRE(B_lo != nullptr && A_lo != A_hi && B_lo != B_hi, CRUSE_E_SHAPE, "gemm_bf16x3_nt: B_lo missing");
     CRUSE_REQUIRE(((uintptr_t)A_lo % 16) == 0 && ((uintptr_t)B_lo % 16) == 0, CRUSE_E_ALIGN, "gemm_bf16x3_nt: unaligned low planes");
     return gemm_bf16_impl(M, N, K, A_hi, A_lo, lda, a_kstride, B_hi, B_lo, ldb, b_kstride, C, ldc, bias, accumulate, 1, stream);
 }

@@ -148,10 +148,17 @@ def ggru_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], prefix: str, group
 
     def layer(inp, lname):
         gi = torch.empty(B, T, g * 3 * Hg, device=x.device, dtype=torch.float32)
-        # The forward projection runs split-bf16 x3: its operand rounding otherwise dominates the forward error of the
-        # bf16 mode (enhanced spectrum 1.25e-3 -> 4.8e-4 rel-L2 on fixture G6); the backward GEMMs stay plain bf16.
-        x3 = (int(os.environ.get("CRUSE_GI_X3", "3")) >> (0 if lname == "gru_list1" else 1)) & 1
-        inp_hi, inp_lo = ops.cast_bf16_padded(inp, pad=64 if Hg % 64 else 0, split=True) if fast else (None, None)
+        # The forward projection corrects the bf16 rounding of W_ih (a second pass with its low plane): that rounding
+        # dominates the forward error of the bf16 mode (enhanced spectrum 1.25e-3 -> 5.1e-4 rel-L2 on fixture G6;
+        # correcting x too only reaches 4.8e-4).  CRUSE_GI_X3: bit 0 / 1 = layer 1 / 2 corrected, bit 2 = also split x.
+        knob = int(os.environ.get("CRUSE_GI_X3", "3"))
+        x3 = (knob >> (0 if lname == "gru_list1" else 1)) & 1
+        split_x = bool(knob & 4) and x3
+        pad = 64 if Hg % 64 else 0
+        if fast and split_x:
+            inp_hi, inp_lo = ops.cast_bf16_padded(inp, pad=pad, split=True)
+        else:
+            inp_hi, inp_lo = (ops.cast_bf16_padded(inp, pad=pad) if fast else None), None
         kp = (Hg + 63) // 64 * 64
         for i in range(g):
             w_ih, b_ih = P[f"{prefix}{lname}.{i}.weight_ih_l0"], P[f"{prefix}{lname}.{i}.bias_ih_l0"]

@@ -249,11 +249,13 @@ def cast_bf16_padded(x, pad=64, split=False):
 
 def gemm_bf16x3_nt(M, N, K, A_hi, A_lo, a_off, lda, B_hi, B_lo, b_off, ldb, C, c_off, ldc, bias=None, accumulate=False,
                    a_kstride=64, b_kstride=64):
-    """Split-bf16 x3 form of gemm_bf16_nt: (A_hi + A_lo) . (B_hi + B_lo)^T without the lo.lo term."""
+    """Split-bf16 form of gemm_bf16_nt: (A_hi + A_lo) . (B_hi + B_lo)^T without the lo.lo term; A_lo = None drops
+    the A_lo.B_hi term too (two passes: only B's rounding is corrected)."""
     for t_ in (A_hi, A_lo, B_hi, B_lo):
-        if t_.dtype != torch.bfloat16:
+        if t_ is not None and t_.dtype != torch.bfloat16:
             raise RuntimeError("gemm_bf16x3_nt needs bf16 planes")
-    check(lib.cruse_gemm_bf16x3_nt(M, N, K, A_hi.data_ptr() + 2 * a_off, A_lo.data_ptr() + 2 * a_off, lda, a_kstride,
+    check(lib.cruse_gemm_bf16x3_nt(M, N, K, A_hi.data_ptr() + 2 * a_off,
+                                   None if A_lo is None else A_lo.data_ptr() + 2 * a_off, lda, a_kstride,
                                    B_hi.data_ptr() + 2 * b_off, B_lo.data_ptr() + 2 * b_off, ldb, b_kstride,
                                    C.data_ptr() + 4 * c_off, ldc, _p(bias), 1 if accumulate else 0, _stream()))
 

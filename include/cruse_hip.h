@@ -172,9 +172,9 @@ int cruse_ktile_bf16(const float* x, int rows, int cols, long long ld, void* y, 
 /* y = bf16(x) and y_lo = bf16(x - y) (nullable) */
 int cruse_cast_bf16_split(const float* x, void* y, void* y_lo, long long n, void* stream);
 /* Split-bf16 x3 form of cruse_gemm_bf16_nt: A = A_hi + A_lo, B = B_hi + B_lo (bf16 planes, same layout each);
- * C = A_hi.B_hi + A_hi.B_lo + A_lo.B_hi accumulated in one pass (~f32 operand accuracy, 3x the MFMAs).  Used for
- * the FORWARD gate projection gi = x W_ih^T, whose bf16 operand rounding otherwise dominates the forward error of
- * CRUSE_PREC_BF16 (1.25e-3 -> 4.8e-4 on fixture G6).  No split-K. */
+ * C = A_hi.B_hi + A_hi.B_lo [+ A_lo.B_hi] accumulated in one pass.  A_lo may be NULL: two passes, only B's rounding
+ * is corrected.  Used for the FORWARD gate projection gi = x W_ih^T: the bf16 rounding of W_ih dominates the
+ * forward error of CRUSE_PREC_BF16 (enhanced spectrum 1.25e-3; 5.1e-4 with W split, 4.8e-4 with both).  No split-K. */
 int cruse_gemm_bf16x3_nt(int M, int N, int K, const void* A_hi, const void* A_lo, long long lda, long long a_kstride,
                          const void* B_hi, const void* B_lo, long long ldb, long long b_kstride,
                          float* C, long long ldc, const float* bias, int accumulate, void* stream);
