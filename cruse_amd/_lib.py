@@ -12,6 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcruse_hip.so")
 
+ABI_VERSION = 2
 PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 PREC_BY_NAME = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
 
@@ -62,6 +63,8 @@ SIGNATURES = {
     "cruse_sigmoid_bwd": ("pppqp", "i"),
     "cruse_axpby": ("pppffqp", "i"),
     "cruse_adam_step": ("ppppqfffffifp", "i"),
+    "cruse_adam_step_guarded": ("ppppqfffffiffppppp", "i"),
+    "cruse_sumsq": ("pqpip", "i"),
 }
 
 
@@ -75,8 +78,8 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = [_T[c] for c in args]
         fn.restype = ctypes.c_char_p if res == "s" else _T[res]
-    if lib.cruse_abi_version() != 1:
-        raise ImportError(f"libcruse_hip.so ABI version {lib.cruse_abi_version()} != 1")
+    if lib.cruse_abi_version() != ABI_VERSION:
+        raise ImportError(f"libcruse_hip.so ABI version {lib.cruse_abi_version()} != {ABI_VERSION}")
     return lib
 
 

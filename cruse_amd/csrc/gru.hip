@@ -510,7 +510,11 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
 // NKW = ceil(Hg/32 / 4) k-steps per wave, NS = ceil(Hg/128) sweep slots per thread; FULL: Hg % 128 == 0, every k-step
 // of every wave exists (the guards below then vanish at compile time -- as run-time tests they cost the bench shape
 // 0.9 us per step: the compiler no longer overlaps the fragment reads of one k-step with the MFMAs of the previous)
-template <int NKW, int NS, bool FULL>
+// WLO: W_hh is carried as TWO bf16 planes (hi + lo, ~2^-17 relative) and every k-step issues a second MFMA with the low
+// plane on the same accumulators.  The rounding of the recurrent WEIGHTS is the systematic part of the bf16 recurrence
+// error (the same perturbation at every one of the T steps; the rounding of h is fresh noise per step): see DESIGN.md
+// section 2 for the measured effect.  Costs 6*NKW more MFMAs per wave and step and 24*NKW more registers per lane.
+template <int NKW, int NS, bool FULL, bool WLO>
 __global__ __launch_bounds__(256) void gru_fwd_lean_kernel(GruArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int Hg = a.Hg, H = a.G * Hg, LD = Hg + 8, KS = Hg >> 5;
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(256) void gru_fwd_lean_kernel(GruArgs a) {
     for (int i = tid; i < 16 * LD; i += 256) hB[i] = (__bf16)0.f;
 
     // resident weight fragments: tile j = gate*2 + half; this wave's k-steps ks = wv + 4*i
-    bf16x8 wf[6][NKW];
+    bf16x8 wf[6][NKW], wl[WLO ? 6 : 1][WLO ? NKW : 1];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         const int row = (j >> 1) * Hg + u0 + (j & 1) * 16 + (lane & 15);
@@ -540,8 +544,11 @@ __global__ __launch_bounds__(256) void gru_fwd_lean_kernel(GruArgs a) {
         for (int i = 0; i < NKW; ++i) {
             const int ks = wv + 4 * i;
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                wf[j][i][e] = (FULL || ks < KS) ? (__bf16)W[(long long)row * Hg + ks * 32 + (lane >> 4) * 8 + e] : (__bf16)0.f;
+            for (int e = 0; e < 8; ++e) {
+                const float w = (FULL || ks < KS) ? W[(long long)row * Hg + ks * 32 + (lane >> 4) * 8 + e] : 0.f;
+                wf[j][i][e] = (__bf16)w;
+                if constexpr (WLO) wl[j][i][e] = (__bf16)(w - (float)wf[j][i][e]);
+            }
         }
     }
 
@@ -645,6 +652,10 @@ __global__ __launch_bounds__(256) void gru_fwd_lean_kernel(GruArgs a) {
                     const bf16x8 fb = *reinterpret_cast<const bf16x8*>(hB + (lane & 15) * LD + (wv + 4 * i) * 32 + (lane >> 4) * 8);
 #pragma unroll
                     for (int j = 0; j < 6; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][i], fb, acc[j], 0, 0, 0);
+                    if constexpr (WLO) {
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j][i], fb, acc[j], 0, 0, 0);
+                    }
                 }
             }
 #pragma unroll
@@ -1184,24 +1195,35 @@ bool fwd_lean_eligible(int Bg, int Hg, int prec) {
     if (getenv("CRUSE_GRU_FWD_LEAN") && atoi(getenv("CRUSE_GRU_FWD_LEAN")) == 0) return false;   // A/B switch (tests, probes)
     return prec == CRUSE_PREC_BF16 && Bg == 8 && Hg % 32 == 0 && Hg <= 640;
 }
-int dispatch_fwd_lean(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
+// W_hh low plane in the lean forward recurrence: CRUSE_GRU_WLO = 1 always, 0 never; default: when the second plane is
+// nearly free (Hg <= 320: at most 48 extra registers and 12 extra MFMAs per wave and step)
+bool fwd_wlo(int Hg) {
+    const char* e = getenv("CRUSE_GRU_WLO");
+    if (e) return atoi(e) != 0;
+    return Hg <= 320;
+}
+template <bool WLO>
+int dispatch_fwd_lean_w(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
     const int n = (a.Hg + 127) / 128;            // = k-steps per wave = sweep slots per thread
     if (a.Hg % 128 == 0) {
         switch (n) {
-            case 1: return launch_one(gru_fwd_lean_kernel<1, 1, true>, a, grid, lds, s, "gru_seq_fwd");
-            case 2: return launch_one(gru_fwd_lean_kernel<2, 2, true>, a, grid, lds, s, "gru_seq_fwd");
-            case 3: return launch_one(gru_fwd_lean_kernel<3, 3, true>, a, grid, lds, s, "gru_seq_fwd");
-            case 4: return launch_one(gru_fwd_lean_kernel<4, 4, true>, a, grid, lds, s, "gru_seq_fwd");
-            default: return launch_one(gru_fwd_lean_kernel<5, 5, true>, a, grid, lds, s, "gru_seq_fwd");
+            case 1: return launch_one(gru_fwd_lean_kernel<1, 1, true, WLO>, a, grid, lds, s, "gru_seq_fwd");
+            case 2: return launch_one(gru_fwd_lean_kernel<2, 2, true, WLO>, a, grid, lds, s, "gru_seq_fwd");
+            case 3: return launch_one(gru_fwd_lean_kernel<3, 3, true, WLO>, a, grid, lds, s, "gru_seq_fwd");
+            case 4: return launch_one(gru_fwd_lean_kernel<4, 4, true, WLO>, a, grid, lds, s, "gru_seq_fwd");
+            default: return launch_one(gru_fwd_lean_kernel<5, 5, true, WLO>, a, grid, lds, s, "gru_seq_fwd");
         }
     }
     switch (n) {
-        case 1: return launch_one(gru_fwd_lean_kernel<1, 1, false>, a, grid, lds, s, "gru_seq_fwd");
-        case 2: return launch_one(gru_fwd_lean_kernel<2, 2, false>, a, grid, lds, s, "gru_seq_fwd");
-        case 3: return launch_one(gru_fwd_lean_kernel<3, 3, false>, a, grid, lds, s, "gru_seq_fwd");
-        case 4: return launch_one(gru_fwd_lean_kernel<4, 4, false>, a, grid, lds, s, "gru_seq_fwd");
-        default: return launch_one(gru_fwd_lean_kernel<5, 5, false>, a, grid, lds, s, "gru_seq_fwd");
+        case 1: return launch_one(gru_fwd_lean_kernel<1, 1, false, WLO>, a, grid, lds, s, "gru_seq_fwd");
+        case 2: return launch_one(gru_fwd_lean_kernel<2, 2, false, WLO>, a, grid, lds, s, "gru_seq_fwd");
+        case 3: return launch_one(gru_fwd_lean_kernel<3, 3, false, WLO>, a, grid, lds, s, "gru_seq_fwd");
+        case 4: return launch_one(gru_fwd_lean_kernel<4, 4, false, WLO>, a, grid, lds, s, "gru_seq_fwd");
+        default: return launch_one(gru_fwd_lean_kernel<5, 5, false, WLO>, a, grid, lds, s, "gru_seq_fwd");
     }
+}
+int dispatch_fwd_lean(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
+    return fwd_wlo(a.Hg) ? dispatch_fwd_lean_w<true>(a, grid, lds, s) : dispatch_fwd_lean_w<false>(a, grid, lds, s);
 }
 
 template <int PREC>
@@ -1304,7 +1326,7 @@ extern "C" int cruse_gru_seq_fwd(const float* gi, const float* const* w_hh, cons
     Plan pl;
     CRUSE_REQUIRE(make_plan(B, G, Hg, pl) == 0, CRUSE_E_SHAPE, "gru_seq_fwd: G*Hg/32 exceeds the CU count");
     hipStream_t s = (hipStream_t)stream;
-    { int zrc = cruse_zero_async(ws, cruse_gru_ws_bytes(B, G, Hg), s, "gru_seq_fwd memset"); if (zrc) return zrc; }
+    { int zrc = cruse_zero_async((char*)ws + 256, cruse_gru_ws_bytes(B, G, Hg) - 256, s, "gru_seq_fwd memset"); if (zrc) return zrc; }   // the 256-byte header (status word) is sticky
     GruArgs a = {};
     a.gi = gi; a.h = h; a.coef = coef; a.an = an; a.z = z;
     for (int g = 0; g < G; ++g) { a.p.w_hh[g] = w_hh[g]; a.p.b_hh[g] = b_hh[g]; }
@@ -1321,7 +1343,7 @@ extern "C" int cruse_gru_seq_bwd(const float* dout, const float* const* w_hh, co
     Plan pl;
     CRUSE_REQUIRE(make_plan(B, G, Hg, pl) == 0, CRUSE_E_SHAPE, "gru_seq_bwd: G*Hg/32 exceeds the CU count");
     hipStream_t s = (hipStream_t)stream;
-    { int zrc = cruse_zero_async(ws, cruse_gru_ws_bytes(B, G, Hg), s, "gru_seq_bwd memset"); if (zrc) return zrc; }
+    { int zrc = cruse_zero_async((char*)ws + 256, cruse_gru_ws_bytes(B, G, Hg) - 256, s, "gru_seq_bwd memset"); if (zrc) return zrc; }   // the 256-byte header (status word) is sticky
     GruArgs a = {};
     a.dout = dout; a.coefs = coef; a.zs = z; a.dh = dh;
     for (int g = 0; g < G; ++g) { a.p.w_hh[g] = w_hh[g]; a.p.b_hh[g] = nullptr; }

@@ -546,8 +546,29 @@ __global__ void axpby_kernel(float* out, const float* x, const float* y, float a
         out[i] = a * x[i] + (y ? b * y[i] : 0.f);
 }
 
+// guard words (all optional): the step is SKIPPED -- parameters and moments untouched, *skipped += 1 -- when
+// *skip_flag != 0 (a GRU hand-off timed out: the gradients are garbage), when *loss_check is not finite, or when the
+// gradient norm is not finite.  gsumsq (sum of squares of g BEFORE grad_scale) with max_norm > 0 applies
+// torch.nn.utils.clip_grad_norm_'s coefficient min(1, max_norm / (norm + 1e-6)) on top of grad_scale.
 __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2,
-                            float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+                            float eps, float wd, float bc1, float bc2_sqrt, float gscale, float max_norm,
+                            const double* gsumsq, const unsigned* skip_flag, const double* loss_check,
+                            unsigned* skipped) {
+    bool skip = false;
+    if (skip_flag && *skip_flag != 0u) skip = true;
+    if (loss_check && !isfinite(*loss_check)) skip = true;
+    if (gsumsq) {
+        const double norm = sqrt(*gsumsq) * (double)gscale;
+        if (!isfinite(norm)) skip = true;
+        else if (max_norm > 0.f) {
+            const double coef = (double)max_norm / (norm + 1e-6);
+            if (coef < 1.0) gscale = (float)((double)gscale * coef);
+        }
+    }
+    if (skip) {
+        if (skipped && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skipped, 1u);
+        return;
+    }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float gi = g[i] * gscale;
         const float pi = p[i];
@@ -557,6 +578,28 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long l
         m[i] = mi; v[i] = vi;
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
         p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
+// sum of squares of a flat f32 buffer in f64 (the total gradient norm of clip_grad_norm_): float4 streams,
+// one same-address f64 atomic per 1024-thread block
+__global__ __launch_bounds__(1024) void sumsq_kernel(const float* x, long long n, double* out) {
+    __shared__ double part[16];
+    double acc = 0.0;
+    const long long n4 = n >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 a = x4[i];
+        acc += (double)(a.x * a.x + a.y * a.y) + (double)(a.z * a.z + a.w * a.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float a = x[(n4 << 2) + threadIdx.x]; acc += (double)a * a; }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        double t = threadIdx.x < (blockDim.x >> 6) ? part[threadIdx.x] : 0.0;
+        t = wave_sum_d(t);
+        if (threadIdx.x == 0) atomicAdd(out, t);
     }
 }
 
@@ -695,14 +738,34 @@ extern "C" int cruse_axpby(float* out, const float* x, const float* y, float a, 
     return CRUSE_OK;
 }
 
-extern "C" int cruse_adam_step(float* p, const float* g, float* m, float* v, long long n,
-                               float lr, float beta1, float beta2, float eps, float weight_decay,
-                               int step, float grad_scale, void* stream) {
+extern "C" int cruse_adam_step_guarded(float* p, const float* g, float* m, float* v, long long n,
+                                       float lr, float beta1, float beta2, float eps, float weight_decay,
+                                       int step, float grad_scale, float max_norm, const double* gsumsq,
+                                       const unsigned* skip_flag, const double* loss_check, unsigned* skipped,
+                                       void* stream) {
     CRUSE_REQUIRE(n > 0 && step >= 1, CRUSE_E_SHAPE, "adam_step: n=%lld step=%d", n, step);
+    CRUSE_REQUIRE(max_norm <= 0.f || gsumsq != nullptr, CRUSE_E_SHAPE, "adam_step: max_norm needs the gradient sum of squares");
     const double bc1 = 1.0 - pow((double)beta1, step);
     const double bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, ST(stream), p, g, m, v, n, lr, beta1, beta2,
-                       eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+                       eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale, max_norm, gsumsq, skip_flag,
+                       loss_check, skipped);
     CRUSE_LAUNCH_CHECK("adam_step");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_adam_step(float* p, const float* g, float* m, float* v, long long n,
+                               float lr, float beta1, float beta2, float eps, float weight_decay,
+                               int step, float grad_scale, void* stream) {
+    return cruse_adam_step_guarded(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, 0.f, nullptr,
+                                   nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int cruse_sumsq(const float* x, long long n, double* out, int accumulate, void* stream) {
+    CRUSE_REQUIRE(n > 0, CRUSE_E_SHAPE, "sumsq: n=%lld", n);
+    CRUSE_REQUIRE(((uintptr_t)x & 15) == 0, CRUSE_E_ALIGN, "sumsq: x must be 16-byte aligned");
+    if (!accumulate) { int zrc = cruse_zero_async(out, sizeof(double), ST(stream), "sumsq memset"); if (zrc) return zrc; }
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 4096 * 4, 256)), dim3(1024), 0, ST(stream), x, n, out);
+    CRUSE_LAUNCH_CHECK("sumsq");
     return CRUSE_OK;
 }

@@ -115,6 +115,7 @@ class TrainEngine:
             _, _, cmag = ops.stft(clean, self.n_fft, self.hop, want_ri=False, mag_bins=self.f_stft, mag_eps=0.0)
         mask, ctx = unet2_forward(mag.view(B, 1, T, self.f_net), self.flat.P, self.Bf, self.model.ch,
                                   self.model.rnn_groups, self.prec, training=True)
+        self._last_mask = mask
         if self.loss == "wo_male":
             loss_sum, _, dlogit, _, _ = ops.mask_loss(mask, nre, nim, cmag, B * T, self.f_net, self.f_stft,
                                                       self.loss_alpha, self.loss_beta, want_dlogit=True)

@@ -151,7 +151,9 @@ def ggru_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], prefix: str, group
         # The forward projection corrects the bf16 rounding of W_ih (a second pass with its low plane): that rounding
         # dominates the forward error of the bf16 mode (enhanced spectrum 1.25e-3 -> 5.1e-4 rel-L2 on fixture G6;
         # correcting x too only reaches 4.8e-4).  CRUSE_GI_X3: bit 0 / 1 = layer 1 / 2 corrected, bit 2 = also split x.
-        knob = int(os.environ.get("CRUSE_GI_X3", "3"))
+        # Default: W_ih split on both layers; x split as well when Hg <= 320 (K is then short enough that the third pass
+        # costs < 0.04 ms per step, and the grouped configurations need it for the 1e-3 bar at T = 401: DESIGN.md section 2)
+        knob = int(os.environ.get("CRUSE_GI_X3", "7" if Hg <= 320 else "3"))
         x3 = (knob >> (0 if lname == "gru_list1" else 1)) & 1
         split_x = bool(knob & 4) and x3
         pad = 64 if Hg % 64 else 0

@@ -115,7 +115,12 @@ _wgrad_ws = {}
 def _ws(key, nbytes: int, device) -> torch.Tensor:
     buf = _wgrad_ws.get((key, device))
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        old = buf
+        # zero-filled: the GRU workspace starts with a STICKY 256-byte header (hand-off status word) that the library
+        # never clears (include/cruse_hip.h, cruse_gru_seq_fwd); a grown buffer inherits the old header
+        buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        if old is not None and key == "gru":
+            buf[:256].copy_(old[:256])
         _wgrad_ws[(key, device)] = buf
     return buf
 
@@ -333,12 +338,34 @@ def gru_gate_grads_bf16(dh, coef, an, rows, G, Hg, db_ih, db_hh):
 
 
 def gru_status() -> int:
-    """0 if no recurrence hand-off ever timed out (synchronises)."""
+    """0 if no recurrence hand-off EVER timed out on any device of this process (synchronises).  The status word is
+    sticky: neither the library nor later launches clear it (gru_status_reset does)."""
     bad = 0
     for (key, _dev), buf in _wgrad_ws.items():
         if key == "gru":
             bad |= int(buf[:4].view(torch.int32).item())
     return bad
+
+
+def gru_status_word(device, B: int, G: int, Hg: int) -> torch.Tensor:
+    """The device status word itself (uint8[4] view) -- handed to adam_step as skip_flag so that a step whose
+    recurrence timed out never reaches the parameters.  Allocates the workspace for this shape if needed."""
+    return _ws("gru", lib.cruse_gru_ws_bytes(B, G, Hg), torch.device(device))[:4]
+
+
+def gru_status_reset() -> None:
+    for (key, _dev), buf in _wgrad_ws.items():
+        if key == "gru":
+            buf[:256].zero_()
+
+
+def check_gru_status() -> None:
+    """Raise (CRUSE_E_TIMEOUT) if a recurrence hand-off timed out since the last reset: the outputs of that launch
+    were garbage.  Call once per epoch / before a checkpoint (synchronises)."""
+    if gru_status() != 0:
+        raise RuntimeError("cruse_hip error -5 (CRUSE_E_TIMEOUT): a GRU hand-off timed out -- the persistent recurrence "
+                           "kernel's workgroups were not co-resident (another process or kernel holding CUs?); the "
+                           "affected optimizer steps were skipped")
 
 
 # ---------------------------------------------------------------- mask + loss, misc
@@ -425,6 +452,17 @@ def axpby(out, x, y, a, b):
     return out
 
 
-def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
-    check(lib.cruse_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
-                              grad_scale, _stream()))
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, max_norm=0.0, gsumsq=None,
+              skip_flag=None, loss_check=None, skipped=None):
+    """Fused Adam over flat buffers; the optional device-side guards are described at cruse_adam_step_guarded."""
+    check(lib.cruse_adam_step_guarded(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
+                                      grad_scale, max_norm, _p(gsumsq), _p(skip_flag), _p(loss_check), _p(skipped),
+                                      _stream()))
+
+
+def sumsq(x, out=None, accumulate=False):
+    """sum of squares (f64[1]) of a flat f32 tensor: the squared total gradient norm of clip_grad_norm_."""
+    if out is None:
+        out = torch.empty(1, device=x.device, dtype=torch.float64)
+    check(lib.cruse_sumsq(_p(x), x.numel(), _p(out), 1 if accumulate else 0, _stream()))
+    return out

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CRUSE_ABI_VERSION 1
+#define CRUSE_ABI_VERSION 2
 
 enum {
     CRUSE_OK = 0,
@@ -192,8 +192,11 @@ int cruse_transpose_bf16(const float* x, long long rows, int cols, long long ld,
  *   coef [B,T,G,3*Hg] = d(W_hh h + b_hh)-gradient coefficients (c_r, c_z, c_n): dgh_t = dh_t * coef_t
  *                       (bf16 elements when prec == CRUSE_PREC_BF16, f32 otherwise),
  *   an   [B,T,G*Hg]   = dgi_n coefficient ((1-z)(1-n^2)),   z [B,T,G*Hg] = update gate.
- * Hg % 32 == 0, Hg <= 1024.  ws: cruse_gru_ws_bytes() bytes of device scratch (status word +
- * hand-off panels; zeroed by the callee; word 0 becomes non-zero if a hand-off ever timed out). */
+ * Hg % 32 == 0, Hg <= 1024.  ws: cruse_gru_ws_bytes() bytes of device scratch.  Its first 256 bytes are a STICKY
+ * header the CALLER zeroes once when it allocates the buffer: word 0 becomes non-zero if a hand-off ever timed out
+ * (the launch then completes unsynchronised and its outputs are garbage) and is never cleared by the library, so it
+ * can be polled once per epoch and handed to cruse_adam_step_guarded as skip_flag.  The hand-off panels behind the
+ * header are zeroed by the callee on every call. */
 size_t cruse_gru_ws_bytes(int B, int G, int Hg);
 int cruse_gru_seq_fwd(const float* gi, const float* const* w_hh, const float* const* b_hh,
                       float* h, void* coef, float* an, float* z,
@@ -273,6 +276,21 @@ int cruse_axpby(float* out, const float* x, const float* y, float a, float b, lo
 int cruse_adam_step(float* p, const float* g, float* m, float* v, long long n,
                     float lr, float beta1, float beta2, float eps, float weight_decay,
                     int step, float grad_scale, void* stream);
+/* The same step behind device-side guards, so that one bad batch cannot poison the parameters and no host
+ * synchronisation is needed to decide (all pointers optional):
+ *   skip_flag  : *skip_flag != 0 skips the step (the sticky GRU hand-off status word, see cruse_gru_seq_fwd);
+ *   loss_check : a non-finite *loss_check skips the step (the reference has no such check: a 0/0 bin in wo_male,
+ *                loss_func/loss.py:141, would turn every parameter into NaN);
+ *   gsumsq     : sum of squares of g (cruse_sumsq); a non-finite norm skips the step; with max_norm > 0 the gradient is
+ *                scaled by min(1, max_norm / (sqrt(gsumsq)*grad_scale + 1e-6)) = torch.nn.utils.clip_grad_norm_
+ *                (train_base/trainer/base_trainer.py:75 `clip_grad_norm_value`);
+ *   skipped    : += 1 for every skipped step. */
+int cruse_adam_step_guarded(float* p, const float* g, float* m, float* v, long long n,
+                            float lr, float beta1, float beta2, float eps, float weight_decay,
+                            int step, float grad_scale, float max_norm, const double* gsumsq,
+                            const unsigned* skip_flag, const double* loss_check, unsigned* skipped, void* stream);
+/* out (+)= sum x[i]^2 in f64 (total gradient norm for clip_grad_norm_); x 16-byte aligned */
+int cruse_sumsq(const float* x, long long n, double* out, int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,8 @@ def test_library_exports_every_header_symbol():
         assert SIGNATURES[name] == sig, f"{name}: ctypes signature {SIGNATURES[name]} != header {sig}"
     assert set(SIGNATURES) == set(hdr)
     lib.cruse_abi_version.restype = ctypes.c_int
-    assert lib.cruse_abi_version() == 1
+    from cruse_amd._lib import ABI_VERSION
+    assert lib.cruse_abi_version() == ABI_VERSION == 2
 
 
 def test_error_channel_without_gpu():
