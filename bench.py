@@ -40,8 +40,8 @@ def log(msg):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--groups", type=int, default=1)
@@ -49,7 +49,52 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the T=401 oracle parity figure (parity_rel_l2)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the f32 gate-mode and hop=320 STFT rows")
+    ap.add_argument("--bucketed", action="store_true", help="force the segmented (multi-GPU) schedule at world 1")
     return ap.parse_args()
+
+
+# algorithmic work per frame of the training step (F = 160 geometry)
+F_ALG_MFLOP = {1: 32.84, 4: 10.73}            # MFLOP / frame, training = 3 x forward
+B_ALG_ELEMS = 16640                           # retained elements / frame; B_alg = 1280 + 2 * 16640 * s bytes
+
+
+def parity_figure(model, groups: int, prec: str, B: int = 8, T: int = 401):
+    """Enhanced-spectrum rel-L2 of THIS model (its weights, its precision mode) vs the CPU oracle at the bench's
+    sequence length.  The oracle is the checker here, never the thing measured."""
+    from cruse_amd import ops
+    from cruse_amd.model.cruse_net import unet2_forward
+    from oracle import cruse_oracle as O
+    o = O.unet_2(rnn_groups=groups)
+    o.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    o.train()
+    noisy, _ = O.synth_pair(B, (T - 1) * 160, seed=11)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    with torch.no_grad():
+        _, est_o, _ = O.enhanced_spectrum(o, noisy)
+    P = dict(model.named_parameters()); P = {k: v.data for k, v in P.items()}
+    Bf = {k: v.clone() for k, v in model.named_buffers()}
+    nre, nim, mag = ops.stft(noisy.cuda(), 320, 160, mag_bins=160, mag_eps=1e-8)
+    mask, _ = unet2_forward(mag.view(B, 1, T, 160), P, Bf, model.ch, groups, prec, training=True, save=False,
+                            update_running=False)
+    er, ei = ops.mask_apply(mask.contiguous().view(B * T, 160), nre, nim, B * T, 160, 161)
+    est = torch.stack([er.view(B, T, 161), ei.view(B, T, 161)], dim=-1).double().cpu()
+    return float((est - est_o.double()).norm() / est_o.double().norm())
+
+
+def profile_avg_ns(kernel_substr: str):
+    """average in-graph duration of a kernel from the newest committed rocprofv3 kernel-stats CSV (profiles/)."""
+    import csv, glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_kernel_stats*.csv")))
+    for f in reversed(files):
+        if "r02" not in os.path.basename(f):
+            continue
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if kernel_substr in r["Name"]:
+                    return float(r["AverageNs"]), os.path.basename(f)
+    return None, None
 
 
 def cpu_baseline(groups: int, budget_s: float = 15.0):
@@ -140,7 +185,18 @@ class KernelTimer:
         return tot, cnt
 
 
-PMC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.csv")
+def _pmc_file():
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    for name in ("r02_pmc_hbm_traffic.csv", "r01_pmc_hbm_traffic.csv"):
+        if os.path.exists(os.path.join(d, name)):
+            return os.path.join(d, name)
+    return os.path.join(d, "r02_pmc_hbm_traffic.csv")
+
+
+PMC_FILE = _pmc_file()
+
+
+PMC_STEPS = 4            # the PMC passes ran `bench.py --steps 3 --warmup 1`: launch counts in the CSV are per 4 steps
 
 
 def pmc_traffic():
@@ -161,6 +217,7 @@ def pmc_traffic():
             a[0] += n; a[1] += n * b
     for fam, (n, tot) in acc.items():
         out[fam] = tot / max(n, 1)
+    out["__step_total__"] = sum(tot for _, tot in acc.values()) / float(PMC_STEPS)
     out["conv_gather"] = out["conv_scatter2"] = out.get("conv", 0.0) or None
     return out
 
@@ -204,6 +261,77 @@ def kernel_rooflines(B, T, H, G, prec, per_step_ms, calls):
     return out
 
 
+def step_roofline(fps: float, groups: int, prec: str, B: int, T: int):
+    """BASELINE.md section 4 / SURVEY 8(d): whole-step achieved fraction, both terms."""
+    f_alg = F_ALG_MFLOP.get(groups)
+    out = {}
+    if f_alg:
+        tf = fps * f_alg * 1e6 / 1e12
+        out["mfma"] = {"achieved": round(tf, 2), "peak": PEAK_MFMA_TFLOPS[prec], "unit": "TFLOP/s",
+                       "frac": round(tf / PEAK_MFMA_TFLOPS[prec], 5), "F_alg_MFLOP_per_frame": f_alg}
+    for name, sz in (("hbm_f32_storage", 4), ("hbm_bf16_storage", 2)):
+        b_alg = 1280 + 2 * B_ALG_ELEMS * sz
+        gbs = fps * b_alg / 1e9
+        out[name] = {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 5),
+                     "B_alg_bytes_per_frame": b_alg}
+    out["achieved"] = max(v["frac"] for v in out.values())
+    pmc = pmc_traffic()
+    if pmc.get("__step_total__") and (B, T, groups, prec) == (64, 401, 1, "bf16"):
+        tot = pmc["__step_total__"]
+        b_alg = (1280 + 2 * B_ALG_ELEMS * 4) * B * T
+        out["pmc_hbm_bytes_per_step"] = round(tot)
+        out["pmc_vs_B_alg_f32"] = round(tot / b_alg, 2)
+        out["pmc_source"] = "profiles/" + os.path.basename(PMC_FILE)
+    return out
+
+
+def secondary_rows(a, dev, pool):
+    """Not the headline: (1) the same step in the parity-GATE mode (exact-f32 MFMA), (2) the literal reading of
+    BASELINE.json's "20ms-hop": a forward STFT at hop = 320 (T = 201; hop = win violates NOLA, so no iSTFT / training
+    step exists for it -- SURVEY 8d)."""
+    from cruse_amd import ops
+    from cruse_amd.engine import TrainEngine
+    from cruse_amd.model.cruse_net import unet_2
+    out = {}
+    try:
+        torch.manual_seed(0)
+        m = unet_2(rnn_groups=a.groups, precision="f32").to(dev)
+        e = TrainEngine(m, lr=1e-3, use_graph=not a.no_graph)
+        for s in range(3):
+            e.step(*pool[s % len(pool)])
+        torch.cuda.synchronize()
+        n = 10
+        t0 = time.perf_counter()
+        for s in range(n):
+            e.step(*pool[s % len(pool)])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        B, L = pool[0][0].shape
+        out["f32_gate_mode"] = {"value": round(B * (1 + L // 160) / dt, 1), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3),
+                                "steps": n, "dtype": "f32", "note": "same step, v_mfma_f32_16x16x4_f32 everywhere (parity <= 1e-6)"}
+        del e, m
+    except Exception as ex:                                  # secondary rows never break the headline line
+        out["f32_gate_mode"] = {"error": repr(ex)[:200]}
+    try:
+        x = pool[0][0]
+        B, L = x.shape
+        ops.stft(x, 320, 320, mag_bins=160, mag_eps=1e-8); torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            ops.stft(x, 320, 320, mag_bins=160, mag_eps=1e-8)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        T2 = 1 + L // 320
+        byts = B * (L * 4 + T2 * (161 * 8 + 160 * 4))
+        out["stft_hop320_forward"] = {"value": round(B * T2 / (ms * 1e-3), 1), "unit": "frames/s", "frames_per_clip": T2,
+                                      "ms": round(ms, 4), "hbm_GBs": round(byts / (ms * 1e-3) / 1e9, 1),
+                                      "note": "forward STFT only, hop = win = 320 (20 ms hop)"}
+    except Exception as ex:
+        out["stft_hop320_forward"] = {"error": repr(ex)[:200]}
+    return out
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -231,7 +359,12 @@ def main():
 
     torch.manual_seed(0)
     model = unet_2(rnn_groups=a.groups, precision=a.prec).to(dev)
-    eng = TrainEngine(model, lr=1e-3, use_graph=not a.no_graph)
+    parity = None
+    if rank == 0 and not a.no_parity:
+        log("parity figure: this model vs the CPU oracle at T=401, B=8 ...")
+        parity = parity_figure(model, a.groups, a.prec)
+        log(f"parity_rel_l2 = {parity:.3e}")
+    eng = TrainEngine(model, lr=1e-3, use_graph=not a.no_graph, bucketed=True if a.bucketed else None)
     B, L = a.batch, int(a.seconds * 16000)
     T = 1 + L // 160
     pool = [synth_batch(B, L, dev, 1234 + 1000 * rank + s) for s in range(4)]
@@ -246,18 +379,23 @@ def main():
         eng.step(*pool[s % len(pool)])
     sync()
     log("timed region ...")
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for s in range(a.steps):
         ls = eng.step(*pool[s % len(pool)])
+        marks[s + 1].record()                 # on the compute stream, after this step's Adam
     sync()
     el = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+    med_ms = step_ms[len(step_ms) // 2]
     if world > 1:
         tmax = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         el = float(tmax.item())
     loss = eng.loss_value(ls)
     status = ops.gru_status()
-    log(f"timed region done: {el / a.steps * 1e3:.2f} ms/step")
+    log(f"timed region done: {el / a.steps * 1e3:.2f} ms/step (median step {med_ms:.2f} ms)")
 
     roof, breakdown = None, None
     if rank == 0 and not a.no_kernel_timing:
@@ -282,7 +420,21 @@ def main():
                                  "frac": None, "traffic": None}))
         roof["kernel"] = dom
         roof["ms_per_step_all_launches"] = round(per_step[dom], 3)
+        # the same fraction from the committed rocprofv3 trace of the GRAPH run (the kernel beside its side-stream
+        # co-runners), next to the isolated HIP-event figure above
+        kname = {"gru_seq_bwd": "gru_bwd_rs_kernel", "gru_seq_fwd": "gru_fwd_lean_kernel"}.get(dom)
+        if kname and roof.get("avg_launch_ms") and (B, a.seconds, a.groups, a.prec) == (64, 4.0, 1, "bf16"):
+            ns, src = profile_avg_ns(kname)
+            if ns:
+                roof["frac_isolated"] = roof["frac"]
+                roof["avg_launch_ms_in_graph"] = round(ns * 1e-6, 4)
+                roof["frac_in_graph"] = round(roof["frac"] * roof["avg_launch_ms"] / (ns * 1e-6), 5)
+                roof["in_graph_source"] = "profiles/" + src
         roof["others"] = {k: v for k, v in rl.items() if k != dom}
+
+    secondary = None
+    if rank == 0 and world == 1 and not a.no_secondary:
+        secondary = secondary_rows(a, dev, pool)
 
     if rank == 0:
         frames = world * B * T * a.steps
@@ -297,8 +449,13 @@ def main():
                                    f"{a.prec} MFMA operands, f32 accumulate/statistics",
                        "global_batch": world * B, "per_gpu_batch": B, "frames_per_clip": T,
                        "parallelism": f"dp{world}", "hip_graph": not a.no_graph},
-            "final_loss": round(loss, 6), "gru_handoff_timeouts": status,
-            "roofline": roof, "kernel_ms_per_step": breakdown, "cpu_baseline": cpu,
+            "ms_per_step_median": round(med_ms, 3),
+            "value_at_median_step": round(world * B * T / (med_ms * 1e-3), 1),
+            "parity_rel_l2": None if parity is None else float(f"{parity:.4g}"),
+            "parity_note": "enhanced-spectrum rel-L2 of this model/mode vs the CPU oracle at T=401, B=8 (bar 1e-3)",
+            "final_loss": round(loss, 6), "gru_handoff_timeouts": status, "skipped_steps": eng.skipped_steps(),
+            "roofline": roof, "roofline_step": step_roofline(frames / el, a.groups, a.prec, B, T),
+            "kernel_ms_per_step": breakdown, "cpu_baseline": cpu, "secondary": secondary,
         }
         print(json.dumps(out))
     if world > 1:

@@ -65,6 +65,9 @@ SIGNATURES = {
     "cruse_adam_step": ("ppppqfffffifp", "i"),
     "cruse_adam_step_guarded": ("ppppqfffffiffppppp", "i"),
     "cruse_sumsq": ("pqpip", "i"),
+    "cruse_zero": ("pzp", "i"),
+    "cruse_accum_f64": ("ppip", "i"),
+    "cruse_counters_add": ("piqp", "i"),
 }
 
 

@@ -546,6 +546,17 @@ __global__ void axpby_kernel(float* out, const float* x, const float* y, float a
         out[i] = a * x[i] + (y ? b * y[i] : 0.f);
 }
 
+// host bookkeeping that must not leave the stream: f64 accumulation of per-step loss sums, BatchNorm batch counters
+__global__ void accum_f64_kernel(double* acc, const double* x, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) acc[i] += x[i];
+}
+struct CounterPtrs { long long* p[32]; };
+__global__ void counters_add_kernel(CounterPtrs c, int n, long long v) {
+    const int i = threadIdx.x;
+    if (i < n) *c.p[i] += v;
+}
+
 // guard words (all optional): the step is SKIPPED -- parameters and moments untouched, *skipped += 1 -- when
 // *skip_flag != 0 (a GRU hand-off timed out: the gradients are garbage), when *loss_check is not finite, or when the
 // gradient norm is not finite.  gsumsq (sum of squares of g BEFORE grad_scale) with max_norm > 0 applies
@@ -736,6 +747,27 @@ extern "C" int cruse_axpby(float* out, const float* x, const float* y, float a, 
     hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, ST(stream), out, x, y, a, b, n);
     CRUSE_LAUNCH_CHECK("axpby");
     return CRUSE_OK;
+}
+
+extern "C" int cruse_accum_f64(double* acc, const double* x, int n, void* stream) {
+    CRUSE_REQUIRE(n > 0, CRUSE_E_SHAPE, "accum_f64: n=%d", n);
+    hipLaunchKernelGGL(accum_f64_kernel, dim3(cdiv(n, 64)), dim3(64), 0, ST(stream), acc, x, n);
+    CRUSE_LAUNCH_CHECK("accum_f64");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_counters_add(long long* const* counters, int n, long long v, void* stream) {
+    CRUSE_REQUIRE(n > 0 && n <= 32, CRUSE_E_SHAPE, "counters_add: n=%d (1..32)", n);
+    CounterPtrs c = {};
+    for (int i = 0; i < n; ++i) c.p[i] = counters[i];
+    hipLaunchKernelGGL(counters_add_kernel, dim3(1), dim3(64), 0, ST(stream), c, n, v);
+    CRUSE_LAUNCH_CHECK("counters_add");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_zero(void* p, size_t bytes, void* stream) {
+    CRUSE_REQUIRE(bytes % 4 == 0, CRUSE_E_SHAPE, "zero: %zu bytes is not a multiple of 4", bytes);
+    return cruse_zero_async(p, bytes, ST(stream), "zero");
 }
 
 extern "C" int cruse_adam_step_guarded(float* p, const float* g, float* m, float* v, long long n,

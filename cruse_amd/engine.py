@@ -1,24 +1,37 @@
 """The training step the reference never wrote (train/trainer_casual.py is empty):
 
-    STFT(noisy), STFT(clean) -> unet_2 -> mask * spectrum -> WO-MALE -> backward
-    -> gradient all-reduce (RCCL) -> Adam
+    STFT(noisy), STFT(clean) -> unet_2 -> mask * spectrum -> loss -> backward
+    -> bucketed gradient all-reduce (RCCL, overlapped with backward) -> clip -> Adam
 
 run on one MI355X per process.  Parameters, gradients and Adam moments live in flat,
-64-float-aligned buffers (one all-reduce, one fused Adam launch); the forward+backward
-kernel sequence is recorded once into a HIP graph and replayed.
+64-float-aligned buffers ordered by GRADIENT BUCKET (the order the backward pass finishes them), so a bucket is
+one contiguous slice = one collective; the kernel sequence is recorded once into HIP graphs and replayed.
+
+Data-parallel schedule (world > 1; SURVEY 8e, base_trainer.py:31 is DDP's bucketed overlap):
+
+    graph 0: STFTs, forward, loss, decoder backward, GGRU backward        -> all-reduce(bucket 0) on RCCL's stream
+    graph 1: layer-1 GRU dW GEMMs (side stream) | encoder levels L..L/2+1 -> all-reduce(bucket 1)
+    graph 2: encoder levels L/2..1                                          -> all-reduce(bucket 2)
+    wait for the three collectives -> [gradient norm] -> fused Adam (1/world folded in)
+
+so the 10 MB of bucket 0 travel while graph 1 runs and the 10 MB of bucket 1 while graph 2 runs; only the encoder's
+130 kB are exposed.  With world == 1 the whole step is one graph (no boundaries).
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Tuple
+import os
+from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
 import torch.nn as nn
 
 from . import ops
-from .model.cruse_net import unet2_backward, unet2_forward, unet_2
+from .model.cruse_net import N_BUCKETS, SIDE, bucket_of, unet2_backward, unet2_forward, unet_2
 
 ALIGN = 64  # floats
+
+LOSSES = ("wo_male", "si_snr", "sdnr")
 
 
 def unused_parameter(name: str) -> bool:
@@ -26,19 +39,39 @@ def unused_parameter(name: str) -> bool:
     return name.startswith("fc.") or name.startswith("bn1_t.")
 
 
+def _dist_on() -> bool:
+    """a process group with peers -- or CRUSE_FORCE_COLLECTIVES=1, which makes a world of ONE issue its collectives
+    anyway (the RCCL code path of the bucketed step can then be exercised on a single-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("CRUSE_FORCE_COLLECTIVES") == "1"
+
+
 class FlatParams:
-    """Views of a model's trainable parameters inside one contiguous buffer (plus grads / Adam state).
+    """Views of a model's trainable parameters inside one contiguous buffer (plus grads / Adam state), laid out
+    bucket by bucket (`bucket(name)` -> int; buckets are contiguous, 64-float aligned slices).
 
-    Works on any device (the CPU/gloo tests exercise the layout and the all-reduce)."""
+    Works on any device (the CPU/gloo tests exercise the layout and the collectives)."""
 
-    def __init__(self, model: nn.Module, skip=unused_parameter):
+    def __init__(self, model: nn.Module, skip=unused_parameter, bucket: Callable[[str], int] = bucket_of,
+                 n_buckets: int = N_BUCKETS):
         named = [(n, p) for n, p in model.named_parameters() if not skip(n)]
+        self.order = [n for n, _ in model.named_parameters()]            # torch.optim parameter indices
+        self.shapes = {n: tuple(p.shape) for n, p in model.named_parameters()}
+        self.bucket_id = {n: int(bucket(n)) for n, _ in named}
+        assert all(0 <= b < n_buckets for b in self.bucket_id.values())
+        named.sort(key=lambda np_: self.bucket_id[np_[0]])                # stable: state-dict order inside a bucket
         self.names = [n for n, _ in named]
         self.offsets: Dict[str, int] = {}
+        self.bucket_range: List[Tuple[int, int]] = []
         off = 0
-        for n, p in named:
-            self.offsets[n] = off
-            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        for b in range(n_buckets):
+            start = off
+            for n, p in named:
+                if self.bucket_id[n] == b:
+                    self.offsets[n] = off
+                    off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+            self.bucket_range.append((start, off))
         self.total = off
         dev = named[0][1].device
         self.params = torch.zeros(off, device=dev, dtype=torch.float32)
@@ -60,15 +93,36 @@ class FlatParams:
             if n not in self.P:
                 self.P[n] = p.data
 
+    def view(self, flat: torch.Tensor, name: str) -> torch.Tensor:
+        o = self.offsets[name]
+        shape = self.shapes[name]
+        k = 1
+        for d in shape:
+            k *= d
+        return flat[o:o + k].view(shape)
+
     def broadcast(self, src: int = 0) -> None:
         """identical initial weights on all ranks (cf. loss_func/distrib.py:57-72)."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if _dist_on():
             dist.broadcast(self.params, src)
 
+    def bucket_grads(self, b: int) -> torch.Tensor:
+        s, e = self.bucket_range[b]
+        return self.grads[s:e]
+
+    def all_reduce_bucket(self, b: int, async_op: bool = True):
+        """SUM over ranks of one bucket; the 1/world_size factor is folded into the Adam kernel.  Returns the Work
+        handle (None outside a process group or for an empty bucket)."""
+        s, e = self.bucket_range[b]
+        if not _dist_on() or e == s:
+            return None
+        return dist.all_reduce(self.grads[s:e], op=dist.ReduceOp.SUM, async_op=async_op)
+
     def all_reduce_grads(self) -> None:
-        """sum over ranks; the 1/world_size factor is folded into the Adam kernel."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM)
+        """all buckets, blocking (tests / un-bucketed callers)."""
+        for w in [self.all_reduce_bucket(b) for b in range(len(self.bucket_range))]:
+            if w is not None:
+                w.wait()
 
     def attach_grads(self, model: nn.Module) -> None:
         """expose the flat gradients as param.grad (checkpoint / clip_grad_norm_ compatibility)."""
@@ -76,11 +130,53 @@ class FlatParams:
             if n in self.G:
                 p.grad = self.G[n]
 
+    # ---- torch.optim.Adam.state_dict() layout (base_trainer.py:199-221 saves optimizer.state_dict()) -------------
+    def adam_state_dict(self, step: int, lr, betas, eps, weight_decay) -> dict:
+        state = {}
+        for idx, n in enumerate(self.order):
+            if n in self.offsets and step > 0:                 # torch creates state only for parameters that got a gradient
+                state[idx] = {"step": torch.tensor(float(step)),
+                              "exp_avg": self.view(self.exp_avg, n).detach().cpu().clone(),
+                              "exp_avg_sq": self.view(self.exp_avg_sq, n).detach().cpu().clone()}
+        group = {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": weight_decay, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": False, "params": list(range(len(self.order)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_adam_state_dict(self, sd: dict) -> int:
+        """-> step count.  Accepts what torch.optim.Adam(model.parameters()).state_dict() holds (sizes validated)."""
+        groups = sd["param_groups"]
+        ids = [i for g in groups for i in g["params"]]
+        if len(ids) != len(self.order):
+            raise RuntimeError(f"optimizer state has {len(ids)} parameters, the model has {len(self.order)}")
+        step = 0
+        self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+        for pos, pid in enumerate(ids):
+            st = sd["state"].get(pid)
+            if st is None:
+                continue
+            n = self.order[pos]
+            if n not in self.offsets:
+                continue                                        # fc / bn1_t: never trained here
+            for key, flat in (("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
+                t = st[key]
+                if tuple(t.shape) != self.shapes[n]:
+                    raise RuntimeError(f"optimizer state {key} of {n}: shape {tuple(t.shape)} != {self.shapes[n]}")
+                self.view(flat, n).copy_(t)
+            step = max(step, int(float(st["step"])))
+        return step
+
 
 class TrainEngine:
+    """loss: "wo_male" (loss_func/loss.py:121-148, alpha/beta), "si_snr" (train_base/loss.py:7-25 through the iSTFT)
+    or "sdnr" (loss_func/loss.py:151-175 with the mask as gain; `snr_db`, `sdnr_beta_db`).
+    clip_grad_norm > 0: torch.nn.utils.clip_grad_norm_ semantics on the (averaged) gradient, folded into Adam.
+    bucketed: None = when world > 1; True forces the segmented schedule (tests, single-GPU cost measurements)."""
+
     def __init__(self, model: unet_2, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
                  n_fft=320, hop=160, precision: Optional[str] = None, use_graph: bool = True,
-                 loss_alpha=2.0, loss_beta=1.0, loss: str = "wo_male"):
+                 loss_alpha=2.0, loss_beta=1.0, loss: str = "wo_male", clip_grad_norm: float = 0.0,
+                 snr_db: float = 0.0, sdnr_beta_db: float = 20.0, bucketed: Optional[bool] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("cruse_amd.TrainEngine needs a HIP device (there is no CPU path)")
         self.model = model
@@ -92,47 +188,84 @@ class TrainEngine:
         self.prec = model.precision
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.loss_alpha, self.loss_beta = loss_alpha, loss_beta
-        if loss not in ("wo_male", "si_snr"):
-            raise ValueError(f"unknown loss {loss!r} (wo_male | si_snr)")
+        self.snr_db, self.sdnr_beta_db = snr_db, sdnr_beta_db
+        if loss not in LOSSES:
+            raise ValueError(f"unknown loss {loss!r} ({' | '.join(LOSSES)})")
         self.loss = loss
+        self.clip = float(clip_grad_norm or 0.0)
         self.flat = FlatParams(model)
         self.flat.broadcast(0)
         self.Bf = dict(model.named_buffers())
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.bucketed = (self.world > 1) if bucketed is None else bool(bucketed)
         self.step_count = 0
         self.use_graph = use_graph
-        self._graph = None
+        self._graphs = None
         self._static = None
         self._shape = None
+        dev = self.flat.params.device
+        self._gsumsq = torch.zeros(1, device=dev, dtype=torch.float64)
+        self._skipped = torch.zeros(1, device=dev, dtype=torch.int32)
+        self._loss_acc = torch.zeros(1, device=dev, dtype=torch.float64)
+        self._loss_steps = 0
+        self._norm = 1.0
+        self._works: List = []
 
-    # -- one forward + loss + backward, gradients left in flat.grads --------------------
-    def _fwd_bwd(self, noisy: torch.Tensor, clean: torch.Tensor) -> torch.Tensor:
+    # -- forward + loss (+ dL/dlogit when training) ------------------------------------------------------------------
+    def _forward_loss(self, noisy: torch.Tensor, clean: torch.Tensor, training: bool):
         B, L = noisy.shape
         T = ops.stft_frames(L, self.hop)
         nre, nim, mag = ops.stft(noisy, self.n_fft, self.hop, mag_bins=self.f_net, mag_eps=1e-8)
-        cmag = None
+        cre = cim = cmag = None
         if self.loss == "wo_male":
             _, _, cmag = ops.stft(clean, self.n_fft, self.hop, want_ri=False, mag_bins=self.f_stft, mag_eps=0.0)
+        elif self.loss == "sdnr":
+            cre, cim, _ = ops.stft(clean, self.n_fft, self.hop)
         mask, ctx = unet2_forward(mag.view(B, 1, T, self.f_net), self.flat.P, self.Bf, self.model.ch,
-                                  self.model.rnn_groups, self.prec, training=True)
+                                  self.model.rnn_groups, self.prec, training=training, save=training,
+                                  update_running=training)
         self._last_mask = mask
+        rows = B * T
+        dlogit = None
         if self.loss == "wo_male":
-            loss_sum, _, dlogit, _, _ = ops.mask_loss(mask, nre, nim, cmag, B * T, self.f_net, self.f_stft,
-                                                      self.loss_alpha, self.loss_beta, want_dlogit=True)
-            self._norm = float(B * T * self.f_stft)
+            loss_sum, _, dlogit, _, _ = ops.mask_loss(mask, nre, nim, cmag, rows, self.f_net, self.f_stft,
+                                                      self.loss_alpha, self.loss_beta, want_dlogit=training)
+            self._norm = float(rows * self.f_stft)
+        elif self.loss == "sdnr":
+            loss_sum, _, dlogit = ops.mask_sdnr(mask, cre, cim, nre, nim, rows, self.f_net, self.f_stft, B, self.snr_db,
+                                                self.sdnr_beta_db, want_dlogit=training)
+            self._norm = float(B * self.f_stft)
         else:
             # waveform in -> waveform loss: est = iSTFT(mask * N); SI-SNR(est, clean) and back through both
-            ere, eim = ops.mask_apply(mask, nre, nim, B * T, self.f_net, self.f_stft)
+            ere, eim = ops.mask_apply(mask, nre, nim, rows, self.f_net, self.f_stft)
             est = ops.istft(ere.view(B, T, self.f_stft), eim.view(B, T, self.f_stft), self.n_fft, self.hop, L)
             loss_sum, coef = ops.sisnr_fwd(est, clean)
-            dwave = ops.sisnr_bwd(est, clean, coef)
-            dre, dim = ops.istft_bwd(dwave, T, self.n_fft, self.hop)
-            dlogit = ops.mask_apply_bwd(dre, dim, nre, nim, mask, B * T, self.f_net, self.f_stft)
+            if training:
+                dwave = ops.sisnr_bwd(est, clean, coef)
+                dre, dim = ops.istft_bwd(dwave, T, self.n_fft, self.hop)
+                dlogit = ops.mask_apply_bwd(dre, dim, nre, nim, mask, rows, self.f_net, self.f_stft)
             self._norm = 1.0
-        self.flat.grads.zero_()
-        unet2_backward(ctx, dlogit.view(B, T, 1, self.f_net), self.flat.P, self.flat.G)
+        return loss_sum, dlogit, ctx
+
+    # -- one forward + loss + backward, gradients left in flat.grads --------------------
+    def _fwd_bwd(self, noisy: torch.Tensor, clean: torch.Tensor, boundary=None) -> torch.Tensor:
+        B, L = noisy.shape
+        T = ops.stft_frames(L, self.hop)
+        loss_sum, dlogit, ctx = self._forward_loss(noisy, clean, training=True)
+        ops.zero_(self.flat.grads)
+        unet2_backward(ctx, dlogit.view(B, T, 1, self.f_net), self.flat.P, self.flat.G, boundary=boundary)
         return loss_sum
 
+    @torch.no_grad()
+    def eval_loss(self, noisy: torch.Tensor, clean: torch.Tensor) -> float:
+        """validation: the configured loss with BatchNorm in eval mode (running statistics), no gradients."""
+        norm = self._norm
+        loss_sum, _, _ = self._forward_loss(noisy, clean, training=False)
+        v = float(loss_sum.item()) / self._norm
+        self._norm = norm
+        return v
+
+    # -- graph capture: one graph, or one per segment when the step is bucketed ----------------------------------
     def _capture(self, noisy, clean):
         self._static = (noisy.clone(), clean.clone())
         # the warm-up run below must leave no trace: BatchNorm running statistics and counters are restored
@@ -140,37 +273,121 @@ class TrainEngine:
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):           # warm-up on a side stream (allocations, LDS attributes)
-            self._fwd_bwd(*self._static)
+            self._fwd_bwd(*self._static, boundary=self._warmup_boundary if self.bucketed else None)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         for k, v in saved.items():
             self.Bf[k].copy_(v)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._static_loss = self._fwd_bwd(*self._static)
-        self._graph = g
+        graphs: List[Tuple[torch.cuda.CUDAGraph, int]] = []
+        pool = torch.cuda.graph_pool_handle()
+        cur: Dict[str, object] = {}
+
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            cm = torch.cuda.graph(g, pool=pool)
+            cm.__enter__()
+            cur["g"], cur["cm"] = g, cm
+
+        def end(bucket: int):
+            cur["cm"].__exit__(None, None, None)
+            graphs.append((cur["g"], bucket))
+
+        def boundary(bucket: int):
+            SIDE.join(flush=False)           # every ISSUED leaf joined; queued leaves move to the next segment
+            end(bucket)
+            begin()
+            SIDE.flush()
+
+        begin()
+        try:
+            self._static_loss = self._fwd_bwd(*self._static, boundary=boundary if self.bucketed else None)
+        except BaseException:
+            cur["cm"].__exit__(None, None, None)
+            raise
+        end(N_BUCKETS - 1)
+        self._graphs = graphs
         self._shape = tuple(noisy.shape)
+
+    @staticmethod
+    def _warmup_boundary(bucket: int):
+        SIDE.join(flush=False)
+        SIDE.flush()
+
+    def _plain_boundary(self, bucket: int):
+        SIDE.join(flush=False)
+        self._launch_bucket(bucket)
+        SIDE.flush()
+
+    def _launch_bucket(self, b: int):
+        """Start the all-reduce of every bucket that became final with segment b.  Un-bucketed graphs end with the
+        last bucket id: everything goes at once."""
+        first = b if self.bucketed else 0
+        for i in range(first, b + 1):
+            w = self.flat.all_reduce_bucket(i, async_op=True)
+            if w is not None:
+                self._works.append(w)
 
     def step(self, noisy: torch.Tensor, clean: torch.Tensor) -> torch.Tensor:
         """One optimizer step; returns the (device, f64) loss sum -- divide by .loss_norm for the loss."""
+        self._works = []
         if self.use_graph:
-            if self._graph is None or self._shape != tuple(noisy.shape):
+            if self._graphs is None or self._shape != tuple(noisy.shape):
                 self._capture(noisy, clean)
             self._static[0].copy_(noisy)
             self._static[1].copy_(clean)
-            self._graph.replay()
+            for g, bucket in self._graphs:
+                g.replay()
+                self._launch_bucket(bucket)      # RCCL's stream waits for the replay; the next replay overlaps it
             loss_sum = self._static_loss
         else:
-            loss_sum = self._fwd_bwd(noisy, clean)
-        self.flat.all_reduce_grads()
+            loss_sum = self._fwd_bwd(noisy, clean, boundary=self._plain_boundary if self.bucketed else None)
+            self._launch_bucket(N_BUCKETS - 1)
+        for w in self._works:
+            w.wait()                             # the compute stream waits for the collectives (no host block on RCCL)
         self.step_count += 1
+        gs = None
+        if self.clip > 0.0:
+            gs = ops.sumsq(self.flat.grads, out=self._gsumsq)
+        B = noisy.shape[0]
+        g = self.model.rnn_groups
+        flag = ops.gru_status_word(noisy.device, B, g, self.model.hidden_size // g)
         ops.adam_step(self.flat.params, self.flat.grads, self.flat.exp_avg, self.flat.exp_avg_sq, self.lr,
-                      self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, 1.0 / self.world)
+                      self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, 1.0 / self.world,
+                      max_norm=self.clip, gsumsq=gs, skip_flag=flag, loss_check=loss_sum, skipped=self._skipped)
+        ops.accum_f64(self._loss_acc, loss_sum)
+        self._loss_steps += 1
         return loss_sum
 
+    # -- host-side read-outs (each synchronises) --------------------------------------------------------------------
     @property
     def loss_norm(self) -> float:
         return self._norm
 
     def loss_value(self, loss_sum: torch.Tensor) -> float:
         return float(loss_sum.item()) / self._norm
+
+    def mean_loss(self, reset: bool = True) -> float:
+        """mean loss over the steps since the last reset -- ONE synchronisation per epoch / log interval."""
+        n = max(self._loss_steps, 1)
+        v = float(self._loss_acc.item()) / self._norm / n
+        if reset:
+            self._loss_acc.zero_()
+            self._loss_steps = 0
+        return v
+
+    def skipped_steps(self) -> int:
+        return int(self._skipped.item())
+
+    def check_health(self) -> None:
+        """Raise if a GRU hand-off ever timed out (CRUSE_E_TIMEOUT; those steps were skipped by the guarded Adam)."""
+        ops.check_gru_status()
+
+    # -- optimizer state in torch.optim.Adam layout ------------------------------------------------------------------
+    def optimizer_state_dict(self) -> dict:
+        return self.flat.adam_state_dict(self.step_count, self.lr, self.betas, self.eps, self.wd)
+
+    def load_optimizer_state_dict(self, sd: dict) -> None:
+        self.step_count = self.flat.load_adam_state_dict(sd)
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps = g["lr"], tuple(g["betas"]), g["eps"]
+        self.wd = g.get("weight_decay", 0.0)

@@ -77,3 +77,34 @@ def si_snr_loss():
             raise RuntimeError(f"Dimension mismatch when calculate si_snr, {x.shape} vs {s.shape}")
         return _SiSnrFn.apply(x, s, float(eps))
     return si_snr
+
+
+class _MaskedSdnrFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mask, cre, cim, nre, nim, snr_db, beta_db):
+        B, _, T, Fn = mask.shape
+        Fs = nre.shape[-1]
+        rows = B * T
+        need = mask.requires_grad
+        loss_sum, dmask, _ = ops.mask_sdnr(mask.contiguous(), cre.contiguous(), cim.contiguous(), nre.contiguous(),
+                                           nim.contiguous(), rows, Fn, Fs, B, snr_db, beta_db, want_dmask=need)
+        ctx.dmask, ctx.shape = dmask, mask.shape
+        return (loss_sum / float(B * Fs)).to(torch.float32).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.dmask.view(ctx.shape) * g, None, None, None, None, None, None
+
+
+def masked_sdnr(mask, clean_real, clean_imag, noisy_real, noisy_imag, snr_db=0.0, beta_db=20.0):
+    """sdnr(ref_clean, est_g = mask, ref_noise = noisy - clean, snr) of loss_func/loss.py:151-175 (vad == 1).
+    mask [B,1,T,Fn]; spectra [B,T,Fs] (or [B,1,T,Fs]); gain bins Fn..Fs-1 are zero (R8)."""
+    if mask.dim() != 4:
+        raise RuntimeError(f"masked_sdnr: mask must be [B,1,T,F], got {tuple(mask.shape)}")
+    B, _, T, Fn = mask.shape
+    Fs = noisy_real.shape[-1]
+    for name, t in (("clean_real", clean_real), ("clean_imag", clean_imag), ("noisy_real", noisy_real),
+                    ("noisy_imag", noisy_imag)):
+        if t.numel() != B * T * Fs:
+            raise RuntimeError(f"Dimension mismatch when calculate sdnr, {name} {tuple(t.shape)} vs mask {tuple(mask.shape)}")
+    return _MaskedSdnrFn.apply(mask, clean_real, clean_imag, noisy_real, noisy_imag, float(snr_db), float(beta_db))

@@ -100,14 +100,23 @@ class _SideStream:
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
 
-    def join(self):
-        if self.enabled and self.deferred:       # nothing left to hide behind: issue what is still queued
+    def flush(self):
+        """Issue everything still queued by defer() on the side stream now."""
+        if self.deferred:
             fns, self.deferred = self.deferred, []
             for fn in fns:
                 self.run(fn)
+
+    def join(self, flush: bool = True):
+        """Main stream waits for the side stream.  flush=False keeps the deferred (not yet issued) leaves queued: a
+        SEGMENT boundary of the bucketed data-parallel step (engine.py) ends a graph capture with every ISSUED leaf
+        joined, and carries the queued ones into the next segment."""
+        if flush and self.enabled:               # nothing left to hide behind: issue what is still queued
+            self.flush()
         if self.enabled and self.active:
             torch.cuda.current_stream().wait_stream(self.streams[torch.cuda.current_device()])
-            self.keep.clear()
+            if not self.deferred:
+                self.keep.clear()
             self.active = False
 
 
@@ -190,9 +199,11 @@ def ggru_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], prefix: str, group
 
 def ggru_backward(ctx, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor],
                   need_dx: bool = True, join: bool = True, dx_init: Optional[torch.Tensor] = None,
-                  dx_ready=None) -> Optional[torch.Tensor]:
+                  dx_ready=None, defer_last: bool = False) -> Optional[torch.Tensor]:
     """dout [B,T,H] -> dx; parameter gradients are ACCUMULATED into G[name].  dx_init: a [B,T,H] tensor the input
-    gradient is ADDED to (and returned) instead of a fresh one; dx_ready() is called right before it is touched."""
+    gradient is ADDED to (and returned) instead of a fresh one; dx_ready() is called right before it is touched.
+    defer_last: queue layer 1's weight-gradient leaf (SIDE.defer) instead of issuing it -- the caller ends a segment
+    right after this function and issues it with SIDE.flush() at the start of the next one."""
     B, T, H, g, prec, prefix = ctx["B"], ctx["T"], ctx["H"], ctx["g"], ctx["prec"], ctx["prefix"]
     Hg = H // g
     rows = B * T
@@ -237,7 +248,9 @@ def ggru_backward(ctx, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[s
                 w_t = ops.transpose_bf16(P[nm + "weight_ih_l0"], 3 * Hg, Hg)          # K-tiled [ceil(3*Hg/64), Hg, 64]
                 ops.gemm_bf16_nt(rows, Hg, w_t.shape[0] * 64, dgi, i * 3 * Hg, 3 * H, w_t, 0, 64, dinp, i * Hg, H,
                                  accumulate=acc_dx, b_kstride=Hg * 64)
-        if last:
+        if last and defer_last:
+            SIDE.defer(weight_grads, dgT, h, inp, inpT, hpT, kind=0xffff)
+        elif last:
             SIDE.run(weight_grads, dgT, h, inp, inpT, hpT)
         else:
             SIDE.defer(weight_grads, dgT, h, inp, inpT, hpT, kind=4)
@@ -269,7 +282,9 @@ def ggru_backward(ctx, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[s
             for i in range(g):
                 ops.gemm(False, False, rows, Hg, 3 * Hg, dgi, i * 3 * Hg, 3 * H,
                          P[f"{prefix}{lname}.{i}.weight_ih_l0"], 0, Hg, dinp, i * Hg, H, accumulate=acc_dx, prec=prec)
-        if last:
+        if last and defer_last:
+            SIDE.defer(weight_grads, dgi, dgh, h, inp, kind=0xffff)
+        elif last:
             SIDE.run(weight_grads, dgi, dgh, h, inp)
         else:
             SIDE.defer(weight_grads, dgi, dgh, h, inp, kind=4)
@@ -298,7 +313,7 @@ _PENDING_COUNTERS = []      # num_batches_tracked buffers of this forward: bumpe
 
 def _flush_counters():
     if _PENDING_COUNTERS:
-        torch._foreach_add_(list(_PENDING_COUNTERS), 1)
+        ops.counters_add(list(_PENDING_COUNTERS), 1)
         _PENDING_COUNTERS.clear()
 
 
@@ -367,8 +382,29 @@ def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, tor
     return mask.view(B, ch[0], T, F0), ctx
 
 
-def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor]) -> None:
-    """dlogit = dL/d(pre-sigmoid) [B,T,1,F0]; parameter gradients are ACCUMULATED into G[name]."""
+def bucket_of(name: str) -> int:
+    """Gradient bucket of a unet_2 parameter, in the order the backward pass FINISHES them:
+    0 = decoder convT / BN, skip convs and GGRU layer 2 (+ ln2) -- final when the layer-1 recurrence has run;
+    1 = GGRU layer 1 (+ ln1) -- its dW GEMMs run beside the first half of the encoder backward;
+    2 = encoder convs / BN."""
+    if name.startswith("gru.gru_list1.") or name.startswith("gru.ln1."):
+        return 1
+    if name.startswith("gru.") or name.startswith("skip_connect_") or "_t." in name:
+        return 0
+    return 2
+
+
+N_BUCKETS = 3
+
+
+def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor],
+                   boundary=None) -> None:
+    """dlogit = dL/d(pre-sigmoid) [B,T,1,F0]; parameter gradients are ACCUMULATED into G[name].
+
+    boundary(b): called at the two points where gradient bucket b (bucket_of) has just become final once the issued
+    side-stream leaves are joined -- after the GGRU backward (b = 0) and half way down the encoder (b = 1).  The
+    callback must SIDE.join(flush=False), may end a graph capture / launch the bucket's all-reduce, and must
+    SIDE.flush() before returning.  Bucket 2 is final when this function returns."""
     B, T, Fk, ch, L, training = ctx["B"], ctx["T"], ctx["F"], ctx["ch"], ctx["L"], ctx["training"]
     prec = ctx["prec"]
     rows = B * T
@@ -415,7 +451,10 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
     # ---- bottleneck: u_L = ggru(e_L) + skip_L --------------------------------------------
     H = ch[L] * Fk[L]
     de = ggru_backward(ctx["gctx"], du.view(B, T, H), P, G, join=False, dx_init=de_pre[L].view(B, T, H),
-                       dx_ready=lambda: SIDE.wait(skips_done)).view(B, T, ch[L], Fk[L])
+                       dx_ready=lambda: SIDE.wait(skips_done), defer_last=boundary is not None).view(B, T, ch[L], Fk[L])
+    if boundary is not None:
+        boundary(0)
+    cut = max(L // 2, 1)                          # levels L..cut+1, [bucket 1 final], levels cut..1
     # ---- encoder levels L..1: de_k already holds the skip path ------------------------------
     for k in range(L, 0, -1):
         mean, rstd = stats[k]
@@ -428,6 +467,8 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
         if k > 1:
             de = ops.conv_scatter2(dy, P[f"conv{k}.weight"], None, B, T, ch[k], Fk[k], ch[k - 1], KT=2, pad=1,
                                    out=de_pre[k - 1], accum=True, prec=prec)
+        if boundary is not None and k == cut + 1:
+            boundary(1)
     SIDE.join()
 
 

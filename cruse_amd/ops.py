@@ -460,6 +460,28 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=
                                       _stream()))
 
 
+def zero_(t: torch.Tensor) -> torch.Tensor:
+    """stream-ordered zero fill (kernel node; see cruse_zero)."""
+    check(lib.cruse_zero(_p(t), t.numel() * t.element_size(), _stream()))
+    return t
+
+
+def accum_f64(acc: torch.Tensor, x: torch.Tensor) -> None:
+    if acc.dtype != torch.float64 or x.dtype != torch.float64 or acc.numel() != x.numel():
+        raise RuntimeError("accum_f64 needs two f64 tensors of the same size")
+    check(lib.cruse_accum_f64(_p(acc), _p(x), acc.numel(), _stream()))
+
+
+def counters_add(counters: Sequence[torch.Tensor], v: int = 1) -> None:
+    """every int64 scalar tensor in `counters` += v with ONE launch (BatchNorm num_batches_tracked)."""
+    for c in counters:
+        if c.dtype != torch.int64:
+            raise RuntimeError("counters_add needs int64 tensors")
+    for i in range(0, len(counters), 32):
+        part = counters[i:i + 32]
+        check(lib.cruse_counters_add(ctypes.cast(_ptr_array(part), ctypes.c_void_p), len(part), v, _stream()))
+
+
 def sumsq(x, out=None, accumulate=False):
     """sum of squares (f64[1]) of a flat f32 tensor: the squared total gradient norm of clip_grad_norm_."""
     if out is None:

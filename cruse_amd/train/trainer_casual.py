@@ -1,10 +1,21 @@
 """The DDP trainer `train/trainer_casual.py` was meant to hold (the reference file is empty).
 
-Accepts exactly the keyword arguments tools/train_stand.py:79-88 passes and exposes
-train() like train_base/trainer/base_trainer.py:378-424.  One process per GPU; gradients are
-all-reduced over RCCL (torch.distributed backend "nccl") by cruse_amd.engine.TrainEngine --
-no DistributedDataParallel wrapper, BatchNorm statistics stay rank-local as with the
-reference's plain DDP (base_trainer.py:31, no SyncBN).
+Accepts exactly the keyword arguments tools/train_stand.py:79-88 passes and exposes train() like
+train_base/trainer/base_trainer.py:378-424.  One process per GPU; gradients are all-reduced over RCCL
+(torch.distributed backend "nccl") by cruse_amd.engine.TrainEngine in buckets overlapped with the backward pass --
+no DistributedDataParallel wrapper; BatchNorm statistics stay rank-local as with the reference's plain DDP
+(base_trainer.py:31, no SyncBN) and rank 0's are the ones saved (base_trainer.py:206-207).
+
+What the reference's knobs do here:
+  loss_function               -> the fused engine loss named by its `.cruse_loss` tag (train_base/loss.py); a loss
+                                 without a fused form (l1_loss, mse_loss) raises
+  optimizer (torch Adam)      -> lr / betas / eps / weight_decay are read from it; its state_dict() layout is what
+                                 latest_model.tar stores and what resume loads (base_trainer.py:167,199-203)
+  clip_grad_norm_value        -> torch.nn.utils.clip_grad_norm_ semantics, folded into the fused Adam (base_trainer.py:75)
+  meta.preloaded_model_path   -> model weights from a checkpoint, strict=False (base_trainer.py:130-146)
+  save_checkpoint_interval, validation_interval, save_max_metric_score -> as base_trainer.py:72-86,395-418
+The validation score is the configured loss on the validation set (the reference's STOI / PESQ metrics are host-side
+libraries outside this path), so `save_max_metric_score = false` is the meaningful setting.
 """
 from __future__ import annotations
 
@@ -13,6 +24,7 @@ import time
 
 import torch
 
+from .. import ops
 from ..engine import TrainEngine
 
 
@@ -24,96 +36,135 @@ class Trainer:
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.model = model.to(self.device)
         self.optimizer = optimizer
-        self.loss_function = loss_function            # kept for interface parity; the engine fuses WO-MALE
+        self.loss_function = loss_function
         self.train_dataloader = train_dataloader
         self.validation_dataloader = validation_dataloader
         ac = config["acoustics"]
         tr = config["trainer"]["train"]
+        va = config["trainer"].get("validation", {})
         self.epochs = tr["epochs"]
         self.save_checkpoint_interval = tr.get("save_checkpoint_interval", 1)
         self.clip_grad_norm_value = tr.get("clip_grad_norm_value", None)
-        assert self.save_checkpoint_interval >= 1                      # base_trainer.py:76
+        assert self.save_checkpoint_interval >= 1, \
+            "Check the 'save_checkpoint_interval' parameter in the config. It should be large than one."   # base_trainer.py:76
+        self.validation_interval = va.get("validation_interval", 1)
+        self.save_max_metric_score = va.get("save_max_metric_score", False)
+        assert self.validation_interval >= 1, \
+            "Check the 'validation_interval' parameter in the config. It should be large than one."       # base_trainer.py:84
         self.save_dir = os.path.join(config["meta"]["save_dir"], config["meta"].get("experiment_name", "exp"))
         self.checkpoints_dir = os.path.join(self.save_dir, "checkpoints")
+        tag = getattr(loss_function, "cruse_loss", None)
+        if tag is None:
+            raise RuntimeError(f"loss_function {loss_function!r} has no fused HIP form: use wo_male_loss, si_snr_loss or "
+                               "sdnr_loss from train_base.loss (config [loss_function].name)")
+        loss_name, loss_kwargs = tag
         g = optimizer.param_groups[0]
         self.engine = TrainEngine(self.model, lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"],
                                   weight_decay=g.get("weight_decay", 0.0), n_fft=ac["n_fft"], hop=ac["hop_length"],
-                                  precision=config["meta"].get("precision", None))
+                                  precision=config["meta"].get("precision", None), loss=loss_name,
+                                  clip_grad_norm=float(self.clip_grad_norm_value or 0.0), **loss_kwargs)
         self.start_epoch = 1
-        self.best_score = float("inf")
+        self.best_score = -float("inf") if self.save_max_metric_score else float("inf")      # base_trainer.py:93
         if rank == 0:
             os.makedirs(self.checkpoints_dir, exist_ok=True)
         if resume:
             self._resume_checkpoint()
+        pre = config["meta"].get("preloaded_model_path")
+        if pre:
+            self._preload_model(pre)
 
-    # -- checkpoint schema of base_trainer.py:186-232 (latest_model.tar) --------------------
-    def _save_checkpoint(self, epoch):
+    # -- checkpoint schema of base_trainer.py:130-232 -----------------------------------------------------------------
+    def _preload_model(self, model_path):
+        model_path = os.path.abspath(os.path.expanduser(model_path))
+        assert os.path.exists(model_path), f"The file {model_path} is not exist. please check path."
+        ck = torch.load(model_path, map_location="cpu")
+        self.model.load_state_dict(ck["model"] if "model" in ck else ck, strict=False)     # base_trainer.py:143
+        if self.rank == 0:
+            print(f"Model preloaded successfully from {model_path}.")
+
+    def _save_checkpoint(self, epoch, is_best_epoch=False):
         state = {"epoch": epoch, "best_score": self.best_score,
-                 "optimizer": {"step": self.engine.step_count, "exp_avg": self.engine.flat.exp_avg.cpu(),
-                               "exp_avg_sq": self.engine.flat.exp_avg_sq.cpu()},
-                 "scaler": None,
+                 "optimizer": self.engine.optimizer_state_dict(),          # torch.optim.Adam.state_dict() layout
+                 "scaler": {},                                              # GradScaler(enabled=False).state_dict()
                  "model": {k: v.detach().cpu() for k, v in self.model.state_dict().items()}}
         torch.save(state, os.path.join(self.checkpoints_dir, "latest_model.tar"))
         torch.save(state["model"], os.path.join(self.checkpoints_dir, f"model_{str(epoch).zfill(4)}.pth"))
+        if is_best_epoch:
+            torch.save(state, os.path.join(self.checkpoints_dir, "best_model.tar"))
 
     def _resume_checkpoint(self):
         path = os.path.join(self.checkpoints_dir, "latest_model.tar")
         assert os.path.exists(path), f"{path} does not exist, can not load latest checkpoint."
         if self.dist is not None and self.dist.is_initialized():
             self.dist.barrier()                                          # base_trainer.py:161
-        ck = torch.load(path, map_location="cpu")
+        ck = torch.load(path, map_location="cpu", weights_only=False)
         self.start_epoch = ck["epoch"] + 1
         self.best_score = ck["best_score"]
+        self.engine.load_optimizer_state_dict(ck["optimizer"])
         self.model.load_state_dict(ck["model"])
-        self.engine.step_count = ck["optimizer"]["step"]
-        self.engine.flat.exp_avg.copy_(ck["optimizer"]["exp_avg"])
-        self.engine.flat.exp_avg_sq.copy_(ck["optimizer"]["exp_avg_sq"])
+        if self.rank == 0:
+            print(f"Model checkpoint loaded. Training will begin at {self.start_epoch} epoch.")
+
+    def _is_best_epoch(self, score, save_max_metric_score=True):        # base_trainer.py:234-246
+        if save_max_metric_score and score >= self.best_score:
+            self.best_score = score
+            return True
+        if not save_max_metric_score and score <= self.best_score:
+            self.best_score = score
+            return True
+        return False
 
     def _train_epoch(self, epoch):
-        total, nb, frames = 0.0, 0, 0
+        sampler = getattr(self.train_dataloader, "sampler", None)
+        if hasattr(sampler, "set_epoch"):
+            sampler.set_epoch(epoch)                                     # a different shuffle every epoch
+        nb, frames = 0, 0
         t0 = time.time()
+        self.engine.mean_loss(reset=True)
         for noisy, clean in self.train_dataloader:
             noisy = noisy.to(self.device, non_blocking=True).float().contiguous()
             clean = clean.to(self.device, non_blocking=True).float().contiguous()
-            ls = self.engine.step(noisy, clean)
-            total += self.engine.loss_value(ls)
+            self.engine.step(noisy, clean)                               # no host synchronisation inside the loop
             nb += 1
             frames += noisy.shape[0] * (1 + noisy.shape[1] // self.engine.hop)
+        mean = self.engine.mean_loss(reset=True)                         # one synchronisation per epoch
+        self.engine.check_health()                                       # raises on a GRU hand-off time-out
+        skipped = self.engine.skipped_steps()
         dt = time.time() - t0
         if self.rank == 0:
-            print(f"[epoch {epoch}] loss {total / max(nb, 1):.6f}  {frames / max(dt, 1e-9):.0f} frames/s/rank")
-        return total / max(nb, 1)
+            note = f"  ({skipped} optimizer steps skipped so far: non-finite loss / gradient)" if skipped else ""
+            print(f"[epoch {epoch}] loss {mean:.6f}  {frames / max(dt, 1e-9):.0f} frames/s/rank{note}")
+        return mean
 
     @torch.no_grad()
     def _validation_epoch(self, epoch):
-        from ..acoustics.feature import pre_stft
-        from ..loss import masked_wo_male
-        from .. import ops
-        self.model.eval()
         total, nb = 0.0, 0
         for noisy, clean in self.validation_dataloader:
             noisy = noisy.to(self.device).float().contiguous()
             clean = clean.to(self.device).float().contiguous()
-            f = pre_stft(noisy, self.engine.n_fft, self.engine.hop, self.engine.n_fft, f_net=self.engine.f_net)
-            _, _, cmag = ops.stft(clean, self.engine.n_fft, self.engine.hop, want_ri=False,
-                                  mag_bins=self.engine.f_stft)
-            mask = self.model(f["mag_net"])
-            total += float(masked_wo_male(mask, f["real"], f["imag"], cmag))
+            total += self.engine.eval_loss(noisy, clean)
             nb += 1
-        self.model.train()
         return total / max(nb, 1)
 
     def train(self):
         for epoch in range(self.start_epoch, self.epochs + 1):
-            if self.only_validation and self.rank == 0:
-                print(f"validation loss {self._validation_epoch(epoch):.6f}")
-                return
+            if self.only_validation and self.rank == 0:                  # base_trainer.py:386-396
+                self.model.eval()
+                score = self._validation_epoch(epoch)
+                print(f"[epoch {epoch}] validation loss {score:.6f}")
+                if self._is_best_epoch(score, save_max_metric_score=self.save_max_metric_score):
+                    self._save_checkpoint(epoch, is_best_epoch=True)
+                continue
+            if self.only_validation:
+                continue
             self.model.train()
             self._train_epoch(epoch)
             if self.rank == 0 and epoch % self.save_checkpoint_interval == 0:
                 self._save_checkpoint(epoch)
-            vi = self.config["trainer"].get("validation", {}).get("validation_interval", 0)
-            if self.rank == 0 and vi and epoch % vi == 0 and self.validation_dataloader is not None:
+            if self.rank == 0 and epoch % self.validation_interval == 0 and self.validation_dataloader is not None:
+                self.model.eval()
                 score = self._validation_epoch(epoch)
-                self.best_score = min(self.best_score, score)
                 print(f"[epoch {epoch}] validation loss {score:.6f}")
+                if self._is_best_epoch(score, save_max_metric_score=self.save_max_metric_score):
+                    self._save_checkpoint(epoch, is_best_epoch=True)     # rewrites latest_model.tar with the new best_score
+                self.model.train()

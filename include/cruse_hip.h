@@ -270,6 +270,15 @@ int cruse_sigmoid_bwd(const float* dmask, const float* mask, float* dlogit, long
 /* out = a*x + b*y elementwise (x or y may alias out) */
 int cruse_axpby(float* out, const float* x, const float* y, float a, float b, long long n, void* stream);
 
+/* ---- stream-ordered bookkeeping (keeps the training step free of library kernels) ---- */
+/* zero-fill `bytes` (multiple of 4) with a KERNEL node (hipMemsetAsync nodes raced inside captured graphs) --
+ * optimizer.zero_grad() at the top of the step */
+int cruse_zero(void* p, size_t bytes, void* stream);
+/* acc[i] += x[i] (f64): running loss sum of an epoch without a host synchronisation per step */
+int cruse_accum_f64(double* acc, const double* x, int n, void* stream);
+/* *counters[i] += v for a HOST array of n <= 32 device int64 pointers: BatchNorm2d.num_batches_tracked */
+int cruse_counters_add(long long* const* counters, int n, long long v, void* stream);
+
 /* ---- optimizer (torch.optim.Adam at tools/train_stand.py:68-71) -------------- */
 /* One fused Adam step over a flat parameter buffer; g is multiplied by grad_scale first
  * (1/world_size after a sum all-reduce). step >= 1. */

@@ -1,6 +1,14 @@
-"""GPU: the data-parallel step with 2 ranks (both on cuda:0, gloo for the test rig; production uses
-nccl = RCCL).  Same clips on both ranks => the averaged gradient equals the single-rank gradient, so the
-parameters after 2 Adam steps must match a single-process run and be identical across ranks."""
+"""GPU: the data-parallel step.
+
+* 2 ranks on cuda:0 over gloo (the test rig has one GPU; RCCL refuses two ranks on one device), SAME clips on both
+  ranks, BatchNorm in train mode: the averaged gradient equals the single-rank gradient, so parameters after 2 Adam
+  steps must match a single-process run and be identical across ranks.
+* 2 ranks, DIFFERENT clips per rank, BatchNorm in train mode with rank-LOCAL statistics (the reference wraps the model
+  in plain DDP without SyncBN, base_trainer.py:31): every rank's loss and the SUM of the rank gradients against the
+  CPU oracle run rank by rank (SURVEY 8e verification).
+* backend "nccl" (= RCCL) with world 1 and CRUSE_FORCE_COLLECTIVES=1: the bucketed, graph-segmented schedule with its
+  three asynchronous all-reduces on RCCL's stream, against the single-graph schedule.
+"""
 import os
 import subprocess
 import sys
@@ -8,16 +16,19 @@ import sys
 import pytest
 import torch
 
+from tests.util import rel_l2
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
+mode = sys.argv[3]
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(0)
-if world > 1:
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+if world > 1 or mode == "nccl1":
+    dist.init_process_group("nccl" if mode == "nccl1" else "gloo", rank=rank, world_size=world)
 from cruse_amd.engine import TrainEngine
 from cruse_amd.model.cruse_net import unet_2
 from cruse_amd import ops
@@ -26,37 +37,113 @@ torch.manual_seed(100 + rank)                    # different init per rank: the 
 m = unet_2(rnn_groups=4, precision="f32").cuda()
 if world == 1:
     torch.manual_seed(100); m = unet_2(rnn_groups=4, precision="f32").cuda()
-eng = TrainEngine(m, lr=1e-3, use_graph=True)
+bucketed = None if mode != "nccl1" else (os.environ.get("BUCKETED") == "1")
+eng = TrainEngine(m, lr=1e-3, use_graph=os.environ.get("NOGRAPH") != "1", bucketed=bucketed)
+if mode == "nccl1" and bucketed:
+    assert eng.bucketed and dist.get_backend() == "nccl"
+losses = []
 for step in range(2):
-    noisy, clean = O.synth_pair(2, 3200, seed=50 + step)
-    eng.step(noisy.cuda(), clean.cuda())
+    seed = 50 + step + (1000 * rank if mode == "shards" else 0)
+    noisy, clean = O.synth_pair(2, 3200, seed=seed)
+    ls = eng.step(noisy.cuda(), clean.cuda())
+    losses.append(eng.loss_value(ls))
+    if step == 0:
+        g0 = eng.flat.grads.clone()              # after the all-reduce: the SUM over ranks
 torch.cuda.synchronize()
-assert ops.gru_status() == 0
-torch.save(eng.flat.params.cpu(), sys.argv[2] + f"/p_w{world}_r{rank}.pt")
-if world > 1:
+assert ops.gru_status() == 0 and eng.skipped_steps() == 0
+if mode == "nccl1" and bucketed and os.environ.get("NOGRAPH") != "1":
+    assert len(eng._graphs) == 3, len(eng._graphs)
+tag = sys.argv[4] if len(sys.argv) > 4 else ""
+torch.save({"params": eng.flat.params.cpu(), "losses": losses, "g0": g0.cpu(), "names": eng.flat.names,
+            "offsets": eng.flat.offsets}, sys.argv[2] + f"/p_{mode}{tag}_w{world}_r{rank}.pt")
+if dist.is_initialized():
     dist.barrier(); dist.destroy_process_group()
 print("OK")
 '''
 
 
-def _run(world, tmp, port):
+def _run(world, tmp, port, mode="same", env_extra=None, tag=""):
     script = os.path.join(tmp, "w.py")
     open(script, "w").write(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world))
-    procs = [subprocess.Popen([sys.executable, script, ROOT, tmp], env=dict(env, RANK=str(r)),
+    env.update(env_extra or {})
+    procs = [subprocess.Popen([sys.executable, script, ROOT, tmp, mode, tag], env=dict(env, RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     for p in procs:
         out = p.communicate(timeout=600)[0].decode()
-        assert p.returncode == 0 and "OK" in out, out[-2000:]
+        assert p.returncode == 0 and "OK" in out, out[-3000:]
 
 
 def test_two_rank_step_equals_single_rank(tmp_path):
     tmp = str(tmp_path)
     _run(1, tmp, 29541)
     _run(2, tmp, 29542)
-    p1 = torch.load(tmp + "/p_w1_r0.pt")
-    a = torch.load(tmp + "/p_w2_r0.pt")
-    b = torch.load(tmp + "/p_w2_r1.pt")
+    p1 = torch.load(tmp + "/p_same_w1_r0.pt")["params"]
+    a = torch.load(tmp + "/p_same_w2_r0.pt")["params"]
+    b = torch.load(tmp + "/p_same_w2_r1.pt")["params"]
     assert torch.equal(a, b), "ranks diverged"
-    # sum of two identical gradients * 0.5 == the single-rank gradient (bitwise up to atomic-add order)
-    assert (a - p1).abs().max() <= 5e-4, float((a - p1).abs().max())
+    assert rel_l2(a, p1) < 1e-6
+
+
+def test_two_rank_shards_bn_train_vs_oracle_rank_by_rank(tmp_path):
+    """different clips per rank, rank-local BatchNorm statistics: per-rank loss and the summed gradient vs the oracle."""
+    from oracle import cruse_oracle as O
+    tmp = str(tmp_path)
+    _run(2, tmp, 29543, mode="shards")
+    r = [torch.load(tmp + f"/p_shards_w2_r{k}.pt") for k in range(2)]
+    assert torch.equal(r[0]["params"], r[1]["params"]), "ranks diverged"
+    assert torch.equal(r[0]["g0"], r[1]["g0"]), "all-reduced gradients differ across ranks"
+    torch.manual_seed(100)
+    o = O.unet_2(rnn_groups=4)                                      # == rank 0's init (same seed, same RNG consumption)
+    o.train()
+    init = {k: v.clone() for k, v in o.state_dict().items()}
+    gsum = {}
+    for k in range(2):
+        o.load_state_dict(init)                                      # BN running stats are rank-local too
+        o.zero_grad(set_to_none=True)
+        noisy, clean = O.synth_pair(2, 3200, seed=50 + 1000 * k)
+        loss, _ = O.train_step_loss(o, noisy, clean)
+        loss.backward()
+        assert abs(r[k]["losses"][0] - float(loss.detach())) <= 1e-4 * abs(float(loss.detach())), k
+        for n, p in o.named_parameters():
+            if p.grad is not None:
+                gsum[n] = gsum.get(n, 0) + p.grad.clone()
+    names, offs, g0 = r[0]["names"], r[0]["offsets"], r[0]["g0"]
+    worst = 0.0
+    for n in names:
+        if n.endswith(".bias") and n.startswith("conv") and n != "conv1_t.bias":
+            continue                                                 # bias before BN: true gradient 0
+        got = g0[offs[n]:offs[n] + gsum[n].numel()].view(gsum[n].shape)
+        e = rel_l2(got, gsum[n])
+        worst = max(worst, e)
+        assert e <= 5e-3, (n, e)
+    print(f"[ddp shards] worst per-tensor rel-L2 of the summed gradient vs oracle {worst:.2e}")
+
+
+@pytest.mark.parametrize("nograph", ["0", "1"])
+def test_rccl_bucketed_schedule_world1(tmp_path, nograph):
+    """backend nccl (RCCL): segmented graphs + async per-bucket all-reduce == the single-graph schedule."""
+    tmp = str(tmp_path)
+    _run(1, tmp, 29544, mode="nccl1", env_extra={"CRUSE_FORCE_COLLECTIVES": "1", "BUCKETED": "1", "NOGRAPH": nograph}, tag="b")
+    _run(1, tmp, 29545, mode="nccl1", env_extra={"BUCKETED": "0", "NOGRAPH": nograph}, tag="p")
+    a = torch.load(tmp + "/p_nccl1b_w1_r0.pt")
+    b = torch.load(tmp + "/p_nccl1p_w1_r0.pt")
+    assert rel_l2(a["g0"], b["g0"]) < 1e-6
+    assert rel_l2(a["params"], b["params"]) < 1e-6
+    assert a["losses"] == pytest.approx(b["losses"], rel=1e-6)
+
+
+def test_bucket_layout_follows_backward_order():
+    from cruse_amd.engine import FlatParams
+    from cruse_amd.model.cruse_net import bucket_of, unet_2
+    m = unet_2(rnn_groups=1)
+    fp = FlatParams(m)
+    (s0, e0), (s1, e1), (s2, e2) = fp.bucket_range
+    assert s0 == 0 and e0 == s1 and e1 == s2 and e2 == fp.total
+    for n, o in fp.offsets.items():
+        b = bucket_of(n)
+        assert fp.bucket_range[b][0] <= o < fp.bucket_range[b][1], n
+    assert bucket_of("gru.gru_list2.0.weight_hh_l0") == 0 and bucket_of("conv3_t.weight") == 0
+    assert bucket_of("gru.gru_list1.0.weight_ih_l0") == 1 and bucket_of("conv2.weight") == 2
+    # the two GGRU layers dominate: buckets 0 and 1 each carry about half of the 19.9 MB
+    assert abs((e0 - s0) - (e1 - s1)) < 0.05 * fp.total and (e2 - s2) < 0.02 * fp.total

@@ -1,0 +1,146 @@
+"""GPU: parity of the BENCH precision mode (bf16 MFMA operands) at the bench's sequence length.
+
+VERDICT r1 "weak" 1-2: the 3.3 M frames/s mode was parity-gated at T = 21 only, and its gradients were never
+compared with the oracle at model level.  Here: forward at T = 401 (B = 8; g = 1 and g = 4; closed-form and seeded
+torch-default init) against the CPU oracle with the north_star bar  enhanced-spectrum rel-L2 <= 1e-3 ; and the full
+training step's gradients (fixture G6 at T = 21, and the oracle at T = 401) with stated tolerances."""
+import pytest
+import torch
+
+from tests.util import rel_l2, t
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 1e-3               # north_star: "enhanced-spectrogram output matches the reference ... to <= 1e-3 rel"
+# bf16-mode gradient tolerances (backward GEMMs run on plain bf16 operands, f32 accumulate):
+GRAD_TOL_ALL = 2e-2          # all trained tensors as one vector, rel-L2
+GRAD_TOL_TENSOR = 0.10       # any weight matrix / conv kernel, rel-L2
+GRAD_TOL_SUMS = 0.30         # bias / norm-affine vectors: sums over all frames of signed terms (cancellation)
+
+
+def _pair(grp, init, prec, seed=7):
+    from cruse_amd.model import cruse_net as M
+    from oracle import cruse_oracle as O
+    if init == "closed":
+        o = O.unet_2(rnn_groups=grp); O.closed_form_init(o)
+    else:
+        torch.manual_seed(seed); o = O.unet_2(rnn_groups=grp)
+    m = M.unet_2(rnn_groups=grp, precision=prec)
+    m.load_state_dict(o.state_dict(), strict=True)
+    o.train(); m.train()
+    return o, m.cuda()
+
+
+def _dead_bias(n):
+    """a conv bias that feeds a BatchNorm: its true gradient is exactly 0 (pure rounding noise on both sides)."""
+    return n.endswith(".bias") and n.startswith("conv") and n != "conv1_t.bias"
+
+
+def _grad_report(eng, o):
+    allg, allo, worst = [], [], {}
+    for n, p in o.named_parameters():
+        if n not in eng.flat.G or p.grad is None or _dead_bias(n):
+            continue
+        r = rel_l2(eng.flat.G[n], p.grad)
+        worst[n] = r
+        allg.append(eng.flat.G[n].detach().double().cpu().flatten()); allo.append(p.grad.double().flatten())
+    tot = float((torch.cat(allg) - torch.cat(allo)).norm() / torch.cat(allo).norm())
+    return tot, worst
+
+
+def _check_grads(tot, worst, tag):
+    wmat = max((v, k) for k, v in worst.items() if k.endswith("weight") and "bn" not in k and ".ln" not in k)
+    wsum = max((v, k) for k, v in worst.items() if not (k.endswith("weight") and "bn" not in k and ".ln" not in k))
+    print(f"[grad parity {tag}] all {tot:.3e}  worst matrix {wmat[0]:.3e} ({wmat[1]})  worst bias/affine {wsum[0]:.3e} ({wsum[1]})")
+    assert tot <= GRAD_TOL_ALL, (tag, tot)
+    assert wmat[0] <= GRAD_TOL_TENSOR, (tag, wmat)
+    assert wsum[0] <= GRAD_TOL_SUMS, (tag, wsum)
+
+
+@pytest.mark.parametrize("grp,init", [(1, "closed"), (1, "random"), (4, "closed"), (4, "random")])
+def test_bf16_forward_parity_at_bench_length(grp, init):
+    """T = 401 (4 s clips), B = 8: 401 dependent recurrence steps per layer with h exchanged as bf16."""
+    from cruse_amd import ops
+    from cruse_amd.engine import TrainEngine
+    from cruse_amd.model.cruse_net import unet2_forward
+    from oracle import cruse_oracle as O
+    B, T = 8, 401
+    o, m = _pair(grp, init, "bf16")
+    noisy, clean = O.synth_pair(B, (T - 1) * 160, seed=11)
+    with torch.no_grad():
+        mask_o, est_o, _ = O.enhanced_spectrum(o, noisy)
+    eng = TrainEngine(m, use_graph=False)
+    nre, nim, mag = ops.stft(noisy.cuda(), 320, 160, mag_bins=160, mag_eps=1e-8)
+    assert mag.shape == (B, T, 160)
+    mask, _ = unet2_forward(mag.view(B, 1, T, 160), eng.flat.P, eng.Bf, m.ch, m.rnn_groups, "bf16", training=True,
+                            save=False, update_running=False)
+    er, ei = ops.mask_apply(mask.contiguous().view(B * T, 160), nre, nim, B * T, 160, 161)
+    est = torch.stack([er.view(B, T, 161), ei.view(B, T, 161)], dim=-1)
+    e_est, e_mask = rel_l2(est, est_o), rel_l2(mask.view(B, 1, T, 160), mask_o)
+    print(f"[parity bf16 T=401 B=8 g={grp} {init}] enhanced-spectrum rel-L2 {e_est:.3e}  mask {e_mask:.3e}")
+    assert ops.gru_status() == 0
+    assert e_est <= FWD_TOL and e_mask <= FWD_TOL
+    assert float(est[..., 160, :].abs().max()) == 0.0          # R8: bin 160 of the enhanced spectrum is zero
+
+
+@pytest.mark.parametrize("grp", [1, 4])
+def test_bf16_train_step_vs_golden_g6(golden, grp):
+    """fixture G6 (B = 2, T = 21) in the bench mode: loss, enhanced spectrum, every gradient norm vs the fixture."""
+    from cruse_amd.engine import TrainEngine
+    from cruse_amd import ops
+    g = golden(f"g6_step_g{grp}.npz")
+    o, m = _pair(grp, "closed", "bf16")
+    eng = TrainEngine(m, use_graph=False)
+    noisy, clean = t(g["noisy"]), t(g["clean"])
+    ls = eng._fwd_bwd(noisy, clean)
+    assert abs(eng.loss_value(ls) - float(g["loss"])) <= 2e-4 * abs(float(g["loss"]))
+    assert rel_l2(eng._last_mask.view(2, 1, 21, 160), torch.from_numpy(g["mask"])) <= FWD_TOL
+    worst = 0.0
+    for name in eng.flat.names:
+        if "gn/" + name not in g.files or _dead_bias(name):
+            continue
+        gn, got = float(g["gn/" + name]), float(eng.flat.G[name].norm())
+        is_mat = name.endswith("weight") and "bn" not in name and ".ln" not in name
+        tol = GRAD_TOL_TENSOR if is_mat else GRAD_TOL_SUMS
+        assert abs(got - gn) <= tol * gn + 2e-6, (name, got, gn)
+        worst = max(worst, abs(got - gn) / max(gn, 1e-9))
+    print(f"[grad parity bf16 G6 g={grp}] worst gradient-norm deviation {worst:.3e}")
+    assert ops.gru_status() == 0
+
+
+@pytest.mark.parametrize("grp,init", [(1, "closed"), (1, "random"), (4, "closed"), (4, "random")])
+def test_bf16_gradients_vs_oracle_at_bench_length(grp, init):
+    """The kernels the bench runs (lean forward recurrence, reduce-scatter backward recurrence, bf16-operand GEMMs)
+    against ORACLE autograd -- not against the generic kernels -- at T = 401."""
+    from cruse_amd.engine import TrainEngine
+    from cruse_amd import ops
+    from oracle import cruse_oracle as O
+    B, T = 8, 401
+    o, m = _pair(grp, init, "bf16")
+    noisy, clean = O.synth_pair(B, (T - 1) * 160, seed=11)
+    loss_o, _ = O.train_step_loss(o, noisy, clean)
+    loss_o.backward()
+    eng = TrainEngine(m, use_graph=False)
+    ls = eng._fwd_bwd(noisy.cuda(), clean.cuda())
+    assert abs(eng.loss_value(ls) - float(loss_o.detach())) <= 1e-4 * abs(float(loss_o.detach()))
+    tot, worst = _grad_report(eng, o)
+    _check_grads(tot, worst, f"T=401 g={grp} {init}")
+    assert ops.gru_status() == 0
+
+
+def test_f32_gate_mode_at_bench_length():
+    """the parity-gate mode (exact-f32 MFMA) at T = 401: forward and gradients."""
+    from cruse_amd.engine import TrainEngine
+    from oracle import cruse_oracle as O
+    B, T = 4, 401
+    o, m = _pair(1, "random", "f32")
+    noisy, clean = O.synth_pair(B, (T - 1) * 160, seed=12)
+    loss_o, aux = O.train_step_loss(o, noisy, clean)
+    loss_o.backward()
+    eng = TrainEngine(m, use_graph=False)
+    ls = eng._fwd_bwd(noisy.cuda(), clean.cuda())
+    assert rel_l2(eng._last_mask.view(B, 1, T, 160), aux["mask"]) <= 1e-4
+    assert abs(eng.loss_value(ls) - float(loss_o.detach())) <= 1e-5 * abs(float(loss_o.detach()))
+    tot, worst = _grad_report(eng, o)
+    print(f"[grad parity f32 T=401] all {tot:.3e} worst {max(worst.values()):.3e}")
+    assert tot <= 1e-3 and max(worst.values()) <= 5e-3

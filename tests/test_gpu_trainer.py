@@ -1,0 +1,186 @@
+"""GPU: row a17 end to end -- tools/train_stand.py (reference CLI, TOML sections) -> train.trainer_casual.Trainer
+-> TrainEngine on backend nccl, checkpoint schema of base_trainer.py:186-232, resume, loss selection, clipping."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from tests.util import rel_l2
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+TOML = '''
+[meta]
+seed = 0
+save_dir = "{save_dir}"
+use_amp = false
+precision = "f32"
+port = {port}
+[acoustics]
+n_fft = 320
+hop_length = 160
+win_length = 320
+sr = 16000
+[train_dataset]
+path = "cruse_amd.data.SyntheticPairs"
+[train_dataset.args]
+num = 4
+length = 3200
+seed = 1
+[train_dataset.dataloader]
+batch_size = 2
+num_workers = 0
+drop_last = true
+[validation_dataset]
+path = "cruse_amd.data.SyntheticPairs"
+[validation_dataset.args]
+num = 2
+length = 3200
+seed = 2
+[model]
+path = "model.cruse_net.unet_2"
+[model.args]
+in_feat = 161
+rnn_groups = 2
+[optimizer]
+lr = 0.001
+beta1 = 0.9
+beta2 = 0.999
+[loss_function]
+name = "{loss}"
+{loss_args}
+[trainer]
+path = "train.trainer_casual.Trainer"
+[trainer.train]
+epochs = {epochs}
+save_checkpoint_interval = 1
+clip_grad_norm_value = 10.0
+[trainer.validation]
+validation_interval = 1
+save_max_metric_score = false
+'''
+
+
+def _cli(cfg_path, *flags, port):
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_stand.py"), "-C", cfg_path, *flags],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, cwd=ROOT)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out[-3000:]
+    return out
+
+
+def _write(tmp_path, name, **kw):
+    kw.setdefault("loss_args", "")
+    cfg = tmp_path / f"{name}.toml"
+    cfg.write_text(TOML.format(save_dir=str(tmp_path / "runs"), **kw))
+    return str(cfg)
+
+
+def test_train_stand_end_to_end_save_and_resume(tmp_path):
+    cfg = _write(tmp_path, "tiny", loss="wo_male_loss", loss_args="[loss_function.args]\nalpha = 2.0\nbeta = 1.0", epochs=1, port=29551)
+    out = _cli(cfg, port=29551)
+    assert "[epoch 1] loss" in out and "validation loss" in out
+    ckdir = tmp_path / "runs" / "tiny" / "checkpoints"
+    ck = torch.load(ckdir / "latest_model.tar", map_location="cpu", weights_only=False)
+    assert set(ck) == {"epoch", "best_score", "optimizer", "scaler", "model"} and ck["epoch"] == 1      # base_trainer.py:199-207
+    assert (ckdir / "model_0001.pth").exists() and (ckdir / "best_model.tar").exists()
+    assert ck["best_score"] < float("inf")            # the best-epoch save rewrote latest_model.tar after validation
+    # the reference's resume path: torch.optim.Adam.load_state_dict + GradScaler.load_state_dict on these files
+    from oracle import cruse_oracle as O
+    o = O.unet_2(rnn_groups=2)
+    o.load_state_dict(ck["model"], strict=True)
+    opt = torch.optim.Adam(o.parameters(), lr=1e-3)
+    opt.load_state_dict(ck["optimizer"])
+    st = opt.state_dict()["state"]
+    assert len(st) == len(list(o.parameters())) - 4 and all(float(v["step"]) == 2.0 for v in st.values())    # 2 batches; fc.*, bn1_t.* untouched
+    torch.amp.GradScaler("cpu", enabled=False).load_state_dict(ck["scaler"])
+    # resume: epochs = 2 continues at epoch 2 from the saved optimizer state
+    cfg2 = _write(tmp_path, "tiny", loss="wo_male_loss", epochs=2, port=29552)
+    out2 = _cli(cfg2, "-R", port=29552)
+    assert "Training will begin at 2 epoch" in out2 and "[epoch 2] loss" in out2 and "[epoch 1] loss" not in out2
+    ck2 = torch.load(ckdir / "latest_model.tar", map_location="cpu", weights_only=False)
+    assert ck2["epoch"] == 2 and float(ck2["optimizer"]["state"][0]["step"]) == 4.0
+    # -P preloads model weights (strict=False) and -V only validates
+    out3 = _cli(cfg2, "-V", "-P", str(ckdir / "latest_model.tar"), port=29553)
+    assert "Model preloaded successfully" in out3 and "validation loss" in out3
+
+
+@pytest.mark.parametrize("loss,args", [("si_snr_loss", ""), ("sdnr_loss", "[loss_function.args]\nsnr = 5.0\nbeta = 20.0")])
+def test_train_stand_honours_loss_function_name(tmp_path, loss, args):
+    cfg = _write(tmp_path, "l_" + loss, loss=loss, loss_args=args, epochs=1, port=29554)
+    out = _cli(cfg, port=29554)
+    assert "[epoch 1] loss" in out
+    if loss == "si_snr_loss":
+        v = float(out.split("[epoch 1] loss")[1].split()[0])
+        assert abs(v) > 1.0                     # SI-SNR loss is a dB figure, not the O(0.4) WO-MALE value
+
+
+def test_trainer_refuses_losses_without_fused_form():
+    from cruse_amd.model.cruse_net import unet_2
+    from cruse_amd.train.trainer_casual import Trainer
+    import train_base.loss as L
+    m = unet_2(rnn_groups=1)
+    cfg = {"acoustics": {"n_fft": 320, "hop_length": 160}, "trainer": {"train": {"epochs": 1}},
+           "meta": {"save_dir": "/tmp/cruse_t", "precision": "f32"}}
+    with pytest.raises(RuntimeError, match="no fused HIP form"):
+        Trainer(dist=None, rank=1, config=cfg, resume=False, only_validation=False, model=m, loss_function=L.l1_loss(),
+                optimizer=torch.optim.Adam(m.parameters()), train_dataloader=None, validation_dataloader=None)
+
+
+def test_engine_clip_grad_norm_matches_torch():
+    """clip_grad_norm_value: the fused norm + Adam scale vs torch.nn.utils.clip_grad_norm_ + torch.optim.Adam."""
+    from cruse_amd.engine import TrainEngine
+    from cruse_amd.model.cruse_net import unet_2
+    from oracle import cruse_oracle as O
+    o = O.unet_2(rnn_groups=1); O.closed_form_init(o); o.train()
+    m = unet_2(rnn_groups=1, precision="f32"); m.load_state_dict(o.state_dict()); m = m.cuda()
+    init = {n: p.detach().clone() for n, p in o.named_parameters()}
+    noisy, clean = O.synth_pair(2, 3200, seed=5)
+    loss, _ = O.train_step_loss(o, noisy, clean); loss.backward()
+    trained = [p for n, p in o.named_parameters() if p.grad is not None]
+    total = float(torch.nn.utils.clip_grad_norm_(trained, 1e9))
+    clip = 0.25 * total                                            # forces the clipping branch
+    torch.nn.utils.clip_grad_norm_(trained, clip)
+    opt = torch.optim.Adam(o.parameters(), lr=1e-3); opt.step()
+    eng = TrainEngine(m, lr=1e-3, use_graph=False, clip_grad_norm=clip)
+    eng.step(noisy.cuda(), clean.cuda())
+    assert abs(float(eng._gsumsq.sqrt()) - total) <= 2e-3 * total
+    # first Adam step moves every element by lr*sign(g) whatever the scale: compare the second moments instead
+    for n, p in o.named_parameters():
+        if n in eng.flat.offsets and not (n.endswith(".bias") and n.startswith("conv") and n != "conv1_t.bias"):
+            want = opt.state[p]["exp_avg"]
+            assert rel_l2(eng.flat.view(eng.flat.exp_avg, n), want) <= 5e-3, n
+    assert eng.skipped_steps() == 0
+
+
+def test_guarded_adam_skips_nonfinite_and_timeout_steps():
+    from cruse_amd import ops
+    p = torch.ones(256).cuda(); g = torch.ones(256).cuda(); m = torch.zeros(256).cuda(); v = torch.zeros(256).cuda()
+    skipped = torch.zeros(1, dtype=torch.int32).cuda()
+    bad = torch.tensor([float("nan")], dtype=torch.float64).cuda()
+    ops.adam_step(p, g, m, v, 1e-2, 0.9, 0.999, 1e-8, 0.0, 1, loss_check=bad, skipped=skipped)
+    flag = torch.tensor([1, 0, 0, 0], dtype=torch.uint8).cuda()
+    ops.adam_step(p, g, m, v, 1e-2, 0.9, 0.999, 1e-8, 0.0, 1, skip_flag=flag, skipped=skipped)
+    assert int(skipped) == 2 and torch.equal(p.cpu(), torch.ones(256)) and float(m.abs().max()) == 0.0
+    ok = torch.tensor([1.0], dtype=torch.float64).cuda()
+    ops.adam_step(p, g, m, v, 1e-2, 0.9, 0.999, 1e-8, 0.0, 1, loss_check=ok, skip_flag=torch.zeros(4, dtype=torch.uint8).cuda(),
+                  skipped=skipped)
+    assert int(skipped) == 2 and float(p[0]) < 1.0
+    # the GRU status word is sticky: a later clean launch does not clear it
+    B, T, Hg = 2, 4, 32
+    gi = torch.zeros(B, T, 3 * Hg).cuda()
+    w = [torch.zeros(3 * Hg, Hg).cuda()]; b = [torch.zeros(3 * Hg).cuda()]
+    ops.gru_seq_fwd(gi, w, b, B, T, 1, Hg, "f32", save=False)
+    word = ops.gru_status_word(gi.device, B, 1, Hg)
+    assert ops.gru_status() == 0
+    word.copy_(torch.tensor([1, 0, 0, 0], dtype=torch.uint8))
+    ops.gru_seq_fwd(gi, w, b, B, T, 1, Hg, "f32", save=False)
+    assert ops.gru_status() == 1
+    with pytest.raises(RuntimeError, match="CRUSE_E_TIMEOUT"):
+        ops.check_gru_status()
+    ops.gru_status_reset()
+    assert ops.gru_status() == 0
