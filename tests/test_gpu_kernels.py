@@ -525,12 +525,14 @@ def test_gru_fwd_lean_matches_generic_kernel(ops, H, B, T):
     torch.manual_seed(H + B + 1)
     gi = (0.5 * torch.randn(B, T, 3 * H)).cuda()
     w = [(torch.randn(3 * H, H) / H ** 0.5).cuda()]; b = [(0.1 * torch.randn(3 * H)).cuda()]
-    lean = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16")
-    os.environ["CRUSE_GRU_FWD_LEAN"] = "0"
+    os.environ["CRUSE_GRU_WLO"] = "0"              # same algorithm == without the lean kernel's W_hh low-plane pass
     try:
+        lean = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16")
+        h_nosave = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16", save=False)[0]
+        os.environ["CRUSE_GRU_FWD_LEAN"] = "0"
         gen = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16")
     finally:
-        del os.environ["CRUSE_GRU_FWD_LEAN"]
+        os.environ.pop("CRUSE_GRU_FWD_LEAN", None); os.environ.pop("CRUSE_GRU_WLO", None)
     torch.cuda.synchronize()
     assert ops.gru_status() == 0
     for x, y, name in zip(lean, gen, ("h", "coef", "an", "z")):
@@ -538,7 +540,6 @@ def test_gru_fwd_lean_matches_generic_kernel(ops, H, B, T):
         # difference can flip one bf16 rounding of the exchanged state, so "equal" means well inside bf16 resolution
         tol = 2e-3 if x.dtype == torch.bfloat16 else 1e-4
         assert torch.isfinite(x.float()).all() and rel_l2(x.float(), y.float()) < tol, name
-    h_nosave = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16", save=False)[0]
     assert rel_l2(h_nosave, lean[0]) < 1e-6                # same kernel, saves off: identical
 
 
@@ -557,18 +558,45 @@ def _lean_grouped_case(ops, B, T, G, Hg):
     w = [(torch.randn(3 * Hg, Hg) / Hg ** 0.5).cuda() for _ in range(G)]
     b = [(0.1 * torch.randn(3 * Hg)).cuda() for _ in range(G)]
     dout = torch.randn(B, T, G * Hg).cuda()
-    lean = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16")
-    dh_rs = ops.gru_seq_bwd(dout, w, lean[1], lean[3], B, T, G, Hg, "bf16")
-    os.environ["CRUSE_GRU_FWD_LEAN"] = "0"; os.environ["CRUSE_GRU_BWD_RS"] = "0"
+    os.environ["CRUSE_GRU_WLO"] = "0"              # same algorithm == without the lean kernel's W_hh low-plane pass
     try:
+        lean = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16")
+        dh_rs = ops.gru_seq_bwd(dout, w, lean[1], lean[3], B, T, G, Hg, "bf16")
+        os.environ["CRUSE_GRU_FWD_LEAN"] = "0"; os.environ["CRUSE_GRU_BWD_RS"] = "0"
         gen = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16")
         dh_ag = ops.gru_seq_bwd(dout, w, lean[1], lean[3], B, T, G, Hg, "bf16")
     finally:
-        del os.environ["CRUSE_GRU_FWD_LEAN"], os.environ["CRUSE_GRU_BWD_RS"]
+        for k in ("CRUSE_GRU_FWD_LEAN", "CRUSE_GRU_BWD_RS", "CRUSE_GRU_WLO"):
+            os.environ.pop(k, None)
     torch.cuda.synchronize()
     assert ops.gru_status() == 0
     assert rel_l2(lean[0], gen[0]) < 1e-4 and rel_l2(lean[1].float(), gen[1].float()) < 2e-3
     assert rel_l2(dh_rs, dh_ag) < 5e-3
+
+
+@pytest.mark.parametrize("Hg,G", [(160, 4), (320, 2), (640, 1)])
+def test_gru_fwd_w_hh_low_plane(ops, Hg, G):
+    """The lean forward recurrence with W_hh as hi+lo bf16 planes (default for Hg <= 320): closer to the exact-f32
+    recurrence than the single-plane form, on a long sequence where the weight rounding accumulates."""
+    import os
+    B, T = 8, 201
+    torch.manual_seed(3)
+    gi = (0.5 * torch.randn(B, T, G * 3 * Hg)).cuda()
+    w = [(torch.randn(3 * Hg, Hg) / Hg ** 0.5).cuda() for _ in range(G)]
+    b = [(0.1 * torch.randn(3 * Hg)).cuda() for _ in range(G)]
+    ref = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "f32", save=False)[0]
+    err = {}
+    for knob in ("0", "1"):
+        os.environ["CRUSE_GRU_WLO"] = knob
+        try:
+            err[knob] = rel_l2(ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16", save=False)[0], ref)
+        finally:
+            del os.environ["CRUSE_GRU_WLO"]
+    default = rel_l2(ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16", save=False)[0], ref)
+    print(f"[gru W_hh planes Hg={Hg}] rel-L2 vs f32 recurrence: 1 plane {err['0']:.2e}, 2 planes {err['1']:.2e}, default {default:.2e}")
+    assert ops.gru_status() == 0
+    assert err["1"] < 0.7 * err["0"]
+    assert default == pytest.approx(err["1"] if Hg <= 320 else err["0"], rel=0.2)
 
 
 def test_ktile_bf16_and_padded_k_gemm(ops):
