@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the T=401 oracle parity figure (parity_rel_l2)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the f32 gate-mode and hop=320 STFT rows")
+    ap.add_argument("--df", action="store_true", help="BASELINE config 4: DeepFilter(1,5) head + WO-MALE on its output")
     ap.add_argument("--bucketed", action="store_true", help="force the segmented (multi-GPU) schedule at world 1")
     return ap.parse_args()
 
@@ -364,7 +365,8 @@ def main():
         log("parity figure: this model vs the CPU oracle at T=401, B=8 ...")
         parity = parity_figure(model, a.groups, a.prec)
         log(f"parity_rel_l2 = {parity:.3e}")
-    eng = TrainEngine(model, lr=1e-3, use_graph=not a.no_graph, bucketed=True if a.bucketed else None)
+    eng = TrainEngine(model, lr=1e-3, use_graph=not a.no_graph, bucketed=True if a.bucketed else None,
+                      loss="wo_male_df" if a.df else "wo_male")
     B, L = a.batch, int(a.seconds * 16000)
     T = 1 + L // 160
     pool = [synth_batch(B, L, dev, 1234 + 1000 * rank + s) for s in range(4)]
@@ -445,7 +447,8 @@ def main():
             "vs_baseline": None, "dtype": a.prec, "data": "synthetic",
             "config": {"workload": f"CRUSE unet_2 4-layer enc/dec, {a.groups}xGRU group(s), H=640, "
                                    f"{B} clips x {a.seconds:g} s @16 kHz per GPU, n_fft=320 hop=160 (T={T}), "
-                                   "STFT x2 + fwd + WO-MALE + bwd + grad all-reduce + Adam; f32 storage, "
+                                   + ("STFT x2 + fwd + DeepFilter(1,5) head + WO-MALE + bwd" if a.df else "STFT x2 + fwd + WO-MALE + bwd")
+                                   + " + grad all-reduce + Adam; f32 storage, "
                                    f"{a.prec} MFMA operands, f32 accumulate/statistics",
                        "global_batch": world * B, "per_gpu_batch": B, "frames_per_clip": T,
                        "parallelism": f"dp{world}", "hip_graph": not a.no_graph},

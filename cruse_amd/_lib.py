@@ -65,6 +65,22 @@ SIGNATURES = {
     "cruse_adam_step": ("ppppqfffffifp", "i"),
     "cruse_adam_step_guarded": ("ppppqfffffiffppppp", "i"),
     "cruse_sumsq": ("pqpip", "i"),
+    "cruse_conv2d_nchw": ("ppppiiiiiiiiiiiiiiiiiiipip", "i"),
+    "cruse_conv2d_nchw_wgrad": ("pppiiiiiiiiiiiiiiiiip", "i"),
+    "cruse_nchw_channel_sum": ("piiipp", "i"),
+    "cruse_downsum_w": ("pqiipp", "i"),
+    "cruse_bn_nchw_stats": ("piiipp", "i"),
+    "cruse_bn_nchw_fwd": ("ppppppiiiipp", "i"),
+    "cruse_bn_nchw_bwd": ("pppppppiiiiipppppp", "i"),
+    "cruse_stft_framed": ("ppiiiiiiiiifppp", "i"),
+    "cruse_istft_framed": ("ppppiiiiiiiifipp", "i"),
+    "cruse_mask_ops": ("ippppqfffppp", "i"),
+    "cruse_polar": ("ipppqffppp", "i"),
+    "cruse_rmse": ("ppqfppp", "i"),
+    "cruse_c_rmse": ("ppiqffppp", "i"),
+    "cruse_sisnr_plain_finalize": ("pifppp", "i"),
+    "cruse_wo_male_spec": ("pppiqqqfffppp", "i"),
+    "cruse_snr_mix": ("pppiifppppp", "i"),
     "cruse_zero": ("pzp", "i"),
     "cruse_accum_f64": ("ppip", "i"),
     "cruse_counters_add": ("piqp", "i"),

@@ -1,0 +1,340 @@
+// General NCHW building blocks for the reference's OTHER conv-recurrent blocks -- the callers either side of the
+// unet_2 hot path (8f item 2):
+//   model/based_model/cust_conv.py:15-174  Conv2dNormAct / ConvTranspose2dNormAct / convkxf (normal, transposed,
+//                                           upsample = nearest FreqUpsample + Conv2d; depthwise + 1x1)
+//   model/mtfaa.py:39-193                   ComplexConv2d, PhaseEncoder, TFCM_Block (1x1 -> depthwise dilated causal 3x3 -> 1x1)
+// These take arbitrary kernel sizes, dilations, groups and pads, so they do not fit the 640-floats-per-frame
+// frame-major kernels of the hot path (conv_mfma / conv.hip); they run here on the reference's own [B,C,H,W] layout
+// (H,W = T,F for cust_conv; F,T for mtfaa) as direct VALU convolutions, coalesced along W.  All HBM-bound at these
+// channel counts (8..64); one thread per output element, weights through the scalar/L1 path.
+#include "common.h"
+
+namespace {
+
+struct GConv {
+    const float* x; const float* w; const float* bias; float* y;
+    int B, Cin, Hin, Win, Cout, Hout, Wout;
+    int KH, KW, sh, sw, dh, dw, pt, pl;
+    int groups, up_w, transposed, act, accumulate;
+    const float* slope;
+};
+
+// transposed == 0 (nn.Conv2d, weight [Cout][Cin/g][KH][KW]; also the data gradient of a ConvTranspose2d):
+//   y[b,co,ho,wo] = bias[co] + sum_{ci in group, kh, kw} w[co][ci_l][kh][kw] * X[b, ci, ho*sh - pt + kh*dh, wo*sw - pl + kw*dw]
+//   X = x with zero padding; with up_w > 1, X[.., wi] = x[.., wi / up_w] (nearest FreqUpsample, cust_conv.py:177-184,
+//   folded into the gather index: the upsampled tensor is never materialised) and Win is the size BEFORE upsampling.
+// transposed == 1 (nn.ConvTranspose2d, weight [Cin][Cout/g][KH][KW]; also the data gradient of a Conv2d):
+//   y[b,co,ho,wo] = bias[co] + sum_{ci, kh, kw : (ho + pt - kh*dh) % sh == 0, ...} w[ci][co_l][kh][kw] * x[b, ci, (ho + pt - kh*dh)/sh, (wo + pl - kw*dw)/sw]
+__global__ __launch_bounds__(256) void gconv_kernel(GConv a) {
+    const long long total = (long long)a.B * a.Cout * a.Hout * a.Wout;
+    const int cin_g = a.Cin / a.groups, cout_g = a.Cout / a.groups;
+    const int Wup = a.Win * a.up_w;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int wo = (int)(i % a.Wout);
+        long long r = i / a.Wout;
+        const int ho = (int)(r % a.Hout); r /= a.Hout;
+        const int co = (int)(r % a.Cout);
+        const int b = (int)(r / a.Cout);
+        const int g = co / cout_g, co_l = co - g * cout_g;
+        float acc = a.bias ? a.bias[co] : 0.f;
+        const float* xb = a.x + ((long long)b * a.Cin + (long long)g * cin_g) * a.Hin * a.Win;
+        for (int kh = 0; kh < a.KH; ++kh) {
+            int hi;
+            if (!a.transposed) {
+                hi = ho * a.sh - a.pt + kh * a.dh;
+            } else {
+                const int num = ho + a.pt - kh * a.dh;
+                if (num < 0 || num % a.sh) continue;
+                hi = num / a.sh;
+            }
+            if (hi < 0 || hi >= a.Hin) continue;
+            for (int kw = 0; kw < a.KW; ++kw) {
+                int wi;
+                if (!a.transposed) {
+                    wi = wo * a.sw - a.pl + kw * a.dw;
+                    if (wi < 0 || wi >= Wup) continue;
+                    wi /= a.up_w;
+                } else {
+                    const int num = wo + a.pl - kw * a.dw;
+                    if (num < 0 || num % a.sw) continue;
+                    wi = num / a.sw;
+                    if (wi >= a.Win) continue;
+                }
+                const float* xp = xb + (long long)hi * a.Win + wi;
+                if (!a.transposed) {
+                    const float* wp = a.w + (((long long)co * cin_g) * a.KH + kh) * a.KW + kw;
+                    for (int ci = 0; ci < cin_g; ++ci)
+                        acc += wp[(long long)ci * a.KH * a.KW] * xp[(long long)ci * a.Hin * a.Win];
+                } else {
+                    const float* wp = a.w + ((((long long)g * cin_g) * cout_g + co_l) * a.KH + kh) * a.KW + kw;
+                    for (int ci = 0; ci < cin_g; ++ci)
+                        acc += wp[(long long)ci * cout_g * a.KH * a.KW] * xp[(long long)ci * a.Hin * a.Win];
+                }
+            }
+        }
+        if (a.act == 1) acc = fmaxf(acc, 0.f);
+        else if (a.act == 2) acc = acc >= 0.f ? acc : a.slope[co] * acc;
+        if (a.accumulate) a.y[i] += acc; else a.y[i] = acc;
+    }
+}
+
+// Weight gradient of both forms as ONE contraction:
+//   dw[ca][cb_l][kh][kw] += sum_{n,h,w} S[n,ca,h,w] * Bg[n, g*CBg + cb_l, h*sh - pt + kh*dh, (w*sw - pl + kw*dw) / up_w]
+// Conv2d:          S = dy (ca = co, HxW = output size), Bg = x;   ConvTranspose2d: S = x (ca = ci), Bg = dy.
+struct GWgrad {
+    const float* S; const float* Bg; float* dw;
+    int N, CA, HS, WS, CB, HB, WB;
+    int KH, KW, sh, sw, dh, dw_, pt, pl, groups, up_w;
+};
+__global__ __launch_bounds__(256) void gconv_wgrad_kernel(GWgrad a) {
+    __shared__ float red[4];
+    const int cb_g = a.CB / a.groups, ca_g = a.CA / a.groups;
+    int wi_ = blockIdx.x;                                   // weight element
+    const int kw = wi_ % a.KW; wi_ /= a.KW;
+    const int kh = wi_ % a.KH; wi_ /= a.KH;
+    const int cb_l = wi_ % cb_g;
+    const int ca = wi_ / cb_g;
+    const int g = ca / ca_g;
+    const int cb = g * cb_g + cb_l;
+    const int Wup = a.WB * a.up_w;
+    const int hw = a.HS * a.WS;
+    float acc = 0.f;
+    for (int n = blockIdx.y; n < a.N; n += gridDim.y) {
+        const float* sp = a.S + ((long long)n * a.CA + ca) * hw;
+        const float* bp = a.Bg + ((long long)n * a.CB + cb) * a.HB * a.WB;
+        for (int i = threadIdx.x; i < hw; i += 256) {
+            const int h = i / a.WS, w = i - h * a.WS;
+            const int hb = h * a.sh - a.pt + kh * a.dh;
+            int wb = w * a.sw - a.pl + kw * a.dw_;
+            if (hb < 0 || hb >= a.HB || wb < 0 || wb >= Wup) continue;
+            wb /= a.up_w;
+            acc += sp[i] * bp[(long long)hb * a.WB + wb];
+        }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&a.dw[blockIdx.x], red[0] + red[1] + red[2] + red[3]);
+}
+
+// out[c] += sum_{n,hw} x[n,c,hw]   (conv bias gradient)
+__global__ __launch_bounds__(256) void nchw_channel_sum_kernel(const float* x, int N, int C, int HW, float* out) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    float acc = 0.f;
+    for (int n = blockIdx.y; n < N; n += gridDim.y) {
+        const float* p = x + ((long long)n * C + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += 256) acc += p[i];
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&out[c], red[0] + red[1] + red[2] + red[3]);
+}
+
+// dx[.., w0] = sum_{j < up} dxu[.., w0*up + j]   (gradient of the nearest FreqUpsample)
+__global__ void downsum_w_kernel(const float* dxu, long long rows, int W, int up, float* dx) {
+    const long long n = rows * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / W;
+        const int w = (int)(i - r * W);
+        float s = 0.f;
+        for (int j = 0; j < up; ++j) s += dxu[r * W * up + (long long)w * up + j];
+        dx[i] = s;
+    }
+}
+
+// ---- BatchNorm2d on NCHW (+ ReLU / PReLU) ---------------------------------------------------------
+// sums[c] = sum x, sums[C + c] = sum x^2 in f64 (cruse_bn_finalize turns them into mean / rstd / running stats)
+__global__ __launch_bounds__(256) void bn_nchw_stats_kernel(const float* x, int N, int C, int HW, double* sums) {
+    __shared__ double red[2][4];
+    const int c = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int n = blockIdx.y; n < N; n += gridDim.y) {
+        const float* p = x + ((long long)n * C + c) * HW;
+        float a1 = 0.f, a2 = 0.f;
+        for (int i = threadIdx.x; i < HW; i += 256) { const float v = p[i]; a1 += v; a2 += v * v; }
+        s1 += a1; s2 += a2;
+    }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[c], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(&sums[C + c], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
+// y = act(gamma * (x - mean) * rstd + beta); mean == NULL: no normalisation (plain activation of x)
+__global__ void bn_nchw_fwd_kernel(const float* x, const float* mean, const float* rstd, const float* gamma,
+                                   const float* beta, const float* slope, int act, long long total, int C, int HW, float* y) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)((i / HW) % C);
+        float z = x[i];
+        if (mean) z = (z - mean[c]) * rstd[c] * gamma[c] + beta[c];
+        if (act == 1) z = fmaxf(z, 0.f);
+        else if (act == 2) z = z >= 0.f ? z : slope[c] * z;
+        y[i] = z;
+    }
+}
+
+// per channel: r[c] = sum dz, r[C+c] = sum dz * xhat, r[2C+c] = sum dy * min(z, 0) (PReLU slope gradient); dz = dy through act
+__global__ __launch_bounds__(256) void bn_nchw_bwd_reduce_kernel(const float* dy, const float* x, const float* mean,
+                                                                 const float* rstd, const float* gamma, const float* beta,
+                                                                 const float* slope, int act, int N, int C, int HW,
+                                                                 double* r) {
+    __shared__ double red[3][4];
+    const int c = blockIdx.x;
+    const float m = mean ? mean[c] : 0.f, rs = mean ? rstd[c] : 1.f, ga = mean ? gamma[c] : 1.f, be = mean ? beta[c] : 0.f;
+    const float sl = act == 2 ? slope[c] : 0.f;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int n = blockIdx.y; n < N; n += gridDim.y) {
+        const long long o = ((long long)n * C + c) * HW;
+        float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            const float xh = (x[o + i] - m) * rs;
+            const float z = xh * ga + be;
+            float d = dy[o + i];
+            if (act == 1) d = z > 0.f ? d : 0.f;
+            else if (act == 2) { if (z < 0.f) { a3 += d * z; d *= sl; } }
+            a1 += d; a2 += d * xh;
+        }
+        s1 += a1; s2 += a2; s3 += a3;
+    }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2); s3 = wave_sum_d(s3);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; red[2][threadIdx.x >> 6] = s3; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&r[c], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(&r[C + c], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        atomicAdd(&r[2 * C + c], red[2][0] + red[2][1] + red[2][2] + red[2][3]);
+    }
+}
+
+// dx = gamma * rstd * (dz - [training] (mean(dz) + xhat * mean(dz * xhat)));  mean == NULL: dx = dz
+__global__ void bn_nchw_bwd_apply_kernel(const float* dy, const float* x, const float* mean, const float* rstd,
+                                         const float* gamma, const float* beta, const float* slope, int act,
+                                         const double* r, double inv_count, int training, long long total, int C, int HW,
+                                         float* dx) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)((i / HW) % C);
+        const float m = mean ? mean[c] : 0.f, rs = mean ? rstd[c] : 1.f, ga = mean ? gamma[c] : 1.f, be = mean ? beta[c] : 0.f;
+        const float xh = (x[i] - m) * rs;
+        const float z = xh * ga + be;
+        float d = dy[i];
+        if (act == 1) d = z > 0.f ? d : 0.f;
+        else if (act == 2) d = z >= 0.f ? d : slope[c] * d;
+        if (mean) {
+            if (training) d -= (float)(r[c] * inv_count) + xh * (float)(r[C + c] * inv_count);
+            d *= ga * rs;
+        }
+        dx[i] = d;
+    }
+}
+
+// dgamma += r[C+c], dbeta += r[c], dslope += r[2C+c]
+__global__ void bn_nchw_param_grads_kernel(const double* r, int C, float* dgamma, float* dbeta, float* dslope) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (dbeta) dbeta[c] += (float)r[c];
+    if (dgamma) dgamma[c] += (float)r[C + c];
+    if (dslope) dslope[c] += (float)r[2 * C + c];
+}
+
+inline int gblocks(long long n, int per = 1024, int cap = 8192) {
+    long long g = (n + per - 1) / per;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+}  // namespace
+
+#define ST(s) ((hipStream_t)(s))
+
+extern "C" int cruse_conv2d_nchw(const float* x, const float* w, const float* bias, float* y,
+                                 int B, int Cin, int Hin, int Win, int Cout, int Hout, int Wout,
+                                 int KH, int KW, int sh, int sw, int dh, int dw, int pt, int pl,
+                                 int groups, int up_w, int transposed, int act, const float* slope, int accumulate,
+                                 void* stream) {
+    CRUSE_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, CRUSE_E_SHAPE,
+                  "conv2d_nchw: bad shape B=%d Cin=%d Cout=%d in %dx%d out %dx%d", B, Cin, Cout, Hin, Win, Hout, Wout);
+    CRUSE_REQUIRE(KH > 0 && KW > 0 && sh > 0 && sw > 0 && dh > 0 && dw > 0 && groups > 0 && up_w > 0, CRUSE_E_SHAPE,
+                  "conv2d_nchw: bad kernel geometry");
+    CRUSE_REQUIRE(Cin % groups == 0 && Cout % groups == 0, CRUSE_E_SHAPE, "conv2d_nchw: channels %d/%d not divisible by groups %d", Cin, Cout, groups);
+    CRUSE_REQUIRE(!(transposed && up_w != 1), CRUSE_E_SHAPE, "conv2d_nchw: upsampling only with the conv form");
+    CRUSE_REQUIRE(act >= 0 && act <= 2 && (act != 2 || slope) && !(accumulate && act), CRUSE_E_SHAPE, "conv2d_nchw: bad activation");
+    GConv a = {x, w, bias, y, B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, sh, sw, dh, dw, pt, pl, groups, up_w, transposed, act,
+               accumulate, slope};
+    hipLaunchKernelGGL(gconv_kernel, dim3(gblocks((long long)B * Cout * Hout * Wout, 256, 16384)), dim3(256), 0, ST(stream), a);
+    CRUSE_LAUNCH_CHECK("conv2d_nchw");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_conv2d_nchw_wgrad(const float* S, const float* Bg, float* dw,
+                                       int N, int CA, int HS, int WS, int CB, int HB, int WB,
+                                       int KH, int KW, int sh, int sw, int dh, int dw_, int pt, int pl,
+                                       int groups, int up_w, void* stream) {
+    CRUSE_REQUIRE(N > 0 && CA > 0 && CB > 0 && HS > 0 && WS > 0 && HB > 0 && WB > 0 && KH > 0 && KW > 0, CRUSE_E_SHAPE,
+                  "conv2d_nchw_wgrad: bad shape");
+    CRUSE_REQUIRE(CA % groups == 0 && CB % groups == 0 && up_w > 0, CRUSE_E_SHAPE, "conv2d_nchw_wgrad: groups");
+    GWgrad a = {S, Bg, dw, N, CA, HS, WS, CB, HB, WB, KH, KW, sh, sw, dh, dw_, pt, pl, groups, up_w};
+    const int nw = CA * (CB / groups) * KH * KW;
+    int ny = 1;
+    while (ny < N && (long long)nw * ny < 2048) ny *= 2;
+    if (ny > N) ny = N;
+    hipLaunchKernelGGL(gconv_wgrad_kernel, dim3(nw, ny), dim3(256), 0, ST(stream), a);
+    CRUSE_LAUNCH_CHECK("conv2d_nchw_wgrad");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_nchw_channel_sum(const float* x, int N, int C, int HW, float* out, void* stream) {
+    CRUSE_REQUIRE(N > 0 && C > 0 && HW > 0, CRUSE_E_SHAPE, "nchw_channel_sum: bad shape");
+    hipLaunchKernelGGL(nchw_channel_sum_kernel, dim3(C, N < 16 ? N : 16), dim3(256), 0, ST(stream), x, N, C, HW, out);
+    CRUSE_LAUNCH_CHECK("nchw_channel_sum");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_downsum_w(const float* dxu, long long rows, int W, int up, float* dx, void* stream) {
+    CRUSE_REQUIRE(rows > 0 && W > 0 && up > 0, CRUSE_E_SHAPE, "downsum_w: bad shape");
+    hipLaunchKernelGGL(downsum_w_kernel, dim3(gblocks(rows * W)), dim3(256), 0, ST(stream), dxu, rows, W, up, dx);
+    CRUSE_LAUNCH_CHECK("downsum_w");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_bn_nchw_stats(const float* x, int N, int C, int HW, double* sums, void* stream) {
+    CRUSE_REQUIRE(N > 0 && C > 0 && HW > 0, CRUSE_E_SHAPE, "bn_nchw_stats: bad shape");
+    { int rc = cruse_zero_async(sums, 2 * (size_t)C * sizeof(double), ST(stream), "bn_nchw_stats"); if (rc) return rc; }
+    hipLaunchKernelGGL(bn_nchw_stats_kernel, dim3(C, N < 32 ? N : 32), dim3(256), 0, ST(stream), x, N, C, HW, sums);
+    CRUSE_LAUNCH_CHECK("bn_nchw_stats");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_bn_nchw_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                 const float* slope, int act, int N, int C, int HW, float* y, void* stream) {
+    CRUSE_REQUIRE(N > 0 && C > 0 && HW > 0 && act >= 0 && act <= 2 && (act != 2 || slope), CRUSE_E_SHAPE, "bn_nchw_fwd: bad arguments");
+    CRUSE_REQUIRE((mean == nullptr) == (rstd == nullptr) && (mean == nullptr || (gamma && beta)), CRUSE_E_SHAPE, "bn_nchw_fwd: statistics");
+    const long long total = (long long)N * C * HW;
+    hipLaunchKernelGGL(bn_nchw_fwd_kernel, dim3(gblocks(total)), dim3(256), 0, ST(stream), x, mean, rstd, gamma, beta, slope, act,
+                       total, C, HW, y);
+    CRUSE_LAUNCH_CHECK("bn_nchw_fwd");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_bn_nchw_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                 const float* beta, const float* slope, int act, int training, int N, int C, int HW,
+                                 double* scratch, float* dx, float* dgamma, float* dbeta, float* dslope, void* stream) {
+    CRUSE_REQUIRE(N > 0 && C > 0 && HW > 0 && act >= 0 && act <= 2 && (act != 2 || slope), CRUSE_E_SHAPE, "bn_nchw_bwd: bad arguments");
+    { int rc = cruse_zero_async(scratch, 3 * (size_t)C * sizeof(double), ST(stream), "bn_nchw_bwd"); if (rc) return rc; }
+    hipLaunchKernelGGL(bn_nchw_bwd_reduce_kernel, dim3(C, N < 32 ? N : 32), dim3(256), 0, ST(stream), dy, x, mean, rstd, gamma,
+                       beta, slope, act, N, C, HW, scratch);
+    CRUSE_LAUNCH_CHECK("bn_nchw_bwd_reduce");
+    const long long total = (long long)N * C * HW;
+    hipLaunchKernelGGL(bn_nchw_bwd_apply_kernel, dim3(gblocks(total)), dim3(256), 0, ST(stream), dy, x, mean, rstd, gamma, beta,
+                       slope, act, scratch, 1.0 / ((double)N * HW), training, total, C, HW, dx);
+    CRUSE_LAUNCH_CHECK("bn_nchw_bwd_apply");
+    hipLaunchKernelGGL(bn_nchw_param_grads_kernel, dim3(cdiv(C, 64)), dim3(64), 0, ST(stream), scratch, C,
+                       mean ? dgamma : nullptr, mean ? dbeta : nullptr, act == 2 ? dslope : nullptr);
+    CRUSE_LAUNCH_CHECK("bn_nchw_param_grads");
+    return CRUSE_OK;
+}

@@ -19,6 +19,35 @@ def synth_batch(batch: int, length: int, device, seed: int):
     return (clean + noise).contiguous(), clean.contiguous()
 
 
+def snr_mix(clean_y: torch.Tensor, noise_y: torch.Tensor, snr, eps: float = 1e-7, return_parts: bool = False):
+    """SynDataset.snr_mix (dataset/dataset.py:236-264) for a whole batch ON THE GPU: peak-normalise clean and noise,
+    scale the noise by clean_rms / 10^(snr/20) / (noise_rms + eps), mix.  clean_y, noise_y [B,L] (or [L]); snr: dB, scalar
+    or [B].  Returns noisy (and the normalised clean / scaled noise with return_parts).  The reference's function ends
+    after drawing `noisy_target_dB_FS` (the file is truncated there); RIR convolution is the caller's (host) step."""
+    from . import ops
+    from ._lib import check, lib
+    one = clean_y.dim() == 1
+    c = clean_y.reshape(1, -1) if one else clean_y
+    n = noise_y.reshape(1, -1) if one else noise_y
+    if c.shape != n.shape or c.dim() != 2:
+        raise RuntimeError(f"snr_mix: clean {tuple(clean_y.shape)} and noise {tuple(noise_y.shape)} must match ([B,L] or [L])")
+    c = c.contiguous().float(); n = n.contiguous().float()
+    B, L = c.shape
+    snr_t = torch.as_tensor(snr, dtype=torch.float32, device=c.device).reshape(-1)
+    if snr_t.numel() == 1:
+        snr_t = snr_t.expand(B)
+    snr_t = snr_t.contiguous()
+    scratch = torch.empty(3 * B, device=c.device, dtype=torch.float64)
+    noisy = torch.empty_like(c)
+    co = torch.empty_like(c) if return_parts else None
+    no = torch.empty_like(c) if return_parts else None
+    check(lib.cruse_snr_mix(ops._p(c), ops._p(n), ops._p(snr_t), B, L, eps, ops._p(scratch), ops._p(co), ops._p(no), ops._p(noisy),
+                            ops._stream()))
+    if one:
+        noisy = noisy[0]; co = None if co is None else co[0]; no = None if no is None else no[0]
+    return (noisy, co, no) if return_parts else noisy
+
+
 class SyntheticPairs(Dataset):
     """[train_dataset] plug-in: path = "cruse_amd.data.SyntheticPairs", args = {num, length, seed}."""
 

@@ -31,7 +31,7 @@ from .model.cruse_net import N_BUCKETS, SIDE, bucket_of, unet2_backward, unet2_f
 
 ALIGN = 64  # floats
 
-LOSSES = ("wo_male", "si_snr", "sdnr")
+LOSSES = ("wo_male", "si_snr", "sdnr", "wo_male_df")
 
 
 def unused_parameter(name: str) -> bool:
@@ -168,8 +168,11 @@ class FlatParams:
 
 
 class TrainEngine:
-    """loss: "wo_male" (loss_func/loss.py:121-148, alpha/beta), "si_snr" (train_base/loss.py:7-25 through the iSTFT)
-    or "sdnr" (loss_func/loss.py:151-175 with the mask as gain; `snr_db`, `sdnr_beta_db`).
+    """loss: "wo_male" (loss_func/loss.py:121-148, alpha/beta), "si_snr" (train_base/loss.py:7-25 through the iSTFT),
+    "sdnr" (loss_func/loss.py:151-175 with the mask as gain; `snr_db`, `sdnr_beta_db`) or "wo_male_df" -- BASELINE
+    config 4: the mask is the real part of a DeepFilter(t_dim=1, f_dim=5) coefficient field (model/deep_filter.py:15-41;
+    DECISION recorded in oracle.train_step_loss: filters = (mask padded to 161 bins, 0)), the enhanced spectrum is the
+    filter output and WO-MALE is taken on it.
     clip_grad_norm > 0: torch.nn.utils.clip_grad_norm_ semantics on the (averaged) gradient, folded into Adam.
     bucketed: None = when world > 1; True forces the segmented schedule (tests, single-GPU cost measurements)."""
 
@@ -219,7 +222,7 @@ class TrainEngine:
         cre = cim = cmag = None
         if self.loss == "wo_male":
             _, _, cmag = ops.stft(clean, self.n_fft, self.hop, want_ri=False, mag_bins=self.f_stft, mag_eps=0.0)
-        elif self.loss == "sdnr":
+        elif self.loss in ("sdnr", "wo_male_df"):
             cre, cim, _ = ops.stft(clean, self.n_fft, self.hop)
         mask, ctx = unet2_forward(mag.view(B, 1, T, self.f_net), self.flat.P, self.Bf, self.model.ch,
                                   self.model.rnn_groups, self.prec, training=training, save=training,
@@ -235,6 +238,9 @@ class TrainEngine:
             loss_sum, _, dlogit = ops.mask_sdnr(mask, cre, cim, nre, nim, rows, self.f_net, self.f_stft, B, self.snr_db,
                                                 self.sdnr_beta_db, want_dlogit=training)
             self._norm = float(B * self.f_stft)
+        elif self.loss == "wo_male_df":
+            loss_sum, dlogit = self._deepfilter_loss(mask, nre, nim, cre, cim, B, T, training)
+            self._norm = float(rows * self.f_stft)
         else:
             # waveform in -> waveform loss: est = iSTFT(mask * N); SI-SNR(est, clean) and back through both
             ere, eim = ops.mask_apply(mask, nre, nim, rows, self.f_net, self.f_stft)
@@ -246,6 +252,37 @@ class TrainEngine:
                 dlogit = ops.mask_apply_bwd(dre, dim, nre, nim, mask, rows, self.f_net, self.f_stft)
             self._norm = 1.0
         return loss_sum, dlogit, ctx
+
+    def _deepfilter_loss(self, mask, nre, nim, cre, cim, B, T, training):
+        """DeepFilter(1, 5) head + WO-MALE on its output.  The spectra are frame-major [B,T,F]; the kernel takes [B,F',T']
+        planes, so it is called with the roles of the two axes (and of t_dim / f_dim) exchanged -- no transposition."""
+        from ._lib import check, lib
+        Fs, Fn, rows = self.f_stft, self.f_net, B * T
+        dev = mask.device
+        key = (B, T)
+        if getattr(self, "_df_const", None) is None or self._df_const[0] != key:
+            self._df_const = (key, torch.ones(rows, Fs, device=dev), torch.zeros(rows, Fs, device=dev))
+        _, ones, zeros = self._df_const
+        hr, _ = ops.mask_apply(mask, ones, zeros, rows, Fn, Fs)              # mask padded with the zero Nyquist bin (R8)
+        hi = zeros
+        f_dim, t_dim = 5, 1
+        est = torch.empty(2, B, T, Fs, device=dev)
+        o_r, o_i = ops.deepfilter_fwd(nre.view(B, T, Fs), nim.view(B, T, Fs), hr.view(B, T, Fs), hi.view(B, T, Fs), t_dim, f_dim,
+                                      out=(est[0], est[1]))
+        self._last_est = est
+        ref = torch.stack([cre.view(B, T, Fs), cim.view(B, T, Fs)])          # [2,B,T,F] planes (device copy)
+        unp = torch.stack([nre.view(B, T, Fs), nim.view(B, T, Fs)])
+        loss_sum = torch.empty(1, device=dev, dtype=torch.float64)
+        dest = torch.empty_like(est) if training else None
+        TF = T * Fs
+        check(lib.cruse_wo_male_spec(ops._p(ref), ops._p(est), ops._p(unp), B, TF, TF, B * TF, self.loss_alpha, self.loss_beta,
+                                     1.0, ops._p(loss_sum), ops._p(dest), ops._stream()))
+        if not training:
+            return loss_sum, None
+        _, _, dhr, _ = ops.deepfilter_bwd(dest[0], dest[1], nre.view(B, T, Fs), nim.view(B, T, Fs), hr.view(B, T, Fs),
+                                          hi.view(B, T, Fs), t_dim, f_dim)
+        dlogit = ops.mask_apply_bwd(dhr.view(rows, Fs), zeros, ones, zeros, mask, rows, Fn, Fs)
+        return loss_sum, dlogit
 
     # -- one forward + loss + backward, gradients left in flat.grads --------------------
     def _fwd_bwd(self, noisy: torch.Tensor, clean: torch.Tensor, boundary=None) -> torch.Tensor:

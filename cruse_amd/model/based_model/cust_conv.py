@@ -1,0 +1,274 @@
+"""MI355X-native `model.based_model.cust_conv` conv / grouped-GRU blocks (8f item 2).
+
+Same constructor arguments, child modules (hence state-dict keys and default initialisation) and forward semantics as
+model/based_model/cust_conv.py:15-184 (Conv2dNormAct, ConvTranspose2dNormAct, convkxf with its normal / transposed /
+upsample modes and the depthwise + 1x1 form, FreqUpsample) and :250-416 (GroupedGRULayer, GroupGRU with the inter-layer
+shuffle and add_outputs).  The children are parameter containers; forward runs the fused HIP kernels of
+cruse_amd/nn_generic.py (conv blocks) and the persistent GRU recurrence kernels (cruse_amd/csrc/gru.hip).
+Layout is the reference's [B,C,T,F] / [B,T,I].  No CPU path.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import List, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from ... import ops
+from ...nn_generic import FreqUpsample, HipSequential  # noqa: F401  (FreqUpsample is part of this module's surface)
+
+
+class Conv2dNormAct(HipSequential):
+    """cust_conv.py:15-62.  [B,C,T,F]; causal pad of kernel_size[0]-1 frames on top, frequency stride `fstride`."""
+
+    def __init__(self, in_ch, out_ch, kernel_size, fstride=1, dilation=1, fpad=True, bias=True, separable=False,
+                 norm_layer=torch.nn.BatchNorm2d, activation_layer=torch.nn.ReLU):
+        lookahead = 0
+        kernel_size = (kernel_size, kernel_size) if isinstance(kernel_size, int) else tuple(kernel_size)
+        fpad_ = kernel_size[1] // 2 + dilation - 1 if fpad else 0                     # :33-36
+        pad = (0, 0, kernel_size[0] - 1 - lookahead, lookahead)                        # :37
+        layers = []
+        if any(x > 0 for x in pad):
+            layers.append(nn.ConstantPad2d(pad, 0.0))
+        groups = math.gcd(in_ch, out_ch) if separable else 1                           # :41
+        if groups == 1:
+            separable = False
+        if max(kernel_size) == 1:
+            separable = False
+        layers.append(nn.Conv2d(in_ch, out_ch, kernel_size, padding=(0, fpad_), stride=(1, fstride),
+                                dilation=(1, dilation), groups=groups, bias=bias))    # :46-55
+        if separable:
+            layers.append(nn.Conv2d(out_ch, out_ch, kernel_size=1, bias=False))        # :56-57
+        if norm_layer is not None:
+            layers.append(norm_layer(out_ch))
+        if activation_layer is not None:
+            layers.append(activation_layer())
+        super().__init__(*layers)
+
+
+class ConvTranspose2dNormAct(HipSequential):
+    """cust_conv.py:65-111."""
+
+    def __init__(self, in_ch, out_ch, kernel_size, fstride=1, dilation=1, fpad=True, bias=True, separable=False,
+                 norm_layer=torch.nn.BatchNorm2d, activation_layer=torch.nn.ReLU):
+        lookahead = 0
+        kernel_size = (kernel_size, kernel_size) if isinstance(kernel_size, int) else kernel_size
+        fpad_ = kernel_size[1] // 2 if fpad else 0                                     # :79-82
+        pad = (0, 0, kernel_size[0] - 1 - lookahead, lookahead)
+        layers = []
+        if any(x > 0 for x in pad):
+            layers.append(nn.ConstantPad2d(pad, 0.0))
+        groups = math.gcd(in_ch, out_ch) if separable else 1
+        if groups == 1:
+            separable = False
+        layers.append(nn.ConvTranspose2d(in_ch, out_ch, kernel_size=kernel_size,
+                                         padding=(kernel_size[0] - 1, fpad_ + dilation - 1), output_padding=(0, fpad_),
+                                         stride=(1, fstride), dilation=(1, dilation), groups=groups, bias=bias))  # :93-104
+        if separable:
+            layers.append(nn.Conv2d(out_ch, out_ch, kernel_size=1, bias=False))
+        if norm_layer is not None:
+            layers.append(norm_layer(out_ch))
+        if activation_layer is not None:
+            layers.append(activation_layer())
+        super().__init__(*layers)
+
+
+def convkxf(in_ch, out_ch, k=1, f=3, fstride=2, lookahead=0, batch_norm=False, act=None, mode="normal", depthwise=True,
+            complex_in=False):
+    """cust_conv.py:114-174; `act` defaults to nn.ReLU(inplace=True) as there."""
+    if act is None:
+        act = torch.nn.ReLU(inplace=True)
+    bias = batch_norm is False
+    assert f % 2 == 1
+    stride = 1 if f == 1 else (1, fstride)
+    if out_ch is None:
+        out_ch = in_ch * 2 if mode == "normal" else in_ch // 2
+    fpad = (f - 1) // 2
+    convpad = (0, fpad)
+    modules = []
+    pad = [0, 0, k - 1 - lookahead, lookahead]
+    if any(p > 0 for p in pad):
+        modules.append(("pad", nn.ConstantPad2d(pad, 0.0)))
+    groups = min(in_ch, out_ch) if depthwise else 1
+    if in_ch % groups != 0 or out_ch % groups != 0:
+        groups = 1
+    if complex_in and groups % 2 == 0:
+        groups //= 2
+    convkwargs = {"in_channels": in_ch, "out_channels": out_ch, "kernel_size": (k, f), "stride": stride, "groups": groups,
+                  "bias": bias}
+    if mode == "normal":
+        modules.append(("sconv", nn.Conv2d(padding=convpad, **convkwargs)))
+    elif mode == "transposed":
+        modules.append(("sconv", nn.ConvTranspose2d(padding=(k - 1, fpad), output_padding=convpad, **convkwargs)))
+    elif mode == "upsample":
+        modules.append(("upsample", FreqUpsample(fstride)))
+        convkwargs["stride"] = 1
+        modules.append(("sconv", nn.Conv2d(padding=convpad, **convkwargs)))
+    else:
+        raise NotImplementedError()
+    if groups > 1:
+        modules.append(("1x1conv", nn.Conv2d(out_ch, out_ch, 1, bias=False)))
+    if batch_norm:
+        modules.append(("norm", nn.BatchNorm2d(out_ch)))
+    modules.append(("act", act))
+    return HipSequential(OrderedDict(modules))
+
+
+# ======================================================================================================================
+# grouped GRUs
+# ======================================================================================================================
+class _GroupedGruFn(torch.autograd.Function):
+    """g independent nn.GRU(I/g -> H/g) over feature slices, outputs concatenated (cust_conv.py:303-325); h0 = 0.
+    params = (w_ih_0, w_hh_0, b_ih_0, b_hh_0, w_ih_1, ...).  Exact-f32 MFMA kernels (v_mfma_f32_16x16x4_f32)."""
+
+    @staticmethod
+    def forward(ctx, x, g, *params):
+        x = x.contiguous()
+        B, T, I = x.shape
+        Ig = I // g
+        Hg = params[1].shape[1]
+        H = g * Hg
+        rows = B * T
+        gi = torch.empty(B, T, g * 3 * Hg, device=x.device, dtype=torch.float32)
+        for i in range(g):
+            w_ih, b_ih = params[4 * i], params[4 * i + 2]
+            ops.gemm(False, True, rows, 3 * Hg, Ig, x, i * Ig, I, w_ih.contiguous(), 0, Ig, gi, i * 3 * Hg, 3 * H, bias=b_ih,
+                     prec="f32")
+        w_hh = [params[4 * i + 1].contiguous() for i in range(g)]
+        b_hh = [params[4 * i + 3].contiguous() for i in range(g)]
+        need = any(ctx.needs_input_grad)
+        h, coef, an, z = ops.gru_seq_fwd(gi, w_hh, b_hh, B, T, g, Hg, "f32", save=need)
+        ctx.g, ctx.dims = g, (B, T, I, Ig, Hg)
+        ctx.save_for_backward(x, h, coef, an, z, *params)
+        return h
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, h, coef, an, z, *params = ctx.saved_tensors
+        g = ctx.g
+        B, T, I, Ig, Hg = ctx.dims
+        H, rows = g * Hg, B * T
+        w_hh = [params[4 * i + 1].contiguous() for i in range(g)]
+        dh = ops.gru_seq_bwd(dout.contiguous(), w_hh, coef, z, B, T, g, Hg, "f32")
+        dgi, dgh = ops.gru_gate_grads(dh, coef, an, rows, g, Hg, "f32")
+        grads = []
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        sk = max(1, min(8, rows // 512))
+        for i in range(g):
+            w_ih = params[4 * i].contiguous()
+            dw_ih = torch.zeros_like(w_ih); dw_hh = torch.zeros_like(w_hh[i])
+            db_ih = torch.zeros(3 * Hg, device=x.device); db_hh = torch.zeros(3 * Hg, device=x.device)
+            ops.gemm(True, False, 3 * Hg, Ig, rows, dgi, i * 3 * Hg, 3 * H, x, i * Ig, I, dw_ih, 0, Ig, accumulate=True,
+                     splitk=sk, prec="f32")
+            ops.gemm(True, False, 3 * Hg, Hg, rows, dgh, i * 3 * Hg, 3 * H, h, i * Hg, H, dw_hh, 0, Hg, accumulate=True,
+                     splitk=sk, b_shift_T=T, prec="f32")
+            ops.col_sum(dgi, i * 3 * Hg, rows, 3 * Hg, 3 * H, db_ih)
+            ops.col_sum(dgh, i * 3 * Hg, rows, 3 * Hg, 3 * H, db_hh)
+            if dx is not None:
+                ops.gemm(False, False, rows, Ig, 3 * Hg, dgi, i * 3 * Hg, 3 * H, w_ih, 0, Ig, dx, i * Ig, I, prec="f32")
+            grads += [dw_ih, dw_hh, db_ih, db_hh]
+        return (dx, None) + tuple(grads)
+
+
+def _require_zero_state(h0: Optional[Tensor], what: str) -> None:
+    if h0 is not None and bool((h0 != 0).any()):
+        raise RuntimeError(f"{what}: the HIP recurrence starts from h0 = 0 (model/cruse_net.py never passes a state); "
+                           "a non-zero initial state is not supported")
+
+
+class GroupedGRULayer(nn.Module):
+    """cust_conv.py:250-325."""
+
+    def __init__(self, input_size: int, hidden_size: int, groups: int, batch_first: bool = True, bias=True,
+                 dropout: float = 0, bidirectional=False):
+        super().__init__()
+        assert input_size % groups == 0
+        assert hidden_size % groups == 0
+        if bidirectional or not batch_first or not bias or dropout:
+            raise RuntimeError("cruse_amd GroupedGRULayer: unidirectional, batch_first, biased, dropout-free GRUs only")
+        kwargs = {"bias": bias, "batch_first": batch_first, "dropout": dropout, "bidirectional": bidirectional}
+        self.input_size = input_size // groups
+        self.hidden_size = hidden_size // groups
+        self.out_size = hidden_size
+        self.bidirectional = bidirectional
+        self.num_directions = 1
+        self.groups = groups
+        self.batch_first = batch_first
+        assert (self.hidden_size % groups) == 0, "Hidden size must be divisible by groups"       # :284-285
+        if self.hidden_size % 32:
+            raise RuntimeError(f"cruse_amd GroupedGRULayer: hidden size per group {self.hidden_size} must be a multiple of 32")
+        self.layers = nn.ModuleList(nn.GRU(self.input_size, self.hidden_size, **kwargs) for _ in range(groups))
+
+    def flatten_parameters(self):
+        pass
+
+    def get_h0(self, batch_size: int = 1, device: torch.device = torch.device("cpu")):
+        return torch.zeros(self.groups * self.num_directions, batch_size, self.hidden_size, device=device)
+
+    def forward(self, input: Tensor, h0: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+        _require_zero_state(h0, "GroupedGRULayer")
+        params = []
+        for layer in self.layers:
+            params += [layer.weight_ih_l0, layer.weight_hh_l0, layer.bias_ih_l0, layer.bias_hh_l0]
+        out = _GroupedGruFn.apply(input, self.groups, *params)
+        B, T, H = out.shape
+        # final states [G*D, B, H/g] = the last frame of every group's slice (cust_conv.py:323)
+        h = out[:, -1, :].reshape(B, self.groups, self.hidden_size).transpose(0, 1).contiguous()
+        return out, h
+
+
+class GroupGRU(nn.Module):
+    """cust_conv.py:328-416: stacked GroupedGRULayers with the inter-layer feature shuffle
+    view(B,T,-1,g).transpose(2,3) (:408-410) and optional add_outputs."""
+
+    def __init__(self, input_size, hidden_size, num_layers=1, groups=4, bias=True, batch_first=True, dropout=0.,
+                 bidirectional=False, shuffle=True, add_outputs=False):
+        super().__init__()
+        kwargs = {"groups": groups, "bias": bias, "batch_first": batch_first, "dropout": dropout,
+                  "bidirectional": bidirectional}
+        assert input_size % groups == 0
+        assert hidden_size % groups == 0
+        assert num_layers > 0
+        self.input_size = input_size
+        self.groups = groups
+        self.num_layers = num_layers
+        self.batch_first = batch_first
+        self.hidden_size = hidden_size // groups
+        self.bidirectional = bidirectional
+        self.num_directions = 1
+        if self.groups == 1:
+            shuffle = False
+        self.shuffle = shuffle
+        self.add_outputs = add_outputs
+        self.grus = nn.ModuleList()
+        self.grus.append(GroupedGRULayer(input_size, hidden_size, **kwargs))
+        for _ in range(1, num_layers):
+            self.grus.append(GroupedGRULayer(hidden_size, hidden_size, **kwargs))
+
+    def flatten_parameters(self):
+        pass
+
+    def get_h0(self, batch_size: int, device=None) -> Tensor:
+        # the reference's forward calls get_h0(b, input.device) against a one-argument signature (:383-389,:397): the
+        # evident intent (device optional) is what is implemented
+        return torch.zeros((self.num_layers * self.groups * self.num_directions, batch_size, self.hidden_size), device=device)
+
+    def forward(self, input: Tensor, state: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+        dim0, dim1, _ = input.shape
+        _require_zero_state(state, "GroupGRU")
+        output = None
+        outstates = []
+        for i, gru in enumerate(self.grus):
+            input, s = gru(input, None)
+            outstates.append(s)
+            if self.shuffle and i < self.num_layers - 1:
+                # a pure permutation of the feature axis: new[b*h + a] = old[a*g + b] (device copy, no arithmetic)
+                input = input.view(dim0, dim1, -1, self.groups).transpose(2, 3).reshape(dim0, dim1, -1)
+            if self.add_outputs:
+                from ...nn_generic import add
+                output = input if output is None else add(output, input.contiguous())
+            else:
+                output = input
+        return output, torch.cat(outstates, dim=0)

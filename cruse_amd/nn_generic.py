@@ -1,0 +1,301 @@
+"""HIP execution of the reference's general [B,C,H,W] conv blocks (cust_conv.py, mtfaa.py).
+
+`HipSequential` is an nn.Sequential whose children are the SAME stock torch.nn modules the reference composes
+(ConstantPad2d, Conv2d, ConvTranspose2d, BatchNorm2d, ReLU, PReLU, FreqUpsample) -- kept as parameter containers so
+constructor arguments, state-dict keys and default initialisation match -- but whose forward walks the children and
+runs fused HIP kernels (cruse_amd/csrc/generic.hip): zero pads and the nearest frequency upsampling fold into the
+following convolution's gather index, an activation folds into the preceding BatchNorm (or convolution).
+There is no CPU path.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import check, lib
+
+_p = ops._p
+_stream = ops._stream
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else (int(v[0]), int(v[1]))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# raw kernel wrappers
+# ------------------------------------------------------------------------------------------------------------------
+def _conv_raw(x, w, bias, out_hw, KH, KW, stride, dil, pt, pl, groups, up_w, transposed, Cout, act=0, slope=None,
+              out=None, accumulate=False):
+    B, Cin, Hin, Win = x.shape
+    Hout, Wout = out_hw
+    y = torch.empty(B, Cout, Hout, Wout, device=x.device, dtype=torch.float32) if out is None else out
+    check(lib.cruse_conv2d_nchw(_p(x), _p(w), _p(bias), _p(y), B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, stride[0], stride[1],
+                                dil[0], dil[1], pt, pl, groups, up_w, 1 if transposed else 0, act, _p(slope),
+                                1 if accumulate else 0, _stream()))
+    return y
+
+
+def _wgrad_raw(S, Bg, dw, KH, KW, stride, dil, pt, pl, groups, up_w):
+    N, CA, HS, WS = S.shape
+    _, CB, HB, WB = Bg.shape
+    check(lib.cruse_conv2d_nchw_wgrad(_p(S), _p(Bg), _p(dw), N, CA, HS, WS, CB, HB, WB, KH, KW, stride[0], stride[1], dil[0],
+                                      dil[1], pt, pl, groups, up_w, _stream()))
+
+
+def _channel_sum(dy, out):
+    N, C = dy.shape[:2]
+    check(lib.cruse_nchw_channel_sum(_p(dy), N, C, dy[0, 0].numel(), _p(out), _stream()))
+
+
+class _ConvFn(torch.autograd.Function):
+    """Conv2d (transposed=False) or ConvTranspose2d (True) on NCHW with folded zero pads / upsampling."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, cfg):
+        x = x.contiguous(); w = w.contiguous()
+        (stride, dil, pt, pl, groups, up_w, transposed, out_hw) = cfg
+        KH, KW = w.shape[2], w.shape[3]
+        Cout = w.shape[1] * groups if transposed else w.shape[0]
+        y = _conv_raw(x, w, bias, out_hw, KH, KW, stride, dil, pt, pl, groups, up_w, transposed, Cout)
+        ctx.save_for_backward(x, w)
+        ctx.cfg, ctx.has_bias = cfg, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        (stride, dil, pt, pl, groups, up_w, transposed, out_hw) = ctx.cfg
+        dy = dy.contiguous()
+        KH, KW = w.shape[2], w.shape[3]
+        B, Cin, Hin, Win = x.shape
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if not transposed:
+                dxu = _conv_raw(dy, w, None, (Hin, Win * up_w), KH, KW, stride, dil, pt, pl, groups, 1, True, Cin)
+                if up_w > 1:
+                    dx = torch.empty_like(x)
+                    check(lib.cruse_downsum_w(_p(dxu), B * Cin * Hin, Win, up_w, _p(dx), _stream()))
+                else:
+                    dx = dxu
+            else:
+                dx = _conv_raw(dy, w, None, (Hin, Win), KH, KW, stride, dil, pt, pl, groups, 1, False, Cin)
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(w)
+            if not transposed:
+                _wgrad_raw(dy, x, dw, KH, KW, stride, dil, pt, pl, groups, up_w)
+            else:
+                _wgrad_raw(x, dy, dw, KH, KW, stride, dil, pt, pl, groups, 1)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.zeros(dy.shape[1], device=dy.device, dtype=torch.float32)
+            _channel_sum(dy, db)
+        return dx, dw, db, None
+
+
+def conv2d(x, w, bias=None, stride=(1, 1), dilation=(1, 1), pad=(0, 0, 0, 0), groups=1, up_w=1):
+    """F.conv2d on zero-padded x; pad = (top, bottom, left, right); up_w: nearest upsampling of W folded in front."""
+    stride, dilation = _pair(stride), _pair(dilation)
+    pt, pb, pl, pr = pad
+    _, _, Hin, Win = x.shape
+    KH, KW = w.shape[2], w.shape[3]
+    Hout = (Hin + pt + pb - dilation[0] * (KH - 1) - 1) // stride[0] + 1
+    Wout = (Win * up_w + pl + pr - dilation[1] * (KW - 1) - 1) // stride[1] + 1
+    if Hout <= 0 or Wout <= 0:
+        raise RuntimeError(f"conv2d: kernel {KH}x{KW} does not fit the padded input {Hin}x{Win}")
+    return _ConvFn.apply(x, w, bias, (stride, dilation, pt, pl, groups, up_w, False, (Hout, Wout)))
+
+
+def conv_transpose2d(x, w, bias=None, stride=(1, 1), padding=(0, 0), output_padding=(0, 0), dilation=(1, 1), groups=1,
+                     pre_pad_top=0):
+    """F.conv_transpose2d; pre_pad_top: zero rows in front of x along H (ConstantPad2d before the layer), stride_h == 1."""
+    stride, dilation, padding, output_padding = _pair(stride), _pair(dilation), _pair(padding), _pair(output_padding)
+    if pre_pad_top and stride[0] != 1:
+        raise RuntimeError("conv_transpose2d: a folded top pad needs stride 1 along H")
+    _, _, Hin, Win = x.shape
+    KH, KW = w.shape[2], w.shape[3]
+    Hout = (Hin + pre_pad_top - 1) * stride[0] - 2 * padding[0] + dilation[0] * (KH - 1) + output_padding[0] + 1
+    Wout = (Win - 1) * stride[1] - 2 * padding[1] + dilation[1] * (KW - 1) + output_padding[1] + 1
+    return _ConvFn.apply(x, w, bias, (stride, dilation, padding[0] - pre_pad_top, padding[1], groups, 1, True, (Hout, Wout)))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BatchNorm2d (+ ReLU / PReLU) and bare activations
+# ------------------------------------------------------------------------------------------------------------------
+class _BnActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, slope, mean, rstd, act, training):
+        x = x.contiguous()
+        N, C = x.shape[:2]
+        HW = x[0, 0].numel()
+        y = torch.empty_like(x)
+        check(lib.cruse_bn_nchw_fwd(_p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(slope), act, N, C, HW, _p(y), _stream()))
+        ctx.save_for_backward(x, gamma, beta, slope, mean, rstd)
+        ctx.act, ctx.training = act, training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, slope, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, C = x.shape[:2]
+        HW = x[0, 0].numel()
+        dx = torch.empty_like(x)
+        scratch = torch.empty(3 * C, device=x.device, dtype=torch.float64)
+        dg = torch.zeros(C, device=x.device) if gamma is not None else None
+        db = torch.zeros(C, device=x.device) if beta is not None else None
+        ds = torch.zeros(C, device=x.device) if slope is not None else None
+        check(lib.cruse_bn_nchw_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(slope), ctx.act,
+                                    1 if ctx.training else 0, N, C, HW, _p(scratch), _p(dx), _p(dg), _p(db), _p(ds), _stream()))
+        return dx, dg, db, ds, None, None, None, None
+
+
+def _act_code(m) -> Tuple[int, Optional[torch.Tensor]]:
+    if m is None:
+        return 0, None
+    if isinstance(m, nn.ReLU):
+        return 1, None
+    if isinstance(m, nn.PReLU):
+        return 2, m.weight
+    raise RuntimeError(f"HipSequential: activation {type(m).__name__} has no HIP kernel (ReLU, PReLU)")
+
+
+def batchnorm_act(x, bn: Optional[nn.BatchNorm2d], act_module=None):
+    """bn(x) then act, fused; bn None: activation only.  Training mode updates the running statistics like torch."""
+    act, slope = _act_code(act_module)
+    C = x.shape[1]
+    if act == 2 and slope.numel() != C:
+        if slope.numel() != 1:
+            raise RuntimeError("PReLU: num_parameters must be 1 or the channel count")
+        slope = slope.expand(C).contiguous()
+    if bn is None:
+        return _BnActFn.apply(x, None, None, slope, None, None, act, False)
+    training = bn.training or bn.running_mean is None
+    xc = x.contiguous()
+    N = xc.shape[0]
+    HW = xc[0, 0].numel()
+    if training:
+        sums = torch.empty(2 * C, device=x.device, dtype=torch.float64)
+        check(lib.cruse_bn_nchw_stats(_p(xc), N, C, HW, _p(sums), _stream()))
+        upd = bn.training and bn.running_mean is not None
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        mean, rstd = ops.bn_finalize(sums, N * HW, C, bn.eps, mom, bn.running_mean if upd else None,
+                                     bn.running_var if upd else None)
+        if upd and bn.num_batches_tracked is not None:
+            ops.counters_add([bn.num_batches_tracked], 1)
+    else:
+        mean, rstd = ops.bn_eval_stats(bn.running_mean, bn.running_var, bn.eps)
+    return _BnActFn.apply(xc, bn.weight, bn.bias, slope, mean, rstd, act, training)
+
+
+class _AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        out = torch.empty_like(a)
+        return ops.axpby(out, a.contiguous(), b.contiguous(), 1.0, 1.0)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    if a.shape != b.shape:
+        raise RuntimeError(f"add: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
+    return _AddFn.apply(a, b)
+
+
+class FreqUpsample(nn.Module):
+    """cust_conv.py:177-184: nearest interpolation along the last axis; inside a HipSequential it is folded into the
+    following Conv2d, stand-alone it is a 1x1 identity-free gather (conv kernel with a delta weight is avoided: a
+    dedicated call with KH = KW = 1 and a ones depthwise weight)."""
+
+    def __init__(self, factor, mode="nearest"):
+        super().__init__()
+        self.f = float(factor)
+        self.mode = mode
+        if mode != "nearest" or int(self.f) != self.f:
+            raise RuntimeError("cruse_amd FreqUpsample: integer nearest-neighbour factors only")
+
+    def forward(self, x):
+        C = x.shape[1]
+        ones = torch.ones(C, 1, 1, 1, device=x.device, dtype=torch.float32)
+        return conv2d(x, ones, None, groups=C, up_w=int(self.f))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the executor
+# ------------------------------------------------------------------------------------------------------------------
+def _pad4(m: nn.ConstantPad2d):
+    if float(getattr(m, "value", 0.0)) != 0.0:
+        raise RuntimeError("HipSequential: only zero ConstantPad2d folds into the convolution")
+    l, r, t, b = m.padding
+    return int(t), int(b), int(l), int(r)
+
+
+def run_sequential(mods: Sequence[nn.Module], x: torch.Tensor) -> torch.Tensor:
+    if not x.is_cuda:
+        raise RuntimeError("cruse_amd blocks need tensors on the HIP device (no CPU fallback)")
+    mods = list(mods)
+    i = 0
+    pad = (0, 0, 0, 0)
+    up = 1
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.ConstantPad2d):
+            t, b, l, r = _pad4(m)
+            pad = (pad[0] + t, pad[1] + b, pad[2] + l, pad[3] + r)
+            i += 1
+        elif isinstance(m, FreqUpsample):
+            if pad[2] or pad[3]:                   # (a time pad commutes with the frequency upsampling)
+                raise RuntimeError("HipSequential: a frequency pad before FreqUpsample is not supported")
+            up *= int(m.f)
+            i += 1
+        elif isinstance(m, nn.Conv2d) and not isinstance(m, nn.ConvTranspose2d):
+            if m.padding_mode != "zeros" or isinstance(m.padding, str):
+                raise RuntimeError("HipSequential: Conv2d needs numeric zero padding")
+            ph, pw = _pair(m.padding)
+            x = conv2d(x, m.weight, m.bias, m.stride, m.dilation, (pad[0] + ph, pad[1] + ph, pad[2] + pw, pad[3] + pw),
+                       m.groups, up)
+            pad, up = (0, 0, 0, 0), 1
+            i += 1
+        elif isinstance(m, nn.ConvTranspose2d):
+            if up != 1 or pad[1] or pad[2] or pad[3]:
+                raise RuntimeError("HipSequential: only a top zero pad folds into ConvTranspose2d")
+            x = conv_transpose2d(x, m.weight, m.bias, m.stride, m.padding, m.output_padding, m.dilation, m.groups,
+                                 pre_pad_top=pad[0])
+            pad = (0, 0, 0, 0)
+            i += 1
+        elif isinstance(m, nn.BatchNorm2d):
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if isinstance(nxt, (nn.ReLU, nn.PReLU)):
+                x = batchnorm_act(x, m, nxt)
+                i += 2
+            else:
+                x = batchnorm_act(x, m, None)
+                i += 1
+        elif isinstance(m, (nn.ReLU, nn.PReLU)):
+            x = batchnorm_act(x, None, m)
+            i += 1
+        elif isinstance(m, nn.Identity):
+            i += 1
+        else:
+            x = m(x)                              # a nested HIP module (HipSequential, ComplexConv2d, ...)
+            i += 1
+    if pad != (0, 0, 0, 0) or up != 1:
+        raise RuntimeError("HipSequential: trailing pad / upsample without a convolution")
+    return x
+
+
+class HipSequential(nn.Sequential):
+    def forward(self, x):
+        return run_sequential(list(self), x)
+
+
+class HipConv2d(nn.Conv2d):
+    """nn.Conv2d parameters, HIP forward/backward."""
+
+    def forward(self, x):
+        return run_sequential([self], x)

@@ -426,9 +426,9 @@ def sisnr_bwd(x, s, coef, grad_scale=1.0):
     return dx
 
 
-def deepfilter_fwd(xr, xi, hr, hi, f_dim, t_dim):
+def deepfilter_fwd(xr, xi, hr, hi, f_dim, t_dim, out=None):
     B, F, T = xr.shape
-    o_r = torch.empty_like(xr); o_i = torch.empty_like(xr)
+    o_r, o_i = (torch.empty_like(xr), torch.empty_like(xr)) if out is None else out
     check(lib.cruse_deepfilter_fwd(_p(xr), _p(xi), _p(hr), _p(hi), B, F, T, f_dim, t_dim, _p(o_r), _p(o_i), _stream()))
     return o_r, o_i
 

@@ -270,6 +270,78 @@ int cruse_sigmoid_bwd(const float* dmask, const float* mask, float* dlogit, long
 /* out = a*x + b*y elementwise (x or y may alias out) */
 int cruse_axpby(float* out, const float* x, const float* y, float a, float b, long long n, void* stream);
 
+/* ---- general NCHW blocks: the reference's other conv-recurrent modules (cust_conv.py, mtfaa.py) ---------------- */
+
+/* nn.Conv2d / nn.ConvTranspose2d with arbitrary kernel, stride, dilation, groups and zero padding on [B,C,H,W]
+ * (model/based_model/cust_conv.py:47-55,94-104,150-166; model/mtfaa.py:60-73,170-183), optional nearest
+ * FreqUpsample folded into the gather index (cust_conv.py:163-166,177-184) and a fused ReLU / PReLU.
+ *   transposed 0: y[b,co,ho,wo] = bias[co] + sum w[co][ci_l][kh][kw] * X[b,ci, ho*sh-pt+kh*dh, wo*sw-pl+kw*dw],
+ *                 X = zero-padded x (W index divided by up_w when up_w > 1; Win is the size before upsampling)
+ *   transposed 1: gather form of ConvTranspose2d(padding=(pt,pl)), weight [Cin][Cout/g][KH][KW]
+ * The data gradient of either form is the other form with the same weight tensor.  act 0 none, 1 ReLU, 2 PReLU(slope[co]). */
+int cruse_conv2d_nchw(const float* x, const float* w, const float* bias, float* y,
+                      int B, int Cin, int Hin, int Win, int Cout, int Hout, int Wout,
+                      int KH, int KW, int sh, int sw, int dh, int dw, int pt, int pl,
+                      int groups, int up_w, int transposed, int act, const float* slope, int accumulate, void* stream);
+/* dw[ca][cb_l][kh][kw] += sum_{n,h,w} S[n,ca,h,w] * Bg[n, g*CB/groups + cb_l, h*sh-pt+kh*dh, (w*sw-pl+kw*dw_)/up_w]
+ * Conv2d: S = dy, Bg = x.  ConvTranspose2d: S = x, Bg = dy. */
+int cruse_conv2d_nchw_wgrad(const float* S, const float* Bg, float* dw,
+                            int N, int CA, int HS, int WS, int CB, int HB, int WB,
+                            int KH, int KW, int sh, int sw, int dh, int dw_, int pt, int pl,
+                            int groups, int up_w, void* stream);
+/* out[c] += sum_{n,hw} x[n,c,hw] (conv bias gradient) */
+int cruse_nchw_channel_sum(const float* x, int N, int C, int HW, float* out, void* stream);
+/* gradient of the nearest FreqUpsample: dx[..,w] = sum_{j<up} dxu[.., w*up + j] */
+int cruse_downsum_w(const float* dxu, long long rows, int W, int up, float* dx, void* stream);
+/* nn.BatchNorm2d (+ nn.ReLU / nn.PReLU(C)) on [N,C,HW]: batch sums for cruse_bn_finalize; y = act(gamma*(x-mean)*rstd+beta)
+ * (mean == NULL: activation only); backward with the PReLU slope gradient.  scratch: 3*C doubles. */
+int cruse_bn_nchw_stats(const float* x, int N, int C, int HW, double* sums, void* stream);
+int cruse_bn_nchw_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                      const float* slope, int act, int N, int C, int HW, float* y, void* stream);
+int cruse_bn_nchw_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                      const float* beta, const float* slope, int act, int training, int N, int C, int HW,
+                      double* scratch, float* dx, float* dgamma, float* dbeta, float* dslope, void* stream);
+
+/* ---- other STFT formulations (feature.py:272-398 CustomSTFT/CustomISTFT, conv_stft.py:8-129, mtfaa.py:8-37) ------- */
+/* X[b,t,f] = scale * sum_{n<win_len} window[n] * x_pad[b, t*hop + n + win_off - pad] * exp(-2 pi i f (n + win_off)/n_fft),
+ * f = 0..n_fft/2; x_pad: pad_mode 0 zeros / 1 reflect outside the clip.  re, im [B,T,n_fft/2+1]. */
+int cruse_stft_framed(const float* wave, const float* window, int B, int L, int n_fft, int win_len, int win_off,
+                      int hop, int pad, int pad_mode, int T, float scale, float* re, float* im, void* stream);
+/* overlap-add adjoint: out[b,m] = post[m] * sum_{t,n: t*hop+n+win_off-pad == m} window[n]*scale*sum_f c_f (re cos - im sin);
+ * hermitian 0: c_f = 1 (conv_transpose1d with the analysis kernel, feature.py:395); 1: c_f = 1,2,..,2,1 (inverse DFT of a
+ * one-sided spectrum, conv_stft.py:106-122).  post: L per-sample factors (1 / window-overlap envelope) or NULL. */
+int cruse_istft_framed(const float* re, const float* im, const float* window, const float* post, int B, int T,
+                       int n_fft, int win_len, int win_off, int hop, int pad, int L, float scale, int hermitian,
+                       float* out, void* stream);
+
+/* ---- masks, further losses, data synthesis ------------------------------------------------------------------------ */
+/* train_base/acoustics/mask.py:8-63.  mode 0 IRM (a = noisy_mag, c = clean_mag), 1 cIRM (a,b = noisy re,im; c,d = clean
+ * re,im; out [n,2]), 2 compress_cIRM(a), 3 decompress_cIRM(a), 4 complex_mul (a + ib)(c + id) -> out, out2. */
+int cruse_mask_ops(int mode, const float* a, const float* b, const float* c, const float* d, long long n,
+                   float K, float C, float limit, float* out, float* out2, void* stream);
+/* mode 0: (re, im) -> (sqrt(re^2+im^2+eps)**alpha, atan2(im, re)) (feature.py:363-364, mtfaa.py:136-137,162);
+ * mode 1: (mag, phase) -> (mag cos, mag sin) (feature.py:386-387); mode 2: gradient of mode 0's magnitude (g = upstream). */
+int cruse_polar(int mode, const float* a, const float* b, const float* g, long long n, float eps, float alpha,
+                float* o1, float* o2, void* stream);
+/* rmse (loss_func/loss.py:59-78): loss_sum = sum |est - ref| (divide by B*T*F); dest = sign(est-ref)*grad_scale (may be NULL) */
+int cruse_rmse(const float* ref, const float* est, long long n, float grad_scale, double* loss_sum, float* dest, void* stream);
+/* c_rmse (loss_func/loss.py:88-118) as written; ref, est [B,2,TF]; dest = d loss / d est (may be NULL) */
+int cruse_c_rmse(const float* ref, const float* est, int B, long long TF, float c, float beta, double* loss_sum, float* dest,
+                 void* stream);
+/* wo_male (loss_func/loss.py:121-148) on explicit spectra ref, est, unproc: element (b, j) has its real part at
+ * b*bstride + j and its imaginary part pstride further ([B,2,TF]: 2*TF, TF; [2,B,TF]: TF, B*TF).  loss_sum (divide by
+ * B*T*F) and dest = grad_scale * d loss_sum / d est (may be NULL).  The mask-only step uses the fused cruse_mask_loss_fwd;
+ * the DeepFilter step (BASELINE config 4) uses this form on the filtered spectrum. */
+int cruse_wo_male_spec(const float* ref, const float* est, const float* unproc, int B, long long TF, long long bstride,
+                       long long pstride, float alpha, float beta, float grad_scale, double* loss_sum, float* dest, void* stream);
+/* sisnr (loss_func/loss.py:48-56, no mean removal) from the moments cruse_sisnr_fwd's first pass leaves in `mom`:
+ * value = mean_b 10 log10(.), coef [B,4] for cruse_sisnr_bwd (gradient of the VALUE; the loss is its negative) */
+int cruse_sisnr_plain_finalize(const double* mom, int B, float eps, double* value, float* coef, void* stream);
+/* SynDataset.snr_mix (dataset/dataset.py:236-264) for B clips at once: peak-normalise both, scale the noise to snr_db[b]
+ * from the RMS ratio, mix.  scratch: 24*B bytes.  clean_out / noise_out may be NULL. */
+int cruse_snr_mix(const float* clean, const float* noise, const float* snr_db, int B, int L, float eps,
+                  void* scratch, float* clean_out, float* noise_out, float* noisy, void* stream);
+
 /* ---- stream-ordered bookkeeping (keeps the training step free of library kernels) ---- */
 /* zero-fill `bytes` (multiple of 4) with a KERNEL node (hipMemsetAsync nodes raced inside captured graphs) --
  * optimizer.zero_grad() at the top of the step */

@@ -1,0 +1,471 @@
+"""CPU oracle, part 2 -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (same rules as oracle/cruse_oracle.py: only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import it).
+
+Restatements, with stock torch / numpy only, of the callers and data formats either side of the unet_2 hot path
+(8f items 2-3; BASELINE configs 4-5).  Every function cites the reference
+file:line it follows.  Pinning: tests/golden/make_golden_r2.py runs the reference's OWN code for each of them in the
+build container (importing model.based_model.cust_conv and train_base.acoustics.mask as shipped; lifting the other
+functions from their source files with the documented repairs), asserts equality with this file and stores
+inputs/outputs as tests/golden/g1x_*.npz.  Where a repair is a decision rather than a typo fix it says DECISION.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import cruse_oracle as O
+
+EPSILON = np.finfo(np.float32).eps                       # train_base/constant.py
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# a13: loss_func/loss.py rmse, c_rmse (sisnr / wo_male / sdnr are in cruse_oracle.py)
+# ----------------------------------------------------------------------------------------------------------------------
+def rmse(ref, est, eps=1e-8):
+    """loss_func/loss.py:59-78; repair `torch.size(ref)` (:72) -> ref.size()."""
+    if ref.shape != est.shape:
+        raise RuntimeError(f"Dimension mismatch when calculate rmse, {ref.shape} vs {est.shape}")
+    B, C, T, Fq = ref.size()
+    err = est - ref
+    return torch.sum(torch.sqrt(err ** 2)) / (B * T * Fq)
+
+
+def c_rmse(ref, est, unproc=None, norm=False, eps=1e-8):
+    """loss_func/loss.py:88-118 as written (tmp3 / tmp4 mix magnitudes and phases, :109-111); repair `torch.size` (:98)."""
+    if ref.shape != est.shape:
+        raise RuntimeError(f"Dimension mismatch when calculate c_mse, {ref.shape} vs {est.shape}")
+    c, beta = 0.3, 0.3
+    real_ref, imag_ref = ref[:, 0], ref[:, 1]
+    real_est, imag_est = est[:, 0], est[:, 1]
+    mag_ref = torch.sqrt(real_ref ** 2 + imag_ref ** 2)
+    phase_ref = torch.atan2(imag_ref, real_ref)
+    mag_est = torch.sqrt(real_est ** 2 + imag_est ** 2)
+    phase_est = torch.atan2(imag_est, real_est)
+    tmp1 = torch.pow(mag_est, c)
+    tmp2 = torch.pow(mag_ref, c)
+    tmp3 = tmp1 * torch.cos(phase_ref) + tmp1 * torch.sin(phase_ref) * 1j
+    tmp4 = tmp2 * torch.cos(phase_est) + tmp1 * torch.sin(phase_est) * 1j
+    tmp5 = torch.abs(tmp3 - tmp4)
+    loss1 = (torch.pow(mag_ref, c) - torch.pow(mag_est, c)) ** 2
+    loss2 = tmp5 ** 2
+    return (1 - beta) * torch.sum(loss1) + beta * torch.sum(loss2)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# a14: train_base/acoustics/mask.py
+# ----------------------------------------------------------------------------------------------------------------------
+def compress_cIRM(mask, K=10, C=0.1):
+    """mask.py:43-52."""
+    mask = -100 * (mask <= -100) + mask * (mask > -100)
+    return K * (1 - torch.exp(-C * mask)) / (1 + torch.exp(-C * mask))
+
+
+def decompress_cIRM(mask, K=10, limit=9.9):
+    """mask.py:55-58."""
+    mask = limit * (mask >= limit) - limit * (mask <= -limit) + mask * (torch.abs(mask) < limit)
+    return -K * torch.log((K - mask) / (K + mask))
+
+
+def build_ideal_ratio_mask(noisy_mag, clean_mag):
+    """mask.py:8-21."""
+    return compress_cIRM((clean_mag / (noisy_mag + EPSILON))[..., None], K=10, C=0.1)
+
+
+def build_complex_ideal_ratio_mask(noisy, clean):
+    """mask.py:24-40."""
+    den = torch.square(noisy.real) + torch.square(noisy.imag) + EPSILON
+    mask_real = (noisy.real * clean.real + noisy.imag * clean.imag) / den
+    mask_imag = (noisy.real * clean.imag - noisy.imag * clean.real) / den
+    return compress_cIRM(torch.stack((mask_real, mask_imag), dim=-1), K=10, C=0.1)
+
+
+def complex_mul(noisy_r, noisy_i, mask_r, mask_i):
+    """mask.py:61-64."""
+    return noisy_r * mask_r - noisy_i * mask_i, noisy_r * mask_i + noisy_i * mask_r
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# a9: model/based_model/cust_conv.py conv blocks (stock nn.Sequential of stock children = what the reference builds)
+# ----------------------------------------------------------------------------------------------------------------------
+class FreqUpsample(nn.Module):
+    """cust_conv.py:177-184."""
+
+    def __init__(self, factor, mode="nearest"):
+        super().__init__()
+        self.f = float(factor)
+        self.mode = mode
+
+    def forward(self, x):
+        return F.interpolate(x, scale_factor=(1., self.f), mode=self.mode)
+
+
+def Conv2dNormAct(in_ch, out_ch, kernel_size, fstride=1, dilation=1, fpad=True, bias=True, separable=False,
+                  norm_layer=nn.BatchNorm2d, activation_layer=nn.ReLU):
+    """cust_conv.py:15-62."""
+    kernel_size = (kernel_size, kernel_size) if isinstance(kernel_size, int) else tuple(kernel_size)
+    fpad_ = kernel_size[1] // 2 + dilation - 1 if fpad else 0
+    pad = (0, 0, kernel_size[0] - 1, 0)
+    layers = []
+    if any(x > 0 for x in pad):
+        layers.append(nn.ConstantPad2d(pad, 0.0))
+    groups = math.gcd(in_ch, out_ch) if separable else 1
+    if groups == 1:
+        separable = False
+    if max(kernel_size) == 1:
+        separable = False
+    layers.append(nn.Conv2d(in_ch, out_ch, kernel_size, padding=(0, fpad_), stride=(1, fstride), dilation=(1, dilation),
+                            groups=groups, bias=bias))
+    if separable:
+        layers.append(nn.Conv2d(out_ch, out_ch, kernel_size=1, bias=False))
+    if norm_layer is not None:
+        layers.append(norm_layer(out_ch))
+    if activation_layer is not None:
+        layers.append(activation_layer())
+    return nn.Sequential(*layers)
+
+
+def ConvTranspose2dNormAct(in_ch, out_ch, kernel_size, fstride=1, dilation=1, fpad=True, bias=True, separable=False,
+                           norm_layer=nn.BatchNorm2d, activation_layer=nn.ReLU):
+    """cust_conv.py:65-111."""
+    kernel_size = (kernel_size, kernel_size) if isinstance(kernel_size, int) else kernel_size
+    fpad_ = kernel_size[1] // 2 if fpad else 0
+    pad = (0, 0, kernel_size[0] - 1, 0)
+    layers = []
+    if any(x > 0 for x in pad):
+        layers.append(nn.ConstantPad2d(pad, 0.0))
+    groups = math.gcd(in_ch, out_ch) if separable else 1
+    if groups == 1:
+        separable = False
+    layers.append(nn.ConvTranspose2d(in_ch, out_ch, kernel_size=kernel_size, padding=(kernel_size[0] - 1, fpad_ + dilation - 1),
+                                     output_padding=(0, fpad_), stride=(1, fstride), dilation=(1, dilation), groups=groups,
+                                     bias=bias))
+    if separable:
+        layers.append(nn.Conv2d(out_ch, out_ch, kernel_size=1, bias=False))
+    if norm_layer is not None:
+        layers.append(norm_layer(out_ch))
+    if activation_layer is not None:
+        layers.append(activation_layer())
+    return nn.Sequential(*layers)
+
+
+def convkxf(in_ch, out_ch, k=1, f=3, fstride=2, lookahead=0, batch_norm=False, act=None, mode="normal", depthwise=True,
+            complex_in=False):
+    """cust_conv.py:114-174."""
+    act = nn.ReLU(inplace=True) if act is None else act
+    bias = batch_norm is False
+    stride = 1 if f == 1 else (1, fstride)
+    if out_ch is None:
+        out_ch = in_ch * 2 if mode == "normal" else in_ch // 2
+    fpad = (f - 1) // 2
+    convpad = (0, fpad)
+    modules = []
+    pad = [0, 0, k - 1 - lookahead, lookahead]
+    if any(p > 0 for p in pad):
+        modules.append(("pad", nn.ConstantPad2d(pad, 0.0)))
+    groups = min(in_ch, out_ch) if depthwise else 1
+    if in_ch % groups != 0 or out_ch % groups != 0:
+        groups = 1
+    if complex_in and groups % 2 == 0:
+        groups //= 2
+    kw = dict(in_channels=in_ch, out_channels=out_ch, kernel_size=(k, f), stride=stride, groups=groups, bias=bias)
+    if mode == "normal":
+        modules.append(("sconv", nn.Conv2d(padding=convpad, **kw)))
+    elif mode == "transposed":
+        modules.append(("sconv", nn.ConvTranspose2d(padding=(k - 1, fpad), output_padding=convpad, **kw)))
+    elif mode == "upsample":
+        modules.append(("upsample", FreqUpsample(fstride)))
+        kw["stride"] = 1
+        modules.append(("sconv", nn.Conv2d(padding=convpad, **kw)))
+    else:
+        raise NotImplementedError()
+    if groups > 1:
+        modules.append(("1x1conv", nn.Conv2d(out_ch, out_ch, 1, bias=False)))
+    if batch_norm:
+        modules.append(("norm", nn.BatchNorm2d(out_ch)))
+    modules.append(("act", act))
+    return nn.Sequential(OrderedDict(modules))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# a10: GroupedGRULayer / GroupGRU
+# ----------------------------------------------------------------------------------------------------------------------
+class GroupedGRULayer(nn.Module):
+    """cust_conv.py:250-325 (unidirectional, batch_first)."""
+
+    def __init__(self, input_size, hidden_size, groups):
+        super().__init__()
+        self.input_size, self.hidden_size, self.groups = input_size // groups, hidden_size // groups, groups
+        self.layers = nn.ModuleList(nn.GRU(self.input_size, self.hidden_size, batch_first=True) for _ in range(groups))
+
+    def forward(self, input, h0=None):
+        if h0 is None:
+            h0 = torch.zeros(self.groups, input.shape[0], self.hidden_size)
+        outs, states = [], []
+        for i, layer in enumerate(self.layers):
+            o, s = layer(input[..., i * self.input_size:(i + 1) * self.input_size], h0[i:i + 1].detach())
+            outs.append(o); states.append(s)
+        return torch.cat(outs, dim=-1), torch.cat(states, dim=0)
+
+
+class GroupGRU(nn.Module):
+    """cust_conv.py:328-416.  The reference's forward(state=None) crashes on `get_h0(b, device)` (:397 vs :383); with an
+    explicit zero state it runs, and that is what is restated."""
+
+    def __init__(self, input_size, hidden_size, num_layers=1, groups=4, shuffle=True, add_outputs=False):
+        super().__init__()
+        self.groups, self.num_layers = groups, num_layers
+        self.hidden_size = hidden_size // groups
+        self.shuffle = shuffle and groups != 1
+        self.add_outputs = add_outputs
+        self.grus = nn.ModuleList([GroupedGRULayer(input_size, hidden_size, groups)] +
+                                  [GroupedGRULayer(hidden_size, hidden_size, groups) for _ in range(1, num_layers)])
+
+    def forward(self, input, state=None):
+        dim0, dim1, _ = input.shape
+        if state is None:
+            state = torch.zeros(self.num_layers * self.groups, dim0, self.hidden_size)
+        output = torch.zeros(dim0, dim1, self.hidden_size * self.groups)
+        outstates = []
+        h = self.groups
+        for i, gru in enumerate(self.grus):
+            input, s = gru(input, state[i * h:(i + 1) * h])
+            outstates.append(s)
+            if self.shuffle and i < self.num_layers - 1:
+                input = input.view(dim0, dim1, -1, self.groups).transpose(2, 3).reshape(dim0, dim1, -1)   # :408-410
+            if self.add_outputs:
+                output = output + input
+            else:
+                output = input
+        return output, torch.cat(outstates, dim=0)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# a5: CustomSTFT / CustomISTFT (feature.py:272-398)
+# ----------------------------------------------------------------------------------------------------------------------
+def init_stft_kernel(frame_len, frame_hop, num_fft=None, window="sqrt_hann"):
+    """feature.py:272-292; repair: torch.rfft(x, 1) (removed) -> view_as_real(torch.fft.rfft(x, dim=-1))."""
+    fft_size = 2 ** math.ceil(math.log2(frame_len)) if not num_fft else num_fft
+    window = torch.hann_window(frame_len) ** 0.5
+    S_ = 0.5 * (fft_size * fft_size / frame_hop) ** 0.5
+    kernel = torch.view_as_real(torch.fft.rfft(torch.eye(fft_size) / S_, dim=-1))[:frame_len]     # [win, F, 2]
+    kernel = torch.transpose(kernel, 0, 2) * window                                               # [2, F, win]
+    return torch.reshape(kernel, (fft_size + 2, 1, frame_len))
+
+
+def custom_stft(x, K, stride):
+    """CustomSTFT.forward, feature.py:344-366 -> m, p, r, i [N,F,T]."""
+    if x.dim() == 2:
+        x = torch.unsqueeze(x, 1)
+    c = F.conv1d(x, K, stride=stride, padding=0)
+    r, i = torch.chunk(c, 2, dim=1)
+    return (r ** 2 + i ** 2) ** 0.5, torch.atan2(i, r), r, i
+
+
+def custom_istft(m, p, K, stride):
+    """CustomISTFT.forward, feature.py:375-398 -> [N,1,S]."""
+    r, i = m * torch.cos(p), m * torch.sin(p)
+    return F.conv_transpose1d(torch.cat([r, i], dim=1), K, stride=stride, padding=0)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# a6: conv_stft.STFT (conv_stft.py:8-129)
+# ----------------------------------------------------------------------------------------------------------------------
+class ConvSTFT:
+    """Repairs: scipy.hamming (:20) -> np.hamming (the symmetric window scipy.hamming was); nn.parameter (:23) -> tensor.
+    DECISION (inverse): conv_stft.py:100-129 reads x[:,0] for both parts, concatenates spec_r into the imaginary extension
+    and subtracts the imaginary term although its kernel already carries the minus sign of exp(-i.) -- the restated inverse
+    is the conjugate-symmetric inverse DFT those lines evidently meant: x[:,1], spec_i in the extension, '+'."""
+
+    def __init__(self, win_size=320, hop_size=160):
+        self.win_size, self.hop_size = win_size, hop_size
+        self.n_overlap = win_size // hop_size
+        self.win = F.relu(torch.from_numpy(np.hamming(win_size).astype(np.float32)))
+        basis = np.fft.fft(np.eye(win_size))
+        self.fourier_basis_r = torch.from_numpy(np.real(basis).astype(np.float32))
+        self.fourier_basis_i = torch.from_numpy(np.imag(basis).astype(np.float32))
+        self.idx = torch.tensor(range(win_size // 2 - 1, 0, -1), dtype=torch.long)
+        self.eps = torch.finfo(torch.float32).eps
+
+    def window(self, n_frames):
+        seg = sum([self.win[i * self.hop_size:(i + 1) * self.hop_size] for i in range(self.n_overlap)])
+        seg = seg.unsqueeze(dim=-1).expand((self.hop_size, n_frames - self.n_overlap + 1))
+        return seg.contiguous().view(-1).contiguous()
+
+    def stft(self, sig):
+        """conv_stft.py:70-98 -> spec_r, spec_i, mag, pha [B,T,F]."""
+        B, n = sig.shape
+        cutoff = self.win_size // 2 + 1
+        sig = sig.view(B, 1, n)
+        kr = torch.matmul(self.fourier_basis_r, torch.diag(self.win)).unsqueeze(1)
+        ki = torch.matmul(self.fourier_basis_i, torch.diag(self.win)).unsqueeze(1)
+        pad = self.win_size - self.hop_size
+        spec_r = F.conv1d(sig, kr[:cutoff], stride=self.hop_size, padding=pad).transpose(-1, -2).contiguous()
+        spec_i = F.conv1d(sig, ki[:cutoff], stride=self.hop_size, padding=pad).transpose(-1, -2).contiguous()
+        return spec_r, spec_i, torch.sqrt(spec_r ** 2 + spec_i ** 2), torch.atan2(spec_i, spec_r)
+
+    def istft(self, x):
+        spec_r, spec_i = x[:, 0], x[:, 1]                                                      # DECISION
+        n_frames = spec_r.shape[1]
+        spec_r = torch.cat([spec_r, spec_r.index_select(dim=-1, index=self.idx)], dim=-1)
+        spec_i = torch.cat([spec_i, -spec_i.index_select(dim=-1, index=self.idx)], dim=-1)      # DECISION
+        spec_r = spec_r.transpose(-1, -2).contiguous()
+        spec_i = spec_i.transpose(-1, -2).contiguous()
+        kr = (self.fourier_basis_r / self.win_size).unsqueeze(1).transpose(0, -1)
+        ki = (self.fourier_basis_i / self.win_size).unsqueeze(1).transpose(0, -1)
+        pad = self.win_size - self.hop_size
+        sig = F.conv_transpose1d(spec_r, kr, stride=self.hop_size, padding=pad) + \
+            F.conv_transpose1d(spec_i, ki, stride=self.hop_size, padding=pad)                  # DECISION ('+': ki = -sin/N)
+        sig = sig.squeeze(dim=1)
+        # NOTE the reference's window(): `expand(...).contiguous().view(-1)` lays the result out hop-major (each window
+        # sample repeated n_frames-1 times in a row), not time-major; the time-major periodic window sum is what
+        # overlap-add needs and what is used here (DECISION, same evident intent)
+        seg = sum([self.win[i * self.hop_size:(i + 1) * self.hop_size] for i in range(self.n_overlap)])
+        window = seg.repeat(n_frames - self.n_overlap + 1)
+        return sig / (window + self.eps)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# a16: model/mtfaa.py blocks
+# ----------------------------------------------------------------------------------------------------------------------
+def mtfaa_stft_transform(inp, win_len, hop_len, fft_len, win_type):
+    """STFT.transform, mtfaa.py:20-28: torch.stft -> [B,2,F,T] (repair: return_complex=True + view_as_real on torch >= 2)."""
+    window = {"hann": torch.hann_window(win_len), "hamm": torch.hamming_window(win_len)}[win_type]
+    cspec = torch.view_as_real(torch.stft(inp, fft_len, hop_len, win_len, window, return_complex=True))
+    return cspec.permute(0, 3, 1, 2).contiguous()                                             # "b f t c -> b c f t"
+
+
+def mtfaa_stft_inverse(real, imag, win_len, hop_len, fft_len, win_type):
+    """STFT.inverse, mtfaa.py:30-37; repair: the window is passed in the win_length slot (:35-36)."""
+    window = {"hann": torch.hann_window(win_len), "hamm": torch.hamming_window(win_len)}[win_type]
+    return torch.istft(torch.complex(real, imag), fft_len, hop_len, win_len, window)
+
+
+class ComplexConv2d(nn.Module):
+    """mtfaa.py:39-107 (complex_axis = 1)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=(1, 1), stride=(1, 1), padding=(0, 0), dilation=1, groups=1,
+                 casual=True, complex_axis=1):
+        super().__init__()
+        self.padding, self.causal, self.complex_axis = padding, casual, complex_axis
+        self.real_conv = nn.Conv2d(in_channels // 2, out_channels // 2, kernel_size, stride, padding=(padding[0], 0),
+                                   dilation=dilation, groups=groups)
+        self.imag_conv = nn.Conv2d(in_channels // 2, out_channels // 2, kernel_size, stride, padding=(padding[0], 0),
+                                   dilation=dilation, groups=groups)
+        nn.init.normal_(self.real_conv.weight.data, std=0.05)
+        nn.init.normal_(self.imag_conv.weight.data, std=0.05)
+        nn.init.normal_(self.real_conv.bias, 0.)
+        nn.init.normal_(self.imag_conv.bias, 0.)
+
+    def forward(self, inputs):
+        if self.padding[1] != 0 and self.causal:
+            inputs = F.pad(inputs, [self.padding[1], 0, 0, 0])
+        else:
+            inputs = F.pad(inputs, [self.padding[1], self.padding[1], 0, 0])
+        real, imag = torch.chunk(inputs, 2, self.complex_axis)
+        real2real, imag2imag = self.real_conv(real), self.imag_conv(imag)
+        real2imag, imag2real = self.imag_conv(real), self.real_conv(imag)
+        return torch.cat((real2real - imag2imag, real2imag + imag2real), self.complex_axis)
+
+
+class ComplexLinearProjection(nn.Module):
+    """mtfaa.py:122-138."""
+
+    def __init__(self, cin):
+        super().__init__()
+        self.clp = ComplexConv2d(cin, cin)
+
+    def forward(self, real, imag):
+        real, imag = self.clp(torch.cat((real, imag), 1)).chunk(2, dim=1)
+        return torch.sqrt(real ** 2 + imag ** 2 + 1e-8)
+
+
+class PhaseEncoder(nn.Module):
+    """mtfaa.py:141-163."""
+
+    def __init__(self, cout, n_sig, cin=2, alpha=0.5):
+        super().__init__()
+        self.complexnn = nn.ModuleList(nn.Sequential(nn.ConstantPad2d((2, 0, 0, 0), 0.0), ComplexConv2d(cin, cout, (1, 3)))
+                                       for _ in range(n_sig))
+        self.clp = ComplexLinearProjection(cout * n_sig)
+        self.alpha = alpha
+
+    def forward(self, cspecs):
+        outs = [layer(cspecs[idx]) for idx, layer in enumerate(self.complexnn)]
+        reals, imags = zip(*[o.chunk(2, 1) for o in outs])
+        return self.clp(torch.cat(reals, 1), torch.cat(imags, 1)) ** self.alpha
+
+
+class TFCM_Block(nn.Module):
+    """mtfaa.py:166-193 (causal)."""
+
+    def __init__(self, cin=24, K=(3, 3), dila=1, causal=True):
+        super().__init__()
+        self.pconv1 = nn.Sequential(nn.Conv2d(cin, cin, kernel_size=(1, 1)), nn.BatchNorm2d(cin), nn.PReLU(cin))
+        dila_pad = dila * (K[1] - 1)
+        assert causal
+        self.dila_conv = nn.Sequential(nn.ConstantPad2d((dila_pad, 0, 1, 1), 0.0),
+                                       nn.Conv2d(cin, cin, K, 1, dilation=(1, dila), groups=cin), nn.BatchNorm2d(cin), nn.PReLU(cin))
+        self.pconv2 = nn.Conv2d(cin, cin, kernel_size=(1, 1))
+
+    def forward(self, inps):
+        return self.pconv2(self.dila_conv(self.pconv1(inps))) + inps
+
+
+class TFCM(nn.Module):
+    """mtfaa.py:196-209; repair `super(TFCM).__init__()` (:198)."""
+
+    def __init__(self, cin=24, K=(3, 3), tfcm_layer=6, causal=True):
+        super().__init__()
+        self.tfcm = nn.ModuleList(TFCM_Block(cin, K, 2 ** idx, causal=causal) for idx in range(tfcm_layer))
+
+    def forward(self, inp):
+        for blk in self.tfcm:
+            inp = blk(inp)
+        return inp
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# 8f.3: SynDataset.snr_mix (dataset/dataset.py:236-264)
+# ----------------------------------------------------------------------------------------------------------------------
+def snr_mix(clean_y, noise_y, snr, eps=1e-7):
+    """dataset.py:236-259 (numpy, one clip; rir = None): -> noisy, normalised clean, scaled noise.  The reference function
+    stops after drawing noisy_target_dB_FS (:261-264, file truncated)."""
+    clean_y = clean_y / (np.max(np.abs(clean_y)) + eps)
+    clean_rms = (clean_y ** 2).mean() ** 0.5
+    noise_y = noise_y / (np.max(np.abs(noise_y)) + eps)
+    noise_rms = (noise_y ** 2).mean() ** 0.5
+    snr_scalar = clean_rms / (10 ** (snr / 20)) / (noise_rms + eps)
+    noise_y = noise_y * snr_scalar
+    return clean_y + noise_y, clean_y, noise_y
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# BASELINE config 4: unet_2 + DeepFilter(1, 5) head as a training step
+# ----------------------------------------------------------------------------------------------------------------------
+def train_step_loss_df(model, noisy, clean, n_fft=320, hop=160, win=320):
+    """STFT -> unet_2 -> mask -> DeepFilter(t_dim=1, f_dim=5) (model/deep_filter.py:15-41) -> WO-MALE.
+
+    DECISION (the reference never wires the two): unet_2 (model/cruse_net.py:164) emits ONE real channel, so the mask is
+    the REAL part of the filter-coefficient field and the imaginary part is zero: filters = [pad(mask, 161 bins), 0],
+    inputs = [Re N, Im N] as [B,F,T]; the enhanced spectrum is the DeepFilter output (the 11 x 3 neighbourhood sum of
+    N (.) H, since deep_filter.py:29-36 unfolds inputs and filters alike)."""
+    f_net = (n_fft // 2 + 1) // 2 * 2
+    feats = O.pre_stft(noisy, n_fft, hop, win, f_net=f_net)
+    mask = model(feats["mag_net"])                                        # [B,1,T,160]
+    Fs = feats["real"].shape[-1]
+    h_r = F.pad(mask, (0, Fs - f_net)).squeeze(1).transpose(1, 2)          # [B,F,T]
+    h_i = torch.zeros_like(h_r)
+    x_r = feats["real"].squeeze(1).transpose(1, 2)
+    x_i = feats["imag"].squeeze(1).transpose(1, 2)
+    y = O.DeepFilter(1, 5)([x_r, x_i], [h_r, h_i])                         # [B,2F,T]
+    est = torch.stack([y[:, :Fs].transpose(1, 2), y[:, Fs:].transpose(1, 2)], dim=1)     # [B,2,T,F]
+    cfe = O.pre_stft(clean, n_fft, hop, win)
+    ref = torch.cat([cfe["real"], cfe["imag"]], dim=1)
+    unproc = torch.cat([feats["real"], feats["imag"]], dim=1)
+    return O.wo_male(ref, est, unproc), dict(mask=mask, est=est, ref=ref, unproc=unproc)

@@ -1,0 +1,350 @@
+"""GPU parity of the rows either side of the hot path (8f items 2-3;
+BASELINE config 4) against the round-2 fixtures generated from the reference's own code (tests/golden/make_golden_r2.py)
+and against oracle autograd for the gradients."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import max_abs, rel_l2, t
+
+pytestmark = pytest.mark.gpu
+
+
+def _load_like(product, oracle_mod, scale=1.0):
+    from oracle import cruse_oracle as O
+    O.closed_form_init(oracle_mod, scale)
+    product.load_state_dict(oracle_mod.state_dict(), strict=True)
+    return product.cuda()
+
+
+def _grad_check(product, oracle_mod, x_cpu, tol=2e-4, wtol=None, list_input=False):
+    """same random cotangent through both; input and parameter gradients."""
+    wtol = wtol or 5 * tol
+    gen = torch.Generator().manual_seed(99)
+    if list_input:
+        xo = [a.clone().requires_grad_(True) for a in x_cpu]
+        xp = [a.clone().cuda().requires_grad_(True) for a in x_cpu]
+    else:
+        xo = x_cpu.clone().requires_grad_(True)
+        xp = x_cpu.clone().cuda().requires_grad_(True)
+    yo = oracle_mod(xo)
+    yo = yo[0] if isinstance(yo, tuple) else yo
+    w = torch.randn(yo.shape, generator=gen)
+    (yo * w).sum().backward()
+    yp = product(xp)
+    yp = yp[0] if isinstance(yp, tuple) else yp
+    (yp * w.cuda()).sum().backward()
+    for a, b in zip(xp if list_input else [xp], xo if list_input else [xo]):
+        assert rel_l2(a.grad, b.grad) < tol
+    for (n, po), (_, pp) in zip(oracle_mod.named_parameters(), product.named_parameters()):
+        if po.grad is None:
+            continue
+        gn = float(po.grad.norm())
+        if gn < 1e-6 * max(1.0, float(po.norm())):
+            assert float(pp.grad.norm()) < 1e-4, n                    # e.g. a conv bias in front of a BatchNorm
+            continue
+        assert rel_l2(pp.grad, po.grad) < wtol, n
+
+
+# ---------------------------------------------------------------------------------------------------------------- a13
+def test_rmse_c_rmse_sisnr_wo_male_vs_reference(golden):
+    from cruse_amd import loss_func as L
+    from oracle import cruse_oracle as O
+    from oracle import cruse_oracle_ext as X
+    g = golden("g10_losses.npz")
+    ref, est = torch.from_numpy(g["ref"]), torch.from_numpy(g["est"])
+    for name, fn, ofn, tol in (("rmse", L.rmse, X.rmse, 1e-5), ("c_rmse", L.c_rmse, X.c_rmse, 2e-5)):
+        e = est.clone().cuda().requires_grad_(True)
+        v = fn(ref.cuda(), e)
+        assert abs(float(v) - float(g[name])) <= tol * abs(float(g[name])), name
+        v.backward()
+        eo = est.clone().requires_grad_(True)
+        ofn(ref, eo).backward()
+        assert rel_l2(e.grad, eo.grad) < 1e-4, name
+    g5 = golden("g5_loss.npz")
+    s1, s2 = torch.from_numpy(g5["s1"]), torch.from_numpy(g5["s2"])
+    a = s1.clone().cuda().requires_grad_(True)
+    v = L.sisnr(a, s2.cuda())
+    assert abs(float(v) - float(g5["sisnr"])) <= 1e-5 * abs(float(g5["sisnr"]))          # the reference's own run (G5)
+    v.backward()
+    ao = s1.clone().requires_grad_(True)
+    O.sisnr(ao, s2).backward()
+    assert rel_l2(a.grad, ao.grad) < 1e-4
+    # loss_func selector class (loss_func/loss.py:15-35) incl. wo_male on explicit spectra (value pinned in G5)
+    r5, e5, u5 = (torch.from_numpy(g5[k]) for k in ("ref", "est", "unproc"))
+    lf = L.loss_func("WO_MALE")
+    e = e5.clone().cuda().requires_grad_(True)
+    v = lf.loss(e, r5.cuda(), u5.cuda())
+    assert abs(float(v) - float(g5["wo_male"])) <= 1e-5 * abs(float(g5["wo_male"]))
+    v.backward()
+    eo = e5.clone().requires_grad_(True)
+    O.wo_male(r5, eo, u5).backward()
+    assert rel_l2(e.grad, eo.grad) < 1e-4
+    assert abs(float(L.loss_func("SI-SNR").loss(s1.cuda(), s2.cuda())) + float(g5["sisnr"])) <= 1e-5 * abs(float(g5["sisnr"]))
+    assert abs(float(L.loss_func("MSE").loss(est.cuda(), ref.cuda())) - float(g["rmse"])) <= 1e-5 * float(g["rmse"])
+    with pytest.raises(RuntimeError, match="Dimension mismatch"):
+        L.rmse(ref.cuda(), est[:, :, :5].cuda())
+
+
+# ---------------------------------------------------------------------------------------------------------------- a14
+def test_mask_py_vs_reference(golden):
+    from cruse_amd.acoustics import mask as M
+    g = golden("g9_mask.npz")
+    a, b, c, d = (t(g[k]) for k in "abcd")
+    r, i = M.complex_mul(a, b, c, d)
+    assert max_abs(r, torch.from_numpy(g["cm_r"])) < 1e-6 and max_abs(i, torch.from_numpy(g["cm_i"])) < 1e-6
+    irm = M.build_ideal_ratio_mask(a.abs(), c.abs())
+    assert irm.shape == (2, 5, 7, 1) and rel_l2(irm, torch.from_numpy(g["irm"])) < 1e-5
+    cirm = M.build_complex_ideal_ratio_mask(torch.complex(a, b), torch.complex(c, d))
+    assert cirm.shape == (2, 5, 7, 2) and rel_l2(cirm, torch.from_numpy(g["cirm"])) < 1e-5
+    dec = M.decompress_cIRM(t(g["cirm"]))
+    assert rel_l2(dec, torch.from_numpy(g["decomp"])) < 1e-5
+    x = torch.linspace(-150, 50, 64).cuda()                                   # the -100 clamp branch of compress (mask.py:47)
+    from oracle import cruse_oracle_ext as X
+    assert rel_l2(M.compress_cIRM(x), X.compress_cIRM(x.cpu())) < 1e-5
+    # full-size round trip (B=8, F=161, T=401): decompress(compress(m)) == m inside the limit
+    m = (torch.rand(8, 161, 401, 2) * 8 - 4).cuda()
+    assert rel_l2(M.decompress_cIRM(M.compress_cIRM(m)), m) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------- a9
+CONV_CASES = {
+    "cna": lambda m: m.Conv2dNormAct(1, 16, (2, 3), fstride=2),
+    "cna_sep": lambda m: m.Conv2dNormAct(16, 32, (2, 3), fstride=2, separable=True),
+    "cna_dil": lambda m: m.Conv2dNormAct(16, 16, (3, 3), fstride=1, dilation=2, norm_layer=None),
+    "ctna": lambda m: m.ConvTranspose2dNormAct(16, 8, (2, 3), fstride=2),
+    "ctna_sep": lambda m: m.ConvTranspose2dNormAct(16, 8, (1, 3), fstride=2, separable=True),
+    "kxf_normal": lambda m: m.convkxf(16, 32, k=2, f=3, fstride=2, batch_norm=True),
+    "kxf_transposed": lambda m: m.convkxf(16, 8, k=2, f=3, fstride=2, mode="transposed", batch_norm=True),
+    "kxf_upsample": lambda m: m.convkxf(16, 8, k=2, f=3, fstride=2, mode="upsample", batch_norm=True),
+    "kxf_full": lambda m: m.convkxf(16, 8, k=1, f=3, fstride=2, mode="upsample", depthwise=False),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CONV_CASES))
+def test_cust_conv_blocks_vs_reference(golden, case):
+    """Conv2dNormAct / ConvTranspose2dNormAct / convkxf (normal, transposed, upsample; depthwise + 1x1): outputs of the
+    reference's imported modules in train and eval mode; gradients vs oracle autograd."""
+    from cruse_amd.model.based_model import cust_conv as P
+    from oracle import cruse_oracle_ext as X
+    g = golden("g11_convblocks.npz")
+    o = CONV_CASES[case](X)
+    p = _load_like(CONV_CASES[case](P), o)
+    assert list(p.state_dict().keys()) == list(o.state_dict().keys())
+    x = torch.from_numpy(g[f"{case}/x"])
+    o.train(); p.train()
+    y = p(x.cuda())
+    want = torch.from_numpy(g[f"{case}/y_train"])
+    assert y.shape == want.shape and rel_l2(y, want) < 2e-5, case
+    p.eval()
+    with torch.no_grad():
+        assert rel_l2(p(x.cuda()), torch.from_numpy(g[f"{case}/y_eval"])) < 2e-5, case
+    # gradients (fresh modules: the train-mode call above moved the running statistics)
+    o2 = CONV_CASES[case](X)
+    p2 = _load_like(CONV_CASES[case](P), o2)
+    o2.train(); p2.train()
+    _grad_check(p2, o2, x, tol=5e-4)
+    for k, v in o2.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            assert max_abs(p2.state_dict()[k].float(), v.float()) < 1e-4, (case, k)
+
+
+def test_freq_upsample_standalone(golden):
+    from cruse_amd.model.based_model.cust_conv import FreqUpsample
+    g = golden("g11_convblocks.npz")
+    y = FreqUpsample(2)(t(g["upsample/x"]))
+    assert torch.equal(y.cpu(), torch.from_numpy(g["upsample/y"]))
+
+
+# ---------------------------------------------------------------------------------------------------------------- a10
+@pytest.mark.parametrize("name,kw", [("g2_l2", dict(num_layers=2, groups=2)), ("g4_l3_add", dict(num_layers=3, groups=4, add_outputs=True)),
+                                     ("g2_noshuffle", dict(num_layers=2, groups=2, shuffle=False))])
+def test_group_gru_with_shuffle_vs_reference(golden, name, kw):
+    from cruse_amd.model.based_model.cust_conv import GroupGRU
+    from oracle import cruse_oracle_ext as X
+    g = golden("g12_groupgru.npz")
+    o = X.GroupGRU(128, 128, **kw)
+    p = _load_like(GroupGRU(128, 128, **kw), o, scale=2.0)
+    x = torch.from_numpy(g["x"])
+    y, s = p(x.cuda())
+    assert rel_l2(y, torch.from_numpy(g[f"{name}/y"])) < 1e-5
+    assert rel_l2(s, torch.from_numpy(g[f"{name}/state"])) < 1e-5
+    y2, _ = p(x.cuda(), p.get_h0(2, device="cuda"))                              # explicit zero state: same result
+    assert rel_l2(y2, y) < 1e-7
+    with pytest.raises(RuntimeError, match="h0 = 0"):
+        p(x.cuda(), torch.ones(kw["num_layers"] * kw["groups"], 2, 128 // kw["groups"]).cuda())
+    _grad_check(p, o, x, tol=5e-4, wtol=2e-3)
+
+
+@pytest.mark.parametrize("grp", [1, 2, 4])
+def test_grouped_gru_layer_l1cat_fixture(golden, grp):
+    """the `l1cat_g*` arrays of fixture G3 (cust_conv.GroupedGRULayer = GGRU's first layer before the interleave)."""
+    from cruse_amd.model.based_model.cust_conv import GroupedGRULayer
+    from oracle import cruse_oracle as O
+    g = golden("g3_ggru.npz")
+    mine = O.GGRU(hidden_size=640, groups=grp)
+    O.closed_form_init(mine)
+    lay = GroupedGRULayer(640, 640, grp)
+    for i in range(grp):
+        lay.layers[i].load_state_dict(mine.gru_list1[i].state_dict())
+    lay = lay.cuda()
+    seq = torch.from_numpy(g["x"]).transpose(1, 2).reshape(2, 21, 640)
+    out, h = lay(seq.cuda(), lay.get_h0(2, device="cuda"))
+    assert rel_l2(out, torch.from_numpy(g[f"l1cat_g{grp}"])) < 1e-5
+    assert h.shape == (grp, 2, 640 // grp) and rel_l2(h.transpose(0, 1).reshape(2, 640), out[:, -1]) < 1e-7
+
+
+# ---------------------------------------------------------------------------------------------------------------- a5, a6
+@pytest.mark.parametrize("nfft,tag", [(None, "512"), (320, "320")])
+def test_custom_stft_istft_vs_reference(golden, nfft, tag):
+    from train_base.acoustics.feature import CustomISTFT, CustomSTFT
+    g = golden("g13_stft_variants.npz")
+    wav = t(g["wav"])
+    st = CustomSTFT(320, 160, num_fft=nfft).cuda()
+    ist = CustomISTFT(320, 160, num_fft=nfft).cuda()
+    assert list(st.state_dict().keys()) == ["K"]
+    m, p, r, i = st(wav)
+    F = (512 if nfft is None else nfft) // 2 + 1
+    assert m.shape == (2, F, 19)                                                  # T = (3200 - 320)//160 + 1, no centre padding
+    assert rel_l2(r, torch.from_numpy(g[f"custom{tag}/r"])) < 1e-5 and rel_l2(i, torch.from_numpy(g[f"custom{tag}/i"])) < 1e-5
+    assert rel_l2(m, torch.from_numpy(g[f"custom{tag}/m"])) < 1e-5
+    y = ist(t(g[f"custom{tag}/m"]), t(g[f"custom{tag}/p"]))
+    want = torch.from_numpy(g[f"custom{tag}/y"])
+    assert y.shape == want.shape == (2, 1, 3200) and rel_l2(y, want) < 1e-5
+    # the layer is differentiable wrt the waveform: the adjoint pair
+    x = wav.clone().requires_grad_(True)
+    _, _, r2, i2 = st(x)
+    (r2.square().sum() + i2.square().sum()).backward()
+    from oracle import cruse_oracle_ext as X
+    xo = wav.cpu().clone().requires_grad_(True)
+    _, _, ro, io = X.custom_stft(xo, X.init_stft_kernel(320, 160, num_fft=nfft), 160)
+    (ro.square().sum() + io.square().sum()).backward()
+    assert rel_l2(x.grad, xo.grad) < 1e-4
+    with pytest.raises(RuntimeError, match="Expect 2D/3D"):
+        st(torch.zeros(1, 1, 1, 400).cuda())
+
+
+def test_conv_stft_hamming_vs_reference(golden):
+    from train_base.acoustics.conv_stft import STFT
+    g = golden("g13_stft_variants.npz")
+    wav = t(g["wav"])
+    cs = STFT(320, 160).cuda()
+    assert set(cs.state_dict().keys()) == {"win", "fourier_basis_r", "fourier_basis_i", "idx"}
+    sr, si, mag, pha = cs.stft(wav)
+    assert sr.shape == (2, 21, 161)
+    assert rel_l2(sr, torch.from_numpy(g["conv/spec_r"])) < 1e-5 and rel_l2(si, torch.from_numpy(g["conv/spec_i"])) < 1e-5
+    assert rel_l2(mag, torch.from_numpy(g["conv/mag"])) < 1e-5
+    rt = cs.istft(torch.stack([sr, si], dim=1))
+    assert rt.shape == wav.shape and max_abs(rt, wav) < 5e-6                       # the (repaired) inverse inverts
+    assert rel_l2(rt, torch.from_numpy(g["conv/roundtrip"])) < 1e-4
+    # full size: 64 clips x 4 s
+    big = torch.randn(64, 64000).cuda() * 0.1
+    a, b, _, _ = cs.stft(big)
+    assert a.shape == (64, 401, 161) and max_abs(cs.istft(torch.stack([a, b], dim=1)), big) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------- a16
+def test_mtfaa_stft_and_blocks_vs_reference(golden):
+    from model import mtfaa as P
+    from oracle import cruse_oracle_ext as X
+    g = golden("g14_mtfaa.npz")
+    sig = t(g["sig"])
+    for wt in ("hann", "hamm"):
+        c = P.STFT(320, 160, 320, wt).transform(sig)
+        want = torch.from_numpy(g[f"stft_{wt}"])
+        assert c.shape == want.shape == (2, 2, 161, 26) and rel_l2(c, want) < 1e-5
+    inv = P.STFT(320, 160, 320, "hann").inverse(t(g["stft_hann"][:, 0]), t(g["stft_hann"][:, 1]))
+    assert rel_l2(inv, torch.from_numpy(g["stft_inv"])) < 1e-5 and max_abs(inv, sig) < 1e-5
+    # ComplexConv2d
+    o = X.ComplexConv2d(8, 12, (3, 3), padding=(1, 2))
+    p = _load_like(P.ComplexConv2d(8, 12, (3, 3), padding=(1, 2)), o)
+    xc = torch.from_numpy(g["cconv/x"])
+    assert rel_l2(p(xc.cuda()), torch.from_numpy(g["cconv/y"])) < 1e-5
+    _grad_check(p, o, xc, tol=5e-4)
+    # PhaseEncoder
+    o = X.PhaseEncoder(4, 2)
+    p = _load_like(P.PhaseEncoder(4, 2), o, scale=3.0)
+    cs = [torch.from_numpy(g["pe/x0"]), torch.from_numpy(g["pe/x1"])]
+    y = p([c.cuda() for c in cs])
+    assert rel_l2(y, torch.from_numpy(g["pe/y"])) < 1e-5
+    _grad_check(p, o, cs, tol=1e-3, list_input=True)
+    # TFCM_Block (dilations 1 and 4), train and eval mode
+    xt = torch.from_numpy(g["tfcm/x"])
+    for dila in (1, 4):
+        o = X.TFCM_Block(24, (3, 3), dila)
+        p = _load_like(P.TFCM_Block(24, (3, 3), dila), o, scale=2.0)
+        assert list(p.state_dict().keys()) == list(o.state_dict().keys())
+        o.train(); p.train()
+        assert rel_l2(p(xt.cuda()), torch.from_numpy(g[f"tfcm_d{dila}/y_train"])) < 2e-5
+        p.eval()
+        with torch.no_grad():
+            assert rel_l2(p(xt.cuda()), torch.from_numpy(g[f"tfcm_d{dila}/y_eval"])) < 2e-5
+        o2 = X.TFCM_Block(24, (3, 3), dila)
+        p2 = _load_like(P.TFCM_Block(24, (3, 3), dila), o2, scale=2.0)
+        o2.train(); p2.train()
+        _grad_check(p2, o2, xt, tol=1e-3, wtol=5e-3)
+    # the 6-block stack of config 5 on its stated shape [B,24,161,T]: runs, finite, residual structure
+    stack = P.TFCM(24, (3, 3), 6).cuda()
+    xin = torch.randn(2, 24, 161, 101).cuda()
+    out = stack(xin)
+    assert out.shape == xin.shape and torch.isfinite(out).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------- 8f.3
+def test_snr_mix_vs_reference(golden):
+    from dataset.dataset import SynDataset
+    from cruse_amd.data import snr_mix
+    g = golden("g15_snr_mix.npz")
+    clean, noise, snr = t(g["clean"]), t(g["noise"]), t(g["snr"])
+    noisy, c, n = snr_mix(clean, noise, snr, return_parts=True)
+    assert rel_l2(noisy, torch.from_numpy(g["noisy"])) < 2e-6
+    assert rel_l2(c, torch.from_numpy(g["clean_n"])) < 2e-6 and rel_l2(n, torch.from_numpy(g["noise_s"])) < 2e-6
+    one = SynDataset.snr_mix(clean[1], noise[1], float(snr[1]))                   # single clip, the reference's call shape
+    assert rel_l2(one, torch.from_numpy(g["noisy"][1])) < 2e-6
+    # full size: 64 clips x 4 s; the mixture has the requested SNR and a unit-peak clean part
+    B, L = 64, 64000
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    cl = torch.randn(B, L, device="cuda", generator=gen) * 0.05
+    nz = torch.randn(B, L, device="cuda", generator=gen) * 0.3
+    want = torch.linspace(-5, 25, B).cuda()
+    ny, c, n = snr_mix(cl, nz, want, return_parts=True)
+    got = 10 * torch.log10(c.square().mean(-1) / n.square().mean(-1))
+    assert max_abs(got, want) < 1e-3 and max_abs(c.abs().amax(-1), torch.ones(B)) < 1e-5
+    assert rel_l2(ny, c + n) < 1e-7
+
+
+# ---------------------------------------------------------------------------------------------------------------- config 4
+@pytest.mark.parametrize("grp,prec", [(1, "f32"), (4, "f32"), (1, "bf16")])
+def test_deepfilter_training_step_vs_golden(golden, grp, prec):
+    """BASELINE config 4: unet_2 -> DeepFilter(1,5) head -> WO-MALE as ONE engine step (loss, filtered spectrum, gradients)."""
+    from cruse_amd.engine import TrainEngine
+    from cruse_amd.model import cruse_net as M
+    from oracle import cruse_oracle as O
+    g = golden(f"g16_df_step_g{grp}.npz")
+    o = O.unet_2(rnn_groups=grp); O.closed_form_init(o)
+    m = M.unet_2(rnn_groups=grp, precision=prec)
+    m.load_state_dict(o.state_dict(), strict=True)
+    eng = TrainEngine(m.cuda(), use_graph=False, loss="wo_male_df")
+    ls = eng._fwd_bwd(t(g["noisy"]), t(g["clean"]))
+    ftol = 1e-4 if prec == "f32" else 1e-3
+    assert abs(eng.loss_value(ls) - float(g["loss"])) <= ftol * abs(float(g["loss"]))
+    est = eng._last_est.permute(1, 0, 2, 3)                                        # [2,B,T,F] -> [B,2,T,F]
+    e = rel_l2(est, torch.from_numpy(g["est"]))
+    print(f"[config 4 g={grp} {prec}] filtered-spectrum rel-L2 {e:.3e}")
+    assert e <= ftol
+    gtol = 5e-3 if prec == "f32" else 0.3
+    for name in eng.flat.names:
+        if "gn/" + name not in g.files or (name.endswith(".bias") and name.startswith("conv") and name != "conv1_t.bias"):
+            continue
+        gn, got = float(g["gn/" + name]), float(eng.flat.G[name].norm())
+        assert abs(got - gn) <= gtol * gn + 2e-6, (name, got, gn)
+        if prec == "f32":
+            g8 = torch.from_numpy(g["g8/" + name])
+            assert max_abs(eng.flat.G[name].flatten()[:8], g8) <= 5e-3 * float(g8.abs().max()) + 1e-6 * max(gn, 1.0) + 2e-7, name
+    # and as a graph-captured optimizer step at a larger shape
+    eng2 = TrainEngine(M.unet_2(rnn_groups=grp, precision=prec).cuda(), use_graph=True, loss="wo_male_df")
+    noisy, clean = O.synth_pair(4, 16000, seed=3)
+    l0 = eng2.loss_value(eng2.step(noisy.cuda(), clean.cuda()))
+    for _ in range(4):
+        l1 = eng2.loss_value(eng2.step(noisy.cuda(), clean.cuda()))
+    assert np.isfinite(l0) and l1 < l0

@@ -1,2 +1,3 @@
-"""Drop-in for `train_base.acoustics.feature.stft / istft` (feature.py:10-61) on the HIP path."""
-from cruse_amd.acoustics.feature import istft, pre_stft, stft  # noqa: F401
+"""Drop-in for `train_base.acoustics.feature` (feature.py:10-61 stft / istft, :272-398 CustomSTFT / CustomISTFT) on the HIP path."""
+from cruse_amd.acoustics.feature import (CustomISTFT, CustomSTFT, CustomSTFTBase, init_stft_kernel, istft,  # noqa: F401
+                                         pre_stft, stft)
