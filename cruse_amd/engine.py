@@ -276,7 +276,7 @@ class TrainEngine:
         dest = torch.empty_like(est) if training else None
         TF = T * Fs
         check(lib.cruse_wo_male_spec(ops._p(ref), ops._p(est), ops._p(unp), B, TF, TF, B * TF, self.loss_alpha, self.loss_beta,
-                                     1.0, ops._p(loss_sum), ops._p(dest), ops._stream()))
+                                     1.0 / float(rows * Fs), ops._p(loss_sum), ops._p(dest), ops._stream()))
         if not training:
             return loss_sum, None
         _, _, dhr, _ = ops.deepfilter_bwd(dest[0], dest[1], nre.view(B, T, Fs), nim.view(B, T, Fs), hr.view(B, T, Fs),
