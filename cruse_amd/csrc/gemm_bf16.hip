@@ -13,6 +13,7 @@
 // of 16 B]; chunk c of row r sits at position c ^ (r & 7) -- the swizzle is applied on the per-lane global
 // SOURCE address (the LDS-DMA destination is lane-linear) and undone in the fragment read address.
 #include "common.h"
+#include <stdlib.h>
 
 extern "C" int cruse_cast_bf16_split(const float* x, void* y, void* y_lo, long long n, void* stream);
 
@@ -31,6 +32,7 @@ struct GbArgs {
     long long lda, ldb, ldc, a_ks, b_ks;     // *_ks: elements between consecutive 64-deep k-tiles of one row
     int accumulate, splitk, kt_chunk;
     int tiles_m, tiles_n, nunits, inner;
+    int xcdk;                                // split-K with the k-slices PINNED to XCDs (see the kernel's tile order)
 };
 
 // MODE: C update -- 0 store, 1 read-add-store, 2 atomic add (split-K).
@@ -46,12 +48,24 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_bf16_nt_kernel(con
     const int wm = wv >> 1, wn = wv & 1;
     // XCD-aware tile order, as in gemm.hip: a unit -- the n-tiles of one m-tile, or with split-K the m-tiles of one
     // (k-slice, n-tile) -- stays on one XCD, so the operand panel its tiles share is fetched into that L2 once
+    // xcdk (the K = 25 664 weight gradients): k-slice z is computed ENTIRELY on XCD z % 8 -- all its output tiles, m-major, so
+    // the blocks resident on that XCD at one time walk the same k-range together and share every operand k-tile through
+    // that XCD's L2: each operand byte leaves HBM about once.  (With (k-slice, n-tile) units spread round-robin the big
+    // operand was fetched once per n-tile: 506 MB per launch for 131 MB of operands, PMC r01.)
     const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3;
-    const int inner = qq % g.inner, unit = (qq / g.inner) * 8 + xcd;
-    if (unit >= g.nunits) return;
     int tm, tn, tz;
-    if (g.splitk > 1) { tz = unit / g.tiles_n; tn = unit % g.tiles_n; tm = inner; }
-    else { tz = 0; tm = unit; tn = inner; }
+    if (g.xcdk) {
+        const int ntile = g.tiles_m * g.tiles_n;
+        tz = (qq / ntile) * 8 + xcd;
+        if (tz >= g.splitk) return;
+        const int tl = qq % ntile;
+        tm = tl / g.tiles_n; tn = tl % g.tiles_n;
+    } else {
+        const int inner = qq % g.inner, unit = (qq / g.inner) * 8 + xcd;
+        if (unit >= g.nunits) return;
+        if (g.splitk > 1) { tz = unit / g.tiles_n; tn = unit % g.tiles_n; tm = inner; }
+        else { tz = 0; tm = unit; tn = inner; }
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int nkt = g.K / BK;
     const int kt0 = tz * g.kt_chunk, kt1 = min(nkt, kt0 + g.kt_chunk);
@@ -282,6 +296,8 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
                   ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, CRUSE_E_ALIGN,
                   "gemm_bf16_nt: operands need 16-byte aligned rows and k-tiles (strides multiples of 8)");
     const int nkt = K / BK;
+    const bool xcdk = splitk < -1;             // negative: |splitk| k-slices pinned to XCDs
+    if (xcdk) splitk = -splitk;
     if (splitk < 1) splitk = 1;
     if (splitk > nkt) splitk = nkt;
     const int kt_chunk = cdiv(nkt, splitk);
@@ -293,14 +309,17 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.a_ks = a_kstride; g.b_ks = b_kstride;
     g.accumulate = accumulate; g.splitk = splitk; g.kt_chunk = kt_chunk;
     g.tiles_m = cdiv(M, BM); g.tiles_n = cdiv(N, BN);
+    g.xcdk = (xcdk && splitk > 1) ? 1 : 0;
     if (splitk > 1) { g.nunits = splitk * g.tiles_n; g.inner = g.tiles_m; }
     else { g.nunits = g.tiles_m; g.inner = g.tiles_n; }
-    const long long nblk = (long long)cdiv(g.nunits, 8) * 8 * g.inner;
+    const long long nblk = g.xcdk ? (long long)cdiv(splitk, 8) * 8 * g.tiles_m * g.tiles_n
+                                  : (long long)cdiv(g.nunits, 8) * 8 * g.inner;
     CRUSE_REQUIRE(nblk < (1ll << 31), CRUSE_E_SHAPE, "gemm_bf16_nt: grid too large");
     CRUSE_REQUIRE(splitk == 1 || accumulate, CRUSE_E_SHAPE, "gemm_bf16_nt: split-K adds into C (accumulate = 1)");
     const dim3 grid((unsigned)nblk);
     hipStream_t st = (hipStream_t)stream;
-    const bool deep = kt_chunk >= 64;          // long k-loops: three stages, one block per CU
+    bool deep = kt_chunk >= 64;                // long k-loops: three stages, one block per CU
+    { const char* e = getenv("CRUSE_GB_DEEP"); if (e) deep = atoi(e) != 0; }          // profiling override
     const size_t lds = (size_t)(deep ? 3 : 2) * 2 * TILE_BYTES;
 #define CRUSE_GB_LAUNCH(MODE, NST)                                                                               \
     do {                                                                                                         \

@@ -124,7 +124,11 @@ SIDE = _SideStream()
 
 
 def _splitk_bf16(M: int, N: int, K: int) -> int:
-    """k-slices for gemm_bf16_nt's deep-pipeline form (one block per CU): fill the 256 CUs in one round."""
+    """k-slices for gemm_bf16_nt's deep-pipeline form (one block per CU): fill the 256 CUs in one round.
+    CRUSE_DW_XCDK=<n>: n k-slices pinned to XCDs instead (negative splitk of cruse_gemm_bf16_nt) -- measured, see DESIGN 6."""
+    x = int(os.environ.get("CRUSE_DW_XCDK", "0"))
+    if x > 1:
+        return -x
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     return max(1, min(256 // tiles, K // 1024))
 

@@ -158,7 +158,9 @@ int cruse_gemm(int transA, int transB, int M, int N, int K,
 /* bf16-operand form of the same products for CRUSE_PREC_BF16: C[M,N] (=|+=) A[M,K] . B[N,K]^T (+ bias[n]), C f32,
  * K % 64 == 0.  Operand element (m, k) is A[(k/64)*a_kstride + m*lda + k%64]: a_kstride == 64 is plain row-major
  * (lda >= K); the K-TILED time-major layout of cruse_transpose_bf16 / cruse_gru_gate_grads_bf16 has lda == 64 and
- * a_kstride == 64 * (number of lines).  Same for B.  splitk > 1 adds atomically and needs accumulate != 0.
+ * a_kstride == 64 * (number of lines).  Same for B.  splitk > 1 adds atomically and needs accumulate != 0;
+ * splitk < -1 is |splitk| k-slices with slice z computed entirely on XCD z % 8 (all output tiles of a slice share that
+ * XCD's L2: the long-K weight gradients then read every operand byte from HBM about once).
  * Operand values are the RNE roundings cruse_gemm forms internally. */
 int cruse_gemm_bf16_nt(int M, int N, int K, const void* A, long long lda, long long a_kstride,
                        const void* B, long long ldb, long long b_kstride,

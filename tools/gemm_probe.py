@@ -43,14 +43,26 @@ def main():
     xT = ops.transpose_bf16(x, rows, H); gT = ops.transpose_bf16(g3, rows, 4 * H)
     ldT = xT.shape[0] * 64
     C = torch.zeros(3 * H, H, device=dev)
-    for sk in (2, 3, 6):
+    for sk in (3, 6, -8, -16, -24):
         us = timeit(lambda: ops.gemm_bf16_nt(3 * H, H, ldT, gT, 0, 64, xT, 0, 64, C, 0, H, accumulate=True, splitk=sk,
                                              a_kstride=4 * H * 64, b_kstride=H * 64))
         print(f"dW K-tiled sk={sk}: {us:8.1f} us  {2.0*3*H*H*ldT/us/1e6:7.1f} TF/s")
-    C.zero_()
-    ops.gemm_bf16_nt(3 * H, H, ldT, gT, 0, 64, xT, 0, 64, C, 0, H, accumulate=True, splitk=6, a_kstride=4 * H * 64, b_kstride=H * 64)
     ref = g3[:, :3 * H].to(torch.bfloat16).float().t() @ x.to(torch.bfloat16).float()
-    print("dW K-tiled rel_err", ((C - ref).norm() / ref.norm()).item())
+    for sk in (6, -8, -16):
+        C.zero_()
+        ops.gemm_bf16_nt(3 * H, H, ldT, gT, 0, 64, xT, 0, 64, C, 0, H, accumulate=True, splitk=sk, a_kstride=4 * H * 64, b_kstride=H * 64)
+        print(f"dW K-tiled sk={sk} rel_err", ((C - ref).norm() / ref.norm()).item())
+    # the three weight-gradient products of one GRU layer, as the step issues them
+    hT = ops.transpose_bf16(x, rows, H, shift_T=T)
+    G2 = torch.zeros(3 * H, H, device=dev)
+    ka, kb = 4 * H * 64, H * 64
+    for sk in (0, -8, -16):
+        def layer(sk=sk):
+            s1 = sk or 3; s2 = sk or 5; s3 = sk or 10
+            ops.gemm_bf16_nt(3 * H, H, ldT, gT, 0, 64, xT, 0, 64, C, 0, H, accumulate=True, splitk=s1, a_kstride=ka, b_kstride=kb)
+            ops.gemm_bf16_nt(2 * H, H, ldT, gT, 0, 64, hT, 0, 64, G2, 0, H, accumulate=True, splitk=s2, a_kstride=ka, b_kstride=kb)
+            ops.gemm_bf16_nt(H, H, ldT, gT, 3 * H * 64, 64, hT, 0, 64, G2, 2 * H * H, H, accumulate=True, splitk=s3, a_kstride=ka, b_kstride=kb)
+        print(f"one layer's dW_ih + dW_hh (3 launches), splitk {sk or 'r01 (3,5,10)'}: {timeit(layer):8.1f} us")
     print(f"cast_bf16 [{rows},{H}]: {timeit(lambda: ops.cast_bf16(x)):.1f} us; transpose_bf16: {timeit(lambda: ops.transpose_bf16(x, rows, H)):.1f} us; "
           f"shifted {timeit(lambda: ops.transpose_bf16(x, rows, H, shift_T=T)):.1f} us")
 
