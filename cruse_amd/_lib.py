@@ -80,6 +80,7 @@ SIGNATURES = {
     "cruse_c_rmse": ("ppiqffppp", "i"),
     "cruse_sisnr_plain_finalize": ("pifppp", "i"),
     "cruse_wo_male_spec": ("pppiqqqfffppp", "i"),
+    "cruse_onepole_fir": ("piififpp", "i"),
     "cruse_snr_mix": ("pppiifppppp", "i"),
     "cruse_zero": ("pzp", "i"),
     "cruse_accum_f64": ("ppip", "i"),

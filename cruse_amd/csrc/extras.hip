@@ -233,6 +233,24 @@ __global__ __launch_bounds__(256) void snr_mix_apply_kernel(const float* clean, 
     }
 }
 
+// y[b,n] = gain * (1-a) * sum_{k < taps} a^k x[b,n-k]   (one-pole low-pass as a truncated FIR: the synthetic "speech-like"
+// spectral tilt of the bench / SyntheticPairs clips)
+__global__ __launch_bounds__(256) void onepole_fir_kernel(const float* x, int L, float a, int taps, float gain, float* y) {
+    __shared__ float xs[256 + 128];
+    const int b = blockIdx.y, n0 = blockIdx.x * 256;
+    const float* xb = x + (long long)b * L;
+    for (int i = threadIdx.x; i < 256 + taps - 1; i += 256) {
+        const int n = n0 - (taps - 1) + i;
+        xs[i] = (n >= 0 && n < L) ? xb[n] : 0.f;
+    }
+    __syncthreads();
+    const int n = n0 + threadIdx.x;
+    if (n >= L) return;
+    float acc = 0.f, w = (1.f - a) * gain;
+    for (int k = 0; k < taps; ++k) { acc += w * xs[threadIdx.x + taps - 1 - k]; w *= a; }
+    y[(long long)b * L + n] = acc;
+}
+
 inline int eblocks(long long n, int per = 1024, int cap = 4096) {
     long long g = (n + per - 1) / per;
     if (g < 1) g = 1;
@@ -298,6 +316,13 @@ extern "C" int cruse_sisnr_plain_finalize(const double* mom, int B, float eps, d
     { int rc = cruse_zero_async(value, sizeof(double), ST(stream), "sisnr_plain"); if (rc) return rc; }
     hipLaunchKernelGGL(sisnr_plain_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0, ST(stream), mom, B, (double)eps, value, coef);
     CRUSE_LAUNCH_CHECK("sisnr_plain");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_onepole_fir(const float* x, int B, int L, float a, int taps, float gain, float* y, void* stream) {
+    CRUSE_REQUIRE(B > 0 && L > 0 && taps > 0 && taps <= 128 && x != y, CRUSE_E_SHAPE, "onepole_fir: bad arguments (taps <= 128, out of place)");
+    hipLaunchKernelGGL(onepole_fir_kernel, dim3((L + 255) / 256, B), dim3(256), 0, ST(stream), x, L, a, taps, gain, y);
+    CRUSE_LAUNCH_CHECK("onepole_fir");
     return CRUSE_OK;
 }
 

@@ -7,15 +7,24 @@ from torch.utils.data import Dataset
 
 
 def synth_batch(batch: int, length: int, device, seed: int):
-    """clean = 0.05*N(0,1) through a one-pole low-pass (a=0.95, speech-like tilt), noise = 0.1*N(0,1)."""
-    g = torch.Generator(device=device).manual_seed(seed)
-    white = 0.05 * torch.randn(batch, length, device=device, generator=g)
-    # one-pole low-pass y[n] = a*y[n-1] + (1-a)*x[n], as a truncated FIR (64 taps) via cumulative products
-    a = 0.95
-    taps = (1 - a) * a ** torch.arange(63, -1, -1, device=device, dtype=torch.float32)
-    clean = torch.nn.functional.conv1d(white.unsqueeze(1), taps.view(1, 1, -1), padding=63)[..., :length].squeeze(1)
-    clean = clean * 4.0
-    noise = 0.1 * torch.randn(batch, length, device=device, generator=g)
+    """clean = 4 * one-pole low-pass (a = 0.95, 64-tap FIR) of 0.05*N(0,1) (speech-like tilt), noise = 0.1*N(0,1),
+    noisy = clean + noise.  On a HIP device the filter and the mix are libcruse_hip kernels (cruse_onepole_fir,
+    cruse_axpby); torch only draws the Gaussian samples.  On the CPU (DataLoader workers of SyntheticPairs) the same
+    FIR runs through torch."""
+    dev = torch.device(device)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    white = 0.05 * torch.randn(batch, length, device=dev, generator=g)
+    noise = 0.1 * torch.randn(batch, length, device=dev, generator=g)
+    a, taps = 0.95, 64
+    if dev.type == "cuda":
+        from . import ops
+        from ._lib import check, lib
+        clean = torch.empty_like(white)
+        check(lib.cruse_onepole_fir(ops._p(white), batch, length, a, taps, 4.0, ops._p(clean), ops._stream()))
+        noisy = ops.axpby(torch.empty_like(clean), clean, noise, 1.0, 1.0)
+        return noisy, clean
+    w = (1 - a) * a ** torch.arange(taps - 1, -1, -1, dtype=torch.float32)
+    clean = torch.nn.functional.conv1d(white.unsqueeze(1), w.view(1, 1, -1), padding=taps - 1)[..., :length].squeeze(1) * 4.0
     return (clean + noise).contiguous(), clean.contiguous()
 
 

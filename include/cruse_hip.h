@@ -339,6 +339,8 @@ int cruse_wo_male_spec(const float* ref, const float* est, const float* unproc, 
 /* sisnr (loss_func/loss.py:48-56, no mean removal) from the moments cruse_sisnr_fwd's first pass leaves in `mom`:
  * value = mean_b 10 log10(.), coef [B,4] for cruse_sisnr_bwd (gradient of the VALUE; the loss is its negative) */
 int cruse_sisnr_plain_finalize(const double* mom, int B, float eps, double* value, float* coef, void* stream);
+/* synthetic clips: y[b,n] = gain*(1-a) * sum_{k<taps} a^k x[b,n-k], a one-pole low-pass as a truncated FIR */
+int cruse_onepole_fir(const float* x, int B, int L, float a, int taps, float gain, float* y, void* stream);
 /* SynDataset.snr_mix (dataset/dataset.py:236-264) for B clips at once: peak-normalise both, scale the noise to snr_db[b]
  * from the RMS ratio, mix.  scratch: 24*B bytes.  clean_out / noise_out may be NULL. */
 int cruse_snr_mix(const float* clean, const float* noise, const float* snr_db, int B, int L, float eps,

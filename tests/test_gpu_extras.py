@@ -351,3 +351,15 @@ def test_deepfilter_training_step_vs_golden(golden, grp, prec):
     for _ in range(4):
         l1 = eng2.loss_value(eng2.step(noisy.cuda(), clean.cuda()))
     assert np.isfinite(l0) and l1 < l0
+
+
+def test_synthetic_batch_matches_its_cpu_definition():
+    """cruse_amd.data.synth_batch on the device (HIP one-pole FIR + mix) vs the same filter through torch on the CPU."""
+    from cruse_amd.data import synth_batch
+    noisy, clean = synth_batch(3, 5000, "cuda", 7)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    white = 0.05 * torch.randn(3, 5000, device="cuda", generator=g)
+    noise = 0.1 * torch.randn(3, 5000, device="cuda", generator=g)
+    w = (1 - 0.95) * 0.95 ** torch.arange(63, -1, -1, dtype=torch.float32)
+    ref = torch.nn.functional.conv1d(white.cpu().unsqueeze(1), w.view(1, 1, -1), padding=63)[..., :5000].squeeze(1) * 4.0
+    assert rel_l2(clean, ref) < 1e-5 and rel_l2(noisy, ref + noise.cpu()) < 1e-5
