@@ -132,7 +132,7 @@ class KernelTimer:
     """Wraps cruse_amd.ops entry points with HIP events on torch's current stream (where the kernels run)."""
 
     NAMES = ["stft", "conv_gather", "conv_scatter2", "conv_wgrad", "channel_sum", "col_sum", "bn_stats", "bn_finalize",
-             "bn_act_fwd", "bn_act_bwd", "ln_fwd", "ln_bwd", "gemm", "gemm_bf16_nt", "gemm_bf16x3_nt", "cast_bf16", "cast_bf16_padded",
+             "bn_act_fwd", "bn_finalize_act_fwd", "bn_act_bwd", "ln_fwd", "ln_bwd", "gemm", "gemm_bf16_nt", "gemm_bf16x3_nt", "cast_bf16", "cast_bf16_padded",
              "ktile_bf16", "transpose_bf16",
              "gru_seq_fwd", "gru_seq_bwd", "gru_gate_grads", "gru_gate_grads_bf16", "mask_loss"]
 
@@ -251,7 +251,7 @@ def kernel_rooflines(B, T, H, G, prec, per_step_ms, calls):
             out[gname] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS[prec], "unit": "TFLOP/s",
                           "frac": round(ach / PEAK_MFMA_TFLOPS[prec], 4), "traffic": None,
                           "avg_launch_ms": round(avg_ms, 4)}
-    hbm = {"conv_gather": 2 * 640 * 4.0, "conv_scatter2": 2 * 640 * 4.0, "bn_act_fwd": 2 * 640 * 4.0,
+    hbm = {"conv_gather": 2 * 640 * 4.0, "conv_scatter2": 2 * 640 * 4.0, "bn_act_fwd": 2 * 640 * 4.0, "bn_finalize_act_fwd": 2 * 640 * 4.0,
            "bn_act_bwd": 5 * 640 * 4.0, "conv_wgrad": 2 * 640 * 4.0, "ln_fwd": 2 * 640 * 4.0, "ln_bwd": 3 * 640 * 4.0}
     for name, bpf in hbm.items():
         if name in per_step_ms:
@@ -342,8 +342,10 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     local = local % torch.cuda.device_count()         # (test rigs may oversubscribe one GPU)
     torch.cuda.set_device(local)
-    if world > 1:
+    force_pg = os.environ.get("CRUSE_FORCE_COLLECTIVES") == "1"      # a world of ONE still issues its (RCCL) collectives
+    if world > 1 or force_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group(os.environ.get("CRUSE_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     dev = torch.device("cuda", local)
 
@@ -461,7 +463,7 @@ def main():
             "kernel_ms_per_step": breakdown, "cpu_baseline": cpu, "secondary": secondary,
         }
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_pg:
         dist.barrier()                        # rank 0's instrumented pass and report are done before anyone tears down
         dist.destroy_process_group()
 

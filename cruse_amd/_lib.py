@@ -32,11 +32,12 @@ SIGNATURES = {
     "cruse_conv_wgrad": ("pppiiiiiiiiiipp", "i"),
     "cruse_channel_sum": ("pqiipp", "i"),
     "cruse_col_sum": ("pqiipp", "i"),
-    "cruse_bn_stats": ("pqiipp", "i"),
+    "cruse_bn_stats": ("pqiipip", "i"),
+    "cruse_bn_finalize_act_fwd": ("ppqffppppppppqiiip", "i"),
     "cruse_bn_finalize": ("pqiffppppp", "i"),
     "cruse_bn_eval_stats": ("ppifppp", "i"),
     "cruse_bn_act_fwd": ("pppppppqiiip", "i"),
-    "cruse_bn_act_bwd_reduce": ("ppppppqiiipp", "i"),
+    "cruse_bn_act_bwd_reduce": ("ppppppqiiipip", "i"),
     "cruse_bn_act_bwd_apply": ("pppppppqiiiippppp", "i"),
     "cruse_ln_fwd": ("pppppppqiifp", "i"),
     "cruse_ln_bwd": ("pppppqiipppp", "i"),

@@ -132,6 +132,50 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* y, const f
     }
 }
 
+// bn_finalize + bn_act_fwd in ONE launch: every block derives mean / rstd of the (<= 256) channels from the f64 batch sums
+// itself; block 0 also publishes them (the backward pass reads them) and updates the running statistics.
+__global__ __launch_bounds__(256) void bn_fin_act_fwd_kernel(const float* y, const double* sums, double inv_count, double unb,
+                                                             float eps, float momentum, const float* gamma,
+                                                             const float* beta, const float* skip, float* out, float* mean_o,
+                                                             float* rstd_o, float* rmean, float* rvar, long long rows, int C,
+                                                             int F, int relu) {
+    extern __shared__ float tab[];  // [4][C]
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const double m = sums[c] * inv_count;
+        double var = sums[C + c] * inv_count - m * m;
+        if (var < 0.0) var = 0.0;
+        const float mf = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
+        tab[c] = mf; tab[C + c] = rs; tab[2 * C + c] = gamma[c]; tab[3 * C + c] = beta[c];
+        if (blockIdx.x == 0) {
+            mean_o[c] = mf; rstd_o[c] = rs;
+            if (rmean) {
+                rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * m);
+                rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * var * unb);
+            }
+        }
+    }
+    __syncthreads();
+    const int CF = C * F;
+    const long long n4 = rows * CF / 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(y)[i];
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (skip) s = reinterpret_cast<const float4*>(skip)[i];
+        const int j = (int)((i * 4) % CF);
+        const float in[4] = {v.x, v.y, v.z, v.w};
+        const float sk[4] = {s.x, s.y, s.z, s.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = (j + e) / F;
+            float t = (in[e] - tab[c]) * tab[C + c] * tab[2 * C + c] + tab[3 * C + c];
+            if (relu) t = fmaxf(t, 0.f);
+            o[e] = t + sk[e];
+        }
+        reinterpret_cast<float4*>(out)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 __global__ __launch_bounds__(RED_THREADS) void bn_act_bwd_reduce_kernel(const float* dout, const float* y, const float* mean,
                                                                 const float* rstd, const float* gamma,
                                                                 const float* beta, long long rows, int C, int F,
@@ -625,10 +669,10 @@ inline int grid_for(long long n, int per_block, int cap = 4096) {
 
 #define ST(s) ((hipStream_t)(s))
 
-extern "C" int cruse_bn_stats(const float* y, long long rows, int C, int F, double* sums, void* stream) {
+extern "C" int cruse_bn_stats(const float* y, long long rows, int C, int F, double* sums, int zeroed, void* stream) {
     CRUSE_REQUIRE(rows > 0 && C > 0 && C <= 256 && F > 0, CRUSE_E_SHAPE, "bn_stats: bad shape rows=%lld C=%d F=%d", rows, C, F);
     CRUSE_REQUIRE((C * F) % 4 == 0 && C * F <= 768, CRUSE_E_SHAPE, "bn_stats: C*F=%d must be a multiple of 4 and <= 768", C * F);
-    { int zrc = cruse_zero_async(sums, 2 * C * sizeof(double), ST(stream), "bn_stats memset"); if (zrc) return zrc; }
+    if (!zeroed) { int zrc = cruse_zero_async(sums, 2 * C * sizeof(double), ST(stream), "bn_stats memset"); if (zrc) return zrc; }
     hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(rows, 64, 256)), dim3(RED_THREADS), 0, ST(stream), y, rows, C, F, sums);
     CRUSE_LAUNCH_CHECK("bn_stats");
     return CRUSE_OK;
@@ -664,12 +708,27 @@ extern "C" int cruse_bn_act_fwd(const float* y, const float* mean, const float* 
     return CRUSE_OK;
 }
 
+extern "C" int cruse_bn_finalize_act_fwd(const float* y, const double* sums, long long count, float eps, float momentum,
+                                         const float* gamma, const float* beta, const float* skip, float* out,
+                                         float* mean, float* rstd, float* running_mean, float* running_var,
+                                         long long rows, int C, int F, int relu, void* stream) {
+    CRUSE_REQUIRE(rows > 0 && C > 0 && C <= 256 && F > 0 && count > 0, CRUSE_E_SHAPE, "bn_finalize_act_fwd: bad shape");
+    CRUSE_REQUIRE((C * F) % 4 == 0, CRUSE_E_ALIGN, "bn_finalize_act_fwd: C*F=%d must be a multiple of 4", C * F);
+    CRUSE_REQUIRE((running_mean == nullptr) == (running_var == nullptr) && mean && rstd, CRUSE_E_SHAPE, "bn_finalize_act_fwd: statistics");
+    const double unb = count > 1 ? (double)count / (double)(count - 1) : 1.0;
+    hipLaunchKernelGGL(bn_fin_act_fwd_kernel, dim3(grid_for(rows * C * F / 4, 1024)), dim3(256), 4 * C * sizeof(float), ST(stream),
+                       y, sums, 1.0 / (double)count, unb, eps, momentum, gamma, beta, skip, out, mean, rstd, running_mean,
+                       running_var, rows, C, F, relu);
+    CRUSE_LAUNCH_CHECK("bn_finalize_act_fwd");
+    return CRUSE_OK;
+}
+
 extern "C" int cruse_bn_act_bwd_reduce(const float* dout, const float* y, const float* mean, const float* rstd,
                                        const float* gamma, const float* beta, long long rows, int C, int F,
-                                       int relu, double* sums, void* stream) {
+                                       int relu, double* sums, int zeroed, void* stream) {
     CRUSE_REQUIRE(rows > 0 && C > 0 && C <= 256 && F > 0, CRUSE_E_SHAPE, "bn_act_bwd_reduce: bad shape");
     CRUSE_REQUIRE((C * F) % 4 == 0 && C * F <= 768, CRUSE_E_SHAPE, "bn_act_bwd_reduce: C*F=%d must be a multiple of 4 and <= 768", C * F);
-    { int zrc = cruse_zero_async(sums, 2 * C * sizeof(double), ST(stream), "bn_act_bwd_reduce memset"); if (zrc) return zrc; }
+    if (!zeroed) { int zrc = cruse_zero_async(sums, 2 * C * sizeof(double), ST(stream), "bn_act_bwd_reduce memset"); if (zrc) return zrc; }
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(grid_for(rows, 64, 256)), dim3(RED_THREADS), 0, ST(stream), dout, y, mean,
                        rstd, gamma, beta, rows, C, F, relu, sums);
     CRUSE_LAUNCH_CHECK("bn_act_bwd_reduce");

@@ -288,9 +288,10 @@ class TrainEngine:
     def _fwd_bwd(self, noisy: torch.Tensor, clean: torch.Tensor, boundary=None) -> torch.Tensor:
         B, L = noisy.shape
         T = ops.stft_frames(L, self.hop)
-        loss_sum, dlogit, ctx = self._forward_loss(noisy, clean, training=True)
-        ops.zero_(self.flat.grads)
-        unet2_backward(ctx, dlogit.view(B, T, 1, self.f_net), self.flat.P, self.flat.G, boundary=boundary)
+        with ops.ARENA.step(noisy.device):          # one clear for all reduction accumulators of the step
+            loss_sum, dlogit, ctx = self._forward_loss(noisy, clean, training=True)
+            ops.zero_(self.flat.grads)
+            unet2_backward(ctx, dlogit.view(B, T, 1, self.f_net), self.flat.P, self.flat.G, boundary=boundary)
         return loss_sum
 
     @torch.no_grad()

@@ -321,16 +321,19 @@ def _flush_counters():
         _PENDING_COUNTERS.clear()
 
 
-def _bn_stats(y, rows, C, F, P, Bf, name, training, update_running):
+def _bn_act(y, rows, C, F, P, Bf, name, training, update_running, skip=None):
+    """BatchNorm2d (train: batch statistics, running stats updated; eval: running stats) + ReLU (+ skip) -> (out, mean, rstd)."""
+    gamma, beta = P[name + ".weight"], P[name + ".bias"]
     if training:
         sums = ops.bn_stats(y, rows, C, F)
         rm = Bf[name + ".running_mean"] if update_running else None
         rv = Bf[name + ".running_var"] if update_running else None
-        mean, rstd = ops.bn_finalize(sums, rows * F, C, BN_EPS, BN_MOMENTUM, rm, rv)
         if update_running:
             _PENDING_COUNTERS.append(Bf[name + ".num_batches_tracked"])
-        return mean, rstd
-    return ops.bn_eval_stats(Bf[name + ".running_mean"], Bf[name + ".running_var"], BN_EPS)
+        return ops.bn_finalize_act_fwd(y, sums, rows * F, BN_EPS, BN_MOMENTUM, gamma, beta, skip, rows, C, F, relu=True,
+                                       running_mean=rm, running_var=rv)
+    mean, rstd = ops.bn_eval_stats(Bf[name + ".running_mean"], Bf[name + ".running_var"], BN_EPS)
+    return ops.bn_act_fwd(y, mean, rstd, gamma, beta, skip, rows, C, F, relu=True), mean, rstd
 
 
 def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, torch.Tensor], ch, groups: int,
@@ -353,8 +356,7 @@ def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, tor
     for k in range(1, L + 1):
         y = ops.conv_gather(cur, P[f"conv{k}.weight"], P[f"conv{k}.bias"], B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k],
                             KT=2, S=2, pad=1, prec=prec)
-        mean, rstd = _bn_stats(y, rows, ch[k], Fk[k], P, Bf, f"bn{k}", training, update_running)
-        e = ops.bn_act_fwd(y, mean, rstd, P[f"bn{k}.weight"], P[f"bn{k}.bias"], None, rows, ch[k], Fk[k], relu=True)
+        e, mean, rstd = _bn_act(y, rows, ch[k], Fk[k], P, Bf, f"bn{k}", training, update_running)
         s = torch.empty(B, T, ch[k], Fk[k], device=x.device, dtype=torch.float32)
 
         def skip_conv(e=e, s=s, k=k):
@@ -374,9 +376,7 @@ def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, tor
     for k in range(L, 1, -1):
         v = ops.conv_scatter2(u, P[f"conv{k}_t.weight"], P[f"conv{k}_t.bias"], B, T, ch[k], Fk[k], ch[k - 1], KT=1, pad=0,
                               prec=prec)
-        mean, rstd = _bn_stats(v, rows, ch[k - 1], Fk[k - 1], P, Bf, f"bn{k}_t", training, update_running)
-        u = ops.bn_act_fwd(v, mean, rstd, P[f"bn{k}_t.weight"], P[f"bn{k}_t.bias"], ss[k - 1], rows, ch[k - 1],
-                           Fk[k - 1], relu=True)
+        u, mean, rstd = _bn_act(v, rows, ch[k - 1], Fk[k - 1], P, Bf, f"bn{k}_t", training, update_running, skip=ss[k - 1])
         vs[k] = v; dstats[k] = (mean, rstd); us[k - 1] = u
     mask = ops.conv_scatter2(u, P["conv1_t.weight"], P["conv1_t.bias"], B, T, ch[1], Fk[1], ch[0], KT=1, pad=0, act=1,
                              prec=prec)

@@ -144,11 +144,66 @@ def col_sum(g, g_off, rows, ncol, ld, out):
     check(lib.cruse_col_sum(g.data_ptr() + 4 * g_off, rows, ncol, ld, _p(out), _stream()))
 
 
+# ---------------------------------------------------------------- zeroed scratch for the step's reductions
+class _ZeroArena:
+    """f64 accumulators for the reductions of ONE training step (BatchNorm batch sums, backward sums, loss sums), carved
+    from one buffer that a single cruse_zero clears at the top of the step -- instead of one memset launch in front of
+    every reduction kernel (15 launches per step).  Inactive outside `with ARENA.step(device):` -- callers then get a
+    fresh tensor and the kernel clears it itself.  Under HIP-graph capture the slices are handed out in the same order on
+    every capture, so the captured pointers stay valid."""
+
+    CAP = 1 << 14           # doubles (128 KiB)
+
+    def __init__(self):
+        self.bufs = {}
+        self.active = None
+        self.off = 0
+
+    def step(self, device):
+        arena = self
+
+        class _Ctx:
+            def __enter__(self_):
+                dev = torch.device(device)
+                buf = arena.bufs.get(dev)
+                if buf is None:
+                    buf = arena.bufs[dev] = torch.zeros(arena.CAP, device=dev, dtype=torch.float64)
+                arena.active, arena.off = buf, 0
+                zero_(buf)
+                return arena
+
+            def __exit__(self_, *exc):
+                arena.active = None
+        return _Ctx()
+
+    def take(self, n: int, device):
+        """-> (f64 tensor of n elements, zeroed flag)."""
+        if self.active is None or self.active.device != device or self.off + n > self.CAP:
+            return torch.empty(n, device=device, dtype=torch.float64), 0
+        t = self.active[self.off:self.off + n]
+        self.off += (n + 1) // 2 * 2                    # keep 16-byte alignment
+        return t, 1
+
+
+ARENA = _ZeroArena()
+
+
 # ---------------------------------------------------------------- BatchNorm
 def bn_stats(y, rows, C, F):
-    sums = torch.empty(2 * C, device=y.device, dtype=torch.float64)
-    check(lib.cruse_bn_stats(_p(y), rows, C, F, _p(sums), _stream()))
+    sums, z = ARENA.take(2 * C, y.device)
+    check(lib.cruse_bn_stats(_p(y), rows, C, F, _p(sums), z, _stream()))
     return sums
+
+
+def bn_finalize_act_fwd(y, sums, count, eps, momentum, gamma, beta, skip, rows, C, F, relu=True, running_mean=None,
+                        running_var=None):
+    """bn_finalize + bn_act_fwd in one launch -> (out, mean, rstd)."""
+    out = torch.empty_like(y)
+    mean = torch.empty(C, device=y.device, dtype=torch.float32)
+    rstd = torch.empty(C, device=y.device, dtype=torch.float32)
+    check(lib.cruse_bn_finalize_act_fwd(_p(y), _p(sums), count, eps, momentum, _p(gamma), _p(beta), _p(skip), _p(out), _p(mean),
+                                        _p(rstd), _p(running_mean), _p(running_var), rows, C, F, 1 if relu else 0, _stream()))
+    return out, mean, rstd
 
 
 def bn_finalize(sums, count, C, eps, momentum, running_mean=None, running_var=None):
@@ -175,9 +230,9 @@ def bn_act_fwd(y, mean, rstd, gamma, beta, skip, rows, C, F, relu=True):
 
 
 def bn_act_bwd(dout, y, mean, rstd, gamma, beta, rows, C, F, relu, training, dgamma, dbeta, dbias=None):
-    sums = torch.empty(2 * C, device=y.device, dtype=torch.float64)
+    sums, z = ARENA.take(2 * C, y.device)
     check(lib.cruse_bn_act_bwd_reduce(_p(dout), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), rows, C, F,
-                                      1 if relu else 0, _p(sums), _stream()))
+                                      1 if relu else 0, _p(sums), z, _stream()))
     dy = torch.empty_like(y)
     check(lib.cruse_bn_act_bwd_apply(_p(dout), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(sums), rows, C, F,
                                      1 if relu else 0, 1 if training else 0, _p(dy), _p(dgamma), _p(dbeta),

@@ -108,8 +108,9 @@ int cruse_col_sum(const float* g, long long rows, int ncol, int ld, float* out, 
 
 /* ---- BatchNorm2d (+ReLU, + skip add) (cruse_net.py:141-142,149-152,161-163) ---- */
 
-/* sums[0..C) = sum y, sums[C..2C) = sum y^2 over rows x F (f64; zeroed by the callee) */
-int cruse_bn_stats(const float* y, long long rows, int C, int F, double* sums, void* stream);
+/* sums[0..C) = sum y, sums[C..2C) = sum y^2 over rows x F (f64).  zeroed != 0: the caller hands over accumulators that are
+ * already zero (the step's scratch arena, cleared by ONE cruse_zero per step) -- otherwise the callee clears them first. */
+int cruse_bn_stats(const float* y, long long rows, int C, int F, double* sums, int zeroed, void* stream);
 /* training: mean/rstd from sums (biased var), running stats updated with momentum and
  * unbiased var when running_mean != NULL (torch BatchNorm2d semantics). */
 int cruse_bn_finalize(const double* sums, long long count, int C, float eps, float momentum,
@@ -121,10 +122,16 @@ int cruse_bn_eval_stats(const float* running_mean, const float* running_var, int
 int cruse_bn_act_fwd(const float* y, const float* mean, const float* rstd, const float* gamma,
                      const float* beta, const float* skip, float* out,
                      long long rows, int C, int F, int relu, void* stream);
-/* sums[0..C) = sum g, sums[C..2C) = sum g*xhat with g = dout * [bn(y) > 0] (zeroed by the callee) */
+/* cruse_bn_finalize + cruse_bn_act_fwd as one launch (training): mean / rstd come from the batch sums inside the kernel,
+ * are also written out (the backward pass needs them) and the running statistics are updated. */
+int cruse_bn_finalize_act_fwd(const float* y, const double* sums, long long count, float eps, float momentum,
+                              const float* gamma, const float* beta, const float* skip, float* out,
+                              float* mean, float* rstd, float* running_mean, float* running_var,
+                              long long rows, int C, int F, int relu, void* stream);
+/* sums[0..C) = sum g, sums[C..2C) = sum g*xhat with g = dout * [bn(y) > 0]; `zeroed` as for cruse_bn_stats */
 int cruse_bn_act_bwd_reduce(const float* dout, const float* y, const float* mean, const float* rstd,
                             const float* gamma, const float* beta, long long rows, int C, int F,
-                            int relu, double* sums, void* stream);
+                            int relu, double* sums, int zeroed, void* stream);
 /* dy = gamma*rstd*(g - [training](sum_g + xhat*sum_gx)/count); dgamma += sum_gx; dbeta += sum_g;
  * dbias (nullable) += per-channel sum of dy -- the gradient of the bias of the conv that feeds this BN */
 int cruse_bn_act_bwd_apply(const float* dout, const float* y, const float* mean, const float* rstd,
