@@ -206,6 +206,7 @@ class TrainEngine:
         self._graphs = None
         self._static = None
         self._shape = None
+        self._graph_cache: Dict[Tuple[int, ...], tuple] = {}     # input shape -> (graphs, static inputs, static loss)
         dev = self.flat.params.device
         self._gsumsq = torch.zeros(1, device=dev, dtype=torch.float64)
         self._skipped = torch.zeros(1, device=dev, dtype=torch.int32)
@@ -345,6 +346,8 @@ class TrainEngine:
         end(N_BUCKETS - 1)
         self._graphs = graphs
         self._shape = tuple(noisy.shape)
+        # one capture per input shape (a last, partial batch of an epoch would otherwise force two re-captures per epoch)
+        self._graph_cache[self._shape] = (graphs, self._static, self._static_loss)
 
     @staticmethod
     def _warmup_boundary(bucket: int):
@@ -370,7 +373,12 @@ class TrainEngine:
         self._works = []
         if self.use_graph:
             if self._graphs is None or self._shape != tuple(noisy.shape):
-                self._capture(noisy, clean)
+                hit = self._graph_cache.get(tuple(noisy.shape))
+                if hit is not None:
+                    self._graphs, self._static, self._static_loss = hit
+                    self._shape = tuple(noisy.shape)
+                else:
+                    self._capture(noisy, clean)
             self._static[0].copy_(noisy)
             self._static[1].copy_(clean)
             for g, bucket in self._graphs:

@@ -184,3 +184,22 @@ def test_guarded_adam_skips_nonfinite_and_timeout_steps():
         ops.check_gru_status()
     ops.gru_status_reset()
     assert ops.gru_status() == 0
+
+
+def test_engine_caches_one_graph_per_input_shape():
+    """a partial last batch must not force a re-capture on every epoch: graphs are cached per shape."""
+    from cruse_amd.engine import TrainEngine
+    from cruse_amd.model.cruse_net import unet_2
+    from oracle import cruse_oracle as O
+    torch.manual_seed(0)
+    eng = TrainEngine(unet_2(rnn_groups=2, precision="f32").cuda(), use_graph=True)
+    a = [t_.cuda() for t_ in O.synth_pair(3, 3200, seed=1)]
+    b = [t_.cuda() for t_ in O.synth_pair(2, 3200, seed=2)]
+    eng.step(*a); ga = eng._graphs
+    eng.step(*b); gb = eng._graphs
+    eng.step(*a)
+    assert eng._graphs is ga and len(eng._graph_cache) == 2
+    eng.step(*b)
+    assert eng._graphs is gb
+    torch.cuda.synchronize()
+    assert eng.skipped_steps() == 0 and eng.step_count == 4
