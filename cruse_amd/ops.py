@@ -110,6 +110,7 @@ def conv_scatter2(g, w, bias, B, T, Cs, Fg, Cout, KT, pad, act=0, out=None, accu
 
 
 _wgrad_ws = {}
+_ws_retired = []          # outgrown workspaces: captured HIP graphs may still point at them, so they are never freed
 
 
 def _ws(key, nbytes: int, device) -> torch.Tensor:
@@ -119,8 +120,10 @@ def _ws(key, nbytes: int, device) -> torch.Tensor:
         # zero-filled: the GRU workspace starts with a STICKY 256-byte header (hand-off status word) that the library
         # never clears (include/cruse_hip.h, cruse_gru_seq_fwd); a grown buffer inherits the old header
         buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
-        if old is not None and key == "gru":
-            buf[:256].copy_(old[:256])
+        if old is not None:
+            _ws_retired.append((key, old))
+            if key == "gru":
+                buf[:256].copy_(old[:256])
         _wgrad_ws[(key, device)] = buf
     return buf
 
@@ -399,6 +402,9 @@ def gru_status() -> int:
     for (key, _dev), buf in _wgrad_ws.items():
         if key == "gru":
             bad |= int(buf[:4].view(torch.int32).item())
+    for key, buf in _ws_retired:                       # graphs captured before the workspace grew still report here
+        if key == "gru":
+            bad |= int(buf[:4].view(torch.int32).item())
     return bad
 
 
@@ -410,6 +416,9 @@ def gru_status_word(device, B: int, G: int, Hg: int) -> torch.Tensor:
 
 def gru_status_reset() -> None:
     for (key, _dev), buf in _wgrad_ws.items():
+        if key == "gru":
+            buf[:256].zero_()
+    for key, buf in _ws_retired:
         if key == "gru":
             buf[:256].zero_()
 
