@@ -131,19 +131,3 @@ def test_rccl_bucketed_schedule_world1(tmp_path, nograph):
     assert rel_l2(a["g0"], b["g0"]) < 1e-6
     assert rel_l2(a["params"], b["params"]) < 1e-4        # split-K atomics: noise-level entries move through Adam
     assert a["losses"] == pytest.approx(b["losses"], rel=1e-6)
-
-
-def test_bucket_layout_follows_backward_order():
-    from cruse_amd.engine import FlatParams
-    from cruse_amd.model.cruse_net import bucket_of, unet_2
-    m = unet_2(rnn_groups=1)
-    fp = FlatParams(m)
-    (s0, e0), (s1, e1), (s2, e2) = fp.bucket_range
-    assert s0 == 0 and e0 == s1 and e1 == s2 and e2 == fp.total
-    for n, o in fp.offsets.items():
-        b = bucket_of(n)
-        assert fp.bucket_range[b][0] <= o < fp.bucket_range[b][1], n
-    assert bucket_of("gru.gru_list2.0.weight_hh_l0") == 0 and bucket_of("conv3_t.weight") == 0
-    assert bucket_of("gru.gru_list1.0.weight_ih_l0") == 1 and bucket_of("conv2.weight") == 2
-    # the two GGRU layers dominate: buckets 0 and 1 each carry about half of the 19.9 MB
-    assert abs((e0 - s0) - (e1 - s1)) < 0.05 * fp.total and (e2 - s2) < 0.02 * fp.total

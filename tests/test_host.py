@@ -147,3 +147,63 @@ def test_inferencer_import_path_and_int16_scaling():
     from train_base.inferencer.base_inferencer import Inferencer
     w = Inferencer.to_int16(np.array([0.0, 0.25, -0.5], dtype=np.float32))
     assert w.dtype == np.int16 and w.tolist() == [0, int(0.8 * 32767 * 0.5), int(-0.8 * 32767)]
+
+
+def test_bucket_layout_follows_backward_order():
+    from cruse_amd.engine import FlatParams
+    from cruse_amd.model.cruse_net import bucket_of, unet_2
+    m = unet_2(rnn_groups=1)
+    fp = FlatParams(m)
+    (s0, e0), (s1, e1), (s2, e2) = fp.bucket_range
+    assert s0 == 0 and e0 == s1 and e1 == s2 and e2 == fp.total
+    for n, o in fp.offsets.items():
+        b = bucket_of(n)
+        assert fp.bucket_range[b][0] <= o < fp.bucket_range[b][1], n
+    assert bucket_of("gru.gru_list2.0.weight_hh_l0") == 0 and bucket_of("conv3_t.weight") == 0
+    assert bucket_of("gru.gru_list1.0.weight_ih_l0") == 1 and bucket_of("conv2.weight") == 2
+    # the two GGRU layers dominate: buckets 0 and 1 each carry about half of the 19.9 MB
+    assert abs((e0 - s0) - (e1 - s1)) < 0.05 * fp.total and (e2 - s2) < 0.02 * fp.total
+
+
+def test_adam_state_dict_is_torch_adam_layout():
+    """FlatParams.adam_state_dict / load_adam_state_dict <-> torch.optim.Adam.state_dict() (base_trainer.py:167,199-203)."""
+    from cruse_amd.engine import FlatParams
+    from oracle import cruse_oracle as O
+    m = O.unet_2(rnn_groups=2)
+    fp = FlatParams(m)
+    fp.exp_avg.copy_(torch.sin(torch.arange(fp.total, dtype=torch.float32)))
+    fp.exp_avg_sq.copy_(torch.cos(torch.arange(fp.total, dtype=torch.float32)) ** 2)
+    sd = fp.adam_state_dict(7, 1e-3, (0.9, 0.999), 1e-8, 0.0)
+    opt = torch.optim.Adam(m.parameters(), lr=5e-4)
+    opt.load_state_dict(sd)                                   # the reference's resume path accepts it
+    st = opt.state_dict()
+    names = [n for n, _ in m.named_parameters()]
+    assert set(st["state"]) == {i for i, n in enumerate(names) if n in fp.offsets}
+    i = names.index("gru.gru_list1.0.weight_hh_l0")
+    assert torch.equal(st["state"][i]["exp_avg"], fp.view(fp.exp_avg, names[i])) and float(st["state"][i]["step"]) == 7.0
+    fp2 = FlatParams(O.unet_2(rnn_groups=2))
+    assert fp2.load_adam_state_dict(st) == 7
+    for n in fp.names:                                        # (the alignment gaps between tensors are not state)
+        assert torch.equal(fp2.view(fp2.exp_avg, n), fp.view(fp.exp_avg, n)), n
+        assert torch.equal(fp2.view(fp2.exp_avg_sq, n), fp.view(fp.exp_avg_sq, n)), n
+    bad = dict(st, param_groups=[dict(st["param_groups"][0], params=st["param_groups"][0]["params"][:-1])])
+    with pytest.raises(RuntimeError, match="parameters"):
+        fp2.load_adam_state_dict(bad)
+
+
+def test_loss_factories_carry_engine_tags():
+    import train_base.loss as L
+    assert L.wo_male_loss(alpha=3.0).cruse_loss == ("wo_male", {"loss_alpha": 3.0, "loss_beta": 1.0})
+    assert L.si_snr_loss().cruse_loss == ("si_snr", {})
+    assert L.sdnr_loss(snr=5.0).cruse_loss == ("sdnr", {"snr_db": 5.0, "sdnr_beta_db": 20.0})
+    assert not hasattr(L.l1_loss(), "cruse_loss")
+
+
+def test_reference_dotted_paths_resolve():
+    """every reference import path this repo stands in for (train_base/utils.py:68-100 loads by dotted path)."""
+    from train_base.utils import initialize_module
+    for path in ("model.based_model.cust_conv.GroupGRU", "model.based_model.cust_conv.convkxf", "model.mtfaa.TFCM_Block",
+                 "train_base.acoustics.conv_stft.STFT", "train_base.acoustics.feature.CustomSTFT",
+                 "train_base.acoustics.mask.compress_cIRM", "loss_func.loss.loss_func", "dataset.dataset.SynDataset",
+                 "model.deep_filter.DeepFilter"):
+        assert initialize_module(path, initialize=False) is not None, path

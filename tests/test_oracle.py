@@ -119,3 +119,69 @@ def test_interleave_is_not_groupgru_shuffle():
     for i in range(g):
         for j in range(h):
             assert new[j * g + i] == cat[i * h + j]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 2: oracle part 2 against the fixtures generated from the reference's own code (tests/golden/make_golden_r2.py)
+# ---------------------------------------------------------------------------------------------------------------------
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_oracle_ext_losses_and_snr_mix(golden):
+    from oracle import cruse_oracle_ext as X
+    g = golden("g10_losses.npz")
+    ref, est = _t(g["ref"]), _t(g["est"])
+    assert torch.equal(X.rmse(ref, est), _t(g["rmse"])) and torch.equal(X.c_rmse(ref, est), _t(g["c_rmse"]))
+    s = golden("g15_snr_mix.npz")
+    for b in range(3):
+        noisy, c, n = X.snr_mix(s["clean"][b].copy(), s["noise"][b].copy(), float(s["snr"][b]))
+        assert np.array_equal(noisy, s["noisy"][b]) and np.array_equal(c, s["clean_n"][b]) and np.array_equal(n, s["noise_s"][b])
+
+
+def test_oracle_ext_conv_blocks_and_group_gru(golden):
+    from oracle import cruse_oracle as O
+    from oracle import cruse_oracle_ext as X
+    g = golden("g11_convblocks.npz")
+    cases = {"cna": lambda: X.Conv2dNormAct(1, 16, (2, 3), fstride=2),
+             "ctna_sep": lambda: X.ConvTranspose2dNormAct(16, 8, (1, 3), fstride=2, separable=True),
+             "kxf_upsample": lambda: X.convkxf(16, 8, k=2, f=3, fstride=2, mode="upsample", batch_norm=True)}
+    for name, build in cases.items():
+        m = build(); O.closed_form_init(m); m.train()
+        assert torch.equal(m(_t(g[f"{name}/x"])), _t(g[f"{name}/y_train"])), name
+        m.eval()
+        assert torch.equal(m(_t(g[f"{name}/x"])), _t(g[f"{name}/y_eval"])), name
+    gg = golden("g12_groupgru.npz")
+    m = X.GroupGRU(128, 128, num_layers=3, groups=4, add_outputs=True)
+    O.closed_form_init(m, scale=2.0)
+    y, s = m(_t(gg["x"]))
+    assert torch.equal(y, _t(gg["g4_l3_add/y"])) and torch.equal(s, _t(gg["g4_l3_add/state"]))
+
+
+def test_oracle_ext_stft_variants_and_mtfaa(golden):
+    from oracle import cruse_oracle as O
+    from oracle import cruse_oracle_ext as X
+    g = golden("g13_stft_variants.npz")
+    wav = _t(g["wav"])
+    K = X.init_stft_kernel(320, 160)
+    m, p, r, i = X.custom_stft(wav, K, 160)
+    assert torch.equal(r, _t(g["custom512/r"])) and torch.equal(m, _t(g["custom512/m"]))
+    assert torch.equal(X.custom_istft(_t(g["custom512/m"]), _t(g["custom512/p"]), K, 160), _t(g["custom512/y"]))
+    cs = X.ConvSTFT(320, 160)
+    sr, si, mag, _ = cs.stft(wav)
+    assert torch.equal(sr, _t(g["conv/spec_r"])) and torch.equal(si, _t(g["conv/spec_i"]))
+    assert float((cs.istft(torch.stack([sr, si], 1)) - wav).abs().max()) < 2e-6           # the (decided) inverse inverts
+    a = golden("g14_mtfaa.npz")
+    assert torch.equal(X.mtfaa_stft_transform(_t(a["sig"]), 320, 160, 320, "hamm"), _t(a["stft_hamm"]))
+    blk = X.TFCM_Block(24, (3, 3), 4); O.closed_form_init(blk, 2.0); blk.train()
+    assert torch.equal(blk(_t(a["tfcm/x"])), _t(a["tfcm_d4/y_train"]))
+
+
+def test_oracle_ext_deepfilter_step(golden):
+    from oracle import cruse_oracle as O
+    from oracle import cruse_oracle_ext as X
+    g = golden("g16_df_step_g1.npz")
+    m = O.unet_2(rnn_groups=1); O.closed_form_init(m); m.train()
+    loss, aux = X.train_step_loss_df(m, _t(g["noisy"]), _t(g["clean"]))
+    assert torch.equal(loss, _t(g["loss"])) and torch.equal(aux["est"], _t(g["est"]))
+    assert float(aux["est"][:, :, :, 160].abs().max()) > 0.0        # the 11-bin neighbourhood reaches the Nyquist bin

@@ -1,0 +1,51 @@
+"""BASELINE config 5 (alt-model stress of the STFT + conv kernels): the blocks model/mtfaa.py actually defines --
+STFT.transform -> PhaseEncoder -> 6 x TFCM_Block (dilations 1..32) -- forward + backward on B clips of `seconds` s.
+The file has no axial attention and its `Banks` needs the absent `spafe`, so this is all there is to
+stress.  Prints frames/s (10 ms hop) of fwd+bwd; f32 storage, direct VALU convolutions (generic.hip)."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--seconds", type=float, default=4.0)
+    ap.add_argument("--steps", type=int, default=5)
+    a = ap.parse_args()
+    from model import mtfaa as M
+    torch.manual_seed(0)
+    stft = M.STFT(320, 160, 320, "hann")
+    pe = M.PhaseEncoder(4, 1).cuda()                 # 1 signal: [B,2,F,T] -> |.|^0.5 [B,2,F,T]
+    tfcm = M.TFCM(24, (3, 3), 6).cuda()
+    L = int(a.seconds * 16000)
+    x = (0.1 * torch.randn(a.batch, L)).cuda()
+    params = [p for m in (pe, tfcm) for p in m.parameters()]
+
+    def step():
+        c = stft.transform(x)                        # [B,2,161,T]
+        amp = pe([c])                                # [B,2,161,T]
+        h = torch.cat([amp] * 12, dim=1)             # [B,24,161,T] (channel plumbing)
+        y = tfcm(h)
+        for p in params:
+            p.grad = None
+        y.square().mean().backward()
+        return y
+    y = step(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        y = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    T = y.shape[-1]
+    print(f"mtfaa blocks fwd+bwd: B={a.batch} x {a.seconds:g} s, activations [B,24,161,{T}]: {dt * 1e3:.1f} ms/step, "
+          f"{a.batch * T / dt:,.0f} frames/s; finite={bool(torch.isfinite(y).all())}")
+
+
+if __name__ == "__main__":
+    main()
