@@ -78,6 +78,43 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConv a) {
     }
 }
 
+// 1x1, stride 1, groups 1 (the pointwise convolutions of TFCM_Block / the depthwise-separable blocks, either form): one
+// thread per POSITION computes all Cout outputs from Cin coalesced loads -- the general kernel above issues Cin loads per
+// OUTPUT (Cout x more).  Weights sit in LDS as [Cout][Cin] (transposed == 1: read from the [Cin][Cout] tensor).
+template <int MAXCO>
+__global__ __launch_bounds__(256) void gconv_pointwise_kernel(GConv a) {
+    extern __shared__ float wl[];                    // [Cout][Cin]
+    for (int i = threadIdx.x; i < a.Cout * a.Cin; i += 256) {
+        const int co = i / a.Cin, ci = i - co * a.Cin;
+        wl[i] = a.transposed ? a.w[(long long)ci * a.Cout + co] : a.w[i];
+    }
+    __syncthreads();
+    const long long hw = (long long)a.Hin * a.Win, total = (long long)a.B * hw;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long b = i / hw, p = i - b * hw;
+        const float* xp = a.x + b * a.Cin * hw + p;
+        float acc[MAXCO];
+#pragma unroll
+        for (int co = 0; co < MAXCO; ++co) acc[co] = (co < a.Cout && a.bias) ? a.bias[co] : 0.f;
+        for (int ci = 0; ci < a.Cin; ++ci) {
+            const float v = xp[(long long)ci * hw];
+#pragma unroll
+            for (int co = 0; co < MAXCO; ++co)
+                if (co < a.Cout) acc[co] += wl[co * a.Cin + ci] * v;
+        }
+        float* yp = a.y + b * a.Cout * hw + p;
+#pragma unroll
+        for (int co = 0; co < MAXCO; ++co) {
+            if (co < a.Cout) {
+                float v = acc[co];
+                if (a.act == 1) v = fmaxf(v, 0.f);
+                else if (a.act == 2) v = v >= 0.f ? v : a.slope[co] * v;
+                if (a.accumulate) yp[(long long)co * hw] += v; else yp[(long long)co * hw] = v;
+            }
+        }
+    }
+}
+
 // Weight gradient of both forms as ONE contraction:
 //   dw[ca][cb_l][kh][kw] += sum_{n,h,w} S[n,ca,h,w] * Bg[n, g*CBg + cb_l, h*sh - pt + kh*dh, (w*sw - pl + kw*dw) / up_w]
 // Conv2d:          S = dy (ca = co, HxW = output size), Bg = x;   ConvTranspose2d: S = x (ca = ci), Bg = dy.
@@ -115,6 +152,49 @@ __global__ __launch_bounds__(256) void gconv_wgrad_kernel(GWgrad a) {
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(&a.dw[blockIdx.x], red[0] + red[1] + red[2] + red[3]);
+}
+
+// Row-tiled form of the same contraction for small channel counts: a block owns one (n, h) row of S, stages it ([CA][WS]) and,
+// for each kh, the matching row of Bg ([CB][WB]) in LDS ONCE, and every thread accumulates its weight elements (ca, cb_l, kw)
+// over the row from LDS; one atomic per weight element and block.  The per-weight kernel above streams one plane of S and one of
+// Bg per BLOCK -- CA*CB/groups*KH*KW times the tensors' bytes (2.3 GB for a 24 x 24 pointwise layer on [8,24,161,401]).
+__global__ __launch_bounds__(256) void gconv_wgrad_rows_kernel(GWgrad a) {
+    extern __shared__ float sm[];
+    float* Ss = sm;                                   // [CA][WS]
+    float* Bs = sm + (size_t)a.CA * a.WS;             // [CB][WB]
+    const int n = blockIdx.x / a.HS, h = blockIdx.x - n * a.HS;
+    const int cb_g = a.CB / a.groups, ca_g = a.CA / a.groups;
+    const int nwk = a.CA * cb_g * a.KW;               // weight elements per kh
+    const int Wup = a.WB * a.up_w;
+    for (int i = threadIdx.x; i < a.CA * a.WS; i += 256) {
+        const int ca = i / a.WS, w = i - ca * a.WS;
+        Ss[i] = a.S[(((long long)n * a.CA + ca) * a.HS + h) * a.WS + w];
+    }
+    for (int kh = 0; kh < a.KH; ++kh) {
+        const int hb = h * a.sh - a.pt + kh * a.dh;
+        __syncthreads();                              // S staged / previous kh's reads done
+        if (hb < 0 || hb >= a.HB) continue;           // block-uniform
+        for (int i = threadIdx.x; i < a.CB * a.WB; i += 256) {
+            const int cb = i / a.WB, w = i - cb * a.WB;
+            Bs[i] = a.Bg[(((long long)n * a.CB + cb) * a.HB + hb) * a.WB + w];
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < nwk; e += 256) {
+            const int kw = e % a.KW;
+            const int r = e / a.KW;
+            const int cb_l = r % cb_g, ca = r / cb_g;
+            const int cb = (ca / ca_g) * cb_g + cb_l;
+            const float* sp = Ss + (size_t)ca * a.WS;
+            const float* bp = Bs + (size_t)cb * a.WB;
+            const int off = kw * a.dw_ - a.pl;
+            float acc = 0.f;
+            for (int w = 0; w < a.WS; ++w) {
+                const int wb = w * a.sw + off;
+                if (wb >= 0 && wb < Wup) acc += sp[w] * bp[wb / a.up_w];
+            }
+            atomicAdd(&a.dw[((long long)(ca * cb_g + cb_l) * a.KH + kh) * a.KW + kw], acc);
+        }
+    }
 }
 
 // out[c] += sum_{n,hw} x[n,c,hw]   (conv bias gradient)
@@ -266,6 +346,16 @@ extern "C" int cruse_conv2d_nchw(const float* x, const float* w, const float* bi
     CRUSE_REQUIRE(act >= 0 && act <= 2 && (act != 2 || slope) && !(accumulate && act), CRUSE_E_SHAPE, "conv2d_nchw: bad activation");
     GConv a = {x, w, bias, y, B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, sh, sw, dh, dw, pt, pl, groups, up_w, transposed, act,
                accumulate, slope};
+    if (KH == 1 && KW == 1 && sh == 1 && sw == 1 && pt == 0 && pl == 0 && groups == 1 && up_w == 1 && Hout == Hin && Wout == Win &&
+        Cout <= 64 && Cin <= 256) {
+        const size_t lds = (size_t)Cout * Cin * sizeof(float);
+        const int nb = gblocks((long long)B * Hin * Win, 256, 8192);
+        if (Cout <= 16) hipLaunchKernelGGL(gconv_pointwise_kernel<16>, dim3(nb), dim3(256), lds, ST(stream), a);
+        else if (Cout <= 32) hipLaunchKernelGGL(gconv_pointwise_kernel<32>, dim3(nb), dim3(256), lds, ST(stream), a);
+        else hipLaunchKernelGGL(gconv_pointwise_kernel<64>, dim3(nb), dim3(256), lds, ST(stream), a);
+        CRUSE_LAUNCH_CHECK("conv2d_nchw pointwise");
+        return CRUSE_OK;
+    }
     hipLaunchKernelGGL(gconv_kernel, dim3(gblocks((long long)B * Cout * Hout * Wout, 256, 16384)), dim3(256), 0, ST(stream), a);
     CRUSE_LAUNCH_CHECK("conv2d_nchw");
     return CRUSE_OK;
@@ -279,6 +369,14 @@ extern "C" int cruse_conv2d_nchw_wgrad(const float* S, const float* Bg, float* d
                   "conv2d_nchw_wgrad: bad shape");
     CRUSE_REQUIRE(CA % groups == 0 && CB % groups == 0 && up_w > 0, CRUSE_E_SHAPE, "conv2d_nchw_wgrad: groups");
     GWgrad a = {S, Bg, dw, N, CA, HS, WS, CB, HB, WB, KH, KW, sh, sw, dh, dw_, pt, pl, groups, up_w};
+    const size_t row_lds = ((size_t)CA * WS + (size_t)CB * WB) * sizeof(float);
+    if (row_lds <= 150 * 1024 && (long long)N * HS >= 8) {        // a row pair fits LDS (the per-weight kernel below is the fallback)
+        int rc = cruse_ensure_dyn_lds((const void*)gconv_wgrad_rows_kernel, row_lds, "conv2d_nchw_wgrad");
+        if (rc) return rc;
+        hipLaunchKernelGGL(gconv_wgrad_rows_kernel, dim3(N * HS), dim3(256), row_lds, ST(stream), a);
+        CRUSE_LAUNCH_CHECK("conv2d_nchw_wgrad rows");
+        return CRUSE_OK;
+    }
     const int nw = CA * (CB / groups) * KH * KW;
     int ny = 1;
     while (ny < N && (long long)nw * ny < 2048) ny *= 2;
