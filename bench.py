@@ -453,7 +453,7 @@ def main():
                                    + " + grad all-reduce + Adam; f32 storage, "
                                    f"{a.prec} MFMA operands, f32 accumulate/statistics",
                        "global_batch": world * B, "per_gpu_batch": B, "frames_per_clip": T,
-                       "parallelism": f"dp{world}", "hip_graph": not a.no_graph},
+                       "parallelism": f"dp{world}", "hip_graph": bool(eng.use_graph), "bucketed_allreduce": bool(eng.bucketed)},
             "ms_per_step_median": round(med_ms, 3),
             "value_at_median_step": round(world * B * T / (med_ms * 1e-3), 1),
             "parity_rel_l2": None if parity is None else float(f"{parity:.4g}"),

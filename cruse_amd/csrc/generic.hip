@@ -188,9 +188,27 @@ __global__ __launch_bounds__(256) void gconv_wgrad_rows_kernel(GWgrad a) {
             const float* bp = Bs + (size_t)cb * a.WB;
             const int off = kw * a.dw_ - a.pl;
             float acc = 0.f;
-            for (int w = 0; w < a.WS; ++w) {
-                const int wb = w * a.sw + off;
-                if (wb >= 0 && wb < Wup) acc += sp[w] * bp[wb / a.up_w];
+            if (a.up_w == 1) {
+                // valid w range hoisted out of the loop: 0 <= w*sw + off < WB  (no per-element division or branch)
+                int w_lo = off >= 0 ? 0 : (-off + a.sw - 1) / a.sw;
+                int w_hi = (Wup - 1 - off) >= 0 ? (Wup - 1 - off) / a.sw + 1 : 0;
+                if (w_hi > a.WS) w_hi = a.WS;
+                const float* bq = bp + off;
+                int w = w_lo;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                for (; w + 3 < w_hi; w += 4) {
+                    a0 += sp[w] * bq[w * a.sw];
+                    a1 += sp[w + 1] * bq[(w + 1) * a.sw];
+                    a2 += sp[w + 2] * bq[(w + 2) * a.sw];
+                    a3 += sp[w + 3] * bq[(w + 3) * a.sw];
+                }
+                for (; w < w_hi; ++w) a0 += sp[w] * bq[w * a.sw];
+                acc = (a0 + a1) + (a2 + a3);
+            } else {
+                for (int w = 0; w < a.WS; ++w) {
+                    const int wb = w * a.sw + off;
+                    if (wb >= 0 && wb < Wup) acc += sp[w] * bp[wb / a.up_w];
+                }
             }
             atomicAdd(&a.dw[((long long)(ca * cb_g + cb_l) * a.KH + kh) * a.KW + kw], acc);
         }

@@ -323,7 +323,8 @@ class TrainEngine:
 
         def begin():
             g = torch.cuda.CUDAGraph()
-            cm = torch.cuda.graph(g, pool=pool)
+            # thread_local: ProcessGroupNCCL's watchdog thread may query its events while this thread captures
+            cm = torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local")
             cm.__enter__()
             cur["g"], cur["cm"] = g, cm
 
@@ -378,7 +379,17 @@ class TrainEngine:
                     self._graphs, self._static, self._static_loss = hit
                     self._shape = tuple(noisy.shape)
                 else:
-                    self._capture(noisy, clean)
+                    try:
+                        self._capture(noisy, clean)
+                    except RuntimeError as ex:
+                        # still the HIP path, just launched kernel by kernel: say so loudly and carry on
+                        import sys
+                        print(f"[cruse_amd] HIP-graph capture failed ({str(ex)[:200]}); continuing WITHOUT graphs", file=sys.stderr, flush=True)
+                        self.use_graph = False
+                        self._graphs = None
+                        SIDE.join()
+                        torch.cuda.synchronize()
+                        return self.step(noisy, clean)
             self._static[0].copy_(noisy)
             self._static[1].copy_(clean)
             for g, bucket in self._graphs:
