@@ -443,7 +443,7 @@ def main():
     if rank == 0:
         frames = world * B * T * a.steps
         out = {
-            "metric": "spectrogram frames/sec training CRUSE 16kHz 20ms-frame/10ms-hop",
+            "metric": "spectrogram frames/sec training CRUSE 16kHz 20ms-hop at 1/2/4/8 MI355X",
             "value": round(frames / el, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(el / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.prec, "data": "synthetic",
@@ -452,6 +452,9 @@ def main():
                                    + ("STFT x2 + fwd + DeepFilter(1,5) head + WO-MALE + bwd" if a.df else "STFT x2 + fwd + WO-MALE + bwd")
                                    + " + grad all-reduce + Adam; f32 storage, "
                                    f"{a.prec} MFMA operands, f32 accumulate/statistics",
+                       "framing": "20 ms frames (n_fft = win = 320) at a 10 ms hop (160): the reference's framing (conv_stft.py:10-11, "
+                                  "audioAug.py:191); a literal 20 ms hop = win violates NOLA, so no iSTFT / training step exists for "
+                                  "it -- its forward STFT is the secondary row stft_hop320_forward (SURVEY 8d)",
                        "global_batch": world * B, "per_gpu_batch": B, "frames_per_clip": T,
                        "parallelism": f"dp{world}", "hip_graph": bool(eng.use_graph), "bucketed_allreduce": bool(eng.bucketed)},
             "ms_per_step_median": round(med_ms, 3),
