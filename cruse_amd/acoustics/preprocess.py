@@ -1,0 +1,94 @@
+"""MI355X-native `utils.utils.PreProcess` (utils/utils.py:365-455): STFT front end as that class
+writes it -- Hann window of fft_len, center=True with ZERO ("constant") padding, [B,1,T,F] real / imag / magnitude
+sqrt(.+1e-8) / phase -- the three masking modes and the iSTFT reconstruction, on HIP kernels.
+
+Repair: `torch.stft` is called without `return_complex` (:390-396), a RuntimeError on torch >= 2 -> the real view of the
+complex result.  `reconstruction` (:443-455) hands the [B,T,F,2] tensor `masking` returns straight to `torch.istft`, which
+wants [B,F,T] complex: both layouts are accepted here.  (The training hot path uses feature.stft's REFLECT padding with
+this class's layout and magnitude: cruse_amd.acoustics.feature.pre_stft, SURVEY 8a row a2's decision; the two differ in
+frames 0 and T-1 only.)
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import ops
+from .._lib import check, lib
+from .feature import istft_ri, mag_phase, stft_framed
+
+_p, _stream = ops._p, ops._stream
+
+
+def _pair_op(mode, a, b, c, d):
+    a, b, c, d = (t.contiguous().float() for t in (a, b, c, d))
+    o1 = torch.empty_like(a); o2 = torch.empty_like(a)
+    check(lib.cruse_mask_ops(mode, _p(a), _p(b), _p(c), _p(d), a.numel(), 0.0, 0.0, 0.0, _p(o1), _p(o2), _stream()))
+    return o1, o2
+
+
+class PreProcess:
+    def __init__(self, win_len, win_inc, fft_len, win_type, post_process_mode, loss_mode, use_cuda=False):
+        self.win_len = win_len
+        self.win_inc = win_inc
+        self.fft_len = fft_len
+        self.win_type = win_type
+        self.post_process_mode = post_process_mode
+        self.loss_mode = loss_mode
+        self.use_cuda = use_cuda
+        if win_type == "hanning":
+            self.window = torch.hann_window(self.fft_len)
+        else:
+            raise ValueError("ERROR window type")
+        if win_len != fft_len:
+            raise RuntimeError("PreProcess: the window is built with fft_len (:384), so win_len must equal fft_len")
+        self.window = self.window.cuda()                 # the HIP path has no CPU form
+
+    def pre_stft(self, inputs):
+        """[B,L] -> stft_inputs [B,2,T,F], real, imag, spec_mags, spec_phase [B,1,T,F] (utils/utils.py:389-412)."""
+        if inputs.dim() != 2:
+            raise RuntimeError(f"PreProcess.pre_stft expects [B,L], got {tuple(inputs.shape)}")
+        L = inputs.shape[1]
+        re, im = stft_framed(inputs, self.window, self.fft_len, self.win_inc, win_off=0, pad=self.fft_len // 2,
+                             pad_mode="constant", frames=1 + L // self.win_inc)                  # [B,T,F]
+        mags = torch.empty_like(re); phase = torch.empty_like(re)
+        check(lib.cruse_polar(0, _p(re), _p(im), None, re.numel(), 1e-8, 1.0, _p(mags), _p(phase), _stream()))
+        stft_inputs = torch.stack([re, im], dim=1)                                              # [B,2,T,F] (:397)
+        self.real, self.imag = re.unsqueeze(1), im.unsqueeze(1)
+        self.spec_mags, self.spec_phase = mags.unsqueeze(1), phase.unsqueeze(1)
+        return stft_inputs, self.real, self.imag, self.spec_mags, self.spec_phase
+
+    def log_transform(self):
+        x = self.spec_mags.contiguous()
+        out = torch.empty_like(x)
+        check(lib.cruse_mask_ops(6, _p(x), None, None, None, x.numel(), 0.0, 0.0, 0.0, _p(out), None, _stream()))
+        self.spec_mags = out
+
+    def masking(self, mask_real, mask_imag=None):
+        """-> [B,T,F,2] (utils/utils.py:417-433).  Masks are [B,1,T,F] like the spectra."""
+        if self.post_process_mode == "mag_mapping":
+            out_real, out_imag = _pair_op(5, self.real, self.imag, mask_real, mask_real)
+        elif self.post_process_mode == "complex_mapping":
+            out_real, out_imag = _pair_op(5, self.real, self.imag, mask_real, mask_imag)
+        elif self.post_process_mode == "mapping":
+            out_real, out_imag = mask_real, mask_imag
+        else:
+            raise NotImplementedError(self.post_process_mode)      # the reference evaluates the bare name (:427)
+        return torch.stack([out_real.squeeze(1), out_imag.squeeze(1)], dim=-1).contiguous()
+
+    def refsig_process(self, indatas):
+        if self.loss_mode == "freq":
+            out, _, _, _, _ = self.pre_stft(indatas)
+        elif self.loss_mode == "time":
+            out = indatas
+        return out
+
+    def reconstruction(self, stft_outputs, sig_len=None):
+        """[B,T,F,2] (what masking returns) or complex [B,F,T] -> [B,L] (utils/utils.py:443-455)."""
+        if not isinstance(stft_outputs, torch.Tensor):
+            stft_outputs = torch.from_numpy(stft_outputs).type(torch.FloatTensor)
+        stft_outputs = stft_outputs.cuda()
+        if stft_outputs.is_complex():
+            re, im = stft_outputs.real.transpose(1, 2), stft_outputs.imag.transpose(1, 2)
+        else:
+            re, im = stft_outputs[..., 0], stft_outputs[..., 1]
+        return istft_ri(re, im, self.fft_len, self.win_inc, sig_len)

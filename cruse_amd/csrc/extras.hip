@@ -26,6 +26,8 @@ __device__ __forceinline__ float decompress_cirm(float m, float K, float limit) 
 // mode 1: cIRM = compress([ (nr*cr + ni*ci)/den, (nr*ci - ni*cr)/den ]), den = nr^2 + ni^2 + EPS   -> out[n][2]
 // mode 2: compress(a)          mode 3: decompress(a)
 // mode 4: complex_mul (a + ib)(c + id) -> out = real, out2 = imag
+// mode 5: element-wise pair product out = a*c, out2 = b*d   (PreProcess.masking "complex_mapping", utils/utils.py:421-423)
+// mode 6: out = log(a)                                       (PreProcess.log_transform, utils/utils.py:414-415)
 __global__ void mask_ops_kernel(int mode, const float* a, const float* b, const float* c, const float* d, long long n,
                                 float K, float C, float limit, float* out, float* out2) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -40,10 +42,15 @@ __global__ void mask_ops_kernel(int mode, const float* a, const float* b, const 
             out[i] = compress_cirm(a[i], K, C);
         } else if (mode == 3) {
             out[i] = decompress_cirm(a[i], K, limit);
-        } else {
+        } else if (mode == 4) {
             const float nr = a[i], ni = b[i], mr = c[i], mi = d[i];
             out[i] = nr * mr - ni * mi;
             out2[i] = nr * mi + ni * mr;
+        } else if (mode == 5) {
+            out[i] = a[i] * c[i];
+            out2[i] = b[i] * d[i];
+        } else {
+            out[i] = logf(a[i]);
         }
     }
 }
@@ -264,8 +271,8 @@ inline int eblocks(long long n, int per = 1024, int cap = 4096) {
 
 extern "C" int cruse_mask_ops(int mode, const float* a, const float* b, const float* c, const float* d, long long n,
                               float K, float C, float limit, float* out, float* out2, void* stream) {
-    CRUSE_REQUIRE(mode >= 0 && mode <= 4 && n > 0 && a && out, CRUSE_E_SHAPE, "mask_ops: bad arguments (mode %d, n %lld)", mode, n);
-    CRUSE_REQUIRE(!(mode == 0 && !c) && !((mode == 1 || mode == 4) && !(b && c && d)) && !(mode == 4 && !out2), CRUSE_E_SHAPE,
+    CRUSE_REQUIRE(mode >= 0 && mode <= 6 && n > 0 && a && out, CRUSE_E_SHAPE, "mask_ops: bad arguments (mode %d, n %lld)", mode, n);
+    CRUSE_REQUIRE(!(mode == 0 && !c) && !((mode == 1 || mode == 4 || mode == 5) && !(b && c && d)) && !((mode == 4 || mode == 5) && !out2), CRUSE_E_SHAPE,
                   "mask_ops: missing operand for mode %d", mode);
     hipLaunchKernelGGL(mask_ops_kernel, dim3(eblocks(n)), dim3(256), 0, ST(stream), mode, a, b, c, d, n, K, C, limit, out, out2);
     CRUSE_LAUNCH_CHECK("mask_ops");

@@ -325,7 +325,8 @@ int cruse_istft_framed(const float* re, const float* im, const float* window, co
 
 /* ---- masks, further losses, data synthesis ------------------------------------------------------------------------ */
 /* train_base/acoustics/mask.py:8-63.  mode 0 IRM (a = noisy_mag, c = clean_mag), 1 cIRM (a,b = noisy re,im; c,d = clean
- * re,im; out [n,2]), 2 compress_cIRM(a), 3 decompress_cIRM(a), 4 complex_mul (a + ib)(c + id) -> out, out2. */
+ * re,im; out [n,2]), 2 compress_cIRM(a), 3 decompress_cIRM(a), 4 complex_mul (a + ib)(c + id) -> out, out2;
+ * PreProcess (utils/utils.py:414-423): 5 pair product out = a*c, out2 = b*d ("complex_mapping"), 6 out = log(a). */
 int cruse_mask_ops(int mode, const float* a, const float* b, const float* c, const float* d, long long n,
                    float K, float C, float limit, float* out, float* out2, void* stream);
 /* mode 0: (re, im) -> (sqrt(re^2+im^2+eps)**alpha, atan2(im, re)) (feature.py:363-364, mtfaa.py:136-137,162);

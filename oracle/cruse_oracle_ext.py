@@ -25,6 +25,44 @@ EPSILON = np.finfo(np.float32).eps                       # train_base/constant.p
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# a2-a4 as written: utils/utils.py PreProcess (constant padding; the hot path's reflect-padded form is cruse_oracle.pre_stft)
+# ----------------------------------------------------------------------------------------------------------------------
+class PreProcess:
+    """utils/utils.py:365-455.  Repair: torch.stft without return_complex (:390-396) -> real view of the complex result."""
+
+    def __init__(self, win_len, win_inc, fft_len, win_type, post_process_mode, loss_mode, use_cuda=False):
+        self.win_len, self.win_inc, self.fft_len = win_len, win_inc, fft_len
+        self.post_process_mode, self.loss_mode = post_process_mode, loss_mode
+        if win_type != "hanning":
+            raise ValueError("ERROR window type")
+        self.window = torch.hann_window(self.fft_len)
+
+    def pre_stft(self, inputs):
+        stft_inputs = torch.view_as_real(torch.stft(inputs, n_fft=self.fft_len, hop_length=self.win_inc, win_length=self.win_len,
+                                                    window=self.window, center=True, pad_mode="constant", return_complex=True))
+        stft_inputs = stft_inputs.transpose(1, 3).contiguous()             # [B,2,T,F]
+        real, imag = stft_inputs[:, 0], stft_inputs[:, 1]
+        self.real, self.imag = real.unsqueeze(1), imag.unsqueeze(1)
+        self.spec_mags = torch.sqrt(real ** 2 + imag ** 2 + 1e-8).unsqueeze(1)
+        self.spec_phase = torch.atan2(imag, real).unsqueeze(1)
+        return stft_inputs, self.real, self.imag, self.spec_mags, self.spec_phase
+
+    def masking(self, mask_real, mask_imag=None):
+        if self.post_process_mode == "mag_mapping":
+            out_real, out_imag = mask_real * self.real, mask_real * self.imag
+        elif self.post_process_mode == "complex_mapping":
+            out_real, out_imag = mask_real * self.real, mask_imag * self.imag
+        else:
+            out_real, out_imag = mask_real, mask_imag
+        return torch.stack([out_real.squeeze(1), out_imag.squeeze(1)], dim=-1).contiguous()
+
+    def reconstruction(self, stft_outputs, sig_len=None):
+        """:443-455 with a [B,F,T] complex input (what torch.istft accepts)."""
+        return torch.istft(stft_outputs, n_fft=self.fft_len, hop_length=self.win_inc, win_length=self.win_len,
+                           window=self.window, center=True, length=sig_len)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # a13: loss_func/loss.py rmse, c_rmse (sisnr / wo_male / sdnr are in cruse_oracle.py)
 # ----------------------------------------------------------------------------------------------------------------------
 def rmse(ref, est, eps=1e-8):

@@ -363,3 +363,30 @@ def test_synthetic_batch_matches_its_cpu_definition():
     w = (1 - 0.95) * 0.95 ** torch.arange(63, -1, -1, dtype=torch.float32)
     ref = torch.nn.functional.conv1d(white.cpu().unsqueeze(1), w.view(1, 1, -1), padding=63)[..., :5000].squeeze(1) * 4.0
     assert rel_l2(clean, ref) < 1e-5 and rel_l2(noisy, ref + noise.cpu()) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------- a2-a4
+@pytest.mark.parametrize("mode", ["mag_mapping", "complex_mapping", "mapping"])
+def test_preprocess_as_written_vs_reference(golden, mode):
+    """utils.utils.PreProcess (constant-padded STFT, the three masking modes, reconstruction) vs the reference's class."""
+    from utils.utils import PreProcess
+    g = golden("g17_preprocess.npz")
+    pp = PreProcess(320, 160, 320, "hanning", mode, "freq")
+    stft_in, real, imag, mags, phase = pp.pre_stft(t(g["wav"]))
+    assert stft_in.shape == (2, 2, 21, 161) and real.shape == (2, 1, 21, 161)
+    assert rel_l2(stft_in, torch.from_numpy(g["stft"])) < 1e-5 and rel_l2(mags, torch.from_numpy(g["mags"])) < 1e-5
+    big = torch.from_numpy(g["mags"]) > 1e-2                                   # phase is ill-conditioned where |X| ~ 0
+    assert max_abs(phase.cpu()[big], torch.from_numpy(g["phase"])[big]) < 1e-3
+    ms = pp.masking(t(g["mask_real"]), t(g["mask_imag"]))
+    assert ms.shape == (2, 21, 161, 2) and rel_l2(ms, torch.from_numpy(g[f"{mode}/masked"])) < 1e-5
+    spec = torch.complex(real[:, 0], imag[:, 0]).transpose(1, 2)                # [B,F,T], what torch.istft takes
+    rec = pp.reconstruction(spec, sig_len=3200)
+    assert rel_l2(rec, torch.from_numpy(g["reconstruction"])) < 1e-5
+    rec2 = pp.reconstruction(torch.stack([real[:, 0], imag[:, 0]], dim=-1), sig_len=3200)   # the [B,T,F,2] masking() returns
+    assert rel_l2(rec2, rec) < 1e-7
+    # differs from the hot path's reflect-padded STFT in frames 0 and T-1 only (SURVEY 8a row a2)
+    from cruse_amd.acoustics.feature import pre_stft
+    refl = pre_stft(t(g["wav"]), 320, 160, 320)["real"]
+    assert max_abs(refl[:, :, 1:-1], real[:, :, 1:-1]) < 1e-5 and max_abs(refl[:, :, 0], real[:, :, 0]) > 1e-3
+    pp.log_transform()
+    assert rel_l2(pp.spec_mags, torch.log(torch.from_numpy(g["mags"]))) < 1e-5

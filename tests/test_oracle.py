@@ -185,3 +185,12 @@ def test_oracle_ext_deepfilter_step(golden):
     loss, aux = X.train_step_loss_df(m, _t(g["noisy"]), _t(g["clean"]))
     assert torch.equal(loss, _t(g["loss"])) and torch.equal(aux["est"], _t(g["est"]))
     assert float(aux["est"][:, :, :, 160].abs().max()) > 0.0        # the 11-bin neighbourhood reaches the Nyquist bin
+
+
+def test_oracle_ext_preprocess(golden):
+    from oracle import cruse_oracle_ext as X
+    g = golden("g17_preprocess.npz")
+    pp = X.PreProcess(320, 160, 320, "hanning", "complex_mapping", "freq")
+    out = pp.pre_stft(_t(g["wav"]))
+    assert torch.equal(out[0], _t(g["stft"])) and torch.equal(out[3], _t(g["mags"]))
+    assert torch.equal(pp.masking(_t(g["mask_real"]), _t(g["mask_imag"])), _t(g["complex_mapping/masked"]))
