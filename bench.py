@@ -46,7 +46,9 @@ def parse():
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--groups", type=int, default=1)
     ap.add_argument("--prec", default="bf16", choices=["bf16", "bf16x3", "f32"])
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels eagerly (no HIP graph)")
+    ap.add_argument("--graph", action="store_true", help="replay the step from HIP graph(s); default: time both forms during "
+                                                          "warm-up and keep the faster")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the T=401 oracle parity figure (parity_rel_l2)")
@@ -379,7 +381,32 @@ def main():
         torch.cuda.synchronize()
 
     log("inputs ready; warm-up (includes HIP-graph capture) ...")
-    for s in range(a.warmup):
+    launch_choice = None
+    if not a.no_graph and not a.graph:
+        # the same step, replayed from HIP graph(s) or launched eagerly: keep the faster form (all ranks take rank 0's verdict)
+        def timed(mode, n=3):
+            eng.use_graph = mode
+            eng.step(*pool[0])                              # (capture / first-use work outside the measurement)
+            sync()
+            t = time.perf_counter()
+            for i in range(n):
+                eng.step(*pool[i % len(pool)])
+            sync()
+            return (time.perf_counter() - t) / n
+        # two rounds each, best of the two: one-time stalls (stream / communicator set-up on first use) must not decide
+        t_graph, t_eager = timed(True), timed(False)
+        t_graph, t_eager = min(t_graph, timed(True)), min(t_eager, timed(False))
+        verdict = torch.tensor([1.0 if t_graph <= t_eager else 0.0], device=dev)
+        if world > 1:
+            dist.broadcast(verdict, 0)
+        eng.use_graph = bool(verdict.item() > 0.5)
+        launch_choice = {"graph_ms": round(t_graph * 1e3, 3), "eager_ms": round(t_eager * 1e3, 3),
+                         "kept": "graph" if eng.use_graph else "eager"}
+        log(f"launch form: graph {t_graph * 1e3:.2f} ms, eager {t_eager * 1e3:.2f} ms -> {launch_choice['kept']}")
+        done = 16
+    else:
+        done = 0
+    for s in range(max(a.warmup - done, 0)):                # (the form timing above already ran 16 untimed steps)
         eng.step(*pool[s % len(pool)])
     sync()
     log("timed region ...")
@@ -440,6 +467,9 @@ def main():
     if rank == 0 and world == 1 and not a.no_secondary:
         secondary = secondary_rows(a, dev, pool)
 
+    if world > 1 or force_pg:
+        dist.barrier()                        # rank 0's instrumented pass is done before anyone tears down
+        dist.destroy_process_group()
     if rank == 0:
         frames = world * B * T * a.steps
         out = {
@@ -456,7 +486,7 @@ def main():
                                   "audioAug.py:191); a literal 20 ms hop = win violates NOLA, so no iSTFT / training step exists for "
                                   "it -- its forward STFT is the secondary row stft_hop320_forward (SURVEY 8d)",
                        "global_batch": world * B, "per_gpu_batch": B, "frames_per_clip": T,
-                       "parallelism": f"dp{world}", "hip_graph": bool(eng.use_graph), "bucketed_allreduce": bool(eng.bucketed)},
+                       "parallelism": f"dp{world}", "hip_graph": bool(eng.use_graph), "launch_form_timing": launch_choice, "bucketed_allreduce": bool(eng.bucketed)},
             "ms_per_step_median": round(med_ms, 3),
             "value_at_median_step": round(world * B * T / (med_ms * 1e-3), 1),
             "parity_rel_l2": None if parity is None else float(f"{parity:.4g}"),
@@ -465,10 +495,14 @@ def main():
             "roofline": roof, "roofline_step": step_roofline(frames / el, a.groups, a.prec, B, T),
             "kernel_ms_per_step": breakdown, "cpu_baseline": cpu, "secondary": secondary,
         }
-        print(json.dumps(out))
-    if world > 1 or force_pg:
-        dist.barrier()                        # rank 0's instrumented pass and report are done before anyone tears down
-        dist.destroy_process_group()
+        # RCCL writes a version banner through C stdio; push it out first so that the JSON line is the LAST line of stdout
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -173,6 +173,9 @@ class TrainEngine:
     config 4: the mask is the real part of a DeepFilter(t_dim=1, f_dim=5) coefficient field (model/deep_filter.py:15-41;
     DECISION recorded in oracle.train_step_loss: filters = (mask padded to 161 bins, 0)), the enhanced spectrum is the
     filter output and WO-MALE is taken on it.
+    use_graph: replay the step from HIP graph(s) (True) or launch its ~170 kernels eagerly (False).  On the bench step the
+    eager form is the faster one once the host keeps ahead (7.38 vs 7.56 ms) -- bench.py times both during warm-up
+    and keeps the winner; the default here stays the graph, which does not depend on host speed.
     clip_grad_norm > 0: torch.nn.utils.clip_grad_norm_ semantics on the (averaged) gradient, folded into Adam.
     bucketed: None = when world > 1; True forces the segmented schedule (tests, single-GPU cost measurements)."""
 
@@ -214,6 +217,7 @@ class TrainEngine:
         self._loss_steps = 0
         self._norm = 1.0
         self._works: List = []
+        self._launcher = None
 
     # -- forward + loss (+ dL/dlogit when training) ------------------------------------------------------------------
     def _forward_loss(self, noisy: torch.Tensor, clean: torch.Tensor, training: bool):
@@ -356,8 +360,25 @@ class TrainEngine:
         SIDE.flush()
 
     def _plain_boundary(self, bucket: int):
-        SIDE.join(flush=False)
-        self._launch_bucket(bucket)
+        """eager launches: the bucket's collective must follow everything issued so far on the main AND the side streams,
+        but the main stream itself need not wait for the leaves -- the collective is issued from a launcher stream that waits
+        for both (ProcessGroupNCCL orders its stream after the stream it is called from)."""
+        if not _dist_on():
+            SIDE.flush()
+            return
+        if os.environ.get("CRUSE_EAGER_BOUNDARY") == "join":       # A/B: join the leaves on the main stream instead
+            SIDE.join(flush=False)
+            self._launch_bucket(bucket)
+            SIDE.flush()
+            return
+        main = torch.cuda.current_stream()
+        if self._launcher is None:
+            self._launcher = torch.cuda.Stream()
+        self._launcher.wait_stream(main)
+        for s_ in SIDE.used:
+            self._launcher.wait_stream(s_)
+        with torch.cuda.stream(self._launcher):
+            self._launch_bucket(bucket)
         SIDE.flush()
 
     def _launch_bucket(self, b: int):
@@ -372,6 +393,7 @@ class TrainEngine:
     def step(self, noisy: torch.Tensor, clean: torch.Tensor) -> torch.Tensor:
         """One optimizer step; returns the (device, f64) loss sum -- divide by .loss_norm for the loss."""
         self._works = []
+        SIDE.for_mode(self.use_graph)
         if self.use_graph:
             if self._graphs is None or self._shape != tuple(noisy.shape):
                 hit = self._graph_cache.get(tuple(noisy.shape))

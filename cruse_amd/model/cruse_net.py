@@ -26,62 +26,95 @@ DEFAULT_PREC = "f32"
 
 
 class _SideStream:
-    """Runs LEAF kernels (weight gradients, bias sums, skip convs) on a second HIP stream so they fill the
-    ~96 CUs the persistent GRU kernels leave idle.  Leaves only read tensors produced on the main stream and
-    write parameter gradients / tensors consumed after join(); they allocate nothing.  Tensors handed to the
-    side stream are kept alive until join().  CRUSE_OVERLAP=0 disables it."""
+    """Runs LEAF kernels (weight gradients, bias sums, skip convs) on side HIP streams so they fill the
+    ~96 CUs the persistent GRU kernels leave idle and overlap the HBM-bound main path elsewhere.  Leaves only read
+    tensors produced on the main stream and write parameter gradients / tensors consumed after join(); they allocate
+    nothing and are independent of each other, so they are dealt round-robin over CRUSE_SIDE_STREAMS streams.
+    Tensors handed to a side stream are kept alive until join().  CRUSE_OVERLAP=0 disables it."""
 
     def __init__(self):
         self.enabled = os.environ.get("CRUSE_OVERLAP", "1") == "1"
         self.defer_mask = int(os.environ.get("CRUSE_DEFER", "1"))   # 1 skip convs, 2 decoder leaves, 4 GRU weight grads
+        self.nside = max(1, int(os.environ.get("CRUSE_SIDE_STREAMS", "1")))
+        # lane -> stream: leaves are tagged 0 conv weight gradients, 1 skip-conv leaves, 2 GRU dW GEMMs; CRUSE_SIDE_MAP
+        # "abc" sends lane i to side stream int(abc[i]) (needs that many streams); unset: round-robin over nside streams
+        self.env_map = os.environ.get("CRUSE_SIDE_MAP")
+        self.set_map(self.env_map if self.env_map is not None else "012")
         self.streams = {}
         self.keep = []
         self.deferred = []
         self.active = False
+        self.rr = 0
+        self.used = []                 # side streams forked from the main stream since the last join()
+        self.last = None               # the stream the most recent leaf went to
 
-    def _side(self):
+    def set_map(self, m: str, force: bool = False) -> None:
+        """lane -> side stream assignment.  Measured on the bench step: replayed from a HIP graph the three lanes
+        are best on three streams ("012": 7.56 vs 7.78 ms on one); launched eagerly one stream is best ("000": 7.38 vs 7.46).
+        An explicit CRUSE_SIDE_MAP wins unless force."""
+        if self.env_map is not None and not force:
+            m = self.env_map
+        self.lane_map = [int(c) for c in m] if m else None
+        if self.lane_map:
+            self.nside = max(self.nside, max(self.lane_map) + 1)
+
+    def for_mode(self, use_graph: bool) -> None:
+        self.set_map("012" if use_graph else "000")
+
+    def _sides(self):
         dev = torch.cuda.current_device()
-        side = self.streams.get(dev)
-        if side is None:
-            side = self.streams[dev] = torch.cuda.Stream()
-        return side
+        sides = self.streams.get(dev)
+        if sides is None:
+            sides = self.streams[dev] = []
+        while len(sides) < self.nside:
+            sides.append(torch.cuda.Stream())
+        return sides
 
-    def defer(self, fn, *tensors, kind=7):
+    def _next(self, lane=None):
+        sides = self._sides()
+        if self.lane_map is not None and lane is not None:
+            s = sides[self.lane_map[lane % len(self.lane_map)] % len(sides)]
+        else:
+            s = sides[self.rr % len(sides)]
+            self.rr += 1
+        if s not in self.used:         # only forked streams may be recorded on / joined (HIP-graph capture rule)
+            self.used.append(s)
+        self.last = s
+        return s
+
+    def defer(self, fn, *tensors, kind=7, lane=None):
         """Queue a leaf for the next release_around(): it then starts WITH the next recurrence kernel (which leaves
         ~96 CUs idle for its whole duration) instead of competing with the throughput-bound kernels before it."""
         if not (self.enabled and (self.defer_mask & kind)):
-            self.run(fn, *tensors)
+            self.run(fn, *tensors, lane=lane)
             return
-        self.deferred.append(fn)
+        self.deferred.append((fn, lane))
         self.keep.extend(tensors)
 
     def release_around(self, launch):
         """launch() issues a recurrence kernel on the main stream; the deferred leaves are issued right after it on
-        the side stream, ordered only after the work that preceded the recurrence launch."""
+        the side streams, ordered only after the work that preceded the recurrence launch."""
         if not (self.enabled and self.deferred):
             return launch()
         main = torch.cuda.current_stream()
         ev = torch.cuda.Event()
         ev.record(main)
         out = launch()
-        side = self._side()
-        side.wait_event(ev)
-        with torch.cuda.stream(side):
-            for fn in self.deferred:
+        for fn, lane in self.deferred:
+            side = self._next(lane)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
                 fn()
         self.deferred.clear()
         self.active = True
         return out
 
-    def run(self, fn, *tensors):
+    def run(self, fn, *tensors, lane=None):
         if not self.enabled:
             fn()
             return
         main = torch.cuda.current_stream()
-        dev = torch.cuda.current_device()
-        side = self.streams.get(dev)
-        if side is None:
-            side = self.streams[dev] = torch.cuda.Stream()
+        side = self._next(lane)
         side.wait_stream(main)
         self.keep.extend(tensors)
         self.active = True
@@ -89,32 +122,38 @@ class _SideStream:
             fn()
 
     def mark(self):
-        """Event after everything issued on the side stream so far (None when nothing runs there)."""
+        """Events after everything issued on the side streams so far (None when nothing runs there)."""
         if not (self.enabled and self.active):
             return None
-        ev = torch.cuda.Event()
-        ev.record(self._side())
-        return ev
+        evs = []
+        for s in self.used:
+            ev = torch.cuda.Event()
+            ev.record(s)
+            evs.append(ev)
+        return evs
 
-    def wait(self, ev):
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
+    def wait(self, evs):
+        if evs is not None:
+            for ev in evs:
+                torch.cuda.current_stream().wait_event(ev)
 
     def flush(self):
-        """Issue everything still queued by defer() on the side stream now."""
+        """Issue everything still queued by defer() on the side streams now."""
         if self.deferred:
             fns, self.deferred = self.deferred, []
-            for fn in fns:
-                self.run(fn)
+            for fn, lane in fns:
+                self.run(fn, lane=lane)
 
     def join(self, flush: bool = True):
-        """Main stream waits for the side stream.  flush=False keeps the deferred (not yet issued) leaves queued: a
+        """Main stream waits for the side streams.  flush=False keeps the deferred (not yet issued) leaves queued: a
         SEGMENT boundary of the bucketed data-parallel step (engine.py) ends a graph capture with every ISSUED leaf
         joined, and carries the queued ones into the next segment."""
         if flush and self.enabled:               # nothing left to hide behind: issue what is still queued
             self.flush()
         if self.enabled and self.active:
-            torch.cuda.current_stream().wait_stream(self.streams[torch.cuda.current_device()])
+            for s in self.used:
+                torch.cuda.current_stream().wait_stream(s)
+            self.used = []
             if not self.deferred:
                 self.keep.clear()
             self.active = False
@@ -253,11 +292,11 @@ def ggru_backward(ctx, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[s
                 ops.gemm_bf16_nt(rows, Hg, w_t.shape[0] * 64, dgi, i * 3 * Hg, 3 * H, w_t, 0, 64, dinp, i * Hg, H,
                                  accumulate=acc_dx, b_kstride=Hg * 64)
         if last and defer_last:
-            SIDE.defer(weight_grads, dgT, h, inp, inpT, hpT, kind=0xffff)
+            SIDE.defer(weight_grads, dgT, h, inp, inpT, hpT, kind=0xffff, lane=2)
         elif last:
-            SIDE.run(weight_grads, dgT, h, inp, inpT, hpT)
+            SIDE.run(weight_grads, dgT, h, inp, inpT, hpT, lane=2)
         else:
-            SIDE.defer(weight_grads, dgT, h, inp, inpT, hpT, kind=4)
+            SIDE.defer(weight_grads, dgT, h, inp, inpT, hpT, kind=4, lane=2)
         return dinp
 
     def layer_bwd(dout_h, lname, inp, h, coef, an, z, need_dinp, last):
@@ -287,11 +326,11 @@ def ggru_backward(ctx, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[s
                 ops.gemm(False, False, rows, Hg, 3 * Hg, dgi, i * 3 * Hg, 3 * H,
                          P[f"{prefix}{lname}.{i}.weight_ih_l0"], 0, Hg, dinp, i * Hg, H, accumulate=acc_dx, prec=prec)
         if last and defer_last:
-            SIDE.defer(weight_grads, dgi, dgh, h, inp, kind=0xffff)
+            SIDE.defer(weight_grads, dgi, dgh, h, inp, kind=0xffff, lane=2)
         elif last:
-            SIDE.run(weight_grads, dgi, dgh, h, inp)
+            SIDE.run(weight_grads, dgi, dgh, h, inp, lane=2)
         else:
-            SIDE.defer(weight_grads, dgi, dgh, h, inp, kind=4)
+            SIDE.defer(weight_grads, dgi, dgh, h, inp, kind=4, lane=2)
         return dinp
 
     dh2 = ops.ln_bwd(dout, ctx["h2"], ctx["m2"], ctx["s2"], P[prefix + "ln2.weight"], rows, H, 1,
@@ -363,7 +402,7 @@ def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, tor
             ops.conv_gather(e, P[f"skip_connect_{k}.weight"], None, B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1,
                             out=s, prec=prec)
         if k < L:
-            SIDE.defer(skip_conv, e, s, kind=1)  # needed by the decoder only: issued with the GRU forward
+            SIDE.defer(skip_conv, e, s, kind=1, lane=1)  # needed by the decoder only: issued with the GRU forward
         else:
             skip_conv()
         ys.append(y); es.append(e); ss.append(s); stats.append((mean, rstd))
@@ -419,7 +458,7 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
     def leaf_dec1(dv=dv):
         ops.channel_sum(dv, rows, ch[0], Fk[0], G["conv1_t.bias"])
         ops.conv_wgrad(us[1], dv, G["conv1_t.weight"], B, T, ch[1], Fk[1], ch[0], Fk[0], KT=1, S=2, pad=0, prec=prec)
-    SIDE.defer(leaf_dec1, dv, kind=2)                           # decoder leaves: issued with the first GRU backward
+    SIDE.defer(leaf_dec1, dv, kind=2, lane=0)                           # decoder leaves: issued with the first GRU backward
     du = ops.conv_gather(dv, P["conv1_t.weight"], None, B, T, ch[0], Fk[0], ch[1], Fk[1], KT=1, S=2, pad=0, prec=prec)
     ds = {1: du}                                        # gradient wrt skip_{k} output = du_k
     # skip_k = conv1x3(e_k) is a leaf of the decoder: its data gradient W^T ds_k and its weight gradient ds_k (*) e_k
@@ -435,7 +474,7 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
                             w_layout=1, out=out, prec=prec)
             ops.conv_wgrad(dsk, es[k], G[f"skip_connect_{k}.weight"], B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1,
                            prec=prec)
-        SIDE.run(leaf, ds[k], de_pre[k])
+        SIDE.run(leaf, ds[k], de_pre[k], lane=1)
     skip_leaves(1)
     # ---- decoder levels 2..L ------------------------------------------------------------
     for k in range(2, L + 1):
@@ -446,7 +485,7 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
 
         def leaf_dec(dv=dv, k=k):
             ops.conv_wgrad(us[k], dv, G[f"conv{k}_t.weight"], B, T, ch[k], Fk[k], ch[k - 1], Fk[k - 1], KT=1, S=2, pad=0, prec=prec)
-        SIDE.defer(leaf_dec, dv, kind=2)
+        SIDE.defer(leaf_dec, dv, kind=2, lane=0)
         du = ops.conv_gather(dv, P[f"conv{k}_t.weight"], None, B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k], KT=1, S=2, pad=0,
                              prec=prec)
         ds[k] = du
@@ -467,7 +506,7 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
 
         def leaf_enc(dy=dy, k=k):
             ops.conv_wgrad(dy, es[k - 1], G[f"conv{k}.weight"], B, T, ch[k], Fk[k], ch[k - 1], Fk[k - 1], KT=2, S=2, pad=1, prec=prec)
-        SIDE.run(leaf_enc, dy)
+        SIDE.run(leaf_enc, dy, lane=0)
         if k > 1:
             de = ops.conv_scatter2(dy, P[f"conv{k}.weight"], None, B, T, ch[k], Fk[k], ch[k - 1], KT=2, pad=1,
                                    out=de_pre[k - 1], accum=True, prec=prec)

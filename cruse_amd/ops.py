@@ -134,7 +134,8 @@ WGRAD_PREC = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "valu":
 def conv_wgrad(a, bt, dw, B, T, Ca, Fa, Cb, Fb, KT, S, pad, prec=None):
     """dw[ca][cb][kt][kf] += ... (dw is a contiguous f32 tensor of Ca*Cb*KT*3 elements)."""
     nbytes = lib.cruse_conv_wgrad_ws_bytes(Ca, Cb, KT)
-    ws = _ws("wgrad", nbytes, a.device)
+    # one partial-slab workspace PER STREAM: weight-gradient leaves may run concurrently on several side streams
+    ws = _ws(("wgrad", _stream()), nbytes, a.device)
     pc = -1 if prec is None else (WGRAD_PREC[prec] if isinstance(prec, str) else int(prec))
     check(lib.cruse_conv_wgrad(_p(a), _p(bt), _p(dw), B, T, Ca, Fa, Cb, Fb, KT, S, pad, pc, _p(ws), _stream()))
 
