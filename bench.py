@@ -488,6 +488,7 @@ def main():
                        "global_batch": world * B, "per_gpu_batch": B, "frames_per_clip": T,
                        "parallelism": f"dp{world}", "hip_graph": bool(eng.use_graph), "launch_form_timing": launch_choice, "bucketed_allreduce": bool(eng.bucketed)},
             "ms_per_step_median": round(med_ms, 3),
+            "ms_per_step_p90_max": [round(step_ms[min(len(step_ms) - 1, int(0.9 * len(step_ms)))], 3), round(step_ms[-1], 3)],
             "value_at_median_step": round(world * B * T / (med_ms * 1e-3), 1),
             "parity_rel_l2": None if parity is None else float(f"{parity:.4g}"),
             "parity_note": "enhanced-spectrum rel-L2 of this model/mode vs the CPU oracle at T=401, B=8 (bar 1e-3)",
