@@ -450,6 +450,12 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
     SIDE.flush() before returning.  Bucket 2 is final when this function returns."""
     B, T, Fk, ch, L, training = ctx["B"], ctx["T"], ctx["F"], ctx["ch"], ctx["L"], ctx["training"]
     prec = ctx["prec"]
+    # data-gradient convolutions of the bf16 mode: plain bf16 operands (one MFMA, one conversion per element) like every
+    # other backward contraction of that mode -- the split-bf16 x3 form is what the FORWARD convs need for the 1e-3 bar
+    # (CRUSE_CONV_BWD_X3=1 restores x3 in backward)
+    dprec = prec
+    if ops.prec_code(prec) == ops.PREC_BF16 and os.environ.get("CRUSE_CONV_BWD_X3", "0") != "1":
+        dprec = ops.PREC_BF16
     rows = B * T
     ys, es, stats, us, vs, dstats = ctx["ys"], ctx["es"], ctx["stats"], ctx["us"], ctx["vs"], ctx["dstats"]
     # ---- decoder level 1: v1 = convT_1(u1) -------------------------------------------
@@ -459,7 +465,7 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
         ops.channel_sum(dv, rows, ch[0], Fk[0], G["conv1_t.bias"])
         ops.conv_wgrad(us[1], dv, G["conv1_t.weight"], B, T, ch[1], Fk[1], ch[0], Fk[0], KT=1, S=2, pad=0, prec=prec)
     SIDE.defer(leaf_dec1, dv, kind=2, lane=0)                           # decoder leaves: issued with the first GRU backward
-    du = ops.conv_gather(dv, P["conv1_t.weight"], None, B, T, ch[0], Fk[0], ch[1], Fk[1], KT=1, S=2, pad=0, prec=prec)
+    du = ops.conv_gather(dv, P["conv1_t.weight"], None, B, T, ch[0], Fk[0], ch[1], Fk[1], KT=1, S=2, pad=0, prec=dprec)
     ds = {1: du}                                        # gradient wrt skip_{k} output = du_k
     # skip_k = conv1x3(e_k) is a leaf of the decoder: its data gradient W^T ds_k and its weight gradient ds_k (*) e_k
     # are issued here, on the side stream, into the buffer de_pre[k] that the encoder backward later ACCUMULATES its
@@ -471,7 +477,7 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
 
         def leaf(k=k, dsk=ds[k], out=de_pre[k]):
             ops.conv_gather(dsk, P[f"skip_connect_{k}.weight"], None, B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1,
-                            w_layout=1, out=out, prec=prec)
+                            w_layout=1, out=out, prec=dprec)
             ops.conv_wgrad(dsk, es[k], G[f"skip_connect_{k}.weight"], B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1,
                            prec=prec)
         SIDE.run(leaf, ds[k], de_pre[k], lane=1)
@@ -487,7 +493,7 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
             ops.conv_wgrad(us[k], dv, G[f"conv{k}_t.weight"], B, T, ch[k], Fk[k], ch[k - 1], Fk[k - 1], KT=1, S=2, pad=0, prec=prec)
         SIDE.defer(leaf_dec, dv, kind=2, lane=0)
         du = ops.conv_gather(dv, P[f"conv{k}_t.weight"], None, B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k], KT=1, S=2, pad=0,
-                             prec=prec)
+                             prec=dprec)
         ds[k] = du
         skip_leaves(k)
     skips_done = SIDE.mark()
@@ -509,7 +515,7 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
         SIDE.run(leaf_enc, dy, lane=0)
         if k > 1:
             de = ops.conv_scatter2(dy, P[f"conv{k}.weight"], None, B, T, ch[k], Fk[k], ch[k - 1], KT=2, pad=1,
-                                   out=de_pre[k - 1], accum=True, prec=prec)
+                                   out=de_pre[k - 1], accum=True, prec=dprec)
         if boundary is not None and k == cut + 1:
             boundary(1)
     SIDE.join()
