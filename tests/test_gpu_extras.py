@@ -390,3 +390,18 @@ def test_preprocess_as_written_vs_reference(golden, mode):
     assert max_abs(refl[:, :, 1:-1], real[:, :, 1:-1]) < 1e-5 and max_abs(refl[:, :, 0], real[:, :, 0]) > 1e-3
     pp.log_transform()
     assert rel_l2(pp.spec_mags, torch.log(torch.from_numpy(g["mags"]))) < 1e-5
+
+
+def test_sdnr_kernel_vs_reference_fixture(golden):
+    """cruse_mask_sdnr_fwd against the values the reference's own sdnr (vad == 1 repair) produced (fixture G18)."""
+    from cruse_amd import ops
+    g = golden("g18_sdnr.npz")
+    clean, noise, gain = t(g["clean"]), t(g["noise"]), t(g["gain"])
+    B, _, T, Fs = clean.shape
+    noisy = clean + noise
+    for k, snr in enumerate(g["snr"]):
+        ls, _, _ = ops.mask_sdnr(gain[:, 0, :, :160].contiguous().view(B * T, 160), clean[:, 0].contiguous().view(B * T, Fs),
+                                 clean[:, 1].contiguous().view(B * T, Fs), noisy[:, 0].contiguous().view(B * T, Fs),
+                                 noisy[:, 1].contiguous().view(B * T, Fs), B * T, 160, Fs, B, float(snr), 20.0)
+        want = float(g["value"][k])
+        assert abs(float(ls) / (B * Fs) - want) <= 2e-5 * abs(want), (snr, float(ls) / (B * Fs), want)

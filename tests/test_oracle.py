@@ -194,3 +194,11 @@ def test_oracle_ext_preprocess(golden):
     out = pp.pre_stft(_t(g["wav"]))
     assert torch.equal(out[0], _t(g["stft"])) and torch.equal(out[3], _t(g["mags"]))
     assert torch.equal(pp.masking(_t(g["mask_real"]), _t(g["mask_imag"])), _t(g["complex_mapping/masked"]))
+
+
+def test_oracle_sdnr_vs_reference_fixture(golden):
+    """sdnr (loss_func/loss.py:151-175) was parity-unpinned in round 1: G18 holds the reference function's own values (vad == 1)."""
+    g = golden("g18_sdnr.npz")
+    for k, snr in enumerate(g["snr"]):
+        v = O.sdnr(_t(g["clean"]), _t(g["gain"]), _t(g["noise"]), float(snr), beta=20.0)
+        assert abs(float(v) - float(g["value"][k])) <= 1e-6 * abs(float(g["value"][k])), snr
