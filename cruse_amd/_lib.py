@@ -83,6 +83,8 @@ SIGNATURES = {
     "cruse_wo_male_spec": ("pppiqqqfffppp", "i"),
     "cruse_onepole_fir": ("piififpp", "i"),
     "cruse_snr_mix": ("pppiifppppp", "i"),
+    "cruse_stream_create_masked": ("ppi", "i"),
+    "cruse_cu_census": ("piip", "i"),
     "cruse_zero": ("pzp", "i"),
     "cruse_accum_f64": ("ppip", "i"),
     "cruse_counters_add": ("piqp", "i"),

@@ -53,3 +53,34 @@ int cruse_zero_async(void* p, size_t bytes, hipStream_t stream, const char* name
     }
     return CRUSE_OK;
 }
+
+// ---- CU-masked streams and a placement census (profiling / scheduling aid) -----------------------------------------
+// hipExtStreamCreateWithCUMask: a stream whose kernels may only run on the CUs whose bit is set.  Used to keep the
+// side-stream leaves off the CUs that hold the persistent GRU workgroups.
+extern "C" int cruse_stream_create_masked(void** stream_out, const unsigned* mask, int nwords) {
+    hipStream_t s = nullptr;
+    hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)nwords, mask);
+    if (e != hipSuccess) {
+        cruse_set_error("stream_create_masked: %s", hipGetErrorString(e));
+        return CRUSE_E_HIP;
+    }
+    *stream_out = (void*)s;
+    return CRUSE_OK;
+}
+
+// out[block] = {HW_REG_XCC_ID, HW_REG_HW_ID}: which XCD / SE / CU a block ran on; every block spins `spin` clock ticks so
+// that a launch of <= 256 blocks is spread one block per CU.
+__global__ void cruse_census_kernel(unsigned* out, unsigned spin) {
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);     // HW_REG_XCC_ID
+        out[2 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID
+    }
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < spin) __builtin_amdgcn_s_sleep(8);
+}
+extern "C" int cruse_cu_census(unsigned* out, int nblocks, unsigned spin, void* stream) {
+    hipLaunchKernelGGL(cruse_census_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, out, spin);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cruse_set_error("cu_census: %s", hipGetErrorString(e)); return CRUSE_E_HIP; }
+    return CRUSE_OK;
+}

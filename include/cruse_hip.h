@@ -354,6 +354,12 @@ int cruse_onepole_fir(const float* x, int B, int L, float a, int taps, float gai
 int cruse_snr_mix(const float* clean, const float* noise, const float* snr_db, int B, int L, float eps,
                   void* scratch, float* clean_out, float* noise_out, float* noisy, void* stream);
 
+/* ---- scheduling aids ------------------------------------------------------------------------------------------------ */
+/* a HIP stream restricted to the CUs whose bit is set in mask[0..nwords) (hipExtStreamCreateWithCUMask) */
+int cruse_stream_create_masked(void** stream_out, const unsigned* mask, int nwords);
+/* out[2*b], out[2*b+1] = HW_REG_XCC_ID, HW_REG_HW_ID of block b (each block idles `spin` clock ticks): placement census */
+int cruse_cu_census(unsigned* out, int nblocks, unsigned spin, void* stream);
+
 /* ---- stream-ordered bookkeeping (keeps the training step free of library kernels) ---- */
 /* zero-fill `bytes` (multiple of 4) with a KERNEL node (hipMemsetAsync nodes raced inside captured graphs) --
  * optimizer.zero_grad() at the top of the step */
