@@ -409,6 +409,11 @@ def main():
     for s in range(max(a.warmup - done, 0)):                # (the form timing above already ran 16 untimed steps)
         eng.step(*pool[s % len(pool)])
     sync()
+    # eager launches: a generational GC pause on the host (tens of ms over torch's object graph) is long enough to drain
+    # the device queue and shows up as one 20-30 ms step in a hundred; the loop below allocates nothing that needs the GC
+    import gc
+    gc.collect()
+    gc.disable()
     log("timed region ...")
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
@@ -418,6 +423,7 @@ def main():
         marks[s + 1].record()                 # on the compute stream, after this step's Adam
     sync()
     el = time.perf_counter() - t0
+    gc.enable()
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
     med_ms = step_ms[len(step_ms) // 2]
     if world > 1:

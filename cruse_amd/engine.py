@@ -225,10 +225,17 @@ class TrainEngine:
         T = ops.stft_frames(L, self.hop)
         nre, nim, mag = ops.stft(noisy, self.n_fft, self.hop, mag_bins=self.f_net, mag_eps=1e-8)
         cre = cim = cmag = None
-        if self.loss == "wo_male":
-            _, _, cmag = ops.stft(clean, self.n_fft, self.hop, want_ri=False, mag_bins=self.f_stft, mag_eps=0.0)
-        elif self.loss in ("sdnr", "wo_male_df"):
-            cre, cim, _ = ops.stft(clean, self.n_fft, self.hop)
+        # the clean spectrum is only needed by the loss: a leaf beside the encoder (joined by unet2_forward before the decoder)
+        if self.loss != "si_snr":
+            # (outputs are allocated here, on the main stream, so that the leaf itself allocates nothing)
+            if self.loss == "wo_male":
+                cmag = torch.empty(B, T, self.f_stft, device=clean.device, dtype=torch.float32)
+                SIDE.run(lambda: ops.stft(clean, self.n_fft, self.hop, want_ri=False, mag_eps=0.0, out=(None, None, cmag)),
+                         clean, cmag, lane=0)
+            else:
+                cre = torch.empty(B, T, self.f_stft, device=clean.device, dtype=torch.float32)
+                cim = torch.empty_like(cre)
+                SIDE.run(lambda: ops.stft(clean, self.n_fft, self.hop, out=(cre, cim, None)), clean, cre, cim, lane=0)
         mask, ctx = unet2_forward(mag.view(B, 1, T, self.f_net), self.flat.P, self.Bf, self.model.ch,
                                   self.model.rnn_groups, self.prec, training=training, save=training,
                                   update_running=training)

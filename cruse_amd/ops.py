@@ -46,17 +46,22 @@ def stft_frames(L: int, hop: int) -> int:
 
 
 def stft(wave: torch.Tensor, n_fft: int, hop: int, want_ri: bool = True, mag_bins: int = 0,
-         mag_eps: float = 0.0):
-    """wave [B,L] -> (re [B,T,F], im [B,T,F], mag [B,T,mag_bins]); absent outputs are None."""
+         mag_eps: float = 0.0, out=None):
+    """wave [B,L] -> (re [B,T,F], im [B,T,F], mag [B,T,mag_bins]); absent outputs are None.
+    out = (re, im, mag): write into these (None entries are not produced) instead of allocating."""
     _f32(wave, "stft")
     if wave.dim() != 2:
         raise RuntimeError(f"stft expects [B,L], got {tuple(wave.shape)}")
     B, L = wave.shape
     T = stft_frames(L, hop)
     F = n_fft // 2 + 1
-    re = torch.empty(B, T, F, device=wave.device, dtype=torch.float32) if want_ri else None
-    im = torch.empty(B, T, F, device=wave.device, dtype=torch.float32) if want_ri else None
-    mag = torch.empty(B, T, mag_bins, device=wave.device, dtype=torch.float32) if mag_bins > 0 else None
+    if out is not None:
+        re, im, mag = out
+        mag_bins = mag.shape[-1] if mag is not None else 0
+    else:
+        re = torch.empty(B, T, F, device=wave.device, dtype=torch.float32) if want_ri else None
+        im = torch.empty(B, T, F, device=wave.device, dtype=torch.float32) if want_ri else None
+        mag = torch.empty(B, T, mag_bins, device=wave.device, dtype=torch.float32) if mag_bins > 0 else None
     check(lib.cruse_stft_fwd(_p(wave), B, L, n_fft, hop, _p(re), _p(im), _p(mag), mag_bins, mag_eps, _stream()))
     return re, im, mag
 

@@ -117,18 +117,24 @@ class Trainer:
         return False
 
     def _train_epoch(self, epoch):
+        import gc
         sampler = getattr(self.train_dataloader, "sampler", None)
         if hasattr(sampler, "set_epoch"):
             sampler.set_epoch(epoch)                                     # a different shuffle every epoch
         nb, frames = 0, 0
         t0 = time.time()
         self.engine.mean_loss(reset=True)
-        for noisy, clean in self.train_dataloader:
-            noisy = noisy.to(self.device, non_blocking=True).float().contiguous()
-            clean = clean.to(self.device, non_blocking=True).float().contiguous()
-            self.engine.step(noisy, clean)                               # no host synchronisation inside the loop
-            nb += 1
-            frames += noisy.shape[0] * (1 + noisy.shape[1] // self.engine.hop)
+        gc.collect()
+        gc.disable()     # a generational GC pause (tens of ms) is long enough to drain the device queue of eager launches
+        try:
+            for noisy, clean in self.train_dataloader:
+                noisy = noisy.to(self.device, non_blocking=True).float().contiguous()
+                clean = clean.to(self.device, non_blocking=True).float().contiguous()
+                self.engine.step(noisy, clean)                           # no host synchronisation inside the loop
+                nb += 1
+                frames += noisy.shape[0] * (1 + noisy.shape[1] // self.engine.hop)
+        finally:
+            gc.enable()
         mean = self.engine.mean_loss(reset=True)                         # one synchronisation per epoch
         self.engine.check_health()                                       # raises on a GRU hand-off time-out
         skipped = self.engine.skipped_steps()
