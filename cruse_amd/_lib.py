@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcruse_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 PREC_BY_NAME = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
 
@@ -28,6 +28,8 @@ SIGNATURES = {
     "cruse_istft_bwd": ("piiiiippp", "i"),
     "cruse_conv_gather": ("ppppiiiiiiiiiiiiip", "i"),
     "cruse_conv_scatter2": ("ppppiiiiiiiiiiip", "i"),
+    "cruse_conv_gather_bnstats": ("ppppiiiiiiiiiipip", "i"),
+    "cruse_conv_scatter2_bnstats": ("ppppiiiiiiiiipip", "i"),
     "cruse_conv_wgrad_ws_bytes": ("iii", "z"),
     "cruse_conv_wgrad": ("pppiiiiiiiiiipp", "i"),
     "cruse_channel_sum": ("pqiipp", "i"),

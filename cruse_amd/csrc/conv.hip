@@ -372,11 +372,13 @@ int set_smem(K kern, size_t bytes, const char* name) {
 
 int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float* bias, float* y,
                         int B, int T, int Cin, int Fin, int Cout, int Fout, int KT, int S, int pad,
-                        int w_layout, int act, int accum, int prec, hipStream_t stream);
+                        int w_layout, int act, int accum, int prec, double* bn_sums, hipStream_t stream);
 
-extern "C" int cruse_conv_gather(const float* x, const float* w, const float* bias, float* y,
-                                 int B, int T, int Cin, int Fin, int Cout, int Fout,
-                                 int KT, int S, int pad, int w_layout, int act, int accum, int prec, void* stream) {
+namespace {
+
+int conv_gather_impl(const float* x, const float* w, const float* bias, float* y,
+                     int B, int T, int Cin, int Fin, int Cout, int Fout,
+                     int KT, int S, int pad, int w_layout, int act, int accum, int prec, double* bn_sums, void* stream) {
     CRUSE_REQUIRE(B > 0 && T > 0 && Cin > 0 && Cout > 0 && Fin > 0 && Fout > 0, CRUSE_E_SHAPE,
                   "conv_gather: empty shape B=%d T=%d Cin=%d Cout=%d Fin=%d Fout=%d", B, T, Cin, Cout, Fin, Fout);
     CRUSE_REQUIRE((KT == 1 || KT == 2) && (S == 1 || S == 2) && (pad == 0 || pad == 1), CRUSE_E_SHAPE,
@@ -387,7 +389,7 @@ extern "C" int cruse_conv_gather(const float* x, const float* w, const float* bi
     CRUSE_REQUIRE(!(accum && act), CRUSE_E_SHAPE, "conv_gather: accum with activation");
     if (prec >= 0) {
         const int r = cruse_conv_mfma_try(0, x, w, bias, y, B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout, act, accum,
-                                          prec, (hipStream_t)stream);
+                                          prec, bn_sums, (hipStream_t)stream);
         if (r != 0) return r < 0 ? r : CRUSE_OK;
     }
     ConvArgs a{x, w, bias, y, B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout, act, accum};
@@ -404,12 +406,14 @@ extern "C" int cruse_conv_gather(const float* x, const float* w, const float* bi
         hipLaunchKernelGGL(conv_gather_kernel<1>, dim3(grid), dim3(CONV_THREADS), lds, (hipStream_t)stream, a);
     }
     CRUSE_LAUNCH_CHECK("conv_gather");
+    // the VALU kernel has no statistics epilogue: one more pass over y
+    if (bn_sums) return cruse_bn_stats(y, (long long)B * T, Cout, Fout, bn_sums, 1, stream);
     return CRUSE_OK;
 }
 
-extern "C" int cruse_conv_scatter2(const float* g, const float* w, const float* bias, float* y,
-                                   int B, int T, int Cs, int Fg, int Cout, int Fout,
-                                   int KT, int pad, int act, int accum, int prec, void* stream) {
+int conv_scatter2_impl(const float* g, const float* w, const float* bias, float* y,
+                       int B, int T, int Cs, int Fg, int Cout, int Fout,
+                       int KT, int pad, int act, int accum, int prec, double* bn_sums, void* stream) {
     CRUSE_REQUIRE(B > 0 && T > 0 && Cs > 0 && Cout > 0 && Fg > 0, CRUSE_E_SHAPE, "conv_scatter2: empty shape");
     CRUSE_REQUIRE(Fout == 2 * Fg, CRUSE_E_SHAPE, "conv_scatter2: Fout=%d must be 2*Fg=%d", Fout, 2 * Fg);
     CRUSE_REQUIRE((KT == 1 || KT == 2) && (pad == 0 || pad == 1), CRUSE_E_SHAPE,
@@ -417,7 +421,7 @@ extern "C" int cruse_conv_scatter2(const float* g, const float* w, const float* 
     CRUSE_REQUIRE(!(accum && act), CRUSE_E_SHAPE, "conv_scatter2: accum with activation");
     if (prec >= 0) {
         const int r = cruse_conv_mfma_try(1, g, w, bias, y, B, T, Cs, Fg, Cout, Fout, KT, 2, pad, 0, act, accum, prec,
-                                          (hipStream_t)stream);
+                                          bn_sums, (hipStream_t)stream);
         if (r != 0) return r < 0 ? r : CRUSE_OK;
     }
     ConvArgs a{g, w, bias, y, B, T, Cs, Fg, Cout, Fout, KT, 2, pad, 0, act, accum};
@@ -434,7 +438,44 @@ extern "C" int cruse_conv_scatter2(const float* g, const float* w, const float* 
         hipLaunchKernelGGL(conv_scatter2_kernel<1>, dim3(grid), dim3(CONV_THREADS), lds, (hipStream_t)stream, a);
     }
     CRUSE_LAUNCH_CHECK("conv_scatter2");
+    if (bn_sums) return cruse_bn_stats(y, (long long)B * T, Cout, Fout, bn_sums, 1, stream);
     return CRUSE_OK;
+}
+
+int prep_sums(double* sums, int Cout, int zeroed, void* stream, const char* who) {
+    CRUSE_REQUIRE(sums != nullptr, CRUSE_E_SHAPE, "%s: sums is NULL", who);
+    if (!zeroed) return cruse_zero_async(sums, 2 * (size_t)Cout * sizeof(double), (hipStream_t)stream, who);
+    return CRUSE_OK;
+}
+
+}  // namespace
+
+extern "C" int cruse_conv_gather(const float* x, const float* w, const float* bias, float* y,
+                                 int B, int T, int Cin, int Fin, int Cout, int Fout,
+                                 int KT, int S, int pad, int w_layout, int act, int accum, int prec, void* stream) {
+    return conv_gather_impl(x, w, bias, y, B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout, act, accum, prec, nullptr, stream);
+}
+
+extern "C" int cruse_conv_scatter2(const float* g, const float* w, const float* bias, float* y,
+                                   int B, int T, int Cs, int Fg, int Cout, int Fout,
+                                   int KT, int pad, int act, int accum, int prec, void* stream) {
+    return conv_scatter2_impl(g, w, bias, y, B, T, Cs, Fg, Cout, Fout, KT, pad, act, accum, prec, nullptr, stream);
+}
+
+extern "C" int cruse_conv_gather_bnstats(const float* x, const float* w, const float* bias, float* y,
+                                         int B, int T, int Cin, int Fin, int Cout, int Fout,
+                                         int KT, int S, int pad, int prec, double* sums, int zeroed, void* stream) {
+    int rc = prep_sums(sums, Cout, zeroed, stream, "conv_gather_bnstats");
+    if (rc) return rc;
+    return conv_gather_impl(x, w, bias, y, B, T, Cin, Fin, Cout, Fout, KT, S, pad, 0, 0, 0, prec, sums, stream);
+}
+
+extern "C" int cruse_conv_scatter2_bnstats(const float* g, const float* w, const float* bias, float* y,
+                                           int B, int T, int Cs, int Fg, int Cout, int Fout,
+                                           int KT, int pad, int prec, double* sums, int zeroed, void* stream) {
+    int rc = prep_sums(sums, Cout, zeroed, stream, "conv_scatter2_bnstats");
+    if (rc) return rc;
+    return conv_scatter2_impl(g, w, bias, y, B, T, Cs, Fg, Cout, Fout, KT, pad, 0, 0, prec, sums, stream);
 }
 
 extern "C" size_t cruse_conv_wgrad_ws_bytes(int Ca, int Cb, int KT) {

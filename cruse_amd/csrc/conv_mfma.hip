@@ -33,6 +33,7 @@ struct CMArgs {
     int nrows;                                   // staged frames = TFM + halo
     long long sco, sci;                          // weight strides of co and ci (tap index is fastest, 3*KT long)
     int act, accum;
+    double* sums;                                // BatchNorm batch sums of y ([2][Cout]: sum, sum of squares) or null
     TapClass cls[2];
 };
 
@@ -79,7 +80,11 @@ __device__ __forceinline__ Frag<PREC> get_frag(const typename OpStore<PREC>::ele
     return f;
 }
 
-template <int PREC, int MT>
+// STATS: the epilogue also accumulates the per-channel sum / sum of squares of the values it stores (the
+// batch statistics of the BatchNorm2d that follows every encoder / decoder conv, cruse_net.py:139,150) --
+// per lane over its tiles in f32 (<= a few hundred values), then 16 lanes -> 4 waves -> one f64 atomic per
+// channel and workgroup.  This replaces a separate pass over y (65 MB, ~28 us, on the serial chain).
+template <int PREC, int MT, bool STATS>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
     typedef typename OpStore<PREC>::elem elem;
     constexpr int NPL = OpStore<PREC>::NPL;
@@ -142,6 +147,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
             const int co = mt * 16 + (lane >> 4) * 4 + r4;
             biasr[mt][r4] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
         }
+    float s1[STATS ? MT : 1][4], s2[STATS ? MT : 1][4];
+    if constexpr (STATS) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) { s1[mt][r4] = 0.f; s2[mt][r4] = 0.f; }
+    }
     float4 pre[MAXV];
     auto prefetch = [&](int tile) {
         const int b = tile / ntile;
@@ -226,9 +238,33 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
                             if (a.accum) v += *yp;
                             else if (a.act == 1) v = sigmoid_acc(v);
                             *yp = v;
+                            if constexpr (STATS) { s1[mt][r4] += v; s2[mt][r4] += v * v; }
                         }
                     }
                 }
+            }
+        }
+    }
+    if constexpr (STATS) {
+        __shared__ float s_red[4][2][MT * 16];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                float u = s1[mt][r4], u2 = s2[mt][r4];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { u += __shfl_xor(u, o, 64); u2 += __shfl_xor(u2, o, 64); }
+                if ((lane & 15) == 0) {
+                    const int co = mt * 16 + (lane >> 4) * 4 + r4;
+                    s_red[wv][0][co] = u; s_red[wv][1][co] = u2;
+                }
+            }
+        __syncthreads();
+        if (tid < 2 * MT * 16) {
+            const int which = tid / (MT * 16), co = tid - which * (MT * 16);
+            if (co < a.Cout) {
+                const float u = (s_red[0][which][co] + s_red[1][which][co]) + (s_red[2][which][co] + s_red[3][which][co]);
+                atomicAdd(a.sums + which * a.Cout + co, (double)u);
             }
         }
     }
@@ -238,15 +274,21 @@ template <int PREC>
 int launch_mt(const CMArgs& a, int grid, size_t lds, hipStream_t s) {
     const int mt = (a.Cout + 15) / 16;
     int rc;
+#define CM_LAUNCH1(MTV, STV)                                                                               \
+    do {                                                                                                   \
+        if ((rc = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(conv_mfma_kernel<PREC, MTV, STV>), lds, "conv_mfma"))) return rc; \
+        hipLaunchKernelGGL((conv_mfma_kernel<PREC, MTV, STV>), dim3(grid), dim3(256), lds, s, a);          \
+    } while (0)
 #define CM_LAUNCH(MTV)                                                                                     \
     do {                                                                                                   \
-        if ((rc = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(conv_mfma_kernel<PREC, MTV>), lds, "conv_mfma"))) return rc; \
-        hipLaunchKernelGGL((conv_mfma_kernel<PREC, MTV>), dim3(grid), dim3(256), lds, s, a);               \
+        if (a.sums) CM_LAUNCH1(MTV, true);                                                                 \
+        else CM_LAUNCH1(MTV, false);                                                                       \
     } while (0)
     if (mt <= 1) CM_LAUNCH(1);
     else if (mt <= 2) CM_LAUNCH(2);
     else CM_LAUNCH(4);
 #undef CM_LAUNCH
+#undef CM_LAUNCH1
     return CRUSE_OK;
 }
 
@@ -256,12 +298,12 @@ int launch_mt(const CMArgs& a, int grid, size_t lds, hipStream_t s) {
 // to the VALU kernel), < 0 on error.
 int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float* bias, float* y,
                         int B, int T, int Cin, int Fin, int Cout, int Fout, int KT, int S, int pad,
-                        int w_layout, int act, int accum, int prec, hipStream_t stream) {
+                        int w_layout, int act, int accum, int prec, double* bn_sums, hipStream_t stream) {
     if (Cin % 8 != 0 || (Cin & (Cin - 1)) != 0 || Cout < 8 || Cout > 64 || (TFM * (Fout / (scatter ? 2 : 1))) % 16 != 0) return 0;
     CMArgs a = {};
     a.x = x; a.w = w; a.bias = bias; a.y = y;
     a.B = B; a.T = T; a.Cin = Cin; a.Fin = Fin; a.Cout = Cout; a.Fout = Fout;
-    a.act = act; a.accum = accum;
+    a.act = act; a.accum = accum; a.sums = bn_sums;
     if (!scatter) {
         // y[co,fo] = sum W(co,ci,kt,kf) x[t-(KT-1)+kt, ci, fo*S - pad + kf]
         a.S = S; a.OS = 1; a.nclass = 1; a.halo_lo = KT - 1;

@@ -354,17 +354,23 @@ BN_MOMENTUM = 0.1
 _PENDING_COUNTERS = []      # num_batches_tracked buffers of this forward: bumped by ONE kernel at its end, not seven
 
 
+# BatchNorm batch sums accumulated by the producing conv's epilogue (CRUSE_FUSE_BN_STATS=0: separate bn_stats pass)
+_FUSE_BN_STATS = os.environ.get("CRUSE_FUSE_BN_STATS", "1") != "0"
+
+
 def _flush_counters():
     if _PENDING_COUNTERS:
         ops.counters_add(list(_PENDING_COUNTERS), 1)
         _PENDING_COUNTERS.clear()
 
 
-def _bn_act(y, rows, C, F, P, Bf, name, training, update_running, skip=None):
-    """BatchNorm2d (train: batch statistics, running stats updated; eval: running stats) + ReLU (+ skip) -> (out, mean, rstd)."""
+def _bn_act(y, rows, C, F, P, Bf, name, training, update_running, skip=None, sums=None):
+    """BatchNorm2d (train: batch statistics, running stats updated; eval: running stats) + ReLU (+ skip) -> (out, mean, rstd).
+    sums: the batch sums of y when the conv that produced it has already accumulated them (ops.conv_*_bnstats)."""
     gamma, beta = P[name + ".weight"], P[name + ".bias"]
     if training:
-        sums = ops.bn_stats(y, rows, C, F)
+        if sums is None:
+            sums = ops.bn_stats(y, rows, C, F)
         rm = Bf[name + ".running_mean"] if update_running else None
         rv = Bf[name + ".running_var"] if update_running else None
         if update_running:
@@ -393,9 +399,13 @@ def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, tor
     _PENDING_COUNTERS.clear()
     ys, es, ss, stats = [None], [x], [None], [None]
     for k in range(1, L + 1):
-        y = ops.conv_gather(cur, P[f"conv{k}.weight"], P[f"conv{k}.bias"], B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k],
-                            KT=2, S=2, pad=1, prec=prec)
-        e, mean, rstd = _bn_act(y, rows, ch[k], Fk[k], P, Bf, f"bn{k}", training, update_running)
+        if training and _FUSE_BN_STATS:
+            y, sums = ops.conv_gather_bnstats(cur, P[f"conv{k}.weight"], P[f"conv{k}.bias"], B, T, ch[k - 1], Fk[k - 1], ch[k],
+                                              Fk[k], KT=2, S=2, pad=1, prec=prec)
+        else:
+            y, sums = ops.conv_gather(cur, P[f"conv{k}.weight"], P[f"conv{k}.bias"], B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k],
+                                      KT=2, S=2, pad=1, prec=prec), None
+        e, mean, rstd = _bn_act(y, rows, ch[k], Fk[k], P, Bf, f"bn{k}", training, update_running, sums=sums)
         s = torch.empty(B, T, ch[k], Fk[k], device=x.device, dtype=torch.float32)
 
         def skip_conv(e=e, s=s, k=k):
@@ -413,9 +423,14 @@ def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, tor
     SIDE.join()
     us, vs, dstats = {L: u}, {}, {}
     for k in range(L, 1, -1):
-        v = ops.conv_scatter2(u, P[f"conv{k}_t.weight"], P[f"conv{k}_t.bias"], B, T, ch[k], Fk[k], ch[k - 1], KT=1, pad=0,
-                              prec=prec)
-        u, mean, rstd = _bn_act(v, rows, ch[k - 1], Fk[k - 1], P, Bf, f"bn{k}_t", training, update_running, skip=ss[k - 1])
+        if training and _FUSE_BN_STATS:
+            v, sums = ops.conv_scatter2_bnstats(u, P[f"conv{k}_t.weight"], P[f"conv{k}_t.bias"], B, T, ch[k], Fk[k], ch[k - 1],
+                                                KT=1, pad=0, prec=prec)
+        else:
+            v, sums = ops.conv_scatter2(u, P[f"conv{k}_t.weight"], P[f"conv{k}_t.bias"], B, T, ch[k], Fk[k], ch[k - 1], KT=1,
+                                        pad=0, prec=prec), None
+        u, mean, rstd = _bn_act(v, rows, ch[k - 1], Fk[k - 1], P, Bf, f"bn{k}_t", training, update_running, skip=ss[k - 1],
+                                sums=sums)
         vs[k] = v; dstats[k] = (mean, rstd); us[k - 1] = u
     mask = ops.conv_scatter2(u, P["conv1_t.weight"], P["conv1_t.bias"], B, T, ch[1], Fk[1], ch[0], KT=1, pad=0, act=1,
                              prec=prec)

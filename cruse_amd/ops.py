@@ -114,6 +114,24 @@ def conv_scatter2(g, w, bias, B, T, Cs, Fg, Cout, KT, pad, act=0, out=None, accu
     return out
 
 
+def conv_gather_bnstats(x, w, bias, B, T, Cin, Fin, Cout, Fout, KT, S, pad, prec=None):
+    """conv_gather + the BatchNorm batch sums of its output, accumulated by the conv's epilogue -> (y, sums)."""
+    out = torch.empty(B, T, Cout, Fout, device=x.device, dtype=torch.float32)
+    sums, z = ARENA.take(2 * Cout, x.device)
+    check(lib.cruse_conv_gather_bnstats(_p(x), _p(w), _p(bias), _p(out), B, T, Cin, Fin, Cout, Fout, KT, S, pad,
+                                        conv_prec(prec), _p(sums), z, _stream()))
+    return out, sums
+
+
+def conv_scatter2_bnstats(g, w, bias, B, T, Cs, Fg, Cout, KT, pad, prec=None):
+    Fout = 2 * Fg
+    out = torch.empty(B, T, Cout, Fout, device=g.device, dtype=torch.float32)
+    sums, z = ARENA.take(2 * Cout, g.device)
+    check(lib.cruse_conv_scatter2_bnstats(_p(g), _p(w), _p(bias), _p(out), B, T, Cs, Fg, Cout, Fout, KT, pad,
+                                          conv_prec(prec), _p(sums), z, _stream()))
+    return out, sums
+
+
 _wgrad_ws = {}
 _ws_retired = []          # outgrown workspaces: captured HIP graphs may still point at them, so they are never freed
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CRUSE_ABI_VERSION 2
+#define CRUSE_ABI_VERSION 3
 
 enum {
     CRUSE_OK = 0,
@@ -91,6 +91,18 @@ int cruse_conv_gather(const float* x, const float* w, const float* bias, float* 
 int cruse_conv_scatter2(const float* g, const float* w, const float* bias, float* y,
                         int B, int T, int Cs, int Fg, int Cout, int Fout,
                         int KT, int pad, int act, int accum, int prec, void* stream);
+
+/* Both forms with the batch statistics of the BatchNorm2d that follows every encoder / decoder conv
+ * (cruse_net.py:139,150) accumulated by the conv's own epilogue: y = conv (no activation, no accumulate),
+ * sums[0..Cout) += sum_{b,t,f} y, sums[Cout..2Cout) += sum y^2 -- what cruse_bn_stats(y) would add, without the
+ * extra pass over y.  zeroed != 0: the caller has cleared sums (else cleared here, on `stream`).  Shapes the MFMA
+ * kernel does not take (Cin == 1) run the VALU conv followed by the cruse_bn_stats kernel. */
+int cruse_conv_gather_bnstats(const float* x, const float* w, const float* bias, float* y,
+                              int B, int T, int Cin, int Fin, int Cout, int Fout,
+                              int KT, int S, int pad, int prec, double* sums, int zeroed, void* stream);
+int cruse_conv_scatter2_bnstats(const float* g, const float* w, const float* bias, float* y,
+                                int B, int T, int Cs, int Fg, int Cout, int Fout,
+                                int KT, int pad, int prec, double* sums, int zeroed, void* stream);
 
 /* weight gradient of either form:
  *   dw[ca][cb][kt][kf] += sum_{b,t,fa} a[b,t,ca,fa] * bt[b, t-(KT-1)+kt, cb, fa*S - pad + kf]

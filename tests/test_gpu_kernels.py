@@ -187,6 +187,37 @@ def test_conv_golden_and_causality(ops, golden):
     assert torch.equal(ya[:, :5], yb[:, :5]) and not torch.equal(ya[:, 5:], yb[:, 5:])
 
 
+@pytest.mark.parametrize("lvl", range(4))
+@pytest.mark.parametrize("prec", [None, "f32", "bf16x3", "bf16"])
+def test_conv_bnstats_epilogue(ops, lvl, prec):
+    """cruse_conv_*_bnstats: same y as the plain conv (bit-exact), sums == f64 sums of that y; T = 21 leaves a ragged
+    8-frame tile, B*T tiles exceed nothing; the arena-less call clears the sums itself."""
+    Cin, Fin, Cout, Fout = LEVELS[lvl]
+    B, T = 3, 21
+    gen = torch.Generator().manual_seed(70 + lvl)
+    x = (torch.randn(B, T, Cin, Fin, generator=gen) + 0.3).cuda()
+    w = (torch.randn(Cout, Cin, 2, 3, generator=gen) * 0.2).cuda()
+    b = torch.randn(Cout, generator=gen).cuda()
+    y0 = ops.conv_gather(x, w, b, B, T, Cin, Fin, Cout, Fout, KT=2, S=2, pad=1, prec=prec)
+    y, sums = ops.conv_gather_bnstats(x, w, b, B, T, Cin, Fin, Cout, Fout, KT=2, S=2, pad=1, prec=prec)
+    assert torch.equal(y, y0)
+    ref = torch.cat([y.double().sum(dim=(0, 1, 3)), (y.double() ** 2).sum(dim=(0, 1, 3))])
+    assert rel_l2(sums, ref) < 1e-6
+    # decoder form: convT k maps ch[k] x F_k -> ch[k-1] x 2 F_k
+    u = (torch.randn(B, T, Cout, Fout, generator=gen) - 0.2).cuda()
+    wt = (torch.randn(Cout, Cin, 1, 3, generator=gen) * 0.2).cuda()
+    bt = torch.randn(Cin, generator=gen).cuda()
+    v0 = ops.conv_scatter2(u, wt, bt, B, T, Cout, Fout, Cin, KT=1, pad=0, prec=prec)
+    v, sums = ops.conv_scatter2_bnstats(u, wt, bt, B, T, Cout, Fout, Cin, KT=1, pad=0, prec=prec)
+    assert torch.equal(v, v0)
+    ref = torch.cat([v.double().sum(dim=(0, 1, 3)), (v.double() ** 2).sum(dim=(0, 1, 3))])
+    assert rel_l2(sums, ref) < 1e-6
+    with ops.ARENA.step(x.device):      # pre-zeroed arena slices, as the training step uses them
+        _, s1 = ops.conv_gather_bnstats(x, w, b, B, T, Cin, Fin, Cout, Fout, KT=2, S=2, pad=1, prec=prec)
+        _, s2 = ops.conv_scatter2_bnstats(u, wt, bt, B, T, Cout, Fout, Cin, KT=1, pad=0, prec=prec)
+        assert rel_l2(s2, ref) < 1e-6 and s1.data_ptr() != s2.data_ptr()
+
+
 def test_conv_shape_errors(ops):
     x = torch.zeros(1, 4, 1, 160).cuda(); w = torch.zeros(8, 1, 2, 3).cuda()
     with pytest.raises(RuntimeError, match="Fout"):
