@@ -20,6 +20,7 @@ constexpr int CONV_THREADS = 320;
 struct ConvArgs {
     const float* x; const float* w; const float* bias; float* y;
     int B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout, act, accum;
+    double* sums;            // gather form only: BatchNorm batch sums of y ([2][Cout]) accumulated by the epilogue, or null
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -41,6 +42,10 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_gather_kernel(ConvArgs a) {
     const int ntile = (a.T + TF - 1) / TF;
     const int b = blockIdx.x / ntile;
     const int t0 = (blockIdx.x % ntile) * TF;
+    // f64 cells: adding f32-valued partials in f64 is exact, so the result does not depend on the order of the atomics
+    // (f32 cells made the batch mean vary by an ulp from run to run -- enough to flip a ReLU decision sitting on it)
+    __shared__ double s_stat[2][64];
+    if (a.sums && tid < 128) (&s_stat[0][0])[tid] = 0.0;        // ordered by the staging barrier below
 
     // stage weights: wl[(ci*KT+kt)*3+kf][co]
     for (int i = tid; i < K3 * a.Cout; i += CONV_THREADS) {
@@ -103,6 +108,9 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_gather_kernel(ConvArgs a) {
                 }
             }
         }
+        float st1[CO_T], st2[CO_T];
+#pragma unroll
+        for (int c = 0; c < CO_T; ++c) { st1[c] = 0.f; st2[c] = 0.f; }
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) {
             const int t = t0 + set * TT + tt;
@@ -113,7 +121,22 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_gather_kernel(ConvArgs a) {
                 float v = acc[tt][c];
                 if (a.accum) v += a.y[idx]; else v = apply_act(v, a.act);
                 a.y[idx] = v;
+                st1[c] += v; st2[c] += v * v;
             }
+        }
+        if (a.sums) {
+#pragma unroll
+            for (int c = 0; c < CO_T; ++c) {
+                atomicAdd(&s_stat[0][co0 + c], (double)st1[c]);
+                atomicAdd(&s_stat[1][co0 + c], (double)st2[c]);
+            }
+        }
+    }
+    if (a.sums) {       // Cout <= 64 (host-checked): 8 frames x Fout values per channel in f32, then one f64 atomic each
+        __syncthreads();
+        if (tid < 2 * a.Cout) {
+            const int which = tid / a.Cout, co = tid - which * a.Cout;
+            atomicAdd(a.sums + which * a.Cout + co, s_stat[which][co]);
         }
     }
 }
@@ -392,7 +415,8 @@ int conv_gather_impl(const float* x, const float* w, const float* bias, float* y
                                           prec, bn_sums, (hipStream_t)stream);
         if (r != 0) return r < 0 ? r : CRUSE_OK;
     }
-    ConvArgs a{x, w, bias, y, B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout, act, accum};
+    const bool fuse = bn_sums && Cout <= 64;
+    ConvArgs a{x, w, bias, y, B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout, act, accum, fuse ? bn_sums : nullptr};
     const size_t lds = (((size_t)Cin * KT * 3 * Cout + 3) & ~(size_t)3) * 4 +
                        (size_t)(TF + KT - 1) * Cin * (Fin + 2) * 4;
     CRUSE_REQUIRE(lds <= 160 * 1024, CRUSE_E_SHAPE, "conv_gather: tile needs %zu B of LDS", lds);
@@ -406,8 +430,7 @@ int conv_gather_impl(const float* x, const float* w, const float* bias, float* y
         hipLaunchKernelGGL(conv_gather_kernel<1>, dim3(grid), dim3(CONV_THREADS), lds, (hipStream_t)stream, a);
     }
     CRUSE_LAUNCH_CHECK("conv_gather");
-    // the VALU kernel has no statistics epilogue: one more pass over y
-    if (bn_sums) return cruse_bn_stats(y, (long long)B * T, Cout, Fout, bn_sums, 1, stream);
+    if (bn_sums && !fuse) return cruse_bn_stats(y, (long long)B * T, Cout, Fout, bn_sums, 1, stream);
     return CRUSE_OK;
 }
 
@@ -424,7 +447,7 @@ int conv_scatter2_impl(const float* g, const float* w, const float* bias, float*
                                           bn_sums, (hipStream_t)stream);
         if (r != 0) return r < 0 ? r : CRUSE_OK;
     }
-    ConvArgs a{g, w, bias, y, B, T, Cs, Fg, Cout, Fout, KT, 2, pad, 0, act, accum};
+    ConvArgs a{g, w, bias, y, B, T, Cs, Fg, Cout, Fout, KT, 2, pad, 0, act, accum, nullptr};
     const size_t lds = (((size_t)Cs * KT * 3 * Cout + 3) & ~(size_t)3) * 4 +
                        (size_t)(TF + KT - 1) * Cs * (Fg + 2) * 4;
     CRUSE_REQUIRE(lds <= 160 * 1024, CRUSE_E_SHAPE, "conv_scatter2: tile needs %zu B of LDS", lds);
@@ -438,6 +461,7 @@ int conv_scatter2_impl(const float* g, const float* w, const float* bias, float*
         hipLaunchKernelGGL(conv_scatter2_kernel<1>, dim3(grid), dim3(CONV_THREADS), lds, (hipStream_t)stream, a);
     }
     CRUSE_LAUNCH_CHECK("conv_scatter2");
+    // the VALU scatter kernel has no statistics epilogue: one more pass over y
     if (bn_sums) return cruse_bn_stats(y, (long long)B * T, Cout, Fout, bn_sums, 1, stream);
     return CRUSE_OK;
 }

@@ -145,7 +145,9 @@ int cruse_bn_act_bwd_reduce(const float* dout, const float* y, const float* mean
                             const float* gamma, const float* beta, long long rows, int C, int F,
                             int relu, double* sums, int zeroed, void* stream);
 /* dy = gamma*rstd*(g - [training](sum_g + xhat*sum_gx)/count); dgamma += sum_gx; dbeta += sum_g;
- * dbias (nullable) += per-channel sum of dy -- the gradient of the bias of the conv that feeds this BN */
+ * dbias (nullable) += per-channel sum of dy -- the gradient of the bias of the conv that feeds this BN -- in closed
+ * form from the sums: gamma*rstd*sum_g with running statistics, and exactly 0 with batch statistics (sum xhat = 0:
+ * the bias is cancelled by the mean subtraction; autograd leaves rounding noise there) */
 int cruse_bn_act_bwd_apply(const float* dout, const float* y, const float* mean, const float* rstd,
                            const float* gamma, const float* beta, const double* sums,
                            long long rows, int C, int F, int relu, int training,

@@ -251,6 +251,13 @@ def test_batchnorm_relu_skip_fwd_bwd(ops, C, Fq):
                         True, True, dg, db)
     assert rel_l2(_nchw(dy), yr.grad) < 2e-5
     assert rel_l2(dg, bn.weight.grad) < 2e-5 and rel_l2(db, bn.bias.grad) < 2e-5
+    # with batch statistics the conv-bias gradient sum(dy) is exactly 0 (the mean subtraction cancels the bias): the
+    # library reports the closed form, the data sum is rounding noise
+    dbz = torch.zeros(C).cuda()
+    ops.bn_act_bwd(dout.cuda(), y.cuda(), mean, rstd, bn.weight.detach().cuda(), bn.bias.detach().cuda(), rows, C, Fq,
+                   True, True, torch.zeros(C).cuda(), torch.zeros(C).cuda(), dbias=dbz)
+    assert float(dbz.abs().max()) == 0.0
+    assert float(dy.double().sum(dim=(0, 1, 3)).abs().max()) < 1e-4 * float(dy.double().abs().sum(dim=(0, 1, 3)).max())
     # eval mode uses the running statistics
     bn.eval()
     m2, r2 = ops.bn_eval_stats(rm, rv, 1e-5)
