@@ -71,11 +71,18 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_gather_kernel(ConvArgs a) {
     __syncthreads();
 
     const int tpf = (a.Cout / CO_T) * a.Fout;
-    for (int item = tid; item < NSET * tpf; item += CONV_THREADS) {
-        const int set = item / tpf;
-        const int o = item % tpf;
+    // wave-uniform trip count (the statistics epilogue below uses wave reductions): lanes past the end idle
+    for (int base = 0; base < NSET * tpf; base += CONV_THREADS) {
+        const int item = base + tid;
+        const bool valid = item < NSET * tpf;
+        const int set = valid ? item / tpf : 0;
+        const int o = valid ? item % tpf : 0;
         const int cq = o / a.Fout, fo = o % a.Fout;
         const int co0 = cq * CO_T;
+        float st1[CO_T], st2[CO_T];
+#pragma unroll
+        for (int c = 0; c < CO_T; ++c) { st1[c] = 0.f; st2[c] = 0.f; }
+        if (valid) {
         float acc[TT][CO_T];
 #pragma unroll
         for (int c = 0; c < CO_T; ++c) {
@@ -108,9 +115,6 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_gather_kernel(ConvArgs a) {
                 }
             }
         }
-        float st1[CO_T], st2[CO_T];
-#pragma unroll
-        for (int c = 0; c < CO_T; ++c) { st1[c] = 0.f; st2[c] = 0.f; }
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) {
             const int t = t0 + set * TT + tt;
@@ -124,11 +128,27 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_gather_kernel(ConvArgs a) {
                 st1[c] += v; st2[c] += v * v;
             }
         }
+        }   // valid
         if (a.sums) {
+            // a wave's 64 consecutive items span at most a few channel groups: one wave reduction (fixed order) per
+            // group present, then ONE lane adds the group's 2 x CO_T sums to the LDS cells.  (Every lane adding its own
+            // values made 320 threads queue on 16 cells: 95 us for the 1 -> 8 layer against 53 without statistics.)
+            unsigned long long left = __ballot(1);
+            while (left) {
+                const int lead = __ffsll((long long)left) - 1;
+                const int key = __shfl(cq, lead, 64);
+                const bool mine = cq == key;
+                float r1[CO_T], r2[CO_T];
 #pragma unroll
-            for (int c = 0; c < CO_T; ++c) {
-                atomicAdd(&s_stat[0][co0 + c], (double)st1[c]);
-                atomicAdd(&s_stat[1][co0 + c], (double)st2[c]);
+                for (int c = 0; c < CO_T; ++c) { r1[c] = wave_sum(mine ? st1[c] : 0.f); r2[c] = wave_sum(mine ? st2[c] : 0.f); }
+                if ((int)(threadIdx.x & 63) == lead) {
+#pragma unroll
+                    for (int c = 0; c < CO_T; ++c) {
+                        atomicAdd(&s_stat[0][key * CO_T + c], (double)r1[c]);
+                        atomicAdd(&s_stat[1][key * CO_T + c], (double)r2[c]);
+                    }
+                }
+                left &= ~__ballot(mine);
             }
         }
     }
