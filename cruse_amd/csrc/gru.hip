@@ -53,6 +53,8 @@ struct GruArgs {
     unsigned long long* xg;           // granule panels [chain][parity][Bg][Hg]
     unsigned xg_bytes;
     unsigned* status;
+    int xcd_rot;                      // chain c of a launch runs on PHYSICAL XCD (c + xcd_rot) % 8 (concurrent launches: disjoint XCDs)
+    unsigned* tickets;                // [8] per-XCD workgroup counters of this launch (zeroed with the panels)
     int dbg;                          // profiling only (CRUSE_GRU_DBG): 1 = do not wait for tags, 2 = also skip MFMA
 };
 
@@ -278,6 +280,34 @@ __device__ __forceinline__ bool team_shares_xcd(unsigned long long* slots, int P
     return s_same != 0;
 }
 
+// Workgroup -> (chain, part) by the PHYSICAL XCD the workgroup landed on.  A dispatch deals its workgroups round-robin
+// over the 8 XCDs, but from a base that differs from dispatch to dispatch (census, tools/cu_mask_probe.py: bases 6, 7, 0
+// for consecutive launches), so block ids say which workgroups share an XCD, not which XCD that is.  Each workgroup
+// therefore reads its XCC id and draws a ticket from that XCD's counter: ticket t on XCD x is part t % P of chain
+// (t / P) * 8 + ((x - xcd_rot) & 7).  A team always shares one XCD (plain-store hand-off, team_shares_xcd), and two
+// concurrent launches with xcd_rot 0 and 4 and <= 4 chains each use disjoint XCDs whatever their dispatch bases.
+// If an XCD ever received more workgroups than it has places (not observed), the surplus ones take the places left
+// on the other XCDs: every place is always filled, placement is speed only.
+__device__ __forceinline__ bool claim_chain(const GruArgs& a, int P, int& chain, int& part) {
+    __shared__ int s_claim[2];
+    if (threadIdx.x == 0) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;      // HW_REG_XCC_ID
+        const unsigned places = (unsigned)(gridDim.x >> 3);         // per XCD: chain groups x P
+        unsigned x = xcc, t = 0;
+        for (int k = 0; k < 8; ++k) {
+            x = (xcc + k) & 7u;
+            t = __hip_atomic_fetch_add(a.tickets + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t < places) break;
+        }
+        const int c = (int)(t / (unsigned)P) * 8 + (int)((x - (unsigned)a.xcd_rot) & 7u);
+        s_claim[0] = (t < places && c < a.nchains) ? c : -1;
+        s_claim[1] = (int)(t % (unsigned)P);
+    }
+    __syncthreads();
+    chain = s_claim[0]; part = s_claim[1];
+    return chain >= 0;
+}
+
 // publish the own unit pair (u, u+1) of clip bl; pair_index = bl*Hg/2 + (u0+u)/2
 template <int PREC>
 __device__ __forceinline__ void publish_pair(__amdgpu_buffer_rsrc_t rs, unsigned panel_base, unsigned pair_index,
@@ -333,11 +363,8 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
     elem* hB = reinterpret_cast<elem*>(smem_raw);                 // [NPL][16][LD]  B operand (h_{t-1})
     float* red = reinterpret_cast<float*>(hB + NPL * PLANE);      // [4 waves][6 tiles][64 lanes][4]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    // block id -> (chain, part) with chain % 8 == id % 8: under the observed id%8 -> XCD dispatch a whole
-    // team lands on one XCD for ANY number of chains (speed only; see team_shares_xcd)
-    const int chain = (int)(blockIdx.x / (8 * a.P)) * 8 + (int)(blockIdx.x & 7);
-    const int part = (int)((blockIdx.x >> 3) % a.P);
-    if (chain >= a.nchains) return;
+    int chain, part;
+    if (!claim_chain(a, a.P, chain, part)) return;
     const int grp = chain % a.G, bgi = a.bg_off + chain / a.G;
     const int b0 = bgi * a.Bg, nb = min(a.Bg, a.B - b0);
     const int u0 = part * U;
@@ -521,9 +548,8 @@ __global__ __launch_bounds__(256) void gru_fwd_lean_kernel(GruArgs a) {
     __bf16* hB = reinterpret_cast<__bf16*>(smem_raw);                    // [16][LD]  B operand (h_{t-1})
     float* red = reinterpret_cast<float*>(hB + 16 * LD);                  // [4 waves][6 tiles][64 lanes][4]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int chain = (int)(blockIdx.x / (8 * a.P)) * 8 + (int)(blockIdx.x & 7);
-    const int part = (int)((blockIdx.x >> 3) % a.P);
-    if (chain >= a.nchains) return;
+    int chain, part;
+    if (!claim_chain(a, a.P, chain, part)) return;
     const int grp = chain % a.G, bgi = a.bg_off + chain / a.G;
     const int b0 = bgi * 8, nb = min(8, a.B - b0);
     const int u0 = part * U;
@@ -718,11 +744,8 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruArgs a) {
     elem* dB = reinterpret_cast<elem*>(smem_raw);                 // [NPL][16][LD]  B operand (dh_{s+1} * c_{s+1})
     float* red = reinterpret_cast<float*>(dB + NPL * PLANE);      // [4 waves][2 tiles][64][4]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    // block id -> (chain, part) with chain % 8 == id % 8: under the observed id%8 -> XCD dispatch a whole
-    // team lands on one XCD for ANY number of chains (speed only; see team_shares_xcd)
-    const int chain = (int)(blockIdx.x / (8 * a.P)) * 8 + (int)(blockIdx.x & 7);
-    const int part = (int)((blockIdx.x >> 3) % a.P);
-    if (chain >= a.nchains) return;
+    int chain, part;
+    if (!claim_chain(a, a.P, chain, part)) return;
     const int grp = chain % a.G, bgi = a.bg_off + chain / a.G;
     const int b0 = bgi * a.Bg, nb = min(a.Bg, a.B - b0);
     const int u0 = part * U;
@@ -852,9 +875,8 @@ __global__ __launch_bounds__(256) void gru_bwd_rs_kernel(GruArgs a) {
     __shared__ __attribute__((aligned(16))) __bf16 panel[2][16 * KP];
     const int Hg = a.Hg, H = a.G * Hg, K3 = 3 * Hg, P = a.P, NTt = Hg >> 4;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int chain = (int)(blockIdx.x / (8 * P)) * 8 + (int)(blockIdx.x & 7);
-    const int part = (int)((blockIdx.x >> 3) % P);
-    if (chain >= a.nchains) return;
+    int chain, part;
+    if (!claim_chain(a, P, chain, part)) return;
     const int grp = chain % a.G, bgi = a.bg_off + chain / a.G;
     const int b0 = bgi * 8, nb = min(8, a.B - b0);
     const int u0 = part * U;
@@ -1167,6 +1189,7 @@ int make_plan(int B, int G, int Hg, Plan& pl) {
     return 0;
 }
 
+constexpr int MAX_LAUNCH_TICKETS = 64;      // launches of one call that get their own ticket counters
 size_t xid_bytes_total(int B, int G) { return (size_t)cdiv(B, 8) * G * 64 * 8; }
 
 // granules (8 bytes) of one parity of one chain: all-gather forms keep up to 16 rows of Hg values; the
@@ -1273,13 +1296,18 @@ int check_common(int B, int T, int G, int Hg, int prec, const char* name) {
 }
 
 template <bool FWD>
-int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* ws, size_t lds, hipStream_t s) {
-    a.status = (unsigned*)ws;
-    char* xid_base = (char*)ws + 256;
+int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* panels, unsigned* status, int xcd_rot,
+                 size_t lds, hipStream_t s) {
+    a.status = status;
+    a.xcd_rot = xcd_rot & 7;
+    char* xid_base = (char*)panels;
     char* xg_base = xid_base + xid_bytes_total(a.B, G);
+    unsigned* tickets_base = (unsigned*)(xg_base + xg_bytes_total(a.B, G, Hg));        // [launch][8]
     a.Bg = pl.Bg; a.P = pl.P;
     { const char* e = getenv("CRUSE_GRU_DBG"); a.dbg = e ? atoi(e) : 0; }
     int rc = CRUSE_OK;
+    CRUSE_REQUIRE(pl.nlaunch <= MAX_LAUNCH_TICKETS, CRUSE_E_SHAPE, "gru_seq: batch %d needs %d launches (max %d)", a.B, pl.nlaunch,
+                  MAX_LAUNCH_TICKETS);
     for (int L = 0; L < pl.nlaunch; ++L) {
         const int bg_off = L * pl.bg_per_launch;
         const int nbg_here = (pl.nbg - bg_off) < pl.bg_per_launch ? (pl.nbg - bg_off) : pl.bg_per_launch;
@@ -1287,6 +1315,7 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* ws, 
         a.nchains = nbg_here * G;
         // every launch gets its own panel region: chain index inside the launch + offset
         a.xid = (unsigned long long*)xid_base + (size_t)bg_off * G * 64;
+        a.tickets = tickets_base + (size_t)L * 8;
         const bool rs_form = !FWD && bwd_rs_eligible(pl.Bg, Hg, prec);
         const size_t gpp = rs_form ? rs_gran_per_parity(Hg) : (size_t)pl.Bg * Hg;      // granules per parity and chain
         a.xg = (unsigned long long*)xg_base + (size_t)bg_off * G * 2 * gpp;
@@ -1313,12 +1342,13 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* ws, 
 }  // namespace
 
 extern "C" size_t cruse_gru_ws_bytes(int B, int G, int Hg) {
-    return 256 + xid_bytes_total(B, G) + xg_bytes_total(B, G, Hg);
+    return 256 + xid_bytes_total(B, G) + xg_bytes_total(B, G, Hg) + (size_t)MAX_LAUNCH_TICKETS * 8 * sizeof(unsigned);
 }
 
-extern "C" int cruse_gru_seq_fwd(const float* gi, const float* const* w_hh, const float* const* b_hh,
-                                 float* h, void* coef, float* an, float* z,
-                                 int B, int T, int G, int Hg, int prec, void* ws, void* stream) {
+extern "C" int cruse_gru_seq_fwd_on(const float* gi, const float* const* w_hh, const float* const* b_hh,
+                                    float* h, void* coef, float* an, float* z,
+                                    int B, int T, int G, int Hg, int prec, void* panels, unsigned* status, int xcd_rot,
+                                    void* stream) {
     int rc = check_common(B, T, G, Hg, prec, "gru_seq_fwd");
     if (rc) return rc;
     CRUSE_REQUIRE((coef == nullptr) == (an == nullptr) && (coef == nullptr) == (z == nullptr), CRUSE_E_SHAPE,
@@ -1326,24 +1356,34 @@ extern "C" int cruse_gru_seq_fwd(const float* gi, const float* const* w_hh, cons
     Plan pl;
     CRUSE_REQUIRE(make_plan(B, G, Hg, pl) == 0, CRUSE_E_SHAPE, "gru_seq_fwd: G*Hg/32 exceeds the CU count");
     hipStream_t s = (hipStream_t)stream;
-    { int zrc = cruse_zero_async((char*)ws + 256, cruse_gru_ws_bytes(B, G, Hg) - 256, s, "gru_seq_fwd memset"); if (zrc) return zrc; }   // the 256-byte header (status word) is sticky
+    CRUSE_REQUIRE(panels != nullptr && status != nullptr, CRUSE_E_SHAPE, "gru_seq_fwd: workspace / status pointer is NULL");
+    { int zrc = cruse_zero_async(panels, cruse_gru_ws_bytes(B, G, Hg) - 256, s, "gru_seq_fwd memset"); if (zrc) return zrc; }   // the status word is sticky: never cleared here
     GruArgs a = {};
     a.gi = gi; a.h = h; a.coef = coef; a.an = an; a.z = z;
     for (int g = 0; g < G; ++g) { a.p.w_hh[g] = w_hh[g]; a.p.b_hh[g] = b_hh[g]; }
     a.B = B; a.T = T; a.G = G; a.Hg = Hg;
     const size_t esz = prec == CRUSE_PREC_F32 ? 4 : 2, npl = prec == CRUSE_PREC_BF16X3 ? 2 : 1;
     const size_t lds = (size_t)16 * (Hg + (prec == CRUSE_PREC_F32 ? 4 : 8)) * esz * npl + 4 * 6 * 64 * 4 * sizeof(float);
-    return run_launches<true>(a, pl, G, Hg, prec, ws, lds, s);
+    return run_launches<true>(a, pl, G, Hg, prec, panels, status, xcd_rot, lds, s);
 }
 
-extern "C" int cruse_gru_seq_bwd(const float* dout, const float* const* w_hh, const void* coef, const float* z,
-                                 float* dh, int B, int T, int G, int Hg, int prec, void* ws, void* stream) {
+extern "C" int cruse_gru_seq_fwd(const float* gi, const float* const* w_hh, const float* const* b_hh,
+                                 float* h, void* coef, float* an, float* z,
+                                 int B, int T, int G, int Hg, int prec, void* ws, void* stream) {
+    return cruse_gru_seq_fwd_on(gi, w_hh, b_hh, h, coef, an, z, B, T, G, Hg, prec, ws ? (char*)ws + 256 : nullptr, (unsigned*)ws, 0,
+                                stream);
+}
+
+extern "C" int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh, const void* coef, const float* z,
+                                    float* dh, int B, int T, int G, int Hg, int prec, void* panels, unsigned* status,
+                                    int xcd_rot, void* stream) {
     int rc = check_common(B, T, G, Hg, prec, "gru_seq_bwd");
     if (rc) return rc;
     Plan pl;
     CRUSE_REQUIRE(make_plan(B, G, Hg, pl) == 0, CRUSE_E_SHAPE, "gru_seq_bwd: G*Hg/32 exceeds the CU count");
     hipStream_t s = (hipStream_t)stream;
-    { int zrc = cruse_zero_async((char*)ws + 256, cruse_gru_ws_bytes(B, G, Hg) - 256, s, "gru_seq_bwd memset"); if (zrc) return zrc; }   // the 256-byte header (status word) is sticky
+    CRUSE_REQUIRE(panels != nullptr && status != nullptr, CRUSE_E_SHAPE, "gru_seq_bwd: workspace / status pointer is NULL");
+    { int zrc = cruse_zero_async(panels, cruse_gru_ws_bytes(B, G, Hg) - 256, s, "gru_seq_bwd memset"); if (zrc) return zrc; }   // the status word is sticky: never cleared here
     GruArgs a = {};
     a.dout = dout; a.coefs = coef; a.zs = z; a.dh = dh;
     for (int g = 0; g < G; ++g) { a.p.w_hh[g] = w_hh[g]; a.p.b_hh[g] = nullptr; }
@@ -1351,7 +1391,13 @@ extern "C" int cruse_gru_seq_bwd(const float* dout, const float* const* w_hh, co
     const size_t esz = prec == CRUSE_PREC_F32 ? 4 : 2, npl = prec == CRUSE_PREC_BF16X3 ? 2 : 1;
     const size_t lds = (size_t)16 * (3 * Hg + (prec == CRUSE_PREC_F32 ? 4 : 8)) * esz * npl + 4 * 2 * 64 * 4 * sizeof(float);
     CRUSE_REQUIRE(lds <= 160 * 1024, CRUSE_E_SHAPE, "gru_seq_bwd: Hg=%d needs %zu B of LDS", Hg, lds);
-    return run_launches<false>(a, pl, G, Hg, prec, ws, lds, s);
+    return run_launches<false>(a, pl, G, Hg, prec, panels, status, xcd_rot, lds, s);
+}
+
+extern "C" int cruse_gru_seq_bwd(const float* dout, const float* const* w_hh, const void* coef, const float* z,
+                                 float* dh, int B, int T, int G, int Hg, int prec, void* ws, void* stream) {
+    return cruse_gru_seq_bwd_on(dout, w_hh, coef, z, dh, B, T, G, Hg, prec, ws ? (char*)ws + 256 : nullptr, (unsigned*)ws, 0,
+                                stream);
 }
 
 extern "C" int cruse_gru_gate_grads(const float* dh, const void* coef, const float* an, float* dgi, float* dgh,

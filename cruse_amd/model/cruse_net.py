@@ -88,7 +88,11 @@ class _SideStream:
         if not (self.enabled and (self.defer_mask & kind)):
             self.run(fn, *tensors, lane=lane)
             return
-        self.deferred.append((fn, lane))
+        # the leaf's inputs are complete on the stream that defers it -- which need not be the stream that later releases
+        # it (half-batch pipelines, ggru_forward): remember that point
+        dep = torch.cuda.Event()
+        dep.record(torch.cuda.current_stream())
+        self.deferred.append((fn, lane, dep))
         self.keep.extend(tensors)
 
     def release_around(self, launch):
@@ -100,22 +104,27 @@ class _SideStream:
         ev = torch.cuda.Event()
         ev.record(main)
         out = launch()
-        for fn, lane in self.deferred:
+        for fn, lane, dep in self.deferred:
             side = self._next(lane)
             side.wait_event(ev)
+            side.wait_event(dep)
             with torch.cuda.stream(side):
                 fn()
         self.deferred.clear()
         self.active = True
         return out
 
-    def run(self, fn, *tensors, lane=None):
+    def run(self, fn, *tensors, lane=None, dep=None):
         if not self.enabled:
+            if dep is not None:
+                torch.cuda.current_stream().wait_event(dep)
             fn()
             return
         main = torch.cuda.current_stream()
         side = self._next(lane)
         side.wait_stream(main)
+        if dep is not None:
+            side.wait_event(dep)
         self.keep.extend(tensors)
         self.active = True
         with torch.cuda.stream(side):
@@ -141,8 +150,8 @@ class _SideStream:
         """Issue everything still queued by defer() on the side streams now."""
         if self.deferred:
             fns, self.deferred = self.deferred, []
-            for fn, lane in fns:
-                self.run(fn, lane=lane)
+            for fn, lane, dep in fns:
+                self.run(fn, lane=lane, dep=dep)
 
     def join(self, flush: bool = True):
         """Main stream waits for the side streams.  flush=False keeps the deferred (not yet issued) leaves queued: a
@@ -160,6 +169,47 @@ class _SideStream:
 
 
 SIDE = _SideStream()
+
+
+class _Pipes:
+    """Half-batch pipelines through the GGRU block (CRUSE_GRU_PIPES=2; default OFF).  The persistent recurrence kernels are
+    latency-bound -- their time does not depend on how many 8-clip chains run -- while the projections, layer norms and
+    gate gradients between them keep the recurrence waiting.  With the batch cut into n slices on n streams, staggered by
+    one pre-stage, the in-between work of one slice runs beside the recurrence of the other, and the recurrences of the
+    slices (4 chains each at B = 64, on disjoint XCDs: cruse_gru_seq_fwd_on) overlap each other.  BatchNorm needs the
+    whole batch, so only the GGRU block is sliced.
+    Measured on the bench step: 7.55 ms against 6.94 ms single-stream.  The two half recurrences do overlap
+    (642 us for the pair against 610 us for one), but the in-between kernels then run on the 96 CUs the recurrences leave
+    free -- 2.7x slower than alone (the half-batch gate GEMM: 242 us against 84 us) -- and those CUs are already used by
+    the weight-gradient leaves, so the stagger between the slices costs more than the overlap saves."""
+
+    def __init__(self):
+        self.n = max(1, int(os.environ.get("CRUSE_GRU_PIPES", "1")))
+        self.streams = {}
+
+    def count(self, B: int, g: int, Hg: int) -> int:
+        n = self.n
+        if n < 2 or not SIDE.enabled or B % (8 * n) != 0:
+            return 1
+        chains = (B // n // 8) * g          # 8-clip chains per slice, Hg/32 workgroups each, one workgroup per CU
+        per_xcd = (chains + 7) // 8 * (Hg // 32)
+        if chains * n <= 8 or per_xcd * n <= 28:
+            return n
+        return 1
+
+    def rot(self, k: int, n: int, B: int, g: int) -> int:
+        chains = (B // n // 8) * g
+        return (k * (8 // n)) % 8 if chains * n <= 8 else 0
+
+    def stream(self, k: int):
+        dev = torch.cuda.current_device()
+        lst = self.streams.setdefault(dev, [])
+        while len(lst) < k:
+            lst.append(torch.cuda.Stream())
+        return lst[k - 1]
+
+
+PIPES = _Pipes()
 
 
 def _splitk_bf16(M: int, N: int, K: int) -> int:
@@ -189,12 +239,44 @@ def _splitk(M: int, N: int, K: int) -> int:
 # ======================================================================================
 def ggru_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], prefix: str, groups: int, prec,
                  residual: Optional[torch.Tensor] = None, save: bool = True):
-    """x [B,T,H] -> (ln2(gru2(ln1(interleave(gru1(x))))) [+ residual], ctx).  cruse_net.py:37-55."""
+    """x [B,T,H] -> (ln2(gru2(ln1(interleave(gru1(x))))) [+ residual], ctx).  cruse_net.py:37-55.
+    With CRUSE_GRU_PIPES=2, batches of 16k clips run as half-batch pipelines on two streams (_Pipes); ctx then holds one
+    context per slice."""
+    B, T, H = x.shape
+    n = PIPES.count(B, groups, H // groups)
+    if n == 1:
+        return _ggru_forward_one(x, P, prefix, groups, prec, residual, save)
+    Bh = B // n
+    out = torch.empty_like(x)
+    main = torch.cuda.current_stream()
+    fork = torch.cuda.Event()
+    fork.record(main)
+    ctxs, gate_prev = [], None
+    for k in range(n):
+        sl = slice(k * Bh, (k + 1) * Bh)
+        st = main if k == 0 else PIPES.stream(k)
+        gate = torch.cuda.Event()
+        if k > 0:
+            st.wait_event(fork)
+            st.wait_event(gate_prev)         # stagger: this slice's projection runs beside the previous slice's recurrence
+        with torch.cuda.stream(st):
+            _, c = _ggru_forward_one(x[sl], P, prefix, groups, prec, None if residual is None else residual[sl], save,
+                                     out=out[sl], slot=k, xcd_rot=PIPES.rot(k, n, B, groups),
+                                     pre_done=lambda gate=gate, st=st: gate.record(st))
+        ctxs.append(c)
+        gate_prev = gate
+    for k in range(1, n):
+        main.wait_stream(PIPES.stream(k))
+    return out, dict(B=B, T=T, H=H, g=groups, prec=prec, prefix=prefix, has_res=residual is not None, pipes=ctxs)
+
+
+def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=None, slot=0, xcd_rot=0, pre_done=None):
     B, T, H = x.shape
     g = groups
     Hg = H // g
     rows = B * T
-    ctx = dict(B=B, T=T, H=H, g=g, prec=prec, x=x, prefix=prefix, has_res=residual is not None)
+    ctx = dict(B=B, T=T, H=H, g=g, prec=prec, x=x, prefix=prefix, has_res=residual is not None, slot=slot, xcd_rot=xcd_rot)
+    hooks = [pre_done] if pre_done is not None else []
 
     fast = _bf16_gemm_path(prec, Hg)
 
@@ -228,12 +310,15 @@ def ggru_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], prefix: str, group
                          prec=prec)
         w_hh = [P[f"{prefix}{lname}.{i}.weight_hh_l0"] for i in range(g)]
         b_hh = [P[f"{prefix}{lname}.{i}.bias_hh_l0"] for i in range(g)]
-        return SIDE.release_around(lambda: ops.gru_seq_fwd(gi, w_hh, b_hh, B, T, g, Hg, prec, save=save))
+        if hooks:
+            hooks.pop()()                    # the pre-stage of this slice is issued: the next slice may start its own
+        return SIDE.release_around(lambda: ops.gru_seq_fwd(gi, w_hh, b_hh, B, T, g, Hg, prec, save=save, slot=slot,
+                                                           xcd_rot=xcd_rot))
 
     h1, c1, a1, z1 = layer(x, "gru_list1")
     l1, m1, s1 = ops.ln_fwd(h1, P[prefix + "ln1.weight"], P[prefix + "ln1.bias"], None, rows, H, g, save=save)
     h2, c2, a2, z2 = layer(l1, "gru_list2")
-    out, m2, s2 = ops.ln_fwd(h2, P[prefix + "ln2.weight"], P[prefix + "ln2.bias"], residual, rows, H, 1, save=save)
+    out, m2, s2 = ops.ln_fwd(h2, P[prefix + "ln2.weight"], P[prefix + "ln2.bias"], residual, rows, H, 1, save=save, out=out)
     if save:
         ctx.update(h1=h1, c1=c1, a1=a1, z1=z1, l1=l1, m1=m1, s1=s1,
                    h2=h2, c2=c2, a2=a2, z2=z2, m2=m2, s2=s2)
@@ -248,23 +333,74 @@ def ggru_backward(ctx, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[s
     defer_last: queue layer 1's weight-gradient leaf (SIDE.defer) instead of issuing it -- the caller ends a segment
     right after this function and issues it with SIDE.flush() at the start of the next one."""
     B, T, H, g, prec, prefix = ctx["B"], ctx["T"], ctx["H"], ctx["g"], ctx["prec"], ctx["prefix"]
+    if "pipes" in ctx:
+        n = len(ctx["pipes"])
+        Bh = B // n
+        dx = None
+        if need_dx:
+            dx = dx_init.view(B, T, H) if dx_init is not None else torch.empty(B, T, H, device=dout.device, dtype=torch.float32)
+        main = torch.cuda.current_stream()
+        fork = torch.cuda.Event()
+        fork.record(main)
+        gate_prev = None
+        for k, c in enumerate(ctx["pipes"]):
+            sl = slice(k * Bh, (k + 1) * Bh)
+            st = main if k == 0 else PIPES.stream(k)
+            gate = torch.cuda.Event()
+            if k > 0:
+                st.wait_event(fork)
+                st.wait_event(gate_prev)
+            with torch.cuda.stream(st):
+                # every slice ADDS its input gradient into its rows of dx when the caller pre-filled them (dx_init)
+                _ggru_backward_one(c, dout[sl], P, G, need_dx, dx[sl] if need_dx else None, dx_init is not None, dx_ready,
+                                   defer_last, pre_done=lambda gate=gate, st=st: gate.record(st))
+            gate_prev = gate
+        for k in range(1, n):
+            main.wait_stream(PIPES.stream(k))
+        if join:
+            SIDE.join()
+        return dx
+    dx = None
+    if need_dx:
+        if dx_init is not None:
+            dx = dx_init.view(B, T, H)
+        else:
+            dx = torch.empty(B, T, H, device=dout.device, dtype=torch.float32)
+    _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_init is not None, dx_ready, defer_last)
+    if join:
+        SIDE.join()
+    return dx
+
+
+def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_last, pre_done=None):
+    """One batch slice of ggru_backward on the current stream; dx: the [B,T,H] rows its input gradient is written to
+    (added to when dx_accum)."""
+    B, T, H, g, prec, prefix = ctx["B"], ctx["T"], ctx["H"], ctx["g"], ctx["prec"], ctx["prefix"]
+    slot, xcd_rot = ctx.get("slot", 0), ctx.get("xcd_rot", 0)
     Hg = H // g
     rows = B * T
+    hooks = [pre_done] if pre_done is not None else []
+
+    def run_bwd(dout_h, w_hh, coef, z):
+        if hooks:
+            hooks.pop()()
+        return SIDE.release_around(lambda: ops.gru_seq_bwd(dout_h, w_hh, coef, z, B, T, g, Hg, prec, slot=slot,
+                                                           xcd_rot=xcd_rot))
 
     def dinp_buffer(dout_h, need_dinp, last):
         if not need_dinp:
             return None, False
-        if last and dx_init is not None:
-            if dx_ready is not None:
+        if last:
+            if dx_accum and dx_ready is not None:
                 dx_ready()
-            return dx_init.view(B, T, H), True
+            return dx, dx_accum
         return torch.empty(B, T, H, device=dout_h.device, dtype=torch.float32), False
 
     def layer_bwd_bf16(dout_h, lname, inp, h, coef, an, z, need_dinp, last):
         """CRUSE_PREC_BF16: every product as gemm_bf16_nt on bf16 operand copies (see gemm_bf16.hip)."""
         names = [f"{prefix}{lname}.{i}." for i in range(g)]
         w_hh = [P[nm + "weight_hh_l0"] for nm in names]
-        dh = SIDE.release_around(lambda: ops.gru_seq_bwd(dout_h, w_hh, coef, z, B, T, g, Hg, prec))
+        dh = run_bwd(dout_h, w_hh, coef, z)
         dgi, dgT, ldT = ops.gru_gate_grads_bf16(dh, coef, an, rows, g, Hg, [G[nm + "bias_ih_l0"] for nm in names],
                                                 [G[nm + "bias_hh_l0"] for nm in names])
         inpT = torch.empty(ldT // 64, H, 64, device=dh.device, dtype=torch.bfloat16)
@@ -304,7 +440,7 @@ def ggru_backward(ctx, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[s
         if _bf16_gemm_path(prec, Hg):
             return layer_bwd_bf16(dout_h, lname, inp, h, coef, an, z, need_dinp, last)
         w_hh = [P[f"{prefix}{lname}.{i}.weight_hh_l0"] for i in range(g)]
-        dh = SIDE.release_around(lambda: ops.gru_seq_bwd(dout_h, w_hh, coef, z, B, T, g, Hg, prec))
+        dh = run_bwd(dout_h, w_hh, coef, z)
         dgi, dgh = ops.gru_gate_grads(dh, coef, an, rows, g, Hg, prec)
         sk = _splitk(3 * Hg, Hg, rows)
 
@@ -338,10 +474,7 @@ def ggru_backward(ctx, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[s
     dl1 = layer_bwd(dh2, "gru_list2", ctx["l1"], ctx["h2"], ctx["c2"], ctx["a2"], ctx["z2"], True, False)
     dh1 = ops.ln_bwd(dl1, ctx["h1"], ctx["m1"], ctx["s1"], P[prefix + "ln1.weight"], rows, H, g,
                      G[prefix + "ln1.weight"], G[prefix + "ln1.bias"])
-    dx = layer_bwd(dh1, "gru_list1", ctx["x"], ctx["h1"], ctx["c1"], ctx["a1"], ctx["z1"], need_dx, True)
-    if join:
-        SIDE.join()
-    return dx
+    layer_bwd(dh1, "gru_list1", ctx["x"], ctx["h1"], ctx["c1"], ctx["a1"], ctx["z1"], need_dx, True)
 
 
 # ======================================================================================

@@ -268,8 +268,8 @@ def bn_act_bwd(dout, y, mean, rstd, gamma, beta, rows, C, F, relu, training, dga
 
 
 # ---------------------------------------------------------------- LayerNorm
-def ln_fwd(x, gamma, beta, res, rows, H, interleave_g=1, eps=1e-5, save=True):
-    y = torch.empty_like(x)
+def ln_fwd(x, gamma, beta, res, rows, H, interleave_g=1, eps=1e-5, save=True, out=None):
+    y = torch.empty_like(x) if out is None else out
     mean = torch.empty(rows, device=x.device, dtype=torch.float32) if save else None
     rstd = torch.empty(rows, device=x.device, dtype=torch.float32) if save else None
     check(lib.cruse_ln_fwd(_p(x), _p(gamma), _p(beta), _p(res), _p(y), _p(mean), _p(rstd), rows, H, interleave_g,
@@ -364,8 +364,21 @@ def _ptr_array(ts: Sequence[torch.Tensor]):
     return arr
 
 
-def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G, Hg, prec, save=True):
-    """-> (h, coef, an, z); the last three are None when save is False (inference)."""
+def _gru_ws(B, G, Hg, dev, slot: int):
+    """-> (panel scratch pointer, status word pointer).  slot 0 is the library's classic workspace (sticky header +
+    panels); slots > 0 -- concurrent recurrences on other streams -- get their own panel scratch and share slot 0's
+    status word, so one word still guards the optimizer step."""
+    nbytes = lib.cruse_gru_ws_bytes(B, G, Hg)
+    ws = _ws("gru", nbytes, dev)
+    if slot == 0:
+        return ws.data_ptr() + 256, ws.data_ptr()
+    panels = _ws(("gru_panels", slot), nbytes - 256, dev)
+    return panels.data_ptr(), ws.data_ptr()
+
+
+def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G, Hg, prec, save=True, slot=0, xcd_rot=0):
+    """-> (h, coef, an, z); the last three are None when save is False (inference).  slot / xcd_rot: see
+    cruse_gru_seq_fwd_on (concurrent half-batch recurrences)."""
     dev = gi.device
     H = G * Hg
     h = torch.empty(B, T, H, device=dev, dtype=torch.float32)
@@ -375,20 +388,20 @@ def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G,
         an = torch.empty_like(h); z = torch.empty_like(h)
     else:
         coef = an = z = None
-    ws = _ws("gru", lib.cruse_gru_ws_bytes(B, G, Hg), dev)
+    panels, status = _gru_ws(B, G, Hg, dev, slot)
     wa, ba = _ptr_array(w_hh), _ptr_array(b_hh)
-    check(lib.cruse_gru_seq_fwd(_p(gi), ctypes.cast(wa, ctypes.c_void_p), ctypes.cast(ba, ctypes.c_void_p), _p(h),
-                                _p(coef), _p(an), _p(z), B, T, G, Hg, prec_code(prec), _p(ws), _stream()))
+    check(lib.cruse_gru_seq_fwd_on(_p(gi), ctypes.cast(wa, ctypes.c_void_p), ctypes.cast(ba, ctypes.c_void_p), _p(h),
+                                   _p(coef), _p(an), _p(z), B, T, G, Hg, prec_code(prec), panels, status, xcd_rot, _stream()))
     return h, coef, an, z
 
 
-def gru_seq_bwd(dout, w_hh: List[torch.Tensor], coef, z, B, T, G, Hg, prec):
+def gru_seq_bwd(dout, w_hh: List[torch.Tensor], coef, z, B, T, G, Hg, prec, slot=0, xcd_rot=0):
     """dout [B,T,H] -> dh [B,T,H] (total gradient reaching every h_t)."""
     dh = torch.empty_like(dout)
-    ws = _ws("gru", lib.cruse_gru_ws_bytes(B, G, Hg), dout.device)
+    panels, status = _gru_ws(B, G, Hg, dout.device, slot)
     wa = _ptr_array(w_hh)
-    check(lib.cruse_gru_seq_bwd(_p(dout), ctypes.cast(wa, ctypes.c_void_p), _p(coef), _p(z), _p(dh), B, T, G, Hg,
-                                prec_code(prec), _p(ws), _stream()))
+    check(lib.cruse_gru_seq_bwd_on(_p(dout), ctypes.cast(wa, ctypes.c_void_p), _p(coef), _p(z), _p(dh), B, T, G, Hg,
+                                   prec_code(prec), panels, status, xcd_rot, _stream()))
     return dh
 
 

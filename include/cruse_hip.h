@@ -228,6 +228,18 @@ int cruse_gru_seq_fwd(const float* gi, const float* const* w_hh, const float* co
  * dh_s = dout_s + z_{s+1}*dh_{s+1} + (dh_{s+1}*coef_{s+1}) W_hh. */
 int cruse_gru_seq_bwd(const float* dout, const float* const* w_hh, const void* coef, const float* z,
                       float* dh, int B, int T, int G, int Hg, int prec, void* ws, void* stream);
+/* The same two launches for CONCURRENT recurrences (half batches on two streams, so that the projections / layer norms
+ * of one half run beside the recurrence of the other): the workspace is given as a per-launch panel scratch of
+ * cruse_gru_ws_bytes(B,G,Hg) - 256 bytes (zeroed here) plus a caller-owned sticky status word that several launches may
+ * share, and chain c of the launch runs on XCD (c + xcd_rot) % 8 instead of c % 8.  A recurrence workgroup owns its CU;
+ * two launches of <= 4 chains with xcd_rot 0 and 4 occupy disjoint XCDs and are co-resident, with the same xcd_rot they
+ * would queue for the same CUs.  cruse_gru_seq_fwd/bwd(ws) == _on(ws + 256, (unsigned*)ws, 0). */
+int cruse_gru_seq_fwd_on(const float* gi, const float* const* w_hh, const float* const* b_hh,
+                         float* h, void* coef, float* an, float* z,
+                         int B, int T, int G, int Hg, int prec, void* panels, unsigned* status, int xcd_rot, void* stream);
+int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh, const void* coef, const float* z,
+                         float* dh, int B, int T, int G, int Hg, int prec, void* panels, unsigned* status, int xcd_rot,
+                         void* stream);
 /* dgi = dh*(c_r,c_z,a_n) (gradient wrt gi), dgh = dh*(c_r,c_z,c_n) (gradient wrt W_hh h + b_hh), both
  * [rows,G,3*Hg]; dW_ih, dW_hh, dX and the bias gradients follow from cruse_gemm / cruse_col_sum. */
 int cruse_gru_gate_grads(const float* dh, const void* coef, const float* an, float* dgi, float* dgh,

@@ -237,3 +237,43 @@ def test_inferencer_matches_oracle_waveform():
     assert res[0][0] == "clip0" and 0 < res[0][1] < 10.0
     w = Inferencer.to_int16(ref.squeeze(0).numpy())
     assert w.dtype == np.int16 and abs(int(np.abs(w).max()) - int(0.8 * 32767)) <= 1
+
+
+@pytest.mark.parametrize("grp,prec", [(1, "bf16"), (4, "bf16"), (1, "f32"), (2, "bf16x3")])
+def test_ggru_half_batch_pipelines_match_single_stream(grp, prec):
+    """ggru_forward / ggru_backward cut a batch of 16k clips into two half-batch pipelines on two streams (recurrences on
+    disjoint XCDs, cruse_gru_seq_fwd_on): same output as the single-stream form (the clips are independent), same
+    parameter gradients up to the summation order of the split-K weight-gradient GEMMs."""
+    from cruse_amd.model import cruse_net as M
+    from cruse_amd import ops
+    _, m = _oracle_and_product(grp, prec=prec, cls="GGRU")
+    P = {n: p.detach() for n, p in m.named_parameters()}
+    gen = torch.Generator().manual_seed(5)
+    B, T, H = 16, 21, 640
+    x = torch.randn(B, T, H, generator=gen).cuda()
+    res = torch.randn(B, T, H, generator=gen).cuda()
+    dout = torch.randn(B, T, H, generator=gen).cuda()
+    base = torch.randn(B, T, H, generator=gen).cuda()
+    got = {}
+    saved = M.PIPES.n
+    try:
+        for n in (1, 2):
+            M.PIPES.n = n
+            assert M.PIPES.count(B, grp, H // grp) == n
+            G = {k: torch.zeros_like(v) for k, v in P.items()}
+            out, ctx = M.ggru_forward(x, P, "", grp, prec, residual=res)
+            assert ("pipes" in ctx) == (n == 2)
+            dx0 = M.ggru_backward(ctx, dout, P, G)
+            G2 = {k: torch.zeros_like(v) for k, v in P.items()}
+            out2, ctx2 = M.ggru_forward(x, P, "", grp, prec, residual=res)
+            dx1 = M.ggru_backward(ctx2, dout, P, G2, dx_init=base.clone())       # accumulate form (the U-Net's skip path)
+            torch.cuda.synchronize()
+            got[n] = (out, dx0, dx1, G)
+            ops.check_gru_status()
+    finally:
+        M.PIPES.n = saved
+    assert torch.equal(got[1][0], got[2][0])
+    assert rel_l2(got[2][1], got[1][1]) < 1e-6 and rel_l2(got[2][2], got[1][2]) < 1e-6
+    assert rel_l2(got[1][2] - base, got[1][1]) < 1e-5
+    for k in P:
+        assert rel_l2(got[2][3][k], got[1][3][k]) < (2e-3 if prec == "bf16" else 1e-5), k
