@@ -35,7 +35,7 @@ SIGNATURES = {
     "cruse_channel_sum": ("pqiipp", "i"),
     "cruse_col_sum": ("pqiipp", "i"),
     "cruse_bn_stats": ("pqiipip", "i"),
-    "cruse_bn_finalize_act_fwd": ("ppqffppppppppqiiip", "i"),
+    "cruse_bn_finalize_act_fwd": ("ppiqffppppppppqiiip", "i"),
     "cruse_bn_finalize": ("pqiffppppp", "i"),
     "cruse_bn_eval_stats": ("ppifppp", "i"),
     "cruse_bn_act_fwd": ("pppppppqiiip", "i"),

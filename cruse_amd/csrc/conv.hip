@@ -156,7 +156,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv_gather_kernel(ConvArgs a) {
         __syncthreads();
         if (tid < 2 * a.Cout) {
             const int which = tid / a.Cout, co = tid - which * a.Cout;
-            atomicAdd(a.sums + which * a.Cout + co, s_stat[which][co]);
+            atomicAdd(a.sums + (size_t)(blockIdx.x % CRUSE_BN_STAT_REPLICAS) * 2 * a.Cout + which * a.Cout + co, s_stat[which][co]);
         }
     }
 }
@@ -488,7 +488,7 @@ int conv_scatter2_impl(const float* g, const float* w, const float* bias, float*
 
 int prep_sums(double* sums, int Cout, int zeroed, void* stream, const char* who) {
     CRUSE_REQUIRE(sums != nullptr, CRUSE_E_SHAPE, "%s: sums is NULL", who);
-    if (!zeroed) return cruse_zero_async(sums, 2 * (size_t)Cout * sizeof(double), (hipStream_t)stream, who);
+    if (!zeroed) return cruse_zero_async(sums, 2 * (size_t)Cout * CRUSE_BN_STAT_REPLICAS * sizeof(double), (hipStream_t)stream, who);
     return CRUSE_OK;
 }
 

@@ -33,7 +33,7 @@ struct CMArgs {
     int nrows;                                   // staged frames = TFM + halo
     long long sco, sci;                          // weight strides of co and ci (tap index is fastest, 3*KT long)
     int act, accum;
-    double* sums;                                // BatchNorm batch sums of y ([2][Cout]: sum, sum of squares) or null
+    double* sums;                                // BatchNorm batch sums of y ([replica][2][Cout]: sum, sum of squares) or null
     TapClass cls[2];
 };
 
@@ -83,8 +83,10 @@ __device__ __forceinline__ Frag<PREC> get_frag(const typename OpStore<PREC>::ele
 // STATS: the epilogue also accumulates the per-channel sum / sum of squares of the values it stores (the
 // batch statistics of the BatchNorm2d that follows every encoder / decoder conv, cruse_net.py:139,150) --
 // per lane over its tiles in f32 (<= a few hundred values), then 16 lanes -> 4 waves -> one f64 atomic per
-// channel and workgroup.  This replaces a separate pass over y (65 MB, ~28 us, on the serial chain).
-template <int PREC, int MT, bool STATS>
+// channel and workgroup, into replica (block id mod CRUSE_BN_STAT_REPLICAS) of the sums.  This replaces a separate pass over y (65 MB, ~28 us, on the serial chain).
+// NV: float4 per thread of the staged tile (the next tile's prefetch lives in registers across the whole N-tile
+// loop: 6 instead of 8 is what keeps the MT = 2 / 4 statistics variants at 4 / 3 waves per SIMD).
+template <int PREC, int MT, bool STATS, int NV>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
     typedef typename OpStore<PREC>::elem elem;
     constexpr int NPL = OpStore<PREC>::NPL;
@@ -97,6 +99,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
     elem* wl = reinterpret_cast<elem*>(smem_raw);          // [NPL][nfrag][64 lanes][8]  (pre-converted once)
     float* xl = reinterpret_cast<float*>(wl + NPL * wplane);   // [nrows][Cin][Fin]: RAW copy of the frame rows
     __shared__ int2 s_tap2[2][MAXTAP];
+    __shared__ float s_bias[MT * 16];
 
     const int ntile = (a.T + TFM - 1) / TFM;
 
@@ -104,6 +107,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
         const int c = tid / MAXTAP, i = tid % MAXTAP;
         s_tap2[c][i] = make_int2(a.cls[c].dt[i] * a.Cin * a.Fin + a.cls[c].df[i], a.cls[c].df[i]);
     }
+    // per-channel biases in LDS (read back per N-tile epilogue: a global load inside the N-tile loop forces an in-order
+    // vmcnt wait on every older request -- the next tile's prefetch and the previous N-tile's stores -- ~2 us per N-tile;
+    // holding them in registers instead costs 4 x MT VGPRs across the whole kernel)
+    if (tid < MT * 16) s_bias[tid] = (a.bias && tid < a.Cout) ? a.bias[tid] : 0.f;
     const int ntaps0 = a.cls[0].ntaps, ntaps1 = a.cls[1].ntaps, par0 = a.cls[0].par, par1 = a.cls[1].par;
     // weight fragments: frag (c, mt, ks), lane l, element e -> W[co = mt*16 + (l&15)][k = ks*32 + (l>>4)*8 + e].
     // One (fragment, lane) pair per work item: the index arithmetic is done once per 8 elements and the 8 loads
@@ -136,17 +143,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
     // version transposed to channel-fastest rows while storing: with 32..80-byte pitches those 2-byte stores
     // were 8..16-way bank conflicted and cost ~10 us per 8-frame tile.)  The MFMA B fragment -- 8 consecutive
     // ci of one tap at one position -- is gathered with 8 scalar ds_reads (lanes differ in f: conflict-light).
-    // per-lane output channels are tile-invariant: fetch their biases ONCE.  (A global load inside the N-tile
-    // loop forces an in-order vmcnt wait on every older request -- the next tile's prefetch and the previous
-    // N-tile's stores -- and cost ~2 us per N-tile.)
-    float biasr[MT][4];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-            const int co = mt * 16 + (lane >> 4) * 4 + r4;
-            biasr[mt][r4] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
-        }
     float s1[STATS ? MT : 1][4], s2[STATS ? MT : 1][4];
     if constexpr (STATS) {
 #pragma unroll
@@ -154,13 +150,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) { s1[mt][r4] = 0.f; s2[mt][r4] = 0.f; }
     }
-    float4 pre[MAXV];
+    float4 pre[NV];
     auto prefetch = [&](int tile) {
         const int b = tile / ntile;
         const int t0 = (tile - b * ntile) * TFM;
         const float* src = a.x + ((long long)b * a.T + (t0 - a.halo_lo)) * rowlen;
 #pragma unroll
-        for (int q = 0; q < MAXV; ++q) {
+        for (int q = 0; q < NV; ++q) {
             const int i = tid + 256 * q;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < nvec) {
@@ -177,7 +173,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
         const int t0 = (tile - b * ntile) * TFM;
         __syncthreads();                                   // previous tile's reads of xl are done
 #pragma unroll
-        for (int q = 0; q < MAXV; ++q) {
+        for (int q = 0; q < NV; ++q) {
             const int i = tid + 256 * q;
             if (i < nvec) *reinterpret_cast<float4*>(xl + i * 4) = pre[q];
         }
@@ -229,12 +225,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
                 float* yb = a.y + (((long long)b * a.T + t) * a.Cout + (lane >> 4) * 4) * a.Fout + fo;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
+                    const float4 bq = *reinterpret_cast<const float4*>(&s_bias[mt * 16 + (lane >> 4) * 4]);
+                    const float bqv[4] = {bq.x, bq.y, bq.z, bq.w};
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) {
                         const int co = mt * 16 + (lane >> 4) * 4 + r4;
                         if (co < a.Cout) {
                             float* yp = yb + (mt * 16 + r4) * a.Fout;
-                            float v = acc[mt][r4] + biasr[mt][r4];
+                            float v = acc[mt][r4] + bqv[r4];
                             if (a.accum) v += *yp;
                             else if (a.act == 1) v = sigmoid_acc(v);
                             *yp = v;
@@ -264,7 +262,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
             const int which = tid / (MT * 16), co = tid - which * (MT * 16);
             if (co < a.Cout) {
                 const float u = (s_red[0][which][co] + s_red[1][which][co]) + (s_red[2][which][co] + s_red[3][which][co]);
-                atomicAdd(a.sums + which * a.Cout + co, (double)u);
+                atomicAdd(a.sums + (size_t)(blockIdx.x % CRUSE_BN_STAT_REPLICAS) * 2 * a.Cout + which * a.Cout + co, (double)u);
             }
         }
     }
@@ -273,11 +271,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
 template <int PREC>
 int launch_mt(const CMArgs& a, int grid, size_t lds, hipStream_t s) {
     const int mt = (a.Cout + 15) / 16;
+    const int nv = (a.nrows * a.Cin * a.Fin / 4 + 255) / 256;          // float4 per thread of one staged tile
     int rc;
+#define CM_LAUNCH2(MTV, STV, NVV)                                                                          \
+    do {                                                                                                   \
+        if ((rc = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(conv_mfma_kernel<PREC, MTV, STV, NVV>), lds, "conv_mfma"))) return rc; \
+        hipLaunchKernelGGL((conv_mfma_kernel<PREC, MTV, STV, NVV>), dim3(grid), dim3(256), lds, s, a);     \
+    } while (0)
 #define CM_LAUNCH1(MTV, STV)                                                                               \
     do {                                                                                                   \
-        if ((rc = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(conv_mfma_kernel<PREC, MTV, STV>), lds, "conv_mfma"))) return rc; \
-        hipLaunchKernelGGL((conv_mfma_kernel<PREC, MTV, STV>), dim3(grid), dim3(256), lds, s, a);          \
+        if (nv <= 6) CM_LAUNCH2(MTV, STV, 6);                                                              \
+        else CM_LAUNCH2(MTV, STV, MAXV);                                                                   \
     } while (0)
 #define CM_LAUNCH(MTV)                                                                                     \
     do {                                                                                                   \
@@ -289,6 +293,7 @@ int launch_mt(const CMArgs& a, int grid, size_t lds, hipStream_t s) {
     else CM_LAUNCH(4);
 #undef CM_LAUNCH
 #undef CM_LAUNCH1
+#undef CM_LAUNCH2
     return CRUSE_OK;
 }
 

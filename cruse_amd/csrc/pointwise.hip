@@ -152,15 +152,17 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* y, const f
 
 // bn_finalize + bn_act_fwd in ONE launch: every block derives mean / rstd of the (<= 256) channels from the f64 batch sums
 // itself; block 0 also publishes them (the backward pass reads them) and updates the running statistics.
-__global__ __launch_bounds__(256) void bn_fin_act_fwd_kernel(const float* y, const double* sums, double inv_count, double unb,
+__global__ __launch_bounds__(256) void bn_fin_act_fwd_kernel(const float* y, const double* sums, int nrep, double inv_count, double unb,
                                                              float eps, float momentum, const float* gamma,
                                                              const float* beta, const float* skip, float* out, float* mean_o,
                                                              float* rstd_o, float* rmean, float* rvar, long long rows, int C,
                                                              int F, int relu) {
     extern __shared__ float tab[];  // [4][C]
     for (int c = threadIdx.x; c < C; c += 256) {
-        const double m = sums[c] * inv_count;
-        double var = sums[C + c] * inv_count - m * m;
+        double t1 = 0.0, t2 = 0.0;
+        for (int r = 0; r < nrep; ++r) { t1 += sums[(long long)r * 2 * C + c]; t2 += sums[(long long)r * 2 * C + C + c]; }
+        const double m = t1 * inv_count;
+        double var = t2 * inv_count - m * m;
         if (var < 0.0) var = 0.0;
         const float mf = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
         tab[c] = mf; tab[C + c] = rs; tab[2 * C + c] = gamma[c]; tab[3 * C + c] = beta[c];
@@ -723,16 +725,16 @@ extern "C" int cruse_bn_act_fwd(const float* y, const float* mean, const float* 
     return CRUSE_OK;
 }
 
-extern "C" int cruse_bn_finalize_act_fwd(const float* y, const double* sums, long long count, float eps, float momentum,
+extern "C" int cruse_bn_finalize_act_fwd(const float* y, const double* sums, int sum_replicas, long long count, float eps, float momentum,
                                          const float* gamma, const float* beta, const float* skip, float* out,
                                          float* mean, float* rstd, float* running_mean, float* running_var,
                                          long long rows, int C, int F, int relu, void* stream) {
-    CRUSE_REQUIRE(rows > 0 && C > 0 && C <= 256 && F > 0 && count > 0, CRUSE_E_SHAPE, "bn_finalize_act_fwd: bad shape");
+    CRUSE_REQUIRE(rows > 0 && C > 0 && C <= 256 && F > 0 && count > 0 && sum_replicas >= 1, CRUSE_E_SHAPE, "bn_finalize_act_fwd: bad shape");
     CRUSE_REQUIRE((C * F) % 4 == 0, CRUSE_E_ALIGN, "bn_finalize_act_fwd: C*F=%d must be a multiple of 4", C * F);
     CRUSE_REQUIRE((running_mean == nullptr) == (running_var == nullptr) && mean && rstd, CRUSE_E_SHAPE, "bn_finalize_act_fwd: statistics");
     const double unb = count > 1 ? (double)count / (double)(count - 1) : 1.0;
     hipLaunchKernelGGL(bn_fin_act_fwd_kernel, dim3(grid_for(rows * C * F / 4, 1024)), dim3(256), 4 * C * sizeof(float), ST(stream),
-                       y, sums, 1.0 / (double)count, unb, eps, momentum, gamma, beta, skip, out, mean, rstd, running_mean,
+                       y, sums, sum_replicas, 1.0 / (double)count, unb, eps, momentum, gamma, beta, skip, out, mean, rstd, running_mean,
                        running_var, rows, C, F, relu);
     CRUSE_LAUNCH_CHECK("bn_finalize_act_fwd");
     return CRUSE_OK;

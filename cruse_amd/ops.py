@@ -117,7 +117,7 @@ def conv_scatter2(g, w, bias, B, T, Cs, Fg, Cout, KT, pad, act=0, out=None, accu
 def conv_gather_bnstats(x, w, bias, B, T, Cin, Fin, Cout, Fout, KT, S, pad, prec=None):
     """conv_gather + the BatchNorm batch sums of its output, accumulated by the conv's epilogue -> (y, sums)."""
     out = torch.empty(B, T, Cout, Fout, device=x.device, dtype=torch.float32)
-    sums, z = ARENA.take(2 * Cout, x.device)
+    sums, z = ARENA.take(2 * Cout * BN_STAT_REPLICAS, x.device)
     check(lib.cruse_conv_gather_bnstats(_p(x), _p(w), _p(bias), _p(out), B, T, Cin, Fin, Cout, Fout, KT, S, pad,
                                         conv_prec(prec), _p(sums), z, _stream()))
     return out, sums
@@ -126,7 +126,7 @@ def conv_gather_bnstats(x, w, bias, B, T, Cin, Fin, Cout, Fout, KT, S, pad, prec
 def conv_scatter2_bnstats(g, w, bias, B, T, Cs, Fg, Cout, KT, pad, prec=None):
     Fout = 2 * Fg
     out = torch.empty(B, T, Cout, Fout, device=g.device, dtype=torch.float32)
-    sums, z = ARENA.take(2 * Cout, g.device)
+    sums, z = ARENA.take(2 * Cout * BN_STAT_REPLICAS, g.device)
     check(lib.cruse_conv_scatter2_bnstats(_p(g), _p(w), _p(bias), _p(out), B, T, Cs, Fg, Cout, Fout, KT, pad,
                                           conv_prec(prec), _p(sums), z, _stream()))
     return out, sums
@@ -222,13 +222,19 @@ def bn_stats(y, rows, C, F):
     return sums
 
 
+BN_STAT_REPLICAS = 16      # CRUSE_BN_STAT_REPLICAS (include/cruse_hip.h): layout of the sums of conv_*_bnstats
+
+
 def bn_finalize_act_fwd(y, sums, count, eps, momentum, gamma, beta, skip, rows, C, F, relu=True, running_mean=None,
                         running_var=None):
-    """bn_finalize + bn_act_fwd in one launch -> (out, mean, rstd)."""
+    """bn_finalize + bn_act_fwd in one launch -> (out, mean, rstd).  sums: [2*C] (bn_stats) or [replicas, 2*C]
+    (conv_*_bnstats); the statistic is the sum over the replicas."""
+    if sums.numel() % (2 * C) != 0:
+        raise RuntimeError(f"bn_finalize_act_fwd: {sums.numel()} sums for {C} channels")
     out = torch.empty_like(y)
     mean = torch.empty(C, device=y.device, dtype=torch.float32)
     rstd = torch.empty(C, device=y.device, dtype=torch.float32)
-    check(lib.cruse_bn_finalize_act_fwd(_p(y), _p(sums), count, eps, momentum, _p(gamma), _p(beta), _p(skip), _p(out), _p(mean),
+    check(lib.cruse_bn_finalize_act_fwd(_p(y), _p(sums), sums.numel() // (2 * C), count, eps, momentum, _p(gamma), _p(beta), _p(skip), _p(out), _p(mean),
                                         _p(rstd), _p(running_mean), _p(running_var), rows, C, F, 1 if relu else 0, _stream()))
     return out, mean, rstd
 

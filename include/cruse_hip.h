@@ -93,10 +93,14 @@ int cruse_conv_scatter2(const float* g, const float* w, const float* bias, float
                         int KT, int pad, int act, int accum, int prec, void* stream);
 
 /* Both forms with the batch statistics of the BatchNorm2d that follows every encoder / decoder conv
- * (cruse_net.py:139,150) accumulated by the conv's own epilogue: y = conv (no activation, no accumulate),
- * sums[0..Cout) += sum_{b,t,f} y, sums[Cout..2Cout) += sum y^2 -- what cruse_bn_stats(y) would add, without the
- * extra pass over y.  zeroed != 0: the caller has cleared sums (else cleared here, on `stream`).  Shapes the MFMA
- * kernel does not take (Cin == 1) run the VALU conv followed by the cruse_bn_stats kernel. */
+ * (cruse_net.py:139,150) accumulated by the conv's own epilogue: y = conv (no activation, no accumulate), and what
+ * cruse_bn_stats(y) would add -- sum_{b,t,f} y and sum y^2 per channel -- without the extra pass over y.
+ * sums is [CRUSE_BN_STAT_REPLICAS][2*Cout] doubles: a workgroup adds its partial sums to replica (block id mod
+ * replicas), so the f64 atomics of ~1000 workgroups do not queue on 2*Cout addresses (that queue cost 15-30 us per
+ * layer); the statistic is the sum over the replicas -- cruse_bn_finalize_act_fwd(sum_replicas) folds them.  The
+ * partial sums are f32-valued, so the f64 additions are exact and the result does not depend on their order.
+ * zeroed != 0: the caller has cleared sums (else cleared here, on `stream`). */
+#define CRUSE_BN_STAT_REPLICAS 16
 int cruse_conv_gather_bnstats(const float* x, const float* w, const float* bias, float* y,
                               int B, int T, int Cin, int Fin, int Cout, int Fout,
                               int KT, int S, int pad, int prec, double* sums, int zeroed, void* stream);
@@ -135,8 +139,10 @@ int cruse_bn_act_fwd(const float* y, const float* mean, const float* rstd, const
                      const float* beta, const float* skip, float* out,
                      long long rows, int C, int F, int relu, void* stream);
 /* cruse_bn_finalize + cruse_bn_act_fwd as one launch (training): mean / rstd come from the batch sums inside the kernel,
- * are also written out (the backward pass needs them) and the running statistics are updated. */
-int cruse_bn_finalize_act_fwd(const float* y, const double* sums, long long count, float eps, float momentum,
+ * are also written out (the backward pass needs them) and the running statistics are updated.  sums is
+ * [sum_replicas][2*C] and the statistic the sum over the replicas: 1 after cruse_bn_stats, CRUSE_BN_STAT_REPLICAS after
+ * cruse_conv_*_bnstats. */
+int cruse_bn_finalize_act_fwd(const float* y, const double* sums, int sum_replicas, long long count, float eps, float momentum,
                               const float* gamma, const float* beta, const float* skip, float* out,
                               float* mean, float* rstd, float* running_mean, float* running_var,
                               long long rows, int C, int F, int relu, void* stream);

@@ -202,7 +202,8 @@ def test_conv_bnstats_epilogue(ops, lvl, prec):
     y, sums = ops.conv_gather_bnstats(x, w, b, B, T, Cin, Fin, Cout, Fout, KT=2, S=2, pad=1, prec=prec)
     assert torch.equal(y, y0)
     ref = torch.cat([y.double().sum(dim=(0, 1, 3)), (y.double() ** 2).sum(dim=(0, 1, 3))])
-    assert rel_l2(sums, ref) < 1e-6
+    assert sums.numel() == ops.BN_STAT_REPLICAS * 2 * Cout           # [replica][2][Cout]: the statistic is the sum over replicas
+    assert rel_l2(sums.view(-1, 2 * Cout).sum(0), ref) < 1e-6
     # decoder form: convT k maps ch[k] x F_k -> ch[k-1] x 2 F_k
     u = (torch.randn(B, T, Cout, Fout, generator=gen) - 0.2).cuda()
     wt = (torch.randn(Cout, Cin, 1, 3, generator=gen) * 0.2).cuda()
@@ -211,11 +212,16 @@ def test_conv_bnstats_epilogue(ops, lvl, prec):
     v, sums = ops.conv_scatter2_bnstats(u, wt, bt, B, T, Cout, Fout, Cin, KT=1, pad=0, prec=prec)
     assert torch.equal(v, v0)
     ref = torch.cat([v.double().sum(dim=(0, 1, 3)), (v.double() ** 2).sum(dim=(0, 1, 3))])
-    assert rel_l2(sums, ref) < 1e-6
+    assert rel_l2(sums.view(-1, 2 * Cin).sum(0), ref) < 1e-6
+    # the consumer folds the replicas: same mean / rstd as from a separate bn_stats pass
+    gam = torch.ones(Cin).cuda(); bet = torch.zeros(Cin).cuda()
+    _, m_a, r_a = ops.bn_finalize_act_fwd(v, sums, B * T * Fin, 1e-5, 0.1, gam, bet, None, B * T, Cin, Fin)
+    _, m_b, r_b = ops.bn_finalize_act_fwd(v, ops.bn_stats(v, B * T, Cin, Fin), B * T * Fin, 1e-5, 0.1, gam, bet, None, B * T, Cin, Fin)
+    assert rel_l2(m_a, m_b) < 1e-6 and rel_l2(r_a, r_b) < 1e-6
     with ops.ARENA.step(x.device):      # pre-zeroed arena slices, as the training step uses them
         _, s1 = ops.conv_gather_bnstats(x, w, b, B, T, Cin, Fin, Cout, Fout, KT=2, S=2, pad=1, prec=prec)
         _, s2 = ops.conv_scatter2_bnstats(u, wt, bt, B, T, Cout, Fout, Cin, KT=1, pad=0, prec=prec)
-        assert rel_l2(s2, ref) < 1e-6 and s1.data_ptr() != s2.data_ptr()
+        assert rel_l2(s2.view(-1, 2 * Cin).sum(0), ref) < 1e-6 and s1.data_ptr() != s2.data_ptr()
 
 
 def test_conv_shape_errors(ops):
