@@ -47,6 +47,7 @@ class _SideStream:
         self.rr = 0
         self.used = []                 # side streams forked from the main stream since the last join()
         self.last = None               # the stream the most recent leaf went to
+        self.multi_stream = False      # leaves may be deferred on one stream and released from another (_Pipes)
 
     def set_map(self, m: str, force: bool = False) -> None:
         """lane -> side stream assignment.  Measured on the bench step: replayed from a HIP graph the three lanes
@@ -88,10 +89,13 @@ class _SideStream:
         if not (self.enabled and (self.defer_mask & kind)):
             self.run(fn, *tensors, lane=lane)
             return
-        # the leaf's inputs are complete on the stream that defers it -- which need not be the stream that later releases
-        # it (half-batch pipelines, ggru_forward): remember that point
-        dep = torch.cuda.Event()
-        dep.record(torch.cuda.current_stream())
+        # the leaf's inputs are complete on the stream that defers it -- which, with half-batch pipelines (ggru_forward),
+        # need not be the stream that later releases it: remember that point.  (Only then: an event record is a barrier
+        # packet on the recording stream, ~6 us of idle queue per record.)
+        dep = None
+        if self.multi_stream:
+            dep = torch.cuda.Event()
+            dep.record(torch.cuda.current_stream())
         self.deferred.append((fn, lane, dep))
         self.keep.extend(tensors)
 
@@ -107,7 +111,8 @@ class _SideStream:
         for fn, lane, dep in self.deferred:
             side = self._next(lane)
             side.wait_event(ev)
-            side.wait_event(dep)
+            if dep is not None:
+                side.wait_event(dep)
             with torch.cuda.stream(side):
                 fn()
         self.deferred.clear()
@@ -238,19 +243,22 @@ def _splitk(M: int, N: int, K: int) -> int:
 # GGRU functional core on [B,T,H] rows
 # ======================================================================================
 def ggru_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], prefix: str, groups: int, prec,
-                 residual: Optional[torch.Tensor] = None, save: bool = True):
+                 residual: Optional[torch.Tensor] = None, save: bool = True, residual_ready=None):
     """x [B,T,H] -> (ln2(gru2(ln1(interleave(gru1(x))))) [+ residual], ctx).  cruse_net.py:37-55.
     With CRUSE_GRU_PIPES=2, batches of 16k clips run as half-batch pipelines on two streams (_Pipes); ctx then holds one
     context per slice."""
     B, T, H = x.shape
     n = PIPES.count(B, groups, H // groups)
     if n == 1:
-        return _ggru_forward_one(x, P, prefix, groups, prec, residual, save)
+        return _ggru_forward_one(x, P, prefix, groups, prec, residual, save, residual_ready=residual_ready)
+    if residual_ready is not None:
+        residual_ready()
     Bh = B // n
     out = torch.empty_like(x)
     main = torch.cuda.current_stream()
     fork = torch.cuda.Event()
     fork.record(main)
+    SIDE.multi_stream = True
     ctxs, gate_prev = [], None
     for k in range(n):
         sl = slice(k * Bh, (k + 1) * Bh)
@@ -270,7 +278,10 @@ def ggru_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], prefix: str, group
     return out, dict(B=B, T=T, H=H, g=groups, prec=prec, prefix=prefix, has_res=residual is not None, pipes=ctxs)
 
 
-def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=None, slot=0, xcd_rot=0, pre_done=None):
+def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=None, slot=0, xcd_rot=0, pre_done=None,
+                      residual_ready=None):
+    """residual_ready(): called right before the residual is read (the last layer norm) -- the caller may still be
+    producing it on a side stream while the recurrences run."""
     B, T, H = x.shape
     g = groups
     Hg = H // g
@@ -318,6 +329,8 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
     h1, c1, a1, z1 = layer(x, "gru_list1")
     l1, m1, s1 = ops.ln_fwd(h1, P[prefix + "ln1.weight"], P[prefix + "ln1.bias"], None, rows, H, g, save=save)
     h2, c2, a2, z2 = layer(l1, "gru_list2")
+    if residual_ready is not None:
+        residual_ready()
     out, m2, s2 = ops.ln_fwd(h2, P[prefix + "ln2.weight"], P[prefix + "ln2.bias"], residual, rows, H, 1, save=save, out=out)
     if save:
         ctx.update(h1=h1, c1=c1, a1=a1, z1=z1, l1=l1, m1=m1, s1=s1,
@@ -342,6 +355,7 @@ def ggru_backward(ctx, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[s
         main = torch.cuda.current_stream()
         fork = torch.cuda.Event()
         fork.record(main)
+        SIDE.multi_stream = True
         gate_prev = None
         for k, c in enumerate(ctx["pipes"]):
             sl = slice(k * Bh, (k + 1) * Bh)
@@ -544,14 +558,13 @@ def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, tor
         def skip_conv(e=e, s=s, k=k):
             ops.conv_gather(e, P[f"skip_connect_{k}.weight"], None, B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1,
                             out=s, prec=prec)
-        if k < L:
-            SIDE.defer(skip_conv, e, s, kind=1, lane=1)  # needed by the decoder only: issued with the GRU forward
-        else:
-            skip_conv()
+        # needed by the decoder only (level L: by the layer norm that closes the GGRU block): issued with the GRU forward
+        SIDE.defer(skip_conv, e, s, kind=1, lane=1)
         ys.append(y); es.append(e); ss.append(s); stats.append((mean, rstd))
         cur = e
     H = ch[L] * Fk[L]
-    u, gctx = ggru_forward(cur.view(B, T, H), P, "gru.", groups, prec, residual=ss[L].view(B, T, H), save=save)
+    u, gctx = ggru_forward(cur.view(B, T, H), P, "gru.", groups, prec, residual=ss[L].view(B, T, H), save=save,
+                           residual_ready=SIDE.join)
     u = u.view(B, T, ch[L], Fk[L])
     SIDE.join()
     us, vs, dstats = {L: u}, {}, {}
