@@ -417,12 +417,17 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
         dh = run_bwd(dout_h, w_hh, coef, z)
         dgi, dgT, ldT = ops.gru_gate_grads_bf16(dh, coef, an, rows, g, Hg, [G[nm + "bias_ih_l0"] for nm in names],
                                                 [G[nm + "bias_hh_l0"] for nm in names])
-        inpT = torch.empty(ldT // 64, H, 64, device=dh.device, dtype=torch.bfloat16)
-        hpT = torch.empty(ldT // 64, H, 64, device=dh.device, dtype=torch.bfloat16)
+        early = early_T.pop(lname, None)         # layer 1: transposed by a leaf of the FIRST recurrence (see below)
+        if early is not None:
+            inpT, hpT = early
+        else:
+            inpT = torch.empty(ldT // 64, H, 64, device=dh.device, dtype=torch.bfloat16)
+            hpT = torch.empty(ldT // 64, H, 64, device=dh.device, dtype=torch.bfloat16)
 
         def weight_grads():                      # leaves: overlap with the next recurrence / encoder backward
-            ops.transpose_bf16(inp, rows, H, out=inpT)
-            ops.transpose_bf16(h, rows, H, shift_T=T, out=hpT)
+            if early is None:
+                ops.transpose_bf16(inp, rows, H, out=inpT)
+                ops.transpose_bf16(h, rows, H, shift_T=T, out=hpT)
             ka, kb = 4 * H * 64, H * 64          # k-tile strides of the K-tiled time-major operands (lda = ldb = 64)
             for i, nm in enumerate(names):
                 # dW_ih += (r, z, n_i)^T x ; dW_hh += (r, z)^T h_{t-1} and n_h^T h_{t-1}
@@ -483,6 +488,21 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
             SIDE.defer(weight_grads, dgi, dgh, h, inp, kind=4, lane=2)
         return dinp
 
+    # The time-major bf16 copies of layer 1's x and h_{t-1} (the K operands of its weight-gradient GEMMs) depend on the
+    # forward pass only: they are made by a leaf of the FIRST backward recurrence, whose window the side streams do not
+    # fill -- not after the second one, where the side streams' queue (layer 1's GEMMs, the encoder's weight gradients)
+    # is what the optimizer step waits for.
+    early_T = {}
+    if _bf16_gemm_path(prec, Hg) and SIDE.enabled and os.environ.get("CRUSE_EARLY_T", "1") == "1":
+        ldT1 = (rows + 63) // 64 * 64
+        x1T = torch.empty(ldT1 // 64, H, 64, device=dout.device, dtype=torch.bfloat16)
+        h1T = torch.empty(ldT1 // 64, H, 64, device=dout.device, dtype=torch.bfloat16)
+        early_T["gru_list1"] = (x1T, h1T)
+
+        def early_transposes(x1=ctx["x"], h1=ctx["h1"]):
+            ops.transpose_bf16(x1, rows, H, out=x1T)
+            ops.transpose_bf16(h1, rows, H, shift_T=T, out=h1T)
+        SIDE.defer(early_transposes, x1T, h1T, kind=4, lane=2)
     dh2 = ops.ln_bwd(dout, ctx["h2"], ctx["m2"], ctx["s2"], P[prefix + "ln2.weight"], rows, H, 1,
                      G[prefix + "ln2.weight"], G[prefix + "ln2.bias"])
     dl1 = layer_bwd(dh2, "gru_list2", ctx["l1"], ctx["h2"], ctx["c2"], ctx["a2"], ctx["z2"], True, False)
