@@ -34,7 +34,9 @@ class _SideStream:
 
     def __init__(self):
         self.enabled = os.environ.get("CRUSE_OVERLAP", "1") == "1"
-        self.defer_mask = int(os.environ.get("CRUSE_DEFER", "1"))   # 1 skip convs, 2 decoder leaves, 4 GRU weight grads
+        # leaves queued for the next recurrence launch instead of issued at once: 1 skip convs (forward), 2 decoder weight
+        # gradients, 4 GRU weight gradients, 8 skip-conv backward leaves
+        self.defer_mask = int(os.environ.get("CRUSE_DEFER", "15"))
         self.nside = max(1, int(os.environ.get("CRUSE_SIDE_STREAMS", "1")))
         # lane -> stream: leaves are tagged 0 conv weight gradients, 1 skip-conv leaves, 2 GRU dW GEMMs; CRUSE_SIDE_MAP
         # "abc" sends lane i to side stream int(abc[i]) (needs that many streams); unset: round-robin over nside streams
@@ -661,7 +663,10 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
                             w_layout=1, out=out, prec=dprec)
             ops.conv_wgrad(dsk, es[k], G[f"skip_connect_{k}.weight"], B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1,
                            prec=prec)
-        SIDE.run(leaf, ds[k], de_pre[k], lane=1)
+        # deferred to the first backward recurrence: its window has room for them (the side streams idle for ~0.5 ms
+        # of it), issuing them here costs an event record on the main stream per level and makes the decoder's
+        # BatchNorm backward share HBM with them
+        SIDE.defer(leaf, ds[k], de_pre[k], kind=8, lane=1)
     skip_leaves(1)
     # ---- decoder levels 2..L ------------------------------------------------------------
     for k in range(2, L + 1):
@@ -677,11 +682,11 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
                              prec=dprec)
         ds[k] = du
         skip_leaves(k)
-    skips_done = SIDE.mark()
     # ---- bottleneck: u_L = ggru(e_L) + skip_L --------------------------------------------
     H = ch[L] * Fk[L]
+    # de_pre[L] is written by a skip leaf: wait for the leaves issued so far right before the GGRU adds into it
     de = ggru_backward(ctx["gctx"], du.view(B, T, H), P, G, join=False, dx_init=de_pre[L].view(B, T, H),
-                       dx_ready=lambda: SIDE.wait(skips_done), defer_last=boundary is not None).view(B, T, ch[L], Fk[L])
+                       dx_ready=lambda: SIDE.wait(SIDE.mark()), defer_last=boundary is not None).view(B, T, ch[L], Fk[L])
     if boundary is not None:
         boundary(0)
     cut = max(L // 2, 1)                          # levels L..cut+1, [bucket 1 final], levels cut..1
