@@ -7,6 +7,7 @@
 // utils/utils.py:418-420 (mask application), loss_func/loss.py:121-148 (WO-MALE),
 // tools/train_stand.py:68-71 (Adam).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -469,8 +470,10 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const float* x, const f
     }
 }
 
-constexpr int LNB_NR = 1;
-__global__ __launch_bounds__(RED_THREADS) void ln_bwd_vec_kernel(const float* dy, const float* x, const float* mean,
+// NQ float4 groups per lane (H <= 256 * NQ), NR rows per wave in flight: (3, 2) for the step's H = 640 -- with the
+// generic (4, 1) a wave had one row's loads outstanding at a time and the pass ran at 3.5 TB/s
+template <int NQ, int LNB_NR>
+__global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const float* dy, const float* x, const float* mean,
                                                          const float* rstd, const float* gamma, long long rows, int H,
                                                          float* dx, float* dgamma, float* dbeta) {
     __shared__ float sdg[1024], sdb[1024];
@@ -480,15 +483,15 @@ __global__ __launch_bounds__(RED_THREADS) void ln_bwd_vec_kernel(const float* dy
     const int nw = blockDim.x >> 6;
     const long long wave = (long long)blockIdx.x * nw + (threadIdx.x >> 6);
     const long long nwave = (long long)gridDim.x * nw;
-    float4 gm[LNV_MAXQ], adg[LNV_MAXQ], adb[LNV_MAXQ];
+    float4 gm[NQ], adg[NQ], adb[NQ];
 #pragma unroll
-    for (int e = 0; e < LNV_MAXQ; ++e) {
+    for (int e = 0; e < NQ; ++e) {
         const int q = lane + 64 * e;
         gm[e] = q < nq ? reinterpret_cast<const float4*>(gamma)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
         adg[e] = make_float4(0.f, 0.f, 0.f, 0.f); adb[e] = adg[e];
     }
     for (long long r0 = wave * LNB_NR; r0 < rows; r0 += nwave * LNB_NR) {
-        float4 xh[LNB_NR][LNV_MAXQ], gd[LNB_NR][LNV_MAXQ];
+        float4 xh[LNB_NR][NQ], gd[LNB_NR][NQ];
         float s1[LNB_NR], s2[LNB_NR], rsv[LNB_NR];
 #pragma unroll
         for (int k = 0; k < LNB_NR; ++k) {
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(RED_THREADS) void ln_bwd_vec_kernel(const float* dy
             rsv[k] = rok ? rstd[r] : 0.f;
             s1[k] = 0.f; s2[k] = 0.f;
 #pragma unroll
-            for (int e = 0; e < LNV_MAXQ; ++e) {
+            for (int e = 0; e < NQ; ++e) {
                 const int q = lane + 64 * e;
                 if (q < nq && rok) {
                     const float4 d = reinterpret_cast<const float4*>(dy + r * H)[q];
@@ -523,7 +526,7 @@ __global__ __launch_bounds__(RED_THREADS) void ln_bwd_vec_kernel(const float* dy
             const long long r = r0 + k;
             if (r >= rows) continue;
 #pragma unroll
-            for (int e = 0; e < LNV_MAXQ; ++e) {
+            for (int e = 0; e < NQ; ++e) {
                 const int q = lane + 64 * e;
                 if (q < nq) {
                     float4 o;
@@ -537,7 +540,7 @@ __global__ __launch_bounds__(RED_THREADS) void ln_bwd_vec_kernel(const float* dy
         }
     }
 #pragma unroll
-    for (int e = 0; e < LNV_MAXQ; ++e) {
+    for (int e = 0; e < NQ; ++e) {
         const int q = lane + 64 * e;
         if (q < nq) {
             atomicAdd(&sdg[q * 4], adg[e].x); atomicAdd(&sdg[q * 4 + 1], adg[e].y);
@@ -782,6 +785,8 @@ extern "C" int cruse_ln_fwd(const float* x, const float* gamma, const float* bet
     return CRUSE_OK;
 }
 
+static int lnb_grid() { const char* e = getenv("CRUSE_LNB_GRID"); return e ? atoi(e) : 512; }
+
 extern "C" int cruse_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                             const float* gamma, long long rows, int H, int interleave_g,
                             float* dx, float* dgamma, float* dbeta, void* stream) {
@@ -789,8 +794,11 @@ extern "C" int cruse_ln_bwd(const float* dy, const float* x, const float* mean, 
     CRUSE_REQUIRE(interleave_g >= 1 && H % interleave_g == 0, CRUSE_E_SHAPE, "ln_bwd: groups=%d must divide H=%d", interleave_g, H);
     const bool vec = interleave_g == 1 && H % 4 == 0 && H <= 256 * LNV_MAXQ &&
                      ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)gamma) & 15) == 0);
-    if (vec)
-        hipLaunchKernelGGL(ln_bwd_vec_kernel, dim3(grid_for(rows, 128, 256)), dim3(RED_THREADS), 0, ST(stream), dy, x, mean,
+    if (vec && H <= 768)
+        hipLaunchKernelGGL((ln_bwd_vec_kernel<3, 2>), dim3(grid_for(rows, 16, lnb_grid())), dim3(256), 0, ST(stream), dy, x, mean,
+                           rstd, gamma, rows, H, dx, dgamma, dbeta);
+    else if (vec)
+        hipLaunchKernelGGL((ln_bwd_vec_kernel<4, 1>), dim3(grid_for(rows, 16, lnb_grid())), dim3(256), 0, ST(stream), dy, x, mean,
                            rstd, gamma, rows, H, dx, dgamma, dbeta);
     else
         hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid_for(rows, 32, 1024)), dim3(256), 0, ST(stream), dy, x, mean, rstd,

@@ -53,6 +53,10 @@ def main():
     print(f"ln_fwd {t:6.1f} us ({2 * mb / t:5.2f} TB/s)")
     t = timeit(lambda: ops.ln_bwd(dy, x, mean, rstd, g, rows, H, 1, dg, db))
     print(f"ln_bwd {t:6.1f} us ({3 * mb / t:5.2f} TB/s)")
+    from cruse_amd.ops import lib, _p, _stream, check
+    dx = torch.empty_like(x)
+    t = timeit(lambda: check(lib.cruse_ln_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(g), rows, H, 1, _p(dx), None, None, _stream())))
+    print(f"ln_bwd without dgamma/dbeta {t:6.1f} us")
 
 
 if __name__ == "__main__":
