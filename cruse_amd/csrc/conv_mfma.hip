@@ -18,6 +18,11 @@
 namespace {
 
 constexpr int TFM = 8;                  // frames per workgroup tile
+// 5 wavefronts per workgroup: every U-Net level has 8 frames x F = 10 * 2^k positions = 5 * 2^k N-tiles of 16 per tile,
+// so five waves share them evenly.  (With four, the 64-channel layers -- 5 N-tiles -- left three waves idle behind the
+// tile barrier while the fourth ran its second N-tile: 62 % of the N-tile slots used, SQ_WAIT_ANY 61 % of wave time.)
+// NW is a template parameter: 5 where a tile has 5 or 10 N-tiles (the 64-channel level), 4 elsewhere (levels with 20+
+// N-tiles lose more to the larger workgroup than they gain: measured 38 -> 45 us on the 8 -> 16 layer).
 constexpr int MAXTAP = 6;
 constexpr int MAXV = 8;                 // float4 per thread of a staged tile (<= 8192 floats)
 
@@ -85,9 +90,11 @@ __device__ __forceinline__ Frag<PREC> get_frag(const typename OpStore<PREC>::ele
 // per lane over its tiles in f32 (<= a few hundred values), then 16 lanes -> 4 waves -> one f64 atomic per
 // channel and workgroup, into replica (block id mod CRUSE_BN_STAT_REPLICAS) of the sums.  This replaces a separate pass over y (65 MB, ~28 us, on the serial chain).
 // NV: float4 per thread of the staged tile (the next tile's prefetch lives in registers across the whole N-tile
-// loop: 6 instead of 8 is what keeps the MT = 2 / 4 statistics variants at 4 / 3 waves per SIMD).
-template <int PREC, int MT, bool STATS, int NV>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
+// loop: 5 (of 320 threads) instead of 8 is what keeps the MT = 2 / 4 statistics variants at 4 / 3 waves per SIMD).
+template <int PREC, int MT, bool STATS, int NV, int NW>
+// (two 5-wave workgroups per CU need 4 wave slots on some SIMD: the 5-wave variants are held to 128 registers)
+__global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMArgs a) {
+    constexpr int NTHR = NW * 64;
     typedef typename OpStore<PREC>::elem elem;
     constexpr int NPL = OpStore<PREC>::NPL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -116,7 +123,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
     // One (fragment, lane) pair per work item: the index arithmetic is done once per 8 elements and the 8 loads
     // are independent (Cin is a power of two, so tap/ci come from shifts).
     const int lg_cin = 31 - __clz(a.Cin);                  // Cin is a power of two (host-checked)
-    for (int it = tid; it < nfrag * 64; it += 256) {
+    for (int it = tid; it < nfrag * 64; it += NTHR) {
         const int l = it & 63, fr = it >> 6;
         int c = 0, rem = fr;
         if (rem >= MT * ks0) { c = 1; rem -= MT * ks0; }
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
         const float* src = a.x + ((long long)b * a.T + (t0 - a.halo_lo)) * rowlen;
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
-            const int i = tid + 256 * q;
+            const int i = tid + NTHR * q;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < nvec) {
                 const int r = (i * 4) / rowlen;
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
         __syncthreads();                                   // previous tile's reads of xl are done
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
-            const int i = tid + 256 * q;
+            const int i = tid + NTHR * q;
             if (i < nvec) *reinterpret_cast<float4*>(xl + i * 4) = pre[q];
         }
         __syncthreads();
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
         // N-tile loop, kept free of integer divisions (Cin is a power of two, positions via a float reciprocal)
         // and of global loads; one 64-bit base address per N-tile.  (Keeping several N-tiles in flight per wave
         // was measured and is slower: 78 vs 57 us on the 8->16 layer.)
-        for (int nt = wv; nt < a.nclass * ntile_c; nt += 4) {
+        for (int nt = wv; nt < a.nclass * ntile_c; nt += NW) {
             const int c = nt >= ntile_c ? 1 : 0;
             const int p = (nt - c * ntile_c) * 16 + (lane & 15);
             const int tl = (int)(((float)p + 0.5f) * inv_mpos);
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
         }
     }
     if constexpr (STATS) {
-        __shared__ float s_red[4][2][MT * 16];
+        __shared__ float s_red[NW][2][MT * 16];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -261,7 +268,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
         if (tid < 2 * MT * 16) {
             const int which = tid / (MT * 16), co = tid - which * (MT * 16);
             if (co < a.Cout) {
-                const float u = (s_red[0][which][co] + s_red[1][which][co]) + (s_red[2][which][co] + s_red[3][which][co]);
+                float u = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) u += s_red[w][which][co];
                 atomicAdd(a.sums + (size_t)(blockIdx.x % CRUSE_BN_STAT_REPLICAS) * 2 * a.Cout + which * a.Cout + co, (double)u);
             }
         }
@@ -269,18 +278,25 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(CMArgs a) {
 }
 
 template <int PREC>
-int launch_mt(const CMArgs& a, int grid, size_t lds, hipStream_t s) {
+int launch_mt(const CMArgs& a, int grid, size_t lds, int nw, hipStream_t s) {
     const int mt = (a.Cout + 15) / 16;
-    const int nv = (a.nrows * a.Cin * a.Fin / 4 + 255) / 256;          // float4 per thread of one staged tile
+    const int nthr = nw * 64;
+    const int nv = (a.nrows * a.Cin * a.Fin / 4 + nthr - 1) / nthr;    // float4 per thread of one staged tile
     int rc;
+#define CM_LAUNCH3(MTV, STV, NVV, NWV)                                                                     \
+    do {                                                                                                   \
+        if ((rc = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(conv_mfma_kernel<PREC, MTV, STV, NVV, NWV>), lds, "conv_mfma"))) return rc; \
+        hipLaunchKernelGGL((conv_mfma_kernel<PREC, MTV, STV, NVV, NWV>), dim3(grid), dim3(NWV * 64), lds, s, a); \
+    } while (0)
 #define CM_LAUNCH2(MTV, STV, NVV)                                                                          \
     do {                                                                                                   \
-        if ((rc = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(conv_mfma_kernel<PREC, MTV, STV, NVV>), lds, "conv_mfma"))) return rc; \
-        hipLaunchKernelGGL((conv_mfma_kernel<PREC, MTV, STV, NVV>), dim3(grid), dim3(256), lds, s, a);     \
+        if (nw == 5) CM_LAUNCH3(MTV, STV, NVV, 5);                                                         \
+        else CM_LAUNCH3(MTV, STV, NVV, 4);                                                                 \
     } while (0)
 #define CM_LAUNCH1(MTV, STV)                                                                               \
     do {                                                                                                   \
-        if (nv <= 6) CM_LAUNCH2(MTV, STV, 6);                                                              \
+        if (nv <= 5) CM_LAUNCH2(MTV, STV, 5);                                                              \
+        else if (nv <= 6) CM_LAUNCH2(MTV, STV, 6);                                                         \
         else CM_LAUNCH2(MTV, STV, MAXV);                                                                   \
     } while (0)
 #define CM_LAUNCH(MTV)                                                                                     \
@@ -294,6 +310,7 @@ int launch_mt(const CMArgs& a, int grid, size_t lds, hipStream_t s) {
 #undef CM_LAUNCH
 #undef CM_LAUNCH1
 #undef CM_LAUNCH2
+#undef CM_LAUNCH3
     return CRUSE_OK;
 }
 
@@ -356,9 +373,12 @@ int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float
     { const char* e = getenv("CRUSE_CM_GRID"); if (e) gmax = atoi(e); }
     const int grid = ntiles < gmax ? ntiles : gmax;
     int rc;
-    if (prec == CRUSE_PREC_F32) rc = launch_mt<CRUSE_PREC_F32>(a, grid, lds, stream);
-    else if (prec == CRUSE_PREC_BF16) rc = launch_mt<CRUSE_PREC_BF16>(a, grid, lds, stream);
-    else rc = launch_mt<CRUSE_PREC_BF16X3>(a, grid, lds, stream);
+    const int ntile_wg = a.nclass * (TFM * (Fout / a.OS) / 16);       // N-tiles of one workgroup tile
+    int nw = (ntile_wg == 5 || (ntile_wg == 10 && (Cin >= 64 || Cout >= 64))) ? 5 : 4;
+    { const char* e = getenv("CRUSE_CM_NW"); if (e && (atoi(e) == 4 || atoi(e) == 5)) nw = atoi(e); }       // profiling knob
+    if (prec == CRUSE_PREC_F32) rc = launch_mt<CRUSE_PREC_F32>(a, grid, lds, nw, stream);
+    else if (prec == CRUSE_PREC_BF16) rc = launch_mt<CRUSE_PREC_BF16>(a, grid, lds, nw, stream);
+    else rc = launch_mt<CRUSE_PREC_BF16X3>(a, grid, lds, nw, stream);
     if (rc) return rc;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { cruse_set_error("conv_mfma: HIP launch failed: %s", hipGetErrorString(e)); return CRUSE_E_HIP; }
