@@ -867,12 +867,19 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruArgs a) {
 // NP: tile PAIRS per wavefront -- a pair is the 32 units of one consumer; wave w owns pairs [w*NP, w*NP + NP), NP = ceil(P/4).
 // FULL: P % 4 == 0 (Hg % 128 == 0): every pair and every producer slot exists, the validity masks fold away at
 // compile time.
+// LOADER WAVE: the per-step operands (dout_s, z_{s+1}, the three coefficient rows c_s of the 8 clips x 32 own units:
+// 3.5 KB per step) used to be loaded by the compute threads one step ahead -- but vmcnt returns in order, so those HBM
+// loads sat in front of the NEXT step's granule sweep and every step waited for them: 0.8 us of a 2.7 us step
+// (CRUSE_GRU_DBG=7 drops them: 769 vs 1087 us per launch alone, tools/gru_hog_probe.py).  A fifth wavefront now streams
+// them into a 4-slot LDS ring four steps ahead on its own vmcnt counter; the compute waves read them with ds_reads.
 template <int NP, bool FULL>
-__global__ __launch_bounds__(256) void gru_bwd_rs_kernel(GruArgs a) {
+__global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
     constexpr int KP = 96 + 8;                   // panel row stride (bf16): 208 B, de-phases the 16 rows of a b128 read
     constexpr int NT = 2 * NP;                   // 16-unit output tiles per wavefront
     constexpr int NL = NP;                       // 16-byte loads per thread and sweep: producers quarter*NL + j, j < NL = ceil(P/4)
     __shared__ __attribute__((aligned(16))) __bf16 panel[2][16 * KP];
+    __shared__ __attribute__((aligned(16))) float op_d[4][8][32], op_z[4][8][32];       // ring slot = iteration & 3
+    __shared__ __attribute__((aligned(16))) __bf16 op_c[4][8][96];
     const int Hg = a.Hg, H = a.G * Hg, K3 = 3 * Hg, P = a.P, NTt = Hg >> 4;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int chain, part;
@@ -886,7 +893,69 @@ __global__ __launch_bounds__(256) void gru_bwd_rs_kernel(GruArgs a) {
     const unsigned panel_bytes = (unsigned)P * cons_bytes;          // one parity of one chain
     const unsigned cbase = (unsigned)chain * 2u * panel_bytes;
 
-    for (int i = tid; i < 2 * 16 * KP; i += 256) panel[0][i] = (__bf16)0.f;
+    for (int i = tid; i < 2 * 16 * KP; i += 320) panel[0][i] = (__bf16)0.f;
+
+    const unsigned frame_bytes = (unsigned)H * 4u, crow_bytes = (unsigned)(a.G * K3) * 2u;
+    const unsigned tot_f32 = (unsigned)min((long long)a.B * a.T * H * 4, 0xffffffffll);
+    const unsigned tot_cf = (unsigned)min((long long)a.B * a.T * a.G * K3 * 2, 0xffffffffll);
+    const __amdgpu_buffer_rsrc_t rs_dout = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dout), 0, tot_f32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.zs), 0, tot_f32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dh = __builtin_amdgcn_make_buffer_rsrc(a.dh, 0, tot_f32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_cf = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.coefs), 0, tot_cf, 0x00020000);
+    const bool nodata = a.dbg == 7;                      // profiling: no operand streams
+
+    if (wv == 4) {
+        // ---- loader wave.  Iteration j needs dout_{T-1-j}, c_{T-1-j} and z_{T-j}; lane = (clip, 16-byte chunk).
+        const int lc = lane >> 3, lq = lane & 7;                                   // dout / z: 8 clips x 8 chunks of 4 floats
+        const unsigned dv = (unsigned)(((long long)(b0 + (lc < nb ? lc : 0)) * a.T * H + grp * Hg + u0 + 4 * lq) * 4);
+        unsigned cv[2], cdst[2];
+        bool cok[2];
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {                                           // coef: 8 clips x 3 gates x 4 chunks of 8 bf16
+            const int idx = lane + 64 * i2;
+            cok[i2] = idx < 96;
+            const int cl = min(idx, 95) / 12, rem = min(idx, 95) % 12, gate = rem >> 2, chk = rem & 3;
+            cv[i2] = (unsigned)((((long long)(b0 + (cl < nb ? cl : 0)) * a.T * a.G + grp) * K3 + gate * Hg + u0 + 8 * chk) * 2);
+            cdst[i2] = (unsigned)(cl * 96 + gate * 32 + chk * 8);
+        }
+        struct OpSet { u32x4 d, z, c0, c1; };
+        auto issue = [&](int j, OpSet& o) {
+            const u32x4 zero = {0u, 0u, 0u, 0u};
+            o.d = zero; o.z = zero; o.c0 = zero; o.c1 = zero;
+            if (j >= a.T || nodata) return;
+            const unsigned st = (unsigned)(a.T - 1 - j);
+            o.d = __builtin_amdgcn_raw_buffer_load_b128(rs_dout, dv, st * frame_bytes, 0);
+            if (j > 0) o.z = __builtin_amdgcn_raw_buffer_load_b128(rs_z, dv, (st + 1u) * frame_bytes, 0);
+            o.c0 = __builtin_amdgcn_raw_buffer_load_b128(rs_cf, cv[0], st * crow_bytes, 0);
+            if (cok[1]) o.c1 = __builtin_amdgcn_raw_buffer_load_b128(rs_cf, cv[1], st * crow_bytes, 0);
+        };
+        auto put = [&](int j, const OpSet& o) {
+            const int slot = j & 3;
+            *reinterpret_cast<u32x4*>(&op_d[slot][lc][4 * lq]) = o.d;
+            *reinterpret_cast<u32x4*>(&op_z[slot][lc][4 * lq]) = o.z;
+            *reinterpret_cast<u32x4*>(&op_c[slot][0][0] + cdst[0]) = o.c0;
+            if (cok[1]) *reinterpret_cast<u32x4*>(&op_c[slot][0][0] + cdst[1]) = o.c1;
+        };
+        OpSet s0, s1;
+        issue(0, s0); issue(1, s1);
+        put(0, s0); put(1, s1);
+        issue(2, s0); issue(3, s1);
+        if (a.dbg != 9) (void)team_shares_xcd(a.xid + (size_t)chain * 64, P, part, a.status, tid);    // mirrors the compute waves' barriers
+        __syncthreads();
+        // Iteration k: the set issued two iterations ago (for iteration k + 2) goes to its slot before this iteration's
+        // barrier -- the compute waves read it after the NEXT barrier -- and the set is re-issued for iteration k + 4.
+        for (int k = 0; k < a.T; k += 2) {
+            put(k + 2, s0);
+            issue(k + 4, s0);
+            if (a.T - 1 - k == 0) break;
+            __syncthreads();
+            put(k + 3, s1);
+            issue(k + 5, s1);
+            if (a.T - 2 - k == 0) break;
+            __syncthreads();
+        }
+        return;
+    }
 
     // A operand = W_hh[own gate rows, :]^T: A[row = output unit][k = own gate row]; k = gate*32 + unit, so k-step == gate
     bf16x8 wf[NT][3];
@@ -907,13 +976,6 @@ __global__ __launch_bounds__(256) void gru_bwd_rs_kernel(GruArgs a) {
     const int quarter = tid & 3, pp = (tid >> 2) & 7, bl = tid >> 5;
     const bool active = bl < nb;
     const int blc = active ? bl : 0;                                  // inactive threads shadow clip 0 (loads only)
-    const unsigned frame_bytes = (unsigned)H * 4u, crow_bytes = (unsigned)(a.G * K3) * 2u;
-    const unsigned tot_f32 = (unsigned)min((long long)a.B * a.T * H * 4, 0xffffffffll);
-    const unsigned tot_cf = (unsigned)min((long long)a.B * a.T * a.G * K3 * 2, 0xffffffffll);
-    const __amdgpu_buffer_rsrc_t rs_dout = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dout), 0, tot_f32, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.zs), 0, tot_f32, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_dh = __builtin_amdgcn_make_buffer_rsrc(a.dh, 0, tot_f32, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_cf = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.coefs), 0, tot_cf, 0x00020000);
     const unsigned own_v = (unsigned)(((long long)(b0 + blc) * a.T * H + grp * Hg + u0 + 4 * pp + quarter) * 4);   // + s*frame_bytes
     const unsigned cf_v = (unsigned)((((long long)(b0 + blc) * a.T * a.G + grp) * K3 + u0 + 4 * pp + quarter) * 2);  // + s*crow_bytes
     const unsigned hg2 = (unsigned)Hg * 2u;
@@ -941,17 +1003,13 @@ __global__ __launch_bounds__(256) void gru_bwd_rs_kernel(GruArgs a) {
     const int pw = blc * KP + 4 * pp + quarter;                      // panel element of the own unit (+ gate*32)
 
     float dh = 0.f, dd = 0.f, zz = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;  // operands of the current step (time s)
-    {
-        const unsigned s = (unsigned)(a.T - 1);
-        dd = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_dout, own_v, s * frame_bytes, 0));
-        c0 = bf16lo(__builtin_amdgcn_raw_buffer_load_b16(rs_cf, cf_v, s * crow_bytes, 0));
-        c1 = bf16lo(__builtin_amdgcn_raw_buffer_load_b16(rs_cf, cf_v + hg2, s * crow_bytes, 0));
-        c2 = bf16lo(__builtin_amdgcn_raw_buffer_load_b16(rs_cf, cf_v + 2 * hg2, s * crow_bytes, 0));
-    }
+    const int ou = 4 * pp + quarter;                                  // own unit inside the workgroup's 32
     float sv_dh = 0.f;
-    bool nowait = a.dbg >= 1 && a.dbg < 8;
+    bool nowait = a.dbg >= 1 && a.dbg < 7;
     const bool plain = a.dbg != 9 && team_shares_xcd(a.xid + (size_t)chain * 64, P, part, a.status, tid);
-    __syncthreads();
+    __syncthreads();                                                  // ring slots 0 and 1 are filled
+    dd = op_d[0][blc][ou];
+    c0 = (float)op_c[0][blc][ou]; c1 = (float)op_c[0][blc][32 + ou]; c2 = (float)op_c[0][blc][64 + ou];
 
     for (int k = 0; k < a.T; ++k) {
         const int s = a.T - 1 - k;
@@ -997,13 +1055,11 @@ __global__ __launch_bounds__(256) void gru_bwd_rs_kernel(GruArgs a) {
         }
         if (s == 0) break;                                 // nothing consumes the partials of time 0
         // operands of step k+1 (time s-1): dout_{s-1}, z_s, c_{s-1}
-        {
-            const unsigned sp = (unsigned)(s - 1);
-            dd = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_dout, own_v, sp * frame_bytes, 0));
-            zz = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_z, own_v, (unsigned)s * frame_bytes, 0));
-            c0 = bf16lo(__builtin_amdgcn_raw_buffer_load_b16(rs_cf, cf_v, sp * crow_bytes, 0));
-            c1 = bf16lo(__builtin_amdgcn_raw_buffer_load_b16(rs_cf, cf_v + hg2, sp * crow_bytes, 0));
-            c2 = bf16lo(__builtin_amdgcn_raw_buffer_load_b16(rs_cf, cf_v + 2 * hg2, sp * crow_bytes, 0));
+        {                                                  // from the loader wave's ring (slot = iteration & 3)
+            const int slot = (k + 1) & 3;
+            dd = op_d[slot][blc][ou];
+            zz = op_z[slot][blc][ou];
+            c0 = (float)op_c[slot][blc][ou]; c1 = (float)op_c[slot][blc][32 + ou]; c2 = (float)op_c[slot][blc][64 + ou];
         }
         __syncthreads();                                   // panel[k & 1] complete; panel[(k+1) & 1] is free again
         // tile PAIRS, each finished (3 k-steps, the two tiles interleaved so no MFMA waits on its own accumulator) and
@@ -1206,10 +1262,10 @@ size_t xg_bytes_total(int B, int G, int Hg) {
 }
 
 template <typename Kern>
-int launch_one(Kern k, const GruArgs& a, int grid, size_t lds, hipStream_t s, const char* name) {
+int launch_one(Kern k, const GruArgs& a, int grid, size_t lds, hipStream_t s, const char* name, int threads = 256) {
     int rc0 = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(k), lds, name);
     if (rc0) return rc0;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds, s, a);
     CRUSE_LAUNCH_CHECK(name);
     return CRUSE_OK;
 }
@@ -1270,19 +1326,19 @@ int dispatch_bwd_rs(const GruArgs& a, int grid, hipStream_t s) {
     const int P = a.Hg / 32, np = (P + 3) / 4;   // tile pairs per wavefront
     if (P % 4 == 0) {
         switch (np) {
-            case 1: return launch_one(gru_bwd_rs_kernel<1, true>, a, grid, 0, s, "gru_seq_bwd");
-            case 2: return launch_one(gru_bwd_rs_kernel<2, true>, a, grid, 0, s, "gru_seq_bwd");
-            case 3: return launch_one(gru_bwd_rs_kernel<3, true>, a, grid, 0, s, "gru_seq_bwd");
-            case 4: return launch_one(gru_bwd_rs_kernel<4, true>, a, grid, 0, s, "gru_seq_bwd");
-            default: return launch_one(gru_bwd_rs_kernel<5, true>, a, grid, 0, s, "gru_seq_bwd");
+            case 1: return launch_one(gru_bwd_rs_kernel<1, true>, a, grid, 0, s, "gru_seq_bwd", 320);
+            case 2: return launch_one(gru_bwd_rs_kernel<2, true>, a, grid, 0, s, "gru_seq_bwd", 320);
+            case 3: return launch_one(gru_bwd_rs_kernel<3, true>, a, grid, 0, s, "gru_seq_bwd", 320);
+            case 4: return launch_one(gru_bwd_rs_kernel<4, true>, a, grid, 0, s, "gru_seq_bwd", 320);
+            default: return launch_one(gru_bwd_rs_kernel<5, true>, a, grid, 0, s, "gru_seq_bwd", 320);
         }
     }
     switch (np) {
-        case 1: return launch_one(gru_bwd_rs_kernel<1, false>, a, grid, 0, s, "gru_seq_bwd");
-        case 2: return launch_one(gru_bwd_rs_kernel<2, false>, a, grid, 0, s, "gru_seq_bwd");
-        case 3: return launch_one(gru_bwd_rs_kernel<3, false>, a, grid, 0, s, "gru_seq_bwd");
-        case 4: return launch_one(gru_bwd_rs_kernel<4, false>, a, grid, 0, s, "gru_seq_bwd");
-        default: return launch_one(gru_bwd_rs_kernel<5, false>, a, grid, 0, s, "gru_seq_bwd");
+        case 1: return launch_one(gru_bwd_rs_kernel<1, false>, a, grid, 0, s, "gru_seq_bwd", 320);
+        case 2: return launch_one(gru_bwd_rs_kernel<2, false>, a, grid, 0, s, "gru_seq_bwd", 320);
+        case 3: return launch_one(gru_bwd_rs_kernel<3, false>, a, grid, 0, s, "gru_seq_bwd", 320);
+        case 4: return launch_one(gru_bwd_rs_kernel<4, false>, a, grid, 0, s, "gru_seq_bwd", 320);
+        default: return launch_one(gru_bwd_rs_kernel<5, false>, a, grid, 0, s, "gru_seq_bwd", 320);
     }
 }
 
