@@ -50,6 +50,7 @@ class _SideStream:
         self.used = []                 # side streams forked from the main stream since the last join()
         self.last = None               # the stream the most recent leaf went to
         self.multi_stream = False      # leaves may be deferred on one stream and released from another (_Pipes)
+        self.after_release = None      # one-shot callback run by the next release_around() once its leaves are issued
 
     def set_map(self, m: str, force: bool = False) -> None:
         """lane -> side stream assignment.  Measured on the bench step: replayed from a HIP graph the three lanes
@@ -119,6 +120,9 @@ class _SideStream:
                 fn()
         self.deferred.clear()
         self.active = True
+        if self.after_release is not None:
+            cb, self.after_release = self.after_release, None
+            cb()
         return out
 
     def run(self, fn, *tensors, lane=None, dep=None):
@@ -684,9 +688,17 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
         skip_leaves(k)
     # ---- bottleneck: u_L = ggru(e_L) + skip_L --------------------------------------------
     H = ch[L] * Fk[L]
-    # de_pre[L] is written by a skip leaf: wait for the leaves issued so far right before the GGRU adds into it
+    # de_pre[L] is written by a skip leaf, issued with the first backward recurrence: the GGRU waits, right before it adds
+    # into de_pre[L], for what the side streams had been given by THAT launch -- not for the layer-2 weight-gradient GEMMs
+    # queued behind it later (waiting for those stalled the main stream for 0.27 ms once the recurrence got shorter)
+    marks = {}
+    SIDE.after_release = lambda: marks.__setitem__("ev", SIDE.mark())
+
+    def de_pre_ready():
+        SIDE.after_release = None
+        SIDE.wait(marks["ev"] if "ev" in marks else SIDE.mark())
     de = ggru_backward(ctx["gctx"], du.view(B, T, H), P, G, join=False, dx_init=de_pre[L].view(B, T, H),
-                       dx_ready=lambda: SIDE.wait(SIDE.mark()), defer_last=boundary is not None).view(B, T, ch[L], Fk[L])
+                       dx_ready=de_pre_ready, defer_last=boundary is not None).view(B, T, ch[L], Fk[L])
     if boundary is not None:
         boundary(0)
     cut = max(L // 2, 1)                          # levels L..cut+1, [bucket 1 final], levels cut..1
