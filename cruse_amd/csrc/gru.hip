@@ -541,9 +541,17 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
 // plane on the same accumulators.  The rounding of the recurrent WEIGHTS is the systematic part of the bf16 recurrence
 // error (the same perturbation at every one of the T steps; the rounding of h is fresh noise per step): see DESIGN.md
 // section 2 for the measured effect.  Costs 6*NKW more MFMAs per wave and step and 24*NKW more registers per lane.
+// HELPER WAVE (HW; every variant but the Hg > 384 two-plane one, whose weights leave no room for a fifth wave): the
+// compute waves' gi loads and their six saves per step (h, three coefficient rows, a_n, z) sat in the same in-order vmcnt
+// queue as the next step's granule sweep (CRUSE_GRU_DBG=6 drops both: 675 vs 797 us per launch, tools/gru_hog_probe.py).
+// A fifth wavefront streams the gi rows into a 4-slot LDS ring four steps ahead and writes the saves -- which the compute
+// threads leave in LDS -- to HBM as 16-byte stores one step behind.
 template <int NKW, int NS, bool FULL, bool WLO>
-__global__ __launch_bounds__(256) void gru_fwd_lean_kernel(GruArgs a) {
+__global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_kernel(GruArgs a) {
+    constexpr bool HW = !(WLO && NKW > 3);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ __attribute__((aligned(16))) float gi_r[HW ? 4 : 1][8][96];        // gi ring: slot = t & 3, [clip][gate*32 + unit]
+    __shared__ __attribute__((aligned(16))) float sv_l[HW ? 2 : 1][6][8][32];     // saves of step t in parity t & 1
     const int Hg = a.Hg, H = a.G * Hg, LD = Hg + 8, KS = Hg >> 5;
     __bf16* hB = reinterpret_cast<__bf16*>(smem_raw);                    // [16][LD]  B operand (h_{t-1})
     float* red = reinterpret_cast<float*>(hB + 16 * LD);                  // [4 waves][6 tiles][64 lanes][4]
@@ -559,7 +567,96 @@ __global__ __launch_bounds__(256) void gru_fwd_lean_kernel(GruArgs a) {
     const unsigned panel_bytes = (unsigned)(8 * Hg) * 4u;              // bf16-pair granules: 4 B per value
     const unsigned cbase = (unsigned)chain * 2u * panel_bytes;
 
-    for (int i = tid; i < 16 * LD; i += 256) hB[i] = (__bf16)0.f;
+    for (int i = tid; i < 16 * LD; i += (HW ? 320 : 256)) hB[i] = (__bf16)0.f;
+
+    const unsigned frame_bytes = (unsigned)H * 4u, grow_bytes = (unsigned)(a.G * 3 * Hg) * 4u, crow_bytes = grow_bytes >> 1;
+    const unsigned tot_h = (unsigned)min((long long)a.B * a.T * H * 4, 0xffffffffll);
+    const unsigned tot_g = (unsigned)min((long long)a.B * a.T * a.G * 3 * Hg * 4, 0xffffffffll);
+    const __amdgpu_buffer_rsrc_t rs_gi = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gi), 0, tot_g, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(a.h, 0, tot_h, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_an = __builtin_amdgcn_make_buffer_rsrc(a.an, 0, a.an ? tot_h : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(a.z, 0, a.z ? tot_h : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_cf = __builtin_amdgcn_make_buffer_rsrc(a.coef, 0, a.coef ? tot_g >> 1 : 0u, 0x00020000);
+    const bool save = a.coef != nullptr;
+
+    if (HW && wv == 4) {
+        // ---- helper wave ---------------------------------------------------------------------------------------------
+        // gi: 8 clips x 3 gates x 8 chunks of 4 floats = 192 lane-loads per step (3 instructions)
+        unsigned gv[3], gdst[3];
+#pragma unroll
+        for (int i3 = 0; i3 < 3; ++i3) {
+            const int idx = lane + 64 * i3, cl = idx / 24, rem = idx % 24, gate = rem >> 3, chk = rem & 7;
+            gv[i3] = (unsigned)((((long long)(b0 + (cl < nb ? cl : 0)) * a.T * a.G + grp) * 3 * Hg + gate * Hg + u0 + 4 * chk) * 4);
+            gdst[i3] = (unsigned)(cl * 96 + gate * 32 + chk * 4);
+        }
+        // saves: h / a_n / z rows: lane = (clip, chunk of 4 floats); coefficient rows: 8 clips x 3 gates x 4 chunks of 8 bf16
+        const int lc = lane >> 3, lq = lane & 7;
+        const bool rok = lc < nb;
+        const unsigned hv = (unsigned)(((long long)(b0 + (rok ? lc : 0)) * a.T * H + grp * Hg + u0 + 4 * lq) * 4);
+        unsigned cv[2], csrc[2];
+        bool cok[2];
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+            const int idx = min(lane + 64 * i2, 95), cl = idx / 12, rem = idx % 12, gate = rem >> 2, chk = rem & 3;
+            cok[i2] = lane + 64 * i2 < 96 && cl < nb;
+            cv[i2] = (unsigned)((((long long)(b0 + (cl < nb ? cl : 0)) * a.T * a.G + grp) * 3 * Hg + gate * Hg + u0 + 8 * chk) * 2);
+            csrc[i2] = (unsigned)(((1 + gate) * 8 + cl) * 32 + chk * 8);
+        }
+        struct GiSet { u32x4 v[3]; };
+        auto issue = [&](int t, GiSet& o) {
+            const unsigned so = (unsigned)min(t, a.T - 1) * grow_bytes;
+#pragma unroll
+            for (int i3 = 0; i3 < 3; ++i3) o.v[i3] = __builtin_amdgcn_raw_buffer_load_b128(rs_gi, gv[i3], so, 0);
+        };
+        auto put = [&](int t, const GiSet& o) {
+            float* d = &gi_r[t & 3][0][0];
+#pragma unroll
+            for (int i3 = 0; i3 < 3; ++i3) *reinterpret_cast<u32x4*>(d + gdst[i3]) = o.v[i3];
+        };
+        auto flush = [&](int t) {                       // saves of step t from parity t & 1
+            const float* sl = &sv_l[t & 1][0][0][0];
+            const unsigned so = (unsigned)t * frame_bytes, sc = (unsigned)t * crow_bytes;
+            if (rok) {
+                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(sl + (0 * 8 + lc) * 32 + 4 * lq), rs_h, hv, so, 0);
+                if (save) {
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(sl + (4 * 8 + lc) * 32 + 4 * lq), rs_an, hv, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(sl + (5 * 8 + lc) * 32 + 4 * lq), rs_z, hv, so, 0);
+                }
+            }
+            if (save) {
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2) {
+                    if (cok[i2]) {
+                        const float4 p0 = *reinterpret_cast<const float4*>(sl + csrc[i2]);
+                        const float4 p1 = *reinterpret_cast<const float4*>(sl + csrc[i2] + 4);
+                        const u32x4 w = {pack2(p0.x, p0.y), pack2(p0.z, p0.w), pack2(p1.x, p1.y), pack2(p1.z, p1.w)};
+                        __builtin_amdgcn_raw_buffer_store_b128(w, rs_cf, cv[i2], sc, 0);
+                    }
+                }
+            }
+        };
+        GiSet s0, s1;
+        issue(0, s0); issue(1, s1);
+        put(0, s0); put(1, s1);
+        issue(2, s0); issue(3, s1);
+        if (a.dbg != 9) (void)team_shares_xcd(a.xid + (size_t)chain * 64, a.P, part, a.status, tid);   // mirrors the compute waves' barriers
+        __syncthreads();
+        // step t: two barriers (t > 0).  The gi set for step t + 2 goes to its ring slot, the set is re-issued for step
+        // t + 4; the saves of step t - 1 are in LDS once the first barrier of step t has passed.
+        for (int t = 0; t < a.T; t += 2) {
+            if (t > 0) __syncthreads();
+            put(t + 2, s0); issue(t + 4, s0);
+            if (t > 0) { flush(t - 1); __syncthreads(); }
+            if (t + 1 >= a.T) break;
+            __syncthreads();
+            put(t + 3, s1); issue(t + 5, s1);
+            flush(t);
+            __syncthreads();
+        }
+        __syncthreads();                                // the last step's saves are in LDS
+        flush(a.T - 1);
+        return;
+    }
 
     // resident weight fragments: tile j = gate*2 + half; this wave's k-steps ks = wv + 4*i
     bf16x8 wf[6][NKW], wl[WLO ? 6 : 1][WLO ? NKW : 1];
@@ -600,27 +697,24 @@ __global__ __launch_bounds__(256) void gru_fwd_lean_kernel(GruArgs a) {
     float bias[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) bias[g] = bh[g * Hg + u0 + u];
-    const unsigned frame_bytes = (unsigned)H * 4u, grow_bytes = (unsigned)(a.G * 3 * Hg) * 4u, crow_bytes = grow_bytes >> 1;
-    const unsigned tot_h = (unsigned)min((long long)a.B * a.T * H * 4, 0xffffffffll);
-    const unsigned tot_g = (unsigned)min((long long)a.B * a.T * a.G * 3 * Hg * 4, 0xffffffffll);
-    const __amdgpu_buffer_rsrc_t rs_gi = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gi), 0, tot_g, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(a.h, 0, tot_h, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_an = __builtin_amdgcn_make_buffer_rsrc(a.an, 0, a.an ? tot_h : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(a.z, 0, a.z ? tot_h : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_cf = __builtin_amdgcn_make_buffer_rsrc(a.coef, 0, a.coef ? tot_g >> 1 : 0u, 0x00020000);
     const unsigned own_v = (unsigned)(((long long)(b0 + blc) * a.T * H + grp * Hg + u0 + u) * 4);                    // + t*frame_bytes
     const unsigned g_v = (unsigned)((((long long)(b0 + blc) * a.T * a.G + grp) * 3 * Hg + u0 + u) * 4);               // + t*grow_bytes
     const unsigned hg4 = (unsigned)Hg * 4u;
-    const bool save = a.coef != nullptr;
     const unsigned pub_v = (unsigned)((bl * Hg + u0 + u) >> 1) * 8u;
     const bool pub_lane = act && !(u & 1);
 
     float hp = 0.f, gic[3], sv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if constexpr (!HW) {
 #pragma unroll
-    for (int g = 0; g < 3; ++g) gic[g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_gi, g_v + g * hg4, 0, 0));
-    bool nowait = a.dbg >= 1 && a.dbg < 8;
+        for (int g = 0; g < 3; ++g) gic[g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_gi, g_v + g * hg4, 0, 0));
+    }
+    bool nowait = a.dbg >= 1 && a.dbg < 6;
     const bool plain = a.dbg != 9 && team_shares_xcd(a.xid + (size_t)chain * 64, a.P, part, a.status, tid);
     __syncthreads();
+    if constexpr (HW) {                                    // ring slots 0 and 1 are filled
+#pragma unroll
+        for (int g = 0; g < 3; ++g) gic[g] = gi_r[0][blc][g * 32 + u];
+    }
 
     for (int t = 0; t < a.T; ++t) {
         if (t > 0) {
@@ -646,7 +740,8 @@ __global__ __launch_bounds__(256) void gru_fwd_lean_kernel(GruArgs a) {
                 *reinterpret_cast<u32x2*>(hB + sw_l[j]) = w;
             }
             // saves of step t-1: issued after the sweep has returned, old by the time of the next one
-            if (act) {
+            // (helper-wave variants: the helper writes them from LDS)
+            if (!HW && act && a.dbg != 6) {                // dbg 6 (profiling): no saves either
                 const unsigned so = (unsigned)(t - 1) * frame_bytes;
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv[0]), rs_h, own_v, so, 0);
                 if (save) {
@@ -660,8 +755,8 @@ __global__ __launch_bounds__(256) void gru_fwd_lean_kernel(GruArgs a) {
             }
         }
         // gi rows of step t+1 (clamped at the end: the extra row is never used)
-        float gin_[3];
-        {
+        float gin_[3] = {0.1f, -0.2f, 0.3f};
+        if (!HW && a.dbg != 7 && a.dbg != 6) {             // dbg 6 / 7 (profiling): no gi stream
             const unsigned so = (unsigned)min(t + 1, a.T - 1) * grow_bytes;
 #pragma unroll
             for (int g = 0; g < 3; ++g) gin_[g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_gi, g_v + g * hg4, so, 0));
@@ -713,8 +808,24 @@ __global__ __launch_bounds__(256) void gru_fwd_lean_kernel(GruArgs a) {
         sv[4] = an;
         sv[5] = z;
         hp = h;
+        if constexpr (HW) {
+            // saves into parity t & 1 (the helper reads them after the next barrier); gi of step t + 1 from the ring
+            float* sl = &sv_l[t & 1][0][blc][u];
+            if (act) {
 #pragma unroll
-        for (int g = 0; g < 3; ++g) gic[g] = gin_[g];
+                for (int q = 0; q < 6; ++q) sl[q * 256] = sv[q];
+            }
+            const int slot = (t + 1) & 3;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) gic[g] = gi_r[slot][blc][g * 32 + u];
+        } else {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) gic[g] = gin_[g];
+        }
+    }
+    if constexpr (HW) {
+        __syncthreads();                                   // hands the last step's saves to the helper wave
+        return;
     }
     if (act) {
         const unsigned so = (unsigned)(a.T - 1) * frame_bytes, sc = (unsigned)(a.T - 1) * crow_bytes;
@@ -1286,19 +1397,19 @@ int dispatch_fwd_lean_w(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
     const int n = (a.Hg + 127) / 128;            // = k-steps per wave = sweep slots per thread
     if (a.Hg % 128 == 0) {
         switch (n) {
-            case 1: return launch_one(gru_fwd_lean_kernel<1, 1, true, WLO>, a, grid, lds, s, "gru_seq_fwd");
-            case 2: return launch_one(gru_fwd_lean_kernel<2, 2, true, WLO>, a, grid, lds, s, "gru_seq_fwd");
-            case 3: return launch_one(gru_fwd_lean_kernel<3, 3, true, WLO>, a, grid, lds, s, "gru_seq_fwd");
-            case 4: return launch_one(gru_fwd_lean_kernel<4, 4, true, WLO>, a, grid, lds, s, "gru_seq_fwd");
-            default: return launch_one(gru_fwd_lean_kernel<5, 5, true, WLO>, a, grid, lds, s, "gru_seq_fwd");
+            case 1: return launch_one(gru_fwd_lean_kernel<1, 1, true, WLO>, a, grid, lds, s, "gru_seq_fwd", (WLO && 1 > 3) ? 256 : 320);
+            case 2: return launch_one(gru_fwd_lean_kernel<2, 2, true, WLO>, a, grid, lds, s, "gru_seq_fwd", (WLO && 2 > 3) ? 256 : 320);
+            case 3: return launch_one(gru_fwd_lean_kernel<3, 3, true, WLO>, a, grid, lds, s, "gru_seq_fwd", (WLO && 3 > 3) ? 256 : 320);
+            case 4: return launch_one(gru_fwd_lean_kernel<4, 4, true, WLO>, a, grid, lds, s, "gru_seq_fwd", (WLO && 4 > 3) ? 256 : 320);
+            default: return launch_one(gru_fwd_lean_kernel<5, 5, true, WLO>, a, grid, lds, s, "gru_seq_fwd", (WLO && 5 > 3) ? 256 : 320);
         }
     }
     switch (n) {
-        case 1: return launch_one(gru_fwd_lean_kernel<1, 1, false, WLO>, a, grid, lds, s, "gru_seq_fwd");
-        case 2: return launch_one(gru_fwd_lean_kernel<2, 2, false, WLO>, a, grid, lds, s, "gru_seq_fwd");
-        case 3: return launch_one(gru_fwd_lean_kernel<3, 3, false, WLO>, a, grid, lds, s, "gru_seq_fwd");
-        case 4: return launch_one(gru_fwd_lean_kernel<4, 4, false, WLO>, a, grid, lds, s, "gru_seq_fwd");
-        default: return launch_one(gru_fwd_lean_kernel<5, 5, false, WLO>, a, grid, lds, s, "gru_seq_fwd");
+        case 1: return launch_one(gru_fwd_lean_kernel<1, 1, false, WLO>, a, grid, lds, s, "gru_seq_fwd", (WLO && 1 > 3) ? 256 : 320);
+        case 2: return launch_one(gru_fwd_lean_kernel<2, 2, false, WLO>, a, grid, lds, s, "gru_seq_fwd", (WLO && 2 > 3) ? 256 : 320);
+        case 3: return launch_one(gru_fwd_lean_kernel<3, 3, false, WLO>, a, grid, lds, s, "gru_seq_fwd", (WLO && 3 > 3) ? 256 : 320);
+        case 4: return launch_one(gru_fwd_lean_kernel<4, 4, false, WLO>, a, grid, lds, s, "gru_seq_fwd", (WLO && 4 > 3) ? 256 : 320);
+        default: return launch_one(gru_fwd_lean_kernel<5, 5, false, WLO>, a, grid, lds, s, "gru_seq_fwd", (WLO && 5 > 3) ? 256 : 320);
     }
 }
 int dispatch_fwd_lean(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
