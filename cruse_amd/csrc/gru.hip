@@ -1088,8 +1088,6 @@ __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
     const bool active = bl < nb;
     const int blc = active ? bl : 0;                                  // inactive threads shadow clip 0 (loads only)
     const unsigned own_v = (unsigned)(((long long)(b0 + blc) * a.T * H + grp * Hg + u0 + 4 * pp + quarter) * 4);   // + s*frame_bytes
-    const unsigned cf_v = (unsigned)((((long long)(b0 + blc) * a.T * a.G + grp) * K3 + u0 + 4 * pp + quarter) * 2);  // + s*crow_bytes
-    const unsigned hg2 = (unsigned)Hg * 2u;
     unsigned sweep_v[NL];
     bool sweep_ok[NL];                                                // the producer exists (P % 4 != 0: the last ones may not)
 #pragma unroll

@@ -309,22 +309,38 @@ int launch_mt(const WMArgs& p, int mt, int ntw, int grid, size_t lds, hipStream_
 int cruse_wgrad_mfma_try(const float* a, const float* bt, float* partial, int max_slabs,
                          int B, int T, int Ca, int Fa, int Cb, int Fb, int KT, int S, int pad, int prec,
                          int* nblk_out, hipStream_t stream) {
-    int tfw = (prec == CRUSE_PREC_BF16) ? 8 : 4;
-    { const char* e = getenv("CRUSE_WG_TFW"); if (e && atoi(e) == 4) tfw = 4; }      // profiling override
     const int FaP = (Fa + 7) / 8 * 8, NCH = FaP / 8;
     const int ntaps = KT * 3;
     const int mt = Ca <= 16 ? 1 : (Ca <= 32 ? 2 : 4);
     const int ntiles_n = (ntaps * Cb + 15) / 16;
     const int ntw = (ntiles_n + 3) / 4;
     if (Ca > 64 || ntw > 3) return 0;
-    if ((tfw * NCH) % 4 != 0) return 0;
     if ((Ca * Fa) % 4 != 0 || (Cb * Fb) % 4 != 0 || ((uintptr_t)a % 16) != 0 || ((uintptr_t)bt % 16) != 0) return 0;
-    if (tfw * Ca * Fa > MAXV * 1024 || (tfw + KT - 1) * Cb * Fb > MAXV * 1024) return 0;
-    if (tfw * Fa > 768) return 0;
     const int esz = (prec == CRUSE_PREC_F32) ? 4 : 2, npl = (prec == CRUSE_PREC_BF16X3) ? 2 : 1;
-    const size_t lds = ((size_t)mt * 16 + (size_t)ntw * 64) * (tfw * FaP + RPAD) * esz * npl +
-                       (size_t)(tfw + KT - 1) * Cb * Fb * 4;
-    if (lds > 150 * 1024) return 0;
+    auto lds_of = [&](int tf) {
+        return ((size_t)mt * 16 + (size_t)ntw * 64) * (tf * FaP + RPAD) * esz * npl + (size_t)(tf + KT - 1) * Cb * Fb * 4;
+    };
+    auto fits = [&](int tf) {
+        return (tf * NCH) % 4 == 0 && tf * Ca * Fa <= MAXV * 1024 && (tf + KT - 1) * Cb * Fb <= MAXV * 1024 && tf * Fa <= 768 &&
+               lds_of(tf) <= 150 * 1024;
+    };
+    // Frames per tile and workgroups per CU.  The kernel runs one wave per SIMD per workgroup and is latency-bound in
+    // every phase (staging, patch build, K loop: SQ_WAIT_ANY 47 % of wave time), so TWO workgroups per CU are worth more
+    // than long tiles: 8-frame tiles where two of them fit the CU's LDS (12 launches alone: 766 -> 588 us in total),
+    // else 4-frame tiles; one 8-frame workgroup per CU only where neither fits twice.
+    const size_t two_wg = 156 * 1024;
+    int tfw = 4, gcap = 256;
+    if (prec == CRUSE_PREC_BF16) {
+        if (fits(8) && 2 * lds_of(8) <= two_wg) { tfw = 8; gcap = 512; }
+        else if (fits(4) && 2 * lds_of(4) <= two_wg) { tfw = 4; gcap = 512; }
+        else if (fits(8)) { tfw = 8; gcap = 256; }
+    } else if (fits(4) && 2 * lds_of(4) <= two_wg) {
+        gcap = 512;
+    }
+    { const char* e = getenv("CRUSE_WG_TFW"); if (e && (atoi(e) == 4 || (atoi(e) == 8 && prec == CRUSE_PREC_BF16))) tfw = atoi(e); }   // profiling overrides
+    { const char* e = getenv("CRUSE_WG_GRID"); if (e && atoi(e) > 0) gcap = atoi(e); }
+    if (!fits(tfw)) return 0;
+    const size_t lds = lds_of(tfw);
     WMArgs p = {};
     p.a = a; p.bt = bt; p.partial = partial;
     p.B = B; p.T = T; p.Ca = Ca; p.Fa = Fa; p.Cb = Cb; p.Fb = Fb; p.KT = KT; p.S = S; p.pad = pad;
@@ -332,8 +348,7 @@ int cruse_wgrad_mfma_try(const float* a, const float* bt, float* partial, int ma
     p.ntiles_total = B * ((T + tfw - 1) / tfw);
     { const char* e = getenv("CRUSE_WG_DBG"); p.dbg = e ? atoi(e) : 0; }
     int grid = p.ntiles_total < max_slabs ? p.ntiles_total : max_slabs;
-    if (grid > 256) grid = 256;                 // one resident block per CU; fewer partial slabs to reduce
-    { const char* e = getenv("CRUSE_WG_GRID"); if (e && atoi(e) > 0 && atoi(e) < grid) grid = atoi(e); }   // profiling override
+    if (grid > gcap) grid = gcap;               // resident blocks only; fewer partial slabs to reduce
     int rc;
     if (prec == CRUSE_PREC_F32) rc = launch_mt<CRUSE_PREC_F32, 4>(p, mt, ntw, grid, lds, stream);
     else if (prec == CRUSE_PREC_BF16X3) rc = launch_mt<CRUSE_PREC_BF16X3, 4>(p, mt, ntw, grid, lds, stream);

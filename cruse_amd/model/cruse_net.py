@@ -531,6 +531,9 @@ _PENDING_COUNTERS = []      # num_batches_tracked buffers of this forward: bumpe
 _FUSE_BN_STATS = os.environ.get("CRUSE_FUSE_BN_STATS", "1") != "0"
 
 
+_INLINE = int(os.environ.get("CRUSE_INLINE", "0"))      # backward leaves kept on the main stream (unet2_backward)
+
+
 def _flush_counters():
     if _PENDING_COUNTERS:
         ops.counters_add(list(_PENDING_COUNTERS), 1)
@@ -662,15 +665,26 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
     def skip_leaves(k):
         de_pre[k] = torch.empty(B, T, ch[k], Fk[k], device=dlogit.device, dtype=torch.float32)
 
-        def leaf(k=k, dsk=ds[k], out=de_pre[k]):
+        def dgrad(k=k, dsk=ds[k], out=de_pre[k]):
             ops.conv_gather(dsk, P[f"skip_connect_{k}.weight"], None, B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1,
                             w_layout=1, out=out, prec=dprec)
+
+        def wgrad(k=k, dsk=ds[k]):
             ops.conv_wgrad(dsk, es[k], G[f"skip_connect_{k}.weight"], B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1,
                            prec=prec)
-        # deferred to the first backward recurrence: its window has room for them (the side streams idle for ~0.5 ms
-        # of it), issuing them here costs an event record on the main stream per level and makes the decoder's
-        # BatchNorm backward share HBM with them
-        SIDE.defer(leaf, ds[k], de_pre[k], kind=8, lane=1)
+        # Deferred to the first backward recurrence (issuing them here costs an event record on the main stream per level
+        # and makes the decoder's BatchNorm backward share HBM with them).  Since the recurrences got shorter the side
+        # queue -- not the main stream -- is what the optimizer step waits for, and a leaf beside a recurrence takes 2-2.7x
+        # its time alone (96 free CUs): _INLINE moves leaves back onto the main stream where that shortens the step
+        # (bit 0 skip data gradients, bit 1 skip weight gradients, bit 2 decoder weight gradients).
+        if _INLINE & 1:
+            dgrad()
+        else:
+            SIDE.defer(dgrad, ds[k], de_pre[k], kind=8, lane=1)
+        if _INLINE & 2:
+            wgrad()
+        else:
+            SIDE.defer(wgrad, ds[k], kind=8, lane=1)
     skip_leaves(1)
     # ---- decoder levels 2..L ------------------------------------------------------------
     for k in range(2, L + 1):
@@ -681,7 +695,10 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
 
         def leaf_dec(dv=dv, k=k):
             ops.conv_wgrad(us[k], dv, G[f"conv{k}_t.weight"], B, T, ch[k], Fk[k], ch[k - 1], Fk[k - 1], KT=1, S=2, pad=0, prec=prec)
-        SIDE.defer(leaf_dec, dv, kind=2, lane=0)
+        if _INLINE & 4:
+            leaf_dec()
+        else:
+            SIDE.defer(leaf_dec, dv, kind=2, lane=0)
         du = ops.conv_gather(dv, P[f"conv{k}_t.weight"], None, B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k], KT=1, S=2, pad=0,
                              prec=dprec)
         ds[k] = du
