@@ -450,7 +450,7 @@ def main():
             for fam, ent in rl.items():
                 if pmc.get(fam):
                     ent["traffic"] = round(pmc[fam])
-                    ent["traffic_unit"] = "HBM bytes per launch (rocprofv3 PMC 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_hbm_traffic.csv)"
+                    ent["traffic_unit"] = "HBM bytes per launch (rocprofv3 PMC 2*FETCH_SIZE + WRITE_SIZE, " "profiles/" + os.path.basename(PMC_FILE) + ")"
         dom = max(per_step, key=per_step.get)
         breakdown = {k: round(v, 3) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])}
         roof = dict(rl.get(dom, {"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
