@@ -174,13 +174,15 @@ class TrainEngine:
     DECISION recorded in oracle.train_step_loss: filters = (mask padded to 161 bins, 0)), the enhanced spectrum is the
     filter output and WO-MALE is taken on it.
     use_graph: replay the step from HIP graph(s) (True) or launch its ~170 kernels eagerly (False).  On the bench step the
-    eager form is the faster one once the host keeps ahead (7.38 vs 7.56 ms) -- bench.py times both during warm-up
-    and keeps the winner; the default here stays the graph, which does not depend on host speed.
+    eager form is the faster one once the host keeps ahead (6.08 vs 6.3 ms); a busy or slow host favours the
+    graph.  "auto" decides by measurement on the first real steps: 1 + 3 steps from the graph, 1 + 3 launched eagerly
+    (HIP-event times of the measured ones, one host synchronisation each), then the faster form is kept for good -- no
+    extra steps are run, every rank takes rank 0's verdict.  bench.py does the same during its warm-up.
     clip_grad_norm > 0: torch.nn.utils.clip_grad_norm_ semantics on the (averaged) gradient, folded into Adam.
     bucketed: None = when world > 1; True forces the segmented schedule (tests, single-GPU cost measurements)."""
 
     def __init__(self, model: unet_2, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 n_fft=320, hop=160, precision: Optional[str] = None, use_graph: bool = True,
+                 n_fft=320, hop=160, precision: Optional[str] = None, use_graph=True,
                  loss_alpha=2.0, loss_beta=1.0, loss: str = "wo_male", clip_grad_norm: float = 0.0,
                  snr_db: float = 0.0, sdnr_beta_db: float = 20.0, bucketed: Optional[bool] = None):
         if not torch.cuda.is_available():
@@ -205,7 +207,11 @@ class TrainEngine:
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         self.bucketed = (self.world > 1) if bucketed is None else bool(bucketed)
         self.step_count = 0
-        self.use_graph = use_graph
+        if not (isinstance(use_graph, bool) or use_graph == "auto"):
+            raise ValueError(f"use_graph must be True, False or 'auto', not {use_graph!r}")
+        self._auto = {"n": 0, "t": {True: [], False: []}} if use_graph == "auto" else None
+        self.use_graph = True if use_graph == "auto" else use_graph
+        self.launch_form_timing = None           # {"graph_ms", "eager_ms", "kept"} once "auto" has decided
         self._graphs = None
         self._static = None
         self._shape = None
@@ -397,8 +403,43 @@ class TrainEngine:
             if w is not None:
                 self._works.append(w)
 
+    _AUTO_PLAN = (True, True, True, True, False, False, False, False)      # first step of each form is not measured
+
+    def _auto_step(self, noisy, clean):
+        st = self._auto
+        i = st["n"]
+        form = self._AUTO_PLAN[i]
+        self.use_graph = form
+        measured = i not in (0, 4)
+        if measured:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        self._auto = None                        # (step() below must not recurse into the tuner)
+        out = self.step(noisy, clean)
+        self._auto = st
+        if form and not self.use_graph:          # capture failed: step() has fallen back to eager launches for good
+            self._auto = None
+            return out
+        if measured:
+            e1.record()
+            e1.synchronize()
+            st["t"][form].append(e0.elapsed_time(e1))
+        st["n"] = i + 1
+        if st["n"] == len(self._AUTO_PLAN):
+            tg, te = sorted(st["t"][True])[1], sorted(st["t"][False])[1]          # medians of three
+            verdict = torch.tensor([1.0 if tg <= te else 0.0], device=noisy.device)
+            if _dist_on():
+                dist.broadcast(verdict, 0)
+            self.use_graph = bool(verdict.item() > 0.5)
+            self.launch_form_timing = {"graph_ms": round(tg, 3), "eager_ms": round(te, 3),
+                                       "kept": "graph" if self.use_graph else "eager"}
+            self._auto = None
+        return out
+
     def step(self, noisy: torch.Tensor, clean: torch.Tensor) -> torch.Tensor:
         """One optimizer step; returns the (device, f64) loss sum -- divide by .loss_norm for the loss."""
+        if self._auto is not None:
+            return self._auto_step(noisy, clean)
         self._works = []
         SIDE.for_mode(self.use_graph)
         if self.use_graph:

@@ -249,14 +249,15 @@ def _splitk(M: int, N: int, K: int) -> int:
 # GGRU functional core on [B,T,H] rows
 # ======================================================================================
 def ggru_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], prefix: str, groups: int, prec,
-                 residual: Optional[torch.Tensor] = None, save: bool = True, residual_ready=None):
+                 residual: Optional[torch.Tensor] = None, save: bool = True, residual_ready=None, late_leaves=None):
     """x [B,T,H] -> (ln2(gru2(ln1(interleave(gru1(x))))) [+ residual], ctx).  cruse_net.py:37-55.
     With CRUSE_GRU_PIPES=2, batches of 16k clips run as half-batch pipelines on two streams (_Pipes); ctx then holds one
     context per slice."""
     B, T, H = x.shape
     n = PIPES.count(B, groups, H // groups)
     if n == 1:
-        return _ggru_forward_one(x, P, prefix, groups, prec, residual, save, residual_ready=residual_ready)
+        return _ggru_forward_one(x, P, prefix, groups, prec, residual, save, residual_ready=residual_ready,
+                                 late_leaves=late_leaves)
     if residual_ready is not None:
         residual_ready()
     Bh = B // n
@@ -285,7 +286,7 @@ def ggru_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], prefix: str, group
 
 
 def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=None, slot=0, xcd_rot=0, pre_done=None,
-                      residual_ready=None):
+                      residual_ready=None, late_leaves=None):
     """residual_ready(): called right before the residual is read (the last layer norm) -- the caller may still be
     producing it on a side stream while the recurrences run."""
     B, T, H = x.shape
@@ -334,10 +335,32 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
 
     h1, c1, a1, z1 = layer(x, "gru_list1")
     l1, m1, s1 = ops.ln_fwd(h1, P[prefix + "ln1.weight"], P[prefix + "ln1.bias"], None, rows, H, g, save=save)
+    # The K-tiled time-major bf16 copies of x, h1, l1, h2 -- the K operands of the four weight-gradient GEMMs -- depend on
+    # the forward pass only.  From the first backward recurrence on, the side streams' queue is what the optimizer step
+    # waits for, while in the forward pass they idle: three of the copies are made beside the second forward recurrence,
+    # the fourth beside the decoder (late_leaves: the caller issues it after it has joined the side streams).
+    fwd_T = save and fast and SIDE.enabled and slot == 0 and _EARLY_T >= 2
+    if fwd_T:
+        ldT = (rows + 63) // 64 * 64
+        xT, h1T, l1T, h2T = (torch.empty(ldT // 64, H, 64, device=x.device, dtype=torch.bfloat16) for _ in range(4))
+
+        def t_layer1(x=x, h1=h1, l1=l1):
+            ops.transpose_bf16(x, rows, H, out=xT)
+            ops.transpose_bf16(h1, rows, H, shift_T=T, out=h1T)
+            ops.transpose_bf16(l1, rows, H, out=l1T)
+        SIDE.defer(t_layer1, x, h1, l1, xT, h1T, l1T, kind=1, lane=2)
     h2, c2, a2, z2 = layer(l1, "gru_list2")
     if residual_ready is not None:
         residual_ready()
     out, m2, s2 = ops.ln_fwd(h2, P[prefix + "ln2.weight"], P[prefix + "ln2.bias"], residual, rows, H, 1, save=save, out=out)
+    if fwd_T:
+        def t_h2(h2=h2):
+            ops.transpose_bf16(h2, rows, H, shift_T=T, out=h2T)
+        if late_leaves is not None:
+            late_leaves.append((t_h2, (h2, h2T)))
+        else:
+            SIDE.defer(t_h2, h2, h2T, kind=1, lane=2)
+        ctx.update(T1=(xT, h1T), T2=(l1T, h2T))
     if save:
         ctx.update(h1=h1, c1=c1, a1=a1, z1=z1, l1=l1, m1=m1, s1=s1,
                    h2=h2, c2=c2, a2=a2, z2=z2, m2=m2, s2=s2)
@@ -499,7 +522,9 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
     # fill -- not after the second one, where the side streams' queue (layer 1's GEMMs, the encoder's weight gradients)
     # is what the optimizer step waits for.
     early_T = {}
-    if _bf16_gemm_path(prec, Hg) and SIDE.enabled and os.environ.get("CRUSE_EARLY_T", "1") == "1":
+    if "T1" in ctx:                                      # made in the forward pass (_ggru_forward_one)
+        early_T["gru_list1"], early_T["gru_list2"] = ctx["T1"], ctx["T2"]
+    elif _bf16_gemm_path(prec, Hg) and SIDE.enabled and _EARLY_T >= 1:
         ldT1 = (rows + 63) // 64 * 64
         x1T = torch.empty(ldT1 // 64, H, 64, device=dout.device, dtype=torch.bfloat16)
         h1T = torch.empty(ldT1 // 64, H, 64, device=dout.device, dtype=torch.bfloat16)
@@ -532,6 +557,9 @@ _FUSE_BN_STATS = os.environ.get("CRUSE_FUSE_BN_STATS", "1") != "0"
 
 
 _INLINE = int(os.environ.get("CRUSE_INLINE", "0"))      # backward leaves kept on the main stream (unet2_backward)
+# dW operand transposes: 0 inside each layer's weight-gradient leaf, 1 layer 1's with the first backward recurrence,
+# 2 all four in the forward pass (beside the second forward recurrence / the decoder)
+_EARLY_T = int(os.environ.get("CRUSE_EARLY_T", "2"))
 
 
 def _flush_counters():
@@ -592,10 +620,13 @@ def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, tor
         ys.append(y); es.append(e); ss.append(s); stats.append((mean, rstd))
         cur = e
     H = ch[L] * Fk[L]
+    late = []
     u, gctx = ggru_forward(cur.view(B, T, H), P, "gru.", groups, prec, residual=ss[L].view(B, T, H), save=save,
-                           residual_ready=SIDE.join)
+                           residual_ready=SIDE.join, late_leaves=late)
     u = u.view(B, T, ch[L], Fk[L])
     SIDE.join()
+    for fn, keep in late:                               # beside the decoder: nothing on the main stream waits for these
+        SIDE.run(fn, *keep, lane=2)
     us, vs, dstats = {L: u}, {}, {}
     for k in range(L, 1, -1):
         if training and _FUSE_BN_STATS:

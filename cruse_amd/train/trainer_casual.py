@@ -13,7 +13,8 @@ What the reference's knobs do here:
                                  latest_model.tar stores and what resume loads (base_trainer.py:167,199-203)
   clip_grad_norm_value        -> torch.nn.utils.clip_grad_norm_ semantics, folded into the fused Adam (base_trainer.py:75)
   meta.preloaded_model_path   -> model weights from a checkpoint, strict=False (base_trainer.py:130-146)
-  meta.hip_graph (this repo)  -> replay the step from HIP graphs (default true: robust to a busy host) or launch eagerly
+  meta.hip_graph (this repo)  -> true: replay the step from HIP graphs, false: launch eagerly, "auto" (default): time both
+                                 on the first eight real steps and keep the faster
   save_checkpoint_interval, validation_interval, save_max_metric_score -> as base_trainer.py:72-86,395-418
 The validation score is the configured loss on the validation set (the reference's STOI / PESQ metrics are host-side
 libraries outside this path), so `save_max_metric_score = false` is the meaningful setting.
@@ -27,6 +28,15 @@ import torch
 
 from .. import ops
 from ..engine import TrainEngine
+
+
+def _graph_mode(v):
+    """meta.hip_graph: true / false / "auto"."""
+    if isinstance(v, str):
+        if v.lower() == "auto":
+            return "auto"
+        return v.lower() in ("1", "true", "yes", "on")
+    return bool(v)
 
 
 class Trainer:
@@ -63,7 +73,7 @@ class Trainer:
         self.engine = TrainEngine(self.model, lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"],
                                   weight_decay=g.get("weight_decay", 0.0), n_fft=ac["n_fft"], hop=ac["hop_length"],
                                   precision=config["meta"].get("precision", None),
-                                  use_graph=bool(config["meta"].get("hip_graph", True)), loss=loss_name,
+                                  use_graph=_graph_mode(config["meta"].get("hip_graph", "auto")), loss=loss_name,
                                   clip_grad_norm=float(self.clip_grad_norm_value or 0.0), **loss_kwargs)
         self.start_epoch = 1
         self.best_score = -float("inf") if self.save_max_metric_score else float("inf")      # base_trainer.py:93

@@ -203,3 +203,31 @@ def test_engine_caches_one_graph_per_input_shape():
     assert eng._graphs is gb
     torch.cuda.synchronize()
     assert eng.skipped_steps() == 0 and eng.step_count == 4
+
+
+def test_engine_auto_launch_form_decides_on_real_steps():
+    """use_graph="auto": eight real steps (4 from the graph, 4 eager), then one form is kept; the run is the same
+    training run as with a fixed form (same batches, same number of steps, same parameters up to summation order)."""
+    from cruse_amd.engine import TrainEngine
+    from cruse_amd.model.cruse_net import unet_2
+    from cruse_amd.data import synth_batch
+    res = {}
+    for mode in ("auto", False):
+        torch.manual_seed(3)
+        m = unet_2(rnn_groups=1, precision="bf16").cuda()
+        eng = TrainEngine(m, lr=1e-3, use_graph=mode)
+        for i in range(10):
+            eng.step(*synth_batch(8, 3200, "cuda", 50 + i))
+        torch.cuda.synchronize()
+        if mode == "auto":
+            assert eng._auto is None and eng.launch_form_timing["kept"] in ("graph", "eager")
+            assert eng.use_graph == (eng.launch_form_timing["kept"] == "graph")
+        assert eng.step_count == 10 and eng.skipped_steps() == 0
+        res[mode] = (eng.flat.params.clone(), eng.mean_loss())
+    # bf16 mode: Adam moves noise-level gradient entries by +-lr per step, so the parameters agree to ~lr * steps; the
+    # loss trajectory is the meaningful comparison
+    d = (res["auto"][0] - res[False][0]).norm() / res[False][0].norm()
+    assert float(d) < 2e-2
+    assert abs(res["auto"][1] - res[False][1]) < 2e-3 * abs(res[False][1])
+    with pytest.raises(ValueError):
+        TrainEngine(unet_2(rnn_groups=1).cuda(), use_graph="sometimes")
