@@ -35,13 +35,13 @@ SIGNATURES = {
     "cruse_channel_sum": ("pqiipp", "i"),
     "cruse_col_sum": ("pqiipp", "i"),
     "cruse_bn_stats": ("pqiipip", "i"),
-    "cruse_bn_finalize_act_fwd": ("ppiqffppppppppqiiip", "i"),
+    "cruse_bn_finalize_act_fwd": ("ppiqffpppppppppqiiip", "i"),
     "cruse_bn_finalize": ("pqiffppppp", "i"),
     "cruse_bn_eval_stats": ("ppifppp", "i"),
     "cruse_bn_act_fwd": ("pppppppqiiip", "i"),
     "cruse_bn_act_bwd_reduce": ("ppppppqiiipip", "i"),
     "cruse_bn_act_bwd_apply": ("pppppppqiiiippppp", "i"),
-    "cruse_ln_fwd": ("pppppppqiifp", "i"),
+    "cruse_ln_fwd": ("ppppppppqiifp", "i"),
     "cruse_ln_bwd": ("pppppqiipppp", "i"),
     "cruse_gemm": ("iiiiipipipipiiiip", "i"),
     "cruse_gemm_bf16_nt": ("iiipqqpqqpqpiip", "i"),

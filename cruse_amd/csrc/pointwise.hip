@@ -155,9 +155,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* y, const f
 // itself; block 0 also publishes them (the backward pass reads them) and updates the running statistics.
 __global__ __launch_bounds__(256) void bn_fin_act_fwd_kernel(const float* y, const double* sums, int nrep, double inv_count, double unb,
                                                              float eps, float momentum, const float* gamma,
-                                                             const float* beta, const float* skip, float* out, float* mean_o,
-                                                             float* rstd_o, float* rmean, float* rvar, long long rows, int C,
-                                                             int F, int relu) {
+                                                             const float* beta, const float* skip, float* out, __bf16* out_bf,
+                                                             float* mean_o, float* rstd_o, float* rmean, float* rvar,
+                                                             long long rows, int C, int F, int relu) {
     extern __shared__ float tab[];  // [4][C]
     for (int c = threadIdx.x; c < C; c += 256) {
         double t1 = 0.0, t2 = 0.0;
@@ -194,6 +194,12 @@ __global__ __launch_bounds__(256) void bn_fin_act_fwd_kernel(const float* y, con
             o[e] = t + sk[e];
         }
         reinterpret_cast<float4*>(out)[i] = make_float4(o[0], o[1], o[2], o[3]);
+        if (out_bf) {                                     // the bf16 operand copy the next gate GEMM reads (saves a cast pass)
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
+            bf16x4_ b;
+            b[0] = (__bf16)o[0]; b[1] = (__bf16)o[1]; b[2] = (__bf16)o[2]; b[3] = (__bf16)o[3];
+            reinterpret_cast<bf16x4_*>(out_bf)[i] = b;
+        }
     }
 }
 
@@ -407,7 +413,7 @@ constexpr int LNV_MAXQ = 4;   // H <= 1024
 constexpr int LNV_NR = 2;     // forward; the backward kernel keeps one row per wave in flight (register budget)
 
 __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const float* x, const float* gamma, const float* beta,
-                                                         const float* res, float* y, float* mean, float* rstd,
+                                                         const float* res, float* y, __bf16* y_bf, float* mean, float* rstd,
                                                          long long rows, int H, float eps) {
     const int lane = threadIdx.x & 63, nq = H >> 2;
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -464,6 +470,12 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const float* x, const f
                     o.z = (v[k][e].z - m[k]) * rs * gm[e].z + bt[e].z + rv[k][e].z;
                     o.w = (v[k][e].w - m[k]) * rs * gm[e].w + bt[e].w + rv[k][e].w;
                     reinterpret_cast<float4*>(y + r * H)[q] = o;
+                    if (y_bf) {
+                        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
+                        bf16x4_ b;
+                        b[0] = (__bf16)o.x; b[1] = (__bf16)o.y; b[2] = (__bf16)o.z; b[3] = (__bf16)o.w;
+                        reinterpret_cast<bf16x4_*>(y_bf + r * H)[q] = b;
+                    }
                 }
             }
         }
@@ -687,6 +699,8 @@ inline int grid_for(long long n, int per_block, int cap = 4096) {
 
 }  // namespace
 
+extern "C" int cruse_cast_bf16_split(const float* x, void* y, void* y_lo, long long n, void* stream);
+
 #define ST(s) ((hipStream_t)(s))
 
 extern "C" int cruse_bn_stats(const float* y, long long rows, int C, int F, double* sums, int zeroed, void* stream) {
@@ -729,7 +743,7 @@ extern "C" int cruse_bn_act_fwd(const float* y, const float* mean, const float* 
 }
 
 extern "C" int cruse_bn_finalize_act_fwd(const float* y, const double* sums, int sum_replicas, long long count, float eps, float momentum,
-                                         const float* gamma, const float* beta, const float* skip, float* out,
+                                         const float* gamma, const float* beta, const float* skip, float* out, void* out_bf16,
                                          float* mean, float* rstd, float* running_mean, float* running_var,
                                          long long rows, int C, int F, int relu, void* stream) {
     CRUSE_REQUIRE(rows > 0 && C > 0 && C <= 256 && F > 0 && count > 0 && sum_replicas >= 1, CRUSE_E_SHAPE, "bn_finalize_act_fwd: bad shape");
@@ -737,7 +751,7 @@ extern "C" int cruse_bn_finalize_act_fwd(const float* y, const double* sums, int
     CRUSE_REQUIRE((running_mean == nullptr) == (running_var == nullptr) && mean && rstd, CRUSE_E_SHAPE, "bn_finalize_act_fwd: statistics");
     const double unb = count > 1 ? (double)count / (double)(count - 1) : 1.0;
     hipLaunchKernelGGL(bn_fin_act_fwd_kernel, dim3(grid_for(rows * C * F / 4, 1024)), dim3(256), 4 * C * sizeof(float), ST(stream),
-                       y, sums, sum_replicas, 1.0 / (double)count, unb, eps, momentum, gamma, beta, skip, out, mean, rstd, running_mean,
+                       y, sums, sum_replicas, 1.0 / (double)count, unb, eps, momentum, gamma, beta, skip, out, (__bf16*)out_bf16, mean, rstd, running_mean,
                        running_var, rows, C, F, relu);
     CRUSE_LAUNCH_CHECK("bn_finalize_act_fwd");
     return CRUSE_OK;
@@ -769,19 +783,21 @@ extern "C" int cruse_bn_act_bwd_apply(const float* dout, const float* y, const f
 }
 
 extern "C" int cruse_ln_fwd(const float* x, const float* gamma, const float* beta, const float* res,
-                            float* y, float* mean, float* rstd, long long rows, int H, int interleave_g,
+                            float* y, void* y_bf16, float* mean, float* rstd, long long rows, int H, int interleave_g,
                             float eps, void* stream) {
     CRUSE_REQUIRE(rows > 0 && H > 0 && H <= 64 * LN_MAXE, CRUSE_E_SHAPE, "ln_fwd: H=%d must be in 1..%d", H, 64 * LN_MAXE);
     CRUSE_REQUIRE(interleave_g >= 1 && H % interleave_g == 0, CRUSE_E_SHAPE, "ln_fwd: groups=%d must divide H=%d", interleave_g, H);
     const bool vec = interleave_g == 1 && H % 4 == 0 && H <= 256 * LNV_MAXQ &&
                      ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)res) & 15) == 0);
+    const bool bf_inline = vec && y_bf16 && (((uintptr_t)y_bf16 & 7) == 0);
     if (vec)
         hipLaunchKernelGGL(ln_fwd_vec_kernel, dim3(grid_for(rows, 16, 2048)), dim3(256), 0, ST(stream), x, gamma, beta,
-                           res, y, mean, rstd, rows, H, eps);
+                           res, y, bf_inline ? (__bf16*)y_bf16 : nullptr, mean, rstd, rows, H, eps);
     else
         hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid_for(rows, 4, 2048)), dim3(256), 0, ST(stream), x, gamma, beta, res, y,
                            mean, rstd, rows, H, interleave_g, eps);
     CRUSE_LAUNCH_CHECK("ln_fwd");
+    if (y_bf16 && !bf_inline) return cruse_cast_bf16_split(y, y_bf16, nullptr, rows * H, stream);     // interleaved form: one more pass
     return CRUSE_OK;
 }
 

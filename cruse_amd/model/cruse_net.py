@@ -239,6 +239,17 @@ def _bf16_gemm_path(prec, Hg: int) -> bool:
     return ops.prec_code(prec) == ops.PREC_BF16 and Hg % 32 == 0
 
 
+def _gi_x3_knob(Hg: int) -> int:
+    return int(os.environ.get("CRUSE_GI_X3", "7" if Hg <= 320 else "3"))
+
+
+def _gi_takes_bf16_copy(prec, Hg: int) -> bool:
+    """The gate projections read ONE bf16 plane of their activation operand, unpadded: the producer (BatchNorm / LayerNorm
+    kernel) can then write that copy itself instead of a separate cast pass."""
+    return (_bf16_gemm_path(prec, Hg) and Hg % 64 == 0 and not (_gi_x3_knob(Hg) & 4)
+            and os.environ.get("CRUSE_FUSE_CAST", "1") == "1")
+
+
 def _splitk(M: int, N: int, K: int) -> int:
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     sk = max(1, (512 + tiles - 1) // tiles)
@@ -249,7 +260,8 @@ def _splitk(M: int, N: int, K: int) -> int:
 # GGRU functional core on [B,T,H] rows
 # ======================================================================================
 def ggru_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], prefix: str, groups: int, prec,
-                 residual: Optional[torch.Tensor] = None, save: bool = True, residual_ready=None, late_leaves=None):
+                 residual: Optional[torch.Tensor] = None, save: bool = True, residual_ready=None, late_leaves=None,
+                 x_bf16=None):
     """x [B,T,H] -> (ln2(gru2(ln1(interleave(gru1(x))))) [+ residual], ctx).  cruse_net.py:37-55.
     With CRUSE_GRU_PIPES=2, batches of 16k clips run as half-batch pipelines on two streams (_Pipes); ctx then holds one
     context per slice."""
@@ -257,7 +269,7 @@ def ggru_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], prefix: str, group
     n = PIPES.count(B, groups, H // groups)
     if n == 1:
         return _ggru_forward_one(x, P, prefix, groups, prec, residual, save, residual_ready=residual_ready,
-                                 late_leaves=late_leaves)
+                                 late_leaves=late_leaves, x_bf16=x_bf16)
     if residual_ready is not None:
         residual_ready()
     Bh = B // n
@@ -286,7 +298,7 @@ def ggru_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], prefix: str, group
 
 
 def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=None, slot=0, xcd_rot=0, pre_done=None,
-                      residual_ready=None, late_leaves=None):
+                      residual_ready=None, late_leaves=None, x_bf16=None):
     """residual_ready(): called right before the residual is read (the last layer norm) -- the caller may still be
     producing it on a side stream while the recurrences run."""
     B, T, H = x.shape
@@ -298,18 +310,20 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
 
     fast = _bf16_gemm_path(prec, Hg)
 
-    def layer(inp, lname):
+    def layer(inp, lname, inp_bf=None):
         gi = torch.empty(B, T, g * 3 * Hg, device=x.device, dtype=torch.float32)
         # The forward projection corrects the bf16 rounding of W_ih (a second pass with its low plane): that rounding
         # dominates the forward error of the bf16 mode (enhanced spectrum 1.25e-3 -> 5.1e-4 rel-L2 on fixture G6;
         # correcting x too only reaches 4.8e-4).  CRUSE_GI_X3: bit 0 / 1 = layer 1 / 2 corrected, bit 2 = also split x.
         # Default: W_ih split on both layers; x split as well when Hg <= 320 (K is then short enough that the third pass
         # costs < 0.04 ms per step, and the grouped configurations need it for the 1e-3 bar at T = 401: DESIGN.md section 2)
-        knob = int(os.environ.get("CRUSE_GI_X3", "7" if Hg <= 320 else "3"))
+        knob = _gi_x3_knob(Hg)
         x3 = (knob >> (0 if lname == "gru_list1" else 1)) & 1
         split_x = bool(knob & 4) and x3
         pad = 64 if Hg % 64 else 0
-        if fast and split_x:
+        if inp_bf is not None:                   # written by the kernel that produced inp (_gi_takes_bf16_copy)
+            inp_hi, inp_lo = inp_bf, None
+        elif fast and split_x:
             inp_hi, inp_lo = ops.cast_bf16_padded(inp, pad=pad, split=True)
         else:
             inp_hi, inp_lo = (ops.cast_bf16_padded(inp, pad=pad) if fast else None), None
@@ -333,8 +347,9 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
         return SIDE.release_around(lambda: ops.gru_seq_fwd(gi, w_hh, b_hh, B, T, g, Hg, prec, save=save, slot=slot,
                                                            xcd_rot=xcd_rot))
 
-    h1, c1, a1, z1 = layer(x, "gru_list1")
-    l1, m1, s1 = ops.ln_fwd(h1, P[prefix + "ln1.weight"], P[prefix + "ln1.bias"], None, rows, H, g, save=save)
+    h1, c1, a1, z1 = layer(x, "gru_list1", x_bf16)
+    l1_bf = torch.empty(rows * H, device=x.device, dtype=torch.bfloat16) if _gi_takes_bf16_copy(prec, Hg) else None
+    l1, m1, s1 = ops.ln_fwd(h1, P[prefix + "ln1.weight"], P[prefix + "ln1.bias"], None, rows, H, g, save=save, out_bf16=l1_bf)
     # The K-tiled time-major bf16 copies of x, h1, l1, h2 -- the K operands of the four weight-gradient GEMMs -- depend on
     # the forward pass only.  From the first backward recurrence on, the side streams' queue is what the optimizer step
     # waits for, while in the forward pass they idle: three of the copies are made beside the second forward recurrence,
@@ -349,7 +364,7 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
             ops.transpose_bf16(h1, rows, H, shift_T=T, out=h1T)
             ops.transpose_bf16(l1, rows, H, out=l1T)
         SIDE.defer(t_layer1, x, h1, l1, xT, h1T, l1T, kind=1, lane=2)
-    h2, c2, a2, z2 = layer(l1, "gru_list2")
+    h2, c2, a2, z2 = layer(l1, "gru_list2", l1_bf)
     if residual_ready is not None:
         residual_ready()
     out, m2, s2 = ops.ln_fwd(h2, P[prefix + "ln2.weight"], P[prefix + "ln2.bias"], residual, rows, H, 1, save=save, out=out)
@@ -556,7 +571,7 @@ _PENDING_COUNTERS = []      # num_batches_tracked buffers of this forward: bumpe
 _FUSE_BN_STATS = os.environ.get("CRUSE_FUSE_BN_STATS", "1") != "0"
 
 
-_INLINE = int(os.environ.get("CRUSE_INLINE", "0"))      # backward leaves kept on the main stream (unet2_backward)
+_INLINE = int(os.environ.get("CRUSE_INLINE", "8"))      # backward leaves kept on the main stream (unet2_backward)
 # dW operand transposes: 0 inside each layer's weight-gradient leaf, 1 layer 1's with the first backward recurrence,
 # 2 all four in the forward pass (beside the second forward recurrence / the decoder)
 _EARLY_T = int(os.environ.get("CRUSE_EARLY_T", "2"))
@@ -568,7 +583,7 @@ def _flush_counters():
         _PENDING_COUNTERS.clear()
 
 
-def _bn_act(y, rows, C, F, P, Bf, name, training, update_running, skip=None, sums=None):
+def _bn_act(y, rows, C, F, P, Bf, name, training, update_running, skip=None, sums=None, out_bf16=None):
     """BatchNorm2d (train: batch statistics, running stats updated; eval: running stats) + ReLU (+ skip) -> (out, mean, rstd).
     sums: the batch sums of y when the conv that produced it has already accumulated them (ops.conv_*_bnstats)."""
     gamma, beta = P[name + ".weight"], P[name + ".bias"]
@@ -580,7 +595,7 @@ def _bn_act(y, rows, C, F, P, Bf, name, training, update_running, skip=None, sum
         if update_running:
             _PENDING_COUNTERS.append(Bf[name + ".num_batches_tracked"])
         return ops.bn_finalize_act_fwd(y, sums, rows * F, BN_EPS, BN_MOMENTUM, gamma, beta, skip, rows, C, F, relu=True,
-                                       running_mean=rm, running_var=rv)
+                                       running_mean=rm, running_var=rv, out_bf16=out_bf16)
     mean, rstd = ops.bn_eval_stats(Bf[name + ".running_mean"], Bf[name + ".running_var"], BN_EPS)
     return ops.bn_act_fwd(y, mean, rstd, gamma, beta, skip, rows, C, F, relu=True), mean, rstd
 
@@ -609,7 +624,11 @@ def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, tor
         else:
             y, sums = ops.conv_gather(cur, P[f"conv{k}.weight"], P[f"conv{k}.bias"], B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k],
                                       KT=2, S=2, pad=1, prec=prec), None
-        e, mean, rstd = _bn_act(y, rows, ch[k], Fk[k], P, Bf, f"bn{k}", training, update_running, sums=sums)
+        e_bf = None
+        if k == L and training and PIPES.count(B, groups, ch[L] * Fk[L] // groups) == 1 and \
+                _gi_takes_bf16_copy(prec, ch[L] * Fk[L] // groups):
+            e_bf = torch.empty(rows * ch[L] * Fk[L], device=x.device, dtype=torch.bfloat16)     # gate GEMM 1's operand
+        e, mean, rstd = _bn_act(y, rows, ch[k], Fk[k], P, Bf, f"bn{k}", training, update_running, sums=sums, out_bf16=e_bf)
         s = torch.empty(B, T, ch[k], Fk[k], device=x.device, dtype=torch.float32)
 
         def skip_conv(e=e, s=s, k=k):
@@ -622,7 +641,7 @@ def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, tor
     H = ch[L] * Fk[L]
     late = []
     u, gctx = ggru_forward(cur.view(B, T, H), P, "gru.", groups, prec, residual=ss[L].view(B, T, H), save=save,
-                           residual_ready=SIDE.join, late_leaves=late)
+                           residual_ready=SIDE.join, late_leaves=late, x_bf16=e_bf)
     u = u.view(B, T, ch[L], Fk[L])
     SIDE.join()
     for fn, keep in late:                               # beside the decoder: nothing on the main stream waits for these
@@ -758,7 +777,12 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
 
         def leaf_enc(dy=dy, k=k):
             ops.conv_wgrad(dy, es[k - 1], G[f"conv{k}.weight"], B, T, ch[k], Fk[k], ch[k - 1], Fk[k - 1], KT=2, S=2, pad=1, prec=prec)
-        SIDE.run(leaf_enc, dy, lane=0)
+        # the optimizer step waits for the side queue, not for the main stream: the LAST levels' weight gradients run on
+        # the main stream itself (_INLINE bits 3, 4: level 1, level 2), beside what is still queued on the side
+        if (k == 1 and _INLINE & 8) or (k == 2 and _INLINE & 16):
+            leaf_enc()
+        else:
+            SIDE.run(leaf_enc, dy, lane=0)
         if k > 1:
             de = ops.conv_scatter2(dy, P[f"conv{k}.weight"], None, B, T, ch[k], Fk[k], ch[k - 1], KT=2, pad=1,
                                    out=de_pre[k - 1], accum=True, prec=dprec)

@@ -226,7 +226,7 @@ BN_STAT_REPLICAS = 16      # CRUSE_BN_STAT_REPLICAS (include/cruse_hip.h): layou
 
 
 def bn_finalize_act_fwd(y, sums, count, eps, momentum, gamma, beta, skip, rows, C, F, relu=True, running_mean=None,
-                        running_var=None):
+                        running_var=None, out_bf16=None):
     """bn_finalize + bn_act_fwd in one launch -> (out, mean, rstd).  sums: [2*C] (bn_stats) or [replicas, 2*C]
     (conv_*_bnstats); the statistic is the sum over the replicas."""
     if sums.numel() % (2 * C) != 0:
@@ -234,7 +234,9 @@ def bn_finalize_act_fwd(y, sums, count, eps, momentum, gamma, beta, skip, rows, 
     out = torch.empty_like(y)
     mean = torch.empty(C, device=y.device, dtype=torch.float32)
     rstd = torch.empty(C, device=y.device, dtype=torch.float32)
-    check(lib.cruse_bn_finalize_act_fwd(_p(y), _p(sums), sums.numel() // (2 * C), count, eps, momentum, _p(gamma), _p(beta), _p(skip), _p(out), _p(mean),
+    if out_bf16 is not None and (out_bf16.dtype != torch.bfloat16 or out_bf16.numel() < y.numel()):
+        raise RuntimeError("bn_finalize_act_fwd: out_bf16 must be a bf16 tensor of at least y.numel() elements")
+    check(lib.cruse_bn_finalize_act_fwd(_p(y), _p(sums), sums.numel() // (2 * C), count, eps, momentum, _p(gamma), _p(beta), _p(skip), _p(out), _p(out_bf16), _p(mean),
                                         _p(rstd), _p(running_mean), _p(running_var), rows, C, F, 1 if relu else 0, _stream()))
     return out, mean, rstd
 
@@ -274,11 +276,13 @@ def bn_act_bwd(dout, y, mean, rstd, gamma, beta, rows, C, F, relu, training, dga
 
 
 # ---------------------------------------------------------------- LayerNorm
-def ln_fwd(x, gamma, beta, res, rows, H, interleave_g=1, eps=1e-5, save=True, out=None):
+def ln_fwd(x, gamma, beta, res, rows, H, interleave_g=1, eps=1e-5, save=True, out=None, out_bf16=None):
     y = torch.empty_like(x) if out is None else out
     mean = torch.empty(rows, device=x.device, dtype=torch.float32) if save else None
     rstd = torch.empty(rows, device=x.device, dtype=torch.float32) if save else None
-    check(lib.cruse_ln_fwd(_p(x), _p(gamma), _p(beta), _p(res), _p(y), _p(mean), _p(rstd), rows, H, interleave_g,
+    if out_bf16 is not None and (out_bf16.dtype != torch.bfloat16 or out_bf16.numel() < x.numel()):
+        raise RuntimeError("ln_fwd: out_bf16 must be a bf16 tensor of at least x.numel() elements")
+    check(lib.cruse_ln_fwd(_p(x), _p(gamma), _p(beta), _p(res), _p(y), _p(out_bf16), _p(mean), _p(rstd), rows, H, interleave_g,
                            eps, _stream()))
     return y, mean, rstd
 

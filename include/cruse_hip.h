@@ -138,12 +138,14 @@ int cruse_bn_eval_stats(const float* running_mean, const float* running_var, int
 int cruse_bn_act_fwd(const float* y, const float* mean, const float* rstd, const float* gamma,
                      const float* beta, const float* skip, float* out,
                      long long rows, int C, int F, int relu, void* stream);
-/* cruse_bn_finalize + cruse_bn_act_fwd as one launch (training): mean / rstd come from the batch sums inside the kernel,
+/* out_bf16 (nullable): also a bf16 copy of out, [rows, C*F] -- the operand of the gate GEMM that reads the encoder's last
+ * level, saving a cast pass.
+ * cruse_bn_finalize + cruse_bn_act_fwd as one launch (training): mean / rstd come from the batch sums inside the kernel,
  * are also written out (the backward pass needs them) and the running statistics are updated.  sums is
  * [sum_replicas][2*C] and the statistic the sum over the replicas: 1 after cruse_bn_stats, CRUSE_BN_STAT_REPLICAS after
  * cruse_conv_*_bnstats. */
 int cruse_bn_finalize_act_fwd(const float* y, const double* sums, int sum_replicas, long long count, float eps, float momentum,
-                              const float* gamma, const float* beta, const float* skip, float* out,
+                              const float* gamma, const float* beta, const float* skip, float* out, void* out_bf16,
                               float* mean, float* rstd, float* running_mean, float* running_var,
                               long long rows, int C, int F, int relu, void* stream);
 /* sums[0..C) = sum g, sums[C..2C) = sum g*xhat with g = dout * [bn(y) > 0]; `zeroed` as for cruse_bn_stats */
@@ -163,9 +165,10 @@ int cruse_bn_act_bwd_apply(const float* dout, const float* y, const float* mean,
 
 /* y[row, P(c)] = (x[row,c]-mean)*rstd*gamma[P(c)] + beta[P(c)] (+ res[row,P(c)])
  * P(i*Hg + j) = j*g + i with Hg = H/g is the stack(dim=-1)+flatten of cruse_net.py:43-45
- * (interleave_g = g; 1 = identity / the plain cat of :49-50). eps = 1e-5. */
+ * (interleave_g = g; 1 = identity / the plain cat of :49-50). eps = 1e-5.
+ * y_bf16 (nullable): also a bf16 copy of y [rows, H] (the next gate GEMM's operand). */
 int cruse_ln_fwd(const float* x, const float* gamma, const float* beta, const float* res,
-                 float* y, float* mean, float* rstd, long long rows, int H, int interleave_g,
+                 float* y, void* y_bf16, float* mean, float* rstd, long long rows, int H, int interleave_g,
                  float eps, void* stream);
 int cruse_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                  const float* gamma, long long rows, int H, int interleave_g,

@@ -680,3 +680,23 @@ def test_gemm_bf16x3_forward_projection(ops):
         C1 = torch.zeros(rows, 3 * Hg).cuda()
         ops.gemm_bf16_nt(rows, 3 * Hg, 192, x_hi, i * Hg, 2 * Hg, w_hi, 0, 64, C1, 0, 3 * Hg, bias=b, b_kstride=3 * Hg * 64)
         assert rel_l2(C1, ref) > 50 * rel_l2(C, ref)                # the plain bf16 product is two orders coarser
+
+
+def test_bf16_operand_copies_from_bn_and_ln(ops):
+    """bn_finalize_act_fwd / ln_fwd also write the bf16 copy the next gate GEMM reads: identical to a cast of their f32
+    output (vectorised LayerNorm in-kernel, the group-interleaved form through the cast kernel)."""
+    gen = torch.Generator().manual_seed(81)
+    rows, C, Fq = 37, 64, 10
+    y = torch.randn(rows, C, Fq, generator=gen).cuda()
+    gam = (torch.rand(C, generator=gen) + 0.5).cuda(); bet = torch.randn(C, generator=gen).cuda()
+    sums = ops.bn_stats(y, rows, C, Fq)
+    bf = torch.empty(rows * C * Fq, dtype=torch.bfloat16).cuda()
+    out, _, _ = ops.bn_finalize_act_fwd(y, sums, rows * Fq, 1e-5, 0.1, gam, bet, None, rows, C, Fq, out_bf16=bf)
+    assert torch.equal(bf.view_as(out), out.to(torch.bfloat16))
+    for H, g in ((640, 1), (640, 4)):
+        x = torch.randn(rows, H, generator=gen).cuda()
+        w = (torch.rand(H, generator=gen) + 0.5).cuda(); b = torch.randn(H, generator=gen).cuda()
+        bf = torch.empty(rows * H, dtype=torch.bfloat16).cuda()
+        yl, _, _ = ops.ln_fwd(x, w, b, None, rows, H, g, out_bf16=bf)
+        y0, _, _ = ops.ln_fwd(x, w, b, None, rows, H, g)
+        assert torch.equal(yl, y0) and torch.equal(bf.view_as(yl), yl.to(torch.bfloat16))
