@@ -358,11 +358,16 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
     if fwd_T:
         ldT = (rows + 63) // 64 * 64
         xT, h1T, l1T, h2T = (torch.empty(ldT // 64, H, 64, device=x.device, dtype=torch.bfloat16) for _ in range(4))
+        w_ts = {}                                # K-tiled W_ih^T of both layers: the B operand of the backward dX GEMMs
 
         def t_layer1(x=x, h1=h1, l1=l1):
             ops.transpose_bf16(x, rows, H, out=xT)
             ops.transpose_bf16(h1, rows, H, shift_T=T, out=h1T)
             ops.transpose_bf16(l1, rows, H, out=l1T)
+            for lname in ("gru_list1", "gru_list2"):
+                for i in range(g):
+                    w_ts[(lname, i)] = ops.transpose_bf16(P[f"{prefix}{lname}.{i}.weight_ih_l0"], 3 * Hg, Hg)
+        ctx["w_ts"] = w_ts
         SIDE.defer(t_layer1, x, h1, l1, xT, h1T, l1T, kind=1, lane=2)
     h2, c2, a2, z2 = layer(l1, "gru_list2", l1_bf)
     if residual_ready is not None:
@@ -487,7 +492,9 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
         dinp, acc_dx = dinp_buffer(dout_h, need_dinp, last)
         if need_dinp:
             for i, nm in enumerate(names):
-                w_t = ops.transpose_bf16(P[nm + "weight_ih_l0"], 3 * Hg, Hg)          # K-tiled [ceil(3*Hg/64), Hg, 64]
+                w_t = ctx.get("w_ts", {}).get((lname, i))                             # made in the forward pass (side stream)
+                if w_t is None:
+                    w_t = ops.transpose_bf16(P[nm + "weight_ih_l0"], 3 * Hg, Hg)      # K-tiled [ceil(3*Hg/64), Hg, 64]
                 ops.gemm_bf16_nt(rows, Hg, w_t.shape[0] * 64, dgi, i * 3 * Hg, 3 * H, w_t, 0, 64, dinp, i * Hg, H,
                                  accumulate=acc_dx, b_kstride=Hg * 64)
         if last and defer_last:
