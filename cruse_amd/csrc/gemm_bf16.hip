@@ -318,8 +318,10 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
     CRUSE_REQUIRE(splitk == 1 || accumulate, CRUSE_E_SHAPE, "gemm_bf16_nt: split-K adds into C (accumulate = 1)");
     const dim3 grid((unsigned)nblk);
     hipStream_t st = (hipStream_t)stream;
-    bool deep = kt_chunk >= 64;                // long k-loops: three stages, one block per CU
-    { const char* e = getenv("CRUSE_GB_DEEP"); if (e) deep = atoi(e) != 0; }          // profiling override
+    int deep_min = 64;                         // long k-loops: three stages, one block per CU
+    { const char* e = getenv("CRUSE_GB_DEEP_MIN"); if (e && atoi(e) > 0) deep_min = atoi(e); }      // profiling knobs
+    bool deep = kt_chunk >= deep_min;
+    { const char* e = getenv("CRUSE_GB_DEEP"); if (e) deep = atoi(e) != 0; }
     const size_t lds = (size_t)(deep ? 3 : 2) * 2 * TILE_BYTES;
 #define CRUSE_GB_LAUNCH(MODE, NST)                                                                               \
     do {                                                                                                         \

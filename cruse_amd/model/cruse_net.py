@@ -224,9 +224,12 @@ PIPES = _Pipes()
 
 
 def _splitk_bf16(M: int, N: int, K: int) -> int:
-    """k-slices for gemm_bf16_nt's deep-pipeline form (one block per CU): fill the 256 CUs in one round.
-    CRUSE_DW_XCDK=<n>: n k-slices pinned to XCDs instead (negative splitk of cruse_gemm_bf16_nt) -- measured, see DESIGN 6."""
-    x = int(os.environ.get("CRUSE_DW_XCDK", "0"))
+    """k-slices of the K = 25 664 weight-gradient GEMMs.  Default: 8 slices PINNED to XCDs (negative splitk of
+    cruse_gemm_bf16_nt) -- every XCD walks one k-range over all output tiles, so each operand byte leaves HBM about once
+    (PMC: 217 MB per launch against 506 MB with (k-slice, n-tile) units dealt round-robin; 14.6 instead of 15.9 GB per
+    step) for +0.02 ms of step time.  CRUSE_DW_XCDK=0: the round-robin form that fills the 256 CUs in one round with
+    one block per CU (the fastest launch alone: 142 vs 206 us); CRUSE_DW_XCDK=<n>: n pinned slices."""
+    x = int(os.environ.get("CRUSE_DW_XCDK", "8"))
     if x > 1:
         return -x
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
