@@ -229,10 +229,11 @@ def _splitk_bf16(M: int, N: int, K: int) -> int:
     (PMC: 217 MB per launch against 506 MB with (k-slice, n-tile) units dealt round-robin; 14.6 instead of 15.9 GB per
     step) for +0.02 ms of step time.  CRUSE_DW_XCDK=0: the round-robin form that fills the 256 CUs in one round with
     one block per CU (the fastest launch alone: 142 vs 206 us); CRUSE_DW_XCDK=<n>: n pinned slices."""
-    x = int(os.environ.get("CRUSE_DW_XCDK", "8"))
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    env = os.environ.get("CRUSE_DW_XCDK")
+    x = int(env) if env is not None else (8 if tiles * 8 >= 192 else 0)      # few output tiles (grouped GRUs): keep round-robin
     if x > 1:
         return -x
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
     return max(1, min(256 // tiles, K // 1024))
 
 
