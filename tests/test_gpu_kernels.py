@@ -528,7 +528,8 @@ def test_gru_gate_grads_bf16_matches_f32_form(ops, G, Hg):
 
 
 @pytest.mark.parametrize("H,B,T", [(640, 9, 12), (128, 8, 7), (256, 3, 5), (384, 16, 6), (512, 1, 4), (160, 10, 8),
-                                   (96, 4, 6), (32, 8, 5), (288, 7, 5)])
+                                   (96, 4, 6), (32, 8, 5), (288, 7, 5),
+                                   (640, 8, 1), (640, 5, 2), (640, 8, 3), (320, 3, 1), (320, 11, 2)])   # loader / helper wave prologues
 def test_gru_bwd_reduce_scatter_matches_all_gather_form(ops, H, B, T):
     """bf16 mode has two backward recurrence kernels (gru.hip): both must give the same dh from the same inputs."""
     import os
@@ -562,7 +563,8 @@ def test_gru_bwd_reduce_scatter_matches_all_gather_form(ops, H, B, T):
 
 
 @pytest.mark.parametrize("H,B,T", [(640, 9, 12), (128, 8, 7), (256, 3, 5), (384, 16, 6), (512, 1, 4), (160, 10, 8),
-                                   (96, 4, 6), (32, 8, 5), (288, 7, 5)])
+                                   (96, 4, 6), (32, 8, 5), (288, 7, 5),
+                                   (640, 8, 1), (640, 5, 2), (640, 8, 3), (320, 3, 1), (320, 11, 2)])   # loader / helper wave prologues
 def test_gru_fwd_lean_matches_generic_kernel(ops, H, B, T):
     """bf16 mode has two forward recurrence kernels (gru.hip): same algorithm, so the same h / coefficients."""
     import os
