@@ -41,7 +41,7 @@ class _SideStream:
         # lane -> stream: leaves are tagged 0 conv weight gradients, 1 skip-conv leaves, 2 GRU dW GEMMs; CRUSE_SIDE_MAP
         # "abc" sends lane i to side stream int(abc[i]) (needs that many streams); unset: round-robin over nside streams
         self.env_map = os.environ.get("CRUSE_SIDE_MAP")
-        self.set_map(self.env_map if self.env_map is not None else "012")
+        self.set_map(self.env_map if self.env_map is not None else "000")
         self.streams = {}
         self.keep = []
         self.deferred = []
@@ -53,9 +53,10 @@ class _SideStream:
         self.after_release = None      # one-shot callback run by the next release_around() once its leaves are issued
 
     def set_map(self, m: str, force: bool = False) -> None:
-        """lane -> side stream assignment.  Measured on the bench step: replayed from a HIP graph the three lanes
-        are best on three streams ("012": 7.56 vs 7.78 ms on one); launched eagerly one stream is best ("000": 7.38 vs 7.46).
-        An explicit CRUSE_SIDE_MAP wins unless force."""
+        """lane -> side stream assignment.  One side stream for all three lanes is the measured best in both launch forms
+        on the current kernels (graph replay 6.21 ms against 6.42 on three streams, eager 6.05 against 6.43; at the start
+        of round 2, on slower leaves, three streams won under graph replay: 7.56 vs 7.78).  An explicit CRUSE_SIDE_MAP
+        wins unless force."""
         if self.env_map is not None and not force:
             m = self.env_map
         self.lane_map = [int(c) for c in m] if m else None
@@ -63,7 +64,7 @@ class _SideStream:
             self.nside = max(self.nside, max(self.lane_map) + 1)
 
     def for_mode(self, use_graph: bool) -> None:
-        self.set_map("012" if use_graph else "000")
+        self.set_map("000")
 
     def _sides(self):
         dev = torch.cuda.current_device()
