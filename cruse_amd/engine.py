@@ -231,17 +231,19 @@ class TrainEngine:
         T = ops.stft_frames(L, self.hop)
         nre, nim, mag = ops.stft(noisy, self.n_fft, self.hop, mag_bins=self.f_net, mag_eps=1e-8)
         cre = cim = cmag = None
-        # the clean spectrum is only needed by the loss: a leaf beside the encoder (joined by unet2_forward before the decoder)
+        # the clean spectrum is only needed by the loss: a leaf queued for the first forward recurrence (beside the encoder
+        # it shared HBM with the 1 -> 8 conv: 60 vs 33 us, plus an event record on the main stream); joined by
+        # unet2_forward before the decoder
         if self.loss != "si_snr":
             # (outputs are allocated here, on the main stream, so that the leaf itself allocates nothing)
             if self.loss == "wo_male":
                 cmag = torch.empty(B, T, self.f_stft, device=clean.device, dtype=torch.float32)
-                SIDE.run(lambda: ops.stft(clean, self.n_fft, self.hop, want_ri=False, mag_eps=0.0, out=(None, None, cmag)),
-                         clean, cmag, lane=0)
+                SIDE.defer(lambda: ops.stft(clean, self.n_fft, self.hop, want_ri=False, mag_eps=0.0, out=(None, None, cmag)),
+                           clean, cmag, kind=1, lane=0)
             else:
                 cre = torch.empty(B, T, self.f_stft, device=clean.device, dtype=torch.float32)
                 cim = torch.empty_like(cre)
-                SIDE.run(lambda: ops.stft(clean, self.n_fft, self.hop, out=(cre, cim, None)), clean, cre, cim, lane=0)
+                SIDE.defer(lambda: ops.stft(clean, self.n_fft, self.hop, out=(cre, cim, None)), clean, cre, cim, kind=1, lane=0)
         mask, ctx = unet2_forward(mag.view(B, 1, T, self.f_net), self.flat.P, self.Bf, self.model.ch,
                                   self.model.rnn_groups, self.prec, training=training, save=training,
                                   update_running=training)
