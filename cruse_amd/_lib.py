@@ -54,7 +54,7 @@ SIGNATURES = {
     "cruse_gru_seq_fwd": ("pppppppiiiiipp", "i"),
     "cruse_gru_seq_bwd": ("pppppiiiiipp", "i"),
     "cruse_gru_seq_fwd_on": ("pppppppiiiiippip", "i"),
-    "cruse_gru_seq_bwd_on": ("pppppiiiiippip", "i"),
+    "cruse_gru_seq_bwd_on": ("pppppppiiiiippip", "i"),
     "cruse_gru_gate_grads": ("pppppqiiip", "i"),
     "cruse_gru_gate_grads_bf16": ("pppppqppqiip", "i"),
     "cruse_mask_loss_fwd": ("ppppqiiffpppppp", "i"),

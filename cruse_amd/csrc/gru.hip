@@ -47,6 +47,7 @@ struct GruArgs {
     const float* gi; float* h; void* coef; float* an; float* z;
     // backward
     const float* dout; const void* coefs; const float* zs; float* dh;
+    const float* ans; void* dgi;      // optional (reduce-scatter kernel): a_n rows in, dgi = dh * (c_r, c_z, a_n) rows out
     GruPtrs p;
     int B, T, G, Hg, Bg, nchains, P, bg_off;
     unsigned long long* xid;          // XCD-id handshake granules [chain][64]
@@ -991,6 +992,8 @@ __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
     __shared__ __attribute__((aligned(16))) __bf16 panel[2][16 * KP];
     __shared__ __attribute__((aligned(16))) float op_d[4][8][32], op_z[4][8][32];       // ring slot = iteration & 3
     __shared__ __attribute__((aligned(16))) __bf16 op_c[4][8][96];
+    __shared__ __attribute__((aligned(16))) float op_a[4][8][32];                       // a_n rows (only when dgi is written)
+    __shared__ __attribute__((aligned(16))) float dh_l[2][8][32];                       // dh of iteration k in parity k & 1
     const int Hg = a.Hg, H = a.G * Hg, K3 = 3 * Hg, P = a.P, NTt = Hg >> 4;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int chain, part;
@@ -1029,16 +1032,20 @@ __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
             cv[i2] = (unsigned)((((long long)(b0 + (cl < nb ? cl : 0)) * a.T * a.G + grp) * K3 + gate * Hg + u0 + 8 * chk) * 2);
             cdst[i2] = (unsigned)(cl * 96 + gate * 32 + chk * 8);
         }
-        struct OpSet { u32x4 d, z, c0, c1; };
+        const bool want_dgi = a.dgi != nullptr;
+        const __amdgpu_buffer_rsrc_t rs_an = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ans), 0, a.ans ? tot_f32 : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_dgi = __builtin_amdgcn_make_buffer_rsrc(a.dgi, 0, a.dgi ? tot_cf : 0u, 0x00020000);
+        struct OpSet { u32x4 d, z, c0, c1, an; };
         auto issue = [&](int j, OpSet& o) {
             const u32x4 zero = {0u, 0u, 0u, 0u};
-            o.d = zero; o.z = zero; o.c0 = zero; o.c1 = zero;
+            o.d = zero; o.z = zero; o.c0 = zero; o.c1 = zero; o.an = zero;
             if (j >= a.T || nodata) return;
             const unsigned st = (unsigned)(a.T - 1 - j);
             o.d = __builtin_amdgcn_raw_buffer_load_b128(rs_dout, dv, st * frame_bytes, 0);
             if (j > 0) o.z = __builtin_amdgcn_raw_buffer_load_b128(rs_z, dv, (st + 1u) * frame_bytes, 0);
             o.c0 = __builtin_amdgcn_raw_buffer_load_b128(rs_cf, cv[0], st * crow_bytes, 0);
             if (cok[1]) o.c1 = __builtin_amdgcn_raw_buffer_load_b128(rs_cf, cv[1], st * crow_bytes, 0);
+            if (want_dgi) o.an = __builtin_amdgcn_raw_buffer_load_b128(rs_an, dv, st * frame_bytes, 0);
         };
         auto put = [&](int j, const OpSet& o) {
             const int slot = j & 3;
@@ -1046,6 +1053,35 @@ __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
             *reinterpret_cast<u32x4*>(&op_z[slot][lc][4 * lq]) = o.z;
             *reinterpret_cast<u32x4*>(&op_c[slot][0][0] + cdst[0]) = o.c0;
             if (cok[1]) *reinterpret_cast<u32x4*>(&op_c[slot][0][0] + cdst[1]) = o.c1;
+            if (want_dgi) *reinterpret_cast<u32x4*>(&op_a[slot][lc][4 * lq]) = o.an;
+        };
+        // Results of iteration j (time T-1-j), one iteration behind the compute waves: dh_s as 16-byte stores, and -- when
+        // asked for -- the gate gradients dgi_s = dh_s * (c_r, c_z, a_n) in bf16, the A operand of dX = dgi W_ih: the
+        // separate gate-gradient pass then only has to make the time-major copies for the weight-gradient GEMMs, off the
+        // main stream.  lane = (clip lc, unit quad lq).
+        const unsigned gi_v = (unsigned)((((long long)(b0 + (lc < nb ? lc : 0)) * a.T * a.G + grp) * K3 + u0 + 4 * lq) * 2);
+        auto flush = [&](int j) {
+            if (lc >= nb) return;
+            const unsigned st = (unsigned)(a.T - 1 - j);
+            const float4 d4 = *reinterpret_cast<const float4*>(&dh_l[j & 1][lc][4 * lq]);
+            const u32x4 dw = {__float_as_uint(d4.x), __float_as_uint(d4.y), __float_as_uint(d4.z), __float_as_uint(d4.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(dw, rs_dh, dv, st * frame_bytes, 0);
+            if (want_dgi) {
+                const int slot = j & 3;
+                typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
+                const bf16x4_ cr = *reinterpret_cast<const bf16x4_*>(&op_c[slot][lc][4 * lq]);
+                const bf16x4_ cz = *reinterpret_cast<const bf16x4_*>(&op_c[slot][lc][32 + 4 * lq]);
+                const float4 a4 = *reinterpret_cast<const float4*>(&op_a[slot][lc][4 * lq]);
+                const float d[4] = {d4.x, d4.y, d4.z, d4.w}, an_[4] = {a4.x, a4.y, a4.z, a4.w};
+                bf16x4_ o0, o1, o2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o0[e] = (__bf16)(d[e] * (float)cr[e]); o1[e] = (__bf16)(d[e] * (float)cz[e]); o2[e] = (__bf16)(d[e] * an_[e]);
+                }
+                __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o0), rs_dgi, gi_v, st * crow_bytes, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o1), rs_dgi, gi_v + (unsigned)Hg * 2u, st * crow_bytes, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o2), rs_dgi, gi_v + (unsigned)Hg * 4u, st * crow_bytes, 0);
+            }
         };
         OpSet s0, s1;
         issue(0, s0); issue(1, s1);
@@ -1058,13 +1094,17 @@ __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
         for (int k = 0; k < a.T; k += 2) {
             put(k + 2, s0);
             issue(k + 4, s0);
+            if (k > 0) flush(k - 1);
             if (a.T - 1 - k == 0) break;
             __syncthreads();
             put(k + 3, s1);
             issue(k + 5, s1);
+            flush(k);
             if (a.T - 2 - k == 0) break;
             __syncthreads();
         }
+        __syncthreads();                                // the last iteration's dh is in LDS
+        flush(a.T - 1);
         return;
     }
 
@@ -1087,7 +1127,6 @@ __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
     const int quarter = tid & 3, pp = (tid >> 2) & 7, bl = tid >> 5;
     const bool active = bl < nb;
     const int blc = active ? bl : 0;                                  // inactive threads shadow clip 0 (loads only)
-    const unsigned own_v = (unsigned)(((long long)(b0 + blc) * a.T * H + grp * Hg + u0 + 4 * pp + quarter) * 4);   // + s*frame_bytes
     unsigned sweep_v[NL];
     bool sweep_ok[NL];                                                // the producer exists (P % 4 != 0: the last ones may not)
 #pragma unroll
@@ -1113,7 +1152,6 @@ __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
 
     float dh = 0.f, dd = 0.f, zz = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;  // operands of the current step (time s)
     const int ou = 4 * pp + quarter;                                  // own unit inside the workgroup's 32
-    float sv_dh = 0.f;
     bool nowait = a.dbg >= 1 && a.dbg < 7;
     const bool plain = a.dbg != 9 && team_shares_xcd(a.xid + (size_t)chain * 64, P, part, a.status, tid);
     __syncthreads();                                                  // ring slots 0 and 1 are filled
@@ -1153,13 +1191,11 @@ __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
                 sm[e] += __uint_as_float(dpp_xor2(__float_as_uint(sm[e])));
             }
             m = quarter == 0 ? sm[0] : quarter == 1 ? sm[1] : quarter == 2 ? sm[2] : sm[3];
-            // deferred save of dh_{s+1}: issued after the sweep has returned, old by the time of the next one
-            if (active) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv_dh), rs_dh, own_v, (unsigned)(s + 1) * frame_bytes, 0);
         }
         dh = dd + zz * dh + m;
-        sv_dh = dh;
         __bf16* pn = panel[k & 1];
         if (active) {
+            dh_l[k & 1][bl][ou] = dh;                      // the loader wave writes it (and the gate gradients) to HBM
             pn[pw] = (__bf16)(dh * c0); pn[pw + 32] = (__bf16)(dh * c1); pn[pw + 64] = (__bf16)(dh * c2);
         }
         if (s == 0) break;                                 // nothing consumes the partials of time 0
@@ -1198,7 +1234,7 @@ __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
             }
         }
     }
-    if (active) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv_dh), rs_dh, own_v, 0, 0);          // s = 0
+    __syncthreads();                                       // hands the last iteration's dh to the loader wave
 }
 
 // dgi = dh * (c_r, c_z, a_n), dgh = dh * (c_r, c_z, c_n); layouts [rows][G][3][Hg]
@@ -1274,9 +1310,11 @@ __global__ __launch_bounds__(256) void gru_gate_grads_bf16_kernel(const float* d
                         v[rr][2][e] = d[e] * a[e];         v[rr][3][e] = d[e] * (float)cn[e];
                         o0[e] = (__bf16)v[rr][0][e]; o1[e] = (__bf16)v[rr][1][e]; o2[e] = (__bf16)v[rr][2][e];
                     }
-                    *reinterpret_cast<bf16x4*>(dgi + o3) = o0;
-                    *reinterpret_cast<bf16x4*>(dgi + o3 + Hg) = o1;
-                    *reinterpret_cast<bf16x4*>(dgi + o3 + 2 * Hg) = o2;
+                    if (dgi) {                 // null: the backward recurrence has written dgi itself (cruse_gru_seq_bwd_on)
+                        *reinterpret_cast<bf16x4*>(dgi + o3) = o0;
+                        *reinterpret_cast<bf16x4*>(dgi + o3 + Hg) = o1;
+                        *reinterpret_cast<bf16x4*>(dgi + o3 + 2 * Hg) = o2;
+                    }
                 } else {
 #pragma unroll
                     for (int sl = 0; sl < 4; ++sl)
@@ -1297,7 +1335,7 @@ __global__ __launch_bounds__(256) void gru_gate_grads_bf16_kernel(const float* d
                 }
         }
         __syncthreads();
-        for (int item = tid; item < 4 * CW * 8; item += 256) {
+        for (int item = tid; dgT && item < 4 * CW * 8; item += 256) {
             const int k = item & 7, line = item >> 3;
             const int sl = line / CW, col = line % CW;
             const uint4 w = *reinterpret_cast<const uint4*>(&img[line * 32 + ((k ^ ((line >> 2) & 7)) << 2)]);
@@ -1539,9 +1577,13 @@ extern "C" int cruse_gru_seq_fwd(const float* gi, const float* const* w_hh, cons
                                 stream);
 }
 
+extern "C" int cruse_gru_gate_grads_bf16(const float* dh, const void* coef, const float* an, void* dgi, void* dgT,
+                                         long long ldT, float* const* db_ih, float* const* db_hh,
+                                         long long rows, int G, int Hg, void* stream);
+
 extern "C" int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh, const void* coef, const float* z,
-                                    float* dh, int B, int T, int G, int Hg, int prec, void* panels, unsigned* status,
-                                    int xcd_rot, void* stream) {
+                                    float* dh, const float* an, void* dgi, int B, int T, int G, int Hg, int prec,
+                                    void* panels, unsigned* status, int xcd_rot, void* stream) {
     int rc = check_common(B, T, G, Hg, prec, "gru_seq_bwd");
     if (rc) return rc;
     Plan pl;
@@ -1556,13 +1598,22 @@ extern "C" int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh,
     const size_t esz = prec == CRUSE_PREC_F32 ? 4 : 2, npl = prec == CRUSE_PREC_BF16X3 ? 2 : 1;
     const size_t lds = (size_t)16 * (3 * Hg + (prec == CRUSE_PREC_F32 ? 4 : 8)) * esz * npl + 4 * 2 * 64 * 4 * sizeof(float);
     CRUSE_REQUIRE(lds <= 160 * 1024, CRUSE_E_SHAPE, "gru_seq_bwd: Hg=%d needs %zu B of LDS", Hg, lds);
-    return run_launches<false>(a, pl, G, Hg, prec, panels, status, xcd_rot, lds, s);
+    CRUSE_REQUIRE(dgi == nullptr || (an != nullptr && prec == CRUSE_PREC_BF16), CRUSE_E_SHAPE,
+                  "gru_seq_bwd: dgi needs the a_n rows and CRUSE_PREC_BF16");
+    // the reduce-scatter kernel's loader wave writes dgi itself; the other kernels are followed by the gate-gradient pass
+    const bool in_kernel = dgi != nullptr && bwd_rs_eligible(pl.Bg, Hg, prec);
+    a.ans = in_kernel ? an : nullptr;
+    a.dgi = in_kernel ? dgi : nullptr;
+    rc = run_launches<false>(a, pl, G, Hg, prec, panels, status, xcd_rot, lds, s);
+    if (rc || dgi == nullptr || in_kernel) return rc;
+    const long long rows = (long long)B * T;
+    return cruse_gru_gate_grads_bf16(dh, coef, an, dgi, nullptr, (rows + 63) / 64 * 64, nullptr, nullptr, rows, G, Hg, stream);
 }
 
 extern "C" int cruse_gru_seq_bwd(const float* dout, const float* const* w_hh, const void* coef, const float* z,
                                  float* dh, int B, int T, int G, int Hg, int prec, void* ws, void* stream) {
-    return cruse_gru_seq_bwd_on(dout, w_hh, coef, z, dh, B, T, G, Hg, prec, ws ? (char*)ws + 256 : nullptr, (unsigned*)ws, 0,
-                                stream);
+    return cruse_gru_seq_bwd_on(dout, w_hh, coef, z, dh, nullptr, nullptr, B, T, G, Hg, prec, ws ? (char*)ws + 256 : nullptr,
+                                (unsigned*)ws, 0, stream);
 }
 
 extern "C" int cruse_gru_gate_grads(const float* dh, const void* coef, const float* an, float* dgi, float* dgh,
@@ -1587,6 +1638,7 @@ extern "C" int cruse_gru_gate_grads_bf16(const float* dh, const void* coef, cons
                   "gru_gate_grads_bf16: bad shape rows=%lld G=%d Hg=%d", rows, G, Hg);
     CRUSE_REQUIRE(ldT % 64 == 0 && ldT >= rows && ldT < rows + 64, CRUSE_E_SHAPE,
                   "gru_gate_grads_bf16: ldT=%lld must be rows=%lld rounded up to a multiple of 64", ldT, rows);
+    CRUSE_REQUIRE(dgi != nullptr || dgT != nullptr, CRUSE_E_SHAPE, "gru_gate_grads_bf16: dgi and dgT are both NULL");
     CRUSE_REQUIRE(((uintptr_t)dh % 16) == 0 && ((uintptr_t)an % 16) == 0 && ((uintptr_t)coef % 8) == 0 &&
                   ((uintptr_t)dgi % 8) == 0 && ((uintptr_t)dgT % 16) == 0, CRUSE_E_ALIGN,
                   "gru_gate_grads_bf16: unaligned buffers");

@@ -405,14 +405,30 @@ def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G,
     return h, coef, an, z
 
 
-def gru_seq_bwd(dout, w_hh: List[torch.Tensor], coef, z, B, T, G, Hg, prec, slot=0, xcd_rot=0):
-    """dout [B,T,H] -> dh [B,T,H] (total gradient reaching every h_t)."""
+def dgi_buffer(rows, G, Hg, device):
+    """bf16 [rows, G, 3, Hg] gate-gradient rows, followed by the zero K-padding the dX GEMM may read (K = 3*Hg rounded to 64)."""
+    n = rows * G * 3 * Hg
+    pad = 64 if (3 * Hg) % 64 else 0
+    buf = torch.empty(n + pad, device=device, dtype=torch.bfloat16)
+    if pad:
+        buf[n:].zero_()
+    return buf[:n].view(rows, G, 3, Hg)
+
+
+def gru_seq_bwd(dout, w_hh: List[torch.Tensor], coef, z, B, T, G, Hg, prec, slot=0, xcd_rot=0, an=None, want_dgi=False):
+    """dout [B,T,H] -> dh [B,T,H] (total gradient reaching every h_t).  want_dgi (CRUSE_PREC_BF16, with the a_n rows):
+    -> (dh, dgi) with dgi = dh * (c_r, c_z, a_n) in bf16 written by the recurrence itself (cruse_gru_seq_bwd_on)."""
     dh = torch.empty_like(dout)
+    dgi = None
+    if want_dgi:
+        if an is None or prec_code(prec) != PREC_BF16:
+            raise RuntimeError("gru_seq_bwd: want_dgi needs the a_n rows and the bf16 mode")
+        dgi = dgi_buffer(B * T, G, Hg, dout.device)
     panels, status = _gru_ws(B, G, Hg, dout.device, slot)
     wa = _ptr_array(w_hh)
-    check(lib.cruse_gru_seq_bwd_on(_p(dout), ctypes.cast(wa, ctypes.c_void_p), _p(coef), _p(z), _p(dh), B, T, G, Hg,
-                                   prec_code(prec), panels, status, xcd_rot, _stream()))
-    return dh
+    check(lib.cruse_gru_seq_bwd_on(_p(dout), ctypes.cast(wa, ctypes.c_void_p), _p(coef), _p(z), _p(dh), _p(an) if want_dgi else None,
+                                   _p(dgi), B, T, G, Hg, prec_code(prec), panels, status, xcd_rot, _stream()))
+    return (dh, dgi) if want_dgi else dh
 
 
 def gru_gate_grads(dh, coef, an, rows, G, Hg, prec):
@@ -424,19 +440,15 @@ def gru_gate_grads(dh, coef, an, rows, G, Hg, prec):
     return dgi, dgh
 
 
-def gru_gate_grads_bf16(dh, coef, an, rows, G, Hg, db_ih, db_hh):
+def gru_gate_grads_bf16(dh, coef, an, rows, G, Hg, db_ih, db_hh, want_dgi=True, want_dgT=True):
     """bf16 gate gradients for gemm_bf16_nt: returns (dgi [rows,G,3,Hg] bf16, dgT [ldT/64,G,4,Hg,64] bf16, ldT) and
-    accumulates the bias gradients into the per-group tensors db_ih[g], db_hh[g]."""
+    accumulates the bias gradients into the per-group tensors db_ih[g], db_hh[g].  want_dgi / want_dgT False: that output
+    is not made (None) -- the recurrence may have written dgi itself (gru_seq_bwd(want_dgi=True))."""
     if coef.dtype != torch.bfloat16:
         raise RuntimeError("gru_gate_grads_bf16 needs the bf16 coefficients of CRUSE_PREC_BF16")
     ldT = (rows + 63) // 64 * 64
-    n = rows * G * 3 * Hg
-    pad = 64 if (3 * Hg) % 64 else 0                                           # dX rounds K = 3*Hg up to 64: zeros to read
-    dgi_buf = torch.empty(n + pad, device=dh.device, dtype=torch.bfloat16)
-    if pad:
-        dgi_buf[n:].zero_()
-    dgi = dgi_buf[:n].view(rows, G, 3, Hg)
-    dgT = torch.empty(ldT // 64, G, 4, Hg, 64, device=dh.device, dtype=torch.bfloat16)
+    dgi = dgi_buffer(rows, G, Hg, dh.device) if want_dgi else None
+    dgT = torch.empty(ldT // 64, G, 4, Hg, 64, device=dh.device, dtype=torch.bfloat16) if want_dgT else None
     check(lib.cruse_gru_gate_grads_bf16(_p(dh), _p(coef), _p(an), _p(dgi), _p(dgT), ldT, _ptr_array(db_ih),
                                         _ptr_array(db_hh), rows, G, Hg, _stream()))
     return dgi, dgT, ldT

@@ -242,13 +242,16 @@ int cruse_gru_seq_bwd(const float* dout, const float* const* w_hh, const void* c
  * cruse_gru_ws_bytes(B,G,Hg) - 256 bytes (zeroed here) plus a caller-owned sticky status word that several launches may
  * share, and chain c of the launch runs on XCD (c + xcd_rot) % 8 instead of c % 8.  A recurrence workgroup owns its CU;
  * two launches of <= 4 chains with xcd_rot 0 and 4 occupy disjoint XCDs and are co-resident, with the same xcd_rot they
- * would queue for the same CUs.  cruse_gru_seq_fwd/bwd(ws) == _on(ws + 256, (unsigned*)ws, 0). */
+ * would queue for the same CUs.  cruse_gru_seq_fwd/bwd(ws) == _on(ws + 256, (unsigned*)ws, 0).
+ * _bwd_on: dgi != NULL (CRUSE_PREC_BF16, with the a_n rows `an`): also writes the bf16 gate gradients
+ * dgi [B,T,G,3*Hg] = dh * (c_r, c_z, a_n) -- the dgi output of cruse_gru_gate_grads_bf16 -- from inside the recurrence, so
+ * that dX = dgi W_ih can start right behind it; cruse_gru_gate_grads_bf16(dgi = NULL) then only makes dgT / the bias sums. */
 int cruse_gru_seq_fwd_on(const float* gi, const float* const* w_hh, const float* const* b_hh,
                          float* h, void* coef, float* an, float* z,
                          int B, int T, int G, int Hg, int prec, void* panels, unsigned* status, int xcd_rot, void* stream);
 int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh, const void* coef, const float* z,
-                         float* dh, int B, int T, int G, int Hg, int prec, void* panels, unsigned* status, int xcd_rot,
-                         void* stream);
+                         float* dh, const float* an, void* dgi, int B, int T, int G, int Hg, int prec,
+                         void* panels, unsigned* status, int xcd_rot, void* stream);
 /* dgi = dh*(c_r,c_z,a_n) (gradient wrt gi), dgh = dh*(c_r,c_z,c_n) (gradient wrt W_hh h + b_hh), both
  * [rows,G,3*Hg]; dW_ih, dW_hh, dX and the bias gradients follow from cruse_gemm / cruse_col_sum. */
 int cruse_gru_gate_grads(const float* dh, const void* coef, const float* an, float* dgi, float* dgh,
@@ -257,6 +260,7 @@ int cruse_gru_gate_grads(const float* dh, const void* coef, const float* an, flo
  * slabs (r, z, n_i, n_h) carry both: dgi [rows,G,3,Hg] bf16 = (r,z,n_i) row-major; dgT [ldT/64,G,4,Hg,64] bf16 =
  * the K-tiled time-major transpose (ldT = rows rounded up to 64, zero padded): dW_ih uses slabs 0-2, dW_hh 0,1,3.
  * db_ih / db_hh: HOST arrays of G device pointers (or NULL) to [3*Hg] bias gradients, ACCUMULATED from f32. */
+/* dgi or dgT may be NULL (not both): only the other output (and the bias sums) is produced */
 int cruse_gru_gate_grads_bf16(const float* dh, const void* coef, const float* an, void* dgi, void* dgT,
                               long long ldT, float* const* db_ih, float* const* db_hh,
                               long long rows, int G, int Hg, void* stream);

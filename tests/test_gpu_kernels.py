@@ -702,3 +702,30 @@ def test_bf16_operand_copies_from_bn_and_ln(ops):
         yl, _, _ = ops.ln_fwd(x, w, b, None, rows, H, g, out_bf16=bf)
         y0, _, _ = ops.ln_fwd(x, w, b, None, rows, H, g)
         assert torch.equal(yl, y0) and torch.equal(bf.view_as(yl), yl.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("H,G,B,T", [(640, 1, 9, 12), (640, 4, 3, 7), (320, 1, 8, 1), (640, 1, 5, 2), (512, 1, 16, 5), (288, 1, 7, 5)])
+def test_gru_bwd_writes_gate_gradients_itself(ops, H, G, B, T):
+    """cruse_gru_seq_bwd_on(dgi): the recurrence's loader wave writes dgi = dh * (c_r, c_z, a_n); the same dh as without it
+    and bit-identical to the gate-gradient pass on that dh; cruse_gru_gate_grads_bf16(dgi = NULL) still makes dgT / biases."""
+    Hg = H // G
+    torch.manual_seed(H + B + T)
+    gi = (0.5 * torch.randn(B, T, 3 * H)).cuda()
+    w = [(torch.randn(3 * Hg, Hg) / Hg ** 0.5).cuda() for _ in range(G)]
+    b = [torch.zeros(3 * Hg).cuda() for _ in range(G)]
+    h, coef, an, z = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16")
+    dout = torch.randn(B, T, H).cuda()
+    dh0 = ops.gru_seq_bwd(dout, w, coef, z, B, T, G, Hg, "bf16")
+    dh1, dgi1 = ops.gru_seq_bwd(dout, w, coef, z, B, T, G, Hg, "bf16", an=an, want_dgi=True)
+    torch.cuda.synchronize()
+    assert ops.gru_status() == 0
+    assert torch.equal(dh0, dh1)
+    rows = B * T
+    db_i = [torch.zeros(3 * Hg).cuda() for _ in range(G)]; db_h = [torch.zeros(3 * Hg).cuda() for _ in range(G)]
+    dgi_ref, dgT_ref, ldT = ops.gru_gate_grads_bf16(dh1, coef, an, rows, G, Hg, db_i, db_h)
+    assert torch.equal(dgi1.view(-1), dgi_ref.view(-1))
+    db_i2 = [torch.zeros(3 * Hg).cuda() for _ in range(G)]; db_h2 = [torch.zeros(3 * Hg).cuda() for _ in range(G)]
+    none, dgT2, _ = ops.gru_gate_grads_bf16(dh1, coef, an, rows, G, Hg, db_i2, db_h2, want_dgi=False)
+    assert none is None and torch.equal(dgT2, dgT_ref)
+    for a_, b_ in zip(db_i + db_h, db_i2 + db_h2):
+        assert rel_l2(a_, b_) < 1e-5
