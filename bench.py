@@ -55,7 +55,32 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="skip the f32 gate-mode and hop=320 STFT rows")
     ap.add_argument("--df", action="store_true", help="BASELINE config 4: DeepFilter(1,5) head + WO-MALE on its output")
     ap.add_argument("--bucketed", action="store_true", help="force the segmented (multi-GPU) schedule at world 1")
+    ap.add_argument("--ref-1gpu", type=float, default=None, help="frames/s of the 1-GPU run of the same configuration: adds "
+                                                                 "scaling_efficiency = value / (n_gpus * ref) to the JSON line")
     return ap.parse_args()
+
+
+def self_launch(a) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (the reference does it with mp.spawn,
+    tools/train_stand.py:151-155) -- one process per GPU under torch.distributed.run on 127.0.0.1, rank r bound to device r.
+    More ranks than devices are refused unless CRUSE_DIST_BACKEND=gloo (the single-GPU test rig: every rank on device 0)."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("CRUSE_DIST_BACKEND", "nccl")
+    if a.gpus > ndev and backend != "gloo":
+        raise SystemExit(f"bench.py --gpus {a.gpus}: this node has {ndev} HIP device(s) (RCCL needs one device per rank; "
+                         f"CRUSE_DIST_BACKEND=gloo lets test rigs oversubscribe)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"--gpus {a.gpus} without a launcher: starting {a.gpus} ranks ({backend}) on 127.0.0.1:{port}")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
 
 
 # SURVEY 8(d): algorithmic work per frame of the training step (F = 160 geometry)
@@ -337,7 +362,12 @@ def secondary_rows(a, dev, pool):
 
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus} was started with WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(--nproc-per-node {a.gpus}), or drop the launcher and let bench.py start the ranks itself")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -345,10 +375,13 @@ def main():
     local = local % torch.cuda.device_count()         # (test rigs may oversubscribe one GPU)
     torch.cuda.set_device(local)
     force_pg = os.environ.get("CRUSE_FORCE_COLLECTIVES") == "1"      # a world of ONE still issues its (RCCL) collectives
+    backend = None
     if world > 1 or force_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group(os.environ.get("CRUSE_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+        backend = dist.get_backend()
+        assert dist.get_world_size() == world
     dev = torch.device("cuda", local)
 
     from cruse_amd import ops
@@ -431,7 +464,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         el = float(tmax.item())
     loss = eng.loss_value(ls)
-    status = ops.gru_status()
+    status = ops.gru_status() | eng.timeout_steps()      # (the engine latches and clears the device word every step)
     log(f"timed region done: {el / a.steps * 1e3:.2f} ms/step (median step {med_ms:.2f} ms)")
 
     roof, breakdown = None, None
@@ -483,6 +516,8 @@ def main():
             "value": round(frames / el, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(el / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.prec, "data": "synthetic",
+            "world_size": world, "backend": ("rccl" if backend == "nccl" else backend), "bucketed_allreduce": bool(eng.bucketed),
+            "scaling_efficiency": (None if not a.ref_1gpu else round(frames / el / (world * a.ref_1gpu), 4)),
             "config": {"workload": f"CRUSE unet_2 4-layer enc/dec, {a.groups}xGRU group(s), H=640, "
                                    f"{B} clips x {a.seconds:g} s @16 kHz per GPU, n_fft=320 hop=160 (T={T}), "
                                    + ("STFT x2 + fwd + DeepFilter(1,5) head + WO-MALE + bwd" if a.df else "STFT x2 + fwd + WO-MALE + bwd")

@@ -12,11 +12,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcruse_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
 PREC_BY_NAME = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
 
-_T = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "q": ctypes.c_longlong,
+_T = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "q": ctypes.c_longlong, "d": ctypes.c_double,
       "z": ctypes.c_size_t}
 
 # name -> (argument type string, restype); mirrors include/cruse_hip.h one to one
@@ -68,7 +68,8 @@ SIGNATURES = {
     "cruse_sigmoid_bwd": ("pppqp", "i"),
     "cruse_axpby": ("pppffqp", "i"),
     "cruse_adam_step": ("ppppqfffffifp", "i"),
-    "cruse_adam_step_guarded": ("ppppqfffffiffppppp", "i"),
+    "cruse_adam_step_guarded": ("ppppqfffffiffppippp", "i"),
+    "cruse_step_health": ("ppppdp", "i"),
     "cruse_sumsq": ("pqpip", "i"),
     "cruse_conv2d_nchw": ("ppppiiiiiiiiiiiiiiiiiiipip", "i"),
     "cruse_conv2d_nchw_wgrad": ("pppiiiiiiiiiiiiiiiiip", "i"),
@@ -80,7 +81,7 @@ SIGNATURES = {
     "cruse_stft_framed": ("ppiiiiiiiiifppp", "i"),
     "cruse_istft_framed": ("ppppiiiiiiiifipp", "i"),
     "cruse_mask_ops": ("ippppqfffppp", "i"),
-    "cruse_polar": ("ipppqffppp", "i"),
+    "cruse_polar": ("ippppqffppp", "i"),
     "cruse_rmse": ("ppqfppp", "i"),
     "cruse_c_rmse": ("ppiqffppp", "i"),
     "cruse_sisnr_plain_finalize": ("pifppp", "i"),

@@ -158,20 +158,55 @@ def istft_framed(re, im, window, n_fft, hop, win_off=0, pad=0, length=None, scal
                              float(scale), hermitian)
 
 
-def mag_phase(re, im):
-    """(re, im) -> ((re^2 + im^2) ** 0.5, atan2(im, re)) (feature.py:363-364)."""
-    re = re.contiguous(); im = im.contiguous()
-    m = torch.empty_like(re); p = torch.empty_like(re)
-    check(lib.cruse_polar(0, _p(re), _p(im), None, re.numel(), 0.0, 1.0, _p(m), _p(p), _stream()))
-    return m, p
+class _MagPhaseFn(torch.autograd.Function):
+    """(re, im) -> (sqrt(re^2 + im^2 + eps), atan2(im, re)) with both gradients (cruse_polar modes 0 / 2)."""
+
+    @staticmethod
+    def forward(ctx, re, im, eps):
+        re = re.contiguous(); im = im.contiguous()
+        m = torch.empty_like(re); p = torch.empty_like(re)
+        check(lib.cruse_polar(0, _p(re), _p(im), None, None, re.numel(), eps, 1.0, _p(m), _p(p), _stream()))
+        ctx.save_for_backward(re, im)
+        ctx.eps = eps
+        return m, p
+
+    @staticmethod
+    def backward(ctx, gm, gp):
+        re, im = ctx.saved_tensors
+        gm = None if gm is None else gm.contiguous()
+        gp = None if gp is None else gp.contiguous()
+        dr = torch.empty_like(re); di = torch.empty_like(re)
+        check(lib.cruse_polar(2, _p(re), _p(im), _p(gm), _p(gp), re.numel(), ctx.eps, 1.0, _p(dr), _p(di), _stream()))
+        return dr, di, None
+
+
+class _PolarToRectFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, m, p):
+        m = m.contiguous(); p = p.contiguous()
+        r = torch.empty_like(m); i = torch.empty_like(m)
+        check(lib.cruse_polar(1, _p(m), _p(p), None, None, m.numel(), 0.0, 1.0, _p(r), _p(i), _stream()))
+        ctx.save_for_backward(m, p)
+        return r, i
+
+    @staticmethod
+    def backward(ctx, gr, gi):
+        m, p = ctx.saved_tensors
+        gr = torch.zeros_like(m) if gr is None else gr.contiguous()
+        gi = torch.zeros_like(m) if gi is None else gi.contiguous()
+        dm = torch.empty_like(m); dp = torch.empty_like(m)
+        check(lib.cruse_polar(3, _p(m), _p(p), _p(gr), _p(gi), m.numel(), 0.0, 1.0, _p(dm), _p(dp), _stream()))
+        return dm, dp
+
+
+def mag_phase(re, im, eps: float = 0.0):
+    """(re, im) -> ((re^2 + im^2 + eps) ** 0.5, atan2(im, re)) (feature.py:363-364); differentiable."""
+    return _MagPhaseFn.apply(re, im, float(eps))
 
 
 def polar_to_rect(m, p):
-    """(mag, phase) -> (mag cos, mag sin) (feature.py:386-387)."""
-    m = m.contiguous(); p = p.contiguous()
-    r = torch.empty_like(m); i = torch.empty_like(m)
-    check(lib.cruse_polar(1, _p(m), _p(p), None, m.numel(), 0.0, 1.0, _p(r), _p(i), _stream()))
-    return r, i
+    """(mag, phase) -> (mag cos, mag sin) (feature.py:386-387); differentiable."""
+    return _PolarToRectFn.apply(m, p)
 
 
 def init_stft_kernel(frame_len, frame_hop, num_fft=None, window="sqrt_hann"):

@@ -19,11 +19,38 @@ from .feature import istft_ri, mag_phase, stft_framed
 _p, _stream = ops._p, ops._stream
 
 
-def _pair_op(mode, a, b, c, d):
+def _pair_raw(a, b, c, d):
     a, b, c, d = (t.contiguous().float() for t in (a, b, c, d))
     o1 = torch.empty_like(a); o2 = torch.empty_like(a)
-    check(lib.cruse_mask_ops(mode, _p(a), _p(b), _p(c), _p(d), a.numel(), 0.0, 0.0, 0.0, _p(o1), _p(o2), _stream()))
+    check(lib.cruse_mask_ops(5, _p(a), _p(b), _p(c), _p(d), a.numel(), 0.0, 0.0, 0.0, _p(o1), _p(o2), _stream()))
     return o1, o2
+
+
+class _PairFn(torch.autograd.Function):
+    """(a*c, b*d) -- PreProcess.masking (utils/utils.py:418-423) is applied to the network's mask during training, so it
+    carries its gradient (the same kernel with the roles exchanged)."""
+
+    @staticmethod
+    def forward(ctx, a, b, c, d):
+        ctx.save_for_backward(a, b, c, d)
+        return _pair_raw(a, b, c, d)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        a, b, c, d = ctx.saved_tensors
+        da = db = dc = dd = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            da, db = _pair_raw(g1, g2, c, d)
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            dc, dd = _pair_raw(g1, g2, a, b)
+            dc, dd = dc.view(c.shape), dd.view(d.shape)
+        return da, db, dc, dd
+
+
+def _pair_op(mode, a, b, c, d):
+    if a.shape != c.shape or b.shape != d.shape:
+        raise RuntimeError(f"PreProcess.masking: mask {tuple(c.shape)} does not match the spectrum {tuple(a.shape)}")
+    return _PairFn.apply(a, b, c, d)
 
 
 class PreProcess:
@@ -50,8 +77,7 @@ class PreProcess:
         L = inputs.shape[1]
         re, im = stft_framed(inputs, self.window, self.fft_len, self.win_inc, win_off=0, pad=self.fft_len // 2,
                              pad_mode="constant", frames=1 + L // self.win_inc)                  # [B,T,F]
-        mags = torch.empty_like(re); phase = torch.empty_like(re)
-        check(lib.cruse_polar(0, _p(re), _p(im), None, re.numel(), 1e-8, 1.0, _p(mags), _p(phase), _stream()))
+        mags, phase = mag_phase(re, im, eps=1e-8)
         stft_inputs = torch.stack([re, im], dim=1)                                              # [B,2,T,F] (:397)
         self.real, self.imag = re.unsqueeze(1), im.unsqueeze(1)
         self.spec_mags, self.spec_phase = mags.unsqueeze(1), phase.unsqueeze(1)

@@ -28,6 +28,9 @@ __device__ __forceinline__ float decompress_cirm(float m, float K, float limit) 
 // mode 4: complex_mul (a + ib)(c + id) -> out = real, out2 = imag
 // mode 5: element-wise pair product out = a*c, out2 = b*d   (PreProcess.masking "complex_mapping", utils/utils.py:421-423)
 // mode 6: out = log(a)                                       (PreProcess.log_transform, utils/utils.py:414-415)
+// adjoints (the reference's versions are plain torch and differentiable; they sit between the network and the loss):
+// mode 7: out = c * d compress(a)/da      mode 8: out = c * d decompress(a)/da      (c = upstream gradient)
+// mode 9: (a + ib) * conj(c + id) -> out = a*c + b*d, out2 = b*c - a*d   (both gradients of mode 4)
 __global__ void mask_ops_kernel(int mode, const float* a, const float* b, const float* c, const float* d, long long n,
                                 float K, float C, float limit, float* out, float* out2) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -49,17 +52,30 @@ __global__ void mask_ops_kernel(int mode, const float* a, const float* b, const 
         } else if (mode == 5) {
             out[i] = a[i] * c[i];
             out2[i] = b[i] * d[i];
-        } else {
+        } else if (mode == 6) {
             out[i] = logf(a[i]);
+        } else if (mode == 7) {
+            const float m = a[i];
+            const float e = expf(-C * m);
+            out[i] = m <= -100.f ? 0.f : c[i] * (2.f * K * C * e / ((1.f + e) * (1.f + e)));
+        } else if (mode == 8) {
+            const float m = a[i];
+            out[i] = (m >= limit || m <= -limit) ? 0.f : c[i] * (2.f * K * K / (K * K - m * m));
+        } else {
+            const float gr = a[i], gi = b[i], mr = c[i], mi = d[i];
+            out[i] = gr * mr + gi * mi;
+            out2[i] = gi * mr - gr * mi;
         }
     }
 }
 
 // mode 0: (re, im) -> (mag = sqrt(re^2 + im^2 + eps) ** alpha, phase = atan2(im, re))     [phase may be NULL]
 // mode 1: (mag, phase) -> (re = mag cos p, im = mag sin p)
-// mode 2: backward of mode 0's magnitude: dre = dm * alpha * amp^(alpha-2) * re, dim likewise
-__global__ void polar_kernel(int mode, const float* a, const float* b, const float* g, long long n, float eps, float alpha,
-                             float* o1, float* o2) {
+// mode 2: backward of mode 0: magnitude (g, optional) dre = dm * alpha * amp^(alpha-2) * re, dim likewise; phase (g2,
+//         optional) dre -= dp * im / (re^2 + im^2), dim += dp * re / (re^2 + im^2)
+// mode 3: backward of mode 1 (a = mag, b = phase; g, g2 = d re, d im): o1 = d mag = g cos p + g2 sin p, o2 = d phase
+__global__ void polar_kernel(int mode, const float* a, const float* b, const float* g, const float* g2, long long n,
+                             float eps, float alpha, float* o1, float* o2) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         if (mode == 0) {
             const float r = a[i], im = b[i];
@@ -70,11 +86,22 @@ __global__ void polar_kernel(int mode, const float* a, const float* b, const flo
             float s, c;
             sincosf(b[i], &s, &c);
             o1[i] = a[i] * c; o2[i] = a[i] * s;
-        } else {
+        } else if (mode == 2) {
             const float r = a[i], im = b[i];
             const float q = r * r + im * im + eps;
-            const float k = g[i] * alpha * powf(q, 0.5f * alpha - 1.f);
-            o1[i] = k * r; o2[i] = k * im;
+            const float k = g ? g[i] * alpha * powf(q, 0.5f * alpha - 1.f) : 0.f;
+            float dr = k * r, di = k * im;
+            if (g2) {
+                const float q0 = r * r + im * im;
+                const float w = q0 > 0.f ? g2[i] / q0 : 0.f;
+                dr -= w * im; di += w * r;
+            }
+            o1[i] = dr; o2[i] = di;
+        } else {
+            float sn, cs;
+            sincosf(b[i], &sn, &cs);
+            o1[i] = g[i] * cs + g2[i] * sn;
+            o2[i] = a[i] * (g2[i] * cs - g[i] * sn);
         }
     }
 }
@@ -271,19 +298,20 @@ inline int eblocks(long long n, int per = 1024, int cap = 4096) {
 
 extern "C" int cruse_mask_ops(int mode, const float* a, const float* b, const float* c, const float* d, long long n,
                               float K, float C, float limit, float* out, float* out2, void* stream) {
-    CRUSE_REQUIRE(mode >= 0 && mode <= 6 && n > 0 && a && out, CRUSE_E_SHAPE, "mask_ops: bad arguments (mode %d, n %lld)", mode, n);
-    CRUSE_REQUIRE(!(mode == 0 && !c) && !((mode == 1 || mode == 4 || mode == 5) && !(b && c && d)) && !((mode == 4 || mode == 5) && !out2), CRUSE_E_SHAPE,
+    CRUSE_REQUIRE(mode >= 0 && mode <= 9 && n > 0 && a && out, CRUSE_E_SHAPE, "mask_ops: bad arguments (mode %d, n %lld)", mode, n);
+    CRUSE_REQUIRE(!((mode == 0 || mode == 7 || mode == 8) && !c) && !((mode == 1 || mode == 4 || mode == 5 || mode == 9) && !(b && c && d)) &&
+                  !((mode == 4 || mode == 5 || mode == 9) && !out2), CRUSE_E_SHAPE,
                   "mask_ops: missing operand for mode %d", mode);
     hipLaunchKernelGGL(mask_ops_kernel, dim3(eblocks(n)), dim3(256), 0, ST(stream), mode, a, b, c, d, n, K, C, limit, out, out2);
     CRUSE_LAUNCH_CHECK("mask_ops");
     return CRUSE_OK;
 }
 
-extern "C" int cruse_polar(int mode, const float* a, const float* b, const float* g, long long n, float eps, float alpha,
-                           float* o1, float* o2, void* stream) {
-    CRUSE_REQUIRE(mode >= 0 && mode <= 2 && n > 0 && a && b && o1 && (mode == 0 || o2) && (mode != 2 || g), CRUSE_E_SHAPE,
-                  "polar: bad arguments (mode %d)", mode);
-    hipLaunchKernelGGL(polar_kernel, dim3(eblocks(n)), dim3(256), 0, ST(stream), mode, a, b, g, n, eps, alpha, o1, o2);
+extern "C" int cruse_polar(int mode, const float* a, const float* b, const float* g, const float* g2, long long n, float eps,
+                           float alpha, float* o1, float* o2, void* stream) {
+    CRUSE_REQUIRE(mode >= 0 && mode <= 3 && n > 0 && a && b && o1 && (mode == 0 || o2) && (mode != 2 || g || g2) &&
+                  (mode != 3 || (g && g2)), CRUSE_E_SHAPE, "polar: bad arguments (mode %d)", mode);
+    hipLaunchKernelGGL(polar_kernel, dim3(eblocks(n)), dim3(256), 0, ST(stream), mode, a, b, g, g2, n, eps, alpha, o1, o2);
     CRUSE_LAUNCH_CHECK("polar");
     return CRUSE_OK;
 }

@@ -627,6 +627,22 @@ __global__ void accum_f64_kernel(double* acc, const double* x, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) acc[i] += x[i];
 }
+// Per-step health word of the training step (engine.py): LATCHES the sticky GRU status word into health[0] and clears it
+// (one transient hand-off time-out then costs exactly the step it happened in), health[1] = the loss sum is not finite;
+// the running loss is accumulated with the step's own normalisation (steps of different shapes share one accumulator).
+__global__ void step_health_kernel(unsigned* gru_status, const double* loss_sum, unsigned* health, double* loss_acc,
+                                   double loss_scale) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned to = 0u;
+    if (gru_status) {
+        to = __hip_atomic_load(gru_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ? 1u : 0u;
+        if (to) __hip_atomic_store(gru_status, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const double l = loss_sum ? *loss_sum : 0.0;
+    health[0] = to;
+    health[1] = isfinite(l) ? 0u : 1u;
+    if (loss_acc && isfinite(l)) *loss_acc += l * loss_scale;
+}
 struct CounterPtrs { long long* p[32]; };
 __global__ void counters_add_kernel(CounterPtrs c, int n, long long v) {
     const int i = threadIdx.x;
@@ -639,10 +655,11 @@ __global__ void counters_add_kernel(CounterPtrs c, int n, long long v) {
 // torch.nn.utils.clip_grad_norm_'s coefficient min(1, max_norm / (norm + 1e-6)) on top of grad_scale.
 __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2,
                             float eps, float wd, float bc1, float bc2_sqrt, float gscale, float max_norm,
-                            const double* gsumsq, const unsigned* skip_flag, const double* loss_check,
+                            const double* gsumsq, const unsigned* skip_flag, int n_skip_words, const double* loss_check,
                             unsigned* skipped) {
     bool skip = false;
-    if (skip_flag && *skip_flag != 0u) skip = true;
+    for (int i = 0; i < n_skip_words; ++i)
+        if (skip_flag[i] != 0u) skip = true;
     if (loss_check && !isfinite(*loss_check)) skip = true;
     if (gsumsq) {
         const double norm = sqrt(*gsumsq) * (double)gscale;
@@ -653,7 +670,11 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long l
         }
     }
     if (skip) {
-        if (skipped && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skipped, 1u);
+        if (skipped && blockIdx.x == 0 && threadIdx.x == 0) {
+            atomicAdd(skipped, 1u);
+            for (int i = 0; i < n_skip_words && n_skip_words > 1; ++i)          // per-reason counters behind the total
+                if (skip_flag[i] != 0u) atomicAdd(skipped + 1 + i, 1u);
+        }
         return;
     }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -856,6 +877,14 @@ extern "C" int cruse_accum_f64(double* acc, const double* x, int n, void* stream
     return CRUSE_OK;
 }
 
+extern "C" int cruse_step_health(unsigned* gru_status, const double* loss_sum, unsigned* health, double* loss_acc,
+                                 double loss_scale, void* stream) {
+    CRUSE_REQUIRE(health != nullptr, CRUSE_E_SHAPE, "step_health: health is required");
+    hipLaunchKernelGGL(step_health_kernel, dim3(1), dim3(64), 0, ST(stream), gru_status, loss_sum, health, loss_acc, loss_scale);
+    CRUSE_LAUNCH_CHECK("step_health");
+    return CRUSE_OK;
+}
+
 extern "C" int cruse_counters_add(long long* const* counters, int n, long long v, void* stream) {
     CRUSE_REQUIRE(n > 0 && n <= 32, CRUSE_E_SHAPE, "counters_add: n=%d (1..32)", n);
     CounterPtrs c = {};
@@ -873,15 +902,17 @@ extern "C" int cruse_zero(void* p, size_t bytes, void* stream) {
 extern "C" int cruse_adam_step_guarded(float* p, const float* g, float* m, float* v, long long n,
                                        float lr, float beta1, float beta2, float eps, float weight_decay,
                                        int step, float grad_scale, float max_norm, const double* gsumsq,
-                                       const unsigned* skip_flag, const double* loss_check, unsigned* skipped,
-                                       void* stream) {
+                                       const unsigned* skip_flag, int n_skip_words, const double* loss_check,
+                                       unsigned* skipped, void* stream) {
     CRUSE_REQUIRE(n > 0 && step >= 1, CRUSE_E_SHAPE, "adam_step: n=%lld step=%d", n, step);
+    CRUSE_REQUIRE(n_skip_words >= 0 && n_skip_words <= 8 && (n_skip_words == 0 || skip_flag != nullptr), CRUSE_E_SHAPE,
+                  "adam_step: n_skip_words=%d (0..8, with skip_flag)", n_skip_words);
     CRUSE_REQUIRE(max_norm <= 0.f || gsumsq != nullptr, CRUSE_E_SHAPE, "adam_step: max_norm needs the gradient sum of squares");
     const double bc1 = 1.0 - pow((double)beta1, step);
     const double bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, ST(stream), p, g, m, v, n, lr, beta1, beta2,
                        eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale, max_norm, gsumsq, skip_flag,
-                       loss_check, skipped);
+                       skip_flag ? n_skip_words : 0, loss_check, skipped);
     CRUSE_LAUNCH_CHECK("adam_step");
     return CRUSE_OK;
 }
@@ -890,7 +921,7 @@ extern "C" int cruse_adam_step(float* p, const float* g, float* m, float* v, lon
                                float lr, float beta1, float beta2, float eps, float weight_decay,
                                int step, float grad_scale, void* stream) {
     return cruse_adam_step_guarded(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, 0.f, nullptr,
-                                   nullptr, nullptr, nullptr, stream);
+                                   nullptr, 0, nullptr, nullptr, stream);
 }
 
 extern "C" int cruse_sumsq(const float* x, long long n, double* out, int accumulate, void* stream) {

@@ -218,7 +218,12 @@ class TrainEngine:
         self._graph_cache: Dict[Tuple[int, ...], tuple] = {}     # input shape -> (graphs, static inputs, static loss)
         dev = self.flat.params.device
         self._gsumsq = torch.zeros(1, device=dev, dtype=torch.float64)
-        self._skipped = torch.zeros(1, device=dev, dtype=torch.int32)
+        # [0] skipped steps, [1] of them: a GRU hand-off timed out, [2] of them: the loss was not finite
+        self._skipped = torch.zeros(4, device=dev, dtype=torch.int32)
+        # per-step health words [time-out, non-finite loss]: decided on the device, all-reduced (MAX) over the ranks, so
+        # that every replica takes the SAME skip decision (a rank-local skip would let the replicas drift apart for good)
+        self._health = torch.zeros(2, device=dev, dtype=torch.int32)
+        self._norms: Dict[Tuple[int, ...], float] = {}           # input shape -> loss normalisation of that shape
         self._loss_acc = torch.zeros(1, device=dev, dtype=torch.float64)
         self._loss_steps = 0
         self._norm = 1.0
@@ -368,6 +373,7 @@ class TrainEngine:
         self._shape = tuple(noisy.shape)
         # one capture per input shape (a last, partial batch of an epoch would otherwise force two re-captures per epoch)
         self._graph_cache[self._shape] = (graphs, self._static, self._static_loss)
+        self._norms[self._shape] = self._norm
 
     @staticmethod
     def _warmup_boundary(bucket: int):
@@ -464,26 +470,33 @@ class TrainEngine:
                         return self.step(noisy, clean)
             self._static[0].copy_(noisy)
             self._static[1].copy_(clean)
+            self._norm = self._norms[tuple(noisy.shape)]      # (a cache hit runs no Python forward: the norm is per shape)
             for g, bucket in self._graphs:
                 g.replay()
                 self._launch_bucket(bucket)      # RCCL's stream waits for the replay; the next replay overlaps it
             loss_sum = self._static_loss
         else:
             loss_sum = self._fwd_bwd(noisy, clean, boundary=self._plain_boundary if self.bucketed else None)
+            self._norms[tuple(noisy.shape)] = self._norm
             self._launch_bucket(N_BUCKETS - 1)
+        # health of THIS step: the GRU status word is latched and cleared (a transient hand-off time-out costs one step,
+        # not the rest of the epoch), a non-finite loss is flagged, the running loss takes this step's own normalisation
+        B = noisy.shape[0]
+        g = self.model.rnn_groups
+        word = ops.gru_status_word(noisy.device, B, g, self.model.hidden_size // g)
+        ops.step_health(word, loss_sum, self._health, self._loss_acc, 1.0 / self._norm)
+        if _dist_on():
+            # one rank's time-out / NaN is inside everybody's reduced gradient: everybody skips
+            self._works.append(dist.all_reduce(self._health, op=dist.ReduceOp.MAX, async_op=True))
         for w in self._works:
             w.wait()                             # the compute stream waits for the collectives (no host block on RCCL)
         self.step_count += 1
         gs = None
-        if self.clip > 0.0:
+        if self.clip > 0.0 or _dist_on():        # the norm of the REDUCED gradient: identical on every rank
             gs = ops.sumsq(self.flat.grads, out=self._gsumsq)
-        B = noisy.shape[0]
-        g = self.model.rnn_groups
-        flag = ops.gru_status_word(noisy.device, B, g, self.model.hidden_size // g)
         ops.adam_step(self.flat.params, self.flat.grads, self.flat.exp_avg, self.flat.exp_avg_sq, self.lr,
                       self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, 1.0 / self.world,
-                      max_norm=self.clip, gsumsq=gs, skip_flag=flag, loss_check=loss_sum, skipped=self._skipped)
-        ops.accum_f64(self._loss_acc, loss_sum)
+                      max_norm=self.clip, gsumsq=gs, skip_flag=self._health, skipped=self._skipped)
         self._loss_steps += 1
         return loss_sum
 
@@ -498,18 +511,32 @@ class TrainEngine:
     def mean_loss(self, reset: bool = True) -> float:
         """mean loss over the steps since the last reset -- ONE synchronisation per epoch / log interval."""
         n = max(self._loss_steps, 1)
-        v = float(self._loss_acc.item()) / self._norm / n
+        v = float(self._loss_acc.item()) / n     # (each step was accumulated with its own normalisation)
         if reset:
             self._loss_acc.zero_()
             self._loss_steps = 0
         return v
 
     def skipped_steps(self) -> int:
-        return int(self._skipped.item())
+        return int(self._skipped[0].item())
+
+    def timeout_steps(self) -> int:
+        """steps skipped because a GRU hand-off timed out on ANY rank (the count is the same on every rank)."""
+        return int(self._skipped[1].item())
+
+    def nonfinite_steps(self) -> int:
+        return int(self._skipped[2].item())
 
     def check_health(self) -> None:
-        """Raise if a GRU hand-off ever timed out (CRUSE_E_TIMEOUT; those steps were skipped by the guarded Adam)."""
-        ops.check_gru_status()
+        """Raise (CRUSE_E_TIMEOUT) if a GRU hand-off timed out in any step since the engine was built -- those steps were
+        skipped by the guarded Adam on every rank.  The decision is taken from the all-reduced counter, so all ranks of a
+        data-parallel job raise together (no rank is left waiting in a collective)."""
+        n = self.timeout_steps()
+        if n:
+            raise RuntimeError(f"cruse_hip error -5 (CRUSE_E_TIMEOUT): a GRU hand-off timed out in {n} step(s) -- the "
+                               "persistent recurrence kernel's workgroups were not co-resident (another process or kernel "
+                               "holding CUs?); the affected optimizer steps were skipped on every rank")
+        ops.check_gru_status()                   # a word set outside step() (inference, eval_loss)
 
     # -- optimizer state in torch.optim.Adam layout ------------------------------------------------------------------
     def optimizer_state_dict(self) -> dict:

@@ -22,7 +22,7 @@ class _RmseFn(torch.autograd.Function):
         B, C, T, F = ref.size()
         norm = float(B * T * F)
         loss = torch.empty(1, device=ref.device, dtype=torch.float64)
-        dest = torch.empty_like(est) if est.requires_grad else None
+        dest = torch.empty_like(est) if ctx.needs_input_grad[1] else None
         check(lib.cruse_rmse(_p(ref), _p(est), ref.numel(), 1.0 / norm, _p(loss), _p(dest), _stream()))
         ctx.dest = dest
         return (loss / norm).to(torch.float32).reshape(())
@@ -45,7 +45,7 @@ class _CRmseFn(torch.autograd.Function):
         ref = ref.contiguous(); est = est.contiguous()
         B, C, T, F = ref.size()
         loss = torch.empty(1, device=ref.device, dtype=torch.float64)
-        dest = torch.empty_like(est) if est.requires_grad else None
+        dest = torch.empty_like(est) if ctx.needs_input_grad[1] else None
         check(lib.cruse_c_rmse(_p(ref), _p(est), B, T * F, c, beta, _p(loss), _p(dest), _stream()))
         ctx.dest = dest
         return loss.to(torch.float32).reshape(())
@@ -100,7 +100,7 @@ class _WoMaleSpecFn(torch.autograd.Function):
         B, C, T, F = ref.size()
         norm = float(B * T * F)
         loss = torch.empty(1, device=ref.device, dtype=torch.float64)
-        dest = torch.empty_like(est) if est.requires_grad else None
+        dest = torch.empty_like(est) if ctx.needs_input_grad[1] else None
         check(lib.cruse_wo_male_spec(_p(ref), _p(est), _p(unproc), B, T * F, 2 * T * F, T * F, alpha, beta, 1.0 / norm, _p(loss),
                                      _p(dest), _stream()))
         ctx.dest = dest
@@ -118,6 +118,27 @@ def wo_male(ref, est, unproc, alpha=2.0, beta=1.0, gamma=1.0):
     if gamma != 1.0:
         raise RuntimeError("cruse_amd wo_male: gamma = 1 (the reference's only setting, loss.py:128)")
     return _WoMaleSpecFn.apply(ref, est, unproc, float(alpha), float(beta))
+
+
+def sdnr(ref_clean, est_g, ref_noise, snr=None, beta=20, alpha=None, norm=False, eps=1e-8):
+    """loss_func/loss.py:151-175 (vad == 1): alpha * mean_{B,F} sum_{C,T} (S - g S)^2 + (1 - alpha) * mean_{B,F} sum_{C,T} (N g)^2,
+    alpha = 10^(snr/10) / (10^(snr/10) + 10^(beta/10)); all three [B,C,T,F] real.  Runs the fused gain-loss kernel of the
+    training step (cruse_mask_sdnr_fwd) with zero imaginary parts; differentiable in est_g."""
+    from .loss import _MaskedSdnrFn
+    if ref_clean.dim() != 4 or ref_clean.shape != ref_noise.shape:
+        raise RuntimeError(f"Dimension mismatch when calculate sdnr, {ref_clean.shape} vs {ref_noise.shape}")
+    try:
+        est_g = est_g.expand_as(ref_clean)                      # (the reference's products broadcast a [B,1,T,F] gain)
+    except RuntimeError:
+        raise RuntimeError(f"Dimension mismatch when calculate sdnr, gain {tuple(est_g.shape)} vs {tuple(ref_clean.shape)}")
+    if snr is None:
+        raise TypeError("sdnr: snr is required (loss.py:171 evaluates 10 ** (snr / 10))")
+    B, C, T, F = ref_clean.shape
+    cre = ref_clean.contiguous().float().view(B, C * T, F)
+    zero = torch.zeros_like(cre)
+    nre = torch.empty_like(cre)
+    check(lib.cruse_axpby(_p(nre), _p(cre), _p(ref_noise.contiguous().float()), 1.0, 1.0, cre.numel(), _stream()))   # noisy = S + N
+    return _MaskedSdnrFn.apply(est_g.reshape(B, 1, C * T, F), cre, zero, nre, zero, float(snr), float(beta))
 
 
 class loss_func:

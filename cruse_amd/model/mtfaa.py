@@ -112,7 +112,7 @@ class _AmpPowFn(torch.autograd.Function):
     def forward(ctx, real, imag, eps, alpha):
         real = real.contiguous(); imag = imag.contiguous()
         out = torch.empty_like(real)
-        check(lib.cruse_polar(0, _p(real), _p(imag), None, real.numel(), eps, alpha, _p(out), None, _stream()))
+        check(lib.cruse_polar(0, _p(real), _p(imag), None, None, real.numel(), eps, alpha, _p(out), None, _stream()))
         ctx.save_for_backward(real, imag)
         ctx.eps, ctx.alpha = eps, alpha
         return out
@@ -121,7 +121,7 @@ class _AmpPowFn(torch.autograd.Function):
     def backward(ctx, g):
         real, imag = ctx.saved_tensors
         dr = torch.empty_like(real); di = torch.empty_like(real)
-        check(lib.cruse_polar(2, _p(real), _p(imag), _p(g.contiguous()), real.numel(), ctx.eps, ctx.alpha, _p(dr), _p(di), _stream()))
+        check(lib.cruse_polar(2, _p(real), _p(imag), _p(g.contiguous()), None, real.numel(), ctx.eps, ctx.alpha, _p(dr), _p(di), _stream()))
         return dr, di, None, None
 
 

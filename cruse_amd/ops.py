@@ -577,10 +577,20 @@ def axpby(out, x, y, a, b):
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, max_norm=0.0, gsumsq=None,
               skip_flag=None, loss_check=None, skipped=None):
-    """Fused Adam over flat buffers; the optional device-side guards are described at cruse_adam_step_guarded."""
+    """Fused Adam over flat buffers; the optional device-side guards are described at cruse_adam_step_guarded.
+    skip_flag: a uint8[4k] / int32[k] tensor of k status words (any non-zero word skips the step)."""
+    nw = 0 if skip_flag is None else skip_flag.numel() * skip_flag.element_size() // 4
     check(lib.cruse_adam_step_guarded(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
-                                      grad_scale, max_norm, _p(gsumsq), _p(skip_flag), _p(loss_check), _p(skipped),
+                                      grad_scale, max_norm, _p(gsumsq), _p(skip_flag), nw, _p(loss_check), _p(skipped),
                                       _stream()))
+
+
+def step_health(gru_status, loss_sum, health, loss_acc=None, loss_scale=1.0) -> None:
+    """health[0] = latched-and-cleared GRU status word, health[1] = non-finite loss; loss_acc += loss_sum * loss_scale
+    (cruse_step_health).  health: int32[2]."""
+    if health.dtype != torch.int32 or health.numel() < 2:
+        raise RuntimeError("step_health needs an int32[2] health tensor")
+    check(lib.cruse_step_health(_p(gru_status), _p(loss_sum), _p(health), _p(loss_acc), float(loss_scale), _stream()))
 
 
 def zero_(t: torch.Tensor) -> torch.Tensor:

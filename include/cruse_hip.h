@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CRUSE_ABI_VERSION 3
+#define CRUSE_ABI_VERSION 4
 
 enum {
     CRUSE_OK = 0,
@@ -365,12 +365,15 @@ int cruse_istft_framed(const float* re, const float* im, const float* window, co
 /* ---- masks, further losses, data synthesis ------------------------------------------------------------------------ */
 /* train_base/acoustics/mask.py:8-63.  mode 0 IRM (a = noisy_mag, c = clean_mag), 1 cIRM (a,b = noisy re,im; c,d = clean
  * re,im; out [n,2]), 2 compress_cIRM(a), 3 decompress_cIRM(a), 4 complex_mul (a + ib)(c + id) -> out, out2;
- * PreProcess (utils/utils.py:414-423): 5 pair product out = a*c, out2 = b*d ("complex_mapping"), 6 out = log(a). */
+ * PreProcess (utils/utils.py:414-423): 5 pair product out = a*c, out2 = b*d ("complex_mapping"), 6 out = log(a).
+ * Adjoints (the reference's ops are plain torch, hence differentiable): 7 out = c * compress'(a), 8 out = c * decompress'(a)
+ * (c = upstream gradient), 9 (a + ib) conj(c + id) -> out, out2 (both gradients of mode 4). */
 int cruse_mask_ops(int mode, const float* a, const float* b, const float* c, const float* d, long long n,
                    float K, float C, float limit, float* out, float* out2, void* stream);
 /* mode 0: (re, im) -> (sqrt(re^2+im^2+eps)**alpha, atan2(im, re)) (feature.py:363-364, mtfaa.py:136-137,162);
- * mode 1: (mag, phase) -> (mag cos, mag sin) (feature.py:386-387); mode 2: gradient of mode 0's magnitude (g = upstream). */
-int cruse_polar(int mode, const float* a, const float* b, const float* g, long long n, float eps, float alpha,
+ * mode 1: (mag, phase) -> (mag cos, mag sin) (feature.py:386-387); mode 2: gradient of mode 0 (g = d mag, g2 = d phase,
+ * either may be NULL) -> (d re, d im); mode 3: gradient of mode 1 (a, b = mag, phase; g, g2 = d re, d im) -> (d mag, d phase). */
+int cruse_polar(int mode, const float* a, const float* b, const float* g, const float* g2, long long n, float eps, float alpha,
                 float* o1, float* o2, void* stream);
 /* rmse (loss_func/loss.py:59-78): loss_sum = sum |est - ref| (divide by B*T*F); dest = sign(est-ref)*grad_scale (may be NULL) */
 int cruse_rmse(const float* ref, const float* est, long long n, float grad_scale, double* loss_sum, float* dest, void* stream);
@@ -416,17 +419,28 @@ int cruse_adam_step(float* p, const float* g, float* m, float* v, long long n,
                     int step, float grad_scale, void* stream);
 /* The same step behind device-side guards, so that one bad batch cannot poison the parameters and no host
  * synchronisation is needed to decide (all pointers optional):
- *   skip_flag  : *skip_flag != 0 skips the step (the sticky GRU hand-off status word, see cruse_gru_seq_fwd);
+ *   skip_flag  : n_skip_words u32 words; any non-zero word skips the step (the sticky GRU hand-off status word of
+ *                cruse_gru_seq_fwd, or the -- possibly all-reduced -- health words of cruse_step_health);
  *   loss_check : a non-finite *loss_check skips the step (the reference has no such check: a 0/0 bin in wo_male,
  *                loss_func/loss.py:141, would turn every parameter into NaN);
  *   gsumsq     : sum of squares of g (cruse_sumsq); a non-finite norm skips the step; with max_norm > 0 the gradient is
  *                scaled by min(1, max_norm / (sqrt(gsumsq)*grad_scale + 1e-6)) = torch.nn.utils.clip_grad_norm_
  *                (train_base/trainer/base_trainer.py:75 `clip_grad_norm_value`);
- *   skipped    : += 1 for every skipped step. */
+ *   skipped    : skipped[0] += 1 for every skipped step; with n_skip_words > 1 also skipped[1 + i] += 1 for each
+ *                non-zero word i (per-reason counters). */
 int cruse_adam_step_guarded(float* p, const float* g, float* m, float* v, long long n,
                             float lr, float beta1, float beta2, float eps, float weight_decay,
                             int step, float grad_scale, float max_norm, const double* gsumsq,
-                            const unsigned* skip_flag, const double* loss_check, unsigned* skipped, void* stream);
+                            const unsigned* skip_flag, int n_skip_words, const double* loss_check, unsigned* skipped,
+                            void* stream);
+/* Per-step health of a training step, decided on the device (no reference counterpart: train/trainer_casual.py is empty
+ * and base_trainer.py has no guard).  health[0] = the GRU status word was set -- and CLEARS it, so one transient
+ * hand-off time-out costs the step it happened in, not every later one; health[1] = *loss_sum is not finite.
+ * loss_acc (optional) += *loss_sum * loss_scale when finite (the running epoch loss, each step with its own norm).
+ * Data-parallel callers all-reduce health[0..1] with MAX before handing it to cruse_adam_step_guarded, so that every
+ * rank takes the same skip decision.  gru_status may be NULL. */
+int cruse_step_health(unsigned* gru_status, const double* loss_sum, unsigned* health, double* loss_acc,
+                      double loss_scale, void* stream);
 /* out (+)= sum x[i]^2 in f64 (total gradient norm for clip_grad_norm_); x 16-byte aligned */
 int cruse_sumsq(const float* x, long long n, double* out, int accumulate, void* stream);
 

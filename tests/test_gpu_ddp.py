@@ -42,6 +42,27 @@ eng = TrainEngine(m, lr=1e-3, use_graph=os.environ.get("NOGRAPH") != "1", bucket
 if mode == "nccl1" and bucketed:
     assert eng.bucketed and dist.get_backend() == "nccl"
 losses = []
+if mode == "poison":
+    # rank 1 alone sees a GRU hand-off time-out in step 0: EVERY rank must skip that step (all-reduced health word) and
+    # every rank must train in step 1; a rank-local decision would leave the replicas different for good
+    p_init = eng.flat.params.clone()
+    for step in range(2):
+        noisy, clean = O.synth_pair(2, 3200, seed=50 + step)
+        if step == 0 and rank == 1:
+            ops.gru_status_word("cuda", 2, 4, 160).copy_(torch.tensor([1, 0, 0, 0], dtype=torch.uint8))
+        eng.step(noisy.cuda(), clean.cuda())
+        torch.cuda.synchronize()
+        if step == 0:
+            assert torch.equal(eng.flat.params, p_init), f"rank {rank} applied a step another rank had to skip"
+    assert (eng.skipped_steps(), eng.timeout_steps()) == (1, 1), (rank, eng.skipped_steps(), eng.timeout_steps())
+    assert not torch.equal(eng.flat.params, p_init)
+    try:
+        eng.check_health(); raise SystemExit("check_health did not raise on rank %d" % rank)
+    except RuntimeError as ex:
+        assert "CRUSE_E_TIMEOUT" in str(ex)
+    torch.save({"params": eng.flat.params.cpu()}, sys.argv[2] + f"/p_poison_w{world}_r{rank}.pt")
+    dist.barrier(); dist.destroy_process_group()
+    print("OK"); sys.exit(0)
 for step in range(2):
     seed = 50 + step + (1000 * rank if mode == "shards" else 0)
     noisy, clean = O.synth_pair(2, 3200, seed=seed)
@@ -118,6 +139,37 @@ def test_two_rank_shards_bn_train_vs_oracle_rank_by_rank(tmp_path):
         worst = max(worst, e)
         assert e <= 5e-3, (n, e)
     print(f"[ddp shards] worst per-tensor rel-L2 of the summed gradient vs oracle {worst:.2e}")
+
+
+def test_one_ranks_timeout_skips_the_step_on_every_rank(tmp_path):
+    """the skip decision of the guarded Adam is global -- health words all-reduced with MAX."""
+    tmp = str(tmp_path)
+    _run(2, tmp, 29546, mode="poison")
+    a = torch.load(tmp + "/p_poison_w2_r0.pt")["params"]
+    b = torch.load(tmp + "/p_poison_w2_r1.pt")["params"]
+    assert torch.equal(a, b), "ranks diverged after a one-rank time-out"
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no launcher starts two ranks itself (the reference: mp.spawn, tools/train_stand.py:151-155);
+    on this one-GPU rig over gloo.  The JSON line must say n_gpus 2 / world_size 2."""
+    import json
+    env = dict(os.environ, CRUSE_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "8",
+                          "--seconds", "1", "--no-cpu-baseline", "--no-parity", "--no-secondary", "--no-kernel-timing", "--no-graph"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    line = [l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["world_size"] == 2 and j["backend"] == "gloo" and j["bucketed_allreduce"] is True
+    assert j["config"]["global_batch"] == 16 and j["value"] > 0
+    # more ranks than devices over RCCL is refused, loudly
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(torch.cuda.device_count() + 1)],
+                         env={k: v for k, v in env.items() if k != "CRUSE_DIST_BACKEND"}, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=300)
+    assert bad.returncode != 0 and b"HIP device" in bad.stderr
 
 
 @pytest.mark.parametrize("nograph", ["0", "1"])

@@ -107,6 +107,74 @@ def test_mask_py_vs_reference(golden):
     assert rel_l2(M.decompress_cIRM(M.compress_cIRM(m)), m) < 1e-4
 
 
+def test_elementwise_ops_carry_gradients():
+    """mask.py / PreProcess.masking / CustomSTFT m,p / CustomISTFT are plain (differentiable) torch in the
+    reference and sit between the network and the loss -- the HIP versions must carry the same gradients."""
+    from cruse_amd.acoustics import mask as M
+    from cruse_amd.acoustics.feature import mag_phase, polar_to_rect
+    from cruse_amd.acoustics.preprocess import _pair_op
+    from oracle import cruse_oracle_ext as X
+    torch.manual_seed(3)
+    shp = (2, 5, 7)
+    a, b, c, d = (torch.randn(shp) for _ in range(4))
+    w1, w2 = torch.randn(shp), torch.randn(shp)
+
+    def grads(fn, inputs, dev):
+        xs = [x.clone().to(dev).requires_grad_(True) for x in inputs]
+        outs = fn(*xs)
+        outs = outs if isinstance(outs, tuple) else (outs,)
+        sum((o * w.to(dev)).sum() for o, w in zip(outs, (w1, w2))).backward()
+        return [x.grad.cpu() for x in xs]
+
+    cases = [
+        ("complex_mul", M.complex_mul, lambda nr, ni, mr, mi: (nr * mr - ni * mi, nr * mi + ni * mr), (a, b, c, d)),   # mask.py:61-64
+        ("compress", M.compress_cIRM, X.compress_cIRM, (3 * a,)),
+        ("decompress", M.decompress_cIRM, X.decompress_cIRM, (6 * a,)),                 # incl. elements beyond +-9.9 (clamped: 0)
+        ("pair", lambda p, q, r, s_: _pair_op(5, p, q, r, s_), lambda p, q, r, s_: (p * r, q * s_), (a, b, c, d)),
+        ("mag_phase", mag_phase, lambda r, i: (torch.sqrt(r * r + i * i), torch.atan2(i, r)), (a, b)),
+        ("polar_to_rect", polar_to_rect, lambda m, p: (m * torch.cos(p), m * torch.sin(p)), (a.abs(), b)),
+    ]
+    for name, fn, ref, inputs in cases:
+        got, want = grads(fn, inputs, "cuda"), grads(ref, inputs, "cpu")
+        for k, (g_, w_) in enumerate(zip(got, want)):
+            assert rel_l2(g_, w_) < 1e-5, (name, k, rel_l2(g_, w_))
+    # "mag_mapping" passes the SAME mask twice: both products' gradients must add up in it
+    m = c.clone().cuda().requires_grad_(True)
+    o1, o2 = _pair_op(5, a.cuda(), b.cuda(), m, m)
+    (o1 * w1.cuda() + o2 * w2.cuda()).sum().backward()
+    assert rel_l2(m.grad.cpu(), a * w1 + b * w2) < 1e-6
+
+
+def test_sdnr_wrapper_and_noncontiguous_estimates(golden):
+    """loss_func.sdnr (loss_func/loss.py:151-175) through the dotted path: fixture G18 values, gradient vs oracle autograd;
+    rmse / c_rmse / wo_male with a NON-contiguous estimate (`est.contiguous()` lost requires_grad)."""
+    from loss_func.loss import c_rmse, rmse, sdnr, wo_male
+    from oracle import cruse_oracle as O
+    from oracle import cruse_oracle_ext as X
+    g = golden("g18_sdnr.npz")
+    clean, noise, gain = (torch.from_numpy(g[k]) for k in ("clean", "noise", "gain"))
+    for k, snr in enumerate(g["snr"]):
+        gg = gain.clone().cuda().requires_grad_(True)
+        v = sdnr(clean.cuda(), gg, noise.cuda(), snr=float(snr))
+        want = float(g["value"][k])
+        assert abs(float(v) - want) <= 2e-5 * abs(want)
+        v.backward()
+        go = gain.clone().requires_grad_(True)
+        O.sdnr(clean, go, noise, float(snr), beta=20.0).backward()
+        assert rel_l2(gg.grad, go.grad) < 1e-4
+    g10 = golden("g10_losses.npz")
+    ref, est = torch.from_numpy(g10["ref"]), torch.from_numpy(g10["est"])
+    for fn, ofn in ((rmse, X.rmse), (c_rmse, X.c_rmse), (lambda r, e: wo_male(r, e, r + 0.5 * e.detach()), None)):
+        e_t = est.transpose(2, 3).contiguous().cuda().requires_grad_(True)       # the network's output, then permuted
+        v = fn(ref.cuda(), e_t.transpose(2, 3))
+        v.backward()
+        assert e_t.grad is not None and torch.isfinite(e_t.grad).all()
+        if ofn is not None:
+            eo = est.clone().requires_grad_(True)
+            ofn(ref, eo).backward()
+            assert rel_l2(e_t.grad.transpose(2, 3), eo.grad) < 1e-4
+
+
 # ---------------------------------------------------------------------------------------------------------------- a9
 CONV_CASES = {
     "cna": lambda m: m.Conv2dNormAct(1, 16, (2, 3), fstride=2),

@@ -84,6 +84,37 @@ def test_bf16_forward_parity_at_bench_length(grp, init):
 
 
 @pytest.mark.parametrize("grp", [1, 4])
+def test_bf16_forward_parity_at_the_full_bench_batch(grp):
+    """the BENCH batch itself -- B = 64 x T = 401, i.e. 8 (g = 1) / 32 (g = 4) concurrent GRU chains
+    placed by the per-XCD ticket (gru.hip claim_chain) -- against the CPU oracle, every clip on its own: a chain that
+    picked up another chain's panel, or a clip routed to the wrong batch group, shows as ONE clip far off the rest."""
+    from cruse_amd import ops
+    from cruse_amd.engine import TrainEngine
+    from cruse_amd.model.cruse_net import unet2_forward
+    from oracle import cruse_oracle as O
+    B, T = 64, 401
+    o, m = _pair(grp, "random", "bf16")
+    noisy, _ = O.synth_pair(B, (T - 1) * 160, seed=21)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    with torch.no_grad():
+        mask_o, est_o, _ = O.enhanced_spectrum(o, noisy)
+    eng = TrainEngine(m, use_graph=False)
+    nre, nim, mag = ops.stft(noisy.cuda(), 320, 160, mag_bins=160, mag_eps=1e-8)
+    mask, _ = unet2_forward(mag.view(B, 1, T, 160), eng.flat.P, eng.Bf, m.ch, m.rnn_groups, "bf16", training=True,
+                            save=False, update_running=False)
+    er, ei = ops.mask_apply(mask.contiguous().view(B * T, 160), nre, nim, B * T, 160, 161)
+    est = torch.stack([er.view(B, T, 161), ei.view(B, T, 161)], dim=-1).cpu()
+    assert ops.gru_status() == 0
+    e_all = rel_l2(est, est_o)
+    per_clip = torch.tensor([rel_l2(est[b], est_o[b]) for b in range(B)])
+    print(f"[parity bf16 B=64 T=401 g={grp}] enhanced-spectrum rel-L2 {e_all:.3e}; per clip max {float(per_clip.max()):.3e} "
+          f"median {float(per_clip.median()):.3e}")
+    assert e_all <= FWD_TOL
+    assert float(per_clip.max()) <= 2.5 * FWD_TOL and float(per_clip.max()) <= 6 * float(per_clip.median())
+    # BatchNorm statistics are batch-wide: the B = 8 and B = 64 runs are different computations, both pinned by the oracle
+
+
+@pytest.mark.parametrize("grp", [1, 4])
 def test_bf16_train_step_vs_golden_g6(golden, grp):
     """fixture G6 (B = 2, T = 21) in the bench mode: loss, enhanced spectrum, every gradient norm vs the fixture."""
     from cruse_amd.engine import TrainEngine

@@ -186,6 +186,39 @@ def test_guarded_adam_skips_nonfinite_and_timeout_steps():
     assert ops.gru_status() == 0
 
 
+@pytest.mark.parametrize("graph", [True, False])
+def test_engine_latches_timeout_per_step_and_mean_loss_per_shape(graph):
+    """(i) a GRU time-out costs the step it happened in -- the device word is latched into the step's health
+    word and cleared, the next step trains again, check_health() reports it; (ii) mean_loss() normalises every step with
+    ITS shape's norm (a partial last batch replayed from the graph cache used to be scaled by the other shape's norm)."""
+    from cruse_amd import ops
+    from cruse_amd.engine import TrainEngine
+    from cruse_amd.model.cruse_net import unet_2
+    from oracle import cruse_oracle as O
+    torch.manual_seed(0)
+    eng = TrainEngine(unet_2(rnn_groups=2, precision="f32").cuda(), use_graph=graph)
+    a = [t_.cuda() for t_ in O.synth_pair(3, 3200, seed=1)]
+    b = [t_.cuda() for t_ in O.synth_pair(2, 3200, seed=2)]
+    per_step = []
+    for batch in (a, b, a, b):
+        ls = eng.step(*batch)
+        per_step.append(eng.loss_value(ls))
+    assert eng.mean_loss() == pytest.approx(sum(per_step) / 4, rel=1e-9)
+    p0 = eng.flat.params.clone()
+    word = ops.gru_status_word("cuda", 3, 2, 320)
+    word.copy_(torch.tensor([1, 0, 0, 0], dtype=torch.uint8))           # "a hand-off timed out in this step"
+    eng.step(*a)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.flat.params, p0), "a poisoned step reached the parameters"
+    assert (eng.skipped_steps(), eng.timeout_steps(), eng.nonfinite_steps()) == (1, 1, 0)
+    assert ops.gru_status() == 0                                        # latched and cleared
+    eng.step(*a)
+    torch.cuda.synchronize()
+    assert not torch.equal(eng.flat.params, p0) and eng.skipped_steps() == 1
+    with pytest.raises(RuntimeError, match="CRUSE_E_TIMEOUT"):
+        eng.check_health()
+
+
 def test_engine_caches_one_graph_per_input_shape():
     """a partial last batch must not force a re-capture on every epoch: graphs are cached per shape."""
     from cruse_amd.engine import TrainEngine
