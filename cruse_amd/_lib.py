@@ -55,6 +55,8 @@ SIGNATURES = {
     "cruse_gru_seq_bwd": ("pppppiiiiipp", "i"),
     "cruse_gru_seq_fwd_on": ("pppppppiiiiippip", "i"),
     "cruse_gru_seq_bwd_on": ("pppppppiiiiippip", "i"),
+    "cruse_gru_seq_fwd_ex": ("ppppppppqiiiiiippip", "i"),
+    "cruse_gru_seq_bwd_ex": ("pppppppiiiiiiippip", "i"),
     "cruse_gru_gate_grads": ("pppppqiiip", "i"),
     "cruse_gru_gate_grads_bf16": ("pppppqppqiip", "i"),
     "cruse_mask_loss_fwd": ("ppppqiiffpppppp", "i"),
@@ -88,6 +90,7 @@ SIGNATURES = {
     "cruse_wo_male_spec": ("pppiqqqfffppp", "i"),
     "cruse_onepole_fir": ("piififpp", "i"),
     "cruse_snr_mix": ("pppiifppppp", "i"),
+    "cruse_fir_causal": ("ppqiiipp", "i"),
     "cruse_stream_create_masked": ("ppi", "i"),
     "cruse_cu_census": ("piip", "i"),
     "cruse_zero": ("pzp", "i"),

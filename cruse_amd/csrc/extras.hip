@@ -285,6 +285,43 @@ __global__ __launch_bounds__(256) void onepole_fir_kernel(const float* x, int L,
     y[(long long)b * L + n] = acc;
 }
 
+// y[b,n] = sum_{k < R, k <= n} h[k] x[b,n-k]: scipy.signal.fftconvolve(x, h)[:L], the room-impulse-response step of
+// SynDataset.snr_mix (dataset/dataset.py:245-248), as a direct causal FIR.  One block = 1024 outputs of one clip; the taps
+// are walked in chunks of 256 with the matching input window (1279 samples) staged in LDS; a thread owns outputs
+// n0 + t + 256 j, so the window reads of a wave are 64 consecutive floats (conflict-free) and the tap is a broadcast.
+__global__ __launch_bounds__(256) void fir_causal_kernel(const float* x, const float* h, long long h_bstride, int L, int R, float* y) {
+    constexpr int NO = 1024, KC = 256;
+    __shared__ float xs[NO + KC];
+    __shared__ float hs[KC];
+    const int b = blockIdx.y, n0 = blockIdx.x * NO, t = threadIdx.x;
+    const float* xb = x + (long long)b * L;
+    const float* hb = h + (long long)b * h_bstride;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int kmax = min(R, n0 + NO);                        // taps beyond the last output's index only meet x[< 0]
+    for (int kc = 0; kc < kmax; kc += KC) {
+        __syncthreads();
+        // xs[i] = x[n0 - kc - (KC - 1) + i],  i in [0, NO + KC - 1)
+        for (int i = t; i < NO + KC - 1; i += 256) {
+            const int n = n0 - kc - (KC - 1) + i;
+            xs[i] = (n >= 0 && n < L) ? xb[n] : 0.f;
+        }
+        hs[t] = (kc + t < R) ? hb[kc + t] : 0.f;
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < KC; ++k) {
+            const float w = hs[k];
+            const int o = t + (KC - 1) - k;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += w * xs[o + 256 * j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + t + 256 * j;
+        if (n < L) y[(long long)b * L + n] = acc[j];
+    }
+}
+
 inline int eblocks(long long n, int per = 1024, int cap = 4096) {
     long long g = (n + per - 1) / per;
     if (g < 1) g = 1;
@@ -358,6 +395,14 @@ extern "C" int cruse_onepole_fir(const float* x, int B, int L, float a, int taps
     CRUSE_REQUIRE(B > 0 && L > 0 && taps > 0 && taps <= 128 && x != y, CRUSE_E_SHAPE, "onepole_fir: bad arguments (taps <= 128, out of place)");
     hipLaunchKernelGGL(onepole_fir_kernel, dim3((L + 255) / 256, B), dim3(256), 0, ST(stream), x, L, a, taps, gain, y);
     CRUSE_LAUNCH_CHECK("onepole_fir");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_fir_causal(const float* x, const float* h, long long h_bstride, int B, int L, int R, float* y, void* stream) {
+    CRUSE_REQUIRE(B > 0 && L > 0 && R > 0 && x != y && (h_bstride == 0 || h_bstride >= R), CRUSE_E_SHAPE,
+                  "fir_causal: bad arguments (B=%d L=%d R=%d; out of place; tap rows R apart or shared)", B, L, R);
+    hipLaunchKernelGGL(fir_causal_kernel, dim3((L + 1023) / 1024, B), dim3(256), 0, ST(stream), x, h, h_bstride, L, R, y);
+    CRUSE_LAUNCH_CHECK("fir_causal");
     return CRUSE_OK;
 }
 

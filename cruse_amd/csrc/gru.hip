@@ -57,6 +57,12 @@ struct GruArgs {
     int xcd_rot;                      // chain c of a launch runs on PHYSICAL XCD (c + xcd_rot) % 8 (concurrent launches: disjoint XCDs)
     unsigned* tickets;                // [8] per-XCD workgroup counters of this launch (zeroed with the panels)
     int dbg;                          // profiling only (CRUSE_GRU_DBG): 1 = do not wait for tags, 2 = also skip MFMA
+    // sub-sequences (cruse_gru_seq_*_ex): T steps of tensors whose clips are TS frames apart (TS >= T; the pointers are
+    // already advanced to the first frame of the run)
+    int TS;
+    const float* h0; long long h0_bs; // forward: initial state [B][G*Hg] ("cat" layout), clips h0_bs floats apart; NULL = 0
+    int carry;                        // backward: the first iteration takes dh of frame T-1 from the dh buffer (a later
+                                      // run of the same sequence wrote it) instead of forming it from dout
 };
 
 // LDS panel storage per precision: f32 keeps floats; bf16 / bf16x3 keep 1 / 2 planes of bf16 converted
@@ -379,6 +385,15 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
     make_idx<PREC>(si0, nload, Hg, LD, 0, 0, tid);
 
     for (int i = tid; i < NPL * PLANE; i += 256) hB[i] = (elem)0.f;
+    const bool has_h0 = a.h0 != nullptr;
+    if (has_h0) {                                                 // the panel of step 0 is the initial state
+        __syncthreads();
+        for (int e = tid; e < nb * (Hg >> 1); e += 256) {
+            const int bl_ = e / (Hg >> 1), v = 2 * (e - bl_ * (Hg >> 1));
+            const float2 hv = *reinterpret_cast<const float2*>(a.h0 + (long long)(b0 + bl_) * a.h0_bs + grp * Hg + v);
+            panel_put2<PREC>(hB, PLANE, bl_ * LD + v, hv.x, hv.y);
+        }
+    }
 
     // resident weight fragments: tile j = gate*2 + half; this wave's k-steps ks = wv + 4*i
     Frag<PREC> wf[6][NKW];
@@ -411,11 +426,12 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int bl = (tid >> 5) + 8 * q;
-        gp[q] = a.gi + ((long long)(b0 + bl) * a.T * a.G + grp) * 3 * Hg + u0 + u;
+        gp[q] = a.gi + ((long long)(b0 + bl) * a.TS * a.G + grp) * 3 * Hg + u0 + u;
 #pragma unroll
         for (int g = 0; g < 3; ++g) gic[q][g] = (q < NIT && bl < nb) ? gp[q][g * Hg] : 0.f;
 #pragma unroll
         for (int e = 0; e < 6; ++e) sv[q][e] = 0.f;
+        if (has_h0 && q < NIT && bl < nb) hp[q] = a.h0[(long long)(b0 + bl) * a.h0_bs + grp * Hg + u0 + u];
     }
     bool aborted = a.dbg >= 1 && a.dbg < 8;
     const bool plain = a.dbg != 9 && team_shares_xcd(a.xid + (size_t)chain * 64, a.P, part, a.status, tid);
@@ -423,10 +439,10 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
 
     auto save_step = [&](int q, int t) {
         const int bl = (tid >> 5) + 8 * q;
-        const long long o = ((long long)(b0 + bl) * a.T + t) * H + grp * Hg + u0 + u;
+        const long long o = ((long long)(b0 + bl) * a.TS + t) * H + grp * Hg + u0 + u;
         a.h[o] = sv[q][0];
         if (a.coef) {
-            const long long o3 = (((long long)(b0 + bl) * a.T + t) * a.G + grp) * 3 * Hg + u0 + u;
+            const long long o3 = (((long long)(b0 + bl) * a.TS + t) * a.G + grp) * 3 * Hg + u0 + u;
             if constexpr (PREC == CRUSE_PREC_BF16) {
                 __bf16* cp = reinterpret_cast<__bf16*>(a.coef);
                 cp[o3] = (__bf16)sv[q][1]; cp[o3 + Hg] = (__bf16)sv[q][2]; cp[o3 + 2 * Hg] = (__bf16)sv[q][3];
@@ -454,7 +470,7 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
             for (int g = 0; g < 3; ++g)
                 gin_[q][g] = (act && t + 1 < a.T) ? gp[q][(long long)(t + 1) * gi_row + g * Hg] : 0.f;
         }
-        if (t > 0) {
+        if (t > 0 || has_h0) {
             f32x4 acc[6];
 #pragma unroll
             for (int j = 0; j < 6; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -478,7 +494,7 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
             const int bl = (tid >> 5) + 8 * q;
             const bool act = bl < nb;
             float gh[3] = {bias[0], bias[1], bias[2]};
-            if (t > 0) {
+            if (t > 0 || has_h0) {
                 const int lp = (ru >> 2) * 16 + bl;
 #pragma unroll
                 for (int g = 0; g < 3; ++g)
@@ -571,8 +587,9 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
     for (int i = tid; i < 16 * LD; i += (HW ? 320 : 256)) hB[i] = (__bf16)0.f;
 
     const unsigned frame_bytes = (unsigned)H * 4u, grow_bytes = (unsigned)(a.G * 3 * Hg) * 4u, crow_bytes = grow_bytes >> 1;
-    const unsigned tot_h = (unsigned)min((long long)a.B * a.T * H * 4, 0xffffffffll);
-    const unsigned tot_g = (unsigned)min((long long)a.B * a.T * a.G * 3 * Hg * 4, 0xffffffffll);
+    const long long nrow = (long long)(a.B - 1) * a.TS + a.T;           // rows reachable from the (advanced) base pointers
+    const unsigned tot_h = (unsigned)min(nrow * H * 4, 0xffffffffll);
+    const unsigned tot_g = (unsigned)min(nrow * a.G * 3 * Hg * 4, 0xffffffffll);
     const __amdgpu_buffer_rsrc_t rs_gi = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gi), 0, tot_g, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(a.h, 0, tot_h, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_an = __builtin_amdgcn_make_buffer_rsrc(a.an, 0, a.an ? tot_h : 0u, 0x00020000);
@@ -587,20 +604,20 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
 #pragma unroll
         for (int i3 = 0; i3 < 3; ++i3) {
             const int idx = lane + 64 * i3, cl = idx / 24, rem = idx % 24, gate = rem >> 3, chk = rem & 7;
-            gv[i3] = (unsigned)((((long long)(b0 + (cl < nb ? cl : 0)) * a.T * a.G + grp) * 3 * Hg + gate * Hg + u0 + 4 * chk) * 4);
+            gv[i3] = (unsigned)((((long long)(b0 + (cl < nb ? cl : 0)) * a.TS * a.G + grp) * 3 * Hg + gate * Hg + u0 + 4 * chk) * 4);
             gdst[i3] = (unsigned)(cl * 96 + gate * 32 + chk * 4);
         }
         // saves: h / a_n / z rows: lane = (clip, chunk of 4 floats); coefficient rows: 8 clips x 3 gates x 4 chunks of 8 bf16
         const int lc = lane >> 3, lq = lane & 7;
         const bool rok = lc < nb;
-        const unsigned hv = (unsigned)(((long long)(b0 + (rok ? lc : 0)) * a.T * H + grp * Hg + u0 + 4 * lq) * 4);
+        const unsigned hv = (unsigned)(((long long)(b0 + (rok ? lc : 0)) * a.TS * H + grp * Hg + u0 + 4 * lq) * 4);
         unsigned cv[2], csrc[2];
         bool cok[2];
 #pragma unroll
         for (int i2 = 0; i2 < 2; ++i2) {
             const int idx = min(lane + 64 * i2, 95), cl = idx / 12, rem = idx % 12, gate = rem >> 2, chk = rem & 3;
             cok[i2] = lane + 64 * i2 < 96 && cl < nb;
-            cv[i2] = (unsigned)((((long long)(b0 + (cl < nb ? cl : 0)) * a.T * a.G + grp) * 3 * Hg + gate * Hg + u0 + 8 * chk) * 2);
+            cv[i2] = (unsigned)((((long long)(b0 + (cl < nb ? cl : 0)) * a.TS * a.G + grp) * 3 * Hg + gate * Hg + u0 + 8 * chk) * 2);
             csrc[i2] = (unsigned)(((1 + gate) * 8 + cl) * 32 + chk * 8);
         }
         struct GiSet { u32x4 v[3]; };
@@ -640,14 +657,17 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
         issue(0, s0); issue(1, s1);
         put(0, s0); put(1, s1);
         issue(2, s0); issue(3, s1);
+        if (a.h0 != nullptr) __syncthreads();           // mirrors the compute waves' barrier before the h0 panel fill
         if (a.dbg != 9) (void)team_shares_xcd(a.xid + (size_t)chain * 64, a.P, part, a.status, tid);   // mirrors the compute waves' barriers
         __syncthreads();
         // step t: two barriers (t > 0).  The gi set for step t + 2 goes to its ring slot, the set is re-issued for step
         // t + 4; the saves of step t - 1 are in LDS once the first barrier of step t has passed.
+        const bool h0_step = a.h0 != nullptr;              // step 0 then runs its MFMA phase too (two barriers like any other)
         for (int t = 0; t < a.T; t += 2) {
-            if (t > 0) __syncthreads();
+            if (t > 0 || h0_step) __syncthreads();
             put(t + 2, s0); issue(t + 4, s0);
-            if (t > 0) { flush(t - 1); __syncthreads(); }
+            if (t > 0) flush(t - 1);
+            if (t > 0 || h0_step) __syncthreads();
             if (t + 1 >= a.T) break;
             __syncthreads();
             put(t + 3, s1); issue(t + 5, s1);
@@ -698,13 +718,26 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
     float bias[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) bias[g] = bh[g * Hg + u0 + u];
-    const unsigned own_v = (unsigned)(((long long)(b0 + blc) * a.T * H + grp * Hg + u0 + u) * 4);                    // + t*frame_bytes
-    const unsigned g_v = (unsigned)((((long long)(b0 + blc) * a.T * a.G + grp) * 3 * Hg + u0 + u) * 4);               // + t*grow_bytes
+    const unsigned own_v = (unsigned)(((long long)(b0 + blc) * a.TS * H + grp * Hg + u0 + u) * 4);                    // + t*frame_bytes
+    const unsigned g_v = (unsigned)((((long long)(b0 + blc) * a.TS * a.G + grp) * 3 * Hg + u0 + u) * 4);               // + t*grow_bytes
     const unsigned hg4 = (unsigned)Hg * 4u;
     const unsigned pub_v = (unsigned)((bl * Hg + u0 + u) >> 1) * 8u;
     const bool pub_lane = act && !(u & 1);
 
     float hp = 0.f, gic[3], sv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool has_h0 = a.h0 != nullptr;
+    if (has_h0) {                                          // the panel of step 0 is the initial state (bf16, like any h_{t-1})
+        __syncthreads();                                   // (the zero fill above)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int e = min(tid + 256 * j, nload - 1);
+            const int bl_ = e / per, v = 4 * (e - bl_ * per);
+            const float4 hv = *reinterpret_cast<const float4*>(a.h0 + (long long)(b0 + bl_) * a.h0_bs + grp * Hg + v);
+            const u32x2 w = {pack2(hv.x, hv.y), pack2(hv.z, hv.w)};
+            *reinterpret_cast<u32x2*>(hB + sw_l[j]) = w;
+        }
+        if (act) hp = a.h0[(long long)(b0 + bl) * a.h0_bs + grp * Hg + u0 + u];
+    }
     if constexpr (!HW) {
 #pragma unroll
         for (int g = 0; g < 3; ++g) gic[g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_gi, g_v + g * hg4, 0, 0));
@@ -763,7 +796,7 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
             for (int g = 0; g < 3; ++g) gin_[g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_gi, g_v + g * hg4, so, 0));
         }
         float gh[3] = {bias[0], bias[1], bias[2]};
-        if (t > 0) {
+        if (t > 0 || has_h0) {
             __syncthreads();                               // panel complete
             f32x4 acc[6];
 #pragma unroll
@@ -892,15 +925,15 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruArgs a) {
     const int half = u >> 4, ru = u & 15;
     const int lp = (ru >> 2) * 16 + bl;
     float dh0 = 0.f, dh1 = 0.f;          // dh_{s+1} of the own units
-    const long long own = (long long)(b0 + bl) * a.T * H + grp * Hg + u0 + u;     // + s*H
-    const long long cf_row = (long long)a.T * a.G * K;
-    const coef_t* cf_base = reinterpret_cast<const coef_t*>(a.coefs) + ((long long)b0 * a.T * a.G + grp) * K;   // + s*G*K
+    const long long own = (long long)(b0 + bl) * a.TS * H + grp * Hg + u0 + u;     // + s*H
+    const long long cf_row = (long long)a.TS * a.G * K;
+    const coef_t* cf_base = reinterpret_cast<const coef_t*>(a.coefs) + ((long long)b0 * a.TS * a.G + grp) * K;   // + s*G*K
     SweepIdx<PREC> si0;
     make_idx<PREC>(si0, nload, Hg, LD, cf_row, 0, tid);
     // operands of the CURRENT step k (time s = T-1-k): dout_s, z_{s+1}, coefficient panel c_{s+1}
     float2 dd = make_float2(0.f, 0.f), zz = dd;
     CoefRegs<PREC> cr;
-    if (active) dd = *reinterpret_cast<const float2*>(a.dout + own + (long long)(a.T - 1) * H);
+    if (active) dd = *reinterpret_cast<const float2*>((a.carry ? a.dh : a.dout) + own + (long long)(a.T - 1) * H);
     float2 sv_dh = make_float2(0.f, 0.f);
     bool aborted = a.dbg >= 1 && a.dbg < 8;
     const bool plain = a.dbg != 9 && team_shares_xcd(a.xid + (size_t)chain * 64, a.P, part, a.status, tid);
@@ -1010,8 +1043,9 @@ __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
     for (int i = tid; i < 2 * 16 * KP; i += 320) panel[0][i] = (__bf16)0.f;
 
     const unsigned frame_bytes = (unsigned)H * 4u, crow_bytes = (unsigned)(a.G * K3) * 2u;
-    const unsigned tot_f32 = (unsigned)min((long long)a.B * a.T * H * 4, 0xffffffffll);
-    const unsigned tot_cf = (unsigned)min((long long)a.B * a.T * a.G * K3 * 2, 0xffffffffll);
+    const long long nrow = (long long)(a.B - 1) * a.TS + a.T;           // rows reachable from the (advanced) base pointers
+    const unsigned tot_f32 = (unsigned)min(nrow * H * 4, 0xffffffffll);
+    const unsigned tot_cf = (unsigned)min(nrow * a.G * K3 * 2, 0xffffffffll);
     const __amdgpu_buffer_rsrc_t rs_dout = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dout), 0, tot_f32, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.zs), 0, tot_f32, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_dh = __builtin_amdgcn_make_buffer_rsrc(a.dh, 0, tot_f32, 0x00020000);
@@ -1021,7 +1055,7 @@ __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
     if (wv == 4) {
         // ---- loader wave.  Iteration j needs dout_{T-1-j}, c_{T-1-j} and z_{T-j}; lane = (clip, 16-byte chunk).
         const int lc = lane >> 3, lq = lane & 7;                                   // dout / z: 8 clips x 8 chunks of 4 floats
-        const unsigned dv = (unsigned)(((long long)(b0 + (lc < nb ? lc : 0)) * a.T * H + grp * Hg + u0 + 4 * lq) * 4);
+        const unsigned dv = (unsigned)(((long long)(b0 + (lc < nb ? lc : 0)) * a.TS * H + grp * Hg + u0 + 4 * lq) * 4);
         unsigned cv[2], cdst[2];
         bool cok[2];
 #pragma unroll
@@ -1029,7 +1063,7 @@ __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
             const int idx = lane + 64 * i2;
             cok[i2] = idx < 96;
             const int cl = min(idx, 95) / 12, rem = min(idx, 95) % 12, gate = rem >> 2, chk = rem & 3;
-            cv[i2] = (unsigned)((((long long)(b0 + (cl < nb ? cl : 0)) * a.T * a.G + grp) * K3 + gate * Hg + u0 + 8 * chk) * 2);
+            cv[i2] = (unsigned)((((long long)(b0 + (cl < nb ? cl : 0)) * a.TS * a.G + grp) * K3 + gate * Hg + u0 + 8 * chk) * 2);
             cdst[i2] = (unsigned)(cl * 96 + gate * 32 + chk * 8);
         }
         const bool want_dgi = a.dgi != nullptr;
@@ -1041,7 +1075,9 @@ __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
             o.d = zero; o.z = zero; o.c0 = zero; o.c1 = zero; o.an = zero;
             if (j >= a.T || nodata) return;
             const unsigned st = (unsigned)(a.T - 1 - j);
-            o.d = __builtin_amdgcn_raw_buffer_load_b128(rs_dout, dv, st * frame_bytes, 0);
+            // (a carried run: the dh of its last frame was written by the run that followed it in time)
+            o.d = (j == 0 && a.carry) ? __builtin_amdgcn_raw_buffer_load_b128(rs_dh, dv, st * frame_bytes, 0)
+                                      : __builtin_amdgcn_raw_buffer_load_b128(rs_dout, dv, st * frame_bytes, 0);
             if (j > 0) o.z = __builtin_amdgcn_raw_buffer_load_b128(rs_z, dv, (st + 1u) * frame_bytes, 0);
             o.c0 = __builtin_amdgcn_raw_buffer_load_b128(rs_cf, cv[0], st * crow_bytes, 0);
             if (cok[1]) o.c1 = __builtin_amdgcn_raw_buffer_load_b128(rs_cf, cv[1], st * crow_bytes, 0);
@@ -1059,7 +1095,7 @@ __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
         // asked for -- the gate gradients dgi_s = dh_s * (c_r, c_z, a_n) in bf16, the A operand of dX = dgi W_ih: the
         // separate gate-gradient pass then only has to make the time-major copies for the weight-gradient GEMMs, off the
         // main stream.  lane = (clip lc, unit quad lq).
-        const unsigned gi_v = (unsigned)((((long long)(b0 + (lc < nb ? lc : 0)) * a.T * a.G + grp) * K3 + u0 + 4 * lq) * 2);
+        const unsigned gi_v = (unsigned)((((long long)(b0 + (lc < nb ? lc : 0)) * a.TS * a.G + grp) * K3 + u0 + 4 * lq) * 2);
         auto flush = [&](int j) {
             if (lc >= nb) return;
             const unsigned st = (unsigned)(a.T - 1 - j);
@@ -1548,12 +1584,15 @@ extern "C" size_t cruse_gru_ws_bytes(int B, int G, int Hg) {
     return 256 + xid_bytes_total(B, G) + xg_bytes_total(B, G, Hg) + (size_t)MAX_LAUNCH_TICKETS * 8 * sizeof(unsigned);
 }
 
-extern "C" int cruse_gru_seq_fwd_on(const float* gi, const float* const* w_hh, const float* const* b_hh,
-                                    float* h, void* coef, float* an, float* z,
-                                    int B, int T, int G, int Hg, int prec, void* panels, unsigned* status, int xcd_rot,
+extern "C" int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, const float* const* b_hh,
+                                    float* h, void* coef, float* an, float* z, const float* h0, long long h0_bstride,
+                                    int B, int T, int TS, int G, int Hg, int prec, void* panels, unsigned* status, int xcd_rot,
                                     void* stream) {
     int rc = check_common(B, T, G, Hg, prec, "gru_seq_fwd");
     if (rc) return rc;
+    CRUSE_REQUIRE(TS >= T, CRUSE_E_SHAPE, "gru_seq_fwd: clip stride %d frames < %d steps", TS, T);
+    CRUSE_REQUIRE(h0 == nullptr || (h0_bstride >= (long long)G * Hg && ((uintptr_t)h0 % 16) == 0 && h0_bstride % 4 == 0), CRUSE_E_SHAPE,
+                  "gru_seq_fwd: h0 needs a clip stride >= G*Hg (multiple of 4 floats) and 16-byte alignment");
     CRUSE_REQUIRE((coef == nullptr) == (an == nullptr) && (coef == nullptr) == (z == nullptr), CRUSE_E_SHAPE,
                   "gru_seq_fwd: coef, an, z must all be given or all be NULL");
     Plan pl;
@@ -1565,9 +1604,17 @@ extern "C" int cruse_gru_seq_fwd_on(const float* gi, const float* const* w_hh, c
     a.gi = gi; a.h = h; a.coef = coef; a.an = an; a.z = z;
     for (int g = 0; g < G; ++g) { a.p.w_hh[g] = w_hh[g]; a.p.b_hh[g] = b_hh[g]; }
     a.B = B; a.T = T; a.G = G; a.Hg = Hg;
+    a.TS = TS; a.h0 = h0; a.h0_bs = h0_bstride;
     const size_t esz = prec == CRUSE_PREC_F32 ? 4 : 2, npl = prec == CRUSE_PREC_BF16X3 ? 2 : 1;
     const size_t lds = (size_t)16 * (Hg + (prec == CRUSE_PREC_F32 ? 4 : 8)) * esz * npl + 4 * 6 * 64 * 4 * sizeof(float);
     return run_launches<true>(a, pl, G, Hg, prec, panels, status, xcd_rot, lds, s);
+}
+
+extern "C" int cruse_gru_seq_fwd_on(const float* gi, const float* const* w_hh, const float* const* b_hh,
+                                    float* h, void* coef, float* an, float* z,
+                                    int B, int T, int G, int Hg, int prec, void* panels, unsigned* status, int xcd_rot,
+                                    void* stream) {
+    return cruse_gru_seq_fwd_ex(gi, w_hh, b_hh, h, coef, an, z, nullptr, 0, B, T, T, G, Hg, prec, panels, status, xcd_rot, stream);
 }
 
 extern "C" int cruse_gru_seq_fwd(const float* gi, const float* const* w_hh, const float* const* b_hh,
@@ -1581,11 +1628,12 @@ extern "C" int cruse_gru_gate_grads_bf16(const float* dh, const void* coef, cons
                                          long long ldT, float* const* db_ih, float* const* db_hh,
                                          long long rows, int G, int Hg, void* stream);
 
-extern "C" int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh, const void* coef, const float* z,
-                                    float* dh, const float* an, void* dgi, int B, int T, int G, int Hg, int prec,
-                                    void* panels, unsigned* status, int xcd_rot, void* stream) {
+extern "C" int cruse_gru_seq_bwd_ex(const float* dout, const float* const* w_hh, const void* coef, const float* z,
+                                    float* dh, const float* an, void* dgi, int carry, int B, int T, int TS, int G, int Hg,
+                                    int prec, void* panels, unsigned* status, int xcd_rot, void* stream) {
     int rc = check_common(B, T, G, Hg, prec, "gru_seq_bwd");
     if (rc) return rc;
+    CRUSE_REQUIRE(TS >= T, CRUSE_E_SHAPE, "gru_seq_bwd: clip stride %d frames < %d steps", TS, T);
     Plan pl;
     CRUSE_REQUIRE(make_plan(B, G, Hg, pl) == 0, CRUSE_E_SHAPE, "gru_seq_bwd: G*Hg/32 exceeds the CU count");
     hipStream_t s = (hipStream_t)stream;
@@ -1595,6 +1643,7 @@ extern "C" int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh,
     a.dout = dout; a.coefs = coef; a.zs = z; a.dh = dh;
     for (int g = 0; g < G; ++g) { a.p.w_hh[g] = w_hh[g]; a.p.b_hh[g] = nullptr; }
     a.B = B; a.T = T; a.G = G; a.Hg = Hg;
+    a.TS = TS; a.carry = carry ? 1 : 0;
     const size_t esz = prec == CRUSE_PREC_F32 ? 4 : 2, npl = prec == CRUSE_PREC_BF16X3 ? 2 : 1;
     const size_t lds = (size_t)16 * (3 * Hg + (prec == CRUSE_PREC_F32 ? 4 : 8)) * esz * npl + 4 * 2 * 64 * 4 * sizeof(float);
     CRUSE_REQUIRE(lds <= 160 * 1024, CRUSE_E_SHAPE, "gru_seq_bwd: Hg=%d needs %zu B of LDS", Hg, lds);
@@ -1606,8 +1655,15 @@ extern "C" int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh,
     a.dgi = in_kernel ? dgi : nullptr;
     rc = run_launches<false>(a, pl, G, Hg, prec, panels, status, xcd_rot, lds, s);
     if (rc || dgi == nullptr || in_kernel) return rc;
+    CRUSE_REQUIRE(TS == T, CRUSE_E_SHAPE, "gru_seq_bwd: dgi on a sub-sequence needs the reduce-scatter kernel (bf16, Hg <= 640)");
     const long long rows = (long long)B * T;
     return cruse_gru_gate_grads_bf16(dh, coef, an, dgi, nullptr, (rows + 63) / 64 * 64, nullptr, nullptr, rows, G, Hg, stream);
+}
+
+extern "C" int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh, const void* coef, const float* z,
+                                    float* dh, const float* an, void* dgi, int B, int T, int G, int Hg, int prec,
+                                    void* panels, unsigned* status, int xcd_rot, void* stream) {
+    return cruse_gru_seq_bwd_ex(dout, w_hh, coef, z, dh, an, dgi, 0, B, T, T, G, Hg, prec, panels, status, xcd_rot, stream);
 }
 
 extern "C" int cruse_gru_seq_bwd(const float* dout, const float* const* w_hh, const void* coef, const float* z,

@@ -28,11 +28,33 @@ def synth_batch(batch: int, length: int, device, seed: int):
     return (clean + noise).contiguous(), clean.contiguous()
 
 
-def snr_mix(clean_y: torch.Tensor, noise_y: torch.Tensor, snr, eps: float = 1e-7, return_parts: bool = False):
-    """SynDataset.snr_mix (dataset/dataset.py:236-264) for a whole batch ON THE GPU: peak-normalise clean and noise,
-    scale the noise by clean_rms / 10^(snr/20) / (noise_rms + eps), mix.  clean_y, noise_y [B,L] (or [L]); snr: dB, scalar
-    or [B].  Returns noisy (and the normalised clean / scaled noise with return_parts).  The reference's function ends
-    after drawing `noisy_target_dB_FS` (the file is truncated there); RIR convolution is the caller's (host) step."""
+def fir_causal(x: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
+    """scipy.signal.fftconvolve(x, h)[:len(x)] per clip on the GPU (cruse_fir_causal).  x [B,L]; h [R] (shared) or [B,R]."""
+    from . import ops
+    from ._lib import check, lib
+    x = x.contiguous().float()
+    h = h.to(x.device).contiguous().float()
+    B, L = x.shape
+    if h.dim() == 1:
+        R, hs = h.shape[0], 0
+    elif h.dim() == 2 and h.shape[0] == B:
+        R, hs = h.shape[1], h.shape[1]
+    else:
+        raise RuntimeError(f"fir_causal: taps {tuple(h.shape)} must be [R] or [{B}, R]")
+    y = torch.empty_like(x)
+    check(lib.cruse_fir_causal(ops._p(x), ops._p(h), hs, B, L, R, ops._p(y), ops._stream()))
+    return y
+
+
+def snr_mix(clean_y: torch.Tensor, noise_y: torch.Tensor, snr, target_dB_FS=None, target_dB_FS_floating_val=None, rir=None,
+            rir_noise=None, eps: float = 1e-7, return_parts: bool = False):
+    """SynDataset.snr_mix (dataset/dataset.py:235-264) with the reference's argument order, for a whole batch ON THE GPU:
+    optional room impulse responses `rir` / `rir_noise` ([R] shared or [B,R]: fftconvolve(.)[:L], :245-248, as a direct FIR
+    kernel), peak-normalise clean and noise, scale the noise by clean_rms / 10^(snr/20) / (noise_rms + eps), mix.
+    clean_y, noise_y [B,L] (or [L]); snr: dB, scalar or [B].  Returns noisy (and the normalised clean / scaled noise with
+    return_parts).  The reference's function ENDS after drawing `noisy_target_dB_FS` from
+    np.random.randint(target_dB_FS - floating, target_dB_FS + floating) (the file is truncated there, :261-264): when both
+    are given the draw is made, to consume numpy's RNG exactly as the reference does, and nothing else is done with it."""
     from . import ops
     from ._lib import check, lib
     one = clean_y.dim() == 1
@@ -41,6 +63,10 @@ def snr_mix(clean_y: torch.Tensor, noise_y: torch.Tensor, snr, eps: float = 1e-7
     if c.shape != n.shape or c.dim() != 2:
         raise RuntimeError(f"snr_mix: clean {tuple(clean_y.shape)} and noise {tuple(noise_y.shape)} must match ([B,L] or [L])")
     c = c.contiguous().float(); n = n.contiguous().float()
+    if rir is not None:
+        c = fir_causal(c, torch.as_tensor(rir))
+    if rir_noise is not None:
+        n = fir_causal(n, torch.as_tensor(rir_noise))
     B, L = c.shape
     snr_t = torch.as_tensor(snr, dtype=torch.float32, device=c.device).reshape(-1)
     if snr_t.numel() == 1:
@@ -52,6 +78,9 @@ def snr_mix(clean_y: torch.Tensor, noise_y: torch.Tensor, snr, eps: float = 1e-7
     no = torch.empty_like(c) if return_parts else None
     check(lib.cruse_snr_mix(ops._p(c), ops._p(n), ops._p(snr_t), B, L, eps, ops._p(scratch), ops._p(co), ops._p(no), ops._p(noisy),
                             ops._stream()))
+    if target_dB_FS is not None and target_dB_FS_floating_val is not None:
+        import numpy as np
+        np.random.randint(target_dB_FS - target_dB_FS_floating_val, target_dB_FS + target_dB_FS_floating_val)   # :261-264
     if one:
         noisy = noisy[0]; co = None if co is None else co[0]; no = None if no is None else no[0]
     return (noisy, co, no) if return_parts else noisy

@@ -120,11 +120,12 @@ def convkxf(in_ch, out_ch, k=1, f=3, fstride=2, lookahead=0, batch_norm=False, a
 # grouped GRUs
 # ======================================================================================================================
 class _GroupedGruFn(torch.autograd.Function):
-    """g independent nn.GRU(I/g -> H/g) over feature slices, outputs concatenated (cust_conv.py:303-325); h0 = 0.
-    params = (w_ih_0, w_hh_0, b_ih_0, b_hh_0, w_ih_1, ...).  Exact-f32 MFMA kernels (v_mfma_f32_16x16x4_f32)."""
+    """g independent nn.GRU(I/g -> H/g) over feature slices, outputs concatenated (cust_conv.py:303-325), started from the
+    state h0 [B, H] ("cat" layout) the caller passes -- DETACHED, as the reference does (:318-319): no gradient flows into
+    it -- or from 0.  params = (w_ih_0, w_hh_0, b_ih_0, b_hh_0, w_ih_1, ...).  Exact-f32 MFMA kernels (v_mfma_f32_16x16x4_f32)."""
 
     @staticmethod
-    def forward(ctx, x, g, *params):
+    def forward(ctx, x, g, h0, *params):
         x = x.contiguous()
         B, T, I = x.shape
         Ig = I // g
@@ -139,8 +140,9 @@ class _GroupedGruFn(torch.autograd.Function):
         w_hh = [params[4 * i + 1].contiguous() for i in range(g)]
         b_hh = [params[4 * i + 3].contiguous() for i in range(g)]
         need = any(ctx.needs_input_grad)
-        h, coef, an, z = ops.gru_seq_fwd(gi, w_hh, b_hh, B, T, g, Hg, "f32", save=need)
+        h, coef, an, z = ops.gru_seq_fwd(gi, w_hh, b_hh, B, T, g, Hg, "f32", save=need, h0=h0)
         ctx.g, ctx.dims = g, (B, T, I, Ig, Hg)
+        ctx.h0 = h0
         ctx.save_for_backward(x, h, coef, an, z, *params)
         return h
 
@@ -164,18 +166,17 @@ class _GroupedGruFn(torch.autograd.Function):
                      splitk=sk, prec="f32")
             ops.gemm(True, False, 3 * Hg, Hg, rows, dgh, i * 3 * Hg, 3 * H, h, i * Hg, H, dw_hh, 0, Hg, accumulate=True,
                      splitk=sk, b_shift_T=T, prec="f32")
+            if ctx.h0 is not None:
+                # frame 0's h_{t-1} is h0, not 0: dW_hh += dgh[:, 0]^T h0 (K = B; rows of frame 0 are T frames apart)
+                ops.gemm(True, False, 3 * Hg, Hg, B, dgh, i * 3 * Hg, T * 3 * H, ctx.h0, i * Hg, H, dw_hh, 0, Hg, accumulate=True,
+                         prec="f32")
             ops.col_sum(dgi, i * 3 * Hg, rows, 3 * Hg, 3 * H, db_ih)
             ops.col_sum(dgh, i * 3 * Hg, rows, 3 * Hg, 3 * H, db_hh)
             if dx is not None:
                 ops.gemm(False, False, rows, Ig, 3 * Hg, dgi, i * 3 * Hg, 3 * H, w_ih, 0, Ig, dx, i * Ig, I, prec="f32")
             grads += [dw_ih, dw_hh, db_ih, db_hh]
-        return (dx, None) + tuple(grads)
+        return (dx, None, None) + tuple(grads)
 
-
-def _require_zero_state(h0: Optional[Tensor], what: str) -> None:
-    if h0 is not None and bool((h0 != 0).any()):
-        raise RuntimeError(f"{what}: the HIP recurrence starts from h0 = 0 (model/cruse_net.py never passes a state); "
-                           "a non-zero initial state is not supported")
 
 
 class GroupedGRULayer(nn.Module):
@@ -208,11 +209,17 @@ class GroupedGRULayer(nn.Module):
         return torch.zeros(self.groups * self.num_directions, batch_size, self.hidden_size, device=device)
 
     def forward(self, input: Tensor, h0: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
-        _require_zero_state(h0, "GroupedGRULayer")
+        # state [G*D, B, H/g] (:305-306) -> the kernel's [B, G*H/g] "cat" layout; detached like the reference's (:319)
+        h0c = None
+        if h0 is not None:
+            if tuple(h0.shape) != (self.groups, input.shape[0], self.hidden_size):
+                raise RuntimeError(f"GroupedGRULayer: state {tuple(h0.shape)} != "
+                                   f"{(self.groups, input.shape[0], self.hidden_size)}")
+            h0c = h0.detach().to(input.device, torch.float32).transpose(0, 1).reshape(input.shape[0], -1).contiguous()
         params = []
         for layer in self.layers:
             params += [layer.weight_ih_l0, layer.weight_hh_l0, layer.bias_ih_l0, layer.bias_hh_l0]
-        out = _GroupedGruFn.apply(input, self.groups, *params)
+        out = _GroupedGruFn.apply(input, self.groups, h0c, *params)
         B, T, H = out.shape
         # final states [G*D, B, H/g] = the last frame of every group's slice (cust_conv.py:323)
         h = out[:, -1, :].reshape(B, self.groups, self.hidden_size).transpose(0, 1).contiguous()
@@ -257,11 +264,13 @@ class GroupGRU(nn.Module):
 
     def forward(self, input: Tensor, state: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
         dim0, dim1, _ = input.shape
-        _require_zero_state(state, "GroupGRU")
+        h = self.groups * self.num_directions
+        if state is not None and state.shape[0] != self.num_layers * h:
+            raise RuntimeError(f"GroupGRU: state has {state.shape[0]} rows, expected num_layers*groups = {self.num_layers * h}")
         output = None
         outstates = []
         for i, gru in enumerate(self.grus):
-            input, s = gru(input, None)
+            input, s = gru(input, None if state is None else state[i * h:(i + 1) * h])                  # :402-404
             outstates.append(s)
             if self.shuffle and i < self.num_layers - 1:
                 # a pure permutation of the feature axis: new[b*h + a] = old[a*g + b] (device copy, no arithmetic)

@@ -137,6 +137,9 @@ _ws_retired = []          # outgrown workspaces: captured HIP graphs may still p
 
 
 def _ws(key, nbytes: int, device) -> torch.Tensor:
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:       # "cuda" and "cuda:0" must name the same workspace
+        device = torch.device("cuda", torch.cuda.current_device())
     buf = _wgrad_ws.get((key, device))
     if buf is None or buf.numel() < nbytes:
         old = buf
@@ -386,22 +389,48 @@ def _gru_ws(B, G, Hg, dev, slot: int):
     return panels.data_ptr(), ws.data_ptr()
 
 
-def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G, Hg, prec, save=True, slot=0, xcd_rot=0):
+def _off(t: torch.Tensor, elems: int) -> int:
+    return t.data_ptr() + elems * t.element_size()
+
+
+def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G, Hg, prec, save=True, slot=0, xcd_rot=0,
+                h0=None, out=None, chunk=None):
     """-> (h, coef, an, z); the last three are None when save is False (inference).  slot / xcd_rot: see
-    cruse_gru_seq_fwd_on (concurrent half-batch recurrences)."""
+    cruse_gru_seq_fwd_on (concurrent recurrences).
+    h0 [B, G*Hg] ("cat" layout: feature = group*Hg + unit): initial state (cust_conv.py:305-325); None = 0.
+    chunk = (t0, n): run only frames [t0, t0+n) of the [B,T] tensors into `out` = (h, coef, an, z) from the call that ran
+    the frames before them -- the initial state is then h[:, t0-1] (h0 for t0 == 0).  Consecutive chunks reproduce the
+    single launch (cruse_gru_seq_fwd_ex)."""
     dev = gi.device
     H = G * Hg
-    h = torch.empty(B, T, H, device=dev, dtype=torch.float32)
-    if save:
-        cdt = torch.bfloat16 if prec_code(prec) == PREC_BF16 else torch.float32
-        coef = torch.empty(B, T, 3 * H, device=dev, dtype=cdt)
-        an = torch.empty_like(h); z = torch.empty_like(h)
+    if out is not None:
+        h, coef, an, z = out
     else:
-        coef = an = z = None
+        h = torch.empty(B, T, H, device=dev, dtype=torch.float32)
+        if save:
+            cdt = torch.bfloat16 if prec_code(prec) == PREC_BF16 else torch.float32
+            coef = torch.empty(B, T, 3 * H, device=dev, dtype=cdt)
+            an = torch.empty_like(h); z = torch.empty_like(h)
+        else:
+            coef = an = z = None
+    t0, n = chunk if chunk is not None else (0, T)
+    if not (0 <= t0 and n > 0 and t0 + n <= T):
+        raise RuntimeError(f"gru_seq_fwd: chunk ({t0}, {n}) outside [0, {T})")
+    h0p, h0s = None, 0
+    if t0 > 0:
+        h0p, h0s = _off(h, (t0 - 1) * H), T * H
+    elif h0 is not None:
+        if tuple(h0.shape) != (B, H) or h0.dtype != torch.float32:
+            raise RuntimeError(f"gru_seq_fwd: h0 must be f32 [{B}, {H}], got {tuple(h0.shape)}")
+        _p(h0)
+        h0p, h0s = h0.data_ptr(), H
     panels, status = _gru_ws(B, G, Hg, dev, slot)
     wa, ba = _ptr_array(w_hh), _ptr_array(b_hh)
-    check(lib.cruse_gru_seq_fwd_on(_p(gi), ctypes.cast(wa, ctypes.c_void_p), ctypes.cast(ba, ctypes.c_void_p), _p(h),
-                                   _p(coef), _p(an), _p(z), B, T, G, Hg, prec_code(prec), panels, status, xcd_rot, _stream()))
+    _p(gi); _p(h); _p(coef); _p(an); _p(z)
+    opt = lambda t_, k: None if t_ is None else _off(t_, t0 * k)
+    check(lib.cruse_gru_seq_fwd_ex(_off(gi, t0 * 3 * H), ctypes.cast(wa, ctypes.c_void_p), ctypes.cast(ba, ctypes.c_void_p),
+                                   _off(h, t0 * H), opt(coef, 3 * H), opt(an, H), opt(z, H), h0p, h0s, B, n, T, G, Hg,
+                                   prec_code(prec), panels, status, xcd_rot, _stream()))
     return h, coef, an, z
 
 
@@ -415,19 +444,34 @@ def dgi_buffer(rows, G, Hg, device):
     return buf[:n].view(rows, G, 3, Hg)
 
 
-def gru_seq_bwd(dout, w_hh: List[torch.Tensor], coef, z, B, T, G, Hg, prec, slot=0, xcd_rot=0, an=None, want_dgi=False):
+def gru_seq_bwd(dout, w_hh: List[torch.Tensor], coef, z, B, T, G, Hg, prec, slot=0, xcd_rot=0, an=None, want_dgi=False,
+                out=None, chunk=None):
     """dout [B,T,H] -> dh [B,T,H] (total gradient reaching every h_t).  want_dgi (CRUSE_PREC_BF16, with the a_n rows):
-    -> (dh, dgi) with dgi = dh * (c_r, c_z, a_n) in bf16 written by the recurrence itself (cruse_gru_seq_bwd_on)."""
-    dh = torch.empty_like(dout)
+    -> (dh, dgi) with dgi = dh * (c_r, c_z, a_n) in bf16 written by the recurrence itself (cruse_gru_seq_bwd_on).
+    chunk = (t0, n): only frames [t0, t0+n), into out = dh (or (dh, dgi)); chunks are run from the LAST to the first, and
+    every chunk but the last picks the gradient carried across its end up from dh[:, t0+n] (cruse_gru_seq_bwd_ex)."""
+    H = G * Hg
     dgi = None
-    if want_dgi:
-        if an is None or prec_code(prec) != PREC_BF16:
-            raise RuntimeError("gru_seq_bwd: want_dgi needs the a_n rows and the bf16 mode")
-        dgi = dgi_buffer(B * T, G, Hg, dout.device)
+    if out is not None:
+        dh, dgi = out if want_dgi else (out, None)
+    else:
+        dh = torch.empty_like(dout)
+        if want_dgi:
+            dgi = dgi_buffer(B * T, G, Hg, dout.device)
+    if want_dgi and (an is None or prec_code(prec) != PREC_BF16):
+        raise RuntimeError("gru_seq_bwd: want_dgi needs the a_n rows and the bf16 mode")
+    t0, n = chunk if chunk is not None else (0, T)
+    if not (0 <= t0 and n > 0 and t0 + n <= T):
+        raise RuntimeError(f"gru_seq_bwd: chunk ({t0}, {n}) outside [0, {T})")
+    carry = 1 if t0 + n < T else 0
+    steps = n + carry                                   # a carried chunk re-visits frame t0+n to pick up its dh
     panels, status = _gru_ws(B, G, Hg, dout.device, slot)
     wa = _ptr_array(w_hh)
-    check(lib.cruse_gru_seq_bwd_on(_p(dout), ctypes.cast(wa, ctypes.c_void_p), _p(coef), _p(z), _p(dh), _p(an) if want_dgi else None,
-                                   _p(dgi), B, T, G, Hg, prec_code(prec), panels, status, xcd_rot, _stream()))
+    _p(dout); _p(coef); _p(z); _p(dh); _p(an); _p(dgi)
+    check(lib.cruse_gru_seq_bwd_ex(_off(dout, t0 * H), ctypes.cast(wa, ctypes.c_void_p), _off(coef, t0 * 3 * H), _off(z, t0 * H),
+                                   _off(dh, t0 * H), _off(an, t0 * H) if want_dgi else None,
+                                   None if dgi is None else _off(dgi, t0 * 3 * H), carry, B, steps, T, G, Hg, prec_code(prec),
+                                   panels, status, xcd_rot, _stream()))
     return (dh, dgi) if want_dgi else dh
 
 

@@ -252,6 +252,22 @@ int cruse_gru_seq_fwd_on(const float* gi, const float* const* w_hh, const float*
 int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh, const void* coef, const float* z,
                          float* dh, const float* an, void* dgi, int B, int T, int G, int Hg, int prec,
                          void* panels, unsigned* status, int xcd_rot, void* stream);
+/* SUB-SEQUENCES and INITIAL STATE (cust_conv.py:305-325 passes h0 explicitly; GroupGRU.forward(input, state) :392-416).
+ * T steps of tensors whose clips are TS >= T frames apart; every pointer is already advanced to the first frame of the run.
+ *   _fwd_ex: h0 [B][G*Hg] ("cat" feature layout, clips h0_bstride floats apart, 16-byte aligned) or NULL (= 0).  A long
+ *            sequence can be run as consecutive time chunks: chunk [t0, t0+n) is (gi + t0*G*3*Hg, h + t0*G*Hg, ..., h0 =
+ *            h + (t0-1)*G*Hg with h0_bstride = TS*G*Hg, T = n) -- the results are those of the single launch.
+ *   _bwd_ex: carry != 0: the first iteration takes dh of the run's LAST frame from the dh buffer (written by the run that
+ *            follows it in time) instead of forming it from dout: chunk [t0, t0+n) of a longer sequence is run as the
+ *            n + 1 frames [t0, t0+n] with carry = 1 (the last chunk: n frames, carry = 0).  dgi on a sub-sequence is
+ *            supported by the reduce-scatter kernel only (CRUSE_PREC_BF16, Hg <= 640). */
+int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, const float* const* b_hh,
+                         float* h, void* coef, float* an, float* z, const float* h0, long long h0_bstride,
+                         int B, int T, int TS, int G, int Hg, int prec, void* panels, unsigned* status, int xcd_rot,
+                         void* stream);
+int cruse_gru_seq_bwd_ex(const float* dout, const float* const* w_hh, const void* coef, const float* z,
+                         float* dh, const float* an, void* dgi, int carry, int B, int T, int TS, int G, int Hg,
+                         int prec, void* panels, unsigned* status, int xcd_rot, void* stream);
 /* dgi = dh*(c_r,c_z,a_n) (gradient wrt gi), dgh = dh*(c_r,c_z,c_n) (gradient wrt W_hh h + b_hh), both
  * [rows,G,3*Hg]; dW_ih, dW_hh, dX and the bias gradients follow from cruse_gemm / cruse_col_sum. */
 int cruse_gru_gate_grads(const float* dh, const void* coef, const float* an, float* dgi, float* dgh,
@@ -391,6 +407,10 @@ int cruse_wo_male_spec(const float* ref, const float* est, const float* unproc, 
 int cruse_sisnr_plain_finalize(const double* mom, int B, float eps, double* value, float* coef, void* stream);
 /* synthetic clips: y[b,n] = gain*(1-a) * sum_{k<taps} a^k x[b,n-k], a one-pole low-pass as a truncated FIR */
 int cruse_onepole_fir(const float* x, int B, int L, float a, int taps, float gain, float* y, void* stream);
+/* y[b,n] = sum_{k < R, k <= n} h[b or 0][k] x[b,n-k] = scipy.signal.fftconvolve(x, h)[:L]: the room-impulse-response
+ * convolution at the top of SynDataset.snr_mix (dataset/dataset.py:245-248).  h_bstride = 0: one tap row for all clips,
+ * else tap rows h_bstride >= R floats apart.  Out of place. */
+int cruse_fir_causal(const float* x, const float* h, long long h_bstride, int B, int L, int R, float* y, void* stream);
 /* SynDataset.snr_mix (dataset/dataset.py:236-264) for B clips at once: peak-normalise both, scale the noise to snr_db[b]
  * from the RMS ratio, mix.  scratch: 24*B bytes.  clean_out / noise_out may be NULL. */
 int cruse_snr_mix(const float* clean, const float* noise, const float* snr_db, int B, int L, float eps,

@@ -471,9 +471,15 @@ class TFCM(nn.Module):
 # ----------------------------------------------------------------------------------------------------------------------
 # 8f.3: SynDataset.snr_mix (dataset/dataset.py:236-264)
 # ----------------------------------------------------------------------------------------------------------------------
-def snr_mix(clean_y, noise_y, snr, eps=1e-7):
-    """dataset.py:236-259 (numpy, one clip; rir = None): -> noisy, normalised clean, scaled noise.  The reference function
+def snr_mix(clean_y, noise_y, snr, eps=1e-7, rir=None, rir_noise=None):
+    """dataset.py:236-259 (numpy, one clip): -> noisy, normalised clean, scaled noise.  The reference function
     stops after drawing noisy_target_dB_FS (:261-264, file truncated)."""
+    if rir is not None:                                                     # :245-246
+        from scipy import signal
+        clean_y = signal.fftconvolve(clean_y, rir)[:len(clean_y)]
+    if rir_noise is not None:                                               # :247-248
+        from scipy import signal
+        noise_y = signal.fftconvolve(noise_y, rir_noise)[:len(noise_y)]
     clean_y = clean_y / (np.max(np.abs(clean_y)) + eps)
     clean_rms = (clean_y ** 2).mean() ** 0.5
     noise_y = noise_y / (np.max(np.abs(noise_y)) + eps)

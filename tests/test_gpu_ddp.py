@@ -49,7 +49,7 @@ if mode == "poison":
     for step in range(2):
         noisy, clean = O.synth_pair(2, 3200, seed=50 + step)
         if step == 0 and rank == 1:
-            ops.gru_status_word("cuda", 2, 4, 160).copy_(torch.tensor([1, 0, 0, 0], dtype=torch.uint8))
+            ops.gru_status_word(torch.device("cuda", 0), 2, 4, 160).copy_(torch.tensor([1, 0, 0, 0], dtype=torch.uint8))
         eng.step(noisy.cuda(), clean.cuda())
         torch.cuda.synchronize()
         if step == 0:

@@ -239,9 +239,78 @@ def test_group_gru_with_shuffle_vs_reference(golden, name, kw):
     assert rel_l2(s, torch.from_numpy(g[f"{name}/state"])) < 1e-5
     y2, _ = p(x.cuda(), p.get_h0(2, device="cuda"))                              # explicit zero state: same result
     assert rel_l2(y2, y) < 1e-7
-    with pytest.raises(RuntimeError, match="h0 = 0"):
-        p(x.cuda(), torch.ones(kw["num_layers"] * kw["groups"], 2, 128 // kw["groups"]).cuda())
+    with pytest.raises(RuntimeError, match="state has"):
+        p(x.cuda(), torch.ones(1, 2, 128 // kw["groups"]).cuda())
     _grad_check(p, o, x, tol=5e-4, wtol=2e-3)
+
+
+@pytest.mark.parametrize("name,kw", [("g2_l2", dict(num_layers=2, groups=2)), ("g4_l3_add", dict(num_layers=3, groups=4, add_outputs=True)),
+                                     ("g1_l1", dict(num_layers=1, groups=1))])
+def test_group_gru_nonzero_state_vs_reference(golden, name, kw):
+    """GroupGRU.forward(x, state) with the explicit, NON-ZERO state the reference's working call path
+    passes (cust_conv.py:392-416; fixture G19 = the reference's own run).  The state is detached there (:319), so the
+    gradients wrt input and weights -- including the h0 term of dW_hh -- are compared with oracle autograd."""
+    from cruse_amd.model.based_model.cust_conv import GroupGRU
+    from oracle import cruse_oracle_ext as X
+    g = golden("g19_groupgru_state.npz")
+    o = X.GroupGRU(128, 128, **kw)
+    p = _load_like(GroupGRU(128, 128, **kw), o, scale=2.0)
+    x, st = torch.from_numpy(g["x"]), torch.from_numpy(g[f"{name}/state_in"])
+    y, s = p(x.cuda(), st.cuda())
+    assert rel_l2(y, torch.from_numpy(g[f"{name}/y"])) < 1e-5
+    assert rel_l2(s, torch.from_numpy(g[f"{name}/state"])) < 1e-5
+    xo = x.clone().requires_grad_(True); xp = x.clone().cuda().requires_grad_(True)
+    torch.manual_seed(1)
+    w = torch.randn(y.shape)
+    (o(xo, st)[0] * w).sum().backward()
+    (p(xp, st.cuda())[0] * w.cuda()).sum().backward()
+    assert rel_l2(xp.grad, xo.grad) < 5e-4
+    for (n, po), (_, pp) in zip(o.named_parameters(), p.named_parameters()):
+        assert rel_l2(pp.grad, po.grad) < 2e-3, n
+
+
+@pytest.mark.parametrize("prec,Hg,G", [("f32", 128, 2), ("bf16", 640, 1), ("bf16", 160, 4), ("bf16x3", 96, 1)])
+def test_recurrence_in_time_chunks_equals_one_launch(prec, Hg, G):
+    """cruse_gru_seq_fwd_ex / _bwd_ex: a sequence run as consecutive time chunks (forward: the state carried through h;
+    backward: the gradient carried through dh) gives the results of the single launch -- for the generic kernels and for
+    the lean forward / reduce-scatter backward kernels of the bench mode."""
+    from cruse_amd import ops
+    torch.manual_seed(5)
+    B, T, H = 11, 37, G * Hg
+    gi = torch.randn(B, T, 3 * H).cuda()
+    w = [(torch.randn(3 * Hg, Hg) / Hg ** 0.5).cuda() for _ in range(G)]
+    b = [(0.1 * torch.randn(3 * Hg)).cuda() for _ in range(G)]
+    h0 = (0.5 * torch.randn(B, H)).cuda()
+    dout = torch.randn(B, T, H).cuda()
+    want_dgi = prec == "bf16"
+    h, coef, an, z = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, prec, h0=h0)
+    ref_b = ops.gru_seq_bwd(dout, w, coef, z, B, T, G, Hg, prec, an=an if want_dgi else None, want_dgi=want_dgi)
+    chunks = [(0, 10), (10, 1), (11, 17), (28, 9)]
+    out = tuple(torch.full_like(t_, float("nan")) for t_ in (h, coef, an, z))
+    for c in chunks:
+        ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, prec, h0=h0, out=out, chunk=c)
+    for got, ref in zip(out, (h, coef, an, z)):
+        assert torch.equal(got, ref)
+    dh = torch.full_like(dout, float("nan"))
+    bout = (dh, ops.dgi_buffer(B * T, G, Hg, dh.device)) if want_dgi else dh
+    for c in reversed(chunks):
+        ops.gru_seq_bwd(dout, w, coef, z, B, T, G, Hg, prec, an=an if want_dgi else None, want_dgi=want_dgi, out=bout, chunk=c)
+    if want_dgi:
+        assert torch.equal(bout[0], ref_b[0]) and torch.equal(bout[1], ref_b[1])
+    else:
+        assert torch.equal(bout, ref_b)
+    assert ops.gru_status() == 0
+    # and the initial state matters / is honoured: against a torch reference of step 0
+    h_z, _, _, _ = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, prec, save=False)
+    assert float((h_z[:, 0] - h[:, 0]).abs().max()) > 1e-3
+    for gq in range(G):
+        sl = slice(gq * Hg, (gq + 1) * Hg)
+        gh = h0[:, sl] @ w[gq].t() + b[gq]
+        g0 = gi[:, 0, gq * 3 * Hg:(gq + 1) * 3 * Hg]
+        r = torch.sigmoid(g0[:, :Hg] + gh[:, :Hg]); zz = torch.sigmoid(g0[:, Hg:2 * Hg] + gh[:, Hg:2 * Hg])
+        n = torch.tanh(g0[:, 2 * Hg:] + r * gh[:, 2 * Hg:])
+        want = (1 - zz) * n + zz * h0[:, sl]
+        assert rel_l2(h[:, 0, sl], want) < (2e-2 if prec == "bf16" else 1e-4 if prec == "bf16x3" else 1e-5)
 
 
 @pytest.mark.parametrize("grp", [1, 2, 4])
@@ -379,6 +448,30 @@ def test_snr_mix_vs_reference(golden):
     got = 10 * torch.log10(c.square().mean(-1) / n.square().mean(-1))
     assert max_abs(got, want) < 1e-3 and max_abs(c.abs().amax(-1), torch.ones(B)) < 1e-5
     assert rel_l2(ny, c + n) < 1e-7
+
+
+def test_snr_mix_with_room_impulse_responses_vs_reference(golden):
+    """the reference's full signature -- snr_mix(clean, noise, snr, target_dB_FS, floating, rir, rir_noise)
+    -- with the RIR convolutions (scipy.signal.fftconvolve(.)[:L], dataset.py:245-248) on the GPU as a direct FIR kernel.
+    Fixture G20 = the reference's own function run with two RIRs per clip."""
+    from dataset.dataset import SynDataset
+    from cruse_amd.data import fir_causal, snr_mix
+    g = golden("g20_snr_mix_rir.npz")
+    clean, noise, snr = t(g["clean"]), t(g["noise"]), t(g["snr"])
+    noisy, c, n = snr_mix(clean, noise, snr, -25, 10, rir=t(g["rir"]), rir_noise=t(g["rir_noise"]), return_parts=True)
+    assert rel_l2(noisy, torch.from_numpy(g["noisy"])) < 5e-6
+    assert rel_l2(c, torch.from_numpy(g["clean_n"])) < 5e-6 and rel_l2(n, torch.from_numpy(g["noise_s"])) < 5e-6
+    one = SynDataset.snr_mix(clean[1], noise[1], float(snr[1]), -25, 10, t(g["rir"])[0])        # positional, as the reference is called
+    assert rel_l2(one, torch.from_numpy(g["noisy_clean_rir_only"])) < 5e-6
+    # full size: 64 clips x 4 s through a 0.5 s RIR (8000 taps) against torch's own FFT convolution
+    B, L, R = 64, 64000, 8000
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(B, L, device="cuda", generator=gen)
+    h = torch.randn(R, device="cuda", generator=gen) * torch.exp(-torch.arange(R, device="cuda") / 1500.0)
+    y = fir_causal(x, h)
+    nfft = 1 << 17
+    want = torch.fft.irfft(torch.fft.rfft(x.double(), nfft) * torch.fft.rfft(h.double(), nfft), nfft)[:, :L]
+    assert rel_l2(y, want.float()) < 1e-5
 
 
 # ---------------------------------------------------------------------------------------------------------------- config 4

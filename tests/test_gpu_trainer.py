@@ -205,7 +205,7 @@ def test_engine_latches_timeout_per_step_and_mean_loss_per_shape(graph):
         per_step.append(eng.loss_value(ls))
     assert eng.mean_loss() == pytest.approx(sum(per_step) / 4, rel=1e-9)
     p0 = eng.flat.params.clone()
-    word = ops.gru_status_word("cuda", 3, 2, 320)
+    word = ops.gru_status_word(a[0].device, 3, 2, 320)
     word.copy_(torch.tensor([1, 0, 0, 0], dtype=torch.uint8))           # "a hand-off timed out in this step"
     eng.step(*a)
     torch.cuda.synchronize()

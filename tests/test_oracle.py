@@ -202,3 +202,23 @@ def test_oracle_sdnr_vs_reference_fixture(golden):
     for k, snr in enumerate(g["snr"]):
         v = O.sdnr(_t(g["clean"]), _t(g["gain"]), _t(g["noise"]), float(snr), beta=20.0)
         assert abs(float(v) - float(g["value"][k])) <= 1e-6 * abs(float(g["value"][k])), snr
+
+
+def test_oracle_round3_fixtures(golden):
+    """G19 (GroupGRU with a non-zero state) and G20 (snr_mix with RIRs): the oracle restatements against the reference's
+    own outputs (tests/golden/make_golden_r3.py)."""
+    from oracle import cruse_oracle as O
+    from oracle import cruse_oracle_ext as X
+    g = golden("g19_groupgru_state.npz")
+    x = torch.from_numpy(g["x"])
+    for name, kw in {"g2_l2": dict(num_layers=2, groups=2), "g4_l3_add": dict(num_layers=3, groups=4, add_outputs=True),
+                     "g1_l1": dict(num_layers=1, groups=1)}.items():
+        m = X.GroupGRU(128, 128, **kw)
+        O.closed_form_init(m, scale=2.0)
+        y, s = m(x, torch.from_numpy(g[f"{name}/state_in"]))
+        assert torch.equal(y, torch.from_numpy(g[f"{name}/y"])) and torch.equal(s, torch.from_numpy(g[f"{name}/state"])), name
+    s = golden("g20_snr_mix_rir.npz")
+    for b in range(3):
+        noisy, c, n = X.snr_mix(s["clean"][b].copy(), s["noise"][b].copy(), float(s["snr"][b]), rir=s["rir"][b].copy(),
+                                rir_noise=s["rir_noise"][b].copy())
+        assert np.allclose(noisy, s["noisy"][b], rtol=0, atol=1e-6) and np.allclose(c, s["clean_n"][b], rtol=0, atol=1e-6)
