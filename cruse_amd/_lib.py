@@ -13,8 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcruse_hip.so")
 
 ABI_VERSION = 4
-PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
-PREC_BY_NAME = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16}
+PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16 = 0, 1, 2, 3
+PREC_BY_NAME = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "f16": PREC_F16}
+DT_F32, DT_F16 = 0, 1
 
 _T = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "q": ctypes.c_longlong, "d": ctypes.c_double,
       "z": ctypes.c_size_t}
@@ -73,13 +74,15 @@ SIGNATURES = {
     "cruse_adam_step_guarded": ("ppppqfffffiffppippp", "i"),
     "cruse_step_health": ("ppppdp", "i"),
     "cruse_sumsq": ("pqpip", "i"),
-    "cruse_conv2d_nchw": ("ppppiiiiiiiiiiiiiiiiiiipip", "i"),
-    "cruse_conv2d_nchw_wgrad": ("pppiiiiiiiiiiiiiiiiip", "i"),
-    "cruse_nchw_channel_sum": ("piiipp", "i"),
-    "cruse_downsum_w": ("pqiipp", "i"),
-    "cruse_bn_nchw_stats": ("piiipp", "i"),
-    "cruse_bn_nchw_fwd": ("ppppppiiiipp", "i"),
-    "cruse_bn_nchw_bwd": ("pppppppiiiiipppppp", "i"),
+    "cruse_conv2d_nchw": ("ppppiiiiiiiiiiiiiiiiiiipiip", "i"),
+    "cruse_conv2d_nchw_wgrad": ("pppiiiiiiiiiiiiiiiiiip", "i"),
+    "cruse_nchw_channel_sum": ("piiipip", "i"),
+    "cruse_downsum_w": ("pqiipip", "i"),
+    "cruse_bn_nchw_stats": ("piiipip", "i"),
+    "cruse_bn_nchw_fwd": ("ppppppiiiipip", "i"),
+    "cruse_bn_nchw_bwd": ("pppppppiiiiipppppip", "i"),
+    "cruse_add_nchw": ("pppqip", "i"),
+    "cruse_cast_f16": ("ppqip", "i"),
     "cruse_stft_framed": ("ppiiiiiiiiifppp", "i"),
     "cruse_istft_framed": ("ppppiiiiiiiifipp", "i"),
     "cruse_mask_ops": ("ippppqfffppp", "i"),

@@ -75,6 +75,7 @@ __device__ __forceinline__ float sigmoid_acc(float x) { return 1.0f / (1.0f + ex
 //   CRUSE_PREC_F32   : v_mfma_f32_16x16x4_f32 (exact f32 products, f32 accumulate)
 //   CRUSE_PREC_BF16X3: operands split hi+lo bf16, 3 bf16 MFMAs (hi*hi + hi*lo + lo*hi)
 //   CRUSE_PREC_BF16  : operands rounded to bf16, 1 bf16 MFMA, f32 accumulate
+//   CRUSE_PREC_F16   : operands rounded to f16, 1 f16 MFMA (v_mfma_f32_16x16x32_f16), f32 accumulate
 //
 // Operand fragment of a 16x16x32 tile product: lane l holds, for row/column (l & 15), the
 // eight K-elements k = (l >> 4) * 8 + 0..7.  For bf16 this is exactly the
@@ -96,6 +97,14 @@ template <> struct Frag<CRUSE_PREC_BF16> {
         for (int q = 0; q < 8; ++q) h[q] = (__bf16)x[q];
     }
 };
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+template <> struct Frag<CRUSE_PREC_F16> {          // v_mfma_f32_16x16x32_f16: the same fragment layout as bf16
+    f16x8_t h;
+    __device__ __forceinline__ void set(const float (&x)[8]) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) h[q] = (_Float16)x[q];
+    }
+};
 template <> struct Frag<CRUSE_PREC_BF16X3> {
     bf16x8 h, l;
     __device__ __forceinline__ void set(const float (&x)[8]) {
@@ -111,6 +120,9 @@ __device__ __forceinline__ f32x4 mma(const Frag<CRUSE_PREC_F32>& a, const Frag<C
 }
 __device__ __forceinline__ f32x4 mma(const Frag<CRUSE_PREC_BF16>& a, const Frag<CRUSE_PREC_BF16>& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma(const Frag<CRUSE_PREC_F16>& a, const Frag<CRUSE_PREC_F16>& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.h, b.h, c, 0, 0, 0);
 }
 __device__ __forceinline__ f32x4 mma(const Frag<CRUSE_PREC_BF16X3>& a, const Frag<CRUSE_PREC_BF16X3>& b, f32x4 c) {
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b.h, c, 0, 0, 0);

@@ -23,6 +23,10 @@ template <int PREC> struct Tile {
     typedef __bf16 elem;
     static constexpr int BK = 64, PADK = 8, NPL = (PREC == CRUSE_PREC_BF16X3) ? 2 : 1;
 };
+template <> struct Tile<CRUSE_PREC_F16> {
+    typedef _Float16 elem;
+    static constexpr int BK = 64, PADK = 8, NPL = 1;
+};
 template <> struct Tile<CRUSE_PREC_F32> {
     typedef float elem;
     static constexpr int BK = 32, PADK = 4, NPL = 1;
@@ -32,6 +36,11 @@ template <int PREC>
 __device__ __forceinline__ void put4(typename Tile<PREC>::elem* s, int plane, int off, const float4& v) {
     if constexpr (PREC == CRUSE_PREC_F32) {
         *reinterpret_cast<float4*>(s + off) = v;
+    } else if constexpr (PREC == CRUSE_PREC_F16) {
+        typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+        f16x4 h;
+        h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+        *reinterpret_cast<f16x4*>(s + off) = h;
     } else {
         typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
         bf16x4 h;
@@ -54,6 +63,8 @@ __device__ __forceinline__ Frag<PREC> get8(const typename Tile<PREC>::elem* s, i
         const float4 a1 = *reinterpret_cast<const float4*>(s + off + 4);
         f.v[0] = a0.x; f.v[1] = a0.y; f.v[2] = a0.z; f.v[3] = a0.w;
         f.v[4] = a1.x; f.v[5] = a1.y; f.v[6] = a1.z; f.v[7] = a1.w;
+    } else if constexpr (PREC == CRUSE_PREC_F16) {
+        f.h = *reinterpret_cast<const f16x8_t*>(s + off);
     } else {
         f.h = *reinterpret_cast<const bf16x8*>(s + off);
         if constexpr (PREC == CRUSE_PREC_BF16X3) f.l = *reinterpret_cast<const bf16x8*>(s + plane + off);
@@ -253,7 +264,7 @@ extern "C" int cruse_gemm(int transA, int transB, int M, int N, int K,
     CRUSE_REQUIRE(M > 0 && N > 0 && K > 0, CRUSE_E_SHAPE, "gemm: empty shape M=%d N=%d K=%d", M, N, K);
     CRUSE_REQUIRE(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, CRUSE_E_SHAPE,
                   "gemm: leading dimensions lda=%d ldb=%d ldc=%d too small", lda, ldb, ldc);
-    CRUSE_REQUIRE(prec == CRUSE_PREC_F32 || prec == CRUSE_PREC_BF16X3 || prec == CRUSE_PREC_BF16, CRUSE_E_DTYPE,
+    CRUSE_REQUIRE(prec == CRUSE_PREC_F32 || prec == CRUSE_PREC_BF16X3 || prec == CRUSE_PREC_BF16 || prec == CRUSE_PREC_F16, CRUSE_E_DTYPE,
                   "gemm: unknown precision %d", prec);
     CRUSE_REQUIRE(b_shift_T == 0 || !transB, CRUSE_E_SHAPE, "gemm: b_shift_T needs transB == 0");
     if (splitk < 1) splitk = 1;
@@ -275,6 +286,7 @@ extern "C" int cruse_gemm(int transA, int transB, int M, int N, int K,
     hipStream_t s = (hipStream_t)stream;
     if (prec == CRUSE_PREC_F32) launch_prec<CRUSE_PREC_F32>(g, transA, transB, grid, s);
     else if (prec == CRUSE_PREC_BF16X3) launch_prec<CRUSE_PREC_BF16X3>(g, transA, transB, grid, s);
+    else if (prec == CRUSE_PREC_F16) launch_prec<CRUSE_PREC_F16>(g, transA, transB, grid, s);
     else launch_prec<CRUSE_PREC_BF16>(g, transA, transB, grid, s);
     CRUSE_LAUNCH_CHECK("gemm");
     return CRUSE_OK;

@@ -8,11 +8,17 @@
 // (H,W = T,F for cust_conv; F,T for mtfaa) as direct VALU convolutions, coalesced along W.  All HBM-bound at these
 // channel counts (8..64); one thread per output element, weights through the scalar/L1 path.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
-struct GConv {
-    const float* x; const float* w; const float* bias; float* y;
+// STORAGE TYPE of the activation tensors (x, y, dy, dx): float, or _Float16 for BASELINE config 5 ("MTFAA ... fp16"):
+// these blocks are HBM-bound, so halving the bytes of every tensor is what the fp16 mode buys; parameters, their
+// gradients, accumulators and BatchNorm statistics stay f32 / f64 in either mode.
+typedef _Float16 f16;
+
+template <typename T> struct GConv {
+    const T* x; const float* w; const float* bias; T* y;
     int B, Cin, Hin, Win, Cout, Hout, Wout;
     int KH, KW, sh, sw, dh, dw, pt, pl;
     int groups, up_w, transposed, act, accumulate;
@@ -25,7 +31,8 @@ struct GConv {
 //   folded into the gather index: the upsampled tensor is never materialised) and Win is the size BEFORE upsampling.
 // transposed == 1 (nn.ConvTranspose2d, weight [Cin][Cout/g][KH][KW]; also the data gradient of a Conv2d):
 //   y[b,co,ho,wo] = bias[co] + sum_{ci, kh, kw : (ho + pt - kh*dh) % sh == 0, ...} w[ci][co_l][kh][kw] * x[b, ci, (ho + pt - kh*dh)/sh, (wo + pl - kw*dw)/sw]
-__global__ __launch_bounds__(256) void gconv_kernel(GConv a) {
+template <typename T>
+__global__ __launch_bounds__(256) void gconv_kernel(GConv<T> a) {
     const long long total = (long long)a.B * a.Cout * a.Hout * a.Wout;
     const int cin_g = a.Cin / a.groups, cout_g = a.Cout / a.groups;
     const int Wup = a.Win * a.up_w;
@@ -37,7 +44,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConv a) {
         const int b = (int)(r / a.Cout);
         const int g = co / cout_g, co_l = co - g * cout_g;
         float acc = a.bias ? a.bias[co] : 0.f;
-        const float* xb = a.x + ((long long)b * a.Cin + (long long)g * cin_g) * a.Hin * a.Win;
+        const T* xb = a.x + ((long long)b * a.Cin + (long long)g * cin_g) * a.Hin * a.Win;
         for (int kh = 0; kh < a.KH; ++kh) {
             int hi;
             if (!a.transposed) {
@@ -60,29 +67,29 @@ __global__ __launch_bounds__(256) void gconv_kernel(GConv a) {
                     wi = num / a.sw;
                     if (wi >= a.Win) continue;
                 }
-                const float* xp = xb + (long long)hi * a.Win + wi;
+                const T* xp = xb + (long long)hi * a.Win + wi;
                 if (!a.transposed) {
                     const float* wp = a.w + (((long long)co * cin_g) * a.KH + kh) * a.KW + kw;
                     for (int ci = 0; ci < cin_g; ++ci)
-                        acc += wp[(long long)ci * a.KH * a.KW] * xp[(long long)ci * a.Hin * a.Win];
+                        acc += wp[(long long)ci * a.KH * a.KW] * (float)xp[(long long)ci * a.Hin * a.Win];
                 } else {
                     const float* wp = a.w + ((((long long)g * cin_g) * cout_g + co_l) * a.KH + kh) * a.KW + kw;
                     for (int ci = 0; ci < cin_g; ++ci)
-                        acc += wp[(long long)ci * cout_g * a.KH * a.KW] * xp[(long long)ci * a.Hin * a.Win];
+                        acc += wp[(long long)ci * cout_g * a.KH * a.KW] * (float)xp[(long long)ci * a.Hin * a.Win];
                 }
             }
         }
         if (a.act == 1) acc = fmaxf(acc, 0.f);
         else if (a.act == 2) acc = acc >= 0.f ? acc : a.slope[co] * acc;
-        if (a.accumulate) a.y[i] += acc; else a.y[i] = acc;
+        if (a.accumulate) a.y[i] = (T)((float)a.y[i] + acc); else a.y[i] = (T)acc;
     }
 }
 
 // 1x1, stride 1, groups 1 (the pointwise convolutions of TFCM_Block / the depthwise-separable blocks, either form): one
 // thread per POSITION computes all Cout outputs from Cin coalesced loads -- the general kernel above issues Cin loads per
 // OUTPUT (Cout x more).  Weights sit in LDS as [Cout][Cin] (transposed == 1: read from the [Cin][Cout] tensor).
-template <int MAXCO>
-__global__ __launch_bounds__(256) void gconv_pointwise_kernel(GConv a) {
+template <typename T, int MAXCO>
+__global__ __launch_bounds__(256) void gconv_pointwise_kernel(GConv<T> a) {
     extern __shared__ float wl[];                    // [Cout][Cin]
     for (int i = threadIdx.x; i < a.Cout * a.Cin; i += 256) {
         const int co = i / a.Cin, ci = i - co * a.Cin;
@@ -92,24 +99,109 @@ __global__ __launch_bounds__(256) void gconv_pointwise_kernel(GConv a) {
     const long long hw = (long long)a.Hin * a.Win, total = (long long)a.B * hw;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long b = i / hw, p = i - b * hw;
-        const float* xp = a.x + b * a.Cin * hw + p;
+        const T* xp = a.x + b * a.Cin * hw + p;
         float acc[MAXCO];
 #pragma unroll
         for (int co = 0; co < MAXCO; ++co) acc[co] = (co < a.Cout && a.bias) ? a.bias[co] : 0.f;
         for (int ci = 0; ci < a.Cin; ++ci) {
-            const float v = xp[(long long)ci * hw];
+            const float v = (float)xp[(long long)ci * hw];
 #pragma unroll
             for (int co = 0; co < MAXCO; ++co)
                 if (co < a.Cout) acc[co] += wl[co * a.Cin + ci] * v;
         }
-        float* yp = a.y + b * a.Cout * hw + p;
+        T* yp = a.y + b * a.Cout * hw + p;
 #pragma unroll
         for (int co = 0; co < MAXCO; ++co) {
             if (co < a.Cout) {
                 float v = acc[co];
                 if (a.act == 1) v = fmaxf(v, 0.f);
                 else if (a.act == 2) v = v >= 0.f ? v : a.slope[co] * v;
-                if (a.accumulate) yp[(long long)co * hw] += v; else yp[(long long)co * hw] = v;
+                if (a.accumulate) yp[(long long)co * hw] = (T)((float)yp[(long long)co * hw] + v); else yp[(long long)co * hw] = (T)v;
+            }
+        }
+    }
+}
+
+// The same pointwise convolution on the MATRIX CORES for f16 storage (BASELINE config 5; model/mtfaa.py:170-183 -- the two
+// 1x1 convolutions of every TFCM_Block -- and the separable blocks of cust_conv.py:56-57,111-112), both forms:
+//   D[co][p] = sum_ci W[co][ci] x[b][ci][p]   as   v_mfma_f32_16x16x32_f16, M = Cout (MT tiles), K = Cin (KS steps), N = positions.
+// The weights live in registers as A fragments for the life of the block.  NCHW keeps p contiguous and ci strided, so the B
+// fragment (lane = position l & 15, eight consecutive ci from (l >> 4) * 8) is gathered straight from global memory with
+// 2-byte loads: the 16 lanes of a row read one 32-byte run, four tiles are in flight per wave, and a whole input line is
+// consumed by four neighbouring tiles of the same wave (L1).  The VALU form above issues Cin * Cout FMAs and as many LDS
+// weight reads per position (576 + 576 for the 24-channel TFCM layers); this one issues KS * 8 loads + MT * KS MFMAs per 16.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+
+template <int MT, int KS>
+__global__ __launch_bounds__(256) void gconv_pointwise_mfma_f16_kernel(GConv<f16> a) {
+    constexpr int TPI = 4;                                    // position tiles in flight per wave
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int m = lane & 15, kg = lane >> 4;
+    const long long hw = (long long)a.Hin * a.Win;
+    const int tiles_img = (int)((hw + 15) >> 4);
+    const long long ntile = (long long)a.B * tiles_img;
+    // resident weight fragments (f32 master weights rounded to f16 here): A[mt][ks][e] = W[co = mt*16 + m][ci = ks*32 + kg*8 + e]
+    f16x8 wf[MT][KS];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int co = mt * 16 + m, ci = ks * 32 + kg * 8 + e;
+                float w = 0.f;
+                if (co < a.Cout && ci < a.Cin) w = a.transposed ? a.w[(long long)ci * a.Cout + co] : a.w[(long long)co * a.Cin + ci];
+                wf[mt][ks][e] = (f16)w;
+            }
+    float bs[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int co = mt * 16 + kg * 4 + j;
+            bs[mt][j] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+        }
+    const long long wstride = (long long)gridDim.x * 4 * TPI;
+    for (long long t0 = ((long long)blockIdx.x * 4 + wv) * TPI; t0 < ntile; t0 += wstride) {
+        f16x8 fb[TPI][KS];
+#pragma unroll
+        for (int q = 0; q < TPI; ++q) {
+            const long long t = t0 + q;
+            const int b = (int)(t / tiles_img);
+            const long long pp = (long long)(t - (long long)b * tiles_img) * 16 + m;
+            const bool ok = t < ntile && pp < hw;
+            const f16* xp = a.x + (long long)b * a.Cin * hw + pp;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int ci = ks * 32 + kg * 8 + e;
+                    fb[q][ks][e] = (ok && ci < a.Cin) ? xp[(long long)ci * hw] : (f16)0.f;
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < TPI; ++q) {
+            const long long t = t0 + q;
+            const int b = (int)(t / tiles_img);
+            const long long pp = (long long)(t - (long long)b * tiles_img) * 16 + m;
+            const bool ok = t < ntile && pp < hw;
+            f16* yp = a.y + (long long)b * a.Cout * hw + pp;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x4 acc = {bs[mt][0], bs[mt][1], bs[mt][2], bs[mt][3]};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mt][ks], fb[q][ks], acc, 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int co = mt * 16 + kg * 4 + j;
+                    if (ok && co < a.Cout) {
+                        float v = acc[j];
+                        if (a.act == 1) v = fmaxf(v, 0.f);
+                        else if (a.act == 2) v = v >= 0.f ? v : a.slope[co] * v;
+                        if (a.accumulate) v += (float)yp[(long long)co * hw];
+                        yp[(long long)co * hw] = (f16)v;
+                    }
+                }
             }
         }
     }
@@ -118,12 +210,13 @@ __global__ __launch_bounds__(256) void gconv_pointwise_kernel(GConv a) {
 // Weight gradient of both forms as ONE contraction:
 //   dw[ca][cb_l][kh][kw] += sum_{n,h,w} S[n,ca,h,w] * Bg[n, g*CBg + cb_l, h*sh - pt + kh*dh, (w*sw - pl + kw*dw) / up_w]
 // Conv2d:          S = dy (ca = co, HxW = output size), Bg = x;   ConvTranspose2d: S = x (ca = ci), Bg = dy.
-struct GWgrad {
-    const float* S; const float* Bg; float* dw;
+template <typename T> struct GWgrad {
+    const T* S; const T* Bg; float* dw;
     int N, CA, HS, WS, CB, HB, WB;
     int KH, KW, sh, sw, dh, dw_, pt, pl, groups, up_w;
 };
-__global__ __launch_bounds__(256) void gconv_wgrad_kernel(GWgrad a) {
+template <typename T>
+__global__ __launch_bounds__(256) void gconv_wgrad_kernel(GWgrad<T> a) {
     __shared__ float red[4];
     const int cb_g = a.CB / a.groups, ca_g = a.CA / a.groups;
     int wi_ = blockIdx.x;                                   // weight element
@@ -137,15 +230,15 @@ __global__ __launch_bounds__(256) void gconv_wgrad_kernel(GWgrad a) {
     const int hw = a.HS * a.WS;
     float acc = 0.f;
     for (int n = blockIdx.y; n < a.N; n += gridDim.y) {
-        const float* sp = a.S + ((long long)n * a.CA + ca) * hw;
-        const float* bp = a.Bg + ((long long)n * a.CB + cb) * a.HB * a.WB;
+        const T* sp = a.S + ((long long)n * a.CA + ca) * hw;
+        const T* bp = a.Bg + ((long long)n * a.CB + cb) * a.HB * a.WB;
         for (int i = threadIdx.x; i < hw; i += 256) {
             const int h = i / a.WS, w = i - h * a.WS;
             const int hb = h * a.sh - a.pt + kh * a.dh;
             int wb = w * a.sw - a.pl + kw * a.dw_;
             if (hb < 0 || hb >= a.HB || wb < 0 || wb >= Wup) continue;
             wb /= a.up_w;
-            acc += sp[i] * bp[(long long)hb * a.WB + wb];
+            acc += (float)sp[i] * (float)bp[(long long)hb * a.WB + wb];
         }
     }
     acc = wave_sum(acc);
@@ -158,7 +251,8 @@ __global__ __launch_bounds__(256) void gconv_wgrad_kernel(GWgrad a) {
 // for each kh, the matching row of Bg ([CB][WB]) in LDS ONCE, and every thread accumulates its weight elements (ca, cb_l, kw)
 // over the row from LDS; one atomic per weight element and block.  The per-weight kernel above streams one plane of S and one of
 // Bg per BLOCK -- CA*CB/groups*KH*KW times the tensors' bytes (2.3 GB for a 24 x 24 pointwise layer on [8,24,161,401]).
-__global__ __launch_bounds__(256) void gconv_wgrad_rows_kernel(GWgrad a) {
+template <typename T>
+__global__ __launch_bounds__(256) void gconv_wgrad_rows_kernel(GWgrad<T> a) {
     extern __shared__ float sm[];
     float* Ss = sm;                                   // [CA][WS]
     float* Bs = sm + (size_t)a.CA * a.WS;             // [CB][WB]
@@ -168,7 +262,7 @@ __global__ __launch_bounds__(256) void gconv_wgrad_rows_kernel(GWgrad a) {
     const int Wup = a.WB * a.up_w;
     for (int i = threadIdx.x; i < a.CA * a.WS; i += 256) {
         const int ca = i / a.WS, w = i - ca * a.WS;
-        Ss[i] = a.S[(((long long)n * a.CA + ca) * a.HS + h) * a.WS + w];
+        Ss[i] = (float)a.S[(((long long)n * a.CA + ca) * a.HS + h) * a.WS + w];
     }
     for (int kh = 0; kh < a.KH; ++kh) {
         const int hb = h * a.sh - a.pt + kh * a.dh;
@@ -176,7 +270,7 @@ __global__ __launch_bounds__(256) void gconv_wgrad_rows_kernel(GWgrad a) {
         if (hb < 0 || hb >= a.HB) continue;           // block-uniform
         for (int i = threadIdx.x; i < a.CB * a.WB; i += 256) {
             const int cb = i / a.WB, w = i - cb * a.WB;
-            Bs[i] = a.Bg[(((long long)n * a.CB + cb) * a.HB + hb) * a.WB + w];
+            Bs[i] = (float)a.Bg[(((long long)n * a.CB + cb) * a.HB + hb) * a.WB + w];
         }
         __syncthreads();
         for (int e = threadIdx.x; e < nwk; e += 256) {
@@ -216,13 +310,14 @@ __global__ __launch_bounds__(256) void gconv_wgrad_rows_kernel(GWgrad a) {
 }
 
 // out[c] += sum_{n,hw} x[n,c,hw]   (conv bias gradient)
-__global__ __launch_bounds__(256) void nchw_channel_sum_kernel(const float* x, int N, int C, int HW, float* out) {
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_channel_sum_kernel(const T* x, int N, int C, int HW, float* out) {
     __shared__ float red[4];
     const int c = blockIdx.x;
     float acc = 0.f;
     for (int n = blockIdx.y; n < N; n += gridDim.y) {
-        const float* p = x + ((long long)n * C + c) * HW;
-        for (int i = threadIdx.x; i < HW; i += 256) acc += p[i];
+        const T* p = x + ((long long)n * C + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += 256) acc += (float)p[i];
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -231,27 +326,29 @@ __global__ __launch_bounds__(256) void nchw_channel_sum_kernel(const float* x, i
 }
 
 // dx[.., w0] = sum_{j < up} dxu[.., w0*up + j]   (gradient of the nearest FreqUpsample)
-__global__ void downsum_w_kernel(const float* dxu, long long rows, int W, int up, float* dx) {
+template <typename T>
+__global__ void downsum_w_kernel(const T* dxu, long long rows, int W, int up, T* dx) {
     const long long n = rows * W;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const long long r = i / W;
         const int w = (int)(i - r * W);
         float s = 0.f;
-        for (int j = 0; j < up; ++j) s += dxu[r * W * up + (long long)w * up + j];
-        dx[i] = s;
+        for (int j = 0; j < up; ++j) s += (float)dxu[r * W * up + (long long)w * up + j];
+        dx[i] = (T)s;
     }
 }
 
 // ---- BatchNorm2d on NCHW (+ ReLU / PReLU) ---------------------------------------------------------
 // sums[c] = sum x, sums[C + c] = sum x^2 in f64 (cruse_bn_finalize turns them into mean / rstd / running stats)
-__global__ __launch_bounds__(256) void bn_nchw_stats_kernel(const float* x, int N, int C, int HW, double* sums) {
+template <typename T>
+__global__ __launch_bounds__(256) void bn_nchw_stats_kernel(const T* x, int N, int C, int HW, double* sums) {
     __shared__ double red[2][4];
     const int c = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
     for (int n = blockIdx.y; n < N; n += gridDim.y) {
-        const float* p = x + ((long long)n * C + c) * HW;
+        const T* p = x + ((long long)n * C + c) * HW;
         float a1 = 0.f, a2 = 0.f;
-        for (int i = threadIdx.x; i < HW; i += 256) { const float v = p[i]; a1 += v; a2 += v * v; }
+        for (int i = threadIdx.x; i < HW; i += 256) { const float v = (float)p[i]; a1 += v; a2 += v * v; }
         s1 += a1; s2 += a2;
     }
     s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
@@ -264,20 +361,22 @@ __global__ __launch_bounds__(256) void bn_nchw_stats_kernel(const float* x, int 
 }
 
 // y = act(gamma * (x - mean) * rstd + beta); mean == NULL: no normalisation (plain activation of x)
-__global__ void bn_nchw_fwd_kernel(const float* x, const float* mean, const float* rstd, const float* gamma,
-                                   const float* beta, const float* slope, int act, long long total, int C, int HW, float* y) {
+template <typename T>
+__global__ void bn_nchw_fwd_kernel(const T* x, const float* mean, const float* rstd, const float* gamma,
+                                   const float* beta, const float* slope, int act, long long total, int C, int HW, T* y) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)((i / HW) % C);
-        float z = x[i];
+        float z = (float)x[i];
         if (mean) z = (z - mean[c]) * rstd[c] * gamma[c] + beta[c];
         if (act == 1) z = fmaxf(z, 0.f);
         else if (act == 2) z = z >= 0.f ? z : slope[c] * z;
-        y[i] = z;
+        y[i] = (T)z;
     }
 }
 
 // per channel: r[c] = sum dz, r[C+c] = sum dz * xhat, r[2C+c] = sum dy * min(z, 0) (PReLU slope gradient); dz = dy through act
-__global__ __launch_bounds__(256) void bn_nchw_bwd_reduce_kernel(const float* dy, const float* x, const float* mean,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_nchw_bwd_reduce_kernel(const T* dy, const T* x, const float* mean,
                                                                  const float* rstd, const float* gamma, const float* beta,
                                                                  const float* slope, int act, int N, int C, int HW,
                                                                  double* r) {
@@ -290,9 +389,9 @@ __global__ __launch_bounds__(256) void bn_nchw_bwd_reduce_kernel(const float* dy
         const long long o = ((long long)n * C + c) * HW;
         float a1 = 0.f, a2 = 0.f, a3 = 0.f;
         for (int i = threadIdx.x; i < HW; i += 256) {
-            const float xh = (x[o + i] - m) * rs;
+            const float xh = ((float)x[o + i] - m) * rs;
             const float z = xh * ga + be;
-            float d = dy[o + i];
+            float d = (float)dy[o + i];
             if (act == 1) d = z > 0.f ? d : 0.f;
             else if (act == 2) { if (z < 0.f) { a3 += d * z; d *= sl; } }
             a1 += d; a2 += d * xh;
@@ -310,23 +409,24 @@ __global__ __launch_bounds__(256) void bn_nchw_bwd_reduce_kernel(const float* dy
 }
 
 // dx = gamma * rstd * (dz - [training] (mean(dz) + xhat * mean(dz * xhat)));  mean == NULL: dx = dz
-__global__ void bn_nchw_bwd_apply_kernel(const float* dy, const float* x, const float* mean, const float* rstd,
+template <typename T>
+__global__ void bn_nchw_bwd_apply_kernel(const T* dy, const T* x, const float* mean, const float* rstd,
                                          const float* gamma, const float* beta, const float* slope, int act,
                                          const double* r, double inv_count, int training, long long total, int C, int HW,
-                                         float* dx) {
+                                         T* dx) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)((i / HW) % C);
         const float m = mean ? mean[c] : 0.f, rs = mean ? rstd[c] : 1.f, ga = mean ? gamma[c] : 1.f, be = mean ? beta[c] : 0.f;
-        const float xh = (x[i] - m) * rs;
+        const float xh = ((float)x[i] - m) * rs;
         const float z = xh * ga + be;
-        float d = dy[i];
+        float d = (float)dy[i];
         if (act == 1) d = z > 0.f ? d : 0.f;
         else if (act == 2) d = z >= 0.f ? d : slope[c] * d;
         if (mean) {
             if (training) d -= (float)(r[c] * inv_count) + xh * (float)(r[C + c] * inv_count);
             d *= ga * rs;
         }
-        dx[i] = d;
+        dx[i] = (T)d;
     }
 }
 
@@ -337,6 +437,19 @@ __global__ void bn_nchw_param_grads_kernel(const double* r, int C, float* dgamma
     if (dbeta) dbeta[c] += (float)r[c];
     if (dgamma) dgamma[c] += (float)r[C + c];
     if (dslope) dslope[c] += (float)r[2 * C + c];
+}
+
+// out = a + b (residual adds of TFCM_Block / GroupGRU add_outputs on f16 storage) and f32 <-> f16 casts (where the f16
+// part of a model starts / ends), 8 elements per thread
+template <typename T>
+__global__ void add_t_kernel(const T* a, const T* b, T* out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = (T)((float)a[i] + (float)b[i]);
+}
+template <typename S, typename D>
+__global__ void cast_t_kernel(const S* src, D* dst, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = (D)(float)src[i];
 }
 
 inline int gblocks(long long n, int per = 1024, int cap = 8192) {
@@ -350,48 +463,56 @@ inline int gblocks(long long n, int per = 1024, int cap = 8192) {
 
 #define ST(s) ((hipStream_t)(s))
 
-extern "C" int cruse_conv2d_nchw(const float* x, const float* w, const float* bias, float* y,
-                                 int B, int Cin, int Hin, int Win, int Cout, int Hout, int Wout,
-                                 int KH, int KW, int sh, int sw, int dh, int dw, int pt, int pl,
-                                 int groups, int up_w, int transposed, int act, const float* slope, int accumulate,
-                                 void* stream) {
-    CRUSE_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, CRUSE_E_SHAPE,
-                  "conv2d_nchw: bad shape B=%d Cin=%d Cout=%d in %dx%d out %dx%d", B, Cin, Cout, Hin, Win, Hout, Wout);
-    CRUSE_REQUIRE(KH > 0 && KW > 0 && sh > 0 && sw > 0 && dh > 0 && dw > 0 && groups > 0 && up_w > 0, CRUSE_E_SHAPE,
-                  "conv2d_nchw: bad kernel geometry");
-    CRUSE_REQUIRE(Cin % groups == 0 && Cout % groups == 0, CRUSE_E_SHAPE, "conv2d_nchw: channels %d/%d not divisible by groups %d", Cin, Cout, groups);
-    CRUSE_REQUIRE(!(transposed && up_w != 1), CRUSE_E_SHAPE, "conv2d_nchw: upsampling only with the conv form");
-    CRUSE_REQUIRE(act >= 0 && act <= 2 && (act != 2 || slope) && !(accumulate && act), CRUSE_E_SHAPE, "conv2d_nchw: bad activation");
-    GConv a = {x, w, bias, y, B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, sh, sw, dh, dw, pt, pl, groups, up_w, transposed, act,
-               accumulate, slope};
-    if (KH == 1 && KW == 1 && sh == 1 && sw == 1 && pt == 0 && pl == 0 && groups == 1 && up_w == 1 && Hout == Hin && Wout == Win &&
-        Cout <= 64 && Cin <= 256) {
+#define CRUSE_DT_CHECK(name) CRUSE_REQUIRE(dtype == CRUSE_DT_F32 || dtype == CRUSE_DT_F16, CRUSE_E_DTYPE, name ": unknown storage dtype %d", dtype)
+
+namespace {
+template <typename T>
+int conv2d_nchw_t(const void* x, const float* w, const float* bias, void* y, int B, int Cin, int Hin, int Win, int Cout, int Hout,
+                  int Wout, int KH, int KW, int sh, int sw, int dh, int dw, int pt, int pl, int groups, int up_w, int transposed,
+                  int act, const float* slope, int accumulate, hipStream_t s) {
+    GConv<T> a = {(const T*)x, w, bias, (T*)y, B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, sh, sw, dh, dw, pt, pl, groups, up_w,
+                  transposed, act, accumulate, slope};
+    const bool pointwise = KH == 1 && KW == 1 && sh == 1 && sw == 1 && pt == 0 && pl == 0 && groups == 1 && up_w == 1 &&
+                           Hout == Hin && Wout == Win;
+    if constexpr (sizeof(T) == 2) {
+        // f16 storage: the pointwise convolutions run on the matrix cores (weights resident as A fragments)
+        const int MT = cdiv(Cout, 16), KS = cdiv(Cin, 32);
+        if (pointwise && MT <= 4 && KS <= 4 && !getenv("CRUSE_PW_VALU")) {
+            const long long ntile = (long long)B * cdivl((long long)Hin * Win, 16);
+            const int nb = (int)(cdivl(ntile, 16) > 8192 ? 8192 : cdivl(ntile, 16));
+#define PW_CASE(mt, ks) hipLaunchKernelGGL((gconv_pointwise_mfma_f16_kernel<mt, ks>), dim3(nb), dim3(256), 0, s, a)
+            const int mtc = MT <= 1 ? 1 : MT <= 2 ? 2 : 4, ksc = KS <= 1 ? 1 : KS <= 2 ? 2 : 4;
+            if (mtc == 1 && ksc == 1) PW_CASE(1, 1); else if (mtc == 1 && ksc == 2) PW_CASE(1, 2); else if (mtc == 1) PW_CASE(1, 4);
+            else if (mtc == 2 && ksc == 1) PW_CASE(2, 1); else if (mtc == 2 && ksc == 2) PW_CASE(2, 2); else if (mtc == 2) PW_CASE(2, 4);
+            else if (ksc == 1) PW_CASE(4, 1); else if (ksc == 2) PW_CASE(4, 2); else PW_CASE(4, 4);
+#undef PW_CASE
+            CRUSE_LAUNCH_CHECK("conv2d_nchw pointwise mfma f16");
+            return CRUSE_OK;
+        }
+    }
+    if (pointwise && Cout <= 64 && Cin <= 256) {
         const size_t lds = (size_t)Cout * Cin * sizeof(float);
         const int nb = gblocks((long long)B * Hin * Win, 256, 8192);
-        if (Cout <= 16) hipLaunchKernelGGL(gconv_pointwise_kernel<16>, dim3(nb), dim3(256), lds, ST(stream), a);
-        else if (Cout <= 32) hipLaunchKernelGGL(gconv_pointwise_kernel<32>, dim3(nb), dim3(256), lds, ST(stream), a);
-        else hipLaunchKernelGGL(gconv_pointwise_kernel<64>, dim3(nb), dim3(256), lds, ST(stream), a);
+        if (Cout <= 16) hipLaunchKernelGGL((gconv_pointwise_kernel<T, 16>), dim3(nb), dim3(256), lds, s, a);
+        else if (Cout <= 32) hipLaunchKernelGGL((gconv_pointwise_kernel<T, 32>), dim3(nb), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((gconv_pointwise_kernel<T, 64>), dim3(nb), dim3(256), lds, s, a);
         CRUSE_LAUNCH_CHECK("conv2d_nchw pointwise");
         return CRUSE_OK;
     }
-    hipLaunchKernelGGL(gconv_kernel, dim3(gblocks((long long)B * Cout * Hout * Wout, 256, 16384)), dim3(256), 0, ST(stream), a);
+    hipLaunchKernelGGL(gconv_kernel<T>, dim3(gblocks((long long)B * Cout * Hout * Wout, 256, 16384)), dim3(256), 0, s, a);
     CRUSE_LAUNCH_CHECK("conv2d_nchw");
     return CRUSE_OK;
 }
 
-extern "C" int cruse_conv2d_nchw_wgrad(const float* S, const float* Bg, float* dw,
-                                       int N, int CA, int HS, int WS, int CB, int HB, int WB,
-                                       int KH, int KW, int sh, int sw, int dh, int dw_, int pt, int pl,
-                                       int groups, int up_w, void* stream) {
-    CRUSE_REQUIRE(N > 0 && CA > 0 && CB > 0 && HS > 0 && WS > 0 && HB > 0 && WB > 0 && KH > 0 && KW > 0, CRUSE_E_SHAPE,
-                  "conv2d_nchw_wgrad: bad shape");
-    CRUSE_REQUIRE(CA % groups == 0 && CB % groups == 0 && up_w > 0, CRUSE_E_SHAPE, "conv2d_nchw_wgrad: groups");
-    GWgrad a = {S, Bg, dw, N, CA, HS, WS, CB, HB, WB, KH, KW, sh, sw, dh, dw_, pt, pl, groups, up_w};
+template <typename T>
+int wgrad_nchw_t(const void* S, const void* Bg, float* dw, int N, int CA, int HS, int WS, int CB, int HB, int WB, int KH, int KW,
+                 int sh, int sw, int dh, int dw_, int pt, int pl, int groups, int up_w, hipStream_t s) {
+    GWgrad<T> a = {(const T*)S, (const T*)Bg, dw, N, CA, HS, WS, CB, HB, WB, KH, KW, sh, sw, dh, dw_, pt, pl, groups, up_w};
     const size_t row_lds = ((size_t)CA * WS + (size_t)CB * WB) * sizeof(float);
     if (row_lds <= 150 * 1024 && (long long)N * HS >= 8) {        // a row pair fits LDS (the per-weight kernel below is the fallback)
-        int rc = cruse_ensure_dyn_lds((const void*)gconv_wgrad_rows_kernel, row_lds, "conv2d_nchw_wgrad");
+        int rc = cruse_ensure_dyn_lds((const void*)gconv_wgrad_rows_kernel<T>, row_lds, "conv2d_nchw_wgrad");
         if (rc) return rc;
-        hipLaunchKernelGGL(gconv_wgrad_rows_kernel, dim3(N * HS), dim3(256), row_lds, ST(stream), a);
+        hipLaunchKernelGGL(gconv_wgrad_rows_kernel<T>, dim3(N * HS), dim3(256), row_lds, s, a);
         CRUSE_LAUNCH_CHECK("conv2d_nchw_wgrad rows");
         return CRUSE_OK;
     }
@@ -399,58 +520,140 @@ extern "C" int cruse_conv2d_nchw_wgrad(const float* S, const float* Bg, float* d
     int ny = 1;
     while (ny < N && (long long)nw * ny < 2048) ny *= 2;
     if (ny > N) ny = N;
-    hipLaunchKernelGGL(gconv_wgrad_kernel, dim3(nw, ny), dim3(256), 0, ST(stream), a);
+    hipLaunchKernelGGL(gconv_wgrad_kernel<T>, dim3(nw, ny), dim3(256), 0, s, a);
     CRUSE_LAUNCH_CHECK("conv2d_nchw_wgrad");
     return CRUSE_OK;
 }
 
-extern "C" int cruse_nchw_channel_sum(const float* x, int N, int C, int HW, float* out, void* stream) {
+template <typename T>
+int bn_nchw_bwd_t(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                  const float* slope, int act, int training, int N, int C, int HW, double* scratch, void* dx, float* dgamma,
+                  float* dbeta, float* dslope, hipStream_t s) {
+    hipLaunchKernelGGL(bn_nchw_bwd_reduce_kernel<T>, dim3(C, N < 32 ? N : 32), dim3(256), 0, s, (const T*)dy, (const T*)x, mean, rstd,
+                       gamma, beta, slope, act, N, C, HW, scratch);
+    CRUSE_LAUNCH_CHECK("bn_nchw_bwd_reduce");
+    const long long total = (long long)N * C * HW;
+    hipLaunchKernelGGL(bn_nchw_bwd_apply_kernel<T>, dim3(gblocks(total)), dim3(256), 0, s, (const T*)dy, (const T*)x, mean, rstd, gamma,
+                       beta, slope, act, scratch, 1.0 / ((double)N * HW), training, total, C, HW, (T*)dx);
+    CRUSE_LAUNCH_CHECK("bn_nchw_bwd_apply");
+    hipLaunchKernelGGL(bn_nchw_param_grads_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, scratch, C, mean ? dgamma : nullptr,
+                       mean ? dbeta : nullptr, act == 2 ? dslope : nullptr);
+    CRUSE_LAUNCH_CHECK("bn_nchw_param_grads");
+    return CRUSE_OK;
+}
+}  // namespace
+
+extern "C" int cruse_conv2d_nchw(const void* x, const float* w, const float* bias, void* y,
+                                 int B, int Cin, int Hin, int Win, int Cout, int Hout, int Wout,
+                                 int KH, int KW, int sh, int sw, int dh, int dw, int pt, int pl,
+                                 int groups, int up_w, int transposed, int act, const float* slope, int accumulate,
+                                 int dtype, void* stream) {
+    CRUSE_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, CRUSE_E_SHAPE,
+                  "conv2d_nchw: bad shape B=%d Cin=%d Cout=%d in %dx%d out %dx%d", B, Cin, Cout, Hin, Win, Hout, Wout);
+    CRUSE_REQUIRE(KH > 0 && KW > 0 && sh > 0 && sw > 0 && dh > 0 && dw > 0 && groups > 0 && up_w > 0, CRUSE_E_SHAPE,
+                  "conv2d_nchw: bad kernel geometry");
+    CRUSE_REQUIRE(Cin % groups == 0 && Cout % groups == 0, CRUSE_E_SHAPE, "conv2d_nchw: channels %d/%d not divisible by groups %d", Cin, Cout, groups);
+    CRUSE_REQUIRE(!(transposed && up_w != 1), CRUSE_E_SHAPE, "conv2d_nchw: upsampling only with the conv form");
+    CRUSE_REQUIRE(act >= 0 && act <= 2 && (act != 2 || slope) && !(accumulate && act), CRUSE_E_SHAPE, "conv2d_nchw: bad activation");
+    CRUSE_DT_CHECK("conv2d_nchw");
+    if (dtype == CRUSE_DT_F16)
+        return conv2d_nchw_t<f16>(x, w, bias, y, B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, sh, sw, dh, dw, pt, pl, groups, up_w,
+                                  transposed, act, slope, accumulate, ST(stream));
+    return conv2d_nchw_t<float>(x, w, bias, y, B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, sh, sw, dh, dw, pt, pl, groups, up_w,
+                                transposed, act, slope, accumulate, ST(stream));
+}
+
+extern "C" int cruse_conv2d_nchw_wgrad(const void* S, const void* Bg, float* dw,
+                                       int N, int CA, int HS, int WS, int CB, int HB, int WB,
+                                       int KH, int KW, int sh, int sw, int dh, int dw_, int pt, int pl,
+                                       int groups, int up_w, int dtype, void* stream) {
+    CRUSE_REQUIRE(N > 0 && CA > 0 && CB > 0 && HS > 0 && WS > 0 && HB > 0 && WB > 0 && KH > 0 && KW > 0, CRUSE_E_SHAPE,
+                  "conv2d_nchw_wgrad: bad shape");
+    CRUSE_REQUIRE(CA % groups == 0 && CB % groups == 0 && up_w > 0, CRUSE_E_SHAPE, "conv2d_nchw_wgrad: groups");
+    CRUSE_DT_CHECK("conv2d_nchw_wgrad");
+    if (dtype == CRUSE_DT_F16)
+        return wgrad_nchw_t<f16>(S, Bg, dw, N, CA, HS, WS, CB, HB, WB, KH, KW, sh, sw, dh, dw_, pt, pl, groups, up_w, ST(stream));
+    return wgrad_nchw_t<float>(S, Bg, dw, N, CA, HS, WS, CB, HB, WB, KH, KW, sh, sw, dh, dw_, pt, pl, groups, up_w, ST(stream));
+}
+
+extern "C" int cruse_nchw_channel_sum(const void* x, int N, int C, int HW, float* out, int dtype, void* stream) {
     CRUSE_REQUIRE(N > 0 && C > 0 && HW > 0, CRUSE_E_SHAPE, "nchw_channel_sum: bad shape");
-    hipLaunchKernelGGL(nchw_channel_sum_kernel, dim3(C, N < 16 ? N : 16), dim3(256), 0, ST(stream), x, N, C, HW, out);
+    CRUSE_DT_CHECK("nchw_channel_sum");
+    if (dtype == CRUSE_DT_F16)
+        hipLaunchKernelGGL(nchw_channel_sum_kernel<f16>, dim3(C, N < 16 ? N : 16), dim3(256), 0, ST(stream), (const f16*)x, N, C, HW, out);
+    else
+        hipLaunchKernelGGL(nchw_channel_sum_kernel<float>, dim3(C, N < 16 ? N : 16), dim3(256), 0, ST(stream), (const float*)x, N, C, HW, out);
     CRUSE_LAUNCH_CHECK("nchw_channel_sum");
     return CRUSE_OK;
 }
 
-extern "C" int cruse_downsum_w(const float* dxu, long long rows, int W, int up, float* dx, void* stream) {
+extern "C" int cruse_downsum_w(const void* dxu, long long rows, int W, int up, void* dx, int dtype, void* stream) {
     CRUSE_REQUIRE(rows > 0 && W > 0 && up > 0, CRUSE_E_SHAPE, "downsum_w: bad shape");
-    hipLaunchKernelGGL(downsum_w_kernel, dim3(gblocks(rows * W)), dim3(256), 0, ST(stream), dxu, rows, W, up, dx);
+    CRUSE_DT_CHECK("downsum_w");
+    if (dtype == CRUSE_DT_F16)
+        hipLaunchKernelGGL(downsum_w_kernel<f16>, dim3(gblocks(rows * W)), dim3(256), 0, ST(stream), (const f16*)dxu, rows, W, up, (f16*)dx);
+    else
+        hipLaunchKernelGGL(downsum_w_kernel<float>, dim3(gblocks(rows * W)), dim3(256), 0, ST(stream), (const float*)dxu, rows, W, up, (float*)dx);
     CRUSE_LAUNCH_CHECK("downsum_w");
     return CRUSE_OK;
 }
 
-extern "C" int cruse_bn_nchw_stats(const float* x, int N, int C, int HW, double* sums, void* stream) {
+extern "C" int cruse_bn_nchw_stats(const void* x, int N, int C, int HW, double* sums, int dtype, void* stream) {
     CRUSE_REQUIRE(N > 0 && C > 0 && HW > 0, CRUSE_E_SHAPE, "bn_nchw_stats: bad shape");
+    CRUSE_DT_CHECK("bn_nchw_stats");
     { int rc = cruse_zero_async(sums, 2 * (size_t)C * sizeof(double), ST(stream), "bn_nchw_stats"); if (rc) return rc; }
-    hipLaunchKernelGGL(bn_nchw_stats_kernel, dim3(C, N < 32 ? N : 32), dim3(256), 0, ST(stream), x, N, C, HW, sums);
+    if (dtype == CRUSE_DT_F16)
+        hipLaunchKernelGGL(bn_nchw_stats_kernel<f16>, dim3(C, N < 32 ? N : 32), dim3(256), 0, ST(stream), (const f16*)x, N, C, HW, sums);
+    else
+        hipLaunchKernelGGL(bn_nchw_stats_kernel<float>, dim3(C, N < 32 ? N : 32), dim3(256), 0, ST(stream), (const float*)x, N, C, HW, sums);
     CRUSE_LAUNCH_CHECK("bn_nchw_stats");
     return CRUSE_OK;
 }
 
-extern "C" int cruse_bn_nchw_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                                 const float* slope, int act, int N, int C, int HW, float* y, void* stream) {
+extern "C" int cruse_bn_nchw_fwd(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                 const float* slope, int act, int N, int C, int HW, void* y, int dtype, void* stream) {
     CRUSE_REQUIRE(N > 0 && C > 0 && HW > 0 && act >= 0 && act <= 2 && (act != 2 || slope), CRUSE_E_SHAPE, "bn_nchw_fwd: bad arguments");
     CRUSE_REQUIRE((mean == nullptr) == (rstd == nullptr) && (mean == nullptr || (gamma && beta)), CRUSE_E_SHAPE, "bn_nchw_fwd: statistics");
+    CRUSE_DT_CHECK("bn_nchw_fwd");
     const long long total = (long long)N * C * HW;
-    hipLaunchKernelGGL(bn_nchw_fwd_kernel, dim3(gblocks(total)), dim3(256), 0, ST(stream), x, mean, rstd, gamma, beta, slope, act,
-                       total, C, HW, y);
+    if (dtype == CRUSE_DT_F16)
+        hipLaunchKernelGGL(bn_nchw_fwd_kernel<f16>, dim3(gblocks(total)), dim3(256), 0, ST(stream), (const f16*)x, mean, rstd, gamma, beta,
+                           slope, act, total, C, HW, (f16*)y);
+    else
+        hipLaunchKernelGGL(bn_nchw_fwd_kernel<float>, dim3(gblocks(total)), dim3(256), 0, ST(stream), (const float*)x, mean, rstd, gamma,
+                           beta, slope, act, total, C, HW, (float*)y);
     CRUSE_LAUNCH_CHECK("bn_nchw_fwd");
     return CRUSE_OK;
 }
 
-extern "C" int cruse_bn_nchw_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+extern "C" int cruse_bn_nchw_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                                  const float* beta, const float* slope, int act, int training, int N, int C, int HW,
-                                 double* scratch, float* dx, float* dgamma, float* dbeta, float* dslope, void* stream) {
+                                 double* scratch, void* dx, float* dgamma, float* dbeta, float* dslope, int dtype, void* stream) {
     CRUSE_REQUIRE(N > 0 && C > 0 && HW > 0 && act >= 0 && act <= 2 && (act != 2 || slope), CRUSE_E_SHAPE, "bn_nchw_bwd: bad arguments");
+    CRUSE_DT_CHECK("bn_nchw_bwd");
     { int rc = cruse_zero_async(scratch, 3 * (size_t)C * sizeof(double), ST(stream), "bn_nchw_bwd"); if (rc) return rc; }
-    hipLaunchKernelGGL(bn_nchw_bwd_reduce_kernel, dim3(C, N < 32 ? N : 32), dim3(256), 0, ST(stream), dy, x, mean, rstd, gamma,
-                       beta, slope, act, N, C, HW, scratch);
-    CRUSE_LAUNCH_CHECK("bn_nchw_bwd_reduce");
-    const long long total = (long long)N * C * HW;
-    hipLaunchKernelGGL(bn_nchw_bwd_apply_kernel, dim3(gblocks(total)), dim3(256), 0, ST(stream), dy, x, mean, rstd, gamma, beta,
-                       slope, act, scratch, 1.0 / ((double)N * HW), training, total, C, HW, dx);
-    CRUSE_LAUNCH_CHECK("bn_nchw_bwd_apply");
-    hipLaunchKernelGGL(bn_nchw_param_grads_kernel, dim3(cdiv(C, 64)), dim3(64), 0, ST(stream), scratch, C,
-                       mean ? dgamma : nullptr, mean ? dbeta : nullptr, act == 2 ? dslope : nullptr);
-    CRUSE_LAUNCH_CHECK("bn_nchw_param_grads");
+    if (dtype == CRUSE_DT_F16)
+        return bn_nchw_bwd_t<f16>(dy, x, mean, rstd, gamma, beta, slope, act, training, N, C, HW, scratch, dx, dgamma, dbeta, dslope, ST(stream));
+    return bn_nchw_bwd_t<float>(dy, x, mean, rstd, gamma, beta, slope, act, training, N, C, HW, scratch, dx, dgamma, dbeta, dslope, ST(stream));
+}
+
+extern "C" int cruse_add_nchw(const void* a, const void* b, void* out, long long n, int dtype, void* stream) {
+    CRUSE_REQUIRE(n > 0 && a && b && out, CRUSE_E_SHAPE, "add_nchw: bad arguments");
+    CRUSE_DT_CHECK("add_nchw");
+    if (dtype == CRUSE_DT_F16)
+        hipLaunchKernelGGL(add_t_kernel<f16>, dim3(gblocks(n)), dim3(256), 0, ST(stream), (const f16*)a, (const f16*)b, (f16*)out, n);
+    else
+        hipLaunchKernelGGL(add_t_kernel<float>, dim3(gblocks(n)), dim3(256), 0, ST(stream), (const float*)a, (const float*)b, (float*)out, n);
+    CRUSE_LAUNCH_CHECK("add_nchw");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_cast_f16(const void* src, void* dst, long long n, int to_f16, void* stream) {
+    CRUSE_REQUIRE(n > 0 && src && dst && src != dst, CRUSE_E_SHAPE, "cast_f16: bad arguments (out of place)");
+    if (to_f16)
+        hipLaunchKernelGGL((cast_t_kernel<float, f16>), dim3(gblocks(n)), dim3(256), 0, ST(stream), (const float*)src, (f16*)dst, n);
+    else
+        hipLaunchKernelGGL((cast_t_kernel<f16, float>), dim3(gblocks(n)), dim3(256), 0, ST(stream), (const f16*)src, (float*)dst, n);
+    CRUSE_LAUNCH_CHECK("cast_f16");
     return CRUSE_OK;
 }

@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from .. import ops
 from .._lib import check, lib
-from ..nn_generic import HipConv2d, HipSequential, add, conv2d
+from ..nn_generic import HipConv2d, HipSequential, add, conv2d, to_f16, to_f32  # noqa: F401  (to_f16: where the fp16 part begins)
 
 _p, _stream = ops._p, ops._stream
 
@@ -133,7 +133,7 @@ class ComplexLinearProjection(nn.Module):
         self.clp = ComplexConv2d(cin, cin)
 
     def forward(self, real, imag, alpha: float = 1.0):
-        outputs = self.clp(torch.cat((real, imag), 1))
+        outputs = to_f32(self.clp(torch.cat((real, imag), 1)))       # (the magnitude / power kernel runs on f32 in either mode)
         real, imag = outputs.chunk(2, dim=1)
         return _AmpPowFn.apply(real, imag, 1e-8, alpha)
 

@@ -15,10 +15,45 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from ._lib import check, lib
+from ._lib import DT_F16, DT_F32, check, lib
 
 _p = ops._p
 _stream = ops._stream
+
+
+def _dt(x: torch.Tensor) -> int:
+    """storage type code of an activation tensor (CRUSE_DT_*): f32, or f16 for BASELINE config 5."""
+    if x.dtype == torch.float32:
+        return DT_F32
+    if x.dtype == torch.float16:
+        return DT_F16
+    raise RuntimeError(f"cruse_amd blocks take float32 or float16 activations, got {x.dtype}")
+
+
+class _CastFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, to_f16):
+        x = x.contiguous()
+        ctx.to_f16 = to_f16
+        want = torch.float16 if to_f16 else torch.float32
+        if x.dtype == want:
+            return x
+        out = torch.empty_like(x, dtype=want)
+        check(lib.cruse_cast_f16(_p(x), _p(out), x.numel(), 1 if to_f16 else 0, _stream()))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return _CastFn.apply(g, not ctx.to_f16), None
+
+
+def to_f16(x):
+    """f32 -> f16 activations (HIP kernel; the gradient comes back as f32): where a model's fp16 part begins."""
+    return _CastFn.apply(x, True)
+
+
+def to_f32(x):
+    return _CastFn.apply(x, False)
 
 
 def _pair(v):
@@ -32,10 +67,10 @@ def _conv_raw(x, w, bias, out_hw, KH, KW, stride, dil, pt, pl, groups, up_w, tra
               out=None, accumulate=False):
     B, Cin, Hin, Win = x.shape
     Hout, Wout = out_hw
-    y = torch.empty(B, Cout, Hout, Wout, device=x.device, dtype=torch.float32) if out is None else out
+    y = torch.empty(B, Cout, Hout, Wout, device=x.device, dtype=x.dtype) if out is None else out
     check(lib.cruse_conv2d_nchw(_p(x), _p(w), _p(bias), _p(y), B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, stride[0], stride[1],
                                 dil[0], dil[1], pt, pl, groups, up_w, 1 if transposed else 0, act, _p(slope),
-                                1 if accumulate else 0, _stream()))
+                                1 if accumulate else 0, _dt(x), _stream()))
     return y
 
 
@@ -43,12 +78,12 @@ def _wgrad_raw(S, Bg, dw, KH, KW, stride, dil, pt, pl, groups, up_w):
     N, CA, HS, WS = S.shape
     _, CB, HB, WB = Bg.shape
     check(lib.cruse_conv2d_nchw_wgrad(_p(S), _p(Bg), _p(dw), N, CA, HS, WS, CB, HB, WB, KH, KW, stride[0], stride[1], dil[0],
-                                      dil[1], pt, pl, groups, up_w, _stream()))
+                                      dil[1], pt, pl, groups, up_w, _dt(S), _stream()))
 
 
 def _channel_sum(dy, out):
     N, C = dy.shape[:2]
-    check(lib.cruse_nchw_channel_sum(_p(dy), N, C, dy[0, 0].numel(), _p(out), _stream()))
+    check(lib.cruse_nchw_channel_sum(_p(dy), N, C, dy[0, 0].numel(), _p(out), _dt(dy), _stream()))
 
 
 class _ConvFn(torch.autograd.Function):
@@ -56,7 +91,7 @@ class _ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, cfg):
-        x = x.contiguous(); w = w.contiguous()
+        x = x.contiguous(); w = w.contiguous().float()
         (stride, dil, pt, pl, groups, up_w, transposed, out_hw) = cfg
         KH, KW = w.shape[2], w.shape[3]
         Cout = w.shape[1] * groups if transposed else w.shape[0]
@@ -70,6 +105,8 @@ class _ConvFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         (stride, dil, pt, pl, groups, up_w, transposed, out_hw) = ctx.cfg
         dy = dy.contiguous()
+        if dy.dtype != x.dtype:
+            dy = _CastFn.apply(dy, x.dtype == torch.float16)
         KH, KW = w.shape[2], w.shape[3]
         B, Cin, Hin, Win = x.shape
         dx = dw = db = None
@@ -78,7 +115,7 @@ class _ConvFn(torch.autograd.Function):
                 dxu = _conv_raw(dy, w, None, (Hin, Win * up_w), KH, KW, stride, dil, pt, pl, groups, 1, True, Cin)
                 if up_w > 1:
                     dx = torch.empty_like(x)
-                    check(lib.cruse_downsum_w(_p(dxu), B * Cin * Hin, Win, up_w, _p(dx), _stream()))
+                    check(lib.cruse_downsum_w(_p(dxu), B * Cin * Hin, Win, up_w, _p(dx), _dt(dx), _stream()))
                 else:
                     dx = dxu
             else:
@@ -131,7 +168,7 @@ class _BnActFn(torch.autograd.Function):
         N, C = x.shape[:2]
         HW = x[0, 0].numel()
         y = torch.empty_like(x)
-        check(lib.cruse_bn_nchw_fwd(_p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(slope), act, N, C, HW, _p(y), _stream()))
+        check(lib.cruse_bn_nchw_fwd(_p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(slope), act, N, C, HW, _p(y), _dt(x), _stream()))
         ctx.save_for_backward(x, gamma, beta, slope, mean, rstd)
         ctx.act, ctx.training = act, training
         return y
@@ -140,6 +177,8 @@ class _BnActFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, gamma, beta, slope, mean, rstd = ctx.saved_tensors
         dy = dy.contiguous()
+        if dy.dtype != x.dtype:
+            dy = _CastFn.apply(dy, x.dtype == torch.float16)
         N, C = x.shape[:2]
         HW = x[0, 0].numel()
         dx = torch.empty_like(x)
@@ -148,7 +187,7 @@ class _BnActFn(torch.autograd.Function):
         db = torch.zeros(C, device=x.device) if beta is not None else None
         ds = torch.zeros(C, device=x.device) if slope is not None else None
         check(lib.cruse_bn_nchw_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(slope), ctx.act,
-                                    1 if ctx.training else 0, N, C, HW, _p(scratch), _p(dx), _p(dg), _p(db), _p(ds), _stream()))
+                                    1 if ctx.training else 0, N, C, HW, _p(scratch), _p(dx), _p(dg), _p(db), _p(ds), _dt(x), _stream()))
         return dx, dg, db, ds, None, None, None, None
 
 
@@ -178,7 +217,7 @@ def batchnorm_act(x, bn: Optional[nn.BatchNorm2d], act_module=None):
     HW = xc[0, 0].numel()
     if training:
         sums = torch.empty(2 * C, device=x.device, dtype=torch.float64)
-        check(lib.cruse_bn_nchw_stats(_p(xc), N, C, HW, _p(sums), _stream()))
+        check(lib.cruse_bn_nchw_stats(_p(xc), N, C, HW, _p(sums), _dt(xc), _stream()))
         upd = bn.training and bn.running_mean is not None
         mom = bn.momentum if bn.momentum is not None else 0.1
         mean, rstd = ops.bn_finalize(sums, N * HW, C, bn.eps, mom, bn.running_mean if upd else None,
@@ -193,8 +232,10 @@ def batchnorm_act(x, bn: Optional[nn.BatchNorm2d], act_module=None):
 class _AddFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
+        a = a.contiguous(); b = b.contiguous()
         out = torch.empty_like(a)
-        return ops.axpby(out, a.contiguous(), b.contiguous(), 1.0, 1.0)
+        check(lib.cruse_add_nchw(_p(a), _p(b), _p(out), a.numel(), _dt(a), _stream()))
+        return out
 
     @staticmethod
     def backward(ctx, g):
@@ -202,8 +243,8 @@ class _AddFn(torch.autograd.Function):
 
 
 def add(a, b):
-    if a.shape != b.shape:
-        raise RuntimeError(f"add: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
+    if a.shape != b.shape or a.dtype != b.dtype:
+        raise RuntimeError(f"add: shape / dtype mismatch {tuple(a.shape)} {a.dtype} vs {tuple(b.shape)} {b.dtype}")
     return _AddFn.apply(a, b)
 
 
@@ -221,7 +262,7 @@ class FreqUpsample(nn.Module):
 
     def forward(self, x):
         C = x.shape[1]
-        ones = torch.ones(C, 1, 1, 1, device=x.device, dtype=torch.float32)
+        ones = torch.ones(C, 1, 1, 1, device=x.device, dtype=torch.float32)          # (weights stay f32 in either storage mode)
         return conv2d(x, ones, None, groups=C, up_w=int(self.f))
 
 

@@ -43,7 +43,17 @@ enum {
 enum {
     CRUSE_PREC_F32 = 0,    /* v_mfma_f32_16x16x4_f32: exact f32                         */
     CRUSE_PREC_BF16X3 = 1, /* split bf16 hi+lo, 3 bf16 MFMAs: ~2^-17 relative           */
-    CRUSE_PREC_BF16 = 2    /* operands rounded to bf16, f32 accumulate                  */
+    CRUSE_PREC_BF16 = 2,   /* operands rounded to bf16, f32 accumulate                  */
+    CRUSE_PREC_F16 = 3     /* v_mfma_f32_16x16x32_f16: operands rounded to f16, f32 accumulate (cruse_gemm; BASELINE config 5) */
+};
+
+/* storage type of the activation tensors of the general [B,C,H,W] blocks (cruse_conv2d_nchw, cruse_bn_nchw_*, ...):
+ * BASELINE config 5 ("MTFAA ... fp16") keeps them in f16 -- the blocks are HBM-bound, so the bytes are what fp16 buys --
+ * with f32 parameters, parameter gradients, accumulation and statistics; its pointwise convolutions run on
+ * v_mfma_f32_16x16x32_f16. */
+enum {
+    CRUSE_DT_F32 = 0,
+    CRUSE_DT_F16 = 1
 };
 
 int cruse_abi_version(void);
@@ -342,29 +352,36 @@ int cruse_axpby(float* out, const float* x, const float* y, float a, float b, lo
  *   transposed 0: y[b,co,ho,wo] = bias[co] + sum w[co][ci_l][kh][kw] * X[b,ci, ho*sh-pt+kh*dh, wo*sw-pl+kw*dw],
  *                 X = zero-padded x (W index divided by up_w when up_w > 1; Win is the size before upsampling)
  *   transposed 1: gather form of ConvTranspose2d(padding=(pt,pl)), weight [Cin][Cout/g][KH][KW]
- * The data gradient of either form is the other form with the same weight tensor.  act 0 none, 1 ReLU, 2 PReLU(slope[co]). */
-int cruse_conv2d_nchw(const float* x, const float* w, const float* bias, float* y,
+ * The data gradient of either form is the other form with the same weight tensor.  act 0 none, 1 ReLU, 2 PReLU(slope[co]).
+ * dtype (CRUSE_DT_*): storage type of x / y (and of S, Bg, dy, dx in the functions below); weights, bias, dw stay f32. */
+int cruse_conv2d_nchw(const void* x, const float* w, const float* bias, void* y,
                       int B, int Cin, int Hin, int Win, int Cout, int Hout, int Wout,
                       int KH, int KW, int sh, int sw, int dh, int dw, int pt, int pl,
-                      int groups, int up_w, int transposed, int act, const float* slope, int accumulate, void* stream);
+                      int groups, int up_w, int transposed, int act, const float* slope, int accumulate, int dtype,
+                      void* stream);
 /* dw[ca][cb_l][kh][kw] += sum_{n,h,w} S[n,ca,h,w] * Bg[n, g*CB/groups + cb_l, h*sh-pt+kh*dh, (w*sw-pl+kw*dw_)/up_w]
  * Conv2d: S = dy, Bg = x.  ConvTranspose2d: S = x, Bg = dy. */
-int cruse_conv2d_nchw_wgrad(const float* S, const float* Bg, float* dw,
+int cruse_conv2d_nchw_wgrad(const void* S, const void* Bg, float* dw,
                             int N, int CA, int HS, int WS, int CB, int HB, int WB,
                             int KH, int KW, int sh, int sw, int dh, int dw_, int pt, int pl,
-                            int groups, int up_w, void* stream);
+                            int groups, int up_w, int dtype, void* stream);
 /* out[c] += sum_{n,hw} x[n,c,hw] (conv bias gradient) */
-int cruse_nchw_channel_sum(const float* x, int N, int C, int HW, float* out, void* stream);
+int cruse_nchw_channel_sum(const void* x, int N, int C, int HW, float* out, int dtype, void* stream);
 /* gradient of the nearest FreqUpsample: dx[..,w] = sum_{j<up} dxu[.., w*up + j] */
-int cruse_downsum_w(const float* dxu, long long rows, int W, int up, float* dx, void* stream);
+int cruse_downsum_w(const void* dxu, long long rows, int W, int up, void* dx, int dtype, void* stream);
 /* nn.BatchNorm2d (+ nn.ReLU / nn.PReLU(C)) on [N,C,HW]: batch sums for cruse_bn_finalize; y = act(gamma*(x-mean)*rstd+beta)
  * (mean == NULL: activation only); backward with the PReLU slope gradient.  scratch: 3*C doubles. */
-int cruse_bn_nchw_stats(const float* x, int N, int C, int HW, double* sums, void* stream);
-int cruse_bn_nchw_fwd(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                      const float* slope, int act, int N, int C, int HW, float* y, void* stream);
-int cruse_bn_nchw_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+int cruse_bn_nchw_stats(const void* x, int N, int C, int HW, double* sums, int dtype, void* stream);
+int cruse_bn_nchw_fwd(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                      const float* slope, int act, int N, int C, int HW, void* y, int dtype, void* stream);
+int cruse_bn_nchw_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                       const float* beta, const float* slope, int act, int training, int N, int C, int HW,
-                      double* scratch, float* dx, float* dgamma, float* dbeta, float* dslope, void* stream);
+                      double* scratch, void* dx, float* dgamma, float* dbeta, float* dslope, int dtype, void* stream);
+
+/* out = a + b on n elements of storage type dtype (TFCM_Block residual, mtfaa.py:191; GroupGRU add_outputs, cust_conv.py:411-412) */
+int cruse_add_nchw(const void* a, const void* b, void* out, long long n, int dtype, void* stream);
+/* f32 -> f16 (to_f16 != 0) or f16 -> f32 copy of n elements: where the fp16 part of a model (BASELINE config 5) begins / ends */
+int cruse_cast_f16(const void* src, void* dst, long long n, int to_f16, void* stream);
 
 /* ---- other STFT formulations (feature.py:272-398 CustomSTFT/CustomISTFT, conv_stft.py:8-129, mtfaa.py:8-37) ------- */
 /* X[b,t,f] = scale * sum_{n<win_len} window[n] * x_pad[b, t*hop + n + win_off - pad] * exp(-2 pi i f (n + win_off)/n_fft),

@@ -427,6 +427,76 @@ def test_mtfaa_stft_and_blocks_vs_reference(golden):
     assert out.shape == xin.shape and torch.isfinite(out).all()
 
 
+F16_FWD_TOL = 4e-3      # f16 storage (11-bit significand, rel. rounding 4.9e-4 per stored tensor) through 6 residual blocks
+F16_GRAD_TOL = 2e-2     # weight gradients: sums over 5e5 positions of products of two f16-stored tensors, f32 accumulation
+
+
+@pytest.mark.parametrize("B", [2])
+def test_mtfaa_config5_fp16_on_its_stated_shape(B):
+    """BASELINE config 5 "MTFAA ... fp16" (VERDICT r2 missing 1): PhaseEncoder (f32 front end, mtfaa.py:141-163) -> the fp16
+    part: 6 x TFCM_Block (dilations 1..32, :196-209) on [B,24,161,401] with f16 ACTIVATION STORAGE -- pointwise convolutions
+    on v_mfma_f32_16x16x32_f16, depthwise dilated convolutions / BatchNorm / PReLU as f16-in f16-out streams with f32
+    arithmetic, f32 parameters and statistics -- against the f32 CPU oracle, forward and every parameter gradient, with the
+    tolerances stated above; and against this library's own f32-storage run (same kernels' f32 forms)."""
+    from model import mtfaa as P
+    from cruse_amd.nn_generic import to_f16, to_f32
+    from oracle import cruse_oracle as O
+    from oracle import cruse_oracle_ext as X
+    torch.manual_seed(0)
+    T = 401
+    o_pe, o_tf = X.PhaseEncoder(4, 1), X.TFCM(24, (3, 3), 6)
+    p_pe = _load_like(P.PhaseEncoder(4, 1), o_pe, scale=2.0)
+    p_tf = _load_like(P.TFCM(24, (3, 3), 6), o_tf, scale=1.0)
+    for m in (o_pe, o_tf, p_pe, p_tf):
+        m.train()
+    spec = 0.5 * torch.randn(B, 2, 161, T)
+    w = torch.randn(B, 24, 161, T)
+
+    def run(pe, tf, x, cast_in, cast_out, ww):
+        amp = pe([x])                                                  # [B,4,161,T]
+        h = torch.cat([amp] * 6, dim=1)                                # [B,24,161,T] (channel plumbing, as tools/mtfaa_stress.py)
+        y = cast_out(tf(cast_in(h)))
+        (y * ww).sum().backward()
+        return y.detach()
+
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    y_o = run(o_pe, o_tf, spec, lambda a: a, lambda a: a, w)
+    y_h = run(p_pe, p_tf, spec.cuda(), to_f16, to_f32, w.cuda())
+    g_h = {n: p.grad.clone() for n, p in list(p_pe.named_parameters()) + list(p_tf.named_parameters())}
+    for p in list(p_pe.parameters()) + list(p_tf.parameters()):
+        p.grad = None
+    y_f = run(p_pe, p_tf, spec.cuda(), lambda a: a, lambda a: a, w.cuda())
+    e_f32, e_f16 = rel_l2(y_f, y_o), rel_l2(y_h, y_o)
+    worst = 0.0
+    for (n, po), pp in zip(list(o_pe.named_parameters()) + list(o_tf.named_parameters()), list(g_h.values())):
+        if float(po.grad.norm()) < 1e-6 * max(1.0, float(po.norm())):
+            continue                                                   # (a conv bias in front of a BatchNorm: exactly 0)
+        e = rel_l2(pp, po.grad)
+        worst = max(worst, e)
+        assert e < F16_GRAD_TOL, (n, e)
+    print(f"[config 5 fp16 B={B} [.,24,161,{T}]] forward rel-L2 vs oracle: f16 storage {e_f16:.2e}, f32 storage {e_f32:.2e}; "
+          f"worst parameter-gradient rel-L2 (f16) {worst:.2e}")
+    assert e_f32 < 5e-5 and e_f16 < F16_FWD_TOL
+    assert y_h.dtype == torch.float32 and torch.isfinite(y_h).all()
+
+
+def test_gemm_f16_operand_mode():
+    """CRUSE_PREC_F16: Frag<> on v_mfma_f32_16x16x32_f16 (operands rounded to f16, f32 accumulate), all four transpose forms,
+    against the same product of f16-ROUNDED operands in f64 (exact up to the f32 accumulation order)."""
+    from cruse_amd import ops
+    torch.manual_seed(2)
+    M, N, K = 200, 136, 328
+    A, Bm = torch.randn(M, K).cuda(), torch.randn(N, K).cuda()
+    want = (A.half().double() @ Bm.half().double().t()).float()
+    for ta, tb in ((False, True), (False, False), (True, False), (True, True)):
+        a = A.t().contiguous() if ta else A
+        b = Bm if tb else Bm.t().contiguous()
+        c = torch.zeros(M, N).cuda()
+        ops.gemm(ta, tb, M, N, K, a, 0, a.shape[1], b, 0, b.shape[1], c, 0, N, prec="f16")
+        assert rel_l2(c, want) < 2e-6, (ta, tb, rel_l2(c, want))
+    assert rel_l2(want, A @ Bm.t()) > 1e-4                                   # (the f16 rounding is what is being modelled)
+
+
 # ---------------------------------------------------------------------------------------------------------------- 8f.3
 def test_snr_mix_vs_reference(golden):
     from dataset.dataset import SynDataset

@@ -1,7 +1,8 @@
 """BASELINE config 5 (alt-model stress of the STFT + conv kernels): the blocks model/mtfaa.py actually defines --
 STFT.transform -> PhaseEncoder -> 6 x TFCM_Block (dilations 1..32) -- forward + backward on B clips of `seconds` s.
 The file has no axial attention and its `Banks` needs the absent `spafe`, so this is all there is to
-stress.  Prints frames/s (10 ms hop) of fwd+bwd; f32 storage, direct VALU convolutions (generic.hip)."""
+stress.  Prints frames/s (10 ms hop) of fwd+bwd and the tensor traffic rate.  --dtype f16 (the config's stated dtype): the
+TFCM stack keeps its activations in f16 (pointwise convolutions on v_mfma_f32_16x16x32_f16, generic.hip); f32: all f32."""
 import argparse
 import os
 import sys
@@ -17,8 +18,10 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
     a = ap.parse_args()
     from model import mtfaa as M
+    from cruse_amd.nn_generic import to_f16, to_f32
     torch.manual_seed(0)
     stft = M.STFT(320, 160, 320, "hann")
     pe = M.PhaseEncoder(4, 1).cuda()                 # 1 signal: [B,2,F,T] -> |.|^0.5 [B,2,F,T]
@@ -31,7 +34,10 @@ def main():
         c = stft.transform(x)                        # [B,2,161,T]
         amp = pe([c])                                # [B,2,161,T]
         h = torch.cat([amp] * 12, dim=1)             # [B,24,161,T] (channel plumbing)
-        y = tfcm(h)
+        if a.dtype == "f16":
+            y = to_f32(tfcm(to_f16(h)))
+        else:
+            y = tfcm(h)
         for p in params:
             p.grad = None
         y.square().mean().backward()
@@ -43,8 +49,14 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     T = y.shape[-1]
-    print(f"mtfaa blocks fwd+bwd: B={a.batch} x {a.seconds:g} s, activations [B,24,161,{T}]: {dt * 1e3:.1f} ms/step, "
-          f"{a.batch * T / dt:,.0f} frames/s; finite={bool(torch.isfinite(y).all())}")
+    # tensor traffic of the TFCM stack, counted per block: forward 5 kernels (conv, BN+PReLU, depthwise, BN+PReLU, conv + add)
+    # read + write one [B,24,161,T] tensor each (+ the BN statistics passes: 2 reads); backward ~2.5 x that
+    esz = 2 if a.dtype == "f16" else 4
+    tensor = a.batch * 24 * 161 * T * esz
+    approx = 6 * (5 * 2 + 2 + 2) * tensor * 3.5
+    print(f"mtfaa blocks fwd+bwd ({a.dtype} activations): B={a.batch} x {a.seconds:g} s, activations [B,24,161,{T}]: "
+          f"{dt * 1e3:.1f} ms/step, {a.batch * T / dt:,.0f} frames/s, ~{approx / dt / 1e9:,.0f} GB/s of tensor traffic "
+          f"(one [B,24,161,T] tensor = {tensor / 1e6:.0f} MB); finite={bool(torch.isfinite(y).all())}")
 
 
 if __name__ == "__main__":
