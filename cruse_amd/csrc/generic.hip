@@ -315,9 +315,16 @@ __global__ __launch_bounds__(256) void nchw_channel_sum_kernel(const T* x, int N
     __shared__ float red[4];
     const int c = blockIdx.x;
     float acc = 0.f;
+    // planes are split into gridDim.z chunks: a [8,24,161,401] tensor gives 24 x 8 planes only, far too few blocks to fill
+    // the chip with one block per plane (these reductions ran at 0.4 TB/s)
+    const int chunk = (HW + gridDim.z - 1) / gridDim.z, i0 = blockIdx.z * chunk, i1 = min(HW, i0 + chunk);
     for (int n = blockIdx.y; n < N; n += gridDim.y) {
         const T* p = x + ((long long)n * C + c) * HW;
-        for (int i = threadIdx.x; i < HW; i += 256) acc += (float)p[i];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int i = i0 + threadIdx.x;
+        for (; i + 768 < i1; i += 1024) { a0 += (float)p[i]; a1 += (float)p[i + 256]; a2 += (float)p[i + 512]; a3 += (float)p[i + 768]; }
+        for (; i < i1; i += 256) a0 += (float)p[i];
+        acc += (a0 + a1) + (a2 + a3);
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -345,11 +352,17 @@ __global__ __launch_bounds__(256) void bn_nchw_stats_kernel(const T* x, int N, i
     __shared__ double red[2][4];
     const int c = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
+    const int chunk = (HW + gridDim.z - 1) / gridDim.z, i0 = blockIdx.z * chunk, i1 = min(HW, i0 + chunk);
     for (int n = blockIdx.y; n < N; n += gridDim.y) {
         const T* p = x + ((long long)n * C + c) * HW;
-        float a1 = 0.f, a2 = 0.f;
-        for (int i = threadIdx.x; i < HW; i += 256) { const float v = (float)p[i]; a1 += v; a2 += v * v; }
-        s1 += a1; s2 += a2;
+        float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+        int i = i0 + threadIdx.x;
+        for (; i + 768 < i1; i += 1024) {
+            const float v0 = (float)p[i], v1 = (float)p[i + 256], v2 = (float)p[i + 512], v3 = (float)p[i + 768];
+            a1 += v0 + v1; b1 += v2 + v3; a2 += v0 * v0 + v1 * v1; b2 += v2 * v2 + v3 * v3;
+        }
+        for (; i < i1; i += 256) { const float v = (float)p[i]; a1 += v; a2 += v * v; }
+        s1 += a1 + b1; s2 += a2 + b2;
     }
     s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
@@ -385,10 +398,12 @@ __global__ __launch_bounds__(256) void bn_nchw_bwd_reduce_kernel(const T* dy, co
     const float m = mean ? mean[c] : 0.f, rs = mean ? rstd[c] : 1.f, ga = mean ? gamma[c] : 1.f, be = mean ? beta[c] : 0.f;
     const float sl = act == 2 ? slope[c] : 0.f;
     double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const int chunk = (HW + gridDim.z - 1) / gridDim.z, i0 = blockIdx.z * chunk, i1 = min(HW, i0 + chunk);
     for (int n = blockIdx.y; n < N; n += gridDim.y) {
         const long long o = ((long long)n * C + c) * HW;
         float a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        for (int i = threadIdx.x; i < HW; i += 256) {
+#pragma unroll 4
+        for (int i = i0 + threadIdx.x; i < i1; i += 256) {
             const float xh = ((float)x[o + i] - m) * rs;
             const float z = xh * ga + be;
             float d = (float)dy[o + i];
@@ -450,6 +465,14 @@ template <typename S, typename D>
 __global__ void cast_t_kernel(const S* src, D* dst, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         dst[i] = (D)(float)src[i];
+}
+
+// chunks per plane for the per-channel reductions: enough blocks to fill 256 CUs several times over, at least 4096
+// elements per chunk
+inline int zchunks(int gx, int gy, int HW) {
+    int z = 1;
+    while ((long long)gx * gy * z < 2048 && HW / (z * 2) >= 4096) z *= 2;
+    return z;
 }
 
 inline int gblocks(long long n, int per = 1024, int cap = 8192) {
@@ -529,7 +552,7 @@ template <typename T>
 int bn_nchw_bwd_t(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                   const float* slope, int act, int training, int N, int C, int HW, double* scratch, void* dx, float* dgamma,
                   float* dbeta, float* dslope, hipStream_t s) {
-    hipLaunchKernelGGL(bn_nchw_bwd_reduce_kernel<T>, dim3(C, N < 32 ? N : 32), dim3(256), 0, s, (const T*)dy, (const T*)x, mean, rstd,
+    hipLaunchKernelGGL(bn_nchw_bwd_reduce_kernel<T>, dim3(C, N < 32 ? N : 32, zchunks(C, N < 32 ? N : 32, HW)), dim3(256), 0, s, (const T*)dy, (const T*)x, mean, rstd,
                        gamma, beta, slope, act, N, C, HW, scratch);
     CRUSE_LAUNCH_CHECK("bn_nchw_bwd_reduce");
     const long long total = (long long)N * C * HW;
@@ -580,9 +603,9 @@ extern "C" int cruse_nchw_channel_sum(const void* x, int N, int C, int HW, float
     CRUSE_REQUIRE(N > 0 && C > 0 && HW > 0, CRUSE_E_SHAPE, "nchw_channel_sum: bad shape");
     CRUSE_DT_CHECK("nchw_channel_sum");
     if (dtype == CRUSE_DT_F16)
-        hipLaunchKernelGGL(nchw_channel_sum_kernel<f16>, dim3(C, N < 16 ? N : 16), dim3(256), 0, ST(stream), (const f16*)x, N, C, HW, out);
+        hipLaunchKernelGGL(nchw_channel_sum_kernel<f16>, dim3(C, N < 16 ? N : 16, zchunks(C, N < 16 ? N : 16, HW)), dim3(256), 0, ST(stream), (const f16*)x, N, C, HW, out);
     else
-        hipLaunchKernelGGL(nchw_channel_sum_kernel<float>, dim3(C, N < 16 ? N : 16), dim3(256), 0, ST(stream), (const float*)x, N, C, HW, out);
+        hipLaunchKernelGGL(nchw_channel_sum_kernel<float>, dim3(C, N < 16 ? N : 16, zchunks(C, N < 16 ? N : 16, HW)), dim3(256), 0, ST(stream), (const float*)x, N, C, HW, out);
     CRUSE_LAUNCH_CHECK("nchw_channel_sum");
     return CRUSE_OK;
 }
@@ -603,9 +626,9 @@ extern "C" int cruse_bn_nchw_stats(const void* x, int N, int C, int HW, double* 
     CRUSE_DT_CHECK("bn_nchw_stats");
     { int rc = cruse_zero_async(sums, 2 * (size_t)C * sizeof(double), ST(stream), "bn_nchw_stats"); if (rc) return rc; }
     if (dtype == CRUSE_DT_F16)
-        hipLaunchKernelGGL(bn_nchw_stats_kernel<f16>, dim3(C, N < 32 ? N : 32), dim3(256), 0, ST(stream), (const f16*)x, N, C, HW, sums);
+        hipLaunchKernelGGL(bn_nchw_stats_kernel<f16>, dim3(C, N < 32 ? N : 32, zchunks(C, N < 32 ? N : 32, HW)), dim3(256), 0, ST(stream), (const f16*)x, N, C, HW, sums);
     else
-        hipLaunchKernelGGL(bn_nchw_stats_kernel<float>, dim3(C, N < 32 ? N : 32), dim3(256), 0, ST(stream), (const float*)x, N, C, HW, sums);
+        hipLaunchKernelGGL(bn_nchw_stats_kernel<float>, dim3(C, N < 32 ? N : 32, zchunks(C, N < 32 ? N : 32, HW)), dim3(256), 0, ST(stream), (const float*)x, N, C, HW, sums);
     CRUSE_LAUNCH_CHECK("bn_nchw_stats");
     return CRUSE_OK;
 }

@@ -471,6 +471,46 @@ class TFCM(nn.Module):
 # ----------------------------------------------------------------------------------------------------------------------
 # 8f.3: SynDataset.snr_mix (dataset/dataset.py:236-264)
 # ----------------------------------------------------------------------------------------------------------------------
+class _RoundF16(torch.autograd.Function):
+    """x -> f16 -> f32 in forward AND on the gradient coming back: what storing a tensor (and its gradient) in f16 does."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.half().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.half().float()
+
+
+def emulate_f16_storage(tfcm, round_pointwise_weights=True):
+    """BASELINE config 5 names fp16; the reference (model/mtfaa.py) has no dtype handling of its own, so "fp16" is what
+    `.half()` / autocast would make of it.  This is the oracle's model of the build's fp16 mode: f32 arithmetic, every tensor
+    a TFCM stack STORES (the output of each conv, of each BatchNorm + PReLU pair -- one fused kernel in the build, so nothing
+    is stored between the two -- and of each block's residual add, and the gradients flowing back through them) rounded to
+    f16; optionally the pointwise-conv weights rounded to f16 as MFMA operands.
+    Returns the hook handles (call .remove() on each to undo)."""
+    hooks = []
+    for m in tfcm.modules():
+        if isinstance(m, (nn.Conv2d, nn.PReLU)):
+            hooks.append(m.register_forward_hook(lambda mod, i, o: _RoundF16.apply(o)))
+            if round_pointwise_weights and isinstance(m, nn.Conv2d) and m.kernel_size == (1, 1):
+                def pre(mod, inp):
+                    mod._w_master = mod.weight.data.clone()
+                    mod.weight.data = mod.weight.data.half().float()
+                def post(mod, inp, out):
+                    mod.weight.data = mod._w_master
+                hooks.append(m.register_forward_pre_hook(pre))
+                hooks.append(m.register_forward_hook(post))
+    for blk in tfcm.tfcm:
+        hooks.append(blk.register_forward_hook(lambda mod, i, o: _RoundF16.apply(o)))
+    return hooks
+
+
+def round_f16(x):
+    return _RoundF16.apply(x)
+
+
 def snr_mix(clean_y, noise_y, snr, eps=1e-7, rir=None, rir_noise=None):
     """dataset.py:236-259 (numpy, one clip): -> noisy, normalised clean, scaled noise.  The reference function
     stops after drawing noisy_target_dB_FS (:261-264, file truncated)."""

