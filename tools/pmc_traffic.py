@@ -1,4 +1,6 @@
-"""Turn the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, csv output) into profiles/rNN_pmc_hbm_traffic.csv.
+"""Turn the rocprofv3 PMC passes (HBM traffic: two passes; MFMA utilisation: a third, `--mfma`, see mfma_util) into profiles/ CSVs.
+
+Turn the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, csv output) into profiles/rNN_pmc_hbm_traffic.csv.
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d DIR_F -o p -- python bench.py --steps 3 --warmup 1 \
               --no-graph --no-cpu-baseline --no-kernel-timing --no-parity --no-secondary        (CRUSE_OVERLAP=0; same for WRITE_SIZE)
@@ -40,7 +42,53 @@ def load(path, counter):
     return acc
 
 
+def mfma_util(path, out, n_cu=256, n_xcd=8, steps=4):
+    """Third PMC pass: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace.
+    Per kernel: MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * CUs * 4 SIMDs) -- the share of all matrix
+    pipes' cycles that issued MFMA work while the kernel ran (MI355X_MICROARCH.md: the counter counts cycles, e.g. 32 per
+    v_mfma_f32_32x32x16_bf16; ROCm 7.2 has no gfx950 derived-counter section, so the gfx94x MfmaUtil formula is applied by
+    hand) -- and CU occupancy in time = SQ_BUSY_CU_CYCLES / (GRBM_GUI_ACTIVE * CUs).
+    The csv reports GRBM_GUI_ACTIVE summed over the 8 XCDs (14.9 M "cycles" for the 0.81 ms backward recurrence = 8 x 1.86 M;
+    the derived formulas take reduce(.., max)), so it is divided by n_xcd here.  Cross-checks on the r03 pass: the recurrences
+    show cu_busy 0.60 (160 of 256 CUs hold a workgroup) and 122.88 M MFMA-busy cycles = 30 MFMAs x 401 steps x 640 waves x 16."""
+    acc = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            k = short(r["Kernel_Name"])
+            a = acc.setdefault(k, {})
+            c = a.setdefault(r["Counter_Name"], [0, 0.0])
+            c[0] += 1; c[1] += float(r["Counter_Value"])
+    rows = []
+    for k, a in acc.items():
+        fam = next((fam for key, fam in FAMILY if key in k), None)
+        if fam is None or "GRBM_GUI_ACTIVE" not in a:
+            continue
+        n = a["GRBM_GUI_ACTIVE"][0]
+        gui = a["GRBM_GUI_ACTIVE"][1] / n_xcd
+        mf = a.get("SQ_VALU_MFMA_BUSY_CYCLES", [0, 0.0])[1]
+        bc = a.get("SQ_BUSY_CU_CYCLES", [0, 0.0])[1]
+        wv = a.get("SQ_WAVES", [0, 0.0])[1]
+        rows.append((k, fam, n, gui / n, mf / n, mf / (gui * n_cu * 4) if gui else 0.0, bc / (gui * n_cu) if gui else 0.0, wv / n))
+    rows.sort(key=lambda r: -r[2] * r[3])
+    with open(out, "w") as f:
+        f.write("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace -- python bench.py --steps 3 --warmup 1 --no-graph "
+                "--no-cpu-baseline --no-kernel-timing --no-parity --no-secondary (CRUSE_OVERLAP=0: one kernel at a time)\n")
+        f.write(f"# mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / {n_xcd} XCDs * {n_cu} CUs * 4 SIMDs); cu_busy = SQ_BUSY_CU_CYCLES / (GRBM_GUI_ACTIVE / {n_xcd} * {n_cu}); per-launch averages\n")
+        f.write("kernel,bench_family,launches,gui_active_cycles_per_launch,mfma_busy_cycles_per_launch,mfma_util,cu_busy,waves_per_launch\n")
+        for k, fam, n, gui, mf, u, cb, wv in rows:
+            f.write(f"\"{k}\",{fam},{n},{gui:.0f},{mf:.0f},{u:.4f},{cb:.3f},{wv:.0f}\n")
+    fams = {}
+    for k, fam, n, gui, mf, u, cb, wv in rows:
+        a = fams.setdefault(fam, [0.0, 0.0])
+        a[0] += n * mf; a[1] += n * gui * n_cu * 4
+    print(f"{len(rows)} kernels -> {out}")
+    for fam, (mf, cap) in sorted(fams.items(), key=lambda kv: -kv[1][1]):
+        print(f"  {fam:22s} mfma_util {mf / cap if cap else 0.0:7.4f}   share of GPU-active cycles {cap / sum(v[1] for v in fams.values()):6.3f}")
+
+
 def main():
+    if sys.argv[1] == "--mfma":
+        return mfma_util(sys.argv[2], sys.argv[3])
     fpath, wpath, out = sys.argv[1:4]
     steps = int(sys.argv[4]) if len(sys.argv) > 4 else 4
     F, W = load(fpath, "FETCH_SIZE"), load(wpath, "WRITE_SIZE")
