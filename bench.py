@@ -159,7 +159,7 @@ class KernelTimer:
     """Wraps cruse_amd.ops entry points with HIP events on torch's current stream (where the kernels run)."""
 
     NAMES = ["stft", "conv_gather", "conv_scatter2", "conv_wgrad", "channel_sum", "col_sum", "bn_stats", "bn_finalize",
-             "bn_act_fwd", "bn_finalize_act_fwd", "bn_act_bwd", "ln_fwd", "ln_bwd", "gemm", "gemm_bf16_nt", "gemm_bf16x3_nt", "cast_bf16", "cast_bf16_padded",
+             "bn_act_fwd", "bn_finalize_act_fwd", "bn_act_bwd", "ln_fwd", "ln_bwd", "gemm", "gemm_bf16_nt", "gemm_bf16x3_nt", "gemm_bf16_tn", "gru_gate_bias_sums", "cast_bf16", "cast_bf16_padded",
              "ktile_bf16", "transpose_bf16",
              "gru_seq_fwd", "gru_seq_bwd", "gru_gate_grads", "gru_gate_grads_bf16", "mask_loss"]
 
@@ -265,13 +265,16 @@ def kernel_rooflines(B, T, H, G, prec, per_step_ms, calls):
                          "avg_launch_ms": round(avg_ms, 4),
                          "note": f"latency-bound by design: {T} dependent steps per launch, "
                                  f"{avg_ms * 1e3 / T:.2f} us per step"}
-    for gname in ("gemm", "gemm_bf16_nt", "gemm_bf16x3_nt"):
+    for gname in ("gemm", "gemm_bf16_nt", "gemm_bf16x3_nt", "gemm_bf16_tn"):
         if gname in per_step_ms:
             # ALGORITHMIC flops: 2 layers x (gi, dX, dW_ih, dW_hh); when the forward projections run as split-bf16 x3 in
-            # their own family they are 2 of the 8 products (their 3 MFMA passes are not counted three times)
+            # their own family they are 2 of the 8 products (their 3 MFMA passes are not counted three times); the TN
+            # weight-gradient kernel takes 4 of them (dW_ih, dW_hh of both layers)
             nprod = 8
             if "gemm_bf16x3_nt" in per_step_ms:
                 nprod = 2 if gname == "gemm_bf16x3_nt" else 6
+            if "gemm_bf16_tn" in per_step_ms:
+                nprod = 4 if gname == "gemm_bf16_tn" else (2 if gname in ("gemm_bf16x3_nt", "gemm_bf16_nt") else nprod - 4)
             flops = 2.0 * rows * 3 * Hg * Hg * G * nprod
             avg_ms = per_step_ms[gname] / calls[gname]
             ach = flops / (per_step_ms[gname] * 1e-3) / 1e12

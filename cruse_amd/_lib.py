@@ -46,6 +46,7 @@ SIGNATURES = {
     "cruse_ln_bwd": ("pppppqiipppp", "i"),
     "cruse_gemm": ("iiiiipipipipiiiip", "i"),
     "cruse_gemm_bf16_nt": ("iiipqqpqqpqpiip", "i"),
+    "cruse_gemm_bf16_tn": ("iiqpqpqiipqip", "i"),
     "cruse_cast_bf16": ("ppqp", "i"),
     "cruse_transpose_bf16": ("pqiqpqip", "i"),
     "cruse_ktile_bf16": ("piiqppp", "i"),
@@ -57,9 +58,10 @@ SIGNATURES = {
     "cruse_gru_seq_fwd_on": ("pppppppiiiiippip", "i"),
     "cruse_gru_seq_bwd_on": ("pppppppiiiiippip", "i"),
     "cruse_gru_seq_fwd_ex": ("ppppppppqiiiiiippip", "i"),
-    "cruse_gru_seq_bwd_ex": ("pppppppiiiiiiippip", "i"),
+    "cruse_gru_seq_bwd_ex": ("pppppppiiiiiiiippip", "i"),
     "cruse_gru_gate_grads": ("pppppqiiip", "i"),
     "cruse_gru_gate_grads_bf16": ("pppppqppqiip", "i"),
+    "cruse_gru_gate_bias_sums": ("pqiippp", "i"),
     "cruse_mask_loss_fwd": ("ppppqiiffpppppp", "i"),
     "cruse_mask_apply": ("pppqiippp", "i"),
     "cruse_mask_apply_bwd": ("pppppqiiipp", "i"),

@@ -48,6 +48,8 @@ struct GruArgs {
     // backward
     const float* dout; const void* coefs; const float* zs; float* dh;
     const float* ans; void* dgi;      // optional (reduce-scatter kernel): a_n rows in, dgi = dh * (c_r, c_z, a_n) rows out
+    int dg_slabs;                     // 3: dgi rows [G][3][Hg]; 4: [G][4][Hg] with slab 3 = dh * c_n (the n gate of dgh): one
+                                      // row-major tensor then feeds dX and both TN weight-gradient GEMMs (gemm_bf16_tn)
     GruPtrs p;
     int B, T, G, Hg, Bg, nchains, P, bg_off;
     unsigned long long* xid;          // XCD-id handshake granules [chain][64]
@@ -1068,7 +1070,7 @@ __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
         }
         const bool want_dgi = a.dgi != nullptr;
         const __amdgpu_buffer_rsrc_t rs_an = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ans), 0, a.ans ? tot_f32 : 0u, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_dgi = __builtin_amdgcn_make_buffer_rsrc(a.dgi, 0, a.dgi ? tot_cf : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_dgi = __builtin_amdgcn_make_buffer_rsrc(a.dgi, 0, a.dgi ? (a.dg_slabs == 4 ? (unsigned)min(nrow * a.G * 4 * Hg * 2, 0xffffffffll) : tot_cf) : 0u, 0x00020000);
         struct OpSet { u32x4 d, z, c0, c1, an; };
         auto issue = [&](int j, OpSet& o) {
             const u32x4 zero = {0u, 0u, 0u, 0u};
@@ -1095,7 +1097,9 @@ __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
         // asked for -- the gate gradients dgi_s = dh_s * (c_r, c_z, a_n) in bf16, the A operand of dX = dgi W_ih: the
         // separate gate-gradient pass then only has to make the time-major copies for the weight-gradient GEMMs, off the
         // main stream.  lane = (clip lc, unit quad lq).
-        const unsigned gi_v = (unsigned)((((long long)(b0 + (lc < nb ? lc : 0)) * a.TS * a.G + grp) * K3 + u0 + 4 * lq) * 2);
+        const int NSL = a.dg_slabs == 4 ? 4 : 3;
+        const unsigned dgrow_bytes = (unsigned)(a.G * NSL * Hg) * 2u;
+        const unsigned gi_v = (unsigned)((((long long)(b0 + (lc < nb ? lc : 0)) * a.TS * a.G + grp) * NSL * Hg + u0 + 4 * lq) * 2);
         auto flush = [&](int j) {
             if (lc >= nb) return;
             const unsigned st = (unsigned)(a.T - 1 - j);
@@ -1114,9 +1118,16 @@ __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
                 for (int e = 0; e < 4; ++e) {
                     o0[e] = (__bf16)(d[e] * (float)cr[e]); o1[e] = (__bf16)(d[e] * (float)cz[e]); o2[e] = (__bf16)(d[e] * an_[e]);
                 }
-                __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o0), rs_dgi, gi_v, st * crow_bytes, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o1), rs_dgi, gi_v + (unsigned)Hg * 2u, st * crow_bytes, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o2), rs_dgi, gi_v + (unsigned)Hg * 4u, st * crow_bytes, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o0), rs_dgi, gi_v, st * dgrow_bytes, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o1), rs_dgi, gi_v + (unsigned)Hg * 2u, st * dgrow_bytes, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o2), rs_dgi, gi_v + (unsigned)Hg * 4u, st * dgrow_bytes, 0);
+                if (NSL == 4) {
+                    const bf16x4_ cn = *reinterpret_cast<const bf16x4_*>(&op_c[slot][lc][64 + 4 * lq]);
+                    bf16x4_ o3;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o3[e] = (__bf16)(d[e] * (float)cn[e]);
+                    __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o3), rs_dgi, gi_v + (unsigned)Hg * 6u, st * dgrow_bytes, 0);
+                }
             }
         };
         OpSet s0, s1;
@@ -1578,6 +1589,26 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* pane
     return rc;
 }
 
+// db_ih[g][(r, z, n_i)] += column sums of slabs 0..2, db_hh[g][(r, z, n_h)] += slabs 0, 1, 3 of the 4-slab gate-gradient
+// rows dg [rows][G][4][Hg] bf16 (written by the backward recurrence): thread = column, a block walks RB rows, f32 sums,
+// one atomic per column and block
+__global__ __launch_bounds__(256) void gate_bias_sums_kernel(const __bf16* dg, long long rows, int G, int Hg, GateBiasPtrs bp) {
+    const int W = G * 4 * Hg;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= W) return;
+    const long long rb = (rows + gridDim.y - 1) / gridDim.y, r0 = (long long)blockIdx.y * rb, r1 = min(rows, r0 + rb);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    long long r = r0;
+    for (; r + 3 < r1; r += 4) {
+        a0 += (float)dg[r * W + c]; a1 += (float)dg[(r + 1) * W + c]; a2 += (float)dg[(r + 2) * W + c]; a3 += (float)dg[(r + 3) * W + c];
+    }
+    for (; r < r1; ++r) a0 += (float)dg[r * W + c];
+    const float sum = (a0 + a1) + (a2 + a3);
+    const int g = c / (4 * Hg), sl = (c / Hg) & 3, j = c % Hg;
+    if (sl < 3 && bp.ih[g]) atomicAdd(bp.ih[g] + sl * Hg + j, sum);
+    if (sl != 2 && bp.hh[g]) atomicAdd(bp.hh[g] + (sl == 3 ? 2 : sl) * Hg + j, sum);
+}
+
 }  // namespace
 
 extern "C" size_t cruse_gru_ws_bytes(int B, int G, int Hg) {
@@ -1629,8 +1660,8 @@ extern "C" int cruse_gru_gate_grads_bf16(const float* dh, const void* coef, cons
                                          long long rows, int G, int Hg, void* stream);
 
 extern "C" int cruse_gru_seq_bwd_ex(const float* dout, const float* const* w_hh, const void* coef, const float* z,
-                                    float* dh, const float* an, void* dgi, int carry, int B, int T, int TS, int G, int Hg,
-                                    int prec, void* panels, unsigned* status, int xcd_rot, void* stream) {
+                                    float* dh, const float* an, void* dgi, int dg_slabs, int carry, int B, int T, int TS, int G,
+                                    int Hg, int prec, void* panels, unsigned* status, int xcd_rot, void* stream) {
     int rc = check_common(B, T, G, Hg, prec, "gru_seq_bwd");
     if (rc) return rc;
     CRUSE_REQUIRE(TS >= T, CRUSE_E_SHAPE, "gru_seq_bwd: clip stride %d frames < %d steps", TS, T);
@@ -1651,8 +1682,11 @@ extern "C" int cruse_gru_seq_bwd_ex(const float* dout, const float* const* w_hh,
                   "gru_seq_bwd: dgi needs the a_n rows and CRUSE_PREC_BF16");
     // the reduce-scatter kernel's loader wave writes dgi itself; the other kernels are followed by the gate-gradient pass
     const bool in_kernel = dgi != nullptr && bwd_rs_eligible(pl.Bg, Hg, prec);
+    CRUSE_REQUIRE(dg_slabs == 3 || (dg_slabs == 4 && (dgi == nullptr || in_kernel)), CRUSE_E_SHAPE,
+                  "gru_seq_bwd: dg_slabs = %d (3, or 4 with the reduce-scatter kernel: bf16, Bg = 8, Hg <= 640)", dg_slabs);
     a.ans = in_kernel ? an : nullptr;
     a.dgi = in_kernel ? dgi : nullptr;
+    a.dg_slabs = dg_slabs;
     rc = run_launches<false>(a, pl, G, Hg, prec, panels, status, xcd_rot, lds, s);
     if (rc || dgi == nullptr || in_kernel) return rc;
     CRUSE_REQUIRE(TS == T, CRUSE_E_SHAPE, "gru_seq_bwd: dgi on a sub-sequence needs the reduce-scatter kernel (bf16, Hg <= 640)");
@@ -1663,7 +1697,7 @@ extern "C" int cruse_gru_seq_bwd_ex(const float* dout, const float* const* w_hh,
 extern "C" int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh, const void* coef, const float* z,
                                     float* dh, const float* an, void* dgi, int B, int T, int G, int Hg, int prec,
                                     void* panels, unsigned* status, int xcd_rot, void* stream) {
-    return cruse_gru_seq_bwd_ex(dout, w_hh, coef, z, dh, an, dgi, 0, B, T, T, G, Hg, prec, panels, status, xcd_rot, stream);
+    return cruse_gru_seq_bwd_ex(dout, w_hh, coef, z, dh, an, dgi, 3, 0, B, T, T, G, Hg, prec, panels, status, xcd_rot, stream);
 }
 
 extern "C" int cruse_gru_seq_bwd(const float* dout, const float* const* w_hh, const void* coef, const float* z,
@@ -1709,5 +1743,17 @@ extern "C" int cruse_gru_gate_grads_bf16(const float* dh, const void* coef, cons
         hipLaunchKernelGGL(gru_gate_grads_bf16_kernel<32>, dim3(nrt, G * (Hg / 32)), dim3(256), 0, s, dh,
                            (const __bf16*)coef, an, (__bf16*)dgi, (__bf16*)dgT, ldT, bp, rows, G, Hg);
     CRUSE_LAUNCH_CHECK("gru_gate_grads_bf16");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_gru_gate_bias_sums(const void* dg4, long long rows, int G, int Hg, float* const* db_ih, float* const* db_hh,
+                                        void* stream) {
+    CRUSE_REQUIRE(rows > 0 && G > 0 && G <= MAXG && Hg > 0 && dg4 != nullptr, CRUSE_E_SHAPE, "gru_gate_bias_sums: bad arguments");
+    GateBiasPtrs bp = {};
+    for (int g = 0; g < G; ++g) { bp.ih[g] = db_ih ? db_ih[g] : nullptr; bp.hh[g] = db_hh ? db_hh[g] : nullptr; }
+    const int W = G * 4 * Hg;
+    int ny = (int)(rows / 128); if (ny < 1) ny = 1; if (ny > 256) ny = 256;
+    hipLaunchKernelGGL(gate_bias_sums_kernel, dim3(cdiv(W, 256), ny), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dg4, rows, G, Hg, bp);
+    CRUSE_LAUNCH_CHECK("gru_gate_bias_sums");
     return CRUSE_OK;
 }

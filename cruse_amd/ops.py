@@ -434,18 +434,19 @@ def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G,
     return h, coef, an, z
 
 
-def dgi_buffer(rows, G, Hg, device):
-    """bf16 [rows, G, 3, Hg] gate-gradient rows, followed by the zero K-padding the dX GEMM may read (K = 3*Hg rounded to 64)."""
-    n = rows * G * 3 * Hg
-    pad = 64 if (3 * Hg) % 64 else 0
+def dgi_buffer(rows, G, Hg, device, slabs=3):
+    """bf16 [rows, G, slabs, Hg] gate-gradient rows (slabs 3: r, z, n_i; 4: + n_h, see cruse_gru_seq_bwd_ex), followed by the
+    zero K-padding the dX GEMM may read (K = 3*Hg rounded to 64; with 4 slabs the run-over lands in the n_h slab)."""
+    n = rows * G * slabs * Hg
+    pad = 64 if ((3 * Hg) % 64 and slabs == 3) else 0
     buf = torch.empty(n + pad, device=device, dtype=torch.bfloat16)
     if pad:
         buf[n:].zero_()
-    return buf[:n].view(rows, G, 3, Hg)
+    return buf[:n].view(rows, G, slabs, Hg)
 
 
 def gru_seq_bwd(dout, w_hh: List[torch.Tensor], coef, z, B, T, G, Hg, prec, slot=0, xcd_rot=0, an=None, want_dgi=False,
-                out=None, chunk=None):
+                out=None, chunk=None, dg_slabs=3):
     """dout [B,T,H] -> dh [B,T,H] (total gradient reaching every h_t).  want_dgi (CRUSE_PREC_BF16, with the a_n rows):
     -> (dh, dgi) with dgi = dh * (c_r, c_z, a_n) in bf16 written by the recurrence itself (cruse_gru_seq_bwd_on).
     chunk = (t0, n): only frames [t0, t0+n), into out = dh (or (dh, dgi)); chunks are run from the LAST to the first, and
@@ -457,7 +458,7 @@ def gru_seq_bwd(dout, w_hh: List[torch.Tensor], coef, z, B, T, G, Hg, prec, slot
     else:
         dh = torch.empty_like(dout)
         if want_dgi:
-            dgi = dgi_buffer(B * T, G, Hg, dout.device)
+            dgi = dgi_buffer(B * T, G, Hg, dout.device, dg_slabs)
     if want_dgi and (an is None or prec_code(prec) != PREC_BF16):
         raise RuntimeError("gru_seq_bwd: want_dgi needs the a_n rows and the bf16 mode")
     t0, n = chunk if chunk is not None else (0, T)
@@ -470,9 +471,24 @@ def gru_seq_bwd(dout, w_hh: List[torch.Tensor], coef, z, B, T, G, Hg, prec, slot
     _p(dout); _p(coef); _p(z); _p(dh); _p(an); _p(dgi)
     check(lib.cruse_gru_seq_bwd_ex(_off(dout, t0 * H), ctypes.cast(wa, ctypes.c_void_p), _off(coef, t0 * 3 * H), _off(z, t0 * H),
                                    _off(dh, t0 * H), _off(an, t0 * H) if want_dgi else None,
-                                   None if dgi is None else _off(dgi, t0 * 3 * H), carry, B, steps, T, G, Hg, prec_code(prec),
+                                   None if dgi is None else _off(dgi, t0 * dg_slabs * H), dg_slabs, carry, B, steps, T, G, Hg, prec_code(prec),
                                    panels, status, xcd_rot, _stream()))
     return (dh, dgi) if want_dgi else dh
+
+
+def gemm_bf16_tn(M, N, K, A, a_off, lda, B, b_off, ldb, C, c_off, ldc, b_shift_T=0, splitk=0):
+    """C[M,N] += sum_k A[k, a_off + m] * B[k, b_off + n] (cruse_gemm_bf16_tn): A bf16 rows, B bf16 or f32 rows (f32: read one
+    frame back when b_shift_T > 0 -- the h_{t-1} operand), C f32 holding the running sum."""
+    if A.dtype != torch.bfloat16 or B.dtype not in (torch.bfloat16, torch.float32) or C.dtype != torch.float32:
+        raise RuntimeError("gemm_bf16_tn: A bf16, B bf16 / f32, C f32")
+    _p(A); _p(B); _p(C)
+    check(lib.cruse_gemm_bf16_tn(M, N, K, _off(A, a_off), lda, _off(B, b_off), ldb, 1 if B.dtype == torch.float32 else 0, b_shift_T,
+                                 _off(C, c_off), ldc, splitk, _stream()))
+
+
+def gru_gate_bias_sums(dg4, rows, G, Hg, db_ih, db_hh):
+    check(lib.cruse_gru_gate_bias_sums(_p(dg4), rows, G, Hg, ctypes.cast(_ptr_array(db_ih), ctypes.c_void_p),
+                                       ctypes.cast(_ptr_array(db_hh), ctypes.c_void_p), _stream()))
 
 
 def gru_gate_grads(dh, coef, an, rows, G, Hg, prec):

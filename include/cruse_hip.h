@@ -205,6 +205,14 @@ int cruse_gemm(int transA, int transB, int M, int N, int K,
 int cruse_gemm_bf16_nt(int M, int N, int K, const void* A, long long lda, long long a_kstride,
                        const void* B, long long ldb, long long b_kstride,
                        float* C, long long ldc, const float* bias, int accumulate, int splitk, void* stream);
+/* TN form for the weight gradients of the gate projections (dW_ih += dgi^T x, dW_hh += dgh^T h_{t-1}; nn.GRU backward at
+ * model/cruse_net.py:44,50): C[M,N] += sum_k A[k*lda + m] * B[k*ldb + n] over the K = B*T frames, with A (bf16 gate-gradient
+ * rows) and B (bf16 layer-input rows, or f32 hidden-state rows when b_is_f32) ROW-MAJOR as the backward recurrence / the
+ * forward pass left them -- no time-major copies.  b_shift_T > 0: row k of B is read from row k-1 and is zero when
+ * k % b_shift_T == 0 (the h_{t-1} operand).  M, N multiples of 8.  splitk <= 0: chosen by the library; k-slices are
+ * pinned to XCDs and added atomically (C must hold the running sum / zeros). */
+int cruse_gemm_bf16_tn(int M, int N, long long K, const void* A, long long lda, const void* B, long long ldb,
+                       int b_is_f32, int b_shift_T, float* C, long long ldc, int splitk, void* stream);
 /* y[i] = bf16(x[i]), n % 4 == 0 */
 int cruse_cast_bf16(const float* x, void* y, long long n, void* stream);
 /* K-tiling without transposition: y[(k/64)*rows*64 + n*64 + k%64] = bf16(x[n*ld + k]), zero for cols <= k < ceil64(cols):
@@ -270,14 +278,17 @@ int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh, const void
  *   _bwd_ex: carry != 0: the first iteration takes dh of the run's LAST frame from the dh buffer (written by the run that
  *            follows it in time) instead of forming it from dout: chunk [t0, t0+n) of a longer sequence is run as the
  *            n + 1 frames [t0, t0+n] with carry = 1 (the last chunk: n frames, carry = 0).  dgi on a sub-sequence is
- *            supported by the reduce-scatter kernel only (CRUSE_PREC_BF16, Hg <= 640). */
+ *            supported by the reduce-scatter kernel only (CRUSE_PREC_BF16, Hg <= 640).
+ *            dg_slabs: 3 = dgi rows [G][3][Hg] (r, z, n_i); 4 = [G][4][Hg] with slab 3 = dh * c_n, the n gate of
+ *            dgh = dh * (c_r, c_z, c_n) (reduce-scatter kernel): one row-major tensor that is the A operand of
+ *            dX = dgi W_ih (K = 3*Hg of every 4*Hg) and of both weight-gradient products of cruse_gemm_bf16_tn. */
 int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, const float* const* b_hh,
                          float* h, void* coef, float* an, float* z, const float* h0, long long h0_bstride,
                          int B, int T, int TS, int G, int Hg, int prec, void* panels, unsigned* status, int xcd_rot,
                          void* stream);
 int cruse_gru_seq_bwd_ex(const float* dout, const float* const* w_hh, const void* coef, const float* z,
-                         float* dh, const float* an, void* dgi, int carry, int B, int T, int TS, int G, int Hg,
-                         int prec, void* panels, unsigned* status, int xcd_rot, void* stream);
+                         float* dh, const float* an, void* dgi, int dg_slabs, int carry, int B, int T, int TS, int G,
+                         int Hg, int prec, void* panels, unsigned* status, int xcd_rot, void* stream);
 /* dgi = dh*(c_r,c_z,a_n) (gradient wrt gi), dgh = dh*(c_r,c_z,c_n) (gradient wrt W_hh h + b_hh), both
  * [rows,G,3*Hg]; dW_ih, dW_hh, dX and the bias gradients follow from cruse_gemm / cruse_col_sum. */
 int cruse_gru_gate_grads(const float* dh, const void* coef, const float* an, float* dgi, float* dgh,
@@ -290,6 +301,10 @@ int cruse_gru_gate_grads(const float* dh, const void* coef, const float* an, flo
 int cruse_gru_gate_grads_bf16(const float* dh, const void* coef, const float* an, void* dgi, void* dgT,
                               long long ldT, float* const* db_ih, float* const* db_hh,
                               long long rows, int G, int Hg, void* stream);
+/* bias gradients from the 4-slab gate-gradient rows dg4 [rows][G][4][Hg] bf16 of cruse_gru_seq_bwd_ex(dg_slabs = 4):
+ * db_ih[g][3*Hg] += column sums of slabs (r, z, n_i), db_hh[g][3*Hg] += (r, z, n_h).  HOST arrays of G device pointers. */
+int cruse_gru_gate_bias_sums(const void* dg4, long long rows, int G, int Hg, float* const* db_ih, float* const* db_hh,
+                             void* stream);
 
 /* ---- mask application + weighted spectral loss ------------------------------- */
 
