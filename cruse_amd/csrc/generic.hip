@@ -373,7 +373,8 @@ __global__ __launch_bounds__(256) void bn_nchw_stats_kernel(const T* x, int N, i
     }
 }
 
-// y = act(gamma * (x - mean) * rstd + beta); mean == NULL: no normalisation (plain activation of x)
+// y = act(gamma * (x - mean) * rstd + beta); mean == NULL: no normalisation (plain activation of x); act 0 none, 1 ReLU,
+// 2 PReLU(slope[c]), 3 sigmoid
 template <typename T>
 __global__ void bn_nchw_fwd_kernel(const T* x, const float* mean, const float* rstd, const float* gamma,
                                    const float* beta, const float* slope, int act, long long total, int C, int HW, T* y) {
@@ -383,6 +384,7 @@ __global__ void bn_nchw_fwd_kernel(const T* x, const float* mean, const float* r
         if (mean) z = (z - mean[c]) * rstd[c] * gamma[c] + beta[c];
         if (act == 1) z = fmaxf(z, 0.f);
         else if (act == 2) z = z >= 0.f ? z : slope[c] * z;
+        else if (act == 3) z = 1.f / (1.f + expf(-z));
         y[i] = (T)z;
     }
 }
@@ -409,6 +411,7 @@ __global__ __launch_bounds__(256) void bn_nchw_bwd_reduce_kernel(const T* dy, co
             float d = (float)dy[o + i];
             if (act == 1) d = z > 0.f ? d : 0.f;
             else if (act == 2) { if (z < 0.f) { a3 += d * z; d *= sl; } }
+            else if (act == 3) { const float sg = 1.f / (1.f + expf(-z)); d *= sg * (1.f - sg); }
             a1 += d; a2 += d * xh;
         }
         s1 += a1; s2 += a2; s3 += a3;
@@ -437,6 +440,7 @@ __global__ void bn_nchw_bwd_apply_kernel(const T* dy, const T* x, const float* m
         float d = (float)dy[i];
         if (act == 1) d = z > 0.f ? d : 0.f;
         else if (act == 2) d = z >= 0.f ? d : slope[c] * d;
+        else if (act == 3) { const float sg = 1.f / (1.f + expf(-z)); d *= sg * (1.f - sg); }
         if (mean) {
             if (training) d -= (float)(r[c] * inv_count) + xh * (float)(r[C + c] * inv_count);
             d *= ga * rs;
@@ -635,7 +639,7 @@ extern "C" int cruse_bn_nchw_stats(const void* x, int N, int C, int HW, double* 
 
 extern "C" int cruse_bn_nchw_fwd(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                                  const float* slope, int act, int N, int C, int HW, void* y, int dtype, void* stream) {
-    CRUSE_REQUIRE(N > 0 && C > 0 && HW > 0 && act >= 0 && act <= 2 && (act != 2 || slope), CRUSE_E_SHAPE, "bn_nchw_fwd: bad arguments");
+    CRUSE_REQUIRE(N > 0 && C > 0 && HW > 0 && act >= 0 && act <= 3 && (act != 2 || slope), CRUSE_E_SHAPE, "bn_nchw_fwd: bad arguments");
     CRUSE_REQUIRE((mean == nullptr) == (rstd == nullptr) && (mean == nullptr || (gamma && beta)), CRUSE_E_SHAPE, "bn_nchw_fwd: statistics");
     CRUSE_DT_CHECK("bn_nchw_fwd");
     const long long total = (long long)N * C * HW;
@@ -652,7 +656,7 @@ extern "C" int cruse_bn_nchw_fwd(const void* x, const float* mean, const float* 
 extern "C" int cruse_bn_nchw_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                                  const float* beta, const float* slope, int act, int training, int N, int C, int HW,
                                  double* scratch, void* dx, float* dgamma, float* dbeta, float* dslope, int dtype, void* stream) {
-    CRUSE_REQUIRE(N > 0 && C > 0 && HW > 0 && act >= 0 && act <= 2 && (act != 2 || slope), CRUSE_E_SHAPE, "bn_nchw_bwd: bad arguments");
+    CRUSE_REQUIRE(N > 0 && C > 0 && HW > 0 && act >= 0 && act <= 3 && (act != 2 || slope), CRUSE_E_SHAPE, "bn_nchw_bwd: bad arguments");
     CRUSE_DT_CHECK("bn_nchw_bwd");
     { int rc = cruse_zero_async(scratch, 3 * (size_t)C * sizeof(double), ST(stream), "bn_nchw_bwd"); if (rc) return rc; }
     if (dtype == CRUSE_DT_F16)

@@ -198,7 +198,9 @@ def _act_code(m) -> Tuple[int, Optional[torch.Tensor]]:
         return 1, None
     if isinstance(m, nn.PReLU):
         return 2, m.weight
-    raise RuntimeError(f"HipSequential: activation {type(m).__name__} has no HIP kernel (ReLU, PReLU)")
+    if isinstance(m, nn.Sigmoid):
+        return 3, None
+    raise RuntimeError(f"HipSequential: activation {type(m).__name__} has no HIP kernel (ReLU, PReLU, Sigmoid)")
 
 
 def batchnorm_act(x, bn: Optional[nn.BatchNorm2d], act_module=None):
@@ -311,13 +313,13 @@ def run_sequential(mods: Sequence[nn.Module], x: torch.Tensor) -> torch.Tensor:
             i += 1
         elif isinstance(m, nn.BatchNorm2d):
             nxt = mods[i + 1] if i + 1 < len(mods) else None
-            if isinstance(nxt, (nn.ReLU, nn.PReLU)):
+            if isinstance(nxt, (nn.ReLU, nn.PReLU, nn.Sigmoid)):
                 x = batchnorm_act(x, m, nxt)
                 i += 2
             else:
                 x = batchnorm_act(x, m, None)
                 i += 1
-        elif isinstance(m, (nn.ReLU, nn.PReLU)):
+        elif isinstance(m, (nn.ReLU, nn.PReLU, nn.Sigmoid)):
             x = batchnorm_act(x, None, m)
             i += 1
         elif isinstance(m, nn.Identity):

@@ -384,7 +384,7 @@ int cruse_conv2d_nchw_wgrad(const void* S, const void* Bg, float* dw,
 int cruse_nchw_channel_sum(const void* x, int N, int C, int HW, float* out, int dtype, void* stream);
 /* gradient of the nearest FreqUpsample: dx[..,w] = sum_{j<up} dxu[.., w*up + j] */
 int cruse_downsum_w(const void* dxu, long long rows, int W, int up, void* dx, int dtype, void* stream);
-/* nn.BatchNorm2d (+ nn.ReLU / nn.PReLU(C)) on [N,C,HW]: batch sums for cruse_bn_finalize; y = act(gamma*(x-mean)*rstd+beta)
+/* nn.BatchNorm2d (+ nn.ReLU / nn.PReLU(C) / nn.Sigmoid: act 1 / 2 / 3) on [N,C,HW]: batch sums for cruse_bn_finalize; y = act(gamma*(x-mean)*rstd+beta)
  * (mean == NULL: activation only); backward with the PReLU slope gradient.  scratch: 3*C doubles. */
 int cruse_bn_nchw_stats(const void* x, int N, int C, int HW, double* sums, int dtype, void* stream);
 int cruse_bn_nchw_fwd(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,

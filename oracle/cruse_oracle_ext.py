@@ -11,6 +11,7 @@ inputs/outputs as tests/golden/g1x_*.npz.  Where a repair is a decision rather t
 from __future__ import annotations
 
 import math
+import sys
 from collections import OrderedDict
 from typing import List, Optional, Tuple
 
@@ -228,6 +229,41 @@ def convkxf(in_ch, out_ch, k=1, f=3, fstride=2, lookahead=0, batch_norm=False, a
         modules.append(("norm", nn.BatchNorm2d(out_ch)))
     modules.append(("act", act))
     return nn.Sequential(OrderedDict(modules))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# 8f.2: the "Upsample" decoder variant named by model/cruse.py:14
+# ----------------------------------------------------------------------------------------------------------------------
+class CRUSE4MagAddSkipUpsample(nn.Module):
+    """model/cruse.py:14 is `class CRUSE4MagAddSkipUpsample(nn.Module): pass` -- nothing to restate, so this is a DECISION
+    (parity UNPINNED by reference output for the composition; every BLOCK is the reference's own and pinned: G11 / G3):
+    the unet_2 topology (model/cruse_net.py:129-165, repairs R2-R8: 4 levels, additive conv skips, GGRU bottleneck, sigmoid
+    mask) built from the reference's working blocks -- cust_conv.Conv2dNormAct (2,3)/fstride 2 encoder (:15-62) and
+    cust_conv.convkxf(mode="upsample") decoder (nearest FreqUpsample + Conv2d (1,3), :114-184) -- as the class name says."""
+
+    def __init__(self, in_feat=161, ch=(1, 8, 16, 32, 64), rnn_groups=1, blocks=None, ggru=None):
+        super().__init__()
+        B = blocks if blocks is not None else sys.modules[__name__]          # (the fixture script passes the reference's cust_conv)
+        ggru = ggru if ggru is not None else O.GGRU
+        self.laynum = len(ch) - 1
+        hidden = in_feat // 2 ** self.laynum * ch[-1]
+        for k in range(1, self.laynum + 1):
+            setattr(self, f"enc{k}", B.Conv2dNormAct(ch[k - 1], ch[k], (2, 3), fstride=2))
+            setattr(self, f"skip_connect_{k}", nn.Conv2d(ch[k], ch[k], (1, 3), padding=(0, 1), bias=False))
+            last = k == 1
+            setattr(self, f"dec{k}", B.convkxf(ch[k], ch[k - 1], k=1, f=3, fstride=2, batch_norm=not last,
+                                               act=nn.Sigmoid() if last else nn.ReLU(), mode="upsample", depthwise=False))
+        self.gru = ggru(hidden_size=hidden, groups=rnn_groups)
+
+    def forward(self, x):
+        e, skips = x, []
+        for k in range(1, self.laynum + 1):
+            e = getattr(self, f"enc{k}")(e)
+            skips.append(getattr(self, f"skip_connect_{k}")(e))
+        d = self.gru(e) + skips[-1]
+        for k in range(self.laynum, 1, -1):
+            d = getattr(self, f"dec{k}")(d) + skips[k - 2]
+        return self.dec1(d)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -224,6 +224,42 @@ def test_freq_upsample_standalone(golden):
     assert torch.equal(y.cpu(), torch.from_numpy(g["upsample/y"]))
 
 
+@pytest.mark.parametrize("grp", [1, 4])
+def test_cruse4_mag_add_skip_upsample_model(golden, grp):
+    """model.cruse.CRUSE4MagAddSkipUpsample (model/cruse.py:14): encoder Conv2dNormAct + additive conv skips +
+    GGRU + the nearest-upsample decoder convkxf(mode="upsample"), against fixture G21 (the composition run on the
+    reference's own blocks) -- mask in train and eval mode, every parameter-gradient norm -- and oracle autograd; then the
+    bench clip length."""
+    from model.cruse import CRUSE4MagAddSkipUpsample
+    from oracle import cruse_oracle_ext as X
+    g = golden("g21_cruse_upsample.npz")
+    o = X.CRUSE4MagAddSkipUpsample(rnn_groups=grp)
+    p = _load_like(CRUSE4MagAddSkipUpsample(rnn_groups=grp, precision="f32"), o)
+    assert list(p.state_dict().keys()) == list(o.state_dict().keys())
+    x, w = torch.from_numpy(g["x"]), torch.from_numpy(g["w"])
+    o.train(); p.train()
+    y = p(x.cuda())
+    assert rel_l2(y, torch.from_numpy(g[f"g{grp}/mask_train"])) < 1e-5
+    (y * w.cuda()).sum().backward()
+    for n, q in p.named_parameters():
+        want = float(g[f"g{grp}/gn/{n}"])
+        if want < 1e-6 or (n.startswith("enc") and n.endswith(".1.bias")):
+            continue                                                   # conv biases in front of a BatchNorm: exactly 0 (rounding noise)
+        assert abs(float(q.grad.norm()) - want) <= 2e-3 * want + 1e-7, (n, float(q.grad.norm()), want)
+    p.eval()
+    with torch.no_grad():
+        assert rel_l2(p(x.cuda()), torch.from_numpy(g[f"g{grp}/mask_eval"])) < 1e-5
+    p.train()
+    p.zero_grad(set_to_none=True)
+    _grad_check(p, o, x, tol=1e-3, wtol=5e-3)
+    with pytest.raises(RuntimeError, match="expects"):
+        p(torch.rand(2, 1, 11, 161).cuda())
+    # bench clip length, bf16 bottleneck: runs, mask in (0, 1)
+    big = CRUSE4MagAddSkipUpsample(rnn_groups=grp, precision="bf16").cuda()
+    m = big(torch.rand(8, 1, 401, 160).cuda())
+    assert m.shape == (8, 1, 401, 160) and float(m.min()) > 0.0 and float(m.max()) < 1.0
+
+
 # ---------------------------------------------------------------------------------------------------------------- a10
 @pytest.mark.parametrize("name,kw", [("g2_l2", dict(num_layers=2, groups=2)), ("g4_l3_add", dict(num_layers=3, groups=4, add_outputs=True)),
                                      ("g2_noshuffle", dict(num_layers=2, groups=2, shuffle=False))])

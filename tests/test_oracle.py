@@ -222,3 +222,10 @@ def test_oracle_round3_fixtures(golden):
         noisy, c, n = X.snr_mix(s["clean"][b].copy(), s["noise"][b].copy(), float(s["snr"][b]), rir=s["rir"][b].copy(),
                                 rir_noise=s["rir_noise"][b].copy())
         assert np.allclose(noisy, s["noisy"][b], rtol=0, atol=1e-6) and np.allclose(c, s["clean_n"][b], rtol=0, atol=1e-6)
+    # G21: the CRUSE4MagAddSkipUpsample composition on the oracle's own restated blocks == on the reference's blocks
+    g = golden("g21_cruse_upsample.npz")
+    for grp in (1, 4):
+        m = X.CRUSE4MagAddSkipUpsample(rnn_groups=grp)
+        O.closed_form_init(m)
+        m.train()
+        assert torch.equal(m(torch.from_numpy(g["x"])), torch.from_numpy(g[f"g{grp}/mask_train"]))
