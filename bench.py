@@ -163,15 +163,14 @@ class KernelTimer:
              "ktile_bf16", "transpose_bf16",
              "gru_seq_fwd", "gru_seq_bwd", "gru_gate_grads", "gru_gate_grads_bf16", "mask_loss"]
 
-    def __init__(self, ops):
-        self.ops, self.rec, self.saved = ops, [], {}
+    def __init__(self, ops, eng):
+        self.ops, self.rec, self.saved, self.eng = ops, [], {}, eng
 
     def __enter__(self):
-        from cruse_amd.model import cruse_net
         # leaves run inline for this pass: an event pair around a launch only times that kernel when
         # nothing else shares the device with it
-        self.side, self.side_was = cruse_net.SIDE, cruse_net.SIDE.enabled
-        cruse_net.SIDE.enabled = False
+        self.side, self.side_was = self.eng.side, self.eng.side.enabled
+        self.eng.side.enabled = False
         for n in self.NAMES:
             f = getattr(self.ops, n)
             self.saved[n] = f
@@ -405,8 +404,11 @@ def main():
         log("parity figure: this model vs the CPU oracle at T=401, B=8 ...")
         parity = parity_figure(model, a.groups, a.prec)
         log(f"parity_rel_l2 = {parity:.3e}")
+    # the measured-best defaults unless CRUSE_* variables ask for an A/B variant (EngineConfig.from_env: bench / tools only)
+    from cruse_amd.config import EngineConfig
+    cfg = EngineConfig.from_env()
     eng = TrainEngine(model, lr=1e-3, use_graph=not a.no_graph, bucketed=True if a.bucketed else None,
-                      loss="wo_male_df" if a.df else "wo_male")
+                      loss="wo_male_df" if a.df else "wo_male", config=cfg)
     B, L = a.batch, int(a.seconds * 16000)
     T = 1 + L // 160
     pool = [synth_batch(B, L, dev, 1234 + 1000 * rank + s) for s in range(4)]
@@ -472,7 +474,7 @@ def main():
 
     roof, breakdown = None, None
     if rank == 0 and not a.no_kernel_timing:
-        with KernelTimer(ops) as kt:
+        with KernelTimer(ops, eng) as kt:
             eng._fwd_bwd(*pool[0])                       # un-graphed warm-up: allocator and attribute caches
             torch.cuda.synchronize()
             kt.rec.clear()
@@ -530,7 +532,7 @@ def main():
                                   "audioAug.py:191); a literal 20 ms hop = win violates NOLA, so no iSTFT / training step exists for "
                                   "it -- its forward STFT is the secondary row stft_hop320_forward (SURVEY 8d)",
                        "global_batch": world * B, "per_gpu_batch": B, "frames_per_clip": T,
-                       "parallelism": f"dp{world}", "hip_graph": bool(eng.use_graph), "launch_form_timing": launch_choice, "bucketed_allreduce": bool(eng.bucketed)},
+                       "parallelism": f"dp{world}", "engine_config_non_default": cfg.non_default(), "hip_graph": bool(eng.use_graph), "launch_form_timing": launch_choice, "bucketed_allreduce": bool(eng.bucketed)},
             "ms_per_step_median": round(med_ms, 3),
             "ms_per_step_p90_max": [round(step_ms[min(len(step_ms) - 1, int(0.9 * len(step_ms)))], 3), round(step_ms[-1], 3)],
             "value_at_median_step": round(world * B * T / (med_ms * 1e-3), 1),

@@ -13,7 +13,7 @@ HEADER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include
 def _code(tp: str) -> str:
     tp = tp.strip()
     if "*" in tp:
-        return "p"
+        return "c" if tp.replace("const", "").replace(" ", "") == "char*" else "p"
     base = tp.replace("const", "").strip()
     return {"int": "i", "unsigned": "i", "float": "f", "long long": "q", "size_t": "z", "double": "d", "void": ""}[base]
 
@@ -30,7 +30,7 @@ def parse_header(path: str = HEADER):
                 a = a.strip()
                 tp = a if a.endswith("*") else a.rsplit(" ", 1)[0] + ("*" if "*" in a.rsplit(" ", 1)[1] else "")
                 if "*" in a:
-                    tp = "void*"
+                    tp = "char*" if a.replace("const", "").strip().startswith("char") else "void*"
                 codes += _code(tp)
         r = "s" if ("char" in ret and "*" in ret) else _code(ret)
         out[name] = (codes, r)

@@ -17,13 +17,15 @@ PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16 = 0, 1, 2, 3
 PREC_BY_NAME = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "f16": PREC_F16}
 DT_F32, DT_F16 = 0, 1
 
-_T = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "q": ctypes.c_longlong, "d": ctypes.c_double,
+_T = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "q": ctypes.c_longlong, "d": ctypes.c_double, "c": ctypes.c_char_p,
       "z": ctypes.c_size_t}
 
 # name -> (argument type string, restype); mirrors include/cruse_hip.h one to one
 SIGNATURES = {
     "cruse_abi_version": ("", "i"),
     "cruse_last_error": ("", "s"),
+    "cruse_set_option": ("cii", "i"),
+    "cruse_get_option": ("cpp", "i"),
     "cruse_stft_fwd": ("piiiipppifp", "i"),
     "cruse_istft_fwd": ("ppiiiiipp", "i"),
     "cruse_istft_bwd": ("piiiiippp", "i"),

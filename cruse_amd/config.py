@@ -1,0 +1,92 @@
+"""Scheduling / numerics options of the training step as ONE explicit object.
+
+`EngineConfig()` is the measured-best configuration (what bench.py runs); nothing in the package reads environment variables
+at import or in the step.  `TrainEngine(model, config=EngineConfig(...))` takes its own copy, so two engines in one process do
+not share option or side-stream state.  `EngineConfig.from_env()` -- called by bench.py and tools/*_probe.py only -- builds a
+config from the CRUSE_* variables the A/B measurements of DESIGN.md section 6 were taken with.
+
+Options that measured slower and are gone (DESIGN.md section 6 keeps the figures): half-batch pipelines through the GGRU
+block (CRUSE_GRU_PIPES, 7.55 vs 6.94 ms), several side streams / lane maps (CRUSE_SIDE_STREAMS, CRUSE_SIDE_MAP: 6.43 vs 6.05
+eager), joining the leaves on the main stream at an eager bucket boundary (CRUSE_EAGER_BOUNDARY=join).
+"""
+from __future__ import annotations
+
+import contextlib
+import os
+from dataclasses import dataclass, field, fields, replace
+from typing import Dict, Optional
+
+
+@dataclass
+class EngineConfig:
+    overlap: bool = True            # leaf kernels (weight gradients, skip convs, dW GEMMs, clean STFT) on a side stream
+    defer_mask: int = 15            # leaves queued for the next recurrence launch: 1 skip convs (fwd), 2 decoder weight gradients,
+                                    # 4 GRU weight gradients, 8 skip-conv backward leaves
+    inline_mask: int = 8            # backward leaves kept on the main stream: 1 skip dgrads, 2 skip wgrads, 4 decoder wgrads,
+                                    # 8 / 16 the level-1 / level-2 encoder wgrads (8: -0.025 ms; the others measured slower)
+    early_t: int = 2                # dW operand transposes: 0 inside each layer's leaf, 1 layer 1's beside the first backward
+                                    # recurrence, 2 all four in the forward pass (6.08 vs 6.12 ms)
+    fuse_bn_stats: bool = True      # BatchNorm batch sums in the producing conv's epilogue (False: separate bn_stats pass)
+    fuse_dgi: bool = False          # the backward recurrence writes the bf16 gate gradients itself (measured neutral)
+    fuse_cast: bool = True          # the gate GEMMs' bf16 operand copies written by the producing BatchNorm / LayerNorm kernel
+    gi_x3: Optional[int] = None     # forward gate projections: bit 0 / 1 = W_ih low-plane pass on layer 1 / 2, bit 2 = also split x
+                                    # (None: 7 for Hg <= 320, else 3)
+    dw_xcdk: Optional[int] = None   # k-slices of the dW GEMMs pinned to XCDs (None: 8 where there are >= 24 output tiles, else 0)
+    conv_bwd_x3: bool = False       # backward-data convolutions as split-bf16 x3 instead of plain bf16
+    dw_tn: bool = False             # weight gradients as TN GEMMs on row-major operands (measured slower: 6.35 vs 6.02 ms)
+    lib_options: Dict[str, int] = field(default_factory=dict)       # cruse_set_option(name, value) while this config is active
+
+    _ENV = {"overlap": ("CRUSE_OVERLAP", lambda v: v == "1"), "defer_mask": ("CRUSE_DEFER", int), "inline_mask": ("CRUSE_INLINE", int),
+            "early_t": ("CRUSE_EARLY_T", int), "fuse_bn_stats": ("CRUSE_FUSE_BN_STATS", lambda v: v != "0"),
+            "fuse_dgi": ("CRUSE_FUSE_DGI", lambda v: v == "1"), "fuse_cast": ("CRUSE_FUSE_CAST", lambda v: v == "1"),
+            "gi_x3": ("CRUSE_GI_X3", int), "dw_xcdk": ("CRUSE_DW_XCDK", int), "conv_bwd_x3": ("CRUSE_CONV_BWD_X3", lambda v: v == "1"),
+            "dw_tn": ("CRUSE_DW_TN", lambda v: v == "1")}
+    _LIB_ENV = {"CRUSE_GRU_BWD_RS": "gru_bwd_rs", "CRUSE_GRU_FWD_LEAN": "gru_fwd_lean", "CRUSE_GRU_WLO": "gru_wlo",
+                "CRUSE_GRU_DBG": "gru_dbg", "CRUSE_GRU_BG": "gru_bg", "CRUSE_CM_GRID": "cm_grid", "CRUSE_CM_NW": "cm_nw",
+                "CRUSE_GB_DEEP_MIN": "gb_deep_min", "CRUSE_GB_DEEP": "gb_deep", "CRUSE_PW_VALU": "pw_valu", "CRUSE_LNB_GRID": "lnb_grid",
+                "CRUSE_WG_TFW": "wg_tfw", "CRUSE_WG_GRID": "wg_grid", "CRUSE_WG_DBG": "wg_dbg"}
+
+    @classmethod
+    def from_env(cls, env=None) -> "EngineConfig":
+        """bench.py / tools only: the CRUSE_* variables of the A/B measurements -> an explicit config."""
+        env = os.environ if env is None else env
+        kw = {}
+        for name, (var, conv) in cls._ENV.items():
+            if var in env:
+                kw[name] = conv(env[var])
+        lib = {opt: int(env[var]) for var, opt in cls._LIB_ENV.items() if var in env}
+        return cls(lib_options=lib, **kw)
+
+    def non_default(self) -> dict:
+        d = EngineConfig()
+        return {f.name: getattr(self, f.name) for f in fields(self) if getattr(self, f.name) != getattr(d, f.name)}
+
+    def copy(self, **kw) -> "EngineConfig":
+        return replace(self, lib_options=dict(self.lib_options), **kw)
+
+
+_ACTIVE = EngineConfig()
+
+
+def get() -> EngineConfig:
+    """the configuration of the step being issued (the engine's own inside TrainEngine calls, the default outside)."""
+    return _ACTIVE
+
+
+@contextlib.contextmanager
+def use(cfg: EngineConfig):
+    """make cfg the active configuration (and its library options) for the duration of the block; one Python thread drives a
+    GPU, so this is plain save / restore."""
+    global _ACTIVE
+    from . import ops
+    prev = _ACTIVE
+    saved = {k: ops.get_option(k) for k in cfg.lib_options}
+    _ACTIVE = cfg
+    for k, v in cfg.lib_options.items():
+        ops.set_option(k, v)
+    try:
+        yield cfg
+    finally:
+        _ACTIVE = prev
+        for k, v in saved.items():
+            ops.set_option(k, v)

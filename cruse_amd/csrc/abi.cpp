@@ -18,6 +18,44 @@ extern "C" void cruse_set_error(const char* fmt, ...) {
 extern "C" const char* cruse_last_error(void) { return g_err; }
 extern "C" int cruse_abi_version(void) { return CRUSE_ABI_VERSION; }
 
+// ---- library options: explicit, set by the HOST through the C ABI (the library reads no environment variables) ---------
+// name -> value; unset options take the default the call site passes to cruse_opt().
+#include <atomic>
+#include <limits.h>
+#include <string.h>
+namespace {
+const char* const OPT_NAMES[] = {"gru_bwd_rs", "gru_fwd_lean", "gru_wlo", "gru_dbg", "gru_bg", "cm_grid", "cm_nw", "gb_deep_min", "gb_deep",
+                                 "pw_valu", "lnb_grid", "wg_tfw", "wg_grid", "wg_dbg"};
+constexpr int N_OPT = sizeof(OPT_NAMES) / sizeof(OPT_NAMES[0]);
+std::atomic<int> g_opt[N_OPT];
+struct OptInit { OptInit() { for (auto& o : g_opt) o.store(INT_MIN); } } g_opt_init;
+int opt_index(const char* name) {
+    for (int i = 0; i < N_OPT; ++i)
+        if (name && strcmp(name, OPT_NAMES[i]) == 0) return i;
+    return -1;
+}
+}  // namespace
+int cruse_opt(const char* name, int dflt) {
+    const int i = opt_index(name);
+    if (i < 0) return dflt;
+    const int v = g_opt[i].load(std::memory_order_relaxed);
+    return v == INT_MIN ? dflt : v;
+}
+extern "C" int cruse_set_option(const char* name, int value, int unset) {
+    const int i = opt_index(name);
+    if (i < 0) { cruse_set_error("set_option: unknown option '%s'", name ? name : "(null)"); return CRUSE_E_SHAPE; }
+    g_opt[i].store(unset ? INT_MIN : value);
+    return CRUSE_OK;
+}
+extern "C" int cruse_get_option(const char* name, int* value, int* is_set) {
+    const int i = opt_index(name);
+    if (i < 0 || !value || !is_set) { cruse_set_error("get_option: unknown option '%s'", name ? name : "(null)"); return CRUSE_E_SHAPE; }
+    const int v = g_opt[i].load();
+    *is_set = v != INT_MIN;
+    *value = v == INT_MIN ? 0 : v;
+    return CRUSE_OK;
+}
+
 extern "C" void cruse_set_error(const char* fmt, ...);
 
 int cruse_ensure_dyn_lds(const void* fn, size_t bytes, const char* name) {

@@ -42,6 +42,9 @@ int cruse_ensure_dyn_lds(const void* fn, size_t bytes, const char* name);
 // inside a captured hipGraph, memset nodes were observed to race with the neighbouring kernel nodes).
 int cruse_zero_async(void* p, size_t bytes, hipStream_t stream, const char* name);
 
+// library option `name` (cruse_set_option), or dflt when the host has not set it; the library reads no environment variables
+int cruse_opt(const char* name, int dflt);
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline long long cdivl(long long a, long long b) { return (a + b - 1) / b; }
 

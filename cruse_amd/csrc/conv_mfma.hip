@@ -370,12 +370,12 @@ int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float
     // small weight images: more, lighter workgroups hide latency better (44 vs 60 us on the 8->16 layer);
     // large ones (up to 48 KB of fragments per workgroup) amortise their prologue over more tiles
     int gmax = wbytes <= 16 * 1024 ? 1024 : 512;
-    { const char* e = getenv("CRUSE_CM_GRID"); if (e) gmax = atoi(e); }
+    gmax = cruse_opt("cm_grid", gmax);
     const int grid = ntiles < gmax ? ntiles : gmax;
     int rc;
     const int ntile_wg = a.nclass * (TFM * (Fout / a.OS) / 16);       // N-tiles of one workgroup tile
     int nw = (ntile_wg == 5 || (ntile_wg == 10 && (Cin >= 64 || Cout >= 64))) ? 5 : 4;
-    { const char* e = getenv("CRUSE_CM_NW"); if (e && (atoi(e) == 4 || atoi(e) == 5)) nw = atoi(e); }       // profiling knob
+    { const int e = cruse_opt("cm_nw", 0); if (e == 4 || e == 5) nw = e; }       // profiling option
     if (prec == CRUSE_PREC_F32) rc = launch_mt<CRUSE_PREC_F32>(a, grid, lds, nw, stream);
     else if (prec == CRUSE_PREC_BF16) rc = launch_mt<CRUSE_PREC_BF16>(a, grid, lds, nw, stream);
     else rc = launch_mt<CRUSE_PREC_BF16X3>(a, grid, lds, nw, stream);

@@ -484,9 +484,9 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
     const dim3 grid((unsigned)nblk);
     hipStream_t st = (hipStream_t)stream;
     int deep_min = 64;                         // long k-loops: three stages, one block per CU
-    { const char* e = getenv("CRUSE_GB_DEEP_MIN"); if (e && atoi(e) > 0) deep_min = atoi(e); }      // profiling knobs
+    { const int e = cruse_opt("gb_deep_min", 0); if (e > 0) deep_min = e; }      // profiling options
     bool deep = kt_chunk >= deep_min;
-    { const char* e = getenv("CRUSE_GB_DEEP"); if (e) deep = atoi(e) != 0; }
+    { const int e = cruse_opt("gb_deep", -1); if (e >= 0) deep = e != 0; }
     const size_t lds = (size_t)(deep ? 3 : 2) * 2 * TILE_BYTES;
 #define CRUSE_GB_LAUNCH(MODE, NST)                                                                               \
     do {                                                                                                         \

@@ -504,7 +504,7 @@ int conv2d_nchw_t(const void* x, const float* w, const float* bias, void* y, int
     if constexpr (sizeof(T) == 2) {
         // f16 storage: the pointwise convolutions run on the matrix cores (weights resident as A fragments)
         const int MT = cdiv(Cout, 16), KS = cdiv(Cin, 32);
-        if (pointwise && MT <= 4 && KS <= 4 && !getenv("CRUSE_PW_VALU")) {
+        if (pointwise && MT <= 4 && KS <= 4 && !cruse_opt("pw_valu", 0)) {
             const long long ntile = (long long)B * cdivl((long long)Hin * Win, 16);
             const int nb = (int)(cdivl(ntile, 16) > 8192 ? 8192 : cdivl(ntile, 16));
 #define PW_CASE(mt, ks) hipLaunchKernelGGL((gconv_pointwise_mfma_f16_kernel<mt, ks>), dim3(nb), dim3(256), 0, s, a)

@@ -1429,7 +1429,7 @@ int make_plan(int B, int G, int Hg, Plan& pl) {
     const int maxblk = num_cus();
     if (G * pl.P > maxblk) return -1;
     pl.Bg = 8;
-    { const char* e = getenv("CRUSE_GRU_BG"); if (e && atoi(e) == 16) pl.Bg = 16; }   // profiling override
+    if (cruse_opt("gru_bg", 8) == 16) pl.Bg = 16;   // profiling override
     pl.nbg = cdiv(B, pl.Bg);
     if (pl.nbg * G * pl.P > maxblk) { pl.Bg = 16; pl.nbg = cdiv(B, pl.Bg); }
     pl.bg_per_launch = ((maxblk / pl.P) / 8 * 8) / G;      // chains per launch padded to a multiple of 8
@@ -1445,7 +1445,7 @@ size_t xid_bytes_total(int B, int G) { return (size_t)cdiv(B, 8) * G * 64 * 8; }
 // granules (8 bytes) of one parity of one chain: all-gather forms keep up to 16 rows of Hg values; the
 // reduce-scatter backward keeps [consumer P][clip 8][pair 16][producer P]
 bool bwd_rs_eligible(int Bg, int Hg, int prec) {
-    if (getenv("CRUSE_GRU_BWD_RS") && atoi(getenv("CRUSE_GRU_BWD_RS")) == 0) return false;    // A/B switch (tests, probes)
+    if (cruse_opt("gru_bwd_rs", 1) == 0) return false;    // A/B switch (tests, probes)
     return prec == CRUSE_PREC_BF16 && Bg == 8 && Hg % 32 == 0 && Hg <= 640;
 }
 size_t rs_gran_per_parity(int Hg) { const size_t P = Hg / 32; return P * 8 * 16 * P; }
@@ -1465,14 +1465,14 @@ int launch_one(Kern k, const GruArgs& a, int grid, size_t lds, hipStream_t s, co
 }
 
 bool fwd_lean_eligible(int Bg, int Hg, int prec) {
-    if (getenv("CRUSE_GRU_FWD_LEAN") && atoi(getenv("CRUSE_GRU_FWD_LEAN")) == 0) return false;   // A/B switch (tests, probes)
+    if (cruse_opt("gru_fwd_lean", 1) == 0) return false;   // A/B switch (tests, probes)
     return prec == CRUSE_PREC_BF16 && Bg == 8 && Hg % 32 == 0 && Hg <= 640;
 }
 // W_hh low plane in the lean forward recurrence: CRUSE_GRU_WLO = 1 always, 0 never; default: when the second plane is
 // nearly free (Hg <= 320: at most 48 extra registers and 12 extra MFMAs per wave and step)
 bool fwd_wlo(int Hg) {
-    const char* e = getenv("CRUSE_GRU_WLO");
-    if (e) return atoi(e) != 0;
+    const int e = cruse_opt("gru_wlo", -1);
+    if (e >= 0) return e != 0;
     return Hg <= 320;
 }
 template <bool WLO>
@@ -1554,7 +1554,7 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* pane
     char* xg_base = xid_base + xid_bytes_total(a.B, G);
     unsigned* tickets_base = (unsigned*)(xg_base + xg_bytes_total(a.B, G, Hg));        // [launch][8]
     a.Bg = pl.Bg; a.P = pl.P;
-    { const char* e = getenv("CRUSE_GRU_DBG"); a.dbg = e ? atoi(e) : 0; }
+    a.dbg = cruse_opt("gru_dbg", 0);
     int rc = CRUSE_OK;
     CRUSE_REQUIRE(pl.nlaunch <= MAX_LAUNCH_TICKETS, CRUSE_E_SHAPE, "gru_seq: batch %d needs %d launches (max %d)", a.B, pl.nlaunch,
                   MAX_LAUNCH_TICKETS);

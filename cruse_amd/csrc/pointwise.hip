@@ -822,7 +822,7 @@ extern "C" int cruse_ln_fwd(const float* x, const float* gamma, const float* bet
     return CRUSE_OK;
 }
 
-static int lnb_grid() { const char* e = getenv("CRUSE_LNB_GRID"); return e ? atoi(e) : 512; }
+static int lnb_grid() { return cruse_opt("lnb_grid", 512); }
 
 extern "C" int cruse_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                             const float* gamma, long long rows, int H, int interleave_g,

@@ -337,8 +337,8 @@ int cruse_wgrad_mfma_try(const float* a, const float* bt, float* partial, int ma
     } else if (fits(4) && 2 * lds_of(4) <= two_wg) {
         gcap = 512;
     }
-    { const char* e = getenv("CRUSE_WG_TFW"); if (e && (atoi(e) == 4 || (atoi(e) == 8 && prec == CRUSE_PREC_BF16))) tfw = atoi(e); }   // profiling overrides
-    { const char* e = getenv("CRUSE_WG_GRID"); if (e && atoi(e) > 0) gcap = atoi(e); }
+    { const int e = cruse_opt("wg_tfw", 0); if (e == 4 || (e == 8 && prec == CRUSE_PREC_BF16)) tfw = e; }   // profiling overrides
+    { const int e = cruse_opt("wg_grid", 0); if (e > 0) gcap = e; }
     if (!fits(tfw)) return 0;
     const size_t lds = lds_of(tfw);
     WMArgs p = {};
@@ -346,7 +346,7 @@ int cruse_wgrad_mfma_try(const float* a, const float* bt, float* partial, int ma
     p.B = B; p.T = T; p.Ca = Ca; p.Fa = Fa; p.Cb = Cb; p.Fb = Fb; p.KT = KT; p.S = S; p.pad = pad;
     p.FaP = FaP; p.NCH = NCH; p.ntaps = ntaps; p.nrows = tfw + KT - 1;
     p.ntiles_total = B * ((T + tfw - 1) / tfw);
-    { const char* e = getenv("CRUSE_WG_DBG"); p.dbg = e ? atoi(e) : 0; }
+    p.dbg = cruse_opt("wg_dbg", 0);
     int grid = p.ntiles_total < max_slabs ? p.ntiles_total : max_slabs;
     if (grid > gcap) grid = gcap;               // resident blocks only; fewer partial slabs to reduce
     int rc;

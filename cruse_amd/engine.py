@@ -26,8 +26,11 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from . import config as _config
 from . import ops
-from .model.cruse_net import N_BUCKETS, SIDE, bucket_of, unet2_backward, unet2_forward, unet_2
+from .config import EngineConfig
+from .model import cruse_net as _net
+from .model.cruse_net import N_BUCKETS, bucket_of, unet2_backward, unet2_forward, unet_2
 
 ALIGN = 64  # floats
 
@@ -179,15 +182,20 @@ class TrainEngine:
     (HIP-event times of the measured ones, one host synchronisation each), then the faster form is kept for good -- no
     extra steps are run, every rank takes rank 0's verdict.  bench.py does the same during its warm-up.
     clip_grad_norm > 0: torch.nn.utils.clip_grad_norm_ semantics on the (averaged) gradient, folded into Adam.
-    bucketed: None = when world > 1; True forces the segmented schedule (tests, single-GPU cost measurements)."""
+    bucketed: None = when world > 1; True forces the segmented schedule (tests, single-GPU cost measurements).
+    config: EngineConfig (cruse_amd/config.py) -- scheduling / numerics options; None = the measured-best defaults."""
 
     def __init__(self, model: unet_2, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
                  n_fft=320, hop=160, precision: Optional[str] = None, use_graph=True,
                  loss_alpha=2.0, loss_beta=1.0, loss: str = "wo_male", clip_grad_norm: float = 0.0,
-                 snr_db: float = 0.0, sdnr_beta_db: float = 20.0, bucketed: Optional[bool] = None):
+                 snr_db: float = 0.0, sdnr_beta_db: float = 20.0, bucketed: Optional[bool] = None,
+                 config: Optional[EngineConfig] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("cruse_amd.TrainEngine needs a HIP device (there is no CPU path)")
         self.model = model
+        # this engine's own options and side-stream scheduler (config.py): nothing is shared with another engine of the process
+        self.cfg = config.copy() if config is not None else EngineConfig()
+        self.side = _net._SideStream(self.cfg)
         self.n_fft, self.hop = n_fft, hop
         self.f_net = (n_fft // 2 + 1) // 2 * 2
         self.f_stft = n_fft // 2 + 1
@@ -243,12 +251,12 @@ class TrainEngine:
             # (outputs are allocated here, on the main stream, so that the leaf itself allocates nothing)
             if self.loss == "wo_male":
                 cmag = torch.empty(B, T, self.f_stft, device=clean.device, dtype=torch.float32)
-                SIDE.defer(lambda: ops.stft(clean, self.n_fft, self.hop, want_ri=False, mag_eps=0.0, out=(None, None, cmag)),
+                self.side.defer(lambda: ops.stft(clean, self.n_fft, self.hop, want_ri=False, mag_eps=0.0, out=(None, None, cmag)),
                            clean, cmag, kind=1, lane=0)
             else:
                 cre = torch.empty(B, T, self.f_stft, device=clean.device, dtype=torch.float32)
                 cim = torch.empty_like(cre)
-                SIDE.defer(lambda: ops.stft(clean, self.n_fft, self.hop, out=(cre, cim, None)), clean, cre, cim, kind=1, lane=0)
+                self.side.defer(lambda: ops.stft(clean, self.n_fft, self.hop, out=(cre, cim, None)), clean, cre, cim, kind=1, lane=0)
         mask, ctx = unet2_forward(mag.view(B, 1, T, self.f_net), self.flat.P, self.Bf, self.model.ch,
                                   self.model.rnn_groups, self.prec, training=training, save=training,
                                   update_running=training)
@@ -313,7 +321,7 @@ class TrainEngine:
     def _fwd_bwd(self, noisy: torch.Tensor, clean: torch.Tensor, boundary=None) -> torch.Tensor:
         B, L = noisy.shape
         T = ops.stft_frames(L, self.hop)
-        with ops.ARENA.step(noisy.device):          # one clear for all reduction accumulators of the step
+        with _config.use(self.cfg), _net.use_scheduler(self.side), ops.ARENA.step(noisy.device):      # (one arena clear per step)
             loss_sum, dlogit, ctx = self._forward_loss(noisy, clean, training=True)
             ops.zero_(self.flat.grads)
             unet2_backward(ctx, dlogit.view(B, T, 1, self.f_net), self.flat.P, self.flat.G, boundary=boundary)
@@ -323,7 +331,8 @@ class TrainEngine:
     def eval_loss(self, noisy: torch.Tensor, clean: torch.Tensor) -> float:
         """validation: the configured loss with BatchNorm in eval mode (running statistics), no gradients."""
         norm = self._norm
-        loss_sum, _, _ = self._forward_loss(noisy, clean, training=False)
+        with _config.use(self.cfg), _net.use_scheduler(self.side):
+            loss_sum, _, _ = self._forward_loss(noisy, clean, training=False)
         v = float(loss_sum.item()) / self._norm
         self._norm = norm
         return v
@@ -357,10 +366,10 @@ class TrainEngine:
             graphs.append((cur["g"], bucket))
 
         def boundary(bucket: int):
-            SIDE.join(flush=False)           # every ISSUED leaf joined; queued leaves move to the next segment
+            self.side.join(flush=False)           # every ISSUED leaf joined; queued leaves move to the next segment
             end(bucket)
             begin()
-            SIDE.flush()
+            self.side.flush()
 
         begin()
         try:
@@ -375,32 +384,26 @@ class TrainEngine:
         self._graph_cache[self._shape] = (graphs, self._static, self._static_loss)
         self._norms[self._shape] = self._norm
 
-    @staticmethod
-    def _warmup_boundary(bucket: int):
-        SIDE.join(flush=False)
-        SIDE.flush()
+    def _warmup_boundary(self, bucket: int):
+        self.side.join(flush=False)
+        self.side.flush()
 
     def _plain_boundary(self, bucket: int):
         """eager launches: the bucket's collective must follow everything issued so far on the main AND the side streams,
         but the main stream itself need not wait for the leaves -- the collective is issued from a launcher stream that waits
         for both (ProcessGroupNCCL orders its stream after the stream it is called from)."""
         if not _dist_on():
-            SIDE.flush()
-            return
-        if os.environ.get("CRUSE_EAGER_BOUNDARY") == "join":       # A/B: join the leaves on the main stream instead
-            SIDE.join(flush=False)
-            self._launch_bucket(bucket)
-            SIDE.flush()
+            self.side.flush()
             return
         main = torch.cuda.current_stream()
         if self._launcher is None:
             self._launcher = torch.cuda.Stream()
         self._launcher.wait_stream(main)
-        for s_ in SIDE.used:
+        for s_ in self.side.used:
             self._launcher.wait_stream(s_)
         with torch.cuda.stream(self._launcher):
             self._launch_bucket(bucket)
-        SIDE.flush()
+        self.side.flush()
 
     def _launch_bucket(self, b: int):
         """Start the all-reduce of every bucket that became final with segment b.  Un-bucketed graphs end with the
@@ -449,7 +452,6 @@ class TrainEngine:
         if self._auto is not None:
             return self._auto_step(noisy, clean)
         self._works = []
-        SIDE.for_mode(self.use_graph)
         if self.use_graph:
             if self._graphs is None or self._shape != tuple(noisy.shape):
                 hit = self._graph_cache.get(tuple(noisy.shape))
@@ -465,7 +467,7 @@ class TrainEngine:
                         print(f"[cruse_amd] HIP-graph capture failed ({str(ex)[:200]}); continuing WITHOUT graphs", file=sys.stderr, flush=True)
                         self.use_graph = False
                         self._graphs = None
-                        SIDE.join()
+                        self.side.join()
                         torch.cuda.synchronize()
                         return self.step(noisy, clean)
             self._static[0].copy_(noisy)

@@ -18,73 +18,37 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
-import os
-
-from .. import ops
+from .. import config, ops
 
 DEFAULT_PREC = "f32"
 
 
 class _SideStream:
-    """Runs LEAF kernels (weight gradients, bias sums, skip convs) on side HIP streams so they fill the
-    ~96 CUs the persistent GRU kernels leave idle and overlap the HBM-bound main path elsewhere.  Leaves only read
-    tensors produced on the main stream and write parameter gradients / tensors consumed after join(); they allocate
-    nothing and are independent of each other, so they are dealt round-robin over CRUSE_SIDE_STREAMS streams.
-    Tensors handed to a side stream are kept alive until join().  CRUSE_OVERLAP=0 disables it."""
+    """Runs LEAF kernels (weight gradients, bias sums, skip convs) on a side HIP stream so they fill the ~96 CUs the persistent
+    GRU kernels leave idle and overlap the HBM-bound main path elsewhere.  Leaves only read tensors produced on the main stream
+    and write parameter gradients / tensors consumed after join(); they allocate nothing.  Tensors handed to the side stream are
+    kept alive until join().  One scheduler per TrainEngine (engine.py installs its own with use_scheduler); the module-level
+    default serves the autograd path of the nn.Modules.  EngineConfig.overlap = False disables it."""
 
-    def __init__(self):
-        self.enabled = os.environ.get("CRUSE_OVERLAP", "1") == "1"
-        # leaves queued for the next recurrence launch instead of issued at once: 1 skip convs (forward), 2 decoder weight
-        # gradients, 4 GRU weight gradients, 8 skip-conv backward leaves
-        self.defer_mask = int(os.environ.get("CRUSE_DEFER", "15"))
-        self.nside = max(1, int(os.environ.get("CRUSE_SIDE_STREAMS", "1")))
-        # lane -> stream: leaves are tagged 0 conv weight gradients, 1 skip-conv leaves, 2 GRU dW GEMMs; CRUSE_SIDE_MAP
-        # "abc" sends lane i to side stream int(abc[i]) (needs that many streams); unset: round-robin over nside streams
-        self.env_map = os.environ.get("CRUSE_SIDE_MAP")
-        self.set_map(self.env_map if self.env_map is not None else "000")
+    def __init__(self, cfg=None):
+        cfg = cfg if cfg is not None else config.EngineConfig()
+        self.enabled = bool(cfg.overlap)
+        # leaves queued for the next recurrence launch instead of issued at once (EngineConfig.defer_mask)
+        self.defer_mask = int(cfg.defer_mask)
         self.streams = {}
         self.keep = []
         self.deferred = []
         self.active = False
-        self.rr = 0
         self.used = []                 # side streams forked from the main stream since the last join()
-        self.last = None               # the stream the most recent leaf went to
-        self.multi_stream = False      # leaves may be deferred on one stream and released from another (_Pipes)
         self.after_release = None      # one-shot callback run by the next release_around() once its leaves are issued
 
-    def set_map(self, m: str, force: bool = False) -> None:
-        """lane -> side stream assignment.  One side stream for all three lanes is the measured best in both launch forms
-        on the current kernels (graph replay 6.21 ms against 6.42 on three streams, eager 6.05 against 6.43; at the start
-        of round 2, on slower leaves, three streams won under graph replay: 7.56 vs 7.78).  An explicit CRUSE_SIDE_MAP
-        wins unless force."""
-        if self.env_map is not None and not force:
-            m = self.env_map
-        self.lane_map = [int(c) for c in m] if m else None
-        if self.lane_map:
-            self.nside = max(self.nside, max(self.lane_map) + 1)
-
-    def for_mode(self, use_graph: bool) -> None:
-        self.set_map("000")
-
-    def _sides(self):
-        dev = torch.cuda.current_device()
-        sides = self.streams.get(dev)
-        if sides is None:
-            sides = self.streams[dev] = []
-        while len(sides) < self.nside:
-            sides.append(torch.cuda.Stream())
-        return sides
-
     def _next(self, lane=None):
-        sides = self._sides()
-        if self.lane_map is not None and lane is not None:
-            s = sides[self.lane_map[lane % len(self.lane_map)] % len(sides)]
-        else:
-            s = sides[self.rr % len(sides)]
-            self.rr += 1
+        dev = torch.cuda.current_device()
+        s = self.streams.get(dev)
+        if s is None:
+            s = self.streams[dev] = torch.cuda.Stream()
         if s not in self.used:         # only forked streams may be recorded on / joined (HIP-graph capture rule)
             self.used.append(s)
-        self.last = s
         return s
 
     def defer(self, fn, *tensors, kind=7, lane=None):
@@ -93,19 +57,12 @@ class _SideStream:
         if not (self.enabled and (self.defer_mask & kind)):
             self.run(fn, *tensors, lane=lane)
             return
-        # the leaf's inputs are complete on the stream that defers it -- which, with half-batch pipelines (ggru_forward),
-        # need not be the stream that later releases it: remember that point.  (Only then: an event record is a barrier
-        # packet on the recording stream, ~6 us of idle queue per record.)
-        dep = None
-        if self.multi_stream:
-            dep = torch.cuda.Event()
-            dep.record(torch.cuda.current_stream())
-        self.deferred.append((fn, lane, dep))
+        self.deferred.append((fn, lane, None))
         self.keep.extend(tensors)
 
     def release_around(self, launch):
         """launch() issues a recurrence kernel on the main stream; the deferred leaves are issued right after it on
-        the side streams, ordered only after the work that preceded the recurrence launch."""
+        the side stream, ordered only after the work that preceded the recurrence launch."""
         if not (self.enabled and self.deferred):
             return launch()
         main = torch.cuda.current_stream()
@@ -115,8 +72,6 @@ class _SideStream:
         for fn, lane, dep in self.deferred:
             side = self._next(lane)
             side.wait_event(ev)
-            if dep is not None:
-                side.wait_event(dep)
             with torch.cuda.stream(side):
                 fn()
         self.deferred.clear()
@@ -128,22 +83,18 @@ class _SideStream:
 
     def run(self, fn, *tensors, lane=None, dep=None):
         if not self.enabled:
-            if dep is not None:
-                torch.cuda.current_stream().wait_event(dep)
             fn()
             return
         main = torch.cuda.current_stream()
         side = self._next(lane)
         side.wait_stream(main)
-        if dep is not None:
-            side.wait_event(dep)
         self.keep.extend(tensors)
         self.active = True
         with torch.cuda.stream(side):
             fn()
 
     def mark(self):
-        """Events after everything issued on the side streams so far (None when nothing runs there)."""
+        """Events after everything issued on the side stream so far (None when nothing runs there)."""
         if not (self.enabled and self.active):
             return None
         evs = []
@@ -159,14 +110,14 @@ class _SideStream:
                 torch.cuda.current_stream().wait_event(ev)
 
     def flush(self):
-        """Issue everything still queued by defer() on the side streams now."""
+        """Issue everything still queued by defer() on the side stream now."""
         if self.deferred:
             fns, self.deferred = self.deferred, []
             for fn, lane, dep in fns:
-                self.run(fn, lane=lane, dep=dep)
+                self.run(fn, lane=lane)
 
     def join(self, flush: bool = True):
-        """Main stream waits for the side streams.  flush=False keeps the deferred (not yet issued) leaves queued: a
+        """Main stream waits for the side stream.  flush=False keeps the deferred (not yet issued) leaves queued: a
         SEGMENT boundary of the bucketed data-parallel step (engine.py) ends a graph capture with every ISSUED leaf
         joined, and carries the queued ones into the next segment."""
         if flush and self.enabled:               # nothing left to hide behind: issue what is still queued
@@ -183,45 +134,21 @@ class _SideStream:
 SIDE = _SideStream()
 
 
-class _Pipes:
-    """Half-batch pipelines through the GGRU block (CRUSE_GRU_PIPES=2; default OFF).  The persistent recurrence kernels are
-    latency-bound -- their time does not depend on how many 8-clip chains run -- while the projections, layer norms and
-    gate gradients between them keep the recurrence waiting.  With the batch cut into n slices on n streams, staggered by
-    one pre-stage, the in-between work of one slice runs beside the recurrence of the other, and the recurrences of the
-    slices (4 chains each at B = 64, on disjoint XCDs: cruse_gru_seq_fwd_on) overlap each other.  BatchNorm needs the
-    whole batch, so only the GGRU block is sliced.
-    Measured on the bench step: 7.55 ms against 6.94 ms single-stream.  The two half recurrences do overlap
-    (642 us for the pair against 610 us for one), but the in-between kernels then run on the 96 CUs the recurrences leave
-    free -- 2.7x slower than alone (the half-batch gate GEMM: 242 us against 84 us) -- and those CUs are already used by
-    the weight-gradient leaves, so the stagger between the slices costs more than the overlap saves."""
+class use_scheduler:
+    """with use_scheduler(side): the step issued inside uses THIS scheduler (TrainEngine owns one: two engines in a process do
+    not share side-stream state)."""
 
-    def __init__(self):
-        self.n = max(1, int(os.environ.get("CRUSE_GRU_PIPES", "1")))
-        self.streams = {}
+    def __init__(self, side: "_SideStream"):
+        self.side = side
 
-    def count(self, B: int, g: int, Hg: int) -> int:
-        n = self.n
-        if n < 2 or not SIDE.enabled or B % (8 * n) != 0:
-            return 1
-        chains = (B // n // 8) * g          # 8-clip chains per slice, Hg/32 workgroups each, one workgroup per CU
-        per_xcd = (chains + 7) // 8 * (Hg // 32)
-        if chains * n <= 8 or per_xcd * n <= 28:
-            return n
-        return 1
+    def __enter__(self):
+        global SIDE
+        self.prev, SIDE = SIDE, self.side
+        return self.side
 
-    def rot(self, k: int, n: int, B: int, g: int) -> int:
-        chains = (B // n // 8) * g
-        return (k * (8 // n)) % 8 if chains * n <= 8 else 0
-
-    def stream(self, k: int):
-        dev = torch.cuda.current_device()
-        lst = self.streams.setdefault(dev, [])
-        while len(lst) < k:
-            lst.append(torch.cuda.Stream())
-        return lst[k - 1]
-
-
-PIPES = _Pipes()
+    def __exit__(self, *exc):
+        global SIDE
+        SIDE = self.prev
 
 
 def _splitk_bf16(M: int, N: int, K: int) -> int:
@@ -231,8 +158,8 @@ def _splitk_bf16(M: int, N: int, K: int) -> int:
     step) for +0.02 ms of step time.  CRUSE_DW_XCDK=0: the round-robin form that fills the 256 CUs in one round with
     one block per CU (the fastest launch alone: 142 vs 206 us); CRUSE_DW_XCDK=<n>: n pinned slices."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    env = os.environ.get("CRUSE_DW_XCDK")
-    x = int(env) if env is not None else (8 if tiles * 8 >= 192 else 0)      # few output tiles (grouped GRUs): keep round-robin
+    knob = config.get().dw_xcdk
+    x = int(knob) if knob is not None else (8 if tiles * 8 >= 192 else 0)      # few output tiles (grouped GRUs): keep round-robin
     if x > 1:
         return -x
     return max(1, min(256 // tiles, K // 1024))
@@ -245,14 +172,14 @@ def _bf16_gemm_path(prec, Hg: int) -> bool:
 
 
 def _gi_x3_knob(Hg: int) -> int:
-    return int(os.environ.get("CRUSE_GI_X3", "7" if Hg <= 320 else "3"))
+    knob = config.get().gi_x3
+    return int(knob) if knob is not None else (7 if Hg <= 320 else 3)
 
 
 def _gi_takes_bf16_copy(prec, Hg: int) -> bool:
     """The gate projections read ONE bf16 plane of their activation operand, unpadded: the producer (BatchNorm / LayerNorm
     kernel) can then write that copy itself instead of a separate cast pass."""
-    return (_bf16_gemm_path(prec, Hg) and Hg % 64 == 0 and not (_gi_x3_knob(Hg) & 4)
-            and os.environ.get("CRUSE_FUSE_CAST", "1") == "1")
+    return _bf16_gemm_path(prec, Hg) and Hg % 64 == 0 and not (_gi_x3_knob(Hg) & 4) and config.get().fuse_cast
 
 
 def _dw_tn(prec, Hg: int, B: int, g: int) -> bool:
@@ -261,14 +188,14 @@ def _dw_tn(prec, Hg: int, B: int, g: int) -> bool:
     dg_slabs = 4), so the gate-gradient pass, the four time-major operand transposes and the 131 MB time-major gate-gradient
     copy per layer disappear.  Needs the reduce-scatter recurrence kernel: bf16 mode, Hg <= 640, 8-clip chains (all chains of
     the batch co-resident).
-    OPT-IN (CRUSE_DW_TN=1), because it measured SLOWER on the bench step: 6.35 against 6.02 ms (r03).  The register-transposing
+    OPT-IN (EngineConfig.dw_tn), because it measured SLOWER on the bench step: 6.35 against 6.02 ms (r03).  The register-transposing
     staging keeps one k-tile in flight where the NT kernel's LDS-DMA keeps two or three, so the TN products take 239 / 204 /
     165 us alone (264 TF/s; 344 us with the f32 h operand) against 187 + ~140 + ~80 for the NT ones, and the recurrence pays
     875 instead of 806 us per launch for writing the four bf16 slabs from its loader wave -- more than the removed
     gate-gradient pass (2 x 112 us), transposes (0.15 ms) and 0.8 GB of traffic give back (tools/tn_probe.py)."""
-    if os.environ.get("CRUSE_DW_TN", "0") != "1" or not _bf16_gemm_path(prec, Hg) or Hg > 640 or not SIDE.enabled:
+    if not config.get().dw_tn or not _bf16_gemm_path(prec, Hg) or Hg > 640 or not SIDE.enabled:
         return False
-    if os.environ.get("CRUSE_GRU_BWD_RS") == "0" or os.environ.get("CRUSE_GRU_BG") == "16":
+    if ops.get_option("gru_bwd_rs") == 0 or ops.get_option("gru_bg") == 16:
         return False
     ncu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
     return ((B + 7) // 8) * g * (Hg // 32) <= ncu
@@ -286,39 +213,9 @@ def _splitk(M: int, N: int, K: int) -> int:
 def ggru_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], prefix: str, groups: int, prec,
                  residual: Optional[torch.Tensor] = None, save: bool = True, residual_ready=None, late_leaves=None,
                  x_bf16=None):
-    """x [B,T,H] -> (ln2(gru2(ln1(interleave(gru1(x))))) [+ residual], ctx).  cruse_net.py:37-55.
-    With CRUSE_GRU_PIPES=2, batches of 16k clips run as half-batch pipelines on two streams (_Pipes); ctx then holds one
-    context per slice."""
-    B, T, H = x.shape
-    n = PIPES.count(B, groups, H // groups)
-    if n == 1:
-        return _ggru_forward_one(x, P, prefix, groups, prec, residual, save, residual_ready=residual_ready,
-                                 late_leaves=late_leaves, x_bf16=x_bf16)
-    if residual_ready is not None:
-        residual_ready()
-    Bh = B // n
-    out = torch.empty_like(x)
-    main = torch.cuda.current_stream()
-    fork = torch.cuda.Event()
-    fork.record(main)
-    SIDE.multi_stream = True
-    ctxs, gate_prev = [], None
-    for k in range(n):
-        sl = slice(k * Bh, (k + 1) * Bh)
-        st = main if k == 0 else PIPES.stream(k)
-        gate = torch.cuda.Event()
-        if k > 0:
-            st.wait_event(fork)
-            st.wait_event(gate_prev)         # stagger: this slice's projection runs beside the previous slice's recurrence
-        with torch.cuda.stream(st):
-            _, c = _ggru_forward_one(x[sl], P, prefix, groups, prec, None if residual is None else residual[sl], save,
-                                     out=out[sl], slot=k, xcd_rot=PIPES.rot(k, n, B, groups),
-                                     pre_done=lambda gate=gate, st=st: gate.record(st))
-        ctxs.append(c)
-        gate_prev = gate
-    for k in range(1, n):
-        main.wait_stream(PIPES.stream(k))
-    return out, dict(B=B, T=T, H=H, g=groups, prec=prec, prefix=prefix, has_res=residual is not None, pipes=ctxs)
+    """x [B,T,H] -> (ln2(gru2(ln1(interleave(gru1(x))))) [+ residual], ctx).  cruse_net.py:37-55."""
+    return _ggru_forward_one(x, P, prefix, groups, prec, residual, save, residual_ready=residual_ready,
+                             late_leaves=late_leaves, x_bf16=x_bf16)
 
 
 def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=None, slot=0, xcd_rot=0, pre_done=None,
@@ -378,7 +275,7 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
     # the forward pass only.  From the first backward recurrence on, the side streams' queue is what the optimizer step
     # waits for, while in the forward pass they idle: three of the copies are made beside the second forward recurrence,
     # the fourth beside the decoder (late_leaves: the caller issues it after it has joined the side streams).
-    fwd_T = save and fast and SIDE.enabled and slot == 0 and _EARLY_T >= 2
+    fwd_T = save and fast and SIDE.enabled and slot == 0 and config.get().early_t >= 2
     tn = _dw_tn(prec, Hg, B, g)
     ctx["tn"] = tn
     if tn:                                       # the TN weight-gradient GEMMs read the layer inputs row-major (bf16 copy if made)
@@ -428,34 +325,6 @@ def ggru_backward(ctx, dout: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[s
     defer_last: queue layer 1's weight-gradient leaf (SIDE.defer) instead of issuing it -- the caller ends a segment
     right after this function and issues it with SIDE.flush() at the start of the next one."""
     B, T, H, g, prec, prefix = ctx["B"], ctx["T"], ctx["H"], ctx["g"], ctx["prec"], ctx["prefix"]
-    if "pipes" in ctx:
-        n = len(ctx["pipes"])
-        Bh = B // n
-        dx = None
-        if need_dx:
-            dx = dx_init.view(B, T, H) if dx_init is not None else torch.empty(B, T, H, device=dout.device, dtype=torch.float32)
-        main = torch.cuda.current_stream()
-        fork = torch.cuda.Event()
-        fork.record(main)
-        SIDE.multi_stream = True
-        gate_prev = None
-        for k, c in enumerate(ctx["pipes"]):
-            sl = slice(k * Bh, (k + 1) * Bh)
-            st = main if k == 0 else PIPES.stream(k)
-            gate = torch.cuda.Event()
-            if k > 0:
-                st.wait_event(fork)
-                st.wait_event(gate_prev)
-            with torch.cuda.stream(st):
-                # every slice ADDS its input gradient into its rows of dx when the caller pre-filled them (dx_init)
-                _ggru_backward_one(c, dout[sl], P, G, need_dx, dx[sl] if need_dx else None, dx_init is not None, dx_ready,
-                                   defer_last, pre_done=lambda gate=gate, st=st: gate.record(st))
-            gate_prev = gate
-        for k in range(1, n):
-            main.wait_stream(PIPES.stream(k))
-        if join:
-            SIDE.join()
-        return dx
     dx = None
     if need_dx:
         if dx_init is not None:
@@ -480,7 +349,7 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
     # CRUSE_FUSE_DGI=1: the backward recurrence writes the bf16 gate gradients dgi itself and the gate-gradient pass (then
     # only the time-major copies + bias sums) moves into the weight-gradient leaf.  Measured neutral (6.01-6.04 vs
     # 5.98-6.03 ms): 0.2 ms leave the main stream, 0.14 ms join the side queue, and the step is bound by their sum.
-    fuse_dgi = os.environ.get("CRUSE_FUSE_DGI", "0") == "1"
+    fuse_dgi = config.get().fuse_dgi
 
     def run_bwd(dout_h, w_hh, coef, z, an=None, dg_slabs=3):
         if hooks:
@@ -637,7 +506,7 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
     early_T = {}
     if "T1" in ctx:                                      # made in the forward pass (_ggru_forward_one)
         early_T["gru_list1"], early_T["gru_list2"] = ctx["T1"], ctx["T2"]
-    elif _bf16_gemm_path(prec, Hg) and SIDE.enabled and _EARLY_T >= 1 and not ctx.get("tn"):
+    elif _bf16_gemm_path(prec, Hg) and SIDE.enabled and config.get().early_t >= 1 and not ctx.get("tn"):
         ldT1 = (rows + 63) // 64 * 64
         x1T = torch.empty(ldT1 // 64, H, 64, device=dout.device, dtype=torch.bfloat16)
         h1T = torch.empty(ldT1 // 64, H, 64, device=dout.device, dtype=torch.bfloat16)
@@ -663,16 +532,6 @@ BN_MOMENTUM = 0.1
 
 
 _PENDING_COUNTERS = []      # num_batches_tracked buffers of this forward: bumped by ONE kernel at its end, not seven
-
-
-# BatchNorm batch sums accumulated by the producing conv's epilogue (CRUSE_FUSE_BN_STATS=0: separate bn_stats pass)
-_FUSE_BN_STATS = os.environ.get("CRUSE_FUSE_BN_STATS", "1") != "0"
-
-
-_INLINE = int(os.environ.get("CRUSE_INLINE", "8"))      # backward leaves kept on the main stream (unet2_backward)
-# dW operand transposes: 0 inside each layer's weight-gradient leaf, 1 layer 1's with the first backward recurrence,
-# 2 all four in the forward pass (beside the second forward recurrence / the decoder)
-_EARLY_T = int(os.environ.get("CRUSE_EARLY_T", "2"))
 
 
 def _flush_counters():
@@ -716,15 +575,14 @@ def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, tor
     _PENDING_COUNTERS.clear()
     ys, es, ss, stats = [None], [x], [None], [None]
     for k in range(1, L + 1):
-        if training and _FUSE_BN_STATS:
+        if training and config.get().fuse_bn_stats:
             y, sums = ops.conv_gather_bnstats(cur, P[f"conv{k}.weight"], P[f"conv{k}.bias"], B, T, ch[k - 1], Fk[k - 1], ch[k],
                                               Fk[k], KT=2, S=2, pad=1, prec=prec)
         else:
             y, sums = ops.conv_gather(cur, P[f"conv{k}.weight"], P[f"conv{k}.bias"], B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k],
                                       KT=2, S=2, pad=1, prec=prec), None
         e_bf = None
-        if k == L and training and PIPES.count(B, groups, ch[L] * Fk[L] // groups) == 1 and \
-                _gi_takes_bf16_copy(prec, ch[L] * Fk[L] // groups):
+        if k == L and training and _gi_takes_bf16_copy(prec, ch[L] * Fk[L] // groups):
             e_bf = torch.empty(rows * ch[L] * Fk[L], device=x.device, dtype=torch.bfloat16)     # gate GEMM 1's operand
         e, mean, rstd = _bn_act(y, rows, ch[k], Fk[k], P, Bf, f"bn{k}", training, update_running, sums=sums, out_bf16=e_bf)
         s = torch.empty(B, T, ch[k], Fk[k], device=x.device, dtype=torch.float32)
@@ -746,7 +604,7 @@ def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, tor
         SIDE.run(fn, *keep, lane=2)
     us, vs, dstats = {L: u}, {}, {}
     for k in range(L, 1, -1):
-        if training and _FUSE_BN_STATS:
+        if training and config.get().fuse_bn_stats:
             v, sums = ops.conv_scatter2_bnstats(u, P[f"conv{k}_t.weight"], P[f"conv{k}_t.bias"], B, T, ch[k], Fk[k], ch[k - 1],
                                                 KT=1, pad=0, prec=prec)
         else:
@@ -790,12 +648,13 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
     prec = ctx["prec"]
     # data-gradient convolutions of the bf16 mode: plain bf16 operands (one MFMA, one conversion per element) like every
     # other backward contraction of that mode -- the split-bf16 x3 form is what the FORWARD convs need for the 1e-3 bar
-    # (CRUSE_CONV_BWD_X3=1 restores x3 in backward)
+    # (EngineConfig.conv_bwd_x3 restores x3 in backward)
     dprec = prec
-    if ops.prec_code(prec) == ops.PREC_BF16 and os.environ.get("CRUSE_CONV_BWD_X3", "0") != "1":
+    if ops.prec_code(prec) == ops.PREC_BF16 and not config.get().conv_bwd_x3:
         dprec = ops.PREC_BF16
     rows = B * T
     ys, es, stats, us, vs, dstats = ctx["ys"], ctx["es"], ctx["stats"], ctx["us"], ctx["vs"], ctx["dstats"]
+    _INLINE = config.get().inline_mask
     # ---- decoder level 1: v1 = convT_1(u1) -------------------------------------------
     dv = dlogit
 

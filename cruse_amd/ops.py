@@ -34,6 +34,35 @@ def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
     return t
 
 
+def set_option(name: str, value=None) -> None:
+    """Library option (cruse_set_option: kernel-selection A/B switches and profiling aids -- the library reads no
+    environment variables); value None restores the default."""
+    check(lib.cruse_set_option(name.encode(), 0 if value is None else int(value), 1 if value is None else 0))
+
+
+def get_option(name: str):
+    v, isset = ctypes.c_int(0), ctypes.c_int(0)
+    check(lib.cruse_get_option(name.encode(), ctypes.byref(v), ctypes.byref(isset)))
+    return v.value if isset.value else None
+
+
+class options:
+    """with ops.options(gru_bwd_rs=0, gru_wlo=0): ...  -- library options for the duration of the block."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.saved = {k: get_option(k) for k in self.kw}
+        for k, v in self.kw.items():
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.saved.items():
+            set_option(k, v)
+
+
 def prec_code(prec) -> int:
     if isinstance(prec, str):
         return PREC_BY_NAME[prec]

@@ -58,6 +58,13 @@ enum {
 
 int cruse_abi_version(void);
 const char* cruse_last_error(void);
+/* Library options -- kernel-selection A/B switches and profiling aids, set EXPLICITLY by the host (the library reads no
+ * environment variables): "gru_bwd_rs" / "gru_fwd_lean" 0 = the generic recurrence kernels in bf16 mode; "gru_wlo" 0 / 1 =
+ * W_hh low plane of the lean forward recurrence off / on for every Hg (unset: on for Hg <= 320); "gru_bg" 16; "gru_dbg",
+ * "wg_dbg" phase-skip profiling; "cm_grid", "cm_nw", "gb_deep_min", "gb_deep", "lnb_grid", "wg_tfw", "wg_grid" launch
+ * geometry overrides; "pw_valu" 1 = VALU pointwise convolutions in f16 storage.  unset != 0 restores the default. */
+int cruse_set_option(const char* name, int value, int unset);
+int cruse_get_option(const char* name, int* value, int* is_set);
 
 /* ---- acoustic front end ---------------------------------------------------- */
 

@@ -539,11 +539,8 @@ def test_gru_bwd_reduce_scatter_matches_all_gather_form(ops, H, B, T):
     h, coef, an, z = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16")
     dout = torch.randn(B, T, H).cuda()
     dh_rs = ops.gru_seq_bwd(dout, w, coef, z, B, T, 1, H, "bf16")
-    os.environ["CRUSE_GRU_BWD_RS"] = "0"
-    try:
+    with ops.options(gru_bwd_rs=0):
         dh_ag = ops.gru_seq_bwd(dout, w, coef, z, B, T, 1, H, "bf16")
-    finally:
-        del os.environ["CRUSE_GRU_BWD_RS"]
     torch.cuda.synchronize()
     assert ops.gru_status() == 0
     assert torch.isfinite(dh_rs).all() and rel_l2(dh_rs, dh_ag) < 5e-3
@@ -571,14 +568,11 @@ def test_gru_fwd_lean_matches_generic_kernel(ops, H, B, T):
     torch.manual_seed(H + B + 1)
     gi = (0.5 * torch.randn(B, T, 3 * H)).cuda()
     w = [(torch.randn(3 * H, H) / H ** 0.5).cuda()]; b = [(0.1 * torch.randn(3 * H)).cuda()]
-    os.environ["CRUSE_GRU_WLO"] = "0"              # same algorithm == without the lean kernel's W_hh low-plane pass
-    try:
+    with ops.options(gru_wlo=0):                   # same algorithm == without the lean kernel's W_hh low-plane pass
         lean = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16")
         h_nosave = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16", save=False)[0]
-        os.environ["CRUSE_GRU_FWD_LEAN"] = "0"
-        gen = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16")
-    finally:
-        os.environ.pop("CRUSE_GRU_FWD_LEAN", None); os.environ.pop("CRUSE_GRU_WLO", None)
+        with ops.options(gru_fwd_lean=0):
+            gen = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16")
     torch.cuda.synchronize()
     assert ops.gru_status() == 0
     for x, y, name in zip(lean, gen, ("h", "coef", "an", "z")):
@@ -604,16 +598,12 @@ def _lean_grouped_case(ops, B, T, G, Hg):
     w = [(torch.randn(3 * Hg, Hg) / Hg ** 0.5).cuda() for _ in range(G)]
     b = [(0.1 * torch.randn(3 * Hg)).cuda() for _ in range(G)]
     dout = torch.randn(B, T, G * Hg).cuda()
-    os.environ["CRUSE_GRU_WLO"] = "0"              # same algorithm == without the lean kernel's W_hh low-plane pass
-    try:
+    with ops.options(gru_wlo=0):                   # same algorithm == without the lean kernel's W_hh low-plane pass
         lean = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16")
         dh_rs = ops.gru_seq_bwd(dout, w, lean[1], lean[3], B, T, G, Hg, "bf16")
-        os.environ["CRUSE_GRU_FWD_LEAN"] = "0"; os.environ["CRUSE_GRU_BWD_RS"] = "0"
-        gen = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16")
-        dh_ag = ops.gru_seq_bwd(dout, w, lean[1], lean[3], B, T, G, Hg, "bf16")
-    finally:
-        for k in ("CRUSE_GRU_FWD_LEAN", "CRUSE_GRU_BWD_RS", "CRUSE_GRU_WLO"):
-            os.environ.pop(k, None)
+        with ops.options(gru_fwd_lean=0, gru_bwd_rs=0):
+            gen = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16")
+            dh_ag = ops.gru_seq_bwd(dout, w, lean[1], lean[3], B, T, G, Hg, "bf16")
     torch.cuda.synchronize()
     assert ops.gru_status() == 0
     assert rel_l2(lean[0], gen[0]) < 1e-4 and rel_l2(lean[1].float(), gen[1].float()) < 2e-3
@@ -633,11 +623,8 @@ def test_gru_fwd_w_hh_low_plane(ops, Hg, G):
     ref = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "f32", save=False)[0]
     err = {}
     for knob in ("0", "1"):
-        os.environ["CRUSE_GRU_WLO"] = knob
-        try:
+        with ops.options(gru_wlo=int(knob)):
             err[knob] = rel_l2(ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16", save=False)[0], ref)
-        finally:
-            del os.environ["CRUSE_GRU_WLO"]
     default = rel_l2(ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16", save=False)[0], ref)
     print(f"[gru W_hh planes Hg={Hg}] rel-L2 vs f32 recurrence: 1 plane {err['0']:.2e}, 2 planes {err['1']:.2e}, default {default:.2e}")
     assert ops.gru_status() == 0
@@ -784,8 +771,8 @@ def test_recurrence_writes_four_slab_gate_gradients():
 
 
 @pytest.mark.parametrize("grp", [1, 4])
-def test_tn_weight_gradient_path_matches_the_default(grp, monkeypatch):
-    """CRUSE_DW_TN=1 (opt-in: row-major TN weight-gradient GEMMs fed by the recurrence's own 4-slab gate-gradient rows) gives
+def test_tn_weight_gradient_path_matches_the_default(grp):
+    """EngineConfig(dw_tn=True) (opt-in: row-major TN weight-gradient GEMMs fed by the recurrence's own 4-slab gate-gradient rows) gives
     the training step of the default path (NT GEMMs on time-major copies): same loss, same gradients up to bf16 rounding of
     the bias-gradient terms and the split-K summation order."""
     from cruse_amd.data import synth_batch
@@ -794,13 +781,15 @@ def test_tn_weight_gradient_path_matches_the_default(grp, monkeypatch):
     from cruse_amd.model.cruse_net import unet_2
     res = {}
     noisy, clean = synth_batch(8, 16000, "cuda", 3)
+    from cruse_amd import config
+    from cruse_amd.config import EngineConfig
     for tn in ("0", "1"):
-        monkeypatch.setenv("CRUSE_DW_TN", tn)
         torch.manual_seed(1)
-        eng = TrainEngine(unet_2(rnn_groups=grp, precision="bf16").cuda(), use_graph=False)
+        eng = TrainEngine(unet_2(rnn_groups=grp, precision="bf16").cuda(), use_graph=False, config=EngineConfig(dw_tn=tn == "1"))
         ls = eng._fwd_bwd(noisy, clean)
         torch.cuda.synchronize()
-        assert M._dw_tn("bf16", 640 // grp, 8, grp) == (tn == "1")
+        with config.use(eng.cfg), M.use_scheduler(eng.side):
+            assert M._dw_tn("bf16", 640 // grp, 8, grp) == (tn == "1")
         res[tn] = (eng.loss_value(ls), {k: v.clone() for k, v in eng.flat.G.items()})
     assert res["0"][0] == pytest.approx(res["1"][0], rel=1e-6)
     for k, v in res["0"][1].items():

@@ -1,4 +1,4 @@
-"""Within-process A/B of the GRU recurrence kernels (profiling aid).  CRUSE_GRU_DBG: 0 = shipped,
+"""Within-process A/B of the GRU recurrence kernels (profiling aid).  library option gru_dbg (argv): 0 = shipped,
 9 = force write-through publishes, 1 = no tag waits (wrong results), 2 = also no MFMA."""
 import os, sys, torch
 sys.path.insert(0, '.')
@@ -22,7 +22,7 @@ modes = sys.argv[1:] or ["0", "9"]
 for rnd in range(3):
     out = []
     for m in modes:
-        os.environ["CRUSE_GRU_DBG"] = m
+        ops.set_option("gru_dbg", int(m))
         tf = timeit(lambda: ops.gru_seq_fwd(gi, ws, bs, B, T, G, Hg, "bf16"))
         if int(m) & 16:
             ops.gru_seq_fwd(gi, ws, bs, B, T, G, Hg, "bf16"); torch.cuda.synchronize()
