@@ -207,6 +207,45 @@ __global__ __launch_bounds__(256) void gconv_pointwise_mfma_f16_kernel(GConv<f16
     }
 }
 
+// DEPTHWISE convolution (groups == Cin == Cout, stride 1), either form: TFCM_Block's dilated causal 3x3 (mtfaa.py:174-176) and
+// its data gradient, the depthwise halves of the separable cust_conv blocks.  The general kernel above spends its time on
+// per-element 64-bit index arithmetic and branches (0.3 TB/s on [8,24,161,401]); here a block is one output row chunk of one
+// (image, channel) plane -- no division in the loop, the KH*KW weights of the channel in registers, taps read coalesced along W.
+struct TapTab { int dh[9], dw[9], n; };        // input offset of tap k relative to the output position (either form)
+
+template <typename T>
+__global__ __launch_bounds__(256) void gconv_depthwise_kernel(GConv<T> a, TapTab tt) {
+    const int plane = blockIdx.z, c = plane % a.Cout;
+    const int ho = blockIdx.y;
+    float w[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = k < tt.n ? a.w[c * tt.n + k] : 0.f;
+    const float bias = a.bias ? a.bias[c] : 0.f;
+    const float slope = a.act == 2 ? a.slope[c] : 0.f;
+    const T* xp = a.x + (long long)plane * a.Hin * a.Win;
+    T* yp = a.y + ((long long)plane * a.Hout + ho) * a.Wout;
+    int roff[9];
+    bool rok[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int hi = ho + tt.dh[k];
+        rok[k] = k < tt.n && hi >= 0 && hi < a.Hin;
+        roff[k] = (rok[k] ? hi : 0) * a.Win + tt.dw[k];
+    }
+    for (int wo = threadIdx.x; wo < a.Wout; wo += 256) {
+        float acc = bias;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int wi = wo + tt.dw[k];
+            if (rok[k] && wi >= 0 && wi < a.Win) acc += w[k] * (float)xp[roff[k] + wo];
+        }
+        if (a.act == 1) acc = fmaxf(acc, 0.f);
+        else if (a.act == 2) acc = acc >= 0.f ? acc : slope * acc;
+        if (a.accumulate) acc += (float)yp[wo];
+        yp[wo] = (T)acc;
+    }
+}
+
 // Weight gradient of both forms as ONE contraction:
 //   dw[ca][cb_l][kh][kw] += sum_{n,h,w} S[n,ca,h,w] * Bg[n, g*CBg + cb_l, h*sh - pt + kh*dh, (w*sw - pl + kw*dw) / up_w]
 // Conv2d:          S = dy (ca = co, HxW = output size), Bg = x;   ConvTranspose2d: S = x (ca = ci), Bg = dy.
@@ -307,6 +346,113 @@ __global__ __launch_bounds__(256) void gconv_wgrad_rows_kernel(GWgrad<T> a) {
             atomicAdd(&a.dw[((long long)(ca * cb_g + cb_l) * a.KH + kh) * a.KW + kw], acc);
         }
     }
+}
+
+// Weight gradient of a POINTWISE convolution on the matrix cores (f16 storage): dW[ca][cb] += sum_{n,p} S[n,ca,p] Bg[n,cb,p]
+// with K = positions -- the natural MFMA shape on NCHW: both fragments are 8 consecutive positions of one channel row.  A wave
+// owns a run of positions of one image and keeps the whole [CA x CB] result (MT x NT tiles) in its accumulators; one atomic
+// add per weight and wave at the end.  (Rows of an odd-sized plane are only 2-byte aligned, so the fragments are gathered
+// with 2-byte loads: 16 lanes x 8 x 2 B per channel row, every byte used.)
+template <int MT, int NT>
+__global__ __launch_bounds__(1024) void gconv_wgrad_pw_mfma_f16_kernel(GWgrad<f16> a, int run) {
+    __shared__ float red[MT * NT * 256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;            // 16 waves: enough loads in flight to cover HBM latency
+    const int r = lane & 15, kg = lane >> 4;
+    const long long hw = (long long)a.HS * a.WS;
+    const int runs_img = (int)((hw + run - 1) / run);
+    const int n = blockIdx.x / runs_img;
+    const long long p0 = (long long)(blockIdx.x - n * runs_img) * run, p1 = min(hw, p0 + run);
+    const f16* sp = a.S + (long long)n * a.CA * hw;
+    const f16* bp = a.Bg + (long long)n * a.CB * hw;
+    for (int i = threadIdx.x; i < MT * NT * 256; i += 1024) red[i] = 0.f;
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f16 zero = (f16)0.f;
+    // wave wv takes the 32-position chunks wv, wv + 16, ... of the block's run, two at a time
+    for (long long p = p0 + wv * 32; p < p1; p += 2 * 16 * 32) {
+        f16x8 fa[2][MT], fb[2][NT];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long long pk = p + u * 16 * 32 + kg * 8;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int ca = i * 16 + r;
+                const f16* q = sp + (long long)min(ca, a.CA - 1) * hw + pk;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) fa[u][i][e] = (ca < a.CA && pk + e < p1) ? q[e] : zero;
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int cb = j * 16 + r;
+                const f16* q = bp + (long long)min(cb, a.CB - 1) * hw + pk;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) fb[u][j][e] = (cb < a.CB && pk + e < p1) ? q[e] : zero;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[u][i], fb[u][j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    // acc[i][j][q] = dW[ca = i*16 + kg*4 + q][cb = j*16 + r]: 16 waves -> LDS -> one atomic per weight and block
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) atomicAdd(&red[((i * NT + j) * 16 + kg * 4 + q) * 16 + r], acc[i][j][q]);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < MT * NT * 256; idx += 1024) {
+        const int t = idx >> 8, row = (idx >> 4) & 15, col = idx & 15;
+        const int ca = (t / NT) * 16 + row, cb = (t % NT) * 16 + col;
+        if (ca < a.CA && cb < a.CB) atomicAdd(&a.dw[(long long)ca * a.CB + cb], red[idx]);
+    }
+}
+
+// Weight gradient of a DEPTHWISE convolution: dW[c][kh][kw] += sum_{n,h,w} S[n,c,h,w] Bg[n,c, h*sh - pt + kh*dh, w*sw - pl + kw*dw].
+// A block is a band of rows of one (image, channel) plane; a thread walks W and keeps the KH*KW partial sums in registers.
+template <typename T>
+__global__ __launch_bounds__(256) void gconv_wgrad_depthwise_kernel(GWgrad<T> a, int band, TapTab tt) {
+    __shared__ float red[4][9];
+    const int plane = blockIdx.y, c = plane % a.CA;
+    const int h0 = blockIdx.x * band, h1 = min(a.HS, h0 + band);
+    const T* sp = a.S + (long long)plane * a.HS * a.WS;
+    const T* bp = a.Bg + (long long)plane * a.HB * a.WB;
+    float acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+    for (int h = h0; h < h1; ++h) {
+        int roff[9];
+        bool rok[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int hb = h * a.sh + tt.dh[k];
+            rok[k] = k < tt.n && hb >= 0 && hb < a.HB;
+            roff[k] = (rok[k] ? hb : 0) * a.WB + tt.dw[k];
+        }
+        for (int w = threadIdx.x; w < a.WS; w += 256) {
+            const float sv = (float)sp[h * a.WS + w];
+            const int wb0 = w * a.sw;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int wb = wb0 + tt.dw[k];
+                if (rok[k] && wb >= 0 && wb < a.WB) acc[k] += sv * (float)bp[roff[k] + wb0];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const float v = wave_sum(acc[k]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < tt.n) atomicAdd(&a.dw[c * tt.n + threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // out[c] += sum_{n,hw} x[n,c,hw]   (conv bias gradient)
@@ -526,6 +672,19 @@ int conv2d_nchw_t(const void* x, const float* w, const float* bias, void* y, int
         CRUSE_LAUNCH_CHECK("conv2d_nchw pointwise");
         return CRUSE_OK;
     }
+    if (groups == Cin && Cin == Cout && up_w == 1 && sh == 1 && sw == 1 && KH * KW <= 9 && (long long)B * Cout < 65536 && Hout < 65536 &&
+        (long long)Hin * Win < (1ll << 30) && !cruse_opt("pw_valu", 0)) {
+        TapTab tt = {};
+        tt.n = KH * KW;
+        for (int kh = 0; kh < KH; ++kh)
+            for (int kw = 0; kw < KW; ++kw) {
+                tt.dh[kh * KW + kw] = transposed ? pt - kh * dh : kh * dh - pt;
+                tt.dw[kh * KW + kw] = transposed ? pl - kw * dw : kw * dw - pl;
+            }
+        hipLaunchKernelGGL(gconv_depthwise_kernel<T>, dim3(1, Hout, B * Cout), dim3(256), 0, s, a, tt);
+        CRUSE_LAUNCH_CHECK("conv2d_nchw depthwise");
+        return CRUSE_OK;
+    }
     hipLaunchKernelGGL(gconv_kernel<T>, dim3(gblocks((long long)B * Cout * Hout * Wout, 256, 16384)), dim3(256), 0, s, a);
     CRUSE_LAUNCH_CHECK("conv2d_nchw");
     return CRUSE_OK;
@@ -535,6 +694,34 @@ template <typename T>
 int wgrad_nchw_t(const void* S, const void* Bg, float* dw, int N, int CA, int HS, int WS, int CB, int HB, int WB, int KH, int KW,
                  int sh, int sw, int dh, int dw_, int pt, int pl, int groups, int up_w, hipStream_t s) {
     GWgrad<T> a = {(const T*)S, (const T*)Bg, dw, N, CA, HS, WS, CB, HB, WB, KH, KW, sh, sw, dh, dw_, pt, pl, groups, up_w};
+    const bool fast = !cruse_opt("pw_valu", 0);
+    if constexpr (sizeof(T) == 2) {
+        if (fast && KH == 1 && KW == 1 && groups == 1 && sh == 1 && sw == 1 && pt == 0 && pl == 0 && up_w == 1 && HS == HB && WS == WB &&
+            CA <= 32 && CB <= 32) {
+            const long long hw = (long long)HS * WS;
+            int run = 4096;                                  // positions per 16-wave block (a multiple of 1024)
+            while ((long long)N * cdivl(hw, run) < 512 && run > 1024) run >>= 1;
+            const dim3 grid((unsigned)((long long)N * cdivl(hw, run)));
+            const int mt = cdiv(CA, 16), ntl = cdiv(CB, 16);
+            if (mt == 1 && ntl == 1) hipLaunchKernelGGL((gconv_wgrad_pw_mfma_f16_kernel<1, 1>), grid, dim3(1024), 0, s, a, run);
+            else if (mt == 1) hipLaunchKernelGGL((gconv_wgrad_pw_mfma_f16_kernel<1, 2>), grid, dim3(1024), 0, s, a, run);
+            else if (ntl == 1) hipLaunchKernelGGL((gconv_wgrad_pw_mfma_f16_kernel<2, 1>), grid, dim3(1024), 0, s, a, run);
+            else hipLaunchKernelGGL((gconv_wgrad_pw_mfma_f16_kernel<2, 2>), grid, dim3(1024), 0, s, a, run);
+            CRUSE_LAUNCH_CHECK("conv2d_nchw_wgrad pointwise mfma f16");
+            return CRUSE_OK;
+        }
+    }
+    if (fast && groups == CA && CA == CB && up_w == 1 && KH * KW <= 9 && (long long)N * CA < 65536 && (long long)HB * WB < (1ll << 30)) {
+        int band = 8;
+        while ((long long)N * CA * cdiv(HS, band) < 2048 && band > 1) band >>= 1;
+        TapTab tt = {};
+        tt.n = KH * KW;
+        for (int kh = 0; kh < KH; ++kh)
+            for (int kw = 0; kw < KW; ++kw) { tt.dh[kh * KW + kw] = kh * dh - pt; tt.dw[kh * KW + kw] = kw * dw_ - pl; }
+        hipLaunchKernelGGL(gconv_wgrad_depthwise_kernel<T>, dim3(cdiv(HS, band), N * CA), dim3(256), 0, s, a, band, tt);
+        CRUSE_LAUNCH_CHECK("conv2d_nchw_wgrad depthwise");
+        return CRUSE_OK;
+    }
     const size_t row_lds = ((size_t)CA * WS + (size_t)CB * WB) * sizeof(float);
     if (row_lds <= 150 * 1024 && (long long)N * HS >= 8) {        // a row pair fits LDS (the per-weight kernel below is the fallback)
         int rc = cruse_ensure_dyn_lds((const void*)gconv_wgrad_rows_kernel<T>, row_lds, "conv2d_nchw_wgrad");
