@@ -44,10 +44,11 @@ SIGNATURES = {
     "cruse_bn_act_fwd": ("pppppppqiiip", "i"),
     "cruse_bn_act_bwd_reduce": ("ppppppqiiipip", "i"),
     "cruse_bn_act_bwd_apply": ("pppppppqiiiippppp", "i"),
-    "cruse_ln_fwd": ("ppppppppqiifp", "i"),
+    "cruse_ln_fwd": ("ppppppppqiifiqqp", "i"),
     "cruse_ln_bwd": ("pppppqiipppp", "i"),
     "cruse_gemm": ("iiiiipipipipiiiip", "i"),
     "cruse_gemm_bf16_nt": ("iiipqqpqqpqpiip", "i"),
+    "cruse_gemm_bf16_nt_seg": ("iiippqppqqpqpiiqqp", "i"),
     "cruse_gemm_bf16_tn": ("iiqpqpqiipqip", "i"),
     "cruse_cast_bf16": ("ppqp", "i"),
     "cruse_transpose_bf16": ("pqiqpqip", "i"),

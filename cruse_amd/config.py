@@ -34,13 +34,18 @@ class EngineConfig:
     dw_xcdk: Optional[int] = None   # k-slices of the dW GEMMs pinned to XCDs (None: 8 where there are >= 24 output tiles, else 0)
     conv_bwd_x3: bool = False       # backward-data convolutions as split-bf16 x3 instead of plain bf16
     dw_tn: bool = False             # weight gradients as TN GEMMs on row-major operands (measured slower: 6.35 vs 6.02 ms)
+    fwd_chunks: int = 0             # time chunks of the forward GGRU pipeline: projections / LayerNorm 1 of one chunk run on an
+                                    # auxiliary stream beside the recurrence of another.  OFF (0 / 1): measured 6.11 (2 chunks),
+                                    # 6.20 (3), 6.27 ms (4) against 6.10 -- the 0.33 ms of in-between kernels do disappear from
+                                    # the main stream, but the four recurrence chunks take 1.43 ms instead of 1.21 beside those
+                                    # co-runners (r03 trace: the first layer-1 chunk 459 us for 200 steps)
     lib_options: Dict[str, int] = field(default_factory=dict)       # cruse_set_option(name, value) while this config is active
 
     _ENV = {"overlap": ("CRUSE_OVERLAP", lambda v: v == "1"), "defer_mask": ("CRUSE_DEFER", int), "inline_mask": ("CRUSE_INLINE", int),
             "early_t": ("CRUSE_EARLY_T", int), "fuse_bn_stats": ("CRUSE_FUSE_BN_STATS", lambda v: v != "0"),
             "fuse_dgi": ("CRUSE_FUSE_DGI", lambda v: v == "1"), "fuse_cast": ("CRUSE_FUSE_CAST", lambda v: v == "1"),
             "gi_x3": ("CRUSE_GI_X3", int), "dw_xcdk": ("CRUSE_DW_XCDK", int), "conv_bwd_x3": ("CRUSE_CONV_BWD_X3", lambda v: v == "1"),
-            "dw_tn": ("CRUSE_DW_TN", lambda v: v == "1")}
+            "dw_tn": ("CRUSE_DW_TN", lambda v: v == "1"), "fwd_chunks": ("CRUSE_FWD_CHUNKS", int)}
     _LIB_ENV = {"CRUSE_GRU_BWD_RS": "gru_bwd_rs", "CRUSE_GRU_FWD_LEAN": "gru_fwd_lean", "CRUSE_GRU_WLO": "gru_wlo",
                 "CRUSE_GRU_DBG": "gru_dbg", "CRUSE_GRU_BG": "gru_bg", "CRUSE_CM_GRID": "cm_grid", "CRUSE_CM_NW": "cm_nw",
                 "CRUSE_GB_DEEP_MIN": "gb_deep_min", "CRUSE_GB_DEEP": "gb_deep", "CRUSE_PW_VALU": "pw_valu", "CRUSE_LNB_GRID": "lnb_grid",

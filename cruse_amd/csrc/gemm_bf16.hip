@@ -33,7 +33,17 @@ struct GbArgs {
     int accumulate, splitk, kt_chunk;
     int tiles_m, tiles_n, nunits, inner;
     int xcdk;                                // split-K with the k-slices PINNED to XCDs (see the kernel's tile order)
+    // ROW SEGMENTS on the M side: logical row m of A and C is physical row (m / seg_len) * seg_stride + seg_off + m % seg_len --
+    // frames [seg_off, seg_off + seg_len) of every clip of a [B, T = seg_stride] tensor, i.e. a TIME CHUNK of the batch
+    // (the gate projections of one chunk run beside the recurrence of the previous one).  seg_len == 0: identity.
+    int seg_len; long long seg_stride, seg_off;
 };
+
+__device__ __forceinline__ long long seg_row(const GbArgs& g, int m) {
+    if (g.seg_len == 0) return m;
+    const int q = m / g.seg_len;
+    return (long long)q * g.seg_stride + g.seg_off + (m - q * g.seg_len);
+}
 
 // MODE: C update -- 0 store, 1 read-add-store, 2 atomic add (split-K).
 // NST: LDS stages.  2 = one k-tile of prefetch, two blocks per CU (the short-K products, whose epilogues then
@@ -81,7 +91,7 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_bf16_nt_kernel(con
     for (int i = 0; i < 4; ++i) {
         const int r = (wv * 4 + i) * 8 + (lane >> 3);
         const int ch = (lane & 7) ^ (lane >> 3);
-        ap[i] = g.A + (long long)min(m0 + r, g.M - 1) * g.lda + ch * 8;
+        ap[i] = g.A + seg_row(g, min(m0 + r, g.M - 1)) * g.lda + ch * 8;
         bp[i] = g.B + (long long)min(n0 + r, g.N - 1) * g.ldb + ch * 8;
     }
     auto stage = [&](int v, int buf) {               // v: virtual k-tile index in [0, nvirt)
@@ -182,7 +192,7 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_bf16_nt_kernel(con
             float4 v = *reinterpret_cast<const float4*>(patch + rr * 68 + (lane & 15) * 4);
             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
             if (m < g.M) {
-                float* c = g.C + (long long)m * g.ldc + nq;
+                float* c = g.C + seg_row(g, m) * g.ldc + nq;
                 if (MODE == 2) {
                     if (nq < g.N) atomicAdd(c, v.x);
                     if (nq + 1 < g.N) atomicAdd(c + 1, v.y);
@@ -451,7 +461,11 @@ __global__ __launch_bounds__(256) void ktile_bf16_kernel(const float* x, int row
 
 static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, long long lda, long long a_kstride,
                           const void* B, const void* B_lo, long long ldb, long long b_kstride,
-                          float* C, long long ldc, const float* bias, int accumulate, int splitk, void* stream) {
+                          float* C, long long ldc, const float* bias, int accumulate, int splitk, void* stream,
+                          int seg_len = 0, long long seg_stride = 0, long long seg_off = 0) {
+    CRUSE_REQUIRE(seg_len >= 0 && (seg_len == 0 || (seg_stride >= seg_len && seg_off >= 0 && M % seg_len == 0 && a_kstride == BK)),
+                  CRUSE_E_SHAPE, "gemm_bf16_nt: bad row segments (len %d stride %lld off %lld, M %d; row-major A only)", seg_len,
+                  seg_stride, seg_off, M);
     CRUSE_REQUIRE(M > 0 && N > 0 && K > 0, CRUSE_E_SHAPE, "gemm_bf16_nt: empty shape M=%d N=%d K=%d", M, N, K);
     CRUSE_REQUIRE(K % BK == 0, CRUSE_E_SHAPE, "gemm_bf16_nt: K=%d must be a multiple of %d (pad with zeros)", K, BK);
     CRUSE_REQUIRE(a_kstride >= BK && b_kstride >= BK && ldc >= N, CRUSE_E_SHAPE, "gemm_bf16_nt: strides too small");
@@ -473,6 +487,7 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
     g.b_lo = B_lo ? (const __bf16*)B_lo - (const __bf16*)B : 0;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.a_ks = a_kstride; g.b_ks = b_kstride;
     g.accumulate = accumulate; g.splitk = splitk; g.kt_chunk = kt_chunk;
+    g.seg_len = seg_len; g.seg_stride = seg_stride; g.seg_off = seg_off;
     g.tiles_m = cdiv(M, BM); g.tiles_n = cdiv(N, BN);
     g.xcdk = (xcdk && splitk > 1) ? 1 : 0;
     if (splitk > 1) { g.nunits = splitk * g.tiles_n; g.inner = g.tiles_m; }
@@ -511,6 +526,17 @@ extern "C" int cruse_gemm_bf16_nt(int M, int N, int K, const void* A, long long 
                                   void* stream) {
     return gemm_bf16_impl(M, N, K, A, nullptr, lda, a_kstride, B, nullptr, ldb, b_kstride, C, ldc, bias, accumulate, splitk,
                           stream);
+}
+
+extern "C" int cruse_gemm_bf16_nt_seg(int M, int N, int K, const void* A_hi, const void* A_lo, long long lda,
+                                      const void* B_hi, const void* B_lo, long long ldb, long long b_kstride,
+                                      float* C, long long ldc, const float* bias, int accumulate,
+                                      int seg_len, long long seg_stride, long long seg_off, void* stream) {
+    CRUSE_REQUIRE(seg_len > 0, CRUSE_E_SHAPE, "gemm_bf16_nt_seg: seg_len=%d", seg_len);
+    CRUSE_REQUIRE((A_lo == nullptr || B_lo != nullptr) && ((uintptr_t)A_lo % 16) == 0 && ((uintptr_t)B_lo % 16) == 0, CRUSE_E_ALIGN,
+                  "gemm_bf16_nt_seg: low planes (A_lo needs B_lo; 16-byte aligned)");
+    return gemm_bf16_impl(M, N, K, A_hi, A_lo, lda, BK, B_hi, B_lo, ldb, b_kstride, C, ldc, bias, accumulate, 1, stream, seg_len,
+                          seg_stride, seg_off);
 }
 
 extern "C" int cruse_gemm_bf16x3_nt(int M, int N, int K, const void* A_hi, const void* A_lo, long long lda,

@@ -412,9 +412,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* dy, const floa
 constexpr int LNV_MAXQ = 4;   // H <= 1024
 constexpr int LNV_NR = 2;     // forward; the backward kernel keeps one row per wave in flight (register budget)
 
+struct RowSeg { int len; long long stride, off; };       // logical row r -> (r / len) * stride + off + r % len; len == 0: identity
+__device__ __forceinline__ long long seg_row(const RowSeg& sg, long long r) {
+    if (sg.len == 0) return r;
+    const long long q = r / sg.len;
+    return q * sg.stride + sg.off + (r - q * sg.len);
+}
+
 __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const float* x, const float* gamma, const float* beta,
                                                          const float* res, float* y, __bf16* y_bf, float* mean, float* rstd,
-                                                         long long rows, int H, float eps) {
+                                                         long long rows, int H, float eps, RowSeg sg) {
     const int lane = threadIdx.x & 63, nq = H >> 2;
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long nwave = (long long)gridDim.x * 4;
@@ -430,12 +437,12 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const float* x, const f
         float s[LNV_NR], m[LNV_NR], qq[LNV_NR];
 #pragma unroll
         for (int k = 0; k < LNV_NR; ++k) {
-            const long long r = r0 + k;
+            const long long rl = r0 + k, r = seg_row(sg, rl < rows ? rl : rows - 1);
             s[k] = 0.f;
 #pragma unroll
             for (int e = 0; e < LNV_MAXQ; ++e) {
                 const int q = lane + 64 * e;
-                const bool ok = q < nq && r < rows;
+                const bool ok = q < nq && rl < rows;
                 v[k][e] = ok ? reinterpret_cast<const float4*>(x + r * H)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
                 rv[k][e] = (ok && res) ? reinterpret_cast<const float4*>(res + r * H)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
                 s[k] += (v[k][e].x + v[k][e].y) + (v[k][e].z + v[k][e].w);
@@ -456,9 +463,9 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const float* x, const f
         }
 #pragma unroll
         for (int k = 0; k < LNV_NR; ++k) {
-            const long long r = r0 + k;
             const float rs = 1.0f / sqrtf(wave_sum(qq[k]) / (float)H + eps);
-            if (r >= rows) continue;
+            if (r0 + k >= rows) continue;
+            const long long r = seg_row(sg, r0 + k);
             if (lane == 0) { if (mean) mean[r] = m[k]; if (rstd) rstd[r] = rs; }
 #pragma unroll
             for (int e = 0; e < LNV_MAXQ; ++e) {
@@ -805,7 +812,10 @@ extern "C" int cruse_bn_act_bwd_apply(const float* dout, const float* y, const f
 
 extern "C" int cruse_ln_fwd(const float* x, const float* gamma, const float* beta, const float* res,
                             float* y, void* y_bf16, float* mean, float* rstd, long long rows, int H, int interleave_g,
-                            float eps, void* stream) {
+                            float eps, int seg_len, long long seg_stride, long long seg_off, void* stream) {
+    CRUSE_REQUIRE(seg_len >= 0 && (seg_len == 0 || (seg_stride >= seg_len && seg_off >= 0 && rows % seg_len == 0)), CRUSE_E_SHAPE,
+                  "ln_fwd: bad row segments (len %d stride %lld off %lld, rows %lld)", seg_len, seg_stride, seg_off, rows);
+    const RowSeg sg = {seg_len, seg_stride, seg_off};
     CRUSE_REQUIRE(rows > 0 && H > 0 && H <= 64 * LN_MAXE, CRUSE_E_SHAPE, "ln_fwd: H=%d must be in 1..%d", H, 64 * LN_MAXE);
     CRUSE_REQUIRE(interleave_g >= 1 && H % interleave_g == 0, CRUSE_E_SHAPE, "ln_fwd: groups=%d must divide H=%d", interleave_g, H);
     const bool vec = interleave_g == 1 && H % 4 == 0 && H <= 256 * LNV_MAXQ &&
@@ -813,11 +823,14 @@ extern "C" int cruse_ln_fwd(const float* x, const float* gamma, const float* bet
     const bool bf_inline = vec && y_bf16 && (((uintptr_t)y_bf16 & 7) == 0);
     if (vec)
         hipLaunchKernelGGL(ln_fwd_vec_kernel, dim3(grid_for(rows, 16, 2048)), dim3(256), 0, ST(stream), x, gamma, beta,
-                           res, y, bf_inline ? (__bf16*)y_bf16 : nullptr, mean, rstd, rows, H, eps);
-    else
+                           res, y, bf_inline ? (__bf16*)y_bf16 : nullptr, mean, rstd, rows, H, eps, sg);
+    else {
+        CRUSE_REQUIRE(seg_len == 0, CRUSE_E_SHAPE, "ln_fwd: row segments need the vector form (one group, H %% 4 == 0, aligned)");
         hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid_for(rows, 4, 2048)), dim3(256), 0, ST(stream), x, gamma, beta, res, y,
                            mean, rstd, rows, H, interleave_g, eps);
+    }
     CRUSE_LAUNCH_CHECK("ln_fwd");
+    CRUSE_REQUIRE(seg_len == 0 || !y_bf16 || bf_inline, CRUSE_E_ALIGN, "ln_fwd: row segments need an 8-byte aligned bf16 copy");
     if (y_bf16 && !bf_inline) return cruse_cast_bf16_split(y, y_bf16, nullptr, rows * H, stream);     // interleaved form: one more pass
     return CRUSE_OK;
 }

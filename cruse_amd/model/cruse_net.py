@@ -218,6 +218,119 @@ def ggru_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], prefix: str, group
                              late_leaves=late_leaves, x_bf16=x_bf16)
 
 
+_AUX = {}
+
+
+def _aux_stream():
+    dev = torch.cuda.current_device()
+    if dev not in _AUX:
+        _AUX[dev] = torch.cuda.Stream()
+    return _AUX[dev]
+
+
+def _fwd_chunks(prec, Hg: int, g: int, T: int, slot: int, x_bf16) -> int:
+    """Time chunks of the forward GGRU pipeline (EngineConfig.fwd_chunks; 0 / 1 = off).  Needs the bf16 gate-GEMM path with
+    the operand copies written by the producing kernels (so the projections read row-major bf16 rows: Hg % 64 == 0) and
+    enough frames per chunk to amortise a recurrence launch (its prologue loads the weight slice into registers)."""
+    n = int(config.get().fwd_chunks or 0)
+    if n < 2 or slot != 0 or x_bf16 is None or not _gi_takes_bf16_copy(prec, Hg) or T < 64 * n:
+        return 1
+    return n
+
+
+def _ggru_forward_chunked(x, x_bf16, P, prefix, g, Hg, prec, save, nch, ctx, before_last_launch):
+    """GGRU layers 1 and 2 as a TIME-CHUNK PIPELINE (cruse_gru_seq_fwd_ex: a sequence run as consecutive chunks gives the
+    results of the single launch).  The main stream runs only the recurrences, back to back; an auxiliary stream runs the
+    in-between kernels of one chunk -- the layer-1 projection of the NEXT chunk, then LayerNorm 1 + the layer-2 projection of
+    the chunk the recurrence has just finished -- beside the recurrence of another, on the ~96 CUs a recurrence leaves free
+    (in the forward pass the side stream has little to put there):
+
+        main:  gi1(c0) | rec1(c0) | rec1(c1) | ...      | rec2(c0)          | rec2(c1) | ...
+        aux :           gi1(c1)   | ln1+gi2(c0), gi1(c2) | ... ln1+gi2(c_last) |
+
+    Unchunked, gi1, LayerNorm 1 and gi2 (0.35 ms of the 6.0 ms step, tools/upper_bound_probe.py) sit between the recurrences
+    on the main stream.  Returns (h1, c1, a1, z1, l1, l1_bf, m1, s1, h2, c2, a2, z2)."""
+    B, T, H = x.shape
+    rows = B * T
+    dev = x.device
+    main = torch.cuda.current_stream()
+    aux = _aux_stream()
+    base = T // nch
+    chunks = [(j * base, base if j + 1 < nch else T - j * base) for j in range(nch)]
+    kp = (Hg + 63) // 64 * 64
+    knob = _gi_x3_knob(Hg)
+    # everything the aux stream writes is allocated here, on the main stream
+    gi1 = torch.empty(B, T, g * 3 * Hg, device=dev, dtype=torch.float32)
+    gi2 = torch.empty_like(gi1)
+    l1 = torch.empty(B, T, H, device=dev, dtype=torch.float32)
+    l1_bf = torch.empty(rows * H, device=dev, dtype=torch.bfloat16)
+    m1 = torch.empty(rows, device=dev, dtype=torch.float32) if save else None
+    s1 = torch.empty(rows, device=dev, dtype=torch.float32) if save else None
+    wts = {}
+    for li, lname in enumerate(("gru_list1", "gru_list2")):
+        x3 = (knob >> li) & 1
+        for i in range(g):
+            w_ih = P[f"{prefix}{lname}.{i}.weight_ih_l0"]
+            wts[(lname, i)] = ops.ktile_bf16(w_ih, 3 * Hg, Hg, split=True) if x3 else (ops.ktile_bf16(w_ih, 3 * Hg, Hg), None)
+
+    def proj(lname, inp_bf, gi, c):
+        t0, n = c
+        for i in range(g):
+            w_hi, w_lo = wts[(lname, i)]
+            ops.gemm_bf16_nt_seg(B * n, 3 * Hg, kp, inp_bf, None, i * Hg, H, w_hi, w_lo, 0, 64, gi, i * 3 * Hg, 3 * H, (n, T, t0),
+                                 bias=P[f"{prefix}{lname}.{i}.bias_ih_l0"], b_kstride=3 * Hg * 64)
+
+    def ln1(c, h1):
+        t0, n = c
+        ops.ln_fwd(h1, P[prefix + "ln1.weight"], P[prefix + "ln1.bias"], None, B * n, H, 1, save=save, out=l1, out_bf16=l1_bf,
+                   seg=(n, T, t0), stats=(m1, s1) if save else None)
+
+    def whh(lname):
+        return ([P[f"{prefix}{lname}.{i}.weight_hh_l0"] for i in range(g)], [P[f"{prefix}{lname}.{i}.bias_hh_l0"] for i in range(g)])
+
+    def ev_on(stream):
+        e = torch.cuda.Event()
+        e.record(stream)
+        return e
+
+    w1, b1 = whh("gru_list1")
+    w2, b2 = whh("gru_list2")
+    proj("gru_list1", x_bf16, gi1, chunks[0])
+    start = ev_on(main)                                   # x_bf16 and the K-tiled weights are complete
+    aux.wait_event(start)
+    out1 = None
+    e_p = {}                                              # layer-1 projection of chunk j done (aux)
+    e_q = {}                                              # LayerNorm 1 + layer-2 projection of chunk j done (aux)
+    for j, c in enumerate(chunks):
+        if j > 0:
+            main.wait_event(e_p[j])
+        if j == 0:
+            out1 = SIDE.release_around(lambda: ops.gru_seq_fwd(gi1, w1, b1, B, T, g, Hg, prec, save=save, chunk=c))
+        else:
+            ops.gru_seq_fwd(gi1, w1, b1, B, T, g, Hg, prec, save=save, out=out1, chunk=c)
+        e_r = ev_on(main)
+        with torch.cuda.stream(aux):
+            if j + 1 < nch:
+                proj("gru_list1", x_bf16, gi1, chunks[j + 1])
+                e_p[j + 1] = ev_on(aux)
+            aux.wait_event(e_r)                           # h1 of chunk j is complete
+            ln1(c, out1[0])
+            proj("gru_list2", l1_bf, gi2, c)
+            e_q[j] = ev_on(aux)
+    out2 = None
+    for j, c in enumerate(chunks):
+        main.wait_event(e_q[j])
+        last = j + 1 == nch
+        launch = (lambda c=c: ops.gru_seq_fwd(gi2, w2, b2, B, T, g, Hg, prec, save=save, out=out2, chunk=c))
+        # the leaves of layer 1 (the operand transposes read ALL of h1 and l1) are queued for the LAST chunk's launch
+        if last:
+            before_last_launch(out1[0], l1, l1_bf)
+        out2_ = SIDE.release_around(launch) if last else launch()
+        out2 = out2 if out2 is not None else out2_
+    ctx["fwd_chunks"] = nch
+    return out1 + (l1, l1_bf, m1, s1) + out2
+
+
 def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=None, slot=0, xcd_rot=0, pre_done=None,
                       residual_ready=None, late_leaves=None, x_bf16=None):
     """residual_ready(): called right before the residual is read (the last layer norm) -- the caller may still be
@@ -268,9 +381,6 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
         return SIDE.release_around(lambda: ops.gru_seq_fwd(gi, w_hh, b_hh, B, T, g, Hg, prec, save=save, slot=slot,
                                                            xcd_rot=xcd_rot))
 
-    h1, c1, a1, z1 = layer(x, "gru_list1", x_bf16)
-    l1_bf = torch.empty(rows * H, device=x.device, dtype=torch.bfloat16) if _gi_takes_bf16_copy(prec, Hg) else None
-    l1, m1, s1 = ops.ln_fwd(h1, P[prefix + "ln1.weight"], P[prefix + "ln1.bias"], None, rows, H, g, save=save, out_bf16=l1_bf)
     # The K-tiled time-major bf16 copies of x, h1, l1, h2 -- the K operands of the four weight-gradient GEMMs -- depend on
     # the forward pass only.  From the first backward recurrence on, the side streams' queue is what the optimizer step
     # waits for, while in the forward pass they idle: three of the copies are made beside the second forward recurrence,
@@ -278,19 +388,25 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
     fwd_T = save and fast and SIDE.enabled and slot == 0 and config.get().early_t >= 2
     tn = _dw_tn(prec, Hg, B, g)
     ctx["tn"] = tn
-    if tn:                                       # the TN weight-gradient GEMMs read the layer inputs row-major (bf16 copy if made)
-        ctx["in_bf"] = {"gru_list1": x_bf16, "gru_list2": l1_bf}
-    if fwd_T:
+    tt = {}
+
+    def queue_layer1_leaves(h1, l1, l1_bf):
+        """queued for the (last) launch of the second forward recurrence"""
+        if tn:                                   # the TN weight-gradient GEMMs read the layer inputs row-major (bf16 copy if made)
+            ctx["in_bf"] = {"gru_list1": x_bf16, "gru_list2": l1_bf}
+        if not fwd_T:
+            return
         ldT = (rows + 63) // 64 * 64
         if not tn:
-            xT, h1T, l1T, h2T = (torch.empty(ldT // 64, H, 64, device=x.device, dtype=torch.bfloat16) for _ in range(4))
+            tt["xT"], tt["h1T"], tt["l1T"], tt["h2T"] = (torch.empty(ldT // 64, H, 64, device=x.device, dtype=torch.bfloat16)
+                                                         for _ in range(4))
         w_ts = {}                                # K-tiled W_ih^T of both layers: the B operand of the backward dX GEMMs
 
         def t_layer1(x=x, h1=h1, l1=l1):
             if not tn:
-                ops.transpose_bf16(x, rows, H, out=xT)
-                ops.transpose_bf16(h1, rows, H, shift_T=T, out=h1T)
-                ops.transpose_bf16(l1, rows, H, out=l1T)
+                ops.transpose_bf16(x, rows, H, out=tt["xT"])
+                ops.transpose_bf16(h1, rows, H, shift_T=T, out=tt["h1T"])
+                ops.transpose_bf16(l1, rows, H, out=tt["l1T"])
             for lname in ("gru_list1", "gru_list2"):
                 for i in range(g):
                     w_ts[(lname, i)] = ops.transpose_bf16(P[f"{prefix}{lname}.{i}.weight_ih_l0"], 3 * Hg, Hg)
@@ -298,19 +414,31 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
         if tn:
             SIDE.defer(t_layer1, kind=1, lane=2)
         else:
-            SIDE.defer(t_layer1, x, h1, l1, xT, h1T, l1T, kind=1, lane=2)
-    h2, c2, a2, z2 = layer(l1, "gru_list2", l1_bf)
+            SIDE.defer(t_layer1, x, h1, l1, tt["xT"], tt["h1T"], tt["l1T"], kind=1, lane=2)
+
+    nch = _fwd_chunks(prec, Hg, g, T, slot, x_bf16)
+    if nch > 1:
+        h1, c1, a1, z1, l1, l1_bf, m1, s1, h2, c2, a2, z2 = _ggru_forward_chunked(x, x_bf16, P, prefix, g, Hg, prec, save, nch, ctx,
+                                                                                  queue_layer1_leaves)
+    else:
+        h1, c1, a1, z1 = layer(x, "gru_list1", x_bf16)
+        l1_bf = torch.empty(rows * H, device=x.device, dtype=torch.bfloat16) if _gi_takes_bf16_copy(prec, Hg) else None
+        l1, m1, s1 = ops.ln_fwd(h1, P[prefix + "ln1.weight"], P[prefix + "ln1.bias"], None, rows, H, g, save=save, out_bf16=l1_bf)
+        queue_layer1_leaves(h1, l1, l1_bf)
+        h2, c2, a2, z2 = layer(l1, "gru_list2", l1_bf)
     if residual_ready is not None:
         residual_ready()
     out, m2, s2 = ops.ln_fwd(h2, P[prefix + "ln2.weight"], P[prefix + "ln2.bias"], residual, rows, H, 1, save=save, out=out)
     if fwd_T and not tn:
+        h2T = tt["h2T"]
+
         def t_h2(h2=h2):
             ops.transpose_bf16(h2, rows, H, shift_T=T, out=h2T)
         if late_leaves is not None:
             late_leaves.append((t_h2, (h2, h2T)))
         else:
             SIDE.defer(t_h2, h2, h2T, kind=1, lane=2)
-        ctx.update(T1=(xT, h1T), T2=(l1T, h2T))
+        ctx.update(T1=(tt["xT"], tt["h1T"]), T2=(tt["l1T"], h2T))
     if save:
         ctx.update(h1=h1, c1=c1, a1=a1, z1=z1, l1=l1, m1=m1, s1=s1,
                    h2=h2, c2=c2, a2=a2, z2=z2, m2=m2, s2=s2)

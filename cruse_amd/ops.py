@@ -308,14 +308,21 @@ def bn_act_bwd(dout, y, mean, rstd, gamma, beta, rows, C, F, relu, training, dga
 
 
 # ---------------------------------------------------------------- LayerNorm
-def ln_fwd(x, gamma, beta, res, rows, H, interleave_g=1, eps=1e-5, save=True, out=None, out_bf16=None):
+def ln_fwd(x, gamma, beta, res, rows, H, interleave_g=1, eps=1e-5, save=True, out=None, out_bf16=None, seg=None, stats=None):
+    """seg = (seg_len, seg_stride, seg_off): only the rows of one time chunk (cruse_ln_fwd row segments; rows = B * seg_len),
+    into the full-size out / out_bf16 / stats = (mean, rstd) of the call that owns them."""
     y = torch.empty_like(x) if out is None else out
-    mean = torch.empty(rows, device=x.device, dtype=torch.float32) if save else None
-    rstd = torch.empty(rows, device=x.device, dtype=torch.float32) if save else None
+    if stats is not None:
+        mean, rstd = stats
+    else:
+        nstat = x.numel() // H
+        mean = torch.empty(nstat, device=x.device, dtype=torch.float32) if save else None
+        rstd = torch.empty(nstat, device=x.device, dtype=torch.float32) if save else None
+    sl, ss, so = seg if seg is not None else (0, 0, 0)
     if out_bf16 is not None and (out_bf16.dtype != torch.bfloat16 or out_bf16.numel() < x.numel()):
         raise RuntimeError("ln_fwd: out_bf16 must be a bf16 tensor of at least x.numel() elements")
     check(lib.cruse_ln_fwd(_p(x), _p(gamma), _p(beta), _p(res), _p(y), _p(out_bf16), _p(mean), _p(rstd), rows, H, interleave_g,
-                           eps, _stream()))
+                           eps, sl, ss, so, _stream()))
     return y, mean, rstd
 
 
@@ -345,6 +352,16 @@ def gemm_bf16_nt(M, N, K, A, a_off, lda, Bm, b_off, ldb, C, c_off, ldc, bias=Non
         raise RuntimeError("gemm_bf16_nt needs bf16 operands and an f32 result")
     check(lib.cruse_gemm_bf16_nt(M, N, K, A.data_ptr() + 2 * a_off, lda, a_kstride, Bm.data_ptr() + 2 * b_off, ldb, b_kstride,
                                  C.data_ptr() + 4 * c_off, ldc, _p(bias), 1 if accumulate else 0, splitk, _stream()))
+
+
+def gemm_bf16_nt_seg(M, N, K, A_hi, A_lo, a_off, lda, B_hi, B_lo, b_off, ldb, C, c_off, ldc, seg, bias=None, accumulate=False,
+                     b_kstride=64):
+    """gemm_bf16_nt / gemm_bf16x3_nt (A_lo / B_lo None: plain bf16) on the rows of ONE TIME CHUNK: seg = (seg_len, seg_stride,
+    seg_off), M = B * seg_len (cruse_gemm_bf16_nt_seg)."""
+    lo = lambda t_, off: None if t_ is None else t_.data_ptr() + 2 * off
+    check(lib.cruse_gemm_bf16_nt_seg(M, N, K, A_hi.data_ptr() + 2 * a_off, lo(A_lo, a_off), lda, B_hi.data_ptr() + 2 * b_off,
+                                     lo(B_lo, b_off), ldb, b_kstride, C.data_ptr() + 4 * c_off, ldc, _p(bias),
+                                     1 if accumulate else 0, seg[0], seg[1], seg[2], _stream()))
 
 
 def cast_bf16(x, out=None):

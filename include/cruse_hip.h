@@ -183,10 +183,13 @@ int cruse_bn_act_bwd_apply(const float* dout, const float* y, const float* mean,
 /* y[row, P(c)] = (x[row,c]-mean)*rstd*gamma[P(c)] + beta[P(c)] (+ res[row,P(c)])
  * P(i*Hg + j) = j*g + i with Hg = H/g is the stack(dim=-1)+flatten of cruse_net.py:43-45
  * (interleave_g = g; 1 = identity / the plain cat of :49-50). eps = 1e-5.
- * y_bf16 (nullable): also a bf16 copy of y [rows, H] (the next gate GEMM's operand). */
+ * y_bf16 (nullable): also a bf16 copy of y [rows, H] (the next gate GEMM's operand).
+ * seg_len > 0 (interleave_g == 1): ROW SEGMENTS -- logical row r of every row-indexed array is physical row
+ * (r / seg_len) * seg_stride + seg_off + r % seg_len: frames [seg_off, seg_off + seg_len) of every clip of [B, T = seg_stride]
+ * tensors, i.e. one TIME CHUNK of the batch (run beside the recurrence of the next chunk); rows = B * seg_len. */
 int cruse_ln_fwd(const float* x, const float* gamma, const float* beta, const float* res,
                  float* y, void* y_bf16, float* mean, float* rstd, long long rows, int H, int interleave_g,
-                 float eps, void* stream);
+                 float eps, int seg_len, long long seg_stride, long long seg_off, void* stream);
 int cruse_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                  const float* gamma, long long rows, int H, int interleave_g,
                  float* dx, float* dgamma, float* dbeta, void* stream);
@@ -220,6 +223,14 @@ int cruse_gemm_bf16_nt(int M, int N, int K, const void* A, long long lda, long l
  * pinned to XCDs and added atomically (C must hold the running sum / zeros). */
 int cruse_gemm_bf16_tn(int M, int N, long long K, const void* A, long long lda, const void* B, long long ldb,
                        int b_is_f32, int b_shift_T, float* C, long long ldc, int splitk, void* stream);
+/* cruse_gemm_bf16_nt / cruse_gemm_bf16x3_nt (A_lo, B_lo nullable: plain bf16) on a TIME CHUNK of the batch: logical row m of A
+ * (row-major, lda) and of C is physical row (m / seg_len) * seg_stride + seg_off + m % seg_len; M = B * seg_len.  The gate
+ * projection gi = x W_ih^T of frames [seg_off, seg_off + seg_len) of every clip then runs beside the recurrence of the
+ * frames before them (model/cruse_net.py:44,50 chunked in time; results identical to the unchunked call). */
+int cruse_gemm_bf16_nt_seg(int M, int N, int K, const void* A_hi, const void* A_lo, long long lda,
+                           const void* B_hi, const void* B_lo, long long ldb, long long b_kstride,
+                           float* C, long long ldc, const float* bias, int accumulate,
+                           int seg_len, long long seg_stride, long long seg_off, void* stream);
 /* y[i] = bf16(x[i]), n % 4 == 0 */
 int cruse_cast_bf16(const float* x, void* y, long long n, void* stream);
 /* K-tiling without transposition: y[(k/64)*rows*64 + n*64 + k%64] = bf16(x[n*ld + k]), zero for cols <= k < ceil64(cols):

@@ -263,3 +263,34 @@ def test_two_engines_in_one_process_do_not_share_scheduler_state():
     assert not engs[1].side.streams and engs[0].side.streams    # the engine without overlap never touched a side stream
     assert losses[0] == pytest.approx(losses[1], rel=1e-5)
     assert rel_l2(engs[0].flat.params, engs[1].flat.params) < 1e-5
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_forward_time_chunk_pipeline_is_the_same_computation(graph):
+    """EngineConfig.fwd_chunks: the GGRU forward as a time-chunk pipeline (recurrence chunks on the main stream, the projections /
+    LayerNorm 1 of other chunks on an auxiliary stream; cruse_gru_seq_fwd_ex, cruse_gemm_bf16_nt_seg, cruse_ln_fwd row segments)
+    computes exactly what the unchunked schedule computes: same mask bit for bit, same loss, same gradients up to the
+    summation order of the split-K weight-gradient GEMMs; eager and captured into the HIP graph."""
+    from cruse_amd.config import EngineConfig
+    from cruse_amd.data import synth_batch
+    from cruse_amd.engine import TrainEngine
+    from cruse_amd.model.cruse_net import unet_2
+    from cruse_amd import ops
+    noisy, clean = synth_batch(16, 32000, "cuda", 4)            # T = 201 frames
+    res = {}
+    for nch in (0, 2, 3):
+        torch.manual_seed(5)
+        eng = TrainEngine(unet_2(rnn_groups=1, precision="bf16").cuda(), use_graph=graph, config=EngineConfig(fwd_chunks=nch))
+        ls = eng.step(noisy, clean)                             # (graph mode: capture + first replay)
+        torch.cuda.synchronize()
+        first = (eng.loss_value(ls), eng._last_mask.clone(), eng.flat.grads.clone())
+        ls = eng.step(noisy, clean)
+        torch.cuda.synchronize()
+        res[nch] = first + (eng.loss_value(ls), eng.flat.params.clone())
+        assert eng.skipped_steps() == 0 and ops.gru_status() == 0
+    for nch in (2, 3):
+        # the first step starts from identical parameters: the forward pass must agree bit for bit
+        assert torch.equal(res[nch][1], res[0][1]), f"mask differs with {nch} chunks"
+        assert res[nch][0] == res[0][0]
+        assert rel_l2(res[nch][2], res[0][2]) < 1e-5               # (split-K atomics order in the weight-gradient GEMMs)
+        assert res[nch][3] == pytest.approx(res[0][3], rel=1e-5) and rel_l2(res[nch][4], res[0][4]) < 2e-3      # (Adam moves noise-level entries by +-lr)
