@@ -265,7 +265,7 @@ def test_two_engines_in_one_process_do_not_share_scheduler_state():
     assert rel_l2(engs[0].flat.params, engs[1].flat.params) < 1e-5
 
 
-@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("graph", [False, True])          # (graph mode: the pipeline is not captured -- the step is the unchunked one)
 def test_forward_time_chunk_pipeline_is_the_same_computation(graph):
     """EngineConfig.fwd_chunks: the GGRU forward as a time-chunk pipeline (recurrence chunks on the main stream, the projections /
     LayerNorm 1 of other chunks on an auxiliary stream; cruse_gru_seq_fwd_ex, cruse_gemm_bf16_nt_seg, cruse_ln_fwd row segments)
