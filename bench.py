@@ -114,10 +114,8 @@ def parity_figure(model, groups: int, prec: str, B: int = 8, T: int = 401):
 def profile_avg_ns(kernel_substr: str):
     """average in-graph duration of a kernel from the newest committed rocprofv3 kernel-stats CSV (profiles/)."""
     import csv, glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_kernel_stats*.csv")))
-    for f in reversed(files):
-        if "r02" not in os.path.basename(f):
-            continue
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_kernel_stats_final.csv")))
+    for f in reversed(files):                       # newest round first
         with open(f) as fh:
             for r in csv.DictReader(fh):
                 if kernel_substr in r["Name"]:
@@ -232,10 +230,10 @@ class KernelTimer:
 
 def _pmc_file():
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for name in ("r02_pmc_hbm_traffic.csv", "r01_pmc_hbm_traffic.csv"):
+    for name in ("r03_pmc_hbm_traffic.csv", "r02_pmc_hbm_traffic.csv", "r01_pmc_hbm_traffic.csv"):
         if os.path.exists(os.path.join(d, name)):
             return os.path.join(d, name)
-    return os.path.join(d, "r02_pmc_hbm_traffic.csv")
+    return os.path.join(d, "r03_pmc_hbm_traffic.csv")
 
 
 PMC_FILE = _pmc_file()
