@@ -231,6 +231,7 @@ class TrainEngine:
         # per-step health words [time-out, non-finite loss]: decided on the device, all-reduced (MAX) over the ranks, so
         # that every replica takes the SAME skip decision (a rank-local skip would let the replicas drift apart for good)
         self._health = torch.zeros(2, device=dev, dtype=torch.int32)
+        self._timeouts_seen = 0
         self._norms: Dict[Tuple[int, ...], float] = {}           # input shape -> loss normalisation of that shape
         self._loss_acc = torch.zeros(1, device=dev, dtype=torch.float64)
         self._loss_steps = 0
@@ -529,16 +530,20 @@ class TrainEngine:
     def nonfinite_steps(self) -> int:
         return int(self._skipped[2].item())
 
-    def check_health(self) -> None:
-        """Raise (CRUSE_E_TIMEOUT) if a GRU hand-off timed out in any step since the engine was built -- those steps were
-        skipped by the guarded Adam on every rank.  The decision is taken from the all-reduced counter, so all ranks of a
-        data-parallel job raise together (no rank is left waiting in a collective)."""
-        n = self.timeout_steps()
-        if n:
-            raise RuntimeError(f"cruse_hip error -5 (CRUSE_E_TIMEOUT): a GRU hand-off timed out in {n} step(s) -- the "
-                               "persistent recurrence kernel's workgroups were not co-resident (another process or kernel "
-                               "holding CUs?); the affected optimizer steps were skipped on every rank")
+    def check_health(self, max_new_timeouts: int = 0) -> int:
+        """Steps in which a GRU hand-off timed out SINCE THE LAST CALL (those steps were skipped by the guarded Adam on every
+        rank, so the parameters are intact); raises CRUSE_E_TIMEOUT when there are more than `max_new_timeouts` of them.  The
+        count comes from the all-reduced health words, so all ranks of a data-parallel job see the same number and raise
+        together (no rank is left waiting in a collective)."""
+        total = self.timeout_steps()
+        new = total - self._timeouts_seen
+        self._timeouts_seen = total
+        if new > max_new_timeouts:
+            raise RuntimeError(f"cruse_hip error -5 (CRUSE_E_TIMEOUT): a GRU hand-off timed out in {new} step(s) since the last "
+                               "health check -- the persistent recurrence kernel's workgroups were not co-resident (another "
+                               "process or kernel holding CUs?); the affected optimizer steps were skipped on every rank")
         ops.check_gru_status()                   # a word set outside step() (inference, eval_loss)
+        return new
 
     # -- optimizer state in torch.optim.Adam layout ------------------------------------------------------------------
     def optimizer_state_dict(self) -> dict:

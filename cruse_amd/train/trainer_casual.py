@@ -55,6 +55,7 @@ class Trainer:
         va = config["trainer"].get("validation", {})
         self.epochs = tr["epochs"]
         self.save_checkpoint_interval = tr.get("save_checkpoint_interval", 1)
+        self.max_gru_timeouts_per_epoch = int(config["meta"].get("max_gru_timeouts_per_epoch", 0))
         self.clip_grad_norm_value = tr.get("clip_grad_norm_value", None)
         assert self.save_checkpoint_interval >= 1, \
             "Check the 'save_checkpoint_interval' parameter in the config. It should be large than one."   # base_trainer.py:76
@@ -146,8 +147,10 @@ class Trainer:
         finally:
             gc.enable()
         mean = self.engine.mean_loss(reset=True)                         # one synchronisation per epoch
-        self.engine.check_health()                                       # raises on a GRU hand-off time-out
         skipped = self.engine.skipped_steps()
+        # a timed-out step was skipped on every rank (parameters intact): tolerated up to [meta] max_gru_timeouts_per_epoch
+        # (default 0), checked AFTER the epoch's checkpoint is written (train())
+        self._pending_health = True
         dt = time.time() - t0
         if self.rank == 0:
             note = f"  ({skipped} optimizer steps skipped so far: non-finite loss / gradient)" if skipped else ""
@@ -179,6 +182,11 @@ class Trainer:
             self._train_epoch(epoch)
             if self.rank == 0 and epoch % self.save_checkpoint_interval == 0:
                 self._save_checkpoint(epoch)
+            if getattr(self, "_pending_health", False):
+                self._pending_health = False
+                new = self.engine.check_health(self.max_gru_timeouts_per_epoch)      # raises on EVERY rank together
+                if new and self.rank == 0:
+                    print(f"[epoch {epoch}] {new} step(s) skipped on all ranks after a GRU hand-off time-out")
             if self.rank == 0 and epoch % self.validation_interval == 0 and self.validation_dataloader is not None:
                 self.model.eval()
                 score = self._validation_epoch(epoch)

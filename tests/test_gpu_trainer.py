@@ -217,6 +217,10 @@ def test_engine_latches_timeout_per_step_and_mean_loss_per_shape(graph):
     assert not torch.equal(eng.flat.params, p0) and eng.skipped_steps() == 1
     with pytest.raises(RuntimeError, match="CRUSE_E_TIMEOUT"):
         eng.check_health()
+    assert eng.check_health() == 0                                      # only NEW time-outs count: the next check is clean
+    word.copy_(torch.tensor([1, 0, 0, 0], dtype=torch.uint8))
+    eng.step(*a)
+    assert eng.check_health(max_new_timeouts=1) == 1                    # tolerated (trainer: [meta] max_gru_timeouts_per_epoch)
 
 
 def test_engine_caches_one_graph_per_input_shape():
