@@ -877,6 +877,279 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
 }
 
 // ---------------------------------------------------------------------------------
+// forward, WIDE-CHAIN form of the lean kernel: 16 clips per chain (the full N of the 16x16x32 MFMA -- the lean kernel's
+// chains of 8 leave half of every MFMA's columns empty).  A batch of 64 then needs 4 chains x Hg/32 workgroups = 80 CUs
+// instead of 160: the plan for batches whose chains of 8 exceed the CUs (make_plan), and two such recurrences fit on the
+// chip side by side (cruse_gru_seq_fwd_ex, chain_clips = 16 with xcd_rot 0 / 4: 948 us for the pair, tools/gru_pair_probe.py).
+// A workgroup has twice the lean kernel's hand-off bytes, gate math and saves per step; to keep the per-THREAD work where
+// the lean kernel has it the workgroup has EIGHT compute waves: wave = (K group kg = wave & 3, tile half mg = wave >> 2)
+// owns k-steps kg + 4*i of the three tiles {gate*2 + mg}: 3*NKW MFMAs and 12*NKW weight registers per wave, NS = Hg/128
+// coalesced sweep loads and ONE (clip, unit) of gate math per thread -- plus the helper wave (gi ring, saves).
+// 9 waves = 3 on one SIMD: <= 168 registers per lane.  Arithmetic and summation order are the lean kernel's: results are
+// bit-identical.  Measured alone (B = 64, Hg = 640): 2.25 us per step against the lean kernel's 1.49 -- the sweep is
+// 40 KB per workgroup and step at the ~35 B/clk a CU gets from its L2 with sc1 loads (+0.24 us), the LDS traffic doubles
+// (100 KB per step).  A second form that loaded the MFMA B fragments straight from the granule panel into registers (no
+// LDS image, one barrier per step, four compute waves) ran at 3.5 us: a lane's 32 bytes sit 2560 bytes from its
+// neighbour's, and uncoalesced 16-byte loads cost far more than the LDS round trip they save.
+// CRUSE_PREC_BF16, Hg % 128 == 0, Hg <= 640.
+// ---------------------------------------------------------------------------------
+template <int NKW>
+__global__ __launch_bounds__(576) void gru_fwd_w16_kernel(GruArgs a) {
+    constexpr int NS = NKW, NT = 512;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ __attribute__((aligned(16))) float gi_r[4][16][96];        // gi ring: slot = t & 3, [clip][gate*32 + unit]
+    __shared__ __attribute__((aligned(16))) float sv_l[2][6][16][32];     // saves of step t in parity t & 1
+    const int Hg = a.Hg, H = a.G * Hg, LD = Hg + 8;
+    __bf16* hB = reinterpret_cast<__bf16*>(smem_raw);                    // [16][LD]  B operand (h_{t-1})
+    float* red = reinterpret_cast<float*>(hB + 16 * LD);                  // [4 K groups][6 tiles][64 lanes][4]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int chain, part;
+    if (!claim_chain(a, a.P, chain, part)) return;
+    const int grp = chain % a.G, bgi = a.bg_off + chain / a.G;
+    const int b0 = bgi * 16, nb = min(16, a.B - b0);
+    const int u0 = part * U;
+    const float* W = a.p.w_hh[grp];
+    const float* bh = a.p.b_hh[grp];
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.xg, 0, a.xg_bytes, 0x00020000);
+    const unsigned panel_bytes = (unsigned)(16 * Hg) * 4u;             // bf16-pair granules: 4 B per value
+    const unsigned cbase = (unsigned)chain * 2u * panel_bytes;
+
+    for (int i = tid; i < 16 * LD; i += 576) hB[i] = (__bf16)0.f;
+
+    const unsigned frame_bytes = (unsigned)H * 4u, grow_bytes = (unsigned)(a.G * 3 * Hg) * 4u, crow_bytes = grow_bytes >> 1;
+    const long long nrow = (long long)(a.B - 1) * a.TS + a.T;           // rows reachable from the (advanced) base pointers
+    const unsigned tot_h = (unsigned)min(nrow * H * 4, 0xffffffffll);
+    const unsigned tot_g = (unsigned)min(nrow * a.G * 3 * Hg * 4, 0xffffffffll);
+    const __amdgpu_buffer_rsrc_t rs_gi = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gi), 0, tot_g, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(a.h, 0, tot_h, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_an = __builtin_amdgcn_make_buffer_rsrc(a.an, 0, a.an ? tot_h : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(a.z, 0, a.z ? tot_h : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_cf = __builtin_amdgcn_make_buffer_rsrc(a.coef, 0, a.coef ? tot_g >> 1 : 0u, 0x00020000);
+    const bool save = a.coef != nullptr;
+    const bool has_h0 = a.h0 != nullptr;
+
+    if (wv == 8) {
+        // ---- helper wave: gi rows four steps ahead into the LDS ring; the saves of step t-1 from LDS to HBM ----------
+        // gi: 16 clips x 3 gates x 8 chunks of 4 floats = 384 lane-loads per step (6 instructions)
+        unsigned gv[6], gdst[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int idx = lane + 64 * i, cl = idx / 24, rem = idx % 24, gate = rem >> 3, chk = rem & 7;
+            gv[i] = (unsigned)((((long long)(b0 + (cl < nb ? cl : 0)) * a.TS * a.G + grp) * 3 * Hg + gate * Hg + u0 + 4 * chk) * 4);
+            gdst[i] = (unsigned)(cl * 96 + gate * 32 + chk * 4);
+        }
+        // h / a_n / z rows: 16 clips x 8 chunks of 4 floats (2 stores each); coefficient rows: 16 x 3 gates x 4 chunks of 8 bf16
+        unsigned hv[2], hsrc[2];
+        bool rok[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = lane + 64 * i, lc = idx >> 3, lq = idx & 7;
+            rok[i] = lc < nb;
+            hv[i] = (unsigned)(((long long)(b0 + (rok[i] ? lc : 0)) * a.TS * H + grp * Hg + u0 + 4 * lq) * 4);
+            hsrc[i] = (unsigned)(lc * 32 + 4 * lq);
+        }
+        unsigned cv[3], csrc[3];
+        bool cok[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int idx = lane + 64 * i, cl = idx / 12, rem = idx % 12, gate = rem >> 2, chk = rem & 3;
+            cok[i] = cl < nb;
+            cv[i] = (unsigned)((((long long)(b0 + (cl < nb ? cl : 0)) * a.TS * a.G + grp) * 3 * Hg + gate * Hg + u0 + 8 * chk) * 2);
+            csrc[i] = (unsigned)(((1 + gate) * 16 + cl) * 32 + chk * 8);
+        }
+        struct GiSet { u32x4 v[6]; };
+        auto issue = [&](int t, GiSet& o) {
+            const unsigned so = (unsigned)min(t, a.T - 1) * grow_bytes;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) o.v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_gi, gv[i], so, 0);
+        };
+        auto put = [&](int t, const GiSet& o) {
+            float* d = &gi_r[t & 3][0][0];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) *reinterpret_cast<u32x4*>(d + gdst[i]) = o.v[i];
+        };
+        auto flush = [&](int t) {                       // saves of step t from parity t & 1
+            const float* sl = &sv_l[t & 1][0][0][0];
+            const unsigned so = (unsigned)t * frame_bytes, sc = (unsigned)t * crow_bytes;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (rok[i]) {
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(sl + 0 * 512 + hsrc[i]), rs_h, hv[i], so, 0);
+                    if (save) {
+                        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(sl + 4 * 512 + hsrc[i]), rs_an, hv[i], so, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(sl + 5 * 512 + hsrc[i]), rs_z, hv[i], so, 0);
+                    }
+                }
+            }
+            if (save) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    if (cok[i]) {
+                        const float4 p0 = *reinterpret_cast<const float4*>(sl + csrc[i]);
+                        const float4 p1 = *reinterpret_cast<const float4*>(sl + csrc[i] + 4);
+                        const u32x4 w = {pack2(p0.x, p0.y), pack2(p0.z, p0.w), pack2(p1.x, p1.y), pack2(p1.z, p1.w)};
+                        __builtin_amdgcn_raw_buffer_store_b128(w, rs_cf, cv[i], sc, 0);
+                    }
+                }
+            }
+        };
+        GiSet s0, s1;
+        issue(0, s0); issue(1, s1);
+        put(0, s0); put(1, s1);
+        issue(2, s0); issue(3, s1);
+        if (has_h0) __syncthreads();                    // mirrors the compute waves' barrier before the h0 panel fill
+        (void)team_shares_xcd(a.xid + (size_t)chain * 64, a.P, part, a.status, tid);   // mirrors the compute waves' barriers
+        __syncthreads();
+        for (int t = 0; t < a.T; t += 2) {
+            if (t > 0 || has_h0) __syncthreads();
+            put(t + 2, s0); issue(t + 4, s0);
+            if (t > 0) flush(t - 1);
+            if (t > 0 || has_h0) __syncthreads();
+            if (t + 1 >= a.T) break;
+            __syncthreads();
+            put(t + 3, s1); issue(t + 5, s1);
+            flush(t);
+            __syncthreads();
+        }
+        __syncthreads();                                // the last step's saves are in LDS
+        flush(a.T - 1);
+        return;
+    }
+
+    const int kg = wv & 3, mg = wv >> 2;
+    // resident weight fragments: tile jj of this wave = gate jj, unit half mg; k-steps ks = kg + 4*i
+    bf16x8 wf[3][NKW];
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+        const int row = jj * Hg + u0 + mg * 16 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < NKW; ++i) {
+            const int ks = kg + 4 * i;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wf[jj][i][e] = (__bf16)W[(long long)row * Hg + ks * 32 + (lane >> 4) * 8 + e];
+        }
+    }
+
+    // sweep slots: load e = tid + 512*j covers clip e / (Hg/4), units 4*(e % (Hg/4)) ..+3 (clamped for short chains)
+    const int per = Hg >> 2, nload = nb * per;
+    unsigned sw_v[NS];
+    int sw_l[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int e = min(tid + NT * j, nload - 1);
+        const int bl_ = e / per, v = 4 * (e - bl_ * per);
+        sw_v[j] = (unsigned)e * 16u;
+        sw_l[j] = bl_ * LD + v;
+    }
+
+    // gate math: thread = (clip bl, unit u)
+    const int u = tid & 31, bl = tid >> 5;
+    const bool act = bl < nb;
+    const int blc = act ? bl : 0;
+    const int half = u >> 4, ru = u & 15;
+    const int lp = (ru >> 2) * 16 + bl;
+    float bias[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) bias[g] = bh[g * Hg + u0 + u];
+    const unsigned pub_v = (unsigned)((bl * Hg + u0 + u) >> 1) * 8u;
+    const bool pub_lane = act && !(u & 1);
+
+    float hp = 0.f, gic[3];
+    if (has_h0) {                                          // the panel of step 0 is the initial state (bf16, like any h_{t-1})
+        __syncthreads();                                   // (the zero fill above)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int e = min(tid + NT * j, nload - 1);
+            const int bl_ = e / per, v = 4 * (e - bl_ * per);
+            const float4 hv = *reinterpret_cast<const float4*>(a.h0 + (long long)(b0 + bl_) * a.h0_bs + grp * Hg + v);
+            const u32x2 w = {pack2(hv.x, hv.y), pack2(hv.z, hv.w)};
+            *reinterpret_cast<u32x2*>(hB + sw_l[j]) = w;
+        }
+        if (act) hp = a.h0[(long long)(b0 + bl) * a.h0_bs + grp * Hg + u0 + u];
+    }
+    bool nowait = a.dbg >= 1 && a.dbg < 6;
+    const bool plain = team_shares_xcd(a.xid + (size_t)chain * 64, a.P, part, a.status, tid);
+    __syncthreads();                                       // ring slots 0 and 1 are filled
+#pragma unroll
+    for (int g = 0; g < 3; ++g) gic[g] = gi_r[0][blc][g * 32 + u];
+
+    for (int t = 0; t < a.T; ++t) {
+        if (t > 0) {
+            const unsigned soff = cbase + (unsigned)((t - 1) & 1) * panel_bytes;
+            u32x4 g[NS];
+            unsigned spins = 0;
+            for (;;) {
+#pragma unroll
+                for (int j = 0; j < NS; ++j) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, sw_v[j], soff, 16);
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < NS; ++j) ok = ok & (g[j].x == (unsigned)t) & (g[j].z == (unsigned)t);
+                if (__all(ok || nowait)) break;
+                if (++spins >= SPIN_LIMIT) {
+                    if (lane == 0) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    nowait = true;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                const u32x2 w = {g[j].y, g[j].w};                   // already bf16 pairs: the LDS image as is
+                *reinterpret_cast<u32x2*>(hB + sw_l[j]) = w;
+            }
+        }
+        float gh[3] = {bias[0], bias[1], bias[2]};
+        if (t > 0 || has_h0) {
+            __syncthreads();                               // panel complete
+            f32x4 acc[3];
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) acc[jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < NKW; ++i) {
+                const bf16x8 fb = *reinterpret_cast<const bf16x8*>(hB + (lane & 15) * LD + (kg + 4 * i) * 32 + (lane >> 4) * 8);
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jj][i], fb, acc[jj], 0, 0, 0);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) *reinterpret_cast<f32x4*>(red + ((kg * 6 + jj * 2 + mg) * 64 + lane) * 4) = acc[jj];
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) gh[g] += red[((w * 6 + g * 2 + half) * 64 + lp) * 4 + (ru & 3)];
+        }
+        const float r = lean_sigmoid(gic[0] + gh[0]);
+        const float z = lean_sigmoid(gic[1] + gh[1]);
+        const float n = lean_tanh(gic[2] + r * gh[2]);
+        const float h = (1.f - z) * n + z * hp;
+        {
+            const float hn = __uint_as_float(dpp_xor1(__float_as_uint(h)));
+            if (pub_lane) {
+                const u32x2 w = {(unsigned)(t + 1), pack2(h, hn)};
+                const unsigned soff = cbase + (unsigned)(t & 1) * panel_bytes;
+                if (plain) __builtin_amdgcn_raw_buffer_store_b64(w, rs, pub_v, soff, 0);
+                else __builtin_amdgcn_raw_buffer_store_b64(w, rs, pub_v, soff, 16);
+            }
+        }
+        const float an = (1.f - z) * (1.f - n * n);
+        // saves into parity t & 1 (the helper reads them after the next barrier); gi of step t + 1 from the ring
+        float* sl = &sv_l[t & 1][0][blc][u];
+        if (act) {
+            sl[0 * 512] = h;
+            sl[1 * 512] = an * gh[2] * r * (1.f - r);
+            sl[2 * 512] = (hp - n) * z * (1.f - z);
+            sl[3 * 512] = an * r;
+            sl[4 * 512] = an;
+            sl[5 * 512] = z;
+        }
+        hp = h;
+        const int slot = (t + 1) & 3;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) gic[g] = gi_r[slot][blc][g * 32 + u];
+    }
+    __syncthreads();                                       // hands the last step's saves to the helper wave
+}
+
+// ---------------------------------------------------------------------------------
 // backward: dh_s = dout_s + z_{s+1} * dh_{s+1} + (dh_{s+1} * c_{s+1}) W_hh
 // Same queue discipline: dout/z rows and the coefficient panel of the NEXT step are requested right
 // after this step's sweep has returned; the dh save is deferred by one step.
@@ -1424,14 +1697,25 @@ int num_cus() {
 
 struct Plan { int Bg, P, nbg, bg_per_launch, nlaunch; };
 
-int make_plan(int B, int G, int Hg, Plan& pl) {
+bool bwd_rs_eligible(int Bg, int Hg, int prec);
+bool fwd_lean_eligible(int Bg, int Hg, int prec);
+bool fwd_w16_eligible(int Bg, int Hg, int prec);
+
+// Chains of 8 clips while the batch's chains fit the CUs.  A larger batch: the wide-chain forward kernel (16 clips per chain,
+// one launch of half the workgroups) where it exists; otherwise several launches of the lean / reduce-scatter kernels on
+// chains of 8 (B = 128, Hg = 640: 2 x 0.81 ms backward against 2.75 ms for one launch of the generic kernel on chains of 16);
+// the generic kernels keep their chains of 16.
+int make_plan(int B, int G, int Hg, int prec, bool fwd, int chain_clips, Plan& pl) {
     pl.P = Hg / U;
     const int maxblk = num_cus();
     if (G * pl.P > maxblk) return -1;
-    pl.Bg = 8;
+    pl.Bg = chain_clips == 16 ? 16 : 8;
     if (cruse_opt("gru_bg", 8) == 16) pl.Bg = 16;   // profiling override
     pl.nbg = cdiv(B, pl.Bg);
-    if (pl.nbg * G * pl.P > maxblk) { pl.Bg = 16; pl.nbg = cdiv(B, pl.Bg); }
+    if (pl.nbg * G * pl.P > maxblk && chain_clips != 8) {
+        const bool fast8 = fwd ? fwd_lean_eligible(8, Hg, prec) : bwd_rs_eligible(8, Hg, prec);
+        if ((fwd && fwd_w16_eligible(16, Hg, prec)) || !fast8) { pl.Bg = 16; pl.nbg = cdiv(B, pl.Bg); }
+    }
     pl.bg_per_launch = ((maxblk / pl.P) / 8 * 8) / G;      // chains per launch padded to a multiple of 8
     if (pl.bg_per_launch < 1) pl.bg_per_launch = 1;
     if (pl.bg_per_launch > pl.nbg) pl.bg_per_launch = pl.nbg;
@@ -1440,7 +1724,9 @@ int make_plan(int B, int G, int Hg, Plan& pl) {
 }
 
 constexpr int MAX_LAUNCH_TICKETS = 64;      // launches of one call that get their own ticket counters
-size_t xid_bytes_total(int B, int G) { return (size_t)cdiv(B, 8) * G * 64 * 8; }
+// (sized for chains of 8 or of 16 clips: a 16-clip chain takes the room of two chains of 8)
+int chains8(int B) { return 2 * cdiv(B, 16); }
+size_t xid_bytes_total(int B, int G) { return (size_t)chains8(B) * G * 64 * 8; }
 
 // granules (8 bytes) of one parity of one chain: all-gather forms keep up to 16 rows of Hg values; the
 // reduce-scatter backward keeps [consumer P][clip 8][pair 16][producer P]
@@ -1452,7 +1738,7 @@ size_t rs_gran_per_parity(int Hg) { const size_t P = Hg / 32; return P * 8 * 16 
 size_t xg_bytes_total(int B, int G, int Hg) {
     size_t per = (size_t)16 * Hg;
     if (Hg % 32 == 0 && Hg <= 640 && rs_gran_per_parity(Hg) > per) per = rs_gran_per_parity(Hg);
-    return (size_t)cdiv(B, 8) * G * 2 * per * 8;
+    return (size_t)chains8(B) * G * 2 * per * 8;
 }
 
 template <typename Kern>
@@ -1493,6 +1779,18 @@ int dispatch_fwd_lean_w(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
         case 3: return launch_one(gru_fwd_lean_kernel<3, 3, false, WLO>, a, grid, lds, s, "gru_seq_fwd", (WLO && 3 > 3) ? 256 : 320);
         case 4: return launch_one(gru_fwd_lean_kernel<4, 4, false, WLO>, a, grid, lds, s, "gru_seq_fwd", (WLO && 4 > 3) ? 256 : 320);
         default: return launch_one(gru_fwd_lean_kernel<5, 5, false, WLO>, a, grid, lds, s, "gru_seq_fwd", (WLO && 5 > 3) ? 256 : 320);
+    }
+}
+bool fwd_w16_eligible(int Bg, int Hg, int prec) {
+    return prec == CRUSE_PREC_BF16 && Bg == 16 && Hg % 128 == 0 && Hg <= 640 && cruse_opt("gru_w16", 1) != 0;
+}
+int dispatch_fwd_w16(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
+    switch (a.Hg / 128) {
+        case 1: return launch_one(gru_fwd_w16_kernel<1>, a, grid, lds, s, "gru_seq_fwd", 576);
+        case 2: return launch_one(gru_fwd_w16_kernel<2>, a, grid, lds, s, "gru_seq_fwd", 576);
+        case 3: return launch_one(gru_fwd_w16_kernel<3>, a, grid, lds, s, "gru_seq_fwd", 576);
+        case 4: return launch_one(gru_fwd_w16_kernel<4>, a, grid, lds, s, "gru_seq_fwd", 576);
+        default: return launch_one(gru_fwd_w16_kernel<5>, a, grid, lds, s, "gru_seq_fwd", 576);
     }
 }
 int dispatch_fwd_lean(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
@@ -1571,7 +1869,9 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* pane
         a.xg = (unsigned long long*)xg_base + (size_t)bg_off * G * 2 * gpp;
         a.xg_bytes = (unsigned)((size_t)a.nchains * 2 * gpp * 8);
         const int grid = cdiv(a.nchains, 8) * 8 * pl.P;
-        if (FWD && fwd_lean_eligible(pl.Bg, Hg, prec)) {
+        if (FWD && fwd_w16_eligible(pl.Bg, Hg, prec)) {
+            rc = dispatch_fwd_w16(a, grid, lds, s);
+        } else if (FWD && fwd_lean_eligible(pl.Bg, Hg, prec)) {
             rc = dispatch_fwd_lean(a, grid, lds, s);
         } else if (FWD) {
             if (prec == CRUSE_PREC_F32) rc = dispatch_fwd<CRUSE_PREC_F32>(a, grid, lds, s);
@@ -1617,9 +1917,10 @@ extern "C" size_t cruse_gru_ws_bytes(int B, int G, int Hg) {
 
 extern "C" int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, const float* const* b_hh,
                                     float* h, void* coef, float* an, float* z, const float* h0, long long h0_bstride,
-                                    int B, int T, int TS, int G, int Hg, int prec, void* panels, unsigned* status, int xcd_rot,
-                                    void* stream) {
+                                    int B, int T, int TS, int G, int Hg, int prec, int chain_clips, void* panels, unsigned* status,
+                                    int xcd_rot, void* stream) {
     int rc = check_common(B, T, G, Hg, prec, "gru_seq_fwd");
+    CRUSE_REQUIRE(chain_clips == 0 || chain_clips == 8 || chain_clips == 16, CRUSE_E_SHAPE, "gru_seq_fwd: chain_clips = %d (0, 8, 16)", chain_clips);
     if (rc) return rc;
     CRUSE_REQUIRE(TS >= T, CRUSE_E_SHAPE, "gru_seq_fwd: clip stride %d frames < %d steps", TS, T);
     CRUSE_REQUIRE(h0 == nullptr || (h0_bstride >= (long long)G * Hg && ((uintptr_t)h0 % 16) == 0 && h0_bstride % 4 == 0), CRUSE_E_SHAPE,
@@ -1627,7 +1928,7 @@ extern "C" int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, c
     CRUSE_REQUIRE((coef == nullptr) == (an == nullptr) && (coef == nullptr) == (z == nullptr), CRUSE_E_SHAPE,
                   "gru_seq_fwd: coef, an, z must all be given or all be NULL");
     Plan pl;
-    CRUSE_REQUIRE(make_plan(B, G, Hg, pl) == 0, CRUSE_E_SHAPE, "gru_seq_fwd: G*Hg/32 exceeds the CU count");
+    CRUSE_REQUIRE(make_plan(B, G, Hg, prec, true, chain_clips, pl) == 0, CRUSE_E_SHAPE, "gru_seq_fwd: G*Hg/32 exceeds the CU count");
     hipStream_t s = (hipStream_t)stream;
     CRUSE_REQUIRE(panels != nullptr && status != nullptr, CRUSE_E_SHAPE, "gru_seq_fwd: workspace / status pointer is NULL");
     { int zrc = cruse_zero_async(panels, cruse_gru_ws_bytes(B, G, Hg) - 256, s, "gru_seq_fwd memset"); if (zrc) return zrc; }   // the status word is sticky: never cleared here
@@ -1645,7 +1946,7 @@ extern "C" int cruse_gru_seq_fwd_on(const float* gi, const float* const* w_hh, c
                                     float* h, void* coef, float* an, float* z,
                                     int B, int T, int G, int Hg, int prec, void* panels, unsigned* status, int xcd_rot,
                                     void* stream) {
-    return cruse_gru_seq_fwd_ex(gi, w_hh, b_hh, h, coef, an, z, nullptr, 0, B, T, T, G, Hg, prec, panels, status, xcd_rot, stream);
+    return cruse_gru_seq_fwd_ex(gi, w_hh, b_hh, h, coef, an, z, nullptr, 0, B, T, T, G, Hg, prec, 0, panels, status, xcd_rot, stream);
 }
 
 extern "C" int cruse_gru_seq_fwd(const float* gi, const float* const* w_hh, const float* const* b_hh,
@@ -1661,12 +1962,13 @@ extern "C" int cruse_gru_gate_grads_bf16(const float* dh, const void* coef, cons
 
 extern "C" int cruse_gru_seq_bwd_ex(const float* dout, const float* const* w_hh, const void* coef, const float* z,
                                     float* dh, const float* an, void* dgi, int dg_slabs, int carry, int B, int T, int TS, int G,
-                                    int Hg, int prec, void* panels, unsigned* status, int xcd_rot, void* stream) {
+                                    int Hg, int prec, int chain_clips, void* panels, unsigned* status, int xcd_rot, void* stream) {
     int rc = check_common(B, T, G, Hg, prec, "gru_seq_bwd");
+    CRUSE_REQUIRE(chain_clips == 0 || chain_clips == 8 || chain_clips == 16, CRUSE_E_SHAPE, "gru_seq_bwd: chain_clips = %d (0, 8, 16)", chain_clips);
     if (rc) return rc;
     CRUSE_REQUIRE(TS >= T, CRUSE_E_SHAPE, "gru_seq_bwd: clip stride %d frames < %d steps", TS, T);
     Plan pl;
-    CRUSE_REQUIRE(make_plan(B, G, Hg, pl) == 0, CRUSE_E_SHAPE, "gru_seq_bwd: G*Hg/32 exceeds the CU count");
+    CRUSE_REQUIRE(make_plan(B, G, Hg, prec, false, chain_clips, pl) == 0, CRUSE_E_SHAPE, "gru_seq_bwd: G*Hg/32 exceeds the CU count");
     hipStream_t s = (hipStream_t)stream;
     CRUSE_REQUIRE(panels != nullptr && status != nullptr, CRUSE_E_SHAPE, "gru_seq_bwd: workspace / status pointer is NULL");
     { int zrc = cruse_zero_async(panels, cruse_gru_ws_bytes(B, G, Hg) - 256, s, "gru_seq_bwd memset"); if (zrc) return zrc; }   // the status word is sticky: never cleared here
@@ -1697,7 +1999,7 @@ extern "C" int cruse_gru_seq_bwd_ex(const float* dout, const float* const* w_hh,
 extern "C" int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh, const void* coef, const float* z,
                                     float* dh, const float* an, void* dgi, int B, int T, int G, int Hg, int prec,
                                     void* panels, unsigned* status, int xcd_rot, void* stream) {
-    return cruse_gru_seq_bwd_ex(dout, w_hh, coef, z, dh, an, dgi, 3, 0, B, T, T, G, Hg, prec, panels, status, xcd_rot, stream);
+    return cruse_gru_seq_bwd_ex(dout, w_hh, coef, z, dh, an, dgi, 3, 0, B, T, T, G, Hg, prec, 0, panels, status, xcd_rot, stream);
 }
 
 extern "C" int cruse_gru_seq_bwd(const float* dout, const float* const* w_hh, const void* coef, const float* z,

@@ -235,8 +235,6 @@ def _fwd_chunks(prec, Hg: int, g: int, T: int, slot: int, x_bf16) -> int:
     n = int(config.get().fwd_chunks or 0)
     if n < 2 or slot != 0 or x_bf16 is None or not _gi_takes_bf16_copy(prec, Hg) or T < 64 * n:
         return 1
-    if torch.cuda.is_current_stream_capturing():
-        return 1            # eager launches only: replayed from a captured graph the pipeline gave wrong masks (r03, not pursued)
     return n
 
 
@@ -251,7 +249,17 @@ def _ggru_forward_chunked(x, x_bf16, P, prefix, g, Hg, prec, save, nch, ctx, bef
         aux :           gi1(c1)   | ln1+gi2(c0), gi1(c2) | ... ln1+gi2(c_last) |
 
     Unchunked, gi1, LayerNorm 1 and gi2 (0.35 ms of the 6.0 ms step, tools/upper_bound_probe.py) sit between the recurrences
-    on the main stream.  Returns (h1, c1, a1, z1, l1, l1_bf, m1, s1, h2, c2, a2, z2)."""
+    on the main stream.
+
+    Under HIP-graph capture the auxiliary stream's FIRST captured operation is a one-element dummy.  Without it the replayed
+    graph (ROCm 7.2) left the rows of the layer-1 projection of chunk 1 -- the first kernel node of the freshly forked stream,
+    whose fork event follows the chunk-0 projection -- unwritten or overwritten (frames of chunk 1 onward wrong, deterministically;
+    eager launches right).  Bisected in r03 with lr = 0 replays: forking the stream BEFORE the chunk-0 projection, making the node
+    wait for the first recurrence chunk as well, or putting any other node first all give the eager result; the cause was not
+    established.  The side stream's leaves are not affected (tests/test_gpu_model.py: a replay on a new batch equals the eager
+    launches bit for bit), and this pipeline is checked the same way in both launch forms.
+
+    Returns (h1, c1, a1, z1, l1, l1_bf, m1, s1, h2, c2, a2, z2)."""
     B, T, H = x.shape
     rows = B * T
     dev = x.device
@@ -300,6 +308,11 @@ def _ggru_forward_chunked(x, x_bf16, P, prefix, g, Hg, prec, save, nch, ctx, bef
     proj("gru_list1", x_bf16, gi1, chunks[0])
     start = ev_on(main)                                   # x_bf16 and the K-tiled weights are complete
     aux.wait_event(start)
+    if torch.cuda.is_current_stream_capturing():
+        dummy = torch.zeros(64, device=dev)
+        with torch.cuda.stream(aux):
+            dummy.add_(1.0)
+        ctx["_aux_first_node"] = dummy
     out1 = None
     e_p = {}                                              # layer-1 projection of chunk j done (aux)
     e_q = {}                                              # LayerNorm 1 + layer-2 projection of chunk j done (aux)

@@ -440,13 +440,13 @@ def _off(t: torch.Tensor, elems: int) -> int:
 
 
 def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G, Hg, prec, save=True, slot=0, xcd_rot=0,
-                h0=None, out=None, chunk=None):
+                h0=None, out=None, chunk=None, wide=False):
     """-> (h, coef, an, z); the last three are None when save is False (inference).  slot / xcd_rot: see
     cruse_gru_seq_fwd_on (concurrent recurrences).
     h0 [B, G*Hg] ("cat" layout: feature = group*Hg + unit): initial state (cust_conv.py:305-325); None = 0.
     chunk = (t0, n): run only frames [t0, t0+n) of the [B,T] tensors into `out` = (h, coef, an, z) from the call that ran
     the frames before them -- the initial state is then h[:, t0-1] (h0 for t0 == 0).  Consecutive chunks reproduce the
-    single launch (cruse_gru_seq_fwd_ex)."""
+    single launch (cruse_gru_seq_fwd_ex).  wide: chains of 16 clips (half the workgroups; same results)."""
     dev = gi.device
     H = G * Hg
     if out is not None:
@@ -476,7 +476,7 @@ def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G,
     opt = lambda t_, k: None if t_ is None else _off(t_, t0 * k)
     check(lib.cruse_gru_seq_fwd_ex(_off(gi, t0 * 3 * H), ctypes.cast(wa, ctypes.c_void_p), ctypes.cast(ba, ctypes.c_void_p),
                                    _off(h, t0 * H), opt(coef, 3 * H), opt(an, H), opt(z, H), h0p, h0s, B, n, T, G, Hg,
-                                   prec_code(prec), panels, status, xcd_rot, _stream()))
+                                   prec_code(prec), 16 if wide else 0, panels, status, xcd_rot, _stream()))
     return h, coef, an, z
 
 
@@ -492,7 +492,7 @@ def dgi_buffer(rows, G, Hg, device, slabs=3):
 
 
 def gru_seq_bwd(dout, w_hh: List[torch.Tensor], coef, z, B, T, G, Hg, prec, slot=0, xcd_rot=0, an=None, want_dgi=False,
-                out=None, chunk=None, dg_slabs=3):
+                out=None, chunk=None, dg_slabs=3, wide=False):
     """dout [B,T,H] -> dh [B,T,H] (total gradient reaching every h_t).  want_dgi (CRUSE_PREC_BF16, with the a_n rows):
     -> (dh, dgi) with dgi = dh * (c_r, c_z, a_n) in bf16 written by the recurrence itself (cruse_gru_seq_bwd_on).
     chunk = (t0, n): only frames [t0, t0+n), into out = dh (or (dh, dgi)); chunks are run from the LAST to the first, and
@@ -518,7 +518,7 @@ def gru_seq_bwd(dout, w_hh: List[torch.Tensor], coef, z, B, T, G, Hg, prec, slot
     check(lib.cruse_gru_seq_bwd_ex(_off(dout, t0 * H), ctypes.cast(wa, ctypes.c_void_p), _off(coef, t0 * 3 * H), _off(z, t0 * H),
                                    _off(dh, t0 * H), _off(an, t0 * H) if want_dgi else None,
                                    None if dgi is None else _off(dgi, t0 * dg_slabs * H), dg_slabs, carry, B, steps, T, G, Hg, prec_code(prec),
-                                   panels, status, xcd_rot, _stream()))
+                                   16 if wide else 0, panels, status, xcd_rot, _stream()))
     return (dh, dgi) if want_dgi else dh
 
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CRUSE_ABI_VERSION 4
+#define CRUSE_ABI_VERSION 5
 
 enum {
     CRUSE_OK = 0,
@@ -299,14 +299,19 @@ int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh, const void
  *            supported by the reduce-scatter kernel only (CRUSE_PREC_BF16, Hg <= 640).
  *            dg_slabs: 3 = dgi rows [G][3][Hg] (r, z, n_i); 4 = [G][4][Hg] with slab 3 = dh * c_n, the n gate of
  *            dgh = dh * (c_r, c_z, c_n) (reduce-scatter kernel): one row-major tensor that is the A operand of
- *            dX = dgi W_ih (K = 3*Hg of every 4*Hg) and of both weight-gradient products of cruse_gemm_bf16_tn. */
+ *            dX = dgi W_ih (K = 3*Hg of every 4*Hg) and of both weight-gradient products of cruse_gemm_bf16_tn.
+ *   chain_clips: clips served by one team of Hg/32 workgroups.  0 = the library's plan: chains of 8 while the batch's chains fit
+ *            the CUs; beyond that (B > 96 at Hg = 640) the forward pass takes WIDE chains of 16 (one launch, half the workgroups per
+ *            clip, the full 16 columns of the MFMA; CRUSE_PREC_BF16, Hg % 128 == 0, Hg <= 640: 2.25 us per step against 1.49) and
+ *            the backward pass several launches on chains of 8.  8 / 16 force the width (two wide recurrences with xcd_rot 0 / 4
+ *            run side by side on 2 x 80 CUs: 948 us for the pair at B = 64, tools/gru_pair_probe.py).  Results do not depend on it. */
 int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, const float* const* b_hh,
                          float* h, void* coef, float* an, float* z, const float* h0, long long h0_bstride,
-                         int B, int T, int TS, int G, int Hg, int prec, void* panels, unsigned* status, int xcd_rot,
-                         void* stream);
+                         int B, int T, int TS, int G, int Hg, int prec, int chain_clips, void* panels, unsigned* status,
+                         int xcd_rot, void* stream);
 int cruse_gru_seq_bwd_ex(const float* dout, const float* const* w_hh, const void* coef, const float* z,
                          float* dh, const float* an, void* dgi, int dg_slabs, int carry, int B, int T, int TS, int G,
-                         int Hg, int prec, void* panels, unsigned* status, int xcd_rot, void* stream);
+                         int Hg, int prec, int chain_clips, void* panels, unsigned* status, int xcd_rot, void* stream);
 /* dgi = dh*(c_r,c_z,a_n) (gradient wrt gi), dgh = dh*(c_r,c_z,c_n) (gradient wrt W_hh h + b_hh), both
  * [rows,G,3*Hg]; dW_ih, dW_hh, dX and the bias gradients follow from cruse_gemm / cruse_col_sum. */
 int cruse_gru_gate_grads(const float* dh, const void* coef, const float* an, float* dgi, float* dgh,

@@ -583,6 +583,51 @@ def test_gru_fwd_lean_matches_generic_kernel(ops, H, B, T):
     assert rel_l2(h_nosave, lean[0]) < 1e-6                # same kernel, saves off: identical
 
 
+@pytest.mark.parametrize("H,B,T,G", [(640, 64, 9, 1), (640, 24, 7, 1), (128, 16, 5, 1), (384, 5, 6, 1), (256, 33, 4, 2), (512, 17, 1, 1)])
+def test_gru_fwd_wide_chains_match_lean_kernel_bit_for_bit(ops, H, B, T, G):
+    """cruse_gru_seq_fwd_ex(chain_clips = 16): chains of 16 clips (half the workgroups per clip; gru_fwd_w16_kernel) -- the lean
+    kernel's arithmetic in the lean kernel's summation order, so h and the saved coefficient rows are identical; with an
+    initial state and run as time chunks too."""
+    torch.manual_seed(H + B)
+    Hg = H // G
+    gi = (0.5 * torch.randn(B, T, 3 * H)).cuda()
+    w = [(torch.randn(3 * Hg, Hg) / Hg ** 0.5).cuda() for _ in range(G)]; b = [(0.1 * torch.randn(3 * Hg)).cuda() for _ in range(G)]
+    h0 = (0.3 * torch.randn(B, H)).cuda()
+    with ops.options(gru_wlo=0):                   # (the lean kernel's W_hh low-plane pass for Hg <= 320 has no wide-chain form)
+        for init in (None, h0):
+            lean = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16", h0=init)
+            wide = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16", h0=init, wide=True)
+            for x, y, name in zip(wide, lean, ("h", "coef", "an", "z")):
+                assert torch.equal(x, y), (name, init is not None)
+        if T >= 4:
+            cut = T // 2
+            out = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16", h0=h0, chunk=(0, cut), wide=True)
+            ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16", out=out, chunk=(cut, T - cut), wide=True)
+            for x, y, name in zip(out, lean, ("h", "coef", "an", "z")):
+                assert torch.equal(x, y), ("chunked", name)
+    assert ops.gru_status() == 0
+
+
+def test_gru_batch_beyond_the_cu_count(ops):
+    """B = 136 at Hg = 640: 17 chains of 8 x 20 workgroups do not fit the 256 CUs.  Forward: one launch of the wide-chain kernel
+    (9 chains of 16); backward: several launches of the reduce-scatter kernel on chains of 8.  Same results as the batch run in
+    two parts."""
+    torch.manual_seed(3)
+    B, T, H = 136, 6, 640
+    gi = (0.5 * torch.randn(B, T, 3 * H)).cuda()
+    w = [(torch.randn(3 * H, H) / H ** 0.5).cuda()]; b = [(0.1 * torch.randn(3 * H)).cuda()]
+    dout = torch.randn(B, T, H).cuda()
+    full = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16")
+    dh, dgi = ops.gru_seq_bwd(dout, w, full[1], full[3], B, T, 1, H, "bf16", an=full[2], want_dgi=True)
+    for lo, hi in ((0, 64), (64, 136)):
+        part = ops.gru_seq_fwd(gi[lo:hi].contiguous(), w, b, hi - lo, T, 1, H, "bf16")
+        for x, y, name in zip(part, full, ("h", "coef", "an", "z")):
+            assert torch.equal(x, y[lo:hi]), name
+        dh_p, dgi_p = ops.gru_seq_bwd(dout[lo:hi].contiguous(), w, part[1], part[3], hi - lo, T, 1, H, "bf16", an=part[2], want_dgi=True)
+        assert torch.equal(dh_p, dh[lo:hi]) and torch.equal(dgi_p, dgi[lo * T:hi * T].view(dgi_p.shape))
+    assert ops.gru_status() == 0
+
+
 def test_gru_lean_kernels_with_groups(ops):
     """Grouped GRU (G = 2, Hg = 256) through the bf16-mode lean forward / reduce-scatter backward kernels:
     both must agree with the generic kernels on the same inputs (chains = batch groups x GRU groups)."""

@@ -265,7 +265,34 @@ def test_two_engines_in_one_process_do_not_share_scheduler_state():
     assert rel_l2(engs[0].flat.params, engs[1].flat.params) < 1e-5
 
 
-@pytest.mark.parametrize("graph", [False, True])          # (graph mode: the pipeline is not captured -- the step is the unchunked one)
+@pytest.mark.parametrize("fwd_chunks", [0, 2])
+def test_graph_replay_on_a_new_batch_equals_eager_launches(fwd_chunks):
+    """A captured step replayed on ANOTHER batch computes what the eager launches compute.  lr = 0, so the parameters never move
+    and the forward pass must agree bit for bit (gradients: up to the order of the split-K atomics): a kernel node that ran
+    before its producer would see the tensors of the batch the graph was captured on.  (This is how the auxiliary-stream
+    capture problem of the time-chunk pipeline was found, cruse_net._ggru_forward_chunked.)"""
+    from cruse_amd.config import EngineConfig
+    from cruse_amd.data import synth_batch
+    from cruse_amd.engine import TrainEngine
+    from cruse_amd.model.cruse_net import unet_2
+    from cruse_amd import ops
+    A = synth_batch(16, 32000, "cuda", 4)
+    Bb = synth_batch(16, 32000, "cuda", 11)
+    res = {}
+    for graph in (False, True):
+        torch.manual_seed(5)
+        eng = TrainEngine(unet_2(rnn_groups=1, precision="bf16").cuda(), use_graph=graph, lr=0.0, config=EngineConfig(fwd_chunks=fwd_chunks))
+        eng.step(*A); eng.step(*A)
+        ls = eng.step(*Bb)
+        torch.cuda.synchronize()
+        res[graph] = (eng._last_mask.clone(), eng.loss_value(ls), eng.flat.grads.clone())
+        assert eng.skipped_steps() == 0 and ops.gru_status() == 0
+    assert torch.equal(res[True][0], res[False][0]), "mask of the replay differs from the eager launches"
+    assert res[True][1] == res[False][1]
+    assert rel_l2(res[True][2], res[False][2]) < 1e-5
+
+
+@pytest.mark.parametrize("graph", [False, True])
 def test_forward_time_chunk_pipeline_is_the_same_computation(graph):
     """EngineConfig.fwd_chunks: the GGRU forward as a time-chunk pipeline (recurrence chunks on the main stream, the projections /
     LayerNorm 1 of other chunks on an auxiliary stream; cruse_gru_seq_fwd_ex, cruse_gemm_bf16_nt_seg, cruse_ln_fwd row segments)
