@@ -33,6 +33,8 @@ SIGNATURES = {
     "cruse_conv_scatter2": ("ppppiiiiiiiiiiip", "i"),
     "cruse_conv_gather_bnstats": ("ppppiiiiiiiiiipip", "i"),
     "cruse_conv_scatter2_bnstats": ("ppppiiiiiiiiipip", "i"),
+    "cruse_conv_gather_bnbwd": ("pppiiiiiiiiiiiipppppipip", "i"),
+    "cruse_conv_scatter2_bnbwd": ("pppiiiiiiiiiipppppipip", "i"),
     "cruse_conv_wgrad_ws_bytes": ("iii", "z"),
     "cruse_conv_wgrad": ("pppiiiiiiiiiipp", "i"),
     "cruse_channel_sum": ("pqiipp", "i"),
@@ -43,7 +45,7 @@ SIGNATURES = {
     "cruse_bn_eval_stats": ("ppifppp", "i"),
     "cruse_bn_act_fwd": ("pppppppqiiip", "i"),
     "cruse_bn_act_bwd_reduce": ("ppppppqiiipip", "i"),
-    "cruse_bn_act_bwd_apply": ("pppppppqiiiippppp", "i"),
+    "cruse_bn_act_bwd_apply": ("pppppppiqiiiippppp", "i"),
     "cruse_ln_fwd": ("ppppppppqiifiqqp", "i"),
     "cruse_ln_bwd": ("pppppqiipppp", "i"),
     "cruse_gemm": ("iiiiipipipipiiiip", "i"),

@@ -27,6 +27,7 @@ class EngineConfig:
     early_t: int = 2                # dW operand transposes: 0 inside each layer's leaf, 1 layer 1's beside the first backward
                                     # recurrence, 2 all four in the forward pass (6.08 vs 6.12 ms)
     fuse_bn_stats: bool = True      # BatchNorm batch sums in the producing conv's epilogue (False: separate bn_stats pass)
+    fuse_bn_bwd_stats: bool = True  # BatchNorm BACKWARD sums in the epilogue of the data-gradient conv that produces the incoming gradient
     fuse_dgi: bool = False          # the backward recurrence writes the bf16 gate gradients itself (measured neutral)
     fuse_cast: bool = True          # the gate GEMMs' bf16 operand copies written by the producing BatchNorm / LayerNorm kernel
     gi_x3: Optional[int] = None     # forward gate projections: bit 0 / 1 = W_ih low-plane pass on layer 1 / 2, bit 2 = also split x
@@ -43,7 +44,8 @@ class EngineConfig:
 
     _ENV = {"overlap": ("CRUSE_OVERLAP", lambda v: v == "1"), "defer_mask": ("CRUSE_DEFER", int), "inline_mask": ("CRUSE_INLINE", int),
             "early_t": ("CRUSE_EARLY_T", int), "fuse_bn_stats": ("CRUSE_FUSE_BN_STATS", lambda v: v != "0"),
-            "fuse_dgi": ("CRUSE_FUSE_DGI", lambda v: v == "1"), "fuse_cast": ("CRUSE_FUSE_CAST", lambda v: v == "1"),
+            "fuse_dgi": ("CRUSE_FUSE_DGI", lambda v: v == "1"),
+            "fuse_bn_bwd_stats": ("CRUSE_FUSE_BN_BWD", lambda v: v != "0"), "fuse_cast": ("CRUSE_FUSE_CAST", lambda v: v == "1"),
             "gi_x3": ("CRUSE_GI_X3", int), "dw_xcdk": ("CRUSE_DW_XCDK", int), "conv_bwd_x3": ("CRUSE_CONV_BWD_X3", lambda v: v == "1"),
             "dw_tn": ("CRUSE_DW_TN", lambda v: v == "1"), "fwd_chunks": ("CRUSE_FWD_CHUNKS", int)}
     _LIB_ENV = {"CRUSE_GRU_BWD_RS": "gru_bwd_rs", "CRUSE_GRU_FWD_LEAN": "gru_fwd_lean", "CRUSE_GRU_WLO": "gru_wlo",

@@ -6,6 +6,10 @@
 #include <stdarg.h>
 #include "../../include/cruse_hip.h"
 
+// the BatchNorm(+ReLU) whose input gradient a data-gradient convolution produces (cruse_conv_*_bnbwd): its pre-BN tensor and
+// per-channel statistics / affine parameters
+struct CruseBnBwd { const float* y; const float* mean; const float* rstd; const float* gamma; const float* beta; int relu; };
+
 extern "C" void cruse_set_error(const char* fmt, ...);
 
 #define CRUSE_REQUIRE(cond, code, ...)                                   \

@@ -448,13 +448,17 @@ int set_smem(K kern, size_t bytes, const char* name) {
 
 int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float* bias, float* y,
                         int B, int T, int Cin, int Fin, int Cout, int Fout, int KT, int S, int pad,
-                        int w_layout, int act, int accum, int prec, double* bn_sums, hipStream_t stream);
+                        int w_layout, int act, int accum, int prec, double* bn_sums, const CruseBnBwd* bnb, hipStream_t stream);
+extern "C" int cruse_bn_act_bwd_reduce(const float* dout, const float* y, const float* mean, const float* rstd,
+                                       const float* gamma, const float* beta, long long rows, int C, int F,
+                                       int relu, double* sums, int zeroed, void* stream);
 
 namespace {
 
 int conv_gather_impl(const float* x, const float* w, const float* bias, float* y,
                      int B, int T, int Cin, int Fin, int Cout, int Fout,
-                     int KT, int S, int pad, int w_layout, int act, int accum, int prec, double* bn_sums, void* stream) {
+                     int KT, int S, int pad, int w_layout, int act, int accum, int prec, double* bn_sums, void* stream,
+                     const CruseBnBwd* bnb = nullptr) {
     CRUSE_REQUIRE(B > 0 && T > 0 && Cin > 0 && Cout > 0 && Fin > 0 && Fout > 0, CRUSE_E_SHAPE,
                   "conv_gather: empty shape B=%d T=%d Cin=%d Cout=%d Fin=%d Fout=%d", B, T, Cin, Cout, Fin, Fout);
     CRUSE_REQUIRE((KT == 1 || KT == 2) && (S == 1 || S == 2) && (pad == 0 || pad == 1), CRUSE_E_SHAPE,
@@ -465,10 +469,10 @@ int conv_gather_impl(const float* x, const float* w, const float* bias, float* y
     CRUSE_REQUIRE(!(accum && act), CRUSE_E_SHAPE, "conv_gather: accum with activation");
     if (prec >= 0) {
         const int r = cruse_conv_mfma_try(0, x, w, bias, y, B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout, act, accum,
-                                          prec, bn_sums, (hipStream_t)stream);
+                                          prec, bn_sums, bnb, (hipStream_t)stream);
         if (r != 0) return r < 0 ? r : CRUSE_OK;
     }
-    const bool fuse = bn_sums && Cout <= 64;
+    const bool fuse = bn_sums && Cout <= 64 && bnb == nullptr;
     ConvArgs a{x, w, bias, y, B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout, act, accum, fuse ? bn_sums : nullptr};
     const size_t lds = (((size_t)Cin * KT * 3 * Cout + 3) & ~(size_t)3) * 4 +
                        (size_t)(TF + KT - 1) * Cin * (Fin + 2) * 4;
@@ -483,13 +487,17 @@ int conv_gather_impl(const float* x, const float* w, const float* bias, float* y
         hipLaunchKernelGGL(conv_gather_kernel<1>, dim3(grid), dim3(CONV_THREADS), lds, (hipStream_t)stream, a);
     }
     CRUSE_LAUNCH_CHECK("conv_gather");
+    // no statistics epilogue on this path: one more pass (the backward sums go to replica 0, the others stay zero)
+    if (bnb) return cruse_bn_act_bwd_reduce(y, bnb->y, bnb->mean, bnb->rstd, bnb->gamma, bnb->beta, (long long)B * T, Cout, Fout,
+                                            bnb->relu, bn_sums, 1, stream);
     if (bn_sums && !fuse) return cruse_bn_stats(y, (long long)B * T, Cout, Fout, bn_sums, 1, stream);
     return CRUSE_OK;
 }
 
 int conv_scatter2_impl(const float* g, const float* w, const float* bias, float* y,
                        int B, int T, int Cs, int Fg, int Cout, int Fout,
-                       int KT, int pad, int act, int accum, int prec, double* bn_sums, void* stream) {
+                       int KT, int pad, int act, int accum, int prec, double* bn_sums, void* stream,
+                       const CruseBnBwd* bnb = nullptr) {
     CRUSE_REQUIRE(B > 0 && T > 0 && Cs > 0 && Cout > 0 && Fg > 0, CRUSE_E_SHAPE, "conv_scatter2: empty shape");
     CRUSE_REQUIRE(Fout == 2 * Fg, CRUSE_E_SHAPE, "conv_scatter2: Fout=%d must be 2*Fg=%d", Fout, 2 * Fg);
     CRUSE_REQUIRE((KT == 1 || KT == 2) && (pad == 0 || pad == 1), CRUSE_E_SHAPE,
@@ -497,7 +505,7 @@ int conv_scatter2_impl(const float* g, const float* w, const float* bias, float*
     CRUSE_REQUIRE(!(accum && act), CRUSE_E_SHAPE, "conv_scatter2: accum with activation");
     if (prec >= 0) {
         const int r = cruse_conv_mfma_try(1, g, w, bias, y, B, T, Cs, Fg, Cout, Fout, KT, 2, pad, 0, act, accum, prec,
-                                          bn_sums, (hipStream_t)stream);
+                                          bn_sums, bnb, (hipStream_t)stream);
         if (r != 0) return r < 0 ? r : CRUSE_OK;
     }
     ConvArgs a{g, w, bias, y, B, T, Cs, Fg, Cout, Fout, KT, 2, pad, 0, act, accum, nullptr};
@@ -515,6 +523,8 @@ int conv_scatter2_impl(const float* g, const float* w, const float* bias, float*
     }
     CRUSE_LAUNCH_CHECK("conv_scatter2");
     // the VALU scatter kernel has no statistics epilogue: one more pass over y
+    if (bnb) return cruse_bn_act_bwd_reduce(y, bnb->y, bnb->mean, bnb->rstd, bnb->gamma, bnb->beta, (long long)B * T, Cout, Fout,
+                                            bnb->relu, bn_sums, 1, stream);
     if (bn_sums) return cruse_bn_stats(y, (long long)B * T, Cout, Fout, bn_sums, 1, stream);
     return CRUSE_OK;
 }
@@ -553,6 +563,28 @@ extern "C" int cruse_conv_scatter2_bnstats(const float* g, const float* w, const
     int rc = prep_sums(sums, Cout, zeroed, stream, "conv_scatter2_bnstats");
     if (rc) return rc;
     return conv_scatter2_impl(g, w, bias, y, B, T, Cs, Fg, Cout, Fout, KT, pad, 0, 0, prec, sums, stream);
+}
+
+extern "C" int cruse_conv_gather_bnbwd(const float* x, const float* w, float* y, int B, int T, int Cin, int Fin, int Cout, int Fout,
+                                       int KT, int S, int pad, int w_layout, int accum, int prec,
+                                       const float* bn_y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                       int relu, double* sums, int zeroed, void* stream) {
+    CRUSE_REQUIRE(bn_y && mean && rstd && gamma && beta, CRUSE_E_SHAPE, "conv_gather_bnbwd: BatchNorm tensors missing");
+    int rc = prep_sums(sums, Cout, zeroed, stream, "conv_gather_bnbwd");
+    if (rc) return rc;
+    const CruseBnBwd bnb = {bn_y, mean, rstd, gamma, beta, relu};
+    return conv_gather_impl(x, w, nullptr, y, B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout, 0, accum, prec, sums, stream, &bnb);
+}
+
+extern "C" int cruse_conv_scatter2_bnbwd(const float* g, const float* w, float* y, int B, int T, int Cs, int Fg, int Cout, int Fout,
+                                         int KT, int pad, int accum, int prec,
+                                         const float* bn_y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                         int relu, double* sums, int zeroed, void* stream) {
+    CRUSE_REQUIRE(bn_y && mean && rstd && gamma && beta, CRUSE_E_SHAPE, "conv_scatter2_bnbwd: BatchNorm tensors missing");
+    int rc = prep_sums(sums, Cout, zeroed, stream, "conv_scatter2_bnbwd");
+    if (rc) return rc;
+    const CruseBnBwd bnb = {bn_y, mean, rstd, gamma, beta, relu};
+    return conv_scatter2_impl(g, w, nullptr, y, B, T, Cs, Fg, Cout, Fout, KT, pad, 0, accum, prec, sums, stream, &bnb);
 }
 
 extern "C" size_t cruse_conv_wgrad_ws_bytes(int Ca, int Cb, int KT) {

@@ -39,6 +39,11 @@ struct CMArgs {
     long long sco, sci;                          // weight strides of co and ci (tap index is fastest, 3*KT long)
     int act, accum;
     double* sums;                                // BatchNorm batch sums of y ([replica][2][Cout]: sum, sum of squares) or null
+    // BACKWARD statistics instead (bn_y != null): y is the gradient wrt the OUTPUT of a BatchNorm(+ReLU) whose pre-BN tensor is
+    // bn_y (same [B,T,Cout,Fout] layout); the sums are then those of cruse_bn_act_bwd_reduce -- sum of g and of g * xhat per
+    // channel, g = y masked by the ReLU -- so that pass over (y, bn_y) is not needed
+    const float* bn_y; const float* bn_mean; const float* bn_rstd; const float* bn_gamma; const float* bn_beta;
+    int bn_relu;
     TapClass cls[2];
 };
 
@@ -91,9 +96,16 @@ __device__ __forceinline__ Frag<PREC> get_frag(const typename OpStore<PREC>::ele
 // channel and workgroup, into replica (block id mod CRUSE_BN_STAT_REPLICAS) of the sums.  This replaces a separate pass over y (65 MB, ~28 us, on the serial chain).
 // NV: float4 per thread of the staged tile (the next tile's prefetch lives in registers across the whole N-tile
 // loop: 5 (of 320 threads) instead of 8 is what keeps the MT = 2 / 4 statistics variants at 4 / 3 waves per SIMD).
-template <int PREC, int MT, bool STATS, int NV, int NW>
+// EPI: 0 plain epilogue; 1 forward statistics (STATS above); 2 the epilogue READS per output element -- the old value of y
+// (accum) and / or the pre-BN tensor of the backward statistics (bn_y).  Those reads are issued one N-tile AHEAD, before the
+// MFMAs of the current one: vmcnt retires in order, so a read issued in the epilogue itself waits for the previous N-tile's
+// stores and exposes a full memory round trip per N-tile (the accumulating data gradients of the encoder ran at half the
+// speed of the plain ones; with the backward statistics read that way the step got 0.15 ms SLOWER than with the separate
+// reduce pass, r03).
+template <int PREC, int MT, int EPI, int NV, int NW>
 // (two 5-wave workgroups per CU need 4 wave slots on some SIMD: the 5-wave variants are held to 128 registers)
 __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMArgs a) {
+    constexpr bool STATS = EPI != 0;
     constexpr int NTHR = NW * 64;
     typedef typename OpStore<PREC>::elem elem;
     constexpr int NPL = OpStore<PREC>::NPL;
@@ -107,6 +119,7 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
     float* xl = reinterpret_cast<float*>(wl + NPL * wplane);   // [nrows][Cin][Fin]: RAW copy of the frame rows
     __shared__ int2 s_tap2[2][MAXTAP];
     __shared__ float s_bias[MT * 16];
+    __shared__ float s_bnp[STATS ? 4 : 1][MT * 16];       // mean, rstd, gamma, beta of the backward-statistics form
 
     const int ntile = (a.T + TFM - 1) / TFM;
 
@@ -118,6 +131,13 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
     // vmcnt wait on every older request -- the next tile's prefetch and the previous N-tile's stores -- ~2 us per N-tile;
     // holding them in registers instead costs 4 x MT VGPRs across the whole kernel)
     if (tid < MT * 16) s_bias[tid] = (a.bias && tid < a.Cout) ? a.bias[tid] : 0.f;
+    if constexpr (STATS) {
+        if (a.bn_y != nullptr && tid < MT * 16) {
+            const bool ok = tid < a.Cout;
+            s_bnp[0][tid] = ok ? a.bn_mean[tid] : 0.f; s_bnp[1][tid] = ok ? a.bn_rstd[tid] : 0.f;
+            s_bnp[2][tid] = ok ? a.bn_gamma[tid] : 0.f; s_bnp[3][tid] = ok ? a.bn_beta[tid] : 0.f;
+        }
+    }
     const int ntaps0 = a.cls[0].ntaps, ntaps1 = a.cls[1].ntaps, par0 = a.cls[0].par, par1 = a.cls[1].par;
     // weight fragments: frag (c, mt, ks), lane l, element e -> W[co = mt*16 + (l&15)][k = ks*32 + (l>>4)*8 + e].
     // One (fragment, lane) pair per work item: the index arithmetic is done once per 8 elements and the 8 loads
@@ -185,12 +205,37 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
             if (i < nvec) *reinterpret_cast<float4*>(xl + i * 4) = pre[q];
         }
         __syncthreads();
+        // EPI == 2: old output values / pre-BN values of this lane's MT x 4 outputs of an N-tile
+        float old_c[EPI == 2 ? MT : 1][4], by_c[EPI == 2 ? MT : 1][4], old_n[EPI == 2 ? MT : 1][4], by_n[EPI == 2 ? MT : 1][4];
+        auto aux_load = [&](int nt_, float (&o)[EPI == 2 ? MT : 1][4], float (&y_)[EPI == 2 ? MT : 1][4]) {
+            const int c_ = nt_ >= ntile_c ? 1 : 0;
+            const int p_ = (nt_ - c_ * ntile_c) * 16 + (lane & 15);
+            const int tl_ = (int)(((float)p_ + 0.5f) * inv_mpos);
+            const int m_ = p_ - tl_ * Mpos;
+            const int t_ = t0 + tl_;
+            const long long off = (((long long)b * a.T + t_) * a.Cout + (lane >> 4) * 4) * a.Fout + a.OS * m_ + (c_ ? par1 : par0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const bool ok = t_ < a.T && mt * 16 + (lane >> 4) * 4 + r4 < a.Cout;
+                    const long long e = off + (long long)(mt * 16 + r4) * a.Fout;
+                    o[mt][r4] = (ok && a.accum) ? a.y[e] : 0.f;
+                    y_[mt][r4] = (ok && a.bn_y != nullptr) ? a.bn_y[e] : 0.f;
+                }
+        };
+        if constexpr (EPI == 2) {                          // (ahead of the next tile's prefetch in the in-order queue)
+            if (wv < a.nclass * ntile_c) aux_load(wv, old_c, by_c);
+        }
         if (tile + (int)gridDim.x < a.B * ntile) prefetch(tile + gridDim.x);
 
         // N-tile loop, kept free of integer divisions (Cin is a power of two, positions via a float reciprocal)
         // and of global loads; one 64-bit base address per N-tile.  (Keeping several N-tiles in flight per wave
         // was measured and is slower: 78 vs 57 us on the 8->16 layer.)
         for (int nt = wv; nt < a.nclass * ntile_c; nt += NW) {
+            if constexpr (EPI == 2) {
+                if (nt + NW < a.nclass * ntile_c) aux_load(nt + NW, old_n, by_n);
+            }
             const int c = nt >= ntile_c ? 1 : 0;
             const int p = (nt - c * ntile_c) * 16 + (lane & 15);
             const int tl = (int)(((float)p + 0.5f) * inv_mpos);
@@ -240,17 +285,34 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
                         if (co < a.Cout) {
                             float* yp = yb + (mt * 16 + r4) * a.Fout;
                             float v = acc[mt][r4] + bqv[r4];
-                            if (a.accum) v += *yp;
-                            else if (a.act == 1) v = sigmoid_acc(v);
-                            *yp = v;
-                            if constexpr (STATS) { s1[mt][r4] += v; s2[mt][r4] += v * v; }
+                            if constexpr (EPI == 2) {
+                                v += old_c[mt][r4];                               // (0 unless accum)
+                                *yp = v;
+                                if (a.bn_y != nullptr) {
+                                    const float xh = (by_c[mt][r4] - s_bnp[0][co]) * s_bnp[1][co];
+                                    const float gr = (a.bn_relu && !(xh * s_bnp[2][co] + s_bnp[3][co] > 0.f)) ? 0.f : v;
+                                    s1[mt][r4] += gr; s2[mt][r4] += gr * xh;
+                                }
+                            } else {
+                                if (a.accum) v += *yp;
+                                else if (a.act == 1) v = sigmoid_acc(v);
+                                *yp = v;
+                                if constexpr (EPI == 1) { s1[mt][r4] += v; s2[mt][r4] += v * v; }
+                            }
                         }
                     }
                 }
             }
+            if constexpr (EPI == 2) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) { old_c[mt][r4] = old_n[mt][r4]; by_c[mt][r4] = by_n[mt][r4]; }
+            }
         }
     }
     if constexpr (STATS) {
+        if (a.sums == nullptr) return;                     // (EPI 2 without backward statistics: accumulate only)
         __shared__ float s_red[NW][2][MT * 16];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -301,8 +363,9 @@ int launch_mt(const CMArgs& a, int grid, size_t lds, int nw, hipStream_t s) {
     } while (0)
 #define CM_LAUNCH(MTV)                                                                                     \
     do {                                                                                                   \
-        if (a.sums) CM_LAUNCH1(MTV, true);                                                                 \
-        else CM_LAUNCH1(MTV, false);                                                                       \
+        if (a.accum || a.bn_y) CM_LAUNCH1(MTV, 2);                                                         \
+        else if (a.sums) CM_LAUNCH1(MTV, 1);                                                               \
+        else CM_LAUNCH1(MTV, 0);                                                                           \
     } while (0)
     if (mt <= 1) CM_LAUNCH(1);
     else if (mt <= 2) CM_LAUNCH(2);
@@ -320,12 +383,16 @@ int launch_mt(const CMArgs& a, int grid, size_t lds, int nw, hipStream_t s) {
 // to the VALU kernel), < 0 on error.
 int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float* bias, float* y,
                         int B, int T, int Cin, int Fin, int Cout, int Fout, int KT, int S, int pad,
-                        int w_layout, int act, int accum, int prec, double* bn_sums, hipStream_t stream) {
+                        int w_layout, int act, int accum, int prec, double* bn_sums, const CruseBnBwd* bnb, hipStream_t stream) {
     if (Cin % 8 != 0 || (Cin & (Cin - 1)) != 0 || Cout < 8 || Cout > 64 || (TFM * (Fout / (scatter ? 2 : 1))) % 16 != 0) return 0;
     CMArgs a = {};
     a.x = x; a.w = w; a.bias = bias; a.y = y;
     a.B = B; a.T = T; a.Cin = Cin; a.Fin = Fin; a.Cout = Cout; a.Fout = Fout;
     a.act = act; a.accum = accum; a.sums = bn_sums;
+    if (bnb != nullptr) {
+        a.bn_y = bnb->y; a.bn_mean = bnb->mean; a.bn_rstd = bnb->rstd; a.bn_gamma = bnb->gamma; a.bn_beta = bnb->beta;
+        a.bn_relu = bnb->relu;
+    }
     if (!scatter) {
         // y[co,fo] = sum W(co,ci,kt,kf) x[t-(KT-1)+kt, ci, fo*S - pad + kf]
         a.S = S; a.OS = 1; a.nclass = 1; a.halo_lo = KT - 1;

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(RED_THREADS) void bn_act_bwd_reduce_kernel(const fl
 // (sum xhat = 0; autograd produces rounding noise there) and gamma * rstd * sum g with running statistics.
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* dout, const float* y, const float* mean,
                                                                const float* rstd, const float* gamma,
-                                                               const float* beta, const double* sums, long long rows,
+                                                               const float* beta, const double* sums, int nrep, long long rows,
                                                                int C, int F, int relu, int training, float* dy,
                                                                float* dgamma, float* dbeta, float* dbias) {
     __shared__ float tab[6][256];
@@ -251,13 +251,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* dout
     const int tid = threadIdx.x, lane = tid & 63;
     const int CF = C * F, ng = CF >> 2;
     for (int c = tid; c < C; c += 256) {
+        double sg = 0.0, sgx = 0.0;                       // the statistic is the sum over the replicas
+        for (int r = 0; r < nrep; ++r) { sg += sums[(size_t)r * 2 * C + c]; sgx += sums[(size_t)r * 2 * C + C + c]; }
         tab[0][c] = mean[c]; tab[1][c] = rstd[c]; tab[2][c] = gamma[c]; tab[3][c] = beta[c];
-        tab[4][c] = training ? (float)(sums[c] / cnt) : 0.f;
-        tab[5][c] = training ? (float)(sums[C + c] / cnt) : 0.f;
+        tab[4][c] = training ? (float)(sg / cnt) : 0.f;
+        tab[5][c] = training ? (float)(sgx / cnt) : 0.f;
         if (blockIdx.x == 0) {
-            if (dgamma) dgamma[c] += (float)sums[C + c];
-            if (dbeta) dbeta[c] += (float)sums[c];
-            if (dbias && !training) dbias[c] += gamma[c] * rstd[c] * (float)sums[c];
+            if (dgamma) dgamma[c] += (float)sgx;
+            if (dbeta) dbeta[c] += (float)sg;
+            if (dbias && !training) dbias[c] += gamma[c] * rstd[c] * (float)sg;
         }
     }
     __syncthreads();
@@ -798,14 +800,14 @@ extern "C" int cruse_bn_act_bwd_reduce(const float* dout, const float* y, const 
 }
 
 extern "C" int cruse_bn_act_bwd_apply(const float* dout, const float* y, const float* mean, const float* rstd,
-                                      const float* gamma, const float* beta, const double* sums,
+                                      const float* gamma, const float* beta, const double* sums, int sum_replicas,
                                       long long rows, int C, int F, int relu, int training,
                                       float* dy, float* dgamma, float* dbeta, float* dbias, void* stream) {
-    CRUSE_REQUIRE(rows > 0 && C > 0 && C <= 256 && F > 0, CRUSE_E_SHAPE, "bn_act_bwd_apply: bad shape");
+    CRUSE_REQUIRE(rows > 0 && C > 0 && C <= 256 && F > 0 && sum_replicas >= 1, CRUSE_E_SHAPE, "bn_act_bwd_apply: bad shape");
     CRUSE_REQUIRE((C * F) % 4 == 0 && C * F <= 768, CRUSE_E_SHAPE,
                   "bn_act_bwd_apply: C*F=%d must be a multiple of 4 and <= 768", C * F);
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for(rows, 8, 2048)), dim3(256), 0, ST(stream), dout, y,
-                       mean, rstd, gamma, beta, sums, rows, C, F, relu, training, dy, dgamma, dbeta, dbias);
+                       mean, rstd, gamma, beta, sums, sum_replicas, rows, C, F, relu, training, dy, dgamma, dbeta, dbias);
     CRUSE_LAUNCH_CHECK("bn_act_bwd_apply");
     return CRUSE_OK;
 }

@@ -805,7 +805,22 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
         ops.channel_sum(dv, rows, ch[0], Fk[0], G["conv1_t.bias"])
         ops.conv_wgrad(us[1], dv, G["conv1_t.weight"], B, T, ch[1], Fk[1], ch[0], Fk[0], KT=1, S=2, pad=0, prec=prec)
     SIDE.defer(leaf_dec1, dv, kind=2, lane=0)                           # decoder leaves: issued with the first GRU backward
-    du = ops.conv_gather(dv, P["conv1_t.weight"], None, B, T, ch[0], Fk[0], ch[1], Fk[1], KT=1, S=2, pad=0, prec=dprec)
+    # A data gradient that feeds a BatchNorm backward accumulates that BatchNorm's backward sums (sum g, sum g*xhat per channel)
+    # in its own epilogue (cruse_conv_*_bnbwd): the reduce pass over (du, v) / (de, y) -- 132 MB and ~47 us per level -- is only
+    # left for the level the GGRU feeds.  EngineConfig.fuse_bn_bwd_stats.
+    fuse_bwd = config.get().fuse_bn_bwd_stats
+
+    def bn_of(k, dec):
+        if not fuse_bwd:
+            return None
+        mean_, rstd_ = dstats[k] if dec else stats[k]
+        nm = f"bn{k}_t" if dec else f"bn{k}"
+        return ((vs[k] if dec else ys[k]), mean_, rstd_, P[nm + ".weight"], P[nm + ".bias"], True)
+
+    def split(r):
+        return r if isinstance(r, tuple) else (r, None)
+    du, du_sums = split(ops.conv_gather(dv, P["conv1_t.weight"], None, B, T, ch[0], Fk[0], ch[1], Fk[1], KT=1, S=2, pad=0, prec=dprec,
+                                        bn_bwd=bn_of(2, True) if L >= 2 else None))
     ds = {1: du}                                        # gradient wrt skip_{k} output = du_k
     # skip_k = conv1x3(e_k) is a leaf of the decoder: its data gradient W^T ds_k and its weight gradient ds_k (*) e_k
     # are issued here, on the side stream, into the buffer de_pre[k] that the encoder backward later ACCUMULATES its
@@ -841,7 +856,7 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
         mean, rstd = dstats[k]
         dv = ops.bn_act_bwd(du, vs[k], mean, rstd, P[f"bn{k}_t.weight"], P[f"bn{k}_t.bias"], rows, ch[k - 1],
                             Fk[k - 1], True, training, G[f"bn{k}_t.weight"], G[f"bn{k}_t.bias"],
-                            dbias=G[f"conv{k}_t.bias"])
+                            dbias=G[f"conv{k}_t.bias"], sums=du_sums)
 
         def leaf_dec(dv=dv, k=k):
             ops.conv_wgrad(us[k], dv, G[f"conv{k}_t.weight"], B, T, ch[k], Fk[k], ch[k - 1], Fk[k - 1], KT=1, S=2, pad=0, prec=prec)
@@ -849,8 +864,8 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
             leaf_dec()
         else:
             SIDE.defer(leaf_dec, dv, kind=2, lane=0)
-        du = ops.conv_gather(dv, P[f"conv{k}_t.weight"], None, B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k], KT=1, S=2, pad=0,
-                             prec=dprec)
+        du, du_sums = split(ops.conv_gather(dv, P[f"conv{k}_t.weight"], None, B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k], KT=1, S=2,
+                                            pad=0, prec=dprec, bn_bwd=bn_of(k + 1, True) if k < L else None))
         ds[k] = du
         skip_leaves(k)
     # ---- bottleneck: u_L = ggru(e_L) + skip_L --------------------------------------------
@@ -870,10 +885,11 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
         boundary(0)
     cut = max(L // 2, 1)                          # levels L..cut+1, [bucket 1 final], levels cut..1
     # ---- encoder levels L..1: de_k already holds the skip path ------------------------------
+    de_sums = None
     for k in range(L, 0, -1):
         mean, rstd = stats[k]
         dy = ops.bn_act_bwd(de, ys[k], mean, rstd, P[f"bn{k}.weight"], P[f"bn{k}.bias"], rows, ch[k], Fk[k], True,
-                            training, G[f"bn{k}.weight"], G[f"bn{k}.bias"], dbias=G[f"conv{k}.bias"])
+                            training, G[f"bn{k}.weight"], G[f"bn{k}.bias"], dbias=G[f"conv{k}.bias"], sums=de_sums)
 
         def leaf_enc(dy=dy, k=k):
             ops.conv_wgrad(dy, es[k - 1], G[f"conv{k}.weight"], B, T, ch[k], Fk[k], ch[k - 1], Fk[k - 1], KT=2, S=2, pad=1, prec=prec)
@@ -884,8 +900,8 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
         else:
             SIDE.run(leaf_enc, dy, lane=0)
         if k > 1:
-            de = ops.conv_scatter2(dy, P[f"conv{k}.weight"], None, B, T, ch[k], Fk[k], ch[k - 1], KT=2, pad=1,
-                                   out=de_pre[k - 1], accum=True, prec=dprec)
+            de, de_sums = split(ops.conv_scatter2(dy, P[f"conv{k}.weight"], None, B, T, ch[k], Fk[k], ch[k - 1], KT=2, pad=1,
+                                                  out=de_pre[k - 1], accum=True, prec=dprec, bn_bwd=bn_of(k - 1, False)))
         if boundary is not None and k == cut + 1:
             boundary(1)
     SIDE.join()

@@ -126,18 +126,35 @@ def conv_prec(prec) -> int:
 
 
 def conv_gather(x, w, bias, B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout=0, act=0, out=None, accum=False,
-                prec=None):
+                prec=None, bn_bwd=None):
+    """bn_bwd = (bn_y, mean, rstd, gamma, beta, relu): the output is the gradient wrt the output of that BatchNorm(+ReLU); returns
+    (out, sums) with the backward sums of bn_act_bwd accumulated by the conv's epilogue (cruse_conv_gather_bnbwd)."""
     if out is None:
         out = torch.empty(B, T, Cout, Fout, device=x.device, dtype=torch.float32)
+    if bn_bwd is not None:
+        by, mean, rstd, gamma, beta, relu = bn_bwd
+        sums, z = ARENA.take(2 * Cout * BN_STAT_REPLICAS, x.device)
+        check(lib.cruse_conv_gather_bnbwd(_p(x), _p(w), _p(out), B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout,
+                                          1 if accum else 0, conv_prec(prec), _p(by), _p(mean), _p(rstd), _p(gamma), _p(beta),
+                                          1 if relu else 0, _p(sums), z, _stream()))
+        return out, sums
     check(lib.cruse_conv_gather(_p(x), _p(w), _p(bias), _p(out), B, T, Cin, Fin, Cout, Fout, KT, S, pad,
                                 w_layout, act, 1 if accum else 0, conv_prec(prec), _stream()))
     return out
 
 
-def conv_scatter2(g, w, bias, B, T, Cs, Fg, Cout, KT, pad, act=0, out=None, accum=False, prec=None):
+def conv_scatter2(g, w, bias, B, T, Cs, Fg, Cout, KT, pad, act=0, out=None, accum=False, prec=None, bn_bwd=None):
+    """bn_bwd: as for conv_gather (cruse_conv_scatter2_bnbwd)."""
     Fout = 2 * Fg
     if out is None:
         out = torch.empty(B, T, Cout, Fout, device=g.device, dtype=torch.float32)
+    if bn_bwd is not None:
+        by, mean, rstd, gamma, beta, relu = bn_bwd
+        sums, z = ARENA.take(2 * Cout * BN_STAT_REPLICAS, g.device)
+        check(lib.cruse_conv_scatter2_bnbwd(_p(g), _p(w), _p(out), B, T, Cs, Fg, Cout, Fout, KT, pad, 1 if accum else 0,
+                                            conv_prec(prec), _p(by), _p(mean), _p(rstd), _p(gamma), _p(beta), 1 if relu else 0,
+                                            _p(sums), z, _stream()))
+        return out, sums
     check(lib.cruse_conv_scatter2(_p(g), _p(w), _p(bias), _p(out), B, T, Cs, Fg, Cout, Fout, KT, pad, act,
                                   1 if accum else 0, conv_prec(prec), _stream()))
     return out
@@ -296,12 +313,17 @@ def bn_act_fwd(y, mean, rstd, gamma, beta, skip, rows, C, F, relu=True):
     return out
 
 
-def bn_act_bwd(dout, y, mean, rstd, gamma, beta, rows, C, F, relu, training, dgamma, dbeta, dbias=None):
-    sums, z = ARENA.take(2 * C, y.device)
-    check(lib.cruse_bn_act_bwd_reduce(_p(dout), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), rows, C, F,
-                                      1 if relu else 0, _p(sums), z, _stream()))
+def bn_act_bwd(dout, y, mean, rstd, gamma, beta, rows, C, F, relu, training, dgamma, dbeta, dbias=None, sums=None):
+    """sums: the backward sums the convolution that produced dout has already accumulated (conv_gather / conv_scatter2 with
+    bn_bwd: [BN_STAT_REPLICAS][2*C]); None: the reduce pass runs here."""
+    nrep = BN_STAT_REPLICAS
+    if sums is None:
+        nrep = 1
+        sums, z = ARENA.take(2 * C, y.device)
+        check(lib.cruse_bn_act_bwd_reduce(_p(dout), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), rows, C, F,
+                                          1 if relu else 0, _p(sums), z, _stream()))
     dy = torch.empty_like(y)
-    check(lib.cruse_bn_act_bwd_apply(_p(dout), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(sums), rows, C, F,
+    check(lib.cruse_bn_act_bwd_apply(_p(dout), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(sums), nrep, rows, C, F,
                                      1 if relu else 0, 1 if training else 0, _p(dy), _p(dgamma), _p(dbeta),
                                      _p(dbias), _stream()))
     return dy

@@ -125,6 +125,23 @@ int cruse_conv_scatter2_bnstats(const float* g, const float* w, const float* bia
                                 int B, int T, int Cs, int Fg, int Cout, int Fout,
                                 int KT, int pad, int prec, double* sums, int zeroed, void* stream);
 
+/* DATA-GRADIENT convolutions whose output y is the gradient wrt the OUTPUT of a BatchNorm2d(+ReLU) (the backward pass of
+ * cruse_net.py:139-142,149-152 walks conv -> BN -> ReLU stacks, so every data gradient but the first feeds a BatchNorm
+ * backward): the conv's epilogue also accumulates what cruse_bn_act_bwd_reduce(dout = y, bn_y, ...) would -- sum g and
+ * sum g*xhat per channel, g = y masked by the ReLU, xhat from the pre-BN tensor bn_y [B,T,Cout,Fout] -- into
+ * sums [CRUSE_BN_STAT_REPLICAS][2*Cout] (cruse_bn_act_bwd_apply(sum_replicas) folds them): that pass over (y, bn_y), 132 MB
+ * and ~47 us per level at the bench shape, is not needed.  No bias, no activation; accum != 0: y += conv (the skip path's
+ * gradient is already there) and the statistics are those of the sum.  Shapes without the MFMA kernel run the conv and
+ * then the reduce pass (into replica 0).  The per-workgroup partial sums are f32, added in f64: independent of order. */
+int cruse_conv_gather_bnbwd(const float* x, const float* w, float* y, int B, int T, int Cin, int Fin, int Cout, int Fout,
+                            int KT, int S, int pad, int w_layout, int accum, int prec,
+                            const float* bn_y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                            int relu, double* sums, int zeroed, void* stream);
+int cruse_conv_scatter2_bnbwd(const float* g, const float* w, float* y, int B, int T, int Cs, int Fg, int Cout, int Fout,
+                              int KT, int pad, int accum, int prec,
+                              const float* bn_y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                              int relu, double* sums, int zeroed, void* stream);
+
 /* weight gradient of either form:
  *   dw[ca][cb][kt][kf] += sum_{b,t,fa} a[b,t,ca,fa] * bt[b, t-(KT-1)+kt, cb, fa*S - pad + kf]
  * ws: scratch of cruse_conv_wgrad_ws_bytes() bytes.  prec: CRUSE_PREC_* selects the MFMA kernel
@@ -172,9 +189,10 @@ int cruse_bn_act_bwd_reduce(const float* dout, const float* y, const float* mean
 /* dy = gamma*rstd*(g - [training](sum_g + xhat*sum_gx)/count); dgamma += sum_gx; dbeta += sum_g;
  * dbias (nullable) += per-channel sum of dy -- the gradient of the bias of the conv that feeds this BN -- in closed
  * form from the sums: gamma*rstd*sum_g with running statistics, and exactly 0 with batch statistics (sum xhat = 0:
- * the bias is cancelled by the mean subtraction; autograd leaves rounding noise there) */
+ * the bias is cancelled by the mean subtraction; autograd leaves rounding noise there)
+ * sums is [sum_replicas][2*C] (1 after cruse_bn_act_bwd_reduce, CRUSE_BN_STAT_REPLICAS after cruse_conv_*_bnbwd). */
 int cruse_bn_act_bwd_apply(const float* dout, const float* y, const float* mean, const float* rstd,
-                           const float* gamma, const float* beta, const double* sums,
+                           const float* gamma, const float* beta, const double* sums, int sum_replicas,
                            long long rows, int C, int F, int relu, int training,
                            float* dy, float* dgamma, float* dbeta, float* dbias, void* stream);
 

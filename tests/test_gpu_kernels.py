@@ -583,6 +583,44 @@ def test_gru_fwd_lean_matches_generic_kernel(ops, H, B, T):
     assert rel_l2(h_nosave, lean[0]) < 1e-6                # same kernel, saves off: identical
 
 
+@pytest.mark.parametrize("form,Cin,Cout,Fin,accum", [("gather", 16, 32, 40, False), ("gather", 1, 8, 161, False), ("gather", 32, 64, 20, False),
+                                                     ("scatter2", 64, 32, 10, True), ("scatter2", 16, 8, 40, True), ("scatter2", 32, 16, 20, False)])
+def test_conv_dgrad_accumulates_the_batchnorm_backward_sums(ops, form, Cin, Cout, Fin, accum):
+    """cruse_conv_gather_bnbwd / cruse_conv_scatter2_bnbwd: the data-gradient conv's epilogue accumulates the backward sums of the
+    BatchNorm(+ReLU) its output is the incoming gradient of -- bn_act_bwd with those sums == bn_act_bwd with its own reduce
+    pass over (dout, y); same conv output.  (Cin = 1: the VALU conv + the reduce pass inside the library.)"""
+    torch.manual_seed(Cin * 7 + Cout)
+    B, T = 3, 21
+    prec = "bf16"
+    if form == "gather":                                     # decoder data gradient: KT = 1, stride 2 (Fout = Fin // 2)
+        Fout = Fin // 2
+        x = torch.randn(B, T, Cin, Fin).cuda()
+        w = (0.2 * torch.randn(Cout, Cin, 1, 3)).cuda()
+        run = lambda bn, out: ops.conv_gather(x, w, None, B, T, Cin, Fin, Cout, Fout, KT=1, S=2, pad=0, out=out, accum=accum, prec=prec,
+                                              bn_bwd=bn)
+        C, F = Cout, Fout
+    else:
+        g = torch.randn(B, T, Cin, Fin).cuda()
+        w = (0.2 * torch.randn(Cin, Cout, 2, 3)).cuda()
+        C, F = Cout, 2 * Fin
+        run = lambda bn, out: ops.conv_scatter2(g, w, None, B, T, Cin, Fin, Cout, KT=2, pad=1, out=out, accum=accum, prec=prec, bn_bwd=bn)
+    rows = B * T
+    y = torch.randn(B, T, C, F).cuda()                       # pre-BN tensor of the BatchNorm behind the conv output
+    mean = (0.1 * torch.randn(C)).cuda(); rstd = (1.0 + 0.2 * torch.rand(C)).cuda()
+    gamma = (1.0 + 0.3 * torch.randn(C)).cuda(); beta = (0.2 * torch.randn(C)).cuda()
+    base = torch.randn(B, T, C, F).cuda()
+    out0 = run(None, base.clone() if accum else None)
+    out1, sums = run((y, mean, rstd, gamma, beta, True), base.clone() if accum else None)
+    assert torch.equal(out0, out1)
+    res = []
+    for sm in (None, sums):
+        dg = torch.zeros(C).cuda(); db = torch.zeros(C).cuda()
+        dy = ops.bn_act_bwd(out0, y, mean, rstd, gamma, beta, rows, C, F, True, True, dg, db, sums=sm)
+        res.append((dy, dg, db))
+    for a, b, name in zip(res[1], res[0], ("dy", "dgamma", "dbeta")):
+        assert rel_l2(a, b) < 2e-6, name
+
+
 @pytest.mark.parametrize("H,B,T,G", [(640, 64, 9, 1), (640, 24, 7, 1), (128, 16, 5, 1), (384, 5, 6, 1), (256, 33, 4, 2), (512, 17, 1, 1)])
 def test_gru_fwd_wide_chains_match_lean_kernel_bit_for_bit(ops, H, B, T, G):
     """cruse_gru_seq_fwd_ex(chain_clips = 16): chains of 16 clips (half the workgroups per clip; gru_fwd_w16_kernel) -- the lean
