@@ -36,6 +36,14 @@ constexpr int U = 32;                 // hidden units per workgroup
 constexpr int MAXG = 8;
 constexpr int CH = 10;                // 16-byte granule pairs in flight per thread and sweep batch
 constexpr unsigned SPIN_LIMIT = 1u << 21;
+// K-reduction buffer of the forward kernels: [4 K groups][6 tiles][RED_TS floats]; the f32x4 accumulator vector of lane L sits at
+// float offset (L + (L >> 4)) * 4 of its tile.  A gate thread (clip bl, unit u) reads element (u & 3) of lane ((u & 15) >> 2) * 16
+// + bl of tile gate*2 + (u >> 4): with the plain [64 lanes][4] image all 32 lanes of a half-wave fell on FOUR banks (tile and
+// 16-lane strides are multiples of 32 banks): an 8-way conflict on each of the 12 reads of every thread, ~700 of the ~3200
+// cycles of a step (s_memtime stamps, gru_dbg = 32).  The extra 16 bytes per 16 lanes and the 272-float tile stride (68 vector
+// slots = 4 mod 8) spread them over all 32.
+constexpr int RED_TS = 272;
+__device__ __forceinline__ int red_vec(int lane) { return (lane + (lane >> 4)) * 4; }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -135,6 +143,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 __device__ __forceinline__ unsigned dpp_xor1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false); }   // quad_perm [1,0,3,2]
 __device__ __forceinline__ unsigned dpp_xor2(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false); }   // quad_perm [2,3,0,1]
 __device__ __forceinline__ unsigned dpp_ror8(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false); }  // row_ror:8 == lane ^ 8
+__device__ __forceinline__ unsigned swz_xor16(unsigned v) { return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x401F); }        // ds_swizzle BITMASK_PERM: and 0x1f, xor 0x10
 __device__ __forceinline__ float bf16lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 __device__ __forceinline__ unsigned pack2(float a, float b) {
@@ -487,7 +496,7 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
             }
 #pragma unroll
             for (int j = 0; j < 6; ++j)
-                *reinterpret_cast<f32x4*>(red + ((wv * 6 + j) * 64 + lane) * 4) = acc[j];
+                *reinterpret_cast<f32x4*>(red + (wv * 6 + j) * RED_TS + red_vec(lane)) = acc[j];
             __syncthreads();
         }
 #pragma unroll
@@ -501,7 +510,7 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
 #pragma unroll
                 for (int g = 0; g < 3; ++g)
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) gh[g] += red[((w * 6 + g * 2 + half) * 64 + lp) * 4 + (ru & 3)];
+                    for (int w = 0; w < 4; ++w) gh[g] += red[(w * 6 + g * 2 + half) * RED_TS + red_vec(lp) + (ru & 3)];
             }
             const float r = fast_sigmoid(gic[q][0] + gh[0]);
             const float z = fast_sigmoid(gic[q][1] + gh[1]);
@@ -565,9 +574,13 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
 // queue as the next step's granule sweep (CRUSE_GRU_DBG=6 drops both: 675 vs 797 us per launch, tools/gru_hog_probe.py).
 // A fifth wavefront streams the gi rows into a 4-slot LDS ring four steps ahead and writes the saves -- which the compute
 // threads leave in LDS -- to HBM as 16-byte stores one step behind.
-template <int NKW, int NS, bool FULL, bool WLO>
+// TIMED (profiling, library option gru_dbg = 32 at Hg = 640): s_memtime stamps at the four phase boundaries of a step, summed by
+// workgroup (chain 0, part 0) into the status header (tools/gru_probe.py prints them).
+template <int NKW, int NS, bool FULL, bool WLO, bool TIMED = false>
 __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_kernel(GruArgs a) {
     constexpr bool HW = !(WLO && NKW > 3);
+    unsigned long long tph[5] = {0, 0, 0, 0, 0}, tq0 = 0, tq1 = 0;
+    (void)tph; (void)tq0; (void)tq1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ __attribute__((aligned(16))) float gi_r[HW ? 4 : 1][8][96];        // gi ring: slot = t & 3, [clip][gate*32 + unit]
     __shared__ __attribute__((aligned(16))) float sv_l[HW ? 2 : 1][6][8][32];     // saves of step t in parity t & 1
@@ -753,6 +766,7 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
     }
 
     for (int t = 0; t < a.T; ++t) {
+        if constexpr (TIMED) tq0 = __builtin_amdgcn_s_memtime();
         if (t > 0) {
             const unsigned soff = cbase + (unsigned)((t - 1) & 1) * panel_bytes;
             u32x4 g[NS];
@@ -768,8 +782,10 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
                     if (lane == 0) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     nowait = true;
                 }
+                if constexpr (TIMED) tph[4] += 1;
                 __builtin_amdgcn_s_sleep(1);
             }
+            if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[0] += tq1 - tq0; tq0 = tq1; }
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
                 const u32x2 w = {g[j].y, g[j].w};                   // already bf16 pairs: the LDS image as is
@@ -800,6 +816,7 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
         float gh[3] = {bias[0], bias[1], bias[2]};
         if (t > 0 || has_h0) {
             __syncthreads();                               // panel complete
+            if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[1] += tq1 - tq0; tq0 = tq1; }
             f32x4 acc[6];
 #pragma unroll
             for (int j = 0; j < 6; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -816,12 +833,13 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(red + ((wv * 6 + j) * 64 + lane) * 4) = acc[j];
+            for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(red + (wv * 6 + j) * RED_TS + red_vec(lane)) = acc[j];
             __syncthreads();
+            if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[2] += tq1 - tq0; tq0 = tq1; }
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
-                for (int w = 0; w < 4; ++w) gh[g] += red[((w * 6 + g * 2 + half) * 64 + lp) * 4 + (ru & 3)];
+                for (int w = 0; w < 4; ++w) gh[g] += red[(w * 6 + g * 2 + half) * RED_TS + red_vec(lp) + (ru & 3)];
         }
         const float r = lean_sigmoid(gic[0] + gh[0]);
         const float z = lean_sigmoid(gic[1] + gh[1]);
@@ -836,6 +854,7 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
                 else __builtin_amdgcn_raw_buffer_store_b64(w, rs, pub_v, soff, 16);
             }
         }
+        if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[3] += tq1 - tq0; tq0 = tq1; }
         const float an = (1.f - z) * (1.f - n * n);
         sv[0] = h;
         sv[1] = an * gh[2] * r * (1.f - r);
@@ -857,6 +876,13 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
         } else {
 #pragma unroll
             for (int g = 0; g < 3; ++g) gic[g] = gin_[g];
+        }
+    }
+    if constexpr (TIMED) {
+        if (tid == 0 && chain == 0 && part == 0) {
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.status) + 8;     // byte 64 of the status header
+            for (int i = 0; i < 5; ++i) dst[i] = tph[i];
+            dst[5] = (unsigned long long)a.T;
         }
     }
     if constexpr (HW) {
@@ -1110,12 +1136,12 @@ __global__ __launch_bounds__(576) void gru_fwd_w16_kernel(GruArgs a) {
                 for (int jj = 0; jj < 3; ++jj) acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jj][i], fb, acc[jj], 0, 0, 0);
             }
 #pragma unroll
-            for (int jj = 0; jj < 3; ++jj) *reinterpret_cast<f32x4*>(red + ((kg * 6 + jj * 2 + mg) * 64 + lane) * 4) = acc[jj];
+            for (int jj = 0; jj < 3; ++jj) *reinterpret_cast<f32x4*>(red + (kg * 6 + jj * 2 + mg) * RED_TS + red_vec(lane)) = acc[jj];
             __syncthreads();
 #pragma unroll
             for (int g = 0; g < 3; ++g)
 #pragma unroll
-                for (int w = 0; w < 4; ++w) gh[g] += red[((w * 6 + g * 2 + half) * 64 + lp) * 4 + (ru & 3)];
+                for (int w = 0; w < 4; ++w) gh[g] += red[(w * 6 + g * 2 + half) * RED_TS + red_vec(lp) + (ru & 3)];
         }
         const float r = lean_sigmoid(gic[0] + gh[0]);
         const float z = lean_sigmoid(gic[1] + gh[1]);
@@ -1292,8 +1318,10 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruArgs a) {
 // loads sat in front of the NEXT step's granule sweep and every step waited for them: 0.8 us of a 2.7 us step
 // (CRUSE_GRU_DBG=7 drops them: 769 vs 1087 us per launch alone, tools/gru_hog_probe.py).  A fifth wavefront now streams
 // them into a 4-slot LDS ring four steps ahead on its own vmcnt counter; the compute waves read them with ds_reads.
-template <int NP, bool FULL>
+template <int NP, bool FULL, bool TIMED = false>
 __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
+    unsigned long long tph[5] = {0, 0, 0, 0, 0}, tq0 = 0, tq1 = 0;
+    (void)tph; (void)tq0; (void)tq1;
     constexpr int KP = 96 + 8;                   // panel row stride (bf16): 208 B, de-phases the 16 rows of a b128 read
     constexpr int NT = 2 * NP;                   // 16-unit output tiles per wavefront
     constexpr int NL = NP;                       // 16-byte loads per thread and sweep: producers quarter*NL + j, j < NL = ceil(P/4)
@@ -1325,7 +1353,7 @@ __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
     const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.zs), 0, tot_f32, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_dh = __builtin_amdgcn_make_buffer_rsrc(a.dh, 0, tot_f32, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_cf = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.coefs), 0, tot_cf, 0x00020000);
-    const bool nodata = a.dbg == 7;                      // profiling: no operand streams
+    const bool nodata = a.dbg == 7 || a.dbg == 34;       // profiling: no operand streams
 
     if (wv == 4) {
         // ---- loader wave.  Iteration j needs dout_{T-1-j}, c_{T-1-j} and z_{T-j}; lane = (clip, 16-byte chunk).
@@ -1442,9 +1470,13 @@ __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
         }
     }
 
-    // thread = (clip bl, unit quad pp, quarter): owns unit u0 + 4*pp + quarter and sums, for all four units of its
-    // quad, the producers [quarter*NL, quarter*NL + NL) -- 16-byte loads; the quarters meet through two row moves
-    const int quarter = tid & 3, pp = (tid >> 2) & 7, bl = tid >> 5;
+    // thread = (clip bl, quarter, unit quad pp): owns unit u0 + 4*pp + quarter and sums, for all four units of its
+    // quad, the producers [quarter*NL, quarter*NL + NL) -- 16-byte loads; the quarters meet through two lane exchanges.
+    // pp is the FASTEST lane index: eight consecutive lanes read the 128 contiguous bytes of one (producer, clip) row.  (With
+    // the quarter fastest, neighbouring lanes read rows 5 KB apart -- four 64-byte requests with 16 useful bytes each where
+    // one would do: the first sweep of a step took ~1700 cycles to return against ~700 in the forward kernel, whose sweep
+    // is lane-linear; s_memtime stamps, gru_dbg = 32 / 35.)
+    const int pp = tid & 7, quarter = (tid >> 3) & 3, bl = tid >> 5;
     const bool active = bl < nb;
     const int blc = active ? bl : 0;                                  // inactive threads shadow clip 0 (loads only)
     unsigned sweep_v[NL];
@@ -1473,6 +1505,8 @@ __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
     float dh = 0.f, dd = 0.f, zz = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;  // operands of the current step (time s)
     const int ou = 4 * pp + quarter;                                  // own unit inside the workgroup's 32
     bool nowait = a.dbg >= 1 && a.dbg < 7;
+    const bool nopub = TIMED && a.dbg == 33;                          // profiling: no publishes (and no tag waits): garbage results
+    nowait = nowait || nopub;
     const bool plain = a.dbg != 9 && team_shares_xcd(a.xid + (size_t)chain * 64, P, part, a.status, tid);
     __syncthreads();                                                  // ring slots 0 and 1 are filled
     dd = op_d[0][blc][ou];
@@ -1481,6 +1515,13 @@ __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
     for (int k = 0; k < a.T; ++k) {
         const int s = a.T - 1 - k;
         float m = 0.f;
+        if constexpr (TIMED) tq0 = __builtin_amdgcn_s_memtime();
+        if constexpr (TIMED) {
+            if (a.dbg == 35) {                             // profiling: drain the publish stores first, stamp, then sweep
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                tq1 = __builtin_amdgcn_s_memtime(); tph[4] += tq1 - tq0; tq0 = tq1;
+            }
+        }
         if (k > 0) {
             const unsigned soff = cbase + (unsigned)((k - 1) & 1) * panel_bytes;
             u32x4 g[NL];
@@ -1496,8 +1537,10 @@ __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
                     if (lane == 0) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     nowait = true;
                 }
+                if constexpr (TIMED) { if (a.dbg != 35) tph[4] += 1; }
                 __builtin_amdgcn_s_sleep(1);
             }
+            if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[0] += tq1 - tq0; tq0 = tq1; }
             float sm[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < NL; ++j) {
@@ -1507,8 +1550,8 @@ __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                sm[e] += __uint_as_float(dpp_xor1(__float_as_uint(sm[e])));
-                sm[e] += __uint_as_float(dpp_xor2(__float_as_uint(sm[e])));
+                sm[e] += __uint_as_float(dpp_ror8(__float_as_uint(sm[e])));          // lane ^ 8:  quarter ^ 1
+                sm[e] += __uint_as_float(swz_xor16(__float_as_uint(sm[e])));         // lane ^ 16: quarter ^ 2
             }
             m = quarter == 0 ? sm[0] : quarter == 1 ? sm[1] : quarter == 2 ? sm[2] : sm[3];
         }
@@ -1526,7 +1569,9 @@ __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
             zz = op_z[slot][blc][ou];
             c0 = (float)op_c[slot][blc][ou]; c1 = (float)op_c[slot][blc][32 + ou]; c2 = (float)op_c[slot][blc][64 + ou];
         }
+        if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[1] += tq1 - tq0; tq0 = tq1; }
         __syncthreads();                                   // panel[k & 1] complete; panel[(k+1) & 1] is free again
+        if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[2] += tq1 - tq0; tq0 = tq1; }
         // tile PAIRS, each finished (3 k-steps, the two tiles interleaved so no MFMA waits on its own accumulator) and
         // published before the next pair starts: the stores of the first pairs travel while the MFMAs still run.
         // acc[j]: output unit tile*16 + (lane>>4)*4 + j of clip (lane & 15); see pub_v
@@ -1548,10 +1593,18 @@ __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
             const unsigned b0_ = pack2(c1_[0], c1_[1]), b1_ = pack2(c1_[2], c1_[3]);
             const unsigned x0 = dpp_ror8(b0_), x1 = dpp_ror8(b1_);
             const u32x4 w = {ep, hi8 ? x0 : a0, ep, hi8 ? x1 : a1};
-            if (pub_ok[np]) {
+            if (pub_ok[np] && !nopub) {
                 if (plain) __builtin_amdgcn_raw_buffer_store_b128(w, rs, pub_v[np], soff, 0);
                 else __builtin_amdgcn_raw_buffer_store_b128(w, rs, pub_v[np], soff, 16);
             }
+        }
+        if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[3] += tq1 - tq0; tq0 = tq1; }
+    }
+    if constexpr (TIMED) {
+        if (tid == 0 && chain == 0 && part == 0) {
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.status) + 16;    // byte 128 of the status header
+            for (int i = 0; i < 5; ++i) dst[i] = tph[i];
+            dst[5] = (unsigned long long)a.T;
         }
     }
     __syncthreads();                                       // hands the last iteration's dh to the loader wave
@@ -1794,6 +1847,8 @@ int dispatch_fwd_w16(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
     }
 }
 int dispatch_fwd_lean(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
+    if (a.dbg == 32 && a.Hg == 640 && !fwd_wlo(a.Hg))
+        return launch_one(gru_fwd_lean_kernel<5, 5, true, false, true>, a, grid, lds, s, "gru_seq_fwd", 320);
     return fwd_wlo(a.Hg) ? dispatch_fwd_lean_w<true>(a, grid, lds, s) : dispatch_fwd_lean_w<false>(a, grid, lds, s);
 }
 
@@ -1816,6 +1871,7 @@ int dispatch_bwd(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
 
 int dispatch_bwd_rs(const GruArgs& a, int grid, hipStream_t s) {
     const int P = a.Hg / 32, np = (P + 3) / 4;   // tile pairs per wavefront
+    if (a.dbg >= 32 && a.dbg <= 35 && a.Hg == 640) return launch_one(gru_bwd_rs_kernel<5, true, true>, a, grid, 0, s, "gru_seq_bwd", 320);
     if (P % 4 == 0) {
         switch (np) {
             case 1: return launch_one(gru_bwd_rs_kernel<1, true>, a, grid, 0, s, "gru_seq_bwd", 320);
@@ -1938,7 +1994,7 @@ extern "C" int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, c
     a.B = B; a.T = T; a.G = G; a.Hg = Hg;
     a.TS = TS; a.h0 = h0; a.h0_bs = h0_bstride;
     const size_t esz = prec == CRUSE_PREC_F32 ? 4 : 2, npl = prec == CRUSE_PREC_BF16X3 ? 2 : 1;
-    const size_t lds = (size_t)16 * (Hg + (prec == CRUSE_PREC_F32 ? 4 : 8)) * esz * npl + 4 * 6 * 64 * 4 * sizeof(float);
+    const size_t lds = (size_t)16 * (Hg + (prec == CRUSE_PREC_F32 ? 4 : 8)) * esz * npl + 4 * 6 * RED_TS * sizeof(float);
     return run_launches<true>(a, pl, G, Hg, prec, panels, status, xcd_rot, lds, s);
 }
 

@@ -24,13 +24,23 @@ for rnd in range(3):
     for m in modes:
         ops.set_option("gru_dbg", int(m))
         tf = timeit(lambda: ops.gru_seq_fwd(gi, ws, bs, B, T, G, Hg, "bf16"))
-        if int(m) & 16:
+        if int(m) == 32:                       # phase stamps of the lean forward kernel (workgroup 0 of chain 0)
             ops.gru_seq_fwd(gi, ws, bs, B, T, G, Hg, "bf16"); torch.cuda.synchronize()
             for (key, _d), buf in ops._wgrad_ws.items():
                 if key == "gru":
-                    st = buf[64:96].view(torch.int64).tolist()
-                    n = max(st[3], 1)
-                    print(f"   fwd phases (s_memtime ticks/step, 100 MHz): sweep {st[0]/n:.1f} mfma+red {st[1]/n:.1f} gates+publish {st[2]/n:.1f}")
+                    st = buf[64:112].view(torch.int64).tolist()
+                    n = max(st[5], 1)
+                    tot = sum(st[:4])
+                    print(f"   lean fwd phases (s_memtime ticks per step; {tf*1e3/T:.2f} us/step measured => {tf*1e3/T/(tot/n)*1e3:.1f} ns per tick): "
+                          f"sweep until tags match {st[0]/n:.1f} | LDS write + barrier A {st[1]/n:.1f} | MFMA + red + barrier B {st[2]/n:.1f} | "
+                          f"red read + gates + publish {st[3]/n:.1f} | rest (saves, gi) {tf*1e3/T*0 + 0:.0f}; re-polls per step {st[4]/n:.2f}")
         tb = timeit(lambda: ops.gru_seq_bwd(dout, ws, coef, z, B, T, G, Hg, "bf16"))
+        if int(m) in (32, 33, 34, 35):
+            for (key, _d), buf in ops._wgrad_ws.items():
+                if key == "gru":
+                    st = buf[128:176].view(torch.int64).tolist()
+                    n = max(st[5], 1)
+                    print(f"   rs bwd phases (cycles per step; {tb*1e3/T:.2f} us/step): sweep until tags match {st[0]/n:.0f} | sum + dh + panel write {st[1]/n:.0f} | "
+                          f"barrier {st[2]/n:.0f} | fragment reads + MFMA + publishes {st[3]/n:.0f}; re-polls per step {st[4]/n:.2f}")
         out.append(f"dbg={m}: fwd {tf*1e3/T:.2f} bwd {tb*1e3/T:.2f} us/step")
     print(f"B={B} G={G} round {rnd}: " + " | ".join(out), "status", ops.gru_status())
