@@ -574,6 +574,12 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
 // queue as the next step's granule sweep (CRUSE_GRU_DBG=6 drops both: 675 vs 797 us per launch, tools/gru_hog_probe.py).
 // A fifth wavefront streams the gi rows into a 4-slot LDS ring four steps ahead and writes the saves -- which the compute
 // threads leave in LDS -- to HBM as 16-byte stores one step behind.
+// (A WAVE-LOCAL panel -- a producer-major hand-off panel, every wave sweeping exactly the 1 KB blocks of the producers whose
+// k-steps it multiplies and reading its fragments back without the "panel complete" barrier -- was measured at 1.66 us per step
+// against 1.28, r03: the workgroup then reaches its next sweep ~250 cycles earlier, BEFORE its team mates' granules are in L2,
+// and a missed poll costs a whole L2 round trip (~800 cycles): 1.0 re-polls per step instead of 0.1.  With the barrier the
+// team sits where the first poll just hits: a step is the workgroup's own ~1900 cycles plus one ~700-cycle load round trip,
+// the publish latency hidden under the load's way out.)
 // TIMED (profiling, library option gru_dbg = 32 at Hg = 640): s_memtime stamps at the four phase boundaries of a step, summed by
 // workgroup (chain 0, part 0) into the status header (tools/gru_probe.py prints them).
 template <int NKW, int NS, bool FULL, bool WLO, bool TIMED = false>
@@ -1318,6 +1324,13 @@ __global__ __launch_bounds__(256) void gru_bwd_kernel(GruArgs a) {
 // loads sat in front of the NEXT step's granule sweep and every step waited for them: 0.8 us of a 2.7 us step
 // (CRUSE_GRU_DBG=7 drops them: 769 vs 1087 us per launch alone, tools/gru_hog_probe.py).  A fifth wavefront now streams
 // them into a 4-slot LDS ring four steps ahead on its own vmcnt counter; the compute waves read them with ds_reads.
+// Step anatomy after the lane-linear sweep (s_memtime stamps of workgroup 0, gru_dbg = 32; cycles of a ~3400-cycle step): sweep
+// until the tags match ~1250 | partial sums, dh, panel ~500 | barrier ~240 | fragment reads, 30 MFMAs, 5 publishes ~1550, of
+// which the MFMAs are ~430 and the stores ~420 (gru_dbg 33 / 37).  Measured and NOT kept, all neutral on the step although they
+// shorten the last phase by 100-230 cycles (the team's pace is set by the hand-off -- 20 KB of publishes per workgroup and step
+// take ~490 cycles to drain after the last one is issued, gru_dbg = 35 -- not by one workgroup's own work): issuing pair
+// np + 1's MFMAs before pair np is converted and stored; four accumulators in rotation; compiling the step loop twice instead
+// of choosing plain / write-through stores by two scalar branches per store; delaying the first poll by 64-384 cycles.
 template <int NP, bool FULL, bool TIMED = false>
 __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
     unsigned long long tph[5] = {0, 0, 0, 0, 0}, tq0 = 0, tq1 = 0;
