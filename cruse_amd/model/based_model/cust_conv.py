@@ -187,20 +187,25 @@ class GroupedGRULayer(nn.Module):
         super().__init__()
         assert input_size % groups == 0
         assert hidden_size % groups == 0
-        if bidirectional or not batch_first or not bias or dropout:
-            raise RuntimeError("cruse_amd GroupedGRULayer: unidirectional, batch_first, biased, dropout-free GRUs only")
+        if not batch_first or not bias:
+            raise RuntimeError("cruse_amd GroupedGRULayer: batch_first, biased GRUs only")
+        # dropout: nn.GRU applies it BETWEEN stacked layers only; every group's nn.GRU here has one layer (cust_conv.py:286-287), so the
+        # reference's argument has no effect either (torch warns) -- it is accepted and kept in the sub-modules' kwargs
         kwargs = {"bias": bias, "batch_first": batch_first, "dropout": dropout, "bidirectional": bidirectional}
         self.input_size = input_size // groups
         self.hidden_size = hidden_size // groups
         self.out_size = hidden_size
         self.bidirectional = bidirectional
-        self.num_directions = 1
+        self.num_directions = 2 if bidirectional else 1
         self.groups = groups
         self.batch_first = batch_first
         assert (self.hidden_size % groups) == 0, "Hidden size must be divisible by groups"       # :284-285
         if self.hidden_size % 32:
             raise RuntimeError(f"cruse_amd GroupedGRULayer: hidden size per group {self.hidden_size} must be a multiple of 32")
-        self.layers = nn.ModuleList(nn.GRU(self.input_size, self.hidden_size, **kwargs) for _ in range(groups))
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")                 # (torch: "dropout expects num_layers greater than 1")
+            self.layers = nn.ModuleList(nn.GRU(self.input_size, self.hidden_size, **kwargs) for _ in range(groups))
 
     def flatten_parameters(self):
         pass
@@ -208,22 +213,36 @@ class GroupedGRULayer(nn.Module):
     def get_h0(self, batch_size: int = 1, device: torch.device = torch.device("cpu")):
         return torch.zeros(self.groups * self.num_directions, batch_size, self.hidden_size, device=device)
 
-    def forward(self, input: Tensor, h0: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
-        # state [G*D, B, H/g] (:305-306) -> the kernel's [B, G*H/g] "cat" layout; detached like the reference's (:319)
-        h0c = None
-        if h0 is not None:
-            if tuple(h0.shape) != (self.groups, input.shape[0], self.hidden_size):
-                raise RuntimeError(f"GroupedGRULayer: state {tuple(h0.shape)} != "
-                                   f"{(self.groups, input.shape[0], self.hidden_size)}")
-            h0c = h0.detach().to(input.device, torch.float32).transpose(0, 1).reshape(input.shape[0], -1).contiguous()
+    def _direction(self, x: Tensor, h0c: Optional[Tensor], suffix: str) -> Tensor:
         params = []
         for layer in self.layers:
-            params += [layer.weight_ih_l0, layer.weight_hh_l0, layer.bias_ih_l0, layer.bias_hh_l0]
-        out = _GroupedGruFn.apply(input, self.groups, h0c, *params)
-        B, T, H = out.shape
-        # final states [G*D, B, H/g] = the last frame of every group's slice (cust_conv.py:323)
-        h = out[:, -1, :].reshape(B, self.groups, self.hidden_size).transpose(0, 1).contiguous()
-        return out, h
+            params += [getattr(layer, "weight_ih_l0" + suffix), getattr(layer, "weight_hh_l0" + suffix),
+                       getattr(layer, "bias_ih_l0" + suffix), getattr(layer, "bias_hh_l0" + suffix)]
+        return _GroupedGruFn.apply(x, self.groups, h0c, *params)
+
+    def forward(self, input: Tensor, h0: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+        # state [G*D, B, H/g] (:305-306; group-major, direction-minor) -> the kernel's [B, G*H/g] "cat" layout per direction;
+        # detached like the reference's (:319)
+        B, D, g, Hg = input.shape[0], self.num_directions, self.groups, self.hidden_size
+        h0d = [None] * D
+        if h0 is not None:
+            if tuple(h0.shape) != (g * D, B, Hg):
+                raise RuntimeError(f"GroupedGRULayer: state {tuple(h0.shape)} != {(g * D, B, Hg)}")
+            st = h0.detach().to(input.device, torch.float32).view(g, D, B, Hg)
+            h0d = [st[:, d].transpose(0, 1).reshape(B, -1).contiguous() for d in range(D)]
+        out = self._direction(input, h0d[0], "")
+        if not self.bidirectional:
+            # final states [G, B, H/g] = the last frame of every group's slice (cust_conv.py:323)
+            return out, out[:, -1, :].reshape(B, g, Hg).transpose(0, 1).contiguous()
+        # the reverse direction (nn.GRU(bidirectional=True): weights *_reverse) is the same recurrence on the time-reversed
+        # sequence, its outputs reversed back; a group's output is [forward | reverse] (torch), the groups are concatenated
+        # after that (:322), and a group's two final states are h_{T-1} of the forward and h_0 of the reverse direction
+        rev = torch.flip(self._direction(torch.flip(input, dims=(1,)), h0d[1], "_reverse"), dims=(1,))
+        T = out.shape[1]
+        y = torch.stack((out.view(B, T, g, Hg), rev.view(B, T, g, Hg)), dim=3).reshape(B, T, g * 2 * Hg)
+        hf = out[:, -1, :].reshape(B, g, Hg)
+        hr = rev[:, 0, :].reshape(B, g, Hg)
+        return y, torch.stack((hf, hr), dim=2).permute(1, 2, 0, 3).reshape(g * 2, B, Hg).contiguous()
 
 
 class GroupGRU(nn.Module):

@@ -217,6 +217,16 @@ def test_oracle_round3_fixtures(golden):
         O.closed_form_init(m, scale=2.0)
         y, s = m(x, torch.from_numpy(g[f"{name}/state_in"]))
         assert torch.equal(y, torch.from_numpy(g[f"{name}/y"])) and torch.equal(s, torch.from_numpy(g[f"{name}/state"])), name
+    # G22: GroupedGRULayer(bidirectional=True, dropout=0.3) as shipped
+    g = golden("g22_grouped_gru_bidirectional.npz")
+    x = torch.from_numpy(g["x"])
+    for name, grp in {"g2": 2, "g1": 1}.items():
+        m = X.GroupedGRULayer(128, 128, grp, dropout=0.3, bidirectional=True).train()
+        O.closed_form_init(m, scale=2.0)
+        y, st = m(x, torch.from_numpy(g[f"{name}/state_in"]))
+        assert torch.equal(y, torch.from_numpy(g[f"{name}/y"])) and torch.equal(st, torch.from_numpy(g[f"{name}/state"])), name
+        y0, st0 = m(x)
+        assert torch.equal(y0, torch.from_numpy(g[f"{name}/y_zero_state"])) and torch.equal(st0, torch.from_numpy(g[f"{name}/state_zero_state"]))
     s = golden("g20_snr_mix_rir.npz")
     for b in range(3):
         noisy, c, n = X.snr_mix(s["clean"][b].copy(), s["noise"][b].copy(), float(s["snr"][b]), rir=s["rir"][b].copy(),
