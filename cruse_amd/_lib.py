@@ -33,6 +33,7 @@ SIGNATURES = {
     "cruse_conv_scatter2": ("ppppiiiiiiiiiiip", "i"),
     "cruse_conv_gather_bnstats": ("ppppiiiiiiiiiipip", "i"),
     "cruse_conv_scatter2_bnstats": ("ppppiiiiiiiiipip", "i"),
+    "cruse_conv_mfma_stamps": ("p", "i"),
     "cruse_conv_gather_bnbwd": ("pppiiiiiiiiiiiipppppipip", "i"),
     "cruse_conv_scatter2_bnbwd": ("pppiiiiiiiiiipppppipip", "i"),
     "cruse_conv_wgrad_ws_bytes": ("iii", "z"),

@@ -31,7 +31,13 @@ struct TapClass {
     int dt[MAXTAP], df[MAXTAP], wk[MAXTAP];     // frame offset, input-bin offset, weight tap index (kt*3+kf)
 };
 
+// profiling (library option cm_dbg = 1): s_memtime phase sums of workgroup 0 / wave 0 of the LAST launch:
+// [0] prologue (weight fragments) [1] waiting for + storing the staged tile (two barriers) [2] k-loops (gather + MFMA)
+// [3] epilogues (stores) [4] tiles [5] N-tiles of wave 0 [6] total
+__device__ unsigned long long g_cm_stamps[8];
+
 struct CMArgs {
+    int tdbg;
     const float* x; const float* w; const float* bias; float* y;
     int B, T, Cin, Fin, Cout, Fout;
     int S, OS, nclass, halo_lo;                  // input bin stride, output bin stride, classes, frames of halo before t0
@@ -122,6 +128,9 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
     __shared__ float s_bnp[STATS ? 4 : 1][MT * 16];       // mean, rstd, gamma, beta of the backward-statistics form
 
     const int ntile = (a.T + TFM - 1) / TFM;
+    const bool tdbg = a.tdbg != 0 && blockIdx.x == 0 && wv == 0;
+    unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tq0 = 0, tq1 = 0, tbeg = 0;
+    if (tdbg) { tbeg = tq0 = __builtin_amdgcn_s_memtime(); }
 
     if (tid < 2 * MAXTAP) {
         const int c = tid / MAXTAP, i = tid % MAXTAP;
@@ -195,6 +204,7 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
         }
     };
     if ((int)blockIdx.x < a.B * ntile) prefetch(blockIdx.x);
+    if (tdbg) { tq1 = __builtin_amdgcn_s_memtime(); tsum[0] += tq1 - tq0; tq0 = tq1; }
     for (int tile = blockIdx.x; tile < a.B * ntile; tile += gridDim.x) {
         const int b = tile / ntile;
         const int t0 = (tile - b * ntile) * TFM;
@@ -228,6 +238,7 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
             if (wv < a.nclass * ntile_c) aux_load(wv, old_c, by_c);
         }
         if (tile + (int)gridDim.x < a.B * ntile) prefetch(tile + gridDim.x);
+        if (tdbg) { tq1 = __builtin_amdgcn_s_memtime(); tsum[1] += tq1 - tq0; tq0 = tq1; tsum[4] += 1; }
 
         // N-tile loop, kept free of integer divisions (Cin is a power of two, positions via a float reciprocal)
         // and of global loads; one 64-bit base address per N-tile.  (Keeping several N-tiles in flight per wave
@@ -271,6 +282,7 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
                     acc[mt] = mma(fa, fb, acc[mt]);
                 }
             }
+            if (tdbg) { tq1 = __builtin_amdgcn_s_memtime(); tsum[2] += tq1 - tq0; tq0 = tq1; tsum[5] += 1; }
             const int t = t0 + tl;
             if (t < a.T) {
                 const int fo = a.OS * m + (c ? par1 : par0);
@@ -309,7 +321,12 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) { old_c[mt][r4] = old_n[mt][r4]; by_c[mt][r4] = by_n[mt][r4]; }
             }
+            if (tdbg) { tq1 = __builtin_amdgcn_s_memtime(); tsum[3] += tq1 - tq0; tq0 = tq1; }
         }
+    }
+    if (tdbg && lane == 0) {
+        for (int i = 0; i < 6; ++i) g_cm_stamps[i] = tsum[i];
+        g_cm_stamps[6] = __builtin_amdgcn_s_memtime() - tbeg;
     }
     if constexpr (STATS) {
         if (a.sums == nullptr) return;                     // (EPI 2 without backward statistics: accumulate only)
@@ -389,6 +406,7 @@ int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float
     a.x = x; a.w = w; a.bias = bias; a.y = y;
     a.B = B; a.T = T; a.Cin = Cin; a.Fin = Fin; a.Cout = Cout; a.Fout = Fout;
     a.act = act; a.accum = accum; a.sums = bn_sums;
+    a.tdbg = cruse_opt("cm_dbg", 0);
     if (bnb != nullptr) {
         a.bn_y = bnb->y; a.bn_mean = bnb->mean; a.bn_rstd = bnb->rstd; a.bn_gamma = bnb->gamma; a.bn_beta = bnb->beta;
         a.bn_relu = bnb->relu;
@@ -450,4 +468,9 @@ int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { cruse_set_error("conv_mfma: HIP launch failed: %s", hipGetErrorString(e)); return CRUSE_E_HIP; }
     return 1;
+}
+
+// profiling: the phase stamps of the last conv_mfma launch with option cm_dbg = 1 (see g_cm_stamps)
+extern "C" int cruse_conv_mfma_stamps(unsigned long long* out8) {
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_cm_stamps), 8 * sizeof(unsigned long long)) == hipSuccess ? CRUSE_OK : CRUSE_E_HIP;
 }

@@ -142,6 +142,11 @@ int cruse_conv_scatter2_bnbwd(const float* g, const float* w, float* y, int B, i
                               const float* bn_y, const float* mean, const float* rstd, const float* gamma, const float* beta,
                               int relu, double* sums, int zeroed, void* stream);
 
+/* profiling aid: with cruse_set_option("cm_dbg", 1) workgroup 0 of an MFMA convolution launch stamps s_memtime at its phase
+ * boundaries; this copies the sums of the LAST such launch to out8 (host memory, 8 values: prologue, tile staging incl. the wait
+ * for the prefetch, k-loops, epilogues, tiles, N-tiles of wave 0, total; cycles) -- tools/conv_probe.py */
+int cruse_conv_mfma_stamps(unsigned long long* out8);
+
 /* weight gradient of either form:
  *   dw[ca][cb][kt][kf] += sum_{b,t,fa} a[b,t,ca,fa] * bt[b, t-(KT-1)+kt, cb, fa*S - pad + kf]
  * ws: scratch of cruse_conv_wgrad_ws_bytes() bytes.  prec: CRUSE_PREC_* selects the MFMA kernel
