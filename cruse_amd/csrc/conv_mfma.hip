@@ -37,7 +37,7 @@ struct TapClass {
 __device__ unsigned long long g_cm_stamps[8];
 
 struct CMArgs {
-    int tdbg;
+    int tdbg, kint;
     const float* x; const float* w; const float* bias; float* y;
     int B, T, Cin, Fin, Cout, Fout;
     int S, OS, nclass, halo_lo;                  // input bin stride, output bin stride, classes, frames of halo before t0
@@ -152,6 +152,13 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
     // One (fragment, lane) pair per work item: the index arithmetic is done once per 8 elements and the 8 loads
     // are independent (Cin is a power of two, so tap/ci come from shifts).
     const int lg_cin = 31 - __clz(a.Cin);                  // Cin is a power of two (host-checked)
+    // K ORDER inside a 32-deep k-step.  The lane groups g = lane >> 4 that share a tap (ngrp = min(Cin, 32) / 8 of them) take
+    // INTERLEAVED channels -- element e of group g is channel cbase + e*ngrp + (g % ngrp) -- instead of 8 consecutive ones: the
+    // gather below then reads, per element, channels that are ONE row (Fin floats) apart across the groups instead of EIGHT
+    // (8*Fin floats = a multiple of 32 banks for Fin = 20, 40, 80: all four groups on the same 16 banks, a 4-way conflict on each
+    // of the 8 reads of every k-step; PMC: 25-40 % of these kernels' LDS-active cycles).  The weight fragments are built in the
+    // same order, so nothing else changes.
+    const int cblk = a.kint ? (a.Cin < 32 ? a.Cin : 32) : 8, ngrp = cblk >> 3;       // (option cm_kint = 0: consecutive channels, the A/B switch)
     for (int it = tid; it < nfrag * 64; it += NTHR) {
         const int l = it & 63, fr = it >> 6;
         int c = 0, rem = fr;
@@ -160,12 +167,14 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
         const int mt = rem / ksn, ks = rem - mt * ksn;
         const int co = mt * 16 + (l & 15);
         const int k0 = ks * 32 + (l >> 4) * 8;
-        const int tap = k0 >> lg_cin, ci0 = k0 & (a.Cin - 1);     // 8 | Cin: the 8 elements share one tap
+        const int tap = k0 >> lg_cin;                              // 8 | Cin: the 8 elements share one tap
+        // element e of lane group g is channel cbase + e*ngrp + (g % ngrp) of that tap (see the gather below)
+        const int ci0 = (k0 & (a.Cin - 1) & ~(cblk - 1)) + ((l >> 4) & (ngrp - 1));
         float v[8];
         const bool ok = co < a.Cout && tap < a.cls[c].ntaps;
         const float* wp = a.w + co * a.sco + ci0 * a.sci + (ok ? a.cls[c].wk[tap] : 0);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = ok ? wp[e * a.sci] : 0.f;
+        for (int e = 0; e < 8; ++e) v[e] = ok ? wp[e * ngrp * a.sci] : 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) put_elem<PREC>(wl, wplane, (size_t)it * 8 + e, v[e]);
     }
@@ -261,15 +270,16 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
             for (int ks = 0; ks < ksn; ++ks) {
                 const int k = ks * 32 + q8;
                 int tap = k >> lg_cin;
-                const int ci0 = k & (a.Cin - 1);
+                const int ci0 = (k & (a.Cin - 1) & ~(cblk - 1)) + ((lane >> 4) & (ngrp - 1));
                 if (tap >= ntaps) tap = ntaps - 1;        // zero weights there; keep the address valid
                 const int2 tp = s_tap2[c][tap];           // x = dt*rowlen + df, y = df
                 const int f = a.S * m + tp.y;
                 float bv[8];
                 if (f >= 0 && f < a.Fin) {
                     const float* pb = xl + rowbase + tp.x + ci0 * a.Fin;
+                    const int cstep = ngrp * a.Fin;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) bv[e] = pb[e * a.Fin];
+                    for (int e = 0; e < 8; ++e) bv[e] = pb[e * cstep];
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) bv[e] = 0.f;
@@ -407,6 +417,7 @@ int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float
     a.B = B; a.T = T; a.Cin = Cin; a.Fin = Fin; a.Cout = Cout; a.Fout = Fout;
     a.act = act; a.accum = accum; a.sums = bn_sums;
     a.tdbg = cruse_opt("cm_dbg", 0);
+    a.kint = cruse_opt("cm_kint", 1);
     if (bnb != nullptr) {
         a.bn_y = bnb->y; a.bn_mean = bnb->mean; a.bn_rstd = bnb->rstd; a.bn_gamma = bnb->gamma; a.bn_beta = bnb->beta;
         a.bn_relu = bnb->relu;
