@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the T=401 oracle parity figure (parity_rel_l2)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the f32 gate-mode and hop=320 STFT rows")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the f32 gate-mode, hop=320 STFT and upsample-decoder rows")
     ap.add_argument("--df", action="store_true", help="BASELINE config 4: DeepFilter(1,5) head + WO-MALE on its output")
     ap.add_argument("--bucketed", action="store_true", help="force the segmented (multi-GPU) schedule at world 1")
     ap.add_argument("--ref-1gpu", type=float, default=None, help="frames/s of the 1-GPU run of the same configuration: adds "
@@ -396,6 +396,36 @@ def secondary_rows(a, dev, pool):
                                       "note": "forward STFT only, hop = win = 320 (20 ms hop)"}
     except Exception as ex:
         out["stft_hop320_forward"] = {"error": repr(ex)[:200]}
+    # (3) the nearest-upsample decoder variant (model/cruse.py:14 CRUSE4MagAddSkipUpsample): forward + mask-weighted loss
+    #     + backward through the nn.Module / autograd surface -- general NCHW blocks (generic.hip) around the persistent GRU
+    #     kernels, no hand-scheduled step, no optimizer: the cost of the variant's model, not a training-step figure
+    try:
+        from cruse_amd.model.cruse import CRUSE4MagAddSkipUpsample
+        torch.manual_seed(0)
+        B, L = pool[0][0].shape
+        Bu, T = min(B, 16), 1 + L // 160
+        mu = CRUSE4MagAddSkipUpsample(rnn_groups=a.groups, precision="bf16").to(dev).train()
+        xin = torch.rand(Bu, 1, T, 160, device=dev) + 0.05
+        tgt = torch.rand(Bu, 1, T, 160, device=dev)
+
+        def it():
+            for q in mu.parameters():
+                q.grad = None
+            ((mu(xin) - tgt) ** 2).mean().backward()
+        it(); torch.cuda.synchronize()
+        n = 5
+        t0 = time.perf_counter()
+        for _ in range(n):
+            it()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        out["upsample_decoder_variant"] = {"value": round(Bu * T / dt, 1), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3), "batch": Bu,
+                                           "steps": n, "dtype": "bf16 bottleneck, f32 blocks",
+                                           "note": "CRUSE4MagAddSkipUpsample forward + MSE + backward (autograd over the general NCHW kernels; "
+                                                   "no optimizer)"}
+        del mu
+    except Exception as ex:
+        out["upsample_decoder_variant"] = {"error": repr(ex)[:200]}
     return out
 
 
