@@ -646,6 +646,29 @@ def test_gru_fwd_wide_chains_match_lean_kernel_bit_for_bit(ops, H, B, T, G):
     assert ops.gru_status() == 0
 
 
+def test_gru_wide_chains_at_the_bench_length(ops):
+    """T = 401, B = 64, Hg = 640: the wide-chain forward launch (4 chains of 16 on 80 CUs) against the lean one (8 chains of 8 on
+    160) over the whole sequence -- 401 dependent hand-offs per chain -- bit for bit; two wide launches side by side on the two
+    XCD halves (slots 0 / 1, xcd_rot 0 / 4) as well."""
+    torch.manual_seed(11)
+    B, T, H = 64, 401, 640
+    gi = (0.5 * torch.randn(B, T, 3 * H)).cuda()
+    w = [(torch.randn(3 * H, H) / H ** 0.5).cuda()]; b = [(0.1 * torch.randn(3 * H)).cuda()]
+    lean = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16")
+    wide = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16", wide=True)
+    for x, y, name in zip(wide, lean, ("h", "coef", "an", "z")):
+        assert torch.equal(x, y), name
+    s2 = torch.cuda.Stream()
+    s2.wait_stream(torch.cuda.current_stream())
+    a1 = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16", wide=True, slot=0, xcd_rot=0)
+    with torch.cuda.stream(s2):
+        a2 = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16", wide=True, slot=1, xcd_rot=4)
+    torch.cuda.current_stream().wait_stream(s2)
+    torch.cuda.synchronize()
+    assert torch.equal(a1[0], lean[0]) and torch.equal(a2[0], lean[0])
+    assert ops.gru_status() == 0
+
+
 def test_gru_batch_beyond_the_cu_count(ops):
     """B = 136 at Hg = 640: 17 chains of 8 x 20 workgroups do not fit the 256 CUs.  Forward: one launch of the wide-chain kernel
     (9 chains of 16); backward: several launches of the reduce-scatter kernel on chains of 8.  Same results as the batch run in
