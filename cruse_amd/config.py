@@ -49,7 +49,7 @@ class EngineConfig:
             "gi_x3": ("CRUSE_GI_X3", int), "dw_xcdk": ("CRUSE_DW_XCDK", int), "conv_bwd_x3": ("CRUSE_CONV_BWD_X3", lambda v: v == "1"),
             "dw_tn": ("CRUSE_DW_TN", lambda v: v == "1"), "fwd_chunks": ("CRUSE_FWD_CHUNKS", int)}
     _LIB_ENV = {"CRUSE_GRU_BWD_RS": "gru_bwd_rs", "CRUSE_GRU_FWD_LEAN": "gru_fwd_lean", "CRUSE_GRU_WLO": "gru_wlo",
-                "CRUSE_GRU_DBG": "gru_dbg", "CRUSE_GRU_BG": "gru_bg", "CRUSE_CM_GRID": "cm_grid", "CRUSE_CM_KINT": "cm_kint", "CRUSE_CM_NW": "cm_nw",
+                "CRUSE_GRU_DBG": "gru_dbg", "CRUSE_GRU_BG": "gru_bg", "CRUSE_CM_GRID": "cm_grid", "CRUSE_CM_KINT": "cm_kint", "CRUSE_CM_SWAP": "cm_swap", "CRUSE_CM_NW": "cm_nw",
                 "CRUSE_GB_DEEP_MIN": "gb_deep_min", "CRUSE_GB_DEEP": "gb_deep", "CRUSE_PW_VALU": "pw_valu", "CRUSE_LNB_GRID": "lnb_grid",
                 "CRUSE_WG_TFW": "wg_tfw", "CRUSE_WG_GRID": "wg_grid", "CRUSE_WG_DBG": "wg_dbg"}
 

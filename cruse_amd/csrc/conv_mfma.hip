@@ -37,7 +37,7 @@ struct TapClass {
 __device__ unsigned long long g_cm_stamps[8];
 
 struct CMArgs {
-    int tdbg, kint;
+    int tdbg, kint, swp_ok;
     const float* x; const float* w; const float* bias; float* y;
     int B, T, Cin, Fin, Cout, Fout;
     int S, OS, nclass, halo_lo;                  // input bin stride, output bin stride, classes, frames of halo before t0
@@ -108,7 +108,7 @@ __device__ __forceinline__ Frag<PREC> get_frag(const typename OpStore<PREC>::ele
 // stores and exposes a full memory round trip per N-tile (the accumulating data gradients of the encoder ran at half the
 // speed of the plain ones; with the backward statistics read that way the step got 0.15 ms SLOWER than with the separate
 // reduce pass, r03).
-template <int PREC, int MT, int EPI, int NV, int NW>
+template <int PREC, int MT, int EPI, int NV, int NW, bool SW>
 // (two 5-wave workgroups per CU need 4 wave slots on some SIMD: the 5-wave variants are held to 128 registers)
 __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMArgs a) {
     constexpr bool STATS = EPI != 0;
@@ -188,6 +188,15 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
     // version transposed to channel-fastest rows while storing: with 32..80-byte pitches those 2-byte stores
     // were 8..16-way bank conflicted and cost ~10 us per 8-frame tile.)  The MFMA B fragment -- 8 consecutive
     // ci of one tap at one position -- is gathered with 8 scalar ds_reads (lanes differ in f: conflict-light).
+    // GATHER forms (output bin stride 1) run the MFMA with the PATCHES as its A operand and the weights as B ("swp"): a lane then
+    // holds ONE output channel (lane & 15 of the tile) at FOUR consecutive positions (4 * (lane >> 4) .. +3 of the N-tile) --
+    // consecutive output bins of one frame, written as one 16-byte (or two 8-byte) store per channel tile instead of four 4-byte
+    // ones: a 4-byte-per-lane store instruction costs ~150 cycles of the epilogue (s_memtime stamps, cm_dbg = 1); forward
+    // 16 -> 32: 62 -> 50 us, 32 -> 64: 87 -> 66 us.  The SCATTER forms (stride-2 output bins: no vector store) keep channels in
+    // rows and positions in columns -- with the roles swapped their 4-byte stores land in 64 different rows per instruction and
+    // they run 25-75 % SLOWER (convT 32 -> 16: 41 -> 72 us).
+    // (SW is chosen by the host: gather form, even Mpos, 16-byte aligned tensors)
+    const int vw = (Mpos & 3) == 0 ? 4 : 2;
     float s1[STATS ? MT : 1][4], s2[STATS ? MT : 1][4];
     if constexpr (STATS) {
 #pragma unroll
@@ -226,7 +235,39 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
         __syncthreads();
         // EPI == 2: old output values / pre-BN values of this lane's MT x 4 outputs of an N-tile
         float old_c[EPI == 2 ? MT : 1][4], by_c[EPI == 2 ? MT : 1][4], old_n[EPI == 2 ? MT : 1][4], by_n[EPI == 2 ? MT : 1][4];
-        auto aux_load = [&](int nt_, float (&o)[EPI == 2 ? MT : 1][4], float (&y_)[EPI == 2 ? MT : 1][4]) {
+        // swp: output addressing of an N-tile for this lane -- positions 4*(lane>>4) + e of channel (lane & 15) + 16*mt; the
+        // positions of a vector (4, or 2 + 2) are consecutive bins of one frame
+        auto out_pos = [&](int nt_, long long (&off)[2], bool (&okt)[2]) {
+            const int p0 = nt_ * 16 + (lane >> 4) * 4;     // (one class in the gather forms)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int p_ = p0 + 2 * h;
+                const int tl_ = (int)(((float)p_ + 0.5f) * inv_mpos);
+                const int m_ = p_ - tl_ * Mpos;
+                okt[h] = t0 + tl_ < a.T;
+                off[h] = (((long long)b * a.T + t0 + tl_) * a.Cout + (lane & 15)) * a.Fout + m_ + par0;
+            }
+        };
+        auto aux_load_swp = [&](int nt_, float (&o)[EPI == 2 ? MT : 1][4], float (&y_)[EPI == 2 ? MT : 1][4]) {
+            long long off[2];
+            bool okt[2];
+            out_pos(nt_, off, okt);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const bool okc = mt * 16 + (lane & 15) < a.Cout;
+                const long long cm = (long long)mt * 16 * a.Fout;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const bool ok = okc && okt[h];
+                    const float2 z2 = make_float2(0.f, 0.f);
+                    const float2 ov = (ok && a.accum) ? *reinterpret_cast<const float2*>(a.y + off[h] + cm) : z2;
+                    const float2 yv = (ok && a.bn_y != nullptr) ? *reinterpret_cast<const float2*>(a.bn_y + off[h] + cm) : z2;
+                    o[mt][2 * h] = ov.x; o[mt][2 * h + 1] = ov.y;
+                    y_[mt][2 * h] = yv.x; y_[mt][2 * h + 1] = yv.y;
+                }
+            }
+        };
+        auto aux_load_std = [&](int nt_, float (&o)[EPI == 2 ? MT : 1][4], float (&y_)[EPI == 2 ? MT : 1][4]) {
             const int c_ = nt_ >= ntile_c ? 1 : 0;
             const int p_ = (nt_ - c_ * ntile_c) * 16 + (lane & 15);
             const int tl_ = (int)(((float)p_ + 0.5f) * inv_mpos);
@@ -242,6 +283,9 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
                     o[mt][r4] = (ok && a.accum) ? a.y[e] : 0.f;
                     y_[mt][r4] = (ok && a.bn_y != nullptr) ? a.bn_y[e] : 0.f;
                 }
+        };
+        auto aux_load = [&](int nt_, float (&o)[EPI == 2 ? MT : 1][4], float (&y_)[EPI == 2 ? MT : 1][4]) {
+            if constexpr (SW) aux_load_swp(nt_, o, y_); else aux_load_std(nt_, o, y_);
         };
         if constexpr (EPI == 2) {                          // (ahead of the next tile's prefetch in the in-order queue)
             if (wv < a.nclass * ntile_c) aux_load(wv, old_c, by_c);
@@ -289,12 +333,56 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const Frag<PREC> fa = get_frag<PREC>(wl, wplane, ((size_t)(fbase + mt * ksn + ks) * 64 + lane) * 8);
-                    acc[mt] = mma(fa, fb, acc[mt]);
+                    if constexpr (SW) acc[mt] = mma(fb, fa, acc[mt]); else acc[mt] = mma(fa, fb, acc[mt]);     // swp: rows = positions, columns = channels
                 }
             }
             if (tdbg) { tq1 = __builtin_amdgcn_s_memtime(); tsum[2] += tq1 - tq0; tq0 = tq1; tsum[5] += 1; }
+            if constexpr (SW) {
+                long long off[2];
+                bool okt[2];
+                out_pos(nt, off, okt);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int co = mt * 16 + (lane & 15);
+                    if (co < a.Cout) {
+                        const float bq = s_bias[co];
+                        const long long cm = (long long)mt * 16 * a.Fout;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc[mt][e] + bq;
+                            if constexpr (EPI == 2) v[e] += old_c[mt][e];                       // (0 unless accum)
+                            else if (a.act == 1) v[e] = sigmoid_acc(v[e]);
+                        }
+                        if (vw == 4) {
+                            if (okt[0]) *reinterpret_cast<float4*>(a.y + off[0] + cm) = make_float4(v[0], v[1], v[2], v[3]);
+                        } else {
+                            if (okt[0]) *reinterpret_cast<float2*>(a.y + off[0] + cm) = make_float2(v[0], v[1]);
+                            if (okt[1]) *reinterpret_cast<float2*>(a.y + off[1] + cm) = make_float2(v[2], v[3]);
+                        }
+                        if constexpr (EPI == 1) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (okt[e >> 1]) { s1[mt][0] += v[e]; s2[mt][0] += v[e] * v[e]; }
+                        }
+                        if constexpr (EPI == 2) {
+                            if (a.bn_y != nullptr) {
+                                const float mu = s_bnp[0][co], rs_ = s_bnp[1][co], ga = s_bnp[2][co], be = s_bnp[3][co];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    if (okt[e >> 1]) {
+                                        const float xh = (by_c[mt][e] - mu) * rs_;
+                                        const float gr = (a.bn_relu && !(xh * ga + be > 0.f)) ? 0.f : v[e];
+                                        s1[mt][0] += gr; s2[mt][0] += gr * xh;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
             const int t = t0 + tl;
-            if (t < a.T) {
+            if (!SW && t < a.T) {
                 const int fo = a.OS * m + (c ? par1 : par0);
                 float* yb = a.y + (((long long)b * a.T + t) * a.Cout + (lane >> 4) * 4) * a.Fout + fo;
 #pragma unroll
@@ -341,6 +429,15 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
     if constexpr (STATS) {
         if (a.sums == nullptr) return;                     // (EPI 2 without backward statistics: accumulate only)
         __shared__ float s_red[NW][2][MT * 16];
+        if constexpr (SW) {                                // a lane's channel is (lane & 15): the four lane groups meet
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float u = s1[mt][0], u2 = s2[mt][0];
+                u += __shfl_xor(u, 16, 64); u2 += __shfl_xor(u2, 16, 64);
+                u += __shfl_xor(u, 32, 64); u2 += __shfl_xor(u2, 32, 64);
+                if (lane < 16) { s_red[wv][0][mt * 16 + lane] = u; s_red[wv][1][mt * 16 + lane] = u2; }
+            }
+        } else
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -371,11 +468,19 @@ int launch_mt(const CMArgs& a, int grid, size_t lds, int nw, hipStream_t s) {
     const int mt = (a.Cout + 15) / 16;
     const int nthr = nw * 64;
     const int nv = (a.nrows * a.Cin * a.Fin / 4 + nthr - 1) / nthr;    // float4 per thread of one staged tile
+    // swapped MFMA roles (vector stores): gather forms with an even number of positions per frame and 16-byte aligned tensors
+    const bool swp = a.swp_ok != 0 && a.OS == 1 && ((a.Fout / a.OS) & 1) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.bn_y)) & 15) == 0;
     int rc;
+#define CM_LAUNCH4(MTV, STV, NVV, NWV, SWV)                                                                \
+    do {                                                                                                   \
+        if ((rc = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(conv_mfma_kernel<PREC, MTV, STV, NVV, NWV, SWV>), lds, "conv_mfma"))) return rc; \
+        hipLaunchKernelGGL((conv_mfma_kernel<PREC, MTV, STV, NVV, NWV, SWV>), dim3(grid), dim3(NWV * 64), lds, s, a); \
+    } while (0)
 #define CM_LAUNCH3(MTV, STV, NVV, NWV)                                                                     \
     do {                                                                                                   \
-        if ((rc = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(conv_mfma_kernel<PREC, MTV, STV, NVV, NWV>), lds, "conv_mfma"))) return rc; \
-        hipLaunchKernelGGL((conv_mfma_kernel<PREC, MTV, STV, NVV, NWV>), dim3(grid), dim3(NWV * 64), lds, s, a); \
+        if (swp) CM_LAUNCH4(MTV, STV, NVV, NWV, true);                                                     \
+        else CM_LAUNCH4(MTV, STV, NVV, NWV, false);                                                        \
     } while (0)
 #define CM_LAUNCH2(MTV, STV, NVV)                                                                          \
     do {                                                                                                   \
@@ -401,6 +506,7 @@ int launch_mt(const CMArgs& a, int grid, size_t lds, int nw, hipStream_t s) {
 #undef CM_LAUNCH1
 #undef CM_LAUNCH2
 #undef CM_LAUNCH3
+#undef CM_LAUNCH4
     return CRUSE_OK;
 }
 
@@ -418,6 +524,7 @@ int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float
     a.act = act; a.accum = accum; a.sums = bn_sums;
     a.tdbg = cruse_opt("cm_dbg", 0);
     a.kint = cruse_opt("cm_kint", 1);
+    a.swp_ok = cruse_opt("cm_swap", 1);                  // (A/B switch: 0 = channels in rows for every form)
     if (bnb != nullptr) {
         a.bn_y = bnb->y; a.bn_mean = bnb->mean; a.bn_rstd = bnb->rstd; a.bn_gamma = bnb->gamma; a.bn_beta = bnb->beta;
         a.bn_relu = bnb->relu;
