@@ -137,3 +137,15 @@ __device__ __forceinline__ f32x4 mma(const Frag<CRUSE_PREC_BF16X3>& a, const Fra
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, c, 0, 0, 0);
     return c;
 }
+
+// mma with the operand ROLES swapped (the transposed product: rows of the result follow `b`): the same three split-bf16 terms
+// in the same order as mma(a, b), so a kernel that swaps roles for some launches produces the bits of the one that does not
+template <int PREC>
+__device__ __forceinline__ f32x4 mma_t(const Frag<PREC>& b, const Frag<PREC>& a, f32x4 c) { return mma(b, a, c); }
+template <>
+__device__ __forceinline__ f32x4 mma_t<CRUSE_PREC_BF16X3>(const Frag<CRUSE_PREC_BF16X3>& b, const Frag<CRUSE_PREC_BF16X3>& a, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.h, a.l, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.l, a.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.h, a.h, c, 0, 0, 0);
+    return c;
+}

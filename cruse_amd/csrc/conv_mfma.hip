@@ -108,10 +108,11 @@ __device__ __forceinline__ Frag<PREC> get_frag(const typename OpStore<PREC>::ele
 // stores and exposes a full memory round trip per N-tile (the accumulating data gradients of the encoder ran at half the
 // speed of the plain ones; with the backward statistics read that way the step got 0.15 ms SLOWER than with the separate
 // reduce pass, r03).
-template <int PREC, int MT, int EPI, int NV, int NW, bool SW>
+template <int PREC, int MT, int EPI, int NV, int NW, int SWM>
 // (two 5-wave workgroups per CU need 4 wave slots on some SIMD: the 5-wave variants are held to 128 registers)
 __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMArgs a) {
     constexpr bool STATS = EPI != 0;
+    constexpr bool SW = SWM == 1;              // swapped roles, gather forms; SWM == 2: swapped roles, scatter forms, both parity classes per N-tile
     constexpr int NTHR = NW * 64;
     typedef typename OpStore<PREC>::elem elem;
     constexpr int NPL = OpStore<PREC>::NPL;
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
         auto aux_load = [&](int nt_, float (&o)[EPI == 2 ? MT : 1][4], float (&y_)[EPI == 2 ? MT : 1][4]) {
             if constexpr (SW) aux_load_swp(nt_, o, y_); else aux_load_std(nt_, o, y_);
         };
-        if constexpr (EPI == 2) {                          // (ahead of the next tile's prefetch in the in-order queue)
+        if constexpr (EPI == 2 && SWM != 2) {              // (ahead of the next tile's prefetch in the in-order queue)
             if (wv < a.nclass * ntile_c) aux_load(wv, old_c, by_c);
         }
         if (tile + (int)gridDim.x < a.B * ntile) prefetch(tile + gridDim.x);
@@ -296,6 +297,113 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
         // N-tile loop, kept free of integer divisions (Cin is a power of two, positions via a float reciprocal)
         // and of global loads; one 64-bit base address per N-tile.  (Keeping several N-tiles in flight per wave
         // was measured and is slower: 78 vs 57 us on the 8->16 layer.)
+        if constexpr (SWM == 2) {
+            // SCATTER forms with swapped roles: an N-tile is 16 positions of BOTH parity classes (two k-loops, two accumulator
+            // sets), so a lane holds its channel at output bins 2m .. 2m+3 for each of its two position pairs: two 16-byte stores
+            // per channel tile where the class-by-class form writes eight 4-byte ones with a stride of two bins.  The epilogue's
+            // reads (old value, pre-BN value) are issued at the START of the N-tile: two k-loops later they have long arrived.
+            for (int nt = wv; nt < ntile_c; nt += NW) {
+                const int p = nt * 16 + (lane & 15);
+                const int tl = (int)(((float)p + 0.5f) * inv_mpos);
+                const int m = p - tl * Mpos;
+                const int rowbase = (tl + a.halo_lo) * rowlen + a.S * m;
+                long long off[2];
+                bool okt[2];
+                {
+                    const int p0 = nt * 16 + (lane >> 4) * 4;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int p_ = p0 + 2 * h;
+                        const int tl_ = (int)(((float)p_ + 0.5f) * inv_mpos);
+                        const int m_ = p_ - tl_ * Mpos;
+                        okt[h] = t0 + tl_ < a.T;
+                        off[h] = (((long long)b * a.T + t0 + tl_) * a.Cout + (lane & 15)) * a.Fout + 2 * m_;
+                    }
+                }
+                float4 oldv[EPI == 2 ? MT : 1][2], byv[EPI == 2 ? MT : 1][2];
+                if constexpr (EPI == 2) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const bool okc = mt * 16 + (lane & 15) < a.Cout;
+                        const long long cm = (long long)mt * 16 * a.Fout;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                            oldv[mt][h] = (okc && okt[h] && a.accum) ? *reinterpret_cast<const float4*>(a.y + off[h] + cm) : z4;
+                            byv[mt][h] = (okc && okt[h] && a.bn_y != nullptr) ? *reinterpret_cast<const float4*>(a.bn_y + off[h] + cm) : z4;
+                        }
+                    }
+                }
+                f32x4 acc2[2][MT];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc2[c][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    const int ksn = c ? ks1 : ks0, fbase = c ? MT * ks0 : 0, ntaps = c ? ntaps1 : ntaps0;
+                    for (int ks = 0; ks < ksn; ++ks) {
+                        const int k = ks * 32 + q8;
+                        int tap = k >> lg_cin;
+                        const int ci0 = (k & (a.Cin - 1) & ~(cblk - 1)) + ((lane >> 4) & (ngrp - 1));
+                        if (tap >= ntaps) tap = ntaps - 1;
+                        const int2 tp = s_tap2[c][tap];
+                        const int f = a.S * m + tp.y;
+                        float bv[8];
+                        if (f >= 0 && f < a.Fin) {
+                            const float* pb = xl + rowbase + tp.x + ci0 * a.Fin;
+                            const int cstep = ngrp * a.Fin;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) bv[e] = pb[e * cstep];
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+                        }
+                        Frag<PREC> fb;
+                        fb.set(bv);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            const Frag<PREC> fa = get_frag<PREC>(wl, wplane, ((size_t)(fbase + mt * ksn + ks) * 64 + lane) * 8);
+                            acc2[c][mt] = mma_t<PREC>(fb, fa, acc2[c][mt]);
+                        }
+                    }
+                }
+                if (tdbg) { tq1 = __builtin_amdgcn_s_memtime(); tsum[2] += tq1 - tq0; tq0 = tq1; tsum[5] += 1; }
+                // class c writes output bins of parity cls[c].par: even bins from the class with par 0
+                const int ce = par0 == 0 ? 0 : 1, cod = 1 - ce;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int co = mt * 16 + (lane & 15);
+                    if (co < a.Cout) {
+                        const float bq = s_bias[co];
+                        const long long cm = (long long)mt * 16 * a.Fout;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            float v[4] = {acc2[ce][mt][2 * h] + bq, acc2[cod][mt][2 * h] + bq, acc2[ce][mt][2 * h + 1] + bq, acc2[cod][mt][2 * h + 1] + bq};
+                            if constexpr (EPI == 2) { v[0] += oldv[mt][h].x; v[1] += oldv[mt][h].y; v[2] += oldv[mt][h].z; v[3] += oldv[mt][h].w; }
+                            if (okt[h]) {
+                                *reinterpret_cast<float4*>(a.y + off[h] + cm) = make_float4(v[0], v[1], v[2], v[3]);
+                                if constexpr (EPI == 1) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) { s1[mt][0] += v[e]; s2[mt][0] += v[e] * v[e]; }
+                                }
+                                if constexpr (EPI == 2) {
+                                    if (a.bn_y != nullptr) {
+                                        const float mu = s_bnp[0][co], rs_ = s_bnp[1][co], ga = s_bnp[2][co], be = s_bnp[3][co];
+                                        const float yv[4] = {byv[mt][h].x, byv[mt][h].y, byv[mt][h].z, byv[mt][h].w};
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) {
+                                            const float xh = (yv[e] - mu) * rs_;
+                                            const float gr = (a.bn_relu && !(xh * ga + be > 0.f)) ? 0.f : v[e];
+                                            s1[mt][0] += gr; s2[mt][0] += gr * xh;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                if (tdbg) { tq1 = __builtin_amdgcn_s_memtime(); tsum[3] += tq1 - tq0; tq0 = tq1; }
+            }
+        } else
         for (int nt = wv; nt < a.nclass * ntile_c; nt += NW) {
             if constexpr (EPI == 2) {
                 if (nt + NW < a.nclass * ntile_c) aux_load(nt + NW, old_n, by_n);
@@ -333,7 +441,7 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const Frag<PREC> fa = get_frag<PREC>(wl, wplane, ((size_t)(fbase + mt * ksn + ks) * 64 + lane) * 8);
-                    if constexpr (SW) acc[mt] = mma(fb, fa, acc[mt]); else acc[mt] = mma(fa, fb, acc[mt]);     // swp: rows = positions, columns = channels
+                    if constexpr (SW) acc[mt] = mma_t<PREC>(fb, fa, acc[mt]); else acc[mt] = mma(fa, fb, acc[mt]);     // swp: rows = positions, columns = channels
                 }
             }
             if (tdbg) { tq1 = __builtin_amdgcn_s_memtime(); tsum[2] += tq1 - tq0; tq0 = tq1; tsum[5] += 1; }
@@ -429,7 +537,7 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
     if constexpr (STATS) {
         if (a.sums == nullptr) return;                     // (EPI 2 without backward statistics: accumulate only)
         __shared__ float s_red[NW][2][MT * 16];
-        if constexpr (SW) {                                // a lane's channel is (lane & 15): the four lane groups meet
+        if constexpr (SWM != 0) {                          // a lane's channel is (lane & 15): the four lane groups meet
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 float u = s1[mt][0], u2 = s2[mt][0];
@@ -469,8 +577,13 @@ int launch_mt(const CMArgs& a, int grid, size_t lds, int nw, hipStream_t s) {
     const int nthr = nw * 64;
     const int nv = (a.nrows * a.Cin * a.Fin / 4 + nthr - 1) / nthr;    // float4 per thread of one staged tile
     // swapped MFMA roles (vector stores): gather forms with an even number of positions per frame and 16-byte aligned tensors
-    const bool swp = a.swp_ok != 0 && a.OS == 1 && ((a.Fout / a.OS) & 1) == 0 &&
-                     ((reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.bn_y)) & 15) == 0;
+    const bool al16 = ((reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.bn_y)) & 15) == 0;
+    int swm = 0;
+    if (a.swp_ok != 0 && al16 && ((a.Fout / a.OS) & 1) == 0) {
+        if (a.OS == 1) swm = 1;
+        else if (a.nclass == 2 && a.cls[0].par + a.cls[1].par == 1 && (a.sums != nullptr || a.accum || a.bn_y != nullptr) && !a.act)
+            swm = 2;                             // (plain-epilogue scatter launches keep the class-by-class form)
+    }
     int rc;
 #define CM_LAUNCH4(MTV, STV, NVV, NWV, SWV)                                                                \
     do {                                                                                                   \
@@ -479,8 +592,9 @@ int launch_mt(const CMArgs& a, int grid, size_t lds, int nw, hipStream_t s) {
     } while (0)
 #define CM_LAUNCH3(MTV, STV, NVV, NWV)                                                                     \
     do {                                                                                                   \
-        if (swp) CM_LAUNCH4(MTV, STV, NVV, NWV, true);                                                     \
-        else CM_LAUNCH4(MTV, STV, NVV, NWV, false);                                                        \
+        if (swm == 1) CM_LAUNCH4(MTV, STV, NVV, NWV, 1);                                                   \
+        else if (swm == 2) CM_LAUNCH4(MTV, STV, NVV, NWV, (STV == 0 ? 0 : 2));                             \
+        else CM_LAUNCH4(MTV, STV, NVV, NWV, 0);                                                            \
     } while (0)
 #define CM_LAUNCH2(MTV, STV, NVV)                                                                          \
     do {                                                                                                   \
