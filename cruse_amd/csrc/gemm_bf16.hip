@@ -405,7 +405,21 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const float* x, lon
     const int tid = threadIdx.x;
     const long long r0 = (long long)blockIdx.x * 64;
     const int c0 = blockIdx.y * 64;
-    {
+    // in: 16-byte loads along the columns where the rows allow it (4 per thread), 4-byte ones otherwise
+    const bool vec = (ld & 3) == 0 && (cols & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    if (vec) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int idx = p * 256 + tid, rr = idx >> 4, c4 = (idx & 15) * 4;
+            const long long r = r0 + rr;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < rows && c0 + c4 < cols) {
+                if (shiftT == 0) v = *reinterpret_cast<const float4*>(x + r * ld + c0 + c4);
+                else if (r % shiftT != 0) v = *reinterpret_cast<const float4*>(x + (r - 1) * ld + c0 + c4);
+            }
+            tile[rr][c4] = v.x; tile[rr][c4 + 1] = v.y; tile[rr][c4 + 2] = v.z; tile[rr][c4 + 3] = v.w;
+        }
+    } else {
         const int cc = tid & 63;
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
@@ -421,15 +435,17 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const float* x, lon
     }
     __syncthreads();
     {
-        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-        const int rp = tid & 31;                 // row pair
+        // out: a lane writes 8 consecutive rows of one column = 16 bytes; 8 lanes cover the 128 bytes of a column's 64 rows
+        typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_;
+        const int j = tid & 7;                   // row group
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int cc = p * 8 + (tid >> 5);
+        for (int p = 0; p < 2; ++p) {
+            const int cc = p * 32 + (tid >> 3);
             if (c0 + cc < cols) {
-                bf16x2 h;
-                h[0] = (__bf16)tile[2 * rp][cc]; h[1] = (__bf16)tile[2 * rp + 1][cc];
-                *reinterpret_cast<bf16x2*>(yT + (r0 >> 6) * ((long long)cols * 64) + (long long)(c0 + cc) * 64 + 2 * rp) = h;
+                bf16x8_ h;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) h[e] = (__bf16)tile[8 * j + e][cc];
+                *reinterpret_cast<bf16x8_*>(yT + (r0 >> 6) * ((long long)cols * 64) + (long long)(c0 + cc) * 64 + 8 * j) = h;
             }
         }
     }
@@ -568,6 +584,7 @@ extern "C" int cruse_transpose_bf16(const float* x, long long rows, int cols, lo
     CRUSE_REQUIRE(rows > 0 && cols > 0 && ld >= cols, CRUSE_E_SHAPE, "transpose_bf16: bad shape");
     CRUSE_REQUIRE(ldT % 64 == 0 && ldT >= rows, CRUSE_E_SHAPE,
                   "transpose_bf16: ldT=%lld must be a multiple of 64 and >= rows=%lld", ldT, rows);
+    CRUSE_REQUIRE(((uintptr_t)yT % 16) == 0, CRUSE_E_ALIGN, "transpose_bf16: yT must be 16-byte aligned");
     CRUSE_REQUIRE(shift_T >= 0 && (shift_T == 0 || rows % shift_T == 0), CRUSE_E_SHAPE,
                   "transpose_bf16: rows must be whole clips of shift_T frames");
     CRUSE_REQUIRE(((uintptr_t)yT % 4) == 0, CRUSE_E_ALIGN, "transpose_bf16: unaligned output");
