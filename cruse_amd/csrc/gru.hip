@@ -1623,6 +1623,269 @@ __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
     __syncthreads();                                       // hands the last iteration's dh to the loader wave
 }
 
+// ---------------------------------------------------------------------------------
+// backward, WIDE-CHAIN form of the reduce-scatter kernel: 16 clips per chain (all 16 columns of the MFMA), half the
+// workgroups per clip -- the backward counterpart of gru_fwd_w16_kernel for batches whose chains of 8 exceed the CUs.
+// Eight compute waves: wave w owns the NTW = Hg/128 output tiles [w*NTW, w*NTW + NTW) (every column of their accumulators
+// is a clip now, so a tile is published on its own: 64 lanes x 16 bytes, one 64-byte half row per clip); 512 sweep threads
+// = (clip 16, quarter 4, unit quad 8) with the reduce-scatter kernel's lane order and NL = Hg/128 loads each; the loader wave
+// streams 16 clips of operands.  Granules: [consumer][producer][clip 16][pair 16].  Same arithmetic and summation order as
+// the chains of 8: identical results.  CRUSE_PREC_BF16, Hg % 128 == 0, Hg <= 640.
+// ---------------------------------------------------------------------------------
+template <int NTW>
+__global__ __launch_bounds__(576) void gru_bwd_w16_kernel(GruArgs a) {
+    constexpr int KP = 96 + 8;
+    constexpr int NL = NTW;                      // P / 4 producers per quarter
+    __shared__ __attribute__((aligned(16))) __bf16 panel[2][16 * KP];
+    __shared__ __attribute__((aligned(16))) float op_d[4][16][32], op_z[4][16][32];     // ring slot = iteration & 3
+    __shared__ __attribute__((aligned(16))) __bf16 op_c[4][16][96];
+    __shared__ __attribute__((aligned(16))) float op_a[4][16][32];
+    __shared__ __attribute__((aligned(16))) float dh_l[2][16][32];
+    const int Hg = a.Hg, H = a.G * Hg, K3 = 3 * Hg, P = a.P;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int chain, part;
+    if (!claim_chain(a, P, chain, part)) return;
+    const int grp = chain % a.G, bgi = a.bg_off + chain / a.G;
+    const int b0 = bgi * 16, nb = min(16, a.B - b0);
+    const int u0 = part * U;
+    const float* W = a.p.w_hh[grp];
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.xg, 0, a.xg_bytes, 0x00020000);
+    const unsigned cons_bytes = (unsigned)P * 16u * 16u * 8u;       // [producer P][clip 16][pair 16] granules
+    const unsigned panel_bytes = (unsigned)P * cons_bytes;          // one parity of one chain
+    const unsigned cbase = (unsigned)chain * 2u * panel_bytes;
+
+    for (int i = tid; i < 2 * 16 * KP; i += 576) panel[0][i] = (__bf16)0.f;
+
+    const unsigned frame_bytes = (unsigned)H * 4u, crow_bytes = (unsigned)(a.G * K3) * 2u;
+    const long long nrow = (long long)(a.B - 1) * a.TS + a.T;
+    const unsigned tot_f32 = (unsigned)min(nrow * H * 4, 0xffffffffll);
+    const unsigned tot_cf = (unsigned)min(nrow * a.G * K3 * 2, 0xffffffffll);
+    const __amdgpu_buffer_rsrc_t rs_dout = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dout), 0, tot_f32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.zs), 0, tot_f32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dh = __builtin_amdgcn_make_buffer_rsrc(a.dh, 0, tot_f32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_cf = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.coefs), 0, tot_cf, 0x00020000);
+
+    if (wv == 8) {
+        // ---- loader wave: dout / z / a_n rows 16 clips x 8 chunks of 4 floats (2 slots per lane); coefficient rows 16 clips x
+        //      3 gates x 4 chunks of 8 bf16 (3 slots per lane)
+        unsigned dv[2], ddst[2];
+        bool dok[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = lane + 64 * i, lc = idx >> 3, lq = idx & 7;
+            dok[i] = lc < nb;
+            dv[i] = (unsigned)(((long long)(b0 + (dok[i] ? lc : 0)) * a.TS * H + grp * Hg + u0 + 4 * lq) * 4);
+            ddst[i] = (unsigned)(lc * 32 + 4 * lq);
+        }
+        unsigned cv[3], cdst[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int idx = lane + 64 * i, cl = idx / 12, rem = idx % 12, gate = rem >> 2, chk = rem & 3;
+            cv[i] = (unsigned)((((long long)(b0 + (cl < nb ? cl : 0)) * a.TS * a.G + grp) * K3 + gate * Hg + u0 + 8 * chk) * 2);
+            cdst[i] = (unsigned)(cl * 96 + gate * 32 + chk * 8);
+        }
+        const bool want_dgi = a.dgi != nullptr;
+        const __amdgpu_buffer_rsrc_t rs_an = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ans), 0, a.ans ? tot_f32 : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_dgi = __builtin_amdgcn_make_buffer_rsrc(a.dgi, 0, a.dgi ? (a.dg_slabs == 4 ? (unsigned)min(nrow * a.G * 4 * Hg * 2, 0xffffffffll) : tot_cf) : 0u, 0x00020000);
+        struct OpSet { u32x4 d[2], z[2], c[3], an[2]; };
+        auto issue = [&](int j, OpSet& o) {
+            const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { o.d[i] = zero; o.z[i] = zero; o.an[i] = zero; }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) o.c[i] = zero;
+            if (j >= a.T) return;
+            const unsigned st = (unsigned)(a.T - 1 - j);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                o.d[i] = (j == 0 && a.carry) ? __builtin_amdgcn_raw_buffer_load_b128(rs_dh, dv[i], st * frame_bytes, 0)
+                                             : __builtin_amdgcn_raw_buffer_load_b128(rs_dout, dv[i], st * frame_bytes, 0);
+                if (j > 0) o.z[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_z, dv[i], (st + 1u) * frame_bytes, 0);
+                if (want_dgi) o.an[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_an, dv[i], st * frame_bytes, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) o.c[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_cf, cv[i], st * crow_bytes, 0);
+        };
+        auto put = [&](int j, const OpSet& o) {
+            const int slot = j & 3;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                *reinterpret_cast<u32x4*>(&op_d[slot][0][0] + ddst[i]) = o.d[i];
+                *reinterpret_cast<u32x4*>(&op_z[slot][0][0] + ddst[i]) = o.z[i];
+                if (want_dgi) *reinterpret_cast<u32x4*>(&op_a[slot][0][0] + ddst[i]) = o.an[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(&op_c[slot][0][0] + cdst[i]) = o.c[i];
+        };
+        const int NSL = a.dg_slabs == 4 ? 4 : 3;
+        const unsigned dgrow_bytes = (unsigned)(a.G * NSL * Hg) * 2u;
+        auto flush = [&](int j) {                       // dh (and the gate gradients) of iteration j, one iteration behind
+            const unsigned st = (unsigned)(a.T - 1 - j);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (!dok[i]) continue;
+                const int idx = lane + 64 * i, lc = idx >> 3, lq = idx & 7;
+                const float4 d4 = *reinterpret_cast<const float4*>(&dh_l[j & 1][lc][4 * lq]);
+                const u32x4 dw = {__float_as_uint(d4.x), __float_as_uint(d4.y), __float_as_uint(d4.z), __float_as_uint(d4.w)};
+                __builtin_amdgcn_raw_buffer_store_b128(dw, rs_dh, dv[i], st * frame_bytes, 0);
+                if (want_dgi) {
+                    const int slot = j & 3;
+                    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
+                    const bf16x4_ cr = *reinterpret_cast<const bf16x4_*>(&op_c[slot][lc][4 * lq]);
+                    const bf16x4_ cz = *reinterpret_cast<const bf16x4_*>(&op_c[slot][lc][32 + 4 * lq]);
+                    const float4 a4 = *reinterpret_cast<const float4*>(&op_a[slot][lc][4 * lq]);
+                    const float d[4] = {d4.x, d4.y, d4.z, d4.w}, an_[4] = {a4.x, a4.y, a4.z, a4.w};
+                    bf16x4_ o0, o1, o2;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o0[e] = (__bf16)(d[e] * (float)cr[e]); o1[e] = (__bf16)(d[e] * (float)cz[e]); o2[e] = (__bf16)(d[e] * an_[e]);
+                    }
+                    const unsigned gi_v = (unsigned)((((long long)(b0 + lc) * a.TS * a.G + grp) * NSL * Hg + u0 + 4 * lq) * 2);
+                    __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o0), rs_dgi, gi_v, st * dgrow_bytes, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o1), rs_dgi, gi_v + (unsigned)Hg * 2u, st * dgrow_bytes, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o2), rs_dgi, gi_v + (unsigned)Hg * 4u, st * dgrow_bytes, 0);
+                    if (NSL == 4) {
+                        const bf16x4_ cn = *reinterpret_cast<const bf16x4_*>(&op_c[slot][lc][64 + 4 * lq]);
+                        bf16x4_ o3;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o3[e] = (__bf16)(d[e] * (float)cn[e]);
+                        __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o3), rs_dgi, gi_v + (unsigned)Hg * 6u, st * dgrow_bytes, 0);
+                    }
+                }
+            }
+        };
+        OpSet s0, s1;
+        issue(0, s0); issue(1, s1);
+        put(0, s0); put(1, s1);
+        issue(2, s0); issue(3, s1);
+        (void)team_shares_xcd(a.xid + (size_t)chain * 64, P, part, a.status, tid);    // mirrors the compute waves' barriers
+        __syncthreads();
+        for (int k = 0; k < a.T; k += 2) {
+            put(k + 2, s0);
+            issue(k + 4, s0);
+            if (k > 0) flush(k - 1);
+            if (a.T - 1 - k == 0) break;
+            __syncthreads();
+            put(k + 3, s1);
+            issue(k + 5, s1);
+            flush(k);
+            if (a.T - 2 - k == 0) break;
+            __syncthreads();
+        }
+        __syncthreads();                                // the last iteration's dh is in LDS
+        flush(a.T - 1);
+        return;
+    }
+
+    // A operand = W_hh[own gate rows, :]^T for this wave's NTW output tiles: A[row = output unit][k = own gate row]
+    bf16x8 wf[NTW][3];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int n = (wv * NTW + i) * 16 + (lane & 15);
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                wf[i][kk][e] = (__bf16)W[(long long)(kk * Hg + u0 + (lane >> 4) * 8 + e) * Hg + n];
+    }
+
+    // thread = (clip bl, quarter, unit quad pp): the reduce-scatter kernel's lane order
+    const int pp = tid & 7, quarter = (tid >> 3) & 3, bl = tid >> 5;
+    const bool active = bl < nb;
+    const int blc = active ? bl : 0;
+    unsigned sweep_v[NL];
+#pragma unroll
+    for (int jj = 0; jj < NL; ++jj) {
+        const int pr = quarter * NL + jj;
+        sweep_v[jj] = (unsigned)part * cons_bytes + (unsigned)(((pr * 16 + blc) * 16 + 2 * pp) * 8);
+    }
+    // publish: tile gt of this wave -> consumer gt >> 1, units (gt & 1) * 16 + (lane >> 4) * 4 .. +3 of clip lane & 15
+    unsigned pub_v[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+        const int gt = wv * NTW + i;
+        pub_v[i] = (unsigned)(gt >> 1) * cons_bytes +
+                   (((((unsigned)part * 16u + (unsigned)(lane & 15)) * 16u) + (unsigned)(gt & 1) * 8u + (unsigned)(lane >> 4) * 2u) << 3);
+    }
+    const bool pub_ok = (lane & 15) < nb;
+    const int ou = 4 * pp + quarter;                                  // own unit inside the workgroup's 32
+    const int pw = blc * KP + ou;                                     // panel element of the own unit (+ gate*32)
+
+    float dh = 0.f, dd = 0.f, zz = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    bool nowait = a.dbg >= 1 && a.dbg < 7;
+    const bool plain = team_shares_xcd(a.xid + (size_t)chain * 64, P, part, a.status, tid);
+    __syncthreads();                                                  // ring slots 0 and 1 are filled
+    dd = op_d[0][blc][ou];
+    c0 = (float)op_c[0][blc][ou]; c1 = (float)op_c[0][blc][32 + ou]; c2 = (float)op_c[0][blc][64 + ou];
+
+    for (int k = 0; k < a.T; ++k) {
+        const int s = a.T - 1 - k;
+        float m = 0.f;
+        if (k > 0) {
+            const unsigned soff = cbase + (unsigned)((k - 1) & 1) * panel_bytes;
+            u32x4 g[NL];
+            unsigned spins = 0;
+            for (;;) {
+#pragma unroll
+                for (int j = 0; j < NL; ++j) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, sweep_v[j], soff, 16);
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < NL; ++j) ok = ok & (g[j].x == (unsigned)k) & (g[j].z == (unsigned)k);
+                if (__all(ok || !active || nowait)) break;
+                if (++spins >= SPIN_LIMIT) {
+                    if (lane == 0) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    nowait = true;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            float sm[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                sm[0] += bf16lo(g[j].y); sm[1] += bf16hi(g[j].y);
+                sm[2] += bf16lo(g[j].w); sm[3] += bf16hi(g[j].w);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sm[e] += __uint_as_float(dpp_ror8(__float_as_uint(sm[e])));          // lane ^ 8:  quarter ^ 1
+                sm[e] += __uint_as_float(swz_xor16(__float_as_uint(sm[e])));         // lane ^ 16: quarter ^ 2
+            }
+            m = quarter == 0 ? sm[0] : quarter == 1 ? sm[1] : quarter == 2 ? sm[2] : sm[3];
+        }
+        dh = dd + zz * dh + m;
+        __bf16* pn = panel[k & 1];
+        if (active) {
+            dh_l[k & 1][bl][ou] = dh;
+            pn[pw] = (__bf16)(dh * c0); pn[pw + 32] = (__bf16)(dh * c1); pn[pw + 64] = (__bf16)(dh * c2);
+        }
+        if (s == 0) break;                                 // nothing consumes the partials of time 0
+        {
+            const int slot = (k + 1) & 3;
+            dd = op_d[slot][blc][ou];
+            zz = op_z[slot][blc][ou];
+            c0 = (float)op_c[slot][blc][ou]; c1 = (float)op_c[slot][blc][32 + ou]; c2 = (float)op_c[slot][blc][64 + ou];
+        }
+        __syncthreads();                                   // panel[k & 1] complete; panel[(k+1) & 1] is free again
+        bf16x8 fb[3];
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk)
+            fb[kk] = *reinterpret_cast<const bf16x8*>(pn + (lane & 15) * KP + kk * 32 + (lane >> 4) * 8);
+        const unsigned soff = cbase + (unsigned)(k & 1) * panel_bytes;
+        const unsigned ep = (unsigned)(k + 1);
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) {
+            f32x4 c_ = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][kk], fb[kk], c_, 0, 0, 0);
+            const u32x4 w = {ep, pack2(c_[0], c_[1]), ep, pack2(c_[2], c_[3])};
+            if (pub_ok) {
+                if (plain) __builtin_amdgcn_raw_buffer_store_b128(w, rs, pub_v[i], soff, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(w, rs, pub_v[i], soff, 16);
+            }
+        }
+    }
+    __syncthreads();                                       // hands the last iteration's dh to the loader wave
+}
+
 // dgi = dh * (c_r, c_z, a_n), dgh = dh * (c_r, c_z, c_n); layouts [rows][G][3][Hg]
 template <typename CT>
 __global__ __launch_bounds__(256) void gru_gate_grads_kernel(const float* dh, const CT* coef, const float* an,
@@ -1766,11 +2029,11 @@ struct Plan { int Bg, P, nbg, bg_per_launch, nlaunch; };
 bool bwd_rs_eligible(int Bg, int Hg, int prec);
 bool fwd_lean_eligible(int Bg, int Hg, int prec);
 bool fwd_w16_eligible(int Bg, int Hg, int prec);
+bool bwd_w16_eligible(int Bg, int Hg, int prec);
 
-// Chains of 8 clips while the batch's chains fit the CUs.  A larger batch: the wide-chain forward kernel (16 clips per chain,
-// one launch of half the workgroups) where it exists; otherwise several launches of the lean / reduce-scatter kernels on
-// chains of 8 (B = 128, Hg = 640: 2 x 0.81 ms backward against 2.75 ms for one launch of the generic kernel on chains of 16);
-// the generic kernels keep their chains of 16.
+// Chains of 8 clips while the batch's chains fit the CUs.  A larger batch: the wide-chain kernels (16 clips per chain,
+// one launch of half the workgroups) where they exist; otherwise several launches of the lean / reduce-scatter kernels on
+// chains of 8, whichever takes fewer launch-times (the generic kernels: chains of 16).
 int make_plan(int B, int G, int Hg, int prec, bool fwd, int chain_clips, Plan& pl) {
     pl.P = Hg / U;
     const int maxblk = num_cus();
@@ -1778,12 +2041,17 @@ int make_plan(int B, int G, int Hg, int prec, bool fwd, int chain_clips, Plan& p
     pl.Bg = chain_clips == 16 ? 16 : 8;
     if (cruse_opt("gru_bg", 8) == 16) pl.Bg = 16;   // profiling override
     pl.nbg = cdiv(B, pl.Bg);
-    if (pl.nbg * G * pl.P > maxblk && chain_clips != 8) {
+    int per_launch = ((maxblk / pl.P) / 8 * 8) / G;        // chains per launch padded to a multiple of 8
+    if (per_launch < 1) per_launch = 1;
+    if (pl.nbg * G * pl.P > maxblk && chain_clips != 8 && pl.Bg == 8) {
         const bool fast8 = fwd ? fwd_lean_eligible(8, Hg, prec) : bwd_rs_eligible(8, Hg, prec);
-        if ((fwd && fwd_w16_eligible(16, Hg, prec)) || !fast8) { pl.Bg = 16; pl.nbg = cdiv(B, pl.Bg); }
+        // launches on chains of 8 / of 16; a wide launch takes 1.3x (forward) / 1.8x (backward) the time of one on chains of 8
+        // (tools/gru_bigbatch_probe.py: B = 128 backward 1.27 against 1.38 ms, B = 192 2.48 against 2.06 ms)
+        const int n8 = cdiv(pl.nbg, per_launch), n16 = cdiv(cdiv(B, 16), per_launch);
+        const bool wide = fwd ? (fwd_w16_eligible(16, Hg, prec) && n16 < n8) : (bwd_w16_eligible(16, Hg, prec) && 2 * n16 <= n8);
+        if (wide || !fast8) { pl.Bg = 16; pl.nbg = cdiv(B, pl.Bg); }
     }
-    pl.bg_per_launch = ((maxblk / pl.P) / 8 * 8) / G;      // chains per launch padded to a multiple of 8
-    if (pl.bg_per_launch < 1) pl.bg_per_launch = 1;
+    pl.bg_per_launch = per_launch;
     if (pl.bg_per_launch > pl.nbg) pl.bg_per_launch = pl.nbg;
     pl.nlaunch = cdiv(pl.nbg, pl.bg_per_launch);
     return 0;
@@ -1882,6 +2150,18 @@ int dispatch_bwd(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
     return launch_one(gru_bwd_kernel<PREC, 24>, a, grid, lds, s, "gru_seq_bwd");
 }
 
+bool bwd_w16_eligible(int Bg, int Hg, int prec) {
+    return prec == CRUSE_PREC_BF16 && Bg == 16 && Hg % 128 == 0 && Hg <= 640 && cruse_opt("gru_w16", 1) != 0;
+}
+int dispatch_bwd_w16(const GruArgs& a, int grid, hipStream_t s) {
+    switch (a.Hg / 128) {
+        case 1: return launch_one(gru_bwd_w16_kernel<1>, a, grid, 0, s, "gru_seq_bwd", 576);
+        case 2: return launch_one(gru_bwd_w16_kernel<2>, a, grid, 0, s, "gru_seq_bwd", 576);
+        case 3: return launch_one(gru_bwd_w16_kernel<3>, a, grid, 0, s, "gru_seq_bwd", 576);
+        case 4: return launch_one(gru_bwd_w16_kernel<4>, a, grid, 0, s, "gru_seq_bwd", 576);
+        default: return launch_one(gru_bwd_w16_kernel<5>, a, grid, 0, s, "gru_seq_bwd", 576);
+    }
+}
 int dispatch_bwd_rs(const GruArgs& a, int grid, hipStream_t s) {
     const int P = a.Hg / 32, np = (P + 3) / 4;   // tile pairs per wavefront
     if (a.dbg >= 32 && a.dbg <= 35 && a.Hg == 640) return launch_one(gru_bwd_rs_kernel<5, true, true>, a, grid, 0, s, "gru_seq_bwd", 320);
@@ -1934,7 +2214,8 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* pane
         a.xid = (unsigned long long*)xid_base + (size_t)bg_off * G * 64;
         a.tickets = tickets_base + (size_t)L * 8;
         const bool rs_form = !FWD && bwd_rs_eligible(pl.Bg, Hg, prec);
-        const size_t gpp = rs_form ? rs_gran_per_parity(Hg) : (size_t)pl.Bg * Hg;      // granules per parity and chain
+        const bool w16_bwd = !FWD && bwd_w16_eligible(pl.Bg, Hg, prec);
+        const size_t gpp = rs_form ? rs_gran_per_parity(Hg) : w16_bwd ? 2 * rs_gran_per_parity(Hg) : (size_t)pl.Bg * Hg;      // granules per parity and chain
         a.xg = (unsigned long long*)xg_base + (size_t)bg_off * G * 2 * gpp;
         a.xg_bytes = (unsigned)((size_t)a.nchains * 2 * gpp * 8);
         const int grid = cdiv(a.nchains, 8) * 8 * pl.P;
@@ -1946,6 +2227,8 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* pane
             if (prec == CRUSE_PREC_F32) rc = dispatch_fwd<CRUSE_PREC_F32>(a, grid, lds, s);
             else if (prec == CRUSE_PREC_BF16X3) rc = dispatch_fwd<CRUSE_PREC_BF16X3>(a, grid, lds, s);
             else rc = dispatch_fwd<CRUSE_PREC_BF16>(a, grid, lds, s);
+        } else if (w16_bwd) {
+            rc = dispatch_bwd_w16(a, grid, s);
         } else if (rs_form) {
             rc = dispatch_bwd_rs(a, grid, s);
         } else {
@@ -2052,9 +2335,9 @@ extern "C" int cruse_gru_seq_bwd_ex(const float* dout, const float* const* w_hh,
     CRUSE_REQUIRE(dgi == nullptr || (an != nullptr && prec == CRUSE_PREC_BF16), CRUSE_E_SHAPE,
                   "gru_seq_bwd: dgi needs the a_n rows and CRUSE_PREC_BF16");
     // the reduce-scatter kernel's loader wave writes dgi itself; the other kernels are followed by the gate-gradient pass
-    const bool in_kernel = dgi != nullptr && bwd_rs_eligible(pl.Bg, Hg, prec);
+    const bool in_kernel = dgi != nullptr && (bwd_rs_eligible(pl.Bg, Hg, prec) || bwd_w16_eligible(pl.Bg, Hg, prec));
     CRUSE_REQUIRE(dg_slabs == 3 || (dg_slabs == 4 && (dgi == nullptr || in_kernel)), CRUSE_E_SHAPE,
-                  "gru_seq_bwd: dg_slabs = %d (3, or 4 with the reduce-scatter kernel: bf16, Bg = 8, Hg <= 640)", dg_slabs);
+                  "gru_seq_bwd: dg_slabs = %d (3, or 4 with the reduce-scatter kernels: bf16, Hg <= 640)", dg_slabs);
     a.ans = in_kernel ? an : nullptr;
     a.dgi = in_kernel ? dgi : nullptr;
     a.dg_slabs = dg_slabs;

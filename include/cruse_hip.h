@@ -319,15 +319,16 @@ int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh, const void
  *   _bwd_ex: carry != 0: the first iteration takes dh of the run's LAST frame from the dh buffer (written by the run that
  *            follows it in time) instead of forming it from dout: chunk [t0, t0+n) of a longer sequence is run as the
  *            n + 1 frames [t0, t0+n] with carry = 1 (the last chunk: n frames, carry = 0).  dgi on a sub-sequence is
- *            supported by the reduce-scatter kernel only (CRUSE_PREC_BF16, Hg <= 640).
+ *            supported by the reduce-scatter kernels only (CRUSE_PREC_BF16, Hg <= 640).
  *            dg_slabs: 3 = dgi rows [G][3][Hg] (r, z, n_i); 4 = [G][4][Hg] with slab 3 = dh * c_n, the n gate of
  *            dgh = dh * (c_r, c_z, c_n) (reduce-scatter kernel): one row-major tensor that is the A operand of
  *            dX = dgi W_ih (K = 3*Hg of every 4*Hg) and of both weight-gradient products of cruse_gemm_bf16_tn.
  *   chain_clips: clips served by one team of Hg/32 workgroups.  0 = the library's plan: chains of 8 while the batch's chains fit
- *            the CUs; beyond that (B > 96 at Hg = 640) the forward pass takes WIDE chains of 16 (one launch, half the workgroups per
- *            clip, the full 16 columns of the MFMA; CRUSE_PREC_BF16, Hg % 128 == 0, Hg <= 640: 2.25 us per step against 1.49) and
- *            the backward pass several launches on chains of 8.  8 / 16 force the width (two wide recurrences with xcd_rot 0 / 4
- *            run side by side on 2 x 80 CUs: 948 us for the pair at B = 64, tools/gru_pair_probe.py).  Results do not depend on it. */
+ *            the CUs; beyond that (B > 96 at Hg = 640) WIDE chains of 16 (half the workgroups per clip, the full 16 columns of the
+ *            MFMA; CRUSE_PREC_BF16, Hg % 128 == 0, Hg <= 640; a wide launch takes 1.3x (forward) / 1.8x (backward) the time of a
+ *            launch on chains of 8) where that needs fewer launch-times than several launches on chains of 8 (B = 128: 0.67 against
+ *            1.01 ms forward, 1.27 against 1.38 ms backward; tools/gru_bigbatch_probe.py).  8 / 16 force the width (two wide
+ *            recurrences with xcd_rot 0 / 4 run side by side on 2 x 80 CUs, tools/gru_pair_probe.py).  Results do not depend on it. */
 int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, const float* const* b_hh,
                          float* h, void* coef, float* an, float* z, const float* h0, long long h0_bstride,
                          int B, int T, int TS, int G, int Hg, int prec, int chain_clips, void* panels, unsigned* status,

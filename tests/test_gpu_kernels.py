@@ -646,6 +646,34 @@ def test_gru_fwd_wide_chains_match_lean_kernel_bit_for_bit(ops, H, B, T, G):
     assert ops.gru_status() == 0
 
 
+@pytest.mark.parametrize("H,B,T,G,slabs", [(640, 64, 9, 1, 4), (640, 24, 7, 1, 3), (128, 16, 5, 1, 4), (384, 5, 6, 1, 3), (256, 33, 4, 2, 4),
+                                            (512, 17, 1, 1, 3)])
+def test_gru_bwd_wide_chains_match_reduce_scatter_kernel_bit_for_bit(ops, H, B, T, G, slabs):
+    """cruse_gru_seq_bwd_ex(chain_clips = 16): chains of 16 clips (gru_bwd_w16_kernel) -- the reduce-scatter kernel's arithmetic in
+    its summation order, so dh and the in-kernel gate gradients (3 or 4 slabs) are identical; run as time chunks (last chunk
+    first, the gradient carried across the cut) too."""
+    torch.manual_seed(H + B)
+    Hg = H // G
+    gi = (0.5 * torch.randn(B, T, 3 * H)).cuda()
+    w = [(torch.randn(3 * Hg, Hg) / Hg ** 0.5).cuda() for _ in range(G)]; b = [(0.1 * torch.randn(3 * Hg)).cuda() for _ in range(G)]
+    dout = torch.randn(B, T, H).cuda()
+    h, coef, an, z = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16")
+    ref = ops.gru_seq_bwd(dout, w, coef, z, B, T, G, Hg, "bf16", an=an, want_dgi=True, dg_slabs=slabs)
+    wide = ops.gru_seq_bwd(dout, w, coef, z, B, T, G, Hg, "bf16", an=an, want_dgi=True, dg_slabs=slabs, wide=True)
+    assert torch.equal(wide[0], ref[0]), "dh"
+    assert torch.equal(wide[1].view(torch.int16), ref[1].view(torch.int16)), "dgi"
+    only_dh = ops.gru_seq_bwd(dout, w, coef, z, B, T, G, Hg, "bf16", wide=True)
+    assert torch.equal(only_dh, ref[0])
+    if T >= 4:
+        cut = T // 2
+        out = (torch.zeros_like(ref[0]), torch.zeros_like(ref[1]))
+        ops.gru_seq_bwd(dout, w, coef, z, B, T, G, Hg, "bf16", an=an, want_dgi=True, dg_slabs=slabs, out=out, chunk=(cut, T - cut), wide=True)
+        ops.gru_seq_bwd(dout, w, coef, z, B, T, G, Hg, "bf16", an=an, want_dgi=True, dg_slabs=slabs, out=out, chunk=(0, cut), wide=True)
+        assert torch.equal(out[0], ref[0]), "chunked dh"
+        assert torch.equal(out[1].view(torch.int16), ref[1].view(torch.int16)), "chunked dgi"
+    assert ops.gru_status() == 0
+
+
 def test_gru_wide_chains_at_the_bench_length(ops):
     """T = 401, B = 64, Hg = 640: the wide-chain forward launch (4 chains of 16 on 80 CUs) against the lean one (8 chains of 8 on
     160) over the whole sequence -- 401 dependent hand-offs per chain -- bit for bit; two wide launches side by side on the two
@@ -669,18 +697,20 @@ def test_gru_wide_chains_at_the_bench_length(ops):
     assert ops.gru_status() == 0
 
 
-def test_gru_batch_beyond_the_cu_count(ops):
-    """B = 136 at Hg = 640: 17 chains of 8 x 20 workgroups do not fit the 256 CUs.  Forward: one launch of the wide-chain kernel
-    (9 chains of 16); backward: several launches of the reduce-scatter kernel on chains of 8.  Same results as the batch run in
-    two parts."""
+@pytest.mark.parametrize("B", [136, 104])
+def test_gru_batch_beyond_the_cu_count(ops, B):
+    """Hg = 640, B > 96: the chains of 8 x 20 workgroups do not fit the 256 CUs.  make_plan: B = 136 -- forward two launches of the
+    wide-chain kernel (9 chains of 16, the last with 8 clips), backward three launches of the reduce-scatter kernel on chains
+    of 8 (two wide launches would take longer); B = 104 -- one wide launch each way.  Same results as the batch run in two
+    parts (chains of 8)."""
     torch.manual_seed(3)
-    B, T, H = 136, 6, 640
+    T, H = 6, 640
     gi = (0.5 * torch.randn(B, T, 3 * H)).cuda()
     w = [(torch.randn(3 * H, H) / H ** 0.5).cuda()]; b = [(0.1 * torch.randn(3 * H)).cuda()]
     dout = torch.randn(B, T, H).cuda()
     full = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16")
     dh, dgi = ops.gru_seq_bwd(dout, w, full[1], full[3], B, T, 1, H, "bf16", an=full[2], want_dgi=True)
-    for lo, hi in ((0, 64), (64, 136)):
+    for lo, hi in ((0, 64), (64, B)):
         part = ops.gru_seq_fwd(gi[lo:hi].contiguous(), w, b, hi - lo, T, 1, H, "bf16")
         for x, y, name in zip(part, full, ("h", "coef", "an", "z")):
             assert torch.equal(x, y[lo:hi]), name

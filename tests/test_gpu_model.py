@@ -242,7 +242,12 @@ def test_inferencer_matches_oracle_waveform():
 def test_two_engines_in_one_process_do_not_share_scheduler_state():
     """VERDICT r2 structure 11: options and side-stream state live in the engine (EngineConfig / its own scheduler), not in
     module-level singletons configured from the environment: an engine with the side stream off and one with it on, stepped
-    alternately, each behave like themselves and agree on the result."""
+    alternately, each behave like themselves and agree on the result.
+    (Two runs of ONE configuration are not bit-identical: atomics land in a run-dependent order, gradients differ by ~1e-10, and
+    Adam turns that into up to ~1e-6 on weights whose gradient is noise-level; in the second step a ReLU mask of this 4-clip
+    batch can then flip on a borderline element and move every gradient below it by ~1e-3 (tools/determinism_probe.py: 3 of 12
+    pairs with the BatchNorm-backward sums in the conv epilogues, whose 16 replicas add more run-dependent last bits; 0 of 36
+    with the separate reduce pass -- which this test therefore uses, so that the comparison below means what it says).)"""
     from cruse_amd.config import EngineConfig
     from cruse_amd.data import synth_batch
     from cruse_amd.engine import TrainEngine
@@ -252,7 +257,8 @@ def test_two_engines_in_one_process_do_not_share_scheduler_state():
     engs = []
     for overlap in (True, False):
         torch.manual_seed(2)
-        engs.append(TrainEngine(unet_2(rnn_groups=2, precision="f32").cuda(), use_graph=False, config=EngineConfig(overlap=overlap)))
+        engs.append(TrainEngine(unet_2(rnn_groups=2, precision="f32").cuda(), use_graph=False,
+                                config=EngineConfig(overlap=overlap, fuse_bn_bwd_stats=False)))
     default_side = M.SIDE
     losses = [[], []]
     for _ in range(2):

@@ -17,7 +17,7 @@ def timeit(fn, n=5):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for B in (64, 24, 8):
+for B in (128, 64, 24, 8):
     gi = (0.5 * torch.randn(B, T, 3 * H)).cuda()
     dout = (0.1 * torch.randn(B, T, H)).cuda()
     h0 = (0.3 * torch.randn(B, H)).cuda()
