@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcruse_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16 = 0, 1, 2, 3
 PREC_BY_NAME = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "f16": PREC_F16}
 DT_F32, DT_F16 = 0, 1
@@ -51,6 +51,7 @@ SIGNATURES = {
     "cruse_ln_bwd": ("pppppqiipppp", "i"),
     "cruse_gemm": ("iiiiipipipipiiiip", "i"),
     "cruse_gemm_bf16_nt": ("iiipqqpqqpqpiip", "i"),
+    "cruse_gemm_bf16_nt_obf16": ("iiippqqppqqpqpp", "i"),
     "cruse_gemm_bf16_nt_seg": ("iiippqppqqpqpiiqqp", "i"),
     "cruse_gemm_bf16_tn": ("iiqpqpqiipqip", "i"),
     "cruse_cast_bf16": ("ppqp", "i"),
@@ -63,7 +64,7 @@ SIGNATURES = {
     "cruse_gru_seq_bwd": ("pppppiiiiipp", "i"),
     "cruse_gru_seq_fwd_on": ("pppppppiiiiippip", "i"),
     "cruse_gru_seq_bwd_on": ("pppppppiiiiippip", "i"),
-    "cruse_gru_seq_fwd_ex": ("ppppppppqiiiiiiippip", "i"),
+    "cruse_gru_seq_fwd_ex": ("ppppppppqiiiiiiiippip", "i"),
     "cruse_gru_seq_bwd_ex": ("pppppppiiiiiiiiippip", "i"),
     "cruse_gru_gate_grads": ("pppppqiiip", "i"),
     "cruse_gru_gate_grads_bf16": ("pppppqppqiip", "i"),

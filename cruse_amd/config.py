@@ -32,6 +32,11 @@ class EngineConfig:
     fuse_cast: bool = True          # the gate GEMMs' bf16 operand copies written by the producing BatchNorm / LayerNorm kernel
     gi_x3: Optional[int] = None     # forward gate projections: bit 0 / 1 = W_ih low-plane pass on layer 1 / 2, bit 2 = also split x
                                     # (None: 7 for Hg <= 320, else 3)
+    gi_bf16: bool = False           # the gate pre-activations gi = x W_ih^T + b_ih stored as bf16 rows (f32 accumulation, one rounding;
+                                    # the recurrence widens them on load).  OPT-IN: -0.4 GB per step but time-neutral
+                                    # (5.71 vs 5.72 ms: the projection GEMM is not bound by its store), and the forward error of the
+                                    # bf16 mode grows from 5.7e-4 to 6.9e-4 at T = 401 and from 5.1e-4 to 1.03e-3 -- over the bar -- on
+                                    # fixture G6
     dw_xcdk: Optional[int] = None   # k-slices of the dW GEMMs pinned to XCDs (None: 8 where there are >= 24 output tiles, else 0)
     conv_bwd_x3: bool = False       # backward-data convolutions as split-bf16 x3 instead of plain bf16
     dw_tn: bool = False             # weight gradients as TN GEMMs on row-major operands (measured slower: 6.35 vs 6.02 ms)
@@ -46,7 +51,7 @@ class EngineConfig:
             "early_t": ("CRUSE_EARLY_T", int), "fuse_bn_stats": ("CRUSE_FUSE_BN_STATS", lambda v: v != "0"),
             "fuse_dgi": ("CRUSE_FUSE_DGI", lambda v: v == "1"),
             "fuse_bn_bwd_stats": ("CRUSE_FUSE_BN_BWD", lambda v: v != "0"), "fuse_cast": ("CRUSE_FUSE_CAST", lambda v: v == "1"),
-            "gi_x3": ("CRUSE_GI_X3", int), "dw_xcdk": ("CRUSE_DW_XCDK", int), "conv_bwd_x3": ("CRUSE_CONV_BWD_X3", lambda v: v == "1"),
+            "gi_x3": ("CRUSE_GI_X3", int), "gi_bf16": ("CRUSE_GI_BF16", lambda v: v == "1"), "dw_xcdk": ("CRUSE_DW_XCDK", int), "conv_bwd_x3": ("CRUSE_CONV_BWD_X3", lambda v: v == "1"),
             "dw_tn": ("CRUSE_DW_TN", lambda v: v == "1"), "fwd_chunks": ("CRUSE_FWD_CHUNKS", int)}
     _LIB_ENV = {"CRUSE_GRU_BWD_RS": "gru_bwd_rs", "CRUSE_GRU_FWD_LEAN": "gru_fwd_lean", "CRUSE_GRU_WLO": "gru_wlo",
                 "CRUSE_GRU_DBG": "gru_dbg", "CRUSE_GRU_BG": "gru_bg", "CRUSE_CM_GRID": "cm_grid", "CRUSE_CM_KINT": "cm_kint", "CRUSE_CM_SWAP": "cm_swap", "CRUSE_CM_NW": "cm_nw",

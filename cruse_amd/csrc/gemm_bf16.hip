@@ -45,7 +45,7 @@ __device__ __forceinline__ long long seg_row(const GbArgs& g, int m) {
     return (long long)q * g.seg_stride + g.seg_off + (m - q * g.seg_len);
 }
 
-// MODE: C update -- 0 store, 1 read-add-store, 2 atomic add (split-K).
+// MODE: C update -- 0 store, 1 read-add-store, 2 atomic add (split-K), 3 store as bf16 (C is then a bf16 tensor, ldc in its elements).
 // NST: LDS stages.  2 = one k-tile of prefetch, two blocks per CU (the short-K products, whose epilogues then
 // overlap the other block's k-loop); 3 = two k-tiles in flight behind counted vmcnt waits and one raw barrier per
 // k-tile, one block per CU (the split-K weight gradients: hundreds of k-tiles streamed once, where the k-loop is
@@ -192,6 +192,20 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_bf16_nt_kernel(con
             float4 v = *reinterpret_cast<const float4*>(patch + rr * 68 + (lane & 15) * 4);
             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
             if (m < g.M) {
+                if constexpr (MODE == 3) {                 // bf16 rows: 8-byte stores, 128-byte row segments
+                    __bf16* cb = reinterpret_cast<__bf16*>(g.C) + seg_row(g, m) * g.ldc + nq;
+                    if (nq + 3 < g.N && (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 7) == 0)) {
+                        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
+                        const bf16x4_ o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+                        *reinterpret_cast<bf16x4_*>(cb) = o;
+                    } else {
+                        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (nq + q < g.N) cb[q] = (__bf16)e[q];
+                    }
+                    continue;
+                }
                 float* c = g.C + seg_row(g, m) * g.ldc + nq;
                 if (MODE == 2) {
                     if (nq < g.N) atomicAdd(c, v.x);
@@ -478,7 +492,8 @@ __global__ __launch_bounds__(256) void ktile_bf16_kernel(const float* x, int row
 static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, long long lda, long long a_kstride,
                           const void* B, const void* B_lo, long long ldb, long long b_kstride,
                           float* C, long long ldc, const float* bias, int accumulate, int splitk, void* stream,
-                          int seg_len = 0, long long seg_stride = 0, long long seg_off = 0) {
+                          int seg_len = 0, long long seg_stride = 0, long long seg_off = 0, bool c_bf16 = false) {
+    CRUSE_REQUIRE(!c_bf16 || (!accumulate && splitk == 1), CRUSE_E_SHAPE, "gemm_bf16_nt: a bf16 result is stored, not accumulated");
     CRUSE_REQUIRE(seg_len >= 0 && (seg_len == 0 || (seg_stride >= seg_len && seg_off >= 0 && M % seg_len == 0 && a_kstride == BK)),
                   CRUSE_E_SHAPE, "gemm_bf16_nt: bad row segments (len %d stride %lld off %lld, M %d; row-major A only)", seg_len,
                   seg_stride, seg_off, M);
@@ -527,9 +542,11 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
         hipLaunchKernelGGL((gemm_bf16_nt_kernel<MODE, NST>), grid, dim3(256), lds, st, g);                       \
     } while (0)
     if (deep) {
-        if (splitk > 1) CRUSE_GB_LAUNCH(2, 3); else if (accumulate) CRUSE_GB_LAUNCH(1, 3); else CRUSE_GB_LAUNCH(0, 3);
+        if (c_bf16) CRUSE_GB_LAUNCH(3, 3);
+        else if (splitk > 1) CRUSE_GB_LAUNCH(2, 3); else if (accumulate) CRUSE_GB_LAUNCH(1, 3); else CRUSE_GB_LAUNCH(0, 3);
     } else {
-        if (splitk > 1) CRUSE_GB_LAUNCH(2, 2); else if (accumulate) CRUSE_GB_LAUNCH(1, 2); else CRUSE_GB_LAUNCH(0, 2);
+        if (c_bf16) CRUSE_GB_LAUNCH(3, 2);
+        else if (splitk > 1) CRUSE_GB_LAUNCH(2, 2); else if (accumulate) CRUSE_GB_LAUNCH(1, 2); else CRUSE_GB_LAUNCH(0, 2);
     }
 #undef CRUSE_GB_LAUNCH
     CRUSE_LAUNCH_CHECK("gemm_bf16_nt");
@@ -542,6 +559,15 @@ extern "C" int cruse_gemm_bf16_nt(int M, int N, int K, const void* A, long long 
                                   void* stream) {
     return gemm_bf16_impl(M, N, K, A, nullptr, lda, a_kstride, B, nullptr, ldb, b_kstride, C, ldc, bias, accumulate, splitk,
                           stream);
+}
+
+extern "C" int cruse_gemm_bf16_nt_obf16(int M, int N, int K, const void* A_hi, const void* A_lo, long long lda, long long a_kstride,
+                                        const void* B_hi, const void* B_lo, long long ldb, long long b_kstride,
+                                        void* C, long long ldc, const float* bias, void* stream) {
+    CRUSE_REQUIRE((A_lo == nullptr || B_lo != nullptr) && ((uintptr_t)A_lo % 16) == 0 && ((uintptr_t)B_lo % 16) == 0, CRUSE_E_ALIGN,
+                  "gemm_bf16_nt_obf16: low planes (A_lo needs B_lo; 16-byte aligned)");
+    return gemm_bf16_impl(M, N, K, A_hi, A_lo, lda, a_kstride, B_hi, B_lo, ldb, b_kstride, reinterpret_cast<float*>(C), ldc, bias, 0, 1,
+                          stream, 0, 0, 0, true);
 }
 
 extern "C" int cruse_gemm_bf16_nt_seg(int M, int N, int K, const void* A_hi, const void* A_lo, long long lda,

@@ -53,6 +53,7 @@ struct GruPtrs { const float* w_hh[MAXG]; const float* b_hh[MAXG]; };
 struct GruArgs {
     // forward
     const float* gi; float* h; void* coef; float* an; float* z;
+    int gi_bf16;                      // gi rows are bf16 (written by cruse_gemm_bf16_nt_obf16): half the bytes; widened on load
     // backward
     const float* dout; const void* coefs; const float* zs; float* dh;
     const float* ans; void* dgi;      // optional (reduce-scatter kernel): a_n rows in, dgi = dh * (c_r, c_z, a_n) rows out
@@ -433,13 +434,15 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
     float hp[2] = {0.f, 0.f};
     const long long gi_row = (long long)a.G * 3 * Hg;             // gi floats per frame
     float gic[2][3], sv[2][6];                                    // gi of the CURRENT step; deferred saves
-    const float* gp[2];
+    long long gp[2];                                              // element index of (clip, unit) in the first frame
+    const bool gib = a.gi_bf16 != 0;
+    auto ldgi = [&](long long e) -> float { return gib ? (float)reinterpret_cast<const __bf16*>(a.gi)[e] : a.gi[e]; };
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int bl = (tid >> 5) + 8 * q;
-        gp[q] = a.gi + ((long long)(b0 + bl) * a.TS * a.G + grp) * 3 * Hg + u0 + u;
+        gp[q] = ((long long)(b0 + bl) * a.TS * a.G + grp) * 3 * Hg + u0 + u;
 #pragma unroll
-        for (int g = 0; g < 3; ++g) gic[q][g] = (q < NIT && bl < nb) ? gp[q][g * Hg] : 0.f;
+        for (int g = 0; g < 3; ++g) gic[q][g] = (q < NIT && bl < nb) ? ldgi(gp[q] + g * Hg) : 0.f;
 #pragma unroll
         for (int e = 0; e < 6; ++e) sv[q][e] = 0.f;
         if (has_h0 && q < NIT && bl < nb) hp[q] = a.h0[(long long)(b0 + bl) * a.h0_bs + grp * Hg + u0 + u];
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
             if (act && t > 0) save_step(q, t - 1);
 #pragma unroll
             for (int g = 0; g < 3; ++g)
-                gin_[q][g] = (act && t + 1 < a.T) ? gp[q][(long long)(t + 1) * gi_row + g * Hg] : 0.f;
+                gin_[q][g] = (act && t + 1 < a.T) ? ldgi(gp[q] + (long long)(t + 1) * gi_row + g * Hg) : 0.f;
         }
         if (t > 0 || has_h0) {
             f32x4 acc[6];
@@ -582,7 +585,10 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
 // the publish latency hidden under the load's way out.)
 // TIMED (profiling, library option gru_dbg = 32 at Hg = 640): s_memtime stamps at the four phase boundaries of a step, summed by
 // workgroup (chain 0, part 0) into the status header (tools/gru_probe.py prints them).
-template <int NKW, int NS, bool FULL, bool WLO, bool TIMED = false>
+// GIB: the gi rows are bf16 (a compile-time variant: the f32 instances stay instruction for instruction what they were -- this
+// kernel sits at the 256-register edge, and a run-time switch in the helper wave moved spills into the compute waves' step loop:
+// 2.2 us per step instead of 1.39).
+template <int NKW, int NS, bool FULL, bool WLO, bool TIMED = false, bool GIB = false>
 __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_kernel(GruArgs a) {
     constexpr bool HW = !(WLO && NKW > 3);
     unsigned long long tph[5] = {0, 0, 0, 0, 0}, tq0 = 0, tq1 = 0;
@@ -611,7 +617,8 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
     const long long nrow = (long long)(a.B - 1) * a.TS + a.T;           // rows reachable from the (advanced) base pointers
     const unsigned tot_h = (unsigned)min(nrow * H * 4, 0xffffffffll);
     const unsigned tot_g = (unsigned)min(nrow * a.G * 3 * Hg * 4, 0xffffffffll);
-    const __amdgpu_buffer_rsrc_t rs_gi = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gi), 0, tot_g, 0x00020000);
+    constexpr bool gib = GIB;                                           // bf16 gi rows: the coefficient rows' geometry
+    const __amdgpu_buffer_rsrc_t rs_gi = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gi), 0, gib ? tot_g >> 1 : tot_g, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(a.h, 0, tot_h, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_an = __builtin_amdgcn_make_buffer_rsrc(a.an, 0, a.an ? tot_h : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(a.z, 0, a.z ? tot_h : 0u, 0x00020000);
@@ -641,14 +648,42 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
             cv[i2] = (unsigned)((((long long)(b0 + (cl < nb ? cl : 0)) * a.TS * a.G + grp) * 3 * Hg + gate * Hg + u0 + 8 * chk) * 2);
             csrc[i2] = (unsigned)(((1 + gate) * 8 + cl) * 32 + chk * 8);
         }
+        // bf16 gi: 8 clips x 3 gates x 4 chunks of 8 bf16 = 96 lane-loads per step (the coefficient rows' lane map, cv[] below),
+        // widened to the same f32 ring
+        unsigned gdb[2] = {0u, 0u};
+        if constexpr (gib) {
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2) {
+                const int idx = min(lane + 64 * i2, 95), cl = idx / 12, rem = idx % 12, gate = rem >> 2, chk = rem & 3;
+                gdb[i2] = (unsigned)(cl * 96 + gate * 32 + chk * 8);
+            }
+        }
         struct GiSet { u32x4 v[3]; };
         auto issue = [&](int t, GiSet& o) {
+            if constexpr (gib) {
+                const unsigned so = (unsigned)min(t, a.T - 1) * crow_bytes;
+                o.v[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_gi, cv[0], so, 0);
+                if (lane < 32) o.v[1] = __builtin_amdgcn_raw_buffer_load_b128(rs_gi, cv[1], so, 0);
+                return;
+            }
             const unsigned so = (unsigned)min(t, a.T - 1) * grow_bytes;
 #pragma unroll
             for (int i3 = 0; i3 < 3; ++i3) o.v[i3] = __builtin_amdgcn_raw_buffer_load_b128(rs_gi, gv[i3], so, 0);
         };
         auto put = [&](int t, const GiSet& o) {
             float* d = &gi_r[t & 3][0][0];
+            if constexpr (gib) {
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2) {
+                    if (i2 == 1 && lane >= 32) break;
+                    const u32x4 w = o.v[i2];
+                    const u32x4 lo = {w.x << 16, w.x & 0xffff0000u, w.y << 16, w.y & 0xffff0000u};
+                    const u32x4 hi = {w.z << 16, w.z & 0xffff0000u, w.w << 16, w.w & 0xffff0000u};
+                    *reinterpret_cast<u32x4*>(d + gdb[i2]) = lo;
+                    *reinterpret_cast<u32x4*>(d + gdb[i2] + 4) = hi;
+                }
+                return;
+            }
 #pragma unroll
             for (int i3 = 0; i3 < 3; ++i3) *reinterpret_cast<u32x4*>(d + gdst[i3]) = o.v[i3];
         };
@@ -759,9 +794,13 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
         }
         if (act) hp = a.h0[(long long)(b0 + bl) * a.h0_bs + grp * Hg + u0 + u];
     }
+    auto ldgi = [&](int g, unsigned so) -> float {        // one gi value of this thread's (clip, unit): f32, or bf16 widened
+        if constexpr (gib) return __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs_gi, (g_v + g * hg4) >> 1, so >> 1, 0) << 16);
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_gi, g_v + g * hg4, so, 0));
+    };
     if constexpr (!HW) {
 #pragma unroll
-        for (int g = 0; g < 3; ++g) gic[g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_gi, g_v + g * hg4, 0, 0));
+        for (int g = 0; g < 3; ++g) gic[g] = ldgi(g, 0u);
     }
     bool nowait = a.dbg >= 1 && a.dbg < 6;
     const bool plain = a.dbg != 9 && team_shares_xcd(a.xid + (size_t)chain * 64, a.P, part, a.status, tid);
@@ -817,7 +856,7 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
         if (!HW && a.dbg != 7 && a.dbg != 6) {             // dbg 6 / 7 (profiling): no gi stream
             const unsigned so = (unsigned)min(t + 1, a.T - 1) * grow_bytes;
 #pragma unroll
-            for (int g = 0; g < 3; ++g) gin_[g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_gi, g_v + g * hg4, so, 0));
+            for (int g = 0; g < 3; ++g) gin_[g] = ldgi(g, so);
         }
         float gh[3] = {bias[0], bias[1], bias[2]};
         if (t > 0 || has_h0) {
@@ -952,7 +991,8 @@ __global__ __launch_bounds__(576) void gru_fwd_w16_kernel(GruArgs a) {
     const long long nrow = (long long)(a.B - 1) * a.TS + a.T;           // rows reachable from the (advanced) base pointers
     const unsigned tot_h = (unsigned)min(nrow * H * 4, 0xffffffffll);
     const unsigned tot_g = (unsigned)min(nrow * a.G * 3 * Hg * 4, 0xffffffffll);
-    const __amdgpu_buffer_rsrc_t rs_gi = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gi), 0, tot_g, 0x00020000);
+    const bool gib = a.gi_bf16 != 0;                                    // bf16 gi rows: the coefficient rows' geometry
+    const __amdgpu_buffer_rsrc_t rs_gi = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gi), 0, gib ? tot_g >> 1 : tot_g, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(a.h, 0, tot_h, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_an = __builtin_amdgcn_make_buffer_rsrc(a.an, 0, a.an ? tot_h : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(a.z, 0, a.z ? tot_h : 0u, 0x00020000);
@@ -989,14 +1029,37 @@ __global__ __launch_bounds__(576) void gru_fwd_w16_kernel(GruArgs a) {
             cv[i] = (unsigned)((((long long)(b0 + (cl < nb ? cl : 0)) * a.TS * a.G + grp) * 3 * Hg + gate * Hg + u0 + 8 * chk) * 2);
             csrc[i] = (unsigned)(((1 + gate) * 16 + cl) * 32 + chk * 8);
         }
+        unsigned gdb[3];                                // bf16 gi: 16 clips x 3 gates x 4 chunks of 8 bf16 (the lane map of cv[])
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int idx = lane + 64 * i, cl = idx / 12, rem = idx % 12, gate = rem >> 2, chk = rem & 3;
+            gdb[i] = (unsigned)(cl * 96 + gate * 32 + chk * 8);
+        }
         struct GiSet { u32x4 v[6]; };
         auto issue = [&](int t, GiSet& o) {
+            if (gib) {
+                const unsigned so = (unsigned)min(t, a.T - 1) * crow_bytes;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) o.v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_gi, cv[i], so, 0);
+                return;
+            }
             const unsigned so = (unsigned)min(t, a.T - 1) * grow_bytes;
 #pragma unroll
             for (int i = 0; i < 6; ++i) o.v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_gi, gv[i], so, 0);
         };
         auto put = [&](int t, const GiSet& o) {
             float* d = &gi_r[t & 3][0][0];
+            if (gib) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const u32x4 w = o.v[i];
+                    const u32x4 lo = {w.x << 16, w.x & 0xffff0000u, w.y << 16, w.y & 0xffff0000u};
+                    const u32x4 hi = {w.z << 16, w.z & 0xffff0000u, w.w << 16, w.w & 0xffff0000u};
+                    *reinterpret_cast<u32x4*>(d + gdb[i]) = lo;
+                    *reinterpret_cast<u32x4*>(d + gdb[i] + 4) = hi;
+                }
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < 6; ++i) *reinterpret_cast<u32x4*>(d + gdst[i]) = o.v[i];
         };
@@ -2095,24 +2158,24 @@ bool fwd_wlo(int Hg) {
     if (e >= 0) return e != 0;
     return Hg <= 320;
 }
-template <bool WLO>
+template <bool WLO, bool GIB>
 int dispatch_fwd_lean_w(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
     const int n = (a.Hg + 127) / 128;            // = k-steps per wave = sweep slots per thread
     if (a.Hg % 128 == 0) {
         switch (n) {
-            case 1: return launch_one(gru_fwd_lean_kernel<1, 1, true, WLO>, a, grid, lds, s, "gru_seq_fwd", (WLO && 1 > 3) ? 256 : 320);
-            case 2: return launch_one(gru_fwd_lean_kernel<2, 2, true, WLO>, a, grid, lds, s, "gru_seq_fwd", (WLO && 2 > 3) ? 256 : 320);
-            case 3: return launch_one(gru_fwd_lean_kernel<3, 3, true, WLO>, a, grid, lds, s, "gru_seq_fwd", (WLO && 3 > 3) ? 256 : 320);
-            case 4: return launch_one(gru_fwd_lean_kernel<4, 4, true, WLO>, a, grid, lds, s, "gru_seq_fwd", (WLO && 4 > 3) ? 256 : 320);
-            default: return launch_one(gru_fwd_lean_kernel<5, 5, true, WLO>, a, grid, lds, s, "gru_seq_fwd", (WLO && 5 > 3) ? 256 : 320);
+            case 1: return launch_one(gru_fwd_lean_kernel<1, 1, true, WLO, false, GIB>, a, grid, lds, s, "gru_seq_fwd", (WLO && 1 > 3) ? 256 : 320);
+            case 2: return launch_one(gru_fwd_lean_kernel<2, 2, true, WLO, false, GIB>, a, grid, lds, s, "gru_seq_fwd", (WLO && 2 > 3) ? 256 : 320);
+            case 3: return launch_one(gru_fwd_lean_kernel<3, 3, true, WLO, false, GIB>, a, grid, lds, s, "gru_seq_fwd", (WLO && 3 > 3) ? 256 : 320);
+            case 4: return launch_one(gru_fwd_lean_kernel<4, 4, true, WLO, false, GIB>, a, grid, lds, s, "gru_seq_fwd", (WLO && 4 > 3) ? 256 : 320);
+            default: return launch_one(gru_fwd_lean_kernel<5, 5, true, WLO, false, GIB>, a, grid, lds, s, "gru_seq_fwd", (WLO && 5 > 3) ? 256 : 320);
         }
     }
     switch (n) {
-        case 1: return launch_one(gru_fwd_lean_kernel<1, 1, false, WLO>, a, grid, lds, s, "gru_seq_fwd", (WLO && 1 > 3) ? 256 : 320);
-        case 2: return launch_one(gru_fwd_lean_kernel<2, 2, false, WLO>, a, grid, lds, s, "gru_seq_fwd", (WLO && 2 > 3) ? 256 : 320);
-        case 3: return launch_one(gru_fwd_lean_kernel<3, 3, false, WLO>, a, grid, lds, s, "gru_seq_fwd", (WLO && 3 > 3) ? 256 : 320);
-        case 4: return launch_one(gru_fwd_lean_kernel<4, 4, false, WLO>, a, grid, lds, s, "gru_seq_fwd", (WLO && 4 > 3) ? 256 : 320);
-        default: return launch_one(gru_fwd_lean_kernel<5, 5, false, WLO>, a, grid, lds, s, "gru_seq_fwd", (WLO && 5 > 3) ? 256 : 320);
+        case 1: return launch_one(gru_fwd_lean_kernel<1, 1, false, WLO, false, GIB>, a, grid, lds, s, "gru_seq_fwd", (WLO && 1 > 3) ? 256 : 320);
+        case 2: return launch_one(gru_fwd_lean_kernel<2, 2, false, WLO, false, GIB>, a, grid, lds, s, "gru_seq_fwd", (WLO && 2 > 3) ? 256 : 320);
+        case 3: return launch_one(gru_fwd_lean_kernel<3, 3, false, WLO, false, GIB>, a, grid, lds, s, "gru_seq_fwd", (WLO && 3 > 3) ? 256 : 320);
+        case 4: return launch_one(gru_fwd_lean_kernel<4, 4, false, WLO, false, GIB>, a, grid, lds, s, "gru_seq_fwd", (WLO && 4 > 3) ? 256 : 320);
+        default: return launch_one(gru_fwd_lean_kernel<5, 5, false, WLO, false, GIB>, a, grid, lds, s, "gru_seq_fwd", (WLO && 5 > 3) ? 256 : 320);
     }
 }
 bool fwd_w16_eligible(int Bg, int Hg, int prec) {
@@ -2128,9 +2191,10 @@ int dispatch_fwd_w16(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
     }
 }
 int dispatch_fwd_lean(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
-    if (a.dbg == 32 && a.Hg == 640 && !fwd_wlo(a.Hg))
+    if (a.dbg == 32 && a.Hg == 640 && !fwd_wlo(a.Hg) && !a.gi_bf16)
         return launch_one(gru_fwd_lean_kernel<5, 5, true, false, true>, a, grid, lds, s, "gru_seq_fwd", 320);
-    return fwd_wlo(a.Hg) ? dispatch_fwd_lean_w<true>(a, grid, lds, s) : dispatch_fwd_lean_w<false>(a, grid, lds, s);
+    if (a.gi_bf16) return fwd_wlo(a.Hg) ? dispatch_fwd_lean_w<true, true>(a, grid, lds, s) : dispatch_fwd_lean_w<false, true>(a, grid, lds, s);
+    return fwd_wlo(a.Hg) ? dispatch_fwd_lean_w<true, false>(a, grid, lds, s) : dispatch_fwd_lean_w<false, false>(a, grid, lds, s);
 }
 
 template <int PREC>
@@ -2269,9 +2333,11 @@ extern "C" size_t cruse_gru_ws_bytes(int B, int G, int Hg) {
 
 extern "C" int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, const float* const* b_hh,
                                     float* h, void* coef, float* an, float* z, const float* h0, long long h0_bstride,
-                                    int B, int T, int TS, int G, int Hg, int prec, int chain_clips, void* panels, unsigned* status,
-                                    int xcd_rot, void* stream) {
+                                    int B, int T, int TS, int G, int Hg, int prec, int chain_clips, int gi_bf16, void* panels,
+                                    unsigned* status, int xcd_rot, void* stream) {
     int rc = check_common(B, T, G, Hg, prec, "gru_seq_fwd");
+    CRUSE_REQUIRE(!gi_bf16 || (prec == CRUSE_PREC_BF16 && ((uintptr_t)gi % 16) == 0), CRUSE_E_SHAPE,
+                  "gru_seq_fwd: bf16 gi rows need CRUSE_PREC_BF16 and a 16-byte aligned base");
     CRUSE_REQUIRE(chain_clips == 0 || chain_clips == 8 || chain_clips == 16, CRUSE_E_SHAPE, "gru_seq_fwd: chain_clips = %d (0, 8, 16)", chain_clips);
     if (rc) return rc;
     CRUSE_REQUIRE(TS >= T, CRUSE_E_SHAPE, "gru_seq_fwd: clip stride %d frames < %d steps", TS, T);
@@ -2286,6 +2352,7 @@ extern "C" int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, c
     { int zrc = cruse_zero_async(panels, cruse_gru_ws_bytes(B, G, Hg) - 256, s, "gru_seq_fwd memset"); if (zrc) return zrc; }   // the status word is sticky: never cleared here
     GruArgs a = {};
     a.gi = gi; a.h = h; a.coef = coef; a.an = an; a.z = z;
+    a.gi_bf16 = gi_bf16 ? 1 : 0;
     for (int g = 0; g < G; ++g) { a.p.w_hh[g] = w_hh[g]; a.p.b_hh[g] = b_hh[g]; }
     a.B = B; a.T = T; a.G = G; a.Hg = Hg;
     a.TS = TS; a.h0 = h0; a.h0_bs = h0_bstride;
@@ -2298,7 +2365,7 @@ extern "C" int cruse_gru_seq_fwd_on(const float* gi, const float* const* w_hh, c
                                     float* h, void* coef, float* an, float* z,
                                     int B, int T, int G, int Hg, int prec, void* panels, unsigned* status, int xcd_rot,
                                     void* stream) {
-    return cruse_gru_seq_fwd_ex(gi, w_hh, b_hh, h, coef, an, z, nullptr, 0, B, T, T, G, Hg, prec, 0, panels, status, xcd_rot, stream);
+    return cruse_gru_seq_fwd_ex(gi, w_hh, b_hh, h, coef, an, z, nullptr, 0, B, T, T, G, Hg, prec, 0, 0, panels, status, xcd_rot, stream);
 }
 
 extern "C" int cruse_gru_seq_fwd(const float* gi, const float* const* w_hh, const float* const* b_hh,

@@ -359,8 +359,11 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
 
     fast = _bf16_gemm_path(prec, Hg)
 
+    gi_bf = fast and bool(config.get().gi_bf16)
+
     def layer(inp, lname, inp_bf=None):
-        gi = torch.empty(B, T, g * 3 * Hg, device=x.device, dtype=torch.float32)
+        # (EngineConfig.gi_bf16, opt-in: bf16 rows -- the GEMM rounds its f32 sums once on store)
+        gi = torch.empty(B, T, g * 3 * Hg, device=x.device, dtype=torch.bfloat16 if gi_bf else torch.float32)
         # The forward projection corrects the bf16 rounding of W_ih (a second pass with its low plane): that rounding
         # dominates the forward error of the bf16 mode (enhanced spectrum 1.25e-3 -> 5.1e-4 rel-L2 on fixture G6;
         # correcting x too only reaches 4.8e-4).  CRUSE_GI_X3: bit 0 / 1 = layer 1 / 2 corrected, bit 2 = also split x.

@@ -370,8 +370,14 @@ def gemm_bf16_nt(M, N, K, A, a_off, lda, Bm, b_off, ldb, C, c_off, ldc, bias=Non
                  a_kstride=64, b_kstride=64):
     """C[M,N] (+)= A[M,K] . B[N,K]^T on bf16 operands (element offsets into the tensors' storage).
     *_kstride == 64: row-major operand; larger: the K-tiled time-major layout (lda == 64), see cruse_hip.h."""
-    if A.dtype != torch.bfloat16 or Bm.dtype != torch.bfloat16 or C.dtype != torch.float32:
-        raise RuntimeError("gemm_bf16_nt needs bf16 operands and an f32 result")
+    if A.dtype != torch.bfloat16 or Bm.dtype != torch.bfloat16 or C.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("gemm_bf16_nt needs bf16 operands and an f32 (or stored-as-bf16) result")
+    if C.dtype == torch.bfloat16:               # result rounded to bf16 on store (cruse_gemm_bf16_nt_obf16): no accumulate / split-K
+        if accumulate or splitk != 1:
+            raise RuntimeError("gemm_bf16_nt: a bf16 result is stored, not accumulated")
+        check(lib.cruse_gemm_bf16_nt_obf16(M, N, K, A.data_ptr() + 2 * a_off, None, lda, a_kstride, Bm.data_ptr() + 2 * b_off, None, ldb,
+                                           b_kstride, C.data_ptr() + 2 * c_off, ldc, _p(bias), _stream()))
+        return
     check(lib.cruse_gemm_bf16_nt(M, N, K, A.data_ptr() + 2 * a_off, lda, a_kstride, Bm.data_ptr() + 2 * b_off, ldb, b_kstride,
                                  C.data_ptr() + 4 * c_off, ldc, _p(bias), 1 if accumulate else 0, splitk, _stream()))
 
@@ -422,6 +428,13 @@ def gemm_bf16x3_nt(M, N, K, A_hi, A_lo, a_off, lda, B_hi, B_lo, b_off, ldb, C, c
     for t_ in (A_hi, A_lo, B_hi, B_lo):
         if t_ is not None and t_.dtype != torch.bfloat16:
             raise RuntimeError("gemm_bf16x3_nt needs bf16 planes")
+    if C.dtype == torch.bfloat16:               # result rounded to bf16 on store (cruse_gemm_bf16_nt_obf16)
+        if accumulate:
+            raise RuntimeError("gemm_bf16x3_nt: a bf16 result is stored, not accumulated")
+        check(lib.cruse_gemm_bf16_nt_obf16(M, N, K, A_hi.data_ptr() + 2 * a_off, None if A_lo is None else A_lo.data_ptr() + 2 * a_off,
+                                           lda, a_kstride, B_hi.data_ptr() + 2 * b_off, B_lo.data_ptr() + 2 * b_off, ldb, b_kstride,
+                                           C.data_ptr() + 2 * c_off, ldc, _p(bias), _stream()))
+        return
     check(lib.cruse_gemm_bf16x3_nt(M, N, K, A_hi.data_ptr() + 2 * a_off,
                                    None if A_lo is None else A_lo.data_ptr() + 2 * a_off, lda, a_kstride,
                                    B_hi.data_ptr() + 2 * b_off, B_lo.data_ptr() + 2 * b_off, ldb, b_kstride,
@@ -468,7 +481,10 @@ def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G,
     h0 [B, G*Hg] ("cat" layout: feature = group*Hg + unit): initial state (cust_conv.py:305-325); None = 0.
     chunk = (t0, n): run only frames [t0, t0+n) of the [B,T] tensors into `out` = (h, coef, an, z) from the call that ran
     the frames before them -- the initial state is then h[:, t0-1] (h0 for t0 == 0).  Consecutive chunks reproduce the
-    single launch (cruse_gru_seq_fwd_ex).  wide: chains of 16 clips (half the workgroups; same results)."""
+    single launch (cruse_gru_seq_fwd_ex).  wide: chains of 16 clips (half the workgroups; same results).
+    gi: f32, or bf16 rows (gemm_bf16_nt into a bf16 tensor; bf16 mode only)."""
+    if gi.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError(f"gru_seq_fwd: gi must be f32 or bf16, got {gi.dtype}")
     dev = gi.device
     H = G * Hg
     if out is not None:
@@ -498,7 +514,8 @@ def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G,
     opt = lambda t_, k: None if t_ is None else _off(t_, t0 * k)
     check(lib.cruse_gru_seq_fwd_ex(_off(gi, t0 * 3 * H), ctypes.cast(wa, ctypes.c_void_p), ctypes.cast(ba, ctypes.c_void_p),
                                    _off(h, t0 * H), opt(coef, 3 * H), opt(an, H), opt(z, H), h0p, h0s, B, n, T, G, Hg,
-                                   prec_code(prec), 16 if wide else 0, panels, status, xcd_rot, _stream()))
+                                   prec_code(prec), 16 if wide else 0, 1 if gi.dtype == torch.bfloat16 else 0, panels, status, xcd_rot,
+                                   _stream()))
     return h, coef, an, z
 
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CRUSE_ABI_VERSION 5
+#define CRUSE_ABI_VERSION 6
 
 enum {
     CRUSE_OK = 0,
@@ -238,6 +238,13 @@ int cruse_gemm(int transA, int transB, int M, int N, int K,
 int cruse_gemm_bf16_nt(int M, int N, int K, const void* A, long long lda, long long a_kstride,
                        const void* B, long long ldb, long long b_kstride,
                        float* C, long long ldc, const float* bias, int accumulate, int splitk, void* stream);
+/* The same product -- or, with low planes (A_lo nullable, B_lo nullable: plain bf16), the split-bf16 form of
+ * cruse_gemm_bf16x3_nt -- with the result STORED AS bf16 (C bf16 [M, ldc]; f32 accumulation, bias added in f32 before the one
+ * rounding; no accumulate, no split-K): gi = x W_ih^T + b_ih as bf16 rows for cruse_gru_seq_fwd_ex(gi_bf16 = 1) -- half the bytes
+ * of the largest tensor the GGRU block writes and reads (nn.GRU under bf16 autocast produces bf16 gate pre-activations too). */
+int cruse_gemm_bf16_nt_obf16(int M, int N, int K, const void* A_hi, const void* A_lo, long long lda, long long a_kstride,
+                             const void* B_hi, const void* B_lo, long long ldb, long long b_kstride,
+                             void* C, long long ldc, const float* bias, void* stream);
 /* TN form for the weight gradients of the gate projections (dW_ih += dgi^T x, dW_hh += dgh^T h_{t-1}; nn.GRU backward at
  * model/cruse_net.py:44,50): C[M,N] += sum_k A[k*lda + m] * B[k*ldb + n] over the K = B*T frames, with A (bf16 gate-gradient
  * rows) and B (bf16 layer-input rows, or f32 hidden-state rows when b_is_f32) ROW-MAJOR as the backward recurrence / the
@@ -323,6 +330,8 @@ int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh, const void
  *            dg_slabs: 3 = dgi rows [G][3][Hg] (r, z, n_i); 4 = [G][4][Hg] with slab 3 = dh * c_n, the n gate of
  *            dgh = dh * (c_r, c_z, c_n) (reduce-scatter kernel): one row-major tensor that is the A operand of
  *            dX = dgi W_ih (K = 3*Hg of every 4*Hg) and of both weight-gradient products of cruse_gemm_bf16_tn.
+ *   gi_bf16 (forward): gi points at bf16 rows [.., G*3*Hg] (cruse_gemm_bf16_nt_obf16) instead of f32 ones; CRUSE_PREC_BF16 only.
+ *            The values are widened on load; everything else is unchanged.
  *   chain_clips: clips served by one team of Hg/32 workgroups.  0 = the library's plan: chains of 8 while the batch's chains fit
  *            the CUs; beyond that (B > 96 at Hg = 640) WIDE chains of 16 (half the workgroups per clip, the full 16 columns of the
  *            MFMA; CRUSE_PREC_BF16, Hg % 128 == 0, Hg <= 640; a wide launch takes 1.3x (forward) / 1.8x (backward) the time of a
@@ -331,8 +340,8 @@ int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh, const void
  *            recurrences with xcd_rot 0 / 4 run side by side on 2 x 80 CUs, tools/gru_pair_probe.py).  Results do not depend on it. */
 int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, const float* const* b_hh,
                          float* h, void* coef, float* an, float* z, const float* h0, long long h0_bstride,
-                         int B, int T, int TS, int G, int Hg, int prec, int chain_clips, void* panels, unsigned* status,
-                         int xcd_rot, void* stream);
+                         int B, int T, int TS, int G, int Hg, int prec, int chain_clips, int gi_bf16, void* panels,
+                         unsigned* status, int xcd_rot, void* stream);
 int cruse_gru_seq_bwd_ex(const float* dout, const float* const* w_hh, const void* coef, const float* z,
                          float* dh, const float* an, void* dgi, int dg_slabs, int carry, int B, int T, int TS, int G,
                          int Hg, int prec, int chain_clips, void* panels, unsigned* status, int xcd_rot, void* stream);

@@ -674,6 +674,54 @@ def test_gru_bwd_wide_chains_match_reduce_scatter_kernel_bit_for_bit(ops, H, B, 
     assert ops.gru_status() == 0
 
 
+@pytest.mark.parametrize("H,B,T,G,opts,wide", [(640, 64, 9, 1, {}, False), (640, 24, 7, 1, {}, True), (320, 11, 6, 2, {}, False),
+                                               (512, 9, 5, 1, {"gru_wlo": 1}, False), (256, 13, 6, 1, {"gru_fwd_lean": 0}, False),
+                                               (384, 40, 5, 1, {}, True)])
+def test_gru_fwd_takes_bf16_gate_preactivations(ops, H, B, T, G, opts, wide):
+    """cruse_gru_seq_fwd_ex(gi_bf16 = 1): gi as bf16 rows (cruse_gemm_bf16_nt_obf16) widened on load == the same values handed over
+    as f32 rows, bit for bit, in every forward kernel of the bf16 mode: lean with the helper wave (Hg % 128 == 0 and not), lean
+    without it (W_hh low plane at Hg > 384), wide chains, the generic kernel; with an initial state and in time chunks."""
+    torch.manual_seed(H + B)
+    Hg = H // G
+    gi_bf = (0.5 * torch.randn(B, T, 3 * H)).cuda().to(torch.bfloat16)
+    gi_f = gi_bf.float()
+    w = [(torch.randn(3 * Hg, Hg) / Hg ** 0.5).cuda() for _ in range(G)]; b = [(0.1 * torch.randn(3 * Hg)).cuda() for _ in range(G)]
+    h0 = (0.3 * torch.randn(B, H)).cuda()
+    with ops.options(**opts):
+        for init in (None, h0):
+            ref = ops.gru_seq_fwd(gi_f, w, b, B, T, G, Hg, "bf16", h0=init, wide=wide)
+            got = ops.gru_seq_fwd(gi_bf, w, b, B, T, G, Hg, "bf16", h0=init, wide=wide)
+            for x, y, name in zip(got, ref, ("h", "coef", "an", "z")):
+                assert torch.equal(x, y), (name, init is not None)
+        cut = T // 2
+        out = ops.gru_seq_fwd(gi_bf, w, b, B, T, G, Hg, "bf16", h0=h0, chunk=(0, cut), wide=wide)
+        ops.gru_seq_fwd(gi_bf, w, b, B, T, G, Hg, "bf16", out=out, chunk=(cut, T - cut), wide=wide)
+        for x, y, name in zip(out, ref, ("h", "coef", "an", "z")):
+            assert torch.equal(x, y), ("chunked", name)
+    with pytest.raises(RuntimeError):
+        ops.gru_seq_fwd(gi_bf, w, b, B, T, G, Hg, "f32")            # bf16 rows belong to the bf16 mode
+    assert ops.gru_status() == 0
+
+
+@pytest.mark.parametrize("M,N,K,x3", [(25664, 1920, 640, False), (25664, 1920, 640, True), (333, 200, 128, False), (130, 96, 64, True)])
+def test_gemm_bf16_result_stored_as_bf16(ops, M, N, K, x3):
+    """cruse_gemm_bf16_nt_obf16: the f32 sums (+ bias) of cruse_gemm_bf16_nt / cruse_gemm_bf16x3_nt rounded once (RNE) on store --
+    equal to rounding the f32 result afterwards, bit for bit; ragged tiles included."""
+    torch.manual_seed(M + N)
+    A = torch.randn(M, K).cuda(); Bm = torch.randn(N, K).cuda(); bias = torch.randn(N).cuda()
+    A_hi = A.to(torch.bfloat16); B_hi = Bm.to(torch.bfloat16)
+    B_lo = (Bm - B_hi.float()).to(torch.bfloat16)
+    Cf = torch.empty(M, N).cuda(); Cb = torch.full((M, N), 7.0, dtype=torch.bfloat16).cuda()
+    for C in (Cf, Cb):
+        if x3:
+            ops.gemm_bf16x3_nt(M, N, K, A_hi, None, 0, K, B_hi, B_lo, 0, K, C, 0, N, bias=bias)
+        else:
+            ops.gemm_bf16_nt(M, N, K, A_hi, 0, K, B_hi, 0, K, C, 0, N, bias=bias)
+    assert torch.equal(Cb.view(torch.int16), Cf.to(torch.bfloat16).view(torch.int16))
+    with pytest.raises(RuntimeError):
+        ops.gemm_bf16_nt(M, N, K, A_hi, 0, K, B_hi, 0, K, Cb, 0, N, accumulate=True)
+
+
 def test_gru_wide_chains_at_the_bench_length(ops):
     """T = 401, B = 64, Hg = 640: the wide-chain forward launch (4 chains of 16 on 80 CUs) against the lean one (8 chains of 8 on
     160) over the whole sequence -- 401 dependent hand-offs per chain -- bit for bit; two wide launches side by side on the two

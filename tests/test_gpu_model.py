@@ -271,6 +271,29 @@ def test_two_engines_in_one_process_do_not_share_scheduler_state():
     assert rel_l2(engs[0].flat.params, engs[1].flat.params) < 1e-5
 
 
+def test_engine_with_bf16_gate_preactivations():
+    """EngineConfig.gi_bf16 (opt-in): gi stored as bf16 rows by the projection GEMM and widened by the recurrence -- the step runs
+    end to end on the HIP path and stays the same computation up to that one rounding (mask within 5e-3, loss within 1e-3)."""
+    from cruse_amd.config import EngineConfig
+    from cruse_amd.data import synth_batch
+    from cruse_amd.engine import TrainEngine
+    from cruse_amd.model.cruse_net import unet_2
+    from cruse_amd import ops
+    noisy, clean = synth_batch(16, 32000, "cuda", 4)
+    res = {}
+    for flag in (False, True):
+        torch.manual_seed(5)
+        eng = TrainEngine(unet_2(rnn_groups=1, precision="bf16").cuda(), use_graph=False, config=EngineConfig(gi_bf16=flag))
+        ls = eng.step(noisy, clean)
+        torch.cuda.synchronize()
+        res[flag] = (eng.loss_value(ls), eng._last_mask.clone(), eng.flat.grads.clone())
+        assert eng.skipped_steps() == 0 and ops.gru_status() == 0
+    assert not torch.equal(res[True][1], res[False][1])             # the option did something
+    assert rel_l2(res[True][1], res[False][1]) < 5e-3
+    assert res[True][0] == pytest.approx(res[False][0], rel=1e-3)
+    assert rel_l2(res[True][2], res[False][2]) < 5e-2
+
+
 @pytest.mark.parametrize("fwd_chunks", [0, 2])
 def test_graph_replay_on_a_new_batch_equals_eager_launches(fwd_chunks):
     """A captured step replayed on ANOTHER batch computes what the eager launches compute.  lr = 0, so the parameters never move
