@@ -64,8 +64,8 @@ SIGNATURES = {
     "cruse_gru_seq_bwd": ("pppppiiiiipp", "i"),
     "cruse_gru_seq_fwd_on": ("pppppppiiiiippip", "i"),
     "cruse_gru_seq_bwd_on": ("pppppppiiiiippip", "i"),
-    "cruse_gru_seq_fwd_ex": ("ppppppppqiiiiiiiippip", "i"),
-    "cruse_gru_seq_bwd_ex": ("pppppppiiiiiiiiippip", "i"),
+    "cruse_gru_seq_fwd_ex": ("ppppppppqiiiiiiiipipip", "i"),
+    "cruse_gru_seq_bwd_ex": ("pppppppiiiiiiiiipipip", "i"),
     "cruse_gru_gate_grads": ("pppppqiiip", "i"),
     "cruse_gru_gate_grads_bf16": ("pppppqppqiip", "i"),
     "cruse_gru_gate_bias_sums": ("pqiippp", "i"),

@@ -2334,7 +2334,7 @@ extern "C" size_t cruse_gru_ws_bytes(int B, int G, int Hg) {
 extern "C" int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, const float* const* b_hh,
                                     float* h, void* coef, float* an, float* z, const float* h0, long long h0_bstride,
                                     int B, int T, int TS, int G, int Hg, int prec, int chain_clips, int gi_bf16, void* panels,
-                                    unsigned* status, int xcd_rot, void* stream) {
+                                    int panels_zeroed, unsigned* status, int xcd_rot, void* stream) {
     int rc = check_common(B, T, G, Hg, prec, "gru_seq_fwd");
     CRUSE_REQUIRE(!gi_bf16 || (prec == CRUSE_PREC_BF16 && ((uintptr_t)gi % 16) == 0), CRUSE_E_SHAPE,
                   "gru_seq_fwd: bf16 gi rows need CRUSE_PREC_BF16 and a 16-byte aligned base");
@@ -2349,7 +2349,9 @@ extern "C" int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, c
     CRUSE_REQUIRE(make_plan(B, G, Hg, prec, true, chain_clips, pl) == 0, CRUSE_E_SHAPE, "gru_seq_fwd: G*Hg/32 exceeds the CU count");
     hipStream_t s = (hipStream_t)stream;
     CRUSE_REQUIRE(panels != nullptr && status != nullptr, CRUSE_E_SHAPE, "gru_seq_fwd: workspace / status pointer is NULL");
-    { int zrc = cruse_zero_async(panels, cruse_gru_ws_bytes(B, G, Hg) - 256, s, "gru_seq_fwd memset"); if (zrc) return zrc; }   // the status word is sticky: never cleared here
+    // (the status word is sticky: never cleared here.  panels_zeroed: the caller cleared the scratch itself -- e.g. the scratches of
+    //  all four recurrences of a training step with one launch at the top of the step instead of a memset in front of each)
+    if (!panels_zeroed) { int zrc = cruse_zero_async(panels, cruse_gru_ws_bytes(B, G, Hg) - 256, s, "gru_seq_fwd memset"); if (zrc) return zrc; }
     GruArgs a = {};
     a.gi = gi; a.h = h; a.coef = coef; a.an = an; a.z = z;
     a.gi_bf16 = gi_bf16 ? 1 : 0;
@@ -2365,7 +2367,7 @@ extern "C" int cruse_gru_seq_fwd_on(const float* gi, const float* const* w_hh, c
                                     float* h, void* coef, float* an, float* z,
                                     int B, int T, int G, int Hg, int prec, void* panels, unsigned* status, int xcd_rot,
                                     void* stream) {
-    return cruse_gru_seq_fwd_ex(gi, w_hh, b_hh, h, coef, an, z, nullptr, 0, B, T, T, G, Hg, prec, 0, 0, panels, status, xcd_rot, stream);
+    return cruse_gru_seq_fwd_ex(gi, w_hh, b_hh, h, coef, an, z, nullptr, 0, B, T, T, G, Hg, prec, 0, 0, panels, 0, status, xcd_rot, stream);
 }
 
 extern "C" int cruse_gru_seq_fwd(const float* gi, const float* const* w_hh, const float* const* b_hh,
@@ -2381,7 +2383,8 @@ extern "C" int cruse_gru_gate_grads_bf16(const float* dh, const void* coef, cons
 
 extern "C" int cruse_gru_seq_bwd_ex(const float* dout, const float* const* w_hh, const void* coef, const float* z,
                                     float* dh, const float* an, void* dgi, int dg_slabs, int carry, int B, int T, int TS, int G,
-                                    int Hg, int prec, int chain_clips, void* panels, unsigned* status, int xcd_rot, void* stream) {
+                                    int Hg, int prec, int chain_clips, void* panels, int panels_zeroed, unsigned* status, int xcd_rot,
+                                    void* stream) {
     int rc = check_common(B, T, G, Hg, prec, "gru_seq_bwd");
     CRUSE_REQUIRE(chain_clips == 0 || chain_clips == 8 || chain_clips == 16, CRUSE_E_SHAPE, "gru_seq_bwd: chain_clips = %d (0, 8, 16)", chain_clips);
     if (rc) return rc;
@@ -2390,7 +2393,7 @@ extern "C" int cruse_gru_seq_bwd_ex(const float* dout, const float* const* w_hh,
     CRUSE_REQUIRE(make_plan(B, G, Hg, prec, false, chain_clips, pl) == 0, CRUSE_E_SHAPE, "gru_seq_bwd: G*Hg/32 exceeds the CU count");
     hipStream_t s = (hipStream_t)stream;
     CRUSE_REQUIRE(panels != nullptr && status != nullptr, CRUSE_E_SHAPE, "gru_seq_bwd: workspace / status pointer is NULL");
-    { int zrc = cruse_zero_async(panels, cruse_gru_ws_bytes(B, G, Hg) - 256, s, "gru_seq_bwd memset"); if (zrc) return zrc; }   // the status word is sticky: never cleared here
+    if (!panels_zeroed) { int zrc = cruse_zero_async(panels, cruse_gru_ws_bytes(B, G, Hg) - 256, s, "gru_seq_bwd memset"); if (zrc) return zrc; }   // the status word is sticky: never cleared here
     GruArgs a = {};
     a.dout = dout; a.coefs = coef; a.zs = z; a.dh = dh;
     for (int g = 0; g < G; ++g) { a.p.w_hh[g] = w_hh[g]; a.p.b_hh[g] = nullptr; }
@@ -2418,7 +2421,7 @@ extern "C" int cruse_gru_seq_bwd_ex(const float* dout, const float* const* w_hh,
 extern "C" int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh, const void* coef, const float* z,
                                     float* dh, const float* an, void* dgi, int B, int T, int G, int Hg, int prec,
                                     void* panels, unsigned* status, int xcd_rot, void* stream) {
-    return cruse_gru_seq_bwd_ex(dout, w_hh, coef, z, dh, an, dgi, 3, 0, B, T, T, G, Hg, prec, 0, panels, status, xcd_rot, stream);
+    return cruse_gru_seq_bwd_ex(dout, w_hh, coef, z, dh, an, dgi, 3, 0, B, T, T, G, Hg, prec, 0, panels, 0, status, xcd_rot, stream);
 }
 
 extern "C" int cruse_gru_seq_bwd(const float* dout, const float* const* w_hh, const void* coef, const float* z,

@@ -322,7 +322,9 @@ class TrainEngine:
     def _fwd_bwd(self, noisy: torch.Tensor, clean: torch.Tensor, boundary=None) -> torch.Tensor:
         B, L = noisy.shape
         T = ops.stft_frames(L, self.hop)
-        with _config.use(self.cfg), _net.use_scheduler(self.side), ops.ARENA.step(noisy.device):      # (one arena clear per step)
+        g = self.model.rnn_groups
+        with _config.use(self.cfg), _net.use_scheduler(self.side), ops.ARENA.step(noisy.device), \
+                _net.STEP_SCRATCH.step(B, g, self.model.hidden_size // g, noisy.device):      # (one arena clear, one scratch clear per step)
             loss_sum, dlogit, ctx = self._forward_loss(noisy, clean, training=True)
             ops.zero_(self.flat.grads)
             unet2_backward(ctx, dlogit.view(B, T, 1, self.f_net), self.flat.P, self.flat.G, boundary=boundary)

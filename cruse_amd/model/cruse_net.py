@@ -15,6 +15,7 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Tuple
 
+import contextlib
 import torch
 import torch.nn as nn
 
@@ -169,6 +170,37 @@ def _bf16_gemm_path(prec, Hg: int) -> bool:
     """bf16-operand GEMMs: K = Hg and K = 3*Hg are rounded up to whole 64-deep tiles -- the weight operand is zero
     padded (K-tiled), the activation operand reads on into the next group / row (finite values, zero weights)."""
     return ops.prec_code(prec) == ops.PREC_BF16 and Hg % 32 == 0
+
+
+class _StepScratch:
+    """Recurrence panel scratches of ONE training step: the engine clears the four slots with one launch at the top of the step
+    (ops.gru_step_ws_clear) and every recurrence launch of the step then takes the next slot with zeroed=True -- the memset in
+    front of each recurrence (~7 us of kernel + ~7 us of gap, four times on the main stream) is gone.  Inactive outside
+    `with STEP_SCRATCH.step(...)`, beyond four launches (time-chunk pipelines) and for a different shape: the launch then clears
+    its own scratch as before."""
+
+    def __init__(self):
+        self.key = None
+        self.next = 0
+
+    @contextlib.contextmanager
+    def step(self, B, g, Hg, device):
+        ops.gru_step_ws_clear(B, g, Hg, device)
+        self.key, self.next = (B, g, Hg), 0
+        try:
+            yield self
+        finally:
+            self.key = None
+
+    def take(self, B, g, Hg, slot):
+        """-> (slot, zeroed) for the next recurrence launch"""
+        if self.key != (B, g, Hg) or slot != 0 or self.next >= ops.STEP_SLOTS:
+            return slot, False
+        self.next += 1
+        return ops.STEP_SLOT0 + self.next - 1, True
+
+
+STEP_SCRATCH = _StepScratch()
 
 
 def _gi_x3_knob(Hg: int) -> int:
@@ -396,8 +428,9 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
         b_hh = [P[f"{prefix}{lname}.{i}.bias_hh_l0"] for i in range(g)]
         if hooks:
             hooks.pop()()                    # the pre-stage of this slice is issued: the next slice may start its own
-        return SIDE.release_around(lambda: ops.gru_seq_fwd(gi, w_hh, b_hh, B, T, g, Hg, prec, save=save, slot=slot,
-                                                           xcd_rot=xcd_rot))
+        slot_, zeroed = STEP_SCRATCH.take(B, g, Hg, slot)
+        return SIDE.release_around(lambda: ops.gru_seq_fwd(gi, w_hh, b_hh, B, T, g, Hg, prec, save=save, slot=slot_,
+                                                           xcd_rot=xcd_rot, zeroed=zeroed))
 
     # The K-tiled time-major bf16 copies of x, h1, l1, h2 -- the K operands of the four weight-gradient GEMMs -- depend on
     # the forward pass only.  From the first backward recurrence on, the side streams' queue is what the optimizer step
@@ -500,8 +533,10 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
     def run_bwd(dout_h, w_hh, coef, z, an=None, dg_slabs=3):
         if hooks:
             hooks.pop()()
-        return SIDE.release_around(lambda: ops.gru_seq_bwd(dout_h, w_hh, coef, z, B, T, g, Hg, prec, slot=slot,
-                                                           xcd_rot=xcd_rot, an=an, want_dgi=an is not None, dg_slabs=dg_slabs))
+        slot_, zeroed = STEP_SCRATCH.take(B, g, Hg, slot)
+        return SIDE.release_around(lambda: ops.gru_seq_bwd(dout_h, w_hh, coef, z, B, T, g, Hg, prec, slot=slot_,
+                                                           xcd_rot=xcd_rot, an=an, want_dgi=an is not None, dg_slabs=dg_slabs,
+                                                           zeroed=zeroed))
 
     def layer_bwd_tn(dout_h, lname, inp, h, coef, an, z, need_dinp, last):
         """CRUSE_PREC_BF16 with row-major operands only (_dw_tn): the recurrence writes dh and the 4-slab gate-gradient rows;

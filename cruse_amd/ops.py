@@ -458,16 +458,33 @@ def _ptr_array(ts: Sequence[torch.Tensor]):
     return arr
 
 
+STEP_SLOT0 = 100            # slots STEP_SLOT0 .. +STEP_SLOTS-1: the scratches gru_step_ws_clear() clears with ONE launch
+STEP_SLOTS = 4
+
+
 def _gru_ws(B, G, Hg, dev, slot: int):
     """-> (panel scratch pointer, status word pointer).  slot 0 is the library's classic workspace (sticky header +
     panels); slots > 0 -- concurrent recurrences on other streams -- get their own panel scratch and share slot 0's
-    status word, so one word still guards the optimizer step."""
+    status word, so one word still guards the optimizer step.  Slots STEP_SLOT0.. are carved from one buffer
+    (gru_step_ws_clear)."""
     nbytes = lib.cruse_gru_ws_bytes(B, G, Hg)
     ws = _ws("gru", nbytes, dev)
     if slot == 0:
         return ws.data_ptr() + 256, ws.data_ptr()
+    if STEP_SLOT0 <= slot < STEP_SLOT0 + STEP_SLOTS:
+        per = (nbytes - 256 + 255) // 256 * 256
+        buf = _ws(("gru_step", per), per * STEP_SLOTS, dev)
+        return buf.data_ptr() + (slot - STEP_SLOT0) * per, ws.data_ptr()
     panels = _ws(("gru_panels", slot), nbytes - 256, dev)
     return panels.data_ptr(), ws.data_ptr()
+
+
+def gru_step_ws_clear(B, G, Hg, dev) -> None:
+    """One launch clears the panel scratches of slots STEP_SLOT0 .. STEP_SLOT0 + STEP_SLOTS - 1: the (up to) four recurrences of
+    a training step then run with zeroed=True -- no memset launch in front of each (4 x ~14 us on the main stream)."""
+    nbytes = lib.cruse_gru_ws_bytes(B, G, Hg)
+    per = (nbytes - 256 + 255) // 256 * 256
+    zero_(_ws(("gru_step", per), per * STEP_SLOTS, torch.device(dev)))
 
 
 def _off(t: torch.Tensor, elems: int) -> int:
@@ -475,14 +492,15 @@ def _off(t: torch.Tensor, elems: int) -> int:
 
 
 def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G, Hg, prec, save=True, slot=0, xcd_rot=0,
-                h0=None, out=None, chunk=None, wide=False):
+                h0=None, out=None, chunk=None, wide=False, zeroed=False):
     """-> (h, coef, an, z); the last three are None when save is False (inference).  slot / xcd_rot: see
     cruse_gru_seq_fwd_on (concurrent recurrences).
     h0 [B, G*Hg] ("cat" layout: feature = group*Hg + unit): initial state (cust_conv.py:305-325); None = 0.
     chunk = (t0, n): run only frames [t0, t0+n) of the [B,T] tensors into `out` = (h, coef, an, z) from the call that ran
     the frames before them -- the initial state is then h[:, t0-1] (h0 for t0 == 0).  Consecutive chunks reproduce the
     single launch (cruse_gru_seq_fwd_ex).  wide: chains of 16 clips (half the workgroups; same results).
-    gi: f32, or bf16 rows (gemm_bf16_nt into a bf16 tensor; bf16 mode only)."""
+    gi: f32, or bf16 rows (gemm_bf16_nt into a bf16 tensor; bf16 mode only).  zeroed: the slot's scratch is already clear
+    (gru_step_ws_clear)."""
     if gi.dtype not in (torch.float32, torch.bfloat16):
         raise RuntimeError(f"gru_seq_fwd: gi must be f32 or bf16, got {gi.dtype}")
     dev = gi.device
@@ -514,8 +532,8 @@ def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G,
     opt = lambda t_, k: None if t_ is None else _off(t_, t0 * k)
     check(lib.cruse_gru_seq_fwd_ex(_off(gi, t0 * 3 * H), ctypes.cast(wa, ctypes.c_void_p), ctypes.cast(ba, ctypes.c_void_p),
                                    _off(h, t0 * H), opt(coef, 3 * H), opt(an, H), opt(z, H), h0p, h0s, B, n, T, G, Hg,
-                                   prec_code(prec), 16 if wide else 0, 1 if gi.dtype == torch.bfloat16 else 0, panels, status, xcd_rot,
-                                   _stream()))
+                                   prec_code(prec), 16 if wide else 0, 1 if gi.dtype == torch.bfloat16 else 0, panels, 1 if zeroed else 0,
+                                   status, xcd_rot, _stream()))
     return h, coef, an, z
 
 
@@ -531,7 +549,7 @@ def dgi_buffer(rows, G, Hg, device, slabs=3):
 
 
 def gru_seq_bwd(dout, w_hh: List[torch.Tensor], coef, z, B, T, G, Hg, prec, slot=0, xcd_rot=0, an=None, want_dgi=False,
-                out=None, chunk=None, dg_slabs=3, wide=False):
+                out=None, chunk=None, dg_slabs=3, wide=False, zeroed=False):
     """dout [B,T,H] -> dh [B,T,H] (total gradient reaching every h_t).  want_dgi (CRUSE_PREC_BF16, with the a_n rows):
     -> (dh, dgi) with dgi = dh * (c_r, c_z, a_n) in bf16 written by the recurrence itself (cruse_gru_seq_bwd_on).
     chunk = (t0, n): only frames [t0, t0+n), into out = dh (or (dh, dgi)); chunks are run from the LAST to the first, and
@@ -557,7 +575,7 @@ def gru_seq_bwd(dout, w_hh: List[torch.Tensor], coef, z, B, T, G, Hg, prec, slot
     check(lib.cruse_gru_seq_bwd_ex(_off(dout, t0 * H), ctypes.cast(wa, ctypes.c_void_p), _off(coef, t0 * 3 * H), _off(z, t0 * H),
                                    _off(dh, t0 * H), _off(an, t0 * H) if want_dgi else None,
                                    None if dgi is None else _off(dgi, t0 * dg_slabs * H), dg_slabs, carry, B, steps, T, G, Hg, prec_code(prec),
-                                   16 if wide else 0, panels, status, xcd_rot, _stream()))
+                                   16 if wide else 0, panels, 1 if zeroed else 0, status, xcd_rot, _stream()))
     return (dh, dgi) if want_dgi else dh
 
 

@@ -330,6 +330,9 @@ int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh, const void
  *            dg_slabs: 3 = dgi rows [G][3][Hg] (r, z, n_i); 4 = [G][4][Hg] with slab 3 = dh * c_n, the n gate of
  *            dgh = dh * (c_r, c_z, c_n) (reduce-scatter kernel): one row-major tensor that is the A operand of
  *            dX = dgi W_ih (K = 3*Hg of every 4*Hg) and of both weight-gradient products of cruse_gemm_bf16_tn.
+ *   panels_zeroed: the caller has cleared the panel scratch (cruse_gru_ws_bytes() - 256 bytes at `panels`) since its last use, on
+ *            this stream or ordered before it; 0: the call clears it itself (one memset launch in front of the recurrence).  A
+ *            training step clears the scratches of its four recurrences with one launch at its top.
  *   gi_bf16 (forward): gi points at bf16 rows [.., G*3*Hg] (cruse_gemm_bf16_nt_obf16) instead of f32 ones; CRUSE_PREC_BF16 only.
  *            The values are widened on load; everything else is unchanged.
  *   chain_clips: clips served by one team of Hg/32 workgroups.  0 = the library's plan: chains of 8 while the batch's chains fit
@@ -341,10 +344,11 @@ int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh, const void
 int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, const float* const* b_hh,
                          float* h, void* coef, float* an, float* z, const float* h0, long long h0_bstride,
                          int B, int T, int TS, int G, int Hg, int prec, int chain_clips, int gi_bf16, void* panels,
-                         unsigned* status, int xcd_rot, void* stream);
+                         int panels_zeroed, unsigned* status, int xcd_rot, void* stream);
 int cruse_gru_seq_bwd_ex(const float* dout, const float* const* w_hh, const void* coef, const float* z,
                          float* dh, const float* an, void* dgi, int dg_slabs, int carry, int B, int T, int TS, int G,
-                         int Hg, int prec, int chain_clips, void* panels, unsigned* status, int xcd_rot, void* stream);
+                         int Hg, int prec, int chain_clips, void* panels, int panels_zeroed, unsigned* status, int xcd_rot,
+                         void* stream);
 /* dgi = dh*(c_r,c_z,a_n) (gradient wrt gi), dgh = dh*(c_r,c_z,c_n) (gradient wrt W_hh h + b_hh), both
  * [rows,G,3*Hg]; dW_ih, dW_hh, dX and the bias gradients follow from cruse_gemm / cruse_col_sum. */
 int cruse_gru_gate_grads(const float* dh, const void* coef, const float* an, float* dgi, float* dgh,
