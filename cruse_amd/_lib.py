@@ -51,6 +51,8 @@ SIGNATURES = {
     "cruse_ln_bwd": ("pppppqiipppp", "i"),
     "cruse_gemm": ("iiiiipipipipiiiip", "i"),
     "cruse_gemm_bf16_nt": ("iiipqqpqqpqpiip", "i"),
+    "cruse_gemm_bf16_slab_bytes": ("iii", "z"),
+    "cruse_gemm_bf16_nt_slabs": ("iiipqqpqqpqipzp", "i"),
     "cruse_gemm_bf16_nt_obf16": ("iiippqqppqqpqpp", "i"),
     "cruse_gemm_bf16_nt_seg": ("iiippqppqqpqpiiqqp", "i"),
     "cruse_gemm_bf16_tn": ("iiqpqpqiipqip", "i"),

@@ -33,6 +33,7 @@ struct GbArgs {
     int accumulate, splitk, kt_chunk;
     int tiles_m, tiles_n, nunits, inner;
     int xcdk;                                // split-K with the k-slices PINNED to XCDs (see the kernel's tile order)
+    long long slab;                          // MODE 4: elements between the partial-sum slabs of consecutive k-slices
     // ROW SEGMENTS on the M side: logical row m of A and C is physical row (m / seg_len) * seg_stride + seg_off + m % seg_len --
     // frames [seg_off, seg_off + seg_len) of every clip of a [B, T = seg_stride] tensor, i.e. a TIME CHUNK of the batch
     // (the gate projections of one chunk run beside the recurrence of the previous one).  seg_len == 0: identity.
@@ -45,7 +46,9 @@ __device__ __forceinline__ long long seg_row(const GbArgs& g, int m) {
     return (long long)q * g.seg_stride + g.seg_off + (m - q * g.seg_len);
 }
 
-// MODE: C update -- 0 store, 1 read-add-store, 2 atomic add (split-K), 3 store as bf16 (C is then a bf16 tensor, ldc in its elements).
+// MODE: C update -- 0 store, 1 read-add-store, 2 atomic add (split-K), 3 store as bf16 (C is then a bf16 tensor, ldc in its elements),
+// 4 split-K with every k-slice STORING its partial sums to its own slab C + tz * slab (summed by gemm_slab_reduce_kernel): the
+// f32 atomics of MODE 2 from the 8 XCDs meet at the memory side -- 9.8 M of them per weight-gradient product, 0.14 ms per step.
 // NST: LDS stages.  2 = one k-tile of prefetch, two blocks per CU (the short-K products, whose epilogues then
 // overlap the other block's k-loop); 3 = two k-tiles in flight behind counted vmcnt waits and one raw barrier per
 // k-tile, one block per CU (the split-K weight gradients: hundreds of k-tiles streamed once, where the k-loop is
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_bf16_nt_kernel(con
                     }
                     continue;
                 }
-                float* c = g.C + seg_row(g, m) * g.ldc + nq;
+                float* c = g.C + (MODE == 4 ? (long long)tz * g.slab : 0ll) + seg_row(g, m) * g.ldc + nq;
                 if (MODE == 2) {
                     if (nq < g.N) atomicAdd(c, v.x);
                     if (nq + 1 < g.N) atomicAdd(c + 1, v.y);
@@ -487,12 +490,30 @@ __global__ __launch_bounds__(256) void ktile_bf16_kernel(const float* x, int row
     }
 }
 
+// C[m*ldc + n] += sum_z slabs[z*slab + m*N + n]: the k-slices' partial sums in a fixed order (run-to-run reproducible)
+__global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const float* slabs, int nz, long long slab, int M, int N, float* C,
+                                                               long long ldc) {
+    const int nq = N >> 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)M * nq) return;
+    const int m = (int)(i / nq), q = (int)(i - (long long)m * nq);
+    const float* p = slabs + (long long)m * N + 4 * q;
+    float4 s = *reinterpret_cast<const float4*>(p);
+    for (int z = 1; z < nz; ++z) {
+        const float4 v = *reinterpret_cast<const float4*>(p + (long long)z * slab);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    float* c = C + (long long)m * ldc + 4 * q;
+    c[0] += s.x; c[1] += s.y; c[2] += s.z; c[3] += s.w;
+}
+
 }  // namespace
 
 static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, long long lda, long long a_kstride,
                           const void* B, const void* B_lo, long long ldb, long long b_kstride,
                           float* C, long long ldc, const float* bias, int accumulate, int splitk, void* stream,
-                          int seg_len = 0, long long seg_stride = 0, long long seg_off = 0, bool c_bf16 = false) {
+                          int seg_len = 0, long long seg_stride = 0, long long seg_off = 0, bool c_bf16 = false,
+                          float* slabs = nullptr, size_t slab_bytes = 0) {
     CRUSE_REQUIRE(!c_bf16 || (!accumulate && splitk == 1), CRUSE_E_SHAPE, "gemm_bf16_nt: a bf16 result is stored, not accumulated");
     CRUSE_REQUIRE(seg_len >= 0 && (seg_len == 0 || (seg_stride >= seg_len && seg_off >= 0 && M % seg_len == 0 && a_kstride == BK)),
                   CRUSE_E_SHAPE, "gemm_bf16_nt: bad row segments (len %d stride %lld off %lld, M %d; row-major A only)", seg_len,
@@ -521,6 +542,17 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
     g.seg_len = seg_len; g.seg_stride = seg_stride; g.seg_off = seg_off;
     g.tiles_m = cdiv(M, BM); g.tiles_n = cdiv(N, BN);
     g.xcdk = (xcdk && splitk > 1) ? 1 : 0;
+    g.slab = 0;
+    const bool use_slabs = slabs != nullptr && splitk > 1;
+    float* const c_final = C;
+    const long long ldc_final = ldc;
+    if (use_slabs) {                           // partial sums [slice][M][N] in the caller's scratch, then one ordered sum into C
+        CRUSE_REQUIRE(N % 4 == 0 && ((uintptr_t)slabs % 16) == 0 && seg_len == 0, CRUSE_E_ALIGN, "gemm_bf16_nt: slab form needs N %% 4 == 0");
+        CRUSE_REQUIRE((size_t)splitk * M * N * sizeof(float) <= slab_bytes, CRUSE_E_SHAPE,
+                      "gemm_bf16_nt: %d slabs of %d x %d floats do not fit the %zu-byte scratch", splitk, M, N, slab_bytes);
+        g.C = slabs; g.ldc = N; g.slab = (long long)M * N; g.bias = nullptr;
+        CRUSE_REQUIRE(bias == nullptr, CRUSE_E_SHAPE, "gemm_bf16_nt: slab form has no bias");
+    }
     if (splitk > 1) { g.nunits = splitk * g.tiles_n; g.inner = g.tiles_m; }
     else { g.nunits = g.tiles_m; g.inner = g.tiles_n; }
     const long long nblk = g.xcdk ? (long long)cdiv(splitk, 8) * 8 * g.tiles_m * g.tiles_n
@@ -541,6 +573,15 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
         if (rc0) return rc0;                                                                                     \
         hipLaunchKernelGGL((gemm_bf16_nt_kernel<MODE, NST>), grid, dim3(256), lds, st, g);                       \
     } while (0)
+    if (use_slabs) {
+        if (deep) CRUSE_GB_LAUNCH(4, 3); else CRUSE_GB_LAUNCH(4, 2);
+        CRUSE_LAUNCH_CHECK("gemm_bf16_nt");
+        const long long n4 = (long long)M * (N / 4);
+        hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, slabs, splitk, g.slab, M, N,
+                           c_final, ldc_final);
+        CRUSE_LAUNCH_CHECK("gemm_slab_reduce");
+        return CRUSE_OK;
+    }
     if (deep) {
         if (c_bf16) CRUSE_GB_LAUNCH(3, 3);
         else if (splitk > 1) CRUSE_GB_LAUNCH(2, 3); else if (accumulate) CRUSE_GB_LAUNCH(1, 3); else CRUSE_GB_LAUNCH(0, 3);
@@ -559,6 +600,19 @@ extern "C" int cruse_gemm_bf16_nt(int M, int N, int K, const void* A, long long 
                                   void* stream) {
     return gemm_bf16_impl(M, N, K, A, nullptr, lda, a_kstride, B, nullptr, ldb, b_kstride, C, ldc, bias, accumulate, splitk,
                           stream);
+}
+
+extern "C" size_t cruse_gemm_bf16_slab_bytes(int M, int N, int splitk) {
+    const int z = splitk < 0 ? -splitk : splitk;
+    return (size_t)(z < 1 ? 1 : z) * M * N * sizeof(float);
+}
+
+extern "C" int cruse_gemm_bf16_nt_slabs(int M, int N, int K, const void* A, long long lda, long long a_kstride,
+                                        const void* B, long long ldb, long long b_kstride,
+                                        float* C, long long ldc, int splitk, void* scratch, size_t scratch_bytes, void* stream) {
+    CRUSE_REQUIRE(scratch != nullptr, CRUSE_E_SHAPE, "gemm_bf16_nt_slabs: scratch is NULL");
+    return gemm_bf16_impl(M, N, K, A, nullptr, lda, a_kstride, B, nullptr, ldb, b_kstride, C, ldc, nullptr, 1, splitk, stream, 0, 0, 0,
+                          false, reinterpret_cast<float*>(scratch), scratch_bytes);
 }
 
 extern "C" int cruse_gemm_bf16_nt_obf16(int M, int N, int K, const void* A_hi, const void* A_lo, long long lda, long long a_kstride,

@@ -621,11 +621,11 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
                 # dW_ih += (r, z, n_i)^T x ; dW_hh += (r, z)^T h_{t-1} and n_h^T h_{t-1}
                 a0, b0 = 4 * i * Hg * 64, i * Hg * 64
                 ops.gemm_bf16_nt(3 * Hg, Hg, ldT, dgT, a0, 64, inpT, b0, 64, G[nm + "weight_ih_l0"], 0, Hg,
-                                 accumulate=True, splitk=_splitk_bf16(3 * Hg, Hg, ldT), a_kstride=ka, b_kstride=kb)
+                                 accumulate=True, splitk=_splitk_bf16(3 * Hg, Hg, ldT), slabs=config.get().dw_slabs, a_kstride=ka, b_kstride=kb)
                 ops.gemm_bf16_nt(2 * Hg, Hg, ldT, dgT, a0, 64, hpT, b0, 64, G[nm + "weight_hh_l0"], 0, Hg,
-                                 accumulate=True, splitk=_splitk_bf16(2 * Hg, Hg, ldT), a_kstride=ka, b_kstride=kb)
+                                 accumulate=True, splitk=_splitk_bf16(2 * Hg, Hg, ldT), slabs=config.get().dw_slabs, a_kstride=ka, b_kstride=kb)
                 ops.gemm_bf16_nt(Hg, Hg, ldT, dgT, a0 + 3 * Hg * 64, 64, hpT, b0, 64, G[nm + "weight_hh_l0"],
-                                 2 * Hg * Hg, Hg, accumulate=True, splitk=_splitk_bf16(Hg, Hg, ldT), a_kstride=ka,
+                                 2 * Hg * Hg, Hg, accumulate=True, splitk=_splitk_bf16(Hg, Hg, ldT), slabs=config.get().dw_slabs, a_kstride=ka,
                                  b_kstride=kb)
 
         dinp, acc_dx = dinp_buffer(dout_h, need_dinp, last)

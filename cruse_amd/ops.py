@@ -367,9 +367,19 @@ def gemm(transA, transB, M, N, K, A, a_off, lda, Bm, b_off, ldb, C, c_off, ldc, 
 
 
 def gemm_bf16_nt(M, N, K, A, a_off, lda, Bm, b_off, ldb, C, c_off, ldc, bias=None, accumulate=False, splitk=1,
-                 a_kstride=64, b_kstride=64):
+                 a_kstride=64, b_kstride=64, slabs=False):
     """C[M,N] (+)= A[M,K] . B[N,K]^T on bf16 operands (element offsets into the tensors' storage).
-    *_kstride == 64: row-major operand; larger: the K-tiled time-major layout (lda == 64), see cruse_hip.h."""
+    *_kstride == 64: row-major operand; larger: the K-tiled time-major layout (lda == 64), see cruse_hip.h.
+    slabs (split-K, accumulate): the k-slices store partial sums to a per-stream scratch that one kernel adds to C in slice order
+    -- no atomics (cruse_gemm_bf16_nt_slabs)."""
+    if slabs and accumulate and bias is None and abs(splitk) > 1 and N % 4 == 0 and C.dtype == torch.float32:
+        if A.dtype != torch.bfloat16 or Bm.dtype != torch.bfloat16:
+            raise RuntimeError("gemm_bf16_nt needs bf16 operands")
+        nbytes = lib.cruse_gemm_bf16_slab_bytes(M, N, splitk)
+        ws = _ws(("gemm_slabs", _stream()), nbytes, C.device)
+        check(lib.cruse_gemm_bf16_nt_slabs(M, N, K, A.data_ptr() + 2 * a_off, lda, a_kstride, Bm.data_ptr() + 2 * b_off, ldb, b_kstride,
+                                           C.data_ptr() + 4 * c_off, ldc, splitk, _p(ws), ws.numel(), _stream()))
+        return
     if A.dtype != torch.bfloat16 or Bm.dtype != torch.bfloat16 or C.dtype not in (torch.float32, torch.bfloat16):
         raise RuntimeError("gemm_bf16_nt needs bf16 operands and an f32 (or stored-as-bf16) result")
     if C.dtype == torch.bfloat16:               # result rounded to bf16 on store (cruse_gemm_bf16_nt_obf16): no accumulate / split-K

@@ -238,6 +238,15 @@ int cruse_gemm(int transA, int transB, int M, int N, int K,
 int cruse_gemm_bf16_nt(int M, int N, int K, const void* A, long long lda, long long a_kstride,
                        const void* B, long long ldb, long long b_kstride,
                        float* C, long long ldc, const float* bias, int accumulate, int splitk, void* stream);
+/* The split-K weight-gradient form without atomics: C[M,N] += A . B^T with |splitk| k-slices (splitk < -1: pinned to XCDs as
+ * above), every slice STORING its partial sums to its own [M][N] slab of `scratch` (cruse_gemm_bf16_slab_bytes(M, N, splitk)
+ * bytes, 16-byte aligned) and one kernel adding the slabs to C in slice order.  The f32 atomics of the splitk form from the 8 XCDs
+ * meet at the memory side (9.8 M per gate weight gradient: 0.14 ms of the training step), and their order made dW differ from run
+ * to run in the last bits; this form is reproducible.  N % 4 == 0. */
+size_t cruse_gemm_bf16_slab_bytes(int M, int N, int splitk);
+int cruse_gemm_bf16_nt_slabs(int M, int N, int K, const void* A, long long lda, long long a_kstride,
+                             const void* B, long long ldb, long long b_kstride,
+                             float* C, long long ldc, int splitk, void* scratch, size_t scratch_bytes, void* stream);
 /* The same product -- or, with low planes (A_lo nullable, B_lo nullable: plain bf16), the split-bf16 form of
  * cruse_gemm_bf16x3_nt -- with the result STORED AS bf16 (C bf16 [M, ldc]; f32 accumulation, bias added in f32 before the one
  * rounding; no accumulate, no split-K): gi = x W_ih^T + b_ih as bf16 rows for cruse_gru_seq_fwd_ex(gi_bf16 = 1) -- half the bytes

@@ -722,6 +722,27 @@ def test_gemm_bf16_result_stored_as_bf16(ops, M, N, K, x3):
         ops.gemm_bf16_nt(M, N, K, A_hi, 0, K, B_hi, 0, K, Cb, 0, N, accumulate=True)
 
 
+@pytest.mark.parametrize("M,N,K,splitk", [(1920, 640, 25664, -8), (640, 640, 25664, -8), (200, 96, 4096, 6), (130, 100, 1024, -3)])
+def test_gemm_split_k_slabs_match_atomics_and_are_reproducible(ops, M, N, K, splitk):
+    """cruse_gemm_bf16_nt_slabs: the k-slices' partial sums go to slabs that one kernel adds to C in slice order -- the same sums as
+    the atomic split-K form (up to the order of the f32 additions), on top of what C held, bit-identical from run to run; k-slices
+    pinned to XCDs and dealt round-robin, ragged tiles."""
+    torch.manual_seed(M + K)
+    A = torch.randn(M, K).cuda().to(torch.bfloat16); Bm = torch.randn(N, K).cuda().to(torch.bfloat16)
+    base = torch.randn(M, N).cuda()
+    ref = base.clone()
+    ops.gemm_bf16_nt(M, N, K, A, 0, K, Bm, 0, K, ref, 0, N, accumulate=True, splitk=splitk)
+    outs = []
+    for _ in range(3):
+        c = base.clone()
+        ops.gemm_bf16_nt(M, N, K, A, 0, K, Bm, 0, K, c, 0, N, accumulate=True, splitk=splitk, slabs=True)
+        outs.append(c)
+    assert rel_l2(outs[0], ref) < 2e-6
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    exact = base.double() + A.double() @ Bm.double().t()
+    assert rel_l2(outs[0], exact) < 2e-6
+
+
 def test_gru_wide_chains_at_the_bench_length(ops):
     """T = 401, B = 64, Hg = 640: the wide-chain forward launch (4 chains of 16 on 80 CUs) against the lean one (8 chains of 8 on
     160) over the whole sequence -- 401 dependent hand-offs per chain -- bit for bit; two wide launches side by side on the two
