@@ -924,14 +924,6 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
     cut = max(L // 2, 1)                          # levels L..cut+1, [bucket 1 final], levels cut..1
     # ---- encoder levels L..1: de_k already holds the skip path ------------------------------
     de_sums = None
-    # The encoder's weight-gradient leaves go to the side stream in ONE batch, after the dy of the last side-stream level: the side
-    # queue is still busy with the layer-1 weight-gradient GEMMs until then (tools/rocpd_chain.py), and every hand-over costs the
-    # main stream an event record -- a ~6 us bubble in front of its next kernel.  (Bucketed data-parallel step: level by level, a
-    # segment boundary must find every leaf of its bucket issued.)
-    inline_k = lambda k_: (k_ == 1 and _INLINE & 8) or (k_ == 2 and _INLINE & 16)
-    side_levels = [k_ for k_ in range(1, L + 1) if not inline_k(k_)]
-    batch_from = min(side_levels) if (side_levels and boundary is None and SIDE.enabled) else None
-    pending, pending_keep = [], []
     for k in range(L, 0, -1):
         mean, rstd = stats[k]
         dy = ops.bn_act_bwd(de, ys[k], mean, rstd, P[f"bn{k}.weight"], P[f"bn{k}.bias"], rows, ch[k], Fk[k], True,
@@ -941,15 +933,10 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
             ops.conv_wgrad(dy, es[k - 1], G[f"conv{k}.weight"], B, T, ch[k], Fk[k], ch[k - 1], Fk[k - 1], KT=2, S=2, pad=1, prec=prec)
         # the optimizer step waits for the side queue, not for the main stream: the LAST levels' weight gradients run on
         # the main stream itself (_INLINE bits 3, 4: level 1, level 2), beside what is still queued on the side
-        if inline_k(k):
+        if (k == 1 and _INLINE & 8) or (k == 2 and _INLINE & 16):
             leaf_enc()
-        elif batch_from is None:
-            SIDE.run(leaf_enc, dy, lane=0)
         else:
-            pending.append(leaf_enc); pending_keep.append(dy)
-            if k == batch_from:
-                SIDE.run(lambda fs=tuple(pending): [f() for f in fs], *pending_keep, lane=0)
-                pending, pending_keep = [], []
+            SIDE.run(leaf_enc, dy, lane=0)
         if k > 1:
             de, de_sums = split(ops.conv_scatter2(dy, P[f"conv{k}.weight"], None, B, T, ch[k], Fk[k], ch[k - 1], KT=2, pad=1,
                                                   out=de_pre[k - 1], accum=True, prec=dprec, bn_bwd=bn_of(k - 1, False)))
