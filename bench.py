@@ -251,16 +251,24 @@ def pmc_traffic():
     if not os.path.exists(PMC_FILE):
         return out
     import csv
+    import re
     acc = {}
+    steps = float(PMC_STEPS)
     with open(PMC_FILE) as f:
-        rows = csv.DictReader(l for l in f if not l.startswith("#"))
+        lines = f.readlines()
+    for l in lines:                              # "# ... launches = over the N steps of the run" (tools/pmc_traffic.py)
+        m = re.search(r"over the (\d+) steps", l) if l.startswith("#") else None
+        if m:
+            steps = float(m.group(1))
+    if True:
+        rows = csv.DictReader(l for l in lines if not l.startswith("#"))
         for r in rows:
             n, b = int(r["launches"]), float(r["hbm_bytes_per_launch_corrected"])
             a = acc.setdefault(r["bench_family"], [0, 0.0])
             a[0] += n; a[1] += n * b
     for fam, (n, tot) in acc.items():
         out[fam] = tot / max(n, 1)
-    out["__step_total__"] = sum(tot for _, tot in acc.values()) / float(PMC_STEPS)
+    out["__step_total__"] = sum(tot for _, tot in acc.values()) / steps
     out["conv_gather"] = out["conv_scatter2"] = out.get("conv", 0.0) or None
     return out
 
