@@ -628,6 +628,11 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
                                  2 * Hg * Hg, Hg, accumulate=True, splitk=_splitk_bf16(Hg, Hg, ldT), slabs=config.get().dw_slabs, a_kstride=ka,
                                  b_kstride=kb)
 
+        # The last layer's weight-gradient leaf goes to the side stream BEFORE the dX GEMM is issued: its event then follows the
+        # gate-gradient pass, not the GEMM, and the three dW products start ~150 us earlier (5.40 vs 5.46 ms).
+        early_leaf = last and not defer_last
+        if early_leaf:
+            SIDE.run(weight_grads, dgT, h, inp, inpT, hpT, dh, lane=2)
         dinp, acc_dx = dinp_buffer(dout_h, need_dinp, last)
         if need_dinp:
             for i, nm in enumerate(names):
@@ -636,7 +641,9 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
                     w_t = ops.transpose_bf16(P[nm + "weight_ih_l0"], 3 * Hg, Hg)      # K-tiled [ceil(3*Hg/64), Hg, 64]
                 ops.gemm_bf16_nt(rows, Hg, w_t.shape[0] * 64, dgi, i * 3 * Hg, 3 * H, w_t, 0, 64, dinp, i * Hg, H,
                                  accumulate=acc_dx, b_kstride=Hg * 64)
-        if last and defer_last:
+        if early_leaf:
+            pass
+        elif last and defer_last:
             SIDE.defer(weight_grads, dgT, h, inp, inpT, hpT, dh, kind=0xffff, lane=2)
         elif last:
             SIDE.run(weight_grads, dgT, h, inp, inpT, hpT, dh, lane=2)
