@@ -34,8 +34,10 @@ class _CastFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, to_f16):
         x = x.contiguous()
-        ctx.to_f16 = to_f16
         want = torch.float16 if to_f16 else torch.float32
+        # the gradient goes back in the INPUT's storage type: a cast that was a no-op forward (an f32 model calling
+        # to_f32) must be a no-op backward too -- rounding an f32 gradient through f16 flushes 1e-9 to 0
+        ctx.src_dtype = x.dtype
         if x.dtype == want:
             return x
         out = torch.empty_like(x, dtype=want)
@@ -44,7 +46,9 @@ class _CastFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return _CastFn.apply(g, not ctx.to_f16), None
+        if g.dtype == ctx.src_dtype:
+            return g, None
+        return _CastFn.apply(g, ctx.src_dtype == torch.float16), None
 
 
 def to_f16(x):

@@ -493,6 +493,39 @@ def test_mtfaa_stft_and_blocks_vs_reference(golden):
     assert out.shape == xin.shape and torch.isfinite(out).all()
 
 
+def test_f32_casts_pass_tiny_gradients_through_unchanged(golden):
+    """to_f32 on an already-f32 tensor is a forward no-op and must be a backward no-op too -- the
+    gradient used to be rounded through f16 (1e-9 -> 0, 1e6 -> inf).  mtfaa.py:123-138 (ComplexLinearProjection) in an
+    f32 model with a mean-normalised loss has gradients of 1e-7 and below."""
+    from cruse_amd.nn_generic import to_f16, to_f32
+    x = torch.randn(4096, device="cuda", requires_grad=True)
+    g = torch.tensor([1e-9, 1e6, 1.2345678, -3e-8], device="cuda").repeat(1024)
+    to_f32(x).backward(g)
+    assert torch.equal(x.grad, g)                                      # bit-exact: no rounding at all
+    h = x.detach().half().requires_grad_(True)
+    to_f16(h).backward(g.half())
+    assert h.grad.dtype == torch.float16 and torch.equal(h.grad, g.half())
+    # a real cast: f32 -> f16 forward, the f16 gradient comes back widened to f32 (exactly)
+    x2 = x.detach().clone().requires_grad_(True)
+    y = to_f16(x2)
+    assert y.dtype == torch.float16
+    y.backward(torch.full_like(y, 0.5))
+    assert x2.grad.dtype == torch.float32 and torch.equal(x2.grad, torch.full_like(x2, 0.5))
+    # through the module the advice names, with a loss scaled so that every gradient is ~1e-7
+    from model import mtfaa as P
+    from oracle import cruse_oracle_ext as X
+    o = X.PhaseEncoder(4, 2)
+    p = _load_like(P.PhaseEncoder(4, 2), o, scale=3.0)
+    g14 = golden("g14_mtfaa.npz")
+    cs = [torch.from_numpy(g14["pe/x0"]), torch.from_numpy(g14["pe/x1"])]
+    scale = 1e-7
+    (o([c.clone() for c in cs]).sum() * scale).backward()
+    (p([c.cuda() for c in cs]).sum() * scale).backward()
+    for (n, a), (_, b) in zip(p.named_parameters(), o.named_parameters()):
+        assert a.grad is not None and float(b.grad.abs().max()) < 1e-3
+        assert rel_l2(a.grad, b.grad) < 1e-3, n
+
+
 F16_FWD_TOL = 2e-3        # f16-storage run vs the F32 oracle, forward (measured 4.8e-4 / 7.8e-4)
 F16_EMU_TOL = 1e-3        # f16-storage run vs the oracle's f16-storage model (oracle_ext.emulate_f16_storage), forward (1.0e-4 / 4.5e-4)
 F16_GRAD_EMU_TOL = 1.5e-2 # ... every parameter gradient as ONE vector (measured 2.6e-3 / 8.5e-3)

@@ -3,8 +3,11 @@ import torch
 
 def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
     """global relative L2 error ||a-b|| / ||b|| (SURVEY 8d parity gate)."""
-    a = a.detach().double().cpu().flatten()
-    b = b.detach().double().cpu().flatten()
+    a, b = a.detach().cpu(), b.detach().cpu()
+    if a.is_complex() or b.is_complex():                      # complex spectra: as (re, im) pairs
+        a, b = torch.view_as_real(a.resolve_conj().to(torch.complex128)), torch.view_as_real(b.resolve_conj().to(torch.complex128))
+    a = a.double().flatten()
+    b = b.double().flatten()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
