@@ -1,0 +1,692 @@
+// Persistent grouped-GRU recurrence, round-4 kernels for the bf16 mode (nn.GRU forward / backward at
+// model/cruse_net.py:23-31,44,50): chains of 8 clips, teams of Hg/32 workgroups, register-resident W_hh -- the design of
+// gru.hip -- with two changes to the per-step chain:
+//
+//   1. TAG-FREE HAND-OFF.  The granules of gru.hip carry {epoch u32, 2 x bf16}: half of every published and swept byte is
+//      a tag.  Here the tag rides INSIDE the payload: bit 14 of a bf16 (the top exponent bit) is 0 for every |v| < 2, so it
+//      is free to carry one bit of epoch -- forward the hidden state is a convex combination of tanh values and the previous
+//      state, |h| < 1 always (h0 = 0; a caller-supplied h0 keeps the tagged kernels); backward the partial sums are exchanged
+//      scaled by 2^-64 (exact), so anything below 2^65 qualifies and anything above 2^-62 survives.  A slot of parity p is
+//      written at epochs p+1, p+3, ...: one alternating bit tells "this epoch" from "two epochs ago", bit(e) = ((e+1)>>1)&1,
+//      and bit(first epoch) = 1 differs from the zeroed scratch.  EVERY 2-byte value carries its own tag, so no access wider
+//      than a bf16 has to be single-copy atomic (gru.hip relies on 8-byte halves).  Sweep and publish bytes halve: forward
+//      10 KB per workgroup and step instead of 20 (3 x 16-byte loads per thread instead of 5), backward 10 KB of publishes
+//      in 3 store instructions per wave instead of 20 KB in 5.
+//   2. NO K SPLIT in the forward step.  gru_fwd_lean splits K over the four waves and reduces through LDS (six tile
+//      writes per wave, a barrier, twelve reads per thread).  Here wave w owns units [8w, 8w+8) of the workgroup's 32 and
+//      walks the whole K itself: two 16-row tiles -- rows (r, r, z, z) and (n, n, 0, 0) per unit pair, so that a lane's
+//      accumulators hold all three gates of its (clip, unit pair) -- NK = Hg/32 k-steps, 2 NK MFMAs per wave and step (40 at
+//      Hg = 640 against 30), 8 NK weight registers per lane (160).  The accumulators ARE the gate pre-activations (bias
+//      preloaded); one DPP row rotate hands the second unit of a pair to the idle column lane (the MFMA leaves clips in 8
+//      of its 16 columns) and every lane runs one gate evaluation.  One barrier per step (the LDS image of the panel is
+//      double-buffered by step parity).
+//
+// The helper wave (gi ring, saves) is the one of gru_fwd_lean; the loader wave that of gru_bwd_rs.
+#include "gru_common.h"
+
+namespace {
+
+using namespace cruse_gru;
+
+// lanes 8..15 of every 16-lane row take `src` of lane - 8, lanes 0..7 keep `old` (v_mov_b32_dpp row_ror:8, bank_mask 0xC)
+__device__ __forceinline__ float take_hi8(float old, float src) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp((int)__float_as_uint(old), (int)__float_as_uint(src), 0x128, 0xf, 0xC, false));
+}
+
+// ---------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------
+// NK = Hg / 32 k-steps; NS = ceil(Hg / 256) sweep slots per compute thread; WLO: W_hh as hi + lo bf16 planes (Hg <= 320)
+template <int NK, int NS, bool WLO, bool TIMED = false>
+__global__ __launch_bounds__(320) void gru_fwd_tf_kernel(GruArgs a) {
+    static_assert(!WLO || NK <= 10, "two weight planes fit 256 registers up to Hg = 320");
+    // Row stride of the LDS image: a ds_read_b128 is served in groups of 16 lanes over 64 banks, and a group holds the fragments
+    // of all 8 clips for two neighbouring 16-byte k-chunks (lane >> 4 = q, q + 1): bank quad = (clip * R + q + 4 ks) mod 16 with R the
+    // row stride in 16-byte units -- R = 2 (mod 16) makes the 16 lanes of a group cover all 64 banks (with R = 1 (mod 16), Hg + 8,
+    // clip c chunk q + 1 collided with clip c + 1 chunk q: 2-way conflicts on every fragment read, 1435 instead of ~800 cycles)
+    constexpr int Hg = NK * 32, LD = 8 * (((NK * 4 - 2 + 15) / 16) * 16 + 2);
+    static_assert(LD >= Hg && (LD / 8) % 16 == 2, "LDS row stride");
+    unsigned long long tph[5] = {0, 0, 0, 0, 0}, tq0 = 0, tq1 = 0;
+    (void)tph; (void)tq0; (void)tq1;
+    __shared__ __attribute__((aligned(16))) __bf16 hB[2][8 * LD];                 // B operand (h_{t-1}) by step parity
+    // clip strides of 8 (mod 32) floats: a compute wave's 32-lane half touches 8 clips x 4 units per access -- with strides of
+    // 96 / 32 floats all 8 clips of a unit fell on ONE bank (8-way conflicts on the 3 gi reads and the 6 saves of every step,
+    // ~450 cycles per step that no phase stamp showed)
+    constexpr int GS = 104, SS = 40;
+    __shared__ __attribute__((aligned(16))) float gi_r[4][8][GS];                 // gi ring: slot = t & 3, [clip][gate*32 + unit]
+    __shared__ __attribute__((aligned(16))) float sv_l[2][6][8][SS];              // saves of step t in parity t & 1
+    const int H = a.G * Hg;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int chain, part;
+    if (!claim_chain(a, a.P, chain, part)) return;
+    const int grp = chain % a.G, bgi = a.bg_off + chain / a.G;
+    const int b0 = bgi * 8, nb = min(8, a.B - b0);
+    const int u0 = part * U;
+    const float* W = a.p.w_hh[grp];
+    const float* bh = a.p.b_hh[grp];
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.xg, 0, a.xg_bytes, 0x00020000);
+    constexpr unsigned panel_bytes = (unsigned)(8 * Hg) * 2u;          // [clip][Hg] bf16, the tag inside
+    const unsigned cbase = (unsigned)chain * 2u * panel_bytes;
+
+    const unsigned frame_bytes = (unsigned)H * 4u, grow_bytes = (unsigned)(a.G * 3 * Hg) * 4u, crow_bytes = grow_bytes >> 1;
+    const long long nrow = (long long)(a.B - 1) * a.TS + a.T;           // rows reachable from the (advanced) base pointers
+    const unsigned tot_h = (unsigned)min(nrow * H * 4, 0xffffffffll);
+    const unsigned tot_g = (unsigned)min(nrow * a.G * 3 * Hg * 4, 0xffffffffll);
+    const __amdgpu_buffer_rsrc_t rs_gi = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gi), 0, tot_g, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(a.h, 0, tot_h, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_an = __builtin_amdgcn_make_buffer_rsrc(a.an, 0, a.an ? tot_h : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(a.z, 0, a.z ? tot_h : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_cf = __builtin_amdgcn_make_buffer_rsrc(a.coef, 0, a.coef ? tot_g >> 1 : 0u, 0x00020000);
+    const bool save = a.coef != nullptr;
+
+    if (wv == 4) {
+        // ---- helper wave: gi rows into the ring four steps ahead, the saves of step t - 1 to HBM during step t ------------
+        unsigned gv[3], gdst[3];
+#pragma unroll
+        for (int i3 = 0; i3 < 3; ++i3) {
+            const int idx = lane + 64 * i3, cl = idx / 24, rem = idx % 24, gate = rem >> 3, chk = rem & 7;
+            gv[i3] = (unsigned)((((long long)(b0 + (cl < nb ? cl : 0)) * a.TS * a.G + grp) * 3 * Hg + gate * Hg + u0 + 4 * chk) * 4);
+            gdst[i3] = (unsigned)(cl * GS + gate * 32 + chk * 4);
+        }
+        const int lc = lane >> 3, lq = lane & 7;
+        const bool rok = lc < nb;
+        const unsigned hv = (unsigned)(((long long)(b0 + (rok ? lc : 0)) * a.TS * H + grp * Hg + u0 + 4 * lq) * 4);
+        unsigned cv[2], csrc[2];
+        bool cok[2];
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+            const int idx = min(lane + 64 * i2, 95), cl = idx / 12, rem = idx % 12, gate = rem >> 2, chk = rem & 3;
+            cok[i2] = lane + 64 * i2 < 96 && cl < nb;
+            cv[i2] = (unsigned)((((long long)(b0 + (cl < nb ? cl : 0)) * a.TS * a.G + grp) * 3 * Hg + gate * Hg + u0 + 8 * chk) * 2);
+            csrc[i2] = (unsigned)(((1 + gate) * 8 + cl) * SS + chk * 8);
+        }
+        struct GiSet { u32x4 v[3]; };
+        auto issue = [&](int t, GiSet& o) {
+            const unsigned so = (unsigned)min(t, a.T - 1) * grow_bytes;
+#pragma unroll
+            for (int i3 = 0; i3 < 3; ++i3) o.v[i3] = __builtin_amdgcn_raw_buffer_load_b128(rs_gi, gv[i3], so, 0);
+        };
+        auto put = [&](int t, const GiSet& o) {
+            float* d = &gi_r[t & 3][0][0];
+#pragma unroll
+            for (int i3 = 0; i3 < 3; ++i3) *reinterpret_cast<u32x4*>(d + gdst[i3]) = o.v[i3];
+        };
+        auto flush = [&](int t) {                       // saves of step t from parity t & 1
+            const float* sl = &sv_l[t & 1][0][0][0];
+            const unsigned so = (unsigned)t * frame_bytes, sc = (unsigned)t * crow_bytes;
+            if (rok) {
+                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(sl + (0 * 8 + lc) * SS + 4 * lq), rs_h, hv, so, 0);
+                if (save) {
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(sl + (4 * 8 + lc) * SS + 4 * lq), rs_an, hv, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(sl + (5 * 8 + lc) * SS + 4 * lq), rs_z, hv, so, 0);
+                }
+            }
+            if (save) {
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2) {
+                    if (cok[i2]) {
+                        const float4 p0 = *reinterpret_cast<const float4*>(sl + csrc[i2]);
+                        const float4 p1 = *reinterpret_cast<const float4*>(sl + csrc[i2] + 4);
+                        const u32x4 w = {pack2(p0.x, p0.y), pack2(p0.z, p0.w), pack2(p1.x, p1.y), pack2(p1.z, p1.w)};
+                        __builtin_amdgcn_raw_buffer_store_b128(w, rs_cf, cv[i2], sc, 0);
+                    }
+                }
+            }
+        };
+        GiSet s0, s1;
+        issue(0, s0); issue(1, s1);
+        put(0, s0); put(1, s1);
+        issue(2, s0); issue(3, s1);
+        if (a.dbg != 9) (void)team_shares_xcd(a.xid + (size_t)chain * 64, a.P, part, a.status, tid);   // mirrors the compute waves' barriers
+        __syncthreads();
+        // ONE barrier per step.  After the barrier of step t: the set for step t + 2 goes to its ring slot (the compute waves read
+        // it after the barrier of step t + 1), the set is re-issued for step t + 4, the saves of step t - 1 are in LDS.
+        for (int t = 0; t < a.T; t += 2) {
+            __syncthreads();
+            put(t + 2, s0); issue(t + 4, s0);
+            if (t > 0) flush(t - 1);
+            if (t + 1 >= a.T) break;
+            __syncthreads();
+            put(t + 3, s1); issue(t + 5, s1);
+            flush(t);
+        }
+        __syncthreads();                                // the last step's saves are in LDS
+        flush(a.T - 1);
+        return;
+    }
+
+    // lane = (column c = lane & 15, row group q = lane >> 4): clip c & 7, unit 8 wv + 2q + (c >> 3) of the workgroup's 32
+    const int c16 = lane & 15, q = lane >> 4;
+    const int clip = c16 & 7, uw = 8 * wv + 2 * q + (c16 >> 3);
+    const bool act = clip < nb;
+    const int clipc = act ? clip : 0;
+
+    // resident weight fragments.  A-operand row i = lane & 15 of tile A is gate (i >> 1) & 1 (r, z) of unit 8 wv + 2 (i >> 2) + (i & 1);
+    // of tile B gate n of the same unit for (i & 3) < 2, zero otherwise.  Element e of k-step ks: column ks*32 + q*8 + e.
+    bf16x8 wfA[NK], wfB[NK], wlA[WLO ? NK : 1], wlB[WLO ? NK : 1];
+    {
+        const int i = c16, un = 8 * wv + 2 * (i >> 2) + (i & 1);
+        const int rowA = ((i >> 1) & 1) * Hg + u0 + un, rowB = 2 * Hg + u0 + un;
+        const bool okB = (i & 3) < 2;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float wa = W[(long long)rowA * Hg + ks * 32 + q * 8 + e];
+                const float wb = okB ? W[(long long)rowB * Hg + ks * 32 + q * 8 + e] : 0.f;
+                wfA[ks][e] = (__bf16)wa; wfB[ks][e] = (__bf16)wb;
+                if constexpr (WLO) { wlA[ks][e] = (__bf16)(wa - (float)wfA[ks][e]); wlB[ks][e] = (__bf16)(wb - (float)wfB[ks][e]); }
+            }
+        }
+    }
+    // accumulator start values = b_hh of the rows this lane's accumulators hold: A (r, r', z, z'), B (n, n', -, -) of units 2q, 2q + 1
+    f32x4 biasA, biasB;
+    {
+        const int un = u0 + 8 * wv + 2 * q;
+        biasA = (f32x4){bh[un], bh[un + 1], bh[Hg + un], bh[Hg + un + 1]};
+        biasB = (f32x4){bh[2 * Hg + un], bh[2 * Hg + un + 1], 0.f, 0.f};
+    }
+
+    // sweep slots: 16-byte load e = tid + 256 j covers clip e / (Hg/8), units 8 (e % (Hg/8)) .. +7 (clamped for short chains and
+    // for the slots beyond the panel: the last valid load is then fetched and stored twice)
+    constexpr int per = Hg >> 3;
+    const int nload = nb * per;
+    unsigned sw_v[NS];
+    int sw_l[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int e = min(tid + 256 * j, nload - 1);
+        const int bl = e / per, v = 8 * (e - bl * per);
+        sw_v[j] = (unsigned)e * 16u;
+        sw_l[j] = bl * LD + v;
+    }
+    const unsigned pub_v = (unsigned)(clipc * Hg + u0 + 8 * wv + 2 * q) * 2u;
+    const bool pub_lane = act && c16 < 8;
+    const int fb_off = clip * LD + q * 8;                     // B fragment of k-step ks: + ks * 32 (columns 8..15 re-read clips 0..7)
+    float* const sl0 = &sv_l[0][0][clipc][uw];
+    const float* const gi0 = &gi_r[0][clipc][uw];
+
+    float hp = 0.f;
+    bool nowait = a.dbg >= 1 && a.dbg < 6;
+    const bool plain = a.dbg != 9 && team_shares_xcd(a.xid + (size_t)chain * 64, a.P, part, a.status, tid);
+    __syncthreads();                                           // ring slots 0 and 1 are filled
+
+    for (int t = 0; t < a.T; ++t) {
+        if constexpr (TIMED) tq0 = __builtin_amdgcn_s_memtime();
+        // gi of this step (ring slot t & 3, filled two steps ago)
+        float gic[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) gic[g] = gi0[(t & 3) * (8 * GS) + g * 32];
+        __bf16* const hb = hB[t & 1];
+        if (t > 0) {
+            const unsigned soff = cbase + (unsigned)((t - 1) & 1) * panel_bytes;
+            const unsigned flip = tag_bit((unsigned)t) ? 0xffffffffu : 0u;
+            u32x4 g[NS];
+            unsigned spins = 0;
+            for (int i = 0; i < a.poll_delay; ++i) __builtin_amdgcn_s_sleep(1);     // (see poll_delay)
+            for (;;) {
+#pragma unroll
+                for (int j = 0; j < NS; ++j) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, sw_v[j], soff, 16);
+                unsigned bad = 0u;
+#pragma unroll
+                for (int j = 0; j < NS; ++j) bad |= (g[j].x ^ flip) | (g[j].y ^ flip) | (g[j].z ^ flip) | (g[j].w ^ flip);
+                if (__all((bad & TAGM) == 0u || nowait)) break;
+                if (++spins >= SPIN_LIMIT) {
+                    if (lane == 0) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    nowait = true;
+                }
+                if constexpr (TIMED) tph[4] += 1;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[0] += tq1 - tq0; tq0 = tq1; }
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                const u32x4 w = {g[j].x & ~TAGM, g[j].y & ~TAGM, g[j].z & ~TAGM, g[j].w & ~TAGM};
+                *reinterpret_cast<u32x4*>(hb + sw_l[j]) = w;
+            }
+        }
+        __syncthreads();                                       // panel of step t complete (and the helper's ring / saves hand-over)
+        if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[1] += tq1 - tq0; tq0 = tq1; }
+        f32x4 aA = biasA, aB = biasB;
+        if (t > 0) {
+            f32x4 aA1 = (f32x4){0.f, 0.f, 0.f, 0.f}, aB1 = aA1;
+            // Fragment reads run PF k-steps ahead of their MFMAs; sched_barrier(0) after every k-step pins that order.  (Left to
+            // itself the scheduler keeps two fragment registers and issues each pair of reads right in front of its MFMAs: every
+            // second k-step exposed a full LDS round trip, 1370 cycles for the 40 MFMAs of Hg = 640 instead of ~700 -- s_memtime
+            // stamps, gru_dbg = 32; sched_group_barrier pipelines were followed for six k-steps and then abandoned.)
+            constexpr int PF = NK < 6 ? NK : 6;
+            bf16x8 fr[NK];
+#pragma unroll
+            for (int ks = 0; ks < PF; ++ks) fr[ks] = *reinterpret_cast<const bf16x8*>(hb + fb_off + ks * 32);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                if ((ks & 1) == 0) {
+                    aA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfA[ks], fr[ks], aA, 0, 0, 0);
+                    aB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfB[ks], fr[ks], aB, 0, 0, 0);
+                    if constexpr (WLO) {
+                        aA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlA[ks], fr[ks], aA, 0, 0, 0);
+                        aB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlB[ks], fr[ks], aB, 0, 0, 0);
+                    }
+                } else {
+                    aA1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfA[ks], fr[ks], aA1, 0, 0, 0);
+                    aB1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfB[ks], fr[ks], aB1, 0, 0, 0);
+                    if constexpr (WLO) {
+                        aA1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlA[ks], fr[ks], aA1, 0, 0, 0);
+                        aB1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlB[ks], fr[ks], aB1, 0, 0, 0);
+                    }
+                }
+                if (ks + PF < NK) fr[ks + PF] = *reinterpret_cast<const bf16x8*>(hb + fb_off + (ks + PF) * 32);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            aA += aA1; aB += aB1;
+        }
+        if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[2] += tq1 - tq0; tq0 = tq1; }
+        // gate pre-activations of this lane's (clip, unit): columns 0..7 unit 2q, columns 8..15 unit 2q + 1 of the same clip
+        const float ghr = take_hi8(aA[0], aA[1]);
+        const float ghz = take_hi8(aA[2], aA[3]);
+        const float ghn = take_hi8(aB[0], aB[1]);
+        const float r = lean_sigmoid(gic[0] + ghr);
+        const float z = lean_sigmoid(gic[1] + ghz);
+        const float n = lean_tanh(gic[2] + r * ghn);
+        const float h = (1.f - z) * n + z * hp;
+        {
+            const float hn = __uint_as_float(dpp_ror8(__float_as_uint(h)));       // unit 2q + 1 of the clip, from lane + 8
+            if (pub_lane) {
+                const unsigned w = with_tag(pack2(h, hn), tag_bit((unsigned)(t + 1)) ? TAGM : 0u);
+                const unsigned soff = cbase + (unsigned)(t & 1) * panel_bytes;
+                if (plain) __builtin_amdgcn_raw_buffer_store_b32(w, rs, pub_v, soff, 0);
+                else __builtin_amdgcn_raw_buffer_store_b32(w, rs, pub_v, soff, 16);
+            }
+        }
+        if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[3] += tq1 - tq0; tq0 = tq1; }
+        const float an = (1.f - z) * (1.f - n * n);
+        if (act) {                                             // saves into parity t & 1 (the helper reads them after the next barrier)
+            float* sl = sl0 + (t & 1) * (6 * 8 * SS);
+            sl[0 * 8 * SS] = h;
+            sl[1 * 8 * SS] = an * ghn * r * (1.f - r);
+            sl[2 * 8 * SS] = (hp - n) * z * (1.f - z);
+            sl[3 * 8 * SS] = an * r;
+            sl[4 * 8 * SS] = an;
+            sl[5 * 8 * SS] = z;
+        }
+        hp = h;
+    }
+    if constexpr (TIMED) {
+        if (tid == 0 && chain == 0 && part == 0) {
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.status) + 8;     // byte 64 of the status header
+            for (int i = 0; i < 5; ++i) dst[i] = tph[i];
+            dst[5] = (unsigned long long)a.T;
+        }
+    }
+    __syncthreads();                                           // hands the last step's saves to the helper wave
+}
+
+
+// ---------------------------------------------------------------------------------
+// backward: the reduce-scatter form of gru_bwd_rs (a workgroup contracts over the 96 gate rows it owns and publishes the
+// 8 x Hg partial sums; the consumer sums the P partials of its 32 units) on the tag-free hand-off.
+//   * partials travel as plain bf16, the epoch bit in bit 14, SCALED by 2^-64: the scale is folded into the operand panel
+//     (dh * 2^-64 * c, exact), so the MFMA results are the scaled partials and the consumer multiplies its sum by 2^64 once;
+//   * layout [consumer q][clip][producer p][32 units] bf16: a lane's sweep load is 16 bytes = 8 units of one producer, a quad
+//     reads the 64-byte row of one (clip, producer), the 8 lanes-quads of a clip read 512 contiguous bytes;
+//   * sweep thread = (clip, producer octant og, 16-byte chunk pp): NL = ceil(P/8) loads (3 at Hg = 640 instead of 5), eight
+//     unit sums per thread, then a REDUCE-SCATTER over the octants -- v_permlane32_swap / v_permlane16_swap (one swap + one add
+//     per kept value) and one DPP row rotate -- that leaves every thread with the sum of ONE unit: its own (clip, unit);
+//   * publish: two tile pairs (two consumers) per store instruction -- the second pair's values move to the idle column lanes
+//     (row_ror:8), v_permlane16_swap joins the unit quads of neighbouring row groups into 16-byte pieces -- ceil(NP/2) stores of
+//     64 x 16 bytes per wave and step instead of NP (3 instead of 5 at Hg = 640).
+// ---------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int P, bool TIMED = false>
+__global__ __launch_bounds__(320) void gru_bwd_tf_kernel(GruArgs a) {
+    constexpr int Hg = P * 32, NP = (P + 3) / 4, NT = 2 * NP, NTt = 2 * P, NL = (P + 7) / 8, K3 = 3 * Hg;
+    constexpr bool FULL = P % 4 == 0;
+    constexpr int KP = 96 + 8;
+    constexpr float SC = 5.421010862427522e-20f, ISC = 1.8446744073709552e19f;     // 2^-64, 2^64
+    unsigned long long tph[5] = {0, 0, 0, 0, 0}, tq0 = 0, tq1 = 0;
+    (void)tph; (void)tq0; (void)tq1;
+    __shared__ __attribute__((aligned(16))) __bf16 panel[2][16 * KP];
+    // (rows of 36 floats: a 32-lane half of a sweep wave holds 2 clips x 16 units -- 4 banks apart, no conflicts)
+    constexpr int RS = 36;
+    __shared__ __attribute__((aligned(16))) float op_d[4][8][RS], op_z[4][8][RS];       // ring slot = iteration & 3
+    __shared__ __attribute__((aligned(16))) __bf16 op_c[4][8][96];
+    __shared__ __attribute__((aligned(16))) float op_a[4][8][RS];                       // a_n rows (only when dgi is written)
+    __shared__ __attribute__((aligned(16))) float dh_l[2][8][RS];                       // dh of iteration k in parity k & 1
+    const int H = a.G * Hg;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int chain, part;
+    if (!claim_chain(a, P, chain, part)) return;
+    const int grp = chain % a.G, bgi = a.bg_off + chain / a.G;
+    const int b0 = bgi * 8, nb = min(8, a.B - b0);
+    const int u0 = part * U;
+    const float* W = a.p.w_hh[grp];
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.xg, 0, a.xg_bytes, 0x00020000);
+    constexpr unsigned cons_bytes = (unsigned)(8 * P * 64);         // [clip 8][producer P][32 units] bf16
+    constexpr unsigned panel_bytes = (unsigned)P * cons_bytes;      // one parity of one chain
+    const unsigned cbase = (unsigned)chain * 2u * panel_bytes;
+
+    for (int i = tid; i < 2 * 16 * KP; i += 320) panel[0][i] = (__bf16)0.f;
+
+    const unsigned frame_bytes = (unsigned)H * 4u, crow_bytes = (unsigned)(a.G * K3) * 2u;
+    const long long nrow = (long long)(a.B - 1) * a.TS + a.T;           // rows reachable from the (advanced) base pointers
+    const unsigned tot_f32 = (unsigned)min(nrow * H * 4, 0xffffffffll);
+    const unsigned tot_cf = (unsigned)min(nrow * a.G * K3 * 2, 0xffffffffll);
+    const __amdgpu_buffer_rsrc_t rs_dout = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dout), 0, tot_f32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.zs), 0, tot_f32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dh = __builtin_amdgcn_make_buffer_rsrc(a.dh, 0, tot_f32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_cf = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.coefs), 0, tot_cf, 0x00020000);
+    const bool nodata = a.dbg == 7 || a.dbg == 34;       // profiling: no operand streams
+
+    if (wv == 4) {
+        // ---- loader wave (as in gru_bwd_rs).  Iteration j needs dout_{T-1-j}, c_{T-1-j} and z_{T-j}; lane = (clip, 16-byte chunk).
+        const int lc = lane >> 3, lq = lane & 7;                                   // dout / z: 8 clips x 8 chunks of 4 floats
+        const unsigned dv = (unsigned)(((long long)(b0 + (lc < nb ? lc : 0)) * a.TS * H + grp * Hg + u0 + 4 * lq) * 4);
+        unsigned cv[2], cdst[2];
+        bool cok[2];
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {                                           // coef: 8 clips x 3 gates x 4 chunks of 8 bf16
+            const int idx = lane + 64 * i2;
+            cok[i2] = idx < 96;
+            const int cl = min(idx, 95) / 12, rem = min(idx, 95) % 12, gate = rem >> 2, chk = rem & 3;
+            cv[i2] = (unsigned)((((long long)(b0 + (cl < nb ? cl : 0)) * a.TS * a.G + grp) * K3 + gate * Hg + u0 + 8 * chk) * 2);
+            cdst[i2] = (unsigned)(cl * 96 + gate * 32 + chk * 8);
+        }
+        const bool want_dgi = a.dgi != nullptr;
+        const __amdgpu_buffer_rsrc_t rs_an = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ans), 0, a.ans ? tot_f32 : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_dgi = __builtin_amdgcn_make_buffer_rsrc(a.dgi, 0, a.dgi ? (a.dg_slabs == 4 ? (unsigned)min(nrow * a.G * 4 * Hg * 2, 0xffffffffll) : tot_cf) : 0u, 0x00020000);
+        struct OpSet { u32x4 d, z, c0, c1, an; };
+        auto issue = [&](int j, OpSet& o) {
+            const u32x4 zero = {0u, 0u, 0u, 0u};
+            o.d = zero; o.z = zero; o.c0 = zero; o.c1 = zero; o.an = zero;
+            if (j >= a.T || nodata) return;
+            const unsigned st = (unsigned)(a.T - 1 - j);
+            o.d = (j == 0 && a.carry) ? __builtin_amdgcn_raw_buffer_load_b128(rs_dh, dv, st * frame_bytes, 0)
+                                      : __builtin_amdgcn_raw_buffer_load_b128(rs_dout, dv, st * frame_bytes, 0);
+            if (j > 0) o.z = __builtin_amdgcn_raw_buffer_load_b128(rs_z, dv, (st + 1u) * frame_bytes, 0);
+            o.c0 = __builtin_amdgcn_raw_buffer_load_b128(rs_cf, cv[0], st * crow_bytes, 0);
+            if (cok[1]) o.c1 = __builtin_amdgcn_raw_buffer_load_b128(rs_cf, cv[1], st * crow_bytes, 0);
+            if (want_dgi) o.an = __builtin_amdgcn_raw_buffer_load_b128(rs_an, dv, st * frame_bytes, 0);
+        };
+        auto put = [&](int j, const OpSet& o) {
+            const int slot = j & 3;
+            *reinterpret_cast<u32x4*>(&op_d[slot][lc][4 * lq]) = o.d;
+            *reinterpret_cast<u32x4*>(&op_z[slot][lc][4 * lq]) = o.z;
+            *reinterpret_cast<u32x4*>(&op_c[slot][0][0] + cdst[0]) = o.c0;
+            if (cok[1]) *reinterpret_cast<u32x4*>(&op_c[slot][0][0] + cdst[1]) = o.c1;
+            if (want_dgi) *reinterpret_cast<u32x4*>(&op_a[slot][lc][4 * lq]) = o.an;
+        };
+        const int NSL = a.dg_slabs == 4 ? 4 : 3;
+        const unsigned dgrow_bytes = (unsigned)(a.G * NSL * Hg) * 2u;
+        const unsigned gi_v = (unsigned)((((long long)(b0 + (lc < nb ? lc : 0)) * a.TS * a.G + grp) * NSL * Hg + u0 + 4 * lq) * 2);
+        auto flush = [&](int j) {
+            if (lc >= nb) return;
+            const unsigned st = (unsigned)(a.T - 1 - j);
+            const float4 d4 = *reinterpret_cast<const float4*>(&dh_l[j & 1][lc][4 * lq]);
+            const u32x4 dw = {__float_as_uint(d4.x), __float_as_uint(d4.y), __float_as_uint(d4.z), __float_as_uint(d4.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(dw, rs_dh, dv, st * frame_bytes, 0);
+            if (want_dgi) {
+                const int slot = j & 3;
+                typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
+                const bf16x4_ cr = *reinterpret_cast<const bf16x4_*>(&op_c[slot][lc][4 * lq]);
+                const bf16x4_ cz = *reinterpret_cast<const bf16x4_*>(&op_c[slot][lc][32 + 4 * lq]);
+                const float4 a4 = *reinterpret_cast<const float4*>(&op_a[slot][lc][4 * lq]);
+                const float d[4] = {d4.x, d4.y, d4.z, d4.w}, an_[4] = {a4.x, a4.y, a4.z, a4.w};
+                bf16x4_ o0, o1, o2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o0[e] = (__bf16)(d[e] * (float)cr[e]); o1[e] = (__bf16)(d[e] * (float)cz[e]); o2[e] = (__bf16)(d[e] * an_[e]);
+                }
+                __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o0), rs_dgi, gi_v, st * dgrow_bytes, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o1), rs_dgi, gi_v + (unsigned)Hg * 2u, st * dgrow_bytes, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o2), rs_dgi, gi_v + (unsigned)Hg * 4u, st * dgrow_bytes, 0);
+                if (NSL == 4) {
+                    const bf16x4_ cn = *reinterpret_cast<const bf16x4_*>(&op_c[slot][lc][64 + 4 * lq]);
+                    bf16x4_ o3;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o3[e] = (__bf16)(d[e] * (float)cn[e]);
+                    __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o3), rs_dgi, gi_v + (unsigned)Hg * 6u, st * dgrow_bytes, 0);
+                }
+            }
+        };
+        OpSet s0, s1;
+        issue(0, s0); issue(1, s1);
+        put(0, s0); put(1, s1);
+        issue(2, s0); issue(3, s1);
+        if (a.dbg != 9) (void)team_shares_xcd(a.xid + (size_t)chain * 64, P, part, a.status, tid);    // mirrors the compute waves' barriers
+        __syncthreads();
+        for (int k = 0; k < a.T; k += 2) {
+            put(k + 2, s0);
+            issue(k + 4, s0);
+            if (k > 0) flush(k - 1);
+            if (a.T - 1 - k == 0) break;
+            __syncthreads();
+            put(k + 3, s1);
+            issue(k + 5, s1);
+            flush(k);
+            if (a.T - 2 - k == 0) break;
+            __syncthreads();
+        }
+        __syncthreads();                                // the last iteration's dh is in LDS
+        flush(a.T - 1);
+        return;
+    }
+
+    // A operand = W_hh[own gate rows, :]^T: A[row = output unit][k = own gate row]; k = gate*32 + unit, so k-step == gate
+    bf16x8 wf[NT][3];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int gt = 2 * (wv * NP + (nt >> 1)) + (nt & 1);  // pairs beyond P (P % 4 != 0) carry zero weights
+        const int n = min(gt, NTt - 1) * 16 + (lane & 15);
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                wf[nt][kk][e] = (FULL || gt < NTt) ? (__bf16)W[(long long)(kk * Hg + u0 + (lane >> 4) * 8 + e) * Hg + n] : (__bf16)0.f;
+        }
+    }
+
+    // sweep thread = (clip bl, producer octant og, 16-byte chunk pp): lane bits 0-1 pp, bit 2 the low clip bit, bits 3-5 og
+    const int pp = lane & 3, og = lane >> 3, bl = wv * 2 + ((lane >> 2) & 1);
+    const bool active = bl < nb;
+    const int blc = active ? bl : 0;                                  // inactive threads shadow clip 0 (loads only)
+    unsigned sweep_v[NL];
+    bool sweep_ok[NL];
+#pragma unroll
+    for (int jj = 0; jj < NL; ++jj) {
+        const int pr = og + 8 * jj;
+        sweep_ok[jj] = pr < P;
+        sweep_v[jj] = (unsigned)part * cons_bytes + (unsigned)((blc * P + min(pr, P - 1)) * 64 + pp * 16);
+    }
+    // after the reduce-scatter the thread holds unit 8 pp + 4 b5 + 2 b4 + b3 of clip bl (b = lane bits)
+    const int ou = 8 * pp + 4 * ((lane >> 5) & 1) + 2 * ((lane >> 4) & 1) + ((lane >> 3) & 1);
+    const bool b3 = (lane >> 3) & 1;
+    // publish: lane (c16 = lane & 15, qd = lane >> 4) of a store holds, for clip c16 & 7 and the pair (np + (c16 >> 3)), the 16-byte
+    // piece of units 4 qd .. 4 qd + 7 (qd even: tile 0) or 16 + 4 (qd - 1) .. + 7 (qd odd: tile 1)
+    const int c16 = lane & 15, qd = lane >> 4, hi8 = c16 >> 3;
+    constexpr int NST = (NP + 1) / 2;
+    unsigned pub_v[NST];
+    bool pub_ok[NST];
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+        const int np = 2 * st + hi8;                          // this lane's pair of the store
+        const int cq = wv * NP + np;                          // = consumer
+        pub_ok[st] = np < NP && (FULL || cq < P) && (c16 & 7) < nb;
+        pub_v[st] = (unsigned)min(cq, P - 1) * cons_bytes + (unsigned)(((c16 & 7) * P + part) * 64 + ((qd >> 1) + 2 * (qd & 1)) * 16);
+    }
+    const int pw = blc * KP + ou;                                     // panel element of the own unit (+ gate*32)
+
+    float dh = 0.f, dd = 0.f, zz = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;  // operands of the current step (time s)
+    bool nowait = a.dbg >= 1 && a.dbg < 7;
+    const bool plain = a.dbg != 9 && team_shares_xcd(a.xid + (size_t)chain * 64, P, part, a.status, tid);
+    __syncthreads();                                                  // ring slots 0 and 1 are filled
+    dd = op_d[0][blc][ou];
+    c0 = (float)op_c[0][blc][ou]; c1 = (float)op_c[0][blc][32 + ou]; c2 = (float)op_c[0][blc][64 + ou];
+
+    for (int k = 0; k < a.T; ++k) {
+        const int s = a.T - 1 - k;
+        float m = 0.f;
+        if constexpr (TIMED) tq0 = __builtin_amdgcn_s_memtime();
+        if (k > 0) {
+            const unsigned soff = cbase + (unsigned)((k - 1) & 1) * panel_bytes;
+            const unsigned tm = tag_bit((unsigned)k) ? TAGM : 0u;       // expected tag bits
+            u32x4 g[NL];
+            unsigned spins = 0;
+            for (int i = 0; i < a.poll_delay; ++i) __builtin_amdgcn_s_sleep(1);     // (see poll_delay)
+            for (;;) {
+#pragma unroll
+                for (int j = 0; j < NL; ++j) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, sweep_v[j], soff, 16);
+                unsigned bad = 0u;
+#pragma unroll
+                for (int j = 0; j < NL; ++j) {
+                    const unsigned bj = (g[j].x ^ tm) | (g[j].y ^ tm) | (g[j].z ^ tm) | (g[j].w ^ tm);
+                    bad |= sweep_ok[j] ? bj : 0u;
+                }
+                if (__all((bad & TAGM) == 0u || !active || nowait)) break;
+                if (++spins >= SPIN_LIMIT) {
+                    if (lane == 0) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    nowait = true;
+                }
+                if constexpr (TIMED) tph[4] += 1;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[0] += tq1 - tq0; tq0 = tq1; }
+            f32x2 sm[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};         // units (2i, 2i + 1) of the chunk
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                const unsigned d4[4] = {g[j].x, g[j].y, g[j].z, g[j].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned dm = sweep_ok[j] ? (d4[i] & ~TAGM) : 0u;
+                    const f32x2 v = {__uint_as_float(dm << 16), __uint_as_float(dm & 0xffff0000u)};
+                    sm[i] += v;
+                }
+            }
+            // reduce-scatter over the octants: after the three levels the thread holds the sum of unit `ou`
+            float v8[8] = {sm[0][0], sm[0][1], sm[1][0], sm[1][1], sm[2][0], sm[2][1], sm[3][0], sm[3][1]};
+            float v4[4], v2[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                  // lane bit 5: even half-waves keep units 0..3, odd 4..7
+                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v8[i]), __float_as_uint(v8[i + 4]), false, false);
+                v4[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {                  // lane bit 4
+                const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v4[i]), __float_as_uint(v4[i + 2]), false, false);
+                v2[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            }
+            {                                              // lane bit 3 (lane ^ 8 inside the 16-lane row)
+                const float send = b3 ? v2[0] : v2[1], keep = b3 ? v2[1] : v2[0];
+                m = (keep + __uint_as_float(dpp_ror8(__float_as_uint(send)))) * ISC;
+            }
+        }
+        dh = dd + zz * dh + m;
+        __bf16* pn = panel[k & 1];
+        if (active) {
+            dh_l[k & 1][bl][ou] = dh;                      // the loader wave writes it (and the gate gradients) to HBM
+            const float ds = dh * SC;
+            pn[pw] = (__bf16)(ds * c0); pn[pw + 32] = (__bf16)(ds * c1); pn[pw + 64] = (__bf16)(ds * c2);
+        }
+        if (s == 0) break;                                 // nothing consumes the partials of time 0
+        {                                                  // operands of step k+1 from the loader wave's ring (slot = iteration & 3)
+            const int slot = (k + 1) & 3;
+            dd = op_d[slot][blc][ou];
+            zz = op_z[slot][blc][ou];
+            c0 = (float)op_c[slot][blc][ou]; c1 = (float)op_c[slot][blc][32 + ou]; c2 = (float)op_c[slot][blc][64 + ou];
+        }
+        if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[1] += tq1 - tq0; tq0 = tq1; }
+        __syncthreads();                                   // panel[k & 1] complete; panel[(k+1) & 1] is free again
+        if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[2] += tq1 - tq0; tq0 = tq1; }
+        bf16x8 fb[3];
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk)
+            fb[kk] = *reinterpret_cast<const bf16x8*>(pn + (lane & 15) * KP + kk * 32 + (lane >> 4) * 8);
+        const unsigned soff = cbase + (unsigned)(k & 1) * panel_bytes;
+        const unsigned tagm = tag_bit((unsigned)(k + 1)) ? TAGM : 0u;
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            // pairs 2 st and 2 st + 1 of this wave: tiles (4 st .. 4 st + 3)
+            unsigned a0[2], a1[2], b0_[2], b1_[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int np = 2 * st + h;
+                if (np < NP) {
+                    f32x4 t0 = (f32x4){0.f, 0.f, 0.f, 0.f}, t1 = t0;
+#pragma unroll
+                    for (int kk = 0; kk < 3; ++kk) {
+                        t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * np][kk], fb[kk], t0, 0, 0, 0);
+                        t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * np + 1][kk], fb[kk], t1, 0, 0, 0);
+                    }
+                    a0[h] = pack2(t0[0], t0[1]); a1[h] = pack2(t0[2], t0[3]);
+                    b0_[h] = pack2(t1[0], t1[1]); b1_[h] = pack2(t1[2], t1[3]);
+                } else {
+                    a0[h] = a1[h] = b0_[h] = b1_[h] = 0u;
+                }
+            }
+            // the second pair's values to the idle column lanes (clips sit in columns 0..7): lanes 8..15 of a row take lane - 8
+            const unsigned x0 = (unsigned)__builtin_amdgcn_update_dpp((int)a0[0], (int)a0[1], 0x128, 0xf, 0xC, false);
+            const unsigned x1 = (unsigned)__builtin_amdgcn_update_dpp((int)a1[0], (int)a1[1], 0x128, 0xf, 0xC, false);
+            const unsigned y0 = (unsigned)__builtin_amdgcn_update_dpp((int)b0_[0], (int)b0_[1], 0x128, 0xf, 0xC, false);
+            const unsigned y1 = (unsigned)__builtin_amdgcn_update_dpp((int)b1_[0], (int)b1_[1], 0x128, 0xf, 0xC, false);
+            // even row groups end with (own tile-0 quad, neighbour's tile-0 quad), odd ones with (neighbour's tile-1 quad, own)
+            const auto r0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+            const auto r1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+            const u32x4 w = {with_tag(r0[0], tagm), with_tag(r1[0], tagm), with_tag(r0[1], tagm), with_tag(r1[1], tagm)};
+            if (pub_ok[st]) {
+                if (plain) __builtin_amdgcn_raw_buffer_store_b128(w, rs, pub_v[st], soff, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(w, rs, pub_v[st], soff, 16);
+            }
+        }
+        if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[3] += tq1 - tq0; tq0 = tq1; }
+    }
+    if constexpr (TIMED) {
+        if (tid == 0 && chain == 0 && part == 0) {
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.status) + 16;    // byte 128 of the status header
+            for (int i = 0; i < 5; ++i) dst[i] = tph[i];
+            dst[5] = (unsigned long long)a.T;
+        }
+    }
+    __syncthreads();                                       // hands the last iteration's dh to the loader wave
+}
+
+}  // namespace
+
+namespace cruse_gru {
+
+bool fwd_tf_eligible(int Bg, int Hg, int prec, bool has_h0, bool gi_bf16) {
+    const int tf = cruse_opt("gru_tf", 1);                     // A/B switch (tests, probes): 0 = the tagged kernels of gru.hip
+    if (tf == 0) return false;
+    // Hg = 640: the K-split-free step measured slower than the lean kernel's (1.36 against 1.27 us per step; 40 instead of 30 MFMAs
+    // per wave on the serial chain) -- there the lean kernel runs on the tag-free hand-off instead (gru.hip, TF); gru_tf = 2 forces this one
+    if (Hg == 640 && tf != 2) return false;
+    return prec == CRUSE_PREC_BF16 && Bg == 8 && !has_h0 && !gi_bf16 && (Hg == 160 || Hg == 320 || Hg == 640);
+}
+
+int dispatch_fwd_tf(const GruArgs& a, int grid, bool wlo, hipStream_t s) {
+    if (a.dbg == 32 && a.Hg == 640) return launch_one(gru_fwd_tf_kernel<20, 3, false, true>, a, grid, 0, s, "gru_seq_fwd", 320);
+    switch (a.Hg) {
+        case 160: return wlo ? launch_one(gru_fwd_tf_kernel<5, 1, true>, a, grid, 0, s, "gru_seq_fwd", 320)
+                             : launch_one(gru_fwd_tf_kernel<5, 1, false>, a, grid, 0, s, "gru_seq_fwd", 320);
+        case 320: return wlo ? launch_one(gru_fwd_tf_kernel<10, 2, true>, a, grid, 0, s, "gru_seq_fwd", 320)
+                             : launch_one(gru_fwd_tf_kernel<10, 2, false>, a, grid, 0, s, "gru_seq_fwd", 320);
+        default: return launch_one(gru_fwd_tf_kernel<20, 3, false>, a, grid, 0, s, "gru_seq_fwd", 320);
+    }
+}
+
+bool bwd_tf_eligible(int Bg, int Hg, int prec) {
+    if (cruse_opt("gru_tf", 1) == 0) return false;
+    return prec == CRUSE_PREC_BF16 && Bg == 8 && (Hg == 160 || Hg == 320 || Hg == 640);
+}
+size_t tf_bwd_bytes_per_parity(int Hg) { const size_t P = Hg / 32; return P * 8 * P * 64; }
+
+int dispatch_bwd_tf(const GruArgs& a, int grid, hipStream_t s) {
+    if (a.dbg == 32 && a.Hg == 640) return launch_one(gru_bwd_tf_kernel<20, true>, a, grid, 0, s, "gru_seq_bwd", 320);
+    switch (a.Hg) {
+        case 160: return launch_one(gru_bwd_tf_kernel<5>, a, grid, 0, s, "gru_seq_bwd", 320);
+        case 320: return launch_one(gru_bwd_tf_kernel<10>, a, grid, 0, s, "gru_seq_bwd", 320);
+        default: return launch_one(gru_bwd_tf_kernel<20>, a, grid, 0, s, "gru_seq_bwd", 320);
+    }
+}
+
+}  // namespace cruse_gru

@@ -631,7 +631,9 @@ def test_gru_fwd_wide_chains_match_lean_kernel_bit_for_bit(ops, H, B, T, G):
     gi = (0.5 * torch.randn(B, T, 3 * H)).cuda()
     w = [(torch.randn(3 * Hg, Hg) / Hg ** 0.5).cuda() for _ in range(G)]; b = [(0.1 * torch.randn(3 * Hg)).cuda() for _ in range(G)]
     h0 = (0.3 * torch.randn(B, H)).cuda()
-    with ops.options(gru_wlo=0):                   # (the lean kernel's W_hh low-plane pass for Hg <= 320 has no wide-chain form)
+    # (gru_wlo = 0: the lean kernel's W_hh low-plane pass for Hg <= 320 has no wide-chain form; gru_tf = 0: the K-split-free
+    #  kernel of gru_tf.hip sums in another order -- it has its own tests below)
+    with ops.options(gru_wlo=0, gru_tf=0):
         for init in (None, h0):
             lean = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16", h0=init)
             wide = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16", h0=init, wide=True)
@@ -658,7 +660,8 @@ def test_gru_bwd_wide_chains_match_reduce_scatter_kernel_bit_for_bit(ops, H, B, 
     w = [(torch.randn(3 * Hg, Hg) / Hg ** 0.5).cuda() for _ in range(G)]; b = [(0.1 * torch.randn(3 * Hg)).cuda() for _ in range(G)]
     dout = torch.randn(B, T, H).cuda()
     h, coef, an, z = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16")
-    ref = ops.gru_seq_bwd(dout, w, coef, z, B, T, G, Hg, "bf16", an=an, want_dgi=True, dg_slabs=slabs)
+    with ops.options(gru_tf=0):                    # (the tagged reduce-scatter kernel is the wide kernel's twin; gru_bwd_tf sums in another order)
+        ref = ops.gru_seq_bwd(dout, w, coef, z, B, T, G, Hg, "bf16", an=an, want_dgi=True, dg_slabs=slabs)
     wide = ops.gru_seq_bwd(dout, w, coef, z, B, T, G, Hg, "bf16", an=an, want_dgi=True, dg_slabs=slabs, wide=True)
     assert torch.equal(wide[0], ref[0]), "dh"
     assert torch.equal(wide[1].view(torch.int16), ref[1].view(torch.int16)), "dgi"
@@ -687,7 +690,7 @@ def test_gru_fwd_takes_bf16_gate_preactivations(ops, H, B, T, G, opts, wide):
     gi_f = gi_bf.float()
     w = [(torch.randn(3 * Hg, Hg) / Hg ** 0.5).cuda() for _ in range(G)]; b = [(0.1 * torch.randn(3 * Hg)).cuda() for _ in range(G)]
     h0 = (0.3 * torch.randn(B, H)).cuda()
-    with ops.options(**opts):
+    with ops.options(gru_tf=0, **opts):            # (bf16 gi rows are a variant of the tagged kernels)
         for init in (None, h0):
             ref = ops.gru_seq_fwd(gi_f, w, b, B, T, G, Hg, "bf16", h0=init, wide=wide)
             got = ops.gru_seq_fwd(gi_bf, w, b, B, T, G, Hg, "bf16", h0=init, wide=wide)
@@ -751,7 +754,7 @@ def test_gru_wide_chains_at_the_bench_length(ops):
     B, T, H = 64, 401, 640
     gi = (0.5 * torch.randn(B, T, 3 * H)).cuda()
     w = [(torch.randn(3 * H, H) / H ** 0.5).cuda()]; b = [(0.1 * torch.randn(3 * H)).cuda()]
-    lean = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16")
+    lean = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16")           # (Hg = 640: the lean kernel on the tag-free hand-off -- same sums)
     wide = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16", wide=True)
     for x, y, name in zip(wide, lean, ("h", "coef", "an", "z")):
         assert torch.equal(x, y), name
@@ -771,20 +774,25 @@ def test_gru_batch_beyond_the_cu_count(ops, B):
     """Hg = 640, B > 96: the chains of 8 x 20 workgroups do not fit the 256 CUs.  make_plan: B = 136 -- forward two launches of the
     wide-chain kernel (9 chains of 16, the last with 8 clips), backward three launches of the reduce-scatter kernel on chains
     of 8 (two wide launches would take longer); B = 104 -- one wide launch each way.  Same results as the batch run in two
-    parts (chains of 8)."""
+    parts (chains of 8) -- bit for bit with the tagged kernels (the wide kernels' twins), up to the summation order with the
+    default ones (tag-free hand-off wherever chains of 8 run)."""
     torch.manual_seed(3)
     T, H = 6, 640
     gi = (0.5 * torch.randn(B, T, 3 * H)).cuda()
     w = [(torch.randn(3 * H, H) / H ** 0.5).cuda()]; b = [(0.1 * torch.randn(3 * H)).cuda()]
     dout = torch.randn(B, T, H).cuda()
-    full = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16")
-    dh, dgi = ops.gru_seq_bwd(dout, w, full[1], full[3], B, T, 1, H, "bf16", an=full[2], want_dgi=True)
-    for lo, hi in ((0, 64), (64, B)):
-        part = ops.gru_seq_fwd(gi[lo:hi].contiguous(), w, b, hi - lo, T, 1, H, "bf16")
-        for x, y, name in zip(part, full, ("h", "coef", "an", "z")):
-            assert torch.equal(x, y[lo:hi]), name
-        dh_p, dgi_p = ops.gru_seq_bwd(dout[lo:hi].contiguous(), w, part[1], part[3], hi - lo, T, 1, H, "bf16", an=part[2], want_dgi=True)
-        assert torch.equal(dh_p, dh[lo:hi]) and torch.equal(dgi_p, dgi[lo * T:hi * T].view(dgi_p.shape))
+    with ops.options(gru_tf=0):
+        full = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16")
+        dh, dgi = ops.gru_seq_bwd(dout, w, full[1], full[3], B, T, 1, H, "bf16", an=full[2], want_dgi=True)
+        for lo, hi in ((0, 64), (64, B)):
+            part = ops.gru_seq_fwd(gi[lo:hi].contiguous(), w, b, hi - lo, T, 1, H, "bf16")
+            for x, y, name in zip(part, full, ("h", "coef", "an", "z")):
+                assert torch.equal(x, y[lo:hi]), name
+            dh_p, dgi_p = ops.gru_seq_bwd(dout[lo:hi].contiguous(), w, part[1], part[3], hi - lo, T, 1, H, "bf16", an=part[2], want_dgi=True)
+            assert torch.equal(dh_p, dh[lo:hi]) and torch.equal(dgi_p, dgi[lo * T:hi * T].view(dgi_p.shape))
+    full_d = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16")
+    dh_d, dgi_d = ops.gru_seq_bwd(dout, w, full_d[1], full_d[3], B, T, 1, H, "bf16", an=full_d[2], want_dgi=True)
+    assert rel_l2(full_d[0], full[0]) < 1e-3 and rel_l2(dh_d, dh) < 2e-3 and rel_l2(dgi_d.float(), dgi.float()) < 2e-3
     assert ops.gru_status() == 0
 
 
