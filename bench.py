@@ -79,7 +79,9 @@ def self_launch(a) -> int:
     log(f"--gpus {a.gpus} without a launcher: starting {a.gpus} ranks ({backend}) on 127.0.0.1:{port}")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "8")
+    # N ranks share the host: cap each rank's CPU thread pools (torch / OpenMP default to every core -- N x 128 threads spinning
+    # beside N eager launch loops); the CPU-baseline leg sets its own count on rank 0
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, (os.cpu_count() or 8) // max(a.gpus, 1)))))
     return subprocess.call(cmd, env=env)
 
 
@@ -437,6 +439,141 @@ def secondary_rows(a, dev, pool):
     return out
 
 
+def _time_steps(eng, pool, n_warm=3, n=8):
+    for s_ in range(n_warm):
+        eng.step(*pool[s_ % len(pool)])
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for s_ in range(n):
+        eng.step(*pool[s_ % len(pool)])
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def config_rows(a, dev, pool):
+    """BASELINE.json configs 3, 4 and 5 as driver-visible rows: the per-GPU share of each on ONE device --
+    config 3: g = 4, 64 clips (512 / 8 GPUs); config 4: g = 4 + DeepFilter(1,5) head, 32 clips (256 / 8); config 5: the blocks
+    model/mtfaa.py defines (STFT -> PhaseEncoder -> 6 x TFCM_Block) in fp16 storage, 8 clips.  Each: ms per step (the faster of
+    HIP-graph replay and eager launches, as the headline does), frames/s, the dominant kernel family with its roofline
+    fraction from an instrumented pass, and the enhanced-spectrum (config 5: stack output) rel-L2 against the CPU oracle."""
+    from cruse_amd import ops
+    from cruse_amd.data import synth_batch
+    from cruse_amd.engine import TrainEngine
+    from cruse_amd.model.cruse_net import unet_2
+    out = {}
+    L = pool[0][0].shape[1]
+    T = 1 + L // 160
+
+    def unet_row(name, groups, B, df, note):
+        torch.manual_seed(0)
+        m = unet_2(rnn_groups=groups, precision="bf16").to(dev)
+        bp = [synth_batch(B, L, dev, 7000 + i) for i in range(2)]
+        best = None
+        for graph in (True, False):
+            e = TrainEngine(m, lr=1e-3, use_graph=graph, loss="wo_male_df" if df else "wo_male")
+            ms = _time_steps(e, bp)
+            if best is None or ms < best[0]:
+                best = (ms, graph, e)
+        ms, graph, e = best
+        with KernelTimer(ops, e) as kt:
+            e._fwd_bwd(*bp[0]); torch.cuda.synchronize(); kt.rec.clear()
+            for s_ in range(2):
+                e._fwd_bwd(*bp[s_ % 2]); kt.mark_pass()
+            per_step, calls = kt.summary()
+        rl = kernel_rooflines(B, T, m.hidden_size, groups, "bf16", per_step, calls)
+        dom = max(per_step, key=per_step.get)
+        roof = dict(rl.get(dom, {"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None}))
+        roof["kernel"] = dom; roof["ms_per_step_all_launches"] = round(per_step[dom], 3)
+        fps = B * T / (ms * 1e-3)
+        sr = step_roofline(fps, groups, "bf16", B, T)
+        row = {"value": round(fps, 1), "unit": "frames/s", "ms_per_step": round(ms, 3), "per_gpu_batch": B, "groups": groups,
+               "launch_form": "graph" if graph else "eager", "dtype": "bf16", "roofline": roof,
+               "roofline_step_hbm_f32_storage_frac": sr["hbm_f32_storage"]["frac"], "roofline_step_mfma_frac": sr.get("mfma", {}).get("frac"),
+               "timeouts": ops.gru_status(), "note": note}
+        if not a.no_parity:
+            if df:
+                from oracle import cruse_oracle as O
+                from oracle import cruse_oracle_ext as X
+                o = O.unet_2(rnn_groups=groups)
+                o.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()})
+                o.train()
+                noisy, clean = O.synth_pair(2, (T - 1) * 160, seed=12)
+                torch.set_num_threads(min(os.cpu_count() or 1, 16))
+                with torch.no_grad():
+                    _, aux = X.train_step_loss_df(o, noisy, clean)
+                e2 = TrainEngine(m, lr=0.0, use_graph=False, loss="wo_male_df")
+                e2._fwd_bwd(noisy.to(dev), clean.to(dev)); torch.cuda.synchronize()
+                est = e2._last_est.permute(1, 0, 2, 3).double().cpu()                 # [2,B,T,F] -> [B,2,T,F]
+                row["parity_rel_l2"] = float(f"{float((est - aux['est'].double()).norm() / aux['est'].double().norm()):.4g}")
+                row["parity_note"] = "DeepFilter output (enhanced spectrum) vs oracle_ext.train_step_loss_df at T=401, B=2"
+            else:
+                row["parity_rel_l2"] = float(f"{parity_figure(m, groups, 'bf16', B=2, T=T):.4g}")
+                row["parity_note"] = "enhanced-spectrum rel-L2 vs the CPU oracle at T=401, B=2 (bar 1e-3)"
+        out[name] = row
+
+    for name, args in (("config3_g4", (4, 64, False, "BASELINE config 3 per-GPU share: 4 grouped GRUs of 160, 64 of the 512 clips")),
+                       ("config4_df_g4_b32", (4, 32, True, "BASELINE config 4 per-GPU share: + DeepFilter(1,5) head, 32 of the 256 clips"))):
+        try:
+            unet_row(name, *args)
+        except Exception as ex:                              # secondary rows never break the headline line
+            out[name] = {"error": repr(ex)[:300]}
+    # ---- config 5: tools/mtfaa_stress.py's step (fp16 storage) ---------------------------------------------------------
+    try:
+        from model import mtfaa as M
+        from cruse_amd.nn_generic import to_f16, to_f32
+        torch.manual_seed(0)
+        Bm = 8
+        stft = M.STFT(320, 160, 320, "hann")
+        pe = M.PhaseEncoder(4, 1).to(dev)
+        tfcm = M.TFCM(24, (3, 3), 6).to(dev)
+        x = (0.1 * torch.randn(Bm, L)).to(dev)
+        params = [q for mod in (pe, tfcm) for q in mod.parameters()]
+
+        def step():
+            c = stft.transform(x)
+            h = torch.cat([pe([c])] * 12, dim=1)             # [B,24,161,T] (channel plumbing, as tools/mtfaa_stress.py)
+            y = to_f32(tfcm(to_f16(h)))
+            for q in params:
+                q.grad = None
+            (y.square().mean() * 65536.0).backward()         # (the usual loss scale of fp16 training)
+            return y
+        step(); step(); torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+            y = step()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 4
+        tensor = Bm * 24 * 161 * T * 2                       # one [B,24,161,T] f16 tensor
+        # per block forward: conv, BN+PReLU, depthwise, BN+PReLU, conv + add = 5 kernels reading and writing one tensor each,
+        # + 2 statistics passes; backward ~2.5 x: ~3.5 x (5*2 + 2) tensors per block (the figure tools/mtfaa_stress.py prints)
+        alg_bytes = 6 * (5 * 2 + 2) * tensor * 3.5
+        row = {"value": round(Bm * T / (ms * 1e-3), 1), "unit": "frames/s", "ms_per_step": round(ms, 3), "batch": Bm, "dtype": "f16 storage",
+               "finite": bool(torch.isfinite(y).all()),
+               "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": round(alg_bytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "kernel": "whole TFCM stack (NCHW f16 streams)",
+                            "algorithmic_bytes_per_step": int(alg_bytes)},
+               "note": "BASELINE config 5: STFT -> PhaseEncoder -> 6 x TFCM_Block forward + backward (autograd over the general NCHW "
+                       "kernels, pointwise convs on v_mfma_f32_16x16x32_f16); no optimizer"}
+        if not a.no_parity:
+            from oracle import cruse_oracle_ext as X
+            o = X.TFCM(24, (3, 3), 6)
+            o.load_state_dict({k: v.detach().cpu() for k, v in tfcm.state_dict().items()})
+            o.train(); tfcm.train()
+            xin = torch.randn(1, 24, 161, 201, generator=torch.Generator().manual_seed(5))
+            torch.set_num_threads(min(os.cpu_count() or 1, 16))
+            with torch.no_grad():
+                yo = o(xin)
+                yp = to_f32(tfcm(to_f16(xin.to(dev)))).cpu()
+            row["parity_rel_l2"] = float(f"{float((yp.double() - yo.double()).norm() / yo.double().norm()):.4g}")
+            row["parity_note"] = "6 x TFCM_Block output in f16 storage vs the f32 CPU oracle on [1,24,161,201] (train-mode BatchNorm)"
+        out["config5_mtfaa_fp16"] = row
+    except Exception as ex:
+        out["config5_mtfaa_fp16"] = {"error": repr(ex)[:300]}
+    return out
+
+
 def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -496,7 +633,7 @@ def main():
     log("inputs ready; warm-up (includes HIP-graph capture) ...")
     launch_choice = None
     if not a.no_graph and not a.graph:
-        # the same step, replayed from HIP graph(s) or launched eagerly: keep the faster form (all ranks take rank 0's verdict)
+        # the same step, replayed from HIP graph(s) or launched eagerly: keep the faster form (per-rank timings, MAX over the ranks)
         def timed(mode, n=3):
             eng.use_graph = mode
             eng.step(*pool[0])                              # (capture / first-use work outside the measurement)
@@ -509,10 +646,13 @@ def main():
         # two rounds each, best of the two: one-time stalls (stream / communicator set-up on first use) must not decide
         t_graph, t_eager = timed(True), timed(False)
         t_graph, t_eager = min(t_graph, timed(True)), min(t_eager, timed(False))
-        verdict = torch.tensor([1.0 if t_graph <= t_eager else 0.0], device=dev)
+        # every rank measured its own pair; the job's verdict is taken on the SLOWEST rank's figures (MAX), identically everywhere
+        # -- a step ends when the last rank's gradients arrive, and rank 0's host is not necessarily the busiest one
+        tt = torch.tensor([t_graph, t_eager], device=dev, dtype=torch.float64)
         if world > 1:
-            dist.broadcast(verdict, 0)
-        eng.use_graph = bool(verdict.item() > 0.5)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_graph, t_eager = float(tt[0].item()), float(tt[1].item())
+        eng.use_graph = t_graph <= t_eager
         launch_choice = {"graph_ms": round(t_graph * 1e3, 3), "eager_ms": round(t_eager * 1e3, 3),
                          "kept": "graph" if eng.use_graph else "eager"}
         log(f"launch form: graph {t_graph * 1e3:.2f} ms, eager {t_eager * 1e3:.2f} ms -> {launch_choice['kept']}")
@@ -600,8 +740,16 @@ def main():
     secondary = None
     if rank == 0 and world == 1 and not a.no_secondary:
         secondary = secondary_rows(a, dev, pool)
+        secondary.update(config_rows(a, dev, pool))
 
+    ranks_seen = devices_seen = None
     if world > 1 or force_pg:
+        # which ranks did the collectives of THIS run actually reach: an all-gather of (rank, device index) over the backend
+        ids = torch.tensor([rank, local], device=dev, dtype=torch.int64)
+        got = [torch.zeros_like(ids) for _ in range(world)]
+        dist.all_gather(got, ids)
+        ranks_seen = sorted({int(g_[0].item()) for g_ in got})
+        devices_seen = sorted({int(g_[1].item()) for g_ in got})
         dist.barrier()                        # rank 0's instrumented pass is done before anyone tears down
         dist.destroy_process_group()
     if rank == 0:
@@ -612,6 +760,7 @@ def main():
             "ms_per_step": round(el / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.prec, "data": "synthetic",
             "world_size": world, "backend": ("rccl" if backend == "nccl" else backend), "bucketed_allreduce": bool(eng.bucketed),
+            "rccl_ranks_seen": (None if ranks_seen is None else len(ranks_seen)), "devices_seen": devices_seen,
             "scaling_efficiency": (None if not a.ref_1gpu else round(frames / el / (world * a.ref_1gpu), 4)),
             "config": {"workload": f"CRUSE unet_2 4-layer enc/dec, {a.groups}xGRU group(s), H=640, "
                                    f"{B} clips x {a.seconds:g} s @16 kHz per GPU, n_fft=320 hop=160 (T={T}), "

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcruse_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16 = 0, 1, 2, 3
 PREC_BY_NAME = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "f16": PREC_F16}
 DT_F32, DT_F16 = 0, 1
@@ -77,12 +77,13 @@ SIGNATURES = {
     "cruse_mask_sdnr_fwd": ("pppppqiiiffpppp", "i"),
     "cruse_sisnr_fwd": ("ppiifpppp", "i"),
     "cruse_sisnr_bwd": ("pppiifpp", "i"),
+    "cruse_wave_l1_mse": ("ppqifppp", "i"),
     "cruse_deepfilter_fwd": ("ppppiiiiippp", "i"),
     "cruse_deepfilter_bwd": ("ppppppiiiiippppp", "i"),
     "cruse_sigmoid_bwd": ("pppqp", "i"),
     "cruse_axpby": ("pppffqp", "i"),
     "cruse_adam_step": ("ppppqfffffifp", "i"),
-    "cruse_adam_step_guarded": ("ppppqfffffiffppippp", "i"),
+    "cruse_adam_step_guarded": ("ppppqfffffiffppipppdpp", "i"),
     "cruse_step_health": ("ppppdp", "i"),
     "cruse_sumsq": ("pqpip", "i"),
     "cruse_conv2d_nchw": ("ppppiiiiiiiiiiiiiiiiiiipiip", "i"),

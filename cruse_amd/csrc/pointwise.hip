@@ -663,9 +663,13 @@ __global__ void counters_add_kernel(CounterPtrs c, int n, long long v) {
 // gradient norm is not finite.  gsumsq (sum of squares of g BEFORE grad_scale) with max_norm > 0 applies
 // torch.nn.utils.clip_grad_norm_'s coefficient min(1, max_norm / (norm + 1e-6)) on top of grad_scale.
 __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2,
-                            float eps, float wd, float bc1, float bc2_sqrt, float gscale, float max_norm,
+                            float eps, float wd, int step, float gscale, float max_norm,
                             const double* gsumsq, const unsigned* skip_flag, int n_skip_words, const double* loss_check,
-                            unsigned* skipped) {
+                            unsigned* skipped, const double* loss_sum, double loss_scale, double* loss_acc) {
+    // Adam's step counts the APPLIED steps: skipped[0] is read before this launch can change it (only the skip path below does)
+    const int step_eff = max(1, step - (skipped ? (int)*skipped : 0));
+    const float bc1 = (float)(1.0 - pow((double)b1, (double)step_eff));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)step_eff));
     bool skip = false;
     for (int i = 0; i < n_skip_words; ++i)
         if (skip_flag[i] != 0u) skip = true;
@@ -686,6 +690,7 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long l
         }
         return;
     }
+    if (loss_acc && loss_sum && blockIdx.x == 0 && threadIdx.x == 0) { loss_acc[0] += *loss_sum * loss_scale; loss_acc[1] += 1.0; }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float gi = g[i] * gscale;
         const float pi = p[i];
@@ -918,16 +923,15 @@ extern "C" int cruse_adam_step_guarded(float* p, const float* g, float* m, float
                                        float lr, float beta1, float beta2, float eps, float weight_decay,
                                        int step, float grad_scale, float max_norm, const double* gsumsq,
                                        const unsigned* skip_flag, int n_skip_words, const double* loss_check,
-                                       unsigned* skipped, void* stream) {
+                                       unsigned* skipped, const double* loss_sum, double loss_scale, double* loss_acc,
+                                       void* stream) {
     CRUSE_REQUIRE(n > 0 && step >= 1, CRUSE_E_SHAPE, "adam_step: n=%lld step=%d", n, step);
     CRUSE_REQUIRE(n_skip_words >= 0 && n_skip_words <= 8 && (n_skip_words == 0 || skip_flag != nullptr), CRUSE_E_SHAPE,
                   "adam_step: n_skip_words=%d (0..8, with skip_flag)", n_skip_words);
     CRUSE_REQUIRE(max_norm <= 0.f || gsumsq != nullptr, CRUSE_E_SHAPE, "adam_step: max_norm needs the gradient sum of squares");
-    const double bc1 = 1.0 - pow((double)beta1, step);
-    const double bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, ST(stream), p, g, m, v, n, lr, beta1, beta2,
-                       eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale, max_norm, gsumsq, skip_flag,
-                       skip_flag ? n_skip_words : 0, loss_check, skipped);
+                       eps, weight_decay, step, grad_scale, max_norm, gsumsq, skip_flag,
+                       skip_flag ? n_skip_words : 0, loss_check, skipped, loss_sum, loss_scale, loss_acc);
     CRUSE_LAUNCH_CHECK("adam_step");
     return CRUSE_OK;
 }
@@ -936,7 +940,7 @@ extern "C" int cruse_adam_step(float* p, const float* g, float* m, float* v, lon
                                float lr, float beta1, float beta2, float eps, float weight_decay,
                                int step, float grad_scale, void* stream) {
     return cruse_adam_step_guarded(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, 0.f, nullptr,
-                                   nullptr, 0, nullptr, nullptr, stream);
+                                   nullptr, 0, nullptr, nullptr, nullptr, 1.0, nullptr, stream);
 }
 
 extern "C" int cruse_sumsq(const float* x, long long n, double* out, int accumulate, void* stream) {

@@ -215,3 +215,56 @@ extern "C" int cruse_mask_sdnr_fwd(const float* mask, const float* cre, const fl
     CRUSE_LAUNCH_CHECK("mask_sdnr");
     return CRUSE_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Waveform L1 / MSE (`l1_loss` / `mse_loss` = torch.nn.L1Loss / MSELoss, train_base/loss.py:3-4, reachable through
+// tools/train_stand.py:73-75) on the enhanced waveform est = iSTFT(mask * noisy spectrum): one streaming pass gives the loss
+// sum (f64) and the gradient wrt est -- sign(est - ref) * gscale or 2 (est - ref) * gscale, gscale = 1 / numel for
+// reduction = "mean".  HBM-bound: 8 B in + 4 B out per sample.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+template <bool MSE>
+__global__ __launch_bounds__(256) void wave_l1mse_kernel(const float* x, const float* s, long long n, float gscale,
+                                                         double* loss_sum, float* dx) {
+    __shared__ double sred[4];
+    double acc = 0.0;
+    float part = 0.f;
+    int cnt = 0;
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 a = reinterpret_cast<const float4*>(x)[i], b = reinterpret_cast<const float4*>(s)[i];
+        const float d[4] = {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w};
+        float g[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            part += MSE ? d[e] * d[e] : fabsf(d[e]);
+            g[e] = MSE ? 2.f * d[e] * gscale : (d[e] > 0.f ? gscale : (d[e] < 0.f ? -gscale : 0.f));     // torch: sign(0) = 0
+        }
+        if (dx) reinterpret_cast<float4*>(dx)[i] = make_float4(g[0], g[1], g[2], g[3]);
+        if (++cnt == 8) { acc += part; part = 0.f; cnt = 0; }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) {                       // tail (n % 4 samples)
+        const long long i = (n4 << 2) + threadIdx.x;
+        const float d = x[i] - s[i];
+        part += MSE ? d * d : fabsf(d);
+        if (dx) dx[i] = MSE ? 2.f * d * gscale : (d > 0.f ? gscale : (d < 0.f ? -gscale : 0.f));
+    }
+    acc = wave_sum_d(acc + part);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss_sum, sred[0] + sred[1] + sred[2] + sred[3]);
+}
+}  // namespace
+
+extern "C" int cruse_wave_l1_mse(const float* est, const float* ref, long long n, int mse, float grad_scale,
+                                 double* loss_sum, float* dest, void* stream) {
+    CRUSE_REQUIRE(n > 0 && est != nullptr && ref != nullptr && loss_sum != nullptr, CRUSE_E_SHAPE, "wave_l1_mse: bad arguments");
+    CRUSE_REQUIRE((((uintptr_t)est | (uintptr_t)ref | (uintptr_t)dest) & 15) == 0, CRUSE_E_ALIGN, "wave_l1_mse: unaligned buffers");
+    hipStream_t st = (hipStream_t)stream;
+    { int rc = cruse_zero_async(loss_sum, sizeof(double), st, "wave_l1_mse"); if (rc) return rc; }
+    const int grid = blocks_for(n >> 2, 2048);
+    if (mse) hipLaunchKernelGGL(wave_l1mse_kernel<true>, dim3(grid), dim3(256), 0, st, est, ref, n, grad_scale, loss_sum, dest);
+    else hipLaunchKernelGGL(wave_l1mse_kernel<false>, dim3(grid), dim3(256), 0, st, est, ref, n, grad_scale, loss_sum, dest);
+    CRUSE_LAUNCH_CHECK("wave_l1_mse");
+    return CRUSE_OK;
+}

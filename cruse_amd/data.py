@@ -54,7 +54,8 @@ def snr_mix(clean_y: torch.Tensor, noise_y: torch.Tensor, snr, target_dB_FS=None
     clean_y, noise_y [B,L] (or [L]); snr: dB, scalar or [B].  Returns noisy (and the normalised clean / scaled noise with
     return_parts).  The reference's function ENDS after drawing `noisy_target_dB_FS` from
     np.random.randint(target_dB_FS - floating, target_dB_FS + floating) (the file is truncated there, :261-264): when both
-    are given the draw is made, to consume numpy's RNG exactly as the reference does, and nothing else is done with it."""
+    are given the draw is made -- once per clip of the batch -- to consume numpy's RNG exactly as B calls of the reference's
+    per-clip function do, and nothing else is done with it."""
     from . import ops
     from ._lib import check, lib
     one = clean_y.dim() == 1
@@ -80,7 +81,10 @@ def snr_mix(clean_y: torch.Tensor, noise_y: torch.Tensor, snr, target_dB_FS=None
                             ops._stream()))
     if target_dB_FS is not None and target_dB_FS_floating_val is not None:
         import numpy as np
-        np.random.randint(target_dB_FS - target_dB_FS_floating_val, target_dB_FS + target_dB_FS_floating_val)   # :261-264
+        # one draw PER CLIP: the reference's snr_mix is a per-clip function, so a batch of B clips consumes B draws there
+        # (a single draw per batched call let identically seeded host RNG streams diverge for B > 1)
+        np.random.randint(target_dB_FS - target_dB_FS_floating_val, target_dB_FS + target_dB_FS_floating_val,
+                          size=None if one else B)                                                               # :261-264
     if one:
         noisy = noisy[0]; co = None if co is None else co[0]; no = None if no is None else no[0]
     return (noisy, co, no) if return_parts else noisy

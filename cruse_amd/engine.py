@@ -34,7 +34,8 @@ from .model.cruse_net import N_BUCKETS, bucket_of, unet2_backward, unet2_forward
 
 ALIGN = 64  # floats
 
-LOSSES = ("wo_male", "si_snr", "sdnr", "wo_male_df")
+LOSSES = ("wo_male", "si_snr", "sdnr", "wo_male_df", "l1", "mse")
+WAVE_LOSSES = ("si_snr", "l1", "mse")            # waveform in -> waveform loss: the estimate goes through the iSTFT
 
 
 def unused_parameter(name: str) -> bool:
@@ -172,6 +173,7 @@ class FlatParams:
 
 class TrainEngine:
     """loss: "wo_male" (loss_func/loss.py:121-148, alpha/beta), "si_snr" (train_base/loss.py:7-25 through the iSTFT),
+    "l1" / "mse" (train_base/loss.py:3-4: torch.nn.L1Loss / MSELoss on the enhanced waveform iSTFT(mask * N) vs the clean one),
     "sdnr" (loss_func/loss.py:151-175 with the mask as gain; `snr_db`, `sdnr_beta_db`) or "wo_male_df" -- BASELINE
     config 4: the mask is the real part of a DeepFilter(t_dim=1, f_dim=5) coefficient field (model/deep_filter.py:15-41;
     DECISION recorded in oracle.train_step_loss: filters = (mask padded to 161 bins, 0)), the enhanced spectrum is the
@@ -180,7 +182,7 @@ class TrainEngine:
     eager form is the faster one once the host keeps ahead (6.08 vs 6.3 ms); a busy or slow host favours the
     graph.  "auto" decides by measurement on the first real steps: 1 + 3 steps from the graph, 1 + 3 launched eagerly
     (HIP-event times of the measured ones, one host synchronisation each), then the faster form is kept for good -- no
-    extra steps are run, every rank takes rank 0's verdict.  bench.py does the same during its warm-up.
+    extra steps are run, every rank measures and the verdict is taken on the MAX over the ranks.  bench.py does the same during its warm-up.
     clip_grad_norm > 0: torch.nn.utils.clip_grad_norm_ semantics on the (averaged) gradient, folded into Adam.
     bucketed: None = when world > 1; True forces the segmented schedule (tests, single-GPU cost measurements).
     config: EngineConfig (cruse_amd/config.py) -- scheduling / numerics options; None = the measured-best defaults."""
@@ -233,8 +235,7 @@ class TrainEngine:
         self._health = torch.zeros(2, device=dev, dtype=torch.int32)
         self._timeouts_seen = 0
         self._norms: Dict[Tuple[int, ...], float] = {}           # input shape -> loss normalisation of that shape
-        self._loss_acc = torch.zeros(1, device=dev, dtype=torch.float64)
-        self._loss_steps = 0
+        self._loss_acc = torch.zeros(2, device=dev, dtype=torch.float64)     # [sum of the applied steps' losses, applied steps]
         self._norm = 1.0
         self._works: List = []
         self._launcher = None
@@ -248,7 +249,7 @@ class TrainEngine:
         # the clean spectrum is only needed by the loss: a leaf queued for the first forward recurrence (beside the encoder
         # it shared HBM with the 1 -> 8 conv: 60 vs 33 us, plus an event record on the main stream); joined by
         # unet2_forward before the decoder
-        if self.loss != "si_snr":
+        if self.loss not in WAVE_LOSSES:
             # (outputs are allocated here, on the main stream, so that the leaf itself allocates nothing)
             if self.loss == "wo_male":
                 cmag = torch.empty(B, T, self.f_stft, device=clean.device, dtype=torch.float32)
@@ -279,12 +280,16 @@ class TrainEngine:
             # waveform in -> waveform loss: est = iSTFT(mask * N); SI-SNR(est, clean) and back through both
             ere, eim = ops.mask_apply(mask, nre, nim, rows, self.f_net, self.f_stft)
             est = ops.istft(ere.view(B, T, self.f_stft), eim.view(B, T, self.f_stft), self.n_fft, self.hop, L)
-            loss_sum, coef = ops.sisnr_fwd(est, clean)
+            if self.loss == "si_snr":
+                loss_sum, coef = ops.sisnr_fwd(est, clean)
+                dwave = ops.sisnr_bwd(est, clean, coef) if training else None
+                self._norm = 1.0
+            else:                                                     # reduction "mean" over all B * L samples
+                loss_sum, dwave = ops.wave_l1_mse(est, clean, self.loss == "mse", want_grad=training)
+                self._norm = float(B * L)
             if training:
-                dwave = ops.sisnr_bwd(est, clean, coef)
                 dre, dim = ops.istft_bwd(dwave, T, self.n_fft, self.hop)
                 dlogit = ops.mask_apply_bwd(dre, dim, nre, nim, mask, rows, self.f_net, self.f_stft)
-            self._norm = 1.0
         return loss_sum, dlogit, ctx
 
     def _deepfilter_loss(self, mask, nre, nim, cre, cim, B, T, training):
@@ -441,10 +446,12 @@ class TrainEngine:
         st["n"] = i + 1
         if st["n"] == len(self._AUTO_PLAN):
             tg, te = sorted(st["t"][True])[1], sorted(st["t"][False])[1]          # medians of three
-            verdict = torch.tensor([1.0 if tg <= te else 0.0], device=noisy.device)
             if _dist_on():
-                dist.broadcast(verdict, 0)
-            self.use_graph = bool(verdict.item() > 0.5)
+                # per-rank measurements, the job decides on the SLOWEST rank's figures (MAX): the same verdict on every rank
+                tt = torch.tensor([tg, te], device=noisy.device, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                tg, te = float(tt[0].item()), float(tt[1].item())
+            self.use_graph = tg <= te
             self.launch_form_timing = {"graph_ms": round(tg, 3), "eager_ms": round(te, 3),
                                        "kept": "graph" if self.use_graph else "eager"}
             self._auto = None
@@ -489,7 +496,7 @@ class TrainEngine:
         B = noisy.shape[0]
         g = self.model.rnn_groups
         word = ops.gru_status_word(noisy.device, B, g, self.model.hidden_size // g)
-        ops.step_health(word, loss_sum, self._health, self._loss_acc, 1.0 / self._norm)
+        ops.step_health(word, loss_sum, self._health)
         if _dist_on():
             # one rank's time-out / NaN is inside everybody's reduced gradient: everybody skips
             self._works.append(dist.all_reduce(self._health, op=dist.ReduceOp.MAX, async_op=True))
@@ -501,8 +508,8 @@ class TrainEngine:
             gs = ops.sumsq(self.flat.grads, out=self._gsumsq)
         ops.adam_step(self.flat.params, self.flat.grads, self.flat.exp_avg, self.flat.exp_avg_sq, self.lr,
                       self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, 1.0 / self.world,
-                      max_norm=self.clip, gsumsq=gs, skip_flag=self._health, skipped=self._skipped)
-        self._loss_steps += 1
+                      max_norm=self.clip, gsumsq=gs, skip_flag=self._health, skipped=self._skipped,
+                      loss_sum=loss_sum, loss_scale=1.0 / self._norm, loss_acc=self._loss_acc)
         return loss_sum
 
     # -- host-side read-outs (each synchronises) --------------------------------------------------------------------
@@ -515,11 +522,10 @@ class TrainEngine:
 
     def mean_loss(self, reset: bool = True) -> float:
         """mean loss over the steps since the last reset -- ONE synchronisation per epoch / log interval."""
-        n = max(self._loss_steps, 1)
-        v = float(self._loss_acc.item()) / n     # (each step was accumulated with its own normalisation)
+        acc = self._loss_acc.tolist()            # (each APPLIED step was accumulated with its own normalisation, by the guarded
+        v = acc[0] / max(acc[1], 1.0)            #  Adam itself: a skipped step -- time-out, NaN, on any rank -- adds nothing)
         if reset:
             self._loss_acc.zero_()
-            self._loss_steps = 0
         return v
 
     def skipped_steps(self) -> int:
@@ -549,10 +555,11 @@ class TrainEngine:
 
     # -- optimizer state in torch.optim.Adam layout ------------------------------------------------------------------
     def optimizer_state_dict(self) -> dict:
-        return self.flat.adam_state_dict(self.step_count, self.lr, self.betas, self.eps, self.wd)
+        # Adam's step = the APPLIED steps (the kernel's bias corrections use step_count - skipped, see cruse_adam_step_guarded)
+        return self.flat.adam_state_dict(self.step_count - self.skipped_steps(), self.lr, self.betas, self.eps, self.wd)
 
     def load_optimizer_state_dict(self, sd: dict) -> None:
-        self.step_count = self.flat.load_adam_state_dict(sd)
+        self.step_count = self.flat.load_adam_state_dict(sd) + self.skipped_steps()
         g = sd["param_groups"][0]
         self.lr, self.betas, self.eps = g["lr"], tuple(g["betas"]), g["eps"]
         self.wd = g.get("weight_decay", 0.0)

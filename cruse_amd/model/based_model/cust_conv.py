@@ -187,8 +187,6 @@ class GroupedGRULayer(nn.Module):
         super().__init__()
         assert input_size % groups == 0
         assert hidden_size % groups == 0
-        if not batch_first or not bias:
-            raise RuntimeError("cruse_amd GroupedGRULayer: batch_first, biased GRUs only")
         # dropout: nn.GRU applies it BETWEEN stacked layers only; every group's nn.GRU here has one layer (cust_conv.py:286-287), so the
         # reference's argument has no effect either (torch warns) -- it is accepted and kept in the sub-modules' kwargs
         kwargs = {"bias": bias, "batch_first": batch_first, "dropout": dropout, "bidirectional": bidirectional}
@@ -216,13 +214,34 @@ class GroupedGRULayer(nn.Module):
     def _direction(self, x: Tensor, h0c: Optional[Tensor], suffix: str) -> Tensor:
         params = []
         for layer in self.layers:
-            params += [getattr(layer, "weight_ih_l0" + suffix), getattr(layer, "weight_hh_l0" + suffix),
-                       getattr(layer, "bias_ih_l0" + suffix), getattr(layer, "bias_hh_l0" + suffix)]
+            w_ih, w_hh = getattr(layer, "weight_ih_l0" + suffix), getattr(layer, "weight_hh_l0" + suffix)
+            if layer.bias:
+                b_ih, b_hh = getattr(layer, "bias_ih_l0" + suffix), getattr(layer, "bias_hh_l0" + suffix)
+            else:
+                # nn.GRU(bias=False) (cust_conv.py:262,272) has no bias parameters: the kernels take zero vectors (one shared
+                # buffer, no gradient asked for -- what _GroupedGruFn returns for them is dropped by autograd)
+                b_ih = b_hh = self._zero_bias(w_ih.device)
+            params += [w_ih, w_hh, b_ih, b_hh]
         return _GroupedGruFn.apply(x, self.groups, h0c, *params)
+
+    def _zero_bias(self, device) -> Tensor:
+        z = getattr(self, "_zb", None)
+        if z is None or z.device != device:
+            z = torch.zeros(3 * self.hidden_size, device=device)
+            object.__setattr__(self, "_zb", z)                # (not a buffer: the state dict stays the reference's)
+        return z
 
     def forward(self, input: Tensor, h0: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
         # state [G*D, B, H/g] (:305-306; group-major, direction-minor) -> the kernel's [B, G*H/g] "cat" layout per direction;
         # detached like the reference's (:319)
+        if not self.batch_first:
+            # [T, B, I] (cust_conv.py:306): the kernels are batch-major -- one device transposition in, one out; the state
+            # layout [G*D, B, H/g] does not depend on batch_first (torch)
+            y, hn = self._forward_bf(input.transpose(0, 1), h0)
+            return y.transpose(0, 1).contiguous(), hn
+        return self._forward_bf(input, h0)
+
+    def _forward_bf(self, input: Tensor, h0: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
         B, D, g, Hg = input.shape[0], self.num_directions, self.groups, self.hidden_size
         h0d = [None] * D
         if h0 is not None:

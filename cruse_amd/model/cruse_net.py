@@ -267,7 +267,21 @@ def _fwd_chunks(prec, Hg: int, g: int, T: int, slot: int, x_bf16) -> int:
     n = int(config.get().fwd_chunks or 0)
     if n < 2 or slot != 0 or x_bf16 is None or not _gi_takes_bf16_copy(prec, Hg) or T < 64 * n:
         return 1
+    if torch.cuda.is_current_stream_capturing():
+        # EXPERIMENTAL option, eager launches only: under HIP-graph capture the forked auxiliary stream's first kernel
+        # node once replayed without its input rows; a dummy first node hid that, the cause was never established -- so the
+        # captured step runs the single-launch form (same results: the chunks reproduce it bit for bit)
+        global _CHUNK_CAPTURE_WARNED
+        if not _CHUNK_CAPTURE_WARNED:
+            import sys
+            print("[cruse_amd] EngineConfig.fwd_chunks is ignored under HIP-graph capture (experimental, eager launches only)",
+                  file=sys.stderr, flush=True)
+            _CHUNK_CAPTURE_WARNED = True
+        return 1
     return n
+
+
+_CHUNK_CAPTURE_WARNED = False
 
 
 def _ggru_forward_chunked(x, x_bf16, P, prefix, g, Hg, prec, save, nch, ctx, before_last_launch):

@@ -7,7 +7,7 @@ tensors in frame-major [B,T,C,F] layout unless stated.
 from __future__ import annotations
 
 import ctypes
-from typing import List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence
 
 import torch
 
@@ -193,11 +193,26 @@ def _ws(key, nbytes: int, device) -> torch.Tensor:
         # never clears (include/cruse_hip.h, cruse_gru_seq_fwd); a grown buffer inherits the old header
         buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
         if old is not None:
-            _ws_retired.append((key, old))
-            if key == "gru":
-                buf[:256].copy_(old[:256])
+            _ws_retired.append((key, old))           # (graphs captured on the old buffer keep it alive)
         _wgrad_ws[(key, device)] = buf
     return buf
+
+
+_gru_hdr: Dict[torch.device, torch.Tensor] = {}
+
+
+def gru_header(device) -> torch.Tensor:
+    """The STICKY 256-byte status header of the recurrence kernels (word 0: a hand-off timed out; bytes 64.. / 128..: the
+    s_memtime stamps of the gru_dbg = 32 instances) -- ONE tensor per device for the life of the process, never regrown:
+    HIP graphs captured before the panel scratch grew for a larger batch keep writing their time-outs where step_health and
+    the guarded Adam look (the header used to be the first 256 bytes of the regrowable workspace)."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    h = _gru_hdr.get(device)
+    if h is None:
+        h = _gru_hdr[device] = torch.zeros(256, dtype=torch.uint8, device=device)
+    return h
 
 
 WGRAD_PREC = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "valu": -1}
@@ -478,15 +493,15 @@ def _gru_ws(B, G, Hg, dev, slot: int):
     status word, so one word still guards the optimizer step.  Slots STEP_SLOT0.. are carved from one buffer
     (gru_step_ws_clear)."""
     nbytes = lib.cruse_gru_ws_bytes(B, G, Hg)
-    ws = _ws("gru", nbytes, dev)
+    status = gru_header(dev).data_ptr()
     if slot == 0:
-        return ws.data_ptr() + 256, ws.data_ptr()
+        return _ws("gru", nbytes, dev).data_ptr() + 256, status
     if STEP_SLOT0 <= slot < STEP_SLOT0 + STEP_SLOTS:
         per = (nbytes - 256 + 255) // 256 * 256
         buf = _ws(("gru_step", per), per * STEP_SLOTS, dev)
-        return buf.data_ptr() + (slot - STEP_SLOT0) * per, ws.data_ptr()
+        return buf.data_ptr() + (slot - STEP_SLOT0) * per, status
     panels = _ws(("gru_panels", slot), nbytes - 256, dev)
-    return panels.data_ptr(), ws.data_ptr()
+    return panels.data_ptr(), status
 
 
 def gru_step_ws_clear(B, G, Hg, dev) -> None:
@@ -629,30 +644,22 @@ def gru_gate_grads_bf16(dh, coef, an, rows, G, Hg, db_ih, db_hh, want_dgi=True, 
 
 def gru_status() -> int:
     """0 if no recurrence hand-off EVER timed out on any device of this process (synchronises).  The status word is
-    sticky: neither the library nor later launches clear it (gru_status_reset does)."""
+    sticky: neither the library nor later launches clear it (gru_status_reset and the per-step latch of step_health do)."""
     bad = 0
-    for (key, _dev), buf in _wgrad_ws.items():
-        if key == "gru":
-            bad |= int(buf[:4].view(torch.int32).item())
-    for key, buf in _ws_retired:                       # graphs captured before the workspace grew still report here
-        if key == "gru":
-            bad |= int(buf[:4].view(torch.int32).item())
+    for h in _gru_hdr.values():
+        bad |= int(h[:4].view(torch.int32).item())
     return bad
 
 
-def gru_status_word(device, B: int, G: int, Hg: int) -> torch.Tensor:
-    """The device status word itself (uint8[4] view) -- handed to adam_step as skip_flag so that a step whose
-    recurrence timed out never reaches the parameters.  Allocates the workspace for this shape if needed."""
-    return _ws("gru", lib.cruse_gru_ws_bytes(B, G, Hg), torch.device(device))[:4]
+def gru_status_word(device, B: int = 0, G: int = 0, Hg: int = 0) -> torch.Tensor:
+    """The device status word itself (uint8[4] view of gru_header) -- handed to step_health / adam_step as skip_flag so that
+    a step whose recurrence timed out never reaches the parameters.  (B, G, Hg are accepted for the round-3 callers.)"""
+    return gru_header(device)[:4]
 
 
 def gru_status_reset() -> None:
-    for (key, _dev), buf in _wgrad_ws.items():
-        if key == "gru":
-            buf[:256].zero_()
-    for key, buf in _ws_retired:
-        if key == "gru":
-            buf[:256].zero_()
+    for h in _gru_hdr.values():
+        h.zero_()
 
 
 def check_gru_status() -> None:
@@ -722,6 +729,18 @@ def sisnr_bwd(x, s, coef, grad_scale=1.0):
     return dx
 
 
+def wave_l1_mse(est, ref, mse: bool, want_grad=True):
+    """-> (loss_sum f64[1], dest or None): torch.nn.L1Loss / MSELoss(reduction="mean") terms on waveforms -- the loss is
+    loss_sum / est.numel(), dest its gradient wrt est (train_base/loss.py:3-4)."""
+    if est.shape != ref.shape:
+        raise RuntimeError(f"Dimension mismatch when calculate {'mse' if mse else 'l1'} loss, {tuple(est.shape)} vs {tuple(ref.shape)}")
+    n = est.numel()
+    loss = torch.empty(1, device=est.device, dtype=torch.float64)
+    dest = torch.empty_like(est) if want_grad else None
+    check(lib.cruse_wave_l1_mse(_p(est), _p(ref), n, 1 if mse else 0, 1.0 / n, _p(loss), _p(dest), _stream()))
+    return loss, dest
+
+
 def deepfilter_fwd(xr, xi, hr, hi, f_dim, t_dim, out=None):
     B, F, T = xr.shape
     o_r, o_i = (torch.empty_like(xr), torch.empty_like(xr)) if out is None else out
@@ -749,13 +768,16 @@ def axpby(out, x, y, a, b):
 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, max_norm=0.0, gsumsq=None,
-              skip_flag=None, loss_check=None, skipped=None):
+              skip_flag=None, loss_check=None, skipped=None, loss_sum=None, loss_scale=1.0, loss_acc=None):
     """Fused Adam over flat buffers; the optional device-side guards are described at cruse_adam_step_guarded.
-    skip_flag: a uint8[4k] / int32[k] tensor of k status words (any non-zero word skips the step)."""
+    skip_flag: a uint8[4k] / int32[k] tensor of k status words (any non-zero word skips the step).  `step` counts the CALLS;
+    with `skipped` the bias corrections use step - skipped[0].  loss_acc f64[2] += (loss_sum * loss_scale, 1) when applied."""
     nw = 0 if skip_flag is None else skip_flag.numel() * skip_flag.element_size() // 4
+    if loss_acc is not None and (loss_acc.dtype != torch.float64 or loss_acc.numel() < 2):
+        raise RuntimeError("adam_step: loss_acc must be an f64[2] tensor (sum, applied steps)")
     check(lib.cruse_adam_step_guarded(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
                                       grad_scale, max_norm, _p(gsumsq), _p(skip_flag), nw, _p(loss_check), _p(skipped),
-                                      _stream()))
+                                      _p(loss_sum), float(loss_scale), _p(loss_acc), _stream()))
 
 
 def step_health(gru_status, loss_sum, health, loss_acc=None, loss_scale=1.0) -> None:

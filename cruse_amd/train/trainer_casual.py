@@ -7,8 +7,9 @@ no DistributedDataParallel wrapper; BatchNorm statistics stay rank-local as with
 (base_trainer.py:31, no SyncBN) and rank 0's are the ones saved (base_trainer.py:206-207).
 
 What the reference's knobs do here:
-  loss_function               -> the fused engine loss named by its `.cruse_loss` tag (train_base/loss.py); a loss
-                                 without a fused form (l1_loss, mse_loss) raises
+  loss_function               -> the fused engine loss named by its `.cruse_loss` tag (train_base/loss.py); l1_loss /
+                                 mse_loss (torch.nn.L1Loss / MSELoss instances) -> the waveform losses "l1" / "mse"
+  meta.use_amp                -> true: precision "bf16", false: "f32" (printed); meta.precision overrides (base_trainer.py:41-42)
   optimizer (torch Adam)      -> lr / betas / eps / weight_decay are read from it; its state_dict() layout is what
                                  latest_model.tar stores and what resume loads (base_trainer.py:167,199-203)
   clip_grad_norm_value        -> torch.nn.utils.clip_grad_norm_ semantics, folded into the fused Adam (base_trainer.py:75)
@@ -66,14 +67,29 @@ class Trainer:
         self.save_dir = os.path.join(config["meta"]["save_dir"], config["meta"].get("experiment_name", "exp"))
         self.checkpoints_dir = os.path.join(self.save_dir, "checkpoints")
         tag = getattr(loss_function, "cruse_loss", None)
+        if tag is None and isinstance(loss_function, (torch.nn.L1Loss, torch.nn.MSELoss)):
+            # l1_loss / mse_loss of train_base/loss.py:3-4 (torch.nn.L1Loss / MSELoss): waveform loss through the iSTFT
+            if loss_function.reduction != "mean":
+                raise RuntimeError(f"{type(loss_function).__name__}(reduction={loss_function.reduction!r}): the fused form is "
+                                   "reduction='mean' (the torch default)")
+            tag = ("l1" if isinstance(loss_function, torch.nn.L1Loss) else "mse", {})
         if tag is None:
-            raise RuntimeError(f"loss_function {loss_function!r} has no fused HIP form: use wo_male_loss, si_snr_loss or "
-                               "sdnr_loss from train_base.loss (config [loss_function].name)")
+            raise RuntimeError(f"loss_function {loss_function!r} has no fused HIP form: use l1_loss, mse_loss, wo_male_loss, "
+                               "si_snr_loss or sdnr_loss from train_base.loss (config [loss_function].name)")
         loss_name, loss_kwargs = tag
+        # meta.use_amp (base_trainer.py:41-42: GradScaler(enabled=use_amp)) has no autocast / scaler here; what mixed precision
+        # means on this path is the bf16-operand MFMA mode (f32 storage, statistics and accumulation, no loss scaling needed).
+        # meta.precision (this repo) wins; otherwise use_amp = true -> "bf16", false -> "f32" (the reference's arithmetic).
+        precision = config["meta"].get("precision", None)
+        if precision is None and "use_amp" in config["meta"]:
+            precision = "bf16" if config["meta"]["use_amp"] else "f32"
+            if rank == 0:
+                print(f"[cruse_amd] meta.use_amp = {bool(config['meta']['use_amp'])} -> precision '{precision}' "
+                      "(bf16 MFMA operands with f32 accumulation / exact f32; set meta.precision to choose explicitly)", flush=True)
         g = optimizer.param_groups[0]
         self.engine = TrainEngine(self.model, lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"],
                                   weight_decay=g.get("weight_decay", 0.0), n_fft=ac["n_fft"], hop=ac["hop_length"],
-                                  precision=config["meta"].get("precision", None),
+                                  precision=precision,
                                   use_graph=_graph_mode(config["meta"].get("hip_graph", "auto")), loss=loss_name,
                                   clip_grad_norm=float(self.clip_grad_norm_value or 0.0), **loss_kwargs)
         self.start_epoch = 1

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CRUSE_ABI_VERSION 6
+#define CRUSE_ABI_VERSION 7
 
 enum {
     CRUSE_OK = 0,
@@ -412,6 +412,11 @@ int cruse_sisnr_fwd(const float* x, const float* s, int B, int L, float eps,
 /* dx = grad_scale * d loss / d x */
 int cruse_sisnr_bwd(const float* x, const float* s, const float* coef, int B, int L, float grad_scale,
                     float* dx, void* stream);
+/* l1_loss / mse_loss = torch.nn.L1Loss / MSELoss (train_base/loss.py:3-4; selected by tools/train_stand.py:73-75) on waveforms:
+ * loss_sum[0] = sum |est - ref| (mse = 0) or sum (est - ref)^2 (mse = 1) over n samples (f64; zeroed by the callee);
+ * dest (optional, n floats) = grad_scale * sign(est - ref)  resp.  grad_scale * 2 (est - ref): pass 1/n for reduction "mean". */
+int cruse_wave_l1_mse(const float* est, const float* ref, long long n, int mse, float grad_scale,
+                      double* loss_sum, float* dest, void* stream);
 
 /* ---- DeepFilter head (model/deep_filter.py:15-41, BASELINE config 4) --------------- */
 /* out[b,f,t] = sum over the (2*f_dim+1) x (2*t_dim+1) neighbourhood of X*H (complex, zero outside); all
@@ -548,12 +553,16 @@ int cruse_adam_step(float* p, const float* g, float* m, float* v, long long n,
  *                scaled by min(1, max_norm / (sqrt(gsumsq)*grad_scale + 1e-6)) = torch.nn.utils.clip_grad_norm_
  *                (train_base/trainer/base_trainer.py:75 `clip_grad_norm_value`);
  *   skipped    : skipped[0] += 1 for every skipped step; with n_skip_words > 1 also skipped[1 + i] += 1 for each
- *                non-zero word i (per-reason counters). */
+ *                non-zero word i (per-reason counters).  The bias corrections use step - skipped[0] (the value BEFORE this
+ *                call): a skipped step does not advance Adam's step, as if torch.optim.Adam.step() had not been called;
+ *   loss_sum / loss_acc (ABI 7): when the step is APPLIED, loss_acc[0] += *loss_sum * loss_scale and loss_acc[1] += 1 --
+ *                the running epoch loss counts exactly the steps that reached the parameters (a timed-out step's loss is
+ *                garbage even when finite), each with its own normalisation. */
 int cruse_adam_step_guarded(float* p, const float* g, float* m, float* v, long long n,
                             float lr, float beta1, float beta2, float eps, float weight_decay,
                             int step, float grad_scale, float max_norm, const double* gsumsq,
                             const unsigned* skip_flag, int n_skip_words, const double* loss_check, unsigned* skipped,
-                            void* stream);
+                            const double* loss_sum, double loss_scale, double* loss_acc, void* stream);
 /* Per-step health of a training step, decided on the device (no reference counterpart: train/trainer_casual.py is empty
  * and base_trainer.py has no guard).  health[0] = the GRU status word was set -- and CLEARS it, so one transient
  * hand-off time-out costs the step it happened in, not every later one; health[1] = *loss_sum is not finite.

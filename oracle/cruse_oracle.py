@@ -322,6 +322,13 @@ def train_step_loss(model: nn.Module, noisy: torch.Tensor, clean: torch.Tensor,
         spec = torch.view_as_complex(est.contiguous()).transpose(1, 2)          # [B,F,T]
         wave = istft(spec, n_fft, hop, win, length=noisy.shape[1])
         loss = si_snr_loss(wave, clean)
+    elif loss_mode in ("L1", "MSE"):
+        # train_base/loss.py:3-4: l1_loss / mse_loss are torch.nn.L1Loss / MSELoss, instantiated by tools/train_stand.py:73-75.
+        # DECISION (the reference never wrote the trainer that calls them): like si_snr_loss they compare WAVEFORMS -- the
+        # enhanced waveform of PreProcess.reconstruction (utils/utils.py:443-455) against the clean clip, default reduction "mean"
+        spec = torch.view_as_complex(est.contiguous()).transpose(1, 2)          # [B,F,T]
+        wave = istft(spec, n_fft, hop, win, length=noisy.shape[1])
+        loss = (torch.nn.L1Loss() if loss_mode == "L1" else torch.nn.MSELoss())(wave, clean)
     else:
         raise ValueError(loss_mode)
     return loss, dict(mask=mask, est=est, feats=feats, ref=ref, wave=wave)

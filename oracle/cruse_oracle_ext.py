@@ -270,23 +270,24 @@ class CRUSE4MagAddSkipUpsample(nn.Module):
 # a10: GroupedGRULayer / GroupGRU
 # ----------------------------------------------------------------------------------------------------------------------
 class GroupedGRULayer(nn.Module):
-    """cust_conv.py:250-325 (batch_first).  bidirectional / dropout go to every group's nn.GRU as the reference passes them
+    """cust_conv.py:250-325.  batch_first / bias / bidirectional / dropout go to every group's nn.GRU as the reference passes them
     (:268-273, :286-287); the state is [G*D, B, H/g], group-major (:305-306, :316-319)."""
 
-    def __init__(self, input_size, hidden_size, groups, dropout=0.0, bidirectional=False):
+    def __init__(self, input_size, hidden_size, groups, dropout=0.0, bidirectional=False, batch_first=True, bias=True):
         super().__init__()
         self.input_size, self.hidden_size, self.groups = input_size // groups, hidden_size // groups, groups
         self.num_directions = 2 if bidirectional else 1
+        self.batch_first = batch_first                      # (:259-277: both go to every group's nn.GRU)
         import warnings
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")                 # (dropout on a one-layer nn.GRU: a warning and no effect)
-            self.layers = nn.ModuleList(nn.GRU(self.input_size, self.hidden_size, batch_first=True, dropout=dropout,
-                                               bidirectional=bidirectional) for _ in range(groups))
+            self.layers = nn.ModuleList(nn.GRU(self.input_size, self.hidden_size, batch_first=batch_first, bias=bias,
+                                               dropout=dropout, bidirectional=bidirectional) for _ in range(groups))
 
     def forward(self, input, h0=None):
         D = self.num_directions
         if h0 is None:
-            h0 = torch.zeros(self.groups * D, input.shape[0], self.hidden_size)
+            h0 = torch.zeros(self.groups * D, input.shape[0 if self.batch_first else 1], self.hidden_size)      # :309-312
         outs, states = [], []
         for i, layer in enumerate(self.layers):
             o, s = layer(input[..., i * self.input_size:(i + 1) * self.input_size], h0[i * D:(i + 1) * D].detach())

@@ -335,6 +335,37 @@ def test_grouped_gru_layer_bidirectional(golden, name, grp):
         assert rel_l2(pp.grad, po.grad) < 2e-3, n
 
 
+@pytest.mark.parametrize("name,kw", [("tb_g2", dict(batch_first=False)), ("tb_g2_nobias", dict(batch_first=False, bias=False)),
+                                     ("bt_g2_nobias", dict(bias=False))])
+def test_grouped_gru_layer_time_major_and_bias_free(golden, name, kw):
+    """GroupedGRULayer(batch_first=False) / (bias=False) (cust_conv.py:259-277,303-325; fixture G23 = the reference's class as
+    shipped): [T, B, I] input and output, state [G, B, H/g] either way; the bias-free layer has no bias parameters (state-dict
+    keys as the reference's).  Outputs with and without an initial state vs the fixture, gradients vs oracle autograd."""
+    from cruse_amd.model.based_model.cust_conv import GroupedGRULayer
+    from oracle import cruse_oracle_ext as X
+    g = golden("g23_grouped_gru_layouts.npz")
+    o = X.GroupedGRULayer(128, 128, 2, **kw)
+    p = _load_like(GroupedGRULayer(128, 128, 2, **kw), o, scale=2.0)
+    assert list(p.state_dict().keys()) == list(o.state_dict().keys())
+    assert ("bias" in " ".join(p.state_dict().keys())) == kw.get("bias", True)
+    x_tb = torch.from_numpy(g["x_tb"])
+    x = x_tb if not kw.get("batch_first", True) else x_tb.transpose(0, 1).contiguous()
+    st = torch.from_numpy(g[f"{name}/state_in"])
+    y, s = p(x.cuda(), st.cuda())
+    assert y.shape == x.shape[:2] + (128,)
+    assert rel_l2(y, torch.from_numpy(g[f"{name}/y"])) < 1e-5 and rel_l2(s, torch.from_numpy(g[f"{name}/state"])) < 1e-5
+    y0, _ = p(x.cuda())
+    assert rel_l2(y0, torch.from_numpy(g[f"{name}/y0"])) < 1e-5
+    xo = x.clone().requires_grad_(True); xp = x.clone().cuda().requires_grad_(True)
+    torch.manual_seed(2)
+    w = torch.randn(y.shape)
+    (o(xo, st)[0] * w).sum().backward()
+    (p(xp, st.cuda())[0] * w.cuda()).sum().backward()
+    assert rel_l2(xp.grad, xo.grad) < 5e-4
+    for (n, po), (_, pp) in zip(o.named_parameters(), p.named_parameters()):
+        assert rel_l2(pp.grad, po.grad) < 2e-3, n
+
+
 @pytest.mark.parametrize("prec,Hg,G", [("f32", 128, 2), ("bf16", 640, 1), ("bf16", 160, 4), ("bf16x3", 96, 1)])
 def test_recurrence_in_time_chunks_equals_one_launch(prec, Hg, G):
     """cruse_gru_seq_fwd_ex / _bwd_ex: a sequence run as consecutive time chunks (forward: the state carried through h;

@@ -178,6 +178,33 @@ def test_time_domain_training_step_vs_oracle():
             assert rel_l2(eng.flat.G[n], po.grad) <= 5e-3, n
 
 
+@pytest.mark.parametrize("mode", ["L1", "MSE"])
+def test_l1_mse_training_step_vs_oracle(mode):
+    """l1_loss / mse_loss (train_base/loss.py:3-4 = torch.nn.L1Loss / MSELoss, reachable through tools/train_stand.py:73-75):
+    STFT -> unet_2 -> mask -> iSTFT -> torch's own criterion on the waveform in the oracle; the engine's fused "l1" / "mse"
+    step gives the same loss and gradients.  Kernel alone too (odd length: the tail samples)."""
+    from cruse_amd import ops
+    from cruse_amd.engine import TrainEngine
+    from oracle import cruse_oracle as O
+    crit = torch.nn.L1Loss() if mode == "L1" else torch.nn.MSELoss()
+    x = torch.randn(3, 1001, requires_grad=True); s_ = torch.randn(3, 1001)
+    x.data[0, :5] = s_[0, :5]                                             # exact ties: sign(0) = 0 as in torch
+    want = crit(x, s_); want.backward()
+    ls, dx = ops.wave_l1_mse(x.detach().cuda(), s_.cuda(), mode == "MSE")
+    assert abs(float(ls) / x.numel() - float(want)) <= 1e-6 * abs(float(want)) and rel_l2(dx, x.grad) < 1e-6
+    o, m = _oracle_and_product(1)
+    eng = TrainEngine(m, lr=1e-3, use_graph=False, loss=mode.lower())
+    o.train()
+    noisy, clean = O.synth_pair(2, 3200, seed=92)
+    loss, aux = O.train_step_loss(o, noisy, clean, loss_mode=mode)
+    loss.backward()
+    ls = eng.step(noisy.cuda(), clean.cuda())
+    assert abs(eng.loss_value(ls) - float(loss.detach())) <= 1e-4 * abs(float(loss.detach()))
+    for n, po in o.named_parameters():
+        if n in eng.flat.G and not (n.endswith(".bias") and n.startswith("conv") and n != "conv1_t.bias"):
+            assert rel_l2(eng.flat.G[n], po.grad) <= 5e-3, n
+
+
 def test_deepfilter_golden_and_grad(golden):
     """DeepFilter(1,5) (model/deep_filter.py:15-41): output from the reference's (repaired) code, gradients vs oracle."""
     from cruse_amd.model.deep_filter import DeepFilter

@@ -109,7 +109,7 @@ def test_train_stand_end_to_end_save_and_resume(tmp_path):
     assert "Model preloaded successfully" in out3 and "validation loss" in out3
 
 
-@pytest.mark.parametrize("loss,args", [("si_snr_loss", ""), ("sdnr_loss", "[loss_function.args]\nsnr = 5.0\nbeta = 20.0")])
+@pytest.mark.parametrize("loss,args", [("si_snr_loss", ""), ("sdnr_loss", "[loss_function.args]\nsnr = 5.0\nbeta = 20.0"), ("l1_loss", "")])
 def test_train_stand_honours_loss_function_name(tmp_path, loss, args):
     cfg = _write(tmp_path, "l_" + loss, loss=loss, loss_args=args, epochs=1, port=29554)
     out = _cli(cfg, port=29554)
@@ -119,16 +119,32 @@ def test_train_stand_honours_loss_function_name(tmp_path, loss, args):
         assert abs(v) > 1.0                     # SI-SNR loss is a dB figure, not the O(0.4) WO-MALE value
 
 
-def test_trainer_refuses_losses_without_fused_form():
+def test_trainer_maps_reference_losses_and_use_amp(capsys):
+    """l1_loss / mse_loss of train_base/loss.py:3-4 select the fused waveform losses; a loss without a fused form raises;
+    meta.use_amp (base_trainer.py:41-42) maps to the precision mode with a message, meta.precision overrides it."""
     from cruse_amd.model.cruse_net import unet_2
     from cruse_amd.train.trainer_casual import Trainer
     import train_base.loss as L
-    m = unet_2(rnn_groups=1)
-    cfg = {"acoustics": {"n_fft": 320, "hop_length": 160}, "trainer": {"train": {"epochs": 1}},
-           "meta": {"save_dir": "/tmp/cruse_t", "precision": "f32"}}
+
+    def make(loss_fn, meta):
+        m = unet_2(rnn_groups=1)
+        cfg = {"acoustics": {"n_fft": 320, "hop_length": 160}, "trainer": {"train": {"epochs": 1}},
+               "meta": dict({"save_dir": "/tmp/cruse_t"}, **meta)}
+        return Trainer(dist=None, rank=0, config=cfg, resume=False, only_validation=False, model=m, loss_function=loss_fn,
+                       optimizer=torch.optim.Adam(m.parameters()), train_dataloader=None, validation_dataloader=None)
+    t1 = make(L.l1_loss(), {"precision": "f32"})
+    assert t1.engine.loss == "l1" and t1.engine.prec == "f32"
+    t2 = make(L.mse_loss(), {"use_amp": True})
+    assert t2.engine.loss == "mse" and t2.engine.prec == "bf16"
+    assert "meta.use_amp = True -> precision 'bf16'" in capsys.readouterr().out
+    t3 = make(L.wo_male_loss(), {"use_amp": False})
+    assert t3.engine.prec == "f32"
+    t4 = make(L.wo_male_loss(), {"use_amp": True, "precision": "f32"})
+    assert t4.engine.prec == "f32"                                        # the explicit key wins
+    with pytest.raises(RuntimeError, match="reduction"):
+        make(torch.nn.L1Loss(reduction="sum"), {"precision": "f32"})
     with pytest.raises(RuntimeError, match="no fused HIP form"):
-        Trainer(dist=None, rank=1, config=cfg, resume=False, only_validation=False, model=m, loss_function=L.l1_loss(),
-                optimizer=torch.optim.Adam(m.parameters()), train_dataloader=None, validation_dataloader=None)
+        make(torch.nn.SmoothL1Loss(), {"precision": "f32"})
 
 
 def test_engine_clip_grad_norm_matches_torch():

@@ -239,3 +239,27 @@ def test_oracle_round3_fixtures(golden):
         O.closed_form_init(m)
         m.train()
         assert torch.equal(m(torch.from_numpy(g["x"])), torch.from_numpy(g[f"g{grp}/mask_train"]))
+
+
+def test_oracle_round4_fixtures(golden):
+    """G23: GroupedGRULayer(batch_first=False) / (bias=False) as shipped (tests/golden/make_golden_r4.py); the waveform L1 / MSE
+    step of the oracle is torch's own criterion on iSTFT(mask * N) (a decision, stated in oracle.train_step_loss)."""
+    from oracle import cruse_oracle as O
+    from oracle import cruse_oracle_ext as X
+    g = golden("g23_grouped_gru_layouts.npz")
+    x_tb = torch.from_numpy(g["x_tb"])
+    for name, kw in {"tb_g2": dict(batch_first=False), "tb_g2_nobias": dict(batch_first=False, bias=False),
+                     "bt_g2_nobias": dict(bias=False)}.items():
+        m = X.GroupedGRULayer(128, 128, 2, **kw)
+        O.closed_form_init(m, scale=2.0)
+        x = x_tb if not kw.get("batch_first", True) else x_tb.transpose(0, 1).contiguous()
+        y, s = m(x, torch.from_numpy(g[f"{name}/state_in"]))
+        assert torch.equal(y, torch.from_numpy(g[f"{name}/y"])) and torch.equal(s, torch.from_numpy(g[f"{name}/state"])), name
+        assert torch.equal(m(x)[0], torch.from_numpy(g[f"{name}/y0"]))
+    o = O.unet_2(rnn_groups=1)
+    O.closed_form_init(o)
+    o.train()
+    noisy, clean = O.synth_pair(2, 3200, seed=92)
+    for mode, crit in (("L1", torch.nn.L1Loss()), ("MSE", torch.nn.MSELoss())):
+        loss, aux = O.train_step_loss(o, noisy, clean, loss_mode=mode)
+        assert aux["wave"].shape == clean.shape and torch.equal(loss, crit(aux["wave"], clean))

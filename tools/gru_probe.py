@@ -26,8 +26,8 @@ for rnd in range(3):
         tf = timeit(lambda: ops.gru_seq_fwd(gi, ws, bs, B, T, G, Hg, "bf16"))
         if int(m) == 32:                       # phase stamps of the lean forward kernel (workgroup 0 of chain 0)
             ops.gru_seq_fwd(gi, ws, bs, B, T, G, Hg, "bf16"); torch.cuda.synchronize()
-            for (key, _d), buf in ops._wgrad_ws.items():
-                if key == "gru":
+            for buf in ops._gru_hdr.values():
+                if True:
                     st = buf[64:112].view(torch.int64).tolist()
                     n = max(st[5], 1)
                     tot = sum(st[:4])
@@ -36,8 +36,8 @@ for rnd in range(3):
                           f"red read + gates + publish {st[3]/n:.1f} | rest (saves, gi) {tf*1e3/T*0 + 0:.0f}; re-polls per step {st[4]/n:.2f}")
         tb = timeit(lambda: ops.gru_seq_bwd(dout, ws, coef, z, B, T, G, Hg, "bf16"))
         if int(m) in (32, 33, 34, 35):
-            for (key, _d), buf in ops._wgrad_ws.items():
-                if key == "gru":
+            for buf in ops._gru_hdr.values():
+                if True:
                     st = buf[128:176].view(torch.int64).tolist()
                     n = max(st[5], 1)
                     print(f"   rs bwd phases (cycles per step; {tb*1e3/T:.2f} us/step): sweep until tags match {st[0]/n:.0f} | sum + dh + panel write {st[1]/n:.0f} | "

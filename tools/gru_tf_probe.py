@@ -72,14 +72,14 @@ def stamps(B=64, T=401, H=640):
         with ops.options(gru_tf=tf, gru_dbg=32):
             tw = timeit(lambda: ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16")); torch.cuda.synchronize()
             print(f"  (stamped forward instance: {tw * 1e3 / T:.3f} us/step)")
-            for (key, _d), buf in ops._wgrad_ws.items():
-                if key == "gru":
+            for buf in ops._gru_hdr.values():
+                if True:
                     st = buf[64:112].view(torch.int64).tolist(); n = max(st[5], 1)
                     print(f"  gru_tf={tf} fwd phases (cycles/step): sweep {st[0] / n:.0f} | LDS image + barrier {st[1] / n:.0f} | MFMA phase {st[2] / n:.0f}"
                           f" | gates + publish {st[3] / n:.0f} | re-polls {st[4] / n:.2f}")
             ops.gru_seq_bwd(dout, w, coef, z, B, T, 1, H, "bf16"); torch.cuda.synchronize()
-            for (key, _d), buf in ops._wgrad_ws.items():
-                if key == "gru":
+            for buf in ops._gru_hdr.values():
+                if True:
                     st = buf[128:176].view(torch.int64).tolist(); n = max(st[5], 1)
                     print(f"  gru_tf={tf} bwd phases (cycles/step): sweep {st[0] / n:.0f} | sums + dh + panel {st[1] / n:.0f} | barrier {st[2] / n:.0f}"
                           f" | MFMA + publishes {st[3] / n:.0f} | re-polls {st[4] / n:.2f}")

@@ -3,7 +3,8 @@
 Every factory returns a callable usable stand-alone through autograd (HIP kernels underneath) that ALSO carries
 `.cruse_loss = (engine loss name, kwargs)`: train.trainer_casual.Trainer reads it to select the fused loss of
 cruse_amd.engine.TrainEngine, so `[loss_function] name/args` of the TOML is honoured.  l1_loss / mse_loss keep the
-reference's aliases (train_base/loss.py:3-4); they have no fused form and the Trainer refuses them loudly."""
+reference's aliases (train_base/loss.py:3-4): the Trainer recognises the torch.nn.L1Loss / MSELoss instance and runs the
+fused waveform form (engine losses "l1" / "mse": iSTFT(mask * N) against the clean clip, reduction "mean")."""
 import torch
 
 l1_loss = torch.nn.L1Loss
