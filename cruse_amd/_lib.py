@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libcruse_hip.so")
 ABI_VERSION = 7
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16 = 0, 1, 2, 3
 PREC_BY_NAME = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "f16": PREC_F16}
-DT_F32, DT_F16 = 0, 1
+DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 
 _T = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "q": ctypes.c_longlong, "d": ctypes.c_double, "c": ctypes.c_char_p,
       "z": ctypes.c_size_t}
@@ -29,15 +29,15 @@ SIGNATURES = {
     "cruse_stft_fwd": ("piiiipppifp", "i"),
     "cruse_istft_fwd": ("ppiiiiipp", "i"),
     "cruse_istft_bwd": ("piiiiippp", "i"),
-    "cruse_conv_gather": ("ppppiiiiiiiiiiiiip", "i"),
-    "cruse_conv_scatter2": ("ppppiiiiiiiiiiip", "i"),
+    "cruse_conv_gather": ("ppppiiiiiiiiiiiiiip", "i"),
+    "cruse_conv_scatter2": ("ppppiiiiiiiiiiiip", "i"),
     "cruse_conv_gather_bnstats": ("ppppiiiiiiiiiipip", "i"),
     "cruse_conv_scatter2_bnstats": ("ppppiiiiiiiiipip", "i"),
     "cruse_conv_mfma_stamps": ("p", "i"),
-    "cruse_conv_gather_bnbwd": ("pppiiiiiiiiiiiipppppipip", "i"),
-    "cruse_conv_scatter2_bnbwd": ("pppiiiiiiiiiipppppipip", "i"),
+    "cruse_conv_gather_bnbwd": ("pppiiiiiiiiiiiipppppipiip", "i"),
+    "cruse_conv_scatter2_bnbwd": ("pppiiiiiiiiiipppppipiip", "i"),
     "cruse_conv_wgrad_ws_bytes": ("iii", "z"),
-    "cruse_conv_wgrad": ("pppiiiiiiiiiipp", "i"),
+    "cruse_conv_wgrad": ("pppiiiiiiiiiiiipp", "i"),
     "cruse_channel_sum": ("pqiipp", "i"),
     "cruse_col_sum": ("pqiipp", "i"),
     "cruse_bn_stats": ("pqiipip", "i"),
@@ -46,7 +46,7 @@ SIGNATURES = {
     "cruse_bn_eval_stats": ("ppifppp", "i"),
     "cruse_bn_act_fwd": ("pppppppqiiip", "i"),
     "cruse_bn_act_bwd_reduce": ("ppppppqiiipip", "i"),
-    "cruse_bn_act_bwd_apply": ("pppppppiqiiiippppp", "i"),
+    "cruse_bn_act_bwd_apply": ("pppppppiqiiiipipppp", "i"),
     "cruse_ln_fwd": ("ppppppppqiifiqqp", "i"),
     "cruse_ln_bwd": ("pppppqiipppp", "i"),
     "cruse_gemm": ("iiiiipipipipiiiip", "i"),

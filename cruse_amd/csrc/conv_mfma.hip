@@ -38,6 +38,7 @@ __device__ unsigned long long g_cm_stamps[8];
 
 struct CMArgs {
     int tdbg, kint, swp_ok;
+    int x_bf16;                                  // x holds bf16 elements (a backward-only tensor stored in bf16): widened while staging
     const float* x; const float* w; const float* bias; float* y;
     int B, T, Cin, Fin, Cout, Fout;
     int S, OS, nclass, halo_lo;                  // input bin stride, output bin stride, classes, frames of halo before t0
@@ -108,7 +109,9 @@ __device__ __forceinline__ Frag<PREC> get_frag(const typename OpStore<PREC>::ele
 // stores and exposes a full memory round trip per N-tile (the accumulating data gradients of the encoder ran at half the
 // speed of the plain ones; with the backward statistics read that way the step got 0.15 ms SLOWER than with the separate
 // reduce pass, r03).
-template <int PREC, int MT, int EPI, int NV, int NW, int SWM>
+template <int PREC, int MT, int EPI, int NV, int NW, int SWM, bool XB>
+// (XB: x holds bf16 elements -- a compile-time variant, so that the f32 instances stay instruction for instruction what they were:
+//  this kernel sits at its register cap and a run-time dtype branch cost the f32 forward convs 10 %)
 // (two 5-wave workgroups per CU need 4 wave slots on some SIMD: the 5-wave variants are held to 128 registers)
 __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMArgs a) {
     constexpr bool STATS = EPI != 0;
@@ -209,6 +212,23 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
     auto prefetch = [&](int tile) {
         const int b = tile / ntile;
         const int t0 = (tile - b * ntile) * TFM;
+        // (the dtype branch sits OUTSIDE the slot loop: a branch around every load made the compiler wait for each load at the
+        //  join -- the f32 path lost its batch of loads in flight, 0.3 ms per step over the convolutions)
+        if constexpr (XB) {                                // 8 bf16 = 16 bytes per slot (rowlen % 8 == 0, host-checked): half the slots
+            const __bf16* srcb = reinterpret_cast<const __bf16*>(a.x) + ((long long)b * a.T + (t0 - a.halo_lo)) * rowlen;
+#pragma unroll
+            for (int q = 0; q < (NV + 1) / 2; ++q) {
+                const int i = tid + NTHR * q;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < (nvec >> 1)) {
+                    const int r = (i * 8) / rowlen;
+                    const int t = t0 - a.halo_lo + r;
+                    if (t >= 0 && t < a.T) v = *reinterpret_cast<const float4*>(srcb + i * 8);
+                }
+                pre[q] = v;
+            }
+            return;
+        }
         const float* src = a.x + ((long long)b * a.T + (t0 - a.halo_lo)) * rowlen;
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
@@ -228,10 +248,25 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
         const int b = tile / ntile;
         const int t0 = (tile - b * ntile) * TFM;
         __syncthreads();                                   // previous tile's reads of xl are done
+        if constexpr (XB) {
 #pragma unroll
-        for (int q = 0; q < NV; ++q) {
-            const int i = tid + NTHR * q;
-            if (i < nvec) *reinterpret_cast<float4*>(xl + i * 4) = pre[q];
+            for (int q = 0; q < (NV + 1) / 2; ++q) {
+                const int i = tid + NTHR * q;
+                if (i < (nvec >> 1)) {
+                    const unsigned w0 = __float_as_uint(pre[q].x), w1 = __float_as_uint(pre[q].y), w2 = __float_as_uint(pre[q].z),
+                                   w3 = __float_as_uint(pre[q].w);
+                    *reinterpret_cast<float4*>(xl + i * 8) = make_float4(__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xffff0000u),
+                                                                         __uint_as_float(w1 << 16), __uint_as_float(w1 & 0xffff0000u));
+                    *reinterpret_cast<float4*>(xl + i * 8 + 4) = make_float4(__uint_as_float(w2 << 16), __uint_as_float(w2 & 0xffff0000u),
+                                                                             __uint_as_float(w3 << 16), __uint_as_float(w3 & 0xffff0000u));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const int i = tid + NTHR * q;
+                if (i < nvec) *reinterpret_cast<float4*>(xl + i * 4) = pre[q];
+            }
         }
         __syncthreads();
         // EPI == 2: old output values / pre-BN values of this lane's MT x 4 outputs of an N-tile
@@ -585,10 +620,20 @@ int launch_mt(const CMArgs& a, int grid, size_t lds, int nw, hipStream_t s) {
             swm = 2;                             // (plain-epilogue scatter launches keep the class-by-class form)
     }
     int rc;
+#define CM_LAUNCH5(MTV, STV, NVV, NWV, SWV, XBV)                                                           \
+    do {                                                                                                   \
+        if ((rc = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(conv_mfma_kernel<PREC, MTV, STV, NVV, NWV, SWV, XBV>), lds, "conv_mfma"))) return rc; \
+        hipLaunchKernelGGL((conv_mfma_kernel<PREC, MTV, STV, NVV, NWV, SWV, XBV>), dim3(grid), dim3(NWV * 64), lds, s, a); \
+    } while (0)
+    // bf16 inputs: the data-gradient forms of the bf16 mode only (EPI 0 / 2, PREC bf16)
 #define CM_LAUNCH4(MTV, STV, NVV, NWV, SWV)                                                                \
     do {                                                                                                   \
-        if ((rc = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(conv_mfma_kernel<PREC, MTV, STV, NVV, NWV, SWV>), lds, "conv_mfma"))) return rc; \
-        hipLaunchKernelGGL((conv_mfma_kernel<PREC, MTV, STV, NVV, NWV, SWV>), dim3(grid), dim3(NWV * 64), lds, s, a); \
+        if constexpr (STV != 1 && PREC == CRUSE_PREC_BF16) {                                               \
+            if (a.x_bf16) CM_LAUNCH5(MTV, STV, NVV, NWV, SWV, true);                                       \
+            else CM_LAUNCH5(MTV, STV, NVV, NWV, SWV, false);                                               \
+        } else {                                                                                           \
+            CM_LAUNCH5(MTV, STV, NVV, NWV, SWV, false);                                                    \
+        }                                                                                                  \
     } while (0)
 #define CM_LAUNCH3(MTV, STV, NVV, NWV)                                                                     \
     do {                                                                                                   \
@@ -621,6 +666,7 @@ int launch_mt(const CMArgs& a, int grid, size_t lds, int nw, hipStream_t s) {
 #undef CM_LAUNCH2
 #undef CM_LAUNCH3
 #undef CM_LAUNCH4
+#undef CM_LAUNCH5
     return CRUSE_OK;
 }
 
@@ -630,12 +676,14 @@ int launch_mt(const CMArgs& a, int grid, size_t lds, int nw, hipStream_t s) {
 // to the VALU kernel), < 0 on error.
 int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float* bias, float* y,
                         int B, int T, int Cin, int Fin, int Cout, int Fout, int KT, int S, int pad,
-                        int w_layout, int act, int accum, int prec, double* bn_sums, const CruseBnBwd* bnb, hipStream_t stream) {
+                        int w_layout, int act, int accum, int prec, double* bn_sums, const CruseBnBwd* bnb, int x_bf16,
+                        hipStream_t stream) {
     if (Cin % 8 != 0 || (Cin & (Cin - 1)) != 0 || Cout < 8 || Cout > 64 || (TFM * (Fout / (scatter ? 2 : 1))) % 16 != 0) return 0;
     CMArgs a = {};
     a.x = x; a.w = w; a.bias = bias; a.y = y;
     a.B = B; a.T = T; a.Cin = Cin; a.Fin = Fin; a.Cout = Cout; a.Fout = Fout;
     a.act = act; a.accum = accum; a.sums = bn_sums;
+    a.x_bf16 = x_bf16 ? 1 : 0;
     a.tdbg = cruse_opt("cm_dbg", 0);
     a.kint = cruse_opt("cm_kint", 1);
     a.swp_ok = cruse_opt("cm_swap", 1);                  // (A/B switch: 0 = channels in rows for every form)
@@ -678,6 +726,7 @@ int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float
     const int ks0 = (a.cls[0].ntaps * Cin + 31) / 32, ks1 = a.nclass > 1 ? (a.cls[1].ntaps * Cin + 31) / 32 : 0;
     const int mt = Cout <= 16 ? 1 : (Cout <= 32 ? 2 : 4);
     if ((Cin * Fin) % 4 != 0 || ((uintptr_t)x % 16) != 0) return 0;
+    if (x_bf16 && ((Cin * Fin) % 8 != 0 || prec != CRUSE_PREC_BF16 || bn_sums != nullptr && bnb == nullptr)) return 0;   // (bf16 slots cover 8 elements; bf16 mode, data-gradient forms)
     if ((TFM + KT - 1) * Cin * Fin > MAXV * 256 * 4) return 0;
     const size_t wbytes = (size_t)mt * (ks0 + ks1) * 512 *
                           (prec == CRUSE_PREC_F32 ? 4 : (prec == CRUSE_PREC_BF16X3 ? 4 : 2));

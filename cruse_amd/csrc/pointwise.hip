@@ -244,7 +244,7 @@ __global__ __launch_bounds__(RED_THREADS) void bn_act_bwd_reduce_kernel(const fl
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* dout, const float* y, const float* mean,
                                                                const float* rstd, const float* gamma,
                                                                const float* beta, const double* sums, int nrep, long long rows,
-                                                               int C, int F, int relu, int training, float* dy,
+                                                               int C, int F, int relu, int training, float* dy, int dy_bf16,
                                                                float* dgamma, float* dbeta, float* dbias) {
     __shared__ float tab[6][256];
     const double cnt = (double)rows * F;
@@ -301,7 +301,14 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* dout
                     if (relu && !(xh * pg[g][e] + pb[g][e] > 0.f)) gr = 0.f;
                     o[e] = pg[g][e] * pr[g][e] * (gr - p1[g][e] - xh * p2[g][e]);
                 }
-                *reinterpret_cast<float4*>(dy + i) = make_float4(o[0], o[1], o[2], o[3]);
+                if (dy_bf16) {                             // a backward-only tensor: its consumers round it to bf16 anyway
+                    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
+                    bf16x4_ h;
+                    h[0] = (__bf16)o[0]; h[1] = (__bf16)o[1]; h[2] = (__bf16)o[2]; h[3] = (__bf16)o[3];
+                    *reinterpret_cast<bf16x4_*>(reinterpret_cast<__bf16*>(dy) + i) = h;
+                } else {
+                    *reinterpret_cast<float4*>(dy + i) = make_float4(o[0], o[1], o[2], o[3]);
+                }
             }
         }
     }
@@ -807,12 +814,14 @@ extern "C" int cruse_bn_act_bwd_reduce(const float* dout, const float* y, const 
 extern "C" int cruse_bn_act_bwd_apply(const float* dout, const float* y, const float* mean, const float* rstd,
                                       const float* gamma, const float* beta, const double* sums, int sum_replicas,
                                       long long rows, int C, int F, int relu, int training,
-                                      float* dy, float* dgamma, float* dbeta, float* dbias, void* stream) {
+                                      void* dy, int dy_dtype, float* dgamma, float* dbeta, float* dbias, void* stream) {
+    CRUSE_REQUIRE(dy_dtype == CRUSE_DT_F32 || dy_dtype == CRUSE_DT_BF16, CRUSE_E_DTYPE, "bn_act_bwd_apply: dy_dtype %d (f32 or bf16)", dy_dtype);
     CRUSE_REQUIRE(rows > 0 && C > 0 && C <= 256 && F > 0 && sum_replicas >= 1, CRUSE_E_SHAPE, "bn_act_bwd_apply: bad shape");
     CRUSE_REQUIRE((C * F) % 4 == 0 && C * F <= 768, CRUSE_E_SHAPE,
                   "bn_act_bwd_apply: C*F=%d must be a multiple of 4 and <= 768", C * F);
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for(rows, 8, 2048)), dim3(256), 0, ST(stream), dout, y,
-                       mean, rstd, gamma, beta, sums, sum_replicas, rows, C, F, relu, training, dy, dgamma, dbeta, dbias);
+                       mean, rstd, gamma, beta, sums, sum_replicas, rows, C, F, relu, training, (float*)dy,
+                       dy_dtype == CRUSE_DT_BF16 ? 1 : 0, dgamma, dbeta, dbias);
     CRUSE_LAUNCH_CHECK("bn_act_bwd_apply");
     return CRUSE_OK;
 }

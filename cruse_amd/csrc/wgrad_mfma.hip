@@ -23,6 +23,7 @@ struct WMArgs {
     const float* a; const float* bt; float* partial;
     int B, T, Ca, Fa, Cb, Fb, KT, S, pad;
     int FaP, NCH, ntaps, nrows, ntiles_total;
+    int a_bf16, bt_bf16;                   // operand tensors hold bf16 elements (backward-only tensors stored in bf16; PREC == bf16 only)
     int dbg;                               // profiling only (CRUSE_WG_DBG bit mask: skip 1 patch build, 2 MFMA loop, 4 loads, 8 A/raw image)
 };
 
@@ -165,19 +166,55 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WMArgs p) {
         const int t0 = (tile - b * ntile_t) * TFW;
         const float* srca = p.a + ((long long)b * p.T + t0) * rowa;
         const float* srcb = p.bt + ((long long)b * p.T + (t0 - (p.KT - 1))) * rowb;
+        // (dtype branches OUTSIDE the slot loops: see conv_mfma.hip)
+        const bool ld = !(p.dbg & 4);
+        if (p.a_bf16) {                                      // 4 bf16 = 8 bytes per slot, the bit patterns travel in .x / .y
+            const __bf16* sa = reinterpret_cast<const __bf16*>(p.a) + ((long long)b * p.T + t0) * rowa;
 #pragma unroll
-        for (int q = 0; q < MAXV; ++q) {
-            const int i = tid + 256 * q;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!(p.dbg & 4) && i < nva && t0 + (int)((fr_a >> (4 * q)) & 15u) < p.T)
-                v = *reinterpret_cast<const float4*>(srca + i * 4);
-            pa[q] = v;
-            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < nvb) {
-                const int t = t0 - (p.KT - 1) + (int)((fr_b >> (4 * q)) & 15u);
-                if (!(p.dbg & 4) && t >= 0 && t < p.T) w = *reinterpret_cast<const float4*>(srcb + i * 4);
+            for (int q = 0; q < MAXV; ++q) {
+                const int i = tid + 256 * q;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ld && i < nva && t0 + (int)((fr_a >> (4 * q)) & 15u) < p.T) {
+                    const float2 w2 = *reinterpret_cast<const float2*>(sa + i * 4);
+                    v.x = w2.x; v.y = w2.y;
+                }
+                pa[q] = v;
             }
-            pb[q] = w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < MAXV; ++q) {
+                const int i = tid + 256 * q;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ld && i < nva && t0 + (int)((fr_a >> (4 * q)) & 15u) < p.T) v = *reinterpret_cast<const float4*>(srca + i * 4);
+                pa[q] = v;
+            }
+        }
+        if (p.bt_bf16) {
+            const __bf16* sb = reinterpret_cast<const __bf16*>(p.bt) + ((long long)b * p.T + (t0 - (p.KT - 1))) * rowb;
+#pragma unroll
+            for (int q = 0; q < MAXV; ++q) {
+                const int i = tid + 256 * q;
+                float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < nvb) {
+                    const int t = t0 - (p.KT - 1) + (int)((fr_b >> (4 * q)) & 15u);
+                    if (ld && t >= 0 && t < p.T) {
+                        const float2 w2 = *reinterpret_cast<const float2*>(sb + i * 4);
+                        w.x = w2.x; w.y = w2.y;
+                    }
+                }
+                pb[q] = w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < MAXV; ++q) {
+                const int i = tid + 256 * q;
+                float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < nvb) {
+                    const int t = t0 - (p.KT - 1) + (int)((fr_b >> (4 * q)) & 15u);
+                    if (ld && t >= 0 && t < p.T) w = *reinterpret_cast<const float4*>(srcb + i * 4);
+                }
+                pb[q] = w;
+            }
         }
     };
     if ((int)blockIdx.x < p.ntiles_total) prefetch(blockIdx.x);
@@ -185,14 +222,39 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WMArgs p) {
     for (int tile = blockIdx.x; tile < p.ntiles_total; tile += gridDim.x) {
         __syncthreads();                                     // previous tile's fragment reads are done
         // A image: [t][ca][fa] -> al[ca][tl][fa];  raw bt frames -> rawl (straight copy)
+        if (PREC == CRUSE_PREC_BF16 && p.a_bf16) {           // already the operand's type: two 4-byte stores, no conversion
 #pragma unroll
-        for (int q = 0; q < MAXV; ++q) {
-            if (a_ok[q] && !(p.dbg & 8)) {
-                wput2<PREC>(al, aplane, (size_t)a_off[q][0], pa[q].x, pa[q].y);
-                wput2<PREC>(al, aplane, (size_t)a_off[q][1], pa[q].z, pa[q].w);
+            for (int q = 0; q < MAXV; ++q) {
+                if (a_ok[q] && !(p.dbg & 8)) {
+                    *reinterpret_cast<float*>(al + a_off[q][0]) = pa[q].x;
+                    *reinterpret_cast<float*>(al + a_off[q][1]) = pa[q].y;
+                }
             }
-            const int i = tid + 256 * q;
-            if (i < nvb) *reinterpret_cast<float4*>(rawl + i * 4) = pb[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < MAXV; ++q) {
+                if (a_ok[q] && !(p.dbg & 8)) {
+                    wput2<PREC>(al, aplane, (size_t)a_off[q][0], pa[q].x, pa[q].y);
+                    wput2<PREC>(al, aplane, (size_t)a_off[q][1], pa[q].z, pa[q].w);
+                }
+            }
+        }
+        if (p.bt_bf16) {
+#pragma unroll
+            for (int q = 0; q < MAXV; ++q) {
+                const int i = tid + 256 * q;
+                if (i < nvb) {
+                    const unsigned w0 = __float_as_uint(pb[q].x), w1 = __float_as_uint(pb[q].y);
+                    *reinterpret_cast<float4*>(rawl + i * 4) = make_float4(__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xffff0000u),
+                                                                           __uint_as_float(w1 << 16), __uint_as_float(w1 & 0xffff0000u));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < MAXV; ++q) {
+                const int i = tid + 256 * q;
+                if (i < nvb) *reinterpret_cast<float4*>(rawl + i * 4) = pb[q];
+            }
         }
         __syncthreads();
         if (tile + (int)gridDim.x < p.ntiles_total) prefetch(tile + gridDim.x);
@@ -307,8 +369,9 @@ int launch_mt(const WMArgs& p, int mt, int ntw, int grid, size_t lds, hipStream_
 
 // 1 = handled (partial slabs written, *nblk_out = number of slabs), 0 = not eligible, < 0 error
 int cruse_wgrad_mfma_try(const float* a, const float* bt, float* partial, int max_slabs,
-                         int B, int T, int Ca, int Fa, int Cb, int Fb, int KT, int S, int pad, int prec,
+                         int B, int T, int Ca, int Fa, int Cb, int Fb, int KT, int S, int pad, int prec, int a_bf16, int bt_bf16,
                          int* nblk_out, hipStream_t stream) {
+    if ((a_bf16 || bt_bf16) && prec != CRUSE_PREC_BF16) return 0;      // (bf16-stored tensors belong to the bf16 mode)
     const int FaP = (Fa + 7) / 8 * 8, NCH = FaP / 8;
     const int ntaps = KT * 3;
     const int mt = Ca <= 16 ? 1 : (Ca <= 32 ? 2 : 4);
@@ -347,6 +410,7 @@ int cruse_wgrad_mfma_try(const float* a, const float* bt, float* partial, int ma
     p.FaP = FaP; p.NCH = NCH; p.ntaps = ntaps; p.nrows = tfw + KT - 1;
     p.ntiles_total = B * ((T + tfw - 1) / tfw);
     p.dbg = cruse_opt("wg_dbg", 0);
+    p.a_bf16 = a_bf16 ? 1 : 0; p.bt_bf16 = bt_bf16 ? 1 : 0;
     int grid = p.ntiles_total < max_slabs ? p.ntiles_total : max_slabs;
     if (grid > gcap) grid = gcap;               // resident blocks only; fewer partial slabs to reduce
     int rc;

@@ -857,6 +857,8 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
     rows = B * T
     ys, es, stats, us, vs, dstats = ctx["ys"], ctx["es"], ctx["stats"], ctx["us"], ctx["vs"], ctx["dstats"]
     _INLINE = config.get().inline_mask
+    # backward-only tensors in bf16 (EngineConfig.bf16_dy): only where every consumer rounds them to bf16 operands anyway
+    dy_bf16 = bool(config.get().bf16_dy) and ops.prec_code(prec) == ops.PREC_BF16 and dprec == ops.PREC_BF16
     # ---- decoder level 1: v1 = convT_1(u1) -------------------------------------------
     dv = dlogit
 
@@ -915,7 +917,7 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
         mean, rstd = dstats[k]
         dv = ops.bn_act_bwd(du, vs[k], mean, rstd, P[f"bn{k}_t.weight"], P[f"bn{k}_t.bias"], rows, ch[k - 1],
                             Fk[k - 1], True, training, G[f"bn{k}_t.weight"], G[f"bn{k}_t.bias"],
-                            dbias=G[f"conv{k}_t.bias"], sums=du_sums)
+                            dbias=G[f"conv{k}_t.bias"], sums=du_sums, out_bf16=dy_bf16)
 
         def leaf_dec(dv=dv, k=k):
             ops.conv_wgrad(us[k], dv, G[f"conv{k}_t.weight"], B, T, ch[k], Fk[k], ch[k - 1], Fk[k - 1], KT=1, S=2, pad=0, prec=prec)
@@ -948,7 +950,7 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
     for k in range(L, 0, -1):
         mean, rstd = stats[k]
         dy = ops.bn_act_bwd(de, ys[k], mean, rstd, P[f"bn{k}.weight"], P[f"bn{k}.bias"], rows, ch[k], Fk[k], True,
-                            training, G[f"bn{k}.weight"], G[f"bn{k}.bias"], dbias=G[f"conv{k}.bias"], sums=de_sums)
+                            training, G[f"bn{k}.weight"], G[f"bn{k}.bias"], dbias=G[f"conv{k}.bias"], sums=de_sums, out_bf16=dy_bf16)
 
         def leaf_enc(dy=dy, k=k):
             ops.conv_wgrad(dy, es[k - 1], G[f"conv{k}.weight"], B, T, ch[k], Fk[k], ch[k - 1], Fk[k - 1], KT=2, S=2, pad=1, prec=prec)

@@ -28,6 +28,15 @@ def _p(t: Optional[torch.Tensor]):
     return t.data_ptr()
 
 
+def _xdt(t: torch.Tensor, name: str) -> int:
+    """CRUSE_DT_* of a conv / weight-gradient INPUT: f32, or bf16 for the backward-only tensors of the bf16 mode."""
+    if t.dtype == torch.float32:
+        return 0
+    if t.dtype == torch.bfloat16:
+        return 2
+    raise RuntimeError(f"{name}: expected float32 or bfloat16, got {t.dtype}")
+
+
 def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
     if t.dtype != torch.float32:
         raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
@@ -136,10 +145,10 @@ def conv_gather(x, w, bias, B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout=0, 
         sums, z = ARENA.take(2 * Cout * BN_STAT_REPLICAS, x.device)
         check(lib.cruse_conv_gather_bnbwd(_p(x), _p(w), _p(out), B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout,
                                           1 if accum else 0, conv_prec(prec), _p(by), _p(mean), _p(rstd), _p(gamma), _p(beta),
-                                          1 if relu else 0, _p(sums), z, _stream()))
+                                          1 if relu else 0, _p(sums), z, _xdt(x, "conv_gather"), _stream()))
         return out, sums
     check(lib.cruse_conv_gather(_p(x), _p(w), _p(bias), _p(out), B, T, Cin, Fin, Cout, Fout, KT, S, pad,
-                                w_layout, act, 1 if accum else 0, conv_prec(prec), _stream()))
+                                w_layout, act, 1 if accum else 0, conv_prec(prec), _xdt(x, "conv_gather"), _stream()))
     return out
 
 
@@ -153,10 +162,10 @@ def conv_scatter2(g, w, bias, B, T, Cs, Fg, Cout, KT, pad, act=0, out=None, accu
         sums, z = ARENA.take(2 * Cout * BN_STAT_REPLICAS, g.device)
         check(lib.cruse_conv_scatter2_bnbwd(_p(g), _p(w), _p(out), B, T, Cs, Fg, Cout, Fout, KT, pad, 1 if accum else 0,
                                             conv_prec(prec), _p(by), _p(mean), _p(rstd), _p(gamma), _p(beta), 1 if relu else 0,
-                                            _p(sums), z, _stream()))
+                                            _p(sums), z, _xdt(g, "conv_scatter2"), _stream()))
         return out, sums
     check(lib.cruse_conv_scatter2(_p(g), _p(w), _p(bias), _p(out), B, T, Cs, Fg, Cout, Fout, KT, pad, act,
-                                  1 if accum else 0, conv_prec(prec), _stream()))
+                                  1 if accum else 0, conv_prec(prec), _xdt(g, "conv_scatter2"), _stream()))
     return out
 
 
@@ -224,7 +233,8 @@ def conv_wgrad(a, bt, dw, B, T, Ca, Fa, Cb, Fb, KT, S, pad, prec=None):
     # one partial-slab workspace PER STREAM: weight-gradient leaves may run concurrently on several side streams
     ws = _ws(("wgrad", _stream()), nbytes, a.device)
     pc = -1 if prec is None else (WGRAD_PREC[prec] if isinstance(prec, str) else int(prec))
-    check(lib.cruse_conv_wgrad(_p(a), _p(bt), _p(dw), B, T, Ca, Fa, Cb, Fb, KT, S, pad, pc, _p(ws), _stream()))
+    check(lib.cruse_conv_wgrad(_p(a), _p(bt), _p(dw), B, T, Ca, Fa, Cb, Fb, KT, S, pad, pc, _xdt(a, "conv_wgrad a"),
+                               _xdt(bt, "conv_wgrad bt"), _p(ws), _stream()))
 
 
 def channel_sum(g, rows, C, F, out):
@@ -328,18 +338,21 @@ def bn_act_fwd(y, mean, rstd, gamma, beta, skip, rows, C, F, relu=True):
     return out
 
 
-def bn_act_bwd(dout, y, mean, rstd, gamma, beta, rows, C, F, relu, training, dgamma, dbeta, dbias=None, sums=None):
+def bn_act_bwd(dout, y, mean, rstd, gamma, beta, rows, C, F, relu, training, dgamma, dbeta, dbias=None, sums=None,
+               out_bf16=False):
     """sums: the backward sums the convolution that produced dout has already accumulated (conv_gather / conv_scatter2 with
-    bn_bwd: [BN_STAT_REPLICAS][2*C]); None: the reduce pass runs here."""
+    bn_bwd: [BN_STAT_REPLICAS][2*C]); None: the reduce pass runs here.  out_bf16: dy as a bf16 tensor (its consumers -- the
+    data-gradient conv and the weight gradient of the bf16 mode -- round it to bf16 operands anyway: the same bits, half the
+    bytes written once and read twice)."""
     nrep = BN_STAT_REPLICAS
     if sums is None:
         nrep = 1
         sums, z = ARENA.take(2 * C, y.device)
         check(lib.cruse_bn_act_bwd_reduce(_p(dout), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), rows, C, F,
                                           1 if relu else 0, _p(sums), z, _stream()))
-    dy = torch.empty_like(y)
+    dy = torch.empty_like(y, dtype=torch.bfloat16 if out_bf16 else torch.float32)
     check(lib.cruse_bn_act_bwd_apply(_p(dout), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(sums), nrep, rows, C, F,
-                                     1 if relu else 0, 1 if training else 0, _p(dy), _p(dgamma), _p(dbeta),
+                                     1 if relu else 0, 1 if training else 0, _p(dy), 2 if out_bf16 else 0, _p(dgamma), _p(dbeta),
                                      _p(dbias), _stream()))
     return dy
 

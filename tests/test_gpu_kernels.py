@@ -1010,3 +1010,44 @@ def test_tn_weight_gradient_path_matches_the_default(grp):
             continue
         tol = 5e-3 if "bias_" in k else 2e-4
         assert rel_l2(res["1"][1][k], v) < tol, (k, rel_l2(res["1"][1][k], v))
+
+
+@pytest.mark.parametrize("form", ["gather", "scatter", "wgrad_a", "wgrad_bt"])
+def test_backward_only_tensors_stored_as_bf16_give_the_same_bits(ops, form):
+    """EngineConfig.bf16_dy (round 4): the BatchNorm-backward output is stored as bf16 -- the data-gradient convs (plain bf16
+    operands) and the weight gradient (bf16 mode) round it to bf16 anyway, so a bf16 tensor and the f32 tensor holding the same
+    rounded values must give identical results; cruse_bn_act_bwd_apply(dy_dtype = bf16) == the f32 result rounded once.  The
+    VALU fall-backs refuse a bf16 input loudly."""
+    torch.manual_seed(7)
+    B, T = 3, 21
+    if form == "gather":                                   # decoder data gradient: dv [B,T,8,80] -> du [B,T,16,40]
+        x = torch.randn(B, T, 8, 80).cuda(); w = (0.2 * torch.randn(16, 8, 1, 3)).cuda()
+        run = lambda t_: ops.conv_gather(t_, w, None, B, T, 8, 80, 16, 40, KT=1, S=2, pad=0, prec=ops.PREC_BF16)   # (plain bf16 operands: the data-gradient mode)
+    elif form == "scatter":                                # encoder data gradient: dy [B,T,32,20] -> de [B,T,16,40], accumulating
+        x = torch.randn(B, T, 32, 20).cuda(); w = (0.2 * torch.randn(32, 16, 2, 3)).cuda()
+        base = torch.randn(B, T, 16, 40).cuda()
+        run = lambda t_: ops.conv_scatter2(t_, w, None, B, T, 32, 20, 16, KT=2, pad=1, out=base.clone(), accum=True, prec=ops.PREC_BF16)
+    else:
+        a = torch.randn(B, T, 16, 40).cuda(); bt = torch.randn(B, T, 8, 80).cuda()
+
+        def run(t_):
+            dw = torch.zeros(16, 8, 2, 3).cuda()
+            aa, bb = (t_, bt) if form == "wgrad_a" else (a, t_)
+            ops.conv_wgrad(aa, bb, dw, B, T, 16, 40, 8, 80, KT=2, S=2, pad=1, prec="bf16")
+            return dw
+        x = a if form == "wgrad_a" else bt
+    xb = x.to(torch.bfloat16)
+    assert torch.equal(run(xb), run(xb.float()))
+    if form == "gather":
+        with pytest.raises(RuntimeError, match="bf16"):    # Cin = 1: no MFMA form
+            ops.conv_gather(torch.randn(B, T, 1, 160).cuda().to(torch.bfloat16), (0.2 * torch.randn(8, 1, 1, 3)).cuda(), None,
+                            B, T, 1, 160, 8, 80, KT=1, S=2, pad=0, prec=ops.PREC_BF16)
+        rows, C, F = B * T, 16, 40
+        y = torch.randn(B, T, C, F).cuda(); dout = torch.randn(B, T, C, F).cuda()
+        mean = (0.1 * torch.randn(C)).cuda(); rstd = (1.0 + 0.2 * torch.rand(C)).cuda()
+        gamma = (1.0 + 0.3 * torch.randn(C)).cuda(); beta = (0.2 * torch.randn(C)).cuda()
+        outs = []
+        for bf in (False, True):
+            dg = torch.zeros(C).cuda(); db = torch.zeros(C).cuda()
+            outs.append(ops.bn_act_bwd(dout, y, mean, rstd, gamma, beta, rows, C, F, True, True, dg, db, out_bf16=bf))
+        assert outs[1].dtype == torch.bfloat16 and torch.equal(outs[1], outs[0].to(torch.bfloat16))

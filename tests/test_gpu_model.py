@@ -345,7 +345,7 @@ def test_graph_replay_on_a_new_batch_equals_eager_launches(fwd_chunks):
         assert eng.skipped_steps() == 0 and ops.gru_status() == 0
     assert torch.equal(res[True][0], res[False][0]), "mask of the replay differs from the eager launches"
     assert res[True][1] == res[False][1]
-    assert rel_l2(res[True][2], res[False][2]) < 1e-5
+    assert rel_l2(res[True][2], res[False][2]) < 5e-5      # (atomics order of the BatchNorm sums -> 1e-7 in dy -> a few bf16 roundings of it flip)
 
 
 @pytest.mark.parametrize("graph", [False, True])
@@ -375,5 +375,27 @@ def test_forward_time_chunk_pipeline_is_the_same_computation(graph):
         # the first step starts from identical parameters: the forward pass must agree bit for bit
         assert torch.equal(res[nch][1], res[0][1]), f"mask differs with {nch} chunks"
         assert res[nch][0] == res[0][0]
-        assert rel_l2(res[nch][2], res[0][2]) < 1e-5               # (split-K atomics order in the weight-gradient GEMMs)
+        assert rel_l2(res[nch][2], res[0][2]) < 5e-5               # (run-to-run order of the BatchNorm-sum atomics: 1e-7 in dy, a few of its bf16 roundings flip)
         assert res[nch][3] == pytest.approx(res[0][3], rel=1e-5) and rel_l2(res[nch][4], res[0][4]) < 2e-3      # (Adam moves noise-level entries by +-lr)
+
+
+@pytest.mark.parametrize("grp", [1, 4])
+def test_bf16_stored_batchnorm_gradients_leave_the_step_unchanged(grp):
+    """EngineConfig.bf16_dy: storing the BatchNorm-backward outputs as bf16 changes no operand bit of the bf16 mode -- loss equal,
+    gradients equal up to the run-to-run order of the BatchNorm-sum atomics (2e-7)."""
+    from cruse_amd.config import EngineConfig
+    from cruse_amd.data import synth_batch
+    from cruse_amd.engine import TrainEngine
+    from cruse_amd.model.cruse_net import unet_2
+    from cruse_amd import ops
+    noisy, clean = synth_batch(8, 16000, "cuda", 9)
+    res = {}
+    for flag in (False, True):
+        torch.manual_seed(5)
+        eng = TrainEngine(unet_2(rnn_groups=grp, precision="bf16").cuda(), use_graph=False, lr=0.0, config=EngineConfig(bf16_dy=flag))
+        ls = eng.step(noisy, clean)
+        torch.cuda.synchronize()
+        res[flag] = (eng.loss_value(ls), eng.flat.grads.clone())
+        assert eng.skipped_steps() == 0 and ops.gru_status() == 0
+    assert res[True][0] == res[False][0]
+    assert rel_l2(res[True][1], res[False][1]) < 5e-5
