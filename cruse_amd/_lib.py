@@ -29,13 +29,13 @@ SIGNATURES = {
     "cruse_stft_fwd": ("piiiipppifp", "i"),
     "cruse_istft_fwd": ("ppiiiiipp", "i"),
     "cruse_istft_bwd": ("piiiiippp", "i"),
-    "cruse_conv_gather": ("ppppiiiiiiiiiiiiiip", "i"),
-    "cruse_conv_scatter2": ("ppppiiiiiiiiiiiip", "i"),
+    "cruse_conv_gather": ("ppppiiiiiiiiiiiiiiip", "i"),
+    "cruse_conv_scatter2": ("ppppiiiiiiiiiiiiip", "i"),
     "cruse_conv_gather_bnstats": ("ppppiiiiiiiiiipip", "i"),
     "cruse_conv_scatter2_bnstats": ("ppppiiiiiiiiipip", "i"),
     "cruse_conv_mfma_stamps": ("p", "i"),
-    "cruse_conv_gather_bnbwd": ("pppiiiiiiiiiiiipppppipiip", "i"),
-    "cruse_conv_scatter2_bnbwd": ("pppiiiiiiiiiipppppipiip", "i"),
+    "cruse_conv_gather_bnbwd": ("pppiiiiiiiiiiiipppppipiiip", "i"),
+    "cruse_conv_scatter2_bnbwd": ("pppiiiiiiiiiipppppipiiip", "i"),
     "cruse_conv_wgrad_ws_bytes": ("iii", "z"),
     "cruse_conv_wgrad": ("pppiiiiiiiiiiiipp", "i"),
     "cruse_channel_sum": ("pqiipp", "i"),
@@ -46,7 +46,7 @@ SIGNATURES = {
     "cruse_bn_eval_stats": ("ppifppp", "i"),
     "cruse_bn_act_fwd": ("pppppppqiiip", "i"),
     "cruse_bn_act_bwd_reduce": ("ppppppqiiipip", "i"),
-    "cruse_bn_act_bwd_apply": ("pppppppiqiiiipipppp", "i"),
+    "cruse_bn_act_bwd_apply": ("pppppppiqiiiiipipppp", "i"),
     "cruse_ln_fwd": ("ppppppppqiifiqqp", "i"),
     "cruse_ln_bwd": ("pppppqiipppp", "i"),
     "cruse_gemm": ("iiiiipipipipiiiip", "i"),

@@ -45,6 +45,10 @@ class EngineConfig:
     bf16_dy: bool = True            # bf16 mode: the BatchNorm-backward outputs (dy, dv) are STORED as bf16 -- their two consumers (the
                                     # data-gradient conv on plain bf16 operands and the weight gradient) round them to bf16 anyway,
                                     # so the MFMAs see the same bits; 7 x 65.7 MB less written and 2 x that less read per step
+    bf16_de: bool = True            # ... and the data gradients between a conv and the BatchNorm backward it feeds (du_k, de_k of the
+                                    # levels whose producer AND consumers are MFMA kernels: 2 <= k < L) are stored as bf16 as well:
+                                    # f32 accumulation, one rounding per pass of a backward-only tensor (needs bf16_dy and
+                                    # fuse_bn_bwd_stats: the conv that stores the tensor also delivers its BatchNorm sums)
     fwd_chunks: int = 0             # time chunks of the forward GGRU pipeline: projections / LayerNorm 1 of one chunk run on an
                                     # auxiliary stream beside the recurrence of another.  OFF (0 / 1): measured 6.11 (2 chunks),
                                     # 6.20 (3), 6.27 ms (4) against 6.10 -- the 0.33 ms of in-between kernels do disappear from
@@ -58,7 +62,7 @@ class EngineConfig:
             "fuse_bn_bwd_stats": ("CRUSE_FUSE_BN_BWD", lambda v: v != "0"), "fuse_cast": ("CRUSE_FUSE_CAST", lambda v: v == "1"),
             "gi_x3": ("CRUSE_GI_X3", int), "gi_bf16": ("CRUSE_GI_BF16", lambda v: v == "1"), "dw_xcdk": ("CRUSE_DW_XCDK", int), "conv_bwd_x3": ("CRUSE_CONV_BWD_X3", lambda v: v == "1"),
             "dw_tn": ("CRUSE_DW_TN", lambda v: v == "1"), "dw_slabs": ("CRUSE_DW_SLABS", lambda v: v != "0"), "fwd_chunks": ("CRUSE_FWD_CHUNKS", int),
-            "bf16_dy": ("CRUSE_BF16_DY", lambda v: v != "0")}
+            "bf16_dy": ("CRUSE_BF16_DY", lambda v: v != "0"), "bf16_de": ("CRUSE_BF16_DE", lambda v: v != "0")}
     _LIB_ENV = {"CRUSE_GRU_BWD_RS": "gru_bwd_rs", "CRUSE_GRU_FWD_LEAN": "gru_fwd_lean", "CRUSE_GRU_WLO": "gru_wlo",
                 "CRUSE_GRU_DBG": "gru_dbg", "CRUSE_GRU_BG": "gru_bg", "CRUSE_CM_GRID": "cm_grid", "CRUSE_CM_KINT": "cm_kint", "CRUSE_CM_SWAP": "cm_swap", "CRUSE_CM_NW": "cm_nw",
                 "CRUSE_GB_DEEP_MIN": "gb_deep_min", "CRUSE_GB_DEEP": "gb_deep", "CRUSE_PW_VALU": "pw_valu", "CRUSE_LNB_GRID": "lnb_grid",

@@ -448,7 +448,7 @@ int set_smem(K kern, size_t bytes, const char* name) {
 
 int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float* bias, float* y,
                         int B, int T, int Cin, int Fin, int Cout, int Fout, int KT, int S, int pad,
-                        int w_layout, int act, int accum, int prec, double* bn_sums, const CruseBnBwd* bnb, int x_bf16,
+                        int w_layout, int act, int accum, int prec, double* bn_sums, const CruseBnBwd* bnb, int x_bf16, int y_bf16,
                         hipStream_t stream);
 extern "C" int cruse_bn_act_bwd_reduce(const float* dout, const float* y, const float* mean, const float* rstd,
                                        const float* gamma, const float* beta, long long rows, int C, int F,
@@ -459,8 +459,9 @@ namespace {
 int conv_gather_impl(const float* x, const float* w, const float* bias, float* y,
                      int B, int T, int Cin, int Fin, int Cout, int Fout,
                      int KT, int S, int pad, int w_layout, int act, int accum, int prec, double* bn_sums, void* stream,
-                     const CruseBnBwd* bnb = nullptr, int x_dtype = CRUSE_DT_F32) {
-    CRUSE_REQUIRE(x_dtype == CRUSE_DT_F32 || x_dtype == CRUSE_DT_BF16, CRUSE_E_DTYPE, "conv_gather: x_dtype %d (f32 or bf16)", x_dtype);
+                     const CruseBnBwd* bnb = nullptr, int x_dtype = CRUSE_DT_F32, int y_dtype = CRUSE_DT_F32) {
+    CRUSE_REQUIRE((x_dtype == CRUSE_DT_F32 || x_dtype == CRUSE_DT_BF16) && (y_dtype == CRUSE_DT_F32 || y_dtype == CRUSE_DT_BF16), CRUSE_E_DTYPE,
+                  "conv_gather: x_dtype %d / y_dtype %d (f32 or bf16)", x_dtype, y_dtype);
     CRUSE_REQUIRE(B > 0 && T > 0 && Cin > 0 && Cout > 0 && Fin > 0 && Fout > 0, CRUSE_E_SHAPE,
                   "conv_gather: empty shape B=%d T=%d Cin=%d Cout=%d Fin=%d Fout=%d", B, T, Cin, Cout, Fin, Fout);
     CRUSE_REQUIRE((KT == 1 || KT == 2) && (S == 1 || S == 2) && (pad == 0 || pad == 1), CRUSE_E_SHAPE,
@@ -471,10 +472,11 @@ int conv_gather_impl(const float* x, const float* w, const float* bias, float* y
     CRUSE_REQUIRE(!(accum && act), CRUSE_E_SHAPE, "conv_gather: accum with activation");
     if (prec >= 0) {
         const int r = cruse_conv_mfma_try(0, x, w, bias, y, B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout, act, accum,
-                                          prec, bn_sums, bnb, x_dtype == CRUSE_DT_BF16, (hipStream_t)stream);
+                                          prec, bn_sums, bnb, x_dtype == CRUSE_DT_BF16, y_dtype == CRUSE_DT_BF16, (hipStream_t)stream);
         if (r != 0) return r < 0 ? r : CRUSE_OK;
     }
-    CRUSE_REQUIRE(x_dtype == CRUSE_DT_F32, CRUSE_E_DTYPE, "conv_gather: a bf16 input needs the MFMA kernel (Cin %d, Cout %d, prec %d)", Cin, Cout, prec);
+    CRUSE_REQUIRE(x_dtype == CRUSE_DT_F32 && y_dtype == CRUSE_DT_F32, CRUSE_E_DTYPE,
+                  "conv_gather: a bf16 input / output needs the MFMA kernel in the bf16 data-gradient mode (Cin %d, Cout %d, prec %d)", Cin, Cout, prec);
     const bool fuse = bn_sums && Cout <= 64 && bnb == nullptr;
     ConvArgs a{x, w, bias, y, B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout, act, accum, fuse ? bn_sums : nullptr};
     const size_t lds = (((size_t)Cin * KT * 3 * Cout + 3) & ~(size_t)3) * 4 +
@@ -500,8 +502,9 @@ int conv_gather_impl(const float* x, const float* w, const float* bias, float* y
 int conv_scatter2_impl(const float* g, const float* w, const float* bias, float* y,
                        int B, int T, int Cs, int Fg, int Cout, int Fout,
                        int KT, int pad, int act, int accum, int prec, double* bn_sums, void* stream,
-                       const CruseBnBwd* bnb = nullptr, int x_dtype = CRUSE_DT_F32) {
-    CRUSE_REQUIRE(x_dtype == CRUSE_DT_F32 || x_dtype == CRUSE_DT_BF16, CRUSE_E_DTYPE, "conv_scatter2: x_dtype %d (f32 or bf16)", x_dtype);
+                       const CruseBnBwd* bnb = nullptr, int x_dtype = CRUSE_DT_F32, int y_dtype = CRUSE_DT_F32) {
+    CRUSE_REQUIRE((x_dtype == CRUSE_DT_F32 || x_dtype == CRUSE_DT_BF16) && (y_dtype == CRUSE_DT_F32 || y_dtype == CRUSE_DT_BF16), CRUSE_E_DTYPE,
+                  "conv_scatter2: x_dtype %d / y_dtype %d (f32 or bf16)", x_dtype, y_dtype);
     CRUSE_REQUIRE(B > 0 && T > 0 && Cs > 0 && Cout > 0 && Fg > 0, CRUSE_E_SHAPE, "conv_scatter2: empty shape");
     CRUSE_REQUIRE(Fout == 2 * Fg, CRUSE_E_SHAPE, "conv_scatter2: Fout=%d must be 2*Fg=%d", Fout, 2 * Fg);
     CRUSE_REQUIRE((KT == 1 || KT == 2) && (pad == 0 || pad == 1), CRUSE_E_SHAPE,
@@ -509,10 +512,11 @@ int conv_scatter2_impl(const float* g, const float* w, const float* bias, float*
     CRUSE_REQUIRE(!(accum && act), CRUSE_E_SHAPE, "conv_scatter2: accum with activation");
     if (prec >= 0) {
         const int r = cruse_conv_mfma_try(1, g, w, bias, y, B, T, Cs, Fg, Cout, Fout, KT, 2, pad, 0, act, accum, prec,
-                                          bn_sums, bnb, x_dtype == CRUSE_DT_BF16, (hipStream_t)stream);
+                                          bn_sums, bnb, x_dtype == CRUSE_DT_BF16, y_dtype == CRUSE_DT_BF16, (hipStream_t)stream);
         if (r != 0) return r < 0 ? r : CRUSE_OK;
     }
-    CRUSE_REQUIRE(x_dtype == CRUSE_DT_F32, CRUSE_E_DTYPE, "conv_scatter2: a bf16 input needs the MFMA kernel (Cs %d, Cout %d, prec %d)", Cs, Cout, prec);
+    CRUSE_REQUIRE(x_dtype == CRUSE_DT_F32 && y_dtype == CRUSE_DT_F32, CRUSE_E_DTYPE,
+                  "conv_scatter2: a bf16 input / output needs the MFMA kernel in the bf16 data-gradient mode (Cs %d, Cout %d, prec %d)", Cs, Cout, prec);
     ConvArgs a{g, w, bias, y, B, T, Cs, Fg, Cout, Fout, KT, 2, pad, 0, act, accum, nullptr};
     const size_t lds = (((size_t)Cs * KT * 3 * Cout + 3) & ~(size_t)3) * 4 +
                        (size_t)(TF + KT - 1) * Cs * (Fg + 2) * 4;
@@ -544,15 +548,15 @@ int prep_sums(double* sums, int Cout, int zeroed, void* stream, const char* who)
 
 extern "C" int cruse_conv_gather(const float* x, const float* w, const float* bias, float* y,
                                  int B, int T, int Cin, int Fin, int Cout, int Fout,
-                                 int KT, int S, int pad, int w_layout, int act, int accum, int prec, int x_dtype, void* stream) {
+                                 int KT, int S, int pad, int w_layout, int act, int accum, int prec, int x_dtype, int y_dtype, void* stream) {
     return conv_gather_impl(x, w, bias, y, B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout, act, accum, prec, nullptr, stream, nullptr,
-                            x_dtype);
+                            x_dtype, y_dtype);
 }
 
 extern "C" int cruse_conv_scatter2(const float* g, const float* w, const float* bias, float* y,
                                    int B, int T, int Cs, int Fg, int Cout, int Fout,
-                                   int KT, int pad, int act, int accum, int prec, int x_dtype, void* stream) {
-    return conv_scatter2_impl(g, w, bias, y, B, T, Cs, Fg, Cout, Fout, KT, pad, act, accum, prec, nullptr, stream, nullptr, x_dtype);
+                                   int KT, int pad, int act, int accum, int prec, int x_dtype, int y_dtype, void* stream) {
+    return conv_scatter2_impl(g, w, bias, y, B, T, Cs, Fg, Cout, Fout, KT, pad, act, accum, prec, nullptr, stream, nullptr, x_dtype, y_dtype);
 }
 
 extern "C" int cruse_conv_gather_bnstats(const float* x, const float* w, const float* bias, float* y,
@@ -574,23 +578,23 @@ extern "C" int cruse_conv_scatter2_bnstats(const float* g, const float* w, const
 extern "C" int cruse_conv_gather_bnbwd(const float* x, const float* w, float* y, int B, int T, int Cin, int Fin, int Cout, int Fout,
                                        int KT, int S, int pad, int w_layout, int accum, int prec,
                                        const float* bn_y, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                                       int relu, double* sums, int zeroed, int x_dtype, void* stream) {
+                                       int relu, double* sums, int zeroed, int x_dtype, int y_dtype, void* stream) {
     CRUSE_REQUIRE(bn_y && mean && rstd && gamma && beta, CRUSE_E_SHAPE, "conv_gather_bnbwd: BatchNorm tensors missing");
     int rc = prep_sums(sums, Cout, zeroed, stream, "conv_gather_bnbwd");
     if (rc) return rc;
     const CruseBnBwd bnb = {bn_y, mean, rstd, gamma, beta, relu};
-    return conv_gather_impl(x, w, nullptr, y, B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout, 0, accum, prec, sums, stream, &bnb, x_dtype);
+    return conv_gather_impl(x, w, nullptr, y, B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout, 0, accum, prec, sums, stream, &bnb, x_dtype, y_dtype);
 }
 
 extern "C" int cruse_conv_scatter2_bnbwd(const float* g, const float* w, float* y, int B, int T, int Cs, int Fg, int Cout, int Fout,
                                          int KT, int pad, int accum, int prec,
                                          const float* bn_y, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                                         int relu, double* sums, int zeroed, int x_dtype, void* stream) {
+                                         int relu, double* sums, int zeroed, int x_dtype, int y_dtype, void* stream) {
     CRUSE_REQUIRE(bn_y && mean && rstd && gamma && beta, CRUSE_E_SHAPE, "conv_scatter2_bnbwd: BatchNorm tensors missing");
     int rc = prep_sums(sums, Cout, zeroed, stream, "conv_scatter2_bnbwd");
     if (rc) return rc;
     const CruseBnBwd bnb = {bn_y, mean, rstd, gamma, beta, relu};
-    return conv_scatter2_impl(g, w, nullptr, y, B, T, Cs, Fg, Cout, Fout, KT, pad, 0, accum, prec, sums, stream, &bnb, x_dtype);
+    return conv_scatter2_impl(g, w, nullptr, y, B, T, Cs, Fg, Cout, Fout, KT, pad, 0, accum, prec, sums, stream, &bnb, x_dtype, y_dtype);
 }
 
 extern "C" size_t cruse_conv_wgrad_ws_bytes(int Ca, int Cb, int KT) {

@@ -38,6 +38,7 @@ __device__ unsigned long long g_cm_stamps[8];
 
 struct CMArgs {
     int tdbg, kint, swp_ok;
+    int y_bf16;                                  // y too (swapped-role forms only: vector stores)
     int x_bf16;                                  // x holds bf16 elements (a backward-only tensor stored in bf16): widened while staging
     const float* x; const float* w; const float* bias; float* y;
     int B, T, Cin, Fin, Cout, Fout;
@@ -109,11 +110,15 @@ __device__ __forceinline__ Frag<PREC> get_frag(const typename OpStore<PREC>::ele
 // stores and exposes a full memory round trip per N-tile (the accumulating data gradients of the encoder ran at half the
 // speed of the plain ones; with the backward statistics read that way the step got 0.15 ms SLOWER than with the separate
 // reduce pass, r03).
-template <int PREC, int MT, int EPI, int NV, int NW, int SWM, bool XB>
-// (XB: x holds bf16 elements -- a compile-time variant, so that the f32 instances stay instruction for instruction what they were:
+template <int PREC, int MT, int EPI, int NV, int NW, int SWM, int IOB>
+// (IOB: 1 = x holds bf16 elements, 2 = x AND y do (backward-only tensors of the bf16 mode) -- compile-time variants, so that the f32 instances stay instruction for instruction what they were:
 //  this kernel sits at its register cap and a run-time dtype branch cost the f32 forward convs 10 %)
 // (two 5-wave workgroups per CU need 4 wave slots on some SIMD: the 5-wave variants are held to 128 registers)
 __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMArgs a) {
+    constexpr bool XB = IOB >= 1, YB = IOB == 2;
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+    __bf16* const yb = reinterpret_cast<__bf16*>(a.y);       // (YB: the output tensor's elements)
     constexpr bool STATS = EPI != 0;
     constexpr bool SW = SWM == 1;              // swapped roles, gather forms; SWM == 2: swapped roles, scatter forms, both parity classes per N-tile
     constexpr int NTHR = NW * 64;
@@ -296,7 +301,11 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
                 for (int h = 0; h < 2; ++h) {
                     const bool ok = okc && okt[h];
                     const float2 z2 = make_float2(0.f, 0.f);
-                    const float2 ov = (ok && a.accum) ? *reinterpret_cast<const float2*>(a.y + off[h] + cm) : z2;
+                    float2 ov = z2;
+                    if (ok && a.accum) {
+                        if constexpr (YB) { const bf16x2_ t2 = *reinterpret_cast<const bf16x2_*>(yb + off[h] + cm); ov = make_float2((float)t2[0], (float)t2[1]); }
+                        else ov = *reinterpret_cast<const float2*>(a.y + off[h] + cm);
+                    }
                     const float2 yv = (ok && a.bn_y != nullptr) ? *reinterpret_cast<const float2*>(a.bn_y + off[h] + cm) : z2;
                     o[mt][2 * h] = ov.x; o[mt][2 * h + 1] = ov.y;
                     y_[mt][2 * h] = yv.x; y_[mt][2 * h + 1] = yv.y;
@@ -364,7 +373,15 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                            oldv[mt][h] = (okc && okt[h] && a.accum) ? *reinterpret_cast<const float4*>(a.y + off[h] + cm) : z4;
+                            oldv[mt][h] = z4;
+                            if (okc && okt[h] && a.accum) {
+                                if constexpr (YB) {
+                                    const bf16x4_ t4 = *reinterpret_cast<const bf16x4_*>(yb + off[h] + cm);
+                                    oldv[mt][h] = make_float4((float)t4[0], (float)t4[1], (float)t4[2], (float)t4[3]);
+                                } else {
+                                    oldv[mt][h] = *reinterpret_cast<const float4*>(a.y + off[h] + cm);
+                                }
+                            }
                             byv[mt][h] = (okc && okt[h] && a.bn_y != nullptr) ? *reinterpret_cast<const float4*>(a.bn_y + off[h] + cm) : z4;
                         }
                     }
@@ -415,7 +432,13 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
                             float v[4] = {acc2[ce][mt][2 * h] + bq, acc2[cod][mt][2 * h] + bq, acc2[ce][mt][2 * h + 1] + bq, acc2[cod][mt][2 * h + 1] + bq};
                             if constexpr (EPI == 2) { v[0] += oldv[mt][h].x; v[1] += oldv[mt][h].y; v[2] += oldv[mt][h].z; v[3] += oldv[mt][h].w; }
                             if (okt[h]) {
-                                *reinterpret_cast<float4*>(a.y + off[h] + cm) = make_float4(v[0], v[1], v[2], v[3]);
+                                if constexpr (YB) {
+                                    bf16x4_ t4;
+                                    t4[0] = (__bf16)v[0]; t4[1] = (__bf16)v[1]; t4[2] = (__bf16)v[2]; t4[3] = (__bf16)v[3];
+                                    *reinterpret_cast<bf16x4_*>(yb + off[h] + cm) = t4;
+                                } else {
+                                    *reinterpret_cast<float4*>(a.y + off[h] + cm) = make_float4(v[0], v[1], v[2], v[3]);
+                                }
                                 if constexpr (EPI == 1) {
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) { s1[mt][0] += v[e]; s2[mt][0] += v[e] * v[e]; }
@@ -497,7 +520,18 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
                             if constexpr (EPI == 2) v[e] += old_c[mt][e];                       // (0 unless accum)
                             else if (a.act == 1) v[e] = sigmoid_acc(v[e]);
                         }
-                        if (vw == 4) {
+                        if constexpr (YB) {
+                            bf16x2_ t0, t1;
+                            t0[0] = (__bf16)v[0]; t0[1] = (__bf16)v[1]; t1[0] = (__bf16)v[2]; t1[1] = (__bf16)v[3];
+                            if (vw == 4) {
+                                bf16x4_ t4;
+                                t4[0] = t0[0]; t4[1] = t0[1]; t4[2] = t1[0]; t4[3] = t1[1];
+                                if (okt[0]) *reinterpret_cast<bf16x4_*>(yb + off[0] + cm) = t4;
+                            } else {
+                                if (okt[0]) *reinterpret_cast<bf16x2_*>(yb + off[0] + cm) = t0;
+                                if (okt[1]) *reinterpret_cast<bf16x2_*>(yb + off[1] + cm) = t1;
+                            }
+                        } else if (vw == 4) {
                             if (okt[0]) *reinterpret_cast<float4*>(a.y + off[0] + cm) = make_float4(v[0], v[1], v[2], v[3]);
                         } else {
                             if (okt[0]) *reinterpret_cast<float2*>(a.y + off[0] + cm) = make_float2(v[0], v[1]);
@@ -616,7 +650,7 @@ int launch_mt(const CMArgs& a, int grid, size_t lds, int nw, hipStream_t s) {
     int swm = 0;
     if (a.swp_ok != 0 && al16 && ((a.Fout / a.OS) & 1) == 0) {
         if (a.OS == 1) swm = 1;
-        else if (a.nclass == 2 && a.cls[0].par + a.cls[1].par == 1 && (a.sums != nullptr || a.accum || a.bn_y != nullptr) && !a.act)
+        else if (a.nclass == 2 && a.cls[0].par + a.cls[1].par == 1 && (a.sums != nullptr || a.accum || a.bn_y != nullptr) && !a.act)   // (a bf16 output is always one of these)
             swm = 2;                             // (plain-epilogue scatter launches keep the class-by-class form)
     }
     int rc;
@@ -629,10 +663,13 @@ int launch_mt(const CMArgs& a, int grid, size_t lds, int nw, hipStream_t s) {
 #define CM_LAUNCH4(MTV, STV, NVV, NWV, SWV)                                                                \
     do {                                                                                                   \
         if constexpr (STV != 1 && PREC == CRUSE_PREC_BF16) {                                               \
-            if (a.x_bf16) CM_LAUNCH5(MTV, STV, NVV, NWV, SWV, true);                                       \
-            else CM_LAUNCH5(MTV, STV, NVV, NWV, SWV, false);                                               \
+            if (a.x_bf16 && a.y_bf16) {                                                                    \
+                if constexpr (SWV != 0) CM_LAUNCH5(MTV, STV, NVV, NWV, SWV, 2);                            \
+                else { cruse_set_error("conv_mfma: a bf16 output needs the swapped-role (vector-store) forms"); return CRUSE_E_DTYPE; } \
+            } else if (a.x_bf16) CM_LAUNCH5(MTV, STV, NVV, NWV, SWV, 1);                                   \
+            else CM_LAUNCH5(MTV, STV, NVV, NWV, SWV, 0);                                                   \
         } else {                                                                                           \
-            CM_LAUNCH5(MTV, STV, NVV, NWV, SWV, false);                                                    \
+            CM_LAUNCH5(MTV, STV, NVV, NWV, SWV, 0);                                                        \
         }                                                                                                  \
     } while (0)
 #define CM_LAUNCH3(MTV, STV, NVV, NWV)                                                                     \
@@ -676,14 +713,15 @@ int launch_mt(const CMArgs& a, int grid, size_t lds, int nw, hipStream_t s) {
 // to the VALU kernel), < 0 on error.
 int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float* bias, float* y,
                         int B, int T, int Cin, int Fin, int Cout, int Fout, int KT, int S, int pad,
-                        int w_layout, int act, int accum, int prec, double* bn_sums, const CruseBnBwd* bnb, int x_bf16,
+                        int w_layout, int act, int accum, int prec, double* bn_sums, const CruseBnBwd* bnb, int x_bf16, int y_bf16,
                         hipStream_t stream) {
+    if (y_bf16 && !x_bf16) return 0;                                    // (a bf16 output comes with a bf16 input: the backward chain)
     if (Cin % 8 != 0 || (Cin & (Cin - 1)) != 0 || Cout < 8 || Cout > 64 || (TFM * (Fout / (scatter ? 2 : 1))) % 16 != 0) return 0;
     CMArgs a = {};
     a.x = x; a.w = w; a.bias = bias; a.y = y;
     a.B = B; a.T = T; a.Cin = Cin; a.Fin = Fin; a.Cout = Cout; a.Fout = Fout;
     a.act = act; a.accum = accum; a.sums = bn_sums;
-    a.x_bf16 = x_bf16 ? 1 : 0;
+    a.x_bf16 = x_bf16 ? 1 : 0; a.y_bf16 = y_bf16 ? 1 : 0;
     a.tdbg = cruse_opt("cm_dbg", 0);
     a.kint = cruse_opt("cm_kint", 1);
     a.swp_ok = cruse_opt("cm_swap", 1);                  // (A/B switch: 0 = channels in rows for every form)

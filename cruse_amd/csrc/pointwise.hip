@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* dout
                                                                const float* rstd, const float* gamma,
                                                                const float* beta, const double* sums, int nrep, long long rows,
                                                                int C, int F, int relu, int training, float* dy, int dy_bf16,
-                                                               float* dgamma, float* dbeta, float* dbias) {
+                                                               int dout_bf16, float* dgamma, float* dbeta, float* dbias) {
     __shared__ float tab[6][256];
     const double cnt = (double)rows * F;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -278,13 +278,28 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* dout
         // all of the row's loads first: the stores below may alias as far as the compiler knows, and would otherwise
         // serialise load -> compute -> store per float4 group
         float4 vv[CPR_MAXG], dv[CPR_MAXG];
+        if (dout_bf16) {                                   // (dtype branch outside the group loop: the loads stay one batch)
 #pragma unroll
-        for (int g = 0; g < CPR_MAXG; ++g) {
-            const int q = lane + 64 * g;
-            if (q < ng) {
-                const long long i = r * CF + q * 4;
-                vv[g] = *reinterpret_cast<const float4*>(y + i);
-                dv[g] = *reinterpret_cast<const float4*>(dout + i);
+            for (int g = 0; g < CPR_MAXG; ++g) {
+                const int q = lane + 64 * g;
+                if (q < ng) {
+                    const long long i = r * CF + q * 4;
+                    vv[g] = *reinterpret_cast<const float4*>(y + i);
+                    const float2 w2 = *reinterpret_cast<const float2*>(reinterpret_cast<const __bf16*>(dout) + i);
+                    const unsigned w0 = __float_as_uint(w2.x), w1 = __float_as_uint(w2.y);
+                    dv[g] = make_float4(__uint_as_float(w0 << 16), __uint_as_float(w0 & 0xffff0000u), __uint_as_float(w1 << 16),
+                                        __uint_as_float(w1 & 0xffff0000u));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < CPR_MAXG; ++g) {
+                const int q = lane + 64 * g;
+                if (q < ng) {
+                    const long long i = r * CF + q * 4;
+                    vv[g] = *reinterpret_cast<const float4*>(y + i);
+                    dv[g] = *reinterpret_cast<const float4*>(dout + i);
+                }
             }
         }
 #pragma unroll
@@ -813,15 +828,16 @@ extern "C" int cruse_bn_act_bwd_reduce(const float* dout, const float* y, const 
 
 extern "C" int cruse_bn_act_bwd_apply(const float* dout, const float* y, const float* mean, const float* rstd,
                                       const float* gamma, const float* beta, const double* sums, int sum_replicas,
-                                      long long rows, int C, int F, int relu, int training,
+                                      long long rows, int C, int F, int relu, int training, int dout_dtype,
                                       void* dy, int dy_dtype, float* dgamma, float* dbeta, float* dbias, void* stream) {
-    CRUSE_REQUIRE(dy_dtype == CRUSE_DT_F32 || dy_dtype == CRUSE_DT_BF16, CRUSE_E_DTYPE, "bn_act_bwd_apply: dy_dtype %d (f32 or bf16)", dy_dtype);
+    CRUSE_REQUIRE((dy_dtype == CRUSE_DT_F32 || dy_dtype == CRUSE_DT_BF16) && (dout_dtype == CRUSE_DT_F32 || dout_dtype == CRUSE_DT_BF16),
+                  CRUSE_E_DTYPE, "bn_act_bwd_apply: dout_dtype %d / dy_dtype %d (f32 or bf16)", dout_dtype, dy_dtype);
     CRUSE_REQUIRE(rows > 0 && C > 0 && C <= 256 && F > 0 && sum_replicas >= 1, CRUSE_E_SHAPE, "bn_act_bwd_apply: bad shape");
     CRUSE_REQUIRE((C * F) % 4 == 0 && C * F <= 768, CRUSE_E_SHAPE,
                   "bn_act_bwd_apply: C*F=%d must be a multiple of 4 and <= 768", C * F);
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for(rows, 8, 2048)), dim3(256), 0, ST(stream), dout, y,
                        mean, rstd, gamma, beta, sums, sum_replicas, rows, C, F, relu, training, (float*)dy,
-                       dy_dtype == CRUSE_DT_BF16 ? 1 : 0, dgamma, dbeta, dbias);
+                       dy_dtype == CRUSE_DT_BF16 ? 1 : 0, dout_dtype == CRUSE_DT_BF16 ? 1 : 0, dgamma, dbeta, dbias);
     CRUSE_LAUNCH_CHECK("bn_act_bwd_apply");
     return CRUSE_OK;
 }

@@ -880,6 +880,11 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
 
     def split(r):
         return r if isinstance(r, tuple) else (r, None)
+    # ... and the data gradients of the levels between two MFMA kernels (EngineConfig.bf16_de): du_k / de_k for 2 <= k < L
+    de_bf16 = dy_bf16 and bool(config.get().bf16_de) and fuse_bwd
+
+    def lvl_bf16(k):
+        return de_bf16 and 2 <= k < L
     du, du_sums = split(ops.conv_gather(dv, P["conv1_t.weight"], None, B, T, ch[0], Fk[0], ch[1], Fk[1], KT=1, S=2, pad=0, prec=dprec,
                                         bn_bwd=bn_of(2, True) if L >= 2 else None))
     ds = {1: du}                                        # gradient wrt skip_{k} output = du_k
@@ -889,7 +894,7 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
     de_pre = {}
 
     def skip_leaves(k):
-        de_pre[k] = torch.empty(B, T, ch[k], Fk[k], device=dlogit.device, dtype=torch.float32)
+        de_pre[k] = torch.empty(B, T, ch[k], Fk[k], device=dlogit.device, dtype=torch.bfloat16 if lvl_bf16(k) else torch.float32)
 
         def dgrad(k=k, dsk=ds[k], out=de_pre[k]):
             ops.conv_gather(dsk, P[f"skip_connect_{k}.weight"], None, B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1,
@@ -926,7 +931,7 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
         else:
             SIDE.defer(leaf_dec, dv, kind=2, lane=0)
         du, du_sums = split(ops.conv_gather(dv, P[f"conv{k}_t.weight"], None, B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k], KT=1, S=2,
-                                            pad=0, prec=dprec, bn_bwd=bn_of(k + 1, True) if k < L else None))
+                                            pad=0, prec=dprec, bn_bwd=bn_of(k + 1, True) if k < L else None, out_bf16=lvl_bf16(k)))
         ds[k] = du
         skip_leaves(k)
     # ---- bottleneck: u_L = ggru(e_L) + skip_L --------------------------------------------

@@ -135,37 +135,38 @@ def conv_prec(prec) -> int:
 
 
 def conv_gather(x, w, bias, B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout=0, act=0, out=None, accum=False,
-                prec=None, bn_bwd=None):
+                prec=None, bn_bwd=None, out_bf16=False):
     """bn_bwd = (bn_y, mean, rstd, gamma, beta, relu): the output is the gradient wrt the output of that BatchNorm(+ReLU); returns
     (out, sums) with the backward sums of bn_act_bwd accumulated by the conv's epilogue (cruse_conv_gather_bnbwd)."""
     if out is None:
-        out = torch.empty(B, T, Cout, Fout, device=x.device, dtype=torch.float32)
+        out = torch.empty(B, T, Cout, Fout, device=x.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
     if bn_bwd is not None:
         by, mean, rstd, gamma, beta, relu = bn_bwd
         sums, z = ARENA.take(2 * Cout * BN_STAT_REPLICAS, x.device)
         check(lib.cruse_conv_gather_bnbwd(_p(x), _p(w), _p(out), B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout,
                                           1 if accum else 0, conv_prec(prec), _p(by), _p(mean), _p(rstd), _p(gamma), _p(beta),
-                                          1 if relu else 0, _p(sums), z, _xdt(x, "conv_gather"), _stream()))
+                                          1 if relu else 0, _p(sums), z, _xdt(x, "conv_gather"), _xdt(out, "conv_gather out"), _stream()))
         return out, sums
     check(lib.cruse_conv_gather(_p(x), _p(w), _p(bias), _p(out), B, T, Cin, Fin, Cout, Fout, KT, S, pad,
-                                w_layout, act, 1 if accum else 0, conv_prec(prec), _xdt(x, "conv_gather"), _stream()))
+                                w_layout, act, 1 if accum else 0, conv_prec(prec), _xdt(x, "conv_gather"), _xdt(out, "conv_gather out"),
+                                _stream()))
     return out
 
 
-def conv_scatter2(g, w, bias, B, T, Cs, Fg, Cout, KT, pad, act=0, out=None, accum=False, prec=None, bn_bwd=None):
+def conv_scatter2(g, w, bias, B, T, Cs, Fg, Cout, KT, pad, act=0, out=None, accum=False, prec=None, bn_bwd=None, out_bf16=False):
     """bn_bwd: as for conv_gather (cruse_conv_scatter2_bnbwd)."""
     Fout = 2 * Fg
     if out is None:
-        out = torch.empty(B, T, Cout, Fout, device=g.device, dtype=torch.float32)
+        out = torch.empty(B, T, Cout, Fout, device=g.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
     if bn_bwd is not None:
         by, mean, rstd, gamma, beta, relu = bn_bwd
         sums, z = ARENA.take(2 * Cout * BN_STAT_REPLICAS, g.device)
         check(lib.cruse_conv_scatter2_bnbwd(_p(g), _p(w), _p(out), B, T, Cs, Fg, Cout, Fout, KT, pad, 1 if accum else 0,
                                             conv_prec(prec), _p(by), _p(mean), _p(rstd), _p(gamma), _p(beta), 1 if relu else 0,
-                                            _p(sums), z, _xdt(g, "conv_scatter2"), _stream()))
+                                            _p(sums), z, _xdt(g, "conv_scatter2"), _xdt(out, "conv_scatter2 out"), _stream()))
         return out, sums
     check(lib.cruse_conv_scatter2(_p(g), _p(w), _p(bias), _p(out), B, T, Cs, Fg, Cout, Fout, KT, pad, act,
-                                  1 if accum else 0, conv_prec(prec), _xdt(g, "conv_scatter2"), _stream()))
+                                  1 if accum else 0, conv_prec(prec), _xdt(g, "conv_scatter2"), _xdt(out, "conv_scatter2 out"), _stream()))
     return out
 
 
@@ -348,11 +349,13 @@ def bn_act_bwd(dout, y, mean, rstd, gamma, beta, rows, C, F, relu, training, dga
     if sums is None:
         nrep = 1
         sums, z = ARENA.take(2 * C, y.device)
+        _f32(dout, "bn_act_bwd (reduce pass) dout")       # (a bf16 gradient arrives with its sums from the conv that stored it)
         check(lib.cruse_bn_act_bwd_reduce(_p(dout), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), rows, C, F,
                                           1 if relu else 0, _p(sums), z, _stream()))
     dy = torch.empty_like(y, dtype=torch.bfloat16 if out_bf16 else torch.float32)
     check(lib.cruse_bn_act_bwd_apply(_p(dout), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(sums), nrep, rows, C, F,
-                                     1 if relu else 0, 1 if training else 0, _p(dy), 2 if out_bf16 else 0, _p(dgamma), _p(dbeta),
+                                     1 if relu else 0, 1 if training else 0, _xdt(dout, "bn_act_bwd dout"), _p(dy), 2 if out_bf16 else 0,
+                                     _p(dgamma), _p(dbeta),
                                      _p(dbias), _stream()))
     return dy
 

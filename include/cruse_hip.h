@@ -99,7 +99,7 @@ int cruse_istft_bwd(const float* dwave, int B, int T, int n_fft, int hop, int L,
  * prec < 0, or an ineligible shape (Cin == 1, Cout == 1), runs the exact-f32 VALU kernel. */
 int cruse_conv_gather(const float* x, const float* w, const float* bias, float* y,
                       int B, int T, int Cin, int Fin, int Cout, int Fout,
-                      int KT, int S, int pad, int w_layout, int act, int accum, int prec, int x_dtype, void* stream);
+                      int KT, int S, int pad, int w_layout, int act, int accum, int prec, int x_dtype, int y_dtype, void* stream);
 
 /* scatter form, frequency stride 2:
  *   y[b,t,co,fo] (+)= act(bias[co] + sum_{cs,kt,kf : (fo+pad-kf) even} w[cs][co][kt][kf] *
@@ -108,7 +108,7 @@ int cruse_conv_gather(const float* x, const float* w, const float* bias, float* 
  * KT=1, pad=0, Fout=2*Fg.  Backward-data of the (2,3)/(1,2) encoder conv: KT=2, pad=1. */
 int cruse_conv_scatter2(const float* g, const float* w, const float* bias, float* y,
                         int B, int T, int Cs, int Fg, int Cout, int Fout,
-                        int KT, int pad, int act, int accum, int prec, int x_dtype, void* stream);
+                        int KT, int pad, int act, int accum, int prec, int x_dtype, int y_dtype, void* stream);
 
 /* Both forms with the batch statistics of the BatchNorm2d that follows every encoder / decoder conv
  * (cruse_net.py:139,150) accumulated by the conv's own epilogue: y = conv (no activation, no accumulate), and what
@@ -129,7 +129,10 @@ int cruse_conv_scatter2_bnstats(const float* g, const float* w, const float* bia
 /* x_dtype / a_dtype / bt_dtype / dy_dtype (ABI 7; CRUSE_DT_F32 or CRUSE_DT_BF16): BACKWARD-ONLY tensors of the bf16 mode -- the
  * BatchNorm-backward output dy, which its two consumers (the data-gradient conv and the weight gradient) round to bf16 operands
  * anyway -- may be stored as bf16 in the same [B,T,C,F] layout: half the bytes written once and read twice, the same bits into
- * the MFMAs.  bf16 inputs need the MFMA kernels (CRUSE_PREC_BF16 for the weight gradient); the VALU fall-backs refuse them. */
+ * the MFMAs.  bf16 inputs need the MFMA kernels (CRUSE_PREC_BF16 for the weight gradient); the VALU fall-backs refuse them.
+ * y_dtype / dout_dtype: the data gradients themselves (de, du: conv output -> BatchNorm-backward input, skip-path leaves) as bf16
+ * too -- sums and accumulation stay f32, the stored value is rounded once per pass; a bf16 output goes with a bf16 input and
+ * the swapped-role (vector-store) forms of the MFMA conv. */
 /* DATA-GRADIENT convolutions whose output y is the gradient wrt the OUTPUT of a BatchNorm2d(+ReLU) (the backward pass of
  * cruse_net.py:139-142,149-152 walks conv -> BN -> ReLU stacks, so every data gradient but the first feeds a BatchNorm
  * backward): the conv's epilogue also accumulates what cruse_bn_act_bwd_reduce(dout = y, bn_y, ...) would -- sum g and
@@ -141,11 +144,11 @@ int cruse_conv_scatter2_bnstats(const float* g, const float* w, const float* bia
 int cruse_conv_gather_bnbwd(const float* x, const float* w, float* y, int B, int T, int Cin, int Fin, int Cout, int Fout,
                             int KT, int S, int pad, int w_layout, int accum, int prec,
                             const float* bn_y, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                            int relu, double* sums, int zeroed, int x_dtype, void* stream);
+                            int relu, double* sums, int zeroed, int x_dtype, int y_dtype, void* stream);
 int cruse_conv_scatter2_bnbwd(const float* g, const float* w, float* y, int B, int T, int Cs, int Fg, int Cout, int Fout,
                               int KT, int pad, int accum, int prec,
                               const float* bn_y, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                              int relu, double* sums, int zeroed, int x_dtype, void* stream);
+                              int relu, double* sums, int zeroed, int x_dtype, int y_dtype, void* stream);
 
 /* profiling aid: with cruse_set_option("cm_dbg", 1) workgroup 0 of an MFMA convolution launch stamps s_memtime at its phase
  * boundaries; this copies the sums of the LAST such launch to out8 (host memory, 8 values: prologue, tile staging incl. the wait
@@ -203,7 +206,7 @@ int cruse_bn_act_bwd_reduce(const float* dout, const float* y, const float* mean
  * sums is [sum_replicas][2*C] (1 after cruse_bn_act_bwd_reduce, CRUSE_BN_STAT_REPLICAS after cruse_conv_*_bnbwd). */
 int cruse_bn_act_bwd_apply(const float* dout, const float* y, const float* mean, const float* rstd,
                            const float* gamma, const float* beta, const double* sums, int sum_replicas,
-                           long long rows, int C, int F, int relu, int training,
+                           long long rows, int C, int F, int relu, int training, int dout_dtype,
                            void* dy, int dy_dtype, float* dgamma, float* dbeta, float* dbias, void* stream);
 
 /* ---- LayerNorm (+ group interleave, + residual) (cruse_net.py:32-33,43-51,160) -- */

@@ -1051,3 +1051,30 @@ def test_backward_only_tensors_stored_as_bf16_give_the_same_bits(ops, form):
             dg = torch.zeros(C).cuda(); db = torch.zeros(C).cuda()
             outs.append(ops.bn_act_bwd(dout, y, mean, rstd, gamma, beta, rows, C, F, True, True, dg, db, out_bf16=bf))
         assert outs[1].dtype == torch.bfloat16 and torch.equal(outs[1], outs[0].to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("form", ["gather", "gather_bnbwd", "scatter_accum"])
+def test_data_gradients_stored_as_bf16(ops, form):
+    """EngineConfig.bf16_de: a data-gradient conv of the bf16 mode writes its output as bf16 -- the f32 result rounded once; when
+    it accumulates, (old bf16 + conv) in f32, rounded once; the BatchNorm-backward sums of its epilogue are those of the f32 values."""
+    torch.manual_seed(8)
+    B, T = 3, 21
+    if form.startswith("gather"):
+        x = torch.randn(B, T, 16, 40).cuda().to(torch.bfloat16); w = (0.2 * torch.randn(32, 16, 1, 3)).cuda()
+        C, F = 32, 20
+        run = lambda bf, bn: ops.conv_gather(x, w, None, B, T, 16, 40, 32, 20, KT=1, S=2, pad=0, prec=ops.PREC_BF16, bn_bwd=bn, out_bf16=bf)
+    else:
+        x = torch.randn(B, T, 32, 20).cuda().to(torch.bfloat16); w = (0.2 * torch.randn(32, 16, 2, 3)).cuda()
+        C, F = 16, 40
+        base = torch.randn(B, T, C, F).cuda().to(torch.bfloat16)
+        run = lambda bf, bn: ops.conv_scatter2(x, w, None, B, T, 32, 20, 16, KT=2, pad=1, out=(base.clone() if bf else base.float()), accum=True,
+                                               prec=ops.PREC_BF16, bn_bwd=bn)
+    bn = None
+    if form != "gather":
+        y = torch.randn(B, T, C, F).cuda()
+        bn = (y, (0.1 * torch.randn(C)).cuda(), (1.0 + 0.2 * torch.rand(C)).cuda(), (1.0 + 0.3 * torch.randn(C)).cuda(), (0.2 * torch.randn(C)).cuda(), True)
+    r32, rbf = run(False, bn), run(True, bn)
+    if bn is not None:
+        (r32, s32), (rbf, sbf) = r32, rbf
+        assert rel_l2(sbf, s32) < 1e-6
+    assert rbf.dtype == torch.bfloat16 and torch.equal(rbf, r32.to(torch.bfloat16))

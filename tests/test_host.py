@@ -30,7 +30,7 @@ def test_error_channel_without_gpu():
     # shape validation happens on the host before any HIP call
     rc = lib.cruse_gemm(0, 0, 0, 4, 4, None, 4, None, 4, None, 4, None, 0, 1, 0, 0, None)
     assert rc == -1 and b"gemm" in lib.cruse_last_error()
-    rc = lib.cruse_conv_gather(None, None, None, None, 1, 1, 1, 8, 4, 8, 2, 2, 1, 0, 0, 0, -1, 0, None)
+    rc = lib.cruse_conv_gather(None, None, None, None, 1, 1, 1, 8, 4, 8, 2, 2, 1, 0, 0, 0, -1, 0, 0, None)
     assert rc == -1 and b"Fout" in lib.cruse_last_error()
     rc = lib.cruse_gru_seq_fwd(None, None, None, None, None, None, None, 2, 3, 1, 100, 0, None, None)
     assert rc == -1 and b"multiple of 32" in lib.cruse_last_error()

@@ -39,7 +39,7 @@ def main():
         t_red = timeit(lambda: check(lib.cruse_bn_act_bwd_reduce(_p(dout), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), rows, C, F,
                                                                  1, _p(sm), 1, _stream())))
         t_app = timeit(lambda: check(lib.cruse_bn_act_bwd_apply(_p(dout), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(sm), 1, rows,
-                                                                C, F, 1, 1, _p(dyo), 0, _p(dg), _p(db), _p(dbias), _stream())))
+                                                                C, F, 1, 1, 0, _p(dyo), 0, _p(dg), _p(db), _p(dbias), _stream())))
         print(f"            reduce alone {t_red:6.1f} us ({2 * mb / t_red:5.2f} TB/s)   apply alone {t_app:6.1f} us ({3 * mb / t_app:5.2f} TB/s)")
         print(f"C={C:3d} F={F:3d}: bn_stats {t_stats:6.1f} us ({mb / t_stats:5.2f} TB/s)  fin_act_fwd {t_fwd:6.1f} us "
               f"({3 * mb / t_fwd:5.2f} TB/s)  bn_act_bwd reduce+apply {t_bwd:6.1f} us ({5 * mb / t_bwd:5.2f} TB/s)")
