@@ -232,10 +232,10 @@ class KernelTimer:
 
 def _pmc_file():
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for name in ("r03_pmc_hbm_traffic.csv", "r02_pmc_hbm_traffic.csv", "r01_pmc_hbm_traffic.csv"):
+    for name in ("r04_pmc_hbm_traffic.csv", "r03_pmc_hbm_traffic.csv", "r02_pmc_hbm_traffic.csv", "r01_pmc_hbm_traffic.csv"):
         if os.path.exists(os.path.join(d, name)):
             return os.path.join(d, name)
-    return os.path.join(d, "r03_pmc_hbm_traffic.csv")
+    return os.path.join(d, "r04_pmc_hbm_traffic.csv")
 
 
 PMC_FILE = _pmc_file()
@@ -278,7 +278,9 @@ def pmc_traffic():
 def pmc_mfma_util():
     """MFMA utilisation per kernel family from the committed rocprofv3 PMC pass (profiles/r03_pmc_mfma_util.csv, made by
     tools/pmc_traffic.py --mfma at the bench shape): sum(SQ_VALU_MFMA_BUSY_CYCLES) / sum(GRBM_GUI_ACTIVE / 8 XCDs * 256 CUs * 4)."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_mfma_util.csv")
+    path = os.path.join(ROOT, "profiles", "r04_pmc_mfma_util.csv")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r03_pmc_mfma_util.csv")
     out = {}
     if not os.path.exists(path):
         return out
@@ -714,7 +716,7 @@ def main():
             for fam, ent in rl.items():
                 if util.get(fam) is not None:
                     ent["mfma_util_pmc"] = util[fam]
-                    ent["mfma_util_source"] = "profiles/r03_pmc_mfma_util.csv (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs))"
+                    ent["mfma_util_source"] = "profiles/r04_pmc_mfma_util.csv (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs))"
             for fam, ent in rl.items():
                 if pmc.get(fam):
                     ent["traffic"] = round(pmc[fam])
@@ -727,7 +729,7 @@ def main():
         roof["ms_per_step_all_launches"] = round(per_step[dom], 3)
         # the same fraction from the committed rocprofv3 trace of the GRAPH run (the kernel beside its side-stream
         # co-runners), next to the isolated HIP-event figure above
-        kname = {"gru_seq_bwd": "gru_bwd_rs_kernel", "gru_seq_fwd": "gru_fwd_lean_kernel"}.get(dom)
+        kname = {"gru_seq_bwd": "gru_bwd_tf_kernel", "gru_seq_fwd": "gru_fwd_lean_kernel"}.get(dom)
         if kname and roof.get("avg_launch_ms") and (B, a.seconds, a.groups, a.prec) == (64, 4.0, 1, "bf16"):
             ns, src = profile_avg_ns(kname)
             if ns:
