@@ -15,7 +15,7 @@ def _code(tp: str) -> str:
     if "*" in tp:
         return "c" if tp.replace("const", "").replace(" ", "") == "char*" else "p"
     base = tp.replace("const", "").strip()
-    return {"int": "i", "unsigned": "i", "float": "f", "long long": "q", "size_t": "z", "double": "d", "void": ""}[base]
+    return {"int": "i", "unsigned": "i", "float": "f", "long long": "q", "unsigned long long": "Q", "size_t": "z", "double": "d", "void": ""}[base]
 
 
 def parse_header(path: str = HEADER):

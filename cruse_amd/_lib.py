@@ -18,7 +18,7 @@ PREC_BY_NAME = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "f16"
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 
 _T = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "q": ctypes.c_longlong, "d": ctypes.c_double, "c": ctypes.c_char_p,
-      "z": ctypes.c_size_t}
+      "z": ctypes.c_size_t, "Q": ctypes.c_ulonglong}
 
 # name -> (argument type string, restype); mirrors include/cruse_hip.h one to one
 SIGNATURES = {
@@ -108,6 +108,7 @@ SIGNATURES = {
     "cruse_fir_causal": ("ppqiiipp", "i"),
     "cruse_stream_create_masked": ("ppi", "i"),
     "cruse_cu_census": ("piip", "i"),
+    "cruse_cu_hog": ("iQp", "i"),
     "cruse_zero": ("pzp", "i"),
     "cruse_accum_f64": ("ppip", "i"),
     "cruse_counters_add": ("piqp", "i"),

@@ -122,3 +122,24 @@ extern "C" int cruse_cu_census(unsigned* out, int nblocks, unsigned spin, void* 
     if (e != hipSuccess) { cruse_set_error("cu_census: %s", hipGetErrorString(e)); return CRUSE_E_HIP; }
     return CRUSE_OK;
 }
+
+// A workgroup that HOLDS a CU for `ticks` shader clocks: 128 KB of LDS per block, so no recurrence workgroup (45-60 KB) fits beside
+// it -- what a collective's channels (RCCL) or another tenant's kernel do to the persistent recurrences, which need their teams
+// co-resident.  Test / probe rig (tests/test_gpu_ddp.py, tools/host_contention_probe.py); not used by the product path.
+__global__ __launch_bounds__(256) void cruse_hog_kernel(unsigned long long ticks, unsigned* sink) {
+    extern __shared__ unsigned hog_lds[];
+    hog_lds[threadIdx.x] = threadIdx.x;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+    if (sink && hog_lds[(threadIdx.x + 1) & 255] == 0xffffffffu) *sink = 1u;
+}
+extern "C" int cruse_cu_hog(int nblocks, unsigned long long ticks, void* stream) {
+    if (nblocks <= 0 || nblocks > 256) { cruse_set_error("cu_hog: nblocks=%d (1..256)", nblocks); return CRUSE_E_SHAPE; }
+    const size_t lds = 128 * 1024;
+    int rc = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(cruse_hog_kernel), lds, "cu_hog");
+    if (rc) return rc;
+    hipLaunchKernelGGL(cruse_hog_kernel, dim3(nblocks), dim3(256), lds, (hipStream_t)stream, ticks, (unsigned*)nullptr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { cruse_set_error("cu_hog: %s", hipGetErrorString(e)); return CRUSE_E_HIP; }
+    return CRUSE_OK;
+}

@@ -804,6 +804,12 @@ def step_health(gru_status, loss_sum, health, loss_acc=None, loss_scale=1.0) -> 
     check(lib.cruse_step_health(_p(gru_status), _p(loss_sum), _p(health), _p(loss_acc), float(loss_scale), _stream()))
 
 
+def cu_hog(nblocks: int, microseconds: float, clock_ghz: float = 2.1) -> None:
+    """Test / probe rig: `nblocks` workgroups hold one CU each (128 KB of LDS) for about `microseconds` on the current stream
+    (cruse_cu_hog) -- what a collective's channels or another tenant do to the persistent recurrences."""
+    check(lib.cruse_cu_hog(int(nblocks), int(microseconds * 1e3 * clock_ghz), _stream()))
+
+
 def zero_(t: torch.Tensor) -> torch.Tensor:
     """stream-ordered zero fill (kernel node; see cruse_zero)."""
     check(lib.cruse_zero(_p(t), t.numel() * t.element_size(), _stream()))

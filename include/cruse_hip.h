@@ -535,6 +535,9 @@ int cruse_snr_mix(const float* clean, const float* noise, const float* snr_db, i
 int cruse_stream_create_masked(void** stream_out, const unsigned* mask, int nwords);
 /* out[2*b], out[2*b+1] = HW_REG_XCC_ID, HW_REG_HW_ID of block b (each block idles `spin` clock ticks): placement census */
 int cruse_cu_census(unsigned* out, int nblocks, unsigned spin, void* stream);
+/* test / probe rig: nblocks workgroups that each HOLD a CU (128 KB of LDS) for `ticks` shader clocks -- what a collective's
+ * channels or another tenant do to the persistent recurrences, whose teams must be co-resident (tests/test_gpu_ddp.py) */
+int cruse_cu_hog(int nblocks, unsigned long long ticks, void* stream);
 
 /* ---- stream-ordered bookkeeping (keeps the training step free of library kernels) ---- */
 /* zero-fill `bytes` (multiple of 4) with a KERNEL node (hipMemsetAsync nodes raced inside captured graphs) --

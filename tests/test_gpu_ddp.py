@@ -185,3 +185,30 @@ def test_rccl_bucketed_schedule_world1(tmp_path, nograph):
     assert rel_l2(a["g0"], b["g0"]) < 1e-6
     assert rel_l2(a["params"], b["params"]) < 5e-4        # atomics order: noise-level entries move through Adam (reproducibility)
     assert a["losses"] == pytest.approx(b["losses"], rel=1e-6)
+
+
+@pytest.mark.parametrize("held,us", [(48, 4000.0), (128, 1500.0)])
+def test_recurrences_survive_cu_pressure(held, us):
+    """the persistent recurrences need their 160 workgroups co-resident; a collective's channels (RCCL takes
+    tens of CUs) or another tenant's kernel may hold CUs while a training step runs.  A rig kernel holds `held` CUs (128 KB of LDS
+    each: no recurrence workgroup fits beside it) on another stream for the length of a step -- 48 leaves room for every team,
+    128 does not, so part of a launch has to WAIT for CUs while its resident team mates poll: the step must complete with no
+    hand-off time-out (the spin limit is ~1 s of polling), nothing skipped, and the same loss as an undisturbed step."""
+    from cruse_amd import ops
+    from cruse_amd.data import synth_batch
+    from cruse_amd.engine import TrainEngine
+    from cruse_amd.model.cruse_net import unet_2
+    noisy, clean = synth_batch(64, 64000, "cuda", 21)
+    torch.manual_seed(3)
+    eng = TrainEngine(unet_2(rnn_groups=1, precision="bf16").cuda(), use_graph=False, lr=0.0)
+    ref = eng.loss_value(eng.step(noisy, clean))
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    losses = []
+    for rep in range(3):
+        with torch.cuda.stream(side):
+            ops.cu_hog(held, us)                                # holds its CUs while the step below is issued and runs
+        losses.append(eng.loss_value(eng.step(noisy, clean)))
+        torch.cuda.synchronize()
+    assert ops.gru_status() == 0 and eng.timeout_steps() == 0 and eng.skipped_steps() == 0
+    assert all(v == ref for v in losses), (ref, losses)
