@@ -176,7 +176,7 @@ def cpu_baseline(groups: int, budget_s: float = 14.0):
 class KernelTimer:
     """Wraps cruse_amd.ops entry points with HIP events on torch's current stream (where the kernels run)."""
 
-    NAMES = ["stft", "conv_gather", "conv_scatter2", "conv_wgrad", "channel_sum", "col_sum", "bn_stats", "bn_finalize",
+    NAMES = ["stft", "conv_gather", "conv_scatter2", "conv_gather_bnin", "conv_scatter2_bnin", "conv_wgrad", "channel_sum", "col_sum", "bn_stats", "bn_finalize",
              "bn_act_fwd", "bn_finalize_act_fwd", "bn_act_bwd", "ln_fwd", "ln_bwd", "gemm", "gemm_bf16_nt", "gemm_bf16x3_nt", "gemm_bf16_tn", "gru_gate_bias_sums", "cast_bf16", "cast_bf16_padded",
              "ktile_bf16", "transpose_bf16",
              "gru_seq_fwd", "gru_seq_bwd", "gru_gate_grads", "gru_gate_grads_bf16", "mask_loss"]
@@ -329,7 +329,7 @@ def kernel_rooflines(B, T, H, G, prec, per_step_ms, calls):
             out[gname] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_MFMA_TFLOPS[prec], "unit": "TFLOP/s",
                           "frac": round(ach / PEAK_MFMA_TFLOPS[prec], 4), "traffic": None,
                           "avg_launch_ms": round(avg_ms, 4)}
-    hbm = {"conv_gather": 2 * 640 * 4.0, "conv_scatter2": 2 * 640 * 4.0, "bn_act_fwd": 2 * 640 * 4.0, "bn_finalize_act_fwd": 2 * 640 * 4.0,
+    hbm = {"conv_gather": 2 * 640 * 4.0, "conv_scatter2": 2 * 640 * 4.0, "conv_gather_bnin": 2 * 640 * 4.0, "conv_scatter2_bnin": 3 * 640 * 4.0, "bn_act_fwd": 2 * 640 * 4.0, "bn_finalize_act_fwd": 2 * 640 * 4.0,
            "bn_act_bwd": 5 * 640 * 4.0, "conv_wgrad": 2 * 640 * 4.0, "ln_fwd": 2 * 640 * 4.0, "ln_bwd": 3 * 640 * 4.0}
     for name, bpf in hbm.items():
         if name in per_step_ms:

@@ -37,6 +37,8 @@ SIGNATURES = {
     "cruse_conv_gather_bnbwd": ("pppiiiiiiiiiiiipppppipiiip", "i"),
     "cruse_conv_scatter2_bnbwd": ("pppiiiiiiiiiipppppipiiip", "i"),
     "cruse_conv_wgrad_ws_bytes": ("iii", "z"),
+    "cruse_conv_gather_bnin": ("ppiqffpppppppppppiiiiiiiiiipip", "i"),
+    "cruse_conv_scatter2_bnin": ("ppiqffpppppppppppiiiiiiiiipip", "i"),
     "cruse_conv_wgrad": ("pppiiiiiiiiiiiipp", "i"),
     "cruse_channel_sum": ("pqiipp", "i"),
     "cruse_col_sum": ("pqiipp", "i"),

@@ -9,6 +9,11 @@
 // the BatchNorm(+ReLU) whose input gradient a data-gradient convolution produces (cruse_conv_*_bnbwd): its pre-BN tensor and
 // per-channel statistics / affine parameters
 struct CruseBnBwd { const float* y; const float* mean; const float* rstd; const float* gamma; const float* beta; int relu; };
+// the BatchNorm(+ReLU) a forward convolution applies to its INPUT while staging it (cruse_conv_*_bnin): batch sums of the layer below
+// ([nrep][2*Cin] f64), its affine parameters, where to publish mean / rstd / running statistics (nullable), an optional tensor added
+// after the ReLU (the decoder's skip) and an optional bf16 copy of the transformed rows
+struct CruseBnIn { const double* sums; int nrep; long long count; float eps, momentum; const float* gamma; const float* beta;
+                   float* mean_o; float* rstd_o; float* rmean; float* rvar; const float* add; void* copy_bf16; };
 
 extern "C" void cruse_set_error(const char* fmt, ...);
 

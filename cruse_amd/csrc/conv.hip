@@ -449,7 +449,7 @@ int set_smem(K kern, size_t bytes, const char* name) {
 int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float* bias, float* y,
                         int B, int T, int Cin, int Fin, int Cout, int Fout, int KT, int S, int pad,
                         int w_layout, int act, int accum, int prec, double* bn_sums, const CruseBnBwd* bnb, int x_bf16, int y_bf16,
-                        hipStream_t stream);
+                        const CruseBnIn* bni, hipStream_t stream);
 extern "C" int cruse_bn_act_bwd_reduce(const float* dout, const float* y, const float* mean, const float* rstd,
                                        const float* gamma, const float* beta, long long rows, int C, int F,
                                        int relu, double* sums, int zeroed, void* stream);
@@ -459,7 +459,7 @@ namespace {
 int conv_gather_impl(const float* x, const float* w, const float* bias, float* y,
                      int B, int T, int Cin, int Fin, int Cout, int Fout,
                      int KT, int S, int pad, int w_layout, int act, int accum, int prec, double* bn_sums, void* stream,
-                     const CruseBnBwd* bnb = nullptr, int x_dtype = CRUSE_DT_F32, int y_dtype = CRUSE_DT_F32) {
+                     const CruseBnBwd* bnb = nullptr, int x_dtype = CRUSE_DT_F32, int y_dtype = CRUSE_DT_F32, const CruseBnIn* bni = nullptr) {
     CRUSE_REQUIRE((x_dtype == CRUSE_DT_F32 || x_dtype == CRUSE_DT_BF16) && (y_dtype == CRUSE_DT_F32 || y_dtype == CRUSE_DT_BF16), CRUSE_E_DTYPE,
                   "conv_gather: x_dtype %d / y_dtype %d (f32 or bf16)", x_dtype, y_dtype);
     CRUSE_REQUIRE(B > 0 && T > 0 && Cin > 0 && Cout > 0 && Fin > 0 && Fout > 0, CRUSE_E_SHAPE,
@@ -472,9 +472,10 @@ int conv_gather_impl(const float* x, const float* w, const float* bias, float* y
     CRUSE_REQUIRE(!(accum && act), CRUSE_E_SHAPE, "conv_gather: accum with activation");
     if (prec >= 0) {
         const int r = cruse_conv_mfma_try(0, x, w, bias, y, B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout, act, accum,
-                                          prec, bn_sums, bnb, x_dtype == CRUSE_DT_BF16, y_dtype == CRUSE_DT_BF16, (hipStream_t)stream);
+                                          prec, bn_sums, bnb, x_dtype == CRUSE_DT_BF16, y_dtype == CRUSE_DT_BF16, bni, (hipStream_t)stream);
         if (r != 0) return r < 0 ? r : CRUSE_OK;
     }
+    CRUSE_REQUIRE(bni == nullptr, CRUSE_E_SHAPE, "conv_gather_bnin: the fused input BatchNorm needs the MFMA kernel in the bf16 mode (Cin %d, Cout %d, prec %d)", Cin, Cout, prec);
     CRUSE_REQUIRE(x_dtype == CRUSE_DT_F32 && y_dtype == CRUSE_DT_F32, CRUSE_E_DTYPE,
                   "conv_gather: a bf16 input / output needs the MFMA kernel in the bf16 data-gradient mode (Cin %d, Cout %d, prec %d)", Cin, Cout, prec);
     const bool fuse = bn_sums && Cout <= 64 && bnb == nullptr;
@@ -502,7 +503,7 @@ int conv_gather_impl(const float* x, const float* w, const float* bias, float* y
 int conv_scatter2_impl(const float* g, const float* w, const float* bias, float* y,
                        int B, int T, int Cs, int Fg, int Cout, int Fout,
                        int KT, int pad, int act, int accum, int prec, double* bn_sums, void* stream,
-                       const CruseBnBwd* bnb = nullptr, int x_dtype = CRUSE_DT_F32, int y_dtype = CRUSE_DT_F32) {
+                       const CruseBnBwd* bnb = nullptr, int x_dtype = CRUSE_DT_F32, int y_dtype = CRUSE_DT_F32, const CruseBnIn* bni = nullptr) {
     CRUSE_REQUIRE((x_dtype == CRUSE_DT_F32 || x_dtype == CRUSE_DT_BF16) && (y_dtype == CRUSE_DT_F32 || y_dtype == CRUSE_DT_BF16), CRUSE_E_DTYPE,
                   "conv_scatter2: x_dtype %d / y_dtype %d (f32 or bf16)", x_dtype, y_dtype);
     CRUSE_REQUIRE(B > 0 && T > 0 && Cs > 0 && Cout > 0 && Fg > 0, CRUSE_E_SHAPE, "conv_scatter2: empty shape");
@@ -512,9 +513,10 @@ int conv_scatter2_impl(const float* g, const float* w, const float* bias, float*
     CRUSE_REQUIRE(!(accum && act), CRUSE_E_SHAPE, "conv_scatter2: accum with activation");
     if (prec >= 0) {
         const int r = cruse_conv_mfma_try(1, g, w, bias, y, B, T, Cs, Fg, Cout, Fout, KT, 2, pad, 0, act, accum, prec,
-                                          bn_sums, bnb, x_dtype == CRUSE_DT_BF16, y_dtype == CRUSE_DT_BF16, (hipStream_t)stream);
+                                          bn_sums, bnb, x_dtype == CRUSE_DT_BF16, y_dtype == CRUSE_DT_BF16, bni, (hipStream_t)stream);
         if (r != 0) return r < 0 ? r : CRUSE_OK;
     }
+    CRUSE_REQUIRE(bni == nullptr, CRUSE_E_SHAPE, "conv_scatter2_bnin: the fused input BatchNorm needs the MFMA kernel in the bf16 mode (Cs %d, Cout %d, prec %d)", Cs, Cout, prec);
     CRUSE_REQUIRE(x_dtype == CRUSE_DT_F32 && y_dtype == CRUSE_DT_F32, CRUSE_E_DTYPE,
                   "conv_scatter2: a bf16 input / output needs the MFMA kernel in the bf16 data-gradient mode (Cs %d, Cout %d, prec %d)", Cs, Cout, prec);
     ConvArgs a{g, w, bias, y, B, T, Cs, Fg, Cout, Fout, KT, 2, pad, 0, act, accum, nullptr};
@@ -595,6 +597,36 @@ extern "C" int cruse_conv_scatter2_bnbwd(const float* g, const float* w, float* 
     if (rc) return rc;
     const CruseBnBwd bnb = {bn_y, mean, rstd, gamma, beta, relu};
     return conv_scatter2_impl(g, w, nullptr, y, B, T, Cs, Fg, Cout, Fout, KT, pad, 0, accum, prec, sums, stream, &bnb, x_dtype, y_dtype);
+}
+
+extern "C" int cruse_conv_gather_bnin(const float* x_pre, const double* in_sums, int in_replicas, long long in_count, float eps, float momentum,
+                                      const float* in_gamma, const float* in_beta, float* in_mean, float* in_rstd, float* in_running_mean,
+                                      float* in_running_var, const float* in_add, void* in_copy_bf16,
+                                      const float* w, const float* bias, float* y, int B, int T, int Cin, int Fin, int Cout, int Fout,
+                                      int KT, int S, int pad, int prec, double* out_sums, int zeroed, void* stream) {
+    CRUSE_REQUIRE(x_pre && in_sums && in_gamma && in_beta && in_replicas >= 1 && in_count > 0, CRUSE_E_SHAPE, "conv_gather_bnin: input BatchNorm tensors missing");
+    CRUSE_REQUIRE((in_mean == nullptr) == (in_rstd == nullptr) && (in_running_mean == nullptr) == (in_running_var == nullptr), CRUSE_E_SHAPE,
+                  "conv_gather_bnin: mean / rstd and the running statistics come in pairs");
+    if (out_sums) { int rc = prep_sums(out_sums, Cout, zeroed, stream, "conv_gather_bnin"); if (rc) return rc; }
+    const CruseBnIn bni = {in_sums, in_replicas, in_count, eps, momentum, in_gamma, in_beta, in_mean, in_rstd, in_running_mean, in_running_var,
+                           in_add, in_copy_bf16};
+    return conv_gather_impl(x_pre, w, bias, y, B, T, Cin, Fin, Cout, Fout, KT, S, pad, 0, 0, 0, prec, out_sums, stream, nullptr, CRUSE_DT_F32,
+                            CRUSE_DT_F32, &bni);
+}
+
+extern "C" int cruse_conv_scatter2_bnin(const float* g_pre, const double* in_sums, int in_replicas, long long in_count, float eps, float momentum,
+                                        const float* in_gamma, const float* in_beta, float* in_mean, float* in_rstd, float* in_running_mean,
+                                        float* in_running_var, const float* in_add, void* in_copy_bf16,
+                                        const float* w, const float* bias, float* y, int B, int T, int Cs, int Fg, int Cout, int Fout,
+                                        int KT, int pad, int prec, double* out_sums, int zeroed, void* stream) {
+    CRUSE_REQUIRE(g_pre && in_sums && in_gamma && in_beta && in_replicas >= 1 && in_count > 0, CRUSE_E_SHAPE, "conv_scatter2_bnin: input BatchNorm tensors missing");
+    CRUSE_REQUIRE((in_mean == nullptr) == (in_rstd == nullptr) && (in_running_mean == nullptr) == (in_running_var == nullptr), CRUSE_E_SHAPE,
+                  "conv_scatter2_bnin: mean / rstd and the running statistics come in pairs");
+    if (out_sums) { int rc = prep_sums(out_sums, Cout, zeroed, stream, "conv_scatter2_bnin"); if (rc) return rc; }
+    const CruseBnIn bni = {in_sums, in_replicas, in_count, eps, momentum, in_gamma, in_beta, in_mean, in_rstd, in_running_mean, in_running_var,
+                           in_add, in_copy_bf16};
+    return conv_scatter2_impl(g_pre, w, bias, y, B, T, Cs, Fg, Cout, Fout, KT, pad, 0, 0, prec, out_sums, stream, nullptr, CRUSE_DT_F32,
+                              CRUSE_DT_F32, &bni);
 }
 
 extern "C" size_t cruse_conv_wgrad_ws_bytes(int Ca, int Cb, int KT) {

@@ -39,6 +39,14 @@ __device__ unsigned long long g_cm_stamps[8];
 struct CMArgs {
     int tdbg, kint, swp_ok;
     int y_bf16;                                  // y too (swapped-role forms only: vector stores)
+    // FUSED INPUT BatchNorm (IOB 3 / 4; forward convs of the bf16 mode, training): x is the PRE-BatchNorm tensor of the layer below and
+    // the staging applies e = relu((x - mean) * rstd * gamma + beta) [+ in_add] per input channel -- mean / rstd derived by every
+    // workgroup from that layer's batch sums (in_sums, in_nrep replicas); block 0 of the launch that owns the statistics also writes
+    // them out and updates the running statistics (in_mean_o != null).  in_copy (nullable): a bf16 copy of the transformed rows
+    // [B,T,Cin,Fin] -- the operand the weight gradients of the bf16 mode read.  The normalised tensor itself never exists in HBM.
+    const double* in_sums; int in_nrep; double in_inv_count, in_unb; float in_eps, in_mom;
+    const float* in_gamma; const float* in_beta; float* in_mean_o; float* in_rstd_o; float* in_rmean; float* in_rvar;
+    const float* in_add; void* in_copy;
     int x_bf16;                                  // x holds bf16 elements (a backward-only tensor stored in bf16): widened while staging
     const float* x; const float* w; const float* bias; float* y;
     int B, T, Cin, Fin, Cout, Fout;
@@ -115,7 +123,8 @@ template <int PREC, int MT, int EPI, int NV, int NW, int SWM, int IOB>
 //  this kernel sits at its register cap and a run-time dtype branch cost the f32 forward convs 10 %)
 // (two 5-wave workgroups per CU need 4 wave slots on some SIMD: the 5-wave variants are held to 128 registers)
 __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMArgs a) {
-    constexpr bool XB = IOB >= 1, YB = IOB == 2;
+    constexpr bool XB = IOB == 1 || IOB == 2, YB = IOB == 2;
+    constexpr bool INB = IOB == 3 || IOB == 4, INA = IOB == 4;      // fused input BatchNorm (+ added tensor)
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
     __bf16* const yb = reinterpret_cast<__bf16*>(a.y);       // (YB: the output tensor's elements)
@@ -135,6 +144,7 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
     __shared__ int2 s_tap2[2][MAXTAP];
     __shared__ float s_bias[MT * 16];
     __shared__ float s_bnp[STATS ? 4 : 1][MT * 16];       // mean, rstd, gamma, beta of the backward-statistics form
+    __shared__ float s_inp[INB ? 4 : 1][64];              // mean, rstd, gamma, beta of the fused INPUT BatchNorm (Cin <= 64)
 
     const int ntile = (a.T + TFM - 1) / TFM;
     const bool tdbg = a.tdbg != 0 && blockIdx.x == 0 && wv == 0;
@@ -149,6 +159,24 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
     // vmcnt wait on every older request -- the next tile's prefetch and the previous N-tile's stores -- ~2 us per N-tile;
     // holding them in registers instead costs 4 x MT VGPRs across the whole kernel)
     if (tid < MT * 16) s_bias[tid] = (a.bias && tid < a.Cout) ? a.bias[tid] : 0.f;
+    if constexpr (INB) {
+        if (tid < a.Cin) {                                  // bn_fin_act_fwd's arithmetic, channel by channel
+            double t1 = 0.0, t2 = 0.0;
+            for (int r = 0; r < a.in_nrep; ++r) { t1 += a.in_sums[(long long)r * 2 * a.Cin + tid]; t2 += a.in_sums[(long long)r * 2 * a.Cin + a.Cin + tid]; }
+            const double m = t1 * a.in_inv_count;
+            double var = t2 * a.in_inv_count - m * m;
+            if (var < 0.0) var = 0.0;
+            const float mf = (float)m, rs = (float)(1.0 / sqrt(var + (double)a.in_eps));
+            s_inp[0][tid] = mf; s_inp[1][tid] = rs; s_inp[2][tid] = a.in_gamma[tid]; s_inp[3][tid] = a.in_beta[tid];
+            if (blockIdx.x == 0 && a.in_mean_o != nullptr) {
+                a.in_mean_o[tid] = mf; a.in_rstd_o[tid] = rs;
+                if (a.in_rmean) {
+                    a.in_rmean[tid] = (float)((1.0 - a.in_mom) * a.in_rmean[tid] + a.in_mom * m);
+                    a.in_rvar[tid] = (float)((1.0 - a.in_mom) * a.in_rvar[tid] + a.in_mom * var * a.in_unb);
+                }
+            }
+        }
+    }
     if constexpr (STATS) {
         if (a.bn_y != nullptr && tid < MT * 16) {
             const bool ok = tid < a.Cout;
@@ -214,6 +242,18 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
             for (int r4 = 0; r4 < 4; ++r4) { s1[mt][r4] = 0.f; s2[mt][r4] = 0.f; }
     }
     float4 pre[NV];
+    float4 pre2[INA ? NV : 1];                             // the added tensor's slots (IOB 4)
+    // tile-invariant slot coordinates of the fused-input forms: frame row (4 bits) | first channel (8) | elements before the channel
+    // changes (3): a float4 straddles at most one channel boundary (Fin >= 4)
+    unsigned sinfo[INB ? NV : 1];
+    if constexpr (INB) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int e0 = min((tid + NTHR * q) * 4, max(nvec * 4 - 4, 0));
+            const int r = e0 / rowlen, off = e0 - r * rowlen, c0 = off / a.Fin, nf = min(4, a.Fin - (off - c0 * a.Fin));
+            sinfo[q] = (unsigned)r | ((unsigned)c0 << 4) | ((unsigned)nf << 12);
+        }
+    }
     auto prefetch = [&](int tile) {
         const int b = tile / ntile;
         const int t0 = (tile - b * ntile) * TFM;
@@ -246,6 +286,20 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
             }
             pre[q] = v;
         }
+        if constexpr (INA) {
+            const float* src2 = a.in_add + ((long long)b * a.T + (t0 - a.halo_lo)) * rowlen;
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const int i = tid + NTHR * q;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < nvec) {
+                    const int r = (i * 4) / rowlen;
+                    const int t = t0 - a.halo_lo + r;
+                    if (t >= 0 && t < a.T) v = *reinterpret_cast<const float4*>(src2 + i * 4);
+                }
+                pre2[q] = v;
+            }
+        }
     };
     if ((int)blockIdx.x < a.B * ntile) prefetch(blockIdx.x);
     if (tdbg) { tq1 = __builtin_amdgcn_s_memtime(); tsum[0] += tq1 - tq0; tq0 = tq1; }
@@ -264,6 +318,38 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
                                                                          __uint_as_float(w1 << 16), __uint_as_float(w1 & 0xffff0000u));
                     *reinterpret_cast<float4*>(xl + i * 8 + 4) = make_float4(__uint_as_float(w2 << 16), __uint_as_float(w2 & 0xffff0000u),
                                                                              __uint_as_float(w3 << 16), __uint_as_float(w3 & 0xffff0000u));
+                }
+            }
+        } else if constexpr (INB) {
+            __bf16* const cpy = a.in_copy ? reinterpret_cast<__bf16*>(a.in_copy) + ((long long)b * a.T + (t0 - a.halo_lo)) * rowlen : nullptr;
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const int i = tid + NTHR * q;
+                if (i < nvec) {
+                    const unsigned si = sinfo[q];
+                    const int r = (int)(si & 15u), c0 = (int)((si >> 4) & 255u), nf = (int)(si >> 12);
+                    const int t = t0 - a.halo_lo + r;
+                    const bool ok = t >= 0 && t < a.T;     // (halo rows before the clip stay ZERO: the padding applies to e, not to x)
+                    const int c1 = min(c0 + 1, a.Cin - 1);
+                    const float m0 = s_inp[0][c0], r0 = s_inp[1][c0], g0 = s_inp[2][c0], b0_ = s_inp[3][c0];
+                    const float m1 = s_inp[0][c1], r1 = s_inp[1][c1], g1 = s_inp[2][c1], b1_ = s_inp[3][c1];
+                    const float in[4] = {pre[q].x, pre[q].y, pre[q].z, pre[q].w};
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool lo = e < nf;
+                        float tv = (in[e] - (lo ? m0 : m1)) * (lo ? r0 : r1) * (lo ? g0 : g1) + (lo ? b0_ : b1_);
+                        tv = fmaxf(tv, 0.f);
+                        o[e] = tv;
+                    }
+                    if constexpr (INA) { o[0] += pre2[q].x; o[1] += pre2[q].y; o[2] += pre2[q].z; o[3] += pre2[q].w; }
+                    if (!ok) { o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; }
+                    *reinterpret_cast<float4*>(xl + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
+                    if (cpy != nullptr && ok && r >= a.halo_lo) {         // own rows only: the halo belongs to the tile before
+                        bf16x4_ h4;
+                        h4[0] = (__bf16)o[0]; h4[1] = (__bf16)o[1]; h4[2] = (__bf16)o[2]; h4[3] = (__bf16)o[3];
+                        *reinterpret_cast<bf16x4_*>(cpy + i * 4) = h4;
+                    }
                 }
             }
         } else {
@@ -662,7 +748,11 @@ int launch_mt(const CMArgs& a, int grid, size_t lds, int nw, hipStream_t s) {
     // bf16 inputs: the data-gradient forms of the bf16 mode only (EPI 0 / 2, PREC bf16)
 #define CM_LAUNCH4(MTV, STV, NVV, NWV, SWV)                                                                \
     do {                                                                                                   \
-        if constexpr (STV != 1 && PREC == CRUSE_PREC_BF16) {                                               \
+        if constexpr (STV != 2 && PREC == CRUSE_PREC_BF16X3) {      /* forward convs of the bf16 mode: fused input BatchNorm */ \
+            if (a.in_sums != nullptr && a.in_add != nullptr) CM_LAUNCH5(MTV, STV, NVV, NWV, SWV, 4);       \
+            else if (a.in_sums != nullptr) CM_LAUNCH5(MTV, STV, NVV, NWV, SWV, 3);                         \
+            else CM_LAUNCH5(MTV, STV, NVV, NWV, SWV, 0);                                                   \
+        } else if constexpr (STV != 1 && PREC == CRUSE_PREC_BF16) {                                        \
             if (a.x_bf16 && a.y_bf16) {                                                                    \
                 if constexpr (SWV != 0) CM_LAUNCH5(MTV, STV, NVV, NWV, SWV, 2);                            \
                 else { cruse_set_error("conv_mfma: a bf16 output needs the swapped-role (vector-store) forms"); return CRUSE_E_DTYPE; } \
@@ -714,7 +804,8 @@ int launch_mt(const CMArgs& a, int grid, size_t lds, int nw, hipStream_t s) {
 int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float* bias, float* y,
                         int B, int T, int Cin, int Fin, int Cout, int Fout, int KT, int S, int pad,
                         int w_layout, int act, int accum, int prec, double* bn_sums, const CruseBnBwd* bnb, int x_bf16, int y_bf16,
-                        hipStream_t stream) {
+                        const CruseBnIn* bni, hipStream_t stream) {
+    if (bni != nullptr && (prec != CRUSE_PREC_BF16X3 || Cin > 64 || accum || bnb != nullptr || x_bf16)) return 0;
     if (y_bf16 && !x_bf16) return 0;                                    // (a bf16 output comes with a bf16 input: the backward chain)
     if (Cin % 8 != 0 || (Cin & (Cin - 1)) != 0 || Cout < 8 || Cout > 64 || (TFM * (Fout / (scatter ? 2 : 1))) % 16 != 0) return 0;
     CMArgs a = {};
@@ -722,6 +813,13 @@ int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float
     a.B = B; a.T = T; a.Cin = Cin; a.Fin = Fin; a.Cout = Cout; a.Fout = Fout;
     a.act = act; a.accum = accum; a.sums = bn_sums;
     a.x_bf16 = x_bf16 ? 1 : 0; a.y_bf16 = y_bf16 ? 1 : 0;
+    if (bni != nullptr) {
+        a.in_sums = bni->sums; a.in_nrep = bni->nrep; a.in_inv_count = 1.0 / (double)bni->count;
+        a.in_unb = bni->count > 1 ? (double)bni->count / (double)(bni->count - 1) : 1.0;
+        a.in_eps = bni->eps; a.in_mom = bni->momentum; a.in_gamma = bni->gamma; a.in_beta = bni->beta;
+        a.in_mean_o = bni->mean_o; a.in_rstd_o = bni->rstd_o; a.in_rmean = bni->rmean; a.in_rvar = bni->rvar;
+        a.in_add = bni->add; a.in_copy = bni->copy_bf16;
+    }
     a.tdbg = cruse_opt("cm_dbg", 0);
     a.kint = cruse_opt("cm_kint", 1);
     a.swp_ok = cruse_opt("cm_swap", 1);                  // (A/B switch: 0 = channels in rows for every form)

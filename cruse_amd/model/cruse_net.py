@@ -776,24 +776,55 @@ def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, tor
     cur = x
     _PENDING_COUNTERS.clear()
     ys, es, ss, stats = [None], [x], [None], [None]
+    # EngineConfig.fuse_bn_fwd (bf16 mode, training): BatchNorm-apply + ReLU (+ skip add) of a level run inside the staging of the
+    # convs that consume it -- `pend` describes such a VIRTUAL tensor (ops.BnIn); es[k] / us[k] are then the bf16 copies the
+    # consuming conv writes for the weight gradients, mean / rstd are published by that conv's block 0
+    fz = training and save and config.get().fuse_bn_fwd and config.get().fuse_bn_stats
+    dev = x.device
+
+    def virtual(y_, sums_, C, F, name, add=None):
+        mean_ = torch.empty(C, device=dev, dtype=torch.float32); rstd_ = torch.empty(C, device=dev, dtype=torch.float32)
+        rm = Bf[name + ".running_mean"] if update_running else None
+        rv = Bf[name + ".running_var"] if update_running else None
+        if update_running:
+            _PENDING_COUNTERS.append(Bf[name + ".num_batches_tracked"])
+        return ops.BnIn(y_, sums_, ops.BN_STAT_REPLICAS, rows * F, BN_EPS, BN_MOMENTUM, P[name + ".weight"], P[name + ".bias"], mean_, rstd_,
+                        rm, rv, add=add)
+    pend = None
+    e_bf = None
     for k in range(1, L + 1):
-        if training and config.get().fuse_bn_stats:
+        if pend is not None:
+            y, sums = ops.conv_gather_bnin(pend, P[f"conv{k}.weight"], P[f"conv{k}.bias"], B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k], KT=2, S=2,
+                                           pad=1, prec=prec, publish=True, copy_bf16=es[k - 1], want_sums=True)
+        elif training and config.get().fuse_bn_stats:
             y, sums = ops.conv_gather_bnstats(cur, P[f"conv{k}.weight"], P[f"conv{k}.bias"], B, T, ch[k - 1], Fk[k - 1], ch[k],
                                               Fk[k], KT=2, S=2, pad=1, prec=prec)
         else:
             y, sums = ops.conv_gather(cur, P[f"conv{k}.weight"], P[f"conv{k}.bias"], B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k],
                                       KT=2, S=2, pad=1, prec=prec), None
-        e_bf = None
-        if k == L and training and _gi_takes_bf16_copy(prec, ch[L] * Fk[L] // groups):
-            e_bf = torch.empty(rows * ch[L] * Fk[L], device=x.device, dtype=torch.bfloat16)     # gate GEMM 1's operand
-        e, mean, rstd = _bn_act(y, rows, ch[k], Fk[k], P, Bf, f"bn{k}", training, update_running, sums=sums, out_bf16=e_bf)
         s = torch.empty(B, T, ch[k], Fk[k], device=x.device, dtype=torch.float32)
+        # e_k stays virtual when both of its forward consumers -- conv_{k+1} and skip_k -- take it fused (level L feeds the GGRU)
+        if fz and k < L and ops.bnin_eligible(prec, ch[k], ch[k + 1]) and ops.bnin_eligible(prec, ch[k], ch[k]):
+            pend = virtual(y, sums, ch[k], Fk[k], f"bn{k}")
+            e = torch.empty(B, T, ch[k], Fk[k], device=dev, dtype=torch.bfloat16)        # written by conv_{k+1} while it stages
+            mean, rstd = pend.mean, pend.rstd
 
-        def skip_conv(e=e, s=s, k=k):
-            ops.conv_gather(e, P[f"skip_connect_{k}.weight"], None, B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1,
-                            out=s, prec=prec)
-        # needed by the decoder only (level L: by the layer norm that closes the GGRU block): issued with the GRU forward
-        SIDE.defer(skip_conv, e, s, kind=1, lane=1)
+            def skip_conv(bn=pend, s=s, k=k):
+                ops.conv_gather_bnin(bn, P[f"skip_connect_{k}.weight"], None, B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1,
+                                     prec=prec, out=s)
+            SIDE.defer(skip_conv, y, s, kind=1, lane=1)
+        else:
+            pend = None
+            e_bf = None
+            if k == L and training and _gi_takes_bf16_copy(prec, ch[L] * Fk[L] // groups):
+                e_bf = torch.empty(rows * ch[L] * Fk[L], device=x.device, dtype=torch.bfloat16)     # gate GEMM 1's operand
+            e, mean, rstd = _bn_act(y, rows, ch[k], Fk[k], P, Bf, f"bn{k}", training, update_running, sums=sums, out_bf16=e_bf)
+
+            def skip_conv(e=e, s=s, k=k):
+                ops.conv_gather(e, P[f"skip_connect_{k}.weight"], None, B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1,
+                                out=s, prec=prec)
+            # needed by the decoder only (level L: by the layer norm that closes the GGRU block): issued with the GRU forward
+            SIDE.defer(skip_conv, e, s, kind=1, lane=1)
         ys.append(y); es.append(e); ss.append(s); stats.append((mean, rstd))
         cur = e
     H = ch[L] * Fk[L]
@@ -805,15 +836,26 @@ def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, tor
     for fn, keep in late:                               # beside the decoder: nothing on the main stream waits for these
         SIDE.run(fn, *keep, lane=2)
     us, vs, dstats = {L: u}, {}, {}
+    pend = None
     for k in range(L, 1, -1):
-        if training and config.get().fuse_bn_stats:
+        if pend is not None:                            # u_k = relu(bn(v_{k+1})) + skip_k applied while conv{k}_t stages v_{k+1} and skip_k
+            v, sums = ops.conv_scatter2_bnin(pend, P[f"conv{k}_t.weight"], P[f"conv{k}_t.bias"], B, T, ch[k], Fk[k], ch[k - 1], KT=1, pad=0,
+                                             prec=prec, publish=True, copy_bf16=us[k], want_sums=True)
+        elif training and config.get().fuse_bn_stats:
             v, sums = ops.conv_scatter2_bnstats(u, P[f"conv{k}_t.weight"], P[f"conv{k}_t.bias"], B, T, ch[k], Fk[k], ch[k - 1],
                                                 KT=1, pad=0, prec=prec)
         else:
             v, sums = ops.conv_scatter2(u, P[f"conv{k}_t.weight"], P[f"conv{k}_t.bias"], B, T, ch[k], Fk[k], ch[k - 1], KT=1,
                                         pad=0, prec=prec), None
-        u, mean, rstd = _bn_act(v, rows, ch[k - 1], Fk[k - 1], P, Bf, f"bn{k}_t", training, update_running, skip=ss[k - 1],
-                                sums=sums)
+        # u_{k-1} stays virtual when its consumer conv{k-1}_t takes it fused (the last decoder layer, Cout = 1, is a VALU kernel)
+        if fz and k - 1 >= 2 and ops.bnin_eligible(prec, ch[k - 1], ch[k - 2]):
+            pend = virtual(v, sums, ch[k - 1], Fk[k - 1], f"bn{k}_t", add=ss[k - 1])
+            u = torch.empty(B, T, ch[k - 1], Fk[k - 1], device=dev, dtype=torch.bfloat16)      # written by conv{k-1}_t while it stages
+            mean, rstd = pend.mean, pend.rstd
+        else:
+            pend = None
+            u, mean, rstd = _bn_act(v, rows, ch[k - 1], Fk[k - 1], P, Bf, f"bn{k}_t", training, update_running, skip=ss[k - 1],
+                                    sums=sums)
         vs[k] = v; dstats[k] = (mean, rstd); us[k - 1] = u
     mask = ops.conv_scatter2(u, P["conv1_t.weight"], P["conv1_t.bias"], B, T, ch[1], Fk[1], ch[0], KT=1, pad=0, act=1,
                              prec=prec)

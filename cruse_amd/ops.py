@@ -170,6 +170,47 @@ def conv_scatter2(g, w, bias, B, T, Cs, Fg, Cout, KT, pad, act=0, out=None, accu
     return out
 
 
+class BnIn:
+    """The BatchNorm2d(train) + ReLU a forward conv applies to its INPUT while staging it (cruse_conv_*_bnin): `y_pre` the layer's
+    pre-BN tensor, `sums` its batch sums [BN_STAT_REPLICAS][2C], gamma / beta, count = rows * F; mean / rstd (+ running statistics)
+    are published by the ONE consumer that is handed them (publish=True); add: tensor added after the ReLU (the decoder's skip)."""
+
+    def __init__(self, y_pre, sums, nrep, count, eps, momentum, gamma, beta, mean, rstd, running_mean=None, running_var=None, add=None):
+        self.y_pre, self.sums, self.nrep, self.count, self.eps, self.momentum = y_pre, sums, nrep, count, eps, momentum
+        self.gamma, self.beta, self.mean, self.rstd, self.rm, self.rv, self.add = gamma, beta, mean, rstd, running_mean, running_var, add
+
+    def args(self, publish, copy_bf16):
+        return (_p(self.y_pre), _p(self.sums), self.nrep, self.count, self.eps, self.momentum, _p(self.gamma), _p(self.beta),
+                _p(self.mean) if publish else None, _p(self.rstd) if publish else None, _p(self.rm) if publish else None,
+                _p(self.rv) if publish else None, _p(self.add), _p(copy_bf16))
+
+
+def bnin_eligible(prec, Cin, Cout) -> bool:
+    """shapes / modes cruse_conv_*_bnin takes: the MFMA forward convs of the bf16 mode"""
+    # (the bf16 MODE: its forward convs run split-bf16 x3 and its weight gradients take the bf16 copies as they are)
+    return (prec is not None and prec_code(prec) == PREC_BF16 and conv_prec(prec) == PREC_BF16X3 and 8 <= Cin <= 64
+            and (Cin & (Cin - 1)) == 0 and 8 <= Cout <= 64)
+
+
+def conv_gather_bnin(bn: BnIn, w, bias, B, T, Cin, Fin, Cout, Fout, KT, S, pad, prec, publish=False, copy_bf16=None, want_sums=False,
+                     out=None):
+    """conv_gather on relu(bn(y_pre)) [+ add] without materialising it -> y, or (y, sums) with want_sums."""
+    if out is None:
+        out = torch.empty(B, T, Cout, Fout, device=w.device, dtype=torch.float32)
+    sums, z = ARENA.take(2 * Cout * BN_STAT_REPLICAS, w.device) if want_sums else (None, 0)
+    check(lib.cruse_conv_gather_bnin(*bn.args(publish, copy_bf16), _p(w), _p(bias), _p(out), B, T, Cin, Fin, Cout, Fout, KT, S, pad,
+                                     conv_prec(prec), _p(sums), z, _stream()))
+    return (out, sums) if want_sums else out
+
+
+def conv_scatter2_bnin(bn: BnIn, w, bias, B, T, Cs, Fg, Cout, KT, pad, prec, publish=False, copy_bf16=None, want_sums=False):
+    out = torch.empty(B, T, Cout, 2 * Fg, device=w.device, dtype=torch.float32)
+    sums, z = ARENA.take(2 * Cout * BN_STAT_REPLICAS, w.device) if want_sums else (None, 0)
+    check(lib.cruse_conv_scatter2_bnin(*bn.args(publish, copy_bf16), _p(w), _p(bias), _p(out), B, T, Cs, Fg, Cout, 2 * Fg, KT, pad,
+                                       conv_prec(prec), _p(sums), z, _stream()))
+    return (out, sums) if want_sums else out
+
+
 def conv_gather_bnstats(x, w, bias, B, T, Cin, Fin, Cout, Fout, KT, S, pad, prec=None):
     """conv_gather + the BatchNorm batch sums of its output, accumulated by the conv's epilogue -> (y, sums)."""
     out = torch.empty(B, T, Cout, Fout, device=x.device, dtype=torch.float32)

@@ -126,6 +126,26 @@ int cruse_conv_scatter2_bnstats(const float* g, const float* w, const float* bia
                                 int B, int T, int Cs, int Fg, int Cout, int Fout,
                                 int KT, int pad, int prec, double* sums, int zeroed, void* stream);
 
+/* FORWARD convolutions that apply the BatchNorm2d(train) + ReLU of the layer BELOW to their input while staging it (ABI 7; the
+ * BN -> ReLU -> conv chains of cruse_net.py:149-152,161-163): x_pre / g_pre is the PRE-BatchNorm tensor [B,T,Cin,Fin]; every workgroup
+ * derives mean / rstd from that layer's batch sums in_sums [in_replicas][2*Cin] (in_count = rows*Fin elements per channel) and stages
+ * e = relu((x - mean)*rstd*gamma + beta) [+ in_add, the decoder's skip tensor] -- cruse_bn_finalize_act_fwd's arithmetic, so the
+ * normalised tensor never exists in HBM.  in_mean / in_rstd (nullable pair): block 0 publishes the statistics (the backward pass
+ * reads them) and, with in_running_mean / in_running_var, updates the running statistics -- ONE consumer of a layer passes them.
+ * in_copy_bf16 (nullable): a bf16 copy of the transformed rows, the operand the weight gradients of the bf16 mode read.
+ * out_sums (nullable): the batch sums of y as cruse_conv_*_bnstats.  MFMA kernel only: prec == CRUSE_PREC_BF16X3 (the forward
+ * convs of the bf16 mode), Cin a power of two in 8..64, 8 <= Cout <= 64; anything else is refused (run the unfused passes). */
+int cruse_conv_gather_bnin(const float* x_pre, const double* in_sums, int in_replicas, long long in_count, float eps, float momentum,
+                           const float* in_gamma, const float* in_beta, float* in_mean, float* in_rstd, float* in_running_mean,
+                           float* in_running_var, const float* in_add, void* in_copy_bf16,
+                           const float* w, const float* bias, float* y, int B, int T, int Cin, int Fin, int Cout, int Fout,
+                           int KT, int S, int pad, int prec, double* out_sums, int zeroed, void* stream);
+int cruse_conv_scatter2_bnin(const float* g_pre, const double* in_sums, int in_replicas, long long in_count, float eps, float momentum,
+                             const float* in_gamma, const float* in_beta, float* in_mean, float* in_rstd, float* in_running_mean,
+                             float* in_running_var, const float* in_add, void* in_copy_bf16,
+                             const float* w, const float* bias, float* y, int B, int T, int Cs, int Fg, int Cout, int Fout,
+                             int KT, int pad, int prec, double* out_sums, int zeroed, void* stream);
+
 /* x_dtype / a_dtype / bt_dtype / dy_dtype (ABI 7; CRUSE_DT_F32 or CRUSE_DT_BF16): BACKWARD-ONLY tensors of the bf16 mode -- the
  * BatchNorm-backward output dy, which its two consumers (the data-gradient conv and the weight gradient) round to bf16 operands
  * anyway -- may be stored as bf16 in the same [B,T,C,F] layout: half the bytes written once and read twice, the same bits into

@@ -424,3 +424,31 @@ def test_bf16_stored_data_gradients_stay_within_the_gradient_tolerances():
     worst = max((rel_l2(res[True][2][n], g), n) for n, g in res[False][2].items() if float(g.norm()) > 1e-6 and not n.endswith(".bias"))
     print(f"[bf16_de] all gradients {rel_l2(res[True][1], res[False][1]):.2e}, worst tensor {worst[1]} {worst[0]:.2e}")
     assert worst[0] < 1e-2, worst
+
+
+@pytest.mark.parametrize("grp", [1, 4])
+def test_batchnorm_applied_in_the_consumer_convs_staging_is_the_same_step(grp):
+    """EngineConfig.fuse_bn_fwd: BatchNorm-apply + ReLU (+ decoder skip add) inside the staging of the consuming convs
+    (cruse_conv_*_bnin; cruse_net.py:149-152,161-163) -- the arithmetic of cruse_bn_finalize_act_fwd element for element, so mask and loss
+    are bit-identical to the materialised path, the published mean / rstd and running statistics equal, and the gradients agree up to
+    what the weight gradients' bf16 operand copies round identically anyway (run-to-run atomics order: 5e-5)."""
+    from cruse_amd.config import EngineConfig
+    from cruse_amd.data import synth_batch
+    from cruse_amd.engine import TrainEngine
+    from cruse_amd.model.cruse_net import unet_2
+    from cruse_amd import ops
+    noisy, clean = synth_batch(8, 16000, "cuda", 9)
+    res = {}
+    for flag in (False, True):
+        torch.manual_seed(5)
+        m = unet_2(rnn_groups=grp, precision="bf16").cuda()
+        eng = TrainEngine(m, use_graph=False, lr=0.0, config=EngineConfig(fuse_bn_fwd=flag))
+        ls = eng.step(noisy, clean)
+        torch.cuda.synchronize()
+        res[flag] = (eng.loss_value(ls), eng._last_mask.clone(), eng.flat.grads.clone(),
+                     {k: v.clone() for k, v in m.named_buffers() if "running" in k or "tracked" in k})
+        assert eng.skipped_steps() == 0 and ops.gru_status() == 0
+    assert torch.equal(res[True][1], res[False][1]) and res[True][0] == res[False][0]
+    assert rel_l2(res[True][2], res[False][2]) < 5e-5
+    for k, v in res[False][3].items():
+        assert torch.equal(res[True][3][k], v), k
