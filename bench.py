@@ -408,14 +408,14 @@ def secondary_rows(a, dev, pool):
                                       "note": "forward STFT only, hop = win = 320 (20 ms hop)"}
     except Exception as ex:
         out["stft_hop320_forward"] = {"error": repr(ex)[:200]}
-    # (3) the nearest-upsample decoder variant (model/cruse.py:14 CRUSE4MagAddSkipUpsample): forward + mask-weighted loss
-    #     + backward through the nn.Module / autograd surface -- general NCHW blocks (generic.hip) around the persistent GRU
-    #     kernels, no hand-scheduled step, no optimizer: the cost of the variant's model, not a training-step figure
+    # (3) the nearest-upsample decoder variant (model/cruse.py:14 CRUSE4MagAddSkipUpsample): forward + MSE + backward
+    #     through the nn.Module / autograd surface -- the frame-major engine of unet_2 with dec_mode="upsample" behind one autograd
+    #     node; no optimizer: the cost of the variant's model, not a training-step figure
     try:
         from cruse_amd.model.cruse import CRUSE4MagAddSkipUpsample
         torch.manual_seed(0)
         B, L = pool[0][0].shape
-        Bu, T = min(B, 16), 1 + L // 160
+        Bu, T = min(B, 64), 1 + L // 160
         mu = CRUSE4MagAddSkipUpsample(rnn_groups=a.groups, precision="bf16").to(dev).train()
         xin = torch.rand(Bu, 1, T, 160, device=dev) + 0.05
         tgt = torch.rand(Bu, 1, T, 160, device=dev)
@@ -425,16 +425,16 @@ def secondary_rows(a, dev, pool):
                 q.grad = None
             ((mu(xin) - tgt) ** 2).mean().backward()
         it(); torch.cuda.synchronize()
-        n = 5
+        n = 10
         t0 = time.perf_counter()
         for _ in range(n):
             it()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         out["upsample_decoder_variant"] = {"value": round(Bu * T / dt, 1), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3), "batch": Bu,
-                                           "steps": n, "dtype": "bf16 bottleneck, f32 blocks",
-                                           "note": "CRUSE4MagAddSkipUpsample forward + MSE + backward (autograd over the general NCHW kernels; "
-                                                   "no optimizer)"}
+                                           "steps": n, "dtype": "bf16",
+                                           "note": "CRUSE4MagAddSkipUpsample forward + MSE + backward (one autograd node over the frame-major "
+                                                   "MFMA convs / persistent GRU kernels, nearest upsample materialised once per level; no optimizer)"}
         del mu
     except Exception as ex:
         out["upsample_decoder_variant"] = {"error": repr(ex)[:200]}

@@ -92,6 +92,7 @@ SIGNATURES = {
     "cruse_conv2d_nchw_wgrad": ("pppiiiiiiiiiiiiiiiiiip", "i"),
     "cruse_nchw_channel_sum": ("piiipip", "i"),
     "cruse_downsum_w": ("pqiipip", "i"),
+    "cruse_upsample_w": ("pqiipip", "i"),
     "cruse_bn_nchw_stats": ("piiipip", "i"),
     "cruse_bn_nchw_fwd": ("ppppppiiiipip", "i"),
     "cruse_bn_nchw_bwd": ("pppppppiiiiipppppip", "i"),

@@ -170,13 +170,15 @@ __global__ __launch_bounds__(256) void gconv_pointwise_mfma_f16_kernel(GConv<f16
             const int b = (int)(t / tiles_img);
             const long long pp = (long long)(t - (long long)b * tiles_img) * 16 + m;
             const bool ok = t < ntile && pp < hw;
-            const f16* xp = a.x + (long long)b * a.Cin * hw + pp;
+            // (unconditional loads from clamped addresses, masked afterwards: a branch per element serialises the round trips)
+            const f16* xp = a.x + (long long)(t < ntile ? b : 0) * a.Cin * hw + (ok ? pp : 0);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int ci = ks * 32 + kg * 8 + e;
-                    fb[q][ks][e] = (ok && ci < a.Cin) ? xp[(long long)ci * hw] : (f16)0.f;
+                    const f16 v = xp[(long long)min(ci, a.Cin - 1) * hw];
+                    fb[q][ks][e] = (ok && ci < a.Cin) ? v : (f16)0.f;
                 }
         }
 #pragma unroll
@@ -215,34 +217,38 @@ struct TapTab { int dh[9], dw[9], n; };        // input offset of tap k relative
 
 template <typename T>
 __global__ __launch_bounds__(256) void gconv_depthwise_kernel(GConv<T> a, TapTab tt) {
-    const int plane = blockIdx.z, c = plane % a.Cout;
-    const int ho = blockIdx.y;
+    // A block is DW_U * 256 consecutive outputs of one (image, channel) plane.  Every tap is an UNCONDITIONAL load from a clamped
+    // address, masked afterwards: with a branch per tap the nine loads of an output were nine serialised round trips (one output
+    // row per block, 480 GB/s on [8,24,161,401] f16); now DW_U * 9 loads are in flight per thread.
+    constexpr int DW_U = 8;
+    const int plane = blockIdx.y, c = plane % a.Cout;
     float w[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) w[k] = k < tt.n ? a.w[c * tt.n + k] : 0.f;
     const float bias = a.bias ? a.bias[c] : 0.f;
     const float slope = a.act == 2 ? a.slope[c] : 0.f;
     const T* xp = a.x + (long long)plane * a.Hin * a.Win;
-    T* yp = a.y + ((long long)plane * a.Hout + ho) * a.Wout;
-    int roff[9];
-    bool rok[9];
+    T* yp = a.y + (long long)plane * a.Hout * a.Wout;
+    const int hwo = a.Hout * a.Wout;
+    int e = blockIdx.x * (DW_U * 256) + threadIdx.x;
+    int ho = e / a.Wout, wo = e - ho * a.Wout;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const int hi = ho + tt.dh[k];
-        rok[k] = k < tt.n && hi >= 0 && hi < a.Hin;
-        roff[k] = (rok[k] ? hi : 0) * a.Win + tt.dw[k];
-    }
-    for (int wo = threadIdx.x; wo < a.Wout; wo += 256) {
+    for (int j = 0; j < DW_U; ++j) {
+        const bool in = e < hwo;
         float acc = bias;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            const int wi = wo + tt.dw[k];
-            if (rok[k] && wi >= 0 && wi < a.Win) acc += w[k] * (float)xp[roff[k] + wo];
+            const int hi = ho + tt.dh[k], wi = wo + tt.dw[k];
+            const bool ok = k < tt.n && in && hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win;
+            const float v = (float)xp[ok ? hi * a.Win + wi : 0];
+            acc += ok ? w[k] * v : 0.f;
         }
         if (a.act == 1) acc = fmaxf(acc, 0.f);
         else if (a.act == 2) acc = acc >= 0.f ? acc : slope * acc;
-        if (a.accumulate) acc += (float)yp[wo];
-        yp[wo] = (T)acc;
+        if (a.accumulate) acc += (float)yp[in ? e : 0];
+        if (in) yp[e] = (T)acc;
+        e += 256; wo += 256;
+        while (wo >= a.Wout) { wo -= a.Wout; ++ho; }
     }
 }
 
@@ -380,16 +386,22 @@ __global__ __launch_bounds__(1024) void gconv_wgrad_pw_mfma_f16_kernel(GWgrad<f1
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int ca = i * 16 + r;
-                const f16* q = sp + (long long)min(ca, a.CA - 1) * hw + pk;
+                const f16* q = sp + (long long)min(ca, a.CA - 1) * hw;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) fa[u][i][e] = (ca < a.CA && pk + e < p1) ? q[e] : zero;
+                for (int e = 0; e < 8; ++e) {            // (unconditional loads from clamped positions, masked afterwards)
+                    const f16 v = q[min(pk + e, p1 - 1)];
+                    fa[u][i][e] = (ca < a.CA && pk + e < p1) ? v : zero;
+                }
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int cb = j * 16 + r;
-                const f16* q = bp + (long long)min(cb, a.CB - 1) * hw + pk;
+                const f16* q = bp + (long long)min(cb, a.CB - 1) * hw;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) fb[u][j][e] = (cb < a.CB && pk + e < p1) ? q[e] : zero;
+                for (int e = 0; e < 8; ++e) {
+                    const f16 v = q[min(pk + e, p1 - 1)];
+                    fb[u][j][e] = (cb < a.CB && pk + e < p1) ? v : zero;
+                }
             }
         }
 #pragma unroll
@@ -419,32 +431,31 @@ __global__ __launch_bounds__(1024) void gconv_wgrad_pw_mfma_f16_kernel(GWgrad<f1
 // A block is a band of rows of one (image, channel) plane; a thread walks W and keeps the KH*KW partial sums in registers.
 template <typename T>
 __global__ __launch_bounds__(256) void gconv_wgrad_depthwise_kernel(GWgrad<T> a, int band, TapTab tt) {
+    // band = S positions per thread (a block takes band * 256 consecutive positions of one plane); unconditional clamped tap
+    // loads masked afterwards, as in gconv_depthwise_kernel
     __shared__ float red[4][9];
     const int plane = blockIdx.y, c = plane % a.CA;
-    const int h0 = blockIdx.x * band, h1 = min(a.HS, h0 + band);
     const T* sp = a.S + (long long)plane * a.HS * a.WS;
     const T* bp = a.Bg + (long long)plane * a.HB * a.WB;
+    const int hws = a.HS * a.WS;
     float acc[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = 0.f;
-    for (int h = h0; h < h1; ++h) {
-        int roff[9];
-        bool rok[9];
+    int e = blockIdx.x * (band * 256) + threadIdx.x;
+    int h = e / a.WS, w = e - h * a.WS;
+#pragma unroll 4
+    for (int j = 0; j < band; ++j) {
+        const bool in = e < hws;
+        const float sv = in ? (float)sp[e] : 0.f;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            const int hb = h * a.sh + tt.dh[k];
-            rok[k] = k < tt.n && hb >= 0 && hb < a.HB;
-            roff[k] = (rok[k] ? hb : 0) * a.WB + tt.dw[k];
+            const int hb = h * a.sh + tt.dh[k], wb = w * a.sw + tt.dw[k];
+            const bool ok = k < tt.n && in && hb >= 0 && hb < a.HB && wb >= 0 && wb < a.WB;
+            const float v = (float)bp[ok ? hb * a.WB + wb : 0];
+            acc[k] += ok ? sv * v : 0.f;
         }
-        for (int w = threadIdx.x; w < a.WS; w += 256) {
-            const float sv = (float)sp[h * a.WS + w];
-            const int wb0 = w * a.sw;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const int wb = wb0 + tt.dw[k];
-                if (rok[k] && wb >= 0 && wb < a.WB) acc[k] += sv * (float)bp[roff[k] + wb0];
-            }
-        }
+        e += 256; w += 256;
+        while (w >= a.WS) { w -= a.WS; ++h; }
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
@@ -488,6 +499,29 @@ __global__ void downsum_w_kernel(const T* dxu, long long rows, int W, int up, T*
         float s = 0.f;
         for (int j = 0; j < up; ++j) s += (float)dxu[r * W * up + (long long)w * up + j];
         dx[i] = (T)s;
+    }
+}
+
+// xu[.., w*up + j] = x[.., w]  (nearest FreqUpsample of the frame-major upsample decoder: one thread per 4 outputs when up == 2)
+template <typename T>
+__global__ void upsample_w_kernel(const T* x, long long rows, int W, int up, T* xu) {
+    const long long n = rows * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const T v = x[i];
+        for (int j = 0; j < up; ++j) xu[i * up + j] = v;
+    }
+}
+__global__ void upsample_w2_f32_kernel(const float2* x, long long n2, float4* xu) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
+        const float2 v = x[i];
+        xu[i] = make_float4(v.x, v.x, v.y, v.y);
+    }
+}
+// dx[.., w] = dxu[.., 2w] + dxu[.., 2w + 1] on whole float4 loads
+__global__ void downsum_w2_f32_kernel(const float4* dxu, long long n2, float2* dx) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (long long)gridDim.x * blockDim.x) {
+        const float4 v = dxu[i];
+        dx[i] = make_float2(v.x + v.y, v.z + v.w);
     }
 }
 
@@ -672,8 +706,8 @@ int conv2d_nchw_t(const void* x, const float* w, const float* bias, void* y, int
         CRUSE_LAUNCH_CHECK("conv2d_nchw pointwise");
         return CRUSE_OK;
     }
-    if (groups == Cin && Cin == Cout && up_w == 1 && sh == 1 && sw == 1 && KH * KW <= 9 && (long long)B * Cout < 65536 && Hout < 65536 &&
-        (long long)Hin * Win < (1ll << 30) && !cruse_opt("pw_valu", 0)) {
+    if (groups == Cin && Cin == Cout && up_w == 1 && sh == 1 && sw == 1 && KH * KW <= 9 && (long long)B * Cout < 65536 &&
+        (long long)Hin * Win < (1ll << 30) && (long long)Hout * Wout < (1ll << 30) && !cruse_opt("pw_valu", 0)) {
         TapTab tt = {};
         tt.n = KH * KW;
         for (int kh = 0; kh < KH; ++kh)
@@ -681,7 +715,7 @@ int conv2d_nchw_t(const void* x, const float* w, const float* bias, void* y, int
                 tt.dh[kh * KW + kw] = transposed ? pt - kh * dh : kh * dh - pt;
                 tt.dw[kh * KW + kw] = transposed ? pl - kw * dw : kw * dw - pl;
             }
-        hipLaunchKernelGGL(gconv_depthwise_kernel<T>, dim3(1, Hout, B * Cout), dim3(256), 0, s, a, tt);
+        hipLaunchKernelGGL(gconv_depthwise_kernel<T>, dim3(cdiv(Hout * Wout, 8 * 256), B * Cout), dim3(256), 0, s, a, tt);
         CRUSE_LAUNCH_CHECK("conv2d_nchw depthwise");
         return CRUSE_OK;
     }
@@ -711,14 +745,15 @@ int wgrad_nchw_t(const void* S, const void* Bg, float* dw, int N, int CA, int HS
             return CRUSE_OK;
         }
     }
-    if (fast && groups == CA && CA == CB && up_w == 1 && KH * KW <= 9 && (long long)N * CA < 65536 && (long long)HB * WB < (1ll << 30)) {
-        int band = 8;
-        while ((long long)N * CA * cdiv(HS, band) < 2048 && band > 1) band >>= 1;
+    if (fast && groups == CA && CA == CB && up_w == 1 && KH * KW <= 9 && (long long)N * CA < 65536 && (long long)HB * WB < (1ll << 30) &&
+        (long long)HS * WS < (1ll << 30)) {
+        int band = 16;                                   // S positions per thread
+        while ((long long)N * CA * cdiv(HS * WS, band * 256) < 2048 && band > 4) band >>= 1;
         TapTab tt = {};
         tt.n = KH * KW;
         for (int kh = 0; kh < KH; ++kh)
             for (int kw = 0; kw < KW; ++kw) { tt.dh[kh * KW + kw] = kh * dh - pt; tt.dw[kh * KW + kw] = kw * dw_ - pl; }
-        hipLaunchKernelGGL(gconv_wgrad_depthwise_kernel<T>, dim3(cdiv(HS, band), N * CA), dim3(256), 0, s, a, band, tt);
+        hipLaunchKernelGGL(gconv_wgrad_depthwise_kernel<T>, dim3(cdiv(HS * WS, band * 256), N * CA), dim3(256), 0, s, a, band, tt);
         CRUSE_LAUNCH_CHECK("conv2d_nchw_wgrad depthwise");
         return CRUSE_OK;
     }
@@ -804,11 +839,29 @@ extern "C" int cruse_nchw_channel_sum(const void* x, int N, int C, int HW, float
 extern "C" int cruse_downsum_w(const void* dxu, long long rows, int W, int up, void* dx, int dtype, void* stream) {
     CRUSE_REQUIRE(rows > 0 && W > 0 && up > 0, CRUSE_E_SHAPE, "downsum_w: bad shape");
     CRUSE_DT_CHECK("downsum_w");
+    if (dtype == CRUSE_DT_F32 && up == 2 && ((rows * W) & 1) == 0 && (((uintptr_t)dxu | (uintptr_t)dx) & 15) == 0) {
+        hipLaunchKernelGGL(downsum_w2_f32_kernel, dim3(gblocks(rows * W / 2)), dim3(256), 0, ST(stream), (const float4*)dxu, rows * W / 2, (float2*)dx);
+        CRUSE_LAUNCH_CHECK("downsum_w");
+        return CRUSE_OK;
+    }
     if (dtype == CRUSE_DT_F16)
         hipLaunchKernelGGL(downsum_w_kernel<f16>, dim3(gblocks(rows * W)), dim3(256), 0, ST(stream), (const f16*)dxu, rows, W, up, (f16*)dx);
     else
         hipLaunchKernelGGL(downsum_w_kernel<float>, dim3(gblocks(rows * W)), dim3(256), 0, ST(stream), (const float*)dxu, rows, W, up, (float*)dx);
     CRUSE_LAUNCH_CHECK("downsum_w");
+    return CRUSE_OK;
+}
+
+extern "C" int cruse_upsample_w(const void* x, long long rows, int W, int up, void* xu, int dtype, void* stream) {
+    CRUSE_REQUIRE(rows > 0 && W > 0 && up > 0, CRUSE_E_SHAPE, "upsample_w: bad shape");
+    CRUSE_DT_CHECK("upsample_w");
+    if (dtype == CRUSE_DT_F32 && up == 2 && ((rows * W) & 1) == 0 && (((uintptr_t)x | (uintptr_t)xu) & 15) == 0)
+        hipLaunchKernelGGL(upsample_w2_f32_kernel, dim3(gblocks(rows * W / 2)), dim3(256), 0, ST(stream), (const float2*)x, rows * W / 2, (float4*)xu);
+    else if (dtype == CRUSE_DT_F16)
+        hipLaunchKernelGGL(upsample_w_kernel<f16>, dim3(gblocks(rows * W)), dim3(256), 0, ST(stream), (const f16*)x, rows, W, up, (f16*)xu);
+    else
+        hipLaunchKernelGGL(upsample_w_kernel<float>, dim3(gblocks(rows * W)), dim3(256), 0, ST(stream), (const float*)x, rows, W, up, (float*)xu);
+    CRUSE_LAUNCH_CHECK("upsample_w");
     return CRUSE_OK;
 }
 

@@ -13,17 +13,54 @@ this class mirrors child by child): the unet_2 topology (cruse_net.py:129-165 af
     d_k = convkxf(ch[k], ch[k-1], k=1, f=3, fstride=2, batch_norm=True, mode="upsample", depthwise=False)(d_{k+1}) + s_{k-1}
     mask = convkxf(ch[1], ch[0], ..., batch_norm=False, act=Sigmoid, mode="upsample", depthwise=False)(d_2)
 
-Layout [B,C,T,F] throughout (the blocks are the general NCHW ones: generic.hip; the nearest upsampling is folded into the
-following convolution's gather index, never materialised); the bottleneck runs the persistent GRU kernels.  No CPU path.
+The children are the general blocks (they own the parameters, so the state-dict keys are the composition's own), but
+forward() does not call them: the model runs on the frame-major engine of unet_2 (cruse_net.unet2_forward / unet2_backward with
+dec_mode="upsample": MFMA convs with the BatchNorm sums in their epilogues, the persistent GRU kernels, weight-gradient leaves
+on the side streams) through one autograd node.  No CPU path.
 """
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
 
-from ..nn_generic import HipConv2d, add
+from .. import ops
+from ..nn_generic import HipConv2d
 from .based_model.cust_conv import Conv2dNormAct, convkxf
-from .cruse_net import DEFAULT_PREC, GGRU
+from .cruse_net import DEFAULT_PREC, GGRU, unet2_backward, unet2_forward
+
+
+def _unet2_names(laynum: int):
+    """this model's parameter / buffer names -> the names cruse_net.unet2_forward reads (conv{k}, bn{k}, conv{k}_t, bn{k}_t)"""
+    m = {}
+    for k in range(1, laynum + 1):
+        for f in ("weight", "bias"):
+            m[f"enc{k}.1.{f}"] = f"conv{k}.{f}"
+            m[f"dec{k}.sconv.{f}"] = f"conv{k}_t.{f}"
+        for f in ("weight", "bias", "running_mean", "running_var", "num_batches_tracked"):
+            m[f"enc{k}.2.{f}"] = f"bn{k}.{f}"
+            m[f"dec{k}.norm.{f}"] = f"bn{k}_t.{f}"
+    return m
+
+
+class _Cruse4Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod, names, *params):
+        alias = mod._alias
+        P = {alias.get(n, n): p for n, p in zip(names, params)}
+        Bf = {alias.get(n, n): b for n, b in mod.named_buffers()}
+        need = x.requires_grad or any(p.requires_grad for p in params)
+        mask, c = unet2_forward(x, P, Bf, mod.ch, mod.gru.groups, mod.gru.precision, mod.training, save=need, dec_mode="upsample")
+        ctx.c, ctx.P, ctx.names, ctx.alias, ctx.need_dx = c, P, names, alias, x.requires_grad
+        return mask
+
+    @staticmethod
+    def backward(ctx, dmask):
+        P, c = ctx.P, ctx.c
+        G = {n: torch.zeros_like(p) for n, p in P.items()}
+        B, T, F0 = c["B"], c["T"], c["F"][0]
+        dlogit = ops.sigmoid_bwd(dmask.contiguous().view(B, T, 1, F0), c["mask"])
+        dx = unet2_backward(c, dlogit, P, G, need_dx=ctx.need_dx)
+        return (dx.view(B, 1, T, F0) if dx is not None else None, None, None) + tuple(G[ctx.alias.get(n, n)] for n in ctx.names)
 
 
 class CRUSE4MagAddSkipUpsample(nn.Module):
@@ -40,16 +77,12 @@ class CRUSE4MagAddSkipUpsample(nn.Module):
             setattr(self, f"dec{k}", convkxf(ch[k], ch[k - 1], k=1, f=3, fstride=2, batch_norm=not last,
                                              act=nn.Sigmoid() if last else nn.ReLU(), mode="upsample", depthwise=False))
         self.gru = GGRU(hidden_size=hidden, groups=rnn_groups, precision=precision)
+        self._alias = _unet2_names(self.laynum)
 
     def forward(self, x):
         """x [B,1,T,F] magnitude (F = 160 for in_feat 161) -> mask [B,1,T,F]."""
         if x.dim() != 4 or x.shape[1] != self.ch[0] or x.shape[-1] != self.f_net:
             raise RuntimeError(f"CRUSE4MagAddSkipUpsample expects [B,{self.ch[0]},T,{self.f_net}], got {tuple(x.shape)}")
-        e, skips = x, []
-        for k in range(1, self.laynum + 1):
-            e = getattr(self, f"enc{k}")(e)
-            skips.append(getattr(self, f"skip_connect_{k}")(e))
-        d = add(self.gru(e), skips[-1])
-        for k in range(self.laynum, 1, -1):
-            d = add(getattr(self, f"dec{k}")(d), skips[k - 2])
-        return self.dec1(d)
+        names = [n for n, _ in self.named_parameters()]
+        params = [p for _, p in self.named_parameters()]
+        return _Cruse4Fn.apply(x.contiguous().float(), self, names, *params)

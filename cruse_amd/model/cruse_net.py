@@ -760,8 +760,16 @@ def _bn_act(y, rows, C, F, P, Bf, name, training, update_running, skip=None, sum
 
 
 def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, torch.Tensor], ch, groups: int,
-                  prec, training: bool, save: bool = True, update_running: bool = True):
-    """x [B,1,T,F0] (== frame-major [B,T,1,F0]) -> (mask [B,1,T,F0], ctx).  cruse_net.py:147-165."""
+                  prec, training: bool, save: bool = True, update_running: bool = True, dec_mode: str = "transposed"):
+    """x [B,1,T,F0] (== frame-major [B,T,1,F0]) -> (mask [B,1,T,F0], ctx).  cruse_net.py:147-165.
+
+    dec_mode "upsample": the decoder of model/cruse.py:14 (CRUSE4MagAddSkipUpsample) -- cust_conv.convkxf(mode="upsample"),
+    :159-167: nearest FreqUpsample(2) + Conv2d (1,3) pad (0,1) with weights conv{k}_t.weight [Cout][Cin][1][3] (no bias under a
+    BatchNorm) -- on the same frame-major kernels: the upsampled tensor is materialised once (cruse_upsample_w), kept for the
+    weight gradient, and the conv is the gather form at stride 1."""
+    if dec_mode not in ("transposed", "upsample"):
+        raise RuntimeError(f"unet2_forward: unknown dec_mode {dec_mode!r}")
+    ups = dec_mode == "upsample"
     if x.dim() != 4 or x.shape[1] != ch[0]:
         raise RuntimeError(f"unet_2 expects [B,{ch[0]},T,F], got {tuple(x.shape)}")
     if ch[0] != 1:
@@ -835,10 +843,18 @@ def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, tor
     SIDE.join()
     for fn, keep in late:                               # beside the decoder: nothing on the main stream waits for these
         SIDE.run(fn, *keep, lane=2)
-    us, vs, dstats = {L: u}, {}, {}
+    us, vs, dstats, uus = {L: u}, {}, {}, {}
     pend = None
     for k in range(L, 1, -1):
-        if pend is not None:                            # u_k = relu(bn(v_{k+1})) + skip_k applied while conv{k}_t stages v_{k+1} and skip_k
+        if ups:
+            uus[k] = ops.upsample_w(u, rows * ch[k], Fk[k], 2).view(B, T, ch[k], Fk[k - 1])
+            if training and config.get().fuse_bn_stats:
+                v, sums = ops.conv_gather_bnstats(uus[k], P[f"conv{k}_t.weight"], P.get(f"conv{k}_t.bias"), B, T, ch[k], Fk[k - 1], ch[k - 1],
+                                                  Fk[k - 1], KT=1, S=1, pad=1, prec=prec)
+            else:
+                v, sums = ops.conv_gather(uus[k], P[f"conv{k}_t.weight"], P.get(f"conv{k}_t.bias"), B, T, ch[k], Fk[k - 1], ch[k - 1],
+                                          Fk[k - 1], KT=1, S=1, pad=1, prec=prec), None
+        elif pend is not None:                            # u_k = relu(bn(v_{k+1})) + skip_k applied while conv{k}_t stages v_{k+1} and skip_k
             v, sums = ops.conv_scatter2_bnin(pend, P[f"conv{k}_t.weight"], P[f"conv{k}_t.bias"], B, T, ch[k], Fk[k], ch[k - 1], KT=1, pad=0,
                                              prec=prec, publish=True, copy_bf16=us[k], want_sums=True)
         elif training and config.get().fuse_bn_stats:
@@ -848,7 +864,7 @@ def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, tor
             v, sums = ops.conv_scatter2(u, P[f"conv{k}_t.weight"], P[f"conv{k}_t.bias"], B, T, ch[k], Fk[k], ch[k - 1], KT=1,
                                         pad=0, prec=prec), None
         # u_{k-1} stays virtual when its consumer conv{k-1}_t takes it fused (the last decoder layer, Cout = 1, is a VALU kernel)
-        if fz and k - 1 >= 2 and ops.bnin_eligible(prec, ch[k - 1], ch[k - 2]):
+        if fz and not ups and k - 1 >= 2 and ops.bnin_eligible(prec, ch[k - 1], ch[k - 2]):
             pend = virtual(v, sums, ch[k - 1], Fk[k - 1], f"bn{k}_t", add=ss[k - 1])
             u = torch.empty(B, T, ch[k - 1], Fk[k - 1], device=dev, dtype=torch.bfloat16)      # written by conv{k-1}_t while it stages
             mean, rstd = pend.mean, pend.rstd
@@ -857,11 +873,16 @@ def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, tor
             u, mean, rstd = _bn_act(v, rows, ch[k - 1], Fk[k - 1], P, Bf, f"bn{k}_t", training, update_running, skip=ss[k - 1],
                                     sums=sums)
         vs[k] = v; dstats[k] = (mean, rstd); us[k - 1] = u
-    mask = ops.conv_scatter2(u, P["conv1_t.weight"], P["conv1_t.bias"], B, T, ch[1], Fk[1], ch[0], KT=1, pad=0, act=1,
-                             prec=prec)
+    if ups:
+        uus[1] = ops.upsample_w(u, rows * ch[1], Fk[1], 2).view(B, T, ch[1], Fk[0])
+        mask = ops.conv_gather(uus[1], P["conv1_t.weight"], P.get("conv1_t.bias"), B, T, ch[1], Fk[0], ch[0], Fk[0], KT=1, S=1, pad=1,
+                               act=1, prec=prec)
+    else:
+        mask = ops.conv_scatter2(u, P["conv1_t.weight"], P["conv1_t.bias"], B, T, ch[1], Fk[1], ch[0], KT=1, pad=0, act=1,
+                                 prec=prec)
     _flush_counters()
     if save:
-        ctx.update(ys=ys, es=es, stats=stats, gctx=gctx, us=us, vs=vs, dstats=dstats, mask=mask)
+        ctx.update(ys=ys, es=es, stats=stats, gctx=gctx, us=us, vs=vs, dstats=dstats, mask=mask, uus=uus, dec_mode=dec_mode)
     return mask.view(B, ch[0], T, F0), ctx
 
 
@@ -881,8 +902,9 @@ N_BUCKETS = 3
 
 
 def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor],
-                   boundary=None) -> None:
-    """dlogit = dL/d(pre-sigmoid) [B,T,1,F0]; parameter gradients are ACCUMULATED into G[name].
+                   boundary=None, need_dx: bool = False):
+    """dlogit = dL/d(pre-sigmoid) [B,T,1,F0]; parameter gradients are ACCUMULATED into G[name].  need_dx: also return the
+    gradient wrt the input magnitude [B,T,1,F0] (the nn.Module surface; the training step never asks for it).
 
     boundary(b): called at the two points where gradient bucket b (bucket_of) has just become final once the issued
     side-stream leaves are joined -- after the GGRU backward (b = 0) and half way down the encoder (b = 1).  The
@@ -901,12 +923,37 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
     _INLINE = config.get().inline_mask
     # backward-only tensors in bf16 (EngineConfig.bf16_dy): only where every consumer rounds them to bf16 operands anyway
     dy_bf16 = bool(config.get().bf16_dy) and ops.prec_code(prec) == ops.PREC_BF16 and dprec == ops.PREC_BF16
+    ups = ctx.get("dec_mode", "transposed") == "upsample"
+    uus = ctx.get("uus", {})
+
+    def dec_wgrad(k, dv_):
+        """weight gradient of decoder conv k"""
+        if ups and ch[k - 1] % 4 != 0:
+            # (one output channel: the kernel wants the narrow tensor in the second role -- sum uu[ci, f] dv[co, f - 1 + kf] is the
+            # same sum with the taps mirrored)
+            tmp = torch.zeros(ch[k], ch[k - 1], 1, 3, device=dlogit.device, dtype=torch.float32)
+            ops.conv_wgrad(uus[k], dv_, tmp, B, T, ch[k], Fk[k - 1], ch[k - 1], Fk[k - 1], KT=1, S=1, pad=1, prec=prec)
+            G[f"conv{k}_t.weight"].add_(tmp.flip(-1).permute(1, 0, 2, 3))
+        elif ups:       # Conv2d (1,3) on the upsampled input: dW[co][ci][kf] = sum dv[co, f] uu[ci, f - 1 + kf]
+            ops.conv_wgrad(dv_, uus[k], G[f"conv{k}_t.weight"], B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k - 1], KT=1, S=1, pad=1, prec=prec)
+        else:
+            ops.conv_wgrad(us[k], dv_, G[f"conv{k}_t.weight"], B, T, ch[k], Fk[k], ch[k - 1], Fk[k - 1], KT=1, S=2, pad=0, prec=prec)
+
+    def dec_dgrad(k, dv_, bn_bwd, out_bf16=False):
+        """gradient wrt u_k of decoder conv k -> (du_k, backward sums of the BatchNorm above or None)"""
+        if ups:         # W^T dv on the upsampled grid, then the sum of each pair of bins (gradient of the nearest upsample)
+            duu = ops.conv_gather(dv_, P[f"conv{k}_t.weight"], None, B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k - 1], KT=1, S=1, pad=1,
+                                  w_layout=1, prec=dprec)
+            return ops.downsum_w(duu, rows * ch[k], Fk[k], 2).view(B, T, ch[k], Fk[k]), None
+        return split(ops.conv_gather(dv_, P[f"conv{k}_t.weight"], None, B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k], KT=1, S=2, pad=0,
+                                     prec=dprec, bn_bwd=bn_bwd, out_bf16=out_bf16))
     # ---- decoder level 1: v1 = convT_1(u1) -------------------------------------------
     dv = dlogit
 
     def leaf_dec1(dv=dv):
-        ops.channel_sum(dv, rows, ch[0], Fk[0], G["conv1_t.bias"])
-        ops.conv_wgrad(us[1], dv, G["conv1_t.weight"], B, T, ch[1], Fk[1], ch[0], Fk[0], KT=1, S=2, pad=0, prec=prec)
+        if "conv1_t.bias" in G:
+            ops.channel_sum(dv, rows, ch[0], Fk[0], G["conv1_t.bias"])
+        dec_wgrad(1, dv)
     SIDE.defer(leaf_dec1, dv, kind=2, lane=0)                           # decoder leaves: issued with the first GRU backward
     # A data gradient that feeds a BatchNorm backward accumulates that BatchNorm's backward sums (sum g, sum g*xhat per channel)
     # in its own epilogue (cruse_conv_*_bnbwd): the reduce pass over (du, v) / (de, y) -- 132 MB and ~47 us per level -- is only
@@ -923,12 +970,11 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
     def split(r):
         return r if isinstance(r, tuple) else (r, None)
     # ... and the data gradients of the levels between two MFMA kernels (EngineConfig.bf16_de): du_k / de_k for 2 <= k < L
-    de_bf16 = dy_bf16 and bool(config.get().bf16_de) and fuse_bwd
+    de_bf16 = dy_bf16 and bool(config.get().bf16_de) and fuse_bwd and not ups
 
     def lvl_bf16(k):
         return de_bf16 and 2 <= k < L
-    du, du_sums = split(ops.conv_gather(dv, P["conv1_t.weight"], None, B, T, ch[0], Fk[0], ch[1], Fk[1], KT=1, S=2, pad=0, prec=dprec,
-                                        bn_bwd=bn_of(2, True) if L >= 2 else None))
+    du, du_sums = dec_dgrad(1, dv, bn_of(2, True) if L >= 2 else None)
     ds = {1: du}                                        # gradient wrt skip_{k} output = du_k
     # skip_k = conv1x3(e_k) is a leaf of the decoder: its data gradient W^T ds_k and its weight gradient ds_k (*) e_k
     # are issued here, on the side stream, into the buffer de_pre[k] that the encoder backward later ACCUMULATES its
@@ -964,16 +1010,15 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
         mean, rstd = dstats[k]
         dv = ops.bn_act_bwd(du, vs[k], mean, rstd, P[f"bn{k}_t.weight"], P[f"bn{k}_t.bias"], rows, ch[k - 1],
                             Fk[k - 1], True, training, G[f"bn{k}_t.weight"], G[f"bn{k}_t.bias"],
-                            dbias=G[f"conv{k}_t.bias"], sums=du_sums, out_bf16=dy_bf16)
+                            dbias=G.get(f"conv{k}_t.bias"), sums=du_sums, out_bf16=dy_bf16)
 
         def leaf_dec(dv=dv, k=k):
-            ops.conv_wgrad(us[k], dv, G[f"conv{k}_t.weight"], B, T, ch[k], Fk[k], ch[k - 1], Fk[k - 1], KT=1, S=2, pad=0, prec=prec)
+            dec_wgrad(k, dv)
         if _INLINE & 4:
             leaf_dec()
         else:
             SIDE.defer(leaf_dec, dv, kind=2, lane=0)
-        du, du_sums = split(ops.conv_gather(dv, P[f"conv{k}_t.weight"], None, B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k], KT=1, S=2,
-                                            pad=0, prec=dprec, bn_bwd=bn_of(k + 1, True) if k < L else None, out_bf16=lvl_bf16(k)))
+        du, du_sums = dec_dgrad(k, dv, bn_of(k + 1, True) if k < L else None, out_bf16=lvl_bf16(k))
         ds[k] = du
         skip_leaves(k)
     # ---- bottleneck: u_L = ggru(e_L) + skip_L --------------------------------------------
@@ -1012,7 +1057,11 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
                                                   out=de_pre[k - 1], accum=True, prec=dprec, bn_bwd=bn_of(k - 1, False)))
         if boundary is not None and k == cut + 1:
             boundary(1)
+    dx = None
+    if need_dx:
+        dx = ops.conv_scatter2(dy, P["conv1.weight"], None, B, T, ch[1], Fk[1], ch[0], KT=2, pad=1, prec=dprec)
     SIDE.join()
+    return dx
 
 
 # ======================================================================================

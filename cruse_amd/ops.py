@@ -279,6 +279,22 @@ def conv_wgrad(a, bt, dw, B, T, Ca, Fa, Cb, Fb, KT, S, pad, prec=None):
                                _xdt(bt, "conv_wgrad bt"), _p(ws), _stream()))
 
 
+def upsample_w(x, rows, W, up=2):
+    """nearest FreqUpsample along the last axis (cust_conv.py:177-184): x [rows, W] f32 -> [rows, W * up]"""
+    _f32(x, "upsample_w")
+    out = torch.empty(rows, W * up, device=x.device, dtype=torch.float32)
+    check(lib.cruse_upsample_w(_p(x), rows, W, up, _p(out), 0, _stream()))
+    return out
+
+
+def downsum_w(dxu, rows, W, up=2):
+    """its gradient: [rows, W * up] f32 -> [rows, W] (sums of `up` neighbours)"""
+    _f32(dxu, "downsum_w")
+    out = torch.empty(rows, W, device=dxu.device, dtype=torch.float32)
+    check(lib.cruse_downsum_w(_p(dxu), rows, W, up, _p(out), 0, _stream()))
+    return out
+
+
 def channel_sum(g, rows, C, F, out):
     check(lib.cruse_channel_sum(_p(g), rows, C, F, _p(out), _stream()))
 

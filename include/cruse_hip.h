@@ -486,6 +486,9 @@ int cruse_conv2d_nchw_wgrad(const void* S, const void* Bg, float* dw,
 int cruse_nchw_channel_sum(const void* x, int N, int C, int HW, float* out, int dtype, void* stream);
 /* gradient of the nearest FreqUpsample: dx[..,w] = sum_{j<up} dxu[.., w*up + j] */
 int cruse_downsum_w(const void* dxu, long long rows, int W, int up, void* dx, int dtype, void* stream);
+/* nearest FreqUpsample (cust_conv.py:177-184) of a tensor whose last axis is W: xu[.., w*up + j] = x[.., w]; the frame-major
+   upsample decoder (model/cruse.py:14, convkxf mode="upsample") materialises it for its (1,3) conv and that conv's weight gradient */
+int cruse_upsample_w(const void* x, long long rows, int W, int up, void* xu, int dtype, void* stream);
 /* nn.BatchNorm2d (+ nn.ReLU / nn.PReLU(C) / nn.Sigmoid: act 1 / 2 / 3) on [N,C,HW]: batch sums for cruse_bn_finalize; y = act(gamma*(x-mean)*rstd+beta)
  * (mean == NULL: activation only); backward with the PReLU slope gradient.  scratch: 3*C doubles. */
 int cruse_bn_nchw_stats(const void* x, int N, int C, int HW, double* sums, int dtype, void* stream);
