@@ -131,6 +131,13 @@ __global__ __launch_bounds__(256) void gconv_pointwise_kernel(GConv<T> a) {
 // consumed by four neighbouring tiles of the same wave (L1).  The VALU form above issues Cin * Cout FMAs and as many LDS
 // weight reads per position (576 + 576 for the 24-channel TFCM layers); this one issues KS * 8 loads + MT * KS MFMAs per 16.
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+// eight independently loaded f16 (as 16-bit integers, one 32-bit register each so that no load waits for another) -> one fragment
+__device__ __forceinline__ f16x8 pack_f16x8(const unsigned (&h)[8]) {
+    u32x4 u = {h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
+    return __builtin_bit_cast(f16x8, u);
+}
+__device__ __forceinline__ unsigned ld_u16(const f16* p) { return (unsigned)*reinterpret_cast<const unsigned short*>(p); }
 
 template <int MT, int KS>
 __global__ __launch_bounds__(256) void gconv_pointwise_mfma_f16_kernel(GConv<f16> a) {
@@ -161,6 +168,11 @@ __global__ __launch_bounds__(256) void gconv_pointwise_mfma_f16_kernel(GConv<f16
             const int co = mt * 16 + kg * 4 + j;
             bs[mt][j] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
         }
+    float sl[MT][4];                                          // PReLU slopes of the lane's output channels
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sl[mt][j] = a.act == 2 ? a.slope[min(mt * 16 + kg * 4 + j, a.Cout - 1)] : 0.f;
     const long long wstride = (long long)gridDim.x * 4 * TPI;
     for (long long t0 = ((long long)blockIdx.x * 4 + wv) * TPI; t0 < ntile; t0 += wstride) {
         f16x8 fb[TPI][KS];
@@ -169,17 +181,20 @@ __global__ __launch_bounds__(256) void gconv_pointwise_mfma_f16_kernel(GConv<f16
             const long long t = t0 + q;
             const int b = (int)(t / tiles_img);
             const long long pp = (long long)(t - (long long)b * tiles_img) * 16 + m;
-            const bool ok = t < ntile && pp < hw;
+            const int ok = (t < ntile ? 1 : 0) & (pp < hw ? 1 : 0);
             // (unconditional loads from clamped addresses, masked afterwards: a branch per element serialises the round trips)
             const f16* xp = a.x + (long long)(t < ntile ? b : 0) * a.Cin * hw + (ok ? pp : 0);
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
+            for (int ks = 0; ks < KS; ++ks) {
+                unsigned hv[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int ci = ks * 32 + kg * 8 + e;
-                    const f16 v = xp[(long long)min(ci, a.Cin - 1) * hw];
-                    fb[q][ks][e] = (ok && ci < a.Cin) ? v : (f16)0.f;
+                    const unsigned v = ld_u16(xp + (long long)min(ci, a.Cin - 1) * hw);
+                    hv[e] = (ok & (ci < a.Cin ? 1 : 0)) ? v : 0u;
                 }
+                fb[q][ks] = pack_f16x8(hv);
+            }
         }
 #pragma unroll
         for (int q = 0; q < TPI; ++q) {
@@ -196,10 +211,9 @@ __global__ __launch_bounds__(256) void gconv_pointwise_mfma_f16_kernel(GConv<f16
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int co = mt * 16 + kg * 4 + j;
-                    if (ok && co < a.Cout) {
-                        float v = acc[j];
-                        if (a.act == 1) v = fmaxf(v, 0.f);
-                        else if (a.act == 2) v = v >= 0.f ? v : a.slope[co] * v;
+                    float v = acc[j];
+                    v = a.act == 1 ? fmaxf(v, 0.f) : (a.act == 2 ? (v >= 0.f ? v : sl[mt][j] * v) : v);
+                    if ((ok ? 1 : 0) & (co < a.Cout ? 1 : 0)) {
                         if (a.accumulate) v += (float)yp[(long long)co * hw];
                         yp[(long long)co * hw] = (f16)v;
                     }
@@ -230,25 +244,141 @@ __global__ __launch_bounds__(256) void gconv_depthwise_kernel(GConv<T> a, TapTab
     const T* xp = a.x + (long long)plane * a.Hin * a.Win;
     T* yp = a.y + (long long)plane * a.Hout * a.Wout;
     const int hwo = a.Hout * a.Wout;
-    int e = blockIdx.x * (DW_U * 256) + threadIdx.x;
-    int ho = e / a.Wout, wo = e - ho * a.Wout;
+    const int e = blockIdx.x * (DW_U * 256) + threadIdx.x;
+    // (straight-line code: positions first, then all loads, then the arithmetic -- no && / while between them, the taps beyond
+    // tt.n carry weight 0 and offset 0)
+    int hos[DW_U], wos[DW_U];
 #pragma unroll
     for (int j = 0; j < DW_U; ++j) {
-        const bool in = e < hwo;
-        float acc = bias;
+        const unsigned ej = (unsigned)(e + j * 256);
+        hos[j] = (int)(ej / (unsigned)a.Wout);
+        wos[j] = (int)(ej - (unsigned)hos[j] * (unsigned)a.Wout);
+    }
+    T xv[DW_U][9];
+    unsigned okm[DW_U];
+#pragma unroll
+    for (int j = 0; j < DW_U; ++j) {
+        const int in = (e + j * 256 < hwo) ? 1 : 0;
+        okm[j] = 0;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            const int hi = ho + tt.dh[k], wi = wo + tt.dw[k];
-            const bool ok = k < tt.n && in && hi >= 0 && hi < a.Hin && wi >= 0 && wi < a.Win;
-            const float v = (float)xp[ok ? hi * a.Win + wi : 0];
-            acc += ok ? w[k] * v : 0.f;
+            const int hi = hos[j] + tt.dh[k], wi = wos[j] + tt.dw[k];
+            const int ok = in & (hi >= 0 ? 1 : 0) & (hi < a.Hin ? 1 : 0) & (wi >= 0 ? 1 : 0) & (wi < a.Win ? 1 : 0);
+            okm[j] |= (unsigned)ok << k;
+            xv[j][k] = xp[ok * (hi * a.Win + wi)];
         }
+    }
+#pragma unroll
+    for (int j = 0; j < DW_U; ++j) {
+        float acc = bias;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc += ((okm[j] >> k) & 1) ? w[k] * (float)xv[j][k] : 0.f;
         if (a.act == 1) acc = fmaxf(acc, 0.f);
         else if (a.act == 2) acc = acc >= 0.f ? acc : slope * acc;
-        if (a.accumulate) acc += (float)yp[in ? e : 0];
-        if (in) yp[e] = (T)acc;
-        e += 256; wo += 256;
-        while (wo >= a.Wout) { wo -= a.Wout; ++ho; }
+        const int ej = e + j * 256;
+        if (ej < hwo) {
+            if (a.accumulate) acc += (float)yp[ej];
+            yp[ej] = (T)acc;
+        }
+    }
+}
+
+// eight consecutive f16 of one plane row <-> floats: one (unaligned) 16-byte access for a whole group, element accesses for a tail
+__device__ __forceinline__ void ld8_f16(const f16* p, int valid, float (&v)[8]) {
+    if (valid >= 8) {
+        f16x8 t;
+        __builtin_memcpy(&t, p, 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = e < valid ? (float)p[e] : 0.f;
+    }
+}
+__device__ __forceinline__ void st8_f16(f16* p, int valid, const float (&v)[8]) {
+    if (valid >= 8) {
+        f16x8 t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = (f16)v[e];
+        __builtin_memcpy(p, &t, 16);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (e < valid) p[e] = (f16)v[e];
+    }
+}
+
+// f16 storage, either form: the input rows of a band of RB output rows are staged in LDS as a ZERO-PADDED image (PADL / PADR halo
+// columns, zero rows above / below the plane), so the compute loop has no bounds logic at all: a thread owns 8 consecutive outputs
+// of a row and every tap is one (unaligned) 16-byte LDS read + 8 conversions + 8 FMAs.  The element-per-thread forms above spend
+// ~160 VALU instructions per output on index arithmetic and masks -- at 4 cycles per wave64 instruction that, not memory, was
+// their bound (62-84 us on [8,24,161,401]).  Rows are copied with unaligned 16-byte global loads.
+struct DwGeom { int RB, rows, Ws, PADL, dh_lo, gpr; };        // staged rows, LDS row stride (elements), groups per output row
+
+__device__ __forceinline__ void dw_stage_f16(const f16* xp, int Hin, int Win, int row_lo, const DwGeom& g, f16* sx) {
+    // LDS row i holds input row row_lo + i: [PADL zeros][Win elements][zeros up to Ws]
+    const int cpr = g.Ws / 8;                                          // 16-byte chunks per LDS row
+    for (int q = threadIdx.x; q < g.rows * cpr; q += 256) {
+        const int i = q / cpr, ck = q - i * cpr;
+        const int hi = row_lo + i, w0 = ck * 8 - g.PADL;               // first input column of the chunk
+        f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hi >= 0 && hi < Hin && w0 + 8 > 0 && w0 < Win) {
+            const f16* src = xp + (long long)hi * Win + w0;
+            if (w0 >= 0 && w0 + 8 <= Win) __builtin_memcpy(&v, src, 16);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (w0 + e >= 0 && w0 + e < Win) v[e] = src[e];
+            }
+        }
+        *reinterpret_cast<f16x8*>(sx + (size_t)i * g.Ws + ck * 8) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void gconv_depthwise_f16_kernel(GConv<f16> a, TapTab tt, DwGeom g) {
+    extern __shared__ __align__(16) unsigned char dsm_raw[];
+    f16* sx = reinterpret_cast<f16*>(dsm_raw);
+    const int plane = blockIdx.y, c = plane % a.Cout;
+    const int r0 = blockIdx.x * g.RB, nr = min(a.Hout, r0 + g.RB) - r0;
+    dw_stage_f16(a.x + (long long)plane * a.Hin * a.Win, a.Hin, a.Win, r0 + g.dh_lo, g, sx);
+    float w[9];
+    int toff[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        w[k] = k < tt.n ? a.w[c * tt.n + k] : 0.f;
+        toff[k] = (tt.dh[k] - g.dh_lo) * g.Ws + g.PADL + tt.dw[k];       // (taps beyond tt.n: offset of tap 0's row, weight 0)
+    }
+    const float bias = a.bias ? a.bias[c] : 0.f;
+    const float slope = a.act == 2 ? a.slope[c] : 0.f;
+    f16* yp = a.y + ((long long)plane * a.Hout + r0) * a.Wout;
+    __syncthreads();
+    for (int q = threadIdx.x; q < nr * g.gpr; q += 256) {
+        const int hr = q / g.gpr, wo = (q - hr * g.gpr) * 8;
+        const f16* base = sx + hr * g.Ws + wo;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = bias;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            f16x8 v;                                                   // (taps beyond tt.n: weight 0, a valid offset)
+            __builtin_memcpy(&v, base + toff[k], 16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += w[k] * (float)v[e];
+        }
+        f16* dst = yp + hr * a.Wout + wo;
+        const int valid = a.Wout - wo;
+        if (a.accumulate) {
+            float old[8];
+            ld8_f16(dst, valid, old);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += old[e];              // (accumulate comes with act 0: the data-gradient form)
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (a.act == 1) acc[e] = fmaxf(acc[e], 0.f);
+            else if (a.act == 2) acc[e] = acc[e] >= 0.f ? acc[e] : slope * acc[e];
+        }
+        st8_f16(dst, valid, acc);
     }
 }
 
@@ -357,8 +487,8 @@ __global__ __launch_bounds__(256) void gconv_wgrad_rows_kernel(GWgrad<T> a) {
 // Weight gradient of a POINTWISE convolution on the matrix cores (f16 storage): dW[ca][cb] += sum_{n,p} S[n,ca,p] Bg[n,cb,p]
 // with K = positions -- the natural MFMA shape on NCHW: both fragments are 8 consecutive positions of one channel row.  A wave
 // owns a run of positions of one image and keeps the whole [CA x CB] result (MT x NT tiles) in its accumulators; one atomic
-// add per weight and wave at the end.  (Rows of an odd-sized plane are only 2-byte aligned, so the fragments are gathered
-// with 2-byte loads: 16 lanes x 8 x 2 B per channel row, every byte used.)
+// add per weight and wave at the end.  (Rows of an odd-sized plane are only 2-byte aligned: the 16-byte fragment loads are
+// unaligned global loads.)
 template <int MT, int NT>
 __global__ __launch_bounds__(1024) void gconv_wgrad_pw_mfma_f16_kernel(GWgrad<f16> a, int run) {
     __shared__ float red[MT * NT * 256];
@@ -376,32 +506,42 @@ __global__ __launch_bounds__(1024) void gconv_wgrad_pw_mfma_f16_kernel(GWgrad<f1
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const f16 zero = (f16)0.f;
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     // wave wv takes the 32-position chunks wv, wv + 16, ... of the block's run, two at a time
     for (long long p = p0 + wv * 32; p < p1; p += 2 * 16 * 32) {
         f16x8 fa[2][MT], fb[2][NT];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
+            // a fragment = 8 consecutive positions of one channel row = ONE 16-byte load (rows of an odd-sized plane are only 2-byte
+            // aligned: global loads take unaligned addresses on this target, the compiler emits global_load_dwordx4 for the
+            // memcpy); the run's last, partial group is gathered element by element
             const long long pk = p + u * 16 * 32 + kg * 8;
+            const int last = (int)min<long long>(max<long long>(p1 - 1 - pk, -1), 7);      // last valid e (-1: none)
+            const long long pc = min(pk, p1 - 1);
+            const bool full = last == 7;
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int ca = i * 16 + r;
-                const f16* q = sp + (long long)min(ca, a.CA - 1) * hw;
+                const f16* q = sp + (long long)min(ca, a.CA - 1) * hw + pc;
+                f16x8 v;
+                if (full) __builtin_memcpy(&v, q, 16);
+                else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {            // (unconditional loads from clamped positions, masked afterwards)
-                    const f16 v = q[min(pk + e, p1 - 1)];
-                    fa[u][i][e] = (ca < a.CA && pk + e < p1) ? v : zero;
+                    for (int e = 0; e < 8; ++e) v[e] = e <= last ? q[min(e, max(last, 0))] : (f16)0.f;
                 }
+                fa[u][i] = ca < a.CA ? v : zero8;
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int cb = j * 16 + r;
-                const f16* q = bp + (long long)min(cb, a.CB - 1) * hw;
+                const f16* q = bp + (long long)min(cb, a.CB - 1) * hw + pc;
+                f16x8 v;
+                if (full) __builtin_memcpy(&v, q, 16);
+                else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const f16 v = q[min(pk + e, p1 - 1)];
-                    fb[u][j][e] = (cb < a.CB && pk + e < p1) ? v : zero;
+                    for (int e = 0; e < 8; ++e) v[e] = e <= last ? q[min(e, max(last, 0))] : (f16)0.f;
                 }
+                fb[u][j] = cb < a.CB ? v : zero8;
             }
         }
 #pragma unroll
@@ -441,21 +581,74 @@ __global__ __launch_bounds__(256) void gconv_wgrad_depthwise_kernel(GWgrad<T> a,
     float acc[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = 0.f;
-    int e = blockIdx.x * (band * 256) + threadIdx.x;
-    int h = e / a.WS, w = e - h * a.WS;
-#pragma unroll 4
-    for (int j = 0; j < band; ++j) {
-        const bool in = e < hws;
-        const float sv = in ? (float)sp[e] : 0.f;
+    // (straight-line groups of WG_U positions: positions, then all loads, then the arithmetic; taps beyond tt.n have offset 0 and
+    // their sums are never written)
+    constexpr int WG_U = 4;
+    const int e0 = blockIdx.x * (band * 256) + threadIdx.x;
+    for (int j0 = 0; j0 < band; j0 += WG_U) {
+        T bv[WG_U][9];
+        float sv[WG_U];
+        unsigned okm[WG_U];
+#pragma unroll
+        for (int j = 0; j < WG_U; ++j) {
+            const unsigned ej = (unsigned)(e0 + (j0 + j) * 256);
+            const int in = ((int)ej < hws && j0 + j < band) ? 1 : 0;
+            const int h = (int)(ej / (unsigned)a.WS), w = (int)(ej - (unsigned)h * (unsigned)a.WS);
+            sv[j] = in ? (float)sp[in * (int)ej] : 0.f;
+            okm[j] = 0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int hb = h * a.sh + tt.dh[k], wb = w * a.sw + tt.dw[k];
+                const int ok = in & (hb >= 0 ? 1 : 0) & (hb < a.HB ? 1 : 0) & (wb >= 0 ? 1 : 0) & (wb < a.WB ? 1 : 0);
+                okm[j] |= (unsigned)ok << k;
+                bv[j][k] = bp[ok * (hb * a.WB + wb)];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WG_U; ++j)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[k] += ((okm[j] >> k) & 1) ? sv[j] * (float)bv[j][k] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const float v = wave_sum(acc[k]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < tt.n) atomicAdd(&a.dw[c * tt.n + threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ... f16 storage, stride 1: the Bg rows of a band of S rows staged as the same zero-padded LDS image; a thread owns 8 consecutive
+// S positions (one 16-byte global load) and every tap is one 16-byte LDS read + 8 conversions + 8 FMAs into that tap's sum.
+__global__ __launch_bounds__(256) void gconv_wgrad_depthwise_f16_kernel(GWgrad<f16> a, TapTab tt, DwGeom g) {
+    extern __shared__ __align__(16) unsigned char dsm_raw[];
+    f16* sb = reinterpret_cast<f16*>(dsm_raw);
+    __shared__ float red[4][9];
+    const int plane = blockIdx.y, c = plane % a.CA;
+    const int r0 = blockIdx.x * g.RB, nr = min(a.HS, r0 + g.RB) - r0;
+    dw_stage_f16(a.Bg + (long long)plane * a.HB * a.WB, a.HB, a.WB, r0 + g.dh_lo, g, sb);
+    int toff[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) toff[k] = (tt.dh[k] - g.dh_lo) * g.Ws + g.PADL + tt.dw[k];
+    const f16* sp = a.S + ((long long)plane * a.HS + r0) * a.WS;
+    float acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+    __syncthreads();
+    for (int q = threadIdx.x; q < nr * g.gpr; q += 256) {
+        const int hr = q / g.gpr, w0 = (q - hr * g.gpr) * 8;
+        float sv[8];
+        ld8_f16(sp + hr * a.WS + w0, a.WS - w0, sv);                   // (zeros beyond the row's end)
+        const f16* base = sb + hr * g.Ws + w0;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            const int hb = h * a.sh + tt.dh[k], wb = w * a.sw + tt.dw[k];
-            const bool ok = k < tt.n && in && hb >= 0 && hb < a.HB && wb >= 0 && wb < a.WB;
-            const float v = (float)bp[ok ? hb * a.WB + wb : 0];
-            acc[k] += ok ? sv * v : 0.f;
+            f16x8 v;                                                   // (taps beyond tt.n: a valid offset, the sum is never written)
+            __builtin_memcpy(&v, base + toff[k], 16);
+            float t = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t += sv[e] * (float)v[e];
+            acc[k] += t;
         }
-        e += 256; w += 256;
-        while (w >= a.WS) { w -= a.WS; ++h; }
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
@@ -629,6 +822,151 @@ __global__ void bn_nchw_bwd_apply_kernel(const T* dy, const T* x, const float* m
     }
 }
 
+// ---- f16 storage: the same four BatchNorm passes and the channel sum on 16-byte groups -----------------------------------------
+// A plane (n, c) is HW contiguous f16, 2-byte aligned when HW is odd ([.., 161, 401]): a thread takes 8 consecutive elements of
+// ONE plane with one unaligned 16-byte load (the element-per-thread kernels above also pay a 64-bit i / HW % C per element:
+// 0.7-1.5 TB/s on 25 MB tensors); the plane's last, partial group is handled element by element.
+__global__ __launch_bounds__(256) void bn_nchw_stats_f16v_kernel(const f16* x, int N, int C, int HW, double* sums) {
+    __shared__ double red[2][4];
+    const int c = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    const int chunk = ((HW + gridDim.z - 1) / gridDim.z + 7) & ~7, i0 = blockIdx.z * chunk, i1 = min(HW, i0 + chunk);
+    for (int n = blockIdx.y; n < N; n += gridDim.y) {
+        const f16* p = x + ((long long)n * C + c) * HW;
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll 2
+        for (int i = i0 + threadIdx.x * 8; i < i1; i += 2048) {
+            float v[8];
+            ld8_f16(p + i, i1 - i, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a1 += v[e]; a2 += v[e] * v[e]; }
+        }
+        s1 += a1; s2 += a2;
+    }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[c], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(&sums[C + c], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void nchw_channel_sum_f16v_kernel(const f16* x, int N, int C, int HW, float* out) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    float acc = 0.f;
+    const int chunk = ((HW + gridDim.z - 1) / gridDim.z + 7) & ~7, i0 = blockIdx.z * chunk, i1 = min(HW, i0 + chunk);
+    for (int n = blockIdx.y; n < N; n += gridDim.y) {
+        const f16* p = x + ((long long)n * C + c) * HW;
+        float a0 = 0.f;
+#pragma unroll 2
+        for (int i = i0 + threadIdx.x * 8; i < i1; i += 2048) {
+            float v[8];
+            ld8_f16(p + i, i1 - i, v);
+            a0 += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        acc += a0;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&out[c], red[0] + red[1] + red[2] + red[3]);
+}
+
+// grid (groups of a plane / 256, N * C)
+__global__ __launch_bounds__(256) void bn_nchw_fwd_f16v_kernel(const f16* x, const float* mean, const float* rstd, const float* gamma,
+                                                               const float* beta, const float* slope, int act, int C, int HW, f16* y) {
+    const int plane = blockIdx.y, c = plane % C;
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= HW) return;
+    const float m = mean ? mean[c] : 0.f, rs = mean ? rstd[c] : 1.f, ga = mean ? gamma[c] : 1.f, be = mean ? beta[c] : 0.f;
+    const float sl = act == 2 ? slope[c] : 0.f;
+    const long long o = (long long)plane * HW + i;
+    float v[8];
+    ld8_f16(x + o, HW - i, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float z = mean ? (v[e] - m) * rs * ga + be : v[e];
+        if (act == 1) z = fmaxf(z, 0.f);
+        else if (act == 2) z = z >= 0.f ? z : sl * z;
+        else if (act == 3) z = 1.f / (1.f + expf(-z));
+        v[e] = z;
+    }
+    st8_f16(y + o, HW - i, v);
+}
+
+__global__ __launch_bounds__(256) void bn_nchw_bwd_reduce_f16v_kernel(const f16* dy, const f16* x, const float* mean, const float* rstd,
+                                                                      const float* gamma, const float* beta, const float* slope, int act,
+                                                                      int N, int C, int HW, double* r) {
+    __shared__ double red[3][4];
+    const int c = blockIdx.x;
+    const float m = mean ? mean[c] : 0.f, rs = mean ? rstd[c] : 1.f, ga = mean ? gamma[c] : 1.f, be = mean ? beta[c] : 0.f;
+    const float sl = act == 2 ? slope[c] : 0.f;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const int chunk = ((HW + gridDim.z - 1) / gridDim.z + 7) & ~7, i0 = blockIdx.z * chunk, i1 = min(HW, i0 + chunk);
+    for (int n = blockIdx.y; n < N; n += gridDim.y) {
+        const long long o = ((long long)n * C + c) * HW;
+        float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 2
+        for (int i = i0 + threadIdx.x * 8; i < i1; i += 2048) {
+            float xv[8], dv[8];
+            const int valid = i1 - i;
+            ld8_f16(x + o + i, valid, xv);
+            ld8_f16(dy + o + i, valid, dv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xh = (xv[e] - m) * rs;
+                const float z = xh * ga + be;
+                float d = e < valid ? dv[e] : 0.f;
+                if (act == 1) d = z > 0.f ? d : 0.f;
+                else if (act == 2) { if (z < 0.f) { a3 += d * z; d *= sl; } }
+                else if (act == 3) { const float sg = 1.f / (1.f + expf(-z)); d *= sg * (1.f - sg); }
+                a1 += d; a2 += d * xh;
+            }
+        }
+        s1 += a1; s2 += a2; s3 += a3;
+    }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2); s3 = wave_sum_d(s3);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; red[2][threadIdx.x >> 6] = s3; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&r[c], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(&r[C + c], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        atomicAdd(&r[2 * C + c], red[2][0] + red[2][1] + red[2][2] + red[2][3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_nchw_bwd_apply_f16v_kernel(const f16* dy, const f16* x, const float* mean, const float* rstd,
+                                                                     const float* gamma, const float* beta, const float* slope, int act,
+                                                                     const double* r, double inv_count, int training, int C, int HW, f16* dx) {
+    const int plane = blockIdx.y, c = plane % C;
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= HW) return;
+    const float m = mean ? mean[c] : 0.f, rs = mean ? rstd[c] : 1.f, ga = mean ? gamma[c] : 1.f, be = mean ? beta[c] : 0.f;
+    const float sl = act == 2 ? slope[c] : 0.f;
+    const float k1 = (mean && training) ? (float)(r[c] * inv_count) : 0.f, k2 = (mean && training) ? (float)(r[C + c] * inv_count) : 0.f;
+    const long long o = (long long)plane * HW + i;
+    float xv[8], dv[8];
+    ld8_f16(x + o, HW - i, xv);
+    ld8_f16(dy + o, HW - i, dv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float xh = (xv[e] - m) * rs;
+        const float z = xh * ga + be;
+        float d = dv[e];
+        if (act == 1) d = z > 0.f ? d : 0.f;
+        else if (act == 2) d = z >= 0.f ? d : sl * d;
+        else if (act == 3) { const float sg = 1.f / (1.f + expf(-z)); d *= sg * (1.f - sg); }
+        if (mean) {
+            if (training) d -= k1 + xh * k2;
+            d *= ga * rs;
+        }
+        dv[e] = d;
+    }
+    st8_f16(dx + o, HW - i, dv);
+}
+
 // dgamma += r[C+c], dbeta += r[c], dslope += r[2C+c]
 __global__ void bn_nchw_param_grads_kernel(const double* r, int C, float* dgamma, float* dbeta, float* dslope) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -653,6 +991,27 @@ __global__ void cast_t_kernel(const S* src, D* dst, long long n) {
 
 // chunks per plane for the per-channel reductions: enough blocks to fill 256 CUs several times over, at least 4096
 // elements per chunk
+// LDS image of the f16 depthwise kernels: band of RB rows of the iterated tensor (Hiter rows of Witer columns), the staged tensor
+// has Wsrc columns; false if the image does not fit 60 KB
+inline bool dw_geometry(const TapTab& tt, int Hiter, int Wsrc, int Witer, long long planes, DwGeom* g, size_t* lds) {
+    int dh_lo = 0, dh_hi = 0, dw_lo = 0, dw_hi = 0;
+    for (int k = 0; k < tt.n; ++k) {
+        dh_lo = tt.dh[k] < dh_lo ? tt.dh[k] : dh_lo; dh_hi = tt.dh[k] > dh_hi ? tt.dh[k] : dh_hi;
+        dw_lo = tt.dw[k] < dw_lo ? tt.dw[k] : dw_lo; dw_hi = tt.dw[k] > dw_hi ? tt.dw[k] : dw_hi;
+    }
+    int RB = Hiter < 16 ? Hiter : 16;
+    while (planes * cdiv(Hiter, RB) < 1024 && RB > 4) RB >>= 1;
+    g->RB = RB; g->dh_lo = dh_lo; g->rows = RB + dh_hi - dh_lo;
+    g->PADL = (-dw_lo + 7) & ~7;
+    g->gpr = cdiv(Witer, 8);
+    // a group reads columns [wo + dw, wo + dw + 8), wo <= 8 * (gpr - 1): the row must reach PADL + 8 * gpr + dw_hi
+    int need = g->PADL + 8 * g->gpr + dw_hi;
+    if (need < g->PADL + Wsrc) need = g->PADL + Wsrc;
+    g->Ws = (need + 7) & ~7;
+    *lds = (size_t)g->rows * g->Ws * 2 + 16;
+    return *lds <= 60 * 1024 && Hiter > 0;
+}
+
 inline int zchunks(int gx, int gy, int HW) {
     int z = 1;
     while ((long long)gx * gy * z < 2048 && HW / (z * 2) >= 4096) z *= 2;
@@ -715,6 +1074,17 @@ int conv2d_nchw_t(const void* x, const float* w, const float* bias, void* y, int
                 tt.dh[kh * KW + kw] = transposed ? pt - kh * dh : kh * dh - pt;
                 tt.dw[kh * KW + kw] = transposed ? pl - kw * dw : kw * dw - pl;
             }
+        if constexpr (sizeof(T) == 2) {
+            DwGeom g;
+            size_t lds;
+            if (!cruse_opt("dw_nolds", 0) && dw_geometry(tt, Hout, Win, Wout, B * Cout, &g, &lds)) {
+                int rc = cruse_ensure_dyn_lds((const void*)gconv_depthwise_f16_kernel, lds, "conv2d_nchw depthwise");
+                if (rc) return rc;
+                hipLaunchKernelGGL(gconv_depthwise_f16_kernel, dim3(cdiv(Hout, g.RB), B * Cout), dim3(256), lds, s, a, tt, g);
+                CRUSE_LAUNCH_CHECK("conv2d_nchw depthwise (f16, LDS image)");
+                return CRUSE_OK;
+            }
+        }
         hipLaunchKernelGGL(gconv_depthwise_kernel<T>, dim3(cdiv(Hout * Wout, 8 * 256), B * Cout), dim3(256), 0, s, a, tt);
         CRUSE_LAUNCH_CHECK("conv2d_nchw depthwise");
         return CRUSE_OK;
@@ -753,6 +1123,17 @@ int wgrad_nchw_t(const void* S, const void* Bg, float* dw, int N, int CA, int HS
         tt.n = KH * KW;
         for (int kh = 0; kh < KH; ++kh)
             for (int kw = 0; kw < KW; ++kw) { tt.dh[kh * KW + kw] = kh * dh - pt; tt.dw[kh * KW + kw] = kw * dw_ - pl; }
+        if constexpr (sizeof(T) == 2) {
+            DwGeom g;
+            size_t lds;
+            if (sh == 1 && sw == 1 && !cruse_opt("dw_nolds", 0) && dw_geometry(tt, HS, WB, WS, N * CA, &g, &lds)) {
+                int rc = cruse_ensure_dyn_lds((const void*)gconv_wgrad_depthwise_f16_kernel, lds, "conv2d_nchw_wgrad depthwise");
+                if (rc) return rc;
+                hipLaunchKernelGGL(gconv_wgrad_depthwise_f16_kernel, dim3(cdiv(HS, g.RB), N * CA), dim3(256), lds, s, a, tt, g);
+                CRUSE_LAUNCH_CHECK("conv2d_nchw_wgrad depthwise (f16, LDS image)");
+                return CRUSE_OK;
+            }
+        }
         hipLaunchKernelGGL(gconv_wgrad_depthwise_kernel<T>, dim3(cdiv(HS * WS, band * 256), N * CA), dim3(256), 0, s, a, band, tt);
         CRUSE_LAUNCH_CHECK("conv2d_nchw_wgrad depthwise");
         return CRUSE_OK;
@@ -778,10 +1159,24 @@ template <typename T>
 int bn_nchw_bwd_t(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                   const float* slope, int act, int training, int N, int C, int HW, double* scratch, void* dx, float* dgamma,
                   float* dbeta, float* dslope, hipStream_t s) {
+    const long long total = (long long)N * C * HW;
+    if constexpr (sizeof(T) == 2) {
+        if ((long long)N * C < 65536) {                      // (grid.y = planes)
+            hipLaunchKernelGGL(bn_nchw_bwd_reduce_f16v_kernel, dim3(C, N < 32 ? N : 32, zchunks(C, N < 32 ? N : 32, HW)), dim3(256), 0, s, (const f16*)dy,
+                               (const f16*)x, mean, rstd, gamma, beta, slope, act, N, C, HW, scratch);
+            CRUSE_LAUNCH_CHECK("bn_nchw_bwd_reduce");
+            hipLaunchKernelGGL(bn_nchw_bwd_apply_f16v_kernel, dim3(cdiv(cdiv(HW, 8), 256), N * C), dim3(256), 0, s, (const f16*)dy, (const f16*)x, mean, rstd,
+                               gamma, beta, slope, act, scratch, 1.0 / ((double)N * HW), training, C, HW, (f16*)dx);
+            CRUSE_LAUNCH_CHECK("bn_nchw_bwd_apply");
+            hipLaunchKernelGGL(bn_nchw_param_grads_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, scratch, C, mean ? dgamma : nullptr,
+                               mean ? dbeta : nullptr, act == 2 ? dslope : nullptr);
+            CRUSE_LAUNCH_CHECK("bn_nchw_param_grads");
+            return CRUSE_OK;
+        }
+    }
     hipLaunchKernelGGL(bn_nchw_bwd_reduce_kernel<T>, dim3(C, N < 32 ? N : 32, zchunks(C, N < 32 ? N : 32, HW)), dim3(256), 0, s, (const T*)dy, (const T*)x, mean, rstd,
                        gamma, beta, slope, act, N, C, HW, scratch);
     CRUSE_LAUNCH_CHECK("bn_nchw_bwd_reduce");
-    const long long total = (long long)N * C * HW;
     hipLaunchKernelGGL(bn_nchw_bwd_apply_kernel<T>, dim3(gblocks(total)), dim3(256), 0, s, (const T*)dy, (const T*)x, mean, rstd, gamma,
                        beta, slope, act, scratch, 1.0 / ((double)N * HW), training, total, C, HW, (T*)dx);
     CRUSE_LAUNCH_CHECK("bn_nchw_bwd_apply");
@@ -829,7 +1224,7 @@ extern "C" int cruse_nchw_channel_sum(const void* x, int N, int C, int HW, float
     CRUSE_REQUIRE(N > 0 && C > 0 && HW > 0, CRUSE_E_SHAPE, "nchw_channel_sum: bad shape");
     CRUSE_DT_CHECK("nchw_channel_sum");
     if (dtype == CRUSE_DT_F16)
-        hipLaunchKernelGGL(nchw_channel_sum_kernel<f16>, dim3(C, N < 16 ? N : 16, zchunks(C, N < 16 ? N : 16, HW)), dim3(256), 0, ST(stream), (const f16*)x, N, C, HW, out);
+        hipLaunchKernelGGL(nchw_channel_sum_f16v_kernel, dim3(C, N < 16 ? N : 16, zchunks(C, N < 16 ? N : 16, HW)), dim3(256), 0, ST(stream), (const f16*)x, N, C, HW, out);
     else
         hipLaunchKernelGGL(nchw_channel_sum_kernel<float>, dim3(C, N < 16 ? N : 16, zchunks(C, N < 16 ? N : 16, HW)), dim3(256), 0, ST(stream), (const float*)x, N, C, HW, out);
     CRUSE_LAUNCH_CHECK("nchw_channel_sum");
@@ -870,7 +1265,7 @@ extern "C" int cruse_bn_nchw_stats(const void* x, int N, int C, int HW, double* 
     CRUSE_DT_CHECK("bn_nchw_stats");
     { int rc = cruse_zero_async(sums, 2 * (size_t)C * sizeof(double), ST(stream), "bn_nchw_stats"); if (rc) return rc; }
     if (dtype == CRUSE_DT_F16)
-        hipLaunchKernelGGL(bn_nchw_stats_kernel<f16>, dim3(C, N < 32 ? N : 32, zchunks(C, N < 32 ? N : 32, HW)), dim3(256), 0, ST(stream), (const f16*)x, N, C, HW, sums);
+        hipLaunchKernelGGL(bn_nchw_stats_f16v_kernel, dim3(C, N < 32 ? N : 32, zchunks(C, N < 32 ? N : 32, HW)), dim3(256), 0, ST(stream), (const f16*)x, N, C, HW, sums);
     else
         hipLaunchKernelGGL(bn_nchw_stats_kernel<float>, dim3(C, N < 32 ? N : 32, zchunks(C, N < 32 ? N : 32, HW)), dim3(256), 0, ST(stream), (const float*)x, N, C, HW, sums);
     CRUSE_LAUNCH_CHECK("bn_nchw_stats");
@@ -883,7 +1278,10 @@ extern "C" int cruse_bn_nchw_fwd(const void* x, const float* mean, const float* 
     CRUSE_REQUIRE((mean == nullptr) == (rstd == nullptr) && (mean == nullptr || (gamma && beta)), CRUSE_E_SHAPE, "bn_nchw_fwd: statistics");
     CRUSE_DT_CHECK("bn_nchw_fwd");
     const long long total = (long long)N * C * HW;
-    if (dtype == CRUSE_DT_F16)
+    if (dtype == CRUSE_DT_F16 && (long long)N * C < 65536)
+        hipLaunchKernelGGL(bn_nchw_fwd_f16v_kernel, dim3(cdiv(cdiv(HW, 8), 256), N * C), dim3(256), 0, ST(stream), (const f16*)x, mean, rstd, gamma, beta,
+                           slope, act, C, HW, (f16*)y);
+    else if (dtype == CRUSE_DT_F16)
         hipLaunchKernelGGL(bn_nchw_fwd_kernel<f16>, dim3(gblocks(total)), dim3(256), 0, ST(stream), (const f16*)x, mean, rstd, gamma, beta,
                            slope, act, total, C, HW, (f16*)y);
     else
