@@ -130,6 +130,8 @@ __global__ __launch_bounds__(256) void gconv_pointwise_kernel(GConv<T> a) {
 // 2-byte loads: the 16 lanes of a row read one 32-byte run, four tiles are in flight per wave, and a whole input line is
 // consumed by four neighbouring tiles of the same wave (L1).  The VALU form above issues Cin * Cout FMAs and as many LDS
 // weight reads per position (576 + 576 for the 24-channel TFCM layers); this one issues KS * 8 loads + MT * KS MFMAs per 16.
+// (Measured alternative, round 4: a register-blocked f32 FMA form -- 4 positions x all channels per thread, 8-byte row loads -- is
+// scheduled by the compiler into SGPR / VGPR spills whichever way the C x C weights are supplied and ran at 47 us vs 30 us here.)
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 // eight independently loaded f16 (as 16-bit integers, one 32-bit register each so that no load waits for another) -> one fragment
@@ -490,8 +492,10 @@ __global__ __launch_bounds__(256) void gconv_wgrad_rows_kernel(GWgrad<T> a) {
 // add per weight and wave at the end.  (Rows of an odd-sized plane are only 2-byte aligned: the 16-byte fragment loads are
 // unaligned global loads.)
 template <int MT, int NT>
-__global__ __launch_bounds__(1024) void gconv_wgrad_pw_mfma_f16_kernel(GWgrad<f16> a, int run) {
-    __shared__ float red[MT * NT * 256];
+__global__ __launch_bounds__(1024) void gconv_wgrad_pw_mfma_f16_kernel(GWgrad<f16> a, int run_dbg) {
+    const int run = run_dbg & 0xffffff, dbg = run_dbg >> 24;
+    extern __shared__ __align__(16) unsigned char dsm_raw[];
+    float* red = reinterpret_cast<float*>(dsm_raw);                      // [16 waves][MT * NT * 256]: one slab per wave, no LDS atomics
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;            // 16 waves: enough loads in flight to cover HBM latency
     const int r = lane & 15, kg = lane >> 4;
     const long long hw = (long long)a.HS * a.WS;
@@ -500,7 +504,6 @@ __global__ __launch_bounds__(1024) void gconv_wgrad_pw_mfma_f16_kernel(GWgrad<f1
     const long long p0 = (long long)(blockIdx.x - n * runs_img) * run, p1 = min(hw, p0 + run);
     const f16* sp = a.S + (long long)n * a.CA * hw;
     const f16* bp = a.Bg + (long long)n * a.CB * hw;
-    for (int i = threadIdx.x; i < MT * NT * 256; i += 1024) red[i] = 0.f;
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -551,19 +554,24 @@ __global__ __launch_bounds__(1024) void gconv_wgrad_pw_mfma_f16_kernel(GWgrad<f1
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[u][i], fb[u][j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();
-    // acc[i][j][q] = dW[ca = i*16 + kg*4 + q][cb = j*16 + r]: 16 waves -> LDS -> one atomic per weight and block
+    // acc[i][j][q] = dW[ca = i*16 + kg*4 + q][cb = j*16 + r]: every wave stores its tile sums into its own LDS slab (LDS float
+    // atomics from 16 waves cost 20-40 us per launch), a thread then adds the 16 slabs of its weight: one global atomic per
+    // weight and block
+    float* mine = red + wv * (MT * NT * 256);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) atomicAdd(&red[((i * NT + j) * 16 + kg * 4 + q) * 16 + r], acc[i][j][q]);
+            for (int q = 0; q < 4; ++q) mine[((i * NT + j) * 16 + kg * 4 + q) * 16 + r] = acc[i][j][q];
     __syncthreads();
     for (int idx = threadIdx.x; idx < MT * NT * 256; idx += 1024) {
         const int t = idx >> 8, row = (idx >> 4) & 15, col = idx & 15;
         const int ca = (t / NT) * 16 + row, cb = (t % NT) * 16 + col;
-        if (ca < a.CA && cb < a.CB) atomicAdd(&a.dw[(long long)ca * a.CB + cb], red[idx]);
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) v += red[w * (MT * NT * 256) + idx];
+        if (ca < a.CA && cb < a.CB && !(dbg & 1)) atomicAdd(&a.dw[(long long)ca * a.CB + cb], v);
     }
 }
 
@@ -1103,14 +1111,20 @@ int wgrad_nchw_t(const void* S, const void* Bg, float* dw, int N, int CA, int HS
         if (fast && KH == 1 && KW == 1 && groups == 1 && sh == 1 && sw == 1 && pt == 0 && pl == 0 && up_w == 1 && HS == HB && WS == WB &&
             CA <= 32 && CB <= 32) {
             const long long hw = (long long)HS * WS;
-            int run = 4096;                                  // positions per 16-wave block (a multiple of 1024)
-            while ((long long)N * cdivl(hw, run) < 512 && run > 1024) run >>= 1;
+            int run = cruse_opt("wgpw_run", 4096);              // positions per 16-wave block (a multiple of 1024)
+            { const long long want = cruse_opt("wgpw_blocks", 256); while ((long long)N * cdivl(hw, run) < want && run > 1024) run >>= 1; }
             const dim3 grid((unsigned)((long long)N * cdivl(hw, run)));
+            run |= cruse_opt("wgpw_dbg", 0) << 24;
             const int mt = cdiv(CA, 16), ntl = cdiv(CB, 16);
-            if (mt == 1 && ntl == 1) hipLaunchKernelGGL((gconv_wgrad_pw_mfma_f16_kernel<1, 1>), grid, dim3(1024), 0, s, a, run);
-            else if (mt == 1) hipLaunchKernelGGL((gconv_wgrad_pw_mfma_f16_kernel<1, 2>), grid, dim3(1024), 0, s, a, run);
-            else if (ntl == 1) hipLaunchKernelGGL((gconv_wgrad_pw_mfma_f16_kernel<2, 1>), grid, dim3(1024), 0, s, a, run);
-            else hipLaunchKernelGGL((gconv_wgrad_pw_mfma_f16_kernel<2, 2>), grid, dim3(1024), 0, s, a, run);
+#define WGPW_CASE(m_, n_) do { const size_t lds = (size_t)16 * m_ * n_ * 256 * sizeof(float); \
+                int rc = cruse_ensure_dyn_lds((const void*)gconv_wgrad_pw_mfma_f16_kernel<m_, n_>, lds, "conv2d_nchw_wgrad pointwise"); \
+                if (rc) return rc; \
+                hipLaunchKernelGGL((gconv_wgrad_pw_mfma_f16_kernel<m_, n_>), grid, dim3(1024), lds, s, a, run); } while (0)
+            if (mt == 1 && ntl == 1) WGPW_CASE(1, 1);
+            else if (mt == 1) WGPW_CASE(1, 2);
+            else if (ntl == 1) WGPW_CASE(2, 1);
+            else WGPW_CASE(2, 2);
+#undef WGPW_CASE
             CRUSE_LAUNCH_CHECK("conv2d_nchw_wgrad pointwise mfma f16");
             return CRUSE_OK;
         }

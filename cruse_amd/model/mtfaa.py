@@ -29,10 +29,18 @@ class STFT(nn.Module):
         window = {"hann": torch.hann_window(win_len), "hamm": torch.hamming_window(win_len)}
         assert win_type in window.keys()
         self.window = window[win_type]
+        self._cache = {}            # device copies of the window / inverse envelopes: made once, not per call (a host-to-device
+                                    # copy per call also rules out HIP-graph capture of a step that contains the transform)
+
+    def _window_on(self, device):
+        key = ("w", str(device))
+        if key not in self._cache:
+            self._cache[key] = self.window.to(device)
+        return self._cache[key]
 
     def transform(self, inp):
         from ..acoustics.feature import stft_framed
-        w = self.window.to(inp.device)
+        w = self._window_on(inp.device)
         re, im = stft_framed(inp, w, self.nfft, self.hop, win_off=(self.nfft - self.win) // 2, pad=self.nfft // 2,
                              pad_mode="reflect", frames=1 + inp.shape[-1] // self.hop)
         return torch.stack([re.transpose(1, 2), im.transpose(1, 2)], dim=1)          # "b f t c -> b c f t"
@@ -40,19 +48,22 @@ class STFT(nn.Module):
     def inverse(self, real, imag):
         """real, imag: [B,F,T] -> [B, hop*(T-1)] (torch.istft, center=True)."""
         from ..acoustics.feature import istft_framed
-        w = self.window.to(real.device)
+        w = self._window_on(real.device)
         T = real.shape[-1]
         L = self.hop * (T - 1)
         off = (self.nfft - self.win) // 2
-        # window-square overlap envelope: periodic in hop away from the clip edges; torch.istft divides by it
-        env = torch.zeros(self.nfft + L + self.nfft)
-        w2 = torch.nn.functional.pad(self.window ** 2, (off, self.nfft - self.win - off))
-        for t in range(T):
-            env[t * self.hop:t * self.hop + self.nfft] += w2
-        env = env[self.nfft // 2:self.nfft // 2 + L]
+        key = ("env", T, str(real.device))
+        if key not in self._cache:
+            # window-square overlap envelope: periodic in hop away from the clip edges; torch.istft divides by it
+            # (one overlap-add of T copies of w^2 as a fold, once per clip length)
+            w2 = torch.nn.functional.pad(self.window ** 2, (off, self.nfft - self.win - off))
+            env = torch.nn.functional.fold(w2.view(1, self.nfft, 1).expand(1, self.nfft, T).contiguous(), (1, self.nfft + self.hop * (T - 1)),
+                                           (1, self.nfft), stride=(1, self.hop)).view(-1)
+            env = env[self.nfft // 2:self.nfft // 2 + L]
+            self._cache[key] = (1.0 / env).to(real.device)
         return istft_framed(real.transpose(1, 2).contiguous(), imag.transpose(1, 2).contiguous(), w, self.nfft, self.hop,
                             win_off=off, pad=self.nfft // 2, length=L, scale=1.0 / self.nfft, hermitian=True,
-                            post_full=(1.0 / env).to(real.device))
+                            post_full=self._cache[key])
 
 
 class ComplexConv2d(nn.Module):
