@@ -127,6 +127,7 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
     constexpr bool INB = IOB == 3 || IOB == 4, INA = IOB == 4;      // fused input BatchNorm (+ added tensor)
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+    typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
     __bf16* const yb = reinterpret_cast<__bf16*>(a.y);       // (YB: the output tensor's elements)
     constexpr bool STATS = EPI != 0;
     constexpr bool SW = SWM == 1;              // swapped roles, gather forms; SWM == 2: swapped roles, scatter forms, both parity classes per N-tile
@@ -140,7 +141,22 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
     const int nfrag = MT * (ks0 + ks1);
     const size_t wplane = (size_t)nfrag * 512;             // elements per weight plane
     elem* wl = reinterpret_cast<elem*>(smem_raw);          // [NPL][nfrag][64 lanes][8]  (pre-converted once)
-    float* xl = reinterpret_cast<float*>(wl + NPL * wplane);   // [nrows][Cin][Fin]: RAW copy of the frame rows
+    float* xl = reinterpret_cast<float*>(wl + NPL * wplane);   // [nrows][Cin][Fin]: RAW copy of the frame rows (f32 mode)
+    // CF (the bf16 modes): the staged tile is kept CHANNEL-FASTEST and PRE-CONVERTED -- [plane][row][1 + Fin + 1 positions][Cin]
+    // bf16, zero columns at both ends of a row -- so that a lane's MFMA fragment (8 consecutive channels of one tap at one position)
+    // is ONE ds_read_b128 per plane and the k-loop has no conversion and no bounds logic.  (The raw [t][c][f] image made it 8 scalar
+    // ds_reads + 8 (x3: 24) conversions per lane and k-step, repeated for every tap that touches an element: the k-loops were 65-80 %
+    // of a tile's time, issue-bound -- cm_dbg stamps, tools/conv_probe.py.)
+    constexpr bool CF = PREC != CRUSE_PREC_F32;
+    // image geometry in 16-byte CHUNKS (8 channels of one position): chunk L = (row * FP + 1 + bin) * nch + octet lives at chunk
+    // L ^ ((L >> 4) & (d - 1)), d = min(S * nch, 16): the 16 lanes of a ds_read_b128 group read positions S bins apart, i.e. chunks
+    // d apart -- un-swizzled they fall on 16 / d distinct chunks of the 256-byte bank window (d-way conflicts); the XOR spreads
+    // every aligned run of d chunks differently from one 16-chunk window to the next: 16 distinct chunks, no padding bytes
+    const int FP = a.Fin + 2, nch = a.Cin >> 3, lg_nch = 31 - __clz(nch);
+    const int swz_m = min(a.S * nch, 16) - 1;
+    const int cplane = ((a.nrows * FP * nch + 15) & ~15) * 8;      // elements per plane of the CF image (whole 16-chunk windows: the swizzle stays inside)
+    __bf16* const xc = reinterpret_cast<__bf16*>(wl + NPL * wplane);
+    auto cf_off = [&](int L) -> int { return (L ^ ((L >> 4) & swz_m)) << 3; };       // chunk index -> element offset
     __shared__ int2 s_tap2[2][MAXTAP];
     __shared__ float s_bias[MT * 16];
     __shared__ float s_bnp[STATS ? 4 : 1][MT * 16];       // mean, rstd, gamma, beta of the backward-statistics form
@@ -153,7 +169,8 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
 
     if (tid < 2 * MAXTAP) {
         const int c = tid / MAXTAP, i = tid % MAXTAP;
-        s_tap2[c][i] = make_int2(a.cls[c].dt[i] * a.Cin * a.Fin + a.cls[c].df[i], a.cls[c].df[i]);
+        s_tap2[c][i] = CF ? make_int2((a.cls[c].dt[i] * FP + a.cls[c].df[i]) * nch, a.cls[c].df[i])
+                          : make_int2(a.cls[c].dt[i] * a.Cin * a.Fin + a.cls[c].df[i], a.cls[c].df[i]);
     }
     // per-channel biases in LDS (read back per N-tile epilogue: a global load inside the N-tile loop forces an in-order
     // vmcnt wait on every older request -- the next tile's prefetch and the previous N-tile's stores -- ~2 us per N-tile;
@@ -195,7 +212,7 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
     // (8*Fin floats = a multiple of 32 banks for Fin = 20, 40, 80: all four groups on the same 16 banks, a 4-way conflict on each
     // of the 8 reads of every k-step; PMC: 25-40 % of these kernels' LDS-active cycles).  The weight fragments are built in the
     // same order, so nothing else changes.
-    const int cblk = a.kint ? (a.Cin < 32 ? a.Cin : 32) : 8, ngrp = cblk >> 3;       // (option cm_kint = 0: consecutive channels, the A/B switch)
+    const int cblk = (a.kint && !CF) ? (a.Cin < 32 ? a.Cin : 32) : 8, ngrp = cblk >> 3;       // (option cm_kint = 0: consecutive channels, the A/B switch; CF: consecutive)
     for (int it = tid; it < nfrag * 64; it += NTHR) {
         const int l = it & 63, fr = it >> 6;
         int c = 0, rem = fr;
@@ -241,24 +258,88 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) { s1[mt][r4] = 0.f; s2[mt][r4] = 0.f; }
     }
-    float4 pre[NV];
-    float4 pre2[INA ? NV : 1];                             // the added tensor's slots (IOB 4)
-    // tile-invariant slot coordinates of the fused-input forms: frame row (4 bits) | first channel (8) | elements before the channel
-    // changes (3): a float4 straddles at most one channel boundary (Fin >= 4)
-    unsigned sinfo[INB ? NV : 1];
-    if constexpr (INB) {
+    float4 pre[CF ? 1 : NV];
+    float4 pre2[(INA && !CF) ? NV : 1];                    // the added tensor's slots (IOB 4)
+    // CF staging items: item = (row r, channel octet o, bin group j of VW bins), it = (r * nch + o) * Fin/VW + j; a thread loads
+    // the 8 channels of its VW bins (a channel row of Fin elements is contiguous over the lanes) and writes VW 16-byte chunks per
+    // plane.  VW = 4 where Fin % 4 == 0 (16-byte loads of f32, 8-byte loads of bf16; one item per thread), else 2 (two items per
+    // thread: slot 0 in the .xy halves of the registers below, slot 1 in .zw)
+    float4 c4[(CF && !XB) ? 8 : 1], c4b[(CF && INA) ? 8 : 1];
+    uint2 cb[(CF && XB) ? 8 : 1];
+    const bool vw4 = (a.Fin & 3) == 0;
+    int c_src[CF ? 2 : 1], c_pos[CF ? 2 : 1], c_row[CF ? 2 : 1], c_oct[CF ? 2 : 1];
+    if constexpr (CF) {
+        const int vw = vw4 ? 4 : 2;
+        const int jn = a.Fin / vw, per_row = jn * nch, items = a.nrows * per_row;
 #pragma unroll
-        for (int q = 0; q < NV; ++q) {
-            const int e0 = min((tid + NTHR * q) * 4, max(nvec * 4 - 4, 0));
-            const int r = e0 / rowlen, off = e0 - r * rowlen, c0 = off / a.Fin, nf = min(4, a.Fin - (off - c0 * a.Fin));
-            sinfo[q] = (unsigned)r | ((unsigned)c0 << 4) | ((unsigned)nf << 12);
+        for (int q = 0; q < 2; ++q) {
+            const int it = tid + NTHR * q;
+            const bool v = it < items && (q == 0 || !vw4);
+            const int itc = v ? it : 0;
+            const int r = itc / per_row, rem = itc - r * per_row, o = rem / jn, j = rem - o * jn;
+            c_row[q] = v ? r : -1;
+            c_oct[q] = o;
+            c_src[q] = (r * a.Cin + 8 * o) * a.Fin + vw * j;
+            c_pos[q] = r * FP + vw * j + 1;
         }
+        for (int i = tid; i < NPL * cplane / 8; i += NTHR) reinterpret_cast<float4*>(xc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     auto prefetch = [&](int tile) {
         const int b = tile / ntile;
         const int t0 = (tile - b * ntile) * TFM;
-        // (the dtype branch sits OUTSIDE the slot loop: a branch around every load made the compiler wait for each load at the
-        //  join -- the f32 path lost its batch of loads in flight, 0.3 ms per step over the convolutions)
+        if constexpr (CF) {
+            // unconditional loads (rows outside the clip read frame 0 of the tensor and are zeroed when stored): a branch around
+            // a load makes the compiler wait for it at the join
+            const long long base = ((long long)b * a.T + (t0 - a.halo_lo)) * rowlen;
+            auto slot_off = [&](int q) -> long long {
+                const int t = t0 - a.halo_lo + c_row[q];
+                const bool ok = c_row[q] >= 0 && t >= 0 && t < a.T;
+                return (ok ? base : 0ll) + c_src[q];
+            };
+            if (vw4) {
+                const long long off = slot_off(0);
+                if constexpr (XB) {
+                    const __bf16* sp = reinterpret_cast<const __bf16*>(a.x) + off;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) cb[e] = *reinterpret_cast<const uint2*>(sp + e * a.Fin);
+                } else {
+                    const float* sp = a.x + off;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) c4[e] = *reinterpret_cast<const float4*>(sp + e * a.Fin);
+                    if constexpr (INA) {
+                        const float* sp2 = a.in_add + off;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) c4b[e] = *reinterpret_cast<const float4*>(sp2 + e * a.Fin);
+                    }
+                }
+            } else {
+                const long long off0 = slot_off(0), off1 = slot_off(1);
+                if constexpr (XB) {
+                    const __bf16* sp0 = reinterpret_cast<const __bf16*>(a.x) + off0;
+                    const __bf16* sp1 = reinterpret_cast<const __bf16*>(a.x) + off1;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { cb[e].x = *reinterpret_cast<const unsigned*>(sp0 + e * a.Fin); cb[e].y = *reinterpret_cast<const unsigned*>(sp1 + e * a.Fin); }
+                } else {
+                    const float* sp0 = a.x + off0;
+                    const float* sp1 = a.x + off1;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float2 u0 = *reinterpret_cast<const float2*>(sp0 + e * a.Fin), u1 = *reinterpret_cast<const float2*>(sp1 + e * a.Fin);
+                        c4[e] = make_float4(u0.x, u0.y, u1.x, u1.y);
+                    }
+                    if constexpr (INA) {
+                        const float* sq0 = a.in_add + off0;
+                        const float* sq1 = a.in_add + off1;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float2 u0 = *reinterpret_cast<const float2*>(sq0 + e * a.Fin), u1 = *reinterpret_cast<const float2*>(sq1 + e * a.Fin);
+                            c4b[e] = make_float4(u0.x, u0.y, u1.x, u1.y);
+                        }
+                    }
+                }
+            }
+            return;
+        }
         if constexpr (XB) {                                // 8 bf16 = 16 bytes per slot (rowlen % 8 == 0, host-checked): half the slots
             const __bf16* srcb = reinterpret_cast<const __bf16*>(a.x) + ((long long)b * a.T + (t0 - a.halo_lo)) * rowlen;
 #pragma unroll
@@ -307,7 +388,87 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
         const int b = tile / ntile;
         const int t0 = (tile - b * ntile) * TFM;
         __syncthreads();                                   // previous tile's reads of xl are done
-        if constexpr (XB) {
+        if constexpr (CF) {
+            __bf16* const cpy = (INB && a.in_copy) ? reinterpret_cast<__bf16*>(a.in_copy) + ((long long)b * a.T + (t0 - a.halo_lo)) * rowlen : nullptr;
+            // bins [e0, e0 + nb) of the register set (0..3) belong to slot q
+            auto put_slot = [&](int q, int e0, int nb) {
+                if (c_row[q] < 0) return;
+                const int t = t0 - a.halo_lo + c_row[q];
+                const bool ok = t >= 0 && t < a.T;         // (rows outside the clip are ZERO: the padding applies to e, not to x)
+                const int L0 = (c_pos[q] << lg_nch) + c_oct[q];
+                if constexpr (XB) {
+                    // dword (e >> 1) of channel c holds bins e (low half) and e + 1: per bin one 16-byte run of 8 channels
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (e < e0 || e >= e0 + nb) continue;
+                        u32x4_ w;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const unsigned lo = (e & 2) ? cb[2 * i].y : cb[2 * i].x, hi = (e & 2) ? cb[2 * i + 1].y : cb[2 * i + 1].x;
+                            w[i] = ok ? __builtin_amdgcn_perm(hi, lo, (e & 1) ? 0x07060302u : 0x05040100u) : 0u;
+                        }
+                        *reinterpret_cast<u32x4_*>(xc + cf_off(L0 + ((e - e0) << lg_nch))) = w;
+                    }
+                } else {
+                    float cm[8], cr[8], cg[8], cbt[8];
+                    if constexpr (INB) {
+                        const int c0 = 8 * c_oct[q];
+                        *reinterpret_cast<float4*>(&cm[0]) = *reinterpret_cast<const float4*>(&s_inp[0][c0]); *reinterpret_cast<float4*>(&cm[4]) = *reinterpret_cast<const float4*>(&s_inp[0][c0 + 4]);
+                        *reinterpret_cast<float4*>(&cr[0]) = *reinterpret_cast<const float4*>(&s_inp[1][c0]); *reinterpret_cast<float4*>(&cr[4]) = *reinterpret_cast<const float4*>(&s_inp[1][c0 + 4]);
+                        *reinterpret_cast<float4*>(&cg[0]) = *reinterpret_cast<const float4*>(&s_inp[2][c0]); *reinterpret_cast<float4*>(&cg[4]) = *reinterpret_cast<const float4*>(&s_inp[2][c0 + 4]);
+                        *reinterpret_cast<float4*>(&cbt[0]) = *reinterpret_cast<const float4*>(&s_inp[3][c0]); *reinterpret_cast<float4*>(&cbt[4]) = *reinterpret_cast<const float4*>(&s_inp[3][c0 + 4]);
+                    }
+                    bf16x8 hs[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (e < e0 || e >= e0 + nb) continue;
+                        float v[8];
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            const float xin = e == 0 ? c4[c].x : e == 1 ? c4[c].y : e == 2 ? c4[c].z : c4[c].w;
+                            float tv = xin;
+                            if constexpr (INB) {
+                                tv = (xin - cm[c]) * cr[c] * cg[c] + cbt[c];
+                                tv = fmaxf(tv, 0.f);
+                                if constexpr (INA) tv += e == 0 ? c4b[c].x : e == 1 ? c4b[c].y : e == 2 ? c4b[c].z : c4b[c].w;
+                            }
+                            v[c] = ok ? tv : 0.f;
+                        }
+                        bf16x8 h;
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) h[c] = (__bf16)v[c];
+                        hs[e] = h;
+                        const int off = cf_off(L0 + ((e - e0) << lg_nch));
+                        *reinterpret_cast<bf16x8*>(xc + off) = h;
+                        if constexpr (NPL == 2) {
+                            bf16x8 l;
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) l[c] = (__bf16)(v[c] - (float)h[c]);
+                            *reinterpret_cast<bf16x8*>(xc + cplane + off) = l;
+                        }
+                    }
+                    if constexpr (INB) {
+                        if (cpy != nullptr && ok && c_row[q] >= a.halo_lo) {       // own rows only: the halo belongs to the tile before
+                            // bf16 copy in the tensor's own [c][f] order: nb bins per channel
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) {
+                                if (nb == 4) {
+                                    bf16x4_ p4;
+                                    p4[0] = hs[0][c]; p4[1] = hs[1][c]; p4[2] = hs[2][c]; p4[3] = hs[3][c];
+                                    *reinterpret_cast<bf16x4_*>(cpy + c_src[q] + c * a.Fin) = p4;
+                                } else {
+                                    bf16x2_ p2;
+                                    p2[0] = e0 == 0 ? hs[0][c] : hs[2][c]; p2[1] = e0 == 0 ? hs[1][c] : hs[3][c];
+                                    *reinterpret_cast<bf16x2_*>(cpy + c_src[q] + c * a.Fin) = p2;
+                                }
+                            }
+                        }
+                    }
+                }
+            };
+            if (vw4) put_slot(0, 0, 4);
+            else { put_slot(0, 0, 2); put_slot(1, 2, 2); }
+        } else if constexpr (XB) {
 #pragma unroll
             for (int q = 0; q < (NV + 1) / 2; ++q) {
                 const int i = tid + NTHR * q;
@@ -318,38 +479,6 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
                                                                          __uint_as_float(w1 << 16), __uint_as_float(w1 & 0xffff0000u));
                     *reinterpret_cast<float4*>(xl + i * 8 + 4) = make_float4(__uint_as_float(w2 << 16), __uint_as_float(w2 & 0xffff0000u),
                                                                              __uint_as_float(w3 << 16), __uint_as_float(w3 & 0xffff0000u));
-                }
-            }
-        } else if constexpr (INB) {
-            __bf16* const cpy = a.in_copy ? reinterpret_cast<__bf16*>(a.in_copy) + ((long long)b * a.T + (t0 - a.halo_lo)) * rowlen : nullptr;
-#pragma unroll
-            for (int q = 0; q < NV; ++q) {
-                const int i = tid + NTHR * q;
-                if (i < nvec) {
-                    const unsigned si = sinfo[q];
-                    const int r = (int)(si & 15u), c0 = (int)((si >> 4) & 255u), nf = (int)(si >> 12);
-                    const int t = t0 - a.halo_lo + r;
-                    const bool ok = t >= 0 && t < a.T;     // (halo rows before the clip stay ZERO: the padding applies to e, not to x)
-                    const int c1 = min(c0 + 1, a.Cin - 1);
-                    const float m0 = s_inp[0][c0], r0 = s_inp[1][c0], g0 = s_inp[2][c0], b0_ = s_inp[3][c0];
-                    const float m1 = s_inp[0][c1], r1 = s_inp[1][c1], g1 = s_inp[2][c1], b1_ = s_inp[3][c1];
-                    const float in[4] = {pre[q].x, pre[q].y, pre[q].z, pre[q].w};
-                    float o[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const bool lo = e < nf;
-                        float tv = (in[e] - (lo ? m0 : m1)) * (lo ? r0 : r1) * (lo ? g0 : g1) + (lo ? b0_ : b1_);
-                        tv = fmaxf(tv, 0.f);
-                        o[e] = tv;
-                    }
-                    if constexpr (INA) { o[0] += pre2[q].x; o[1] += pre2[q].y; o[2] += pre2[q].z; o[3] += pre2[q].w; }
-                    if (!ok) { o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; }
-                    *reinterpret_cast<float4*>(xl + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
-                    if (cpy != nullptr && ok && r >= a.halo_lo) {         // own rows only: the halo belongs to the tile before
-                        bf16x4_ h4;
-                        h4[0] = (__bf16)o[0]; h4[1] = (__bf16)o[1]; h4[2] = (__bf16)o[2]; h4[3] = (__bf16)o[3];
-                        *reinterpret_cast<bf16x4_*>(cpy + i * 4) = h4;
-                    }
                 }
             }
         } else {
@@ -437,6 +566,7 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
                 const int tl = (int)(((float)p + 0.5f) * inv_mpos);
                 const int m = p - tl * Mpos;
                 const int rowbase = (tl + a.halo_lo) * rowlen + a.S * m;
+                const int rowbase_cf = ((tl + a.halo_lo) * FP + a.S * m + 1) << lg_nch;
                 long long off[2];
                 bool okt[2];
                 {
@@ -484,6 +614,12 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
                         const int ci0 = (k & (a.Cin - 1) & ~(cblk - 1)) + ((lane >> 4) & (ngrp - 1));
                         if (tap >= ntaps) tap = ntaps - 1;
                         const int2 tp = s_tap2[c][tap];
+                        Frag<PREC> fb;
+                        if constexpr (CF) {
+                            const __bf16* pb = xc + cf_off(rowbase_cf + tp.x + ((k & (a.Cin - 1)) >> 3));
+                            fb.h = *reinterpret_cast<const bf16x8*>(pb);
+                            if constexpr (NPL == 2) fb.l = *reinterpret_cast<const bf16x8*>(pb + cplane);
+                        } else {
                         const int f = a.S * m + tp.y;
                         float bv[8];
                         if (f >= 0 && f < a.Fin) {
@@ -495,8 +631,8 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
 #pragma unroll
                             for (int e = 0; e < 8; ++e) bv[e] = 0.f;
                         }
-                        Frag<PREC> fb;
                         fb.set(bv);
+                        }
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
                             const Frag<PREC> fa = get_frag<PREC>(wl, wplane, ((size_t)(fbase + mt * ksn + ks) * 64 + lane) * 8);
@@ -563,12 +699,19 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int rowbase = (tl + a.halo_lo) * rowlen + a.S * m;
+            const int rowbase_cf = ((tl + a.halo_lo) * FP + a.S * m + 1) << lg_nch;
             for (int ks = 0; ks < ksn; ++ks) {
                 const int k = ks * 32 + q8;
                 int tap = k >> lg_cin;
                 const int ci0 = (k & (a.Cin - 1) & ~(cblk - 1)) + ((lane >> 4) & (ngrp - 1));
                 if (tap >= ntaps) tap = ntaps - 1;        // zero weights there; keep the address valid
                 const int2 tp = s_tap2[c][tap];           // x = dt*rowlen + df, y = df
+                Frag<PREC> fb;
+                if constexpr (CF) {
+                    const __bf16* pb = xc + cf_off(rowbase_cf + tp.x + ((k & (a.Cin - 1)) >> 3));
+                    fb.h = *reinterpret_cast<const bf16x8*>(pb);
+                    if constexpr (NPL == 2) fb.l = *reinterpret_cast<const bf16x8*>(pb + cplane);
+                } else {
                 const int f = a.S * m + tp.y;
                 float bv[8];
                 if (f >= 0 && f < a.Fin) {
@@ -580,8 +723,8 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
 #pragma unroll
                     for (int e = 0; e < 8; ++e) bv[e] = 0.f;
                 }
-                Frag<PREC> fb;
                 fb.set(bv);
+                }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const Frag<PREC> fa = get_frag<PREC>(wl, wplane, ((size_t)(fbase + mt * ksn + ks) * 64 + lane) * 8);
@@ -866,7 +1009,10 @@ int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float
     if ((TFM + KT - 1) * Cin * Fin > MAXV * 256 * 4) return 0;
     const size_t wbytes = (size_t)mt * (ks0 + ks1) * 512 *
                           (prec == CRUSE_PREC_F32 ? 4 : (prec == CRUSE_PREC_BF16X3 ? 4 : 2));
-    const size_t lds = wbytes + (size_t)a.nrows * Cin * Fin * sizeof(float);
+    const bool cf = prec != CRUSE_PREC_F32;      // channel-fastest pre-converted bf16 image (see the kernel)
+    if (cf && ((Fin & 1) != 0 || a.nrows * (Fin / ((Fin & 3) ? 2 : 4)) * (Cin / 8) > ((Fin & 3) ? 2 : 1) * 256)) return 0;
+    const size_t lds = wbytes + (cf ? (size_t)(prec == CRUSE_PREC_BF16X3 ? 2 : 1) * (size_t)((a.nrows * (Fin + 2) * (Cin / 8) + 15) & ~15) * 16
+                                    : (size_t)a.nrows * Cin * Fin * sizeof(float));
     if (lds > 150 * 1024) return 0;
     const int ntiles = B * ((T + TFM - 1) / TFM);
     // small weight images: more, lighter workgroups hide latency better (44 vs 60 us on the 8->16 layer);

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(320) void gru_fwd_tf_kernel(GruArgs a) {
 // ---------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int P, bool TIMED = false>
+template <int P, bool TIMED = false, bool STAG = false>
 __global__ __launch_bounds__(320) void gru_bwd_tf_kernel(GruArgs a) {
     constexpr int Hg = P * 32, NP = (P + 3) / 4, NT = 2 * NP, NTt = 2 * P, NL = (P + 7) / 8, K3 = 3 * Hg;
     constexpr bool FULL = P % 4 == 0;
@@ -534,22 +534,53 @@ __global__ __launch_bounds__(320) void gru_bwd_tf_kernel(GruArgs a) {
             u32x4 g[NL];
             unsigned spins = 0;
             for (int i = 0; i < a.poll_delay; ++i) __builtin_amdgcn_s_sleep(1);     // (see poll_delay)
-            for (;;) {
-#pragma unroll
-                for (int j = 0; j < NL; ++j) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, sweep_v[j], soff, 16);
+            auto tags_ok = [&](const u32x4* q) -> bool {
                 unsigned bad = 0u;
 #pragma unroll
                 for (int j = 0; j < NL; ++j) {
-                    const unsigned bj = (g[j].x ^ tm) | (g[j].y ^ tm) | (g[j].z ^ tm) | (g[j].w ^ tm);
+                    const unsigned bj = (q[j].x ^ tm) | (q[j].y ^ tm) | (q[j].z ^ tm) | (q[j].w ^ tm);
                     bad |= sweep_ok[j] ? bj : 0u;
                 }
-                if (__all((bad & TAGM) == 0u || !active || nowait)) break;
+                return __all((bad & TAGM) == 0u || !active || nowait);
+            };
+            auto give_up = [&]() {
                 if (++spins >= SPIN_LIMIT) {
                     if (lane == 0) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     nowait = true;
                 }
                 if constexpr (TIMED) tph[4] += 1;
-                __builtin_amdgcn_s_sleep(1);
+            };
+            if constexpr (STAG) {
+                // TWO polls in flight, a.poll_stagger sleep periods apart: loads return in order, so while the older set is examined
+                // the younger one is already half way -- a missed poll costs the stagger, not a whole L2 round trip
+                u32x4 g2[NL];
+#pragma unroll
+                for (int j = 0; j < NL; ++j) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, sweep_v[j], soff, 16);
+                for (;;) {
+                    for (int i = 0; i < a.poll_stagger; ++i) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                    for (int j = 0; j < NL; ++j) g2[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, sweep_v[j], soff, 16);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (tags_ok(g)) break;
+                    give_up();
+#pragma unroll
+                    for (int j = 0; j < NL; ++j) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, sweep_v[j], soff, 16);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (tags_ok(g2)) {
+#pragma unroll
+                        for (int j = 0; j < NL; ++j) g[j] = g2[j];
+                        break;
+                    }
+                    give_up();
+                }
+            } else {
+                for (;;) {
+#pragma unroll
+                    for (int j = 0; j < NL; ++j) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, sweep_v[j], soff, 16);
+                    if (tags_ok(g)) break;
+                    give_up();
+                    __builtin_amdgcn_s_sleep(1);
+                }
             }
             if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[0] += tq1 - tq0; tq0 = tq1; }
             f32x2 sm[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};         // units (2i, 2i + 1) of the chunk
@@ -681,7 +712,15 @@ bool bwd_tf_eligible(int Bg, int Hg, int prec) {
 size_t tf_bwd_bytes_per_parity(int Hg) { const size_t P = Hg / 32; return P * 8 * P * 64; }
 
 int dispatch_bwd_tf(const GruArgs& a, int grid, hipStream_t s) {
-    if (a.dbg == 32 && a.Hg == 640) return launch_one(gru_bwd_tf_kernel<20, true>, a, grid, 0, s, "gru_seq_bwd", 320);
+    if (a.dbg == 32 && a.Hg == 640) return a.poll_stagger > 0 ? launch_one(gru_bwd_tf_kernel<20, true, true>, a, grid, 0, s, "gru_seq_bwd", 320)
+                                                               : launch_one(gru_bwd_tf_kernel<20, true>, a, grid, 0, s, "gru_seq_bwd", 320);
+    if (a.poll_stagger > 0) {
+        switch (a.Hg) {
+            case 160: return launch_one(gru_bwd_tf_kernel<5, false, true>, a, grid, 0, s, "gru_seq_bwd", 320);
+            case 320: return launch_one(gru_bwd_tf_kernel<10, false, true>, a, grid, 0, s, "gru_seq_bwd", 320);
+            default: return launch_one(gru_bwd_tf_kernel<20, false, true>, a, grid, 0, s, "gru_seq_bwd", 320);
+        }
+    }
     switch (a.Hg) {
         case 160: return launch_one(gru_bwd_tf_kernel<5>, a, grid, 0, s, "gru_seq_bwd", 320);
         case 320: return launch_one(gru_bwd_tf_kernel<10>, a, grid, 0, s, "gru_seq_bwd", 320);

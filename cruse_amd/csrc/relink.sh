@@ -1,0 +1,16 @@
+#!/usr/bin/env bash
+# Rebuild only the named sources (default: none) and relink libcruse_hip.so from build/*.o.  usage: relink.sh [gru_tf gemm_bf16 ...]
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+pids=()
+for f in "$@"; do
+  if [ "$f" = abi ]; then "$HIPCC" $FLAGS -x hip -c "$here/abi.cpp" -o "$here/build/abi.o" & else "$HIPCC" $FLAGS -c "$here/$f.hip" -o "$here/build/$f.o" & fi
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait "$p"; done
+objs=()
+for f in stft stft_general conv conv_mfma wgrad_mfma pointwise gemm gemm_bf16 gru gru_tf tdloss deepfilter generic extras abi; do objs+=("$here/build/$f.o"); done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$here/../libcruse_hip.so"
+echo "relinked"
