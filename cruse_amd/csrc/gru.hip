@@ -260,9 +260,14 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
 // TF: the TAG-FREE hand-off of gru_tf.hip (the epoch bit inside every published bf16, half the sweep and publish bytes: 3 instead of
 // 5 sweep loads per thread at Hg = 640) under this kernel's K-split step -- at Hg = 640 the K-split-free step of gru_fwd_tf_kernel
 // measured slower (1.36 against 1.27 us per step), the hand-off alone pays.  Needs h0 == NULL (|h| < 1).
-template <int NKW, int NS, bool FULL, bool WLO, bool TIMED = false, bool GIB = false, bool TF = false>
+// RD (with TF): REGISTER-DIRECT sweep -- no LDS image of the panel.  A wave sweeps exactly the 16-byte chunks that ARE its MFMA B fragments
+// (its k-steps wv + 4 i of every clip: NKW loads per lane) and checks its own tags; the panel is laid out CLIP-MINOR ([k chunk of 8][clip][8])
+// so that the 8 clips of one (k-step, lane group) are one 128-byte line and a load instruction is 512 contiguous bytes.  The panel barrier
+// stays (the helper wave's hand-over point), the image write, the wait for it and the fragment reads go.
+template <int NKW, int NS, bool FULL, bool WLO, bool TIMED = false, bool GIB = false, bool TF = false, bool RD = false>
 __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_kernel(GruArgs a) {
     static_assert(!TF || FULL, "tag-free sweeps are built for Hg % 128 == 0");
+    static_assert(!RD || (TF && !WLO), "register-direct sweep: tag-free hand-off");
     constexpr int NSW = TF ? (NKW * 128 + 255) / 256 : NS;      // sweep slots per thread
     constexpr bool HW = !(WLO && NKW > 3);
     unsigned long long tph[5] = {0, 0, 0, 0, 0}, tq0 = 0, tq1 = 0;
@@ -393,6 +398,9 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
         // step t: two barriers (t > 0).  The gi set for step t + 2 goes to its ring slot, the set is re-issued for step
         // t + 4; the saves of step t - 1 are in LDS once the first barrier of step t has passed.
         const bool h0_step = a.h0 != nullptr;              // step 0 then runs its MFMA phase too (two barriers like any other)
+        // (RD: the panel barrier stays although nothing is shared through it any more -- it is the helper wave's hand-over point.  With
+        //  per-wave "sweep done" flags in LDS instead, the helper started only after the LAST wave's sweep and became the long pole of the
+        //  second barrier: 1.25 against 1.18 us per step.)
         for (int t = 0; t < a.T; t += 2) {
             if (t > 0 || h0_step) __syncthreads();
             put(t + 2, s0); issue(t + 4, s0);
@@ -452,10 +460,14 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
     const unsigned own_v = (unsigned)(((long long)(b0 + blc) * a.TS * H + grp * Hg + u0 + u) * 4);                    // + t*frame_bytes
     const unsigned g_v = (unsigned)((((long long)(b0 + blc) * a.TS * a.G + grp) * 3 * Hg + u0 + u) * 4);               // + t*grow_bytes
     const unsigned hg4 = (unsigned)Hg * 4u;
-    const unsigned pub_v = (unsigned)((bl * Hg + u0 + u) >> 1) * (TF ? 4u : 8u);
+    const unsigned pub_v = RD ? (unsigned)(((((u0 + u) >> 3) * 8 + bl) * 8 + (u & 7)) * 2) : (unsigned)((bl * Hg + u0 + u) >> 1) * (TF ? 4u : 8u);
+    const unsigned rd_v = (unsigned)(((wv * 4 + (lane >> 4)) * 8 + (lane & 7)) * 16);         // RD: + i * 2048 bytes = k-step wv + 4 i
+    const unsigned rd_v2 = rd_v + (((lane >> 3) & 1) ? 2048u : 0u);                           // (columns 8..15: the odd k-step of a pair)
+    const bool rd_ok = (lane & 7) < nb;
     const bool pub_lane = act && !(u & 1);
 
     float hp = 0.f, gic[3], sv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    unsigned xsink = 0u;
     const bool has_h0 = a.h0 != nullptr;
     if (!TF && has_h0) {                                   // the panel of step 0 is the initial state (bf16, like any h_{t-1})
         __syncthreads();                                   // (the zero fill above)
@@ -487,7 +499,40 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
 
     for (int t = 0; t < a.T; ++t) {
         if constexpr (TIMED) tq0 = __builtin_amdgcn_s_memtime();
-        if (t > 0) {
+        constexpr int NLR = RD ? (NKW + 1) / 2 : 1;       // RD: two k-steps per load -- columns 8..15 of the MFMA fetch the odd one (gru_bwd_ag_kernel)
+        u32x4 gr[NLR];
+        if (RD && t > 0) {
+            const unsigned soff = cbase + (unsigned)((t - 1) & 1) * panel_bytes;
+            const bool expect1 = tag_bit((unsigned)t) != 0u;
+            unsigned spins = 0;
+            for (int i = 0; i < a.poll_delay; ++i) __builtin_amdgcn_s_sleep(1);
+            for (;;) {
+#pragma unroll
+                for (int j = 0; j < NLR; ++j)
+                    gr[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (2 * j + 1 < NKW || j + 1 < NLR) ? rd_v2 : rd_v, soff + (unsigned)(j * 4096), 16);
+                unsigned bad;
+                if (expect1) {
+                    unsigned n = 0xffffffffu;
+#pragma unroll
+                    for (int i = 0; i < NLR; ++i) n = n & (gr[i].x & gr[i].y) & (gr[i].z & gr[i].w);
+                    bad = ~n;
+                } else {
+                    unsigned o = 0u;
+#pragma unroll
+                    for (int i = 0; i < NLR; ++i) o = o | (gr[i].x | gr[i].y) | (gr[i].z | gr[i].w);
+                    bad = o;
+                }
+                if (__all((bad & TAGM) == 0u || !rd_ok || nowait)) break;
+                if (++spins >= SPIN_LIMIT) {
+                    if (lane == 0) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    nowait = true;
+                }
+                if constexpr (TIMED) tph[4] += 1;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[0] += tq1 - tq0; tq0 = tq1; }
+        }
+        if (!RD && t > 0) {
             const unsigned soff = cbase + (unsigned)((t - 1) & 1) * panel_bytes;
             u32x4 g[NSW];
             unsigned spins = 0;
@@ -495,6 +540,10 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
             for (;;) {
 #pragma unroll
                 for (int j = 0; j < NSW; ++j) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, sw_v[j], soff, 16);
+                for (int rep = 0; rep < a.xsweep; ++rep) {      // profiling (gru_xsweep): the sweep volume of an all-gather backward
+#pragma unroll
+                    for (int j = 0; j < NSW; ++j) { const u32x4 gx = __builtin_amdgcn_raw_buffer_load_b128(rs, sw_v[j], soff, 16); xsink ^= gx.x ^ gx.w; }
+                }
                 bool ok = true;
                 if constexpr (TF) {
                     unsigned bad = 0u;
@@ -548,7 +597,7 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
         }
         float gh[3] = {bias[0], bias[1], bias[2]};
         if (t > 0 || has_h0) {
-            __syncthreads();                               // panel complete
+            __syncthreads();                               // panel complete (RD: the helper wave's hand-over point)
             if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[1] += tq1 - tq0; tq0 = tq1; }
             f32x4 acc[6];
 #pragma unroll
@@ -556,7 +605,15 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
 #pragma unroll
             for (int i = 0; i < NKW; ++i) {
                 if (FULL || wv + 4 * i < KS) {              // wave-uniform
-                    const bf16x8 fb = *reinterpret_cast<const bf16x8*>(hB + (lane & 15) * LD + (wv + 4 * i) * 32 + (lane >> 4) * 8);
+                    bf16x8 fb;
+                    if constexpr (RD) {
+                        const u32x4 gg = gr[RD ? (i >> 1) : 0];
+                        u32x4 w = {gg.x & ~TAGM, gg.y & ~TAGM, gg.z & ~TAGM, gg.w & ~TAGM};
+                        if (i & 1) { w.x = dpp_ror8(w.x); w.y = dpp_ror8(w.y); w.z = dpp_ror8(w.z); w.w = dpp_ror8(w.w); }     // columns 8..15 -> 0..7
+                        fb = __builtin_bit_cast(bf16x8, w);
+                    } else {
+                        fb = *reinterpret_cast<const bf16x8*>(hB + (lane & 15) * LD + (wv + 4 * i) * 32 + (lane >> 4) * 8);
+                    }
 #pragma unroll
                     for (int j = 0; j < 6; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][i], fb, acc[j], 0, 0, 0);
                     if constexpr (WLO) {
@@ -586,6 +643,7 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
                     const unsigned w = with_tag(pack2(h, hn), tag_bit((unsigned)(t + 1)) ? TAGM : 0u);
                     if (plain) __builtin_amdgcn_raw_buffer_store_b32(w, rs, pub_v, soff, 0);
                     else __builtin_amdgcn_raw_buffer_store_b32(w, rs, pub_v, soff, 16);
+                    for (int rep = 0; rep < a.xsweep; ++rep) __builtin_amdgcn_raw_buffer_store_b32(w, rs, pub_v, soff, 0);
                 } else {
                     const u32x2 w = {(unsigned)(t + 1), pack2(h, hn)};
                     if (plain) __builtin_amdgcn_raw_buffer_store_b64(w, rs, pub_v, soff, 0);
@@ -617,6 +675,7 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
             for (int g = 0; g < 3; ++g) gic[g] = gin_[g];
         }
     }
+    if (xsink == 0x9E3779B9u && a.xsweep > 1000) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (keeps the profiling loads alive)
     if constexpr (TIMED) {
         if (tid == 0 && chain == 0 && part == 0) {
             unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.status) + 8;     // byte 64 of the status header
@@ -1908,6 +1967,10 @@ int dispatch_fwd_w16(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
 int dispatch_fwd_lean(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
     // Hg = 640: the K-split step on the tag-free hand-off (library option gru_tf = 0 / 2: the tagged hand-off / the K-split-free kernel)
     const bool tf640 = a.Hg == 640 && !fwd_wlo(a.Hg) && !a.gi_bf16 && a.h0 == nullptr && cruse_opt("gru_tf", 1) != 0;
+    if (tf640 && cruse_opt("gru_fwd_rd", 1) != 0) {      // register-direct sweep (see the kernel)
+        if (a.dbg == 32) return launch_one(gru_fwd_lean_kernel<5, 5, true, false, true, false, true, true>, a, grid, lds, s, "gru_seq_fwd", 320);
+        return launch_one(gru_fwd_lean_kernel<5, 5, true, false, false, false, true, true>, a, grid, lds, s, "gru_seq_fwd", 320);
+    }
     if (a.dbg == 32 && tf640) return launch_one(gru_fwd_lean_kernel<5, 5, true, false, true, false, true>, a, grid, lds, s, "gru_seq_fwd", 320);
     if (tf640) return launch_one(gru_fwd_lean_kernel<5, 5, true, false, false, false, true>, a, grid, lds, s, "gru_seq_fwd", 320);
     if (a.dbg == 32 && a.Hg == 640 && !fwd_wlo(a.Hg) && !a.gi_bf16)
@@ -1985,6 +2048,7 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* pane
     unsigned* tickets_base = (unsigned*)(xg_base + xg_bytes_total(a.B, G, Hg));        // [launch][8]
     a.Bg = pl.Bg; a.P = pl.P;
     a.dbg = cruse_opt("gru_dbg", 0);
+    a.xsweep = cruse_opt("gru_xsweep", 0);
     int rc = CRUSE_OK;
     CRUSE_REQUIRE(pl.nlaunch <= MAX_LAUNCH_TICKETS, CRUSE_E_SHAPE, "gru_seq: batch %d needs %d launches (max %d)", a.B, pl.nlaunch,
                   MAX_LAUNCH_TICKETS);
@@ -2006,7 +2070,7 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* pane
             rc = dispatch_fwd_w16(a, grid, lds, s);
         } else if (FWD && fwd_lean_eligible(pl.Bg, Hg, prec)) {
             if (fwd_tf_eligible(pl.Bg, Hg, prec, a.h0 != nullptr, a.gi_bf16 != 0)) { a.poll_delay = cruse_opt("gru_poll_fwd", 8); rc = dispatch_fwd_tf(a, grid, fwd_wlo(Hg), s); }
-            else rc = dispatch_fwd_lean(a, grid, lds, s);
+            else { a.poll_delay = cruse_opt("gru_poll_fwd", 0); rc = dispatch_fwd_lean(a, grid, lds, s); }
         } else if (FWD) {
             if (prec == CRUSE_PREC_F32) rc = dispatch_fwd<CRUSE_PREC_F32>(a, grid, lds, s);
             else if (prec == CRUSE_PREC_BF16X3) rc = dispatch_fwd<CRUSE_PREC_BF16X3>(a, grid, lds, s);
@@ -2015,7 +2079,7 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* pane
             rc = dispatch_bwd_w16(a, grid, s);
         } else if (rs_form) {
             // (the tag-free kernel's panels are half the size of the reduce-scatter kernel's: the same regions hold them)
-            if (bwd_tf_eligible(pl.Bg, Hg, prec)) { a.poll_delay = cruse_opt("gru_poll_bwd", 10); a.poll_stagger = cruse_opt("gru_stag_bwd", 0); rc = dispatch_bwd_tf(a, grid, s); }
+            if (bwd_tf_eligible(pl.Bg, Hg, prec)) { a.poll_delay = cruse_opt("gru_poll_bwd", (Hg == 640 && cruse_opt("gru_bwd_ag", 2) != 0) ? 5 : 10); a.poll_stagger = cruse_opt("gru_stag_bwd", 0); rc = dispatch_bwd_tf(a, grid, s); }
             else rc = dispatch_bwd_rs(a, grid, s);
         } else {
             if (prec == CRUSE_PREC_F32) rc = dispatch_bwd<CRUSE_PREC_F32>(a, grid, lds, s);

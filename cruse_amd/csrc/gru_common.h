@@ -42,6 +42,7 @@ struct GruArgs {
     int xcd_rot;                      // chain c of a launch runs on PHYSICAL XCD (c + xcd_rot) % 8 (concurrent launches: disjoint XCDs)
     unsigned* tickets;                // [8] per-XCD workgroup counters of this launch (zeroed with the panels)
     int poll_delay;                   // tag-free kernels: s_sleep(1) periods between a step's publish and its first poll
+    int xsweep;                       // profiling: extra sweep / publish repetitions per step of the forward lean kernel (gru_xsweep)
     int poll_stagger;                 // backward tag-free kernel: > 0 = two polls in flight, this many s_sleep(1) periods apart
     int dbg;                          // profiling only (CRUSE_GRU_DBG): 1 = do not wait for tags, 2 = also skip MFMA
     // sub-sequences (cruse_gru_seq_*_ex): T steps of tensors whose clips are TS frames apart (TS >= T; the pointers are

@@ -681,6 +681,390 @@ __global__ __launch_bounds__(320) void gru_bwd_tf_kernel(GruArgs a) {
     __syncthreads();                                       // hands the last iteration's dh to the loader wave
 }
 
+
+// ---------------------------------------------------------------------------------
+// backward, ALL-GATHER form on the tag-free hand-off (round 4).  dh_{s-1} = dout_{s-1} + z_s . dh_s + (dh_s . c_s) W_hh:
+// a workgroup owns 32 OUTPUT units and contracts over the whole K = 3 Hg itself -- the forward lean kernel's step with the
+// product panel p_s = (dh_s . c_r, dh_s . c_z, dh_s . c_n) as its B operand and W_hh^T as the resident A operand:
+//   * publish: the 3 x 32 products of the own units per clip, bf16 with the epoch bit in bit 14, scaled by 2^-64 (exact; the
+//     reduced sum is multiplied by 2^64): 1.5 KB per workgroup and step instead of the reduce-scatter form's 10 KB;
+//   * sweep: the whole panel [clip][gate][Hg] (30 KB at Hg = 640, 8 x 16-byte loads per thread) straight into the LDS image --
+//     measured on the forward kernel (gru_xsweep: 30 KB swept + 3 publishes per step): sweep 590 -> 890 cycles, against the
+//     1520 cycles the reduce-scatter kernel waits for its 20 producers' partial sums;
+//   * 3 Hg / 32 k-steps split over the four waves (15 each at Hg = 640), two 16-unit tiles: 30 MFMAs per wave and step as
+//     before, the K reduction through LDS is two tiles per wave instead of the forward's six;
+//   * the partial sums are never rounded: f32 accumulation over the whole K (the reduce-scatter form exchanged 20 bf16 partials).
+// The loader wave (operand ring, dh / gate-gradient rows to HBM) is that of gru_bwd_tf_kernel with the forward helper's two
+// barriers per step.
+// ---------------------------------------------------------------------------------
+// DGI: 0 = dh only; 3 / 4 = the gate-gradient rows too (a.dg_slabs slabs) -- compile-time, so that the loader wave's loop is
+// straight-line code and the compiler's in-order vmcnt counts are EXACT (see the loader)
+// RD: no LDS image -- a wave sweeps exactly the chunks that ARE its MFMA B fragments (k-steps wv + 4 i of every clip: NKW 16-byte loads per
+// lane, one base address + immediate offsets) straight into registers and checks its own tags; the tag bits are cleared beside the MFMAs.
+template <int P, bool TIMED = false, int DGI = 0, bool RD = false>
+__global__ __launch_bounds__(320) void gru_bwd_ag_kernel(GruArgs a) {
+    constexpr int Hg = P * 32, K3 = 3 * Hg, NKS = K3 / 32, NKW = (NKS + 3) / 4, LD = K3 + 8;
+    constexpr int NCH = K3 / 8, NS = (8 * NCH + 255) / 256;         // 16-byte chunks per clip row; sweep slots per thread
+    constexpr float SC = 5.421010862427522e-20f, ISC = 1.8446744073709552e19f;     // 2^-64, 2^64
+    unsigned long long tph[5] = {0, 0, 0, 0, 0}, tq0 = 0, tq1 = 0;
+    (void)tph; (void)tq0; (void)tq1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* const pB = reinterpret_cast<__bf16*>(smem_raw);                             // [8 clips][LD]: B operand (p_s)
+    float* const red = reinterpret_cast<float*>(pB + 8 * LD);                           // [4 waves][2 tiles][RED_TS]
+    constexpr int RS = 36;
+    __shared__ __attribute__((aligned(16))) float op_d[4][8][RS], op_z[4][8][RS];       // ring slot = iteration & 3
+    __shared__ __attribute__((aligned(16))) __bf16 op_c[4][8][96];
+    __shared__ __attribute__((aligned(16))) float op_a[4][8][RS];                       // a_n rows (only when dgi is written)
+    __shared__ __attribute__((aligned(16))) float dh_l[2][8][RS];                       // dh of iteration k in parity k & 1
+    const int H = a.G * Hg;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int chain, part;
+    if (!claim_chain(a, P, chain, part)) return;
+    const int grp = chain % a.G, bgi = a.bg_off + chain / a.G;
+    const int b0 = bgi * 8, nb = min(8, a.B - b0);
+    const int u0 = part * U;
+    const float* W = a.p.w_hh[grp];
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.xg, 0, a.xg_bytes, 0x00020000);
+    constexpr unsigned panel_bytes = (unsigned)(8 * K3) * 2u;          // [clip][gate][Hg] bf16, the tag inside
+    const unsigned cbase = (unsigned)chain * 2u * panel_bytes;
+
+    for (int i = tid; i < 8 * LD / 8; i += 320) reinterpret_cast<u32x4*>(pB)[i] = (u32x4){0u, 0u, 0u, 0u};
+
+    const unsigned frame_bytes = (unsigned)H * 4u, crow_bytes = (unsigned)(a.G * K3) * 2u;
+    const long long nrow = (long long)(a.B - 1) * a.TS + a.T;           // rows reachable from the (advanced) base pointers
+    const unsigned tot_f32 = (unsigned)min(nrow * H * 4, 0xffffffffll);
+    const unsigned tot_cf = (unsigned)min(nrow * a.G * K3 * 2, 0xffffffffll);
+    const __amdgpu_buffer_rsrc_t rs_dout = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dout), 0, tot_f32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.zs), 0, tot_f32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dh = __builtin_amdgcn_make_buffer_rsrc(a.dh, 0, tot_f32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_cf = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.coefs), 0, tot_cf, 0x00020000);
+
+    if (wv == 4) {
+        // ---- loader wave.  Iteration j needs dout_{T-1-j}, c_{T-1-j} and z_{T-j}; lane = (clip, 16-byte chunk).
+        // BRANCH-FREE: every iteration issues exactly NLD loads and NST stores -- rows beyond the sequence are clamped (never used),
+        // lanes without a clip / chunk address beyond the buffer (raw-buffer loads return 0 there, stores are dropped) -- so the
+        // compiler counts the in-order vmcnt queue exactly and waits only for the set it is about to use (issued two iterations
+        // earlier).  With data-dependent branches around the loads / stores it assumed none of the younger ones had been issued and
+        // waited for ALL of them, the stores of the running iteration included: 0.4 us per step (gru_dbg = 7: 1.36 against 1.76).
+        const int lc = lane >> 3, lq = lane & 7;                                   // dout / z: 8 clips x 8 chunks of 4 floats
+        constexpr unsigned OOB = 0xfffffff0u;
+        const unsigned dv = lc < nb ? (unsigned)(((long long)(b0 + lc) * a.TS * H + grp * Hg + u0 + 4 * lq) * 4) : OOB;
+        unsigned cv[2], cdst[2];
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {                                           // coef: 8 clips x 3 gates x 4 chunks of 8 bf16
+            const int idx = lane + 64 * i2;
+            const int cl = min(idx, 95) / 12, rem = min(idx, 95) % 12, gate = rem >> 2, chk = rem & 3;
+            cv[i2] = (idx < 96 && cl < nb) ? (unsigned)((((long long)(b0 + cl) * a.TS * a.G + grp) * K3 + gate * Hg + u0 + 8 * chk) * 2) : OOB;
+            cdst[i2] = (unsigned)(cl * 96 + gate * 32 + chk * 8);
+        }
+        const bool c1ok = lane < 32;                                               // (slots 64..95 of the coefficient set)
+        const __amdgpu_buffer_rsrc_t rs_an = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ans), 0, a.ans ? tot_f32 : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_dgi = __builtin_amdgcn_make_buffer_rsrc(a.dgi, 0, a.dgi ? (DGI == 4 ? (unsigned)min(nrow * a.G * 4 * Hg * 2, 0xffffffffll) : tot_cf) : 0u, 0x00020000);
+        struct OpSet { u32x4 d, z, c0, c1, an; };
+        auto issue = [&](int j, OpSet& o) {                                        // j >= 1
+            const unsigned st = (unsigned)max(a.T - 1 - j, 0);
+            o.d = __builtin_amdgcn_raw_buffer_load_b128(rs_dout, dv, st * frame_bytes, 0);
+            o.z = __builtin_amdgcn_raw_buffer_load_b128(rs_z, dv, min(st + 1u, (unsigned)(a.T - 1)) * frame_bytes, 0);
+            o.c0 = __builtin_amdgcn_raw_buffer_load_b128(rs_cf, cv[0], st * crow_bytes, 0);
+            o.c1 = __builtin_amdgcn_raw_buffer_load_b128(rs_cf, cv[1], st * crow_bytes, 0);
+            if constexpr (DGI != 0) o.an = __builtin_amdgcn_raw_buffer_load_b128(rs_an, dv, st * frame_bytes, 0);
+        };
+        auto put = [&](int j, const OpSet& o) {
+            const int slot = j & 3;
+            *reinterpret_cast<u32x4*>(&op_d[slot][lc][4 * lq]) = o.d;
+            *reinterpret_cast<u32x4*>(&op_z[slot][lc][4 * lq]) = o.z;
+            *reinterpret_cast<u32x4*>(&op_c[slot][0][0] + cdst[0]) = o.c0;
+            if (c1ok) *reinterpret_cast<u32x4*>(&op_c[slot][0][0] + cdst[1]) = o.c1;
+            if constexpr (DGI != 0) *reinterpret_cast<u32x4*>(&op_a[slot][lc][4 * lq]) = o.an;
+        };
+        constexpr int NSL = DGI == 4 ? 4 : 3;
+        const unsigned dgrow_bytes = (unsigned)(a.G * NSL * Hg) * 2u;
+        const unsigned gi_v = lc < nb ? (unsigned)((((long long)(b0 + lc) * a.TS * a.G + grp) * NSL * Hg + u0 + 4 * lq) * 2) : OOB - 8u * (unsigned)Hg;
+        auto flush = [&](int j) {
+            const unsigned st = (unsigned)(a.T - 1 - j);
+            const float4 d4 = *reinterpret_cast<const float4*>(&dh_l[j & 1][lc][4 * lq]);
+            const u32x4 dw = {__float_as_uint(d4.x), __float_as_uint(d4.y), __float_as_uint(d4.z), __float_as_uint(d4.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(dw, rs_dh, dv, st * frame_bytes, 0);
+            if constexpr (DGI != 0) {
+                const int slot = j & 3;
+                typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
+                const bf16x4_ cr = *reinterpret_cast<const bf16x4_*>(&op_c[slot][lc][4 * lq]);
+                const bf16x4_ cz = *reinterpret_cast<const bf16x4_*>(&op_c[slot][lc][32 + 4 * lq]);
+                const float4 a4 = *reinterpret_cast<const float4*>(&op_a[slot][lc][4 * lq]);
+                const float d[4] = {d4.x, d4.y, d4.z, d4.w}, an_[4] = {a4.x, a4.y, a4.z, a4.w};
+                bf16x4_ o0, o1, o2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o0[e] = (__bf16)(d[e] * (float)cr[e]); o1[e] = (__bf16)(d[e] * (float)cz[e]); o2[e] = (__bf16)(d[e] * an_[e]);
+                }
+                __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o0), rs_dgi, gi_v, st * dgrow_bytes, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o1), rs_dgi, gi_v + (unsigned)Hg * 2u, st * dgrow_bytes, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o2), rs_dgi, gi_v + (unsigned)Hg * 4u, st * dgrow_bytes, 0);
+                if constexpr (DGI == 4) {
+                    const bf16x4_ cn = *reinterpret_cast<const bf16x4_*>(&op_c[slot][lc][64 + 4 * lq]);
+                    bf16x4_ o3;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o3[e] = (__bf16)(d[e] * (float)cn[e]);
+                    __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o3), rs_dgi, gi_v + (unsigned)Hg * 6u, st * dgrow_bytes, 0);
+                }
+            }
+        };
+        OpSet s0, s1;
+        {                                                                          // iteration 0: dh of the last frame may be carried in; no z
+            const unsigned st = (unsigned)(a.T - 1);
+            const u32x4 zero = {0u, 0u, 0u, 0u};
+            s0.d = a.carry ? __builtin_amdgcn_raw_buffer_load_b128(rs_dh, dv, st * frame_bytes, 0)
+                           : __builtin_amdgcn_raw_buffer_load_b128(rs_dout, dv, st * frame_bytes, 0);
+            s0.z = zero;
+            s0.c0 = __builtin_amdgcn_raw_buffer_load_b128(rs_cf, cv[0], st * crow_bytes, 0);
+            s0.c1 = __builtin_amdgcn_raw_buffer_load_b128(rs_cf, cv[1], st * crow_bytes, 0);
+            s0.an = zero;
+            if constexpr (DGI != 0) s0.an = __builtin_amdgcn_raw_buffer_load_b128(rs_an, dv, st * frame_bytes, 0);
+        }
+        issue(1, s1);
+        put(0, s0); put(1, s1);
+        issue(2, s0); issue(3, s1);
+        if (a.dbg != 9) (void)team_shares_xcd(a.xid + (size_t)chain * 64, P, part, a.status, tid);    // mirrors the compute waves' barriers
+        __syncthreads();
+        // iteration k > 0 has two barriers (image complete; partial sums complete).  ALL loader work sits between them, right after
+        // the sweep has returned: its loads then have the whole MFMA + pointwise + publish time to come back before the next sweep
+        // is issued (loads of the loader in flight DURING a sweep delay it -- the CU's vector-memory return path is shared: with
+        // the ring work after the second barrier a step took 1.78 us instead of 1.36 without streams), and the only wait is for
+        // the set issued two iterations earlier (exact counts: the loop is branch-free).
+        put(2, s0); issue(4, s0);
+        for (int k = 1; k < a.T; k += 2) {
+            __syncthreads(); put(k + 2, s1); issue(k + 4, s1); flush(k - 1); __syncthreads();
+            if (k + 1 >= a.T) break;
+            __syncthreads(); put(k + 3, s0); issue(k + 5, s0); flush(k); __syncthreads();
+        }
+        __syncthreads();                                // the last iteration's dh is in LDS
+        flush(a.T - 1);
+        return;
+    }
+
+    // resident A fragments: tile j (units u0 + 16 j .. + 15), this wave's k-steps ks = wv + 4 i; k = gate * Hg + unit
+    bf16x8 wf[2][NKW];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = u0 + j * 16 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < NKW; ++i) {
+            const int ks = wv + 4 * i;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int kk = ks * 32 + (lane >> 4) * 8 + e;
+                wf[j][i][e] = ks < NKS ? (__bf16)W[(long long)kk * Hg + n] : (__bf16)0.f;
+            }
+        }
+    }
+
+    // sweep slots: 16-byte chunk e = tid + 256 j of the panel = clip e / NCH, elements 8 (e % NCH) .. + 7 of its row (clamped for
+    // short chains and beyond the panel: the last valid chunk is then fetched and stored twice)
+    const int nload = nb * NCH;
+    unsigned sw_v[NS];
+    int sw_l[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int e = min(tid + 256 * j, nload - 1);
+        const int bl_ = e / NCH, v = 8 * (e - bl_ * NCH);
+        sw_v[j] = (unsigned)e * 16u;
+        sw_l[j] = bl_ * LD + v;
+    }
+
+    // pointwise: thread = (clip bl, unit u)
+    const int u = tid & 31, bl = tid >> 5;
+    const bool act = bl < nb;
+    const int blc = act ? bl : 0;
+    const int half = u >> 4, ru = u & 15;
+    const int lp = (ru >> 2) * 16 + bl;
+    const unsigned pub_v = RD ? (unsigned)(((((u0 + u) >> 3) * 8 + blc) * 8 + (u & 7)) * 2)           // + gate * (Hg / 8) * 128
+                              : (unsigned)((blc * 3) * Hg + u0 + u) * 2u;                            // + gate * Hg * 2
+    constexpr unsigned pub_gs = RD ? (unsigned)(Hg / 8) * 128u : (unsigned)Hg * 2u;
+    const bool pub_lane = act && !(u & 1);
+    const int fb_off = (lane & 7) * LD + (lane >> 4) * 8;                 // (columns 8..15 re-read clips 0..7)
+    static_assert(!RD || NKS % 4 == 0, "register-direct sweep: every wave has all its k-steps");
+    // RD panel layout: CLIP-MINOR -- [k chunk of 8 elements][clip][8] -- so that the 8 clips of one (k-step, lane group) are one 128-byte
+    // line and a wave's load instruction is 512 contiguous bytes (clip-major rows made every 16-lane pass touch 8 lines: 4500-cycle sweeps)
+    const unsigned rd_v = (unsigned)(((wv * 4 + (lane >> 4)) * 8 + (lane & 7)) * 16);         // + i * 2048 bytes: k-step wv + 4 i
+    // (columns 8..15: the odd k-step of the pair, + 2048; in the last, half-empty pair they re-read the even one)
+    const unsigned rd_v2 = rd_v + (((lane >> 3) & 1) ? 2048u : 0u), rd_v2l = rd_v;
+    const bool rd_ok = (lane & 7) < nb;                                  // (columns 8..15 re-read clips 0..7; masking them off made every load a branch: slower)
+
+    float dh = 0.f, dd = 0.f, zz = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;    // operands of the current step (time s)
+    bool nowait = a.dbg >= 1 && a.dbg < 7;
+    const bool plain = a.dbg != 9 && team_shares_xcd(a.xid + (size_t)chain * 64, P, part, a.status, tid);
+    __syncthreads();                                                      // ring slots 0 and 1 are filled (and the image is zeroed)
+    dd = op_d[0][blc][u];
+    c0 = (float)op_c[0][blc][u]; c1 = (float)op_c[0][blc][32 + u]; c2 = (float)op_c[0][blc][64 + u];
+
+    for (int k = 0; k < a.T; ++k) {
+        const int s = a.T - 1 - k;
+        float m = 0.f;
+        if constexpr (TIMED) tq0 = __builtin_amdgcn_s_memtime();
+        if (k > 0 && RD) {
+            // NL = ceil(NKW / 2) loads per lane: columns 0..7 of the MFMA (lanes with (lane & 15) < 8) fetch the fragment of k-step 2 j, the
+            // otherwise idle columns 8..15 that of k-step 2 j + 1 of the same clip; a DPP row rotate brings it over when its MFMAs are due.
+            // (With every lane loading its own column's fragment -- columns 8..15 duplicates -- the 60 load instructions of a workgroup
+            //  kept the CU's address unit busy for ~1000 cycles: sweep 1700 cycles.)
+            constexpr int NL = (NKW + 1) / 2;
+            const unsigned soff = cbase + (unsigned)((k - 1) & 1) * panel_bytes;
+            const bool expect1 = tag_bit((unsigned)k) != 0u;
+            u32x4 g[NL];
+            unsigned spins = 0;
+            for (int i = 0; i < a.poll_delay; ++i) __builtin_amdgcn_s_sleep(1);     // (see poll_delay)
+            for (;;) {
+#pragma unroll
+                for (int j = 0; j < NL; ++j)
+                    g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (2 * j + 1 < NKW || j + 1 < NL) ? rd_v2 : rd_v2l, soff + (unsigned)(j * 4096), 16);
+                unsigned bad;
+                if (expect1) {                                 // every tag bit set <=> the AND of all dwords has both
+                    unsigned n = 0xffffffffu;
+#pragma unroll
+                    for (int j = 0; j < NL; ++j) n = n & (g[j].x & g[j].y) & (g[j].z & g[j].w);
+                    bad = ~n;
+                } else {
+                    unsigned o = 0u;
+#pragma unroll
+                    for (int j = 0; j < NL; ++j) o = o | (g[j].x | g[j].y) | (g[j].z | g[j].w);
+                    bad = o;
+                }
+                if (__all((bad & TAGM) == 0u || !rd_ok || nowait)) break;
+                if (++spins >= SPIN_LIMIT) {
+                    if (lane == 0) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    nowait = true;
+                }
+                if constexpr (TIMED) tph[4] += 1;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[0] += tq1 - tq0; tq0 = tq1; }
+            __syncthreads();                                   // (the loader wave's hand-over point: every wave's sweep has returned)
+            if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[1] += tq1 - tq0; tq0 = tq1; }
+            f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+#pragma unroll
+            for (int i = 0; i < NKW; ++i) {
+                const u32x4 gg = g[i >> 1];
+                u32x4 w = {gg.x & ~TAGM, gg.y & ~TAGM, gg.z & ~TAGM, gg.w & ~TAGM};
+                if (i & 1) { w.x = dpp_ror8(w.x); w.y = dpp_ror8(w.y); w.z = dpp_ror8(w.z); w.w = dpp_ror8(w.w); }     // columns 8..15 -> 0..7
+                const bf16x8 fb = __builtin_bit_cast(bf16x8, w);
+                if (i & 1) {
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][i], fb, acc2, 0, 0, 0);
+                    acc3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][i], fb, acc3, 0, 0, 0);
+                } else {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][i], fb, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][i], fb, acc1, 0, 0, 0);
+                }
+            }
+            acc0 += acc2; acc1 += acc3;
+            *reinterpret_cast<f32x4*>(red + (wv * 2 + 0) * RED_TS + red_vec(lane)) = acc0;
+            *reinterpret_cast<f32x4*>(red + (wv * 2 + 1) * RED_TS + red_vec(lane)) = acc1;
+            __syncthreads();
+            if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[2] += tq1 - tq0; tq0 = tq1; }
+#pragma unroll
+            for (int w = 0; w < 4; ++w) m += red[(w * 2 + half) * RED_TS + red_vec(lp) + (ru & 3)];
+            m *= ISC;
+        }
+        if (k > 0 && !RD) {
+            const unsigned soff = cbase + (unsigned)((k - 1) & 1) * panel_bytes;
+            const unsigned flip = tag_bit((unsigned)k) ? 0xffffffffu : 0u;
+            u32x4 g[NS];
+            unsigned spins = 0;
+            for (int i = 0; i < a.poll_delay; ++i) __builtin_amdgcn_s_sleep(1);     // (see poll_delay)
+            for (;;) {
+#pragma unroll
+                for (int j = 0; j < NS; ++j) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, sw_v[j], soff, 16);
+                unsigned bad = 0u;
+#pragma unroll
+                for (int j = 0; j < NS; ++j) bad |= (g[j].x ^ flip) | (g[j].y ^ flip) | (g[j].z ^ flip) | (g[j].w ^ flip);
+                if (__all((bad & TAGM) == 0u || nowait)) break;
+                if (++spins >= SPIN_LIMIT) {
+                    if (lane == 0) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    nowait = true;
+                }
+                if constexpr (TIMED) tph[4] += 1;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[0] += tq1 - tq0; tq0 = tq1; }
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                const u32x4 w = {g[j].x & ~TAGM, g[j].y & ~TAGM, g[j].z & ~TAGM, g[j].w & ~TAGM};
+                *reinterpret_cast<u32x4*>(pB + sw_l[j]) = w;
+            }
+            __syncthreads();                                   // image complete
+            if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[1] += tq1 - tq0; tq0 = tq1; }
+            // four accumulator chains (two per tile): with two, every MFMA waited for the one issued just before its predecessor
+            // (1445 cycles for the 30 MFMAs against the forward kernel's 1040 with six chains, s_memtime stamps)
+            f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+            // fragment reads run PF k-steps ahead of their MFMAs, pinned by sched_barrier (left alone the scheduler keeps two fragment
+            // registers and exposes an LDS round trip every second k-step -- as in gru_fwd_tf_kernel)
+            constexpr int PF = NKW < 6 ? NKW : 6;
+            bf16x8 fr[NKW];
+#pragma unroll
+            for (int i = 0; i < PF; ++i) fr[i] = *reinterpret_cast<const bf16x8*>(pB + fb_off + min(wv + 4 * i, NKS - 1) * 32);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NKW; ++i) {
+                if (NKS % 4 == 0 || wv + 4 * i < NKS) {        // wave-uniform (weights beyond NKS are zero anyway)
+                    if (i & 1) {
+                        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][i], fr[i], acc2, 0, 0, 0);
+                        acc3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][i], fr[i], acc3, 0, 0, 0);
+                    } else {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][i], fr[i], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][i], fr[i], acc1, 0, 0, 0);
+                    }
+                }
+                if (i + PF < NKW) fr[i + PF] = *reinterpret_cast<const bf16x8*>(pB + fb_off + min(wv + 4 * (i + PF), NKS - 1) * 32);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            acc0 += acc2; acc1 += acc3;
+            *reinterpret_cast<f32x4*>(red + (wv * 2 + 0) * RED_TS + red_vec(lane)) = acc0;
+            *reinterpret_cast<f32x4*>(red + (wv * 2 + 1) * RED_TS + red_vec(lane)) = acc1;
+            __syncthreads();
+            if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[2] += tq1 - tq0; tq0 = tq1; }
+#pragma unroll
+            for (int w = 0; w < 4; ++w) m += red[(w * 2 + half) * RED_TS + red_vec(lp) + (ru & 3)];
+            m *= ISC;
+        }
+        dh = dd + zz * dh + m;
+        if (act) dh_l[k & 1][bl][u] = dh;                      // the loader wave writes it (and the gate gradients) to HBM
+        if (s == 0) break;                                     // nothing consumes the products of time 0
+        {
+            const float ds = dh * SC;
+            const unsigned tagm = tag_bit((unsigned)(k + 1)) ? TAGM : 0u;
+            const unsigned soff = cbase + (unsigned)(k & 1) * panel_bytes;
+            const float p0 = ds * c0, p1 = ds * c1, p2 = ds * c2;
+            const float q0 = __uint_as_float(dpp_xor1(__float_as_uint(p0)));
+            const float q1 = __uint_as_float(dpp_xor1(__float_as_uint(p1)));
+            const float q2 = __uint_as_float(dpp_xor1(__float_as_uint(p2)));
+            if (pub_lane) {
+                const unsigned w0 = with_tag(pack2(p0, q0), tagm), w1 = with_tag(pack2(p1, q1), tagm), w2 = with_tag(pack2(p2, q2), tagm);
+                if (plain) {
+                    __builtin_amdgcn_raw_buffer_store_b32(w0, rs, pub_v, soff, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(w1, rs, pub_v + pub_gs, soff, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(w2, rs, pub_v + 2u * pub_gs, soff, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b32(w0, rs, pub_v, soff, 16);
+                    __builtin_amdgcn_raw_buffer_store_b32(w1, rs, pub_v + pub_gs, soff, 16);
+                    __builtin_amdgcn_raw_buffer_store_b32(w2, rs, pub_v + 2u * pub_gs, soff, 16);
+                }
+            }
+        }
+        if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[3] += tq1 - tq0; tq0 = tq1; }
+        {                                                      // operands of step k+1 from the loader wave's ring (slot = iteration & 3)
+            const int slot = (k + 1) & 3;
+            dd = op_d[slot][blc][u];
+            zz = op_z[slot][blc][u];
+            c0 = (float)op_c[slot][blc][u]; c1 = (float)op_c[slot][blc][32 + u]; c2 = (float)op_c[slot][blc][64 + u];
+        }
+    }
+    if constexpr (TIMED) {
+        if (tid == 0 && chain == 0 && part == 0) {
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.status) + 16;    // byte 128 of the status header
+            for (int i = 0; i < 5; ++i) dst[i] = tph[i];
+            dst[5] = (unsigned long long)a.T;
+        }
+    }
+    __syncthreads();                                           // hands the last iteration's dh to the loader wave
+}
 }  // namespace
 
 namespace cruse_gru {
@@ -711,7 +1095,22 @@ bool bwd_tf_eligible(int Bg, int Hg, int prec) {
 }
 size_t tf_bwd_bytes_per_parity(int Hg) { const size_t P = Hg / 32; return P * 8 * P * 64; }
 
+size_t bwd_ag_lds(int Hg) { return (size_t)8 * (3 * Hg + 8) * 2 + (size_t)4 * 2 * RED_TS * 4; }
+
 int dispatch_bwd_tf(const GruArgs& a, int grid, hipStream_t s) {
+    // all-gather form (option gru_bwd_ag, default on at Hg = 640): see gru_bwd_ag_kernel
+    if (a.Hg == 640 && cruse_opt("gru_bwd_ag", 2) != 0) {
+        if (cruse_opt("gru_bwd_ag", 2) == 2) {          // register-direct sweep (no LDS image)
+            if (a.dbg == 32) return launch_one(gru_bwd_ag_kernel<20, true, 0, true>, a, grid, bwd_ag_lds(640), s, "gru_seq_bwd", 320);
+            if (a.dgi == nullptr) return launch_one(gru_bwd_ag_kernel<20, false, 0, true>, a, grid, bwd_ag_lds(640), s, "gru_seq_bwd", 320);
+            if (a.dg_slabs == 4) return launch_one(gru_bwd_ag_kernel<20, false, 4, true>, a, grid, bwd_ag_lds(640), s, "gru_seq_bwd", 320);
+            return launch_one(gru_bwd_ag_kernel<20, false, 3, true>, a, grid, bwd_ag_lds(640), s, "gru_seq_bwd", 320);
+        }
+        if (a.dbg == 32) return launch_one(gru_bwd_ag_kernel<20, true, 0>, a, grid, bwd_ag_lds(640), s, "gru_seq_bwd", 320);
+        if (a.dgi == nullptr) return launch_one(gru_bwd_ag_kernel<20, false, 0>, a, grid, bwd_ag_lds(640), s, "gru_seq_bwd", 320);
+        if (a.dg_slabs == 4) return launch_one(gru_bwd_ag_kernel<20, false, 4>, a, grid, bwd_ag_lds(640), s, "gru_seq_bwd", 320);
+        return launch_one(gru_bwd_ag_kernel<20, false, 3>, a, grid, bwd_ag_lds(640), s, "gru_seq_bwd", 320);
+    }
     if (a.dbg == 32 && a.Hg == 640) return a.poll_stagger > 0 ? launch_one(gru_bwd_tf_kernel<20, true, true>, a, grid, 0, s, "gru_seq_bwd", 320)
                                                                : launch_one(gru_bwd_tf_kernel<20, true>, a, grid, 0, s, "gru_seq_bwd", 320);
     if (a.poll_stagger > 0) {

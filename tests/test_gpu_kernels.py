@@ -931,6 +931,54 @@ def test_gru_bwd_writes_gate_gradients_itself(ops, H, G, B, T):
         assert rel_l2(a_, b_) < 1e-5
 
 
+@pytest.mark.parametrize("B,T", [(9, 12), (3, 1), (5, 2), (8, 3), (20, 37), (64, 60)])
+def test_gru_register_direct_sweeps_and_all_gather_backward(ops, B, T):
+    """Round-4 recurrence kernels at Hg = 640 (bf16 mode).  Forward: the register-direct sweep (gru_fwd_rd, default) gives the bits
+    of the LDS-image form.  Backward: the all-gather kernel in its register-direct (gru_bwd_ag = 2, default) and LDS-image (1) forms
+    give the same bits; both and the reduce-scatter kernel (0) agree with the f64 recurrence on the saved coefficients; the gate
+    gradients written by the loader wave are those of the separate pass on the same dh."""
+    H = 640
+    torch.manual_seed(B * 100 + T)
+    gi = (0.5 * torch.randn(B, T, 3 * H)).cuda()
+    w = [(torch.randn(3 * H, H) / H ** 0.5).cuda()]; b = [(0.1 * torch.randn(3 * H)).cuda()]
+    with ops.options(gru_fwd_rd=0):
+        f0 = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16")
+    f1 = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16")
+    torch.cuda.synchronize()
+    assert ops.gru_status() == 0
+    for x, y in zip(f0, f1):
+        assert torch.equal(x, y)
+    h, coef, an, z = f1
+    dout = (3.0 * torch.randn(B, T, H)).cuda()
+    out = {}
+    for ag in (0, 1, 2):
+        with ops.options(gru_bwd_ag=ag):
+            out[ag] = ops.gru_seq_bwd(dout, w, coef, z, B, T, 1, H, "bf16", an=an, want_dgi=True)
+            plain = ops.gru_seq_bwd(dout, w, coef, z, B, T, 1, H, "bf16")
+            torch.cuda.synchronize()
+            assert ops.gru_status() == 0 and torch.equal(plain, out[ag][0])
+    assert torch.equal(out[1][0], out[2][0]) and torch.equal(out[1][1], out[2][1])
+    c = coef.float().view(B, T, 3, H)
+    wd = w[0].double()
+    ref = torch.zeros(B, T, H, dtype=torch.float64, device="cuda")
+    nxt = torch.zeros(B, H, dtype=torch.float64, device="cuda")
+    for s_ in range(T - 1, -1, -1):
+        cur = dout[:, s_].double()
+        if s_ < T - 1:
+            dgh = (nxt.unsqueeze(1) * c[:, s_ + 1].double()).reshape(B, 3 * H)
+            cur = cur + z[:, s_ + 1].double() * nxt + dgh @ wd
+        ref[:, s_] = cur
+        nxt = cur
+    for ag in (0, 2):
+        assert torch.isfinite(out[ag][0]).all() and rel_l2(out[ag][0], ref) < 1e-2, (ag, rel_l2(out[ag][0], ref))
+    # (the all-gather form accumulates the whole K in f32; the reduce-scatter form exchanges bf16 partial sums)
+    assert rel_l2(out[2][0], ref) <= 1.05 * rel_l2(out[0][0], ref) + 1e-6
+    rows = B * T
+    db_i = [torch.zeros(3 * H).cuda()]; db_h = [torch.zeros(3 * H).cuda()]
+    dgi_ref, _, _ = ops.gru_gate_grads_bf16(out[2][0], coef, an, rows, 1, H, db_i, db_h)
+    assert torch.equal(out[2][1].view(-1), dgi_ref.view(-1))
+
+
 @pytest.mark.parametrize("b_f32,shift", [(False, 0), (True, 0), (True, 7), (False, 7)])
 def test_gemm_bf16_tn_weight_gradient_form(b_f32, shift):
     """cruse_gemm_bf16_tn: C += A^T B over K rows with ROW-MAJOR operands (register-transposing LDS staging), against the
