@@ -758,7 +758,7 @@ def main():
         roof["ms_per_step_all_launches"] = round(per_step[dom], 3)
         # the same fraction from the committed rocprofv3 trace of the GRAPH run (the kernel beside its side-stream
         # co-runners), next to the isolated HIP-event figure above
-        kname = {"gru_seq_bwd": "gru_bwd_tf_kernel", "gru_seq_fwd": "gru_fwd_lean_kernel"}.get(dom)
+        kname = {"gru_seq_bwd": "gru_bwd_ag_kernel", "gru_seq_fwd": "gru_fwd_lean_kernel"}.get(dom)
         if kname and roof.get("avg_launch_ms") and (B, a.seconds, a.groups, a.prec) == (64, 4.0, 1, "bf16"):
             ns, src = profile_avg_ns(kname)
             if ns:

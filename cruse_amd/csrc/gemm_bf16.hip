@@ -53,10 +53,17 @@ __device__ __forceinline__ long long seg_row(const GbArgs& g, int m) {
 // overlap the other block's k-loop); 3 = two k-tiles in flight behind counted vmcnt waits and one raw barrier per
 // k-tile, one block per CU (the split-K weight gradients: hundreds of k-tiles streamed once, where the k-loop is
 // bound by the latency of the next tile's loads).
-template <int MODE, int NST>
-__global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_bf16_nt_kernel(const GbArgs g) {
+// BMT: 1 = 128 x 128 tiles on 4 wavefronts; 2 = 256 x 128 tiles on 8 wavefronts (4 x 2, the same 64 x 64 block per wave) with THREE
+// stages -- 96 KB of operands in flight per CU instead of 64, 48 KB instead of 64 KB per 256 x 128 x 64 of work.  MEASURED SLOWER and off
+// (library option gb_bm256): gi 96 -> 118 us, dX 85 -> 105 us alone (r4): one 8-wave block per CU loses more at its barriers than two
+// independent 4-wave blocks that fill each other's stalls.  Alone these two products run at 0.66 / 0.74 PFLOP/s; their 150-165 us in the
+// step are cold operands and the side stream's traffic, not this loop.
+template <int MODE, int NST, int BMT = 1>
+__global__ __launch_bounds__(256 * BMT, (NST == 2 && BMT == 1) ? 2 : 1) void gemm_bf16_nt_kernel(const GbArgs g) {
+    constexpr int BM_ = BM * BMT, A_BYTES = TILE_BYTES * BMT, STAGE_BYTES = A_BYTES + TILE_BYTES;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_dyn[];
-    unsigned char (*smem)[2][TILE_BYTES] = reinterpret_cast<unsigned char (*)[2][TILE_BYTES]>(smem_dyn);   // [stage][A|B]
+    auto As_ = [&](int buf) -> unsigned char* { return smem_dyn + (size_t)buf * STAGE_BYTES; };            // [stage][A | B]
+    auto Bs_ = [&](int buf) -> unsigned char* { return smem_dyn + (size_t)buf * STAGE_BYTES + A_BYTES; };
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv >> 1, wn = wv & 1;
     // XCD-aware tile order, as in gemm.hip: a unit -- the n-tiles of one m-tile, or with split-K the m-tiles of one
@@ -79,7 +86,7 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_bf16_nt_kernel(con
         if (g.splitk > 1) { tz = unit / g.tiles_n; tn = unit % g.tiles_n; tm = inner; }
         else { tz = 0; tm = unit; tn = inner; }
     }
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BM_, n0 = tn * BN;
     const int nkt = g.K / BK;
     const int kt0 = tz * g.kt_chunk, kt1 = min(nkt, kt0 + g.kt_chunk);
     // split-bf16 forms: the k-range is walked again on the same accumulators for every correction term -- (A_hi, B_lo)
@@ -87,14 +94,21 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_bf16_nt_kernel(con
     const int nreal = kt1 - kt0;
     const int nvirt = (g.b_lo ? (g.a_lo ? 3 : 2) : 1) * nreal;      // (hi,hi) [, (hi,lo) [, (lo,hi)]]
 
-    // staging: wave wv fills rows [wv*32, wv*32+32) of both tiles, 8 rows (1 KiB) per instruction
+    // staging: wave wv fills rows [wv*32, wv*32+32) of the A tile and its share of the B tile (32 rows of 128 on 4 waves, 16 on 8),
+    // 8 rows (1 KiB) per instruction
+    constexpr int NB_I = 4 / BMT;
     const __bf16* ap[4];
-    const __bf16* bp[4];
+    const __bf16* bp[NB_I];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (wv * 4 + i) * 8 + (lane >> 3);
         const int ch = (lane & 7) ^ (lane >> 3);
         ap[i] = g.A + seg_row(g, min(m0 + r, g.M - 1)) * g.lda + ch * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < NB_I; ++i) {
+        const int r = (wv * NB_I + i) * 8 + (lane >> 3);
+        const int ch = (lane & 7) ^ (lane >> 3);
         bp[i] = g.B + (long long)min(n0 + r, g.N - 1) * g.ldb + ch * 8;
     }
     auto stage = [&](int v, int buf) {               // v: virtual k-tile index in [0, nvirt)
@@ -103,10 +117,11 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_bf16_nt_kernel(con
         const long long oa = (long long)kt * g.a_ks + (seg == 2 ? g.a_lo : 0);
         const long long ob = (long long)kt * g.b_ks + (seg == 1 ? g.b_lo : 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(ap[i] + oa), (lds_ptr_t*)&smem[buf][0][(wv * 4 + i) * 1024], 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(bp[i] + ob), (lds_ptr_t*)&smem[buf][1][(wv * 4 + i) * 1024], 16, 0, 0);
-        }
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(ap[i] + oa), (lds_ptr_t*)(As_(buf) + (wv * 4 + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NB_I; ++i)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(bp[i] + ob), (lds_ptr_t*)(Bs_(buf) + (wv * NB_I + i) * 1024), 16, 0, 0);
     };
 
     f32x4 acc[4][4];
@@ -125,8 +140,8 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_bf16_nt_kernel(con
     }
 
     auto compute = [&](int buf) {
-        const unsigned char* As = smem[buf][0];
-        const unsigned char* Bs = smem[buf][1];
+        const unsigned char* As = As_(buf);
+        const unsigned char* Bs = Bs_(buf);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 fa[4], fb[4];
@@ -151,12 +166,12 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_bf16_nt_kernel(con
             compute(buf);
         }
     } else {
-        // each stage() is 8 LDS-DMA loads per wave, retired in order: vmcnt(8) == "all but the newest tile landed"
+        // each stage() is 8 (BMT 2: 6) LDS-DMA loads per wave, retired in order: vmcnt(8 / 6) == "all but the newest tile landed"
         if (nvirt > 0) stage(0, 0);
         if (nvirt > 1) stage(1, 1);
         int buf = 0;
         for (int v = 0; v < nvirt; ++v) {
-            if (v + 1 < nvirt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (v + 1 < nvirt) { if constexpr (BMT == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();      // tile v is in LDS for every wave; stage (v+2)%3 == (v-1)%3 is drained
             if (v + 2 < nvirt) stage(v + 2, buf == 0 ? 2 : buf - 1);
@@ -540,7 +555,9 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.a_ks = a_kstride; g.b_ks = b_kstride;
     g.accumulate = accumulate; g.splitk = splitk; g.kt_chunk = kt_chunk;
     g.seg_len = seg_len; g.seg_stride = seg_stride; g.seg_off = seg_off;
-    g.tiles_m = cdiv(M, BM); g.tiles_n = cdiv(N, BN);
+    // 256-row tiles (8 waves, three stages) for the un-split products with many row tiles: the gate projections and dX (option gb_bm256)
+    const bool big = splitk == 1 && !slabs && M >= 16 * BM && cruse_opt("gb_bm256", 0) != 0;
+    g.tiles_m = cdiv(M, big ? 2 * BM : BM); g.tiles_n = cdiv(N, BN);
     g.xcdk = (xcdk && splitk > 1) ? 1 : 0;
     g.slab = 0;
     const bool use_slabs = slabs != nullptr && splitk > 1;
@@ -565,7 +582,7 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
     { const int e = cruse_opt("gb_deep_min", 0); if (e > 0) deep_min = e; }      // profiling options
     bool deep = kt_chunk >= deep_min;
     { const int e = cruse_opt("gb_deep", -1); if (e >= 0) deep = e != 0; }
-    const size_t lds = (size_t)(deep ? 3 : 2) * 2 * TILE_BYTES;
+    const size_t lds = big ? (size_t)3 * 3 * TILE_BYTES : (size_t)(deep ? 3 : 2) * 2 * TILE_BYTES;
 #define CRUSE_GB_LAUNCH(MODE, NST)                                                                               \
     do {                                                                                                         \
         int rc0 = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_bf16_nt_kernel<MODE, NST>), lds,       \
@@ -573,6 +590,19 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
         if (rc0) return rc0;                                                                                     \
         hipLaunchKernelGGL((gemm_bf16_nt_kernel<MODE, NST>), grid, dim3(256), lds, st, g);                       \
     } while (0)
+    if (big) {
+#define CRUSE_GB_LAUNCH_BIG(MODE)                                                                                \
+    do {                                                                                                         \
+        int rc0 = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_bf16_nt_kernel<MODE, 3, 2>), lds,      \
+                                       "gemm_bf16_nt");                                                          \
+        if (rc0) return rc0;                                                                                     \
+        hipLaunchKernelGGL((gemm_bf16_nt_kernel<MODE, 3, 2>), grid, dim3(512), lds, st, g);                      \
+    } while (0)
+        if (c_bf16) CRUSE_GB_LAUNCH_BIG(3); else if (accumulate) CRUSE_GB_LAUNCH_BIG(1); else CRUSE_GB_LAUNCH_BIG(0);
+#undef CRUSE_GB_LAUNCH_BIG
+        CRUSE_LAUNCH_CHECK("gemm_bf16_nt");
+        return CRUSE_OK;
+    }
     if (use_slabs) {
         if (deep) CRUSE_GB_LAUNCH(4, 3); else CRUSE_GB_LAUNCH(4, 2);
         CRUSE_LAUNCH_CHECK("gemm_bf16_nt");

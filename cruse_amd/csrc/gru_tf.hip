@@ -37,7 +37,9 @@ __device__ __forceinline__ float take_hi8(float old, float src) {
 // forward
 // ---------------------------------------------------------------------------------
 // NK = Hg / 32 k-steps; NS = ceil(Hg / 256) sweep slots per compute thread; WLO: W_hh as hi + lo bf16 planes (Hg <= 320)
-template <int NK, int NS, bool WLO, bool TIMED = false>
+// RD: register-direct sweep (see gru_fwd_lean_kernel / gru_bwd_ag_kernel): clip-minor panel, every wave loads ITS B fragments -- here the
+// whole K: ceil(NK / 2) 16-byte loads per lane, the MFMA's idle columns 8..15 fetching the odd k-step of each pair -- no LDS image.
+template <int NK, int NS, bool WLO, bool TIMED = false, bool RD = false>
 __global__ __launch_bounds__(320) void gru_fwd_tf_kernel(GruArgs a) {
     static_assert(!WLO || NK <= 10, "two weight planes fit 256 registers up to Hg = 320");
     // Row stride of the LDS image: a ds_read_b128 is served in groups of 16 lanes over 64 banks, and a group holds the fragments
@@ -200,8 +202,10 @@ __global__ __launch_bounds__(320) void gru_fwd_tf_kernel(GruArgs a) {
         sw_v[j] = (unsigned)e * 16u;
         sw_l[j] = bl * LD + v;
     }
-    const unsigned pub_v = (unsigned)(clipc * Hg + u0 + 8 * wv + 2 * q) * 2u;
+    const unsigned pub_v = RD ? (unsigned)(((((u0 >> 3) + wv) * 8 + clipc) * 8 + 2 * q) * 2) : (unsigned)(clipc * Hg + u0 + 8 * wv + 2 * q) * 2u;
     const bool pub_lane = act && c16 < 8;
+    constexpr int NLR = (NK + 1) / 2;
+    const unsigned rd_v = (unsigned)((q * 8 + clip) * 16), rd_v2 = rd_v + ((c16 >> 3) ? 512u : 0u);     // + j * 1024: k-steps 2 j, 2 j + 1
     const int fb_off = clip * LD + q * 8;                     // B fragment of k-step ks: + ks * 32 (columns 8..15 re-read clips 0..7)
     float* const sl0 = &sv_l[0][0][clipc][uw];
     const float* const gi0 = &gi_r[0][clipc][uw];
@@ -218,7 +222,39 @@ __global__ __launch_bounds__(320) void gru_fwd_tf_kernel(GruArgs a) {
 #pragma unroll
         for (int g = 0; g < 3; ++g) gic[g] = gi0[(t & 3) * (8 * GS) + g * 32];
         __bf16* const hb = hB[t & 1];
-        if (t > 0) {
+        u32x4 gr[RD ? NLR : 1];
+        if (RD && t > 0) {
+            const unsigned soff = cbase + (unsigned)((t - 1) & 1) * panel_bytes;
+            const bool expect1 = tag_bit((unsigned)t) != 0u;
+            unsigned spins = 0;
+            for (int i = 0; i < a.poll_delay; ++i) __builtin_amdgcn_s_sleep(1);     // (see poll_delay)
+            for (;;) {
+#pragma unroll
+                for (int j = 0; j < (RD ? NLR : 1); ++j)
+                    gr[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (2 * j + 1 < NK || j + 1 < NLR) ? rd_v2 : rd_v, soff + (unsigned)(j * 1024), 16);
+                unsigned bad;
+                if (expect1) {
+                    unsigned n = 0xffffffffu;
+#pragma unroll
+                    for (int j = 0; j < (RD ? NLR : 1); ++j) n = n & (gr[j].x & gr[j].y) & (gr[j].z & gr[j].w);
+                    bad = ~n;
+                } else {
+                    unsigned o = 0u;
+#pragma unroll
+                    for (int j = 0; j < (RD ? NLR : 1); ++j) o = o | (gr[j].x | gr[j].y) | (gr[j].z | gr[j].w);
+                    bad = o;
+                }
+                if (__all((bad & TAGM) == 0u || !act || nowait)) break;
+                if (++spins >= SPIN_LIMIT) {
+                    if (lane == 0) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    nowait = true;
+                }
+                if constexpr (TIMED) tph[4] += 1;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[0] += tq1 - tq0; tq0 = tq1; }
+        }
+        if (!RD && t > 0) {
             const unsigned soff = cbase + (unsigned)((t - 1) & 1) * panel_bytes;
             const unsigned flip = tag_bit((unsigned)t) ? 0xffffffffu : 0u;
             u32x4 g[NS];
@@ -256,28 +292,56 @@ __global__ __launch_bounds__(320) void gru_fwd_tf_kernel(GruArgs a) {
             // stamps, gru_dbg = 32; sched_group_barrier pipelines were followed for six k-steps and then abandoned.)
             constexpr int PF = NK < 6 ? NK : 6;
             bf16x8 fr[NK];
+            if constexpr (RD) {
 #pragma unroll
-            for (int ks = 0; ks < PF; ++ks) fr[ks] = *reinterpret_cast<const bf16x8*>(hb + fb_off + ks * 32);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int ks = 0; ks < NK; ++ks) {
+                    const u32x4 gg = gr[ks >> 1];
+                    u32x4 w = {gg.x & ~TAGM, gg.y & ~TAGM, gg.z & ~TAGM, gg.w & ~TAGM};
+                    if (ks & 1) { w.x = dpp_ror8(w.x); w.y = dpp_ror8(w.y); w.z = dpp_ror8(w.z); w.w = dpp_ror8(w.w); }     // columns 8..15 -> 0..7
+                    fr[ks] = __builtin_bit_cast(bf16x8, w);
+                }
 #pragma unroll
-            for (int ks = 0; ks < NK; ++ks) {
-                if ((ks & 1) == 0) {
-                    aA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfA[ks], fr[ks], aA, 0, 0, 0);
-                    aB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfB[ks], fr[ks], aB, 0, 0, 0);
-                    if constexpr (WLO) {
-                        aA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlA[ks], fr[ks], aA, 0, 0, 0);
-                        aB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlB[ks], fr[ks], aB, 0, 0, 0);
-                    }
-                } else {
-                    aA1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfA[ks], fr[ks], aA1, 0, 0, 0);
-                    aB1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfB[ks], fr[ks], aB1, 0, 0, 0);
-                    if constexpr (WLO) {
-                        aA1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlA[ks], fr[ks], aA1, 0, 0, 0);
-                        aB1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlB[ks], fr[ks], aB1, 0, 0, 0);
+                for (int ks = 0; ks < NK; ++ks) {
+                    if ((ks & 1) == 0) {
+                        aA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfA[ks], fr[ks], aA, 0, 0, 0);
+                        aB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfB[ks], fr[ks], aB, 0, 0, 0);
+                        if constexpr (WLO) {
+                            aA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlA[ks], fr[ks], aA, 0, 0, 0);
+                            aB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlB[ks], fr[ks], aB, 0, 0, 0);
+                        }
+                    } else {
+                        aA1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfA[ks], fr[ks], aA1, 0, 0, 0);
+                        aB1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfB[ks], fr[ks], aB1, 0, 0, 0);
+                        if constexpr (WLO) {
+                            aA1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlA[ks], fr[ks], aA1, 0, 0, 0);
+                            aB1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlB[ks], fr[ks], aB1, 0, 0, 0);
+                        }
                     }
                 }
-                if (ks + PF < NK) fr[ks + PF] = *reinterpret_cast<const bf16x8*>(hb + fb_off + (ks + PF) * 32);
+            } else {
+    #pragma unroll
+                for (int ks = 0; ks < PF; ++ks) fr[ks] = *reinterpret_cast<const bf16x8*>(hb + fb_off + ks * 32);
                 __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int ks = 0; ks < NK; ++ks) {
+                    if ((ks & 1) == 0) {
+                        aA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfA[ks], fr[ks], aA, 0, 0, 0);
+                        aB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfB[ks], fr[ks], aB, 0, 0, 0);
+                        if constexpr (WLO) {
+                            aA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlA[ks], fr[ks], aA, 0, 0, 0);
+                            aB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlB[ks], fr[ks], aB, 0, 0, 0);
+                        }
+                    } else {
+                        aA1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfA[ks], fr[ks], aA1, 0, 0, 0);
+                        aB1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfB[ks], fr[ks], aB1, 0, 0, 0);
+                        if constexpr (WLO) {
+                            aA1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlA[ks], fr[ks], aA1, 0, 0, 0);
+                            aB1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlB[ks], fr[ks], aB1, 0, 0, 0);
+                        }
+                    }
+                    if (ks + PF < NK) fr[ks + PF] = *reinterpret_cast<const bf16x8*>(hb + fb_off + (ks + PF) * 32);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             aA += aA1; aB += aB1;
         }
@@ -1079,6 +1143,14 @@ bool fwd_tf_eligible(int Bg, int Hg, int prec, bool has_h0, bool gi_bf16) {
 }
 
 int dispatch_fwd_tf(const GruArgs& a, int grid, bool wlo, hipStream_t s) {
+    // (Hg = 640, reached with gru_tf = 2 only: the K-split-free step with a register-direct sweep needs 10 fragment loads + 160 weight
+    //  registers per lane -- 332 bytes of scratch, 1.41 us per step against the lean kernel's 1.14: not instantiated)
+    if (cruse_opt("gru_fwd_rd", 1) != 0 && a.dbg != 32 && (a.Hg == 160 || a.Hg == 320)) {       // register-direct sweep
+        if (a.Hg == 160) return wlo ? launch_one(gru_fwd_tf_kernel<5, 1, true, false, true>, a, grid, 0, s, "gru_seq_fwd", 320)
+                                    : launch_one(gru_fwd_tf_kernel<5, 1, false, false, true>, a, grid, 0, s, "gru_seq_fwd", 320);
+        return wlo ? launch_one(gru_fwd_tf_kernel<10, 2, true, false, true>, a, grid, 0, s, "gru_seq_fwd", 320)
+                   : launch_one(gru_fwd_tf_kernel<10, 2, false, false, true>, a, grid, 0, s, "gru_seq_fwd", 320);
+    }
     if (a.dbg == 32 && a.Hg == 640) return launch_one(gru_fwd_tf_kernel<20, 3, false, true>, a, grid, 0, s, "gru_seq_fwd", 320);
     switch (a.Hg) {
         case 160: return wlo ? launch_one(gru_fwd_tf_kernel<5, 1, true>, a, grid, 0, s, "gru_seq_fwd", 320)
