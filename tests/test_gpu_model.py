@@ -375,7 +375,9 @@ def test_forward_time_chunk_pipeline_is_the_same_computation(graph):
         # the first step starts from identical parameters: the forward pass must agree bit for bit
         assert torch.equal(res[nch][1], res[0][1]), f"mask differs with {nch} chunks"
         assert res[nch][0] == res[0][0]
-        assert rel_l2(res[nch][2], res[0][2]) < 5e-5               # (run-to-run order of the BatchNorm-sum atomics: 1e-7 in dy, a few of its bf16 roundings flip)
+        # (two RUNS are compared: the order of the BatchNorm-sum atomics moves dy by 1e-7, a few of its bf16 roundings flip and the
+        #  backward recurrences carry that on; six repetitions on one box gave 3e-5 .. 5.3e-5)
+        assert rel_l2(res[nch][2], res[0][2]) < 1e-4
         assert res[nch][3] == pytest.approx(res[0][3], rel=1e-5) and rel_l2(res[nch][4], res[0][4]) < 2e-3      # (Adam moves noise-level entries by +-lr)
 
 
