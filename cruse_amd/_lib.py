@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcruse_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16 = 0, 1, 2, 3
 PREC_BY_NAME = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "f16": PREC_F16}
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
@@ -37,6 +37,8 @@ SIGNATURES = {
     "cruse_conv_gather_bnbwd": ("pppiiiiiiiiiiiipppppipiiip", "i"),
     "cruse_conv_scatter2_bnbwd": ("pppiiiiiiiiiipppppipiiip", "i"),
     "cruse_conv_wgrad_ws_bytes": ("iii", "z"),
+    "cruse_conv_gather_bnbwd_in": ("pipppppp" + "iii" + "pppp" + "pp" + "iiiiiiiiiiii" + "pppppi" + "piip", "i"),
+    "cruse_conv_scatter2_bnbwd_in": ("pipppppp" + "iii" + "pppp" + "pp" + "iiiiiiiiii" + "pppppi" + "piip", "i"),
     "cruse_conv_gather_bnin": ("ppiqffpppppppppppiiiiiiiiiipip", "i"),
     "cruse_conv_scatter2_bnin": ("ppiqffpppppppppppiiiiiiiiipip", "i"),
     "cruse_conv_wgrad": ("pppiiiiiiiiiiiipp", "i"),

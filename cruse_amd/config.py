@@ -45,6 +45,9 @@ class EngineConfig:
     fuse_bn_fwd: bool = True        # bf16 mode, training: BatchNorm-apply + ReLU (+ decoder skip add) of a level run inside the STAGING of
                                     # the convs that consume it (cruse_conv_*_bnin) -- the normalised tensors e_k (k < L) and u_k (k >= 2)
                                     # never exist in f32; the weight gradients read a bf16 copy the consuming conv writes while staging
+    fuse_bn_bwd_apply: bool = True  # bf16 mode: the BatchNorm-backward "apply" pass (dy from dout, the pre-BN tensor and the batch sums) runs inside the
+                                    # STAGING of the data-gradient conv that consumes dy (cruse_conv_*_bnbwd_in), which also writes the bf16 dy the
+                                    # weight gradient reads; levels whose incoming gradient is f32 (from the GGRU / the last decoder layer) keep the pass
     bf16_dy: bool = True            # bf16 mode: the BatchNorm-backward outputs (dy, dv) are STORED as bf16 -- their two consumers (the
                                     # data-gradient conv on plain bf16 operands and the weight gradient) round them to bf16 anyway,
                                     # so the MFMAs see the same bits; 7 x 65.7 MB less written and 2 x that less read per step
@@ -65,7 +68,7 @@ class EngineConfig:
             "fuse_bn_bwd_stats": ("CRUSE_FUSE_BN_BWD", lambda v: v != "0"), "fuse_cast": ("CRUSE_FUSE_CAST", lambda v: v == "1"),
             "gi_x3": ("CRUSE_GI_X3", int), "gi_bf16": ("CRUSE_GI_BF16", lambda v: v == "1"), "dw_xcdk": ("CRUSE_DW_XCDK", int), "conv_bwd_x3": ("CRUSE_CONV_BWD_X3", lambda v: v == "1"),
             "dw_tn": ("CRUSE_DW_TN", lambda v: v == "1"), "dw_slabs": ("CRUSE_DW_SLABS", lambda v: v != "0"), "fwd_chunks": ("CRUSE_FWD_CHUNKS", int),
-            "fuse_bn_fwd": ("CRUSE_FUSE_BN_FWD", lambda v: v != "0"), "bf16_dy": ("CRUSE_BF16_DY", lambda v: v != "0"), "bf16_de": ("CRUSE_BF16_DE", lambda v: v != "0")}
+            "fuse_bn_fwd": ("CRUSE_FUSE_BN_FWD", lambda v: v != "0"), "fuse_bn_bwd_apply": ("CRUSE_FUSE_BN_BWD_APPLY", lambda v: v != "0"), "bf16_dy": ("CRUSE_BF16_DY", lambda v: v != "0"), "bf16_de": ("CRUSE_BF16_DE", lambda v: v != "0")}
     _LIB_ENV = {"CRUSE_GRU_BWD_RS": "gru_bwd_rs", "CRUSE_GRU_FWD_LEAN": "gru_fwd_lean", "CRUSE_GRU_WLO": "gru_wlo",
                 "CRUSE_GRU_DBG": "gru_dbg", "CRUSE_GRU_BG": "gru_bg", "CRUSE_CM_GRID": "cm_grid", "CRUSE_CM_KINT": "cm_kint", "CRUSE_CM_SWAP": "cm_swap", "CRUSE_CM_NW": "cm_nw",
                 "CRUSE_GB_DEEP_MIN": "gb_deep_min", "CRUSE_GB_DEEP": "gb_deep", "CRUSE_GB_BM256": "gb_bm256", "CRUSE_PW_VALU": "pw_valu", "CRUSE_LNB_GRID": "lnb_grid",

@@ -15,6 +15,12 @@ struct CruseBnBwd { const float* y; const float* mean; const float* rstd; const 
 struct CruseBnIn { const double* sums; int nrep; long long count; float eps, momentum; const float* gamma; const float* beta;
                    float* mean_o; float* rstd_o; float* rmean; float* rvar; const float* add; void* copy_bf16; };
 
+// the BatchNorm(+ReLU) BACKWARD a data-gradient convolution applies to its INPUT while staging it (cruse_conv_*_bnbwd_in): x is the gradient
+// wrt that BatchNorm's output (bf16), y its pre-BN tensor, sums its backward batch sums ([nrep][2*Cin] f64: sum g, sum g*xhat); copy_bf16
+// receives dy (the tensor the separate cruse_bn_act_bwd_apply pass would store); dgamma / dbeta / dbias (nullable) are ADDED to once
+struct CruseBnBwdIn { const float* y; const double* sums; int nrep; long long count; const float* mean; const float* rstd; const float* gamma;
+                      const float* beta; int relu, training; void* copy_bf16; float* dgamma; float* dbeta; float* dbias; };
+
 extern "C" void cruse_set_error(const char* fmt, ...);
 
 #define CRUSE_REQUIRE(cond, code, ...)                                   \

@@ -449,7 +449,10 @@ int set_smem(K kern, size_t bytes, const char* name) {
 int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float* bias, float* y,
                         int B, int T, int Cin, int Fin, int Cout, int Fout, int KT, int S, int pad,
                         int w_layout, int act, int accum, int prec, double* bn_sums, const CruseBnBwd* bnb, int x_bf16, int y_bf16,
-                        const CruseBnIn* bni, hipStream_t stream);
+                        const CruseBnIn* bni, hipStream_t stream, const CruseBnBwdIn* bbi = nullptr);
+extern "C" int cruse_bn_act_bwd_apply(const float* dout, const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                      const double* sums, int sum_replicas, long long rows, int C, int F, int relu, int training, int dout_dtype,
+                                      void* dy, int dy_dtype, float* dgamma, float* dbeta, float* dbias, void* stream);
 extern "C" int cruse_bn_act_bwd_reduce(const float* dout, const float* y, const float* mean, const float* rstd,
                                        const float* gamma, const float* beta, long long rows, int C, int F,
                                        int relu, double* sums, int zeroed, void* stream);
@@ -459,7 +462,8 @@ namespace {
 int conv_gather_impl(const float* x, const float* w, const float* bias, float* y,
                      int B, int T, int Cin, int Fin, int Cout, int Fout,
                      int KT, int S, int pad, int w_layout, int act, int accum, int prec, double* bn_sums, void* stream,
-                     const CruseBnBwd* bnb = nullptr, int x_dtype = CRUSE_DT_F32, int y_dtype = CRUSE_DT_F32, const CruseBnIn* bni = nullptr) {
+                     const CruseBnBwd* bnb = nullptr, int x_dtype = CRUSE_DT_F32, int y_dtype = CRUSE_DT_F32, const CruseBnIn* bni = nullptr,
+                     const CruseBnBwdIn* bbi = nullptr) {
     CRUSE_REQUIRE((x_dtype == CRUSE_DT_F32 || x_dtype == CRUSE_DT_BF16) && (y_dtype == CRUSE_DT_F32 || y_dtype == CRUSE_DT_BF16), CRUSE_E_DTYPE,
                   "conv_gather: x_dtype %d / y_dtype %d (f32 or bf16)", x_dtype, y_dtype);
     CRUSE_REQUIRE(B > 0 && T > 0 && Cin > 0 && Cout > 0 && Fin > 0 && Fout > 0, CRUSE_E_SHAPE,
@@ -472,9 +476,10 @@ int conv_gather_impl(const float* x, const float* w, const float* bias, float* y
     CRUSE_REQUIRE(!(accum && act), CRUSE_E_SHAPE, "conv_gather: accum with activation");
     if (prec >= 0) {
         const int r = cruse_conv_mfma_try(0, x, w, bias, y, B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout, act, accum,
-                                          prec, bn_sums, bnb, x_dtype == CRUSE_DT_BF16, y_dtype == CRUSE_DT_BF16, bni, (hipStream_t)stream);
+                                          prec, bn_sums, bnb, x_dtype == CRUSE_DT_BF16, y_dtype == CRUSE_DT_BF16, bni, (hipStream_t)stream, bbi);
         if (r != 0) return r < 0 ? r : CRUSE_OK;
     }
+    if (bbi != nullptr) return 1;                    // (not handled: the caller runs the separate BatchNorm-backward pass)
     CRUSE_REQUIRE(bni == nullptr, CRUSE_E_SHAPE, "conv_gather_bnin: the fused input BatchNorm needs the MFMA kernel in the bf16 mode (Cin %d, Cout %d, prec %d)", Cin, Cout, prec);
     CRUSE_REQUIRE(x_dtype == CRUSE_DT_F32 && y_dtype == CRUSE_DT_F32, CRUSE_E_DTYPE,
                   "conv_gather: a bf16 input / output needs the MFMA kernel in the bf16 data-gradient mode (Cin %d, Cout %d, prec %d)", Cin, Cout, prec);
@@ -503,7 +508,8 @@ int conv_gather_impl(const float* x, const float* w, const float* bias, float* y
 int conv_scatter2_impl(const float* g, const float* w, const float* bias, float* y,
                        int B, int T, int Cs, int Fg, int Cout, int Fout,
                        int KT, int pad, int act, int accum, int prec, double* bn_sums, void* stream,
-                       const CruseBnBwd* bnb = nullptr, int x_dtype = CRUSE_DT_F32, int y_dtype = CRUSE_DT_F32, const CruseBnIn* bni = nullptr) {
+                       const CruseBnBwd* bnb = nullptr, int x_dtype = CRUSE_DT_F32, int y_dtype = CRUSE_DT_F32, const CruseBnIn* bni = nullptr,
+                       const CruseBnBwdIn* bbi = nullptr) {
     CRUSE_REQUIRE((x_dtype == CRUSE_DT_F32 || x_dtype == CRUSE_DT_BF16) && (y_dtype == CRUSE_DT_F32 || y_dtype == CRUSE_DT_BF16), CRUSE_E_DTYPE,
                   "conv_scatter2: x_dtype %d / y_dtype %d (f32 or bf16)", x_dtype, y_dtype);
     CRUSE_REQUIRE(B > 0 && T > 0 && Cs > 0 && Cout > 0 && Fg > 0, CRUSE_E_SHAPE, "conv_scatter2: empty shape");
@@ -513,9 +519,10 @@ int conv_scatter2_impl(const float* g, const float* w, const float* bias, float*
     CRUSE_REQUIRE(!(accum && act), CRUSE_E_SHAPE, "conv_scatter2: accum with activation");
     if (prec >= 0) {
         const int r = cruse_conv_mfma_try(1, g, w, bias, y, B, T, Cs, Fg, Cout, Fout, KT, 2, pad, 0, act, accum, prec,
-                                          bn_sums, bnb, x_dtype == CRUSE_DT_BF16, y_dtype == CRUSE_DT_BF16, bni, (hipStream_t)stream);
+                                          bn_sums, bnb, x_dtype == CRUSE_DT_BF16, y_dtype == CRUSE_DT_BF16, bni, (hipStream_t)stream, bbi);
         if (r != 0) return r < 0 ? r : CRUSE_OK;
     }
+    if (bbi != nullptr) return 1;                    // (not handled: the caller runs the separate BatchNorm-backward pass)
     CRUSE_REQUIRE(bni == nullptr, CRUSE_E_SHAPE, "conv_scatter2_bnin: the fused input BatchNorm needs the MFMA kernel in the bf16 mode (Cs %d, Cout %d, prec %d)", Cs, Cout, prec);
     CRUSE_REQUIRE(x_dtype == CRUSE_DT_F32 && y_dtype == CRUSE_DT_F32, CRUSE_E_DTYPE,
                   "conv_scatter2: a bf16 input / output needs the MFMA kernel in the bf16 data-gradient mode (Cs %d, Cout %d, prec %d)", Cs, Cout, prec);
@@ -627,6 +634,65 @@ extern "C" int cruse_conv_scatter2_bnin(const float* g_pre, const double* in_sum
                            in_add, in_copy_bf16};
     return conv_scatter2_impl(g_pre, w, bias, y, B, T, Cs, Fg, Cout, Fout, KT, pad, 0, 0, prec, out_sums, stream, nullptr, CRUSE_DT_F32,
                               CRUSE_DT_F32, &bni);
+}
+
+// Data-gradient convolutions with the BatchNorm(+ReLU) BACKWARD of their input applied while staging (see CruseBnBwdIn): one entry point =
+// cruse_bn_act_bwd_apply(dout -> dy_bf16, parameter gradients) + cruse_conv_*[_bnbwd](dy_bf16 -> y).  Shapes / modes the MFMA kernel does not
+// take run exactly those two calls.
+static int bnbwd_in_fallback(const CruseBnBwdIn& bb, const void* dout, int dout_dtype, long long rows, int C, int F, void* stream) {
+    CRUSE_REQUIRE(bb.copy_bf16 != nullptr, CRUSE_E_SHAPE, "conv_*_bnbwd_in: dy_bf16 is required");
+    return cruse_bn_act_bwd_apply(reinterpret_cast<const float*>(dout), bb.y, bb.mean, bb.rstd, bb.gamma, bb.beta, bb.sums, bb.nrep, rows, C, F,
+                                  bb.relu, bb.training, dout_dtype, bb.copy_bf16, CRUSE_DT_BF16, bb.dgamma, bb.dbeta, bb.dbias, stream);
+}
+
+extern "C" int cruse_conv_gather_bnbwd_in(const void* dout, int dout_dtype, const float* in_y, const float* in_mean, const float* in_rstd,
+                                          const float* in_gamma, const float* in_beta, const double* in_sums, int in_replicas, int in_relu,
+                                          int in_training, void* dy_bf16, float* in_dgamma, float* in_dbeta, float* in_dbias,
+                                          const float* w, void* y, int B, int T, int Cin, int Fin, int Cout, int Fout, int KT, int S, int pad,
+                                          int w_layout, int accum, int prec,
+                                          const float* bn_y, const float* mean, const float* rstd, const float* gamma, const float* beta, int relu,
+                                          double* sums, int zeroed, int y_dtype, void* stream) {
+    CRUSE_REQUIRE(dout && in_y && in_mean && in_rstd && in_gamma && in_beta && in_sums && in_replicas >= 1, CRUSE_E_SHAPE,
+                  "conv_gather_bnbwd_in: input BatchNorm tensors missing");
+    CRUSE_REQUIRE((bn_y == nullptr) == (sums == nullptr), CRUSE_E_SHAPE, "conv_gather_bnbwd_in: bn_y and sums come together");
+    if (sums) { int rc = prep_sums(sums, Cout, zeroed, stream, "conv_gather_bnbwd_in"); if (rc) return rc; }
+    const CruseBnBwdIn bb = {in_y, in_sums, in_replicas, (long long)B * T * Fin, in_mean, in_rstd, in_gamma, in_beta, in_relu, in_training, dy_bf16,
+                             in_dgamma, in_dbeta, in_dbias};
+    const CruseBnBwd bnb = {bn_y, mean, rstd, gamma, beta, relu};
+    if (dout_dtype == CRUSE_DT_BF16) {
+        const int rc = conv_gather_impl(reinterpret_cast<const float*>(dout), w, nullptr, reinterpret_cast<float*>(y), B, T, Cin, Fin, Cout, Fout, KT, S,
+                                        pad, w_layout, 0, accum, prec, sums, stream, bn_y ? &bnb : nullptr, CRUSE_DT_BF16, y_dtype, nullptr, &bb);
+        if (rc <= 0) return rc;
+    }
+    int rc = bnbwd_in_fallback(bb, dout, dout_dtype, (long long)B * T, Cin, Fin, stream);
+    if (rc) return rc;
+    return conv_gather_impl(reinterpret_cast<const float*>(dy_bf16), w, nullptr, reinterpret_cast<float*>(y), B, T, Cin, Fin, Cout, Fout, KT, S, pad,
+                            w_layout, 0, accum, prec, sums, stream, bn_y ? &bnb : nullptr, CRUSE_DT_BF16, y_dtype);
+}
+
+extern "C" int cruse_conv_scatter2_bnbwd_in(const void* dout, int dout_dtype, const float* in_y, const float* in_mean, const float* in_rstd,
+                                            const float* in_gamma, const float* in_beta, const double* in_sums, int in_replicas, int in_relu,
+                                            int in_training, void* dy_bf16, float* in_dgamma, float* in_dbeta, float* in_dbias,
+                                            const float* w, void* y, int B, int T, int Cs, int Fg, int Cout, int Fout, int KT, int pad, int accum,
+                                            int prec,
+                                            const float* bn_y, const float* mean, const float* rstd, const float* gamma, const float* beta, int relu,
+                                            double* sums, int zeroed, int y_dtype, void* stream) {
+    CRUSE_REQUIRE(dout && in_y && in_mean && in_rstd && in_gamma && in_beta && in_sums && in_replicas >= 1, CRUSE_E_SHAPE,
+                  "conv_scatter2_bnbwd_in: input BatchNorm tensors missing");
+    CRUSE_REQUIRE((bn_y == nullptr) == (sums == nullptr), CRUSE_E_SHAPE, "conv_scatter2_bnbwd_in: bn_y and sums come together");
+    if (sums) { int rc = prep_sums(sums, Cout, zeroed, stream, "conv_scatter2_bnbwd_in"); if (rc) return rc; }
+    const CruseBnBwdIn bb = {in_y, in_sums, in_replicas, (long long)B * T * Fg, in_mean, in_rstd, in_gamma, in_beta, in_relu, in_training, dy_bf16,
+                             in_dgamma, in_dbeta, in_dbias};
+    const CruseBnBwd bnb = {bn_y, mean, rstd, gamma, beta, relu};
+    if (dout_dtype == CRUSE_DT_BF16) {
+        const int rc = conv_scatter2_impl(reinterpret_cast<const float*>(dout), w, nullptr, reinterpret_cast<float*>(y), B, T, Cs, Fg, Cout, Fout, KT, pad,
+                                          0, accum, prec, sums, stream, bn_y ? &bnb : nullptr, CRUSE_DT_BF16, y_dtype, nullptr, &bb);
+        if (rc <= 0) return rc;
+    }
+    int rc = bnbwd_in_fallback(bb, dout, dout_dtype, (long long)B * T, Cs, Fg, stream);
+    if (rc) return rc;
+    return conv_scatter2_impl(reinterpret_cast<const float*>(dy_bf16), w, nullptr, reinterpret_cast<float*>(y), B, T, Cs, Fg, Cout, Fout, KT, pad, 0,
+                              accum, prec, sums, stream, bn_y ? &bnb : nullptr, CRUSE_DT_BF16, y_dtype);
 }
 
 extern "C" size_t cruse_conv_wgrad_ws_bytes(int Ca, int Cb, int KT) {

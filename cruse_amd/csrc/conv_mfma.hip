@@ -47,6 +47,13 @@ struct CMArgs {
     const double* in_sums; int in_nrep; double in_inv_count, in_unb; float in_eps, in_mom;
     const float* in_gamma; const float* in_beta; float* in_mean_o; float* in_rstd_o; float* in_rmean; float* in_rvar;
     const float* in_add; void* in_copy;
+    // FUSED INPUT BatchNorm BACKWARD (IOB 5 / 6; data-gradient convs of the bf16 mode): x is the gradient wrt the OUTPUT of the BatchNorm(+ReLU)
+    // (bf16), bb_y that BatchNorm's pre-BN tensor (f32); the staging forms dy = gamma rstd (g - mean g - xhat mean(g xhat)) -- the arithmetic of
+    // bn_act_bwd_apply_kernel, from the same batch sums -- rounds it to bf16 for the MFMA (what the separate pass stored) and writes the bf16
+    // copy the weight gradient reads (bb_copy).  Block 0 adds the parameter gradients (dgamma, dbeta; dbias in eval mode).
+    const float* bb_y; const double* bb_sums; int bb_nrep; double bb_inv_count;
+    const float* bb_mean; const float* bb_rstd; const float* bb_gamma; const float* bb_beta; int bb_relu, bb_training;
+    void* bb_copy; float* bb_dgamma; float* bb_dbeta; float* bb_dbias;
     int x_bf16;                                  // x holds bf16 elements (a backward-only tensor stored in bf16): widened while staging
     const float* x; const float* w; const float* bias; float* y;
     int B, T, Cin, Fin, Cout, Fout;
@@ -123,7 +130,8 @@ template <int PREC, int MT, int EPI, int NV, int NW, int SWM, int IOB>
 //  this kernel sits at its register cap and a run-time dtype branch cost the f32 forward convs 10 %)
 // (two 5-wave workgroups per CU need 4 wave slots on some SIMD: the 5-wave variants are held to 128 registers)
 __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMArgs a) {
-    constexpr bool XB = IOB == 1 || IOB == 2, YB = IOB == 2;
+    constexpr bool BBI = IOB == 5 || IOB == 6;             // fused input BatchNorm backward (y f32 / bf16)
+    constexpr bool XB = IOB == 1 || IOB == 2 || BBI, YB = IOB == 2 || IOB == 6;
     constexpr bool INB = IOB == 3 || IOB == 4, INA = IOB == 4;      // fused input BatchNorm (+ added tensor)
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
     __shared__ int2 s_tap2[2][MAXTAP];
     __shared__ float s_bias[MT * 16];
     __shared__ float s_bnp[STATS ? 4 : 1][MT * 16];       // mean, rstd, gamma, beta of the backward-statistics form
-    __shared__ float s_inp[INB ? 4 : 1][64];              // mean, rstd, gamma, beta of the fused INPUT BatchNorm (Cin <= 64)
+    __shared__ float s_inp[(INB || BBI) ? (BBI ? 6 : 4) : 1][64];   // mean, rstd, gamma, beta (BBI: + mean g, mean g xhat) of the fused INPUT BatchNorm (Cin <= 64)
 
     const int ntile = (a.T + TFM - 1) / TFM;
     const bool tdbg = a.tdbg != 0 && blockIdx.x == 0 && wv == 0;
@@ -191,6 +199,20 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
                     a.in_rmean[tid] = (float)((1.0 - a.in_mom) * a.in_rmean[tid] + a.in_mom * m);
                     a.in_rvar[tid] = (float)((1.0 - a.in_mom) * a.in_rvar[tid] + a.in_mom * var * a.in_unb);
                 }
+            }
+        }
+    }
+    if constexpr (BBI) {
+        if (tid < a.Cin) {                                  // bn_act_bwd_apply_kernel's table, channel by channel
+            double sg = 0.0, sgx = 0.0;
+            for (int r = 0; r < a.bb_nrep; ++r) { sg += a.bb_sums[(size_t)r * 2 * a.Cin + tid]; sgx += a.bb_sums[(size_t)r * 2 * a.Cin + a.Cin + tid]; }
+            s_inp[0][tid] = a.bb_mean[tid]; s_inp[1][tid] = a.bb_rstd[tid]; s_inp[2][tid] = a.bb_gamma[tid]; s_inp[3][tid] = a.bb_beta[tid];
+            s_inp[4][tid] = a.bb_training ? (float)(sg * a.bb_inv_count) : 0.f;
+            s_inp[5][tid] = a.bb_training ? (float)(sgx * a.bb_inv_count) : 0.f;
+            if (blockIdx.x == 0) {
+                if (a.bb_dgamma) a.bb_dgamma[tid] += (float)sgx;
+                if (a.bb_dbeta) a.bb_dbeta[tid] += (float)sg;
+                if (a.bb_dbias && !a.bb_training) a.bb_dbias[tid] += a.bb_gamma[tid] * a.bb_rstd[tid] * (float)sg;
             }
         }
     }
@@ -264,7 +286,7 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
     // the 8 channels of its VW bins (a channel row of Fin elements is contiguous over the lanes) and writes VW 16-byte chunks per
     // plane.  VW = 4 where Fin % 4 == 0 (16-byte loads of f32, 8-byte loads of bf16; one item per thread), else 2 (two items per
     // thread: slot 0 in the .xy halves of the registers below, slot 1 in .zw)
-    float4 c4[(CF && !XB) ? 8 : 1], c4b[(CF && INA) ? 8 : 1];
+    float4 c4[(CF && (!XB || BBI)) ? 8 : 1], c4b[(CF && INA) ? 8 : 1];        // (BBI: c4 holds the pre-BN tensor, cb the gradient)
     uint2 cb[(CF && XB) ? 8 : 1];
     const bool vw4 = (a.Fin & 3) == 0;
     int c_src[CF ? 2 : 1], c_pos[CF ? 2 : 1], c_row[CF ? 2 : 1], c_oct[CF ? 2 : 1];
@@ -302,6 +324,11 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
                     const __bf16* sp = reinterpret_cast<const __bf16*>(a.x) + off;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) cb[e] = *reinterpret_cast<const uint2*>(sp + e * a.Fin);
+                    if constexpr (BBI) {
+                        const float* sy = a.bb_y + off;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) c4[e] = *reinterpret_cast<const float4*>(sy + e * a.Fin);
+                    }
                 } else {
                     const float* sp = a.x + off;
 #pragma unroll
@@ -319,6 +346,15 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
                     const __bf16* sp1 = reinterpret_cast<const __bf16*>(a.x) + off1;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { cb[e].x = *reinterpret_cast<const unsigned*>(sp0 + e * a.Fin); cb[e].y = *reinterpret_cast<const unsigned*>(sp1 + e * a.Fin); }
+                    if constexpr (BBI) {
+                        const float* sy0 = a.bb_y + off0;
+                        const float* sy1 = a.bb_y + off1;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float2 u0 = *reinterpret_cast<const float2*>(sy0 + e * a.Fin), u1 = *reinterpret_cast<const float2*>(sy1 + e * a.Fin);
+                            c4[e] = make_float4(u0.x, u0.y, u1.x, u1.y);
+                        }
+                    }
                 } else {
                     const float* sp0 = a.x + off0;
                     const float* sp1 = a.x + off1;
@@ -396,7 +432,50 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
                 const int t = t0 - a.halo_lo + c_row[q];
                 const bool ok = t >= 0 && t < a.T;         // (rows outside the clip are ZERO: the padding applies to e, not to x)
                 const int L0 = (c_pos[q] << lg_nch) + c_oct[q];
-                if constexpr (XB) {
+                if constexpr (BBI) {
+                    __bf16* const bcp = a.bb_copy ? reinterpret_cast<__bf16*>(a.bb_copy) + ((long long)b * a.T + (t0 - a.halo_lo)) * rowlen : nullptr;
+                    const int c0 = 8 * c_oct[q];
+                    float cm[8], cr[8], cg[8], cbt[8], c1[8], c2[8];
+                    *reinterpret_cast<float4*>(&cm[0]) = *reinterpret_cast<const float4*>(&s_inp[0][c0]); *reinterpret_cast<float4*>(&cm[4]) = *reinterpret_cast<const float4*>(&s_inp[0][c0 + 4]);
+                    *reinterpret_cast<float4*>(&cr[0]) = *reinterpret_cast<const float4*>(&s_inp[1][c0]); *reinterpret_cast<float4*>(&cr[4]) = *reinterpret_cast<const float4*>(&s_inp[1][c0 + 4]);
+                    *reinterpret_cast<float4*>(&cg[0]) = *reinterpret_cast<const float4*>(&s_inp[2][c0]); *reinterpret_cast<float4*>(&cg[4]) = *reinterpret_cast<const float4*>(&s_inp[2][c0 + 4]);
+                    *reinterpret_cast<float4*>(&cbt[0]) = *reinterpret_cast<const float4*>(&s_inp[3][c0]); *reinterpret_cast<float4*>(&cbt[4]) = *reinterpret_cast<const float4*>(&s_inp[3][c0 + 4]);
+                    *reinterpret_cast<float4*>(&c1[0]) = *reinterpret_cast<const float4*>(&s_inp[4][c0]); *reinterpret_cast<float4*>(&c1[4]) = *reinterpret_cast<const float4*>(&s_inp[4][c0 + 4]);
+                    *reinterpret_cast<float4*>(&c2[0]) = *reinterpret_cast<const float4*>(&s_inp[5][c0]); *reinterpret_cast<float4*>(&c2[4]) = *reinterpret_cast<const float4*>(&s_inp[5][c0 + 4]);
+                    bf16x8 hs[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (e < e0 || e >= e0 + nb) continue;
+                        bf16x8 h;
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            const unsigned dw = (e & 2) ? cb[c].y : cb[c].x;
+                            const float dd = (e & 1) ? __uint_as_float(dw & 0xffff0000u) : __uint_as_float(dw << 16);
+                            const float in = e == 0 ? c4[c].x : e == 1 ? c4[c].y : e == 2 ? c4[c].z : c4[c].w;
+                            const float xh = (in - cm[c]) * cr[c];
+                            float gr = dd;
+                            if (a.bb_relu && !(xh * cg[c] + cbt[c] > 0.f)) gr = 0.f;
+                            const float o = cg[c] * cr[c] * (gr - c1[c] - xh * c2[c]);
+                            h[c] = (__bf16)(ok ? o : 0.f);
+                        }
+                        hs[e] = h;
+                        *reinterpret_cast<bf16x8*>(xc + cf_off(L0 + ((e - e0) << lg_nch))) = h;
+                    }
+                    if (bcp != nullptr && ok && c_row[q] >= a.halo_lo) {          // own rows only: the halo belongs to the tile before
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            if (nb == 4) {
+                                bf16x4_ p4;
+                                p4[0] = hs[0][c]; p4[1] = hs[1][c]; p4[2] = hs[2][c]; p4[3] = hs[3][c];
+                                *reinterpret_cast<bf16x4_*>(bcp + c_src[q] + c * a.Fin) = p4;
+                            } else {
+                                bf16x2_ p2;
+                                p2[0] = e0 == 0 ? hs[0][c] : hs[2][c]; p2[1] = e0 == 0 ? hs[1][c] : hs[3][c];
+                                *reinterpret_cast<bf16x2_*>(bcp + c_src[q] + c * a.Fin) = p2;
+                            }
+                        }
+                    }
+                } else if constexpr (XB) {
                     // dword (e >> 1) of channel c holds bins e (low half) and e + 1: per bin one 16-byte run of 8 channels
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -896,7 +975,12 @@ int launch_mt(const CMArgs& a, int grid, size_t lds, int nw, hipStream_t s) {
             else if (a.in_sums != nullptr) CM_LAUNCH5(MTV, STV, NVV, NWV, SWV, 3);                         \
             else CM_LAUNCH5(MTV, STV, NVV, NWV, SWV, 0);                                                   \
         } else if constexpr (STV != 1 && PREC == CRUSE_PREC_BF16) {                                        \
-            if (a.x_bf16 && a.y_bf16) {                                                                    \
+            if (a.bb_y != nullptr) {                                                                       \
+                if (a.y_bf16) {                                                                            \
+                    if constexpr (SWV != 0) CM_LAUNCH5(MTV, STV, NVV, NWV, SWV, 6);                        \
+                    else { cruse_set_error("conv_mfma: a bf16 output needs the swapped-role (vector-store) forms"); return CRUSE_E_DTYPE; } \
+                } else CM_LAUNCH5(MTV, STV, NVV, NWV, SWV, 5);                                             \
+            } else if (a.x_bf16 && a.y_bf16) {                                                             \
                 if constexpr (SWV != 0) CM_LAUNCH5(MTV, STV, NVV, NWV, SWV, 2);                            \
                 else { cruse_set_error("conv_mfma: a bf16 output needs the swapped-role (vector-store) forms"); return CRUSE_E_DTYPE; } \
             } else if (a.x_bf16) CM_LAUNCH5(MTV, STV, NVV, NWV, SWV, 1);                                   \
@@ -918,7 +1002,8 @@ int launch_mt(const CMArgs& a, int grid, size_t lds, int nw, hipStream_t s) {
     } while (0)
 #define CM_LAUNCH1(MTV, STV)                                                                               \
     do {                                                                                                   \
-        if (nv <= 5) CM_LAUNCH2(MTV, STV, 5);                                                              \
+        if constexpr (PREC != CRUSE_PREC_F32) CM_LAUNCH2(MTV, STV, 5);     /* (the channel-fastest staging has no NV) */ \
+        else if (nv <= 5) CM_LAUNCH2(MTV, STV, 5);                                                         \
         else if (nv <= 6) CM_LAUNCH2(MTV, STV, 6);                                                         \
         else CM_LAUNCH2(MTV, STV, MAXV);                                                                   \
     } while (0)
@@ -947,8 +1032,9 @@ int launch_mt(const CMArgs& a, int grid, size_t lds, int nw, hipStream_t s) {
 int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float* bias, float* y,
                         int B, int T, int Cin, int Fin, int Cout, int Fout, int KT, int S, int pad,
                         int w_layout, int act, int accum, int prec, double* bn_sums, const CruseBnBwd* bnb, int x_bf16, int y_bf16,
-                        const CruseBnIn* bni, hipStream_t stream) {
+                        const CruseBnIn* bni, hipStream_t stream, const CruseBnBwdIn* bbi) {
     if (bni != nullptr && (prec != CRUSE_PREC_BF16X3 || Cin > 64 || accum || bnb != nullptr || x_bf16)) return 0;
+    if (bbi != nullptr && (prec != CRUSE_PREC_BF16 || Cin > 64 || !x_bf16 || bni != nullptr || act)) return 0;
     if (y_bf16 && !x_bf16) return 0;                                    // (a bf16 output comes with a bf16 input: the backward chain)
     if (Cin % 8 != 0 || (Cin & (Cin - 1)) != 0 || Cout < 8 || Cout > 64 || (TFM * (Fout / (scatter ? 2 : 1))) % 16 != 0) return 0;
     CMArgs a = {};
@@ -956,6 +1042,11 @@ int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float
     a.B = B; a.T = T; a.Cin = Cin; a.Fin = Fin; a.Cout = Cout; a.Fout = Fout;
     a.act = act; a.accum = accum; a.sums = bn_sums;
     a.x_bf16 = x_bf16 ? 1 : 0; a.y_bf16 = y_bf16 ? 1 : 0;
+    if (bbi != nullptr) {
+        a.bb_y = bbi->y; a.bb_sums = bbi->sums; a.bb_nrep = bbi->nrep; a.bb_inv_count = 1.0 / (double)bbi->count;
+        a.bb_mean = bbi->mean; a.bb_rstd = bbi->rstd; a.bb_gamma = bbi->gamma; a.bb_beta = bbi->beta; a.bb_relu = bbi->relu;
+        a.bb_training = bbi->training; a.bb_copy = bbi->copy_bf16; a.bb_dgamma = bbi->dgamma; a.bb_dbeta = bbi->dbeta; a.bb_dbias = bbi->dbias;
+    }
     if (bni != nullptr) {
         a.in_sums = bni->sums; a.in_nrep = bni->nrep; a.in_inv_count = 1.0 / (double)bni->count;
         a.in_unb = bni->count > 1 ? (double)bni->count / (double)(bni->count - 1) : 1.0;
@@ -1005,7 +1096,7 @@ int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float
     const int ks0 = (a.cls[0].ntaps * Cin + 31) / 32, ks1 = a.nclass > 1 ? (a.cls[1].ntaps * Cin + 31) / 32 : 0;
     const int mt = Cout <= 16 ? 1 : (Cout <= 32 ? 2 : 4);
     if ((Cin * Fin) % 4 != 0 || ((uintptr_t)x % 16) != 0) return 0;
-    if (x_bf16 && ((Cin * Fin) % 8 != 0 || prec != CRUSE_PREC_BF16 || bn_sums != nullptr && bnb == nullptr)) return 0;   // (bf16 slots cover 8 elements; bf16 mode, data-gradient forms)
+    if (x_bf16 && ((Cin * Fin) % 8 != 0 || prec != CRUSE_PREC_BF16 || (bn_sums != nullptr && bnb == nullptr))) return 0;   // (bf16 slots cover 8 elements; bf16 mode, data-gradient forms)
     if ((TFM + KT - 1) * Cin * Fin > MAXV * 256 * 4) return 0;
     const size_t wbytes = (size_t)mt * (ks0 + ks1) * 512 *
                           (prec == CRUSE_PREC_F32 ? 4 : (prec == CRUSE_PREC_BF16X3 ? 4 : 2));
@@ -1024,6 +1115,9 @@ int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float
     const int ntile_wg = a.nclass * (TFM * (Fout / a.OS) / 16);       // N-tiles of one workgroup tile
     int nw = (ntile_wg == 5 || (ntile_wg == 10 && (Cin >= 64 || Cout >= 64))) ? 5 : 4;
     { const int e = cruse_opt("cm_nw", 0); if (e == 4 || e == 5) nw = e; }       // profiling option
+    // the fused input BatchNorm backward holds 48 more prefetch registers per thread: the 5-wave (128-register) and 64-row variants spill
+    // (decoder level 4: 223 us against 38 + 49 for the two separate kernels) -- those shapes keep the separate pass
+    if (bbi != nullptr && (nw == 5 || mt > 2)) return 0;
     if (prec == CRUSE_PREC_F32) rc = launch_mt<CRUSE_PREC_F32>(a, grid, lds, nw, stream);
     else if (prec == CRUSE_PREC_BF16) rc = launch_mt<CRUSE_PREC_BF16>(a, grid, lds, nw, stream);
     else rc = launch_mt<CRUSE_PREC_BF16X3>(a, grid, lds, nw, stream);

@@ -1006,11 +1006,22 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
             SIDE.defer(wgrad, ds[k], kind=8, lane=1)
     skip_leaves(1)
     # ---- decoder levels 2..L ------------------------------------------------------------
+    # EngineConfig.fuse_bn_bwd_apply: where the incoming gradient is a bf16 tensor that arrived with its sums, the BatchNorm-backward apply
+    # pass runs inside the staging of the data-gradient conv (which also writes the bf16 dy for the weight gradient)
+    fuse_apply = bool(config.get().fuse_bn_bwd_apply) and dy_bf16 and fuse_bwd and not ups
     for k in range(2, L + 1):
         mean, rstd = dstats[k]
-        dv = ops.bn_act_bwd(du, vs[k], mean, rstd, P[f"bn{k}_t.weight"], P[f"bn{k}_t.bias"], rows, ch[k - 1],
-                            Fk[k - 1], True, training, G[f"bn{k}_t.weight"], G[f"bn{k}_t.bias"],
-                            dbias=G.get(f"conv{k}_t.bias"), sums=du_sums, out_bf16=dy_bf16)
+        fused = fuse_apply and du.dtype == torch.bfloat16 and du_sums is not None
+        if fused:
+            du, du_sums, dv = ops.conv_gather_bwd_in(
+                du, (vs[k], mean, rstd, P[f"bn{k}_t.weight"], P[f"bn{k}_t.bias"], du_sums, True, training, G[f"bn{k}_t.weight"],
+                     G[f"bn{k}_t.bias"], G.get(f"conv{k}_t.bias")),
+                P[f"conv{k}_t.weight"], B, T, ch[k - 1], Fk[k - 1], ch[k], Fk[k], KT=1, S=2, pad=0, prec=dprec,
+                bn_bwd=bn_of(k + 1, True) if k < L else None, out_bf16=lvl_bf16(k))
+        else:
+            dv = ops.bn_act_bwd(du, vs[k], mean, rstd, P[f"bn{k}_t.weight"], P[f"bn{k}_t.bias"], rows, ch[k - 1],
+                                Fk[k - 1], True, training, G[f"bn{k}_t.weight"], G[f"bn{k}_t.bias"],
+                                dbias=G.get(f"conv{k}_t.bias"), sums=du_sums, out_bf16=dy_bf16)
 
         def leaf_dec(dv=dv, k=k):
             dec_wgrad(k, dv)
@@ -1018,7 +1029,8 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
             leaf_dec()
         else:
             SIDE.defer(leaf_dec, dv, kind=2, lane=0)
-        du, du_sums = dec_dgrad(k, dv, bn_of(k + 1, True) if k < L else None, out_bf16=lvl_bf16(k))
+        if not fused:
+            du, du_sums = dec_dgrad(k, dv, bn_of(k + 1, True) if k < L else None, out_bf16=lvl_bf16(k))
         ds[k] = du
         skip_leaves(k)
     # ---- bottleneck: u_L = ggru(e_L) + skip_L --------------------------------------------
@@ -1041,8 +1053,16 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
     de_sums = None
     for k in range(L, 0, -1):
         mean, rstd = stats[k]
-        dy = ops.bn_act_bwd(de, ys[k], mean, rstd, P[f"bn{k}.weight"], P[f"bn{k}.bias"], rows, ch[k], Fk[k], True,
-                            training, G[f"bn{k}.weight"], G[f"bn{k}.bias"], dbias=G[f"conv{k}.bias"], sums=de_sums, out_bf16=dy_bf16)
+        fused = fuse_apply and k > 1 and de.dtype == torch.bfloat16 and de_sums is not None
+        if fused:
+            de_new, de_sums_new, dy = ops.conv_scatter2_bwd_in(
+                de, (ys[k], mean, rstd, P[f"bn{k}.weight"], P[f"bn{k}.bias"], de_sums, True, training, G[f"bn{k}.weight"], G[f"bn{k}.bias"],
+                     G[f"conv{k}.bias"]),
+                P[f"conv{k}.weight"], B, T, ch[k], Fk[k], ch[k - 1], KT=2, pad=1, out=de_pre[k - 1], accum=True, prec=dprec,
+                bn_bwd=bn_of(k - 1, False))
+        else:
+            dy = ops.bn_act_bwd(de, ys[k], mean, rstd, P[f"bn{k}.weight"], P[f"bn{k}.bias"], rows, ch[k], Fk[k], True,
+                                training, G[f"bn{k}.weight"], G[f"bn{k}.bias"], dbias=G[f"conv{k}.bias"], sums=de_sums, out_bf16=dy_bf16)
 
         def leaf_enc(dy=dy, k=k):
             ops.conv_wgrad(dy, es[k - 1], G[f"conv{k}.weight"], B, T, ch[k], Fk[k], ch[k - 1], Fk[k - 1], KT=2, S=2, pad=1, prec=prec)
@@ -1052,7 +1072,9 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
             leaf_enc()
         else:
             SIDE.run(leaf_enc, dy, lane=0)
-        if k > 1:
+        if fused:
+            de, de_sums = de_new, de_sums_new
+        elif k > 1:
             de, de_sums = split(ops.conv_scatter2(dy, P[f"conv{k}.weight"], None, B, T, ch[k], Fk[k], ch[k - 1], KT=2, pad=1,
                                                   out=de_pre[k - 1], accum=True, prec=dprec, bn_bwd=bn_of(k - 1, False)))
         if boundary is not None and k == cut + 1:

@@ -170,6 +170,43 @@ def conv_scatter2(g, w, bias, B, T, Cs, Fg, Cout, KT, pad, act=0, out=None, accu
     return out
 
 
+def _bwd_in_args(dout, bn_in):
+    y, mean, rstd, gamma, beta, sums, relu, training, dgamma, dbeta, dbias = bn_in
+    dv = torch.empty(y.shape, device=y.device, dtype=torch.bfloat16)
+    return dv, (_p(dout), _xdt(dout, "conv bnbwd_in dout"), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(sums), BN_STAT_REPLICAS,
+                1 if relu else 0, 1 if training else 0, _p(dv), _p(dgamma), _p(dbeta), _p(dbias))
+
+
+def conv_gather_bwd_in(dout, bn_in, w, B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout=0, out=None, accum=False, prec=None, bn_bwd=None,
+                       out_bf16=False):
+    """Data gradient with the BatchNorm(+ReLU) backward of its INPUT fused into the staging (cruse_conv_gather_bnbwd_in).
+    bn_in = (y_pre, mean, rstd, gamma, beta, sums [BN_STAT_REPLICAS][2*Cin], relu, training, dgamma, dbeta, dbias or None): `dout` is the gradient
+    wrt that BatchNorm's output.  Returns (out, output-side sums or None, dy [B,T,Cin,Fin] bf16 -- the weight gradient's operand)."""
+    if out is None:
+        out = torch.empty(B, T, Cout, Fout, device=dout.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    dv, head = _bwd_in_args(dout, bn_in)
+    sums, z = (ARENA.take(2 * Cout * BN_STAT_REPLICAS, dout.device) if bn_bwd is not None else (None, 0))
+    by, mean, rstd, gamma, beta, relu = bn_bwd if bn_bwd is not None else (None, None, None, None, None, False)
+    check(lib.cruse_conv_gather_bnbwd_in(*head, _p(w), _p(out), B, T, Cin, Fin, Cout, Fout, KT, S, pad, w_layout, 1 if accum else 0, conv_prec(prec),
+                                         _p(by), _p(mean), _p(rstd), _p(gamma), _p(beta), 1 if relu else 0, _p(sums), z,
+                                         _xdt(out, "conv_gather_bwd_in out"), _stream()))
+    return out, sums, dv
+
+
+def conv_scatter2_bwd_in(dout, bn_in, w, B, T, Cs, Fg, Cout, KT, pad, out=None, accum=False, prec=None, bn_bwd=None, out_bf16=False):
+    """As conv_gather_bwd_in for the stride-2 transposed form (cruse_conv_scatter2_bnbwd_in)."""
+    Fout = 2 * Fg
+    if out is None:
+        out = torch.empty(B, T, Cout, Fout, device=dout.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    dv, head = _bwd_in_args(dout, bn_in)
+    sums, z = (ARENA.take(2 * Cout * BN_STAT_REPLICAS, dout.device) if bn_bwd is not None else (None, 0))
+    by, mean, rstd, gamma, beta, relu = bn_bwd if bn_bwd is not None else (None, None, None, None, None, False)
+    check(lib.cruse_conv_scatter2_bnbwd_in(*head, _p(w), _p(out), B, T, Cs, Fg, Cout, Fout, KT, pad, 1 if accum else 0, conv_prec(prec),
+                                           _p(by), _p(mean), _p(rstd), _p(gamma), _p(beta), 1 if relu else 0, _p(sums), z,
+                                           _xdt(out, "conv_scatter2_bwd_in out"), _stream()))
+    return out, sums, dv
+
+
 class BnIn:
     """The BatchNorm2d(train) + ReLU a forward conv applies to its INPUT while staging it (cruse_conv_*_bnin): `y_pre` the layer's
     pre-BN tensor, `sums` its batch sums [BN_STAT_REPLICAS][2C], gamma / beta, count = rows * F; mean / rstd (+ running statistics)

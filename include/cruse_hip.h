@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CRUSE_ABI_VERSION 7
+#define CRUSE_ABI_VERSION 8
 
 enum {
     CRUSE_OK = 0,
@@ -169,6 +169,29 @@ int cruse_conv_scatter2_bnbwd(const float* g, const float* w, float* y, int B, i
                               int KT, int pad, int accum, int prec,
                               const float* bn_y, const float* mean, const float* rstd, const float* gamma, const float* beta,
                               int relu, double* sums, int zeroed, int x_dtype, int y_dtype, void* stream);
+
+/* (ABI 8) DATA-GRADIENT convolutions that also apply the BatchNorm2d(+ReLU) BACKWARD of their INPUT: dout is the gradient wrt the OUTPUT of
+ * the BatchNorm above the convolution being differentiated (cruse_net.py:139-142,149-152: conv -> BN -> ReLU), in_y that BatchNorm's pre-BN
+ * tensor [B,T,Cin,Fin], in_sums its backward batch sums [in_replicas][2*Cin] (sum g, sum g*xhat -- from cruse_conv_*_bnbwd or
+ * cruse_bn_act_bwd_reduce).  One call = cruse_bn_act_bwd_apply(dout -> dy_bf16; in_dgamma / in_dbeta / in_dbias += ...) followed by
+ * cruse_conv_gather / _scatter2 [_bnbwd] (dy_bf16 -> y): in the bf16 data-gradient mode with a bf16 dout the MFMA kernel forms dy while it
+ * stages its tiles (the arithmetic of cruse_bn_act_bwd_apply, rounded to bf16 once) and writes dy_bf16 [B,T,Cin,Fin] -- the operand of the weight
+ * gradient -- on the way: the separate pass over (dout, in_y), 132 MB and 40-95 us per level in the step, is gone.  Any other shape / dtype runs
+ * the two calls.  bn_y / mean / ... / sums: the OUTPUT-side statistics of cruse_conv_*_bnbwd (bn_y == NULL and sums == NULL: none). */
+int cruse_conv_gather_bnbwd_in(const void* dout, int dout_dtype, const float* in_y, const float* in_mean, const float* in_rstd,
+                               const float* in_gamma, const float* in_beta, const double* in_sums, int in_replicas, int in_relu,
+                               int in_training, void* dy_bf16, float* in_dgamma, float* in_dbeta, float* in_dbias,
+                               const float* w, void* y, int B, int T, int Cin, int Fin, int Cout, int Fout, int KT, int S, int pad,
+                               int w_layout, int accum, int prec,
+                               const float* bn_y, const float* mean, const float* rstd, const float* gamma, const float* beta, int relu,
+                               double* sums, int zeroed, int y_dtype, void* stream);
+int cruse_conv_scatter2_bnbwd_in(const void* dout, int dout_dtype, const float* in_y, const float* in_mean, const float* in_rstd,
+                                 const float* in_gamma, const float* in_beta, const double* in_sums, int in_replicas, int in_relu,
+                                 int in_training, void* dy_bf16, float* in_dgamma, float* in_dbeta, float* in_dbias,
+                                 const float* w, void* y, int B, int T, int Cs, int Fg, int Cout, int Fout, int KT, int pad, int accum,
+                                 int prec,
+                                 const float* bn_y, const float* mean, const float* rstd, const float* gamma, const float* beta, int relu,
+                                 double* sums, int zeroed, int y_dtype, void* stream);
 
 /* profiling aid: with cruse_set_option("cm_dbg", 1) workgroup 0 of an MFMA convolution launch stamps s_memtime at its phase
  * boundaries; this copies the sums of the LAST such launch to out8 (host memory, 8 values: prologue, tile staging incl. the wait

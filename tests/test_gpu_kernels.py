@@ -931,6 +931,70 @@ def test_gru_bwd_writes_gate_gradients_itself(ops, H, G, B, T):
         assert rel_l2(a_, b_) < 1e-5
 
 
+@pytest.mark.parametrize("form,dout_bf16", [("gather", True), ("scatter", True), ("scatter_mt4", True), ("gather", False)])
+def test_conv_data_gradient_with_fused_batchnorm_backward_input(ops, form, dout_bf16):
+    """cruse_conv_*_bnbwd_in (ABI 8): one call == cruse_bn_act_bwd_apply(dout -> dy bf16, parameter gradients) + the data-gradient conv on
+    that dy, with the output-side BatchNorm sums.  In the bf16 data-gradient mode with a bf16 dout the MFMA kernel forms dy while staging:
+    the dy it writes must be the separate pass's bits (same arithmetic, one rounding), hence the same conv output and sums; a shape the fused
+    kernel declines (64-row tiles) and an f32 dout run the two calls."""
+    torch.manual_seed(3)
+    B, T = 3, 21
+    if form == "gather":                                   # decoder data gradient: dv [B,T,16,40] -> du [B,T,32,20]
+        Ci, Fi, Co, Fo = 16, 40, 32, 20
+        w = (0.2 * torch.randn(Co, Ci, 1, 3)).cuda()
+    elif form == "scatter":                                # encoder data gradient: dy [B,T,32,20] -> de [B,T,16,40], accumulating
+        Ci, Fi, Co, Fo = 32, 20, 16, 40
+        w = (0.2 * torch.randn(Ci, Co, 2, 3)).cuda()
+    else:                                                  # dy [B,T,16,40] -> de [B,T,... 64 output channels: declined by the fused kernel
+        Ci, Fi, Co, Fo = 16, 40, 64, 80
+        w = (0.2 * torch.randn(Ci, Co, 2, 3)).cuda()
+    rows = B * T
+    dout32 = torch.randn(B, T, Ci, Fi).cuda()
+    dout = dout32.bfloat16() if dout_bf16 else dout32
+    y_in = torch.randn(B, T, Ci, Fi).cuda()
+    mean = y_in.mean(dim=(0, 1, 3)).contiguous(); rstd = (1.0 / (y_in.var(dim=(0, 1, 3), unbiased=False) + 1e-5).sqrt()).contiguous()
+    gamma = (torch.rand(Ci) + 0.5).cuda(); beta = (0.1 * torch.randn(Ci)).cuda()
+    # backward sums of the input BatchNorm: replica 0 holds them (as after cruse_bn_act_bwd_reduce)
+    xh = (y_in - mean.view(1, 1, -1, 1)) * rstd.view(1, 1, -1, 1)
+    g = dout.float() * ((xh * gamma.view(1, 1, -1, 1) + beta.view(1, 1, -1, 1)) > 0)
+    sums = torch.zeros(ops.BN_STAT_REPLICAS, 2 * Ci, dtype=torch.float64).cuda()
+    sums[0, :Ci] = g.double().sum(dim=(0, 1, 3)); sums[0, Ci:] = (g.double() * xh.double()).sum(dim=(0, 1, 3))
+    # output-side BatchNorm (the level the data gradient feeds)
+    by = torch.randn(B, T, Co, Fo).cuda()
+    om = by.mean(dim=(0, 1, 3)).contiguous(); orr = (1.0 / (by.var(dim=(0, 1, 3), unbiased=False) + 1e-5).sqrt()).contiguous()
+    og = (torch.rand(Co) + 0.5).cuda(); ob = (0.1 * torch.randn(Co)).cuda()
+    bnb = (by, om, orr, og, ob, True)
+    base = torch.randn(B, T, Co, Fo).cuda()
+    res = {}
+    for fused in (False, True):
+        dg = torch.zeros(Ci).cuda(); db = torch.zeros(Ci).cuda()
+        bn_in = (y_in, mean, rstd, gamma, beta, sums, True, True, dg, db, None)
+        if fused:
+            if form == "gather":
+                out, osums, dy = ops.conv_gather_bwd_in(dout, bn_in, w, B, T, Ci, Fi, Co, Fo, KT=1, S=2, pad=0, prec=ops.PREC_BF16, bn_bwd=bnb)
+            else:
+                out, osums, dy = ops.conv_scatter2_bwd_in(dout, bn_in, w, B, T, Ci, Fi, Co, KT=2, pad=1, out=base.clone(), accum=True,
+                                                          prec=ops.PREC_BF16, bn_bwd=bnb)
+        else:
+            dy = ops.bn_act_bwd(dout, y_in, mean, rstd, gamma, beta, rows, Ci, Fi, True, True, dg, db, sums=sums, out_bf16=True)
+            if form == "gather":
+                out, osums = ops.conv_gather(dy, w, None, B, T, Ci, Fi, Co, Fo, KT=1, S=2, pad=0, prec=ops.PREC_BF16, bn_bwd=bnb)
+            else:
+                out, osums = ops.conv_scatter2(dy, w, None, B, T, Ci, Fi, Co, KT=2, pad=1, out=base.clone(), accum=True, prec=ops.PREC_BF16,
+                                               bn_bwd=bnb)
+        torch.cuda.synchronize()
+        res[fused] = (dy.float().clone(), out.clone(), osums.view(ops.BN_STAT_REPLICAS, -1).sum(0).clone(), dg.clone(), db.clone())
+    assert torch.equal(res[True][0], res[False][0]), "dy written while staging differs from the separate pass"
+    assert torch.equal(res[True][1], res[False][1])
+    assert rel_l2(res[True][2], res[False][2]) < 1e-6
+    assert torch.equal(res[True][3], res[False][3]) and torch.equal(res[True][4], res[False][4])
+    # and against the closed form of the BatchNorm backward
+    cnt = rows * Fi
+    want = gamma.view(1, 1, -1, 1) * rstd.view(1, 1, -1, 1) * (g - (sums[0, :Ci] / cnt).float().view(1, 1, -1, 1)
+                                                                 - xh * (sums[0, Ci:] / cnt).float().view(1, 1, -1, 1))
+    assert rel_l2(res[True][0], want) < 5e-3               # (bf16 storage)
+
+
 @pytest.mark.parametrize("B,T", [(9, 12), (3, 1), (5, 2), (8, 3), (20, 37), (64, 60)])
 def test_gru_register_direct_sweeps_and_all_gather_backward(ops, B, T):
     """Round-4 recurrence kernels at Hg = 640 (bf16 mode).  Forward: the register-direct sweep (gru_fwd_rd, default) gives the bits
