@@ -23,7 +23,9 @@ class EngineConfig:
     defer_mask: int = 15            # leaves queued for the next recurrence launch: 1 skip convs (fwd), 2 decoder weight gradients,
                                     # 4 GRU weight gradients, 8 skip-conv backward leaves
     inline_mask: int = 8            # backward leaves kept on the main stream: 1 skip dgrads, 2 skip wgrads, 4 decoder wgrads,
-                                    # 8 / 16 the level-1 / level-2 encoder wgrads (8: -0.025 ms; the others measured slower)
+                                    # 8 << (k - 1) the level-k encoder wgrad (8: -0.025 ms; the others measured slower or equal), 128 << (k - 1)
+                                    # the level-k encoder wgrad on the main stream AFTER its serial chain (r4: the side queue ends ~190 us after
+                                    # the main stream's last kernel, but moving its tail over buys < 0.02 ms: both streams are bound by the same HBM)
     early_t: int = 2                # dW operand transposes: 0 inside each layer's leaf, 1 layer 1's beside the first backward
                                     # recurrence, 2 all four in the forward pass (6.08 vs 6.12 ms)
     fuse_bn_stats: bool = True      # BatchNorm batch sums in the producing conv's epilogue (False: separate bn_stats pass)

@@ -1051,6 +1051,7 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
     cut = max(L // 2, 1)                          # levels L..cut+1, [bucket 1 final], levels cut..1
     # ---- encoder levels L..1: de_k already holds the skip path ------------------------------
     de_sums = None
+    late_main = []
     for k in range(L, 0, -1):
         mean, rstd = stats[k]
         fused = fuse_apply and k > 1 and de.dtype == torch.bfloat16 and de_sums is not None
@@ -1068,8 +1069,10 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
             ops.conv_wgrad(dy, es[k - 1], G[f"conv{k}.weight"], B, T, ch[k], Fk[k], ch[k - 1], Fk[k - 1], KT=2, S=2, pad=1, prec=prec)
         # the optimizer step waits for the side queue, not for the main stream: the LAST levels' weight gradients run on
         # the main stream itself (_INLINE bits 3, 4: level 1, level 2), beside what is still queued on the side
-        if (k == 1 and _INLINE & 8) or (k == 2 and _INLINE & 16):
+        if _INLINE & (8 << (k - 1)):                       # bits 3.. = levels 1..
             leaf_enc()
+        elif _INLINE & (128 << (k - 1)):                   # bits 7.. = levels 1..: on the main stream too, but AFTER its serial chain
+            late_main.append(leaf_enc)                     # (the side queue, not the main stream, is what the optimizer waits for)
         else:
             SIDE.run(leaf_enc, dy, lane=0)
         if fused:
@@ -1082,6 +1085,8 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
     dx = None
     if need_dx:
         dx = ops.conv_scatter2(dy, P["conv1.weight"], None, B, T, ch[1], Fk[1], ch[0], KT=2, pad=1, prec=dprec)
+    for fn in late_main:
+        fn()
     SIDE.join()
     return dx
 
