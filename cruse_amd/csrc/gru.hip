@@ -2079,7 +2079,7 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* pane
             rc = dispatch_bwd_w16(a, grid, s);
         } else if (rs_form) {
             // (the tag-free kernel's panels are half the size of the reduce-scatter kernel's: the same regions hold them)
-            if (bwd_tf_eligible(pl.Bg, Hg, prec)) { a.poll_delay = cruse_opt("gru_poll_bwd", (Hg == 640 && cruse_opt("gru_bwd_ag", 2) != 0) ? 5 : 10); a.poll_stagger = cruse_opt("gru_stag_bwd", 0); rc = dispatch_bwd_tf(a, grid, s); }
+            if (bwd_tf_eligible(pl.Bg, Hg, prec)) { a.poll_delay = cruse_opt("gru_poll_bwd", cruse_opt("gru_bwd_ag", 2) != 0 ? (Hg == 640 ? 5 : 7) : 10); a.poll_stagger = cruse_opt("gru_stag_bwd", 0); rc = dispatch_bwd_tf(a, grid, s); }
             else rc = dispatch_bwd_rs(a, grid, s);
         } else {
             if (prec == CRUSE_PREC_F32) rc = dispatch_bwd<CRUSE_PREC_F32>(a, grid, lds, s);

@@ -946,12 +946,21 @@ __global__ __launch_bounds__(320) void gru_bwd_ag_kernel(GruArgs a) {
     constexpr unsigned pub_gs = RD ? (unsigned)(Hg / 8) * 128u : (unsigned)Hg * 2u;
     const bool pub_lane = act && !(u & 1);
     const int fb_off = (lane & 7) * LD + (lane >> 4) * 8;                 // (columns 8..15 re-read clips 0..7)
-    static_assert(!RD || NKS % 4 == 0, "register-direct sweep: every wave has all its k-steps");
+    // (NKS % 4 != 0 -- Hg = 160, 320: the last waves' missing k-steps re-read k-step NKS - 1 (valid tags, finite data) against zero weights)
     // RD panel layout: CLIP-MINOR -- [k chunk of 8 elements][clip][8] -- so that the 8 clips of one (k-step, lane group) are one 128-byte
     // line and a wave's load instruction is 512 contiguous bytes (clip-major rows made every 16-lane pass touch 8 lines: 4500-cycle sweeps)
     const unsigned rd_v = (unsigned)(((wv * 4 + (lane >> 4)) * 8 + (lane & 7)) * 16);         // + i * 2048 bytes: k-step wv + 4 i
     // (columns 8..15: the odd k-step of the pair, + 2048; in the last, half-empty pair they re-read the even one)
     const unsigned rd_v2 = rd_v + (((lane >> 3) & 1) ? 2048u : 0u), rd_v2l = rd_v;
+    constexpr int NL_ = (NKW + 1) / 2;
+    unsigned rd_o[(RD && NKS % 4 != 0) ? NL_ : 1];          // per-load byte offsets where k-steps have to be clamped
+    if constexpr (RD && NKS % 4 != 0) {
+#pragma unroll
+        for (int j = 0; j < NL_; ++j) {
+            const int i = min(2 * j + ((lane >> 3) & 1), NKW - 1);
+            rd_o[j] = (unsigned)(((min(wv + 4 * i, NKS - 1) * 4 + (lane >> 4)) * 8 + (lane & 7)) * 16);
+        }
+    }
     const bool rd_ok = (lane & 7) < nb;                                  // (columns 8..15 re-read clips 0..7; masking them off made every load a branch: slower)
 
     float dh = 0.f, dd = 0.f, zz = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;    // operands of the current step (time s)
@@ -978,8 +987,10 @@ __global__ __launch_bounds__(320) void gru_bwd_ag_kernel(GruArgs a) {
             for (int i = 0; i < a.poll_delay; ++i) __builtin_amdgcn_s_sleep(1);     // (see poll_delay)
             for (;;) {
 #pragma unroll
-                for (int j = 0; j < NL; ++j)
-                    g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (2 * j + 1 < NKW || j + 1 < NL) ? rd_v2 : rd_v2l, soff + (unsigned)(j * 4096), 16);
+                for (int j = 0; j < NL; ++j) {
+                    if constexpr (NKS % 4 != 0) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, rd_o[j], soff, 16);
+                    else g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (2 * j + 1 < NKW || j + 1 < NL) ? rd_v2 : rd_v2l, soff + (unsigned)(j * 4096), 16);
+                }
                 unsigned bad;
                 if (expect1) {                                 // every tag bit set <=> the AND of all dwords has both
                     unsigned n = 0xffffffffu;
@@ -1170,19 +1181,23 @@ size_t tf_bwd_bytes_per_parity(int Hg) { const size_t P = Hg / 32; return P * 8 
 size_t bwd_ag_lds(int Hg) { return (size_t)8 * (3 * Hg + 8) * 2 + (size_t)4 * 2 * RED_TS * 4; }
 
 int dispatch_bwd_tf(const GruArgs& a, int grid, hipStream_t s) {
-    // all-gather form (option gru_bwd_ag, default on at Hg = 640): see gru_bwd_ag_kernel
-    if (a.Hg == 640 && cruse_opt("gru_bwd_ag", 2) != 0) {
-        if (cruse_opt("gru_bwd_ag", 2) == 2) {          // register-direct sweep (no LDS image)
-            if (a.dbg == 32) return launch_one(gru_bwd_ag_kernel<20, true, 0, true>, a, grid, bwd_ag_lds(640), s, "gru_seq_bwd", 320);
-            if (a.dgi == nullptr) return launch_one(gru_bwd_ag_kernel<20, false, 0, true>, a, grid, bwd_ag_lds(640), s, "gru_seq_bwd", 320);
-            if (a.dg_slabs == 4) return launch_one(gru_bwd_ag_kernel<20, false, 4, true>, a, grid, bwd_ag_lds(640), s, "gru_seq_bwd", 320);
-            return launch_one(gru_bwd_ag_kernel<20, false, 3, true>, a, grid, bwd_ag_lds(640), s, "gru_seq_bwd", 320);
-        }
-        if (a.dbg == 32) return launch_one(gru_bwd_ag_kernel<20, true, 0>, a, grid, bwd_ag_lds(640), s, "gru_seq_bwd", 320);
-        if (a.dgi == nullptr) return launch_one(gru_bwd_ag_kernel<20, false, 0>, a, grid, bwd_ag_lds(640), s, "gru_seq_bwd", 320);
-        if (a.dg_slabs == 4) return launch_one(gru_bwd_ag_kernel<20, false, 4>, a, grid, bwd_ag_lds(640), s, "gru_seq_bwd", 320);
-        return launch_one(gru_bwd_ag_kernel<20, false, 3>, a, grid, bwd_ag_lds(640), s, "gru_seq_bwd", 320);
+    // all-gather form (option gru_bwd_ag: 2 register-direct sweep -- the default --, 1 LDS image (Hg = 640 only), 0 the reduce-scatter kernel)
+    const int ag = cruse_opt("gru_bwd_ag", 2);
+#define CRUSE_AG_LAUNCH(PV, RDV)                                                                                                        \
+    do {                                                                                                                                \
+        if (a.dbg == 32) return launch_one(gru_bwd_ag_kernel<PV, true, 0, RDV>, a, grid, bwd_ag_lds(32 * PV), s, "gru_seq_bwd", 320);    \
+        if (a.dgi == nullptr) return launch_one(gru_bwd_ag_kernel<PV, false, 0, RDV>, a, grid, bwd_ag_lds(32 * PV), s, "gru_seq_bwd", 320); \
+        if (a.dg_slabs == 4) return launch_one(gru_bwd_ag_kernel<PV, false, 4, RDV>, a, grid, bwd_ag_lds(32 * PV), s, "gru_seq_bwd", 320); \
+        return launch_one(gru_bwd_ag_kernel<PV, false, 3, RDV>, a, grid, bwd_ag_lds(32 * PV), s, "gru_seq_bwd", 320);                    \
+    } while (0)
+    if (ag == 2) {
+        if (a.Hg == 640) CRUSE_AG_LAUNCH(20, true);
+        if (a.Hg == 320) CRUSE_AG_LAUNCH(10, true);
+        if (a.Hg == 160) CRUSE_AG_LAUNCH(5, true);
+    } else if (ag == 1 && a.Hg == 640) {
+        CRUSE_AG_LAUNCH(20, false);
     }
+#undef CRUSE_AG_LAUNCH
     if (a.dbg == 32 && a.Hg == 640) return a.poll_stagger > 0 ? launch_one(gru_bwd_tf_kernel<20, true, true>, a, grid, 0, s, "gru_seq_bwd", 320)
                                                                : launch_one(gru_bwd_tf_kernel<20, true>, a, grid, 0, s, "gru_seq_bwd", 320);
     if (a.poll_stagger > 0) {

@@ -995,6 +995,35 @@ def test_conv_data_gradient_with_fused_batchnorm_backward_input(ops, form, dout_
     assert rel_l2(res[True][0], want) < 5e-3               # (bf16 storage)
 
 
+@pytest.mark.parametrize("G,B,T", [(4, 9, 12), (4, 3, 1), (4, 5, 2), (2, 20, 37), (2, 8, 3), (4, 64, 60)])
+def test_gru_all_gather_backward_on_grouped_widths(ops, G, B, T):
+    """The all-gather backward kernel with the register-direct sweep at Hg = 160 / 320 (3 Hg / 32 k-steps do not divide over the four
+    waves: the missing ones re-read the last k-step against zero weights): against the reduce-scatter kernel and the exact-f32 kernels,
+    with the gate gradients written by the loader wave."""
+    H = 640; Hg = H // G
+    torch.manual_seed(G * 1000 + B + T)
+    gi = (0.5 * torch.randn(B, T, 3 * H)).cuda()
+    w = [(torch.randn(3 * Hg, Hg) / Hg ** 0.5).cuda() for _ in range(G)]; b = [(0.1 * torch.randn(3 * Hg)).cuda() for _ in range(G)]
+    dout = (2.0 * torch.randn(B, T, H)).cuda()
+    f32 = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "f32")
+    ref = ops.gru_seq_bwd(dout, w, f32[1], f32[3], B, T, G, Hg, "f32")
+    f = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16")
+    out = {}
+    for ag in (0, 2):
+        with ops.options(gru_bwd_ag=ag):
+            out[ag] = ops.gru_seq_bwd(dout, w, f[1], f[3], B, T, G, Hg, "bf16", an=f[2], want_dgi=True)
+            plain = ops.gru_seq_bwd(dout, w, f[1], f[3], B, T, G, Hg, "bf16")
+            torch.cuda.synchronize()
+            assert ops.gru_status() == 0 and torch.equal(plain, out[ag][0])
+    assert torch.isfinite(out[2][0]).all() and rel_l2(out[2][0], out[0][0]) < 5e-3
+    if T > 1:
+        assert rel_l2(out[2][0], ref) < 1e-2 and rel_l2(out[2][0], ref) <= 1.05 * rel_l2(out[0][0], ref) + 1e-6
+    rows = B * T
+    db_i = [torch.zeros(3 * Hg).cuda() for _ in range(G)]; db_h = [torch.zeros(3 * Hg).cuda() for _ in range(G)]
+    dgi_ref, _, _ = ops.gru_gate_grads_bf16(out[2][0], f[1], f[2], rows, G, Hg, db_i, db_h)
+    assert torch.equal(out[2][1].view(-1), dgi_ref.view(-1))
+
+
 @pytest.mark.parametrize("B,T", [(9, 12), (3, 1), (5, 2), (8, 3), (20, 37), (64, 60)])
 def test_gru_register_direct_sweeps_and_all_gather_backward(ops, B, T):
     """Round-4 recurrence kernels at Hg = 640 (bf16 mode).  Forward: the register-direct sweep (gru_fwd_rd, default) gives the bits
