@@ -423,6 +423,11 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
     for (int tile = blockIdx.x; tile < a.B * ntile; tile += gridDim.x) {
         const int b = tile / ntile;
         const int t0 = (tile - b * ntile) * TFM;
+        const int cfo = a.Cout * a.Fout;
+        const long long tbase = ((long long)b * a.T + t0) * cfo;          // this tile's first output row (uniform)
+        float* const yt = a.y + tbase;
+        __bf16* const ybt = yb + tbase;
+        const float* const bnyt = a.bn_y + tbase;                          // (dereferenced only where a.bn_y != null)
         __syncthreads();                                   // previous tile's reads of xl are done
         if constexpr (CF) {
             __bf16* const cpy = (INB && a.in_copy) ? reinterpret_cast<__bf16*>(a.in_copy) + ((long long)b * a.T + (t0 - a.halo_lo)) * rowlen : nullptr;
@@ -572,35 +577,38 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
         float old_c[EPI == 2 ? MT : 1][4], by_c[EPI == 2 ? MT : 1][4], old_n[EPI == 2 ? MT : 1][4], by_n[EPI == 2 ? MT : 1][4];
         // swp: output addressing of an N-tile for this lane -- positions 4*(lane>>4) + e of channel (lane & 15) + 16*mt; the
         // positions of a vector (4, or 2 + 2) are consecutive bins of one frame
-        auto out_pos = [&](int nt_, long long (&off)[2], bool (&okt)[2]) {
+        // (32-bit element offsets inside the tile's output rows -- yt / ybt / bnyt below: the 64-bit products per N-tile were a third of
+        //  the ~165 instructions between an N-tile's last MFMA and the next one's first, which is 70 % of an N-tile's instruction count)
+        auto out_pos = [&](int nt_, int (&off)[2], bool (&okt)[2]) {
             const int p0 = nt_ * 16 + (lane >> 4) * 4;     // (one class in the gather forms)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
+                if (h == 1 && vw == 4) { okt[1] = okt[0]; off[1] = off[0] + 2; continue; }     // (one 4-bin vector: the same frame)
                 const int p_ = p0 + 2 * h;
                 const int tl_ = (int)(((float)p_ + 0.5f) * inv_mpos);
                 const int m_ = p_ - tl_ * Mpos;
                 okt[h] = t0 + tl_ < a.T;
-                off[h] = (((long long)b * a.T + t0 + tl_) * a.Cout + (lane & 15)) * a.Fout + m_ + par0;
+                off[h] = tl_ * cfo + (lane & 15) * a.Fout + m_ + par0;
             }
         };
         auto aux_load_swp = [&](int nt_, float (&o)[EPI == 2 ? MT : 1][4], float (&y_)[EPI == 2 ? MT : 1][4]) {
-            long long off[2];
+            int off[2];
             bool okt[2];
             out_pos(nt_, off, okt);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const bool okc = mt * 16 + (lane & 15) < a.Cout;
-                const long long cm = (long long)mt * 16 * a.Fout;
+                const int cm = mt * 16 * a.Fout;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const bool ok = okc && okt[h];
                     const float2 z2 = make_float2(0.f, 0.f);
                     float2 ov = z2;
                     if (ok && a.accum) {
-                        if constexpr (YB) { const bf16x2_ t2 = *reinterpret_cast<const bf16x2_*>(yb + off[h] + cm); ov = make_float2((float)t2[0], (float)t2[1]); }
-                        else ov = *reinterpret_cast<const float2*>(a.y + off[h] + cm);
+                        if constexpr (YB) { const bf16x2_ t2 = *reinterpret_cast<const bf16x2_*>(ybt + off[h] + cm); ov = make_float2((float)t2[0], (float)t2[1]); }
+                        else ov = *reinterpret_cast<const float2*>(yt + off[h] + cm);
                     }
-                    const float2 yv = (ok && a.bn_y != nullptr) ? *reinterpret_cast<const float2*>(a.bn_y + off[h] + cm) : z2;
+                    const float2 yv = (ok && a.bn_y != nullptr) ? *reinterpret_cast<const float2*>(bnyt + off[h] + cm) : z2;
                     o[mt][2 * h] = ov.x; o[mt][2 * h + 1] = ov.y;
                     y_[mt][2 * h] = yv.x; y_[mt][2 * h + 1] = yv.y;
                 }
@@ -646,7 +654,7 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
                 const int m = p - tl * Mpos;
                 const int rowbase = (tl + a.halo_lo) * rowlen + a.S * m;
                 const int rowbase_cf = ((tl + a.halo_lo) * FP + a.S * m + 1) << lg_nch;
-                long long off[2];
+                int off[2];
                 bool okt[2];
                 {
                     const int p0 = nt * 16 + (lane >> 4) * 4;
@@ -656,7 +664,7 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
                         const int tl_ = (int)(((float)p_ + 0.5f) * inv_mpos);
                         const int m_ = p_ - tl_ * Mpos;
                         okt[h] = t0 + tl_ < a.T;
-                        off[h] = (((long long)b * a.T + t0 + tl_) * a.Cout + (lane & 15)) * a.Fout + 2 * m_;
+                        off[h] = tl_ * cfo + (lane & 15) * a.Fout + 2 * m_;
                     }
                 }
                 float4 oldv[EPI == 2 ? MT : 1][2], byv[EPI == 2 ? MT : 1][2];
@@ -664,20 +672,20 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         const bool okc = mt * 16 + (lane & 15) < a.Cout;
-                        const long long cm = (long long)mt * 16 * a.Fout;
+                        const int cm = mt * 16 * a.Fout;
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
                             oldv[mt][h] = z4;
                             if (okc && okt[h] && a.accum) {
                                 if constexpr (YB) {
-                                    const bf16x4_ t4 = *reinterpret_cast<const bf16x4_*>(yb + off[h] + cm);
+                                    const bf16x4_ t4 = *reinterpret_cast<const bf16x4_*>(ybt + off[h] + cm);
                                     oldv[mt][h] = make_float4((float)t4[0], (float)t4[1], (float)t4[2], (float)t4[3]);
                                 } else {
-                                    oldv[mt][h] = *reinterpret_cast<const float4*>(a.y + off[h] + cm);
+                                    oldv[mt][h] = *reinterpret_cast<const float4*>(yt + off[h] + cm);
                                 }
                             }
-                            byv[mt][h] = (okc && okt[h] && a.bn_y != nullptr) ? *reinterpret_cast<const float4*>(a.bn_y + off[h] + cm) : z4;
+                            byv[mt][h] = (okc && okt[h] && a.bn_y != nullptr) ? *reinterpret_cast<const float4*>(bnyt + off[h] + cm) : z4;
                         }
                     }
                 }
@@ -727,7 +735,7 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
                     const int co = mt * 16 + (lane & 15);
                     if (co < a.Cout) {
                         const float bq = s_bias[co];
-                        const long long cm = (long long)mt * 16 * a.Fout;
+                        const int cm = mt * 16 * a.Fout;
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             float v[4] = {acc2[ce][mt][2 * h] + bq, acc2[cod][mt][2 * h] + bq, acc2[ce][mt][2 * h + 1] + bq, acc2[cod][mt][2 * h + 1] + bq};
@@ -736,9 +744,9 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
                                 if constexpr (YB) {
                                     bf16x4_ t4;
                                     t4[0] = (__bf16)v[0]; t4[1] = (__bf16)v[1]; t4[2] = (__bf16)v[2]; t4[3] = (__bf16)v[3];
-                                    *reinterpret_cast<bf16x4_*>(yb + off[h] + cm) = t4;
+                                    *reinterpret_cast<bf16x4_*>(ybt + off[h] + cm) = t4;
                                 } else {
-                                    *reinterpret_cast<float4*>(a.y + off[h] + cm) = make_float4(v[0], v[1], v[2], v[3]);
+                                    *reinterpret_cast<float4*>(yt + off[h] + cm) = make_float4(v[0], v[1], v[2], v[3]);
                                 }
                                 if constexpr (EPI == 1) {
 #pragma unroll
@@ -812,7 +820,7 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
             }
             if (tdbg) { tq1 = __builtin_amdgcn_s_memtime(); tsum[2] += tq1 - tq0; tq0 = tq1; tsum[5] += 1; }
             if constexpr (SW) {
-                long long off[2];
+                int off[2];
                 bool okt[2];
                 out_pos(nt, off, okt);
 #pragma unroll
@@ -820,7 +828,7 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
                     const int co = mt * 16 + (lane & 15);
                     if (co < a.Cout) {
                         const float bq = s_bias[co];
-                        const long long cm = (long long)mt * 16 * a.Fout;
+                        const int cm = mt * 16 * a.Fout;
                         float v[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -834,16 +842,16 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
                             if (vw == 4) {
                                 bf16x4_ t4;
                                 t4[0] = t0[0]; t4[1] = t0[1]; t4[2] = t1[0]; t4[3] = t1[1];
-                                if (okt[0]) *reinterpret_cast<bf16x4_*>(yb + off[0] + cm) = t4;
+                                if (okt[0]) *reinterpret_cast<bf16x4_*>(ybt + off[0] + cm) = t4;
                             } else {
-                                if (okt[0]) *reinterpret_cast<bf16x2_*>(yb + off[0] + cm) = t0;
-                                if (okt[1]) *reinterpret_cast<bf16x2_*>(yb + off[1] + cm) = t1;
+                                if (okt[0]) *reinterpret_cast<bf16x2_*>(ybt + off[0] + cm) = t0;
+                                if (okt[1]) *reinterpret_cast<bf16x2_*>(ybt + off[1] + cm) = t1;
                             }
                         } else if (vw == 4) {
-                            if (okt[0]) *reinterpret_cast<float4*>(a.y + off[0] + cm) = make_float4(v[0], v[1], v[2], v[3]);
+                            if (okt[0]) *reinterpret_cast<float4*>(yt + off[0] + cm) = make_float4(v[0], v[1], v[2], v[3]);
                         } else {
-                            if (okt[0]) *reinterpret_cast<float2*>(a.y + off[0] + cm) = make_float2(v[0], v[1]);
-                            if (okt[1]) *reinterpret_cast<float2*>(a.y + off[1] + cm) = make_float2(v[2], v[3]);
+                            if (okt[0]) *reinterpret_cast<float2*>(yt + off[0] + cm) = make_float2(v[0], v[1]);
+                            if (okt[1]) *reinterpret_cast<float2*>(yt + off[1] + cm) = make_float2(v[2], v[3]);
                         }
                         if constexpr (EPI == 1) {
 #pragma unroll
