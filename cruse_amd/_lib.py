@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcruse_hip.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16 = 0, 1, 2, 3
 PREC_BY_NAME = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "f16": PREC_F16}
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
@@ -46,12 +46,14 @@ SIGNATURES = {
     "cruse_col_sum": ("pqiipp", "i"),
     "cruse_bn_stats": ("pqiipip", "i"),
     "cruse_bn_finalize_act_fwd": ("ppiqffpppppppppqiiip", "i"),
+    "cruse_bn_finalize_act_fwd_c": ("ppiqffpppppippppqiiip", "i"),
     "cruse_bn_finalize": ("pqiffppppp", "i"),
     "cruse_bn_eval_stats": ("ppifppp", "i"),
     "cruse_bn_act_fwd": ("pppppppqiiip", "i"),
     "cruse_bn_act_bwd_reduce": ("ppppppqiiipip", "i"),
     "cruse_bn_act_bwd_apply": ("pppppppiqiiiiipipppp", "i"),
     "cruse_ln_fwd": ("ppppppppqiifiqqp", "i"),
+    "cruse_ln_fwd_c": ("ppppppippqiifiqqp", "i"),
     "cruse_ln_bwd": ("pppppqiipppp", "i"),
     "cruse_gemm": ("iiiiipipipipiiiip", "i"),
     "cruse_gemm_bf16_nt": ("iiipqqpqqpqpiip", "i"),
@@ -63,6 +65,8 @@ SIGNATURES = {
     "cruse_cast_bf16": ("ppqp", "i"),
     "cruse_transpose_bf16": ("pqiqpqip", "i"),
     "cruse_ktile_bf16": ("piiqppp", "i"),
+    "cruse_ktile_f16": ("piiqpp", "i"),
+    "cruse_gemm_f16_nt": ("iiipqqpqqpqpp", "i"),
     "cruse_cast_bf16_split": ("pppqp", "i"),
     "cruse_gemm_bf16x3_nt": ("iiippqqppqqpqpip", "i"),
     "cruse_gru_ws_bytes": ("iii", "z"),

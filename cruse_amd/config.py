@@ -34,6 +34,10 @@ class EngineConfig:
     fuse_cast: bool = True          # the gate GEMMs' bf16 operand copies written by the producing BatchNorm / LayerNorm kernel
     gi_x3: Optional[int] = None     # forward gate projections: bit 0 / 1 = W_ih low-plane pass on layer 1 / 2, bit 2 = also split x
                                     # (None: 7 for Hg <= 320, else 3)
+    gi_f16: int = 2                 # forward gate projections as ONE pass on IEEE-f16 operands (cruse_gemm_f16_nt; with g = 1 the BatchNorm /
+                                    # LayerNorm producers write the f16 operand copies) instead of bf16 x with W_ih hi / lo planes (gi_x3): both
+                                    # operands carry 11 significant bits -- enhanced-spectrum rel-L2 at T = 401 4.6e-4 -> 3.8e-4 (closed-form init),
+                                    # 3.6e-4 -> 1.6e-4 (random init) -- and the step loses the low-plane pass (4.85 -> 4.76 ms, r4).  False: gi_x3 form
     gi_bf16: bool = False           # the gate pre-activations gi = x W_ih^T + b_ih stored as bf16 rows (f32 accumulation, one rounding;
                                     # the recurrence widens them on load).  OPT-IN: -0.4 GB per step but time-neutral
                                     # (5.71 vs 5.72 ms: the projection GEMM is not bound by its store), and the forward error of the
@@ -68,7 +72,7 @@ class EngineConfig:
             "early_t": ("CRUSE_EARLY_T", int), "fuse_bn_stats": ("CRUSE_FUSE_BN_STATS", lambda v: v != "0"),
             "fuse_dgi": ("CRUSE_FUSE_DGI", lambda v: v == "1"),
             "fuse_bn_bwd_stats": ("CRUSE_FUSE_BN_BWD", lambda v: v != "0"), "fuse_cast": ("CRUSE_FUSE_CAST", lambda v: v == "1"),
-            "gi_x3": ("CRUSE_GI_X3", int), "gi_bf16": ("CRUSE_GI_BF16", lambda v: v == "1"), "dw_xcdk": ("CRUSE_DW_XCDK", int), "conv_bwd_x3": ("CRUSE_CONV_BWD_X3", lambda v: v == "1"),
+            "gi_x3": ("CRUSE_GI_X3", int), "gi_f16": ("CRUSE_GI_F16", int), "gi_bf16": ("CRUSE_GI_BF16", lambda v: v == "1"), "dw_xcdk": ("CRUSE_DW_XCDK", int), "conv_bwd_x3": ("CRUSE_CONV_BWD_X3", lambda v: v == "1"),
             "dw_tn": ("CRUSE_DW_TN", lambda v: v == "1"), "dw_slabs": ("CRUSE_DW_SLABS", lambda v: v != "0"), "fwd_chunks": ("CRUSE_FWD_CHUNKS", int),
             "fuse_bn_fwd": ("CRUSE_FUSE_BN_FWD", lambda v: v != "0"), "fuse_bn_bwd_apply": ("CRUSE_FUSE_BN_BWD_APPLY", lambda v: v != "0"), "bf16_dy": ("CRUSE_BF16_DY", lambda v: v != "0"), "bf16_de": ("CRUSE_BF16_DE", lambda v: v != "0")}
     _LIB_ENV = {"CRUSE_GRU_BWD_RS": "gru_bwd_rs", "CRUSE_GRU_FWD_LEAN": "gru_fwd_lean", "CRUSE_GRU_WLO": "gru_wlo",

@@ -58,7 +58,9 @@ __device__ __forceinline__ long long seg_row(const GbArgs& g, int m) {
 // (library option gb_bm256): gi 96 -> 118 us, dX 85 -> 105 us alone (r4): one 8-wave block per CU loses more at its barriers than two
 // independent 4-wave blocks that fill each other's stalls.  Alone these two products run at 0.66 / 0.74 PFLOP/s; their 150-165 us in the
 // step are cold operands and the side stream's traffic, not this loop.
-template <int MODE, int NST, int BMT = 1>
+// F16: the operands are IEEE f16 (same bytes per element, same staging and fragment layout; v_mfma_f32_16x16x32_f16): the forward gate
+// projection as ONE pass -- 11 significant bits on both operands against 8 + the W_ih low-plane pass of the split-bf16 form (cruse_gemm_f16_nt).
+template <int MODE, int NST, int BMT = 1, bool F16 = false>
 __global__ __launch_bounds__(256 * BMT, (NST == 2 && BMT == 1) ? 2 : 1) void gemm_bf16_nt_kernel(const GbArgs g) {
     constexpr int BM_ = BM * BMT, A_BYTES = TILE_BYTES * BMT, STAGE_BYTES = A_BYTES + TILE_BYTES;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_dyn[];
@@ -154,7 +156,13 @@ __global__ __launch_bounds__(256 * BMT, (NST == 2 && BMT == 1) ? 2 : 1) void gem
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    if constexpr (F16) {
+                        typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_, fa[i]), __builtin_bit_cast(f16x8_, fb[j]),
+                                                                           acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    }
         }
     };
     if constexpr (NST == 2) {
@@ -486,22 +494,31 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const float* x, lon
 // K-tiling WITHOUT transposition: element (n, k) of x [rows n][cols k] goes to y[(k/64)*rows*64 + n*64 + k%64];
 // k in [cols, kp) is zero-filled (kp = cols rounded up to 64) -- the K-contiguous operand whose K is not a
 // multiple of 64 (W_ih with Hg = 160)
+template <bool F16>
 __global__ __launch_bounds__(256) void ktile_bf16_kernel(const float* x, int rows, int cols, long long ld, __bf16* y,
                                                          __bf16* y_lo, int kp) {
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
     const int kq = kp >> 2;
     const long long n4 = (long long)rows * kq;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         const int n = (int)(i / kq), k = (int)(i - (long long)n * kq) * 4;
-        bf16x4 h, l;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float f = (k + e < cols) ? x[n * ld + k + e] : 0.f;
-            h[e] = (__bf16)f; l[e] = (__bf16)(f - (float)h[e]);
-        }
         const long long o = (long long)(k >> 6) * rows * 64 + (long long)n * 64 + (k & 63);
-        *reinterpret_cast<bf16x4*>(y + o) = h;
-        if (y_lo) *reinterpret_cast<bf16x4*>(y_lo + o) = l;
+        if constexpr (F16) {                     // (no low plane: the f16 projection is one pass)
+            f16x4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = (_Float16)((k + e < cols) ? x[n * ld + k + e] : 0.f);
+            *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(y) + o) = h;
+        } else {
+            bf16x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float f = (k + e < cols) ? x[n * ld + k + e] : 0.f;
+                h[e] = (__bf16)f; l[e] = (__bf16)(f - (float)h[e]);
+            }
+            *reinterpret_cast<bf16x4*>(y + o) = h;
+            if (y_lo) *reinterpret_cast<bf16x4*>(y_lo + o) = l;
+        }
     }
 }
 
@@ -528,7 +545,9 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
                           const void* B, const void* B_lo, long long ldb, long long b_kstride,
                           float* C, long long ldc, const float* bias, int accumulate, int splitk, void* stream,
                           int seg_len = 0, long long seg_stride = 0, long long seg_off = 0, bool c_bf16 = false,
-                          float* slabs = nullptr, size_t slab_bytes = 0) {
+                          float* slabs = nullptr, size_t slab_bytes = 0, bool f16 = false) {
+    CRUSE_REQUIRE(!f16 || (!A_lo && !B_lo && !c_bf16 && !slabs && splitk == 1 && !accumulate), CRUSE_E_SHAPE,
+                  "gemm_f16_nt: one pass, f32 result stored (no low planes, no split-K, no accumulation)");
     CRUSE_REQUIRE(!c_bf16 || (!accumulate && splitk == 1), CRUSE_E_SHAPE, "gemm_bf16_nt: a bf16 result is stored, not accumulated");
     CRUSE_REQUIRE(seg_len >= 0 && (seg_len == 0 || (seg_stride >= seg_len && seg_off >= 0 && M % seg_len == 0 && a_kstride == BK)),
                   CRUSE_E_SHAPE, "gemm_bf16_nt: bad row segments (len %d stride %lld off %lld, M %d; row-major A only)", seg_len,
@@ -556,7 +575,7 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
     g.accumulate = accumulate; g.splitk = splitk; g.kt_chunk = kt_chunk;
     g.seg_len = seg_len; g.seg_stride = seg_stride; g.seg_off = seg_off;
     // 256-row tiles (8 waves, three stages) for the un-split products with many row tiles: the gate projections and dX (option gb_bm256)
-    const bool big = splitk == 1 && !slabs && M >= 16 * BM && cruse_opt("gb_bm256", 0) != 0;
+    const bool big = splitk == 1 && !slabs && !f16 && M >= 16 * BM && cruse_opt("gb_bm256", 0) != 0;
     g.tiles_m = cdiv(M, big ? 2 * BM : BM); g.tiles_n = cdiv(N, BN);
     g.xcdk = (xcdk && splitk > 1) ? 1 : 0;
     g.slab = 0;
@@ -612,6 +631,14 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
         CRUSE_LAUNCH_CHECK("gemm_slab_reduce");
         return CRUSE_OK;
     }
+    if (f16) {
+        const size_t lds16 = (size_t)2 * 2 * TILE_BYTES;
+        int rc0 = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_bf16_nt_kernel<0, 2, 1, true>), lds16, "gemm_f16_nt");
+        if (rc0) return rc0;
+        hipLaunchKernelGGL((gemm_bf16_nt_kernel<0, 2, 1, true>), grid, dim3(256), lds16, st, g);
+        CRUSE_LAUNCH_CHECK("gemm_f16_nt");
+        return CRUSE_OK;
+    }
     if (deep) {
         if (c_bf16) CRUSE_GB_LAUNCH(3, 3);
         else if (splitk > 1) CRUSE_GB_LAUNCH(2, 3); else if (accumulate) CRUSE_GB_LAUNCH(1, 3); else CRUSE_GB_LAUNCH(0, 3);
@@ -630,6 +657,14 @@ extern "C" int cruse_gemm_bf16_nt(int M, int N, int K, const void* A, long long 
                                   void* stream) {
     return gemm_bf16_impl(M, N, K, A, nullptr, lda, a_kstride, B, nullptr, ldb, b_kstride, C, ldc, bias, accumulate, splitk,
                           stream);
+}
+
+// C[M,N] = A[M,K] . B[N,K]^T + bias with IEEE-f16 operands (layouts as cruse_gemm_bf16_nt): the forward gate projection in one pass
+extern "C" int cruse_gemm_f16_nt(int M, int N, int K, const void* A, long long lda, long long a_kstride,
+                                 const void* B, long long ldb, long long b_kstride,
+                                 float* C, long long ldc, const float* bias, void* stream) {
+    return gemm_bf16_impl(M, N, K, A, nullptr, lda, a_kstride, B, nullptr, ldb, b_kstride, C, ldc, bias, 0, 1, stream, 0, 0, 0, false,
+                          nullptr, 0, true);
 }
 
 extern "C" size_t cruse_gemm_bf16_slab_bytes(int M, int N, int splitk) {
@@ -711,9 +746,22 @@ extern "C" int cruse_ktile_bf16(const float* x, int rows, int cols, long long ld
     const int kp = (cols + 63) / 64 * 64;
     long long nb = ((long long)rows * (kp / 4) + 255) / 256;
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(ktile_bf16_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, (__bf16*)y,
+    hipLaunchKernelGGL(ktile_bf16_kernel<false>, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, (__bf16*)y,
                        (__bf16*)y_lo, kp);
     CRUSE_LAUNCH_CHECK("ktile_bf16");
+    return CRUSE_OK;
+}
+
+// the same K-tiled layout with IEEE-f16 elements (the B operand of cruse_gemm_f16_nt)
+extern "C" int cruse_ktile_f16(const float* x, int rows, int cols, long long ld, void* y, void* stream) {
+    CRUSE_REQUIRE(rows > 0 && cols > 0 && ld >= cols, CRUSE_E_SHAPE, "ktile_f16: bad shape");
+    CRUSE_REQUIRE(((uintptr_t)y % 8) == 0, CRUSE_E_ALIGN, "ktile_f16: unaligned output");
+    const int kp = (cols + 63) / 64 * 64;
+    long long nb = ((long long)rows * (kp / 4) + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(ktile_bf16_kernel<true>, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, (__bf16*)y,
+                       (__bf16*)nullptr, kp);
+    CRUSE_LAUNCH_CHECK("ktile_f16");
     return CRUSE_OK;
 }
 

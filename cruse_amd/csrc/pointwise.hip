@@ -151,13 +151,27 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* y, const f
     }
 }
 
+// the 2-byte operand copy the next gate GEMM reads: bf16, or f16 (copy_f16: the single-pass f16 gate projection, cruse_gemm_f16_nt)
+__device__ __forceinline__ void store_copy4(void* base, long long elem, const float o0, const float o1, const float o2, const float o3,
+                                            const int copy_f16) {
+    if (copy_f16) {
+        typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_;
+        const f16x4_ b = {(_Float16)o0, (_Float16)o1, (_Float16)o2, (_Float16)o3};
+        *reinterpret_cast<f16x4_*>(reinterpret_cast<_Float16*>(base) + elem) = b;
+    } else {
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
+        const bf16x4_ b = {(__bf16)o0, (__bf16)o1, (__bf16)o2, (__bf16)o3};
+        *reinterpret_cast<bf16x4_*>(reinterpret_cast<__bf16*>(base) + elem) = b;
+    }
+}
+
 // bn_finalize + bn_act_fwd in ONE launch: every block derives mean / rstd of the (<= 256) channels from the f64 batch sums
 // itself; block 0 also publishes them (the backward pass reads them) and updates the running statistics.
 __global__ __launch_bounds__(256) void bn_fin_act_fwd_kernel(const float* y, const double* sums, int nrep, double inv_count, double unb,
                                                              float eps, float momentum, const float* gamma,
                                                              const float* beta, const float* skip, float* out, __bf16* out_bf,
                                                              float* mean_o, float* rstd_o, float* rmean, float* rvar,
-                                                             long long rows, int C, int F, int relu) {
+                                                             long long rows, int C, int F, int relu, int copy_f16) {
     extern __shared__ float tab[];  // [4][C]
     for (int c = threadIdx.x; c < C; c += 256) {
         double t1 = 0.0, t2 = 0.0;
@@ -221,12 +235,7 @@ __global__ __launch_bounds__(256) void bn_fin_act_fwd_kernel(const float* y, con
                         o[e] = t + sk[e];
                     }
                     *reinterpret_cast<float4*>(out + i) = make_float4(o[0], o[1], o[2], o[3]);
-                    if (out_bf) {                         // the bf16 operand copy the next gate GEMM reads (saves a cast pass)
-                        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
-                        bf16x4_ b;
-                        b[0] = (__bf16)o[0]; b[1] = (__bf16)o[1]; b[2] = (__bf16)o[2]; b[3] = (__bf16)o[3];
-                        *reinterpret_cast<bf16x4_*>(out_bf + i) = b;
-                    }
+                    if (out_bf) store_copy4(out_bf, i, o[0], o[1], o[2], o[3], copy_f16);     // the operand copy the next gate GEMM reads (saves a cast pass)
                 }
             }
         }
@@ -249,12 +258,7 @@ __global__ __launch_bounds__(256) void bn_fin_act_fwd_kernel(const float* y, con
             o[e] = t + sk[e];
         }
         reinterpret_cast<float4*>(out)[i] = make_float4(o[0], o[1], o[2], o[3]);
-        if (out_bf) {                                     // the bf16 operand copy the next gate GEMM reads (saves a cast pass)
-            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
-            bf16x4_ b;
-            b[0] = (__bf16)o[0]; b[1] = (__bf16)o[1]; b[2] = (__bf16)o[2]; b[3] = (__bf16)o[3];
-            reinterpret_cast<bf16x4_*>(out_bf)[i] = b;
-        }
+        if (out_bf) store_copy4(out_bf, i * 4, o[0], o[1], o[2], o[3], copy_f16);
     }
 }
 
@@ -500,7 +504,7 @@ __device__ __forceinline__ long long seg_row(const RowSeg& sg, long long r) {
 
 __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const float* x, const float* gamma, const float* beta,
                                                          const float* res, float* y, __bf16* y_bf, float* mean, float* rstd,
-                                                         long long rows, int H, float eps, RowSeg sg) {
+                                                         long long rows, int H, float eps, RowSeg sg, int copy_f16) {
     const int lane = threadIdx.x & 63, nq = H >> 2;
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long nwave = (long long)gridDim.x * 4;
@@ -556,12 +560,7 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const float* x, const f
                     o.z = (v[k][e].z - m[k]) * rs * gm[e].z + bt[e].z + rv[k][e].z;
                     o.w = (v[k][e].w - m[k]) * rs * gm[e].w + bt[e].w + rv[k][e].w;
                     reinterpret_cast<float4*>(y + r * H)[q] = o;
-                    if (y_bf) {
-                        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
-                        bf16x4_ b;
-                        b[0] = (__bf16)o.x; b[1] = (__bf16)o.y; b[2] = (__bf16)o.z; b[3] = (__bf16)o.w;
-                        reinterpret_cast<bf16x4_*>(y_bf + r * H)[q] = b;
-                    }
+                    if (y_bf) store_copy4(y_bf, r * H + 4 * q, o.x, o.y, o.z, o.w, copy_f16);
                 }
             }
         }
@@ -854,10 +853,24 @@ extern "C" int cruse_bn_act_fwd(const float* y, const float* mean, const float* 
     return CRUSE_OK;
 }
 
+extern "C" int cruse_bn_finalize_act_fwd_c(const float* y, const double* sums, int sum_replicas, long long count, float eps, float momentum,
+                                           const float* gamma, const float* beta, const float* skip, float* out, void* out_copy, int copy_dtype,
+                                           float* mean, float* rstd, float* running_mean, float* running_var,
+                                           long long rows, int C, int F, int relu, void* stream);
+
 extern "C" int cruse_bn_finalize_act_fwd(const float* y, const double* sums, int sum_replicas, long long count, float eps, float momentum,
                                          const float* gamma, const float* beta, const float* skip, float* out, void* out_bf16,
                                          float* mean, float* rstd, float* running_mean, float* running_var,
                                          long long rows, int C, int F, int relu, void* stream) {
+    return cruse_bn_finalize_act_fwd_c(y, sums, sum_replicas, count, eps, momentum, gamma, beta, skip, out, out_bf16, CRUSE_DT_BF16, mean, rstd,
+                                       running_mean, running_var, rows, C, F, relu, stream);
+}
+
+extern "C" int cruse_bn_finalize_act_fwd_c(const float* y, const double* sums, int sum_replicas, long long count, float eps, float momentum,
+                                           const float* gamma, const float* beta, const float* skip, float* out, void* out_bf16, int copy_dtype,
+                                           float* mean, float* rstd, float* running_mean, float* running_var,
+                                           long long rows, int C, int F, int relu, void* stream) {
+    CRUSE_REQUIRE(copy_dtype == CRUSE_DT_BF16 || copy_dtype == CRUSE_DT_F16, CRUSE_E_DTYPE, "bn_finalize_act_fwd: copy_dtype %d (bf16 or f16)", copy_dtype);
     CRUSE_REQUIRE(rows > 0 && C > 0 && C <= 256 && F > 0 && count > 0 && sum_replicas >= 1, CRUSE_E_SHAPE, "bn_finalize_act_fwd: bad shape");
     CRUSE_REQUIRE((C * F) % 4 == 0, CRUSE_E_ALIGN, "bn_finalize_act_fwd: C*F=%d must be a multiple of 4", C * F);
     CRUSE_REQUIRE((running_mean == nullptr) == (running_var == nullptr) && mean && rstd, CRUSE_E_SHAPE, "bn_finalize_act_fwd: statistics");
@@ -865,7 +878,7 @@ extern "C" int cruse_bn_finalize_act_fwd(const float* y, const double* sums, int
     const bool rowwise = C * F <= 64 * CPR_MAXG * 4 && (C * F) % 4 == 0;
     hipLaunchKernelGGL(bn_fin_act_fwd_kernel, dim3(rowwise ? grid_for(rows, 8, 2048) : grid_for(rows * C * F / 4, 1024)), dim3(256), 4 * C * sizeof(float), ST(stream),
                        y, sums, sum_replicas, 1.0 / (double)count, unb, eps, momentum, gamma, beta, skip, out, (__bf16*)out_bf16, mean, rstd, running_mean,
-                       running_var, rows, C, F, relu);
+                       running_var, rows, C, F, relu, copy_dtype == CRUSE_DT_F16 ? 1 : 0);
     CRUSE_LAUNCH_CHECK("bn_finalize_act_fwd");
     return CRUSE_OK;
 }
@@ -898,9 +911,21 @@ extern "C" int cruse_bn_act_bwd_apply(const float* dout, const float* y, const f
     return CRUSE_OK;
 }
 
+extern "C" int cruse_ln_fwd_c(const float* x, const float* gamma, const float* beta, const float* res,
+                              float* y, void* y_copy, int copy_dtype, float* mean, float* rstd, long long rows, int H, int interleave_g,
+                              float eps, int seg_len, long long seg_stride, long long seg_off, void* stream);
+
 extern "C" int cruse_ln_fwd(const float* x, const float* gamma, const float* beta, const float* res,
                             float* y, void* y_bf16, float* mean, float* rstd, long long rows, int H, int interleave_g,
                             float eps, int seg_len, long long seg_stride, long long seg_off, void* stream) {
+    return cruse_ln_fwd_c(x, gamma, beta, res, y, y_bf16, CRUSE_DT_BF16, mean, rstd, rows, H, interleave_g, eps, seg_len, seg_stride, seg_off,
+                          stream);
+}
+
+extern "C" int cruse_ln_fwd_c(const float* x, const float* gamma, const float* beta, const float* res,
+                              float* y, void* y_bf16, int copy_dtype, float* mean, float* rstd, long long rows, int H, int interleave_g,
+                              float eps, int seg_len, long long seg_stride, long long seg_off, void* stream) {
+    CRUSE_REQUIRE(copy_dtype == CRUSE_DT_BF16 || copy_dtype == CRUSE_DT_F16, CRUSE_E_DTYPE, "ln_fwd: copy_dtype %d (bf16 or f16)", copy_dtype);
     CRUSE_REQUIRE(seg_len >= 0 && (seg_len == 0 || (seg_stride >= seg_len && seg_off >= 0 && rows % seg_len == 0)), CRUSE_E_SHAPE,
                   "ln_fwd: bad row segments (len %d stride %lld off %lld, rows %lld)", seg_len, seg_stride, seg_off, rows);
     const RowSeg sg = {seg_len, seg_stride, seg_off};
@@ -911,7 +936,7 @@ extern "C" int cruse_ln_fwd(const float* x, const float* gamma, const float* bet
     const bool bf_inline = vec && y_bf16 && (((uintptr_t)y_bf16 & 7) == 0);
     if (vec)
         hipLaunchKernelGGL(ln_fwd_vec_kernel, dim3(grid_for(rows, 16, 2048)), dim3(256), 0, ST(stream), x, gamma, beta,
-                           res, y, bf_inline ? (__bf16*)y_bf16 : nullptr, mean, rstd, rows, H, eps, sg);
+                           res, y, bf_inline ? (__bf16*)y_bf16 : nullptr, mean, rstd, rows, H, eps, sg, copy_dtype == CRUSE_DT_F16 ? 1 : 0);
     else {
         CRUSE_REQUIRE(seg_len == 0, CRUSE_E_SHAPE, "ln_fwd: row segments need the vector form (one group, H %% 4 == 0, aligned)");
         hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid_for(rows, 4, 2048)), dim3(256), 0, ST(stream), x, gamma, beta, res, y,
@@ -919,6 +944,7 @@ extern "C" int cruse_ln_fwd(const float* x, const float* gamma, const float* bet
     }
     CRUSE_LAUNCH_CHECK("ln_fwd");
     CRUSE_REQUIRE(seg_len == 0 || !y_bf16 || bf_inline, CRUSE_E_ALIGN, "ln_fwd: row segments need an 8-byte aligned bf16 copy");
+    CRUSE_REQUIRE(copy_dtype == CRUSE_DT_BF16 || !y_bf16 || bf_inline, CRUSE_E_DTYPE, "ln_fwd: the f16 copy needs the vector form (one group)");
     if (y_bf16 && !bf_inline) return cruse_cast_bf16_split(y, y_bf16, nullptr, rows * H, stream);     // interleaved form: one more pass
     return CRUSE_OK;
 }

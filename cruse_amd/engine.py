@@ -244,8 +244,16 @@ class TrainEngine:
     def _forward_loss(self, noisy: torch.Tensor, clean: torch.Tensor, training: bool):
         B, L = noisy.shape
         T = ops.stft_frames(L, self.hop)
-        nre, nim, mag = ops.stft(noisy, self.n_fft, self.hop, mag_bins=self.f_net, mag_eps=1e-8)
-        cre = cim = cmag = None
+        if self.loss == "wo_male_df":
+            # config 4: the DeepFilter loss reads both spectra as [2,B,T,F] plane pairs -- the STFTs write them in place
+            unp = torch.empty(2, B, T, self.f_stft, device=noisy.device, dtype=torch.float32)
+            mag = torch.empty(B, T, self.f_net, device=noisy.device, dtype=torch.float32)
+            ops.stft(noisy, self.n_fft, self.hop, mag_eps=1e-8, out=(unp[0], unp[1], mag))
+            nre, nim = unp[0], unp[1]
+        else:
+            unp = None
+            nre, nim, mag = ops.stft(noisy, self.n_fft, self.hop, mag_bins=self.f_net, mag_eps=1e-8)
+        cre = cim = cmag = ref = None
         # the clean spectrum is only needed by the loss: a leaf queued for the first forward recurrence (beside the encoder
         # it shared HBM with the 1 -> 8 conv: 60 vs 33 us, plus an event record on the main stream); joined by
         # unet2_forward before the decoder
@@ -256,8 +264,12 @@ class TrainEngine:
                 self.side.defer(lambda: ops.stft(clean, self.n_fft, self.hop, want_ri=False, mag_eps=0.0, out=(None, None, cmag)),
                            clean, cmag, kind=1, lane=0)
             else:
-                cre = torch.empty(B, T, self.f_stft, device=clean.device, dtype=torch.float32)
-                cim = torch.empty_like(cre)
+                if self.loss == "wo_male_df":
+                    ref = torch.empty(2, B, T, self.f_stft, device=clean.device, dtype=torch.float32)
+                    cre, cim = ref[0], ref[1]
+                else:
+                    cre = torch.empty(B, T, self.f_stft, device=clean.device, dtype=torch.float32)
+                    cim = torch.empty_like(cre)
                 self.side.defer(lambda: ops.stft(clean, self.n_fft, self.hop, out=(cre, cim, None)), clean, cre, cim, kind=1, lane=0)
         mask, ctx = unet2_forward(mag.view(B, 1, T, self.f_net), self.flat.P, self.Bf, self.model.ch,
                                   self.model.rnn_groups, self.prec, training=training, save=training,
@@ -274,7 +286,7 @@ class TrainEngine:
                                                 self.sdnr_beta_db, want_dlogit=training)
             self._norm = float(B * self.f_stft)
         elif self.loss == "wo_male_df":
-            loss_sum, dlogit = self._deepfilter_loss(mask, nre, nim, cre, cim, B, T, training)
+            loss_sum, dlogit = self._deepfilter_loss(mask, unp, ref, B, T, training)
             self._norm = float(rows * self.f_stft)
         else:
             # waveform in -> waveform loss: est = iSTFT(mask * N); SI-SNR(est, clean) and back through both
@@ -292,13 +304,14 @@ class TrainEngine:
                 dlogit = ops.mask_apply_bwd(dre, dim, nre, nim, mask, rows, self.f_net, self.f_stft)
         return loss_sum, dlogit, ctx
 
-    def _deepfilter_loss(self, mask, nre, nim, cre, cim, B, T, training):
+    def _deepfilter_loss(self, mask, unp, ref, B, T, training):
         """DeepFilter(1, 5) head + WO-MALE on its output.  The spectra are frame-major [B,T,F]; the kernel takes [B,F',T']
         planes, so it is called with the roles of the two axes (and of t_dim / f_dim) exchanged -- no transposition."""
         from ._lib import check, lib
         Fs, Fn, rows = self.f_stft, self.f_net, B * T
         dev = mask.device
         key = (B, T)
+        nre, nim = unp[0], unp[1]
         if getattr(self, "_df_const", None) is None or self._df_const[0] != key:
             self._df_const = (key, torch.ones(rows, Fs, device=dev), torch.zeros(rows, Fs, device=dev))
         _, ones, zeros = self._df_const
@@ -309,8 +322,6 @@ class TrainEngine:
         o_r, o_i = ops.deepfilter_fwd(nre.view(B, T, Fs), nim.view(B, T, Fs), hr.view(B, T, Fs), hi.view(B, T, Fs), t_dim, f_dim,
                                       out=(est[0], est[1]))
         self._last_est = est
-        ref = torch.stack([cre.view(B, T, Fs), cim.view(B, T, Fs)])          # [2,B,T,F] planes (device copy)
-        unp = torch.stack([nre.view(B, T, Fs), nim.view(B, T, Fs)])
         loss_sum = torch.empty(1, device=dev, dtype=torch.float64)
         dest = torch.empty_like(est) if training else None
         TF = T * Fs

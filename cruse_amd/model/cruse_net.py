@@ -214,6 +214,21 @@ def _gi_takes_bf16_copy(prec, Hg: int) -> bool:
     return _bf16_gemm_path(prec, Hg) and Hg % 64 == 0 and not (_gi_x3_knob(Hg) & 4) and config.get().fuse_cast
 
 
+def _gi_f16(prec, Hg: int, layer: int) -> bool:
+    """Forward gate projections as ONE pass on IEEE-f16 operands (EngineConfig.gi_f16, cruse_gemm_f16_nt): 11 significant bits on x
+    and W_ih, where the split-bf16 form keeps x at 8 bits and spends a second (Hg <= 320: and a third) pass on low planes.  The
+    producers' operand copies are then f16 tensors (g = 1; with g > 1 the interleaving LayerNorm has no fused copy and a cast pass
+    makes it) and W_ih is K-tiled as f16.  The operands are BatchNorm + ReLU / LayerNorm outputs and |W_ih| ~ 1 / sqrt(Hg): inside
+    f16's range; a value past 65504 would surface as a non-finite loss and the guarded optimizer step skips (engine.step_health).
+    Not with the row-major TN weight gradients or the time-chunk pipeline, which read the bf16 copies.
+    Only where the split-bf16 form does NOT split x as well (Hg > 320 by default, i.e. g = 1 at H = 640): the three-pass form of the
+    grouped configurations carries ~16 bits on both operands and measured BETTER than f16 there (enhanced spectrum at T = 401, closed-form
+    init, g = 4: 3.1e-4 against 1.7e-3; g = 2: 9e-5 against 5.5e-4), so those keep it."""
+    c = config.get()
+    return (bool((int(c.gi_f16) * 3 if isinstance(c.gi_f16, bool) else int(c.gi_f16 or 0)) >> layer & 1) and _bf16_gemm_path(prec, Hg) and not (_gi_x3_knob(Hg) & 4) and not c.dw_tn and int(c.fwd_chunks or 0) < 2
+            and not c.gi_bf16)
+
+
 def _dw_tn(prec, Hg: int, B: int, g: int) -> bool:
     """Weight gradients of the gate projections as TN GEMMs on ROW-MAJOR operands (cruse_gemm_bf16_tn): the backward
     recurrence's loader wave writes the 4-slab gate-gradient rows dg4 [rows, G, 4, Hg] itself (cruse_gru_seq_bwd_ex,
@@ -419,6 +434,12 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
         x3 = (knob >> (0 if lname == "gru_list1" else 1)) & 1
         split_x = bool(knob & 4) and x3
         pad = 64 if Hg % 64 else 0
+        if _gi_f16(prec, Hg, 0 if lname == "gru_list1" else 1) and (inp_bf is None or inp_bf.dtype != torch.float16):
+            # (eval, g > 1 or Hg % 64 != 0: no fused copy -- the same f16 operand from a cast pass, zero tail for the K round-up)
+            inp_bf = torch.empty(rows * H + pad, device=x.device, dtype=torch.float16)
+            if pad:
+                inp_bf[rows * H:].zero_()
+            ops.check(ops.lib.cruse_cast_f16(ops._p(inp), ops._p(inp_bf), rows * H, 1, ops._stream()))
         if inp_bf is not None:                   # written by the kernel that produced inp (_gi_takes_bf16_copy)
             inp_hi, inp_lo = inp_bf, None
         elif fast and split_x:
@@ -428,7 +449,10 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
         kp = (Hg + 63) // 64 * 64
         for i in range(g):
             w_ih, b_ih = P[f"{prefix}{lname}.{i}.weight_ih_l0"], P[f"{prefix}{lname}.{i}.bias_ih_l0"]
-            if fast and x3:
+            if inp_bf is not None and inp_bf.dtype == torch.float16:          # _gi_f16: one pass, 11-bit operands
+                ops.gemm_f16_nt(rows, 3 * Hg, kp, inp_bf, i * Hg, H, ops.ktile_f16(w_ih, 3 * Hg, Hg), 0, 64, gi, i * 3 * Hg, 3 * H,
+                                bias=b_ih, b_kstride=3 * Hg * 64)
+            elif fast and x3:
                 w_hi, w_lo = ops.ktile_bf16(w_ih, 3 * Hg, Hg, split=True)
                 ops.gemm_bf16x3_nt(rows, 3 * Hg, kp, inp_hi, inp_lo, i * Hg, H, w_hi, w_lo, 0, 64, gi, i * 3 * Hg, 3 * H,
                                    bias=b_ih, b_kstride=3 * Hg * 64)
@@ -487,7 +511,9 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
                                                                                   queue_layer1_leaves)
     else:
         h1, c1, a1, z1 = layer(x, "gru_list1", x_bf16)
-        l1_bf = torch.empty(rows * H, device=x.device, dtype=torch.bfloat16) if _gi_takes_bf16_copy(prec, Hg) else None
+        f16 = _gi_f16(prec, Hg, 1)
+        l1_bf = (torch.empty(rows * H, device=x.device, dtype=torch.float16 if f16 else torch.bfloat16)
+                 if _gi_takes_bf16_copy(prec, Hg) and not (f16 and g > 1) else None)
         l1, m1, s1 = ops.ln_fwd(h1, P[prefix + "ln1.weight"], P[prefix + "ln1.bias"], None, rows, H, g, save=save, out_bf16=l1_bf)
         queue_layer1_leaves(h1, l1, l1_bf)
         h2, c2, a2, z2 = layer(l1, "gru_list2", l1_bf)
@@ -825,7 +851,8 @@ def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, tor
             pend = None
             e_bf = None
             if k == L and training and _gi_takes_bf16_copy(prec, ch[L] * Fk[L] // groups):
-                e_bf = torch.empty(rows * ch[L] * Fk[L], device=x.device, dtype=torch.bfloat16)     # gate GEMM 1's operand
+                e_bf = torch.empty(rows * ch[L] * Fk[L], device=x.device,                          # gate GEMM 1's operand
+                                   dtype=torch.float16 if _gi_f16(prec, ch[L] * Fk[L] // groups, 0) else torch.bfloat16)
             e, mean, rstd = _bn_act(y, rows, ch[k], Fk[k], P, Bf, f"bn{k}", training, update_running, sums=sums, out_bf16=e_bf)
 
             def skip_conv(e=e, s=s, k=k):

@@ -403,10 +403,12 @@ def bn_finalize_act_fwd(y, sums, count, eps, momentum, gamma, beta, skip, rows, 
     out = torch.empty_like(y)
     mean = torch.empty(C, device=y.device, dtype=torch.float32)
     rstd = torch.empty(C, device=y.device, dtype=torch.float32)
-    if out_bf16 is not None and (out_bf16.dtype != torch.bfloat16 or out_bf16.numel() < y.numel()):
-        raise RuntimeError("bn_finalize_act_fwd: out_bf16 must be a bf16 tensor of at least y.numel() elements")
-    check(lib.cruse_bn_finalize_act_fwd(_p(y), _p(sums), sums.numel() // (2 * C), count, eps, momentum, _p(gamma), _p(beta), _p(skip), _p(out), _p(out_bf16), _p(mean),
-                                        _p(rstd), _p(running_mean), _p(running_var), rows, C, F, 1 if relu else 0, _stream()))
+    if out_bf16 is not None and (out_bf16.dtype not in (torch.bfloat16, torch.float16) or out_bf16.numel() < y.numel()):
+        raise RuntimeError("bn_finalize_act_fwd: out_bf16 must be a bf16 (or f16) tensor of at least y.numel() elements")
+    # (the operand copy takes the element type of the tensor handed in: bf16, or f16 for the single-pass f16 gate projection)
+    check(lib.cruse_bn_finalize_act_fwd_c(_p(y), _p(sums), sums.numel() // (2 * C), count, eps, momentum, _p(gamma), _p(beta), _p(skip), _p(out),
+                                          _p(out_bf16), _copy_dt(out_bf16), _p(mean), _p(rstd), _p(running_mean), _p(running_var), rows, C, F,
+                                          1 if relu else 0, _stream()))
     return out, mean, rstd
 
 
@@ -454,6 +456,11 @@ def bn_act_bwd(dout, y, mean, rstd, gamma, beta, rows, C, F, relu, training, dga
     return dy
 
 
+def _copy_dt(t) -> int:
+    """CRUSE_DT_* of a 2-byte operand copy (CRUSE_DT_F16 = 1, CRUSE_DT_BF16 = 2; None: bf16)"""
+    return 1 if (t is not None and t.dtype == torch.float16) else 2
+
+
 # ---------------------------------------------------------------- LayerNorm
 def ln_fwd(x, gamma, beta, res, rows, H, interleave_g=1, eps=1e-5, save=True, out=None, out_bf16=None, seg=None, stats=None):
     """seg = (seg_len, seg_stride, seg_off): only the rows of one time chunk (cruse_ln_fwd row segments; rows = B * seg_len),
@@ -466,10 +473,10 @@ def ln_fwd(x, gamma, beta, res, rows, H, interleave_g=1, eps=1e-5, save=True, ou
         mean = torch.empty(nstat, device=x.device, dtype=torch.float32) if save else None
         rstd = torch.empty(nstat, device=x.device, dtype=torch.float32) if save else None
     sl, ss, so = seg if seg is not None else (0, 0, 0)
-    if out_bf16 is not None and (out_bf16.dtype != torch.bfloat16 or out_bf16.numel() < x.numel()):
-        raise RuntimeError("ln_fwd: out_bf16 must be a bf16 tensor of at least x.numel() elements")
-    check(lib.cruse_ln_fwd(_p(x), _p(gamma), _p(beta), _p(res), _p(y), _p(out_bf16), _p(mean), _p(rstd), rows, H, interleave_g,
-                           eps, sl, ss, so, _stream()))
+    if out_bf16 is not None and (out_bf16.dtype not in (torch.bfloat16, torch.float16) or out_bf16.numel() < x.numel()):
+        raise RuntimeError("ln_fwd: out_bf16 must be a bf16 (or f16) tensor of at least x.numel() elements")
+    check(lib.cruse_ln_fwd_c(_p(x), _p(gamma), _p(beta), _p(res), _p(y), _p(out_bf16), _copy_dt(out_bf16), _p(mean), _p(rstd), rows, H,
+                             interleave_g, eps, sl, ss, so, _stream()))
     return y, mean, rstd
 
 
@@ -540,6 +547,23 @@ def ktile_bf16(x, rows, cols, split=False):
     lo = torch.empty_like(y) if split else None
     check(lib.cruse_ktile_bf16(_p(x), rows, cols, cols, _p(y), _p(lo), _stream()))
     return (y, lo) if split else y
+
+
+def ktile_f16(x, rows, cols):
+    """x [rows, cols] f32 -> K-tiled IEEE f16 [ceil(cols/64), rows, 64] (the layout of ktile_bf16): the B operand of gemm_f16_nt"""
+    y = torch.empty((cols + 63) // 64, rows, 64, device=x.device, dtype=torch.float16)
+    check(lib.cruse_ktile_f16(_p(x), rows, cols, cols, _p(y), _stream()))
+    return y
+
+
+def gemm_f16_nt(M, N, K, A, a_off, lda, B, b_off, ldb, C, c_off, ldc, bias=None, a_kstride=64, b_kstride=64):
+    """C[M,N] = A[M,K] . B[N,K]^T + bias on IEEE-f16 operands (cruse_gemm_f16_nt; offsets in elements): the forward gate projection
+    in one pass."""
+    if A.dtype != torch.float16 or B.dtype != torch.float16 or C.dtype != torch.float32:
+        raise RuntimeError("gemm_f16_nt needs f16 operands and an f32 result")
+    check(lib.cruse_gemm_f16_nt(M, N, K, A.data_ptr() + 2 * a_off, lda, a_kstride, B.data_ptr() + 2 * b_off, ldb, b_kstride,
+                                C.data_ptr() + 4 * c_off, ldc, _p(bias), _stream()))
+    return C
 
 
 def cast_bf16_padded(x, pad=64, split=False):

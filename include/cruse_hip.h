@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CRUSE_ABI_VERSION 8
+#define CRUSE_ABI_VERSION 9
 
 enum {
     CRUSE_OK = 0,
@@ -239,6 +239,12 @@ int cruse_bn_finalize_act_fwd(const float* y, const double* sums, int sum_replic
                               float* mean, float* rstd, float* running_mean, float* running_var,
                               long long rows, int C, int F, int relu, void* stream);
 /* sums[0..C) = sum g, sums[C..2C) = sum g*xhat with g = dout * [bn(y) > 0]; `zeroed` as for cruse_bn_stats */
+/* (ABI 9) the same with the element type of the 2-byte operand copy chosen: copy_dtype = CRUSE_DT_BF16 (the function above) or
+ * CRUSE_DT_F16 -- the operand of the single-pass f16 gate projection cruse_gemm_f16_nt. */
+int cruse_bn_finalize_act_fwd_c(const float* y, const double* sums, int sum_replicas, long long count, float eps, float momentum,
+                                const float* gamma, const float* beta, const float* skip, float* out, void* out_copy, int copy_dtype,
+                                float* mean, float* rstd, float* running_mean, float* running_var,
+                                long long rows, int C, int F, int relu, void* stream);
 int cruse_bn_act_bwd_reduce(const float* dout, const float* y, const float* mean, const float* rstd,
                             const float* gamma, const float* beta, long long rows, int C, int F,
                             int relu, double* sums, int zeroed, void* stream);
@@ -264,6 +270,10 @@ int cruse_bn_act_bwd_apply(const float* dout, const float* y, const float* mean,
 int cruse_ln_fwd(const float* x, const float* gamma, const float* beta, const float* res,
                  float* y, void* y_bf16, float* mean, float* rstd, long long rows, int H, int interleave_g,
                  float eps, int seg_len, long long seg_stride, long long seg_off, void* stream);
+/* (ABI 9) cruse_ln_fwd with the element type of the operand copy chosen (CRUSE_DT_BF16 or CRUSE_DT_F16; f16 needs interleave_g == 1) */
+int cruse_ln_fwd_c(const float* x, const float* gamma, const float* beta, const float* res,
+                   float* y, void* y_copy, int copy_dtype, float* mean, float* rstd, long long rows, int H, int interleave_g,
+                   float eps, int seg_len, long long seg_stride, long long seg_off, void* stream);
 int cruse_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                  const float* gamma, long long rows, int H, int interleave_g,
                  float* dx, float* dgamma, float* dbeta, void* stream);
@@ -327,6 +337,15 @@ int cruse_cast_bf16(const float* x, void* y, long long n, void* stream);
  * a K-contiguous operand (W_ih [3Hg, Hg]) whose K is not a multiple of 64.  y_lo (nullable): the low plane
  * bf16(x - y) of the split-bf16 x3 form, same layout. */
 int cruse_ktile_bf16(const float* x, int rows, int cols, long long ld, void* y, void* y_lo, void* stream);
+/* (ABI 9) the same K-tiled layout with IEEE-f16 elements: the B operand of cruse_gemm_f16_nt */
+int cruse_ktile_f16(const float* x, int rows, int cols, long long ld, void* y, void* stream);
+/* (ABI 9) C[M,N] = A[M,K] . B[N,K]^T + bias[n] with IEEE-f16 operands in the layouts of cruse_gemm_bf16_nt, f32 accumulation
+ * (v_mfma_f32_16x16x32_f16): the FORWARD gate projection gi = x W_ih^T (cruse_net.py:23-31,44,50) in ONE pass -- 11 significant bits
+ * on both operands, where the split-bf16 form above spends a second pass to correct W_ih only and keeps x at 8 bits.  The operands
+ * are O(1) activations (BatchNorm + ReLU / LayerNorm outputs) and |W_ih| <= 1 / sqrt(Hg): inside f16's range. */
+int cruse_gemm_f16_nt(int M, int N, int K, const void* A, long long lda, long long a_kstride,
+                      const void* B, long long ldb, long long b_kstride,
+                      float* C, long long ldc, const float* bias, void* stream);
 /* y = bf16(x) and y_lo = bf16(x - y) (nullable) */
 int cruse_cast_bf16_split(const float* x, void* y, void* y_lo, long long n, void* stream);
 /* Split-bf16 x3 form of cruse_gemm_bf16_nt: A = A_hi + A_lo, B = B_hi + B_lo (bf16 planes, same layout each);

@@ -1139,7 +1139,7 @@ def test_tn_weight_gradient_path_matches_the_default(grp):
     from cruse_amd.config import EngineConfig
     for tn in ("0", "1"):
         torch.manual_seed(1)
-        eng = TrainEngine(unet_2(rnn_groups=grp, precision="bf16").cuda(), use_graph=False, config=EngineConfig(dw_tn=tn == "1"))
+        eng = TrainEngine(unet_2(rnn_groups=grp, precision="bf16").cuda(), use_graph=False, config=EngineConfig(dw_tn=tn == "1", gi_f16=0))    # (the TN path projects in the split-bf16 form)
         ls = eng._fwd_bwd(noisy, clean)
         torch.cuda.synchronize()
         with config.use(eng.cfg), M.use_scheduler(eng.side):

@@ -363,7 +363,7 @@ def test_forward_time_chunk_pipeline_is_the_same_computation(graph):
     res = {}
     for nch in (0, 2, 3):
         torch.manual_seed(5)
-        eng = TrainEngine(unet_2(rnn_groups=1, precision="bf16").cuda(), use_graph=graph, config=EngineConfig(fwd_chunks=nch))
+        eng = TrainEngine(unet_2(rnn_groups=1, precision="bf16").cuda(), use_graph=graph, config=EngineConfig(fwd_chunks=nch, gi_f16=0))     # (the chunk pipeline projects in the split-bf16 form)
         ls = eng.step(noisy, clean)                             # (graph mode: capture + first replay)
         torch.cuda.synchronize()
         first = (eng.loss_value(ls), eng._last_mask.clone(), eng.flat.grads.clone())
