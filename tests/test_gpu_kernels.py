@@ -725,6 +725,61 @@ def test_gemm_bf16_result_stored_as_bf16(ops, M, N, K, x3):
         ops.gemm_bf16_nt(M, N, K, A_hi, 0, K, B_hi, 0, K, Cb, 0, N, accumulate=True)
 
 
+@pytest.mark.parametrize("M,N,K", [(25664, 1920, 640), (2500, 200, 160), (4133, 640, 640), (130, 96, 64)])
+def test_gemm_f16_single_pass_gate_projection(ops, M, N, K):
+    """cruse_gemm_f16_nt + cruse_ktile_f16 (ABI 9): gi = x W_ih^T + b_ih (cruse_net.py:23-31,44,50) in one pass on IEEE-f16 operands --
+    exact (f32 accumulation order aside) on the f16-rounded operands, 8 x closer to the f32 product than a bf16 pass; K not a
+    multiple of 64 (zero-padded K tile, the A rows read on into their neighbours), ragged M / N tiles."""
+    torch.manual_seed(M + N + K)
+    kp = (K + 63) // 64 * 64
+    A = torch.randn(M, K).cuda(); W = (torch.randn(N, K) / K ** 0.5).cuda(); bias = torch.randn(N).cuda()
+    ld = kp + 64
+    Ah = torch.full((M, ld), 3.0, dtype=torch.float16).cuda()                  # (finite garbage beside the K columns, as a neighbouring group's)
+    Ah[:, :K] = A.half()
+    Wt = ops.ktile_f16(W, N, K)
+    assert Wt.shape == (kp // 64, N, 64)
+    want_t = torch.zeros(N, kp, dtype=torch.float16).cuda(); want_t[:, :K] = W.half()
+    assert torch.equal(Wt.permute(1, 0, 2).reshape(N, kp), want_t)
+    C = torch.full((M, N), 7.0).cuda()
+    ops.gemm_f16_nt(M, N, kp, Ah, 0, ld, Wt, 0, 64, C, 0, N, bias=bias, b_kstride=N * 64)
+    ref16 = A.half().double() @ W.half().double().t() + bias.double()
+    exact = A.double() @ W.double().t() + bias.double()
+    assert rel_l2(C, ref16) < 2e-6
+    e16 = rel_l2(C, exact)
+    Cb = torch.empty(M, N).cuda()
+    ops.gemm_bf16_nt(M, N, kp, Ah.to(torch.bfloat16), 0, ld, ops.ktile_bf16(W, N, K), 0, 64, Cb, 0, N, bias=bias, b_kstride=N * 64)
+    assert e16 < 5e-4 and e16 < 0.2 * rel_l2(Cb, exact)
+    with pytest.raises(RuntimeError):
+        ops.gemm_f16_nt(M, N, kp, Ah.to(torch.bfloat16), 0, ld, Wt, 0, 64, C, 0, N)
+
+
+def test_f16_operand_copies_from_the_producers(ops):
+    """cruse_ln_fwd_c / cruse_bn_finalize_act_fwd_c (ABI 9): the 2-byte operand copy the next gate projection reads takes the element
+    type asked for -- f16 copy == out.half(), bf16 copy == out.bfloat16(), the f32 outputs identical either way."""
+    torch.manual_seed(3)
+    rows, H = 777, 640
+    x = torch.randn(rows, H).cuda(); gam = (1 + 0.1 * torch.randn(H)).cuda(); bet = (0.1 * torch.randn(H)).cuda()
+    outs = {}
+    for dt in (torch.float16, torch.bfloat16):
+        cp = torch.empty(rows * H, dtype=dt).cuda()
+        y, _, _ = ops.ln_fwd(x, gam, bet, None, rows, H, 1, out_bf16=cp)
+        assert torch.equal(cp.view(rows, H), y.to(dt))
+        outs[dt] = y
+    assert torch.equal(outs[torch.float16], outs[torch.bfloat16])
+    with pytest.raises(RuntimeError):                                          # the interleaving form (g > 1) has no fused f16 copy
+        ops.ln_fwd(x, gam, bet, None, rows, H, 4, out_bf16=torch.empty(rows * H, dtype=torch.float16).cuda())
+    C, F = 64, 10
+    yb = torch.randn(rows, C, F).cuda(); g2 = (1 + 0.1 * torch.randn(C)).cuda(); b2 = (0.1 * torch.randn(C)).cuda()
+    sums = torch.stack([yb.double().sum((0, 2)), (yb.double() ** 2).sum((0, 2))]).flatten().contiguous()
+    outs = {}
+    for dt in (torch.float16, torch.bfloat16):
+        cp = torch.empty(rows * C * F, dtype=dt).cuda()
+        e, _, _ = ops.bn_finalize_act_fwd(yb, sums, rows * F, 1e-5, 0.1, g2, b2, None, rows, C, F, out_bf16=cp)
+        assert torch.equal(cp.view(rows, C, F), e.to(dt))
+        outs[dt] = e
+    assert torch.equal(outs[torch.float16], outs[torch.bfloat16])
+
+
 @pytest.mark.parametrize("M,N,K,splitk", [(1920, 640, 25664, -8), (640, 640, 25664, -8), (200, 96, 4096, 6), (130, 100, 1024, -3)])
 def test_gemm_split_k_slabs_match_atomics_and_are_reproducible(ops, M, N, K, splitk):
     """cruse_gemm_bf16_nt_slabs: the k-slices' partial sums go to slabs that one kernel adds to C in slice order -- the same sums as

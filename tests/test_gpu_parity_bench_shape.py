@@ -83,6 +83,39 @@ def test_bf16_forward_parity_at_bench_length(grp, init):
     assert float(est[..., 160, :].abs().max()) == 0.0          # R8: bin 160 of the enhanced spectrum is zero
 
 
+@pytest.mark.parametrize("init", ["closed", "random"])
+def test_f16_gate_projection_masks_at_bench_length(init):
+    """EngineConfig.gi_f16 (round 4): the forward gate projections of GGRU layer 1 / 2 (bit 0 / 1) as one pass on f16 operands
+    (cruse_gemm_f16_nt) instead of bf16 x with W_ih hi / lo planes.  Every mask meets the north_star bar at T = 401; the default (2)
+    and the all-f16 form (3) are not further from the oracle than the split-bf16 form (0) they replace."""
+    from cruse_amd import ops
+    from cruse_amd.config import EngineConfig
+    from cruse_amd.engine import TrainEngine
+    from cruse_amd.model.cruse_net import unet2_forward
+    from cruse_amd import config
+    from cruse_amd.model import cruse_net as M
+    from oracle import cruse_oracle as O
+    B, T = 8, 401
+    noisy, _ = O.synth_pair(B, (T - 1) * 160, seed=11)
+    err = {}
+    for mask_bits in (0, 1, 2, 3):
+        o, m = _pair(1, init, "bf16")
+        with torch.no_grad():
+            mask_o, est_o, _ = O.enhanced_spectrum(o, noisy)
+        eng = TrainEngine(m, use_graph=False, config=EngineConfig(gi_f16=mask_bits))
+        nre, nim, mag = ops.stft(noisy.cuda(), 320, 160, mag_bins=160, mag_eps=1e-8)
+        with config.use(eng.cfg), M.use_scheduler(eng.side):
+            mask, _ = unet2_forward(mag.view(B, 1, T, 160), eng.flat.P, eng.Bf, m.ch, m.rnn_groups, "bf16", training=True,
+                                    save=False, update_running=False)
+        er, ei = ops.mask_apply(mask.contiguous().view(B * T, 160), nre, nim, B * T, 160, 161)
+        est = torch.stack([er.view(B, T, 161), ei.view(B, T, 161)], dim=-1)
+        err[mask_bits] = rel_l2(est, est_o)
+        assert err[mask_bits] <= FWD_TOL
+    print(f"[parity bf16 T=401 g=1 {init}] enhanced-spectrum rel-L2 by gi_f16 mask: " + ", ".join(f"{k}: {v:.3e}" for k, v in err.items()))
+    assert EngineConfig().gi_f16 == 2
+    assert err[2] <= 1.05 * err[0] and err[3] <= 1.05 * err[0]
+
+
 @pytest.mark.parametrize("grp", [1, 4])
 def test_bf16_forward_parity_at_the_full_bench_batch(grp):
     """the BENCH batch itself -- B = 64 x T = 401, i.e. 8 (g = 1) / 32 (g = 4) concurrent GRU chains
