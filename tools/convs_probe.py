@@ -5,6 +5,7 @@ from cruse_amd import ops
 B, T = 64, 401
 ch, F = [1, 8, 16, 32, 64], [160, 80, 40, 20, 10]
 PREC = os.environ.get("PREC", "bf16")
+PREC = int(PREC) if PREC.isdigit() else PREC
 
 
 def timeit(fn, n=10):
