@@ -283,6 +283,7 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
     if (!claim_chain(a, a.P, chain, part)) return;
     const int grp = chain % a.G, bgi = a.bg_off + chain / a.G;
     const int b0 = bgi * 8, nb = min(8, a.B - b0);
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(1); else if (a.prio == 2) __builtin_amdgcn_s_setprio(2); else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
     const int u0 = part * U;
     const float* W = a.p.w_hh[grp];
     const float* bh = a.p.b_hh[grp];
@@ -2056,6 +2057,7 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* pane
         const int bg_off = L * pl.bg_per_launch;
         const int nbg_here = (pl.nbg - bg_off) < pl.bg_per_launch ? (pl.nbg - bg_off) : pl.bg_per_launch;
         a.bg_off = bg_off;
+        a.prio = cruse_opt("gru_prio", 0);
         a.nchains = nbg_here * G;
         // every launch gets its own panel region: chain index inside the launch + offset
         a.xid = (unsigned long long*)xid_base + (size_t)bg_off * G * 64;

@@ -41,6 +41,8 @@ struct GruArgs {
     unsigned* status;
     int xcd_rot;                      // chain c of a launch runs on PHYSICAL XCD (c + xcd_rot) % 8 (concurrent launches: disjoint XCDs)
     unsigned* tickets;                // [8] per-XCD workgroup counters of this launch (zeroed with the panels)
+    int prio;                         // s_setprio level of the compute waves (option gru_prio): the recurrence's instructions issue ahead of
+                                      // co-resident side-stream waves on the same SIMD
     int poll_delay;                   // tag-free kernels: s_sleep(1) periods between a step's publish and its first poll
     int xsweep;                       // profiling: extra sweep / publish repetitions per step of the forward lean kernel (gru_xsweep)
     int poll_stagger;                 // backward tag-free kernel: > 0 = two polls in flight, this many s_sleep(1) periods apart

@@ -61,6 +61,7 @@ __global__ __launch_bounds__(320) void gru_fwd_tf_kernel(GruArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int chain, part;
     if (!claim_chain(a, a.P, chain, part)) return;
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(1); else if (a.prio == 2) __builtin_amdgcn_s_setprio(2); else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
     const int grp = chain % a.G, bgi = a.bg_off + chain / a.G;
     const int b0 = bgi * 8, nb = min(8, a.B - b0);
     const int u0 = part * U;
@@ -784,6 +785,7 @@ __global__ __launch_bounds__(320) void gru_bwd_ag_kernel(GruArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int chain, part;
     if (!claim_chain(a, P, chain, part)) return;
+    if (a.prio == 1) __builtin_amdgcn_s_setprio(1); else if (a.prio == 2) __builtin_amdgcn_s_setprio(2); else if (a.prio == 3) __builtin_amdgcn_s_setprio(3);
     const int grp = chain % a.G, bgi = a.bg_off + chain / a.G;
     const int b0 = bgi * 8, nb = min(8, a.B - b0);
     const int u0 = part * U;
