@@ -38,6 +38,10 @@ struct GbArgs {
     // frames [seg_off, seg_off + seg_len) of every clip of a [B, T = seg_stride] tensor, i.e. a TIME CHUNK of the batch
     // (the gate projections of one chunk run beside the recurrence of the previous one).  seg_len == 0: identity.
     int seg_len; long long seg_stride, seg_off;
+    // CONCATENATED products (cruse_gemm_bf16_nt_slabs_cat): row tiles [0, tm_b1) are product 0 (A, B as above), [tm_b1, tm_b2) product 1,
+    // [tm_b2, ..) product 2 -- each with its own B operand and its own first A row (a_shift*: elements added to the A address of the
+    // VIRTUAL row), all sharing N, K, the strides and one output [sum of the M_i, N].  tm_b1 = tm_b2 = INT_MAX: one product.
+    int tm_b1, tm_b2; long long a_shift1, a_shift2; const __bf16* B1; const __bf16* B2;
 };
 
 __device__ __forceinline__ long long seg_row(const GbArgs& g, int m) {
@@ -89,6 +93,10 @@ __global__ __launch_bounds__(256 * BMT, (NST == 2 && BMT == 1) ? 2 : 1) void gem
         else { tz = 0; tm = unit; tn = inner; }
     }
     const int m0 = tm * BM_, n0 = tn * BN;
+    const __bf16* Abase = g.A;
+    const __bf16* Bbase = g.B;
+    if (tm >= g.tm_b2) { Abase += g.a_shift2; Bbase = g.B2; }
+    else if (tm >= g.tm_b1) { Abase += g.a_shift1; Bbase = g.B1; }
     const int nkt = g.K / BK;
     const int kt0 = tz * g.kt_chunk, kt1 = min(nkt, kt0 + g.kt_chunk);
     // split-bf16 forms: the k-range is walked again on the same accumulators for every correction term -- (A_hi, B_lo)
@@ -105,13 +113,13 @@ __global__ __launch_bounds__(256 * BMT, (NST == 2 && BMT == 1) ? 2 : 1) void gem
     for (int i = 0; i < 4; ++i) {
         const int r = (wv * 4 + i) * 8 + (lane >> 3);
         const int ch = (lane & 7) ^ (lane >> 3);
-        ap[i] = g.A + seg_row(g, min(m0 + r, g.M - 1)) * g.lda + ch * 8;
+        ap[i] = Abase + seg_row(g, min(m0 + r, g.M - 1)) * g.lda + ch * 8;
     }
 #pragma unroll
     for (int i = 0; i < NB_I; ++i) {
         const int r = (wv * NB_I + i) * 8 + (lane >> 3);
         const int ch = (lane & 7) ^ (lane >> 3);
-        bp[i] = g.B + (long long)min(n0 + r, g.N - 1) * g.ldb + ch * 8;
+        bp[i] = Bbase + (long long)min(n0 + r, g.N - 1) * g.ldb + ch * 8;
     }
     auto stage = [&](int v, int buf) {               // v: virtual k-tile index in [0, nvirt)
         const int seg = v >= 2 * nreal ? 2 : (v >= nreal ? 1 : 0);
@@ -541,11 +549,13 @@ __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const float* slab
 
 }  // namespace
 
+struct GbCat { int tm_b1, tm_b2; long long a_shift1, a_shift2; const __bf16* B1; const __bf16* B2; };
+
 static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, long long lda, long long a_kstride,
                           const void* B, const void* B_lo, long long ldb, long long b_kstride,
                           float* C, long long ldc, const float* bias, int accumulate, int splitk, void* stream,
                           int seg_len = 0, long long seg_stride = 0, long long seg_off = 0, bool c_bf16 = false,
-                          float* slabs = nullptr, size_t slab_bytes = 0, bool f16 = false) {
+                          float* slabs = nullptr, size_t slab_bytes = 0, bool f16 = false, const GbCat* cat = nullptr) {
     CRUSE_REQUIRE(!f16 || (!A_lo && !B_lo && !c_bf16 && !slabs && splitk == 1 && !accumulate), CRUSE_E_SHAPE,
                   "gemm_f16_nt: one pass, f32 result stored (no low planes, no split-K, no accumulation)");
     CRUSE_REQUIRE(!c_bf16 || (!accumulate && splitk == 1), CRUSE_E_SHAPE, "gemm_bf16_nt: a bf16 result is stored, not accumulated");
@@ -574,8 +584,10 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.a_ks = a_kstride; g.b_ks = b_kstride;
     g.accumulate = accumulate; g.splitk = splitk; g.kt_chunk = kt_chunk;
     g.seg_len = seg_len; g.seg_stride = seg_stride; g.seg_off = seg_off;
+    g.tm_b1 = g.tm_b2 = 0x7fffffff; g.a_shift1 = g.a_shift2 = 0; g.B1 = g.B2 = nullptr;
+    if (cat) { g.tm_b1 = cat->tm_b1; g.tm_b2 = cat->tm_b2; g.a_shift1 = cat->a_shift1; g.a_shift2 = cat->a_shift2; g.B1 = cat->B1; g.B2 = cat->B2; }
     // 256-row tiles (8 waves, three stages) for the un-split products with many row tiles: the gate projections and dX (option gb_bm256)
-    const bool big = splitk == 1 && !slabs && !f16 && M >= 16 * BM && cruse_opt("gb_bm256", 0) != 0;
+    const bool big = splitk == 1 && !slabs && !f16 && !cat && M >= 16 * BM && cruse_opt("gb_bm256", 0) != 0;
     g.tiles_m = cdiv(M, big ? 2 * BM : BM); g.tiles_n = cdiv(N, BN);
     g.xcdk = (xcdk && splitk > 1) ? 1 : 0;
     g.slab = 0;
@@ -678,6 +690,35 @@ extern "C" int cruse_gemm_bf16_nt_slabs(int M, int N, int K, const void* A, long
     CRUSE_REQUIRE(scratch != nullptr, CRUSE_E_SHAPE, "gemm_bf16_nt_slabs: scratch is NULL");
     return gemm_bf16_impl(M, N, K, A, nullptr, lda, a_kstride, B, nullptr, ldb, b_kstride, C, ldc, nullptr, 1, splitk, stream, 0, 0, 0,
                           false, reinterpret_cast<float*>(scratch), scratch_bytes);
+}
+
+// Up to three products that share N, K, the operand strides and the A tensor, concatenated along M into ONE launch and one output:
+//   C[sum M_i, N] += cat_i( A[a_rows[i] .. a_rows[i] + M_i) . B_i^T )          (slab form: split-K without atomics, as above)
+// The three weight-gradient products of a GRU layer -- (r, z, n_i)^T x, (r, z)^T h_{t-1}, n_h^T h_{t-1} -- are such a set: their A rows are
+// slabs of the one time-major gate-gradient tensor, and dW_ih / dW_hh lie back to back in the flat gradient buffer.  One launch walks all 150
+// output tiles of a k-slice on its XCD: the gate-gradient k-tiles are fetched once for the three products, and two launches + two reduce
+// passes with their ramps and tails go.  M_i % 128 == 0 for every product but the last.
+extern "C" int cruse_gemm_bf16_nt_slabs_cat(int nprob, const int* Ms, int N, int K, const void* A, const long long* a_rows, long long lda,
+                                            long long a_kstride, const void* const* Bs, long long ldb, long long b_kstride,
+                                            float* C, long long ldc, int splitk, void* scratch, size_t scratch_bytes, void* stream) {
+    CRUSE_REQUIRE(nprob >= 1 && nprob <= 3 && Ms && a_rows && Bs && scratch, CRUSE_E_SHAPE, "gemm_bf16_nt_slabs_cat: 1..3 products");
+    int M = 0, tb[3] = {0, 0, 0};
+    for (int i = 0; i < nprob; ++i) {
+        CRUSE_REQUIRE(Ms[i] > 0 && (i == nprob - 1 || Ms[i] % BM == 0) && a_rows[i] >= 0 && Bs[i] != nullptr && ((uintptr_t)Bs[i] % 16) == 0,
+                      CRUSE_E_SHAPE, "gemm_bf16_nt_slabs_cat: product %d (M = %d: a multiple of %d except for the last)", i, Ms[i], BM);
+        tb[i] = M / BM; M += Ms[i];
+    }
+    GbCat cat;
+    cat.tm_b1 = nprob > 1 ? tb[1] : 0x7fffffff; cat.tm_b2 = nprob > 2 ? tb[2] : 0x7fffffff;
+    // virtual row m of product i is A row a_rows[i] + (m - first virtual row of i); the kernel adds m * lda itself
+    const long long first1 = nprob > 1 ? (long long)tb[1] * BM : 0, first2 = nprob > 2 ? (long long)tb[2] * BM : 0;
+    cat.a_shift1 = nprob > 1 ? (a_rows[1] - a_rows[0] - first1) * lda : 0;
+    cat.a_shift2 = nprob > 2 ? (a_rows[2] - a_rows[0] - first2) * lda : 0;
+    cat.B1 = nprob > 1 ? (const __bf16*)Bs[1] : nullptr; cat.B2 = nprob > 2 ? (const __bf16*)Bs[2] : nullptr;
+    const __bf16* A0 = (const __bf16*)A + a_rows[0] * lda;
+    CRUSE_REQUIRE(a_kstride > BK, CRUSE_E_SHAPE, "gemm_bf16_nt_slabs_cat: K-tiled A operand (rows lda apart inside a k-tile)");
+    return gemm_bf16_impl(M, N, K, A0, nullptr, lda, a_kstride, Bs[0], nullptr, ldb, b_kstride, C, ldc, nullptr, 1, splitk, stream, 0, 0, 0,
+                          false, reinterpret_cast<float*>(scratch), scratch_bytes, false, &cat);
 }
 
 extern "C" int cruse_gemm_bf16_nt_obf16(int M, int N, int K, const void* A_hi, const void* A_lo, long long lda, long long a_kstride,

@@ -524,6 +524,22 @@ def gemm_bf16_nt(M, N, K, A, a_off, lda, Bm, b_off, ldb, C, c_off, ldc, bias=Non
                                  C.data_ptr() + 4 * c_off, ldc, _p(bias), 1 if accumulate else 0, splitk, _stream()))
 
 
+def gemm_bf16_nt_cat(Ms, N, K, A, a_rows, lda, Bs, b_off, ldb, C, c_off, ldc, splitk, a_kstride=64, b_kstride=64):
+    """C[sum Ms, N] += cat_i(A[a_rows[i] : a_rows[i] + Ms[i]] . Bs[i]^T): up to three split-K slab products in ONE launch
+    (cruse_gemm_bf16_nt_slabs_cat; a_rows in rows of A, b_off / c_off in elements)."""
+    n = len(Ms)
+    if A.dtype != torch.bfloat16 or any(b.dtype != torch.bfloat16 for b in Bs) or C.dtype != torch.float32:
+        raise RuntimeError("gemm_bf16_nt_cat needs bf16 operands and an f32 result")
+    nbytes = lib.cruse_gemm_bf16_slab_bytes(int(sum(Ms)), N, splitk)
+    ws = _ws(("gemm_slabs", _stream()), nbytes, C.device)
+    ms = (ctypes.c_int * n)(*[int(m) for m in Ms])
+    ar = (ctypes.c_longlong * n)(*[int(r) for r in a_rows])
+    bs = (ctypes.c_void_p * n)(*[b.data_ptr() + 2 * b_off for b in Bs])
+    check(lib.cruse_gemm_bf16_nt_slabs_cat(n, ctypes.cast(ms, ctypes.c_void_p), N, K, A.data_ptr(), ctypes.cast(ar, ctypes.c_void_p), lda, a_kstride,
+                                           ctypes.cast(bs, ctypes.c_void_p), ldb, b_kstride, C.data_ptr() + 4 * c_off, ldc, splitk, _p(ws),
+                                           ws.numel(), _stream()))
+
+
 def gemm_bf16_nt_seg(M, N, K, A_hi, A_lo, a_off, lda, B_hi, B_lo, b_off, ldb, C, c_off, ldc, seg, bias=None, accumulate=False,
                      b_kstride=64):
     """gemm_bf16_nt / gemm_bf16x3_nt (A_lo / B_lo None: plain bf16) on the rows of ONE TIME CHUNK: seg = (seg_len, seg_stride,

@@ -308,6 +308,14 @@ size_t cruse_gemm_bf16_slab_bytes(int M, int N, int splitk);
 int cruse_gemm_bf16_nt_slabs(int M, int N, int K, const void* A, long long lda, long long a_kstride,
                              const void* B, long long ldb, long long b_kstride,
                              float* C, long long ldc, int splitk, void* scratch, size_t scratch_bytes, void* stream);
+/* (ABI 9) Up to three products that share N, K, the operand strides and the A tensor, concatenated along M into ONE launch and ONE output:
+ *   C[sum M_i, N] += cat_i( A[a_rows[i] .. a_rows[i] + M_i) . B_i^T )      slab form as above; M_i % 128 == 0 for all but the last product.
+ * The three weight-gradient products of an nn.GRU layer (cruse_net.py:23-31: dW_ih += (r, z, n_i)^T x, dW_hh += (r, z)^T h_{t-1} and
+ * n_h^T h_{t-1}) are such a set: their A rows are slabs of the one time-major gate-gradient tensor, and dW_ih / dW_hh lie back to back in
+ * the flat gradient buffer.  Ms, a_rows, Bs: HOST arrays of nprob (1..3) entries. */
+int cruse_gemm_bf16_nt_slabs_cat(int nprob, const int* Ms, int N, int K, const void* A, const long long* a_rows, long long lda,
+                                 long long a_kstride, const void* const* Bs, long long ldb, long long b_kstride,
+                                 float* C, long long ldc, int splitk, void* scratch, size_t scratch_bytes, void* stream);
 /* The same product -- or, with low planes (A_lo nullable, B_lo nullable: plain bf16), the split-bf16 form of
  * cruse_gemm_bf16x3_nt -- with the result STORED AS bf16 (C bf16 [M, ldc]; f32 accumulation, bias added in f32 before the one
  * rounding; no accumulate, no split-K): gi = x W_ih^T + b_ih as bf16 rows for cruse_gru_seq_fwd_ex(gi_bf16 = 1) -- half the bytes
