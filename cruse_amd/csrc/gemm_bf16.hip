@@ -42,6 +42,9 @@ struct GbArgs {
     // [tm_b2, ..) product 2 -- each with its own B operand and its own first A row (a_shift*: elements added to the A address of the
     // VIRTUAL row), all sharing N, K, the strides and one output [sum of the M_i, N].  tm_b1 = tm_b2 = INT_MAX: one product.
     int tm_b1, tm_b2; long long a_shift1, a_shift2; const __bf16* B1; const __bf16* B2;
+    // ATR (cruse_gemm_bf16_nt_atr): A is read from its TIME-MAJOR K-tiled image -- element (m, k) at A[(m / 64) * a_mbs + k * 64 + m % 64], the
+    // layout of the gate-gradient tensor dgT the weight-gradient GEMMs consume -- so the row-major copy dgi need not exist.  a_ks = 64 * 64.
+    long long a_mbs; int a_mb_last;
 };
 
 __device__ __forceinline__ long long seg_row(const GbArgs& g, int m) {
@@ -64,8 +67,15 @@ __device__ __forceinline__ long long seg_row(const GbArgs& g, int m) {
 // step are cold operands and the side stream's traffic, not this loop.
 // F16: the operands are IEEE f16 (same bytes per element, same staging and fragment layout; v_mfma_f32_16x16x32_f16): the forward gate
 // projection as ONE pass -- 11 significant bits on both operands against 8 + the W_ih low-plane pass of the split-bf16 form (cruse_gemm_f16_nt).
-template <int MODE, int NST, int BMT = 1, bool F16 = false>
+// ATR: the A tile is staged from a k-major source ([64 k][64 m] per 64-row block: 8 KB contiguous per block and k-tile, lane-linear LDS-DMA as
+// ever) and its MFMA fragments are TRANSPOSING LDS reads: ds_read_b64_tr_b16 hands lane c of a 16-lane group the four k of column c of a [4 k][16 m]
+// block whose rows the lanes 4 r .. 4 r + 3 address (measured, tools/probes/tr16_probe.hip) -- two reads per fragment.  The k-rows of the image are 128
+// bytes (32 banks) apart, and a 32-lane service group reads rows {0..3} + 8 kg of one parity class each: the 16-byte chunks of row k are XOR-swizzled
+// (on the global SOURCE address, as for the row-major image) by ((k >> 1 & 1) | (k >> 3 & 1) << 1) << 1, which puts the four same-parity rows of a
+// group on four different 32-byte bank windows -- conflict-free.
+template <int MODE, int NST, int BMT = 1, bool F16 = false, bool ATR = false, bool PIPE = false>
 __global__ __launch_bounds__(256 * BMT, (NST == 2 && BMT == 1) ? 2 : 1) void gemm_bf16_nt_kernel(const GbArgs g) {
+    static_assert(!ATR || (BMT == 1 && !F16), "transposed-A staging: 128-row tiles, bf16");
     constexpr int BM_ = BM * BMT, A_BYTES = TILE_BYTES * BMT, STAGE_BYTES = A_BYTES + TILE_BYTES;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_dyn[];
     auto As_ = [&](int buf) -> unsigned char* { return smem_dyn + (size_t)buf * STAGE_BYTES; };            // [stage][A | B]
@@ -111,9 +121,17 @@ __global__ __launch_bounds__(256 * BMT, (NST == 2 && BMT == 1) ? 2 : 1) void gem
     const __bf16* bp[NB_I];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int r = (wv * 4 + i) * 8 + (lane >> 3);
-        const int ch = (lane & 7) ^ (lane >> 3);
-        ap[i] = Abase + seg_row(g, min(m0 + r, g.M - 1)) * g.lda + ch * 8;
+        if constexpr (ATR) {
+            const int j = wv * 4 + i;                            // instruction j fills k-rows (j & 7) * 8 .. + 8 of 64-row block j >> 3
+            const int krow = (j & 7) * 8 + (lane >> 3);
+            const int ch = (lane & 7) ^ ((((krow >> 1) & 1) | (((krow >> 3) & 1) << 1)) << 1);
+            const int mb = min(2 * tm + (j >> 3), g.a_mb_last);  // (rows past M: the last block again -- computed, never stored)
+            ap[i] = Abase + (long long)mb * g.a_mbs + krow * 64 + ch * 8;
+        } else {
+            const int r = (wv * 4 + i) * 8 + (lane >> 3);
+            const int ch = (lane & 7) ^ (lane >> 3);
+            ap[i] = Abase + seg_row(g, min(m0 + r, g.M - 1)) * g.lda + ch * 8;
+        }
     }
 #pragma unroll
     for (int i = 0; i < NB_I; ++i) {
@@ -149,7 +167,64 @@ __global__ __launch_bounds__(256 * BMT, (NST == 2 && BMT == 1) ? 2 : 1) void gem
         offb[kk] = (wn * 64 + (lane & 15)) * 128 + c * 16;
     }
 
-    auto compute = [&](int buf) {
+    // ATR: byte offset of this lane's 8-byte piece for sub-tile i (k-row kg * 8 + q of the half (kk, h) added as a constant)
+    int offt[4];
+    if constexpr (ATR) {
+        const int c15 = lane & 15, q = c15 >> 2, kg = lane >> 4;
+        const int gsw = ((q >> 1) & 1) | ((kg & 1) << 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            offt[i] = wm * 8192 + (kg * 8 + q) * 128 + (((i ^ gsw) * 2 + ((c15 & 3) >> 1)) * 16) + (c15 & 1) * 8;
+    }
+
+    // One k-tile = two 32-deep halves of 16 MFMAs per wave.  CRUSE_GB_PIPE: the fragment reads of both halves first, the order then pinned with
+    // sched_group_barrier (reads of half 0, one read of half 1 behind each of the first MFMAs of half 0, the remaining MFMAs) -- left to itself the
+    // scheduler re-uses the A fragment registers and waits with lgkmcnt(0) in front of every group of 4 to 8 MFMAs, which measured no slower.
+    auto compute_pipe = [&](int buf) {
+        const unsigned char* As = As_(buf);
+        const unsigned char* Bs = Bs_(buf);
+        bf16x8 fa[2][4], fb[2][4];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (ATR) {
+                    typedef __attribute__((ext_vector_type(4))) short s16x4_;
+                    typedef __attribute__((address_space(3))) s16x4_ lds_s16x4;
+                    typedef __attribute__((ext_vector_type(8))) short s16x8_;
+                    const s16x4_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(As + offt[i] + kk * 32 * 128));
+                    const s16x4_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(As + offt[i] + kk * 32 * 128 + 4 * 128));
+                    const s16x8_ both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    fa[kk][i] = __builtin_bit_cast(bf16x8, both);
+                } else {
+                    fa[kk][i] = *reinterpret_cast<const bf16x8*>(As + offa[kk] + i * 16 * 128);
+                }
+                fb[kk][i] = *reinterpret_cast<const bf16x8*>(Bs + offb[kk] + i * 16 * 128);
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if constexpr (F16) {
+                        typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_, fa[kk][i]), __builtin_bit_cast(f16x8_, fb[kk][j]),
+                                                                           acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+                    }
+        constexpr int NLH = ATR ? 12 : 8;                    // LDS reads per half
+        __builtin_amdgcn_sched_group_barrier(0x100, NLH, 0);
+#pragma unroll
+        for (int r = 0; r < NLH; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 32 - NLH, 0);
+    };
+    auto compute_plain = [&](int buf) {
         const unsigned char* As = As_(buf);
         const unsigned char* Bs = Bs_(buf);
 #pragma unroll
@@ -157,7 +232,17 @@ __global__ __launch_bounds__(256 * BMT, (NST == 2 && BMT == 1) ? 2 : 1) void gem
             bf16x8 fa[4], fb[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                fa[i] = *reinterpret_cast<const bf16x8*>(As + offa[kk] + i * 16 * 128);
+                if constexpr (ATR) {
+                    typedef __attribute__((ext_vector_type(4))) short s16x4_;
+                    typedef __attribute__((address_space(3))) s16x4_ lds_s16x4;
+                    typedef __attribute__((ext_vector_type(8))) short s16x8_;
+                    const s16x4_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(As + offt[i] + kk * 32 * 128));
+                    const s16x4_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(As + offt[i] + kk * 32 * 128 + 4 * 128));
+                    const s16x8_ both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    fa[i] = __builtin_bit_cast(bf16x8, both);
+                } else {
+                    fa[i] = *reinterpret_cast<const bf16x8*>(As + offa[kk] + i * 16 * 128);
+                }
                 fb[i] = *reinterpret_cast<const bf16x8*>(Bs + offb[kk] + i * 16 * 128);
             }
 #pragma unroll
@@ -173,6 +258,7 @@ __global__ __launch_bounds__(256 * BMT, (NST == 2 && BMT == 1) ? 2 : 1) void gem
                     }
         }
     };
+    auto compute = [&](int buf) { if constexpr (PIPE) compute_pipe(buf); else compute_plain(buf); };
     if constexpr (NST == 2) {
         if (nvirt > 0) stage(0, 0);
         for (int v = 0; v < nvirt; ++v) {
@@ -555,7 +641,11 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
                           const void* B, const void* B_lo, long long ldb, long long b_kstride,
                           float* C, long long ldc, const float* bias, int accumulate, int splitk, void* stream,
                           int seg_len = 0, long long seg_stride = 0, long long seg_off = 0, bool c_bf16 = false,
-                          float* slabs = nullptr, size_t slab_bytes = 0, bool f16 = false, const GbCat* cat = nullptr) {
+                          float* slabs = nullptr, size_t slab_bytes = 0, bool f16 = false, const GbCat* cat = nullptr,
+                          long long atr_mbs = 0, int atr_mb_last = 0) {
+    const bool atr = atr_mbs != 0;
+    CRUSE_REQUIRE(!atr || (!A_lo && !B_lo && !c_bf16 && !slabs && splitk == 1 && !f16 && !cat && seg_len == 0), CRUSE_E_SHAPE,
+                  "gemm_bf16_nt_atr: plain bf16, one pass, no split-K");
     CRUSE_REQUIRE(!f16 || (!A_lo && !B_lo && !c_bf16 && !slabs && splitk == 1 && !accumulate), CRUSE_E_SHAPE,
                   "gemm_f16_nt: one pass, f32 result stored (no low planes, no split-K, no accumulation)");
     CRUSE_REQUIRE(!c_bf16 || (!accumulate && splitk == 1), CRUSE_E_SHAPE, "gemm_bf16_nt: a bf16 result is stored, not accumulated");
@@ -584,10 +674,11 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.a_ks = a_kstride; g.b_ks = b_kstride;
     g.accumulate = accumulate; g.splitk = splitk; g.kt_chunk = kt_chunk;
     g.seg_len = seg_len; g.seg_stride = seg_stride; g.seg_off = seg_off;
+    g.a_mbs = atr_mbs; g.a_mb_last = atr_mb_last;
     g.tm_b1 = g.tm_b2 = 0x7fffffff; g.a_shift1 = g.a_shift2 = 0; g.B1 = g.B2 = nullptr;
     if (cat) { g.tm_b1 = cat->tm_b1; g.tm_b2 = cat->tm_b2; g.a_shift1 = cat->a_shift1; g.a_shift2 = cat->a_shift2; g.B1 = cat->B1; g.B2 = cat->B2; }
     // 256-row tiles (8 waves, three stages) for the un-split products with many row tiles: the gate projections and dX (option gb_bm256)
-    const bool big = splitk == 1 && !slabs && !f16 && !cat && M >= 16 * BM && cruse_opt("gb_bm256", 0) != 0;
+    const bool big = splitk == 1 && !slabs && !f16 && !cat && !atr && M >= 16 * BM && cruse_opt("gb_bm256", 0) != 0;
     g.tiles_m = cdiv(M, big ? 2 * BM : BM); g.tiles_n = cdiv(N, BN);
     g.xcdk = (xcdk && splitk > 1) ? 1 : 0;
     g.slab = 0;
@@ -613,9 +704,16 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
     { const int e = cruse_opt("gb_deep_min", 0); if (e > 0) deep_min = e; }      // profiling options
     bool deep = kt_chunk >= deep_min;
     { const int e = cruse_opt("gb_deep", -1); if (e >= 0) deep = e != 0; }
+    const bool pipe = cruse_opt("gb_pipe", 0) != 0;     // pinned instruction order inside a k-tile (see compute_pipe)
     const size_t lds = big ? (size_t)3 * 3 * TILE_BYTES : (size_t)(deep ? 3 : 2) * 2 * TILE_BYTES;
 #define CRUSE_GB_LAUNCH(MODE, NST)                                                                               \
     do {                                                                                                         \
+        if (pipe) {                                                                                              \
+            int rc0 = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_bf16_nt_kernel<MODE, NST, 1, false, false, true>), lds, "gemm_bf16_nt"); \
+            if (rc0) return rc0;                                                                                 \
+            hipLaunchKernelGGL((gemm_bf16_nt_kernel<MODE, NST, 1, false, false, true>), grid, dim3(256), lds, st, g); \
+            break;                                                                                               \
+        }                                                                                                        \
         int rc0 = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_bf16_nt_kernel<MODE, NST>), lds,       \
                                        "gemm_bf16_nt");                                                          \
         if (rc0) return rc0;                                                                                     \
@@ -641,6 +739,20 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
         hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, slabs, splitk, g.slab, M, N,
                            c_final, ldc_final);
         CRUSE_LAUNCH_CHECK("gemm_slab_reduce");
+        return CRUSE_OK;
+    }
+    if (atr) {
+        const size_t ldsa = (size_t)2 * 2 * TILE_BYTES;
+        if (accumulate) {
+            int rc0 = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_bf16_nt_kernel<1, 2, 1, false, true>), ldsa, "gemm_bf16_nt_atr");
+            if (rc0) return rc0;
+            hipLaunchKernelGGL((gemm_bf16_nt_kernel<1, 2, 1, false, true>), grid, dim3(256), ldsa, st, g);
+        } else {
+            int rc0 = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_bf16_nt_kernel<0, 2, 1, false, true>), ldsa, "gemm_bf16_nt_atr");
+            if (rc0) return rc0;
+            hipLaunchKernelGGL((gemm_bf16_nt_kernel<0, 2, 1, false, true>), grid, dim3(256), ldsa, st, g);
+        }
+        CRUSE_LAUNCH_CHECK("gemm_bf16_nt_atr");
         return CRUSE_OK;
     }
     if (f16) {
@@ -677,6 +789,19 @@ extern "C" int cruse_gemm_f16_nt(int M, int N, int K, const void* A, long long l
                                  float* C, long long ldc, const float* bias, void* stream) {
     return gemm_bf16_impl(M, N, K, A, nullptr, lda, a_kstride, B, nullptr, ldb, b_kstride, C, ldc, bias, 0, 1, stream, 0, 0, 0, false,
                           nullptr, 0, true);
+}
+
+// C[M,N] (+)= A[M,K] . B[N,K]^T with A given as its TIME-MAJOR K-tiled image: element (m, k) at A_T[(m / 64) * a_mb_stride + k * 64 + m % 64],
+// n_mb 64-row blocks present (rows M <= m < 64 * n_mb hold finite values).  This is the layout of the gate-gradient tensor dgT
+// [ceil(rows / 64)][G][4][Hg][64] the weight-gradient GEMMs consume (A_T = dgT + group * 4 * Hg * 64, a_mb_stride = G * 4 * Hg * 64): the input
+// gradient dX = dgi . W_ih is formed from it directly and the row-major copy dgi is never written.  K % 64 == 0.
+extern "C" int cruse_gemm_bf16_nt_atr(int M, int N, int K, const void* A_T, long long a_mb_stride, int n_mb,
+                                      const void* B, long long ldb, long long b_kstride,
+                                      float* C, long long ldc, int accumulate, void* stream) {
+    CRUSE_REQUIRE(a_mb_stride >= (long long)K * 64 && a_mb_stride % 8 == 0 && n_mb >= 1 && (long long)n_mb * 64 >= M, CRUSE_E_SHAPE,
+                  "gemm_bf16_nt_atr: a_mb_stride=%lld n_mb=%d for M=%d K=%d", a_mb_stride, n_mb, M, K);
+    return gemm_bf16_impl(M, N, K, A_T, nullptr, 64, 64 * 64, B, nullptr, ldb, b_kstride, C, ldc, nullptr, accumulate, 1, stream, 0, 0, 0, false,
+                          nullptr, 0, false, nullptr, a_mb_stride, n_mb - 1);
 }
 
 extern "C" size_t cruse_gemm_bf16_slab_bytes(int M, int N, int splitk) {

@@ -316,6 +316,14 @@ int cruse_gemm_bf16_nt_slabs(int M, int N, int K, const void* A, long long lda, 
 int cruse_gemm_bf16_nt_slabs_cat(int nprob, const int* Ms, int N, int K, const void* A, const long long* a_rows, long long lda,
                                  long long a_kstride, const void* const* Bs, long long ldb, long long b_kstride,
                                  float* C, long long ldc, int splitk, void* scratch, size_t scratch_bytes, void* stream);
+/* (ABI 9) C[M,N] (+)= A[M,K] . B[N,K]^T with A given as its TIME-MAJOR K-tiled image: element (m, k) at A_T[(m / 64) * a_mb_stride + k * 64 + m % 64],
+ * n_mb 64-row blocks present (rows M <= m < 64 * n_mb hold finite values); B, C as cruse_gemm_bf16_nt; K % 64 == 0.  That is the layout of the
+ * gate-gradient tensor dgT [ceil(rows / 64)][G][4][Hg][64] of cruse_gru_gate_grads_bf16 (A_T = dgT + group * 4 * Hg * 64, a_mb_stride =
+ * G * 4 * Hg * 64): the input gradient of nn.GRU's x W_ih^T (cruse_net.py:23-31) is formed from it directly -- the MFMA fragments are transposing
+ * LDS reads (ds_read_b64_tr_b16) -- and the row-major copy dgi is never written. */
+int cruse_gemm_bf16_nt_atr(int M, int N, int K, const void* A_T, long long a_mb_stride, int n_mb,
+                           const void* B, long long ldb, long long b_kstride,
+                           float* C, long long ldc, int accumulate, void* stream);
 /* The same product -- or, with low planes (A_lo nullable, B_lo nullable: plain bf16), the split-bf16 form of
  * cruse_gemm_bf16x3_nt -- with the result STORED AS bf16 (C bf16 [M, ldc]; f32 accumulation, bias added in f32 before the one
  * rounding; no accumulate, no split-K): gi = x W_ih^T + b_ih as bf16 rows for cruse_gru_seq_fwd_ex(gi_bf16 = 1) -- half the bytes

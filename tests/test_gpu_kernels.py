@@ -837,6 +837,35 @@ def test_gemm_concatenated_weight_gradient_products(ops, Hg, K, Ms):
         ops.gemm_bf16_nt_cat([70, 128], Hg, ldT, dgT, [0, 0], 64, [xT, hT], 0, 64, cc, 0, Hg, -8, a_kstride=ka, b_kstride=kb)
 
 
+@pytest.mark.parametrize("rows,G,Hg", [(25664, 1, 640), (1000, 2, 128), (64 * 3 + 5, 1, 64)])
+def test_gemm_input_gradient_from_the_time_major_gate_gradients(ops, rows, G, Hg):
+    """cruse_gemm_bf16_nt_atr (ABI 9, EngineConfig.dx_atr): dX = dgi . W_ih (autograd of nn.GRU's x W_ih^T, cruse_net.py:23-31) with the A
+    operand read from the TIME-MAJOR gate-gradient tensor dgT through transposing LDS reads -- the same bf16 values in the same MFMA order as
+    the row-major form: bit-identical, store and accumulate, every group, ragged last row block."""
+    torch.manual_seed(rows + Hg)
+    H = G * Hg
+    dh = (torch.randn(rows, H) * 0.1).cuda()
+    coef = torch.randn(rows, G, 3, Hg).cuda().to(torch.bfloat16)
+    an = torch.randn(rows, H).cuda()
+    bi = [torch.zeros(3 * Hg).cuda() for _ in range(G)]; bh = [torch.zeros(3 * Hg).cuda() for _ in range(G)]
+    dgi, dgT, ldT = ops.gru_gate_grads_bf16(dh, coef, an, rows, G, Hg, bi, bh)
+    _, dgT2, _ = ops.gru_gate_grads_bf16(dh, coef, an, rows, G, Hg, bi, bh, want_dgi=False)
+    assert torch.equal(dgT2.view(torch.int16), dgT.view(torch.int16))
+    for i in range(G):
+        W = (torch.randn(3 * Hg, Hg) / Hg ** 0.5).cuda()
+        w_t = ops.transpose_bf16(W, 3 * Hg, Hg)
+        for acc in (False, True):
+            base = torch.randn(rows, H).cuda()
+            c0, c1 = base.clone(), base.clone()
+            ops.gemm_bf16_nt(rows, Hg, w_t.shape[0] * 64, dgi, i * 3 * Hg, 3 * H, w_t, 0, 64, c0, i * Hg, H, accumulate=acc, b_kstride=Hg * 64)
+            ops.gemm_bf16_nt_atr(rows, Hg, 3 * Hg, dgT, 4 * i * Hg * 64, G * 4 * Hg * 64, ldT // 64, w_t, 0, 64, c1, i * Hg, H, accumulate=acc,
+                                 b_kstride=Hg * 64)
+            assert torch.equal(c0, c1), (i, acc)
+    want = dgi.view(rows, G, 3 * Hg)[:, 0].double() @ W.double().to(torch.bfloat16).double() if G == 1 else None
+    if want is not None:
+        assert rel_l2(c1 - base, want) < 1e-5
+
+
 def test_gru_wide_chains_at_the_bench_length(ops):
     """T = 401, B = 64, Hg = 640: the wide-chain forward launch (4 chains of 16 on 80 CUs) against the lean one (8 chains of 8 on
     160) over the whole sequence -- 401 dependent hand-offs per chain -- bit for bit; two wide launches side by side on the two
