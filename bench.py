@@ -178,8 +178,10 @@ class KernelTimer:
 
     NAMES = ["stft", "conv_gather", "conv_scatter2", "conv_gather_bnin", "conv_scatter2_bnin", "conv_wgrad", "channel_sum", "col_sum", "bn_stats", "bn_finalize",
              "bn_act_fwd", "bn_finalize_act_fwd", "bn_act_bwd", "ln_fwd", "ln_bwd", "gemm", "gemm_bf16_nt", "gemm_bf16x3_nt", "gemm_bf16_tn", "gru_gate_bias_sums", "cast_bf16", "cast_bf16_padded",
-             "ktile_bf16", "transpose_bf16",
+             "ktile_bf16", "transpose_bf16", "gemm_bf16_nt_cat", "gemm_bf16_nt_atr", "gemm_f16_nt", "ktile_f16",
              "gru_seq_fwd", "gru_seq_bwd", "gru_gate_grads", "gru_gate_grads_bf16", "mask_loss"]
+    # entry points that launch the same kernel as another one are booked under that family
+    FAMILY = {"gemm_bf16_nt_cat": "gemm_bf16_nt", "gemm_bf16_nt_atr": "gemm_bf16_nt", "ktile_f16": "ktile_bf16"}
 
     def __init__(self, ops, eng):
         self.ops, self.rec, self.saved, self.eng = ops, [], {}, eng
@@ -193,7 +195,7 @@ class KernelTimer:
             f = getattr(self.ops, n)
             self.saved[n] = f
 
-            def wrap(*a, _f=f, _n=n, **k):
+            def wrap(*a, _f=f, _n=self.FAMILY.get(n, n), **k):
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(); out = _f(*a, **k); e1.record()
                 self.rec.append((_n, e0, e1))
@@ -294,7 +296,7 @@ def pmc_mfma_util():
     for fam, (busy, cap) in acc.items():
         out[fam] = round(busy / cap, 4) if cap else 0.0
     out["conv_gather"] = out["conv_scatter2"] = out.get("conv")
-    out["gemm_bf16x3_nt"] = out.get("gemm_bf16_nt")
+    out["gemm_bf16x3_nt"] = out["gemm_f16_nt"] = out.get("gemm_bf16_nt")
     return out
 
 
@@ -313,16 +315,19 @@ def kernel_rooflines(B, T, H, G, prec, per_step_ms, calls):
                          "avg_launch_ms": round(avg_ms, 4),
                          "note": f"latency-bound by design: {T} dependent steps per launch, "
                                  f"{avg_ms * 1e3 / T:.2f} us per step"}
-    for gname in ("gemm", "gemm_bf16_nt", "gemm_bf16x3_nt", "gemm_bf16_tn"):
+    # ALGORITHMIC flops: 2 layers x (gi, dX, dW_ih, dW_hh) = 8 products of 2 * rows * 3 Hg * Hg * G flops.  The forward projections run in their
+    # own families -- split-bf16 x3 (its extra MFMA passes are not counted) and / or the single f16 pass: one launch per group and layer, so
+    # launches / G = products --, the TN weight-gradient kernel takes 4 (dW_ih, dW_hh of both layers), the rest is gemm_bf16_nt's (the
+    # concatenated weight-gradient launch and the transposed-A dX are booked there).
+    fwd_prod = {f: calls[f] / float(G) for f in ("gemm_bf16x3_nt", "gemm_f16_nt") if f in per_step_ms}
+    for gname in ("gemm", "gemm_bf16_nt", "gemm_bf16x3_nt", "gemm_f16_nt", "gemm_bf16_tn"):
         if gname in per_step_ms:
-            # ALGORITHMIC flops: 2 layers x (gi, dX, dW_ih, dW_hh); when the forward projections run as split-bf16 x3 in
-            # their own family they are 2 of the 8 products (their 3 MFMA passes are not counted three times); the TN
-            # weight-gradient kernel takes 4 of them (dW_ih, dW_hh of both layers)
-            nprod = 8
-            if "gemm_bf16x3_nt" in per_step_ms:
-                nprod = 2 if gname == "gemm_bf16x3_nt" else 6
-            if "gemm_bf16_tn" in per_step_ms:
-                nprod = 4 if gname == "gemm_bf16_tn" else (2 if gname in ("gemm_bf16x3_nt", "gemm_bf16_nt") else nprod - 4)
+            if gname in fwd_prod:
+                nprod = fwd_prod[gname]
+            elif gname == "gemm_bf16_tn":
+                nprod = 4
+            else:
+                nprod = 8 - sum(fwd_prod.values()) - (4 if "gemm_bf16_tn" in per_step_ms else 0)
             flops = 2.0 * rows * 3 * Hg * Hg * G * nprod
             avg_ms = per_step_ms[gname] / calls[gname]
             ach = flops / (per_step_ms[gname] * 1e-3) / 1e12

@@ -42,6 +42,9 @@ struct GbArgs {
     // [tm_b2, ..) product 2 -- each with its own B operand and its own first A row (a_shift*: elements added to the A address of the
     // VIRTUAL row), all sharing N, K, the strides and one output [sum of the M_i, N].  tm_b1 = tm_b2 = INT_MAX: one product.
     int tm_b1, tm_b2; long long a_shift1, a_shift2; const __bf16* B1; const __bf16* B2;
+    // (products whose M_i is not a multiple of 128 occupy whole row tiles all the same: m_end* = end of product's VIRTUAL rows -- rows past it are
+    // computed and dropped --, c_rows* = output row of a virtual row minus that virtual row)
+    int m_end0, m_end1, m_end2; int c_rows1, c_rows2;
     // ATR (cruse_gemm_bf16_nt_atr): A is read from its TIME-MAJOR K-tiled image -- element (m, k) at A[(m / 64) * a_mbs + k * 64 + m % 64], the
     // layout of the gate-gradient tensor dgT the weight-gradient GEMMs consume -- so the row-major copy dgi need not exist.  a_ks = 64 * 64.
     long long a_mbs; int a_mb_last;
@@ -105,8 +108,9 @@ __global__ __launch_bounds__(256 * BMT, (NST == 2 && BMT == 1) ? 2 : 1) void gem
     const int m0 = tm * BM_, n0 = tn * BN;
     const __bf16* Abase = g.A;
     const __bf16* Bbase = g.B;
-    if (tm >= g.tm_b2) { Abase += g.a_shift2; Bbase = g.B2; }
-    else if (tm >= g.tm_b1) { Abase += g.a_shift1; Bbase = g.B1; }
+    int m_lim = g.m_end0, c_sh = 0;
+    if (tm >= g.tm_b2) { Abase += g.a_shift2; Bbase = g.B2; m_lim = g.m_end2; c_sh = g.c_rows2; }
+    else if (tm >= g.tm_b1) { Abase += g.a_shift1; Bbase = g.B1; m_lim = g.m_end1; c_sh = g.c_rows1; }
     const int nkt = g.K / BK;
     const int kt0 = tz * g.kt_chunk, kt1 = min(nkt, kt0 + g.kt_chunk);
     // split-bf16 forms: the k-range is walked again on the same accumulators for every correction term -- (A_hi, B_lo)
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256 * BMT, (NST == 2 && BMT == 1) ? 2 : 1) void gem
         } else {
             const int r = (wv * 4 + i) * 8 + (lane >> 3);
             const int ch = (lane & 7) ^ (lane >> 3);
-            ap[i] = Abase + seg_row(g, min(m0 + r, g.M - 1)) * g.lda + ch * 8;
+            ap[i] = Abase + seg_row(g, min(m0 + r, m_lim - 1)) * g.lda + ch * 8;
         }
     }
 #pragma unroll
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(256 * BMT, (NST == 2 && BMT == 1) ? 2 : 1) void gem
             const int m = m0 + wm * 64 + half * 32 + rr;
             float4 v = *reinterpret_cast<const float4*>(patch + rr * 68 + (lane & 15) * 4);
             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-            if (m < g.M) {
+            if (m < m_lim) {
                 if constexpr (MODE == 3) {                 // bf16 rows: 8-byte stores, 128-byte row segments
                     __bf16* cb = reinterpret_cast<__bf16*>(g.C) + seg_row(g, m) * g.ldc + nq;
                     if (nq + 3 < g.N && (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 7) == 0)) {
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(256 * BMT, (NST == 2 && BMT == 1) ? 2 : 1) void gem
                     }
                     continue;
                 }
-                float* c = g.C + (MODE == 4 ? (long long)tz * g.slab : 0ll) + seg_row(g, m) * g.ldc + nq;
+                float* c = g.C + (MODE == 4 ? (long long)tz * g.slab : 0ll) + (seg_row(g, m) + c_sh) * g.ldc + nq;
                 if (MODE == 2) {
                     if (nq < g.N) atomicAdd(c, v.x);
                     if (nq + 1 < g.N) atomicAdd(c + 1, v.y);
@@ -635,7 +639,7 @@ __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const float* slab
 
 }  // namespace
 
-struct GbCat { int tm_b1, tm_b2; long long a_shift1, a_shift2; const __bf16* B1; const __bf16* B2; };
+struct GbCat { int tm_b1, tm_b2; long long a_shift1, a_shift2; const __bf16* B1; const __bf16* B2; int m_end[3], c_rows[3], M_out; };
 
 static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, long long lda, long long a_kstride,
                           const void* B, const void* B_lo, long long ldb, long long b_kstride,
@@ -676,7 +680,13 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
     g.seg_len = seg_len; g.seg_stride = seg_stride; g.seg_off = seg_off;
     g.a_mbs = atr_mbs; g.a_mb_last = atr_mb_last;
     g.tm_b1 = g.tm_b2 = 0x7fffffff; g.a_shift1 = g.a_shift2 = 0; g.B1 = g.B2 = nullptr;
-    if (cat) { g.tm_b1 = cat->tm_b1; g.tm_b2 = cat->tm_b2; g.a_shift1 = cat->a_shift1; g.a_shift2 = cat->a_shift2; g.B1 = cat->B1; g.B2 = cat->B2; }
+    g.m_end0 = g.m_end1 = g.m_end2 = M; g.c_rows1 = g.c_rows2 = 0;
+    int M_out = M;                                   // rows of the output (cat: the products' rows without the tile padding between them)
+    if (cat) {
+        g.tm_b1 = cat->tm_b1; g.tm_b2 = cat->tm_b2; g.a_shift1 = cat->a_shift1; g.a_shift2 = cat->a_shift2; g.B1 = cat->B1; g.B2 = cat->B2;
+        g.m_end0 = cat->m_end[0]; g.m_end1 = cat->m_end[1]; g.m_end2 = cat->m_end[2]; g.c_rows1 = cat->c_rows[1]; g.c_rows2 = cat->c_rows[2];
+        M_out = cat->M_out;
+    }
     // 256-row tiles (8 waves, three stages) for the un-split products with many row tiles: the gate projections and dX (option gb_bm256)
     const bool big = splitk == 1 && !slabs && !f16 && !cat && !atr && M >= 16 * BM && cruse_opt("gb_bm256", 0) != 0;
     g.tiles_m = cdiv(M, big ? 2 * BM : BM); g.tiles_n = cdiv(N, BN);
@@ -687,9 +697,9 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
     const long long ldc_final = ldc;
     if (use_slabs) {                           // partial sums [slice][M][N] in the caller's scratch, then one ordered sum into C
         CRUSE_REQUIRE(N % 4 == 0 && ((uintptr_t)slabs % 16) == 0 && seg_len == 0, CRUSE_E_ALIGN, "gemm_bf16_nt: slab form needs N %% 4 == 0");
-        CRUSE_REQUIRE((size_t)splitk * M * N * sizeof(float) <= slab_bytes, CRUSE_E_SHAPE,
-                      "gemm_bf16_nt: %d slabs of %d x %d floats do not fit the %zu-byte scratch", splitk, M, N, slab_bytes);
-        g.C = slabs; g.ldc = N; g.slab = (long long)M * N; g.bias = nullptr;
+        CRUSE_REQUIRE((size_t)splitk * M_out * N * sizeof(float) <= slab_bytes, CRUSE_E_SHAPE,
+                      "gemm_bf16_nt: %d slabs of %d x %d floats do not fit the %zu-byte scratch", splitk, M_out, N, slab_bytes);
+        g.C = slabs; g.ldc = N; g.slab = (long long)M_out * N; g.bias = nullptr;
         CRUSE_REQUIRE(bias == nullptr, CRUSE_E_SHAPE, "gemm_bf16_nt: slab form has no bias");
     }
     if (splitk > 1) { g.nunits = splitk * g.tiles_n; g.inner = g.tiles_m; }
@@ -735,8 +745,8 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
     if (use_slabs) {
         if (deep) CRUSE_GB_LAUNCH(4, 3); else CRUSE_GB_LAUNCH(4, 2);
         CRUSE_LAUNCH_CHECK("gemm_bf16_nt");
-        const long long n4 = (long long)M * (N / 4);
-        hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, slabs, splitk, g.slab, M, N,
+        const long long n4 = (long long)M_out * (N / 4);
+        hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, slabs, splitk, g.slab, M_out, N,
                            c_final, ldc_final);
         CRUSE_LAUNCH_CHECK("gemm_slab_reduce");
         return CRUSE_OK;
@@ -822,27 +832,33 @@ extern "C" int cruse_gemm_bf16_nt_slabs(int M, int N, int K, const void* A, long
 // The three weight-gradient products of a GRU layer -- (r, z, n_i)^T x, (r, z)^T h_{t-1}, n_h^T h_{t-1} -- are such a set: their A rows are
 // slabs of the one time-major gate-gradient tensor, and dW_ih / dW_hh lie back to back in the flat gradient buffer.  One launch walks all 150
 // output tiles of a k-slice on its XCD: the gate-gradient k-tiles are fetched once for the three products, and two launches + two reduce
-// passes with their ramps and tails go.  M_i % 128 == 0 for every product but the last.
+// passes with their ramps and tails go.  A product whose M_i is not a multiple of 128 still starts on a row tile of its own (the padding rows are
+// computed and dropped); the output rows stay contiguous.
 extern "C" int cruse_gemm_bf16_nt_slabs_cat(int nprob, const int* Ms, int N, int K, const void* A, const long long* a_rows, long long lda,
                                             long long a_kstride, const void* const* Bs, long long ldb, long long b_kstride,
                                             float* C, long long ldc, int splitk, void* scratch, size_t scratch_bytes, void* stream) {
     CRUSE_REQUIRE(nprob >= 1 && nprob <= 3 && Ms && a_rows && Bs && scratch, CRUSE_E_SHAPE, "gemm_bf16_nt_slabs_cat: 1..3 products");
-    int M = 0, tb[3] = {0, 0, 0};
+    GbCat cat = {};
+    int tiles = 0, rows = 0, first[3] = {0, 0, 0};
+    for (int i = 0; i < 3; ++i) { cat.m_end[i] = 0; cat.c_rows[i] = 0; }
     for (int i = 0; i < nprob; ++i) {
-        CRUSE_REQUIRE(Ms[i] > 0 && (i == nprob - 1 || Ms[i] % BM == 0) && a_rows[i] >= 0 && Bs[i] != nullptr && ((uintptr_t)Bs[i] % 16) == 0,
-                      CRUSE_E_SHAPE, "gemm_bf16_nt_slabs_cat: product %d (M = %d: a multiple of %d except for the last)", i, Ms[i], BM);
-        tb[i] = M / BM; M += Ms[i];
+        CRUSE_REQUIRE(Ms[i] > 0 && a_rows[i] >= 0 && Bs[i] != nullptr && ((uintptr_t)Bs[i] % 16) == 0, CRUSE_E_SHAPE,
+                      "gemm_bf16_nt_slabs_cat: product %d (M = %d)", i, Ms[i]);
+        first[i] = tiles * BM;                       // a product starts on a row tile; the rows that pad its last tile are computed and dropped
+        cat.m_end[i] = first[i] + Ms[i];
+        cat.c_rows[i] = rows - first[i];
+        tiles += cdiv(Ms[i], BM); rows += Ms[i];
     }
-    GbCat cat;
-    cat.tm_b1 = nprob > 1 ? tb[1] : 0x7fffffff; cat.tm_b2 = nprob > 2 ? tb[2] : 0x7fffffff;
-    // virtual row m of product i is A row a_rows[i] + (m - first virtual row of i); the kernel adds m * lda itself
-    const long long first1 = nprob > 1 ? (long long)tb[1] * BM : 0, first2 = nprob > 2 ? (long long)tb[2] * BM : 0;
-    cat.a_shift1 = nprob > 1 ? (a_rows[1] - a_rows[0] - first1) * lda : 0;
-    cat.a_shift2 = nprob > 2 ? (a_rows[2] - a_rows[0] - first2) * lda : 0;
+    cat.M_out = rows;
+    cat.tm_b1 = nprob > 1 ? first[1] / BM : 0x7fffffff; cat.tm_b2 = nprob > 2 ? first[2] / BM : 0x7fffffff;
+    // virtual row m of product i is A row a_rows[i] + (m - first[i]); the kernel adds m * lda itself
+    cat.a_shift1 = nprob > 1 ? (a_rows[1] - a_rows[0] - first[1]) * lda : 0;
+    cat.a_shift2 = nprob > 2 ? (a_rows[2] - a_rows[0] - first[2]) * lda : 0;
     cat.B1 = nprob > 1 ? (const __bf16*)Bs[1] : nullptr; cat.B2 = nprob > 2 ? (const __bf16*)Bs[2] : nullptr;
     const __bf16* A0 = (const __bf16*)A + a_rows[0] * lda;
     CRUSE_REQUIRE(a_kstride > BK, CRUSE_E_SHAPE, "gemm_bf16_nt_slabs_cat: K-tiled A operand (rows lda apart inside a k-tile)");
-    return gemm_bf16_impl(M, N, K, A0, nullptr, lda, a_kstride, Bs[0], nullptr, ldb, b_kstride, C, ldc, nullptr, 1, splitk, stream, 0, 0, 0,
+    const int M_virtual = first[nprob - 1] + Ms[nprob - 1];
+    return gemm_bf16_impl(M_virtual, N, K, A0, nullptr, lda, a_kstride, Bs[0], nullptr, ldb, b_kstride, C, ldc, nullptr, 1, splitk, stream, 0, 0, 0,
                           false, reinterpret_cast<float*>(scratch), scratch_bytes, false, &cat);
 }
 

@@ -663,8 +663,8 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
                 # dW_ih += (r, z, n_i)^T x ; dW_hh += (r, z)^T h_{t-1} and n_h^T h_{t-1}
                 a0, b0 = 4 * i * Hg * 64, i * Hg * 64
                 g_ih, g_hh = G[nm + "weight_ih_l0"], G[nm + "weight_hh_l0"]
-                sk = _splitk_bf16(3 * Hg, Hg, ldT)
-                if (config.get().dw_cat and config.get().dw_slabs and sk < -1 and Hg % 128 == 0
+                sk = _splitk_bf16(6 * Hg, Hg, ldT)       # (k-slices for the 6 Hg x Hg concatenated output)
+                if (config.get().dw_cat and config.get().dw_slabs and abs(sk) > 1
                         and g_hh.data_ptr() == g_ih.data_ptr() + 4 * 3 * Hg * Hg):
                     # the three products as ONE launch on the concatenated output [dW_ih ; dW_hh] (back to back in the flat gradient buffer)
                     ops.gemm_bf16_nt_cat([3 * Hg, 2 * Hg, Hg], Hg, ldT, dgT, [4 * i * Hg, 4 * i * Hg, 4 * i * Hg + 3 * Hg], 64,

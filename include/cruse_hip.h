@@ -309,7 +309,8 @@ int cruse_gemm_bf16_nt_slabs(int M, int N, int K, const void* A, long long lda, 
                              const void* B, long long ldb, long long b_kstride,
                              float* C, long long ldc, int splitk, void* scratch, size_t scratch_bytes, void* stream);
 /* (ABI 9) Up to three products that share N, K, the operand strides and the A tensor, concatenated along M into ONE launch and ONE output:
- *   C[sum M_i, N] += cat_i( A[a_rows[i] .. a_rows[i] + M_i) . B_i^T )      slab form as above; M_i % 128 == 0 for all but the last product.
+ *   C[sum M_i, N] += cat_i( A[a_rows[i] .. a_rows[i] + M_i) . B_i^T )      slab form as above (a product whose M_i is not a multiple of 128 still starts on a
+ *   row tile of its own; the output rows stay contiguous).
  * The three weight-gradient products of an nn.GRU layer (cruse_net.py:23-31: dW_ih += (r, z, n_i)^T x, dW_hh += (r, z)^T h_{t-1} and
  * n_h^T h_{t-1}) are such a set: their A rows are slabs of the one time-major gate-gradient tensor, and dW_ih / dW_hh lie back to back in
  * the flat gradient buffer.  Ms, a_rows, Bs: HOST arrays of nprob (1..3) entries. */

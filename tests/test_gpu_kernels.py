@@ -801,11 +801,12 @@ def test_gemm_split_k_slabs_match_atomics_and_are_reproducible(ops, M, N, K, spl
     assert rel_l2(outs[0], exact) < 2e-6
 
 
-@pytest.mark.parametrize("Hg,K,Ms", [(640, 25664, None), (128, 4096, None), (128, 1100, (256, 128, 70))])
+@pytest.mark.parametrize("Hg,K,Ms", [(640, 25664, None), (128, 4096, None), (128, 1100, (256, 128, 70)), (160, 6000, None), (96, 2000, (70, 200, 33))])
 def test_gemm_concatenated_weight_gradient_products(ops, Hg, K, Ms):
     """cruse_gemm_bf16_nt_slabs_cat (ABI 9): the three weight-gradient products of a GRU layer -- (r, z, n_i)^T x, (r, z)^T h_{t-1},
     n_h^T h_{t-1} (autograd of nn.GRU, cruse_net.py:23-31) -- as ONE launch on the concatenated output [dW_ih ; dW_hh]: bit-identical to the
-    three slab launches it replaces, and right against f64; a ragged last product and K not a multiple of 64 (zero frames) as well."""
+    three slab launches it replaces, and right against f64; products that are not whole row tiles (the grouped GRUs: Hg = 160) and K not a
+    multiple of 64 (zero frames) as well; k-slices pinned to XCDs and dealt round-robin."""
     torch.manual_seed(Hg + K)
     ldT = (K + 63) // 64 * 64
     dgT = (torch.randn(ldT // 64, 1, 4, Hg, 64) * 0.1).cuda().to(torch.bfloat16)
@@ -819,22 +820,21 @@ def test_gemm_concatenated_weight_gradient_products(ops, Hg, K, Ms):
     a_rows = (0, 0, 3 * Hg)
     Bs = (xT, hT, hT)
     base = torch.randn(sum(Ms), Hg).cuda()
-    c3 = base.clone()
-    off = 0
-    for M, ar, Bm in zip(Ms, a_rows, Bs):
-        ops.gemm_bf16_nt(M, Hg, ldT, dgT, ar * 64, 64, Bm, 0, 64, c3, off * Hg, Hg, accumulate=True, splitk=-8, slabs=True, a_kstride=ka, b_kstride=kb)
-        off += M
-    cc = base.clone()
-    ops.gemm_bf16_nt_cat(list(Ms), Hg, ldT, dgT, list(a_rows), 64, list(Bs), 0, 64, cc, 0, Hg, -8, a_kstride=ka, b_kstride=kb)
-    assert torch.equal(cc, c3)
+    for sk in (-8, 5):
+        c3 = base.clone()
+        off = 0
+        for M, ar, Bm in zip(Ms, a_rows, Bs):
+            ops.gemm_bf16_nt(M, Hg, ldT, dgT, ar * 64, 64, Bm, 0, 64, c3, off * Hg, Hg, accumulate=True, splitk=sk, slabs=True, a_kstride=ka, b_kstride=kb)
+            off += M
+        cc = base.clone()
+        ops.gemm_bf16_nt_cat(list(Ms), Hg, ldT, dgT, list(a_rows), 64, list(Bs), 0, 64, cc, 0, Hg, sk, a_kstride=ka, b_kstride=kb)
+        assert torch.equal(cc, c3), sk
     A = dgT.float().permute(0, 4, 1, 2, 3).reshape(ldT, 4 * Hg).double()          # [frame][slab * Hg + unit]
     ref, off = base.double().clone(), 0
     for M, ar, Bm in zip(Ms, a_rows, Bs):
         ref[off:off + M] += A[:, ar:ar + M].t() @ Bm.float().permute(0, 2, 1).reshape(ldT, Hg).double()
         off += M
     assert rel_l2(cc, ref) < 2e-6
-    with pytest.raises(RuntimeError):                                              # only the last product may be ragged
-        ops.gemm_bf16_nt_cat([70, 128], Hg, ldT, dgT, [0, 0], 64, [xT, hT], 0, 64, cc, 0, Hg, -8, a_kstride=ka, b_kstride=kb)
 
 
 @pytest.mark.parametrize("rows,G,Hg", [(25664, 1, 640), (1000, 2, 128), (64 * 3 + 5, 1, 64)])
