@@ -61,6 +61,7 @@ SIGNATURES = {
     "cruse_gemm_bf16_nt_slabs": ("iiipqqpqqpqipzp", "i"),
     "cruse_gemm_bf16_nt_slabs_cat": ("ipiippqqpqqpqipzp", "i"),
     "cruse_gemm_bf16_nt_atr": ("iiipqipqqpqip", "i"),
+    "cruse_gemm_bf16_nt_groups": ("iiiippqqppqqqpqqpqip", "i"),
     "cruse_gemm_bf16_nt_obf16": ("iiippqqppqqpqpp", "i"),
     "cruse_gemm_bf16_nt_seg": ("iiippqppqqpqpiiqqp", "i"),
     "cruse_gemm_bf16_tn": ("iiqpqpqiipqip", "i"),

@@ -48,6 +48,8 @@ class EngineConfig:
                                     # atomics that meet at the memory side (5.53 vs 5.67 ms; dW reproducible from run to run)
     dw_cat: bool = True             # Hg % 128 == 0: the three weight-gradient products of a GRU layer as ONE launch on the concatenated output
                                     # [dW_ih ; dW_hh] (cruse_gemm_bf16_nt_slabs_cat): the gate-gradient k-tiles are fetched once for all three
+    gemm_groups: bool = True        # rnn_groups > 1: the forward gate projections and the input gradients of all groups of a layer as ONE launch each
+                                    # (cruse_gemm_bf16_nt_groups) instead of one per group
     dx_atr: bool = False            # Hg % 64 == 0: the input-gradient GEMM of a GRU layer reads the TIME-MAJOR gate-gradient tensor through transposing
                                     # LDS reads (cruse_gemm_bf16_nt_atr); the gate-gradient pass then writes no row-major dgi (98 MB per layer)
     conv_bwd_x3: bool = False       # backward-data convolutions as split-bf16 x3 instead of plain bf16
@@ -77,7 +79,7 @@ class EngineConfig:
             "fuse_dgi": ("CRUSE_FUSE_DGI", lambda v: v == "1"),
             "fuse_bn_bwd_stats": ("CRUSE_FUSE_BN_BWD", lambda v: v != "0"), "fuse_cast": ("CRUSE_FUSE_CAST", lambda v: v == "1"),
             "gi_x3": ("CRUSE_GI_X3", int), "gi_f16": ("CRUSE_GI_F16", int), "gi_bf16": ("CRUSE_GI_BF16", lambda v: v == "1"), "dw_xcdk": ("CRUSE_DW_XCDK", int), "conv_bwd_x3": ("CRUSE_CONV_BWD_X3", lambda v: v == "1"),
-            "dw_tn": ("CRUSE_DW_TN", lambda v: v == "1"), "dw_slabs": ("CRUSE_DW_SLABS", lambda v: v != "0"), "dw_cat": ("CRUSE_DW_CAT", lambda v: v != "0"), "dx_atr": ("CRUSE_DX_ATR", lambda v: v == "1"), "fwd_chunks": ("CRUSE_FWD_CHUNKS", int),
+            "dw_tn": ("CRUSE_DW_TN", lambda v: v == "1"), "dw_slabs": ("CRUSE_DW_SLABS", lambda v: v != "0"), "dw_cat": ("CRUSE_DW_CAT", lambda v: v != "0"), "dx_atr": ("CRUSE_DX_ATR", lambda v: v == "1"), "gemm_groups": ("CRUSE_GEMM_GROUPS", lambda v: v != "0"), "fwd_chunks": ("CRUSE_FWD_CHUNKS", int),
             "fuse_bn_fwd": ("CRUSE_FUSE_BN_FWD", lambda v: v != "0"), "fuse_bn_bwd_apply": ("CRUSE_FUSE_BN_BWD_APPLY", lambda v: v != "0"), "bf16_dy": ("CRUSE_BF16_DY", lambda v: v != "0"), "bf16_de": ("CRUSE_BF16_DE", lambda v: v != "0")}
     _LIB_ENV = {"CRUSE_GRU_BWD_RS": "gru_bwd_rs", "CRUSE_GRU_FWD_LEAN": "gru_fwd_lean", "CRUSE_GRU_WLO": "gru_wlo",
                 "CRUSE_GRU_DBG": "gru_dbg", "CRUSE_GRU_PRIO": "gru_prio", "CRUSE_GRU_BG": "gru_bg", "CRUSE_CM_GRID": "cm_grid", "CRUSE_CM_KINT": "cm_kint", "CRUSE_CM_SWAP": "cm_swap", "CRUSE_CM_NW": "cm_nw",

@@ -45,6 +45,9 @@ struct GbArgs {
     // (products whose M_i is not a multiple of 128 occupy whole row tiles all the same: m_end* = end of product's VIRTUAL rows -- rows past it are
     // computed and dropped --, c_rows* = output row of a virtual row minus that virtual row)
     int m_end0, m_end1, m_end2; int c_rows1, c_rows2;
+    // GROUPS along N (cruse_gemm_bf16_nt_groups): the column tiles [q * tn_per_g, (q + 1) * tn_per_g) are product q -- N columns each, A columns
+    // a_gstep further right, B / bias / C columns b_gstep / bias_gstep / c_gstep elements further on -- the GRU groups of one layer in ONE launch.
+    int tn_per_g; long long a_gstep, b_gstep, c_gstep, bias_gstep;
     // ATR (cruse_gemm_bf16_nt_atr): A is read from its TIME-MAJOR K-tiled image -- element (m, k) at A[(m / 64) * a_mbs + k * 64 + m % 64], the
     // layout of the gate-gradient tensor dgT the weight-gradient GEMMs consume -- so the row-major copy dgi need not exist.  a_ks = 64 * 64.
     long long a_mbs; int a_mb_last;
@@ -105,9 +108,11 @@ __global__ __launch_bounds__(256 * BMT, (NST == 2 && BMT == 1) ? 2 : 1) void gem
         if (g.splitk > 1) { tz = unit / g.tiles_n; tn = unit % g.tiles_n; tm = inner; }
         else { tz = 0; tm = unit; tn = inner; }
     }
+    const int gq = g.tn_per_g > 0 ? tn / g.tn_per_g : 0;                  // product (GRU group) of this column tile
+    if (g.tn_per_g > 0) tn -= gq * g.tn_per_g;
     const int m0 = tm * BM_, n0 = tn * BN;
-    const __bf16* Abase = g.A;
-    const __bf16* Bbase = g.B;
+    const __bf16* Abase = g.A + gq * g.a_gstep;
+    const __bf16* Bbase = g.B + gq * g.b_gstep;
     int m_lim = g.m_end0, c_sh = 0;
     if (tm >= g.tm_b2) { Abase += g.a_shift2; Bbase = g.B2; m_lim = g.m_end2; c_sh = g.c_rows2; }
     else if (tm >= g.tm_b1) { Abase += g.a_shift1; Bbase = g.B1; m_lim = g.m_end1; c_sh = g.c_rows1; }
@@ -295,10 +300,11 @@ __global__ __launch_bounds__(256 * BMT, (NST == 2 && BMT == 1) ? 2 : 1) void gem
     const int nq = n0 + wn * 64 + (lane & 15) * 4;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (add_bias) {
-        bv.x = nq < g.N ? g.bias[nq] : 0.f; bv.y = nq + 1 < g.N ? g.bias[nq + 1] : 0.f;
-        bv.z = nq + 2 < g.N ? g.bias[nq + 2] : 0.f; bv.w = nq + 3 < g.N ? g.bias[nq + 3] : 0.f;
+        const float* bias = g.bias + gq * g.bias_gstep;
+        bv.x = nq < g.N ? bias[nq] : 0.f; bv.y = nq + 1 < g.N ? bias[nq + 1] : 0.f;
+        bv.z = nq + 2 < g.N ? bias[nq + 2] : 0.f; bv.w = nq + 3 < g.N ? bias[nq + 3] : 0.f;
     }
-    const bool vec = (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0) && nq + 3 < g.N;
+    const bool vec = (g.ldc % 4 == 0) && (g.c_gstep % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0) && nq + 3 < g.N;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(256 * BMT, (NST == 2 && BMT == 1) ? 2 : 1) void gem
                     }
                     continue;
                 }
-                float* c = g.C + (MODE == 4 ? (long long)tz * g.slab : 0ll) + (seg_row(g, m) + c_sh) * g.ldc + nq;
+                float* c = g.C + (MODE == 4 ? (long long)tz * g.slab : 0ll) + (seg_row(g, m) + c_sh) * g.ldc + gq * g.c_gstep + nq;
                 if (MODE == 2) {
                     if (nq < g.N) atomicAdd(c, v.x);
                     if (nq + 1 < g.N) atomicAdd(c + 1, v.y);
@@ -639,6 +645,7 @@ __global__ __launch_bounds__(256) void gemm_slab_reduce_kernel(const float* slab
 
 }  // namespace
 
+struct GbGroups { int G; long long a_gstep, b_gstep, c_gstep, bias_gstep; };
 struct GbCat { int tm_b1, tm_b2; long long a_shift1, a_shift2; const __bf16* B1; const __bf16* B2; int m_end[3], c_rows[3], M_out; };
 
 static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, long long lda, long long a_kstride,
@@ -646,7 +653,9 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
                           float* C, long long ldc, const float* bias, int accumulate, int splitk, void* stream,
                           int seg_len = 0, long long seg_stride = 0, long long seg_off = 0, bool c_bf16 = false,
                           float* slabs = nullptr, size_t slab_bytes = 0, bool f16 = false, const GbCat* cat = nullptr,
-                          long long atr_mbs = 0, int atr_mb_last = 0) {
+                          long long atr_mbs = 0, int atr_mb_last = 0, const GbGroups* grp = nullptr) {
+    CRUSE_REQUIRE(!grp || (!c_bf16 && !slabs && splitk == 1 && !cat && atr_mbs == 0 && seg_len == 0 && a_kstride == BK), CRUSE_E_SHAPE,
+                  "gemm_bf16_nt_groups: row-major A, f32 result, no split-K");
     const bool atr = atr_mbs != 0;
     CRUSE_REQUIRE(!atr || (!A_lo && !B_lo && !c_bf16 && !slabs && splitk == 1 && !f16 && !cat && seg_len == 0), CRUSE_E_SHAPE,
                   "gemm_bf16_nt_atr: plain bf16, one pass, no split-K");
@@ -679,6 +688,7 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
     g.accumulate = accumulate; g.splitk = splitk; g.kt_chunk = kt_chunk;
     g.seg_len = seg_len; g.seg_stride = seg_stride; g.seg_off = seg_off;
     g.a_mbs = atr_mbs; g.a_mb_last = atr_mb_last;
+    g.tn_per_g = 0; g.a_gstep = g.b_gstep = g.c_gstep = g.bias_gstep = 0;
     g.tm_b1 = g.tm_b2 = 0x7fffffff; g.a_shift1 = g.a_shift2 = 0; g.B1 = g.B2 = nullptr;
     g.m_end0 = g.m_end1 = g.m_end2 = M; g.c_rows1 = g.c_rows2 = 0;
     int M_out = M;                                   // rows of the output (cat: the products' rows without the tile padding between them)
@@ -688,8 +698,12 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
         M_out = cat->M_out;
     }
     // 256-row tiles (8 waves, three stages) for the un-split products with many row tiles: the gate projections and dX (option gb_bm256)
-    const bool big = splitk == 1 && !slabs && !f16 && !cat && !atr && M >= 16 * BM && cruse_opt("gb_bm256", 0) != 0;
+    const bool big = splitk == 1 && !slabs && !f16 && !cat && !atr && !grp && M >= 16 * BM && cruse_opt("gb_bm256", 0) != 0;
     g.tiles_m = cdiv(M, big ? 2 * BM : BM); g.tiles_n = cdiv(N, BN);
+    if (grp) {
+        g.tn_per_g = g.tiles_n; g.tiles_n *= grp->G;
+        g.a_gstep = grp->a_gstep; g.b_gstep = grp->b_gstep; g.c_gstep = grp->c_gstep; g.bias_gstep = grp->bias_gstep;
+    }
     g.xcdk = (xcdk && splitk > 1) ? 1 : 0;
     g.slab = 0;
     const bool use_slabs = slabs != nullptr && splitk > 1;
@@ -812,6 +826,24 @@ extern "C" int cruse_gemm_bf16_nt_atr(int M, int N, int K, const void* A_T, long
                   "gemm_bf16_nt_atr: a_mb_stride=%lld n_mb=%d for M=%d K=%d", a_mb_stride, n_mb, M, K);
     return gemm_bf16_impl(M, N, K, A_T, nullptr, 64, 64 * 64, B, nullptr, ldb, b_kstride, C, ldc, nullptr, accumulate, 1, stream, 0, 0, 0, false,
                           nullptr, 0, false, nullptr, a_mb_stride, n_mb - 1);
+}
+
+// G products of the same shape in ONE launch, side by side along N -- the GRU groups of a layer:
+//   C[:, q * c_gstep + (0 .. N)] (+)= A[:, q * a_gstep + (0 .. K)] . B_q^T + bias_q      B_q = B + q * b_gstep, bias_q = bias + q * bias_gstep
+// A row-major [M, lda] (planes A_hi / A_lo nullable as cruse_gemm_bf16x3_nt), B in the layouts of cruse_gemm_bf16_nt (B_lo nullable, the same
+// group stride).  The forward gate projections gi_q = x_q W_ih,q^T + b_ih,q and the input gradients dx_q = dgi_q W_ih,q of a grouped GGRU layer
+// (cruse_net.py:14-55 with rnn_groups > 1) were G launches of [rows x 3 Hg or Hg] each -- 2 to 4 column tiles, 400 to 800 blocks.
+extern "C" int cruse_gemm_bf16_nt_groups(int M, int N, int K, int G, const void* A_hi, const void* A_lo, long long lda, long long a_gstep,
+                                         const void* B_hi, const void* B_lo, long long ldb, long long b_kstride, long long b_gstep,
+                                         float* C, long long ldc, long long c_gstep, const float* bias, long long bias_gstep, int accumulate,
+                                         void* stream) {
+    CRUSE_REQUIRE(G >= 1 && a_gstep % 8 == 0 && b_gstep % 8 == 0 && c_gstep >= N && (long long)(G - 1) * c_gstep + N <= ldc, CRUSE_E_SHAPE,
+                  "gemm_bf16_nt_groups: G=%d a_gstep=%lld b_gstep=%lld c_gstep=%lld", G, a_gstep, b_gstep, c_gstep);
+    CRUSE_REQUIRE((A_lo == nullptr || B_lo != nullptr) && ((uintptr_t)A_lo % 16) == 0 && ((uintptr_t)B_lo % 16) == 0, CRUSE_E_ALIGN,
+                  "gemm_bf16_nt_groups: low planes (A_lo needs B_lo; 16-byte aligned)");
+    const GbGroups grp = {G, a_gstep, b_gstep, c_gstep, bias_gstep};
+    return gemm_bf16_impl(M, N, K, A_hi, A_lo, lda, BK, B_hi, B_lo, ldb, b_kstride, C, ldc, bias, accumulate, 1, stream, 0, 0, 0, false, nullptr, 0,
+                          false, nullptr, 0, 0, &grp);
 }
 
 extern "C" size_t cruse_gemm_bf16_slab_bytes(int M, int N, int splitk) {

@@ -447,7 +447,21 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
         else:
             inp_hi, inp_lo = (ops.cast_bf16_padded(inp, pad=pad) if fast else None), None
         kp = (Hg + 63) // 64 * 64
-        for i in range(g):
+        b_ihs = [P[f"{prefix}{lname}.{i}.bias_ih_l0"] for i in range(g)]
+        bstep = ops.uniform_stride(b_ihs)
+        if (fast and g > 1 and config.get().gemm_groups and not gi_bf and inp_hi is not None and inp_hi.dtype == torch.bfloat16
+                and bstep is not None):
+            # all groups of the layer in ONE launch: the K-tiled W_ih planes stacked [g][kp / 64][3 Hg][64], columns of x / gi per group
+            W_hi = torch.empty(g, kp // 64, 3 * Hg, 64, device=x.device, dtype=torch.bfloat16)
+            W_lo = torch.empty_like(W_hi) if x3 else None
+            for i in range(g):
+                ops.ktile_bf16(P[f"{prefix}{lname}.{i}.weight_ih_l0"], 3 * Hg, Hg, split=bool(x3), out=(W_hi[i], W_lo[i] if x3 else None))
+            ops.gemm_bf16_nt_groups(rows, 3 * Hg, kp, g, inp_hi, inp_lo if x3 else None, H, Hg, W_hi, W_lo, 64, W_hi[0].numel(), gi, 3 * H, 3 * Hg,
+                                    bias=b_ihs[0], bias_gstep=bstep, b_kstride=3 * Hg * 64)
+            grouped = True
+        else:
+            grouped = False
+        for i in range(0 if not grouped else g, g):
             w_ih, b_ih = P[f"{prefix}{lname}.{i}.weight_ih_l0"], P[f"{prefix}{lname}.{i}.bias_ih_l0"]
             if inp_bf is not None and inp_bf.dtype == torch.float16:          # _gi_f16: one pass, 11-bit operands
                 ops.gemm_f16_nt(rows, 3 * Hg, kp, inp_bf, i * Hg, H, ops.ktile_f16(w_ih, 3 * Hg, Hg), 0, 64, gi, i * 3 * Hg, 3 * H,
@@ -497,8 +511,11 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
                 ops.transpose_bf16(h1, rows, H, shift_T=T, out=tt["h1T"])
                 ops.transpose_bf16(l1, rows, H, out=tt["l1T"])
             for lname in ("gru_list1", "gru_list2"):
+                # (one stacked tensor per layer [g][ceil(3 Hg / 64)][Hg][64]: the grouped dX launch walks it with a group stride)
+                stack = torch.empty(g, (3 * Hg + 63) // 64, Hg, 64, device=x.device, dtype=torch.bfloat16)
                 for i in range(g):
-                    w_ts[(lname, i)] = ops.transpose_bf16(P[f"{prefix}{lname}.{i}.weight_ih_l0"], 3 * Hg, Hg)
+                    w_ts[(lname, i)] = ops.transpose_bf16(P[f"{prefix}{lname}.{i}.weight_ih_l0"], 3 * Hg, Hg, out=stack[i])
+                w_ts[(lname, "stack")] = stack
         ctx["w_ts"] = w_ts
         if tn:
             SIDE.defer(t_layer1, kind=1, lane=2)
@@ -684,7 +701,12 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
         if early_leaf:
             SIDE.run(weight_grads, dgT, h, inp, inpT, hpT, dh, lane=2)
         dinp, acc_dx = dinp_buffer(dout_h, need_dinp, last)
-        if need_dinp:
+        stack = ctx.get("w_ts", {}).get((lname, "stack"))
+        if need_dinp and g > 1 and stack is not None and dgi is not None and config.get().gemm_groups:
+            # all groups in ONE launch (cruse_gemm_bf16_nt_groups): columns [q * 3 Hg, ...) of dgi against W_ih,q^T into columns [q * Hg, ...) of dX
+            ops.gemm_bf16_nt_groups(rows, Hg, stack.shape[1] * 64, g, dgi, None, 3 * H, 3 * Hg, stack, None, 64, stack[0].numel(), dinp, H, Hg,
+                                    accumulate=acc_dx, b_kstride=Hg * 64)
+        elif need_dinp:
             for i, nm in enumerate(names):
                 w_t = ctx.get("w_ts", {}).get((lname, i))                             # made in the forward pass (side stream)
                 if w_t is None:

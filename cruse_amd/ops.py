@@ -550,6 +550,31 @@ def gemm_bf16_nt_atr(M, N, K, A_T, a_off, a_mb_stride, n_mb, Bm, b_off, ldb, C, 
     return C
 
 
+def gemm_bf16_nt_groups(M, N, K, G, A_hi, A_lo, lda, a_gstep, B_hi, B_lo, ldb, b_gstep, C, ldc, c_gstep, bias=None, bias_gstep=0,
+                        accumulate=False, b_kstride=64):
+    """G equal-shape products side by side along N in one launch (cruse_gemm_bf16_nt_groups): the GRU groups of a layer.
+    bias: the first group's bias tensor (the others bias_gstep floats apart)."""
+    for t_ in (A_hi, A_lo, B_hi, B_lo):
+        if t_ is not None and t_.dtype != torch.bfloat16:
+            raise RuntimeError("gemm_bf16_nt_groups needs bf16 planes")
+    if C.dtype != torch.float32:
+        raise RuntimeError("gemm_bf16_nt_groups: f32 result")
+    check(lib.cruse_gemm_bf16_nt_groups(M, N, K, G, _p(A_hi), _p(A_lo), lda, a_gstep, _p(B_hi), _p(B_lo), ldb, b_kstride, b_gstep,
+                                        _p(C), ldc, c_gstep, _p(bias), bias_gstep, 1 if accumulate else 0, _stream()))
+    return C
+
+
+def uniform_stride(tensors) -> Optional[int]:
+    """element stride between equally shaped f32 tensors if it is the same for all consecutive pairs (the per-group parameters in the flat
+    buffer), else None"""
+    if len(tensors) < 2:
+        return 0
+    d = [tensors[i + 1].data_ptr() - tensors[i].data_ptr() for i in range(len(tensors) - 1)]
+    if any(x != d[0] for x in d) or d[0] <= 0 or d[0] % 4:
+        return None
+    return d[0] // 4
+
+
 def gemm_bf16_nt_seg(M, N, K, A_hi, A_lo, a_off, lda, B_hi, B_lo, b_off, ldb, C, c_off, ldc, seg, bias=None, accumulate=False,
                      b_kstride=64):
     """gemm_bf16_nt / gemm_bf16x3_nt (A_lo / B_lo None: plain bf16) on the rows of ONE TIME CHUNK: seg = (seg_len, seg_stride,
@@ -566,11 +591,14 @@ def cast_bf16(x, out=None):
     return y
 
 
-def ktile_bf16(x, rows, cols, split=False):
+def ktile_bf16(x, rows, cols, split=False, out=None):
     """x [rows, cols] f32 -> K-tiled bf16 [ceil(cols/64), rows, 64] (k = column index, zero padded): no transposition.
-    split: returns (hi, lo) planes with x ~= hi + lo."""
-    y = torch.empty((cols + 63) // 64, rows, 64, device=x.device, dtype=torch.bfloat16)
-    lo = torch.empty_like(y) if split else None
+    split: returns (hi, lo) planes with x ~= hi + lo.  out = (y, lo or None): write into these."""
+    if out is not None:
+        y, lo = out
+    else:
+        y = torch.empty((cols + 63) // 64, rows, 64, device=x.device, dtype=torch.bfloat16)
+        lo = torch.empty_like(y) if split else None
     check(lib.cruse_ktile_bf16(_p(x), rows, cols, cols, _p(y), _p(lo), _stream()))
     return (y, lo) if split else y
 

@@ -325,6 +325,14 @@ int cruse_gemm_bf16_nt_slabs_cat(int nprob, const int* Ms, int N, int K, const v
 int cruse_gemm_bf16_nt_atr(int M, int N, int K, const void* A_T, long long a_mb_stride, int n_mb,
                            const void* B, long long ldb, long long b_kstride,
                            float* C, long long ldc, int accumulate, void* stream);
+/* (ABI 9) G products of the same shape in ONE launch, side by side along N -- the GRU groups of one layer (GGRU with rnn_groups > 1,
+ * cruse_net.py:14-55):  C[:, q * c_gstep + (0..N)] (+)= A[:, q * a_gstep + (0..K)] . B_q^T + bias_q,  B_q = B + q * b_gstep, bias_q = bias + q * bias_gstep.
+ * A row-major (planes A_hi / A_lo nullable as in cruse_gemm_bf16x3_nt), B as in cruse_gemm_bf16_nt (B_lo nullable, same group stride).  Used for
+ * the forward gate projections and the input gradients of the grouped configurations: G launches of 2-4 column tiles each become one. */
+int cruse_gemm_bf16_nt_groups(int M, int N, int K, int G, const void* A_hi, const void* A_lo, long long lda, long long a_gstep,
+                              const void* B_hi, const void* B_lo, long long ldb, long long b_kstride, long long b_gstep,
+                              float* C, long long ldc, long long c_gstep, const float* bias, long long bias_gstep, int accumulate,
+                              void* stream);
 /* The same product -- or, with low planes (A_lo nullable, B_lo nullable: plain bf16), the split-bf16 form of
  * cruse_gemm_bf16x3_nt -- with the result STORED AS bf16 (C bf16 [M, ldc]; f32 accumulation, bias added in f32 before the one
  * rounding; no accumulate, no split-K): gi = x W_ih^T + b_ih as bf16 rows for cruse_gru_seq_fwd_ex(gi_bf16 = 1) -- half the bytes

@@ -866,6 +866,52 @@ def test_gemm_input_gradient_from_the_time_major_gate_gradients(ops, rows, G, Hg
         assert rel_l2(c1 - base, want) < 1e-5
 
 
+@pytest.mark.parametrize("rows,G,Hg,x3", [(25664, 4, 160, 2), (25664, 4, 160, 1), (1000, 2, 320, 0), (333, 3, 96, 2)])
+def test_gemm_all_groups_in_one_launch(ops, rows, G, Hg, x3):
+    """cruse_gemm_bf16_nt_groups (ABI 9): the forward gate projections gi_q = x_q W_ih,q^T + b_ih,q and the input gradients dx_q = dgi_q W_ih,q of
+    the G groups of a GGRU layer (cruse_net.py:14-55, rnn_groups > 1) as ONE launch each -- bit-identical to the G launches they replace;
+    x3: 0 plain bf16, 1 W_ih hi / lo planes, 2 x split as well; K rounded up to 64 (the operand reads on into the next group), accumulate."""
+    torch.manual_seed(rows + Hg)
+    H, kp = G * Hg, (Hg + 63) // 64 * 64
+    x = torch.randn(rows, H).cuda()
+    Ws = [(torch.randn(3 * Hg, Hg) / Hg ** 0.5).cuda() for _ in range(G)]
+    bias_all = torch.randn(G, 3 * Hg + 8).cuda()                      # (uniformly strided per-group biases, as in the flat parameter buffer)
+    biases = [bias_all[q, :3 * Hg] for q in range(G)]
+    assert ops.uniform_stride(biases) == 3 * Hg + 8
+    x_hi, x_lo = ops.cast_bf16_padded(x, pad=64, split=True)
+    if x3 < 2:
+        x_lo = None
+    W_hi = torch.empty(G, kp // 64, 3 * Hg, 64, dtype=torch.bfloat16).cuda()
+    W_lo = torch.empty_like(W_hi) if x3 else None
+    for q in range(G):
+        ops.ktile_bf16(Ws[q], 3 * Hg, Hg, split=bool(x3), out=(W_hi[q], W_lo[q] if x3 else None))
+    gi0 = torch.full((rows, 3 * H), 7.0).cuda(); gi1 = gi0.clone()
+    for q in range(G):
+        if x3:
+            ops.gemm_bf16x3_nt(rows, 3 * Hg, kp, x_hi, x_lo, q * Hg, H, W_hi[q], W_lo[q], 0, 64, gi0, q * 3 * Hg, 3 * H, bias=biases[q], b_kstride=3 * Hg * 64)
+        else:
+            ops.gemm_bf16_nt(rows, 3 * Hg, kp, x_hi, q * Hg, H, W_hi[q], 0, 64, gi0, q * 3 * Hg, 3 * H, bias=biases[q], b_kstride=3 * Hg * 64)
+    ops.gemm_bf16_nt_groups(rows, 3 * Hg, kp, G, x_hi, x_lo, H, Hg, W_hi, W_lo, 64, W_hi[0].numel(), gi1, 3 * H, 3 * Hg, bias=biases[0],
+                            bias_gstep=3 * Hg + 8, b_kstride=3 * Hg * 64)
+    assert torch.equal(gi0, gi1)
+    ref = torch.cat([x[:, q * Hg:(q + 1) * Hg].double() @ Ws[q].double().t() + biases[q].double() for q in range(G)], 1)
+    assert rel_l2(gi1, ref) < (1e-2 if x3 == 0 else 3e-3 if x3 == 1 else 3e-5)
+    # input gradients: dgi [rows, G, 3, Hg] bf16 (padded buffer) against the stacked K-tiled transposes of W_ih
+    dgi = ops.dgi_buffer(rows, G, Hg, "cuda")
+    dgi.view(-1)[:rows * 3 * H] = (torch.randn(rows * 3 * H) * 0.1).cuda().to(torch.bfloat16)
+    stack = torch.empty(G, (3 * Hg + 63) // 64, Hg, 64, dtype=torch.bfloat16).cuda()
+    for q in range(G):
+        ops.transpose_bf16(Ws[q], 3 * Hg, Hg, out=stack[q])
+    for acc in (False, True):
+        base = torch.randn(rows, H).cuda()
+        d0, d1 = base.clone(), base.clone()
+        for q in range(G):
+            ops.gemm_bf16_nt(rows, Hg, stack.shape[1] * 64, dgi, q * 3 * Hg, 3 * H, stack[q], 0, 64, d0, q * Hg, H, accumulate=acc, b_kstride=Hg * 64)
+        ops.gemm_bf16_nt_groups(rows, Hg, stack.shape[1] * 64, G, dgi, None, 3 * H, 3 * Hg, stack, None, 64, stack[0].numel(), d1, H, Hg,
+                                accumulate=acc, b_kstride=Hg * 64)
+        assert torch.equal(d0, d1), acc
+
+
 def test_gru_wide_chains_at_the_bench_length(ops):
     """T = 401, B = 64, Hg = 640: the wide-chain forward launch (4 chains of 16 on 80 CUs) against the lean one (8 chains of 8 on
     160) over the whole sequence -- 401 dependent hand-offs per chain -- bit for bit; two wide launches side by side on the two
