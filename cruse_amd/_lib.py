@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcruse_hip.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16 = 0, 1, 2, 3
 PREC_BY_NAME = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "f16": PREC_F16}
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
@@ -77,8 +77,8 @@ SIGNATURES = {
     "cruse_gru_seq_bwd": ("pppppiiiiipp", "i"),
     "cruse_gru_seq_fwd_on": ("pppppppiiiiippip", "i"),
     "cruse_gru_seq_bwd_on": ("pppppppiiiiippip", "i"),
-    "cruse_gru_seq_fwd_ex": ("ppppppppqiiiiiiiipipip", "i"),
-    "cruse_gru_seq_bwd_ex": ("pppppppiiiiiiiiipipip", "i"),
+    "cruse_gru_seq_fwd_ex": ("ppppppppqiiiiiiiipipiiip", "i"),
+    "cruse_gru_seq_bwd_ex": ("pppppppiiiiiiiiipipiiip", "i"),
     "cruse_gru_gate_grads": ("pppppqiiip", "i"),
     "cruse_gru_gate_grads_bf16": ("pppppqppqiip", "i"),
     "cruse_gru_gate_bias_sums": ("pqiippp", "i"),

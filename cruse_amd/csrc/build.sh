@@ -8,7 +8,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 objs=()
 pids=()
 mkdir -p "$here/build"
-for f in stft stft_general conv conv_mfma wgrad_mfma pointwise gemm gemm_bf16 gru gru_tf tdloss deepfilter generic extras; do
+for f in stft stft_general conv conv_mfma wgrad_mfma pointwise gemm gemm_bf16 gru gru_tf gru_w16 tdloss deepfilter generic extras; do
   "$HIPCC" $FLAGS -c "$here/$f.hip" -o "$here/build/$f.o" &
   pids+=($!)
   objs+=("$here/build/$f.o")

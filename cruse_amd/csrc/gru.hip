@@ -702,323 +702,6 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
 }
 
 // ---------------------------------------------------------------------------------
-// forward, WIDE-CHAIN form of the lean kernel: 16 clips per chain (the full N of the 16x16x32 MFMA -- the lean kernel's
-// chains of 8 leave half of every MFMA's columns empty).  A batch of 64 then needs 4 chains x Hg/32 workgroups = 80 CUs
-// instead of 160: the plan for batches whose chains of 8 exceed the CUs (make_plan), and two such recurrences fit on the
-// chip side by side (cruse_gru_seq_fwd_ex, chain_clips = 16 with xcd_rot 0 / 4: 948 us for the pair, tools/gru_pair_probe.py).
-// A workgroup has twice the lean kernel's hand-off bytes, gate math and saves per step; to keep the per-THREAD work where
-// the lean kernel has it the workgroup has EIGHT compute waves: wave = (K group kg = wave & 3, tile half mg = wave >> 2)
-// owns k-steps kg + 4*i of the three tiles {gate*2 + mg}: 3*NKW MFMAs and 12*NKW weight registers per wave, NS = Hg/128
-// coalesced sweep loads and ONE (clip, unit) of gate math per thread -- plus the helper wave (gi ring, saves).
-// 9 waves = 3 on one SIMD: <= 168 registers per lane.  Arithmetic and summation order are the lean kernel's: results are
-// bit-identical.  Measured alone (B = 64, Hg = 640): 2.25 us per step against the lean kernel's 1.49 -- the sweep is
-// 40 KB per workgroup and step at the ~35 B/clk a CU gets from its L2 with sc1 loads (+0.24 us), the LDS traffic doubles
-// (100 KB per step).  A second form that loaded the MFMA B fragments straight from the granule panel into registers (no
-// LDS image, one barrier per step, four compute waves) ran at 3.5 us: a lane's 32 bytes sit 2560 bytes from its
-// neighbour's, and uncoalesced 16-byte loads cost far more than the LDS round trip they save.
-// CRUSE_PREC_BF16, Hg % 128 == 0, Hg <= 640.
-// ---------------------------------------------------------------------------------
-template <int NKW>
-__global__ __launch_bounds__(576) void gru_fwd_w16_kernel(GruArgs a) {
-    constexpr int NS = NKW, NT = 512, NSW = NS;
-    constexpr bool TF = false;                                          // (this kernel keeps the tagged hand-off)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    __shared__ __attribute__((aligned(16))) float gi_r[4][16][96];        // gi ring: slot = t & 3, [clip][gate*32 + unit]
-    __shared__ __attribute__((aligned(16))) float sv_l[2][6][16][32];     // saves of step t in parity t & 1
-    const int Hg = a.Hg, H = a.G * Hg, LD = Hg + 8;
-    __bf16* hB = reinterpret_cast<__bf16*>(smem_raw);                    // [16][LD]  B operand (h_{t-1})
-    float* red = reinterpret_cast<float*>(hB + 16 * LD);                  // [4 K groups][6 tiles][64 lanes][4]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int chain, part;
-    if (!claim_chain(a, a.P, chain, part)) return;
-    const int grp = chain % a.G, bgi = a.bg_off + chain / a.G;
-    const int b0 = bgi * 16, nb = min(16, a.B - b0);
-    const int u0 = part * U;
-    const float* W = a.p.w_hh[grp];
-    const float* bh = a.p.b_hh[grp];
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.xg, 0, a.xg_bytes, 0x00020000);
-    const unsigned panel_bytes = (unsigned)(16 * Hg) * 4u;             // bf16-pair granules: 4 B per value
-    const unsigned cbase = (unsigned)chain * 2u * panel_bytes;
-
-    for (int i = tid; i < 16 * LD; i += 576) hB[i] = (__bf16)0.f;
-
-    const unsigned frame_bytes = (unsigned)H * 4u, grow_bytes = (unsigned)(a.G * 3 * Hg) * 4u, crow_bytes = grow_bytes >> 1;
-    const long long nrow = (long long)(a.B - 1) * a.TS + a.T;           // rows reachable from the (advanced) base pointers
-    const unsigned tot_h = (unsigned)min(nrow * H * 4, 0xffffffffll);
-    const unsigned tot_g = (unsigned)min(nrow * a.G * 3 * Hg * 4, 0xffffffffll);
-    const bool gib = a.gi_bf16 != 0;                                    // bf16 gi rows: the coefficient rows' geometry
-    const __amdgpu_buffer_rsrc_t rs_gi = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gi), 0, gib ? tot_g >> 1 : tot_g, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(a.h, 0, tot_h, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_an = __builtin_amdgcn_make_buffer_rsrc(a.an, 0, a.an ? tot_h : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(a.z, 0, a.z ? tot_h : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_cf = __builtin_amdgcn_make_buffer_rsrc(a.coef, 0, a.coef ? tot_g >> 1 : 0u, 0x00020000);
-    const bool save = a.coef != nullptr;
-    const bool has_h0 = a.h0 != nullptr;
-
-    if (wv == 8) {
-        // ---- helper wave: gi rows four steps ahead into the LDS ring; the saves of step t-1 from LDS to HBM ----------
-        // gi: 16 clips x 3 gates x 8 chunks of 4 floats = 384 lane-loads per step (6 instructions)
-        unsigned gv[6], gdst[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int idx = lane + 64 * i, cl = idx / 24, rem = idx % 24, gate = rem >> 3, chk = rem & 7;
-            gv[i] = (unsigned)((((long long)(b0 + (cl < nb ? cl : 0)) * a.TS * a.G + grp) * 3 * Hg + gate * Hg + u0 + 4 * chk) * 4);
-            gdst[i] = (unsigned)(cl * 96 + gate * 32 + chk * 4);
-        }
-        // h / a_n / z rows: 16 clips x 8 chunks of 4 floats (2 stores each); coefficient rows: 16 x 3 gates x 4 chunks of 8 bf16
-        unsigned hv[2], hsrc[2];
-        bool rok[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = lane + 64 * i, lc = idx >> 3, lq = idx & 7;
-            rok[i] = lc < nb;
-            hv[i] = (unsigned)(((long long)(b0 + (rok[i] ? lc : 0)) * a.TS * H + grp * Hg + u0 + 4 * lq) * 4);
-            hsrc[i] = (unsigned)(lc * 32 + 4 * lq);
-        }
-        unsigned cv[3], csrc[3];
-        bool cok[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int idx = lane + 64 * i, cl = idx / 12, rem = idx % 12, gate = rem >> 2, chk = rem & 3;
-            cok[i] = cl < nb;
-            cv[i] = (unsigned)((((long long)(b0 + (cl < nb ? cl : 0)) * a.TS * a.G + grp) * 3 * Hg + gate * Hg + u0 + 8 * chk) * 2);
-            csrc[i] = (unsigned)(((1 + gate) * 16 + cl) * 32 + chk * 8);
-        }
-        unsigned gdb[3];                                // bf16 gi: 16 clips x 3 gates x 4 chunks of 8 bf16 (the lane map of cv[])
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int idx = lane + 64 * i, cl = idx / 12, rem = idx % 12, gate = rem >> 2, chk = rem & 3;
-            gdb[i] = (unsigned)(cl * 96 + gate * 32 + chk * 8);
-        }
-        struct GiSet { u32x4 v[6]; };
-        auto issue = [&](int t, GiSet& o) {
-            if (gib) {
-                const unsigned so = (unsigned)min(t, a.T - 1) * crow_bytes;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) o.v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_gi, cv[i], so, 0);
-                return;
-            }
-            const unsigned so = (unsigned)min(t, a.T - 1) * grow_bytes;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) o.v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_gi, gv[i], so, 0);
-        };
-        auto put = [&](int t, const GiSet& o) {
-            float* d = &gi_r[t & 3][0][0];
-            if (gib) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const u32x4 w = o.v[i];
-                    const u32x4 lo = {w.x << 16, w.x & 0xffff0000u, w.y << 16, w.y & 0xffff0000u};
-                    const u32x4 hi = {w.z << 16, w.z & 0xffff0000u, w.w << 16, w.w & 0xffff0000u};
-                    *reinterpret_cast<u32x4*>(d + gdb[i]) = lo;
-                    *reinterpret_cast<u32x4*>(d + gdb[i] + 4) = hi;
-                }
-                return;
-            }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) *reinterpret_cast<u32x4*>(d + gdst[i]) = o.v[i];
-        };
-        auto flush = [&](int t) {                       // saves of step t from parity t & 1
-            const float* sl = &sv_l[t & 1][0][0][0];
-            const unsigned so = (unsigned)t * frame_bytes, sc = (unsigned)t * crow_bytes;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (rok[i]) {
-                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(sl + 0 * 512 + hsrc[i]), rs_h, hv[i], so, 0);
-                    if (save) {
-                        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(sl + 4 * 512 + hsrc[i]), rs_an, hv[i], so, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(sl + 5 * 512 + hsrc[i]), rs_z, hv[i], so, 0);
-                    }
-                }
-            }
-            if (save) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    if (cok[i]) {
-                        const float4 p0 = *reinterpret_cast<const float4*>(sl + csrc[i]);
-                        const float4 p1 = *reinterpret_cast<const float4*>(sl + csrc[i] + 4);
-                        const u32x4 w = {pack2(p0.x, p0.y), pack2(p0.z, p0.w), pack2(p1.x, p1.y), pack2(p1.z, p1.w)};
-                        __builtin_amdgcn_raw_buffer_store_b128(w, rs_cf, cv[i], sc, 0);
-                    }
-                }
-            }
-        };
-        GiSet s0, s1;
-        issue(0, s0); issue(1, s1);
-        put(0, s0); put(1, s1);
-        issue(2, s0); issue(3, s1);
-        if (has_h0) __syncthreads();                    // mirrors the compute waves' barrier before the h0 panel fill
-        (void)team_shares_xcd(a.xid + (size_t)chain * 64, a.P, part, a.status, tid);   // mirrors the compute waves' barriers
-        __syncthreads();
-        for (int t = 0; t < a.T; t += 2) {
-            if (t > 0 || has_h0) __syncthreads();
-            put(t + 2, s0); issue(t + 4, s0);
-            if (t > 0) flush(t - 1);
-            if (t > 0 || has_h0) __syncthreads();
-            if (t + 1 >= a.T) break;
-            __syncthreads();
-            put(t + 3, s1); issue(t + 5, s1);
-            flush(t);
-            __syncthreads();
-        }
-        __syncthreads();                                // the last step's saves are in LDS
-        flush(a.T - 1);
-        return;
-    }
-
-    const int kg = wv & 3, mg = wv >> 2;
-    // resident weight fragments: tile jj of this wave = gate jj, unit half mg; k-steps ks = kg + 4*i
-    bf16x8 wf[3][NKW];
-#pragma unroll
-    for (int jj = 0; jj < 3; ++jj) {
-        const int row = jj * Hg + u0 + mg * 16 + (lane & 15);
-#pragma unroll
-        for (int i = 0; i < NKW; ++i) {
-            const int ks = kg + 4 * i;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) wf[jj][i][e] = (__bf16)W[(long long)row * Hg + ks * 32 + (lane >> 4) * 8 + e];
-        }
-    }
-
-    // sweep slots: load e = tid + 512*j covers clip e / (Hg/4), units 4*(e % (Hg/4)) ..+3 (clamped for short chains)
-    const int per = Hg >> 2, nload = nb * per;
-    unsigned sw_v[NS];
-    int sw_l[NS];
-#pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        const int e = min(tid + NT * j, nload - 1);
-        const int bl_ = e / per, v = 4 * (e - bl_ * per);
-        sw_v[j] = (unsigned)e * 16u;
-        sw_l[j] = bl_ * LD + v;
-    }
-
-    // gate math: thread = (clip bl, unit u)
-    const int u = tid & 31, bl = tid >> 5;
-    const bool act = bl < nb;
-    const int blc = act ? bl : 0;
-    const int half = u >> 4, ru = u & 15;
-    const int lp = (ru >> 2) * 16 + bl;
-    float bias[3];
-#pragma unroll
-    for (int g = 0; g < 3; ++g) bias[g] = bh[g * Hg + u0 + u];
-    const unsigned pub_v = (unsigned)((bl * Hg + u0 + u) >> 1) * (TF ? 4u : 8u);
-    const bool pub_lane = act && !(u & 1);
-
-    float hp = 0.f, gic[3];
-    if (!TF && has_h0) {                                   // the panel of step 0 is the initial state (bf16, like any h_{t-1})
-        __syncthreads();                                   // (the zero fill above)
-#pragma unroll
-        for (int j = 0; j < NS && j < NSW; ++j) {
-            const int e = min(tid + NT * j, nload - 1);
-            const int bl_ = e / per, v = 4 * (e - bl_ * per);
-            const float4 hv = *reinterpret_cast<const float4*>(a.h0 + (long long)(b0 + bl_) * a.h0_bs + grp * Hg + v);
-            const u32x2 w = {pack2(hv.x, hv.y), pack2(hv.z, hv.w)};
-            *reinterpret_cast<u32x2*>(hB + sw_l[j]) = w;
-        }
-        if (act) hp = a.h0[(long long)(b0 + bl) * a.h0_bs + grp * Hg + u0 + u];
-    }
-    bool nowait = a.dbg >= 1 && a.dbg < 6;
-    const bool plain = team_shares_xcd(a.xid + (size_t)chain * 64, a.P, part, a.status, tid);
-    __syncthreads();                                       // ring slots 0 and 1 are filled
-#pragma unroll
-    for (int g = 0; g < 3; ++g) gic[g] = gi_r[0][blc][g * 32 + u];
-
-    for (int t = 0; t < a.T; ++t) {
-        if (t > 0) {
-            const unsigned soff = cbase + (unsigned)((t - 1) & 1) * panel_bytes;
-            u32x4 g[NSW];
-            unsigned spins = 0;
-            const unsigned flip = tag_bit((unsigned)t) ? 0xffffffffu : 0u;
-            for (;;) {
-#pragma unroll
-                for (int j = 0; j < NSW; ++j) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, sw_v[j], soff, 16);
-                bool ok = true;
-                if constexpr (TF) {
-                    unsigned bad = 0u;
-#pragma unroll
-                    for (int j = 0; j < NSW; ++j) bad |= (g[j].x ^ flip) | (g[j].y ^ flip) | (g[j].z ^ flip) | (g[j].w ^ flip);
-                    ok = (bad & TAGM) == 0u;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < NSW; ++j) ok = ok & (g[j].x == (unsigned)t) & (g[j].z == (unsigned)t);
-                }
-                if (__all(ok || nowait)) break;
-                if (++spins >= SPIN_LIMIT) {
-                    if (lane == 0) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    nowait = true;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-#pragma unroll
-            for (int j = 0; j < NSW; ++j) {
-                if constexpr (TF) {
-                    const u32x4 w = {g[j].x & ~TAGM, g[j].y & ~TAGM, g[j].z & ~TAGM, g[j].w & ~TAGM};
-                    *reinterpret_cast<u32x4*>(hB + sw_l[j]) = w;
-                } else {
-                    const u32x2 w = {g[j].y, g[j].w};               // already bf16 pairs: the LDS image as is
-                    *reinterpret_cast<u32x2*>(hB + sw_l[j]) = w;
-                }
-            }
-        }
-        float gh[3] = {bias[0], bias[1], bias[2]};
-        if (t > 0 || has_h0) {
-            __syncthreads();                               // panel complete
-            f32x4 acc[3];
-#pragma unroll
-            for (int jj = 0; jj < 3; ++jj) acc[jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < NKW; ++i) {
-                const bf16x8 fb = *reinterpret_cast<const bf16x8*>(hB + (lane & 15) * LD + (kg + 4 * i) * 32 + (lane >> 4) * 8);
-#pragma unroll
-                for (int jj = 0; jj < 3; ++jj) acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jj][i], fb, acc[jj], 0, 0, 0);
-            }
-#pragma unroll
-            for (int jj = 0; jj < 3; ++jj) *reinterpret_cast<f32x4*>(red + (kg * 6 + jj * 2 + mg) * RED_TS + red_vec(lane)) = acc[jj];
-            __syncthreads();
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-#pragma unroll
-                for (int w = 0; w < 4; ++w) gh[g] += red[(w * 6 + g * 2 + half) * RED_TS + red_vec(lp) + (ru & 3)];
-        }
-        const float r = lean_sigmoid(gic[0] + gh[0]);
-        const float z = lean_sigmoid(gic[1] + gh[1]);
-        const float n = lean_tanh(gic[2] + r * gh[2]);
-        const float h = (1.f - z) * n + z * hp;
-        {
-            const float hn = __uint_as_float(dpp_xor1(__float_as_uint(h)));
-            if (pub_lane) {
-                const unsigned soff = cbase + (unsigned)(t & 1) * panel_bytes;
-                if constexpr (TF) {
-                    const unsigned w = with_tag(pack2(h, hn), tag_bit((unsigned)(t + 1)) ? TAGM : 0u);
-                    if (plain) __builtin_amdgcn_raw_buffer_store_b32(w, rs, pub_v, soff, 0);
-                    else __builtin_amdgcn_raw_buffer_store_b32(w, rs, pub_v, soff, 16);
-                } else {
-                    const u32x2 w = {(unsigned)(t + 1), pack2(h, hn)};
-                    if (plain) __builtin_amdgcn_raw_buffer_store_b64(w, rs, pub_v, soff, 0);
-                    else __builtin_amdgcn_raw_buffer_store_b64(w, rs, pub_v, soff, 16);
-                }
-            }
-        }
-        const float an = (1.f - z) * (1.f - n * n);
-        // saves into parity t & 1 (the helper reads them after the next barrier); gi of step t + 1 from the ring
-        float* sl = &sv_l[t & 1][0][blc][u];
-        if (act) {
-            sl[0 * 512] = h;
-            sl[1 * 512] = an * gh[2] * r * (1.f - r);
-            sl[2 * 512] = (hp - n) * z * (1.f - z);
-            sl[3 * 512] = an * r;
-            sl[4 * 512] = an;
-            sl[5 * 512] = z;
-        }
-        hp = h;
-        const int slot = (t + 1) & 3;
-#pragma unroll
-        for (int g = 0; g < 3; ++g) gic[g] = gi_r[slot][blc][g * 32 + u];
-    }
-    __syncthreads();                                       // hands the last step's saves to the helper wave
-}
-
-// ---------------------------------------------------------------------------------
 // backward: dh_s = dout_s + z_{s+1} * dh_{s+1} + (dh_{s+1} * c_{s+1}) W_hh
 // Same queue discipline: dout/z rows and the coefficient panel of the NEXT step are requested right
 // after this step's sweep has returned; the dh save is deferred by one step.
@@ -1460,269 +1143,6 @@ __global__ __launch_bounds__(320) void gru_bwd_rs_kernel(GruArgs a) {
     __syncthreads();                                       // hands the last iteration's dh to the loader wave
 }
 
-// ---------------------------------------------------------------------------------
-// backward, WIDE-CHAIN form of the reduce-scatter kernel: 16 clips per chain (all 16 columns of the MFMA), half the
-// workgroups per clip -- the backward counterpart of gru_fwd_w16_kernel for batches whose chains of 8 exceed the CUs.
-// Eight compute waves: wave w owns the NTW = Hg/128 output tiles [w*NTW, w*NTW + NTW) (every column of their accumulators
-// is a clip now, so a tile is published on its own: 64 lanes x 16 bytes, one 64-byte half row per clip); 512 sweep threads
-// = (clip 16, quarter 4, unit quad 8) with the reduce-scatter kernel's lane order and NL = Hg/128 loads each; the loader wave
-// streams 16 clips of operands.  Granules: [consumer][producer][clip 16][pair 16].  Same arithmetic and summation order as
-// the chains of 8: identical results.  CRUSE_PREC_BF16, Hg % 128 == 0, Hg <= 640.
-// ---------------------------------------------------------------------------------
-template <int NTW>
-__global__ __launch_bounds__(576) void gru_bwd_w16_kernel(GruArgs a) {
-    constexpr int KP = 96 + 8;
-    constexpr int NL = NTW;                      // P / 4 producers per quarter
-    __shared__ __attribute__((aligned(16))) __bf16 panel[2][16 * KP];
-    __shared__ __attribute__((aligned(16))) float op_d[4][16][32], op_z[4][16][32];     // ring slot = iteration & 3
-    __shared__ __attribute__((aligned(16))) __bf16 op_c[4][16][96];
-    __shared__ __attribute__((aligned(16))) float op_a[4][16][32];
-    __shared__ __attribute__((aligned(16))) float dh_l[2][16][32];
-    const int Hg = a.Hg, H = a.G * Hg, K3 = 3 * Hg, P = a.P;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int chain, part;
-    if (!claim_chain(a, P, chain, part)) return;
-    const int grp = chain % a.G, bgi = a.bg_off + chain / a.G;
-    const int b0 = bgi * 16, nb = min(16, a.B - b0);
-    const int u0 = part * U;
-    const float* W = a.p.w_hh[grp];
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.xg, 0, a.xg_bytes, 0x00020000);
-    const unsigned cons_bytes = (unsigned)P * 16u * 16u * 8u;       // [producer P][clip 16][pair 16] granules
-    const unsigned panel_bytes = (unsigned)P * cons_bytes;          // one parity of one chain
-    const unsigned cbase = (unsigned)chain * 2u * panel_bytes;
-
-    for (int i = tid; i < 2 * 16 * KP; i += 576) panel[0][i] = (__bf16)0.f;
-
-    const unsigned frame_bytes = (unsigned)H * 4u, crow_bytes = (unsigned)(a.G * K3) * 2u;
-    const long long nrow = (long long)(a.B - 1) * a.TS + a.T;
-    const unsigned tot_f32 = (unsigned)min(nrow * H * 4, 0xffffffffll);
-    const unsigned tot_cf = (unsigned)min(nrow * a.G * K3 * 2, 0xffffffffll);
-    const __amdgpu_buffer_rsrc_t rs_dout = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dout), 0, tot_f32, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.zs), 0, tot_f32, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_dh = __builtin_amdgcn_make_buffer_rsrc(a.dh, 0, tot_f32, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_cf = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.coefs), 0, tot_cf, 0x00020000);
-
-    if (wv == 8) {
-        // ---- loader wave: dout / z / a_n rows 16 clips x 8 chunks of 4 floats (2 slots per lane); coefficient rows 16 clips x
-        //      3 gates x 4 chunks of 8 bf16 (3 slots per lane)
-        unsigned dv[2], ddst[2];
-        bool dok[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = lane + 64 * i, lc = idx >> 3, lq = idx & 7;
-            dok[i] = lc < nb;
-            dv[i] = (unsigned)(((long long)(b0 + (dok[i] ? lc : 0)) * a.TS * H + grp * Hg + u0 + 4 * lq) * 4);
-            ddst[i] = (unsigned)(lc * 32 + 4 * lq);
-        }
-        unsigned cv[3], cdst[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int idx = lane + 64 * i, cl = idx / 12, rem = idx % 12, gate = rem >> 2, chk = rem & 3;
-            cv[i] = (unsigned)((((long long)(b0 + (cl < nb ? cl : 0)) * a.TS * a.G + grp) * K3 + gate * Hg + u0 + 8 * chk) * 2);
-            cdst[i] = (unsigned)(cl * 96 + gate * 32 + chk * 8);
-        }
-        const bool want_dgi = a.dgi != nullptr;
-        const __amdgpu_buffer_rsrc_t rs_an = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ans), 0, a.ans ? tot_f32 : 0u, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_dgi = __builtin_amdgcn_make_buffer_rsrc(a.dgi, 0, a.dgi ? (a.dg_slabs == 4 ? (unsigned)min(nrow * a.G * 4 * Hg * 2, 0xffffffffll) : tot_cf) : 0u, 0x00020000);
-        struct OpSet { u32x4 d[2], z[2], c[3], an[2]; };
-        auto issue = [&](int j, OpSet& o) {
-            const u32x4 zero = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int i = 0; i < 2; ++i) { o.d[i] = zero; o.z[i] = zero; o.an[i] = zero; }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) o.c[i] = zero;
-            if (j >= a.T) return;
-            const unsigned st = (unsigned)(a.T - 1 - j);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                o.d[i] = (j == 0 && a.carry) ? __builtin_amdgcn_raw_buffer_load_b128(rs_dh, dv[i], st * frame_bytes, 0)
-                                             : __builtin_amdgcn_raw_buffer_load_b128(rs_dout, dv[i], st * frame_bytes, 0);
-                if (j > 0) o.z[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_z, dv[i], (st + 1u) * frame_bytes, 0);
-                if (want_dgi) o.an[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_an, dv[i], st * frame_bytes, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) o.c[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_cf, cv[i], st * crow_bytes, 0);
-        };
-        auto put = [&](int j, const OpSet& o) {
-            const int slot = j & 3;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                *reinterpret_cast<u32x4*>(&op_d[slot][0][0] + ddst[i]) = o.d[i];
-                *reinterpret_cast<u32x4*>(&op_z[slot][0][0] + ddst[i]) = o.z[i];
-                if (want_dgi) *reinterpret_cast<u32x4*>(&op_a[slot][0][0] + ddst[i]) = o.an[i];
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) *reinterpret_cast<u32x4*>(&op_c[slot][0][0] + cdst[i]) = o.c[i];
-        };
-        const int NSL = a.dg_slabs == 4 ? 4 : 3;
-        const unsigned dgrow_bytes = (unsigned)(a.G * NSL * Hg) * 2u;
-        auto flush = [&](int j) {                       // dh (and the gate gradients) of iteration j, one iteration behind
-            const unsigned st = (unsigned)(a.T - 1 - j);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (!dok[i]) continue;
-                const int idx = lane + 64 * i, lc = idx >> 3, lq = idx & 7;
-                const float4 d4 = *reinterpret_cast<const float4*>(&dh_l[j & 1][lc][4 * lq]);
-                const u32x4 dw = {__float_as_uint(d4.x), __float_as_uint(d4.y), __float_as_uint(d4.z), __float_as_uint(d4.w)};
-                __builtin_amdgcn_raw_buffer_store_b128(dw, rs_dh, dv[i], st * frame_bytes, 0);
-                if (want_dgi) {
-                    const int slot = j & 3;
-                    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
-                    const bf16x4_ cr = *reinterpret_cast<const bf16x4_*>(&op_c[slot][lc][4 * lq]);
-                    const bf16x4_ cz = *reinterpret_cast<const bf16x4_*>(&op_c[slot][lc][32 + 4 * lq]);
-                    const float4 a4 = *reinterpret_cast<const float4*>(&op_a[slot][lc][4 * lq]);
-                    const float d[4] = {d4.x, d4.y, d4.z, d4.w}, an_[4] = {a4.x, a4.y, a4.z, a4.w};
-                    bf16x4_ o0, o1, o2;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        o0[e] = (__bf16)(d[e] * (float)cr[e]); o1[e] = (__bf16)(d[e] * (float)cz[e]); o2[e] = (__bf16)(d[e] * an_[e]);
-                    }
-                    const unsigned gi_v = (unsigned)((((long long)(b0 + lc) * a.TS * a.G + grp) * NSL * Hg + u0 + 4 * lq) * 2);
-                    __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o0), rs_dgi, gi_v, st * dgrow_bytes, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o1), rs_dgi, gi_v + (unsigned)Hg * 2u, st * dgrow_bytes, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o2), rs_dgi, gi_v + (unsigned)Hg * 4u, st * dgrow_bytes, 0);
-                    if (NSL == 4) {
-                        const bf16x4_ cn = *reinterpret_cast<const bf16x4_*>(&op_c[slot][lc][64 + 4 * lq]);
-                        bf16x4_ o3;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o3[e] = (__bf16)(d[e] * (float)cn[e]);
-                        __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o3), rs_dgi, gi_v + (unsigned)Hg * 6u, st * dgrow_bytes, 0);
-                    }
-                }
-            }
-        };
-        OpSet s0, s1;
-        issue(0, s0); issue(1, s1);
-        put(0, s0); put(1, s1);
-        issue(2, s0); issue(3, s1);
-        (void)team_shares_xcd(a.xid + (size_t)chain * 64, P, part, a.status, tid);    // mirrors the compute waves' barriers
-        __syncthreads();
-        for (int k = 0; k < a.T; k += 2) {
-            put(k + 2, s0);
-            issue(k + 4, s0);
-            if (k > 0) flush(k - 1);
-            if (a.T - 1 - k == 0) break;
-            __syncthreads();
-            put(k + 3, s1);
-            issue(k + 5, s1);
-            flush(k);
-            if (a.T - 2 - k == 0) break;
-            __syncthreads();
-        }
-        __syncthreads();                                // the last iteration's dh is in LDS
-        flush(a.T - 1);
-        return;
-    }
-
-    // A operand = W_hh[own gate rows, :]^T for this wave's NTW output tiles: A[row = output unit][k = own gate row]
-    bf16x8 wf[NTW][3];
-#pragma unroll
-    for (int i = 0; i < NTW; ++i) {
-        const int n = (wv * NTW + i) * 16 + (lane & 15);
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk)
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                wf[i][kk][e] = (__bf16)W[(long long)(kk * Hg + u0 + (lane >> 4) * 8 + e) * Hg + n];
-    }
-
-    // thread = (clip bl, quarter, unit quad pp): the reduce-scatter kernel's lane order
-    const int pp = tid & 7, quarter = (tid >> 3) & 3, bl = tid >> 5;
-    const bool active = bl < nb;
-    const int blc = active ? bl : 0;
-    unsigned sweep_v[NL];
-#pragma unroll
-    for (int jj = 0; jj < NL; ++jj) {
-        const int pr = quarter * NL + jj;
-        sweep_v[jj] = (unsigned)part * cons_bytes + (unsigned)(((pr * 16 + blc) * 16 + 2 * pp) * 8);
-    }
-    // publish: tile gt of this wave -> consumer gt >> 1, units (gt & 1) * 16 + (lane >> 4) * 4 .. +3 of clip lane & 15
-    unsigned pub_v[NTW];
-#pragma unroll
-    for (int i = 0; i < NTW; ++i) {
-        const int gt = wv * NTW + i;
-        pub_v[i] = (unsigned)(gt >> 1) * cons_bytes +
-                   (((((unsigned)part * 16u + (unsigned)(lane & 15)) * 16u) + (unsigned)(gt & 1) * 8u + (unsigned)(lane >> 4) * 2u) << 3);
-    }
-    const bool pub_ok = (lane & 15) < nb;
-    const int ou = 4 * pp + quarter;                                  // own unit inside the workgroup's 32
-    const int pw = blc * KP + ou;                                     // panel element of the own unit (+ gate*32)
-
-    float dh = 0.f, dd = 0.f, zz = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
-    bool nowait = a.dbg >= 1 && a.dbg < 7;
-    const bool plain = team_shares_xcd(a.xid + (size_t)chain * 64, P, part, a.status, tid);
-    __syncthreads();                                                  // ring slots 0 and 1 are filled
-    dd = op_d[0][blc][ou];
-    c0 = (float)op_c[0][blc][ou]; c1 = (float)op_c[0][blc][32 + ou]; c2 = (float)op_c[0][blc][64 + ou];
-
-    for (int k = 0; k < a.T; ++k) {
-        const int s = a.T - 1 - k;
-        float m = 0.f;
-        if (k > 0) {
-            const unsigned soff = cbase + (unsigned)((k - 1) & 1) * panel_bytes;
-            u32x4 g[NL];
-            unsigned spins = 0;
-            for (;;) {
-#pragma unroll
-                for (int j = 0; j < NL; ++j) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, sweep_v[j], soff, 16);
-                bool ok = true;
-#pragma unroll
-                for (int j = 0; j < NL; ++j) ok = ok & (g[j].x == (unsigned)k) & (g[j].z == (unsigned)k);
-                if (__all(ok || !active || nowait)) break;
-                if (++spins >= SPIN_LIMIT) {
-                    if (lane == 0) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    nowait = true;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            float sm[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < NL; ++j) {
-                sm[0] += bf16lo(g[j].y); sm[1] += bf16hi(g[j].y);
-                sm[2] += bf16lo(g[j].w); sm[3] += bf16hi(g[j].w);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                sm[e] += __uint_as_float(dpp_ror8(__float_as_uint(sm[e])));          // lane ^ 8:  quarter ^ 1
-                sm[e] += __uint_as_float(swz_xor16(__float_as_uint(sm[e])));         // lane ^ 16: quarter ^ 2
-            }
-            m = quarter == 0 ? sm[0] : quarter == 1 ? sm[1] : quarter == 2 ? sm[2] : sm[3];
-        }
-        dh = dd + zz * dh + m;
-        __bf16* pn = panel[k & 1];
-        if (active) {
-            dh_l[k & 1][bl][ou] = dh;
-            pn[pw] = (__bf16)(dh * c0); pn[pw + 32] = (__bf16)(dh * c1); pn[pw + 64] = (__bf16)(dh * c2);
-        }
-        if (s == 0) break;                                 // nothing consumes the partials of time 0
-        {
-            const int slot = (k + 1) & 3;
-            dd = op_d[slot][blc][ou];
-            zz = op_z[slot][blc][ou];
-            c0 = (float)op_c[slot][blc][ou]; c1 = (float)op_c[slot][blc][32 + ou]; c2 = (float)op_c[slot][blc][64 + ou];
-        }
-        __syncthreads();                                   // panel[k & 1] complete; panel[(k+1) & 1] is free again
-        bf16x8 fb[3];
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk)
-            fb[kk] = *reinterpret_cast<const bf16x8*>(pn + (lane & 15) * KP + kk * 32 + (lane >> 4) * 8);
-        const unsigned soff = cbase + (unsigned)(k & 1) * panel_bytes;
-        const unsigned ep = (unsigned)(k + 1);
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) {
-            f32x4 c_ = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < 3; ++kk) c_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][kk], fb[kk], c_, 0, 0, 0);
-            const u32x4 w = {ep, pack2(c_[0], c_[1]), ep, pack2(c_[2], c_[3])};
-            if (pub_ok) {
-                if (plain) __builtin_amdgcn_raw_buffer_store_b128(w, rs, pub_v[i], soff, 0);
-                else __builtin_amdgcn_raw_buffer_store_b128(w, rs, pub_v[i], soff, 16);
-            }
-        }
-    }
-    __syncthreads();                                       // hands the last iteration's dh to the loader wave
-}
-
 // dgi = dh * (c_r, c_z, a_n), dgh = dh * (c_r, c_z, c_n); layouts [rows][G][3][Hg]
 template <typename CT>
 __global__ __launch_bounds__(256) void gru_gate_grads_kernel(const float* dh, const CT* coef, const float* an,
@@ -1861,7 +1281,7 @@ int num_cus() {
     return cached;
 }
 
-struct Plan { int Bg, P, nbg, bg_per_launch, nlaunch; };
+struct Plan { int Bg, P, nbg, bg_per_launch, nlaunch; bool wide; };
 
 }  // namespace
 namespace cruse_gru {       // gru_tf.hip: the tag-free hand-off kernels (bf16, chains of 8, Hg in {160, 320, 640})
@@ -1869,33 +1289,36 @@ bool fwd_tf_eligible(int Bg, int Hg, int prec, bool has_h0, bool gi_bf16);
 bool bwd_tf_eligible(int Bg, int Hg, int prec);
 int dispatch_fwd_tf(const GruArgs& a, int grid, bool wlo, hipStream_t s);
 int dispatch_bwd_tf(const GruArgs& a, int grid, hipStream_t s);
+// gru_w16.hip: wide chains (16 clips), tag-free register-direct hand-off, epochs continuing across time chunks
+bool w16_eligible(int Hg, int prec);
+size_t w16_panel_bytes_per_parity(int Hg, bool fwd);
+int dispatch_fwd_w16(const GruArgs& a, int grid, hipStream_t s);
+int dispatch_bwd_w16(const GruArgs& a, int grid, hipStream_t s);
 }
 namespace {
 
 bool bwd_rs_eligible(int Bg, int Hg, int prec);
 bool fwd_lean_eligible(int Bg, int Hg, int prec);
-bool fwd_w16_eligible(int Bg, int Hg, int prec);
-bool bwd_w16_eligible(int Bg, int Hg, int prec);
 
-// Chains of 8 clips while the batch's chains fit the CUs.  A larger batch: the wide-chain kernels (16 clips per chain,
-// one launch of half the workgroups) where they exist; otherwise several launches of the lean / reduce-scatter kernels on
-// chains of 8, whichever takes fewer launch-times (the generic kernels: chains of 16).
-int make_plan(int B, int G, int Hg, int prec, bool fwd, int chain_clips, Plan& pl) {
+// Chains of 8 clips while the batch's chains fit the CUs.  A larger batch: WIDE chains (16 clips per chain, one launch of
+// half the workgroups, gru_w16.hip) where that kernel applies (wide_ok) and needs fewer launches; otherwise several launches on
+// chains of 8 (the generic kernels: chains of 16).  chain_clips = 16 asks for wide chains outright (the GGRU wavefront: both
+// layers' recurrences co-resident).
+int make_plan(int B, int G, int Hg, int prec, bool fwd, int chain_clips, bool wide_ok, Plan& pl) {
     pl.P = Hg / U;
     const int maxblk = num_cus();
     if (G * pl.P > maxblk) return -1;
-    pl.Bg = chain_clips == 16 ? 16 : 8;
-    if (cruse_opt("gru_bg", 8) == 16) pl.Bg = 16;   // profiling override
+    wide_ok = wide_ok && w16_eligible(Hg, prec);
+    pl.wide = chain_clips == 16 && wide_ok;
+    pl.Bg = pl.wide ? 16 : 8;
     pl.nbg = cdiv(B, pl.Bg);
     int per_launch = ((maxblk / pl.P) / 8 * 8) / G;        // chains per launch padded to a multiple of 8
     if (per_launch < 1) per_launch = 1;
     if (pl.nbg * G * pl.P > maxblk && chain_clips != 8 && pl.Bg == 8) {
         const bool fast8 = fwd ? fwd_lean_eligible(8, Hg, prec) : bwd_rs_eligible(8, Hg, prec);
-        // launches on chains of 8 / of 16; a wide launch takes 1.3x (forward) / 1.8x (backward) the time of one on chains of 8
-        // (tools/gru_bigbatch_probe.py: B = 128 backward 1.27 against 1.38 ms, B = 192 2.48 against 2.06 ms)
         const int n8 = cdiv(pl.nbg, per_launch), n16 = cdiv(cdiv(B, 16), per_launch);
-        const bool wide = fwd ? (fwd_w16_eligible(16, Hg, prec) && n16 < n8) : (bwd_w16_eligible(16, Hg, prec) && 2 * n16 <= n8);
-        if (wide || !fast8) { pl.Bg = 16; pl.nbg = cdiv(B, pl.Bg); }
+        if (wide_ok && n16 < n8) { pl.wide = true; pl.Bg = 16; pl.nbg = cdiv(B, 16); }
+        else if (!fast8) { pl.Bg = 16; pl.nbg = cdiv(B, 16); }          // the generic kernels serve chains of 16
     }
     pl.bg_per_launch = per_launch;
     if (pl.bg_per_launch > pl.nbg) pl.bg_per_launch = pl.nbg;
@@ -1953,18 +1376,6 @@ int dispatch_fwd_lean_w(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
         default: return launch_one(gru_fwd_lean_kernel<5, 5, false, WLO, false, GIB>, a, grid, lds, s, "gru_seq_fwd", (WLO && 5 > 3) ? 256 : 320);
     }
 }
-bool fwd_w16_eligible(int Bg, int Hg, int prec) {
-    return prec == CRUSE_PREC_BF16 && Bg == 16 && Hg % 128 == 0 && Hg <= 640 && cruse_opt("gru_w16", 1) != 0;
-}
-int dispatch_fwd_w16(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
-    switch (a.Hg / 128) {
-        case 1: return launch_one(gru_fwd_w16_kernel<1>, a, grid, lds, s, "gru_seq_fwd", 576);
-        case 2: return launch_one(gru_fwd_w16_kernel<2>, a, grid, lds, s, "gru_seq_fwd", 576);
-        case 3: return launch_one(gru_fwd_w16_kernel<3>, a, grid, lds, s, "gru_seq_fwd", 576);
-        case 4: return launch_one(gru_fwd_w16_kernel<4>, a, grid, lds, s, "gru_seq_fwd", 576);
-        default: return launch_one(gru_fwd_w16_kernel<5>, a, grid, lds, s, "gru_seq_fwd", 576);
-    }
-}
 int dispatch_fwd_lean(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
     // Hg = 640: the K-split step on the tag-free hand-off (library option gru_tf = 0 / 2: the tagged hand-off / the K-split-free kernel)
     const bool tf640 = a.Hg == 640 && !fwd_wlo(a.Hg) && !a.gi_bf16 && a.h0 == nullptr && cruse_opt("gru_tf", 1) != 0;
@@ -1997,18 +1408,6 @@ int dispatch_bwd(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
     return launch_one(gru_bwd_kernel<PREC, 24>, a, grid, lds, s, "gru_seq_bwd");
 }
 
-bool bwd_w16_eligible(int Bg, int Hg, int prec) {
-    return prec == CRUSE_PREC_BF16 && Bg == 16 && Hg % 128 == 0 && Hg <= 640 && cruse_opt("gru_w16", 1) != 0;
-}
-int dispatch_bwd_w16(const GruArgs& a, int grid, hipStream_t s) {
-    switch (a.Hg / 128) {
-        case 1: return launch_one(gru_bwd_w16_kernel<1>, a, grid, 0, s, "gru_seq_bwd", 576);
-        case 2: return launch_one(gru_bwd_w16_kernel<2>, a, grid, 0, s, "gru_seq_bwd", 576);
-        case 3: return launch_one(gru_bwd_w16_kernel<3>, a, grid, 0, s, "gru_seq_bwd", 576);
-        case 4: return launch_one(gru_bwd_w16_kernel<4>, a, grid, 0, s, "gru_seq_bwd", 576);
-        default: return launch_one(gru_bwd_w16_kernel<5>, a, grid, 0, s, "gru_seq_bwd", 576);
-    }
-}
 int dispatch_bwd_rs(const GruArgs& a, int grid, hipStream_t s) {
     const int P = a.Hg / 32, np = (P + 3) / 4;   // tile pairs per wavefront
     if (a.dbg >= 32 && a.dbg <= 35 && a.Hg == 640) return launch_one(gru_bwd_rs_kernel<5, true, true>, a, grid, 0, s, "gru_seq_bwd", 320);
@@ -2051,8 +1450,9 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* pane
     a.dbg = cruse_opt("gru_dbg", 0);
     a.xsweep = cruse_opt("gru_xsweep", 0);
     int rc = CRUSE_OK;
-    CRUSE_REQUIRE(pl.nlaunch <= MAX_LAUNCH_TICKETS, CRUSE_E_SHAPE, "gru_seq: batch %d needs %d launches (max %d)", a.B, pl.nlaunch,
-                  MAX_LAUNCH_TICKETS);
+    // (a.seq: the run's index among the launches that share this scratch since it was cleared -- time chunks of one recurrence)
+    CRUSE_REQUIRE((a.seq + 1) * pl.nlaunch <= MAX_LAUNCH_TICKETS, CRUSE_E_SHAPE, "gru_seq: batch %d needs %d launches x %d runs (max %d)", a.B,
+                  pl.nlaunch, a.seq + 1, MAX_LAUNCH_TICKETS);
     for (int L = 0; L < pl.nlaunch; ++L) {
         const int bg_off = L * pl.bg_per_launch;
         const int nbg_here = (pl.nbg - bg_off) < pl.bg_per_launch ? (pl.nbg - bg_off) : pl.bg_per_launch;
@@ -2061,15 +1461,15 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* pane
         a.nchains = nbg_here * G;
         // every launch gets its own panel region: chain index inside the launch + offset
         a.xid = (unsigned long long*)xid_base + (size_t)bg_off * G * 64;
-        a.tickets = tickets_base + (size_t)L * 8;
-        const bool rs_form = !FWD && bwd_rs_eligible(pl.Bg, Hg, prec);
-        const bool w16_bwd = !FWD && bwd_w16_eligible(pl.Bg, Hg, prec);
-        const size_t gpp = rs_form ? rs_gran_per_parity(Hg) : w16_bwd ? 2 * rs_gran_per_parity(Hg) : (size_t)pl.Bg * Hg;      // granules per parity and chain
+        a.tickets = tickets_base + ((size_t)a.seq * pl.nlaunch + L) * 8;
+        const bool rs_form = !FWD && !pl.wide && bwd_rs_eligible(pl.Bg, Hg, prec);
+        const size_t gpp = pl.wide ? w16_panel_bytes_per_parity(Hg, FWD) / 8 : rs_form ? rs_gran_per_parity(Hg) : (size_t)pl.Bg * Hg;      // granules per parity and chain
         a.xg = (unsigned long long*)xg_base + (size_t)bg_off * G * 2 * gpp;
         a.xg_bytes = (unsigned)((size_t)a.nchains * 2 * gpp * 8);
         const int grid = cdiv(a.nchains, 8) * 8 * pl.P;
-        if (FWD && fwd_w16_eligible(pl.Bg, Hg, prec)) {
-            rc = dispatch_fwd_w16(a, grid, lds, s);
+        if (FWD && pl.wide) {
+            a.poll_delay = cruse_opt("gru_poll_fwd16", 0);
+            rc = dispatch_fwd_w16(a, grid, s);
         } else if (FWD && fwd_lean_eligible(pl.Bg, Hg, prec)) {
             if (fwd_tf_eligible(pl.Bg, Hg, prec, a.h0 != nullptr, a.gi_bf16 != 0)) { a.poll_delay = cruse_opt("gru_poll_fwd", 8); rc = dispatch_fwd_tf(a, grid, fwd_wlo(Hg), s); }
             else { a.poll_delay = cruse_opt("gru_poll_fwd", 0); rc = dispatch_fwd_lean(a, grid, lds, s); }
@@ -2077,7 +1477,8 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* pane
             if (prec == CRUSE_PREC_F32) rc = dispatch_fwd<CRUSE_PREC_F32>(a, grid, lds, s);
             else if (prec == CRUSE_PREC_BF16X3) rc = dispatch_fwd<CRUSE_PREC_BF16X3>(a, grid, lds, s);
             else rc = dispatch_fwd<CRUSE_PREC_BF16>(a, grid, lds, s);
-        } else if (w16_bwd) {
+        } else if (pl.wide) {
+            a.poll_delay = cruse_opt("gru_poll_bwd16", 5);
             rc = dispatch_bwd_w16(a, grid, s);
         } else if (rs_form) {
             // (the tag-free kernel's panels are half the size of the reduce-scatter kernel's: the same regions hold them)
@@ -2122,8 +1523,10 @@ extern "C" size_t cruse_gru_ws_bytes(int B, int G, int Hg) {
 extern "C" int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, const float* const* b_hh,
                                     float* h, void* coef, float* an, float* z, const float* h0, long long h0_bstride,
                                     int B, int T, int TS, int G, int Hg, int prec, int chain_clips, int gi_bf16, void* panels,
-                                    int panels_zeroed, unsigned* status, int xcd_rot, void* stream) {
+                                    int panels_zeroed, unsigned* status, int xcd_rot, int epoch0, int seq, void* stream) {
     int rc = check_common(B, T, G, Hg, prec, "gru_seq_fwd");
+    CRUSE_REQUIRE(epoch0 >= 0 && seq >= 0 && (epoch0 == 0 || h0 != nullptr), CRUSE_E_SHAPE,
+                  "gru_seq_fwd: epoch0 = %d, seq = %d (a continuation takes its state from h0)", epoch0, seq);
     CRUSE_REQUIRE(!gi_bf16 || (prec == CRUSE_PREC_BF16 && ((uintptr_t)gi % 16) == 0), CRUSE_E_SHAPE,
                   "gru_seq_fwd: bf16 gi rows need CRUSE_PREC_BF16 and a 16-byte aligned base");
     CRUSE_REQUIRE(chain_clips == 0 || chain_clips == 8 || chain_clips == 16, CRUSE_E_SHAPE, "gru_seq_fwd: chain_clips = %d (0, 8, 16)", chain_clips);
@@ -2134,7 +1537,11 @@ extern "C" int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, c
     CRUSE_REQUIRE((coef == nullptr) == (an == nullptr) && (coef == nullptr) == (z == nullptr), CRUSE_E_SHAPE,
                   "gru_seq_fwd: coef, an, z must all be given or all be NULL");
     Plan pl;
-    CRUSE_REQUIRE(make_plan(B, G, Hg, prec, true, chain_clips, pl) == 0, CRUSE_E_SHAPE, "gru_seq_fwd: G*Hg/32 exceeds the CU count");
+    // wide chains: f32 gi rows; their tag-free hand-off needs |h| < 1, so an initial state is taken only where the caller asks for
+    // wide chains outright and thereby vouches for |h0| < 1 (the continuation of a sequence that started from zero)
+    const bool wide_ok = !gi_bf16 && (h0 == nullptr || chain_clips == 16);
+    CRUSE_REQUIRE(make_plan(B, G, Hg, prec, true, chain_clips, wide_ok, pl) == 0, CRUSE_E_SHAPE, "gru_seq_fwd: G*Hg/32 exceeds the CU count");
+    CRUSE_REQUIRE(pl.wide || epoch0 == 0 || !panels_zeroed, CRUSE_E_SHAPE, "gru_seq_fwd: continuing epochs (epoch0 = %d) need the wide-chain kernel", epoch0);
     hipStream_t s = (hipStream_t)stream;
     CRUSE_REQUIRE(panels != nullptr && status != nullptr, CRUSE_E_SHAPE, "gru_seq_fwd: workspace / status pointer is NULL");
     // (the status word is sticky: never cleared here.  panels_zeroed: the caller cleared the scratch itself -- e.g. the scratches of
@@ -2146,6 +1553,7 @@ extern "C" int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, c
     for (int g = 0; g < G; ++g) { a.p.w_hh[g] = w_hh[g]; a.p.b_hh[g] = b_hh[g]; }
     a.B = B; a.T = T; a.G = G; a.Hg = Hg;
     a.TS = TS; a.h0 = h0; a.h0_bs = h0_bstride;
+    a.e0 = pl.wide ? epoch0 : 0; a.seq = seq;
     const size_t esz = prec == CRUSE_PREC_F32 ? 4 : 2, npl = prec == CRUSE_PREC_BF16X3 ? 2 : 1;
     const size_t lds = (size_t)16 * (Hg + (prec == CRUSE_PREC_F32 ? 4 : 8)) * esz * npl + 4 * 6 * RED_TS * sizeof(float);
     return run_launches<true>(a, pl, G, Hg, prec, panels, status, xcd_rot, lds, s);
@@ -2155,7 +1563,7 @@ extern "C" int cruse_gru_seq_fwd_on(const float* gi, const float* const* w_hh, c
                                     float* h, void* coef, float* an, float* z,
                                     int B, int T, int G, int Hg, int prec, void* panels, unsigned* status, int xcd_rot,
                                     void* stream) {
-    return cruse_gru_seq_fwd_ex(gi, w_hh, b_hh, h, coef, an, z, nullptr, 0, B, T, T, G, Hg, prec, 0, 0, panels, 0, status, xcd_rot, stream);
+    return cruse_gru_seq_fwd_ex(gi, w_hh, b_hh, h, coef, an, z, nullptr, 0, B, T, T, G, Hg, prec, 0, 0, panels, 0, status, xcd_rot, 0, 0, stream);
 }
 
 extern "C" int cruse_gru_seq_fwd(const float* gi, const float* const* w_hh, const float* const* b_hh,
@@ -2172,13 +1580,16 @@ extern "C" int cruse_gru_gate_grads_bf16(const float* dh, const void* coef, cons
 extern "C" int cruse_gru_seq_bwd_ex(const float* dout, const float* const* w_hh, const void* coef, const float* z,
                                     float* dh, const float* an, void* dgi, int dg_slabs, int carry, int B, int T, int TS, int G,
                                     int Hg, int prec, int chain_clips, void* panels, int panels_zeroed, unsigned* status, int xcd_rot,
-                                    void* stream) {
+                                    int epoch0, int seq, void* stream) {
     int rc = check_common(B, T, G, Hg, prec, "gru_seq_bwd");
+    CRUSE_REQUIRE(epoch0 >= 0 && seq >= 0 && (epoch0 == 0 || carry), CRUSE_E_SHAPE,
+                  "gru_seq_bwd: epoch0 = %d, seq = %d (a continuation carries dh in)", epoch0, seq);
     CRUSE_REQUIRE(chain_clips == 0 || chain_clips == 8 || chain_clips == 16, CRUSE_E_SHAPE, "gru_seq_bwd: chain_clips = %d (0, 8, 16)", chain_clips);
     if (rc) return rc;
     CRUSE_REQUIRE(TS >= T, CRUSE_E_SHAPE, "gru_seq_bwd: clip stride %d frames < %d steps", TS, T);
     Plan pl;
-    CRUSE_REQUIRE(make_plan(B, G, Hg, prec, false, chain_clips, pl) == 0, CRUSE_E_SHAPE, "gru_seq_bwd: G*Hg/32 exceeds the CU count");
+    CRUSE_REQUIRE(make_plan(B, G, Hg, prec, false, chain_clips, true, pl) == 0, CRUSE_E_SHAPE, "gru_seq_bwd: G*Hg/32 exceeds the CU count");
+    CRUSE_REQUIRE(pl.wide || epoch0 == 0 || !panels_zeroed, CRUSE_E_SHAPE, "gru_seq_bwd: continuing epochs (epoch0 = %d) need the wide-chain kernel", epoch0);
     hipStream_t s = (hipStream_t)stream;
     CRUSE_REQUIRE(panels != nullptr && status != nullptr, CRUSE_E_SHAPE, "gru_seq_bwd: workspace / status pointer is NULL");
     if (!panels_zeroed) { int zrc = cruse_zero_async(panels, cruse_gru_ws_bytes(B, G, Hg) - 256, s, "gru_seq_bwd memset"); if (zrc) return zrc; }   // the status word is sticky: never cleared here
@@ -2187,13 +1598,14 @@ extern "C" int cruse_gru_seq_bwd_ex(const float* dout, const float* const* w_hh,
     for (int g = 0; g < G; ++g) { a.p.w_hh[g] = w_hh[g]; a.p.b_hh[g] = nullptr; }
     a.B = B; a.T = T; a.G = G; a.Hg = Hg;
     a.TS = TS; a.carry = carry ? 1 : 0;
+    a.e0 = pl.wide ? epoch0 : 0; a.seq = seq;
     const size_t esz = prec == CRUSE_PREC_F32 ? 4 : 2, npl = prec == CRUSE_PREC_BF16X3 ? 2 : 1;
     const size_t lds = (size_t)16 * (3 * Hg + (prec == CRUSE_PREC_F32 ? 4 : 8)) * esz * npl + 4 * 2 * 64 * 4 * sizeof(float);
     CRUSE_REQUIRE(lds <= 160 * 1024, CRUSE_E_SHAPE, "gru_seq_bwd: Hg=%d needs %zu B of LDS", Hg, lds);
     CRUSE_REQUIRE(dgi == nullptr || (an != nullptr && prec == CRUSE_PREC_BF16), CRUSE_E_SHAPE,
                   "gru_seq_bwd: dgi needs the a_n rows and CRUSE_PREC_BF16");
     // the reduce-scatter kernel's loader wave writes dgi itself; the other kernels are followed by the gate-gradient pass
-    const bool in_kernel = dgi != nullptr && (bwd_rs_eligible(pl.Bg, Hg, prec) || bwd_w16_eligible(pl.Bg, Hg, prec));
+    const bool in_kernel = dgi != nullptr && (pl.wide || bwd_rs_eligible(pl.Bg, Hg, prec));
     CRUSE_REQUIRE(dg_slabs == 3 || (dg_slabs == 4 && (dgi == nullptr || in_kernel)), CRUSE_E_SHAPE,
                   "gru_seq_bwd: dg_slabs = %d (3, or 4 with the reduce-scatter kernels: bf16, Hg <= 640)", dg_slabs);
     a.ans = in_kernel ? an : nullptr;
@@ -2209,7 +1621,7 @@ extern "C" int cruse_gru_seq_bwd_ex(const float* dout, const float* const* w_hh,
 extern "C" int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh, const void* coef, const float* z,
                                     float* dh, const float* an, void* dgi, int B, int T, int G, int Hg, int prec,
                                     void* panels, unsigned* status, int xcd_rot, void* stream) {
-    return cruse_gru_seq_bwd_ex(dout, w_hh, coef, z, dh, an, dgi, 3, 0, B, T, T, G, Hg, prec, 0, panels, 0, status, xcd_rot, stream);
+    return cruse_gru_seq_bwd_ex(dout, w_hh, coef, z, dh, an, dgi, 3, 0, B, T, T, G, Hg, prec, 0, panels, 0, status, xcd_rot, 0, 0, stream);
 }
 
 extern "C" int cruse_gru_seq_bwd(const float* dout, const float* const* w_hh, const void* coef, const float* z,

@@ -11,6 +11,6 @@ for f in "$@"; do
 done
 for p in "${pids[@]}"; do wait "$p"; done
 objs=()
-for f in stft stft_general conv conv_mfma wgrad_mfma pointwise gemm gemm_bf16 gru gru_tf tdloss deepfilter generic extras abi; do objs+=("$here/build/$f.o"); done
+for f in stft stft_general conv conv_mfma wgrad_mfma pointwise gemm gemm_bf16 gru gru_tf gru_w16 tdloss deepfilter generic extras abi; do objs+=("$here/build/$f.o"); done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$here/../libcruse_hip.so"
 echo "relinked"

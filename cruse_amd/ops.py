@@ -705,7 +705,7 @@ def _off(t: torch.Tensor, elems: int) -> int:
 
 
 def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G, Hg, prec, save=True, slot=0, xcd_rot=0,
-                h0=None, out=None, chunk=None, wide=False, zeroed=False):
+                h0=None, out=None, chunk=None, wide=False, zeroed=False, seq=None):
     """-> (h, coef, an, z); the last three are None when save is False (inference).  slot / xcd_rot: see
     cruse_gru_seq_fwd_on (concurrent recurrences).
     h0 [B, G*Hg] ("cat" layout: feature = group*Hg + unit): initial state (cust_conv.py:305-325); None = 0.
@@ -713,7 +713,8 @@ def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G,
     the frames before them -- the initial state is then h[:, t0-1] (h0 for t0 == 0).  Consecutive chunks reproduce the
     single launch (cruse_gru_seq_fwd_ex).  wide: chains of 16 clips (half the workgroups; same results).
     gi: f32, or bf16 rows (gemm_bf16_nt into a bf16 tensor; bf16 mode only).  zeroed: the slot's scratch is already clear
-    (gru_step_ws_clear)."""
+    (gru_step_ws_clear).  seq (wide chains, zeroed): this chunk's index among the chunks of ONE sequence that share the slot's
+    scratch without clearing it in between -- the hand-off epochs then continue from chunk to chunk (epoch0 = t0)."""
     if gi.dtype not in (torch.float32, torch.bfloat16):
         raise RuntimeError(f"gru_seq_fwd: gi must be f32 or bf16, got {gi.dtype}")
     dev = gi.device
@@ -735,6 +736,9 @@ def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G,
     if t0 > 0:
         h0p, h0s = _off(h, (t0 - 1) * H), T * H
     elif h0 is not None:
+        if wide:
+            raise RuntimeError("gru_seq_fwd: wide chains take no caller-supplied h0 (their hand-off needs |h| < 1); chunk "
+                               "continuations are fine")
         if tuple(h0.shape) != (B, H) or h0.dtype != torch.float32:
             raise RuntimeError(f"gru_seq_fwd: h0 must be f32 [{B}, {H}], got {tuple(h0.shape)}")
         _p(h0)
@@ -746,7 +750,7 @@ def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G,
     check(lib.cruse_gru_seq_fwd_ex(_off(gi, t0 * 3 * H), ctypes.cast(wa, ctypes.c_void_p), ctypes.cast(ba, ctypes.c_void_p),
                                    _off(h, t0 * H), opt(coef, 3 * H), opt(an, H), opt(z, H), h0p, h0s, B, n, T, G, Hg,
                                    prec_code(prec), 16 if wide else 0, 1 if gi.dtype == torch.bfloat16 else 0, panels, 1 if zeroed else 0,
-                                   status, xcd_rot, _stream()))
+                                   status, xcd_rot, t0 if seq is not None else 0, seq or 0, _stream()))
     return h, coef, an, z
 
 
@@ -762,11 +766,12 @@ def dgi_buffer(rows, G, Hg, device, slabs=3):
 
 
 def gru_seq_bwd(dout, w_hh: List[torch.Tensor], coef, z, B, T, G, Hg, prec, slot=0, xcd_rot=0, an=None, want_dgi=False,
-                out=None, chunk=None, dg_slabs=3, wide=False, zeroed=False):
+                out=None, chunk=None, dg_slabs=3, wide=False, zeroed=False, seq=None):
     """dout [B,T,H] -> dh [B,T,H] (total gradient reaching every h_t).  want_dgi (CRUSE_PREC_BF16, with the a_n rows):
     -> (dh, dgi) with dgi = dh * (c_r, c_z, a_n) in bf16 written by the recurrence itself (cruse_gru_seq_bwd_on).
     chunk = (t0, n): only frames [t0, t0+n), into out = dh (or (dh, dgi)); chunks are run from the LAST to the first, and
-    every chunk but the last picks the gradient carried across its end up from dh[:, t0+n] (cruse_gru_seq_bwd_ex)."""
+    every chunk but the last picks the gradient carried across its end up from dh[:, t0+n] (cruse_gru_seq_bwd_ex).
+    seq: as in gru_seq_fwd (wide chains; epoch0 = the iterations the later chunks have run)."""
     H = G * Hg
     dgi = None
     if out is not None:
@@ -788,7 +793,8 @@ def gru_seq_bwd(dout, w_hh: List[torch.Tensor], coef, z, B, T, G, Hg, prec, slot
     check(lib.cruse_gru_seq_bwd_ex(_off(dout, t0 * H), ctypes.cast(wa, ctypes.c_void_p), _off(coef, t0 * 3 * H), _off(z, t0 * H),
                                    _off(dh, t0 * H), _off(an, t0 * H) if want_dgi else None,
                                    None if dgi is None else _off(dgi, t0 * dg_slabs * H), dg_slabs, carry, B, steps, T, G, Hg, prec_code(prec),
-                                   16 if wide else 0, panels, 1 if zeroed else 0, status, xcd_rot, _stream()))
+                                   16 if wide else 0, panels, 1 if zeroed else 0, status, xcd_rot,
+                                   (T - t0 - steps) if seq is not None else 0, seq or 0, _stream()))
     return (dh, dgi) if want_dgi else dh
 
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CRUSE_ABI_VERSION 9
+#define CRUSE_ABI_VERSION 10
 
 enum {
     CRUSE_OK = 0,
@@ -441,18 +441,24 @@ int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh, const void
  *            The values are widened on load; everything else is unchanged.
  *   chain_clips: clips served by one team of Hg/32 workgroups.  0 = the library's plan: chains of 8 while the batch's chains fit
  *            the CUs; beyond that (B > 96 at Hg = 640) WIDE chains of 16 (half the workgroups per clip, the full 16 columns of the
- *            MFMA; CRUSE_PREC_BF16, Hg % 128 == 0, Hg <= 640; a wide launch takes 1.3x (forward) / 1.8x (backward) the time of a
- *            launch on chains of 8) where that needs fewer launch-times than several launches on chains of 8 (B = 128: 0.67 against
- *            1.01 ms forward, 1.27 against 1.38 ms backward; tools/gru_bigbatch_probe.py).  8 / 16 force the width (two wide
- *            recurrences with xcd_rot 0 / 4 run side by side on 2 x 80 CUs, tools/gru_pair_probe.py).  Results do not depend on it. */
+ *            MFMA; CRUSE_PREC_BF16, Hg % 128 == 0, Hg <= 640, f32 gi rows, h0 == NULL) where that needs fewer launches.
+ *            8 / 16 force the width: with 16 a batch of 64 at Hg = 640 takes 80 CUs, so the recurrences of BOTH GGRU layers are
+ *            co-resident and run as a time-chunk wavefront (layer 2 at frame t needs layer 1 at frames <= t only).  The forward
+ *            results do not depend on the width (same sums in the same order); the backward ones up to the f32 summation order.
+ *            chain_clips = 16 WITH h0: the caller vouches for |h0| < 1 (the wide kernels' hand-off keeps the epoch bit in the top
+ *            exponent bit of every exchanged bf16) -- true for the continuation of a sequence that started from h0 = 0.
+ *   epoch0, seq: a sequence run as consecutive time chunks on WIDE chains may share one panel scratch that is cleared once
+ *            (panels_zeroed = 1 on every chunk): epoch0 = the number of steps the earlier chunks of the same sequence took on this
+ *            scratch (forward: t0; backward: the iterations already run), seq = the chunk's index (< 64: its own XCD tickets and
+ *            team handshake).  epoch0 > 0 needs h0 (forward) / carry (backward).  0, 0 for a run on a freshly cleared scratch. */
 int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, const float* const* b_hh,
                          float* h, void* coef, float* an, float* z, const float* h0, long long h0_bstride,
                          int B, int T, int TS, int G, int Hg, int prec, int chain_clips, int gi_bf16, void* panels,
-                         int panels_zeroed, unsigned* status, int xcd_rot, void* stream);
+                         int panels_zeroed, unsigned* status, int xcd_rot, int epoch0, int seq, void* stream);
 int cruse_gru_seq_bwd_ex(const float* dout, const float* const* w_hh, const void* coef, const float* z,
                          float* dh, const float* an, void* dgi, int dg_slabs, int carry, int B, int T, int TS, int G,
                          int Hg, int prec, int chain_clips, void* panels, int panels_zeroed, unsigned* status, int xcd_rot,
-                         void* stream);
+                         int epoch0, int seq, void* stream);
 /* dgi = dh*(c_r,c_z,a_n) (gradient wrt gi), dgh = dh*(c_r,c_z,c_n) (gradient wrt W_hh h + b_hh), both
  * [rows,G,3*Hg]; dW_ih, dW_hh, dX and the bias gradients follow from cruse_gemm / cruse_col_sum. */
 int cruse_gru_gate_grads(const float* dh, const void* coef, const float* an, float* dgi, float* dgh,

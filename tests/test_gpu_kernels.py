@@ -623,63 +623,81 @@ def test_conv_dgrad_accumulates_the_batchnorm_backward_sums(ops, form, Cin, Cout
 
 @pytest.mark.parametrize("H,B,T,G", [(640, 64, 9, 1), (640, 24, 7, 1), (128, 16, 5, 1), (384, 5, 6, 1), (256, 33, 4, 2), (512, 17, 1, 1)])
 def test_gru_fwd_wide_chains_match_lean_kernel_bit_for_bit(ops, H, B, T, G):
-    """cruse_gru_seq_fwd_ex(chain_clips = 16): chains of 16 clips (half the workgroups per clip; gru_fwd_w16_kernel) -- the lean
-    kernel's arithmetic in the lean kernel's summation order, so h and the saved coefficient rows are identical; with an
-    initial state and run as time chunks too."""
+    """cruse_gru_seq_fwd_ex(chain_clips = 16): chains of 16 clips (half the workgroups per clip; gru_fwd_w16_kernel, gru_w16.hip) -- the
+    lean kernel's arithmetic in the lean kernel's summation order, so h and the saved coefficient rows are identical; run as time
+    chunks too: every chunk on its own cleared scratch, and all chunks on ONE scratch cleared once with the hand-off epochs
+    continuing (epoch0 / seq) -- the form the GGRU wavefront uses."""
     torch.manual_seed(H + B)
     Hg = H // G
     gi = (0.5 * torch.randn(B, T, 3 * H)).cuda()
     w = [(torch.randn(3 * Hg, Hg) / Hg ** 0.5).cuda() for _ in range(G)]; b = [(0.1 * torch.randn(3 * Hg)).cuda() for _ in range(G)]
-    h0 = (0.3 * torch.randn(B, H)).cuda()
-    # (gru_wlo = 0: the lean kernel's W_hh low-plane pass for Hg <= 320 has no wide-chain form; gru_tf = 0: the K-split-free
-    #  kernel of gru_tf.hip sums in another order -- it has its own tests below)
-    with ops.options(gru_wlo=0, gru_tf=0):
-        for init in (None, h0):
-            lean = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16", h0=init)
-            wide = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16", h0=init, wide=True)
-            for x, y, name in zip(wide, lean, ("h", "coef", "an", "z")):
-                assert torch.equal(x, y), (name, init is not None)
+    # (gru_wlo = 0: the lean kernel's W_hh low-plane pass for Hg <= 320 has no wide-chain form)
+    with ops.options(gru_wlo=0):
+        lean = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16")
+        wide = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16", wide=True)
+        for x, y, name in zip(wide, lean, ("h", "coef", "an", "z")):
+            assert torch.equal(x, y), name
+        nosave = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16", wide=True, save=False)
+        assert torch.equal(nosave[0], lean[0])
         if T >= 4:
-            cut = T // 2
-            out = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16", h0=h0, chunk=(0, cut), wide=True)
-            ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16", out=out, chunk=(cut, T - cut), wide=True)
+            cuts = [(0, T // 2), (T // 2, T - T // 2)] if T < 7 else [(0, 2), (2, 1), (3, T - 5), (T - 2, 2)]
+            out = None
+            for c in cuts:                                   # every chunk clears its own scratch
+                out = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16", out=out, chunk=c, wide=True)
             for x, y, name in zip(out, lean, ("h", "coef", "an", "z")):
                 assert torch.equal(x, y), ("chunked", name)
+            ops.gru_step_ws_clear(B, G, Hg, "cuda")
+            out = None
+            for i, c in enumerate(cuts):                     # one scratch, cleared once: the epochs continue
+                out = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16", out=out, chunk=c, wide=True, slot=ops.STEP_SLOT0, zeroed=True, seq=i)
+            for x, y, name in zip(out, lean, ("h", "coef", "an", "z")):
+                assert torch.equal(x, y), ("chunked on one scratch", name)
+    with pytest.raises(RuntimeError):
+        ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16", h0=torch.zeros(B, H).cuda(), wide=True)
     assert ops.gru_status() == 0
 
 
 @pytest.mark.parametrize("H,B,T,G,slabs", [(640, 64, 9, 1, 4), (640, 24, 7, 1, 3), (128, 16, 5, 1, 4), (384, 5, 6, 1, 3), (256, 33, 4, 2, 4),
                                             (512, 17, 1, 1, 3)])
-def test_gru_bwd_wide_chains_match_reduce_scatter_kernel_bit_for_bit(ops, H, B, T, G, slabs):
-    """cruse_gru_seq_bwd_ex(chain_clips = 16): chains of 16 clips (gru_bwd_w16_kernel) -- the reduce-scatter kernel's arithmetic in
-    its summation order, so dh and the in-kernel gate gradients (3 or 4 slabs) are identical; run as time chunks (last chunk
-    first, the gradient carried across the cut) too."""
+def test_gru_bwd_wide_chains_match_the_chains_of_8(ops, H, B, T, G, slabs):
+    """cruse_gru_seq_bwd_ex(chain_clips = 16): chains of 16 clips (gru_bwd_w16_kernel: the all-gather step on eight compute waves) --
+    dh and the in-kernel gate gradients (3 or 4 slabs) equal those of the chains of 8 up to the f32 summation order / one bf16 rounding
+    of the exchanged products, and the exact-f32 recurrence within the bf16 mode's error; run as time chunks (last chunk first, the
+    gradient carried across the cut) on their own scratches and on one scratch with continuing epochs: bit-identical to the one launch."""
     torch.manual_seed(H + B)
     Hg = H // G
     gi = (0.5 * torch.randn(B, T, 3 * H)).cuda()
     w = [(torch.randn(3 * Hg, Hg) / Hg ** 0.5).cuda() for _ in range(G)]; b = [(0.1 * torch.randn(3 * Hg)).cuda() for _ in range(G)]
     dout = torch.randn(B, T, H).cuda()
     h, coef, an, z = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16")
-    with ops.options(gru_tf=0):                    # (the tagged reduce-scatter kernel is the wide kernel's twin; gru_bwd_tf sums in another order)
-        ref = ops.gru_seq_bwd(dout, w, coef, z, B, T, G, Hg, "bf16", an=an, want_dgi=True, dg_slabs=slabs)
+    ref = ops.gru_seq_bwd(dout, w, coef, z, B, T, G, Hg, "bf16", an=an, want_dgi=True, dg_slabs=slabs)
     wide = ops.gru_seq_bwd(dout, w, coef, z, B, T, G, Hg, "bf16", an=an, want_dgi=True, dg_slabs=slabs, wide=True)
-    assert torch.equal(wide[0], ref[0]), "dh"
-    assert torch.equal(wide[1].view(torch.int16), ref[1].view(torch.int16)), "dgi"
+    assert rel_l2(wide[0], ref[0]) < 3e-3, "dh"
+    assert rel_l2(wide[1].float(), ref[1].float()) < 4e-3, "dgi"
+    exact = ops.gru_seq_bwd(dout, w, coef.float(), z, B, T, G, Hg, "f32")
+    assert rel_l2(wide[0], exact) < 4e-3
     only_dh = ops.gru_seq_bwd(dout, w, coef, z, B, T, G, Hg, "bf16", wide=True)
-    assert torch.equal(only_dh, ref[0])
+    assert torch.equal(only_dh, wide[0])
     if T >= 4:
-        cut = T // 2
+        cuts = [(0, T // 2), (T // 2, T - T // 2)] if T < 7 else [(0, 2), (2, 1), (3, T - 5), (T - 2, 2)]
         out = (torch.zeros_like(ref[0]), torch.zeros_like(ref[1]))
-        ops.gru_seq_bwd(dout, w, coef, z, B, T, G, Hg, "bf16", an=an, want_dgi=True, dg_slabs=slabs, out=out, chunk=(cut, T - cut), wide=True)
-        ops.gru_seq_bwd(dout, w, coef, z, B, T, G, Hg, "bf16", an=an, want_dgi=True, dg_slabs=slabs, out=out, chunk=(0, cut), wide=True)
-        assert torch.equal(out[0], ref[0]), "chunked dh"
-        assert torch.equal(out[1].view(torch.int16), ref[1].view(torch.int16)), "chunked dgi"
+        for c in reversed(cuts):
+            ops.gru_seq_bwd(dout, w, coef, z, B, T, G, Hg, "bf16", an=an, want_dgi=True, dg_slabs=slabs, out=out, chunk=c, wide=True)
+        assert torch.equal(out[0], wide[0]), "chunked dh"
+        assert torch.equal(out[1].view(torch.int16), wide[1].view(torch.int16)), "chunked dgi"
+        ops.gru_step_ws_clear(B, G, Hg, "cuda")
+        out = (torch.zeros_like(ref[0]), torch.zeros_like(ref[1]))
+        for i, c in enumerate(reversed(cuts)):
+            ops.gru_seq_bwd(dout, w, coef, z, B, T, G, Hg, "bf16", an=an, want_dgi=True, dg_slabs=slabs, out=out, chunk=c, wide=True,
+                            slot=ops.STEP_SLOT0 + 1, zeroed=True, seq=i)
+        assert torch.equal(out[0], wide[0]), "chunked dh on one scratch"
+        assert torch.equal(out[1].view(torch.int16), wide[1].view(torch.int16)), "chunked dgi on one scratch"
     assert ops.gru_status() == 0
 
 
-@pytest.mark.parametrize("H,B,T,G,opts,wide", [(640, 64, 9, 1, {}, False), (640, 24, 7, 1, {}, True), (320, 11, 6, 2, {}, False),
+@pytest.mark.parametrize("H,B,T,G,opts,wide", [(640, 64, 9, 1, {}, False), (640, 24, 7, 1, {}, False), (320, 11, 6, 2, {}, False),
                                                (512, 9, 5, 1, {"gru_wlo": 1}, False), (256, 13, 6, 1, {"gru_fwd_lean": 0}, False),
-                                               (384, 40, 5, 1, {}, True)])
+                                               (384, 40, 5, 1, {}, False)])
 def test_gru_fwd_takes_bf16_gate_preactivations(ops, H, B, T, G, opts, wide):
     """cruse_gru_seq_fwd_ex(gi_bf16 = 1): gi as bf16 rows (cruse_gemm_bf16_nt_obf16) widened on load == the same values handed over
     as f32 rows, bit for bit, in every forward kernel of the bf16 mode: lean with the helper wave (Hg % 128 == 0 and not), lean
@@ -937,28 +955,23 @@ def test_gru_wide_chains_at_the_bench_length(ops):
 
 @pytest.mark.parametrize("B", [136, 104])
 def test_gru_batch_beyond_the_cu_count(ops, B):
-    """Hg = 640, B > 96: the chains of 8 x 20 workgroups do not fit the 256 CUs.  make_plan: B = 136 -- forward two launches of the
-    wide-chain kernel (9 chains of 16, the last with 8 clips), backward three launches of the reduce-scatter kernel on chains
-    of 8 (two wide launches would take longer); B = 104 -- one wide launch each way.  Same results as the batch run in two
-    parts (chains of 8) -- bit for bit with the tagged kernels (the wide kernels' twins), up to the summation order with the
-    default ones (tag-free hand-off wherever chains of 8 run)."""
+    """Hg = 640, B > 96: the chains of 8 x 20 workgroups do not fit the 256 CUs; make_plan then takes WIDE chains (gru_w16.hip): B = 136 --
+    two launches of 8 + 1 chains of 16 (the last chain with 8 clips) instead of three on chains of 8; B = 104 -- one wide launch each
+    way.  Same results as the batch run in two parts on chains of 8: forward bit for bit (same sums in the same order), backward up to
+    the f32 summation order."""
     torch.manual_seed(3)
     T, H = 6, 640
     gi = (0.5 * torch.randn(B, T, 3 * H)).cuda()
     w = [(torch.randn(3 * H, H) / H ** 0.5).cuda()]; b = [(0.1 * torch.randn(3 * H)).cuda()]
     dout = torch.randn(B, T, H).cuda()
-    with ops.options(gru_tf=0):
-        full = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16")
-        dh, dgi = ops.gru_seq_bwd(dout, w, full[1], full[3], B, T, 1, H, "bf16", an=full[2], want_dgi=True)
-        for lo, hi in ((0, 64), (64, B)):
-            part = ops.gru_seq_fwd(gi[lo:hi].contiguous(), w, b, hi - lo, T, 1, H, "bf16")
-            for x, y, name in zip(part, full, ("h", "coef", "an", "z")):
-                assert torch.equal(x, y[lo:hi]), name
-            dh_p, dgi_p = ops.gru_seq_bwd(dout[lo:hi].contiguous(), w, part[1], part[3], hi - lo, T, 1, H, "bf16", an=part[2], want_dgi=True)
-            assert torch.equal(dh_p, dh[lo:hi]) and torch.equal(dgi_p, dgi[lo * T:hi * T].view(dgi_p.shape))
-    full_d = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16")
-    dh_d, dgi_d = ops.gru_seq_bwd(dout, w, full_d[1], full_d[3], B, T, 1, H, "bf16", an=full_d[2], want_dgi=True)
-    assert rel_l2(full_d[0], full[0]) < 1e-3 and rel_l2(dh_d, dh) < 2e-3 and rel_l2(dgi_d.float(), dgi.float()) < 2e-3
+    full = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16")
+    dh, dgi = ops.gru_seq_bwd(dout, w, full[1], full[3], B, T, 1, H, "bf16", an=full[2], want_dgi=True)
+    for lo, hi in ((0, 64), (64, B)):
+        part = ops.gru_seq_fwd(gi[lo:hi].contiguous(), w, b, hi - lo, T, 1, H, "bf16")
+        for x, y, name in zip(part, full, ("h", "coef", "an", "z")):
+            assert torch.equal(x, y[lo:hi]), name
+        dh_p, dgi_p = ops.gru_seq_bwd(dout[lo:hi].contiguous(), w, part[1], part[3], hi - lo, T, 1, H, "bf16", an=part[2], want_dgi=True)
+        assert rel_l2(dh_p, dh[lo:hi]) < 3e-3 and rel_l2(dgi_p.float(), dgi[lo * T:hi * T].view(dgi_p.shape).float()) < 4e-3
     assert ops.gru_status() == 0
 
 
