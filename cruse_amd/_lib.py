@@ -55,6 +55,7 @@ SIGNATURES = {
     "cruse_ln_fwd": ("ppppppppqiifiqqp", "i"),
     "cruse_ln_fwd_c": ("ppppppippqiifiqqp", "i"),
     "cruse_ln_bwd": ("pppppqiipppp", "i"),
+    "cruse_ln_bwd_seg": ("pppppqiipppiqqp", "i"),
     "cruse_gemm": ("iiiiipipipipiiiip", "i"),
     "cruse_gemm_bf16_nt": ("iiipqqpqqpqpiip", "i"),
     "cruse_gemm_bf16_slab_bytes": ("iii", "z"),
@@ -70,6 +71,7 @@ SIGNATURES = {
     "cruse_ktile_bf16": ("piiqppp", "i"),
     "cruse_ktile_f16": ("piiqpp", "i"),
     "cruse_gemm_f16_nt": ("iiipqqpqqpqpp", "i"),
+    "cruse_gemm_f16_nt_seg": ("iiipqpqqpqpiqqp", "i"),
     "cruse_cast_bf16_split": ("pppqp", "i"),
     "cruse_gemm_bf16x3_nt": ("iiippqqppqqpqpip", "i"),
     "cruse_gru_ws_bytes": ("iii", "z"),

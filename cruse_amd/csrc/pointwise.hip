@@ -572,7 +572,7 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const float* x, const f
 template <int NQ, int LNB_NR>
 __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const float* dy, const float* x, const float* mean,
                                                          const float* rstd, const float* gamma, long long rows, int H,
-                                                         float* dx, float* dgamma, float* dbeta) {
+                                                         float* dx, float* dgamma, float* dbeta, RowSeg sg) {
     __shared__ float sdg[1024], sdb[1024];
     const int lane = threadIdx.x & 63, nq = H >> 2;
     for (int c = threadIdx.x; c < H; c += blockDim.x) { sdg[c] = 0.f; sdb[c] = 0.f; }
@@ -592,8 +592,8 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const float* dy, const 
         float s1[LNB_NR], s2[LNB_NR], rsv[LNB_NR];
 #pragma unroll
         for (int k = 0; k < LNB_NR; ++k) {
-            const long long r = r0 + k;
-            const bool rok = r < rows;
+            const bool rok = r0 + k < rows;
+            const long long r = seg_row(sg, rok ? r0 + k : rows - 1);
             const float m = rok ? mean[r] : 0.f;
             rsv[k] = rok ? rstd[r] : 0.f;
             s1[k] = 0.f; s2[k] = 0.f;
@@ -620,8 +620,8 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const float* dy, const 
         for (int k = 0; k < LNB_NR; ++k) { s1[k] = wave_sum(s1[k]) / (float)H; s2[k] = wave_sum(s2[k]) / (float)H; }
 #pragma unroll
         for (int k = 0; k < LNB_NR; ++k) {
-            const long long r = r0 + k;
-            if (r >= rows) continue;
+            if (r0 + k >= rows) continue;
+            const long long r = seg_row(sg, r0 + k);
 #pragma unroll
             for (int e = 0; e < NQ; ++e) {
                 const int q = lane + 64 * e;
@@ -951,24 +951,35 @@ extern "C" int cruse_ln_fwd_c(const float* x, const float* gamma, const float* b
 
 static int lnb_grid() { return cruse_opt("lnb_grid", 512); }
 
-extern "C" int cruse_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
-                            const float* gamma, long long rows, int H, int interleave_g,
-                            float* dx, float* dgamma, float* dbeta, void* stream) {
+extern "C" int cruse_ln_bwd_seg(const float* dy, const float* x, const float* mean, const float* rstd,
+                                const float* gamma, long long rows, int H, int interleave_g,
+                                float* dx, float* dgamma, float* dbeta, int seg_len, long long seg_stride, long long seg_off, void* stream) {
     CRUSE_REQUIRE(rows > 0 && H > 0 && H <= 64 * LN_MAXE, CRUSE_E_SHAPE, "ln_bwd: H=%d must be in 1..%d", H, 64 * LN_MAXE);
     CRUSE_REQUIRE(interleave_g >= 1 && H % interleave_g == 0, CRUSE_E_SHAPE, "ln_bwd: groups=%d must divide H=%d", interleave_g, H);
+    CRUSE_REQUIRE(seg_len >= 0 && (seg_len == 0 || (seg_stride >= seg_len && seg_off >= 0 && rows % seg_len == 0)), CRUSE_E_SHAPE,
+                  "ln_bwd: bad row segments (len %d stride %lld off %lld, rows %lld)", seg_len, seg_stride, seg_off, rows);
+    const RowSeg sg = {seg_len, seg_stride, seg_off};
     const bool vec = interleave_g == 1 && H % 4 == 0 && H <= 256 * LNV_MAXQ &&
                      ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)gamma) & 15) == 0);
     if (vec && H <= 768)
         hipLaunchKernelGGL((ln_bwd_vec_kernel<3, 2>), dim3(grid_for(rows, 16, lnb_grid())), dim3(256), 0, ST(stream), dy, x, mean,
-                           rstd, gamma, rows, H, dx, dgamma, dbeta);
+                           rstd, gamma, rows, H, dx, dgamma, dbeta, sg);
     else if (vec)
         hipLaunchKernelGGL((ln_bwd_vec_kernel<4, 1>), dim3(grid_for(rows, 16, lnb_grid())), dim3(256), 0, ST(stream), dy, x, mean,
-                           rstd, gamma, rows, H, dx, dgamma, dbeta);
-    else
+                           rstd, gamma, rows, H, dx, dgamma, dbeta, sg);
+    else {
+        CRUSE_REQUIRE(seg_len == 0, CRUSE_E_SHAPE, "ln_bwd: row segments need the vector form (one group, H %% 4 == 0, aligned)");
         hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid_for(rows, 32, 1024)), dim3(256), 0, ST(stream), dy, x, mean, rstd,
                            gamma, rows, H, interleave_g, dx, dgamma, dbeta);
+    }
     CRUSE_LAUNCH_CHECK("ln_bwd");
     return CRUSE_OK;
+}
+
+extern "C" int cruse_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
+                            const float* gamma, long long rows, int H, int interleave_g,
+                            float* dx, float* dgamma, float* dbeta, void* stream) {
+    return cruse_ln_bwd_seg(dy, x, mean, rstd, gamma, rows, H, interleave_g, dx, dgamma, dbeta, 0, 0, 0, stream);
 }
 
 extern "C" int cruse_mask_loss_fwd(const float* mask, const float* nre, const float* nim, const float* cmag,

@@ -225,7 +225,7 @@ def _gi_f16(prec, Hg: int, layer: int) -> bool:
     grouped configurations carries ~16 bits on both operands and measured BETTER than f16 there (enhanced spectrum at T = 401, closed-form
     init, g = 4: 3.1e-4 against 1.7e-3; g = 2: 9e-5 against 5.5e-4), so those keep it."""
     c = config.get()
-    return (bool((int(c.gi_f16) * 3 if isinstance(c.gi_f16, bool) else int(c.gi_f16 or 0)) >> layer & 1) and _bf16_gemm_path(prec, Hg) and not (_gi_x3_knob(Hg) & 4) and not c.dw_tn and int(c.fwd_chunks or 0) < 2
+    return (bool((int(c.gi_f16) * 3 if isinstance(c.gi_f16, bool) else int(c.gi_f16 or 0)) >> layer & 1) and _bf16_gemm_path(prec, Hg) and not (_gi_x3_knob(Hg) & 4) and not c.dw_tn
             and not c.gi_bf16)
 
 
@@ -268,143 +268,106 @@ def ggru_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], prefix: str, group
 _AUX = {}
 
 
-def _aux_stream():
+def _wave_streams():
+    """the two extra streams of the GGRU wavefront: [0] the second recurrence, [1] the in-between kernels of a chunk"""
     dev = torch.cuda.current_device()
     if dev not in _AUX:
-        _AUX[dev] = torch.cuda.Stream()
+        _AUX[dev] = (torch.cuda.Stream(), torch.cuda.Stream())
     return _AUX[dev]
 
 
-def _fwd_chunks(prec, Hg: int, g: int, T: int, slot: int, x_bf16) -> int:
-    """Time chunks of the forward GGRU pipeline (EngineConfig.fwd_chunks; 0 / 1 = off).  Needs the bf16 gate-GEMM path with
-    the operand copies written by the producing kernels (so the projections read row-major bf16 rows: Hg % 64 == 0) and
-    enough frames per chunk to amortise a recurrence launch (its prologue loads the weight slice into registers)."""
-    n = int(config.get().fwd_chunks or 0)
-    if n < 2 or slot != 0 or x_bf16 is None or not _gi_takes_bf16_copy(prec, Hg) or T < 64 * n:
+def _time_chunks(T: int, n: int):
+    base = T // n
+    return [(j * base, base if j + 1 < n else T - j * base) for j in range(n)]
+
+
+def _wave_chunks(prec, Hg: int, g: int, B: int, T: int, slot: int, x_bf16, save: bool) -> int:
+    """Time chunks of the GGRU WAVEFRONT (EngineConfig.ggru_wave; 0 / 1 = off): layer 2 at frame t needs layer 1 at frames <= t only
+    (cruse_net.py:41-51: the LayerNorm between them is per frame, the gate projection a GEMM over rows), so on WIDE chains
+    (gru_w16.hip: 16 clips per chain, half the workgroups) the two recurrences are co-resident and run one chunk apart -- forward
+    and, mirrored, backward.  Needs the bf16 gate-GEMM path with the operand copies written by the producing kernels, one group
+    (the LayerNorm's interleave is then the identity), Hg % 128 == 0 <= 640, both layers' teams on the chip at once, and enough
+    frames per chunk to amortise a recurrence launch (~18 us: weights to registers)."""
+    n = int(config.get().ggru_wave or 0)
+    if (n < 2 or slot != 0 or g != 1 or not save or x_bf16 is None or not _gi_takes_bf16_copy(prec, Hg) or Hg % 128 or Hg > 640
+            or not SIDE.enabled):
         return 1
-    if torch.cuda.is_current_stream_capturing():
-        # EXPERIMENTAL option, eager launches only (ADVICE r3): under HIP-graph capture the forked auxiliary stream's first kernel
-        # node once replayed without its input rows; a dummy first node hid that, the cause was never established -- so the
-        # captured step runs the single-launch form (same results: the chunks reproduce it bit for bit)
-        global _CHUNK_CAPTURE_WARNED
-        if not _CHUNK_CAPTURE_WARNED:
-            import sys
-            print("[cruse_amd] EngineConfig.fwd_chunks is ignored under HIP-graph capture (experimental, eager launches only)",
-                  file=sys.stderr, flush=True)
-            _CHUNK_CAPTURE_WARNED = True
+    # (<= 4 chains per layer: with xcd_rot 0 / 4 the two launches then sit on disjoint XCD halves)
+    if (B + 15) // 16 > 4 or torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count < 8 * (Hg // 32):
         return 1
+    while n > 1 and T < 32 * n:
+        n -= 1
     return n
 
 
-_CHUNK_CAPTURE_WARNED = False
+def _ggru_forward_wave(x, x_bf16, P, prefix, g, Hg, prec, save, nch, ctx, project):
+    """GGRU layers 1 and 2 as a time-chunk WAVEFRONT on wide chains (cruse_gru_seq_fwd_ex(chain_clips = 16, epoch0, seq): the chunks
+    of a recurrence share one panel scratch and continue its hand-off epochs; results identical to the single launches):
 
+        main:  gi1 | rec1(c0) | rec1(c1) | rec1(c2) | ...
+        aux :             ln1 + gi2 (c0) | ln1 + gi2 (c1) | ...
+        sB  :                            rec2(c0)  | rec2(c1) | ...
 
-def _ggru_forward_chunked(x, x_bf16, P, prefix, g, Hg, prec, save, nch, ctx, before_last_launch):
-    """GGRU layers 1 and 2 as a TIME-CHUNK PIPELINE (cruse_gru_seq_fwd_ex: a sequence run as consecutive chunks gives the
-    results of the single launch).  The main stream runs only the recurrences, back to back; an auxiliary stream runs the
-    in-between kernels of one chunk -- the layer-1 projection of the NEXT chunk, then LayerNorm 1 + the layer-2 projection of
-    the chunk the recurrence has just finished -- beside the recurrence of another, on the ~96 CUs a recurrence leaves free
-    (in the forward pass the side stream has little to put there):
-
-        main:  gi1(c0) | rec1(c0) | rec1(c1) | ...      | rec2(c0)          | rec2(c1) | ...
-        aux :           gi1(c1)   | ln1+gi2(c0), gi1(c2) | ... ln1+gi2(c_last) |
-
-    Unchunked, gi1, LayerNorm 1 and gi2 (0.35 ms of the 6.0 ms step, tools/upper_bound_probe.py) sit between the recurrences
-    on the main stream.
-
-    Under HIP-graph capture the auxiliary stream's FIRST captured operation is a one-element dummy.  Without it the replayed
-    graph (ROCm 7.2) left the rows of the layer-1 projection of chunk 1 -- the first kernel node of the freshly forked stream,
-    whose fork event follows the chunk-0 projection -- unwritten or overwritten (frames of chunk 1 onward wrong, deterministically;
-    eager launches right).  Bisected in r03 with lr = 0 replays: forking the stream BEFORE the chunk-0 projection, making the node
-    wait for the first recurrence chunk as well, or putting any other node first all give the eager result; the cause was not
-    established.  The side stream's leaves are not affected (tests/test_gpu_model.py: a replay on a new batch equals the eager
-    launches bit for bit), and this pipeline is checked the same way in both launch forms.
-
-    Returns (h1, c1, a1, z1, l1, l1_bf, m1, s1, h2, c2, a2, z2)."""
+    project(inp, inp_copy, lname, gi, seg): the layer's gate projection (whole tensor or one chunk).
+    Returns (h1, c1, a1, z1, l1, l1_copy, m1, s1, h2, c2, a2, z2)."""
     B, T, H = x.shape
     rows = B * T
     dev = x.device
     main = torch.cuda.current_stream()
-    aux = _aux_stream()
-    base = T // nch
-    chunks = [(j * base, base if j + 1 < nch else T - j * base) for j in range(nch)]
-    kp = (Hg + 63) // 64 * 64
-    knob = _gi_x3_knob(Hg)
-    # everything the aux stream writes is allocated here, on the main stream
+    sB, aux = _wave_streams()
+    chunks = _time_chunks(T, nch)
+    f16_2 = _gi_f16(prec, Hg, 1)
+    # everything the other streams touch is allocated here, on the main stream
     gi1 = torch.empty(B, T, g * 3 * Hg, device=dev, dtype=torch.float32)
     gi2 = torch.empty_like(gi1)
     l1 = torch.empty(B, T, H, device=dev, dtype=torch.float32)
-    l1_bf = torch.empty(rows * H, device=dev, dtype=torch.bfloat16)
-    m1 = torch.empty(rows, device=dev, dtype=torch.float32) if save else None
-    s1 = torch.empty(rows, device=dev, dtype=torch.float32) if save else None
-    wts = {}
-    for li, lname in enumerate(("gru_list1", "gru_list2")):
-        x3 = (knob >> li) & 1
-        for i in range(g):
-            w_ih = P[f"{prefix}{lname}.{i}.weight_ih_l0"]
-            wts[(lname, i)] = ops.ktile_bf16(w_ih, 3 * Hg, Hg, split=True) if x3 else (ops.ktile_bf16(w_ih, 3 * Hg, Hg), None)
-
-    def proj(lname, inp_bf, gi, c):
-        t0, n = c
-        for i in range(g):
-            w_hi, w_lo = wts[(lname, i)]
-            ops.gemm_bf16_nt_seg(B * n, 3 * Hg, kp, inp_bf, None, i * Hg, H, w_hi, w_lo, 0, 64, gi, i * 3 * Hg, 3 * H, (n, T, t0),
-                                 bias=P[f"{prefix}{lname}.{i}.bias_ih_l0"], b_kstride=3 * Hg * 64)
-
-    def ln1(c, h1):
-        t0, n = c
-        ops.ln_fwd(h1, P[prefix + "ln1.weight"], P[prefix + "ln1.bias"], None, B * n, H, 1, save=save, out=l1, out_bf16=l1_bf,
-                   seg=(n, T, t0), stats=(m1, s1) if save else None)
-
-    def whh(lname):
-        return ([P[f"{prefix}{lname}.{i}.weight_hh_l0"] for i in range(g)], [P[f"{prefix}{lname}.{i}.bias_hh_l0"] for i in range(g)])
+    l1_c = torch.empty(rows * H, device=dev, dtype=torch.float16 if f16_2 else torch.bfloat16)
+    m1 = torch.empty(rows, device=dev, dtype=torch.float32)
+    s1 = torch.empty(rows, device=dev, dtype=torch.float32)
+    outs = []
+    for _ in range(2):
+        h = torch.empty(B, T, H, device=dev, dtype=torch.float32)
+        outs.append((h, torch.empty(B, T, 3 * H, device=dev, dtype=torch.bfloat16), torch.empty_like(h), torch.empty_like(h)))
+    out1, out2 = outs
+    w1 = [P[f"{prefix}gru_list1.{i}.weight_hh_l0"] for i in range(g)]; b1 = [P[f"{prefix}gru_list1.{i}.bias_hh_l0"] for i in range(g)]
+    w2 = [P[f"{prefix}gru_list2.{i}.weight_hh_l0"] for i in range(g)]; b2 = [P[f"{prefix}gru_list2.{i}.bias_hh_l0"] for i in range(g)]
+    project(x, x_bf16, "gru_list1", gi1, None)
+    prep2 = project(None, None, "gru_list2", None, None)          # (the K-tiled W_ih of layer 2, made once, on the main stream)
+    slot1, z1 = STEP_SCRATCH.take(B, g, Hg, 0)
+    slot2, z2 = STEP_SCRATCH.take(B, g, Hg, 0)
+    if not z1 or not z2:                                           # outside a training step: two private scratches, cleared per launch
+        slot1, z1, slot2, z2 = 1, False, 2, False
 
     def ev_on(stream):
         e = torch.cuda.Event()
         e.record(stream)
         return e
 
-    w1, b1 = whh("gru_list1")
-    w2, b2 = whh("gru_list2")
-    proj("gru_list1", x_bf16, gi1, chunks[0])
-    start = ev_on(main)                                   # x_bf16 and the K-tiled weights are complete
-    aux.wait_event(start)
-    if torch.cuda.is_current_stream_capturing():
-        dummy = torch.zeros(64, device=dev)
-        with torch.cuda.stream(aux):
-            dummy.add_(1.0)
-        ctx["_aux_first_node"] = dummy
-    out1 = None
-    e_p = {}                                              # layer-1 projection of chunk j done (aux)
-    e_q = {}                                              # LayerNorm 1 + layer-2 projection of chunk j done (aux)
+    start = ev_on(main)
+    sB.wait_event(start); aux.wait_event(start)
     for j, c in enumerate(chunks):
-        if j > 0:
-            main.wait_event(e_p[j])
+        launch = (lambda c=c, j=j: ops.gru_seq_fwd(gi1, w1, b1, B, T, g, Hg, prec, save=save, out=out1, chunk=c, wide=True, slot=slot1,
+                                                   zeroed=z1, seq=j if z1 else None, xcd_rot=0))
         if j == 0:
-            out1 = SIDE.release_around(lambda: ops.gru_seq_fwd(gi1, w1, b1, B, T, g, Hg, prec, save=save, chunk=c))
+            SIDE.release_around(launch)
         else:
-            ops.gru_seq_fwd(gi1, w1, b1, B, T, g, Hg, prec, save=save, out=out1, chunk=c)
+            launch()
         e_r = ev_on(main)
         with torch.cuda.stream(aux):
-            if j + 1 < nch:
-                proj("gru_list1", x_bf16, gi1, chunks[j + 1])
-                e_p[j + 1] = ev_on(aux)
             aux.wait_event(e_r)                           # h1 of chunk j is complete
-            ln1(c, out1[0])
-            proj("gru_list2", l1_bf, gi2, c)
-            e_q[j] = ev_on(aux)
-    out2 = None
-    for j, c in enumerate(chunks):
-        main.wait_event(e_q[j])
-        last = j + 1 == nch
-        launch = (lambda c=c: ops.gru_seq_fwd(gi2, w2, b2, B, T, g, Hg, prec, save=save, out=out2, chunk=c))
-        # the leaves of layer 1 (the operand transposes read ALL of h1 and l1) are queued for the LAST chunk's launch
-        if last:
-            before_last_launch(out1[0], l1, l1_bf)
-        out2_ = SIDE.release_around(launch) if last else launch()
-        out2 = out2 if out2 is not None else out2_
-    ctx["fwd_chunks"] = nch
-    return out1 + (l1, l1_bf, m1, s1) + out2
+            ops.ln_fwd(out1[0], P[prefix + "ln1.weight"], P[prefix + "ln1.bias"], None, B * c[1], H, 1, save=True, out=l1, out_bf16=l1_c,
+                       seg=(c[1], T, c[0]), stats=(m1, s1))
+            project(l1, l1_c, "gru_list2", gi2, (c[1], T, c[0]), prep2)
+            e_q = ev_on(aux)
+        with torch.cuda.stream(sB):
+            sB.wait_event(e_q)
+            ops.gru_seq_fwd(gi2, w2, b2, B, T, g, Hg, prec, save=save, out=out2, chunk=c, wide=True, slot=slot2, zeroed=z2,
+                            seq=j if z2 else None, xcd_rot=4)
+    main.wait_stream(aux)
+    main.wait_stream(sB)
+    ctx["wave"] = nch
+    ctx["_wave_keep"] = (gi1, gi2)
+    return out1 + (l1, l1_c, m1, s1) + out2
 
 
 def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=None, slot=0, xcd_rot=0, pre_done=None,
@@ -493,8 +456,8 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
     ctx["tn"] = tn
     tt = {}
 
-    def queue_layer1_leaves(h1, l1, l1_bf):
-        """queued for the (last) launch of the second forward recurrence"""
+    def queue_layer1_leaves(h1, l1, l1_bf, late=None):
+        """queued for the launch of the second forward recurrence (wavefront: for the decoder -- `late` -- both recurrences have run)"""
         if tn:                                   # the TN weight-gradient GEMMs read the layer inputs row-major (bf16 copy if made)
             ctx["in_bf"] = {"gru_list1": x_bf16, "gru_list2": l1_bf}
         if not fwd_T:
@@ -517,15 +480,44 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
                     w_ts[(lname, i)] = ops.transpose_bf16(P[f"{prefix}{lname}.{i}.weight_ih_l0"], 3 * Hg, Hg, out=stack[i])
                 w_ts[(lname, "stack")] = stack
         ctx["w_ts"] = w_ts
-        if tn:
+        if late is not None:
+            late.append((t_layer1, (x, h1, l1) + (() if tn else (tt["xT"], tt["h1T"], tt["l1T"]))))
+        elif tn:
             SIDE.defer(t_layer1, kind=1, lane=2)
         else:
             SIDE.defer(t_layer1, x, h1, l1, tt["xT"], tt["h1T"], tt["l1T"], kind=1, lane=2)
 
-    nch = _fwd_chunks(prec, Hg, g, T, slot, x_bf16)
+    def wave_project(inp, inp_c, lname, gi, seg, prep=None):
+        """g == 1 gate projection of the wavefront: the whole tensor (seg None) or one time chunk; gi None: only prepare (and return)
+        the K-tiled W_ih operand planes"""
+        li = 0 if lname == "gru_list1" else 1
+        w_ih, b_ih = P[f"{prefix}{lname}.0.weight_ih_l0"], P[f"{prefix}{lname}.0.bias_ih_l0"]
+        f16 = _gi_f16(prec, Hg, li)
+        x3 = (_gi_x3_knob(Hg) >> li) & 1
+        if prep is None:
+            prep = ((ops.ktile_f16(w_ih, 3 * Hg, Hg), None) if f16 else
+                    ops.ktile_bf16(w_ih, 3 * Hg, Hg, split=True) if x3 else (ops.ktile_bf16(w_ih, 3 * Hg, Hg), None))
+        if gi is None:
+            return prep
+        w_hi, w_lo = prep
+        if f16 and seg is None:
+            ops.gemm_f16_nt(rows, 3 * Hg, Hg, inp_c, 0, H, w_hi, 0, 64, gi, 0, 3 * H, bias=b_ih, b_kstride=3 * Hg * 64)
+        elif f16:
+            ops.gemm_f16_nt_seg(B * seg[0], 3 * Hg, Hg, inp_c, 0, H, w_hi, 0, 64, gi, 0, 3 * H, seg, bias=b_ih, b_kstride=3 * Hg * 64)
+        elif seg is not None:
+            ops.gemm_bf16_nt_seg(B * seg[0], 3 * Hg, Hg, inp_c, None, 0, H, w_hi, w_lo, 0, 64, gi, 0, 3 * H, seg, bias=b_ih, b_kstride=3 * Hg * 64)
+        elif x3:
+            ops.gemm_bf16x3_nt(rows, 3 * Hg, Hg, inp_c, None, 0, H, w_hi, w_lo, 0, 64, gi, 0, 3 * H, bias=b_ih, b_kstride=3 * Hg * 64)
+        else:
+            ops.gemm_bf16_nt(rows, 3 * Hg, Hg, inp_c, 0, H, w_hi, 0, 64, gi, 0, 3 * H, bias=b_ih, b_kstride=3 * Hg * 64)
+        return prep
+
+    nch = _wave_chunks(prec, Hg, g, B, T, slot, x_bf16, save)
     if nch > 1:
-        h1, c1, a1, z1, l1, l1_bf, m1, s1, h2, c2, a2, z2 = _ggru_forward_chunked(x, x_bf16, P, prefix, g, Hg, prec, save, nch, ctx,
-                                                                                  queue_layer1_leaves)
+        if hooks:
+            hooks.pop()()
+        h1, c1, a1, z1, l1, l1_bf, m1, s1, h2, c2, a2, z2 = _ggru_forward_wave(x, x_bf16, P, prefix, g, Hg, prec, save, nch, ctx, wave_project)
+        queue_layer1_leaves(h1, l1, l1_bf, late=late_leaves)
     else:
         h1, c1, a1, z1 = layer(x, "gru_list1", x_bf16)
         f16 = _gi_f16(prec, Hg, 1)
@@ -640,14 +632,21 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
             return dx, dx_accum
         return torch.empty(B, T, H, device=dout_h.device, dtype=torch.float32), False
 
-    def layer_bwd_bf16(dout_h, lname, inp, h, coef, an, z, need_dinp, last):
-        """CRUSE_PREC_BF16: every product as gemm_bf16_nt on bf16 operand copies (see gemm_bf16.hip)."""
+    def layer_bwd_bf16(dout_h, lname, inp, h, coef, an, z, need_dinp, last, pre=None):
+        """CRUSE_PREC_BF16: every product as gemm_bf16_nt on bf16 operand copies (see gemm_bf16.hip).
+        pre = (dh, dgi): the wavefront has already run the recurrence and the input gradient in time chunks -- only the
+        weight-gradient leaf is left (issued at once for layer 2: the side stream then waits for the last layer-2 chunk only)."""
         names = [f"{prefix}{lname}.{i}." for i in range(g)]
         w_hh = [P[nm + "weight_hh_l0"] for nm in names]
         bias_ih = [G[nm + "bias_ih_l0"] for nm in names]
         bias_hh = [G[nm + "bias_hh_l0"] for nm in names]
         ldT = (rows + 63) // 64 * 64
-        if fuse_dgi and SIDE.enabled:
+        if pre is not None:
+            dh, dgi = pre
+            dgT = torch.empty(ldT // 64, g, 4, Hg, 64, device=dh.device, dtype=torch.bfloat16)
+            made_dgT = False
+            need_dinp = False
+        elif fuse_dgi and SIDE.enabled:
             # the recurrence writes dgi itself (its loader wave), dX starts right behind it; the time-major copies for the
             # weight-gradient GEMMs and the bias sums are made by the weight-gradient leaf, off the main stream
             dh, dgi = run_bwd(dout_h, w_hh, coef, z, an)
@@ -697,7 +696,7 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
 
         # The last layer's weight-gradient leaf goes to the side stream BEFORE the dX GEMM is issued: its event then follows the
         # gate-gradient pass, not the GEMM, and the three dW products start ~150 us earlier (5.40 vs 5.46 ms).
-        early_leaf = last and not defer_last
+        early_leaf = (last and not defer_last) or (pre is not None and not last)
         if early_leaf:
             SIDE.run(weight_grads, dgT, h, inp, inpT, hpT, dh, lane=2)
         dinp, acc_dx = dinp_buffer(dout_h, need_dinp, last)
@@ -782,6 +781,89 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
         SIDE.defer(early_transposes, x1T, h1T, kind=4, lane=2)
     dh2 = ops.ln_bwd(dout, ctx["h2"], ctx["m2"], ctx["s2"], P[prefix + "ln2.weight"], rows, H, 1,
                      G[prefix + "ln2.weight"], G[prefix + "ln2.bias"])
+    nch = int(ctx.get("wave", 0))
+    if nch > 1 and _bf16_gemm_path(prec, Hg) and g == 1 and not ctx.get("tn") and SIDE.enabled and int(config.get().ggru_wave or 0) >= 2:
+        # ---- the backward WAVEFRONT (see _ggru_forward_wave): in reverse time, layer 2's recurrence one chunk ahead of layer 1's ----
+        #   main:  rec2'(c3) | rec2'(c2) | rec2'(c1) | rec2'(c0) |                  (+ layer 2's weight-gradient leaf on the side stream)
+        #   aux :            dX2 + ln1'(c3) | dX2 + ln1'(c2), dX1(c3) | ...                       | dX1(c0)
+        #   sB  :                           rec1'(c3)            | rec1'(c2) | ...
+        # Both recurrences write their gate-gradient rows themselves (DGI); the time-major copies the weight gradients read are
+        # made by the leaves, off the critical path.
+        if hooks:
+            hooks.pop()()
+        dev = dout.device
+        main = torch.cuda.current_stream()
+        sB, aux = _wave_streams()
+        chunks = _time_chunks(T, nch)
+        dhh2 = torch.empty(B, T, H, device=dev, dtype=torch.float32); dhh1 = torch.empty_like(dhh2)
+        dgi2 = ops.dgi_buffer(rows, g, Hg, dev); dgi1 = ops.dgi_buffer(rows, g, Hg, dev)
+        dl1 = torch.empty(B, T, H, device=dev, dtype=torch.float32); dh1_in = torch.empty_like(dl1)
+        w_ts = ctx.get("w_ts", {})
+        wt = {}
+        for lname in ("gru_list1", "gru_list2"):
+            wt[lname] = w_ts.get((lname, 0))
+            if wt[lname] is None:
+                wt[lname] = ops.transpose_bf16(P[f"{prefix}{lname}.0.weight_ih_l0"], 3 * Hg, Hg)
+        whh = {ln_: [P[f"{prefix}{ln_}.0.weight_hh_l0"]] for ln_ in ("gru_list1", "gru_list2")}
+        slot2, z2 = STEP_SCRATCH.take(B, g, Hg, slot)
+        slot1, z1 = STEP_SCRATCH.take(B, g, Hg, slot)
+        if not z1 or not z2:
+            slot1, z1, slot2, z2 = 1, False, 2, False
+
+        def ev_on(stream):
+            e = torch.cuda.Event()
+            e.record(stream)
+            return e
+
+        def dX(lname, dgi_, out_, c, acc):
+            ops.gemm_bf16_nt_seg(B * c[1], Hg, wt[lname].shape[0] * 64, dgi_, None, 0, 3 * H, wt[lname], None, 0, 64, out_, 0, H, (c[1], T, c[0]),
+                                 accumulate=acc, b_kstride=Hg * 64)
+
+        start = ev_on(main)
+        sB.wait_event(start); aux.wait_event(start)
+        e_l1, prev_c = None, None
+        dx_checked = False
+
+        def dX1(c):
+            nonlocal dx_checked
+            if not need_dx:
+                return
+            if not dx_checked and dx_accum and dx_ready is not None:
+                dx_ready()                                   # (on the aux stream: the skip leaf that fills dx has run)
+            dx_checked = True
+            dX("gru_list1", dgi1, dx, c, dx_accum)
+
+        for j, c in enumerate(reversed(chunks)):
+            launch = (lambda c=c, j=j: ops.gru_seq_bwd(dh2, whh["gru_list2"], ctx["c2"], ctx["z2"], B, T, g, Hg, prec, an=ctx["a2"], want_dgi=True,
+                                                       out=(dhh2, dgi2), chunk=c, wide=True, slot=slot2, zeroed=z2, seq=j if z2 else None, xcd_rot=0))
+            if j == 0:
+                SIDE.release_around(launch)
+            else:
+                launch()
+            e_r = ev_on(main)
+            with torch.cuda.stream(aux):
+                aux.wait_event(e_r)
+                dX("gru_list2", dgi2, dl1, c, False)
+                ops.ln_bwd(dl1, ctx["h1"], ctx["m1"], ctx["s1"], P[prefix + "ln1.weight"], B * c[1], H, 1, G[prefix + "ln1.weight"],
+                           G[prefix + "ln1.bias"], seg=(c[1], T, c[0]), out=dh1_in)
+                e_q = ev_on(aux)
+                if e_l1 is not None:                         # layer 1's input gradient of the chunk before
+                    aux.wait_event(e_l1)
+                    dX1(prev_c)
+            with torch.cuda.stream(sB):
+                sB.wait_event(e_q)
+                ops.gru_seq_bwd(dh1_in, whh["gru_list1"], ctx["c1"], ctx["z1"], B, T, g, Hg, prec, an=ctx["a1"], want_dgi=True,
+                                out=(dhh1, dgi1), chunk=c, wide=True, slot=slot1, zeroed=z1, seq=j if z1 else None, xcd_rot=4)
+                e_l1, prev_c = ev_on(sB), c
+        # layer 2's weight gradients: the side stream waits for the main stream = the last layer-2 chunk
+        layer_bwd_bf16(dh2, "gru_list2", ctx["l1"], ctx["h2"], ctx["c2"], ctx["a2"], ctx["z2"], False, False, pre=(dhh2, dgi2))
+        with torch.cuda.stream(aux):
+            aux.wait_event(e_l1)
+            dX1(prev_c)
+        main.wait_stream(sB)
+        main.wait_stream(aux)
+        layer_bwd_bf16(dh1_in, "gru_list1", ctx["x"], ctx["h1"], ctx["c1"], ctx["a1"], ctx["z1"], False, True, pre=(dhh1, dgi1))
+        return
     dl1 = layer_bwd(dh2, "gru_list2", ctx["l1"], ctx["h2"], ctx["c2"], ctx["a2"], ctx["z2"], True, False)
     dh1 = ops.ln_bwd(dl1, ctx["h1"], ctx["m1"], ctx["s1"], P[prefix + "ln1.weight"], rows, H, g,
                      G[prefix + "ln1.weight"], G[prefix + "ln1.bias"])

@@ -480,10 +480,13 @@ def ln_fwd(x, gamma, beta, res, rows, H, interleave_g=1, eps=1e-5, save=True, ou
     return y, mean, rstd
 
 
-def ln_bwd(dy, x, mean, rstd, gamma, rows, H, interleave_g, dgamma, dbeta):
-    dx = torch.empty_like(x)
-    check(lib.cruse_ln_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), rows, H, interleave_g, _p(dx), _p(dgamma),
-                           _p(dbeta), _stream()))
+def ln_bwd(dy, x, mean, rstd, gamma, rows, H, interleave_g, dgamma, dbeta, seg=None, out=None):
+    """seg = (seg_len, seg_stride, seg_off): only the rows of one time chunk (rows = B * seg_len) into the full-size `out`
+    (cruse_ln_bwd_seg); dgamma / dbeta are accumulated."""
+    dx = torch.empty_like(x) if out is None else out
+    sl, ss, so = seg if seg is not None else (0, 0, 0)
+    check(lib.cruse_ln_bwd_seg(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), rows, H, interleave_g, _p(dx), _p(dgamma),
+                               _p(dbeta), sl, ss, so, _stream()))
     return dx
 
 
@@ -617,6 +620,15 @@ def gemm_f16_nt(M, N, K, A, a_off, lda, B, b_off, ldb, C, c_off, ldc, bias=None,
         raise RuntimeError("gemm_f16_nt needs f16 operands and an f32 result")
     check(lib.cruse_gemm_f16_nt(M, N, K, A.data_ptr() + 2 * a_off, lda, a_kstride, B.data_ptr() + 2 * b_off, ldb, b_kstride,
                                 C.data_ptr() + 4 * c_off, ldc, _p(bias), _stream()))
+    return C
+
+
+def gemm_f16_nt_seg(M, N, K, A, a_off, lda, B, b_off, ldb, C, c_off, ldc, seg, bias=None, b_kstride=64):
+    """gemm_f16_nt on the rows of ONE TIME CHUNK: seg = (seg_len, seg_stride, seg_off), M = B * seg_len (cruse_gemm_f16_nt_seg)."""
+    if A.dtype != torch.float16 or B.dtype != torch.float16 or C.dtype != torch.float32:
+        raise RuntimeError("gemm_f16_nt_seg needs f16 operands and an f32 result")
+    check(lib.cruse_gemm_f16_nt_seg(M, N, K, A.data_ptr() + 2 * a_off, lda, B.data_ptr() + 2 * b_off, ldb, b_kstride,
+                                    C.data_ptr() + 4 * c_off, ldc, _p(bias), seg[0], seg[1], seg[2], _stream()))
     return C
 
 

@@ -277,6 +277,12 @@ int cruse_ln_fwd_c(const float* x, const float* gamma, const float* beta, const 
 int cruse_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                  const float* gamma, long long rows, int H, int interleave_g,
                  float* dx, float* dgamma, float* dbeta, void* stream);
+/* (ABI 10) cruse_ln_bwd on the rows of ONE TIME CHUNK (row segments as in cruse_ln_fwd: logical row r is physical row
+ * (r / seg_len) * seg_stride + seg_off + r % seg_len, rows = clips * seg_len; interleave_g == 1): the LayerNorm between the two GGRU
+ * recurrences in the backward wavefront (cruse_net.py:41-51).  dgamma / dbeta are ACCUMULATED, as in cruse_ln_bwd. */
+int cruse_ln_bwd_seg(const float* dy, const float* x, const float* mean, const float* rstd,
+                     const float* gamma, long long rows, int H, int interleave_g,
+                     float* dx, float* dgamma, float* dbeta, int seg_len, long long seg_stride, long long seg_off, void* stream);
 
 /* ---- MFMA GEMM (GRU gate projections nn.GRU at cruse_net.py:23-31; their dX / dW) -- */
 
@@ -371,6 +377,11 @@ int cruse_ktile_f16(const float* x, int rows, int cols, long long ld, void* y, v
 int cruse_gemm_f16_nt(int M, int N, int K, const void* A, long long lda, long long a_kstride,
                       const void* B, long long ldb, long long b_kstride,
                       float* C, long long ldc, const float* bias, void* stream);
+/* (ABI 10) ... on the rows of one time chunk (row-major A; row segments as in cruse_gemm_bf16_nt_seg): the layer-2 gate projection
+ * of a chunk, run beside the recurrences of the GGRU wavefront */
+int cruse_gemm_f16_nt_seg(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, long long b_kstride,
+                          float* C, long long ldc, const float* bias, int seg_len, long long seg_stride, long long seg_off,
+                          void* stream);
 /* y = bf16(x) and y_lo = bf16(x - y) (nullable) */
 int cruse_cast_bf16_split(const float* x, void* y, void* y_lo, long long n, void* stream);
 /* Split-bf16 x3 form of cruse_gemm_bf16_nt: A = A_hi + A_lo, B = B_hi + B_lo (bf16 planes, same layout each);

@@ -321,12 +321,12 @@ def test_engine_with_bf16_gate_preactivations():
     assert rel_l2(res[True][2], res[False][2]) < 5e-2
 
 
-@pytest.mark.parametrize("fwd_chunks", [0, 2])
-def test_graph_replay_on_a_new_batch_equals_eager_launches(fwd_chunks):
+@pytest.mark.parametrize("ggru_wave", [0, 4])
+def test_graph_replay_on_a_new_batch_equals_eager_launches(ggru_wave):
     """A captured step replayed on ANOTHER batch computes what the eager launches compute.  lr = 0, so the parameters never move
     and the forward pass must agree bit for bit (gradients: up to the order of the split-K atomics): a kernel node that ran
-    before its producer would see the tensors of the batch the graph was captured on.  (This is how the auxiliary-stream
-    capture problem of the time-chunk pipeline was found, cruse_net._ggru_forward_chunked.)"""
+    before its producer would see the tensors of the batch the graph was captured on -- the GGRU wavefront's three streams
+    (cruse_net._ggru_forward_wave) included."""
     from cruse_amd.config import EngineConfig
     from cruse_amd.data import synth_batch
     from cruse_amd.engine import TrainEngine
@@ -337,7 +337,7 @@ def test_graph_replay_on_a_new_batch_equals_eager_launches(fwd_chunks):
     res = {}
     for graph in (False, True):
         torch.manual_seed(5)
-        eng = TrainEngine(unet_2(rnn_groups=1, precision="bf16").cuda(), use_graph=graph, lr=0.0, config=EngineConfig(fwd_chunks=fwd_chunks))
+        eng = TrainEngine(unet_2(rnn_groups=1, precision="bf16").cuda(), use_graph=graph, lr=0.0, config=EngineConfig(ggru_wave=ggru_wave))
         eng.step(*A); eng.step(*A)
         ls = eng.step(*Bb)
         torch.cuda.synchronize()
@@ -349,11 +349,12 @@ def test_graph_replay_on_a_new_batch_equals_eager_launches(fwd_chunks):
 
 
 @pytest.mark.parametrize("graph", [False, True])
-def test_forward_time_chunk_pipeline_is_the_same_computation(graph):
-    """EngineConfig.fwd_chunks: the GGRU forward as a time-chunk pipeline (recurrence chunks on the main stream, the projections /
-    LayerNorm 1 of other chunks on an auxiliary stream; cruse_gru_seq_fwd_ex, cruse_gemm_bf16_nt_seg, cruse_ln_fwd row segments)
-    computes exactly what the unchunked schedule computes: same mask bit for bit, same loss, same gradients up to the
-    summation order of the split-K weight-gradient GEMMs; eager and captured into the HIP graph."""
+def test_ggru_wavefront_is_the_same_computation(graph):
+    """EngineConfig.ggru_wave: the two GGRU recurrences as a time-chunk wavefront on wide chains (layer 2 one chunk behind layer 1, the
+    LayerNorm + projection of a chunk on a third stream; backward mirrored; cruse_gru_seq_*_ex(chain_clips = 16, epoch0, seq),
+    cruse_gemm_*_nt_seg, cruse_ln_fwd / cruse_ln_bwd_seg row segments) computes what the serial schedule computes: the forward pass --
+    mask and loss -- bit for bit (the wide forward kernel sums in the order of the chains of 8), the gradients up to the f32 summation
+    order of the wide backward recurrence and of the split-K weight-gradient GEMMs; eager and captured into the HIP graph."""
     from cruse_amd.config import EngineConfig
     from cruse_amd.data import synth_batch
     from cruse_amd.engine import TrainEngine
@@ -361,9 +362,9 @@ def test_forward_time_chunk_pipeline_is_the_same_computation(graph):
     from cruse_amd import ops
     noisy, clean = synth_batch(16, 32000, "cuda", 4)            # T = 201 frames
     res = {}
-    for nch in (0, 2, 3):
+    for nch in (0, 2, 3, 4):
         torch.manual_seed(5)
-        eng = TrainEngine(unet_2(rnn_groups=1, precision="bf16").cuda(), use_graph=graph, config=EngineConfig(fwd_chunks=nch, gi_f16=0))     # (the chunk pipeline projects in the split-bf16 form)
+        eng = TrainEngine(unet_2(rnn_groups=1, precision="bf16").cuda(), use_graph=graph, config=EngineConfig(ggru_wave=nch))
         ls = eng.step(noisy, clean)                             # (graph mode: capture + first replay)
         torch.cuda.synchronize()
         first = (eng.loss_value(ls), eng._last_mask.clone(), eng.flat.grads.clone())
@@ -371,14 +372,14 @@ def test_forward_time_chunk_pipeline_is_the_same_computation(graph):
         torch.cuda.synchronize()
         res[nch] = first + (eng.loss_value(ls), eng.flat.params.clone())
         assert eng.skipped_steps() == 0 and ops.gru_status() == 0
-    for nch in (2, 3):
+    for nch in (2, 3, 4):
         # the first step starts from identical parameters: the forward pass must agree bit for bit
         assert torch.equal(res[nch][1], res[0][1]), f"mask differs with {nch} chunks"
         assert res[nch][0] == res[0][0]
-        # (two RUNS are compared: the order of the BatchNorm-sum atomics moves dy by 1e-7, a few of its bf16 roundings flip and the
-        #  backward recurrences carry that on; six repetitions on one box gave 3e-5 .. 5.3e-5)
-        assert rel_l2(res[nch][2], res[0][2]) < 1e-4
-        assert res[nch][3] == pytest.approx(res[0][3], rel=1e-5) and rel_l2(res[nch][4], res[0][4]) < 2e-3      # (Adam moves noise-level entries by +-lr)
+        assert rel_l2(res[nch][2], res[0][2]) < 3e-3
+        assert res[nch][3] == pytest.approx(res[0][3], rel=1e-4) and rel_l2(res[nch][4], res[0][4]) < 5e-3      # (Adam moves noise-level entries by +-lr)
+    # the chunk count does not change the wavefront's arithmetic at all: same recurrence kernels, same epochs
+    assert rel_l2(res[2][2], res[4][2]) < 1e-4
 
 
 @pytest.mark.parametrize("grp", [1, 4])
