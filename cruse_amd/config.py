@@ -71,6 +71,8 @@ class EngineConfig:
                                     # chain, gru_w16.hip) the recurrences of BOTH layers are co-resident -- layer 2 runs one chunk behind layer 1
                                     # (forward) / layer 1 one chunk behind layer 2 (backward), the LayerNorm + gate projection (backward: input
                                     # gradient + LayerNorm backward) of a chunk on a third stream in between (cruse_net._ggru_forward_wave)
+    ggru_wave_fwd: bool = True      # ... its forward / backward halves (A/B switches: False = that pass runs its two recurrences one after the other)
+    ggru_wave_bwd: bool = True
     lib_options: Dict[str, int] = field(default_factory=dict)       # cruse_set_option(name, value) while this config is active
 
     _ENV = {"overlap": ("CRUSE_OVERLAP", lambda v: v == "1"), "defer_mask": ("CRUSE_DEFER", int), "inline_mask": ("CRUSE_INLINE", int),
@@ -78,7 +80,7 @@ class EngineConfig:
             "fuse_dgi": ("CRUSE_FUSE_DGI", lambda v: v == "1"),
             "fuse_bn_bwd_stats": ("CRUSE_FUSE_BN_BWD", lambda v: v != "0"), "fuse_cast": ("CRUSE_FUSE_CAST", lambda v: v == "1"),
             "gi_x3": ("CRUSE_GI_X3", int), "gi_f16": ("CRUSE_GI_F16", int), "gi_bf16": ("CRUSE_GI_BF16", lambda v: v == "1"), "dw_xcdk": ("CRUSE_DW_XCDK", int), "conv_bwd_x3": ("CRUSE_CONV_BWD_X3", lambda v: v == "1"),
-            "dw_tn": ("CRUSE_DW_TN", lambda v: v == "1"), "dw_slabs": ("CRUSE_DW_SLABS", lambda v: v != "0"), "dw_cat": ("CRUSE_DW_CAT", lambda v: v != "0"), "dx_atr": ("CRUSE_DX_ATR", lambda v: v == "1"), "gemm_groups": ("CRUSE_GEMM_GROUPS", lambda v: v != "0"), "ggru_wave": ("CRUSE_GGRU_WAVE", int),
+            "dw_tn": ("CRUSE_DW_TN", lambda v: v == "1"), "dw_slabs": ("CRUSE_DW_SLABS", lambda v: v != "0"), "dw_cat": ("CRUSE_DW_CAT", lambda v: v != "0"), "dx_atr": ("CRUSE_DX_ATR", lambda v: v == "1"), "gemm_groups": ("CRUSE_GEMM_GROUPS", lambda v: v != "0"), "ggru_wave": ("CRUSE_GGRU_WAVE", int), "ggru_wave_bwd": ("CRUSE_GGRU_WAVE_BWD", lambda v: v != "0"), "ggru_wave_fwd": ("CRUSE_GGRU_WAVE_FWD", lambda v: v != "0"),
             "fuse_bn_fwd": ("CRUSE_FUSE_BN_FWD", lambda v: v != "0"), "fuse_bn_bwd_apply": ("CRUSE_FUSE_BN_BWD_APPLY", lambda v: v != "0"), "bf16_dy": ("CRUSE_BF16_DY", lambda v: v != "0"), "bf16_de": ("CRUSE_BF16_DE", lambda v: v != "0")}
     _LIB_ENV = {"CRUSE_GRU_BWD_RS": "gru_bwd_rs", "CRUSE_GRU_FWD_LEAN": "gru_fwd_lean", "CRUSE_GRU_WLO": "gru_wlo",
                 "CRUSE_GRU_DBG": "gru_dbg", "CRUSE_GRU_PRIO": "gru_prio", "CRUSE_GRU_BG": "gru_bg", "CRUSE_CM_GRID": "cm_grid", "CRUSE_CM_KINT": "cm_kint", "CRUSE_CM_SWAP": "cm_swap", "CRUSE_CM_NW": "cm_nw",

@@ -397,6 +397,7 @@ class TrainEngine:
             cur["cm"].__exit__(None, None, None)
             raise
         end(N_BUCKETS - 1)
+        _net.release_capture_events()         # (kept alive until every segment's capture has ended: see cruse_net.record_event)
         self._graphs = graphs
         self._shape = tuple(noisy.shape)
         # one capture per input shape (a last, partial batch of an epoch would otherwise force two re-captures per epoch)

@@ -24,6 +24,33 @@ from .. import config, ops
 DEFAULT_PREC = "f32"
 
 
+# Events recorded while a HIP graph is being captured are kept alive until the capture has ended (TrainEngine clears the list):
+# hipStreamEndCapture (ROCm 7.2) walks the events that took part in the capture, and an event that torch had already destroyed --
+# every temporary of Stream.wait_stream(), every Event dropped at the end of a loop iteration -- is then a dangling pointer there.
+# Whether that bites depends on what the allocator did with the freed block: the step captured for four rounds, the backward
+# wavefront's extra events made hipStreamEndCapture segfault deterministically ("Add EmptyNode", then a crash).
+_KEEP_EVENTS: list = []
+
+
+def record_event(stream) -> "torch.cuda.Event":
+    e = torch.cuda.Event()
+    e.record(stream)
+    if torch.cuda.is_current_stream_capturing():
+        if len(_KEEP_EVENTS) > 200000:
+            del _KEEP_EVENTS[:100000]
+        _KEEP_EVENTS.append(e)
+    return e
+
+
+def wait_stream(waiter, stream) -> None:
+    """waiter.wait_stream(stream) with the temporary event kept alive during graph capture"""
+    waiter.wait_event(record_event(stream))
+
+
+def release_capture_events() -> None:
+    _KEEP_EVENTS.clear()
+
+
 class _SideStream:
     """Runs LEAF kernels (weight gradients, bias sums, skip convs) on a side HIP stream so they fill the ~96 CUs the persistent
     GRU kernels leave idle and overlap the HBM-bound main path elsewhere.  Leaves only read tensors produced on the main stream
@@ -67,8 +94,7 @@ class _SideStream:
         if not (self.enabled and self.deferred):
             return launch()
         main = torch.cuda.current_stream()
-        ev = torch.cuda.Event()
-        ev.record(main)
+        ev = record_event(main)
         out = launch()
         for fn, lane, dep in self.deferred:
             side = self._next(lane)
@@ -88,7 +114,7 @@ class _SideStream:
             return
         main = torch.cuda.current_stream()
         side = self._next(lane)
-        side.wait_stream(main)
+        wait_stream(side, main)
         self.keep.extend(tensors)
         self.active = True
         with torch.cuda.stream(side):
@@ -100,9 +126,7 @@ class _SideStream:
             return None
         evs = []
         for s in self.used:
-            ev = torch.cuda.Event()
-            ev.record(s)
-            evs.append(ev)
+            evs.append(record_event(s))
         return evs
 
     def wait(self, evs):
@@ -125,7 +149,7 @@ class _SideStream:
             self.flush()
         if self.enabled and self.active:
             for s in self.used:
-                torch.cuda.current_stream().wait_stream(s)
+                wait_stream(torch.cuda.current_stream(), s)
             self.used = []
             if not self.deferred:
                 self.keep.clear()
@@ -338,11 +362,7 @@ def _ggru_forward_wave(x, x_bf16, P, prefix, g, Hg, prec, save, nch, ctx, projec
     if not z1 or not z2:                                           # outside a training step: two private scratches, cleared per launch
         slot1, z1, slot2, z2 = 1, False, 2, False
 
-    def ev_on(stream):
-        e = torch.cuda.Event()
-        e.record(stream)
-        return e
-
+    ev_on = record_event
     start = ev_on(main)
     sB.wait_event(start); aux.wait_event(start)
     for j, c in enumerate(chunks):
@@ -363,9 +383,8 @@ def _ggru_forward_wave(x, x_bf16, P, prefix, g, Hg, prec, save, nch, ctx, projec
             sB.wait_event(e_q)
             ops.gru_seq_fwd(gi2, w2, b2, B, T, g, Hg, prec, save=save, out=out2, chunk=c, wide=True, slot=slot2, zeroed=z2,
                             seq=j if z2 else None, xcd_rot=4)
-    main.wait_stream(aux)
-    main.wait_stream(sB)
-    ctx["wave"] = nch
+    wait_stream(main, aux)
+    wait_stream(main, sB)
     ctx["_wave_keep"] = (gi1, gi2)
     return out1 + (l1, l1_c, m1, s1) + out2
 
@@ -513,7 +532,8 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
         return prep
 
     nch = _wave_chunks(prec, Hg, g, B, T, slot, x_bf16, save)
-    if nch > 1:
+    ctx["wave"] = nch
+    if nch > 1 and config.get().ggru_wave_fwd:
         if hooks:
             hooks.pop()()
         h1, c1, a1, z1, l1, l1_bf, m1, s1, h2, c2, a2, z2 = _ggru_forward_wave(x, x_bf16, P, prefix, g, Hg, prec, save, nch, ctx, wave_project)
@@ -782,11 +802,11 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
     dh2 = ops.ln_bwd(dout, ctx["h2"], ctx["m2"], ctx["s2"], P[prefix + "ln2.weight"], rows, H, 1,
                      G[prefix + "ln2.weight"], G[prefix + "ln2.bias"])
     nch = int(ctx.get("wave", 0))
-    if nch > 1 and _bf16_gemm_path(prec, Hg) and g == 1 and not ctx.get("tn") and SIDE.enabled and int(config.get().ggru_wave or 0) >= 2:
+    if nch > 1 and _bf16_gemm_path(prec, Hg) and g == 1 and not ctx.get("tn") and SIDE.enabled and int(config.get().ggru_wave or 0) >= 2 and config.get().ggru_wave_bwd:
         # ---- the backward WAVEFRONT (see _ggru_forward_wave): in reverse time, layer 2's recurrence one chunk ahead of layer 1's ----
         #   main:  rec2'(c3) | rec2'(c2) | rec2'(c1) | rec2'(c0) |                  (+ layer 2's weight-gradient leaf on the side stream)
-        #   aux :            dX2 + ln1'(c3) | dX2 + ln1'(c2), dX1(c3) | ...                       | dX1(c0)
-        #   sB  :                           rec1'(c3)            | rec1'(c2) | ...
+        #   aux :            dX2 + ln1'(c3) | dX2 + ln1'(c2) | ...
+        #   sB  :                           rec1'(c3), dX1(c3) | rec1'(c2), dX1(c2) | ...
         # Both recurrences write their gate-gradient rows themselves (DGI); the time-major copies the weight gradients read are
         # made by the leaves, off the critical path.
         if hooks:
@@ -810,26 +830,22 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
         if not z1 or not z2:
             slot1, z1, slot2, z2 = 1, False, 2, False
 
-        def ev_on(stream):
-            e = torch.cuda.Event()
-            e.record(stream)
-            return e
+        ev_on = record_event
 
         def dX(lname, dgi_, out_, c, acc):
             ops.gemm_bf16_nt_seg(B * c[1], Hg, wt[lname].shape[0] * 64, dgi_, None, 0, 3 * H, wt[lname], None, 0, 64, out_, 0, H, (c[1], T, c[0]),
                                  accumulate=acc, b_kstride=Hg * 64)
 
+        dx_checked = False
         start = ev_on(main)
         sB.wait_event(start); aux.wait_event(start)
-        e_l1, prev_c = None, None
-        dx_checked = False
 
         def dX1(c):
             nonlocal dx_checked
             if not need_dx:
                 return
             if not dx_checked and dx_accum and dx_ready is not None:
-                dx_ready()                                   # (on the aux stream: the skip leaf that fills dx has run)
+                dx_ready()                                   # (on the stream that adds into dx: the skip leaf that fills it has run)
             dx_checked = True
             dX("gru_list1", dgi1, dx, c, dx_accum)
 
@@ -847,21 +863,19 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
                 ops.ln_bwd(dl1, ctx["h1"], ctx["m1"], ctx["s1"], P[prefix + "ln1.weight"], B * c[1], H, 1, G[prefix + "ln1.weight"],
                            G[prefix + "ln1.bias"], seg=(c[1], T, c[0]), out=dh1_in)
                 e_q = ev_on(aux)
-                if e_l1 is not None:                         # layer 1's input gradient of the chunk before
-                    aux.wait_event(e_l1)
-                    dX1(prev_c)
             with torch.cuda.stream(sB):
                 sB.wait_event(e_q)
                 ops.gru_seq_bwd(dh1_in, whh["gru_list1"], ctx["c1"], ctx["z1"], B, T, g, Hg, prec, an=ctx["a1"], want_dgi=True,
                                 out=(dhh1, dgi1), chunk=c, wide=True, slot=slot1, zeroed=z1, seq=j if z1 else None, xcd_rot=4)
-                e_l1, prev_c = ev_on(sB), c
+                # layer 1's input gradient of the chunk, behind its recurrence on the SAME stream: the next chunk cannot start before
+                # layer 2's next chunk + its dX + LayerNorm backward have run anyway (~ this GEMM's time).  (Not on the aux stream: sB
+                # already waits for aux's events, and with aux waiting for sB's as well hipStreamEndCapture (ROCm 7.2) recursed between
+                # the two until the stack overflowed.)
+                dX1(c)
         # layer 2's weight gradients: the side stream waits for the main stream = the last layer-2 chunk
         layer_bwd_bf16(dh2, "gru_list2", ctx["l1"], ctx["h2"], ctx["c2"], ctx["a2"], ctx["z2"], False, False, pre=(dhh2, dgi2))
-        with torch.cuda.stream(aux):
-            aux.wait_event(e_l1)
-            dX1(prev_c)
-        main.wait_stream(sB)
-        main.wait_stream(aux)
+        wait_stream(main, aux)
+        wait_stream(main, sB)
         layer_bwd_bf16(dh1_in, "gru_list1", ctx["x"], ctx["h1"], ctx["c1"], ctx["a1"], ctx["z1"], False, True, pre=(dhh1, dgi1))
         return
     dl1 = layer_bwd(dh2, "gru_list2", ctx["l1"], ctx["h2"], ctx["c2"], ctx["a2"], ctx["z2"], True, False)
