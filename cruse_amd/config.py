@@ -67,10 +67,15 @@ class EngineConfig:
                                     # levels whose producer AND consumers are MFMA kernels: 2 <= k < L) are stored as bf16 as well:
                                     # f32 accumulation, one rounding per pass of a backward-only tensor (needs bf16_dy and
                                     # fuse_bn_bwd_stats: the conv that stores the tensor also delivers its BatchNorm sums)
-    ggru_wave: int = 4              # time chunks of the GGRU WAVEFRONT (g = 1, B <= 64, Hg % 128 == 0; 0 / 1 = off): on wide chains (16 clips per
+    ggru_wave: int = 0              # time chunks of the GGRU WAVEFRONT (g = 1, B <= 64, Hg % 128 == 0; 0 / 1 = off): on wide chains (16 clips per
                                     # chain, gru_w16.hip) the recurrences of BOTH layers are co-resident -- layer 2 runs one chunk behind layer 1
                                     # (forward) / layer 1 one chunk behind layer 2 (backward), the LayerNorm + gate projection (backward: input
-                                    # gradient + LayerNorm backward) of a chunk on a third stream in between (cruse_net._ggru_forward_wave)
+                                    # gradient + LayerNorm backward) of a chunk on a third stream in between (cruse_net._ggru_forward_wave).
+                                    # OFF: measured SLOWER on the bench step (r5: 5.65 ms with 4 chunks, 6.0 / 6.6 with 6 / 8, forward half
+                                    # alone 5.06, against 4.88 serial) -- alone the pair of wide recurrences runs at 1.59 us per step (636 us for
+                                    # both layers against 2 x 469), but beside the step's leaves and the chunk GEMMs every wide step stretches
+                                    # to 1.7-2.4 us forward / 2.5-3.2 us backward and a chunk launch costs ~50-70 us of CU acquisition instead
+                                    # of 18 (profiles/r05_wavefront_chain.txt): the window is bound by the memory system, not by the dependency
     ggru_wave_fwd: bool = True      # ... its forward / backward halves (A/B switches: False = that pass runs its two recurrences one after the other)
     ggru_wave_bwd: bool = True
     lib_options: Dict[str, int] = field(default_factory=dict)       # cruse_set_option(name, value) while this config is active
