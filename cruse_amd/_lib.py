@@ -79,8 +79,10 @@ SIGNATURES = {
     "cruse_gru_seq_bwd": ("pppppiiiiipp", "i"),
     "cruse_gru_seq_fwd_on": ("pppppppiiiiippip", "i"),
     "cruse_gru_seq_bwd_on": ("pppppppiiiiippip", "i"),
-    "cruse_gru_seq_fwd_ex": ("ppppppppqiiiiiiiipipiiip", "i"),
-    "cruse_gru_seq_bwd_ex": ("pppppppiiiiiiiiipipiiip", "i"),
+    "cruse_gru_seq_fwd_ex": ("ppppppppqiiiiiiiipipiiiip", "i"),
+    "cruse_gru_seq_bwd_ex": ("pppppppiiiiiiiiipipiiiip", "i"),
+    "cruse_gru_ws_signal_offset": ("iii", "z"),
+    "cruse_stream_wait_counter": ("pipp", "i"),
     "cruse_gru_gate_grads": ("pppppqiiip", "i"),
     "cruse_gru_gate_grads_bf16": ("pppppqppqiip", "i"),
     "cruse_gru_gate_bias_sums": ("pqiippp", "i"),

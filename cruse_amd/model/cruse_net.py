@@ -296,8 +296,28 @@ def _wave_streams():
     """the two extra streams of the GGRU wavefront: [0] the second recurrence, [1] the in-between kernels of a chunk"""
     dev = torch.cuda.current_device()
     if dev not in _AUX:
-        _AUX[dev] = (torch.cuda.Stream(), torch.cuda.Stream())
+        import os
+        pr = int(os.environ.get("CRUSE_WAVE_PRIO", "0"))
+        _AUX[dev] = (torch.cuda.Stream(priority=-1 if pr & 1 else 0), torch.cuda.Stream(priority=-1 if pr & 2 else 0))
     return _AUX[dev]
+
+
+_FORK_DUMMY = {}
+
+
+def fork_stream(stream, main) -> None:
+    """`stream` joins the work of `main` (event fork).  Under HIP-graph capture the stream's FIRST captured node is a one-word dummy
+    fill: on ROCm 7.2 the first kernel node of a freshly forked stream has been seen to replay BEFORE the node it depends on (r3: the
+    chunk pipeline's projection read the previous replay's rows; r5: the chunk-signal wait ran before the step's scratch clear and
+    let LayerNorm 1 through early -- test_graph_replay_on_a_new_batch_equals_eager_launches); with any other node first the replay
+    equals the eager launches."""
+    stream.wait_event(record_event(main))
+    if torch.cuda.is_current_stream_capturing():
+        dev = torch.cuda.current_device()
+        if dev not in _FORK_DUMMY:
+            _FORK_DUMMY[dev] = torch.zeros(64, device="cuda", dtype=torch.float32)
+        with torch.cuda.stream(stream):
+            ops.zero_(_FORK_DUMMY[dev])
 
 
 def _time_chunks(T: int, n: int):
@@ -322,6 +342,20 @@ def _wave_chunks(prec, Hg: int, g: int, B: int, T: int, slot: int, x_bf16, save:
     while n > 1 and T < 32 * n:
         n -= 1
     return n
+
+
+def _overlap_chunks(prec, Hg: int, g: int, B: int, T: int, slot: int, fwd: bool) -> int:
+    """Time chunks of the CHUNK-SIGNAL overlap (EngineConfig.ggru_overlap; 0 / 1 = off): the recurrence runs as ONE launch and counts
+    a chunk's workgroups in as their rows reach HBM (cruse_gru_seq_*_ex(chunk_len)); an auxiliary stream waits for the count
+    (cruse_stream_wait_counter) and runs the kernels BETWEEN the two recurrences chunk by chunk beside the running one -- forward
+    LayerNorm 1 + the layer-2 gate projection, backward the input-gradient GEMM + LayerNorm-1 backward (and layer 1's input gradient
+    beside its own recurrence) -- so only the last chunk's share of them is left on the main stream's chain.  Inside a training step
+    only (the step's one scratch clear also zeroes the counters), g = 1."""
+    n = int(config.get().ggru_overlap or 0)
+    if n < 2 or slot != 0 or g != 1 or not SIDE.enabled or STEP_SCRATCH.key != (B, g, Hg) or T < 16 * n:
+        return 0
+    cl = (T + n - 1) // n
+    return n if ops.gru_chunk_signals_ok(B, T, g, Hg, prec, fwd, cl) else 0
 
 
 def _ggru_forward_wave(x, x_bf16, P, prefix, g, Hg, prec, save, nch, ctx, project):
@@ -463,8 +497,9 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
         if hooks:
             hooks.pop()()                    # the pre-stage of this slice is issued: the next slice may start its own
         slot_, zeroed = STEP_SCRATCH.take(B, g, Hg, slot)
+        wide = int(config.get().gru_wide or 0) & 1 and not gi_bf
         return SIDE.release_around(lambda: ops.gru_seq_fwd(gi, w_hh, b_hh, B, T, g, Hg, prec, save=save, slot=slot_,
-                                                           xcd_rot=xcd_rot, zeroed=zeroed))
+                                                           xcd_rot=xcd_rot, zeroed=zeroed, wide=bool(wide)))
 
     # The K-tiled time-major bf16 copies of x, h1, l1, h2 -- the K operands of the four weight-gradient GEMMs -- depend on
     # the forward pass only.  From the first backward recurrence on, the side streams' queue is what the optimizer step
@@ -538,6 +573,43 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
             hooks.pop()()
         h1, c1, a1, z1, l1, l1_bf, m1, s1, h2, c2, a2, z2 = _ggru_forward_wave(x, x_bf16, P, prefix, g, Hg, prec, save, nch, ctx, wave_project)
         queue_layer1_leaves(h1, l1, l1_bf, late=late_leaves)
+    elif (save and x_bf16 is not None and _gi_takes_bf16_copy(prec, Hg) and not gi_bf
+          and _overlap_chunks(prec, Hg, g, B, T, slot, True) > 1):
+        # ---- chunk-signal overlap: LayerNorm 1 + the layer-2 projection of a chunk run on the aux stream beside the layer-1 recurrence ----
+        nov = _overlap_chunks(prec, Hg, g, B, T, slot, True)
+        CL = (T + nov - 1) // nov
+        dev = x.device
+        gi1 = torch.empty(B, T, 3 * H, device=dev, dtype=torch.float32)
+        gi2 = torch.empty_like(gi1)
+        f16 = _gi_f16(prec, Hg, 1)
+        l1 = torch.empty(B, T, H, device=dev, dtype=torch.float32)
+        l1_bf = torch.empty(rows * H, device=dev, dtype=torch.float16 if f16 else torch.bfloat16)
+        m1 = torch.empty(rows, device=dev, dtype=torch.float32); s1 = torch.empty(rows, device=dev, dtype=torch.float32)
+        wave_project(x, x_bf16, "gru_list1", gi1, None)
+        prep2 = wave_project(None, None, "gru_list2", None, None)
+        if hooks:
+            hooks.pop()()
+        w1 = [P[f"{prefix}gru_list1.0.weight_hh_l0"]]; b1 = [P[f"{prefix}gru_list1.0.bias_hh_l0"]]
+        w2 = [P[f"{prefix}gru_list2.0.weight_hh_l0"]]; b2 = [P[f"{prefix}gru_list2.0.bias_hh_l0"]]
+        main = torch.cuda.current_stream()
+        aux = _wave_streams()[1]
+        slot1, zr1 = STEP_SCRATCH.take(B, g, Hg, slot)
+        fork_stream(aux, main)
+        h1, c1, a1, z1 = SIDE.release_around(lambda: ops.gru_seq_fwd(gi1, w1, b1, B, T, g, Hg, prec, save=save, slot=slot1, xcd_rot=xcd_rot,
+                                                                     zeroed=zr1, chunk_len=CL))
+        with torch.cuda.stream(aux):
+            for c in range((T + CL - 1) // CL):
+                seg = (min(CL, T - c * CL), T, c * CL)
+                ops.gru_wait_chunk(B, g, Hg, dev, slot1, c)
+                ops.ln_fwd(h1, P[prefix + "ln1.weight"], P[prefix + "ln1.bias"], None, B * seg[0], H, 1, save=True, out=l1, out_bf16=l1_bf,
+                           seg=seg, stats=(m1, s1))
+                wave_project(l1, l1_bf, "gru_list2", gi2, seg, prep2)
+        wait_stream(main, aux)
+        queue_layer1_leaves(h1, l1, l1_bf)
+        slot2, zr2 = STEP_SCRATCH.take(B, g, Hg, slot)
+        h2, c2, a2, z2 = SIDE.release_around(lambda: ops.gru_seq_fwd(gi2, w2, b2, B, T, g, Hg, prec, save=save, slot=slot2, xcd_rot=xcd_rot,
+                                                                     zeroed=zr2))
+        ctx["_ov_keep"] = (gi1, gi2)
     else:
         h1, c1, a1, z1 = layer(x, "gru_list1", x_bf16)
         f16 = _gi_f16(prec, Hg, 1)
@@ -603,9 +675,10 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
         if hooks:
             hooks.pop()()
         slot_, zeroed = STEP_SCRATCH.take(B, g, Hg, slot)
+        wide = int(config.get().gru_wide or 0) & 2
         return SIDE.release_around(lambda: ops.gru_seq_bwd(dout_h, w_hh, coef, z, B, T, g, Hg, prec, slot=slot_,
                                                            xcd_rot=xcd_rot, an=an, want_dgi=an is not None, dg_slabs=dg_slabs,
-                                                           zeroed=zeroed))
+                                                           zeroed=zeroed, wide=bool(wide)))
 
     def layer_bwd_tn(dout_h, lname, inp, h, coef, an, z, need_dinp, last):
         """CRUSE_PREC_BF16 with row-major operands only (_dw_tn): the recurrence writes dh and the 4-slab gate-gradient rows;
@@ -876,6 +949,65 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
         layer_bwd_bf16(dh2, "gru_list2", ctx["l1"], ctx["h2"], ctx["c2"], ctx["a2"], ctx["z2"], False, False, pre=(dhh2, dgi2))
         wait_stream(main, aux)
         wait_stream(main, sB)
+        layer_bwd_bf16(dh1_in, "gru_list1", ctx["x"], ctx["h1"], ctx["c1"], ctx["a1"], ctx["z1"], False, True, pre=(dhh1, dgi1))
+        return
+    nov = _overlap_chunks(prec, Hg, g, B, T, slot, False) if (_bf16_gemm_path(prec, Hg) and not ctx.get("tn")) else 0
+    if nov > 1:
+        # ---- chunk-signal overlap (see _overlap_chunks): both recurrences write their gate-gradient rows themselves and count their chunks in;
+        # the aux stream runs dX2 + LayerNorm-1 backward of a chunk beside the layer-2 recurrence, layer 1's dX beside the layer-1 recurrence
+        if hooks:
+            hooks.pop()()
+        CL = (T + nov - 1) // nov
+        dev = dout.device
+        main = torch.cuda.current_stream()
+        aux = _wave_streams()[1]
+        dhh2 = torch.empty(B, T, H, device=dev, dtype=torch.float32); dhh1 = torch.empty_like(dhh2)
+        dgi2 = ops.dgi_buffer(rows, g, Hg, dev); dgi1 = ops.dgi_buffer(rows, g, Hg, dev)
+        dl1 = torch.empty(B, T, H, device=dev, dtype=torch.float32); dh1_in = torch.empty_like(dl1)
+        w_ts = ctx.get("w_ts", {})
+        wt = {}
+        for lname in ("gru_list1", "gru_list2"):
+            wt[lname] = w_ts.get((lname, 0))
+            if wt[lname] is None:
+                wt[lname] = ops.transpose_bf16(P[f"{prefix}{lname}.0.weight_ih_l0"], 3 * Hg, Hg)
+        whh = {ln_: [P[f"{prefix}{ln_}.0.weight_hh_l0"]] for ln_ in ("gru_list1", "gru_list2")}
+
+        def segs():
+            """(chunk index, row segment) in the order the backward recurrence finishes them: iterations [j CL, (j + 1) CL) from the last frame"""
+            for j in range((T + CL - 1) // CL):
+                hi = T - j * CL
+                lo = max(0, hi - CL)
+                yield j, (hi - lo, T, lo)
+
+        def dX(lname, dgi_, out_, seg, acc):
+            ops.gemm_bf16_nt_seg(B * seg[0], Hg, wt[lname].shape[0] * 64, dgi_, None, 0, 3 * H, wt[lname], None, 0, 64, out_, 0, H, seg,
+                                 accumulate=acc, b_kstride=Hg * 64)
+
+        slot2, zr2 = STEP_SCRATCH.take(B, g, Hg, slot)
+        fork_stream(aux, main)
+        SIDE.release_around(lambda: ops.gru_seq_bwd(dh2, whh["gru_list2"], ctx["c2"], ctx["z2"], B, T, g, Hg, prec, an=ctx["a2"], want_dgi=True,
+                                                    out=(dhh2, dgi2), slot=slot2, xcd_rot=xcd_rot, zeroed=zr2, chunk_len=CL))
+        with torch.cuda.stream(aux):
+            for j, seg in segs():
+                ops.gru_wait_chunk(B, g, Hg, dev, slot2, j)
+                dX("gru_list2", dgi2, dl1, seg, False)
+                ops.ln_bwd(dl1, ctx["h1"], ctx["m1"], ctx["s1"], P[prefix + "ln1.weight"], B * seg[0], H, 1, G[prefix + "ln1.weight"],
+                           G[prefix + "ln1.bias"], seg=seg, out=dh1_in)
+        # layer 2's weight gradients: the side stream waits for the main stream = the layer-2 recurrence
+        layer_bwd_bf16(dh2, "gru_list2", ctx["l1"], ctx["h2"], ctx["c2"], ctx["a2"], ctx["z2"], False, False, pre=(dhh2, dgi2))
+        wait_stream(main, aux)
+        slot1, zr1 = STEP_SCRATCH.take(B, g, Hg, slot)
+        fork_stream(aux, main)
+        SIDE.release_around(lambda: ops.gru_seq_bwd(dh1_in, whh["gru_list1"], ctx["c1"], ctx["z1"], B, T, g, Hg, prec, an=ctx["a1"], want_dgi=True,
+                                                    out=(dhh1, dgi1), slot=slot1, xcd_rot=xcd_rot, zeroed=zr1, chunk_len=CL if need_dx else 0))
+        if need_dx:
+            with torch.cuda.stream(aux):
+                if dx_accum and dx_ready is not None:
+                    dx_ready()                               # (on the stream that adds into dx: the skip leaf that fills it has run)
+                for j, seg in segs():
+                    ops.gru_wait_chunk(B, g, Hg, dev, slot1, j)
+                    dX("gru_list1", dgi1, dx, seg, dx_accum)
+        wait_stream(main, aux)
         layer_bwd_bf16(dh1_in, "gru_list1", ctx["x"], ctx["h1"], ctx["c1"], ctx["a1"], ctx["z1"], False, True, pre=(dhh1, dgi1))
         return
     dl1 = layer_bwd(dh2, "gru_list2", ctx["l1"], ctx["h2"], ctx["c2"], ctx["a2"], ctx["z2"], True, False)

@@ -712,12 +712,32 @@ def gru_step_ws_clear(B, G, Hg, dev) -> None:
     zero_(_ws(("gru_step", per), per * STEP_SLOTS, torch.device(dev)))
 
 
+def gru_chunk_signals_ok(B, T, G, Hg, prec, fwd: bool, chunk_len: int) -> bool:
+    """chunk signals (gru_seq_*(chunk_len=)) exist for the default kernels of the bf16 mode on chains of 8, one launch per recurrence"""
+    ncu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    if prec_code(prec) != PREC_BF16 or chunk_len <= 0 or (T + chunk_len - 1) // chunk_len > 64:
+        return False
+    if ((B + 7) // 8 + 7) // 8 * 8 * G * (Hg // 32) > ncu or get_option("gru_tf") == 0:
+        return False
+    if fwd:
+        return Hg == 640 and get_option("gru_fwd_lean") in (None, 1) and get_option("gru_wlo") in (None, 0) and get_option("gru_tf") in (None, 1)
+    return Hg in (160, 320, 640) and get_option("gru_bwd_ag") in (None, 2) and get_option("gru_bwd_rs") in (None, 1)
+
+
+def gru_wait_chunk(B, G, Hg, dev, slot: int, chunk: int) -> None:
+    """On the CURRENT stream: wait until every workgroup of the recurrence that runs on `slot`'s scratch (launched with chunk_len > 0)
+    has written its rows of time chunk `chunk` (cruse_stream_wait_counter); the kernels issued behind this call on the stream run after it."""
+    panels, status = _gru_ws(B, G, Hg, dev, slot)
+    target = ((B + 7) // 8) * G * (Hg // 32)
+    check(lib.cruse_stream_wait_counter(panels + lib.cruse_gru_ws_signal_offset(B, G, Hg) + 4 * chunk, target, status, _stream()))
+
+
 def _off(t: torch.Tensor, elems: int) -> int:
     return t.data_ptr() + elems * t.element_size()
 
 
 def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G, Hg, prec, save=True, slot=0, xcd_rot=0,
-                h0=None, out=None, chunk=None, wide=False, zeroed=False, seq=None):
+                h0=None, out=None, chunk=None, wide=False, zeroed=False, seq=None, chunk_len=0):
     """-> (h, coef, an, z); the last three are None when save is False (inference).  slot / xcd_rot: see
     cruse_gru_seq_fwd_on (concurrent recurrences).
     h0 [B, G*Hg] ("cat" layout: feature = group*Hg + unit): initial state (cust_conv.py:305-325); None = 0.
@@ -762,7 +782,7 @@ def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G,
     check(lib.cruse_gru_seq_fwd_ex(_off(gi, t0 * 3 * H), ctypes.cast(wa, ctypes.c_void_p), ctypes.cast(ba, ctypes.c_void_p),
                                    _off(h, t0 * H), opt(coef, 3 * H), opt(an, H), opt(z, H), h0p, h0s, B, n, T, G, Hg,
                                    prec_code(prec), 16 if wide else 0, 1 if gi.dtype == torch.bfloat16 else 0, panels, 1 if zeroed else 0,
-                                   status, xcd_rot, t0 if seq is not None else 0, seq or 0, _stream()))
+                                   status, xcd_rot, t0 if seq is not None else 0, seq or 0, chunk_len, _stream()))
     return h, coef, an, z
 
 
@@ -778,7 +798,7 @@ def dgi_buffer(rows, G, Hg, device, slabs=3):
 
 
 def gru_seq_bwd(dout, w_hh: List[torch.Tensor], coef, z, B, T, G, Hg, prec, slot=0, xcd_rot=0, an=None, want_dgi=False,
-                out=None, chunk=None, dg_slabs=3, wide=False, zeroed=False, seq=None):
+                out=None, chunk=None, dg_slabs=3, wide=False, zeroed=False, seq=None, chunk_len=0):
     """dout [B,T,H] -> dh [B,T,H] (total gradient reaching every h_t).  want_dgi (CRUSE_PREC_BF16, with the a_n rows):
     -> (dh, dgi) with dgi = dh * (c_r, c_z, a_n) in bf16 written by the recurrence itself (cruse_gru_seq_bwd_on).
     chunk = (t0, n): only frames [t0, t0+n), into out = dh (or (dh, dgi)); chunks are run from the LAST to the first, and
@@ -806,7 +826,7 @@ def gru_seq_bwd(dout, w_hh: List[torch.Tensor], coef, z, B, T, G, Hg, prec, slot
                                    _off(dh, t0 * H), _off(an, t0 * H) if want_dgi else None,
                                    None if dgi is None else _off(dgi, t0 * dg_slabs * H), dg_slabs, carry, B, steps, T, G, Hg, prec_code(prec),
                                    16 if wide else 0, panels, 1 if zeroed else 0, status, xcd_rot,
-                                   (T - t0 - steps) if seq is not None else 0, seq or 0, _stream()))
+                                   (T - t0 - steps) if seq is not None else 0, seq or 0, chunk_len, _stream()))
     return (dh, dgi) if want_dgi else dh
 
 

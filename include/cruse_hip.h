@@ -465,11 +465,20 @@ int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh, const void
 int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, const float* const* b_hh,
                          float* h, void* coef, float* an, float* z, const float* h0, long long h0_bstride,
                          int B, int T, int TS, int G, int Hg, int prec, int chain_clips, int gi_bf16, void* panels,
-                         int panels_zeroed, unsigned* status, int xcd_rot, int epoch0, int seq, void* stream);
+                         int panels_zeroed, unsigned* status, int xcd_rot, int epoch0, int seq, int chunk_len, void* stream);
 int cruse_gru_seq_bwd_ex(const float* dout, const float* const* w_hh, const void* coef, const float* z,
                          float* dh, const float* an, void* dgi, int dg_slabs, int carry, int B, int T, int TS, int G,
                          int Hg, int prec, int chain_clips, void* panels, int panels_zeroed, unsigned* status, int xcd_rot,
-                         int epoch0, int seq, void* stream);
+                         int epoch0, int seq, int chunk_len, void* stream);
+/* (ABI 10) CHUNK SIGNALS of a running recurrence.  chunk_len > 0 (the _ex calls; bf16 mode, chains of 8, one launch: Hg = 640 forward,
+ * Hg in {160, 320, 640} backward): when a workgroup's rows of time chunk c (forward: frames [c L, (c + 1) L); backward: the iterations
+ * [c L, (c + 1) L) counted from the last frame) have been written, it releases them at agent scope and adds 1 to counter c of the
+ * MAX 64 counters at panels + cruse_gru_ws_signal_offset() (cleared with the panel scratch).  cruse_stream_wait_counter(counter, target):
+ * one wave on `stream` that returns once *counter >= target = workgroups with a chain = ceil(B / 8) * G * Hg / 32 (bounded: a
+ * time-out sets *status) -- the kernels queued behind it (the LayerNorm + gate projection of the chunk; backward: its input gradient
+ * + LayerNorm backward) then run beside the recurrence instead of behind it (cruse_net.py:41-51). */
+size_t cruse_gru_ws_signal_offset(int B, int G, int Hg);
+int cruse_stream_wait_counter(const unsigned* counter, unsigned target, unsigned* status, void* stream);
 /* dgi = dh*(c_r,c_z,a_n) (gradient wrt gi), dgh = dh*(c_r,c_z,c_n) (gradient wrt W_hh h + b_hh), both
  * [rows,G,3*Hg]; dW_ih, dW_hh, dX and the bias gradients follow from cruse_gemm / cruse_col_sum. */
 int cruse_gru_gate_grads(const float* dh, const void* coef, const float* an, float* dgi, float* dgh,

@@ -382,6 +382,37 @@ def test_ggru_wavefront_is_the_same_computation(graph):
     assert rel_l2(res[2][2], res[4][2]) < 1e-4
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_ggru_chunk_signal_overlap_is_the_same_computation(graph):
+    """EngineConfig.ggru_overlap: the recurrences count their time chunks in (cruse_gru_seq_*_ex(chunk_len), cruse_stream_wait_counter) and
+    the kernels between them -- LayerNorm 1 + layer-2 projection, backward the input-gradient GEMMs + LayerNorm-1 backward -- run chunk by
+    chunk on an auxiliary stream beside the running recurrence.  Same kernels on the same values: mask and loss bit for bit, gradients up
+    to the order of the f32 atomics (LayerNorm affine gradients, BatchNorm sums); eager and captured; several chunk counts, one of them
+    leaving a short last chunk."""
+    from cruse_amd.config import EngineConfig
+    from cruse_amd.data import synth_batch
+    from cruse_amd.engine import TrainEngine
+    from cruse_amd.model.cruse_net import unet_2
+    from cruse_amd import ops
+    noisy, clean = synth_batch(16, 32000, "cuda", 4)            # T = 201 frames
+    res = {}
+    for nov in (0, 2, 4, 7):
+        torch.manual_seed(5)
+        eng = TrainEngine(unet_2(rnn_groups=1, precision="bf16").cuda(), use_graph=graph, config=EngineConfig(ggru_overlap=nov))
+        ls = eng.step(noisy, clean)
+        torch.cuda.synchronize()
+        first = (eng.loss_value(ls), eng._last_mask.clone(), eng.flat.grads.clone())
+        ls = eng.step(noisy, clean)
+        torch.cuda.synchronize()
+        res[nov] = first + (eng.loss_value(ls),)
+        assert eng.skipped_steps() == 0 and ops.gru_status() == 0
+    for nov in (2, 4, 7):
+        assert torch.equal(res[nov][1], res[0][1]), f"mask differs with {nov} chunks"
+        assert res[nov][0] == res[0][0]
+        assert rel_l2(res[nov][2], res[0][2]) < 1e-4
+        assert res[nov][3] == pytest.approx(res[0][3], rel=1e-5)
+
+
 @pytest.mark.parametrize("grp", [1, 4])
 def test_bf16_stored_batchnorm_gradients_leave_the_step_unchanged(grp):
     """EngineConfig.bf16_dy: storing the BatchNorm-backward outputs as bf16 changes no operand bit of the bf16 mode -- loss equal,
