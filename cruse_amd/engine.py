@@ -440,7 +440,7 @@ class TrainEngine:
         st = self._auto
         i = st["n"]
         form = self._AUTO_PLAN[i]
-        self.use_graph = form
+        self.use_graph = form and not st.get("capture_failed")
         measured = i not in (0, 4)
         if measured:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -448,13 +448,17 @@ class TrainEngine:
         self._auto = None                        # (step() below must not recurse into the tuner)
         out = self.step(noisy, clean)
         self._auto = st
-        if form and not self.use_graph:          # capture failed: step() has fallen back to eager launches for good
-            self._auto = None
-            return out
+        if form and not self.use_graph:
+            # capture failed on THIS rank: step() has fallen back to eager launches.  The plan is still walked to its end -- the verdict
+            # below is a collective (a rank that left early let the others wait in all_reduce for ever) -- with graph
+            # times of +inf, so that every rank keeps eager launches
+            st["capture_failed"] = True
+        if st.get("capture_failed"):
+            self.use_graph = False
         if measured:
             e1.record()
             e1.synchronize()
-            st["t"][form].append(e0.elapsed_time(e1))
+            st["t"][form].append(float("inf") if (form and st.get("capture_failed")) else e0.elapsed_time(e1))
         st["n"] = i + 1
         if st["n"] == len(self._AUTO_PLAN):
             tg, te = sorted(st["t"][True])[1], sorted(st["t"][False])[1]          # medians of three
@@ -464,7 +468,7 @@ class TrainEngine:
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 tg, te = float(tt[0].item()), float(tt[1].item())
             self.use_graph = tg <= te
-            self.launch_form_timing = {"graph_ms": round(tg, 3), "eager_ms": round(te, 3),
+            self.launch_form_timing = {"graph_ms": round(tg, 3) if tg != float("inf") else None, "eager_ms": round(te, 3),
                                        "kept": "graph" if self.use_graph else "eager"}
             self._auto = None
         return out

@@ -1213,7 +1213,10 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
     ys, es, stats, us, vs, dstats = ctx["ys"], ctx["es"], ctx["stats"], ctx["us"], ctx["vs"], ctx["dstats"]
     _INLINE = config.get().inline_mask
     # backward-only tensors in bf16 (EngineConfig.bf16_dy): only where every consumer rounds them to bf16 operands anyway
-    dy_bf16 = bool(config.get().bf16_dy) and ops.prec_code(prec) == ops.PREC_BF16 and dprec == ops.PREC_BF16
+    # ... and every consumer is an MFMA kernel (the VALU fallbacks of the convs and weight gradients take f32 only: channel counts
+    # beyond 64 or not a power of two keep the f32 tensors -- ADVICE r4)
+    all_mfma = all(8 <= c <= 64 and (c & (c - 1)) == 0 for c in ch[1:])
+    dy_bf16 = bool(config.get().bf16_dy) and ops.prec_code(prec) == ops.PREC_BF16 and dprec == ops.PREC_BF16 and all_mfma
     ups = ctx.get("dec_mode", "transposed") == "upsample"
     uus = ctx.get("uus", {})
 
@@ -1353,8 +1356,10 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
                 P[f"conv{k}.weight"], B, T, ch[k], Fk[k], ch[k - 1], KT=2, pad=1, out=de_pre[k - 1], accum=True, prec=dprec,
                 bn_bwd=bn_of(k - 1, False))
         else:
+            # (level 1 with need_dx: its data gradient into the one-channel input is a VALU conv -- f32 dy)
             dy = ops.bn_act_bwd(de, ys[k], mean, rstd, P[f"bn{k}.weight"], P[f"bn{k}.bias"], rows, ch[k], Fk[k], True,
-                                training, G[f"bn{k}.weight"], G[f"bn{k}.bias"], dbias=G[f"conv{k}.bias"], sums=de_sums, out_bf16=dy_bf16)
+                                training, G[f"bn{k}.weight"], G[f"bn{k}.bias"], dbias=G[f"conv{k}.bias"], sums=de_sums,
+                                out_bf16=dy_bf16 and not (need_dx and k == 1))
 
         def leaf_enc(dy=dy, k=k):
             ops.conv_wgrad(dy, es[k - 1], G[f"conv{k}.weight"], B, T, ch[k], Fk[k], ch[k - 1], Fk[k - 1], KT=2, S=2, pad=1, prec=prec)

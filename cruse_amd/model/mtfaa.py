@@ -54,6 +54,8 @@ class STFT(nn.Module):
         off = (self.nfft - self.win) // 2
         key = ("env", T, str(real.device))
         if key not in self._cache:
+            if len(self._cache) >= 8:                        # (variable clip lengths: keep a handful of envelopes, not one per length for ever)
+                self._cache.pop(next(iter(self._cache)))
             # window-square overlap envelope: periodic in hop away from the clip edges; torch.istft divides by it
             # (one overlap-add of T copies of w^2 as a fold, once per clip length)
             w2 = torch.nn.functional.pad(self.window ** 2, (off, self.nfft - self.win - off))

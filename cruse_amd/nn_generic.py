@@ -69,27 +69,34 @@ def _pair(v):
 # ------------------------------------------------------------------------------------------------------------------
 _ZCHUNK = 1 << 16                  # floats per pool chunk (256 KB)
 _ZPOOL = {}                        # device -> [chunk, next free offset]
+import threading
+_ZLOCK = threading.Lock()          # (autograd may run backward() on worker threads)
 
 
 def _zeros_f32(shape, device) -> torch.Tensor:
     """A zero tensor carved from a pre-zeroed chunk: one fill launch per 64 K floats instead of one per tensor (the backward pass
     of config 5 made 77 of them per step, 4.7 us each, for tensors of 24-576 floats).  Chunks are never reused -- a slice stays
-    valid for as long as anything (a .grad) refers to it -- and big requests get their own torch.zeros."""
+    valid for as long as anything (a .grad) refers to it -- and big requests get their own torch.zeros.
+    Memory note (ADVICE r4): autograd's AccumulateGrad may keep a slice as the parameter's .grad, which keeps its 256 KB chunk alive;
+    a step's ~80 small gradients share one or two chunks, so what stays pinned is bounded by a chunk or two per set of live .grad
+    tensors -- but torch.save of such a .grad writes the whole chunk: clone() it first."""
     n = 1
     for d in shape:
         n *= int(d)
     if n > _ZCHUNK // 8 or torch.cuda.is_current_stream_capturing():
         return torch.zeros(shape, device=device, dtype=torch.float32)
     dev = torch.device(device)
-    ent = _ZPOOL.get(dev)
     need = (n + 63) // 64 * 64                 # 256-byte slots
-    if ent is None or ent[1] + need > _ZCHUNK or ent[2] != torch.cuda.current_stream(dev):
-        # (a chunk is zeroed on the stream that allocates it: slices are handed out on that stream only)
-        ent = [torch.zeros(_ZCHUNK, device=dev, dtype=torch.float32), 0, torch.cuda.current_stream(dev)]
-        _ZPOOL[dev] = ent
-    out = ent[0][ent[1]:ent[1] + n].view(shape)
-    ent[1] += need
+    with _ZLOCK:
+        ent = _ZPOOL.get(dev)
+        if ent is None or ent[1] + need > _ZCHUNK or ent[2] != torch.cuda.current_stream(dev):
+            # (a chunk is zeroed on the stream that allocates it: slices are handed out on that stream only)
+            ent = [torch.zeros(_ZCHUNK, device=dev, dtype=torch.float32), 0, torch.cuda.current_stream(dev)]
+            _ZPOOL[dev] = ent
+        out = ent[0][ent[1]:ent[1] + n].view(shape)
+        ent[1] += need
     return out
+
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -842,3 +842,33 @@ def test_sdnr_kernel_vs_reference_fixture(golden):
                                  noisy[:, 1].contiguous().view(B * T, Fs), B * T, 160, Fs, B, float(snr), 20.0)
         want = float(g["value"][k])
         assert abs(float(ls) / (B * Fs) - want) <= 2e-5 * abs(want), (snr, float(ls) / (B * Fs), want)
+
+
+def test_bf16_mode_with_channels_beyond_the_mfma_kernels_and_an_input_gradient():
+    """the bf16 storage of backward-only tensors (EngineConfig.bf16_dy / bf16_de) is taken only where every consumer is an MFMA
+    kernel.  A bf16-mode unet_2 with a 128-channel level (VALU convs and weight gradients: f32 tensors) and the upsample model with
+    x.requires_grad (level 1's data gradient into the one-channel input is a VALU conv) run their backward passes and agree with the
+    f32 mode of the same weights."""
+    from model.cruse import CRUSE4MagAddSkipUpsample
+    from model.cruse_net import unet_2
+    torch.manual_seed(7)
+    wide = unet_2(ch=(1, 16, 32, 64, 128), rnn_groups=2, precision="bf16").cuda()
+    ref = unet_2(ch=(1, 16, 32, 64, 128), rnn_groups=2, precision="f32").cuda()
+    ref.load_state_dict(wide.state_dict())
+    x = (torch.rand(2, 1, 21, 160) + 0.05).cuda(); w = torch.randn(2, 1, 21, 160).cuda()
+    for m in (wide, ref):
+        m.train()
+        (m(x) * w).sum().backward()
+    gb = torch.cat([p.grad.flatten() for p in wide.parameters() if p.grad is not None])
+    gf = torch.cat([p.grad.flatten() for p in ref.parameters() if p.grad is not None])
+    assert torch.isfinite(gb).all() and rel_l2(gb, gf) < 5e-2
+    up = CRUSE4MagAddSkipUpsample(rnn_groups=1, precision="bf16").cuda()
+    upf = CRUSE4MagAddSkipUpsample(rnn_groups=1, precision="f32").cuda()
+    upf.load_state_dict(up.state_dict())
+    grads = []
+    for m in (up, upf):
+        m.train()
+        xi = x.clone().requires_grad_(True)
+        (m(xi) * w).sum().backward()
+        grads.append(xi.grad.clone())
+    assert torch.isfinite(grads[0]).all() and rel_l2(grads[0], grads[1]) < 5e-2
