@@ -454,6 +454,103 @@ def secondary_rows(a, dev, pool):
     return out
 
 
+def trainer_path_rows(a, dev, headline_fps):
+    """epoch throughput of the TRAINER -- train.trainer_casual.Trainer._train_epoch as tools/train_stand.py's entry()
+    drives it (torch DataLoader built from the [train_dataset] section, DistributedSampler, Adam, wo_male_loss, clip 10) -- for
+      device: the device-resident dataset plug-in (cruse_amd.data.DevicePairs: pools in HBM, gather + on-GPU snr_mix per batch),
+      host:   a host dataset behind the reference's DataLoader (cruse_amd.data.HostPoolPairs, 4 workers) through the trainer's pinned,
+              double-buffered prefetcher on its own copy stream (PCIe-inclusive: 32.8 MB per step);
+    frames/s of the SECOND epoch (the first holds graph capture / the launch-form tuner) and the ratio to the headline line."""
+    from torch.utils.data import DataLoader, DistributedSampler
+    import train_base.loss as L
+    from cruse_amd.data import DevicePairs, HostPoolPairs
+    from cruse_amd.model.cruse_net import unet_2
+    from cruse_amd.train.trainer_casual import Trainer
+    B, Ls = a.batch, int(a.seconds * 16000)
+    nb = 48
+    out = {}
+    for name, ds, kw in (("device_dataset", DevicePairs(num=nb * B, length=Ls, seed=1, pool=128), dict(num_workers=0)),
+                         ("host_dataset_prefetched", HostPoolPairs(num=nb * B, length=Ls, seed=1, pool=128),
+                          dict(num_workers=4, persistent_workers=True, prefetch_factor=2))):
+        try:
+            torch.manual_seed(0)
+            m = unet_2(rnn_groups=a.groups)
+            cfg = {"acoustics": {"n_fft": 320, "hop_length": 160}, "trainer": {"train": {"epochs": 3, "clip_grad_norm_value": 10.0}},
+                   "meta": {"save_dir": "/tmp/cruse_bench_trainer", "precision": a.prec, "hip_graph": "auto"}}
+            sampler = DistributedSampler(dataset=ds, num_replicas=1, rank=0, shuffle=True)
+            loader = DataLoader(dataset=ds, sampler=sampler, shuffle=False, batch_size=B, drop_last=True, **kw)
+            tr = Trainer(dist=None, rank=0, config=cfg, resume=False, only_validation=False, model=m, loss_function=L.wo_male_loss(),
+                         optimizer=torch.optim.Adam(m.parameters(), lr=1e-3), train_dataloader=loader, validation_dataloader=None)
+            import contextlib, io
+            fps = []
+            with contextlib.redirect_stdout(io.StringIO()):
+                for ep in (1, 2, 3):
+                    tr._train_epoch(ep)
+                    fps.append(tr.last_epoch_frames_per_s)
+            best = max(fps[1:])
+            out[name] = {"value": round(best, 1), "unit": "frames/s", "epochs_frames_per_s": [round(f, 1) for f in fps],
+                         "batches_per_epoch": nb, "ratio_to_headline": round(best / headline_fps, 4),
+                         "launch_form": getattr(tr.engine, "launch_form_timing", None)}
+            del tr, loader
+        except Exception as ex:
+            out[name] = {"error": repr(ex)[:300]}
+    out["note"] = ("Trainer._train_epoch (tools/train_stand.py flow: DataLoader + DistributedSampler + Adam + wo_male_loss + clip) on 48 batches "
+                   "of the headline shape; epoch 1 holds capture / tuning, the better of epochs 2-3 is the figure; host row = PCIe-inclusive")
+    return out
+
+
+def rccl_world1_row(a, dev, pool):
+    """what the multi-GPU SCHEDULE costs before a byte crosses xGMI -- the headline step on backend nccl (= RCCL) at
+    world size 1 with the collectives forced (CRUSE_FORCE_COLLECTIVES=1): three gradient buckets all-reduced asynchronously between
+    three graph segments (or from the launcher stream when launched eagerly), the health words MAX-reduced, 1 / world folded into Adam
+    -- beside the same engine without a process group.  Runs LAST (it initialises a process group in this process)."""
+    import socket
+    from cruse_amd.config import EngineConfig
+    from cruse_amd.engine import TrainEngine
+    from cruse_amd.model.cruse_net import unet_2
+    out = {}
+    try:
+        torch.manual_seed(0)
+        cfg = EngineConfig.from_env()
+
+        def run(bucketed):
+            m = unet_2(rnn_groups=a.groups, precision=a.prec).to(dev)
+            e = TrainEngine(m, lr=1e-3, use_graph=True, bucketed=bucketed, config=cfg)
+            forms = {}
+            for form in (True, False):
+                e.use_graph = form
+                forms["graph" if form else "eager"] = _time_steps(e, pool, n_warm=4, n=10)
+            return forms, e
+        single, _ = run(False)
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        os.environ["CRUSE_FORCE_COLLECTIVES"] = "1"
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        try:
+            bucketed, eng = run(True)
+            ids = torch.tensor([0], device=dev, dtype=torch.int64)
+            got = [torch.zeros_like(ids)]
+            dist.all_gather(got, ids)
+            seen = len({int(g_.item()) for g_ in got})
+            nb = [4 * (e_ - s_) for s_, e_ in eng.flat.bucket_range]
+        finally:
+            dist.destroy_process_group()
+            os.environ.pop("CRUSE_FORCE_COLLECTIVES", None)
+        best_s, best_b = min(single.values()), min(bucketed.values())
+        out = {"ms_per_step": round(best_b, 3), "ms_per_step_by_form": {k: round(v, 3) for k, v in bucketed.items()},
+               "single_segment_ms_per_step": round(best_s, 3), "single_segment_by_form": {k: round(v, 3) for k, v in single.items()},
+               "bucketed_over_single": round(best_b / best_s, 4), "backend": "rccl", "rccl_ranks_seen": seen, "world_size": 1,
+               "bucket_bytes": nb,
+               "note": "headline step with forced collectives on backend nccl at world 1: 3 gradient buckets all-reduced asynchronously "
+                       "between 3 graph segments / from the launcher stream + MAX-reduced health words, against the same engine with no "
+                       "process group (one segment); the gap bounds what the schedule itself costs at N > 1 before any xGMI traffic"}
+    except Exception as ex:
+        out = {"error": repr(ex)[:300]}
+    return out
+
+
 def _time_steps(eng, pool, n_warm=3, n=8):
     for s_ in range(n_warm):
         eng.step(*pool[s_ % len(pool)])
@@ -782,9 +879,15 @@ def main():
         roof["others"] = {k: v for k, v in rl.items() if k != dom}
 
     secondary = None
+    frames_per_s_headline = world * B * T * a.steps / el
     if rank == 0 and world == 1 and not a.no_secondary:
         secondary = secondary_rows(a, dev, pool)
         secondary.update(config_rows(a, dev, pool))
+        log("secondary: trainer path (device-resident / host dataset) ...")
+        secondary["trainer_path"] = trainer_path_rows(a, dev, frames_per_s_headline)
+        if not force_pg:
+            log("secondary: rccl world-1 bucketed schedule ...")
+            secondary["rccl_world1_bucketed"] = rccl_world1_row(a, dev, pool)
 
     ranks_seen = devices_seen = None
     if world > 1 or force_pg:

@@ -102,3 +102,71 @@ class SyntheticPairs(Dataset):
     def __getitem__(self, i):
         noisy, clean = synth_batch(1, self.length, "cpu", self.seed * 100003 + i)
         return noisy[0], clean[0]
+
+
+class HostPoolPairs(Dataset):
+    """[train_dataset] plug-in for a HOST dataset that costs the workers nothing per item: `pool` clips are synthesised once (per
+    process) and item i is a view of clip i % pool -- the DataLoader's workers only collate.  With the trainer's pinned, double-buffered
+    prefetcher (trainer_casual._Prefetcher) this measures what the reference's DataLoader path (tools/train_stand.py:46-57) can feed.
+    path = "cruse_amd.data.HostPoolPairs", args = {num, length, seed, pool}."""
+
+    def __init__(self, num: int = 2048, length: int = 64000, seed: int = 0, pool: int = 128):
+        self.num, self.length, self.seed, self.pool = num, length, seed, max(1, min(pool, num))
+        self._data = None
+
+    def __len__(self):
+        return self.num
+
+    def _ensure(self):
+        if self._data is None:
+            noisy, clean = synth_batch(self.pool, self.length, "cpu", self.seed * 100003 + 17)
+            self._data = (noisy.share_memory_(), clean.share_memory_())      # (forked workers read the parent's pages)
+        return self._data
+
+    def __getitem__(self, i):
+        noisy, clean = self._ensure()
+        return noisy[i % self.pool], clean[i % self.pool]
+
+
+class DevicePairs(Dataset):
+    """[train_dataset] plug-in for a DEVICE-RESIDENT dataset ("so real-data training is not host-bound"): clean and noise
+    pools live in HBM and a batch is an index gather + the on-GPU SynDataset.snr_mix (dataset/dataset.py:235-264, cruse_snr_mix: peak
+    normalisation, RMS-based SNR scaling, mix) at a per-clip SNR drawn from [snr_low, snr_high] dB -- no host tensor, no PCIe copy.
+    The trainer recognises `device_resident` and asks for whole batches (device_batch) with the indices of the DataLoader's own
+    sampler; the DataLoader object the reference flow builds around the dataset is never iterated.  __getitem__ still works (host
+    copies of one pair) for anything that wants to look at an item.
+    path = "cruse_amd.data.DevicePairs", args = {num, length, seed, pool, snr_low, snr_high}."""
+
+    device_resident = True
+
+    def __init__(self, num: int = 2048, length: int = 64000, seed: int = 0, pool: int = 128, snr_low: float = 0.0, snr_high: float = 20.0):
+        self.num, self.length, self.seed, self.pool = num, length, seed, max(1, min(pool, num))
+        self.snr_low, self.snr_high = float(snr_low), float(snr_high)
+        self._pools = {}
+
+    def __len__(self):
+        return self.num
+
+    def _ensure(self, device):
+        device = torch.device(device)
+        if device not in self._pools:
+            g = torch.Generator(device=device).manual_seed(self.seed * 100003 + 29)
+            _, clean = synth_batch(self.pool, self.length, device, self.seed * 100003 + 17)
+            noise = torch.randn(self.pool, self.length, device=device, generator=g)
+            snr = self.snr_low + (self.snr_high - self.snr_low) * torch.rand(self.num, device=device, generator=g)
+            self._pools[device] = (clean, noise, snr)
+        return self._pools[device]
+
+    def device_batch(self, idx: torch.Tensor, device):
+        """idx [B] int64 (host or device): -> (noisy, clean) [B, length] f32 on `device`, issued on the current stream"""
+        clean_p, noise_p, snr = self._ensure(device)
+        idx = idx.to(device, non_blocking=True)
+        c = clean_p.index_select(0, idx % self.pool)
+        n = noise_p.index_select(0, (idx * 7 + 3) % self.pool)
+        noisy, clean, _ = snr_mix(c, n, snr.index_select(0, idx % self.num), return_parts=True)
+        return noisy, clean
+
+    def __getitem__(self, i):
+        dev = torch.device("cuda", torch.cuda.current_device())
+        noisy, clean = self.device_batch(torch.tensor([int(i)]), dev)
+        return noisy[0].cpu(), clean[0].cpu()

@@ -31,6 +31,109 @@ from .. import ops
 from ..engine import TrainEngine
 
 
+class _Prefetcher:
+    """Device batches one step AHEAD of the training loop, off the compute stream (the loop used to copy an un-pinned
+    [B, L] pair over PCIe on the compute stream, in series with every step).
+      * a HOST dataset (the reference's DataLoader, its kwargs untouched): a background thread pulls batches from the DataLoader and
+        stages them in a ring of four PINNED host buffers; the copy stream moves a staged pair to the device with non-blocking copies
+        (32.8 MB at B = 64: ~0.5 ms of PCIe beside a ~5 ms step) and records the event the compute stream waits for;
+      * a DEVICE-RESIDENT dataset (`dataset.device_resident`, e.g. cruse_amd.data.DevicePairs): the DataLoader is never iterated --
+        the indices of its own sampler go to dataset.device_batch() on the data stream (gather + on-GPU snr_mix).
+    Batch k + 1 is issued before batch k is handed to the loop.  The device tensors are allocated on the data stream and marked as used
+    by the compute stream (record_stream), so their memory is not reused before the step that reads them has run; a pinned buffer is
+    re-staged only after its copy's event has completed.  Iterating yields (noisy, clean) f32 device tensors ready on the CURRENT stream."""
+
+    NPIN = 4
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, device
+        self.stream = torch.cuda.Stream(device=device)
+        self.resident = bool(getattr(getattr(loader, "dataset", None), "device_resident", False))
+
+    def _index_batches(self):
+        bs, drop = self.loader.batch_size, self.loader.drop_last
+        buf = []
+        for i in self.loader.sampler:
+            buf.append(int(i))
+            if len(buf) == bs:
+                yield torch.tensor(buf, dtype=torch.int64)
+                buf = []
+        if buf and not drop:
+            yield torch.tensor(buf, dtype=torch.int64)
+
+    def _resident_items(self, main):
+        for idx in self._index_batches():
+            with torch.cuda.stream(self.stream):
+                noisy, clean = self.loader.dataset.device_batch(idx, self.device)
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+            yield noisy, clean, ev
+
+    def _host_items(self, main):
+        import queue
+        import threading
+        q: "queue.Queue" = queue.Queue(maxsize=2)
+        copy_done = [None] * self.NPIN             # event behind the H2D copy that last read pinned slot s
+        pinned = {}
+
+        def stage(t, slot, name):
+            if t.is_pinned():                      # (pin_memory=True in the DataLoader kwargs: a fresh pinned tensor per batch)
+                return t
+            key = (slot, name, tuple(t.shape), t.dtype)
+            if key not in pinned:
+                pinned[key] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+            pinned[key].copy_(t)
+            return pinned[key]
+
+        def work():
+            try:
+                for k, (noisy, clean) in enumerate(self.loader):
+                    s_ = k % self.NPIN
+                    # (two batches queued + this one: the copy of the batch that used slot s_ four batches ago was issued long ago)
+                    if copy_done[s_] is not None:
+                        copy_done[s_].synchronize()
+                    q.put((s_, stage(noisy, s_, "n"), stage(clean, s_, "c")))
+                q.put(None)
+            except BaseException as ex:            # surfaces in the training loop
+                q.put(ex)
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        while True:
+            item = q.get()
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            s_, hn, hc = item
+            with torch.cuda.stream(self.stream):
+                noisy = hn.to(self.device, non_blocking=True)
+                clean = hc.to(self.device, non_blocking=True)
+                if noisy.dtype != torch.float32:
+                    noisy, clean = noisy.float(), clean.float()
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+            copy_done[s_] = ev
+            yield noisy.contiguous(), clean.contiguous(), ev
+        th.join()
+
+    def __iter__(self):
+        main = torch.cuda.current_stream(self.device)
+        prev = None
+        for item in (self._resident_items(main) if self.resident else self._host_items(main)):
+            if prev is not None:
+                yield self._hand(prev, main)
+            prev = item
+        if prev is not None:
+            yield self._hand(prev, main)
+
+    @staticmethod
+    def _hand(item, main):
+        noisy, clean, ev = item
+        main.wait_event(ev)
+        noisy.record_stream(main); clean.record_stream(main)
+        return noisy, clean
+
+
 def _graph_mode(v):
     """meta.hip_graph: true / false / "auto"."""
     if isinstance(v, str):
@@ -154,9 +257,7 @@ class Trainer:
         gc.collect()
         gc.disable()     # a generational GC pause (tens of ms) is long enough to drain the device queue of eager launches
         try:
-            for noisy, clean in self.train_dataloader:
-                noisy = noisy.to(self.device, non_blocking=True).float().contiguous()
-                clean = clean.to(self.device, non_blocking=True).float().contiguous()
+            for noisy, clean in _Prefetcher(self.train_dataloader, self.device):
                 self.engine.step(noisy, clean)                           # no host synchronisation inside the loop
                 nb += 1
                 frames += noisy.shape[0] * (1 + noisy.shape[1] // self.engine.hop)
@@ -168,6 +269,7 @@ class Trainer:
         # (default 0), checked AFTER the epoch's checkpoint is written (train())
         self._pending_health = True
         dt = time.time() - t0
+        self.last_epoch_frames_per_s = frames / max(dt, 1e-9)             # (per rank; bench.py secondary.trainer_path reads it)
         if self.rank == 0:
             note = f"  ({skipped} optimizer steps skipped so far: non-finite loss / gradient)" if skipped else ""
             print(f"[epoch {epoch}] loss {mean:.6f}  {frames / max(dt, 1e-9):.0f} frames/s/rank{note}")
