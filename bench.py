@@ -458,8 +458,9 @@ def trainer_path_rows(a, dev, headline_fps):
     """epoch throughput of the TRAINER -- train.trainer_casual.Trainer._train_epoch as tools/train_stand.py's entry()
     drives it (torch DataLoader built from the [train_dataset] section, DistributedSampler, Adam, wo_male_loss, clip 10) -- for
       device: the device-resident dataset plug-in (cruse_amd.data.DevicePairs: pools in HBM, gather + on-GPU snr_mix per batch),
-      host:   a host dataset behind the reference's DataLoader (cruse_amd.data.HostPoolPairs, 4 workers) through the trainer's pinned,
-              double-buffered prefetcher on its own copy stream (PCIe-inclusive: 32.8 MB per step);
+      host:   a host dataset behind the reference's DataLoader (cruse_amd.data.HostPoolPairs, 4 workers; samples stored as f16 / f32) through
+              the trainer's pinned prefetcher on its own copy stream (PCIe-inclusive: 16.4 / 32.8 MB per step) -- bounded by the consumer
+              side of torch's DataLoader, which hands a [64, 64000] f32 pair over every ~5-9 ms on the bench host whatever the worker count;
     frames/s of the SECOND epoch (the first holds graph capture / the launch-form tuner) and the ratio to the headline line."""
     from torch.utils.data import DataLoader, DistributedSampler
     import train_base.loss as L
@@ -467,10 +468,12 @@ def trainer_path_rows(a, dev, headline_fps):
     from cruse_amd.model.cruse_net import unet_2
     from cruse_amd.train.trainer_casual import Trainer
     B, Ls = a.batch, int(a.seconds * 16000)
-    nb = 48
+    nb = 120
     out = {}
     for name, ds, kw in (("device_dataset", DevicePairs(num=nb * B, length=Ls, seed=1, pool=128), dict(num_workers=0)),
-                         ("host_dataset_prefetched", HostPoolPairs(num=nb * B, length=Ls, seed=1, pool=128),
+                         ("host_dataset_f16_prefetched", HostPoolPairs(num=nb * B, length=Ls, seed=1, pool=128, dtype="float16"),
+                          dict(num_workers=4, persistent_workers=True, prefetch_factor=2)),
+                         ("host_dataset_f32_prefetched", HostPoolPairs(num=nb * B, length=Ls, seed=1, pool=128),
                           dict(num_workers=4, persistent_workers=True, prefetch_factor=2))):
         try:
             torch.manual_seed(0)
@@ -494,7 +497,7 @@ def trainer_path_rows(a, dev, headline_fps):
             del tr, loader
         except Exception as ex:
             out[name] = {"error": repr(ex)[:300]}
-    out["note"] = ("Trainer._train_epoch (tools/train_stand.py flow: DataLoader + DistributedSampler + Adam + wo_male_loss + clip) on 48 batches "
+    out["note"] = ("Trainer._train_epoch (tools/train_stand.py flow: DataLoader + DistributedSampler + Adam + wo_male_loss + clip) on 120 batches "
                    "of the headline shape; epoch 1 holds capture / tuning, the better of epochs 2-3 is the figure; host row = PCIe-inclusive")
     return out
 

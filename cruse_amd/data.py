@@ -108,10 +108,13 @@ class HostPoolPairs(Dataset):
     """[train_dataset] plug-in for a HOST dataset that costs the workers nothing per item: `pool` clips are synthesised once (per
     process) and item i is a view of clip i % pool -- the DataLoader's workers only collate.  With the trainer's pinned, double-buffered
     prefetcher (trainer_casual._Prefetcher) this measures what the reference's DataLoader path (tools/train_stand.py:46-57) can feed.
-    path = "cruse_amd.data.HostPoolPairs", args = {num, length, seed, pool}."""
+    path = "cruse_amd.data.HostPoolPairs", args = {num, length, seed, pool, dtype}."""
 
-    def __init__(self, num: int = 2048, length: int = 64000, seed: int = 0, pool: int = 128):
+    def __init__(self, num: int = 2048, length: int = 64000, seed: int = 0, pool: int = 128, dtype: str = "float32"):
         self.num, self.length, self.seed, self.pool = num, length, seed, max(1, min(pool, num))
+        # "float16": the samples are STORED as 16-bit values (as PCM audio is) -- half the bytes through the DataLoader's queue, the
+        # staging copy and PCIe; the trainer widens them on the device (exactly)
+        self.dtype = {"float32": torch.float32, "float16": torch.float16}[dtype]
         self._data = None
 
     def __len__(self):
@@ -120,7 +123,7 @@ class HostPoolPairs(Dataset):
     def _ensure(self):
         if self._data is None:
             noisy, clean = synth_batch(self.pool, self.length, "cpu", self.seed * 100003 + 17)
-            self._data = (noisy.share_memory_(), clean.share_memory_())      # (forked workers read the parent's pages)
+            self._data = (noisy.to(self.dtype).share_memory_(), clean.to(self.dtype).share_memory_())      # (forked workers read the parent's pages)
         return self._data
 
     def __getitem__(self, i):

@@ -72,6 +72,7 @@ class _Prefetcher:
     def _host_items(self, main):
         import queue
         import threading
+        import numpy as np
         q: "queue.Queue" = queue.Queue(maxsize=2)
         copy_done = [None] * self.NPIN             # event behind the H2D copy that last read pinned slot s
         pinned = {}
@@ -82,21 +83,45 @@ class _Prefetcher:
             key = (slot, name, tuple(t.shape), t.dtype)
             if key not in pinned:
                 pinned[key] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
-            pinned[key].copy_(t)
+            # ONE thread copies (numpy memcpy, GIL released): the batch sits in freshly mapped shared-memory pages, and torch's
+            # multi-threaded copy_ faults them in from 128 threads that serialise on the process's mm lock -- 65-78 ms per
+            # [64, 64000] pair on the bench host against 2.9 ms for the single memcpy (tools/scratch/loader_probe2.py)
+            if t.is_contiguous() and t.dtype != torch.bfloat16:
+                np.copyto(pinned[key].numpy(), t.numpy())
+            else:
+                pinned[key].copy_(t)
             return pinned[key]
 
-        def work():
+        raw: "queue.Queue" = queue.Queue(maxsize=2)
+
+        def pull():                                # stage 1: the DataLoader's consumer side (~5 ms per 32.8 MB batch on the bench host)
             try:
-                for k, (noisy, clean) in enumerate(self.loader):
+                for item in self.loader:
+                    raw.put(item)
+                raw.put(None)
+            except BaseException as ex:
+                raw.put(ex)
+
+        def work():                                # stage 2: shared-memory pages -> pinned ring (~3 ms), beside stage 1
+            try:
+                k = 0
+                while True:
+                    item = raw.get()
+                    if item is None or isinstance(item, BaseException):
+                        q.put(item)
+                        return
+                    noisy, clean = item
                     s_ = k % self.NPIN
                     # (two batches queued + this one: the copy of the batch that used slot s_ four batches ago was issued long ago)
                     if copy_done[s_] is not None:
                         copy_done[s_].synchronize()
                     q.put((s_, stage(noisy, s_, "n"), stage(clean, s_, "c")))
-                q.put(None)
+                    k += 1
             except BaseException as ex:            # surfaces in the training loop
                 q.put(ex)
+        th0 = threading.Thread(target=pull, daemon=True)
         th = threading.Thread(target=work, daemon=True)
+        th0.start()
         th.start()
         while True:
             item = q.get()
@@ -115,6 +140,7 @@ class _Prefetcher:
             copy_done[s_] = ev
             yield noisy.contiguous(), clean.contiguous(), ev
         th.join()
+        th0.join()
 
     def __iter__(self):
         main = torch.cuda.current_stream(self.device)
@@ -251,11 +277,16 @@ class Trainer:
         sampler = getattr(self.train_dataloader, "sampler", None)
         if hasattr(sampler, "set_epoch"):
             sampler.set_epoch(epoch)                                     # a different shuffle every epoch
+        import sys
         nb, frames = 0, 0
-        t0 = time.time()
         self.engine.mean_loss(reset=True)
-        gc.collect()
+        gc.collect()     # (~50 ms over torch's object graph: before the clock starts)
         gc.disable()     # a generational GC pause (tens of ms) is long enough to drain the device queue of eager launches
+        # the prefetcher's staging thread shares the GIL with this loop: at the default 5 ms switch interval every hand-over of the GIL
+        # between the two costs up to a whole training step (measured: 41 ms per batch instead of 4.2 with a host DataLoader)
+        swi = sys.getswitchinterval()
+        sys.setswitchinterval(2e-4)
+        t0 = time.time()
         try:
             for noisy, clean in _Prefetcher(self.train_dataloader, self.device):
                 self.engine.step(noisy, clean)                           # no host synchronisation inside the loop
@@ -263,6 +294,7 @@ class Trainer:
                 frames += noisy.shape[0] * (1 + noisy.shape[1] // self.engine.hop)
         finally:
             gc.enable()
+            sys.setswitchinterval(swi)
         mean = self.engine.mean_loss(reset=True)                         # one synchronisation per epoch
         skipped = self.engine.skipped_steps()
         # a timed-out step was skipped on every rank (parameters intact): tolerated up to [meta] max_gru_timeouts_per_epoch
