@@ -1077,7 +1077,9 @@ def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, tor
     # EngineConfig.fuse_bn_fwd (bf16 mode, training): BatchNorm-apply + ReLU (+ skip add) of a level run inside the staging of the
     # convs that consume it -- `pend` describes such a VIRTUAL tensor (ops.BnIn); es[k] / us[k] are then the bf16 copies the
     # consuming conv writes for the weight gradients, mean / rstd are published by that conv's block 0
-    fz = training and save and config.get().fuse_bn_fwd and config.get().fuse_bn_stats
+    # (the MFMA convs stage whole frame rows: up to 640 elements per row and level -- wider networks run the VALU kernels, unfused)
+    fz = (training and save and config.get().fuse_bn_fwd and config.get().fuse_bn_stats
+          and all(ch[k] * Fk[k] <= 640 for k in range(1, L + 1)))
     dev = x.device
 
     def virtual(y_, sums_, C, F, name, add=None):
@@ -1215,7 +1217,7 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
     # backward-only tensors in bf16 (EngineConfig.bf16_dy): only where every consumer rounds them to bf16 operands anyway
     # ... and every consumer is an MFMA kernel (the VALU fallbacks of the convs and weight gradients take f32 only: channel counts
     # beyond 64 or not a power of two keep the f32 tensors -- ADVICE r4)
-    all_mfma = all(8 <= c <= 64 and (c & (c - 1)) == 0 for c in ch[1:])
+    all_mfma = all(8 <= c <= 64 and (c & (c - 1)) == 0 for c in ch[1:]) and all(ch[k] * Fk[k] <= 640 for k in range(1, L + 1))
     dy_bf16 = bool(config.get().bf16_dy) and ops.prec_code(prec) == ops.PREC_BF16 and dprec == ops.PREC_BF16 and all_mfma
     ups = ctx.get("dec_mode", "transposed") == "upsample"
     uus = ctx.get("uus", {})

@@ -85,7 +85,7 @@ class _Prefetcher:
                 pinned[key] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
             # ONE thread copies (numpy memcpy, GIL released): the batch sits in freshly mapped shared-memory pages, and torch's
             # multi-threaded copy_ faults them in from 128 threads that serialise on the process's mm lock -- 65-78 ms per
-            # [64, 64000] pair on the bench host against 2.9 ms for the single memcpy (tools/scratch/loader_probe2.py)
+            # [64, 64000] pair on the bench host against 2.9 ms for the single memcpy (tools/loader_probe.py)
             if t.is_contiguous() and t.dtype != torch.bfloat16:
                 np.copyto(pinned[key].numpy(), t.numpy())
             else:

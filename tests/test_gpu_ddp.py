@@ -83,7 +83,15 @@ print("OK")
 '''
 
 
-def _run(world, tmp, port, mode="same", env_extra=None, tag=""):
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _run(world, tmp, port=None, mode="same", env_extra=None, tag=""):
+    port = port or _free_port()
     script = os.path.join(tmp, "w.py")
     open(script, "w").write(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world))
@@ -97,8 +105,8 @@ def _run(world, tmp, port, mode="same", env_extra=None, tag=""):
 
 def test_two_rank_step_equals_single_rank(tmp_path):
     tmp = str(tmp_path)
-    _run(1, tmp, 29541)
-    _run(2, tmp, 29542)
+    _run(1, tmp, None)
+    _run(2, tmp, None)
     p1 = torch.load(tmp + "/p_same_w1_r0.pt")["params"]
     a = torch.load(tmp + "/p_same_w2_r0.pt")["params"]
     b = torch.load(tmp + "/p_same_w2_r1.pt")["params"]
@@ -112,7 +120,7 @@ def test_two_rank_shards_bn_train_vs_oracle_rank_by_rank(tmp_path):
     """different clips per rank, rank-local BatchNorm statistics: per-rank loss and the summed gradient vs the oracle."""
     from oracle import cruse_oracle as O
     tmp = str(tmp_path)
-    _run(2, tmp, 29543, mode="shards")
+    _run(2, tmp, None, mode="shards")
     r = [torch.load(tmp + f"/p_shards_w2_r{k}.pt") for k in range(2)]
     assert torch.equal(r[0]["params"], r[1]["params"]), "ranks diverged"
     assert torch.equal(r[0]["g0"], r[1]["g0"]), "all-reduced gradients differ across ranks"
@@ -146,7 +154,7 @@ def test_two_rank_shards_bn_train_vs_oracle_rank_by_rank(tmp_path):
 def test_one_ranks_timeout_skips_the_step_on_every_rank(tmp_path):
     """the skip decision of the guarded Adam is global -- health words all-reduced with MAX."""
     tmp = str(tmp_path)
-    _run(2, tmp, 29546, mode="poison")
+    _run(2, tmp, None, mode="poison")
     a = torch.load(tmp + "/p_poison_w2_r0.pt")["params"]
     b = torch.load(tmp + "/p_poison_w2_r1.pt")["params"]
     assert torch.equal(a, b), "ranks diverged after a one-rank time-out"
@@ -178,8 +186,8 @@ def test_bench_self_launches_its_ranks():
 def test_rccl_bucketed_schedule_world1(tmp_path, nograph):
     """backend nccl (RCCL): segmented graphs + async per-bucket all-reduce == the single-graph schedule."""
     tmp = str(tmp_path)
-    _run(1, tmp, 29544, mode="nccl1", env_extra={"CRUSE_FORCE_COLLECTIVES": "1", "BUCKETED": "1", "NOGRAPH": nograph}, tag="b")
-    _run(1, tmp, 29545, mode="nccl1", env_extra={"BUCKETED": "0", "NOGRAPH": nograph}, tag="p")
+    _run(1, tmp, None, mode="nccl1", env_extra={"CRUSE_FORCE_COLLECTIVES": "1", "BUCKETED": "1", "NOGRAPH": nograph}, tag="b")
+    _run(1, tmp, None, mode="nccl1", env_extra={"BUCKETED": "0", "NOGRAPH": nograph}, tag="p")
     a = torch.load(tmp + "/p_nccl1b_w1_r0.pt")
     b = torch.load(tmp + "/p_nccl1p_w1_r0.pt")
     assert rel_l2(a["g0"], b["g0"]) < 1e-6

@@ -10,6 +10,23 @@ import torch
 from tests.util import rel_l2
 
 pytestmark = pytest.mark.gpu
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+_PORTS = {}
+
+
+def _port(tag: int) -> int:
+    """one free rendezvous port per (test-local) tag: the config file and the launcher must name the same one"""
+    if tag not in _PORTS:
+        _PORTS[tag] = _free_port()
+    return _PORTS[tag]
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 TOML = '''
@@ -81,8 +98,8 @@ def _write(tmp_path, name, **kw):
 
 
 def test_train_stand_end_to_end_save_and_resume(tmp_path):
-    cfg = _write(tmp_path, "tiny", loss="wo_male_loss", loss_args="[loss_function.args]\nalpha = 2.0\nbeta = 1.0", epochs=1, port=29551)
-    out = _cli(cfg, port=29551)
+    cfg = _write(tmp_path, "tiny", loss="wo_male_loss", loss_args="[loss_function.args]\nalpha = 2.0\nbeta = 1.0", epochs=1, port=_port(29551))
+    out = _cli(cfg, port=_port(29551))
     assert "[epoch 1] loss" in out and "validation loss" in out
     ckdir = tmp_path / "runs" / "tiny" / "checkpoints"
     ck = torch.load(ckdir / "latest_model.tar", map_location="cpu", weights_only=False)
@@ -99,20 +116,20 @@ def test_train_stand_end_to_end_save_and_resume(tmp_path):
     assert len(st) == len(list(o.parameters())) - 4 and all(float(v["step"]) == 2.0 for v in st.values())    # 2 batches; fc.*, bn1_t.* untouched
     torch.amp.GradScaler("cpu", enabled=False).load_state_dict(ck["scaler"])
     # resume: epochs = 2 continues at epoch 2 from the saved optimizer state
-    cfg2 = _write(tmp_path, "tiny", loss="wo_male_loss", epochs=2, port=29552)
-    out2 = _cli(cfg2, "-R", port=29552)
+    cfg2 = _write(tmp_path, "tiny", loss="wo_male_loss", epochs=2, port=_port(29552))
+    out2 = _cli(cfg2, "-R", port=_port(29552))
     assert "Training will begin at 2 epoch" in out2 and "[epoch 2] loss" in out2 and "[epoch 1] loss" not in out2
     ck2 = torch.load(ckdir / "latest_model.tar", map_location="cpu", weights_only=False)
     assert ck2["epoch"] == 2 and float(ck2["optimizer"]["state"][0]["step"]) == 4.0
     # -P preloads model weights (strict=False) and -V only validates
-    out3 = _cli(cfg2, "-V", "-P", str(ckdir / "latest_model.tar"), port=29553)
+    out3 = _cli(cfg2, "-V", "-P", str(ckdir / "latest_model.tar"), port=_port(29553))
     assert "Model preloaded successfully" in out3 and "validation loss" in out3
 
 
 @pytest.mark.parametrize("loss,args", [("si_snr_loss", ""), ("sdnr_loss", "[loss_function.args]\nsnr = 5.0\nbeta = 20.0"), ("l1_loss", "")])
 def test_train_stand_honours_loss_function_name(tmp_path, loss, args):
-    cfg = _write(tmp_path, "l_" + loss, loss=loss, loss_args=args, epochs=1, port=29554)
-    out = _cli(cfg, port=29554)
+    cfg = _write(tmp_path, "l_" + loss, loss=loss, loss_args=args, epochs=1, port=_port(29554))
+    out = _cli(cfg, port=_port(29554))
     assert "[epoch 1] loss" in out
     if loss == "si_snr_loss":
         v = float(out.split("[epoch 1] loss")[1].split()[0])
