@@ -55,7 +55,6 @@ SIGNATURES = {
     "cruse_ln_fwd": ("ppppppppqiifiqqp", "i"),
     "cruse_ln_fwd_c": ("ppppppippqiifiqqp", "i"),
     "cruse_ln_bwd": ("pppppqiipppp", "i"),
-    "cruse_ln_bwd_seg": ("pppppqiipppiqqp", "i"),
     "cruse_gemm": ("iiiiipipipipiiiip", "i"),
     "cruse_gemm_bf16_nt": ("iiipqqpqqpqpiip", "i"),
     "cruse_gemm_bf16_slab_bytes": ("iii", "z"),
@@ -71,7 +70,6 @@ SIGNATURES = {
     "cruse_ktile_bf16": ("piiqppp", "i"),
     "cruse_ktile_f16": ("piiqpp", "i"),
     "cruse_gemm_f16_nt": ("iiipqqpqqpqpp", "i"),
-    "cruse_gemm_f16_nt_seg": ("iiipqpqqpqpiqqp", "i"),
     "cruse_cast_bf16_split": ("pppqp", "i"),
     "cruse_gemm_bf16x3_nt": ("iiippqqppqqpqpip", "i"),
     "cruse_gru_ws_bytes": ("iii", "z"),
@@ -79,10 +77,8 @@ SIGNATURES = {
     "cruse_gru_seq_bwd": ("pppppiiiiipp", "i"),
     "cruse_gru_seq_fwd_on": ("pppppppiiiiippip", "i"),
     "cruse_gru_seq_bwd_on": ("pppppppiiiiippip", "i"),
-    "cruse_gru_seq_fwd_ex": ("ppppppppqiiiiiiiipipiiiip", "i"),
-    "cruse_gru_seq_bwd_ex": ("pppppppiiiiiiiiipipiiiip", "i"),
-    "cruse_gru_ws_signal_offset": ("iii", "z"),
-    "cruse_stream_wait_counter": ("pipp", "i"),
+    "cruse_gru_seq_fwd_ex": ("ppppppppqiiiiiiiipipip", "i"),
+    "cruse_gru_seq_bwd_ex": ("pppppppiiiiiiiiipipip", "i"),
     "cruse_gru_gate_grads": ("pppppqiiip", "i"),
     "cruse_gru_gate_grads_bf16": ("pppppqppqiip", "i"),
     "cruse_gru_gate_bias_sums": ("pqiippp", "i"),

@@ -67,26 +67,6 @@ class EngineConfig:
                                     # levels whose producer AND consumers are MFMA kernels: 2 <= k < L) are stored as bf16 as well:
                                     # f32 accumulation, one rounding per pass of a backward-only tensor (needs bf16_dy and
                                     # fuse_bn_bwd_stats: the conv that stores the tensor also delivers its BatchNorm sums)
-    ggru_overlap: int = 0           # time chunks of the CHUNK-SIGNAL overlap inside the GGRU block (g = 1, Hg = 640, inside a training step; 0 / 1 = off):
-                                    # each recurrence stays ONE launch and counts its chunks in as their rows reach HBM; an auxiliary stream waits
-                                    # for the count and runs the kernels between the two recurrences (LayerNorm 1 + layer-2 projection; backward:
-                                    # input-gradient GEMM + LayerNorm-1 backward, and layer 1's input gradient) chunk by chunk beside the running
-                                    # recurrence.  OFF: measured neutral to slower (r5: 4.96 / 5.01 / 5.14 / 5.21 ms with 3 / 4 / 6 / 8 chunks against
-                                    # 4.98 on the same box) -- beside a recurrence (160 of 256 CUs) a chunk GEMM takes 150-175 us instead of 30 and the
-                                    # recurrence itself 564 instead of 505 us: profiles/r05_chunk_signal_overlap_chain.txt
-    ggru_wave: int = 0              # time chunks of the GGRU WAVEFRONT (g = 1, B <= 64, Hg % 128 == 0; 0 / 1 = off): on wide chains (16 clips per
-                                    # chain, gru_w16.hip) the recurrences of BOTH layers are co-resident -- layer 2 runs one chunk behind layer 1
-                                    # (forward) / layer 1 one chunk behind layer 2 (backward), the LayerNorm + gate projection (backward: input
-                                    # gradient + LayerNorm backward) of a chunk on a third stream in between (cruse_net._ggru_forward_wave).
-                                    # OFF: measured SLOWER on the bench step (r5: 5.65 ms with 4 chunks, 6.0 / 6.6 with 6 / 8, forward half
-                                    # alone 5.06, against 4.88 serial) -- alone the pair of wide recurrences runs at 1.59 us per step (636 us for
-                                    # both layers against 2 x 469), but beside the step's leaves and the chunk GEMMs every wide step stretches
-                                    # to 1.7-2.4 us forward / 2.5-3.2 us backward and a chunk launch costs ~50-70 us of CU acquisition instead
-                                    # of 18 (profiles/r05_wavefront_chain.txt): the window is bound by the memory system, not by the dependency
-    gru_wide: int = 0               # serial schedule on WIDE chains (bit 0 forward, bit 1 backward): a recurrence then holds 80 CUs instead of 160
-                                    # at B = 64 (1.32 / 1.61 us per step alone against 1.17 / 1.34) and the leaves beside it get 176 instead of 96
-    ggru_wave_fwd: bool = True      # ... its forward / backward halves (A/B switches: False = that pass runs its two recurrences one after the other)
-    ggru_wave_bwd: bool = True
     lib_options: Dict[str, int] = field(default_factory=dict)       # cruse_set_option(name, value) while this config is active
 
     _ENV = {"overlap": ("CRUSE_OVERLAP", lambda v: v == "1"), "defer_mask": ("CRUSE_DEFER", int), "inline_mask": ("CRUSE_INLINE", int),
@@ -94,7 +74,7 @@ class EngineConfig:
             "fuse_dgi": ("CRUSE_FUSE_DGI", lambda v: v == "1"),
             "fuse_bn_bwd_stats": ("CRUSE_FUSE_BN_BWD", lambda v: v != "0"), "fuse_cast": ("CRUSE_FUSE_CAST", lambda v: v == "1"),
             "gi_x3": ("CRUSE_GI_X3", int), "gi_f16": ("CRUSE_GI_F16", int), "gi_bf16": ("CRUSE_GI_BF16", lambda v: v == "1"), "dw_xcdk": ("CRUSE_DW_XCDK", int), "conv_bwd_x3": ("CRUSE_CONV_BWD_X3", lambda v: v == "1"),
-            "dw_tn": ("CRUSE_DW_TN", lambda v: v == "1"), "dw_slabs": ("CRUSE_DW_SLABS", lambda v: v != "0"), "dw_cat": ("CRUSE_DW_CAT", lambda v: v != "0"), "dx_atr": ("CRUSE_DX_ATR", lambda v: v == "1"), "gemm_groups": ("CRUSE_GEMM_GROUPS", lambda v: v != "0"), "ggru_wave": ("CRUSE_GGRU_WAVE", int), "ggru_overlap": ("CRUSE_GGRU_OVERLAP", int), "gru_wide": ("CRUSE_GRU_WIDE", int), "ggru_wave_bwd": ("CRUSE_GGRU_WAVE_BWD", lambda v: v != "0"), "ggru_wave_fwd": ("CRUSE_GGRU_WAVE_FWD", lambda v: v != "0"),
+            "dw_tn": ("CRUSE_DW_TN", lambda v: v == "1"), "dw_slabs": ("CRUSE_DW_SLABS", lambda v: v != "0"), "dw_cat": ("CRUSE_DW_CAT", lambda v: v != "0"), "dx_atr": ("CRUSE_DX_ATR", lambda v: v == "1"), "gemm_groups": ("CRUSE_GEMM_GROUPS", lambda v: v != "0"), 
             "fuse_bn_fwd": ("CRUSE_FUSE_BN_FWD", lambda v: v != "0"), "fuse_bn_bwd_apply": ("CRUSE_FUSE_BN_BWD_APPLY", lambda v: v != "0"), "bf16_dy": ("CRUSE_BF16_DY", lambda v: v != "0"), "bf16_de": ("CRUSE_BF16_DE", lambda v: v != "0")}
     _LIB_ENV = {"CRUSE_GRU_BWD_RS": "gru_bwd_rs", "CRUSE_GRU_FWD_LEAN": "gru_fwd_lean", "CRUSE_GRU_WLO": "gru_wlo",
                 "CRUSE_GRU_DBG": "gru_dbg", "CRUSE_GRU_PRIO": "gru_prio", "CRUSE_GRU_BG": "gru_bg", "CRUSE_CM_GRID": "cm_grid", "CRUSE_CM_KINT": "cm_kint", "CRUSE_CM_SWAP": "cm_swap", "CRUSE_CM_NW": "cm_nw",

@@ -815,15 +815,6 @@ extern "C" int cruse_gemm_f16_nt(int M, int N, int K, const void* A, long long l
                           nullptr, 0, true);
 }
 
-// ... on the rows of one time chunk (row segments as in cruse_gemm_bf16_nt_seg; row-major A)
-extern "C" int cruse_gemm_f16_nt_seg(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, long long b_kstride,
-                                     float* C, long long ldc, const float* bias, int seg_len, long long seg_stride, long long seg_off,
-                                     void* stream) {
-    CRUSE_REQUIRE(seg_len > 0, CRUSE_E_SHAPE, "gemm_f16_nt_seg: seg_len=%d", seg_len);
-    return gemm_bf16_impl(M, N, K, A, nullptr, lda, BK, B, nullptr, ldb, b_kstride, C, ldc, bias, 0, 1, stream, seg_len, seg_stride, seg_off,
-                          false, nullptr, 0, true);
-}
-
 // C[M,N] (+)= A[M,K] . B[N,K]^T with A given as its TIME-MAJOR K-tiled image: element (m, k) at A_T[(m / 64) * a_mb_stride + k * 64 + m % 64],
 // n_mb 64-row blocks present (rows M <= m < 64 * n_mb hold finite values).  This is the layout of the gate-gradient tensor dgT
 // [ceil(rows / 64)][G][4][Hg][64] the weight-gradient GEMMs consume (A_T = dgT + group * 4 * Hg * 64, a_mb_stride = G * 4 * Hg * 64): the input

@@ -402,26 +402,19 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
         // (RD: the panel barrier stays although nothing is shared through it any more -- it is the helper wave's hand-over point.  With
         //  per-wave "sweep done" flags in LDS instead, the helper started only after the LAST wave's sweep and became the long pole of the
         //  second barrier: 1.25 against 1.18 us per step.)
-        // chunk signals (GruArgs::chunk_len): after the saves of a chunk's last frame have been issued
-        const int CL = a.chunk_len;
-        int sig_t = CL > 0 ? CL - 1 : 0x7fffffff, sig_c = 0;           // next frame that closes a chunk
-        auto flushed = [&](int t) {
-            if (t >= sig_t) { chunk_signal(a.sig, sig_c, lane); ++sig_c; sig_t += CL; }
-        };
         for (int t = 0; t < a.T; t += 2) {
             if (t > 0 || h0_step) __syncthreads();
             put(t + 2, s0); issue(t + 4, s0);
-            if (t > 0) { flush(t - 1); flushed(t - 1); }
+            if (t > 0) flush(t - 1);
             if (t > 0 || h0_step) __syncthreads();
             if (t + 1 >= a.T) break;
             __syncthreads();
             put(t + 3, s1); issue(t + 5, s1);
-            flush(t); flushed(t);
+            flush(t);
             __syncthreads();
         }
         __syncthreads();                                // the last step's saves are in LDS
         flush(a.T - 1);
-        if (CL > 0) chunk_signal(a.sig, (a.T - 1) / CL, lane);
         return;
     }
 
@@ -1334,7 +1327,6 @@ int make_plan(int B, int G, int Hg, int prec, bool fwd, int chain_clips, bool wi
 }
 
 constexpr int MAX_LAUNCH_TICKETS = 64;      // launches of one call that get their own ticket counters
-constexpr int MAX_CHUNKS = 64;              // chunk counters of a launch that signals its progress (GruArgs::chunk_len)
 // (sized for chains of 8 or of 16 clips: a 16-clip chain takes the room of two chains of 8)
 int chains8(int B) { return 2 * cdiv(B, 16); }
 size_t xid_bytes_total(int B, int G) { return (size_t)chains8(B) * G * 64 * 8; }
@@ -1455,21 +1447,11 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* pane
     char* xg_base = xid_base + xid_bytes_total(a.B, G);
     unsigned* tickets_base = (unsigned*)(xg_base + xg_bytes_total(a.B, G, Hg));        // [launch][8]
     a.Bg = pl.Bg; a.P = pl.P;
-    a.sig = tickets_base + (size_t)MAX_LAUNCH_TICKETS * 8;
-    if (a.chunk_len > 0) {
-        // chunk signals exist in the kernels of the bench shape's default path: the lean forward kernel with its helper wave and the
-        // all-gather backward kernel (bf16, chains of 8), one launch for the whole batch
-        const bool ok = !pl.wide && pl.nlaunch == 1 && cdiv(a.T, a.chunk_len) <= MAX_CHUNKS && pl.Bg == 8 && prec == CRUSE_PREC_BF16 &&
-                        (FWD ? (fwd_lean_eligible(8, Hg, prec) && !fwd_tf_eligible(8, Hg, prec, a.h0 != nullptr, a.gi_bf16 != 0) && !(fwd_wlo(Hg) && Hg > 384))
-                             : (bwd_rs_eligible(8, Hg, prec) && bwd_tf_eligible(8, Hg, prec) && cruse_opt("gru_bwd_ag", 2) == 2));
-        CRUSE_REQUIRE(ok, CRUSE_E_SHAPE, "gru_seq: chunk signals (chunk_len = %d) are not available for this shape / kernel selection", a.chunk_len);
-    }
     a.dbg = cruse_opt("gru_dbg", 0);
     a.xsweep = cruse_opt("gru_xsweep", 0);
     int rc = CRUSE_OK;
-    // (a.seq: the run's index among the launches that share this scratch since it was cleared -- time chunks of one recurrence)
-    CRUSE_REQUIRE((a.seq + 1) * pl.nlaunch <= MAX_LAUNCH_TICKETS, CRUSE_E_SHAPE, "gru_seq: batch %d needs %d launches x %d runs (max %d)", a.B,
-                  pl.nlaunch, a.seq + 1, MAX_LAUNCH_TICKETS);
+    CRUSE_REQUIRE(pl.nlaunch <= MAX_LAUNCH_TICKETS, CRUSE_E_SHAPE, "gru_seq: batch %d needs %d launches (max %d)", a.B, pl.nlaunch,
+                  MAX_LAUNCH_TICKETS);
     for (int L = 0; L < pl.nlaunch; ++L) {
         const int bg_off = L * pl.bg_per_launch;
         const int nbg_here = (pl.nbg - bg_off) < pl.bg_per_launch ? (pl.nbg - bg_off) : pl.bg_per_launch;
@@ -1478,7 +1460,7 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* pane
         a.nchains = nbg_here * G;
         // every launch gets its own panel region: chain index inside the launch + offset
         a.xid = (unsigned long long*)xid_base + (size_t)bg_off * G * 64;
-        a.tickets = tickets_base + ((size_t)a.seq * pl.nlaunch + L) * 8;
+        a.tickets = tickets_base + (size_t)L * 8;
         const bool rs_form = !FWD && !pl.wide && bwd_rs_eligible(pl.Bg, Hg, prec);
         const size_t gpp = pl.wide ? w16_panel_bytes_per_parity(Hg, FWD) / 8 : rs_form ? rs_gran_per_parity(Hg) : (size_t)pl.Bg * Hg;      // granules per parity and chain
         a.xg = (unsigned long long*)xg_base + (size_t)bg_off * G * 2 * gpp;
@@ -1533,42 +1515,15 @@ __global__ __launch_bounds__(256) void gate_bias_sums_kernel(const __bf16* dg, l
 
 }  // namespace
 
-// One wave that waits until *counter >= target: everything behind it in its stream then runs after the producers that counted in
-// (chunk signals of a running recurrence: GruArgs::chunk_len; the producers release their rows at agent scope before they count, the
-// kernels behind this one acquire at their start like any kernel).  Bounded: a time-out sets the sticky status word.
-__global__ __launch_bounds__(64) void wait_counter_kernel(const unsigned* counter, unsigned target, unsigned* status) {
-    if (threadIdx.x != 0) return;
-    for (unsigned spins = 0;; ++spins) {
-        if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return;
-        if (spins >= (1u << 24)) { if (status) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
-        __builtin_amdgcn_s_sleep(32);
-    }
-}
-
-extern "C" int cruse_stream_wait_counter(const unsigned* counter, unsigned target, unsigned* status, void* stream) {
-    CRUSE_REQUIRE(counter != nullptr, CRUSE_E_SHAPE, "stream_wait_counter: NULL counter");
-    hipLaunchKernelGGL(wait_counter_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, target, status);
-    CRUSE_LAUNCH_CHECK("stream_wait_counter");
-    return CRUSE_OK;
-}
-
 extern "C" size_t cruse_gru_ws_bytes(int B, int G, int Hg) {
-    return 256 + xid_bytes_total(B, G) + xg_bytes_total(B, G, Hg) + (size_t)MAX_LAUNCH_TICKETS * 8 * sizeof(unsigned) + MAX_CHUNKS * sizeof(unsigned);
-}
-
-// byte offset, from the panel scratch (`panels` of the _ex calls), of the MAX_CHUNKS chunk counters a launch with chunk_len > 0 counts up
-extern "C" size_t cruse_gru_ws_signal_offset(int B, int G, int Hg) {
-    return xid_bytes_total(B, G) + xg_bytes_total(B, G, Hg) + (size_t)MAX_LAUNCH_TICKETS * 8 * sizeof(unsigned);
+    return 256 + xid_bytes_total(B, G) + xg_bytes_total(B, G, Hg) + (size_t)MAX_LAUNCH_TICKETS * 8 * sizeof(unsigned);
 }
 
 extern "C" int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, const float* const* b_hh,
                                     float* h, void* coef, float* an, float* z, const float* h0, long long h0_bstride,
                                     int B, int T, int TS, int G, int Hg, int prec, int chain_clips, int gi_bf16, void* panels,
-                                    int panels_zeroed, unsigned* status, int xcd_rot, int epoch0, int seq, int chunk_len, void* stream) {
+                                    int panels_zeroed, unsigned* status, int xcd_rot, void* stream) {
     int rc = check_common(B, T, G, Hg, prec, "gru_seq_fwd");
-    CRUSE_REQUIRE(chunk_len >= 0, CRUSE_E_SHAPE, "gru_seq_fwd: chunk_len = %d", chunk_len);
-    CRUSE_REQUIRE(epoch0 >= 0 && seq >= 0 && (epoch0 == 0 || h0 != nullptr), CRUSE_E_SHAPE,
-                  "gru_seq_fwd: epoch0 = %d, seq = %d (a continuation takes its state from h0)", epoch0, seq);
     CRUSE_REQUIRE(!gi_bf16 || (prec == CRUSE_PREC_BF16 && ((uintptr_t)gi % 16) == 0), CRUSE_E_SHAPE,
                   "gru_seq_fwd: bf16 gi rows need CRUSE_PREC_BF16 and a 16-byte aligned base");
     CRUSE_REQUIRE(chain_clips == 0 || chain_clips == 8 || chain_clips == 16, CRUSE_E_SHAPE, "gru_seq_fwd: chain_clips = %d (0, 8, 16)", chain_clips);
@@ -1583,7 +1538,6 @@ extern "C" int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, c
     // wide chains outright and thereby vouches for |h0| < 1 (the continuation of a sequence that started from zero)
     const bool wide_ok = !gi_bf16 && (h0 == nullptr || chain_clips == 16);
     CRUSE_REQUIRE(make_plan(B, G, Hg, prec, true, chain_clips, wide_ok, pl) == 0, CRUSE_E_SHAPE, "gru_seq_fwd: G*Hg/32 exceeds the CU count");
-    CRUSE_REQUIRE(pl.wide || epoch0 == 0 || !panels_zeroed, CRUSE_E_SHAPE, "gru_seq_fwd: continuing epochs (epoch0 = %d) need the wide-chain kernel", epoch0);
     hipStream_t s = (hipStream_t)stream;
     CRUSE_REQUIRE(panels != nullptr && status != nullptr, CRUSE_E_SHAPE, "gru_seq_fwd: workspace / status pointer is NULL");
     // (the status word is sticky: never cleared here.  panels_zeroed: the caller cleared the scratch itself -- e.g. the scratches of
@@ -1595,7 +1549,6 @@ extern "C" int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, c
     for (int g = 0; g < G; ++g) { a.p.w_hh[g] = w_hh[g]; a.p.b_hh[g] = b_hh[g]; }
     a.B = B; a.T = T; a.G = G; a.Hg = Hg;
     a.TS = TS; a.h0 = h0; a.h0_bs = h0_bstride;
-    a.e0 = pl.wide ? epoch0 : 0; a.seq = seq; a.chunk_len = chunk_len;
     const size_t esz = prec == CRUSE_PREC_F32 ? 4 : 2, npl = prec == CRUSE_PREC_BF16X3 ? 2 : 1;
     const size_t lds = (size_t)16 * (Hg + (prec == CRUSE_PREC_F32 ? 4 : 8)) * esz * npl + 4 * 6 * RED_TS * sizeof(float);
     return run_launches<true>(a, pl, G, Hg, prec, panels, status, xcd_rot, lds, s);
@@ -1605,7 +1558,7 @@ extern "C" int cruse_gru_seq_fwd_on(const float* gi, const float* const* w_hh, c
                                     float* h, void* coef, float* an, float* z,
                                     int B, int T, int G, int Hg, int prec, void* panels, unsigned* status, int xcd_rot,
                                     void* stream) {
-    return cruse_gru_seq_fwd_ex(gi, w_hh, b_hh, h, coef, an, z, nullptr, 0, B, T, T, G, Hg, prec, 0, 0, panels, 0, status, xcd_rot, 0, 0, 0, stream);
+    return cruse_gru_seq_fwd_ex(gi, w_hh, b_hh, h, coef, an, z, nullptr, 0, B, T, T, G, Hg, prec, 0, 0, panels, 0, status, xcd_rot, stream);
 }
 
 extern "C" int cruse_gru_seq_fwd(const float* gi, const float* const* w_hh, const float* const* b_hh,
@@ -1622,17 +1575,13 @@ extern "C" int cruse_gru_gate_grads_bf16(const float* dh, const void* coef, cons
 extern "C" int cruse_gru_seq_bwd_ex(const float* dout, const float* const* w_hh, const void* coef, const float* z,
                                     float* dh, const float* an, void* dgi, int dg_slabs, int carry, int B, int T, int TS, int G,
                                     int Hg, int prec, int chain_clips, void* panels, int panels_zeroed, unsigned* status, int xcd_rot,
-                                    int epoch0, int seq, int chunk_len, void* stream) {
+                                    void* stream) {
     int rc = check_common(B, T, G, Hg, prec, "gru_seq_bwd");
-    CRUSE_REQUIRE(chunk_len >= 0, CRUSE_E_SHAPE, "gru_seq_bwd: chunk_len = %d", chunk_len);
-    CRUSE_REQUIRE(epoch0 >= 0 && seq >= 0 && (epoch0 == 0 || carry), CRUSE_E_SHAPE,
-                  "gru_seq_bwd: epoch0 = %d, seq = %d (a continuation carries dh in)", epoch0, seq);
     CRUSE_REQUIRE(chain_clips == 0 || chain_clips == 8 || chain_clips == 16, CRUSE_E_SHAPE, "gru_seq_bwd: chain_clips = %d (0, 8, 16)", chain_clips);
     if (rc) return rc;
     CRUSE_REQUIRE(TS >= T, CRUSE_E_SHAPE, "gru_seq_bwd: clip stride %d frames < %d steps", TS, T);
     Plan pl;
     CRUSE_REQUIRE(make_plan(B, G, Hg, prec, false, chain_clips, true, pl) == 0, CRUSE_E_SHAPE, "gru_seq_bwd: G*Hg/32 exceeds the CU count");
-    CRUSE_REQUIRE(pl.wide || epoch0 == 0 || !panels_zeroed, CRUSE_E_SHAPE, "gru_seq_bwd: continuing epochs (epoch0 = %d) need the wide-chain kernel", epoch0);
     hipStream_t s = (hipStream_t)stream;
     CRUSE_REQUIRE(panels != nullptr && status != nullptr, CRUSE_E_SHAPE, "gru_seq_bwd: workspace / status pointer is NULL");
     if (!panels_zeroed) { int zrc = cruse_zero_async(panels, cruse_gru_ws_bytes(B, G, Hg) - 256, s, "gru_seq_bwd memset"); if (zrc) return zrc; }   // the status word is sticky: never cleared here
@@ -1641,7 +1590,6 @@ extern "C" int cruse_gru_seq_bwd_ex(const float* dout, const float* const* w_hh,
     for (int g = 0; g < G; ++g) { a.p.w_hh[g] = w_hh[g]; a.p.b_hh[g] = nullptr; }
     a.B = B; a.T = T; a.G = G; a.Hg = Hg;
     a.TS = TS; a.carry = carry ? 1 : 0;
-    a.e0 = pl.wide ? epoch0 : 0; a.seq = seq; a.chunk_len = chunk_len;
     const size_t esz = prec == CRUSE_PREC_F32 ? 4 : 2, npl = prec == CRUSE_PREC_BF16X3 ? 2 : 1;
     const size_t lds = (size_t)16 * (3 * Hg + (prec == CRUSE_PREC_F32 ? 4 : 8)) * esz * npl + 4 * 2 * 64 * 4 * sizeof(float);
     CRUSE_REQUIRE(lds <= 160 * 1024, CRUSE_E_SHAPE, "gru_seq_bwd: Hg=%d needs %zu B of LDS", Hg, lds);
@@ -1664,7 +1612,7 @@ extern "C" int cruse_gru_seq_bwd_ex(const float* dout, const float* const* w_hh,
 extern "C" int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh, const void* coef, const float* z,
                                     float* dh, const float* an, void* dgi, int B, int T, int G, int Hg, int prec,
                                     void* panels, unsigned* status, int xcd_rot, void* stream) {
-    return cruse_gru_seq_bwd_ex(dout, w_hh, coef, z, dh, an, dgi, 3, 0, B, T, T, G, Hg, prec, 0, panels, 0, status, xcd_rot, 0, 0, 0, stream);
+    return cruse_gru_seq_bwd_ex(dout, w_hh, coef, z, dh, an, dgi, 3, 0, B, T, T, G, Hg, prec, 0, panels, 0, status, xcd_rot, stream);
 }
 
 extern "C" int cruse_gru_seq_bwd(const float* dout, const float* const* w_hh, const void* coef, const float* z,

@@ -53,24 +53,7 @@ struct GruArgs {
     const float* h0; long long h0_bs; // forward: initial state [B][G*Hg] ("cat" layout), clips h0_bs floats apart; NULL = 0
     int carry;                        // backward: the first iteration takes dh of frame T-1 from the dh buffer (a later
                                       // run of the same sequence wrote it) instead of forming it from dout
-    int e0;                           // wide-chain kernels (gru_w16.hip): hand-off epoch of the run's first step -- the steps the earlier
-                                      // runs of the same sequence took on this (uncleared) panel scratch
-    int seq;                          // ... and the run's index among them: its own XCD tickets and team-handshake magic
-    // CHUNK SIGNALS (chunk_len > 0): when a workgroup's rows of the frames of time chunk c (forward: frames [c L, (c+1) L); backward:
-    // iterations [c L, (c+1) L) counted from the last frame) have left for HBM, its helper / loader wave releases them at agent scope
-    // and adds 1 to sig[c] -- a kernel that waits for sig[c] == number of workgroups (cruse_stream_wait_counter) and everything
-    // behind it in its stream may then read those rows while the recurrence is still running on the later chunks
-    int chunk_len;
-    unsigned* sig;
 };
-
-// (helper / loader wave) the rows of chunk c are written: make them visible to other kernels, then count this workgroup in
-__device__ __forceinline__ void chunk_signal(unsigned* sig, int c, int lane) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(sig + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // LDS panel storage per precision: f32 keeps floats; bf16 / bf16x3 keep 1 / 2 planes of bf16 converted
 // once when the granules arrive, so an MFMA B fragment is one ds_read_b128 per plane.
@@ -272,11 +255,10 @@ __device__ __forceinline__ bool sweep_panel(typename Panel<PREC>::elem* lds, int
 // common coherence point: the step payload can then be published with PLAIN stores (the line stays in that
 // L2, consumers read it with L1-bypassing sc1 loads) instead of write-through stores -- ~0.5 us per step
 // faster.  Any other placement keeps the write-through form; correctness never depends on placement.
-// MAGIC: distinct per launch where several launches share uncleared slots (time chunks: GruArgs::seq).
-__device__ __forceinline__ bool team_shares_xcd(unsigned long long* slots, int P, int part, unsigned* status, int tid,
-                                                const unsigned MAGIC = 0xC0DEFFFFu) {
+__device__ __forceinline__ bool team_shares_xcd(unsigned long long* slots, int P, int part, unsigned* status, int tid) {
     __shared__ int s_same;
     const unsigned my = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xf;      // HW_REG_XCC_ID
+    constexpr unsigned MAGIC = 0xC0DE0001u;
     if (tid == 0)
         __hip_atomic_store(slots + part, ((unsigned long long)my << 32) | MAGIC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid < 64) {

@@ -898,20 +898,13 @@ __global__ __launch_bounds__(320) void gru_bwd_ag_kernel(GruArgs a) {
         // the ring work after the second barrier a step took 1.78 us instead of 1.36 without streams), and the only wait is for
         // the set issued two iterations earlier (exact counts: the loop is branch-free).
         put(2, s0); issue(4, s0);
-        // chunk signals (GruArgs::chunk_len): after the rows of a chunk's last iteration have been issued
-        const int CL = a.chunk_len;
-        int sig_k = CL > 0 ? CL - 1 : 0x7fffffff, sig_c = 0;
-        auto flushed = [&](int k) {
-            if (k >= sig_k) { chunk_signal(a.sig, sig_c, lane); ++sig_c; sig_k += CL; }
-        };
         for (int k = 1; k < a.T; k += 2) {
-            __syncthreads(); put(k + 2, s1); issue(k + 4, s1); flush(k - 1); flushed(k - 1); __syncthreads();
+            __syncthreads(); put(k + 2, s1); issue(k + 4, s1); flush(k - 1); __syncthreads();
             if (k + 1 >= a.T) break;
-            __syncthreads(); put(k + 3, s0); issue(k + 5, s0); flush(k); flushed(k); __syncthreads();
+            __syncthreads(); put(k + 3, s0); issue(k + 5, s0); flush(k); __syncthreads();
         }
         __syncthreads();                                // the last iteration's dh is in LDS
         flush(a.T - 1);
-        if (CL > 0) chunk_signal(a.sig, (a.T - 1) / CL, lane);
         return;
     }
 

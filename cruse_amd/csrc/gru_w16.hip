@@ -1,8 +1,10 @@
 // Persistent GRU recurrence on WIDE chains: 16 clips per chain -- every column of the 16x16x32 MFMA carries a clip (the chains of 8
 // of gru.hip / gru_tf.hip leave columns 8..15 empty: PMC MFMA utilisation 0.09 against 0.043 algorithmic) -- so a batch of 64 at
-// Hg = 640 is 4 chains x 20 workgroups = 80 CUs per recurrence, and BOTH layers of the GGRU (nn.GRU x 2, model/cruse_net.py:41-51)
-// are co-resident: layer 2 at frame t needs layer 1 at frames <= t only, so the two recurrences run as a time-chunk wavefront
-// (cruse_amd/model/cruse_net.py: _ggru_forward_wave / _ggru_backward_wave) instead of one after the other.
+// Hg = 640 is 4 chains x 20 workgroups = 80 CUs per recurrence and a batch of 128 fits the chip in ONE launch (nn.GRU forward / backward
+// at model/cruse_net.py:23-31,44,50).  This is the library's plan for batches whose chains of 8 exceed the CUs (make_plan: B > 96 at
+// Hg = 640; forward 1.32 us per step for 16 clips against 1.17 for 8, backward 1.61 against 1.34 -- the round-3 wide kernels took 1.77 /
+// 3.08).  Round 5 also ran both GGRU layers co-resident on these chains as a time-chunk wavefront: slower than the serial schedule on
+// chains of 8 at B = 64 (profiles/r05_wavefront_chain.txt) -- that schedule is gone, the kernels stay.
 //
 // Both kernels are the round-4 kernels' steps widened (bf16 mode, Hg % 128 == 0, Hg <= 640):
 //   * hand-off: tag-free (the epoch bit in bit 14 of every published bf16, gru_tf.hip) and REGISTER-DIRECT -- the panel is laid out
@@ -16,10 +18,8 @@
 //   * backward (gru_bwd_w16_kernel): gru_bwd_ag_kernel<.., RD>'s all-gather step on EIGHT compute waves (K = 3 Hg split eight ways:
 //     16 weight + 8 fragment vectors per lane instead of 30 + 15, which would not fit the 256 registers a five-wave workgroup
 //     leaves) plus the loader wave: 9 waves, <= 168 registers, one (clip, unit) of pointwise work per thread;
-//   * EPOCHS CONTINUE ACROSS LAUNCHES (GruArgs::e0): a sequence run as consecutive time chunks keeps counting its hand-off epochs
-//     where the previous chunk stopped, so the chunks of one recurrence share ONE panel scratch that is cleared once per training
-//     step; the first step of a continuation takes its state from the h / dh rows the previous launch wrote (kernel boundary), not
-//     from a panel.  Per-launch state (XCD tickets, the team handshake) is keyed by GruArgs::seq.
+//   * a sequence may be run as consecutive time chunks (cruse_gru_seq_*_ex sub-sequences): the first step of a continuation takes its
+//     state from the h / dh rows the previous launch wrote (kernel boundary), not from a panel.
 #include "gru_common.h"
 
 namespace {
@@ -54,7 +54,6 @@ __global__ __launch_bounds__(320) void gru_fwd_w16_kernel(GruArgs a) {
     const float* bh = a.p.b_hh[grp];
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.xg, 0, a.xg_bytes, 0x00020000);
     const unsigned cbase = (unsigned)chain * 2u * panel_bytes;
-    const unsigned magic = 0xC0DE0000u | ((unsigned)a.seq & 0xffffu);
 
     const unsigned frame_bytes = (unsigned)H * 4u, grow_bytes = (unsigned)(a.G * 3 * Hg) * 4u, crow_bytes = grow_bytes >> 1;
     const long long nrow = (long long)(a.B - 1) * a.TS + a.T;           // rows reachable from the (advanced) base pointers
@@ -126,7 +125,7 @@ __global__ __launch_bounds__(320) void gru_fwd_w16_kernel(GruArgs a) {
         issue(0, s0); issue(1, s1);
         put(0, s0); put(1, s1);
         issue(2, s0); issue(3, s1);
-        (void)team_shares_xcd(a.xid + (size_t)chain * 64, a.P, part, a.status, tid, magic);   // mirrors the compute waves' barriers
+        (void)team_shares_xcd(a.xid + (size_t)chain * 64, a.P, part, a.status, tid);   // mirrors the compute waves' barriers
         __syncthreads();
         // step t: two barriers (t > 0, or a continuation's first step).  The gi set for step t + 2 goes to its ring slot, the set is
         // re-issued for step t + 4; the saves of step t - 1 are in LDS once the first barrier of step t has passed.
@@ -191,14 +190,14 @@ __global__ __launch_bounds__(320) void gru_fwd_w16_kernel(GruArgs a) {
         hp[0] = hs[0]; hp[1] = hs[1];
     }
     bool nowait = false;
-    const bool plain = team_shares_xcd(a.xid + (size_t)chain * 64, a.P, part, a.status, tid, magic);
+    const bool plain = team_shares_xcd(a.xid + (size_t)chain * 64, a.P, part, a.status, tid);
     __syncthreads();                                       // ring slots 0 and 1 are filled
     float gic[3][2];
 #pragma unroll
     for (int g = 0; g < 3; ++g) { const float2 v = *reinterpret_cast<const float2*>(gi0 + g * 32); gic[g][0] = v.x; gic[g][1] = v.y; }
 
     for (int t = 0; t < a.T; ++t) {
-        const unsigned et = (unsigned)(t + a.e0);          // epoch of this step's INPUT panel (parity (et - 1) & 1)
+        const unsigned et = (unsigned)t;                   // epoch of this step's INPUT panel (parity (et - 1) & 1)
         if constexpr (TIMED) tq0 = __builtin_amdgcn_s_memtime();
         if (t > 0) {
             const unsigned soff = cbase + ((et - 1u) & 1u) * panel_bytes;
@@ -332,7 +331,6 @@ __global__ __launch_bounds__(576) void gru_bwd_w16_kernel(GruArgs a) {
     const float* W = a.p.w_hh[grp];
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.xg, 0, a.xg_bytes, 0x00020000);
     const unsigned cbase = (unsigned)chain * 2u * panel_bytes;
-    const unsigned magic = 0xC0DE0000u | ((unsigned)a.seq & 0xffffu);
 
     const unsigned frame_bytes = (unsigned)H * 4u, crow_bytes = (unsigned)(a.G * K3) * 2u;
     const long long nrow = (long long)(a.B - 1) * a.TS + a.T;           // rows reachable from the (advanced) base pointers
@@ -443,7 +441,7 @@ __global__ __launch_bounds__(576) void gru_bwd_w16_kernel(GruArgs a) {
         issue(1, s1);
         put(0, s0); put(1, s1);
         issue(2, s0); issue(3, s1);
-        (void)team_shares_xcd(a.xid + (size_t)chain * 64, P, part, a.status, tid, magic);    // mirrors the compute waves' barriers
+        (void)team_shares_xcd(a.xid + (size_t)chain * 64, P, part, a.status, tid);    // mirrors the compute waves' barriers
         __syncthreads();
         // iteration k > 0 has two barriers (sweep returned; partial sums complete); ALL loader work sits between them (gru_bwd_ag_kernel)
         put(2, s0); issue(4, s0);
@@ -492,14 +490,14 @@ __global__ __launch_bounds__(576) void gru_bwd_w16_kernel(GruArgs a) {
 
     float dh = 0.f, dd = 0.f, zz = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;    // operands of the current step (time s)
     bool nowait = false;
-    const bool plain = team_shares_xcd(a.xid + (size_t)chain * 64, P, part, a.status, tid, magic);
+    const bool plain = team_shares_xcd(a.xid + (size_t)chain * 64, P, part, a.status, tid);
     __syncthreads();                                                      // ring slots 0 and 1 are filled
     dd = (&op_d[0][0][0])[opo];
     c0 = (float)op_c[0][clip][u]; c1 = (float)op_c[0][clip][32 + u]; c2 = (float)op_c[0][clip][64 + u];
 
     for (int k = 0; k < a.T; ++k) {
         const int s = a.T - 1 - k;
-        const unsigned ek = (unsigned)(k + a.e0);
+        const unsigned ek = (unsigned)k;
         float m = 0.f;
         if constexpr (TIMED) tq0 = __builtin_amdgcn_s_memtime();
         if (k > 0) {
@@ -603,8 +601,8 @@ __global__ __launch_bounds__(576) void gru_bwd_w16_kernel(GruArgs a) {
 
 namespace cruse_gru {
 
-// wide chains: bf16 mode, whole 128-unit k groups; the forward kernel takes f32 gi rows and either no initial state or the
-// continuation of its own sequence (e0 > 0: |h| < 1 is what the tag-free format needs)
+// wide chains: bf16 mode, whole 128-unit k groups; the forward kernel takes f32 gi rows and either no initial state or one with
+// |h0| < 1 (the continuation of a sequence that started from zero: the tag-free format needs |h| < 2)
 bool w16_eligible(int Hg, int prec) {
     return prec == CRUSE_PREC_BF16 && Hg % 128 == 0 && Hg >= 128 && Hg <= 640;
 }

@@ -951,9 +951,9 @@ extern "C" int cruse_ln_fwd_c(const float* x, const float* gamma, const float* b
 
 static int lnb_grid() { return cruse_opt("lnb_grid", 512); }
 
-extern "C" int cruse_ln_bwd_seg(const float* dy, const float* x, const float* mean, const float* rstd,
-                                const float* gamma, long long rows, int H, int interleave_g,
-                                float* dx, float* dgamma, float* dbeta, int seg_len, long long seg_stride, long long seg_off, void* stream) {
+static int ln_bwd_impl(const float* dy, const float* x, const float* mean, const float* rstd,
+                       const float* gamma, long long rows, int H, int interleave_g,
+                       float* dx, float* dgamma, float* dbeta, int seg_len, long long seg_stride, long long seg_off, void* stream) {
     CRUSE_REQUIRE(rows > 0 && H > 0 && H <= 64 * LN_MAXE, CRUSE_E_SHAPE, "ln_bwd: H=%d must be in 1..%d", H, 64 * LN_MAXE);
     CRUSE_REQUIRE(interleave_g >= 1 && H % interleave_g == 0, CRUSE_E_SHAPE, "ln_bwd: groups=%d must divide H=%d", interleave_g, H);
     CRUSE_REQUIRE(seg_len >= 0 && (seg_len == 0 || (seg_stride >= seg_len && seg_off >= 0 && rows % seg_len == 0)), CRUSE_E_SHAPE,
@@ -979,7 +979,7 @@ extern "C" int cruse_ln_bwd_seg(const float* dy, const float* x, const float* me
 extern "C" int cruse_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                             const float* gamma, long long rows, int H, int interleave_g,
                             float* dx, float* dgamma, float* dbeta, void* stream) {
-    return cruse_ln_bwd_seg(dy, x, mean, rstd, gamma, rows, H, interleave_g, dx, dgamma, dbeta, 0, 0, 0, stream);
+    return ln_bwd_impl(dy, x, mean, rstd, gamma, rows, H, interleave_g, dx, dgamma, dbeta, 0, 0, 0, stream);
 }
 
 extern "C" int cruse_mask_loss_fwd(const float* mask, const float* nre, const float* nim, const float* cmag,

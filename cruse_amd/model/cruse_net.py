@@ -289,140 +289,6 @@ def ggru_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], prefix: str, group
                              late_leaves=late_leaves, x_bf16=x_bf16)
 
 
-_AUX = {}
-
-
-def _wave_streams():
-    """the two extra streams of the GGRU wavefront: [0] the second recurrence, [1] the in-between kernels of a chunk"""
-    dev = torch.cuda.current_device()
-    if dev not in _AUX:
-        import os
-        pr = int(os.environ.get("CRUSE_WAVE_PRIO", "0"))
-        _AUX[dev] = (torch.cuda.Stream(priority=-1 if pr & 1 else 0), torch.cuda.Stream(priority=-1 if pr & 2 else 0))
-    return _AUX[dev]
-
-
-_FORK_DUMMY = {}
-
-
-def fork_stream(stream, main) -> None:
-    """`stream` joins the work of `main` (event fork).  Under HIP-graph capture the stream's FIRST captured node is a one-word dummy
-    fill: on ROCm 7.2 the first kernel node of a freshly forked stream has been seen to replay BEFORE the node it depends on (r3: the
-    chunk pipeline's projection read the previous replay's rows; r5: the chunk-signal wait ran before the step's scratch clear and
-    let LayerNorm 1 through early -- test_graph_replay_on_a_new_batch_equals_eager_launches); with any other node first the replay
-    equals the eager launches."""
-    stream.wait_event(record_event(main))
-    if torch.cuda.is_current_stream_capturing():
-        dev = torch.cuda.current_device()
-        if dev not in _FORK_DUMMY:
-            _FORK_DUMMY[dev] = torch.zeros(64, device="cuda", dtype=torch.float32)
-        with torch.cuda.stream(stream):
-            ops.zero_(_FORK_DUMMY[dev])
-
-
-def _time_chunks(T: int, n: int):
-    base = T // n
-    return [(j * base, base if j + 1 < n else T - j * base) for j in range(n)]
-
-
-def _wave_chunks(prec, Hg: int, g: int, B: int, T: int, slot: int, x_bf16, save: bool) -> int:
-    """Time chunks of the GGRU WAVEFRONT (EngineConfig.ggru_wave; 0 / 1 = off): layer 2 at frame t needs layer 1 at frames <= t only
-    (cruse_net.py:41-51: the LayerNorm between them is per frame, the gate projection a GEMM over rows), so on WIDE chains
-    (gru_w16.hip: 16 clips per chain, half the workgroups) the two recurrences are co-resident and run one chunk apart -- forward
-    and, mirrored, backward.  Needs the bf16 gate-GEMM path with the operand copies written by the producing kernels, one group
-    (the LayerNorm's interleave is then the identity), Hg % 128 == 0 <= 640, both layers' teams on the chip at once, and enough
-    frames per chunk to amortise a recurrence launch (~18 us: weights to registers)."""
-    n = int(config.get().ggru_wave or 0)
-    if (n < 2 or slot != 0 or g != 1 or not save or x_bf16 is None or not _gi_takes_bf16_copy(prec, Hg) or Hg % 128 or Hg > 640
-            or not SIDE.enabled):
-        return 1
-    # (<= 4 chains per layer: with xcd_rot 0 / 4 the two launches then sit on disjoint XCD halves)
-    if (B + 15) // 16 > 4 or torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count < 8 * (Hg // 32):
-        return 1
-    while n > 1 and T < 32 * n:
-        n -= 1
-    return n
-
-
-def _overlap_chunks(prec, Hg: int, g: int, B: int, T: int, slot: int, fwd: bool) -> int:
-    """Time chunks of the CHUNK-SIGNAL overlap (EngineConfig.ggru_overlap; 0 / 1 = off): the recurrence runs as ONE launch and counts
-    a chunk's workgroups in as their rows reach HBM (cruse_gru_seq_*_ex(chunk_len)); an auxiliary stream waits for the count
-    (cruse_stream_wait_counter) and runs the kernels BETWEEN the two recurrences chunk by chunk beside the running one -- forward
-    LayerNorm 1 + the layer-2 gate projection, backward the input-gradient GEMM + LayerNorm-1 backward (and layer 1's input gradient
-    beside its own recurrence) -- so only the last chunk's share of them is left on the main stream's chain.  Inside a training step
-    only (the step's one scratch clear also zeroes the counters), g = 1."""
-    n = int(config.get().ggru_overlap or 0)
-    if n < 2 or slot != 0 or g != 1 or not SIDE.enabled or STEP_SCRATCH.key != (B, g, Hg) or T < 16 * n:
-        return 0
-    cl = (T + n - 1) // n
-    return n if ops.gru_chunk_signals_ok(B, T, g, Hg, prec, fwd, cl) else 0
-
-
-def _ggru_forward_wave(x, x_bf16, P, prefix, g, Hg, prec, save, nch, ctx, project):
-    """GGRU layers 1 and 2 as a time-chunk WAVEFRONT on wide chains (cruse_gru_seq_fwd_ex(chain_clips = 16, epoch0, seq): the chunks
-    of a recurrence share one panel scratch and continue its hand-off epochs; results identical to the single launches):
-
-        main:  gi1 | rec1(c0) | rec1(c1) | rec1(c2) | ...
-        aux :             ln1 + gi2 (c0) | ln1 + gi2 (c1) | ...
-        sB  :                            rec2(c0)  | rec2(c1) | ...
-
-    project(inp, inp_copy, lname, gi, seg): the layer's gate projection (whole tensor or one chunk).
-    Returns (h1, c1, a1, z1, l1, l1_copy, m1, s1, h2, c2, a2, z2)."""
-    B, T, H = x.shape
-    rows = B * T
-    dev = x.device
-    main = torch.cuda.current_stream()
-    sB, aux = _wave_streams()
-    chunks = _time_chunks(T, nch)
-    f16_2 = _gi_f16(prec, Hg, 1)
-    # everything the other streams touch is allocated here, on the main stream
-    gi1 = torch.empty(B, T, g * 3 * Hg, device=dev, dtype=torch.float32)
-    gi2 = torch.empty_like(gi1)
-    l1 = torch.empty(B, T, H, device=dev, dtype=torch.float32)
-    l1_c = torch.empty(rows * H, device=dev, dtype=torch.float16 if f16_2 else torch.bfloat16)
-    m1 = torch.empty(rows, device=dev, dtype=torch.float32)
-    s1 = torch.empty(rows, device=dev, dtype=torch.float32)
-    outs = []
-    for _ in range(2):
-        h = torch.empty(B, T, H, device=dev, dtype=torch.float32)
-        outs.append((h, torch.empty(B, T, 3 * H, device=dev, dtype=torch.bfloat16), torch.empty_like(h), torch.empty_like(h)))
-    out1, out2 = outs
-    w1 = [P[f"{prefix}gru_list1.{i}.weight_hh_l0"] for i in range(g)]; b1 = [P[f"{prefix}gru_list1.{i}.bias_hh_l0"] for i in range(g)]
-    w2 = [P[f"{prefix}gru_list2.{i}.weight_hh_l0"] for i in range(g)]; b2 = [P[f"{prefix}gru_list2.{i}.bias_hh_l0"] for i in range(g)]
-    project(x, x_bf16, "gru_list1", gi1, None)
-    prep2 = project(None, None, "gru_list2", None, None)          # (the K-tiled W_ih of layer 2, made once, on the main stream)
-    slot1, z1 = STEP_SCRATCH.take(B, g, Hg, 0)
-    slot2, z2 = STEP_SCRATCH.take(B, g, Hg, 0)
-    if not z1 or not z2:                                           # outside a training step: two private scratches, cleared per launch
-        slot1, z1, slot2, z2 = 1, False, 2, False
-
-    ev_on = record_event
-    start = ev_on(main)
-    sB.wait_event(start); aux.wait_event(start)
-    for j, c in enumerate(chunks):
-        launch = (lambda c=c, j=j: ops.gru_seq_fwd(gi1, w1, b1, B, T, g, Hg, prec, save=save, out=out1, chunk=c, wide=True, slot=slot1,
-                                                   zeroed=z1, seq=j if z1 else None, xcd_rot=0))
-        if j == 0:
-            SIDE.release_around(launch)
-        else:
-            launch()
-        e_r = ev_on(main)
-        with torch.cuda.stream(aux):
-            aux.wait_event(e_r)                           # h1 of chunk j is complete
-            ops.ln_fwd(out1[0], P[prefix + "ln1.weight"], P[prefix + "ln1.bias"], None, B * c[1], H, 1, save=True, out=l1, out_bf16=l1_c,
-                       seg=(c[1], T, c[0]), stats=(m1, s1))
-            project(l1, l1_c, "gru_list2", gi2, (c[1], T, c[0]), prep2)
-            e_q = ev_on(aux)
-        with torch.cuda.stream(sB):
-            sB.wait_event(e_q)
-            ops.gru_seq_fwd(gi2, w2, b2, B, T, g, Hg, prec, save=save, out=out2, chunk=c, wide=True, slot=slot2, zeroed=z2,
-                            seq=j if z2 else None, xcd_rot=4)
-    wait_stream(main, aux)
-    wait_stream(main, sB)
-    ctx["_wave_keep"] = (gi1, gi2)
-    return out1 + (l1, l1_c, m1, s1) + out2
-
-
 def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=None, slot=0, xcd_rot=0, pre_done=None,
                       residual_ready=None, late_leaves=None, x_bf16=None):
     """residual_ready(): called right before the residual is read (the last layer norm) -- the caller may still be
@@ -497,9 +363,8 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
         if hooks:
             hooks.pop()()                    # the pre-stage of this slice is issued: the next slice may start its own
         slot_, zeroed = STEP_SCRATCH.take(B, g, Hg, slot)
-        wide = int(config.get().gru_wide or 0) & 1 and not gi_bf
         return SIDE.release_around(lambda: ops.gru_seq_fwd(gi, w_hh, b_hh, B, T, g, Hg, prec, save=save, slot=slot_,
-                                                           xcd_rot=xcd_rot, zeroed=zeroed, wide=bool(wide)))
+                                                           xcd_rot=xcd_rot, zeroed=zeroed))
 
     # The K-tiled time-major bf16 copies of x, h1, l1, h2 -- the K operands of the four weight-gradient GEMMs -- depend on
     # the forward pass only.  From the first backward recurrence on, the side streams' queue is what the optimizer step
@@ -510,8 +375,8 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
     ctx["tn"] = tn
     tt = {}
 
-    def queue_layer1_leaves(h1, l1, l1_bf, late=None):
-        """queued for the launch of the second forward recurrence (wavefront: for the decoder -- `late` -- both recurrences have run)"""
+    def queue_layer1_leaves(h1, l1, l1_bf):
+        """queued for the launch of the second forward recurrence"""
         if tn:                                   # the TN weight-gradient GEMMs read the layer inputs row-major (bf16 copy if made)
             ctx["in_bf"] = {"gru_list1": x_bf16, "gru_list2": l1_bf}
         if not fwd_T:
@@ -534,90 +399,18 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
                     w_ts[(lname, i)] = ops.transpose_bf16(P[f"{prefix}{lname}.{i}.weight_ih_l0"], 3 * Hg, Hg, out=stack[i])
                 w_ts[(lname, "stack")] = stack
         ctx["w_ts"] = w_ts
-        if late is not None:
-            late.append((t_layer1, (x, h1, l1) + (() if tn else (tt["xT"], tt["h1T"], tt["l1T"]))))
-        elif tn:
+        if tn:
             SIDE.defer(t_layer1, kind=1, lane=2)
         else:
             SIDE.defer(t_layer1, x, h1, l1, tt["xT"], tt["h1T"], tt["l1T"], kind=1, lane=2)
 
-    def wave_project(inp, inp_c, lname, gi, seg, prep=None):
-        """g == 1 gate projection of the wavefront: the whole tensor (seg None) or one time chunk; gi None: only prepare (and return)
-        the K-tiled W_ih operand planes"""
-        li = 0 if lname == "gru_list1" else 1
-        w_ih, b_ih = P[f"{prefix}{lname}.0.weight_ih_l0"], P[f"{prefix}{lname}.0.bias_ih_l0"]
-        f16 = _gi_f16(prec, Hg, li)
-        x3 = (_gi_x3_knob(Hg) >> li) & 1
-        if prep is None:
-            prep = ((ops.ktile_f16(w_ih, 3 * Hg, Hg), None) if f16 else
-                    ops.ktile_bf16(w_ih, 3 * Hg, Hg, split=True) if x3 else (ops.ktile_bf16(w_ih, 3 * Hg, Hg), None))
-        if gi is None:
-            return prep
-        w_hi, w_lo = prep
-        if f16 and seg is None:
-            ops.gemm_f16_nt(rows, 3 * Hg, Hg, inp_c, 0, H, w_hi, 0, 64, gi, 0, 3 * H, bias=b_ih, b_kstride=3 * Hg * 64)
-        elif f16:
-            ops.gemm_f16_nt_seg(B * seg[0], 3 * Hg, Hg, inp_c, 0, H, w_hi, 0, 64, gi, 0, 3 * H, seg, bias=b_ih, b_kstride=3 * Hg * 64)
-        elif seg is not None:
-            ops.gemm_bf16_nt_seg(B * seg[0], 3 * Hg, Hg, inp_c, None, 0, H, w_hi, w_lo, 0, 64, gi, 0, 3 * H, seg, bias=b_ih, b_kstride=3 * Hg * 64)
-        elif x3:
-            ops.gemm_bf16x3_nt(rows, 3 * Hg, Hg, inp_c, None, 0, H, w_hi, w_lo, 0, 64, gi, 0, 3 * H, bias=b_ih, b_kstride=3 * Hg * 64)
-        else:
-            ops.gemm_bf16_nt(rows, 3 * Hg, Hg, inp_c, 0, H, w_hi, 0, 64, gi, 0, 3 * H, bias=b_ih, b_kstride=3 * Hg * 64)
-        return prep
-
-    nch = _wave_chunks(prec, Hg, g, B, T, slot, x_bf16, save)
-    ctx["wave"] = nch
-    if nch > 1 and config.get().ggru_wave_fwd:
-        if hooks:
-            hooks.pop()()
-        h1, c1, a1, z1, l1, l1_bf, m1, s1, h2, c2, a2, z2 = _ggru_forward_wave(x, x_bf16, P, prefix, g, Hg, prec, save, nch, ctx, wave_project)
-        queue_layer1_leaves(h1, l1, l1_bf, late=late_leaves)
-    elif (save and x_bf16 is not None and _gi_takes_bf16_copy(prec, Hg) and not gi_bf
-          and _overlap_chunks(prec, Hg, g, B, T, slot, True) > 1):
-        # ---- chunk-signal overlap: LayerNorm 1 + the layer-2 projection of a chunk run on the aux stream beside the layer-1 recurrence ----
-        nov = _overlap_chunks(prec, Hg, g, B, T, slot, True)
-        CL = (T + nov - 1) // nov
-        dev = x.device
-        gi1 = torch.empty(B, T, 3 * H, device=dev, dtype=torch.float32)
-        gi2 = torch.empty_like(gi1)
-        f16 = _gi_f16(prec, Hg, 1)
-        l1 = torch.empty(B, T, H, device=dev, dtype=torch.float32)
-        l1_bf = torch.empty(rows * H, device=dev, dtype=torch.float16 if f16 else torch.bfloat16)
-        m1 = torch.empty(rows, device=dev, dtype=torch.float32); s1 = torch.empty(rows, device=dev, dtype=torch.float32)
-        wave_project(x, x_bf16, "gru_list1", gi1, None)
-        prep2 = wave_project(None, None, "gru_list2", None, None)
-        if hooks:
-            hooks.pop()()
-        w1 = [P[f"{prefix}gru_list1.0.weight_hh_l0"]]; b1 = [P[f"{prefix}gru_list1.0.bias_hh_l0"]]
-        w2 = [P[f"{prefix}gru_list2.0.weight_hh_l0"]]; b2 = [P[f"{prefix}gru_list2.0.bias_hh_l0"]]
-        main = torch.cuda.current_stream()
-        aux = _wave_streams()[1]
-        slot1, zr1 = STEP_SCRATCH.take(B, g, Hg, slot)
-        fork_stream(aux, main)
-        h1, c1, a1, z1 = SIDE.release_around(lambda: ops.gru_seq_fwd(gi1, w1, b1, B, T, g, Hg, prec, save=save, slot=slot1, xcd_rot=xcd_rot,
-                                                                     zeroed=zr1, chunk_len=CL))
-        with torch.cuda.stream(aux):
-            for c in range((T + CL - 1) // CL):
-                seg = (min(CL, T - c * CL), T, c * CL)
-                ops.gru_wait_chunk(B, g, Hg, dev, slot1, c)
-                ops.ln_fwd(h1, P[prefix + "ln1.weight"], P[prefix + "ln1.bias"], None, B * seg[0], H, 1, save=True, out=l1, out_bf16=l1_bf,
-                           seg=seg, stats=(m1, s1))
-                wave_project(l1, l1_bf, "gru_list2", gi2, seg, prep2)
-        wait_stream(main, aux)
-        queue_layer1_leaves(h1, l1, l1_bf)
-        slot2, zr2 = STEP_SCRATCH.take(B, g, Hg, slot)
-        h2, c2, a2, z2 = SIDE.release_around(lambda: ops.gru_seq_fwd(gi2, w2, b2, B, T, g, Hg, prec, save=save, slot=slot2, xcd_rot=xcd_rot,
-                                                                     zeroed=zr2))
-        ctx["_ov_keep"] = (gi1, gi2)
-    else:
-        h1, c1, a1, z1 = layer(x, "gru_list1", x_bf16)
-        f16 = _gi_f16(prec, Hg, 1)
-        l1_bf = (torch.empty(rows * H, device=x.device, dtype=torch.float16 if f16 else torch.bfloat16)
-                 if _gi_takes_bf16_copy(prec, Hg) and not (f16 and g > 1) else None)
-        l1, m1, s1 = ops.ln_fwd(h1, P[prefix + "ln1.weight"], P[prefix + "ln1.bias"], None, rows, H, g, save=save, out_bf16=l1_bf)
-        queue_layer1_leaves(h1, l1, l1_bf)
-        h2, c2, a2, z2 = layer(l1, "gru_list2", l1_bf)
+    h1, c1, a1, z1 = layer(x, "gru_list1", x_bf16)
+    f16 = _gi_f16(prec, Hg, 1)
+    l1_bf = (torch.empty(rows * H, device=x.device, dtype=torch.float16 if f16 else torch.bfloat16)
+             if _gi_takes_bf16_copy(prec, Hg) and not (f16 and g > 1) else None)
+    l1, m1, s1 = ops.ln_fwd(h1, P[prefix + "ln1.weight"], P[prefix + "ln1.bias"], None, rows, H, g, save=save, out_bf16=l1_bf)
+    queue_layer1_leaves(h1, l1, l1_bf)
+    h2, c2, a2, z2 = layer(l1, "gru_list2", l1_bf)
     if residual_ready is not None:
         residual_ready()
     out, m2, s2 = ops.ln_fwd(h2, P[prefix + "ln2.weight"], P[prefix + "ln2.bias"], residual, rows, H, 1, save=save, out=out)
@@ -675,10 +468,9 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
         if hooks:
             hooks.pop()()
         slot_, zeroed = STEP_SCRATCH.take(B, g, Hg, slot)
-        wide = int(config.get().gru_wide or 0) & 2
         return SIDE.release_around(lambda: ops.gru_seq_bwd(dout_h, w_hh, coef, z, B, T, g, Hg, prec, slot=slot_,
                                                            xcd_rot=xcd_rot, an=an, want_dgi=an is not None, dg_slabs=dg_slabs,
-                                                           zeroed=zeroed, wide=bool(wide)))
+                                                           zeroed=zeroed))
 
     def layer_bwd_tn(dout_h, lname, inp, h, coef, an, z, need_dinp, last):
         """CRUSE_PREC_BF16 with row-major operands only (_dw_tn): the recurrence writes dh and the 4-slab gate-gradient rows;
@@ -725,21 +517,14 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
             return dx, dx_accum
         return torch.empty(B, T, H, device=dout_h.device, dtype=torch.float32), False
 
-    def layer_bwd_bf16(dout_h, lname, inp, h, coef, an, z, need_dinp, last, pre=None):
-        """CRUSE_PREC_BF16: every product as gemm_bf16_nt on bf16 operand copies (see gemm_bf16.hip).
-        pre = (dh, dgi): the wavefront has already run the recurrence and the input gradient in time chunks -- only the
-        weight-gradient leaf is left (issued at once for layer 2: the side stream then waits for the last layer-2 chunk only)."""
+    def layer_bwd_bf16(dout_h, lname, inp, h, coef, an, z, need_dinp, last):
+        """CRUSE_PREC_BF16: every product as gemm_bf16_nt on bf16 operand copies (see gemm_bf16.hip)."""
         names = [f"{prefix}{lname}.{i}." for i in range(g)]
         w_hh = [P[nm + "weight_hh_l0"] for nm in names]
         bias_ih = [G[nm + "bias_ih_l0"] for nm in names]
         bias_hh = [G[nm + "bias_hh_l0"] for nm in names]
         ldT = (rows + 63) // 64 * 64
-        if pre is not None:
-            dh, dgi = pre
-            dgT = torch.empty(ldT // 64, g, 4, Hg, 64, device=dh.device, dtype=torch.bfloat16)
-            made_dgT = False
-            need_dinp = False
-        elif fuse_dgi and SIDE.enabled:
+        if fuse_dgi and SIDE.enabled:
             # the recurrence writes dgi itself (its loader wave), dX starts right behind it; the time-major copies for the
             # weight-gradient GEMMs and the bias sums are made by the weight-gradient leaf, off the main stream
             dh, dgi = run_bwd(dout_h, w_hh, coef, z, an)
@@ -789,7 +574,7 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
 
         # The last layer's weight-gradient leaf goes to the side stream BEFORE the dX GEMM is issued: its event then follows the
         # gate-gradient pass, not the GEMM, and the three dW products start ~150 us earlier (5.40 vs 5.46 ms).
-        early_leaf = (last and not defer_last) or (pre is not None and not last)
+        early_leaf = last and not defer_last
         if early_leaf:
             SIDE.run(weight_grads, dgT, h, inp, inpT, hpT, dh, lane=2)
         dinp, acc_dx = dinp_buffer(dout_h, need_dinp, last)
@@ -874,142 +659,6 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
         SIDE.defer(early_transposes, x1T, h1T, kind=4, lane=2)
     dh2 = ops.ln_bwd(dout, ctx["h2"], ctx["m2"], ctx["s2"], P[prefix + "ln2.weight"], rows, H, 1,
                      G[prefix + "ln2.weight"], G[prefix + "ln2.bias"])
-    nch = int(ctx.get("wave", 0))
-    if nch > 1 and _bf16_gemm_path(prec, Hg) and g == 1 and not ctx.get("tn") and SIDE.enabled and int(config.get().ggru_wave or 0) >= 2 and config.get().ggru_wave_bwd:
-        # ---- the backward WAVEFRONT (see _ggru_forward_wave): in reverse time, layer 2's recurrence one chunk ahead of layer 1's ----
-        #   main:  rec2'(c3) | rec2'(c2) | rec2'(c1) | rec2'(c0) |                  (+ layer 2's weight-gradient leaf on the side stream)
-        #   aux :            dX2 + ln1'(c3) | dX2 + ln1'(c2) | ...
-        #   sB  :                           rec1'(c3), dX1(c3) | rec1'(c2), dX1(c2) | ...
-        # Both recurrences write their gate-gradient rows themselves (DGI); the time-major copies the weight gradients read are
-        # made by the leaves, off the critical path.
-        if hooks:
-            hooks.pop()()
-        dev = dout.device
-        main = torch.cuda.current_stream()
-        sB, aux = _wave_streams()
-        chunks = _time_chunks(T, nch)
-        dhh2 = torch.empty(B, T, H, device=dev, dtype=torch.float32); dhh1 = torch.empty_like(dhh2)
-        dgi2 = ops.dgi_buffer(rows, g, Hg, dev); dgi1 = ops.dgi_buffer(rows, g, Hg, dev)
-        dl1 = torch.empty(B, T, H, device=dev, dtype=torch.float32); dh1_in = torch.empty_like(dl1)
-        w_ts = ctx.get("w_ts", {})
-        wt = {}
-        for lname in ("gru_list1", "gru_list2"):
-            wt[lname] = w_ts.get((lname, 0))
-            if wt[lname] is None:
-                wt[lname] = ops.transpose_bf16(P[f"{prefix}{lname}.0.weight_ih_l0"], 3 * Hg, Hg)
-        whh = {ln_: [P[f"{prefix}{ln_}.0.weight_hh_l0"]] for ln_ in ("gru_list1", "gru_list2")}
-        slot2, z2 = STEP_SCRATCH.take(B, g, Hg, slot)
-        slot1, z1 = STEP_SCRATCH.take(B, g, Hg, slot)
-        if not z1 or not z2:
-            slot1, z1, slot2, z2 = 1, False, 2, False
-
-        ev_on = record_event
-
-        def dX(lname, dgi_, out_, c, acc):
-            ops.gemm_bf16_nt_seg(B * c[1], Hg, wt[lname].shape[0] * 64, dgi_, None, 0, 3 * H, wt[lname], None, 0, 64, out_, 0, H, (c[1], T, c[0]),
-                                 accumulate=acc, b_kstride=Hg * 64)
-
-        dx_checked = False
-        start = ev_on(main)
-        sB.wait_event(start); aux.wait_event(start)
-
-        def dX1(c):
-            nonlocal dx_checked
-            if not need_dx:
-                return
-            if not dx_checked and dx_accum and dx_ready is not None:
-                dx_ready()                                   # (on the stream that adds into dx: the skip leaf that fills it has run)
-            dx_checked = True
-            dX("gru_list1", dgi1, dx, c, dx_accum)
-
-        for j, c in enumerate(reversed(chunks)):
-            launch = (lambda c=c, j=j: ops.gru_seq_bwd(dh2, whh["gru_list2"], ctx["c2"], ctx["z2"], B, T, g, Hg, prec, an=ctx["a2"], want_dgi=True,
-                                                       out=(dhh2, dgi2), chunk=c, wide=True, slot=slot2, zeroed=z2, seq=j if z2 else None, xcd_rot=0))
-            if j == 0:
-                SIDE.release_around(launch)
-            else:
-                launch()
-            e_r = ev_on(main)
-            with torch.cuda.stream(aux):
-                aux.wait_event(e_r)
-                dX("gru_list2", dgi2, dl1, c, False)
-                ops.ln_bwd(dl1, ctx["h1"], ctx["m1"], ctx["s1"], P[prefix + "ln1.weight"], B * c[1], H, 1, G[prefix + "ln1.weight"],
-                           G[prefix + "ln1.bias"], seg=(c[1], T, c[0]), out=dh1_in)
-                e_q = ev_on(aux)
-            with torch.cuda.stream(sB):
-                sB.wait_event(e_q)
-                ops.gru_seq_bwd(dh1_in, whh["gru_list1"], ctx["c1"], ctx["z1"], B, T, g, Hg, prec, an=ctx["a1"], want_dgi=True,
-                                out=(dhh1, dgi1), chunk=c, wide=True, slot=slot1, zeroed=z1, seq=j if z1 else None, xcd_rot=4)
-                # layer 1's input gradient of the chunk, behind its recurrence on the SAME stream: the next chunk cannot start before
-                # layer 2's next chunk + its dX + LayerNorm backward have run anyway (~ this GEMM's time).  (Not on the aux stream: sB
-                # already waits for aux's events, and with aux waiting for sB's as well hipStreamEndCapture (ROCm 7.2) recursed between
-                # the two until the stack overflowed.)
-                dX1(c)
-        # layer 2's weight gradients: the side stream waits for the main stream = the last layer-2 chunk
-        layer_bwd_bf16(dh2, "gru_list2", ctx["l1"], ctx["h2"], ctx["c2"], ctx["a2"], ctx["z2"], False, False, pre=(dhh2, dgi2))
-        wait_stream(main, aux)
-        wait_stream(main, sB)
-        layer_bwd_bf16(dh1_in, "gru_list1", ctx["x"], ctx["h1"], ctx["c1"], ctx["a1"], ctx["z1"], False, True, pre=(dhh1, dgi1))
-        return
-    nov = _overlap_chunks(prec, Hg, g, B, T, slot, False) if (_bf16_gemm_path(prec, Hg) and not ctx.get("tn")) else 0
-    if nov > 1:
-        # ---- chunk-signal overlap (see _overlap_chunks): both recurrences write their gate-gradient rows themselves and count their chunks in;
-        # the aux stream runs dX2 + LayerNorm-1 backward of a chunk beside the layer-2 recurrence, layer 1's dX beside the layer-1 recurrence
-        if hooks:
-            hooks.pop()()
-        CL = (T + nov - 1) // nov
-        dev = dout.device
-        main = torch.cuda.current_stream()
-        aux = _wave_streams()[1]
-        dhh2 = torch.empty(B, T, H, device=dev, dtype=torch.float32); dhh1 = torch.empty_like(dhh2)
-        dgi2 = ops.dgi_buffer(rows, g, Hg, dev); dgi1 = ops.dgi_buffer(rows, g, Hg, dev)
-        dl1 = torch.empty(B, T, H, device=dev, dtype=torch.float32); dh1_in = torch.empty_like(dl1)
-        w_ts = ctx.get("w_ts", {})
-        wt = {}
-        for lname in ("gru_list1", "gru_list2"):
-            wt[lname] = w_ts.get((lname, 0))
-            if wt[lname] is None:
-                wt[lname] = ops.transpose_bf16(P[f"{prefix}{lname}.0.weight_ih_l0"], 3 * Hg, Hg)
-        whh = {ln_: [P[f"{prefix}{ln_}.0.weight_hh_l0"]] for ln_ in ("gru_list1", "gru_list2")}
-
-        def segs():
-            """(chunk index, row segment) in the order the backward recurrence finishes them: iterations [j CL, (j + 1) CL) from the last frame"""
-            for j in range((T + CL - 1) // CL):
-                hi = T - j * CL
-                lo = max(0, hi - CL)
-                yield j, (hi - lo, T, lo)
-
-        def dX(lname, dgi_, out_, seg, acc):
-            ops.gemm_bf16_nt_seg(B * seg[0], Hg, wt[lname].shape[0] * 64, dgi_, None, 0, 3 * H, wt[lname], None, 0, 64, out_, 0, H, seg,
-                                 accumulate=acc, b_kstride=Hg * 64)
-
-        slot2, zr2 = STEP_SCRATCH.take(B, g, Hg, slot)
-        fork_stream(aux, main)
-        SIDE.release_around(lambda: ops.gru_seq_bwd(dh2, whh["gru_list2"], ctx["c2"], ctx["z2"], B, T, g, Hg, prec, an=ctx["a2"], want_dgi=True,
-                                                    out=(dhh2, dgi2), slot=slot2, xcd_rot=xcd_rot, zeroed=zr2, chunk_len=CL))
-        with torch.cuda.stream(aux):
-            for j, seg in segs():
-                ops.gru_wait_chunk(B, g, Hg, dev, slot2, j)
-                dX("gru_list2", dgi2, dl1, seg, False)
-                ops.ln_bwd(dl1, ctx["h1"], ctx["m1"], ctx["s1"], P[prefix + "ln1.weight"], B * seg[0], H, 1, G[prefix + "ln1.weight"],
-                           G[prefix + "ln1.bias"], seg=seg, out=dh1_in)
-        # layer 2's weight gradients: the side stream waits for the main stream = the layer-2 recurrence
-        layer_bwd_bf16(dh2, "gru_list2", ctx["l1"], ctx["h2"], ctx["c2"], ctx["a2"], ctx["z2"], False, False, pre=(dhh2, dgi2))
-        wait_stream(main, aux)
-        slot1, zr1 = STEP_SCRATCH.take(B, g, Hg, slot)
-        fork_stream(aux, main)
-        SIDE.release_around(lambda: ops.gru_seq_bwd(dh1_in, whh["gru_list1"], ctx["c1"], ctx["z1"], B, T, g, Hg, prec, an=ctx["a1"], want_dgi=True,
-                                                    out=(dhh1, dgi1), slot=slot1, xcd_rot=xcd_rot, zeroed=zr1, chunk_len=CL if need_dx else 0))
-        if need_dx:
-            with torch.cuda.stream(aux):
-                if dx_accum and dx_ready is not None:
-                    dx_ready()                               # (on the stream that adds into dx: the skip leaf that fills it has run)
-                for j, seg in segs():
-                    ops.gru_wait_chunk(B, g, Hg, dev, slot1, j)
-                    dX("gru_list1", dgi1, dx, seg, dx_accum)
-        wait_stream(main, aux)
-        layer_bwd_bf16(dh1_in, "gru_list1", ctx["x"], ctx["h1"], ctx["c1"], ctx["a1"], ctx["z1"], False, True, pre=(dhh1, dgi1))
-        return
     dl1 = layer_bwd(dh2, "gru_list2", ctx["l1"], ctx["h2"], ctx["c2"], ctx["a2"], ctx["z2"], True, False)
     dh1 = ops.ln_bwd(dl1, ctx["h1"], ctx["m1"], ctx["s1"], P[prefix + "ln1.weight"], rows, H, g,
                      G[prefix + "ln1.weight"], G[prefix + "ln1.bias"])

@@ -480,13 +480,10 @@ def ln_fwd(x, gamma, beta, res, rows, H, interleave_g=1, eps=1e-5, save=True, ou
     return y, mean, rstd
 
 
-def ln_bwd(dy, x, mean, rstd, gamma, rows, H, interleave_g, dgamma, dbeta, seg=None, out=None):
-    """seg = (seg_len, seg_stride, seg_off): only the rows of one time chunk (rows = B * seg_len) into the full-size `out`
-    (cruse_ln_bwd_seg); dgamma / dbeta are accumulated."""
-    dx = torch.empty_like(x) if out is None else out
-    sl, ss, so = seg if seg is not None else (0, 0, 0)
-    check(lib.cruse_ln_bwd_seg(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), rows, H, interleave_g, _p(dx), _p(dgamma),
-                               _p(dbeta), sl, ss, so, _stream()))
+def ln_bwd(dy, x, mean, rstd, gamma, rows, H, interleave_g, dgamma, dbeta):
+    dx = torch.empty_like(x)
+    check(lib.cruse_ln_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), rows, H, interleave_g, _p(dx), _p(dgamma),
+                           _p(dbeta), _stream()))
     return dx
 
 
@@ -623,15 +620,6 @@ def gemm_f16_nt(M, N, K, A, a_off, lda, B, b_off, ldb, C, c_off, ldc, bias=None,
     return C
 
 
-def gemm_f16_nt_seg(M, N, K, A, a_off, lda, B, b_off, ldb, C, c_off, ldc, seg, bias=None, b_kstride=64):
-    """gemm_f16_nt on the rows of ONE TIME CHUNK: seg = (seg_len, seg_stride, seg_off), M = B * seg_len (cruse_gemm_f16_nt_seg)."""
-    if A.dtype != torch.float16 or B.dtype != torch.float16 or C.dtype != torch.float32:
-        raise RuntimeError("gemm_f16_nt_seg needs f16 operands and an f32 result")
-    check(lib.cruse_gemm_f16_nt_seg(M, N, K, A.data_ptr() + 2 * a_off, lda, B.data_ptr() + 2 * b_off, ldb, b_kstride,
-                                    C.data_ptr() + 4 * c_off, ldc, _p(bias), seg[0], seg[1], seg[2], _stream()))
-    return C
-
-
 def cast_bf16_padded(x, pad=64, split=False):
     """bf16 copy of x followed by `pad` zero elements, so a GEMM whose K is rounded up to 64 may read past the last row.
     split: returns (hi, lo) planes with x ~= hi + lo (both padded)."""
@@ -712,32 +700,12 @@ def gru_step_ws_clear(B, G, Hg, dev) -> None:
     zero_(_ws(("gru_step", per), per * STEP_SLOTS, torch.device(dev)))
 
 
-def gru_chunk_signals_ok(B, T, G, Hg, prec, fwd: bool, chunk_len: int) -> bool:
-    """chunk signals (gru_seq_*(chunk_len=)) exist for the default kernels of the bf16 mode on chains of 8, one launch per recurrence"""
-    ncu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-    if prec_code(prec) != PREC_BF16 or chunk_len <= 0 or (T + chunk_len - 1) // chunk_len > 64:
-        return False
-    if ((B + 7) // 8 + 7) // 8 * 8 * G * (Hg // 32) > ncu or get_option("gru_tf") == 0:
-        return False
-    if fwd:
-        return Hg == 640 and get_option("gru_fwd_lean") in (None, 1) and get_option("gru_wlo") in (None, 0) and get_option("gru_tf") in (None, 1)
-    return Hg in (160, 320, 640) and get_option("gru_bwd_ag") in (None, 2) and get_option("gru_bwd_rs") in (None, 1)
-
-
-def gru_wait_chunk(B, G, Hg, dev, slot: int, chunk: int) -> None:
-    """On the CURRENT stream: wait until every workgroup of the recurrence that runs on `slot`'s scratch (launched with chunk_len > 0)
-    has written its rows of time chunk `chunk` (cruse_stream_wait_counter); the kernels issued behind this call on the stream run after it."""
-    panels, status = _gru_ws(B, G, Hg, dev, slot)
-    target = ((B + 7) // 8) * G * (Hg // 32)
-    check(lib.cruse_stream_wait_counter(panels + lib.cruse_gru_ws_signal_offset(B, G, Hg) + 4 * chunk, target, status, _stream()))
-
-
 def _off(t: torch.Tensor, elems: int) -> int:
     return t.data_ptr() + elems * t.element_size()
 
 
 def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G, Hg, prec, save=True, slot=0, xcd_rot=0,
-                h0=None, out=None, chunk=None, wide=False, zeroed=False, seq=None, chunk_len=0):
+                h0=None, out=None, chunk=None, wide=False, zeroed=False):
     """-> (h, coef, an, z); the last three are None when save is False (inference).  slot / xcd_rot: see
     cruse_gru_seq_fwd_on (concurrent recurrences).
     h0 [B, G*Hg] ("cat" layout: feature = group*Hg + unit): initial state (cust_conv.py:305-325); None = 0.
@@ -745,8 +713,7 @@ def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G,
     the frames before them -- the initial state is then h[:, t0-1] (h0 for t0 == 0).  Consecutive chunks reproduce the
     single launch (cruse_gru_seq_fwd_ex).  wide: chains of 16 clips (half the workgroups; same results).
     gi: f32, or bf16 rows (gemm_bf16_nt into a bf16 tensor; bf16 mode only).  zeroed: the slot's scratch is already clear
-    (gru_step_ws_clear).  seq (wide chains, zeroed): this chunk's index among the chunks of ONE sequence that share the slot's
-    scratch without clearing it in between -- the hand-off epochs then continue from chunk to chunk (epoch0 = t0)."""
+    (gru_step_ws_clear)."""
     if gi.dtype not in (torch.float32, torch.bfloat16):
         raise RuntimeError(f"gru_seq_fwd: gi must be f32 or bf16, got {gi.dtype}")
     dev = gi.device
@@ -782,7 +749,7 @@ def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G,
     check(lib.cruse_gru_seq_fwd_ex(_off(gi, t0 * 3 * H), ctypes.cast(wa, ctypes.c_void_p), ctypes.cast(ba, ctypes.c_void_p),
                                    _off(h, t0 * H), opt(coef, 3 * H), opt(an, H), opt(z, H), h0p, h0s, B, n, T, G, Hg,
                                    prec_code(prec), 16 if wide else 0, 1 if gi.dtype == torch.bfloat16 else 0, panels, 1 if zeroed else 0,
-                                   status, xcd_rot, t0 if seq is not None else 0, seq or 0, chunk_len, _stream()))
+                                   status, xcd_rot, _stream()))
     return h, coef, an, z
 
 
@@ -798,12 +765,11 @@ def dgi_buffer(rows, G, Hg, device, slabs=3):
 
 
 def gru_seq_bwd(dout, w_hh: List[torch.Tensor], coef, z, B, T, G, Hg, prec, slot=0, xcd_rot=0, an=None, want_dgi=False,
-                out=None, chunk=None, dg_slabs=3, wide=False, zeroed=False, seq=None, chunk_len=0):
+                out=None, chunk=None, dg_slabs=3, wide=False, zeroed=False):
     """dout [B,T,H] -> dh [B,T,H] (total gradient reaching every h_t).  want_dgi (CRUSE_PREC_BF16, with the a_n rows):
     -> (dh, dgi) with dgi = dh * (c_r, c_z, a_n) in bf16 written by the recurrence itself (cruse_gru_seq_bwd_on).
     chunk = (t0, n): only frames [t0, t0+n), into out = dh (or (dh, dgi)); chunks are run from the LAST to the first, and
-    every chunk but the last picks the gradient carried across its end up from dh[:, t0+n] (cruse_gru_seq_bwd_ex).
-    seq: as in gru_seq_fwd (wide chains; epoch0 = the iterations the later chunks have run)."""
+    every chunk but the last picks the gradient carried across its end up from dh[:, t0+n] (cruse_gru_seq_bwd_ex)."""
     H = G * Hg
     dgi = None
     if out is not None:
@@ -825,8 +791,7 @@ def gru_seq_bwd(dout, w_hh: List[torch.Tensor], coef, z, B, T, G, Hg, prec, slot
     check(lib.cruse_gru_seq_bwd_ex(_off(dout, t0 * H), ctypes.cast(wa, ctypes.c_void_p), _off(coef, t0 * 3 * H), _off(z, t0 * H),
                                    _off(dh, t0 * H), _off(an, t0 * H) if want_dgi else None,
                                    None if dgi is None else _off(dgi, t0 * dg_slabs * H), dg_slabs, carry, B, steps, T, G, Hg, prec_code(prec),
-                                   16 if wide else 0, panels, 1 if zeroed else 0, status, xcd_rot,
-                                   (T - t0 - steps) if seq is not None else 0, seq or 0, chunk_len, _stream()))
+                                   16 if wide else 0, panels, 1 if zeroed else 0, status, xcd_rot, _stream()))
     return (dh, dgi) if want_dgi else dh
 
 

@@ -277,12 +277,6 @@ int cruse_ln_fwd_c(const float* x, const float* gamma, const float* beta, const 
 int cruse_ln_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
                  const float* gamma, long long rows, int H, int interleave_g,
                  float* dx, float* dgamma, float* dbeta, void* stream);
-/* (ABI 10) cruse_ln_bwd on the rows of ONE TIME CHUNK (row segments as in cruse_ln_fwd: logical row r is physical row
- * (r / seg_len) * seg_stride + seg_off + r % seg_len, rows = clips * seg_len; interleave_g == 1): the LayerNorm between the two GGRU
- * recurrences in the backward wavefront (cruse_net.py:41-51).  dgamma / dbeta are ACCUMULATED, as in cruse_ln_bwd. */
-int cruse_ln_bwd_seg(const float* dy, const float* x, const float* mean, const float* rstd,
-                     const float* gamma, long long rows, int H, int interleave_g,
-                     float* dx, float* dgamma, float* dbeta, int seg_len, long long seg_stride, long long seg_off, void* stream);
 
 /* ---- MFMA GEMM (GRU gate projections nn.GRU at cruse_net.py:23-31; their dX / dW) -- */
 
@@ -377,11 +371,6 @@ int cruse_ktile_f16(const float* x, int rows, int cols, long long ld, void* y, v
 int cruse_gemm_f16_nt(int M, int N, int K, const void* A, long long lda, long long a_kstride,
                       const void* B, long long ldb, long long b_kstride,
                       float* C, long long ldc, const float* bias, void* stream);
-/* (ABI 10) ... on the rows of one time chunk (row-major A; row segments as in cruse_gemm_bf16_nt_seg): the layer-2 gate projection
- * of a chunk, run beside the recurrences of the GGRU wavefront */
-int cruse_gemm_f16_nt_seg(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, long long b_kstride,
-                          float* C, long long ldc, const float* bias, int seg_len, long long seg_stride, long long seg_off,
-                          void* stream);
 /* y = bf16(x) and y_lo = bf16(x - y) (nullable) */
 int cruse_cast_bf16_split(const float* x, void* y, void* y_lo, long long n, void* stream);
 /* Split-bf16 x3 form of cruse_gemm_bf16_nt: A = A_hi + A_lo, B = B_hi + B_lo (bf16 planes, same layout each);
@@ -454,31 +443,18 @@ int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh, const void
  *            the CUs; beyond that (B > 96 at Hg = 640) WIDE chains of 16 (half the workgroups per clip, the full 16 columns of the
  *            MFMA; CRUSE_PREC_BF16, Hg % 128 == 0, Hg <= 640, f32 gi rows, h0 == NULL) where that needs fewer launches.
  *            8 / 16 force the width: with 16 a batch of 64 at Hg = 640 takes 80 CUs, so the recurrences of BOTH GGRU layers are
- *            co-resident and run as a time-chunk wavefront (layer 2 at frame t needs layer 1 at frames <= t only).  The forward
+ *            co-resident (measured slower than one after the other on chains of 8: DESIGN.md section 8).  The forward
  *            results do not depend on the width (same sums in the same order); the backward ones up to the f32 summation order.
  *            chain_clips = 16 WITH h0: the caller vouches for |h0| < 1 (the wide kernels' hand-off keeps the epoch bit in the top
- *            exponent bit of every exchanged bf16) -- true for the continuation of a sequence that started from h0 = 0.
- *   epoch0, seq: a sequence run as consecutive time chunks on WIDE chains may share one panel scratch that is cleared once
- *            (panels_zeroed = 1 on every chunk): epoch0 = the number of steps the earlier chunks of the same sequence took on this
- *            scratch (forward: t0; backward: the iterations already run), seq = the chunk's index (< 64: its own XCD tickets and
- *            team handshake).  epoch0 > 0 needs h0 (forward) / carry (backward).  0, 0 for a run on a freshly cleared scratch. */
+ *            exponent bit of every exchanged bf16) -- true for the continuation of a sequence that started from h0 = 0. */
 int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, const float* const* b_hh,
                          float* h, void* coef, float* an, float* z, const float* h0, long long h0_bstride,
                          int B, int T, int TS, int G, int Hg, int prec, int chain_clips, int gi_bf16, void* panels,
-                         int panels_zeroed, unsigned* status, int xcd_rot, int epoch0, int seq, int chunk_len, void* stream);
+                         int panels_zeroed, unsigned* status, int xcd_rot, void* stream);
 int cruse_gru_seq_bwd_ex(const float* dout, const float* const* w_hh, const void* coef, const float* z,
                          float* dh, const float* an, void* dgi, int dg_slabs, int carry, int B, int T, int TS, int G,
                          int Hg, int prec, int chain_clips, void* panels, int panels_zeroed, unsigned* status, int xcd_rot,
-                         int epoch0, int seq, int chunk_len, void* stream);
-/* (ABI 10) CHUNK SIGNALS of a running recurrence.  chunk_len > 0 (the _ex calls; bf16 mode, chains of 8, one launch: Hg = 640 forward,
- * Hg in {160, 320, 640} backward): when a workgroup's rows of time chunk c (forward: frames [c L, (c + 1) L); backward: the iterations
- * [c L, (c + 1) L) counted from the last frame) have been written, it releases them at agent scope and adds 1 to counter c of the
- * MAX 64 counters at panels + cruse_gru_ws_signal_offset() (cleared with the panel scratch).  cruse_stream_wait_counter(counter, target):
- * one wave on `stream` that returns once *counter >= target = workgroups with a chain = ceil(B / 8) * G * Hg / 32 (bounded: a
- * time-out sets *status) -- the kernels queued behind it (the LayerNorm + gate projection of the chunk; backward: its input gradient
- * + LayerNorm backward) then run beside the recurrence instead of behind it (cruse_net.py:41-51). */
-size_t cruse_gru_ws_signal_offset(int B, int G, int Hg);
-int cruse_stream_wait_counter(const unsigned* counter, unsigned target, unsigned* status, void* stream);
+                         void* stream);
 /* dgi = dh*(c_r,c_z,a_n) (gradient wrt gi), dgh = dh*(c_r,c_z,c_n) (gradient wrt W_hh h + b_hh), both
  * [rows,G,3*Hg]; dW_ih, dW_hh, dX and the bias gradients follow from cruse_gemm / cruse_col_sum. */
 int cruse_gru_gate_grads(const float* dh, const void* coef, const float* an, float* dgi, float* dgh,

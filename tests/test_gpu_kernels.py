@@ -625,8 +625,7 @@ def test_conv_dgrad_accumulates_the_batchnorm_backward_sums(ops, form, Cin, Cout
 def test_gru_fwd_wide_chains_match_lean_kernel_bit_for_bit(ops, H, B, T, G):
     """cruse_gru_seq_fwd_ex(chain_clips = 16): chains of 16 clips (half the workgroups per clip; gru_fwd_w16_kernel, gru_w16.hip) -- the
     lean kernel's arithmetic in the lean kernel's summation order, so h and the saved coefficient rows are identical; run as time
-    chunks too: every chunk on its own cleared scratch, and all chunks on ONE scratch cleared once with the hand-off epochs
-    continuing (epoch0 / seq) -- the form the GGRU wavefront uses."""
+    chunks too (a continuation takes its state from the h rows the previous launch wrote)."""
     torch.manual_seed(H + B)
     Hg = H // G
     gi = (0.5 * torch.randn(B, T, 3 * H)).cuda()
@@ -646,12 +645,6 @@ def test_gru_fwd_wide_chains_match_lean_kernel_bit_for_bit(ops, H, B, T, G):
                 out = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16", out=out, chunk=c, wide=True)
             for x, y, name in zip(out, lean, ("h", "coef", "an", "z")):
                 assert torch.equal(x, y), ("chunked", name)
-            ops.gru_step_ws_clear(B, G, Hg, "cuda")
-            out = None
-            for i, c in enumerate(cuts):                     # one scratch, cleared once: the epochs continue
-                out = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16", out=out, chunk=c, wide=True, slot=ops.STEP_SLOT0, zeroed=True, seq=i)
-            for x, y, name in zip(out, lean, ("h", "coef", "an", "z")):
-                assert torch.equal(x, y), ("chunked on one scratch", name)
     with pytest.raises(RuntimeError):
         ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16", h0=torch.zeros(B, H).cuda(), wide=True)
     assert ops.gru_status() == 0
@@ -663,7 +656,7 @@ def test_gru_bwd_wide_chains_match_the_chains_of_8(ops, H, B, T, G, slabs):
     """cruse_gru_seq_bwd_ex(chain_clips = 16): chains of 16 clips (gru_bwd_w16_kernel: the all-gather step on eight compute waves) --
     dh and the in-kernel gate gradients (3 or 4 slabs) equal those of the chains of 8 up to the f32 summation order / one bf16 rounding
     of the exchanged products, and the exact-f32 recurrence within the bf16 mode's error; run as time chunks (last chunk first, the
-    gradient carried across the cut) on their own scratches and on one scratch with continuing epochs: bit-identical to the one launch."""
+    gradient carried across the cut): bit-identical to the one launch."""
     torch.manual_seed(H + B)
     Hg = H // G
     gi = (0.5 * torch.randn(B, T, 3 * H)).cuda()
@@ -685,13 +678,6 @@ def test_gru_bwd_wide_chains_match_the_chains_of_8(ops, H, B, T, G, slabs):
             ops.gru_seq_bwd(dout, w, coef, z, B, T, G, Hg, "bf16", an=an, want_dgi=True, dg_slabs=slabs, out=out, chunk=c, wide=True)
         assert torch.equal(out[0], wide[0]), "chunked dh"
         assert torch.equal(out[1].view(torch.int16), wide[1].view(torch.int16)), "chunked dgi"
-        ops.gru_step_ws_clear(B, G, Hg, "cuda")
-        out = (torch.zeros_like(ref[0]), torch.zeros_like(ref[1]))
-        for i, c in enumerate(reversed(cuts)):
-            ops.gru_seq_bwd(dout, w, coef, z, B, T, G, Hg, "bf16", an=an, want_dgi=True, dg_slabs=slabs, out=out, chunk=c, wide=True,
-                            slot=ops.STEP_SLOT0 + 1, zeroed=True, seq=i)
-        assert torch.equal(out[0], wide[0]), "chunked dh on one scratch"
-        assert torch.equal(out[1].view(torch.int16), wide[1].view(torch.int16)), "chunked dgi on one scratch"
     assert ops.gru_status() == 0
 
 

@@ -321,12 +321,10 @@ def test_engine_with_bf16_gate_preactivations():
     assert rel_l2(res[True][2], res[False][2]) < 5e-2
 
 
-@pytest.mark.parametrize("ggru_wave", [0, 4])
-def test_graph_replay_on_a_new_batch_equals_eager_launches(ggru_wave):
+def test_graph_replay_on_a_new_batch_equals_eager_launches():
     """A captured step replayed on ANOTHER batch computes what the eager launches compute.  lr = 0, so the parameters never move
     and the forward pass must agree bit for bit (gradients: up to the order of the split-K atomics): a kernel node that ran
-    before its producer would see the tensors of the batch the graph was captured on -- the GGRU wavefront's three streams
-    (cruse_net._ggru_forward_wave) included."""
+    before its producer would see the tensors of the batch the graph was captured on."""
     from cruse_amd.config import EngineConfig
     from cruse_amd.data import synth_batch
     from cruse_amd.engine import TrainEngine
@@ -337,7 +335,7 @@ def test_graph_replay_on_a_new_batch_equals_eager_launches(ggru_wave):
     res = {}
     for graph in (False, True):
         torch.manual_seed(5)
-        eng = TrainEngine(unet_2(rnn_groups=1, precision="bf16").cuda(), use_graph=graph, lr=0.0, config=EngineConfig(ggru_wave=ggru_wave))
+        eng = TrainEngine(unet_2(rnn_groups=1, precision="bf16").cuda(), use_graph=graph, lr=0.0, config=EngineConfig())
         eng.step(*A); eng.step(*A)
         ls = eng.step(*Bb)
         torch.cuda.synchronize()
@@ -346,71 +344,6 @@ def test_graph_replay_on_a_new_batch_equals_eager_launches(ggru_wave):
     assert torch.equal(res[True][0], res[False][0]), "mask of the replay differs from the eager launches"
     assert res[True][1] == res[False][1]
     assert rel_l2(res[True][2], res[False][2]) < 5e-5      # (atomics order of the BatchNorm sums -> 1e-7 in dy -> a few bf16 roundings of it flip)
-
-
-@pytest.mark.parametrize("graph", [False, True])
-def test_ggru_wavefront_is_the_same_computation(graph):
-    """EngineConfig.ggru_wave: the two GGRU recurrences as a time-chunk wavefront on wide chains (layer 2 one chunk behind layer 1, the
-    LayerNorm + projection of a chunk on a third stream; backward mirrored; cruse_gru_seq_*_ex(chain_clips = 16, epoch0, seq),
-    cruse_gemm_*_nt_seg, cruse_ln_fwd / cruse_ln_bwd_seg row segments) computes what the serial schedule computes: the forward pass --
-    mask and loss -- bit for bit (the wide forward kernel sums in the order of the chains of 8), the gradients up to the f32 summation
-    order of the wide backward recurrence and of the split-K weight-gradient GEMMs; eager and captured into the HIP graph."""
-    from cruse_amd.config import EngineConfig
-    from cruse_amd.data import synth_batch
-    from cruse_amd.engine import TrainEngine
-    from cruse_amd.model.cruse_net import unet_2
-    from cruse_amd import ops
-    noisy, clean = synth_batch(16, 32000, "cuda", 4)            # T = 201 frames
-    res = {}
-    for nch in (0, 2, 3, 4):
-        torch.manual_seed(5)
-        eng = TrainEngine(unet_2(rnn_groups=1, precision="bf16").cuda(), use_graph=graph, config=EngineConfig(ggru_wave=nch))
-        ls = eng.step(noisy, clean)                             # (graph mode: capture + first replay)
-        torch.cuda.synchronize()
-        first = (eng.loss_value(ls), eng._last_mask.clone(), eng.flat.grads.clone())
-        ls = eng.step(noisy, clean)
-        torch.cuda.synchronize()
-        res[nch] = first + (eng.loss_value(ls), eng.flat.params.clone())
-        assert eng.skipped_steps() == 0 and ops.gru_status() == 0
-    for nch in (2, 3, 4):
-        # the first step starts from identical parameters: the forward pass must agree bit for bit
-        assert torch.equal(res[nch][1], res[0][1]), f"mask differs with {nch} chunks"
-        assert res[nch][0] == res[0][0]
-        assert rel_l2(res[nch][2], res[0][2]) < 3e-3
-        assert res[nch][3] == pytest.approx(res[0][3], rel=1e-4) and rel_l2(res[nch][4], res[0][4]) < 5e-3      # (Adam moves noise-level entries by +-lr)
-    # the chunk count does not change the wavefront's arithmetic at all: same recurrence kernels, same epochs
-    assert rel_l2(res[2][2], res[4][2]) < 1e-4
-
-
-@pytest.mark.parametrize("graph", [False, True])
-def test_ggru_chunk_signal_overlap_is_the_same_computation(graph):
-    """EngineConfig.ggru_overlap: the recurrences count their time chunks in (cruse_gru_seq_*_ex(chunk_len), cruse_stream_wait_counter) and
-    the kernels between them -- LayerNorm 1 + layer-2 projection, backward the input-gradient GEMMs + LayerNorm-1 backward -- run chunk by
-    chunk on an auxiliary stream beside the running recurrence.  Same kernels on the same values: mask and loss bit for bit, gradients up
-    to the order of the f32 atomics (LayerNorm affine gradients, BatchNorm sums); eager and captured; several chunk counts, one of them
-    leaving a short last chunk."""
-    from cruse_amd.config import EngineConfig
-    from cruse_amd.data import synth_batch
-    from cruse_amd.engine import TrainEngine
-    from cruse_amd.model.cruse_net import unet_2
-    from cruse_amd import ops
-    noisy, clean = synth_batch(16, 32000, "cuda", 4)            # T = 201 frames
-    res = {}
-    for nov in (0, 2, 4, 7):
-        torch.manual_seed(5)
-        eng = TrainEngine(unet_2(rnn_groups=1, precision="bf16").cuda(), use_graph=graph, config=EngineConfig(ggru_overlap=nov))
-        ls = eng.step(noisy, clean)
-        torch.cuda.synchronize()
-        first = (eng.loss_value(ls), eng._last_mask.clone(), eng.flat.grads.clone())
-        ls = eng.step(noisy, clean)
-        torch.cuda.synchronize()
-        res[nov] = first + (eng.loss_value(ls),)
-        assert eng.skipped_steps() == 0 and ops.gru_status() == 0
-    for nov in (2, 4, 7):
-        assert torch.equal(res[nov][1], res[0][1]), f"mask differs with {nov} chunks"
-        assert res[nov][0] == res[0][0]
-        assert rel_l2(res[nov][2], res[0][2]) < 1e-4
-        assert res[nov][3] == pytest.approx(res[0][3], rel=1e-5)
 
 
 @pytest.mark.parametrize("grp", [1, 4])

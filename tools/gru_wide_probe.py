@@ -39,16 +39,14 @@ print(f"bwd dh: wide vs 8 {rel(dw[0], dl[0]):.2e}, wide vs f32 {rel(dw[0], dx):.
       f"status {ops.gru_status()}", flush=True)
 # chunks on one scratch
 cuts = [(0, 100), (100, 100), (200, 100), (300, 101)]
-ops.gru_step_ws_clear(B, G, Hg, "cuda")
 out = None
 for i, c in enumerate(cuts):
-    out = ops.gru_seq_fwd(gi[0], ws, bs, B, T, G, Hg, "bf16", out=out, chunk=c, wide=True, slot=ops.STEP_SLOT0, zeroed=True, seq=i)
+    out = ops.gru_seq_fwd(gi[0], ws, bs, B, T, G, Hg, "bf16", out=out, chunk=c, wide=True)
 bo = (torch.zeros_like(dw[0]), torch.zeros_like(dw[1]))
 for i, c in enumerate(reversed(cuts)):
-    ops.gru_seq_bwd(dout[0], ws, lean[1], lean[3], B, T, G, Hg, "bf16", an=lean[2], want_dgi=True, out=bo, chunk=c, wide=True,
-                    slot=ops.STEP_SLOT0 + 1, zeroed=True, seq=i)
+    ops.gru_seq_bwd(dout[0], ws, lean[1], lean[3], B, T, G, Hg, "bf16", an=lean[2], want_dgi=True, out=bo, chunk=c, wide=True)
 torch.cuda.synchronize()
-print("chunked on one scratch: fwd h equal", bool(torch.equal(out[0], lean[0])), "bwd dh equal", bool(torch.equal(bo[0], dw[0])),
+print("chunked: fwd h equal", bool(torch.equal(out[0], lean[0])), "bwd dh equal", bool(torch.equal(bo[0], dw[0])),
       "dgi equal", bool(torch.equal(bo[1].view(torch.int16), dw[1].view(torch.int16))), "status", ops.gru_status(), flush=True)
 
 outs = [ops.gru_seq_fwd(gi[i], ws, bs, B, T, G, Hg, "bf16", slot=i, xcd_rot=4 * i, wide=True) for i in range(2)]
@@ -98,14 +96,12 @@ for nch in (4, 8):
     cs = [(j * base, base if j + 1 < nch else T - j * base) for j in range(nch)]
 
     def fchunks():
-        ops.gru_step_ws_clear(B, G, Hg, "cuda")
         for i, c in enumerate(cs):
-            ops.gru_seq_fwd(gi[0], ws, bs, B, T, G, Hg, "bf16", out=outs[0], chunk=c, wide=True, slot=ops.STEP_SLOT0, zeroed=True, seq=i)
+            ops.gru_seq_fwd(gi[0], ws, bs, B, T, G, Hg, "bf16", out=outs[0], chunk=c, wide=True)
 
     def bchunks():
-        ops.gru_step_ws_clear(B, G, Hg, "cuda")
         for i, c in enumerate(reversed(cs)):
-            ops.gru_seq_bwd(dout[0], ws, outs[0][1], outs[0][3], B, T, G, Hg, "bf16", out=dhs[0], chunk=c, wide=True, slot=ops.STEP_SLOT0 + 1, zeroed=True, seq=i)
+            ops.gru_seq_bwd(dout[0], ws, outs[0][1], outs[0][3], B, T, G, Hg, "bf16", out=dhs[0], chunk=c, wide=True)
     print(f"{nch} chunk launches back to back: fwd {timeit(fchunks):.0f} us, bwd {timeit(bchunks):.0f} us; status {ops.gru_status()}", flush=True)
 
 if not quick:
