@@ -177,7 +177,7 @@ class KernelTimer:
     """Wraps cruse_amd.ops entry points with HIP events on torch's current stream (where the kernels run)."""
 
     NAMES = ["stft", "conv_gather", "conv_scatter2", "conv_gather_bnin", "conv_scatter2_bnin", "conv_wgrad", "channel_sum", "col_sum", "bn_stats", "bn_finalize",
-             "bn_act_fwd", "bn_finalize_act_fwd", "bn_act_bwd", "ln_fwd", "ln_bwd", "gemm", "gemm_bf16_nt", "gemm_bf16x3_nt", "gemm_bf16_tn", "gru_gate_bias_sums", "cast_bf16", "cast_bf16_padded",
+             "bn_act_fwd", "bn_finalize_act_fwd", "bn_act_bwd", "ln_fwd", "ln_bwd", "gemm", "gemm_bf16_nt", "gemm_bf16x3_nt", "cast_bf16", "cast_bf16_padded",
              "ktile_bf16", "transpose_bf16", "gemm_bf16_nt_cat", "gemm_bf16_nt_atr", "gemm_f16_nt", "ktile_f16",
              "gru_seq_fwd", "gru_seq_bwd", "gru_gate_grads", "gru_gate_grads_bf16", "mask_loss"]
     # entry points that launch the same kernel as another one are booked under that family
@@ -317,17 +317,15 @@ def kernel_rooflines(B, T, H, G, prec, per_step_ms, calls):
                                  f"{avg_ms * 1e3 / T:.2f} us per step"}
     # ALGORITHMIC flops: 2 layers x (gi, dX, dW_ih, dW_hh) = 8 products of 2 * rows * 3 Hg * Hg * G flops.  The forward projections run in their
     # own families -- split-bf16 x3 (its extra MFMA passes are not counted) and / or the single f16 pass: one launch per group and layer, so
-    # launches / G = products --, the TN weight-gradient kernel takes 4 (dW_ih, dW_hh of both layers), the rest is gemm_bf16_nt's (the
+    # launches / G = products --, the rest is gemm_bf16_nt's (the
     # concatenated weight-gradient launch and the transposed-A dX are booked there).
     fwd_prod = {f: calls[f] / float(G) for f in ("gemm_bf16x3_nt", "gemm_f16_nt") if f in per_step_ms}
-    for gname in ("gemm", "gemm_bf16_nt", "gemm_bf16x3_nt", "gemm_f16_nt", "gemm_bf16_tn"):
+    for gname in ("gemm", "gemm_bf16_nt", "gemm_bf16x3_nt", "gemm_f16_nt"):
         if gname in per_step_ms:
             if gname in fwd_prod:
                 nprod = fwd_prod[gname]
-            elif gname == "gemm_bf16_tn":
-                nprod = 4
             else:
-                nprod = 8 - sum(fwd_prod.values()) - (4 if "gemm_bf16_tn" in per_step_ms else 0)
+                nprod = 8 - sum(fwd_prod.values())
             flops = 2.0 * rows * 3 * Hg * Hg * G * nprod
             avg_ms = per_step_ms[gname] / calls[gname]
             ach = flops / (per_step_ms[gname] * 1e-3) / 1e12

@@ -64,7 +64,6 @@ SIGNATURES = {
     "cruse_gemm_bf16_nt_groups": ("iiiippqqppqqqpqqpqip", "i"),
     "cruse_gemm_bf16_nt_obf16": ("iiippqqppqqpqpp", "i"),
     "cruse_gemm_bf16_nt_seg": ("iiippqppqqpqpiiqqp", "i"),
-    "cruse_gemm_bf16_tn": ("iiqpqpqiipqip", "i"),
     "cruse_cast_bf16": ("ppqp", "i"),
     "cruse_transpose_bf16": ("pqiqpqip", "i"),
     "cruse_ktile_bf16": ("piiqppp", "i"),
@@ -81,7 +80,6 @@ SIGNATURES = {
     "cruse_gru_seq_bwd_ex": ("pppppppiiiiiiiiipipip", "i"),
     "cruse_gru_gate_grads": ("pppppqiiip", "i"),
     "cruse_gru_gate_grads_bf16": ("pppppqppqiip", "i"),
-    "cruse_gru_gate_bias_sums": ("pqiippp", "i"),
     "cruse_mask_loss_fwd": ("ppppqiiffpppppp", "i"),
     "cruse_mask_apply": ("pppqiippp", "i"),
     "cruse_mask_apply_bwd": ("pppppqiiipp", "i"),

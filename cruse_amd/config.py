@@ -53,7 +53,6 @@ class EngineConfig:
     dx_atr: bool = False            # Hg % 64 == 0: the input-gradient GEMM of a GRU layer reads the TIME-MAJOR gate-gradient tensor through transposing
                                     # LDS reads (cruse_gemm_bf16_nt_atr); the gate-gradient pass then writes no row-major dgi (98 MB per layer)
     conv_bwd_x3: bool = False       # backward-data convolutions as split-bf16 x3 instead of plain bf16
-    dw_tn: bool = False             # weight gradients as TN GEMMs on row-major operands (measured slower: 6.35 vs 6.02 ms)
     fuse_bn_fwd: bool = True        # bf16 mode, training: BatchNorm-apply + ReLU (+ decoder skip add) of a level run inside the STAGING of
                                     # the convs that consume it (cruse_conv_*_bnin) -- the normalised tensors e_k (k < L) and u_k (k >= 2)
                                     # never exist in f32; the weight gradients read a bf16 copy the consuming conv writes while staging
@@ -74,10 +73,10 @@ class EngineConfig:
             "fuse_dgi": ("CRUSE_FUSE_DGI", lambda v: v == "1"),
             "fuse_bn_bwd_stats": ("CRUSE_FUSE_BN_BWD", lambda v: v != "0"), "fuse_cast": ("CRUSE_FUSE_CAST", lambda v: v == "1"),
             "gi_x3": ("CRUSE_GI_X3", int), "gi_f16": ("CRUSE_GI_F16", int), "gi_bf16": ("CRUSE_GI_BF16", lambda v: v == "1"), "dw_xcdk": ("CRUSE_DW_XCDK", int), "conv_bwd_x3": ("CRUSE_CONV_BWD_X3", lambda v: v == "1"),
-            "dw_tn": ("CRUSE_DW_TN", lambda v: v == "1"), "dw_slabs": ("CRUSE_DW_SLABS", lambda v: v != "0"), "dw_cat": ("CRUSE_DW_CAT", lambda v: v != "0"), "dx_atr": ("CRUSE_DX_ATR", lambda v: v == "1"), "gemm_groups": ("CRUSE_GEMM_GROUPS", lambda v: v != "0"), 
+            "dw_slabs": ("CRUSE_DW_SLABS", lambda v: v != "0"), "dw_cat": ("CRUSE_DW_CAT", lambda v: v != "0"), "dx_atr": ("CRUSE_DX_ATR", lambda v: v == "1"), "gemm_groups": ("CRUSE_GEMM_GROUPS", lambda v: v != "0"), 
             "fuse_bn_fwd": ("CRUSE_FUSE_BN_FWD", lambda v: v != "0"), "fuse_bn_bwd_apply": ("CRUSE_FUSE_BN_BWD_APPLY", lambda v: v != "0"), "bf16_dy": ("CRUSE_BF16_DY", lambda v: v != "0"), "bf16_de": ("CRUSE_BF16_DE", lambda v: v != "0")}
     _LIB_ENV = {"CRUSE_GRU_BWD_RS": "gru_bwd_rs", "CRUSE_GRU_FWD_LEAN": "gru_fwd_lean", "CRUSE_GRU_WLO": "gru_wlo",
-                "CRUSE_GRU_DBG": "gru_dbg", "CRUSE_GRU_PRIO": "gru_prio", "CRUSE_GRU_BG": "gru_bg", "CRUSE_CM_GRID": "cm_grid", "CRUSE_CM_KINT": "cm_kint", "CRUSE_CM_SWAP": "cm_swap", "CRUSE_CM_NW": "cm_nw",
+                "CRUSE_GRU_DBG": "gru_dbg", "CRUSE_GRU_PRIO": "gru_prio", "CRUSE_CM_GRID": "cm_grid", "CRUSE_CM_KINT": "cm_kint", "CRUSE_CM_SWAP": "cm_swap", "CRUSE_CM_NW": "cm_nw",
                 "CRUSE_GB_DEEP_MIN": "gb_deep_min", "CRUSE_GB_DEEP": "gb_deep", "CRUSE_GB_BM256": "gb_bm256", "CRUSE_GB_PIPE": "gb_pipe", "CRUSE_PW_VALU": "pw_valu", "CRUSE_LNB_GRID": "lnb_grid",
                 "CRUSE_GRU_TF": "gru_tf", "CRUSE_GRU_POLL_FWD": "gru_poll_fwd", "CRUSE_GRU_POLL_BWD": "gru_poll_bwd", "CRUSE_GRU_BWD_AG": "gru_bwd_ag", "CRUSE_GRU_FWD_RD": "gru_fwd_rd", "CRUSE_WG_TFW": "wg_tfw", "CRUSE_WG_GRID": "wg_grid", "CRUSE_WG_DBG": "wg_dbg", "CRUSE_WG_SR": "wg_sr"}
 

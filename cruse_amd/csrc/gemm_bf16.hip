@@ -360,171 +360,6 @@ __global__ __launch_bounds__(256 * BMT, (NST == 2 && BMT == 1) ? 2 : 1) void gem
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// TN form for the K = B*T weight gradients:  C[M,N] += sum_k A[k][m] * B[k][n]
-//   A = the gate-gradient rows dg [rows][lda] bf16 as the backward recurrence writes them (row-major, m contiguous),
-//   B = the layer input x_bf [rows][ldb] bf16, or h [rows][ldb] f32 read one frame back (h_{t-1}; zero at the first frame
-//       of a clip) -- both as the forward pass left them.
-// The NT kernel above needs K-contiguous operands, which cost four time-major transposes per step and a 131 MB time-major
-// copy of the gate gradients per layer (0.25 ms of kernels, 0.8 GB of HBM traffic).  Here the transposition happens on the
-// way into LDS: a thread loads a 4 (k) x 8 (m) block -- four 16-byte row pieces, 256 contiguous bytes per 16 lanes -- turns
-// it with 16 v_perm_b32 into eight 8-byte k-runs and writes them with ds_write_b64 into the SAME [128 rows][8 chunks of
-// 16 B] image the MFMA fragment reads of the NT kernel expect (chunk swizzle (m & 7) ^ ((m >> 3) & 7): conflict-free for the
-// b128 fragment reads, 2-way for the b64 writes).  Global loads of tile v+1 are in flight in registers while tile v is
-// multiplied; one barrier per k-tile.  Split-K with atomic adds, k-slices pinned to XCDs as above.
-struct GtArgs {
-    const __bf16* A; const void* B; float* C;
-    int M, N; long long K;
-    long long lda, ldb, ldc;
-    int b_f32, shiftT;
-    int splitk, kt_chunk, tiles_m, tiles_n;
-};
-
-__device__ __forceinline__ unsigned perm_lo(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }   // {a.lo16, b.lo16}
-__device__ __forceinline__ unsigned perm_hi(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }   // {a.hi16, b.hi16}
-
-template <bool B_F32>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(const GtArgs g) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2][2][TILE_BYTES];      // [stage][A|B]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wm = wv >> 1, wn = wv & 1;
-    const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3;
-    const int ntile = g.tiles_m * g.tiles_n;
-    const int tz = (qq / ntile) * 8 + xcd;                   // k-slice tz is computed entirely on XCD tz % 8
-    if (tz >= g.splitk) return;
-    const int tl = qq % ntile, tm = tl / g.tiles_n, tn = tl % g.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const long long nkt = (g.K + BK - 1) / BK;
-    const long long kt0 = (long long)tz * g.kt_chunk, kt1 = min(nkt, kt0 + g.kt_chunk);
-    const int nt = (int)(kt1 - kt0);
-
-    // staging role: rows k = kq*4 .. +3 of the k-tile, column chunk mc (8 columns)
-    const int kq = tid >> 4, mc = tid & 15;
-    const bool a_ok = m0 + mc * 8 < g.M, b_ok = n0 + mc * 8 < g.N;
-    const __bf16* ap = g.A + m0 + mc * 8;
-    uint4 ra[4], rb[4];
-    auto load = [&](int v) {
-        const long long k = (kt0 + v) * BK + kq * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const long long kk = k + j;
-            const int kki = (int)kk;                         // (K < 2^31: checked by the host)
-            ra[j] = make_uint4(0u, 0u, 0u, 0u);
-            rb[j] = make_uint4(0u, 0u, 0u, 0u);
-            if (kk < g.K) {
-                if (a_ok) ra[j] = *reinterpret_cast<const uint4*>(ap + kk * g.lda);
-                if (b_ok) {
-                    if constexpr (B_F32) {
-                        if (g.shiftT == 0 || kki % g.shiftT != 0) {
-                            const float* bp = reinterpret_cast<const float*>(g.B) + (kk - (g.shiftT ? 1 : 0)) * g.ldb + n0 + mc * 8;
-                            const float4 f0 = *reinterpret_cast<const float4*>(bp), f1 = *reinterpret_cast<const float4*>(bp + 4);
-                            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
-                            auto pk = [](float a, float b) { bf16x2_ h; h[0] = (__bf16)a; h[1] = (__bf16)b; return __builtin_bit_cast(unsigned, h); };
-                            rb[j] = make_uint4(pk(f0.x, f0.y), pk(f0.z, f0.w), pk(f1.x, f1.y), pk(f1.z, f1.w));
-                        }
-                    } else {
-                        if (g.shiftT == 0 || kki % g.shiftT != 0)
-                            rb[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(g.B) + (kk - (g.shiftT ? 1 : 0)) * g.ldb + n0 + mc * 8);
-                    }
-                }
-            }
-        }
-    };
-    // 4 (k) x 8 (col) block -> eight 8-byte k-runs, one per column, into the [row = column][k] image
-    const int chunk = kq >> 1, half8 = (kq & 1) * 8;
-    auto store = [&](int buf) {
-        unsigned char* As = smem[buf][0];
-        unsigned char* Bs = smem[buf][1];
-        const unsigned a0[4] = {ra[0].x, ra[0].y, ra[0].z, ra[0].w}, a1[4] = {ra[1].x, ra[1].y, ra[1].z, ra[1].w};
-        const unsigned a2[4] = {ra[2].x, ra[2].y, ra[2].z, ra[2].w}, a3[4] = {ra[3].x, ra[3].y, ra[3].z, ra[3].w};
-        const unsigned b0[4] = {rb[0].x, rb[0].y, rb[0].z, rb[0].w}, b1[4] = {rb[1].x, rb[1].y, rb[1].z, rb[1].w};
-        const unsigned b2[4] = {rb[2].x, rb[2].y, rb[2].z, rb[2].w}, b3[4] = {rb[3].x, rb[3].y, rb[3].z, rb[3].w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int row = mc * 8 + e;
-            const int off = row * 128 + ((chunk ^ (e ^ (mc & 7))) << 4) + half8;       // (row & 7) == e, (row >> 3) & 7 == mc & 7
-            const int w = e >> 1;
-            uint2 va, vb;
-            if (e & 1) { va = make_uint2(perm_hi(a0[w], a1[w]), perm_hi(a2[w], a3[w])); vb = make_uint2(perm_hi(b0[w], b1[w]), perm_hi(b2[w], b3[w])); }
-            else { va = make_uint2(perm_lo(a0[w], a1[w]), perm_lo(a2[w], a3[w])); vb = make_uint2(perm_lo(b0[w], b1[w]), perm_lo(b2[w], b3[w])); }
-            *reinterpret_cast<uint2*>(As + off) = va;
-            *reinterpret_cast<uint2*>(Bs + off) = vb;
-        }
-    };
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    int offa[2][4], offb[2][4];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ra_ = wm * 64 + i * 16 + (lane & 15), rb_ = wn * 64 + i * 16 + (lane & 15);
-            offa[kk][i] = ra_ * 128 + (((kk * 4 + (lane >> 4)) ^ ((ra_ & 7) ^ ((ra_ >> 3) & 7))) << 4);
-            offb[kk][i] = rb_ * 128 + (((kk * 4 + (lane >> 4)) ^ ((rb_ & 7) ^ ((rb_ >> 3) & 7))) << 4);
-        }
-    auto compute = [&](int buf) {
-        const unsigned char* As = smem[buf][0];
-        const unsigned char* Bs = smem[buf][1];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 fa[4], fb[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                fa[i] = *reinterpret_cast<const bf16x8*>(As + offa[kk][i]);
-                fb[i] = *reinterpret_cast<const bf16x8*>(Bs + offb[kk][i]);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-    };
-    if (nt > 0) {
-        load(0);
-        store(0);
-        __syncthreads();
-        for (int v = 0; v < nt; ++v) {
-            if (v + 1 < nt) load(v + 1);           // in flight while tile v is multiplied
-            compute(v & 1);
-            if (v + 1 < nt) store((v + 1) & 1);    // buffer (v+1)&1 was last read in iteration v-1, before that iteration's barrier
-            __syncthreads();
-        }
-    }
-    // epilogue: atomic adds, row-contiguous through a per-wave LDS patch (as the NT kernel)
-    float* patch = reinterpret_cast<float*>(&smem[0][0][0]) + wv * (32 * 68);
-    const int nq = n0 + wn * 64 + (lane & 15) * 4;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    patch[(ii * 16 + (lane >> 4) * 4 + r) * 68 + j * 16 + (lane & 15)] = acc[half * 2 + ii][j][r];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int p_ = 0; p_ < 8; ++p_) {
-            const int rr = p_ * 4 + (lane >> 4);
-            const int m = m0 + wm * 64 + half * 32 + rr;
-            const float4 v = *reinterpret_cast<const float4*>(patch + rr * 68 + (lane & 15) * 4);
-            if (m < g.M) {
-                float* c = g.C + (long long)m * g.ldc + nq;
-                if (nq < g.N) atomicAdd(c, v.x);
-                if (nq + 1 < g.N) atomicAdd(c + 1, v.y);
-                if (nq + 2 < g.N) atomicAdd(c + 2, v.z);
-                if (nq + 3 < g.N) atomicAdd(c + 3, v.w);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
 // y = bf16(x), same layout; y_lo (optional) = bf16(x - y): the low plane of the split-bf16 x3 form
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* x, __bf16* y, __bf16* y_lo, long long n4) {
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -979,29 +814,3 @@ extern "C" int cruse_ktile_f16(const float* x, int rows, int cols, long long ld,
     return CRUSE_OK;
 }
 
-extern "C" int cruse_gemm_bf16_tn(int M, int N, long long K, const void* A, long long lda, const void* B, long long ldb,
-                                  int b_is_f32, int b_shift_T, float* C, long long ldc, int splitk, void* stream) {
-    CRUSE_REQUIRE(M > 0 && N > 0 && K > 0 && K < (1ll << 31) && M % 8 == 0 && N % 8 == 0, CRUSE_E_SHAPE,
-                  "gemm_bf16_tn: M=%d N=%d (multiples of 8) K=%lld", M, N, K);
-    CRUSE_REQUIRE(lda >= M && ldb >= N && ldc >= N && b_shift_T >= 0, CRUSE_E_SHAPE, "gemm_bf16_tn: strides too small");
-    CRUSE_REQUIRE(lda % 8 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ldb % (b_is_f32 ? 4 : 8) == 0, CRUSE_E_ALIGN,
-                  "gemm_bf16_tn: operand rows must be 16-byte aligned");
-    const long long nkt = (K + BK - 1) / BK;
-    GtArgs g;
-    g.A = (const __bf16*)A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-    g.b_f32 = b_is_f32 ? 1 : 0; g.shiftT = b_shift_T;
-    g.tiles_m = cdiv(M, BM); g.tiles_n = cdiv(N, BN);
-    if (splitk < 1) {                                   // default: fill 256 CUs twice, whole multiples of the 8 XCDs
-        const int tiles = g.tiles_m * g.tiles_n;
-        splitk = cdiv(cdiv(512, tiles), 8) * 8;
-    }
-    if (splitk > nkt) splitk = (int)nkt;
-    g.kt_chunk = (int)((nkt + splitk - 1) / splitk);
-    g.splitk = (int)((nkt + g.kt_chunk - 1) / g.kt_chunk);
-    const long long nblk = (long long)cdiv(g.splitk, 8) * 8 * g.tiles_m * g.tiles_n;
-    CRUSE_REQUIRE(nblk < (1ll << 31), CRUSE_E_SHAPE, "gemm_bf16_tn: grid too large");
-    if (b_is_f32) hipLaunchKernelGGL(gemm_bf16_tn_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, g);
-    else hipLaunchKernelGGL(gemm_bf16_tn_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, g);
-    CRUSE_LAUNCH_CHECK("gemm_bf16_tn");
-    return CRUSE_OK;
-}

@@ -1493,25 +1493,6 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* pane
     return rc;
 }
 
-// db_ih[g][(r, z, n_i)] += column sums of slabs 0..2, db_hh[g][(r, z, n_h)] += slabs 0, 1, 3 of the 4-slab gate-gradient
-// rows dg [rows][G][4][Hg] bf16 (written by the backward recurrence): thread = column, a block walks RB rows, f32 sums,
-// one atomic per column and block
-__global__ __launch_bounds__(256) void gate_bias_sums_kernel(const __bf16* dg, long long rows, int G, int Hg, GateBiasPtrs bp) {
-    const int W = G * 4 * Hg;
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= W) return;
-    const long long rb = (rows + gridDim.y - 1) / gridDim.y, r0 = (long long)blockIdx.y * rb, r1 = min(rows, r0 + rb);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    long long r = r0;
-    for (; r + 3 < r1; r += 4) {
-        a0 += (float)dg[r * W + c]; a1 += (float)dg[(r + 1) * W + c]; a2 += (float)dg[(r + 2) * W + c]; a3 += (float)dg[(r + 3) * W + c];
-    }
-    for (; r < r1; ++r) a0 += (float)dg[r * W + c];
-    const float sum = (a0 + a1) + (a2 + a3);
-    const int g = c / (4 * Hg), sl = (c / Hg) & 3, j = c % Hg;
-    if (sl < 3 && bp.ih[g]) atomicAdd(bp.ih[g] + sl * Hg + j, sum);
-    if (sl != 2 && bp.hh[g]) atomicAdd(bp.hh[g] + (sl == 3 ? 2 : sl) * Hg + j, sum);
-}
 
 }  // namespace
 
@@ -1661,14 +1642,3 @@ extern "C" int cruse_gru_gate_grads_bf16(const float* dh, const void* coef, cons
     return CRUSE_OK;
 }
 
-extern "C" int cruse_gru_gate_bias_sums(const void* dg4, long long rows, int G, int Hg, float* const* db_ih, float* const* db_hh,
-                                        void* stream) {
-    CRUSE_REQUIRE(rows > 0 && G > 0 && G <= MAXG && Hg > 0 && dg4 != nullptr, CRUSE_E_SHAPE, "gru_gate_bias_sums: bad arguments");
-    GateBiasPtrs bp = {};
-    for (int g = 0; g < G; ++g) { bp.ih[g] = db_ih ? db_ih[g] : nullptr; bp.hh[g] = db_hh ? db_hh[g] : nullptr; }
-    const int W = G * 4 * Hg;
-    int ny = (int)(rows / 128); if (ny < 1) ny = 1; if (ny > 256) ny = 256;
-    hipLaunchKernelGGL(gate_bias_sums_kernel, dim3(cdiv(W, 256), ny), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dg4, rows, G, Hg, bp);
-    CRUSE_LAUNCH_CHECK("gru_gate_bias_sums");
-    return CRUSE_OK;
-}

@@ -249,27 +249,8 @@ def _gi_f16(prec, Hg: int, layer: int) -> bool:
     grouped configurations carries ~16 bits on both operands and measured BETTER than f16 there (enhanced spectrum at T = 401, closed-form
     init, g = 4: 3.1e-4 against 1.7e-3; g = 2: 9e-5 against 5.5e-4), so those keep it."""
     c = config.get()
-    return (bool((int(c.gi_f16) * 3 if isinstance(c.gi_f16, bool) else int(c.gi_f16 or 0)) >> layer & 1) and _bf16_gemm_path(prec, Hg) and not (_gi_x3_knob(Hg) & 4) and not c.dw_tn
+    return (bool((int(c.gi_f16) * 3 if isinstance(c.gi_f16, bool) else int(c.gi_f16 or 0)) >> layer & 1) and _bf16_gemm_path(prec, Hg) and not (_gi_x3_knob(Hg) & 4)
             and not c.gi_bf16)
-
-
-def _dw_tn(prec, Hg: int, B: int, g: int) -> bool:
-    """Weight gradients of the gate projections as TN GEMMs on ROW-MAJOR operands (cruse_gemm_bf16_tn): the backward
-    recurrence's loader wave writes the 4-slab gate-gradient rows dg4 [rows, G, 4, Hg] itself (cruse_gru_seq_bwd_ex,
-    dg_slabs = 4), so the gate-gradient pass, the four time-major operand transposes and the 131 MB time-major gate-gradient
-    copy per layer disappear.  Needs the reduce-scatter recurrence kernel: bf16 mode, Hg <= 640, 8-clip chains (all chains of
-    the batch co-resident).
-    OPT-IN (EngineConfig.dw_tn), because it measured SLOWER on the bench step: 6.35 against 6.02 ms (r03).  The register-transposing
-    staging keeps one k-tile in flight where the NT kernel's LDS-DMA keeps two or three, so the TN products take 239 / 204 /
-    165 us alone (264 TF/s; 344 us with the f32 h operand) against 187 + ~140 + ~80 for the NT ones, and the recurrence pays
-    875 instead of 806 us per launch for writing the four bf16 slabs from its loader wave -- more than the removed
-    gate-gradient pass (2 x 112 us), transposes (0.15 ms) and 0.8 GB of traffic give back (tools/tn_probe.py)."""
-    if not config.get().dw_tn or not _bf16_gemm_path(prec, Hg) or Hg > 640 or not SIDE.enabled:
-        return False
-    if ops.get_option("gru_bwd_rs") == 0 or ops.get_option("gru_bg") == 16:
-        return False
-    ncu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-    return ((B + 7) // 8) * g * (Hg // 32) <= ncu
 
 
 def _splitk(M: int, N: int, K: int) -> int:
@@ -371,27 +352,21 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
     # waits for, while in the forward pass they idle: three of the copies are made beside the second forward recurrence,
     # the fourth beside the decoder (late_leaves: the caller issues it after it has joined the side streams).
     fwd_T = save and fast and SIDE.enabled and slot == 0 and config.get().early_t >= 2
-    tn = _dw_tn(prec, Hg, B, g)
-    ctx["tn"] = tn
     tt = {}
 
     def queue_layer1_leaves(h1, l1, l1_bf):
         """queued for the launch of the second forward recurrence"""
-        if tn:                                   # the TN weight-gradient GEMMs read the layer inputs row-major (bf16 copy if made)
-            ctx["in_bf"] = {"gru_list1": x_bf16, "gru_list2": l1_bf}
         if not fwd_T:
             return
         ldT = (rows + 63) // 64 * 64
-        if not tn:
-            tt["xT"], tt["h1T"], tt["l1T"], tt["h2T"] = (torch.empty(ldT // 64, H, 64, device=x.device, dtype=torch.bfloat16)
-                                                         for _ in range(4))
+        tt["xT"], tt["h1T"], tt["l1T"], tt["h2T"] = (torch.empty(ldT // 64, H, 64, device=x.device, dtype=torch.bfloat16)
+                                                     for _ in range(4))
         w_ts = {}                                # K-tiled W_ih^T of both layers: the B operand of the backward dX GEMMs
 
         def t_layer1(x=x, h1=h1, l1=l1):
-            if not tn:
-                ops.transpose_bf16(x, rows, H, out=tt["xT"])
-                ops.transpose_bf16(h1, rows, H, shift_T=T, out=tt["h1T"])
-                ops.transpose_bf16(l1, rows, H, out=tt["l1T"])
+            ops.transpose_bf16(x, rows, H, out=tt["xT"])
+            ops.transpose_bf16(h1, rows, H, shift_T=T, out=tt["h1T"])
+            ops.transpose_bf16(l1, rows, H, out=tt["l1T"])
             for lname in ("gru_list1", "gru_list2"):
                 # (one stacked tensor per layer [g][ceil(3 Hg / 64)][Hg][64]: the grouped dX launch walks it with a group stride)
                 stack = torch.empty(g, (3 * Hg + 63) // 64, Hg, 64, device=x.device, dtype=torch.bfloat16)
@@ -399,10 +374,7 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
                     w_ts[(lname, i)] = ops.transpose_bf16(P[f"{prefix}{lname}.{i}.weight_ih_l0"], 3 * Hg, Hg, out=stack[i])
                 w_ts[(lname, "stack")] = stack
         ctx["w_ts"] = w_ts
-        if tn:
-            SIDE.defer(t_layer1, kind=1, lane=2)
-        else:
-            SIDE.defer(t_layer1, x, h1, l1, tt["xT"], tt["h1T"], tt["l1T"], kind=1, lane=2)
+        SIDE.defer(t_layer1, x, h1, l1, tt["xT"], tt["h1T"], tt["l1T"], kind=1, lane=2)
 
     h1, c1, a1, z1 = layer(x, "gru_list1", x_bf16)
     f16 = _gi_f16(prec, Hg, 1)
@@ -414,7 +386,7 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
     if residual_ready is not None:
         residual_ready()
     out, m2, s2 = ops.ln_fwd(h2, P[prefix + "ln2.weight"], P[prefix + "ln2.bias"], residual, rows, H, 1, save=save, out=out)
-    if fwd_T and not tn:
+    if fwd_T:
         h2T = tt["h2T"]
 
         def t_h2(h2=h2):
@@ -471,42 +443,6 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
         return SIDE.release_around(lambda: ops.gru_seq_bwd(dout_h, w_hh, coef, z, B, T, g, Hg, prec, slot=slot_,
                                                            xcd_rot=xcd_rot, an=an, want_dgi=an is not None, dg_slabs=dg_slabs,
                                                            zeroed=zeroed))
-
-    def layer_bwd_tn(dout_h, lname, inp, h, coef, an, z, need_dinp, last):
-        """CRUSE_PREC_BF16 with row-major operands only (_dw_tn): the recurrence writes dh and the 4-slab gate-gradient rows;
-        dX is the NT GEMM on them (K = 3*Hg of every 4*Hg), the weight gradients are TN GEMMs, the bias gradients a column sum."""
-        names = [f"{prefix}{lname}.{i}." for i in range(g)]
-        w_hh = [P[nm + "weight_hh_l0"] for nm in names]
-        bias_ih = [G[nm + "bias_ih_l0"] for nm in names]
-        bias_hh = [G[nm + "bias_hh_l0"] for nm in names]
-        dh, dg4 = run_bwd(dout_h, w_hh, coef, z, an, dg_slabs=4)
-        inp_bf = ctx.get("in_bf", {}).get(lname)
-        xin = inp_bf if inp_bf is not None else inp          # (f32 rows are converted while staging)
-
-        def weight_grads():
-            ops.gru_gate_bias_sums(dg4, rows, g, Hg, bias_ih, bias_hh)
-            for i, nm in enumerate(names):
-                a0 = 4 * i * Hg
-                ops.gemm_bf16_tn(3 * Hg, Hg, rows, dg4, a0, 4 * H, xin, i * Hg, H, G[nm + "weight_ih_l0"], 0, Hg)
-                ops.gemm_bf16_tn(2 * Hg, Hg, rows, dg4, a0, 4 * H, h, i * Hg, H, G[nm + "weight_hh_l0"], 0, Hg, b_shift_T=T)
-                ops.gemm_bf16_tn(Hg, Hg, rows, dg4, a0 + 3 * Hg, 4 * H, h, i * Hg, H, G[nm + "weight_hh_l0"], 2 * Hg * Hg, Hg,
-                                 b_shift_T=T)
-
-        dinp, acc_dx = dinp_buffer(dout_h, need_dinp, last)
-        if need_dinp:
-            for i, nm in enumerate(names):
-                w_t = ctx.get("w_ts", {}).get((lname, i))
-                if w_t is None:
-                    w_t = ops.transpose_bf16(P[nm + "weight_ih_l0"], 3 * Hg, Hg)
-                ops.gemm_bf16_nt(rows, Hg, w_t.shape[0] * 64, dg4, 4 * i * Hg, 4 * H, w_t, 0, 64, dinp, i * Hg, H,
-                                 accumulate=acc_dx, b_kstride=Hg * 64)
-        if last and defer_last:
-            SIDE.defer(weight_grads, dg4, h, xin, dh, kind=0xffff, lane=2)
-        elif last:
-            SIDE.run(weight_grads, dg4, h, xin, dh, lane=2)
-        else:
-            SIDE.defer(weight_grads, dg4, h, xin, dh, kind=4, lane=2)
-        return dinp
 
     def dinp_buffer(dout_h, need_dinp, last):
         if not need_dinp:
@@ -606,8 +542,6 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
 
     def layer_bwd(dout_h, lname, inp, h, coef, an, z, need_dinp, last):
         """last: no recurrence follows, so the weight-gradient leaves start at once instead of with the next one."""
-        if ctx.get("tn"):
-            return layer_bwd_tn(dout_h, lname, inp, h, coef, an, z, need_dinp, last)
         if _bf16_gemm_path(prec, Hg):
             return layer_bwd_bf16(dout_h, lname, inp, h, coef, an, z, need_dinp, last)
         w_hh = [P[f"{prefix}{lname}.{i}.weight_hh_l0"] for i in range(g)]
@@ -647,7 +581,7 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
     early_T = {}
     if "T1" in ctx:                                      # made in the forward pass (_ggru_forward_one)
         early_T["gru_list1"], early_T["gru_list2"] = ctx["T1"], ctx["T2"]
-    elif _bf16_gemm_path(prec, Hg) and SIDE.enabled and config.get().early_t >= 1 and not ctx.get("tn"):
+    elif _bf16_gemm_path(prec, Hg) and SIDE.enabled and config.get().early_t >= 1:
         ldT1 = (rows + 63) // 64 * 64
         x1T = torch.empty(ldT1 // 64, H, 64, device=dout.device, dtype=torch.bfloat16)
         h1T = torch.empty(ldT1 // 64, H, 64, device=dout.device, dtype=torch.bfloat16)

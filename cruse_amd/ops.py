@@ -795,21 +795,6 @@ def gru_seq_bwd(dout, w_hh: List[torch.Tensor], coef, z, B, T, G, Hg, prec, slot
     return (dh, dgi) if want_dgi else dh
 
 
-def gemm_bf16_tn(M, N, K, A, a_off, lda, B, b_off, ldb, C, c_off, ldc, b_shift_T=0, splitk=0):
-    """C[M,N] += sum_k A[k, a_off + m] * B[k, b_off + n] (cruse_gemm_bf16_tn): A bf16 rows, B bf16 or f32 rows (f32: read one
-    frame back when b_shift_T > 0 -- the h_{t-1} operand), C f32 holding the running sum."""
-    if A.dtype != torch.bfloat16 or B.dtype not in (torch.bfloat16, torch.float32) or C.dtype != torch.float32:
-        raise RuntimeError("gemm_bf16_tn: A bf16, B bf16 / f32, C f32")
-    _p(A); _p(B); _p(C)
-    check(lib.cruse_gemm_bf16_tn(M, N, K, _off(A, a_off), lda, _off(B, b_off), ldb, 1 if B.dtype == torch.float32 else 0, b_shift_T,
-                                 _off(C, c_off), ldc, splitk, _stream()))
-
-
-def gru_gate_bias_sums(dg4, rows, G, Hg, db_ih, db_hh):
-    check(lib.cruse_gru_gate_bias_sums(_p(dg4), rows, G, Hg, ctypes.cast(_ptr_array(db_ih), ctypes.c_void_p),
-                                       ctypes.cast(_ptr_array(db_hh), ctypes.c_void_p), _stream()))
-
-
 def gru_gate_grads(dh, coef, an, rows, G, Hg, prec):
     if (coef.dtype == torch.bfloat16) != (prec_code(prec) == PREC_BF16):
         raise RuntimeError("gru_gate_grads: coef dtype does not match the precision mode")

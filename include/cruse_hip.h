@@ -340,14 +340,6 @@ int cruse_gemm_bf16_nt_groups(int M, int N, int K, int G, const void* A_hi, cons
 int cruse_gemm_bf16_nt_obf16(int M, int N, int K, const void* A_hi, const void* A_lo, long long lda, long long a_kstride,
                              const void* B_hi, const void* B_lo, long long ldb, long long b_kstride,
                              void* C, long long ldc, const float* bias, void* stream);
-/* TN form for the weight gradients of the gate projections (dW_ih += dgi^T x, dW_hh += dgh^T h_{t-1}; nn.GRU backward at
- * model/cruse_net.py:44,50): C[M,N] += sum_k A[k*lda + m] * B[k*ldb + n] over the K = B*T frames, with A (bf16 gate-gradient
- * rows) and B (bf16 layer-input rows, or f32 hidden-state rows when b_is_f32) ROW-MAJOR as the backward recurrence / the
- * forward pass left them -- no time-major copies.  b_shift_T > 0: row k of B is read from row k-1 and is zero when
- * k % b_shift_T == 0 (the h_{t-1} operand).  M, N multiples of 8.  splitk <= 0: chosen by the library; k-slices are
- * pinned to XCDs and added atomically (C must hold the running sum / zeros). */
-int cruse_gemm_bf16_tn(int M, int N, long long K, const void* A, long long lda, const void* B, long long ldb,
-                       int b_is_f32, int b_shift_T, float* C, long long ldc, int splitk, void* stream);
 /* cruse_gemm_bf16_nt / cruse_gemm_bf16x3_nt (A_lo, B_lo nullable: plain bf16) on a TIME CHUNK of the batch: logical row m of A
  * (row-major, lda) and of C is physical row (m / seg_len) * seg_stride + seg_off + m % seg_len; M = B * seg_len.  The gate
  * projection gi = x W_ih^T of frames [seg_off, seg_off + seg_len) of every clip then runs beside the recurrence of the
@@ -433,7 +425,7 @@ int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh, const void
  *            supported by the reduce-scatter kernels only (CRUSE_PREC_BF16, Hg <= 640).
  *            dg_slabs: 3 = dgi rows [G][3][Hg] (r, z, n_i); 4 = [G][4][Hg] with slab 3 = dh * c_n, the n gate of
  *            dgh = dh * (c_r, c_z, c_n) (reduce-scatter kernel): one row-major tensor that is the A operand of
- *            dX = dgi W_ih (K = 3*Hg of every 4*Hg) and of both weight-gradient products of cruse_gemm_bf16_tn.
+ *            dX = dgi W_ih (K = 3*Hg of every 4*Hg) (the row-major TN weight-gradient products that also read it are gone: measured slower, r3).
  *   panels_zeroed: the caller has cleared the panel scratch (cruse_gru_ws_bytes() - 256 bytes at `panels`) since its last use, on
  *            this stream or ordered before it; 0: the call clears it itself (one memset launch in front of the recurrence).  A
  *            training step clears the scratches of its four recurrences with one launch at its top.
@@ -467,10 +459,6 @@ int cruse_gru_gate_grads(const float* dh, const void* coef, const float* an, flo
 int cruse_gru_gate_grads_bf16(const float* dh, const void* coef, const float* an, void* dgi, void* dgT,
                               long long ldT, float* const* db_ih, float* const* db_hh,
                               long long rows, int G, int Hg, void* stream);
-/* bias gradients from the 4-slab gate-gradient rows dg4 [rows][G][4][Hg] bf16 of cruse_gru_seq_bwd_ex(dg_slabs = 4):
- * db_ih[g][3*Hg] += column sums of slabs (r, z, n_i), db_hh[g][3*Hg] += (r, z, n_h).  HOST arrays of G device pointers. */
-int cruse_gru_gate_bias_sums(const void* dg4, long long rows, int G, int Hg, float* const* db_ih, float* const* db_hh,
-                             void* stream);
 
 /* ---- mask application + weighted spectral loss ------------------------------- */
 

@@ -846,14 +846,14 @@ def test_sdnr_kernel_vs_reference_fixture(golden):
 
 def test_bf16_mode_with_channels_beyond_the_mfma_kernels_and_an_input_gradient():
     """the bf16 storage of backward-only tensors (EngineConfig.bf16_dy / bf16_de) is taken only where every consumer is an MFMA
-    kernel.  A bf16-mode unet_2 with 24- / 48-channel levels (not powers of two: VALU convs and weight gradients, f32 tensors) and the upsample model with
+    kernel.  A bf16-mode unet_2 with 12- / 24-channel levels (not powers of two: VALU convs and weight gradients, f32 tensors) and the upsample model with
     x.requires_grad (level 1's data gradient into the one-channel input is a VALU conv) run their backward passes and agree with the
     f32 mode of the same weights."""
     from model.cruse import CRUSE4MagAddSkipUpsample
     from model.cruse_net import unet_2
     torch.manual_seed(7)
-    wide = unet_2(ch=(1, 8, 16, 24, 48), rnn_groups=1, precision="bf16").cuda()
-    ref = unet_2(ch=(1, 8, 16, 24, 48), rnn_groups=1, precision="f32").cuda()
+    wide = unet_2(ch=(1, 8, 12, 24, 64), rnn_groups=1, precision="bf16").cuda()
+    ref = unet_2(ch=(1, 8, 12, 24, 64), rnn_groups=1, precision="f32").cuda()
     ref.load_state_dict(wide.state_dict())
     x = (torch.rand(2, 1, 21, 160) + 0.05).cuda(); w = torch.randn(2, 1, 21, 160).cuda()
     for m in (wide, ref):

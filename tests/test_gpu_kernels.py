@@ -1237,85 +1237,6 @@ def test_gru_register_direct_sweeps_and_all_gather_backward(ops, B, T):
     assert torch.equal(out[2][1].view(-1), dgi_ref.view(-1))
 
 
-@pytest.mark.parametrize("b_f32,shift", [(False, 0), (True, 0), (True, 7), (False, 7)])
-def test_gemm_bf16_tn_weight_gradient_form(b_f32, shift):
-    """cruse_gemm_bf16_tn: C += A^T B over K rows with ROW-MAJOR operands (register-transposing LDS staging), against the
-    same contraction of the bf16-rounded operands in f64; M, N not multiples of the 128-wide tile, K not a multiple of 64,
-    column offsets / row strides as the GRU backward uses them (4-slab gate-gradient rows), the h_{t-1} row shift."""
-    from cruse_amd import ops
-    torch.manual_seed(11)
-    K, lda, ldb = 7 * 39, 4 * 168, 168                 # 39 clips of 7 frames
-    M, N, a_off, b_off = 3 * 168 - 8, 168 - 16, 8, 16
-    A = torch.randn(K, lda).cuda().bfloat16()
-    Bm = torch.randn(K, ldb).cuda()
-    Bop = Bm if b_f32 else Bm.bfloat16()
-    C0 = torch.randn(M, 200).cuda()
-    Bsh = Bm.bfloat16().double()
-    if shift:
-        Bsh = torch.roll(Bsh, 1, 0)
-        Bsh[torch.arange(K) % shift == 0] = 0
-    want = C0[:, :N].double() + A[:, a_off:a_off + M].double().t() @ Bsh[:, b_off:b_off + N]
-    for sk in (0, 1, 3):
-        C = C0.clone()
-        ops.gemm_bf16_tn(M, N, K, A, a_off, lda, Bop, b_off, ldb, C, 0, 200, b_shift_T=shift, splitk=sk)
-        assert rel_l2(C[:, :N], want) < 2e-6, (sk, rel_l2(C[:, :N], want))
-        assert torch.equal(C[:, N:], C0[:, N:])
-
-
-def test_recurrence_writes_four_slab_gate_gradients():
-    """cruse_gru_seq_bwd_ex(dg_slabs = 4): the loader wave's dg4 [rows, G, 4, Hg] (r, z, n_i, n_h) against the separate
-    gate-gradient pass, and the bias column sums from it."""
-    from cruse_amd import ops
-    torch.manual_seed(4)
-    B, T, G, Hg = 11, 19, 2, 160
-    H = G * Hg
-    gi = torch.randn(B, T, 3 * H).cuda()
-    w = [(torch.randn(3 * Hg, Hg) / Hg ** 0.5).cuda() for _ in range(G)]
-    b = [(0.1 * torch.randn(3 * Hg)).cuda() for _ in range(G)]
-    dout = torch.randn(B, T, H).cuda()
-    h, coef, an, z = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16")
-    dh, dg4 = ops.gru_seq_bwd(dout, w, coef, z, B, T, G, Hg, "bf16", an=an, want_dgi=True, dg_slabs=4)
-    db_ih = [torch.zeros(3 * Hg).cuda() for _ in range(G)]; db_hh = [torch.zeros(3 * Hg).cuda() for _ in range(G)]
-    dgi, dgT, ldT = ops.gru_gate_grads_bf16(dh, coef, an, B * T, G, Hg, db_ih, db_hh)
-    assert dg4.shape == (B * T, G, 4, Hg)
-    assert torch.equal(dg4[:, :, :3], dgi.view(B * T, G, 3, Hg))
-    cn = coef.view(B * T, G, 3, Hg)[:, :, 2].float()
-    want_nh = (dh.view(B * T, G, Hg) * cn).bfloat16()
-    assert torch.equal(dg4[:, :, 3], want_nh)
-    s_ih = [torch.zeros(3 * Hg).cuda() for _ in range(G)]; s_hh = [torch.zeros(3 * Hg).cuda() for _ in range(G)]
-    ops.gru_gate_bias_sums(dg4, B * T, G, Hg, s_ih, s_hh)
-    for g_ in range(G):
-        assert rel_l2(s_ih[g_], db_ih[g_]) < 3e-3 and rel_l2(s_hh[g_], db_hh[g_]) < 3e-3      # (bf16-rounded terms vs f32 terms)
-    assert ops.gru_status() == 0
-
-
-@pytest.mark.parametrize("grp", [1, 4])
-def test_tn_weight_gradient_path_matches_the_default(grp):
-    """EngineConfig(dw_tn=True) (opt-in: row-major TN weight-gradient GEMMs fed by the recurrence's own 4-slab gate-gradient rows) gives
-    the training step of the default path (NT GEMMs on time-major copies): same loss, same gradients up to bf16 rounding of
-    the bias-gradient terms and the split-K summation order."""
-    from cruse_amd.data import synth_batch
-    from cruse_amd.engine import TrainEngine
-    from cruse_amd.model import cruse_net as M
-    from cruse_amd.model.cruse_net import unet_2
-    res = {}
-    noisy, clean = synth_batch(8, 16000, "cuda", 3)
-    from cruse_amd import config
-    from cruse_amd.config import EngineConfig
-    for tn in ("0", "1"):
-        torch.manual_seed(1)
-        eng = TrainEngine(unet_2(rnn_groups=grp, precision="bf16").cuda(), use_graph=False, config=EngineConfig(dw_tn=tn == "1", gi_f16=0))    # (the TN path projects in the split-bf16 form)
-        ls = eng._fwd_bwd(noisy, clean)
-        torch.cuda.synchronize()
-        with config.use(eng.cfg), M.use_scheduler(eng.side):
-            assert M._dw_tn("bf16", 640 // grp, 8, grp) == (tn == "1")
-        res[tn] = (eng.loss_value(ls), {k: v.clone() for k, v in eng.flat.G.items()})
-    assert res["0"][0] == pytest.approx(res["1"][0], rel=1e-6)
-    for k, v in res["0"][1].items():
-        if float(v.norm()) < 1e-7:
-            continue
-        tol = 5e-3 if "bias_" in k else 2e-4
-        assert rel_l2(res["1"][1][k], v) < tol, (k, rel_l2(res["1"][1][k], v))
 
 
 @pytest.mark.parametrize("form", ["gather", "scatter", "wgrad_a", "wgrad_bt"])
