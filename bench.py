@@ -178,10 +178,10 @@ class KernelTimer:
 
     NAMES = ["stft", "conv_gather", "conv_scatter2", "conv_gather_bnin", "conv_scatter2_bnin", "conv_wgrad", "channel_sum", "col_sum", "bn_stats", "bn_finalize",
              "bn_act_fwd", "bn_finalize_act_fwd", "bn_act_bwd", "ln_fwd", "ln_bwd", "gemm", "gemm_bf16_nt", "gemm_bf16x3_nt", "cast_bf16", "cast_bf16_padded",
-             "ktile_bf16", "transpose_bf16", "gemm_bf16_nt_cat", "gemm_bf16_nt_atr", "gemm_f16_nt", "ktile_f16",
+             "ktile_bf16", "transpose_bf16", "gemm_bf16_nt_cat", "gemm_f16_nt", "ktile_f16",
              "gru_seq_fwd", "gru_seq_bwd", "gru_gate_grads", "gru_gate_grads_bf16", "mask_loss"]
     # entry points that launch the same kernel as another one are booked under that family
-    FAMILY = {"gemm_bf16_nt_cat": "gemm_bf16_nt", "gemm_bf16_nt_atr": "gemm_bf16_nt", "ktile_f16": "ktile_bf16"}
+    FAMILY = {"gemm_bf16_nt_cat": "gemm_bf16_nt", "ktile_f16": "ktile_bf16"}
 
     def __init__(self, ops, eng):
         self.ops, self.rec, self.saved, self.eng = ops, [], {}, eng

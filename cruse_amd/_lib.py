@@ -60,9 +60,7 @@ SIGNATURES = {
     "cruse_gemm_bf16_slab_bytes": ("iii", "z"),
     "cruse_gemm_bf16_nt_slabs": ("iiipqqpqqpqipzp", "i"),
     "cruse_gemm_bf16_nt_slabs_cat": ("ipiippqqpqqpqipzp", "i"),
-    "cruse_gemm_bf16_nt_atr": ("iiipqipqqpqip", "i"),
     "cruse_gemm_bf16_nt_groups": ("iiiippqqppqqqpqqpqip", "i"),
-    "cruse_gemm_bf16_nt_obf16": ("iiippqqppqqpqpp", "i"),
     "cruse_gemm_bf16_nt_seg": ("iiippqppqqpqpiiqqp", "i"),
     "cruse_cast_bf16": ("ppqp", "i"),
     "cruse_transpose_bf16": ("pqiqpqip", "i"),
@@ -76,7 +74,7 @@ SIGNATURES = {
     "cruse_gru_seq_bwd": ("pppppiiiiipp", "i"),
     "cruse_gru_seq_fwd_on": ("pppppppiiiiippip", "i"),
     "cruse_gru_seq_bwd_on": ("pppppppiiiiippip", "i"),
-    "cruse_gru_seq_fwd_ex": ("ppppppppqiiiiiiiipipip", "i"),
+    "cruse_gru_seq_fwd_ex": ("ppppppppqiiiiiiipipip", "i"),
     "cruse_gru_seq_bwd_ex": ("pppppppiiiiiiiiipipip", "i"),
     "cruse_gru_gate_grads": ("pppppqiiip", "i"),
     "cruse_gru_gate_grads_bf16": ("pppppqppqiip", "i"),

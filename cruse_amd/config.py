@@ -23,36 +23,17 @@ class EngineConfig:
     defer_mask: int = 15            # leaves queued for the next recurrence launch: 1 skip convs (fwd), 2 decoder weight gradients,
                                     # 4 GRU weight gradients, 8 skip-conv backward leaves
     inline_mask: int = 8            # backward leaves kept on the main stream: 1 skip dgrads, 2 skip wgrads, 4 decoder wgrads,
-                                    # 8 << (k - 1) the level-k encoder wgrad (8: -0.025 ms; the others measured slower or equal), 128 << (k - 1)
-                                    # the level-k encoder wgrad on the main stream AFTER its serial chain (r4: the side queue ends ~190 us after
-                                    # the main stream's last kernel, but moving its tail over buys < 0.02 ms: both streams are bound by the same HBM)
+                                    # 8 << (k - 1) the level-k encoder wgrad, k = 1..4 (8: -0.025 ms; the others measured slower or equal)
     early_t: int = 2                # dW operand transposes: 0 inside each layer's leaf, 1 layer 1's beside the first backward
                                     # recurrence, 2 all four in the forward pass (6.08 vs 6.12 ms)
     fuse_bn_stats: bool = True      # BatchNorm batch sums in the producing conv's epilogue (False: separate bn_stats pass)
     fuse_bn_bwd_stats: bool = True  # BatchNorm BACKWARD sums in the epilogue of the data-gradient conv that produces the incoming gradient
-    fuse_dgi: bool = False          # the backward recurrence writes the bf16 gate gradients itself (measured neutral)
-    fuse_cast: bool = True          # the gate GEMMs' bf16 operand copies written by the producing BatchNorm / LayerNorm kernel
     gi_x3: Optional[int] = None     # forward gate projections: bit 0 / 1 = W_ih low-plane pass on layer 1 / 2, bit 2 = also split x
                                     # (None: 7 for Hg <= 320, else 3)
     gi_f16: int = 2                 # forward gate projections as ONE pass on IEEE-f16 operands (cruse_gemm_f16_nt; with g = 1 the BatchNorm /
                                     # LayerNorm producers write the f16 operand copies) instead of bf16 x with W_ih hi / lo planes (gi_x3): both
                                     # operands carry 11 significant bits -- enhanced-spectrum rel-L2 at T = 401 4.6e-4 -> 3.8e-4 (closed-form init),
                                     # 3.6e-4 -> 1.6e-4 (random init) -- and the step loses the low-plane pass (4.85 -> 4.76 ms, r4).  False: gi_x3 form
-    gi_bf16: bool = False           # the gate pre-activations gi = x W_ih^T + b_ih stored as bf16 rows (f32 accumulation, one rounding;
-                                    # the recurrence widens them on load).  OPT-IN: -0.4 GB per step but time-neutral
-                                    # (5.71 vs 5.72 ms: the projection GEMM is not bound by its store), and the forward error of the
-                                    # bf16 mode grows from 5.7e-4 to 6.9e-4 at T = 401 and from 5.1e-4 to 1.03e-3 -- over the bar -- on
-                                    # fixture G6
-    dw_xcdk: Optional[int] = None   # k-slices of the dW GEMMs pinned to XCDs (None: 8 where there are >= 24 output tiles, else 0)
-    dw_slabs: bool = True           # the dW GEMMs' k-slices store partial sums to slabs that one kernel adds in order, instead of f32
-                                    # atomics that meet at the memory side (5.53 vs 5.67 ms; dW reproducible from run to run)
-    dw_cat: bool = True             # Hg % 128 == 0: the three weight-gradient products of a GRU layer as ONE launch on the concatenated output
-                                    # [dW_ih ; dW_hh] (cruse_gemm_bf16_nt_slabs_cat): the gate-gradient k-tiles are fetched once for all three
-    gemm_groups: bool = True        # rnn_groups > 1: the forward gate projections and the input gradients of all groups of a layer as ONE launch each
-                                    # (cruse_gemm_bf16_nt_groups) instead of one per group
-    dx_atr: bool = False            # Hg % 64 == 0: the input-gradient GEMM of a GRU layer reads the TIME-MAJOR gate-gradient tensor through transposing
-                                    # LDS reads (cruse_gemm_bf16_nt_atr); the gate-gradient pass then writes no row-major dgi (98 MB per layer)
-    conv_bwd_x3: bool = False       # backward-data convolutions as split-bf16 x3 instead of plain bf16
     fuse_bn_fwd: bool = True        # bf16 mode, training: BatchNorm-apply + ReLU (+ decoder skip add) of a level run inside the STAGING of
                                     # the convs that consume it (cruse_conv_*_bnin) -- the normalised tensors e_k (k < L) and u_k (k >= 2)
                                     # never exist in f32; the weight gradients read a bf16 copy the consuming conv writes while staging
@@ -70,15 +51,15 @@ class EngineConfig:
 
     _ENV = {"overlap": ("CRUSE_OVERLAP", lambda v: v == "1"), "defer_mask": ("CRUSE_DEFER", int), "inline_mask": ("CRUSE_INLINE", int),
             "early_t": ("CRUSE_EARLY_T", int), "fuse_bn_stats": ("CRUSE_FUSE_BN_STATS", lambda v: v != "0"),
-            "fuse_dgi": ("CRUSE_FUSE_DGI", lambda v: v == "1"),
-            "fuse_bn_bwd_stats": ("CRUSE_FUSE_BN_BWD", lambda v: v != "0"), "fuse_cast": ("CRUSE_FUSE_CAST", lambda v: v == "1"),
-            "gi_x3": ("CRUSE_GI_X3", int), "gi_f16": ("CRUSE_GI_F16", int), "gi_bf16": ("CRUSE_GI_BF16", lambda v: v == "1"), "dw_xcdk": ("CRUSE_DW_XCDK", int), "conv_bwd_x3": ("CRUSE_CONV_BWD_X3", lambda v: v == "1"),
-            "dw_slabs": ("CRUSE_DW_SLABS", lambda v: v != "0"), "dw_cat": ("CRUSE_DW_CAT", lambda v: v != "0"), "dx_atr": ("CRUSE_DX_ATR", lambda v: v == "1"), "gemm_groups": ("CRUSE_GEMM_GROUPS", lambda v: v != "0"), 
+            
+            "fuse_bn_bwd_stats": ("CRUSE_FUSE_BN_BWD", lambda v: v != "0"), 
+            "gi_x3": ("CRUSE_GI_X3", int), "gi_f16": ("CRUSE_GI_F16", int), 
+             
             "fuse_bn_fwd": ("CRUSE_FUSE_BN_FWD", lambda v: v != "0"), "fuse_bn_bwd_apply": ("CRUSE_FUSE_BN_BWD_APPLY", lambda v: v != "0"), "bf16_dy": ("CRUSE_BF16_DY", lambda v: v != "0"), "bf16_de": ("CRUSE_BF16_DE", lambda v: v != "0")}
-    _LIB_ENV = {"CRUSE_GRU_BWD_RS": "gru_bwd_rs", "CRUSE_GRU_FWD_LEAN": "gru_fwd_lean", "CRUSE_GRU_WLO": "gru_wlo",
-                "CRUSE_GRU_DBG": "gru_dbg", "CRUSE_GRU_PRIO": "gru_prio", "CRUSE_CM_GRID": "cm_grid", "CRUSE_CM_KINT": "cm_kint", "CRUSE_CM_SWAP": "cm_swap", "CRUSE_CM_NW": "cm_nw",
-                "CRUSE_GB_DEEP_MIN": "gb_deep_min", "CRUSE_GB_DEEP": "gb_deep", "CRUSE_GB_BM256": "gb_bm256", "CRUSE_GB_PIPE": "gb_pipe", "CRUSE_PW_VALU": "pw_valu", "CRUSE_LNB_GRID": "lnb_grid",
-                "CRUSE_GRU_TF": "gru_tf", "CRUSE_GRU_POLL_FWD": "gru_poll_fwd", "CRUSE_GRU_POLL_BWD": "gru_poll_bwd", "CRUSE_GRU_BWD_AG": "gru_bwd_ag", "CRUSE_GRU_FWD_RD": "gru_fwd_rd", "CRUSE_WG_TFW": "wg_tfw", "CRUSE_WG_GRID": "wg_grid", "CRUSE_WG_DBG": "wg_dbg", "CRUSE_WG_SR": "wg_sr"}
+    _LIB_ENV = {"CRUSE_GRU_BWD_RS": "gru_bwd_rs", "CRUSE_GRU_FWD_LEAN": "gru_fwd_lean", "CRUSE_GRU_WLO": "gru_wlo", "CRUSE_GRU_DBG": "gru_dbg",
+                "CRUSE_GRU_TF": "gru_tf", "CRUSE_GRU_POLL_FWD": "gru_poll_fwd", "CRUSE_GRU_POLL_BWD": "gru_poll_bwd", "CRUSE_CM_KINT": "cm_kint",
+                "CRUSE_CM_SWAP": "cm_swap", "CRUSE_CM_NW": "cm_nw", "CRUSE_PW_VALU": "pw_valu", "CRUSE_WG_TFW": "wg_tfw", "CRUSE_WG_DBG": "wg_dbg",
+                "CRUSE_WG_SR": "wg_sr"}
 
     @classmethod
     def from_env(cls, env=None) -> "EngineConfig":

@@ -24,8 +24,8 @@ extern "C" int cruse_abi_version(void) { return CRUSE_ABI_VERSION; }
 #include <limits.h>
 #include <string.h>
 namespace {
-const char* const OPT_NAMES[] = {"gru_bwd_rs", "gru_fwd_lean", "gru_tf", "gru_poll_fwd", "gru_poll_bwd", "gru_stag_fwd", "gru_stag_bwd", "gru_bwd_ag", "gru_fwd_rd", "gru_xsweep", "gru_wlo", "gru_dbg", "gru_poll_fwd16", "gru_poll_bwd16", "gru_prio", "cm_grid", "cm_nw", "cm_dbg", "cm_kint", "cm_swap", "gb_deep_min", "gb_deep", "gb_bm256", "gb_pipe",
-                                 "pw_valu", "dw_nolds", "wgpw_blocks", "wgpw_run", "wgpw_dbg", "lnb_grid", "wg_tfw", "wg_grid", "wg_dbg", "wg_sr"};
+const char* const OPT_NAMES[] = {"gru_bwd_rs", "gru_fwd_lean", "gru_tf", "gru_poll_fwd", "gru_poll_bwd", "gru_wlo", "gru_dbg", "cm_dbg", "cm_nw", "cm_kint", "cm_swap",
+                                 "pw_valu", "wg_sr", "wg_dbg", "wg_tfw"};
 constexpr int N_OPT = sizeof(OPT_NAMES) / sizeof(OPT_NAMES[0]);
 std::atomic<int> g_opt[N_OPT];
 struct OptInit { OptInit() { for (auto& o : g_opt) o.store(INT_MIN); } } g_opt_init;

@@ -492,6 +492,7 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
     CRUSE_REQUIRE(!grp || (!c_bf16 && !slabs && splitk == 1 && !cat && atr_mbs == 0 && seg_len == 0 && a_kstride == BK), CRUSE_E_SHAPE,
                   "gemm_bf16_nt_groups: row-major A, f32 result, no split-K");
     const bool atr = atr_mbs != 0;
+    CRUSE_REQUIRE(!atr && !c_bf16, CRUSE_E_SHAPE, "gemm_bf16_nt: the transposed-A and bf16-output forms were removed (measured neutral / slower, r3-r4)");
     CRUSE_REQUIRE(!atr || (!A_lo && !B_lo && !c_bf16 && !slabs && splitk == 1 && !f16 && !cat && seg_len == 0), CRUSE_E_SHAPE,
                   "gemm_bf16_nt_atr: plain bf16, one pass, no split-K");
     CRUSE_REQUIRE(!f16 || (!A_lo && !B_lo && !c_bf16 && !slabs && splitk == 1 && !accumulate), CRUSE_E_SHAPE,
@@ -532,9 +533,7 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
         g.m_end0 = cat->m_end[0]; g.m_end1 = cat->m_end[1]; g.m_end2 = cat->m_end[2]; g.c_rows1 = cat->c_rows[1]; g.c_rows2 = cat->c_rows[2];
         M_out = cat->M_out;
     }
-    // 256-row tiles (8 waves, three stages) for the un-split products with many row tiles: the gate projections and dX (option gb_bm256)
-    const bool big = splitk == 1 && !slabs && !f16 && !cat && !atr && !grp && M >= 16 * BM && cruse_opt("gb_bm256", 0) != 0;
-    g.tiles_m = cdiv(M, big ? 2 * BM : BM); g.tiles_n = cdiv(N, BN);
+    g.tiles_m = cdiv(M, BM); g.tiles_n = cdiv(N, BN);
     if (grp) {
         g.tn_per_g = g.tiles_n; g.tiles_n *= grp->G;
         g.a_gstep = grp->a_gstep; g.b_gstep = grp->b_gstep; g.c_gstep = grp->c_gstep; g.bias_gstep = grp->bias_gstep;
@@ -559,38 +558,15 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
     CRUSE_REQUIRE(splitk == 1 || accumulate, CRUSE_E_SHAPE, "gemm_bf16_nt: split-K adds into C (accumulate = 1)");
     const dim3 grid((unsigned)nblk);
     hipStream_t st = (hipStream_t)stream;
-    int deep_min = 64;                         // long k-loops: three stages, one block per CU
-    { const int e = cruse_opt("gb_deep_min", 0); if (e > 0) deep_min = e; }      // profiling options
-    bool deep = kt_chunk >= deep_min;
-    { const int e = cruse_opt("gb_deep", -1); if (e >= 0) deep = e != 0; }
-    const bool pipe = cruse_opt("gb_pipe", 0) != 0;     // pinned instruction order inside a k-tile (see compute_pipe)
-    const size_t lds = big ? (size_t)3 * 3 * TILE_BYTES : (size_t)(deep ? 3 : 2) * 2 * TILE_BYTES;
+    const bool deep = kt_chunk >= 64;          // long k-loops: three stages, one block per CU
+    const size_t lds = (size_t)(deep ? 3 : 2) * 2 * TILE_BYTES;
 #define CRUSE_GB_LAUNCH(MODE, NST)                                                                               \
     do {                                                                                                         \
-        if (pipe) {                                                                                              \
-            int rc0 = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_bf16_nt_kernel<MODE, NST, 1, false, false, true>), lds, "gemm_bf16_nt"); \
-            if (rc0) return rc0;                                                                                 \
-            hipLaunchKernelGGL((gemm_bf16_nt_kernel<MODE, NST, 1, false, false, true>), grid, dim3(256), lds, st, g); \
-            break;                                                                                               \
-        }                                                                                                        \
         int rc0 = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_bf16_nt_kernel<MODE, NST>), lds,       \
                                        "gemm_bf16_nt");                                                          \
         if (rc0) return rc0;                                                                                     \
         hipLaunchKernelGGL((gemm_bf16_nt_kernel<MODE, NST>), grid, dim3(256), lds, st, g);                       \
     } while (0)
-    if (big) {
-#define CRUSE_GB_LAUNCH_BIG(MODE)                                                                                \
-    do {                                                                                                         \
-        int rc0 = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_bf16_nt_kernel<MODE, 3, 2>), lds,      \
-                                       "gemm_bf16_nt");                                                          \
-        if (rc0) return rc0;                                                                                     \
-        hipLaunchKernelGGL((gemm_bf16_nt_kernel<MODE, 3, 2>), grid, dim3(512), lds, st, g);                      \
-    } while (0)
-        if (c_bf16) CRUSE_GB_LAUNCH_BIG(3); else if (accumulate) CRUSE_GB_LAUNCH_BIG(1); else CRUSE_GB_LAUNCH_BIG(0);
-#undef CRUSE_GB_LAUNCH_BIG
-        CRUSE_LAUNCH_CHECK("gemm_bf16_nt");
-        return CRUSE_OK;
-    }
     if (use_slabs) {
         if (deep) CRUSE_GB_LAUNCH(4, 3); else CRUSE_GB_LAUNCH(4, 2);
         CRUSE_LAUNCH_CHECK("gemm_bf16_nt");
@@ -598,20 +574,6 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
         hipLaunchKernelGGL(gemm_slab_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, slabs, splitk, g.slab, M_out, N,
                            c_final, ldc_final);
         CRUSE_LAUNCH_CHECK("gemm_slab_reduce");
-        return CRUSE_OK;
-    }
-    if (atr) {
-        const size_t ldsa = (size_t)2 * 2 * TILE_BYTES;
-        if (accumulate) {
-            int rc0 = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_bf16_nt_kernel<1, 2, 1, false, true>), ldsa, "gemm_bf16_nt_atr");
-            if (rc0) return rc0;
-            hipLaunchKernelGGL((gemm_bf16_nt_kernel<1, 2, 1, false, true>), grid, dim3(256), ldsa, st, g);
-        } else {
-            int rc0 = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_bf16_nt_kernel<0, 2, 1, false, true>), ldsa, "gemm_bf16_nt_atr");
-            if (rc0) return rc0;
-            hipLaunchKernelGGL((gemm_bf16_nt_kernel<0, 2, 1, false, true>), grid, dim3(256), ldsa, st, g);
-        }
-        CRUSE_LAUNCH_CHECK("gemm_bf16_nt_atr");
         return CRUSE_OK;
     }
     if (f16) {
@@ -623,11 +585,9 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
         return CRUSE_OK;
     }
     if (deep) {
-        if (c_bf16) CRUSE_GB_LAUNCH(3, 3);
-        else if (splitk > 1) CRUSE_GB_LAUNCH(2, 3); else if (accumulate) CRUSE_GB_LAUNCH(1, 3); else CRUSE_GB_LAUNCH(0, 3);
+        if (splitk > 1) CRUSE_GB_LAUNCH(2, 3); else if (accumulate) CRUSE_GB_LAUNCH(1, 3); else CRUSE_GB_LAUNCH(0, 3);
     } else {
-        if (c_bf16) CRUSE_GB_LAUNCH(3, 2);
-        else if (splitk > 1) CRUSE_GB_LAUNCH(2, 2); else if (accumulate) CRUSE_GB_LAUNCH(1, 2); else CRUSE_GB_LAUNCH(0, 2);
+        if (splitk > 1) CRUSE_GB_LAUNCH(2, 2); else if (accumulate) CRUSE_GB_LAUNCH(1, 2); else CRUSE_GB_LAUNCH(0, 2);
     }
 #undef CRUSE_GB_LAUNCH
     CRUSE_LAUNCH_CHECK("gemm_bf16_nt");
@@ -650,18 +610,6 @@ extern "C" int cruse_gemm_f16_nt(int M, int N, int K, const void* A, long long l
                           nullptr, 0, true);
 }
 
-// C[M,N] (+)= A[M,K] . B[N,K]^T with A given as its TIME-MAJOR K-tiled image: element (m, k) at A_T[(m / 64) * a_mb_stride + k * 64 + m % 64],
-// n_mb 64-row blocks present (rows M <= m < 64 * n_mb hold finite values).  This is the layout of the gate-gradient tensor dgT
-// [ceil(rows / 64)][G][4][Hg][64] the weight-gradient GEMMs consume (A_T = dgT + group * 4 * Hg * 64, a_mb_stride = G * 4 * Hg * 64): the input
-// gradient dX = dgi . W_ih is formed from it directly and the row-major copy dgi is never written.  K % 64 == 0.
-extern "C" int cruse_gemm_bf16_nt_atr(int M, int N, int K, const void* A_T, long long a_mb_stride, int n_mb,
-                                      const void* B, long long ldb, long long b_kstride,
-                                      float* C, long long ldc, int accumulate, void* stream) {
-    CRUSE_REQUIRE(a_mb_stride >= (long long)K * 64 && a_mb_stride % 8 == 0 && n_mb >= 1 && (long long)n_mb * 64 >= M, CRUSE_E_SHAPE,
-                  "gemm_bf16_nt_atr: a_mb_stride=%lld n_mb=%d for M=%d K=%d", a_mb_stride, n_mb, M, K);
-    return gemm_bf16_impl(M, N, K, A_T, nullptr, 64, 64 * 64, B, nullptr, ldb, b_kstride, C, ldc, nullptr, accumulate, 1, stream, 0, 0, 0, false,
-                          nullptr, 0, false, nullptr, a_mb_stride, n_mb - 1);
-}
 
 // G products of the same shape in ONE launch, side by side along N -- the GRU groups of a layer:
 //   C[:, q * c_gstep + (0 .. N)] (+)= A[:, q * a_gstep + (0 .. K)] . B_q^T + bias_q      B_q = B + q * b_gstep, bias_q = bias + q * bias_gstep
@@ -729,14 +677,6 @@ extern "C" int cruse_gemm_bf16_nt_slabs_cat(int nprob, const int* Ms, int N, int
                           false, reinterpret_cast<float*>(scratch), scratch_bytes, false, &cat);
 }
 
-extern "C" int cruse_gemm_bf16_nt_obf16(int M, int N, int K, const void* A_hi, const void* A_lo, long long lda, long long a_kstride,
-                                        const void* B_hi, const void* B_lo, long long ldb, long long b_kstride,
-                                        void* C, long long ldc, const float* bias, void* stream) {
-    CRUSE_REQUIRE((A_lo == nullptr || B_lo != nullptr) && ((uintptr_t)A_lo % 16) == 0 && ((uintptr_t)B_lo % 16) == 0, CRUSE_E_ALIGN,
-                  "gemm_bf16_nt_obf16: low planes (A_lo needs B_lo; 16-byte aligned)");
-    return gemm_bf16_impl(M, N, K, A_hi, A_lo, lda, a_kstride, B_hi, B_lo, ldb, b_kstride, reinterpret_cast<float*>(C), ldc, bias, 0, 1,
-                          stream, 0, 0, 0, true);
-}
 
 extern "C" int cruse_gemm_bf16_nt_seg(int M, int N, int K, const void* A_hi, const void* A_lo, long long lda,
                                       const void* B_hi, const void* B_lo, long long ldb, long long b_kstride,

@@ -1377,17 +1377,14 @@ int dispatch_fwd_lean_w(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
     }
 }
 int dispatch_fwd_lean(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
-    // Hg = 640: the K-split step on the tag-free hand-off (library option gru_tf = 0 / 2: the tagged hand-off / the K-split-free kernel)
-    const bool tf640 = a.Hg == 640 && !fwd_wlo(a.Hg) && !a.gi_bf16 && a.h0 == nullptr && cruse_opt("gru_tf", 1) != 0;
-    if (tf640 && cruse_opt("gru_fwd_rd", 1) != 0) {      // register-direct sweep (see the kernel)
+    // Hg = 640: the K-split step on the tag-free hand-off with the register-direct sweep (library option gru_tf = 0: the tagged hand-off)
+    const bool tf640 = a.Hg == 640 && !fwd_wlo(a.Hg) && a.h0 == nullptr && cruse_opt("gru_tf", 1) != 0;
+    if (tf640) {
         if (a.dbg == 32) return launch_one(gru_fwd_lean_kernel<5, 5, true, false, true, false, true, true>, a, grid, lds, s, "gru_seq_fwd", 320);
         return launch_one(gru_fwd_lean_kernel<5, 5, true, false, false, false, true, true>, a, grid, lds, s, "gru_seq_fwd", 320);
     }
-    if (a.dbg == 32 && tf640) return launch_one(gru_fwd_lean_kernel<5, 5, true, false, true, false, true>, a, grid, lds, s, "gru_seq_fwd", 320);
-    if (tf640) return launch_one(gru_fwd_lean_kernel<5, 5, true, false, false, false, true>, a, grid, lds, s, "gru_seq_fwd", 320);
-    if (a.dbg == 32 && a.Hg == 640 && !fwd_wlo(a.Hg) && !a.gi_bf16)
+    if (a.dbg == 32 && a.Hg == 640 && !fwd_wlo(a.Hg))
         return launch_one(gru_fwd_lean_kernel<5, 5, true, false, true>, a, grid, lds, s, "gru_seq_fwd", 320);
-    if (a.gi_bf16) return fwd_wlo(a.Hg) ? dispatch_fwd_lean_w<true, true>(a, grid, lds, s) : dispatch_fwd_lean_w<false, true>(a, grid, lds, s);
     return fwd_wlo(a.Hg) ? dispatch_fwd_lean_w<true, false>(a, grid, lds, s) : dispatch_fwd_lean_w<false, false>(a, grid, lds, s);
 }
 
@@ -1448,7 +1445,6 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* pane
     unsigned* tickets_base = (unsigned*)(xg_base + xg_bytes_total(a.B, G, Hg));        // [launch][8]
     a.Bg = pl.Bg; a.P = pl.P;
     a.dbg = cruse_opt("gru_dbg", 0);
-    a.xsweep = cruse_opt("gru_xsweep", 0);
     int rc = CRUSE_OK;
     CRUSE_REQUIRE(pl.nlaunch <= MAX_LAUNCH_TICKETS, CRUSE_E_SHAPE, "gru_seq: batch %d needs %d launches (max %d)", a.B, pl.nlaunch,
                   MAX_LAUNCH_TICKETS);
@@ -1456,7 +1452,6 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* pane
         const int bg_off = L * pl.bg_per_launch;
         const int nbg_here = (pl.nbg - bg_off) < pl.bg_per_launch ? (pl.nbg - bg_off) : pl.bg_per_launch;
         a.bg_off = bg_off;
-        a.prio = cruse_opt("gru_prio", 0);
         a.nchains = nbg_here * G;
         // every launch gets its own panel region: chain index inside the launch + offset
         a.xid = (unsigned long long*)xid_base + (size_t)bg_off * G * 64;
@@ -1467,7 +1462,7 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* pane
         a.xg_bytes = (unsigned)((size_t)a.nchains * 2 * gpp * 8);
         const int grid = cdiv(a.nchains, 8) * 8 * pl.P;
         if (FWD && pl.wide) {
-            a.poll_delay = cruse_opt("gru_poll_fwd16", 0);
+            a.poll_delay = 0;
             rc = dispatch_fwd_w16(a, grid, s);
         } else if (FWD && fwd_lean_eligible(pl.Bg, Hg, prec)) {
             if (fwd_tf_eligible(pl.Bg, Hg, prec, a.h0 != nullptr, a.gi_bf16 != 0)) { a.poll_delay = cruse_opt("gru_poll_fwd", 8); rc = dispatch_fwd_tf(a, grid, fwd_wlo(Hg), s); }
@@ -1477,11 +1472,11 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* pane
             else if (prec == CRUSE_PREC_BF16X3) rc = dispatch_fwd<CRUSE_PREC_BF16X3>(a, grid, lds, s);
             else rc = dispatch_fwd<CRUSE_PREC_BF16>(a, grid, lds, s);
         } else if (pl.wide) {
-            a.poll_delay = cruse_opt("gru_poll_bwd16", 5);
+            a.poll_delay = 6;                         // (tools/gru_wide_probe.py: 1.62 us per step at 5..8 periods, 1.67 at 0, 1.71 at 12)
             rc = dispatch_bwd_w16(a, grid, s);
         } else if (rs_form) {
             // (the tag-free kernel's panels are half the size of the reduce-scatter kernel's: the same regions hold them)
-            if (bwd_tf_eligible(pl.Bg, Hg, prec)) { a.poll_delay = cruse_opt("gru_poll_bwd", cruse_opt("gru_bwd_ag", 2) != 0 ? (Hg == 640 ? 5 : 7) : 10); a.poll_stagger = cruse_opt("gru_stag_bwd", 0); rc = dispatch_bwd_tf(a, grid, s); }
+            if (bwd_tf_eligible(pl.Bg, Hg, prec)) { a.poll_delay = cruse_opt("gru_poll_bwd", Hg == 640 ? 5 : 7); rc = dispatch_bwd_tf(a, grid, s); }
             else rc = dispatch_bwd_rs(a, grid, s);
         } else {
             if (prec == CRUSE_PREC_F32) rc = dispatch_bwd<CRUSE_PREC_F32>(a, grid, lds, s);
@@ -1502,11 +1497,9 @@ extern "C" size_t cruse_gru_ws_bytes(int B, int G, int Hg) {
 
 extern "C" int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, const float* const* b_hh,
                                     float* h, void* coef, float* an, float* z, const float* h0, long long h0_bstride,
-                                    int B, int T, int TS, int G, int Hg, int prec, int chain_clips, int gi_bf16, void* panels,
+                                    int B, int T, int TS, int G, int Hg, int prec, int chain_clips, void* panels,
                                     int panels_zeroed, unsigned* status, int xcd_rot, void* stream) {
     int rc = check_common(B, T, G, Hg, prec, "gru_seq_fwd");
-    CRUSE_REQUIRE(!gi_bf16 || (prec == CRUSE_PREC_BF16 && ((uintptr_t)gi % 16) == 0), CRUSE_E_SHAPE,
-                  "gru_seq_fwd: bf16 gi rows need CRUSE_PREC_BF16 and a 16-byte aligned base");
     CRUSE_REQUIRE(chain_clips == 0 || chain_clips == 8 || chain_clips == 16, CRUSE_E_SHAPE, "gru_seq_fwd: chain_clips = %d (0, 8, 16)", chain_clips);
     if (rc) return rc;
     CRUSE_REQUIRE(TS >= T, CRUSE_E_SHAPE, "gru_seq_fwd: clip stride %d frames < %d steps", TS, T);
@@ -1517,7 +1510,7 @@ extern "C" int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, c
     Plan pl;
     // wide chains: f32 gi rows; their tag-free hand-off needs |h| < 1, so an initial state is taken only where the caller asks for
     // wide chains outright and thereby vouches for |h0| < 1 (the continuation of a sequence that started from zero)
-    const bool wide_ok = !gi_bf16 && (h0 == nullptr || chain_clips == 16);
+    const bool wide_ok = h0 == nullptr || chain_clips == 16;
     CRUSE_REQUIRE(make_plan(B, G, Hg, prec, true, chain_clips, wide_ok, pl) == 0, CRUSE_E_SHAPE, "gru_seq_fwd: G*Hg/32 exceeds the CU count");
     hipStream_t s = (hipStream_t)stream;
     CRUSE_REQUIRE(panels != nullptr && status != nullptr, CRUSE_E_SHAPE, "gru_seq_fwd: workspace / status pointer is NULL");
@@ -1526,7 +1519,6 @@ extern "C" int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, c
     if (!panels_zeroed) { int zrc = cruse_zero_async(panels, cruse_gru_ws_bytes(B, G, Hg) - 256, s, "gru_seq_fwd memset"); if (zrc) return zrc; }
     GruArgs a = {};
     a.gi = gi; a.h = h; a.coef = coef; a.an = an; a.z = z;
-    a.gi_bf16 = gi_bf16 ? 1 : 0;
     for (int g = 0; g < G; ++g) { a.p.w_hh[g] = w_hh[g]; a.p.b_hh[g] = b_hh[g]; }
     a.B = B; a.T = T; a.G = G; a.Hg = Hg;
     a.TS = TS; a.h0 = h0; a.h0_bs = h0_bstride;
@@ -1539,7 +1531,7 @@ extern "C" int cruse_gru_seq_fwd_on(const float* gi, const float* const* w_hh, c
                                     float* h, void* coef, float* an, float* z,
                                     int B, int T, int G, int Hg, int prec, void* panels, unsigned* status, int xcd_rot,
                                     void* stream) {
-    return cruse_gru_seq_fwd_ex(gi, w_hh, b_hh, h, coef, an, z, nullptr, 0, B, T, T, G, Hg, prec, 0, 0, panels, 0, status, xcd_rot, stream);
+    return cruse_gru_seq_fwd_ex(gi, w_hh, b_hh, h, coef, an, z, nullptr, 0, B, T, T, G, Hg, prec, 0, panels, 0, status, xcd_rot, stream);
 }
 
 extern "C" int cruse_gru_seq_fwd(const float* gi, const float* const* w_hh, const float* const* b_hh,

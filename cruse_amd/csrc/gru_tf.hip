@@ -388,364 +388,7 @@ __global__ __launch_bounds__(320) void gru_fwd_tf_kernel(GruArgs a) {
 }
 
 
-// ---------------------------------------------------------------------------------
-// backward: the reduce-scatter form of gru_bwd_rs (a workgroup contracts over the 96 gate rows it owns and publishes the
-// 8 x Hg partial sums; the consumer sums the P partials of its 32 units) on the tag-free hand-off.
-//   * partials travel as plain bf16, the epoch bit in bit 14, SCALED by 2^-64: the scale is folded into the operand panel
-//     (dh * 2^-64 * c, exact), so the MFMA results are the scaled partials and the consumer multiplies its sum by 2^64 once;
-//   * layout [consumer q][clip][producer p][32 units] bf16: a lane's sweep load is 16 bytes = 8 units of one producer, a quad
-//     reads the 64-byte row of one (clip, producer), the 8 lanes-quads of a clip read 512 contiguous bytes;
-//   * sweep thread = (clip, producer octant og, 16-byte chunk pp): NL = ceil(P/8) loads (3 at Hg = 640 instead of 5), eight
-//     unit sums per thread, then a REDUCE-SCATTER over the octants -- v_permlane32_swap / v_permlane16_swap (one swap + one add
-//     per kept value) and one DPP row rotate -- that leaves every thread with the sum of ONE unit: its own (clip, unit);
-//   * publish: two tile pairs (two consumers) per store instruction -- the second pair's values move to the idle column lanes
-//     (row_ror:8), v_permlane16_swap joins the unit quads of neighbouring row groups into 16-byte pieces -- ceil(NP/2) stores of
-//     64 x 16 bytes per wave and step instead of NP (3 instead of 5 at Hg = 640).
-// ---------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-template <int P, bool TIMED = false, bool STAG = false>
-__global__ __launch_bounds__(320) void gru_bwd_tf_kernel(GruArgs a) {
-    constexpr int Hg = P * 32, NP = (P + 3) / 4, NT = 2 * NP, NTt = 2 * P, NL = (P + 7) / 8, K3 = 3 * Hg;
-    constexpr bool FULL = P % 4 == 0;
-    constexpr int KP = 96 + 8;
-    constexpr float SC = 5.421010862427522e-20f, ISC = 1.8446744073709552e19f;     // 2^-64, 2^64
-    unsigned long long tph[5] = {0, 0, 0, 0, 0}, tq0 = 0, tq1 = 0;
-    (void)tph; (void)tq0; (void)tq1;
-    __shared__ __attribute__((aligned(16))) __bf16 panel[2][16 * KP];
-    // (rows of 36 floats: a 32-lane half of a sweep wave holds 2 clips x 16 units -- 4 banks apart, no conflicts)
-    constexpr int RS = 36;
-    __shared__ __attribute__((aligned(16))) float op_d[4][8][RS], op_z[4][8][RS];       // ring slot = iteration & 3
-    __shared__ __attribute__((aligned(16))) __bf16 op_c[4][8][96];
-    __shared__ __attribute__((aligned(16))) float op_a[4][8][RS];                       // a_n rows (only when dgi is written)
-    __shared__ __attribute__((aligned(16))) float dh_l[2][8][RS];                       // dh of iteration k in parity k & 1
-    const int H = a.G * Hg;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int chain, part;
-    if (!claim_chain(a, P, chain, part)) return;
-    const int grp = chain % a.G, bgi = a.bg_off + chain / a.G;
-    const int b0 = bgi * 8, nb = min(8, a.B - b0);
-    const int u0 = part * U;
-    const float* W = a.p.w_hh[grp];
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.xg, 0, a.xg_bytes, 0x00020000);
-    constexpr unsigned cons_bytes = (unsigned)(8 * P * 64);         // [clip 8][producer P][32 units] bf16
-    constexpr unsigned panel_bytes = (unsigned)P * cons_bytes;      // one parity of one chain
-    const unsigned cbase = (unsigned)chain * 2u * panel_bytes;
-
-    for (int i = tid; i < 2 * 16 * KP; i += 320) panel[0][i] = (__bf16)0.f;
-
-    const unsigned frame_bytes = (unsigned)H * 4u, crow_bytes = (unsigned)(a.G * K3) * 2u;
-    const long long nrow = (long long)(a.B - 1) * a.TS + a.T;           // rows reachable from the (advanced) base pointers
-    const unsigned tot_f32 = (unsigned)min(nrow * H * 4, 0xffffffffll);
-    const unsigned tot_cf = (unsigned)min(nrow * a.G * K3 * 2, 0xffffffffll);
-    const __amdgpu_buffer_rsrc_t rs_dout = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dout), 0, tot_f32, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.zs), 0, tot_f32, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_dh = __builtin_amdgcn_make_buffer_rsrc(a.dh, 0, tot_f32, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_cf = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.coefs), 0, tot_cf, 0x00020000);
-    const bool nodata = a.dbg == 7 || a.dbg == 34;       // profiling: no operand streams
-
-    if (wv == 4) {
-        // ---- loader wave (as in gru_bwd_rs).  Iteration j needs dout_{T-1-j}, c_{T-1-j} and z_{T-j}; lane = (clip, 16-byte chunk).
-        const int lc = lane >> 3, lq = lane & 7;                                   // dout / z: 8 clips x 8 chunks of 4 floats
-        const unsigned dv = (unsigned)(((long long)(b0 + (lc < nb ? lc : 0)) * a.TS * H + grp * Hg + u0 + 4 * lq) * 4);
-        unsigned cv[2], cdst[2];
-        bool cok[2];
-#pragma unroll
-        for (int i2 = 0; i2 < 2; ++i2) {                                           // coef: 8 clips x 3 gates x 4 chunks of 8 bf16
-            const int idx = lane + 64 * i2;
-            cok[i2] = idx < 96;
-            const int cl = min(idx, 95) / 12, rem = min(idx, 95) % 12, gate = rem >> 2, chk = rem & 3;
-            cv[i2] = (unsigned)((((long long)(b0 + (cl < nb ? cl : 0)) * a.TS * a.G + grp) * K3 + gate * Hg + u0 + 8 * chk) * 2);
-            cdst[i2] = (unsigned)(cl * 96 + gate * 32 + chk * 8);
-        }
-        const bool want_dgi = a.dgi != nullptr;
-        const __amdgpu_buffer_rsrc_t rs_an = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ans), 0, a.ans ? tot_f32 : 0u, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_dgi = __builtin_amdgcn_make_buffer_rsrc(a.dgi, 0, a.dgi ? (a.dg_slabs == 4 ? (unsigned)min(nrow * a.G * 4 * Hg * 2, 0xffffffffll) : tot_cf) : 0u, 0x00020000);
-        struct OpSet { u32x4 d, z, c0, c1, an; };
-        auto issue = [&](int j, OpSet& o) {
-            const u32x4 zero = {0u, 0u, 0u, 0u};
-            o.d = zero; o.z = zero; o.c0 = zero; o.c1 = zero; o.an = zero;
-            if (j >= a.T || nodata) return;
-            const unsigned st = (unsigned)(a.T - 1 - j);
-            o.d = (j == 0 && a.carry) ? __builtin_amdgcn_raw_buffer_load_b128(rs_dh, dv, st * frame_bytes, 0)
-                                      : __builtin_amdgcn_raw_buffer_load_b128(rs_dout, dv, st * frame_bytes, 0);
-            if (j > 0) o.z = __builtin_amdgcn_raw_buffer_load_b128(rs_z, dv, (st + 1u) * frame_bytes, 0);
-            o.c0 = __builtin_amdgcn_raw_buffer_load_b128(rs_cf, cv[0], st * crow_bytes, 0);
-            if (cok[1]) o.c1 = __builtin_amdgcn_raw_buffer_load_b128(rs_cf, cv[1], st * crow_bytes, 0);
-            if (want_dgi) o.an = __builtin_amdgcn_raw_buffer_load_b128(rs_an, dv, st * frame_bytes, 0);
-        };
-        auto put = [&](int j, const OpSet& o) {
-            const int slot = j & 3;
-            *reinterpret_cast<u32x4*>(&op_d[slot][lc][4 * lq]) = o.d;
-            *reinterpret_cast<u32x4*>(&op_z[slot][lc][4 * lq]) = o.z;
-            *reinterpret_cast<u32x4*>(&op_c[slot][0][0] + cdst[0]) = o.c0;
-            if (cok[1]) *reinterpret_cast<u32x4*>(&op_c[slot][0][0] + cdst[1]) = o.c1;
-            if (want_dgi) *reinterpret_cast<u32x4*>(&op_a[slot][lc][4 * lq]) = o.an;
-        };
-        const int NSL = a.dg_slabs == 4 ? 4 : 3;
-        const unsigned dgrow_bytes = (unsigned)(a.G * NSL * Hg) * 2u;
-        const unsigned gi_v = (unsigned)((((long long)(b0 + (lc < nb ? lc : 0)) * a.TS * a.G + grp) * NSL * Hg + u0 + 4 * lq) * 2);
-        auto flush = [&](int j) {
-            if (lc >= nb) return;
-            const unsigned st = (unsigned)(a.T - 1 - j);
-            const float4 d4 = *reinterpret_cast<const float4*>(&dh_l[j & 1][lc][4 * lq]);
-            const u32x4 dw = {__float_as_uint(d4.x), __float_as_uint(d4.y), __float_as_uint(d4.z), __float_as_uint(d4.w)};
-            __builtin_amdgcn_raw_buffer_store_b128(dw, rs_dh, dv, st * frame_bytes, 0);
-            if (want_dgi) {
-                const int slot = j & 3;
-                typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
-                const bf16x4_ cr = *reinterpret_cast<const bf16x4_*>(&op_c[slot][lc][4 * lq]);
-                const bf16x4_ cz = *reinterpret_cast<const bf16x4_*>(&op_c[slot][lc][32 + 4 * lq]);
-                const float4 a4 = *reinterpret_cast<const float4*>(&op_a[slot][lc][4 * lq]);
-                const float d[4] = {d4.x, d4.y, d4.z, d4.w}, an_[4] = {a4.x, a4.y, a4.z, a4.w};
-                bf16x4_ o0, o1, o2;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    o0[e] = (__bf16)(d[e] * (float)cr[e]); o1[e] = (__bf16)(d[e] * (float)cz[e]); o2[e] = (__bf16)(d[e] * an_[e]);
-                }
-                __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o0), rs_dgi, gi_v, st * dgrow_bytes, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o1), rs_dgi, gi_v + (unsigned)Hg * 2u, st * dgrow_bytes, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o2), rs_dgi, gi_v + (unsigned)Hg * 4u, st * dgrow_bytes, 0);
-                if (NSL == 4) {
-                    const bf16x4_ cn = *reinterpret_cast<const bf16x4_*>(&op_c[slot][lc][64 + 4 * lq]);
-                    bf16x4_ o3;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o3[e] = (__bf16)(d[e] * (float)cn[e]);
-                    __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2*>(&o3), rs_dgi, gi_v + (unsigned)Hg * 6u, st * dgrow_bytes, 0);
-                }
-            }
-        };
-        OpSet s0, s1;
-        issue(0, s0); issue(1, s1);
-        put(0, s0); put(1, s1);
-        issue(2, s0); issue(3, s1);
-        if (a.dbg != 9) (void)team_shares_xcd(a.xid + (size_t)chain * 64, P, part, a.status, tid);    // mirrors the compute waves' barriers
-        __syncthreads();
-        for (int k = 0; k < a.T; k += 2) {
-            put(k + 2, s0);
-            issue(k + 4, s0);
-            if (k > 0) flush(k - 1);
-            if (a.T - 1 - k == 0) break;
-            __syncthreads();
-            put(k + 3, s1);
-            issue(k + 5, s1);
-            flush(k);
-            if (a.T - 2 - k == 0) break;
-            __syncthreads();
-        }
-        __syncthreads();                                // the last iteration's dh is in LDS
-        flush(a.T - 1);
-        return;
-    }
-
-    // A operand = W_hh[own gate rows, :]^T: A[row = output unit][k = own gate row]; k = gate*32 + unit, so k-step == gate
-    bf16x8 wf[NT][3];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int gt = 2 * (wv * NP + (nt >> 1)) + (nt & 1);  // pairs beyond P (P % 4 != 0) carry zero weights
-        const int n = min(gt, NTt - 1) * 16 + (lane & 15);
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                wf[nt][kk][e] = (FULL || gt < NTt) ? (__bf16)W[(long long)(kk * Hg + u0 + (lane >> 4) * 8 + e) * Hg + n] : (__bf16)0.f;
-        }
-    }
-
-    // sweep thread = (clip bl, producer octant og, 16-byte chunk pp): lane bits 0-1 pp, bit 2 the low clip bit, bits 3-5 og
-    const int pp = lane & 3, og = lane >> 3, bl = wv * 2 + ((lane >> 2) & 1);
-    const bool active = bl < nb;
-    const int blc = active ? bl : 0;                                  // inactive threads shadow clip 0 (loads only)
-    unsigned sweep_v[NL];
-    bool sweep_ok[NL];
-#pragma unroll
-    for (int jj = 0; jj < NL; ++jj) {
-        const int pr = og + 8 * jj;
-        sweep_ok[jj] = pr < P;
-        sweep_v[jj] = (unsigned)part * cons_bytes + (unsigned)((blc * P + min(pr, P - 1)) * 64 + pp * 16);
-    }
-    // after the reduce-scatter the thread holds unit 8 pp + 4 b5 + 2 b4 + b3 of clip bl (b = lane bits)
-    const int ou = 8 * pp + 4 * ((lane >> 5) & 1) + 2 * ((lane >> 4) & 1) + ((lane >> 3) & 1);
-    const bool b3 = (lane >> 3) & 1;
-    // publish: lane (c16 = lane & 15, qd = lane >> 4) of a store holds, for clip c16 & 7 and the pair (np + (c16 >> 3)), the 16-byte
-    // piece of units 4 qd .. 4 qd + 7 (qd even: tile 0) or 16 + 4 (qd - 1) .. + 7 (qd odd: tile 1)
-    const int c16 = lane & 15, qd = lane >> 4, hi8 = c16 >> 3;
-    constexpr int NST = (NP + 1) / 2;
-    unsigned pub_v[NST];
-    bool pub_ok[NST];
-#pragma unroll
-    for (int st = 0; st < NST; ++st) {
-        const int np = 2 * st + hi8;                          // this lane's pair of the store
-        const int cq = wv * NP + np;                          // = consumer
-        pub_ok[st] = np < NP && (FULL || cq < P) && (c16 & 7) < nb;
-        pub_v[st] = (unsigned)min(cq, P - 1) * cons_bytes + (unsigned)(((c16 & 7) * P + part) * 64 + ((qd >> 1) + 2 * (qd & 1)) * 16);
-    }
-    const int pw = blc * KP + ou;                                     // panel element of the own unit (+ gate*32)
-
-    float dh = 0.f, dd = 0.f, zz = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;  // operands of the current step (time s)
-    bool nowait = a.dbg >= 1 && a.dbg < 7;
-    const bool plain = a.dbg != 9 && team_shares_xcd(a.xid + (size_t)chain * 64, P, part, a.status, tid);
-    __syncthreads();                                                  // ring slots 0 and 1 are filled
-    dd = op_d[0][blc][ou];
-    c0 = (float)op_c[0][blc][ou]; c1 = (float)op_c[0][blc][32 + ou]; c2 = (float)op_c[0][blc][64 + ou];
-
-    for (int k = 0; k < a.T; ++k) {
-        const int s = a.T - 1 - k;
-        float m = 0.f;
-        if constexpr (TIMED) tq0 = __builtin_amdgcn_s_memtime();
-        if (k > 0) {
-            const unsigned soff = cbase + (unsigned)((k - 1) & 1) * panel_bytes;
-            const unsigned tm = tag_bit((unsigned)k) ? TAGM : 0u;       // expected tag bits
-            u32x4 g[NL];
-            unsigned spins = 0;
-            for (int i = 0; i < a.poll_delay; ++i) __builtin_amdgcn_s_sleep(1);     // (see poll_delay)
-            auto tags_ok = [&](const u32x4* q) -> bool {
-                unsigned bad = 0u;
-#pragma unroll
-                for (int j = 0; j < NL; ++j) {
-                    const unsigned bj = (q[j].x ^ tm) | (q[j].y ^ tm) | (q[j].z ^ tm) | (q[j].w ^ tm);
-                    bad |= sweep_ok[j] ? bj : 0u;
-                }
-                return __all((bad & TAGM) == 0u || !active || nowait);
-            };
-            auto give_up = [&]() {
-                if (++spins >= SPIN_LIMIT) {
-                    if (lane == 0) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    nowait = true;
-                }
-                if constexpr (TIMED) tph[4] += 1;
-            };
-            if constexpr (STAG) {
-                // TWO polls in flight, a.poll_stagger sleep periods apart: loads return in order, so while the older set is examined
-                // the younger one is already half way -- a missed poll costs the stagger, not a whole L2 round trip
-                u32x4 g2[NL];
-#pragma unroll
-                for (int j = 0; j < NL; ++j) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, sweep_v[j], soff, 16);
-                for (;;) {
-                    for (int i = 0; i < a.poll_stagger; ++i) __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-                    for (int j = 0; j < NL; ++j) g2[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, sweep_v[j], soff, 16);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (tags_ok(g)) break;
-                    give_up();
-#pragma unroll
-                    for (int j = 0; j < NL; ++j) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, sweep_v[j], soff, 16);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (tags_ok(g2)) {
-#pragma unroll
-                        for (int j = 0; j < NL; ++j) g[j] = g2[j];
-                        break;
-                    }
-                    give_up();
-                }
-            } else {
-                for (;;) {
-#pragma unroll
-                    for (int j = 0; j < NL; ++j) g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, sweep_v[j], soff, 16);
-                    if (tags_ok(g)) break;
-                    give_up();
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[0] += tq1 - tq0; tq0 = tq1; }
-            f32x2 sm[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};         // units (2i, 2i + 1) of the chunk
-#pragma unroll
-            for (int j = 0; j < NL; ++j) {
-                const unsigned d4[4] = {g[j].x, g[j].y, g[j].z, g[j].w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const unsigned dm = sweep_ok[j] ? (d4[i] & ~TAGM) : 0u;
-                    const f32x2 v = {__uint_as_float(dm << 16), __uint_as_float(dm & 0xffff0000u)};
-                    sm[i] += v;
-                }
-            }
-            // reduce-scatter over the octants: after the three levels the thread holds the sum of unit `ou`
-            float v8[8] = {sm[0][0], sm[0][1], sm[1][0], sm[1][1], sm[2][0], sm[2][1], sm[3][0], sm[3][1]};
-            float v4[4], v2[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {                  // lane bit 5: even half-waves keep units 0..3, odd 4..7
-                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v8[i]), __float_as_uint(v8[i + 4]), false, false);
-                v4[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {                  // lane bit 4
-                const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v4[i]), __float_as_uint(v4[i + 2]), false, false);
-                v2[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-            }
-            {                                              // lane bit 3 (lane ^ 8 inside the 16-lane row)
-                const float send = b3 ? v2[0] : v2[1], keep = b3 ? v2[1] : v2[0];
-                m = (keep + __uint_as_float(dpp_ror8(__float_as_uint(send)))) * ISC;
-            }
-        }
-        dh = dd + zz * dh + m;
-        __bf16* pn = panel[k & 1];
-        if (active) {
-            dh_l[k & 1][bl][ou] = dh;                      // the loader wave writes it (and the gate gradients) to HBM
-            const float ds = dh * SC;
-            pn[pw] = (__bf16)(ds * c0); pn[pw + 32] = (__bf16)(ds * c1); pn[pw + 64] = (__bf16)(ds * c2);
-        }
-        if (s == 0) break;                                 // nothing consumes the partials of time 0
-        {                                                  // operands of step k+1 from the loader wave's ring (slot = iteration & 3)
-            const int slot = (k + 1) & 3;
-            dd = op_d[slot][blc][ou];
-            zz = op_z[slot][blc][ou];
-            c0 = (float)op_c[slot][blc][ou]; c1 = (float)op_c[slot][blc][32 + ou]; c2 = (float)op_c[slot][blc][64 + ou];
-        }
-        if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[1] += tq1 - tq0; tq0 = tq1; }
-        __syncthreads();                                   // panel[k & 1] complete; panel[(k+1) & 1] is free again
-        if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[2] += tq1 - tq0; tq0 = tq1; }
-        bf16x8 fb[3];
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk)
-            fb[kk] = *reinterpret_cast<const bf16x8*>(pn + (lane & 15) * KP + kk * 32 + (lane >> 4) * 8);
-        const unsigned soff = cbase + (unsigned)(k & 1) * panel_bytes;
-        const unsigned tagm = tag_bit((unsigned)(k + 1)) ? TAGM : 0u;
-#pragma unroll
-        for (int st = 0; st < NST; ++st) {
-            // pairs 2 st and 2 st + 1 of this wave: tiles (4 st .. 4 st + 3)
-            unsigned a0[2], a1[2], b0_[2], b1_[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int np = 2 * st + h;
-                if (np < NP) {
-                    f32x4 t0 = (f32x4){0.f, 0.f, 0.f, 0.f}, t1 = t0;
-#pragma unroll
-                    for (int kk = 0; kk < 3; ++kk) {
-                        t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * np][kk], fb[kk], t0, 0, 0, 0);
-                        t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[2 * np + 1][kk], fb[kk], t1, 0, 0, 0);
-                    }
-                    a0[h] = pack2(t0[0], t0[1]); a1[h] = pack2(t0[2], t0[3]);
-                    b0_[h] = pack2(t1[0], t1[1]); b1_[h] = pack2(t1[2], t1[3]);
-                } else {
-                    a0[h] = a1[h] = b0_[h] = b1_[h] = 0u;
-                }
-            }
-            // the second pair's values to the idle column lanes (clips sit in columns 0..7): lanes 8..15 of a row take lane - 8
-            const unsigned x0 = (unsigned)__builtin_amdgcn_update_dpp((int)a0[0], (int)a0[1], 0x128, 0xf, 0xC, false);
-            const unsigned x1 = (unsigned)__builtin_amdgcn_update_dpp((int)a1[0], (int)a1[1], 0x128, 0xf, 0xC, false);
-            const unsigned y0 = (unsigned)__builtin_amdgcn_update_dpp((int)b0_[0], (int)b0_[1], 0x128, 0xf, 0xC, false);
-            const unsigned y1 = (unsigned)__builtin_amdgcn_update_dpp((int)b1_[0], (int)b1_[1], 0x128, 0xf, 0xC, false);
-            // even row groups end with (own tile-0 quad, neighbour's tile-0 quad), odd ones with (neighbour's tile-1 quad, own)
-            const auto r0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
-            const auto r1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
-            const u32x4 w = {with_tag(r0[0], tagm), with_tag(r1[0], tagm), with_tag(r0[1], tagm), with_tag(r1[1], tagm)};
-            if (pub_ok[st]) {
-                if (plain) __builtin_amdgcn_raw_buffer_store_b128(w, rs, pub_v[st], soff, 0);
-                else __builtin_amdgcn_raw_buffer_store_b128(w, rs, pub_v[st], soff, 16);
-            }
-        }
-        if constexpr (TIMED) { tq1 = __builtin_amdgcn_s_memtime(); tph[3] += tq1 - tq0; tq0 = tq1; }
-    }
-    if constexpr (TIMED) {
-        if (tid == 0 && chain == 0 && part == 0) {
-            unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.status) + 16;    // byte 128 of the status header
-            for (int i = 0; i < 5; ++i) dst[i] = tph[i];
-            dst[5] = (unsigned long long)a.T;
-        }
-    }
-    __syncthreads();                                       // hands the last iteration's dh to the loader wave
-}
-
 
 // ---------------------------------------------------------------------------------
 // backward, ALL-GATHER form on the tag-free hand-off (round 4).  dh_{s-1} = dout_{s-1} + z_s . dh_s + (dh_s . c_s) W_hh:
@@ -1147,73 +790,39 @@ __global__ __launch_bounds__(320) void gru_bwd_ag_kernel(GruArgs a) {
 namespace cruse_gru {
 
 bool fwd_tf_eligible(int Bg, int Hg, int prec, bool has_h0, bool gi_bf16) {
-    const int tf = cruse_opt("gru_tf", 1);                     // A/B switch (tests, probes): 0 = the tagged kernels of gru.hip
-    if (tf == 0) return false;
+    if (cruse_opt("gru_tf", 1) == 0) return false;             // A/B switch (tests, probes): 0 = the tagged kernels of gru.hip
     // Hg = 640: the K-split-free step measured slower than the lean kernel's (1.36 against 1.27 us per step; 40 instead of 30 MFMAs
-    // per wave on the serial chain) -- there the lean kernel runs on the tag-free hand-off instead (gru.hip, TF); gru_tf = 2 forces this one
-    if (Hg == 640 && tf != 2) return false;
-    return prec == CRUSE_PREC_BF16 && Bg == 8 && !has_h0 && !gi_bf16 && (Hg == 160 || Hg == 320 || Hg == 640);
+    // per wave on the serial chain) -- there the lean kernel runs on the tag-free hand-off instead (gru.hip, TF)
+    return prec == CRUSE_PREC_BF16 && Bg == 8 && !has_h0 && !gi_bf16 && (Hg == 160 || Hg == 320);
 }
 
 int dispatch_fwd_tf(const GruArgs& a, int grid, bool wlo, hipStream_t s) {
-    // (Hg = 640, reached with gru_tf = 2 only: the K-split-free step with a register-direct sweep needs 10 fragment loads + 160 weight
-    //  registers per lane -- 332 bytes of scratch, 1.41 us per step against the lean kernel's 1.14: not instantiated)
-    if (cruse_opt("gru_fwd_rd", 1) != 0 && a.dbg != 32 && (a.Hg == 160 || a.Hg == 320)) {       // register-direct sweep
-        if (a.Hg == 160) return wlo ? launch_one(gru_fwd_tf_kernel<5, 1, true, false, true>, a, grid, 0, s, "gru_seq_fwd", 320)
-                                    : launch_one(gru_fwd_tf_kernel<5, 1, false, false, true>, a, grid, 0, s, "gru_seq_fwd", 320);
-        return wlo ? launch_one(gru_fwd_tf_kernel<10, 2, true, false, true>, a, grid, 0, s, "gru_seq_fwd", 320)
-                   : launch_one(gru_fwd_tf_kernel<10, 2, false, false, true>, a, grid, 0, s, "gru_seq_fwd", 320);
-    }
-    if (a.dbg == 32 && a.Hg == 640) return launch_one(gru_fwd_tf_kernel<20, 3, false, true>, a, grid, 0, s, "gru_seq_fwd", 320);
-    switch (a.Hg) {
-        case 160: return wlo ? launch_one(gru_fwd_tf_kernel<5, 1, true>, a, grid, 0, s, "gru_seq_fwd", 320)
-                             : launch_one(gru_fwd_tf_kernel<5, 1, false>, a, grid, 0, s, "gru_seq_fwd", 320);
-        case 320: return wlo ? launch_one(gru_fwd_tf_kernel<10, 2, true>, a, grid, 0, s, "gru_seq_fwd", 320)
-                             : launch_one(gru_fwd_tf_kernel<10, 2, false>, a, grid, 0, s, "gru_seq_fwd", 320);
-        default: return launch_one(gru_fwd_tf_kernel<20, 3, false>, a, grid, 0, s, "gru_seq_fwd", 320);
-    }
+    if (a.Hg == 160) return wlo ? launch_one(gru_fwd_tf_kernel<5, 1, true, false, true>, a, grid, 0, s, "gru_seq_fwd", 320)
+                                : launch_one(gru_fwd_tf_kernel<5, 1, false, false, true>, a, grid, 0, s, "gru_seq_fwd", 320);
+    return wlo ? launch_one(gru_fwd_tf_kernel<10, 2, true, false, true>, a, grid, 0, s, "gru_seq_fwd", 320)
+               : launch_one(gru_fwd_tf_kernel<10, 2, false, false, true>, a, grid, 0, s, "gru_seq_fwd", 320);
 }
 
 bool bwd_tf_eligible(int Bg, int Hg, int prec) {
     if (cruse_opt("gru_tf", 1) == 0) return false;
     return prec == CRUSE_PREC_BF16 && Bg == 8 && (Hg == 160 || Hg == 320 || Hg == 640);
 }
-size_t tf_bwd_bytes_per_parity(int Hg) { const size_t P = Hg / 32; return P * 8 * P * 64; }
 
 size_t bwd_ag_lds(int Hg) { return (size_t)8 * (3 * Hg + 8) * 2 + (size_t)4 * 2 * RED_TS * 4; }
 
+// the all-gather kernel with the register-direct sweep (the LDS-image form and the tag-free reduce-scatter kernel measured slower: r4)
 int dispatch_bwd_tf(const GruArgs& a, int grid, hipStream_t s) {
-    // all-gather form (option gru_bwd_ag: 2 register-direct sweep -- the default --, 1 LDS image (Hg = 640 only), 0 the reduce-scatter kernel)
-    const int ag = cruse_opt("gru_bwd_ag", 2);
-#define CRUSE_AG_LAUNCH(PV, RDV)                                                                                                        \
+#define CRUSE_AG_LAUNCH(PV)                                                                                                             \
     do {                                                                                                                                \
-        if (a.dbg == 32) return launch_one(gru_bwd_ag_kernel<PV, true, 0, RDV>, a, grid, bwd_ag_lds(32 * PV), s, "gru_seq_bwd", 320);    \
-        if (a.dgi == nullptr) return launch_one(gru_bwd_ag_kernel<PV, false, 0, RDV>, a, grid, bwd_ag_lds(32 * PV), s, "gru_seq_bwd", 320); \
-        if (a.dg_slabs == 4) return launch_one(gru_bwd_ag_kernel<PV, false, 4, RDV>, a, grid, bwd_ag_lds(32 * PV), s, "gru_seq_bwd", 320); \
-        return launch_one(gru_bwd_ag_kernel<PV, false, 3, RDV>, a, grid, bwd_ag_lds(32 * PV), s, "gru_seq_bwd", 320);                    \
+        if (a.dbg == 32) return launch_one(gru_bwd_ag_kernel<PV, true, 0, true>, a, grid, bwd_ag_lds(32 * PV), s, "gru_seq_bwd", 320);   \
+        if (a.dgi == nullptr) return launch_one(gru_bwd_ag_kernel<PV, false, 0, true>, a, grid, bwd_ag_lds(32 * PV), s, "gru_seq_bwd", 320); \
+        if (a.dg_slabs == 4) return launch_one(gru_bwd_ag_kernel<PV, false, 4, true>, a, grid, bwd_ag_lds(32 * PV), s, "gru_seq_bwd", 320); \
+        return launch_one(gru_bwd_ag_kernel<PV, false, 3, true>, a, grid, bwd_ag_lds(32 * PV), s, "gru_seq_bwd", 320);                   \
     } while (0)
-    if (ag == 2) {
-        if (a.Hg == 640) CRUSE_AG_LAUNCH(20, true);
-        if (a.Hg == 320) CRUSE_AG_LAUNCH(10, true);
-        if (a.Hg == 160) CRUSE_AG_LAUNCH(5, true);
-    } else if (ag == 1 && a.Hg == 640) {
-        CRUSE_AG_LAUNCH(20, false);
-    }
+    if (a.Hg == 640) CRUSE_AG_LAUNCH(20);
+    if (a.Hg == 320) CRUSE_AG_LAUNCH(10);
+    CRUSE_AG_LAUNCH(5);
 #undef CRUSE_AG_LAUNCH
-    if (a.dbg == 32 && a.Hg == 640) return a.poll_stagger > 0 ? launch_one(gru_bwd_tf_kernel<20, true, true>, a, grid, 0, s, "gru_seq_bwd", 320)
-                                                               : launch_one(gru_bwd_tf_kernel<20, true>, a, grid, 0, s, "gru_seq_bwd", 320);
-    if (a.poll_stagger > 0) {
-        switch (a.Hg) {
-            case 160: return launch_one(gru_bwd_tf_kernel<5, false, true>, a, grid, 0, s, "gru_seq_bwd", 320);
-            case 320: return launch_one(gru_bwd_tf_kernel<10, false, true>, a, grid, 0, s, "gru_seq_bwd", 320);
-            default: return launch_one(gru_bwd_tf_kernel<20, false, true>, a, grid, 0, s, "gru_seq_bwd", 320);
-        }
-    }
-    switch (a.Hg) {
-        case 160: return launch_one(gru_bwd_tf_kernel<5>, a, grid, 0, s, "gru_seq_bwd", 320);
-        case 320: return launch_one(gru_bwd_tf_kernel<10>, a, grid, 0, s, "gru_seq_bwd", 320);
-        default: return launch_one(gru_bwd_tf_kernel<20>, a, grid, 0, s, "gru_seq_bwd", 320);
-    }
 }
 
 }  // namespace cruse_gru

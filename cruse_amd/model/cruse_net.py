@@ -183,8 +183,7 @@ def _splitk_bf16(M: int, N: int, K: int) -> int:
     step) for +0.02 ms of step time.  CRUSE_DW_XCDK=0: the round-robin form that fills the 256 CUs in one round with
     one block per CU (the fastest launch alone: 142 vs 206 us); CRUSE_DW_XCDK=<n>: n pinned slices."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    knob = config.get().dw_xcdk
-    x = int(knob) if knob is not None else (8 if tiles * 8 >= 192 else 0)      # few output tiles (grouped GRUs): keep round-robin
+    x = 8 if tiles * 8 >= 192 else 0      # few output tiles (grouped GRUs): keep round-robin
     if x > 1:
         return -x
     return max(1, min(256 // tiles, K // 1024))
@@ -235,7 +234,7 @@ def _gi_x3_knob(Hg: int) -> int:
 def _gi_takes_bf16_copy(prec, Hg: int) -> bool:
     """The gate projections read ONE bf16 plane of their activation operand, unpadded: the producer (BatchNorm / LayerNorm
     kernel) can then write that copy itself instead of a separate cast pass."""
-    return _bf16_gemm_path(prec, Hg) and Hg % 64 == 0 and not (_gi_x3_knob(Hg) & 4) and config.get().fuse_cast
+    return _bf16_gemm_path(prec, Hg) and Hg % 64 == 0 and not (_gi_x3_knob(Hg) & 4)
 
 
 def _gi_f16(prec, Hg: int, layer: int) -> bool:
@@ -249,8 +248,7 @@ def _gi_f16(prec, Hg: int, layer: int) -> bool:
     grouped configurations carries ~16 bits on both operands and measured BETTER than f16 there (enhanced spectrum at T = 401, closed-form
     init, g = 4: 3.1e-4 against 1.7e-3; g = 2: 9e-5 against 5.5e-4), so those keep it."""
     c = config.get()
-    return (bool((int(c.gi_f16) * 3 if isinstance(c.gi_f16, bool) else int(c.gi_f16 or 0)) >> layer & 1) and _bf16_gemm_path(prec, Hg) and not (_gi_x3_knob(Hg) & 4)
-            and not c.gi_bf16)
+    return (bool((int(c.gi_f16) * 3 if isinstance(c.gi_f16, bool) else int(c.gi_f16 or 0)) >> layer & 1) and _bf16_gemm_path(prec, Hg) and not (_gi_x3_knob(Hg) & 4))
 
 
 def _splitk(M: int, N: int, K: int) -> int:
@@ -283,11 +281,9 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
 
     fast = _bf16_gemm_path(prec, Hg)
 
-    gi_bf = fast and bool(config.get().gi_bf16)
 
     def layer(inp, lname, inp_bf=None):
-        # (EngineConfig.gi_bf16, opt-in: bf16 rows -- the GEMM rounds its f32 sums once on store)
-        gi = torch.empty(B, T, g * 3 * Hg, device=x.device, dtype=torch.bfloat16 if gi_bf else torch.float32)
+        gi = torch.empty(B, T, g * 3 * Hg, device=x.device, dtype=torch.float32)
         # The forward projection corrects the bf16 rounding of W_ih (a second pass with its low plane): that rounding
         # dominates the forward error of the bf16 mode (enhanced spectrum 1.25e-3 -> 5.1e-4 rel-L2 on fixture G6;
         # correcting x too only reaches 4.8e-4).  CRUSE_GI_X3: bit 0 / 1 = layer 1 / 2 corrected, bit 2 = also split x.
@@ -312,7 +308,7 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
         kp = (Hg + 63) // 64 * 64
         b_ihs = [P[f"{prefix}{lname}.{i}.bias_ih_l0"] for i in range(g)]
         bstep = ops.uniform_stride(b_ihs)
-        if (fast and g > 1 and config.get().gemm_groups and not gi_bf and inp_hi is not None and inp_hi.dtype == torch.bfloat16
+        if (fast and g > 1 and inp_hi is not None and inp_hi.dtype == torch.bfloat16
                 and bstep is not None):
             # all groups of the layer in ONE launch: the K-tiled W_ih planes stacked [g][kp / 64][3 Hg][64], columns of x / gi per group
             W_hi = torch.empty(g, kp // 64, 3 * Hg, 64, device=x.device, dtype=torch.bfloat16)
@@ -431,11 +427,6 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
     rows = B * T
     hooks = [pre_done] if pre_done is not None else []
 
-    # CRUSE_FUSE_DGI=1: the backward recurrence writes the bf16 gate gradients dgi itself and the gate-gradient pass (then
-    # only the time-major copies + bias sums) moves into the weight-gradient leaf.  Measured neutral (6.01-6.04 vs
-    # 5.98-6.03 ms): 0.2 ms leave the main stream, 0.14 ms join the side queue, and the step is bound by their sum.
-    fuse_dgi = config.get().fuse_dgi
-
     def run_bwd(dout_h, w_hh, coef, z, an=None, dg_slabs=3):
         if hooks:
             hooks.pop()()
@@ -460,18 +451,8 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
         bias_ih = [G[nm + "bias_ih_l0"] for nm in names]
         bias_hh = [G[nm + "bias_hh_l0"] for nm in names]
         ldT = (rows + 63) // 64 * 64
-        if fuse_dgi and SIDE.enabled:
-            # the recurrence writes dgi itself (its loader wave), dX starts right behind it; the time-major copies for the
-            # weight-gradient GEMMs and the bias sums are made by the weight-gradient leaf, off the main stream
-            dh, dgi = run_bwd(dout_h, w_hh, coef, z, an)
-            dgT = torch.empty(ldT // 64, g, 4, Hg, 64, device=dh.device, dtype=torch.bfloat16)
-            made_dgT = False
-        else:
-            dh = run_bwd(dout_h, w_hh, coef, z)
-            # dx_atr: dX reads the time-major tensor dgT through transposing LDS reads (cruse_gemm_bf16_nt_atr) -- no row-major dgi is written
-            dx_atr = bool(config.get().dx_atr) and Hg % 64 == 0 and need_dinp
-            dgi, dgT, ldT = ops.gru_gate_grads_bf16(dh, coef, an, rows, g, Hg, bias_ih, bias_hh, want_dgi=not dx_atr)
-            made_dgT = True
+        dh = run_bwd(dout_h, w_hh, coef, z)
+        dgi, dgT, ldT = ops.gru_gate_grads_bf16(dh, coef, an, rows, g, Hg, bias_ih, bias_hh)
         early = early_T.pop(lname, None)         # layer 1: transposed by a leaf of the FIRST recurrence (see below)
         if early is not None:
             inpT, hpT = early
@@ -480,11 +461,6 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
             hpT = torch.empty(ldT // 64, H, 64, device=dh.device, dtype=torch.bfloat16)
 
         def weight_grads():                      # leaves: overlap with the next recurrence / encoder backward
-            if not made_dgT:
-                check_rc = ops.lib.cruse_gru_gate_grads_bf16(ops._p(dh), ops._p(coef), ops._p(an), None, ops._p(dgT), ldT,
-                                                             ops._ptr_array(bias_ih), ops._ptr_array(bias_hh), rows, g, Hg,
-                                                             ops._stream())
-                ops.check(check_rc)
             if early is None:
                 ops.transpose_bf16(inp, rows, H, out=inpT)
                 ops.transpose_bf16(h, rows, H, shift_T=T, out=hpT)
@@ -494,18 +470,18 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
                 a0, b0 = 4 * i * Hg * 64, i * Hg * 64
                 g_ih, g_hh = G[nm + "weight_ih_l0"], G[nm + "weight_hh_l0"]
                 sk = _splitk_bf16(6 * Hg, Hg, ldT)       # (k-slices for the 6 Hg x Hg concatenated output)
-                if (config.get().dw_cat and config.get().dw_slabs and abs(sk) > 1
+                if (abs(sk) > 1
                         and g_hh.data_ptr() == g_ih.data_ptr() + 4 * 3 * Hg * Hg):
                     # the three products as ONE launch on the concatenated output [dW_ih ; dW_hh] (back to back in the flat gradient buffer)
                     ops.gemm_bf16_nt_cat([3 * Hg, 2 * Hg, Hg], Hg, ldT, dgT, [4 * i * Hg, 4 * i * Hg, 4 * i * Hg + 3 * Hg], 64,
                                          [inpT, hpT, hpT], b0, 64, g_ih, 0, Hg, sk, a_kstride=ka, b_kstride=kb)
                     continue
                 ops.gemm_bf16_nt(3 * Hg, Hg, ldT, dgT, a0, 64, inpT, b0, 64, G[nm + "weight_ih_l0"], 0, Hg,
-                                 accumulate=True, splitk=_splitk_bf16(3 * Hg, Hg, ldT), slabs=config.get().dw_slabs, a_kstride=ka, b_kstride=kb)
+                                 accumulate=True, splitk=_splitk_bf16(3 * Hg, Hg, ldT), slabs=True, a_kstride=ka, b_kstride=kb)
                 ops.gemm_bf16_nt(2 * Hg, Hg, ldT, dgT, a0, 64, hpT, b0, 64, G[nm + "weight_hh_l0"], 0, Hg,
-                                 accumulate=True, splitk=_splitk_bf16(2 * Hg, Hg, ldT), slabs=config.get().dw_slabs, a_kstride=ka, b_kstride=kb)
+                                 accumulate=True, splitk=_splitk_bf16(2 * Hg, Hg, ldT), slabs=True, a_kstride=ka, b_kstride=kb)
                 ops.gemm_bf16_nt(Hg, Hg, ldT, dgT, a0 + 3 * Hg * 64, 64, hpT, b0, 64, G[nm + "weight_hh_l0"],
-                                 2 * Hg * Hg, Hg, accumulate=True, splitk=_splitk_bf16(Hg, Hg, ldT), slabs=config.get().dw_slabs, a_kstride=ka,
+                                 2 * Hg * Hg, Hg, accumulate=True, splitk=_splitk_bf16(Hg, Hg, ldT), slabs=True, a_kstride=ka,
                                  b_kstride=kb)
 
         # The last layer's weight-gradient leaf goes to the side stream BEFORE the dX GEMM is issued: its event then follows the
@@ -515,7 +491,7 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
             SIDE.run(weight_grads, dgT, h, inp, inpT, hpT, dh, lane=2)
         dinp, acc_dx = dinp_buffer(dout_h, need_dinp, last)
         stack = ctx.get("w_ts", {}).get((lname, "stack"))
-        if need_dinp and g > 1 and stack is not None and dgi is not None and config.get().gemm_groups:
+        if need_dinp and g > 1 and stack is not None:
             # all groups in ONE launch (cruse_gemm_bf16_nt_groups): columns [q * 3 Hg, ...) of dgi against W_ih,q^T into columns [q * Hg, ...) of dX
             ops.gemm_bf16_nt_groups(rows, Hg, stack.shape[1] * 64, g, dgi, None, 3 * H, 3 * Hg, stack, None, 64, stack[0].numel(), dinp, H, Hg,
                                     accumulate=acc_dx, b_kstride=Hg * 64)
@@ -524,10 +500,6 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
                 w_t = ctx.get("w_ts", {}).get((lname, i))                             # made in the forward pass (side stream)
                 if w_t is None:
                     w_t = ops.transpose_bf16(P[nm + "weight_ih_l0"], 3 * Hg, Hg)      # K-tiled [ceil(3*Hg/64), Hg, 64]
-                if dgi is None:
-                    ops.gemm_bf16_nt_atr(rows, Hg, 3 * Hg, dgT, 4 * i * Hg * 64, g * 4 * Hg * 64, ldT // 64, w_t, 0, 64, dinp, i * Hg, H,
-                                         accumulate=acc_dx, b_kstride=Hg * 64)
-                    continue
                 ops.gemm_bf16_nt(rows, Hg, w_t.shape[0] * 64, dgi, i * 3 * Hg, 3 * H, w_t, 0, 64, dinp, i * Hg, H,
                                  accumulate=acc_dx, b_kstride=Hg * 64)
         if early_leaf:
@@ -790,9 +762,8 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
     prec = ctx["prec"]
     # data-gradient convolutions of the bf16 mode: plain bf16 operands (one MFMA, one conversion per element) like every
     # other backward contraction of that mode -- the split-bf16 x3 form is what the FORWARD convs need for the 1e-3 bar
-    # (EngineConfig.conv_bwd_x3 restores x3 in backward)
     dprec = prec
-    if ops.prec_code(prec) == ops.PREC_BF16 and not config.get().conv_bwd_x3:
+    if ops.prec_code(prec) == ops.PREC_BF16:
         dprec = ops.PREC_BF16
     rows = B * T
     ys, es, stats, us, vs, dstats = ctx["ys"], ctx["es"], ctx["stats"], ctx["us"], ctx["vs"], ctx["dstats"]
@@ -930,7 +901,6 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
     cut = max(L // 2, 1)                          # levels L..cut+1, [bucket 1 final], levels cut..1
     # ---- encoder levels L..1: de_k already holds the skip path ------------------------------
     de_sums = None
-    late_main = []
     for k in range(L, 0, -1):
         mean, rstd = stats[k]
         fused = fuse_apply and k > 1 and de.dtype == torch.bfloat16 and de_sums is not None
@@ -952,8 +922,6 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
         # the main stream itself (_INLINE bits 3, 4: level 1, level 2), beside what is still queued on the side
         if _INLINE & (8 << (k - 1)):                       # bits 3.. = levels 1..
             leaf_enc()
-        elif _INLINE & (128 << (k - 1)):                   # bits 7.. = levels 1..: on the main stream too, but AFTER its serial chain
-            late_main.append(leaf_enc)                     # (the side queue, not the main stream, is what the optimizer waits for)
         else:
             SIDE.run(leaf_enc, dy, lane=0)
         if fused:
@@ -966,8 +934,6 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
     dx = None
     if need_dx:
         dx = ops.conv_scatter2(dy, P["conv1.weight"], None, B, T, ch[1], Fk[1], ch[0], KT=2, pad=1, prec=dprec)
-    for fn in late_main:
-        fn()
     SIDE.join()
     return dx
 

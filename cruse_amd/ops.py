@@ -512,14 +512,8 @@ def gemm_bf16_nt(M, N, K, A, a_off, lda, Bm, b_off, ldb, C, c_off, ldc, bias=Non
         check(lib.cruse_gemm_bf16_nt_slabs(M, N, K, A.data_ptr() + 2 * a_off, lda, a_kstride, Bm.data_ptr() + 2 * b_off, ldb, b_kstride,
                                            C.data_ptr() + 4 * c_off, ldc, splitk, _p(ws), ws.numel(), _stream()))
         return
-    if A.dtype != torch.bfloat16 or Bm.dtype != torch.bfloat16 or C.dtype not in (torch.float32, torch.bfloat16):
-        raise RuntimeError("gemm_bf16_nt needs bf16 operands and an f32 (or stored-as-bf16) result")
-    if C.dtype == torch.bfloat16:               # result rounded to bf16 on store (cruse_gemm_bf16_nt_obf16): no accumulate / split-K
-        if accumulate or splitk != 1:
-            raise RuntimeError("gemm_bf16_nt: a bf16 result is stored, not accumulated")
-        check(lib.cruse_gemm_bf16_nt_obf16(M, N, K, A.data_ptr() + 2 * a_off, None, lda, a_kstride, Bm.data_ptr() + 2 * b_off, None, ldb,
-                                           b_kstride, C.data_ptr() + 2 * c_off, ldc, _p(bias), _stream()))
-        return
+    if A.dtype != torch.bfloat16 or Bm.dtype != torch.bfloat16 or C.dtype != torch.float32:
+        raise RuntimeError("gemm_bf16_nt needs bf16 operands and an f32 result")
     check(lib.cruse_gemm_bf16_nt(M, N, K, A.data_ptr() + 2 * a_off, lda, a_kstride, Bm.data_ptr() + 2 * b_off, ldb, b_kstride,
                                  C.data_ptr() + 4 * c_off, ldc, _p(bias), 1 if accumulate else 0, splitk, _stream()))
 
@@ -538,16 +532,6 @@ def gemm_bf16_nt_cat(Ms, N, K, A, a_rows, lda, Bs, b_off, ldb, C, c_off, ldc, sp
     check(lib.cruse_gemm_bf16_nt_slabs_cat(n, ctypes.cast(ms, ctypes.c_void_p), N, K, A.data_ptr(), ctypes.cast(ar, ctypes.c_void_p), lda, a_kstride,
                                            ctypes.cast(bs, ctypes.c_void_p), ldb, b_kstride, C.data_ptr() + 4 * c_off, ldc, splitk, _p(ws),
                                            ws.numel(), _stream()))
-
-
-def gemm_bf16_nt_atr(M, N, K, A_T, a_off, a_mb_stride, n_mb, Bm, b_off, ldb, C, c_off, ldc, accumulate=False, b_kstride=64):
-    """C[M,N] (+)= A . B^T with A read from its time-major K-tiled image (element (m, k) at A_T[a_off + (m // 64) * a_mb_stride + k * 64 + m % 64]):
-    cruse_gemm_bf16_nt_atr -- dX straight from the gate-gradient tensor dgT, no row-major dgi."""
-    if A_T.dtype != torch.bfloat16 or Bm.dtype != torch.bfloat16 or C.dtype != torch.float32:
-        raise RuntimeError("gemm_bf16_nt_atr needs bf16 operands and an f32 result")
-    check(lib.cruse_gemm_bf16_nt_atr(M, N, K, A_T.data_ptr() + 2 * a_off, a_mb_stride, n_mb, Bm.data_ptr() + 2 * b_off, ldb, b_kstride,
-                                     C.data_ptr() + 4 * c_off, ldc, 1 if accumulate else 0, _stream()))
-    return C
 
 
 def gemm_bf16_nt_groups(M, N, K, G, A_hi, A_lo, lda, a_gstep, B_hi, B_lo, ldb, b_gstep, C, ldc, c_gstep, bias=None, bias_gstep=0,
@@ -641,13 +625,8 @@ def gemm_bf16x3_nt(M, N, K, A_hi, A_lo, a_off, lda, B_hi, B_lo, b_off, ldb, C, c
     for t_ in (A_hi, A_lo, B_hi, B_lo):
         if t_ is not None and t_.dtype != torch.bfloat16:
             raise RuntimeError("gemm_bf16x3_nt needs bf16 planes")
-    if C.dtype == torch.bfloat16:               # result rounded to bf16 on store (cruse_gemm_bf16_nt_obf16)
-        if accumulate:
-            raise RuntimeError("gemm_bf16x3_nt: a bf16 result is stored, not accumulated")
-        check(lib.cruse_gemm_bf16_nt_obf16(M, N, K, A_hi.data_ptr() + 2 * a_off, None if A_lo is None else A_lo.data_ptr() + 2 * a_off,
-                                           lda, a_kstride, B_hi.data_ptr() + 2 * b_off, B_lo.data_ptr() + 2 * b_off, ldb, b_kstride,
-                                           C.data_ptr() + 2 * c_off, ldc, _p(bias), _stream()))
-        return
+    if C.dtype != torch.float32:
+        raise RuntimeError("gemm_bf16x3_nt needs an f32 result")
     check(lib.cruse_gemm_bf16x3_nt(M, N, K, A_hi.data_ptr() + 2 * a_off,
                                    None if A_lo is None else A_lo.data_ptr() + 2 * a_off, lda, a_kstride,
                                    B_hi.data_ptr() + 2 * b_off, B_lo.data_ptr() + 2 * b_off, ldb, b_kstride,
@@ -712,10 +691,10 @@ def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G,
     chunk = (t0, n): run only frames [t0, t0+n) of the [B,T] tensors into `out` = (h, coef, an, z) from the call that ran
     the frames before them -- the initial state is then h[:, t0-1] (h0 for t0 == 0).  Consecutive chunks reproduce the
     single launch (cruse_gru_seq_fwd_ex).  wide: chains of 16 clips (half the workgroups; same results).
-    gi: f32, or bf16 rows (gemm_bf16_nt into a bf16 tensor; bf16 mode only).  zeroed: the slot's scratch is already clear
+    zeroed: the slot's scratch is already clear
     (gru_step_ws_clear)."""
-    if gi.dtype not in (torch.float32, torch.bfloat16):
-        raise RuntimeError(f"gru_seq_fwd: gi must be f32 or bf16, got {gi.dtype}")
+    if gi.dtype != torch.float32:
+        raise RuntimeError(f"gru_seq_fwd: gi must be f32, got {gi.dtype}")
     dev = gi.device
     H = G * Hg
     if out is not None:
@@ -748,7 +727,7 @@ def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G,
     opt = lambda t_, k: None if t_ is None else _off(t_, t0 * k)
     check(lib.cruse_gru_seq_fwd_ex(_off(gi, t0 * 3 * H), ctypes.cast(wa, ctypes.c_void_p), ctypes.cast(ba, ctypes.c_void_p),
                                    _off(h, t0 * H), opt(coef, 3 * H), opt(an, H), opt(z, H), h0p, h0s, B, n, T, G, Hg,
-                                   prec_code(prec), 16 if wide else 0, 1 if gi.dtype == torch.bfloat16 else 0, panels, 1 if zeroed else 0,
+                                   prec_code(prec), 16 if wide else 0, panels, 1 if zeroed else 0,
                                    status, xcd_rot, _stream()))
     return h, coef, an, z
 

@@ -317,14 +317,6 @@ int cruse_gemm_bf16_nt_slabs(int M, int N, int K, const void* A, long long lda, 
 int cruse_gemm_bf16_nt_slabs_cat(int nprob, const int* Ms, int N, int K, const void* A, const long long* a_rows, long long lda,
                                  long long a_kstride, const void* const* Bs, long long ldb, long long b_kstride,
                                  float* C, long long ldc, int splitk, void* scratch, size_t scratch_bytes, void* stream);
-/* (ABI 9) C[M,N] (+)= A[M,K] . B[N,K]^T with A given as its TIME-MAJOR K-tiled image: element (m, k) at A_T[(m / 64) * a_mb_stride + k * 64 + m % 64],
- * n_mb 64-row blocks present (rows M <= m < 64 * n_mb hold finite values); B, C as cruse_gemm_bf16_nt; K % 64 == 0.  That is the layout of the
- * gate-gradient tensor dgT [ceil(rows / 64)][G][4][Hg][64] of cruse_gru_gate_grads_bf16 (A_T = dgT + group * 4 * Hg * 64, a_mb_stride =
- * G * 4 * Hg * 64): the input gradient of nn.GRU's x W_ih^T (cruse_net.py:23-31) is formed from it directly -- the MFMA fragments are transposing
- * LDS reads (ds_read_b64_tr_b16) -- and the row-major copy dgi is never written. */
-int cruse_gemm_bf16_nt_atr(int M, int N, int K, const void* A_T, long long a_mb_stride, int n_mb,
-                           const void* B, long long ldb, long long b_kstride,
-                           float* C, long long ldc, int accumulate, void* stream);
 /* (ABI 9) G products of the same shape in ONE launch, side by side along N -- the GRU groups of one layer (GGRU with rnn_groups > 1,
  * cruse_net.py:14-55):  C[:, q * c_gstep + (0..N)] (+)= A[:, q * a_gstep + (0..K)] . B_q^T + bias_q,  B_q = B + q * b_gstep, bias_q = bias + q * bias_gstep.
  * A row-major (planes A_hi / A_lo nullable as in cruse_gemm_bf16x3_nt), B as in cruse_gemm_bf16_nt (B_lo nullable, same group stride).  Used for
@@ -333,13 +325,6 @@ int cruse_gemm_bf16_nt_groups(int M, int N, int K, int G, const void* A_hi, cons
                               const void* B_hi, const void* B_lo, long long ldb, long long b_kstride, long long b_gstep,
                               float* C, long long ldc, long long c_gstep, const float* bias, long long bias_gstep, int accumulate,
                               void* stream);
-/* The same product -- or, with low planes (A_lo nullable, B_lo nullable: plain bf16), the split-bf16 form of
- * cruse_gemm_bf16x3_nt -- with the result STORED AS bf16 (C bf16 [M, ldc]; f32 accumulation, bias added in f32 before the one
- * rounding; no accumulate, no split-K): gi = x W_ih^T + b_ih as bf16 rows for cruse_gru_seq_fwd_ex(gi_bf16 = 1) -- half the bytes
- * of the largest tensor the GGRU block writes and reads (nn.GRU under bf16 autocast produces bf16 gate pre-activations too). */
-int cruse_gemm_bf16_nt_obf16(int M, int N, int K, const void* A_hi, const void* A_lo, long long lda, long long a_kstride,
-                             const void* B_hi, const void* B_lo, long long ldb, long long b_kstride,
-                             void* C, long long ldc, const float* bias, void* stream);
 /* cruse_gemm_bf16_nt / cruse_gemm_bf16x3_nt (A_lo, B_lo nullable: plain bf16) on a TIME CHUNK of the batch: logical row m of A
  * (row-major, lda) and of C is physical row (m / seg_len) * seg_stride + seg_off + m % seg_len; M = B * seg_len.  The gate
  * projection gi = x W_ih^T of frames [seg_off, seg_off + seg_len) of every clip then runs beside the recurrence of the
@@ -429,11 +414,9 @@ int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh, const void
  *   panels_zeroed: the caller has cleared the panel scratch (cruse_gru_ws_bytes() - 256 bytes at `panels`) since its last use, on
  *            this stream or ordered before it; 0: the call clears it itself (one memset launch in front of the recurrence).  A
  *            training step clears the scratches of its four recurrences with one launch at its top.
- *   gi_bf16 (forward): gi points at bf16 rows [.., G*3*Hg] (cruse_gemm_bf16_nt_obf16) instead of f32 ones; CRUSE_PREC_BF16 only.
- *            The values are widened on load; everything else is unchanged.
  *   chain_clips: clips served by one team of Hg/32 workgroups.  0 = the library's plan: chains of 8 while the batch's chains fit
  *            the CUs; beyond that (B > 96 at Hg = 640) WIDE chains of 16 (half the workgroups per clip, the full 16 columns of the
- *            MFMA; CRUSE_PREC_BF16, Hg % 128 == 0, Hg <= 640, f32 gi rows, h0 == NULL) where that needs fewer launches.
+ *            MFMA; CRUSE_PREC_BF16, Hg % 128 == 0, Hg <= 640, h0 == NULL) where that needs fewer launches.
  *            8 / 16 force the width: with 16 a batch of 64 at Hg = 640 takes 80 CUs, so the recurrences of BOTH GGRU layers are
  *            co-resident (measured slower than one after the other on chains of 8: DESIGN.md section 8).  The forward
  *            results do not depend on the width (same sums in the same order); the backward ones up to the f32 summation order.
@@ -441,7 +424,7 @@ int cruse_gru_seq_bwd_on(const float* dout, const float* const* w_hh, const void
  *            exponent bit of every exchanged bf16) -- true for the continuation of a sequence that started from h0 = 0. */
 int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, const float* const* b_hh,
                          float* h, void* coef, float* an, float* z, const float* h0, long long h0_bstride,
-                         int B, int T, int TS, int G, int Hg, int prec, int chain_clips, int gi_bf16, void* panels,
+                         int B, int T, int TS, int G, int Hg, int prec, int chain_clips, void* panels,
                          int panels_zeroed, unsigned* status, int xcd_rot, void* stream);
 int cruse_gru_seq_bwd_ex(const float* dout, const float* const* w_hh, const void* coef, const float* z,
                          float* dh, const float* an, void* dgi, int dg_slabs, int carry, int B, int T, int TS, int G,

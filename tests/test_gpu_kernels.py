@@ -681,54 +681,6 @@ def test_gru_bwd_wide_chains_match_the_chains_of_8(ops, H, B, T, G, slabs):
     assert ops.gru_status() == 0
 
 
-@pytest.mark.parametrize("H,B,T,G,opts,wide", [(640, 64, 9, 1, {}, False), (640, 24, 7, 1, {}, False), (320, 11, 6, 2, {}, False),
-                                               (512, 9, 5, 1, {"gru_wlo": 1}, False), (256, 13, 6, 1, {"gru_fwd_lean": 0}, False),
-                                               (384, 40, 5, 1, {}, False)])
-def test_gru_fwd_takes_bf16_gate_preactivations(ops, H, B, T, G, opts, wide):
-    """cruse_gru_seq_fwd_ex(gi_bf16 = 1): gi as bf16 rows (cruse_gemm_bf16_nt_obf16) widened on load == the same values handed over
-    as f32 rows, bit for bit, in every forward kernel of the bf16 mode: lean with the helper wave (Hg % 128 == 0 and not), lean
-    without it (W_hh low plane at Hg > 384), wide chains, the generic kernel; with an initial state and in time chunks."""
-    torch.manual_seed(H + B)
-    Hg = H // G
-    gi_bf = (0.5 * torch.randn(B, T, 3 * H)).cuda().to(torch.bfloat16)
-    gi_f = gi_bf.float()
-    w = [(torch.randn(3 * Hg, Hg) / Hg ** 0.5).cuda() for _ in range(G)]; b = [(0.1 * torch.randn(3 * Hg)).cuda() for _ in range(G)]
-    h0 = (0.3 * torch.randn(B, H)).cuda()
-    with ops.options(gru_tf=0, **opts):            # (bf16 gi rows are a variant of the tagged kernels)
-        for init in (None, h0):
-            ref = ops.gru_seq_fwd(gi_f, w, b, B, T, G, Hg, "bf16", h0=init, wide=wide)
-            got = ops.gru_seq_fwd(gi_bf, w, b, B, T, G, Hg, "bf16", h0=init, wide=wide)
-            for x, y, name in zip(got, ref, ("h", "coef", "an", "z")):
-                assert torch.equal(x, y), (name, init is not None)
-        cut = T // 2
-        out = ops.gru_seq_fwd(gi_bf, w, b, B, T, G, Hg, "bf16", h0=h0, chunk=(0, cut), wide=wide)
-        ops.gru_seq_fwd(gi_bf, w, b, B, T, G, Hg, "bf16", out=out, chunk=(cut, T - cut), wide=wide)
-        for x, y, name in zip(out, ref, ("h", "coef", "an", "z")):
-            assert torch.equal(x, y), ("chunked", name)
-    with pytest.raises(RuntimeError):
-        ops.gru_seq_fwd(gi_bf, w, b, B, T, G, Hg, "f32")            # bf16 rows belong to the bf16 mode
-    assert ops.gru_status() == 0
-
-
-@pytest.mark.parametrize("M,N,K,x3", [(25664, 1920, 640, False), (25664, 1920, 640, True), (333, 200, 128, False), (130, 96, 64, True)])
-def test_gemm_bf16_result_stored_as_bf16(ops, M, N, K, x3):
-    """cruse_gemm_bf16_nt_obf16: the f32 sums (+ bias) of cruse_gemm_bf16_nt / cruse_gemm_bf16x3_nt rounded once (RNE) on store --
-    equal to rounding the f32 result afterwards, bit for bit; ragged tiles included."""
-    torch.manual_seed(M + N)
-    A = torch.randn(M, K).cuda(); Bm = torch.randn(N, K).cuda(); bias = torch.randn(N).cuda()
-    A_hi = A.to(torch.bfloat16); B_hi = Bm.to(torch.bfloat16)
-    B_lo = (Bm - B_hi.float()).to(torch.bfloat16)
-    Cf = torch.empty(M, N).cuda(); Cb = torch.full((M, N), 7.0, dtype=torch.bfloat16).cuda()
-    for C in (Cf, Cb):
-        if x3:
-            ops.gemm_bf16x3_nt(M, N, K, A_hi, None, 0, K, B_hi, B_lo, 0, K, C, 0, N, bias=bias)
-        else:
-            ops.gemm_bf16_nt(M, N, K, A_hi, 0, K, B_hi, 0, K, C, 0, N, bias=bias)
-    assert torch.equal(Cb.view(torch.int16), Cf.to(torch.bfloat16).view(torch.int16))
-    with pytest.raises(RuntimeError):
-        ops.gemm_bf16_nt(M, N, K, A_hi, 0, K, B_hi, 0, K, Cb, 0, N, accumulate=True)
-
-
 @pytest.mark.parametrize("M,N,K", [(25664, 1920, 640), (2500, 200, 160), (4133, 640, 640), (130, 96, 64)])
 def test_gemm_f16_single_pass_gate_projection(ops, M, N, K):
     """cruse_gemm_f16_nt + cruse_ktile_f16 (ABI 9): gi = x W_ih^T + b_ih (cruse_net.py:23-31,44,50) in one pass on IEEE-f16 operands --
@@ -839,35 +791,6 @@ def test_gemm_concatenated_weight_gradient_products(ops, Hg, K, Ms):
         ref[off:off + M] += A[:, ar:ar + M].t() @ Bm.float().permute(0, 2, 1).reshape(ldT, Hg).double()
         off += M
     assert rel_l2(cc, ref) < 2e-6
-
-
-@pytest.mark.parametrize("rows,G,Hg", [(25664, 1, 640), (1000, 2, 128), (64 * 3 + 5, 1, 64)])
-def test_gemm_input_gradient_from_the_time_major_gate_gradients(ops, rows, G, Hg):
-    """cruse_gemm_bf16_nt_atr (ABI 9, EngineConfig.dx_atr): dX = dgi . W_ih (autograd of nn.GRU's x W_ih^T, cruse_net.py:23-31) with the A
-    operand read from the TIME-MAJOR gate-gradient tensor dgT through transposing LDS reads -- the same bf16 values in the same MFMA order as
-    the row-major form: bit-identical, store and accumulate, every group, ragged last row block."""
-    torch.manual_seed(rows + Hg)
-    H = G * Hg
-    dh = (torch.randn(rows, H) * 0.1).cuda()
-    coef = torch.randn(rows, G, 3, Hg).cuda().to(torch.bfloat16)
-    an = torch.randn(rows, H).cuda()
-    bi = [torch.zeros(3 * Hg).cuda() for _ in range(G)]; bh = [torch.zeros(3 * Hg).cuda() for _ in range(G)]
-    dgi, dgT, ldT = ops.gru_gate_grads_bf16(dh, coef, an, rows, G, Hg, bi, bh)
-    _, dgT2, _ = ops.gru_gate_grads_bf16(dh, coef, an, rows, G, Hg, bi, bh, want_dgi=False)
-    assert torch.equal(dgT2.view(torch.int16), dgT.view(torch.int16))
-    for i in range(G):
-        W = (torch.randn(3 * Hg, Hg) / Hg ** 0.5).cuda()
-        w_t = ops.transpose_bf16(W, 3 * Hg, Hg)
-        for acc in (False, True):
-            base = torch.randn(rows, H).cuda()
-            c0, c1 = base.clone(), base.clone()
-            ops.gemm_bf16_nt(rows, Hg, w_t.shape[0] * 64, dgi, i * 3 * Hg, 3 * H, w_t, 0, 64, c0, i * Hg, H, accumulate=acc, b_kstride=Hg * 64)
-            ops.gemm_bf16_nt_atr(rows, Hg, 3 * Hg, dgT, 4 * i * Hg * 64, G * 4 * Hg * 64, ldT // 64, w_t, 0, 64, c1, i * Hg, H, accumulate=acc,
-                                 b_kstride=Hg * 64)
-            assert torch.equal(c0, c1), (i, acc)
-    want = dgi.view(rows, G, 3 * Hg)[:, 0].double() @ W.double().to(torch.bfloat16).double() if G == 1 else None
-    if want is not None:
-        assert rel_l2(c1 - base, want) < 1e-5
 
 
 @pytest.mark.parametrize("rows,G,Hg,x3", [(25664, 4, 160, 2), (25664, 4, 160, 1), (1000, 2, 320, 0), (333, 3, 96, 2)])
@@ -1174,8 +1097,8 @@ def test_gru_all_gather_backward_on_grouped_widths(ops, G, B, T):
     ref = ops.gru_seq_bwd(dout, w, f32[1], f32[3], B, T, G, Hg, "f32")
     f = ops.gru_seq_fwd(gi, w, b, B, T, G, Hg, "bf16")
     out = {}
-    for ag in (0, 2):
-        with ops.options(gru_bwd_ag=ag):
+    for ag, opts in ((0, dict(gru_tf=0)), (2, {})):                  # 0: the tagged reduce-scatter kernel, 2: the default all-gather kernel
+        with ops.options(**opts):
             out[ag] = ops.gru_seq_bwd(dout, w, f[1], f[3], B, T, G, Hg, "bf16", an=f[2], want_dgi=True)
             plain = ops.gru_seq_bwd(dout, w, f[1], f[3], B, T, G, Hg, "bf16")
             torch.cuda.synchronize()
@@ -1191,15 +1114,15 @@ def test_gru_all_gather_backward_on_grouped_widths(ops, G, B, T):
 
 @pytest.mark.parametrize("B,T", [(9, 12), (3, 1), (5, 2), (8, 3), (20, 37), (64, 60)])
 def test_gru_register_direct_sweeps_and_all_gather_backward(ops, B, T):
-    """Round-4 recurrence kernels at Hg = 640 (bf16 mode).  Forward: the register-direct sweep (gru_fwd_rd, default) gives the bits
-    of the LDS-image form.  Backward: the all-gather kernel in its register-direct (gru_bwd_ag = 2, default) and LDS-image (1) forms
-    give the same bits; both and the reduce-scatter kernel (0) agree with the f64 recurrence on the saved coefficients; the gate
-    gradients written by the loader wave are those of the separate pass on the same dh."""
+    """Round-4 recurrence kernels at Hg = 640 (bf16 mode).  Forward: the tag-free register-direct sweep (default) gives the bits of the
+    tagged lean kernel (gru_tf = 0: same sums, same bf16 hand-off values).  Backward: the all-gather kernel and the tagged reduce-scatter
+    kernel agree with the f64 recurrence on the saved coefficients; the gate gradients written by the loader wave are those of the
+    separate pass on the same dh."""
     H = 640
     torch.manual_seed(B * 100 + T)
     gi = (0.5 * torch.randn(B, T, 3 * H)).cuda()
     w = [(torch.randn(3 * H, H) / H ** 0.5).cuda()]; b = [(0.1 * torch.randn(3 * H)).cuda()]
-    with ops.options(gru_fwd_rd=0):
+    with ops.options(gru_tf=0):
         f0 = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16")
     f1 = ops.gru_seq_fwd(gi, w, b, B, T, 1, H, "bf16")
     torch.cuda.synchronize()
@@ -1209,13 +1132,12 @@ def test_gru_register_direct_sweeps_and_all_gather_backward(ops, B, T):
     h, coef, an, z = f1
     dout = (3.0 * torch.randn(B, T, H)).cuda()
     out = {}
-    for ag in (0, 1, 2):
-        with ops.options(gru_bwd_ag=ag):
+    for ag, opts in ((0, dict(gru_tf=0)), (2, {})):
+        with ops.options(**opts):
             out[ag] = ops.gru_seq_bwd(dout, w, coef, z, B, T, 1, H, "bf16", an=an, want_dgi=True)
             plain = ops.gru_seq_bwd(dout, w, coef, z, B, T, 1, H, "bf16")
             torch.cuda.synchronize()
             assert ops.gru_status() == 0 and torch.equal(plain, out[ag][0])
-    assert torch.equal(out[1][0], out[2][0]) and torch.equal(out[1][1], out[2][1])
     c = coef.float().view(B, T, 3, H)
     wd = w[0].double()
     ref = torch.zeros(B, T, H, dtype=torch.float64, device="cuda")
