@@ -8,7 +8,12 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 objs=()
 pids=()
 mkdir -p "$here/build"
-for f in stft stft_general conv conv_mfma wgrad_mfma pointwise gemm gemm_bf16 gru gru_tf gru_w16 tdloss deepfilter generic extras; do
+for k in 0 1 2 3; do
+  "$HIPCC" $FLAGS -DCM_TU=$k -c "$here/conv_mfma.hip" -o "$here/build/conv_mfma_$k.o" &
+  pids+=($!)
+  objs+=("$here/build/conv_mfma_$k.o")
+done
+for f in stft stft_general conv wgrad_mfma pointwise gemm gemm_bf16 gru gru_tf gru_w16 tdloss deepfilter generic extras; do
   "$HIPCC" $FLAGS -c "$here/$f.hip" -o "$here/build/$f.o" &
   pids+=($!)
   objs+=("$here/build/$f.o")

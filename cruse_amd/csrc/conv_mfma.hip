@@ -12,10 +12,18 @@
 // encoder conv) are two position classes (even / odd output bins) with their own tap lists,
 // so every class is a dense GEMM.  The kernel moves 2 x 640 floats per frame through HBM
 // against <= 0.25 MFLOP per frame: it is HBM-bound, the MFMA time is negligible.
+//
+// BUILD: this source is compiled FOUR times (build.sh, -DCM_TU=k): k = 0 the dispatcher (cruse_conv_mfma_try, no kernels), k = 1 / 2 / 3
+// the kernels of one precision mode each (exact f32 / split-bf16 x3 / plain bf16) -- ~100 kernels per object in parallel compile jobs
+// instead of ~300 in one (100 s).
 #include "common.h"
 #include <stdlib.h>
 
-namespace {
+#ifndef CM_TU
+#define CM_TU 0
+#endif
+
+namespace cruse_cm {
 
 constexpr int TFM = 8;                  // frames per workgroup tile
 // 5 wavefronts per workgroup: every U-Net level has 8 frames x F = 10 * 2^k positions = 5 * 2^k N-tiles of 16 per tile,
@@ -34,7 +42,7 @@ struct TapClass {
 // profiling (library option cm_dbg = 1): s_memtime phase sums of workgroup 0 / wave 0 of the LAST launch:
 // [0] prologue (weight fragments) [1] waiting for + storing the staged tile (two barriers) [2] k-loops (gather + MFMA)
 // [3] epilogues (stores) [4] tiles [5] N-tiles of wave 0 [6] total
-__device__ unsigned long long g_cm_stamps[8];
+static __device__ unsigned long long g_cm_stamps[8];
 
 struct CMArgs {
     int tdbg, kint, swp_ok;
@@ -984,7 +992,8 @@ int launch_mt(const CMArgs& a, int grid, size_t lds, int nw, hipStream_t s) {
             else CM_LAUNCH5(MTV, STV, NVV, NWV, SWV, 0);                                                   \
         } else if constexpr (STV != 1 && PREC == CRUSE_PREC_BF16) {                                        \
             if (a.bb_y != nullptr) {                                                                       \
-                if (a.y_bf16) {                                                                            \
+                if constexpr (NWV != 4 || MTV > 2) { cruse_set_error("conv_mfma: the fused BatchNorm-backward input is a 4-wave, <= 32-row form"); return CRUSE_E_SHAPE; } \
+                else if (a.y_bf16) {                                                                       \
                     if constexpr (SWV != 0) CM_LAUNCH5(MTV, STV, NVV, NWV, SWV, 6);                        \
                     else { cruse_set_error("conv_mfma: a bf16 output needs the swapped-role (vector-store) forms"); return CRUSE_E_DTYPE; } \
                 } else CM_LAUNCH5(MTV, STV, NVV, NWV, SWV, 5);                                             \
@@ -1005,7 +1014,8 @@ int launch_mt(const CMArgs& a, int grid, size_t lds, int nw, hipStream_t s) {
     } while (0)
 #define CM_LAUNCH2(MTV, STV, NVV)                                                                          \
     do {                                                                                                   \
-        if (nw == 5) CM_LAUNCH3(MTV, STV, NVV, 5);                                                         \
+        if constexpr (PREC == CRUSE_PREC_F32) CM_LAUNCH3(MTV, STV, NVV, 4);     /* (the exact-f32 gate mode: four waves everywhere) */ \
+        else if (nw == 5) CM_LAUNCH3(MTV, STV, NVV, 5);                                                    \
         else CM_LAUNCH3(MTV, STV, NVV, 4);                                                                 \
     } while (0)
 #define CM_LAUNCH1(MTV, STV)                                                                               \
@@ -1033,7 +1043,29 @@ int launch_mt(const CMArgs& a, int grid, size_t lds, int nw, hipStream_t s) {
     return CRUSE_OK;
 }
 
-}  // namespace
+}  // namespace cruse_cm
+using namespace cruse_cm;
+
+// per-precision launchers and their phase-stamp readers: one translation unit each (CM_TU)
+int cruse_cm_launch_f32(const CMArgs& a, int grid, size_t lds, int nw, hipStream_t s);
+int cruse_cm_launch_x3(const CMArgs& a, int grid, size_t lds, int nw, hipStream_t s);
+int cruse_cm_launch_bf16(const CMArgs& a, int grid, size_t lds, int nw, hipStream_t s);
+int cruse_cm_stamps_f32(unsigned long long* out8);
+int cruse_cm_stamps_x3(unsigned long long* out8);
+int cruse_cm_stamps_bf16(unsigned long long* out8);
+#define CM_DEFINE_TU(SUFFIX, PRECV)                                                                                   \
+    int cruse_cm_launch_##SUFFIX(const CMArgs& a, int grid, size_t lds, int nw, hipStream_t s) { return launch_mt<PRECV>(a, grid, lds, nw, s); } \
+    int cruse_cm_stamps_##SUFFIX(unsigned long long* out8) {                                                          \
+        return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_cm_stamps), 8 * sizeof(unsigned long long)) == hipSuccess ? CRUSE_OK : CRUSE_E_HIP; \
+    }
+#if CM_TU == 1
+CM_DEFINE_TU(f32, CRUSE_PREC_F32)
+#elif CM_TU == 2
+CM_DEFINE_TU(x3, CRUSE_PREC_BF16X3)
+#elif CM_TU == 3
+CM_DEFINE_TU(bf16, CRUSE_PREC_BF16)
+#else
+static int g_cm_last_prec = CRUSE_PREC_F32;
 
 // Returns 1 if the MFMA path handled the call, 0 if the shape is not eligible (caller falls back
 // to the VALU kernel), < 0 on error.
@@ -1123,12 +1155,14 @@ int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float
     const int ntile_wg = a.nclass * (TFM * (Fout / a.OS) / 16);       // N-tiles of one workgroup tile
     int nw = (ntile_wg == 5 || (ntile_wg == 10 && (Cin >= 64 || Cout >= 64))) ? 5 : 4;
     { const int e = cruse_opt("cm_nw", 0); if (e == 4 || e == 5) nw = e; }       // profiling option
+    if (prec == CRUSE_PREC_F32) nw = 4;
     // the fused input BatchNorm backward holds 48 more prefetch registers per thread: the 5-wave (128-register) and 64-row variants spill
     // (decoder level 4: 223 us against 38 + 49 for the two separate kernels) -- those shapes keep the separate pass
     if (bbi != nullptr && (nw == 5 || mt > 2)) return 0;
-    if (prec == CRUSE_PREC_F32) rc = launch_mt<CRUSE_PREC_F32>(a, grid, lds, nw, stream);
-    else if (prec == CRUSE_PREC_BF16) rc = launch_mt<CRUSE_PREC_BF16>(a, grid, lds, nw, stream);
-    else rc = launch_mt<CRUSE_PREC_BF16X3>(a, grid, lds, nw, stream);
+    g_cm_last_prec = prec;
+    if (prec == CRUSE_PREC_F32) rc = cruse_cm_launch_f32(a, grid, lds, nw, stream);
+    else if (prec == CRUSE_PREC_BF16) rc = cruse_cm_launch_bf16(a, grid, lds, nw, stream);
+    else rc = cruse_cm_launch_x3(a, grid, lds, nw, stream);
     if (rc) return rc;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { cruse_set_error("conv_mfma: HIP launch failed: %s", hipGetErrorString(e)); return CRUSE_E_HIP; }
@@ -1137,5 +1171,7 @@ int cruse_conv_mfma_try(int scatter, const float* x, const float* w, const float
 
 // profiling: the phase stamps of the last conv_mfma launch with option cm_dbg = 1 (see g_cm_stamps)
 extern "C" int cruse_conv_mfma_stamps(unsigned long long* out8) {
-    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_cm_stamps), 8 * sizeof(unsigned long long)) == hipSuccess ? CRUSE_OK : CRUSE_E_HIP;
+    if (g_cm_last_prec == CRUSE_PREC_F32) return cruse_cm_stamps_f32(out8);
+    return g_cm_last_prec == CRUSE_PREC_BF16 ? cruse_cm_stamps_bf16(out8) : cruse_cm_stamps_x3(out8);
 }
+#endif   // CM_TU
