@@ -232,15 +232,17 @@ class KernelTimer:
         return tot, cnt
 
 
-def _pmc_file():
+def _newest_profile(suffix: str) -> str:
+    """profiles/rNN_<suffix> of the latest round that committed one (the PMC passes are separate rocprofv3 runs, tools/profile_round.sh)"""
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    for name in ("r04_pmc_hbm_traffic.csv", "r03_pmc_hbm_traffic.csv", "r02_pmc_hbm_traffic.csv", "r01_pmc_hbm_traffic.csv"):
-        if os.path.exists(os.path.join(d, name)):
-            return os.path.join(d, name)
-    return os.path.join(d, "r04_pmc_hbm_traffic.csv")
+    for r in range(9, 0, -1):
+        if os.path.exists(os.path.join(d, f"r{r:02d}_{suffix}")):
+            return os.path.join(d, f"r{r:02d}_{suffix}")
+    return os.path.join(d, f"r01_{suffix}")
 
 
-PMC_FILE = _pmc_file()
+PMC_FILE = _newest_profile("pmc_hbm_traffic.csv")
+PMC_MFMA_FILE = _newest_profile("pmc_mfma_util.csv")
 
 
 PMC_STEPS = 4            # the PMC passes ran `bench.py --steps 3 --warmup 1`: launch counts in the CSV are per 4 steps
@@ -280,9 +282,7 @@ def pmc_traffic():
 def pmc_mfma_util():
     """MFMA utilisation per kernel family from the committed rocprofv3 PMC pass (profiles/r03_pmc_mfma_util.csv, made by
     tools/pmc_traffic.py --mfma at the bench shape): sum(SQ_VALU_MFMA_BUSY_CYCLES) / sum(GRBM_GUI_ACTIVE / 8 XCDs * 256 CUs * 4)."""
-    path = os.path.join(ROOT, "profiles", "r04_pmc_mfma_util.csv")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r03_pmc_mfma_util.csv")
+    path = PMC_MFMA_FILE
     out = {}
     if not os.path.exists(path):
         return out
@@ -856,7 +856,7 @@ def main():
             for fam, ent in rl.items():
                 if util.get(fam) is not None:
                     ent["mfma_util_pmc"] = util[fam]
-                    ent["mfma_util_source"] = "profiles/r04_pmc_mfma_util.csv (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs))"
+                    ent["mfma_util_source"] = f"profiles/{os.path.basename(PMC_MFMA_FILE)} (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs))"
             for fam, ent in rl.items():
                 if pmc.get(fam):
                     ent["traffic"] = round(pmc[fam])

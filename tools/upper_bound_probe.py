@@ -20,13 +20,15 @@ def main():
     m = unet_2(rnn_groups=1, precision="bf16").cuda()
     eng = TrainEngine(m, use_graph=False)
     pool = [synth_batch(64, 64000, "cuda", 1234 + s) for s in range(4)]
-    variants = {"baseline": [], "fwd gate GEMMs free": ["gemm_bf16x3_nt"], "fwd gate GEMMs + ln_fwd free": ["gemm_bf16x3_nt", "ln_fwd"],
+    variants = {"baseline": [], "fwd gate GEMMs free": ["gemm_f16_nt", "gemm_bf16x3_nt"], "fwd gate GEMMs + ln_fwd free": ["gemm_f16_nt", "gemm_bf16x3_nt", "ln_fwd"],
+                "gate grads free": ["gru_gate_grads_bf16"], "dX GEMMs free": ["gemm_bf16_nt"], "ln_bwd free": ["ln_bwd"],
+                "GRU dW GEMMs free": ["gemm_bf16_nt_cat"], "transposes free": ["transpose_bf16"],
                 "bwd gate grads + dX + ln_bwd free": ["gru_gate_grads_bf16", "gemm_bf16_nt", "ln_bwd"],
-                "all of them free": ["gemm_bf16x3_nt", "ln_fwd", "gru_gate_grads_bf16", "gemm_bf16_nt", "ln_bwd"],
-                # conv stack (r03: what would bf16 storage of the backward-only tensors be worth at most?)
-                "BatchNorm backward free": ["bn_act_bwd"], "data-gradient + skip convs free": ["conv_gather", "conv_scatter2"],
-                "conv weight gradients free": ["conv_wgrad"],
-                "BN backward + dgrad + wgrad free": ["bn_act_bwd", "conv_gather", "conv_scatter2", "conv_wgrad"]}
+                # conv stack
+                "BatchNorm backward free": ["bn_act_bwd"], "conv weight gradients free": ["conv_wgrad"],
+                "skip convs (fwd + dgrad) free": ["conv_gather"],
+                "dW + wgrad free": ["gemm_bf16_nt_cat", "conv_wgrad"],
+                "recurrences free": ["gru_seq_fwd", "gru_seq_bwd"]}
     if len(sys.argv) > 1:
         variants = {k: v for k, v in variants.items() if k == "baseline" or any(a in k for a in sys.argv[1:])}
     for name, fns in variants.items():
