@@ -13,7 +13,7 @@ for k in 0 1 2 3; do
   pids+=($!)
   objs+=("$here/build/conv_mfma_$k.o")
 done
-for f in stft stft_general conv wgrad_mfma pointwise gemm gemm_bf16 gru gru_tf gru_w16 tdloss deepfilter generic extras; do
+for f in stft stft_general conv wgrad_mfma wgrad_rd pointwise gemm gemm_bf16 gru gru_tf gru_w16 tdloss deepfilter generic extras; do
   "$HIPCC" $FLAGS -c "$here/$f.hip" -o "$here/build/$f.o" &
   pids+=($!)
   objs+=("$here/build/$f.o")

@@ -297,7 +297,7 @@ struct WgradArgs {
 };
 
 constexpr int WG_THREADS = 256;
-constexpr int WG_MAX_BLOCKS = 512;
+constexpr int WG_MAX_BLOCKS = 1024;
 
 template <int CB_T, int KT>
 __global__ __launch_bounds__(WG_THREADS) void conv_wgrad_kernel(WgradArgs p) {
@@ -696,12 +696,16 @@ extern "C" int cruse_conv_scatter2_bnbwd_in(const void* dout, int dout_dtype, co
 }
 
 extern "C" size_t cruse_conv_wgrad_ws_bytes(int Ca, int Cb, int KT) {
-    return (size_t)WG_MAX_BLOCKS * Ca * Cb * KT * 3 * sizeof(float);
+    // partial slabs: [slab][Ca][Cb][KT][3] (LDS-staged and VALU kernels) or accumulator images of 16 x 16 tiles (register-direct kernel)
+    return (size_t)WG_MAX_BLOCKS * ((Ca + 15) / 16 * 16) * ((Cb + 15) / 16 * 16) * KT * 3 * sizeof(float);
 }
 
 int cruse_wgrad_mfma_try(const float* a, const float* bt, float* partial, int max_slabs,
                          int B, int T, int Ca, int Fa, int Cb, int Fb, int KT, int S, int pad, int prec, int a_bf16, int bt_bf16,
                          int* nblk_out, hipStream_t stream);
+int cruse_wgrad_rd_try(const float* a, const float* bt, float* partial, size_t ws_bytes, float* dw,
+                       int B, int T, int Ca, int Fa, int Cb, int Fb, int KT, int S, int pad, int prec, int a_bf16, int bt_bf16,
+                       int* nblk_out, hipStream_t stream);
 
 extern "C" int cruse_conv_wgrad(const float* a, const float* bt, float* dw,
                                 int B, int T, int Ca, int Fa, int Cb, int Fb,
@@ -713,9 +717,13 @@ extern "C" int cruse_conv_wgrad(const float* a, const float* bt, float* dw,
                   "conv_wgrad: unsupported KT=%d S=%d pad=%d", KT, S, pad);
     if (prec >= 0) {
         int nblk = 0;
-        const int r = cruse_wgrad_mfma_try(a, bt, (float*)ws, WG_MAX_BLOCKS, B, T, Ca, Fa, Cb, Fb, KT, S, pad, prec,
-                                           a_dtype == CRUSE_DT_BF16, bt_dtype == CRUSE_DT_BF16, &nblk, (hipStream_t)stream);
+        // register-direct stream (plain bf16 mode, the bench shapes), else the LDS-staged kernel
+        int r = cruse_wgrad_rd_try(a, bt, (float*)ws, cruse_conv_wgrad_ws_bytes(Ca, Cb, KT), dw, B, T, Ca, Fa, Cb, Fb, KT, S, pad, prec,
+                                   a_dtype == CRUSE_DT_BF16, bt_dtype == CRUSE_DT_BF16, &nblk, (hipStream_t)stream);
+        if (r == 0) r = cruse_wgrad_mfma_try(a, bt, (float*)ws, WG_MAX_BLOCKS, B, T, Ca, Fa, Cb, Fb, KT, S, pad, prec,
+                                             a_dtype == CRUSE_DT_BF16, bt_dtype == CRUSE_DT_BF16, &nblk, (hipStream_t)stream);
         if (r < 0) return r;
+        if (r == 1 && nblk == 0) return CRUSE_OK;      // (the register-direct kernel reduces its slabs itself)
         if (r == 1) {
             const int nout = Ca * Cb * KT * 3;
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(nout, 256), cdiv(nblk, 16)), dim3(256), 0, (hipStream_t)stream,

@@ -15,6 +15,6 @@ for f in "$@"; do
 done
 for p in "${pids[@]}"; do wait "$p"; done
 objs=()
-for f in stft stft_general conv conv_mfma_0 conv_mfma_1 conv_mfma_2 conv_mfma_3 wgrad_mfma pointwise gemm gemm_bf16 gru gru_tf gru_w16 tdloss deepfilter generic extras abi; do objs+=("$here/build/$f.o"); done
+for f in stft stft_general conv conv_mfma_0 conv_mfma_1 conv_mfma_2 conv_mfma_3 wgrad_mfma wgrad_rd pointwise gemm gemm_bf16 gru gru_tf gru_w16 tdloss deepfilter generic extras abi; do objs+=("$here/build/$f.o"); done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$here/../libcruse_hip.so"
 echo "relinked"

@@ -200,8 +200,9 @@ int cruse_conv_mfma_stamps(unsigned long long* out8);
 
 /* weight gradient of either form:
  *   dw[ca][cb][kt][kf] += sum_{b,t,fa} a[b,t,ca,fa] * bt[b, t-(KT-1)+kt, cb, fa*S - pad + kf]
- * ws: scratch of cruse_conv_wgrad_ws_bytes() bytes.  prec: CRUSE_PREC_* selects the MFMA kernel
- * (patch matrix materialised in LDS); prec < 0 or an ineligible shape runs the f32 VALU kernel. */
+ * ws: scratch of cruse_conv_wgrad_ws_bytes() bytes.  prec: CRUSE_PREC_* selects an MFMA kernel -- CRUSE_PREC_BF16 with rows of >= 8
+ * (even) positions and Fb == S * Fa: fragments loaded straight from the two tensors (wgrad_rd.hip); otherwise the patch matrix is
+ * materialised in LDS (wgrad_mfma.hip); prec < 0 or an ineligible shape runs the f32 VALU kernel. */
 size_t cruse_conv_wgrad_ws_bytes(int Ca, int Cb, int KT);
 int cruse_conv_wgrad(const float* a, const float* bt, float* dw,
                      int B, int T, int Ca, int Fa, int Cb, int Fb,

@@ -1161,6 +1161,66 @@ def test_gru_register_direct_sweeps_and_all_gather_backward(ops, B, T):
 
 
 
+def _wgrad_ref(a, bt, KT, S, pad):
+    """dw[ca][cb][kt][kf] = sum a[b,t,ca,fa] * bt[b, t-(KT-1)+kt, cb, fa*S - pad + kf] in f64 (include/cruse_hip.h, cruse_conv_wgrad)"""
+    B, T, Ca, Fa = a.shape
+    _, _, Cb, Fb = bt.shape
+    a64, b64 = a.double(), bt.double()
+    dw = torch.zeros(Ca, Cb, KT, 3, dtype=torch.float64)
+    for kt in range(KT):
+        sh = KT - 1 - kt                                      # source frame t - sh
+        src = torch.zeros_like(b64)
+        src[:, sh:] = b64[:, :T - sh] if sh else b64
+        for kf in range(3):
+            idx = torch.arange(Fa) * S - pad + kf
+            ok = (idx >= 0) & (idx < Fb)
+            g = torch.zeros(B, T, Cb, Fa, dtype=torch.float64)
+            g[..., ok] = src[..., idx[ok]]
+            dw[:, :, kt, kf] = torch.einsum("btaf,btcf->ac", a64, g)
+    return dw
+
+
+@pytest.mark.parametrize("shape", [
+    # (B, T, Ca, Fa, Cb, KT, S, pad): the three conv forms at ragged sizes -- rows of 8 / 12 / 20 / 10 positions (one window; an end-aligned
+    # last window that overlaps the one before it by 4 / 4 / 6 positions), channel counts that leave padding rows / columns in the
+    # 16 x 16 tiles and partial 16-channel source tiles, one- and two-frame clips (frame t - 1 of every clip's first frame is zero)
+    (2, 5, 8, 8, 1, 2, 2, 1), (3, 1, 16, 12, 8, 2, 2, 1), (1, 2, 32, 20, 16, 2, 2, 1), (2, 7, 64, 10, 32, 2, 2, 1), (2, 9, 24, 10, 12, 2, 2, 1),
+    (2, 5, 8, 40, 1, 1, 2, 0), (3, 3, 16, 12, 8, 1, 2, 0), (2, 4, 64, 10, 32, 1, 2, 0), (1, 6, 40, 20, 24, 1, 2, 0),
+    (2, 5, 8, 16, 8, 1, 1, 1), (3, 3, 32, 20, 32, 1, 1, 1), (2, 4, 64, 10, 64, 1, 1, 1), (1, 11, 12, 12, 40, 1, 1, 1),
+    (5, 21, 16, 40, 8, 2, 2, 1)])
+def test_conv_wgrad_register_direct_kernel(ops, shape):
+    """wgrad_rd.hip (bf16 mode): fragments loaded straight from the two tensors.  Against the f64 contraction of the bf16-rounded operands
+    (only the f32 accumulation order differs: 2e-5) and -- same operand bits, same products -- the LDS-staged kernel; every bf16 / f32
+    storage combination of the two operands gives the same bits."""
+    B, T, Ca, Fa, Cb, KT, S, pad = shape
+    Fb = S * Fa
+    gen = torch.Generator().manual_seed(sum(shape))
+    a = torch.randn(B, T, Ca, Fa, generator=gen).to(torch.bfloat16)
+    bt = torch.randn(B, T, Cb, Fb, generator=gen).to(torch.bfloat16)
+    ref = _wgrad_ref(a.float(), bt.float(), KT, S, pad)
+    outs = {}
+    for rd in (1, 0):
+        ops.set_option("wg_rd", rd)
+        try:
+            for da, db in ((torch.bfloat16, torch.bfloat16), (torch.float32, torch.bfloat16), (torch.bfloat16, torch.float32), (torch.float32, torch.float32)):
+                dw = torch.zeros(Ca, Cb, KT, 3).cuda()
+                ops.conv_wgrad(a.to(da).cuda(), bt.to(db).cuda(), dw, B, T, Ca, Fa, Cb, Fb, KT=KT, S=S, pad=pad, prec="bf16")
+                outs[(rd, da, db)] = dw.cpu()
+        finally:
+            ops.set_option("wg_rd", None)
+    first = outs[(1, torch.bfloat16, torch.bfloat16)]
+    assert rel_l2(first, ref) < 2e-5
+    for key, dw in outs.items():
+        if key[0] == 1:
+            assert torch.equal(dw, first), key
+        else:
+            assert rel_l2(dw, ref) < 2e-5, key
+    # accumulation into an existing gradient
+    dw = torch.full((Ca, Cb, KT, 3), 0.5).cuda()
+    ops.conv_wgrad(a.cuda(), bt.cuda(), dw, B, T, Ca, Fa, Cb, Fb, KT=KT, S=S, pad=pad, prec="bf16")
+    assert torch.allclose(dw.cpu(), first + 0.5, rtol=1e-6, atol=1e-5)
+
+
 @pytest.mark.parametrize("form", ["gather", "scatter", "wgrad_a", "wgrad_bt"])
 def test_backward_only_tensors_stored_as_bf16_give_the_same_bits(ops, form):
     """EngineConfig.bf16_dy (round 4): the BatchNorm-backward output is stored as bf16 -- the data-gradient convs (plain bf16
