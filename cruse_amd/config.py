@@ -58,8 +58,8 @@ class EngineConfig:
             "fuse_bn_fwd": ("CRUSE_FUSE_BN_FWD", lambda v: v != "0"), "fuse_bn_bwd_apply": ("CRUSE_FUSE_BN_BWD_APPLY", lambda v: v != "0"), "bf16_dy": ("CRUSE_BF16_DY", lambda v: v != "0"), "bf16_de": ("CRUSE_BF16_DE", lambda v: v != "0")}
     _LIB_ENV = {"CRUSE_GRU_BWD_RS": "gru_bwd_rs", "CRUSE_GRU_FWD_LEAN": "gru_fwd_lean", "CRUSE_GRU_WLO": "gru_wlo", "CRUSE_GRU_DBG": "gru_dbg",
                 "CRUSE_GRU_TF": "gru_tf", "CRUSE_GRU_POLL_FWD": "gru_poll_fwd", "CRUSE_GRU_POLL_BWD": "gru_poll_bwd", "CRUSE_CM_KINT": "cm_kint",
-                "CRUSE_CM_SWAP": "cm_swap", "CRUSE_CM_NW": "cm_nw", "CRUSE_PW_VALU": "pw_valu", "CRUSE_WG_TFW": "wg_tfw", "CRUSE_WG_DBG": "wg_dbg",
-                "CRUSE_WG_SR": "wg_sr", "CRUSE_WG_RD": "wg_rd", "CRUSE_WG_GRID": "wg_grid"}
+                "CRUSE_CM_SWAP": "cm_swap", "CRUSE_CM_NW": "cm_nw", "CRUSE_PW_VALU": "pw_valu", "CRUSE_WG_DBG": "wg_dbg",
+                "CRUSE_WG_RD": "wg_rd", "CRUSE_WG_GRID": "wg_grid"}
 
     @classmethod
     def from_env(cls, env=None) -> "EngineConfig":

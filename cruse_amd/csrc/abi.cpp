@@ -25,7 +25,7 @@ extern "C" int cruse_abi_version(void) { return CRUSE_ABI_VERSION; }
 #include <string.h>
 namespace {
 const char* const OPT_NAMES[] = {"gru_bwd_rs", "gru_fwd_lean", "gru_tf", "gru_poll_fwd", "gru_poll_bwd", "gru_wlo", "gru_dbg", "cm_dbg", "cm_nw", "cm_kint", "cm_swap",
-                                 "pw_valu", "wg_sr", "wg_dbg", "wg_tfw", "wg_rd", "wg_grid"};
+                                 "pw_valu", "wg_dbg", "wg_rd", "wg_grid"};
 constexpr int N_OPT = sizeof(OPT_NAMES) / sizeof(OPT_NAMES[0]);
 std::atomic<int> g_opt[N_OPT];
 struct OptInit { OptInit() { for (auto& o : g_opt) o.store(INT_MIN); } } g_opt_init;

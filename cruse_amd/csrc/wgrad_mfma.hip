@@ -23,7 +23,6 @@ struct WMArgs {
     const float* a; const float* bt; float* partial;
     int B, T, Ca, Fa, Cb, Fb, KT, S, pad;
     int FaP, NCH, ntaps, nrows, ntiles_total;
-    int FbS;                               // SR: elements per source row (bins of one parity + 8 zero columns on each side, rounded)
     int a_bf16, bt_bf16;                   // operand tensors hold bf16 elements (backward-only tensors stored in bf16; PREC == bf16 only)
     int dbg;                               // profiling only (CRUSE_WG_DBG bit mask: skip 1 patch build, 2 MFMA loop, 4 loads, 8 A/raw image)
 };
@@ -76,14 +75,10 @@ __device__ __forceinline__ Frag<PREC> wget(const typename WStore<PREC>::elem* ba
 }
 
 // TFW frames per tile; MT = ceil(Ca/16) row tiles; NTW = column tiles per wavefront
-// SR ("shifted rows", plain bf16 only): NO patch matrix.  The raw bt frames are staged once as bf16 rows [frame][cb][parity][FbS] -- for the
-// stride-2 convs de-interleaved into an even-bin and an odd-bin row, zero columns on both sides -- and the B fragment of column (tap, cb) for 8
-// consecutive positions is ONE 16-byte LDS read from the row of frame tl + kt, parity (kf - pad) & 1, shifted by floor((kf - pad) / 2) elements
-// (a 2-byte aligned read where the shift is odd; stride 1: shifted by kf - pad).  Gone: the patch build (the largest LDS phase: three 4-byte
-// stores and 4-5 reads per bin pair, channel and kt), its barrier and 2/3 of the LDS footprint.
-template <int PREC, int TFW, int MT, int NTW, bool SR = false>
+// (The plain-bf16 mode of the training step runs wgrad_rd.hip -- fragments straight from global memory, no LDS image; this kernel serves the
+// f32 / split-bf16 modes and the bf16 shapes that one does not take: rows of fewer than 8 or an odd number of positions, Fb != S * Fa.)
+template <int PREC, int TFW, int MT, int NTW>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WMArgs p) {
-    static_assert(!SR || PREC == CRUSE_PREC_BF16, "shifted-row operand: plain bf16");
     typedef typename WStore<PREC>::elem elem;
     constexpr int NPL = WStore<PREC>::NPL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -97,9 +92,6 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WMArgs p) {
     elem* al = reinterpret_cast<elem*>(smem_raw);           // [NPL][MT*16][TFW][FaP]
     elem* pl = al + NPL * aplane;                            // [NPL][NJ][TFW][FaP]
     float* rawl = reinterpret_cast<float*>(pl + NPL * bplane);   // [nrows][Cb][Fb]
-    // SR: source rows [frame][cb][parity][FbS] bf16 right behind the A image; logical element x of a row sits at 8 + x
-    const int NP = p.S, FbS = p.FbS;
-    __bf16* const srl = reinterpret_cast<__bf16*>(al + NPL * aplane);
     const int rowa = p.Ca * p.Fa, rowb = p.Cb * p.Fb;
     const int ntile_t = (p.T + TFW - 1) / TFW;
     const int nva = TFW * rowa / 4, nvb = p.nrows * rowb / 4;
@@ -107,8 +99,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WMArgs p) {
     // zero both operand images once: pad bins, pad rows and pad columns stay zero for good
     {
         uint4* z = reinterpret_cast<uint4*>(al);             // both images are multiples of 16 bytes
-        const size_t n16 = SR ? (aplane * sizeof(elem) + (size_t)p.nrows * p.Cb * NP * FbS * 2 + 15) / 16
-                              : NPL * (aplane + bplane) * sizeof(elem) / 16;
+        const size_t n16 = NPL * (aplane + bplane) * sizeof(elem) / 16;
         for (size_t i = tid; i < n16; i += 256) z[i] = make_uint4(0u, 0u, 0u, 0u);
     }
 
@@ -171,30 +162,6 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WMArgs p) {
         fr_a |= (unsigned)min(15, (i * 4) / rowa) << (4 * q);
         fr_b |= (unsigned)min(15, (i * 4) / rowb) << (4 * q);
     }
-    // SR: element offset of a staged slot's first bin (4 consecutive bins of one (frame, cb) row; Fb % 4 == 0): stride 1 at 8 + f,
-    // stride 2 the even pair at 8 + f / 2 of parity 0 and the odd pair at the same index of parity 1
-    int s_off[SR ? MAXV : 1];
-    if constexpr (SR) {
-#pragma unroll
-        for (int q = 0; q < MAXV; ++q) {
-            const int e = min(tid + 256 * q, max(nvb - 1, 0)) * 4;
-            const int r = e / rowb, j = e - r * rowb, c = j / p.Fb, f = j - c * p.Fb;
-            s_off[q] = ((r * p.Cb + c) * NP) * FbS + 8 + (NP == 2 ? (f >> 1) : f);
-        }
-    }
-    // SR: B-fragment base of this lane's NTW columns: column (tap = kt*3 + kf, cb) -> row (kt, cb, parity) + 8 + shift
-    int b_base[SR ? NTW : 1];
-    if constexpr (SR) {
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) {
-            const int col = min((wv * NTW + j) * 16 + (lane & 15), p.ntaps * p.Cb - 1);       // (padding columns re-read the last one: finite)
-            const int tap = col / p.Cb, cb = col - tap * p.Cb, kt = tap / 3, kf = tap - 3 * kt;
-            const int qq = kf - p.pad;                                                        // source bin = S * fa + qq
-            const int par = NP == 2 ? (qq & 1) : 0, sh = NP == 2 ? ((qq - par) >> 1) : qq;
-            b_base[j] = ((kt * p.Cb + cb) * NP + par) * FbS + 8 + sh;
-        }
-    }
-    const int sr_frame = p.Cb * NP * FbS;                    // elements between consecutive frames of the source image
     float4 pa[MAXV], pb[MAXV];
     auto prefetch = [&](int tile) {
         const int b = tile / ntile_t;
@@ -274,28 +241,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WMArgs p) {
                 }
             }
         }
-        if constexpr (SR) {
-            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2s;
-#pragma unroll
-            for (int q = 0; q < MAXV; ++q) {
-                const int i = tid + 256 * q;
-                if (i < nvb) {
-                    unsigned w0, w1;                             // bins (f, f+1) and (f+2, f+3) as packed bf16 pairs
-                    if (p.bt_bf16) { w0 = __float_as_uint(pb[q].x); w1 = __float_as_uint(pb[q].y); }
-                    else {
-                        bf16x2s h0, h1;
-                        h0[0] = (__bf16)pb[q].x; h0[1] = (__bf16)pb[q].y; h1[0] = (__bf16)pb[q].z; h1[1] = (__bf16)pb[q].w;
-                        w0 = __builtin_bit_cast(unsigned, h0); w1 = __builtin_bit_cast(unsigned, h1);
-                    }
-                    if (NP == 2) {
-                        *reinterpret_cast<unsigned*>(srl + s_off[q]) = __builtin_amdgcn_perm(w1, w0, 0x05040100u);          // even bins f, f+2
-                        *reinterpret_cast<unsigned*>(srl + s_off[q] + FbS) = __builtin_amdgcn_perm(w1, w0, 0x07060302u);    // odd bins f+1, f+3
-                    } else {
-                        *reinterpret_cast<uint2*>(srl + s_off[q]) = make_uint2(w0, w1);
-                    }
-                }
-            }
-        } else if (p.bt_bf16) {
+        if (p.bt_bf16) {
 #pragma unroll
             for (int q = 0; q < MAXV; ++q) {
                 const int i = tid + 256 * q;
@@ -316,7 +262,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WMArgs p) {
         if (tile + (int)gridDim.x < p.ntiles_total) prefetch(tile + gridDim.x);
         // patch image: pl[j = tap*Cb + cb][tl][fa] = bt[tl + kt][cb][fa*S - pad + kf]
 #pragma unroll
-        for (int sidx = 0; sidx < (SR ? 0 : MAXP); ++sidx) {
+        for (int sidx = 0; sidx < MAXP; ++sidx) {
             if (p_dst[sidx] < 0 || (p.dbg & 1)) continue;
             const unsigned ok = p_ok[sidx];
             int dst = p_dst[sidx], src = p_src[sidx];
@@ -359,7 +305,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WMArgs p) {
                 src += ngroups * p.Fb;
             }
         }
-        if constexpr (!SR) __syncthreads();
+        __syncthreads();
         // K steps: lane group (lane >> 4) takes chunk ks*4 + group; (frame, bin-chunk) advance without dividing
         int tl = (lane >> 4) / p.NCH, fc = (lane >> 4) - tl * p.NCH;
         for (int ks = 0; ks < ((p.dbg & 2) ? 0 : nks); ++ks) {
@@ -370,13 +316,8 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WMArgs p) {
                 fa_[i] = wget<PREC>(al, aplane, (size_t)(i * 16 + (lane & 15)) * RS + poff);
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
-                Frag<PREC> fb_;
-                if constexpr (SR) {
-                    __builtin_memcpy(&fb_.h, srl + b_base[j] + tl * sr_frame + fc * 8, 16);       // (2-byte aligned where the shift is odd)
-                } else {
-                    const int col = (wv * NTW + j) * 16 + (lane & 15);
-                    fb_ = wget<PREC>(pl, bplane, (size_t)col * RS + poff);
-                }
+                const int col = (wv * NTW + j) * 16 + (lane & 15);
+                const Frag<PREC> fb_ = wget<PREC>(pl, bplane, (size_t)col * RS + poff);
 #pragma unroll
                 for (int i = 0; i < MT; ++i) acc[i][j] = mma(fa_[i], fb_, acc[i][j]);
             }
@@ -408,14 +349,6 @@ int launch_ntw(const WMArgs& p, int ntw, int grid, size_t lds, hipStream_t s) {
     int rc;
 #define WM_LAUNCH(NTWV)                                                                                       \
     do {                                                                                                      \
-        if constexpr (PREC == CRUSE_PREC_BF16) {                                                              \
-            if (p.FbS > 0) {                                                                                  \
-                if ((rc = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(wgrad_mfma_kernel<PREC, TFW, MT, NTWV, true>), lds, \
-                                               "wgrad_mfma"))) return rc;                                     \
-                hipLaunchKernelGGL((wgrad_mfma_kernel<PREC, TFW, MT, NTWV, true>), dim3(grid), dim3(256), lds, s, p); \
-                break;                                                                                        \
-            }                                                                                                 \
-        }                                                                                                     \
         if ((rc = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(wgrad_mfma_kernel<PREC, TFW, MT, NTWV>), lds, \
                                        "wgrad_mfma"))) return rc;                                             \
         hipLaunchKernelGGL((wgrad_mfma_kernel<PREC, TFW, MT, NTWV>), dim3(grid), dim3(256), lds, s, p);       \
@@ -449,15 +382,7 @@ int cruse_wgrad_mfma_try(const float* a, const float* bt, float* partial, int ma
     if (Ca > 64 || ntw > 3) return 0;
     if ((Ca * Fa) % 4 != 0 || (Cb * Fb) % 4 != 0 || ((uintptr_t)a % 16) != 0 || ((uintptr_t)bt % 16) != 0) return 0;
     const int esz = (prec == CRUSE_PREC_F32) ? 4 : 2, npl = (prec == CRUSE_PREC_BF16X3) ? 2 : 1;
-    // shifted-row operand (plain bf16; option wg_sr): source rows of flen + 16 elements, row pitch == 4 (mod 8) elements so that the 16 rows a
-    // fragment read touches start 8 bytes apart modulo the bank window
-    // (measured per shape at the bench point, tools/scratch/wg_sr2.py: 20-33 % faster for Ca <= 32 and for the 64-row (2,3)-tap layer on 256
-    //  workgroups; the 64-row single-frame-tap layers are faster on the patch matrix)
-    const bool sr = prec == CRUSE_PREC_BF16 && Fb % 4 == 0 && (S == 1 || S == 2) && Fb % S == 0 && (mt <= 2 || KT == 2) &&
-                    cruse_opt("wg_sr", 1) != 0;
-    const int fbs = sr ? ((Fb / S + 16 + 3) / 8 * 8 + 4) : 0;
     auto lds_of = [&](int tf) {
-        if (sr) return (size_t)mt * 16 * (tf * FaP + RPAD) * 2 + ((size_t)(tf + KT - 1) * Cb * S * fbs * 2 + 15) / 16 * 16;
         return ((size_t)mt * 16 + (size_t)ntw * 64) * (tf * FaP + RPAD) * esz * npl + (size_t)(tf + KT - 1) * Cb * Fb * 4;
     };
     auto fits = [&](int tf) {
@@ -470,22 +395,19 @@ int cruse_wgrad_mfma_try(const float* a, const float* bt, float* partial, int ma
     // else 4-frame tiles; one 8-frame workgroup per CU only where neither fits twice.
     const size_t two_wg = 156 * 1024;
     int tfw = 4, gcap = 256;
-    if (sr && mt > 2 && fits(8)) { tfw = 8; gcap = 256; }
-    else if (prec == CRUSE_PREC_BF16) {
+    if (prec == CRUSE_PREC_BF16) {
         if (fits(8) && 2 * lds_of(8) <= two_wg) { tfw = 8; gcap = 512; }
         else if (fits(4) && 2 * lds_of(4) <= two_wg) { tfw = 4; gcap = 512; }
         else if (fits(8)) { tfw = 8; gcap = 256; }
     } else if (fits(4) && 2 * lds_of(4) <= two_wg) {
         gcap = 512;
     }
-    { const int e = cruse_opt("wg_tfw", 0); if (e == 4 || (e == 8 && prec == CRUSE_PREC_BF16)) tfw = e; }   // profiling overrides
-    { const int e = cruse_opt("wg_grid", 0); if (e > 0) gcap = e; }
     if (!fits(tfw)) return 0;
     const size_t lds = lds_of(tfw);
     WMArgs p = {};
     p.a = a; p.bt = bt; p.partial = partial;
     p.B = B; p.T = T; p.Ca = Ca; p.Fa = Fa; p.Cb = Cb; p.Fb = Fb; p.KT = KT; p.S = S; p.pad = pad;
-    p.FaP = FaP; p.NCH = NCH; p.ntaps = ntaps; p.nrows = tfw + KT - 1; p.FbS = fbs;
+    p.FaP = FaP; p.NCH = NCH; p.ntaps = ntaps; p.nrows = tfw + KT - 1;
     p.ntiles_total = B * ((T + tfw - 1) / tfw);
     p.dbg = cruse_opt("wg_dbg", 0);
     p.a_bf16 = a_bf16 ? 1 : 0; p.bt_bf16 = bt_bf16 ? 1 : 0;

@@ -731,6 +731,8 @@ def unet2_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], Bf: Dict[str, tor
     _flush_counters()
     if save:
         ctx.update(ys=ys, es=es, stats=stats, gctx=gctx, us=us, vs=vs, dstats=dstats, mask=mask, uus=uus, dec_mode=dec_mode)
+        if e_bf is not None and e_bf.dtype == torch.bfloat16:
+            ctx["e_bf"] = e_bf.view(B, T, ch[L], Fk[L])        # RNE(e_L): the operand bits the bf16 weight gradient forms from e_L anyway
     return mask.view(B, ch[0], T, F0), ctx
 
 
@@ -839,7 +841,10 @@ def unet2_backward(ctx, dlogit: torch.Tensor, P: Dict[str, torch.Tensor], G: Dic
                             w_layout=1, out=out, prec=dprec)
 
         def wgrad(k=k, dsk=ds[k]):
-            ops.conv_wgrad(dsk, es[k], G[f"skip_connect_{k}.weight"], B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1,
+            ek = es[k]
+            if k == L and "e_bf" in ctx and ops.prec_code(prec) == ops.PREC_BF16 and all_mfma:
+                ek = ctx["e_bf"]                            # (the gate GEMM's bf16 copy of e_L: half the bytes, the same operand bits)
+            ops.conv_wgrad(dsk, ek, G[f"skip_connect_{k}.weight"], B, T, ch[k], Fk[k], ch[k], Fk[k], KT=1, S=1, pad=1,
                            prec=prec)
         # Deferred to the first backward recurrence (issuing them here costs an event record on the main stream per level
         # and makes the decoder's BatchNorm backward share HBM with them).  Since the recurrences got shorter the side
