@@ -6,16 +6,21 @@
 // The contraction index of the MFMA is the POSITION, and both tensors are bin-contiguous: the 8 consecutive positions a lane feeds
 // v_mfma_f32_16x16x32_bf16 are 16 contiguous bytes of `a` and -- for stride 1 -- of `bt`, shifted by the tap; for stride 2 they are
 // the even or the odd elements of 32 contiguous bytes.  So no LDS image, no patch matrix and no barrier: every wavefront loads its
-// fragments straight from global memory (4-byte aligned 16-byte loads; the tap shift is a v_alignbit / v_perm on the loaded dwords),
-// masks the bins that fall outside the row, and accumulates.  A workgroup is 8 wavefronts that interleave 32-position steps of one
-// contiguous range of frames and share nothing until the end, where their accumulators are summed through LDS (a fixed tree: the
-// slab is deterministic) into one partial slab for wgrad_reduce_kernel.  The kernel is a stream over both tensors: what bounds it is
-// bytes in flight per CU -- 16 independent waves with all loads of a step (or, for the one-tile layers, of 2-4 steps) issued at once.
+// fragments straight from global memory (4-byte aligned 16-byte loads, 32-bit element offsets) and accumulates.  A SOURCE WINDOW --
+// (frame offset kt, 16 channels cb) x the S * 8 bins under 8 positions, plus the dword before / after them -- is loaded once and serves
+// the three taps kf: v_alignbit (stride 1) or v_perm (stride 2) of the same dwords.
 //
-// Lane (l & 15) is the row `ca` of the A fragment / the column (tap, cb) of the B fragment; lane group l >> 4 takes the (frame, chunk)
+// Lane (l & 15) is the row `ca` of the A fragment / the channel `cb` of the B fragments; lane group l >> 4 takes the (frame, window)
 // pair 4 * step + group.  A row of Fa positions is cut into ceil(Fa / 8) windows of 8; the LAST window is end-aligned ([Fa - 8, Fa)) so
-// that no load leaves its row, and the positions it shares with the window before it are masked.  The masks live on the B fragment only
-// (a product with a zero B element is zero: the A window is always inside the tensor, hence finite for finite inputs).
+// that no load leaves its row.  Zeroed: the dword before the first / after the last window of a row (bins -1 and Fb), the whole source
+// window of frame t - 1 at a clip's first frame, and -- on the A fragments, once per step -- the positions the end-aligned window shares
+// with the one before it and the lanes past the frame range.
+//
+// A workgroup is 8 wavefronts that interleave 32-position steps of one contiguous range of frames and share nothing until the end,
+// where their accumulators are summed through LDS (a fixed tree) into one slab -- the accumulator image itself, 256-byte stores -- that
+// wgrad_rd_reduce_kernel sums over the slabs and scatters to dw[ca][cb][kt][kf].  ONE workgroup per CU: the per-workgroup costs (index
+// set-up, LDS tree, slab + its reduction) outweigh what more resident waves hide (cruse_wgrad_rd_try).  Layers whose 3 * MT * pairs
+// accumulator tiles exceed 12 per wave split their source windows over TG workgroups per slab, placed on one XCD (shared L2 for `a`).
 #include "common.h"
 #include <stdlib.h>
 
