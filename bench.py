@@ -185,6 +185,13 @@ class KernelTimer:
 
     def __init__(self, ops, eng):
         self.ops, self.rec, self.saved, self.eng = ops, [], {}, eng
+        self.bytes, self.ncall = {}, {}                    # operand bytes of every call of a family (all passes) / its calls
+
+    def bytes_per_launch(self):
+        """ALGORITHMIC bytes of a launch, dtype-aware: the distinct tensors (>= 1 MB) a call takes and returns, each counted once --
+        what a kernel that reads its inputs once and writes its outputs once must move (round 5: half the step's tensors are bf16 now,
+        the fixed f32 figures of DESIGN section 4 overstated the achieved GB/s of the kernels that take them)."""
+        return {n: self.bytes[n] / max(self.ncall.get(n, 1), 1) for n in self.bytes}
 
     def __enter__(self):
         # leaves run inline for this pass: an event pair around a launch only times that kernel when
@@ -199,6 +206,8 @@ class KernelTimer:
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(); out = _f(*a, **k); e1.record()
                 self.rec.append((_n, e0, e1))
+                self.bytes[_n] = self.bytes.get(_n, 0) + _operand_bytes((a, k, out))
+                self.ncall[_n] = self.ncall.get(_n, 0) + 1
                 return out
             setattr(self.ops, n, wrap)
         return self
@@ -230,6 +239,25 @@ class KernelTimer:
             tot[n] = tot.get(n, 0.0) + min(p[i][1] for p in passes)
             cnt[n] = cnt.get(n, 0) + 1
         return tot, cnt
+
+
+def _operand_bytes(obj, seen=None, depth=0) -> int:
+    """bytes of the distinct large tensors reachable from a call's arguments / results (lists, tuples, dicts, plain objects)"""
+    seen = set() if seen is None else seen
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda and obj.numel() * obj.element_size() >= (1 << 20) and obj.data_ptr() not in seen:
+            seen.add(obj.data_ptr())
+            return obj.numel() * obj.element_size()
+        return 0
+    if depth > 3 or obj is None or isinstance(obj, (int, float, str, bool)):
+        return 0
+    if isinstance(obj, dict):
+        return sum(_operand_bytes(v, seen, depth + 1) for v in obj.values())
+    if isinstance(obj, (list, tuple)):
+        return sum(_operand_bytes(v, seen, depth + 1) for v in obj)
+    if hasattr(obj, "__dict__"):
+        return sum(_operand_bytes(v, seen, depth + 1) for v in vars(obj).values())
+    return 0
 
 
 def _newest_profile(suffix: str) -> str:
@@ -300,7 +328,7 @@ def pmc_mfma_util():
     return out
 
 
-def kernel_rooflines(B, T, H, G, prec, per_step_ms, calls):
+def kernel_rooflines(B, T, H, G, prec, per_step_ms, calls, op_bytes=None):
     """Algorithmic work per launch for the kernels that can dominate."""
     Hg = H // G
     rows = B * T
@@ -337,9 +365,13 @@ def kernel_rooflines(B, T, H, G, prec, per_step_ms, calls):
     for name, bpf in hbm.items():
         if name in per_step_ms:
             avg_ms = per_step_ms[name] / calls[name]
-            ach = bpf * rows / (avg_ms * 1e-3) / 1e9
+            nbytes, src = bpf * rows, "f32 tensors of DESIGN section 4"
+            if op_bytes and op_bytes.get(name):
+                nbytes, src = op_bytes[name], "distinct tensor operands of the calls, as stored (f32 / bf16 / f16)"
+            ach = nbytes / (avg_ms * 1e-3) / 1e9
             out[name] = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4)}
+                         "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                         "algorithmic_bytes_per_launch": int(nbytes), "algorithmic_bytes_source": src}
     return out
 
 
@@ -594,7 +626,7 @@ def config_rows(a, dev, pool):
             for s_ in range(2):
                 e._fwd_bwd(*bp[s_ % 2]); kt.mark_pass()
             per_step, calls = kt.summary()
-        rl = kernel_rooflines(B, T, m.hidden_size, groups, "bf16", per_step, calls)
+        rl = kernel_rooflines(B, T, m.hidden_size, groups, "bf16", per_step, calls, kt.bytes_per_launch())
         dom = max(per_step, key=per_step.get)
         roof = dict(rl.get(dom, {"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None}))
         roof["kernel"] = dom; roof["ms_per_step_all_launches"] = round(per_step[dom], 3)
@@ -849,7 +881,7 @@ def main():
                 eng._fwd_bwd(*pool[s % len(pool)])
                 kt.mark_pass()
             per_step, calls = kt.summary()
-        rl = kernel_rooflines(B, T, model.hidden_size, a.groups, a.prec, per_step, calls)
+        rl = kernel_rooflines(B, T, model.hidden_size, a.groups, a.prec, per_step, calls, kt.bytes_per_launch())
         if (B, a.seconds, a.groups, a.prec) == (64, 4.0, 1, "bf16"):         # the shape the PMC passes were taken at
             pmc = pmc_traffic()
             util = pmc_mfma_util()

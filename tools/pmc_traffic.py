@@ -15,7 +15,7 @@ import sys
 
 FAMILY = [("gru_bwd", "gru_seq_bwd"), ("gru_fwd", "gru_seq_fwd"), ("gru_gate_grads", "gru_gate_grads_bf16"),
           ("gemm_bf16_nt_kernel", "gemm_bf16_nt"), ("gemm_slab_reduce", "gemm_bf16_nt"), ("conv_mfma", "conv"), ("conv_gather", "conv"), ("conv_scatter2", "conv"),
-          ("wgrad_mfma", "conv_wgrad"), ("wgrad_reduce", "conv_wgrad"), ("bn_act_bwd", "bn_act_bwd"), ("bn_act_fwd", "bn_act_fwd"),
+          ("wgrad_mfma", "conv_wgrad"), ("wgrad_rd", "conv_wgrad"), ("wgrad_reduce", "conv_wgrad"), ("bn_act_bwd", "bn_act_bwd"), ("bn_act_fwd", "bn_act_fwd"),
           ("bn_fin_act_fwd", "bn_act_fwd"),      # (r03's table had no key for this one: its 7 launches per step, 1.15 GB, were dropped)
           ("bn_stats", "bn_stats"), ("bn_finalize", "bn_stats"), ("channel_pair_reduce", "bn_stats"), ("ln_bwd", "ln_bwd"), ("ln_fwd", "ln_fwd"), ("transpose_bf16", "transpose_bf16"),
           ("cast_bf16", "cast_bf16"), ("ktile_bf16", "cast_bf16"), ("adam", "adam"), ("stft320", "stft"), ("mask_loss", "mask_loss"),
