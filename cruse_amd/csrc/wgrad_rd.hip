@@ -364,6 +364,7 @@ int cruse_wgrad_rd_try(const float* a, const float* bt, float* partial, size_t w
     // costs (index set-up, the LDS tree, the slab and its reduction) outweigh what more waves hide; deeper unrolling (U x 2) measured equal
     int ns = cruse_opt("wg_grid", 0) > 0 ? cruse_opt("wg_grid", 0) : 256 / TG;
     const size_t slab_bytes = (size_t)TG * mtw * nwp * 3 * 256 * sizeof(float);
+    if (slab_bytes > ws_bytes) return 0;
     if ((size_t)ns * slab_bytes > ws_bytes) ns = (int)(ws_bytes / slab_bytes);
     if ((long long)ns > nframes / 4) ns = (int)(nframes / 4);   // (small problems: <= 16 slabs, i.e. one chunk of the reduction -- a fixed summation order)
     if (ns < 1) ns = 1;
