@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcruse_hip.so")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16 = 0, 1, 2, 3
 PREC_BY_NAME = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "f16": PREC_F16}
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
@@ -95,12 +95,16 @@ SIGNATURES = {
     "cruse_sumsq": ("pqpip", "i"),
     "cruse_conv2d_nchw": ("ppppiiiiiiiiiiiiiiiiiiipiip", "i"),
     "cruse_conv2d_nchw_wgrad": ("pppiiiiiiiiiiiiiiiiiip", "i"),
+    "cruse_conv2d_nchw_wgrad_ex": ("ppppiiiiiiiiiiiiiiiiiip", "i"),
     "cruse_nchw_channel_sum": ("piiipip", "i"),
     "cruse_downsum_w": ("pqiipip", "i"),
     "cruse_upsample_w": ("pqiipip", "i"),
     "cruse_bn_nchw_stats": ("piiipip", "i"),
     "cruse_bn_nchw_fwd": ("ppppppiiiipip", "i"),
     "cruse_bn_nchw_bwd": ("pppppppiiiiipppppip", "i"),
+    "cruse_bn_nchw_bwd_ex": ("pppppppiiiiipipppppip", "i"),
+    "cruse_bn_nchw_stats_ex": ("piiipiip", "i"),
+    "cruse_bn_nchw_fwd_train": ("ppffpppiiiippppppip", "i"),
     "cruse_add_nchw": ("pppqip", "i"),
     "cruse_cast_f16": ("ppqip", "i"),
     "cruse_stft_framed": ("ppiiiiiiiiifppp", "i"),

@@ -391,6 +391,7 @@ template <typename T> struct GWgrad {
     const T* S; const T* Bg; float* dw;
     int N, CA, HS, WS, CB, HB, WB;
     int KH, KW, sh, sw, dh, dw_, pt, pl, groups, up_w;
+    float* db;                             // optional: db[ca] += sum_{n,h,w} S[n,ca,h,w] (the bias gradient of a Conv2d: S = dy)
 };
 template <typename T>
 __global__ __launch_bounds__(256) void gconv_wgrad_kernel(GWgrad<T> a) {
@@ -544,7 +545,13 @@ __global__ __launch_bounds__(1024) void gconv_wgrad_pw_mfma_f16_kernel(GWgrad<f1
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = e <= last ? q[min(e, max(last, 0))] : (f16)0.f;
                 }
-                fb[u][j] = cb < a.CB ? v : zero8;
+                if (a.db != nullptr && cb == a.CB) {           // first padding column: the constant 1 -> its dW column is the bias gradient
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = e <= last ? (f16)1.f : (f16)0.f;
+                    fb[u][j] = v;
+                } else {
+                    fb[u][j] = cb < a.CB ? v : zero8;
+                }
             }
         }
 #pragma unroll
@@ -572,6 +579,7 @@ __global__ __launch_bounds__(1024) void gconv_wgrad_pw_mfma_f16_kernel(GWgrad<f1
 #pragma unroll
         for (int w = 0; w < 16; ++w) v += red[w * (MT * NT * 256) + idx];
         if (ca < a.CA && cb < a.CB && !(dbg & 1)) atomicAdd(&a.dw[(long long)ca * a.CB + cb], v);
+        else if (ca < a.CA && cb == a.CB && a.db != nullptr) atomicAdd(&a.db[ca], v);
     }
 }
 
@@ -904,18 +912,56 @@ __global__ __launch_bounds__(256) void bn_nchw_fwd_f16v_kernel(const f16* x, con
     st8_f16(y + o, HW - i, v);
 }
 
+// The same with the batch statistics FINALISED in the kernel (training): every block forms its channel's mean / rstd from the f64 sums
+// (two loads, one rsqrt), block (0, plane c of clip 0) also publishes them for the backward pass, updates the running statistics and --
+// block (0, 0) -- the batch counter: cruse_bn_finalize + cruse_counters_add + cruse_bn_nchw_fwd were three launches per BatchNorm2d.
+__global__ __launch_bounds__(256) void bn_nchw_fwd_train_f16v_kernel(const f16* x, const double* sums, double inv_count, double unbias, float eps,
+                                                                     float momentum, const float* gamma, const float* beta, const float* slope, int act,
+                                                                     int C, int HW, f16* y, float* mean_o, float* rstd_o, float* rmean, float* rvar,
+                                                                     long long* nbt) {
+    const int plane = blockIdx.y, c = plane % C;
+    const double md = sums[c] * inv_count;
+    double var = sums[C + c] * inv_count - md * md;
+    if (var < 0.0) var = 0.0;
+    const float m = (float)md, rs = (float)(1.0 / sqrt(var + (double)eps));
+    if (blockIdx.x == 0 && plane < C && threadIdx.x == 0) {
+        mean_o[c] = m; rstd_o[c] = rs;
+        if (rmean) {
+            rmean[c] = (float)((1.0 - momentum) * rmean[c] + momentum * md);
+            rvar[c] = (float)((1.0 - momentum) * rvar[c] + momentum * var * unbias);
+        }
+        if (nbt && plane == 0) *nbt += 1;
+    }
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= HW) return;
+    const float ga = gamma[c], be = beta[c];
+    const float sl = act == 2 ? slope[c] : 0.f;
+    const long long o = (long long)plane * HW + i;
+    float v[8];
+    ld8_f16(x + o, HW - i, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float z = (v[e] - m) * rs * ga + be;
+        if (act == 1) z = fmaxf(z, 0.f);
+        else if (act == 2) z = z >= 0.f ? z : sl * z;
+        else if (act == 3) z = 1.f / (1.f + expf(-z));
+        v[e] = z;
+    }
+    st8_f16(y + o, HW - i, v);
+}
+
 __global__ __launch_bounds__(256) void bn_nchw_bwd_reduce_f16v_kernel(const f16* dy, const f16* x, const float* mean, const float* rstd,
                                                                       const float* gamma, const float* beta, const float* slope, int act,
-                                                                      int N, int C, int HW, double* r) {
-    __shared__ double red[3][4];
+                                                                      int N, int C, int HW, double* r, int r4) {
+    __shared__ double red[4][4];
     const int c = blockIdx.x;
     const float m = mean ? mean[c] : 0.f, rs = mean ? rstd[c] : 1.f, ga = mean ? gamma[c] : 1.f, be = mean ? beta[c] : 0.f;
     const float sl = act == 2 ? slope[c] : 0.f;
-    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;
     const int chunk = ((HW + gridDim.z - 1) / gridDim.z + 7) & ~7, i0 = blockIdx.z * chunk, i1 = min(HW, i0 + chunk);
     for (int n = blockIdx.y; n < N; n += gridDim.y) {
         const long long o = ((long long)n * C + c) * HW;
-        float a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        float a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
 #pragma unroll 2
         for (int i = i0 + threadIdx.x * 8; i < i1; i += 2048) {
             float xv[8], dv[8];
@@ -931,25 +977,42 @@ __global__ __launch_bounds__(256) void bn_nchw_bwd_reduce_f16v_kernel(const f16*
                 else if (act == 2) { if (z < 0.f) { a3 += d * z; d *= sl; } }
                 else if (act == 3) { const float sg = 1.f / (1.f + expf(-z)); d *= sg * (1.f - sg); }
                 a1 += d; a2 += d * xh;
+                if (e < valid) a4 += xh;
             }
         }
-        s1 += a1; s2 += a2; s3 += a3;
+        s1 += a1; s2 += a2; s3 += a3; s4 += a4;
     }
-    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2); s3 = wave_sum_d(s3);
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; red[2][threadIdx.x >> 6] = s3; }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2); s3 = wave_sum_d(s3); s4 = wave_sum_d(s4);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; red[2][threadIdx.x >> 6] = s3; red[3][threadIdx.x >> 6] = s4; }
     __syncthreads();
     if (threadIdx.x == 0) {
         atomicAdd(&r[c], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
         atomicAdd(&r[C + c], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
         atomicAdd(&r[2 * C + c], red[2][0] + red[2][1] + red[2][2] + red[2][3]);
+        if (r4) atomicAdd(&r[3 * C + c], red[3][0] + red[3][1] + red[3][2] + red[3][3]);
     }
 }
 
+// pg: block (0, plane c of clip 0) also adds the parameter gradients from the finished sums r (the separate bn_nchw_param_grads launch) and,
+// with dx_sum, the sum over the channel of dx -- the bias gradient of the convolution that feeds this BatchNorm -- in closed form from r
+// (r[3C + c] = sum of xhat, accumulated by the reduce pass), which would otherwise be a channel-sum pass over the dx just stored.
 __global__ __launch_bounds__(256) void bn_nchw_bwd_apply_f16v_kernel(const f16* dy, const f16* x, const float* mean, const float* rstd,
                                                                      const float* gamma, const float* beta, const float* slope, int act,
-                                                                     const double* r, double inv_count, int training, int C, int HW, f16* dx) {
+                                                                     const double* r, double inv_count, int training, int C, int HW, f16* dx,
+                                                                     float* dx_sum, int pg, float* dgamma, float* dbeta, float* dslope) {
     const int plane = blockIdx.y, c = plane % C;
     const int i = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (pg && blockIdx.x == 0 && plane < C && threadIdx.x == 0) {
+        if (dbeta) dbeta[c] += (float)r[c];
+        if (dgamma) dgamma[c] += (float)r[C + c];
+        if (dslope) dslope[c] += (float)r[2 * C + c];
+        if (dx_sum) {
+            // sum over the channel of dx = ga rs (d - k1 - xh k2): the d and k1 terms cancel exactly, what is left is the rounding of the
+            // mean in sum(xh) -- computed from the sums instead of re-reading the dx just stored (eval mode: ga rs sum(d))
+            const double gr = mean ? (double)gamma[c] * (double)rstd[c] : 1.0;
+            dx_sum[c] += (float)((mean && training) ? -gr * (r[C + c] * inv_count) * r[3 * C + c] : gr * r[c]);
+        }
+    }
     if (i >= HW) return;
     const float m = mean ? mean[c] : 0.f, rs = mean ? rstd[c] : 1.f, ga = mean ? gamma[c] : 1.f, be = mean ? beta[c] : 0.f;
     const float sl = act == 2 ? slope[c] : 0.f;
@@ -1104,9 +1167,18 @@ int conv2d_nchw_t(const void* x, const float* w, const float* bias, void* y, int
 
 template <typename T>
 int wgrad_nchw_t(const void* S, const void* Bg, float* dw, int N, int CA, int HS, int WS, int CB, int HB, int WB, int KH, int KW,
-                 int sh, int sw, int dh, int dw_, int pt, int pl, int groups, int up_w, hipStream_t s) {
-    GWgrad<T> a = {(const T*)S, (const T*)Bg, dw, N, CA, HS, WS, CB, HB, WB, KH, KW, sh, sw, dh, dw_, pt, pl, groups, up_w};
+                 int sh, int sw, int dh, int dw_, int pt, int pl, int groups, int up_w, hipStream_t s, float* db = nullptr) {
+    GWgrad<T> a = {(const T*)S, (const T*)Bg, dw, N, CA, HS, WS, CB, HB, WB, KH, KW, sh, sw, dh, dw_, pt, pl, groups, up_w, nullptr};
     const bool fast = !cruse_opt("pw_valu", 0);
+    // db: only the pointwise MFMA kernel delivers it (a spare column of its last column tile carries the constant 1); every other form
+    // runs the channel-sum pass first
+    const bool pw_db = db != nullptr && sizeof(T) == 2 && fast && KH == 1 && KW == 1 && groups == 1 && sh == 1 && sw == 1 && pt == 0 && pl == 0 &&
+                       up_w == 1 && HS == HB && WS == WB && CA <= 32 && CB < 32 && CB % 16 != 0;
+    if (db != nullptr && !pw_db) {
+        const int rc = cruse_nchw_channel_sum(S, N, CA, HS * WS, db, sizeof(T) == 2 ? CRUSE_DT_F16 : CRUSE_DT_F32, s);
+        if (rc) return rc;
+    }
+    a.db = pw_db ? db : nullptr;
     if constexpr (sizeof(T) == 2) {
         if (fast && KH == 1 && KW == 1 && groups == 1 && sh == 1 && sw == 1 && pt == 0 && pl == 0 && up_w == 1 && HS == HB && WS == WB &&
             CA <= 32 && CB <= 32) {
@@ -1169,22 +1241,23 @@ int wgrad_nchw_t(const void* S, const void* Bg, float* dw, int N, int CA, int HS
     return CRUSE_OK;
 }
 
+}  // namespace
+extern "C" int cruse_nchw_channel_sum(const void* x, int N, int C, int HW, float* out, int dtype, void* stream);
+namespace {
 template <typename T>
 int bn_nchw_bwd_t(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                   const float* slope, int act, int training, int N, int C, int HW, double* scratch, void* dx, float* dgamma,
-                  float* dbeta, float* dslope, hipStream_t s) {
+                  float* dbeta, float* dslope, hipStream_t s, float* dx_sum = nullptr) {
     const long long total = (long long)N * C * HW;
     if constexpr (sizeof(T) == 2) {
         if ((long long)N * C < 65536) {                      // (grid.y = planes)
             hipLaunchKernelGGL(bn_nchw_bwd_reduce_f16v_kernel, dim3(C, N < 32 ? N : 32, zchunks(C, N < 32 ? N : 32, HW)), dim3(256), 0, s, (const f16*)dy,
-                               (const f16*)x, mean, rstd, gamma, beta, slope, act, N, C, HW, scratch);
+                               (const f16*)x, mean, rstd, gamma, beta, slope, act, N, C, HW, scratch, dx_sum != nullptr ? 1 : 0);
             CRUSE_LAUNCH_CHECK("bn_nchw_bwd_reduce");
             hipLaunchKernelGGL(bn_nchw_bwd_apply_f16v_kernel, dim3(cdiv(cdiv(HW, 8), 256), N * C), dim3(256), 0, s, (const f16*)dy, (const f16*)x, mean, rstd,
-                               gamma, beta, slope, act, scratch, 1.0 / ((double)N * HW), training, C, HW, (f16*)dx);
+                               gamma, beta, slope, act, scratch, 1.0 / ((double)N * HW), training, C, HW, (f16*)dx, dx_sum, 1,
+                               mean ? dgamma : nullptr, mean ? dbeta : nullptr, act == 2 ? dslope : nullptr);
             CRUSE_LAUNCH_CHECK("bn_nchw_bwd_apply");
-            hipLaunchKernelGGL(bn_nchw_param_grads_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, scratch, C, mean ? dgamma : nullptr,
-                               mean ? dbeta : nullptr, act == 2 ? dslope : nullptr);
-            CRUSE_LAUNCH_CHECK("bn_nchw_param_grads");
             return CRUSE_OK;
         }
     }
@@ -1197,6 +1270,7 @@ int bn_nchw_bwd_t(const void* dy, const void* x, const float* mean, const float*
     hipLaunchKernelGGL(bn_nchw_param_grads_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, scratch, C, mean ? dgamma : nullptr,
                        mean ? dbeta : nullptr, act == 2 ? dslope : nullptr);
     CRUSE_LAUNCH_CHECK("bn_nchw_param_grads");
+    if (dx_sum != nullptr) return cruse_nchw_channel_sum(dx, N, C, HW, dx_sum, sizeof(T) == 2 ? CRUSE_DT_F16 : CRUSE_DT_F32, s);
     return CRUSE_OK;
 }
 }  // namespace
@@ -1232,6 +1306,21 @@ extern "C" int cruse_conv2d_nchw_wgrad(const void* S, const void* Bg, float* dw,
     if (dtype == CRUSE_DT_F16)
         return wgrad_nchw_t<f16>(S, Bg, dw, N, CA, HS, WS, CB, HB, WB, KH, KW, sh, sw, dh, dw_, pt, pl, groups, up_w, ST(stream));
     return wgrad_nchw_t<float>(S, Bg, dw, N, CA, HS, WS, CB, HB, WB, KH, KW, sh, sw, dh, dw_, pt, pl, groups, up_w, ST(stream));
+}
+
+// cruse_conv2d_nchw_wgrad of a Conv2d (S = dy) that also accumulates the bias gradient db[ca] += sum_{n,h,w} dy[n,ca,h,w] -- inside the
+// pointwise MFMA kernel where that form runs (one launch for nn.Conv2d's weight + bias gradients), else by the channel-sum pass
+extern "C" int cruse_conv2d_nchw_wgrad_ex(const void* S, const void* Bg, float* dw, float* db,
+                                          int N, int CA, int HS, int WS, int CB, int HB, int WB,
+                                          int KH, int KW, int sh, int sw, int dh, int dw_, int pt, int pl,
+                                          int groups, int up_w, int dtype, void* stream) {
+    CRUSE_REQUIRE(N > 0 && CA > 0 && CB > 0 && HS > 0 && WS > 0 && HB > 0 && WB > 0 && KH > 0 && KW > 0, CRUSE_E_SHAPE,
+                  "conv2d_nchw_wgrad_ex: bad shape");
+    CRUSE_REQUIRE(CA % groups == 0 && CB % groups == 0 && up_w > 0, CRUSE_E_SHAPE, "conv2d_nchw_wgrad_ex: groups");
+    CRUSE_DT_CHECK("conv2d_nchw_wgrad_ex");
+    if (dtype == CRUSE_DT_F16)
+        return wgrad_nchw_t<f16>(S, Bg, dw, N, CA, HS, WS, CB, HB, WB, KH, KW, sh, sw, dh, dw_, pt, pl, groups, up_w, ST(stream), db);
+    return wgrad_nchw_t<float>(S, Bg, dw, N, CA, HS, WS, CB, HB, WB, KH, KW, sh, sw, dh, dw_, pt, pl, groups, up_w, ST(stream), db);
 }
 
 extern "C" int cruse_nchw_channel_sum(const void* x, int N, int C, int HW, float* out, int dtype, void* stream) {
@@ -1286,6 +1375,19 @@ extern "C" int cruse_bn_nchw_stats(const void* x, int N, int C, int HW, double* 
     return CRUSE_OK;
 }
 
+// cruse_bn_nchw_stats into sums the caller has already cleared (zeroed != 0: no fill launch in front of the pass)
+extern "C" int cruse_bn_nchw_stats_ex(const void* x, int N, int C, int HW, double* sums, int zeroed, int dtype, void* stream) {
+    CRUSE_REQUIRE(N > 0 && C > 0 && HW > 0, CRUSE_E_SHAPE, "bn_nchw_stats_ex: bad shape");
+    CRUSE_DT_CHECK("bn_nchw_stats_ex");
+    if (!zeroed) { int rc = cruse_zero_async(sums, 2 * (size_t)C * sizeof(double), ST(stream), "bn_nchw_stats_ex"); if (rc) return rc; }
+    if (dtype == CRUSE_DT_F16)
+        hipLaunchKernelGGL(bn_nchw_stats_f16v_kernel, dim3(C, N < 32 ? N : 32, zchunks(C, N < 32 ? N : 32, HW)), dim3(256), 0, ST(stream), (const f16*)x, N, C, HW, sums);
+    else
+        hipLaunchKernelGGL(bn_nchw_stats_kernel<float>, dim3(C, N < 32 ? N : 32, zchunks(C, N < 32 ? N : 32, HW)), dim3(256), 0, ST(stream), (const float*)x, N, C, HW, sums);
+    CRUSE_LAUNCH_CHECK("bn_nchw_stats_ex");
+    return CRUSE_OK;
+}
+
 extern "C" int cruse_bn_nchw_fwd(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                                  const float* slope, int act, int N, int C, int HW, void* y, int dtype, void* stream) {
     CRUSE_REQUIRE(N > 0 && C > 0 && HW > 0 && act >= 0 && act <= 3 && (act != 2 || slope), CRUSE_E_SHAPE, "bn_nchw_fwd: bad arguments");
@@ -1314,6 +1416,48 @@ extern "C" int cruse_bn_nchw_bwd(const void* dy, const void* x, const float* mea
     if (dtype == CRUSE_DT_F16)
         return bn_nchw_bwd_t<f16>(dy, x, mean, rstd, gamma, beta, slope, act, training, N, C, HW, scratch, dx, dgamma, dbeta, dslope, ST(stream));
     return bn_nchw_bwd_t<float>(dy, x, mean, rstd, gamma, beta, slope, act, training, N, C, HW, scratch, dx, dgamma, dbeta, dslope, ST(stream));
+}
+
+// cruse_bn_nchw_bwd that ALSO accumulates dx_sum[c] += sum of the stored dx of channel c (nullable): the bias gradient of the convolution in
+// front of the BatchNorm (nn.Conv2d -> nn.BatchNorm2d -> act: mtfaa.py:166-193, cust_conv.py:15-111) without a channel-sum pass over dx
+extern "C" int cruse_bn_nchw_bwd_ex(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                                    const float* beta, const float* slope, int act, int training, int N, int C, int HW,
+                                    double* scratch, int scratch_zeroed, void* dx, float* dgamma, float* dbeta, float* dslope, float* dx_sum,
+                                    int dtype, void* stream) {
+    CRUSE_REQUIRE(N > 0 && C > 0 && HW > 0 && act >= 0 && act <= 3 && (act != 2 || slope), CRUSE_E_SHAPE, "bn_nchw_bwd_ex: bad arguments");
+    CRUSE_DT_CHECK("bn_nchw_bwd_ex");
+    if (!scratch_zeroed) { int rc = cruse_zero_async(scratch, 4 * (size_t)C * sizeof(double), ST(stream), "bn_nchw_bwd_ex"); if (rc) return rc; }
+    if (dtype == CRUSE_DT_F16)
+        return bn_nchw_bwd_t<f16>(dy, x, mean, rstd, gamma, beta, slope, act, training, N, C, HW, scratch, dx, dgamma, dbeta, dslope, ST(stream), dx_sum);
+    return bn_nchw_bwd_t<float>(dy, x, mean, rstd, gamma, beta, slope, act, training, N, C, HW, scratch, dx, dgamma, dbeta, dslope, ST(stream), dx_sum);
+}
+
+extern "C" int cruse_bn_finalize(const double* sums, long long count, int C, float eps, float momentum,
+                                 float* mean, float* rstd, float* running_mean, float* running_var, void* stream);
+extern "C" int cruse_counters_add(long long* const* counters, int n, long long v, void* stream);
+
+// Training-mode BatchNorm2d (+ activation) forward from the batch SUMS of cruse_bn_nchw_stats: mean / rstd are formed in the kernel and written to
+// mean_out / rstd_out for the backward pass, the running statistics (nullable pair) and the batch counter (nullable) are updated as
+// nn.BatchNorm2d does (momentum, unbiased variance) -- one launch for cruse_bn_finalize + cruse_counters_add + cruse_bn_nchw_fwd
+extern "C" int cruse_bn_nchw_fwd_train(const void* x, const double* sums, float eps, float momentum, const float* gamma, const float* beta,
+                                       const float* slope, int act, int N, int C, int HW, void* y, float* mean_out, float* rstd_out,
+                                       float* running_mean, float* running_var, long long* num_batches_tracked, int dtype, void* stream) {
+    CRUSE_REQUIRE(N > 0 && C > 0 && HW > 0 && act >= 0 && act <= 3 && (act != 2 || slope), CRUSE_E_SHAPE, "bn_nchw_fwd_train: bad arguments");
+    CRUSE_REQUIRE(sums && gamma && beta && mean_out && rstd_out && (running_mean == nullptr) == (running_var == nullptr), CRUSE_E_SHAPE,
+                  "bn_nchw_fwd_train: statistics / affine / output pointers");
+    CRUSE_DT_CHECK("bn_nchw_fwd_train");
+    const long long count = (long long)N * HW;
+    if (dtype == CRUSE_DT_F16 && (long long)N * C < 65536) {
+        hipLaunchKernelGGL(bn_nchw_fwd_train_f16v_kernel, dim3(cdiv(cdiv(HW, 8), 256), N * C), dim3(256), 0, ST(stream), (const f16*)x, sums,
+                           1.0 / (double)count, count > 1 ? (double)count / (double)(count - 1) : 1.0, eps, momentum, gamma, beta, slope, act, C, HW,
+                           (f16*)y, mean_out, rstd_out, running_mean, running_var, num_batches_tracked);
+        CRUSE_LAUNCH_CHECK("bn_nchw_fwd_train");
+        return CRUSE_OK;
+    }
+    int rc = cruse_bn_finalize(sums, count, C, eps, momentum, mean_out, rstd_out, running_mean, running_var, stream);
+    if (rc) return rc;
+    if (num_batches_tracked) { long long* one[1] = {num_batches_tracked}; rc = cruse_counters_add(one, 1, 1, stream); if (rc) return rc; }
+    return cruse_bn_nchw_fwd(x, mean_out, rstd_out, gamma, beta, slope, act, N, C, HW, y, dtype, stream);
 }
 
 extern "C" int cruse_add_nchw(const void* a, const void* b, void* out, long long n, int dtype, void* stream) {

@@ -80,19 +80,28 @@ def _zeros_f32(shape, device) -> torch.Tensor:
     Memory note (ADVICE r4): autograd's AccumulateGrad may keep a slice as the parameter's .grad, which keeps its 256 KB chunk alive;
     a step's ~80 small gradients share one or two chunks, so what stays pinned is bounded by a chunk or two per set of live .grad
     tensors -- but torch.save of such a .grad writes the whole chunk: clone() it first."""
+    return _zeros_pool(shape, device, torch.float32)
+
+
+def _zeros_f64(shape, device) -> torch.Tensor:
+    """the same for the f64 accumulators of the BatchNorm passes (batch sums, backward sums): their fill launches were 24 of config 5's step"""
+    return _zeros_pool(shape, device, torch.float64)
+
+
+def _zeros_pool(shape, device, dtype) -> torch.Tensor:
     n = 1
     for d in shape:
         n *= int(d)
     if n > _ZCHUNK // 8 or torch.cuda.is_current_stream_capturing():
-        return torch.zeros(shape, device=device, dtype=torch.float32)
+        return torch.zeros(shape, device=device, dtype=dtype)
     dev = torch.device(device)
-    need = (n + 63) // 64 * 64                 # 256-byte slots
+    need = (n + 63) // 64 * 64                 # 256- / 512-byte slots
     with _ZLOCK:
-        ent = _ZPOOL.get(dev)
+        ent = _ZPOOL.get((dev, dtype))
         if ent is None or ent[1] + need > _ZCHUNK or ent[2] != torch.cuda.current_stream(dev):
             # (a chunk is zeroed on the stream that allocates it: slices are handed out on that stream only)
-            ent = [torch.zeros(_ZCHUNK, device=dev, dtype=torch.float32), 0, torch.cuda.current_stream(dev)]
-            _ZPOOL[dev] = ent
+            ent = [torch.zeros(_ZCHUNK, device=dev, dtype=dtype), 0, torch.cuda.current_stream(dev)]
+            _ZPOOL[(dev, dtype)] = ent
         out = ent[0][ent[1]:ent[1] + n].view(shape)
         ent[1] += need
     return out
@@ -113,11 +122,36 @@ def _conv_raw(x, w, bias, out_hw, KH, KW, stride, dil, pt, pl, groups, up_w, tra
     return y
 
 
-def _wgrad_raw(S, Bg, dw, KH, KW, stride, dil, pt, pl, groups, up_w):
+def _wgrad_raw(S, Bg, dw, KH, KW, stride, dil, pt, pl, groups, up_w, db=None):
+    """db (Conv2d form only: S = dy): the bias gradient accumulated in the same call (cruse_conv2d_nchw_wgrad_ex)"""
     N, CA, HS, WS = S.shape
     _, CB, HB, WB = Bg.shape
+    if db is not None:
+        check(lib.cruse_conv2d_nchw_wgrad_ex(_p(S), _p(Bg), _p(dw), _p(db), N, CA, HS, WS, CB, HB, WB, KH, KW, stride[0], stride[1], dil[0],
+                                             dil[1], pt, pl, groups, up_w, _dt(S), _stream()))
+        return
     check(lib.cruse_conv2d_nchw_wgrad(_p(S), _p(Bg), _p(dw), N, CA, HS, WS, CB, HB, WB, KH, KW, stride[0], stride[1], dil[0],
                                       dil[1], pt, pl, groups, up_w, _dt(S), _stream()))
+
+
+# Bias gradient of a convolution that feeds a BatchNorm: the BatchNorm's backward apply pass (cruse_bn_nchw_bwd_ex) sums the dx it stores per
+# channel -- the convolution's backward finds that sum here instead of re-reading dx (one 17 us pass per Conv2d -> BatchNorm2d pair at the
+# config-5 shape).  Keyed by the gradient tensor's storage address; the entry holds the tensor itself, so the address cannot be reused while
+# the entry lives; a few entries at most (a consumer without a bias gradient never collects its entry).
+_DX_SUMS = {}
+
+
+def _stash_dx_sum(dx, sums):
+    if len(_DX_SUMS) >= 8:
+        _DX_SUMS.clear()
+    _DX_SUMS[dx.data_ptr()] = (dx, sums)
+
+
+def _take_dx_sum(dy):
+    ent = _DX_SUMS.pop(dy.data_ptr(), None)
+    if ent is not None and ent[0].shape == dy.shape and ent[0].dtype == dy.dtype and ent[0]._version == dy._version:
+        return ent[1]
+    return None
 
 
 def _channel_sum(dy, out):
@@ -159,14 +193,18 @@ class _ConvFn(torch.autograd.Function):
                     dx = dxu
             else:
                 dx = _conv_raw(dy, w, None, (Hin, Win), KH, KW, stride, dil, pt, pl, groups, 1, False, Cin)
+        pre = _take_dx_sum(dy)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if want_db:
+            db = pre if pre is not None else _zeros_f32((dy.shape[1],), dy.device)
+        db_in_wgrad = want_db and pre is None and ctx.needs_input_grad[1] and not transposed
         if ctx.needs_input_grad[1]:
             dw = _zeros_f32(tuple(w.shape), w.device)
             if not transposed:
-                _wgrad_raw(dy, x, dw, KH, KW, stride, dil, pt, pl, groups, up_w)
+                _wgrad_raw(dy, x, dw, KH, KW, stride, dil, pt, pl, groups, up_w, db=db if db_in_wgrad else None)
             else:
                 _wgrad_raw(x, dy, dw, KH, KW, stride, dil, pt, pl, groups, 1)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _zeros_f32((dy.shape[1],), dy.device)
+        if want_db and pre is None and not db_in_wgrad:
             _channel_sum(dy, db)
         return dx, dw, db, None
 
@@ -230,6 +268,45 @@ class _BnActFn(torch.autograd.Function):
         return dx, dg, db, ds, None, None, None, None
 
 
+class _BnTrainActFn(torch.autograd.Function):
+    """Training-mode BatchNorm2d (+ act) from the batch sums: statistics finalised inside the forward kernel (running statistics and batch
+    counter updated there), parameter gradients and -- want_dx_sum -- the preceding convolution's bias gradient inside the backward apply
+    pass (cruse_bn_nchw_fwd_train / cruse_bn_nchw_bwd_ex)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, slope, sums, eps, momentum, rmean, rvar, nbt, act, want_dx_sum):
+        N, C = x.shape[:2]
+        HW = x[0, 0].numel()
+        y = torch.empty_like(x)
+        mean = torch.empty(C, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(C, device=x.device, dtype=torch.float32)
+        check(lib.cruse_bn_nchw_fwd_train(_p(x), _p(sums), float(eps), float(momentum), _p(gamma), _p(beta), _p(slope), act, N, C, HW, _p(y),
+                                          _p(mean), _p(rstd), _p(rmean), _p(rvar), _p(nbt), _dt(x), _stream()))
+        ctx.save_for_backward(x, gamma, beta, slope, mean, rstd)
+        ctx.act, ctx.want_dx_sum = act, bool(want_dx_sum)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, slope, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype != x.dtype:
+            dy = _CastFn.apply(dy, x.dtype == torch.float16)
+        N, C = x.shape[:2]
+        HW = x[0, 0].numel()
+        dx = torch.empty_like(x)
+        scratch = _zeros_f64((4 * C,), x.device)
+        dg = _zeros_f32((C,), x.device)
+        db = _zeros_f32((C,), x.device)
+        ds = _zeros_f32((C,), x.device) if slope is not None else None
+        dxs = _zeros_f32((C,), x.device) if ctx.want_dx_sum else None
+        check(lib.cruse_bn_nchw_bwd_ex(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(slope), ctx.act, 1, N, C, HW, _p(scratch), 1,
+                                       _p(dx), _p(dg), _p(db), _p(ds), _p(dxs), _dt(x), _stream()))
+        if dxs is not None:
+            _stash_dx_sum(dx, dxs)
+        return dx, dg, db, ds, None, None, None, None, None, None, None, None
+
+
 def _act_code(m) -> Tuple[int, Optional[torch.Tensor]]:
     if m is None:
         return 0, None
@@ -242,8 +319,10 @@ def _act_code(m) -> Tuple[int, Optional[torch.Tensor]]:
     raise RuntimeError(f"HipSequential: activation {type(m).__name__} has no HIP kernel (ReLU, PReLU, Sigmoid)")
 
 
-def batchnorm_act(x, bn: Optional[nn.BatchNorm2d], act_module=None):
-    """bn(x) then act, fused; bn None: activation only.  Training mode updates the running statistics like torch."""
+def batchnorm_act(x, bn: Optional[nn.BatchNorm2d], act_module=None, conv_bias_in_front: bool = False):
+    """bn(x) then act, fused; bn None: activation only.  Training mode updates the running statistics like torch.
+    conv_bias_in_front: x is the output of a convolution with a bias -- its bias gradient (the channel sums of this BatchNorm's input
+    gradient) is then delivered by the backward pass of this call (see _DX_SUMS)."""
     act, slope = _act_code(act_module)
     C = x.shape[1]
     if act == 2 and slope.numel() != C:
@@ -257,10 +336,15 @@ def batchnorm_act(x, bn: Optional[nn.BatchNorm2d], act_module=None):
     N = xc.shape[0]
     HW = xc[0, 0].numel()
     if training:
-        sums = torch.empty(2 * C, device=x.device, dtype=torch.float64)
-        check(lib.cruse_bn_nchw_stats(_p(xc), N, C, HW, _p(sums), _dt(xc), _stream()))
+        sums = _zeros_f64((2 * C,), x.device)
+        check(lib.cruse_bn_nchw_stats_ex(_p(xc), N, C, HW, _p(sums), 1, _dt(xc), _stream()))
         upd = bn.training and bn.running_mean is not None
         mom = bn.momentum if bn.momentum is not None else 0.1
+        if bn.weight is not None and bn.bias is not None and (bn.momentum is not None or not upd):
+            # (momentum None = cumulative average: the separate finalize below)
+            return _BnTrainActFn.apply(xc, bn.weight, bn.bias, slope, sums, bn.eps, mom, bn.running_mean if upd else None,
+                                       bn.running_var if upd else None, bn.num_batches_tracked if upd else None, act,
+                                       conv_bias_in_front)
         mean, rstd = ops.bn_finalize(sums, N * HW, C, bn.eps, mom, bn.running_mean if upd else None,
                                      bn.running_var if upd else None)
         if upd and bn.num_batches_tracked is not None:
@@ -324,8 +408,12 @@ def run_sequential(mods: Sequence[nn.Module], x: torch.Tensor) -> torch.Tensor:
     i = 0
     pad = (0, 0, 0, 0)
     up = 1
+    biased_conv = False                           # the previous module was a Conv2d with a trainable bias (and nothing came in between)
     while i < len(mods):
         m = mods[i]
+        was_conv, biased_conv = biased_conv, False
+        if isinstance(m, nn.BatchNorm2d):
+            biased_conv = was_conv
         if isinstance(m, nn.ConstantPad2d):
             t, b, l, r = _pad4(m)
             pad = (pad[0] + t, pad[1] + b, pad[2] + l, pad[3] + r)
@@ -343,6 +431,8 @@ def run_sequential(mods: Sequence[nn.Module], x: torch.Tensor) -> torch.Tensor:
                        m.groups, up)
             pad, up = (0, 0, 0, 0), 1
             i += 1
+            biased_conv = m.bias is not None and m.bias.requires_grad
+            continue
         elif isinstance(m, nn.ConvTranspose2d):
             if up != 1 or pad[1] or pad[2] or pad[3]:
                 raise RuntimeError("HipSequential: only a top zero pad folds into ConvTranspose2d")
@@ -353,10 +443,10 @@ def run_sequential(mods: Sequence[nn.Module], x: torch.Tensor) -> torch.Tensor:
         elif isinstance(m, nn.BatchNorm2d):
             nxt = mods[i + 1] if i + 1 < len(mods) else None
             if isinstance(nxt, (nn.ReLU, nn.PReLU, nn.Sigmoid)):
-                x = batchnorm_act(x, m, nxt)
+                x = batchnorm_act(x, m, nxt, conv_bias_in_front=biased_conv)
                 i += 2
             else:
-                x = batchnorm_act(x, m, None)
+                x = batchnorm_act(x, m, None, conv_bias_in_front=biased_conv)
                 i += 1
         elif isinstance(m, (nn.ReLU, nn.PReLU, nn.Sigmoid)):
             x = batchnorm_act(x, None, m)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CRUSE_ABI_VERSION 10
+#define CRUSE_ABI_VERSION 11
 
 enum {
     CRUSE_OK = 0,
@@ -523,6 +523,12 @@ int cruse_conv2d_nchw_wgrad(const void* S, const void* Bg, float* dw,
                             int N, int CA, int HS, int WS, int CB, int HB, int WB,
                             int KH, int KW, int sh, int sw, int dh, int dw_, int pt, int pl,
                             int groups, int up_w, int dtype, void* stream);
+/* (round 5, ABI 11) the same for nn.Conv2d (S = dy) with the bias gradient db[ca] += sum_{n,h,w} dy[n,ca,h,w] in the same call: inside the
+ * pointwise MFMA kernel (the constant 1 rides a spare column of the last column tile), else by cruse_nchw_channel_sum.  db nullable. */
+int cruse_conv2d_nchw_wgrad_ex(const void* S, const void* Bg, float* dw, float* db,
+                               int N, int CA, int HS, int WS, int CB, int HB, int WB,
+                               int KH, int KW, int sh, int sw, int dh, int dw_, int pt, int pl,
+                               int groups, int up_w, int dtype, void* stream);
 /* out[c] += sum_{n,hw} x[n,c,hw] (conv bias gradient) */
 int cruse_nchw_channel_sum(const void* x, int N, int C, int HW, float* out, int dtype, void* stream);
 /* gradient of the nearest FreqUpsample: dx[..,w] = sum_{j<up} dxu[.., w*up + j] */
@@ -538,6 +544,26 @@ int cruse_bn_nchw_fwd(const void* x, const float* mean, const float* rstd, const
 int cruse_bn_nchw_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                       const float* beta, const float* slope, int act, int training, int N, int C, int HW,
                       double* scratch, void* dx, float* dgamma, float* dbeta, float* dslope, int dtype, void* stream);
+
+/* Round 5 (ABI 11): the same two passes with their small companions folded in.
+ * cruse_bn_nchw_fwd_train: training-mode nn.BatchNorm2d (+ act) from the batch sums of cruse_bn_nchw_stats -- mean / rstd are formed inside the
+ *   kernel and published to mean_out / rstd_out, running_mean / running_var (nullable pair: momentum, unbiased variance) and
+ *   num_batches_tracked (nullable, += 1) are updated: cruse_bn_finalize + cruse_counters_add + cruse_bn_nchw_fwd in one launch
+ *   (nn.Conv2d -> nn.BatchNorm2d -> nn.PReLU of TFCM_Block, mtfaa.py:166-193; Conv2dNormAct, cust_conv.py:15-111).
+ * cruse_bn_nchw_bwd_ex: cruse_bn_nchw_bwd (scratch: 4*C doubles) whose apply pass also adds the parameter gradients and, when dx_sum != NULL,
+ *   dx_sum[c] += sum over the channel of dx -- the bias gradient of the convolution in front of the BatchNorm -- in closed form from the
+ *   reduce pass's sums (training: -gamma rstd mean(d xhat) sum(xhat), the rounding of the batch mean; eval: gamma rstd sum(d)) instead of a
+ *   channel-sum pass over dx. */
+int cruse_bn_nchw_fwd_train(const void* x, const double* sums, float eps, float momentum, const float* gamma, const float* beta,
+                            const float* slope, int act, int N, int C, int HW, void* y, float* mean_out, float* rstd_out,
+                            float* running_mean, float* running_var, long long* num_batches_tracked, int dtype, void* stream);
+int cruse_bn_nchw_bwd_ex(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                         const float* beta, const float* slope, int act, int training, int N, int C, int HW,
+                         double* scratch, int scratch_zeroed, void* dx, float* dgamma, float* dbeta, float* dslope, float* dx_sum, int dtype,
+                         void* stream);
+/* cruse_bn_nchw_stats into sums the caller cleared itself (zeroed != 0; like scratch_zeroed above: one fill launch per pool chunk of
+ * accumulators instead of one per call) */
+int cruse_bn_nchw_stats_ex(const void* x, int N, int C, int HW, double* sums, int zeroed, int dtype, void* stream);
 
 /* out = a + b on n elements of storage type dtype (TFCM_Block residual, mtfaa.py:191; GroupGRU add_outputs, cust_conv.py:411-412) */
 int cruse_add_nchw(const void* a, const void* b, void* out, long long n, int dtype, void* stream);
