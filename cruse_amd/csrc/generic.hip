@@ -225,6 +225,138 @@ __global__ __launch_bounds__(256) void gconv_pointwise_mfma_f16_kernel(GConv<f16
     }
 }
 
+// The same product with the operand TRANSPOSED THROUGH LDS (round 5).  The gather above issues eight 2-byte loads per fragment and eight
+// 2-byte stores per tile and lane -- 16 memory instructions of 128 bytes per 16 positions: 30 us for 50 MB at the config-5 shape.  Here a
+// wave moves 64 positions of all channels per step with 16-byte accesses: rows [ci][64 positions] are copied into a wave-private LDS image,
+// the MFMA operand of a 16-position tile (lane = position, eight consecutive ci) is two TRANSPOSING reads (ds_read_b64_tr_b16: a 16-lane
+// group reads a [4 ci][16 positions] block, lane c gets the four ci of position c); the product runs with the roles swapped
+// (D^T[p][co] = x^T W^T: a lane then owns FOUR CONSECUTIVE positions of one output channel = one 8-byte LDS write), and the output rows
+// [co][64 positions] leave through 16-byte stores.  No block barrier: the four waves of a block share nothing.
+template <int MT, int KS>
+__global__ __launch_bounds__(256) void gconv_pointwise_tr_f16_kernel(GConv<f16> a) {
+    constexpr int ROWB = 144;                                 // bytes per LDS row: 64 positions + 16 (rows 4 apart land on different banks)
+    constexpr int KR = KS * 32, MR = MT * 16;
+    typedef __attribute__((ext_vector_type(4))) short s16x4_;
+    typedef __attribute__((address_space(3))) s16x4_ lds_s16x4;
+    extern __shared__ __align__(16) unsigned char dsm_raw[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int m = lane & 15, kg = lane >> 4;
+    unsigned char* in_img = dsm_raw + (size_t)wv * (KR + MR) * ROWB;
+    unsigned char* out_img = in_img + KR * ROWB;
+    const long long hw = (long long)a.Hin * a.Win;
+    const int nch = (int)((hw + 63) >> 6);
+    const long long total = (long long)a.B * nch;
+    // resident weight fragments, now the B operand: B[mt][ks][e] = W[co = mt*16 + m][ci = ks*32 + kg*8 + e]
+    f16x8 wf[MT][KS];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int co = mt * 16 + m, ci = ks * 32 + kg * 8 + e;
+                float w = 0.f;
+                if (co < a.Cout && ci < a.Cin) w = a.transposed ? a.w[(long long)ci * a.Cout + co] : a.w[(long long)co * a.Cin + ci];
+                wf[mt][ks][e] = (f16)w;
+            }
+    float bs[MT], sl[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int co = mt * 16 + m;
+        bs[mt] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+        sl[mt] = a.act == 2 ? a.slope[min(co, a.Cout - 1)] : 0.f;
+    }
+    const int rr = lane >> 3, ck = lane & 7;                   // staging: row rr (+ 8 per pass), 16-byte chunk ck of the 64 positions
+    const int tr_r = m >> 2, tr_s = m & 3;                     // transposing read: this lane addresses row tr_r, positions 4 tr_s .. + 4 of the block
+    // the rows of a chunk, loaded one chunk AHEAD (a wave walks several chunks: the next one's loads fly under this one's LDS / MFMA / store phases)
+    f16x8 pre[KR / 8];
+    auto fetch = [&](long long ch) {
+        const int b = (int)(ch / nch);
+        const long long pos = (ch - (long long)b * nch) * 64 + ck * 8;
+        const int valid = (int)min<long long>(max<long long>(hw - pos, 0), 8);
+        const f16* xb = a.x + (long long)b * a.Cin * hw + pos;
+#pragma unroll
+        for (int it = 0; it < KR / 8; ++it) {
+            const int ci = it * 8 + rr;
+            f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (ci < a.Cin && valid > 0) {
+                const f16* q = xb + (long long)ci * hw;
+                if (valid == 8) __builtin_memcpy(&v, q, 16);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = e < valid ? q[e] : (f16)0.f;
+                }
+            }
+            pre[it] = v;
+        }
+    };
+    const long long ch0 = (long long)blockIdx.x * 4 + wv, chs = (long long)gridDim.x * 4;
+    if (ch0 < total) fetch(ch0);
+    for (long long ch = ch0; ch < total; ch += chs) {
+        const int b = (int)(ch / nch);
+        const long long p0 = (ch - (long long)b * nch) * 64;
+        const long long pos = p0 + ck * 8;
+        const int valid = (int)min<long long>(max<long long>(hw - pos, 0), 8);
+        // ---- rows [ci][64 positions] -> LDS
+#pragma unroll
+        for (int it = 0; it < KR / 8; ++it) *reinterpret_cast<f16x8*>(in_img + (it * 8 + rr) * ROWB + ck * 16) = pre[it];
+        if (ch + chs < total) fetch(ch + chs);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- four tiles of 16 positions
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f16x8 fa[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const unsigned char* bp = in_img + (ks * 32 + kg * 8 + tr_r) * ROWB + (q * 16 + 4 * tr_s) * 2;
+                const s16x4_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)bp);
+                const s16x4_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(bp + 4 * ROWB));
+                typedef __attribute__((ext_vector_type(8))) short s16x8_;
+                const s16x8_ both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                fa[ks] = __builtin_bit_cast(f16x8, both);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x4 acc = {bs[mt], bs[mt], bs[mt], bs[mt]};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ks], wf[mt][ks], acc, 0, 0, 0);
+                typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_;
+                f16x4_ o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = acc[j];                           // D^T[position kg*4 + j][co = mt*16 + m]
+                    v = a.act == 1 ? fmaxf(v, 0.f) : (a.act == 2 ? (v >= 0.f ? v : sl[mt] * v) : v);
+                    o[j] = (f16)v;
+                }
+                *reinterpret_cast<f16x4_*>(out_img + (mt * 16 + m) * ROWB + (q * 16 + kg * 4) * 2) = o;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- rows [co][64 positions] -> global
+        f16* yb = a.y + (long long)b * a.Cout * hw + pos;
+#pragma unroll
+        for (int it = 0; it < MR / 8; ++it) {
+            const int co = it * 8 + rr;
+            if (co < a.Cout && valid > 0) {
+                const f16x8 v = *reinterpret_cast<const f16x8*>(out_img + co * ROWB + ck * 16);
+                f16* q = yb + (long long)co * hw;
+                if (valid == 8) __builtin_memcpy(q, &v, 16);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (e < valid) q[e] = v[e];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // DEPTHWISE convolution (groups == Cin == Cout, stride 1), either form: TFCM_Block's dilated causal 3x3 (mtfaa.py:174-176) and
 // its data gradient, the depthwise halves of the separable cust_conv blocks.  The general kernel above spends its time on
 // per-element 64-bit index arithmetic and branches (0.3 TB/s on [8,24,161,401]); here a block is one output row chunk of one
@@ -1114,7 +1246,22 @@ int conv2d_nchw_t(const void* x, const float* w, const float* bias, void* y, int
     if constexpr (sizeof(T) == 2) {
         // f16 storage: the pointwise convolutions run on the matrix cores (weights resident as A fragments)
         const int MT = cdiv(Cout, 16), KS = cdiv(Cin, 32);
-        if (pointwise && MT <= 4 && KS <= 4 && !cruse_opt("pw_valu", 0)) {
+        if (pointwise && MT <= 2 && KS <= 2 && !accumulate && !cruse_opt("pw_valu", 0)) {        // (pw_valu = 2: the gather kernel below)
+            // operand transposed through LDS (gconv_pointwise_tr_f16_kernel): 16-byte accesses on both sides
+            const long long nchunk = (long long)B * cdivl((long long)Hin * Win, 64);
+            const int cap = 768;                                                             // (blocks; measured 256 .. 2048 at the config-5 shape: 26.9 / 19.0 / 17.9 / 19.2 / 21.3 / 23.3 us)
+            const int nb = (int)(cdivl(nchunk, 4) > cap ? cap : cdivl(nchunk, 4));
+            const int mtc = MT <= 1 ? 1 : 2, ksc = KS <= 1 ? 1 : 2;
+            const size_t lds = (size_t)4 * (ksc * 32 + mtc * 16) * 144;
+#define PWT_CASE(mt, ks) do { int rc = cruse_ensure_dyn_lds((const void*)gconv_pointwise_tr_f16_kernel<mt, ks>, lds, "conv2d_nchw pointwise"); \
+                if (rc) return rc; \
+                hipLaunchKernelGGL((gconv_pointwise_tr_f16_kernel<mt, ks>), dim3(nb), dim3(256), lds, s, a); } while (0)
+            if (mtc == 1 && ksc == 1) PWT_CASE(1, 1); else if (mtc == 1) PWT_CASE(1, 2); else if (ksc == 1) PWT_CASE(2, 1); else PWT_CASE(2, 2);
+#undef PWT_CASE
+            CRUSE_LAUNCH_CHECK("conv2d_nchw pointwise mfma f16 (LDS-transposed)");
+            return CRUSE_OK;
+        }
+        if (pointwise && MT <= 4 && KS <= 4 && cruse_opt("pw_valu", 0) != 1) {
             const long long ntile = (long long)B * cdivl((long long)Hin * Win, 16);
             const int nb = (int)(cdivl(ntile, 16) > 8192 ? 8192 : cdivl(ntile, 16));
 #define PW_CASE(mt, ks) hipLaunchKernelGGL((gconv_pointwise_mfma_f16_kernel<mt, ks>), dim3(nb), dim3(256), 0, s, a)
@@ -1137,7 +1284,7 @@ int conv2d_nchw_t(const void* x, const float* w, const float* bias, void* y, int
         return CRUSE_OK;
     }
     if (groups == Cin && Cin == Cout && up_w == 1 && sh == 1 && sw == 1 && KH * KW <= 9 && (long long)B * Cout < 65536 &&
-        (long long)Hin * Win < (1ll << 30) && (long long)Hout * Wout < (1ll << 30) && !cruse_opt("pw_valu", 0)) {
+        (long long)Hin * Win < (1ll << 30) && (long long)Hout * Wout < (1ll << 30) && cruse_opt("pw_valu", 0) != 1) {
         TapTab tt = {};
         tt.n = KH * KW;
         for (int kh = 0; kh < KH; ++kh)
@@ -1169,7 +1316,7 @@ template <typename T>
 int wgrad_nchw_t(const void* S, const void* Bg, float* dw, int N, int CA, int HS, int WS, int CB, int HB, int WB, int KH, int KW,
                  int sh, int sw, int dh, int dw_, int pt, int pl, int groups, int up_w, hipStream_t s, float* db = nullptr) {
     GWgrad<T> a = {(const T*)S, (const T*)Bg, dw, N, CA, HS, WS, CB, HB, WB, KH, KW, sh, sw, dh, dw_, pt, pl, groups, up_w, nullptr};
-    const bool fast = !cruse_opt("pw_valu", 0);
+    const bool fast = cruse_opt("pw_valu", 0) != 1;
     // db: only the pointwise MFMA kernel delivers it (a spare column of its last column tile carries the constant 1); every other form
     // runs the channel-sum pass first
     const bool pw_db = db != nullptr && sizeof(T) == 2 && fast && KH == 1 && KW == 1 && groups == 1 && sh == 1 && sw == 1 && pt == 0 && pl == 0 &&
