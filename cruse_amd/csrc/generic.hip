@@ -23,6 +23,9 @@ template <typename T> struct GConv {
     int KH, KW, sh, sw, dh, dw, pt, pl;
     int groups, up_w, transposed, act, accumulate;
     const float* slope;
+    // optional (f16 MFMA-pointwise / LDS-depthwise kernels): the BatchNorm batch sums of the STORED outputs, bn_sums[rep][2 Cout] f64 with
+    // rep = block % bn_nrep (sum, then sum of squares) -- what cruse_bn_nchw_stats would read back from y
+    double* bn_sums; int bn_nrep;
 };
 
 // transposed == 0 (nn.Conv2d, weight [Cout][Cin/g][KH][KW]; also the data gradient of a ConvTranspose2d):
@@ -290,6 +293,9 @@ __global__ __launch_bounds__(256) void gconv_pointwise_tr_f16_kernel(GConv<f16> 
             pre[it] = v;
         }
     };
+    float st1[MR / 8], st2[MR / 8];                            // BatchNorm sums of this lane's output rows (co = it * 8 + rr)
+#pragma unroll
+    for (int it = 0; it < MR / 8; ++it) { st1[it] = 0.f; st2[it] = 0.f; }
     const long long ch0 = (long long)blockIdx.x * 4 + wv, chs = (long long)gridDim.x * 4;
     if (ch0 < total) fetch(ch0);
     for (long long ch = ch0; ch < total; ch += chs) {
@@ -343,6 +349,11 @@ __global__ __launch_bounds__(256) void gconv_pointwise_tr_f16_kernel(GConv<f16> 
             const int co = it * 8 + rr;
             if (co < a.Cout && valid > 0) {
                 const f16x8 v = *reinterpret_cast<const f16x8*>(out_img + co * ROWB + ck * 16);
+                if (a.bn_sums != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (e < valid) { const float u = (float)v[e]; st1[it] += u; st2[it] += u * u; }
+                }
                 f16* q = yb + (long long)co * hw;
                 if (valid == 8) __builtin_memcpy(q, &v, 16);
                 else {
@@ -354,6 +365,24 @@ __global__ __launch_bounds__(256) void gconv_pointwise_tr_f16_kernel(GConv<f16> 
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    }
+    if (a.bn_sums != nullptr) {                                // 8 lanes share a row; 4 waves share the block: one f64 atomic per channel, sum and block
+        __shared__ float bred[4][2][MR];
+#pragma unroll
+        for (int it = 0; it < MR / 8; ++it) {
+            float u = st1[it], u2 = st2[it];
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) { u += __shfl_xor(u, o, 64); u2 += __shfl_xor(u2, o, 64); }
+            if (ck == 0) { bred[wv][0][it * 8 + rr] = u; bred[wv][1][it * 8 + rr] = u2; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * MR) {
+            const int which = threadIdx.x / MR, co = threadIdx.x - which * MR;
+            if (co < a.Cout) {
+                const double t = (double)bred[0][which][co] + (double)bred[1][which][co] + (double)bred[2][which][co] + (double)bred[3][which][co];
+                atomicAdd(a.bn_sums + (size_t)(blockIdx.x % a.bn_nrep) * 2 * a.Cout + which * a.Cout + co, t);
+            }
+        }
     }
 }
 
@@ -485,6 +514,7 @@ __global__ __launch_bounds__(256) void gconv_depthwise_f16_kernel(GConv<f16> a, 
     const float bias = a.bias ? a.bias[c] : 0.f;
     const float slope = a.act == 2 ? a.slope[c] : 0.f;
     f16* yp = a.y + ((long long)plane * a.Hout + r0) * a.Wout;
+    float bn1 = 0.f, bn2 = 0.f;                                        // BatchNorm sums of the stored outputs (a.bn_sums)
     __syncthreads();
     for (int q = threadIdx.x; q < nr * g.gpr; q += 256) {
         const int hr = q / g.gpr, wo = (q - hr * g.gpr) * 8;
@@ -513,6 +543,21 @@ __global__ __launch_bounds__(256) void gconv_depthwise_f16_kernel(GConv<f16> a, 
             else if (a.act == 2) acc[e] = acc[e] >= 0.f ? acc[e] : slope * acc[e];
         }
         st8_f16(dst, valid, acc);
+        if (a.bn_sums != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (e < valid) { const float u = (float)(f16)acc[e]; bn1 += u; bn2 += u * u; }
+        }
+    }
+    if (a.bn_sums != nullptr) {                                        // one (image, channel) band per block: two f64 atomics
+        __shared__ float bred[2][4];
+        bn1 = wave_sum(bn1); bn2 = wave_sum(bn2);
+        if ((threadIdx.x & 63) == 0) { bred[0][threadIdx.x >> 6] = bn1; bred[1][threadIdx.x >> 6] = bn2; }
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            const double t = (double)bred[threadIdx.x][0] + (double)bred[threadIdx.x][1] + (double)bred[threadIdx.x][2] + (double)bred[threadIdx.x][3];
+            atomicAdd(a.bn_sums + (size_t)((blockIdx.x + blockIdx.y) % a.bn_nrep) * 2 * a.Cout + threadIdx.x * a.Cout + c, t);
+        }
     }
 }
 
@@ -1047,13 +1092,15 @@ __global__ __launch_bounds__(256) void bn_nchw_fwd_f16v_kernel(const f16* x, con
 // The same with the batch statistics FINALISED in the kernel (training): every block forms its channel's mean / rstd from the f64 sums
 // (two loads, one rsqrt), block (0, plane c of clip 0) also publishes them for the backward pass, updates the running statistics and --
 // block (0, 0) -- the batch counter: cruse_bn_finalize + cruse_counters_add + cruse_bn_nchw_fwd were three launches per BatchNorm2d.
-__global__ __launch_bounds__(256) void bn_nchw_fwd_train_f16v_kernel(const f16* x, const double* sums, double inv_count, double unbias, float eps,
+__global__ __launch_bounds__(256) void bn_nchw_fwd_train_f16v_kernel(const f16* x, const double* sums, int nrep, double inv_count, double unbias, float eps,
                                                                      float momentum, const float* gamma, const float* beta, const float* slope, int act,
                                                                      int C, int HW, f16* y, float* mean_o, float* rstd_o, float* rmean, float* rvar,
                                                                      long long* nbt) {
     const int plane = blockIdx.y, c = plane % C;
-    const double md = sums[c] * inv_count;
-    double var = sums[C + c] * inv_count - md * md;
+    double t1 = 0.0, t2 = 0.0;
+    for (int r = 0; r < nrep; ++r) { t1 += sums[(size_t)r * 2 * C + c]; t2 += sums[(size_t)r * 2 * C + C + c]; }
+    const double md = t1 * inv_count;
+    double var = t2 * inv_count - md * md;
     if (var < 0.0) var = 0.0;
     const float m = (float)md, rs = (float)(1.0 / sqrt(var + (double)eps));
     if (blockIdx.x == 0 && plane < C && threadIdx.x == 0) {
@@ -1238,9 +1285,11 @@ namespace {
 template <typename T>
 int conv2d_nchw_t(const void* x, const float* w, const float* bias, void* y, int B, int Cin, int Hin, int Win, int Cout, int Hout,
                   int Wout, int KH, int KW, int sh, int sw, int dh, int dw, int pt, int pl, int groups, int up_w, int transposed,
-                  int act, const float* slope, int accumulate, hipStream_t s) {
+                  int act, const float* slope, int accumulate, hipStream_t s, double* bn_sums = nullptr, int bn_nrep = 1,
+                  bool* bn_done = nullptr) {
     GConv<T> a = {(const T*)x, w, bias, (T*)y, B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, sh, sw, dh, dw, pt, pl, groups, up_w,
-                  transposed, act, accumulate, slope};
+                  transposed, act, accumulate, slope, nullptr, 1};
+    if (bn_done) *bn_done = false;
     const bool pointwise = KH == 1 && KW == 1 && sh == 1 && sw == 1 && pt == 0 && pl == 0 && groups == 1 && up_w == 1 &&
                            Hout == Hin && Wout == Win;
     if constexpr (sizeof(T) == 2) {
@@ -1253,6 +1302,7 @@ int conv2d_nchw_t(const void* x, const float* w, const float* bias, void* y, int
             const int nb = (int)(cdivl(nchunk, 4) > cap ? cap : cdivl(nchunk, 4));
             const int mtc = MT <= 1 ? 1 : 2, ksc = KS <= 1 ? 1 : 2;
             const size_t lds = (size_t)4 * (ksc * 32 + mtc * 16) * 144;
+            if (bn_sums) { a.bn_sums = bn_sums; a.bn_nrep = bn_nrep; *bn_done = true; }
 #define PWT_CASE(mt, ks) do { int rc = cruse_ensure_dyn_lds((const void*)gconv_pointwise_tr_f16_kernel<mt, ks>, lds, "conv2d_nchw pointwise"); \
                 if (rc) return rc; \
                 hipLaunchKernelGGL((gconv_pointwise_tr_f16_kernel<mt, ks>), dim3(nb), dim3(256), lds, s, a); } while (0)
@@ -1298,6 +1348,7 @@ int conv2d_nchw_t(const void* x, const float* w, const float* bias, void* y, int
             if (!cruse_opt("dw_nolds", 0) && dw_geometry(tt, Hout, Win, Wout, B * Cout, &g, &lds)) {
                 int rc = cruse_ensure_dyn_lds((const void*)gconv_depthwise_f16_kernel, lds, "conv2d_nchw depthwise");
                 if (rc) return rc;
+                if (bn_sums) { a.bn_sums = bn_sums; a.bn_nrep = bn_nrep; *bn_done = true; }
                 hipLaunchKernelGGL(gconv_depthwise_f16_kernel, dim3(cdiv(Hout, g.RB), B * Cout), dim3(256), lds, s, a, tt, g);
                 CRUSE_LAUNCH_CHECK("conv2d_nchw depthwise (f16, LDS image)");
                 return CRUSE_OK;
@@ -1440,6 +1491,35 @@ extern "C" int cruse_conv2d_nchw(const void* x, const float* w, const float* bia
                                   transposed, act, slope, accumulate, ST(stream));
     return conv2d_nchw_t<float>(x, w, bias, y, B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, sh, sw, dh, dw, pt, pl, groups, up_w,
                                 transposed, act, slope, accumulate, ST(stream));
+}
+
+extern "C" int cruse_bn_nchw_stats_ex(const void* x, int N, int C, int HW, double* sums, int zeroed, int dtype, void* stream);
+
+// cruse_conv2d_nchw (no accumulation) that ALSO delivers the BatchNorm batch sums of its output -- bn_sums [bn_nrep][2 * Cout] f64, CLEARED BY THE
+// CALLER, the statistic is the sum over the replicas (cruse_bn_nchw_fwd_train folds them) -- from the epilogue of the f16 pointwise-MFMA and
+// LDS-depthwise kernels (nn.Conv2d -> nn.BatchNorm2d of TFCM_Block, mtfaa.py:170-183; Conv2dNormAct, cust_conv.py:15-111); every other form
+// runs the statistics pass over y into replica 0.
+extern "C" int cruse_conv2d_nchw_bnstats(const void* x, const float* w, const float* bias, void* y,
+                                         int B, int Cin, int Hin, int Win, int Cout, int Hout, int Wout,
+                                         int KH, int KW, int sh, int sw, int dh, int dw, int pt, int pl,
+                                         int groups, int up_w, int transposed, int act, const float* slope,
+                                         double* bn_sums, int bn_nrep, int dtype, void* stream) {
+    CRUSE_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, CRUSE_E_SHAPE, "conv2d_nchw_bnstats: bad shape");
+    CRUSE_REQUIRE(KH > 0 && KW > 0 && sh > 0 && sw > 0 && dh > 0 && dw > 0 && groups > 0 && up_w > 0, CRUSE_E_SHAPE,
+                  "conv2d_nchw_bnstats: bad kernel geometry");
+    CRUSE_REQUIRE(Cin % groups == 0 && Cout % groups == 0 && !(transposed && up_w != 1), CRUSE_E_SHAPE, "conv2d_nchw_bnstats: groups / form");
+    CRUSE_REQUIRE(act >= 0 && act <= 2 && (act != 2 || slope) && bn_sums != nullptr && bn_nrep >= 1, CRUSE_E_SHAPE, "conv2d_nchw_bnstats: arguments");
+    CRUSE_DT_CHECK("conv2d_nchw_bnstats");
+    bool done = false;
+    int rc;
+    if (dtype == CRUSE_DT_F16)
+        rc = conv2d_nchw_t<f16>(x, w, bias, y, B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, sh, sw, dh, dw, pt, pl, groups, up_w, transposed, act, slope,
+                                0, ST(stream), bn_sums, bn_nrep, &done);
+    else
+        rc = conv2d_nchw_t<float>(x, w, bias, y, B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, sh, sw, dh, dw, pt, pl, groups, up_w, transposed, act, slope,
+                                  0, ST(stream), bn_sums, bn_nrep, &done);
+    if (rc || done) return rc;
+    return cruse_bn_nchw_stats_ex(y, B, Cout, Hout * Wout, bn_sums, 1, dtype, stream);
 }
 
 extern "C" int cruse_conv2d_nchw_wgrad(const void* S, const void* Bg, float* dw,
@@ -1586,21 +1666,22 @@ extern "C" int cruse_counters_add(long long* const* counters, int n, long long v
 // Training-mode BatchNorm2d (+ activation) forward from the batch SUMS of cruse_bn_nchw_stats: mean / rstd are formed in the kernel and written to
 // mean_out / rstd_out for the backward pass, the running statistics (nullable pair) and the batch counter (nullable) are updated as
 // nn.BatchNorm2d does (momentum, unbiased variance) -- one launch for cruse_bn_finalize + cruse_counters_add + cruse_bn_nchw_fwd
-extern "C" int cruse_bn_nchw_fwd_train(const void* x, const double* sums, float eps, float momentum, const float* gamma, const float* beta,
+extern "C" int cruse_bn_nchw_fwd_train(const void* x, const double* sums, int sum_replicas, float eps, float momentum, const float* gamma, const float* beta,
                                        const float* slope, int act, int N, int C, int HW, void* y, float* mean_out, float* rstd_out,
                                        float* running_mean, float* running_var, long long* num_batches_tracked, int dtype, void* stream) {
     CRUSE_REQUIRE(N > 0 && C > 0 && HW > 0 && act >= 0 && act <= 3 && (act != 2 || slope), CRUSE_E_SHAPE, "bn_nchw_fwd_train: bad arguments");
-    CRUSE_REQUIRE(sums && gamma && beta && mean_out && rstd_out && (running_mean == nullptr) == (running_var == nullptr), CRUSE_E_SHAPE,
+    CRUSE_REQUIRE(sums && sum_replicas >= 1 && gamma && beta && mean_out && rstd_out && (running_mean == nullptr) == (running_var == nullptr), CRUSE_E_SHAPE,
                   "bn_nchw_fwd_train: statistics / affine / output pointers");
     CRUSE_DT_CHECK("bn_nchw_fwd_train");
     const long long count = (long long)N * HW;
     if (dtype == CRUSE_DT_F16 && (long long)N * C < 65536) {
-        hipLaunchKernelGGL(bn_nchw_fwd_train_f16v_kernel, dim3(cdiv(cdiv(HW, 8), 256), N * C), dim3(256), 0, ST(stream), (const f16*)x, sums,
+        hipLaunchKernelGGL(bn_nchw_fwd_train_f16v_kernel, dim3(cdiv(cdiv(HW, 8), 256), N * C), dim3(256), 0, ST(stream), (const f16*)x, sums, sum_replicas,
                            1.0 / (double)count, count > 1 ? (double)count / (double)(count - 1) : 1.0, eps, momentum, gamma, beta, slope, act, C, HW,
                            (f16*)y, mean_out, rstd_out, running_mean, running_var, num_batches_tracked);
         CRUSE_LAUNCH_CHECK("bn_nchw_fwd_train");
         return CRUSE_OK;
     }
+    CRUSE_REQUIRE(sum_replicas == 1, CRUSE_E_SHAPE, "bn_nchw_fwd_train: replicated sums come with the f16 kernels only");
     int rc = cruse_bn_finalize(sums, count, C, eps, momentum, mean_out, rstd_out, running_mean, running_var, stream);
     if (rc) return rc;
     if (num_batches_tracked) { long long* one[1] = {num_batches_tracked}; rc = cruse_counters_add(one, 1, 1, stream); if (rc) return rc; }

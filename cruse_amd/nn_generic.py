@@ -111,11 +111,21 @@ def _zeros_pool(shape, device, dtype) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------------------------
 # raw kernel wrappers
 # ------------------------------------------------------------------------------------------------------------------
+BN_STAT_REPLICAS = 8               # replicas of the batch sums a convolution's epilogue adds into (spreads its f64 atomics)
+
+
 def _conv_raw(x, w, bias, out_hw, KH, KW, stride, dil, pt, pl, groups, up_w, transposed, Cout, act=0, slope=None,
-              out=None, accumulate=False):
+              out=None, accumulate=False, bn_sums=None):
+    """bn_sums: a zeroed [BN_STAT_REPLICAS, 2 * Cout] f64 tensor -- the convolution also delivers the BatchNorm batch sums of its output
+    (cruse_conv2d_nchw_bnstats)"""
     B, Cin, Hin, Win = x.shape
     Hout, Wout = out_hw
     y = torch.empty(B, Cout, Hout, Wout, device=x.device, dtype=x.dtype) if out is None else out
+    if bn_sums is not None:
+        check(lib.cruse_conv2d_nchw_bnstats(_p(x), _p(w), _p(bias), _p(y), B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, stride[0], stride[1],
+                                            dil[0], dil[1], pt, pl, groups, up_w, 1 if transposed else 0, act, _p(slope), _p(bn_sums),
+                                            bn_sums.shape[0], _dt(x), _stream()))
+        return y
     check(lib.cruse_conv2d_nchw(_p(x), _p(w), _p(bias), _p(y), B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, stride[0], stride[1],
                                 dil[0], dil[1], pt, pl, groups, up_w, 1 if transposed else 0, act, _p(slope),
                                 1 if accumulate else 0, _dt(x), _stream()))
@@ -154,6 +164,23 @@ def _take_dx_sum(dy):
     return None
 
 
+# ... and the other way round: a convolution that feeds a training-mode BatchNorm delivers that BatchNorm's batch sums from its epilogue
+_BN_SUMS = {}
+
+
+def _stash_bn_sums(y, sums):
+    if len(_BN_SUMS) >= 8:
+        _BN_SUMS.clear()
+    _BN_SUMS[y.data_ptr()] = (y, sums)
+
+
+def _take_bn_sums(x):
+    ent = _BN_SUMS.pop(x.data_ptr(), None)
+    if ent is not None and ent[0].shape == x.shape and ent[0].dtype == x.dtype and ent[0]._version == x._version:
+        return ent[1]
+    return None
+
+
 def _channel_sum(dy, out):
     N, C = dy.shape[:2]
     check(lib.cruse_nchw_channel_sum(_p(dy), N, C, dy[0, 0].numel(), _p(out), _dt(dy), _stream()))
@@ -165,10 +192,14 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, cfg):
         x = x.contiguous(); w = w.contiguous().float()
-        (stride, dil, pt, pl, groups, up_w, transposed, out_hw) = cfg
+        (stride, dil, pt, pl, groups, up_w, transposed, out_hw) = cfg[:8]
+        want_bn = len(cfg) > 8 and cfg[8]
         KH, KW = w.shape[2], w.shape[3]
         Cout = w.shape[1] * groups if transposed else w.shape[0]
-        y = _conv_raw(x, w, bias, out_hw, KH, KW, stride, dil, pt, pl, groups, up_w, transposed, Cout)
+        sums = _zeros_f64((BN_STAT_REPLICAS, 2 * Cout), x.device) if want_bn else None
+        y = _conv_raw(x, w, bias, out_hw, KH, KW, stride, dil, pt, pl, groups, up_w, transposed, Cout, bn_sums=sums)
+        if want_bn:
+            _stash_bn_sums(y, sums)
         ctx.save_for_backward(x, w)
         ctx.cfg, ctx.has_bias = cfg, bias is not None
         return y
@@ -176,7 +207,7 @@ class _ConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        (stride, dil, pt, pl, groups, up_w, transposed, out_hw) = ctx.cfg
+        (stride, dil, pt, pl, groups, up_w, transposed, out_hw) = ctx.cfg[:8]
         dy = dy.contiguous()
         if dy.dtype != x.dtype:
             dy = _CastFn.apply(dy, x.dtype == torch.float16)
@@ -209,8 +240,9 @@ class _ConvFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
-def conv2d(x, w, bias=None, stride=(1, 1), dilation=(1, 1), pad=(0, 0, 0, 0), groups=1, up_w=1):
-    """F.conv2d on zero-padded x; pad = (top, bottom, left, right); up_w: nearest upsampling of W folded in front."""
+def conv2d(x, w, bias=None, stride=(1, 1), dilation=(1, 1), pad=(0, 0, 0, 0), groups=1, up_w=1, bn_stats=False):
+    """F.conv2d on zero-padded x; pad = (top, bottom, left, right); up_w: nearest upsampling of W folded in front.
+    bn_stats: a training-mode BatchNorm2d consumes the output next -- its batch sums come out of this call (see _BN_SUMS)."""
     stride, dilation = _pair(stride), _pair(dilation)
     pt, pb, pl, pr = pad
     _, _, Hin, Win = x.shape
@@ -219,7 +251,7 @@ def conv2d(x, w, bias=None, stride=(1, 1), dilation=(1, 1), pad=(0, 0, 0, 0), gr
     Wout = (Win * up_w + pl + pr - dilation[1] * (KW - 1) - 1) // stride[1] + 1
     if Hout <= 0 or Wout <= 0:
         raise RuntimeError(f"conv2d: kernel {KH}x{KW} does not fit the padded input {Hin}x{Win}")
-    return _ConvFn.apply(x, w, bias, (stride, dilation, pt, pl, groups, up_w, False, (Hout, Wout)))
+    return _ConvFn.apply(x, w, bias, (stride, dilation, pt, pl, groups, up_w, False, (Hout, Wout), bool(bn_stats)))
 
 
 def conv_transpose2d(x, w, bias=None, stride=(1, 1), padding=(0, 0), output_padding=(0, 0), dilation=(1, 1), groups=1,
@@ -280,7 +312,8 @@ class _BnTrainActFn(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = torch.empty(C, device=x.device, dtype=torch.float32)
         rstd = torch.empty(C, device=x.device, dtype=torch.float32)
-        check(lib.cruse_bn_nchw_fwd_train(_p(x), _p(sums), float(eps), float(momentum), _p(gamma), _p(beta), _p(slope), act, N, C, HW, _p(y),
+        check(lib.cruse_bn_nchw_fwd_train(_p(x), _p(sums), sums.shape[0] if sums.dim() == 2 else 1, float(eps), float(momentum), _p(gamma), _p(beta),
+                                          _p(slope), act, N, C, HW, _p(y),
                                           _p(mean), _p(rstd), _p(rmean), _p(rvar), _p(nbt), _dt(x), _stream()))
         ctx.save_for_backward(x, gamma, beta, slope, mean, rstd)
         ctx.act, ctx.want_dx_sum = act, bool(want_dx_sum)
@@ -336,11 +369,16 @@ def batchnorm_act(x, bn: Optional[nn.BatchNorm2d], act_module=None, conv_bias_in
     N = xc.shape[0]
     HW = xc[0, 0].numel()
     if training:
-        sums = _zeros_f64((2 * C,), x.device)
-        check(lib.cruse_bn_nchw_stats_ex(_p(xc), N, C, HW, _p(sums), 1, _dt(xc), _stream()))
+        fusable = bn.weight is not None and bn.bias is not None and (bn.momentum is not None or not (bn.training and bn.running_mean is not None))
+        sums = _take_bn_sums(xc)
+        if sums is not None and not fusable:
+            sums = sums.sum(0)
+        if sums is None:
+            sums = _zeros_f64((2 * C,), x.device)
+            check(lib.cruse_bn_nchw_stats_ex(_p(xc), N, C, HW, _p(sums), 1, _dt(xc), _stream()))
         upd = bn.training and bn.running_mean is not None
         mom = bn.momentum if bn.momentum is not None else 0.1
-        if bn.weight is not None and bn.bias is not None and (bn.momentum is not None or not upd):
+        if fusable:
             # (momentum None = cumulative average: the separate finalize below)
             return _BnTrainActFn.apply(xc, bn.weight, bn.bias, slope, sums, bn.eps, mom, bn.running_mean if upd else None,
                                        bn.running_var if upd else None, bn.num_batches_tracked if upd else None, act,
@@ -427,8 +465,10 @@ def run_sequential(mods: Sequence[nn.Module], x: torch.Tensor) -> torch.Tensor:
             if m.padding_mode != "zeros" or isinstance(m.padding, str):
                 raise RuntimeError("HipSequential: Conv2d needs numeric zero padding")
             ph, pw = _pair(m.padding)
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            bn_next = isinstance(nxt, nn.BatchNorm2d) and (nxt.training or nxt.running_mean is None) and x.dtype == torch.float16
             x = conv2d(x, m.weight, m.bias, m.stride, m.dilation, (pad[0] + ph, pad[1] + ph, pad[2] + pw, pad[3] + pw),
-                       m.groups, up)
+                       m.groups, up, bn_stats=bn_next)
             pad, up = (0, 0, 0, 0), 1
             i += 1
             biased_conv = m.bias is not None and m.bias.requires_grad
