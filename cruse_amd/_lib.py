@@ -105,7 +105,7 @@ SIGNATURES = {
     "cruse_bn_nchw_bwd_ex": ("pppppppiiiiipipppppip", "i"),
     "cruse_bn_nchw_stats_ex": ("piiipiip", "i"),
     "cruse_bn_nchw_fwd_train": ("ppiffpppiiiippppppip", "i"),
-    "cruse_conv2d_nchw_bnstats": ("pppp" + "iiiiiii" + "iiiiiiii" + "iiii" + "p" + "pi" + "ip", "i"),
+    "cruse_conv2d_nchw_ex": ("ppppp" + "iiiiiii" + "iiiiiiii" + "iiii" + "p" + "pi" + "ip", "i"),
     "cruse_add_nchw": ("pppqip", "i"),
     "cruse_cast_f16": ("ppqip", "i"),
     "cruse_stft_framed": ("ppiiiiiiiiifppp", "i"),

@@ -26,6 +26,7 @@ template <typename T> struct GConv {
     // optional (f16 MFMA-pointwise / LDS-depthwise kernels): the BatchNorm batch sums of the STORED outputs, bn_sums[rep][2 Cout] f64 with
     // rep = block % bn_nrep (sum, then sum of squares) -- what cruse_bn_nchw_stats would read back from y
     double* bn_sums; int bn_nrep;
+    const T* res;                          // optional (f16 LDS-transposed pointwise kernel): y = T(T(conv) + res), the residual add of a block
 };
 
 // transposed == 0 (nn.Conv2d, weight [Cout][Cin/g][KH][KW]; also the data gradient of a ConvTranspose2d):
@@ -348,7 +349,19 @@ __global__ __launch_bounds__(256) void gconv_pointwise_tr_f16_kernel(GConv<f16> 
         for (int it = 0; it < MR / 8; ++it) {
             const int co = it * 8 + rr;
             if (co < a.Cout && valid > 0) {
-                const f16x8 v = *reinterpret_cast<const f16x8*>(out_img + co * ROWB + ck * 16);
+                f16x8 v = *reinterpret_cast<const f16x8*>(out_img + co * ROWB + ck * 16);
+                if (a.res != nullptr) {                        // (two roundings, as the convolution followed by cruse_add_nchw)
+                    const f16* rq = a.res + (long long)b * a.Cout * hw + pos + (long long)co * hw;
+                    f16x8 r8 = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (valid == 8) __builtin_memcpy(&r8, rq, 16);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (e < valid) r8[e] = rq[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] + (float)r8[e]);
+                }
                 if (a.bn_sums != nullptr) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
@@ -1286,10 +1299,11 @@ template <typename T>
 int conv2d_nchw_t(const void* x, const float* w, const float* bias, void* y, int B, int Cin, int Hin, int Win, int Cout, int Hout,
                   int Wout, int KH, int KW, int sh, int sw, int dh, int dw, int pt, int pl, int groups, int up_w, int transposed,
                   int act, const float* slope, int accumulate, hipStream_t s, double* bn_sums = nullptr, int bn_nrep = 1,
-                  bool* bn_done = nullptr) {
+                  bool* bn_done = nullptr, const void* res = nullptr, bool* res_done = nullptr) {
     GConv<T> a = {(const T*)x, w, bias, (T*)y, B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, sh, sw, dh, dw, pt, pl, groups, up_w,
-                  transposed, act, accumulate, slope, nullptr, 1};
+                  transposed, act, accumulate, slope, nullptr, 1, nullptr};
     if (bn_done) *bn_done = false;
+    if (res_done) *res_done = false;
     const bool pointwise = KH == 1 && KW == 1 && sh == 1 && sw == 1 && pt == 0 && pl == 0 && groups == 1 && up_w == 1 &&
                            Hout == Hin && Wout == Win;
     if constexpr (sizeof(T) == 2) {
@@ -1303,6 +1317,7 @@ int conv2d_nchw_t(const void* x, const float* w, const float* bias, void* y, int
             const int mtc = MT <= 1 ? 1 : 2, ksc = KS <= 1 ? 1 : 2;
             const size_t lds = (size_t)4 * (ksc * 32 + mtc * 16) * 144;
             if (bn_sums) { a.bn_sums = bn_sums; a.bn_nrep = bn_nrep; *bn_done = true; }
+            if (res) { a.res = (const T*)res; *res_done = true; }
 #define PWT_CASE(mt, ks) do { int rc = cruse_ensure_dyn_lds((const void*)gconv_pointwise_tr_f16_kernel<mt, ks>, lds, "conv2d_nchw pointwise"); \
                 if (rc) return rc; \
                 hipLaunchKernelGGL((gconv_pointwise_tr_f16_kernel<mt, ks>), dim3(nb), dim3(256), lds, s, a); } while (0)
@@ -1495,31 +1510,38 @@ extern "C" int cruse_conv2d_nchw(const void* x, const float* w, const float* bia
 
 extern "C" int cruse_bn_nchw_stats_ex(const void* x, int N, int C, int HW, double* sums, int zeroed, int dtype, void* stream);
 
-// cruse_conv2d_nchw (no accumulation) that ALSO delivers the BatchNorm batch sums of its output -- bn_sums [bn_nrep][2 * Cout] f64, CLEARED BY THE
-// CALLER, the statistic is the sum over the replicas (cruse_bn_nchw_fwd_train folds them) -- from the epilogue of the f16 pointwise-MFMA and
-// LDS-depthwise kernels (nn.Conv2d -> nn.BatchNorm2d of TFCM_Block, mtfaa.py:170-183; Conv2dNormAct, cust_conv.py:15-111); every other form
-// runs the statistics pass over y into replica 0.
-extern "C" int cruse_conv2d_nchw_bnstats(const void* x, const float* w, const float* bias, void* y,
-                                         int B, int Cin, int Hin, int Win, int Cout, int Hout, int Wout,
-                                         int KH, int KW, int sh, int sw, int dh, int dw, int pt, int pl,
-                                         int groups, int up_w, int transposed, int act, const float* slope,
-                                         double* bn_sums, int bn_nrep, int dtype, void* stream) {
-    CRUSE_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, CRUSE_E_SHAPE, "conv2d_nchw_bnstats: bad shape");
+extern "C" int cruse_add_nchw(const void* a, const void* b, void* out, long long n, int dtype, void* stream);
+
+// cruse_conv2d_nchw (no accumulation) with the two things that follow a convolution in the reference's blocks folded in (both optional):
+//   residual != NULL: y = conv(x) + residual (TFCM_Block's `outs + inps`, mtfaa.py:191) -- in the epilogue of the f16 LDS-transposed pointwise
+//     kernel, else by cruse_add_nchw on y;
+//   bn_sums != NULL: the BatchNorm batch sums of the output, [bn_nrep][2 * Cout] f64 CLEARED BY THE CALLER, the statistic is the sum over the
+//     replicas (cruse_bn_nchw_fwd_train folds them) -- from the epilogue of the f16 pointwise-MFMA and LDS-depthwise kernels (nn.Conv2d ->
+//     nn.BatchNorm2d, mtfaa.py:170-183; Conv2dNormAct, cust_conv.py:15-111), else by the statistics pass over y into replica 0.
+extern "C" int cruse_conv2d_nchw_ex(const void* x, const float* w, const float* bias, const void* residual, void* y,
+                                    int B, int Cin, int Hin, int Win, int Cout, int Hout, int Wout,
+                                    int KH, int KW, int sh, int sw, int dh, int dw, int pt, int pl,
+                                    int groups, int up_w, int transposed, int act, const float* slope,
+                                    double* bn_sums, int bn_nrep, int dtype, void* stream) {
+    CRUSE_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, CRUSE_E_SHAPE, "conv2d_nchw_ex: bad shape");
     CRUSE_REQUIRE(KH > 0 && KW > 0 && sh > 0 && sw > 0 && dh > 0 && dw > 0 && groups > 0 && up_w > 0, CRUSE_E_SHAPE,
-                  "conv2d_nchw_bnstats: bad kernel geometry");
-    CRUSE_REQUIRE(Cin % groups == 0 && Cout % groups == 0 && !(transposed && up_w != 1), CRUSE_E_SHAPE, "conv2d_nchw_bnstats: groups / form");
-    CRUSE_REQUIRE(act >= 0 && act <= 2 && (act != 2 || slope) && bn_sums != nullptr && bn_nrep >= 1, CRUSE_E_SHAPE, "conv2d_nchw_bnstats: arguments");
-    CRUSE_DT_CHECK("conv2d_nchw_bnstats");
-    bool done = false;
+                  "conv2d_nchw_ex: bad kernel geometry");
+    CRUSE_REQUIRE(Cin % groups == 0 && Cout % groups == 0 && !(transposed && up_w != 1), CRUSE_E_SHAPE, "conv2d_nchw_ex: groups / form");
+    CRUSE_REQUIRE(act >= 0 && act <= 2 && (act != 2 || slope) && (bn_sums == nullptr || bn_nrep >= 1) && !(bn_sums && residual), CRUSE_E_SHAPE,
+                  "conv2d_nchw_ex: arguments (statistics of a sum are not offered)");
+    CRUSE_DT_CHECK("conv2d_nchw_ex");
+    bool done = false, rdone = false;
     int rc;
     if (dtype == CRUSE_DT_F16)
         rc = conv2d_nchw_t<f16>(x, w, bias, y, B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, sh, sw, dh, dw, pt, pl, groups, up_w, transposed, act, slope,
-                                0, ST(stream), bn_sums, bn_nrep, &done);
+                                0, ST(stream), bn_sums, bn_nrep, &done, residual, &rdone);
     else
         rc = conv2d_nchw_t<float>(x, w, bias, y, B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, sh, sw, dh, dw, pt, pl, groups, up_w, transposed, act, slope,
-                                  0, ST(stream), bn_sums, bn_nrep, &done);
-    if (rc || done) return rc;
-    return cruse_bn_nchw_stats_ex(y, B, Cout, Hout * Wout, bn_sums, 1, dtype, stream);
+                                  0, ST(stream), bn_sums, bn_nrep, &done, residual, &rdone);
+    if (rc) return rc;
+    if (residual && !rdone) return cruse_add_nchw(y, residual, y, (long long)B * Cout * Hout * Wout, dtype, stream);
+    if (bn_sums && !done) return cruse_bn_nchw_stats_ex(y, B, Cout, Hout * Wout, bn_sums, 1, dtype, stream);
+    return CRUSE_OK;
 }
 
 extern "C" int cruse_conv2d_nchw_wgrad(const void* S, const void* Bg, float* dw,

@@ -197,10 +197,11 @@ class TFCM_Block(nn.Module):
         self.dila_pad = dila_pad
 
     def forward(self, inps):
-        outs = self.pconv1(inps)
+        # (the input also feeds the residual: it is handed through pconv1's autograd node, so that the residual path's gradient is added inside
+        #  pconv1's data-gradient kernel instead of by an accumulation pass)
+        outs, skip = self.pconv1.forward_tap(inps)
         outs = self.dila_conv(outs)
-        outs = self.pconv2(outs)
-        return add(outs, inps)
+        return self.pconv2.forward_add(outs, skip)
 
 
 class TFCM(nn.Module):

@@ -115,16 +115,16 @@ BN_STAT_REPLICAS = 8               # replicas of the batch sums a convolution's 
 
 
 def _conv_raw(x, w, bias, out_hw, KH, KW, stride, dil, pt, pl, groups, up_w, transposed, Cout, act=0, slope=None,
-              out=None, accumulate=False, bn_sums=None):
-    """bn_sums: a zeroed [BN_STAT_REPLICAS, 2 * Cout] f64 tensor -- the convolution also delivers the BatchNorm batch sums of its output
-    (cruse_conv2d_nchw_bnstats)"""
+              out=None, accumulate=False, bn_sums=None, residual=None):
+    """bn_sums: a zeroed [BN_STAT_REPLICAS, 2 * Cout] f64 tensor -- the convolution also delivers the BatchNorm batch sums of its output;
+    residual: y = conv(x) + residual (cruse_conv2d_nchw_ex)"""
     B, Cin, Hin, Win = x.shape
     Hout, Wout = out_hw
     y = torch.empty(B, Cout, Hout, Wout, device=x.device, dtype=x.dtype) if out is None else out
-    if bn_sums is not None:
-        check(lib.cruse_conv2d_nchw_bnstats(_p(x), _p(w), _p(bias), _p(y), B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, stride[0], stride[1],
-                                            dil[0], dil[1], pt, pl, groups, up_w, 1 if transposed else 0, act, _p(slope), _p(bn_sums),
-                                            bn_sums.shape[0], _dt(x), _stream()))
+    if bn_sums is not None or residual is not None:
+        check(lib.cruse_conv2d_nchw_ex(_p(x), _p(w), _p(bias), _p(residual), _p(y), B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, stride[0],
+                                       stride[1], dil[0], dil[1], pt, pl, groups, up_w, 1 if transposed else 0, act, _p(slope), _p(bn_sums),
+                                       bn_sums.shape[0] if bn_sums is not None else 1, _dt(x), _stream()))
         return y
     check(lib.cruse_conv2d_nchw(_p(x), _p(w), _p(bias), _p(y), B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, stride[0], stride[1],
                                 dil[0], dil[1], pt, pl, groups, up_w, 1 if transposed else 0, act, _p(slope),
@@ -190,40 +190,59 @@ class _ConvFn(torch.autograd.Function):
     """Conv2d (transposed=False) or ConvTranspose2d (True) on NCHW with folded zero pads / upsampling."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, cfg):
+    def forward(ctx, x, w, bias, cfg, res=None):
+        """res: a tensor of the output's shape added to it (the residual of a block); its gradient is the output's"""
         x = x.contiguous(); w = w.contiguous().float()
+        if res is not None:
+            res = res.contiguous()
+            if res.dtype != x.dtype:
+                raise RuntimeError("conv + residual: storage types differ")
         (stride, dil, pt, pl, groups, up_w, transposed, out_hw) = cfg[:8]
         want_bn = len(cfg) > 8 and cfg[8]
         KH, KW = w.shape[2], w.shape[3]
         Cout = w.shape[1] * groups if transposed else w.shape[0]
         sums = _zeros_f64((BN_STAT_REPLICAS, 2 * Cout), x.device) if want_bn else None
-        y = _conv_raw(x, w, bias, out_hw, KH, KW, stride, dil, pt, pl, groups, up_w, transposed, Cout, bn_sums=sums)
+        if res is not None and tuple(res.shape) != (x.shape[0], Cout, out_hw[0], out_hw[1]):
+            raise RuntimeError(f"conv + residual: residual shape {tuple(res.shape)} is not the output's")
+        y = _conv_raw(x, w, bias, out_hw, KH, KW, stride, dil, pt, pl, groups, up_w, transposed, Cout, bn_sums=sums, residual=res)
         if want_bn:
             _stash_bn_sums(y, sums)
         ctx.save_for_backward(x, w)
-        ctx.cfg, ctx.has_bias = cfg, bias is not None
+        ctx.cfg, ctx.has_bias, ctx.has_res = cfg, bias is not None, res is not None
+        ctx.tap = len(cfg) > 9 and cfg[9]
+        if ctx.tap:
+            # the input handed on beside the output: a block that ALSO adds its input to its result (TFCM_Block) takes the residual from here,
+            # so that the residual path's gradient arrives in THIS backward and is added inside the data-gradient kernel (no accumulation pass)
+            return y, x.view(x.shape)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dtap=None):
         x, w = ctx.saved_tensors
         (stride, dil, pt, pl, groups, up_w, transposed, out_hw) = ctx.cfg[:8]
         dy = dy.contiguous()
+        if dtap is not None:
+            dtap = dtap.contiguous()
+            if dtap.dtype != x.dtype:
+                dtap = _CastFn.apply(dtap, x.dtype == torch.float16)
         if dy.dtype != x.dtype:
             dy = _CastFn.apply(dy, x.dtype == torch.float16)
         KH, KW = w.shape[2], w.shape[3]
         B, Cin, Hin, Win = x.shape
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
+            fold = dtap if (dtap is not None and up_w == 1) else None           # the tapped input's gradient rides the data-gradient kernel
             if not transposed:
-                dxu = _conv_raw(dy, w, None, (Hin, Win * up_w), KH, KW, stride, dil, pt, pl, groups, 1, True, Cin)
+                dxu = _conv_raw(dy, w, None, (Hin, Win * up_w), KH, KW, stride, dil, pt, pl, groups, 1, True, Cin, residual=fold)
                 if up_w > 1:
                     dx = torch.empty_like(x)
                     check(lib.cruse_downsum_w(_p(dxu), B * Cin * Hin, Win, up_w, _p(dx), _dt(dx), _stream()))
                 else:
                     dx = dxu
             else:
-                dx = _conv_raw(dy, w, None, (Hin, Win), KH, KW, stride, dil, pt, pl, groups, 1, False, Cin)
+                dx = _conv_raw(dy, w, None, (Hin, Win), KH, KW, stride, dil, pt, pl, groups, 1, False, Cin, residual=fold)
+            if dtap is not None and fold is None:
+                dx = add(dx, dtap)
         pre = _take_dx_sum(dy)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if want_db:
@@ -237,10 +256,10 @@ class _ConvFn(torch.autograd.Function):
                 _wgrad_raw(x, dy, dw, KH, KW, stride, dil, pt, pl, groups, 1)
         if want_db and pre is None and not db_in_wgrad:
             _channel_sum(dy, db)
-        return dx, dw, db, None
+        return dx, dw, db, None, (dy if ctx.has_res and ctx.needs_input_grad[4] else None)
 
 
-def conv2d(x, w, bias=None, stride=(1, 1), dilation=(1, 1), pad=(0, 0, 0, 0), groups=1, up_w=1, bn_stats=False):
+def conv2d(x, w, bias=None, stride=(1, 1), dilation=(1, 1), pad=(0, 0, 0, 0), groups=1, up_w=1, bn_stats=False, residual=None, tap_input=False):
     """F.conv2d on zero-padded x; pad = (top, bottom, left, right); up_w: nearest upsampling of W folded in front.
     bn_stats: a training-mode BatchNorm2d consumes the output next -- its batch sums come out of this call (see _BN_SUMS)."""
     stride, dilation = _pair(stride), _pair(dilation)
@@ -251,7 +270,8 @@ def conv2d(x, w, bias=None, stride=(1, 1), dilation=(1, 1), pad=(0, 0, 0, 0), gr
     Wout = (Win * up_w + pl + pr - dilation[1] * (KW - 1) - 1) // stride[1] + 1
     if Hout <= 0 or Wout <= 0:
         raise RuntimeError(f"conv2d: kernel {KH}x{KW} does not fit the padded input {Hin}x{Win}")
-    return _ConvFn.apply(x, w, bias, (stride, dilation, pt, pl, groups, up_w, False, (Hout, Wout), bool(bn_stats)))
+    # tap_input: returns (y, x'): x' is x handed through the convolution's autograd node (see _ConvFn.forward)
+    return _ConvFn.apply(x, w, bias, (stride, dilation, pt, pl, groups, up_w, False, (Hout, Wout), bool(bn_stats), bool(tap_input)), residual)
 
 
 def conv_transpose2d(x, w, bias=None, stride=(1, 1), padding=(0, 0), output_padding=(0, 0), dilation=(1, 1), groups=1,
@@ -439,10 +459,12 @@ def _pad4(m: nn.ConstantPad2d):
     return int(t), int(b), int(l), int(r)
 
 
-def run_sequential(mods: Sequence[nn.Module], x: torch.Tensor) -> torch.Tensor:
+def run_sequential(mods: Sequence[nn.Module], x: torch.Tensor, tap_first_conv: bool = False):
+    """tap_first_conv: returns (out, x') with x' the sequence's input handed through its first Conv2d's autograd node (conv2d(tap_input=True))"""
     if not x.is_cuda:
         raise RuntimeError("cruse_amd blocks need tensors on the HIP device (no CPU fallback)")
     mods = list(mods)
+    tapped = None
     i = 0
     pad = (0, 0, 0, 0)
     up = 1
@@ -467,8 +489,11 @@ def run_sequential(mods: Sequence[nn.Module], x: torch.Tensor) -> torch.Tensor:
             ph, pw = _pair(m.padding)
             nxt = mods[i + 1] if i + 1 < len(mods) else None
             bn_next = isinstance(nxt, nn.BatchNorm2d) and (nxt.training or nxt.running_mean is None) and x.dtype == torch.float16
+            tap = tap_first_conv and tapped is None and i == 0
             x = conv2d(x, m.weight, m.bias, m.stride, m.dilation, (pad[0] + ph, pad[1] + ph, pad[2] + pw, pad[3] + pw),
-                       m.groups, up, bn_stats=bn_next)
+                       m.groups, up, bn_stats=bn_next, tap_input=tap)
+            if tap:
+                x, tapped = x
             pad, up = (0, 0, 0, 0), 1
             i += 1
             biased_conv = m.bias is not None and m.bias.requires_grad
@@ -498,6 +523,10 @@ def run_sequential(mods: Sequence[nn.Module], x: torch.Tensor) -> torch.Tensor:
             i += 1
     if pad != (0, 0, 0, 0) or up != 1:
         raise RuntimeError("HipSequential: trailing pad / upsample without a convolution")
+    if tap_first_conv:
+        if tapped is None:
+            raise RuntimeError("HipSequential: tap_first_conv needs a Conv2d as the first module")
+        return x, tapped
     return x
 
 
@@ -505,9 +534,22 @@ class HipSequential(nn.Sequential):
     def forward(self, x):
         return run_sequential(list(self), x)
 
+    def forward_tap(self, x):
+        """(self(x), x'): x' carries x through the first convolution's autograd node (for a residual taken from the block's input)"""
+        return run_sequential(list(self), x, tap_first_conv=True)
+
 
 class HipConv2d(nn.Conv2d):
     """nn.Conv2d parameters, HIP forward/backward."""
 
     def forward(self, x):
         return run_sequential([self], x)
+
+    def forward_add(self, x, res):
+        """self(x) + res in one launch where the kernel offers it (the residual of TFCM_Block, mtfaa.py:191)"""
+        if not x.is_cuda:
+            raise RuntimeError("cruse_amd blocks need tensors on the HIP device (no CPU fallback)")
+        if self.padding_mode != "zeros" or isinstance(self.padding, str):
+            raise RuntimeError("HipConv2d: numeric zero padding")
+        ph, pw = _pair(self.padding)
+        return conv2d(x, self.weight, self.bias, self.stride, self.dilation, (ph, ph, pw, pw), self.groups, 1, residual=res)

@@ -550,10 +550,11 @@ int cruse_bn_nchw_bwd(const void* dy, const void* x, const float* mean, const fl
  *   kernel and published to mean_out / rstd_out, running_mean / running_var (nullable pair: momentum, unbiased variance) and
  *   num_batches_tracked (nullable, += 1) are updated: cruse_bn_finalize + cruse_counters_add + cruse_bn_nchw_fwd in one launch
  *   (nn.Conv2d -> nn.BatchNorm2d -> nn.PReLU of TFCM_Block, mtfaa.py:166-193; Conv2dNormAct, cust_conv.py:15-111).
- *   sums may be sum_replicas x [2C] (cruse_conv2d_nchw_bnstats): the statistic is the sum over the replicas.
- * cruse_conv2d_nchw_bnstats: cruse_conv2d_nchw (no accumulation) that also delivers the batch sums of its output into bn_sums
- *   [bn_nrep][2*Cout] f64 (cleared by the caller) from the epilogue of the f16 pointwise-MFMA / LDS-depthwise kernels; other forms run the
- *   statistics pass over y into replica 0.
+ *   sums may be sum_replicas x [2C] (cruse_conv2d_nchw_ex): the statistic is the sum over the replicas.
+ * cruse_conv2d_nchw_ex: cruse_conv2d_nchw (no accumulation) with what follows a convolution in the reference's blocks folded in, both optional:
+ *   residual != NULL: y = conv(x) + residual (TFCM_Block, mtfaa.py:191) in the epilogue of the f16 LDS-transposed pointwise kernel (else by
+ *   cruse_add_nchw); bn_sums != NULL: the batch sums of the output into bn_sums [bn_nrep][2*Cout] f64 (cleared by the caller) from the
+ *   epilogue of the f16 pointwise-MFMA / LDS-depthwise kernels (else the statistics pass over y into replica 0).  Not both.
  * cruse_bn_nchw_bwd_ex: cruse_bn_nchw_bwd (scratch: 4*C doubles) whose apply pass also adds the parameter gradients and, when dx_sum != NULL,
  *   dx_sum[c] += sum over the channel of dx -- the bias gradient of the convolution in front of the BatchNorm -- in closed form from the
  *   reduce pass's sums (training: -gamma rstd mean(d xhat) sum(xhat), the rounding of the batch mean; eval: gamma rstd sum(d)) instead of a
@@ -561,11 +562,11 @@ int cruse_bn_nchw_bwd(const void* dy, const void* x, const float* mean, const fl
 int cruse_bn_nchw_fwd_train(const void* x, const double* sums, int sum_replicas, float eps, float momentum, const float* gamma, const float* beta,
                             const float* slope, int act, int N, int C, int HW, void* y, float* mean_out, float* rstd_out,
                             float* running_mean, float* running_var, long long* num_batches_tracked, int dtype, void* stream);
-int cruse_conv2d_nchw_bnstats(const void* x, const float* w, const float* bias, void* y,
-                              int B, int Cin, int Hin, int Win, int Cout, int Hout, int Wout,
-                              int KH, int KW, int sh, int sw, int dh, int dw, int pt, int pl,
-                              int groups, int up_w, int transposed, int act, const float* slope,
-                              double* bn_sums, int bn_nrep, int dtype, void* stream);
+int cruse_conv2d_nchw_ex(const void* x, const float* w, const float* bias, const void* residual, void* y,
+                         int B, int Cin, int Hin, int Win, int Cout, int Hout, int Wout,
+                         int KH, int KW, int sh, int sw, int dh, int dw, int pt, int pl,
+                         int groups, int up_w, int transposed, int act, const float* slope,
+                         double* bn_sums, int bn_nrep, int dtype, void* stream);
 int cruse_bn_nchw_bwd_ex(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                          const float* beta, const float* slope, int act, int training, int N, int C, int HW,
                          double* scratch, int scratch_zeroed, void* dx, float* dgamma, float* dbeta, float* dslope, float* dx_sum, int dtype,
