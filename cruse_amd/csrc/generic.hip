@@ -1110,12 +1110,23 @@ __global__ __launch_bounds__(256) void bn_nchw_fwd_train_f16v_kernel(const f16* 
                                                                      int C, int HW, f16* y, float* mean_o, float* rstd_o, float* rmean, float* rvar,
                                                                      long long* nbt) {
     const int plane = blockIdx.y, c = plane % C;
-    double t1 = 0.0, t2 = 0.0;
-    for (int r = 0; r < nrep; ++r) { t1 += sums[(size_t)r * 2 * C + c]; t2 += sums[(size_t)r * 2 * C + C + c]; }
-    const double md = t1 * inv_count;
-    double var = t2 * inv_count - md * md;
-    if (var < 0.0) var = 0.0;
-    const float m = (float)md, rs = (float)(1.0 / sqrt(var + (double)eps));
+    // the statistic: wave 0 folds the replicas (one lane each, fixed order of the shuffle tree) and hands mean / rstd to the block
+    __shared__ float s_m, s_rs;
+    __shared__ double s_md, s_var;
+    if (threadIdx.x < 64) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int r = threadIdx.x; r < nrep; r += 64) { t1 += sums[(size_t)r * 2 * C + c]; t2 += sums[(size_t)r * 2 * C + C + c]; }
+        t1 = wave_sum_d(t1); t2 = wave_sum_d(t2);
+        if (threadIdx.x == 0) {
+            const double md0 = t1 * inv_count;
+            double var0 = t2 * inv_count - md0 * md0;
+            if (var0 < 0.0) var0 = 0.0;
+            s_md = md0; s_var = var0; s_m = (float)md0; s_rs = (float)(1.0 / sqrt(var0 + (double)eps));
+        }
+    }
+    __syncthreads();
+    const double md = s_md, var = s_var;
+    const float m = s_m, rs = s_rs;
     if (blockIdx.x == 0 && plane < C && threadIdx.x == 0) {
         mean_o[c] = m; rstd_o[c] = rs;
         if (rmean) {
