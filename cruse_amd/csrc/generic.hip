@@ -1288,7 +1288,7 @@ inline bool dw_geometry(const TapTab& tt, int Hiter, int Wsrc, int Witer, long l
 
 inline int zchunks(int gx, int gy, int HW) {
     int z = 1;
-    while ((long long)gx * gy * z < 2048 && HW / (z * 2) >= 4096) z *= 2;
+    while ((long long)gx * gy * z < 512 && HW / (z * 2) >= 1024) z *= 2;     // (768 blocks at the config-5 shape: 20 us; 1536: 25, 6144: 49 -- the f64 atomics of many small blocks)
     return z;
 }
 
