@@ -686,6 +686,130 @@ def test_pointwise_conv_f16_mfma_kernel(Cin, Cout, transposed):
     assert rel_l2(acc.double(), base.double() + want - bias.double().view(1, -1, 1, 1)) < 1e-3
 
 
+@pytest.mark.parametrize("Cin,Cout,transposed", [(24, 24, False), (24, 24, True), (40, 8, False), (8, 32, True)])
+def test_pointwise_conv_f16_transposed_through_lds_equals_the_gather_kernel(Cin, Cout, transposed):
+    """gconv_pointwise_tr_f16_kernel (operand rows copied to LDS, MFMA tile by transposing LDS reads, swapped roles) computes the same
+    products in the same order as the gather kernel (library option pw_valu = 2): identical bits -- on a plane whose size is neither a
+    multiple of 64 nor of 8 (tails of a chunk, of a 16-byte group), with bias and PReLU."""
+    from cruse_amd import ops
+    from cruse_amd.nn_generic import _conv_raw
+    torch.manual_seed(3 * Cin + Cout)
+    B, H, W = 3, 11, 29
+    x = torch.randn(B, Cin, H, W).cuda().half()
+    w = (torch.randn(Cin, Cout, 1, 1) if transposed else torch.randn(Cout, Cin, 1, 1)).cuda()
+    bias, slope = torch.randn(Cout).cuda(), torch.rand(Cout).cuda()
+    outs = {}
+    for v in (0, 2):
+        ops.set_option("pw_valu", v)
+        try:
+            outs[v] = (_conv_raw(x, w, bias, (H, W), 1, 1, (1, 1), (1, 1), 0, 0, 1, 1, transposed, Cout),
+                       _conv_raw(x, w, None, (H, W), 1, 1, (1, 1), (1, 1), 0, 0, 1, 1, transposed, Cout, act=2, slope=slope))
+        finally:
+            ops.set_option("pw_valu", None)
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
+
+
+@pytest.mark.parametrize("kind", ["pointwise", "depthwise", "general"])
+def test_conv_ex_delivers_batch_sums_and_residual(kind):
+    """cruse_conv2d_nchw_ex: the BatchNorm batch sums are those of the STORED output (what cruse_bn_nchw_stats reads back), summed over the
+    replicas; y = conv + residual is the convolution followed by the add (two roundings).  Pointwise / depthwise: in the kernels' epilogues;
+    a 3x3 full convolution: the fallback passes."""
+    from cruse_amd.nn_generic import BN_STAT_REPLICAS, _conv_raw, _zeros_f64
+    torch.manual_seed(11)
+    B, C, H, W = 3, 24, 13, 37
+    x = torch.randn(B, C, H, W).cuda().half()
+    if kind == "pointwise":
+        w, geo = torch.randn(C, C, 1, 1).cuda() * 0.3, dict(KH=1, KW=1, dil=(1, 1), pt=0, pl=0, groups=1)
+    elif kind == "depthwise":
+        w, geo = torch.randn(C, 1, 3, 3).cuda() * 0.3, dict(KH=3, KW=3, dil=(1, 2), pt=1, pl=4, groups=C)
+    else:
+        w, geo = torch.randn(C, C, 3, 3).cuda() * 0.1, dict(KH=3, KW=3, dil=(1, 1), pt=1, pl=1, groups=1)
+    Wout = W + (4 if kind == "depthwise" else (2 if kind == "general" else 0)) - geo["dil"][1] * (geo["KW"] - 1)
+    bias = torch.randn(C).cuda()
+
+    def run(**kw):
+        return _conv_raw(x, w, bias, (H, Wout), geo["KH"], geo["KW"], (1, 1), geo["dil"], geo["pt"], geo["pl"], geo["groups"], 1, False, C, **kw)
+    y = run()
+    sums = _zeros_f64((BN_STAT_REPLICAS, 2 * C), x.device)
+    y2 = run(bn_sums=sums)
+    assert torch.equal(y, y2)
+    tot = sums.sum(0).cpu()
+    yd = y.double().cpu()
+    assert torch.allclose(tot[:C], yd.sum((0, 2, 3)), rtol=1e-5, atol=1e-3) and torch.allclose(tot[C:], (yd * yd).sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
+    res = torch.randn(B, C, H, Wout).cuda().half()
+    y3 = run(residual=res)
+    assert torch.equal(y3, (y.float() + res.float()).half())
+
+
+def test_batchnorm_nchw_fused_train_forward_and_backward_ex():
+    """cruse_bn_nchw_fwd_train == cruse_bn_finalize + cruse_counters_add + cruse_bn_nchw_fwd (output bits, mean / rstd, running statistics, batch
+    counter; sums given as 1 or 8 replicas); cruse_bn_nchw_bwd_ex == cruse_bn_nchw_bwd (dx bits, parameter gradients) and its dx_sum is the
+    channel sum of dx up to the f16 rounding of the stored values (closed form: DESIGN 7c)."""
+    from cruse_amd import ops
+    from cruse_amd._lib import check, lib
+    from cruse_amd.ops import _p, _stream
+    torch.manual_seed(5)
+    N, C, H, W = 4, 24, 9, 53
+    HW = H * W
+    x = (torch.randn(N, C, H, W) * 1.5 + 0.7).cuda().half()
+    dy = torch.randn(N, C, H, W).cuda().half()
+    gamma, beta, slope = (1 + 0.3 * torch.randn(C)).cuda(), (0.2 * torch.randn(C)).cuda(), torch.rand(C).cuda()
+    sums = torch.zeros(2 * C, dtype=torch.float64).cuda()
+    check(lib.cruse_bn_nchw_stats(_p(x), N, C, HW, _p(sums), 1, _stream()))
+    rm0, rv0 = torch.randn(C).cuda(), torch.rand(C).cuda() + 0.5
+    # separate passes
+    rm, rv, nbt = rm0.clone(), rv0.clone(), torch.tensor(3, dtype=torch.int64).cuda()
+    mean, rstd = ops.bn_finalize(sums, N * HW, C, 1e-5, 0.1, rm, rv)
+    ops.counters_add([nbt], 1)
+    y = torch.empty_like(x)
+    check(lib.cruse_bn_nchw_fwd(_p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(slope), 2, N, C, HW, _p(y), 1, _stream()))
+    for nrep in (1, 8):
+        s_in = sums.clone() if nrep == 1 else torch.cat([sums.view(1, -1) * f for f in (0.5, 0.25, 0.125, 0.125, 0, 0, 0, 0)]).contiguous()
+        rm2, rv2, nbt2 = rm0.clone(), rv0.clone(), torch.tensor(3, dtype=torch.int64).cuda()
+        y2, mean2, rstd2 = torch.empty_like(x), torch.empty(C).cuda(), torch.empty(C).cuda()
+        check(lib.cruse_bn_nchw_fwd_train(_p(x), _p(s_in), nrep, 1e-5, 0.1, _p(gamma), _p(beta), _p(slope), 2, N, C, HW, _p(y2), _p(mean2), _p(rstd2),
+                                          _p(rm2), _p(rv2), _p(nbt2), 1, _stream()))
+        assert torch.equal(y, y2) and torch.equal(mean, mean2) and torch.equal(rstd, rstd2), nrep
+        assert torch.allclose(rm, rm2, rtol=1e-6, atol=1e-7) and torch.allclose(rv, rv2, rtol=1e-6, atol=1e-7) and int(nbt2) == int(nbt) == 4
+    # backward
+    out = {}
+    for ex in (False, True):
+        dx = torch.empty_like(x)
+        scratch = torch.zeros(4 * C, dtype=torch.float64).cuda()
+        dg, db, ds, dxs = (torch.zeros(C).cuda() for _ in range(4))
+        if ex:
+            check(lib.cruse_bn_nchw_bwd_ex(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(slope), 2, 1, N, C, HW, _p(scratch), 1, _p(dx),
+                                           _p(dg), _p(db), _p(ds), _p(dxs), 1, _stream()))
+        else:
+            check(lib.cruse_bn_nchw_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(slope), 2, 1, N, C, HW, _p(scratch), _p(dx),
+                                        _p(dg), _p(db), _p(ds), 1, _stream()))
+        out[ex] = (dx, dg, db, ds, dxs)
+    assert torch.equal(out[False][0], out[True][0])
+    for i in (1, 2, 3):
+        assert torch.allclose(out[False][i], out[True][i], rtol=1e-5, atol=1e-5), i
+    dxd = out[True][0].double()
+    # the stored dx are f16: their sum scatters around the exact one by ~2^-11 |dx| sqrt(n); the closed form is the exact one
+    noise = dxd.abs().sum((0, 2, 3)) * 2.0 ** -11 / (N * HW) ** 0.5 * 8 + 1e-4
+    assert ((out[True][4].double() - dxd.sum((0, 2, 3))).abs() <= noise).all()
+
+
+def test_pointwise_wgrad_ex_delivers_the_bias_gradient():
+    """cruse_conv2d_nchw_wgrad_ex: dw as cruse_conv2d_nchw_wgrad, db = channel sums of dy -- inside the pointwise MFMA kernel (24 channels: a spare
+    tile column carries the constant 1) and by the channel-sum pass where that kernel does not run (32 channels: no spare column; 3x3)."""
+    from cruse_amd.nn_generic import _wgrad_raw
+    torch.manual_seed(9)
+    for C, K in ((24, 1), (32, 1), (8, 3)):
+        B, H, W = 3, 9, 41
+        x = torch.randn(B, C, H, W).cuda().half()
+        dy = torch.randn(B, C, H, W).cuda().half()
+        dw0, dw1, db = torch.zeros(C, C, K, K).cuda(), torch.zeros(C, C, K, K).cuda(), torch.zeros(C).cuda()
+        p = K // 2
+        _wgrad_raw(dy, x, dw0, K, K, (1, 1), (1, 1), p, p, 1, 1)
+        _wgrad_raw(dy, x, dw1, K, K, (1, 1), (1, 1), p, p, 1, 1, db=db)
+        assert torch.allclose(dw0, dw1, rtol=1e-5, atol=1e-4), (C, K)
+        assert torch.allclose(db.double(), dy.double().sum((0, 2, 3)), rtol=1e-5, atol=1e-3), (C, K)
+
+
 def test_gemm_f16_operand_mode():
     """CRUSE_PREC_F16: Frag<> on v_mfma_f32_16x16x32_f16 (operands rounded to f16, f32 accumulate), all four transpose forms,
     against the same product of f16-ROUNDED operands in f64 (exact up to the f32 accumulation order)."""
