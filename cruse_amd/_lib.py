@@ -102,7 +102,8 @@ SIGNATURES = {
     "cruse_bn_nchw_stats": ("piiipip", "i"),
     "cruse_bn_nchw_fwd": ("ppppppiiiipip", "i"),
     "cruse_bn_nchw_bwd": ("pppppppiiiiipppppip", "i"),
-    "cruse_bn_nchw_bwd_ex": ("pppppppiiiiipipppppip", "i"),
+    "cruse_bn_nchw_bwd_ex": ("pppppppiiiiipiipppppip", "i"),
+    "cruse_conv2d_nchw_bnbwd": ("ppp" + "iiiiiii" + "iiiiiiii" + "ii" + "pppppp" + "i" + "pip" + "ip", "i"),
     "cruse_bn_nchw_stats_ex": ("piiipiip", "i"),
     "cruse_bn_nchw_fwd_train": ("ppiffpppiiiippppppip", "i"),
     "cruse_conv2d_nchw_ex": ("ppppp" + "iiiiiii" + "iiiiiiii" + "iiii" + "p" + "pi" + "ip", "i"),

@@ -27,6 +27,11 @@ template <typename T> struct GConv {
     // rep = block % bn_nrep (sum, then sum of squares) -- what cruse_bn_nchw_stats would read back from y
     double* bn_sums; int bn_nrep;
     const T* res;                          // optional (f16 LDS-transposed pointwise kernel): y = T(T(conv) + res), the residual add of a block
+    // optional (same two f16 kernels): y is the gradient wrt the OUTPUT of a BatchNorm (+ act) whose input is bb_x -- the epilogue accumulates that
+    // BatchNorm's backward sums of the stored y, bb_r[rep][4][Cout] f64: sum d, sum d xhat, sum d z [z < 0] (PReLU slope), sum xhat with
+    // d = y act'(z), z = gamma xhat + beta -- what cruse_bn_nchw_bwd's reduce pass would read y and bb_x again for
+    const T* bb_x; const float* bb_mean; const float* bb_rstd; const float* bb_gamma; const float* bb_beta; const float* bb_slope;
+    int bb_act; double* bb_r; int bb_nrep;
 };
 
 // transposed == 0 (nn.Conv2d, weight [Cout][Cin/g][KH][KW]; also the data gradient of a ConvTranspose2d):
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(256) void gconv_pointwise_mfma_f16_kernel(GConv<f16
 // group reads a [4 ci][16 positions] block, lane c gets the four ci of position c); the product runs with the roles swapped
 // (D^T[p][co] = x^T W^T: a lane then owns FOUR CONSECUTIVE positions of one output channel = one 8-byte LDS write), and the output rows
 // [co][64 positions] leave through 16-byte stores.  No block barrier: the four waves of a block share nothing.
-template <int MT, int KS>
+template <int MT, int KS, int EPI>      // EPI: 0 plain, 1 BatchNorm batch sums of the output (a.bn_sums), 2 BatchNorm-backward sums (a.bb_r)
 __global__ __launch_bounds__(256) void gconv_pointwise_tr_f16_kernel(GConv<f16> a) {
     constexpr int ROWB = 144;                                 // bytes per LDS row: 64 positions + 16 (rows 4 apart land on different banks)
     constexpr int KR = KS * 32, MR = MT * 16;
@@ -295,8 +300,9 @@ __global__ __launch_bounds__(256) void gconv_pointwise_tr_f16_kernel(GConv<f16> 
         }
     };
     float st1[MR / 8], st2[MR / 8];                            // BatchNorm sums of this lane's output rows (co = it * 8 + rr)
+    float bq[MR / 8][4];                                       // ... / BatchNorm-backward sums (a.bb_r)
 #pragma unroll
-    for (int it = 0; it < MR / 8; ++it) { st1[it] = 0.f; st2[it] = 0.f; }
+    for (int it = 0; it < MR / 8; ++it) { st1[it] = 0.f; st2[it] = 0.f; bq[it][0] = bq[it][1] = bq[it][2] = bq[it][3] = 0.f; }
     const long long ch0 = (long long)blockIdx.x * 4 + wv, chs = (long long)gridDim.x * 4;
     if (ch0 < total) fetch(ch0);
     for (long long ch = ch0; ch < total; ch += chs) {
@@ -362,10 +368,34 @@ __global__ __launch_bounds__(256) void gconv_pointwise_tr_f16_kernel(GConv<f16> 
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (f16)((float)v[e] + (float)r8[e]);
                 }
-                if (a.bn_sums != nullptr) {
+                if constexpr (EPI == 1) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
                         if (e < valid) { const float u = (float)v[e]; st1[it] += u; st2[it] += u * u; }
+                }
+                if constexpr (EPI == 2) {
+                    const f16* xq = a.bb_x + (long long)b * a.Cout * hw + pos + (long long)co * hw;
+                    f16x8 x8 = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (valid == 8) __builtin_memcpy(&x8, xq, 16);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (e < valid) x8[e] = xq[e];
+                    }
+                    const float m_ = a.bb_mean[co], rs_ = a.bb_rstd[co], ga_ = a.bb_gamma[co], be_ = a.bb_beta[co];
+                    const float sl_ = a.bb_act == 2 ? a.bb_slope[co] : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if (e < valid) {
+                            const float xh = ((float)x8[e] - m_) * rs_;
+                            const float z = xh * ga_ + be_;
+                            float d = (float)v[e];
+                            if (a.bb_act == 1) d = z > 0.f ? d : 0.f;
+                            else if (a.bb_act == 2) { if (z < 0.f) { bq[it][2] += d * z; d *= sl_; } }
+                            else if (a.bb_act == 3) { const float sg = 1.f / (1.f + expf(-z)); d *= sg * (1.f - sg); }
+                            bq[it][0] += d; bq[it][1] += d * xh; bq[it][3] += xh;
+                        }
+                    }
                 }
                 f16* q = yb + (long long)co * hw;
                 if (valid == 8) __builtin_memcpy(q, &v, 16);
@@ -379,7 +409,7 @@ __global__ __launch_bounds__(256) void gconv_pointwise_tr_f16_kernel(GConv<f16> 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    if (a.bn_sums != nullptr) {                                // 8 lanes share a row; 4 waves share the block: one f64 atomic per channel, sum and block
+    if constexpr (EPI == 1) {                                // 8 lanes share a row; 4 waves share the block: one f64 atomic per channel, sum and block
         __shared__ float bred[4][2][MR];
 #pragma unroll
         for (int it = 0; it < MR / 8; ++it) {
@@ -394,6 +424,26 @@ __global__ __launch_bounds__(256) void gconv_pointwise_tr_f16_kernel(GConv<f16> 
             if (co < a.Cout) {
                 const double t = (double)bred[0][which][co] + (double)bred[1][which][co] + (double)bred[2][which][co] + (double)bred[3][which][co];
                 atomicAdd(a.bn_sums + (size_t)(blockIdx.x % a.bn_nrep) * 2 * a.Cout + which * a.Cout + co, t);
+            }
+        }
+    }
+    if constexpr (EPI == 2) {
+        __shared__ float bred4[4][4][MR];
+#pragma unroll
+        for (int it = 0; it < MR / 8; ++it)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float u = bq[it][k];
+#pragma unroll
+                for (int o = 1; o < 8; o <<= 1) u += __shfl_xor(u, o, 64);
+                if (ck == 0) bred4[wv][k][it * 8 + rr] = u;
+            }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 4 * MR; i += 256) {
+            const int which = i / MR, co = i - which * MR;
+            if (co < a.Cout) {
+                const double t = (double)bred4[0][which][co] + (double)bred4[1][which][co] + (double)bred4[2][which][co] + (double)bred4[3][which][co];
+                atomicAdd(a.bb_r + (size_t)(blockIdx.x % a.bb_nrep) * 4 * a.Cout + which * a.Cout + co, t);
             }
         }
     }
@@ -528,6 +578,9 @@ __global__ __launch_bounds__(256) void gconv_depthwise_f16_kernel(GConv<f16> a, 
     const float slope = a.act == 2 ? a.slope[c] : 0.f;
     f16* yp = a.y + ((long long)plane * a.Hout + r0) * a.Wout;
     float bn1 = 0.f, bn2 = 0.f;                                        // BatchNorm sums of the stored outputs (a.bn_sums)
+    float bq0 = 0.f, bq1 = 0.f, bq2 = 0.f, bq3 = 0.f;                  // BatchNorm-backward sums (a.bb_r)
+    const float bm_ = a.bb_r ? a.bb_mean[c] : 0.f, brs_ = a.bb_r ? a.bb_rstd[c] : 1.f, bga_ = a.bb_r ? a.bb_gamma[c] : 1.f, bbe_ = a.bb_r ? a.bb_beta[c] : 0.f;
+    const float bsl_ = (a.bb_r && a.bb_act == 2) ? a.bb_slope[c] : 0.f;
     __syncthreads();
     for (int q = threadIdx.x; q < nr * g.gpr; q += 256) {
         const int hr = q / g.gpr, wo = (q - hr * g.gpr) * 8;
@@ -560,6 +613,32 @@ __global__ __launch_bounds__(256) void gconv_depthwise_f16_kernel(GConv<f16> a, 
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 if (e < valid) { const float u = (float)(f16)acc[e]; bn1 += u; bn2 += u * u; }
+        }
+        if (a.bb_r != nullptr) {
+            float xv[8];
+            ld8_f16(a.bb_x + ((long long)plane * a.Hout + r0 + hr) * a.Wout + wo, valid, xv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (e < valid) {
+                    const float xh = (xv[e] - bm_) * brs_;
+                    const float z = xh * bga_ + bbe_;
+                    float d = (float)(f16)acc[e];
+                    if (a.bb_act == 1) d = z > 0.f ? d : 0.f;
+                    else if (a.bb_act == 2) { if (z < 0.f) { bq2 += d * z; d *= bsl_; } }
+                    else if (a.bb_act == 3) { const float sg = 1.f / (1.f + expf(-z)); d *= sg * (1.f - sg); }
+                    bq0 += d; bq1 += d * xh; bq3 += xh;
+                }
+            }
+        }
+    }
+    if (a.bb_r != nullptr) {
+        __shared__ float bred4[4][4];
+        bq0 = wave_sum(bq0); bq1 = wave_sum(bq1); bq2 = wave_sum(bq2); bq3 = wave_sum(bq3);
+        if ((threadIdx.x & 63) == 0) { const int w_ = threadIdx.x >> 6; bred4[0][w_] = bq0; bred4[1][w_] = bq1; bred4[2][w_] = bq2; bred4[3][w_] = bq3; }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            const double t = (double)bred4[threadIdx.x][0] + (double)bred4[threadIdx.x][1] + (double)bred4[threadIdx.x][2] + (double)bred4[threadIdx.x][3];
+            atomicAdd(a.bb_r + (size_t)((blockIdx.x + blockIdx.y) % a.bb_nrep) * 4 * a.Cout + threadIdx.x * a.Cout + c, t);
         }
     }
     if (a.bn_sums != nullptr) {                                        // one (image, channel) band per block: two f64 atomics
@@ -1201,25 +1280,36 @@ __global__ __launch_bounds__(256) void bn_nchw_bwd_reduce_f16v_kernel(const f16*
 // (r[3C + c] = sum of xhat, accumulated by the reduce pass), which would otherwise be a channel-sum pass over the dx just stored.
 __global__ __launch_bounds__(256) void bn_nchw_bwd_apply_f16v_kernel(const f16* dy, const f16* x, const float* mean, const float* rstd,
                                                                      const float* gamma, const float* beta, const float* slope, int act,
-                                                                     const double* r, double inv_count, int training, int C, int HW, f16* dx,
+                                                                     const double* rg, int nrep, double inv_count, int training, int C, int HW, f16* dx,
                                                                      float* dx_sum, int pg, float* dgamma, float* dbeta, float* dslope) {
     const int plane = blockIdx.y, c = plane % C;
     const int i = (blockIdx.x * 256 + threadIdx.x) * 8;
+    // the channel's four sums: rg is [nrep][4][C] when a convolution's epilogue delivered them (cruse_conv2d_nchw_bnbwd), else [4 or 3][C]
+    __shared__ double r[4];
+    if (threadIdx.x < 32) {           // lane = replica * 4 + sum: eight replicas load at once, three exchanges fold them
+        const int k = threadIdx.x & 3;
+        double t = 0.0;
+        if (nrep > 1) { for (int q = threadIdx.x >> 2; q < nrep; q += 8) t += rg[((size_t)q * 4 + k) * C + c]; }
+        else if (threadIdx.x < 4 && (k < 3 || dx_sum != nullptr)) t = rg[(size_t)k * C + c];
+        t += __shfl_xor(t, 4); t += __shfl_xor(t, 8); t += __shfl_xor(t, 16);
+        if (threadIdx.x < 4) r[k] = t;
+    }
+    __syncthreads();
     if (pg && blockIdx.x == 0 && plane < C && threadIdx.x == 0) {
-        if (dbeta) dbeta[c] += (float)r[c];
-        if (dgamma) dgamma[c] += (float)r[C + c];
-        if (dslope) dslope[c] += (float)r[2 * C + c];
+        if (dbeta) dbeta[c] += (float)r[0];
+        if (dgamma) dgamma[c] += (float)r[1];
+        if (dslope) dslope[c] += (float)r[2];
         if (dx_sum) {
             // sum over the channel of dx = ga rs (d - k1 - xh k2): the d and k1 terms cancel exactly, what is left is the rounding of the
             // mean in sum(xh) -- computed from the sums instead of re-reading the dx just stored (eval mode: ga rs sum(d))
             const double gr = mean ? (double)gamma[c] * (double)rstd[c] : 1.0;
-            dx_sum[c] += (float)((mean && training) ? -gr * (r[C + c] * inv_count) * r[3 * C + c] : gr * r[c]);
+            dx_sum[c] += (float)((mean && training) ? -gr * (r[1] * inv_count) * r[3] : gr * r[0]);
         }
     }
     if (i >= HW) return;
     const float m = mean ? mean[c] : 0.f, rs = mean ? rstd[c] : 1.f, ga = mean ? gamma[c] : 1.f, be = mean ? beta[c] : 0.f;
     const float sl = act == 2 ? slope[c] : 0.f;
-    const float k1 = (mean && training) ? (float)(r[c] * inv_count) : 0.f, k2 = (mean && training) ? (float)(r[C + c] * inv_count) : 0.f;
+    const float k1 = (mean && training) ? (float)(r[0] * inv_count) : 0.f, k2 = (mean && training) ? (float)(r[1] * inv_count) : 0.f;
     const long long o = (long long)plane * HW + i;
     float xv[8], dv[8];
     ld8_f16(x + o, HW - i, xv);
@@ -1310,11 +1400,18 @@ template <typename T>
 int conv2d_nchw_t(const void* x, const float* w, const float* bias, void* y, int B, int Cin, int Hin, int Win, int Cout, int Hout,
                   int Wout, int KH, int KW, int sh, int sw, int dh, int dw, int pt, int pl, int groups, int up_w, int transposed,
                   int act, const float* slope, int accumulate, hipStream_t s, double* bn_sums = nullptr, int bn_nrep = 1,
-                  bool* bn_done = nullptr, const void* res = nullptr, bool* res_done = nullptr) {
+                  bool* bn_done = nullptr, const void* res = nullptr, bool* res_done = nullptr, const GConv<T>* bb = nullptr, bool* bb_done = nullptr) {
     GConv<T> a = {(const T*)x, w, bias, (T*)y, B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, sh, sw, dh, dw, pt, pl, groups, up_w,
                   transposed, act, accumulate, slope, nullptr, 1, nullptr};
     if (bn_done) *bn_done = false;
     if (res_done) *res_done = false;
+    if (bb_done) *bb_done = false;
+    auto set_bb = [&]() {
+        if (bb == nullptr) return;
+        a.bb_x = bb->bb_x; a.bb_mean = bb->bb_mean; a.bb_rstd = bb->bb_rstd; a.bb_gamma = bb->bb_gamma; a.bb_beta = bb->bb_beta; a.bb_slope = bb->bb_slope;
+        a.bb_act = bb->bb_act; a.bb_r = bb->bb_r; a.bb_nrep = bb->bb_nrep;
+        *bb_done = true;
+    };
     const bool pointwise = KH == 1 && KW == 1 && sh == 1 && sw == 1 && pt == 0 && pl == 0 && groups == 1 && up_w == 1 &&
                            Hout == Hin && Wout == Win;
     if constexpr (sizeof(T) == 2) {
@@ -1329,11 +1426,15 @@ int conv2d_nchw_t(const void* x, const float* w, const float* bias, void* y, int
             const size_t lds = (size_t)4 * (ksc * 32 + mtc * 16) * 144;
             if (bn_sums) { a.bn_sums = bn_sums; a.bn_nrep = bn_nrep; *bn_done = true; }
             if (res) { a.res = (const T*)res; *res_done = true; }
-#define PWT_CASE(mt, ks) do { int rc = cruse_ensure_dyn_lds((const void*)gconv_pointwise_tr_f16_kernel<mt, ks>, lds, "conv2d_nchw pointwise"); \
+            set_bb();
+            const int epi = a.bb_r ? 2 : (a.bn_sums ? 1 : 0);                                // (never both: the sums of the output / of the BatchNorm in front of a data gradient)
+#define PWT_LAUNCH(mt, ks, ep) do { int rc = cruse_ensure_dyn_lds((const void*)gconv_pointwise_tr_f16_kernel<mt, ks, ep>, lds, "conv2d_nchw pointwise"); \
                 if (rc) return rc; \
-                hipLaunchKernelGGL((gconv_pointwise_tr_f16_kernel<mt, ks>), dim3(nb), dim3(256), lds, s, a); } while (0)
+                hipLaunchKernelGGL((gconv_pointwise_tr_f16_kernel<mt, ks, ep>), dim3(nb), dim3(256), lds, s, a); } while (0)
+#define PWT_CASE(mt, ks) do { if (epi == 0) PWT_LAUNCH(mt, ks, 0); else if (epi == 1) PWT_LAUNCH(mt, ks, 1); else PWT_LAUNCH(mt, ks, 2); } while (0)
             if (mtc == 1 && ksc == 1) PWT_CASE(1, 1); else if (mtc == 1) PWT_CASE(1, 2); else if (ksc == 1) PWT_CASE(2, 1); else PWT_CASE(2, 2);
 #undef PWT_CASE
+#undef PWT_LAUNCH
             CRUSE_LAUNCH_CHECK("conv2d_nchw pointwise mfma f16 (LDS-transposed)");
             return CRUSE_OK;
         }
@@ -1375,6 +1476,7 @@ int conv2d_nchw_t(const void* x, const float* w, const float* bias, void* y, int
                 int rc = cruse_ensure_dyn_lds((const void*)gconv_depthwise_f16_kernel, lds, "conv2d_nchw depthwise");
                 if (rc) return rc;
                 if (bn_sums) { a.bn_sums = bn_sums; a.bn_nrep = bn_nrep; *bn_done = true; }
+                set_bb();
                 hipLaunchKernelGGL(gconv_depthwise_f16_kernel, dim3(cdiv(Hout, g.RB), B * Cout), dim3(256), lds, s, a, tt, g);
                 CRUSE_LAUNCH_CHECK("conv2d_nchw depthwise (f16, LDS image)");
                 return CRUSE_OK;
@@ -1471,20 +1573,23 @@ namespace {
 template <typename T>
 int bn_nchw_bwd_t(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                   const float* slope, int act, int training, int N, int C, int HW, double* scratch, void* dx, float* dgamma,
-                  float* dbeta, float* dslope, hipStream_t s, float* dx_sum = nullptr) {
+                  float* dbeta, float* dslope, hipStream_t s, float* dx_sum = nullptr, int reduce_done = 0, int r_nrep = 1) {
     const long long total = (long long)N * C * HW;
     if constexpr (sizeof(T) == 2) {
         if ((long long)N * C < 65536) {                      // (grid.y = planes)
-            hipLaunchKernelGGL(bn_nchw_bwd_reduce_f16v_kernel, dim3(C, N < 32 ? N : 32, zchunks(C, N < 32 ? N : 32, HW)), dim3(256), 0, s, (const f16*)dy,
-                               (const f16*)x, mean, rstd, gamma, beta, slope, act, N, C, HW, scratch, dx_sum != nullptr ? 1 : 0);
-            CRUSE_LAUNCH_CHECK("bn_nchw_bwd_reduce");
+            if (!reduce_done) {
+                hipLaunchKernelGGL(bn_nchw_bwd_reduce_f16v_kernel, dim3(C, N < 32 ? N : 32, zchunks(C, N < 32 ? N : 32, HW)), dim3(256), 0, s, (const f16*)dy,
+                                   (const f16*)x, mean, rstd, gamma, beta, slope, act, N, C, HW, scratch, dx_sum != nullptr ? 1 : 0);
+                CRUSE_LAUNCH_CHECK("bn_nchw_bwd_reduce");
+            }
             hipLaunchKernelGGL(bn_nchw_bwd_apply_f16v_kernel, dim3(cdiv(cdiv(HW, 8), 256), N * C), dim3(256), 0, s, (const f16*)dy, (const f16*)x, mean, rstd,
-                               gamma, beta, slope, act, scratch, 1.0 / ((double)N * HW), training, C, HW, (f16*)dx, dx_sum, 1,
+                               gamma, beta, slope, act, scratch, reduce_done ? r_nrep : 1, 1.0 / ((double)N * HW), training, C, HW, (f16*)dx, dx_sum, 1,
                                mean ? dgamma : nullptr, mean ? dbeta : nullptr, act == 2 ? dslope : nullptr);
             CRUSE_LAUNCH_CHECK("bn_nchw_bwd_apply");
             return CRUSE_OK;
         }
     }
+    if (reduce_done) { cruse_set_error("bn_nchw_bwd_ex: sums delivered by a convolution come with the f16 kernels only"); return CRUSE_E_SHAPE; }
     hipLaunchKernelGGL(bn_nchw_bwd_reduce_kernel<T>, dim3(C, N < 32 ? N : 32, zchunks(C, N < 32 ? N : 32, HW)), dim3(256), 0, s, (const T*)dy, (const T*)x, mean, rstd,
                        gamma, beta, slope, act, N, C, HW, scratch);
     CRUSE_LAUNCH_CHECK("bn_nchw_bwd_reduce");
@@ -1522,6 +1627,37 @@ extern "C" int cruse_conv2d_nchw(const void* x, const float* w, const float* bia
 extern "C" int cruse_bn_nchw_stats_ex(const void* x, int N, int C, int HW, double* sums, int zeroed, int dtype, void* stream);
 
 extern "C" int cruse_add_nchw(const void* a, const void* b, void* out, long long n, int dtype, void* stream);
+
+// cruse_conv2d_nchw (no bias, no activation, no accumulation) whose output y is the GRADIENT wrt the output of a BatchNorm2d (+ act) with input
+// bn_x (the data gradient of the convolution that consumed that BatchNorm's output): the f16 pointwise / depthwise kernels also accumulate that
+// BatchNorm's backward sums of the stored y into r[r_nrep][4][Cout] f64 (cleared by the caller; cruse_bn_nchw_bwd_ex(sums_replicas = r_nrep) then
+// skips its reduce pass over y and bn_x).  Returns *delivered = 0 when the form that ran has no such epilogue (the caller runs the plain backward).
+extern "C" int cruse_conv2d_nchw_bnbwd(const void* x, const float* w, void* y,
+                                       int B, int Cin, int Hin, int Win, int Cout, int Hout, int Wout,
+                                       int KH, int KW, int sh, int sw, int dh, int dw, int pt, int pl, int groups, int transposed,
+                                       const void* bn_x, const float* bn_mean, const float* bn_rstd, const float* bn_gamma, const float* bn_beta,
+                                       const float* bn_slope, int bn_act, double* r, int r_nrep, int* delivered, int dtype, void* stream) {
+    CRUSE_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, CRUSE_E_SHAPE, "conv2d_nchw_bnbwd: bad shape");
+    CRUSE_REQUIRE(KH > 0 && KW > 0 && sh > 0 && sw > 0 && dh > 0 && dw > 0 && groups > 0 && Cin % groups == 0 && Cout % groups == 0, CRUSE_E_SHAPE,
+                  "conv2d_nchw_bnbwd: bad kernel geometry");
+    CRUSE_REQUIRE(bn_x && bn_mean && bn_rstd && bn_gamma && bn_beta && bn_act >= 0 && bn_act <= 3 && (bn_act != 2 || bn_slope) && r && r_nrep >= 1 && delivered,
+                  CRUSE_E_SHAPE, "conv2d_nchw_bnbwd: BatchNorm arguments");
+    CRUSE_DT_CHECK("conv2d_nchw_bnbwd");
+    bool done = false;
+    int rc;
+    if (dtype == CRUSE_DT_F16) {
+        GConv<f16> bb = {};
+        bb.bb_x = (const f16*)bn_x; bb.bb_mean = bn_mean; bb.bb_rstd = bn_rstd; bb.bb_gamma = bn_gamma; bb.bb_beta = bn_beta; bb.bb_slope = bn_slope;
+        bb.bb_act = bn_act; bb.bb_r = r; bb.bb_nrep = r_nrep;
+        rc = conv2d_nchw_t<f16>(x, w, nullptr, y, B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, sh, sw, dh, dw, pt, pl, groups, 1, transposed, 0, nullptr,
+                                0, ST(stream), nullptr, 1, nullptr, nullptr, nullptr, &bb, &done);
+    } else {
+        rc = conv2d_nchw_t<float>(x, w, nullptr, y, B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, sh, sw, dh, dw, pt, pl, groups, 1, transposed, 0, nullptr,
+                                  0, ST(stream));
+    }
+    *delivered = done ? 1 : 0;
+    return rc;
+}
 
 // cruse_conv2d_nchw (no accumulation) with the two things that follow a convolution in the reference's blocks folded in (both optional):
 //   residual != NULL: y = conv(x) + residual (TFCM_Block's `outs + inps`, mtfaa.py:191) -- in the epilogue of the f16 LDS-transposed pointwise
@@ -1682,10 +1818,15 @@ extern "C" int cruse_bn_nchw_bwd(const void* dy, const void* x, const float* mea
 // front of the BatchNorm (nn.Conv2d -> nn.BatchNorm2d -> act: mtfaa.py:166-193, cust_conv.py:15-111) without a channel-sum pass over dx
 extern "C" int cruse_bn_nchw_bwd_ex(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                                     const float* beta, const float* slope, int act, int training, int N, int C, int HW,
-                                    double* scratch, int scratch_zeroed, void* dx, float* dgamma, float* dbeta, float* dslope, float* dx_sum,
-                                    int dtype, void* stream) {
-    CRUSE_REQUIRE(N > 0 && C > 0 && HW > 0 && act >= 0 && act <= 3 && (act != 2 || slope), CRUSE_E_SHAPE, "bn_nchw_bwd_ex: bad arguments");
+                                    double* scratch, int scratch_zeroed, int sums_replicas, void* dx, float* dgamma, float* dbeta, float* dslope,
+                                    float* dx_sum, int dtype, void* stream) {
+    CRUSE_REQUIRE(N > 0 && C > 0 && HW > 0 && act >= 0 && act <= 3 && (act != 2 || slope) && sums_replicas >= 0, CRUSE_E_SHAPE, "bn_nchw_bwd_ex: bad arguments");
     CRUSE_DT_CHECK("bn_nchw_bwd_ex");
+    if (sums_replicas > 0) {       // scratch = [sums_replicas][4][C], ALREADY FILLED by cruse_conv2d_nchw_bnbwd: the reduce pass is skipped
+        CRUSE_REQUIRE(dtype == CRUSE_DT_F16 && (long long)N * C < 65536, CRUSE_E_SHAPE, "bn_nchw_bwd_ex: delivered sums come with the f16 kernels");
+        return bn_nchw_bwd_t<f16>(dy, x, mean, rstd, gamma, beta, slope, act, training, N, C, HW, scratch, dx, dgamma, dbeta, dslope, ST(stream), dx_sum, 1,
+                                  sums_replicas);
+    }
     if (!scratch_zeroed) { int rc = cruse_zero_async(scratch, 4 * (size_t)C * sizeof(double), ST(stream), "bn_nchw_bwd_ex"); if (rc) return rc; }
     if (dtype == CRUSE_DT_F16)
         return bn_nchw_bwd_t<f16>(dy, x, mean, rstd, gamma, beta, slope, act, training, N, C, HW, scratch, dx, dgamma, dbeta, dslope, ST(stream), dx_sum);

@@ -11,6 +11,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
 
+import ctypes
+
 import torch
 import torch.nn as nn
 
@@ -181,6 +183,28 @@ def _take_bn_sums(x):
     return None
 
 
+# ... and backwards again: a convolution whose input came out of a training-mode BatchNorm (+ act) computes, in its data-gradient kernel's
+# epilogue, that BatchNorm's backward sums (cruse_conv2d_nchw_bnbwd) -- the BatchNorm's forward leaves what that takes under its output's
+# address (_BN_OUT), the convolution's backward leaves the sums under its input gradient's address (_BN_R)
+_BN_OUT = {}
+_BN_R = {}
+BN_BWD_REPLICAS = 8
+
+
+def _stash(table, key_tensor, payload):
+    if len(table) >= 8:
+        table.clear()
+    table[key_tensor.data_ptr()] = (key_tensor, key_tensor._version, payload)       # holding the tensor keeps its address from being reused
+
+
+def _take(table, t):
+    # the version is the one at stash time: a gradient autograd accumulated into in place is the same tensor, but no longer what the sums describe
+    ent = table.pop(t.data_ptr(), None)
+    if ent is not None and ent[0].shape == t.shape and ent[0].dtype == t.dtype and ent[1] == t._version:
+        return ent[2]
+    return None
+
+
 def _channel_sum(dy, out):
     N, C = dy.shape[:2]
     check(lib.cruse_nchw_channel_sum(_p(dy), N, C, dy[0, 0].numel(), _p(out), _dt(dy), _stream()))
@@ -209,6 +233,7 @@ class _ConvFn(torch.autograd.Function):
             _stash_bn_sums(y, sums)
         ctx.save_for_backward(x, w)
         ctx.cfg, ctx.has_bias, ctx.has_res = cfg, bias is not None, res is not None
+        ctx.bn_src = _take(_BN_OUT, x) if (x.dtype == torch.float16 and up_w == 1) else None
         ctx.tap = len(cfg) > 9 and cfg[9]
         if ctx.tap:
             # the input handed on beside the output: a block that ALSO adds its input to its result (TFCM_Block) takes the residual from here,
@@ -232,7 +257,19 @@ class _ConvFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             fold = dtap if (dtap is not None and up_w == 1) else None           # the tapped input's gradient rides the data-gradient kernel
-            if not transposed:
+            if ctx.bn_src is not None and fold is None and up_w == 1:
+                # the input was a BatchNorm (+ act) output: the data-gradient kernel also delivers that BatchNorm's backward sums
+                bx, bmean, brstd, bgamma, bbeta, bslope, bact = ctx.bn_src
+                dx = torch.empty_like(x)
+                r = _zeros_f64((BN_BWD_REPLICAS, 4, Cin), x.device)
+                got = ctypes.c_int(0)
+                check(lib.cruse_conv2d_nchw_bnbwd(_p(dy), _p(w), _p(dx), B, dy.shape[1], dy.shape[2], dy.shape[3], Cin, Hin, Win, KH, KW, stride[0],
+                                                  stride[1], dil[0], dil[1], pt, pl, groups, 0 if transposed else 1, _p(bx), _p(bmean), _p(brstd),
+                                                  _p(bgamma), _p(bbeta), _p(bslope), bact, _p(r), BN_BWD_REPLICAS, ctypes.addressof(got), _dt(x),
+                                                  _stream()))
+                if got.value:
+                    _stash(_BN_R, dx, r)
+            elif not transposed:
                 dxu = _conv_raw(dy, w, None, (Hin, Win * up_w), KH, KW, stride, dil, pt, pl, groups, 1, True, Cin, residual=fold)
                 if up_w > 1:
                     dx = torch.empty_like(x)
@@ -337,6 +374,8 @@ class _BnTrainActFn(torch.autograd.Function):
                                           _p(mean), _p(rstd), _p(rmean), _p(rvar), _p(nbt), _dt(x), _stream()))
         ctx.save_for_backward(x, gamma, beta, slope, mean, rstd)
         ctx.act, ctx.want_dx_sum = act, bool(want_dx_sum)
+        if x.dtype == torch.float16:
+            _stash(_BN_OUT, y, (x, mean, rstd, gamma, beta, slope, act))
         return y
 
     @staticmethod
@@ -348,13 +387,14 @@ class _BnTrainActFn(torch.autograd.Function):
         N, C = x.shape[:2]
         HW = x[0, 0].numel()
         dx = torch.empty_like(x)
-        scratch = _zeros_f64((4 * C,), x.device)
+        delivered = _take(_BN_R, dy)                       # the producer of dy has already formed the sums (see _BN_OUT / _BN_R)
+        scratch = delivered if delivered is not None else _zeros_f64((4 * C,), x.device)
         dg = _zeros_f32((C,), x.device)
         db = _zeros_f32((C,), x.device)
         ds = _zeros_f32((C,), x.device) if slope is not None else None
         dxs = _zeros_f32((C,), x.device) if ctx.want_dx_sum else None
         check(lib.cruse_bn_nchw_bwd_ex(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(slope), ctx.act, 1, N, C, HW, _p(scratch), 1,
-                                       _p(dx), _p(dg), _p(db), _p(ds), _p(dxs), _dt(x), _stream()))
+                                       delivered.shape[0] if delivered is not None else 0, _p(dx), _p(dg), _p(db), _p(ds), _p(dxs), _dt(x), _stream()))
         if dxs is not None:
             _stash_dx_sum(dx, dxs)
         return dx, dg, db, ds, None, None, None, None, None, None, None, None

@@ -569,8 +569,19 @@ int cruse_conv2d_nchw_ex(const void* x, const float* w, const float* bias, const
                          double* bn_sums, int bn_nrep, int dtype, void* stream);
 int cruse_bn_nchw_bwd_ex(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                          const float* beta, const float* slope, int act, int training, int N, int C, int HW,
-                         double* scratch, int scratch_zeroed, void* dx, float* dgamma, float* dbeta, float* dslope, float* dx_sum, int dtype,
-                         void* stream);
+                         double* scratch, int scratch_zeroed, int sums_replicas, void* dx, float* dgamma, float* dbeta, float* dslope, float* dx_sum,
+                         int dtype, void* stream);
+/* The data gradient of a convolution whose INPUT was a BatchNorm2d (+ act) output: y = conv(x) (no bias / act / accumulation) is the gradient wrt that
+ * output; the f16 pointwise-MFMA / LDS-depthwise kernels also accumulate the BatchNorm's backward sums of the stored y against bn_x (its input) into
+ * r [r_nrep][4][Cout] f64 (cleared by the caller): cruse_bn_nchw_bwd_ex(scratch = r, sums_replicas = r_nrep) then skips its reduce pass.
+ * *delivered = 0: the form that ran has no such epilogue -- run the plain backward (sums_replicas = 0).
+ * Replaces autograd's conv_backward(input) + the reduction half of batch_norm_backward for nn.Conv2d after nn.BatchNorm2d + nn.PReLU
+ * (TFCM_Block, mtfaa.py:170-183; Conv2dNormAct, cust_conv.py:15-111). */
+int cruse_conv2d_nchw_bnbwd(const void* x, const float* w, void* y,
+                            int B, int Cin, int Hin, int Win, int Cout, int Hout, int Wout,
+                            int KH, int KW, int sh, int sw, int dh, int dw, int pt, int pl, int groups, int transposed,
+                            const void* bn_x, const float* bn_mean, const float* bn_rstd, const float* bn_gamma, const float* bn_beta,
+                            const float* bn_slope, int bn_act, double* r, int r_nrep, int* delivered, int dtype, void* stream);
 /* cruse_bn_nchw_stats into sums the caller cleared itself (zeroed != 0; like scratch_zeroed above: one fill launch per pool chunk of
  * accumulators instead of one per call) */
 int cruse_bn_nchw_stats_ex(const void* x, int N, int C, int HW, double* sums, int zeroed, int dtype, void* stream);

@@ -778,7 +778,7 @@ def test_batchnorm_nchw_fused_train_forward_and_backward_ex():
         scratch = torch.zeros(4 * C, dtype=torch.float64).cuda()
         dg, db, ds, dxs = (torch.zeros(C).cuda() for _ in range(4))
         if ex:
-            check(lib.cruse_bn_nchw_bwd_ex(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(slope), 2, 1, N, C, HW, _p(scratch), 1, _p(dx),
+            check(lib.cruse_bn_nchw_bwd_ex(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(slope), 2, 1, N, C, HW, _p(scratch), 1, 0, _p(dx),
                                            _p(dg), _p(db), _p(ds), _p(dxs), 1, _stream()))
         else:
             check(lib.cruse_bn_nchw_bwd(_p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(slope), 2, 1, N, C, HW, _p(scratch), _p(dx),
@@ -791,6 +791,62 @@ def test_batchnorm_nchw_fused_train_forward_and_backward_ex():
     # the stored dx are f16: their sum scatters around the exact one by ~2^-11 |dx| sqrt(n); the closed form is the exact one
     noise = dxd.abs().sum((0, 2, 3)) * 2.0 ** -11 / (N * HW) ** 0.5 * 8 + 1e-4
     assert ((out[True][4].double() - dxd.sum((0, 2, 3))).abs() <= noise).all()
+
+
+def test_data_gradient_conv_delivers_the_batchnorm_backward_sums():
+    """cruse_conv2d_nchw_bnbwd: the data gradient of a pointwise / depthwise convolution that follows BatchNorm (+PReLU) equals the plain convolution's,
+    and the four sums it leaves ([nrep][4][C]: sum d, sum d xh, sum d z[z<0], sum xh) make cruse_bn_nchw_bwd_ex (sums_replicas = nrep) produce
+    the dx bits and parameter gradients of the pass that reduces them itself."""
+    import ctypes
+    from cruse_amd import ops
+    from cruse_amd._lib import check, lib
+    from cruse_amd.nn_generic import _conv_raw
+    from cruse_amd.ops import _p, _stream
+    torch.manual_seed(11)
+    N, C, H, W = 3, 24, 10, 77
+    HW = H * W
+    NREP = 8
+    for kind in ("pointwise", "depthwise"):
+        xb = (torch.randn(N, C, H, W) * 1.2 + 0.3).cuda().half()           # the BatchNorm's input
+        gamma, beta, slope = (1 + 0.3 * torch.randn(C)).cuda(), (0.2 * torch.randn(C)).cuda(), torch.rand(C).cuda()
+        sums = torch.zeros(2 * C, dtype=torch.float64).cuda()
+        check(lib.cruse_bn_nchw_stats(_p(xb), N, C, HW, _p(sums), 1, _stream()))
+        mean, rstd = ops.bn_finalize(sums, N * HW, C, 1e-5, 0.1, torch.zeros(C).cuda(), torch.ones(C).cuda())
+        if kind == "pointwise":
+            Co, KH, KW, dil, pt, pl, groups = 40, 1, 1, (1, 1), 0, 0, 1
+            w = (torch.randn(Co, C, 1, 1) * 0.2).cuda()
+            Ho, Wo = H, W
+        else:
+            Co, KH, KW, dil, pt, pl, groups = C, 3, 3, (2, 1), 4, 1, C       # causal along H (pad 4 on top), same along W
+            w = (torch.randn(C, 1, 3, 3) * 0.3).cuda()
+            Ho, Wo = H, W
+        dyc = torch.randn(N, Co, Ho, Wo).cuda().half()                      # gradient of the convolution's output
+        # reference: plain data-gradient convolution, then the BatchNorm backward that reduces its own sums
+        d_ref = _conv_raw(dyc, w, None, (H, W), KH, KW, (1, 1), dil, pt, pl, groups, 1, True, C)
+        r = torch.zeros(NREP, 4, C, dtype=torch.float64).cuda()
+        d_new = torch.empty_like(d_ref)
+        got = ctypes.c_int(0)
+        check(lib.cruse_conv2d_nchw_bnbwd(_p(dyc), _p(w), _p(d_new), N, Co, Ho, Wo, C, H, W, KH, KW, 1, 1, dil[0], dil[1], pt, pl, groups, 1,
+                                          _p(xb), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(slope), 2, _p(r), NREP, ctypes.addressof(got), 1,
+                                          _stream()))
+        assert got.value == 1, kind
+        assert torch.equal(d_ref, d_new), kind
+        out = {}
+        for delivered in (False, True):
+            dx = torch.empty_like(xb)
+            scratch = r if delivered else torch.zeros(4 * C, dtype=torch.float64).cuda()
+            dg, db, ds, dxs = (torch.zeros(C).cuda() for _ in range(4))
+            check(lib.cruse_bn_nchw_bwd_ex(_p(d_ref), _p(xb), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(slope), 2, 1, N, C, HW, _p(scratch), 1,
+                                           NREP if delivered else 0, _p(dx), _p(dg), _p(db), _p(ds), _p(dxs), 1, _stream()))
+            out[delivered] = (dx, dg, db, ds, dxs, scratch)
+        rs = r.sum(0)
+        ref4 = out[False][5].view(4, C)
+        assert torch.allclose(rs, ref4, rtol=1e-5, atol=1e-4), (kind, (rs - ref4).abs().max())
+        # the sums agree to f32 rounding of the partials, so dx may differ in the last f16 place of a few elements
+        ddx = (out[False][0].float() - out[True][0].float()).abs()
+        assert ddx.max() <= 2e-3 * out[False][0].float().abs().max() and (ddx > 0).float().mean() < 0.02, (kind, ddx.max())
+        for i in (1, 2, 3, 4):
+            assert torch.allclose(out[False][i], out[True][i], rtol=1e-4, atol=1e-3), (kind, i)
 
 
 def test_pointwise_wgrad_ex_delivers_the_bias_gradient():
