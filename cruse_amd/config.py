@@ -24,8 +24,6 @@ class EngineConfig:
                                     # 4 GRU weight gradients, 8 skip-conv backward leaves
     inline_mask: int = 8            # backward leaves kept on the main stream: 1 skip dgrads, 2 skip wgrads, 4 decoder wgrads,
                                     # 8 << (k - 1) the level-k encoder wgrad, k = 1..4 (8: -0.025 ms; the others measured slower or equal)
-    early_t: int = 2                # dW operand transposes: 0 inside each layer's leaf, 1 layer 1's beside the first backward
-                                    # recurrence, 2 all four in the forward pass (6.08 vs 6.12 ms)
     fuse_bn_stats: bool = True      # BatchNorm batch sums in the producing conv's epilogue (False: separate bn_stats pass)
     fuse_bn_bwd_stats: bool = True  # BatchNorm BACKWARD sums in the epilogue of the data-gradient conv that produces the incoming gradient
     gi_x3: Optional[int] = None     # forward gate projections: bit 0 / 1 = W_ih low-plane pass on layer 1 / 2, bit 2 = also split x
@@ -50,7 +48,7 @@ class EngineConfig:
     lib_options: Dict[str, int] = field(default_factory=dict)       # cruse_set_option(name, value) while this config is active
 
     _ENV = {"overlap": ("CRUSE_OVERLAP", lambda v: v == "1"), "defer_mask": ("CRUSE_DEFER", int), "inline_mask": ("CRUSE_INLINE", int),
-            "early_t": ("CRUSE_EARLY_T", int), "fuse_bn_stats": ("CRUSE_FUSE_BN_STATS", lambda v: v != "0"),
+            "fuse_bn_stats": ("CRUSE_FUSE_BN_STATS", lambda v: v != "0"),
             
             "fuse_bn_bwd_stats": ("CRUSE_FUSE_BN_BWD", lambda v: v != "0"), 
             "gi_x3": ("CRUSE_GI_X3", int), "gi_f16": ("CRUSE_GI_F16", int), 

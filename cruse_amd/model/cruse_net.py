@@ -350,7 +350,7 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
     # the forward pass only.  From the first backward recurrence on, the side streams' queue is what the optimizer step
     # waits for, while in the forward pass they idle: three of the copies are made beside the second forward recurrence,
     # the fourth beside the decoder (late_leaves: the caller issues it after it has joined the side streams).
-    fwd_T = save and fast and SIDE.enabled and slot == 0 and config.get().early_t >= 2
+    fwd_T = save and fast and SIDE.enabled and slot == 0
     tt = {}
 
     def queue_layer1_leaves(h1, l1, l1_bf):
@@ -556,7 +556,7 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
     early_T = {}
     if "T1" in ctx:                                      # made in the forward pass (_ggru_forward_one)
         early_T["gru_list1"], early_T["gru_list2"] = ctx["T1"], ctx["T2"]
-    elif _bf16_gemm_path(prec, Hg) and SIDE.enabled and config.get().early_t >= 1:
+    elif _bf16_gemm_path(prec, Hg) and SIDE.enabled:
         ldT1 = (rows + 63) // 64 * 64
         x1T = torch.empty(ldT1 // 64, H, 64, device=dout.device, dtype=torch.bfloat16)
         h1T = torch.empty(ldT1 // 64, H, 64, device=dout.device, dtype=torch.bfloat16)
