@@ -1,0 +1,247 @@
+"""ABI-level parity: every core entry point of libcruse_hip.so against its plain-C CPU twin (oracle/cruse_ref.c, pinned
+by tests/test_ref_twins.py) -- the SAME argument list goes to both, host arrays to the twin and their device copies to the HIP entry
+point, and every output buffer is compared.  Exact modes (VALU kernels, v_mfma_f32_16x16x4_f32) to f32 rounding, the bf16 MFMA modes to
+the rounding of their operands."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ref_lib as R  # noqa: E402
+from ref_lib import LL  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return R.load()
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from cruse_amd._lib import lib
+    return lib
+
+
+class Side:
+    """an argument that differs between the two sides (scratch buffers, host arrays of device / host pointers)"""
+    def __init__(self, hip, ref):
+        self.hip, self.ref = hip, ref
+
+
+def rng(seed):
+    return np.random.default_rng(seed)
+
+
+def rnd(g, *shape, scale=1.0, shift=0.0):
+    return np.ascontiguousarray((g.standard_normal(shape) * scale + shift).astype(np.float32))
+
+
+def both(hip, ref, name, args, outs, tol, l2=False):
+    """call entry point `name` and its twin with `args` (numpy arrays are mirrored to the device); compare the arrays at the
+    positions `outs`.  tol: max |a - b| / max |b| (or rel-L2 with l2=True); a dict {position: tol} sets it per output."""
+    from cruse_amd._lib import check
+    dev = {}
+    hargs, rargs = [], []
+    for i, a in enumerate(args):
+        if isinstance(a, Side):
+            hargs.append(a.hip); rargs.append(a.ref)
+        elif isinstance(a, np.ndarray):
+            t = torch.from_numpy(a).cuda()
+            dev[i] = t
+            hargs.append(t.data_ptr()); rargs.append(a)
+        elif isinstance(a, LL):
+            hargs.append(a.value); rargs.append(a)
+        else:
+            hargs.append(a); rargs.append(a)
+    hargs[-1] = torch.cuda.current_stream().cuda_stream
+    check(getattr(hip, name)(*hargs))
+    torch.cuda.synchronize()
+    R.call(ref, name, *rargs)
+    for i in outs:
+        got = dev[i].cpu().numpy()
+        want = args[i]
+        if got.dtype == np.uint16:                                # bf16 payloads
+            got = (got.astype(np.uint32) << 16).view(np.float32)
+            want = (want.astype(np.uint32) << 16).view(np.float32)
+        got, want = got.astype(np.float64), want.astype(np.float64)
+        assert np.isfinite(got).all(), (name, i)
+        tl = tol[i] if isinstance(tol, dict) else tol
+        if l2:
+            err = np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30)
+        else:
+            err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
+        assert err <= tl, (name, i, err, tl)
+
+
+def test_stft_and_istft(hip, ref):
+    g = rng(0)
+    for (B, L, n_fft, hop) in ((2, 3200, 320, 160), (2, 3199, 320, 160), (2, 1000, 64, 16)):
+        T, Fb = 1 + L // hop, n_fft // 2 + 1
+        x = rnd(g, B, L, scale=0.1)
+        re, im, mag = (np.zeros((B, T, Fb), np.float32) for _ in range(3))
+        both(hip, ref, "cruse_stft_fwd", [x, B, L, n_fft, hop, re, im, mag, Fb, 1e-12, None], (5, 6, 7), 3e-5)
+        if n_fft != 320:
+            continue                                               # (cruse_istft_fwd is the 320-point form; other sizes: cruse_istft_framed)
+        L2 = (T - 1) * hop
+        wave = np.zeros((B, L2), np.float32)
+        both(hip, ref, "cruse_istft_fwd", [rnd(g, B, T, Fb), rnd(g, B, T, Fb), B, T, n_fft, hop, L2, wave, None], (7,), 3e-5)
+
+
+def test_conv_forms(hip, ref):
+    g = rng(1)
+    B, T = 2, 5
+    # (Cin, Fin, Cout, Fout, KT, S, pad, w_layout): the encoder's first conv (VALU only), an MFMA-eligible encoder conv, the stride-1 data gradient
+    for (Cin, Fin, Cout, Fout, KT, S, pad, wl) in ((1, 160, 16, 80, 2, 2, 1, 0), (16, 80, 32, 40, 2, 2, 1, 0), (16, 40, 16, 40, 1, 1, 1, 1),
+                                                    (16, 40, 16, 40, 1, 1, 1, 0)):
+        x = rnd(g, B, T, Cin, Fin)
+        w = rnd(g, *((Cin, Cout, 1, 3) if wl else (Cout, Cin, KT, 3)), scale=0.3)
+        bias = rnd(g, Cout)
+        for prec, tol in ((-1, 2e-5), (0, 2e-5), (1, 1e-4), (2, 2e-2)):
+            y = np.zeros((B, T, Cout, Fout), np.float32)
+            both(hip, ref, "cruse_conv_gather", [x, w, bias, y, B, T, Cin, Fin, Cout, Fout, KT, S, pad, wl, 0, 0, prec, 0, 0, None], (3,), tol,
+                 l2=prec > 0)
+        y = rnd(g, B, T, Cout, Fout)
+        both(hip, ref, "cruse_conv_gather", [x, w, None, y, B, T, Cin, Fin, Cout, Fout, KT, S, pad, wl, 0, 1, -1, 0, 0, None], (3,), 2e-5)   # accumulate
+        y = np.zeros((B, T, Cout, Fout), np.float32)
+        both(hip, ref, "cruse_conv_gather", [x, w, bias, y, B, T, Cin, Fin, Cout, Fout, KT, S, pad, wl, 1, 0, -1, 0, 0, None], (3,), 2e-5)   # sigmoid
+    # scatter form: the decoder's ConvTranspose2d (KT 1, pad 0) and the data gradient of the encoder conv (KT 2, pad 1)
+    for (Cs, Fg, Cout, KT, pad) in ((32, 20, 16, 1, 0), (32, 20, 16, 2, 1), (16, 80, 1, 1, 0)):
+        gq = rnd(g, B, T, Cs, Fg)
+        w = rnd(g, Cs, Cout, KT, 3, scale=0.3)
+        bias = rnd(g, Cout)
+        for prec, tol in ((-1, 2e-5), (0, 2e-5), (2, 2e-2)):
+            y = np.zeros((B, T, Cout, 2 * Fg), np.float32)
+            both(hip, ref, "cruse_conv_scatter2", [gq, w, bias, y, B, T, Cs, Fg, Cout, 2 * Fg, KT, pad, 0, 0, prec, 0, 0, None], (3,), tol, l2=prec > 0)
+        y = rnd(g, B, T, Cout, 2 * Fg)
+        both(hip, ref, "cruse_conv_scatter2", [gq, w, None, y, B, T, Cs, Fg, Cout, 2 * Fg, KT, pad, 0, 1, -1, 0, 0, None], (3,), 2e-5)
+
+
+def test_conv_weight_gradient_and_channel_sum(hip, ref):
+    g = rng(2)
+    B, T = 2, 6
+    for (Ca, Fa, Cb, Fb, KT, S, pad) in ((32, 40, 16, 80, 2, 2, 1), (16, 80, 16, 80, 1, 1, 1), (16, 80, 1, 160, 2, 2, 1)):
+        a, bt = rnd(g, B, T, Ca, Fa), rnd(g, B, T, Cb, Fb)
+        nws = hip.cruse_conv_wgrad_ws_bytes(Ca, Cb, KT)
+        ws = torch.zeros(max(nws, 16), dtype=torch.uint8, device="cuda")
+        for prec, tol in ((-1, 3e-5), (0, 3e-5), (2, 2e-2)):
+            dw = rnd(g, Ca, Cb, KT, 3)                              # "+=": the gradient buffer already holds something
+            both(hip, ref, "cruse_conv_wgrad", [a, bt, dw, B, T, Ca, Fa, Cb, Fb, KT, S, pad, prec, 0, 0, Side(ws.data_ptr(), None), None], (2,), tol,
+                 l2=prec > 0)
+    x = rnd(g, B * T, 24, 33)
+    out = rnd(g, 24)
+    both(hip, ref, "cruse_channel_sum", [x, LL(B * T), 24, 33, out, None], (4,), 2e-5)
+
+
+def test_batchnorm_family(hip, ref):
+    g = rng(3)
+    rows, C, Fq = 42, 16, 40
+    y = rnd(g, rows, C, Fq, scale=1.5, shift=0.3)
+    gamma, beta = rnd(g, C, scale=0.2, shift=1.0), rnd(g, C, scale=0.1)
+    sums = np.zeros(2 * C)
+    both(hip, ref, "cruse_bn_stats", [y, LL(rows), C, Fq, sums, 0, None], (4,), 1e-6)
+    R.call(ref, "cruse_bn_stats", y, LL(rows), C, Fq, sums, 0, None)
+    mean, rstd = np.zeros(C, np.float32), np.zeros(C, np.float32)
+    rm, rv = rnd(g, C), np.abs(rnd(g, C)) + 0.5
+    both(hip, ref, "cruse_bn_finalize", [sums, LL(rows * Fq), C, 1e-5, 0.1, mean, rstd, rm, rv, None], (5, 6, 7, 8), 2e-6)
+    R.call(ref, "cruse_bn_finalize", sums, LL(rows * Fq), C, 1e-5, 0.1, mean, rstd, None, None, None)
+    skip, dout = rnd(g, rows, C, Fq), rnd(g, rows, C, Fq)
+    for relu in (1, 0):
+        out = np.zeros((rows, C, Fq), np.float32)
+        both(hip, ref, "cruse_bn_act_fwd", [y, mean, rstd, gamma, beta, skip, out, LL(rows), C, Fq, relu, None], (6,), 2e-6)
+        bs = np.zeros(2 * C)
+        both(hip, ref, "cruse_bn_act_bwd_reduce", [dout, y, mean, rstd, gamma, beta, LL(rows), C, Fq, relu, bs, 0, None], (10,), 1e-5)
+        R.call(ref, "cruse_bn_act_bwd_reduce", dout, y, mean, rstd, gamma, beta, LL(rows), C, Fq, relu, bs, 0, None)
+        for training in (1, 0):
+            dy = np.zeros((rows, C, Fq), np.float32)
+            dg, db, dbias = rnd(g, C), rnd(g, C), rnd(g, C)
+            both(hip, ref, "cruse_bn_act_bwd_apply", [dout, y, mean, rstd, gamma, beta, bs, 1, LL(rows), C, Fq, relu, training, 0, dy, 0, dg, db, dbias,
+                                                     None], (14, 16, 17, 18), 1e-5)
+
+
+def test_layernorm(hip, ref):
+    g = rng(4)
+    rows = 42
+    for (H, ig) in ((640, 1), (640, 4), (128, 2)):
+        x, res = rnd(g, rows, H), rnd(g, rows, H)
+        gamma, beta = rnd(g, H, scale=0.3, shift=1.0), rnd(g, H, scale=0.2)
+        y, mean, rstd = np.zeros((rows, H), np.float32), np.zeros(rows, np.float32), np.zeros(rows, np.float32)
+        yb = np.zeros((rows, H), np.uint16)
+        both(hip, ref, "cruse_ln_fwd", [x, gamma, beta, res, y, yb, mean, rstd, LL(rows), H, ig, 1e-5, 0, LL(0), LL(0), None], (4, 5, 6, 7),
+             {4: 3e-6, 5: 8e-3, 6: 3e-6, 7: 3e-6})               # (the bf16 copy: one rounding step of 2^-8 where the f32 values differ in the last place)
+        R.call(ref, "cruse_ln_fwd", x, gamma, beta, res, y, None, mean, rstd, LL(rows), H, ig, 1e-5, 0, LL(0), LL(0), None)
+        dy = rnd(g, rows, H)
+        dx, dgm, dbt = np.zeros((rows, H), np.float32), rnd(g, H), rnd(g, H)
+        both(hip, ref, "cruse_ln_bwd", [dy, x, mean, rstd, gamma, LL(rows), H, ig, dx, dgm, dbt, None], (8, 9, 10), 2e-5)
+
+
+def test_gemm(hip, ref):
+    g = rng(5)
+    M, N, K = 136, 200, 96
+    A, Bm, bias = rnd(g, M, K), rnd(g, K, N), rnd(g, N)
+    for tA in (0, 1):
+        for tB in (0, 1):
+            a = np.ascontiguousarray(A.T) if tA else A
+            b = np.ascontiguousarray(Bm.T) if tB else Bm
+            for prec, tol in ((0, 2e-5), (2, 1e-5)):                # (bf16: the twin rounds the operands the same way; the products are then exact in f32)
+                C = rnd(g, M, N)
+                both(hip, ref, "cruse_gemm", [tA, tB, M, N, K, a, a.shape[1], b, b.shape[1], C, N, bias, 1, 1, 0, prec, None], (9,), tol)
+    C = np.zeros((M, N), np.float32)
+    both(hip, ref, "cruse_gemm", [0, 0, M, N, K, A, K, Bm, N, C, N, None, 0, 1, 8, 0, None], (9,), 2e-5)      # the shifted h_{t-1} operand
+
+
+def test_gru_recurrence_and_gate_gradients(hip, ref):
+    g = rng(6)
+    for (B, T, G, Hg) in ((3, 9, 2, 32), (9, 7, 1, 64)):
+        H = G * Hg
+        gi = rnd(g, B, T, G, 3 * Hg)
+        w = [rnd(g, 3 * Hg, Hg, scale=1.0 / np.sqrt(Hg)) for _ in range(G)]
+        bh = [rnd(g, 3 * Hg, scale=0.1) for _ in range(G)]
+        wd, bd = [torch.from_numpy(a).cuda() for a in w], [torch.from_numpy(a).cuda() for a in bh]
+        wa = Side(ctypes.cast((ctypes.c_void_p * G)(*[t.data_ptr() for t in wd]), ctypes.c_void_p), R.ptr_array(w))
+        ba = Side(ctypes.cast((ctypes.c_void_p * G)(*[t.data_ptr() for t in bd]), ctypes.c_void_p), R.ptr_array(bh))
+        ws = torch.zeros(hip.cruse_gru_ws_bytes(B, G, Hg), dtype=torch.uint8, device="cuda")
+        wsa = Side(ws.data_ptr(), None)
+        dout = rnd(g, B, T, H)
+        for prec, tol in ((0, 2e-5), (2, 2e-2)):
+            h, an, z = (np.zeros((B, T, H), np.float32) for _ in range(3))
+            coef = np.zeros((B, T, G, 3 * Hg), np.uint16 if prec == 2 else np.float32)
+            both(hip, ref, "cruse_gru_seq_fwd", [gi, wa, ba, h, coef, an, z, B, T, G, Hg, prec, wsa, None], (3, 4, 5, 6), tol, l2=prec == 2)
+            R.call(ref, "cruse_gru_seq_fwd", gi, wa.ref, ba.ref, h, coef, an, z, B, T, G, Hg, prec, None, None)
+            dh = np.zeros((B, T, H), np.float32)
+            both(hip, ref, "cruse_gru_seq_bwd", [dout, wa, coef, z, dh, B, T, G, Hg, prec, wsa, None], (4,), tol, l2=prec == 2)
+            R.call(ref, "cruse_gru_seq_bwd", dout, wa.ref, coef, z, dh, B, T, G, Hg, prec, None, None)
+            dgi, dgh = np.zeros((B * T, G, 3 * Hg), np.float32), np.zeros((B * T, G, 3 * Hg), np.float32)
+            both(hip, ref, "cruse_gru_gate_grads", [dh, coef, an, dgi, dgh, LL(B * T), G, Hg, prec, None], (3, 4), 2e-6)
+        assert int(ws[:4].view(torch.int32)[0]) == 0             # no hand-off time-out
+
+
+def test_mask_loss_deepfilter_adam(hip, ref):
+    g = rng(7)
+    rows, Fn, Fs = 42, 160, 161
+    mask = np.ascontiguousarray(g.uniform(0.05, 0.95, (rows, Fn)).astype(np.float32))
+    nre, nim = rnd(g, rows, Fs), rnd(g, rows, Fs)
+    cmag = np.abs(rnd(g, rows, Fs))
+    ls = np.zeros(1)
+    dmask, dlogit = np.zeros((rows, Fn), np.float32), np.zeros((rows, Fn), np.float32)
+    er, ei = np.zeros((rows, Fs), np.float32), np.zeros((rows, Fs), np.float32)
+    both(hip, ref, "cruse_mask_loss_fwd", [mask, nre, nim, cmag, LL(rows), Fn, Fs, 2.0, 1.0, ls, dmask, dlogit, er, ei, None], (9, 10, 11, 12, 13),
+         {9: 1e-5, 10: 5e-5, 11: 5e-5, 12: 1e-6, 13: 1e-6})
+    er2, ei2 = np.zeros_like(er), np.zeros_like(ei)
+    both(hip, ref, "cruse_mask_apply", [mask, nre, nim, LL(rows), Fn, Fs, er2, ei2, None], (6, 7), 1e-6)
+    dl = np.zeros((rows, Fn), np.float32)
+    both(hip, ref, "cruse_sigmoid_bwd", [rnd(g, rows, Fn), mask, dl, LL(rows * Fn), None], (2,), 1e-6)
+    B, Fq, T = 2, 161, 50
+    xs = [rnd(g, B, Fq, T) for _ in range(4)]
+    o_r, o_i = np.zeros((B, Fq, T), np.float32), np.zeros((B, Fq, T), np.float32)
+    both(hip, ref, "cruse_deepfilter_fwd", xs + [B, Fq, T, 5, 1, o_r, o_i, None], (9, 10), 1e-5)
+    n = 5000
+    p, gr = rnd(g, n), rnd(g, n)
+    m, v = rnd(g, n, scale=0.1), np.abs(rnd(g, n, scale=0.1))
+    for wd in (0.0, 0.01):
+        both(hip, ref, "cruse_adam_step", [p, gr, m, v, LL(n), 1e-3, 0.9, 0.999, 1e-8, wd, 3, 0.5, None], (0, 2, 3), 2e-6)
