@@ -1,4 +1,4 @@
-/* oracle/cruse_ref.c -- plain-C CPU twins of the core entry points of include/cruse_hip.h ("every entry also has
+/* oracle/cruse_ref.c -- plain-C CPU twins of 33 entry points of include/cruse_hip.h ("every entry also has
  * a *_ref plain-C++ CPU twin ... used for ABI-level parity tests").
  *
  * TEST INFRASTRUCTURE, NOT PRODUCT: only tests/ loads this library (tests/test_oracle.py pins it against torch's ops -- the library
@@ -618,5 +618,200 @@ int cruse_adam_step_ref(float* p, const float* g, float* m, float* v, long long 
         v[i] = (float)vi;
         p[i] = (float)((double)p[i] - (double)lr / bc1 * (mi / (sqrt(vi) / bc2 + (double)eps)));
     }
+    return REF_OK;
+}
+
+/* ---- further twins (round 5): adjoints, time-domain losses, small layout / bookkeeping entry points --------------------------------- */
+
+/* adjoint of cruse_istft_fwd_ref (the backward of torch.istft): dwave [B,L] -> dre, dim [B,T,n_fft/2+1]; the imaginary parts of bins 0 and
+ * n_fft/2 do not reach the output of an inverse real FFT, so their gradients are 0 */
+int cruse_istft_bwd_ref(const float* dwave, int B, int T, int n_fft, int hop, int L, float* dre, float* dim, void* stream) {
+    (void)stream;
+    if (B <= 0 || T <= 0 || n_fft <= 0 || (n_fft & 1) || hop <= 0 || L <= 0) return REF_E_SHAPE;
+    const int Fb = n_fft / 2 + 1, half = n_fft / 2;
+    const long long full = (long long)(T - 1) * hop + n_fft;
+    double* win = (double*)malloc(sizeof(double) * n_fft);
+    double* env = (double*)calloc((size_t)full, sizeof(double));
+    double* dfr = (double*)malloc(sizeof(double) * n_fft);
+    for (int n = 0; n < n_fft; ++n) win[n] = 0.5 - 0.5 * cos(2.0 * M_PI * n / n_fft);
+    for (int t = 0; t < T; ++t)
+        for (int n = 0; n < n_fft; ++n) env[(long long)t * hop + n] += win[n] * win[n];
+    for (int b = 0; b < B; ++b)
+        for (int t = 0; t < T; ++t) {
+            for (int n = 0; n < n_fft; ++n) {
+                const long long j = (long long)t * hop + n, i = j - half;
+                dfr[n] = (i >= 0 && i < L && env[j] > 1e-11) ? (double)dwave[(long long)b * L + i] / env[j] * win[n] / n_fft : 0.0;
+            }
+            for (int k = 0; k < Fb; ++k) {
+                const double c = (k == 0 || k == half) ? 1.0 : 2.0;
+                double sr = 0.0, si = 0.0;
+                for (int n = 0; n < n_fft; ++n) {
+                    const double ph = 2.0 * M_PI * (double)(((long long)k * n) % n_fft) / n_fft;
+                    sr += dfr[n] * cos(ph);
+                    si -= dfr[n] * sin(ph);
+                }
+                const long long o = ((long long)b * T + t) * Fb + k;
+                dre[o] = (float)(c * sr);
+                dim[o] = (k == 0 || k == half) ? 0.f : (float)(c * si);
+            }
+        }
+    free(win);
+    free(env);
+    free(dfr);
+    return REF_OK;
+}
+
+/* backward of cruse_mask_apply: dout[rows,Fn] = (dre nre + dim nim) [* mask (1 - mask) through the sigmoid] */
+int cruse_mask_apply_bwd_ref(const float* dre, const float* dim, const float* nre, const float* nim, const float* mask, long long rows,
+                             int Fn, int Fs, int through_sigmoid, float* dout, void* stream) {
+    (void)stream;
+    if (rows <= 0 || Fn <= 0 || Fs < Fn) return REF_E_SHAPE;
+    for (long long r = 0; r < rows; ++r)
+        for (int f = 0; f < Fn; ++f) {
+            const long long j = r * Fs + f;
+            double d = (double)dre[j] * (double)nre[j] + (double)dim[j] * (double)nim[j];
+            if (through_sigmoid) d *= (double)mask[r * Fn + f] * (1.0 - (double)mask[r * Fn + f]);
+            dout[r * Fn + f] = (float)d;
+        }
+    return REF_OK;
+}
+
+/* si_snr_loss (train_base/loss.py:7-25): loss = -mean_b 20 log10(eps + |t| / (|x_zm - t| + eps)), t = <x_zm, s_zm> s_zm / (|s_zm|^2 + eps);
+ * mom [B,5] = (sum x, sum s, sum x^2, sum s^2, sum x s); coef [B,4] = (A, C, mean_x, mean_s) with d loss / d x = A (x - mean_x) + C (s - mean_s) */
+int cruse_sisnr_fwd_ref(const float* x, const float* s, int B, int L, float eps_, double* mom, double* loss, float* coef, void* stream) {
+    (void)stream;
+    if (B <= 0 || L <= 0) return REF_E_SHAPE;
+    const double eps = (double)eps_, n = (double)L;
+    loss[0] = 0.0;
+    for (int b = 0; b < B; ++b) {
+        double m[5] = {0, 0, 0, 0, 0};
+        for (int i = 0; i < L; ++i) {
+            const double a = (double)x[(long long)b * L + i], c = (double)s[(long long)b * L + i];
+            m[0] += a; m[1] += c; m[2] += a * a; m[3] += c * c; m[4] += a * c;
+        }
+        for (int k = 0; k < 5; ++k) mom[b * 5 + k] = m[k];
+        const double mx = m[0] / n, ms = m[1] / n;
+        const double P = m[4] - n * mx * ms;
+        double S2 = m[3] - n * ms * ms; if (S2 < 0) S2 = 0;
+        double X2 = m[2] - n * mx * mx; if (X2 < 0) X2 = 0;
+        const double S = S2 + eps, alpha = P / S, nt = fabs(alpha) * sqrt(S2);
+        double e2 = X2 - 2.0 * alpha * P + alpha * alpha * S2; if (e2 < 0) e2 = 0;
+        const double ne = sqrt(e2), r = nt / (ne + eps);
+        loss[0] += -20.0 * log10(eps + r) / (double)B;
+        const double dr = -20.0 / (log(10.0) * (eps + r)) / (double)B;
+        const double sgn = alpha >= 0 ? 1.0 : -1.0, es = P - alpha * S2;
+        const double k_nt = dr / (ne + eps) * sgn * sqrt(S2) / S;
+        const double k_ne = ne > 0 ? -dr * nt / ((ne + eps) * (ne + eps)) / ne : 0.0;
+        coef[b * 4 + 0] = (float)k_ne;
+        coef[b * 4 + 1] = (float)(k_nt - k_ne * (alpha + es / S));
+        coef[b * 4 + 2] = (float)mx;
+        coef[b * 4 + 3] = (float)ms;
+    }
+    return REF_OK;
+}
+
+int cruse_sisnr_bwd_ref(const float* x, const float* s, const float* coef, int B, int L, float grad_scale, float* dx, void* stream) {
+    (void)stream;
+    if (B <= 0 || L <= 0) return REF_E_SHAPE;
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < L; ++i) {
+            const long long o = (long long)b * L + i;
+            dx[o] = (float)((double)grad_scale * ((double)coef[b * 4] * ((double)x[o] - (double)coef[b * 4 + 2]) +
+                                                 (double)coef[b * 4 + 1] * ((double)s[o] - (double)coef[b * 4 + 3])));
+        }
+    return REF_OK;
+}
+
+/* torch.nn.L1Loss / MSELoss on waveforms (train_base/loss.py:3-4): the SUM and, optionally, grad_scale * d sum / d est */
+int cruse_wave_l1_mse_ref(const float* est, const float* ref, long long n, int mse, float grad_scale, double* loss_sum, float* dest,
+                          void* stream) {
+    (void)stream;
+    if (n <= 0) return REF_E_SHAPE;
+    double acc = 0.0;
+    for (long long i = 0; i < n; ++i) {
+        const double d = (double)est[i] - (double)ref[i];
+        acc += mse ? d * d : fabs(d);
+        if (dest) dest[i] = (float)((double)grad_scale * (mse ? 2.0 * d : (d > 0 ? 1.0 : (d < 0 ? -1.0 : 0.0))));
+    }
+    loss_sum[0] = acc;
+    return REF_OK;
+}
+
+/* backward of cruse_deepfilter_fwd: (g_r, g_i) = box(dout) (the box sum is its own adjoint), then the four operand gradients of X * H */
+int cruse_deepfilter_bwd_ref(const float* dout_r, const float* dout_i, const float* xr, const float* xi, const float* hr, const float* hi,
+                             int B, int F, int T, int f_dim, int t_dim, float* dxr, float* dxi, float* dhr, float* dhi, void* stream) {
+    (void)stream;
+    if (B <= 0 || F <= 0 || T <= 0 || f_dim < 0 || t_dim < 0) return REF_E_SHAPE;
+    for (int b = 0; b < B; ++b)
+        for (int f = 0; f < F; ++f)
+            for (int t = 0; t < T; ++t) {
+                double gr = 0.0, gi = 0.0;
+                for (int df = -f_dim; df <= f_dim; ++df)
+                    for (int dt = -t_dim; dt <= t_dim; ++dt) {
+                        const int ff = f + df, tt = t + dt;
+                        if (ff < 0 || ff >= F || tt < 0 || tt >= T) continue;
+                        gr += (double)dout_r[((long long)b * F + ff) * T + tt];
+                        gi += (double)dout_i[((long long)b * F + ff) * T + tt];
+                    }
+                const long long o = ((long long)b * F + f) * T + t;
+                dxr[o] = (float)(gr * (double)hr[o] + gi * (double)hi[o]);
+                dxi[o] = (float)(-gr * (double)hi[o] + gi * (double)hr[o]);
+                dhr[o] = (float)(gr * (double)xr[o] + gi * (double)xi[o]);
+                dhi[o] = (float)(-gr * (double)xi[o] + gi * (double)xr[o]);
+            }
+    return REF_OK;
+}
+
+/* eval-mode BatchNorm2d: mean = running_mean, rstd = 1 / sqrt(running_var + eps) */
+int cruse_bn_eval_stats_ref(const float* running_mean, const float* running_var, int C, float eps, float* mean, float* rstd, void* stream) {
+    (void)stream;
+    if (C <= 0) return REF_E_SHAPE;
+    for (int c = 0; c < C; ++c) { mean[c] = running_mean[c]; rstd[c] = (float)(1.0 / sqrt((double)running_var[c] + (double)eps)); }
+    return REF_OK;
+}
+
+/* cruse_bn_finalize + cruse_bn_act_fwd as one call; sums is [sum_replicas][2*C], the statistic the sum over the replicas; out_bf16: a bf16 copy */
+int cruse_bn_finalize_act_fwd_ref(const float* y, const double* sums, int sum_replicas, long long count, float eps, float momentum,
+                                  const float* gamma, const float* beta, const float* skip, float* out, void* out_bf16, float* mean,
+                                  float* rstd, float* running_mean, float* running_var, long long rows, int C, int F, int relu, void* stream) {
+    if (sum_replicas <= 0 || C <= 0) return REF_E_SHAPE;
+    double* tot = (double*)calloc((size_t)2 * C, sizeof(double));
+    for (int q = 0; q < sum_replicas; ++q)
+        for (int c = 0; c < 2 * C; ++c) tot[c] += sums[(size_t)q * 2 * C + c];
+    int rc = cruse_bn_finalize_ref(tot, count, C, eps, momentum, mean, rstd, running_mean, running_var, stream);
+    free(tot);
+    if (rc) return rc;
+    rc = cruse_bn_act_fwd_ref(y, mean, rstd, gamma, beta, skip, out, rows, C, F, relu, stream);
+    if (rc) return rc;
+    if (out_bf16)
+        for (long long i = 0; i < rows * C * F; ++i) ((uint16_t*)out_bf16)[i] = bf16_rne(out[i]);
+    return REF_OK;
+}
+
+/* out[j] += sum_rows g[row*ld + j], j < ncol (GRU bias gradients) */
+int cruse_col_sum_ref(const float* g, long long rows, int ncol, int ld, float* out, void* stream) {
+    (void)stream;
+    if (rows <= 0 || ncol <= 0 || ld < ncol) return REF_E_SHAPE;
+    for (int j = 0; j < ncol; ++j) {
+        double s = 0.0;
+        for (long long r = 0; r < rows; ++r) s += (double)g[r * ld + j];
+        out[j] = (float)((double)out[j] + s);
+    }
+    return REF_OK;
+}
+
+/* out = a x + b y (y may be NULL) */
+int cruse_axpby_ref(float* out, const float* x, const float* y, float a, float b, long long n, void* stream) {
+    (void)stream;
+    if (n <= 0) return REF_E_SHAPE;
+    for (long long i = 0; i < n; ++i) out[i] = a * x[i] + (y ? b * y[i] : 0.f);
+    return REF_OK;
+}
+
+/* y = bf16(x), round to nearest even */
+int cruse_cast_bf16_ref(const float* x, void* y, long long n, void* stream) {
+    (void)stream;
+    if (n <= 0) return REF_E_SHAPE;
+    for (long long i = 0; i < n; ++i) ((uint16_t*)y)[i] = bf16_rne(x[i]);
     return REF_OK;
 }

@@ -245,3 +245,54 @@ def test_mask_loss_deepfilter_adam(hip, ref):
     m, v = rnd(g, n, scale=0.1), np.abs(rnd(g, n, scale=0.1))
     for wd in (0.0, 0.01):
         both(hip, ref, "cruse_adam_step", [p, gr, m, v, LL(n), 1e-3, 0.9, 0.999, 1e-8, wd, 3, 0.5, None], (0, 2, 3), 2e-6)
+
+
+def test_adjoints_time_domain_losses_and_bookkeeping(hip, ref):
+    g = rng(8)
+    B, T, Fb, L = 2, 21, 161, 3200
+    dre, dim = np.zeros((B, T, Fb), np.float32), np.zeros((B, T, Fb), np.float32)
+    both(hip, ref, "cruse_istft_bwd", [rnd(g, B, L), B, T, 320, 160, L, dre, dim, None], (6, 7), 3e-5)
+    rows, Fn, Fs = 42, 160, 161
+    mask = np.ascontiguousarray(g.uniform(0.05, 0.95, (rows, Fn)).astype(np.float32))
+    for through in (0, 1):
+        out = np.zeros((rows, Fn), np.float32)
+        both(hip, ref, "cruse_mask_apply_bwd", [rnd(g, rows, Fs), rnd(g, rows, Fs), rnd(g, rows, Fs), rnd(g, rows, Fs), mask, LL(rows), Fn, Fs, through, out,
+                                               None], (9,), 3e-6)
+    Bq, Lq = 5, 16000
+    x, s = rnd(g, Bq, Lq), rnd(g, Bq, Lq)
+    x += 0.5 * s
+    mom, loss, coef = np.zeros((Bq, 5)), np.zeros(1), np.zeros((Bq, 4), np.float32)
+    both(hip, ref, "cruse_sisnr_fwd", [x, s, Bq, Lq, 1e-8, mom, loss, coef, None], (5, 6, 7), {5: 1e-6, 6: 1e-6, 7: 2e-5})
+    dx = np.zeros((Bq, Lq), np.float32)
+    both(hip, ref, "cruse_sisnr_bwd", [x, s, coef, Bq, Lq, 0.25, dx, None], (6,), 2e-6)
+    n = 50000
+    est, refw = rnd(g, n), rnd(g, n)
+    for mse in (0, 1):
+        ls, d = np.zeros(1), np.zeros(n, np.float32)
+        both(hip, ref, "cruse_wave_l1_mse", [est, refw, LL(n), mse, 1.0 / n, ls, d, None], (5, 6), 2e-6)
+    Bd, Fq, Td = 2, 161, 50
+    ts = [rnd(g, Bd, Fq, Td) for _ in range(6)]
+    outs = [np.zeros((Bd, Fq, Td), np.float32) for _ in range(4)]
+    both(hip, ref, "cruse_deepfilter_bwd", ts + [Bd, Fq, Td, 5, 1] + outs + [None], (11, 12, 13, 14), 1e-5)
+    C, Fc = 16, 40
+    rm, rv = rnd(g, C), np.abs(rnd(g, C)) + 0.5
+    mean, rstd = np.zeros(C, np.float32), np.zeros(C, np.float32)
+    both(hip, ref, "cruse_bn_eval_stats", [rm, rv, C, 1e-5, mean, rstd, None], (4, 5), 2e-6)
+    y = rnd(g, rows, C, Fc, scale=1.4, shift=0.2)
+    s1 = np.zeros(2 * C)
+    R.call(ref, "cruse_bn_stats", y, LL(rows), C, Fc, s1, 0, None)
+    reps = np.ascontiguousarray(np.stack([s1 * w for w in (0.5, 0.25, 0.125, 0.125)]))
+    gamma, beta, skip = rnd(g, C, scale=0.2, shift=1.0), rnd(g, C, scale=0.1), rnd(g, rows, C, Fc)
+    out, ob = np.zeros((rows, C, Fc), np.float32), np.zeros((rows, C, Fc), np.uint16)
+    both(hip, ref, "cruse_bn_finalize_act_fwd", [y, reps, 4, LL(rows * Fc), 1e-5, 0.1, gamma, beta, skip, out, ob, mean, rstd, rm, rv, LL(rows), C, Fc, 1,
+                                                None], (9, 10, 11, 12, 13, 14), {9: 3e-6, 10: 8e-3, 11: 2e-6, 12: 2e-6, 13: 2e-6, 14: 2e-6})
+    xg = rnd(g, rows * 20)
+    o = rnd(g, 6)
+    both(hip, ref, "cruse_col_sum", [xg, LL(rows - 1), 6, 20, o, None], (4,), 3e-6)
+    a, b = rnd(g, 10000), rnd(g, 10000)
+    o = np.zeros(10000, np.float32)
+    both(hip, ref, "cruse_axpby", [o, a, b, 0.5, -2.0, LL(10000), None], (0,), 1e-6)
+    both(hip, ref, "cruse_axpby", [o, a, None, 3.0, 0.0, LL(10000), None], (0,), 1e-6)
+    xs = np.ascontiguousarray(np.concatenate([rnd(g, 4090), np.array([1.00390625, 1.01171875, -1.00390625, 3.3895314e38, 0.0, -0.0], np.float32)]))
+    yb = np.zeros(xs.size, np.uint16)
+    both(hip, ref, "cruse_cast_bf16", [xs, yb, LL(xs.size), None], (1,), 0.0)

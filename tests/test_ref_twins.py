@@ -37,7 +37,7 @@ def close(a, b, tol):
 def test_twins_mirror_the_header():
     """every twin is an entry point of include/cruse_hip.h with the same parameter list (types and order)"""
     names = R.twin_names()
-    assert len(names) >= 22
+    assert len(names) >= 33
     for n in names:
         hp, sp = R.header_params(n), R.source_params(n)
         assert len(hp) == len(sp), (n, hp, sp)
@@ -324,3 +324,105 @@ def test_adam_twin_vs_torch_adam(ref):
             opt.step()
             call(ref, "cruse_adam_step", p, f32(g * 4.0), m, v, LL(n), 1e-3, 0.9, 0.999, 1e-8, wd, step, 0.25, None)
         close(p, p_t.detach(), 2e-6)
+
+
+def test_adjoint_and_time_domain_twins_vs_torch(ref):
+    from oracle import cruse_oracle as O
+    torch.manual_seed(7)
+    # istft backward = autograd of torch.istft
+    B, T, Fb, L = 2, 9, 161, 1280
+    X = torch.randn(B, Fb, T, dtype=torch.complex128, requires_grad=True)
+    y = torch.istft(X, 320, 160, 320, torch.hann_window(320, dtype=torch.float64), center=True, length=L)
+    dw = torch.randn(B, L, dtype=torch.float64)
+    gX, = torch.autograd.grad(y, X, dw)
+    dre, dim = np.zeros((B, T, Fb), np.float32), np.zeros((B, T, Fb), np.float32)
+    call(ref, "cruse_istft_bwd", f32(dw), B, T, 320, 160, L, dre, dim, None)
+    # (torch hands back the gradient of a complex leaf as dre + i dim; bins 0 and 160 carry no imaginary gradient)
+    close(dre, gX.real.permute(0, 2, 1), 5e-6)
+    gi = gX.imag.permute(0, 2, 1).clone()
+    gi[..., 0] = 0; gi[..., -1] = 0
+    close(dim, gi, 5e-6)
+    # mask_apply backward
+    rows, Fn, Fs = 6, 8, 9
+    mask = torch.rand(rows, Fn, dtype=torch.float64, requires_grad=True)
+    logit = torch.randn(rows, Fn, dtype=torch.float64, requires_grad=True)
+    nre, nim = torch.randn(rows, Fs, dtype=torch.float64), torch.randn(rows, Fs, dtype=torch.float64)
+    dre_t, dim_t = torch.randn(rows, Fs, dtype=torch.float64), torch.randn(rows, Fs, dtype=torch.float64)
+    for through in (0, 1):
+        m = torch.sigmoid(logit) if through else mask
+        mf = F.pad(m, (0, Fs - Fn))
+        g, = torch.autograd.grad(((mf * nre) * dre_t + (mf * nim) * dim_t).sum(), logit if through else mask)
+        out = np.zeros((rows, Fn), np.float32)
+        call(ref, "cruse_mask_apply_bwd", f32(dre_t), f32(dim_t), f32(nre), f32(nim), f32(m.detach()), LL(rows), Fn, Fs, through, out, None)
+        close(out, g, 3e-6)
+    # si_snr_loss (train_base/loss.py:7-25) through the pinned oracle
+    Bq, Lq = 3, 400
+    x = torch.randn(Bq, Lq, dtype=torch.float64, requires_grad=True)
+    s = torch.randn(Bq, Lq, dtype=torch.float64)
+    loss_t = O.si_snr_loss(x, s)
+    gx, = torch.autograd.grad(loss_t, x)
+    mom, loss, coef = np.zeros((Bq, 5)), np.zeros(1), np.zeros((Bq, 4), np.float32)
+    call(ref, "cruse_sisnr_fwd", f32(x.detach()), f32(s), Bq, Lq, 1e-8, mom, loss, coef, None)
+    assert abs(loss[0] - float(loss_t)) <= 1e-5 * abs(float(loss_t))
+    dx = np.zeros((Bq, Lq), np.float32)
+    call(ref, "cruse_sisnr_bwd", f32(x.detach()), f32(s), coef, Bq, Lq, 0.5, dx, None)
+    close(dx, 0.5 * gx, 2e-5)
+    # L1 / MSE on waveforms
+    est = torch.randn(1000, dtype=torch.float64, requires_grad=True)
+    refw = torch.randn(1000, dtype=torch.float64)
+    for mse, fn in ((0, F.l1_loss), (1, F.mse_loss)):
+        lt = fn(est, refw, reduction="sum")
+        g, = torch.autograd.grad(lt, est)
+        ls, d = np.zeros(1), np.zeros(1000, np.float32)
+        call(ref, "cruse_wave_l1_mse", f32(est.detach()), f32(refw), LL(1000), mse, 0.001, ls, d, None)
+        assert abs(ls[0] - float(lt)) <= 2e-6 * abs(float(lt))
+        close(d, 0.001 * g, 2e-6)
+    # DeepFilter backward through the oracle's module (pinned by G8)
+    ts = [torch.randn(2, 9, 11, dtype=torch.float64, requires_grad=True) for _ in range(4)]
+    w = torch.randn(2, 18, 11, dtype=torch.float64)
+    (O.DeepFilter(1, 2).double()(ts[:2], ts[2:]) * w).sum().backward()
+    outs = [np.zeros((2, 9, 11), np.float32) for _ in range(4)]
+    call(ref, "cruse_deepfilter_bwd", f32(w[:, :9]), f32(w[:, 9:]), *[f32(t.detach()) for t in ts], 2, 9, 11, 2, 1, *outs, None)
+    for o, t in zip(outs, ts):
+        close(o, t.grad, 3e-6)
+
+
+def test_bookkeeping_twins(ref):
+    g = np.random.default_rng(8)
+    C, rows, Fq = 5, 12, 7
+    rm, rv = f32(g.standard_normal(C)), f32(np.abs(g.standard_normal(C)) + 0.5)
+    mean, rstd = np.zeros(C, np.float32), np.zeros(C, np.float32)
+    call(ref, "cruse_bn_eval_stats", rm, rv, C, 1e-5, mean, rstd, None)
+    close(mean, rm, 0.0)
+    close(rstd, 1.0 / np.sqrt(rv.astype(np.float64) + 1e-5), 1e-6)
+    # the fused forward == finalize + act on the folded replicas
+    y = f32(g.standard_normal((rows, C, Fq)) * 1.3 + 0.2)
+    gamma, beta, skip = f32(g.standard_normal(C)), f32(g.standard_normal(C)), f32(g.standard_normal((rows, C, Fq)))
+    s1 = np.zeros(2 * C)
+    call(ref, "cruse_bn_stats", y, LL(rows), C, Fq, s1, 0, None)
+    reps = np.ascontiguousarray(np.stack([s1 * 0.5, s1 * 0.25, s1 * 0.25, s1 * 0.0]))
+    m1, r1, m2, r2 = (np.zeros(C, np.float32) for _ in range(4))
+    ra, rb, rc, rd = rm.copy(), rv.copy(), rm.copy(), rv.copy()
+    o1, o2 = np.zeros((rows, C, Fq), np.float32), np.zeros((rows, C, Fq), np.float32)
+    call(ref, "cruse_bn_finalize", s1, LL(rows * Fq), C, 1e-5, 0.1, m1, r1, ra, rb, None)
+    call(ref, "cruse_bn_act_fwd", y, m1, r1, gamma, beta, skip, o1, LL(rows), C, Fq, 1, None)
+    ob = np.zeros((rows, C, Fq), np.uint16)
+    call(ref, "cruse_bn_finalize_act_fwd", y, reps, 4, LL(rows * Fq), 1e-5, 0.1, gamma, beta, skip, o2, ob, m2, r2, rc, rd, LL(rows), C, Fq, 1, None)
+    for a, b in ((o1, o2), (m1, m2), (r1, r2), (ra, rc), (rb, rd)):
+        assert np.array_equal(a, b)
+    close(torch.from_numpy(ob.astype(np.int32) << 16).view(torch.float32), torch.from_numpy(o2).to(torch.bfloat16).float(), 0.0)
+    x = f32(g.standard_normal((rows, 20)))
+    out = np.full(6, 3.0, np.float32)
+    call(ref, "cruse_col_sum", np.ascontiguousarray(x.reshape(-1)[4:]), LL(rows - 1), 6, 20, out, None)     # a column slice: ld 20, first column 4
+    close(out - 3.0, x[:rows - 1, 4:10].astype(np.float64).sum(0), 2e-6)
+    a, b = f32(g.standard_normal(100)), f32(g.standard_normal(100))
+    o = np.zeros(100, np.float32)
+    call(ref, "cruse_axpby", o, a, b, 0.5, -2.0, LL(100), None)
+    close(o, 0.5 * a.astype(np.float64) - 2.0 * b, 1e-6)
+    call(ref, "cruse_axpby", o, a, None, 3.0, 1.0, LL(100), None)
+    close(o, 3.0 * a.astype(np.float64), 1e-6)
+    xs = f32(np.concatenate([g.standard_normal(1000), [1.00390625, 1.01171875, -1.00390625, 3.3895314e38, 1e-40, 0.0]]))   # ties, overflow edge, subnormal
+    yb = np.zeros(xs.size, np.uint16)
+    call(ref, "cruse_cast_bf16", xs, yb, LL(xs.size), None)
+    want = torch.from_numpy(xs).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+    assert np.array_equal(yb, want)
