@@ -64,8 +64,8 @@ def run_stages(B, T, grp, init, prec, rec_prec):
     if rec_prec:
         real = ops.gru_seq_fwd
 
-        def patched(gi, w_hh, b_hh, B_, T_, G_, Hg_, prec_, save=True):
-            return real(gi, w_hh, b_hh, B_, T_, G_, Hg_, rec_prec, save=save)
+        def patched(gi, w_hh, b_hh, B_, T_, G_, Hg_, prec_, **kw):
+            return real(gi, w_hh, b_hh, B_, T_, G_, Hg_, rec_prec, **kw)
         ops.gru_seq_fwd = patched
     mask, ctx = unet2_forward(mag.view(B, 1, T, 160), eng.flat.P, eng.Bf, m.ch, m.rnn_groups, prec, training=True,
                               save=True, update_running=False)
