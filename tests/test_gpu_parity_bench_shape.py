@@ -13,9 +13,10 @@ pytestmark = pytest.mark.gpu
 
 FWD_TOL = 1e-3               # north_star: "enhanced-spectrogram output matches the reference ... to <= 1e-3 rel"
 # bf16-mode gradient tolerances (backward GEMMs run on plain bf16 operands, f32 accumulate):
-GRAD_TOL_ALL = 2e-2          # all trained tensors as one vector, rel-L2
-GRAD_TOL_TENSOR = 0.10       # any weight matrix / conv kernel, rel-L2
-GRAD_TOL_SUMS = 0.30         # bias / norm-affine vectors: sums over all frames of signed terms (cancellation)
+GRAD_TOL_ALL = 1.5e-2        # all trained tensors as one vector, rel-L2 (measured r5: <= 1.15e-2 over g = 1 / 4, both inits)
+GRAD_TOL_TENSOR = 0.07       # any weight matrix / conv kernel, rel-L2 (measured: <= 5.1e-2, conv4.weight)
+GRAD_TOL_SUMS = 0.22         # bias / norm-affine vectors: sums over all frames of signed terms (cancellation; measured: <= 0.149 at T = 401,
+                             # 0.187 on the T = 21 fixture G6) -- tightened in r5 from 2e-2 / 0.10 / 0.30; the figures repeat to four digits run to run
 
 
 def _pair(grp, init, prec, seed=7):
