@@ -380,6 +380,7 @@ int cruse_wgrad_mfma_try(const float* a, const float* bt, float* partial, int ma
     const int ntiles_n = (ntaps * Cb + 15) / 16;
     const int ntw = (ntiles_n + 3) / 4;
     if (Ca > 64 || ntw > 3) return 0;
+    if (Fa & 1) return 0;            // the staging works on PAIRS of bins of one row (kernel: "Fa is even"): odd widths go to the exact VALU kernel
     if ((Ca * Fa) % 4 != 0 || (Cb * Fb) % 4 != 0 || ((uintptr_t)a % 16) != 0 || ((uintptr_t)bt % 16) != 0) return 0;
     const int esz = (prec == CRUSE_PREC_F32) ? 4 : 2, npl = (prec == CRUSE_PREC_BF16X3) ? 2 : 1;
     auto lds_of = [&](int tf) {

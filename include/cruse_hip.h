@@ -372,7 +372,8 @@ int cruse_transpose_bf16(const float* x, long long rows, int cols, long long ld,
  *   coef [B,T,G,3*Hg] = d(W_hh h + b_hh)-gradient coefficients (c_r, c_z, c_n): dgh_t = dh_t * coef_t
  *                       (bf16 elements when prec == CRUSE_PREC_BF16, f32 otherwise),
  *   an   [B,T,G*Hg]   = dgi_n coefficient ((1-z)(1-n^2)),   z [B,T,G*Hg] = update gate.
- * Hg % 32 == 0, Hg <= 1024.  ws: cruse_gru_ws_bytes() bytes of device scratch.  Its first 256 bytes are a STICKY
+ * Hg % 32 == 0, Hg <= 1024 (the BACKWARD recurrence keeps a [16][3*Hg] operand image in LDS: Hg <= 800 in the f32 and split-bf16
+ * modes, 1024 in CRUSE_PREC_BF16; larger is refused with CRUSE_E_SHAPE).  ws: cruse_gru_ws_bytes() bytes of device scratch.  Its first 256 bytes are a STICKY
  * header the CALLER zeroes once when it allocates the buffer: word 0 becomes non-zero if a hand-off ever timed out
  * (the launch then completes unsynchronised and its outputs are garbage) and is never cleared by the library, so it
  * can be polled once per epoch and handed to cruse_adam_step_guarded as skip_flag.  The hand-off panels behind the

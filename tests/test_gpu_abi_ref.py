@@ -296,3 +296,114 @@ def test_adjoints_time_domain_losses_and_bookkeeping(hip, ref):
     xs = np.ascontiguousarray(np.concatenate([rnd(g, 4090), np.array([1.00390625, 1.01171875, -1.00390625, 3.3895314e38, 0.0, -0.0], np.float32)]))
     yb = np.zeros(xs.size, np.uint16)
     both(hip, ref, "cruse_cast_bf16", [xs, yb, LL(xs.size), None], (1,), 0.0)
+
+
+def test_edge_shapes(hip, ref):
+    """the smallest and the ragged cases: one clip, one frame, one channel, odd widths, channel counts off the MFMA tiles' multiples"""
+    g = rng(9)
+    refused = []
+
+    def both_(name, args, outs, tol, l2=False):
+        """both(), or a LOUD refusal: an entry point may decline a shape outside its documented domain (CRUSE_E_SHAPE + message), never answer wrongly"""
+        try:
+            both(hip, ref, name, args, outs, tol, l2)
+        except RuntimeError as ex:
+            assert "cruse_hip error -1: " in str(ex) and len(str(ex)) > 30, ex
+            refused.append((name, str(ex)[20:90]))
+    # convolutions: (B, T, Cin, Fin, Cout, Fout, KT, S, pad)
+    for (B, T, Cin, Fin, Cout, Fout, KT, S, pad) in ((1, 1, 1, 5, 1, 5, 1, 1, 1), (1, 1, 8, 10, 8, 5, 2, 2, 1), (3, 2, 24, 20, 40, 10, 2, 2, 1),
+                                                     (1, 7, 8, 7, 64, 7, 1, 1, 1), (2, 3, 64, 6, 8, 3, 2, 2, 1), (1, 2, 12, 9, 20, 9, 1, 1, 1)):
+        x, w, bias = rnd(g, B, T, Cin, Fin), rnd(g, Cout, Cin, KT, 3, scale=0.3), rnd(g, Cout)
+        for prec, tol in ((-1, 2e-5), (0, 3e-5), (2, 2e-2)):
+            y = np.zeros((B, T, Cout, Fout), np.float32)
+            both_("cruse_conv_gather", [x, w, bias, y, B, T, Cin, Fin, Cout, Fout, KT, S, pad, 0, 0, 0, prec, 0, 0, None], (3,), tol, l2=prec > 0)
+            if Cout % 4 or (Cin % 4 and Cin != 1):
+                continue                                           # (cruse_conv_wgrad: Ca a multiple of 4, Cb a multiple of 4 or 1 -- refused otherwise, below)
+            dw = rnd(g, Cout, Cin, KT, 3)
+            nws = hip.cruse_conv_wgrad_ws_bytes(Cout, Cin, KT)
+            ws = torch.zeros(max(nws, 16), dtype=torch.uint8, device="cuda")
+            both_("cruse_conv_wgrad", [rnd(g, B, T, Cout, Fout), x, dw, B, T, Cout, Fout, Cin, Fin, KT, S, pad, prec, 0, 0,
+                                       Side(ws.data_ptr(), None), None], (2,), 3e-5 if prec <= 0 else 2e-2, l2=prec > 0)
+    for (B, T, Cs, Fg, Cout, KT, pad) in ((1, 1, 1, 1, 1, 1, 0), (1, 1, 8, 3, 8, 2, 1), (2, 3, 40, 5, 24, 1, 0), (1, 2, 64, 4, 64, 2, 1)):
+        gq, w, bias = rnd(g, B, T, Cs, Fg), rnd(g, Cs, Cout, KT, 3, scale=0.3), rnd(g, Cout)
+        for prec, tol in ((-1, 2e-5), (0, 3e-5), (2, 2e-2)):
+            y = np.zeros((B, T, Cout, 2 * Fg), np.float32)
+            both_("cruse_conv_scatter2", [gq, w, bias, y, B, T, Cs, Fg, Cout, 2 * Fg, KT, pad, 0, 0, prec, 0, 0, None], (3,), tol, l2=prec > 0)
+    # normalisations on one row / one position
+    for (rows, C, Fq) in ((1, 1, 1), (1, 3, 7), (5, 130, 3)):
+        y = rnd(g, rows, C, Fq, shift=0.5)
+        sums = np.zeros(2 * C)
+        both_("cruse_bn_stats", [y, LL(rows), C, Fq, sums, 0, None], (4,), 1e-6)
+        o = rnd(g, C)
+        both_("cruse_channel_sum", [y, LL(rows), C, Fq, o, None], (4,), 2e-5)
+    for (rows, H, ig) in ((1, 32, 1), (3, 96, 3), (2, 1024, 4)):
+        x, res = rnd(g, rows, H), rnd(g, rows, H)
+        gamma, beta = rnd(g, H, scale=0.3, shift=1.0), rnd(g, H, scale=0.2)
+        y, mean, rstd = np.zeros((rows, H), np.float32), np.zeros(rows, np.float32), np.zeros(rows, np.float32)
+        both_("cruse_ln_fwd", [x, gamma, beta, res, y, None, mean, rstd, LL(rows), H, ig, 1e-5, 0, LL(0), LL(0), None], (4, 6, 7), 5e-6)
+        dx, dgm, dbt = np.zeros((rows, H), np.float32), rnd(g, H), rnd(g, H)
+        both_("cruse_ln_bwd", [rnd(g, rows, H), x, mean, rstd, gamma, LL(rows), H, ig, dx, dgm, dbt, None], (8, 9, 10), 2e-5)
+    # the recurrence on one clip / one frame / the largest unit count, and a batch that is not a multiple of a chain
+    for (B, T, G, Hg) in ((1, 1, 1, 32), (1, 5, 1, 1024), (13, 3, 4, 32), (17, 2, 1, 160)):
+        H = G * Hg
+        gi = rnd(g, B, T, G, 3 * Hg)
+        w = [rnd(g, 3 * Hg, Hg, scale=1.0 / np.sqrt(Hg)) for _ in range(G)]
+        bh = [rnd(g, 3 * Hg, scale=0.1) for _ in range(G)]
+        wd, bd = [torch.from_numpy(a).cuda() for a in w], [torch.from_numpy(a).cuda() for a in bh]
+        wa = Side(ctypes.cast((ctypes.c_void_p * G)(*[t.data_ptr() for t in wd]), ctypes.c_void_p), R.ptr_array(w))
+        ba = Side(ctypes.cast((ctypes.c_void_p * G)(*[t.data_ptr() for t in bd]), ctypes.c_void_p), R.ptr_array(bh))
+        ws = torch.zeros(hip.cruse_gru_ws_bytes(B, G, Hg), dtype=torch.uint8, device="cuda")
+        wsa = Side(ws.data_ptr(), None)
+        for prec, tol in ((0, 3e-5), (2, 3e-2)):
+            h, an, z = (np.zeros((B, T, H), np.float32) for _ in range(3))
+            coef = np.zeros((B, T, G, 3 * Hg), np.uint16 if prec == 2 else np.float32)
+            both_("cruse_gru_seq_fwd", [gi, wa, ba, h, coef, an, z, B, T, G, Hg, prec, wsa, None], (3, 4, 5, 6), tol, l2=prec == 2)
+            dh = np.zeros((B, T, H), np.float32)
+            both_("cruse_gru_seq_bwd", [rnd(g, B, T, H), wa, coef, z, dh, B, T, G, Hg, prec, wsa, None], (4,), tol, l2=prec == 2)
+        assert int(ws[:4].view(torch.int32)[0]) == 0
+    # a shape outside an entry point's domain is refused with CRUSE_E_SHAPE and a message, never computed wrongly
+    a1, b1, d1 = (torch.zeros(8, device="cuda") for _ in range(3))
+    assert hip.cruse_conv_wgrad(a1.data_ptr(), b1.data_ptr(), d1.data_ptr(), 1, 1, 1, 5, 1, 5, 1, 1, 1, -1, 0, 0, None, None) == -1
+    assert b"multiple of 4" in hip.cruse_last_error()
+    # STFT of clips shorter than a frame and a half (reflect padding reaches back over most of the clip; at L = 161, the shortest torch
+    # admits, both frames are mirror-symmetric and the imaginary part is identically 0 -- compared on the real part there)
+    for L, outs in ((161, (5,)), (200, (5, 6)), (321, (5, 6))):
+        T = 1 + L // 160
+        x = rnd(g, 1, L, scale=0.1)
+        re, im = np.zeros((1, T, 161), np.float32), np.zeros((1, T, 161), np.float32)
+        both_("cruse_stft_fwd", [x, 1, L, 320, 160, re, im, None, 0, 0.0, None], outs, 3e-5)
+    print("refused (outside the documented domain):", sorted(set(refused)))
+    # the convolutions, the forward recurrence and the STFT take every shape above; the documented limits that do refuse: bn_stats rows of C*F % 4 != 0 or
+    # > 768 floats, weight-gradient tile counts the exact VALU kernel cannot split over 256 threads, the f32 backward recurrence beyond Hg = 800 (LDS)
+    assert not any(n in ("cruse_conv_gather", "cruse_conv_scatter2", "cruse_gru_seq_fwd", "cruse_stft_fwd", "cruse_ln_fwd", "cruse_ln_bwd") for n, _ in refused)
+    assert all("Hg=1024" in m for n, m in refused if n == "cruse_gru_seq_bwd")
+    assert set(n for n, _ in refused) <= {"cruse_bn_stats", "cruse_conv_wgrad", "cruse_gru_seq_bwd"}
+
+
+def test_conv_wgrad_sweep_over_small_and_odd_widths(hip, ref):
+    """every width 1..13 (odd ones used to reach the LDS-staged MFMA kernel, which pairs the bins of a row: wrong sums, found by this sweep in r5 --
+    they now take the exact VALU kernel), T of 1 and 5, both strides and tap counts, in the f32-MFMA and bf16 modes: the result is the twin's or the
+    call is refused"""
+    g = rng(10)
+    checked = 0
+    for prec, tol in ((0, 1e-4), (2, 3e-2)):
+        for KT, S in ((1, 1), (2, 2), (1, 2), (2, 1)):
+            for Ca, Cb in ((8, 8), (64, 8), (20, 12), (8, 64)):
+                for Fa in range(1, 14):
+                    for T in (1, 5):
+                        B, Fb = 2, Fa * S
+                        a, x, dw = rnd(g, B, T, Ca, Fa), rnd(g, B, T, Cb, Fb), rnd(g, Ca, Cb, KT, 3)
+                        want = dw.copy()
+                        R.call(ref, "cruse_conv_wgrad", a, x, want, B, T, Ca, Fa, Cb, Fb, KT, S, 1, prec, 0, 0, None, None)
+                        ws = torch.zeros(max(hip.cruse_conv_wgrad_ws_bytes(Ca, Cb, KT), 16), dtype=torch.uint8, device="cuda")
+                        ad, xd, dd = torch.from_numpy(a).cuda(), torch.from_numpy(x).cuda(), torch.from_numpy(dw).cuda()
+                        rc = hip.cruse_conv_wgrad(ad.data_ptr(), xd.data_ptr(), dd.data_ptr(), B, T, Ca, Fa, Cb, Fb, KT, S, 1, prec, 0, 0, ws.data_ptr(),
+                                                  torch.cuda.current_stream().cuda_stream)
+                        if rc != 0:
+                            assert rc == -1 and hip.cruse_last_error(), (prec, KT, S, Ca, Cb, Fa, T)
+                            continue
+                        got = dd.cpu().numpy().astype(np.float64)
+                        err = np.abs(got - want).max() / np.abs(want).max()
+                        assert err <= tol, (prec, KT, S, Ca, Cb, Fa, T, err)
+                        checked += 1
+    assert checked > 600
