@@ -407,3 +407,53 @@ def test_conv_wgrad_sweep_over_small_and_odd_widths(hip, ref):
                         assert err <= tol, (prec, KT, S, Ca, Cb, Fa, T, err)
                         checked += 1
     assert checked > 600
+
+
+def test_conv_sweep_over_small_and_odd_widths(hip, ref):
+    """gather and scatter forms over widths 1 ... 40 (odd ones too), one and three frames, every tap / stride / pad / weight-layout form and channel
+    pairs on and off the MFMA tiles, in the f32-MFMA, split-bf16 and bf16 modes: the twin's result, or a refusal"""
+    g = rng(11)
+    st = torch.cuda.current_stream().cuda_stream
+    checked = 0
+    for prec, tol in ((0, 1e-4), (1, 2e-4), (2, 3e-2)):
+        for KT, S, pad, wl in ((2, 2, 1, 0), (1, 1, 1, 1), (2, 1, 1, 0), (1, 2, 0, 0)):
+            for Cin, Cout in ((8, 8), (64, 16), (24, 40), (8, 1), (1, 8)):
+                for Fin in (1, 3, 5, 8, 9, 17, 40):
+                    for T in (1, 3):
+                        B, Fout = 2, (Fin + 2 * pad - 3) // S + 1
+                        if Fout <= 0:
+                            continue
+                        x, bias = rnd(g, B, T, Cin, Fin), rnd(g, Cout)
+                        w = rnd(g, *((Cin, Cout, 1, 3) if wl else (Cout, Cin, KT, 3)), scale=0.3)
+                        want = np.zeros((B, T, Cout, Fout), np.float32)
+                        R.call(ref, "cruse_conv_gather", x, w, bias, want, B, T, Cin, Fin, Cout, Fout, KT, S, pad, wl, 0, 0, prec, 0, 0, None)
+                        xd, wd, bd = torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda(), torch.from_numpy(bias).cuda()
+                        yd = torch.zeros(B, T, Cout, Fout, device="cuda")
+                        rc = hip.cruse_conv_gather(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), yd.data_ptr(), B, T, Cin, Fin, Cout, Fout, KT, S, pad, wl, 0, 0,
+                                                   prec, 0, 0, st)
+                        if rc != 0:
+                            assert rc == -1 and hip.cruse_last_error()
+                            continue
+                        got = yd.cpu().numpy().astype(np.float64)
+                        err = np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30)
+                        assert err <= tol, ("gather", prec, KT, S, pad, wl, Cin, Cout, Fin, T, err)
+                        checked += 1
+        for KT, pad in ((1, 0), (2, 1)):
+            for Cs, Cout in ((8, 8), (64, 64), (40, 24), (16, 1)):
+                for Fg in (1, 3, 5, 8, 13, 40):
+                    for T in (1, 3):
+                        B = 2
+                        gq, w, bias = rnd(g, B, T, Cs, Fg), rnd(g, Cs, Cout, KT, 3, scale=0.3), rnd(g, Cout)
+                        want = np.zeros((B, T, Cout, 2 * Fg), np.float32)
+                        R.call(ref, "cruse_conv_scatter2", gq, w, bias, want, B, T, Cs, Fg, Cout, 2 * Fg, KT, pad, 0, 0, prec, 0, 0, None)
+                        gd, wd, bd = torch.from_numpy(gq).cuda(), torch.from_numpy(w).cuda(), torch.from_numpy(bias).cuda()
+                        yd = torch.zeros(B, T, Cout, 2 * Fg, device="cuda")
+                        rc = hip.cruse_conv_scatter2(gd.data_ptr(), wd.data_ptr(), bd.data_ptr(), yd.data_ptr(), B, T, Cs, Fg, Cout, 2 * Fg, KT, pad, 0, 0, prec, 0, 0, st)
+                        if rc != 0:
+                            assert rc == -1 and hip.cruse_last_error()
+                            continue
+                        got = yd.cpu().numpy().astype(np.float64)
+                        err = np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30)
+                        assert err <= tol, ("scatter2", prec, KT, pad, Cs, Cout, Fg, T, err)
+                        checked += 1
+    assert checked > 900
