@@ -324,7 +324,9 @@ __global__ __launch_bounds__(NW * 64, NW == 5 ? 4 : 1) void conv_mfma_kernel(CMA
             auto slot_off = [&](int q) -> long long {
                 const int t = t0 - a.halo_lo + c_row[q];
                 const bool ok = c_row[q] >= 0 && t >= 0 && t < a.T;
-                return (ok ? base : 0ll) + c_src[q];
+                // (a row outside the clip reads the same columns of FRAME 0 OF THE TENSOR -- not of tile row r: a tensor of fewer than
+                //  nrows frames, e.g. one clip of four, ends before that)
+                return ok ? base + c_src[q] : (long long)(c_src[q] - max(c_row[q], 0) * rowlen);
             };
             if (vw4) {
                 const long long off = slot_off(0);

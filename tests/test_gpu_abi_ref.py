@@ -34,6 +34,12 @@ class Side:
         self.hip, self.ref = hip, ref
 
 
+def PLACE(a):
+    """device mirror of a host array (tools/abi_guard_sweep.py swaps this for a placement at the very end of an allocator segment, so that a
+    read or write past a tensor leaves the mapping and faults)"""
+    return torch.from_numpy(a).cuda()
+
+
 def rng(seed):
     return np.random.default_rng(seed)
 
@@ -52,7 +58,7 @@ def both(hip, ref, name, args, outs, tol, l2=False):
         if isinstance(a, Side):
             hargs.append(a.hip); rargs.append(a.ref)
         elif isinstance(a, np.ndarray):
-            t = torch.from_numpy(a).cuda()
+            t = PLACE(a)
             dev[i] = t
             hargs.append(t.data_ptr()); rargs.append(a)
         elif isinstance(a, LL):
@@ -202,7 +208,7 @@ def test_gru_recurrence_and_gate_gradients(hip, ref):
         gi = rnd(g, B, T, G, 3 * Hg)
         w = [rnd(g, 3 * Hg, Hg, scale=1.0 / np.sqrt(Hg)) for _ in range(G)]
         bh = [rnd(g, 3 * Hg, scale=0.1) for _ in range(G)]
-        wd, bd = [torch.from_numpy(a).cuda() for a in w], [torch.from_numpy(a).cuda() for a in bh]
+        wd, bd = [PLACE(a) for a in w], [PLACE(a) for a in bh]
         wa = Side(ctypes.cast((ctypes.c_void_p * G)(*[t.data_ptr() for t in wd]), ctypes.c_void_p), R.ptr_array(w))
         ba = Side(ctypes.cast((ctypes.c_void_p * G)(*[t.data_ptr() for t in bd]), ctypes.c_void_p), R.ptr_array(bh))
         ws = torch.zeros(hip.cruse_gru_ws_bytes(B, G, Hg), dtype=torch.uint8, device="cuda")
@@ -349,7 +355,7 @@ def test_edge_shapes(hip, ref):
         gi = rnd(g, B, T, G, 3 * Hg)
         w = [rnd(g, 3 * Hg, Hg, scale=1.0 / np.sqrt(Hg)) for _ in range(G)]
         bh = [rnd(g, 3 * Hg, scale=0.1) for _ in range(G)]
-        wd, bd = [torch.from_numpy(a).cuda() for a in w], [torch.from_numpy(a).cuda() for a in bh]
+        wd, bd = [PLACE(a) for a in w], [PLACE(a) for a in bh]
         wa = Side(ctypes.cast((ctypes.c_void_p * G)(*[t.data_ptr() for t in wd]), ctypes.c_void_p), R.ptr_array(w))
         ba = Side(ctypes.cast((ctypes.c_void_p * G)(*[t.data_ptr() for t in bd]), ctypes.c_void_p), R.ptr_array(bh))
         ws = torch.zeros(hip.cruse_gru_ws_bytes(B, G, Hg), dtype=torch.uint8, device="cuda")
@@ -396,7 +402,7 @@ def test_conv_wgrad_sweep_over_small_and_odd_widths(hip, ref):
                         want = dw.copy()
                         R.call(ref, "cruse_conv_wgrad", a, x, want, B, T, Ca, Fa, Cb, Fb, KT, S, 1, prec, 0, 0, None, None)
                         ws = torch.zeros(max(hip.cruse_conv_wgrad_ws_bytes(Ca, Cb, KT), 16), dtype=torch.uint8, device="cuda")
-                        ad, xd, dd = torch.from_numpy(a).cuda(), torch.from_numpy(x).cuda(), torch.from_numpy(dw).cuda()
+                        ad, xd, dd = PLACE(a), PLACE(x), PLACE(dw)
                         rc = hip.cruse_conv_wgrad(ad.data_ptr(), xd.data_ptr(), dd.data_ptr(), B, T, Ca, Fa, Cb, Fb, KT, S, 1, prec, 0, 0, ws.data_ptr(),
                                                   torch.cuda.current_stream().cuda_stream)
                         if rc != 0:
@@ -427,8 +433,8 @@ def test_conv_sweep_over_small_and_odd_widths(hip, ref):
                         w = rnd(g, *((Cin, Cout, 1, 3) if wl else (Cout, Cin, KT, 3)), scale=0.3)
                         want = np.zeros((B, T, Cout, Fout), np.float32)
                         R.call(ref, "cruse_conv_gather", x, w, bias, want, B, T, Cin, Fin, Cout, Fout, KT, S, pad, wl, 0, 0, prec, 0, 0, None)
-                        xd, wd, bd = torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda(), torch.from_numpy(bias).cuda()
-                        yd = torch.zeros(B, T, Cout, Fout, device="cuda")
+                        xd, wd, bd = PLACE(x), PLACE(w), PLACE(bias)
+                        yd = PLACE(np.zeros((B, T, Cout, Fout), np.float32))
                         rc = hip.cruse_conv_gather(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), yd.data_ptr(), B, T, Cin, Fin, Cout, Fout, KT, S, pad, wl, 0, 0,
                                                    prec, 0, 0, st)
                         if rc != 0:
@@ -446,8 +452,8 @@ def test_conv_sweep_over_small_and_odd_widths(hip, ref):
                         gq, w, bias = rnd(g, B, T, Cs, Fg), rnd(g, Cs, Cout, KT, 3, scale=0.3), rnd(g, Cout)
                         want = np.zeros((B, T, Cout, 2 * Fg), np.float32)
                         R.call(ref, "cruse_conv_scatter2", gq, w, bias, want, B, T, Cs, Fg, Cout, 2 * Fg, KT, pad, 0, 0, prec, 0, 0, None)
-                        gd, wd, bd = torch.from_numpy(gq).cuda(), torch.from_numpy(w).cuda(), torch.from_numpy(bias).cuda()
-                        yd = torch.zeros(B, T, Cout, 2 * Fg, device="cuda")
+                        gd, wd, bd = PLACE(gq), PLACE(w), PLACE(bias)
+                        yd = PLACE(np.zeros((B, T, Cout, 2 * Fg), np.float32))
                         rc = hip.cruse_conv_scatter2(gd.data_ptr(), wd.data_ptr(), bd.data_ptr(), yd.data_ptr(), B, T, Cs, Fg, Cout, 2 * Fg, KT, pad, 0, 0, prec, 0, 0, st)
                         if rc != 0:
                             assert rc == -1 and hip.cruse_last_error()
