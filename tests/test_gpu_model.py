@@ -364,3 +364,36 @@ def test_batchnorm_applied_in_the_consumer_convs_staging_is_the_same_step(grp):
     assert rel_l2(res[True][2], res[False][2]) < 5e-5
     for k, v in res[False][3].items():
         assert torch.equal(res[True][3][k], v), k
+
+
+@pytest.mark.parametrize("prec,ltol,gtol", [("f32", 2e-5, 2e-3), ("bf16", 2e-3, 0.12)])
+def test_engine_step_at_odd_batch_sizes_and_clip_lengths(prec, ltol, gtol):
+    """one engine step (loss, every gradient as one vector) against oracle autograd where tensors are shorter than the kernels' tiles or ragged
+    against them: one clip of 2 / 4 / 6 frames, 3 / 9 / 17 clips, clip lengths off the hop, every group count (r5: a one-clip batch of the g = 4 model
+    made the conv staging read past its input)"""
+    from cruse_amd import ops
+    from cruse_amd.engine import TrainEngine
+    from cruse_amd.model import cruse_net as M
+    from oracle import cruse_oracle as O
+    for grp in (1, 2, 4):
+        for (B, L) in ((1, 161), (1, 480), (1, 800), (3, 1000), (2, 3199), (9, 1600), (17, 800)):
+            torch.manual_seed(B * 7 + grp)
+            o = O.unet_2(rnn_groups=grp)
+            m = M.unet_2(rnn_groups=grp, precision=prec)
+            m.load_state_dict(o.state_dict(), strict=True)
+            o.train()
+            noisy, clean = O.synth_pair(B, L, seed=B + L)
+            loss_o, _ = O.train_step_loss(o, noisy, clean)
+            loss_o.backward()
+            eng = TrainEngine(m.cuda(), use_graph=False)
+            ls = eng._fwd_bwd(noisy.cuda(), clean.cuda())
+            torch.cuda.synchronize()
+            assert abs(eng.loss_value(ls) - float(loss_o)) <= ltol * abs(float(loss_o)), (grp, B, L)
+            allg, allo = [], []
+            for name, p in o.named_parameters():
+                dead = name.endswith(".bias") and name.startswith("conv") and name != "conv1_t.bias"     # a bias in front of a BatchNorm: d/db == 0
+                if name in eng.flat.G and p.grad is not None and not dead:
+                    allg.append(eng.flat.G[name].detach().double().cpu().flatten()); allo.append(p.grad.double().flatten())
+            err = float((torch.cat(allg) - torch.cat(allo)).norm() / torch.cat(allo).norm())
+            assert err <= gtol, (grp, B, L, err)
+            assert ops.gru_status() == 0
