@@ -12,6 +12,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_abi_ref as T  # noqa: E402
+import test_gpu_abi_sweeps as T2  # noqa: E402
 import ref_lib as R  # noqa: E402
 
 SEG = 20 * 1024 * 1024
@@ -33,15 +34,18 @@ def guard_place(a):
 def main():
     from cruse_amd._lib import lib
     T.PLACE = guard_place
+    T2.PLACE = guard_place
     ref = R.load()
-    names = [n for n in dir(T) if n.startswith("test_")]
     pick = sys.argv[1:]
-    for n in names:
-        if pick and not any(p in n for p in pick):
-            continue
-        print("running", n, flush=True)
-        getattr(T, n)(lib, ref)
-        torch.cuda.synchronize()
+    import inspect
+    for mod in (T, T2):
+        for n in [n for n in dir(mod) if n.startswith("test_")]:
+            if pick and not any(p in n for p in pick):
+                continue
+            print("running", n, flush=True)
+            fn = getattr(mod, n)
+            fn(*[{"hip": lib, "ref": ref}[a] for a in inspect.signature(fn).parameters])
+            torch.cuda.synchronize()
     print("no out-of-bounds access reached an unmapped page")
 
 
