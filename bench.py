@@ -434,6 +434,36 @@ def secondary_rows(a, dev, pool):
         del e, m
     except Exception as ex:                                  # secondary rows never break the headline line
         out["f32_gate_mode"] = {"error": repr(ex)[:200]}
+    # (1b) the headline's bf16 mode with GGRU layer 1's gate projection on f16 x against two f16 planes of W_ih as well (EngineConfig.gi_f16 = 3;
+    #      cruse_gemm_f16x2_nt): the same two passes as the default's bf16 x . W hi / lo, 11 instead of 8 bits on x.  Not the default: one vector of
+    #      the closed-form fixture G16 leaves its gradient-norm tolerance by 0.006
+    try:
+        from cruse_amd import config as _cfg
+        torch.manual_seed(0)
+        m = unet_2(rnn_groups=a.groups, precision="bf16").to(dev)
+        cfg = _cfg.EngineConfig(gi_f16=3)
+        n = 20
+        forms = {}
+        # both launch forms, the faster is the figure (as the headline and the config rows: host threads of the CPU legs may still be winding down)
+        for form in ([False] if a.no_graph else [True, False]):
+            e = TrainEngine(m, lr=1e-3, use_graph=form, config=cfg)
+            forms["graph" if form else "eager"] = _time_steps(e, pool, n_warm=4, n=n) * 1e-3
+        kept = min(forms, key=forms.get)
+        dt = forms[kept]
+        B, L = pool[0][0].shape
+        row = {"value": round(B * (1 + L // 160) / dt, 1), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3), "steps": n, "dtype": "bf16",
+               "launch_form": kept, "ms_per_step_by_form": {k: round(v * 1e3, 3) for k, v in forms.items()}, "timeouts": ops.gru_status(),
+               "note": "the headline step with EngineConfig.gi_f16 = 3: layer-1 gate projection as f16 x . (W_ih hi + lo)^T (cruse_gemm_f16x2_nt)"}
+        if not a.no_parity:
+            torch.manual_seed(0)
+            m2 = unet_2(rnn_groups=a.groups, precision="bf16").to(dev)          # (fresh weights, as the headline's parity figure)
+            with _cfg.use(cfg):
+                row["parity_rel_l2"] = float(f"{parity_figure(m2, a.groups, 'bf16'):.4g}")
+            row["parity_note"] = "enhanced-spectrum rel-L2 vs the CPU oracle at T=401, B=8 (bar 1e-3; the default mode: parity_rel_l2 of the main line)"
+        out["layer1_f16x2_mode"] = row
+        del e, m
+    except Exception as ex:
+        out["layer1_f16x2_mode"] = {"error": repr(ex)[:200]}
     try:
         x = pool[0][0]
         B, L = x.shape

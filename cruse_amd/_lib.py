@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcruse_hip.so")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16 = 0, 1, 2, 3
 PREC_BY_NAME = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "f16": PREC_F16}
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
@@ -67,6 +67,8 @@ SIGNATURES = {
     "cruse_ktile_bf16": ("piiqppp", "i"),
     "cruse_ktile_f16": ("piiqpp", "i"),
     "cruse_gemm_f16_nt": ("iiipqqpqqpqpp", "i"),
+    "cruse_gemm_f16x2_nt": ("iiipqqppqqpqpp", "i"),
+    "cruse_ktile_f16_split": ("piiqppp", "i"),
     "cruse_cast_bf16_split": ("pppqp", "i"),
     "cruse_gemm_bf16x3_nt": ("iiippqqppqqpqpip", "i"),
     "cruse_gru_ws_bytes": ("iii", "z"),

@@ -28,10 +28,13 @@ class EngineConfig:
     fuse_bn_bwd_stats: bool = True  # BatchNorm BACKWARD sums in the epilogue of the data-gradient conv that produces the incoming gradient
     gi_x3: Optional[int] = None     # forward gate projections: bit 0 / 1 = W_ih low-plane pass on layer 1 / 2, bit 2 = also split x
                                     # (None: 7 for Hg <= 320, else 3)
-    gi_f16: int = 2                 # forward gate projections as ONE pass on IEEE-f16 operands (cruse_gemm_f16_nt; with g = 1 the BatchNorm /
-                                    # LayerNorm producers write the f16 operand copies) instead of bf16 x with W_ih hi / lo planes (gi_x3): both
-                                    # operands carry 11 significant bits -- enhanced-spectrum rel-L2 at T = 401 4.6e-4 -> 3.8e-4 (closed-form init),
-                                    # 3.6e-4 -> 1.6e-4 (random init) -- and the step loses the low-plane pass (4.85 -> 4.76 ms, r4).  False: gi_x3 form
+    gi_f16: int = 2                 # forward gate projections on IEEE-f16 operands (bit 0 / 1 = GGRU layer 1 / 2; with g = 1 the BatchNorm / LayerNorm
+                                    # producers write the f16 operand copies) instead of bf16 x with W_ih hi / lo planes (gi_x3): x carries 11 bits instead of 8.
+                                    # Layer 2 (default): ONE pass (cruse_gemm_f16_nt), 4.85 -> 4.76 ms (r4).  Layer 1 (bit 0, off by default): f16 x against f16
+                                    # hi + lo planes of W_ih (cruse_gemm_f16x2_nt: two passes, the time of the bf16 form it replaces) -- mask 3 measures
+                                    # 1.6e-4 instead of 2.8e-4 (torch init) / 3.7e-4 instead of 4.1e-4 (closed-form) at T = 401 and better gradients at bench
+                                    # length and on fixture G6, but moves ONE vector of the closed-form fixture G16 (gru.ln1.bias) to 0.306 of its 0.30
+                                    # tolerance, with or without the low plane: DESIGN.md section 2.  0: the gi_x3 forms on both layers
     fuse_bn_fwd: bool = True        # bf16 mode, training: BatchNorm-apply + ReLU (+ decoder skip add) of a level run inside the STAGING of
                                     # the convs that consume it (cruse_conv_*_bnin) -- the normalised tensors e_k (k < L) and u_k (k >= 2)
                                     # never exist in f32; the weight gradients read a bf16 copy the consuming conv writes while staging

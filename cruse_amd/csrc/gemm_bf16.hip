@@ -443,11 +443,15 @@ __global__ __launch_bounds__(256) void ktile_bf16_kernel(const float* x, int row
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         const int n = (int)(i / kq), k = (int)(i - (long long)n * kq) * 4;
         const long long o = (long long)(k >> 6) * rows * 64 + (long long)n * 64 + (k & 63);
-        if constexpr (F16) {                     // (no low plane: the f16 projection is one pass)
-            f16x4 h;
+        if constexpr (F16) {                     // (y_lo: the low plane f16(x - f16(x)) of the two-pass form cruse_gemm_f16x2_nt)
+            f16x4 h, l;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) h[e] = (_Float16)((k + e < cols) ? x[n * ld + k + e] : 0.f);
+            for (int e = 0; e < 4; ++e) {
+                const float f = (k + e < cols) ? x[n * ld + k + e] : 0.f;
+                h[e] = (_Float16)f; l[e] = (_Float16)(f - (float)h[e]);
+            }
             *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(y) + o) = h;
+            if (y_lo) *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(y_lo) + o) = l;
         } else {
             bf16x4 h, l;
 #pragma unroll
@@ -495,8 +499,8 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
     CRUSE_REQUIRE(!atr && !c_bf16, CRUSE_E_SHAPE, "gemm_bf16_nt: the transposed-A and bf16-output forms were removed (measured neutral / slower, r3-r4)");
     CRUSE_REQUIRE(!atr || (!A_lo && !B_lo && !c_bf16 && !slabs && splitk == 1 && !f16 && !cat && seg_len == 0), CRUSE_E_SHAPE,
                   "gemm_bf16_nt_atr: plain bf16, one pass, no split-K");
-    CRUSE_REQUIRE(!f16 || (!A_lo && !B_lo && !c_bf16 && !slabs && splitk == 1 && !accumulate), CRUSE_E_SHAPE,
-                  "gemm_f16_nt: one pass, f32 result stored (no low planes, no split-K, no accumulation)");
+    CRUSE_REQUIRE(!f16 || (!A_lo && !c_bf16 && !slabs && splitk == 1 && !accumulate), CRUSE_E_SHAPE,
+                  "gemm_f16_nt: f32 result stored (no A low plane, no split-K, no accumulation)");
     CRUSE_REQUIRE(!c_bf16 || (!accumulate && splitk == 1), CRUSE_E_SHAPE, "gemm_bf16_nt: a bf16 result is stored, not accumulated");
     CRUSE_REQUIRE(seg_len >= 0 && (seg_len == 0 || (seg_stride >= seg_len && seg_off >= 0 && M % seg_len == 0 && a_kstride == BK)),
                   CRUSE_E_SHAPE, "gemm_bf16_nt: bad row segments (len %d stride %lld off %lld, M %d; row-major A only)", seg_len,
@@ -600,6 +604,17 @@ extern "C" int cruse_gemm_bf16_nt(int M, int N, int K, const void* A, long long 
                                   void* stream) {
     return gemm_bf16_impl(M, N, K, A, nullptr, lda, a_kstride, B, nullptr, ldb, b_kstride, C, ldc, bias, accumulate, splitk,
                           stream);
+}
+
+// ... with B = B_hi + B_lo (two f16 planes, same layout): C = A . B_hi^T + A . B_lo^T in one launch (the second k-range on the same accumulators) --
+// 11 significant bits on the activations and ~20 on the weights: the forward gate projection of GGRU layer 1 (the rounding of W_ih is the same in
+// every frame and does not average out of the gradients the way the per-frame rounding of x does)
+extern "C" int cruse_gemm_f16x2_nt(int M, int N, int K, const void* A, long long lda, long long a_kstride,
+                                   const void* B_hi, const void* B_lo, long long ldb, long long b_kstride,
+                                   float* C, long long ldc, const float* bias, void* stream) {
+    CRUSE_REQUIRE(B_lo != nullptr, CRUSE_E_SHAPE, "gemm_f16x2_nt: B_lo is required (one plane: cruse_gemm_f16_nt)");
+    return gemm_bf16_impl(M, N, K, A, nullptr, lda, a_kstride, B_hi, B_lo, ldb, b_kstride, C, ldc, bias, 0, 1, stream, 0, 0, 0, false,
+                          nullptr, 0, true);
 }
 
 // C[M,N] = A[M,K] . B[N,K]^T + bias with IEEE-f16 operands (layouts as cruse_gemm_bf16_nt): the forward gate projection in one pass
@@ -742,15 +757,22 @@ extern "C" int cruse_ktile_bf16(const float* x, int rows, int cols, long long ld
 }
 
 // the same K-tiled layout with IEEE-f16 elements (the B operand of cruse_gemm_f16_nt)
-extern "C" int cruse_ktile_f16(const float* x, int rows, int cols, long long ld, void* y, void* stream) {
+static int ktile_f16_impl(const float* x, int rows, int cols, long long ld, void* y, void* y_lo, void* stream) {
     CRUSE_REQUIRE(rows > 0 && cols > 0 && ld >= cols, CRUSE_E_SHAPE, "ktile_f16: bad shape");
-    CRUSE_REQUIRE(((uintptr_t)y % 8) == 0, CRUSE_E_ALIGN, "ktile_f16: unaligned output");
+    CRUSE_REQUIRE(((uintptr_t)y % 8) == 0 && ((uintptr_t)y_lo % 8) == 0, CRUSE_E_ALIGN, "ktile_f16: unaligned output");
     const int kp = (cols + 63) / 64 * 64;
     long long nb = ((long long)rows * (kp / 4) + 255) / 256;
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(ktile_bf16_kernel<true>, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, (__bf16*)y,
-                       (__bf16*)nullptr, kp);
+                       (__bf16*)y_lo, kp);
     CRUSE_LAUNCH_CHECK("ktile_f16");
     return CRUSE_OK;
+}
+extern "C" int cruse_ktile_f16(const float* x, int rows, int cols, long long ld, void* y, void* stream) {
+    return ktile_f16_impl(x, rows, cols, ld, y, nullptr, stream);
+}
+extern "C" int cruse_ktile_f16_split(const float* x, int rows, int cols, long long ld, void* y, void* y_lo, void* stream) {
+    CRUSE_REQUIRE(y_lo != nullptr, CRUSE_E_SHAPE, "ktile_f16_split: y_lo is required");
+    return ktile_f16_impl(x, rows, cols, ld, y, y_lo, stream);
 }
 

@@ -325,7 +325,10 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
             grouped = False
         for i in range(0 if not grouped else g, g):
             w_ih, b_ih = P[f"{prefix}{lname}.{i}.weight_ih_l0"], P[f"{prefix}{lname}.{i}.bias_ih_l0"]
-            if inp_bf is not None and inp_bf.dtype == torch.float16:          # _gi_f16: one pass, 11-bit operands
+            if inp_bf is not None and inp_bf.dtype == torch.float16 and x3 and lname == "gru_list1":   # layer 1 on f16 (gi_f16 bit 0) with its gi_x3 bit: f16 x against W_ih hi + lo planes
+                w_hi, w_lo = ops.ktile_f16(w_ih, 3 * Hg, Hg, split=True)
+                ops.gemm_f16_nt(rows, 3 * Hg, kp, inp_bf, i * Hg, H, w_hi, 0, 64, gi, i * 3 * Hg, 3 * H, bias=b_ih, b_kstride=3 * Hg * 64, B_lo=w_lo)
+            elif inp_bf is not None and inp_bf.dtype == torch.float16:        # _gi_f16: one pass, 11-bit operands
                 ops.gemm_f16_nt(rows, 3 * Hg, kp, inp_bf, i * Hg, H, ops.ktile_f16(w_ih, 3 * Hg, Hg), 0, 64, gi, i * 3 * Hg, 3 * H,
                                 bias=b_ih, b_kstride=3 * Hg * 64)
             elif fast and x3:

@@ -587,18 +587,27 @@ def ktile_bf16(x, rows, cols, split=False, out=None):
     return (y, lo) if split else y
 
 
-def ktile_f16(x, rows, cols):
-    """x [rows, cols] f32 -> K-tiled IEEE f16 [ceil(cols/64), rows, 64] (the layout of ktile_bf16): the B operand of gemm_f16_nt"""
+def ktile_f16(x, rows, cols, split=False):
+    """x [rows, cols] f32 -> K-tiled IEEE f16 [ceil(cols/64), rows, 64] (the layout of ktile_bf16): the B operand of gemm_f16_nt.
+    split: returns (hi, lo) with lo = f16(x - hi) (cruse_ktile_f16_split): the planes of gemm_f16_nt(B_lo=...)"""
     y = torch.empty((cols + 63) // 64, rows, 64, device=x.device, dtype=torch.float16)
+    if split:
+        lo = torch.empty_like(y)
+        check(lib.cruse_ktile_f16_split(_p(x), rows, cols, cols, _p(y), _p(lo), _stream()))
+        return y, lo
     check(lib.cruse_ktile_f16(_p(x), rows, cols, cols, _p(y), _stream()))
     return y
 
 
-def gemm_f16_nt(M, N, K, A, a_off, lda, B, b_off, ldb, C, c_off, ldc, bias=None, a_kstride=64, b_kstride=64):
+def gemm_f16_nt(M, N, K, A, a_off, lda, B, b_off, ldb, C, c_off, ldc, bias=None, a_kstride=64, b_kstride=64, B_lo=None):
     """C[M,N] = A[M,K] . B[N,K]^T + bias on IEEE-f16 operands (cruse_gemm_f16_nt; offsets in elements): the forward gate projection
-    in one pass."""
-    if A.dtype != torch.float16 or B.dtype != torch.float16 or C.dtype != torch.float32:
+    in one pass.  B_lo: the low plane of B (ktile_f16(split=True)) -- two passes on the same accumulators (cruse_gemm_f16x2_nt)."""
+    if A.dtype != torch.float16 or B.dtype != torch.float16 or C.dtype != torch.float32 or (B_lo is not None and B_lo.dtype != torch.float16):
         raise RuntimeError("gemm_f16_nt needs f16 operands and an f32 result")
+    if B_lo is not None:
+        check(lib.cruse_gemm_f16x2_nt(M, N, K, A.data_ptr() + 2 * a_off, lda, a_kstride, B.data_ptr() + 2 * b_off, B_lo.data_ptr() + 2 * b_off, ldb,
+                                      b_kstride, C.data_ptr() + 4 * c_off, ldc, _p(bias), _stream()))
+        return C
     check(lib.cruse_gemm_f16_nt(M, N, K, A.data_ptr() + 2 * a_off, lda, a_kstride, B.data_ptr() + 2 * b_off, ldb, b_kstride,
                                 C.data_ptr() + 4 * c_off, ldc, _p(bias), _stream()))
     return C

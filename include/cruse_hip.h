@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CRUSE_ABI_VERSION 11
+#define CRUSE_ABI_VERSION 12
 
 enum {
     CRUSE_OK = 0,
@@ -342,6 +342,8 @@ int cruse_cast_bf16(const float* x, void* y, long long n, void* stream);
 int cruse_ktile_bf16(const float* x, int rows, int cols, long long ld, void* y, void* y_lo, void* stream);
 /* (ABI 9) the same K-tiled layout with IEEE-f16 elements: the B operand of cruse_gemm_f16_nt */
 int cruse_ktile_f16(const float* x, int rows, int cols, long long ld, void* y, void* stream);
+/* (ABI 12) ... with the low plane y_lo = f16(x - f16(x)), same layout: the B_lo operand of cruse_gemm_f16x2_nt */
+int cruse_ktile_f16_split(const float* x, int rows, int cols, long long ld, void* y, void* y_lo, void* stream);
 /* (ABI 9) C[M,N] = A[M,K] . B[N,K]^T + bias[n] with IEEE-f16 operands in the layouts of cruse_gemm_bf16_nt, f32 accumulation
  * (v_mfma_f32_16x16x32_f16): the FORWARD gate projection gi = x W_ih^T (cruse_net.py:23-31,44,50) in ONE pass -- 11 significant bits
  * on both operands, where the split-bf16 form above spends a second pass to correct W_ih only and keeps x at 8 bits.  The operands
@@ -349,6 +351,11 @@ int cruse_ktile_f16(const float* x, int rows, int cols, long long ld, void* y, v
 int cruse_gemm_f16_nt(int M, int N, int K, const void* A, long long lda, long long a_kstride,
                       const void* B, long long ldb, long long b_kstride,
                       float* C, long long ldc, const float* bias, void* stream);
+/* (ABI 12) C = A . (B_hi + B_lo)^T + bias[n]: f16 activations against TWO f16 planes of the weights in one launch (the k-range is walked twice on the
+ * same accumulators) -- the forward gate projection of GGRU layer 1 (nn.GRU input projection, cruse_net.py:23-31): 11 bits on x, ~20 on W_ih. */
+int cruse_gemm_f16x2_nt(int M, int N, int K, const void* A, long long lda, long long a_kstride,
+                        const void* B_hi, const void* B_lo, long long ldb, long long b_kstride,
+                        float* C, long long ldc, const float* bias, void* stream);
 /* y = bf16(x) and y_lo = bf16(x - y) (nullable) */
 int cruse_cast_bf16_split(const float* x, void* y, void* y_lo, long long n, void* stream);
 /* Split-bf16 x3 form of cruse_gemm_bf16_nt: A = A_hi + A_lo, B = B_hi + B_lo (bf16 planes, same layout each);

@@ -28,7 +28,7 @@
 #define M_PI 3.14159265358979323846
 #endif
 
-int cruse_ref_abi_version(void) { return 11; } /* the CRUSE_ABI_VERSION these twins were written against */
+int cruse_ref_abi_version(void) { return 12; } /* the CRUSE_ABI_VERSION these twins were written against */
 
 static uint16_t bf16_rne(float f) {
     uint32_t u;

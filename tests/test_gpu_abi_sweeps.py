@@ -173,6 +173,17 @@ def test_bf16_gemm_family_and_layout_kernels(hip):
         torch.cuda.synchronize()
         if rc: print("refused f16", M, N, K, hip.cruse_last_error())
         else: chk(("gemm_f16_nt", M, N, K), Cd.cpu().numpy(), A16.astype(np.float64) @ B16.astype(np.float64).T + bias, 2e-5)
+        # two f16 planes of B (cruse_ktile_f16_split makes them from f32 weights; here row-major planes built the same way)
+        Bw = rnd(N, K) * 0.05
+        Bhi = Bw.astype(np.float16); Blo = (Bw - Bhi.astype(np.float32)).astype(np.float16)
+        Cd = Z(M, N); bh, bl = D(Bhi.view(np.uint16)), D(Blo.view(np.uint16))
+        rc = hip.cruse_gemm_f16x2_nt(M, N, K, a16.data_ptr(), K, 64, bh.data_ptr(), bl.data_ptr(), K, 64, Cd.data_ptr(), N, bd.data_ptr(), st())
+        torch.cuda.synchronize()
+        if rc: bad.append(("refused f16x2", M, N, K))
+        else:
+            chk(("gemm_f16x2_nt", M, N, K), Cd.cpu().numpy(), A16.astype(np.float64) @ (Bhi.astype(np.float64) + Blo.astype(np.float64)).T + bias, 2e-5)
+            # ... and the two planes carry the f32 weights to ~2^-20
+            chk(("f16x2 vs f32 weights", M, N, K), Cd.cpu().numpy(), A16.astype(np.float64) @ Bw.astype(np.float64).T + bias, 3e-5)
     # layout kernels: transpose (K-tiled time-major), ktile, cast split
     for (rows, cols) in ((1, 32), (3, 64), (65, 160), (130, 640), (401, 96), (64, 1920)):
         x = rnd(rows, cols)
@@ -192,6 +203,15 @@ def test_bf16_gemm_family_and_layout_kernels(hip):
         y, ylo = Z(kp // 64, rows, 64, dtype=np.uint16), Z(kp // 64, rows, 64, dtype=np.uint16); xd = D(x)
         rc = hip.cruse_ktile_bf16(xd.data_ptr(), rows, cols, cols, y.data_ptr(), ylo.data_ptr(), st())
         torch.cuda.synchronize()
+        y16, y16lo = Z(kp // 64, rows, 64, dtype=np.uint16), Z(kp // 64, rows, 64, dtype=np.uint16)
+        rc2 = hip.cruse_ktile_f16_split(xd.data_ptr(), rows, cols, cols, y16.data_ptr(), y16lo.data_ptr(), st())
+        torch.cuda.synchronize()
+        if rc2: bad.append(("refused ktile_f16_split", rows, cols))
+        else:
+            xp16 = np.zeros((rows, kp), np.float32); xp16[:, :cols] = x
+            h16 = xp16.astype(np.float16); l16 = (xp16 - h16.astype(np.float32)).astype(np.float16)
+            chk(("ktile_f16 hi", rows, cols), y16.cpu().numpy().view(np.float16).astype(np.float32), h16.astype(np.float32).reshape(rows, kp // 64, 64).transpose(1, 0, 2), 0.0)
+            chk(("ktile_f16 lo", rows, cols), y16lo.cpu().numpy().view(np.float16).astype(np.float32), l16.astype(np.float32).reshape(rows, kp // 64, 64).transpose(1, 0, 2), 0.0)
         if rc: print("refused ktile", rows, cols, hip.cruse_last_error())
         else:
             xp = np.zeros((rows, kp), np.float32); xp[:, :cols] = x

@@ -87,8 +87,8 @@ def test_bf16_forward_parity_at_bench_length(grp, init):
 @pytest.mark.parametrize("init", ["closed", "random"])
 def test_f16_gate_projection_masks_at_bench_length(init):
     """EngineConfig.gi_f16 (round 4): the forward gate projections of GGRU layer 1 / 2 (bit 0 / 1) as one pass on f16 operands
-    (cruse_gemm_f16_nt) instead of bf16 x with W_ih hi / lo planes.  Every mask meets the north_star bar at T = 401; the default (2)
-    and the all-f16 form (3) are not further from the oracle than the split-bf16 form (0) they replace."""
+    (cruse_gemm_f16_nt) instead of bf16 x with W_ih hi / lo planes.  Every mask meets the north_star bar at T = 401; the default (2) is not
+    further from the oracle than the split-bf16 form (0) it replaced; mask 3 (layer 1 on f16 x against two f16 planes of W_ih) is the closest."""
     from cruse_amd import ops
     from cruse_amd.config import EngineConfig
     from cruse_amd.engine import TrainEngine
@@ -113,8 +113,8 @@ def test_f16_gate_projection_masks_at_bench_length(init):
         err[mask_bits] = rel_l2(est, est_o)
         assert err[mask_bits] <= FWD_TOL
     print(f"[parity bf16 T=401 g=1 {init}] enhanced-spectrum rel-L2 by gi_f16 mask: " + ", ".join(f"{k}: {v:.3e}" for k, v in err.items()))
-    assert EngineConfig().gi_f16 == 2
-    assert err[2] <= 1.05 * err[0] and err[3] <= 1.05 * err[0]
+    assert EngineConfig().gi_f16 == 2                     # (layer 2: one f16 pass; mask 3 adds layer 1 on f16 x against W_ih hi + lo planes)
+    assert err[2] <= 1.05 * err[0] and err[3] <= err[2]
 
 
 @pytest.mark.parametrize("grp", [1, 4])

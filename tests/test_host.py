@@ -22,7 +22,7 @@ def test_library_exports_every_header_symbol():
     assert set(SIGNATURES) == set(hdr)
     lib.cruse_abi_version.restype = ctypes.c_int
     from cruse_amd._lib import ABI_VERSION
-    assert lib.cruse_abi_version() == ABI_VERSION == 11
+    assert lib.cruse_abi_version() == ABI_VERSION == 12
 
 
 def test_error_channel_without_gpu():
