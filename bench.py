@@ -434,10 +434,13 @@ def secondary_rows(a, dev, pool):
         del e, m
     except Exception as ex:                                  # secondary rows never break the headline line
         out["f32_gate_mode"] = {"error": repr(ex)[:200]}
+    skip = os.environ.get("CRUSE_BENCH_SKIP", "").split(",")
     # (1b) the headline's bf16 mode with GGRU layer 1's gate projection on f16 x against two f16 planes of W_ih as well (EngineConfig.gi_f16 = 3;
     #      cruse_gemm_f16x2_nt): the same two passes as the default's bf16 x . W hi / lo, 11 instead of 8 bits on x.  Not the default: one vector of
     #      the closed-form fixture G16 leaves its gradient-norm tolerance by 0.006
     try:
+        if "layer1_f16x2_mode" in skip:
+            raise RuntimeError("skipped")
         from cruse_amd import config as _cfg
         torch.manual_seed(0)
         m = unet_2(rnn_groups=a.groups, precision="bf16").to(dev)
@@ -614,15 +617,23 @@ def rccl_world1_row(a, dev, pool):
     return out
 
 
+HOST_ISSUE_MS = {}           # id(engine) -> host time to ISSUE one step of the last _time_steps() call (no synchronisation inside)
+
+
 def _time_steps(eng, pool, n_warm=3, n=8):
+    """device ms per step (HIP events around n steps); the host's issue time per step of the same loop is left in HOST_ISSUE_MS:
+    a form whose issue time is about its device time is HOST-bound (an eager B = 32 step issues ~400 launches in ~3 ms)"""
     for s_ in range(n_warm):
         eng.step(*pool[s_ % len(pool)])
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
+    t0 = time.perf_counter()
     for s_ in range(n):
         eng.step(*pool[s_ % len(pool)])
+    t_issue = time.perf_counter() - t0
     e1.record(); torch.cuda.synchronize()
+    HOST_ISSUE_MS[id(eng)] = t_issue / n * 1e3
     return e0.elapsed_time(e1) / n
 
 
@@ -644,10 +655,11 @@ def config_rows(a, dev, pool):
         torch.manual_seed(0)
         m = unet_2(rnn_groups=groups, precision="bf16").to(dev)
         bp = [synth_batch(B, L, dev, 7000 + i) for i in range(2)]
-        best = None
+        best, forms = None, {}
         for graph in (True, False):
             e = TrainEngine(m, lr=1e-3, use_graph=graph, loss="wo_male_df" if df else "wo_male")
             ms = _time_steps(e, bp)
+            forms["graph" if graph else "eager"] = {"ms": round(ms, 3), "host_issue_ms": round(HOST_ISSUE_MS[id(e)], 3)}
             if best is None or ms < best[0]:
                 best = (ms, graph, e)
         ms, graph, e = best
@@ -662,8 +674,9 @@ def config_rows(a, dev, pool):
         roof["kernel"] = dom; roof["ms_per_step_all_launches"] = round(per_step[dom], 3)
         fps = B * T / (ms * 1e-3)
         sr = step_roofline(fps, groups, "bf16", B, T)
-        row = {"value": round(fps, 1), "unit": "frames/s", "ms_per_step": round(ms, 3), "per_gpu_batch": B, "groups": groups,
-               "launch_form": "graph" if graph else "eager", "dtype": "bf16", "roofline": roof,
+        kms = {k: round(v, 3) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])[:8]}
+        row = {"kernel_ms_per_step_top8": kms, "value": round(fps, 1), "unit": "frames/s", "ms_per_step": round(ms, 3), "per_gpu_batch": B, "groups": groups,
+               "launch_form": "graph" if graph else "eager", "by_form": forms, "dtype": "bf16", "roofline": roof,
                "roofline_step_hbm_f32_storage_frac": sr["hbm_f32_storage"]["frac"], "roofline_step_mfma_frac": sr.get("mfma", {}).get("frac"),
                "timeouts": ops.gru_status(), "note": note}
         if not a.no_parity:

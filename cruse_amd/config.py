@@ -48,6 +48,9 @@ class EngineConfig:
                                     # levels whose producer AND consumers are MFMA kernels: 2 <= k < L) are stored as bf16 as well:
                                     # f32 accumulation, one rounding per pass of a backward-only tensor (needs bf16_dy and
                                     # fuse_bn_bwd_stats: the conv that stores the tensor also delivers its BatchNorm sums)
+    pick_launch_stream: bool = True # HIP-graph form: time the replay of a fresh capture from the current stream and three pool streams and
+                                    # keep the fastest launcher (engine._pick_launch_stream: a graph's own side-branch streams may share
+                                    # the launching stream's hardware queue, which serialises the branches -- +25..35 % per step)
     lib_options: Dict[str, int] = field(default_factory=dict)       # cruse_set_option(name, value) while this config is active
 
     _ENV = {"overlap": ("CRUSE_OVERLAP", lambda v: v == "1"), "defer_mask": ("CRUSE_DEFER", int), "inline_mask": ("CRUSE_INLINE", int),
@@ -56,7 +59,8 @@ class EngineConfig:
             "fuse_bn_bwd_stats": ("CRUSE_FUSE_BN_BWD", lambda v: v != "0"), 
             "gi_x3": ("CRUSE_GI_X3", int), "gi_f16": ("CRUSE_GI_F16", int), 
              
-            "fuse_bn_fwd": ("CRUSE_FUSE_BN_FWD", lambda v: v != "0"), "fuse_bn_bwd_apply": ("CRUSE_FUSE_BN_BWD_APPLY", lambda v: v != "0"), "bf16_dy": ("CRUSE_BF16_DY", lambda v: v != "0"), "bf16_de": ("CRUSE_BF16_DE", lambda v: v != "0")}
+            "fuse_bn_fwd": ("CRUSE_FUSE_BN_FWD", lambda v: v != "0"), "fuse_bn_bwd_apply": ("CRUSE_FUSE_BN_BWD_APPLY", lambda v: v != "0"), "bf16_dy": ("CRUSE_BF16_DY", lambda v: v != "0"), "bf16_de": ("CRUSE_BF16_DE", lambda v: v != "0"),
+            "pick_launch_stream": ("CRUSE_PICK_LAUNCH_STREAM", lambda v: v != "0")}
     _LIB_ENV = {"CRUSE_GRU_BWD_RS": "gru_bwd_rs", "CRUSE_GRU_FWD_LEAN": "gru_fwd_lean", "CRUSE_GRU_WLO": "gru_wlo", "CRUSE_GRU_DBG": "gru_dbg",
                 "CRUSE_GRU_TF": "gru_tf", "CRUSE_GRU_POLL_FWD": "gru_poll_fwd", "CRUSE_GRU_POLL_BWD": "gru_poll_bwd", "CRUSE_CM_KINT": "cm_kint",
                 "CRUSE_CM_SWAP": "cm_swap", "CRUSE_CM_NW": "cm_nw", "CRUSE_PW_VALU": "pw_valu", "CRUSE_WG_DBG": "wg_dbg",

@@ -223,6 +223,8 @@ class TrainEngine:
         self.use_graph = True if use_graph == "auto" else use_graph
         self.launch_form_timing = None           # {"graph_ms", "eager_ms", "kept"} once "auto" has decided
         self._graphs = None
+        self._launch_stream = None               # the stream the current capture is replayed from (None: the current stream)
+        self.launch_stream_timing = None
         self._static = None
         self._shape = None
         self._graph_cache: Dict[Tuple[int, ...], tuple] = {}     # input shape -> (graphs, static inputs, static loss)
@@ -400,9 +402,59 @@ class TrainEngine:
         _net.release_capture_events()         # (kept alive until every segment's capture has ended: see cruse_net.record_event)
         self._graphs = graphs
         self._shape = tuple(noisy.shape)
+        self._launch_stream = self._pick_launch_stream(graphs, saved)
         # one capture per input shape (a last, partial batch of an epoch would otherwise force two re-captures per epoch)
-        self._graph_cache[self._shape] = (graphs, self._static, self._static_loss)
+        self._graph_cache[self._shape] = (graphs, self._static, self._static_loss, self._launch_stream)
         self._norms[self._shape] = self._norm
+
+    def _pick_launch_stream(self, graphs, saved_buffers):
+        """The stream this capture is REPLAYED from, chosen by timing.  A replay runs the graph's main branch on the launching
+        stream and its side branches on streams the graph created for itself when it was instantiated; ROCm places all of them on
+        a handful of hardware queues in creation order, and when a side branch shares the launching stream's queue (or, for a
+        high-priority launching stream, its pipe) the branches serialise: 4.9 instead of 3.6 ms, 6.6 instead of 4.9 ms per step
+        (round 6, cruse_amd/streams.py; which capture of a process was hit depended on how many streams had been drawn before
+        it).  Nothing tells which queue the graph's own streams got, so the replay is timed from the current stream and from up to
+        three normal-priority pool streams (2 replays each) and the fastest launching stream is kept; the current stream stays
+        unless another one is > 4 % faster.  The timing replays are forward + backward passes of the static batch: they rewrite the
+        gradients (the real replay follows) and the BatchNorm running statistics, which are restored."""
+        cur = torch.cuda.current_stream()
+        if not self.cfg.pick_launch_stream:
+            return None
+
+        def timed(stream):
+            stream.wait_stream(cur)
+            with torch.cuda.stream(stream):
+                for g, _ in graphs:
+                    g.replay()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(2):
+                    for g, _ in graphs:
+                        g.replay()
+                e1.record()
+            e1.synchronize()
+            cur.wait_stream(stream)
+            return e0.elapsed_time(e1) / 2
+
+        t_cur = timed(cur)
+        best, tried = (t_cur, None), [round(t_cur, 3)]
+        seen = {int(cur.cuda_stream)}
+        for _ in range(3):
+            cand = torch.cuda.Stream()
+            if int(cand.cuda_stream) in seen:
+                continue
+            seen.add(int(cand.cuda_stream))
+            t = timed(cand)
+            tried.append(round(t, 3))
+            if t < best[0]:
+                best = (t, cand)
+        if best[1] is not None and best[0] > 0.96 * t_cur:
+            best = (t_cur, None)
+        for k, v in saved_buffers.items():
+            self.Bf[k].copy_(v)
+        self.launch_stream_timing = {"replay_ms_current_then_candidates": tried, "kept": "current" if best[1] is None else "other",
+                                     "kept_ms": round(best[0], 3)}
+        return best[1]
 
     def _warmup_boundary(self, bucket: int):
         self.side.join(flush=False)
@@ -482,7 +534,7 @@ class TrainEngine:
             if self._graphs is None or self._shape != tuple(noisy.shape):
                 hit = self._graph_cache.get(tuple(noisy.shape))
                 if hit is not None:
-                    self._graphs, self._static, self._static_loss = hit
+                    self._graphs, self._static, self._static_loss, self._launch_stream = hit
                     self._shape = tuple(noisy.shape)
                 else:
                     try:
@@ -499,9 +551,21 @@ class TrainEngine:
             self._static[0].copy_(noisy)
             self._static[1].copy_(clean)
             self._norm = self._norms[tuple(noisy.shape)]      # (a cache hit runs no Python forward: the norm is per shape)
-            for g, bucket in self._graphs:
-                g.replay()
-                self._launch_bucket(bucket)      # RCCL's stream waits for the replay; the next replay overlaps it
+            ls = self._launch_stream
+            if ls is None:
+                for g, bucket in self._graphs:
+                    g.replay()
+                    self._launch_bucket(bucket)      # RCCL's stream waits for the replay; the next replay overlaps it
+            else:
+                # replayed from the stream _pick_launch_stream measured as the fastest launcher of THIS capture; the collectives are
+                # issued from it too (ProcessGroupNCCL orders its stream behind the stream it is called from)
+                cur = torch.cuda.current_stream()
+                ls.wait_stream(cur)
+                with torch.cuda.stream(ls):
+                    for g, bucket in self._graphs:
+                        g.replay()
+                        self._launch_bucket(bucket)
+                cur.wait_stream(ls)
             loss_sum = self._static_loss
         else:
             loss_sum = self._fwd_bwd(noisy, clean, boundary=self._plain_boundary if self.bucketed else None)

@@ -19,7 +19,7 @@ import contextlib
 import torch
 import torch.nn as nn
 
-from .. import config, ops
+from .. import config, ops, streams
 
 DEFAULT_PREC = "f32"
 
@@ -63,7 +63,8 @@ class _SideStream:
         self.enabled = bool(cfg.overlap)
         # leaves queued for the next recurrence launch instead of issued at once (EngineConfig.defer_mask)
         self.defer_mask = int(cfg.defer_mask)
-        self.streams = {}
+        self.streams = {}              # (device, main stream) -> side stream proven to overlap with it
+        self._capture_streams = {}     # the same for capture streams (unproven: a replay runs on the graph's own streams)
         self.keep = []
         self.deferred = []
         self.active = False
@@ -71,10 +72,16 @@ class _SideStream:
         self.after_release = None      # one-shot callback run by the next release_around() once its leaves are issued
 
     def _next(self, lane=None):
-        dev = torch.cuda.current_device()
-        s = self.streams.get(dev)
+        # The side stream is chosen PER MAIN STREAM by measurement (cruse_amd/streams.py): torch's pool streams share a handful of
+        # hardware queues, and a side stream that lands on the main stream's queue (every fourth) serialises the leaves with the
+        # chain they were meant to hide behind -- 5.8 instead of 3.5 ms per step.  During a HIP-graph capture any stream will do.
+        main = torch.cuda.current_stream()
+        key = (main.device_index, int(main.cuda_stream))
+        capturing = torch.cuda.is_current_stream_capturing()
+        table = self._capture_streams if capturing else self.streams
+        s = table.get(key)
         if s is None:
-            s = self.streams[dev] = torch.cuda.Stream()
+            s = table[key] = streams.side_stream_for(main)
         if s not in self.used:         # only forked streams may be recorded on / joined (HIP-graph capture rule)
             self.used.append(s)
         return s
