@@ -360,6 +360,20 @@ class TrainEngine:
 
     # -- graph capture: one graph, or one per segment when the step is bucketed ----------------------------------
     def _capture(self, noisy, clean):
+        """Record the step for this input shape and decide where it is replayed from.
+
+        A replay runs the graph's main branch on the launching stream and its side branches on streams the graph created for itself
+        when it was instantiated.  ROCm places all streams on a handful of hardware queues in creation order, and a queue whose head
+        is a pending wait holds its pipe for a time slice: when a side branch's stream shares the queue / pipe of the launching
+        stream the branches serialise (round 6: 5.5 instead of 4.7 ms for one capture in eight on the default stream;
+        cruse_amd/streams.py has the eager-launch side of the same story).  Nothing tells which queue the graph's own streams got,
+        so it is measured (_pick_launch_stream): the step's real pattern -- a small kernel on the caller's stream, replay from
+        launcher L, the caller's stream waits for L -- is timed from the caller's stream and three pool streams and the fastest
+        launcher is kept (the caller's own unless another is > 3 % faster).  The timing replays are forward + backward passes of the
+        static batch: they rewrite the gradients (the real replay follows) and the BatchNorm running statistics, which are restored.
+        NOT curable from here: a HIGH-PRIORITY caller stream.  Replayed from it, or merely waiting for a launcher, it slows every
+        capture's side branches (3.5 -> 5.0 ms, 4.8 -> 6.0 ms whatever the launcher; re-instantiating does not help): graph replays
+        belong on normal-priority streams (launch_stream_timing["caller_priority"] records what the capture saw)."""
         self._static = (noisy.clone(), clean.clone())
         # the warm-up run below must leave no trace: BatchNorm running statistics and counters are restored
         saved = {k: v.clone() for k, v in self.Bf.items()}
@@ -371,6 +385,22 @@ class TrainEngine:
         torch.cuda.synchronize()
         for k, v in saved.items():
             self.Bf[k].copy_(v)
+        graphs, static_loss = self._capture_once()
+        launcher = None
+        if self.cfg.pick_launch_stream:
+            launcher, t_pattern, t_pure, tried = self._pick_launch_stream(graphs)
+            for k, v in saved.items():
+                self.Bf[k].copy_(v)
+            self.launch_stream_timing = {"pure_replay_ms": tried[0], "step_pattern_ms": tried[1], "kept_ms": round(t_pattern, 3),
+                                         "kept": "current" if launcher is None else "other",
+                                         "caller_priority": getattr(torch.cuda.current_stream(), "priority", None)}
+        self._graphs, self._static_loss, self._launch_stream = graphs, static_loss, launcher
+        self._shape = tuple(noisy.shape)
+        # one capture per input shape (a last, partial batch of an epoch would otherwise force two re-captures per epoch)
+        self._graph_cache[self._shape] = (graphs, self._static, self._static_loss, self._launch_stream)
+        self._norms[self._shape] = self._norm
+
+    def _capture_once(self):
         graphs: List[Tuple[torch.cuda.CUDAGraph, int]] = []
         pool = torch.cuda.graph_pool_handle()
         cur: Dict[str, object] = {}
@@ -394,67 +424,64 @@ class TrainEngine:
 
         begin()
         try:
-            self._static_loss = self._fwd_bwd(*self._static, boundary=boundary if self.bucketed else None)
+            static_loss = self._fwd_bwd(*self._static, boundary=boundary if self.bucketed else None)
         except BaseException:
             cur["cm"].__exit__(None, None, None)
             raise
         end(N_BUCKETS - 1)
         _net.release_capture_events()         # (kept alive until every segment's capture has ended: see cruse_net.record_event)
-        self._graphs = graphs
-        self._shape = tuple(noisy.shape)
-        self._launch_stream = self._pick_launch_stream(graphs, saved)
-        # one capture per input shape (a last, partial batch of an epoch would otherwise force two re-captures per epoch)
-        self._graph_cache[self._shape] = (graphs, self._static, self._static_loss, self._launch_stream)
-        self._norms[self._shape] = self._norm
+        return graphs, static_loss
 
-    def _pick_launch_stream(self, graphs, saved_buffers):
-        """The stream this capture is REPLAYED from, chosen by timing.  A replay runs the graph's main branch on the launching
-        stream and its side branches on streams the graph created for itself when it was instantiated; ROCm places all of them on
-        a handful of hardware queues in creation order, and when a side branch shares the launching stream's queue (or, for a
-        high-priority launching stream, its pipe) the branches serialise: 4.9 instead of 3.6 ms, 6.6 instead of 4.9 ms per step
-        (round 6, cruse_amd/streams.py; which capture of a process was hit depended on how many streams had been drawn before
-        it).  Nothing tells which queue the graph's own streams got, so the replay is timed from the current stream and from up to
-        three normal-priority pool streams (2 replays each) and the fastest launching stream is kept; the current stream stays
-        unless another one is > 4 % faster.  The timing replays are forward + backward passes of the static batch: they rewrite the
-        gradients (the real replay follows) and the BatchNorm running statistics, which are restored."""
+    def _pick_launch_stream(self, graphs):
+        """-> (launcher or None for the current stream, ms of the step pattern from it, ms of the fastest back-to-back replay,
+        [pure times, pattern times] by candidate)"""
         cur = torch.cuda.current_stream()
-        if not self.cfg.pick_launch_stream:
-            return None
+        cands, seen = [cur], {int(cur.cuda_stream)}
+        for _ in range(6):
+            c = torch.cuda.Stream()
+            if int(c.cuda_stream) not in seen and len(cands) < 4:
+                seen.add(int(c.cuda_stream))
+                cands.append(c)
 
-        def timed(stream):
-            stream.wait_stream(cur)
+        def replay_on(stream):
             with torch.cuda.stream(stream):
                 for g, _ in graphs:
                     g.replay()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(2):
-                    for g, _ in graphs:
-                        g.replay()
-                e1.record()
+
+        def pure(stream, n=2):
+            stream.wait_stream(cur)
+            replay_on(stream)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(n):
+                replay_on(stream)
+            e1.record(stream)
             e1.synchronize()
             cur.wait_stream(stream)
-            return e0.elapsed_time(e1) / 2
+            return e0.elapsed_time(e1) / n
 
-        t_cur = timed(cur)
-        best, tried = (t_cur, None), [round(t_cur, 3)]
-        seen = {int(cur.cuda_stream)}
-        for _ in range(3):
-            cand = torch.cuda.Stream()
-            if int(cand.cuda_stream) in seen:
-                continue
-            seen.add(int(cand.cuda_stream))
-            t = timed(cand)
-            tried.append(round(t, 3))
-            if t < best[0]:
-                best = (t, cand)
-        if best[1] is not None and best[0] > 0.96 * t_cur:
-            best = (t_cur, None)
-        for k, v in saved_buffers.items():
-            self.Bf[k].copy_(v)
-        self.launch_stream_timing = {"replay_ms_current_then_candidates": tried, "kept": "current" if best[1] is None else "other",
-                                     "kept_ms": round(best[0], 3)}
-        return best[1]
+        def pattern(stream, n=2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for i in range(n + 1):
+                if i == 1:
+                    e0.record(cur)
+                ops.zero_(self._gsumsq)               # (stands for the step's own kernels on the caller's stream: input copies, Adam)
+                if stream is cur:
+                    replay_on(cur)
+                else:
+                    stream.wait_stream(cur)
+                    replay_on(stream)
+                    cur.wait_stream(stream)
+            e1.record(cur)
+            e1.synchronize()
+            return e0.elapsed_time(e1) / n
+
+        t_pure = [pure(c) for c in cands]
+        t_pat = [pattern(c) for c in cands]
+        k = min(range(len(cands)), key=lambda i: t_pat[i])
+        if k != 0 and t_pat[k] > 0.97 * t_pat[0]:
+            k = 0                                       # the caller's own stream unless another launcher is clearly faster
+        return (None if k == 0 else cands[k]), t_pat[k], min(t_pure), [[round(t, 3) for t in t_pure], [round(t, 3) for t in t_pat]]
 
     def _warmup_boundary(self, bucket: int):
         self.side.join(flush=False)

@@ -8,9 +8,9 @@ the bad stream depended on how many streams the process had drawn before -- BENC
 when one more bench row was inserted in front of it).  `torch.cuda.Stream()` hands out pool streams round-robin, so the
 only reliable statement about a pair of streams is a measurement:
 
-    pair_overlaps(main, side): one workgroup idles ~60 us on each stream (cruse_cu_hog), the side one ordered behind an
-    event of the main stream as the engine's leaves are; overlapping streams finish both in ~1.0x one kernel's time,
-    serialised ones in ~1.6-1.8x.
+    pair_overlaps(main, side): one workgroup idles ~100 us on each stream (cruse_cu_hog), the side one ordered behind an
+    event of the main stream as the engine's leaves are; read against one such kernel alone and two back to back on the
+    main stream, overlapping streams come out at a serial fraction of 0.1-0.3, serialised ones at 0.85-1.1.
 
 `side_stream_for(main)` draws pool streams until one overlaps (at most 8 draws, the best otherwise) and remembers the choice
 per main stream for the process, so every engine of a process uses the same proven pair.  Nothing here runs during HIP-graph
@@ -24,50 +24,61 @@ import torch
 
 from . import ops
 
-HOG_US = 60.0
-GOOD_RATIO = 1.30          # pair time / single time: overlapping pairs measure 1.00-1.10, serialised ones 1.55-1.80
+HOG_US = 100.0
 MAX_DRAWS = 8
 
 _CHOSEN: Dict[Tuple[int, int], torch.cuda.Stream] = {}
 REPORT: List[dict] = []     # one entry per selection: what was measured (bench.py prints it)
 
 
-def _timed(fn, main) -> float:
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    e0.record(main)
-    fn()
-    e1.record(main)
-    e1.synchronize()
-    return e0.elapsed_time(e1)
+def _timed(fn, main, trials: int = 3) -> float:
+    best = float("inf")
+    for _ in range(trials):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(main)
+        fn()
+        e1.record(main)
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return best
 
 
-def single_ms(main, trials: int = 2) -> float:
-    def one():
-        with torch.cuda.stream(main):
+def _hog(stream, n: int = 1) -> None:
+    with torch.cuda.stream(stream):
+        for _ in range(n):
             ops.cu_hog(1, HOG_US)
-    return min(_timed(one, main) for _ in range(trials))
 
 
-def pair_ms(main, side, trials: int = 2) -> float:
-    """both streams idle one workgroup for HOG_US, the side stream behind an event of the main stream; main joins the side"""
+def calibrate(main) -> Tuple[float, float]:
+    """-> (ms of one idling kernel, ms of two back to back) on `main`: the two ends of the scale a pair is read against"""
+    main.synchronize()
+    return _timed(lambda: _hog(main, 1), main), _timed(lambda: _hog(main, 2), main)
+
+
+def pair_ms(main, side) -> float:
+    """both streams idle one workgroup for HOG_US, the side stream behind an event of the main stream (as the engine's leaves are);
+    main joins the side stream"""
     def one():
         ev = torch.cuda.Event()
         ev.record(main)
-        with torch.cuda.stream(main):
-            ops.cu_hog(1, HOG_US)
+        _hog(main)
         side.wait_event(ev)
-        with torch.cuda.stream(side):
-            ops.cu_hog(1, HOG_US)
+        _hog(side)
         main.wait_stream(side)
-    return min(_timed(one, main) for _ in range(trials))
+    return _timed(one, main)
 
 
-def pair_overlaps(main, side) -> Tuple[bool, float]:
-    main.synchronize()
-    t1 = single_ms(main)
-    tp = pair_ms(main, side)
-    return tp < GOOD_RATIO * t1, tp / max(t1, 1e-6)
+def serial_fraction(main, side, cal=None) -> float:
+    """0 = the two kernels ran side by side, 1 = one after the other (self-calibrated: event and cross-stream overheads cancel to
+    first order; overlapping pairs measure 0.1-0.3, serialised ones 0.85-1.1)"""
+    t1, t2 = cal if cal is not None else calibrate(main)
+    return (pair_ms(main, side) - t1) / max(t2 - t1, 1e-6)
+
+
+def pair_overlaps(main, side, cal=None) -> Tuple[bool, float]:
+    f = serial_fraction(main, side, cal)
+    return f < 0.5, f
 
 
 def side_stream_for(main: Optional[torch.cuda.Stream] = None) -> torch.cuda.Stream:
@@ -81,20 +92,21 @@ def side_stream_for(main: Optional[torch.cuda.Stream] = None) -> torch.cuda.Stre
         # no measurement inside a capture (and none needed: the replay's streams are the graph's own) -- not remembered
         return torch.cuda.Stream()
     tried, best = [], None
+    cal = calibrate(main)
     for _ in range(MAX_DRAWS):
         cand = torch.cuda.Stream()
         if int(cand.cuda_stream) == int(main.cuda_stream):
             continue
-        ok, ratio = pair_overlaps(main, cand)
-        tried.append(round(ratio, 3))
-        if best is None or ratio < best[0]:
-            best = (ratio, cand)
+        ok, frac = pair_overlaps(main, cand, cal)
+        tried.append(round(frac, 2))
+        if best is None or frac < best[0]:
+            best = (frac, cand)
         if ok:
             break
     s = best[1]
     _CHOSEN[key] = s
-    REPORT.append({"main_stream": hex(key[1]), "main_priority": getattr(main, "priority", None), "pair_over_single": tried,
-                   "kept": round(best[0], 3), "overlaps": bool(best[0] < GOOD_RATIO)})
+    REPORT.append({"main_stream": hex(key[1]), "main_priority": getattr(main, "priority", None), "serial_fraction_by_draw": tried,
+                   "kept": round(best[0], 2), "overlaps": bool(best[0] < 0.5)})
     return s
 
 
