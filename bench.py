@@ -651,7 +651,8 @@ def config_rows(a, dev, pool):
     L = pool[0][0].shape[1]
     T = 1 + L // 160
 
-    def unet_row(name, groups, B, df, note):
+    def unet_row(name, groups, B, df, note, parity=True, into=None):
+        into = out if into is None else into
         torch.manual_seed(0)
         m = unet_2(rnn_groups=groups, precision="bf16").to(dev)
         bp = [synth_batch(B, L, dev, 7000 + i) for i in range(2)]
@@ -679,7 +680,9 @@ def config_rows(a, dev, pool):
                "launch_form": "graph" if graph else "eager", "by_form": forms, "dtype": "bf16", "roofline": roof,
                "roofline_step_hbm_f32_storage_frac": sr["hbm_f32_storage"]["frac"], "roofline_step_mfma_frac": sr.get("mfma", {}).get("frac"),
                "timeouts": ops.gru_status(), "note": note}
-        if not a.no_parity:
+        row["gru_plan"] = {"fwd": ops.gru_plan(B, groups, m.hidden_size // groups, "bf16", True),
+                           "bwd": ops.gru_plan(B, groups, m.hidden_size // groups, "bf16", False)}
+        if parity and not a.no_parity:
             if df:
                 from oracle import cruse_oracle as O
                 from oracle import cruse_oracle_ext as X
@@ -698,7 +701,8 @@ def config_rows(a, dev, pool):
             else:
                 row["parity_rel_l2"] = float(f"{parity_figure(m, groups, 'bf16', B=2, T=T):.4g}")
                 row["parity_note"] = "enhanced-spectrum rel-L2 vs the CPU oracle at T=401, B=2 (bar 1e-3)"
-        out[name] = row
+        into[name] = row
+        del e, best
 
     for name, args in (("config3_g4", (4, 64, False, "BASELINE config 3 per-GPU share: 4 grouped GRUs of 160, 64 of the 512 clips")),
                        ("config4_df_g4_b32", (4, 32, True, "BASELINE config 4 per-GPU share: + DeepFilter(1,5) head, 32 of the 256 clips"))):
@@ -706,6 +710,17 @@ def config_rows(a, dev, pool):
             unet_row(name, *args)
         except Exception as ex:                              # secondary rows never break the headline line
             out[name] = {"error": repr(ex)[:300]}
+    # ---- batch sweep ("B per GPU should be as large as memory allows ... stated next to the roofline fraction"):
+    #      the headline model at 128 and 256 clips per GPU.  Above 96 clips make_plan takes the 16-clip-chain kernels (gru_w16.hip);
+    #      tests/test_gpu_parity_bench_shape.py::test_wide_chain_plan_at_b128_vs_oracle checks that plan against the oracle
+    sweep = {}
+    for Bs in (128, 256):
+        try:
+            unet_row(f"B={Bs}", a.groups, Bs, False, f"the headline model and step at {Bs} clips x 4 s per GPU", parity=False, into=sweep)
+        except Exception as ex:
+            sweep[f"B={Bs}"] = {"error": repr(ex)[:300]}
+        torch.cuda.empty_cache()
+    out["batch_sweep"] = sweep
     # ---- config 5: tools/mtfaa_stress.py's step (fp16 storage) ---------------------------------------------------------
     # The row runs on a stream of its own: autograd's AccumulateGrad nodes remember the stream of the first backward pass, and a capture
     # that has to synchronise with the legacy DEFAULT stream through them crashes in hipStreamEndCapture (rounds 2-5 ran this row on the
@@ -828,7 +843,7 @@ def regression_guard(out, threshold=0.08):
             if isinstance(v, dict):
                 if v.get("ms_per_step") is not None:
                     r[k] = v["ms_per_step"]
-                for k2, v2 in v.items():                          # nested rows (trainer_path.*): higher-is-better values as 1 / value
+                for k2, v2 in v.items():                          # nested rows (trainer_path.*, batch_sweep.*): time per frame
                     if isinstance(v2, dict) and v2.get("value") and v2.get("unit") == "frames/s":
                         r[f"{k}.{k2}"] = 1e6 / v2["value"]
         return r

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcruse_hip.so")
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 PREC_F32, PREC_BF16X3, PREC_BF16, PREC_F16 = 0, 1, 2, 3
 PREC_BY_NAME = {"f32": PREC_F32, "bf16x3": PREC_BF16X3, "bf16": PREC_BF16, "f16": PREC_F16}
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
@@ -72,6 +72,7 @@ SIGNATURES = {
     "cruse_cast_bf16_split": ("pppqp", "i"),
     "cruse_gemm_bf16x3_nt": ("iiippqqppqqpqpip", "i"),
     "cruse_gru_ws_bytes": ("iii", "z"),
+    "cruse_gru_plan": ("iiiiip", "i"),
     "cruse_gru_seq_fwd": ("pppppppiiiiipp", "i"),
     "cruse_gru_seq_bwd": ("pppppiiiiipp", "i"),
     "cruse_gru_seq_fwd_on": ("pppppppiiiiippip", "i"),

@@ -1491,6 +1491,14 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* pane
 
 }  // namespace
 
+extern "C" int cruse_gru_plan(int B, int G, int Hg, int prec, int fwd, int* out) {
+    CRUSE_REQUIRE(out != nullptr && B >= 1 && G >= 1 && Hg >= 32 && Hg % 32 == 0, CRUSE_E_SHAPE, "gru_plan: B = %d, G = %d, Hg = %d", B, G, Hg);
+    Plan pl;
+    CRUSE_REQUIRE(make_plan(B, G, Hg, prec, fwd != 0, 0, true, pl) == 0, CRUSE_E_SHAPE, "gru_plan: G*Hg/32 exceeds the CU count");
+    out[0] = pl.Bg; out[1] = pl.nbg; out[2] = pl.bg_per_launch; out[3] = pl.nlaunch; out[4] = pl.P; out[5] = pl.wide ? 1 : 0;
+    return CRUSE_OK;
+}
+
 extern "C" size_t cruse_gru_ws_bytes(int B, int G, int Hg) {
     return 256 + xid_bytes_total(B, G) + xg_bytes_total(B, G, Hg) + (size_t)MAX_LAUNCH_TICKETS * 8 * sizeof(unsigned);
 }

@@ -952,6 +952,14 @@ def step_health(gru_status, loss_sum, health, loss_acc=None, loss_scale=1.0) -> 
     check(lib.cruse_step_health(_p(gru_status), _p(loss_sum), _p(health), _p(loss_acc), float(loss_scale), _stream()))
 
 
+def gru_plan(B: int, groups: int, Hg: int, prec="bf16", fwd: bool = True) -> dict:
+    """the launch plan of the recurrence for this shape (cruse_gru_plan): which kernels a batch size runs on"""
+    out = (ctypes.c_int * 6)()
+    check(lib.cruse_gru_plan(int(B), int(groups), int(Hg), prec_code(prec), 1 if fwd else 0, ctypes.cast(out, ctypes.c_void_p)))
+    return {"clips_per_chain": out[0], "chains_per_group": out[1], "chains_per_launch": out[2], "launches": out[3],
+            "workgroups_per_chain": out[4], "wide": bool(out[5])}
+
+
 def cu_hog(nblocks: int, microseconds: float, clock_ghz: float = 2.1) -> None:
     """Test / probe rig: `nblocks` workgroups hold one CU each (128 KB of LDS) for about `microseconds` on the current stream
     (cruse_cu_hog) -- what a collective's channels or another tenant do to the persistent recurrences."""

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define CRUSE_ABI_VERSION 12
+#define CRUSE_ABI_VERSION 13
 
 enum {
     CRUSE_OK = 0,
@@ -386,6 +386,11 @@ int cruse_transpose_bf16(const float* x, long long rows, int cols, long long ld,
  * can be polled once per epoch and handed to cruse_adam_step_guarded as skip_flag.  The hand-off panels behind the
  * header are zeroed by the callee on every call. */
 size_t cruse_gru_ws_bytes(int B, int G, int Hg);
+/* The launch plan cruse_gru_seq_fwd (fwd != 0) / cruse_gru_seq_bwd take for this shape and precision with h0 = 0 and no explicit chain width:
+ * out[0] clips per chain (8, or 16: the wide-chain kernels of gru_w16.hip), out[1] chains per group, out[2] chains per group and launch,
+ * out[3] launches, out[4] workgroups per chain (Hg / 32), out[5] 1 = wide-chain kernels.  A query: no device work.  Replaces nothing in the
+ * reference (nn.GRU has no launch plan, model/cruse_net.py:23-31); it lets tests and bench.py state which kernels a batch size runs on. */
+int cruse_gru_plan(int B, int G, int Hg, int prec, int fwd, int* out);
 int cruse_gru_seq_fwd(const float* gi, const float* const* w_hh, const float* const* b_hh,
                       float* h, void* coef, float* an, float* z,
                       int B, int T, int G, int Hg, int prec, void* ws, void* stream);

@@ -209,3 +209,36 @@ def test_f32_gate_mode_at_bench_length():
     tot, worst = _grad_report(eng, o)
     print(f"[grad parity f32 T=401] all {tot:.3e} worst {max(worst.values()):.3e}")
     assert tot <= 1e-3 and max(worst.values()) <= 5e-3
+
+
+def test_wide_chain_plan_at_b128_vs_oracle():
+    """make_plan (csrc/gru.hip) switches to the 16-clip-chain kernels (gru_w16.hip) when B > 96 at Hg = 640, and until
+    round 6 only kernel-vs-kernel tests covered them.  unet_2(rnn_groups = 1) at B = 128 x T = 401 in the bench mode against the CPU
+    oracle: loss, enhanced spectrum of every clip, and all gradients against oracle autograd at the bench-length tolerances."""
+    from cruse_amd import ops
+    from cruse_amd.engine import TrainEngine
+    from oracle import cruse_oracle as O
+    B, T = 128, 401
+    o, m = _pair(1, "random", "bf16")
+    noisy, clean = O.synth_pair(B, (T - 1) * 160, seed=31)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    with torch.no_grad():
+        _, est_o, _ = O.enhanced_spectrum(o, noisy)
+    loss_o, _ = O.train_step_loss(o, noisy, clean)
+    loss_o.backward()
+    eng = TrainEngine(m, use_graph=False)
+    nz = noisy.cuda()
+    ls = eng._fwd_bwd(nz, clean.cuda())
+    assert ops.gru_status() == 0
+    assert abs(eng.loss_value(ls) - float(loss_o.detach())) <= 1e-4 * abs(float(loss_o.detach()))
+    nre, nim, _ = ops.stft(nz, 320, 160, mag_bins=160, mag_eps=1e-8)
+    er, ei = ops.mask_apply(eng._last_mask.contiguous().view(B * T, 160), nre, nim, B * T, 160, 161)
+    est = torch.stack([er.view(B, T, 161), ei.view(B, T, 161)], dim=-1).cpu()
+    per_clip = torch.tensor([rel_l2(est[b], est_o[b]) for b in range(B)])
+    e_all = rel_l2(est, est_o)
+    print(f"[parity bf16 B=128 T=401 g=1, wide chains] enhanced-spectrum rel-L2 {e_all:.3e}; per clip max {float(per_clip.max()):.3e}")
+    assert e_all <= FWD_TOL and float(per_clip.max()) <= 2.5 * FWD_TOL
+    tot, worst = _grad_report(eng, o)
+    _check_grads(tot, worst, "B=128 T=401 g=1 wide chains")
+    # the plan really is the wide one at this batch (and the chains of 8 below it)
+    assert ops.gru_plan(B, 1, 640)["clips_per_chain"] == 16 and ops.gru_plan(64, 1, 640)["clips_per_chain"] == 8
