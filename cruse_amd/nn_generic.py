@@ -146,24 +146,58 @@ def _wgrad_raw(S, Bg, dw, KH, KW, stride, dil, pt, pl, groups, up_w, db=None):
                                       dil[1], pt, pl, groups, up_w, _dt(S), _stream()))
 
 
+# Hand-off tables between ADJACENT autograd nodes, keyed by a tensor's storage address (they used to hold strong references to
+# whole activations and gradients until a consumer popped the entry -- an entry no HIP consumer takes, e.g. the last block's BatchNorm
+# output, stayed alive across steps -- and were mutated without a lock although autograd runs backward on worker threads).  An entry
+# now holds its key tensor WEAKLY and disappears with it (a finalizer pops the entry when the tensor dies, so the address cannot be
+# matched by a later tensor that reuses it); what travels with the entry (batch sums, the BatchNorm's constants) lives exactly as long
+# as the tensor it describes.  The version is the one at stash time: a gradient autograd accumulated into in place is the same tensor,
+# but no longer what the sums describe.  One re-entrant lock (a finalizer may run while it is held).
+import weakref
+_HLOCK = threading.RLock()
+
+
+def _stash(table, key_tensor, payload):
+    k = key_tensor.data_ptr()
+
+    def drop(ref, k=k, table=table):
+        with _HLOCK:
+            ent = table.get(k)
+            if ent is not None and ent[0] is ref:
+                del table[k]
+    with _HLOCK:
+        table[k] = (weakref.ref(key_tensor, drop), key_tensor._version, payload)
+
+
+def _take(table, t):
+    with _HLOCK:
+        ent = table.pop(t.data_ptr(), None)
+    if ent is None:
+        return None
+    src = ent[0]()
+    if src is not None and src.shape == t.shape and src.dtype == t.dtype and ent[1] == t._version:
+        return ent[2]
+    return None
+
+
+def handoff_entries() -> int:
+    """entries waiting in the hand-off tables (tests: 0 once a step's tensors are gone)"""
+    with _HLOCK:
+        return len(_DX_SUMS) + len(_BN_SUMS) + len(_BN_OUT) + len(_BN_R)
+
+
 # Bias gradient of a convolution that feeds a BatchNorm: the BatchNorm's backward apply pass (cruse_bn_nchw_bwd_ex) sums the dx it stores per
 # channel -- the convolution's backward finds that sum here instead of re-reading dx (one 17 us pass per Conv2d -> BatchNorm2d pair at the
-# config-5 shape).  Keyed by the gradient tensor's storage address; the entry holds the tensor itself, so the address cannot be reused while
-# the entry lives; a few entries at most (a consumer without a bias gradient never collects its entry).
+# config-5 shape).
 _DX_SUMS = {}
 
 
 def _stash_dx_sum(dx, sums):
-    if len(_DX_SUMS) >= 8:
-        _DX_SUMS.clear()
-    _DX_SUMS[dx.data_ptr()] = (dx, sums)
+    _stash(_DX_SUMS, dx, sums)
 
 
 def _take_dx_sum(dy):
-    ent = _DX_SUMS.pop(dy.data_ptr(), None)
-    if ent is not None and ent[0].shape == dy.shape and ent[0].dtype == dy.dtype and ent[0]._version == dy._version:
-        return ent[1]
-    return None
+    return _take(_DX_SUMS, dy)
 
 
 # ... and the other way round: a convolution that feeds a training-mode BatchNorm delivers that BatchNorm's batch sums from its epilogue
@@ -171,16 +205,11 @@ _BN_SUMS = {}
 
 
 def _stash_bn_sums(y, sums):
-    if len(_BN_SUMS) >= 8:
-        _BN_SUMS.clear()
-    _BN_SUMS[y.data_ptr()] = (y, sums)
+    _stash(_BN_SUMS, y, sums)
 
 
 def _take_bn_sums(x):
-    ent = _BN_SUMS.pop(x.data_ptr(), None)
-    if ent is not None and ent[0].shape == x.shape and ent[0].dtype == x.dtype and ent[0]._version == x._version:
-        return ent[1]
-    return None
+    return _take(_BN_SUMS, x)
 
 
 # ... and backwards again: a convolution whose input came out of a training-mode BatchNorm (+ act) computes, in its data-gradient kernel's
@@ -189,20 +218,6 @@ def _take_bn_sums(x):
 _BN_OUT = {}
 _BN_R = {}
 BN_BWD_REPLICAS = 8
-
-
-def _stash(table, key_tensor, payload):
-    if len(table) >= 8:
-        table.clear()
-    table[key_tensor.data_ptr()] = (key_tensor, key_tensor._version, payload)       # holding the tensor keeps its address from being reused
-
-
-def _take(table, t):
-    # the version is the one at stash time: a gradient autograd accumulated into in place is the same tensor, but no longer what the sums describe
-    ent = table.pop(t.data_ptr(), None)
-    if ent is not None and ent[0].shape == t.shape and ent[0].dtype == t.dtype and ent[1] == t._version:
-        return ent[2]
-    return None
 
 
 def _channel_sum(dy, out):
@@ -357,6 +372,11 @@ class _BnActFn(torch.autograd.Function):
         return dx, dg, db, ds, None, None, None, None
 
 
+def _fused_bn_takes_replicas(x) -> bool:
+    """cruse_bn_nchw_fwd_train / cruse_bn_nchw_bwd_ex fold replicated f64 sums only in their f16 kernels, whose grid is (blocks, N * C): N * C < 65536"""
+    return x.dtype == torch.float16 and x.shape[0] * x.shape[1] < 65536
+
+
 class _BnTrainActFn(torch.autograd.Function):
     """Training-mode BatchNorm2d (+ act) from the batch sums: statistics finalised inside the forward kernel (running statistics and batch
     counter updated there), parameter gradients and -- want_dx_sum -- the preceding convolution's bias gradient inside the backward apply
@@ -369,12 +389,14 @@ class _BnTrainActFn(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = torch.empty(C, device=x.device, dtype=torch.float32)
         rstd = torch.empty(C, device=x.device, dtype=torch.float32)
+        if sums.dim() == 2 and not _fused_bn_takes_replicas(x):
+            sums = sums.sum(0)          # (the kernels that fold replicated sums are the f16 ones with N * C < 65536)
         check(lib.cruse_bn_nchw_fwd_train(_p(x), _p(sums), sums.shape[0] if sums.dim() == 2 else 1, float(eps), float(momentum), _p(gamma), _p(beta),
                                           _p(slope), act, N, C, HW, _p(y),
                                           _p(mean), _p(rstd), _p(rmean), _p(rvar), _p(nbt), _dt(x), _stream()))
         ctx.save_for_backward(x, gamma, beta, slope, mean, rstd)
         ctx.act, ctx.want_dx_sum = act, bool(want_dx_sum)
-        if x.dtype == torch.float16:
+        if _fused_bn_takes_replicas(x):
             _stash(_BN_OUT, y, (x, mean, rstd, gamma, beta, slope, act))
         return y
 
@@ -388,6 +410,8 @@ class _BnTrainActFn(torch.autograd.Function):
         HW = x[0, 0].numel()
         dx = torch.empty_like(x)
         delivered = _take(_BN_R, dy)                       # the producer of dy has already formed the sums (see _BN_OUT / _BN_R)
+        if delivered is not None and not _fused_bn_takes_replicas(x):
+            delivered = None                               # (not produced for such shapes; recomputed by the kernel's own reduce pass)
         scratch = delivered if delivered is not None else _zeros_f64((4 * C,), x.device)
         dg = _zeros_f32((C,), x.device)
         db = _zeros_f32((C,), x.device)

@@ -110,6 +110,34 @@ def side_stream_for(main: Optional[torch.cuda.Stream] = None) -> torch.cuda.Stre
     return s
 
 
+def stream_beside(main: Optional[torch.cuda.Stream] = None, avoid=(), tag: str = "copy") -> torch.cuda.Stream:
+    """a further pool stream that overlaps with `main` AND with every stream in `avoid` (e.g. the trainer's H2D copy stream beside the
+    compute stream and its leaf stream), chosen once per (main stream, tag) for the process -- so a stream is not drawn anew every epoch
+    (blocks the caching allocator holds for a dropped stream cannot be reused by the next one)"""
+    main = torch.cuda.current_stream() if main is None else main
+    key = (main.device_index, int(main.cuda_stream), tag)
+    s = _CHOSEN.get(key)
+    if s is not None:
+        return s
+    taken = {int(main.cuda_stream)} | {int(a.cuda_stream) for a in avoid}
+    cal = calibrate(main)
+    tried, best = [], None
+    for _ in range(MAX_DRAWS):
+        cand = torch.cuda.Stream()
+        if int(cand.cuda_stream) in taken:
+            continue
+        frac = max([serial_fraction(main, cand, cal)] + [serial_fraction(a, cand) for a in avoid])
+        tried.append(round(frac, 2))
+        if best is None or frac < best[0]:
+            best = (frac, cand)
+        if frac < 0.5:
+            break
+    s = best[1] if best is not None else torch.cuda.Stream()
+    _CHOSEN[key] = s
+    REPORT.append({"main_stream": hex(key[1]), "tag": tag, "serial_fraction_by_draw": tried, "kept": round(best[0], 2) if best else None})
+    return s
+
+
 def reset() -> None:
     _CHOSEN.clear()
     REPORT.clear()

@@ -46,20 +46,23 @@ class _Prefetcher:
     NPIN = 4
 
     def __init__(self, loader, device):
+        from .. import streams
         self.loader, self.device = loader, device
-        self.stream = torch.cuda.Stream(device=device)
+        # ONE data stream per compute stream for the life of the process (a stream per epoch strands the blocks the caching allocator
+        # holds for the old one), proven to overlap with the compute stream and its leaf stream (cruse_amd/streams.py: a copy stream
+        # that shares their hardware queue would put every H2D copy in series with the step)
+        with torch.cuda.device(device):
+            main = torch.cuda.current_stream(device)
+            self.stream = streams.stream_beside(main, avoid=(streams.side_stream_for(main),), tag="data")
         self.resident = bool(getattr(getattr(loader, "dataset", None), "device_resident", False))
 
     def _index_batches(self):
-        bs, drop = self.loader.batch_size, self.loader.drop_last
-        buf = []
-        for i in self.loader.sampler:
-            buf.append(int(i))
-            if len(buf) == bs:
-                yield torch.tensor(buf, dtype=torch.int64)
-                buf = []
-        if buf and not drop:
-            yield torch.tensor(buf, dtype=torch.int64)
+        """the index lists of the DataLoader's OWN batch sampler (batch_size / drop_last / sampler, or a custom batch_sampler=)"""
+        bsamp = getattr(self.loader, "batch_sampler", None)
+        if bsamp is None:
+            raise RuntimeError("a device-resident dataset needs a DataLoader with automatic batching (batch_size or batch_sampler)")
+        for idx in bsamp:
+            yield torch.as_tensor(list(idx), dtype=torch.int64)
 
     def _resident_items(self, main):
         for idx in self._index_batches():
@@ -93,54 +96,85 @@ class _Prefetcher:
             return pinned[key]
 
         raw: "queue.Queue" = queue.Queue(maxsize=2)
+        stop = threading.Event()                   # set when the consumer leaves early (an exception or a break in the training loop)
+
+        def put(qu, item):
+            """qu.put that gives up when the consumer has left (-> False)"""
+            while not stop.is_set():
+                try:
+                    qu.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    pass
+            return False
 
         def pull():                                # stage 1: the DataLoader's consumer side (~5 ms per 32.8 MB batch on the bench host)
             try:
-                for item in self.loader:
-                    raw.put(item)
-                raw.put(None)
+                it = iter(self.loader)
+                try:
+                    for item in it:
+                        if not put(raw, item):
+                            return
+                finally:
+                    del it                         # (lets a non-persistent DataLoader shut its workers down)
+                put(raw, None)
             except BaseException as ex:
-                raw.put(ex)
+                put(raw, ex)
 
         def work():                                # stage 2: shared-memory pages -> pinned ring (~3 ms), beside stage 1
             try:
                 k = 0
-                while True:
-                    item = raw.get()
+                while not stop.is_set():
+                    try:
+                        item = raw.get(timeout=0.05)
+                    except queue.Empty:
+                        continue
                     if item is None or isinstance(item, BaseException):
-                        q.put(item)
+                        put(q, item)
                         return
                     noisy, clean = item
                     s_ = k % self.NPIN
                     # (two batches queued + this one: the copy of the batch that used slot s_ four batches ago was issued long ago)
                     if copy_done[s_] is not None:
                         copy_done[s_].synchronize()
-                    q.put((s_, stage(noisy, s_, "n"), stage(clean, s_, "c")))
+                    if not put(q, (s_, stage(noisy, s_, "n"), stage(clean, s_, "c"))):
+                        return
                     k += 1
             except BaseException as ex:            # surfaces in the training loop
-                q.put(ex)
+                put(q, ex)
         th0 = threading.Thread(target=pull, daemon=True)
         th = threading.Thread(target=work, daemon=True)
         th0.start()
         th.start()
-        while True:
-            item = q.get()
-            if item is None:
-                break
-            if isinstance(item, BaseException):
-                raise item
-            s_, hn, hc = item
-            with torch.cuda.stream(self.stream):
-                noisy = hn.to(self.device, non_blocking=True)
-                clean = hc.to(self.device, non_blocking=True)
-                if noisy.dtype != torch.float32:
-                    noisy, clean = noisy.float(), clean.float()
-                ev = torch.cuda.Event()
-                ev.record(self.stream)
-            copy_done[s_] = ev
-            yield noisy.contiguous(), clean.contiguous(), ev
-        th.join()
-        th0.join()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                s_, hn, hc = item
+                with torch.cuda.stream(self.stream):
+                    noisy = hn.to(self.device, non_blocking=True)
+                    clean = hc.to(self.device, non_blocking=True)
+                    if noisy.dtype != torch.float32:
+                        noisy, clean = noisy.float(), clean.float()
+                    ev = torch.cuda.Event()
+                    ev.record(self.stream)
+                copy_done[s_] = ev
+                yield noisy.contiguous(), clean.contiguous(), ev
+        finally:
+            # also reached when the generator is CLOSED at its yield (the training loop raised or broke): both threads see `stop`
+            # within 50 ms, drop what they hold and end -- the DataLoader iterator, its workers and the pinned ring go with them
+            stop.set()
+            for qu in (q, raw):
+                try:
+                    while True:
+                        qu.get_nowait()
+                except queue.Empty:
+                    pass
+            th.join(timeout=5.0)
+            th0.join(timeout=5.0)
 
     def __iter__(self):
         main = torch.cuda.current_stream(self.device)

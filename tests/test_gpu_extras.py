@@ -1052,3 +1052,63 @@ def test_bf16_mode_with_channels_beyond_the_mfma_kernels_and_an_input_gradient()
         (m(xi) * w).sum().backward()
         grads.append(xi.grad.clone())
     assert torch.isfinite(grads[0]).all() and rel_l2(grads[0], grads[1]) < 5e-2
+
+
+@pytest.mark.gpu
+def test_nchw_handoff_tables_hold_nothing_once_a_steps_tensors_are_gone():
+    """the address-keyed hand-off tables of nn_generic (BatchNorm sums out of a convolution's epilogue and back) used to keep whole
+    activations / gradients alive across steps whenever no HIP consumer popped an entry (the last block's BatchNorm output, a forward under
+    no_grad in train mode).  Entries now die with their key tensor: after a forward + backward of the TFCM stack, a train-mode forward under
+    no_grad and a bare Conv2d -> BatchNorm2d whose output nothing consumes, the tables are empty -- and the fused paths still deliver
+    (the f16 result equals a second run bit for bit and stays inside the f16 tolerance of the oracle test above)."""
+    import gc
+    from cruse_amd import nn_generic as NG
+    from cruse_amd.nn_generic import to_f16, to_f32
+    from model import mtfaa as M
+    torch.manual_seed(1)
+    tf = M.TFCM(24, (3, 3), 2).cuda().train()
+    x = torch.randn(2, 24, 33, 41, device="cuda")
+
+    def run():
+        for q in tf.parameters():
+            q.grad = None
+        y = to_f32(tf(to_f16(x)))
+        y.square().mean().backward()
+        return y.detach().clone(), [q.grad.clone() for q in tf.parameters()]
+    y1, g1 = run()
+    y2, g2 = run()
+    assert torch.equal(y1, y2)
+    with torch.no_grad():
+        tf(to_f16(x))                                   # train-mode forward whose BatchNorm outputs no backward ever collects
+    from model.based_model.cust_conv import Conv2dNormAct
+    blk = Conv2dNormAct(24, 8, (1, 3), fstride=1).cuda().train()
+    out = blk(x)                                        # the block's last BatchNorm output: no HIP conv consumes it
+    del out, y1, y2, g1, g2
+    gc.collect()
+    torch.cuda.synchronize()
+    assert NG.handoff_entries() == 0, (len(NG._BN_OUT), len(NG._BN_R), len(NG._BN_SUMS), len(NG._DX_SUMS))
+
+
+@pytest.mark.gpu
+def test_f16_conv_batchnorm_pair_with_many_planes():
+    """a Conv2d -> BatchNorm2d pair in f16 training with B * C >= 65536 planes -- the fused BatchNorm kernels that fold the
+    convolution's 8 replicated batch sums take N * C < 65536 only, and the call used to fail with CRUSE_E_SHAPE; the replicas are now folded
+    before the generic kernels.  Forward and parameter gradients against torch f32 on the same weights."""
+    import torch.nn as nn
+    from cruse_amd.nn_generic import HipSequential, to_f16, to_f32
+    torch.manual_seed(0)
+    B, C, H, W = 300, 256, 2, 16                       # 76 800 planes
+    seq = HipSequential(nn.Conv2d(C, C, (1, 1), bias=True), nn.BatchNorm2d(C), nn.ReLU()).cuda().train()
+    ref = nn.Sequential(nn.Conv2d(C, C, (1, 1), bias=True), nn.BatchNorm2d(C), nn.ReLU()).train()
+    ref.load_state_dict({k: v.detach().cpu() for k, v in seq.state_dict().items()})
+    x = torch.randn(B, C, H, W)
+    wgt = torch.randn(B, C, H, W)
+    y = to_f32(seq(to_f16(x.cuda())))
+    (y * wgt.cuda()).sum().backward()
+    yr = ref(x)
+    (yr * wgt).sum().backward()
+    assert rel_l2(y, yr) < 3e-3
+    for (n, p), (_, q) in zip(seq.named_parameters(), ref.named_parameters()):
+        if n == "0.bias":
+            continue                                    # feeds a BatchNorm: the true gradient is 0
+        assert rel_l2(p.grad, q.grad) < 2e-2, n

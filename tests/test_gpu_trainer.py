@@ -364,3 +364,49 @@ def test_trainer_epoch_is_not_input_bound():
         del tr, loader
     print("trainer / resident-engine throughput:", {k: round(v, 3) for k, v in ratios.items()}, f"(engine {ref_fps:.0f} frames/s)")
     assert ratios["device"] >= 0.95 and ratios["host"] >= 0.40 and ratios["host_f16"] >= 0.65, ratios
+
+
+@pytest.mark.gpu
+def test_prefetcher_shuts_down_when_the_loop_leaves_early_and_follows_a_batch_sampler():
+    """(1) a training loop that raises or breaks closes the prefetcher's generator at its yield -- its two staging threads
+    must end (they used to stay blocked in queue.put for ever, holding the DataLoader iterator, its workers and the pinned ring);
+    (2) the data stream is one per compute stream, not one per epoch; (3) the device-resident path follows the DataLoader's own
+    batch_sampler -- a DataLoader built with batch_sampler= has batch_size None and used to arrive as one huge batch."""
+    import threading
+    import time
+    from torch.utils.data import BatchSampler, DataLoader, SequentialSampler
+    from cruse_amd.data import DevicePairs, HostPoolPairs
+    from cruse_amd.train.trainer_casual import _Prefetcher
+    dev = torch.device("cuda", torch.cuda.current_device())
+    host = HostPoolPairs(num=64, length=3200, seed=3, pool=16)
+    ld = DataLoader(host, batch_size=4, shuffle=False, num_workers=2)
+    before = threading.active_count()
+    pf = _Prefetcher(ld, dev)
+    for k, (n, c) in enumerate(pf):
+        if k == 2:
+            break                                   # 13 batches are still to come: both threads are blocked in put()
+    deadline = time.time() + 10.0
+    while threading.active_count() > before and time.time() < deadline:
+        time.sleep(0.05)
+    assert threading.active_count() <= before, [t.name for t in threading.enumerate()]
+    with pytest.raises(ZeroDivisionError):
+        for k, (n, c) in enumerate(_Prefetcher(ld, dev)):
+            if k == 1:
+                1 / 0
+    deadline = time.time() + 10.0
+    while threading.active_count() > before and time.time() < deadline:
+        time.sleep(0.05)
+    assert threading.active_count() <= before
+    assert _Prefetcher(ld, dev).stream is pf.stream                       # (2)
+    # (3) a custom batch sampler: batches of 3 in reverse order
+    dp = DevicePairs(num=12, length=3200, seed=3, pool=16)
+
+    class Rev(BatchSampler):
+        def __iter__(self):
+            return iter(reversed(list(super().__iter__())))
+    ld2 = DataLoader(dp, batch_sampler=Rev(SequentialSampler(dp), batch_size=3, drop_last=False))
+    assert ld2.batch_size is None
+    res = list(_Prefetcher(ld2, dev))
+    assert [tuple(n.shape) for n, _ in res] == [(3, 3200)] * 4
+    n_last, c_last = dp.device_batch(torch.tensor([9, 10, 11]), dev)
+    assert torch.equal(res[0][0], n_last) and torch.equal(res[0][1], c_last)
