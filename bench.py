@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="skip the f32 gate-mode, hop=320 STFT and upsample-decoder rows")
     ap.add_argument("--df", action="store_true", help="BASELINE config 4: DeepFilter(1,5) head + WO-MALE on its output")
     ap.add_argument("--bucketed", action="store_true", help="force the segmented (multi-GPU) schedule at world 1")
+    ap.add_argument("--no-pin", action="store_true", help="multi-GPU runs: do NOT pin each rank's host threads to its GPU's NUMA-local cores "
+                                                           "(cruse_amd/hostpin.py)")
     ap.add_argument("--ref-1gpu", type=float, default=None, help="frames/s of the 1-GPU run of the same configuration: adds "
                                                                  "scaling_efficiency = value / (n_gpus * ref) to the JSON line")
     return ap.parse_args()
@@ -620,6 +622,57 @@ def rccl_world1_row(a, dev, pool):
 HOST_ISSUE_MS = {}           # id(engine) -> host time to ISSUE one step of the last _time_steps() call (no synchronisation inside)
 
 
+def host_contention_row(a, dev, pool, nsib=7, steps=30):
+    """what seven sibling ranks do to THIS rank's launch loop, without the node -- the headline step (eager launches and
+    graph replay) alone, beside seven processes spinning the host side of a launch loop (ctypes calls into the library that are rejected
+    before any device work: tools/host_contention_probe.py) unpinned, and with every process on the core slice cruse_amd/hostpin.py gives
+    rank r of 8 (this process = rank 0).  The figure that matters at N = 8 is pinned / alone."""
+    import multiprocessing as mp
+    from cruse_amd import hostpin
+    from cruse_amd.engine import TrainEngine
+    from cruse_amd.model.cruse_net import unet_2
+    from tools.host_contention_probe import sibling
+    torch.manual_seed(0)
+    m = unet_2(rnn_groups=a.groups, precision=a.prec).to(dev)
+    engs = {"graph": TrainEngine(m, lr=1e-3, use_graph=True), "eager": TrainEngine(m, lr=1e-3, use_graph=False)}
+
+    def measure():
+        return {k: round(_time_steps(e, pool, n_warm=4, n=steps), 3) for k, e in engs.items()}
+    out = {"alone": measure(), "siblings": nsib, "host_cores": os.cpu_count()}
+    allowed = sorted(os.sched_getaffinity(0))
+    ctx = mp.get_context("spawn")
+    try:
+        for label, pinned in (("unpinned", False), ("pinned", True)):
+            stop = ctx.Event()
+            procs = [ctx.Process(target=sibling, args=(stop, i), daemon=True) for i in range(nsib)]
+            for p in procs:
+                p.start()
+            try:
+                if pinned:
+                    none = {r: None for r in range(nsib + 1)}
+                    for i, p in enumerate(procs):
+                        os.sched_setaffinity(p.pid, hostpin.plan(i + 1, nsib + 1, allowed, none))
+                    mine = hostpin.plan(0, nsib + 1, allowed, none)
+                    os.sched_setaffinity(0, mine)
+                    out["cores_per_rank"] = len(mine)
+                time.sleep(1.5)                                 # (the siblings' interpreters are up and spinning)
+                out[label] = measure()
+            finally:
+                stop.set()
+                for p in procs:
+                    p.join(timeout=10)
+                    if p.is_alive():
+                        p.terminate()
+    finally:
+        os.sched_setaffinity(0, allowed)
+    for label in ("unpinned", "pinned"):
+        if label in out:
+            out[label + "_over_alone"] = {k: round(out[label][k] / out["alone"][k], 4) for k in out["alone"]}
+    out["note"] = ("headline step beside seven host-side launch loops: ms per step by launch form; pinned = every process on its own "
+                   "1/8 slice of the allowed cores (cruse_amd/hostpin.py: what bench.py / tools/train_stand.py do per rank at N > 1)")
+    return out
+
+
 def _time_steps(eng, pool, n_warm=3, n=8):
     """device ms per step (HIP events around n steps); the host's issue time per step of the same loop is left in HOST_ISSUE_MS:
     a form whose issue time is about its device time is HOST-bound (an eager B = 32 step issues ~400 launches in ~3 ms)"""
@@ -873,6 +926,9 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
     local = local % torch.cuda.device_count()         # (test rigs may oversubscribe one GPU)
     torch.cuda.set_device(local)
+    from cruse_amd import hostpin
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    pin = hostpin.pin_rank(int(os.environ.get("LOCAL_RANK", "0")), local_world, device_index=local, enable=not a.no_pin)
     force_pg = os.environ.get("CRUSE_FORCE_COLLECTIVES") == "1"      # a world of ONE still issues its (RCCL) collectives
     backend = None
     if world > 1 or force_pg:
@@ -1031,6 +1087,11 @@ def main():
         secondary.update(config_rows(a, dev, pool))
         log("secondary: trainer path (device-resident / host dataset) ...")
         secondary["trainer_path"] = trainer_path_rows(a, dev, frames_per_s_headline)
+        try:
+            log("secondary: host contention (7 sibling launch loops, unpinned / pinned) ...")
+            secondary["host_contention"] = host_contention_row(a, dev, pool)
+        except Exception as ex:
+            secondary["host_contention"] = {"error": repr(ex)[:300]}
         if not force_pg:
             log("secondary: rccl world-1 bucketed schedule ...")
             secondary["rccl_world1_bucketed"] = rccl_world1_row(a, dev, pool)
@@ -1053,7 +1114,7 @@ def main():
             "ms_per_step": round(el / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.prec, "data": "synthetic",
             "world_size": world, "backend": ("rccl" if backend == "nccl" else backend), "bucketed_allreduce": bool(eng.bucketed),
-            "rccl_ranks_seen": (None if ranks_seen is None else len(ranks_seen)), "devices_seen": devices_seen,
+            "rccl_ranks_seen": (None if ranks_seen is None else len(ranks_seen)), "devices_seen": devices_seen, "host_pinning_rank0": pin,
             "scaling_efficiency": (None if not a.ref_1gpu else round(frames / el / (world * a.ref_1gpu), 4)),
             "config": {"workload": f"CRUSE unet_2 4-layer enc/dec, {a.groups}xGRU group(s), H=640, "
                                    f"{B} clips x {a.seconds:g} s @16 kHz per GPU, n_fft=320 hop=160 (T={T}), "

@@ -22,7 +22,7 @@ def test_library_exports_every_header_symbol():
     assert set(SIGNATURES) == set(hdr)
     lib.cruse_abi_version.restype = ctypes.c_int
     from cruse_amd._lib import ABI_VERSION
-    assert lib.cruse_abi_version() == ABI_VERSION == 12
+    assert lib.cruse_abi_version() == ABI_VERSION == 13
 
 
 def test_error_channel_without_gpu():
@@ -211,3 +211,25 @@ def test_reference_dotted_paths_resolve():
                  "train_base.acoustics.mask.compress_cIRM", "loss_func.loss.loss_func", "dataset.dataset.SynDataset",
                  "model.deep_filter.DeepFilter"):
         assert initialize_module(path, initialize=False) is not None, path
+
+
+def test_hostpin_plan_gives_every_rank_its_own_cores():
+    """cruse_amd/hostpin.py: ranks whose GPUs share a NUMA node split that node's cores, ranks without locality information split the allowed
+    cores evenly; slices are disjoint, inside the allowed set and never empty"""
+    from cruse_amd import hostpin
+    assert hostpin._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    allowed = list(range(256))
+    node0, node1 = list(range(0, 64)) + list(range(128, 192)), list(range(64, 128)) + list(range(192, 256))
+    by_rank = {r: (node0 if r < 4 else node1) for r in range(8)}
+    slices = [hostpin.plan(r, 8, allowed, by_rank) for r in range(8)]
+    assert all(len(s) == 32 for s in slices)
+    assert all(set(s) <= set(node0 if r < 4 else node1) for r, s in enumerate(slices))
+    assert len(set().union(*map(set, slices))) == 256                      # disjoint and complete
+    none = {r: None for r in range(8)}
+    slices = [hostpin.plan(r, 8, allowed[:8], none) for r in range(8)]
+    assert sorted(c for s in slices for c in s) == list(range(8))          # one core each on an 8-core box
+    assert hostpin.plan(5, 8, [3], none) == [3]                            # fewer cores than ranks: shared, not empty
+    # sysfs says nothing in this container / for a missing device: no exception
+    assert hostpin.gpu_local_cores(0) is None or isinstance(hostpin.gpu_local_cores(0), list)
+    info = hostpin.pin_rank(0, 1)
+    assert info["pinned"] is False

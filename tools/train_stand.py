@@ -39,6 +39,15 @@ def entry(rank, world_size, config, resume, only_validation):
     use_gpu = torch.cuda.is_available()
     if use_gpu:
         torch.cuda.set_device(rank % torch.cuda.device_count())
+        # each rank's host threads on its GPU's NUMA-local cores ([meta] pin_cores = false opts out): the reference pins nothing
+        # (train_stand.py:151-155); eight unpinned launch loops cost an eager step ~20 % (cruse_amd/hostpin.py)
+        from cruse_amd import hostpin
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(min(world_size, torch.cuda.device_count()))))
+        info = hostpin.pin_rank(rank % max(local_world, 1), local_world, device_index=rank % torch.cuda.device_count(),
+                                enable=bool(config["meta"].get("pin_cores", True)))
+        if rank == 0 and info.get("pinned"):
+            print(f"[train_stand] rank 0 pinned to {info['cores']} cores ({info['first_core']}..{info['last_core']}, "
+                  f"{'NUMA-local' if info['numa_local'] else 'even slice'})")
     dist.init_process_group("nccl" if use_gpu else "gloo", rank=rank, world_size=world_size)
     if rank == 0:
         os.makedirs(config["meta"]["save_dir"], exist_ok=True)
