@@ -496,7 +496,10 @@ class TrainEngine:
             return
         main = torch.cuda.current_stream()
         if self._launcher is None:
-            self._launcher = torch.cuda.Stream()
+            # a stream proven to run beside the main AND the leaf stream (cruse_amd/streams.py): the launcher's head is a pending wait
+            # for most of a segment, and a waiting queue that shares their hardware queue / pipe stalls them (+4 % per step, round 6)
+            from . import streams
+            self._launcher = streams.stream_beside(main, avoid=tuple(self.side.used), tag="launcher")
         self._launcher.wait_stream(main)
         for s_ in self.side.used:
             self._launcher.wait_stream(s_)
