@@ -1,0 +1,76 @@
+"""is the G16 `gru.ln1.bias` gradient (0.306 of a 9e-4 norm with gi_f16 = 3) an ACCUMULATION problem?
+The fixture is B = 2 x T = 21: the bias gradient is a sum over 42 rows.  This probe captures the incoming gradient dy of LayerNorm 1 in the
+engine's backward pass and compares, per gi_f16 mask: the kernel's dbeta against the float64 column sum of the SAME dy (accumulation error),
+and both against oracle autograd (what the rounding of the operands that made dy costs).
+    python tools/ln1_bias_probe.py"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cruse_amd import ops                              # noqa: E402
+from cruse_amd.config import EngineConfig              # noqa: E402
+from cruse_amd.engine import TrainEngine               # noqa: E402
+from cruse_amd.model import cruse_net as M             # noqa: E402
+from oracle import cruse_oracle as O                   # noqa: E402
+from oracle import cruse_oracle_ext as X               # noqa: E402
+
+
+def rel(a, b):
+    a, b = a.double().cpu().flatten(), b.double().cpu().flatten()
+    return float((a - b).norm() / b.norm())
+
+
+def main():
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g16_df_step_g1.npz"))
+    noisy, clean = torch.from_numpy(g["noisy"]).float(), torch.from_numpy(g["clean"]).float()
+    o = O.unet_2(rnn_groups=1); O.closed_form_init(o); o.train()
+    loss, _ = X.train_step_loss_df(o, noisy, clean)
+    loss.backward()
+    ref = o.gru.ln1.bias.grad
+    print(f"oracle |d ln1.bias| = {float(ref.norm()):.3e}   (|d skip_connect_4.weight| = {float(o.skip_connect_4.weight.grad.norm()):.3e})")
+    real = ops.ln_bwd
+    for mask in (0, 2, 3):
+        cap = {}
+
+        def spy(dy, x, mean, rstd, gamma, rows, H, ig, dgamma, dbeta):
+            out = real(dy, x, mean, rstd, gamma, rows, H, ig, dgamma, dbeta)
+            cap.setdefault("calls", []).append((dy.clone(), dbeta))
+            return out
+        ops.ln_bwd = spy
+        real_gemm = ops.gemm_bf16_nt
+
+        def spy_gemm(Mm, N, K, A, a_off, lda, *a_, **k_):
+            if Mm == 42 and N == 640 and lda == 1920 and "dgi2" not in cap:
+                cap["dgi2"] = A.clone()
+            return real_gemm(Mm, N, K, A, a_off, lda, *a_, **k_)
+        ops.gemm_bf16_nt = spy_gemm
+        try:
+            m = M.unet_2(rnn_groups=1, precision="bf16")
+            m.load_state_dict(o.state_dict(), strict=True)
+            eng = TrainEngine(m.cuda(), use_graph=False, loss="wo_male_df", config=EngineConfig(gi_f16=mask))
+            eng._fwd_bwd(noisy.cuda(), clean.cuda())
+            torch.cuda.synchronize()
+        finally:
+            ops.ln_bwd = real
+            ops.gemm_bf16_nt = real_gemm
+        dy, _ = cap["calls"][1]                            # second call of the backward pass = LayerNorm 1
+        got = eng.flat.G["gru.ln1.bias"]
+        f64 = dy.double().sum(0) if dy.dim() == 2 else dy.double().view(-1, 640).sum(0)
+        if "dgi2" in cap:
+            W = eng.flat.P["gru.gru_list2.0.weight_ih_l0"].double()
+            dg = cap["dgi2"].view(-1)[:42 * 1920].view(42, 1920).double()
+            ex = (dg @ W).sum(0)                              # the engine's own (bf16-rounded) dgi2 against UNROUNDED W_ih2, in float64
+            exb = (dg @ W.bfloat16().double()).sum(0)         # ... against bf16-rounded W_ih2 (what the dX GEMM multiplies)
+            dgo = None
+            print(f"           layer-2 dX from the engine's dgi2 in float64: exact W {rel(ex, ref):.3f}, bf16 W {rel(exb, ref):.3f} (vs oracle); "
+                  f"kernel dy column sum vs that bf16-W product {rel(f64, exb):.2e}")
+        print(f"gi_f16 = {mask}: rows summed {dy.numel() // 640};  kernel dbeta vs float64 sum of the same dy: {rel(got, f64):.2e};  "
+              f"kernel vs oracle: {rel(got, ref):.3f};  float64 sum vs oracle: {rel(f64, ref):.3f};  norm deviation {abs(float(got.norm()) - float(ref.norm())) / float(ref.norm()):.3f}")
+
+
+if __name__ == "__main__":
+    main()
