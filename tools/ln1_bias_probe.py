@@ -28,8 +28,12 @@ def main():
     g = np.load(os.path.join(ROOT, "tests", "golden", "g16_df_step_g1.npz"))
     noisy, clean = torch.from_numpy(g["noisy"]).float(), torch.from_numpy(g["clean"]).float()
     o = O.unet_2(rnn_groups=1); O.closed_form_init(o); o.train()
+    hook = {}
+    hd = o.gru.ln1.register_full_backward_hook(lambda mod, gin, gout: hook.__setitem__("dl1", gout[0].detach().clone()))
     loss, _ = X.train_step_loss_df(o, noisy, clean)
     loss.backward()
+    hd.remove()
+    dl1_o = hook["dl1"].reshape(-1, 640)                   # oracle gradient reaching LayerNorm 1's output, [B*T, 640]
     ref = o.gru.ln1.bias.grad
     print(f"oracle |d ln1.bias| = {float(ref.norm()):.3e}   (|d skip_connect_4.weight| = {float(o.skip_connect_4.weight.grad.norm()):.3e})")
     real = ops.ln_bwd
@@ -68,6 +72,12 @@ def main():
             dgo = None
             print(f"           layer-2 dX from the engine's dgi2 in float64: exact W {rel(ex, ref):.3f}, bf16 W {rel(exb, ref):.3f} (vs oracle); "
                   f"kernel dy column sum vs that bf16-W product {rel(f64, exb):.2e}")
+        dyr = dy.double().view(-1, 640).cpu()
+        d = dyr - dl1_o.double()
+        per_row = d.norm(dim=1) / dl1_o.double().norm(dim=1)
+        print(f"           dl1 rows vs oracle: all {rel(dyr, dl1_o):.3e}; per frame t (clip 0): " + " ".join(f"{float(v):.2f}" for v in per_row[:21]))
+        print(f"           |sum of rows| oracle {float(dl1_o.double().sum(0).norm()):.3e}, typical |row| {float(dl1_o.double().norm(dim=1).mean()):.3e}, "
+              f"|sum of row errors| {float(d.sum(0).norm()):.3e}, sqrt(sum |row error|^2) {float(d.norm()):.3e}")
         print(f"gi_f16 = {mask}: rows summed {dy.numel() // 640};  kernel dbeta vs float64 sum of the same dy: {rel(got, f64):.2e};  "
               f"kernel vs oracle: {rel(got, ref):.3f};  float64 sum vs oracle: {rel(f64, ref):.3f};  norm deviation {abs(float(got.norm()) - float(ref.norm())) / float(ref.norm()):.3f}")
 
