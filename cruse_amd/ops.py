@@ -270,7 +270,10 @@ _wgrad_ws = {}
 _ws_retired = []          # outgrown workspaces: captured HIP graphs may still point at them, so they are never freed
 
 
-def _ws(key, nbytes: int, device) -> torch.Tensor:
+def _ws(key, nbytes: int, device, zero: bool = True) -> torch.Tensor:
+    """zero = False: a scratch whose user writes every byte it reads (weight-gradient / split-K slabs).  Those are keyed by STREAM, so a
+    HIP-graph capture meets new keys -- and a torch.zeros made during capture is a fill NODE that replays with every step (round 6: eight
+    5-15 us fills in the leaf chain of the captured step)."""
     device = torch.device(device)
     if device.type == "cuda" and device.index is None:       # "cuda" and "cuda:0" must name the same workspace
         device = torch.device("cuda", torch.cuda.current_device())
@@ -279,7 +282,7 @@ def _ws(key, nbytes: int, device) -> torch.Tensor:
         old = buf
         # zero-filled: the GRU workspace starts with a STICKY 256-byte header (hand-off status word) that the library
         # never clears (include/cruse_hip.h, cruse_gru_seq_fwd); a grown buffer inherits the old header
-        buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        buf = (torch.zeros if zero else torch.empty)(nbytes, dtype=torch.uint8, device=device)
         if old is not None:
             _ws_retired.append((key, old))           # (graphs captured on the old buffer keep it alive)
         _wgrad_ws[(key, device)] = buf
@@ -310,7 +313,7 @@ def conv_wgrad(a, bt, dw, B, T, Ca, Fa, Cb, Fb, KT, S, pad, prec=None):
     """dw[ca][cb][kt][kf] += ... (dw is a contiguous f32 tensor of Ca*Cb*KT*3 elements)."""
     nbytes = lib.cruse_conv_wgrad_ws_bytes(Ca, Cb, KT)
     # one partial-slab workspace PER STREAM: weight-gradient leaves may run concurrently on several side streams
-    ws = _ws(("wgrad", _stream()), nbytes, a.device)
+    ws = _ws(("wgrad", _stream()), nbytes, a.device, zero=False)
     pc = -1 if prec is None else (WGRAD_PREC[prec] if isinstance(prec, str) else int(prec))
     check(lib.cruse_conv_wgrad(_p(a), _p(bt), _p(dw), B, T, Ca, Fa, Cb, Fb, KT, S, pad, pc, _xdt(a, "conv_wgrad a"),
                                _xdt(bt, "conv_wgrad bt"), _p(ws), _stream()))
@@ -508,7 +511,7 @@ def gemm_bf16_nt(M, N, K, A, a_off, lda, Bm, b_off, ldb, C, c_off, ldc, bias=Non
         if A.dtype != torch.bfloat16 or Bm.dtype != torch.bfloat16:
             raise RuntimeError("gemm_bf16_nt needs bf16 operands")
         nbytes = lib.cruse_gemm_bf16_slab_bytes(M, N, splitk)
-        ws = _ws(("gemm_slabs", _stream()), nbytes, C.device)
+        ws = _ws(("gemm_slabs", _stream()), nbytes, C.device, zero=False)
         check(lib.cruse_gemm_bf16_nt_slabs(M, N, K, A.data_ptr() + 2 * a_off, lda, a_kstride, Bm.data_ptr() + 2 * b_off, ldb, b_kstride,
                                            C.data_ptr() + 4 * c_off, ldc, splitk, _p(ws), ws.numel(), _stream()))
         return
@@ -525,7 +528,7 @@ def gemm_bf16_nt_cat(Ms, N, K, A, a_rows, lda, Bs, b_off, ldb, C, c_off, ldc, sp
     if A.dtype != torch.bfloat16 or any(b.dtype != torch.bfloat16 for b in Bs) or C.dtype != torch.float32:
         raise RuntimeError("gemm_bf16_nt_cat needs bf16 operands and an f32 result")
     nbytes = lib.cruse_gemm_bf16_slab_bytes(int(sum(Ms)), N, splitk)
-    ws = _ws(("gemm_slabs", _stream()), nbytes, C.device)
+    ws = _ws(("gemm_slabs", _stream()), nbytes, C.device, zero=False)
     ms = (ctypes.c_int * n)(*[int(m) for m in Ms])
     ar = (ctypes.c_longlong * n)(*[int(r) for r in a_rows])
     bs = (ctypes.c_void_p * n)(*[b.data_ptr() + 2 * b_off for b in Bs])
