@@ -67,6 +67,7 @@ SIGNATURES = {
     "cruse_ktile_bf16": ("piiqppp", "i"),
     "cruse_ktile_f16": ("piiqpp", "i"),
     "cruse_gemm_f16_nt": ("iiipqqpqqpqpp", "i"),
+    "cruse_gemm_nt_out16": ("iiippqqppqqpqpiip", "i"),
     "cruse_gemm_f16x2_nt": ("iiipqqppqqpqpp", "i"),
     "cruse_ktile_f16_split": ("piiqppp", "i"),
     "cruse_cast_bf16_split": ("pppqp", "i"),
@@ -78,6 +79,7 @@ SIGNATURES = {
     "cruse_gru_seq_fwd_on": ("pppppppiiiiippip", "i"),
     "cruse_gru_seq_bwd_on": ("pppppppiiiiippip", "i"),
     "cruse_gru_seq_fwd_ex": ("ppppppppqiiiiiiipipip", "i"),
+    "cruse_gru_seq_fwd_gi16": ("pippppppiiiiiipipip", "i"),
     "cruse_gru_seq_bwd_ex": ("pppppppiiiiiiiiipipip", "i"),
     "cruse_gru_gate_grads": ("pppppqiiip", "i"),
     "cruse_gru_gate_grads_bf16": ("pppppqppqiip", "i"),

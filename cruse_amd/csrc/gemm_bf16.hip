@@ -51,6 +51,7 @@ struct GbArgs {
     // ATR (cruse_gemm_bf16_nt_atr): A is read from its TIME-MAJOR K-tiled image -- element (m, k) at A[(m / 64) * a_mbs + k * 64 + m % 64], the
     // layout of the gate-gradient tensor dgT the weight-gradient GEMMs consume -- so the row-major copy dgi need not exist.  a_ks = 64 * 64.
     long long a_mbs; int a_mb_last;
+    int c_f16;                               // MODE 3: the 2-byte result rows are IEEE f16 (0: bf16)
 };
 
 __device__ __forceinline__ long long seg_row(const GbArgs& g, int m) {
@@ -324,6 +325,20 @@ __global__ __launch_bounds__(256 * BMT, (NST == 2 && BMT == 1) ? 2 : 1) void gem
             if (m < m_lim) {
                 if constexpr (MODE == 3) {                 // bf16 rows: 8-byte stores, 128-byte row segments
                     __bf16* cb = reinterpret_cast<__bf16*>(g.C) + seg_row(g, m) * g.ldc + nq;
+                    if (g.c_f16) {                          // (same rows, IEEE f16 elements: the gi rows cruse_gru_seq_fwd_gi16 reads)
+                        _Float16* ch = reinterpret_cast<_Float16*>(cb);
+                        if (nq + 3 < g.N && (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 7) == 0)) {
+                            typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_;
+                            const f16x4_ o = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                            *reinterpret_cast<f16x4_*>(ch) = o;
+                        } else {
+                            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (nq + q < g.N) ch[q] = (_Float16)e[q];
+                        }
+                        continue;
+                    }
                     if (nq + 3 < g.N && (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.C) & 7) == 0)) {
                         typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
                         const bf16x4_ o = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
@@ -492,14 +507,14 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
                           float* C, long long ldc, const float* bias, int accumulate, int splitk, void* stream,
                           int seg_len = 0, long long seg_stride = 0, long long seg_off = 0, bool c_bf16 = false,
                           float* slabs = nullptr, size_t slab_bytes = 0, bool f16 = false, const GbCat* cat = nullptr,
-                          long long atr_mbs = 0, int atr_mb_last = 0, const GbGroups* grp = nullptr) {
+                          long long atr_mbs = 0, int atr_mb_last = 0, const GbGroups* grp = nullptr, bool c_f16 = false) {
     CRUSE_REQUIRE(!grp || (!c_bf16 && !slabs && splitk == 1 && !cat && atr_mbs == 0 && seg_len == 0 && a_kstride == BK), CRUSE_E_SHAPE,
                   "gemm_bf16_nt_groups: row-major A, f32 result, no split-K");
     const bool atr = atr_mbs != 0;
-    CRUSE_REQUIRE(!atr && !c_bf16, CRUSE_E_SHAPE, "gemm_bf16_nt: the transposed-A and bf16-output forms were removed (measured neutral / slower, r3-r4)");
+    CRUSE_REQUIRE(!atr, CRUSE_E_SHAPE, "gemm_bf16_nt: the transposed-A form was removed (measured neutral, r4)");
     CRUSE_REQUIRE(!atr || (!A_lo && !B_lo && !c_bf16 && !slabs && splitk == 1 && !f16 && !cat && seg_len == 0), CRUSE_E_SHAPE,
                   "gemm_bf16_nt_atr: plain bf16, one pass, no split-K");
-    CRUSE_REQUIRE(!f16 || (!A_lo && !c_bf16 && !slabs && splitk == 1 && !accumulate), CRUSE_E_SHAPE,
+    CRUSE_REQUIRE(!f16 || (!A_lo && !slabs && splitk == 1 && !accumulate), CRUSE_E_SHAPE,
                   "gemm_f16_nt: f32 result stored (no A low plane, no split-K, no accumulation)");
     CRUSE_REQUIRE(!c_bf16 || (!accumulate && splitk == 1), CRUSE_E_SHAPE, "gemm_bf16_nt: a bf16 result is stored, not accumulated");
     CRUSE_REQUIRE(seg_len >= 0 && (seg_len == 0 || (seg_stride >= seg_len && seg_off >= 0 && M % seg_len == 0 && a_kstride == BK)),
@@ -528,6 +543,7 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
     g.accumulate = accumulate; g.splitk = splitk; g.kt_chunk = kt_chunk;
     g.seg_len = seg_len; g.seg_stride = seg_stride; g.seg_off = seg_off;
     g.a_mbs = atr_mbs; g.a_mb_last = atr_mb_last;
+    g.c_f16 = c_f16 ? 1 : 0;
     g.tn_per_g = 0; g.a_gstep = g.b_gstep = g.c_gstep = g.bias_gstep = 0;
     g.tm_b1 = g.tm_b2 = 0x7fffffff; g.a_shift1 = g.a_shift2 = 0; g.B1 = g.B2 = nullptr;
     g.m_end0 = g.m_end1 = g.m_end2 = M; g.c_rows1 = g.c_rows2 = 0;
@@ -580,6 +596,14 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
         CRUSE_LAUNCH_CHECK("gemm_slab_reduce");
         return CRUSE_OK;
     }
+    if (f16 && c_bf16) {
+        const size_t lds16 = (size_t)2 * 2 * TILE_BYTES;
+        int rc0 = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_bf16_nt_kernel<3, 2, 1, true>), lds16, "gemm_nt_out16");
+        if (rc0) return rc0;
+        hipLaunchKernelGGL((gemm_bf16_nt_kernel<3, 2, 1, true>), grid, dim3(256), lds16, st, g);
+        CRUSE_LAUNCH_CHECK("gemm_nt_out16");
+        return CRUSE_OK;
+    }
     if (f16) {
         const size_t lds16 = (size_t)2 * 2 * TILE_BYTES;
         int rc0 = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_bf16_nt_kernel<0, 2, 1, true>), lds16, "gemm_f16_nt");
@@ -589,9 +613,11 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
         return CRUSE_OK;
     }
     if (deep) {
-        if (splitk > 1) CRUSE_GB_LAUNCH(2, 3); else if (accumulate) CRUSE_GB_LAUNCH(1, 3); else CRUSE_GB_LAUNCH(0, 3);
+        if (c_bf16) CRUSE_GB_LAUNCH(3, 3);
+        else if (splitk > 1) CRUSE_GB_LAUNCH(2, 3); else if (accumulate) CRUSE_GB_LAUNCH(1, 3); else CRUSE_GB_LAUNCH(0, 3);
     } else {
-        if (splitk > 1) CRUSE_GB_LAUNCH(2, 2); else if (accumulate) CRUSE_GB_LAUNCH(1, 2); else CRUSE_GB_LAUNCH(0, 2);
+        if (c_bf16) CRUSE_GB_LAUNCH(3, 2);
+        else if (splitk > 1) CRUSE_GB_LAUNCH(2, 2); else if (accumulate) CRUSE_GB_LAUNCH(1, 2); else CRUSE_GB_LAUNCH(0, 2);
     }
 #undef CRUSE_GB_LAUNCH
     CRUSE_LAUNCH_CHECK("gemm_bf16_nt");
@@ -615,6 +641,21 @@ extern "C" int cruse_gemm_f16x2_nt(int M, int N, int K, const void* A, long long
     CRUSE_REQUIRE(B_lo != nullptr, CRUSE_E_SHAPE, "gemm_f16x2_nt: B_lo is required (one plane: cruse_gemm_f16_nt)");
     return gemm_bf16_impl(M, N, K, A, nullptr, lda, a_kstride, B_hi, B_lo, ldb, b_kstride, C, ldc, bias, 0, 1, stream, 0, 0, 0, false,
                           nullptr, 0, true);
+}
+
+// The forward gate projections with a 2-BYTE RESULT: C[M,N] = (A_hi + A_lo) . (B_hi + B_lo)^T + bias stored as IEEE f16 (out_dtype = CRUSE_DT_F16) or
+// bf16 (CRUSE_DT_BF16) rows -- gi is the largest tensor of the forward pass (197 MB at the bench shape), written once here and read once by the
+// recurrence (cruse_gru_seq_fwd_gi16).  operands_f16 = 0: bf16 operand planes (the forms of cruse_gemm_bf16_nt / cruse_gemm_bf16x3_nt: A_lo, B_lo
+// nullable, A_lo needs B_lo); 1: IEEE-f16 planes (cruse_gemm_f16_nt / cruse_gemm_f16x2_nt: no A_lo).  The accumulation is the f32 one of
+// those entry points; the result is rounded once at the store.  Replaces the output side of nn.GRU's input projection (model/cruse_net.py:23-31).
+extern "C" int cruse_gemm_nt_out16(int M, int N, int K, const void* A_hi, const void* A_lo, long long lda, long long a_kstride,
+                                   const void* B_hi, const void* B_lo, long long ldb, long long b_kstride,
+                                   void* C, long long ldc, const float* bias, int operands_f16, int out_dtype, void* stream) {
+    CRUSE_REQUIRE(out_dtype == CRUSE_DT_F16 || out_dtype == CRUSE_DT_BF16, CRUSE_E_DTYPE, "gemm_nt_out16: out_dtype %d (CRUSE_DT_F16, CRUSE_DT_BF16)", out_dtype);
+    CRUSE_REQUIRE((A_lo == nullptr || (B_lo != nullptr && !operands_f16)) && ((uintptr_t)A_lo % 16) == 0 && ((uintptr_t)B_lo % 16) == 0, CRUSE_E_ALIGN,
+                  "gemm_nt_out16: low planes (A_lo needs B_lo and bf16 operands; 16-byte aligned)");
+    return gemm_bf16_impl(M, N, K, A_hi, A_lo, lda, a_kstride, B_hi, B_lo, ldb, b_kstride, reinterpret_cast<float*>(C), ldc, bias, 0, 1, stream, 0, 0, 0,
+                          true, nullptr, 0, operands_f16 != 0, nullptr, 0, 0, nullptr, out_dtype == CRUSE_DT_F16);
 }
 
 // C[M,N] = A[M,K] . B[N,K]^T + bias with IEEE-f16 operands (layouts as cruse_gemm_bf16_nt): the forward gate projection in one pass

@@ -264,8 +264,11 @@ __global__ __launch_bounds__(256) void gru_fwd_kernel(GruArgs a) {
 // (its k-steps wv + 4 i of every clip: NKW loads per lane) and checks its own tags; the panel is laid out CLIP-MINOR ([k chunk of 8][clip][8])
 // so that the 8 clips of one (k-step, lane group) are one 128-byte line and a load instruction is 512 contiguous bytes.  The panel barrier
 // stays (the helper wave's hand-over point), the image write, the wait for it and the fragment reads go.
-template <int NKW, int NS, bool FULL, bool WLO, bool TIMED = false, bool GIB = false, bool TF = false, bool RD = false>
+// GIH (with GIB, round 6): the 2-byte gi rows are IEEE f16, not bf16 (written by cruse_gemm_nt_out16; 11 significant bits: the enhanced spectrum
+// at T = 401 moves 4.10e-4 -> 4.25e-4 / 2.81e-4 -> 2.81e-4, where bf16 rows leave the G6 fixture's bar) -- the helper wave widens with v_cvt_f32_f16.
+template <int NKW, int NS, bool FULL, bool WLO, bool TIMED = false, bool GIB = false, bool TF = false, bool RD = false, bool GIH = false>
 __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_kernel(GruArgs a) {
+    static_assert(!GIH || GIB, "f16 gi rows use the 2-byte row geometry of the bf16 form");
     static_assert(!TF || FULL, "tag-free sweeps are built for Hg % 128 == 0");
     static_assert(!RD || (TF && !WLO), "register-direct sweep: tag-free hand-off");
     constexpr int NSW = TF ? (NKW * 128 + 255) / 256 : NS;      // sweep slots per thread
@@ -357,6 +360,13 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
                 for (int i2 = 0; i2 < 2; ++i2) {
                     if (i2 == 1 && lane >= 32) break;
                     const u32x4 w = o.v[i2];
+                    if constexpr (GIH) {
+                        auto lo16 = [](unsigned x) -> float { return (float)__builtin_bit_cast(_Float16, (unsigned short)(x & 0xffffu)); };
+                        auto hi16 = [](unsigned x) -> float { return (float)__builtin_bit_cast(_Float16, (unsigned short)(x >> 16)); };
+                        *reinterpret_cast<float4*>(d + gdb[i2]) = make_float4(lo16(w.x), hi16(w.x), lo16(w.y), hi16(w.y));
+                        *reinterpret_cast<float4*>(d + gdb[i2] + 4) = make_float4(lo16(w.z), hi16(w.z), lo16(w.w), hi16(w.w));
+                        continue;
+                    }
                     const u32x4 lo = {w.x << 16, w.x & 0xffff0000u, w.y << 16, w.y & 0xffff0000u};
                     const u32x4 hi = {w.z << 16, w.z & 0xffff0000u, w.w << 16, w.w & 0xffff0000u};
                     *reinterpret_cast<u32x4*>(d + gdb[i2]) = lo;
@@ -483,6 +493,7 @@ __global__ __launch_bounds__((WLO && NKW > 3) ? 256 : 320) void gru_fwd_lean_ker
         if (act) hp = a.h0[(long long)(b0 + bl) * a.h0_bs + grp * Hg + u0 + u];
     }
     auto ldgi = [&](int g, unsigned so) -> float {        // one gi value of this thread's (clip, unit): f32, or bf16 widened
+        if constexpr (GIH) return (float)__builtin_bit_cast(_Float16, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs_gi, (g_v + g * hg4) >> 1, so >> 1, 0));
         if constexpr (gib) return __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs_gi, (g_v + g * hg4) >> 1, so >> 1, 0) << 16);
         return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_gi, g_v + g * hg4, so, 0));
     };
@@ -1379,6 +1390,11 @@ int dispatch_fwd_lean_w(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
 int dispatch_fwd_lean(const GruArgs& a, int grid, size_t lds, hipStream_t s) {
     // Hg = 640: the K-split step on the tag-free hand-off with the register-direct sweep (library option gru_tf = 0: the tagged hand-off)
     const bool tf640 = a.Hg == 640 && !fwd_wlo(a.Hg) && a.h0 == nullptr && cruse_opt("gru_tf", 1) != 0;
+    if (a.gi_bf16 == 2) {
+        // f16 gi rows: built for the bench step's kernel only (Hg = 640, chains of 8, tag-free register-direct hand-off, h0 = 0)
+        if (!tf640) { cruse_set_error("gru_seq_fwd: f16 gi rows are served at Hg = 640 with h0 = NULL on chains of 8 only (cruse_gru_plan)"); return CRUSE_E_SHAPE; }
+        return launch_one(gru_fwd_lean_kernel<5, 5, true, false, false, true, true, true, true>, a, grid, lds, s, "gru_seq_fwd", 320);
+    }
     if (tf640) {
         if (a.dbg == 32) return launch_one(gru_fwd_lean_kernel<5, 5, true, false, true, false, true, true>, a, grid, lds, s, "gru_seq_fwd", 320);
         return launch_one(gru_fwd_lean_kernel<5, 5, true, false, false, false, true, true>, a, grid, lds, s, "gru_seq_fwd", 320);
@@ -1461,6 +1477,10 @@ int run_launches(GruArgs& a, const Plan& pl, int G, int Hg, int prec, void* pane
         a.xg = (unsigned long long*)xg_base + (size_t)bg_off * G * 2 * gpp;
         a.xg_bytes = (unsigned)((size_t)a.nchains * 2 * gpp * 8);
         const int grid = cdiv(a.nchains, 8) * 8 * pl.P;
+        if (FWD && a.gi_bf16 == 2 && (pl.wide || !fwd_lean_eligible(pl.Bg, Hg, prec))) {
+            cruse_set_error("gru_seq_fwd: f16 gi rows are served at Hg = 640, CRUSE_PREC_BF16, on chains of 8 clips only (B <= 96: cruse_gru_plan)");
+            return CRUSE_E_SHAPE;
+        }
         if (FWD && pl.wide) {
             a.poll_delay = 0;
             rc = dispatch_fwd_w16(a, grid, s);
@@ -1503,10 +1523,10 @@ extern "C" size_t cruse_gru_ws_bytes(int B, int G, int Hg) {
     return 256 + xid_bytes_total(B, G) + xg_bytes_total(B, G, Hg) + (size_t)MAX_LAUNCH_TICKETS * 8 * sizeof(unsigned);
 }
 
-extern "C" int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, const float* const* b_hh,
-                                    float* h, void* coef, float* an, float* z, const float* h0, long long h0_bstride,
-                                    int B, int T, int TS, int G, int Hg, int prec, int chain_clips, void* panels,
-                                    int panels_zeroed, unsigned* status, int xcd_rot, void* stream) {
+static int gru_seq_fwd_impl(const float* gi, const float* const* w_hh, const float* const* b_hh,
+                            float* h, void* coef, float* an, float* z, const float* h0, long long h0_bstride,
+                            int B, int T, int TS, int G, int Hg, int prec, int chain_clips, void* panels,
+                            int panels_zeroed, unsigned* status, int xcd_rot, void* stream, int gi_dtype) {
     int rc = check_common(B, T, G, Hg, prec, "gru_seq_fwd");
     CRUSE_REQUIRE(chain_clips == 0 || chain_clips == 8 || chain_clips == 16, CRUSE_E_SHAPE, "gru_seq_fwd: chain_clips = %d (0, 8, 16)", chain_clips);
     if (rc) return rc;
@@ -1530,9 +1550,32 @@ extern "C" int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, c
     for (int g = 0; g < G; ++g) { a.p.w_hh[g] = w_hh[g]; a.p.b_hh[g] = b_hh[g]; }
     a.B = B; a.T = T; a.G = G; a.Hg = Hg;
     a.TS = TS; a.h0 = h0; a.h0_bs = h0_bstride;
+    a.gi_bf16 = gi_dtype == CRUSE_DT_F16 ? 2 : 0;
     const size_t esz = prec == CRUSE_PREC_F32 ? 4 : 2, npl = prec == CRUSE_PREC_BF16X3 ? 2 : 1;
     const size_t lds = (size_t)16 * (Hg + (prec == CRUSE_PREC_F32 ? 4 : 8)) * esz * npl + 4 * 6 * RED_TS * sizeof(float);
     return run_launches<true>(a, pl, G, Hg, prec, panels, status, xcd_rot, lds, s);
+}
+
+extern "C" int cruse_gru_seq_fwd_ex(const float* gi, const float* const* w_hh, const float* const* b_hh,
+                                    float* h, void* coef, float* an, float* z, const float* h0, long long h0_bstride,
+                                    int B, int T, int TS, int G, int Hg, int prec, int chain_clips, void* panels,
+                                    int panels_zeroed, unsigned* status, int xcd_rot, void* stream) {
+    return gru_seq_fwd_impl(gi, w_hh, b_hh, h, coef, an, z, h0, h0_bstride, B, T, TS, G, Hg, prec, chain_clips, panels, panels_zeroed, status,
+                            xcd_rot, stream, CRUSE_DT_F32);
+}
+
+// gi rows stored as IEEE f16 ([B,T,G,3*Hg] halves: cruse_gemm_nt_out16 writes them): half the bytes of the largest tensor of the forward pass,
+// written once and read once.  Served where the bench step runs -- CRUSE_PREC_BF16, Hg = 640, h0 = NULL, chains of 8 clips (B <= 96) --
+// and refused with CRUSE_E_SHAPE elsewhere (the caller keeps f32 rows there).  gi_dtype: CRUSE_DT_F16 or CRUSE_DT_F32 (= cruse_gru_seq_fwd_ex).
+extern "C" int cruse_gru_seq_fwd_gi16(const void* gi, int gi_dtype, const float* const* w_hh, const float* const* b_hh,
+                                      float* h, void* coef, float* an, float* z,
+                                      int B, int T, int TS, int G, int Hg, int prec, void* panels,
+                                      int panels_zeroed, unsigned* status, int xcd_rot, void* stream) {
+    CRUSE_REQUIRE(gi_dtype == CRUSE_DT_F16 || gi_dtype == CRUSE_DT_F32, CRUSE_E_DTYPE, "gru_seq_fwd_gi16: gi_dtype %d (CRUSE_DT_F32, CRUSE_DT_F16)", gi_dtype);
+    CRUSE_REQUIRE(gi_dtype == CRUSE_DT_F32 || (prec == CRUSE_PREC_BF16 && Hg == 640), CRUSE_E_SHAPE,
+                  "gru_seq_fwd_gi16: f16 gi rows need CRUSE_PREC_BF16 and Hg = 640");
+    return gru_seq_fwd_impl(reinterpret_cast<const float*>(gi), w_hh, b_hh, h, coef, an, z, nullptr, 0, B, T, TS, G, Hg, prec, 0, panels,
+                            panels_zeroed, status, xcd_rot, stream, gi_dtype);
 }
 
 extern "C" int cruse_gru_seq_fwd_on(const float* gi, const float* const* w_hh, const float* const* b_hh,

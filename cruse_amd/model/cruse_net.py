@@ -293,7 +293,12 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
 
 
     def layer(inp, lname, inp_bf=None):
-        gi = torch.empty(B, T, g * 3 * Hg, device=x.device, dtype=torch.float32)
+        # gi rows: f32, or IEEE f16 where the recurrence reads them (EngineConfig.gi_store_f16: bf16 mode, one group of 640, chains of 8 clips
+        # -- cruse_gru_seq_fwd_gi16): the largest tensor of the forward pass, written once and read once -- 197 -> 98 MB per layer at the bench shape
+        gi16 = (bool(config.get().gi_store_f16) and fast and g == 1 and Hg == 640 and slot == 0
+                and ops.gru_plan(B, 1, Hg, prec)["clips_per_chain"] == 8 and ops.get_option("gru_tf") in (None, 1) and ops.get_option("gru_wlo") in (None, 0)
+                and ops.get_option("gru_fwd_lean") in (None, 1))
+        gi = torch.empty(B, T, g * 3 * Hg, device=x.device, dtype=torch.float16 if gi16 else torch.float32)
         # The forward projection corrects the bf16 rounding of W_ih (a second pass with its low plane): that rounding
         # dominates the forward error of the bf16 mode (enhanced spectrum 1.25e-3 -> 5.1e-4 rel-L2 on fixture G6;
         # correcting x too only reaches 4.8e-4).  CRUSE_GI_X3: bit 0 / 1 = layer 1 / 2 corrected, bit 2 = also split x.

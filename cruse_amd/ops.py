@@ -515,6 +515,8 @@ def gemm_bf16_nt(M, N, K, A, a_off, lda, Bm, b_off, ldb, C, c_off, ldc, bias=Non
         check(lib.cruse_gemm_bf16_nt_slabs(M, N, K, A.data_ptr() + 2 * a_off, lda, a_kstride, Bm.data_ptr() + 2 * b_off, ldb, b_kstride,
                                            C.data_ptr() + 4 * c_off, ldc, splitk, _p(ws), ws.numel(), _stream()))
         return
+    if C.dtype in _OUT16 and A.dtype == torch.bfloat16 and Bm.dtype == torch.bfloat16 and not accumulate and abs(splitk) <= 1:
+        return _gemm_nt_out16(M, N, K, A, None, a_off, lda, a_kstride, Bm, None, b_off, ldb, b_kstride, C, c_off, ldc, bias, False)
     if A.dtype != torch.bfloat16 or Bm.dtype != torch.bfloat16 or C.dtype != torch.float32:
         raise RuntimeError("gemm_bf16_nt needs bf16 operands and an f32 result")
     check(lib.cruse_gemm_bf16_nt(M, N, K, A.data_ptr() + 2 * a_off, lda, a_kstride, Bm.data_ptr() + 2 * b_off, ldb, b_kstride,
@@ -602,11 +604,26 @@ def ktile_f16(x, rows, cols, split=False):
     return y
 
 
+_OUT16 = {torch.float16: 1, torch.bfloat16: 2}        # CRUSE_DT_F16 / CRUSE_DT_BF16
+
+
+def _gemm_nt_out16(M, N, K, A_hi, A_lo, a_off, lda, a_kstride, B_hi, B_lo, b_off, ldb, b_kstride, C, c_off, ldc, bias, operands_f16):
+    """2-byte result rows (cruse_gemm_nt_out16): C is an f16 / bf16 tensor -- the gi rows gru_seq_fwd reads in that dtype"""
+    check(lib.cruse_gemm_nt_out16(M, N, K, A_hi.data_ptr() + 2 * a_off, None if A_lo is None else A_lo.data_ptr() + 2 * a_off, lda, a_kstride,
+                                  B_hi.data_ptr() + 2 * b_off, None if B_lo is None else B_lo.data_ptr() + 2 * b_off, ldb, b_kstride,
+                                  C.data_ptr() + 2 * c_off, ldc, _p(bias), 1 if operands_f16 else 0, _OUT16[C.dtype], _stream()))
+    return C
+
+
 def gemm_f16_nt(M, N, K, A, a_off, lda, B, b_off, ldb, C, c_off, ldc, bias=None, a_kstride=64, b_kstride=64, B_lo=None):
     """C[M,N] = A[M,K] . B[N,K]^T + bias on IEEE-f16 operands (cruse_gemm_f16_nt; offsets in elements): the forward gate projection
     in one pass.  B_lo: the low plane of B (ktile_f16(split=True)) -- two passes on the same accumulators (cruse_gemm_f16x2_nt)."""
-    if A.dtype != torch.float16 or B.dtype != torch.float16 or C.dtype != torch.float32 or (B_lo is not None and B_lo.dtype != torch.float16):
-        raise RuntimeError("gemm_f16_nt needs f16 operands and an f32 result")
+    if A.dtype != torch.float16 or B.dtype != torch.float16 or (B_lo is not None and B_lo.dtype != torch.float16):
+        raise RuntimeError("gemm_f16_nt needs f16 operands")
+    if C.dtype in _OUT16:
+        return _gemm_nt_out16(M, N, K, A, None, a_off, lda, a_kstride, B, B_lo, b_off, ldb, b_kstride, C, c_off, ldc, bias, True)
+    if C.dtype != torch.float32:
+        raise RuntimeError("gemm_f16_nt: the result is f32, or f16 / bf16 rows (cruse_gemm_nt_out16)")
     if B_lo is not None:
         check(lib.cruse_gemm_f16x2_nt(M, N, K, A.data_ptr() + 2 * a_off, lda, a_kstride, B.data_ptr() + 2 * b_off, B_lo.data_ptr() + 2 * b_off, ldb,
                                       b_kstride, C.data_ptr() + 4 * c_off, ldc, _p(bias), _stream()))
@@ -637,8 +654,10 @@ def gemm_bf16x3_nt(M, N, K, A_hi, A_lo, a_off, lda, B_hi, B_lo, b_off, ldb, C, c
     for t_ in (A_hi, A_lo, B_hi, B_lo):
         if t_ is not None and t_.dtype != torch.bfloat16:
             raise RuntimeError("gemm_bf16x3_nt needs bf16 planes")
+    if C.dtype in _OUT16 and not accumulate:
+        return _gemm_nt_out16(M, N, K, A_hi, A_lo, a_off, lda, a_kstride, B_hi, B_lo, b_off, ldb, b_kstride, C, c_off, ldc, bias, False)
     if C.dtype != torch.float32:
-        raise RuntimeError("gemm_bf16x3_nt needs an f32 result")
+        raise RuntimeError("gemm_bf16x3_nt needs an f32 result (f16 / bf16 rows without accumulation: cruse_gemm_nt_out16)")
     check(lib.cruse_gemm_bf16x3_nt(M, N, K, A_hi.data_ptr() + 2 * a_off,
                                    None if A_lo is None else A_lo.data_ptr() + 2 * a_off, lda, a_kstride,
                                    B_hi.data_ptr() + 2 * b_off, B_lo.data_ptr() + 2 * b_off, ldb, b_kstride,
@@ -705,8 +724,10 @@ def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G,
     single launch (cruse_gru_seq_fwd_ex).  wide: chains of 16 clips (half the workgroups; same results).
     zeroed: the slot's scratch is already clear
     (gru_step_ws_clear)."""
-    if gi.dtype != torch.float32:
-        raise RuntimeError(f"gru_seq_fwd: gi must be f32, got {gi.dtype}")
+    if gi.dtype not in (torch.float32, torch.float16):
+        raise RuntimeError(f"gru_seq_fwd: gi must be f32 (or f16 rows: cruse_gru_seq_fwd_gi16), got {gi.dtype}")
+    if gi.dtype == torch.float16 and (h0 is not None or chunk is not None or wide):
+        raise RuntimeError("gru_seq_fwd: f16 gi rows are served for whole sequences from h0 = 0 on chains of 8 clips")
     dev = gi.device
     H = G * Hg
     if out is not None:
@@ -737,6 +758,12 @@ def gru_seq_fwd(gi, w_hh: List[torch.Tensor], b_hh: List[torch.Tensor], B, T, G,
     wa, ba = _ptr_array(w_hh), _ptr_array(b_hh)
     _p(gi); _p(h); _p(coef); _p(an); _p(z)
     opt = lambda t_, k: None if t_ is None else _off(t_, t0 * k)
+    if gi.dtype == torch.float16:
+        check(lib.cruse_gru_seq_fwd_gi16(gi.data_ptr(), 1, ctypes.cast(wa, ctypes.c_void_p), ctypes.cast(ba, ctypes.c_void_p), h.data_ptr(),
+                                         None if coef is None else coef.data_ptr(), None if an is None else an.data_ptr(),
+                                         None if z is None else z.data_ptr(), B, T, T, G, Hg, prec_code(prec), panels, 1 if zeroed else 0,
+                                         status, xcd_rot, _stream()))
+        return h, coef, an, z
     check(lib.cruse_gru_seq_fwd_ex(_off(gi, t0 * 3 * H), ctypes.cast(wa, ctypes.c_void_p), ctypes.cast(ba, ctypes.c_void_p),
                                    _off(h, t0 * H), opt(coef, 3 * H), opt(an, H), opt(z, H), h0p, h0s, B, n, T, G, Hg,
                                    prec_code(prec), 16 if wide else 0, panels, 1 if zeroed else 0,

@@ -344,6 +344,14 @@ int cruse_ktile_bf16(const float* x, int rows, int cols, long long ld, void* y, 
 int cruse_ktile_f16(const float* x, int rows, int cols, long long ld, void* y, void* stream);
 /* (ABI 12) ... with the low plane y_lo = f16(x - f16(x)), same layout: the B_lo operand of cruse_gemm_f16x2_nt */
 int cruse_ktile_f16_split(const float* x, int rows, int cols, long long ld, void* y, void* y_lo, void* stream);
+/* (ABI 13) The forward gate projections with a 2-BYTE RESULT: C[M,N] = (A_hi + A_lo) . (B_hi + B_lo)^T + bias stored as IEEE f16 (out_dtype =
+ * CRUSE_DT_F16) or bf16 (CRUSE_DT_BF16) rows [M, ldc] -- gi is the largest tensor of the forward pass (197 MB in f32 at the bench shape), written once
+ * here and read once by cruse_gru_seq_fwd_gi16.  operands_f16 = 0: bf16 operand planes in the layouts of cruse_gemm_bf16_nt / cruse_gemm_bf16x3_nt
+ * (A_lo, B_lo nullable; A_lo needs B_lo); 1: IEEE-f16 planes (cruse_gemm_f16_nt / cruse_gemm_f16x2_nt; no A_lo).  f32 accumulation, ONE rounding at
+ * the store.  Replaces the output side of nn.GRU's input projection (model/cruse_net.py:23-31,44,50). */
+int cruse_gemm_nt_out16(int M, int N, int K, const void* A_hi, const void* A_lo, long long lda, long long a_kstride,
+                        const void* B_hi, const void* B_lo, long long ldb, long long b_kstride,
+                        void* C, long long ldc, const float* bias, int operands_f16, int out_dtype, void* stream);
 /* (ABI 9) C[M,N] = A[M,K] . B[N,K]^T + bias[n] with IEEE-f16 operands in the layouts of cruse_gemm_bf16_nt, f32 accumulation
  * (v_mfma_f32_16x16x32_f16): the FORWARD gate projection gi = x W_ih^T (cruse_net.py:23-31,44,50) in ONE pass -- 11 significant bits
  * on both operands, where the split-bf16 form above spends a second pass to correct W_ih only and keeps x at 8 bits.  The operands
@@ -444,6 +452,14 @@ int cruse_gru_seq_bwd_ex(const float* dout, const float* const* w_hh, const void
                          float* dh, const float* an, void* dgi, int dg_slabs, int carry, int B, int T, int TS, int G,
                          int Hg, int prec, int chain_clips, void* panels, int panels_zeroed, unsigned* status, int xcd_rot,
                          void* stream);
+/* (ABI 13) gi rows stored as IEEE f16 ([B,T,G,3*Hg] halves, written by cruse_gemm_nt_out16): half the bytes of the largest tensor of the forward
+ * pass.  gi_dtype: CRUSE_DT_F16, or CRUSE_DT_F32 (then exactly cruse_gru_seq_fwd_ex with h0 = NULL, chain_clips = 0).  f16 rows are served where the
+ * bench step runs -- CRUSE_PREC_BF16, Hg = 640, chains of 8 clips (cruse_gru_plan: B <= 96) -- and refused with CRUSE_E_SHAPE elsewhere.
+ * Replaces the recurrence of nn.GRU (model/cruse_net.py:23-31, :41-51) like cruse_gru_seq_fwd_ex. */
+int cruse_gru_seq_fwd_gi16(const void* gi, int gi_dtype, const float* const* w_hh, const float* const* b_hh,
+                           float* h, void* coef, float* an, float* z,
+                           int B, int T, int TS, int G, int Hg, int prec, void* panels,
+                           int panels_zeroed, unsigned* status, int xcd_rot, void* stream);
 /* dgi = dh*(c_r,c_z,a_n) (gradient wrt gi), dgh = dh*(c_r,c_z,c_n) (gradient wrt W_hh h + b_hh), both
  * [rows,G,3*Hg]; dW_ih, dW_hh, dX and the bias gradients follow from cruse_gemm / cruse_col_sum. */
 int cruse_gru_gate_grads(const float* dh, const void* coef, const float* an, float* dgi, float* dgh,

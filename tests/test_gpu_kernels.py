@@ -1287,3 +1287,60 @@ def test_data_gradients_stored_as_bf16(ops, form):
         (r32, s32), (rbf, sbf) = r32, rbf
         assert rel_l2(sbf, s32) < 1e-6
     assert rbf.dtype == torch.bfloat16 and torch.equal(rbf, r32.to(torch.bfloat16))
+
+
+# ---------------------------------------------------------------------------------------------------------------- round 6: 2-byte gi rows
+@pytest.mark.parametrize("M,N,K", [(25664, 1920, 640), (4133, 640, 640), (130, 96, 64), (77, 50, 128)])
+def test_gate_projection_with_two_byte_result_rows(ops, M, N, K):
+    """cruse_gemm_nt_out16 (ABI 13): the forward gate projections storing f16 / bf16 rows -- the f32 accumulation of the entry point with the
+    f32 result, rounded once at the store: BIT-IDENTICAL to rounding that entry point's result, for every operand form the step uses
+    (bf16 one plane, bf16 x . (W hi + lo), f16 one plane, f16 x . (W hi + lo)); ragged tiles, a row stride that is no multiple of 4 (scalar stores)."""
+    torch.manual_seed(M + K)
+    A = torch.randn(M, K).cuda(); W = (torch.randn(N, K) / K ** 0.5).cuda(); bias = torch.randn(N).cuda()
+    Ab, Ah = A.to(torch.bfloat16), A.half()
+    Wb, Wbl = ops.ktile_bf16(W, N, K, split=True)
+    Wh, Whl = ops.ktile_f16(W, N, K, split=True)
+    ks = N * 64
+    forms = {"bf16": lambda C: ops.gemm_bf16_nt(M, N, K, Ab, 0, K, Wb, 0, 64, C, 0, C.shape[1], bias=bias, b_kstride=ks),
+             "bf16 x . (W hi + lo)": lambda C: ops.gemm_bf16x3_nt(M, N, K, Ab, None, 0, K, Wb, Wbl, 0, 64, C, 0, C.shape[1], bias=bias, b_kstride=ks),
+             "f16": lambda C: ops.gemm_f16_nt(M, N, K, Ah, 0, K, Wh, 0, 64, C, 0, C.shape[1], bias=bias, b_kstride=ks),
+             "f16 x . (W hi + lo)": lambda C: ops.gemm_f16_nt(M, N, K, Ah, 0, K, Wh, 0, 64, C, 0, C.shape[1], bias=bias, b_kstride=ks, B_lo=Whl)}
+    for name, fn in forms.items():
+        C32 = torch.empty(M, N).cuda()
+        fn(C32)
+        for dt in (torch.float16, torch.bfloat16):
+            for ldc in (N, N + 3):
+                C16 = torch.full((M, ldc), 5.0, dtype=dt).cuda()
+                fn(C16)
+                assert torch.equal(C16[:, :N], C32.to(dt)), (name, dt, ldc)
+                assert ldc == N or bool((C16[:, N:] == 5.0).all()), "columns beyond N are not touched"
+    with pytest.raises(RuntimeError):                     # a 2-byte result is stored, not accumulated
+        ops.gemm_bf16x3_nt(M, N, K, Ab, None, 0, K, Wb, Wbl, 0, 64, torch.zeros(M, N, dtype=torch.float16).cuda(), 0, N, accumulate=True, b_kstride=ks)
+
+
+@pytest.mark.parametrize("B,T", [(8, 9), (64, 33), (13, 1), (96, 5)])
+def test_forward_recurrence_on_f16_gi_rows(ops, B, T):
+    """cruse_gru_seq_fwd_gi16 (ABI 13): the bench step's forward recurrence (Hg = 640, chains of 8, tag-free register-direct hand-off) reading gi as
+    IEEE f16 rows -- the helper wave widens them exactly, so h / coefficients / a_n / z are BIT-IDENTICAL to the f32-row kernel on the f16-rounded
+    values; refused (CRUSE_E_SHAPE) where no kernel serves them: other widths, wide chains (B > 96), the f32 modes."""
+    H = 640
+    torch.manual_seed(B * 7 + T)
+    gi = (0.7 * torch.randn(B, T, 3 * H)).cuda()
+    w = [(torch.randn(3 * H, H) / H ** 0.5).cuda()]; b = [(0.1 * torch.randn(3 * H)).cuda()]
+    g16 = gi.half()
+    a = ops.gru_seq_fwd(g16, w, b, B, T, 1, H, "bf16")
+    r = ops.gru_seq_fwd(g16.float(), w, b, B, T, 1, H, "bf16")
+    torch.cuda.synchronize()
+    assert ops.gru_status() == 0
+    for x, y, name in zip(a, r, ("h", "coef", "an", "z")):
+        assert torch.equal(x.view(torch.int16) if x.dtype == torch.bfloat16 else x, y.view(torch.int16) if y.dtype == torch.bfloat16 else y), name
+    h_only = ops.gru_seq_fwd(g16, w, b, B, T, 1, H, "bf16", save=False)[0]
+    assert torch.equal(h_only, a[0])
+    assert ops.gru_plan(B, 1, H)["clips_per_chain"] == 8
+    for bad in (lambda: ops.gru_seq_fwd(gi[:, :, :3 * 320].contiguous().half(), [w[0][:960, :320].contiguous()], [b[0][:960].contiguous()], B, T, 1, 320, "bf16"),
+                lambda: ops.gru_seq_fwd(torch.zeros(128, 2, 3 * H, dtype=torch.float16).cuda(), w, b, 128, 2, 1, H, "bf16"),
+                lambda: ops.gru_seq_fwd(g16, w, b, B, T, 1, H, "f32"),
+                lambda: ops.gru_seq_fwd(g16, w, b, B, T, 1, H, "bf16", h0=torch.zeros(B, H).cuda())):
+        with pytest.raises(RuntimeError):
+            bad()
+    assert ops.gru_status() == 0
