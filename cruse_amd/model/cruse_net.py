@@ -261,6 +261,23 @@ def _gi_f16(prec, Hg: int, layer: int) -> bool:
     return (bool((int(c.gi_f16) * 3 if isinstance(c.gi_f16, bool) else int(c.gi_f16 or 0)) >> layer & 1) and _bf16_gemm_path(prec, Hg) and not (_gi_x3_knob(Hg) & 4))
 
 
+_GI16_PLAN: Dict[tuple, bool] = {}
+
+
+def _gi16_served(B: int, Hg: int, prec: int) -> bool:
+    """does the forward recurrence read f16 gi rows at this shape (cruse_gru_seq_fwd_gi16: chains of 8 on the tag-free lean kernel)?  The plan is a
+    pure function of the shape (cached: two ctypes round trips per layer and step otherwise); the three library options that select another
+    kernel are A/B switches of probes and tests, looked up only when one is set."""
+    key = (B, Hg, prec)
+    ok = _GI16_PLAN.get(key)
+    if ok is None:
+        ok = _GI16_PLAN[key] = ops.gru_plan(B, 1, Hg, prec)["clips_per_chain"] == 8
+    if ok and config.get().lib_options:
+        lo = config.get().lib_options
+        ok = lo.get("gru_tf", 1) == 1 and lo.get("gru_wlo", 0) == 0 and lo.get("gru_fwd_lean", 1) == 1
+    return ok
+
+
 def _splitk(M: int, N: int, K: int) -> int:
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     sk = max(1, (512 + tiles - 1) // tiles)
@@ -295,9 +312,7 @@ def _ggru_forward_one(x, P, prefix, groups, prec, residual=None, save=True, out=
     def layer(inp, lname, inp_bf=None):
         # gi rows: f32, or IEEE f16 where the recurrence reads them (EngineConfig.gi_store_f16: bf16 mode, one group of 640, chains of 8 clips
         # -- cruse_gru_seq_fwd_gi16): the largest tensor of the forward pass, written once and read once -- 197 -> 98 MB per layer at the bench shape
-        gi16 = (bool(config.get().gi_store_f16) and fast and g == 1 and Hg == 640 and slot == 0
-                and ops.gru_plan(B, 1, Hg, prec)["clips_per_chain"] == 8 and ops.get_option("gru_tf") in (None, 1) and ops.get_option("gru_wlo") in (None, 0)
-                and ops.get_option("gru_fwd_lean") in (None, 1))
+        gi16 = bool(config.get().gi_store_f16) and fast and g == 1 and Hg == 640 and slot == 0 and _gi16_served(B, Hg, ops.prec_code(prec))
         gi = torch.empty(B, T, g * 3 * Hg, device=x.device, dtype=torch.float16 if gi16 else torch.float32)
         # The forward projection corrects the bf16 rounding of W_ih (a second pass with its low plane): that rounding
         # dominates the forward error of the bf16 mode (enhanced spectrum 1.25e-3 -> 5.1e-4 rel-L2 on fixture G6;
