@@ -48,10 +48,13 @@ class EngineConfig:
                                     # levels whose producer AND consumers are MFMA kernels: 2 <= k < L) are stored as bf16 as well:
                                     # f32 accumulation, one rounding per pass of a backward-only tensor (needs bf16_dy and
                                     # fuse_bn_bwd_stats: the conv that stores the tensor also delivers its BatchNorm sums)
-    gi_store_f16: bool = True       # bf16 mode, g = 1 at Hg = 640, chains of 8 clips: the gate pre-activations gi = x W_ih^T + b_ih are STORED as IEEE f16 rows
-                                    # (cruse_gemm_nt_out16 -> cruse_gru_seq_fwd_gi16): f32 accumulation, one rounding to 11 bits at the store; 2 x 197 MB less
-                                    # written and read per step.  Enhanced spectrum at T = 401: 4.10e-4 -> 4.25e-4 (closed-form) / 2.81e-4 -> 2.81e-4 (torch init);
-                                    # every fixture of the bf16 mode holds (bf16 rows do not: 5.7e-4 -> 6.9e-4 and past G6's bar, r3)
+    gi_store_f16: bool = False      # bf16 mode, g = 1 at Hg = 640, chains of 8 clips: the gate pre-activations gi = x W_ih^T + b_ih STORED as IEEE f16 rows
+                                    # (cruse_gemm_nt_out16 -> cruse_gru_seq_fwd_gi16): f32 accumulation, one rounding to 11 bits at the store; 12.72 -> 12.33 GB
+                                    # of HBM traffic per step (PMC, profiles/r06_pmc_hbm_traffic_gi_store_f16.csv).  Enhanced spectrum at T = 401: 4.10e-4 ->
+                                    # 4.25e-4 (closed-form) / 2.81e-4 -> 2.81e-4 (torch init), every fixture of the bf16 mode holds (bf16 rows do not, r3).
+                                    # OFF by default: the step is 0.05-0.08 ms SLOWER with it on two boxes of three (equal on the third; interleaved A/B of
+                                    # 4 x 100 steps in one process) although the kernels alone net +3..10 us (projections -5 us each, the recurrence's helper
+                                    # wave +40 cycles per step for the conversions) -- bytes are not what this step waits for at that point
     pick_launch_stream: bool = True # HIP-graph form: time the replay of a fresh capture from the current stream and three pool streams and
                                     # keep the fastest launcher (engine._pick_launch_stream: a graph's own side-branch streams may share
                                     # the launching stream's hardware queue, which serialises the branches -- +25..35 % per step)

@@ -400,16 +400,15 @@ def test_engine_step_at_odd_batch_sizes_and_clip_lengths(prec, ltol, gtol):
 
 
 @pytest.mark.gpu
-def test_gi_rows_stored_as_f16_is_the_default_and_stays_close_to_f32_rows():
+def test_gi_rows_stored_as_f16_stay_close_to_f32_rows():
     """EngineConfig.gi_store_f16 (round 6): the gate pre-activations of both GGRU layers live in HBM as IEEE f16 rows (cruse_gemm_nt_out16 ->
     cruse_gru_seq_fwd_gi16) in the bench configuration.  Against the same step with f32 rows: loss within 2e-5, enhanced-spectrum mask within 2e-4, all
-    gradients within 3e-3 (the oracle-facing bars are held by tests/test_gpu_parity_bench_shape.py with the default on); the plan falls back to f32 rows
-    where no kernel reads f16 ones (g = 4, B = 128) without the caller noticing."""
+    gradients within 3e-3; with the option on, shapes no kernel reads f16 rows for (g = 4, B = 128) keep f32 rows without the caller noticing."""
     from cruse_amd.config import EngineConfig
     from cruse_amd.data import synth_batch
     from cruse_amd.engine import TrainEngine
     from cruse_amd.model.cruse_net import unet_2
-    assert EngineConfig().gi_store_f16 is True
+    assert EngineConfig().gi_store_f16 is False           # opt-in: fewer bytes, but measured 1-2 % slower in the step (config.py)
     noisy, clean = synth_batch(8, 16000, torch.device("cuda"), 3)
     res = {}
     for on in (True, False):
@@ -422,6 +421,6 @@ def test_gi_rows_stored_as_f16_is_the_default_and_stays_close_to_f32_rows():
     assert rel_l2(res[True][2], res[False][2]) < 3e-3
     for groups, B in ((4, 8), (1, 128)):
         torch.manual_seed(0)
-        e = TrainEngine(unet_2(rnn_groups=groups, precision="bf16").cuda(), lr=0.0, use_graph=False)
+        e = TrainEngine(unet_2(rnn_groups=groups, precision="bf16").cuda(), lr=0.0, use_graph=False, config=EngineConfig(gi_store_f16=True))
         nz, cl = synth_batch(B, 1600, torch.device("cuda"), 4)
         assert np.isfinite(e.loss_value(e._fwd_bwd(nz, cl)))

@@ -242,3 +242,44 @@ def test_wide_chain_plan_at_b128_vs_oracle():
     _check_grads(tot, worst, "B=128 T=401 g=1 wide chains")
     # the plan really is the wide one at this batch (and the chains of 8 below it)
     assert ops.gru_plan(B, 1, 640)["clips_per_chain"] == 16 and ops.gru_plan(64, 1, 640)["clips_per_chain"] == 8
+
+
+@pytest.mark.parametrize("init", ["closed", "random"])
+def test_f16_stored_gate_preactivations_hold_the_oracle_bars(init, golden):
+    """EngineConfig.gi_store_f16 (round 6, opt-in): gi rows of both GGRU layers stored as IEEE f16.  Against the CPU oracle at T = 401, B = 8: enhanced
+    spectrum inside the north_star bar and no further from the oracle than 1.1 x the f32-row default; gradients inside the bench-mode tolerances; and the
+    closed-form step fixture G6 holds."""
+    from cruse_amd import config, ops
+    from cruse_amd.config import EngineConfig
+    from cruse_amd.engine import TrainEngine
+    from cruse_amd.model import cruse_net as M
+    from oracle import cruse_oracle as O
+    B, T = 8, 401
+    noisy, clean = O.synth_pair(B, (T - 1) * 160, seed=11)
+    err = {}
+    for on in (False, True):
+        o, m = _pair(1, init, "bf16")
+        if on:
+            loss_o, _ = O.train_step_loss(o, noisy, clean)
+            loss_o.backward()
+        with torch.no_grad():
+            _, est_o, _ = O.enhanced_spectrum(o, noisy)
+        eng = TrainEngine(m, use_graph=False, config=EngineConfig(gi_store_f16=on))
+        ls = eng._fwd_bwd(noisy.cuda(), clean.cuda())
+        nre, nim, _ = ops.stft(noisy.cuda(), 320, 160, mag_bins=160, mag_eps=1e-8)
+        er, ei = ops.mask_apply(eng._last_mask.contiguous().view(B * T, 160), nre, nim, B * T, 160, 161)
+        est = torch.stack([er.view(B, T, 161), ei.view(B, T, 161)], dim=-1)
+        err[on] = rel_l2(est, est_o)
+        if on:
+            tot, worst = _grad_report(eng, o)
+            _check_grads(tot, worst, f"gi_store_f16 T=401 g=1 {init}")
+    print(f"[parity bf16 T=401 g=1 {init}] enhanced-spectrum rel-L2 with f32 / f16 gi rows: {err[False]:.3e} / {err[True]:.3e}")
+    assert err[True] <= FWD_TOL and err[True] <= 1.1 * err[False]
+    if init == "closed":
+        g = golden("g6_step_g1.npz")
+        o, m = _pair(1, "closed", "bf16")
+        eng = TrainEngine(m, use_graph=False, config=EngineConfig(gi_store_f16=True))
+        ls = eng._fwd_bwd(t(g["noisy"]), t(g["clean"]))
+        assert abs(eng.loss_value(ls) - float(g["loss"])) <= 2e-4 * abs(float(g["loss"]))
+        assert rel_l2(eng._last_mask.view(2, 1, 21, 160), torch.from_numpy(g["mask"])) <= FWD_TOL
+    assert ops.gru_status() == 0
