@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 so = os.path.join(HERE, "guard_alloc", "libguard_alloc.so")
 if not os.path.exists(so):
     import subprocess
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O2", "-o", so, os.path.join(HERE, "guard_alloc", "guard_alloc.cpp")])
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-O2", "-o", so, os.path.join(HERE, "guard_alloc", "guard_alloc.cpp")])
 alloc = torch.cuda.memory.CUDAPluggableAllocator(so, "guard_malloc", "guard_free")
 torch.cuda.memory.change_current_allocator(alloc)
 sys.argv = sys.argv[1:]

@@ -15,7 +15,7 @@ static const size_t GRAN = 2u << 20;                  // hipMalloc maps whole 2 
 extern "C" void* guard_malloc(ssize_t size, int device, hipStream_t stream) {
     (void)stream;
     if (size <= 0) return nullptr;
-    hipSetDevice(device);
+    (void)hipSetDevice(device);
     const size_t need = ((size_t)size + 15) & ~(size_t)15;
     const size_t total = (need + GRAN - 1) / GRAN * GRAN;
     void* base = nullptr;
@@ -37,6 +37,6 @@ extern "C" void guard_free(void* p, ssize_t size, int device, hipStream_t stream
         base = it->second;
         g_base.erase(it);
     }
-    hipDeviceSynchronize();
-    hipFree(base);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(base);
 }
