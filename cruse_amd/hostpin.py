@@ -69,6 +69,10 @@ def pin_rank(local_rank: int, local_world: int, device_index: Optional[int] = No
     allowed = sorted(os.sched_getaffinity(0))
     if local_world <= 1 or not enable:
         return {"pinned": False, "reason": "single rank" if local_world <= 1 else "disabled", "allowed_cores": len(allowed)}
+    if len(allowed) < 4 * local_world:
+        # a rank runs its launch thread, RCCL's proxy thread and its DataLoader workers: with fewer than four cores each, slices would
+        # serialise them -- leave the scheduler alone
+        return {"pinned": False, "reason": f"{len(allowed)} allowed cores for {local_world} ranks", "allowed_cores": len(allowed)}
     import torch
     ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
     by_rank = {r: (gpu_local_cores(r % ndev) if ndev else None) for r in range(local_world)}
