@@ -31,6 +31,79 @@ from .. import ops
 from ..engine import TrainEngine
 
 
+class _RingCollate:
+    """collate_fn wrapper that runs inside the DataLoader's WORKERS (round 6).  torch hands a collated batch to the main process as freshly
+    created shared-memory tensors: per batch two file descriptors fetched from the worker's resource-sharer thread (an authenticated socket
+    round trip each: `recvmsg` was 0.96 ms per storage, 3 ms per batch of the consumer's 4.2 ms -- cProfile on the bench host, whatever the
+    worker count), an mmap / munmap of 32.8 MB and page faults on every first touch.  Here a worker stacks its samples straight into ITS slots
+    of a shared ring the trainer allocated before the workers were forked and returns (tag, slot, count) -- a few bytes through the queue, pages
+    that stay resident.  Anything that is not a batch of (tensor, tensor) pairs of the ring's shape goes through the original collate_fn."""
+
+    TAG = "__cruse_ring__"
+
+    def __init__(self, inner, ring, per_worker):
+        self.inner, self.ring, self.k, self.count = inner, ring, int(per_worker), 0
+
+    def __call__(self, batch):
+        from torch.utils.data import get_worker_info
+        info, ring = get_worker_info(), self.ring
+        try:
+            shp, dt = ring.shape[3:], ring.dtype
+            ok = (info is not None and 0 < len(batch) <= ring.shape[2] and (info.id + 1) * self.k <= ring.shape[0]
+                  and all(isinstance(s_, (tuple, list)) and len(s_) == 2 and isinstance(s_[0], torch.Tensor) and isinstance(s_[1], torch.Tensor)
+                          and s_[0].shape == shp and s_[1].shape == shp and s_[0].dtype == dt and s_[1].dtype == dt for s_ in batch))
+        except Exception:
+            ok = False
+        if not ok:
+            return self.inner(batch)
+        slot = info.id * self.k + self.count % self.k
+        self.count += 1
+        b = len(batch)
+        torch.stack([s_[0] for s_ in batch], 0, out=ring[slot, 0, :b])
+        torch.stack([s_[1] for s_ in batch], 0, out=ring[slot, 1, :b])
+        return (self.TAG, slot, b)
+
+
+def _install_ring(loader, max_bytes=2 << 30):
+    """-> the shared ring of `loader` (installing it on first use), or None where it does not apply: no workers, workers already running
+    (a persistent iterator made before), manual batching, samples that are not (tensor, tensor) pairs of one shape, or a ring beyond max_bytes.
+    Slots per worker: prefetch_factor batches the DataLoader keeps outstanding per worker + what the prefetcher holds before its staging copy
+    (two queued, one being copied) + one spare."""
+    ring = getattr(loader, "_cruse_ring", None)
+    if ring is not None:
+        return ring
+    if getattr(loader, "_cruse_ring_tried", False):
+        return None
+    try:
+        loader._cruse_ring_tried = True
+    except Exception:
+        return None
+    nw, bs = int(getattr(loader, "num_workers", 0) or 0), getattr(loader, "batch_size", None)
+    if nw <= 0 or bs is None or getattr(loader, "_iterator", None) is not None or getattr(loader, "collate_fn", None) is None:
+        return None
+    try:
+        s0 = loader.dataset[0]
+    except Exception:
+        return None
+    if not (isinstance(s0, (tuple, list)) and len(s0) == 2 and all(isinstance(t_, torch.Tensor) for t_ in s0)
+            and s0[0].shape == s0[1].shape and s0[0].dtype == s0[1].dtype and s0[0].dim() >= 1):
+        return None
+    k = int(getattr(loader, "prefetch_factor", None) or 2) + 5          # outstanding per worker + pull thread's hand (1) + queue (2) + staging (1) + spare (1)
+    shape = (nw * k, 2, int(bs)) + tuple(s0[0].shape)
+    nbytes = s0[0].element_size()
+    for d in shape:
+        nbytes *= d
+    if nbytes > max_bytes:
+        return None
+    try:
+        ring = torch.empty(shape, dtype=s0[0].dtype).share_memory_()
+        loader.collate_fn = _RingCollate(loader.collate_fn, ring, k)
+        loader._cruse_ring = ring
+    except Exception:
+        return None
+    return ring
+
+
 class _Prefetcher:
     """Device batches one step AHEAD of the training loop, off the compute stream (the loop used to copy an un-pinned
     [B, L] pair over PCIe on the compute stream, in series with every step).
@@ -45,9 +118,9 @@ class _Prefetcher:
 
     NPIN = 4
 
-    def __init__(self, loader, device):
+    def __init__(self, loader, device, use_ring=True):
         from .. import streams
-        self.loader, self.device = loader, device
+        self.loader, self.device, self.use_ring = loader, device, bool(use_ring)
         # ONE data stream per compute stream for the life of the process (a stream per epoch strands the blocks the caching allocator
         # holds for the old one), proven to overlap with the compute stream and its leaf stream (cruse_amd/streams.py: a copy stream
         # that shares their hardware queue would put every H2D copy in series with the step)
@@ -108,11 +181,15 @@ class _Prefetcher:
                     pass
             return False
 
-        def pull():                                # stage 1: the DataLoader's consumer side (~5 ms per 32.8 MB batch on the bench host)
-            try:
+        ring = _install_ring(self.loader) if self.use_ring else None
+
+        def pull():                                # stage 1: the DataLoader's consumer side (~4 ms per 32.8 MB batch on the bench host; with the
+            try:                                   # shared ring a few bytes per batch)
                 it = iter(self.loader)
                 try:
                     for item in it:
+                        if ring is not None and isinstance(item, tuple) and len(item) == 3 and item[0] == _RingCollate.TAG:
+                            item = (ring[item[1], 0, :item[2]], ring[item[1], 1, :item[2]])      # views: copied out by the staging thread
                         if not put(raw, item):
                             return
                 finally:
@@ -220,6 +297,7 @@ class Trainer:
         self.epochs = tr["epochs"]
         self.save_checkpoint_interval = tr.get("save_checkpoint_interval", 1)
         self.max_gru_timeouts_per_epoch = int(config["meta"].get("max_gru_timeouts_per_epoch", 0))
+        self.shm_ring = bool(config["meta"].get("shm_ring", True))          # host datasets: workers collate into a shared ring (_RingCollate)
         self.clip_grad_norm_value = tr.get("clip_grad_norm_value", None)
         assert self.save_checkpoint_interval >= 1, \
             "Check the 'save_checkpoint_interval' parameter in the config. It should be large than one."   # base_trainer.py:76
@@ -322,7 +400,7 @@ class Trainer:
         sys.setswitchinterval(2e-4)
         t0 = time.time()
         try:
-            for noisy, clean in _Prefetcher(self.train_dataloader, self.device):
+            for noisy, clean in _Prefetcher(self.train_dataloader, self.device, use_ring=self.shm_ring):
                 self.engine.step(noisy, clean)                           # no host synchronisation inside the loop
                 nb += 1
                 frames += noisy.shape[0] * (1 + noisy.shape[1] // self.engine.hop)
