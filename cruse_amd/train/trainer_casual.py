@@ -81,10 +81,17 @@ def _install_ring(loader, max_bytes=2 << 30):
     nw, bs = int(getattr(loader, "num_workers", 0) or 0), getattr(loader, "batch_size", None)
     if nw <= 0 or bs is None or getattr(loader, "_iterator", None) is not None or getattr(loader, "collate_fn", None) is None:
         return None
+    # one sample decides the ring's geometry; the host RNGs are put back afterwards (a dataset that augments with torch / numpy / random draws
+    # would otherwise shift the DataLoader's base seed and with it every shuffle of the run)
+    import random as _random
+    import numpy as _np
+    rng = (torch.random.get_rng_state(), _np.random.get_state(), _random.getstate())
     try:
         s0 = loader.dataset[0]
     except Exception:
         return None
+    finally:
+        torch.random.set_rng_state(rng[0]); _np.random.set_state(rng[1]); _random.setstate(rng[2])
     if not (isinstance(s0, (tuple, list)) and len(s0) == 2 and all(isinstance(t_, torch.Tensor) for t_ in s0)
             and s0[0].shape == s0[1].shape and s0[0].dtype == s0[1].dtype and s0[0].dim() >= 1):
         return None
