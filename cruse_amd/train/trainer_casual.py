@@ -102,6 +102,13 @@ def _install_ring(loader, max_bytes=2 << 30):
         nbytes *= d
     if nbytes > max_bytes:
         return None
+    try:                                                     # the ring lives in /dev/shm: a tmpfs that is too small fails at first TOUCH (SIGBUS)
+        import os as _os
+        st = _os.statvfs("/dev/shm")
+        if st.f_bavail * st.f_frsize < 2 * nbytes:
+            return None
+    except OSError:
+        pass
     try:
         ring = torch.empty(shape, dtype=s0[0].dtype).share_memory_()
         loader.collate_fn = _RingCollate(loader.collate_fn, ring, k)
