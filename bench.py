@@ -871,6 +871,17 @@ def config_rows(a, dev, pool):
     return out
 
 
+def _stream_probe_report():
+    """what cruse_amd/streams.py measured when it chose this process's side / launcher / data streams (serial fraction per pool stream drawn:
+    ~0.3 = runs beside the main stream, ~1 = shares its hardware queue) -- the first entries, the headline engine's among them"""
+    try:
+        from cruse_amd import streams
+        return {"selections": len(streams.REPORT), "rejected_draws": sum(1 for r in streams.REPORT for f in r.get("serial_fraction_by_draw", [])[:-1]),
+                "first": streams.REPORT[:4]}
+    except Exception as ex:
+        return {"error": repr(ex)[:120]}
+
+
 def regression_guard(out, threshold=0.08):
     """every row of this run against the newest COMMITTED bench line (profiles/rNN_bench_final.json): a row
     whose ms per step grew by more than `threshold` is flagged -- in the JSON line and on stderr.  BENCH_r05's config-4 row went
@@ -1132,6 +1143,7 @@ def main():
             "parity_rel_l2": None if parity is None else float(f"{parity:.4g}"),
             "parity_note": "enhanced-spectrum rel-L2 of this model/mode vs the CPU oracle at T=401, B=8 (bar 1e-3)",
             "final_loss": round(loss, 6), "gru_handoff_timeouts": status, "skipped_steps": eng.skipped_steps(),
+            "stream_probe": _stream_probe_report(),
             "roofline": roof, "roofline_step": step_roofline(frames / el, a.groups, a.prec, B, T),
             "kernel_ms_per_step": breakdown, "cpu_baseline": cpu, "secondary": secondary,
         }
