@@ -68,6 +68,7 @@ SIGNATURES = {
     "cruse_ktile_f16": ("piiqpp", "i"),
     "cruse_gemm_f16_nt": ("iiipqqpqqpqpp", "i"),
     "cruse_gemm_nt_out16": ("iiippqqppqqpqpiip", "i"),
+    "cruse_gemm_bf16_nt_atr": ("iiipqipqqpqip", "i"),
     "cruse_gemm_f16x2_nt": ("iiipqqppqqpqpp", "i"),
     "cruse_ktile_f16_split": ("piiqppp", "i"),
     "cruse_cast_bf16_split": ("pppqp", "i"),

@@ -55,6 +55,11 @@ class EngineConfig:
                                     # OFF by default: the step is 0.05-0.08 ms SLOWER with it on two boxes of three (equal on the third; interleaved A/B of
                                     # 4 x 100 steps in one process) although the kernels alone net +3..10 us (projections -5 us each, the recurrence's helper
                                     # wave +40 cycles per step for the conversions) -- bytes are not what this step waits for at that point
+    dx_atr: bool = True             # bf16 mode, g = 1: the input gradient dX = dgi . W_ih is formed from the TIME-MAJOR gate gradients dgT (the operand of the
+                                    # weight-gradient GEMMs) through transposing LDS reads (cruse_gemm_bf16_nt_atr): the gate-gradient pass writes no row-major dgi
+                                    # (98 MB per layer written and read).  Same products, same summation order (bit-identical GEMM: tests/test_gpu_kernels.py).
+                                    # Round 4 measured it time-neutral and pruned it; round 6 (fixed stream conditions): 4.676 against 4.688 ms in four
+                                    # interleaved A/B pairs of 100 steps, -0.2 GB of HBM traffic per step
     pick_launch_stream: bool = True # HIP-graph form: time the replay of a fresh capture from the current stream and three pool streams and
                                     # keep the fastest launcher (engine._pick_launch_stream: a graph's own side-branch streams may share
                                     # the launching stream's hardware queue, which serialises the branches -- +25..35 % per step)
@@ -67,7 +72,8 @@ class EngineConfig:
             "gi_x3": ("CRUSE_GI_X3", int), "gi_f16": ("CRUSE_GI_F16", int), 
              
             "fuse_bn_fwd": ("CRUSE_FUSE_BN_FWD", lambda v: v != "0"), "fuse_bn_bwd_apply": ("CRUSE_FUSE_BN_BWD_APPLY", lambda v: v != "0"), "bf16_dy": ("CRUSE_BF16_DY", lambda v: v != "0"), "bf16_de": ("CRUSE_BF16_DE", lambda v: v != "0"),
-            "pick_launch_stream": ("CRUSE_PICK_LAUNCH_STREAM", lambda v: v != "0"), "gi_store_f16": ("CRUSE_GI_STORE_F16", lambda v: v != "0")}
+            "pick_launch_stream": ("CRUSE_PICK_LAUNCH_STREAM", lambda v: v != "0"), "gi_store_f16": ("CRUSE_GI_STORE_F16", lambda v: v != "0"),
+            "dx_atr": ("CRUSE_DX_ATR", lambda v: v != "0")}
     _LIB_ENV = {"CRUSE_GRU_BWD_RS": "gru_bwd_rs", "CRUSE_GRU_FWD_LEAN": "gru_fwd_lean", "CRUSE_GRU_WLO": "gru_wlo", "CRUSE_GRU_DBG": "gru_dbg",
                 "CRUSE_GRU_TF": "gru_tf", "CRUSE_GRU_POLL_FWD": "gru_poll_fwd", "CRUSE_GRU_POLL_BWD": "gru_poll_bwd", "CRUSE_CM_KINT": "cm_kint",
                 "CRUSE_CM_SWAP": "cm_swap", "CRUSE_CM_NW": "cm_nw", "CRUSE_PW_VALU": "pw_valu", "CRUSE_WG_DBG": "wg_dbg",

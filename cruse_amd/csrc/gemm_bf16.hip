@@ -511,7 +511,6 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
     CRUSE_REQUIRE(!grp || (!c_bf16 && !slabs && splitk == 1 && !cat && atr_mbs == 0 && seg_len == 0 && a_kstride == BK), CRUSE_E_SHAPE,
                   "gemm_bf16_nt_groups: row-major A, f32 result, no split-K");
     const bool atr = atr_mbs != 0;
-    CRUSE_REQUIRE(!atr, CRUSE_E_SHAPE, "gemm_bf16_nt: the transposed-A form was removed (measured neutral, r4)");
     CRUSE_REQUIRE(!atr || (!A_lo && !B_lo && !c_bf16 && !slabs && splitk == 1 && !f16 && !cat && seg_len == 0), CRUSE_E_SHAPE,
                   "gemm_bf16_nt_atr: plain bf16, one pass, no split-K");
     CRUSE_REQUIRE(!f16 || (!A_lo && !slabs && splitk == 1 && !accumulate), CRUSE_E_SHAPE,
@@ -596,6 +595,20 @@ static int gemm_bf16_impl(int M, int N, int K, const void* A, const void* A_lo, 
         CRUSE_LAUNCH_CHECK("gemm_slab_reduce");
         return CRUSE_OK;
     }
+    if (atr) {
+        const size_t ldsa = (size_t)2 * 2 * TILE_BYTES;
+        if (accumulate) {
+            int rc0 = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_bf16_nt_kernel<1, 2, 1, false, true>), ldsa, "gemm_bf16_nt_atr");
+            if (rc0) return rc0;
+            hipLaunchKernelGGL((gemm_bf16_nt_kernel<1, 2, 1, false, true>), grid, dim3(256), ldsa, st, g);
+        } else {
+            int rc0 = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_bf16_nt_kernel<0, 2, 1, false, true>), ldsa, "gemm_bf16_nt_atr");
+            if (rc0) return rc0;
+            hipLaunchKernelGGL((gemm_bf16_nt_kernel<0, 2, 1, false, true>), grid, dim3(256), ldsa, st, g);
+        }
+        CRUSE_LAUNCH_CHECK("gemm_bf16_nt_atr");
+        return CRUSE_OK;
+    }
     if (f16 && c_bf16) {
         const size_t lds16 = (size_t)2 * 2 * TILE_BYTES;
         int rc0 = cruse_ensure_dyn_lds(reinterpret_cast<const void*>(gemm_bf16_nt_kernel<3, 2, 1, true>), lds16, "gemm_nt_out16");
@@ -666,6 +679,19 @@ extern "C" int cruse_gemm_f16_nt(int M, int N, int K, const void* A, long long l
                           nullptr, 0, true);
 }
 
+
+// C[M,N] (+)= A[M,K] . B[N,K]^T with A given as its TIME-MAJOR K-tiled image: element (m, k) at A_T[(m / 64) * a_mb_stride + k * 64 + m % 64],
+// n_mb 64-row blocks present (rows M <= m < 64 * n_mb hold finite values).  This is the layout of the gate-gradient tensor dgT
+// [ceil(rows / 64)][G][4][Hg][64] the weight-gradient GEMMs consume (A_T = dgT + group * 4 * Hg * 64, a_mb_stride = G * 4 * Hg * 64): the input
+// gradient dX = dgi . W_ih is formed from it directly and the row-major copy dgi is never written (round 4; back in round 6 for its bytes).  K % 64 == 0.
+extern "C" int cruse_gemm_bf16_nt_atr(int M, int N, int K, const void* A_T, long long a_mb_stride, int n_mb,
+                                      const void* B, long long ldb, long long b_kstride,
+                                      float* C, long long ldc, int accumulate, void* stream) {
+    CRUSE_REQUIRE(a_mb_stride >= (long long)K * 64 && a_mb_stride % 8 == 0 && n_mb >= 1 && (long long)n_mb * 64 >= M, CRUSE_E_SHAPE,
+                  "gemm_bf16_nt_atr: a_mb_stride=%lld n_mb=%d for M=%d K=%d", a_mb_stride, n_mb, M, K);
+    return gemm_bf16_impl(M, N, K, A_T, nullptr, 64, 64 * 64, B, nullptr, ldb, b_kstride, C, ldc, nullptr, accumulate, 1, stream, 0, 0, 0, false,
+                          nullptr, 0, false, nullptr, a_mb_stride, n_mb - 1);
+}
 
 // G products of the same shape in ONE launch, side by side along N -- the GRU groups of a layer:
 //   C[:, q * c_gstep + (0 .. N)] (+)= A[:, q * a_gstep + (0 .. K)] . B_q^T + bias_q      B_q = B + q * b_gstep, bias_q = bias + q * bias_gstep

@@ -485,7 +485,9 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
         bias_hh = [G[nm + "bias_hh_l0"] for nm in names]
         ldT = (rows + 63) // 64 * 64
         dh = run_bwd(dout_h, w_hh, coef, z)
-        dgi, dgT, ldT = ops.gru_gate_grads_bf16(dh, coef, an, rows, g, Hg, bias_ih, bias_hh)
+        # EngineConfig.dx_atr: dX reads the time-major tensor dgT through transposing LDS reads (cruse_gemm_bf16_nt_atr) -- no row-major dgi is written
+        dx_atr = bool(config.get().dx_atr) and Hg % 64 == 0 and need_dinp and g == 1
+        dgi, dgT, ldT = ops.gru_gate_grads_bf16(dh, coef, an, rows, g, Hg, bias_ih, bias_hh, want_dgi=not dx_atr)
         early = early_T.pop(lname, None)         # layer 1: transposed by a leaf of the FIRST recurrence (see below)
         if early is not None:
             inpT, hpT = early
@@ -533,6 +535,10 @@ def _ggru_backward_one(ctx, dout, P, G, need_dx, dx, dx_accum, dx_ready, defer_l
                 w_t = ctx.get("w_ts", {}).get((lname, i))                             # made in the forward pass (side stream)
                 if w_t is None:
                     w_t = ops.transpose_bf16(P[nm + "weight_ih_l0"], 3 * Hg, Hg)      # K-tiled [ceil(3*Hg/64), Hg, 64]
+                if dgi is None:
+                    ops.gemm_bf16_nt_atr(rows, Hg, 3 * Hg, dgT, 4 * i * Hg * 64, g * 4 * Hg * 64, ldT // 64, w_t, 0, 64, dinp, i * Hg, H,
+                                         accumulate=acc_dx, b_kstride=Hg * 64)
+                    continue
                 ops.gemm_bf16_nt(rows, Hg, w_t.shape[0] * 64, dgi, i * 3 * Hg, 3 * H, w_t, 0, 64, dinp, i * Hg, H,
                                  accumulate=acc_dx, b_kstride=Hg * 64)
         if early_leaf:

@@ -539,6 +539,16 @@ def gemm_bf16_nt_cat(Ms, N, K, A, a_rows, lda, Bs, b_off, ldb, C, c_off, ldc, sp
                                            ws.numel(), _stream()))
 
 
+def gemm_bf16_nt_atr(M, N, K, A_T, a_off, a_mb_stride, n_mb, Bm, b_off, ldb, C, c_off, ldc, accumulate=False, b_kstride=64):
+    """C[M,N] (+)= A . B^T with A read from its time-major K-tiled image (element (m, k) at A_T[a_off + (m // 64) * a_mb_stride + k * 64 + m % 64]):
+    cruse_gemm_bf16_nt_atr -- dX straight from the gate-gradient tensor dgT, no row-major dgi."""
+    if A_T.dtype != torch.bfloat16 or Bm.dtype != torch.bfloat16 or C.dtype != torch.float32:
+        raise RuntimeError("gemm_bf16_nt_atr needs bf16 operands and an f32 result")
+    check(lib.cruse_gemm_bf16_nt_atr(M, N, K, A_T.data_ptr() + 2 * a_off, a_mb_stride, n_mb, Bm.data_ptr() + 2 * b_off, ldb, b_kstride,
+                                     C.data_ptr() + 4 * c_off, ldc, 1 if accumulate else 0, _stream()))
+    return C
+
+
 def gemm_bf16_nt_groups(M, N, K, G, A_hi, A_lo, lda, a_gstep, B_hi, B_lo, ldb, b_gstep, C, ldc, c_gstep, bias=None, bias_gstep=0,
                         accumulate=False, b_kstride=64):
     """G equal-shape products side by side along N in one launch (cruse_gemm_bf16_nt_groups): the GRU groups of a layer.

@@ -344,6 +344,13 @@ int cruse_ktile_bf16(const float* x, int rows, int cols, long long ld, void* y, 
 int cruse_ktile_f16(const float* x, int rows, int cols, long long ld, void* y, void* stream);
 /* (ABI 12) ... with the low plane y_lo = f16(x - f16(x)), same layout: the B_lo operand of cruse_gemm_f16x2_nt */
 int cruse_ktile_f16_split(const float* x, int rows, int cols, long long ld, void* y, void* y_lo, void* stream);
+/* (ABI 13; first in ABI 9-10) C[M,N] (+)= A[M,K] . B[N,K]^T with A read from its TIME-MAJOR K-tiled image -- element (m, k) at
+ * A_T[(m / 64) * a_mb_stride + k * 64 + m % 64], n_mb 64-row blocks present -- the layout of the gate-gradient tensor dgT the weight-gradient GEMMs
+ * consume: the input gradient dX = dgi . W_ih of nn.GRU's backward (model/cruse_net.py:23-31,44,50) straight from it, so that the row-major copy dgi
+ * (98 MB per layer at the bench shape) is never written.  B as cruse_gemm_bf16_nt; plain bf16, one pass, K % 64 == 0.  Bit-identical to the row-major form. */
+int cruse_gemm_bf16_nt_atr(int M, int N, int K, const void* A_T, long long a_mb_stride, int n_mb,
+                           const void* B, long long ldb, long long b_kstride,
+                           float* C, long long ldc, int accumulate, void* stream);
 /* (ABI 13) The forward gate projections with a 2-BYTE RESULT: C[M,N] = (A_hi + A_lo) . (B_hi + B_lo)^T + bias stored as IEEE f16 (out_dtype =
  * CRUSE_DT_F16) or bf16 (CRUSE_DT_BF16) rows [M, ldc] -- gi is the largest tensor of the forward pass (197 MB in f32 at the bench shape), written once
  * here and read once by cruse_gru_seq_fwd_gi16.  operands_f16 = 0: bf16 operand planes in the layouts of cruse_gemm_bf16_nt / cruse_gemm_bf16x3_nt

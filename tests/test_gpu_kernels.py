@@ -1344,3 +1344,25 @@ def test_forward_recurrence_on_f16_gi_rows(ops, B, T):
         with pytest.raises(RuntimeError):
             bad()
     assert ops.gru_status() == 0
+
+
+@pytest.mark.parametrize("rows,Hg,accumulate", [(25664, 640, False), (25664, 640, True), (1000, 128, False), (77, 64, True)])
+def test_input_gradient_gemm_from_time_major_gate_gradients(ops, rows, Hg, accumulate):
+    """cruse_gemm_bf16_nt_atr (round 4, back in round 6 as EngineConfig.dx_atr): dX = dgi . W_ih read from the TIME-MAJOR K-tiled gate gradients dgT
+    [ceil(rows / 64)][4][Hg][64] -- the operand the weight-gradient GEMMs consume -- through transposing LDS reads: BIT-IDENTICAL to the row-major
+    product on the same bf16 values (same k order, same accumulation), ragged last row block included."""
+    torch.manual_seed(rows + Hg)
+    dh = torch.randn(rows, Hg).cuda() * 1e-3
+    coef = torch.randn(rows, 3 * Hg).cuda().to(torch.bfloat16)
+    an = torch.rand(rows, Hg).cuda()
+    db_ih, db_hh = [torch.zeros(3 * Hg).cuda()], [torch.zeros(3 * Hg).cuda()]
+    dgi, dgT, ldT = ops.gru_gate_grads_bf16(dh, coef, an, rows, 1, Hg, db_ih, db_hh)
+    W = (torch.randn(3 * Hg, Hg) / Hg ** 0.5).cuda()
+    w_t = ops.transpose_bf16(W, 3 * Hg, Hg)                       # K-tiled [ceil(3 Hg / 64), Hg, 64]
+    init = torch.randn(rows, Hg).cuda()
+    a, b = init.clone(), init.clone()
+    ops.gemm_bf16_nt(rows, Hg, w_t.shape[0] * 64, dgi, 0, 3 * Hg, w_t, 0, 64, a, 0, Hg, accumulate=accumulate, b_kstride=Hg * 64)
+    ops.gemm_bf16_nt_atr(rows, Hg, 3 * Hg, dgT, 0, 4 * Hg * 64, ldT // 64, w_t, 0, 64, b, 0, Hg, accumulate=accumulate, b_kstride=Hg * 64)
+    assert torch.equal(a, b)
+    want = dgi.view(rows, 3 * Hg).double() @ W.to(torch.bfloat16).double() + (init.double() if accumulate else 0.0)
+    assert rel_l2(b, want) < 1e-5
